@@ -1,0 +1,273 @@
+"""CPU oracle for the sBayes likelihood hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+This file is a NumPy restatement of the reference algorithm (NicoNeureiter/sBayes,
+snapshot 2025-06-20) for the path named in BASELINE.json `north_star`.  Only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import it, and
+only as the checker / the timed CPU baseline -- never as the thing shipped.  The product
+(`sbayes_amd/`) never imports this module and fails loudly when its HIP library is missing.
+
+Parity status: PINNED.  The reference has no executed test that pins these numbers
+(`test/test_model.py:96-207` is commented out), so the oracle is pinned against outputs
+of the reference itself, generated in the build container by
+`tests/golden/make_golden.py` (stub-imported reference, numba decorators = identity, i.e.
+the NumPy path BASELINE.json names) and committed as `tests/golden/*.npz`.
+`tests/test_oracle_golden.py` checks every function below against those vectors, plus the
+hand-derivable known answers of the reference's commented-out test
+(`test/test_model.py:157-207`).
+
+Every function cites the reference lines it restates.  Float32 rounding points of the
+reference are kept exactly: probability tables and normalised weights are
+rounded to float32, everything downstream of them is float64; the collapsed likelihood is
+float32 per feature and float32-summed per group.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.special import gammaln as _gammaln
+
+FLOAT_TYPE = np.float32  # sbayes/util.py:32
+
+
+# --------------------------------------------------------------------------------------
+# a4  normalize                                                   sbayes/util.py:990-1007
+# --------------------------------------------------------------------------------------
+def normalize(x, axis=-1):
+    """x / sum(x, axis) computed in x's dtype, THEN rounded to float32 (util.py:1006-1007).
+    The reference asserts that all sums are positive (util.py:1006)."""
+    x = np.asarray(x)
+    total = np.sum(x, axis=axis, keepdims=True)
+    if not np.all(total > 0):
+        raise AssertionError(float(np.min(x)))
+    return (x / total).astype(FLOAT_TYPE)
+
+
+# --------------------------------------------------------------------------------------
+# a1  compute_component_likelihood                     sbayes/model/likelihood.py:104-133
+# --------------------------------------------------------------------------------------
+def compute_component_likelihood(features, probs, groups, changed_groups, out):
+    """For each changed group i: out[members(i), :] = sum_s features[members, :, s] * probs[i, :, s].
+    Rows of objects that are in no group are zeroed first (likelihood.py:121-123); rows of
+    members of groups that are NOT in `changed_groups` keep whatever `out` held
+    (likelihood.py:126-130).  Later groups overwrite earlier ones.  Returns `out`."""
+    in_any = groups.sum(axis=0) != 0
+    out[~in_any, :] = 0.0
+    for i in changed_groups:
+        members = groups[i]
+        one_hot = features[members]                    # bool [n_g, F, S]
+        table = probs[i]                               # [F, S]
+        out[members, :] = (one_hot * table[None, :, :]).sum(axis=-1)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# a2  compute_component_likelihood_exact               sbayes/model/likelihood.py:136-150
+# --------------------------------------------------------------------------------------
+def compute_component_likelihood_exact(features, probs, groups, changed_groups, out):
+    """Same as a1 but probs[i] is a per-member table [n_in_group, F, S] (leave-one-out
+    tables built by likelihood_per_component_exact)."""
+    out[~groups.any(axis=0), :] = 0.0
+    for i in changed_groups:
+        members = groups[i]
+        out[members, :] = np.einsum("nfs,nfs->nf", features[members], probs[i])
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# a5  normalize_weights / has_components   likelihood.py:171-190, sampling/state.py:353-376
+# --------------------------------------------------------------------------------------
+def has_components(groups_by_component):
+    """bool [N, C]: object n is affected by component c iff it is in any group of c
+    (state.py:358-362: clusters.any_cluster() and conf.any_group())."""
+    return np.stack([np.any(g, axis=0) for g in groups_by_component], axis=1)
+
+
+def normalize_weights(weights, has_comp):
+    """Mask the per-feature mixture weights [F, C] with each object's has_components row and
+    renormalise over components -> [N, F, C].  Computed once per distinct row pattern and
+    broadcast through the inverse index (likelihood.py:183-190).  dtype follows `weights`
+    (float32 in the sampler: state.py:546)."""
+    pattern, inverse = np.unique(has_comp, axis=0, return_inverse=True)
+    w = pattern[:, None, :] * weights[None, :, :]
+    w /= w.sum(axis=-1, keepdims=True)
+    return w[np.asarray(inverse).reshape(-1)]
+
+
+def weight_patterns(weights, has_comp):
+    """The factorised form of normalize_weights: (w_pat [P, F, C], pattern_id [N]).  Same
+    arithmetic as above, without the broadcast (this is what crosses the C-ABI)."""
+    pattern, inverse = np.unique(has_comp, axis=0, return_inverse=True)
+    w = pattern[:, None, :] * weights[None, :, :]
+    w /= w.sum(axis=-1, keepdims=True)
+    return w, np.asarray(inverse).reshape(-1)
+
+
+# --------------------------------------------------------------------------------------
+# a9  feature counts                                       sbayes/sampling/counts.py:10-95
+# --------------------------------------------------------------------------------------
+def compute_effect_counts(features, group_assignment, source_is_component, object_subset=slice(None)):
+    """counts[g, f, s] = #{n in g (and in object_subset): source_is_component[n, f] and
+    features[n, f, s]} as float32 (counts.py:20, 28-30)."""
+    group_assignment = group_assignment[:, object_subset]
+    n_groups = group_assignment.shape[0]
+    _, n_features, n_states = features.shape
+    counts = np.zeros((n_groups, n_features, n_states), dtype=FLOAT_TYPE)
+    if not group_assignment.any():
+        return counts
+    src = source_is_component[object_subset]
+    feat = features[object_subset]
+    for i_g in range(n_groups):
+        members = group_assignment[i_g]
+        if members.any():
+            counts[i_g] = np.count_nonzero(src[members][:, :, None] & feat[members], axis=0)
+    return counts
+
+
+def recalculate_feature_counts(features, groups_by_component, source):
+    """counts.py:35-52: one compute_effect_counts per mixture component; component c uses
+    source[..., c]."""
+    return [
+        compute_effect_counts(features, groups, source[..., c])
+        for c, groups in enumerate(groups_by_component)
+    ]
+
+
+def update_feature_counts(counts, features, groups_old, groups_new, source_old, source_new, object_subset):
+    """counts.py:55-95: delta update restricted to `object_subset`; returns new count arrays
+    and, per component, the bool mask of groups whose counts changed (state.py:349-350)."""
+    new_counts, changed = [], []
+    for c in range(len(counts)):
+        old_c = compute_effect_counts(features, groups_old[c], source_old[..., c], object_subset)
+        new_c = compute_effect_counts(features, groups_new[c], source_new[..., c], object_subset)
+        diff = new_c - old_c
+        new_counts.append(counts[c] + diff)
+        changed.append(np.any(diff != 0, axis=(1, 2)))
+    return new_counts, changed
+
+
+# --------------------------------------------------------------------------------------
+# a8  dirichlet_categorical_logpdf                             sbayes/util.py:1373-1394
+# --------------------------------------------------------------------------------------
+def dirichlet_categorical_logpdf(counts, a):
+    """Per feature: lgamma(sum a) - lgamma(n + sum a) + sum_{s: a>0} (lgamma(c + a) - lgamma(a)),
+    rounded to float32 (util.py:1390-1394).  lgamma(0) = +inf in the dead lanes is masked
+    by the `a > 0` select."""
+    counts = np.asarray(counts)
+    a = np.asarray(a)
+    n = counts.sum(axis=-1)
+    sum_a = a.sum(axis=-1)
+    const = _gammaln(sum_a) - _gammaln(n + sum_a)
+    with np.errstate(invalid="ignore"):
+        series = np.where(a > 0, _gammaln(counts + a) - _gammaln(a), 0.0)
+    return (const + series.sum(axis=-1)).astype(FLOAT_TYPE)
+
+
+# --------------------------------------------------------------------------------------
+# a7  Likelihood.__call__ (collapsed form)              sbayes/model/likelihood.py:47-101
+# --------------------------------------------------------------------------------------
+def collapsed_group_logliks(counts, concentration):
+    """float64 [G]: per group the float32 `.sum()` over features of a8 (likelihood.py:74-77,
+    95-99), stored into the float64 per-group cache (state.py:401-404).
+    `concentration` is [F, S] (clusters: prior.py:453-455) or [G, F, S] (confounders:
+    prior.py:285)."""
+    n_groups = counts.shape[0]
+    out = np.empty(n_groups, dtype=np.float64)
+    for g in range(n_groups):
+        a = concentration if concentration.ndim == 2 else concentration[g]
+        out[g] = dirichlet_categorical_logpdf(counts[g], a).sum()
+    return out
+
+
+def collapsed_loglik(counts_by_component, concentration_by_component):
+    """Likelihood.__call__: sum over components of the float64 sum over groups of the
+    per-group values (likelihood.py:58-63, 79, 101)."""
+    log_lh = 0.0
+    for counts, conc in zip(counts_by_component, concentration_by_component):
+        log_lh += collapsed_group_logliks(counts, conc).sum()
+    return log_lh
+
+
+# --------------------------------------------------------------------------------------
+# a10 conditional_effect_mean                       sbayes/sampling/conditionals.py:105-122
+# --------------------------------------------------------------------------------------
+def conditional_effect_mean(prior_counts, feature_counts, unif_counts=None,
+                            prior_temperature=None, temperature=None):
+    if prior_temperature is not None:
+        assert unif_counts is not None
+        prior_counts = unif_counts + (prior_counts - unif_counts) / prior_temperature
+    if temperature is not None:
+        feature_counts = feature_counts / temperature
+    return normalize(feature_counts + prior_counts, axis=-1)
+
+
+# --------------------------------------------------------------------------------------
+# a3  likelihood_per_component                     sbayes/sampling/conditionals.py:152-223
+# --------------------------------------------------------------------------------------
+def component_probs(counts, concentration):
+    """normalize(counts + prior) -> float32 [G, F, S] (conditionals.py:175-179, 200-204).
+    A 2-D concentration [F, S] broadcasts over groups (cluster effect prior)."""
+    return normalize(counts + concentration, axis=-1)
+
+
+def likelihood_per_component(features, na_values, groups_by_component, counts_by_component,
+                             concentration_by_component, changed_by_component=None, out=None):
+    """float64 [N, F, C].  Component c's slice is written by a1 through the strided view
+    out[..., c] (conditionals.py:182-188, 208-214); finally NA observations are set to 1 in
+    every component (conditionals.py:216).  `changed_by_component=None` means caching=False
+    (all groups, state.py:251-252); components whose changed list is empty are skipped
+    (conditionals.py:173, 196-197)."""
+    n_objects, n_features, _ = features.shape
+    n_comp = len(groups_by_component)
+    if out is None:
+        out = np.empty((n_objects, n_features, n_comp), dtype=np.float64)
+    for c in range(n_comp):
+        groups = groups_by_component[c]
+        changed = np.arange(groups.shape[0]) if changed_by_component is None else changed_by_component[c]
+        if len(changed) == 0:
+            continue
+        probs = component_probs(counts_by_component[c], concentration_by_component[c])
+        compute_component_likelihood(features, probs, groups, changed, out[..., c])
+    out[na_values] = 1.0
+    return out
+
+
+def likelihood_per_component_exact(features, na_values, groups_by_component, counts_by_component,
+                                   concentration_by_component, source):
+    """conditionals.py:300-367: leave-one-out tables -- each member's own observation
+    (where its source is this component) is subtracted from the group's posterior counts
+    before normalising."""
+    n_objects, n_features, _ = features.shape
+    n_comp = len(groups_by_component)
+    out = np.empty((n_objects, n_features, n_comp), dtype=np.float64)
+    for c in range(n_comp):
+        groups = groups_by_component[c]
+        post = counts_by_component[c] + concentration_by_component[c]
+        tables = []
+        for g in range(groups.shape[0]):
+            members = groups[g]
+            own = features[members] * source[members, :, c, None]
+            tables.append(normalize(post[None, g, :, :] - own, axis=-1))
+        compute_component_likelihood_exact(features, tables, groups, np.arange(groups.shape[0]), out[..., c])
+    out[na_values] = 1.0
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# a6 + SURVEY.md 8(d): the mixture log-likelihood scalar ("one eval")
+#     loggers.py:355-357 / operators.py:568-574 / operators.py:1060-1061
+# --------------------------------------------------------------------------------------
+def mixture_observation_lh(weights_normalized, component_lh):
+    """float64 [N, F]: sum_c w[n,f,c] * lh[n,f,c] (float32 x float64 -> float64)."""
+    return np.sum(weights_normalized * component_lh, axis=-1)
+
+
+def mixture_loglik(features, na_values, groups_by_component, counts_by_component,
+                   concentration_by_component, weights):
+    """One uncached eval of LL = sum_{n,f not NA} log sum_c w[n,f,c] p_c[g_c(n), f, x(n,f)].
+    Reference composition:
+      np.log(np.sum(update_weights(s, caching=False) *
+                    likelihood_per_component(model, s, caching=False), axis=-1))[~na].sum()"""
+    lh = likelihood_per_component(features, na_values, groups_by_component,
+                                  counts_by_component, concentration_by_component)
+    w = normalize_weights(weights, has_components(groups_by_component))
+    with np.errstate(divide="ignore"):
+        return np.log(mixture_observation_lh(w, lh))[~na_values].sum()

@@ -1,0 +1,410 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE implementation.
+
+Runs only in the build container (needs /root/reference, read-only).  The reference is a
+Python package that cannot be imported as-is here (numba & geo deps missing), so it is
+imported through the stubs in _ref_stubs.py (numba decorators = identity => the NumPy
+path BASELINE.json names).  The fixtures are DATA: inputs and the reference's outputs on
+them.  No reference source travels.
+
+  python tests/golden/make_golden.py            # regenerates every fixture
+
+Fixtures
+  cfg1.npz            50x30x5 synthetic (ragged states): full arrays of every a1..a10 output
+  headline.json       1000x200x10 synthetic: generator seeds + scalars + CRCs + spot values
+  stress.json         5000x500x20 synthetic: same
+  south_america.npz   experiments/south_america real data through the reference loader:
+                      tensors, real Dirichlet prior tables, initial sample, all outputs
+  south_america_trace.npz   400 MCMC steps of the reference sampler: per-step state + scalars
+  test_files.npz      test/test_files (5 objects x 2 features): tensors + outputs
+  test_files_trace.npz  300 MCMC steps on it
+  known_answers.json  hand-derivable cases from the reference's commented-out test
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import random
+import shutil
+import sys
+import zlib
+from collections import OrderedDict
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(REPO))
+
+import _ref_stubs  # noqa: E402
+
+_ref_stubs.install()
+
+from sbayes.load_data import Confounder, Data, Features  # noqa: E402
+from sbayes.model import Model  # noqa: E402
+from sbayes.model.likelihood import (  # noqa: E402
+    Likelihood, compute_component_likelihood, normalize_weights, update_weights)
+from sbayes.model.model_shapes import ModelShapes  # noqa: E402
+from sbayes.sampling.conditionals import (  # noqa: E402
+    conditional_effect_mean, likelihood_per_component, likelihood_per_component_exact)
+from sbayes.sampling.counts import (  # noqa: E402
+    compute_effect_counts, recalculate_feature_counts, update_feature_counts)
+from sbayes.sampling.state import Sample  # noqa: E402
+from sbayes.util import dirichlet_categorical_logpdf, normalize  # noqa: E402
+
+from sbayes_amd.synthetic import make_workload  # noqa: E402
+
+WORK = Path("/tmp/sbayes_amd_golden_work")
+
+
+def crc(a) -> int:
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def sha(a) -> str:
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ----------------------------------------------------------------------------------------
+# reference objects for a synthetic workload
+# ----------------------------------------------------------------------------------------
+class _ConfPrior:
+    any_dynamic_priors = False
+
+    def __init__(self, arr):
+        self._arr = arr
+
+    def concentration_array(self, sample):
+        return self._arr
+
+
+def reference_objects(wl):
+    n_objects, n_features, n_states = wl.shape
+    features = Features(
+        values=wl.features,
+        names=np.array([f"F{i}" for i in range(n_features)]),
+        states=wl.states_per_feature,
+        state_names=[[f"s{j}" for j in range(int(k))] for k in wl.states_per_feature.sum(axis=1)],
+        na_number=int(wl.na_values.sum()),
+    )
+    confounders = OrderedDict()
+    for name, g in zip(wl.component_names[1:], wl.groups[1:]):
+        confounders[name] = Confounder(name=name, group_assignment=g,
+                                       group_names=[f"g{j}" for j in range(g.shape[0])])
+    shapes = ModelShapes(
+        n_clusters=wl.clusters.shape[0], n_sites=n_objects, n_features=n_features,
+        n_states=n_states, states_per_feature=wl.states_per_feature,
+        n_confounders=len(confounders),
+        n_groups={k: c.n_groups for k, c in confounders.items()},
+    )
+    prior = SimpleNamespace(
+        prior_cluster_effect=SimpleNamespace(concentration_array=wl.concentration[0]),
+        prior_confounding_effects={
+            name: _ConfPrior(conc) for name, conc in zip(wl.component_names[1:], wl.concentration[1:])
+        },
+    )
+    data = SimpleNamespace(features=features, confounders=confounders)
+    model = SimpleNamespace(data=data, prior=prior, shapes=shapes)
+    model.likelihood = Likelihood(data=data, shapes=shapes, prior=prior)
+    counts0 = {"clusters": np.zeros((shapes.n_clusters, n_features, n_states), dtype=np.float32)}
+    for name, c in confounders.items():
+        counts0[name] = np.zeros((c.n_groups, n_features, n_states), dtype=np.float32)
+    sample = Sample.from_numpy_arrays(
+        clusters=wl.clusters.copy(), weights=wl.weights.copy(), confounders=confounders,
+        source=wl.source.copy(), feature_counts=counts0, model_shapes=shapes)
+    recalculate_feature_counts(features.values, sample)
+    return model, sample
+
+
+def concentration_list(model, sample):
+    out = [np.asarray(model.prior.prior_cluster_effect.concentration_array, dtype=np.float64)]
+    for name in sample.confounders:
+        out.append(np.asarray(model.prior.prior_confounding_effects[name].concentration_array(sample),
+                              dtype=np.float64))
+    return out
+
+
+def reference_outputs(model, sample, full: bool):
+    """Everything the reference computes on the hot path for one sample."""
+    feats = model.data.features
+    na = feats.na_values
+    names = sample.component_names
+    groups = [sample.clusters.value] + [c.group_assignment for c in sample.confounders.values()]
+    conc = concentration_list(model, sample)
+    counts = [sample.feature_counts[k].value.copy() for k in names]
+    probs = [normalize(counts[i] + conc[i], axis=-1) for i in range(len(names))]
+
+    lh = likelihood_per_component(model, sample, caching=False).copy()
+    w = update_weights(sample, caching=False).copy()
+    obs = np.sum(w * lh, axis=-1)
+    with np.errstate(divide="ignore"):
+        mixture_ll = float(np.log(obs)[~na].sum())
+    collapsed = float(model.likelihood(sample, caching=False))
+    group_lh = [sample.cache.group_likelihoods[k].value.copy() for k in names]
+    lh_exact = likelihood_per_component_exact(model, sample)
+    obs_exact = np.sum(w * lh_exact, axis=2)
+
+    scal = dict(mixture_ll=mixture_ll, collapsed_ll=collapsed,
+                mixture_ll_exact=float(np.log(obs_exact)[~na].sum()))
+    arrs = dict()
+    for i, k in enumerate(names):
+        arrs[f"groups_{i}"] = groups[i]
+        arrs[f"conc_{i}"] = conc[i]
+        arrs[f"counts_{i}"] = counts[i]
+        arrs[f"group_lh_{i}"] = group_lh[i]
+        if full:
+            arrs[f"probs_{i}"] = probs[i]
+            a = conc[i] if conc[i].ndim == 3 else np.broadcast_to(conc[i], counts[i].shape)
+            arrs[f"dcl_{i}"] = np.stack([dirichlet_categorical_logpdf(counts[i][g], a[g])
+                                         for g in range(counts[i].shape[0])])
+    if full:
+        arrs.update(lh_per_component=lh, weights_normalized=w, obs_lh=obs, lh_exact=lh_exact)
+    digests = dict(
+        lh_crc=crc(lh), lh_sum=float(lh.sum()), w_crc=crc(w), obs_crc=crc(obs),
+        lh_exact_crc=crc(lh_exact),
+        probs_crc=[crc(p) for p in probs], counts_crc=[crc(c) for c in counts],
+        group_lh=[g.tolist() for g in group_lh],
+    )
+    return scal, arrs, digests
+
+
+def partial_update_case(model, sample, rng):
+    """compute_component_likelihood with a strict subset of changed groups and a
+    sentinel-filled strided `out` view."""
+    feats = model.data.features.values
+    n, f, _ = feats.shape
+    clusters = sample.clusters.value
+    k = clusters.shape[0]
+    counts = sample.feature_counts["clusters"].value
+    probs = normalize(counts + model.prior.prior_cluster_effect.concentration_array, axis=-1)
+    buf = rng.random((n, f, 3))
+    before = buf.copy()
+    changed = np.array(sorted(rng.choice(k, size=max(1, k // 2), replace=False)), dtype=np.int64)
+    compute_component_likelihood(features=feats, probs=probs, groups=clusters,
+                                 changed_groups=changed, out=buf[..., 1])
+    return dict(partial_before=before, partial_changed=changed, partial_after=buf)
+
+
+def delta_counts_case(model, sample, rng):
+    """update_feature_counts on an object subset after moving objects between clusters
+    and flipping their source (counts.py:55-95)."""
+    feats = model.data.features.values
+    n, f, c = sample.source.value.shape
+    new = sample.copy()
+    subset = np.sort(rng.choice(n, size=min(12, n), replace=False))
+    k = sample.n_clusters
+    with new.clusters.edit() as cl:
+        cl[:, subset] = False
+        tgt = rng.integers(0, k + 1, size=len(subset))
+        for o, t in zip(subset, tgt):
+            if t < k:
+                cl[t, o] = True
+    has = np.stack([new.clusters.value.any(axis=0)] +
+                   [cf.any_group() for cf in new.confounders.values()], axis=1)
+    with new.source.edit() as src:
+        for o in subset:
+            allowed = np.flatnonzero(has[o])
+            pick = rng.choice(allowed, size=f)
+            src[o] = np.eye(c, dtype=bool)[pick]
+            src[o][model.data.features.na_values[o]] = False
+    update_feature_counts(sample, new, feats, subset)
+    out = dict(delta_subset=subset, delta_clusters_new=new.clusters.value.copy(),
+               delta_source_new=new.source.value.copy())
+    for i, name in enumerate(new.component_names):
+        out[f"delta_counts_{i}"] = new.feature_counts[name].value.copy()
+    # the delta result must equal a full recount (reference's own verify_counts idea)
+    chk = new.copy()
+    recalculate_feature_counts(feats, chk)
+    for i, name in enumerate(new.component_names):
+        assert np.array_equal(chk.feature_counts[name].value, out[f"delta_counts_{i}"])
+    return out
+
+
+def effect_mean_case(model, sample):
+    counts = sample.feature_counts["clusters"].value
+    prior = np.broadcast_to(model.prior.prior_cluster_effect.concentration_array, counts.shape)
+    unif = np.broadcast_to(model.shapes.states_per_feature.astype(float), counts.shape)
+    return dict(
+        cem_plain=conditional_effect_mean(prior, counts),
+        cem_temp=conditional_effect_mean(prior, counts, unif_counts=unif,
+                                         prior_temperature=1.7, temperature=2.5),
+    )
+
+
+def synthetic_fixture(name: str, full: bool):
+    wl = make_workload(name)
+    model, sample = reference_objects(wl)
+    scal, arrs, dig = reference_outputs(model, sample, full=full)
+    meta = dict(name=name, shape=list(wl.shape), seeds=list(wl.seeds),
+                n_components=wl.n_components, groups=[int(g.shape[0]) for g in wl.groups],
+                input_crc=dict(features=crc(wl.features), weights=crc(wl.weights), source=crc(wl.source),
+                               groups=[crc(g) for g in wl.groups]),
+                **scal, **dig)
+    if full:
+        rng = np.random.default_rng(7)
+        extra = {}
+        extra.update(partial_update_case(model, sample, rng))
+        extra.update(delta_counts_case(model, sample, rng))
+        extra.update(effect_mean_case(model, sample))
+        np.savez_compressed(
+            HERE / f"{name}.npz", features=wl.features, states_per_feature=wl.states_per_feature,
+            weights=wl.weights, source=wl.source, meta=json.dumps(meta), **arrs, **extra)
+    else:
+        # spot values of the big arrays so a mismatch can be localised without the CRC
+        lh = likelihood_per_component(model, sample, caching=False)
+        idx = np.random.default_rng(11).integers(0, lh.size, size=64)
+        meta["lh_spot_idx"] = idx.tolist()
+        meta["lh_spot_val"] = lh.reshape(-1)[idx].tolist()
+        with open(HERE / f"{name}.json", "w") as fh:
+            json.dump(meta, fh, indent=1)
+    print(f"[golden] {name}: mixture_ll={scal['mixture_ll']!r} collapsed_ll={scal['collapsed_ll']!r}")
+
+
+# ----------------------------------------------------------------------------------------
+# real configs through the reference's own loader + sampler
+# ----------------------------------------------------------------------------------------
+def stage_config(src_dir: Path, dst_name: str, edits=None) -> Path:
+    dst = WORK / dst_name
+    if dst.exists():
+        shutil.rmtree(dst)
+    shutil.copytree(src_dir, dst)
+    return dst
+
+
+def real_fixture(tag: str, config_path: Path, n_trace_steps: int, seed: int):
+    from sbayes.experiment_setup import Experiment
+    from sbayes.sampling.initializers import SbayesInitializer
+    from sbayes.sampling.mcmc_chain import MCMCChain
+
+    np.random.seed(seed)
+    random.seed(seed)
+    cwd = os.getcwd()
+    os.chdir(config_path.parent)
+    try:
+        experiment = Experiment(config_file=config_path, experiment_name=f"golden_{tag}", log=False)
+        data = Data.from_config(experiment.config)
+        model = Model(data, experiment.config.model)
+        mcmc_cfg = experiment.config.mcmc
+        init = SbayesInitializer(
+            model=model, data=data,
+            initial_size=mcmc_cfg.initialization.objects_per_cluster,
+            attempts=mcmc_cfg.initialization.attempts,
+            initial_cluster_steps=mcmc_cfg.initialization._initial_cluster_steps,
+        )
+        sample = init.generate_sample(c=0)
+        recalculate_feature_counts(data.features.values, sample)
+
+        scal, arrs, dig = reference_outputs(model, sample, full=True)
+        rng = np.random.default_rng(5)
+        extra = {}
+        extra.update(partial_update_case(model, sample, rng))
+        extra.update(delta_counts_case(model, sample, rng))
+        meta = dict(name=tag, shape=list(data.features.values.shape),
+                    component_names=sample.component_names,
+                    groups=[int(sample.n_groups(k)) for k in sample.component_names], **scal, **dig)
+        np.savez_compressed(
+            HERE / f"{tag}.npz", features=data.features.values,
+            states_per_feature=data.features.states,
+            weights=sample.weights.value, source=sample.source.value,
+            meta=json.dumps(meta), **arrs, **extra)
+        print(f"[golden] {tag}: mixture_ll={scal['mixture_ll']!r} collapsed_ll={scal['collapsed_ll']!r}")
+
+        # ---- recorded MCMC trace (SURVEY.md 8(c) "trace-replay") -------------------------
+        chain = MCMCChain(model=model, data=data, operators=mcmc_cfg.operators, sample_loggers=[])
+        chain._ll = chain.likelihood(sample)
+        chain._prior = chain.prior(sample)
+        na = data.features.na_values
+        rec = dict(clusters=[], weights=[], source=[], last_lh=[], mixture_ll=[], lh_sha=[],
+                   collapsed_uncached=[], group_lh=[], operator=[])
+        for i_step in range(1, n_trace_steps + 1):
+            sample = chain.step(sample)
+            sample.i_step = i_step
+            lh = likelihood_per_component(model, sample, caching=True)
+            w = update_weights(sample, caching=True)
+            with np.errstate(divide="ignore"):
+                mix = float(np.log(np.sum(w * lh, axis=-1))[~na].sum())
+            rec["clusters"].append(np.packbits(sample.clusters.value))
+            rec["weights"].append(sample.weights.value.copy())
+            rec["source"].append(np.packbits(sample.source.value))
+            rec["last_lh"].append(float(chain._ll))
+            rec["mixture_ll"].append(mix)
+            rec["lh_sha"].append(sha(lh))
+            rec["group_lh"].append(np.concatenate(
+                [sample.cache.group_likelihoods[k].value for k in sample.component_names]))
+            rec["operator"].append(chain.previous_operator.operator_name)
+        # a few uncached cross-checks of the reference against itself
+        final = sample.copy()
+        rec_final_uncached = float(model.likelihood(final, caching=False))
+        assert np.allclose(rec_final_uncached, rec["last_lh"][-1])
+        np.savez_compressed(
+            HERE / f"{tag}_trace.npz",
+            clusters=np.stack(rec["clusters"]), weights=np.stack(rec["weights"]),
+            source=np.stack(rec["source"]), last_lh=np.array(rec["last_lh"]),
+            mixture_ll=np.array(rec["mixture_ll"]), lh_sha=np.array(rec["lh_sha"]),
+            group_lh=np.stack(rec["group_lh"]), operator=np.array(rec["operator"]),
+            clusters_shape=np.array(sample.clusters.value.shape),
+            source_shape=np.array(sample.source.value.shape),
+            final_collapsed_uncached=rec_final_uncached,
+        )
+        n_acc = len({s.tobytes() for s in rec["clusters"]})
+        print(f"[golden] {tag}_trace: {n_trace_steps} steps, {n_acc} distinct cluster states, "
+              f"ll {rec['last_lh'][0]:.3f} -> {rec['last_lh'][-1]:.3f}")
+    finally:
+        os.chdir(cwd)
+
+
+# ----------------------------------------------------------------------------------------
+# hand-derivable known answers (test/test_model.py:157-207, commented out in the reference)
+# ----------------------------------------------------------------------------------------
+def known_answers():
+    """3 objects x 1 binary feature.  Evaluate the reference's own functions on the
+    hand-derivable configurations so the expected values are both derived and observed."""
+    feats = np.array([[[True, False]], [[True, False]], [[False, True]]])   # states: 0, 0, 1
+    cases = []
+    # case A: everyone in the universal group only, p = (0.5, 0.5): lh = 0.5^3 = 0.125
+    groups = np.ones((1, 3), dtype=bool)
+    probs = np.array([[[0.5, 0.5]]], dtype=np.float32)
+    out = compute_component_likelihood(feats, probs, groups, np.arange(1), np.empty((3, 1)))
+    cases.append(dict(name="uniform_0.125", per_obs=out.ravel().tolist(), product=float(out.prod()),
+                      expected=0.125))
+    # case B: p = (0.75, 0.25): objects 0,1 see 0.75, object 2 sees 0.25 -> 0.25 * 0.75^2
+    probs = np.array([[[0.75, 0.25]]], dtype=np.float32)
+    out = compute_component_likelihood(feats, probs, groups, np.arange(1), np.empty((3, 1)))
+    cases.append(dict(name="skewed_0.25x0.75^2", per_obs=out.ravel().tolist(), product=float(out.prod()),
+                      expected=0.25 * 0.75 ** 2))
+    # case C: deterministic table (1, 0): object 2 has likelihood 0 -> product 0
+    probs = np.array([[[1.0, 0.0]]], dtype=np.float32)
+    out = compute_component_likelihood(feats, probs, groups, np.arange(1), np.empty((3, 1)))
+    cases.append(dict(name="zero", per_obs=out.ravel().tolist(), product=float(out.prod()), expected=0.0))
+    # case D: mixture weights 1/2,1/2 over a cluster (objects 0,1; table (1,0)) and universal (0.5,0.5)
+    hc = np.array([[True, True], [True, True], [False, True]])
+    w = normalize_weights(np.array([[0.5, 0.5]], dtype=np.float32), hc)
+    cases.append(dict(name="weights_pattern", w=w.tolist(),
+                      expected=[[[0.5, 0.5]], [[0.5, 0.5]], [[0.0, 1.0]]]))
+    # Dirichlet-categorical doctest value (util.py:1386-1388): log(1/12)
+    v = dirichlet_categorical_logpdf(np.array([[2, 1, 0, 0]], dtype=np.float32),
+                                     np.array([[1.0, 1.0, 0.0, 0.0]]))
+    cases.append(dict(name="dirichlet_categorical_log_1_12", value=float(v[0]), expected=float(np.log(1 / 12))))
+    with open(HERE / "known_answers.json", "w") as fh:
+        json.dump(cases, fh, indent=1)
+    print("[golden] known_answers.json")
+
+
+def main():
+    WORK.mkdir(parents=True, exist_ok=True)
+    known_answers()
+    synthetic_fixture("cfg1", full=True)
+    synthetic_fixture("headline", full=False)
+    synthetic_fixture("stress", full=False)
+    sa = stage_config(Path("/root/reference/experiments/south_america"), "south_america")
+    real_fixture("south_america", sa / "config.yaml", n_trace_steps=400, seed=123)
+    tf = stage_config(Path("/root/reference/test/test_files"), "test_files")
+    real_fixture("test_files", tf / "config.yaml", n_trace_steps=300, seed=321)
+
+
+if __name__ == "__main__":
+    main()
