@@ -1,0 +1,198 @@
+/* sbe_engine.h -- C ABI of the MI355X-native sBayes likelihood engine ("sbe").
+ *
+ * This is the drop-in boundary for the hot path named in BASELINE.json `north_star`
+ * (SURVEY.md section 8): plain C, opaque handle, plain pointers and sizes, no torch / numpy
+ * types.  The reference (NicoNeureiter/sBayes, pure Python) has no FFI of its own; each
+ * entry point below names the reference function (file:line under /root/reference) whose
+ * arithmetic it replaces.  The ctypes binding a reference maintainer would add is shown in
+ * INTEGRATION.md and shipped as sbayes_amd/_lib.py.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message is available
+ *     through sbe_last_error().  No exception crosses the ABI.
+ *   - the caller owns every host buffer; the engine copies what it needs during the call
+ *     and never retains host pointers.  The engine owns all device memory.
+ *   - the one-hot feature block is uploaded once (sbe_create) and stays resident in HBM.
+ *   - sample state lives in *slots* (0 .. n_slots-1) so that several MCMC states (chains,
+ *     or current + candidate) are resident at once; every state call names its slot.
+ *   - one engine per process per GPU; calls on one engine must be serialised by the caller.
+ *     Calls are synchronous unless the name ends in _async.
+ *   - bool arrays are one byte per element (NumPy bool layout), C order.
+ */
+#ifndef SBE_ENGINE_H
+#define SBE_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sbe_engine sbe_engine;
+
+#define SBE_ABI_VERSION 1
+
+/* error codes */
+#define SBE_OK 0
+#define SBE_ERR_ARG 1        /* invalid argument / shape                                   */
+#define SBE_ERR_HIP 2        /* HIP runtime error (message holds hipGetErrorString)        */
+#define SBE_ERR_STATE 3      /* call sequence error (e.g. probs not set)                   */
+#define SBE_ERR_DATA 4       /* data violates a precondition the reference asserts         */
+#define SBE_ERR_NODEVICE 5   /* no usable GPU                                              */
+
+/* fused-kernel variants (sbe_set_option(SBE_OPT_MIXTURE_KERNEL, ...)) */
+#define SBE_OPT_MIXTURE_KERNEL 1
+#define SBE_MIXTURE_PACKED 0   /* reads the packed state-index block  (N*F bytes)           */
+#define SBE_MIXTURE_ONEHOT 1   /* reads the one-hot block as handed over (N*F*S bytes)      */
+#define SBE_OPT_LOG_MODE 2
+#define SBE_LOG_PER_OBS 0      /* fp64 log per observation, fp64 sum                        */
+#define SBE_LOG_PRODUCT 1      /* fp64 mantissa product + integer exponent, one log/thread  */
+
+typedef struct sbe_info {
+    int32_t abi_version;
+    int32_t device;
+    int32_t n_objects, n_features, n_states, n_components, n_slots;
+    int32_t n_groups_total;
+    int64_t n_na;              /* observations with an all-False state row (load_data.py:105) */
+    int64_t hbm_bytes;         /* device memory held by the engine                          */
+    int32_t compute_units;
+    char device_name[64];
+} sbe_info;
+
+int sbe_abi_version(void);
+int sbe_device_count(int* out_count);
+
+/* Global (handle-less) error text for failures of sbe_create itself. */
+const char* sbe_last_error(const sbe_engine* e);
+
+/* ---- lifetime ------------------------------------------------------------------------
+ * Likelihood.__init__ (sbayes/model/likelihood.py:36-45): stores features, derives
+ * na_features = (sum over states == 0).  Here: uploads the one-hot block, validates that
+ * every (object, feature) row has at most one set state, derives the packed state-index
+ * block [N][F] (0xFF = NA) on the device.
+ *   n_groups[c]: number of groups of mixture component c (c = 0: clusters, K;
+ *                c >= 1: confounders, load_data.py:138-184).  */
+int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int n_states,
+               int n_components, const int32_t* n_groups, int n_slots,
+               const uint8_t* features_onehot /* [N][F][S] bool */);
+int sbe_destroy(sbe_engine* e);
+int sbe_get_info(const sbe_engine* e, sbe_info* out);
+int sbe_get_na(const sbe_engine* e, uint8_t* out_na /* [N][F] bool */);
+int sbe_set_option(sbe_engine* e, int option, int value);
+int sbe_sync(sbe_engine* e);
+
+/* ---- a1: compute_component_likelihood (sbayes/model/likelihood.py:104-133) -------------
+ * out[g_i, :] = sum_s features[g_i, :, s] * probs[i, :, s] for i in changed_groups; rows of
+ * objects in no group <- 0; rows of members of unchanged groups are left untouched; later
+ * groups overwrite earlier ones.  `out` is a strided host view (the reference passes
+ * component_likelihood[..., i], element stride C*8 bytes along F).  Stateless: touches no slot.
+ *   probs_f64: 0 = float32 tables (what normalize() returns, util.py:1007), 1 = float64.  */
+int sbe_component_lh(sbe_engine* e, const void* probs /* [G][F][S] */, int probs_f64, int n_groups,
+                     const uint8_t* groups /* [G][N] bool */, const int64_t* changed_groups,
+                     int n_changed, double* out, int64_t out_stride_n_bytes, int64_t out_stride_f_bytes);
+
+/* ---- a2: compute_component_likelihood_exact (likelihood.py:136-150) via
+ * likelihood_per_component_exact (sbayes/sampling/conditionals.py:300-367): leave-one-out
+ * tables built from the slot's counts + concentration and the slot's source; all components;
+ * NA observations <- 1.  out: dense [N][F][C] float64. */
+int sbe_likelihood_per_component_exact(sbe_engine* e, int slot, double* out);
+
+/* ---- slot state: groups (state.py Clusters / load_data.py Confounder.group_assignment) --
+ * An object that is in several groups of one component takes the LAST one (what a1 does
+ * when all groups are recomputed).  Also refreshes has_components (state.py:353-376). */
+int sbe_set_groups(sbe_engine* e, int slot, int component, const uint8_t* groups /* [G_c][N] bool */);
+int sbe_set_group_ids(sbe_engine* e, int slot, int component, const int32_t* ids /* [N], -1 = none */);
+
+/* ---- slot state: source (state.py:510, bool [N][F][C] one-hot over components) --------- */
+int sbe_set_source(sbe_engine* e, int slot, const uint8_t* source /* [N][F][C] bool */);
+int sbe_set_source_rows(sbe_engine* e, int slot, const int32_t* objects, int n_rows,
+                        const uint8_t* rows /* [n_rows][F][C] bool */);
+
+/* ---- a9: feature counts (sbayes/sampling/counts.py:10-95) ------------------------------
+ * sbe_recount: recalculate_feature_counts (counts.py:35-52) for one component (or all: -1)
+ *              from the slot's groups + source.
+ * sbe_accumulate_counts: one half of update_feature_counts (counts.py:55-95): adds
+ *              sign * compute_effect_counts(groups, source, object_subset) using the slot's
+ *              CURRENT groups/source; call with sign=-1 before editing the slot and sign=+1
+ *              after.  changed_groups_out[G_total] (may be NULL) receives 1 for every group
+ *              whose counts changed in this call (FeatureCounts.add_changes, state.py:340-350).
+ * Counts are integers; they are exchanged as float32 (FLOAT_TYPE, counts.py:20).          */
+int sbe_recount(sbe_engine* e, int slot, int component);
+/* update_feature_counts(sample_old, sample_new, features, object_subset) (counts.py:55-95):
+ * counts[slot_new] += compute_effect_counts(new state, subset) - compute_effect_counts(old
+ * state, subset), for every component, in one launch.  Precondition: counts[slot_new] hold
+ * the old state's counts (sbe_copy_slot, then edit groups / source rows of slot_new).
+ * changed_groups_out[G_total] = np.any(diff != 0, axis=(1,2)) per group (state.py:349-350). */
+int sbe_update_counts(sbe_engine* e, int slot_new, int slot_old, const int32_t* objects,
+                      int n_objects_subset, uint8_t* changed_groups_out);
+int sbe_accumulate_counts(sbe_engine* e, int slot, const int32_t* objects, int n_objects_subset,
+                          int sign, uint8_t* changed_groups_out);
+int sbe_set_counts(sbe_engine* e, int slot, int component, const float* counts /* [G_c][F][S] */);
+int sbe_get_counts(sbe_engine* e, int slot, int component, float* out /* [G_c][F][S] */);
+
+/* ---- Dirichlet concentration tables (sbayes/model/prior.py:325-354, 453-455) -----------
+ * per_group = 0: [F][S] broadcast over groups (cluster effect prior); 1: [G_c][F][S]. Shared
+ * by all slots. */
+int sbe_set_concentration(sbe_engine* e, int component, const double* conc, int per_group);
+
+/* ---- a4 + a3/a10: probability tables ----------------------------------------------------
+ * sbe_update_probs: probs = normalize(counts/T + prior') -> float32 (util.py:990-1007 called
+ *   from conditionals.py:175-179, 200-204; tempered form conditionals.py:105-122 with
+ *   prior' = unif + (prior - unif)/T_prior when prior_temperature > 0).  temperature <= 0
+ *   and prior_temperature <= 0 mean "not given".  Fails with SBE_ERR_DATA when a row sum
+ *   is not positive (the reference's assert, util.py:1006).
+ * sbe_set_probs: explicit tables instead. */
+int sbe_update_probs(sbe_engine* e, int slot, int component, double temperature,
+                     double prior_temperature, const double* unif_counts /* [F][S] or NULL */);
+int sbe_set_probs(sbe_engine* e, int slot, int component, const float* probs /* [G_c][F][S] */);
+int sbe_get_probs(sbe_engine* e, int slot, int component, float* out /* [G_c][F][S] */);
+
+/* ---- a5: normalize_weights / update_weights (likelihood.py:153-190) ---------------------
+ * Stores the mixture weights [F][C] (float32, state.py:546) and builds the per-pattern
+ * normalised tables on the device from the slot's has_components. */
+int sbe_set_weights(sbe_engine* e, int slot, const float* weights /* [F][C] */);
+int sbe_get_weights_normalized(sbe_engine* e, int slot, float* out /* [N][F][C] */);
+
+/* ---- a3: likelihood_per_component (sbayes/sampling/conditionals.py:152-223) -------------
+ * Dense float64 [N][F][C] from the slot's groups + probs; NA observations <- 1, objects in
+ * no group of a component <- 0. */
+int sbe_likelihood_per_component(sbe_engine* e, int slot, double* out /* [N][F][C] */);
+
+/* ---- a6: per-observation mixture likelihood sum_c w*lh (loggers.py:355-357,
+ * operators.py:568-574, 1060-1061): float64 [N][F]; NA observations get sum_c w. */
+int sbe_observation_lh(sbe_engine* e, int slot, double* out /* [N][F] */);
+
+/* ---- north-star kernel: one mixture log-likelihood eval ----------------
+ * LL = sum_{n,f not NA} log sum_c w[n,f,c] * p_c[g_c(n), f, x(n,f)]: fused gather + weighted
+ * sum + log + wavefront/block reduction; scalar double out.
+ * _batch evaluates slots first_slot .. first_slot+n-1 in one launch sequence.
+ * _async variants only enqueue; results land in the engine's result buffer and are fetched
+ * with sbe_fetch_results after sbe_sync. */
+int sbe_mixture_loglik(sbe_engine* e, int slot, double* out);
+int sbe_mixture_loglik_batch(sbe_engine* e, int first_slot, int n, double* out /* [n] */);
+int sbe_mixture_loglik_batch_async(sbe_engine* e, int first_slot, int n);
+int sbe_fetch_results(sbe_engine* e, int first_slot, int n, double* out /* [n] */);
+
+/* ---- a7 + a8: collapsed Dirichlet-categorical likelihood (likelihood.py:47-101,
+ * util.py:1373-1394): per group float32-sum over features of the per-feature float32 log-pdf,
+ * from the slot's counts and the component's concentration.  per_group_out: float64 [G_c];
+ * per_feature_out (may be NULL): float32 [G_c][F]. */
+int sbe_collapsed_loglik(sbe_engine* e, int slot, int component, double* per_group_out,
+                         float* per_feature_out);
+
+/* ---- slot management -------------------------------------------------------------------- */
+int sbe_copy_slot(sbe_engine* e, int dst_slot, int src_slot);
+
+/* ---- measurement support (bench.py): HIP events on the engine's own stream -------------- */
+int sbe_timer_start(sbe_engine* e);
+int sbe_timer_stop(sbe_engine* e, float* elapsed_ms);
+/* Times `iters` back-to-back launches of the fused mixture kernel sequence on slots
+ * [first_slot, first_slot+n) with one HIP event pair per launch sequence; returns the sum and
+ * the per-launch average of the dominant kernel's duration in milliseconds. */
+int sbe_profile_mixture(sbe_engine* e, int first_slot, int n, int iters, float* total_ms,
+                        float* main_kernel_avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBE_ENGINE_H */

@@ -1,0 +1,101 @@
+"""ctypes binding of the C-ABI engine library (include/sbe_engine.h).
+
+The product has NO CPU fallback: if the HIP library is missing or no GPU is usable the
+loader / sbe_create raise -- nothing silently routes around the device."""
+from __future__ import annotations
+
+import ctypes as ct
+import os
+from pathlib import Path
+
+LIB_NAME = "libsbe_engine.so"
+_LIB = None
+
+c_engine_p = ct.c_void_p
+u8p = ct.POINTER(ct.c_uint8)
+i32p = ct.POINTER(ct.c_int32)
+i64p = ct.POINTER(ct.c_int64)
+f32p = ct.POINTER(ct.c_float)
+f64p = ct.POINTER(ct.c_double)
+
+
+class SbeInfo(ct.Structure):
+    _fields_ = [
+        ("abi_version", ct.c_int32), ("device", ct.c_int32),
+        ("n_objects", ct.c_int32), ("n_features", ct.c_int32), ("n_states", ct.c_int32),
+        ("n_components", ct.c_int32), ("n_slots", ct.c_int32), ("n_groups_total", ct.c_int32),
+        ("n_na", ct.c_int64), ("hbm_bytes", ct.c_int64), ("compute_units", ct.c_int32),
+        ("device_name", ct.c_char * 64),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/sbe_engine.h one to one
+PROTOTYPES = {
+    "sbe_abi_version": (ct.c_int, []),
+    "sbe_device_count": (ct.c_int, [ct.POINTER(ct.c_int)]),
+    "sbe_last_error": (ct.c_char_p, [c_engine_p]),
+    "sbe_create": (ct.c_int, [ct.POINTER(c_engine_p), ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int,
+                              i32p, ct.c_int, ct.c_void_p]),
+    "sbe_destroy": (ct.c_int, [c_engine_p]),
+    "sbe_get_info": (ct.c_int, [c_engine_p, ct.POINTER(SbeInfo)]),
+    "sbe_get_na": (ct.c_int, [c_engine_p, ct.c_void_p]),
+    "sbe_set_option": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int]),
+    "sbe_sync": (ct.c_int, [c_engine_p]),
+    "sbe_component_lh": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p,
+                                    ct.c_int, ct.c_void_p, ct.c_int64, ct.c_int64]),
+    "sbe_likelihood_per_component_exact": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
+    "sbe_set_groups": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
+    "sbe_set_group_ids": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
+    "sbe_set_source": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
+    "sbe_set_source_rows": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),
+    "sbe_recount": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int]),
+    "sbe_update_counts": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),
+    "sbe_accumulate_counts": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p]),
+    "sbe_set_counts": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
+    "sbe_get_counts": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
+    "sbe_set_concentration": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int]),
+    "sbe_update_probs": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_double, ct.c_double, ct.c_void_p]),
+    "sbe_set_probs": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
+    "sbe_get_probs": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
+    "sbe_set_weights": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
+    "sbe_get_weights_normalized": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
+    "sbe_likelihood_per_component": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
+    "sbe_observation_lh": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
+    "sbe_mixture_loglik": (ct.c_int, [c_engine_p, ct.c_int, f64p]),
+    "sbe_mixture_loglik_batch": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
+    "sbe_mixture_loglik_batch_async": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int]),
+    "sbe_fetch_results": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
+    "sbe_collapsed_loglik": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p]),
+    "sbe_copy_slot": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int]),
+    "sbe_timer_start": (ct.c_int, [c_engine_p]),
+    "sbe_timer_stop": (ct.c_int, [c_engine_p, ct.POINTER(ct.c_float)]),
+    "sbe_profile_mixture": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_int, ct.POINTER(ct.c_float),
+                                       ct.POINTER(ct.c_float)]),
+}
+
+
+def lib_path() -> Path:
+    env = os.environ.get("SBAYES_AMD_LIB")
+    return Path(env) if env else Path(__file__).resolve().parent / LIB_NAME
+
+
+def load():
+    """Load the in-tree HIP library and attach prototypes.  Raises if it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not path.exists():
+        raise RuntimeError(
+            f"sbayes_amd: HIP engine library not found at {path}. Build it with "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` (or ./build.sh). "
+            f"There is no CPU fallback.")
+    lib = ct.CDLL(str(path))
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.sbe_abi_version() != 1:
+        raise RuntimeError(f"sbayes_amd: ABI version mismatch ({lib.sbe_abi_version()} != 1)")
+    _LIB = lib
+    return lib

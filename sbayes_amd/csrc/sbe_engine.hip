@@ -1,0 +1,1049 @@
+// sbe_engine.hip -- host side of the MI355X sBayes likelihood engine: the C ABI declared in
+// include/sbe_engine.h over the gfx950 kernels in sbe_kernels.hip.h.
+//
+// Plain HIP runtime (own stream, own events, own device memory); no torch, no compatibility
+// layer.  One engine = one process' view of one GPU.  The one-hot feature block and every
+// slot's state stay resident in HBM; only small tables / id vectors cross PCIe per call.
+#include "sbe_kernels.hip.h"
+#include "../../include/sbe_engine.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace sbe;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct Slot {
+    std::vector<uint16_t> h_gid;          // [C][N] host mirror (pattern derivation)
+    std::vector<uint8_t> h_pid;           // [N]
+    std::vector<uint32_t> patterns;       // distinct has_components bit patterns, sorted like np.unique
+    bool groups_set = false, weights_set = false, source_set = false;
+    std::vector<uint8_t> probs_set, counts_set;   // per component
+    bool patterns_dirty = true;
+};
+
+}  // namespace
+
+struct sbe_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    int N = 0, F = 0, S = 0, C = 0, n_slots = 0;
+    int Fp = 0, rs_pitch = 0, Gtot = 0, Pmax = 0;
+    int compute_units = 256;
+    std::vector<int> G, goff;
+    int64_t n_na = 0;
+    int64_t hbm_bytes = 0;
+    std::string last_error;
+    char device_name[64] = {0};
+
+    // options
+    int opt_kernel = SBE_MIXTURE_PACKED;
+    int opt_log = SBE_LOG_PRODUCT;
+
+    // resident data
+    uint8_t* d_onehot = nullptr;   // [N][rs_pitch]
+    uint8_t* d_state = nullptr;    // [N][Fp]
+    // slot-strided state
+    uint16_t* d_gid = nullptr;     // [slots][C][N]
+    uint8_t* d_pid = nullptr;      // [slots][N]
+    uint8_t* d_src = nullptr;      // [slots][N][Fp]
+    int32_t* d_counts = nullptr;   // [slots][Gtot][F][S]
+    float* d_probs = nullptr;      // [slots][Gtot][F][S]
+    float* d_weights = nullptr;    // [slots][F][C]
+    float* d_wpat = nullptr;       // [slots][Pmax][F][C]
+    uint32_t* d_patbits = nullptr; // [slots][Pmax]
+    double* d_conc = nullptr;      // [Gtot][F][S]
+    double* d_unif = nullptr;      // [F][S]
+    std::vector<uint8_t> conc_set;
+    // scratch
+    double* d_partials = nullptr;  int64_t partials_stride = 0;   // [slots][max_blocks]
+    double* d_results = nullptr;   // [slots]
+    double* h_results = nullptr;   // pinned [slots]
+    int* d_status = nullptr;       // [ST_WORDS]
+    int* h_status = nullptr;       // pinned
+    uint8_t* d_changed = nullptr;  // [Gtot]
+    uint8_t* d_scratch = nullptr;  size_t scratch_bytes = 0;     // general staging
+    uint8_t* h_pinned = nullptr;   size_t pinned_bytes = 0;      // pinned D2H staging
+    std::vector<Slot> slots;
+
+    int64_t table_elems() const { return (int64_t)Gtot * F * S; }
+};
+
+namespace {
+
+int fail(sbe_engine* e, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (e) e->last_error = buf;
+    return code;
+}
+
+#define HIPCHK(e, call)                                                                        \
+    do {                                                                                       \
+        hipError_t _err = (call);                                                              \
+        if (_err != hipSuccess)                                                                \
+            return fail(e, SBE_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_err), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+#define CHECK_ENGINE(e) \
+    if (!(e)) return fail(nullptr, SBE_ERR_ARG, "null engine handle")
+#define CHECK_SLOT(e, s) \
+    if ((s) < 0 || (s) >= (e)->n_slots) return fail(e, SBE_ERR_ARG, "slot %d out of range [0,%d)", (s), (e)->n_slots)
+#define CHECK_COMP(e, c) \
+    if ((c) < 0 || (c) >= (e)->C) return fail(e, SBE_ERR_ARG, "component %d out of range [0,%d)", (c), (e)->C)
+#define CHECK_PTR(e, p) \
+    if (!(p)) return fail(e, SBE_ERR_ARG, "null pointer argument: %s", #p)
+
+inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+template <class T>
+int dmalloc(sbe_engine* e, T** p, int64_t n) {
+    const size_t bytes = std::max<int64_t>(n, 1) * sizeof(T);
+    HIPCHK(e, hipMalloc((void**)p, bytes));
+    e->hbm_bytes += (int64_t)bytes;
+    return SBE_OK;
+}
+
+int ensure_scratch(sbe_engine* e, size_t bytes) {
+    if (bytes <= e->scratch_bytes) return SBE_OK;
+    if (e->d_scratch) { HIPCHK(e, hipStreamSynchronize(e->stream)); HIPCHK(e, hipFree(e->d_scratch)); }
+    e->scratch_bytes = bytes + bytes / 4 + 4096;
+    HIPCHK(e, hipMalloc((void**)&e->d_scratch, e->scratch_bytes));
+    return SBE_OK;
+}
+
+int ensure_pinned(sbe_engine* e, size_t bytes) {
+    if (bytes <= e->pinned_bytes) return SBE_OK;
+    if (e->h_pinned) { HIPCHK(e, hipStreamSynchronize(e->stream)); HIPCHK(e, hipHostFree(e->h_pinned)); }
+    e->pinned_bytes = bytes + bytes / 4 + 4096;
+    HIPCHK(e, hipHostMalloc((void**)&e->h_pinned, e->pinned_bytes, hipHostMallocDefault));
+    return SBE_OK;
+}
+
+// D2H through the pinned staging buffer (pageable destinations would be staged by the
+// runtime anyway, in smaller pieces)
+int d2h(sbe_engine* e, void* dst, const void* src_dev, size_t bytes) {
+    int rc = ensure_pinned(e, bytes);
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpyAsync(e->h_pinned, src_dev, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    memcpy(dst, e->h_pinned, bytes);
+    return SBE_OK;
+}
+
+int h2d(sbe_engine* e, void* dst_dev, const void* src, size_t bytes) {
+    HIPCHK(e, hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, e->stream));
+    // pageable source: the runtime has consumed `src` when the call returns only after a
+    // synchronize; callers own their buffers, so make the hand-over explicit.
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return SBE_OK;
+}
+
+int read_status(sbe_engine* e) {
+    HIPCHK(e, hipMemcpyAsync(e->h_status, e->d_status, ST_WORDS * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return SBE_OK;
+}
+
+int clear_status_word(sbe_engine* e, int word) {
+    HIPCHK(e, hipMemsetAsync(e->d_status + word, 0, sizeof(int), e->stream));
+    return SBE_OK;
+}
+
+// has_components patterns in np.unique(axis=0) order: rows compared lexicographically over
+// components 0..C-1 with False < True (likelihood.py:183).
+void derive_patterns(sbe_engine* e, Slot& s) {
+    const int N = e->N, C = e->C;
+    std::vector<uint32_t> bits(N);
+    for (int n = 0; n < N; ++n) {
+        uint32_t b = 0;
+        for (int c = 0; c < C; ++c)
+            if (s.h_gid[(size_t)c * N + n] != kNoGroup) b |= 1u << c;
+        bits[n] = b;
+    }
+    auto key = [C](uint32_t b) {   // component 0 most significant => lexicographic row order
+        uint32_t k = 0;
+        for (int c = 0; c < C; ++c) k |= ((b >> c) & 1u) << (C - 1 - c);
+        return k;
+    };
+    std::vector<uint32_t> uniq(bits);
+    std::sort(uniq.begin(), uniq.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    s.patterns = uniq;
+    s.h_pid.resize(N);
+    for (int n = 0; n < N; ++n) {
+        const auto it = std::find(uniq.begin(), uniq.end(), bits[n]);
+        s.h_pid[n] = (uint8_t)(it - uniq.begin());
+    }
+}
+
+int upload_patterns_and_weights(sbe_engine* e, int slot) {
+    Slot& s = e->slots[slot];
+    if (s.patterns_dirty) {
+        derive_patterns(e, s);
+        if ((int)s.patterns.size() > e->Pmax)
+            return fail(e, SBE_ERR_ARG, "%zu distinct has_components patterns exceed capacity %d",
+                        s.patterns.size(), e->Pmax);
+        HIPCHK(e, hipMemcpyAsync(e->d_pid + (int64_t)slot * e->N, s.h_pid.data(), e->N,
+                                 hipMemcpyHostToDevice, e->stream));
+        HIPCHK(e, hipMemcpyAsync(e->d_patbits + (int64_t)slot * e->Pmax, s.patterns.data(),
+                                 s.patterns.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        s.patterns_dirty = false;
+    }
+    if (s.weights_set) {
+        const int P = (int)s.patterns.size();
+        k_weight_patterns<<<div_up((int64_t)P * e->F, 256), 256, 0, e->stream>>>(
+            e->d_weights + (int64_t)slot * e->F * e->C, e->d_patbits + (int64_t)slot * e->Pmax,
+            e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, P, e->F, e->C);
+        HIPCHK(e, hipGetLastError());
+    }
+    return SBE_OK;
+}
+
+// ---- geometry of the fused kernel ----------------------------------------------------------
+struct MixGeom {
+    int ft, ft_shift, n_ftiles, objs_per_chunk, n_chunks, n_blocks;
+    size_t lds_bytes;
+};
+
+MixGeom mix_geometry(const sbe_engine* e, int P, int n_batch) {
+    MixGeom g{};
+    // widest power-of-two feature tile whose tables fit the LDS budget; <= 64 KB keeps two
+    // blocks per CU resident, beyond that fall back to narrower tiles down to 16.
+    const size_t budget = 64 * 1024, hard = 150 * 1024;
+    int ft = 64;
+    auto lds_for = [&](int t) { return ((size_t)e->Gtot * t * e->S + (size_t)P * t * e->C) * sizeof(float); };
+    while (ft > 16 && lds_for(ft) > budget) ft >>= 1;
+    if (lds_for(ft) > hard) ft = 0;   // caller reports
+    g.ft = ft;
+    if (!ft) return g;
+    g.ft_shift = ft == 64 ? 6 : ft == 32 ? 5 : 4;
+    g.n_ftiles = div_up(e->F, ft);
+    g.lds_bytes = lds_for(ft);
+    // enough blocks to cover the chip ~4x over the whole batch, at least ~1 dword/16B step per thread
+    const int64_t target_blocks = (int64_t)4 * e->compute_units;
+    int64_t chunks = std::max<int64_t>(1, target_blocks / ((int64_t)g.n_ftiles * std::max(1, n_batch)));
+    const int min_objs = std::max(1, kBlock / (ft / 4));       // one packed step for every thread
+    int opc = std::max<int>(min_objs, div_up(e->N, chunks));
+    g.objs_per_chunk = opc;
+    g.n_chunks = div_up(e->N, opc);
+    g.n_blocks = g.n_chunks * g.n_ftiles;
+    return g;
+}
+
+template <int MODE, bool ONEHOT>
+void launch_mixture(const MixParams& p, dim3 grid, size_t lds, hipStream_t st) {
+    k_mixture<MODE, ONEHOT><<<grid, kBlock, lds, st>>>(p);
+}
+
+int max_patterns(sbe_engine* e, int first_slot, int n) {
+    int P = 1;
+    for (int s = first_slot; s < first_slot + n; ++s) P = std::max<int>(P, (int)e->slots[s].patterns.size());
+    return P;
+}
+
+int check_slot_ready(sbe_engine* e, int slot, bool need_weights) {
+    Slot& s = e->slots[slot];
+    if (!s.groups_set) return fail(e, SBE_ERR_STATE, "slot %d: groups not set for every component", slot);
+    for (int c = 0; c < e->C; ++c)
+        if (!s.probs_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: probability tables of component %d not set", slot, c);
+    if (need_weights && !s.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: weights not set", slot);
+    return SBE_OK;
+}
+
+int enqueue_mixture(sbe_engine* e, int first_slot, int n, int mode, double* d_obs, MixGeom* geom_out) {
+    for (int s = first_slot; s < first_slot + n; ++s) {
+        int rc = check_slot_ready(e, s, true);
+        if (rc) return rc;
+        if (e->slots[s].patterns_dirty) { rc = upload_patterns_and_weights(e, s); if (rc) return rc; }
+    }
+    const int P = max_patterns(e, first_slot, n);
+    MixGeom g = mix_geometry(e, P, n);
+    if (!g.ft) return fail(e, SBE_ERR_ARG, "probability tables too large for LDS staging (G_total=%d, S=%d)", e->Gtot, e->S);
+    if (g.n_blocks > e->partials_stride) return fail(e, SBE_ERR_STATE, "internal: partials buffer too small");
+    MixParams p{};
+    p.N = e->N; p.F = e->F; p.S = e->S; p.C = e->C; p.Fp = e->Fp; p.rs_pitch = e->rs_pitch;
+    p.Gtot = e->Gtot; p.P = P;
+    p.ft = g.ft; p.ft_shift = g.ft_shift; p.n_ftiles = g.n_ftiles; p.n_chunks = g.n_chunks;
+    p.objs_per_chunk = g.objs_per_chunk;
+    p.s_magic = (uint32_t)(((1u << 24) + e->S - 1) / e->S);
+    p.state = e->d_state; p.onehot = e->d_onehot;
+    p.gid = e->d_gid; p.gid_stride = (int64_t)e->C * e->N;
+    p.pid = e->d_pid; p.pid_stride = e->N;
+    p.probs = e->d_probs; p.probs_stride = e->table_elems();
+    p.wpat = e->d_wpat; p.wpat_stride = (int64_t)e->Pmax * e->F * e->C;
+    p.partials = e->d_partials; p.partials_stride = e->partials_stride;
+    p.obs = d_obs; p.first_slot = first_slot;
+    const dim3 grid(g.n_blocks, n);
+    const bool onehot = e->opt_kernel == SBE_MIXTURE_ONEHOT;
+    if (mode == WRITE_OBS) {
+        launch_mixture<WRITE_OBS, false>(p, grid, g.lds_bytes, e->stream);
+    } else if (mode == LOG_PRODUCT) {
+        if (onehot) launch_mixture<LOG_PRODUCT, true>(p, grid, g.lds_bytes, e->stream);
+        else launch_mixture<LOG_PRODUCT, false>(p, grid, g.lds_bytes, e->stream);
+    } else {
+        if (onehot) launch_mixture<LOG_PER_OBS, true>(p, grid, g.lds_bytes, e->stream);
+        else launch_mixture<LOG_PER_OBS, false>(p, grid, g.lds_bytes, e->stream);
+    }
+    HIPCHK(e, hipGetLastError());
+    if (mode != WRITE_OBS) {
+        k_reduce_partials<<<n, kBlock, 0, e->stream>>>(e->d_partials, e->partials_stride, g.n_blocks,
+                                                      e->d_results, first_slot);
+        HIPCHK(e, hipGetLastError());
+    }
+    if (geom_out) *geom_out = g;
+    return SBE_OK;
+}
+
+int counts_launch(sbe_engine* e, int slot_a, int sign_a, int slot_b, int sign_b, const int32_t* d_objects,
+                  int n_listed, int dst_slot, bool single_chunk, uint8_t* d_changed) {
+    CountSide A{e->d_gid + (int64_t)slot_a * e->C * e->N, e->d_src + (int64_t)slot_a * e->N * e->Fp, sign_a};
+    CountSide B{e->d_gid + (int64_t)slot_b * e->C * e->N, e->d_src + (int64_t)slot_b * e->N * e->Fp, sign_b};
+    int32_t* counts = e->d_counts + (int64_t)dst_slot * e->table_elems();
+    // feature tile: as wide as fits the LDS budget
+    int ft = 32;
+    auto lds_for = [&](int t) { return (size_t)e->Gtot * t * e->S * sizeof(int32_t); };
+    while (ft > 4 && lds_for(ft) > 96 * 1024) ft >>= 1;
+    if (lds_for(ft) > 150 * 1024) {
+        k_counts_global<<<div_up((int64_t)n_listed * e->F, 256), 256, 0, e->stream>>>(
+            e->d_state, A, B, d_objects, n_listed, e->N, e->F, e->S, e->C, e->Fp, counts, d_changed);
+        HIPCHK(e, hipGetLastError());
+        return SBE_OK;
+    }
+    const int n_ftiles = div_up(e->F, ft);
+    int chunks = 1;
+    if (!single_chunk) chunks = std::max(1, std::min(div_up(n_listed, 32), div_up(2 * e->compute_units, n_ftiles)));
+    const int opc = div_up(n_listed, chunks);
+    chunks = div_up(n_listed, opc);
+    k_counts<<<dim3(n_ftiles, chunks), kBlock, lds_for(ft), e->stream>>>(
+        e->d_state, A, B, d_objects, n_listed, opc, e->N, e->F, e->S, e->C, e->Fp, e->Gtot, ft, counts, d_changed);
+    HIPCHK(e, hipGetLastError());
+    return SBE_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int sbe_abi_version(void) { return SBE_ABI_VERSION; }
+
+int sbe_device_count(int* out_count) {
+    if (!out_count) return fail(nullptr, SBE_ERR_ARG, "null out_count");
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess) { *out_count = 0; return fail(nullptr, SBE_ERR_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(err)); }
+    *out_count = n;
+    return SBE_OK;
+}
+
+const char* sbe_last_error(const sbe_engine* e) { return e ? e->last_error.c_str() : g_last_error.c_str(); }
+
+int sbe_destroy(sbe_engine* e) {
+    if (!e) return SBE_OK;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    void* dev_ptrs[] = {e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
+                        e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_unif, e->d_partials,
+                        e->d_results, e->d_status, e->d_changed, e->d_scratch};
+    for (void* p : dev_ptrs) if (p) (void)hipFree(p);
+    if (e->h_results) (void)hipHostFree(e->h_results);
+    if (e->h_status) (void)hipHostFree(e->h_status);
+    if (e->h_pinned) (void)hipHostFree(e->h_pinned);
+    for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return SBE_OK;
+}
+
+int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int n_states,
+               int n_components, const int32_t* n_groups, int n_slots, const uint8_t* features_onehot) {
+    if (!out) return fail(nullptr, SBE_ERR_ARG, "null out handle");
+    *out = nullptr;
+    if (!features_onehot || !n_groups) return fail(nullptr, SBE_ERR_ARG, "null features / n_groups");
+    if (n_objects < 1 || n_features < 1) return fail(nullptr, SBE_ERR_ARG, "empty feature block (%d objects x %d features)", n_objects, n_features);
+    if (n_states < 1 || n_states > 254) return fail(nullptr, SBE_ERR_ARG, "n_states=%d unsupported (1..254; state index is one byte, 0xFF = NA)", n_states);
+    if (n_components < 1 || n_components > kMaxComponents) return fail(nullptr, SBE_ERR_ARG, "n_components=%d unsupported (1..%d)", n_components, kMaxComponents);
+    if (n_slots < 1 || n_slots > 4096) return fail(nullptr, SBE_ERR_ARG, "n_slots=%d unsupported (1..4096)", n_slots);
+    int64_t gtot = 0;
+    for (int c = 0; c < n_components; ++c) {
+        if (n_groups[c] < 1) return fail(nullptr, SBE_ERR_ARG, "component %d has %d groups", c, n_groups[c]);
+        gtot += n_groups[c];
+    }
+    if (gtot >= 0xFFFF) return fail(nullptr, SBE_ERR_ARG, "%lld groups in total exceed the 16-bit group index", (long long)gtot);
+
+    int ndev = 0;
+    hipError_t err = hipGetDeviceCount(&ndev);
+    if (err != hipSuccess || ndev == 0)
+        return fail(nullptr, SBE_ERR_NODEVICE, "no HIP device available (%s); the engine has no CPU fallback",
+                    err != hipSuccess ? hipGetErrorString(err) : "device count 0");
+    if (device < 0 || device >= ndev) return fail(nullptr, SBE_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+
+    sbe_engine* e = new sbe_engine();
+    e->device = device;
+    e->N = n_objects; e->F = n_features; e->S = n_states; e->C = n_components; e->n_slots = n_slots;
+    e->G.assign(n_groups, n_groups + n_components);
+    e->goff.resize(n_components);
+    for (int c = 0, o = 0; c < n_components; ++c) { e->goff[c] = o; o += n_groups[c]; }
+    e->Gtot = (int)gtot;
+    e->Fp = round_up(n_features, 64);
+    e->rs_pitch = round_up(n_features * n_states, 16);
+    e->Pmax = std::min(1 << n_components, 64);
+    e->conc_set.assign(n_components, 0);
+    e->slots.resize(n_slots);
+    for (Slot& s : e->slots) {
+        s.h_gid.assign((size_t)n_components * n_objects, kNoGroup);
+        s.probs_set.assign(n_components, 0);
+        s.counts_set.assign(n_components, 0);
+    }
+
+#define CREATE_CHK(call)                                                                        \
+    do {                                                                                        \
+        hipError_t _e2 = (call);                                                                \
+        if (_e2 != hipSuccess) {                                                                \
+            int _rc = fail(nullptr, SBE_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e2)); \
+            sbe_destroy(e);                                                                     \
+            return _rc;                                                                         \
+        }                                                                                       \
+    } while (0)
+#define CREATE_RC(expr)                                        \
+    do {                                                       \
+        int _rc = (expr);                                      \
+        if (_rc) { g_last_error = e->last_error; sbe_destroy(e); return _rc; } \
+    } while (0)
+
+    CREATE_CHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CREATE_CHK(hipGetDeviceProperties(&prop, device));
+    e->compute_units = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    snprintf(e->device_name, sizeof e->device_name, "%s", prop.name);
+    CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    CREATE_CHK(hipEventCreate(&e->ev0));
+    CREATE_CHK(hipEventCreate(&e->ev1));
+
+    const int64_t N = e->N, F = e->F, S = e->S, C = e->C, NS = n_slots;
+    CREATE_RC(dmalloc(e, &e->d_onehot, N * e->rs_pitch));
+    CREATE_RC(dmalloc(e, &e->d_state, N * e->Fp));
+    CREATE_RC(dmalloc(e, &e->d_gid, NS * C * N));
+    CREATE_RC(dmalloc(e, &e->d_pid, NS * N));
+    CREATE_RC(dmalloc(e, &e->d_src, NS * N * e->Fp));
+    CREATE_RC(dmalloc(e, &e->d_counts, NS * e->table_elems()));
+    CREATE_RC(dmalloc(e, &e->d_probs, NS * e->table_elems()));
+    CREATE_RC(dmalloc(e, &e->d_weights, NS * F * C));
+    CREATE_RC(dmalloc(e, &e->d_wpat, NS * e->Pmax * F * C));
+    CREATE_RC(dmalloc(e, &e->d_patbits, NS * e->Pmax));
+    CREATE_RC(dmalloc(e, &e->d_conc, e->table_elems()));
+    CREATE_RC(dmalloc(e, &e->d_unif, F * S));
+    // partials: worst-case block count of the fused kernel (ft = 16, one packed step per thread)
+    {
+        const int64_t min_objs = kBlock / (16 / 4);
+        e->partials_stride = std::max<int64_t>(div_up(F, 16) * std::max<int64_t>(div_up(N, min_objs), 4 * e->compute_units), 1024);
+    }
+    CREATE_RC(dmalloc(e, &e->d_partials, NS * e->partials_stride));
+    CREATE_RC(dmalloc(e, &e->d_results, NS));
+    CREATE_RC(dmalloc(e, &e->d_status, (int64_t)ST_WORDS));
+    CREATE_RC(dmalloc(e, &e->d_changed, (int64_t)e->Gtot));
+    CREATE_CHK(hipHostMalloc((void**)&e->h_results, NS * sizeof(double), hipHostMallocDefault));
+    CREATE_CHK(hipHostMalloc((void**)&e->h_status, ST_WORDS * sizeof(int), hipHostMallocDefault));
+
+    CREATE_CHK(hipMemsetAsync(e->d_status, 0, ST_WORDS * sizeof(int), e->stream));
+    CREATE_CHK(hipMemsetAsync(e->d_onehot, 0, N * e->rs_pitch, e->stream));
+    CREATE_CHK(hipMemsetAsync(e->d_state, 0xFF, N * e->Fp, e->stream));
+    CREATE_CHK(hipMemsetAsync(e->d_src, 0xFF, NS * N * e->Fp, e->stream));
+    CREATE_CHK(hipMemsetAsync(e->d_gid, 0xFF, NS * C * N * sizeof(uint16_t), e->stream));
+    CREATE_CHK(hipMemsetAsync(e->d_pid, 0, NS * N, e->stream));
+    CREATE_CHK(hipMemsetAsync(e->d_counts, 0, NS * e->table_elems() * sizeof(int32_t), e->stream));
+
+    // ingest: raw one-hot -> normalised padded copy + packed state index + validation
+    CREATE_RC(ensure_scratch(e, (size_t)(N * F * S)));
+    CREATE_CHK(hipMemcpyAsync(e->d_scratch, features_onehot, (size_t)(N * F * S), hipMemcpyHostToDevice, e->stream));
+    k_ingest_onehot<<<div_up(N * F, 256), 256, 0, e->stream>>>(e->d_scratch, e->d_onehot, e->d_state, e->N,
+                                                              e->F, e->S, e->rs_pitch, e->Fp, e->d_status);
+    CREATE_CHK(hipGetLastError());
+    CREATE_RC(read_status(e));
+    if (e->h_status[ST_MULTI_STATE] != 0) {
+        int rc = fail(nullptr, SBE_ERR_DATA, "features are not one-hot: %d (object, feature) rows have more than one state set",
+                      e->h_status[ST_MULTI_STATE]);
+        sbe_destroy(e);
+        return rc;
+    }
+    e->n_na = e->h_status[ST_NA_COUNT];
+#undef CREATE_CHK
+#undef CREATE_RC
+    *out = e;
+    return SBE_OK;
+}
+
+int sbe_get_info(const sbe_engine* e, sbe_info* out) {
+    CHECK_ENGINE(e);
+    if (!out) return fail(nullptr, SBE_ERR_ARG, "null out");
+    memset(out, 0, sizeof *out);
+    out->abi_version = SBE_ABI_VERSION;
+    out->device = e->device;
+    out->n_objects = e->N; out->n_features = e->F; out->n_states = e->S;
+    out->n_components = e->C; out->n_slots = e->n_slots; out->n_groups_total = e->Gtot;
+    out->n_na = e->n_na; out->hbm_bytes = e->hbm_bytes; out->compute_units = e->compute_units;
+    memcpy(out->device_name, e->device_name, sizeof out->device_name);
+    return SBE_OK;
+}
+
+int sbe_get_na(const sbe_engine* ce, uint8_t* out_na) {
+    sbe_engine* e = const_cast<sbe_engine*>(ce);
+    CHECK_ENGINE(e); CHECK_PTR(e, out_na);
+    HIPCHK(e, hipSetDevice(e->device));
+    std::vector<uint8_t> st((size_t)e->N * e->Fp);
+    int rc = d2h(e, st.data(), e->d_state, st.size());
+    if (rc) return rc;
+    for (int n = 0; n < e->N; ++n)
+        for (int f = 0; f < e->F; ++f) out_na[(size_t)n * e->F + f] = st[(size_t)n * e->Fp + f] == kNA;
+    return SBE_OK;
+}
+
+int sbe_set_option(sbe_engine* e, int option, int value) {
+    CHECK_ENGINE(e);
+    if (option == SBE_OPT_MIXTURE_KERNEL && (value == SBE_MIXTURE_PACKED || value == SBE_MIXTURE_ONEHOT)) { e->opt_kernel = value; return SBE_OK; }
+    if (option == SBE_OPT_LOG_MODE && (value == SBE_LOG_PER_OBS || value == SBE_LOG_PRODUCT)) { e->opt_log = value; return SBE_OK; }
+    return fail(e, SBE_ERR_ARG, "unknown option %d / value %d", option, value);
+}
+
+int sbe_sync(sbe_engine* e) {
+    CHECK_ENGINE(e);
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return SBE_OK;
+}
+
+// ---- a1 -------------------------------------------------------------------------------------
+int sbe_component_lh(sbe_engine* e, const void* probs, int probs_f64, int n_groups, const uint8_t* groups,
+                     const int64_t* changed_groups, int n_changed, double* out, int64_t out_stride_n_bytes,
+                     int64_t out_stride_f_bytes) {
+    CHECK_ENGINE(e); CHECK_PTR(e, probs); CHECK_PTR(e, groups); CHECK_PTR(e, out);
+    if (n_groups < 1) return fail(e, SBE_ERR_ARG, "n_groups=%d", n_groups);
+    if (n_changed < 0 || (n_changed > 0 && !changed_groups)) return fail(e, SBE_ERR_ARG, "bad changed_groups");
+    for (int k = 0; k < n_changed; ++k)
+        if (changed_groups[k] < 0 || changed_groups[k] >= n_groups)
+            return fail(e, SBE_ERR_ARG, "changed_groups[%d]=%lld out of range [0,%d)", k, (long long)changed_groups[k], n_groups);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int N = e->N, F = e->F, S = e->S;
+    // row selector: -2 untouched, -1 zero, >=0 table index (last changed group wins)
+    std::vector<int32_t> sel(N, -2);
+    for (int n = 0; n < N; ++n) {
+        bool any = false;
+        for (int g = 0; g < n_groups && !any; ++g) any = groups[(size_t)g * N + n] != 0;
+        if (!any) sel[n] = -1;
+    }
+    for (int k = 0; k < n_changed; ++k) {
+        const int64_t g = changed_groups[k];
+        const uint8_t* row = groups + (size_t)g * N;
+        for (int n = 0; n < N; ++n) if (row[n]) sel[n] = (int32_t)g;
+    }
+    const size_t esz = probs_f64 ? sizeof(double) : sizeof(float);
+    const size_t tab_bytes = (size_t)n_groups * F * S * esz;
+    const size_t tab_pad = (tab_bytes + 255) / 256 * 256;
+    const size_t sel_bytes = ((size_t)N * sizeof(int32_t) + 255) / 256 * 256;
+    const size_t out_bytes = (size_t)N * F * sizeof(double);
+    int rc = ensure_scratch(e, tab_pad + sel_bytes + out_bytes);
+    if (rc) return rc;
+    uint8_t* d_tab = e->d_scratch;
+    int32_t* d_sel = (int32_t*)(e->d_scratch + tab_pad);
+    double* d_out = (double*)(e->d_scratch + tab_pad + sel_bytes);
+    HIPCHK(e, hipMemcpyAsync(d_tab, probs, tab_bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(d_sel, sel.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    const int blocks = div_up((int64_t)N * F, 256);
+    if (probs_f64) k_component_lh<double><<<blocks, 256, 0, e->stream>>>(e->d_state, (const double*)d_tab, d_sel, d_out, N, F, S, e->Fp);
+    else k_component_lh<float><<<blocks, 256, 0, e->stream>>>(e->d_state, (const float*)d_tab, d_sel, d_out, N, F, S, e->Fp);
+    HIPCHK(e, hipGetLastError());
+    rc = ensure_pinned(e, out_bytes);
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpyAsync(e->h_pinned, d_out, out_bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    const double* dense = (const double*)e->h_pinned;
+    char* base = (char*)out;
+    for (int n = 0; n < N; ++n) {
+        if (sel[n] == -2) continue;
+        char* row = base + (int64_t)n * out_stride_n_bytes;
+        const double* srow = dense + (size_t)n * F;
+        if (out_stride_f_bytes == (int64_t)sizeof(double)) memcpy(row, srow, (size_t)F * sizeof(double));
+        else for (int f = 0; f < F; ++f) *(double*)(row + (int64_t)f * out_stride_f_bytes) = srow[f];
+    }
+    return SBE_OK;
+}
+
+// ---- groups -----------------------------------------------------------------------------------
+static int set_gid_common(sbe_engine* e, int slot, int component, const std::vector<uint16_t>& ids) {
+    Slot& s = e->slots[slot];
+    std::copy(ids.begin(), ids.end(), s.h_gid.begin() + (size_t)component * e->N);
+    HIPCHK(e, hipMemcpyAsync(e->d_gid + ((int64_t)slot * e->C + component) * e->N, ids.data(),
+                             (size_t)e->N * sizeof(uint16_t), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    s.patterns_dirty = true;
+    s.groups_set = true;   // components never set keep "no group" ids
+    return SBE_OK;
+}
+
+int sbe_set_groups(sbe_engine* e, int slot, int component, const uint8_t* groups) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component); CHECK_PTR(e, groups);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int N = e->N, G = e->G[component], off = e->goff[component];
+    std::vector<uint16_t> ids(N, kNoGroup);
+    for (int g = 0; g < G; ++g) {
+        const uint8_t* row = groups + (size_t)g * N;
+        for (int n = 0; n < N; ++n) if (row[n]) ids[n] = (uint16_t)(off + g);
+    }
+    return set_gid_common(e, slot, component, ids);
+}
+
+int sbe_set_group_ids(sbe_engine* e, int slot, int component, const int32_t* ids_in) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component); CHECK_PTR(e, ids_in);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int N = e->N, G = e->G[component], off = e->goff[component];
+    std::vector<uint16_t> ids(N, kNoGroup);
+    for (int n = 0; n < N; ++n) {
+        if (ids_in[n] >= G) return fail(e, SBE_ERR_ARG, "group id %d of object %d out of range [0,%d)", ids_in[n], n, G);
+        if (ids_in[n] >= 0) ids[n] = (uint16_t)(off + ids_in[n]);
+    }
+    return set_gid_common(e, slot, component, ids);
+}
+
+// ---- source -----------------------------------------------------------------------------------
+int sbe_set_source(sbe_engine* e, int slot, const uint8_t* source) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, source);
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t bytes = (size_t)e->N * e->F * e->C;
+    int rc = ensure_scratch(e, bytes);
+    if (rc) return rc;
+    rc = clear_status_word(e, ST_MULTI_SOURCE);
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpyAsync(e->d_scratch, source, bytes, hipMemcpyHostToDevice, e->stream));
+    k_ingest_source<<<div_up((int64_t)e->N * e->F, 256), 256, 0, e->stream>>>(
+        e->d_scratch, nullptr, e->d_src + (int64_t)slot * e->N * e->Fp, e->N, e->F, e->C, e->Fp, e->d_status);
+    HIPCHK(e, hipGetLastError());
+    rc = read_status(e);
+    if (rc) return rc;
+    if (e->h_status[ST_MULTI_SOURCE]) return fail(e, SBE_ERR_DATA, "source is not one-hot over components in %d observations", e->h_status[ST_MULTI_SOURCE]);
+    e->slots[slot].source_set = true;
+    return SBE_OK;
+}
+
+int sbe_set_source_rows(sbe_engine* e, int slot, const int32_t* objects, int n_rows, const uint8_t* rows) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot);
+    if (n_rows == 0) return SBE_OK;
+    CHECK_PTR(e, objects); CHECK_PTR(e, rows);
+    if (n_rows < 0) return fail(e, SBE_ERR_ARG, "n_rows=%d", n_rows);
+    for (int i = 0; i < n_rows; ++i)
+        if (objects[i] < 0 || objects[i] >= e->N) return fail(e, SBE_ERR_ARG, "object index %d out of range", objects[i]);
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t row_bytes = (size_t)n_rows * e->F * e->C;
+    const size_t row_pad = (row_bytes + 255) / 256 * 256;
+    int rc = ensure_scratch(e, row_pad + (size_t)n_rows * sizeof(int32_t));
+    if (rc) return rc;
+    rc = clear_status_word(e, ST_MULTI_SOURCE);
+    if (rc) return rc;
+    int32_t* d_obj = (int32_t*)(e->d_scratch + row_pad);
+    HIPCHK(e, hipMemcpyAsync(e->d_scratch, rows, row_bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(d_obj, objects, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    k_ingest_source<<<div_up((int64_t)n_rows * e->F, 256), 256, 0, e->stream>>>(
+        e->d_scratch, d_obj, e->d_src + (int64_t)slot * e->N * e->Fp, n_rows, e->F, e->C, e->Fp, e->d_status);
+    HIPCHK(e, hipGetLastError());
+    rc = read_status(e);
+    if (rc) return rc;
+    if (e->h_status[ST_MULTI_SOURCE]) return fail(e, SBE_ERR_DATA, "source rows are not one-hot over components");
+    return SBE_OK;
+}
+
+// ---- counts -----------------------------------------------------------------------------------
+int sbe_recount(sbe_engine* e, int slot, int component) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot);
+    if (component != -1) CHECK_COMP(e, component);
+    Slot& s = e->slots[slot];
+    if (!s.source_set) return fail(e, SBE_ERR_STATE, "slot %d: source not set", slot);
+    if (!s.groups_set) return fail(e, SBE_ERR_STATE, "slot %d: groups not set", slot);
+    HIPCHK(e, hipSetDevice(e->device));
+    // the kernel counts every component in one pass (each observation has one source
+    // component); a single-component request recounts all and is still exact.
+    HIPCHK(e, hipMemsetAsync(e->d_counts + (int64_t)slot * e->table_elems(), 0, e->table_elems() * sizeof(int32_t), e->stream));
+    int rc = counts_launch(e, slot, +1, slot, 0, nullptr, e->N, slot, false, nullptr);
+    if (rc) return rc;
+    std::fill(s.counts_set.begin(), s.counts_set.end(), 1);
+    return SBE_OK;
+}
+
+int sbe_update_counts(sbe_engine* e, int slot_new, int slot_old, const int32_t* objects, int n_subset,
+                      uint8_t* changed_groups_out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot_new); CHECK_SLOT(e, slot_old);
+    if (n_subset < 0) return fail(e, SBE_ERR_ARG, "n_subset=%d", n_subset);
+    if (n_subset > 0) CHECK_PTR(e, objects);
+    for (int i = 0; i < n_subset; ++i)
+        if (objects[i] < 0 || objects[i] >= e->N) return fail(e, SBE_ERR_ARG, "object index %d out of range", objects[i]);
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipMemsetAsync(e->d_changed, 0, e->Gtot, e->stream));
+    if (n_subset > 0) {
+        int rc = ensure_scratch(e, (size_t)n_subset * sizeof(int32_t));
+        if (rc) return rc;
+        HIPCHK(e, hipMemcpyAsync(e->d_scratch, objects, (size_t)n_subset * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+        rc = counts_launch(e, slot_new, +1, slot_old, -1, (const int32_t*)e->d_scratch, n_subset, slot_new, true, e->d_changed);
+        if (rc) return rc;
+    }
+    if (changed_groups_out) {
+        int rc = d2h(e, changed_groups_out, e->d_changed, e->Gtot);
+        if (rc) return rc;
+    } else {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+    }
+    return SBE_OK;
+}
+
+int sbe_accumulate_counts(sbe_engine* e, int slot, const int32_t* objects, int n_subset, int sign,
+                          uint8_t* changed_groups_out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot);
+    if (sign != 1 && sign != -1) return fail(e, SBE_ERR_ARG, "sign must be +1 or -1");
+    if (n_subset < 0) return fail(e, SBE_ERR_ARG, "n_subset=%d", n_subset);
+    if (n_subset > 0) CHECK_PTR(e, objects);
+    for (int i = 0; i < n_subset; ++i)
+        if (objects[i] < 0 || objects[i] >= e->N) return fail(e, SBE_ERR_ARG, "object index %d out of range", objects[i]);
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipMemsetAsync(e->d_changed, 0, e->Gtot, e->stream));
+    if (n_subset > 0) {
+        int rc = ensure_scratch(e, (size_t)n_subset * sizeof(int32_t));
+        if (rc) return rc;
+        HIPCHK(e, hipMemcpyAsync(e->d_scratch, objects, (size_t)n_subset * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+        rc = counts_launch(e, slot, sign, slot, 0, (const int32_t*)e->d_scratch, n_subset, slot, true, e->d_changed);
+        if (rc) return rc;
+    }
+    if (changed_groups_out) return d2h(e, changed_groups_out, e->d_changed, e->Gtot);
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return SBE_OK;
+}
+
+int sbe_set_counts(sbe_engine* e, int slot, int component, const float* counts) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component); CHECK_PTR(e, counts);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int64_t n = (int64_t)e->G[component] * e->F * e->S;
+    int rc = ensure_scratch(e, n * sizeof(float));
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpyAsync(e->d_scratch, counts, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    int32_t* dst = e->d_counts + (int64_t)slot * e->table_elems() + (int64_t)e->goff[component] * e->F * e->S;
+    k_f32_to_i32<<<div_up(n, 256), 256, 0, e->stream>>>((const float*)e->d_scratch, dst, n);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->slots[slot].counts_set[component] = 1;
+    return SBE_OK;
+}
+
+int sbe_get_counts(sbe_engine* e, int slot, int component, float* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component); CHECK_PTR(e, out);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int64_t n = (int64_t)e->G[component] * e->F * e->S;
+    int rc = ensure_scratch(e, n * sizeof(float));
+    if (rc) return rc;
+    const int32_t* src = e->d_counts + (int64_t)slot * e->table_elems() + (int64_t)e->goff[component] * e->F * e->S;
+    k_i32_to_f32<<<div_up(n, 256), 256, 0, e->stream>>>(src, (float*)e->d_scratch, n);
+    HIPCHK(e, hipGetLastError());
+    return d2h(e, out, e->d_scratch, n * sizeof(float));
+}
+
+// ---- concentration / probs ----------------------------------------------------------------------
+int sbe_set_concentration(sbe_engine* e, int component, const double* conc, int per_group) {
+    CHECK_ENGINE(e); CHECK_COMP(e, component); CHECK_PTR(e, conc);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int64_t fs = (int64_t)e->F * e->S;
+    double* dst = e->d_conc + (int64_t)e->goff[component] * fs;
+    if (per_group) {
+        HIPCHK(e, hipMemcpyAsync(dst, conc, e->G[component] * fs * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    } else {
+        for (int g = 0; g < e->G[component]; ++g)
+            HIPCHK(e, hipMemcpyAsync(dst + g * fs, conc, fs * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    }
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->conc_set[component] = 1;
+    return SBE_OK;
+}
+
+int sbe_update_probs(sbe_engine* e, int slot, int component, double temperature, double prior_temperature,
+                     const double* unif_counts) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component);
+    Slot& s = e->slots[slot];
+    if (!e->conc_set[component]) return fail(e, SBE_ERR_STATE, "concentration of component %d not set", component);
+    if (!s.counts_set[component]) return fail(e, SBE_ERR_STATE, "slot %d: counts of component %d not set", slot, component);
+    if (prior_temperature > 0.0 && !unif_counts) return fail(e, SBE_ERR_ARG, "prior_temperature given without unif_counts (conditionals.py:114)");
+    HIPCHK(e, hipSetDevice(e->device));
+    const double* d_unif = nullptr;
+    if (prior_temperature > 0.0) {
+        HIPCHK(e, hipMemcpyAsync(e->d_unif, unif_counts, (size_t)e->F * e->S * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        d_unif = e->d_unif;
+    }
+    int rc = clear_status_word(e, ST_BAD_NORMALIZE);
+    if (rc) return rc;
+    const int g_lo = e->goff[component], g_hi = g_lo + e->G[component];
+    k_probs<<<div_up((int64_t)(g_hi - g_lo) * e->F, 256), 256, 0, e->stream>>>(
+        e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc, d_unif,
+        e->d_probs + (int64_t)slot * e->table_elems(), g_lo, g_hi, e->F, e->S, temperature, prior_temperature, e->d_status);
+    HIPCHK(e, hipGetLastError());
+    rc = read_status(e);
+    if (rc) return rc;
+    if (e->h_status[ST_BAD_NORMALIZE])
+        return fail(e, SBE_ERR_DATA, "normalize: %d rows of component %d have a non-positive sum (sbayes/util.py:1006 assert)",
+                    e->h_status[ST_BAD_NORMALIZE], component);
+    s.probs_set[component] = 1;
+    return SBE_OK;
+}
+
+int sbe_set_probs(sbe_engine* e, int slot, int component, const float* probs) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component); CHECK_PTR(e, probs);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int64_t n = (int64_t)e->G[component] * e->F * e->S;
+    float* dst = e->d_probs + (int64_t)slot * e->table_elems() + (int64_t)e->goff[component] * e->F * e->S;
+    int rc = h2d(e, dst, probs, n * sizeof(float));
+    if (rc) return rc;
+    e->slots[slot].probs_set[component] = 1;
+    return SBE_OK;
+}
+
+int sbe_get_probs(sbe_engine* e, int slot, int component, float* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component); CHECK_PTR(e, out);
+    if (!e->slots[slot].probs_set[component]) return fail(e, SBE_ERR_STATE, "slot %d: probs of component %d not set", slot, component);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int64_t n = (int64_t)e->G[component] * e->F * e->S;
+    const float* src = e->d_probs + (int64_t)slot * e->table_elems() + (int64_t)e->goff[component] * e->F * e->S;
+    return d2h(e, out, src, n * sizeof(float));
+}
+
+// ---- weights ------------------------------------------------------------------------------------
+int sbe_set_weights(sbe_engine* e, int slot, const float* weights) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, weights);
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = h2d(e, e->d_weights + (int64_t)slot * e->F * e->C, weights, (size_t)e->F * e->C * sizeof(float));
+    if (rc) return rc;
+    e->slots[slot].weights_set = true;
+    return upload_patterns_and_weights(e, slot);
+}
+
+int sbe_get_weights_normalized(sbe_engine* e, int slot, float* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, out);
+    Slot& s = e->slots[slot];
+    if (!s.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: weights not set", slot);
+    HIPCHK(e, hipSetDevice(e->device));
+    if (s.patterns_dirty) { int rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
+    const int64_t n = (int64_t)e->N * e->F * e->C;
+    int rc = ensure_scratch(e, n * sizeof(float));
+    if (rc) return rc;
+    k_expand_weights<<<div_up(n, 256), 256, 0, e->stream>>>(e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C,
+                                                           e->d_pid + (int64_t)slot * e->N, (float*)e->d_scratch, e->N, e->F, e->C);
+    HIPCHK(e, hipGetLastError());
+    return d2h(e, out, e->d_scratch, n * sizeof(float));
+}
+
+// ---- a3 / a2 / a6 dense outputs ------------------------------------------------------------------
+int sbe_likelihood_per_component(sbe_engine* e, int slot, double* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, out);
+    int rc = check_slot_ready(e, slot, false);
+    if (rc) return rc;
+    HIPCHK(e, hipSetDevice(e->device));
+    const int64_t n = (int64_t)e->N * e->F * e->C;
+    rc = ensure_scratch(e, n * sizeof(double));
+    if (rc) return rc;
+    k_lh_dense<<<div_up((int64_t)e->N * e->F, 256), 256, 0, e->stream>>>(
+        e->d_state, e->d_gid + (int64_t)slot * e->C * e->N, e->d_probs + (int64_t)slot * e->table_elems(),
+        (double*)e->d_scratch, e->N, e->F, e->S, e->C, e->Fp);
+    HIPCHK(e, hipGetLastError());
+    return d2h(e, out, e->d_scratch, n * sizeof(double));
+}
+
+int sbe_likelihood_per_component_exact(sbe_engine* e, int slot, double* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, out);
+    Slot& s = e->slots[slot];
+    if (!s.groups_set || !s.source_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source not set", slot);
+    for (int c = 0; c < e->C; ++c)
+        if (!s.counts_set[c] || !e->conc_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts / concentration of component %d not set", slot, c);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int64_t n = (int64_t)e->N * e->F * e->C;
+    int rc = ensure_scratch(e, n * sizeof(double));
+    if (rc) return rc;
+    rc = clear_status_word(e, ST_BAD_NORMALIZE);
+    if (rc) return rc;
+    k_lh_exact<<<div_up((int64_t)e->N * e->F, 256), 256, 0, e->stream>>>(
+        e->d_state, e->d_src + (int64_t)slot * e->N * e->Fp, e->d_gid + (int64_t)slot * e->C * e->N,
+        e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc, (double*)e->d_scratch, e->N, e->F, e->S, e->C, e->Fp, e->d_status);
+    HIPCHK(e, hipGetLastError());
+    rc = d2h(e, out, e->d_scratch, n * sizeof(double));
+    if (rc) return rc;
+    rc = read_status(e);
+    if (rc) return rc;
+    if (e->h_status[ST_BAD_NORMALIZE]) return fail(e, SBE_ERR_DATA, "normalize: non-positive row sum in leave-one-out tables (sbayes/util.py:1006 assert)");
+    return SBE_OK;
+}
+
+int sbe_observation_lh(sbe_engine* e, int slot, double* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, out);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int64_t n = (int64_t)e->N * e->F;
+    int rc = ensure_scratch(e, n * sizeof(double));
+    if (rc) return rc;
+    rc = enqueue_mixture(e, slot, 1, WRITE_OBS, (double*)e->d_scratch, nullptr);
+    if (rc) return rc;
+    return d2h(e, out, e->d_scratch, n * sizeof(double));
+}
+
+// ---- north-star scalar ----------------------------------------------------------------------------
+int sbe_mixture_loglik_batch_async(sbe_engine* e, int first_slot, int n) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, first_slot);
+    if (n < 1 || first_slot + n > e->n_slots) return fail(e, SBE_ERR_ARG, "slot range [%d,%d) out of range", first_slot, first_slot + n);
+    HIPCHK(e, hipSetDevice(e->device));
+    return enqueue_mixture(e, first_slot, n, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr);
+}
+
+int sbe_fetch_results(sbe_engine* e, int first_slot, int n, double* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, first_slot); CHECK_PTR(e, out);
+    if (n < 1 || first_slot + n > e->n_slots) return fail(e, SBE_ERR_ARG, "slot range out of range");
+    HIPCHK(e, hipMemcpyAsync(e->h_results + first_slot, e->d_results + first_slot, (size_t)n * sizeof(double),
+                             hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    memcpy(out, e->h_results + first_slot, (size_t)n * sizeof(double));
+    return SBE_OK;
+}
+
+int sbe_mixture_loglik_batch(sbe_engine* e, int first_slot, int n, double* out) {
+    CHECK_ENGINE(e); CHECK_PTR(e, out);
+    int rc = sbe_mixture_loglik_batch_async(e, first_slot, n);
+    if (rc) return rc;
+    return sbe_fetch_results(e, first_slot, n, out);
+}
+
+int sbe_mixture_loglik(sbe_engine* e, int slot, double* out) { return sbe_mixture_loglik_batch(e, slot, 1, out); }
+
+// ---- collapsed likelihood -------------------------------------------------------------------------
+int sbe_collapsed_loglik(sbe_engine* e, int slot, int component, double* per_group_out, float* per_feature_out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component); CHECK_PTR(e, per_group_out);
+    Slot& s = e->slots[slot];
+    if (!s.counts_set[component]) return fail(e, SBE_ERR_STATE, "slot %d: counts of component %d not set", slot, component);
+    if (!e->conc_set[component]) return fail(e, SBE_ERR_STATE, "concentration of component %d not set", component);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int G = e->G[component], g_lo = e->goff[component];
+    const size_t pf_bytes = ((size_t)G * e->F * sizeof(float) + 255) / 256 * 256;
+    int rc = ensure_scratch(e, pf_bytes + (size_t)G * sizeof(double));
+    if (rc) return rc;
+    float* d_pf = (float*)e->d_scratch;
+    double* d_pg = (double*)(e->d_scratch + pf_bytes);
+    k_dcl<<<div_up((int64_t)G * e->F, 256), 256, 0, e->stream>>>(e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc,
+                                                              d_pf, g_lo, g_lo + G, e->F, e->S);
+    HIPCHK(e, hipGetLastError());
+    k_group_sum_f32<<<div_up(G, 64), 64, 0, e->stream>>>(d_pf, d_pg, G, e->F);
+    HIPCHK(e, hipGetLastError());
+    rc = d2h(e, per_group_out, d_pg, (size_t)G * sizeof(double));
+    if (rc) return rc;
+    if (per_feature_out) return d2h(e, per_feature_out, d_pf, (size_t)G * e->F * sizeof(float));
+    return SBE_OK;
+}
+
+// ---- slots ------------------------------------------------------------------------------------------
+int sbe_copy_slot(sbe_engine* e, int dst, int src) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, dst); CHECK_SLOT(e, src);
+    if (dst == src) return SBE_OK;
+    HIPCHK(e, hipSetDevice(e->device));
+    const int64_t N = e->N, F = e->F, C = e->C, T = e->table_elems();
+#define D2D(ptr, elems)                                                                             \
+    HIPCHK(e, hipMemcpyAsync((ptr) + (int64_t)dst * (elems), (ptr) + (int64_t)src * (elems),        \
+                             (size_t)(elems) * sizeof(*(ptr)), hipMemcpyDeviceToDevice, e->stream))
+    D2D(e->d_gid, C * N); D2D(e->d_pid, N); D2D(e->d_src, N * e->Fp); D2D(e->d_counts, T); D2D(e->d_probs, T);
+    D2D(e->d_weights, F * C); D2D(e->d_wpat, (int64_t)e->Pmax * F * C); D2D(e->d_patbits, (int64_t)e->Pmax);
+#undef D2D
+    e->slots[dst] = e->slots[src];
+    return SBE_OK;
+}
+
+// ---- measurement -------------------------------------------------------------------------------------
+int sbe_timer_start(sbe_engine* e) {
+    CHECK_ENGINE(e);
+    HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+    return SBE_OK;
+}
+
+int sbe_timer_stop(sbe_engine* e, float* elapsed_ms) {
+    CHECK_ENGINE(e); CHECK_PTR(e, elapsed_ms);
+    HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+    HIPCHK(e, hipEventSynchronize(e->ev1));
+    HIPCHK(e, hipEventElapsedTime(elapsed_ms, e->ev0, e->ev1));
+    return SBE_OK;
+}
+
+int sbe_profile_mixture(sbe_engine* e, int first_slot, int n, int iters, float* total_ms, float* main_kernel_avg_ms) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, first_slot); CHECK_PTR(e, total_ms); CHECK_PTR(e, main_kernel_avg_ms);
+    if (iters < 1 || iters > 100000) return fail(e, SBE_ERR_ARG, "iters=%d", iters);
+    if (n < 1 || first_slot + n > e->n_slots) return fail(e, SBE_ERR_ARG, "slot range out of range");
+    HIPCHK(e, hipSetDevice(e->device));
+    // event pairs around the dominant kernel only (the fused gather/log/reduce kernel); the
+    // small fixed-order partial reduction that follows is outside the pair.
+    while ((int)e->ev_pool.size() < 2 * iters) {
+        hipEvent_t ev;
+        HIPCHK(e, hipEventCreate(&ev));
+        e->ev_pool.push_back(ev);
+    }
+    const int mode = e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS;
+    // resolve lazily-built state outside the timed region
+    int rc = enqueue_mixture(e, first_slot, n, mode, nullptr, nullptr);
+    if (rc) return rc;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+    for (int it = 0; it < iters; ++it) {
+        // replicate enqueue_mixture with events around the main kernel
+        const int P = max_patterns(e, first_slot, n);
+        MixGeom g = mix_geometry(e, P, n);
+        MixParams p{};
+        p.N = e->N; p.F = e->F; p.S = e->S; p.C = e->C; p.Fp = e->Fp; p.rs_pitch = e->rs_pitch;
+        p.Gtot = e->Gtot; p.P = P; p.ft = g.ft; p.ft_shift = g.ft_shift; p.n_ftiles = g.n_ftiles;
+        p.n_chunks = g.n_chunks; p.objs_per_chunk = g.objs_per_chunk;
+        p.s_magic = (uint32_t)(((1u << 24) + e->S - 1) / e->S);
+        p.state = e->d_state; p.onehot = e->d_onehot;
+        p.gid = e->d_gid; p.gid_stride = (int64_t)e->C * e->N;
+        p.pid = e->d_pid; p.pid_stride = e->N;
+        p.probs = e->d_probs; p.probs_stride = e->table_elems();
+        p.wpat = e->d_wpat; p.wpat_stride = (int64_t)e->Pmax * e->F * e->C;
+        p.partials = e->d_partials; p.partials_stride = e->partials_stride;
+        p.obs = nullptr; p.first_slot = first_slot;
+        const dim3 grid(g.n_blocks, n);
+        const bool onehot = e->opt_kernel == SBE_MIXTURE_ONEHOT;
+        HIPCHK(e, hipEventRecord(e->ev_pool[2 * it], e->stream));
+        if (mode == LOG_PRODUCT) {
+            if (onehot) launch_mixture<LOG_PRODUCT, true>(p, grid, g.lds_bytes, e->stream);
+            else launch_mixture<LOG_PRODUCT, false>(p, grid, g.lds_bytes, e->stream);
+        } else {
+            if (onehot) launch_mixture<LOG_PER_OBS, true>(p, grid, g.lds_bytes, e->stream);
+            else launch_mixture<LOG_PER_OBS, false>(p, grid, g.lds_bytes, e->stream);
+        }
+        HIPCHK(e, hipEventRecord(e->ev_pool[2 * it + 1], e->stream));
+        k_reduce_partials<<<n, kBlock, 0, e->stream>>>(e->d_partials, e->partials_stride, g.n_blocks, e->d_results, first_slot);
+    }
+    HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+    HIPCHK(e, hipEventSynchronize(e->ev1));
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipEventElapsedTime(total_ms, e->ev0, e->ev1));
+    double acc = 0.0;
+    for (int it = 0; it < iters; ++it) {
+        float ms = 0.f;
+        HIPCHK(e, hipEventElapsedTime(&ms, e->ev_pool[2 * it], e->ev_pool[2 * it + 1]));
+        acc += ms;
+    }
+    *main_kernel_avg_ms = (float)(acc / iters);
+    return SBE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,624 @@
+// sbe_kernels.hip.h -- gfx950 (MI355X / CDNA4) device code of the sBayes likelihood engine.
+//
+// Everything here is a categorical gather-multiply-reduce over the objects x features x states
+// block: HBM/L2/LDS-bound byte and table traffic, no MFMA (SURVEY.md 8(d) "Bound").
+// Wave = 64 lanes; blocks are 256 threads (4 waves, one per SIMD of a CU).
+//
+// Numerics contract: probability tables and normalised weights are float32 and
+// are produced with NumPy's exact operation order (pairwise reduction order of
+// numpy/_core/src/umath/loops_utils.h.src, IEEE division, one rounding to float32), so they are
+// bit-identical to the reference's; everything downstream of them is float64.  The file is
+// compiled with -ffp-contract=off: NumPy never fuses a multiply into an add.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sbe {
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+constexpr int kMaxComponents = 8;
+constexpr uint16_t kNoGroup = 0xFFFF;
+constexpr uint8_t kNA = 0xFF;
+
+// status words written by kernels (d_status[...])
+enum StatusWord : int {
+    ST_MULTI_STATE = 0,      // (object, feature) rows with more than one set state
+    ST_NA_COUNT = 1,         // NA observations
+    ST_BAD_NORMALIZE = 2,    // normalize(): a row sum was not > 0 (util.py:1006 assert)
+    ST_MULTI_SOURCE = 3,     // source rows with more than one component set
+    ST_WORDS = 8
+};
+
+// ------------------------------------------------------------------------------------------
+// NumPy reduction order (pairwise sum, PW_BLOCKSIZE = 128, 8-way unrolled block).
+// `get(i)` returns element i as T.  Matches @TYPE@_pairwise_sum for any n.
+// ------------------------------------------------------------------------------------------
+template <class T, class Get>
+__device__ __forceinline__ T np_block_sum(Get get, int lo, int n) {
+    if (n < 8) {
+        T res = T(0);
+        for (int i = 0; i < n; ++i) res = res + get(lo + i);
+        return res;
+    }
+    T r0 = get(lo + 0), r1 = get(lo + 1), r2 = get(lo + 2), r3 = get(lo + 3);
+    T r4 = get(lo + 4), r5 = get(lo + 5), r6 = get(lo + 6), r7 = get(lo + 7);
+    int i = 8;
+    const int lim = n - (n % 8);
+    for (; i < lim; i += 8) {
+        r0 = r0 + get(lo + i + 0); r1 = r1 + get(lo + i + 1);
+        r2 = r2 + get(lo + i + 2); r3 = r3 + get(lo + i + 3);
+        r4 = r4 + get(lo + i + 4); r5 = r5 + get(lo + i + 5);
+        r6 = r6 + get(lo + i + 6); r7 = r7 + get(lo + i + 7);
+    }
+    T res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res = res + get(lo + i);
+    return res;
+}
+
+template <class T, class Get>
+__device__ T np_pairwise_sum(Get get, int n) {
+    if (n <= 128) return np_block_sum<T>(get, 0, n);
+    // iterative post-order walk of NumPy's recursion: split n2 = n/2 - (n/2)%8
+    struct Frame { int lo, n, stage; T left; };
+    Frame st[28];
+    int sp = 0;
+    T ret = T(0);
+    st[sp++] = Frame{0, n, 0, T(0)};
+    while (sp > 0) {
+        Frame& f = st[sp - 1];
+        if (f.stage == 0) {
+            if (f.n <= 128) { ret = np_block_sum<T>(get, f.lo, f.n); --sp; }
+            else { int n2 = f.n / 2; n2 -= n2 % 8; f.stage = 1; st[sp++] = Frame{f.lo, n2, 0, T(0)}; }
+        } else if (f.stage == 1) {
+            f.left = ret; f.stage = 2;
+            int n2 = f.n / 2; n2 -= n2 % 8;
+            st[sp++] = Frame{f.lo + n2, f.n - n2, 0, T(0)};
+        } else {
+            ret = f.left + ret; --sp;
+        }
+    }
+    return ret;
+}
+
+// ------------------------------------------------------------------------------------------
+// wave64 / block reductions (fixed order => run-to-run deterministic)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+__device__ __forceinline__ double block_sum(double v, double* lds4) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
+    if (lane == 0) lds4[wid] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+    return r;   // valid in thread 0
+}
+
+// ------------------------------------------------------------------------------------------
+// K0: one-hot ingest.  raw [N][F*S] (any non-zero byte = True) -> normalised 0/1 copy with a
+// 16-byte-aligned row pitch, packed state index [N][Fp] (0xFF = NA), validation counters.
+// ------------------------------------------------------------------------------------------
+__global__ void k_ingest_onehot(const uint8_t* __restrict__ raw, uint8_t* __restrict__ onehot,
+                                uint8_t* __restrict__ state, int N, int F, int S, int rs_pitch,
+                                int Fp, int* __restrict__ status) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // observation index
+    int multi = 0, na = 0;
+    if (i < (int64_t)N * F) {
+        const int n = (int)(i / F), f = (int)(i % F);
+        const uint8_t* src = raw + (int64_t)i * S;
+        uint8_t* dst = onehot + (int64_t)n * rs_pitch + (int64_t)f * S;
+        int x = -1, cnt = 0;
+        for (int s = 0; s < S; ++s) {
+            const uint8_t b = src[s] != 0;
+            dst[s] = b;
+            if (b) { x = s; ++cnt; }
+        }
+        state[(int64_t)n * Fp + f] = cnt == 0 ? kNA : (uint8_t)x;
+        multi = cnt > 1;
+        na = cnt == 0;
+    }
+    const int m = __popcll(__ballot(multi)), a = __popcll(__ballot(na));
+    if ((threadIdx.x & 63) == 0) {
+        if (m) atomicAdd(&status[ST_MULTI_STATE], m);
+        if (a) atomicAdd(&status[ST_NA_COUNT], a);
+    }
+}
+
+// K0b: source ingest.  bool rows [rows][F][C] -> component id per observation (0xFF = none).
+// `objects` == nullptr: row r is object r.
+__global__ void k_ingest_source(const uint8_t* __restrict__ rows, const int32_t* __restrict__ objects,
+                                uint8_t* __restrict__ src_id, int n_rows, int F, int C, int Fp,
+                                int* __restrict__ status) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int multi = 0;
+    if (i < (int64_t)n_rows * F) {
+        const int r = (int)(i / F), f = (int)(i % F);
+        const int n = objects ? objects[r] : r;
+        const uint8_t* p = rows + (int64_t)i * C;
+        int id = kNA, cnt = 0;
+        for (int c = 0; c < C; ++c)
+            if (p[c]) { id = c; ++cnt; }
+        src_id[(int64_t)n * Fp + f] = (uint8_t)id;
+        multi = cnt > 1;
+    }
+    const int m = __popcll(__ballot(multi));
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&status[ST_MULTI_SOURCE], m);
+}
+
+// ------------------------------------------------------------------------------------------
+// a9: feature counts (counts.py:10-52, 55-95).
+// counts[gg][f][s] (int32, gg = global group index over all components) accumulates
+//   sign_a * [object in A-state] + sign_b * [object in B-state]
+// over the listed objects.  Block = feature tile (ft features) x all listed objects of its
+// chunk; privatised LDS histogram hist[Gtot][ft][S]; lanes of a wave sit on different features
+// so LDS atomics only collide across object lanes.  Non-zero cells are flushed with one global
+// atomic each; `changed[gg]` is raised for groups with a non-zero net delta in this block.
+// With a single object chunk (delta updates) that is exactly the reference's
+// np.any(diff != 0) per group (state.py:349-350).
+// ------------------------------------------------------------------------------------------
+struct CountSide {
+    const uint16_t* gid;   // [C][N] global group index or 0xFFFF
+    const uint8_t* src;    // [N][Fp] source component id
+    int sign;              // 0 = side unused
+};
+
+__global__ __launch_bounds__(kBlock) void k_counts(
+    const uint8_t* __restrict__ state, CountSide A, CountSide B, const int32_t* __restrict__ objects,
+    int n_listed, int objs_per_chunk, int N, int F, int S, int C, int Fp, int Gtot, int ft,
+    int32_t* __restrict__ counts, uint8_t* __restrict__ changed) {
+    extern __shared__ int32_t hist[];
+    const int f0 = blockIdx.x * ft;
+    const int cells = Gtot * ft * S;
+    for (int i = threadIdx.x; i < cells; i += kBlock) hist[i] = 0;
+    __syncthreads();
+
+    const int fl = threadIdx.x % ft, ol = threadIdx.x / ft, olanes = kBlock / ft;
+    const int f = f0 + fl;
+    const int i0 = blockIdx.y * objs_per_chunk;
+    const int i1 = min(n_listed, i0 + objs_per_chunk);
+    if (f < F) {
+        for (int i = i0 + ol; i < i1; i += olanes) {
+            const int n = objects ? objects[i] : i;
+            const uint8_t x = state[(int64_t)n * Fp + f];
+            if (x == kNA) continue;
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const CountSide& sd = side ? B : A;
+                if (sd.sign == 0) continue;
+                const uint8_t c = sd.src[(int64_t)n * Fp + f];
+                if (c >= C) continue;
+                const uint16_t gg = sd.gid[(int64_t)c * N + n];
+                if (gg == kNoGroup) continue;
+                atomicAdd(&hist[((int)gg * ft + fl) * S + x], sd.sign);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cells; i += kBlock) {
+        const int h = hist[i];
+        if (h != 0) {
+            const int gg = i / (ft * S), r = i % (ft * S);
+            const int ff = f0 + r / S, s = r % S;
+            atomicAdd(&counts[((int64_t)gg * F + ff) * S + s], h);
+            if (changed) changed[gg] = 1;
+        }
+    }
+}
+
+// Fallback for histograms that do not fit in LDS: one global atomic per observation.
+__global__ void k_counts_global(const uint8_t* __restrict__ state, CountSide A, CountSide B,
+                                const int32_t* __restrict__ objects, int n_listed, int N, int F, int S,
+                                int C, int Fp, int32_t* __restrict__ counts, uint8_t* __restrict__ changed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_listed * F) return;
+    const int r = (int)(i / F), f = (int)(i % F);
+    const int n = objects ? objects[r] : r;
+    const uint8_t x = state[(int64_t)n * Fp + f];
+    if (x == kNA) return;
+    for (int side = 0; side < 2; ++side) {
+        const CountSide& sd = side ? B : A;
+        if (sd.sign == 0) continue;
+        const uint8_t c = sd.src[(int64_t)n * Fp + f];
+        if (c >= C) continue;
+        const uint16_t gg = sd.gid[(int64_t)c * N + n];
+        if (gg == kNoGroup) continue;
+        atomicAdd(&counts[((int64_t)gg * F + f) * S + x], sd.sign);
+        if (changed) changed[gg] = 1;   // over-approximation (no cancellation visible here)
+    }
+}
+
+__global__ void k_i32_to_f32(const int32_t* __restrict__ in, float* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+__global__ void k_f32_to_i32(const float* __restrict__ in, int32_t* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)in[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// a4 / a10: probs = normalize(counts/T + prior') -> float32   (util.py:990-1007,
+// conditionals.py:105-122, 175-179).  One thread per (group, feature) row of S states.
+//   counts are float32 in the reference (counts.py:20): counts / T is a float32 division
+//   (NumPy: float32 array / Python float), then + float64 prior -> float64.
+// ------------------------------------------------------------------------------------------
+__global__ void k_probs(const int32_t* __restrict__ counts, const double* __restrict__ conc,
+                        const double* __restrict__ unif /* [F][S] or null */, float* __restrict__ probs,
+                        int g_lo, int g_hi, int F, int S, double temperature, double prior_temperature,
+                        int* __restrict__ status) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_rows = (int64_t)(g_hi - g_lo) * F;
+    if (row >= n_rows) return;
+    const int64_t base = ((int64_t)g_lo * F + row) * S;
+    const int f = (int)(row % F);
+    const bool tempered = temperature > 0.0;
+    const bool prior_tempered = prior_temperature > 0.0 && unif != nullptr;
+    const float t32 = (float)temperature;
+    auto post = [&](int s) -> double {
+        float c = (float)counts[base + s];
+        if (tempered) c = c / t32;
+        double a = conc[base + s];
+        if (prior_tempered) {
+            const double u = unif[(int64_t)f * S + s];
+            a = u + (a - u) / prior_temperature;
+        }
+        return (double)c + a;
+    };
+    const double total = np_pairwise_sum<double>(post, S);
+    if (!(total > 0.0)) atomicAdd(&status[ST_BAD_NORMALIZE], 1);
+    for (int s = 0; s < S; ++s) probs[base + s] = (float)(post(s) / total);
+}
+
+// ------------------------------------------------------------------------------------------
+// a5: per-pattern normalised weights (likelihood.py:171-190).  One thread per (pattern, f).
+//   w = pattern * weights (bool x float32 -> float32);  w /= sum_c w   (float32, NumPy order)
+// ------------------------------------------------------------------------------------------
+__global__ void k_weight_patterns(const float* __restrict__ weights /* [F][C] */,
+                                  const uint32_t* __restrict__ pattern_bits /* [P] */,
+                                  float* __restrict__ wpat /* [P][F][C] */, int P, int F, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * F) return;
+    const int p = i / F, f = i % F;
+    const uint32_t bits = pattern_bits[p];
+    const float* w = weights + (int64_t)f * C;
+    auto masked = [&](int c) -> float { return ((bits >> c) & 1u) ? w[c] : 0.0f * w[c]; };
+    const float total = np_pairwise_sum<float>(masked, C);
+    float* out = wpat + ((int64_t)p * F + f) * C;
+    for (int c = 0; c < C; ++c) out[c] = masked(c) / total;
+}
+
+__global__ void k_expand_weights(const float* __restrict__ wpat, const uint8_t* __restrict__ pid,
+                                 float* __restrict__ out /* [N][F][C] */, int N, int F, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * F * C) return;
+    const int n = (int)(i / ((int64_t)F * C));
+    const int64_t r = i % ((int64_t)F * C);
+    out[i] = wpat[(int64_t)pid[n] * F * C + r];
+}
+
+// ------------------------------------------------------------------------------------------
+// a1: compute_component_likelihood (likelihood.py:104-133), dense device side.
+//   sel[n] >= 0 : row n takes table sel[n];  -1 : row <- 0 (object in no group);
+//   -2 : row untouched (member of an unchanged group) -- the host scatter skips it.
+// One-hot => the float32 sum over states has exactly one non-zero term: value = probs[.][f][x]
+// converted exactly to float64; NA rows sum to 0.
+// ------------------------------------------------------------------------------------------
+template <class TP>
+__global__ void k_component_lh(const uint8_t* __restrict__ state, const TP* __restrict__ probs,
+                               const int32_t* __restrict__ sel, double* __restrict__ out /* [N][F] */,
+                               int N, int F, int S, int Fp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * F) return;
+    const int n = (int)(i / F), f = (int)(i % F);
+    const int g = sel[n];
+    double v = 0.0;
+    if (g >= 0) {
+        const uint8_t x = state[(int64_t)n * Fp + f];
+        if (x != kNA) v = (double)probs[((int64_t)g * F + f) * S + x];
+    }
+    out[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// a3: likelihood_per_component (conditionals.py:152-223): dense [N][F][C] float64 from the
+// slot's group ids and tables; NA <- 1 (conditionals.py:216), no group <- 0 (likelihood.py:122).
+// ------------------------------------------------------------------------------------------
+__global__ void k_lh_dense(const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid,
+                           const float* __restrict__ probs, double* __restrict__ out, int N, int F,
+                           int S, int C, int Fp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * F) return;
+    const int n = (int)(i / F), f = (int)(i % F);
+    const uint8_t x = state[(int64_t)n * Fp + f];
+    double* o = out + i * C;
+    for (int c = 0; c < C; ++c) {
+        double v = 1.0;
+        if (x != kNA) {
+            const uint16_t gg = gid[(int64_t)c * N + n];
+            v = gg == kNoGroup ? 0.0 : (double)probs[((int64_t)gg * F + f) * S + x];
+        }
+        o[c] = v;
+    }
+}
+
+// a2: likelihood_per_component_exact (conditionals.py:300-367): leave-one-out tables.
+// For observation (n, f) in group g of component c the table row is
+//   normalize(counts[g,f,:] + prior[g,f,:] - onehot(n,f,:) * source[n,f,c])   (float32)
+__global__ void k_lh_exact(const uint8_t* __restrict__ state, const uint8_t* __restrict__ src,
+                           const uint16_t* __restrict__ gid, const int32_t* __restrict__ counts,
+                           const double* __restrict__ conc, double* __restrict__ out, int N, int F,
+                           int S, int C, int Fp, int* __restrict__ status) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * F) return;
+    const int n = (int)(i / F), f = (int)(i % F);
+    const uint8_t x = state[(int64_t)n * Fp + f];
+    const uint8_t sc = src[(int64_t)n * Fp + f];
+    double* o = out + i * C;
+    for (int c = 0; c < C; ++c) {
+        double v = 1.0;
+        if (x != kNA) {
+            const uint16_t gg = gid[(int64_t)c * N + n];
+            if (gg == kNoGroup) v = 0.0;
+            else {
+                const int64_t base = ((int64_t)gg * F + f) * S;
+                const double own = sc == c ? 1.0 : 0.0;
+                auto post = [&](int s) -> double {
+                    const double a = (double)(float)counts[base + s] + conc[base + s];
+                    return s == x ? a - own : a - 0.0;
+                };
+                const double total = np_pairwise_sum<double>(post, S);
+                if (!(total > 0.0)) atomicAdd(&status[ST_BAD_NORMALIZE], 1);
+                v = (double)(float)(post(x) / total);
+            }
+        }
+        o[c] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a7 + a8: collapsed Dirichlet-categorical log-pdf (util.py:1373-1394, likelihood.py:65-101).
+// k_dcl: one thread per (group, feature):
+//   float32( lgamma(sum a) - lgamma(n + sum a) + sum_{s: a>0} (lgamma(c + a) - lgamma(a)) )
+// k_group_sum_f32: one thread per group: float32 NumPy-order sum over features -> float64 cache.
+// ------------------------------------------------------------------------------------------
+__global__ void k_dcl(const int32_t* __restrict__ counts, const double* __restrict__ conc,
+                      float* __restrict__ per_feature, int g_lo, int g_hi, int F, int S) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= (int64_t)(g_hi - g_lo) * F) return;
+    const int64_t base = ((int64_t)g_lo * F + row) * S;
+    auto cnt = [&](int s) -> float { return (float)counts[base + s]; };
+    auto a = [&](int s) -> double { return conc[base + s]; };
+    const float n = np_pairwise_sum<float>(cnt, S);
+    const double sum_a = np_pairwise_sum<double>(a, S);
+    const double cst = lgamma(sum_a) - lgamma((double)n + sum_a);
+    auto series = [&](int s) -> double {
+        const double as = conc[base + s];
+        return as > 0.0 ? lgamma((double)(float)counts[base + s] + as) - lgamma(as) : 0.0;
+    };
+    per_feature[row] = (float)(cst + np_pairwise_sum<double>(series, S));
+}
+
+__global__ void k_group_sum_f32(const float* __restrict__ per_feature, double* __restrict__ per_group,
+                                int n_groups, int F) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const float* p = per_feature + (int64_t)g * F;
+    auto get = [&](int i) -> float { return p[i]; };
+    per_group[g] = (double)np_pairwise_sum<float>(get, F);
+}
+
+// ------------------------------------------------------------------------------------------
+// THE north-star kernel: fused a3 + a5 + a6 + log + reduce.
+//
+//   LL = sum_{n,f not NA} log sum_c w[pat(n)][f][c] * p_c[g_c(n)][f][x(n,f)]
+//
+// Work decomposition: a block owns a tile of `ft` features x one chunk of objects.
+//   LDS: tab[Gtot][ft][S] float32 probability rows of the tile's features for every group of
+//        every component (the "LDS-staged per-feature state probabilities"), and
+//        wl[P][ft][C] float32 normalised weight rows.
+//   Streamed operand (coalesced, read exactly once per eval):
+//        PACKED : state index bytes, one dword (4 observations) per lane per step
+//        ONEHOT : the one-hot block as handed over, 16 bytes per lane per step; set bytes are
+//                 located with bit tricks, byte offset j in the tile row indexes tab directly.
+//   Per observation: C LDS gathers + C weight reads, C fp64 multiplies, fp64 adds in NumPy
+//   order, then the log accumulation.
+//   Reduction: per-thread partial -> wave64 shuffle tree -> 4 partials through LDS -> one
+//   double per block -> k_reduce_partials sums them in fixed order (deterministic).
+//
+// Log accumulation modes:
+//   LOG_PER_OBS : acc += log(v)                       (fp64 log per observation)
+//   LOG_PRODUCT : mantissa product m *= v with the exponent stripped into an integer after
+//                 every multiply; one fp64 log per thread at the end.  v <= 0 or NaN falls
+//                 back to the per-observation log so -inf / NaN propagate like NumPy's.
+//   WRITE_OBS   : no reduction; v is written to obs[N][F] (a6, loggers.py:355-357); NA
+//                 observations get sum_c w (the reference multiplies w by lh = 1).
+// ------------------------------------------------------------------------------------------
+enum MixMode : int { LOG_PER_OBS = 0, LOG_PRODUCT = 1, WRITE_OBS = 2 };
+
+struct MixParams {
+    // geometry
+    int N, F, S, C, Fp, rs_pitch, Gtot, P;
+    int ft, ft_shift;          // feature tile width (power of two, >= 16)
+    int n_ftiles, n_chunks, objs_per_chunk;
+    uint32_t s_magic;          // ceil(2^24 / S): j / S == (j * s_magic) >> 24 for j < 2^16
+    // resident data
+    const uint8_t* state;      // [N][Fp]
+    const uint8_t* onehot;     // [N][rs_pitch]
+    // slot-strided state (element strides between consecutive slots)
+    const uint16_t* gid;  int64_t gid_stride;     // [C][N]
+    const uint8_t* pid;   int64_t pid_stride;     // [N]
+    const float* probs;   int64_t probs_stride;   // [Gtot][F][S]
+    const float* wpat;    int64_t wpat_stride;    // [P][F][C]
+    double* partials;     int64_t partials_stride;  // [n_blocks]
+    double* obs;                                  // WRITE_OBS only: [N][F]
+    int first_slot;
+};
+
+struct LogAcc {
+    double sum;      // LOG_PER_OBS accumulator (also the fallback path of LOG_PRODUCT)
+    double mant;     // LOG_PRODUCT: in [1, 2)
+    int expo;        // LOG_PRODUCT: accumulated binary exponent
+};
+
+template <int MODE>
+__device__ __forceinline__ void acc_add(LogAcc& a, double v) {
+    if (MODE == LOG_PER_OBS) {
+        a.sum += log(v);
+    } else if (MODE == LOG_PRODUCT) {
+        // normal positive finite doubles only; everything else through log()
+        const uint32_t hi = (uint32_t)(__double_as_longlong(v) >> 32);
+        const uint32_t ex = (hi >> 20) & 0x7FFu;
+        if (__builtin_expect((hi >> 31) == 0 && ex != 0 && ex != 0x7FFu, 1)) {
+            double m = a.mant * v;                       // in [2^-1022, 4)
+            uint64_t bits = (uint64_t)__double_as_longlong(m);
+            a.expo += (int)((bits >> 52) & 0x7FFu) - 1023;
+            bits = (bits & 0x800FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+            a.mant = __longlong_as_double((long long)bits);
+        } else {
+            a.sum += log(v);
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ double acc_finish(const LogAcc& a) {
+    if (MODE == LOG_PRODUCT) return a.sum + (log(a.mant) + (double)a.expo * 0.693147180559945309417232);
+    return a.sum;
+}
+
+template <int MODE, bool ONEHOT>
+__global__ __launch_bounds__(kBlock) void k_mixture(MixParams p) {
+    extern __shared__ float lds[];
+    __shared__ double red4[4];
+    const int slot = p.first_slot + blockIdx.y;
+    const int tile = blockIdx.x % p.n_ftiles, chunk = blockIdx.x / p.n_ftiles;
+    const int f0 = tile << p.ft_shift;
+    const int ft = p.ft, S = p.S, C = p.C, F = p.F;
+    const int fw = min(ft, F - f0);                // valid features in this tile
+
+    float* tab = lds;                              // [Gtot][ft*S]
+    float* wl = lds + (int64_t)p.Gtot * ft * S;    // [P][ft][C]
+
+    // ---- stage tables: rows of fw*S contiguous floats per group ---------------------------
+    const float* probs = p.probs + (int64_t)slot * p.probs_stride;
+    const int row_len = fw * S, row_pitch = ft * S;
+    for (int i = threadIdx.x; i < p.Gtot * row_len; i += kBlock) {
+        const int gg = i / row_len, r = i - gg * row_len;
+        tab[gg * row_pitch + r] = probs[((int64_t)gg * F + f0) * S + r];
+    }
+    const float* wpat = p.wpat + (int64_t)slot * p.wpat_stride;
+    const int wrow = fw * C;
+    for (int i = threadIdx.x; i < p.P * wrow; i += kBlock) {
+        const int pp = i / wrow, r = i - pp * wrow;
+        wl[pp * ft * C + r] = wpat[((int64_t)pp * F + f0) * C + r];
+    }
+    __syncthreads();
+
+    const uint16_t* gid = p.gid + (int64_t)slot * p.gid_stride;
+    const uint8_t* pid = p.pid + (int64_t)slot * p.pid_stride;
+    const int n0 = chunk * p.objs_per_chunk;
+    const int n_obj = min(p.objs_per_chunk, p.N - n0);
+
+    LogAcc acc{0.0, 1.0, 0};
+
+    auto observe = [&](int n, int fl, int x, int pidn, const uint16_t* g) {
+        // v = ((0 + w0*l0) + w1*l1) + ...   NumPy order, no FMA contraction (operators.py:1060)
+        double v = 0.0;
+        const float* wrow_p = wl + (pidn * ft + fl) * C;
+#pragma unroll
+        for (int c = 0; c < kMaxComponents; ++c) {
+            if (c < C) {
+                const double w = (double)wrow_p[c];
+                const double l = g[c] == kNoGroup ? 0.0 : (double)tab[(int)g[c] * row_pitch + fl * S + x];
+                v = v + w * l;
+            }
+        }
+        if (MODE == WRITE_OBS) p.obs[(int64_t)n * F + f0 + fl] = v;
+        else acc_add<MODE>(acc, v);
+    };
+
+    if (!ONEHOT) {
+        // lane <-> 4 consecutive features of one object (one dword of state bytes)
+        const int q_shift = p.ft_shift - 2;
+        const int n_quads = n_obj << q_shift;
+        for (int q = threadIdx.x; q < n_quads; q += kBlock) {
+            const int nl = q >> q_shift, fq = q & ((1 << q_shift) - 1);
+            const int n = n0 + nl;
+            const uint32_t xs = *reinterpret_cast<const uint32_t*>(p.state + (int64_t)n * p.Fp + f0 + fq * 4);
+            if (MODE != WRITE_OBS && xs == 0xFFFFFFFFu) continue;
+            uint16_t g[kMaxComponents];
+#pragma unroll
+            for (int c = 0; c < kMaxComponents; ++c) g[c] = c < C ? gid[(int64_t)c * p.N + n] : kNoGroup;
+            const int pidn = pid[n];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = (xs >> (8 * k)) & 0xFF;
+                const int fl = fq * 4 + k;
+                if (x != kNA) observe(n, fl, x, pidn, g);
+                else if (MODE == WRITE_OBS && fl < fw) {
+                    double v = 0.0;                 // NA: lh = 1 in every component
+                    for (int c = 0; c < C; ++c) v = v + (double)wl[(pidn * ft + fl) * C + c] * 1.0;
+                    p.obs[(int64_t)n * F + f0 + fl] = v;
+                }
+            }
+        }
+    } else {
+        // lane <-> 16 consecutive bytes of one object's one-hot row inside the tile
+        const int row_bytes = ft * S;                   // multiple of 16 (ft >= 16)
+        const int chunks_per_row = row_bytes >> 4;
+        const int n_chunks16 = n_obj * chunks_per_row;
+        for (int q = threadIdx.x; q < n_chunks16; q += kBlock) {
+            const int nl = q / chunks_per_row, ch = q - nl * chunks_per_row;
+            const int n = n0 + nl;
+            const int64_t off = (int64_t)n * p.rs_pitch + (int64_t)f0 * S + ch * 16;
+            if ((int64_t)f0 * S + ch * 16 >= p.rs_pitch) continue;          // tail tile past the row end
+            const uint4 d = *reinterpret_cast<const uint4*>(p.onehot + off);
+            if ((d.x | d.y | d.z | d.w) == 0u) continue;
+            uint16_t g[kMaxComponents];
+#pragma unroll
+            for (int c = 0; c < kMaxComponents; ++c) g[c] = c < C ? gid[(int64_t)c * p.N + n] : kNoGroup;
+            const int pidn = pid[n];
+            const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // bytes are 0/1: gather bit 0 of each byte into a 4-bit mask
+                uint32_t m = ((dw[k] * 0x00204081u) >> 21) & 0xFu;
+                while (m) {
+                    const int b = __builtin_ctz(m);
+                    m &= m - 1;
+                    const int j = ch * 16 + k * 4 + b;                  // byte offset in the tile row
+                    const int fl = (int)(((uint32_t)j * p.s_magic) >> 24);
+                    const int x = j - fl * S;
+                    observe(n, fl, x, pidn, g);
+                }
+            }
+        }
+    }
+
+    if (MODE != WRITE_OBS) {
+        const double total = block_sum(acc_finish<MODE>(acc), red4);
+        if (threadIdx.x == 0)
+            p.partials[(int64_t)slot * p.partials_stride + blockIdx.x] = total;
+    }
+}
+
+// Final fixed-order reduction of the per-block partials: one block per slot.
+__global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __restrict__ partials,
+                                                           int64_t partials_stride, int n_blocks,
+                                                           double* __restrict__ results, int first_slot) {
+    __shared__ double red4[4];
+    const int slot = first_slot + blockIdx.x;
+    const double* p = partials + (int64_t)slot * partials_stride;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n_blocks; i += kBlock) v += p[i];
+    const double total = block_sum(v, red4);
+    if (threadIdx.x == 0) results[slot] = total;
+}
+
+}  // namespace sbe

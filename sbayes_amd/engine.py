@@ -1,0 +1,320 @@
+"""Engine: thin NumPy-facing wrapper of the C-ABI handle (include/sbe_engine.h).
+
+Shape / dtype validation happens here, before the call crosses the ABI (SURVEY.md 8(b)
+"Errors"); every non-zero return code becomes a RuntimeError carrying sbe_last_error().
+Device handles are created lazily per process and are never pickled (MC3 workers and
+`copy(model)` re-create them: sbayes/mcmc_setup.py:299, sbayes/model/model.py:53-54).
+"""
+from __future__ import annotations
+
+import ctypes as ct
+
+import numpy as np
+
+from . import _lib
+
+MIXTURE_PACKED, MIXTURE_ONEHOT = 0, 1
+LOG_PER_OBS, LOG_PRODUCT = 0, 1
+_OPT_KERNEL, _OPT_LOG = 1, 2
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"sbe error {code}: {message}")
+        self.code = code
+
+
+def _c(a, dtype):
+    """C-contiguous view/copy with the exact dtype the ABI expects."""
+    a = np.asarray(a)
+    if a.dtype == np.bool_ and dtype == np.uint8:
+        a = a.view(np.uint8) if a.flags.c_contiguous else np.ascontiguousarray(a).view(np.uint8)
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ct.c_void_p)
+
+
+def device_count() -> int:
+    lib = _lib.load()
+    n = ct.c_int(0)
+    lib.sbe_device_count(ct.byref(n))
+    return n.value
+
+
+class Engine:
+    """One resident one-hot feature block + `n_slots` sample states on one GPU."""
+
+    def __init__(self, features, n_groups, n_slots=2, device=0):
+        self._lib = _lib.load()
+        self._h = ct.c_void_p()
+        features = np.asarray(features)
+        if features.ndim != 3:
+            raise ValueError(f"features must be [n_objects, n_features, n_states], got shape {features.shape}")
+        if features.dtype != np.bool_ and features.dtype != np.uint8:
+            raise TypeError(f"features must be bool (one-hot), got {features.dtype}")
+        self.n_objects, self.n_features, self.n_states = (int(v) for v in features.shape)
+        self.n_groups = [int(g) for g in n_groups]
+        self.n_components = len(self.n_groups)
+        self.n_slots = int(n_slots)
+        self.device = int(device)
+        feats = _c(features, np.uint8)
+        ng = np.asarray(self.n_groups, dtype=np.int32)
+        rc = self._lib.sbe_create(ct.byref(self._h), self.device, self.n_objects, self.n_features,
+                                  self.n_states, self.n_components,
+                                  ng.ctypes.data_as(ct.POINTER(ct.c_int32)), self.n_slots, _ptr(feats))
+        if rc != 0:
+            msg = self._lib.sbe_last_error(None)
+            self._h = ct.c_void_p()
+            raise EngineError(rc, msg.decode() if msg else "sbe_create failed")
+        self.group_offsets = np.concatenate([[0], np.cumsum(self.n_groups)]).astype(int)
+        self.n_groups_total = int(self.group_offsets[-1])
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.sbe_last_error(self._h)
+            raise EngineError(rc, msg.decode() if msg else "?")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.sbe_destroy(self._h)
+            self._h = ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __getstate__(self):
+        raise TypeError("Engine holds device memory and is not picklable; re-create it in the new process")
+
+    def info(self):
+        inf = _lib.SbeInfo()
+        self._check(self._lib.sbe_get_info(self._h, ct.byref(inf)))
+        return {k: (getattr(inf, k).decode() if k == "device_name" else getattr(inf, k)) for k, _ in inf._fields_}
+
+    def set_option(self, kernel=None, log_mode=None):
+        if kernel is not None:
+            self._check(self._lib.sbe_set_option(self._h, _OPT_KERNEL, int(kernel)))
+        if log_mode is not None:
+            self._check(self._lib.sbe_set_option(self._h, _OPT_LOG, int(log_mode)))
+
+    def sync(self):
+        self._check(self._lib.sbe_sync(self._h))
+
+    def na_values(self):
+        out = np.empty((self.n_objects, self.n_features), dtype=np.bool_)
+        self._check(self._lib.sbe_get_na(self._h, _ptr(out)))
+        return out
+
+    # -- a1 -------------------------------------------------------------------------------------
+    def component_lh(self, probs, groups, changed_groups, out):
+        """compute_component_likelihood (likelihood.py:104-133): in-place partial update of the
+        (possibly strided) float64 view `out` [N, F]."""
+        probs = np.asarray(probs)
+        groups = np.asarray(groups)
+        n_groups = groups.shape[0]
+        if groups.shape != (n_groups, self.n_objects):
+            raise ValueError(f"groups must be [n_groups, {self.n_objects}], got {groups.shape}")
+        if probs.shape != (n_groups, self.n_features, self.n_states):
+            raise ValueError(f"probs must be {(n_groups, self.n_features, self.n_states)}, got {probs.shape}")
+        if not isinstance(out, np.ndarray) or out.dtype != np.float64 or out.shape != (self.n_objects, self.n_features):
+            raise ValueError("out must be a float64 ndarray (view) of shape [n_objects, n_features]")
+        if not out.flags.writeable:
+            raise ValueError("out is read-only")
+        f64 = probs.dtype == np.float64
+        p = _c(probs, np.float64 if f64 else np.float32)
+        g = _c(groups.astype(bool, copy=False), np.uint8)
+        ch = np.ascontiguousarray(changed_groups, dtype=np.int64).reshape(-1)
+        self._check(self._lib.sbe_component_lh(self._h, _ptr(p), int(f64), n_groups, _ptr(g), _ptr(ch), ch.size,
+                                               ct.c_void_p(out.ctypes.data), out.strides[0], out.strides[1]))
+        return out
+
+    # -- slot state -----------------------------------------------------------------------------
+    def set_groups(self, slot, component, groups):
+        g = np.asarray(groups)
+        if g.shape != (self.n_groups[component], self.n_objects):
+            raise ValueError(f"groups of component {component} must be {(self.n_groups[component], self.n_objects)}, got {g.shape}")
+        g = _c(g.astype(bool, copy=False), np.uint8)
+        self._check(self._lib.sbe_set_groups(self._h, slot, component, _ptr(g)))
+
+    def set_group_ids(self, slot, component, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        if ids.shape != (self.n_objects,):
+            raise ValueError("ids must be [n_objects]")
+        self._check(self._lib.sbe_set_group_ids(self._h, slot, component, _ptr(ids)))
+
+    def set_source(self, slot, source):
+        s = np.asarray(source)
+        if s.shape != (self.n_objects, self.n_features, self.n_components):
+            raise ValueError(f"source must be {(self.n_objects, self.n_features, self.n_components)}, got {s.shape}")
+        s = _c(s.astype(bool, copy=False), np.uint8)
+        self._check(self._lib.sbe_set_source(self._h, slot, _ptr(s)))
+
+    def set_source_rows(self, slot, objects, rows):
+        objects = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        rows = np.asarray(rows)
+        if rows.shape != (objects.size, self.n_features, self.n_components):
+            raise ValueError("rows must be [len(objects), n_features, n_components]")
+        rows = _c(rows.astype(bool, copy=False), np.uint8)
+        self._check(self._lib.sbe_set_source_rows(self._h, slot, _ptr(objects), objects.size, _ptr(rows)))
+
+    def recount(self, slot, component=-1):
+        self._check(self._lib.sbe_recount(self._h, slot, component))
+
+    def update_counts(self, slot_new, slot_old, objects):
+        """update_feature_counts (counts.py:55-95); returns bool[G_total] of changed groups."""
+        objects = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        changed = np.zeros(self.n_groups_total, dtype=np.uint8)
+        self._check(self._lib.sbe_update_counts(self._h, slot_new, slot_old, _ptr(objects), objects.size, _ptr(changed)))
+        return changed.astype(bool)
+
+    def accumulate_counts(self, slot, objects, sign):
+        objects = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        changed = np.zeros(self.n_groups_total, dtype=np.uint8)
+        self._check(self._lib.sbe_accumulate_counts(self._h, slot, _ptr(objects), objects.size, int(sign), _ptr(changed)))
+        return changed.astype(bool)
+
+    def set_counts(self, slot, component, counts):
+        c = _c(counts, np.float32)
+        if c.shape != (self.n_groups[component], self.n_features, self.n_states):
+            raise ValueError("bad counts shape")
+        self._check(self._lib.sbe_set_counts(self._h, slot, component, _ptr(c)))
+
+    def get_counts(self, slot, component):
+        out = np.empty((self.n_groups[component], self.n_features, self.n_states), dtype=np.float32)
+        self._check(self._lib.sbe_get_counts(self._h, slot, component, _ptr(out)))
+        return out
+
+    def set_concentration(self, component, conc):
+        conc = _c(conc, np.float64)
+        fs = (self.n_features, self.n_states)
+        if conc.shape == fs:
+            per_group = 0
+        elif conc.shape == (self.n_groups[component],) + fs:
+            per_group = 1
+        else:
+            raise ValueError(f"concentration of component {component} must be {fs} or [G]+{fs}, got {conc.shape}")
+        self._check(self._lib.sbe_set_concentration(self._h, component, _ptr(conc), per_group))
+
+    def update_probs(self, slot, component, temperature=None, prior_temperature=None, unif_counts=None):
+        """probs = normalize(counts [/T] + prior['] ) on the device (conditionals.py:105-122, 175-179)."""
+        t = float(temperature) if temperature is not None else 0.0
+        tp = float(prior_temperature) if prior_temperature is not None else 0.0
+        u = None
+        if prior_temperature is not None:
+            if unif_counts is None:
+                raise AssertionError("unif_counts required with prior_temperature (conditionals.py:114)")
+            u = _c(unif_counts, np.float64)
+            if u.shape != (self.n_features, self.n_states):
+                raise ValueError("unif_counts must be [n_features, n_states]")
+        self._check(self._lib.sbe_update_probs(self._h, slot, component, t, tp, _ptr(u) if u is not None else None))
+
+    def set_probs(self, slot, component, probs):
+        p = _c(probs, np.float32)
+        if p.shape != (self.n_groups[component], self.n_features, self.n_states):
+            raise ValueError("bad probs shape")
+        self._check(self._lib.sbe_set_probs(self._h, slot, component, _ptr(p)))
+
+    def get_probs(self, slot, component):
+        out = np.empty((self.n_groups[component], self.n_features, self.n_states), dtype=np.float32)
+        self._check(self._lib.sbe_get_probs(self._h, slot, component, _ptr(out)))
+        return out
+
+    def set_weights(self, slot, weights):
+        w = _c(weights, np.float32)
+        if w.shape != (self.n_features, self.n_components):
+            raise ValueError(f"weights must be {(self.n_features, self.n_components)}, got {w.shape}")
+        self._check(self._lib.sbe_set_weights(self._h, slot, _ptr(w)))
+
+    def weights_normalized(self, slot):
+        out = np.empty((self.n_objects, self.n_features, self.n_components), dtype=np.float32)
+        self._check(self._lib.sbe_get_weights_normalized(self._h, slot, _ptr(out)))
+        return out
+
+    # -- dense outputs ---------------------------------------------------------------------------
+    def likelihood_per_component(self, slot, out=None):
+        if out is None:
+            out = np.empty((self.n_objects, self.n_features, self.n_components), dtype=np.float64)
+        assert out.flags.c_contiguous and out.dtype == np.float64
+        self._check(self._lib.sbe_likelihood_per_component(self._h, slot, _ptr(out)))
+        return out
+
+    def likelihood_per_component_exact(self, slot):
+        out = np.empty((self.n_objects, self.n_features, self.n_components), dtype=np.float64)
+        self._check(self._lib.sbe_likelihood_per_component_exact(self._h, slot, _ptr(out)))
+        return out
+
+    def observation_lh(self, slot):
+        out = np.empty((self.n_objects, self.n_features), dtype=np.float64)
+        self._check(self._lib.sbe_observation_lh(self._h, slot, _ptr(out)))
+        return out
+
+    # -- north-star scalar -------------------------------------------------------------------------
+    def mixture_loglik(self, slot=0) -> float:
+        out = ct.c_double(0.0)
+        self._check(self._lib.sbe_mixture_loglik(self._h, slot, ct.byref(out)))
+        return out.value
+
+    def mixture_loglik_batch(self, first_slot, n):
+        out = np.empty(n, dtype=np.float64)
+        self._check(self._lib.sbe_mixture_loglik_batch(self._h, first_slot, n, _ptr(out)))
+        return out
+
+    def mixture_loglik_batch_async(self, first_slot, n):
+        self._check(self._lib.sbe_mixture_loglik_batch_async(self._h, first_slot, n))
+
+    def fetch_results(self, first_slot, n):
+        out = np.empty(n, dtype=np.float64)
+        self._check(self._lib.sbe_fetch_results(self._h, first_slot, n, _ptr(out)))
+        return out
+
+    def collapsed_loglik(self, slot, component, per_feature=False):
+        g = self.n_groups[component]
+        per_group = np.empty(g, dtype=np.float64)
+        pf = np.empty((g, self.n_features), dtype=np.float32) if per_feature else None
+        self._check(self._lib.sbe_collapsed_loglik(self._h, slot, component, _ptr(per_group),
+                                                   _ptr(pf) if pf is not None else None))
+        return (per_group, pf) if per_feature else per_group
+
+    def copy_slot(self, dst, src):
+        self._check(self._lib.sbe_copy_slot(self._h, dst, src))
+
+    # -- measurement ---------------------------------------------------------------------------------
+    def timer_start(self):
+        self._check(self._lib.sbe_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = ct.c_float(0.0)
+        self._check(self._lib.sbe_timer_stop(self._h, ct.byref(ms)))
+        return ms.value
+
+    def profile_mixture(self, first_slot, n, iters):
+        total, avg = ct.c_float(0.0), ct.c_float(0.0)
+        self._check(self._lib.sbe_profile_mixture(self._h, first_slot, n, iters, ct.byref(total), ct.byref(avg)))
+        return total.value, avg.value
+
+    # -- convenience: load a whole workload state into a slot ---------------------------------------
+    def load_state(self, slot, groups, weights, source=None, counts=None, probs=None, recount=True):
+        for c, g in enumerate(groups):
+            self.set_groups(slot, c, g)
+        if source is not None:
+            self.set_source(slot, source)
+        if counts is not None:
+            for c, cnt in enumerate(counts):
+                self.set_counts(slot, c, cnt)
+        elif source is not None and recount:
+            self.recount(slot)
+        if probs is not None:
+            for c, p in enumerate(probs):
+                self.set_probs(slot, c, p)
+        self.set_weights(slot, weights)
