@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X sBayes likelihood engine.
+
+Metric (BASELINE.json): log-likelihood evals/sec at 1000 sites x 200 feats x 10 states,
+1/2/4/8-GPU chains.  One "eval" = one uncached mixture log-likelihood of one sample state
+(SURVEY.md 8(d)):  LL = sum_{n,f not NA} log sum_c w[n,f,c] * p_c[g_c(n), f, x(n,f)].
+
+A "step" = one pass of the hot path over one batch: `--batch` B distinct resident sample
+states (independent chains / candidate states of the sampler, sbayes/sampling/mcmc.py:239-241)
+evaluated by one launch sequence of the fused kernel.  Everything (feature block, group ids,
+probability tables, weights) is resident in HBM before the timed region; the B scalars are
+fetched to the host inside the timed region.
+
+  python bench.py                       # 1 GPU, defaults finish in well under a minute
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: independent chains shard one engine per GPU, no data-path collective ("weak"
+scaling); torch.distributed is used only for the barrier and the
+max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line on stdout.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="headline", choices=["cfg1", "headline", "stress"])
+    ap.add_argument("--batch", type=int, default=64, help="resident sample states evaluated per step")
+    ap.add_argument("--kernel", default="packed", choices=["packed", "onehot"])
+    ap.add_argument("--log-mode", default="product", choices=["product", "per_obs"])
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--explore", action="store_true", help="print extra latency / batch-size figures to stderr")
+    return ap.parse_args()
+
+
+def setup_engine(wl, batch, device, kernel, log_mode):
+    from sbayes_amd.engine import (LOG_PER_OBS, LOG_PRODUCT, MIXTURE_ONEHOT, MIXTURE_PACKED, Engine)
+    from sbayes_amd.synthetic import make_state
+
+    eng = Engine(wl.features, [g.shape[0] for g in wl.groups], n_slots=batch, device=device)
+    eng.set_option(kernel=MIXTURE_ONEHOT if kernel == "onehot" else MIXTURE_PACKED,
+                   log_mode=LOG_PRODUCT if log_mode == "product" else LOG_PER_OBS)
+    for c in range(wl.n_components):
+        eng.set_concentration(c, wl.concentration[c])
+    states = []
+    for b in range(batch):
+        if b == 0:
+            clusters, weights, source = wl.clusters, wl.weights, wl.source
+        else:
+            clusters, weights, source = make_state(wl.features, wl.groups[1:], wl.clusters.shape[0], seed=1000 + b)
+        groups = [clusters] + wl.groups[1:]
+        eng.load_state(b, groups, weights, source=source)      # counts on the device (a9)
+        for c in range(wl.n_components):
+            eng.update_probs(b, c)                             # tables on the device (a4)
+        states.append((groups, weights, source))
+    return eng, states
+
+
+def cpu_baseline(wl, seconds):
+    """The CPU oracle (NumPy restatement of the reference path, validated against the reference's
+    golden vectors) timed single-threaded on this host.  Checker/baseline only."""
+    from oracle import sbayes_oracle as orc
+    counts = orc.recalculate_feature_counts(wl.features, wl.groups, wl.source)
+    args = (wl.features, wl.na_values, wl.groups, counts, wl.concentration, wl.weights)
+    ll = orc.mixture_loglik(*args)          # warm-up call
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.mixture_loglik(*args)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 100000:
+            break
+    return ll, n / el, n, el
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        log(f"[bench] WORLD_SIZE={world} differs from --gpus {args.gpus}; using WORLD_SIZE")
+    n_gpus = world
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        use_cuda = torch.cuda.is_available()
+        if use_cuda:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl" if use_cuda else "gloo")
+
+    from sbayes_amd.engine import device_count
+    from sbayes_amd.synthetic import algorithmic_bytes, make_workload
+
+    ndev = device_count()
+    if ndev < 1:
+        raise RuntimeError("bench.py needs a GPU: the engine has no CPU fallback")
+    device = local_rank % ndev
+
+    wl = make_workload(args.workload)
+    n_obj, n_feat, n_states = wl.shape
+    B = args.batch
+    eng, states = setup_engine(wl, B, device, args.kernel, args.log_mode)
+    info = eng.info()
+
+    # ---- parity gate reported with the timing (rank-local, cheap): slot 0 vs the oracle ------
+    parity = None
+    if rank == 0:
+        from oracle import sbayes_oracle as orc
+        counts = orc.recalculate_feature_counts(wl.features, wl.groups, wl.source)
+        want = orc.mixture_loglik(wl.features, wl.na_values, wl.groups, counts, wl.concentration, wl.weights)
+        got = eng.mixture_loglik(0)
+        parity = abs(got - want) / abs(want)
+        log(f"[bench] parity slot0: gpu {got!r} oracle {want!r} rel.err {parity:.3e}")
+        if parity > 1e-10:
+            raise RuntimeError(f"parity gate failed: rel.err {parity:.3e} > 1e-10")
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            dist.barrier()
+        eng.sync()
+
+    def step():
+        eng.mixture_loglik_batch_async(0, B)
+
+    for _ in range(args.warmup):
+        step()
+    eng.fetch_results(0, B)
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    results = eng.fetch_results(0, B)          # D2H of the B scalars + stream sync, inside the timed region
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert np.all(np.isfinite(results))
+
+    evals = args.steps * B * n_gpus
+    value = evals / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel, HIP events on the engine's stream ---------------------
+    n_pat = 2 if args.workload != "stress" else 8
+    packed = args.kernel == "packed"
+    b_eval = algorithmic_bytes(n_obj, n_feat, n_states, [g.shape[0] for g in wl.groups], n_pat, packed=packed)
+    prof_iters = min(max(args.steps, 20), 200)
+    _total_ms, kern_ms = eng.profile_mixture(0, B, prof_iters)
+    achieved = b_eval * B / (kern_ms * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "kernel": f"k_mixture<{args.log_mode},{'onehot' if not packed else 'packed'}>",
+        "kernel_avg_us": round(kern_ms * 1e3, 3),
+        "algorithmic_bytes_per_eval": b_eval, "evals_per_launch": B,
+        "representation": "packed state index (N*F bytes)" if packed else "one-hot (N*F*S bytes)",
+    }
+    traffic_file = REPO / "profiles" / "traffic_latest.json"
+    if traffic_file.exists():
+        try:
+            tr = json.loads(traffic_file.read_text())
+            key = f"{args.workload}:{args.kernel}:{B}"
+            if key in tr:
+                roofline["traffic"] = tr[key]
+        except Exception:
+            pass
+
+    extra = {}
+    if args.explore and rank == 0:
+        # single-eval latency (host-synchronous, what one chain's MH step sees) and batch sweep
+        for _ in range(20):
+            eng.mixture_loglik(0)
+        t1 = time.perf_counter()
+        n_lat = 500
+        for _ in range(n_lat):
+            eng.mixture_loglik(0)
+        lat = (time.perf_counter() - t1) / n_lat
+        extra["single_eval_sync_us"] = round(lat * 1e6, 2)
+        _t, k1 = eng.profile_mixture(0, 1, 100)
+        extra["single_eval_kernel_us"] = round(k1 * 1e3, 3)
+        for b in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+            if b > B:
+                break
+            eng.sync()
+            t1 = time.perf_counter()
+            reps = 100
+            for _ in range(reps):
+                eng.mixture_loglik_batch_async(0, b)
+            eng.fetch_results(0, b)
+            dt = time.perf_counter() - t1
+            _t, kb = eng.profile_mixture(0, b, 50)
+            log(f"[explore] batch {b:4d}: {reps * b / dt:12.0f} evals/s  step {dt / reps * 1e6:9.1f} us  "
+                f"main kernel {kb * 1e3:9.2f} us")
+        log(f"[explore] single eval: sync latency {extra['single_eval_sync_us']} us, kernel {extra['single_eval_kernel_us']} us")
+
+    cpu = None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        ll_cpu, cpu_rate, n_cpu, cpu_el = cpu_baseline(wl, args.cpu_seconds)
+        cpu = {"value": round(cpu_rate, 3), "unit": "evals/s", "cores": 1, "kind": "port",
+               "sample": f"{n_cpu} uncached mixture-LL evals of the {args.workload} workload in {cpu_el:.1f} s, "
+                         f"single-thread NumPy oracle (oracle/sbayes_oracle.py), host has {os.cpu_count()} cores"}
+
+    if rank == 0:
+        line = {
+            "metric": "log-likelihood evals/sec at 1000 sites x 200 feats x 10 states; 1/2/4/8-GPU chains",
+            "value": round(value, 2), "unit": "evals/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload} synthetic {n_obj}x{n_feat}x{n_states}, K={wl.clusters.shape[0]}, "
+                                   f"C={wl.n_components} (BASELINE.json configs[2])" if args.workload == "headline"
+                       else f"{args.workload} synthetic {n_obj}x{n_feat}x{n_states}",
+                       "evals_per_step": B, "chains_per_gpu": B, "kernel": args.kernel, "log_mode": args.log_mode,
+                       "parallelism": f"{n_gpus} independent engine(s), one per GPU, no collectives"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "parity_rel_err": parity,
+            "device": info["device_name"],
+        }
+        if cpu:
+            line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -436,7 +436,7 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, device));
     e->compute_units = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    snprintf(e->device_name, sizeof e->device_name, "%s", prop.name);
+    snprintf(e->device_name, sizeof e->device_name, "%s%s%s", prop.name, prop.name[0] ? " " : "", prop.gcnArchName);
     CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     CREATE_CHK(hipEventCreate(&e->ev0));
     CREATE_CHK(hipEventCreate(&e->ev1));
