@@ -180,6 +180,28 @@ int sbe_fetch_results(sbe_engine* e, int first_slot, int n, double* out /* [n] *
 int sbe_collapsed_loglik(sbe_engine* e, int slot, int component, double* per_group_out,
                          float* per_feature_out);
 
+/* ---- stateless forms of the reference's free functions (no slot involved) ----------------
+ * sbe_normalize_tables : normalize(counts [/T] + prior['], axis=-1) -> float32
+ *                        (sbayes/util.py:990-1007; conditionals.py:105-122, 175-179)
+ * sbe_dirichlet_logpdf : dirichlet_categorical_logpdf per (group, feature) -> float32 [G][F]
+ *                        and its float32 NumPy-order sum per group -> float64 [G]
+ *                        (sbayes/util.py:1373-1394, likelihood.py:74-77)
+ * sbe_effect_counts    : compute_effect_counts(features, group_assignment,
+ *                        source_is_component, object_subset) (counts.py:10-32);
+ *                        n_subset = -1 means all objects
+ * sbe_normalize_weights: normalize_weights(weights, has_components) (likelihood.py:171-190) */
+int sbe_normalize_tables(sbe_engine* e, const float* counts /* [G][F][S] */, int n_groups,
+                         const double* conc, int conc_per_group, double temperature,
+                         double prior_temperature, const double* unif_counts, float* out);
+int sbe_dirichlet_logpdf(sbe_engine* e, const float* counts /* [G][F][S] */, int n_groups,
+                         const double* conc, int conc_per_group, float* per_feature_out,
+                         double* per_group_out);
+int sbe_effect_counts(sbe_engine* e, const uint8_t* groups /* [G][N] bool */, int n_groups,
+                      const uint8_t* source_is_component /* [N][F] bool */, const int32_t* objects,
+                      int n_subset, float* out /* [G][F][S] */);
+int sbe_normalize_weights(sbe_engine* e, const float* weights /* [F][C] */, int n_comp,
+                          const uint8_t* has_components /* [N][C] bool */, float* out /* [N][F][C] */);
+
 /* ---- slot management -------------------------------------------------------------------- */
 int sbe_copy_slot(sbe_engine* e, int dst_slot, int src_slot);
 

@@ -1,0 +1,122 @@
+"""Drop-in for the likelihood part of sbayes/sampling/conditionals.py
+plus the fused north-star evaluation.
+
+  likelihood_per_component(model, sample, caching=True)   conditionals.py:152-223
+  likelihood_per_component_exact(model, sample)           conditionals.py:300-367
+  conditional_effect_mean(...)                            conditionals.py:105-122
+  mixture_log_likelihood(model, sample)                   SURVEY.md 8(d): the composition
+        np.log(np.sum(update_weights(s) * likelihood_per_component(model, s), -1))[~na].sum()
+        evaluated by ONE fused kernel with everything resident on the device.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .likelihood import compute_component_likelihood
+from .registry import get_engine
+
+
+def _engine(model):
+    lik = getattr(model, "likelihood", None)
+    if lik is not None and hasattr(lik, "engine"):
+        return lik.engine
+    n_groups = [model.shapes.n_clusters] + [c.n_groups for c in model.data.confounders.values()]
+    return get_engine(model.data.features.values, n_groups)
+
+
+def conditional_effect_mean(prior_counts, feature_counts, unif_counts=None, prior_temperature=None,
+                            temperature=None, features=None, engine=None):
+    """normalize(feature_counts/T + unif + (prior - unif)/T_prior) on the device.  The engine is
+    found through `features` (or given); tables are [n_groups, n_features, n_states]."""
+    eng = engine if engine is not None else get_engine(features)
+    feature_counts = np.asarray(feature_counts)
+    prior_counts = np.asarray(prior_counts, dtype=np.float64)
+    if prior_counts.shape != feature_counts.shape:
+        prior_counts = np.broadcast_to(prior_counts, feature_counts.shape)
+    if prior_temperature is not None:
+        assert unif_counts is not None
+    return eng.normalize_tables(feature_counts, prior_counts, temperature=temperature,
+                                prior_temperature=prior_temperature, unif_counts=unif_counts)
+
+
+def likelihood_per_component(model, sample, caching=True):
+    """float64 [n_objects, n_features, n_components] component likelihoods, cached in
+    sample.cache.component_likelihoods with the reference's partial-update semantics."""
+    features = model.data.features
+    confounders = model.data.confounders
+    feature_counts = sample.feature_counts
+    eng = _engine(model)
+
+    cache = sample.cache.component_likelihoods
+    if caching and not cache.is_outdated():
+        return cache.value
+
+    with cache.edit() as component_likelihood:
+        changed_clusters = cache.what_changed(input_key=["clusters", "clusters_counts"], caching=caching)
+        if len(changed_clusters) > 0:
+            cluster_effect = eng.normalize_tables(
+                feature_counts["clusters"].value, np.asarray(model.prior.prior_cluster_effect.concentration_array))
+            compute_component_likelihood(
+                features=features.values, probs=cluster_effect, groups=sample.clusters.value,
+                changed_groups=changed_clusters, out=component_likelihood[..., 0])
+
+        for i, conf in enumerate(confounders.keys(), start=1):
+            conf_prior = model.prior.prior_confounding_effects[conf]
+            hyperprior_has_changed = conf_prior.any_dynamic_priors and cache.ahead_of("universal_counts")
+            changed_groups = cache.what_changed(input_key=f"{conf}_counts",
+                                                caching=caching and not hyperprior_has_changed)
+            if len(changed_groups) == 0:
+                continue
+            conf_effect = eng.normalize_tables(feature_counts[conf].value,
+                                               np.asarray(conf_prior.concentration_array(sample)))
+            compute_component_likelihood(
+                features=features.values, probs=conf_effect, groups=confounders[conf].group_assignment,
+                changed_groups=changed_groups, out=component_likelihood[..., i])
+
+        component_likelihood[features.na_values] = 1.0
+    return cache.value
+
+
+def _bind_slot(eng, model, sample, slot, with_source=False):
+    """Upload one sample's state into an engine slot: group ids, counts, weights (small),
+    optionally the source assignment.  Probability tables are then built on the device."""
+    names = sample.component_names
+    groups = [sample.clusters.value] + [c.group_assignment for c in sample.confounders.values()]
+    conc = [np.asarray(model.prior.prior_cluster_effect.concentration_array)] + [
+        np.asarray(model.prior.prior_confounding_effects[k].concentration_array(sample)) for k in names[1:]]
+    for c, name in enumerate(names):
+        eng.set_groups(slot, c, groups[c])
+        eng.set_concentration(c, conc[c])
+        eng.set_counts(slot, c, sample.feature_counts[name].value)
+    if with_source:
+        eng.set_source(slot, sample.source.value)
+    eng.set_weights(slot, sample.weights.value)
+
+
+def likelihood_per_component_exact(model, sample, slot=0):
+    """Leave-one-out component likelihoods (used by the reference's LikelihoodLogger)."""
+    eng = _engine(model)
+    _bind_slot(eng, model, sample, slot, with_source=True)
+    return eng.likelihood_per_component_exact(slot)
+
+
+def mixture_log_likelihood(model, sample, slot=0) -> float:
+    """One uncached eval of the marginal mixture log-likelihood by the fused kernel."""
+    eng = _engine(model)
+    _bind_slot(eng, model, sample, slot)
+    for c in range(eng.n_components):
+        eng.update_probs(slot, c)
+    return eng.mixture_loglik(slot)
+
+
+def observation_likelihoods(model, sample, slot=0, exact=False):
+    """float64 [n_objects, n_features]: sum_c w * lh per observation (loggers.py:355-357)."""
+    eng = _engine(model)
+    if exact:
+        from .likelihood import update_weights
+        lh = likelihood_per_component_exact(model, sample, slot)
+        return np.sum(update_weights(sample, features=model.data.features.values) * lh, axis=2)
+    _bind_slot(eng, model, sample, slot)
+    for c in range(eng.n_components):
+        eng.update_probs(slot, c)
+    return eng.observation_lh(slot)

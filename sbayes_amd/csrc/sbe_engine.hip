@@ -38,6 +38,8 @@ struct sbe_engine {
     std::vector<hipEvent_t> ev_pool;
     int N = 0, F = 0, S = 0, C = 0, n_slots = 0;
     int Fp = 0, rs_pitch = 0, Gtot = 0, Pmax = 0;
+    int Np = 0, NQ = 0;            // objects padded to a multiple of 4; object quads
+    int ft = 64, n_ftiles = 0, Fq = 0;   // v2 fused-kernel feature tile width, tiles, padded features
     int compute_units = 256;
     std::vector<int> G, goff;
     int64_t n_na = 0;
@@ -52,6 +54,9 @@ struct sbe_engine {
     // resident data
     uint8_t* d_onehot = nullptr;   // [N][rs_pitch]
     uint8_t* d_state = nullptr;    // [N][Fp]
+    uint8_t* d_state_q = nullptr;  // [NQ][Fq][4]  object-quad interleaved (v2 fused kernel)
+    float* d_probs_t = nullptr;    // [slots][n_ftiles][Gtot+1][S][ft]
+    double* d_wpat_t = nullptr;    // [slots][n_ftiles][Pmax][C][ft]
     // slot-strided state
     uint16_t* d_gid = nullptr;     // [slots][C][N]
     uint8_t* d_pid = nullptr;      // [slots][N]
@@ -76,6 +81,10 @@ struct sbe_engine {
     std::vector<Slot> slots;
 
     int64_t table_elems() const { return (int64_t)Gtot * F * S; }
+    int64_t tile_tab_elems() const { return (int64_t)(Gtot + 1) * S * ft; }
+    int64_t probs_t_elems() const { return (int64_t)n_ftiles * tile_tab_elems(); }
+    int64_t wpat_tile_elems() const { return (int64_t)Pmax * C * ft; }
+    int64_t wpat_t_elems() const { return (int64_t)n_ftiles * wpat_tile_elems(); }
 };
 
 namespace {
@@ -199,7 +208,7 @@ int upload_patterns_and_weights(sbe_engine* e, int slot) {
         if ((int)s.patterns.size() > e->Pmax)
             return fail(e, SBE_ERR_ARG, "%zu distinct has_components patterns exceed capacity %d",
                         s.patterns.size(), e->Pmax);
-        HIPCHK(e, hipMemcpyAsync(e->d_pid + (int64_t)slot * e->N, s.h_pid.data(), e->N,
+        HIPCHK(e, hipMemcpyAsync(e->d_pid + (int64_t)slot * e->Np, s.h_pid.data(), e->N,
                                  hipMemcpyHostToDevice, e->stream));
         HIPCHK(e, hipMemcpyAsync(e->d_patbits + (int64_t)slot * e->Pmax, s.patterns.data(),
                                  s.patterns.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
@@ -212,44 +221,68 @@ int upload_patterns_and_weights(sbe_engine* e, int slot) {
             e->d_weights + (int64_t)slot * e->F * e->C, e->d_patbits + (int64_t)slot * e->Pmax,
             e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, P, e->F, e->C);
         HIPCHK(e, hipGetLastError());
+        k_tile_weights<<<div_up((int64_t)P * e->C * e->ft * e->n_ftiles, 256), 256, 0, e->stream>>>(
+            e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, e->d_wpat_t + (int64_t)slot * e->wpat_t_elems(),
+            P, e->Pmax, e->F, e->C, e->ft, e->n_ftiles);
+        HIPCHK(e, hipGetLastError());
     }
     return SBE_OK;
 }
 
-// ---- geometry of the fused kernel ----------------------------------------------------------
+// refresh the tile-transposed copy of one component's probability tables (v2 fused kernel)
+int retile_probs(sbe_engine* e, int slot, int component) {
+    const int g_lo = e->goff[component], g_hi = g_lo + e->G[component];
+    const int64_t n = (int64_t)(g_hi - g_lo) * e->S * e->ft * e->n_ftiles;
+    k_tile_probs<<<div_up(n, 256), 256, 0, e->stream>>>(
+        e->d_probs + (int64_t)slot * e->table_elems(), e->d_probs_t + (int64_t)slot * e->probs_t_elems(),
+        g_lo, g_hi, e->Gtot, e->F, e->S, e->ft, e->n_ftiles);
+    HIPCHK(e, hipGetLastError());
+    return SBE_OK;
+}
+
+// ---- geometry + launch of the fused kernel ---------------------------------------------------
 struct MixGeom {
     int ft, ft_shift, n_ftiles, objs_per_chunk, n_chunks, n_blocks;
     size_t lds_bytes;
+    bool v2;
 };
 
-MixGeom mix_geometry(const sbe_engine* e, int P, int n_batch) {
+// v1 geometry (one-hot variant and the per-observation output mode)
+MixGeom mix_geometry_v1(const sbe_engine* e, int P, int n_batch) {
     MixGeom g{};
-    // widest power-of-two feature tile whose tables fit the LDS budget; <= 64 KB keeps two
-    // blocks per CU resident, beyond that fall back to narrower tiles down to 16.
     const size_t budget = 64 * 1024, hard = 150 * 1024;
     int ft = 64;
     auto lds_for = [&](int t) { return ((size_t)e->Gtot * t * e->S + (size_t)P * t * e->C) * sizeof(float); };
     while (ft > 16 && lds_for(ft) > budget) ft >>= 1;
-    if (lds_for(ft) > hard) ft = 0;   // caller reports
+    if (lds_for(ft) > hard) ft = 0;
     g.ft = ft;
     if (!ft) return g;
     g.ft_shift = ft == 64 ? 6 : ft == 32 ? 5 : 4;
     g.n_ftiles = div_up(e->F, ft);
     g.lds_bytes = lds_for(ft);
-    // enough blocks to cover the chip ~4x over the whole batch, at least ~1 dword/16B step per thread
     const int64_t target_blocks = (int64_t)4 * e->compute_units;
     int64_t chunks = std::max<int64_t>(1, target_blocks / ((int64_t)g.n_ftiles * std::max(1, n_batch)));
-    const int min_objs = std::max(1, kBlock / (ft / 4));       // one packed step for every thread
-    int opc = std::max<int>(min_objs, div_up(e->N, chunks));
-    g.objs_per_chunk = opc;
-    g.n_chunks = div_up(e->N, opc);
+    const int min_objs = std::max(1, kBlock / (ft / 4));
+    g.objs_per_chunk = std::max<int>(min_objs, div_up(e->N, chunks));
+    g.n_chunks = div_up(e->N, g.objs_per_chunk);
     g.n_blocks = g.n_chunks * g.n_ftiles;
     return g;
 }
 
-template <int MODE, bool ONEHOT>
-void launch_mixture(const MixParams& p, dim3 grid, size_t lds, hipStream_t st) {
-    k_mixture<MODE, ONEHOT><<<grid, kBlock, lds, st>>>(p);
+// v2 geometry: chunks of object quads; one wave step = 64/ft quads
+MixGeom mix_geometry_v2(const sbe_engine* e, int P, int n_batch) {
+    MixGeom g{};
+    g.v2 = true;
+    g.ft = e->ft;
+    g.n_ftiles = e->n_ftiles;
+    g.lds_bytes = (size_t)e->tile_tab_elems() * sizeof(float) + (size_t)P * e->C * e->ft * sizeof(double);
+    const int64_t target_blocks = (int64_t)4 * e->compute_units;
+    int64_t chunks = std::max<int64_t>(1, target_blocks / ((int64_t)g.n_ftiles * std::max(1, n_batch)));
+    const int min_quads = 4 * (kWave / e->ft);            // one step for each of the 4 waves
+    g.objs_per_chunk = std::max<int>(min_quads, div_up(e->NQ, chunks));   // in quads
+    g.n_chunks = div_up(e->NQ, g.objs_per_chunk);
+    g.n_blocks = g.n_chunks * g.n_ftiles;
+    return g;
 }
 
 int max_patterns(sbe_engine* e, int first_slot, int n) {
@@ -267,54 +300,93 @@ int check_slot_ready(sbe_engine* e, int slot, bool need_weights) {
     return SBE_OK;
 }
 
-int enqueue_mixture(sbe_engine* e, int first_slot, int n, int mode, double* d_obs, MixGeom* geom_out) {
-    for (int s = first_slot; s < first_slot + n; ++s) {
-        int rc = check_slot_ready(e, s, true);
-        if (rc) return rc;
-        if (e->slots[s].patterns_dirty) { rc = upload_patterns_and_weights(e, s); if (rc) return rc; }
+template <int MODE, bool ONEHOT>
+void launch_v1(const MixParams& p, dim3 grid, size_t lds, hipStream_t st) {
+    k_mixture<MODE, ONEHOT><<<grid, kBlock, lds, st>>>(p);
+}
+
+template <int MODE, int FT>
+void launch_v2_ft(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
+    switch (C) {
+        case 1: k_mixture_v2<MODE, FT, 1><<<grid, kBlock, lds, st>>>(p); break;
+        case 2: k_mixture_v2<MODE, FT, 2><<<grid, kBlock, lds, st>>>(p); break;
+        case 3: k_mixture_v2<MODE, FT, 3><<<grid, kBlock, lds, st>>>(p); break;
+        case 4: k_mixture_v2<MODE, FT, 4><<<grid, kBlock, lds, st>>>(p); break;
+        default: k_mixture_v2<MODE, FT, 0><<<grid, kBlock, lds, st>>>(p); break;
     }
+}
+
+template <int MODE>
+void launch_v2(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
+    if (ft == 64) launch_v2_ft<MODE, 64>(C, p, grid, lds, st);
+    else if (ft == 32) launch_v2_ft<MODE, 32>(C, p, grid, lds, st);
+    else launch_v2_ft<MODE, 16>(C, p, grid, lds, st);
+}
+
+// Enqueue the dominant kernel (optionally bracketed by an event pair) and the fixed-order
+// partial reduction.  mode: LOG_PER_OBS / LOG_PRODUCT / WRITE_OBS.
+int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, double* d_obs, hipEvent_t ev_a, hipEvent_t ev_b) {
     const int P = max_patterns(e, first_slot, n);
-    MixGeom g = mix_geometry(e, P, n);
-    if (!g.ft) return fail(e, SBE_ERR_ARG, "probability tables too large for LDS staging (G_total=%d, S=%d)", e->Gtot, e->S);
-    if (g.n_blocks > e->partials_stride) return fail(e, SBE_ERR_STATE, "internal: partials buffer too small");
-    MixParams p{};
-    p.N = e->N; p.F = e->F; p.S = e->S; p.C = e->C; p.Fp = e->Fp; p.rs_pitch = e->rs_pitch;
-    p.Gtot = e->Gtot; p.P = P;
-    p.ft = g.ft; p.ft_shift = g.ft_shift; p.n_ftiles = g.n_ftiles; p.n_chunks = g.n_chunks;
-    p.objs_per_chunk = g.objs_per_chunk;
-    p.s_magic = (uint32_t)(((1u << 24) + e->S - 1) / e->S);
-    p.state = e->d_state; p.onehot = e->d_onehot;
-    p.gid = e->d_gid; p.gid_stride = (int64_t)e->C * e->N;
-    p.pid = e->d_pid; p.pid_stride = e->N;
-    p.probs = e->d_probs; p.probs_stride = e->table_elems();
-    p.wpat = e->d_wpat; p.wpat_stride = (int64_t)e->Pmax * e->F * e->C;
-    p.partials = e->d_partials; p.partials_stride = e->partials_stride;
-    p.obs = d_obs; p.first_slot = first_slot;
-    const dim3 grid(g.n_blocks, n);
     const bool onehot = e->opt_kernel == SBE_MIXTURE_ONEHOT;
-    if (mode == WRITE_OBS) {
-        launch_mixture<WRITE_OBS, false>(p, grid, g.lds_bytes, e->stream);
-    } else if (mode == LOG_PRODUCT) {
-        if (onehot) launch_mixture<LOG_PRODUCT, true>(p, grid, g.lds_bytes, e->stream);
-        else launch_mixture<LOG_PRODUCT, false>(p, grid, g.lds_bytes, e->stream);
+    const bool v2 = !onehot && mode != WRITE_OBS;
+    MixGeom g = v2 ? mix_geometry_v2(e, P, n) : mix_geometry_v1(e, P, n);
+    if (!g.ft) return fail(e, SBE_ERR_ARG, "probability tables too large for LDS staging (G_total=%d, S=%d)", e->Gtot, e->S);
+    if (g.n_blocks > e->partials_stride) return fail(e, SBE_ERR_STATE, "internal: partials buffer too small (%d > %lld)", g.n_blocks, (long long)e->partials_stride);
+    const dim3 grid(g.n_blocks, n);
+    if (ev_a) HIPCHK(e, hipEventRecord(ev_a, e->stream));
+    if (v2) {
+        Mix2Params p{};
+        p.N = e->N; p.NQ = e->NQ; p.Np = e->Np; p.F = e->F; p.Fq = e->Fq; p.S = e->S; p.C = e->C;
+        p.Gtot = e->Gtot; p.P = P; p.n_ftiles = g.n_ftiles; p.quads_per_chunk = g.objs_per_chunk;
+        p.state_q = reinterpret_cast<const uint32_t*>(e->d_state_q);
+        p.gid = e->d_gid; p.gid_stride = (int64_t)e->C * e->Np;
+        p.pid = e->d_pid; p.pid_stride = e->Np;
+        p.probs_t = e->d_probs_t; p.probs_t_stride = e->probs_t_elems();
+        p.wpat_t = e->d_wpat_t; p.wpat_t_stride = e->wpat_t_elems(); p.wpat_tile_stride = (int)e->wpat_tile_elems();
+        p.partials = e->d_partials; p.partials_stride = e->partials_stride; p.first_slot = first_slot;
+        if (mode == LOG_PRODUCT) launch_v2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
+        else launch_v2<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
     } else {
-        if (onehot) launch_mixture<LOG_PER_OBS, true>(p, grid, g.lds_bytes, e->stream);
-        else launch_mixture<LOG_PER_OBS, false>(p, grid, g.lds_bytes, e->stream);
+        MixParams p{};
+        p.N = e->N; p.Np = e->Np; p.F = e->F; p.S = e->S; p.C = e->C; p.Fp = e->Fp; p.rs_pitch = e->rs_pitch;
+        p.Gtot = e->Gtot; p.P = P;
+        p.ft = g.ft; p.ft_shift = g.ft_shift; p.n_ftiles = g.n_ftiles; p.n_chunks = g.n_chunks;
+        p.objs_per_chunk = g.objs_per_chunk;
+        p.s_magic = (uint32_t)(((1u << 24) + e->S - 1) / e->S);
+        p.state = e->d_state; p.onehot = e->d_onehot;
+        p.gid = e->d_gid; p.gid_stride = (int64_t)e->C * e->Np;
+        p.pid = e->d_pid; p.pid_stride = e->Np;
+        p.probs = e->d_probs; p.probs_stride = e->table_elems();
+        p.wpat = e->d_wpat; p.wpat_stride = (int64_t)e->Pmax * e->F * e->C;
+        p.partials = e->d_partials; p.partials_stride = e->partials_stride;
+        p.obs = d_obs; p.first_slot = first_slot;
+        if (mode == WRITE_OBS) launch_v1<WRITE_OBS, false>(p, grid, g.lds_bytes, e->stream);
+        else if (mode == LOG_PRODUCT) launch_v1<LOG_PRODUCT, true>(p, grid, g.lds_bytes, e->stream);
+        else launch_v1<LOG_PER_OBS, true>(p, grid, g.lds_bytes, e->stream);
     }
+    if (ev_b) HIPCHK(e, hipEventRecord(ev_b, e->stream));
     HIPCHK(e, hipGetLastError());
     if (mode != WRITE_OBS) {
         k_reduce_partials<<<n, kBlock, 0, e->stream>>>(e->d_partials, e->partials_stride, g.n_blocks,
                                                       e->d_results, first_slot);
         HIPCHK(e, hipGetLastError());
     }
-    if (geom_out) *geom_out = g;
     return SBE_OK;
+}
+
+int enqueue_mixture(sbe_engine* e, int first_slot, int n, int mode, double* d_obs) {
+    for (int s = first_slot; s < first_slot + n; ++s) {
+        int rc = check_slot_ready(e, s, true);
+        if (rc) return rc;
+        if (e->slots[s].patterns_dirty) { rc = upload_patterns_and_weights(e, s); if (rc) return rc; }
+    }
+    return launch_mixture(e, first_slot, n, mode, d_obs, nullptr, nullptr);
 }
 
 int counts_launch(sbe_engine* e, int slot_a, int sign_a, int slot_b, int sign_b, const int32_t* d_objects,
                   int n_listed, int dst_slot, bool single_chunk, uint8_t* d_changed) {
-    CountSide A{e->d_gid + (int64_t)slot_a * e->C * e->N, e->d_src + (int64_t)slot_a * e->N * e->Fp, sign_a};
-    CountSide B{e->d_gid + (int64_t)slot_b * e->C * e->N, e->d_src + (int64_t)slot_b * e->N * e->Fp, sign_b};
+    CountSide A{e->d_gid + (int64_t)slot_a * e->C * e->Np, e->d_src + (int64_t)slot_a * e->N * e->Fp, sign_a};
+    CountSide B{e->d_gid + (int64_t)slot_b * e->C * e->Np, e->d_src + (int64_t)slot_b * e->N * e->Fp, sign_b};
     int32_t* counts = e->d_counts + (int64_t)dst_slot * e->table_elems();
     // feature tile: as wide as fits the LDS budget
     int ft = 32;
@@ -322,7 +394,7 @@ int counts_launch(sbe_engine* e, int slot_a, int sign_a, int slot_b, int sign_b,
     while (ft > 4 && lds_for(ft) > 96 * 1024) ft >>= 1;
     if (lds_for(ft) > 150 * 1024) {
         k_counts_global<<<div_up((int64_t)n_listed * e->F, 256), 256, 0, e->stream>>>(
-            e->d_state, A, B, d_objects, n_listed, e->N, e->F, e->S, e->C, e->Fp, counts, d_changed);
+            e->d_state, A, B, d_objects, n_listed, e->Np, e->F, e->S, e->C, e->Fp, counts, d_changed);
         HIPCHK(e, hipGetLastError());
         return SBE_OK;
     }
@@ -332,7 +404,7 @@ int counts_launch(sbe_engine* e, int slot_a, int sign_a, int slot_b, int sign_b,
     const int opc = div_up(n_listed, chunks);
     chunks = div_up(n_listed, opc);
     k_counts<<<dim3(n_ftiles, chunks), kBlock, lds_for(ft), e->stream>>>(
-        e->d_state, A, B, d_objects, n_listed, opc, e->N, e->F, e->S, e->C, e->Fp, e->Gtot, ft, counts, d_changed);
+        e->d_state, A, B, d_objects, n_listed, opc, e->Np, e->F, e->S, e->C, e->Fp, e->Gtot, ft, counts, d_changed);
     HIPCHK(e, hipGetLastError());
     return SBE_OK;
 }
@@ -361,7 +433,7 @@ int sbe_destroy(sbe_engine* e) {
     if (!e) return SBE_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* dev_ptrs[] = {e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
+    void* dev_ptrs[] = {e->d_state_q, e->d_probs_t, e->d_wpat_t, e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
                         e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_unif, e->d_partials,
                         e->d_results, e->d_status, e->d_changed, e->d_scratch};
     for (void* p : dev_ptrs) if (p) (void)hipFree(p);
@@ -409,6 +481,19 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     e->Fp = round_up(n_features, 64);
     e->rs_pitch = round_up(n_features * n_states, 16);
     e->Pmax = std::min(1 << n_components, 64);
+    e->Np = round_up(n_objects, 4);
+    e->NQ = e->Np / 4;
+    {   // v2 feature-tile width: widest of 64/32/16 whose LDS image leaves two blocks per CU
+        const char* env = getenv("SBE_FT");
+        int ft = 64;
+        auto lds_for = [&](int t) { return ((size_t)(gtot + 1) * t * n_states) * sizeof(float) + (size_t)std::min(e->Pmax, 16) * n_components * t * sizeof(double); };
+        while (ft > 16 && lds_for(ft) > 78 * 1024) ft >>= 1;
+        if (env && (atoi(env) == 64 || atoi(env) == 32 || atoi(env) == 16)) ft = atoi(env);
+        if (lds_for(ft) > 156 * 1024) { delete e; return fail(nullptr, SBE_ERR_ARG, "probability tables too large for LDS staging (G_total=%lld, S=%d)", (long long)gtot, n_states); }
+        e->ft = ft;
+        e->n_ftiles = div_up(n_features, ft);
+        e->Fq = e->n_ftiles * ft;
+    }
     e->conc_set.assign(n_components, 0);
     e->slots.resize(n_slots);
     for (Slot& s : e->slots) {
@@ -444,8 +529,11 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     const int64_t N = e->N, F = e->F, S = e->S, C = e->C, NS = n_slots;
     CREATE_RC(dmalloc(e, &e->d_onehot, N * e->rs_pitch));
     CREATE_RC(dmalloc(e, &e->d_state, N * e->Fp));
-    CREATE_RC(dmalloc(e, &e->d_gid, NS * C * N));
-    CREATE_RC(dmalloc(e, &e->d_pid, NS * N));
+    CREATE_RC(dmalloc(e, &e->d_state_q, (int64_t)e->NQ * e->Fq * 4));
+    CREATE_RC(dmalloc(e, &e->d_probs_t, NS * e->probs_t_elems()));
+    CREATE_RC(dmalloc(e, &e->d_wpat_t, NS * e->wpat_t_elems()));
+    CREATE_RC(dmalloc(e, &e->d_gid, NS * C * e->Np));
+    CREATE_RC(dmalloc(e, &e->d_pid, NS * e->Np));
     CREATE_RC(dmalloc(e, &e->d_src, NS * N * e->Fp));
     CREATE_RC(dmalloc(e, &e->d_counts, NS * e->table_elems()));
     CREATE_RC(dmalloc(e, &e->d_probs, NS * e->table_elems()));
@@ -470,15 +558,18 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_CHK(hipMemsetAsync(e->d_onehot, 0, N * e->rs_pitch, e->stream));
     CREATE_CHK(hipMemsetAsync(e->d_state, 0xFF, N * e->Fp, e->stream));
     CREATE_CHK(hipMemsetAsync(e->d_src, 0xFF, NS * N * e->Fp, e->stream));
-    CREATE_CHK(hipMemsetAsync(e->d_gid, 0xFF, NS * C * N * sizeof(uint16_t), e->stream));
-    CREATE_CHK(hipMemsetAsync(e->d_pid, 0, NS * N, e->stream));
+    CREATE_CHK(hipMemsetAsync(e->d_gid, 0xFF, NS * C * e->Np * sizeof(uint16_t), e->stream));
+    CREATE_CHK(hipMemsetAsync(e->d_pid, 0, NS * e->Np, e->stream));
+    CREATE_CHK(hipMemsetAsync(e->d_state_q, 0xFF, (int64_t)e->NQ * e->Fq * 4, e->stream));
+    CREATE_CHK(hipMemsetAsync(e->d_probs_t, 0, NS * e->probs_t_elems() * sizeof(float), e->stream));
+    CREATE_CHK(hipMemsetAsync(e->d_wpat_t, 0, NS * e->wpat_t_elems() * sizeof(double), e->stream));
     CREATE_CHK(hipMemsetAsync(e->d_counts, 0, NS * e->table_elems() * sizeof(int32_t), e->stream));
 
     // ingest: raw one-hot -> normalised padded copy + packed state index + validation
     CREATE_RC(ensure_scratch(e, (size_t)(N * F * S)));
     CREATE_CHK(hipMemcpyAsync(e->d_scratch, features_onehot, (size_t)(N * F * S), hipMemcpyHostToDevice, e->stream));
-    k_ingest_onehot<<<div_up(N * F, 256), 256, 0, e->stream>>>(e->d_scratch, e->d_onehot, e->d_state, e->N,
-                                                              e->F, e->S, e->rs_pitch, e->Fp, e->d_status);
+    k_ingest_onehot<<<div_up(N * F, 256), 256, 0, e->stream>>>(e->d_scratch, e->d_onehot, e->d_state, e->d_state_q,
+                                                              e->N, e->F, e->S, e->rs_pitch, e->Fp, e->Fq, e->d_status);
     CREATE_CHK(hipGetLastError());
     CREATE_RC(read_status(e));
     if (e->h_status[ST_MULTI_STATE] != 0) {
@@ -592,7 +683,7 @@ int sbe_component_lh(sbe_engine* e, const void* probs, int probs_f64, int n_grou
 static int set_gid_common(sbe_engine* e, int slot, int component, const std::vector<uint16_t>& ids) {
     Slot& s = e->slots[slot];
     std::copy(ids.begin(), ids.end(), s.h_gid.begin() + (size_t)component * e->N);
-    HIPCHK(e, hipMemcpyAsync(e->d_gid + ((int64_t)slot * e->C + component) * e->N, ids.data(),
+    HIPCHK(e, hipMemcpyAsync(e->d_gid + ((int64_t)slot * e->C + component) * e->Np, ids.data(),
                              (size_t)e->N * sizeof(uint16_t), hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     s.patterns_dirty = true;
@@ -794,15 +885,17 @@ int sbe_update_probs(sbe_engine* e, int slot, int component, double temperature,
     int rc = clear_status_word(e, ST_BAD_NORMALIZE);
     if (rc) return rc;
     const int g_lo = e->goff[component], g_hi = g_lo + e->G[component];
-    k_probs<<<div_up((int64_t)(g_hi - g_lo) * e->F, 256), 256, 0, e->stream>>>(
+    k_probs<int32_t><<<div_up((int64_t)(g_hi - g_lo) * e->F, 256), 256, 0, e->stream>>>(
         e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc, d_unif,
-        e->d_probs + (int64_t)slot * e->table_elems(), g_lo, g_hi, e->F, e->S, temperature, prior_temperature, e->d_status);
+        e->d_probs + (int64_t)slot * e->table_elems(), g_lo, g_hi, e->F, e->S, temperature, prior_temperature, 1, e->d_status);
     HIPCHK(e, hipGetLastError());
     rc = read_status(e);
     if (rc) return rc;
     if (e->h_status[ST_BAD_NORMALIZE])
         return fail(e, SBE_ERR_DATA, "normalize: %d rows of component %d have a non-positive sum (sbayes/util.py:1006 assert)",
                     e->h_status[ST_BAD_NORMALIZE], component);
+    rc = retile_probs(e, slot, component);
+    if (rc) return rc;
     s.probs_set[component] = 1;
     return SBE_OK;
 }
@@ -813,6 +906,8 @@ int sbe_set_probs(sbe_engine* e, int slot, int component, const float* probs) {
     const int64_t n = (int64_t)e->G[component] * e->F * e->S;
     float* dst = e->d_probs + (int64_t)slot * e->table_elems() + (int64_t)e->goff[component] * e->F * e->S;
     int rc = h2d(e, dst, probs, n * sizeof(float));
+    if (rc) return rc;
+    rc = retile_probs(e, slot, component);
     if (rc) return rc;
     e->slots[slot].probs_set[component] = 1;
     return SBE_OK;
@@ -847,7 +942,7 @@ int sbe_get_weights_normalized(sbe_engine* e, int slot, float* out) {
     int rc = ensure_scratch(e, n * sizeof(float));
     if (rc) return rc;
     k_expand_weights<<<div_up(n, 256), 256, 0, e->stream>>>(e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C,
-                                                           e->d_pid + (int64_t)slot * e->N, (float*)e->d_scratch, e->N, e->F, e->C);
+                                                           e->d_pid + (int64_t)slot * e->Np, (float*)e->d_scratch, e->N, e->F, e->C);
     HIPCHK(e, hipGetLastError());
     return d2h(e, out, e->d_scratch, n * sizeof(float));
 }
@@ -862,8 +957,8 @@ int sbe_likelihood_per_component(sbe_engine* e, int slot, double* out) {
     rc = ensure_scratch(e, n * sizeof(double));
     if (rc) return rc;
     k_lh_dense<<<div_up((int64_t)e->N * e->F, 256), 256, 0, e->stream>>>(
-        e->d_state, e->d_gid + (int64_t)slot * e->C * e->N, e->d_probs + (int64_t)slot * e->table_elems(),
-        (double*)e->d_scratch, e->N, e->F, e->S, e->C, e->Fp);
+        e->d_state, e->d_gid + (int64_t)slot * e->C * e->Np, e->d_probs + (int64_t)slot * e->table_elems(),
+        (double*)e->d_scratch, e->N, e->Np, e->F, e->S, e->C, e->Fp);
     HIPCHK(e, hipGetLastError());
     return d2h(e, out, e->d_scratch, n * sizeof(double));
 }
@@ -881,8 +976,8 @@ int sbe_likelihood_per_component_exact(sbe_engine* e, int slot, double* out) {
     rc = clear_status_word(e, ST_BAD_NORMALIZE);
     if (rc) return rc;
     k_lh_exact<<<div_up((int64_t)e->N * e->F, 256), 256, 0, e->stream>>>(
-        e->d_state, e->d_src + (int64_t)slot * e->N * e->Fp, e->d_gid + (int64_t)slot * e->C * e->N,
-        e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc, (double*)e->d_scratch, e->N, e->F, e->S, e->C, e->Fp, e->d_status);
+        e->d_state, e->d_src + (int64_t)slot * e->N * e->Fp, e->d_gid + (int64_t)slot * e->C * e->Np,
+        e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc, (double*)e->d_scratch, e->N, e->Np, e->F, e->S, e->C, e->Fp, e->d_status);
     HIPCHK(e, hipGetLastError());
     rc = d2h(e, out, e->d_scratch, n * sizeof(double));
     if (rc) return rc;
@@ -898,7 +993,7 @@ int sbe_observation_lh(sbe_engine* e, int slot, double* out) {
     const int64_t n = (int64_t)e->N * e->F;
     int rc = ensure_scratch(e, n * sizeof(double));
     if (rc) return rc;
-    rc = enqueue_mixture(e, slot, 1, WRITE_OBS, (double*)e->d_scratch, nullptr);
+    rc = enqueue_mixture(e, slot, 1, WRITE_OBS, (double*)e->d_scratch);
     if (rc) return rc;
     return d2h(e, out, e->d_scratch, n * sizeof(double));
 }
@@ -908,7 +1003,7 @@ int sbe_mixture_loglik_batch_async(sbe_engine* e, int first_slot, int n) {
     CHECK_ENGINE(e); CHECK_SLOT(e, first_slot);
     if (n < 1 || first_slot + n > e->n_slots) return fail(e, SBE_ERR_ARG, "slot range [%d,%d) out of range", first_slot, first_slot + n);
     HIPCHK(e, hipSetDevice(e->device));
-    return enqueue_mixture(e, first_slot, n, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr);
+    return enqueue_mixture(e, first_slot, n, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr);
 }
 
 int sbe_fetch_results(sbe_engine* e, int first_slot, int n, double* out) {
@@ -943,8 +1038,8 @@ int sbe_collapsed_loglik(sbe_engine* e, int slot, int component, double* per_gro
     if (rc) return rc;
     float* d_pf = (float*)e->d_scratch;
     double* d_pg = (double*)(e->d_scratch + pf_bytes);
-    k_dcl<<<div_up((int64_t)G * e->F, 256), 256, 0, e->stream>>>(e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc,
-                                                              d_pf, g_lo, g_lo + G, e->F, e->S);
+    k_dcl<int32_t><<<div_up((int64_t)G * e->F, 256), 256, 0, e->stream>>>(e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc,
+                                                                       d_pf, g_lo, g_lo + G, e->F, e->S, 1);
     HIPCHK(e, hipGetLastError());
     k_group_sum_f32<<<div_up(G, 64), 64, 0, e->stream>>>(d_pf, d_pg, G, e->F);
     HIPCHK(e, hipGetLastError());
@@ -952,6 +1047,164 @@ int sbe_collapsed_loglik(sbe_engine* e, int slot, int component, double* per_gro
     if (rc) return rc;
     if (per_feature_out) return d2h(e, per_feature_out, d_pf, (size_t)G * e->F * sizeof(float));
     return SBE_OK;
+}
+
+
+// =============================================================================================
+// Stateless entry points: the reference's free functions, one call each, no slot involved.
+// They run the same kernels on scratch buffers.
+// =============================================================================================
+int sbe_normalize_tables(sbe_engine* e, const float* counts, int n_groups, const double* conc, int conc_per_group,
+                         double temperature, double prior_temperature, const double* unif_counts, float* out) {
+    CHECK_ENGINE(e); CHECK_PTR(e, counts); CHECK_PTR(e, conc); CHECK_PTR(e, out);
+    if (n_groups < 1) return fail(e, SBE_ERR_ARG, "n_groups=%d", n_groups);
+    if (prior_temperature > 0.0 && !unif_counts) return fail(e, SBE_ERR_ARG, "prior_temperature given without unif_counts (conditionals.py:114)");
+    HIPCHK(e, hipSetDevice(e->device));
+    const int64_t fs = (int64_t)e->F * e->S, n = (int64_t)n_groups * fs;
+    const size_t cb = ((size_t)n * sizeof(float) + 255) / 256 * 256;
+    const size_t ab = ((size_t)(conc_per_group ? n : fs) * sizeof(double) + 255) / 256 * 256;
+    const size_t ub = ((size_t)fs * sizeof(double) + 255) / 256 * 256;
+    int rc = ensure_scratch(e, 2 * cb + ab + ub);
+    if (rc) return rc;
+    float* d_cnt = (float*)e->d_scratch;
+    double* d_a = (double*)(e->d_scratch + cb);
+    double* d_u = (double*)(e->d_scratch + cb + ab);
+    float* d_out = (float*)(e->d_scratch + cb + ab + ub);
+    HIPCHK(e, hipMemcpyAsync(d_cnt, counts, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(d_a, conc, (size_t)(conc_per_group ? n : fs) * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    const double* d_unif = nullptr;
+    if (prior_temperature > 0.0) {
+        HIPCHK(e, hipMemcpyAsync(d_u, unif_counts, (size_t)fs * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        d_unif = d_u;
+    }
+    rc = clear_status_word(e, ST_BAD_NORMALIZE);
+    if (rc) return rc;
+    k_probs<float><<<div_up((int64_t)n_groups * e->F, 256), 256, 0, e->stream>>>(
+        d_cnt, d_a, d_unif, d_out, 0, n_groups, e->F, e->S, temperature, prior_temperature, conc_per_group ? 1 : 0, e->d_status);
+    HIPCHK(e, hipGetLastError());
+    rc = d2h(e, out, d_out, (size_t)n * sizeof(float));
+    if (rc) return rc;
+    rc = read_status(e);
+    if (rc) return rc;
+    if (e->h_status[ST_BAD_NORMALIZE])
+        return fail(e, SBE_ERR_DATA, "normalize: %d rows have a non-positive sum (sbayes/util.py:1006 assert)", e->h_status[ST_BAD_NORMALIZE]);
+    return SBE_OK;
+}
+
+int sbe_dirichlet_logpdf(sbe_engine* e, const float* counts, int n_groups, const double* conc, int conc_per_group,
+                         float* per_feature_out, double* per_group_out) {
+    CHECK_ENGINE(e); CHECK_PTR(e, counts); CHECK_PTR(e, conc);
+    if (!per_feature_out && !per_group_out) return fail(e, SBE_ERR_ARG, "no output requested");
+    if (n_groups < 1) return fail(e, SBE_ERR_ARG, "n_groups=%d", n_groups);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int64_t fs = (int64_t)e->F * e->S, n = (int64_t)n_groups * fs;
+    const size_t cb = ((size_t)n * sizeof(float) + 255) / 256 * 256;
+    const size_t ab = ((size_t)(conc_per_group ? n : fs) * sizeof(double) + 255) / 256 * 256;
+    const size_t pf = ((size_t)n_groups * e->F * sizeof(float) + 255) / 256 * 256;
+    int rc = ensure_scratch(e, cb + ab + pf + (size_t)n_groups * sizeof(double));
+    if (rc) return rc;
+    float* d_cnt = (float*)e->d_scratch;
+    double* d_a = (double*)(e->d_scratch + cb);
+    float* d_pf = (float*)(e->d_scratch + cb + ab);
+    double* d_pg = (double*)(e->d_scratch + cb + ab + pf);
+    HIPCHK(e, hipMemcpyAsync(d_cnt, counts, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(d_a, conc, (size_t)(conc_per_group ? n : fs) * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    k_dcl<float><<<div_up((int64_t)n_groups * e->F, 256), 256, 0, e->stream>>>(d_cnt, d_a, d_pf, 0, n_groups, e->F, e->S, conc_per_group ? 1 : 0);
+    HIPCHK(e, hipGetLastError());
+    if (per_group_out) {
+        k_group_sum_f32<<<div_up(n_groups, 64), 64, 0, e->stream>>>(d_pf, d_pg, n_groups, e->F);
+        HIPCHK(e, hipGetLastError());
+        rc = d2h(e, per_group_out, d_pg, (size_t)n_groups * sizeof(double));
+        if (rc) return rc;
+    }
+    if (per_feature_out) return d2h(e, per_feature_out, d_pf, (size_t)n_groups * e->F * sizeof(float));
+    return SBE_OK;
+}
+
+int sbe_effect_counts(sbe_engine* e, const uint8_t* groups, int n_groups, const uint8_t* source_is_component,
+                      const int32_t* objects, int n_subset, float* out) {
+    CHECK_ENGINE(e); CHECK_PTR(e, groups); CHECK_PTR(e, source_is_component); CHECK_PTR(e, out);
+    if (n_groups < 1) return fail(e, SBE_ERR_ARG, "n_groups=%d", n_groups);
+    if (n_subset < -1 || (n_subset > 0 && !objects)) return fail(e, SBE_ERR_ARG, "bad object subset");
+    for (int i = 0; i < n_subset; ++i)
+        if (objects[i] < 0 || objects[i] >= e->N) return fail(e, SBE_ERR_ARG, "object index %d out of range", objects[i]);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int N = e->N, F = e->F, S = e->S;
+    const int64_t n_out = (int64_t)n_groups * F * S;
+    const int n_listed = n_subset < 0 ? N : n_subset;
+    const size_t gb = ((size_t)n_groups * N + 255) / 256 * 256;
+    const size_t mb = ((size_t)N * F + 255) / 256 * 256;
+    const size_t ob = ((size_t)std::max(n_listed, 1) * sizeof(int32_t) + 255) / 256 * 256;
+    const size_t cb = ((size_t)n_out * sizeof(int32_t) + 255) / 256 * 256;
+    int rc = ensure_scratch(e, gb + mb + ob + 2 * cb);
+    if (rc) return rc;
+    uint8_t* d_groups = e->d_scratch;
+    uint8_t* d_mask = e->d_scratch + gb;
+    int32_t* d_obj = (int32_t*)(e->d_scratch + gb + mb);
+    int32_t* d_cnt = (int32_t*)(e->d_scratch + gb + mb + ob);
+    float* d_out = (float*)(e->d_scratch + gb + mb + ob + cb);
+    HIPCHK(e, hipMemcpyAsync(d_groups, groups, (size_t)n_groups * N, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(d_mask, source_is_component, (size_t)N * F, hipMemcpyHostToDevice, e->stream));
+    if (n_subset > 0) HIPCHK(e, hipMemcpyAsync(d_obj, objects, (size_t)n_subset * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemsetAsync(d_cnt, 0, (size_t)n_out * sizeof(int32_t), e->stream));
+    if (n_listed > 0) {
+        int ft = 32;
+        auto lds_for = [&](int t) { return (size_t)n_groups * t * S * sizeof(int32_t); };
+        while (ft > 1 && lds_for(ft) > 64 * 1024) ft >>= 1;
+        if (lds_for(ft) > 150 * 1024) return fail(e, SBE_ERR_ARG, "effect counts: %d groups x %d states exceed the LDS histogram", n_groups, S);
+        const int n_ftiles = div_up(F, ft);
+        int chunks = std::max(1, std::min(div_up(n_listed, 32), div_up(2 * e->compute_units, n_ftiles)));
+        const int opc = div_up(n_listed, chunks);
+        chunks = div_up(n_listed, opc);
+        k_effect_counts<<<dim3(n_ftiles, chunks), kBlock, lds_for(ft), e->stream>>>(
+            e->d_state, d_groups, d_mask, n_subset >= 0 ? d_obj : nullptr, n_listed, opc, N, F, S, e->Fp, n_groups, ft, d_cnt);
+        HIPCHK(e, hipGetLastError());
+    }
+    k_i32_to_f32<<<div_up(n_out, 256), 256, 0, e->stream>>>(d_cnt, d_out, n_out);
+    HIPCHK(e, hipGetLastError());
+    return d2h(e, out, d_out, (size_t)n_out * sizeof(float));
+}
+
+int sbe_normalize_weights(sbe_engine* e, const float* weights, int n_comp, const uint8_t* has_components, float* out) {
+    CHECK_ENGINE(e); CHECK_PTR(e, weights); CHECK_PTR(e, has_components); CHECK_PTR(e, out);
+    if (n_comp < 1 || n_comp > kMaxComponents) return fail(e, SBE_ERR_ARG, "n_comp=%d unsupported (1..%d)", n_comp, kMaxComponents);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int N = e->N, F = e->F, C = n_comp;
+    // distinct rows in np.unique(axis=0) order (lexicographic, False < True)
+    std::vector<uint32_t> bits(N);
+    for (int n = 0; n < N; ++n) {
+        uint32_t b = 0;
+        for (int c = 0; c < C; ++c) if (has_components[(size_t)n * C + c]) b |= 1u << c;
+        bits[n] = b;
+    }
+    auto key = [C](uint32_t b) { uint32_t k = 0; for (int c = 0; c < C; ++c) k |= ((b >> c) & 1u) << (C - 1 - c); return k; };
+    std::vector<uint32_t> uniq(bits);
+    std::sort(uniq.begin(), uniq.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    const int P = (int)uniq.size();
+    if (P > 255) return fail(e, SBE_ERR_ARG, "%d distinct has_components patterns", P);
+    std::vector<uint8_t> pid(N);
+    for (int n = 0; n < N; ++n) pid[n] = (uint8_t)(std::find(uniq.begin(), uniq.end(), bits[n]) - uniq.begin());
+    const size_t wb = ((size_t)F * C * sizeof(float) + 255) / 256 * 256;
+    const size_t pb = ((size_t)P * sizeof(uint32_t) + 255) / 256 * 256;
+    const size_t tb = ((size_t)P * F * C * sizeof(float) + 255) / 256 * 256;
+    const size_t ib = ((size_t)N + 255) / 256 * 256;
+    const int64_t n_out = (int64_t)N * F * C;
+    int rc = ensure_scratch(e, wb + pb + tb + ib + (size_t)n_out * sizeof(float));
+    if (rc) return rc;
+    float* d_w = (float*)e->d_scratch;
+    uint32_t* d_pb = (uint32_t*)(e->d_scratch + wb);
+    float* d_tab = (float*)(e->d_scratch + wb + pb);
+    uint8_t* d_pid = e->d_scratch + wb + pb + tb;
+    float* d_out = (float*)(e->d_scratch + wb + pb + tb + ib);
+    HIPCHK(e, hipMemcpyAsync(d_w, weights, (size_t)F * C * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(d_pb, uniq.data(), (size_t)P * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(d_pid, pid.data(), (size_t)N, hipMemcpyHostToDevice, e->stream));
+    k_weight_patterns<<<div_up((int64_t)P * F, 256), 256, 0, e->stream>>>(d_w, d_pb, d_tab, P, F, C);
+    HIPCHK(e, hipGetLastError());
+    k_expand_weights<<<div_up(n_out, 256), 256, 0, e->stream>>>(d_tab, d_pid, d_out, N, F, C);
+    HIPCHK(e, hipGetLastError());
+    return d2h(e, out, d_out, (size_t)n_out * sizeof(float));
 }
 
 // ---- slots ------------------------------------------------------------------------------------------
@@ -963,7 +1216,8 @@ int sbe_copy_slot(sbe_engine* e, int dst, int src) {
 #define D2D(ptr, elems)                                                                             \
     HIPCHK(e, hipMemcpyAsync((ptr) + (int64_t)dst * (elems), (ptr) + (int64_t)src * (elems),        \
                              (size_t)(elems) * sizeof(*(ptr)), hipMemcpyDeviceToDevice, e->stream))
-    D2D(e->d_gid, C * N); D2D(e->d_pid, N); D2D(e->d_src, N * e->Fp); D2D(e->d_counts, T); D2D(e->d_probs, T);
+    D2D(e->d_gid, C * e->Np); D2D(e->d_pid, (int64_t)e->Np); D2D(e->d_src, N * e->Fp); D2D(e->d_counts, T); D2D(e->d_probs, T);
+    D2D(e->d_probs_t, e->probs_t_elems()); D2D(e->d_wpat_t, e->wpat_t_elems());
     D2D(e->d_weights, F * C); D2D(e->d_wpat, (int64_t)e->Pmax * F * C); D2D(e->d_patbits, (int64_t)e->Pmax);
 #undef D2D
     e->slots[dst] = e->slots[src];
@@ -990,51 +1244,24 @@ int sbe_profile_mixture(sbe_engine* e, int first_slot, int n, int iters, float* 
     if (iters < 1 || iters > 100000) return fail(e, SBE_ERR_ARG, "iters=%d", iters);
     if (n < 1 || first_slot + n > e->n_slots) return fail(e, SBE_ERR_ARG, "slot range out of range");
     HIPCHK(e, hipSetDevice(e->device));
-    // event pairs around the dominant kernel only (the fused gather/log/reduce kernel); the
-    // small fixed-order partial reduction that follows is outside the pair.
+    // one event pair per launch around the dominant kernel only (the fused gather/log/reduce
+    // kernel); the small fixed-order partial reduction that follows is outside the pair.
     while ((int)e->ev_pool.size() < 2 * iters) {
         hipEvent_t ev;
         HIPCHK(e, hipEventCreate(&ev));
         e->ev_pool.push_back(ev);
     }
     const int mode = e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS;
-    // resolve lazily-built state outside the timed region
-    int rc = enqueue_mixture(e, first_slot, n, mode, nullptr, nullptr);
+    int rc = enqueue_mixture(e, first_slot, n, mode, nullptr);     // resolves lazily-built state
     if (rc) return rc;
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
     for (int it = 0; it < iters; ++it) {
-        // replicate enqueue_mixture with events around the main kernel
-        const int P = max_patterns(e, first_slot, n);
-        MixGeom g = mix_geometry(e, P, n);
-        MixParams p{};
-        p.N = e->N; p.F = e->F; p.S = e->S; p.C = e->C; p.Fp = e->Fp; p.rs_pitch = e->rs_pitch;
-        p.Gtot = e->Gtot; p.P = P; p.ft = g.ft; p.ft_shift = g.ft_shift; p.n_ftiles = g.n_ftiles;
-        p.n_chunks = g.n_chunks; p.objs_per_chunk = g.objs_per_chunk;
-        p.s_magic = (uint32_t)(((1u << 24) + e->S - 1) / e->S);
-        p.state = e->d_state; p.onehot = e->d_onehot;
-        p.gid = e->d_gid; p.gid_stride = (int64_t)e->C * e->N;
-        p.pid = e->d_pid; p.pid_stride = e->N;
-        p.probs = e->d_probs; p.probs_stride = e->table_elems();
-        p.wpat = e->d_wpat; p.wpat_stride = (int64_t)e->Pmax * e->F * e->C;
-        p.partials = e->d_partials; p.partials_stride = e->partials_stride;
-        p.obs = nullptr; p.first_slot = first_slot;
-        const dim3 grid(g.n_blocks, n);
-        const bool onehot = e->opt_kernel == SBE_MIXTURE_ONEHOT;
-        HIPCHK(e, hipEventRecord(e->ev_pool[2 * it], e->stream));
-        if (mode == LOG_PRODUCT) {
-            if (onehot) launch_mixture<LOG_PRODUCT, true>(p, grid, g.lds_bytes, e->stream);
-            else launch_mixture<LOG_PRODUCT, false>(p, grid, g.lds_bytes, e->stream);
-        } else {
-            if (onehot) launch_mixture<LOG_PER_OBS, true>(p, grid, g.lds_bytes, e->stream);
-            else launch_mixture<LOG_PER_OBS, false>(p, grid, g.lds_bytes, e->stream);
-        }
-        HIPCHK(e, hipEventRecord(e->ev_pool[2 * it + 1], e->stream));
-        k_reduce_partials<<<n, kBlock, 0, e->stream>>>(e->d_partials, e->partials_stride, g.n_blocks, e->d_results, first_slot);
+        rc = launch_mixture(e, first_slot, n, mode, nullptr, e->ev_pool[2 * it], e->ev_pool[2 * it + 1]);
+        if (rc) return rc;
     }
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
     HIPCHK(e, hipEventSynchronize(e->ev1));
-    HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipEventElapsedTime(total_ms, e->ev0, e->ev1));
     double acc = 0.0;
     for (int it = 0; it < iters; ++it) {

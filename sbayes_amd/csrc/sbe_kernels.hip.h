@@ -105,8 +105,8 @@ __device__ __forceinline__ double block_sum(double v, double* lds4) {
 // 16-byte-aligned row pitch, packed state index [N][Fp] (0xFF = NA), validation counters.
 // ------------------------------------------------------------------------------------------
 __global__ void k_ingest_onehot(const uint8_t* __restrict__ raw, uint8_t* __restrict__ onehot,
-                                uint8_t* __restrict__ state, int N, int F, int S, int rs_pitch,
-                                int Fp, int* __restrict__ status) {
+                                uint8_t* __restrict__ state, uint8_t* __restrict__ state_q, int N, int F,
+                                int S, int rs_pitch, int Fp, int Fq, int* __restrict__ status) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // observation index
     int multi = 0, na = 0;
     if (i < (int64_t)N * F) {
@@ -119,7 +119,10 @@ __global__ void k_ingest_onehot(const uint8_t* __restrict__ raw, uint8_t* __rest
             dst[s] = b;
             if (b) { x = s; ++cnt; }
         }
-        state[(int64_t)n * Fp + f] = cnt == 0 ? kNA : (uint8_t)x;
+        const uint8_t xb = cnt == 0 ? kNA : (uint8_t)x;
+        state[(int64_t)n * Fp + f] = xb;
+        // object-quad interleaved copy: dword (n/4, f) holds objects 4*(n/4) .. +3 of feature f
+        state_q[((int64_t)(n >> 2) * Fq + f) * 4 + (n & 3)] = xb;
         multi = cnt > 1;
         na = cnt == 0;
     }
@@ -170,7 +173,7 @@ struct CountSide {
 
 __global__ __launch_bounds__(kBlock) void k_counts(
     const uint8_t* __restrict__ state, CountSide A, CountSide B, const int32_t* __restrict__ objects,
-    int n_listed, int objs_per_chunk, int N, int F, int S, int C, int Fp, int Gtot, int ft,
+    int n_listed, int objs_per_chunk, int Np, int F, int S, int C, int Fp, int Gtot, int ft,
     int32_t* __restrict__ counts, uint8_t* __restrict__ changed) {
     extern __shared__ int32_t hist[];
     const int f0 = blockIdx.x * ft;
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_counts(
                 if (sd.sign == 0) continue;
                 const uint8_t c = sd.src[(int64_t)n * Fp + f];
                 if (c >= C) continue;
-                const uint16_t gg = sd.gid[(int64_t)c * N + n];
+                const uint16_t gg = sd.gid[(int64_t)c * Np + n];
                 if (gg == kNoGroup) continue;
                 atomicAdd(&hist[((int)gg * ft + fl) * S + x], sd.sign);
             }
@@ -211,9 +214,43 @@ __global__ __launch_bounds__(kBlock) void k_counts(
     }
 }
 
+// Stateless compute_effect_counts (counts.py:10-32): arbitrary bool group matrix [G][N]
+// (overlapping groups count the object in each, as the reference's per-group loop does).
+__global__ __launch_bounds__(kBlock) void k_effect_counts(
+    const uint8_t* __restrict__ state, const uint8_t* __restrict__ groups, const uint8_t* __restrict__ mask,
+    const int32_t* __restrict__ objects, int n_listed, int objs_per_chunk, int N, int F, int S, int Fp, int G,
+    int ft, int32_t* __restrict__ counts) {
+    extern __shared__ int32_t hist[];
+    const int f0 = blockIdx.x * ft;
+    const int cells = G * ft * S;
+    for (int i = threadIdx.x; i < cells; i += kBlock) hist[i] = 0;
+    __syncthreads();
+    const int fl = threadIdx.x % ft, ol = threadIdx.x / ft, olanes = kBlock / ft;
+    const int f = f0 + fl;
+    const int i0 = blockIdx.y * objs_per_chunk;
+    const int i1 = min(n_listed, i0 + objs_per_chunk);
+    if (f < F) {
+        for (int i = i0 + ol; i < i1; i += olanes) {
+            const int n = objects ? objects[i] : i;
+            const uint8_t x = state[(int64_t)n * Fp + f];
+            if (x == kNA || !mask[(int64_t)n * F + f]) continue;
+            for (int g = 0; g < G; ++g)
+                if (groups[(int64_t)g * N + n]) atomicAdd(&hist[(g * ft + fl) * S + x], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cells; i += kBlock) {
+        const int h = hist[i];
+        if (h != 0) {
+            const int g = i / (ft * S), r = i % (ft * S);
+            atomicAdd(&counts[((int64_t)g * F + f0 + r / S) * S + r % S], h);
+        }
+    }
+}
+
 // Fallback for histograms that do not fit in LDS: one global atomic per observation.
 __global__ void k_counts_global(const uint8_t* __restrict__ state, CountSide A, CountSide B,
-                                const int32_t* __restrict__ objects, int n_listed, int N, int F, int S,
+                                const int32_t* __restrict__ objects, int n_listed, int Np, int F, int S,
                                 int C, int Fp, int32_t* __restrict__ counts, uint8_t* __restrict__ changed) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n_listed * F) return;
@@ -226,11 +263,19 @@ __global__ void k_counts_global(const uint8_t* __restrict__ state, CountSide A, 
         if (sd.sign == 0) continue;
         const uint8_t c = sd.src[(int64_t)n * Fp + f];
         if (c >= C) continue;
-        const uint16_t gg = sd.gid[(int64_t)c * N + n];
+        const uint16_t gg = sd.gid[(int64_t)c * Np + n];
         if (gg == kNoGroup) continue;
         atomicAdd(&counts[((int64_t)gg * F + f) * S + x], sd.sign);
         if (changed) changed[gg] = 1;   // over-approximation (no cancellation visible here)
     }
+}
+
+// source_is_component bool [N][F] -> src id 0 / 0xFF in the [N][Fp] layout (stateless a9 call)
+__global__ void k_mask_to_src(const uint8_t* __restrict__ mask, uint8_t* __restrict__ src, int N, int F, int Fp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * F) return;
+    const int n = (int)(i / F), f = (int)(i % F);
+    src[(int64_t)n * Fp + f] = mask[i] ? 0 : kNA;
 }
 
 __global__ void k_i32_to_f32(const int32_t* __restrict__ in, float* __restrict__ out, int64_t n) {
@@ -248,10 +293,11 @@ __global__ void k_f32_to_i32(const float* __restrict__ in, int32_t* __restrict__
 //   counts are float32 in the reference (counts.py:20): counts / T is a float32 division
 //   (NumPy: float32 array / Python float), then + float64 prior -> float64.
 // ------------------------------------------------------------------------------------------
-__global__ void k_probs(const int32_t* __restrict__ counts, const double* __restrict__ conc,
+template <class TC>
+__global__ void k_probs(const TC* __restrict__ counts, const double* __restrict__ conc,
                         const double* __restrict__ unif /* [F][S] or null */, float* __restrict__ probs,
                         int g_lo, int g_hi, int F, int S, double temperature, double prior_temperature,
-                        int* __restrict__ status) {
+                        int conc_per_group, int* __restrict__ status) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n_rows = (int64_t)(g_hi - g_lo) * F;
     if (row >= n_rows) return;
@@ -263,7 +309,7 @@ __global__ void k_probs(const int32_t* __restrict__ counts, const double* __rest
     auto post = [&](int s) -> double {
         float c = (float)counts[base + s];
         if (tempered) c = c / t32;
-        double a = conc[base + s];
+        double a = conc_per_group ? conc[base + s] : conc[(int64_t)f * S + s];
         if (prior_tempered) {
             const double u = unif[(int64_t)f * S + s];
             a = u + (a - u) / prior_temperature;
@@ -330,7 +376,7 @@ __global__ void k_component_lh(const uint8_t* __restrict__ state, const TP* __re
 // slot's group ids and tables; NA <- 1 (conditionals.py:216), no group <- 0 (likelihood.py:122).
 // ------------------------------------------------------------------------------------------
 __global__ void k_lh_dense(const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid,
-                           const float* __restrict__ probs, double* __restrict__ out, int N, int F,
+                           const float* __restrict__ probs, double* __restrict__ out, int N, int Np, int F,
                            int S, int C, int Fp) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)N * F) return;
@@ -340,7 +386,7 @@ __global__ void k_lh_dense(const uint8_t* __restrict__ state, const uint16_t* __
     for (int c = 0; c < C; ++c) {
         double v = 1.0;
         if (x != kNA) {
-            const uint16_t gg = gid[(int64_t)c * N + n];
+            const uint16_t gg = gid[(int64_t)c * Np + n];
             v = gg == kNoGroup ? 0.0 : (double)probs[((int64_t)gg * F + f) * S + x];
         }
         o[c] = v;
@@ -352,7 +398,7 @@ __global__ void k_lh_dense(const uint8_t* __restrict__ state, const uint16_t* __
 //   normalize(counts[g,f,:] + prior[g,f,:] - onehot(n,f,:) * source[n,f,c])   (float32)
 __global__ void k_lh_exact(const uint8_t* __restrict__ state, const uint8_t* __restrict__ src,
                            const uint16_t* __restrict__ gid, const int32_t* __restrict__ counts,
-                           const double* __restrict__ conc, double* __restrict__ out, int N, int F,
+                           const double* __restrict__ conc, double* __restrict__ out, int N, int Np, int F,
                            int S, int C, int Fp, int* __restrict__ status) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)N * F) return;
@@ -363,7 +409,7 @@ __global__ void k_lh_exact(const uint8_t* __restrict__ state, const uint8_t* __r
     for (int c = 0; c < C; ++c) {
         double v = 1.0;
         if (x != kNA) {
-            const uint16_t gg = gid[(int64_t)c * N + n];
+            const uint16_t gg = gid[(int64_t)c * Np + n];
             if (gg == kNoGroup) v = 0.0;
             else {
                 const int64_t base = ((int64_t)gg * F + f) * S;
@@ -387,11 +433,14 @@ __global__ void k_lh_exact(const uint8_t* __restrict__ state, const uint8_t* __r
 //   float32( lgamma(sum a) - lgamma(n + sum a) + sum_{s: a>0} (lgamma(c + a) - lgamma(a)) )
 // k_group_sum_f32: one thread per group: float32 NumPy-order sum over features -> float64 cache.
 // ------------------------------------------------------------------------------------------
-__global__ void k_dcl(const int32_t* __restrict__ counts, const double* __restrict__ conc,
-                      float* __restrict__ per_feature, int g_lo, int g_hi, int F, int S) {
+template <class TC>
+__global__ void k_dcl(const TC* __restrict__ counts, const double* __restrict__ conc_in,
+                      float* __restrict__ per_feature, int g_lo, int g_hi, int F, int S, int conc_per_group) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= (int64_t)(g_hi - g_lo) * F) return;
     const int64_t base = ((int64_t)g_lo * F + row) * S;
+    // concentration either per group [G][F][S] or one [F][S] table broadcast over groups
+    const double* conc = conc_per_group ? conc_in : conc_in - base + (row % F) * (int64_t)S;
     auto cnt = [&](int s) -> float { return (float)counts[base + s]; };
     auto a = [&](int s) -> double { return conc[base + s]; };
     const float n = np_pairwise_sum<float>(cnt, S);
@@ -443,7 +492,7 @@ enum MixMode : int { LOG_PER_OBS = 0, LOG_PRODUCT = 1, WRITE_OBS = 2 };
 
 struct MixParams {
     // geometry
-    int N, F, S, C, Fp, rs_pitch, Gtot, P;
+    int N, Np, F, S, C, Fp, rs_pitch, Gtot, P;
     int ft, ft_shift;          // feature tile width (power of two, >= 16)
     int n_ftiles, n_chunks, objs_per_chunk;
     uint32_t s_magic;          // ceil(2^24 / S): j / S == (j * s_magic) >> 24 for j < 2^16
@@ -508,9 +557,23 @@ __global__ __launch_bounds__(kBlock) void k_mixture(MixParams p) {
     // ---- stage tables: rows of fw*S contiguous floats per group ---------------------------
     const float* probs = p.probs + (int64_t)slot * p.probs_stride;
     const int row_len = fw * S, row_pitch = ft * S;
-    for (int i = threadIdx.x; i < p.Gtot * row_len; i += kBlock) {
-        const int gg = i / row_len, r = i - gg * row_len;
-        tab[gg * row_pitch + r] = probs[((int64_t)gg * F + f0) * S + r];
+    {
+        const int total = p.Gtot * row_len;
+        for (int i0 = threadIdx.x; i0 < total; i0 += 8 * kBlock) {
+            float v8[8];
+            int dst8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {            // issue all loads, then all LDS stores
+                const int i = i0 + u * kBlock;
+                const int ic = i < total ? i : 0;
+                const int gg = ic / row_len, r = ic - gg * row_len;
+                dst8[u] = i < total ? gg * row_pitch + r : -1;
+                v8[u] = probs[((int64_t)gg * F + f0) * S + r];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (dst8[u] >= 0) tab[dst8[u]] = v8[u];
+        }
     }
     const float* wpat = p.wpat + (int64_t)slot * p.wpat_stride;
     const int wrow = fw * C;
@@ -554,7 +617,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture(MixParams p) {
             if (MODE != WRITE_OBS && xs == 0xFFFFFFFFu) continue;
             uint16_t g[kMaxComponents];
 #pragma unroll
-            for (int c = 0; c < kMaxComponents; ++c) g[c] = c < C ? gid[(int64_t)c * p.N + n] : kNoGroup;
+            for (int c = 0; c < kMaxComponents; ++c) g[c] = c < C ? gid[(int64_t)c * p.Np + n] : kNoGroup;
             const int pidn = pid[n];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -582,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture(MixParams p) {
             if ((d.x | d.y | d.z | d.w) == 0u) continue;
             uint16_t g[kMaxComponents];
 #pragma unroll
-            for (int c = 0; c < kMaxComponents; ++c) g[c] = c < C ? gid[(int64_t)c * p.N + n] : kNoGroup;
+            for (int c = 0; c < kMaxComponents; ++c) g[c] = c < C ? gid[(int64_t)c * p.Np + n] : kNoGroup;
             const int pidn = pid[n];
             const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
@@ -619,6 +682,179 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __rest
     for (int i = threadIdx.x; i < n_blocks; i += kBlock) v += p[i];
     const double total = block_sum(v, red4);
     if (threadIdx.x == 0) results[slot] = total;
+}
+
+
+// ==========================================================================================
+// Fused mixture log-likelihood, v2 (the default PACKED path).
+//
+// Mapping (chosen from rocprof/HIP-event measurements of v1):
+//   lane   <-> feature inside a tile of FT features (FT = 64: one wave spans the tile)
+//   dword  <-> 4 consecutive objects of that feature: the state block is kept in an
+//              object-quad-interleaved layout state_q[N/4][Fq] (uint32), so one coalesced
+//              256-byte wave load brings 4 objects x 64 features
+//   LDS    <-> tab[(g*S + x)*FT + fl]: state-major tile image => the gather's bank is fl mod 32
+//              for every x and g (conflict-free); image is a straight float4 copy of the
+//              tile-transposed global table probs_t[tile][Gtot+1][S][FT] (row Gtot = zeros:
+//              "object in no group" needs no branch).  Weights sit in LDS as float64
+//              wl[(p*C + c)*FT + fl] (conflict-free ds_read_b64, no conversion per use).
+//   ids    <-> FT = 64: the object quad is wave-uniform, group / pattern ids are 8-byte /
+//              4-byte scalar loads; FT < 64: 64/FT quads per wave, per-lane broadcast loads.
+// ==========================================================================================
+struct Mix2Params {
+    int N, NQ, Np, F, Fq, S, C, Gtot, P;
+    int n_ftiles, quads_per_chunk;
+    const uint32_t* state_q;                       // [NQ][Fq]
+    const uint16_t* gid;   int64_t gid_stride;     // per slot [C][Np]
+    const uint8_t* pid;    int64_t pid_stride;     // per slot [Np]
+    const float* probs_t;  int64_t probs_t_stride; // per slot [n_ftiles][(Gtot+1)*S*FT]
+    const double* wpat_t;  int64_t wpat_t_stride;  // per slot [n_ftiles][Pmax*C*FT]
+    int wpat_tile_stride;                          // Pmax*C*FT
+    double* partials;      int64_t partials_stride;
+    int first_slot;
+};
+
+// accumulate the product of two observation likelihoods (LOG_PRODUCT renormalises once per pair:
+// each factor is >= 2^-298 when it is a normal product of two float32-derived doubles, so
+// mant * (a*b) stays far above the fp64 underflow threshold).
+template <int MODE>
+__device__ __forceinline__ void acc_add2(LogAcc& a, double v0, double v1) {
+    if (MODE == LOG_PRODUCT) {
+        const double t = v0 * v1;
+        const uint32_t hi = (uint32_t)(__double_as_longlong(t) >> 32);
+        const uint32_t ex = (hi >> 20) & 0x7FFu;
+        if (__builtin_expect((hi >> 31) == 0 && ex != 0 && ex < 0x7FEu, 1)) {
+            const double m = a.mant * t;
+            uint64_t bits = (uint64_t)__double_as_longlong(m);
+            a.expo += (int)((bits >> 52) & 0x7FFu) - 1023;
+            bits = (bits & 0x800FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+            a.mant = __longlong_as_double((long long)bits);
+        } else {
+            a.sum += log(v0) + log(v1);      // zero / denormal / NaN / huge: exactly NumPy's log path
+        }
+    } else {
+        a.sum += log(v0);
+        a.sum += log(v1);
+    }
+}
+
+template <int MODE, int FT, int CT>     // CT: compile-time component count (1..4), 0 = runtime (<= 8)
+__global__ __launch_bounds__(kBlock) void k_mixture_v2(Mix2Params p) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ double red4[4];
+    const int slot = p.first_slot + blockIdx.y;
+    const int tile = blockIdx.x % p.n_ftiles, chunk = blockIdx.x / p.n_ftiles;
+    const int S = p.S;
+    const int C = CT ? CT : p.C;
+    constexpr int CU = CT ? CT : kMaxComponents;
+    const int tab_elems = (p.Gtot + 1) * S * FT;            // multiple of 16
+    float* tab = reinterpret_cast<float*>(lds_raw);
+    double* wl = reinterpret_cast<double*>(lds_raw + (size_t)tab_elems * sizeof(float));
+
+    // ---- stage the tile image: contiguous float4 copy, 4 loads in flight per thread ----------
+    {
+        const float4* src = reinterpret_cast<const float4*>(
+            p.probs_t + (int64_t)slot * p.probs_t_stride + (int64_t)tile * tab_elems);
+        float4* dst = reinterpret_cast<float4*>(tab);
+        const int n4 = tab_elems >> 2;
+        int i = threadIdx.x;
+        for (; i + 3 * kBlock < n4; i += 4 * kBlock) {
+            const float4 a = src[i], b = src[i + kBlock], c = src[i + 2 * kBlock], d = src[i + 3 * kBlock];
+            dst[i] = a; dst[i + kBlock] = b; dst[i + 2 * kBlock] = c; dst[i + 3 * kBlock] = d;
+        }
+        for (; i < n4; i += kBlock) dst[i] = src[i];
+        const double2* wsrc = reinterpret_cast<const double2*>(
+            p.wpat_t + (int64_t)slot * p.wpat_t_stride + (int64_t)tile * p.wpat_tile_stride);
+        double2* wdst = reinterpret_cast<double2*>(wl);
+        const int w2 = (p.P * C * FT) >> 1;
+        for (int k = threadIdx.x; k < w2; k += kBlock) wdst[k] = wsrc[k];
+    }
+    __syncthreads();
+
+    constexpr int ROWS = kWave / FT;                        // object quads per wave step
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
+    const int fl = lane % FT, sub = lane / FT;
+    const int f = tile * FT + fl;
+    const uint16_t* gid = p.gid + (int64_t)slot * p.gid_stride;
+    const uint8_t* pid = p.pid + (int64_t)slot * p.pid_stride;
+    const int q0 = chunk * p.quads_per_chunk;
+    const int q1 = min(p.NQ, q0 + p.quads_per_chunk);
+    const float* tab_l = tab + fl;
+    const double* wl_l = wl + fl;
+    const uint32_t gmax = (uint32_t)p.Gtot;
+    const uint32_t row = (uint32_t)S * FT;                  // floats per group row
+
+    LogAcc acc{0.0, 1.0, 0};
+    for (int qb = q0 + wid * ROWS; qb < q1; qb += 4 * ROWS) {
+        int q = qb + sub;
+        if (FT == kWave) q = __builtin_amdgcn_readfirstlane(q);   // wave-uniform: ids via scalar loads
+        if (q >= q1) continue;
+        const uint32_t xs = p.state_q[(int64_t)q * p.Fq + f];
+        uint64_t gq[CU];
+#pragma unroll
+        for (int c = 0; c < CU; ++c)
+            gq[c] = (CT || c < C) ? *reinterpret_cast<const uint64_t*>(gid + (int64_t)c * p.Np + 4 * q) : ~0ull;
+        const uint32_t pq = *reinterpret_cast<const uint32_t*>(pid + 4 * q);
+        if (xs == 0xFFFFFFFFu) continue;
+        double v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t x = (xs >> (8 * j)) & 0xFFu;
+            const bool valid = x != kNA;
+            const uint32_t xc = valid ? x : 0u;
+            const uint32_t pj = (pq >> (8 * j)) & 0xFFu;
+            const float* tj = tab_l + xc * FT;
+            const double* wj = wl_l + pj * (uint32_t)(C * FT);
+            double vj = 0.0;
+#pragma unroll
+            for (int c = 0; c < CU; ++c) {
+                if (CT || c < C) {
+                    uint32_t g = (uint32_t)(gq[c] >> (16 * j)) & 0xFFFFu;
+                    g = g < gmax ? g : gmax;                        // no group -> zero row
+                    const double t = wj[c * FT] * (double)tj[g * row];
+                    vj = c == 0 ? t : vj + t;                       // NumPy order, no FMA
+                }
+            }
+            v[j] = valid ? vj : 1.0;                                // NA: log 1 = 0
+        }
+        acc_add2<MODE>(acc, v[0], v[1]);
+        acc_add2<MODE>(acc, v[2], v[3]);
+    }
+    const double total = block_sum(acc_finish<MODE>(acc), red4);
+    if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + blockIdx.x] = total;
+}
+
+// canonical probs [Gtot][F][S] -> tile-transposed probs_t [n_ftiles][Gtot+1][S][FT] for the
+// groups [g_lo, g_hi).  Row Gtot and features >= F stay zero (set once at creation).
+__global__ void k_tile_probs(const float* __restrict__ probs, float* __restrict__ probs_t, int g_lo,
+                             int g_hi, int Gtot, int F, int S, int ft, int n_ftiles) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_tile = (int64_t)(g_hi - g_lo) * S * ft;
+    if (i >= per_tile * n_ftiles) return;
+    const int tile = (int)(i / per_tile);
+    int64_t r = i % per_tile;
+    const int g = g_lo + (int)(r / ((int64_t)S * ft));
+    r %= (int64_t)S * ft;
+    const int s = (int)(r / ft), fl = (int)(r % ft);
+    const int f = tile * ft + fl;
+    const float v = f < F ? probs[((int64_t)g * F + f) * S + s] : 0.0f;
+    probs_t[(((int64_t)tile * (Gtot + 1) + g) * S + s) * ft + fl] = v;
+}
+
+// wpat [P][F][C] float32 -> wpat_t [n_ftiles][Pmax][C][FT] float64 (exact widening)
+__global__ void k_tile_weights(const float* __restrict__ wpat, double* __restrict__ wpat_t, int P, int Pmax,
+                               int F, int C, int ft, int n_ftiles) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_tile = (int64_t)P * C * ft;
+    if (i >= per_tile * n_ftiles) return;
+    const int tile = (int)(i / per_tile);
+    int64_t r = i % per_tile;
+    const int pp = (int)(r / ((int64_t)C * ft));
+    r %= (int64_t)C * ft;
+    const int c = (int)(r / ft), fl = (int)(r % ft);
+    const int f = tile * ft + fl;
+    const double v = f < F ? (double)wpat[((int64_t)pp * F + f) * C + c] : 0.0;
+    wpat_t[(((int64_t)tile * Pmax + pp) * C + c) * ft + fl] = v;
 }
 
 }  // namespace sbe

@@ -286,6 +286,84 @@ class Engine:
                                                    _ptr(pf) if pf is not None else None))
         return (per_group, pf) if per_feature else per_group
 
+    # -- stateless forms of the reference's free functions -----------------------------------------
+    def normalize_tables(self, counts, concentration, temperature=None, prior_temperature=None, unif_counts=None):
+        """normalize(counts [/T] + prior['], axis=-1) -> float32 [G, F, S] (util.py:990-1007)."""
+        counts = _c(counts, np.float32)
+        fs = (self.n_features, self.n_states)
+        if counts.ndim != 3 or counts.shape[1:] != fs:
+            raise ValueError(f"counts must be [G, {fs[0]}, {fs[1]}], got {counts.shape}")
+        conc = _c(concentration, np.float64)
+        if conc.shape == fs:
+            per_group = 0
+        elif conc.shape == counts.shape:
+            per_group = 1
+        else:
+            raise ValueError(f"concentration must be {fs} or {counts.shape}, got {conc.shape}")
+        t = float(temperature) if temperature is not None else 0.0
+        tp = float(prior_temperature) if prior_temperature is not None else 0.0
+        u = None
+        if prior_temperature is not None:
+            assert unif_counts is not None
+            u = _c(np.broadcast_to(unif_counts, counts.shape)[0] if np.ndim(unif_counts) == 3 else unif_counts, np.float64)
+        out = np.empty(counts.shape, dtype=np.float32)
+        self._check(self._lib.sbe_normalize_tables(self._h, _ptr(counts), counts.shape[0], _ptr(conc), per_group, t, tp,
+                                                   _ptr(u) if u is not None else None, _ptr(out)))
+        return out
+
+    def dirichlet_logpdf(self, counts, concentration, per_group=False):
+        """dirichlet_categorical_logpdf (util.py:1373-1394) for [G, F, S] counts -> float32 [G, F]
+        (and the float32-summed float64 [G] when per_group)."""
+        counts = _c(counts, np.float32)
+        squeeze = counts.ndim == 2
+        if squeeze:
+            counts = counts[None]
+        fs = (self.n_features, self.n_states)
+        conc = _c(concentration, np.float64)
+        if conc.shape == fs:
+            pg = 0
+        elif conc.shape == counts.shape:
+            pg = 1
+        else:
+            raise ValueError(f"concentration must be {fs} or {counts.shape}, got {conc.shape}")
+        pf = np.empty(counts.shape[:2], dtype=np.float32)
+        g = np.empty(counts.shape[0], dtype=np.float64) if per_group else None
+        self._check(self._lib.sbe_dirichlet_logpdf(self._h, _ptr(counts), counts.shape[0], _ptr(conc), pg, _ptr(pf),
+                                                   _ptr(g) if g is not None else None))
+        pf = pf[0] if squeeze else pf
+        return (pf, g) if per_group else pf
+
+    def effect_counts(self, group_assignment, source_is_component, object_subset=None):
+        """compute_effect_counts (counts.py:10-32) -> float32 [G, F, S]."""
+        g = np.asarray(group_assignment)
+        if g.ndim != 2 or g.shape[1] != self.n_objects:
+            raise ValueError(f"group_assignment must be [G, {self.n_objects}], got {g.shape}")
+        g = _c(g.astype(bool, copy=False), np.uint8)
+        m = np.asarray(source_is_component)
+        if m.shape != (self.n_objects, self.n_features):
+            raise ValueError("source_is_component must be [n_objects, n_features]")
+        m = _c(m.astype(bool, copy=False), np.uint8)
+        out = np.empty((g.shape[0], self.n_features, self.n_states), dtype=np.float32)
+        if object_subset is None:
+            objs, n_sub = None, -1
+        else:
+            objs = np.ascontiguousarray(object_subset, dtype=np.int32).reshape(-1)
+            n_sub = objs.size
+        self._check(self._lib.sbe_effect_counts(self._h, _ptr(g), g.shape[0], _ptr(m),
+                                                _ptr(objs) if objs is not None and n_sub > 0 else None, n_sub, _ptr(out)))
+        return out
+
+    def normalize_weights(self, weights, has_components):
+        """normalize_weights (likelihood.py:171-190) -> float32 [N, F, C]."""
+        w = _c(weights, np.float32)
+        hc = np.asarray(has_components)
+        if w.ndim != 2 or w.shape[0] != self.n_features or hc.shape != (self.n_objects, w.shape[1]):
+            raise ValueError("weights must be [n_features, C] and has_components [n_objects, C]")
+        hc = _c(hc.astype(bool, copy=False), np.uint8)
+        out = np.empty((self.n_objects, self.n_features, w.shape[1]), dtype=np.float32)
+        self._check(self._lib.sbe_normalize_weights(self._h, _ptr(w), w.shape[1], _ptr(hc), _ptr(out)))
+        return out
+
     def copy_slot(self, dst, src):
         self._check(self._lib.sbe_copy_slot(self._h, dst, src))
 

@@ -1,0 +1,68 @@
+"""Minimal Model / Data / Prior containers with the attribute names the likelihood path reads
+(sbayes/model/model.py:24-51, prior.py:325-354, 453-455).  Used where real sBayes is not
+importable (GPU box, replay driver, tests); with real sBayes its own objects are used."""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+
+from .likelihood import Likelihood
+from .state import Confounder, Features, ModelShapes, Sample
+
+
+class ClusterEffectPrior:
+    def __init__(self, concentration_array):
+        self.concentration_array = np.asarray(concentration_array, dtype=np.float64)
+
+
+class ConfoundingEffectsPrior:
+    any_dynamic_priors = False
+
+    def __init__(self, concentration_array):
+        self._concentration_array = np.asarray(concentration_array, dtype=np.float64)
+
+    def concentration_array(self, sample=None):
+        return self._concentration_array
+
+
+class Prior:
+    def __init__(self, cluster_concentration, confounder_concentrations: dict):
+        self.prior_cluster_effect = ClusterEffectPrior(cluster_concentration)
+        self.prior_confounding_effects = {k: ConfoundingEffectsPrior(v) for k, v in confounder_concentrations.items()}
+
+
+class Data:
+    def __init__(self, features, confounders):
+        self.features = features
+        self.confounders = confounders
+
+
+class Model:
+    def __init__(self, data, n_clusters, prior):
+        self.data = data
+        self.confounders = data.confounders
+        self.n_clusters = n_clusters
+        n, f, s = data.features.values.shape
+        self.shapes = ModelShapes(
+            n_clusters=n_clusters, n_sites=n, n_features=f, n_states=s,
+            states_per_feature=data.features.states, n_confounders=len(data.confounders),
+            n_groups={k: c.n_groups for k, c in data.confounders.items()})
+        self.prior = prior
+        self.likelihood = Likelihood(data=data, shapes=self.shapes, prior=prior)
+
+
+def build(features, states_per_feature, component_names, groups, concentration, weights, source, counts=None):
+    """(model, sample) from plain arrays (fixtures / synthetic workloads).  counts=None leaves
+    zero counts: call recalculate_feature_counts(model.data.features.values, sample)."""
+    feats = Features(features, states=states_per_feature)
+    confounders = OrderedDict((name, Confounder(name, g)) for name, g in zip(component_names[1:], groups[1:]))
+    prior = Prior(concentration[0], dict(zip(component_names[1:], concentration[1:])))
+    model = Model(Data(feats, confounders), n_clusters=groups[0].shape[0], prior=prior)
+    n, f, s = feats.values.shape
+    if counts is None:
+        counts = [np.zeros((g.shape[0], f, s), dtype=np.float32) for g in groups]
+    sample = Sample.from_numpy_arrays(
+        clusters=groups[0], weights=weights, confounders=confounders, source=source,
+        feature_counts=dict(zip(component_names, counts)), model_shapes=model.shapes)
+    return model, sample

@@ -1,0 +1,64 @@
+"""install(): route real sBayes' likelihood path through the MI355X engine.
+
+Patches the names through which the reference reaches the path:
+  sbayes.model.likelihood.{Likelihood, compute_component_likelihood, update_weights, normalize_weights}
+  sbayes.model.{Likelihood, ...} re-exports, sbayes.model.model.Likelihood (model.py:7, :45)
+  sbayes.sampling.conditionals.{compute_component_likelihood, likelihood_per_component,
+                                update_weights}                      (conditionals.py:14)
+  sbayes.sampling.counts.{compute_effect_counts, recalculate_feature_counts, update_feature_counts}
+Only when sBayes is importable; raises otherwise.  uninstall() restores the originals."""
+from __future__ import annotations
+
+import importlib
+
+_SAVED = []
+
+
+def install():
+    from . import conditionals as my_cond
+    from . import counts as my_counts
+    from . import likelihood as my_lik
+    try:
+        lik = importlib.import_module("sbayes.model.likelihood")
+        model_pkg = importlib.import_module("sbayes.model")
+        model_mod = importlib.import_module("sbayes.model.model")
+        cond = importlib.import_module("sbayes.sampling.conditionals")
+        counts = importlib.import_module("sbayes.sampling.counts")
+    except ImportError as exc:
+        raise RuntimeError("sbayes_amd.patch.install(): sBayes is not importable") from exc
+
+    def swap(mod, name, new):
+        if hasattr(mod, name):
+            _SAVED.append((mod, name, getattr(mod, name)))
+            setattr(mod, name, new)
+
+    for mod in (lik, model_pkg, model_mod):
+        swap(mod, "Likelihood", my_lik.Likelihood)
+    for mod in (lik, model_pkg, cond):
+        swap(mod, "compute_component_likelihood", my_lik.compute_component_likelihood)
+        swap(mod, "update_weights", my_lik.update_weights)
+        swap(mod, "normalize_weights", my_lik.normalize_weights)
+    swap(cond, "likelihood_per_component", my_cond.likelihood_per_component)
+    for mod in (counts, lik, cond):
+        swap(mod, "compute_effect_counts", my_counts.compute_effect_counts)
+        swap(mod, "recalculate_feature_counts", my_counts.recalculate_feature_counts)
+        swap(mod, "update_feature_counts", my_counts.update_feature_counts)
+    # modules that imported the names earlier (operators, initializers, loggers, mcmc_setup)
+    for modname in ("sbayes.sampling.operators", "sbayes.sampling.initializers", "sbayes.sampling.loggers"):
+        try:
+            m = importlib.import_module(modname)
+        except ImportError:
+            continue
+        for name, new in (("likelihood_per_component", my_cond.likelihood_per_component),
+                          ("update_weights", my_lik.update_weights),
+                          ("normalize_weights", my_lik.normalize_weights),
+                          ("recalculate_feature_counts", my_counts.recalculate_feature_counts),
+                          ("update_feature_counts", my_counts.update_feature_counts),
+                          ("compute_component_likelihood", my_lik.compute_component_likelihood)):
+            swap(m, name, new)
+
+
+def uninstall():
+    while _SAVED:
+        mod, name, old = _SAVED.pop()
+        setattr(mod, name, old)

@@ -394,9 +394,83 @@ def known_answers():
     print("[golden] known_answers.json")
 
 
+# ----------------------------------------------------------------------------------------
+# boundary types (a11): a scripted edit sequence on the REFERENCE's Sample / CacheNode classes;
+# the recorded version counters, group versions and what_changed() answers pin the mirror in
+# sbayes_amd/state.py (tests/test_state_cpu.py replays the same script on it).
+# ----------------------------------------------------------------------------------------
+def state_script(sample, np_mod=np):
+    """The scripted sequence.  Works on any Sample-like object (reference or mirror)."""
+    log = []
+
+    def snap(tag, s):
+        cl, cc = s.cache.component_likelihoods, s.cache.group_likelihoods["clusters"]
+        log.append(dict(
+            tag=tag,
+            clusters_version=int(s.clusters.version), clusters_gv=[float(v) for v in s.clusters.group_versions],
+            counts_version=int(s.feature_counts["clusters"].version),
+            counts_gv=[float(v) for v in s.feature_counts["clusters"].group_versions],
+            weights_version=int(s.weights.version), source_version=int(s.source.version),
+            lh_outdated=bool(cl.is_outdated()),
+            lh_changed=[int(v) for v in cl.what_changed(["clusters", "clusters_counts"], caching=True)],
+            lh_changed_nocache=[int(v) for v in cl.what_changed(["clusters", "clusters_counts"], caching=False)],
+            grp_changed=[int(v) for v in cc.what_changed("counts", caching=True)],
+            w_outdated=bool(s.cache.weights_normalized.is_outdated()),
+            has_components_col0=[bool(v) for v in s.cache.has_components.value[:, 0]],
+            clusters_shared=bool(s.clusters.shared),
+        ))
+
+    snap("initial", sample)
+    with sample.cache.component_likelihoods.edit():
+        pass
+    with sample.cache.group_likelihoods["clusters"].edit():
+        pass
+    sample.cache.weights_normalized.update_value(sample.cache.weights_normalized.value)
+    snap("caches_up_to_date", sample)
+    free = int(np_mod.flatnonzero(~sample.clusters.value.any(axis=0))[0])
+    sample.clusters.add_object(1, free)
+    snap("add_object_cluster1", sample)
+    cand = sample.copy()
+    snap("after_copy_original", sample)
+    snap("after_copy_candidate", cand)
+    member = int(np_mod.flatnonzero(cand.clusters.value[0])[0])
+    cand.clusters.remove_object(0, member)
+    snap("candidate_remove_object_cluster0", cand)
+    snap("original_after_candidate_edit", sample)
+    diff = np_mod.zeros(cand.feature_counts["clusters"].value.shape, dtype=np_mod.float32)
+    diff[1, 2, 0] = 1.0
+    cand.feature_counts["clusters"].add_changes(diff)
+    snap("candidate_counts_add_changes_group1", cand)
+    with cand.cache.component_likelihoods.edit():
+        pass
+    snap("candidate_lh_cache_refreshed", cand)
+    cand.weights.set_value(cand.weights.value.copy())
+    snap("candidate_weights_set_value", cand)
+    with cand.source.edit() as src:
+        src[0, 0, :] = False
+    snap("candidate_source_edit", cand)
+    cand.feature_counts["clusters"].set_value(cand.feature_counts["clusters"].value.copy())
+    snap("candidate_counts_set_value", cand)
+    cand.clusters.set_items((0, member), True)
+    snap("candidate_clusters_set_items", cand)
+    cand.everything_changed()
+    snap("candidate_everything_changed", cand)
+    return log
+
+
+def state_fixture():
+    wl = make_workload("cfg1")
+    _, sample = reference_objects(wl)
+    log = state_script(sample)
+    with open(HERE / "state_versions.json", "w") as fh:
+        json.dump(log, fh, indent=1)
+    print(f"[golden] state_versions.json ({len(log)} snapshots)")
+
+
 def main():
     WORK.mkdir(parents=True, exist_ok=True)
     known_answers()
+    state_fixture()
     synthetic_fixture("cfg1", full=True)
     synthetic_fixture("headline", full=False)
     synthetic_fixture("stress", full=False)
