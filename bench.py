@@ -98,30 +98,17 @@ def cpu_baseline(wl, seconds):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from sbayes_amd import chains
+    rank, local_rank, world = chains.env_rank()
     if world != args.gpus and world > 1:
         log(f"[bench] WORLD_SIZE={world} differs from --gpus {args.gpus}; using WORLD_SIZE")
     n_gpus = world
-
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        use_cuda = torch.cuda.is_available()
-        if use_cuda:
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl" if use_cuda else "gloo")
+    dist = chains.init_process_group()
 
     from sbayes_amd.engine import device_count
     from sbayes_amd.synthetic import algorithmic_bytes, make_workload
 
-    ndev = device_count()
-    if ndev < 1:
-        raise RuntimeError("bench.py needs a GPU: the engine has no CPU fallback")
-    device = local_rank % ndev
+    device = chains.device_for(local_rank, device_count())
 
     wl = make_workload(args.workload)
     n_obj, n_feat, n_states = wl.shape
@@ -143,8 +130,7 @@ def main():
 
     def barrier():
         eng.sync()
-        if dist is not None:
-            dist.barrier()
+        chains.barrier(dist)
         eng.sync()
 
     def step():
@@ -160,12 +146,7 @@ def main():
         step()
     results = eng.fetch_results(0, B)          # D2H of the B scalars + stream sync, inside the timed region
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = chains.max_over_ranks(time.perf_counter() - t0, dist)
     assert np.all(np.isfinite(results))
 
     evals = args.steps * B * n_gpus

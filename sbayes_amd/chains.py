@@ -1,0 +1,76 @@
+"""Independent MCMC chains across GPUs: chains are replicas, one engine per
+process per GPU, no data-path collective.  torch.distributed is used only for the barrier
+and for gathering host scalars (timings, per-chain log-likelihoods) -- RCCL ("nccl") on GPUs,
+gloo on CPU.  This mirrors the reference's MC3 layout (one OS process per chain exchanging
+host scalars: sbayes/mcmc_setup.py:271-299, 386-409)."""
+from __future__ import annotations
+
+import os
+
+
+def env_rank():
+    """(rank, local_rank, world_size) from the torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def shard_chains(n_chains: int, world_size: int, rank: int):
+    """Contiguous block partition of chain ids over ranks (sizes differ by at most one)."""
+    if not 0 <= rank < world_size:
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    base, extra = divmod(n_chains, world_size)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return list(range(lo, hi))
+
+
+def device_for(local_rank: int, n_devices: int) -> int:
+    if n_devices < 1:
+        raise RuntimeError("no GPU visible: the engine has no CPU fallback")
+    return local_rank % n_devices
+
+
+def init_process_group(backend=None):
+    """Initialise torch.distributed when launched with WORLD_SIZE > 1; returns the module or None."""
+    _, local_rank, world = env_rank()
+    if world <= 1:
+        return None
+    import torch
+    import torch.distributed as dist
+    if backend is None:
+        backend = os.environ.get("SBAYES_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend)
+    return dist
+
+
+def barrier(dist):
+    if dist is not None:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, dist) -> float:
+    if dist is None:
+        return value
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_chain_values(local_ids, local_values, n_chains: int, dist):
+    """All ranks receive the per-chain host scalars (e.g. log-likelihoods for an MC3 swap
+    decision) ordered by chain id."""
+    import numpy as np
+    out = np.full(n_chains, np.nan)
+    if dist is None:
+        out[list(local_ids)] = local_values
+        return out
+    gathered = [None] * dist.get_world_size()
+    dist.all_gather_object(gathered, (list(local_ids), [float(v) for v in local_values]))
+    for ids, vals in gathered:
+        out[ids] = vals
+    return out

@@ -269,19 +269,22 @@ MixGeom mix_geometry_v1(const sbe_engine* e, int P, int n_batch) {
     return g;
 }
 
-// v2 geometry: chunks of object quads; one wave step = 64/ft quads
+// v2 geometry: chunks of object quads; one wave step = 64/ft quads.  The chunk's ids are staged
+// in LDS (8*C + 4 bytes per quad), which caps the chunk length.
 MixGeom mix_geometry_v2(const sbe_engine* e, int P, int n_batch) {
     MixGeom g{};
     g.v2 = true;
     g.ft = e->ft;
     g.n_ftiles = e->n_ftiles;
-    g.lds_bytes = (size_t)e->tile_tab_elems() * sizeof(float) + (size_t)P * e->C * e->ft * sizeof(double);
     const int64_t target_blocks = (int64_t)4 * e->compute_units;
     int64_t chunks = std::max<int64_t>(1, target_blocks / ((int64_t)g.n_ftiles * std::max(1, n_batch)));
     const int min_quads = 4 * (kWave / e->ft);            // one step for each of the 4 waves
-    g.objs_per_chunk = std::max<int>(min_quads, div_up(e->NQ, chunks));   // in quads
+    const int max_quads = std::max(min_quads, (8 * 1024) / (8 * e->C + 4));
+    g.objs_per_chunk = std::min<int>(max_quads, std::max<int>(min_quads, div_up(e->NQ, chunks)));   // in quads
     g.n_chunks = div_up(e->NQ, g.objs_per_chunk);
     g.n_blocks = g.n_chunks * g.n_ftiles;
+    g.lds_bytes = (size_t)e->tile_tab_elems() * sizeof(float) + (size_t)P * e->C * e->ft * sizeof(double) +
+                  (size_t)g.objs_per_chunk * (8 * e->C + 4);
     return g;
 }
 

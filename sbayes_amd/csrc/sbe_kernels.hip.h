@@ -714,28 +714,30 @@ struct Mix2Params {
     int first_slot;
 };
 
-// accumulate the product of two observation likelihoods (LOG_PRODUCT renormalises once per pair:
-// each factor is >= 2^-298 when it is a normal product of two float32-derived doubles, so
-// mant * (a*b) stays far above the fp64 underflow threshold).
-template <int MODE>
-__device__ __forceinline__ void acc_add2(LogAcc& a, double v0, double v1) {
-    if (MODE == LOG_PRODUCT) {
-        const double t = v0 * v1;
-        const uint32_t hi = (uint32_t)(__double_as_longlong(t) >> 32);
-        const uint32_t ex = (hi >> 20) & 0x7FFu;
-        if (__builtin_expect((hi >> 31) == 0 && ex != 0 && ex < 0x7FEu, 1)) {
-            const double m = a.mant * t;
-            uint64_t bits = (uint64_t)__double_as_longlong(m);
-            a.expo += (int)((bits >> 52) & 0x7FFu) - 1023;
-            bits = (bits & 0x800FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
-            a.mant = __longlong_as_double((long long)bits);
-        } else {
-            a.sum += log(v0) + log(v1);      // zero / denormal / NaN / huge: exactly NumPy's log path
-        }
-    } else {
-        a.sum += log(v0);
-        a.sum += log(v1);
-    }
+// LOG_PRODUCT, branch-free form used by the v2 kernel: the four observation likelihoods of a
+// step are multiplied into the running mantissa and the binary exponent is stripped once per
+// step.  Anything that is not a positive normal double (an observed state with probability 0,
+// NaN / inf tables, or an underflowing product of pathologically small factors) leaves exponent
+// bits 0 or 0x7FF or a set sign bit in the product; that raises `bad`, and the thread then
+// recomputes its whole contribution with the per-observation log (exactly NumPy's path), so the
+// fast path never has to be right for such inputs.
+struct ProdAcc {
+    double mant;     // in [1, 2) while good
+    int expo;        // sum of stripped biased exponents
+    int steps;       // number of strips (bias correction 1023 * steps)
+    uint32_t bad;    // sticky
+};
+
+__device__ __forceinline__ void prod_add4(ProdAcc& a, double v0, double v1, double v2, double v3) {
+    const double m = a.mant * ((v0 * v1) * (v2 * v3));
+    const uint32_t hi = (uint32_t)(__double_as_longlong(m) >> 32);
+    const uint32_t ex = (hi >> 20) & 0xFFFu;                 // sign + exponent field
+    // good: positive, finite, and >= 2^-1019 so that (factors <= 2) neither the 4-product nor
+    // its two pair products were subnormal (no silent precision loss)
+    a.bad |= (ex - 4u) >= 0x7FBu;
+    a.expo += (int)ex;
+    const uint32_t hi2 = (hi & 0x000FFFFFu) | 0x3FF00000u;
+    a.mant = __hiloint2double((int)hi2, __double2loint(m));
 }
 
 template <int MODE, int FT, int CT>     // CT: compile-time component count (1..4), 0 = runtime (<= 8)
@@ -775,28 +777,59 @@ __global__ __launch_bounds__(kBlock) void k_mixture_v2(Mix2Params p) {
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
     const int fl = lane % FT, sub = lane / FT;
     const int f = tile * FT + fl;
-    const uint16_t* gid = p.gid + (int64_t)slot * p.gid_stride;
-    const uint8_t* pid = p.pid + (int64_t)slot * p.pid_stride;
     const int q0 = chunk * p.quads_per_chunk;
     const int q1 = min(p.NQ, q0 + p.quads_per_chunk);
+    const int nq = q1 - q0;                                 // >= 1
     const float* tab_l = tab + fl;
     const double* wl_l = wl + fl;
     const uint32_t gmax = (uint32_t)p.Gtot;
     const uint32_t row = (uint32_t)S * FT;                  // floats per group row
 
-    LogAcc acc{0.0, 1.0, 0};
-    for (int qb = q0 + wid * ROWS; qb < q1; qb += 4 * ROWS) {
-        int q = qb + sub;
-        if (FT == kWave) q = __builtin_amdgcn_readfirstlane(q);   // wave-uniform: ids via scalar loads
-        if (q >= q1) continue;
-        const uint32_t xs = p.state_q[(int64_t)q * p.Fq + f];
+    // ---- stage the chunk's ids: group ids (4 x u16 per quad and component) and pattern ids ----
+    // (LDS reads are in-order on lgkmcnt and ~64 cycles; scalar loads would serialise behind
+    //  every LDS wait, per-lane global loads would triple the VMEM instructions)
+    uint64_t* ids_g = reinterpret_cast<uint64_t*>(wl + (size_t)p.P * C * FT);      // [C][quads_per_chunk]
+    uint32_t* ids_p = reinterpret_cast<uint32_t*>(ids_g + (size_t)C * p.quads_per_chunk);
+    {
+        const uint16_t* gid = p.gid + (int64_t)slot * p.gid_stride;
+        const uint8_t* pid = p.pid + (int64_t)slot * p.pid_stride;
+        for (int i = threadIdx.x; i < nq * C; i += kBlock) {
+            const int c = i / nq, qi = i - c * nq;
+            ids_g[c * p.quads_per_chunk + qi] =
+                *reinterpret_cast<const uint64_t*>(gid + (int64_t)c * p.Np + 4 * (q0 + qi));
+        }
+        for (int i = threadIdx.x; i < nq; i += kBlock)
+            ids_p[i] = *reinterpret_cast<const uint32_t*>(pid + 4 * (q0 + i));
+    }
+    __syncthreads();
+
+    const int n_steps = (nq + 4 * ROWS - 1) / (4 * ROWS);   // same for every wave: uniform loop
+    const uint32_t* sq = p.state_q + (int64_t)q0 * p.Fq + f;
+
+    auto local_quad = [&](int k) { return (k * 4 + wid) * ROWS + sub; };
+    auto load_state = [&](int k) -> uint32_t {
+        const int i = local_quad(k);
+        const uint32_t xs = sq[(int64_t)min(i, nq - 1) * p.Fq];        // always in bounds
+        return i < nq ? xs : 0xFFFFFFFFu;                             // past the chunk: 4 x NA
+    };
+    // the four observation likelihoods of step k (NA -> exactly 1.0)
+    auto step_values = [&](int k, uint32_t xs, double (&v)[4]) {
+        const int qi = min(local_quad(k), nq - 1);
         uint64_t gq[CU];
+        uint32_t pq = ids_p[qi];
 #pragma unroll
-        for (int c = 0; c < CU; ++c)
-            gq[c] = (CT || c < C) ? *reinterpret_cast<const uint64_t*>(gid + (int64_t)c * p.Np + 4 * q) : ~0ull;
-        const uint32_t pq = *reinterpret_cast<const uint32_t*>(pid + 4 * q);
-        if (xs == 0xFFFFFFFFu) continue;
-        double v[4];
+        for (int c = 0; c < CU; ++c) gq[c] = (CT || c < C) ? ids_g[c * p.quads_per_chunk + qi] : ~0ull;
+        if (FT == kWave) {                                   // wave-uniform quad: ids to SGPRs
+            pq = __builtin_amdgcn_readfirstlane(pq);
+#pragma unroll
+            for (int c = 0; c < CU; ++c) {
+                if (CT || c < C) {
+                    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)gq[c]);
+                    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(gq[c] >> 32));
+                    gq[c] = ((uint64_t)hi << 32) | lo;
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t x = (xs >> (8 * j)) & 0xFFu;
@@ -817,10 +850,43 @@ __global__ __launch_bounds__(kBlock) void k_mixture_v2(Mix2Params p) {
             }
             v[j] = valid ? vj : 1.0;                                // NA: log 1 = 0
         }
-        acc_add2<MODE>(acc, v[0], v[1]);
-        acc_add2<MODE>(acc, v[2], v[3]);
+    };
+
+    double thread_ll;
+    if (MODE == LOG_PRODUCT) {
+        ProdAcc pa{1.0, 0, 0, 0u};
+        uint32_t xs_next = load_state(0);
+        for (int k = 0; k < n_steps; ++k) {
+            const uint32_t xs = xs_next;
+            xs_next = load_state(k + 1);                     // in flight while this step computes
+            double v[4];
+            step_values(k, xs, v);
+            prod_add4(pa, v[0], v[1], v[2], v[3]);
+        }
+        pa.steps = n_steps;
+        thread_ll = log(pa.mant) + (double)(pa.expo - 1023 * pa.steps) * 0.693147180559945309417232;
+        if (__builtin_expect(pa.bad != 0u, 0)) {             // rare: redo this thread per observation
+            double sum = 0.0;
+            for (int k = 0; k < n_steps; ++k) {
+                double v[4];
+                step_values(k, load_state(k), v);
+                sum += log(v[0]); sum += log(v[1]); sum += log(v[2]); sum += log(v[3]);
+            }
+            thread_ll = sum;
+        }
+    } else {
+        double sum = 0.0;
+        uint32_t xs_next = load_state(0);
+        for (int k = 0; k < n_steps; ++k) {
+            const uint32_t xs = xs_next;
+            xs_next = load_state(k + 1);
+            double v[4];
+            step_values(k, xs, v);
+            sum += log(v[0]); sum += log(v[1]); sum += log(v[2]); sum += log(v[3]);
+        }
+        thread_ll = sum;
     }
-    const double total = block_sum(acc_finish<MODE>(acc), red4);
+    const double total = block_sum(thread_ll, red4);
     if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + blockIdx.x] = total;
 }
 
