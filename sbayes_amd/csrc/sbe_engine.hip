@@ -71,8 +71,8 @@ struct sbe_engine {
     std::vector<uint8_t> conc_set;
     // scratch
     double* d_partials = nullptr;  int64_t partials_stride = 0;   // [slots][max_blocks]
-    double* d_results = nullptr;   // [slots]
-    double* h_results = nullptr;   // pinned [slots]
+    double* d_results = nullptr;   // [slots] device view of h_results (host-mapped)
+    double* h_results = nullptr;   // pinned + mapped [slots]: k_reduce_partials writes straight to the host
     int* d_status = nullptr;       // [ST_WORDS]
     int* h_status = nullptr;       // pinned
     uint8_t* d_changed = nullptr;  // [Gtot]
@@ -438,7 +438,7 @@ int sbe_destroy(sbe_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     void* dev_ptrs[] = {e->d_state_q, e->d_probs_t, e->d_wpat_t, e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
                         e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_unif, e->d_partials,
-                        e->d_results, e->d_status, e->d_changed, e->d_scratch};
+                        e->d_status, e->d_changed, e->d_scratch};
     for (void* p : dev_ptrs) if (p) (void)hipFree(p);
     if (e->h_results) (void)hipHostFree(e->h_results);
     if (e->h_status) (void)hipHostFree(e->h_status);
@@ -551,10 +551,10 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
         e->partials_stride = std::max<int64_t>(div_up(F, 16) * std::max<int64_t>(div_up(N, min_objs), 4 * e->compute_units), 1024);
     }
     CREATE_RC(dmalloc(e, &e->d_partials, NS * e->partials_stride));
-    CREATE_RC(dmalloc(e, &e->d_results, NS));
     CREATE_RC(dmalloc(e, &e->d_status, (int64_t)ST_WORDS));
     CREATE_RC(dmalloc(e, &e->d_changed, (int64_t)e->Gtot));
-    CREATE_CHK(hipHostMalloc((void**)&e->h_results, NS * sizeof(double), hipHostMallocDefault));
+    CREATE_CHK(hipHostMalloc((void**)&e->h_results, NS * sizeof(double), hipHostMallocMapped));
+    CREATE_CHK(hipHostGetDevicePointer((void**)&e->d_results, e->h_results, 0));
     CREATE_CHK(hipHostMalloc((void**)&e->h_status, ST_WORDS * sizeof(int), hipHostMallocDefault));
 
     CREATE_CHK(hipMemsetAsync(e->d_status, 0, ST_WORDS * sizeof(int), e->stream));
@@ -1012,9 +1012,7 @@ int sbe_mixture_loglik_batch_async(sbe_engine* e, int first_slot, int n) {
 int sbe_fetch_results(sbe_engine* e, int first_slot, int n, double* out) {
     CHECK_ENGINE(e); CHECK_SLOT(e, first_slot); CHECK_PTR(e, out);
     if (n < 1 || first_slot + n > e->n_slots) return fail(e, SBE_ERR_ARG, "slot range out of range");
-    HIPCHK(e, hipMemcpyAsync(e->h_results + first_slot, e->d_results + first_slot, (size_t)n * sizeof(double),
-                             hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));     // results were written straight into mapped host memory
     memcpy(out, e->h_results + first_slot, (size_t)n * sizeof(double));
     return SBE_OK;
 }
