@@ -1,0 +1,38 @@
+"""patch.install() swaps the engine-backed functions into a real sBayes by module-level name
+(SURVEY.md 8(b)).  Needs the reference importable, so it runs only in the build container
+(skipped on the GPU box, where /root/reference does not exist)."""
+import os
+import sys
+
+import pytest
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference sBayes not present")
+
+
+def test_install_and_uninstall_swap_names():
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import _ref_stubs
+    _ref_stubs.install()
+    import sbayes.model.likelihood as ref_lik
+    import sbayes.model.model as ref_model
+    import sbayes.sampling.conditionals as ref_cond
+    import sbayes.sampling.counts as ref_counts
+    import sbayes.sampling.operators as ref_ops
+
+    from sbayes_amd import conditionals, counts, likelihood, patch
+    orig = (ref_model.Likelihood, ref_cond.compute_component_likelihood, ref_cond.likelihood_per_component,
+            ref_counts.update_feature_counts, ref_ops.update_weights)
+    patch.install()
+    try:
+        assert ref_model.Likelihood is likelihood.Likelihood
+        assert ref_lik.Likelihood is likelihood.Likelihood
+        assert ref_cond.compute_component_likelihood is likelihood.compute_component_likelihood
+        assert ref_cond.likelihood_per_component is conditionals.likelihood_per_component
+        assert ref_counts.update_feature_counts is counts.update_feature_counts
+        assert ref_ops.update_weights is likelihood.update_weights
+        assert ref_ops.likelihood_per_component is conditionals.likelihood_per_component
+    finally:
+        patch.uninstall()
+    assert (ref_model.Likelihood, ref_cond.compute_component_likelihood, ref_cond.likelihood_per_component,
+            ref_counts.update_feature_counts, ref_ops.update_weights) == orig
