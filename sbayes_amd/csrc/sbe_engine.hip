@@ -319,6 +319,24 @@ void launch_v2_ft(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t
     }
 }
 
+template <int MODE, int FT>
+void launch_oh2_ft(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
+    switch (C) {
+        case 1: k_mixture_onehot_v2<MODE, FT, 1><<<grid, kBlock, lds, st>>>(p); break;
+        case 2: k_mixture_onehot_v2<MODE, FT, 2><<<grid, kBlock, lds, st>>>(p); break;
+        case 3: k_mixture_onehot_v2<MODE, FT, 3><<<grid, kBlock, lds, st>>>(p); break;
+        case 4: k_mixture_onehot_v2<MODE, FT, 4><<<grid, kBlock, lds, st>>>(p); break;
+        default: k_mixture_onehot_v2<MODE, FT, 0><<<grid, kBlock, lds, st>>>(p); break;
+    }
+}
+
+template <int MODE>
+void launch_oh2(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
+    if (ft == 64) launch_oh2_ft<MODE, 64>(C, p, grid, lds, st);
+    else if (ft == 32) launch_oh2_ft<MODE, 32>(C, p, grid, lds, st);
+    else launch_oh2_ft<MODE, 16>(C, p, grid, lds, st);
+}
+
 template <int MODE>
 void launch_v2(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
     if (ft == 64) launch_v2_ft<MODE, 64>(C, p, grid, lds, st);
@@ -331,10 +349,13 @@ void launch_v2(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStr
 int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, double* d_obs, hipEvent_t ev_a, hipEvent_t ev_b) {
     const int P = max_patterns(e, first_slot, n);
     const bool onehot = e->opt_kernel == SBE_MIXTURE_ONEHOT;
-    const bool v2 = !onehot && mode != WRITE_OBS;
+    const bool v2 = mode != WRITE_OBS;
     MixGeom g = v2 ? mix_geometry_v2(e, P, n) : mix_geometry_v1(e, P, n);
     if (!g.ft) return fail(e, SBE_ERR_ARG, "probability tables too large for LDS staging (G_total=%d, S=%d)", e->Gtot, e->S);
     if (g.n_blocks > e->partials_stride) return fail(e, SBE_ERR_STATE, "internal: partials buffer too small (%d > %lld)", g.n_blocks, (long long)e->partials_stride);
+    if (g.lds_bytes > 159 * 1024)
+        return fail(e, SBE_ERR_ARG, "probability / weight tables too large for LDS staging at tile width %d (%zu bytes; G_total=%d, S=%d, P=%d)",
+                    g.ft, g.lds_bytes, e->Gtot, e->S, P);
     const dim3 grid(g.n_blocks, n);
     if (ev_a) HIPCHK(e, hipEventRecord(ev_a, e->stream));
     if (v2) {
@@ -342,12 +363,16 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, double* d_obs
         p.N = e->N; p.NQ = e->NQ; p.Np = e->Np; p.F = e->F; p.Fq = e->Fq; p.S = e->S; p.C = e->C;
         p.Gtot = e->Gtot; p.P = P; p.n_ftiles = g.n_ftiles; p.quads_per_chunk = g.objs_per_chunk;
         p.state_q = reinterpret_cast<const uint32_t*>(e->d_state_q);
+        p.onehot = e->d_onehot; p.rs_pitch = e->rs_pitch;
         p.gid = e->d_gid; p.gid_stride = (int64_t)e->C * e->Np;
         p.pid = e->d_pid; p.pid_stride = e->Np;
         p.probs_t = e->d_probs_t; p.probs_t_stride = e->probs_t_elems();
         p.wpat_t = e->d_wpat_t; p.wpat_t_stride = e->wpat_t_elems(); p.wpat_tile_stride = (int)e->wpat_tile_elems();
         p.partials = e->d_partials; p.partials_stride = e->partials_stride; p.first_slot = first_slot;
-        if (mode == LOG_PRODUCT) launch_v2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
+        if (onehot) {
+            if (mode == LOG_PRODUCT) launch_oh2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
+            else launch_oh2<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
+        } else if (mode == LOG_PRODUCT) launch_v2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
         else launch_v2<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
     } else {
         MixParams p{};
@@ -363,9 +388,7 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, double* d_obs
         p.wpat = e->d_wpat; p.wpat_stride = (int64_t)e->Pmax * e->F * e->C;
         p.partials = e->d_partials; p.partials_stride = e->partials_stride;
         p.obs = d_obs; p.first_slot = first_slot;
-        if (mode == WRITE_OBS) launch_v1<WRITE_OBS, false>(p, grid, g.lds_bytes, e->stream);
-        else if (mode == LOG_PRODUCT) launch_v1<LOG_PRODUCT, true>(p, grid, g.lds_bytes, e->stream);
-        else launch_v1<LOG_PER_OBS, true>(p, grid, g.lds_bytes, e->stream);
+        launch_v1<WRITE_OBS, false>(p, grid, g.lds_bytes, e->stream);
     }
     if (ev_b) HIPCHK(e, hipEventRecord(ev_b, e->stream));
     HIPCHK(e, hipGetLastError());
@@ -489,7 +512,7 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     {   // v2 feature-tile width: widest of 64/32/16 whose LDS image leaves two blocks per CU
         const char* env = getenv("SBE_FT");
         int ft = 64;
-        auto lds_for = [&](int t) { return ((size_t)(gtot + 1) * t * n_states) * sizeof(float) + (size_t)std::min(e->Pmax, 16) * n_components * t * sizeof(double); };
+        auto lds_for = [&](int t) { return ((size_t)(gtot + 1) * t * n_states) * sizeof(float) + (size_t)e->Pmax * n_components * t * sizeof(double) + 8 * 1024; };
         while (ft > 16 && lds_for(ft) > 78 * 1024) ft >>= 1;
         if (env && (atoi(env) == 64 || atoi(env) == 32 || atoi(env) == 16)) ft = atoi(env);
         if (lds_for(ft) > 156 * 1024) { delete e; return fail(nullptr, SBE_ERR_ARG, "probability tables too large for LDS staging (G_total=%lld, S=%d)", (long long)gtot, n_states); }

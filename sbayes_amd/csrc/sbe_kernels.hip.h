@@ -705,6 +705,7 @@ struct Mix2Params {
     int N, NQ, Np, F, Fq, S, C, Gtot, P;
     int n_ftiles, quads_per_chunk;
     const uint32_t* state_q;                       // [NQ][Fq]
+    const uint8_t* onehot; int rs_pitch;           // [N][rs_pitch] (one-hot variant)
     const uint16_t* gid;   int64_t gid_stride;     // per slot [C][Np]
     const uint8_t* pid;    int64_t pid_stride;     // per slot [Np]
     const float* probs_t;  int64_t probs_t_stride; // per slot [n_ftiles][(Gtot+1)*S*FT]
@@ -740,6 +741,55 @@ __device__ __forceinline__ void prod_add4(ProdAcc& a, double v0, double v1, doub
     a.mant = __hiloint2double((int)hi2, __double2loint(m));
 }
 
+// Shared prologue of the v2 kernels: LDS image of the tile (tables, weights) and of the chunk's ids.
+struct V2Lds {
+    float* tab;          // [(Gtot+1)][S][FT]
+    double* wl;          // [P][C][FT]
+    uint16_t* ids_g;     // [C][4*quads_per_chunk]   (one u16 per object)
+    uint8_t* ids_p;      // [4*quads_per_chunk]
+};
+
+template <int FT>
+__device__ __forceinline__ V2Lds v2_stage(const Mix2Params& p, unsigned char* lds_raw, int slot, int tile, int C,
+                                          int q0, int nq) {
+    V2Lds L;
+    const int tab_elems = (p.Gtot + 1) * p.S * FT;            // multiple of 16
+    L.tab = reinterpret_cast<float*>(lds_raw);
+    L.wl = reinterpret_cast<double*>(lds_raw + (size_t)tab_elems * sizeof(float));
+    uint64_t* ids_g64 = reinterpret_cast<uint64_t*>(L.wl + (size_t)p.P * C * FT);      // [C][quads_per_chunk]
+    uint32_t* ids_p32 = reinterpret_cast<uint32_t*>(ids_g64 + (size_t)C * p.quads_per_chunk);
+    L.ids_g = reinterpret_cast<uint16_t*>(ids_g64);
+    L.ids_p = reinterpret_cast<uint8_t*>(ids_p32);
+    // tile image: contiguous float4 copy, 4 loads in flight per thread
+    const float4* src = reinterpret_cast<const float4*>(
+        p.probs_t + (int64_t)slot * p.probs_t_stride + (int64_t)tile * tab_elems);
+    float4* dst = reinterpret_cast<float4*>(L.tab);
+    const int n4 = tab_elems >> 2;
+    int i = threadIdx.x;
+    for (; i + 3 * kBlock < n4; i += 4 * kBlock) {
+        const float4 a = src[i], b = src[i + kBlock], c = src[i + 2 * kBlock], d = src[i + 3 * kBlock];
+        dst[i] = a; dst[i + kBlock] = b; dst[i + 2 * kBlock] = c; dst[i + 3 * kBlock] = d;
+    }
+    for (; i < n4; i += kBlock) dst[i] = src[i];
+    const double2* wsrc = reinterpret_cast<const double2*>(
+        p.wpat_t + (int64_t)slot * p.wpat_t_stride + (int64_t)tile * p.wpat_tile_stride);
+    double2* wdst = reinterpret_cast<double2*>(L.wl);
+    const int w2 = (p.P * C * FT) >> 1;
+    for (int k = threadIdx.x; k < w2; k += kBlock) wdst[k] = wsrc[k];
+    // the chunk's ids: group ids (4 x u16 per quad and component) and pattern ids (LDS reads are
+    // in-order on lgkmcnt and ~64 cycles; scalar loads would serialise behind every LDS wait)
+    const uint16_t* gid = p.gid + (int64_t)slot * p.gid_stride;
+    const uint8_t* pid = p.pid + (int64_t)slot * p.pid_stride;
+    for (int k = threadIdx.x; k < nq * C; k += kBlock) {
+        const int c = k / nq, qi = k - c * nq;
+        ids_g64[c * p.quads_per_chunk + qi] = *reinterpret_cast<const uint64_t*>(gid + (int64_t)c * p.Np + 4 * (q0 + qi));
+    }
+    for (int k = threadIdx.x; k < nq; k += kBlock)
+        ids_p32[k] = *reinterpret_cast<const uint32_t*>(pid + 4 * (q0 + k));
+    __syncthreads();
+    return L;
+}
+
 template <int MODE, int FT, int CT>     // CT: compile-time component count (1..4), 0 = runtime (<= 8)
 __global__ __launch_bounds__(kBlock) void k_mixture_v2(Mix2Params p) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -749,59 +799,21 @@ __global__ __launch_bounds__(kBlock) void k_mixture_v2(Mix2Params p) {
     const int S = p.S;
     const int C = CT ? CT : p.C;
     constexpr int CU = CT ? CT : kMaxComponents;
-    const int tab_elems = (p.Gtot + 1) * S * FT;            // multiple of 16
-    float* tab = reinterpret_cast<float*>(lds_raw);
-    double* wl = reinterpret_cast<double*>(lds_raw + (size_t)tab_elems * sizeof(float));
-
-    // ---- stage the tile image: contiguous float4 copy, 4 loads in flight per thread ----------
-    {
-        const float4* src = reinterpret_cast<const float4*>(
-            p.probs_t + (int64_t)slot * p.probs_t_stride + (int64_t)tile * tab_elems);
-        float4* dst = reinterpret_cast<float4*>(tab);
-        const int n4 = tab_elems >> 2;
-        int i = threadIdx.x;
-        for (; i + 3 * kBlock < n4; i += 4 * kBlock) {
-            const float4 a = src[i], b = src[i + kBlock], c = src[i + 2 * kBlock], d = src[i + 3 * kBlock];
-            dst[i] = a; dst[i + kBlock] = b; dst[i + 2 * kBlock] = c; dst[i + 3 * kBlock] = d;
-        }
-        for (; i < n4; i += kBlock) dst[i] = src[i];
-        const double2* wsrc = reinterpret_cast<const double2*>(
-            p.wpat_t + (int64_t)slot * p.wpat_t_stride + (int64_t)tile * p.wpat_tile_stride);
-        double2* wdst = reinterpret_cast<double2*>(wl);
-        const int w2 = (p.P * C * FT) >> 1;
-        for (int k = threadIdx.x; k < w2; k += kBlock) wdst[k] = wsrc[k];
-    }
-    __syncthreads();
+    const int q0 = chunk * p.quads_per_chunk;
+    const int q1 = min(p.NQ, q0 + p.quads_per_chunk);
+    const int nq = q1 - q0;                                 // >= 1
+    const V2Lds L = v2_stage<FT>(p, lds_raw, slot, tile, C, q0, nq);
+    const uint64_t* ids_g = reinterpret_cast<const uint64_t*>(L.ids_g);
+    const uint32_t* ids_p = reinterpret_cast<const uint32_t*>(L.ids_p);
 
     constexpr int ROWS = kWave / FT;                        // object quads per wave step
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
     const int fl = lane % FT, sub = lane / FT;
     const int f = tile * FT + fl;
-    const int q0 = chunk * p.quads_per_chunk;
-    const int q1 = min(p.NQ, q0 + p.quads_per_chunk);
-    const int nq = q1 - q0;                                 // >= 1
-    const float* tab_l = tab + fl;
-    const double* wl_l = wl + fl;
+    const float* tab_l = L.tab + fl;
+    const double* wl_l = L.wl + fl;
     const uint32_t gmax = (uint32_t)p.Gtot;
     const uint32_t row = (uint32_t)S * FT;                  // floats per group row
-
-    // ---- stage the chunk's ids: group ids (4 x u16 per quad and component) and pattern ids ----
-    // (LDS reads are in-order on lgkmcnt and ~64 cycles; scalar loads would serialise behind
-    //  every LDS wait, per-lane global loads would triple the VMEM instructions)
-    uint64_t* ids_g = reinterpret_cast<uint64_t*>(wl + (size_t)p.P * C * FT);      // [C][quads_per_chunk]
-    uint32_t* ids_p = reinterpret_cast<uint32_t*>(ids_g + (size_t)C * p.quads_per_chunk);
-    {
-        const uint16_t* gid = p.gid + (int64_t)slot * p.gid_stride;
-        const uint8_t* pid = p.pid + (int64_t)slot * p.pid_stride;
-        for (int i = threadIdx.x; i < nq * C; i += kBlock) {
-            const int c = i / nq, qi = i - c * nq;
-            ids_g[c * p.quads_per_chunk + qi] =
-                *reinterpret_cast<const uint64_t*>(gid + (int64_t)c * p.Np + 4 * (q0 + qi));
-        }
-        for (int i = threadIdx.x; i < nq; i += kBlock)
-            ids_p[i] = *reinterpret_cast<const uint32_t*>(pid + 4 * (q0 + i));
-    }
-    __syncthreads();
 
     const int n_steps = (nq + 4 * ROWS - 1) / (4 * ROWS);   // same for every wave: uniform loop
     const uint32_t* sq = p.state_q + (int64_t)q0 * p.Fq + f;
@@ -883,6 +895,137 @@ __global__ __launch_bounds__(kBlock) void k_mixture_v2(Mix2Params p) {
             double v[4];
             step_values(k, xs, v);
             sum += log(v[0]); sum += log(v[1]); sum += log(v[2]); sum += log(v[3]);
+        }
+        thread_ll = sum;
+    }
+    const double total = block_sum(thread_ll, red4);
+    if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + blockIdx.x] = total;
+}
+
+// ------------------------------------------------------------------------------------------
+// One-hot variant of the v2 kernel: streams the one-hot block exactly as the reference hands it
+// over ([N][F][S] bool, N*F*S bytes per eval -- the contract figure of SURVEY.md 8(d)) with
+// coalesced 16-byte lane loads, and shares the LDS image, the id staging and the log
+// accumulation with the packed kernel.
+//   item  <-> (object, 16-byte chunk of the object's tile row segment of FT*S bytes)
+//   flags <-> bytes are 0/1, so m = d.x | d.y<<1 | d.z<<2 | d.w<<3 holds the 16 flags at distinct
+//             bit positions (bit 8k+i = byte k of dword i); set bytes are walked with ffbl / m&(m-1)
+//   (fl,x) <-> byte offset j in the row segment: fl = floor((j + 0.5)/S) in f32 (exact for
+//             j < 2^16, S <= 254), x = j - fl*S
+// ------------------------------------------------------------------------------------------
+template <int MODE, int FT, int CT>
+__global__ __launch_bounds__(kBlock) void k_mixture_onehot_v2(Mix2Params p) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ double red4[4];
+    const int slot = p.first_slot + blockIdx.y;
+    const int tile = blockIdx.x % p.n_ftiles, chunk = blockIdx.x / p.n_ftiles;
+    const int S = p.S;
+    const int C = CT ? CT : p.C;
+    constexpr int CU = CT ? CT : kMaxComponents;
+    const int q0 = chunk * p.quads_per_chunk;
+    const int q1 = min(p.NQ, q0 + p.quads_per_chunk);
+    const int nq = q1 - q0;
+    const V2Lds L = v2_stage<FT>(p, lds_raw, slot, tile, C, q0, nq);
+
+    const int n0 = 4 * q0;
+    const int n_obj = min(4 * nq, p.N - n0);
+    const int seg_off = tile * FT * S;                             // byte offset of the tile in a row (mult. of 16)
+    const int seg16 = min(FT * S, p.rs_pitch - seg_off) >> 4;      // 16-byte chunks of the segment inside the row
+    const int n_items = n_obj * seg16;
+    const int n_steps = (n_items + kBlock - 1) / kBlock;
+    const uint32_t gmax = (uint32_t)p.Gtot;
+    const uint32_t row = (uint32_t)S * FT;
+    const float inv_s = 1.0f / (float)S, half_inv_s = 0.5f / (float)S;
+    const float inv_seg = 1.0f / (float)seg16, half_inv_seg = 0.5f / (float)seg16;
+    const int ids_pitch = 4 * p.quads_per_chunk;
+    const uint8_t* oh = p.onehot + (int64_t)n0 * p.rs_pitch + seg_off;
+
+    struct Item { uint4 d; int nl, ch; };
+    auto fetch = [&](int k) -> Item {
+        Item it;
+        const int i = k * kBlock + (int)threadIdx.x;
+        const int ic = min(i, n_items - 1);
+        it.nl = (int)(((float)ic + 0.5f) * inv_seg);               // ic / seg16, exact (see header)
+        it.ch = ic - it.nl * seg16;
+        it.d = *reinterpret_cast<const uint4*>(oh + (int64_t)it.nl * p.rs_pitch + it.ch * 16);
+        if (i >= n_items) it.d = make_uint4(0u, 0u, 0u, 0u);
+        return it;
+    };
+    (void)half_inv_seg;
+
+    // likelihood of the observation whose set byte is the lowest flag of m (1.0 if m == 0)
+    auto observe = [&](uint32_t m, const Item& it, const uint32_t (&g)[CU], uint32_t pidn) -> double {
+        const bool has = m != 0u;
+        const int b = has ? __builtin_ctz(m) : 0;
+        const int j = it.ch * 16 + ((b & 7) << 2) + (b >> 3);       // byte offset in the row segment
+        const int fl = (int)((float)j * inv_s + half_inv_s);        // j / S
+        const int x = j - fl * S;
+        const float* tj = L.tab + x * FT + fl;
+        const double* wj = L.wl + pidn * (uint32_t)(C * FT) + fl;
+        double vj = 0.0;
+#pragma unroll
+        for (int c = 0; c < CU; ++c) {
+            if (CT || c < C) {
+                const double t = wj[c * FT] * (double)tj[g[c] * row];
+                vj = c == 0 ? t : vj + t;
+            }
+        }
+        return has ? vj : 1.0;
+    };
+    auto item_ids = [&](const Item& it, uint32_t (&g)[CU], uint32_t& pidn) {
+        pidn = L.ids_p[it.nl];
+#pragma unroll
+        for (int c = 0; c < CU; ++c) {
+            if (CT || c < C) {
+                const uint32_t gg = L.ids_g[c * ids_pitch + it.nl];
+                g[c] = gg < gmax ? gg : gmax;
+            } else g[c] = gmax;
+        }
+    };
+
+    double thread_ll;
+    if (MODE == LOG_PRODUCT) {
+        ProdAcc pa{1.0, 0, 0, 0u};
+        int n_strips = 0;
+        Item nxt = fetch(0);
+        for (int k = 0; k < n_steps; ++k) {
+            const Item it = nxt;
+            nxt = fetch(k + 1);
+            uint32_t m = it.d.x | (it.d.y << 1) | (it.d.z << 2) | (it.d.w << 3);
+            uint32_t g[CU], pidn;
+            item_ids(it, g, pidn);
+            // walk the set bytes; the trip count is wave-uniform (max over lanes), idle lanes multiply by 1
+            while (__builtin_amdgcn_ballot_w64(m != 0u)) {
+                const double a = observe(m, it, g, pidn);
+                m &= m - 1u;
+                const double b = observe(m, it, g, pidn);
+                m &= m - 1u;
+                prod_add4(pa, a, b, 1.0, 1.0);
+                ++n_strips;
+            }
+        }
+        thread_ll = log(pa.mant) + (double)(pa.expo - 1023 * n_strips) * 0.693147180559945309417232;
+        if (__builtin_expect(pa.bad != 0u, 0)) {
+            double sum = 0.0;
+            for (int k = 0; k < n_steps; ++k) {
+                const Item it = fetch(k);
+                uint32_t m = it.d.x | (it.d.y << 1) | (it.d.z << 2) | (it.d.w << 3);
+                uint32_t g[CU], pidn;
+                item_ids(it, g, pidn);
+                while (m) { sum += log(observe(m, it, g, pidn)); m &= m - 1u; }
+            }
+            thread_ll = sum;
+        }
+    } else {
+        double sum = 0.0;
+        Item nxt = fetch(0);
+        for (int k = 0; k < n_steps; ++k) {
+            const Item it = nxt;
+            nxt = fetch(k + 1);
+            uint32_t m = it.d.x | (it.d.y << 1) | (it.d.z << 2) | (it.d.w << 3);
+            uint32_t g[CU], pidn;
+            item_ids(it, g, pidn);
+            while (m) { sum += log(observe(m, it, g, pidn)); m &= m - 1u; }
         }
         thread_ll = sum;
     }

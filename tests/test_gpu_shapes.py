@@ -1,0 +1,134 @@
+"""Randomised shape sweep: every kernel family against the oracle on ragged / edge shapes the
+fixtures do not reach -- N not a multiple of 4, F not a multiple of the tile width, S = 1 ..,
+C = 1..6 (compile-time 1..4 and the runtime-C instantiation), many groups, objects in no group,
+all three feature-tile widths (SBE_FT), both streamed representations, both log modes."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import sbayes_oracle as orc
+from sbayes_amd.engine import (LOG_PER_OBS, LOG_PRODUCT, MIXTURE_ONEHOT, MIXTURE_PACKED, Engine, EngineError)
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # N,   F,   S,  groups per component,        na_rate
+    (1,    1,   1,  [1],                         0.0),
+    (3,    2,   2,  [1, 1],                      0.3),
+    (5,    15,  3,  [2, 1],                      0.1),
+    (7,    16,  7,  [3, 2, 1],                   0.05),
+    (50,   17,  5,  [2, 1, 4],                   0.03),
+    (129,  65,  4,  [4, 1, 3, 2],                0.03),
+    (257,  130, 6,  [3, 1, 2, 2, 5],             0.02),      # C = 5: runtime-C kernel instantiation
+    (64,   33,  33, [2, 1, 2, 3, 2, 2],          0.02),      # C = 6, S = 33
+    (100,  40,  20, [30, 1, 25],                 0.03),      # many groups: narrower LDS tile
+    (41,   70,  2,  [5, 1],                      0.9),       # almost everything NA
+]
+
+
+def random_case(rng, N, F, S, n_groups, na_rate):
+    x = rng.integers(0, S, size=(N, F))
+    na = rng.random((N, F)) < na_rate
+    feats = np.zeros((N, F, S), dtype=bool)
+    nn, ff = np.nonzero(~na)
+    feats[nn, ff, x[nn, ff]] = True
+    groups = []
+    for c, G in enumerate(n_groups):
+        if c == 1:
+            g = np.ones((G, N), dtype=bool) if G == 1 else None
+        if c != 1 or G != 1:
+            a = rng.integers(0, G + (1 if c != 1 else 0) + (G if c == 0 else 0), size=N)   # some objects in no group
+            g = np.stack([a == k for k in range(G)])
+        groups.append(g)
+    C = len(n_groups)
+    if C == 1:                                   # a lone component must cover every object with data
+        groups[0] = np.stack([np.arange(N) % n_groups[0] == k for k in range(n_groups[0])])
+    weights = rng.dirichlet(np.ones(C), size=F).astype(np.float32)
+    hc = orc.has_components(groups)
+    w = hc[:, None, :] * weights[None].astype(np.float64)
+    tot = w.sum(-1, keepdims=True)
+    w = np.divide(w, tot, out=np.full_like(w, 1.0 / C), where=tot > 0)
+    cdf = np.cumsum(w, -1)
+    src_idx = np.argmax(rng.random((N, F, 1)) < cdf / cdf[..., -1:], axis=-1)
+    source = np.eye(C, dtype=bool)[src_idx]
+    source[~feats.any(-1)] = False
+    source[~hc.any(1)] = False
+    source &= hc[:, None, :]
+    conc = [rng.choice([0.5, 1.0, 2.0], size=((G, F, S) if c else (F, S))) for c, G in enumerate(n_groups)]
+    return feats, groups, weights, source, conc
+
+
+@pytest.mark.parametrize("ft", ["16", "32", "64"])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: f"N{s[0]}F{s[1]}S{s[2]}C{len(s[3])}")
+def test_shape_sweep(shape, ft, monkeypatch):
+    N, F, S, n_groups, na_rate = shape
+    monkeypatch.setenv("SBE_FT", ft)
+    rng = np.random.default_rng(hash((N, F, S, len(n_groups))) % (2 ** 32))
+    feats, groups, weights, source, conc = random_case(rng, N, F, S, n_groups, na_rate)
+    try:
+        _run_case(feats, groups, weights, source, conc, n_groups, rng)
+    except EngineError as exc:                     # a forced tile too wide for the tables is a valid refusal
+        assert "too large for LDS" in str(exc) and ft != "16", exc
+
+
+def test_default_tile_width_never_refuses():
+    """Without SBE_FT the engine picks a tile width that fits for every shape of the sweep."""
+    for shape in SHAPES:
+        N, F, S, n_groups, na_rate = shape
+        rng = np.random.default_rng(7)
+        feats, groups, weights, source, conc = random_case(rng, N, F, S, n_groups, na_rate)
+        _run_case(feats, groups, weights, source, conc, n_groups, rng, light=True)
+
+
+def _run_case(feats, groups, weights, source, conc, n_groups, rng, light=False):
+    N = feats.shape[0]
+    na = ~feats.any(-1)
+    hc = orc.has_components(groups)
+    covered = hc.any(axis=1)
+    with Engine(feats, n_groups, n_slots=2) as eng:
+        C = len(n_groups)
+        for c in range(C):
+            eng.set_concentration(c, conc[c])
+            eng.set_groups(0, c, groups[c])
+        eng.set_source(0, source)
+        eng.recount(0)
+        counts = orc.recalculate_feature_counts(feats, groups, source)
+        for c in range(C):
+            assert np.array_equal(eng.get_counts(0, c), counts[c])
+            eng.update_probs(0, c)
+            assert np.array_equal(eng.get_probs(0, c), orc.component_probs(counts[c], conc[c]))
+        eng.set_weights(0, weights)
+        lh = orc.likelihood_per_component(feats, na, groups, counts, conc)
+        assert np.array_equal(eng.likelihood_per_component(0), lh)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            w = orc.normalize_weights(weights, hc)
+            obs = orc.mixture_observation_lh(w, lh)
+            got_w = eng.weights_normalized(0)
+            assert np.array_equal(got_w[covered], w[covered])
+            assert np.array_equal(eng.observation_lh(0)[covered], obs[covered])
+            assert np.array_equal(eng.likelihood_per_component_exact(0),
+                                  orc.likelihood_per_component_exact(feats, na, groups, counts, conc, source))
+            want = np.log(obs)[~na].sum()
+        for kernel in (MIXTURE_PACKED, MIXTURE_ONEHOT):
+            for log_mode in (LOG_PER_OBS, LOG_PRODUCT):
+                eng.set_option(kernel=kernel, log_mode=log_mode)
+                got = eng.mixture_loglik(0)
+                if np.isfinite(want):
+                    assert abs(got - want) <= 1e-10 * max(abs(want), 1e-300), (kernel, log_mode, got, want)
+                else:
+                    assert (np.isnan(got) and np.isnan(want)) or got == want, (kernel, log_mode, got, want)
+        if light:
+            return
+        # collapsed likelihood and the stateless forms
+        for c in range(C):
+            pg, pf = eng.collapsed_loglik(0, c, per_feature=True)
+            a = conc[c] if conc[c].ndim == 3 else np.broadcast_to(conc[c], counts[c].shape)
+            want_pf = np.stack([orc.dirichlet_categorical_logpdf(counts[c][g], a[g]) for g in range(n_groups[c])])
+            np.testing.assert_allclose(pf, want_pf, rtol=3e-6, atol=2e-6)
+            np.testing.assert_allclose(pg, orc.collapsed_group_logliks(counts[c], conc[c]), rtol=2e-6, atol=1e-5)
+            assert np.array_equal(eng.effect_counts(groups[c], source[..., c]), counts[c])
+            sub = rng.choice(N, size=max(1, N // 3), replace=False)
+            assert np.array_equal(eng.effect_counts(groups[c], source[..., c], sub),
+                                  orc.compute_effect_counts(feats, groups[c], source[..., c], sub))
+            assert np.array_equal(eng.normalize_tables(counts[c], conc[c]), orc.component_probs(counts[c], conc[c]))
