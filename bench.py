@@ -154,7 +154,8 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
 
     # ---- roofline of the dominant kernel, HIP events on the engine's stream ---------------------
-    n_pat = 2 if args.workload != "stress" else 8
+    has_comp = np.stack([g.any(axis=0) for g in wl.groups], axis=1)
+    n_pat = len(np.unique(has_comp, axis=0))          # distinct has_components rows (likelihood.py:183)
     packed = args.kernel == "packed"
     b_eval = algorithmic_bytes(n_obj, n_feat, n_states, [g.shape[0] for g in wl.groups], n_pat, packed=packed)
     prof_iters = min(max(args.steps, 20), 200)

@@ -356,9 +356,16 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, double* d_obs
     if (g.lds_bytes > 159 * 1024)
         return fail(e, SBE_ERR_ARG, "probability / weight tables too large for LDS staging at tile width %d (%zu bytes; G_total=%d, S=%d, P=%d)",
                     g.ft, g.lds_bytes, e->Gtot, e->S, P);
-    const dim3 grid(g.n_blocks, n);
+    dim3 grid(g.n_blocks, n);
     if (ev_a) HIPCHK(e, hipEventRecord(ev_a, e->stream));
     if (v2) {
+        // XCD-aware 1-D grid (see k_mixture_v2): units = work items x slot groups, unit u on XCD u % 8
+        int gcd8 = 8;
+        while (g.n_blocks % gcd8) gcd8 >>= 1;
+        const int slot_groups = std::max(1, std::min(8 / gcd8, n));
+        const int slots_per_group = div_up(n, slot_groups);
+        const int n_units = g.n_blocks * slot_groups;
+        grid = dim3(8 * div_up(n_units, 8) * slots_per_group, 1);
         Mix2Params p{};
         p.N = e->N; p.NQ = e->NQ; p.Np = e->Np; p.F = e->F; p.Fq = e->Fq; p.S = e->S; p.C = e->C;
         p.Gtot = e->Gtot; p.P = P; p.n_ftiles = g.n_ftiles; p.quads_per_chunk = g.objs_per_chunk;
@@ -369,6 +376,8 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, double* d_obs
         p.probs_t = e->d_probs_t; p.probs_t_stride = e->probs_t_elems();
         p.wpat_t = e->d_wpat_t; p.wpat_t_stride = e->wpat_t_elems(); p.wpat_tile_stride = (int)e->wpat_tile_elems();
         p.partials = e->d_partials; p.partials_stride = e->partials_stride; p.first_slot = first_slot;
+        p.n_work = g.n_blocks; p.n_batch = n;
+        p.slot_groups = slot_groups; p.slots_per_group = slots_per_group;
         if (onehot) {
             if (mode == LOG_PRODUCT) launch_oh2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
             else launch_oh2<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);

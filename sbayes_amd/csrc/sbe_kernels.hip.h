@@ -704,6 +704,8 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __rest
 struct Mix2Params {
     int N, NQ, Np, F, Fq, S, C, Gtot, P;
     int n_ftiles, quads_per_chunk;
+    int n_work, n_batch;                           // (tile, chunk) work items per slot; slots in this launch
+    int slot_groups, slots_per_group;              // XCD-aware block order (see k_mixture_v2)
     const uint32_t* state_q;                       // [NQ][Fq]
     const uint8_t* onehot; int rs_pitch;           // [N][rs_pitch] (one-hot variant)
     const uint16_t* gid;   int64_t gid_stride;     // per slot [C][Np]
@@ -794,8 +796,19 @@ template <int MODE, int FT, int CT>     // CT: compile-time component count (1..
 __global__ __launch_bounds__(kBlock) void k_mixture_v2(Mix2Params p) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ double red4[4];
-    const int slot = p.first_slot + blockIdx.y;
-    const int tile = blockIdx.x % p.n_ftiles, chunk = blockIdx.x / p.n_ftiles;
+    // XCD-aware 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch; b % 8 labels the
+    // group, speed only).  The slot-blocks of one (tile, chunk) work item get adjacent positions on
+    // one XCD: they run at about the same time and share the streamed feature bytes in its L2.
+    // Units = (work item, slot group); unit u lives on XCD u % 8 (consecutive work items are
+    // interleaved over the XCDs -- neighbouring tiles of the same rows stream together, which the
+    // measured stress-shape runs prefer -- and small grids are balanced by splitting the slots of a
+    // work item into `slot_groups` groups); the slots of a unit are adjacent on that XCD.
+    const int unit = ((int)(blockIdx.x >> 3) / p.slots_per_group) * 8 + (int)(blockIdx.x & 7);
+    const int slot_i = (unit % p.slot_groups) * p.slots_per_group + (int)(blockIdx.x >> 3) % p.slots_per_group;
+    const int work = unit / p.slot_groups;                 // (tile, chunk) index
+    if (work >= p.n_work || slot_i >= p.n_batch) return;   // padding blocks (before any barrier)
+    const int slot = p.first_slot + slot_i;
+    const int tile = work % p.n_ftiles, chunk = work / p.n_ftiles;
     const int S = p.S;
     const int C = CT ? CT : p.C;
     constexpr int CU = CT ? CT : kMaxComponents;
@@ -899,7 +912,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_v2(Mix2Params p) {
         thread_ll = sum;
     }
     const double total = block_sum(thread_ll, red4);
-    if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + blockIdx.x] = total;
+    if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + work] = total;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -917,8 +930,19 @@ template <int MODE, int FT, int CT>
 __global__ __launch_bounds__(kBlock) void k_mixture_onehot_v2(Mix2Params p) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ double red4[4];
-    const int slot = p.first_slot + blockIdx.y;
-    const int tile = blockIdx.x % p.n_ftiles, chunk = blockIdx.x / p.n_ftiles;
+    // XCD-aware 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch; b % 8 labels the
+    // group, speed only).  The slot-blocks of one (tile, chunk) work item get adjacent positions on
+    // one XCD: they run at about the same time and share the streamed feature bytes in its L2.
+    // Units = (work item, slot group); unit u lives on XCD u % 8 (consecutive work items are
+    // interleaved over the XCDs -- neighbouring tiles of the same rows stream together, which the
+    // measured stress-shape runs prefer -- and small grids are balanced by splitting the slots of a
+    // work item into `slot_groups` groups); the slots of a unit are adjacent on that XCD.
+    const int unit = ((int)(blockIdx.x >> 3) / p.slots_per_group) * 8 + (int)(blockIdx.x & 7);
+    const int slot_i = (unit % p.slot_groups) * p.slots_per_group + (int)(blockIdx.x >> 3) % p.slots_per_group;
+    const int work = unit / p.slot_groups;                 // (tile, chunk) index
+    if (work >= p.n_work || slot_i >= p.n_batch) return;   // padding blocks (before any barrier)
+    const int slot = p.first_slot + slot_i;
+    const int tile = work % p.n_ftiles, chunk = work / p.n_ftiles;
     const int S = p.S;
     const int C = CT ? CT : p.C;
     constexpr int CU = CT ? CT : kMaxComponents;
@@ -1030,7 +1054,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_onehot_v2(Mix2Params p) {
         thread_ll = sum;
     }
     const double total = block_sum(thread_ll, red4);
-    if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + blockIdx.x] = total;
+    if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + work] = total;
 }
 
 // canonical probs [Gtot][F][S] -> tile-transposed probs_t [n_ftiles][Gtot+1][S][FT] for the

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/prof_<TAG>/ (written by tools/profile_gpu.sh on the GPU box) into the
+tracked profiles/<TAG>/ directory: rocprofv3 kernel stats, per-kernel PMC means, the FETCH_SIZE
+calibration and profiles/traffic_latest.json (per-launch HBM bytes of the dominant kernel, read by
+bench.py for `roofline.traffic`)."""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r1"
+SRC = REPO / "gpurun_out" / f"prof_{TAG}"
+DST = REPO / "profiles" / TAG
+DST.mkdir(parents=True, exist_ok=True)
+
+
+def counters(dirname):
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(str(SRC / dirname / "*" / "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            out[name][(r["Counter_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+    return out
+
+
+def dominant(rows, prefix):
+    """Means for the kernel whose name starts with `prefix`, at its largest grid (the batched launches)."""
+    res = {}
+    for name, d in rows.items():
+        if not name.startswith(prefix):
+            continue
+        grid = max(g for (_, g) in d)
+        for (cname, g), v in d.items():
+            if g == grid:
+                res[cname] = {"mean": sum(v) / len(v), "dispatches": len(v), "grid_size": g, "kernel": name}
+    return res
+
+
+summary = {}
+# ---- FETCH_SIZE calibration ---------------------------------------------------------------------
+calib = {}
+rows = counters("pmc_fetch_calib")
+for name, d in rows.items():
+    for (cname, g), v in d.items():
+        if cname == "FETCH_SIZE" and name.startswith("read_"):
+            kb = sum(v) / len(v)
+            calib[name] = {"streamed_bytes": 1 << 30, "FETCH_SIZE_KB": kb, "reported_fraction": kb * 1024 / (1 << 30)}
+summary["fetch_calibration"] = calib
+corr4 = 1.0 / calib["read_dword"]["reported_fraction"] if "read_dword" in calib else None
+corr16 = 1.0 / calib["read_dwordx4"]["reported_fraction"] if "read_dwordx4" in calib else None
+
+traffic = {}
+for wl, batch in (("headline", 64), ("stress", 8)):
+    for kern in ("packed", "onehot"):
+        suffix = kern if wl == "headline" else f"stress_{kern}"
+        prefix = "sbe::k_mixture_v2" if kern == "packed" else "sbe::k_mixture_onehot_v2"
+        entry = {}
+        fetch = dominant(counters(f"pmc_fetch_{suffix}"), prefix)
+        write = dominant(counters(f"pmc_write_{suffix}"), prefix) if wl == "headline" else {}
+        if "FETCH_SIZE" in fetch:
+            raw = fetch["FETCH_SIZE"]["mean"] * 1024
+            # packed streams 4-byte lane loads + 16-byte table staging, onehot 16-byte lane loads:
+            # apply the calibrated factor of the dominant access width
+            factor = (corr16 if kern == "onehot" else corr4) or 1.0
+            entry.update(fetch_raw_bytes=raw, fetch_correction=factor, fetch_bytes=raw * factor)
+        if "WRITE_SIZE" in write:
+            entry["write_bytes"] = write["WRITE_SIZE"]["mean"] * 1024
+        if entry:
+            entry["hbm_bytes_per_launch"] = entry.get("fetch_bytes", 0.0) + entry.get("write_bytes", 0.0)
+            entry["evals_per_launch"] = batch
+            traffic[f"{wl}:{kern}:{batch}"] = entry
+        sq = {}
+        for part in ("sq1", "sq2"):
+            if wl == "headline":
+                sq.update({k: v["mean"] for k, v in dominant(counters(f"pmc_{part}_{suffix}"), prefix).items()})
+        if sq:
+            summary[f"sq_counters_{wl}_{kern}_b{batch}"] = sq
+        for f in glob.glob(str(SRC / f"trace_{suffix}" / "*" / "*_kernel_stats.csv")):
+            shutil.copy(f, DST / f"kernel_stats_{wl}_{kern}_b{batch}.csv")
+        b = SRC / f"bench_{suffix}.json"
+        if b.exists() and b.stat().st_size:
+            shutil.copy(b, DST / f"bench_line_{wl}_{kern}_b{batch}_under_rocprof.json")
+summary["traffic"] = traffic
+(DST / "pmc_summary.json").write_text(json.dumps(summary, indent=1))
+(REPO / "profiles" / "traffic_latest.json").write_text(json.dumps(
+    {k: round(v["hbm_bytes_per_launch"]) for k, v in traffic.items()}, indent=1))
+print(json.dumps(summary, indent=1)[:6000])
