@@ -52,7 +52,8 @@ def parse():
     ap.add_argument("--log-mode", default="product", choices=["product", "per_obs"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--explore", action="store_true", help="print extra latency / batch-size figures to stderr")
+    ap.add_argument("--explore", action="store_true", help="also print the batch sweep to stderr")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (latency, sweep, a1/a7 rates)")
     return ap.parse_args()
 
 
@@ -94,6 +95,69 @@ def cpu_baseline(wl, seconds):
         if el >= seconds or n >= 100000:
             break
     return ll, n / el, n, el
+
+
+def _rate(fn, min_time=0.3, min_calls=5):
+    fn()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        el = time.perf_counter() - t0
+        if n >= min_calls and el >= min_time:
+            return n / el
+
+
+def secondary_figures(eng, wl, B, args):
+    """Figures SURVEY.md 8(d) asks to report beside the headline: single-eval latency, batch sweep,
+    the literal a1 / a3 / a7 call rates and the PCIe-inclusive eval (state re-uploaded per eval).
+    Rank 0, N=1 only; bounded to a few seconds."""
+    out = {}
+    for _ in range(20):
+        eng.mixture_loglik(0)
+    out["single_eval_sync_us"] = round(1e6 / _rate(lambda: eng.mixture_loglik(0), 0.2, 200), 2)
+    _t, k1 = eng.profile_mixture(0, 1, 100)
+    out["single_eval_kernel_us"] = round(k1 * 1e3, 3)
+    sweep = {}
+    for b in (1, 8, 64, 256):
+        if b > B:
+            break
+        eng.sync()
+        reps = 100
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            eng.mixture_loglik_batch_async(0, b)
+        eng.fetch_results(0, b)
+        dt = time.perf_counter() - t1
+        _t, kb = eng.profile_mixture(0, b, 50)
+        sweep[str(b)] = {"evals_per_s": round(reps * b / dt), "kernel_us": round(kb * 1e3, 2)}
+        if args.explore:
+            log(f"[explore] batch {b:4d}: {reps * b / dt:12.0f} evals/s  main kernel {kb * 1e3:9.2f} us")
+    out["batch_sweep"] = sweep
+    # literal call surface (results cross PCIe every call: SURVEY.md H3)
+    n_obj, n_feat, _ = wl.shape
+    probs0 = eng.get_probs(0, 0)
+    buf = np.empty((n_obj, n_feat, wl.n_components))
+    all_groups = np.arange(wl.groups[0].shape[0])
+    out["a1_component_lh_calls_per_s"] = round(_rate(lambda: eng.component_lh(probs0, wl.groups[0], all_groups, buf[..., 0])), 1)
+    out["a3_likelihood_per_component_per_s"] = round(_rate(lambda: eng.likelihood_per_component(0, buf)), 1)
+
+    def collapsed():
+        eng.recount(0)
+        return sum(eng.collapsed_loglik(0, c).sum() for c in range(wl.n_components))
+    out["a7_collapsed_uncached_per_s"] = round(_rate(collapsed), 1)
+    # PCIe-inclusive eval: groups + counts + weights re-uploaded, tables rebuilt, one scalar back
+    counts = [eng.get_counts(0, c) for c in range(wl.n_components)]
+
+    def pcie_eval():
+        for c in range(wl.n_components):
+            eng.set_groups(0, c, wl.groups[c])
+            eng.set_counts(0, c, counts[c])
+            eng.update_probs(0, c)
+        eng.set_weights(0, wl.weights)
+        return eng.mixture_loglik(0)
+    out["pcie_inclusive_evals_per_s"] = round(_rate(pcie_eval), 1)
+    return out
 
 
 def main():
@@ -180,32 +244,8 @@ def main():
             pass
 
     extra = {}
-    if args.explore and rank == 0:
-        # single-eval latency (host-synchronous, what one chain's MH step sees) and batch sweep
-        for _ in range(20):
-            eng.mixture_loglik(0)
-        t1 = time.perf_counter()
-        n_lat = 500
-        for _ in range(n_lat):
-            eng.mixture_loglik(0)
-        lat = (time.perf_counter() - t1) / n_lat
-        extra["single_eval_sync_us"] = round(lat * 1e6, 2)
-        _t, k1 = eng.profile_mixture(0, 1, 100)
-        extra["single_eval_kernel_us"] = round(k1 * 1e3, 3)
-        for b in (1, 2, 4, 8, 16, 32, 64, 128, 256):
-            if b > B:
-                break
-            eng.sync()
-            t1 = time.perf_counter()
-            reps = 100
-            for _ in range(reps):
-                eng.mixture_loglik_batch_async(0, b)
-            eng.fetch_results(0, b)
-            dt = time.perf_counter() - t1
-            _t, kb = eng.profile_mixture(0, b, 50)
-            log(f"[explore] batch {b:4d}: {reps * b / dt:12.0f} evals/s  step {dt / reps * 1e6:9.1f} us  "
-                f"main kernel {kb * 1e3:9.2f} us")
-        log(f"[explore] single eval: sync latency {extra['single_eval_sync_us']} us, kernel {extra['single_eval_kernel_us']} us")
+    if rank == 0 and n_gpus == 1 and not args.no_secondary:
+        extra = secondary_figures(eng, wl, B, args)
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
