@@ -42,8 +42,12 @@ typedef struct sbe_engine sbe_engine;
 
 /* fused-kernel variants (sbe_set_option(SBE_OPT_MIXTURE_KERNEL, ...)) */
 #define SBE_OPT_MIXTURE_KERNEL 1
-#define SBE_MIXTURE_PACKED 0   /* reads the packed state-index block  (N*F bytes)           */
+#define SBE_MIXTURE_PACKED 0   /* reads the packed state-index block  (N*F bytes); uses the
+                                  group-tuple form (one log per (tuple, state, feature)
+                                  instead of per observation) whenever it applies          */
 #define SBE_MIXTURE_ONEHOT 1   /* reads the one-hot block as handed over (N*F*S bytes)      */
+#define SBE_MIXTURE_PACKED_GENERAL 2  /* packed, but never the group-tuple form (testing / A-B) */
+#define SBE_MIXTURE_PACKED_TUPLE 3    /* packed, group-tuple form forced (error if not applicable) */
 #define SBE_OPT_LOG_MODE 2
 #define SBE_LOG_PER_OBS 0      /* fp64 log per observation, fp64 sum                        */
 #define SBE_LOG_PRODUCT 1      /* fp64 mantissa product + integer exponent, one log/thread  */

@@ -24,6 +24,7 @@ struct Slot {
     std::vector<uint16_t> h_gid;          // [C][N] host mirror (pattern derivation)
     std::vector<uint8_t> h_pid;           // [N]
     std::vector<uint32_t> patterns;       // distinct has_components bit patterns, sorted like np.unique
+    int n_tuples = 0;                     // distinct group tuples of the objects (0 = more than kMaxTuples)
     bool groups_set = false, weights_set = false, source_set = false;
     std::vector<uint8_t> probs_set, counts_set;   // per component
     bool patterns_dirty = true;
@@ -66,6 +67,9 @@ struct sbe_engine {
     float* d_weights = nullptr;    // [slots][F][C]
     float* d_wpat = nullptr;       // [slots][Pmax][F][C]
     uint32_t* d_patbits = nullptr; // [slots][Pmax]
+    uint8_t* d_tid = nullptr;      // [slots][Np] group-tuple index per object (k_mixture_combo)
+    uint16_t* d_tuple_g = nullptr; // [slots][kMaxTuples][kMaxComponents]
+    uint8_t* d_tuple_p = nullptr;  // [slots][kMaxTuples]
     double* d_conc = nullptr;      // [Gtot][F][S]
     double* d_unif = nullptr;      // [F][S]
     std::vector<uint8_t> conc_set;
@@ -212,6 +216,35 @@ int upload_patterns_and_weights(sbe_engine* e, int slot) {
                                  hipMemcpyHostToDevice, e->stream));
         HIPCHK(e, hipMemcpyAsync(e->d_patbits + (int64_t)slot * e->Pmax, s.patterns.data(),
                                  s.patterns.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        // distinct group tuples (g_0..g_{C-1}) of the objects, for the group-tuple kernel
+        {
+            const int N = e->N, C = e->C;
+            std::vector<uint8_t> tid(e->Np, 0);
+            std::vector<uint16_t> tg((size_t)kMaxTuples * kMaxComponents, (uint16_t)e->Gtot);
+            std::vector<uint8_t> tp(kMaxTuples, 0);
+            std::vector<std::vector<uint16_t>> tuples;
+            bool ok = true;
+            for (int n = 0; n < N && ok; ++n) {
+                std::vector<uint16_t> key(C);
+                for (int c = 0; c < C; ++c) key[c] = s.h_gid[(size_t)c * N + n];
+                size_t t = 0;
+                for (; t < tuples.size(); ++t) if (tuples[t] == key) break;
+                if (t == tuples.size()) {
+                    if ((int)tuples.size() == kMaxTuples) { ok = false; break; }
+                    tuples.push_back(key);
+                    for (int c = 0; c < C; ++c) tg[t * kMaxComponents + c] = key[c] == kNoGroup ? (uint16_t)e->Gtot : key[c];
+                    tp[t] = s.h_pid[n];
+                }
+                tid[n] = (uint8_t)t;
+            }
+            s.n_tuples = ok ? (int)tuples.size() : 0;
+            if (ok) {
+                HIPCHK(e, hipMemcpyAsync(e->d_tid + (int64_t)slot * e->Np, tid.data(), e->Np, hipMemcpyHostToDevice, e->stream));
+                HIPCHK(e, hipMemcpyAsync(e->d_tuple_g + (int64_t)slot * kMaxTuples * kMaxComponents, tg.data(),
+                                         tg.size() * sizeof(uint16_t), hipMemcpyHostToDevice, e->stream));
+                HIPCHK(e, hipMemcpyAsync(e->d_tuple_p + (int64_t)slot * kMaxTuples, tp.data(), tp.size(), hipMemcpyHostToDevice, e->stream));
+            }
+        }
         HIPCHK(e, hipStreamSynchronize(e->stream));
         s.patterns_dirty = false;
     }
@@ -337,6 +370,23 @@ void launch_oh2(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipSt
     else launch_oh2_ft<MODE, 16>(C, p, grid, lds, st);
 }
 
+template <int FT>
+void launch_combo_ft(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
+    switch (C) {
+        case 1: k_mixture_combo<FT, 1><<<grid, kBlock, lds, st>>>(p); break;
+        case 2: k_mixture_combo<FT, 2><<<grid, kBlock, lds, st>>>(p); break;
+        case 3: k_mixture_combo<FT, 3><<<grid, kBlock, lds, st>>>(p); break;
+        case 4: k_mixture_combo<FT, 4><<<grid, kBlock, lds, st>>>(p); break;
+        default: k_mixture_combo<FT, 0><<<grid, kBlock, lds, st>>>(p); break;
+    }
+}
+
+void launch_combo(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
+    if (ft == 64) launch_combo_ft<64>(C, p, grid, lds, st);
+    else if (ft == 32) launch_combo_ft<32>(C, p, grid, lds, st);
+    else launch_combo_ft<16>(C, p, grid, lds, st);
+}
+
 template <int MODE>
 void launch_v2(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
     if (ft == 64) launch_v2_ft<MODE, 64>(C, p, grid, lds, st);
@@ -378,6 +428,33 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, double* d_obs
         p.partials = e->d_partials; p.partials_stride = e->partials_stride; p.first_slot = first_slot;
         p.n_work = g.n_blocks; p.n_batch = n;
         p.slot_groups = slot_groups; p.slots_per_group = slots_per_group;
+        p.tid = e->d_tid; p.tid_stride = e->Np;
+        p.tuple_g = e->d_tuple_g; p.tuple_g_stride = (int64_t)kMaxTuples * kMaxComponents;
+        p.tuple_p = e->d_tuple_p; p.tuple_p_stride = kMaxTuples;
+        // group-tuple form: eligible when every slot of the launch has few distinct tuples, the log
+        // table fits LDS and a block sees enough observations to amortise building it
+        int KT = 0;
+        const bool force_combo = e->opt_kernel == SBE_MIXTURE_PACKED_TUPLE;
+        bool combo = !onehot && (e->opt_kernel == SBE_MIXTURE_PACKED || force_combo);
+        for (int sl = first_slot; sl < first_slot + n && combo; ++sl) {
+            if (e->slots[sl].n_tuples == 0) combo = false;
+            KT = std::max(KT, e->slots[sl].n_tuples);
+        }
+        // LDS image of the group-tuple kernel: T[KT][S+1][ft] f64 | tq[quads] u32 | tuple rows u16 | tuple patterns u32 | weights f64
+        const int cu = e->C <= 4 ? e->C : kMaxComponents;
+        size_t combo_lds = (size_t)KT * (e->S + 1) * g.ft * sizeof(double) + (size_t)g.objs_per_chunk * 4;
+        combo_lds += ((size_t)KT * cu + ((KT * cu) & 1)) * sizeof(uint16_t) + (size_t)KT * sizeof(uint32_t);
+        combo_lds = (combo_lds + 15) / 16 * 16;
+        p.combo_w_off = (int)combo_lds;
+        combo_lds += (size_t)P * e->C * g.ft * sizeof(double);
+        const int64_t obs_per_block = (int64_t)g.objs_per_chunk * 4 * g.ft;
+        if (combo && !force_combo && (combo_lds > 40 * 1024 || obs_per_block < (int64_t)8 * KT * e->S * g.ft)) combo = false;
+        if (force_combo && (!combo || combo_lds > 150 * 1024))
+            return fail(e, SBE_ERR_ARG, "group-tuple kernel forced but not applicable (tuples=%d, LDS %zu bytes)", KT, combo_lds);
+        p.KT = KT;
+        if (combo) {
+            launch_combo(g.ft, e->C, p, grid, combo_lds, e->stream);
+        } else
         if (onehot) {
             if (mode == LOG_PRODUCT) launch_oh2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
             else launch_oh2<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
@@ -468,7 +545,7 @@ int sbe_destroy(sbe_engine* e) {
     if (!e) return SBE_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* dev_ptrs[] = {e->d_state_q, e->d_probs_t, e->d_wpat_t, e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
+    void* dev_ptrs[] = {e->d_tid, e->d_tuple_g, e->d_tuple_p, e->d_state_q, e->d_probs_t, e->d_wpat_t, e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
                         e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_unif, e->d_partials,
                         e->d_status, e->d_changed, e->d_scratch};
     for (void* p : dev_ptrs) if (p) (void)hipFree(p);
@@ -575,6 +652,10 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_RC(dmalloc(e, &e->d_weights, NS * F * C));
     CREATE_RC(dmalloc(e, &e->d_wpat, NS * e->Pmax * F * C));
     CREATE_RC(dmalloc(e, &e->d_patbits, NS * e->Pmax));
+    CREATE_RC(dmalloc(e, &e->d_tid, NS * e->Np));
+    CREATE_RC(dmalloc(e, &e->d_tuple_g, NS * kMaxTuples * kMaxComponents));
+    CREATE_RC(dmalloc(e, &e->d_tuple_p, NS * (int64_t)kMaxTuples));
+    CREATE_CHK(hipMemsetAsync(e->d_tid, 0, NS * e->Np, e->stream));
     CREATE_RC(dmalloc(e, &e->d_conc, e->table_elems()));
     CREATE_RC(dmalloc(e, &e->d_unif, F * S));
     // partials: worst-case block count of the fused kernel (ft = 16, one packed step per thread)
@@ -647,7 +728,7 @@ int sbe_get_na(const sbe_engine* ce, uint8_t* out_na) {
 
 int sbe_set_option(sbe_engine* e, int option, int value) {
     CHECK_ENGINE(e);
-    if (option == SBE_OPT_MIXTURE_KERNEL && (value == SBE_MIXTURE_PACKED || value == SBE_MIXTURE_ONEHOT)) { e->opt_kernel = value; return SBE_OK; }
+    if (option == SBE_OPT_MIXTURE_KERNEL && (value == SBE_MIXTURE_PACKED || value == SBE_MIXTURE_ONEHOT || value == SBE_MIXTURE_PACKED_GENERAL || value == SBE_MIXTURE_PACKED_TUPLE)) { e->opt_kernel = value; return SBE_OK; }
     if (option == SBE_OPT_LOG_MODE && (value == SBE_LOG_PER_OBS || value == SBE_LOG_PRODUCT)) { e->opt_log = value; return SBE_OK; }
     return fail(e, SBE_ERR_ARG, "unknown option %d / value %d", option, value);
 }
@@ -1251,6 +1332,7 @@ int sbe_copy_slot(sbe_engine* e, int dst, int src) {
                              (size_t)(elems) * sizeof(*(ptr)), hipMemcpyDeviceToDevice, e->stream))
     D2D(e->d_gid, C * e->Np); D2D(e->d_pid, (int64_t)e->Np); D2D(e->d_src, N * e->Fp); D2D(e->d_counts, T); D2D(e->d_probs, T);
     D2D(e->d_probs_t, e->probs_t_elems()); D2D(e->d_wpat_t, e->wpat_t_elems());
+    D2D(e->d_tid, (int64_t)e->Np); D2D(e->d_tuple_g, (int64_t)kMaxTuples * kMaxComponents); D2D(e->d_tuple_p, (int64_t)kMaxTuples);
     D2D(e->d_weights, F * C); D2D(e->d_wpat, (int64_t)e->Pmax * F * C); D2D(e->d_patbits, (int64_t)e->Pmax);
 #undef D2D
     e->slots[dst] = e->slots[src];

@@ -18,6 +18,7 @@ namespace sbe {
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 constexpr int kMaxComponents = 8;
+constexpr int kMaxTuples = 64;
 constexpr uint16_t kNoGroup = 0xFFFF;
 constexpr uint8_t kNA = 0xFF;
 
@@ -706,6 +707,12 @@ struct Mix2Params {
     int n_ftiles, quads_per_chunk;
     int n_work, n_batch;                           // (tile, chunk) work items per slot; slots in this launch
     int slot_groups, slots_per_group;              // XCD-aware block order (see k_mixture_v2)
+    // group-tuple form (k_mixture_combo): per slot the distinct (g_0..g_{C-1}) tuples of its objects
+    const uint8_t* tid;      int64_t tid_stride;       // [Np] tuple index per object
+    const uint16_t* tuple_g; int64_t tuple_g_stride;   // [kMaxTuples][kMaxComponents] global group index (Gtot = none)
+    const uint8_t* tuple_p;  int64_t tuple_p_stride;   // [kMaxTuples] pattern id of the tuple
+    int KT;                                            // tuples used by the slots of this launch (max)
+    int combo_w_off;                                   // byte offset of the weight tile in the combo kernel's LDS
     const uint32_t* state_q;                       // [NQ][Fq]
     const uint8_t* onehot; int rs_pitch;           // [N][rs_pitch] (one-hot variant)
     const uint16_t* gid;   int64_t gid_stride;     // per slot [C][Np]
@@ -1054,6 +1061,133 @@ __global__ __launch_bounds__(kBlock) void k_mixture_onehot_v2(Mix2Params p) {
         thread_ll = sum;
     }
     const double total = block_sum(thread_ll, red4);
+    if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + work] = total;
+}
+
+// ==========================================================================================
+// Fused mixture log-likelihood, group-tuple form (default PACKED path when it applies).
+//
+// Observation (n, f) contributes log v with v = sum_c w[pat(n)][f][c] * p_c[g_c(n)][f][x(n,f)]:
+// v depends on n only through the tuple of group indices t(n) = (g_0(n), .., g_{C-1}(n)), and the
+// objects of a sample realise few distinct tuples (headline: 6 = 5 clusters + "no cluster";
+// south_america: <= 28).  The block therefore evaluates
+//        T[t][x][f] = log( sum_c w[pat(t)][f][c] * p_c[g_c(t)][f][x] )
+// once per (tuple, state, feature of its tile) -- same products, same NumPy order, same fp64 log as
+// the general kernel -- into LDS, and the per-observation work collapses to ONE conflict-free 8-byte
+// LDS gather and ONE fp64 add.  Common-subexpression elimination, not an approximation: every
+// eval still recomputes T from the slot's tables and weights (nothing is cached across evals).
+// Row x = S of every tuple holds 0.0: NA observations (state byte 0xFF, clamped to S) add log 1.
+// Eligibility (host): KT <= kMaxTuples, the image fits LDS and a block has enough observations to
+// amortise the KT*S*FT logs; otherwise the general k_mixture_v2 runs.
+// ==========================================================================================
+template <int FT, int CT>
+__global__ __launch_bounds__(kBlock) void k_mixture_combo(Mix2Params p) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ double red4[4];
+    const int unit = ((int)(blockIdx.x >> 3) / p.slots_per_group) * 8 + (int)(blockIdx.x & 7);
+    const int slot_i = (unit % p.slot_groups) * p.slots_per_group + (int)(blockIdx.x >> 3) % p.slots_per_group;
+    const int work = unit / p.slot_groups;
+    if (work >= p.n_work || slot_i >= p.n_batch) return;
+    const int slot = p.first_slot + slot_i;
+    const int tile = work % p.n_ftiles, chunk = work / p.n_ftiles;
+    const int S = p.S, S1 = p.S + 1;
+    const int C = CT ? CT : p.C;
+    constexpr int CU = CT ? CT : kMaxComponents;
+    const int q0 = chunk * p.quads_per_chunk;
+    const int q1 = min(p.NQ, q0 + p.quads_per_chunk);
+    const int nq = q1 - q0;
+    const int KT = p.KT;
+
+    double* T = reinterpret_cast<double*>(lds_raw);                       // [KT][S+1][FT]
+    uint32_t* tq = reinterpret_cast<uint32_t*>(T + (size_t)KT * S1 * FT);  // [quads_per_chunk] 4 tuple ids per quad
+
+    // ---- build the tile's log table: one entry per (tuple, state, feature) --------------------------
+    // small per-slot metadata first (tuple -> group rows / pattern, the tile's weights, tuple ids of the
+    // chunk), then the table itself with the probability loads of 4 entries in flight per thread
+    uint16_t* tgl = reinterpret_cast<uint16_t*>(tq + p.quads_per_chunk);   // [KT][CU] group row of each tuple
+    uint32_t* tpl = reinterpret_cast<uint32_t*>(tgl + (size_t)KT * CU + ((KT * CU) & 1));   // [KT] pattern id
+    double* wls = reinterpret_cast<double*>(lds_raw + p.combo_w_off);      // [P][C][FT] weights of the tile
+    {
+        const uint16_t* tg = p.tuple_g + (int64_t)slot * p.tuple_g_stride;
+        const uint8_t* tp = p.tuple_p + (int64_t)slot * p.tuple_p_stride;
+        for (int k = threadIdx.x; k < KT * CU; k += kBlock) tgl[k] = tg[(k / CU) * kMaxComponents + (k % CU)];
+        for (int k = threadIdx.x; k < KT; k += kBlock) tpl[k] = tp[k];
+        const double* wpat_t = p.wpat_t + (int64_t)slot * p.wpat_t_stride + (int64_t)tile * p.wpat_tile_stride;
+        for (int k = threadIdx.x; k < p.P * C * FT; k += kBlock) wls[k] = wpat_t[k];
+        const uint8_t* tid = p.tid + (int64_t)slot * p.tid_stride;
+        for (int k = threadIdx.x; k < nq; k += kBlock)
+            tq[k] = *reinterpret_cast<const uint32_t*>(tid + 4 * (q0 + k));
+        for (int e = threadIdx.x; e < KT * FT; e += kBlock)                 // NA row
+            T[((e / FT) * S1 + S) * FT + (e % FT)] = 0.0;
+    }
+    __syncthreads();
+    {
+        const float* probs_t = p.probs_t + (int64_t)slot * p.probs_t_stride + (int64_t)tile * ((int64_t)(p.Gtot + 1) * S * FT);
+        const int n_ent = KT * S * FT;
+        constexpr int U = 4;
+        for (int e0 = threadIdx.x; e0 < n_ent; e0 += U * kBlock) {
+            float pr[U][CU];
+            int dst[U], tt[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                                   // issue every load of the group
+                const int e = e0 + u * kBlock;
+                const int ec = e < n_ent ? e : threadIdx.x;                 // in-range stand-in, result unused
+                const int fl = ec % FT, r = ec / FT;
+                const int s = r % S, t = r / S;
+                tt[u] = t;
+                dst[u] = e < n_ent ? (t * S1 + s) * FT + fl : -1;
+#pragma unroll
+                for (int c = 0; c < CU; ++c)
+                    pr[u][c] = (CT || c < C) ? probs_t[((int64_t)tgl[t * CU + c] * S + s) * FT + fl] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (dst[u] < 0) continue;
+                const double* w = wls + tpl[tt[u]] * (uint32_t)(C * FT) + (dst[u] % FT);
+                double v = 0.0;
+#pragma unroll
+                for (int c = 0; c < CU; ++c) {
+                    if (CT || c < C) {
+                        const double term = w[c * FT] * (double)pr[u][c];
+                        v = c == 0 ? term : v + term;                       // NumPy order, no FMA
+                    }
+                }
+                T[dst[u]] = log(v);
+            }
+        }
+    }
+    __syncthreads();
+
+    constexpr int ROWS = kWave / FT;
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
+    const int fl = lane % FT, sub = lane / FT;
+    const int f = tile * FT + fl;
+    const int n_steps = (nq + 4 * ROWS - 1) / (4 * ROWS);
+    const uint32_t* sq = p.state_q + (int64_t)q0 * p.Fq + f;
+    const double* T_l = T + fl;
+    auto local_quad = [&](int k) { return (k * 4 + wid) * ROWS + sub; };
+    auto load_state = [&](int k) -> uint32_t {
+        const int i = local_quad(k);
+        const uint32_t xs = sq[(int64_t)min(i, nq - 1) * p.Fq];
+        return i < nq ? xs : 0xFFFFFFFFu;
+    };
+    double sum0 = 0.0, sum1 = 0.0;
+    uint32_t xs_next = load_state(0);
+    for (int k = 0; k < n_steps; ++k) {
+        const uint32_t xs = xs_next;
+        xs_next = load_state(k + 1);
+        uint32_t t4 = tq[min(local_quad(k), nq - 1)];
+        if (FT == kWave) t4 = __builtin_amdgcn_readfirstlane(t4);
+        double v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t x = min((xs >> (8 * j)) & 0xFFu, (uint32_t)S);   // NA (0xFF) -> zero row
+            const uint32_t t = (t4 >> (8 * j)) & 0xFFu;
+            v[j] = T_l[(t * S1 + x) * FT];
+        }
+        sum0 += v[0]; sum1 += v[1]; sum0 += v[2]; sum1 += v[3];
+    }
+    const double total = block_sum(sum0 + sum1, red4);
     if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + work] = total;
 }
 

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 
-MIXTURE_PACKED, MIXTURE_ONEHOT = 0, 1
+MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE = 0, 1, 2, 3
 LOG_PER_OBS, LOG_PRODUCT = 0, 1
 _OPT_KERNEL, _OPT_LOG = 1, 2
 

@@ -7,8 +7,8 @@ TAG=${1:-r1}
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
-BENCH="python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline"
-for kern in packed onehot; do
+BENCH="python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary"
+for kern in packed packed_general onehot; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$kern -- $BENCH --kernel $kern > $OUT/bench_$kern.json 2> $OUT/bench_$kern.err
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
@@ -17,10 +17,12 @@ for kern in packed onehot; do
 done
 # stress shape (HBM/MALL streaming regime), packed + onehot, kernel trace + FETCH_SIZE
 for kern in packed onehot; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_stress_$kern -- python3 bench.py --workload stress --batch 8 --steps 30 --warmup 5 --no-cpu-baseline --kernel $kern > $OUT/bench_stress_$kern.json 2> $OUT/bench_stress_$kern.err
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_stress_$kern -- python3 bench.py --workload stress --batch 8 --steps 30 --warmup 5 --no-cpu-baseline --kernel $kern > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_stress_$kern -- python3 bench.py --workload stress --batch 8 --steps 30 --warmup 5 --no-cpu-baseline --no-secondary --kernel $kern > $OUT/bench_stress_$kern.json 2> $OUT/bench_stress_$kern.err
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_stress_$kern -- python3 bench.py --workload stress --batch 8 --steps 30 --warmup 5 --no-cpu-baseline --no-secondary --kernel $kern > /dev/null 2>&1
 done
 if [ -x tools/fetch_calib ]; then
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_calib -- ./tools/fetch_calib > $OUT/fetch_calib.log 2>&1
 fi
+# keep the merged-back volume small: the per-dispatch traces are not needed once stats exist
+find $OUT -name '*_kernel_trace.csv' -delete; find $OUT -name '*_agent_info.csv' -delete
 ls $OUT

@@ -54,10 +54,13 @@ corr4 = 1.0 / calib["read_dword"]["reported_fraction"] if "read_dword" in calib 
 corr16 = 1.0 / calib["read_dwordx4"]["reported_fraction"] if "read_dwordx4" in calib else None
 
 traffic = {}
-for wl, batch in (("headline", 64), ("stress", 8)):
-    for kern in ("packed", "onehot"):
+for wl, batch in (("headline", 256), ("stress", 8)):
+    for kern in ("packed", "packed_general", "onehot"):
+        if wl == "stress" and kern == "packed_general":
+            continue
         suffix = kern if wl == "headline" else f"stress_{kern}"
-        prefix = "sbe::k_mixture_v2" if kern == "packed" else "sbe::k_mixture_onehot_v2"
+        prefix = {"packed": "sbe::k_mixture_combo" if wl == "headline" else "sbe::k_mixture_v2",
+                  "packed_general": "sbe::k_mixture_v2", "onehot": "sbe::k_mixture_onehot_v2"}[kern]
         entry = {}
         fetch = dominant(counters(f"pmc_fetch_{suffix}"), prefix)
         write = dominant(counters(f"pmc_write_{suffix}"), prefix) if wl == "headline" else {}
