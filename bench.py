@@ -162,6 +162,11 @@ def secondary_figures(eng, wl, B, args):
         eng.set_weights(0, wl.weights)
         return eng.mixture_loglik(0)
     out["pcie_inclusive_evals_per_s"] = round(_rate(pcie_eval), 1)
+    # cluster-membership marginals of all available objects of one cluster
+    available = np.flatnonzero((~wl.clusters.any(axis=0)) | wl.clusters[0])
+    table = probs0[0]
+    out["f1_cluster_marginals_calls_per_s"] = round(_rate(lambda: eng.cluster_marginals(0, table, available)), 1)
+    out["f1_cluster_marginals_objects"] = int(available.size)
     return out
 
 

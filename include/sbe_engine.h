@@ -206,6 +206,19 @@ int sbe_effect_counts(sbe_engine* e, const uint8_t* groups /* [G][N] bool */, in
 int sbe_normalize_weights(sbe_engine* e, const float* weights /* [F][C] */, int n_comp,
                           const uint8_t* has_components /* [N][C] bool */, float* out /* [N][F][C] */);
 
+/* ---- cluster-membership marginals --------------------------------------
+ * AlterCluster.compute_cluster_posterior (sbayes/sampling/operators.py:1035-1073) and
+ * AlterClusterWide.compute_raw_cluster_probs (:1420-1472), the data-parallel part: for every
+ * listed (available) object and z in {0,1}
+ *     out[z][i] = log prod_f sum_c lh_c(n_i, f) * w_z(n_i)[f][c]
+ * where lh_0 comes from `table` (candidate cluster effect, float32 [F][S]), lh_{c>=1} from the
+ * slot's probability tables, NA observations count 1, and w_0 / w_1 are the weights of
+ * compute_feature_weights_with_and_without (:1075-1095) built from the slot's weights, its
+ * has_components and `prior_temperature`.  Log space: no underflow at large F.
+ * The caller applies ** (1/temperature), the geo-prior factor and the normalisation. */
+int sbe_cluster_marginals(sbe_engine* e, int slot, const float* table /* [F][S] */, const int32_t* objects,
+                          int n_objects_av, double prior_temperature, double* out /* [2][n_objects_av] */);
+
 /* ---- slot management -------------------------------------------------------------------- */
 int sbe_copy_slot(sbe_engine* e, int dst_slot, int src_slot);
 

@@ -271,3 +271,72 @@ def mixture_loglik(features, na_values, groups_by_component, counts_by_component
     w = normalize_weights(weights, has_components(groups_by_component))
     with np.errstate(divide="ignore"):
         return np.log(mixture_observation_lh(w, lh))[~na_values].sum()
+
+
+# --------------------------------------------------------------------------------------
+# cluster-membership posterior
+#     sbayes/sampling/operators.py:1035-1095 (AlterCluster.compute_cluster_posterior,
+#     compute_feature_weights_with_and_without), :1420-1472 (AlterClusterWide.compute_raw_cluster_probs)
+# --------------------------------------------------------------------------------------
+def feature_weights_with_and_without(weights, has_comp, available, prior_temperature=1.0):
+    """float64 [2, n_available, F, C]: normalised weights of every available object if it were
+    outside (z=0) / inside (z=1) a cluster (operators.py:1075-1095)."""
+    w_cur = normalize_weights(weights, has_comp)[available]
+    w_cur = normalize(w_cur ** (1 / prior_temperature), axis=-1)
+    hc = has_comp[available].copy()
+    hc[:, 0] = ~hc[:, 0]
+    w_flip = normalize_weights(weights ** (1 / prior_temperature), hc)
+    out = np.empty((2, *w_cur.shape))
+    out[1] = np.where(hc[:, np.newaxis, [0]], w_flip, w_cur)
+    out[0] = np.where(hc[:, np.newaxis, [0]], w_cur, w_flip)
+    return out
+
+
+def cluster_marginals(features, na_values, lh_per_component, table, available, weights_z01, lh_exponent=None):
+    """float64 [2, n_available]: prod_f sum_c lh[n,f,c] * w_z[n,f,c] with the cluster component's
+    likelihood replaced by the candidate table's (operators.py:1054-1061 / 1444-1451)."""
+    cluster_lh = np.einsum("...i,...i", features[available], table)
+    if lh_exponent is not None:
+        cluster_lh = cluster_lh ** lh_exponent
+    all_lh = lh_per_component[available].copy()
+    all_lh[..., 0] = cluster_lh
+    all_lh[na_values[available], 0] = 1.0
+    feature_lh = np.einsum("...i,...i", all_lh[np.newaxis, ...], weights_z01)
+    return np.prod(feature_lh, axis=-1)
+
+
+def cluster_posterior(features, na_values, groups_by_component, counts_by_component, concentration_by_component,
+                      weights, i_cluster, available, unif_counts, temperature=1.0, prior_temperature=1.0,
+                      additive_smoothing=1e-6, geo_likelihoods=None):
+    """AlterCluster.compute_cluster_posterior (gibbsish, operators.py:1035-1073)."""
+    table = conditional_effect_mean(concentration_by_component[0], counts_by_component[0][[i_cluster]],
+                                    unif_counts=unif_counts, prior_temperature=prior_temperature,
+                                    temperature=temperature)
+    lh = likelihood_per_component(features, na_values, groups_by_component, counts_by_component,
+                                  concentration_by_component)
+    wz = feature_weights_with_and_without(weights, has_components(groups_by_component), available, prior_temperature)
+    m = cluster_marginals(features, na_values, lh, table, available, wz) ** (1 / temperature)
+    if geo_likelihoods is not None:
+        m[1] *= geo_likelihoods
+    post = m[1] / (m[0] + m[1])
+    if additive_smoothing > 0:
+        post = (post + additive_smoothing) / (1 + 2 * additive_smoothing)
+    return post
+
+
+def wide_raw_cluster_probs(features, na_values, groups_by_component, counts_by_component, concentration_by_component,
+                           weights, i_cluster, available, unif_counts, temperature=1.0, prior_temperature=1.0,
+                           geo_prior_ratio=None):
+    """AlterClusterWide.compute_raw_cluster_probs with the `gibbs` effect proposal
+    (operators.py:1254-1282, 1420-1472)."""
+    eps = np.finfo(FLOAT_TYPE).eps
+    c = unif_counts + (concentration_by_component[0] - unif_counts) / prior_temperature \
+        + counts_by_component[0][[i_cluster]] / temperature
+    table = normalize(c, axis=-1)
+    lh = likelihood_per_component(features, na_values, groups_by_component, counts_by_component,
+                                  concentration_by_component)
+    wz = feature_weights_with_and_without(weights, has_components(groups_by_component), available, prior_temperature)
+    m = cluster_marginals(features, na_values, lh, table, available, wz, lh_exponent=1 / temperature) ** (1 / temperature)
+    if geo_prior_ratio is not None:
+        m[1] *= geo_prior_ratio
+    return m[1] / (m[0] + m[1] + eps)

@@ -1321,6 +1321,46 @@ int sbe_normalize_weights(sbe_engine* e, const float* weights, int n_comp, const
     return d2h(e, out, d_out, (size_t)n_out * sizeof(float));
 }
 
+// ---- cluster-membership marginals ---------------------------------------------
+int sbe_cluster_marginals(sbe_engine* e, int slot, const float* table, const int32_t* objects, int n_objects_av,
+                          double prior_temperature, double* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, table); CHECK_PTR(e, out);
+    if (n_objects_av < 0) return fail(e, SBE_ERR_ARG, "n_objects_av=%d", n_objects_av);
+    if (n_objects_av == 0) return SBE_OK;
+    CHECK_PTR(e, objects);
+    if (!(prior_temperature > 0.0)) return fail(e, SBE_ERR_ARG, "prior_temperature must be positive");
+    for (int i = 0; i < n_objects_av; ++i)
+        if (objects[i] < 0 || objects[i] >= e->N) return fail(e, SBE_ERR_ARG, "object index %d out of range", objects[i]);
+    int rc = check_slot_ready(e, slot, true);
+    if (rc) return rc;
+    HIPCHK(e, hipSetDevice(e->device));
+    Slot& s = e->slots[slot];
+    if (s.patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
+    const int P = (int)s.patterns.size(), F = e->F, S = e->S, C = e->C;
+    const size_t tb = ((size_t)F * S * sizeof(float) + 255) / 256 * 256;
+    const size_t wb = ((size_t)P * F * C * sizeof(float) + 255) / 256 * 256;
+    const size_t ob = ((size_t)n_objects_av * sizeof(int32_t) + 255) / 256 * 256;
+    rc = ensure_scratch(e, tb + 2 * wb + ob + (size_t)2 * n_objects_av * sizeof(double));
+    if (rc) return rc;
+    float* d_tab = (float*)e->d_scratch;
+    float* d_wc = (float*)(e->d_scratch + tb);
+    float* d_wf = (float*)(e->d_scratch + tb + wb);
+    int32_t* d_obj = (int32_t*)(e->d_scratch + tb + 2 * wb);
+    double* d_out = (double*)(e->d_scratch + tb + 2 * wb + ob);
+    HIPCHK(e, hipMemcpyAsync(d_tab, table, (size_t)F * S * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(d_obj, objects, (size_t)n_objects_av * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    const double inv = 1.0 / prior_temperature;
+    k_weight_tables_z<<<div_up((int64_t)P * F, 256), 256, 0, e->stream>>>(
+        e->d_weights + (int64_t)slot * F * C, e->d_patbits + (int64_t)slot * e->Pmax, d_wc, d_wf, P, F, C,
+        (float)inv, inv != 1.0 ? 1 : 0);
+    HIPCHK(e, hipGetLastError());
+    k_cluster_marginals<<<div_up(n_objects_av, kBlock / kWave), kBlock, 0, e->stream>>>(
+        e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np,
+        e->d_probs + (int64_t)slot * e->table_elems(), d_tab, d_wc, d_wf, d_obj, n_objects_av, d_out, e->Np, F, S, C, e->Fp);
+    HIPCHK(e, hipGetLastError());
+    return d2h(e, out, d_out, (size_t)2 * n_objects_av * sizeof(double));
+}
+
 // ---- slots ------------------------------------------------------------------------------------------
 int sbe_copy_slot(sbe_engine* e, int dst, int src) {
     CHECK_ENGINE(e); CHECK_SLOT(e, dst); CHECK_SLOT(e, src);

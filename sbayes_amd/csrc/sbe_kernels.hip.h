@@ -1191,6 +1191,81 @@ __global__ __launch_bounds__(kBlock) void k_mixture_combo(Mix2Params p) {
     if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + work] = total;
 }
 
+// ==========================================================================================
+// cluster-membership marginals
+//   (operators.py:1035-1095 AlterCluster.compute_cluster_posterior / compute_feature_weights_
+//    with_and_without, operators.py:1420-1472 AlterClusterWide.compute_raw_cluster_probs)
+// For every available object n and z in {0 = outside, 1 = inside the cluster}:
+//     log m_z(n) = sum_f log sum_c lh_c(n,f) * w_z(n)[f][c]
+// with lh_0 taken from the candidate cluster table, lh_{c>=1} from the slot's tables, NA -> 1.
+// The reference multiplies in linear space (np.prod) and underflows beyond F ~ 300 (SURVEY.md
+// H5); the sums of logs here do not, and exp() of them reproduces the reference's products to
+// ~1e-14 relative where those exist.
+// ==========================================================================================
+// per-pattern weight tables of compute_feature_weights_with_and_without (operators.py:1075-1095):
+//   wcur  = normalize( normalize_weights(weights, pattern) ** (1/T_prior) )
+//   wflip = normalize_weights( weights ** (1/T_prior), pattern with the cluster bit flipped )
+// float32 throughout, NumPy reduction order; x ** 1.0 is exact, other exponents go through powf.
+__global__ void k_weight_tables_z(const float* __restrict__ weights, const uint32_t* __restrict__ pattern_bits,
+                                  float* __restrict__ wcur, float* __restrict__ wflip, int P, int F, int C,
+                                  float inv_tp, int use_pow) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * F) return;
+    const int p = i / F, f = i % F;
+    const uint32_t bits = pattern_bits[p], fbits = bits ^ 1u;
+    const float* w = weights + (int64_t)f * C;
+    auto masked = [&](int c) -> float { return ((bits >> c) & 1u) ? w[c] : 0.0f * w[c]; };
+    const float tot = np_pairwise_sum<float>(masked, C);
+    auto powd = [&](int c) -> float { const float a = masked(c) / tot; return use_pow ? powf(a, inv_tp) : a; };
+    const float tot2 = np_pairwise_sum<float>(powd, C);
+    auto fl = [&](int c) -> float {
+        const float pw = use_pow ? powf(w[c], inv_tp) : w[c];
+        return ((fbits >> c) & 1u) ? pw : 0.0f * pw;
+    };
+    const float tot3 = np_pairwise_sum<float>(fl, C);
+    float* oc = wcur + ((int64_t)p * F + f) * C;
+    float* of = wflip + ((int64_t)p * F + f) * C;
+    for (int c = 0; c < C; ++c) { oc[c] = powd(c) / tot2; of[c] = fl(c) / tot3; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_cluster_marginals(
+    const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid, const uint8_t* __restrict__ pid,
+    const float* __restrict__ probs, const float* __restrict__ table0, const float* __restrict__ wcur,
+    const float* __restrict__ wflip, const int32_t* __restrict__ objects, int n_av, double* __restrict__ out,
+    int Np, int F, int S, int C, int Fp) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int i = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);        // one wave per available object
+    if (i >= n_av) return;
+    const int n = objects[i];
+    const bool inside = gid[n] != kNoGroup;                                  // component 0 = clusters
+    const int p = pid[n];
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int f = lane; f < F; f += kWave) {
+        const uint8_t x = state[(int64_t)n * Fp + f];
+        const float* wc = wcur + ((int64_t)p * F + f) * C;
+        const float* wf = wflip + ((int64_t)p * F + f) * C;
+        double v0 = 0.0, v1 = 0.0;
+        for (int c = 0; c < C; ++c) {
+            double lh = 1.0;
+            if (x != kNA) {
+                if (c == 0) lh = (double)table0[(int64_t)f * S + x];
+                else {
+                    const uint16_t gg = gid[(int64_t)c * Np + n];
+                    lh = gg == kNoGroup ? 0.0 : (double)probs[((int64_t)gg * F + f) * S + x];
+                }
+            }
+            const double a = (double)wc[c], b = (double)wf[c];
+            v1 = v1 + lh * (inside ? a : b);         // z = 1: the object is (or becomes) a cluster member
+            v0 = v0 + lh * (inside ? b : a);
+        }
+        acc0 += log(v0);
+        acc1 += log(v1);
+    }
+    acc0 = wave_sum(acc0);
+    acc1 = wave_sum(acc1);
+    if (lane == 0) { out[i] = acc0; out[(int64_t)n_av + i] = acc1; }
+}
+
 // canonical probs [Gtot][F][S] -> tile-transposed probs_t [n_ftiles][Gtot+1][S][FT] for the
 // groups [g_lo, g_hi).  Row Gtot and features >= F stay zero (set once at creation).
 __global__ void k_tile_probs(const float* __restrict__ probs, float* __restrict__ probs_t, int g_lo,

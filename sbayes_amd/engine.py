@@ -364,6 +364,18 @@ class Engine:
         self._check(self._lib.sbe_normalize_weights(self._h, _ptr(w), w.shape[1], _ptr(hc), _ptr(out)))
         return out
 
+    def cluster_marginals(self, slot, table, objects, prior_temperature=1.0):
+        """float64 [2, n]: log marginal likelihood of each listed object outside (z=0) / inside (z=1)
+        the cluster whose candidate effect table is `table` [F, S] (operators.py:1035-1095)."""
+        t = _c(table, np.float32).reshape(-1, self.n_states)
+        if t.shape != (self.n_features, self.n_states):
+            raise ValueError(f"table must be [{self.n_features}, {self.n_states}] (or [1, F, S])")
+        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        out = np.empty((2, objs.size), dtype=np.float64)
+        self._check(self._lib.sbe_cluster_marginals(self._h, slot, _ptr(t), _ptr(objs), objs.size,
+                                                    float(prior_temperature), _ptr(out)))
+        return out
+
     def copy_slot(self, dst, src):
         self._check(self._lib.sbe_copy_slot(self._h, dst, src))
 

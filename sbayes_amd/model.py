@@ -12,8 +12,12 @@ from .state import Confounder, Features, ModelShapes, Sample
 
 
 class ClusterEffectPrior:
-    def __init__(self, concentration_array):
+    def __init__(self, concentration_array, uniform_concentration_array=None):
         self.concentration_array = np.asarray(concentration_array, dtype=np.float64)
+        # symmetric concentration 1.0 on applicable states (prior.py:184-186)
+        self.uniform_concentration_array = (
+            np.asarray(uniform_concentration_array, dtype=np.float64) if uniform_concentration_array is not None
+            else (self.concentration_array > 0).astype(np.float64))
 
 
 class ConfoundingEffectsPrior:

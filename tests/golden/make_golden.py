@@ -275,6 +275,45 @@ def stage_config(src_dir: Path, dst_name: str, edits=None) -> Path:
     return dst
 
 
+def cluster_posterior_case(model, data, sample, mcmc_cfg):
+    """the reference's cluster-membership posterior
+    (operators.py:1035-1095 AlterCluster.compute_cluster_posterior and operators.py:1420-1472
+    AlterClusterWide.compute_raw_cluster_probs) on the fixture's sample, plain and tempered."""
+    from sbayes.sampling.operators import get_operator_schedule
+    from sbayes.util import inner1d
+    out = {}
+    uni = np.asarray(model.prior.prior_cluster_effect.uniform_concentration_array, dtype=np.float64)
+    out["cp_unif"] = uni
+    for tag, (temp, ptemp) in {"t1": (1.0, 1.0), "mc3": (1.3, 1.5)}.items():
+        ops = get_operator_schedule(mcmc_cfg.operators, model, data, temperature=temp,
+                                    prior_temperature=ptemp, sample_from_prior=False)
+        gib, wide = ops["cluster_gibbsish"], ops["gibbsish_sample_cluster_wide_geo"]
+        assert not gib.consider_geo_prior
+        wide.consider_geo_prior = False          # geo prior is 'uniform' in the golden configs
+        for i_cluster in range(sample.n_clusters):
+            available = gib.available(sample, i_cluster)
+            post = gib.compute_cluster_posterior(sample, i_cluster, available)
+            raw = wide.compute_raw_cluster_probs(sample, i_cluster, available)
+            key = f"cp_{tag}_k{i_cluster}"
+            out[key + "_available"] = available
+            out[key + "_posterior"] = np.asarray(post, dtype=np.float64)
+            out[key + "_wide_raw"] = np.asarray(raw, dtype=np.float64)
+            if i_cluster == 0:
+                wz = gib.compute_feature_weights_with_and_without(sample, available)
+                p = conditional_effect_mean(
+                    prior_counts=model.prior.prior_cluster_effect.concentration_array,
+                    feature_counts=sample.feature_counts["clusters"].value[[i_cluster]],
+                    unif_counts=uni, prior_temperature=ptemp, temperature=temp)
+                all_lh = likelihood_per_component(model, sample, caching=True)[available, :].copy()
+                all_lh[..., 0] = inner1d(data.features.values[available], p)
+                all_lh[data.features.na_values[available], 0] = 1.0
+                out[key + "_weights_z01"] = wz
+                out[key + "_table"] = p
+                out[key + "_marginal_z01"] = np.prod(inner1d(all_lh[np.newaxis, ...], wz), axis=-1)
+    out["cp_additive_smoothing"] = np.float64(gib.additive_smoothing)
+    return out
+
+
 def real_fixture(tag: str, config_path: Path, n_trace_steps: int, seed: int):
     from sbayes.experiment_setup import Experiment
     from sbayes.sampling.initializers import SbayesInitializer
@@ -303,6 +342,7 @@ def real_fixture(tag: str, config_path: Path, n_trace_steps: int, seed: int):
         extra = {}
         extra.update(partial_update_case(model, sample, rng))
         extra.update(delta_counts_case(model, sample, rng))
+        extra.update(cluster_posterior_case(model, data, sample, mcmc_cfg))
         meta = dict(name=tag, shape=list(data.features.values.shape),
                     component_names=sample.component_names,
                     groups=[int(sample.n_groups(k)) for k in sample.component_names], **scal, **dig)

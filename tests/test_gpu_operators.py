@@ -1,0 +1,78 @@
+"""SURVEY.md 8(f) rank 1 on the device: cluster-membership posterior (AlterCluster /
+AlterClusterWide cores) against the reference operators' recorded outputs and the oracle.
+Tolerance 1e-12 relative at temperature 1 (log-space accumulation + exp vs the reference's linear
+np.prod; einsum/FMA order of the host NumPy is not part of the contract); 2e-6 for tempered runs
+(float32 powf of the device vs glibc)."""
+import numpy as np
+import pytest
+
+from oracle import sbayes_oracle as orc
+from sbayes_amd import model as sbm
+from sbayes_amd.counts import recalculate_feature_counts
+from sbayes_amd.operators import compute_cluster_posterior, compute_raw_cluster_probs
+from sbayes_amd.registry import release_all
+from sbayes_amd.synthetic import make_workload
+from tests._fixtures import load_npz
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _fresh_engines():
+    yield
+    release_all()
+
+
+@pytest.mark.parametrize("name", ["south_america", "test_files"])
+def test_cluster_posterior_matches_reference_operators(name):
+    fx = load_npz(name)
+    z = fx.z
+    names = fx.meta["component_names"]
+    model, sample = sbm.build(fx.features, fx.states_per_feature, names, fx.groups, fx.conc, fx.weights, fx.source,
+                              counts=fx.counts)
+    model.prior.prior_cluster_effect.uniform_concentration_array = z["cp_unif"]
+    smoothing = float(z["cp_additive_smoothing"])
+    for tag, (temp, ptemp, rtol) in {"t1": (1.0, 1.0, 1e-12), "mc3": (1.3, 1.5, 2e-6)}.items():
+        for k in range(fx.groups[0].shape[0]):
+            key = f"cp_{tag}_k{k}"
+            available = z[key + "_available"]
+            post = compute_cluster_posterior(model, sample, k, available, temperature=temp, prior_temperature=ptemp,
+                                             additive_smoothing=smoothing)
+            np.testing.assert_allclose(post, z[key + "_posterior"], rtol=rtol, atol=1e-300)
+            raw = compute_raw_cluster_probs(model, sample, k, available, temperature=temp, prior_temperature=ptemp)
+            np.testing.assert_allclose(raw, z[key + "_wide_raw"], rtol=rtol, atol=1e-300)
+            if k == 0 and tag == "t1":
+                log_m = model.likelihood.engine.cluster_marginals(0, z[key + "_table"], np.flatnonzero(available))
+                np.testing.assert_allclose(np.exp(log_m), z[key + "_marginal_z01"], rtol=1e-12)
+
+
+def test_cluster_posterior_large_feature_count_does_not_underflow():
+    """at the stress shape the reference's np.prod underflows to 0/0 = NaN; the
+    log-space device result stays finite and agrees with a log-space evaluation of the oracle."""
+    wl = make_workload("stress", shape=(300, 500, 20, 4, (20,), False))
+    model, sample = sbm.build(wl.features, wl.states_per_feature, wl.component_names, wl.groups, wl.concentration,
+                              wl.weights, wl.source)
+    feats = model.data.features.values
+    recalculate_feature_counts(feats, sample)
+    counts = [sample.feature_counts[k].value for k in sample.component_names]
+    available = (~wl.clusters.any(axis=0)) | wl.clusters[1]
+    unif = wl.states_per_feature.astype(float)
+    post = compute_cluster_posterior(model, sample, 1, available)
+    assert np.all(np.isfinite(post)) and np.all((post > 0) & (post < 1))
+    # oracle in log space: same weights / likelihood arrays, sum of logs instead of np.prod
+    table = orc.conditional_effect_mean(wl.concentration[0], counts[0][[1]], unif_counts=unif,
+                                        prior_temperature=1.0, temperature=1.0)
+    lh = orc.likelihood_per_component(wl.features, wl.na_values, wl.groups, counts, wl.concentration)
+    wz = orc.feature_weights_with_and_without(wl.weights, orc.has_components(wl.groups), available, 1.0)
+    cl = np.einsum("...i,...i", wl.features[available], table)
+    all_lh = lh[available].copy()
+    all_lh[..., 0] = cl
+    all_lh[wl.na_values[available], 0] = 1.0
+    log_m = np.log(np.einsum("...i,...i", all_lh[None], wz)).sum(axis=-1)
+    want = 1.0 / (1.0 + np.exp(log_m[0] - log_m[1]))
+    want = (want + 1e-6) / (1 + 2e-6)
+    np.testing.assert_allclose(post, want, rtol=1e-10)
+    with np.errstate(all="ignore"):
+        linear = orc.cluster_posterior(wl.features, wl.na_values, wl.groups, counts, wl.concentration, wl.weights,
+                                       1, available, unif)
+    assert not np.all(np.isfinite(linear))          # the reference's linear-space form breaks here
