@@ -42,7 +42,13 @@ def init_process_group(backend=None):
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend)
+        try:
+            dist.init_process_group(backend=backend)
+        except Exception as exc:          # the data path has no collective: gloo serves the barrier equally
+            if backend == "gloo":
+                raise
+            print(f"[chains] {backend} init failed ({exc}); falling back to gloo", flush=True)
+            dist.init_process_group(backend="gloo")
     return dist
 
 

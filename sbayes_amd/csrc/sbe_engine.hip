@@ -277,36 +277,12 @@ int retile_probs(sbe_engine* e, int slot, int component) {
 struct MixGeom {
     int ft, ft_shift, n_ftiles, objs_per_chunk, n_chunks, n_blocks;
     size_t lds_bytes;
-    bool v2;
 };
-
-// v1 geometry (one-hot variant and the per-observation output mode)
-MixGeom mix_geometry_v1(const sbe_engine* e, int P, int n_batch) {
-    MixGeom g{};
-    const size_t budget = 64 * 1024, hard = 150 * 1024;
-    int ft = 64;
-    auto lds_for = [&](int t) { return ((size_t)e->Gtot * t * e->S + (size_t)P * t * e->C) * sizeof(float); };
-    while (ft > 16 && lds_for(ft) > budget) ft >>= 1;
-    if (lds_for(ft) > hard) ft = 0;
-    g.ft = ft;
-    if (!ft) return g;
-    g.ft_shift = ft == 64 ? 6 : ft == 32 ? 5 : 4;
-    g.n_ftiles = div_up(e->F, ft);
-    g.lds_bytes = lds_for(ft);
-    const int64_t target_blocks = (int64_t)4 * e->compute_units;
-    int64_t chunks = std::max<int64_t>(1, target_blocks / ((int64_t)g.n_ftiles * std::max(1, n_batch)));
-    const int min_objs = std::max(1, kBlock / (ft / 4));
-    g.objs_per_chunk = std::max<int>(min_objs, div_up(e->N, chunks));
-    g.n_chunks = div_up(e->N, g.objs_per_chunk);
-    g.n_blocks = g.n_chunks * g.n_ftiles;
-    return g;
-}
 
 // v2 geometry: chunks of object quads; one wave step = 64/ft quads.  The chunk's ids are staged
 // in LDS (8*C + 4 bytes per quad), which caps the chunk length.
 MixGeom mix_geometry_v2(const sbe_engine* e, int P, int n_batch) {
     MixGeom g{};
-    g.v2 = true;
     g.ft = e->ft;
     g.n_ftiles = e->n_ftiles;
     const int64_t target_blocks = (int64_t)4 * e->compute_units;
@@ -334,11 +310,6 @@ int check_slot_ready(sbe_engine* e, int slot, bool need_weights) {
         if (!s.probs_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: probability tables of component %d not set", slot, c);
     if (need_weights && !s.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: weights not set", slot);
     return SBE_OK;
-}
-
-template <int MODE, bool ONEHOT>
-void launch_v1(const MixParams& p, dim3 grid, size_t lds, hipStream_t st) {
-    k_mixture<MODE, ONEHOT><<<grid, kBlock, lds, st>>>(p);
 }
 
 template <int MODE, int FT>
@@ -395,12 +366,11 @@ void launch_v2(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStr
 }
 
 // Enqueue the dominant kernel (optionally bracketed by an event pair) and the fixed-order
-// partial reduction.  mode: LOG_PER_OBS / LOG_PRODUCT / WRITE_OBS.
-int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, double* d_obs, hipEvent_t ev_a, hipEvent_t ev_b) {
+// partial reduction.  mode: LOG_PER_OBS / LOG_PRODUCT.
+int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev_a, hipEvent_t ev_b) {
     const int P = max_patterns(e, first_slot, n);
     const bool onehot = e->opt_kernel == SBE_MIXTURE_ONEHOT;
-    const bool v2 = mode != WRITE_OBS;
-    MixGeom g = v2 ? mix_geometry_v2(e, P, n) : mix_geometry_v1(e, P, n);
+    MixGeom g = mix_geometry_v2(e, P, n);
     if (!g.ft) return fail(e, SBE_ERR_ARG, "probability tables too large for LDS staging (G_total=%d, S=%d)", e->Gtot, e->S);
     if (g.n_blocks > e->partials_stride) return fail(e, SBE_ERR_STATE, "internal: partials buffer too small (%d > %lld)", g.n_blocks, (long long)e->partials_stride);
     if (g.lds_bytes > 159 * 1024)
@@ -408,7 +378,7 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, double* d_obs
                     g.ft, g.lds_bytes, e->Gtot, e->S, P);
     dim3 grid(g.n_blocks, n);
     if (ev_a) HIPCHK(e, hipEventRecord(ev_a, e->stream));
-    if (v2) {
+    {
         // XCD-aware 1-D grid (see k_mixture_v2): units = work items x slot groups, unit u on XCD u % 8
         int gcd8 = 8;
         while (g.n_blocks % gcd8) gcd8 >>= 1;
@@ -460,39 +430,22 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, double* d_obs
             else launch_oh2<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
         } else if (mode == LOG_PRODUCT) launch_v2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
         else launch_v2<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
-    } else {
-        MixParams p{};
-        p.N = e->N; p.Np = e->Np; p.F = e->F; p.S = e->S; p.C = e->C; p.Fp = e->Fp; p.rs_pitch = e->rs_pitch;
-        p.Gtot = e->Gtot; p.P = P;
-        p.ft = g.ft; p.ft_shift = g.ft_shift; p.n_ftiles = g.n_ftiles; p.n_chunks = g.n_chunks;
-        p.objs_per_chunk = g.objs_per_chunk;
-        p.s_magic = (uint32_t)(((1u << 24) + e->S - 1) / e->S);
-        p.state = e->d_state; p.onehot = e->d_onehot;
-        p.gid = e->d_gid; p.gid_stride = (int64_t)e->C * e->Np;
-        p.pid = e->d_pid; p.pid_stride = e->Np;
-        p.probs = e->d_probs; p.probs_stride = e->table_elems();
-        p.wpat = e->d_wpat; p.wpat_stride = (int64_t)e->Pmax * e->F * e->C;
-        p.partials = e->d_partials; p.partials_stride = e->partials_stride;
-        p.obs = d_obs; p.first_slot = first_slot;
-        launch_v1<WRITE_OBS, false>(p, grid, g.lds_bytes, e->stream);
     }
     if (ev_b) HIPCHK(e, hipEventRecord(ev_b, e->stream));
     HIPCHK(e, hipGetLastError());
-    if (mode != WRITE_OBS) {
-        k_reduce_partials<<<n, kBlock, 0, e->stream>>>(e->d_partials, e->partials_stride, g.n_blocks,
-                                                      e->d_results, first_slot);
-        HIPCHK(e, hipGetLastError());
-    }
+    k_reduce_partials<<<n, kBlock, 0, e->stream>>>(e->d_partials, e->partials_stride, g.n_blocks,
+                                                  e->d_results, first_slot);
+    HIPCHK(e, hipGetLastError());
     return SBE_OK;
 }
 
-int enqueue_mixture(sbe_engine* e, int first_slot, int n, int mode, double* d_obs) {
+int enqueue_mixture(sbe_engine* e, int first_slot, int n, int mode) {
     for (int s = first_slot; s < first_slot + n; ++s) {
         int rc = check_slot_ready(e, s, true);
         if (rc) return rc;
         if (e->slots[s].patterns_dirty) { rc = upload_patterns_and_weights(e, s); if (rc) return rc; }
     }
-    return launch_mixture(e, first_slot, n, mode, d_obs, nullptr, nullptr);
+    return launch_mixture(e, first_slot, n, mode, nullptr, nullptr);
 }
 
 int counts_launch(sbe_engine* e, int slot_a, int sign_a, int slot_b, int sign_b, const int32_t* d_objects,
@@ -1105,12 +1058,18 @@ int sbe_likelihood_per_component_exact(sbe_engine* e, int slot, double* out) {
 
 int sbe_observation_lh(sbe_engine* e, int slot, double* out) {
     CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, out);
+    int rc = check_slot_ready(e, slot, true);
+    if (rc) return rc;
     HIPCHK(e, hipSetDevice(e->device));
+    if (e->slots[slot].patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
     const int64_t n = (int64_t)e->N * e->F;
-    int rc = ensure_scratch(e, n * sizeof(double));
+    rc = ensure_scratch(e, n * sizeof(double));
     if (rc) return rc;
-    rc = enqueue_mixture(e, slot, 1, WRITE_OBS, (double*)e->d_scratch);
-    if (rc) return rc;
+    k_observation_lh<<<div_up(n, 256), 256, 0, e->stream>>>(
+        e->d_state, e->d_gid + (int64_t)slot * e->C * e->Np, e->d_pid + (int64_t)slot * e->Np,
+        e->d_probs + (int64_t)slot * e->table_elems(), e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C,
+        (double*)e->d_scratch, e->N, e->Np, e->F, e->S, e->C, e->Fp);
+    HIPCHK(e, hipGetLastError());
     return d2h(e, out, e->d_scratch, n * sizeof(double));
 }
 
@@ -1119,7 +1078,7 @@ int sbe_mixture_loglik_batch_async(sbe_engine* e, int first_slot, int n) {
     CHECK_ENGINE(e); CHECK_SLOT(e, first_slot);
     if (n < 1 || first_slot + n > e->n_slots) return fail(e, SBE_ERR_ARG, "slot range [%d,%d) out of range", first_slot, first_slot + n);
     HIPCHK(e, hipSetDevice(e->device));
-    return enqueue_mixture(e, first_slot, n, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr);
+    return enqueue_mixture(e, first_slot, n, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS);
 }
 
 int sbe_fetch_results(sbe_engine* e, int first_slot, int n, double* out) {
@@ -1407,12 +1366,12 @@ int sbe_profile_mixture(sbe_engine* e, int first_slot, int n, int iters, float* 
         e->ev_pool.push_back(ev);
     }
     const int mode = e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS;
-    int rc = enqueue_mixture(e, first_slot, n, mode, nullptr);     // resolves lazily-built state
+    int rc = enqueue_mixture(e, first_slot, n, mode);     // resolves lazily-built state
     if (rc) return rc;
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
     for (int it = 0; it < iters; ++it) {
-        rc = launch_mixture(e, first_slot, n, mode, nullptr, e->ev_pool[2 * it], e->ev_pool[2 * it + 1]);
+        rc = launch_mixture(e, first_slot, n, mode, e->ev_pool[2 * it], e->ev_pool[2 * it + 1]);
         if (rc) return rc;
     }
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));

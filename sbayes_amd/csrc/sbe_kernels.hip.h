@@ -464,213 +464,37 @@ __global__ void k_group_sum_f32(const float* __restrict__ per_feature, double* _
 }
 
 // ------------------------------------------------------------------------------------------
-// THE north-star kernel: fused a3 + a5 + a6 + log + reduce.
-//
-//   LL = sum_{n,f not NA} log sum_c w[pat(n)][f][c] * p_c[g_c(n)][f][x(n,f)]
-//
-// Work decomposition: a block owns a tile of `ft` features x one chunk of objects.
-//   LDS: tab[Gtot][ft][S] float32 probability rows of the tile's features for every group of
-//        every component (the "LDS-staged per-feature state probabilities"), and
-//        wl[P][ft][C] float32 normalised weight rows.
-//   Streamed operand (coalesced, read exactly once per eval):
-//        PACKED : state index bytes, one dword (4 observations) per lane per step
-//        ONEHOT : the one-hot block as handed over, 16 bytes per lane per step; set bytes are
-//                 located with bit tricks, byte offset j in the tile row indexes tab directly.
-//   Per observation: C LDS gathers + C weight reads, C fp64 multiplies, fp64 adds in NumPy
-//   order, then the log accumulation.
-//   Reduction: per-thread partial -> wave64 shuffle tree -> 4 partials through LDS -> one
-//   double per block -> k_reduce_partials sums them in fixed order (deterministic).
-//
-// Log accumulation modes:
-//   LOG_PER_OBS : acc += log(v)                       (fp64 log per observation)
-//   LOG_PRODUCT : mantissa product m *= v with the exponent stripped into an integer after
-//                 every multiply; one fp64 log per thread at the end.  v <= 0 or NaN falls
-//                 back to the per-observation log so -inf / NaN propagate like NumPy's.
-//   WRITE_OBS   : no reduction; v is written to obs[N][F] (a6, loggers.py:355-357); NA
-//                 observations get sum_c w (the reference multiplies w by lh = 1).
+// a6, per-observation form: obs[n][f] = sum_c w[pat(n)][f][c] * lh_c(n, f)   (loggers.py:355-357,
+// operators.py:568-574, 1060-1061) with lh = 1 for NA observations (the reference multiplies the
+// weights by likelihood_per_component's NA value 1) and lh = 0 for "no group".  Dense output
+// kernel (N*F doubles), float64, NumPy order ((0 + t0) + t1) + ..., no FMA: bit-exact.
 // ------------------------------------------------------------------------------------------
+__global__ void k_observation_lh(const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid,
+                                 const uint8_t* __restrict__ pid, const float* __restrict__ probs,
+                                 const float* __restrict__ wpat, double* __restrict__ obs, int N, int Np, int F,
+                                 int S, int C, int Fp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * F) return;
+    const int n = (int)(i / F), f = (int)(i % F);
+    const uint8_t x = state[(int64_t)n * Fp + f];
+    const float* w = wpat + ((int64_t)pid[n] * F + f) * C;
+    double v = 0.0;
+    for (int c = 0; c < C; ++c) {
+        double lh = 1.0;
+        if (x != kNA) {
+            const uint16_t gg = gid[(int64_t)c * Np + n];
+            lh = gg == kNoGroup ? 0.0 : (double)probs[((int64_t)gg * F + f) * S + x];
+        }
+        v = v + (double)w[c] * lh;
+    }
+    obs[i] = v;
+}
+
+// Log-accumulation modes of the fused kernels:
+//   LOG_PER_OBS : fp64 log per observation, fp64 sum
+//   LOG_PRODUCT : the observation likelihoods of a step are multiplied into a running mantissa whose
+//                 binary exponent is stripped with integer ops; one fp64 log per thread (see ProdAcc)
 enum MixMode : int { LOG_PER_OBS = 0, LOG_PRODUCT = 1, WRITE_OBS = 2 };
-
-struct MixParams {
-    // geometry
-    int N, Np, F, S, C, Fp, rs_pitch, Gtot, P;
-    int ft, ft_shift;          // feature tile width (power of two, >= 16)
-    int n_ftiles, n_chunks, objs_per_chunk;
-    uint32_t s_magic;          // ceil(2^24 / S): j / S == (j * s_magic) >> 24 for j < 2^16
-    // resident data
-    const uint8_t* state;      // [N][Fp]
-    const uint8_t* onehot;     // [N][rs_pitch]
-    // slot-strided state (element strides between consecutive slots)
-    const uint16_t* gid;  int64_t gid_stride;     // [C][N]
-    const uint8_t* pid;   int64_t pid_stride;     // [N]
-    const float* probs;   int64_t probs_stride;   // [Gtot][F][S]
-    const float* wpat;    int64_t wpat_stride;    // [P][F][C]
-    double* partials;     int64_t partials_stride;  // [n_blocks]
-    double* obs;                                  // WRITE_OBS only: [N][F]
-    int first_slot;
-};
-
-struct LogAcc {
-    double sum;      // LOG_PER_OBS accumulator (also the fallback path of LOG_PRODUCT)
-    double mant;     // LOG_PRODUCT: in [1, 2)
-    int expo;        // LOG_PRODUCT: accumulated binary exponent
-};
-
-template <int MODE>
-__device__ __forceinline__ void acc_add(LogAcc& a, double v) {
-    if (MODE == LOG_PER_OBS) {
-        a.sum += log(v);
-    } else if (MODE == LOG_PRODUCT) {
-        // normal positive finite doubles only; everything else through log()
-        const uint32_t hi = (uint32_t)(__double_as_longlong(v) >> 32);
-        const uint32_t ex = (hi >> 20) & 0x7FFu;
-        if (__builtin_expect((hi >> 31) == 0 && ex != 0 && ex != 0x7FFu, 1)) {
-            double m = a.mant * v;                       // in [2^-1022, 4)
-            uint64_t bits = (uint64_t)__double_as_longlong(m);
-            a.expo += (int)((bits >> 52) & 0x7FFu) - 1023;
-            bits = (bits & 0x800FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
-            a.mant = __longlong_as_double((long long)bits);
-        } else {
-            a.sum += log(v);
-        }
-    }
-}
-
-template <int MODE>
-__device__ __forceinline__ double acc_finish(const LogAcc& a) {
-    if (MODE == LOG_PRODUCT) return a.sum + (log(a.mant) + (double)a.expo * 0.693147180559945309417232);
-    return a.sum;
-}
-
-template <int MODE, bool ONEHOT>
-__global__ __launch_bounds__(kBlock) void k_mixture(MixParams p) {
-    extern __shared__ float lds[];
-    __shared__ double red4[4];
-    const int slot = p.first_slot + blockIdx.y;
-    const int tile = blockIdx.x % p.n_ftiles, chunk = blockIdx.x / p.n_ftiles;
-    const int f0 = tile << p.ft_shift;
-    const int ft = p.ft, S = p.S, C = p.C, F = p.F;
-    const int fw = min(ft, F - f0);                // valid features in this tile
-
-    float* tab = lds;                              // [Gtot][ft*S]
-    float* wl = lds + (int64_t)p.Gtot * ft * S;    // [P][ft][C]
-
-    // ---- stage tables: rows of fw*S contiguous floats per group ---------------------------
-    const float* probs = p.probs + (int64_t)slot * p.probs_stride;
-    const int row_len = fw * S, row_pitch = ft * S;
-    {
-        const int total = p.Gtot * row_len;
-        for (int i0 = threadIdx.x; i0 < total; i0 += 8 * kBlock) {
-            float v8[8];
-            int dst8[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {            // issue all loads, then all LDS stores
-                const int i = i0 + u * kBlock;
-                const int ic = i < total ? i : 0;
-                const int gg = ic / row_len, r = ic - gg * row_len;
-                dst8[u] = i < total ? gg * row_pitch + r : -1;
-                v8[u] = probs[((int64_t)gg * F + f0) * S + r];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (dst8[u] >= 0) tab[dst8[u]] = v8[u];
-        }
-    }
-    const float* wpat = p.wpat + (int64_t)slot * p.wpat_stride;
-    const int wrow = fw * C;
-    for (int i = threadIdx.x; i < p.P * wrow; i += kBlock) {
-        const int pp = i / wrow, r = i - pp * wrow;
-        wl[pp * ft * C + r] = wpat[((int64_t)pp * F + f0) * C + r];
-    }
-    __syncthreads();
-
-    const uint16_t* gid = p.gid + (int64_t)slot * p.gid_stride;
-    const uint8_t* pid = p.pid + (int64_t)slot * p.pid_stride;
-    const int n0 = chunk * p.objs_per_chunk;
-    const int n_obj = min(p.objs_per_chunk, p.N - n0);
-
-    LogAcc acc{0.0, 1.0, 0};
-
-    auto observe = [&](int n, int fl, int x, int pidn, const uint16_t* g) {
-        // v = ((0 + w0*l0) + w1*l1) + ...   NumPy order, no FMA contraction (operators.py:1060)
-        double v = 0.0;
-        const float* wrow_p = wl + (pidn * ft + fl) * C;
-#pragma unroll
-        for (int c = 0; c < kMaxComponents; ++c) {
-            if (c < C) {
-                const double w = (double)wrow_p[c];
-                const double l = g[c] == kNoGroup ? 0.0 : (double)tab[(int)g[c] * row_pitch + fl * S + x];
-                v = v + w * l;
-            }
-        }
-        if (MODE == WRITE_OBS) p.obs[(int64_t)n * F + f0 + fl] = v;
-        else acc_add<MODE>(acc, v);
-    };
-
-    if (!ONEHOT) {
-        // lane <-> 4 consecutive features of one object (one dword of state bytes)
-        const int q_shift = p.ft_shift - 2;
-        const int n_quads = n_obj << q_shift;
-        for (int q = threadIdx.x; q < n_quads; q += kBlock) {
-            const int nl = q >> q_shift, fq = q & ((1 << q_shift) - 1);
-            const int n = n0 + nl;
-            const uint32_t xs = *reinterpret_cast<const uint32_t*>(p.state + (int64_t)n * p.Fp + f0 + fq * 4);
-            if (MODE != WRITE_OBS && xs == 0xFFFFFFFFu) continue;
-            uint16_t g[kMaxComponents];
-#pragma unroll
-            for (int c = 0; c < kMaxComponents; ++c) g[c] = c < C ? gid[(int64_t)c * p.Np + n] : kNoGroup;
-            const int pidn = pid[n];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int x = (xs >> (8 * k)) & 0xFF;
-                const int fl = fq * 4 + k;
-                if (x != kNA) observe(n, fl, x, pidn, g);
-                else if (MODE == WRITE_OBS && fl < fw) {
-                    double v = 0.0;                 // NA: lh = 1 in every component
-                    for (int c = 0; c < C; ++c) v = v + (double)wl[(pidn * ft + fl) * C + c] * 1.0;
-                    p.obs[(int64_t)n * F + f0 + fl] = v;
-                }
-            }
-        }
-    } else {
-        // lane <-> 16 consecutive bytes of one object's one-hot row inside the tile
-        const int row_bytes = ft * S;                   // multiple of 16 (ft >= 16)
-        const int chunks_per_row = row_bytes >> 4;
-        const int n_chunks16 = n_obj * chunks_per_row;
-        for (int q = threadIdx.x; q < n_chunks16; q += kBlock) {
-            const int nl = q / chunks_per_row, ch = q - nl * chunks_per_row;
-            const int n = n0 + nl;
-            const int64_t off = (int64_t)n * p.rs_pitch + (int64_t)f0 * S + ch * 16;
-            if ((int64_t)f0 * S + ch * 16 >= p.rs_pitch) continue;          // tail tile past the row end
-            const uint4 d = *reinterpret_cast<const uint4*>(p.onehot + off);
-            if ((d.x | d.y | d.z | d.w) == 0u) continue;
-            uint16_t g[kMaxComponents];
-#pragma unroll
-            for (int c = 0; c < kMaxComponents; ++c) g[c] = c < C ? gid[(int64_t)c * p.Np + n] : kNoGroup;
-            const int pidn = pid[n];
-            const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                // bytes are 0/1: gather bit 0 of each byte into a 4-bit mask
-                uint32_t m = ((dw[k] * 0x00204081u) >> 21) & 0xFu;
-                while (m) {
-                    const int b = __builtin_ctz(m);
-                    m &= m - 1;
-                    const int j = ch * 16 + k * 4 + b;                  // byte offset in the tile row
-                    const int fl = (int)(((uint32_t)j * p.s_magic) >> 24);
-                    const int x = j - fl * S;
-                    observe(n, fl, x, pidn, g);
-                }
-            }
-        }
-    }
-
-    if (MODE != WRITE_OBS) {
-        const double total = block_sum(acc_finish<MODE>(acc), red4);
-        if (threadIdx.x == 0)
-            p.partials[(int64_t)slot * p.partials_stride + blockIdx.x] = total;
-    }
-}
 
 // Final fixed-order reduction of the per-block partials: one block per slot.
 __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __restrict__ partials,
