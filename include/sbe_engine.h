@@ -219,6 +219,22 @@ int sbe_normalize_weights(sbe_engine* e, const float* weights /* [F][C] */, int 
 int sbe_cluster_marginals(sbe_engine* e, int slot, const float* table /* [F][S] */, const int32_t* objects,
                           int n_objects_av, double prior_temperature, double* out /* [2][n_objects_av] */);
 
+/* ---- data-parallel cores of Gibbs source resampling ----------------------
+ * sbe_source_posterior: GibbsSampleSource.calculate_source_posterior (operators.py:554-574):
+ *     out[i][f][:] = normalize(lh[n_i][f][:] ** (1/T) * w[n_i][f][:] ** (1/T_prior)) (float32)
+ *     for the listed objects, from the slot's tables, groups and weights.
+ * sbe_subset_lh: the gather of component_likelihood_given_unchanged (operators.py:863-928):
+ *     float32 likelihoods of the listed objects' observations under caller-built tables
+ *     (`tables`: n_tables_total x [F][S]; component c uses rows table_offsets[c] + group_idx[c][i],
+ *     -1 = object in no group -> 0), NA -> 1, then ** (1/T).  Stateless.
+ * Drawing the new assignments (sample_categorical) stays with the caller's RNG. */
+int sbe_source_posterior(sbe_engine* e, int slot, const int32_t* objects, int n_sub, double temperature,
+                         double prior_temperature, float* out /* [n_sub][F][C] */);
+int sbe_subset_lh(sbe_engine* e, const int32_t* objects, int n_sub, int n_comp, const float* tables,
+                  const int32_t* table_offsets /* [n_comp] */, int n_tables_total,
+                  const int32_t* group_idx /* [n_comp][n_sub] */, double temperature,
+                  float* out /* [n_sub][F][n_comp] */);
+
 /* ---- slot management -------------------------------------------------------------------- */
 int sbe_copy_slot(sbe_engine* e, int dst_slot, int src_slot);
 

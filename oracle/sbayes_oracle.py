@@ -340,3 +340,45 @@ def wide_raw_cluster_probs(features, na_values, groups_by_component, counts_by_c
     if geo_prior_ratio is not None:
         m[1] *= geo_prior_ratio
     return m[1] / (m[0] + m[1] + eps)
+
+
+# --------------------------------------------------------------------------------------
+# data-parallel cores of Gibbs source resampling
+#     operators.py:554-574 (calculate_source_posterior), :863-928 (component_likelihood_given_unchanged)
+# --------------------------------------------------------------------------------------
+def source_posterior(lh_per_component, weights_normalized, object_subset, temperature=1.0, prior_temperature=1.0):
+    """float32 [n_subset, F, C]: normalize(lh ** (1/T) * w ** (1/T_prior)) over components."""
+    sp = (lh_per_component[object_subset] ** (1 / temperature)
+          * weights_normalized[object_subset] ** (1 / prior_temperature))
+    return normalize(sp, axis=-1)
+
+
+def component_likelihood_given_unchanged(features, na_values, groups_by_component, counts_by_component,
+                                         concentration_by_component, source, object_subset, i_cluster,
+                                         unif_cluster, unif_confounders, temperature=1.0, prior_temperature=1.0):
+    """float32 [n_subset, F, C]: component likelihoods of the subset's observations under tables
+    built only from the observations that are NOT being resampled (object_subset: bool [N])."""
+    n_sub = np.count_nonzero(object_subset)
+    n_comp = len(groups_by_component)
+    lik = np.zeros((n_sub, features.shape[1], n_comp), dtype=FLOAT_TYPE)
+    cluster = groups_by_component[0][i_cluster]
+    cluster_features = features * source[:, :, 0, None]
+    cluster_effect = conditional_effect_mean(
+        prior_counts=concentration_by_component[0],
+        feature_counts=np.sum(cluster_features[cluster & ~object_subset], axis=0),
+        unif_counts=unif_cluster, prior_temperature=prior_temperature, temperature=temperature)
+    lik[..., 0] = np.sum(cluster_effect[None, ...] * features[object_subset], axis=-1)
+    for c in range(1, n_comp):
+        groups = groups_by_component[c]
+        feats_c = features * source[:, :, c, None]
+        changeable = np.array([np.sum(feats_c[g & object_subset], axis=0) for g in groups])
+        effect = conditional_effect_mean(
+            prior_counts=concentration_by_component[c], feature_counts=counts_by_component[c] - changeable,
+            unif_counts=unif_confounders[c - 1], prior_temperature=prior_temperature, temperature=temperature)
+        sub_groups = groups[:, object_subset]
+        in_subset = np.any(sub_groups, axis=1)
+        feats_sub = features[object_subset]
+        for g, p_g in zip(sub_groups[in_subset], effect[in_subset]):
+            lik[g, :, c] = np.einsum("ijk,jk->ij", feats_sub[g], p_g)
+    lik[na_values[object_subset]] = 1.0
+    return lik ** (1 / temperature)

@@ -75,6 +75,10 @@ PROTOTYPES = {
     "sbe_normalize_weights": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p]),
     "sbe_cluster_marginals": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_double,
                                          ct.c_void_p]),
+    "sbe_source_posterior": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double,
+                                        ct.c_void_p]),
+    "sbe_subset_lh": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int,
+                                 ct.c_void_p, ct.c_double, ct.c_void_p]),
     "sbe_copy_slot": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int]),
     "sbe_timer_start": (ct.c_int, [c_engine_p]),
     "sbe_timer_stop": (ct.c_int, [c_engine_p, ct.POINTER(ct.c_float)]),

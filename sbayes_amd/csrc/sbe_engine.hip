@@ -1320,6 +1320,84 @@ int sbe_cluster_marginals(sbe_engine* e, int slot, const float* table, const int
     return d2h(e, out, d_out, (size_t)2 * n_objects_av * sizeof(double));
 }
 
+// ---- data-parallel cores of Gibbs source resampling ---------------------------
+int sbe_source_posterior(sbe_engine* e, int slot, const int32_t* objects, int n_sub, double temperature,
+                         double prior_temperature, float* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, out);
+    if (n_sub < 0) return fail(e, SBE_ERR_ARG, "n_sub=%d", n_sub);
+    if (n_sub == 0) return SBE_OK;
+    CHECK_PTR(e, objects);
+    if (!(temperature > 0.0) || !(prior_temperature > 0.0)) return fail(e, SBE_ERR_ARG, "temperatures must be positive");
+    for (int i = 0; i < n_sub; ++i)
+        if (objects[i] < 0 || objects[i] >= e->N) return fail(e, SBE_ERR_ARG, "object index %d out of range", objects[i]);
+    int rc = check_slot_ready(e, slot, true);
+    if (rc) return rc;
+    HIPCHK(e, hipSetDevice(e->device));
+    if (e->slots[slot].patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
+    const int64_t n_out = (int64_t)n_sub * e->F * e->C;
+    const size_t ob = ((size_t)n_sub * sizeof(int32_t) + 255) / 256 * 256;
+    rc = ensure_scratch(e, ob + (size_t)n_out * sizeof(float));
+    if (rc) return rc;
+    int32_t* d_obj = (int32_t*)e->d_scratch;
+    float* d_out = (float*)(e->d_scratch + ob);
+    HIPCHK(e, hipMemcpyAsync(d_obj, objects, (size_t)n_sub * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    rc = clear_status_word(e, ST_BAD_NORMALIZE);
+    if (rc) return rc;
+    const double inv_t = 1.0 / temperature, inv_tp = 1.0 / prior_temperature;
+    k_source_posterior<<<div_up((int64_t)n_sub * e->F, 256), 256, 0, e->stream>>>(
+        e->d_state, e->d_gid + (int64_t)slot * e->C * e->Np, e->d_pid + (int64_t)slot * e->Np,
+        e->d_probs + (int64_t)slot * e->table_elems(), e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C,
+        d_obj, n_sub, d_out, e->Np, e->F, e->S, e->C, e->Fp, inv_t, (float)inv_tp, inv_t != 1.0, inv_tp != 1.0, e->d_status);
+    HIPCHK(e, hipGetLastError());
+    rc = d2h(e, out, d_out, (size_t)n_out * sizeof(float));
+    if (rc) return rc;
+    rc = read_status(e);
+    if (rc) return rc;
+    if (e->h_status[ST_BAD_NORMALIZE])
+        return fail(e, SBE_ERR_DATA, "normalize: %d observations have a non-positive posterior sum (sbayes/util.py:1006 assert)", e->h_status[ST_BAD_NORMALIZE]);
+    return SBE_OK;
+}
+
+int sbe_subset_lh(sbe_engine* e, const int32_t* objects, int n_sub, int n_comp, const float* tables,
+                  const int32_t* table_offsets, int n_tables_total, const int32_t* group_idx, double temperature,
+                  float* out) {
+    CHECK_ENGINE(e); CHECK_PTR(e, out);
+    if (n_sub < 0 || n_comp < 1 || n_comp > kMaxComponents || n_tables_total < 1) return fail(e, SBE_ERR_ARG, "bad sizes");
+    if (n_sub == 0) return SBE_OK;
+    CHECK_PTR(e, objects); CHECK_PTR(e, tables); CHECK_PTR(e, table_offsets); CHECK_PTR(e, group_idx);
+    if (!(temperature > 0.0)) return fail(e, SBE_ERR_ARG, "temperature must be positive");
+    for (int i = 0; i < n_sub; ++i)
+        if (objects[i] < 0 || objects[i] >= e->N) return fail(e, SBE_ERR_ARG, "object index %d out of range", objects[i]);
+    for (int c = 0; c < n_comp; ++c) {
+        const int hi = (c + 1 < n_comp ? table_offsets[c + 1] : n_tables_total) - table_offsets[c];
+        if (table_offsets[c] < 0 || hi < 0) return fail(e, SBE_ERR_ARG, "bad table offsets");
+        for (int i = 0; i < n_sub; ++i)
+            if (group_idx[(size_t)c * n_sub + i] >= hi) return fail(e, SBE_ERR_ARG, "group index out of range in component %d", c);
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    const int64_t fs = (int64_t)e->F * e->S;
+    const size_t tb = ((size_t)n_tables_total * fs * sizeof(float) + 255) / 256 * 256;
+    const size_t ob = ((size_t)n_sub * sizeof(int32_t) + 255) / 256 * 256;
+    const size_t gb = ((size_t)n_comp * n_sub * sizeof(int32_t) + 255) / 256 * 256;
+    const int64_t n_out = (int64_t)n_sub * e->F * n_comp;
+    int rc = ensure_scratch(e, tb + ob + gb + 256 + (size_t)n_out * sizeof(float));
+    if (rc) return rc;
+    float* d_tab = (float*)e->d_scratch;
+    int32_t* d_obj = (int32_t*)(e->d_scratch + tb);
+    int32_t* d_gi = (int32_t*)(e->d_scratch + tb + ob);
+    int32_t* d_off = (int32_t*)(e->d_scratch + tb + ob + gb);
+    float* d_out = (float*)(e->d_scratch + tb + ob + gb + 256);
+    HIPCHK(e, hipMemcpyAsync(d_tab, tables, (size_t)n_tables_total * fs * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(d_obj, objects, (size_t)n_sub * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(d_gi, group_idx, (size_t)n_comp * n_sub * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(d_off, table_offsets, (size_t)n_comp * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    const double inv_t = 1.0 / temperature;
+    k_subset_lh<<<div_up((int64_t)n_sub * e->F, 256), 256, 0, e->stream>>>(
+        e->d_state, d_tab, d_off, d_gi, d_obj, n_sub, d_out, e->F, e->S, n_comp, e->Fp, (float)inv_t, inv_t != 1.0);
+    HIPCHK(e, hipGetLastError());
+    return d2h(e, out, d_out, (size_t)n_out * sizeof(float));
+}
+
 // ---- slots ------------------------------------------------------------------------------------------
 int sbe_copy_slot(sbe_engine* e, int dst, int src) {
     CHECK_ENGINE(e); CHECK_SLOT(e, dst); CHECK_SLOT(e, src);

@@ -1090,6 +1090,62 @@ __global__ __launch_bounds__(kBlock) void k_cluster_marginals(
     if (lane == 0) { out[i] = acc0; out[(int64_t)n_av + i] = acc1; }
 }
 
+// ==========================================================================================
+// data-parallel cores of Gibbs source resampling
+// ==========================================================================================
+// GibbsSampleSource.calculate_source_posterior (operators.py:554-574): for the listed objects
+//   p[i][f][:] = normalize( lh[n_i][f][:] ** (1/T) * w[n_i][f][:] ** (1/T_prior) )  -> float32
+// lh as in likelihood_per_component (NA -> 1, no group -> 0), w = normalised weights of the slot.
+__global__ void k_source_posterior(const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid,
+                                   const uint8_t* __restrict__ pid, const float* __restrict__ probs,
+                                   const float* __restrict__ wpat, const int32_t* __restrict__ objects, int n_sub,
+                                   float* __restrict__ out, int Np, int F, int S, int C, int Fp, double inv_t,
+                                   float inv_tp, int pow_lh, int pow_w, int* __restrict__ status) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_sub * F) return;
+    const int r = (int)(i / F), f = (int)(i % F);
+    const int n = objects[r];
+    const uint8_t x = state[(int64_t)n * Fp + f];
+    const float* w = wpat + ((int64_t)pid[n] * F + f) * C;
+    auto term = [&](int c) -> double {
+        double lh = 1.0;
+        if (x != kNA) {
+            const uint16_t gg = gid[(int64_t)c * Np + n];
+            lh = gg == kNoGroup ? 0.0 : (double)probs[((int64_t)gg * F + f) * S + x];
+        }
+        if (pow_lh) lh = pow(lh, inv_t);
+        const float wc = pow_w ? powf(w[c], inv_tp) : w[c];
+        return lh * (double)wc;
+    };
+    const double total = np_pairwise_sum<double>(term, C);
+    if (!(total > 0.0)) atomicAdd(&status[ST_BAD_NORMALIZE], 1);
+    float* o = out + i * C;
+    for (int c = 0; c < C; ++c) o[c] = (float)(term(c) / total);
+}
+
+// component_likelihood_given_unchanged (operators.py:863-928), gather part: float32 likelihood of
+// the listed objects' observations under caller-supplied tables (built from the observations that
+// are not being resampled); group_idx[c][i] = table row of object i in component c (-1: none -> 0);
+// NA -> 1; finally ** (1/T) in float32.
+__global__ void k_subset_lh(const uint8_t* __restrict__ state, const float* __restrict__ tables,
+                            const int32_t* __restrict__ table_offsets, const int32_t* __restrict__ group_idx,
+                            const int32_t* __restrict__ objects, int n_sub, float* __restrict__ out, int F, int S,
+                            int C, int Fp, float inv_t, int use_pow) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_sub * F) return;
+    const int r = (int)(i / F), f = (int)(i % F);
+    const uint8_t x = state[(int64_t)objects[r] * Fp + f];
+    float* o = out + i * C;
+    for (int c = 0; c < C; ++c) {
+        float v = 1.0f;
+        if (x != kNA) {
+            const int g = group_idx[(int64_t)c * n_sub + r];
+            v = g < 0 ? 0.0f : tables[((int64_t)(table_offsets[c] + g) * F + f) * S + x];
+        }
+        o[c] = use_pow ? powf(v, inv_t) : v;
+    }
+}
+
 // canonical probs [Gtot][F][S] -> tile-transposed probs_t [n_ftiles][Gtot+1][S][FT] for the
 // groups [g_lo, g_hi).  Row Gtot and features >= F stay zero (set once at creation).
 __global__ void k_tile_probs(const float* __restrict__ probs, float* __restrict__ probs_t, int g_lo,

@@ -376,6 +376,30 @@ class Engine:
                                                     float(prior_temperature), _ptr(out)))
         return out
 
+    def source_posterior(self, slot, objects, temperature=1.0, prior_temperature=1.0):
+        """float32 [n, F, C]: posterior of the source assignment of the listed objects' observations
+        (GibbsSampleSource.calculate_source_posterior, operators.py:554-574)."""
+        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        out = np.empty((objs.size, self.n_features, self.n_components), dtype=np.float32)
+        self._check(self._lib.sbe_source_posterior(self._h, slot, _ptr(objs), objs.size, float(temperature),
+                                                   float(prior_temperature), _ptr(out)))
+        return out
+
+    def subset_lh(self, objects, tables, group_idx, temperature=1.0):
+        """float32 [n, F, C]: likelihood of the listed objects' observations under per-component tables
+        (`tables`: list of [G_c, F, S] float32; `group_idx`: int [C, n], -1 = no group)."""
+        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        tabs = [_c(t, np.float32).reshape(-1, self.n_features, self.n_states) for t in tables]
+        offsets = np.concatenate([[0], np.cumsum([t.shape[0] for t in tabs])]).astype(np.int32)
+        cat = np.ascontiguousarray(np.concatenate(tabs, axis=0))
+        gi = np.ascontiguousarray(group_idx, dtype=np.int32)
+        if gi.shape != (len(tabs), objs.size):
+            raise ValueError("group_idx must be [n_components, n_objects_in_subset]")
+        out = np.empty((objs.size, self.n_features, len(tabs)), dtype=np.float32)
+        self._check(self._lib.sbe_subset_lh(self._h, _ptr(objs), objs.size, len(tabs), _ptr(cat), _ptr(offsets[:-1].copy()),
+                                            int(offsets[-1]), _ptr(gi), float(temperature), _ptr(out)))
+        return out
+
     def copy_slot(self, dst, src):
         self._check(self._lib.sbe_copy_slot(self._h, dst, src))
 

@@ -23,8 +23,11 @@ class ClusterEffectPrior:
 class ConfoundingEffectsPrior:
     any_dynamic_priors = False
 
-    def __init__(self, concentration_array):
+    def __init__(self, concentration_array, uniform_concentration_array=None):
         self._concentration_array = np.asarray(concentration_array, dtype=np.float64)
+        self.uniform_concentration_array = (
+            np.asarray(uniform_concentration_array, dtype=np.float64) if uniform_concentration_array is not None
+            else (self._concentration_array[0] > 0).astype(np.float64))
 
     def concentration_array(self, sample=None):
         return self._concentration_array

@@ -67,3 +67,49 @@ def compute_raw_cluster_probs(model, sample, i_cluster, available, temperature=1
     if geo_prior_ratio is not None:
         m[1] *= geo_prior_ratio
     return m[1] / (m[0] + m[1] + EPS)
+
+
+def calculate_source_posterior(model, sample, object_subset, temperature=1.0, prior_temperature=1.0, slot=0):
+    """GibbsSampleSource.calculate_source_posterior (operators.py:554-574): float32
+    [n_subset, F, C] posterior of the source assignment of every observation of the subset."""
+    eng = _prepare(model, sample, slot)
+    if isinstance(object_subset, slice):
+        objects = np.arange(sample.n_objects)[object_subset]
+    else:
+        objects = np.asarray(object_subset)
+        if objects.dtype == np.bool_:
+            objects = np.flatnonzero(objects)
+    return eng.source_posterior(slot, objects, temperature, prior_temperature)
+
+
+def component_likelihood_given_unchanged(model, sample, object_subset, i_cluster, temperature=1.0,
+                                         prior_temperature=1.0):
+    """operators.py:863-928: float32 [n_subset, F, C] component likelihoods of the subset's
+    observations under effect tables built only from the observations that are NOT resampled.
+    `object_subset` is a bool mask [n_objects].  Counts (a9) and tables (a10) come from the device."""
+    eng = _engine(model)
+    object_subset = np.asarray(object_subset, dtype=bool)
+    objects = np.flatnonzero(object_subset)
+    source = sample.source.value
+    prior = model.prior.prior_cluster_effect
+    cluster = sample.clusters.value[i_cluster]
+    kept = eng.effect_counts((cluster & ~object_subset)[None, :], source[..., 0])
+    tables = [eng.normalize_tables(kept, np.asarray(prior.concentration_array), temperature=temperature,
+                                   prior_temperature=prior_temperature,
+                                   unif_counts=np.asarray(prior.uniform_concentration_array))]
+    group_idx = [np.zeros(objects.size, dtype=np.int32)]            # every subset object sees the cluster table
+    for i_conf, conf in enumerate(sample.confounders, start=1):
+        conf_prior = model.prior.prior_confounding_effects[conf]
+        groups = sample.confounders[conf].group_assignment
+        changeable = eng.effect_counts(groups & object_subset[None, :], source[..., i_conf])
+        unchangeable = sample.feature_counts[conf].value - changeable
+        if conf_prior.any_dynamic_priors:
+            prior_counts = conf_prior.concentration_array_given_unchanged(sample, changed_objects=object_subset)
+        else:
+            prior_counts = conf_prior.concentration_array(sample)
+        tables.append(eng.normalize_tables(unchangeable, np.asarray(prior_counts), temperature=temperature,
+                                           prior_temperature=prior_temperature,
+                                           unif_counts=np.asarray(conf_prior.uniform_concentration_array)))
+        sub = groups[:, object_subset]
+        group_idx.append(np.where(sub.any(axis=0), sub.argmax(axis=0), -1).astype(np.int32))
+    return eng.subset_lh(objects, tables, np.stack(group_idx), temperature)

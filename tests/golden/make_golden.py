@@ -314,6 +314,31 @@ def cluster_posterior_case(model, data, sample, mcmc_cfg):
     return out
 
 
+def source_posterior_case(model, data, sample, mcmc_cfg):
+    """SURVEY.md 8(f) rank 3 (data-parallel cores of Gibbs source resampling):
+    GibbsSampleSource.calculate_source_posterior (operators.py:554-574) and
+    component_likelihood_given_unchanged (operators.py:863-928), plain and tempered."""
+    from sbayes.sampling.operators import component_likelihood_given_unchanged, get_operator_schedule
+    out = {}
+    n = sample.n_objects
+    subset = np.arange(0, n, 3)[:20]
+    mask = np.isin(np.arange(n), subset)
+    out["sp_subset"] = subset
+    for tag, (temp, ptemp) in {"t1": (1.0, 1.0), "mc3": (1.3, 1.5)}.items():
+        ops = get_operator_schedule(mcmc_cfg.operators, model, data, temperature=temp,
+                                    prior_temperature=ptemp, sample_from_prior=False)
+        out[f"sp_{tag}_posterior"] = ops["gibbs_sample_sources"].calculate_source_posterior(sample, subset)
+        for k in range(sample.n_clusters):
+            out[f"sp_{tag}_k{k}_lh_unchanged"] = component_likelihood_given_unchanged(
+                model, sample, mask, i_cluster=k, temperature=temp, prior_temperature=ptemp)
+    out["sp_conf_unif"] = np.stack([np.asarray(model.prior.prior_confounding_effects[c].uniform_concentration_array)
+                                    for c in sample.confounders]) if all(
+        np.asarray(model.prior.prior_confounding_effects[c].uniform_concentration_array).shape ==
+        np.asarray(model.prior.prior_confounding_effects[next(iter(sample.confounders))].uniform_concentration_array).shape
+        for c in sample.confounders) else np.zeros(0)
+    return out
+
+
 def real_fixture(tag: str, config_path: Path, n_trace_steps: int, seed: int):
     from sbayes.experiment_setup import Experiment
     from sbayes.sampling.initializers import SbayesInitializer
@@ -343,6 +368,7 @@ def real_fixture(tag: str, config_path: Path, n_trace_steps: int, seed: int):
         extra.update(partial_update_case(model, sample, rng))
         extra.update(delta_counts_case(model, sample, rng))
         extra.update(cluster_posterior_case(model, data, sample, mcmc_cfg))
+        extra.update(source_posterior_case(model, data, sample, mcmc_cfg))
         meta = dict(name=tag, shape=list(data.features.values.shape),
                     component_names=sample.component_names,
                     groups=[int(sample.n_groups(k)) for k in sample.component_names], **scal, **dig)

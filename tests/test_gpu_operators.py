@@ -76,3 +76,34 @@ def test_cluster_posterior_large_feature_count_does_not_underflow():
         linear = orc.cluster_posterior(wl.features, wl.na_values, wl.groups, counts, wl.concentration, wl.weights,
                                        1, available, unif)
     assert not np.all(np.isfinite(linear))          # the reference's linear-space form breaks here
+
+
+@pytest.mark.parametrize("name", ["south_america", "test_files"])
+def test_source_resampling_cores(name):
+    """calculate_source_posterior and component_likelihood_given_unchanged on
+    the device == the reference's recorded outputs (bit-exact at temperature 1; float32 pow
+    tolerance when tempered)."""
+    from sbayes_amd.operators import calculate_source_posterior, component_likelihood_given_unchanged
+    fx = load_npz(name)
+    z = fx.z
+    model, sample = sbm.build(fx.features, fx.states_per_feature, fx.meta["component_names"], fx.groups, fx.conc,
+                              fx.weights, fx.source, counts=fx.counts)
+    model.prior.prior_cluster_effect.uniform_concentration_array = z["cp_unif"]
+    for conf, unif in zip(sample.confounders, z["sp_conf_unif"]):
+        model.prior.prior_confounding_effects[conf].uniform_concentration_array = unif
+    subset = z["sp_subset"]
+    mask = np.isin(np.arange(fx.features.shape[0]), subset)
+    for tag, (temp, ptemp) in {"t1": (1.0, 1.0), "mc3": (1.3, 1.5)}.items():
+        post = calculate_source_posterior(model, sample, subset, temp, ptemp)
+        assert post.dtype == np.float32
+        if tag == "t1":
+            assert np.array_equal(post, z[f"sp_{tag}_posterior"])
+        else:
+            np.testing.assert_allclose(post, z[f"sp_{tag}_posterior"], rtol=2e-6, atol=1e-30)
+        for k in range(fx.groups[0].shape[0]):
+            lik = component_likelihood_given_unchanged(model, sample, mask, k, temp, ptemp)
+            assert lik.dtype == np.float32
+            if tag == "t1":
+                assert np.array_equal(lik, z[f"sp_{tag}_k{k}_lh_unchanged"]), k
+            else:
+                np.testing.assert_allclose(lik, z[f"sp_{tag}_k{k}_lh_unchanged"], rtol=3e-6, atol=1e-30)
