@@ -235,6 +235,15 @@ int sbe_subset_lh(sbe_engine* e, const int32_t* objects, int n_sub, int n_comp, 
                   const int32_t* group_idx /* [n_comp][n_sub] */, double temperature,
                   float* out /* [n_sub][F][n_comp] */);
 
+/* ---- SURVEY.md 8(f) rank 4 ------------------------------------------------------------------------
+ * sbe_source_prior: SourcePrior.__call__ (sbayes/model/prior.py:573-611), the per-object values
+ *     sp[n] = float32(sum_{f not NA} log w[n][f][source(n,f)]) stored as float64 [N]; the caller
+ *     keeps the reference's cache logic and sums.
+ * sbe_observation_lh_exact: the row LikelihoodLogger._write_sample stores (loggers.py:354-359):
+ *     sum_c w[n][f][c] * lh_exact[n][f][c] with the leave-one-out tables of a2; float64 [N][F]. */
+int sbe_source_prior(sbe_engine* e, int slot, double* per_object_out /* [N] */);
+int sbe_observation_lh_exact(sbe_engine* e, int slot, double* out /* [N][F] */);
+
 /* ---- slot management -------------------------------------------------------------------- */
 int sbe_copy_slot(sbe_engine* e, int dst_slot, int src_slot);
 

@@ -382,3 +382,21 @@ def component_likelihood_given_unchanged(features, na_values, groups_by_componen
             lik[g, :, c] = np.einsum("ijk,jk->ij", feats_sub[g], p_g)
     lik[na_values[object_subset]] = 1.0
     return lik ** (1 / temperature)
+
+
+# --------------------------------------------------------------------------------------
+# SourcePrior.__call__ (sbayes/model/prior.py:573-611) and the
+# LikelihoodLogger row (sbayes/sampling/loggers.py:354-359)
+# --------------------------------------------------------------------------------------
+def source_prior_per_object(weights_normalized, source, na_values):
+    """float64 [N] holding float32 values: sum over valid features of log(sum_c w * s)."""
+    valid = ~na_values
+    obs_weights = np.sum(weights_normalized * source, axis=-1)
+    with np.errstate(divide="ignore"):
+        obs_log = np.log(obs_weights, where=valid, out=np.zeros_like(obs_weights))
+    return np.sum(obs_log, where=valid, axis=-1).astype(np.float64)
+
+
+def logger_row(weights_normalized, lh_exact):
+    """float64 [N*F]: what LikelihoodLogger._write_sample appends (before the float32 column cast)."""
+    return np.sum(weights_normalized * lh_exact, axis=2).ravel()

@@ -113,10 +113,25 @@ def observation_likelihoods(model, sample, slot=0, exact=False):
     """float64 [n_objects, n_features]: sum_c w * lh per observation (loggers.py:355-357)."""
     eng = _engine(model)
     if exact:
-        from .likelihood import update_weights
-        lh = likelihood_per_component_exact(model, sample, slot)
-        return np.sum(update_weights(sample, features=model.data.features.values) * lh, axis=2)
+        _bind_slot(eng, model, sample, slot, with_source=True)
+        return eng.observation_lh_exact(slot)
     _bind_slot(eng, model, sample, slot)
     for c in range(eng.n_components):
         eng.update_probs(slot, c)
     return eng.observation_lh(slot)
+
+
+def source_prior(model, sample, slot=0, caching=True) -> float:
+    """SourcePrior.__call__ (sbayes/model/prior.py:573-611): log prior of the source assignment given
+    the weights, cached per object in sample.cache.source_prior when the sample has that node."""
+    eng = _engine(model)
+    cache = getattr(sample.cache, "source_prior", None)
+    if cache is not None and caching and not cache.is_outdated():
+        return cache.value.sum()
+    _bind_slot(eng, model, sample, slot, with_source=True)
+    per_object = eng.source_prior(slot)
+    if cache is not None:
+        with cache.edit() as arr:
+            arr[:] = per_object
+        return cache.value.sum()
+    return per_object.sum()

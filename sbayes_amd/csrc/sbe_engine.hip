@@ -1398,6 +1398,50 @@ int sbe_subset_lh(sbe_engine* e, const int32_t* objects, int n_sub, int n_comp, 
     return d2h(e, out, d_out, (size_t)n_out * sizeof(float));
 }
 
+// ---- source prior and the LikelihoodLogger row --------------------------------
+int sbe_source_prior(sbe_engine* e, int slot, double* per_object_out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, per_object_out);
+    Slot& s = e->slots[slot];
+    if (!s.groups_set || !s.source_set || !s.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", slot);
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = SBE_OK;
+    if (s.patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
+    rc = ensure_scratch(e, (size_t)e->N * sizeof(double));
+    if (rc) return rc;
+    k_source_prior<<<div_up(e->N, kBlock / kWave), kBlock, 0, e->stream>>>(
+        e->d_state, e->d_src + (int64_t)slot * e->N * e->Fp, e->d_pid + (int64_t)slot * e->Np,
+        e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, (double*)e->d_scratch, e->N, e->F, e->C, e->Fp);
+    HIPCHK(e, hipGetLastError());
+    return d2h(e, per_object_out, e->d_scratch, (size_t)e->N * sizeof(double));
+}
+
+int sbe_observation_lh_exact(sbe_engine* e, int slot, double* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, out);
+    Slot& s = e->slots[slot];
+    if (!s.groups_set || !s.source_set || !s.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", slot);
+    for (int c = 0; c < e->C; ++c)
+        if (!s.counts_set[c] || !e->conc_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts / concentration of component %d not set", slot, c);
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = SBE_OK;
+    if (s.patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
+    const int64_t n = (int64_t)e->N * e->F;
+    rc = ensure_scratch(e, n * sizeof(double));
+    if (rc) return rc;
+    rc = clear_status_word(e, ST_BAD_NORMALIZE);
+    if (rc) return rc;
+    k_lh_exact<<<div_up(n, 256), 256, 0, e->stream>>>(
+        e->d_state, e->d_src + (int64_t)slot * e->N * e->Fp, e->d_gid + (int64_t)slot * e->C * e->Np,
+        e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc, (double*)e->d_scratch, e->N, e->Np, e->F, e->S, e->C,
+        e->Fp, e->d_status, e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, e->d_pid + (int64_t)slot * e->Np);
+    HIPCHK(e, hipGetLastError());
+    rc = d2h(e, out, e->d_scratch, n * sizeof(double));
+    if (rc) return rc;
+    rc = read_status(e);
+    if (rc) return rc;
+    if (e->h_status[ST_BAD_NORMALIZE]) return fail(e, SBE_ERR_DATA, "normalize: non-positive row sum in leave-one-out tables (sbayes/util.py:1006 assert)");
+    return SBE_OK;
+}
+
 // ---- slots ------------------------------------------------------------------------------------------
 int sbe_copy_slot(sbe_engine* e, int dst, int src) {
     CHECK_ENGINE(e); CHECK_SLOT(e, dst); CHECK_SLOT(e, src);

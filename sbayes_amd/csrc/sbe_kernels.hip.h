@@ -397,16 +397,21 @@ __global__ void k_lh_dense(const uint8_t* __restrict__ state, const uint16_t* __
 // a2: likelihood_per_component_exact (conditionals.py:300-367): leave-one-out tables.
 // For observation (n, f) in group g of component c the table row is
 //   normalize(counts[g,f,:] + prior[g,f,:] - onehot(n,f,:) * source[n,f,c])   (float32)
+// With `wpat` != nullptr the kernel instead writes obs[n][f] = sum_c w[pat(n)][f][c] * lh_exact (the row the
+// reference's LikelihoodLogger stores, loggers.py:354-359), NumPy order, no FMA.
 __global__ void k_lh_exact(const uint8_t* __restrict__ state, const uint8_t* __restrict__ src,
                            const uint16_t* __restrict__ gid, const int32_t* __restrict__ counts,
                            const double* __restrict__ conc, double* __restrict__ out, int N, int Np, int F,
-                           int S, int C, int Fp, int* __restrict__ status) {
+                           int S, int C, int Fp, int* __restrict__ status,
+                           const float* __restrict__ wpat = nullptr, const uint8_t* __restrict__ pid = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)N * F) return;
     const int n = (int)(i / F), f = (int)(i % F);
     const uint8_t x = state[(int64_t)n * Fp + f];
     const uint8_t sc = src[(int64_t)n * Fp + f];
     double* o = out + i * C;
+    const float* w = wpat ? wpat + ((int64_t)pid[n] * F + f) * C : nullptr;
+    double acc = 0.0;
     for (int c = 0; c < C; ++c) {
         double v = 1.0;
         if (x != kNA) {
@@ -424,8 +429,10 @@ __global__ void k_lh_exact(const uint8_t* __restrict__ state, const uint8_t* __r
                 v = (double)(float)(post(x) / total);
             }
         }
-        o[c] = v;
+        if (w) acc = acc + (double)w[c] * v;
+        else o[c] = v;
     }
+    if (w) out[i] = acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1144,6 +1151,30 @@ __global__ void k_subset_lh(const uint8_t* __restrict__ state, const float* __re
         }
         o[c] = use_pow ? powf(v, inv_t) : v;
     }
+}
+
+// SourcePrior.__call__ (prior.py:573-611), per-object values:
+//   sp[n] = float32( sum_{f valid} log( w[pat(n)][f][source(n,f)] ) )     (float32 logs)
+// One wave per object, lanes over features, wave64 shuffle reduce.  An observation whose source has no
+// component set contributes log(0) = -inf like the reference's sum(w * s) = 0.
+__global__ __launch_bounds__(kBlock) void k_source_prior(const uint8_t* __restrict__ state,
+                                                        const uint8_t* __restrict__ src,
+                                                        const uint8_t* __restrict__ pid,
+                                                        const float* __restrict__ wpat, double* __restrict__ out,
+                                                        int N, int F, int C, int Fp) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int n = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* w = wpat + (int64_t)pid[n] * F * C;
+    double acc = 0.0;
+    for (int f = lane; f < F; f += kWave) {
+        if (state[(int64_t)n * Fp + f] == kNA) continue;
+        const uint8_t c = src[(int64_t)n * Fp + f];
+        const float ow = c < C ? w[(int64_t)f * C + c] : 0.0f;
+        acc += (double)logf(ow);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[n] = (double)(float)acc;
 }
 
 // canonical probs [Gtot][F][S] -> tile-transposed probs_t [n_ftiles][Gtot+1][S][FT] for the

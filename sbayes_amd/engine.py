@@ -400,6 +400,18 @@ class Engine:
                                             int(offsets[-1]), _ptr(gi), float(temperature), _ptr(out)))
         return out
 
+    def source_prior(self, slot):
+        """float64 [N]: per-object log source prior (SourcePrior.__call__, prior.py:573-611)."""
+        out = np.empty(self.n_objects, dtype=np.float64)
+        self._check(self._lib.sbe_source_prior(self._h, slot, _ptr(out)))
+        return out
+
+    def observation_lh_exact(self, slot):
+        """float64 [N, F]: sum_c w * lh_exact, the LikelihoodLogger row (loggers.py:354-359)."""
+        out = np.empty((self.n_objects, self.n_features), dtype=np.float64)
+        self._check(self._lib.sbe_observation_lh_exact(self._h, slot, _ptr(out)))
+        return out
+
     def copy_slot(self, dst, src):
         self._check(self._lib.sbe_copy_slot(self._h, dst, src))
 

@@ -339,6 +339,19 @@ def source_posterior_case(model, data, sample, mcmc_cfg):
     return out
 
 
+def source_prior_case(model, sample):
+    """SourcePrior.__call__ (prior.py:573-611) per-object values and the
+    LikelihoodLogger row (loggers.py:354-359: sum_c w * lh_exact, stored as float32)."""
+    from sbayes.model.prior import SourcePrior
+    sp = SourcePrior(na_features=model.data.features.na_values)
+    total = sp(sample, caching=False)
+    w = update_weights(sample)
+    lh_exact = likelihood_per_component_exact(model=model, sample=sample)
+    row = np.sum(w * lh_exact, axis=2).ravel()
+    return dict(spr_per_object=sample.cache.source_prior.value.copy(), spr_total=np.float64(total),
+                logger_row_f32=row.astype(np.float32))
+
+
 def real_fixture(tag: str, config_path: Path, n_trace_steps: int, seed: int):
     from sbayes.experiment_setup import Experiment
     from sbayes.sampling.initializers import SbayesInitializer
@@ -369,6 +382,7 @@ def real_fixture(tag: str, config_path: Path, n_trace_steps: int, seed: int):
         extra.update(delta_counts_case(model, sample, rng))
         extra.update(cluster_posterior_case(model, data, sample, mcmc_cfg))
         extra.update(source_posterior_case(model, data, sample, mcmc_cfg))
+        extra.update(source_prior_case(model, sample))
         meta = dict(name=tag, shape=list(data.features.values.shape),
                     component_names=sample.component_names,
                     groups=[int(sample.n_groups(k)) for k in sample.component_names], **scal, **dig)

@@ -107,3 +107,22 @@ def test_source_resampling_cores(name):
                 assert np.array_equal(lik, z[f"sp_{tag}_k{k}_lh_unchanged"]), k
             else:
                 np.testing.assert_allclose(lik, z[f"sp_{tag}_k{k}_lh_unchanged"], rtol=3e-6, atol=1e-30)
+
+
+@pytest.mark.parametrize("name", ["south_america", "test_files"])
+def test_source_prior_and_logger_row(name):
+    """per-object source prior (float32 logs: 2e-6 relative) and the
+    LikelihoodLogger row (bit-exact in float64, hence in its float32 column)."""
+    from sbayes_amd.conditionals import observation_likelihoods, source_prior
+    fx = load_npz(name)
+    z = fx.z
+    model, sample = sbm.build(fx.features, fx.states_per_feature, fx.meta["component_names"], fx.groups, fx.conc,
+                              fx.weights, fx.source, counts=fx.counts)
+    eng = model.likelihood.engine
+    total = source_prior(model, sample)
+    per_object = eng.source_prior(0)
+    np.testing.assert_allclose(per_object, z["spr_per_object"], rtol=2e-6, atol=1e-6)
+    assert abs(total - float(z["spr_total"])) <= 2e-6 * abs(float(z["spr_total"]))
+    row = observation_likelihoods(model, sample, exact=True).ravel()
+    assert np.array_equal(row, orc.logger_row(z["weights_normalized"], z["lh_exact"]))
+    assert np.array_equal(row.astype(np.float32), z["logger_row_f32"])
