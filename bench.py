@@ -167,6 +167,27 @@ def secondary_figures(eng, wl, B, args):
     table = probs0[0]
     out["f1_cluster_marginals_calls_per_s"] = round(_rate(lambda: eng.cluster_marginals(0, table, available)), 1)
     out["f1_cluster_marginals_objects"] = int(available.size)
+    # resident step flow -- delta in, collapsed + mixture log-likelihood out
+    from sbayes_amd import model as sbm
+    from sbayes_amd.registry import release_all
+    from sbayes_amd.resident import ResidentChain
+    model, sample = sbm.build(wl.features, wl.states_per_feature, wl.component_names, wl.groups, wl.concentration,
+                              wl.weights, wl.source)
+    chain = ResidentChain(model, sample)
+    rng = np.random.default_rng(5)
+    clusters = wl.clusters.copy()
+
+    def resident_step():
+        n = int(rng.integers(0, n_obj))
+        clusters[:, n] = False
+        clusters[int(rng.integers(0, clusters.shape[0])), n] = True
+        objs = np.unique(np.append(rng.integers(0, n_obj, size=19), n))
+        cand = chain.propose(clusters=clusters, source_rows=(objs, wl.source[objs]))
+        ll, mix = cand.collapsed_loglik(), cand.mixture_loglik()
+        chain.accept()
+        return ll, mix
+    out["f2_resident_steps_per_s"] = round(_rate(resident_step), 1)
+    release_all()
     return out
 
 

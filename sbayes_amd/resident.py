@@ -1,0 +1,116 @@
+"""Resident MCMC-step flow: the sample state of a chain lives in engine
+slots; a step ships only the proposed delta (changed cluster rows, changed source rows, weights)
+across PCIe, and counts (a9), probability tables (a4), the collapsed likelihood (a7/a8) and the
+mixture log-likelihood (8(d)) are all recomputed on the device from resident data.
+
+    chain = ResidentChain(model, sample)            # uploads the state once (slot `cur`)
+    cand = chain.propose(clusters=new_clusters, source_rows=(objects, rows), weights=None)
+    ll = cand.collapsed_loglik()                    # Likelihood.__call__ value, device-resident
+    mix = cand.mixture_loglik()                     # fused kernel
+    chain.accept()  /  chain.reject()               # slot swap, no copy on reject
+
+The accept/reject decision, proposal logic and RNG stay with the (reference) sampler."""
+from __future__ import annotations
+
+import numpy as np
+
+from .conditionals import _engine
+
+
+class _SlotView:
+    def __init__(self, chain, slot):
+        self.chain, self.slot = chain, slot
+
+    def collapsed_loglik(self) -> float:
+        """Likelihood.__call__(sample, caching=False) value from the slot's resident counts."""
+        eng = self.chain.eng
+        return float(sum(eng.collapsed_loglik(self.slot, c).sum() for c in range(eng.n_components)))
+
+    def collapsed_group_logliks(self):
+        eng = self.chain.eng
+        return [eng.collapsed_loglik(self.slot, c) for c in range(eng.n_components)]
+
+    def mixture_loglik(self) -> float:
+        eng = self.chain.eng
+        for c in self.chain._probs_dirty[self.slot]:
+            eng.update_probs(self.slot, c)
+        self.chain._probs_dirty[self.slot] = set()
+        return eng.mixture_loglik(self.slot)
+
+    def counts(self, component):
+        return self.chain.eng.get_counts(self.slot, component)
+
+
+class ResidentChain:
+    """Two slots per chain: `cur` (accepted state) and `cand` (proposal under evaluation)."""
+
+    def __init__(self, model, sample, slots=(0, 1)):
+        self.model = model
+        self.eng = _engine(model)
+        if max(slots) >= self.eng.n_slots:
+            raise ValueError(f"engine has {self.eng.n_slots} slots, need slots {slots}")
+        self.cur, self.cand = slots
+        self.names = list(sample.component_names)
+        eng = self.eng
+        conc = [np.asarray(model.prior.prior_cluster_effect.concentration_array)] + [
+            np.asarray(model.prior.prior_confounding_effects[k].concentration_array(sample)) for k in self.names[1:]]
+        groups = [sample.clusters.value] + [c.group_assignment for c in sample.confounders.values()]
+        for c in range(eng.n_components):
+            eng.set_concentration(c, conc[c])
+            eng.set_groups(self.cur, c, groups[c])
+        eng.set_source(self.cur, sample.source.value)
+        eng.recount(self.cur)
+        eng.set_weights(self.cur, sample.weights.value)
+        self._clusters = sample.clusters.value.copy()
+        self._cand_clusters = None
+        self._probs_dirty = {self.cur: set(range(eng.n_components)), self.cand: set()}
+        self.changed_groups = None
+        self._pending = False
+
+    @property
+    def current(self):
+        return _SlotView(self, self.cur)
+
+    def propose(self, clusters=None, source_rows=None, weights=None):
+        """Build the candidate state in the `cand` slot from the current one plus a delta.
+        clusters: full bool [K, N] of the candidate (only N*2 bytes of ids cross PCIe);
+        source_rows: (object indices, bool rows [n, F, C]) of the objects whose source changed;
+        weights: float32 [F, C] or None.  Counts are delta-updated on the device over the union of
+        the objects whose cluster membership or source changed."""
+        eng = self.eng
+        eng.copy_slot(self.cand, self.cur)
+        self._probs_dirty[self.cand] = set(self._probs_dirty[self.cur])
+        moved = np.zeros(eng.n_objects, dtype=bool)
+        self._cand_clusters = self._clusters
+        if clusters is not None:
+            clusters = np.asarray(clusters, dtype=bool)
+            moved |= (clusters != self._clusters).any(axis=0)
+            eng.set_groups(self.cand, 0, clusters)
+            self._cand_clusters = clusters.copy()
+        if source_rows is not None:
+            objects, rows = source_rows
+            objects = np.asarray(objects)
+            if objects.size:
+                eng.set_source_rows(self.cand, objects, rows)
+                moved[objects] = True
+        if weights is not None:
+            eng.set_weights(self.cand, weights)
+        subset = np.flatnonzero(moved)
+        self.changed_groups = eng.update_counts(self.cand, self.cur, subset) if subset.size else \
+            np.zeros(eng.n_groups_total, dtype=bool)
+        off = eng.group_offsets
+        for c in range(eng.n_components):
+            if self.changed_groups[off[c]:off[c + 1]].any():
+                self._probs_dirty[self.cand].add(c)
+        self._pending = True
+        return _SlotView(self, self.cand)
+
+    def accept(self):
+        if not self._pending:
+            raise RuntimeError("no pending proposal")
+        self.cur, self.cand = self.cand, self.cur
+        self._clusters = self._cand_clusters
+        self._pending = False
+
+    def reject(self):
+        self._pending = False

@@ -182,3 +182,49 @@ def test_trace_replay_cached_pipeline(name):
         sample = cand
     if name == "south_america":
         assert n_partial > 20       # the partial-update path (strict subset of groups) was exercised
+
+
+@pytest.mark.parametrize("name", ["test_files", "south_america"])
+def test_trace_replay_resident_flow(name):
+    """the recorded reference trace replayed through the resident flow --
+    state lives in engine slots, each step ships only the delta, counts / tables / collapsed and
+    mixture likelihood are recomputed on the device."""
+    from sbayes_amd.resident import ResidentChain
+    fx = load_npz(name)
+    tr = load_trace(name)
+    model, sample = build(fx)
+    chain = ResidentChain(model, sample)
+    for c in range(fx.n_comp):
+        assert np.array_equal(chain.current.counts(c), fx.counts[c])
+    assert abs(chain.current.collapsed_loglik() - fx.meta["collapsed_ll"]) <= 1e-6 * abs(fx.meta["collapsed_ll"])
+    prev_clusters, prev_source, prev_weights = fx.groups[0], fx.source, fx.weights
+    n_rejected = 0
+    for i in range(tr.n_steps):
+        clusters, source, weights = tr.clusters(i), tr.source(i), tr.weights[i]
+        changed_src = np.flatnonzero((source != prev_source).any(axis=(1, 2)))
+        cand = chain.propose(
+            clusters=clusters if not np.array_equal(clusters, prev_clusters) else None,
+            source_rows=(changed_src, source[changed_src]),
+            weights=weights if not np.array_equal(weights, prev_weights) else None)
+        ll = cand.collapsed_loglik()
+        assert abs(ll - tr.last_lh[i]) <= 1e-6 * abs(tr.last_lh[i]), f"step {i}"
+        np.testing.assert_allclose(np.concatenate(cand.collapsed_group_logliks()), tr.group_lh[i], rtol=1e-6, atol=1e-6)
+        mix = cand.mixture_loglik()
+        assert abs(mix - tr.mixture_ll[i]) <= 1e-10 * abs(tr.mixture_ll[i]), f"step {i}"
+        if i % 50 == 7:            # exercise the reject path: the current slot must be untouched
+            chain.reject()
+            n_rejected += 1
+            cur = chain.current
+            want = tr.mixture_ll[i - 1] if i else fx.meta["mixture_ll"]
+            assert abs(cur.mixture_loglik() - want) <= 1e-10 * abs(want)
+            cand = chain.propose(
+                clusters=clusters if not np.array_equal(clusters, prev_clusters) else None,
+                source_rows=(changed_src, source[changed_src]),
+                weights=weights if not np.array_equal(weights, prev_weights) else None)
+            assert abs(cand.mixture_loglik() - tr.mixture_ll[i]) <= 1e-10 * abs(tr.mixture_ll[i])
+        chain.accept()
+        prev_clusters, prev_source, prev_weights = clusters, source, weights
+    assert n_rejected > 0
+    counts = orc.recalculate_feature_counts(fx.features, [prev_clusters] + fx.groups[1:], prev_source)
+    for c in range(fx.n_comp):
+        assert np.array_equal(chain.current.counts(c), counts[c])
