@@ -51,6 +51,10 @@ typedef struct sbe_engine sbe_engine;
 #define SBE_OPT_LOG_MODE 2
 #define SBE_LOG_PER_OBS 0      /* fp64 log per observation, fp64 sum                        */
 #define SBE_LOG_PRODUCT 1      /* fp64 mantissa product + integer exponent, one log/thread  */
+#define SBE_OPT_DEFERRED_CHECKS 3   /* 1: data checks raised by kernels (normalize's positive-sum
+                                       assert, one-hot source) are reported by the next call that
+                                       synchronizes (sbe_sync, any result fetch) instead of
+                                       immediately, so state-setting calls never stall the stream */
 
 typedef struct sbe_info {
     int32_t abi_version;

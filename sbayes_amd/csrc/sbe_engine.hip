@@ -82,6 +82,9 @@ struct sbe_engine {
     uint8_t* d_changed = nullptr;  // [Gtot]
     uint8_t* d_scratch = nullptr;  size_t scratch_bytes = 0;     // general staging
     uint8_t* h_pinned = nullptr;   size_t pinned_bytes = 0;      // pinned D2H staging
+    uint8_t* h_arena = nullptr;    size_t arena_bytes = 0, arena_off = 0;   // pinned H2D staging ring
+    int opt_deferred = 0;          // SBE_OPT_DEFERRED_CHECKS: data checks reported at the next sync
+    bool status_pending = false;
     std::vector<Slot> slots;
 
     int64_t table_elems() const { return (int64_t)Gtot * F * S; }
@@ -148,6 +151,9 @@ int ensure_pinned(sbe_engine* e, size_t bytes) {
     return SBE_OK;
 }
 
+int upload(sbe_engine* e, void* dst_dev, const void* src, size_t bytes);
+int synced(sbe_engine* e);
+
 // D2H through the pinned staging buffer (pageable destinations would be staged by the
 // runtime anyway, in smaller pieces)
 int d2h(sbe_engine* e, void* dst, const void* src_dev, size_t bytes) {
@@ -156,15 +162,59 @@ int d2h(sbe_engine* e, void* dst, const void* src_dev, size_t bytes) {
     HIPCHK(e, hipMemcpyAsync(e->h_pinned, src_dev, bytes, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     memcpy(dst, e->h_pinned, bytes);
+    return synced(e);
+}
+
+int h2d(sbe_engine* e, void* dst_dev, const void* src, size_t bytes) { return upload(e, dst_dev, src, bytes); }
+
+// H2D of caller-owned (pageable) memory without a stream synchronize: small payloads are copied into a
+// pinned staging ring and sent with a truly asynchronous hipMemcpyAsync, so the caller's buffer is
+// free when the call returns and state-setting calls do not stall the stream.  The ring wraps after a
+// stream synchronize (single in-order stream: everything staged before it has been consumed).
+int upload(sbe_engine* e, void* dst_dev, const void* src, size_t bytes) {
+    if (bytes == 0) return SBE_OK;
+    if (e->h_arena && bytes <= e->arena_bytes / 4) {
+        const size_t need = (bytes + 63) / 64 * 64;
+        if (e->arena_off + need > e->arena_bytes) {
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+            e->arena_off = 0;
+        }
+        uint8_t* stage = e->h_arena + e->arena_off;
+        e->arena_off += need;
+        memcpy(stage, src, bytes);
+        HIPCHK(e, hipMemcpyAsync(dst_dev, stage, bytes, hipMemcpyHostToDevice, e->stream));
+        return SBE_OK;
+    }
+    HIPCHK(e, hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
     return SBE_OK;
 }
 
-int h2d(sbe_engine* e, void* dst_dev, const void* src, size_t bytes) {
-    HIPCHK(e, hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, e->stream));
-    // pageable source: the runtime has consumed `src` when the call returns only after a
-    // synchronize; callers own their buffers, so make the hand-over explicit.
+// Data checks raised by kernels (normalize's positive-sum assert, one-hot source).  Immediate mode:
+// synchronize and report now.  Deferred mode (SBE_OPT_DEFERRED_CHECKS): queue the status read-back and
+// report at the next call that synchronizes anyway.
+int report_status(sbe_engine* e) {
+    const int bad_norm = e->h_status[ST_BAD_NORMALIZE], multi_src = e->h_status[ST_MULTI_SOURCE];
+    if (!bad_norm && !multi_src) return SBE_OK;
+    e->h_status[ST_BAD_NORMALIZE] = e->h_status[ST_MULTI_SOURCE] = 0;
+    (void)hipMemsetAsync(e->d_status + ST_BAD_NORMALIZE, 0, 2 * sizeof(int), e->stream);
+    if (bad_norm)
+        return fail(e, SBE_ERR_DATA, "normalize: %d rows have a non-positive sum (sbayes/util.py:1006 assert)", bad_norm);
+    return fail(e, SBE_ERR_DATA, "source is not one-hot over components in %d observations", multi_src);
+}
+
+int check_after(sbe_engine* e) {          // after enqueuing a kernel that may raise a data check
+    HIPCHK(e, hipMemcpyAsync(e->h_status, e->d_status, ST_WORDS * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    if (e->opt_deferred) { e->status_pending = true; return SBE_OK; }
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    return SBE_OK;
+    e->status_pending = false;
+    return report_status(e);
+}
+
+int synced(sbe_engine* e) {               // call right after any hipStreamSynchronize in a result path
+    if (!e->status_pending) return SBE_OK;
+    e->status_pending = false;
+    return report_status(e);
 }
 
 int read_status(sbe_engine* e) {
@@ -174,6 +224,7 @@ int read_status(sbe_engine* e) {
 }
 
 int clear_status_word(sbe_engine* e, int word) {
+    if (e->status_pending) return SBE_OK;      // sticky until the deferred report has been delivered
     HIPCHK(e, hipMemsetAsync(e->d_status + word, 0, sizeof(int), e->stream));
     return SBE_OK;
 }
@@ -212,10 +263,9 @@ int upload_patterns_and_weights(sbe_engine* e, int slot) {
         if ((int)s.patterns.size() > e->Pmax)
             return fail(e, SBE_ERR_ARG, "%zu distinct has_components patterns exceed capacity %d",
                         s.patterns.size(), e->Pmax);
-        HIPCHK(e, hipMemcpyAsync(e->d_pid + (int64_t)slot * e->Np, s.h_pid.data(), e->N,
-                                 hipMemcpyHostToDevice, e->stream));
-        HIPCHK(e, hipMemcpyAsync(e->d_patbits + (int64_t)slot * e->Pmax, s.patterns.data(),
-                                 s.patterns.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        { int _urc = upload(e, e->d_pid + (int64_t)slot * e->Np, s.h_pid.data(), e->N); if (_urc) return _urc; }
+        { int _urc = upload(e, e->d_patbits + (int64_t)slot * e->Pmax, s.patterns.data(),
+                                 s.patterns.size() * sizeof(uint32_t)); if (_urc) return _urc; }
         // distinct group tuples (g_0..g_{C-1}) of the objects, for the group-tuple kernel
         {
             const int N = e->N, C = e->C;
@@ -239,13 +289,12 @@ int upload_patterns_and_weights(sbe_engine* e, int slot) {
             }
             s.n_tuples = ok ? (int)tuples.size() : 0;
             if (ok) {
-                HIPCHK(e, hipMemcpyAsync(e->d_tid + (int64_t)slot * e->Np, tid.data(), e->Np, hipMemcpyHostToDevice, e->stream));
-                HIPCHK(e, hipMemcpyAsync(e->d_tuple_g + (int64_t)slot * kMaxTuples * kMaxComponents, tg.data(),
-                                         tg.size() * sizeof(uint16_t), hipMemcpyHostToDevice, e->stream));
-                HIPCHK(e, hipMemcpyAsync(e->d_tuple_p + (int64_t)slot * kMaxTuples, tp.data(), tp.size(), hipMemcpyHostToDevice, e->stream));
+                { int _urc = upload(e, e->d_tid + (int64_t)slot * e->Np, tid.data(), e->Np); if (_urc) return _urc; }
+                { int _urc = upload(e, e->d_tuple_g + (int64_t)slot * kMaxTuples * kMaxComponents, tg.data(),
+                                         tg.size() * sizeof(uint16_t)); if (_urc) return _urc; }
+                { int _urc = upload(e, e->d_tuple_p + (int64_t)slot * kMaxTuples, tp.data(), tp.size()); if (_urc) return _urc; }
             }
         }
-        HIPCHK(e, hipStreamSynchronize(e->stream));
         s.patterns_dirty = false;
     }
     if (s.weights_set) {
@@ -505,6 +554,7 @@ int sbe_destroy(sbe_engine* e) {
     if (e->h_results) (void)hipHostFree(e->h_results);
     if (e->h_status) (void)hipHostFree(e->h_status);
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
+    if (e->h_arena) (void)hipHostFree(e->h_arena);
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -622,6 +672,9 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_CHK(hipHostMalloc((void**)&e->h_results, NS * sizeof(double), hipHostMallocMapped));
     CREATE_CHK(hipHostGetDevicePointer((void**)&e->d_results, e->h_results, 0));
     CREATE_CHK(hipHostMalloc((void**)&e->h_status, ST_WORDS * sizeof(int), hipHostMallocDefault));
+    memset(e->h_status, 0, ST_WORDS * sizeof(int));
+    e->arena_bytes = (size_t)16 << 20;
+    CREATE_CHK(hipHostMalloc((void**)&e->h_arena, e->arena_bytes, hipHostMallocDefault));
 
     CREATE_CHK(hipMemsetAsync(e->d_status, 0, ST_WORDS * sizeof(int), e->stream));
     CREATE_CHK(hipMemsetAsync(e->d_onehot, 0, N * e->rs_pitch, e->stream));
@@ -683,13 +736,18 @@ int sbe_set_option(sbe_engine* e, int option, int value) {
     CHECK_ENGINE(e);
     if (option == SBE_OPT_MIXTURE_KERNEL && (value == SBE_MIXTURE_PACKED || value == SBE_MIXTURE_ONEHOT || value == SBE_MIXTURE_PACKED_GENERAL || value == SBE_MIXTURE_PACKED_TUPLE)) { e->opt_kernel = value; return SBE_OK; }
     if (option == SBE_OPT_LOG_MODE && (value == SBE_LOG_PER_OBS || value == SBE_LOG_PRODUCT)) { e->opt_log = value; return SBE_OK; }
+    if (option == SBE_OPT_DEFERRED_CHECKS && (value == 0 || value == 1)) {
+        if (!value && e->status_pending) { HIPCHK(e, hipStreamSynchronize(e->stream)); int rc = synced(e); e->opt_deferred = 0; return rc; }
+        e->opt_deferred = value;
+        return SBE_OK;
+    }
     return fail(e, SBE_ERR_ARG, "unknown option %d / value %d", option, value);
 }
 
 int sbe_sync(sbe_engine* e) {
     CHECK_ENGINE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    return SBE_OK;
+    return synced(e);
 }
 
 // ---- a1 -------------------------------------------------------------------------------------
@@ -726,8 +784,8 @@ int sbe_component_lh(sbe_engine* e, const void* probs, int probs_f64, int n_grou
     uint8_t* d_tab = e->d_scratch;
     int32_t* d_sel = (int32_t*)(e->d_scratch + tab_pad);
     double* d_out = (double*)(e->d_scratch + tab_pad + sel_bytes);
-    HIPCHK(e, hipMemcpyAsync(d_tab, probs, tab_bytes, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(d_sel, sel.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    { int _urc = upload(e, d_tab, probs, tab_bytes); if (_urc) return _urc; }
+    { int _urc = upload(e, d_sel, sel.data(), (size_t)N * sizeof(int32_t)); if (_urc) return _urc; }
     const int blocks = div_up((int64_t)N * F, 256);
     if (probs_f64) k_component_lh<double><<<blocks, 256, 0, e->stream>>>(e->d_state, (const double*)d_tab, d_sel, d_out, N, F, S, e->Fp);
     else k_component_lh<float><<<blocks, 256, 0, e->stream>>>(e->d_state, (const float*)d_tab, d_sel, d_out, N, F, S, e->Fp);
@@ -752,9 +810,8 @@ int sbe_component_lh(sbe_engine* e, const void* probs, int probs_f64, int n_grou
 static int set_gid_common(sbe_engine* e, int slot, int component, const std::vector<uint16_t>& ids) {
     Slot& s = e->slots[slot];
     std::copy(ids.begin(), ids.end(), s.h_gid.begin() + (size_t)component * e->N);
-    HIPCHK(e, hipMemcpyAsync(e->d_gid + ((int64_t)slot * e->C + component) * e->Np, ids.data(),
-                             (size_t)e->N * sizeof(uint16_t), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    { int _urc = upload(e, e->d_gid + ((int64_t)slot * e->C + component) * e->Np, ids.data(),
+                             (size_t)e->N * sizeof(uint16_t)); if (_urc) return _urc; }
     s.patterns_dirty = true;
     s.groups_set = true;   // components never set keep "no group" ids
     return SBE_OK;
@@ -793,15 +850,12 @@ int sbe_set_source(sbe_engine* e, int slot, const uint8_t* source) {
     if (rc) return rc;
     rc = clear_status_word(e, ST_MULTI_SOURCE);
     if (rc) return rc;
-    HIPCHK(e, hipMemcpyAsync(e->d_scratch, source, bytes, hipMemcpyHostToDevice, e->stream));
+    { int _urc = upload(e, e->d_scratch, source, bytes); if (_urc) return _urc; }
     k_ingest_source<<<div_up((int64_t)e->N * e->F, 256), 256, 0, e->stream>>>(
         e->d_scratch, nullptr, e->d_src + (int64_t)slot * e->N * e->Fp, e->N, e->F, e->C, e->Fp, e->d_status);
     HIPCHK(e, hipGetLastError());
-    rc = read_status(e);
-    if (rc) return rc;
-    if (e->h_status[ST_MULTI_SOURCE]) return fail(e, SBE_ERR_DATA, "source is not one-hot over components in %d observations", e->h_status[ST_MULTI_SOURCE]);
     e->slots[slot].source_set = true;
-    return SBE_OK;
+    return check_after(e);
 }
 
 int sbe_set_source_rows(sbe_engine* e, int slot, const int32_t* objects, int n_rows, const uint8_t* rows) {
@@ -819,15 +873,12 @@ int sbe_set_source_rows(sbe_engine* e, int slot, const int32_t* objects, int n_r
     rc = clear_status_word(e, ST_MULTI_SOURCE);
     if (rc) return rc;
     int32_t* d_obj = (int32_t*)(e->d_scratch + row_pad);
-    HIPCHK(e, hipMemcpyAsync(e->d_scratch, rows, row_bytes, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(d_obj, objects, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    { int _urc = upload(e, e->d_scratch, rows, row_bytes); if (_urc) return _urc; }
+    { int _urc = upload(e, d_obj, objects, (size_t)n_rows * sizeof(int32_t)); if (_urc) return _urc; }
     k_ingest_source<<<div_up((int64_t)n_rows * e->F, 256), 256, 0, e->stream>>>(
         e->d_scratch, d_obj, e->d_src + (int64_t)slot * e->N * e->Fp, n_rows, e->F, e->C, e->Fp, e->d_status);
     HIPCHK(e, hipGetLastError());
-    rc = read_status(e);
-    if (rc) return rc;
-    if (e->h_status[ST_MULTI_SOURCE]) return fail(e, SBE_ERR_DATA, "source rows are not one-hot over components");
-    return SBE_OK;
+    return check_after(e);
 }
 
 // ---- counts -----------------------------------------------------------------------------------
@@ -859,15 +910,13 @@ int sbe_update_counts(sbe_engine* e, int slot_new, int slot_old, const int32_t* 
     if (n_subset > 0) {
         int rc = ensure_scratch(e, (size_t)n_subset * sizeof(int32_t));
         if (rc) return rc;
-        HIPCHK(e, hipMemcpyAsync(e->d_scratch, objects, (size_t)n_subset * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+        { int _urc = upload(e, e->d_scratch, objects, (size_t)n_subset * sizeof(int32_t)); if (_urc) return _urc; }
         rc = counts_launch(e, slot_new, +1, slot_old, -1, (const int32_t*)e->d_scratch, n_subset, slot_new, true, e->d_changed);
         if (rc) return rc;
     }
     if (changed_groups_out) {
         int rc = d2h(e, changed_groups_out, e->d_changed, e->Gtot);
         if (rc) return rc;
-    } else {
-        HIPCHK(e, hipStreamSynchronize(e->stream));
     }
     return SBE_OK;
 }
@@ -885,12 +934,11 @@ int sbe_accumulate_counts(sbe_engine* e, int slot, const int32_t* objects, int n
     if (n_subset > 0) {
         int rc = ensure_scratch(e, (size_t)n_subset * sizeof(int32_t));
         if (rc) return rc;
-        HIPCHK(e, hipMemcpyAsync(e->d_scratch, objects, (size_t)n_subset * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+        { int _urc = upload(e, e->d_scratch, objects, (size_t)n_subset * sizeof(int32_t)); if (_urc) return _urc; }
         rc = counts_launch(e, slot, sign, slot, 0, (const int32_t*)e->d_scratch, n_subset, slot, true, e->d_changed);
         if (rc) return rc;
     }
     if (changed_groups_out) return d2h(e, changed_groups_out, e->d_changed, e->Gtot);
-    HIPCHK(e, hipStreamSynchronize(e->stream));
     return SBE_OK;
 }
 
@@ -900,11 +948,10 @@ int sbe_set_counts(sbe_engine* e, int slot, int component, const float* counts) 
     const int64_t n = (int64_t)e->G[component] * e->F * e->S;
     int rc = ensure_scratch(e, n * sizeof(float));
     if (rc) return rc;
-    HIPCHK(e, hipMemcpyAsync(e->d_scratch, counts, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    { int _urc = upload(e, e->d_scratch, counts, n * sizeof(float)); if (_urc) return _urc; }
     int32_t* dst = e->d_counts + (int64_t)slot * e->table_elems() + (int64_t)e->goff[component] * e->F * e->S;
     k_f32_to_i32<<<div_up(n, 256), 256, 0, e->stream>>>((const float*)e->d_scratch, dst, n);
     HIPCHK(e, hipGetLastError());
-    HIPCHK(e, hipStreamSynchronize(e->stream));
     e->slots[slot].counts_set[component] = 1;
     return SBE_OK;
 }
@@ -928,12 +975,11 @@ int sbe_set_concentration(sbe_engine* e, int component, const double* conc, int 
     const int64_t fs = (int64_t)e->F * e->S;
     double* dst = e->d_conc + (int64_t)e->goff[component] * fs;
     if (per_group) {
-        HIPCHK(e, hipMemcpyAsync(dst, conc, e->G[component] * fs * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        { int _urc = upload(e, dst, conc, e->G[component] * fs * sizeof(double)); if (_urc) return _urc; }
     } else {
         for (int g = 0; g < e->G[component]; ++g)
-            HIPCHK(e, hipMemcpyAsync(dst + g * fs, conc, fs * sizeof(double), hipMemcpyHostToDevice, e->stream));
+            { int _urc = upload(e, dst + g * fs, conc, fs * sizeof(double)); if (_urc) return _urc; }
     }
-    HIPCHK(e, hipStreamSynchronize(e->stream));
     e->conc_set[component] = 1;
     return SBE_OK;
 }
@@ -948,7 +994,7 @@ int sbe_update_probs(sbe_engine* e, int slot, int component, double temperature,
     HIPCHK(e, hipSetDevice(e->device));
     const double* d_unif = nullptr;
     if (prior_temperature > 0.0) {
-        HIPCHK(e, hipMemcpyAsync(e->d_unif, unif_counts, (size_t)e->F * e->S * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        { int _urc = upload(e, e->d_unif, unif_counts, (size_t)e->F * e->S * sizeof(double)); if (_urc) return _urc; }
         d_unif = e->d_unif;
     }
     int rc = clear_status_word(e, ST_BAD_NORMALIZE);
@@ -958,15 +1004,10 @@ int sbe_update_probs(sbe_engine* e, int slot, int component, double temperature,
         e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc, d_unif,
         e->d_probs + (int64_t)slot * e->table_elems(), g_lo, g_hi, e->F, e->S, temperature, prior_temperature, 1, e->d_status);
     HIPCHK(e, hipGetLastError());
-    rc = read_status(e);
-    if (rc) return rc;
-    if (e->h_status[ST_BAD_NORMALIZE])
-        return fail(e, SBE_ERR_DATA, "normalize: %d rows of component %d have a non-positive sum (sbayes/util.py:1006 assert)",
-                    e->h_status[ST_BAD_NORMALIZE], component);
     rc = retile_probs(e, slot, component);
     if (rc) return rc;
     s.probs_set[component] = 1;
-    return SBE_OK;
+    return check_after(e);
 }
 
 int sbe_set_probs(sbe_engine* e, int slot, int component, const float* probs) {
@@ -1086,7 +1127,7 @@ int sbe_fetch_results(sbe_engine* e, int first_slot, int n, double* out) {
     if (n < 1 || first_slot + n > e->n_slots) return fail(e, SBE_ERR_ARG, "slot range out of range");
     HIPCHK(e, hipStreamSynchronize(e->stream));     // results were written straight into mapped host memory
     memcpy(out, e->h_results + first_slot, (size_t)n * sizeof(double));
-    return SBE_OK;
+    return synced(e);
 }
 
 int sbe_mixture_loglik_batch(sbe_engine* e, int first_slot, int n, double* out) {
@@ -1143,11 +1184,11 @@ int sbe_normalize_tables(sbe_engine* e, const float* counts, int n_groups, const
     double* d_a = (double*)(e->d_scratch + cb);
     double* d_u = (double*)(e->d_scratch + cb + ab);
     float* d_out = (float*)(e->d_scratch + cb + ab + ub);
-    HIPCHK(e, hipMemcpyAsync(d_cnt, counts, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(d_a, conc, (size_t)(conc_per_group ? n : fs) * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    { int _urc = upload(e, d_cnt, counts, (size_t)n * sizeof(float)); if (_urc) return _urc; }
+    { int _urc = upload(e, d_a, conc, (size_t)(conc_per_group ? n : fs) * sizeof(double)); if (_urc) return _urc; }
     const double* d_unif = nullptr;
     if (prior_temperature > 0.0) {
-        HIPCHK(e, hipMemcpyAsync(d_u, unif_counts, (size_t)fs * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        { int _urc = upload(e, d_u, unif_counts, (size_t)fs * sizeof(double)); if (_urc) return _urc; }
         d_unif = d_u;
     }
     rc = clear_status_word(e, ST_BAD_NORMALIZE);
@@ -1180,8 +1221,8 @@ int sbe_dirichlet_logpdf(sbe_engine* e, const float* counts, int n_groups, const
     double* d_a = (double*)(e->d_scratch + cb);
     float* d_pf = (float*)(e->d_scratch + cb + ab);
     double* d_pg = (double*)(e->d_scratch + cb + ab + pf);
-    HIPCHK(e, hipMemcpyAsync(d_cnt, counts, (size_t)n * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(d_a, conc, (size_t)(conc_per_group ? n : fs) * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    { int _urc = upload(e, d_cnt, counts, (size_t)n * sizeof(float)); if (_urc) return _urc; }
+    { int _urc = upload(e, d_a, conc, (size_t)(conc_per_group ? n : fs) * sizeof(double)); if (_urc) return _urc; }
     k_dcl<float><<<div_up((int64_t)n_groups * e->F, 256), 256, 0, e->stream>>>(d_cnt, d_a, d_pf, 0, n_groups, e->F, e->S, conc_per_group ? 1 : 0);
     HIPCHK(e, hipGetLastError());
     if (per_group_out) {
@@ -1216,9 +1257,9 @@ int sbe_effect_counts(sbe_engine* e, const uint8_t* groups, int n_groups, const 
     int32_t* d_obj = (int32_t*)(e->d_scratch + gb + mb);
     int32_t* d_cnt = (int32_t*)(e->d_scratch + gb + mb + ob);
     float* d_out = (float*)(e->d_scratch + gb + mb + ob + cb);
-    HIPCHK(e, hipMemcpyAsync(d_groups, groups, (size_t)n_groups * N, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(d_mask, source_is_component, (size_t)N * F, hipMemcpyHostToDevice, e->stream));
-    if (n_subset > 0) HIPCHK(e, hipMemcpyAsync(d_obj, objects, (size_t)n_subset * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    { int _urc = upload(e, d_groups, groups, (size_t)n_groups * N); if (_urc) return _urc; }
+    { int _urc = upload(e, d_mask, source_is_component, (size_t)N * F); if (_urc) return _urc; }
+    if (n_subset > 0) { int _urc = upload(e, d_obj, objects, (size_t)n_subset * sizeof(int32_t)); if (_urc) return _urc; }
     HIPCHK(e, hipMemsetAsync(d_cnt, 0, (size_t)n_out * sizeof(int32_t), e->stream));
     if (n_listed > 0) {
         int ft = 32;
@@ -1270,9 +1311,9 @@ int sbe_normalize_weights(sbe_engine* e, const float* weights, int n_comp, const
     float* d_tab = (float*)(e->d_scratch + wb + pb);
     uint8_t* d_pid = e->d_scratch + wb + pb + tb;
     float* d_out = (float*)(e->d_scratch + wb + pb + tb + ib);
-    HIPCHK(e, hipMemcpyAsync(d_w, weights, (size_t)F * C * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(d_pb, uniq.data(), (size_t)P * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(d_pid, pid.data(), (size_t)N, hipMemcpyHostToDevice, e->stream));
+    { int _urc = upload(e, d_w, weights, (size_t)F * C * sizeof(float)); if (_urc) return _urc; }
+    { int _urc = upload(e, d_pb, uniq.data(), (size_t)P * sizeof(uint32_t)); if (_urc) return _urc; }
+    { int _urc = upload(e, d_pid, pid.data(), (size_t)N); if (_urc) return _urc; }
     k_weight_patterns<<<div_up((int64_t)P * F, 256), 256, 0, e->stream>>>(d_w, d_pb, d_tab, P, F, C);
     HIPCHK(e, hipGetLastError());
     k_expand_weights<<<div_up(n_out, 256), 256, 0, e->stream>>>(d_tab, d_pid, d_out, N, F, C);
@@ -1306,8 +1347,8 @@ int sbe_cluster_marginals(sbe_engine* e, int slot, const float* table, const int
     float* d_wf = (float*)(e->d_scratch + tb + wb);
     int32_t* d_obj = (int32_t*)(e->d_scratch + tb + 2 * wb);
     double* d_out = (double*)(e->d_scratch + tb + 2 * wb + ob);
-    HIPCHK(e, hipMemcpyAsync(d_tab, table, (size_t)F * S * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(d_obj, objects, (size_t)n_objects_av * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    { int _urc = upload(e, d_tab, table, (size_t)F * S * sizeof(float)); if (_urc) return _urc; }
+    { int _urc = upload(e, d_obj, objects, (size_t)n_objects_av * sizeof(int32_t)); if (_urc) return _urc; }
     const double inv = 1.0 / prior_temperature;
     k_weight_tables_z<<<div_up((int64_t)P * F, 256), 256, 0, e->stream>>>(
         e->d_weights + (int64_t)slot * F * C, e->d_patbits + (int64_t)slot * e->Pmax, d_wc, d_wf, P, F, C,
@@ -1340,7 +1381,7 @@ int sbe_source_posterior(sbe_engine* e, int slot, const int32_t* objects, int n_
     if (rc) return rc;
     int32_t* d_obj = (int32_t*)e->d_scratch;
     float* d_out = (float*)(e->d_scratch + ob);
-    HIPCHK(e, hipMemcpyAsync(d_obj, objects, (size_t)n_sub * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    { int _urc = upload(e, d_obj, objects, (size_t)n_sub * sizeof(int32_t)); if (_urc) return _urc; }
     rc = clear_status_word(e, ST_BAD_NORMALIZE);
     if (rc) return rc;
     const double inv_t = 1.0 / temperature, inv_tp = 1.0 / prior_temperature;
@@ -1387,10 +1428,10 @@ int sbe_subset_lh(sbe_engine* e, const int32_t* objects, int n_sub, int n_comp, 
     int32_t* d_gi = (int32_t*)(e->d_scratch + tb + ob);
     int32_t* d_off = (int32_t*)(e->d_scratch + tb + ob + gb);
     float* d_out = (float*)(e->d_scratch + tb + ob + gb + 256);
-    HIPCHK(e, hipMemcpyAsync(d_tab, tables, (size_t)n_tables_total * fs * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(d_obj, objects, (size_t)n_sub * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(d_gi, group_idx, (size_t)n_comp * n_sub * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(d_off, table_offsets, (size_t)n_comp * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    { int _urc = upload(e, d_tab, tables, (size_t)n_tables_total * fs * sizeof(float)); if (_urc) return _urc; }
+    { int _urc = upload(e, d_obj, objects, (size_t)n_sub * sizeof(int32_t)); if (_urc) return _urc; }
+    { int _urc = upload(e, d_gi, group_idx, (size_t)n_comp * n_sub * sizeof(int32_t)); if (_urc) return _urc; }
+    { int _urc = upload(e, d_off, table_offsets, (size_t)n_comp * sizeof(int32_t)); if (_urc) return _urc; }
     const double inv_t = 1.0 / temperature;
     k_subset_lh<<<div_up((int64_t)n_sub * e->F, 256), 256, 0, e->stream>>>(
         e->d_state, d_tab, d_off, d_gi, d_obj, n_sub, d_out, e->F, e->S, n_comp, e->Fp, (float)inv_t, inv_t != 1.0);

@@ -15,7 +15,7 @@ from . import _lib
 
 MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE = 0, 1, 2, 3
 LOG_PER_OBS, LOG_PRODUCT = 0, 1
-_OPT_KERNEL, _OPT_LOG = 1, 2
+_OPT_KERNEL, _OPT_LOG, _OPT_DEFERRED = 1, 2, 3
 
 
 class EngineError(RuntimeError):
@@ -102,7 +102,9 @@ class Engine:
         self._check(self._lib.sbe_get_info(self._h, ct.byref(inf)))
         return {k: (getattr(inf, k).decode() if k == "device_name" else getattr(inf, k)) for k, _ in inf._fields_}
 
-    def set_option(self, kernel=None, log_mode=None):
+    def set_option(self, kernel=None, log_mode=None, deferred_checks=None):
+        if deferred_checks is not None:
+            self._check(self._lib.sbe_set_option(self._h, _OPT_DEFERRED, int(bool(deferred_checks))))
         if kernel is not None:
             self._check(self._lib.sbe_set_option(self._h, _OPT_KERNEL, int(kernel)))
         if log_mode is not None:

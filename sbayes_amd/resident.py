@@ -52,6 +52,7 @@ class ResidentChain:
         self.cur, self.cand = slots
         self.names = list(sample.component_names)
         eng = self.eng
+        eng.set_option(deferred_checks=True)      # setters never stall the stream; checks surface at the next fetch
         conc = [np.asarray(model.prior.prior_cluster_effect.concentration_array)] + [
             np.asarray(model.prior.prior_confounding_effects[k].concentration_array(sample)) for k in self.names[1:]]
         groups = [sample.clusters.value] + [c.group_assignment for c in sample.confounders.values()]

@@ -270,3 +270,26 @@ def test_known_answers_on_device():
         eng.load_state(0, [cl, groups], np.array([[0.5, 0.5]], dtype=np.float32),
                        probs=[np.array([[[1.0, 0.0]]], dtype=np.float32), np.array([[[0.5, 0.5]]], dtype=np.float32)])
         assert eng.weights_normalized(0).tolist() == cases["weights_pattern"]["expected"]
+
+
+def test_deferred_checks_surface_at_next_sync():
+    """SBE_OPT_DEFERRED_CHECKS: the normalize() assert raised by a kernel is reported by the next
+    synchronizing call instead of stalling the state-setting call."""
+    feats = np.zeros((3, 1, 2), dtype=bool)
+    feats[0, 0, 0] = feats[1, 0, 0] = feats[2, 0, 1] = True
+    with Engine(feats, [1], n_slots=1) as eng:
+        eng.set_option(deferred_checks=True)
+        eng.set_concentration(0, np.zeros((1, 2)))
+        eng.set_groups(0, 0, np.zeros((1, 3), dtype=bool))
+        eng.set_source(0, np.zeros((3, 1, 1), dtype=bool))
+        eng.recount(0)
+        eng.update_probs(0, 0)                      # does not raise here
+        with pytest.raises(EngineError, match="non-positive sum"):
+            eng.sync()
+        eng.sync()                                  # reported once
+        eng.set_concentration(0, np.ones((1, 2)))
+        eng.set_groups(0, 0, np.ones((1, 3), dtype=bool))
+        eng.update_probs(0, 0)                      # counts 0 + prior 1 -> tables (0.5, 0.5)
+        eng.set_weights(0, np.ones((1, 1), dtype=np.float32))
+        assert np.isclose(eng.mixture_loglik(0), 3 * np.log(0.5), rtol=1e-14)
+        eng.set_option(deferred_checks=False)
