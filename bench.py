@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--workload", default="headline", choices=["cfg1", "headline", "stress"])
     ap.add_argument("--batch", type=int, default=256,
                     help="resident sample states (chains x candidate states) evaluated per step")
-    ap.add_argument("--kernel", default="packed", choices=["packed", "packed_general", "onehot"],
+    ap.add_argument("--kernel", default="packed", choices=["packed", "packed_general", "onehot", "onehot_general"],
                     help="packed: state-index stream, group-tuple form when it applies (default); "
                          "packed_general: never the group-tuple form; onehot: stream the one-hot block")
     ap.add_argument("--log-mode", default="product", choices=["product", "per_obs"])
@@ -61,12 +61,12 @@ def parse():
 
 
 def setup_engine(wl, batch, device, kernel, log_mode):
-    from sbayes_amd.engine import (LOG_PER_OBS, LOG_PRODUCT, MIXTURE_ONEHOT, MIXTURE_PACKED,
+    from sbayes_amd.engine import (LOG_PER_OBS, LOG_PRODUCT, MIXTURE_ONEHOT, MIXTURE_ONEHOT_GENERAL, MIXTURE_PACKED,
                                    MIXTURE_PACKED_GENERAL, Engine)
     from sbayes_amd.synthetic import make_state
 
     eng = Engine(wl.features, [g.shape[0] for g in wl.groups], n_slots=batch, device=device)
-    eng.set_option(kernel={"onehot": MIXTURE_ONEHOT, "packed": MIXTURE_PACKED,
+    eng.set_option(kernel={"onehot": MIXTURE_ONEHOT, "onehot_general": MIXTURE_ONEHOT_GENERAL, "packed": MIXTURE_PACKED,
                            "packed_general": MIXTURE_PACKED_GENERAL}[kernel],
                    log_mode=LOG_PRODUCT if log_mode == "product" else LOG_PER_OBS)
     for c in range(wl.n_components):
@@ -251,7 +251,7 @@ def main():
     # ---- roofline of the dominant kernel, HIP events on the engine's stream ---------------------
     has_comp = np.stack([g.any(axis=0) for g in wl.groups], axis=1)
     n_pat = len(np.unique(has_comp, axis=0))          # distinct has_components rows (likelihood.py:183)
-    packed = args.kernel != "onehot"
+    packed = not args.kernel.startswith("onehot")
     b_eval = algorithmic_bytes(n_obj, n_feat, n_states, [g.shape[0] for g in wl.groups], n_pat, packed=packed)
     prof_iters = min(max(args.steps, 20), 200)
     _total_ms, kern_ms = eng.profile_mixture(0, B, prof_iters)
@@ -261,7 +261,8 @@ def main():
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
         "kernel": {"packed": "k_mixture_combo (group-tuple form; k_mixture_v2 when not applicable)",
                    "packed_general": f"k_mixture_v2<{args.log_mode}>",
-                   "onehot": f"k_mixture_onehot_v2<{args.log_mode}>"}[args.kernel],
+                   "onehot": "k_mixture_combo<onehot> (group-tuple form; k_mixture_onehot_v2 when not applicable)",
+                   "onehot_general": f"k_mixture_onehot_v2<{args.log_mode}>"}[args.kernel],
         "kernel_avg_us": round(kern_ms * 1e3, 3),
         "algorithmic_bytes_per_eval": b_eval, "evals_per_launch": B,
         "representation": "packed state index (N*F bytes)" if packed else "one-hot (N*F*S bytes)",

@@ -45,7 +45,9 @@ typedef struct sbe_engine sbe_engine;
 #define SBE_MIXTURE_PACKED 0   /* reads the packed state-index block  (N*F bytes); uses the
                                   group-tuple form (one log per (tuple, state, feature)
                                   instead of per observation) whenever it applies          */
-#define SBE_MIXTURE_ONEHOT 1   /* reads the one-hot block as handed over (N*F*S bytes)      */
+#define SBE_MIXTURE_ONEHOT 1   /* reads the one-hot block as handed over (N*F*S bytes);
+                                  group-tuple form whenever it applies                      */
+#define SBE_MIXTURE_ONEHOT_GENERAL 4  /* one-hot stream, never the group-tuple form          */
 #define SBE_MIXTURE_PACKED_GENERAL 2  /* packed, but never the group-tuple form (testing / A-B) */
 #define SBE_MIXTURE_PACKED_TUPLE 3    /* packed, group-tuple form forced (error if not applicable) */
 #define SBE_OPT_LOG_MODE 2

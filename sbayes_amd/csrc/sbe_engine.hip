@@ -390,21 +390,22 @@ void launch_oh2(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipSt
     else launch_oh2_ft<MODE, 16>(C, p, grid, lds, st);
 }
 
-template <int FT>
+template <int FT, bool ONEHOT>
 void launch_combo_ft(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
     switch (C) {
-        case 1: k_mixture_combo<FT, 1><<<grid, kBlock, lds, st>>>(p); break;
-        case 2: k_mixture_combo<FT, 2><<<grid, kBlock, lds, st>>>(p); break;
-        case 3: k_mixture_combo<FT, 3><<<grid, kBlock, lds, st>>>(p); break;
-        case 4: k_mixture_combo<FT, 4><<<grid, kBlock, lds, st>>>(p); break;
-        default: k_mixture_combo<FT, 0><<<grid, kBlock, lds, st>>>(p); break;
+        case 1: k_mixture_combo<FT, 1, ONEHOT><<<grid, kBlock, lds, st>>>(p); break;
+        case 2: k_mixture_combo<FT, 2, ONEHOT><<<grid, kBlock, lds, st>>>(p); break;
+        case 3: k_mixture_combo<FT, 3, ONEHOT><<<grid, kBlock, lds, st>>>(p); break;
+        case 4: k_mixture_combo<FT, 4, ONEHOT><<<grid, kBlock, lds, st>>>(p); break;
+        default: k_mixture_combo<FT, 0, ONEHOT><<<grid, kBlock, lds, st>>>(p); break;
     }
 }
 
+template <bool ONEHOT>
 void launch_combo(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
-    if (ft == 64) launch_combo_ft<64>(C, p, grid, lds, st);
-    else if (ft == 32) launch_combo_ft<32>(C, p, grid, lds, st);
-    else launch_combo_ft<16>(C, p, grid, lds, st);
+    if (ft == 64) launch_combo_ft<64, ONEHOT>(C, p, grid, lds, st);
+    else if (ft == 32) launch_combo_ft<32, ONEHOT>(C, p, grid, lds, st);
+    else launch_combo_ft<16, ONEHOT>(C, p, grid, lds, st);
 }
 
 template <int MODE>
@@ -418,7 +419,7 @@ void launch_v2(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStr
 // partial reduction.  mode: LOG_PER_OBS / LOG_PRODUCT.
 int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev_a, hipEvent_t ev_b) {
     const int P = max_patterns(e, first_slot, n);
-    const bool onehot = e->opt_kernel == SBE_MIXTURE_ONEHOT;
+    const bool onehot = e->opt_kernel == SBE_MIXTURE_ONEHOT || e->opt_kernel == SBE_MIXTURE_ONEHOT_GENERAL;
     MixGeom g = mix_geometry_v2(e, P, n);
     if (!g.ft) return fail(e, SBE_ERR_ARG, "probability tables too large for LDS staging (G_total=%d, S=%d)", e->Gtot, e->S);
     if (g.n_blocks > e->partials_stride) return fail(e, SBE_ERR_STATE, "internal: partials buffer too small (%d > %lld)", g.n_blocks, (long long)e->partials_stride);
@@ -454,7 +455,7 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
         // table fits LDS and a block sees enough observations to amortise building it
         int KT = 0;
         const bool force_combo = e->opt_kernel == SBE_MIXTURE_PACKED_TUPLE;
-        bool combo = !onehot && (e->opt_kernel == SBE_MIXTURE_PACKED || force_combo);
+        bool combo = e->opt_kernel == SBE_MIXTURE_PACKED || e->opt_kernel == SBE_MIXTURE_ONEHOT || force_combo;
         for (int sl = first_slot; sl < first_slot + n && combo; ++sl) {
             if (e->slots[sl].n_tuples == 0) combo = false;
             KT = std::max(KT, e->slots[sl].n_tuples);
@@ -466,13 +467,20 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
         combo_lds = (combo_lds + 15) / 16 * 16;
         p.combo_w_off = (int)combo_lds;
         combo_lds += (size_t)P * e->C * g.ft * sizeof(double);
+        if (onehot) {      // byte-position lookup table [seg16][32] u16; a tile row segment must fit one step
+            const int seg16 = g.ft * e->S / 16;
+            if (seg16 > kBlock) combo = false;
+            p.combo_tab_off = (int)combo_lds;
+            combo_lds += (size_t)seg16 * 32 * sizeof(uint16_t);
+        }
         const int64_t obs_per_block = (int64_t)g.objs_per_chunk * 4 * g.ft;
         if (combo && !force_combo && (combo_lds > 40 * 1024 || obs_per_block < (int64_t)8 * KT * e->S * g.ft)) combo = false;
         if (force_combo && (!combo || combo_lds > 150 * 1024))
             return fail(e, SBE_ERR_ARG, "group-tuple kernel forced but not applicable (tuples=%d, LDS %zu bytes)", KT, combo_lds);
         p.KT = KT;
         if (combo) {
-            launch_combo(g.ft, e->C, p, grid, combo_lds, e->stream);
+            if (onehot) launch_combo<true>(g.ft, e->C, p, grid, combo_lds, e->stream);
+            else launch_combo<false>(g.ft, e->C, p, grid, combo_lds, e->stream);
         } else
         if (onehot) {
             if (mode == LOG_PRODUCT) launch_oh2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
@@ -734,7 +742,7 @@ int sbe_get_na(const sbe_engine* ce, uint8_t* out_na) {
 
 int sbe_set_option(sbe_engine* e, int option, int value) {
     CHECK_ENGINE(e);
-    if (option == SBE_OPT_MIXTURE_KERNEL && (value == SBE_MIXTURE_PACKED || value == SBE_MIXTURE_ONEHOT || value == SBE_MIXTURE_PACKED_GENERAL || value == SBE_MIXTURE_PACKED_TUPLE)) { e->opt_kernel = value; return SBE_OK; }
+    if (option == SBE_OPT_MIXTURE_KERNEL && (value == SBE_MIXTURE_PACKED || value == SBE_MIXTURE_ONEHOT || value == SBE_MIXTURE_PACKED_GENERAL || value == SBE_MIXTURE_PACKED_TUPLE || value == SBE_MIXTURE_ONEHOT_GENERAL)) { e->opt_kernel = value; return SBE_OK; }
     if (option == SBE_OPT_LOG_MODE && (value == SBE_LOG_PER_OBS || value == SBE_LOG_PRODUCT)) { e->opt_log = value; return SBE_OK; }
     if (option == SBE_OPT_DEFERRED_CHECKS && (value == 0 || value == 1)) {
         if (!value && e->status_pending) { HIPCHK(e, hipStreamSynchronize(e->stream)); int rc = synced(e); e->opt_deferred = 0; return rc; }

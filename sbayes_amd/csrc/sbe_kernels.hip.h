@@ -544,6 +544,7 @@ struct Mix2Params {
     const uint8_t* tuple_p;  int64_t tuple_p_stride;   // [kMaxTuples] pattern id of the tuple
     int KT;                                            // tuples used by the slots of this launch (max)
     int combo_w_off;                                   // byte offset of the weight tile in the combo kernel's LDS
+    int combo_tab_off;                                 // byte offset of the one-hot byte -> (state, feature) table
     const uint32_t* state_q;                       // [NQ][Fq]
     const uint8_t* onehot; int rs_pitch;           // [N][rs_pitch] (one-hot variant)
     const uint16_t* gid;   int64_t gid_stride;     // per slot [C][Np]
@@ -911,7 +912,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_onehot_v2(Mix2Params p) {
 // Eligibility (host): KT <= kMaxTuples, the image fits LDS and a block has enough observations to
 // amortise the KT*S*FT logs; otherwise the general k_mixture_v2 runs.
 // ==========================================================================================
-template <int FT, int CT>
+template <int FT, int CT, bool ONEHOT>
 __global__ __launch_bounds__(kBlock) void k_mixture_combo(Mix2Params p) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ double red4[4];
@@ -989,6 +990,8 @@ __global__ __launch_bounds__(kBlock) void k_mixture_combo(Mix2Params p) {
     }
     __syncthreads();
 
+    double sum0 = 0.0, sum1 = 0.0;
+    if constexpr (!ONEHOT) {
     constexpr int ROWS = kWave / FT;
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
     const int fl = lane % FT, sub = lane / FT;
@@ -1002,7 +1005,6 @@ __global__ __launch_bounds__(kBlock) void k_mixture_combo(Mix2Params p) {
         const uint32_t xs = sq[(int64_t)min(i, nq - 1) * p.Fq];
         return i < nq ? xs : 0xFFFFFFFFu;
     };
-    double sum0 = 0.0, sum1 = 0.0;
     uint32_t xs_next = load_state(0);
     for (int k = 0; k < n_steps; ++k) {
         const uint32_t xs = xs_next;
@@ -1017,6 +1019,53 @@ __global__ __launch_bounds__(kBlock) void k_mixture_combo(Mix2Params p) {
             v[j] = T_l[(t * S1 + x) * FT];
         }
         sum0 += v[0]; sum1 += v[1]; sum0 += v[2]; sum1 += v[3];
+    }
+    } else {
+        // one-hot stream (the block as the reference hands it over).  A lane owns one 16-byte chunk
+        // position `ch` of the tile row segment and walks down the objects, R = 256 / seg16 objects per
+        // step, so everything that depends on the byte position is lane-constant: the 16 byte flags
+        // are OR-shifted into one word (bit 8k+i = byte k of dword i) and, for each set bit b found with
+        // ffbl, the LDS offset (state, feature) -> x*FT + f of that byte comes from a per-block lookup
+        // table offtab[ch][b] -- no division, no decode arithmetic: one u16 LDS read, one 8-byte LDS
+        // gather and one fp64 add per observation.
+        const int n0 = 4 * q0;
+        const int n_obj = min(4 * nq, p.N - n0);
+        const int seg_off = tile * FT * S;
+        const int seg16 = min(FT * S, p.rs_pitch - seg_off) >> 4;       // <= kBlock (host-checked)
+        const int R = kBlock / seg16;
+        uint16_t* offtab = reinterpret_cast<uint16_t*>(lds_raw + p.combo_tab_off);    // [seg16][32]
+        for (int e = threadIdx.x; e < seg16 * 32; e += kBlock) {
+            const int b = e & 31, chh = e >> 5;
+            const int j = chh * 16 + ((b & 7) << 2) + (b >> 3);
+            const int fj = j / S;
+            offtab[e] = (uint16_t)((j - fj * S) * FT + min(fj, FT - 1));
+        }
+        __syncthreads();
+        const bool active = (int)threadIdx.x < R * seg16;
+        const int ch = active ? (int)threadIdx.x % seg16 : 0, row_off = active ? (int)threadIdx.x / seg16 : 0;
+        const int n_steps = (n_obj + R - 1) / R;
+        const uint8_t* oh = p.onehot + (int64_t)n0 * p.rs_pitch + seg_off + ch * 16;
+        const uint8_t* tidl = reinterpret_cast<const uint8_t*>(tq);       // tuple id per object of the chunk
+        const uint16_t* off_l = offtab + ch * 32;
+        auto fetch = [&](int k) -> uint4 {
+            const int nl = k * R + row_off;
+            const uint4 d = *reinterpret_cast<const uint4*>(oh + (int64_t)min(nl, n_obj - 1) * p.rs_pitch);
+            return (active && nl < n_obj) ? d : make_uint4(0u, 0u, 0u, 0u);
+        };
+        uint4 nxt = fetch(0);
+        for (int k = 0; k < n_steps; ++k) {
+            const uint4 d = nxt;
+            nxt = fetch(k + 1);
+            uint32_t m = d.x | (d.y << 1) | (d.z << 2) | (d.w << 3);
+            const double* Tt = T + (uint32_t)tidl[min(k * R + row_off, n_obj - 1)] * (uint32_t)(S1 * FT);
+            while (__builtin_amdgcn_ballot_w64(m != 0u)) {                // wave-uniform trip count
+                const bool has = m != 0u;
+                const int b = has ? __builtin_ctz(m) : 0;
+                const double v = Tt[off_l[b]];
+                sum0 += has ? v : 0.0;
+                m &= m - 1u;
+            }
+        }
     }
     const double total = block_sum(sum0 + sum1, red4);
     if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + work] = total;
