@@ -956,7 +956,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_combo(Mix2Params p) {
     {
         const float* probs_t = p.probs_t + (int64_t)slot * p.probs_t_stride + (int64_t)tile * ((int64_t)(p.Gtot + 1) * S * FT);
         const int n_ent = KT * S * FT;
-        constexpr int U = 4;
+        constexpr int U = 8;
         for (int e0 = threadIdx.x; e0 < n_ent; e0 += U * kBlock) {
             float pr[U][CU];
             int dst[U], tt[U];
@@ -1005,10 +1005,9 @@ __global__ __launch_bounds__(kBlock) void k_mixture_combo(Mix2Params p) {
         const uint32_t xs = sq[(int64_t)min(i, nq - 1) * p.Fq];
         return i < nq ? xs : 0xFFFFFFFFu;
     };
-    uint32_t xs_next = load_state(0);
-    for (int k = 0; k < n_steps; ++k) {
-        const uint32_t xs = xs_next;
-        xs_next = load_state(k + 1);
+    // two steps (8 objects per lane) per trip, four independent accumulators: the LDS gathers of a trip
+    // are all in flight together and the add chains are short; state dwords are fetched one trip ahead
+    auto gather4 = [&](uint32_t xs, int k, double& a, double& b) {
         uint32_t t4 = tq[min(local_quad(k), nq - 1)];
         if (FT == kWave) t4 = __builtin_amdgcn_readfirstlane(t4);
         double v[4];
@@ -1018,8 +1017,22 @@ __global__ __launch_bounds__(kBlock) void k_mixture_combo(Mix2Params p) {
             const uint32_t t = (t4 >> (8 * j)) & 0xFFu;
             v[j] = T_l[(t * S1 + x) * FT];
         }
-        sum0 += v[0]; sum1 += v[1]; sum0 += v[2]; sum1 += v[3];
+        a += v[0] + v[2];
+        b += v[1] + v[3];
+    };
+    double sum2 = 0.0, sum3 = 0.0;
+    uint32_t xa_next = load_state(0), xb_next = load_state(1);
+    int k = 0;
+    for (; k + 1 < n_steps; k += 2) {
+        const uint32_t xa = xa_next, xb = xb_next;
+        xa_next = load_state(k + 2);
+        xb_next = load_state(k + 3);
+        gather4(xa, k, sum0, sum1);
+        gather4(xb, k + 1, sum2, sum3);
     }
+    if (k < n_steps) gather4(xa_next, k, sum0, sum1);
+    sum0 += sum2;
+    sum1 += sum3;
     } else {
         // one-hot stream (the block as the reference hands it over).  A lane owns one 16-byte chunk
         // position `ch` of the tile row segment and walks down the objects, R = 256 / seg16 objects per
