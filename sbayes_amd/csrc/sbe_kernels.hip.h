@@ -411,7 +411,7 @@ __global__ void k_lh_exact(const uint8_t* __restrict__ state, const uint8_t* __r
     const uint8_t sc = src[(int64_t)n * Fp + f];
     double* o = out + i * C;
     const float* w = wpat ? wpat + ((int64_t)pid[n] * F + f) * C : nullptr;
-    double acc = 0.0;
+    double vals[kMaxComponents];
     for (int c = 0; c < C; ++c) {
         double v = 1.0;
         if (x != kNA) {
@@ -429,10 +429,13 @@ __global__ void k_lh_exact(const uint8_t* __restrict__ state, const uint8_t* __r
                 v = (double)(float)(post(x) / total);
             }
         }
-        if (w) acc = acc + (double)w[c] * v;
+        if (w) vals[c] = (double)w[c] * v;
         else o[c] = v;
     }
-    if (w) out[i] = acc;
+    if (w) {
+        auto term = [&](int c) -> double { return vals[c]; };
+        out[i] = np_pairwise_sum<double>(term, C);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -485,16 +488,15 @@ __global__ void k_observation_lh(const uint8_t* __restrict__ state, const uint16
     const int n = (int)(i / F), f = (int)(i % F);
     const uint8_t x = state[(int64_t)n * Fp + f];
     const float* w = wpat + ((int64_t)pid[n] * F + f) * C;
-    double v = 0.0;
-    for (int c = 0; c < C; ++c) {
+    auto term = [&](int c) -> double {
         double lh = 1.0;
         if (x != kNA) {
             const uint16_t gg = gid[(int64_t)c * Np + n];
             lh = gg == kNoGroup ? 0.0 : (double)probs[((int64_t)gg * F + f) * S + x];
         }
-        v = v + (double)w[c] * lh;
-    }
-    obs[i] = v;
+        return (double)w[c] * lh;
+    };
+    obs[i] = np_pairwise_sum<double>(term, C);       // NumPy's order, also for C >= 8 (8-way unrolled block)
 }
 
 // Log-accumulation modes of the fused kernels:

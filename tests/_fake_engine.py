@@ -1,0 +1,52 @@
+"""Test double for sbayes_amd.engine.Engine built on the CPU oracle -- TEST INFRASTRUCTURE.
+
+Lets the `-m "not gpu"` suite exercise the HOST LOGIC of the drop-in layer (cache nodes,
+`what_changed`, partial updates, copy-on-write samples, pickling) without a GPU.  It lives under
+tests/ and is injected by monkeypatching `registry.get_engine`; the product never sees it."""
+import numpy as np
+
+from oracle import sbayes_oracle as orc
+
+
+class FakeEngine:
+    def __init__(self, features, n_groups=None, n_slots=4, device=0):
+        self.features = np.asarray(features, dtype=bool)
+        self.n_objects, self.n_features, self.n_states = self.features.shape
+        self.n_groups = list(n_groups) if n_groups is not None else [1]
+        self.n_components = len(self.n_groups)
+        self.calls = []
+
+    def close(self):
+        pass
+
+    def na_values(self):
+        return ~self.features.any(axis=-1)
+
+    def component_lh(self, probs, groups, changed_groups, out):
+        self.calls.append(("component_lh", tuple(int(c) for c in changed_groups)))
+        return orc.compute_component_likelihood(self.features, np.asarray(probs), np.asarray(groups, dtype=bool),
+                                                np.asarray(changed_groups, dtype=np.int64), out)
+
+    def normalize_tables(self, counts, concentration, temperature=None, prior_temperature=None, unif_counts=None):
+        self.calls.append(("normalize_tables", np.shape(counts)[0]))
+        return orc.conditional_effect_mean(np.asarray(concentration, dtype=np.float64), np.asarray(counts),
+                                           unif_counts=unif_counts, prior_temperature=prior_temperature,
+                                           temperature=temperature)
+
+    def dirichlet_logpdf(self, counts, concentration, per_group=False):
+        counts = np.asarray(counts, dtype=np.float32)
+        conc = np.asarray(concentration, dtype=np.float64)
+        self.calls.append(("dirichlet_logpdf", counts.shape[0]))
+        a = conc if conc.ndim == 3 else np.broadcast_to(conc, counts.shape)
+        pf = np.stack([orc.dirichlet_categorical_logpdf(counts[g], a[g]) for g in range(counts.shape[0])])
+        if not per_group:
+            return pf
+        return pf, np.array([float(row.sum()) for row in pf])
+
+    def effect_counts(self, group_assignment, source_is_component, object_subset=None):
+        subset = slice(None) if object_subset is None else np.asarray(object_subset)
+        return orc.compute_effect_counts(self.features, np.asarray(group_assignment, dtype=bool),
+                                         np.asarray(source_is_component, dtype=bool), subset)
+
+    def normalize_weights(self, weights, has_components):
+        return orc.normalize_weights(np.asarray(weights, dtype=np.float32), np.asarray(has_components, dtype=bool))

@@ -25,6 +25,9 @@ SHAPES = [
     (64,   33,  33, [2, 1, 2, 3, 2, 2],          0.02),      # C = 6, S = 33
     (100,  40,  20, [30, 1, 25],                 0.03),      # many groups: narrower LDS tile
     (41,   70,  2,  [5, 1],                      0.9),       # almost everything NA
+    (20,   3,   254, [2, 1],                     0.05),      # maximum state count (0xFF is NA)
+    (30,   9,   3,  [2, 1, 2, 2, 2, 2, 2, 2],    0.05),      # maximum component count (8)
+    (2003, 70,  3,  [7, 1],                      0.03),      # several object chunks with a ragged tail
 ]
 
 

@@ -1,0 +1,124 @@
+"""Host logic of the drop-in layer on CPU: the cached pipeline of sbayes_amd.{likelihood,
+conditionals,counts} driven by the recorded reference MCMC traces, with the device replaced by a
+test double (tests/_fake_engine.py, oracle-backed).  Checks what the host code owns: which groups
+it recomputes, that stale rows survive, that caches are keyed on versions, copy-on-write, pickling."""
+import pickle
+
+import numpy as np
+import pytest
+
+from sbayes_amd import conditionals, likelihood, registry
+from sbayes_amd import model as sbm
+from sbayes_amd.counts import recalculate_feature_counts, update_feature_counts
+from tests._fake_engine import FakeEngine
+from tests._fixtures import load_npz, load_trace, sha
+
+
+@pytest.fixture()
+def fake(monkeypatch):
+    engines = {}
+
+    def get_engine(features, n_groups=None, n_slots=4, device=None):
+        key = (np.asarray(features).ctypes.data, np.asarray(features).shape)
+        if key not in engines:
+            engines[key] = FakeEngine(features, n_groups)
+        return engines[key]
+
+    for mod in (registry, likelihood, conditionals):
+        monkeypatch.setattr(mod, "get_engine", get_engine, raising=True)
+    import sbayes_amd.counts as counts_mod
+    monkeypatch.setattr(counts_mod, "get_engine", get_engine, raising=True)
+    monkeypatch.setattr(registry, "_ENGINES", {})
+    return engines
+
+
+def build(fx):
+    names = fx.meta.get("component_names") or ["clusters", "universal"] + [f"conf{i}" for i in range(1, fx.n_comp - 1)]
+    return sbm.build(fx.features, fx.states_per_feature, names, fx.groups, fx.conc, fx.weights, fx.source)
+
+
+@pytest.mark.parametrize("name", ["test_files", "south_america"])
+def test_cached_pipeline_replays_reference_trace(name, fake):
+    fx = load_npz(name)
+    tr = load_trace(name)
+    model, sample = build(fx)
+    feats = model.data.features.values
+    na = model.data.features.na_values
+    recalculate_feature_counts(feats, sample)
+    conditionals.likelihood_per_component(model, sample, caching=True)
+    model.likelihood(sample, caching=True)
+    eng = next(iter(fake.values()))
+    n_partial = n_skipped = 0
+    for i in range(tr.n_steps if name == "test_files" else 150):
+        cand = sample.copy()
+        new_clusters, new_source, new_weights = tr.clusters(i), tr.source(i), tr.weights[i]
+        moved = np.flatnonzero((new_clusters != sample.clusters.value).any(axis=0) |
+                               (new_source != sample.source.value).any(axis=(1, 2)))
+        for k in np.flatnonzero((new_clusters != sample.clusters.value).any(axis=1)):
+            with cand.clusters.edit_cluster(int(k)) as row:
+                row[:] = new_clusters[k]
+        if (new_source != sample.source.value).any():
+            with cand.source.edit() as src:
+                src[moved] = new_source[moved]
+        if not np.array_equal(new_weights, sample.weights.value):
+            cand.weights.set_value(new_weights.copy())
+        if moved.size:
+            update_feature_counts(sample, cand, feats, moved)
+        changed = cand.cache.component_likelihoods.what_changed(["clusters", "clusters_counts"], caching=True)
+        eng.calls.clear()
+        lh = conditionals.likelihood_per_component(model, cand, caching=True)
+        assert sha(lh) == str(tr.lh_sha[i]), f"step {i}"
+        gathered = [c[1] for c in eng.calls if c[0] == "component_lh"]
+        if len(changed):
+            assert tuple(int(c) for c in changed) in gathered           # only the changed clusters are regathered
+            n_partial += len(changed) < cand.n_clusters
+        else:
+            n_skipped += 1
+        w = likelihood.update_weights(cand, caching=True, features=feats)
+        with np.errstate(divide="ignore"):
+            assert np.log(np.sum(w * lh, axis=-1))[~na].sum() == tr.mixture_ll[i]
+        ll = model.likelihood(cand, caching=True)
+        assert ll == pytest.approx(tr.last_lh[i], rel=1e-12)
+        # the candidate shares buffers with its parent until edited (copy-on-write)
+        if not moved.size:
+            assert cand.clusters.value is sample.clusters.value
+        sample = cand
+    if name == "south_america":
+        assert n_partial > 0 and n_skipped > 0      # strict-subset updates and no-op steps both occurred
+
+
+def test_uncached_equals_cached_and_cache_hit_does_no_device_work(fake):
+    fx = load_npz("cfg1")
+    model, sample = build(fx)
+    feats = model.data.features.values
+    recalculate_feature_counts(feats, sample)
+    eng = next(iter(fake.values()))
+    a = conditionals.likelihood_per_component(model, sample, caching=False).copy()
+    assert np.array_equal(a, fx.z["lh_per_component"])
+    eng.calls.clear()
+    b = conditionals.likelihood_per_component(model, sample, caching=True)
+    assert not eng.calls and np.array_equal(a, b)                      # pure cache hit
+    v1 = model.likelihood(sample, caching=True)
+    eng.calls.clear()
+    assert model.likelihood(sample, caching=True) == v1 and not eng.calls
+    assert model.likelihood(sample, caching=False) == pytest.approx(fx.meta["collapsed_ll"], rel=1e-12)
+
+
+def test_likelihood_pickles_without_device_state(fake):
+    fx = load_npz("cfg1")
+    model, sample = build(fx)
+    recalculate_feature_counts(model.data.features.values, sample)
+    _ = model.likelihood.na_features
+    clone = pickle.loads(pickle.dumps(model.likelihood))
+    assert clone._na_features is None                                   # lazily re-derived in the new process
+    assert np.array_equal(clone.features, model.likelihood.features)
+    assert clone.source_index == model.likelihood.source_index
+
+
+def test_argument_validation_happens_before_the_abi():
+    """Shape / dtype errors are raised by the Python shim (SURVEY.md 8(b) 'Errors')."""
+    from sbayes_amd.engine import Engine
+    with pytest.raises(ValueError, match="n_objects, n_features, n_states"):
+        Engine(np.zeros((3, 4), dtype=bool), [1])
+    with pytest.raises(TypeError, match="bool"):
+        Engine(np.zeros((3, 4, 2), dtype=np.float64), [1])
