@@ -8,7 +8,7 @@ OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
 BENCH="python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary"
-for kern in packed packed_general onehot; do
+for kern in packed packed_general onehot onehot_general; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$kern -- $BENCH --kernel $kern > $OUT/bench_$kern.json 2> $OUT/bench_$kern.err
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
@@ -25,4 +25,5 @@ if [ -x tools/fetch_calib ]; then
 fi
 # keep the merged-back volume small: the per-dispatch traces are not needed once stats exist
 find $OUT -name '*_kernel_trace.csv' -delete; find $OUT -name '*_agent_info.csv' -delete
+for f in $(find $OUT -name '*_counter_collection.csv'); do (head -1 $f; grep -E 'k_mixture|read_dword' $f) > $f.tmp && mv $f.tmp $f; done
 ls $OUT
