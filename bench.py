@@ -187,6 +187,16 @@ def secondary_figures(eng, wl, B, args):
         chain.accept()
         return ll, mix
     out["f2_resident_steps_per_s"] = round(_rate(resident_step), 1)
+
+    def one_call_step():
+        n = int(rng.integers(0, n_obj))
+        clusters[:, n] = False
+        clusters[int(rng.integers(0, clusters.shape[0])), n] = True
+        objs = np.unique(np.append(rng.integers(0, n_obj, size=19), n))
+        res = chain.step(clusters=clusters, source_rows=(objs, wl.source[objs]))
+        chain.accept()
+        return res
+    out["f2_one_call_steps_per_s"] = round(_rate(one_call_step), 1)
     release_all()
     return out
 

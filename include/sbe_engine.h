@@ -250,6 +250,25 @@ int sbe_subset_lh(sbe_engine* e, const int32_t* objects, int n_sub, int n_comp, 
 int sbe_source_prior(sbe_engine* e, int slot, double* per_object_out /* [N] */);
 int sbe_observation_lh_exact(sbe_engine* e, int slot, double* out /* [N][F] */);
 
+/* ---- one MCMC step in one call (resident flow) ---------------------------
+ * Builds the candidate state in `cand_slot` from `cur_slot` plus the proposed delta and evaluates it:
+ *   clusters        bool [K][N] of the candidate, or NULL if the clusters did not change
+ *   changed_objects / source_rows  the objects whose source assignment changed and their bool
+ *                   rows [n_changed][F][C]
+ *   weights         float32 [F][C], or NULL if unchanged
+ * On the device: slot copy, id / source-row update, delta update of the feature counts
+ * (counts.py:55-95), probability tables of every component (conditionals.py:175-204), collapsed
+ * per-group log-likelihoods (likelihood.py:65-101) and the fused mixture log-likelihood
+ * (SURVEY.md 8(d)).  One PCIe round trip, one stream synchronisation.
+ *   group_logliks_out  float64 [G_total] (Likelihood.__call__ = their sum)
+ *   mixture_out        float64 scalar
+ *   changed_groups_out bool [G_total] (may be NULL): groups whose counts changed
+ * The caller accepts by swapping the roles of the two slots, rejects by doing nothing. */
+int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters,
+             const int32_t* changed_objects, int n_changed, const uint8_t* source_rows,
+             const float* weights, double* group_logliks_out, double* mixture_out,
+             uint8_t* changed_groups_out);
+
 /* ---- slot management -------------------------------------------------------------------- */
 int sbe_copy_slot(sbe_engine* e, int dst_slot, int src_slot);
 

@@ -80,6 +80,8 @@ struct sbe_engine {
     int* d_status = nullptr;       // [ST_WORDS]
     int* h_status = nullptr;       // pinned
     uint8_t* d_changed = nullptr;  // [Gtot]
+    float* d_step_pf = nullptr;    // [Gtot][F]  per-feature collapsed log-pdf of the fused step call
+    double* d_step_pg = nullptr;   // [Gtot]     per-group collapsed log-likelihood of the fused step call
     uint8_t* d_scratch = nullptr;  size_t scratch_bytes = 0;     // general staging
     uint8_t* h_pinned = nullptr;   size_t pinned_bytes = 0;      // pinned D2H staging
     uint8_t* h_arena = nullptr;    size_t arena_bytes = 0, arena_off = 0;   // pinned H2D staging ring
@@ -555,7 +557,7 @@ int sbe_destroy(sbe_engine* e) {
     if (!e) return SBE_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* dev_ptrs[] = {e->d_tid, e->d_tuple_g, e->d_tuple_p, e->d_state_q, e->d_probs_t, e->d_wpat_t, e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
+    void* dev_ptrs[] = {e->d_step_pf, e->d_step_pg, e->d_tid, e->d_tuple_g, e->d_tuple_p, e->d_state_q, e->d_probs_t, e->d_wpat_t, e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
                         e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_unif, e->d_partials,
                         e->d_status, e->d_changed, e->d_scratch};
     for (void* p : dev_ptrs) if (p) (void)hipFree(p);
@@ -677,6 +679,8 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_RC(dmalloc(e, &e->d_partials, NS * e->partials_stride));
     CREATE_RC(dmalloc(e, &e->d_status, (int64_t)ST_WORDS));
     CREATE_RC(dmalloc(e, &e->d_changed, (int64_t)e->Gtot));
+    CREATE_RC(dmalloc(e, &e->d_step_pf, (int64_t)e->Gtot * F));
+    CREATE_RC(dmalloc(e, &e->d_step_pg, (int64_t)e->Gtot));
     CREATE_CHK(hipHostMalloc((void**)&e->h_results, NS * sizeof(double), hipHostMallocMapped));
     CREATE_CHK(hipHostGetDevicePointer((void**)&e->d_results, e->h_results, 0));
     CREATE_CHK(hipHostMalloc((void**)&e->h_status, ST_WORDS * sizeof(int), hipHostMallocDefault));
@@ -1489,6 +1493,78 @@ int sbe_observation_lh_exact(sbe_engine* e, int slot, double* out) {
     if (rc) return rc;
     if (e->h_status[ST_BAD_NORMALIZE]) return fail(e, SBE_ERR_DATA, "normalize: non-positive row sum in leave-one-out tables (sbayes/util.py:1006 assert)");
     return SBE_OK;
+}
+
+// ---- one MCMC step in one call: delta in, likelihoods out (north_star: "only the proposed cluster-
+// assignment delta crosses PCIe") ---------------------------------------------------------------------
+int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters, const int32_t* changed_objects,
+             int n_changed, const uint8_t* source_rows, const float* weights, double* group_logliks_out,
+             double* mixture_out, uint8_t* changed_groups_out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, cur_slot); CHECK_SLOT(e, cand_slot);
+    CHECK_PTR(e, group_logliks_out); CHECK_PTR(e, mixture_out);
+    if (cur_slot == cand_slot) return fail(e, SBE_ERR_ARG, "current and candidate slot must differ");
+    if (n_changed < 0 || (n_changed > 0 && (!changed_objects || !source_rows)))
+        return fail(e, SBE_ERR_ARG, "changed_objects / source_rows missing for n_changed=%d", n_changed);
+    Slot& cur = e->slots[cur_slot];
+    if (!cur.groups_set || !cur.source_set || !cur.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", cur_slot);
+    for (int c = 0; c < e->C; ++c)
+        if (!cur.counts_set[c] || !e->conc_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts / concentration of component %d not set", cur_slot, c);
+    for (int i = 0; i < n_changed; ++i)
+        if (changed_objects[i] < 0 || changed_objects[i] >= e->N) return fail(e, SBE_ERR_ARG, "object index %d out of range", changed_objects[i]);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int saved_deferred = e->opt_deferred;
+    e->opt_deferred = 1;                       // no intermediate synchronisation inside the step
+    auto done = [&](int rc) { e->opt_deferred = saved_deferred; return rc; };
+    int rc = sbe_copy_slot(e, cand_slot, cur_slot);
+    if (rc) return done(rc);
+    const int N = e->N;
+    // objects whose counts may change: listed source rows + objects whose cluster membership changed
+    std::vector<uint8_t> moved(N, 0);
+    for (int i = 0; i < n_changed; ++i) moved[changed_objects[i]] = 1;
+    if (clusters) {
+        const int K = e->G[0];
+        std::vector<uint16_t> ids(N, kNoGroup);
+        for (int g = 0; g < K; ++g) {
+            const uint8_t* row = clusters + (size_t)g * N;
+            for (int n = 0; n < N; ++n) if (row[n]) ids[n] = (uint16_t)g;      // component 0: offset 0
+        }
+        for (int n = 0; n < N; ++n) if (ids[n] != cur.h_gid[n]) moved[n] = 1;
+        rc = set_gid_common(e, cand_slot, 0, ids);
+        if (rc) return done(rc);
+    }
+    if (n_changed > 0) {
+        rc = sbe_set_source_rows(e, cand_slot, changed_objects, n_changed, source_rows);
+        if (rc) return done(rc);
+    }
+    if (weights) rc = sbe_set_weights(e, cand_slot, weights);
+    else if (e->slots[cand_slot].patterns_dirty) rc = upload_patterns_and_weights(e, cand_slot);
+    if (rc) return done(rc);
+    std::vector<int32_t> subset;
+    for (int n = 0; n < N; ++n) if (moved[n]) subset.push_back(n);
+    rc = sbe_update_counts(e, cand_slot, cur_slot, subset.data(), (int)subset.size(), nullptr);
+    if (rc) return done(rc);
+    for (int c = 0; c < e->C; ++c) {
+        rc = sbe_update_probs(e, cand_slot, c, 0.0, 0.0, nullptr);
+        if (rc) return done(rc);
+    }
+    // collapsed likelihood of every group (a7/a8) into a device buffer
+    k_dcl<int32_t><<<div_up((int64_t)e->Gtot * e->F, 256), 256, 0, e->stream>>>(
+        e->d_counts + (int64_t)cand_slot * e->table_elems(), e->d_conc, e->d_step_pf, 0, e->Gtot, e->F, e->S, 1);
+    k_group_sum_f32<<<div_up(e->Gtot, 64), 64, 0, e->stream>>>(e->d_step_pf, e->d_step_pg, e->Gtot, e->F);
+    HIPCHK(e, hipGetLastError());
+    rc = enqueue_mixture(e, cand_slot, 1, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS);
+    if (rc) return done(rc);
+    // one read-back, one synchronisation
+    const size_t pg_bytes = (size_t)e->Gtot * sizeof(double);
+    rc = ensure_pinned(e, pg_bytes + (size_t)e->Gtot);
+    if (rc) return done(rc);
+    HIPCHK(e, hipMemcpyAsync(e->h_pinned, e->d_step_pg, pg_bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->h_pinned + pg_bytes, e->d_changed, (size_t)e->Gtot, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    memcpy(group_logliks_out, e->h_pinned, pg_bytes);
+    if (changed_groups_out) memcpy(changed_groups_out, e->h_pinned + pg_bytes, (size_t)e->Gtot);
+    *mixture_out = e->h_results[cand_slot];
+    return done(synced(e));
 }
 
 // ---- slots ------------------------------------------------------------------------------------------

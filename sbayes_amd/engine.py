@@ -414,6 +414,38 @@ class Engine:
         self._check(self._lib.sbe_observation_lh_exact(self._h, slot, _ptr(out)))
         return out
 
+    def step(self, cur_slot, cand_slot, clusters=None, changed_objects=None, source_rows=None, weights=None):
+        """One MCMC step in one call: candidate = current + delta, evaluated on the device.
+        Returns (group_logliks float64 [G_total], mixture_ll float, changed_groups bool [G_total])."""
+        cl = None
+        if clusters is not None:
+            cl = np.asarray(clusters)
+            if cl.shape != (self.n_groups[0], self.n_objects):
+                raise ValueError(f"clusters must be {(self.n_groups[0], self.n_objects)}, got {cl.shape}")
+            cl = _c(cl.astype(bool, copy=False), np.uint8)
+        objs = rows = None
+        n_changed = 0
+        if changed_objects is not None and len(changed_objects):
+            objs = np.ascontiguousarray(changed_objects, dtype=np.int32).reshape(-1)
+            rows = np.asarray(source_rows)
+            if rows.shape != (objs.size, self.n_features, self.n_components):
+                raise ValueError("source_rows must be [len(changed_objects), n_features, n_components]")
+            rows = _c(rows.astype(bool, copy=False), np.uint8)
+            n_changed = objs.size
+        w = None
+        if weights is not None:
+            w = _c(weights, np.float32)
+            if w.shape != (self.n_features, self.n_components):
+                raise ValueError("weights must be [n_features, n_components]")
+        glh = np.empty(self.n_groups_total, dtype=np.float64)
+        mix = ct.c_double(0.0)
+        changed = np.zeros(self.n_groups_total, dtype=np.uint8)
+        self._check(self._lib.sbe_step(self._h, cur_slot, cand_slot, _ptr(cl) if cl is not None else None,
+                                       _ptr(objs) if objs is not None else None, n_changed,
+                                       _ptr(rows) if rows is not None else None, _ptr(w) if w is not None else None,
+                                       _ptr(glh), ct.byref(mix), _ptr(changed)))
+        return glh, mix.value, changed.astype(bool)
+
     def copy_slot(self, dst, src):
         self._check(self._lib.sbe_copy_slot(self._h, dst, src))
 

@@ -115,3 +115,16 @@ class ResidentChain:
 
     def reject(self):
         self._pending = False
+
+
+    def step(self, clusters=None, source_rows=None, weights=None):
+        """propose + evaluate in ONE engine call (sbe_step): returns (collapsed log-likelihood, per-group
+        values, mixture log-likelihood).  Follow with accept() or reject()."""
+        objs, rows = (None, None) if source_rows is None else source_rows
+        glh, mix, changed = self.eng.step(self.cur, self.cand, clusters=clusters, changed_objects=objs,
+                                          source_rows=rows, weights=weights)
+        self._cand_clusters = np.asarray(clusters, dtype=bool).copy() if clusters is not None else self._clusters
+        self.changed_groups = changed
+        self._probs_dirty[self.cand] = set()
+        self._pending = True
+        return float(glh.sum()), glh, mix

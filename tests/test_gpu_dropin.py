@@ -228,3 +228,34 @@ def test_trace_replay_resident_flow(name):
     counts = orc.recalculate_feature_counts(fx.features, [prev_clusters] + fx.groups[1:], prev_source)
     for c in range(fx.n_comp):
         assert np.array_equal(chain.current.counts(c), counts[c])
+
+
+@pytest.mark.parametrize("name", ["test_files", "south_america"])
+def test_trace_replay_one_call_steps(name):
+    """The recorded reference trace through sbe_step: one engine call (one PCIe round trip, one
+    synchronisation) per MCMC step -- delta in; collapsed per-group and mixture log-likelihood out."""
+    from sbayes_amd.resident import ResidentChain
+    fx = load_npz(name)
+    tr = load_trace(name)
+    model, sample = build(fx)
+    chain = ResidentChain(model, sample)
+    prev_clusters, prev_source, prev_weights = fx.groups[0], fx.source, fx.weights
+    for i in range(tr.n_steps):
+        clusters, source, weights = tr.clusters(i), tr.source(i), tr.weights[i]
+        changed_src = np.flatnonzero((source != prev_source).any(axis=(1, 2)))
+        kwargs = dict(clusters=clusters if not np.array_equal(clusters, prev_clusters) else None,
+                      source_rows=(changed_src, source[changed_src]),
+                      weights=weights if not np.array_equal(weights, prev_weights) else None)
+        ll, group_lh, mix = chain.step(**kwargs)
+        assert abs(ll - tr.last_lh[i]) <= 1e-6 * abs(tr.last_lh[i]), f"step {i}"
+        np.testing.assert_allclose(group_lh, tr.group_lh[i], rtol=1e-6, atol=1e-6)
+        assert abs(mix - tr.mixture_ll[i]) <= 1e-10 * abs(tr.mixture_ll[i]), f"step {i}"
+        if i % 40 == 3:
+            chain.reject()                          # the current slot is untouched by a rejected step
+            ll2, _, mix2 = chain.step(**kwargs)
+            assert ll2 == ll and mix2 == mix
+        chain.accept()
+        prev_clusters, prev_source, prev_weights = clusters, source, weights
+    counts = orc.recalculate_feature_counts(fx.features, [prev_clusters] + fx.groups[1:], prev_source)
+    for c in range(fx.n_comp):
+        assert np.array_equal(chain.current.counts(c), counts[c])
