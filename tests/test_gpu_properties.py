@@ -1,0 +1,124 @@
+"""Size-independent properties at BASELINE.json's full sizes (headline 1000x200x10, stress
+5000x500x20): additivity over objects, permutation invariance, batch == single, count conservation,
+delta/inverse-delta round trip, idempotence -- checked on the device results themselves."""
+import numpy as np
+import pytest
+
+from sbayes_amd.engine import MIXTURE_ONEHOT, MIXTURE_PACKED, MIXTURE_PACKED_GENERAL, Engine
+from sbayes_amd.registry import get_engine, release_all
+from sbayes_amd.synthetic import make_state, make_workload
+
+pytestmark = pytest.mark.gpu
+
+
+def load(eng, slot, wl, groups=None, weights=None, source=None):
+    groups = groups if groups is not None else wl.groups
+    for c in range(wl.n_components):
+        eng.set_groups(slot, c, groups[c])
+    eng.set_source(slot, source if source is not None else wl.source)
+    eng.recount(slot)
+    for c in range(wl.n_components):
+        eng.update_probs(slot, c)
+    eng.set_weights(slot, weights if weights is not None else wl.weights)
+
+
+@pytest.mark.parametrize("name", ["headline", "stress"])
+def test_full_size_properties(name):
+    wl = make_workload(name)
+    N, F, S = wl.shape
+    n_groups = [g.shape[0] for g in wl.groups]
+    rng = np.random.default_rng(3)
+    with Engine(wl.features, n_groups, n_slots=3) as eng:
+        for c in range(wl.n_components):
+            eng.set_concentration(c, wl.concentration[c])
+        load(eng, 0, wl)
+        total = eng.mixture_loglik(0)
+        # (1) every kernel form agrees on the same resident state
+        for kernel in (MIXTURE_PACKED_GENERAL, MIXTURE_ONEHOT, MIXTURE_PACKED):
+            eng.set_option(kernel=kernel)
+            assert abs(eng.mixture_loglik(0) - total) <= 1e-10 * abs(total)
+        # (2) count conservation: every valid observation whose source is set is counted exactly once
+        counts = [eng.get_counts(0, c) for c in range(wl.n_components)]
+        per_feature = sum(c.sum(axis=(0, 2)) for c in counts)
+        hc = np.stack([g.any(axis=0) for g in wl.groups], axis=1)
+        counted = (wl.source & hc[:, None, :]).any(axis=-1) & ~wl.na_values
+        assert np.array_equal(per_feature, counted.sum(axis=0).astype(np.float32))
+        # (3) idempotence: a second recount and an empty delta change nothing
+        eng.recount(0)
+        for c in range(wl.n_components):
+            assert np.array_equal(eng.get_counts(0, c), counts[c])
+        eng.copy_slot(1, 0)
+        assert not eng.update_counts(1, 0, np.array([], dtype=np.int32)).any()
+        # (4) delta then inverse delta restores the counts bit for bit
+        clusters2, weights2, source2 = make_state(wl.features, wl.groups[1:], wl.clusters.shape[0], seed=77)
+        subset = np.sort(rng.choice(N, size=25, replace=False))
+        new_clusters = wl.clusters.copy()
+        new_clusters[:, subset] = clusters2[:, subset]
+        eng.set_groups(1, 0, new_clusters)
+        eng.set_source_rows(1, subset, source2[subset])
+        changed = eng.update_counts(1, 0, subset)
+        assert changed.any()
+        eng.copy_slot(2, 1)
+        eng.set_groups(2, 0, wl.clusters)
+        eng.set_source_rows(2, subset, wl.source[subset])
+        eng.update_counts(2, 1, subset)
+        for c in range(wl.n_components):
+            assert np.array_equal(eng.get_counts(2, c), counts[c])
+        # (5) batch == singles
+        for c in range(wl.n_components):
+            eng.update_probs(1, c)
+            eng.update_probs(2, c)
+        singles = np.array([eng.mixture_loglik(s) for s in range(3)])
+        assert np.array_equal(eng.mixture_loglik_batch(0, 3), singles)
+        assert singles[2] == singles[0] and singles[1] != singles[0]
+        tables = [eng.get_probs(0, c) for c in range(wl.n_components)]
+
+    # (6) additivity over objects with fixed tables: LL(all) = LL(first half) + LL(second half), the other
+    #     half's observations erased to NA (an NA observation contributes log 1 = 0)
+    parts = []
+    half = np.arange(N) < N // 2
+    for keep in (half, ~half):
+        feats = wl.features.copy()
+        feats[~keep] = False
+        with Engine(feats, n_groups, n_slots=1) as eng:
+            eng.load_state(0, wl.groups, wl.weights, probs=tables)
+            parts.append(eng.mixture_loglik(0))
+    assert abs(sum(parts) - total) <= 1e-10 * abs(total)
+
+    # (7) permutation invariance: relabelling the objects does not change the likelihood
+    perm = rng.permutation(N)
+    with Engine(np.ascontiguousarray(wl.features[perm]), n_groups, n_slots=1) as eng:
+        eng.load_state(0, [g[:, perm] for g in wl.groups], wl.weights, probs=tables)
+        assert abs(eng.mixture_loglik(0) - total) <= 1e-10 * abs(total)
+
+
+def test_small_api_corners():
+    wl = make_workload("cfg1")
+    n_groups = [g.shape[0] for g in wl.groups]
+    with Engine(wl.features, n_groups, n_slots=2) as eng:
+        for c in range(wl.n_components):
+            eng.set_concentration(c, wl.concentration[c])
+        load(eng, 0, wl)
+        ref = eng.mixture_loglik(0)
+        # group ids instead of the bool matrix
+        for c in range(wl.n_components):
+            ids = np.where(wl.groups[c].any(axis=0), wl.groups[c].argmax(axis=0), -1)
+            eng.set_group_ids(1, c, ids)
+        eng.set_source(1, wl.source)
+        eng.recount(1)
+        for c in range(wl.n_components):
+            eng.update_probs(1, c)
+        eng.set_weights(1, wl.weights)
+        assert eng.mixture_loglik(1) == ref
+        eng.timer_start()
+        eng.mixture_loglik_batch_async(0, 2)
+        assert eng.timer_stop() > 0.0
+        total_ms, kernel_ms = eng.profile_mixture(0, 2, 5)
+        assert 0.0 < kernel_ms <= total_ms
+    # the registry re-creates an engine when a caller needs slot state with other group counts
+    release_all()
+    e1 = get_engine(wl.features)                       # stateless use first: placeholder group counts
+    assert e1.n_groups == [1]
+    e2 = get_engine(wl.features, n_groups)
+    assert e2 is not e1 and e2.n_groups == n_groups and get_engine(wl.features) is e2
+    release_all()
