@@ -96,10 +96,15 @@ int sbe_sync(sbe_engine* e);
  * objects in no group <- 0; rows of members of unchanged groups are left untouched; later
  * groups overwrite earlier ones.  `out` is a strided host view (the reference passes
  * component_likelihood[..., i], element stride C*8 bytes along F).  Stateless: touches no slot.
- *   probs_f64: 0 = float32 tables (what normalize() returns, util.py:1007), 1 = float64.  */
+ *   probs_f64: 0 = float32 tables (what normalize() returns, util.py:1007), 1 = float64.
+ *   na_value : value written for NA observations in the rows this call writes: 0.0 is the literal
+ *              a1 result (an all-False one-hot row sums to 0); likelihood_per_component passes 1.0,
+ *              which is what its final `component_likelihood[na_values] = 1.` leaves there
+ *              (conditionals.py:216).  */
 int sbe_component_lh(sbe_engine* e, const void* probs /* [G][F][S] */, int probs_f64, int n_groups,
                      const uint8_t* groups /* [G][N] bool */, const int64_t* changed_groups,
-                     int n_changed, double* out, int64_t out_stride_n_bytes, int64_t out_stride_f_bytes);
+                     int n_changed, double* out, int64_t out_stride_n_bytes, int64_t out_stride_f_bytes,
+                     double na_value);
 
 /* ---- a2: compute_component_likelihood_exact (likelihood.py:136-150) via
  * likelihood_per_component_exact (sbayes/sampling/conditionals.py:300-367): leave-one-out

@@ -42,7 +42,7 @@ PROTOTYPES = {
     "sbe_set_option": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int]),
     "sbe_sync": (ct.c_int, [c_engine_p]),
     "sbe_component_lh": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p,
-                                    ct.c_int, ct.c_void_p, ct.c_int64, ct.c_int64]),
+                                    ct.c_int, ct.c_void_p, ct.c_int64, ct.c_int64, ct.c_double]),
     "sbe_likelihood_per_component_exact": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
     "sbe_set_groups": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
     "sbe_set_group_ids": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),

@@ -58,7 +58,7 @@ def likelihood_per_component(model, sample, caching=True):
                 feature_counts["clusters"].value, np.asarray(model.prior.prior_cluster_effect.concentration_array))
             compute_component_likelihood(
                 features=features.values, probs=cluster_effect, groups=sample.clusters.value,
-                changed_groups=changed_clusters, out=component_likelihood[..., 0])
+                changed_groups=changed_clusters, out=component_likelihood[..., 0], na_value=1.0)
 
         for i, conf in enumerate(confounders.keys(), start=1):
             conf_prior = model.prior.prior_confounding_effects[conf]
@@ -71,9 +71,9 @@ def likelihood_per_component(model, sample, caching=True):
                                                np.asarray(conf_prior.concentration_array(sample)))
             compute_component_likelihood(
                 features=features.values, probs=conf_effect, groups=confounders[conf].group_assignment,
-                changed_groups=changed_groups, out=component_likelihood[..., i])
-
-        component_likelihood[features.na_values] = 1.0
+                changed_groups=changed_groups, out=component_likelihood[..., i], na_value=1.0)
+        # conditionals.py:216 sets NA observations to 1 here; the device has already written 1 for the NA
+        # observations of every row it touched, and untouched rows carry it from the call that wrote them
     return cache.value
 
 

@@ -765,7 +765,7 @@ int sbe_sync(sbe_engine* e) {
 // ---- a1 -------------------------------------------------------------------------------------
 int sbe_component_lh(sbe_engine* e, const void* probs, int probs_f64, int n_groups, const uint8_t* groups,
                      const int64_t* changed_groups, int n_changed, double* out, int64_t out_stride_n_bytes,
-                     int64_t out_stride_f_bytes) {
+                     int64_t out_stride_f_bytes, double na_value) {
     CHECK_ENGINE(e); CHECK_PTR(e, probs); CHECK_PTR(e, groups); CHECK_PTR(e, out);
     if (n_groups < 1) return fail(e, SBE_ERR_ARG, "n_groups=%d", n_groups);
     if (n_changed < 0 || (n_changed > 0 && !changed_groups)) return fail(e, SBE_ERR_ARG, "bad changed_groups");
@@ -799,8 +799,8 @@ int sbe_component_lh(sbe_engine* e, const void* probs, int probs_f64, int n_grou
     { int _urc = upload(e, d_tab, probs, tab_bytes); if (_urc) return _urc; }
     { int _urc = upload(e, d_sel, sel.data(), (size_t)N * sizeof(int32_t)); if (_urc) return _urc; }
     const int blocks = div_up((int64_t)N * F, 256);
-    if (probs_f64) k_component_lh<double><<<blocks, 256, 0, e->stream>>>(e->d_state, (const double*)d_tab, d_sel, d_out, N, F, S, e->Fp);
-    else k_component_lh<float><<<blocks, 256, 0, e->stream>>>(e->d_state, (const float*)d_tab, d_sel, d_out, N, F, S, e->Fp);
+    if (probs_f64) k_component_lh<double><<<blocks, 256, 0, e->stream>>>(e->d_state, (const double*)d_tab, d_sel, d_out, N, F, S, e->Fp, na_value);
+    else k_component_lh<float><<<blocks, 256, 0, e->stream>>>(e->d_state, (const float*)d_tab, d_sel, d_out, N, F, S, e->Fp, na_value);
     HIPCHK(e, hipGetLastError());
     rc = ensure_pinned(e, out_bytes);
     if (rc) return rc;

@@ -359,16 +359,15 @@ __global__ void k_expand_weights(const float* __restrict__ wpat, const uint8_t* 
 template <class TP>
 __global__ void k_component_lh(const uint8_t* __restrict__ state, const TP* __restrict__ probs,
                                const int32_t* __restrict__ sel, double* __restrict__ out /* [N][F] */,
-                               int N, int F, int S, int Fp) {
+                               int N, int F, int S, int Fp, double na_value) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)N * F) return;
     const int n = (int)(i / F), f = (int)(i % F);
     const int g = sel[n];
+    const uint8_t x = state[(int64_t)n * Fp + f];
     double v = 0.0;
-    if (g >= 0) {
-        const uint8_t x = state[(int64_t)n * Fp + f];
-        if (x != kNA) v = (double)probs[((int64_t)g * F + f) * S + x];
-    }
+    if (x == kNA) v = na_value;       // 0 for the literal a1 contract; 1 when serving likelihood_per_component
+    else if (g >= 0) v = (double)probs[((int64_t)g * F + f) * S + x];
     out[i] = v;
 }
 

@@ -119,9 +119,10 @@ class Engine:
         return out
 
     # -- a1 -------------------------------------------------------------------------------------
-    def component_lh(self, probs, groups, changed_groups, out):
+    def component_lh(self, probs, groups, changed_groups, out, na_value=0.0):
         """compute_component_likelihood (likelihood.py:104-133): in-place partial update of the
-        (possibly strided) float64 view `out` [N, F]."""
+        (possibly strided) float64 view `out` [N, F].  `na_value` is written for NA observations of
+        the rows this call writes (0.0 = the literal a1 result, 1.0 = likelihood_per_component's)."""
         probs = np.asarray(probs)
         groups = np.asarray(groups)
         n_groups = groups.shape[0]
@@ -138,7 +139,8 @@ class Engine:
         g = _c(groups.astype(bool, copy=False), np.uint8)
         ch = np.ascontiguousarray(changed_groups, dtype=np.int64).reshape(-1)
         self._check(self._lib.sbe_component_lh(self._h, _ptr(p), int(f64), n_groups, _ptr(g), _ptr(ch), ch.size,
-                                               ct.c_void_p(out.ctypes.data), out.strides[0], out.strides[1]))
+                                               ct.c_void_p(out.ctypes.data), out.strides[0], out.strides[1],
+                                               float(na_value)))
         return out
 
     # -- slot state -----------------------------------------------------------------------------

@@ -91,10 +91,12 @@ class Likelihood:
         return cache.value.sum()
 
 
-def compute_component_likelihood(features, probs, groups, changed_groups, out):
+def compute_component_likelihood(features, probs, groups, changed_groups, out, na_value=0.0):
     """In-place partial update of `out` [n_objects, n_features] (float64, any strides) with the
-    likelihood of every observation under one mixture component; returns `out`."""
-    return get_engine(features).component_lh(probs, groups, changed_groups, out)
+    likelihood of every observation under one mixture component; returns `out`.  `na_value` (not in
+    the reference signature, default = the reference's result 0) lets likelihood_per_component have
+    the device write its NA value 1 directly."""
+    return get_engine(features).component_lh(probs, groups, changed_groups, out, na_value)
 
 
 def compute_component_likelihood_exact(features, probs, groups, changed_groups, out):

@@ -22,10 +22,19 @@ class FakeEngine:
     def na_values(self):
         return ~self.features.any(axis=-1)
 
-    def component_lh(self, probs, groups, changed_groups, out):
+    def component_lh(self, probs, groups, changed_groups, out, na_value=0.0):
         self.calls.append(("component_lh", tuple(int(c) for c in changed_groups)))
-        return orc.compute_component_likelihood(self.features, np.asarray(probs), np.asarray(groups, dtype=bool),
-                                                np.asarray(changed_groups, dtype=np.int64), out)
+        groups = np.asarray(groups, dtype=bool)
+        changed_groups = np.asarray(changed_groups, dtype=np.int64)
+        orc.compute_component_likelihood(self.features, np.asarray(probs), groups, changed_groups, out)
+        if na_value != 0.0:           # rows this call wrote: members of changed groups and no-group objects
+            written = ~groups.any(axis=0)
+            for i in changed_groups:
+                written |= groups[i]
+            rows = out[written]
+            rows[self.na_values()[written]] = na_value
+            out[written] = rows
+        return out
 
     def normalize_tables(self, counts, concentration, temperature=None, prior_temperature=None, unif_counts=None):
         self.calls.append(("normalize_tables", np.shape(counts)[0]))
