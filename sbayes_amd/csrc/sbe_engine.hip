@@ -234,28 +234,29 @@ int clear_status_word(sbe_engine* e, int word) {
 // has_components patterns in np.unique(axis=0) order: rows compared lexicographically over
 // components 0..C-1 with False < True (likelihood.py:183).
 void derive_patterns(sbe_engine* e, Slot& s) {
-    const int N = e->N, C = e->C;
-    std::vector<uint32_t> bits(N);
+    const int N = e->N, C = e->C;          // C <= 8: a pattern is an 8-bit mask
+    std::vector<uint8_t> bits(N);
+    bool seen[256] = {false};
     for (int n = 0; n < N; ++n) {
         uint32_t b = 0;
         for (int c = 0; c < C; ++c)
             if (s.h_gid[(size_t)c * N + n] != kNoGroup) b |= 1u << c;
-        bits[n] = b;
+        bits[n] = (uint8_t)b;
+        seen[b] = true;
     }
-    auto key = [C](uint32_t b) {   // component 0 most significant => lexicographic row order
+    auto key = [C](uint32_t b) {   // component 0 most significant => lexicographic row order of np.unique
         uint32_t k = 0;
         for (int c = 0; c < C; ++c) k |= ((b >> c) & 1u) << (C - 1 - c);
         return k;
     };
-    std::vector<uint32_t> uniq(bits);
+    std::vector<uint32_t> uniq;
+    for (uint32_t b = 0; b < 256; ++b) if (seen[b]) uniq.push_back(b);
     std::sort(uniq.begin(), uniq.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
-    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    uint8_t index_of[256] = {0};
+    for (size_t i = 0; i < uniq.size(); ++i) index_of[uniq[i]] = (uint8_t)i;
     s.patterns = uniq;
     s.h_pid.resize(N);
-    for (int n = 0; n < N; ++n) {
-        const auto it = std::find(uniq.begin(), uniq.end(), bits[n]);
-        s.h_pid[n] = (uint8_t)(it - uniq.begin());
-    }
+    for (int n = 0; n < N; ++n) s.h_pid[n] = index_of[bits[n]];
 }
 
 int upload_patterns_and_weights(sbe_engine* e, int slot) {
@@ -274,22 +275,23 @@ int upload_patterns_and_weights(sbe_engine* e, int slot) {
             std::vector<uint8_t> tid(e->Np, 0);
             std::vector<uint16_t> tg((size_t)kMaxTuples * kMaxComponents, (uint16_t)e->Gtot);
             std::vector<uint8_t> tp(kMaxTuples, 0);
-            std::vector<std::vector<uint16_t>> tuples;
+            uint16_t tuples[kMaxTuples][kMaxComponents];
+            int n_tup = 0;
             bool ok = true;
             for (int n = 0; n < N && ok; ++n) {
-                std::vector<uint16_t> key(C);
+                uint16_t key[kMaxComponents];
                 for (int c = 0; c < C; ++c) key[c] = s.h_gid[(size_t)c * N + n];
-                size_t t = 0;
-                for (; t < tuples.size(); ++t) if (tuples[t] == key) break;
-                if (t == tuples.size()) {
-                    if ((int)tuples.size() == kMaxTuples) { ok = false; break; }
-                    tuples.push_back(key);
-                    for (int c = 0; c < C; ++c) tg[t * kMaxComponents + c] = key[c] == kNoGroup ? (uint16_t)e->Gtot : key[c];
+                int t = 0;
+                for (; t < n_tup; ++t) if (memcmp(tuples[t], key, (size_t)C * sizeof(uint16_t)) == 0) break;
+                if (t == n_tup) {
+                    if (n_tup == kMaxTuples) { ok = false; break; }
+                    memcpy(tuples[n_tup++], key, (size_t)C * sizeof(uint16_t));
+                    for (int c = 0; c < C; ++c) tg[(size_t)t * kMaxComponents + c] = key[c] == kNoGroup ? (uint16_t)e->Gtot : key[c];
                     tp[t] = s.h_pid[n];
                 }
                 tid[n] = (uint8_t)t;
             }
-            s.n_tuples = ok ? (int)tuples.size() : 0;
+            s.n_tuples = ok ? n_tup : 0;
             if (ok) {
                 { int _urc = upload(e, e->d_tid + (int64_t)slot * e->Np, tid.data(), e->Np); if (_urc) return _urc; }
                 { int _urc = upload(e, e->d_tuple_g + (int64_t)slot * kMaxTuples * kMaxComponents, tg.data(),
@@ -1543,10 +1545,19 @@ int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters
     for (int n = 0; n < N; ++n) if (moved[n]) subset.push_back(n);
     rc = sbe_update_counts(e, cand_slot, cur_slot, subset.data(), (int)subset.size(), nullptr);
     if (rc) return done(rc);
-    for (int c = 0; c < e->C; ++c) {
-        rc = sbe_update_probs(e, cand_slot, c, 0.0, 0.0, nullptr);
-        if (rc) return done(rc);
-    }
+    // probability tables of every component in one launch (+ their tile-transposed copy)
+    rc = clear_status_word(e, ST_BAD_NORMALIZE);
+    if (rc) return done(rc);
+    k_probs<int32_t><<<div_up((int64_t)e->Gtot * e->F, 256), 256, 0, e->stream>>>(
+        e->d_counts + (int64_t)cand_slot * e->table_elems(), e->d_conc, nullptr,
+        e->d_probs + (int64_t)cand_slot * e->table_elems(), 0, e->Gtot, e->F, e->S, 0.0, 0.0, 1, e->d_status);
+    k_tile_probs<<<div_up((int64_t)e->Gtot * e->S * e->ft * e->n_ftiles, 256), 256, 0, e->stream>>>(
+        e->d_probs + (int64_t)cand_slot * e->table_elems(), e->d_probs_t + (int64_t)cand_slot * e->probs_t_elems(),
+        0, e->Gtot, e->Gtot, e->F, e->S, e->ft, e->n_ftiles);
+    HIPCHK(e, hipGetLastError());
+    std::fill(e->slots[cand_slot].probs_set.begin(), e->slots[cand_slot].probs_set.end(), 1);
+    rc = check_after(e);
+    if (rc) return done(rc);
     // collapsed likelihood of every group (a7/a8) into a device buffer
     k_dcl<int32_t><<<div_up((int64_t)e->Gtot * e->F, 256), 256, 0, e->stream>>>(
         e->d_counts + (int64_t)cand_slot * e->table_elems(), e->d_conc, e->d_step_pf, 0, e->Gtot, e->F, e->S, 1);
@@ -1573,14 +1584,22 @@ int sbe_copy_slot(sbe_engine* e, int dst, int src) {
     if (dst == src) return SBE_OK;
     HIPCHK(e, hipSetDevice(e->device));
     const int64_t N = e->N, F = e->F, C = e->C, T = e->table_elems();
-#define D2D(ptr, elems)                                                                             \
-    HIPCHK(e, hipMemcpyAsync((ptr) + (int64_t)dst * (elems), (ptr) + (int64_t)src * (elems),        \
-                             (size_t)(elems) * sizeof(*(ptr)), hipMemcpyDeviceToDevice, e->stream))
-    D2D(e->d_gid, C * e->Np); D2D(e->d_pid, (int64_t)e->Np); D2D(e->d_src, N * e->Fp); D2D(e->d_counts, T); D2D(e->d_probs, T);
-    D2D(e->d_probs_t, e->probs_t_elems()); D2D(e->d_wpat_t, e->wpat_t_elems());
-    D2D(e->d_tid, (int64_t)e->Np); D2D(e->d_tuple_g, (int64_t)kMaxTuples * kMaxComponents); D2D(e->d_tuple_p, (int64_t)kMaxTuples);
-    D2D(e->d_weights, F * C); D2D(e->d_wpat, (int64_t)e->Pmax * F * C); D2D(e->d_patbits, (int64_t)e->Pmax);
-#undef D2D
+    // every per-slot array in ONE launch (twelve hipMemcpyAsync calls cost ~40 us of host time per step)
+    CopySegs cs{};
+    uint32_t run = 0;
+    auto seg = [&](auto* ptr, int64_t elems) {
+        const int64_t bytes = elems * (int64_t)sizeof(*ptr);
+        cs.src[cs.n] = reinterpret_cast<const uint32_t*>(ptr + (int64_t)src * elems);
+        cs.dst[cs.n] = reinterpret_cast<uint32_t*>(ptr + (int64_t)dst * elems);
+        run += (uint32_t)(bytes / 4);
+        cs.end[cs.n++] = run;
+    };
+    seg(e->d_gid, C * e->Np); seg(e->d_pid, (int64_t)e->Np); seg(e->d_src, N * e->Fp); seg(e->d_counts, T); seg(e->d_probs, T);
+    seg(e->d_probs_t, e->probs_t_elems()); seg(e->d_wpat_t, e->wpat_t_elems());
+    seg(e->d_tid, (int64_t)e->Np); seg(e->d_tuple_g, (int64_t)kMaxTuples * kMaxComponents); seg(e->d_tuple_p, (int64_t)kMaxTuples);
+    seg(e->d_weights, F * C); seg(e->d_wpat, (int64_t)e->Pmax * F * C); seg(e->d_patbits, (int64_t)e->Pmax);
+    k_multi_copy<<<std::min<int64_t>(div_up(run, 256), 4 * e->compute_units), 256, 0, e->stream>>>(cs);
+    HIPCHK(e, hipGetLastError());
     e->slots[dst] = e->slots[src];
     return SBE_OK;
 }

@@ -1240,6 +1240,24 @@ __global__ __launch_bounds__(kBlock) void k_source_prior(const uint8_t* __restri
     if (lane == 0) out[n] = (double)(float)acc;
 }
 
+// One-launch copy of all per-slot arrays (sbe_copy_slot): up to 16 dword-granular segments.
+struct CopySegs {
+    const uint32_t* src[16];
+    uint32_t* dst[16];
+    uint32_t end[16];        // exclusive prefix end of each segment, in dwords
+    int n;
+};
+
+__global__ void k_multi_copy(CopySegs cs) {
+    const uint32_t total = cs.end[cs.n - 1];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int k = 0;
+        while (i >= cs.end[k]) ++k;
+        const uint32_t base = k ? cs.end[k - 1] : 0u;
+        cs.dst[k][i - base] = cs.src[k][i - base];
+    }
+}
+
 // canonical probs [Gtot][F][S] -> tile-transposed probs_t [n_ftiles][Gtot+1][S][FT] for the
 // groups [g_lo, g_hi).  Row Gtot and features >= F stay zero (set once at creation).
 __global__ void k_tile_probs(const float* __restrict__ probs, float* __restrict__ probs_t, int g_lo,

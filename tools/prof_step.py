@@ -1,0 +1,28 @@
+import sys, time; sys.path.insert(0, ".")
+import numpy as np
+from sbayes_amd import model as sbm
+from sbayes_amd.resident import ResidentChain
+from sbayes_amd.synthetic import make_workload
+wl = make_workload("headline")
+model, sample = sbm.build(wl.features, wl.states_per_feature, wl.component_names, wl.groups, wl.concentration, wl.weights, wl.source)
+chain = ResidentChain(model, sample)
+clusters = wl.clusters.copy()
+objs = np.arange(0, 1000, 50).astype(np.int32)
+rows = wl.source[objs]
+eng = chain.eng
+for variant in ("full", "no_clusters", "no_rows", "nothing"):
+    kw = {}
+    if variant in ("full", "no_rows"): kw["clusters"] = clusters
+    if variant in ("full", "no_clusters"): kw["source_rows"] = (objs, rows)
+    for _ in range(50):
+        chain.step(**kw); chain.accept()
+    t0 = time.perf_counter(); n = 500
+    for _ in range(n):
+        chain.step(**kw); chain.accept()
+    print(variant, round((time.perf_counter() - t0) / n * 1e6, 1), "us/step")
+t0 = time.perf_counter()
+for _ in range(500): eng.copy_slot(1, 0)
+eng.sync(); print("copy_slot", round((time.perf_counter() - t0) / 500 * 1e6, 1), "us")
+t0 = time.perf_counter()
+for _ in range(500): eng.mixture_loglik(0)
+print("mixture", round((time.perf_counter() - t0) / 500 * 1e6, 1), "us")
