@@ -15,6 +15,7 @@ from __future__ import annotations
 import numpy as np
 
 from .counts import recalculate_feature_counts
+from . import registry
 from .registry import get_engine
 
 
@@ -30,6 +31,7 @@ class Likelihood:
         for i, conf in enumerate(self.confounders, start=1):
             self.source_index[conf] = i
         self._na_features = None
+        registry.note_features(self.features, self.n_groups)
 
     # device handles are per process: never pickled, re-created lazily (mcmc_setup.py:299, model.py:53)
     def __getstate__(self):
@@ -124,17 +126,11 @@ def compute_component_likelihood_exact(features, probs, groups, changed_groups, 
 def normalize_weights(weights, has_components, features=None):
     """float32 [n_objects, n_features, n_components]: weights masked by has_components and
     renormalised over components.  `features` (optional) selects the engine explicitly."""
-    from .registry import _ENGINES
     has_components = np.asarray(has_components)
     if features is not None:
         eng = get_engine(features)
     else:
-        candidates = [e for e, _ in _ENGINES.values()
-                      if e.n_objects == has_components.shape[0] and e.n_features == np.shape(weights)[0]]
-        if not candidates:
-            raise RuntimeError("normalize_weights: no engine holds a feature block of matching shape; "
-                               "construct Likelihood(...) first or pass features=")
-        eng = candidates[-1]
+        eng = registry.engine_for_shape(has_components.shape[0], np.shape(weights)[0])
     return eng.normalize_weights(weights, has_components)
 
 

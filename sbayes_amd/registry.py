@@ -44,7 +44,37 @@ def get_engine(features, n_groups=None, n_slots=4, device=None) -> Engine:
     return eng
 
 
+_KNOWN = {}      # (n_objects, n_features) -> (weakref to a feature block, n_groups) noted by Likelihood(...)
+
+
+def note_features(features, n_groups=None):
+    """Remember a feature block (weakly) so that shape-only calls can find / create its engine."""
+    features = np.asarray(features)
+    try:
+        _KNOWN[(features.shape[0], features.shape[1])] = (weakref.ref(features), list(n_groups) if n_groups else None)
+    except TypeError:
+        pass
+
+
+def engine_for_shape(n_objects: int, n_features: int) -> Engine:
+    """Engine for calls that do not carry the feature block (normalize_weights(weights, has_components),
+    likelihood.py:171-190): an existing engine of that shape, else the engine of a block noted by
+    Likelihood(...), else a featureless stand-in of that shape (the call only needs N and F)."""
+    for eng, ref in _ENGINES.values():
+        if eng.n_objects == n_objects and eng.n_features == n_features and (ref is None or ref() is not None):
+            return eng
+    known = _KNOWN.get((n_objects, n_features))
+    if known is not None and known[0]() is not None:
+        return get_engine(known[0](), known[1])
+    key = ("shape", n_objects, n_features)
+    if key not in _ENGINES:
+        _ENGINES[key] = (Engine(np.zeros((n_objects, n_features, 1), dtype=bool), [1], n_slots=1,
+                                device=int(os.environ.get("SBAYES_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))), None)
+    return _ENGINES[key][0]
+
+
 def release_all():
     for eng, _ in list(_ENGINES.values()):
         eng.close()
     _ENGINES.clear()
+    _KNOWN.clear()

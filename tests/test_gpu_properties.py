@@ -122,3 +122,11 @@ def test_small_api_corners():
     e2 = get_engine(wl.features, n_groups)
     assert e2 is not e1 and e2.n_groups == n_groups and get_engine(wl.features) is e2
     release_all()
+    # normalize_weights carries no feature block: it must work before any engine exists (the reference's
+    # initialiser calls update_weights first), through a noted block or a shape-only stand-in
+    from oracle import sbayes_oracle as orc
+    from sbayes_amd.likelihood import normalize_weights
+    hc = orc.has_components(wl.groups)
+    want = orc.normalize_weights(wl.weights, hc)
+    assert np.array_equal(normalize_weights(wl.weights, hc), want)
+    release_all()

@@ -29,6 +29,9 @@ def fake(monkeypatch):
     import sbayes_amd.counts as counts_mod
     monkeypatch.setattr(counts_mod, "get_engine", get_engine, raising=True)
     monkeypatch.setattr(registry, "_ENGINES", {})
+    monkeypatch.setattr(registry, "engine_for_shape",
+                        lambda n, f: next((e for e in engines.values() if e.n_objects == n and e.n_features == f),
+                                          None) or FakeEngine(np.zeros((n, f, 1), dtype=bool)))
     return engines
 
 

@@ -1,0 +1,104 @@
+"""The REAL reference sampler running on the drop-in host layer (build container only).
+
+patch.install() swaps sbayes_amd.{likelihood,conditionals,counts} into the stub-imported reference;
+the device is replaced by the oracle-backed test double (tests/_fake_engine.py), so what is under
+test is the product's host logic under the reference's own usage: operators, initialiser, caches,
+copy-on-write samples, the sampler's cached-vs-uncached debug assertions.  With every RNG seeded,
+the patched and the unpatched run must produce the SAME Markov chain, bit for bit.
+Skipped where /root/reference does not exist (the GPU box)."""
+import os
+import random
+import shutil
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference sBayes not present")
+
+
+def run_chain(config_src: Path, tag: str, n_steps: int, seed: int, patched: bool, monkeypatch, tmp_path):
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import _ref_stubs
+    _ref_stubs.install()
+    import sbayes.mcmc_setup
+    import sbayes.sampling.initializers as ref_init
+    import sbayes.sampling.operators as ref_ops
+    import sbayes.util as ref_util
+    from sbayes.experiment_setup import Experiment
+    from sbayes.load_data import Data
+    from sbayes.sampling.initializers import SbayesInitializer
+    from sbayes.sampling.mcmc_chain import MCMCChain
+
+    from sbayes_amd import conditionals, counts, likelihood, patch, registry
+    from tests._fake_engine import FakeEngine
+
+    work = tmp_path / f"{tag}_{'patched' if patched else 'plain'}"
+    shutil.copytree(config_src, work)
+    engines = {}
+
+    def get_engine(features, n_groups=None, n_slots=4, device=None):
+        key = (np.asarray(features).ctypes.data, np.asarray(features).shape)
+        if key not in engines:
+            engines[key] = FakeEngine(features, n_groups)
+        return engines[key]
+
+    if patched:
+        for mod in (registry, likelihood, conditionals, counts):
+            monkeypatch.setattr(mod, "get_engine", get_engine, raising=True)
+        monkeypatch.setattr(registry, "_ENGINES", {})
+        monkeypatch.setattr(registry, "engine_for_shape",
+                            lambda n, f: next((e for e in engines.values() if e.n_objects == n and e.n_features == f),
+                                              None) or FakeEngine(np.zeros((n, f, 1), dtype=bool)))
+        patch.install()
+    try:
+        np.random.seed(seed)
+        random.seed(seed)
+        for mod in (ref_ops, ref_init, ref_util, sbayes.mcmc_setup):
+            monkeypatch.setattr(mod, "RNG", np.random.default_rng(seed), raising=True)
+        cwd = os.getcwd()
+        os.chdir(work)
+        try:
+            experiment = Experiment(config_file=work / "config.yaml", experiment_name="drop_in", log=False)
+            data = Data.from_config(experiment.config)
+            from sbayes.model import Model
+            model = Model(data, experiment.config.model)
+            if patched:
+                assert type(model.likelihood).__module__ == "sbayes_amd.likelihood"
+            cfg = experiment.config.mcmc
+            init = SbayesInitializer(model=model, data=data, initial_size=cfg.initialization.objects_per_cluster,
+                                     attempts=cfg.initialization.attempts,
+                                     initial_cluster_steps=cfg.initialization._initial_cluster_steps)
+            sample = init.generate_sample(c=0)
+            chain = MCMCChain(model=model, data=data, operators=cfg.operators, sample_loggers=[])
+            chain._ll = chain.likelihood(sample)
+            chain._prior = chain.prior(sample)
+            trace = []
+            for i in range(1, n_steps + 1):
+                sample = chain.step(sample)
+                sample.i_step = i
+                trace.append((float(chain._ll), float(chain._prior), chain.previous_operator.operator_name))
+            return trace, sample.clusters.value.copy(), sample.source.value.copy(), sample.weights.value.copy(), engines
+        finally:
+            os.chdir(cwd)
+    finally:
+        if patched:
+            patch.uninstall()
+
+
+@pytest.mark.parametrize("tag,src,n_steps", [
+    ("test_files", Path(REF) / "test" / "test_files", 250),
+    ("south_america", Path(REF) / "experiments" / "south_america", 60),
+])
+def test_reference_sampler_on_drop_in_layer_is_the_same_markov_chain(tag, src, n_steps, monkeypatch, tmp_path):
+    plain = run_chain(src, tag, n_steps, 11, False, monkeypatch, tmp_path)
+    patched = run_chain(src, tag, n_steps, 11, True, monkeypatch, tmp_path)
+    assert [t[2] for t in patched[0]] == [t[2] for t in plain[0]]            # same operators chosen
+    assert [t[:2] for t in patched[0]] == [t[:2] for t in plain[0]]          # same likelihood / prior, bit for bit
+    assert np.array_equal(patched[1], plain[1]) and np.array_equal(patched[2], plain[2])
+    assert np.array_equal(patched[3], plain[3])
+    eng = next(iter(patched[4].values()))
+    kinds = {c[0] for c in eng.calls}
+    assert {"component_lh", "normalize_tables", "dirichlet_logpdf"} <= kinds   # the path really ran through the layer
