@@ -26,9 +26,18 @@ def install():
         counts = importlib.import_module("sbayes.sampling.counts")
     except ImportError as exc:
         raise RuntimeError("sbayes_amd.patch.install(): sBayes is not importable") from exc
+    # import every module that binds the names BEFORE swapping anything: a module first imported after
+    # the swap would bind the replacements as its "originals" and uninstall() could not restore them
+    importers = []
+    for modname in ("sbayes.sampling.operators", "sbayes.sampling.initializers", "sbayes.sampling.loggers",
+                    "sbayes.sampling.mcmc", "sbayes.sampling.mcmc_chain", "sbayes.mcmc_setup"):
+        try:
+            importers.append(importlib.import_module(modname))
+        except ImportError:
+            continue
 
     def swap(mod, name, new):
-        if hasattr(mod, name):
+        if hasattr(mod, name) and getattr(mod, name) is not new:
             _SAVED.append((mod, name, getattr(mod, name)))
             setattr(mod, name, new)
 
@@ -43,17 +52,13 @@ def install():
         swap(mod, "compute_effect_counts", my_counts.compute_effect_counts)
         swap(mod, "recalculate_feature_counts", my_counts.recalculate_feature_counts)
         swap(mod, "update_feature_counts", my_counts.update_feature_counts)
-    # modules that imported the names earlier (operators, initializers, loggers, mcmc_setup)
-    for modname in ("sbayes.sampling.operators", "sbayes.sampling.initializers", "sbayes.sampling.loggers"):
-        try:
-            m = importlib.import_module(modname)
-        except ImportError:
-            continue
+    for m in importers:
         for name, new in (("likelihood_per_component", my_cond.likelihood_per_component),
                           ("update_weights", my_lik.update_weights),
                           ("normalize_weights", my_lik.normalize_weights),
                           ("recalculate_feature_counts", my_counts.recalculate_feature_counts),
                           ("update_feature_counts", my_counts.update_feature_counts),
+                          ("compute_effect_counts", my_counts.compute_effect_counts),
                           ("compute_component_likelihood", my_lik.compute_component_likelihood)):
             swap(m, name, new)
 
