@@ -41,6 +41,7 @@ struct sbe_engine {
     int Fp = 0, rs_pitch = 0, Gtot = 0, Pmax = 0;
     int Np = 0, NQ = 0;            // objects padded to a multiple of 4; object quads
     int ft = 64, n_ftiles = 0, Fq = 0;   // v2 fused-kernel feature tile width, tiles, padded features
+    bool direct = false;           // tables of a 16-feature tile exceed LDS: gather from the global tiled tables
     int compute_units = 256;
     std::vector<int> G, goff;
     int64_t n_na = 0;
@@ -345,8 +346,8 @@ MixGeom mix_geometry_v2(const sbe_engine* e, int P, int n_batch) {
     g.objs_per_chunk = std::min<int>(max_quads, std::max<int>(min_quads, div_up(e->NQ, chunks)));   // in quads
     g.n_chunks = div_up(e->NQ, g.objs_per_chunk);
     g.n_blocks = g.n_chunks * g.n_ftiles;
-    g.lds_bytes = (size_t)e->tile_tab_elems() * sizeof(float) + (size_t)P * e->C * e->ft * sizeof(double) +
-                  (size_t)g.objs_per_chunk * (8 * e->C + 4);
+    g.lds_bytes = (size_t)g.objs_per_chunk * (8 * e->C + 4);
+    if (!e->direct) g.lds_bytes += (size_t)e->tile_tab_elems() * sizeof(float) + (size_t)P * e->C * e->ft * sizeof(double);
     return g;
 }
 
@@ -365,31 +366,32 @@ int check_slot_ready(sbe_engine* e, int slot, bool need_weights) {
     return SBE_OK;
 }
 
-template <int MODE, int FT>
+template <int MODE, int FT, bool DIRECT = false>
 void launch_v2_ft(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
     switch (C) {
-        case 1: k_mixture_v2<MODE, FT, 1><<<grid, kBlock, lds, st>>>(p); break;
-        case 2: k_mixture_v2<MODE, FT, 2><<<grid, kBlock, lds, st>>>(p); break;
-        case 3: k_mixture_v2<MODE, FT, 3><<<grid, kBlock, lds, st>>>(p); break;
-        case 4: k_mixture_v2<MODE, FT, 4><<<grid, kBlock, lds, st>>>(p); break;
-        default: k_mixture_v2<MODE, FT, 0><<<grid, kBlock, lds, st>>>(p); break;
+        case 1: k_mixture_v2<MODE, FT, 1, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
+        case 2: k_mixture_v2<MODE, FT, 2, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
+        case 3: k_mixture_v2<MODE, FT, 3, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
+        case 4: k_mixture_v2<MODE, FT, 4, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
+        default: k_mixture_v2<MODE, FT, 0, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
     }
 }
 
-template <int MODE, int FT>
+template <int MODE, int FT, bool DIRECT = false>
 void launch_oh2_ft(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
     switch (C) {
-        case 1: k_mixture_onehot_v2<MODE, FT, 1><<<grid, kBlock, lds, st>>>(p); break;
-        case 2: k_mixture_onehot_v2<MODE, FT, 2><<<grid, kBlock, lds, st>>>(p); break;
-        case 3: k_mixture_onehot_v2<MODE, FT, 3><<<grid, kBlock, lds, st>>>(p); break;
-        case 4: k_mixture_onehot_v2<MODE, FT, 4><<<grid, kBlock, lds, st>>>(p); break;
-        default: k_mixture_onehot_v2<MODE, FT, 0><<<grid, kBlock, lds, st>>>(p); break;
+        case 1: k_mixture_onehot_v2<MODE, FT, 1, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
+        case 2: k_mixture_onehot_v2<MODE, FT, 2, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
+        case 3: k_mixture_onehot_v2<MODE, FT, 3, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
+        case 4: k_mixture_onehot_v2<MODE, FT, 4, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
+        default: k_mixture_onehot_v2<MODE, FT, 0, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
     }
 }
 
 template <int MODE>
-void launch_oh2(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
-    if (ft == 64) launch_oh2_ft<MODE, 64>(C, p, grid, lds, st);
+void launch_oh2(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st, bool direct) {
+    if (direct) launch_oh2_ft<MODE, 16, true>(C, p, grid, lds, st);
+    else if (ft == 64) launch_oh2_ft<MODE, 64>(C, p, grid, lds, st);
     else if (ft == 32) launch_oh2_ft<MODE, 32>(C, p, grid, lds, st);
     else launch_oh2_ft<MODE, 16>(C, p, grid, lds, st);
 }
@@ -413,8 +415,9 @@ void launch_combo(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hip
 }
 
 template <int MODE>
-void launch_v2(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
-    if (ft == 64) launch_v2_ft<MODE, 64>(C, p, grid, lds, st);
+void launch_v2(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st, bool direct) {
+    if (direct) launch_v2_ft<MODE, 16, true>(C, p, grid, lds, st);
+    else if (ft == 64) launch_v2_ft<MODE, 64>(C, p, grid, lds, st);
     else if (ft == 32) launch_v2_ft<MODE, 32>(C, p, grid, lds, st);
     else launch_v2_ft<MODE, 16>(C, p, grid, lds, st);
 }
@@ -487,10 +490,10 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
             else launch_combo<false>(g.ft, e->C, p, grid, combo_lds, e->stream);
         } else
         if (onehot) {
-            if (mode == LOG_PRODUCT) launch_oh2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
-            else launch_oh2<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
-        } else if (mode == LOG_PRODUCT) launch_v2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
-        else launch_v2<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
+            if (mode == LOG_PRODUCT) launch_oh2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
+            else launch_oh2<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
+        } else if (mode == LOG_PRODUCT) launch_v2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
+        else launch_v2<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
     }
     if (ev_b) HIPCHK(e, hipEventRecord(ev_b, e->stream));
     HIPCHK(e, hipGetLastError());
@@ -616,7 +619,11 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
         auto lds_for = [&](int t) { return ((size_t)(gtot + 1) * t * n_states) * sizeof(float) + (size_t)e->Pmax * n_components * t * sizeof(double) + 8 * 1024; };
         while (ft > 16 && lds_for(ft) > 78 * 1024) ft >>= 1;
         if (env && (atoi(env) == 64 || atoi(env) == 32 || atoi(env) == 16)) ft = atoi(env);
-        if (lds_for(ft) > 156 * 1024) { delete e; return fail(nullptr, SBE_ERR_ARG, "probability tables too large for LDS staging (G_total=%lld, S=%d)", (long long)gtot, n_states); }
+        if (lds_for(ft) > 156 * 1024) {
+            if (env) { delete e; return fail(nullptr, SBE_ERR_ARG, "probability tables too large for LDS staging at the forced tile width (G_total=%lld, S=%d)", (long long)gtot, n_states); }
+            ft = 16;                 // very many groups x states: no LDS staging of tables (L2-served gathers)
+            e->direct = true;
+        }
         e->ft = ft;
         e->n_ftiles = div_up(n_features, ft);
         e->Fq = e->n_ftiles * ft;

@@ -591,33 +591,44 @@ struct V2Lds {
     uint8_t* ids_p;      // [4*quads_per_chunk]
 };
 
-template <int FT>
+// DIRECT = the tables of a tile do not fit LDS (very many groups x states): tab / wl then point at the
+// tile-transposed GLOBAL tables (served by L2) and only the ids are staged.
+template <int FT, bool DIRECT>
 __device__ __forceinline__ V2Lds v2_stage(const Mix2Params& p, unsigned char* lds_raw, int slot, int tile, int C,
                                           int q0, int nq) {
     V2Lds L;
     const int tab_elems = (p.Gtot + 1) * p.S * FT;            // multiple of 16
-    L.tab = reinterpret_cast<float*>(lds_raw);
-    L.wl = reinterpret_cast<double*>(lds_raw + (size_t)tab_elems * sizeof(float));
-    uint64_t* ids_g64 = reinterpret_cast<uint64_t*>(L.wl + (size_t)p.P * C * FT);      // [C][quads_per_chunk]
+    const float* g_tab = p.probs_t + (int64_t)slot * p.probs_t_stride + (int64_t)tile * tab_elems;
+    const double* g_wl = p.wpat_t + (int64_t)slot * p.wpat_t_stride + (int64_t)tile * p.wpat_tile_stride;
+    uint64_t* ids_g64;
+    if (DIRECT) {
+        L.tab = const_cast<float*>(g_tab);
+        L.wl = const_cast<double*>(g_wl);
+        ids_g64 = reinterpret_cast<uint64_t*>(lds_raw);
+    } else {
+        L.tab = reinterpret_cast<float*>(lds_raw);
+        L.wl = reinterpret_cast<double*>(lds_raw + (size_t)tab_elems * sizeof(float));
+        ids_g64 = reinterpret_cast<uint64_t*>(L.wl + (size_t)p.P * C * FT);            // [C][quads_per_chunk]
+    }
     uint32_t* ids_p32 = reinterpret_cast<uint32_t*>(ids_g64 + (size_t)C * p.quads_per_chunk);
     L.ids_g = reinterpret_cast<uint16_t*>(ids_g64);
     L.ids_p = reinterpret_cast<uint8_t*>(ids_p32);
-    // tile image: contiguous float4 copy, 4 loads in flight per thread
-    const float4* src = reinterpret_cast<const float4*>(
-        p.probs_t + (int64_t)slot * p.probs_t_stride + (int64_t)tile * tab_elems);
-    float4* dst = reinterpret_cast<float4*>(L.tab);
-    const int n4 = tab_elems >> 2;
-    int i = threadIdx.x;
-    for (; i + 3 * kBlock < n4; i += 4 * kBlock) {
-        const float4 a = src[i], b = src[i + kBlock], c = src[i + 2 * kBlock], d = src[i + 3 * kBlock];
-        dst[i] = a; dst[i + kBlock] = b; dst[i + 2 * kBlock] = c; dst[i + 3 * kBlock] = d;
+    if (!DIRECT) {
+        // tile image: contiguous float4 copy, 4 loads in flight per thread
+        const float4* src = reinterpret_cast<const float4*>(g_tab);
+        float4* dst = reinterpret_cast<float4*>(L.tab);
+        const int n4 = tab_elems >> 2;
+        int i = threadIdx.x;
+        for (; i + 3 * kBlock < n4; i += 4 * kBlock) {
+            const float4 a = src[i], b = src[i + kBlock], c = src[i + 2 * kBlock], d = src[i + 3 * kBlock];
+            dst[i] = a; dst[i + kBlock] = b; dst[i + 2 * kBlock] = c; dst[i + 3 * kBlock] = d;
+        }
+        for (; i < n4; i += kBlock) dst[i] = src[i];
+        const double2* wsrc = reinterpret_cast<const double2*>(g_wl);
+        double2* wdst = reinterpret_cast<double2*>(L.wl);
+        const int w2 = (p.P * C * FT) >> 1;
+        for (int k = threadIdx.x; k < w2; k += kBlock) wdst[k] = wsrc[k];
     }
-    for (; i < n4; i += kBlock) dst[i] = src[i];
-    const double2* wsrc = reinterpret_cast<const double2*>(
-        p.wpat_t + (int64_t)slot * p.wpat_t_stride + (int64_t)tile * p.wpat_tile_stride);
-    double2* wdst = reinterpret_cast<double2*>(L.wl);
-    const int w2 = (p.P * C * FT) >> 1;
-    for (int k = threadIdx.x; k < w2; k += kBlock) wdst[k] = wsrc[k];
     // the chunk's ids: group ids (4 x u16 per quad and component) and pattern ids (LDS reads are
     // in-order on lgkmcnt and ~64 cycles; scalar loads would serialise behind every LDS wait)
     const uint16_t* gid = p.gid + (int64_t)slot * p.gid_stride;
@@ -632,7 +643,7 @@ __device__ __forceinline__ V2Lds v2_stage(const Mix2Params& p, unsigned char* ld
     return L;
 }
 
-template <int MODE, int FT, int CT>     // CT: compile-time component count (1..4), 0 = runtime (<= 8)
+template <int MODE, int FT, int CT, bool DIRECT>   // CT: compile-time component count (1..4), 0 = runtime (<= 8)
 __global__ __launch_bounds__(kBlock) void k_mixture_v2(Mix2Params p) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ double red4[4];
@@ -655,7 +666,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_v2(Mix2Params p) {
     const int q0 = chunk * p.quads_per_chunk;
     const int q1 = min(p.NQ, q0 + p.quads_per_chunk);
     const int nq = q1 - q0;                                 // >= 1
-    const V2Lds L = v2_stage<FT>(p, lds_raw, slot, tile, C, q0, nq);
+    const V2Lds L = v2_stage<FT, DIRECT>(p, lds_raw, slot, tile, C, q0, nq);
     const uint64_t* ids_g = reinterpret_cast<const uint64_t*>(L.ids_g);
     const uint32_t* ids_p = reinterpret_cast<const uint32_t*>(L.ids_p);
 
@@ -766,7 +777,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_v2(Mix2Params p) {
 //   (fl,x) <-> byte offset j in the row segment: fl = floor((j + 0.5)/S) in f32 (exact for
 //             j < 2^16, S <= 254), x = j - fl*S
 // ------------------------------------------------------------------------------------------
-template <int MODE, int FT, int CT>
+template <int MODE, int FT, int CT, bool DIRECT>
 __global__ __launch_bounds__(kBlock) void k_mixture_onehot_v2(Mix2Params p) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ double red4[4];
@@ -789,7 +800,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_onehot_v2(Mix2Params p) {
     const int q0 = chunk * p.quads_per_chunk;
     const int q1 = min(p.NQ, q0 + p.quads_per_chunk);
     const int nq = q1 - q0;
-    const V2Lds L = v2_stage<FT>(p, lds_raw, slot, tile, C, q0, nq);
+    const V2Lds L = v2_stage<FT, DIRECT>(p, lds_raw, slot, tile, C, q0, nq);
 
     const int n0 = 4 * q0;
     const int n_obj = min(4 * nq, p.N - n0);

@@ -28,6 +28,7 @@ SHAPES = [
     (20,   3,   254, [2, 1],                     0.05),      # maximum state count (0xFF is NA)
     (30,   9,   3,  [2, 1, 2, 2, 2, 2, 2, 2],    0.05),      # maximum component count (8)
     (2003, 70,  3,  [7, 1],                      0.03),      # several object chunks with a ragged tail
+    (300,  20,  30, [60, 1, 45],                 0.03),      # tables of a 16-feature tile exceed LDS: direct (L2) gathers
 ]
 
 
@@ -73,7 +74,7 @@ def test_shape_sweep(shape, ft, monkeypatch):
     try:
         _run_case(feats, groups, weights, source, conc, n_groups, rng)
     except EngineError as exc:                     # a forced tile too wide for the tables is a valid refusal
-        assert "too large for LDS" in str(exc) and ft != "16", exc
+        assert "too large for LDS" in str(exc) and (ft != "16" or "forced tile width" in str(exc)), exc
 
 
 def test_default_tile_width_never_refuses():
