@@ -979,7 +979,8 @@ __global__ __launch_bounds__(kBlock) void k_mixture_combo(Mix2Params p) {
                 const int fl = ec % FT, r = ec / FT;
                 const int s = r % S, t = r / S;
                 tt[u] = t;
-                dst[u] = e < n_ent ? (t * S1 + s) * FT + fl : -1;
+                // features past F in the last tile are never gathered (their state bytes are NA): no log for them
+                dst[u] = (e < n_ent && tile * FT + fl < p.F) ? (t * S1 + s) * FT + fl : -1;
 #pragma unroll
                 for (int c = 0; c < CU; ++c)
                     pr[u][c] = (CT || c < C) ? probs_t[((int64_t)tgl[t * CU + c] * S + s) * FT + fl] : 0.0f;

@@ -1,0 +1,76 @@
+/* abi_smoke.c -- plain-C caller of the engine's C ABI (include/sbe_engine.h): proves the boundary is
+ * usable without Python / NumPy / torch.  Reads a small binary case written by the pytest wrapper
+ * (tests/test_gpu_c_abi.py), evaluates it through the ABI and prints the results as text.
+ *   gcc -O2 -I include tests/c/abi_smoke.c -o abi_smoke -ldl      (the .so is dlopen'ed)             */
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "sbe_engine.h"
+
+#define LOAD(name) name##_t p_##name = (name##_t)dlsym(lib, #name); if (!p_##name) { fprintf(stderr, "missing %s\n", #name); return 2; }
+typedef int (*sbe_create_t)(sbe_engine**, int, int, int, int, int, const int32_t*, int, const uint8_t*);
+typedef int (*sbe_destroy_t)(sbe_engine*);
+typedef const char* (*sbe_last_error_t)(const sbe_engine*);
+typedef int (*sbe_set_groups_t)(sbe_engine*, int, int, const uint8_t*);
+typedef int (*sbe_set_source_t)(sbe_engine*, int, const uint8_t*);
+typedef int (*sbe_recount_t)(sbe_engine*, int, int);
+typedef int (*sbe_set_concentration_t)(sbe_engine*, int, const double*, int);
+typedef int (*sbe_update_probs_t)(sbe_engine*, int, int, double, double, const double*);
+typedef int (*sbe_set_weights_t)(sbe_engine*, int, const float*);
+typedef int (*sbe_mixture_loglik_t)(sbe_engine*, int, double*);
+typedef int (*sbe_collapsed_loglik_t)(sbe_engine*, int, int, double*, float*);
+typedef int (*sbe_get_info_t)(const sbe_engine*, sbe_info*);
+
+static void* slurp(FILE* f, size_t bytes) {
+    void* p = malloc(bytes ? bytes : 1);
+    if (fread(p, 1, bytes, f) != bytes) { fprintf(stderr, "short read\n"); exit(3); }
+    return p;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) { fprintf(stderr, "usage: %s libsbe_engine.so case.bin\n", argv[0]); return 1; }
+    void* lib = dlopen(argv[1], RTLD_NOW);
+    if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
+    LOAD(sbe_create) LOAD(sbe_destroy) LOAD(sbe_last_error) LOAD(sbe_set_groups) LOAD(sbe_set_source) LOAD(sbe_recount)
+    LOAD(sbe_set_concentration) LOAD(sbe_update_probs) LOAD(sbe_set_weights) LOAD(sbe_mixture_loglik)
+    LOAD(sbe_collapsed_loglik) LOAD(sbe_get_info)
+    FILE* f = fopen(argv[2], "rb");
+    if (!f) { perror("case"); return 1; }
+    int32_t hdr[4];                                   /* N, F, S, C */
+    if (fread(hdr, sizeof hdr, 1, f) != 1) return 3;
+    const int N = hdr[0], F = hdr[1], S = hdr[2], C = hdr[3];
+    int32_t* G = (int32_t*)slurp(f, (size_t)C * sizeof(int32_t));
+    uint8_t* feats = (uint8_t*)slurp(f, (size_t)N * F * S);
+    sbe_engine* e = NULL;
+    if (p_sbe_create(&e, 0, N, F, S, C, G, 1, feats)) { fprintf(stderr, "create: %s\n", p_sbe_last_error(NULL)); return 4; }
+    for (int c = 0; c < C; ++c) {
+        uint8_t* groups = (uint8_t*)slurp(f, (size_t)G[c] * N);
+        double* conc = (double*)slurp(f, (size_t)G[c] * F * S * sizeof(double));
+        if (p_sbe_set_groups(e, 0, c, groups) || p_sbe_set_concentration(e, c, conc, 1)) { fprintf(stderr, "%s\n", p_sbe_last_error(e)); return 5; }
+        free(groups); free(conc);
+    }
+    uint8_t* source = (uint8_t*)slurp(f, (size_t)N * F * C);
+    float* weights = (float*)slurp(f, (size_t)F * C * sizeof(float));
+    if (p_sbe_set_source(e, 0, source) || p_sbe_recount(e, 0, -1)) { fprintf(stderr, "%s\n", p_sbe_last_error(e)); return 6; }
+    for (int c = 0; c < C; ++c)
+        if (p_sbe_update_probs(e, 0, c, 0.0, 0.0, NULL)) { fprintf(stderr, "%s\n", p_sbe_last_error(e)); return 7; }
+    if (p_sbe_set_weights(e, 0, weights)) { fprintf(stderr, "%s\n", p_sbe_last_error(e)); return 8; }
+    double ll = 0.0, collapsed = 0.0;
+    if (p_sbe_mixture_loglik(e, 0, &ll)) { fprintf(stderr, "%s\n", p_sbe_last_error(e)); return 9; }
+    for (int c = 0; c < C; ++c) {
+        double* pg = (double*)malloc((size_t)G[c] * sizeof(double));
+        if (p_sbe_collapsed_loglik(e, 0, c, pg, NULL)) { fprintf(stderr, "%s\n", p_sbe_last_error(e)); return 10; }
+        for (int g = 0; g < G[c]; ++g) collapsed += pg[g];
+        free(pg);
+    }
+    sbe_info info;
+    p_sbe_get_info(e, &info);
+    printf("mixture_ll %.17g\ncollapsed_ll %.17g\nn_na %lld\n", ll, collapsed, (long long)info.n_na);
+    /* error behaviour: a bad slot is reported through the return code + message, not a crash */
+    if (p_sbe_mixture_loglik(e, 7, &ll) == 0) { fprintf(stderr, "bad slot accepted\n"); return 11; }
+    printf("error_text %s\n", p_sbe_last_error(e));
+    p_sbe_destroy(e);
+    fclose(f);
+    return 0;
+}

@@ -1,0 +1,42 @@
+"""The C ABI used from plain C (no Python / NumPy / torch in the caller): tests/c/abi_smoke.c is
+compiled with gcc against include/sbe_engine.h, dlopens the engine library, evaluates the cfg1
+fixture and must reproduce the reference's golden values."""
+import re
+import shutil
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from sbayes_amd import _lib
+from tests._fixtures import load_npz
+
+REPO = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not available")
+def test_plain_c_caller(tmp_path):
+    exe = tmp_path / "abi_smoke"
+    subprocess.run(["gcc", "-O2", "-std=c99", "-Wall", "-I", str(REPO / "include"), str(REPO / "tests" / "c" / "abi_smoke.c"),
+                    "-o", str(exe), "-ldl"], check=True)
+    fx = load_npz("cfg1")
+    n, f, s = fx.features.shape
+    case = tmp_path / "case.bin"
+    with open(case, "wb") as fh:
+        fh.write(np.array([n, f, s, fx.n_comp], dtype=np.int32).tobytes())
+        fh.write(np.array([g.shape[0] for g in fx.groups], dtype=np.int32).tobytes())
+        fh.write(np.ascontiguousarray(fx.features).view(np.uint8).tobytes())
+        for c in range(fx.n_comp):
+            fh.write(np.ascontiguousarray(fx.groups[c]).view(np.uint8).tobytes())
+            conc = fx.conc[c] if fx.conc[c].ndim == 3 else np.broadcast_to(fx.conc[c], (fx.groups[c].shape[0], f, s))
+            fh.write(np.ascontiguousarray(conc, dtype=np.float64).tobytes())
+        fh.write(np.ascontiguousarray(fx.source).view(np.uint8).tobytes())
+        fh.write(np.ascontiguousarray(fx.weights, dtype=np.float32).tobytes())
+    out = subprocess.run([str(exe), str(_lib.lib_path()), str(case)], check=True, capture_output=True, text=True, timeout=120).stdout
+    vals = dict(re.findall(r"^(\w+) (.+)$", out, flags=re.M))
+    assert abs(float(vals["mixture_ll"]) - fx.meta["mixture_ll"]) <= 1e-10 * abs(fx.meta["mixture_ll"])
+    assert abs(float(vals["collapsed_ll"]) - fx.meta["collapsed_ll"]) <= 1e-6 * abs(fx.meta["collapsed_ll"])
+    assert int(vals["n_na"]) == int(fx.na_values.sum())
+    assert "slot 7 out of range" in vals["error_text"]
