@@ -274,6 +274,9 @@ int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters
              const float* weights, double* group_logliks_out, double* mixture_out,
              uint8_t* changed_groups_out);
 
+/* ---- self-test hook: fp64 log used by the group-tuple table build vs the device library's log ---- */
+int sbe_test_fast_log(sbe_engine* e, const double* in, int n, double* out_fast, double* out_lib);
+
 /* ---- slot management -------------------------------------------------------------------- */
 int sbe_copy_slot(sbe_engine* e, int dst_slot, int src_slot);
 

@@ -1585,6 +1585,25 @@ int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters
     return done(synced(e));
 }
 
+// ---- self-test hook: the table-build log against the device library's log -------------------------------
+int sbe_test_fast_log(sbe_engine* e, const double* in, int n, double* out_fast, double* out_lib) {
+    CHECK_ENGINE(e); CHECK_PTR(e, in); CHECK_PTR(e, out_fast); CHECK_PTR(e, out_lib);
+    if (n < 1) return fail(e, SBE_ERR_ARG, "n=%d", n);
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t b = ((size_t)n * sizeof(double) + 255) / 256 * 256;
+    int rc = ensure_scratch(e, 3 * b);
+    if (rc) return rc;
+    double* d_in = (double*)e->d_scratch;
+    double* d_f = (double*)(e->d_scratch + b);
+    double* d_l = (double*)(e->d_scratch + 2 * b);
+    { int _urc = upload(e, d_in, in, (size_t)n * sizeof(double)); if (_urc) return _urc; }
+    k_test_fast_log<<<div_up(n, 256), 256, 0, e->stream>>>(d_in, d_f, d_l, n);
+    HIPCHK(e, hipGetLastError());
+    rc = d2h(e, out_fast, d_f, (size_t)n * sizeof(double));
+    if (rc) return rc;
+    return d2h(e, out_lib, d_l, (size_t)n * sizeof(double));
+}
+
 // ---- slots ------------------------------------------------------------------------------------------
 int sbe_copy_slot(sbe_engine* e, int dst, int src) {
     CHECK_ENGINE(e); CHECK_SLOT(e, dst); CHECK_SLOT(e, src);

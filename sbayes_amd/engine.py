@@ -448,6 +448,13 @@ class Engine:
                                        _ptr(glh), ct.byref(mix), _ptr(changed)))
         return glh, mix.value, changed.astype(bool)
 
+    def test_fast_log(self, x):
+        """(fast, library) fp64 logs of x computed on the device (self-test of the table-build log)."""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        a, b = np.empty_like(x), np.empty_like(x)
+        self._check(self._lib.sbe_test_fast_log(self._h, _ptr(x), x.size, _ptr(a), _ptr(b)))
+        return a, b
+
     def copy_slot(self, dst, src):
         self._check(self._lib.sbe_copy_slot(self._h, dst, src))
 

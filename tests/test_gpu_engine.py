@@ -293,3 +293,29 @@ def test_deferred_checks_surface_at_next_sync():
         eng.set_weights(0, np.ones((1, 1), dtype=np.float32))
         assert np.isclose(eng.mixture_loglik(0), 3 * np.log(0.5), rtol=1e-14)
         eng.set_option(deferred_checks=False)
+
+
+def test_fast_log_accuracy():
+    """The fp64 log of the group-tuple table build: < 1 ulp against NumPy's log over positive normal
+    doubles (probability-like values, the whole exponent range, values around 1), and the special
+    cases go through the library log (0 -> -inf, negative -> NaN)."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([
+        rng.random(200000),                                   # (0, 1)
+        np.float32(rng.random(50000)).astype(np.float64) * np.float32(rng.random(50000)).astype(np.float64),
+        np.exp(rng.uniform(-700, 700, 50000)),                # whole exponent range
+        1.0 + rng.uniform(-1e-3, 1e-3, 50000),                # around 1 (cancellation)
+        np.array([1.0, 0.5, 2.0, np.sqrt(2), np.sqrt(0.5), np.nextafter(1, 2), np.nextafter(1, 0), 2.2250738585072014e-308]),
+    ])
+    x = x[x > 0]
+    with Engine(np.zeros((1, 1, 1), dtype=bool), [1], n_slots=1) as eng:
+        fast, lib = eng.test_fast_log(x)
+        want = np.log(x)
+        ulp = np.spacing(np.abs(want))
+        ulp[want == 0] = np.spacing(1.0) / 2
+        err = np.abs(fast - want) / ulp
+        assert err.max() <= 1.0, (err.max(), x[err.argmax()])
+        assert fast[x == 1.0][0] == 0.0
+        special, _ = eng.test_fast_log(np.array([0.0, -1.0, np.inf, np.nan, 5e-324]))
+        assert special[0] == -np.inf and np.isnan(special[1]) and special[2] == np.inf and np.isnan(special[3])
+        assert np.isclose(special[4], np.log(5e-324), rtol=1e-15)
