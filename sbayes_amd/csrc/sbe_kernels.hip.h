@@ -1053,10 +1053,17 @@ __global__ __launch_bounds__(kBlock) void k_mixture_combo(Mix2Params p) {
     const uint32_t* sq = p.state_q + (int64_t)q0 * p.Fq + f;
     const double* T_l = T + fl;
     auto local_quad = [&](int k) { return (k * 4 + wid) * ROWS + sub; };
-    auto load_state = [&](int k) -> uint32_t {
-        const int i = local_quad(k);
-        const uint32_t xs = sq[(int64_t)min(i, nq - 1) * p.Fq];
-        return i < nq ? xs : 0xFFFFFFFFu;
+    // running 32-bit offsets of the state stream (no 64-bit multiply per step): quad i of the chunk sits at
+    // dword i * Fq; steps advance by 4*ROWS quads; reads past the chunk are clamped to its last quad and masked
+    const uint32_t off_step = (uint32_t)(4 * ROWS) * (uint32_t)p.Fq, off_last = (uint32_t)(nq - 1) * (uint32_t)p.Fq;
+    uint32_t pre_off = (uint32_t)local_quad(0) * (uint32_t)p.Fq;
+    int pre_i = local_quad(0);
+    auto next_state = [&]() -> uint32_t {
+        const uint32_t xs = sq[min(pre_off, off_last)];
+        const uint32_t r = pre_i < nq ? xs : 0xFFFFFFFFu;
+        pre_off += off_step;
+        pre_i += 4 * ROWS;
+        return r;
     };
     // two steps (8 objects per lane) per trip, four independent accumulators: the LDS gathers of a trip
     // are all in flight together and the add chains are short; state dwords are fetched one trip ahead
@@ -1074,12 +1081,12 @@ __global__ __launch_bounds__(kBlock) void k_mixture_combo(Mix2Params p) {
         b += v[1] + v[3];
     };
     double sum2 = 0.0, sum3 = 0.0;
-    uint32_t xa_next = load_state(0), xb_next = load_state(1);
+    uint32_t xa_next = next_state(), xb_next = next_state();
     int k = 0;
     for (; k + 1 < n_steps; k += 2) {
         const uint32_t xa = xa_next, xb = xb_next;
-        xa_next = load_state(k + 2);
-        xb_next = load_state(k + 3);
+        xa_next = next_state();
+        xb_next = next_state();
         gather4(xa, k, sum0, sum1);
         gather4(xb, k + 1, sum2, sum3);
     }
