@@ -335,11 +335,11 @@ struct MixGeom {
 
 // v2 geometry: chunks of object quads; one wave step = 64/ft quads.  The chunk's ids are staged
 // in LDS (8*C + 4 bytes per quad), which caps the chunk length.
-MixGeom mix_geometry_v2(const sbe_engine* e, int P, int n_batch) {
+MixGeom mix_geometry_v2(const sbe_engine* e, int P, int n_batch, int blocks_per_cu = 4) {
     MixGeom g{};
     g.ft = e->ft;
     g.n_ftiles = e->n_ftiles;
-    const int64_t target_blocks = (int64_t)4 * e->compute_units;
+    const int64_t target_blocks = (int64_t)blocks_per_cu * e->compute_units;
     int64_t chunks = std::max<int64_t>(1, target_blocks / ((int64_t)g.n_ftiles * std::max(1, n_batch)));
     const int min_quads = 4 * (kWave / e->ft);            // one step for each of the 4 waves
     const int max_quads = std::max(min_quads, (8 * 1024) / (8 * e->C + 4));
@@ -429,8 +429,43 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     const bool onehot = e->opt_kernel == SBE_MIXTURE_ONEHOT || e->opt_kernel == SBE_MIXTURE_ONEHOT_GENERAL;
     MixGeom g = mix_geometry_v2(e, P, n);
     if (!g.ft) return fail(e, SBE_ERR_ARG, "probability tables too large for LDS staging (G_total=%d, S=%d)", e->Gtot, e->S);
+    // group-tuple form: eligible when every slot of the launch has few distinct tuples, the log table fits
+    // LDS and a block sees enough observations to amortise building it.  It prefers long chunks (one block
+    // per CU is enough: the table build is per block), so it gets its own geometry.
+    int KT = 0;
+    const bool force_combo = e->opt_kernel == SBE_MIXTURE_PACKED_TUPLE;
+    bool combo = e->opt_kernel == SBE_MIXTURE_PACKED || e->opt_kernel == SBE_MIXTURE_ONEHOT || force_combo;
+    for (int sl = first_slot; sl < first_slot + n && combo; ++sl) {
+        if (e->slots[sl].n_tuples == 0) combo = false;
+        KT = std::max(KT, e->slots[sl].n_tuples);
+    }
+    size_t combo_lds = 0;
+    int combo_w_off = 0, combo_tab_off = 0;
+    if (combo) {
+        const MixGeom gc = mix_geometry_v2(e, P, n, 1);
+        // LDS image: T[KT][S+1][ft] f64 | tq[quads] u32 | tuple rows u16 | tuple patterns u32 | weights f64 [| byte table]
+        const int cu = e->C <= 4 ? e->C : kMaxComponents;
+        combo_lds = (size_t)KT * (e->S + 1) * gc.ft * sizeof(double) + (size_t)gc.objs_per_chunk * 4;
+        combo_lds += ((size_t)KT * cu + ((KT * cu) & 1)) * sizeof(uint16_t) + (size_t)KT * sizeof(uint32_t);
+        combo_lds = (combo_lds + 15) / 16 * 16;
+        combo_w_off = (int)combo_lds;
+        combo_lds += (size_t)P * e->C * gc.ft * sizeof(double);
+        if (onehot) {      // byte-position lookup table [seg16][32] u16; a tile row segment must fit one step
+            const int seg16 = gc.ft * e->S / 16;
+            if (seg16 > kBlock) combo = false;
+            combo_tab_off = (int)combo_lds;
+            combo_lds += (size_t)seg16 * 32 * sizeof(uint16_t);
+        }
+        const int64_t obs_per_block = (int64_t)gc.objs_per_chunk * 4 * gc.ft;
+        if (combo && !force_combo && (combo_lds > 40 * 1024 || obs_per_block < (int64_t)3 * KT * e->S * gc.ft)) combo = false;
+        if (force_combo && (!combo || combo_lds > 150 * 1024))
+            return fail(e, SBE_ERR_ARG, "group-tuple kernel forced but not applicable (tuples=%d, LDS %zu bytes)", KT, combo_lds);
+        if (combo) g = gc;
+    } else if (force_combo) {
+        return fail(e, SBE_ERR_ARG, "group-tuple kernel forced but not applicable (tuples=%d, LDS %zu bytes)", KT, combo_lds);
+    }
     if (g.n_blocks > e->partials_stride) return fail(e, SBE_ERR_STATE, "internal: partials buffer too small (%d > %lld)", g.n_blocks, (long long)e->partials_stride);
-    if (g.lds_bytes > 159 * 1024)
+    if (!combo && g.lds_bytes > 159 * 1024)
         return fail(e, SBE_ERR_ARG, "probability / weight tables too large for LDS staging at tile width %d (%zu bytes; G_total=%d, S=%d, P=%d)",
                     g.ft, g.lds_bytes, e->Gtot, e->S, P);
     dim3 grid(g.n_blocks, n);
@@ -458,32 +493,7 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
         p.tid = e->d_tid; p.tid_stride = e->Np;
         p.tuple_g = e->d_tuple_g; p.tuple_g_stride = (int64_t)kMaxTuples * kMaxComponents;
         p.tuple_p = e->d_tuple_p; p.tuple_p_stride = kMaxTuples;
-        // group-tuple form: eligible when every slot of the launch has few distinct tuples, the log
-        // table fits LDS and a block sees enough observations to amortise building it
-        int KT = 0;
-        const bool force_combo = e->opt_kernel == SBE_MIXTURE_PACKED_TUPLE;
-        bool combo = e->opt_kernel == SBE_MIXTURE_PACKED || e->opt_kernel == SBE_MIXTURE_ONEHOT || force_combo;
-        for (int sl = first_slot; sl < first_slot + n && combo; ++sl) {
-            if (e->slots[sl].n_tuples == 0) combo = false;
-            KT = std::max(KT, e->slots[sl].n_tuples);
-        }
-        // LDS image of the group-tuple kernel: T[KT][S+1][ft] f64 | tq[quads] u32 | tuple rows u16 | tuple patterns u32 | weights f64
-        const int cu = e->C <= 4 ? e->C : kMaxComponents;
-        size_t combo_lds = (size_t)KT * (e->S + 1) * g.ft * sizeof(double) + (size_t)g.objs_per_chunk * 4;
-        combo_lds += ((size_t)KT * cu + ((KT * cu) & 1)) * sizeof(uint16_t) + (size_t)KT * sizeof(uint32_t);
-        combo_lds = (combo_lds + 15) / 16 * 16;
-        p.combo_w_off = (int)combo_lds;
-        combo_lds += (size_t)P * e->C * g.ft * sizeof(double);
-        if (onehot) {      // byte-position lookup table [seg16][32] u16; a tile row segment must fit one step
-            const int seg16 = g.ft * e->S / 16;
-            if (seg16 > kBlock) combo = false;
-            p.combo_tab_off = (int)combo_lds;
-            combo_lds += (size_t)seg16 * 32 * sizeof(uint16_t);
-        }
-        const int64_t obs_per_block = (int64_t)g.objs_per_chunk * 4 * g.ft;
-        if (combo && !force_combo && (combo_lds > 40 * 1024 || obs_per_block < (int64_t)8 * KT * e->S * g.ft)) combo = false;
-        if (force_combo && (!combo || combo_lds > 150 * 1024))
-            return fail(e, SBE_ERR_ARG, "group-tuple kernel forced but not applicable (tuples=%d, LDS %zu bytes)", KT, combo_lds);
+        p.combo_w_off = combo_w_off; p.combo_tab_off = combo_tab_off;
         p.KT = KT;
         if (combo) {
             if (onehot) launch_combo<true>(g.ft, e->C, p, grid, combo_lds, e->stream);
