@@ -122,6 +122,9 @@ int sbe_set_group_ids(sbe_engine* e, int slot, int component, const int32_t* ids
 int sbe_set_source(sbe_engine* e, int slot, const uint8_t* source /* [N][F][C] bool */);
 int sbe_set_source_rows(sbe_engine* e, int slot, const int32_t* objects, int n_rows,
                         const uint8_t* rows /* [n_rows][F][C] bool */);
+/* read the listed objects' rows back (after sbe_sample_source wrote them on the device) */
+int sbe_get_source_rows(sbe_engine* e, int slot, const int32_t* objects, int n_rows,
+                        uint8_t* rows_out /* [n_rows][F][C] bool */);
 
 /* ---- a9: feature counts (sbayes/sampling/counts.py:10-95) ------------------------------
  * sbe_recount: recalculate_feature_counts (counts.py:35-52) for one component (or all: -1)
@@ -238,9 +241,28 @@ int sbe_cluster_marginals(sbe_engine* e, int slot, const float* table /* [F][S] 
  *     float32 likelihoods of the listed objects' observations under caller-built tables
  *     (`tables`: n_tables_total x [F][S]; component c uses rows table_offsets[c] + group_idx[c][i],
  *     -1 = object in no group -> 0), NA -> 1, then ** (1/T).  Stateless.
- * Drawing the new assignments (sample_categorical) stays with the caller's RNG. */
+ * sbe_sample_source: the draw of GibbsSampleSource._propose (operators.py:518-528) on the device:
+ *     p = the posterior above (or, from_prior != 0, normalize(w ** (1/T_prior)) in float32,
+ *     operators.py:520-522); sample_categorical (sbayes/preprocessing.py:224-256) with the CALLER's
+ *     uniforms z[i][f] (the reference draws np.random.random([n_sub, F, 1]): pass those numbers and
+ *     the assignments are the reference's, draw for draw): cdf = cumsum(p) / cdf[-1] in float32,
+ *     first component with z < cdf; NA observations get no source (operators.py:527).  The rows of
+ *     the listed objects are written into `dst_slot`'s source (rows of other objects keep what
+ *     dst_slot held: copy the slot first, sbe_copy_slot); counts are NOT touched -- follow with
+ *     sbe_update_counts(dst_slot, slot, objects).  *log_q_out = sum log p[new source] (operators.py:539;
+ *     fp64 logs and sum, the reference's are float32); p_selected_out (nullable) receives the selected
+ *     probabilities [n_sub][F] (1 for NA) so a caller can redo the sum in the reference's precision.
+ * sbe_source_logprob: log_q_back (operators.py:544-550): sum log p_slot[ source of src_slot ] over the
+ *     listed objects, p from `slot`'s current tables.
+ * The random numbers themselves stay with the caller's RNG (the engine holds no RNG state). */
 int sbe_source_posterior(sbe_engine* e, int slot, const int32_t* objects, int n_sub, double temperature,
                          double prior_temperature, float* out /* [n_sub][F][C] */);
+int sbe_sample_source(sbe_engine* e, int slot, int dst_slot, const int32_t* objects, int n_sub, double temperature,
+                      double prior_temperature, int from_prior, const double* z /* [n_sub][F] */,
+                      double* log_q_out, float* p_selected_out /* [n_sub][F] or NULL */);
+int sbe_source_logprob(sbe_engine* e, int slot, int src_slot, const int32_t* objects, int n_sub, double temperature,
+                       double prior_temperature, int from_prior, double* log_q_out,
+                       float* p_selected_out /* [n_sub][F] or NULL */);
 int sbe_subset_lh(sbe_engine* e, const int32_t* objects, int n_sub, int n_comp, const float* tables,
                   const int32_t* table_offsets /* [n_comp] */, int n_tables_total,
                   const int32_t* group_idx /* [n_comp][n_sub] */, double temperature,

@@ -384,6 +384,49 @@ def component_likelihood_given_unchanged(features, na_values, groups_by_componen
     return lik ** (1 / temperature)
 
 
+def sample_categorical(p, z):
+    """sbayes/preprocessing.py:224-256 with the uniforms `z` (shape p.shape[:-1]) passed in instead of
+    drawn from np.random: cumulative sums in p's dtype, divided by the last one, first category whose
+    cdf exceeds z (argmax of the bool row: 0 when none does)."""
+    cdf = np.cumsum(p, axis=-1)
+    cdf /= cdf[..., [-1]]
+    return np.argmax(np.asarray(z)[..., None] < cdf, axis=-1)
+
+
+def gibbs_source_propose(features, na_values, groups_by_component, counts_by_component,
+                         concentration_by_component, weights, source, objects, z, temperature=1.0,
+                         prior_temperature=1.0, sample_from_prior=False):
+    """GibbsSampleSource._propose (sbayes/sampling/operators.py:495-552) for the object indices
+    `objects` with the uniforms z [n_sub, F]: returns (new_source, log_q, log_q_back, new_counts).
+    p is float32, so are its logs and their sums (the reference returns np.float32 scalars)."""
+    objects = np.asarray(objects)
+    temperature, prior_temperature = float(temperature), float(prior_temperature)    # Python floats: weak promotion
+    n_comp = len(groups_by_component)
+    hc = has_components(groups_by_component)
+    w = normalize_weights(weights, hc)
+
+    def posterior(counts):
+        if sample_from_prior:                                   # operators.py:520-522
+            return normalize(w[objects] ** (1 / prior_temperature), axis=-1)
+        lh = likelihood_per_component(features, na_values, groups_by_component, counts, concentration_by_component)
+        return source_posterior(lh, w, objects, temperature, prior_temperature)
+
+    p = posterior(counts_by_component)
+    x = np.eye(n_comp, dtype=bool)[sample_categorical(p, z)]
+    x[na_values[objects]] = False                               # operators.py:527
+    new_source = source.copy()
+    new_source[objects] = x
+    mask = np.zeros(features.shape[0], dtype=bool)
+    mask[objects] = True
+    new_counts, _ = update_feature_counts(counts_by_component, features, groups_by_component, groups_by_component,
+                                          source, new_source, mask)
+    with np.errstate(divide="ignore"):
+        log_q = np.log(p[new_source[objects]]).sum()
+        p_back = p if sample_from_prior else posterior(new_counts)
+        log_q_back = np.log(p_back[source[objects]]).sum()
+    return new_source, log_q, log_q_back, new_counts
+
+
 # --------------------------------------------------------------------------------------
 # SURVEY.md 8(f) rank 4: SourcePrior.__call__ (sbayes/model/prior.py:573-611) and the
 # LikelihoodLogger row (sbayes/sampling/loggers.py:354-359)

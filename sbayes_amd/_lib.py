@@ -48,6 +48,7 @@ PROTOTYPES = {
     "sbe_set_group_ids": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
     "sbe_set_source": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
     "sbe_set_source_rows": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),
+    "sbe_get_source_rows": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_recount": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int]),
     "sbe_update_counts": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_accumulate_counts": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p]),
@@ -77,6 +78,10 @@ PROTOTYPES = {
                                          ct.c_void_p]),
     "sbe_source_posterior": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double,
                                         ct.c_void_p]),
+    "sbe_sample_source": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double,
+                                     ct.c_int, ct.c_void_p, ct.POINTER(ct.c_double), ct.c_void_p]),
+    "sbe_source_logprob": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double,
+                                      ct.c_int, ct.POINTER(ct.c_double), ct.c_void_p]),
     "sbe_subset_lh": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int,
                                  ct.c_void_p, ct.c_double, ct.c_void_p]),
     "sbe_source_prior": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),

@@ -442,7 +442,7 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     size_t combo_lds = 0;
     int combo_w_off = 0, combo_tab_off = 0;
     if (combo) {
-        const MixGeom gc = mix_geometry_v2(e, P, n, 1);
+        const MixGeom gc = mix_geometry_v2(e, P, n, 2);
         // LDS image: T[KT][S+1][ft] f64 | tq[quads] u32 | tuple rows u16 | tuple patterns u32 | weights f64 [| byte table]
         const int cu = e->C <= 4 ? e->C : kMaxComponents;
         combo_lds = (size_t)KT * (e->S + 1) * gc.ft * sizeof(double) + (size_t)gc.objs_per_chunk * 4;
@@ -634,6 +634,7 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
             ft = 16;                 // very many groups x states: no LDS staging of tables (L2-served gathers)
             e->direct = true;
         }
+        if (getenv("SBE_DIRECT") && atoi(getenv("SBE_DIRECT")) == 1) { ft = 16; e->direct = true; }   // experiments / tests
         e->ft = ft;
         e->n_ftiles = div_up(n_features, ft);
         e->Fq = e->n_ftiles * ft;
@@ -910,6 +911,27 @@ int sbe_set_source_rows(sbe_engine* e, int slot, const int32_t* objects, int n_r
         e->d_scratch, d_obj, e->d_src + (int64_t)slot * e->N * e->Fp, n_rows, e->F, e->C, e->Fp, e->d_status);
     HIPCHK(e, hipGetLastError());
     return check_after(e);
+}
+
+int sbe_get_source_rows(sbe_engine* e, int slot, const int32_t* objects, int n_rows, uint8_t* rows_out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot);
+    if (n_rows == 0) return SBE_OK;
+    CHECK_PTR(e, objects); CHECK_PTR(e, rows_out);
+    if (n_rows < 0) return fail(e, SBE_ERR_ARG, "n_rows=%d", n_rows);
+    if (!e->slots[slot].source_set) return fail(e, SBE_ERR_STATE, "slot %d: source not set", slot);
+    for (int i = 0; i < n_rows; ++i)
+        if (objects[i] < 0 || objects[i] >= e->N) return fail(e, SBE_ERR_ARG, "object index %d out of range", objects[i]);
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t row_bytes = (size_t)n_rows * e->F * e->C;
+    const size_t row_pad = (row_bytes + 255) / 256 * 256;
+    int rc = ensure_scratch(e, row_pad + (size_t)n_rows * sizeof(int32_t));
+    if (rc) return rc;
+    int32_t* d_obj = (int32_t*)(e->d_scratch + row_pad);
+    { int _urc = upload(e, d_obj, objects, (size_t)n_rows * sizeof(int32_t)); if (_urc) return _urc; }
+    k_expand_source<<<div_up((int64_t)n_rows * e->F, 256), 256, 0, e->stream>>>(
+        e->d_src + (int64_t)slot * e->N * e->Fp, d_obj, e->d_scratch, n_rows, e->F, e->C, e->Fp);
+    HIPCHK(e, hipGetLastError());
+    return d2h(e, rows_out, e->d_scratch, row_bytes);
 }
 
 // ---- counts -----------------------------------------------------------------------------------
@@ -1393,9 +1415,13 @@ int sbe_cluster_marginals(sbe_engine* e, int slot, const float* table, const int
 }
 
 // ---- data-parallel cores of Gibbs source resampling ---------------------------
-int sbe_source_posterior(sbe_engine* e, int slot, const int32_t* objects, int n_sub, double temperature,
-                         double prior_temperature, float* out) {
-    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, out);
+namespace {
+
+// Shared front end of the source-posterior family: argument checks, object upload, kernel arguments.
+// Scratch layout: [objects | extra bytes requested by the caller].
+int source_posterior_setup(sbe_engine* e, int slot, const int32_t* objects, int n_sub, double temperature,
+                           double prior_temperature, int from_prior, size_t extra_bytes, SrcPostArgs* a,
+                           uint8_t** d_extra) {
     if (n_sub < 0) return fail(e, SBE_ERR_ARG, "n_sub=%d", n_sub);
     if (n_sub == 0) return SBE_OK;
     CHECK_PTR(e, objects);
@@ -1406,28 +1432,97 @@ int sbe_source_posterior(sbe_engine* e, int slot, const int32_t* objects, int n_
     if (rc) return rc;
     HIPCHK(e, hipSetDevice(e->device));
     if (e->slots[slot].patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
-    const int64_t n_out = (int64_t)n_sub * e->F * e->C;
     const size_t ob = ((size_t)n_sub * sizeof(int32_t) + 255) / 256 * 256;
-    rc = ensure_scratch(e, ob + (size_t)n_out * sizeof(float));
+    rc = ensure_scratch(e, ob + extra_bytes);
     if (rc) return rc;
     int32_t* d_obj = (int32_t*)e->d_scratch;
-    float* d_out = (float*)(e->d_scratch + ob);
+    *d_extra = e->d_scratch + ob;
     { int _urc = upload(e, d_obj, objects, (size_t)n_sub * sizeof(int32_t)); if (_urc) return _urc; }
     rc = clear_status_word(e, ST_BAD_NORMALIZE);
     if (rc) return rc;
     const double inv_t = 1.0 / temperature, inv_tp = 1.0 / prior_temperature;
-    k_source_posterior<<<div_up((int64_t)n_sub * e->F, 256), 256, 0, e->stream>>>(
-        e->d_state, e->d_gid + (int64_t)slot * e->C * e->Np, e->d_pid + (int64_t)slot * e->Np,
-        e->d_probs + (int64_t)slot * e->table_elems(), e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C,
-        d_obj, n_sub, d_out, e->Np, e->F, e->S, e->C, e->Fp, inv_t, (float)inv_tp, inv_t != 1.0, inv_tp != 1.0, e->d_status);
-    HIPCHK(e, hipGetLastError());
-    rc = d2h(e, out, d_out, (size_t)n_out * sizeof(float));
-    if (rc) return rc;
-    rc = read_status(e);
+    *a = SrcPostArgs{e->d_state, e->d_gid + (int64_t)slot * e->C * e->Np, e->d_pid + (int64_t)slot * e->Np,
+                     e->d_probs + (int64_t)slot * e->table_elems(), e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C,
+                     d_obj, n_sub, e->Np, e->F, e->S, e->C, e->Fp, inv_t, (float)inv_tp, inv_t != 1.0, inv_tp != 1.0,
+                     from_prior != 0};
+    return SBE_OK;
+}
+
+int source_posterior_status(sbe_engine* e) {
+    int rc = read_status(e);
     if (rc) return rc;
     if (e->h_status[ST_BAD_NORMALIZE])
         return fail(e, SBE_ERR_DATA, "normalize: %d observations have a non-positive posterior sum (sbayes/util.py:1006 assert)", e->h_status[ST_BAD_NORMALIZE]);
     return SBE_OK;
+}
+
+// log_q = sum_i log(p_sel[i]) (fp64, fixed order) -> *out; optionally the selected probabilities themselves.
+int finish_log_q(sbe_engine* e, const float* d_psel, int64_t n, double* d_partials, double* log_q_out, float* p_selected_out) {
+    const int nb = (int)std::min<int64_t>(div_up(n, 4 * kBlock), 256);
+    k_sum_log_f32<<<nb, kBlock, 0, e->stream>>>(d_psel, n, d_partials);
+    HIPCHK(e, hipGetLastError());
+    k_reduce_partials<<<1, kBlock, 0, e->stream>>>(d_partials, 0, nb, d_partials + 256, 0);
+    HIPCHK(e, hipGetLastError());
+    int rc = d2h(e, log_q_out, d_partials + 256, sizeof(double));
+    if (rc) return rc;
+    if (p_selected_out) { rc = d2h(e, p_selected_out, d_psel, (size_t)n * sizeof(float)); if (rc) return rc; }
+    return source_posterior_status(e);
+}
+
+}  // namespace
+
+int sbe_source_posterior(sbe_engine* e, int slot, const int32_t* objects, int n_sub, double temperature,
+                         double prior_temperature, float* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, out);
+    const int64_t n_out = (int64_t)std::max(n_sub, 0) * e->F * e->C;
+    SrcPostArgs a; uint8_t* d_extra = nullptr;
+    int rc = source_posterior_setup(e, slot, objects, n_sub, temperature, prior_temperature, 0, (size_t)n_out * sizeof(float), &a, &d_extra);
+    if (rc || n_sub == 0) return rc;
+    float* d_out = (float*)d_extra;
+    k_source_posterior<<<div_up((int64_t)n_sub * e->F, 256), 256, 0, e->stream>>>(a, d_out, e->d_status);
+    HIPCHK(e, hipGetLastError());
+    rc = d2h(e, out, d_out, (size_t)n_out * sizeof(float));
+    if (rc) return rc;
+    return source_posterior_status(e);
+}
+
+int sbe_sample_source(sbe_engine* e, int slot, int dst_slot, const int32_t* objects, int n_sub, double temperature,
+                      double prior_temperature, int from_prior, const double* z, double* log_q_out,
+                      float* p_selected_out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_SLOT(e, dst_slot); CHECK_PTR(e, log_q_out);
+    if (!e->slots[dst_slot].source_set) return fail(e, SBE_ERR_STATE, "slot %d: source not set (rows outside the subset would be undefined)", dst_slot);
+    if (n_sub == 0) { *log_q_out = 0.0; return SBE_OK; }
+    if (n_sub > 0) CHECK_PTR(e, z);
+    const int64_t n_obs = (int64_t)std::max(n_sub, 0) * e->F;
+    const size_t zb = ((size_t)n_obs * sizeof(double) + 255) / 256 * 256;
+    const size_t pb = ((size_t)n_obs * sizeof(float) + 255) / 256 * 256;
+    SrcPostArgs a; uint8_t* d_extra = nullptr;
+    int rc = source_posterior_setup(e, slot, objects, n_sub, temperature, prior_temperature, from_prior, zb + pb + 257 * sizeof(double), &a, &d_extra);
+    if (rc) return rc;
+    double* d_z = (double*)d_extra;
+    float* d_psel = (float*)(d_extra + zb);
+    double* d_partials = (double*)(d_extra + zb + pb);
+    { int _urc = upload(e, d_z, z, (size_t)n_obs * sizeof(double)); if (_urc) return _urc; }
+    k_sample_source<<<div_up(n_obs, 256), 256, 0, e->stream>>>(a, d_z, e->d_src + (int64_t)dst_slot * e->N * e->Fp, d_psel, e->d_status);
+    HIPCHK(e, hipGetLastError());
+    return finish_log_q(e, d_psel, n_obs, d_partials, log_q_out, p_selected_out);
+}
+
+int sbe_source_logprob(sbe_engine* e, int slot, int src_slot, const int32_t* objects, int n_sub, double temperature,
+                       double prior_temperature, int from_prior, double* log_q_out, float* p_selected_out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_SLOT(e, src_slot); CHECK_PTR(e, log_q_out);
+    if (!e->slots[src_slot].source_set) return fail(e, SBE_ERR_STATE, "slot %d: source not set", src_slot);
+    if (n_sub == 0) { *log_q_out = 0.0; return SBE_OK; }
+    const int64_t n_obs = (int64_t)std::max(n_sub, 0) * e->F;
+    const size_t pb = ((size_t)n_obs * sizeof(float) + 255) / 256 * 256;
+    SrcPostArgs a; uint8_t* d_extra = nullptr;
+    int rc = source_posterior_setup(e, slot, objects, n_sub, temperature, prior_temperature, from_prior, pb + 257 * sizeof(double), &a, &d_extra);
+    if (rc) return rc;
+    float* d_psel = (float*)d_extra;
+    double* d_partials = (double*)(d_extra + pb);
+    k_source_logprob<<<div_up(n_obs, 256), 256, 0, e->stream>>>(a, e->d_src + (int64_t)src_slot * e->N * e->Fp, d_psel, e->d_status);
+    HIPCHK(e, hipGetLastError());
+    return finish_log_q(e, d_psel, n_obs, d_partials, log_q_out, p_selected_out);
 }
 
 int sbe_subset_lh(sbe_engine* e, const int32_t* objects, int n_sub, int n_comp, const float* tables,

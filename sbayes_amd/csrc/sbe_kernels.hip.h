@@ -195,6 +195,17 @@ __global__ void k_ingest_source(const uint8_t* __restrict__ rows, const int32_t*
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(&status[ST_MULTI_SOURCE], m);
 }
 
+// Inverse of K0b for the listed objects: component id -> bool row [F][C] (all False for 0xFF).
+__global__ void k_expand_source(const uint8_t* __restrict__ src_id, const int32_t* __restrict__ objects,
+                                uint8_t* __restrict__ rows, int n_rows, int F, int C, int Fp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_rows * F) return;
+    const int r = (int)(i / F), f = (int)(i % F);
+    const int id = src_id[(int64_t)objects[r] * Fp + f];
+    uint8_t* p = rows + i * C;
+    for (int c = 0; c < C; ++c) p[c] = c == id;
+}
+
 // ------------------------------------------------------------------------------------------
 // a9: feature counts (counts.py:10-52, 55-95).
 // counts[gg][f][s] (int32, gg = global group index over all components) accumulates
@@ -1225,31 +1236,102 @@ __global__ __launch_bounds__(kBlock) void k_cluster_marginals(
 // GibbsSampleSource.calculate_source_posterior (operators.py:554-574): for the listed objects
 //   p[i][f][:] = normalize( lh[n_i][f][:] ** (1/T) * w[n_i][f][:] ** (1/T_prior) )  -> float32
 // lh as in likelihood_per_component (NA -> 1, no group -> 0), w = normalised weights of the slot.
-__global__ void k_source_posterior(const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid,
-                                   const uint8_t* __restrict__ pid, const float* __restrict__ probs,
-                                   const float* __restrict__ wpat, const int32_t* __restrict__ objects, int n_sub,
-                                   float* __restrict__ out, int Np, int F, int S, int C, int Fp, double inv_t,
-                                   float inv_tp, int pow_lh, int pow_w, int* __restrict__ status) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)n_sub * F) return;
-    const int r = (int)(i / F), f = (int)(i % F);
-    const int n = objects[r];
-    const uint8_t x = state[(int64_t)n * Fp + f];
-    const float* w = wpat + ((int64_t)pid[n] * F + f) * C;
+struct SrcPostArgs {
+    const uint8_t* state; const uint16_t* gid; const uint8_t* pid; const float* probs; const float* wpat;
+    const int32_t* objects; int n_sub, Np, F, S, C, Fp;
+    double inv_t; float inv_tp; int pow_lh, pow_w, from_prior;
+};
+
+// One observation's posterior row p[0..C) (float32).  from_prior (operators.py:520-522): p =
+// normalize(w ** (1/T_prior)) entirely in float32, the likelihood plays no part.
+__device__ inline bool source_posterior_row(const SrcPostArgs& a, int n, int f, float* p) {
+    const uint8_t x = a.state[(int64_t)n * a.Fp + f];
+    const float* w = a.wpat + ((int64_t)a.pid[n] * a.F + f) * a.C;
+    if (a.from_prior) {
+        auto term = [&](int c) -> float { return a.pow_w ? powf(w[c], a.inv_tp) : w[c]; };
+        const float total = np_pairwise_sum<float>(term, a.C);
+        for (int c = 0; c < a.C; ++c) p[c] = term(c) / total;
+        return total > 0.0f;
+    }
     auto term = [&](int c) -> double {
         double lh = 1.0;
         if (x != kNA) {
-            const uint16_t gg = gid[(int64_t)c * Np + n];
-            lh = gg == kNoGroup ? 0.0 : (double)probs[((int64_t)gg * F + f) * S + x];
+            const uint16_t gg = a.gid[(int64_t)c * a.Np + n];
+            lh = gg == kNoGroup ? 0.0 : (double)a.probs[((int64_t)gg * a.F + f) * a.S + x];
         }
-        if (pow_lh) lh = pow(lh, inv_t);
-        const float wc = pow_w ? powf(w[c], inv_tp) : w[c];
+        if (a.pow_lh) lh = pow(lh, a.inv_t);
+        const float wc = a.pow_w ? powf(w[c], a.inv_tp) : w[c];
         return lh * (double)wc;
     };
-    const double total = np_pairwise_sum<double>(term, C);
-    if (!(total > 0.0)) atomicAdd(&status[ST_BAD_NORMALIZE], 1);
-    float* o = out + i * C;
-    for (int c = 0; c < C; ++c) o[c] = (float)(term(c) / total);
+    const double total = np_pairwise_sum<double>(term, a.C);
+    for (int c = 0; c < a.C; ++c) p[c] = (float)(term(c) / total);
+    return total > 0.0;
+}
+
+__global__ void k_source_posterior(SrcPostArgs a, float* __restrict__ out, int* __restrict__ status) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)a.n_sub * a.F) return;
+    const int r = (int)(i / a.F), f = (int)(i % a.F);
+    float p[kMaxComponents];
+    if (!source_posterior_row(a, a.objects[r], f, p)) atomicAdd(&status[ST_BAD_NORMALIZE], 1);
+    float* o = out + i * a.C;
+    for (int c = 0; c < a.C; ++c) o[c] = p[c];
+}
+
+// GibbsSampleSource._propose (operators.py:495-552), the draw: sample_categorical
+// (preprocessing.py:224-256) on the posterior row with the caller's uniform z[r][f] --
+//   cdf = cumsum(p) (float32, sequential), cdf /= cdf[-1], k = first c with z < cdf[c] (0 if none)
+// -- writes component k (0xFF for NA observations, operators.py:527) into the destination slot's
+// source and keeps p[k] (1 for NA) for the transition log-probability log_q = sum log p[k].
+__global__ void k_sample_source(SrcPostArgs a, const double* __restrict__ z, uint8_t* __restrict__ src_dst,
+                                float* __restrict__ p_sel, int* __restrict__ status) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)a.n_sub * a.F) return;
+    const int r = (int)(i / a.F), f = (int)(i % a.F);
+    const int n = a.objects[r];
+    float p[kMaxComponents];
+    if (!source_posterior_row(a, n, f, p)) atomicAdd(&status[ST_BAD_NORMALIZE], 1);
+    float cdf[kMaxComponents];
+    float run = p[0];
+    cdf[0] = run;
+    for (int c = 1; c < a.C; ++c) { run = run + p[c]; cdf[c] = run; }
+    const float last = cdf[a.C - 1];
+    const double zz = z[i];
+    int k = 0;
+    for (int c = a.C - 1; c >= 0; --c)
+        if (zz < (double)(cdf[c] / last)) k = c;
+    const bool na = a.state[(int64_t)n * a.Fp + f] == kNA;
+    src_dst[(int64_t)n * a.Fp + f] = na ? (uint8_t)kNA : (uint8_t)k;
+    float sel = 1.0f;
+    for (int c = 0; c < a.C; ++c) sel = (!na && c == k) ? p[c] : sel;
+    p_sel[i] = sel;
+}
+
+// log_q_back (operators.py:544-550): p of `a`'s state evaluated at ANOTHER slot's source assignment.
+__global__ void k_source_logprob(SrcPostArgs a, const uint8_t* __restrict__ src, float* __restrict__ p_sel,
+                                 int* __restrict__ status) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)a.n_sub * a.F) return;
+    const int r = (int)(i / a.F), f = (int)(i % a.F);
+    const int n = a.objects[r];
+    float p[kMaxComponents];
+    if (!source_posterior_row(a, n, f, p)) atomicAdd(&status[ST_BAD_NORMALIZE], 1);
+    const int id = src[(int64_t)n * a.Fp + f];
+    float sel = 1.0f;
+    for (int c = 0; c < a.C; ++c) sel = (c == id) ? p[c] : sel;
+    p_sel[i] = sel;
+}
+
+// partials[b] = sum of log(v[i]) over block b's grid-stride share (fp64 logs, fixed order);
+// k_reduce_partials finishes.
+__global__ __launch_bounds__(kBlock) void k_sum_log_f32(const float* __restrict__ v, int64_t n,
+                                                       double* __restrict__ partials) {
+    __shared__ double red4[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        acc += log((double)v[i]);
+    const double total = block_sum(acc, red4);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total;
 }
 
 // component_likelihood_given_unchanged (operators.py:863-928), gather part: float32 likelihood of

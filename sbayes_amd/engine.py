@@ -172,6 +172,13 @@ class Engine:
         rows = _c(rows.astype(bool, copy=False), np.uint8)
         self._check(self._lib.sbe_set_source_rows(self._h, slot, _ptr(objects), objects.size, _ptr(rows)))
 
+    def get_source_rows(self, slot, objects):
+        """bool [n, F, C]: the listed objects' rows of the slot's source."""
+        objects = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        rows = np.empty((objects.size, self.n_features, self.n_components), dtype=np.uint8)
+        self._check(self._lib.sbe_get_source_rows(self._h, slot, _ptr(objects), objects.size, _ptr(rows)))
+        return rows.view(bool)
+
     def recount(self, slot, component=-1):
         self._check(self._lib.sbe_recount(self._h, slot, component))
 
@@ -388,6 +395,35 @@ class Engine:
         self._check(self._lib.sbe_source_posterior(self._h, slot, _ptr(objs), objs.size, float(temperature),
                                                    float(prior_temperature), _ptr(out)))
         return out
+
+    def sample_source(self, slot, dst_slot, objects, z, temperature=1.0, prior_temperature=1.0, from_prior=False,
+                      return_selected=False):
+        """Draw new source assignments for the listed objects on the device (GibbsSampleSource._propose,
+        operators.py:518-528, with sample_categorical's uniforms `z` [n, F] supplied by the caller) and
+        write them into `dst_slot`'s source.  Returns log_q (float), or (log_q, p_selected float32
+        [n, F]) with return_selected."""
+        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        zz = _c(z, np.float64).reshape(objs.size, -1)
+        if zz.shape != (objs.size, self.n_features):
+            raise ValueError(f"z must be [{objs.size}, {self.n_features}]")
+        sel = np.empty((objs.size, self.n_features), dtype=np.float32) if return_selected else None
+        log_q = ct.c_double()
+        self._check(self._lib.sbe_sample_source(self._h, slot, dst_slot, _ptr(objs), objs.size, float(temperature),
+                                                float(prior_temperature), int(bool(from_prior)), _ptr(zz),
+                                                ct.byref(log_q), _ptr(sel) if return_selected else None))
+        return (log_q.value, sel) if return_selected else log_q.value
+
+    def source_logprob(self, slot, src_slot, objects, temperature=1.0, prior_temperature=1.0, from_prior=False,
+                       return_selected=False):
+        """sum log p_slot[source of src_slot] over the listed objects' observations (log_q_back,
+        operators.py:544-550)."""
+        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        sel = np.empty((objs.size, self.n_features), dtype=np.float32) if return_selected else None
+        log_q = ct.c_double()
+        self._check(self._lib.sbe_source_logprob(self._h, slot, src_slot, _ptr(objs), objs.size, float(temperature),
+                                                 float(prior_temperature), int(bool(from_prior)), ct.byref(log_q),
+                                                 _ptr(sel) if return_selected else None))
+        return (log_q.value, sel) if return_selected else log_q.value
 
     def subset_lh(self, objects, tables, group_idx, temperature=1.0):
         """float32 [n, F, C]: likelihood of the listed objects' observations under per-component tables

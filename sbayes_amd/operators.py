@@ -1,8 +1,11 @@
-"""Data-parallel cores of the reference's cluster operators on the engine.
+"""Data-parallel cores of the reference's operators on the engine.
 
   compute_cluster_posterior   AlterCluster.compute_cluster_posterior      operators.py:1035-1073
   compute_raw_cluster_probs   AlterClusterWide.compute_raw_cluster_probs  operators.py:1420-1472
                               (with the `gibbs` cluster-effect proposal,   operators.py:1254-1282)
+  calculate_source_posterior  GibbsSampleSource.calculate_source_posterior operators.py:554-574
+  gibbs_sample_source         GibbsSampleSource._propose                   operators.py:495-552
+  component_likelihood_given_unchanged                                     operators.py:863-928
 
 The proposal logic, RNG and accept/reject stay the reference's (out of scope); these functions
 return exactly what the reference methods return, so an operator can call them in place of its
@@ -80,6 +83,52 @@ def calculate_source_posterior(model, sample, object_subset, temperature=1.0, pr
         if objects.dtype == np.bool_:
             objects = np.flatnonzero(objects)
     return eng.source_posterior(slot, objects, temperature, prior_temperature)
+
+
+def gibbs_sample_source(model, sample, object_subset=slice(None), temperature=1.0, prior_temperature=1.0,
+                        sample_from_prior=False, z=None, slots=(0, 1)):
+    """GibbsSampleSource._propose (operators.py:495-552) on the device: posterior, draw, new source rows,
+    delta counts, new tables and both transition log-probabilities never leave the GPU; what crosses
+    PCIe is the uniforms in and [n, F] selected probabilities + the subset's new rows out.
+
+    The uniforms are drawn exactly where the reference draws them -- np.random.random([n, F, 1]) inside
+    sample_categorical (preprocessing.py:248) -- so with the same np.random state the proposal is the
+    reference's, draw for draw; pass `z` [n, F] to supply them.  log_q / log_q_back are summed on the
+    host from the selected float32 probabilities, in the reference's float32 precision.
+    Returns (sample_new, log_q, log_q_back) like the reference."""
+    eng = _engine(model)
+    cur, new = slots
+    _bind_slot(eng, model, sample, cur, with_source=True)
+    for c in range(eng.n_components):
+        eng.update_probs(cur, c)
+    n_objects = sample.n_objects
+    if isinstance(object_subset, slice):
+        objects = np.arange(n_objects)[object_subset]
+    else:
+        objects = np.asarray(object_subset)
+        if objects.dtype == np.bool_:
+            objects = np.flatnonzero(objects)
+    if z is None:
+        z = np.random.random([objects.size, eng.n_features, 1])
+    z = np.asarray(z, dtype=np.float64).reshape(objects.size, eng.n_features)
+    eng.copy_slot(new, cur)
+    _, sel = eng.sample_source(cur, new, objects, z, temperature, prior_temperature, sample_from_prior,
+                               return_selected=True)
+    eng.update_counts(new, cur, objects)
+    for c in range(eng.n_components):
+        eng.update_probs(new, c)
+    _, sel_back = eng.source_logprob(new, cur, objects, temperature, prior_temperature, sample_from_prior,
+                                     return_selected=True)
+    valid = ~eng.na_values()[objects]
+    with np.errstate(divide="ignore"):
+        log_q = np.log(sel[valid]).sum()
+        log_q_back = np.log(sel_back[valid]).sum()
+
+    sample_new = sample.copy()
+    sample_new.source.set_groups(object_subset, eng.get_source_rows(new, objects))
+    for c, name in enumerate(sample.component_names):
+        sample_new.feature_counts[name].add_changes(diff=eng.get_counts(new, c) - eng.get_counts(cur, c))
+    return sample_new, log_q, log_q_back
 
 
 def component_likelihood_given_unchanged(model, sample, object_subset, i_cluster, temperature=1.0,

@@ -19,6 +19,8 @@ Fixtures
   test_files.npz      test/test_files (5 objects x 2 features): tensors + outputs
   test_files_trace.npz  300 MCMC steps on it
   known_answers.json  hand-derivable cases from the reference's commented-out test
+  gibbs_source.npz    GibbsSampleSource._propose on south_america with pinned subsets and uniforms
+                      (python tests/golden/make_golden.py gibbs_source regenerates only this one)
 """
 from __future__ import annotations
 
@@ -547,8 +549,74 @@ def state_fixture():
     print(f"[golden] state_versions.json ({len(log)} snapshots)")
 
 
+def gibbs_source_fixture():
+    """SURVEY.md 8(f) rank 3, the whole operator: GibbsSampleSource._propose (operators.py:495-552) on
+    the south_america data with a pinned object subset and a pinned np.random stream.  The uniforms `z`
+    that sample_categorical (preprocessing.py:224-256) draws are stored, so the device sampler can be
+    checked draw for draw: new source rows, log_q, log_q_back and the updated counts."""
+    from sbayes.experiment_setup import Experiment
+    from sbayes.sampling.initializers import SbayesInitializer
+    from sbayes.sampling.operators import get_operator_schedule
+
+    cfg = stage_config(Path("/root/reference/experiments/south_america"), "south_america_gs") / "config.yaml"
+    np.random.seed(77)
+    random.seed(77)
+    cwd = os.getcwd()
+    os.chdir(cfg.parent)
+    try:
+        experiment = Experiment(config_file=cfg, experiment_name="golden_gs", log=False)
+        data = Data.from_config(experiment.config)
+        model = Model(data, experiment.config.model)
+        mcmc_cfg = experiment.config.mcmc
+        init = SbayesInitializer(model=model, data=data, initial_size=mcmc_cfg.initialization.objects_per_cluster,
+                                 attempts=mcmc_cfg.initialization.attempts,
+                                 initial_cluster_steps=mcmc_cfg.initialization._initial_cluster_steps)
+        sample = init.generate_sample(c=0)
+        recalculate_feature_counts(data.features.values, sample)
+        scal, arrs, dig = reference_outputs(model, sample, full=True)
+        names = sample.component_names
+        n, F = sample.n_objects, data.features.values.shape[1]
+        rng = np.random.default_rng(3)
+        some = np.zeros(n, dtype=bool)
+        some[rng.choice(n, size=max(2, n // 4), replace=False)] = True
+        cases = {"all": (slice(None), 1.0, 1.0, False), "subset": (some, 1.0, 1.0, False),
+                 "mc3": (some, 1.3, 1.5, False), "prior": (some, 1.0, 1.5, True)}
+        extra = {}
+        for i_case, (tag, (subset, temp, ptemp, from_prior)) in enumerate(cases.items()):
+            ops = get_operator_schedule(mcmc_cfg.operators, model, data, temperature=temp, prior_temperature=ptemp,
+                                        sample_from_prior=from_prior)
+            op = ops["gibbs_sample_sources"]
+            op.select_object_subset = lambda s, _subset=subset: _subset
+            seed = 1000 + i_case
+            np.random.seed(seed)
+            new, log_q, log_q_back = op._propose(sample)
+            idx = np.arange(n)[subset]
+            np.random.seed(seed)
+            z = np.random.random([idx.size, F, 1])
+            extra[f"gs_{tag}_objects"] = idx.astype(np.int32)
+            extra[f"gs_{tag}_z"] = z[..., 0]
+            extra[f"gs_{tag}_temps"] = np.array([temp, ptemp, float(from_prior)])
+            extra[f"gs_{tag}_new_source"] = new.source.value.copy()
+            extra[f"gs_{tag}_log_q"] = np.float64(log_q)
+            extra[f"gs_{tag}_log_q_back"] = np.float64(log_q_back)
+            for i, k in enumerate(names):
+                extra[f"gs_{tag}_counts_{i}"] = new.feature_counts[k].value.copy()
+            print(f"[golden] gibbs_source {tag}: n={idx.size} log_q={log_q!r} log_q_back={log_q_back!r} "
+                  f"changed={int(np.count_nonzero(new.source.value ^ sample.source.value))}")
+        meta = dict(name="gibbs_source", shape=list(data.features.values.shape), component_names=names,
+                    groups=[int(sample.n_groups(k)) for k in names], cases=list(cases), **scal, **dig)
+        np.savez_compressed(HERE / "gibbs_source.npz", features=data.features.values,
+                            states_per_feature=data.features.states, weights=sample.weights.value,
+                            source=sample.source.value, meta=json.dumps(meta), **arrs, **extra)
+    finally:
+        os.chdir(cwd)
+
+
 def main():
     WORK.mkdir(parents=True, exist_ok=True)
+    if sys.argv[1:] == ["gibbs_source"]:            # one fixture only (the others stay untouched)
+        gibbs_source_fixture()
+        return
     known_answers()
     state_fixture()
     synthetic_fixture("cfg1", full=True)
@@ -558,6 +626,7 @@ def main():
     real_fixture("south_america", sa / "config.yaml", n_trace_steps=400, seed=123)
     tf = stage_config(Path("/root/reference/test/test_files"), "test_files")
     real_fixture("test_files", tf / "config.yaml", n_trace_steps=300, seed=321)
+    gibbs_source_fixture()
 
 
 if __name__ == "__main__":

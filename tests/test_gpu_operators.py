@@ -126,3 +126,77 @@ def test_source_prior_and_logger_row(name):
     row = observation_likelihoods(model, sample, exact=True).ravel()
     assert np.array_equal(row, orc.logger_row(z["weights_normalized"], z["lh_exact"]))
     assert np.array_equal(row.astype(np.float32), z["logger_row_f32"])
+
+
+def _gibbs_fixture():
+    fx = load_npz("gibbs_source")
+    model, sample = sbm.build(fx.features, fx.states_per_feature, fx.meta["component_names"], fx.groups, fx.conc,
+                              fx.weights, fx.source, counts=fx.counts)
+    return fx, model, sample
+
+
+@pytest.mark.parametrize("tag", ["all", "subset", "mc3", "prior"])
+def test_gibbs_source_proposal_draw_for_draw(tag):
+    """SURVEY.md 8(f) rank 3, the whole operator: GibbsSampleSource._propose with the reference's own
+    uniforms -> the reference's new source rows, counts and (float32) log_q / log_q_back.  At
+    temperature 1 everything is bit-exact; the tempered cases carry the float32 powf tolerance in the
+    probabilities (the draws still agree: no uniform of the fixture sits within 1e-6 of a cdf step)."""
+    from sbayes_amd.operators import gibbs_sample_source
+    fx, model, sample = _gibbs_fixture()
+    z = fx.z
+    objects = z[f"gs_{tag}_objects"]
+    temp, ptemp, from_prior = z[f"gs_{tag}_temps"]
+    new, log_q, log_q_back = gibbs_sample_source(model, sample, objects, float(temp), float(ptemp), bool(from_prior),
+                                                 z=z[f"gs_{tag}_z"])
+    assert np.array_equal(new.source.value, z[f"gs_{tag}_new_source"])
+    for c, name in enumerate(sample.component_names):
+        assert np.array_equal(new.feature_counts[name].value, z[f"gs_{tag}_counts_{c}"])
+    assert log_q.dtype == np.float32 and log_q_back.dtype == np.float32
+    if temp == 1.0 and ptemp == 1.0:
+        assert log_q == z[f"gs_{tag}_log_q"] and log_q_back == z[f"gs_{tag}_log_q_back"]
+    else:
+        assert abs(log_q - z[f"gs_{tag}_log_q"]) <= 2e-6 * abs(z[f"gs_{tag}_log_q"])
+        assert abs(log_q_back - z[f"gs_{tag}_log_q_back"]) <= 2e-6 * abs(z[f"gs_{tag}_log_q_back"])
+    # untouched objects keep their rows; the old sample is not modified
+    others = np.setdiff1d(np.arange(sample.n_objects), objects)
+    assert np.array_equal(new.source.value[others], fx.source[others])
+    assert np.array_equal(sample.source.value, fx.source)
+
+
+def test_gibbs_source_same_global_rng_stream_as_reference():
+    """Without explicit uniforms the operator draws np.random.random([n, F, 1]) like sample_categorical
+    does: seeding np.random as the fixture did reproduces the recorded proposal."""
+    from sbayes_amd.operators import gibbs_sample_source
+    fx, model, sample = _gibbs_fixture()
+    z = fx.z
+    np.random.seed(1001)                                   # the seed the "subset" case was recorded with
+    new, log_q, _ = gibbs_sample_source(model, sample, z["gs_subset_objects"])
+    assert np.array_equal(new.source.value, z["gs_subset_new_source"])
+    assert log_q == z["gs_subset_log_q"]
+
+
+def test_device_log_q_and_oracle_agree():
+    """The device's own fp64 log_q / log_q_back sums against the oracle restatement (fp32 sums there)."""
+    fx, model, sample = _gibbs_fixture()
+    z = fx.z
+    eng = model.likelihood.engine
+    from sbayes_amd.conditionals import _bind_slot
+    _bind_slot(eng, model, sample, 0, with_source=True)
+    for c in range(eng.n_components):
+        eng.update_probs(0, c)
+    for tag in fx.meta["cases"]:
+        objects = z[f"gs_{tag}_objects"]
+        temp, ptemp, from_prior = (float(v) for v in z[f"gs_{tag}_temps"])
+        want_src, want_q, want_qb, want_counts = orc.gibbs_source_propose(
+            fx.features, fx.na_values, fx.groups, fx.counts, fx.conc, fx.weights, fx.source, objects, z[f"gs_{tag}_z"],
+            temp, ptemp, bool(from_prior))
+        eng.copy_slot(1, 0)
+        log_q = eng.sample_source(0, 1, objects, z[f"gs_{tag}_z"], temp, ptemp, bool(from_prior))
+        assert np.array_equal(eng.get_source_rows(1, objects), want_src[objects])
+        eng.update_counts(1, 0, objects)
+        for c in range(eng.n_components):
+            assert np.array_equal(eng.get_counts(1, c), want_counts[c])
+            eng.update_probs(1, c)
+        log_q_back = eng.source_logprob(1, 0, objects, temp, ptemp, bool(from_prior))
+        assert abs(log_q - want_q) <= 3e-6 * abs(want_q)
+        assert abs(log_q_back - want_qb) <= 3e-6 * abs(want_qb)

@@ -86,6 +86,17 @@ def test_default_tile_width_never_refuses():
         _run_case(feats, groups, weights, source, conc, n_groups, rng, light=True)
 
 
+def test_forced_direct_mode(monkeypatch):
+    """SBE_DIRECT=1 forces the no-LDS-table form (tables gathered through L2) for every shape, not
+    only the one whose tables do not fit."""
+    monkeypatch.setenv("SBE_DIRECT", "1")
+    for shape in SHAPES:
+        N, F, S, n_groups, na_rate = shape
+        rng = np.random.default_rng(11)
+        feats, groups, weights, source, conc = random_case(rng, N, F, S, n_groups, na_rate)
+        _run_case(feats, groups, weights, source, conc, n_groups, rng, light=True)
+
+
 def _run_case(feats, groups, weights, source, conc, n_groups, rng, light=False):
     N = feats.shape[0]
     na = ~feats.any(-1)
