@@ -254,7 +254,10 @@ int sbe_cluster_marginals(sbe_engine* e, int slot, const float* table /* [F][S] 
  *     probabilities [n_sub][F] (1 for NA) so a caller can redo the sum in the reference's precision.
  * sbe_source_logprob: log_q_back (operators.py:544-550): sum log p_slot[ source of src_slot ] over the
  *     listed objects, p from `slot`'s current tables.
- * The random numbers themselves stay with the caller's RNG (the engine holds no RNG state). */
+ * z == NULL: the uniforms come from the engine's own counter-based stream instead (Philox4x32-10:
+ *     uniform i of draw d = 53 bits of philox(counter = (i, d), key = seed); sbe_set_rng sets
+ *     (seed, d), every z == NULL call uses draw d and then increments it) -- nothing but the object
+ *     ids crosses PCIe.  Statistically equivalent to, not the same numbers as, np.random. */
 int sbe_source_posterior(sbe_engine* e, int slot, const int32_t* objects, int n_sub, double temperature,
                          double prior_temperature, float* out /* [n_sub][F][C] */);
 int sbe_sample_source(sbe_engine* e, int slot, int dst_slot, const int32_t* objects, int n_sub, double temperature,
@@ -263,6 +266,10 @@ int sbe_sample_source(sbe_engine* e, int slot, int dst_slot, const int32_t* obje
 int sbe_source_logprob(sbe_engine* e, int slot, int src_slot, const int32_t* objects, int n_sub, double temperature,
                        double prior_temperature, int from_prior, double* log_q_out,
                        float* p_selected_out /* [n_sub][F] or NULL */);
+int sbe_set_rng(sbe_engine* e, uint64_t seed, uint64_t draw);
+int sbe_get_rng(sbe_engine* e, uint64_t* seed, uint64_t* draw);
+/* test hook: out[i][0..4) = philox4x32_10(counter = ctr_key[i][0..4), key = ctr_key[i][4..6)) */
+int sbe_test_philox(sbe_engine* e, const uint32_t* ctr_key /* [n][6] */, int n, uint32_t* out /* [n][4] */);
 int sbe_subset_lh(sbe_engine* e, const int32_t* objects, int n_sub, int n_comp, const float* tables,
                   const int32_t* table_offsets /* [n_comp] */, int n_tables_total,
                   const int32_t* group_idx /* [n_comp][n_sub] */, double temperature,

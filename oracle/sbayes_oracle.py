@@ -384,6 +384,33 @@ def component_likelihood_given_unchanged(features, na_values, groups_by_componen
     return lik ** (1 / temperature)
 
 
+def philox4x32_10(counter, key):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11;
+    Random123's philox4x32 with 10 rounds).  counter uint32 [..., 4], key uint32 [..., 2] -> uint32 [..., 4].
+    The engine's optional device stream for the Gibbs source draw (not part of the reference, which uses
+    np.random): restated here so the device draws can be checked number for number."""
+    c = [np.asarray(counter, dtype=np.uint64)[..., i].copy() for i in range(4)]
+    k = [np.asarray(key, dtype=np.uint64)[..., i].copy() for i in range(2)]
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k[0], p1 & m32, (p0 >> np.uint64(32)) ^ c[3] ^ k[1], p0 & m32]
+        k = [(k[0] + np.uint64(0x9E3779B9)) & m32, (k[1] + np.uint64(0xBB67AE85)) & m32]
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def philox_uniforms(seed, draw, n):
+    """The engine's uniform i (0 <= i < n) of draw `draw` under `seed`: counter (i_lo, i_hi, draw_lo,
+    draw_hi), key (seed_lo, seed_hi); 53 bits from the first two words like MT19937's genrand_res53."""
+    i = np.arange(n, dtype=np.uint64)
+    ctr = np.stack([i & np.uint64(0xFFFFFFFF), i >> np.uint64(32),
+                    np.full(n, int(draw) & 0xFFFFFFFF, dtype=np.uint64), np.full(n, int(draw) >> 32, dtype=np.uint64)], axis=-1)
+    key = np.array([int(seed) & 0xFFFFFFFF, int(seed) >> 32], dtype=np.uint64)
+    r = philox4x32_10(ctr, np.broadcast_to(key, (n, 2)))
+    return ((r[:, 0] >> 5).astype(np.float64) * 67108864.0 + (r[:, 1] >> 6).astype(np.float64)) / 9007199254740992.0
+
+
 def sample_categorical(p, z):
     """sbayes/preprocessing.py:224-256 with the uniforms `z` (shape p.shape[:-1]) passed in instead of
     drawn from np.random: cumulative sums in p's dtype, divided by the last one, first category whose

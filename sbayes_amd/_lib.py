@@ -82,6 +82,9 @@ PROTOTYPES = {
                                      ct.c_int, ct.c_void_p, ct.POINTER(ct.c_double), ct.c_void_p]),
     "sbe_source_logprob": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double,
                                       ct.c_int, ct.POINTER(ct.c_double), ct.c_void_p]),
+    "sbe_set_rng": (ct.c_int, [c_engine_p, ct.c_uint64, ct.c_uint64]),
+    "sbe_get_rng": (ct.c_int, [c_engine_p, ct.POINTER(ct.c_uint64), ct.POINTER(ct.c_uint64)]),
+    "sbe_test_philox": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_subset_lh": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int,
                                  ct.c_void_p, ct.c_double, ct.c_void_p]),
     "sbe_source_prior": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),

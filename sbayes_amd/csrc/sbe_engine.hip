@@ -42,6 +42,7 @@ struct sbe_engine {
     int Np = 0, NQ = 0;            // objects padded to a multiple of 4; object quads
     int ft = 64, n_ftiles = 0, Fq = 0;   // v2 fused-kernel feature tile width, tiles, padded features
     bool direct = false;           // tables of a 16-feature tile exceed LDS: gather from the global tiled tables
+    uint64_t rng_seed = 0, rng_draw = 0;   // Philox key / draw counter of sbe_sample_source(z = NULL)
     int compute_units = 256;
     std::vector<int> G, goff;
     int64_t n_na = 0;
@@ -1492,9 +1493,8 @@ int sbe_sample_source(sbe_engine* e, int slot, int dst_slot, const int32_t* obje
     CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_SLOT(e, dst_slot); CHECK_PTR(e, log_q_out);
     if (!e->slots[dst_slot].source_set) return fail(e, SBE_ERR_STATE, "slot %d: source not set (rows outside the subset would be undefined)", dst_slot);
     if (n_sub == 0) { *log_q_out = 0.0; return SBE_OK; }
-    if (n_sub > 0) CHECK_PTR(e, z);
     const int64_t n_obs = (int64_t)std::max(n_sub, 0) * e->F;
-    const size_t zb = ((size_t)n_obs * sizeof(double) + 255) / 256 * 256;
+    const size_t zb = z ? ((size_t)n_obs * sizeof(double) + 255) / 256 * 256 : 0;    // z == NULL: device Philox stream
     const size_t pb = ((size_t)n_obs * sizeof(float) + 255) / 256 * 256;
     SrcPostArgs a; uint8_t* d_extra = nullptr;
     int rc = source_posterior_setup(e, slot, objects, n_sub, temperature, prior_temperature, from_prior, zb + pb + 257 * sizeof(double), &a, &d_extra);
@@ -1502,10 +1502,40 @@ int sbe_sample_source(sbe_engine* e, int slot, int dst_slot, const int32_t* obje
     double* d_z = (double*)d_extra;
     float* d_psel = (float*)(d_extra + zb);
     double* d_partials = (double*)(d_extra + zb + pb);
-    { int _urc = upload(e, d_z, z, (size_t)n_obs * sizeof(double)); if (_urc) return _urc; }
-    k_sample_source<<<div_up(n_obs, 256), 256, 0, e->stream>>>(a, d_z, e->d_src + (int64_t)dst_slot * e->N * e->Fp, d_psel, e->d_status);
+    if (z) { int _urc = upload(e, d_z, z, (size_t)n_obs * sizeof(double)); if (_urc) return _urc; }
+    k_sample_source<<<div_up(n_obs, 256), 256, 0, e->stream>>>(a, z ? d_z : nullptr, e->rng_seed, e->rng_draw,
+                                                               e->d_src + (int64_t)dst_slot * e->N * e->Fp, d_psel, e->d_status);
+    if (!z) ++e->rng_draw;
     HIPCHK(e, hipGetLastError());
     return finish_log_q(e, d_psel, n_obs, d_partials, log_q_out, p_selected_out);
+}
+
+int sbe_set_rng(sbe_engine* e, uint64_t seed, uint64_t draw) {
+    CHECK_ENGINE(e);
+    e->rng_seed = seed;
+    e->rng_draw = draw;
+    return SBE_OK;
+}
+
+int sbe_get_rng(sbe_engine* e, uint64_t* seed, uint64_t* draw) {
+    CHECK_ENGINE(e); CHECK_PTR(e, seed); CHECK_PTR(e, draw);
+    *seed = e->rng_seed;
+    *draw = e->rng_draw;
+    return SBE_OK;
+}
+
+int sbe_test_philox(sbe_engine* e, const uint32_t* ctr_key, int n, uint32_t* out) {
+    CHECK_ENGINE(e);
+    if (n <= 0) return SBE_OK;
+    CHECK_PTR(e, ctr_key); CHECK_PTR(e, out);
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t ib = ((size_t)n * 6 * sizeof(uint32_t) + 255) / 256 * 256;
+    int rc = ensure_scratch(e, ib + (size_t)n * 4 * sizeof(uint32_t));
+    if (rc) return rc;
+    { int _urc = upload(e, e->d_scratch, ctr_key, (size_t)n * 6 * sizeof(uint32_t)); if (_urc) return _urc; }
+    k_test_philox<<<div_up(n, 256), 256, 0, e->stream>>>((const uint32_t*)e->d_scratch, n, (uint32_t*)(e->d_scratch + ib));
+    HIPCHK(e, hipGetLastError());
+    return d2h(e, out, e->d_scratch + ib, (size_t)n * 4 * sizeof(uint32_t));
 }
 
 int sbe_source_logprob(sbe_engine* e, int slot, int src_slot, const int32_t* objects, int n_sub, double temperature,

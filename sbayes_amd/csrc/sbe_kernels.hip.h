@@ -1236,6 +1236,36 @@ __global__ __launch_bounds__(kBlock) void k_cluster_marginals(
 // GibbsSampleSource.calculate_source_posterior (operators.py:554-574): for the listed objects
 //   p[i][f][:] = normalize( lh[n_i][f][:] ** (1/T) * w[n_i][f][:] ** (1/T_prior) )  -> float32
 // lh as in likelihood_per_component (NA -> 1, no group -> 0), w = normalised weights of the slot.
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): counter-based,
+// so uniform i of draw d under seed k is a pure function philox((i, d), k) -- no RNG state in HBM, any
+// grid shape gives the same numbers.  oracle/sbayes_oracle.py restates it (and its known-answer vectors).
+__device__ __host__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t* out) {
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// 53-bit uniform in [0, 1) from two words, like MT19937's genrand_res53 that np.random.random uses.
+__device__ inline double philox_uniform(uint64_t seed, uint64_t draw, uint64_t i) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)draw, (uint32_t)(draw >> 32), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+    return ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+__global__ void k_test_philox(const uint32_t* __restrict__ ctr_key, int n, uint32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* p = ctr_key + 6 * (int64_t)i;
+    philox4x32_10(p[0], p[1], p[2], p[3], p[4], p[5], out + 4 * (int64_t)i);
+}
+
 struct SrcPostArgs {
     const uint8_t* state; const uint16_t* gid; const uint8_t* pid; const float* probs; const float* wpat;
     const int32_t* objects; int n_sub, Np, F, S, C, Fp;
@@ -1281,10 +1311,12 @@ __global__ void k_source_posterior(SrcPostArgs a, float* __restrict__ out, int* 
 // GibbsSampleSource._propose (operators.py:495-552), the draw: sample_categorical
 // (preprocessing.py:224-256) on the posterior row with the caller's uniform z[r][f] --
 //   cdf = cumsum(p) (float32, sequential), cdf /= cdf[-1], k = first c with z < cdf[c] (0 if none)
+// (z == nullptr: uniform i of the engine's Philox stream, SURVEY.md 8(f) rank 3 "device RNG")
 // -- writes component k (0xFF for NA observations, operators.py:527) into the destination slot's
 // source and keeps p[k] (1 for NA) for the transition log-probability log_q = sum log p[k].
-__global__ void k_sample_source(SrcPostArgs a, const double* __restrict__ z, uint8_t* __restrict__ src_dst,
-                                float* __restrict__ p_sel, int* __restrict__ status) {
+__global__ void k_sample_source(SrcPostArgs a, const double* __restrict__ z, uint64_t seed, uint64_t draw,
+                                uint8_t* __restrict__ src_dst, float* __restrict__ p_sel,
+                                int* __restrict__ status) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)a.n_sub * a.F) return;
     const int r = (int)(i / a.F), f = (int)(i % a.F);
@@ -1296,7 +1328,7 @@ __global__ void k_sample_source(SrcPostArgs a, const double* __restrict__ z, uin
     cdf[0] = run;
     for (int c = 1; c < a.C; ++c) { run = run + p[c]; cdf[c] = run; }
     const float last = cdf[a.C - 1];
-    const double zz = z[i];
+    const double zz = z ? z[i] : philox_uniform(seed, draw, (uint64_t)i);     // z == nullptr: the engine's own stream
     int k = 0;
     for (int c = a.C - 1; c >= 0; --c)
         if (zz < (double)(cdf[c] / last)) k = c;

@@ -403,15 +403,33 @@ class Engine:
         write them into `dst_slot`'s source.  Returns log_q (float), or (log_q, p_selected float32
         [n, F]) with return_selected."""
         objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
-        zz = _c(z, np.float64).reshape(objs.size, -1)
-        if zz.shape != (objs.size, self.n_features):
-            raise ValueError(f"z must be [{objs.size}, {self.n_features}]")
+        zz = None
+        if z is not None:                        # None: the engine's own Philox stream (set_rng)
+            zz = _c(z, np.float64).reshape(objs.size, -1)
+            if zz.shape != (objs.size, self.n_features):
+                raise ValueError(f"z must be [{objs.size}, {self.n_features}]")
         sel = np.empty((objs.size, self.n_features), dtype=np.float32) if return_selected else None
         log_q = ct.c_double()
         self._check(self._lib.sbe_sample_source(self._h, slot, dst_slot, _ptr(objs), objs.size, float(temperature),
-                                                float(prior_temperature), int(bool(from_prior)), _ptr(zz),
-                                                ct.byref(log_q), _ptr(sel) if return_selected else None))
+                                                float(prior_temperature), int(bool(from_prior)),
+                                                _ptr(zz) if zz is not None else None, ct.byref(log_q),
+                                                _ptr(sel) if return_selected else None))
         return (log_q.value, sel) if return_selected else log_q.value
+
+    def set_rng(self, seed, draw=0):
+        """Key and draw counter of the engine's Philox4x32-10 stream (sample_source with z=None)."""
+        self._check(self._lib.sbe_set_rng(self._h, int(seed) & (2 ** 64 - 1), int(draw) & (2 ** 64 - 1)))
+
+    def get_rng(self):
+        seed, draw = ct.c_uint64(), ct.c_uint64()
+        self._check(self._lib.sbe_get_rng(self._h, ct.byref(seed), ct.byref(draw)))
+        return seed.value, draw.value
+
+    def test_philox(self, ctr_key):
+        ck = _c(ctr_key, np.uint32).reshape(-1, 6)
+        out = np.empty((ck.shape[0], 4), dtype=np.uint32)
+        self._check(self._lib.sbe_test_philox(self._h, _ptr(ck), ck.shape[0], _ptr(out)))
+        return out
 
     def source_logprob(self, slot, src_slot, objects, temperature=1.0, prior_temperature=1.0, from_prior=False,
                        return_selected=False):

@@ -86,7 +86,7 @@ def calculate_source_posterior(model, sample, object_subset, temperature=1.0, pr
 
 
 def gibbs_sample_source(model, sample, object_subset=slice(None), temperature=1.0, prior_temperature=1.0,
-                        sample_from_prior=False, z=None, slots=(0, 1)):
+                        sample_from_prior=False, z=None, slots=(0, 1), device_rng=False):
     """GibbsSampleSource._propose (operators.py:495-552) on the device: posterior, draw, new source rows,
     delta counts, new tables and both transition log-probabilities never leave the GPU; what crosses
     PCIe is the uniforms in and [n, F] selected probabilities + the subset's new rows out.
@@ -95,6 +95,8 @@ def gibbs_sample_source(model, sample, object_subset=slice(None), temperature=1.
     sample_categorical (preprocessing.py:248) -- so with the same np.random state the proposal is the
     reference's, draw for draw; pass `z` [n, F] to supply them.  log_q / log_q_back are summed on the
     host from the selected float32 probabilities, in the reference's float32 precision.
+    device_rng=True takes the uniforms from the engine's Philox stream instead (Engine.set_rng): nothing
+    but the object ids goes up; statistically equivalent, not the same numbers.
     Returns (sample_new, log_q, log_q_back) like the reference."""
     eng = _engine(model)
     cur, new = slots
@@ -108,9 +110,12 @@ def gibbs_sample_source(model, sample, object_subset=slice(None), temperature=1.
         objects = np.asarray(object_subset)
         if objects.dtype == np.bool_:
             objects = np.flatnonzero(objects)
-    if z is None:
-        z = np.random.random([objects.size, eng.n_features, 1])
-    z = np.asarray(z, dtype=np.float64).reshape(objects.size, eng.n_features)
+    if device_rng:
+        z = None
+    else:
+        if z is None:
+            z = np.random.random([objects.size, eng.n_features, 1])
+        z = np.asarray(z, dtype=np.float64).reshape(objects.size, eng.n_features)
     eng.copy_slot(new, cur)
     _, sel = eng.sample_source(cur, new, objects, z, temperature, prior_temperature, sample_from_prior,
                                return_selected=True)

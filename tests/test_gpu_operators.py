@@ -200,3 +200,77 @@ def test_device_log_q_and_oracle_agree():
         log_q_back = eng.source_logprob(1, 0, objects, temp, ptemp, bool(from_prior))
         assert abs(log_q - want_q) <= 3e-6 * abs(want_q)
         assert abs(log_q_back - want_qb) <= 3e-6 * abs(want_qb)
+
+
+PHILOX_KAT = [   # Random123 known-answer vectors for philox4x32-10: (counter, key, output)
+    ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+     (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+]
+
+
+def test_device_philox_known_answers_and_oracle():
+    fx, model, sample = _gibbs_fixture()
+    eng = model.likelihood.engine
+    ck = np.array([c + k for c, k, _ in PHILOX_KAT], dtype=np.uint32)
+    assert np.array_equal(eng.test_philox(ck), np.array([o for _, _, o in PHILOX_KAT], dtype=np.uint32))
+    rng = np.random.default_rng(2)
+    ck = rng.integers(0, 2 ** 32, size=(5000, 6), dtype=np.uint64).astype(np.uint32)
+    assert np.array_equal(eng.test_philox(ck), orc.philox4x32_10(ck[:, :4], ck[:, 4:]))
+
+
+def test_gibbs_source_device_rng_matches_oracle_stream_and_is_reproducible():
+    """z = NULL: the engine's Philox stream.  The draws equal the oracle's sample_categorical fed with
+    the oracle's restatement of that stream; the draw counter advances by one per call; the same
+    (seed, draw) gives the same proposal, another draw a different one."""
+    fx, model, sample = _gibbs_fixture()
+    z = fx.z
+    eng = model.likelihood.engine
+    from sbayes_amd.conditionals import _bind_slot
+    _bind_slot(eng, model, sample, 0, with_source=True)
+    for c in range(eng.n_components):
+        eng.update_probs(0, c)
+    objects = z["gs_subset_objects"]
+    F = fx.features.shape[1]
+    eng.set_rng(seed=0x1234_5678_9ABC_DEF0, draw=41)
+    rows = []
+    for draw in (41, 42):
+        assert eng.get_rng() == (0x1234_5678_9ABC_DEF0, draw)
+        u = orc.philox_uniforms(0x1234_5678_9ABC_DEF0, draw, objects.size * F).reshape(objects.size, F)
+        want_src, want_q, _, _ = orc.gibbs_source_propose(fx.features, fx.na_values, fx.groups, fx.counts, fx.conc,
+                                                          fx.weights, fx.source, objects, u)
+        eng.copy_slot(1, 0)
+        log_q = eng.sample_source(0, 1, objects, None)
+        rows.append(eng.get_source_rows(1, objects))
+        assert np.array_equal(rows[-1], want_src[objects])
+        assert abs(log_q - want_q) <= 3e-6 * abs(want_q)
+    assert not np.array_equal(rows[0], rows[1])
+    eng.set_rng(seed=0x1234_5678_9ABC_DEF0, draw=41)
+    eng.copy_slot(1, 0)
+    eng.sample_source(0, 1, objects, None)
+    assert np.array_equal(eng.get_source_rows(1, objects), rows[0])
+
+
+def test_gibbs_source_device_rng_frequencies_follow_the_posterior():
+    """Many independent device draws of the same rows: the empirical component frequencies of every
+    observation match its posterior row (chi-square over all valid observations, 5 sigma)."""
+    from sbayes_amd.operators import calculate_source_posterior, gibbs_sample_source
+    fx, model, sample = _gibbs_fixture()
+    objects = fx.z["gs_subset_objects"]
+    p = calculate_source_posterior(model, sample, objects).astype(np.float64)
+    eng = model.likelihood.engine
+    eng.set_rng(seed=99)
+    n_draws = 400
+    freq = np.zeros_like(p)
+    for _ in range(n_draws):
+        new, _, _ = gibbs_sample_source(model, sample, objects, device_rng=True)
+        freq += new.source.value[objects]
+    valid = ~fx.na_values[objects]
+    assert np.array_equal(freq.sum(-1)[valid], np.full(valid.sum(), n_draws))
+    expected = p[valid] * n_draws
+    cells = expected > 5
+    chi2 = (((freq[valid] - expected) ** 2)[cells] / expected[cells]).sum()
+    dof = cells.sum() - valid.sum()
+    assert abs(chi2 - dof) < 5 * np.sqrt(2 * dof), (chi2, dof)
+    assert np.all(freq[valid][expected == 0] == 0)
