@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--workload", default="headline", choices=["cfg1", "headline", "stress"])
     ap.add_argument("--batch", type=int, default=256,
                     help="resident sample states (chains x candidate states) evaluated per step")
-    ap.add_argument("--kernel", default="packed", choices=["packed", "packed_general", "onehot", "onehot_general"],
+    ap.add_argument("--kernel", default="packed", choices=["packed", "packed_general", "packed_tuple_lds", "onehot", "onehot_general"],
                     help="packed: state-index stream, group-tuple form when it applies (default); "
                          "packed_general: never the group-tuple form; onehot: stream the one-hot block")
     ap.add_argument("--log-mode", default="product", choices=["product", "per_obs"])
@@ -62,12 +62,12 @@ def parse():
 
 def setup_engine(wl, batch, device, kernel, log_mode):
     from sbayes_amd.engine import (LOG_PER_OBS, LOG_PRODUCT, MIXTURE_ONEHOT, MIXTURE_ONEHOT_GENERAL, MIXTURE_PACKED,
-                                   MIXTURE_PACKED_GENERAL, Engine)
+                                   MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE_LDS, Engine)
     from sbayes_amd.synthetic import make_state
 
     eng = Engine(wl.features, [g.shape[0] for g in wl.groups], n_slots=batch, device=device)
     eng.set_option(kernel={"onehot": MIXTURE_ONEHOT, "onehot_general": MIXTURE_ONEHOT_GENERAL, "packed": MIXTURE_PACKED,
-                           "packed_general": MIXTURE_PACKED_GENERAL}[kernel],
+                           "packed_general": MIXTURE_PACKED_GENERAL, "packed_tuple_lds": MIXTURE_PACKED_TUPLE_LDS}[kernel],
                    log_mode=LOG_PRODUCT if log_mode == "product" else LOG_PER_OBS)
     for c in range(wl.n_components):
         eng.set_concentration(c, wl.concentration[c])

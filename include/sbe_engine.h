@@ -50,6 +50,8 @@ typedef struct sbe_engine sbe_engine;
 #define SBE_MIXTURE_ONEHOT_GENERAL 4  /* one-hot stream, never the group-tuple form          */
 #define SBE_MIXTURE_PACKED_GENERAL 2  /* packed, but never the group-tuple form (testing / A-B) */
 #define SBE_MIXTURE_PACKED_TUPLE 3    /* packed, group-tuple form forced (error if not applicable) */
+#define SBE_MIXTURE_PACKED_TUPLE_LDS 5  /* same, but never the scalar-unit 64-feature-tile variant
+                                          (k_mixture_tuple64): the LDS-metadata kernel (testing / A-B) */
 #define SBE_OPT_LOG_MODE 2
 #define SBE_LOG_PER_OBS 0      /* fp64 log per observation, fp64 sum                        */
 #define SBE_LOG_PRODUCT 1      /* fp64 mantissa product + integer exponent, one log/thread  */
@@ -305,6 +307,8 @@ int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters
 
 /* ---- self-test hook: fp64 log used by the group-tuple table build vs the device library's log ---- */
 int sbe_test_fast_log(sbe_engine* e, const double* in, int n, double* out_fast, double* out_lib);
+/* table-driven fp64 log of k_mixture_tuple64's table build (error <= 1 ulp + 2^-53 absolute) */
+int sbe_test_tab_log(sbe_engine* e, const double* in, int n, double* out);
 
 /* ---- slot management -------------------------------------------------------------------- */
 int sbe_copy_slot(sbe_engine* e, int dst_slot, int src_slot);

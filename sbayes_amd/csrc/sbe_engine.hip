@@ -69,6 +69,9 @@ struct sbe_engine {
     float* d_weights = nullptr;    // [slots][F][C]
     float* d_wpat = nullptr;       // [slots][Pmax][F][C]
     uint32_t* d_patbits = nullptr; // [slots][Pmax]
+    uint16_t* d_state_h = nullptr; // [NQ][Fq][4] prepared LDS offsets of k_mixture_tuple64 (ft == 64, S <= 127) or null
+    double2* d_logtab = nullptr;   // [128] {1/c, log c}: table of tab_log_pos (k_mixture_tuple64's table build)
+    uint32_t* d_toff = nullptr;    // [slots][Np] byte offset of the object's tuple block, tid*(S+1)*512 (k_mixture_tuple64)
     uint8_t* d_tid = nullptr;      // [slots][Np] group-tuple index per object (k_mixture_combo)
     uint16_t* d_tuple_g = nullptr; // [slots][kMaxTuples][kMaxComponents]
     uint8_t* d_tuple_p = nullptr;  // [slots][kMaxTuples]
@@ -275,6 +278,7 @@ int upload_patterns_and_weights(sbe_engine* e, int slot) {
         {
             const int N = e->N, C = e->C;
             std::vector<uint8_t> tid(e->Np, 0);
+            std::vector<uint32_t> toff(e->Np, 0);
             std::vector<uint16_t> tg((size_t)kMaxTuples * kMaxComponents, (uint16_t)e->Gtot);
             std::vector<uint8_t> tp(kMaxTuples, 0);
             uint16_t tuples[kMaxTuples][kMaxComponents];
@@ -292,10 +296,12 @@ int upload_patterns_and_weights(sbe_engine* e, int slot) {
                     tp[t] = s.h_pid[n];
                 }
                 tid[n] = (uint8_t)t;
+                toff[n] = (uint32_t)t * (uint32_t)(e->S + 1) * 512u;
             }
             s.n_tuples = ok ? n_tup : 0;
             if (ok) {
                 { int _urc = upload(e, e->d_tid + (int64_t)slot * e->Np, tid.data(), e->Np); if (_urc) return _urc; }
+                { int _urc = upload(e, e->d_toff + (int64_t)slot * e->Np, toff.data(), (size_t)e->Np * sizeof(uint32_t)); if (_urc) return _urc; }
                 { int _urc = upload(e, e->d_tuple_g + (int64_t)slot * kMaxTuples * kMaxComponents, tg.data(),
                                          tg.size() * sizeof(uint16_t)); if (_urc) return _urc; }
                 { int _urc = upload(e, e->d_tuple_p + (int64_t)slot * kMaxTuples, tp.data(), tp.size()); if (_urc) return _urc; }
@@ -408,6 +414,23 @@ void launch_combo_ft(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStrea
     }
 }
 
+template <bool OFF16>
+void launch_tuple64_o(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
+    switch (C) {
+        case 1: k_mixture_tuple64<1, OFF16><<<grid, kBlock, lds, st>>>(p); break;
+        case 2: k_mixture_tuple64<2, OFF16><<<grid, kBlock, lds, st>>>(p); break;
+        case 3: k_mixture_tuple64<3, OFF16><<<grid, kBlock, lds, st>>>(p); break;
+        case 4: k_mixture_tuple64<4, OFF16><<<grid, kBlock, lds, st>>>(p); break;
+        default: k_mixture_tuple64<0, OFF16><<<grid, kBlock, lds, st>>>(p); break;
+    }
+}
+
+void launch_tuple64(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
+    // 16-bit tuple-block offsets when the whole log table sits below 64 KiB
+    if ((int64_t)p.KT * (p.S + 1) * 512 <= 65536) launch_tuple64_o<true>(C, p, grid, lds, st);
+    else launch_tuple64_o<false>(C, p, grid, lds, st);
+}
+
 template <bool ONEHOT>
 void launch_combo(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
     if (ft == 64) launch_combo_ft<64, ONEHOT>(C, p, grid, lds, st);
@@ -434,7 +457,7 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     // LDS and a block sees enough observations to amortise building it.  It prefers long chunks (one block
     // per CU is enough: the table build is per block), so it gets its own geometry.
     int KT = 0;
-    const bool force_combo = e->opt_kernel == SBE_MIXTURE_PACKED_TUPLE;
+    const bool force_combo = e->opt_kernel == SBE_MIXTURE_PACKED_TUPLE || e->opt_kernel == SBE_MIXTURE_PACKED_TUPLE_LDS;
     bool combo = e->opt_kernel == SBE_MIXTURE_PACKED || e->opt_kernel == SBE_MIXTURE_ONEHOT || force_combo;
     for (int sl = first_slot; sl < first_slot + n && combo; ++sl) {
         if (e->slots[sl].n_tuples == 0) combo = false;
@@ -442,15 +465,23 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     }
     size_t combo_lds = 0;
     int combo_w_off = 0, combo_tab_off = 0;
+    bool tuple64 = false;
     if (combo) {
         const MixGeom gc = mix_geometry_v2(e, P, n, 2);
+        // 64-feature tiles, packed stream: the scalar-unit form (tuple metadata in VGPRs, no id staging)
+        tuple64 = !onehot && gc.ft == 64 && e->d_state_h && e->opt_kernel != SBE_MIXTURE_PACKED_TUPLE_LDS;
         // LDS image: T[KT][S+1][ft] f64 | tq[quads] u32 | tuple rows u16 | tuple patterns u32 | weights f64 [| byte table]
+        //   (tuple64: T | weights)
         const int cu = e->C <= 4 ? e->C : kMaxComponents;
-        combo_lds = (size_t)KT * (e->S + 1) * gc.ft * sizeof(double) + (size_t)gc.objs_per_chunk * 4;
-        combo_lds += ((size_t)KT * cu + ((KT * cu) & 1)) * sizeof(uint16_t) + (size_t)KT * sizeof(uint32_t);
+        combo_lds = (size_t)KT * (e->S + 1) * gc.ft * sizeof(double);
+        if (!tuple64) {
+            combo_lds += (size_t)gc.objs_per_chunk * 4;
+            combo_lds += ((size_t)KT * cu + ((KT * cu) & 1)) * sizeof(uint16_t) + (size_t)KT * sizeof(uint32_t);
+        }
         combo_lds = (combo_lds + 15) / 16 * 16;
         combo_w_off = (int)combo_lds;
         combo_lds += (size_t)P * e->C * gc.ft * sizeof(double);
+        if (tuple64) combo_lds += 4 * sizeof(double) + kLogTabEntries * sizeof(double2);   // reduction scratch (the kernel has no static LDS) + log table
         if (onehot) {      // byte-position lookup table [seg16][32] u16; a tile row segment must fit one step
             const int seg16 = gc.ft * e->S / 16;
             if (seg16 > kBlock) combo = false;
@@ -492,11 +523,35 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
         p.n_work = g.n_blocks; p.n_batch = n;
         p.slot_groups = slot_groups; p.slots_per_group = slots_per_group;
         p.tid = e->d_tid; p.tid_stride = e->Np;
+        p.state_h = reinterpret_cast<const uint2*>(e->d_state_h);
+        p.toff = e->d_toff; p.toff_stride = e->Np;
+        p.logtab = e->d_logtab;
+        p.ragged_w = (tuple64 && e->F % 64 != 0 && e->F % 64 <= 32) ? e->F % 64 : 0;
+        if (combo && tuple64)     // own block order (slots dealt to XCDs, heavy work items first; see the kernel)
+            grid = n >= 8 ? dim3(8 * div_up(n, 8) * g.n_blocks, 1) : dim3(n * g.n_blocks, 1);
         p.tuple_g = e->d_tuple_g; p.tuple_g_stride = (int64_t)kMaxTuples * kMaxComponents;
         p.tuple_p = e->d_tuple_p; p.tuple_p_stride = kMaxTuples;
         p.combo_w_off = combo_w_off; p.combo_tab_off = combo_tab_off;
         p.KT = KT;
-        if (combo) {
+#ifdef SBE_STAMPS
+        static uint64_t* d_stamps = nullptr;
+        if (combo && tuple64 && getenv("SBE_STAMPS_FILE")) {
+            if (!d_stamps) (void)hipMalloc((void**)&d_stamps, (size_t)grid.x * 32 * sizeof(uint64_t));
+            (void)hipMemsetAsync(d_stamps, 0, (size_t)grid.x * 32 * sizeof(uint64_t), e->stream);
+            p.stamps = d_stamps;
+        }
+#endif
+        if (combo && tuple64) launch_tuple64(e->C, p, grid, combo_lds, e->stream);
+#ifdef SBE_STAMPS
+        if (p.stamps) {
+            std::vector<uint64_t> h((size_t)grid.x * 32);
+            (void)hipStreamSynchronize(e->stream);
+            (void)hipMemcpy(h.data(), d_stamps, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
+            FILE* f = fopen(getenv("SBE_STAMPS_FILE"), "wb");
+            if (f) { fwrite(h.data(), sizeof(uint64_t), h.size(), f); fclose(f); }
+        }
+#endif
+        else if (combo) {
             if (onehot) launch_combo<true>(g.ft, e->C, p, grid, combo_lds, e->stream);
             else launch_combo<false>(g.ft, e->C, p, grid, combo_lds, e->stream);
         } else
@@ -573,7 +628,7 @@ int sbe_destroy(sbe_engine* e) {
     if (!e) return SBE_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void* dev_ptrs[] = {e->d_step_pf, e->d_step_pg, e->d_tid, e->d_tuple_g, e->d_tuple_p, e->d_state_q, e->d_probs_t, e->d_wpat_t, e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
+    void* dev_ptrs[] = {e->d_step_pf, e->d_step_pg, e->d_logtab, e->d_state_h, e->d_toff, e->d_tid, e->d_tuple_g, e->d_tuple_p, e->d_state_q, e->d_probs_t, e->d_wpat_t, e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
                         e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_unif, e->d_partials,
                         e->d_status, e->d_changed, e->d_scratch};
     for (void* p : dev_ptrs) if (p) (void)hipFree(p);
@@ -687,6 +742,24 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_RC(dmalloc(e, &e->d_wpat, NS * e->Pmax * F * C));
     CREATE_RC(dmalloc(e, &e->d_patbits, NS * e->Pmax));
     CREATE_RC(dmalloc(e, &e->d_tid, NS * e->Np));
+    CREATE_RC(dmalloc(e, &e->d_toff, NS * e->Np + 64));       // + padding: the kernel prefetches 16 entries ahead
+    CREATE_CHK(hipMemsetAsync(e->d_toff, 0, (NS * e->Np + 64) * sizeof(uint32_t), e->stream));
+    {   // table of tab_log_pos: interval centres c_i = 1 + (i + 1/2)/128 (c_0 = 1), {RN(1/c), RN(-log(RN(1/c)))}
+        std::vector<double> tab(2 * kLogTabEntries);
+        for (int i = 0; i < kLogTabEntries; ++i) {
+            const double c = i == 0 ? 1.0 : 1.0 + (i + 0.5) / kLogTabEntries;
+            const double inv_c = 1.0 / c;
+            tab[2 * i] = inv_c;
+            tab[2 * i + 1] = i == 0 ? 0.0 : (double)(-logl((long double)inv_c));
+        }
+        CREATE_RC(dmalloc(e, &e->d_logtab, (int64_t)kLogTabEntries));
+        CREATE_CHK(hipMemcpy(e->d_logtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (e->ft == 64 && S <= 127 && (int64_t)e->NQ * e->Fq * 8 < ((int64_t)1 << 31)) {
+        CREATE_RC(dmalloc(e, &e->d_state_h, (int64_t)e->NQ * e->Fq * 4));
+        k_init_state_h<<<div_up((int64_t)e->NQ * e->Fq, 256), 256, 0, e->stream>>>(e->d_state_h, (int64_t)e->NQ * e->Fq, e->Fq, e->S);
+        CREATE_CHK(hipGetLastError());
+    }
     CREATE_RC(dmalloc(e, &e->d_tuple_g, NS * kMaxTuples * kMaxComponents));
     CREATE_RC(dmalloc(e, &e->d_tuple_p, NS * (int64_t)kMaxTuples));
     CREATE_CHK(hipMemsetAsync(e->d_tid, 0, NS * e->Np, e->stream));
@@ -715,7 +788,7 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_CHK(hipMemsetAsync(e->d_src, 0xFF, NS * N * e->Fp, e->stream));
     CREATE_CHK(hipMemsetAsync(e->d_gid, 0xFF, NS * C * e->Np * sizeof(uint16_t), e->stream));
     CREATE_CHK(hipMemsetAsync(e->d_pid, 0, NS * e->Np, e->stream));
-    CREATE_CHK(hipMemsetAsync(e->d_state_q, 0xFF, (int64_t)e->NQ * e->Fq * 4, e->stream));
+    CREATE_CHK(hipMemsetAsync(e->d_state_q, S, (int64_t)e->NQ * e->Fq * 4, e->stream));   // NA / padding byte = S
     CREATE_CHK(hipMemsetAsync(e->d_probs_t, 0, NS * e->probs_t_elems() * sizeof(float), e->stream));
     CREATE_CHK(hipMemsetAsync(e->d_wpat_t, 0, NS * e->wpat_t_elems() * sizeof(double), e->stream));
     CREATE_CHK(hipMemsetAsync(e->d_counts, 0, NS * e->table_elems() * sizeof(int32_t), e->stream));
@@ -724,7 +797,7 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_RC(ensure_scratch(e, (size_t)(N * F * S)));
     CREATE_CHK(hipMemcpyAsync(e->d_scratch, features_onehot, (size_t)(N * F * S), hipMemcpyHostToDevice, e->stream));
     k_ingest_onehot<<<div_up(N * F, 256), 256, 0, e->stream>>>(e->d_scratch, e->d_onehot, e->d_state, e->d_state_q,
-                                                              e->N, e->F, e->S, e->rs_pitch, e->Fp, e->Fq, e->d_status);
+                                                              e->d_state_h, e->N, e->F, e->S, e->rs_pitch, e->Fp, e->Fq, e->d_status);
     CREATE_CHK(hipGetLastError());
     CREATE_RC(read_status(e));
     if (e->h_status[ST_MULTI_STATE] != 0) {
@@ -767,7 +840,7 @@ int sbe_get_na(const sbe_engine* ce, uint8_t* out_na) {
 
 int sbe_set_option(sbe_engine* e, int option, int value) {
     CHECK_ENGINE(e);
-    if (option == SBE_OPT_MIXTURE_KERNEL && (value == SBE_MIXTURE_PACKED || value == SBE_MIXTURE_ONEHOT || value == SBE_MIXTURE_PACKED_GENERAL || value == SBE_MIXTURE_PACKED_TUPLE || value == SBE_MIXTURE_ONEHOT_GENERAL)) { e->opt_kernel = value; return SBE_OK; }
+    if (option == SBE_OPT_MIXTURE_KERNEL && (value == SBE_MIXTURE_PACKED || value == SBE_MIXTURE_ONEHOT || value == SBE_MIXTURE_PACKED_GENERAL || value == SBE_MIXTURE_PACKED_TUPLE || value == SBE_MIXTURE_PACKED_TUPLE_LDS || value == SBE_MIXTURE_ONEHOT_GENERAL)) { e->opt_kernel = value; return SBE_OK; }
     if (option == SBE_OPT_LOG_MODE && (value == SBE_LOG_PER_OBS || value == SBE_LOG_PRODUCT)) { e->opt_log = value; return SBE_OK; }
     if (option == SBE_OPT_DEFERRED_CHECKS && (value == 0 || value == 1)) {
         if (!value && e->status_pending) { HIPCHK(e, hipStreamSynchronize(e->stream)); int rc = synced(e); e->opt_deferred = 0; return rc; }
@@ -1739,6 +1812,21 @@ int sbe_test_fast_log(sbe_engine* e, const double* in, int n, double* out_fast, 
     return d2h(e, out_lib, d_l, (size_t)n * sizeof(double));
 }
 
+int sbe_test_tab_log(sbe_engine* e, const double* in, int n, double* out) {
+    CHECK_ENGINE(e); CHECK_PTR(e, in); CHECK_PTR(e, out);
+    if (n < 1) return fail(e, SBE_ERR_ARG, "n=%d", n);
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t b = ((size_t)n * sizeof(double) + 255) / 256 * 256;
+    int rc = ensure_scratch(e, 2 * b);
+    if (rc) return rc;
+    double* d_in = (double*)e->d_scratch;
+    double* d_out = (double*)(e->d_scratch + b);
+    { int _urc = upload(e, d_in, in, (size_t)n * sizeof(double)); if (_urc) return _urc; }
+    k_test_tab_log<<<div_up(n, 256), 256, 0, e->stream>>>(d_in, e->d_logtab, d_out, n);
+    HIPCHK(e, hipGetLastError());
+    return d2h(e, out, d_out, (size_t)n * sizeof(double));
+}
+
 // ---- slots ------------------------------------------------------------------------------------------
 int sbe_copy_slot(sbe_engine* e, int dst, int src) {
     CHECK_ENGINE(e); CHECK_SLOT(e, dst); CHECK_SLOT(e, src);
@@ -1757,7 +1845,7 @@ int sbe_copy_slot(sbe_engine* e, int dst, int src) {
     };
     seg(e->d_gid, C * e->Np); seg(e->d_pid, (int64_t)e->Np); seg(e->d_src, N * e->Fp); seg(e->d_counts, T); seg(e->d_probs, T);
     seg(e->d_probs_t, e->probs_t_elems()); seg(e->d_wpat_t, e->wpat_t_elems());
-    seg(e->d_tid, (int64_t)e->Np); seg(e->d_tuple_g, (int64_t)kMaxTuples * kMaxComponents); seg(e->d_tuple_p, (int64_t)kMaxTuples);
+    seg(e->d_tid, (int64_t)e->Np); seg(e->d_toff, (int64_t)e->Np); seg(e->d_tuple_g, (int64_t)kMaxTuples * kMaxComponents); seg(e->d_tuple_p, (int64_t)kMaxTuples);
     seg(e->d_weights, F * C); seg(e->d_wpat, (int64_t)e->Pmax * F * C); seg(e->d_patbits, (int64_t)e->Pmax);
     k_multi_copy<<<std::min<int64_t>(div_up(run, 256), 4 * e->compute_units), 256, 0, e->stream>>>(cs);
     HIPCHK(e, hipGetLastError());

@@ -142,11 +142,56 @@ __global__ void k_test_fast_log(const double* __restrict__ in, double* __restric
 }
 
 // ------------------------------------------------------------------------------------------
+// Table-driven fp64 log of k_mixture_tuple64's table build (the build is VALU-bound on the log: ~20 vector
+// instructions here against ~48 in fast_log_pos).  v = 2^k * m, m in [1, 2); the top 7 mantissa bits pick
+// an interval with centre c (c = 1 exactly for the first interval, so log(1) = 0 exactly); the table holds
+// inv_c = RN(1/c) and logc = RN(-log(inv_c)) (computed on the host in long double), so that
+// log(v) = k*ln2 + logc + log1p(r) with r = fma(m, inv_c, -1) EXACT up to one rounding and |r| <= 2^-7:
+// degree-8 Taylor of log1p (truncation < 2^-63).  Error: <= 1 ulp of the result + 2^-53 absolute (the
+// rounding of logc; visible only where k*ln2 + logc cancels, i.e. for v just below 1) -- six orders of
+// magnitude inside what the 1e-10 relative tolerance of the summed log-likelihood needs
+// (tests/test_gpu_engine.py::test_fast_log_accuracy).  Not a positive normal double: library log.
+// `tab`: absolute LDS byte address of the 128 {inv_c, logc} pairs.
+// ------------------------------------------------------------------------------------------
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const f64x2_t lds_cf64x2_t;
+constexpr int kLogTabEntries = 128;
+
+__device__ __forceinline__ double tab_log_pos(double v, uint32_t tab) {
+    const uint32_t hi = (uint32_t)__double2hiint(v);
+    const uint32_t ex = hi >> 20;                                 // sign + exponent
+    if (__builtin_expect(ex - 1u >= 0x7FEu, 0)) return log(v);
+    const f64x2_t e = *(lds_cf64x2_t*)(uintptr_t)(tab + ((hi >> 9) & 0x7F0u));        // entry (hi >> 13) & 127
+    const double m = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), __double2loint(v));
+    const double r = fma(m, e.x, -1.0);
+    double q = fma(-0.125, r, 1.0 / 7.0);
+    q = fma(q, r, -1.0 / 6.0);
+    q = fma(q, r, 0.2);
+    q = fma(q, r, -0.25);
+    q = fma(q, r, 1.0 / 3.0);
+    q = fma(q, r, -0.5);
+    const double lp = fma(r * r, q, r);                           // log1p(r)
+    const double kd = (double)((int)ex - 1023);
+    return fma(kd, 6.93147180369123816490e-01, e.y) + fma(kd, 1.90821492927058770002e-10, lp);
+}
+
+__global__ void k_test_tab_log(const double* __restrict__ in, const double2* __restrict__ logtab,
+                               double* __restrict__ out, int n) {
+    __shared__ double2 tab[kLogTabEntries];
+    if (threadIdx.x < kLogTabEntries) tab[threadIdx.x] = logtab[threadIdx.x];
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = tab_log_pos(in[i], (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double2*)tab);
+}
+
+// ------------------------------------------------------------------------------------------
 // K0: one-hot ingest.  raw [N][F*S] (any non-zero byte = True) -> normalised 0/1 copy with a
 // 16-byte-aligned row pitch, packed state index [N][Fp] (0xFF = NA), validation counters.
 // ------------------------------------------------------------------------------------------
 __global__ void k_ingest_onehot(const uint8_t* __restrict__ raw, uint8_t* __restrict__ onehot,
-                                uint8_t* __restrict__ state, uint8_t* __restrict__ state_q, int N, int F,
+                                uint8_t* __restrict__ state, uint8_t* __restrict__ state_q,
+                                uint16_t* __restrict__ state_h /* or null */, int N, int F,
                                 int S, int rs_pitch, int Fp, int Fq, int* __restrict__ status) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // observation index
     int multi = 0, na = 0;
@@ -163,7 +208,11 @@ __global__ void k_ingest_onehot(const uint8_t* __restrict__ raw, uint8_t* __rest
         const uint8_t xb = cnt == 0 ? kNA : (uint8_t)x;
         state[(int64_t)n * Fp + f] = xb;
         // object-quad interleaved copy: dword (n/4, f) holds objects 4*(n/4) .. +3 of feature f
-        state_q[((int64_t)(n >> 2) * Fq + f) * 4 + (n & 3)] = xb;
+        // (NA and padding byte here is S, not 0xFF: it indexes the zero row of the group-tuple log table
+        //  directly; every reader treats any byte >= S as NA)
+        state_q[((int64_t)(n >> 2) * Fq + f) * 4 + (n & 3)] = cnt == 0 ? (uint8_t)S : xb;
+        // k_mixture_tuple64's stream: byte offset of the observation inside a tuple's [S+1][64] f64 block
+        if (state_h) state_h[((int64_t)(n >> 2) * Fq + f) * 4 + (n & 3)] = (uint16_t)((cnt == 0 ? S : x) * 512 + (f & 63) * 8);
         multi = cnt > 1;
         na = cnt == 0;
     }
@@ -172,6 +221,15 @@ __global__ void k_ingest_onehot(const uint8_t* __restrict__ raw, uint8_t* __rest
         if (m) atomicAdd(&status[ST_MULTI_STATE], m);
         if (a) atomicAdd(&status[ST_NA_COUNT], a);
     }
+}
+
+// NA / padding image of the prepared stream: every entry points at the zero row (x = S) of its column.
+__global__ void k_init_state_h(uint16_t* __restrict__ state_h, int64_t n_entries /* NQ*Fq */, int Fq, int S) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_entries) return;
+    const uint16_t v = (uint16_t)(S * 512 + (int)((i % Fq) & 63) * 8);
+    uint16_t* o = state_h + i * 4;
+    o[0] = v; o[1] = v; o[2] = v; o[3] = v;
 }
 
 // K0b: source ingest.  bool rows [rows][F][C] -> component id per observation (0xFF = none).
@@ -598,6 +656,11 @@ struct Mix2Params {
     int combo_w_off;                                   // byte offset of the weight tile in the combo kernel's LDS
     int combo_tab_off;                                 // byte offset of the one-hot byte -> (state, feature) table
     const uint32_t* state_q;                       // [NQ][Fq]
+    const uint2* state_h;                          // [NQ][Fq] 4 x u16 prepared LDS offsets (k_mixture_tuple64), or null
+    const uint32_t* toff;  int64_t toff_stride;    // per slot [Np] byte offset of the object's tuple block
+    const double2* logtab;                         // [128] {1/c, log c} of tab_log_pos
+    int ragged_w;                                  // valid features of the last tile if it runs in sub-row mode (<= 32), else 0
+    uint64_t* stamps;                              // diagnostic builds (-DSBE_STAMPS): [blocks][4 waves][8] cycle stamps
     const uint8_t* onehot; int rs_pitch;           // [N][rs_pitch] (one-hot variant)
     const uint16_t* gid;   int64_t gid_stride;     // per slot [C][Np]
     const uint8_t* pid;    int64_t pid_stride;     // per slot [Np]
@@ -760,7 +823,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_v2(Mix2Params p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t x = (xs >> (8 * j)) & 0xFFu;
-            const bool valid = x != kNA;
+            const bool valid = x < (uint32_t)S;                     // NA byte: S (data) or 0xFF (padding)
             const uint32_t xc = valid ? x : 0u;
             const uint32_t pj = (pq >> (8 * j)) & 0xFFu;
             const float* tj = tab_l + xc * FT;
@@ -1154,6 +1217,322 @@ __global__ __launch_bounds__(kBlock) void k_mixture_combo(Mix2Params p) {
     const double total = block_sum(sum0 + sum1, red4);
     if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + work] = total;
 }
+
+// ==========================================================================================
+// Group-tuple form, 64-feature tiles, packed stream: the scalar-unit version of k_mixture_combo
+// (default PACKED path at tile width 64 and S <= 127).
+//
+// With FT = 64 a wave step is one object quad, so everything that depends on the object -- its tuple, the
+// tuple's table rows -- is wave-uniform and belongs on the scalar side; the vector side is left with, per
+// observation, ONE address add, ONE conflict-free 8-byte LDS gather and ONE fp64 add:
+//   * state stream `state_h` [NQ][Fq] of 4 x u16 (built once by k_ingest_onehot): the entry of (object n,
+//     feature f) is the observation's byte offset inside a tuple's table block, x*512 + (f%64)*8
+//     (x = S for NA / padding: the block's zero row) -- the lane-constant part of the LDS address is folded
+//     into the data, so no shift, no lane term at run time;
+//   * `toff` [Np] u32 per slot (built by the host with the tuple ids): byte offset of the object's tuple
+//     block, tid*(S+1)*512.  The 16 offsets of a batch of 4 quads arrive with one scalar load
+//     (s_load_dwordx16) straight into SGPRs;
+//   * address = v_add_u32_sdwa(SGPR offset, u16 half of the state dword): one VALU op;
+//   * the state stream is read through a buffer descriptor (constant per-lane offset + scalar row offset: no
+//     vector address arithmetic), one batch ahead;
+//   * each wave owns a contiguous range of the chunk's quads.
+// Table build: a wave owns rows r = w, w+4, .. of the KT*S (tuple, state) rows; per-row offsets (probability
+// rows of the C components, weight pattern, destination) are computed 64 rows at a time on the vector side
+// (lane l <-> row l of the wave) and handed to the scalar side with v_readlane; the probability loads of a
+// batch of rows are in flight before the first log.
+// LDS is addressed absolutely (the kernel has no static LDS, so the dynamic block starts at 0; checked).
+// Same products, same NumPy order, same fp64 log per table entry as the other forms.
+// ==========================================================================================
+typedef __attribute__((address_space(3))) const double lds_cdouble_t;
+typedef __attribute__((address_space(3))) double lds_double_t;
+typedef __attribute__((address_space(3))) unsigned char lds_uchar_t;
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+#define SBE_SDWA_ADD(dst, soff, vx, sel0, sel1)                                                             \
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" sel0 " src1_sel:" sel1   \
+        : "=v"(dst) : "s"(soff), "v"(vx))
+
+template <int CT, bool OFF16>
+__global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
+    constexpr int FT = 64;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    // Block order.  Work items = (tile, chunk); the last tile is LIGHT when it runs in sub-row mode (ragged_w).
+    // Slots are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), and inside an XCD all heavy work
+    // items come before all light ones, so that whatever order the dispatcher fills the CUs in, every CU ends
+    // up with the same mix.  Fewer than 8 slots: plain slot-major order.
+    int slot_i, work;
+    {
+        const int n_chunks = p.n_work / p.n_ftiles;
+        const int n_light = p.ragged_w ? n_chunks : 0, n_heavy = p.n_work - n_light;
+        if (p.n_batch >= 8) {
+            const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+            const int slots_here = (p.n_batch - xcd + 7) >> 3;               // slots xcd, xcd + 8, ...
+            const int heavy_here = slots_here * n_heavy;
+            int sl, wk;
+            if (j < heavy_here) { sl = j / n_heavy; wk = j - sl * n_heavy; wk = (wk / (p.n_ftiles - (n_light ? 1 : 0))) * p.n_ftiles + wk % (p.n_ftiles - (n_light ? 1 : 0)); }
+            else { const int jl = j - heavy_here; sl = jl / max(n_light, 1); wk = (jl - sl * max(n_light, 1)) * p.n_ftiles + (p.n_ftiles - 1); }
+            if (sl >= slots_here || (j >= heavy_here && !n_light)) return;  // padding blocks (before any barrier)
+            slot_i = sl * 8 + xcd; work = wk;
+        } else {
+            slot_i = (int)blockIdx.x / p.n_work; work = (int)blockIdx.x - slot_i * p.n_work;
+            if (slot_i >= p.n_batch) return;
+        }
+    }
+    const int slot = p.first_slot + slot_i;
+    const int tile = work % p.n_ftiles, chunk = work / p.n_ftiles;
+    const int S = p.S, S1 = p.S + 1;
+    const int C = CT ? CT : p.C;
+    constexpr int CU = CT ? CT : kMaxComponents;
+    const int q0 = chunk * p.quads_per_chunk;
+    const int nq = min(p.NQ, q0 + p.quads_per_chunk) - q0;
+    const int KT = p.KT;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lane8 = (uint32_t)lane * 8u;
+#ifdef SBE_STAMPS
+    uint64_t stamp[8]; int n_stamp = 0;
+#define SBE_STAMP() do { stamp[n_stamp++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SBE_STAMP() do {} while (0)
+#endif
+    SBE_STAMP();
+    if ((uint32_t)(uintptr_t)(lds_uchar_t*)lds_raw != 0u) {       // absolute LDS addressing needs base 0
+        if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + work] = __longlong_as_double(0x7FF8000000000000ll);
+        return;
+    }
+    // LDS map (bytes): T [KT][S+1][64] f64 at 0 | weights [P][C][64] f64 at combo_w_off | 4 doubles (reduction)
+    //                  | 128 x {1/c, log c} (tab_log_pos)
+    const uint32_t w_off = (uint32_t)p.combo_w_off;
+    const uint32_t red_off = w_off + (uint32_t)(p.P * C * FT) * 8u;
+    const uint32_t tab_off = red_off + 32u;
+    double* red4 = reinterpret_cast<double*>(lds_raw + red_off);
+    const bool ragged = p.ragged_w != 0 && tile == p.n_ftiles - 1;           // block-uniform
+
+    // this wave's quads [qa, qb) of the chunk
+    const int per = (nq + 3) >> 2;
+    const int qa = min(nq, w * per), qb = min(nq, qa + per);
+    const int n_my = qb - qa;
+    const uint4* toff4 = reinterpret_cast<const uint4*>(p.toff + (int64_t)slot * p.toff_stride) + (q0 + qa);
+    const float* probs_tile = p.probs_t + (int64_t)slot * p.probs_t_stride + (int64_t)tile * ((int64_t)(p.Gtot + 1) * S * FT);
+    const uint16_t* tuple_g = p.tuple_g + (int64_t)slot * p.tuple_g_stride;
+    const uint8_t* tuple_p = p.tuple_p + (int64_t)slot * p.tuple_p_stride;
+    const int n_rows = KT * S;
+
+    // ---- gather operands that can be in flight during the table build (full-tile mode) -----------------
+    // tuple-block offsets of this wave's objects: lane l <-> quad l of a group of 64 quads (one coalesced
+    // 16-byte load per lane and group, handed to the scalar side quad by quad with v_readlane)
+    auto load_offsets = [&](int g0) -> uint4 {                            // g0: first quad of the group (wave-relative)
+        return (g0 + lane < n_my) ? toff4[g0 + lane] : make_uint4(0u, 0u, 0u, 0u);
+    };
+    const __amdgpu_buffer_rsrc_t sh_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(p.state_h)), 0, (int)((uint32_t)p.NQ * (uint32_t)p.Fq * 8u), 0x00020000);
+    const int fcol8 = (tile * FT + lane) * 8;
+    const uint32_t qrow_bytes = (uint32_t)p.Fq * 8u;
+    auto load_quad = [&](int q_wave) -> u32x2_t {                         // 4 x u16 of one quad (wave-relative index,
+        const int q = min(q0 + qa + q_wave, q0 + nq - 1);                 //  clamped to the chunk: always in bounds)
+        return __builtin_amdgcn_raw_buffer_load_b64(sh_rsrc, fcol8, (int)((uint32_t)q * qrow_bytes), 0);
+    };
+    constexpr int QB = 4;                                                  // quads per batch
+    uint4 offv = make_uint4(0u, 0u, 0u, 0u);
+    u32x2_t xa[QB], xb[QB];                                                // two batches of state in flight
+    if (!ragged) {
+        offv = load_offsets(0);
+#pragma unroll
+        for (int i = 0; i < QB; ++i) xa[i] = load_quad(i);
+#pragma unroll
+        for (int i = 0; i < QB; ++i) xb[i] = load_quad(QB + i);
+    }
+
+    {   // weights of the tile, the NA rows, the log table
+        const double* wpat_t = p.wpat_t + (int64_t)slot * p.wpat_t_stride + (int64_t)tile * p.wpat_tile_stride;
+        double* wls = reinterpret_cast<double*>(lds_raw + w_off);
+        for (int k = threadIdx.x; k < p.P * C * FT; k += kBlock) wls[k] = wpat_t[k];
+        double* T = reinterpret_cast<double*>(lds_raw);
+        for (int e = threadIdx.x; e < KT * FT; e += kBlock) T[((e >> 6) * S1 + S) * FT + (e & 63)] = 0.0;
+        reinterpret_cast<double*>(lds_raw + tab_off)[threadIdx.x] = reinterpret_cast<const double*>(p.logtab)[threadIdx.x];   // 256 doubles
+    }
+    SBE_STAMP();
+    __syncthreads();
+    SBE_STAMP();
+
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (!ragged) {
+        // ---- log table: a wave owns rows r = w, w+4, .. of the KT*S (tuple, state) rows --------------------
+        {
+            const __amdgpu_buffer_rsrc_t pr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(probs_tile), 0, (int)((uint32_t)(p.Gtot + 1) * (uint32_t)S * FT * 4u), 0x00020000);
+            const bool live = tile * FT + lane < p.F;
+            const int lane4 = lane * 4;
+            const int my_rows = n_rows > w ? (n_rows - w + 3) >> 2 : 0;
+            constexpr int U = CU <= 2 ? 8 : (CU <= 4 ? 4 : 2);
+            for (int base = 0; base < my_rows; base += kWave) {
+                // lane l <-> row base + l of this wave: offsets of everything the row needs
+                const int ri = base + lane;
+                const uint32_t r = (uint32_t)(w + 4 * min(ri, my_rows - 1));
+                const uint32_t t = r / (uint32_t)S, st = r - t * (uint32_t)S;
+                uint32_t v_goff[CU];
+#pragma unroll
+                for (int c = 0; c < CU; ++c)
+                    v_goff[c] = (CT || c < C) ? ((uint32_t)tuple_g[t * kMaxComponents + c] * (uint32_t)S + st) * (FT * 4u) : 0u;
+                const uint32_t v_woff = w_off + (uint32_t)tuple_p[t] * (uint32_t)(C * FT * 8);
+                const uint32_t v_doff = (t * (uint32_t)S1 + st) * (FT * 8u);
+                const int n_here = min(kWave, my_rows - base);
+                for (int i0 = 0; i0 < n_here; i0 += U) {
+                    float pr[U][CU];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (i0 + u < n_here) {
+#pragma unroll
+                            for (int c = 0; c < CU; ++c)
+                                if (CT || c < C)
+                                    pr[u][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                        pr_rsrc, lane4, __builtin_amdgcn_readlane((int)v_goff[c], i0 + u), 0));
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (i0 + u < n_here) {
+                            const uint32_t woff = (uint32_t)__builtin_amdgcn_readlane((int)v_woff, i0 + u) + lane8;
+                            const uint32_t doff = (uint32_t)__builtin_amdgcn_readlane((int)v_doff, i0 + u) + lane8;
+                            double v = 0.0;
+#pragma unroll
+                            for (int c = 0; c < CU; ++c) {
+                                if (CT || c < C) {
+                                    const double wc = *(lds_cdouble_t*)(uintptr_t)(woff + (uint32_t)c * (FT * 8u));
+                                    const double term = wc * (double)pr[u][c];
+                                    v = c == 0 ? term : v + term;               // NumPy order, no FMA
+                                }
+                            }
+#ifdef SBE_ABL_NOLOG
+                            *(lds_double_t*)(uintptr_t)doff = live ? v : 1.0;
+#else
+                            *(lds_double_t*)(uintptr_t)doff = tab_log_pos(live ? v : 1.0, tab_off);   // dead lanes of the last tile: log 1
+#endif
+                        }
+                    }
+                }
+            }
+        }
+        SBE_STAMP();
+        __syncthreads();
+        SBE_STAMP();
+
+        // ---- gather: one address add + one LDS read + one fp64 add per observation ----------------------
+        // OFF16: every tuple block starts below 64 KiB, so two offsets share an SGPR (2 v_readlane per quad
+        // instead of 4) and the address add selects the halves of BOTH operands
+        uint32_t olo = OFF16 ? (offv.x | (offv.y << 16)) : 0u, ohi = OFF16 ? (offv.z | (offv.w << 16)) : 0u;
+        auto quad = [&](const u32x2_t x, int ql) {                          // ql: quad's lane in the offset group
+            uint32_t ad0, ad1, ad2, ad3;
+            if (OFF16) {
+                const uint32_t s01 = (uint32_t)__builtin_amdgcn_readlane((int)olo, ql);
+                const uint32_t s23 = (uint32_t)__builtin_amdgcn_readlane((int)ohi, ql);
+                SBE_SDWA_ADD(ad0, s01, x.x, "WORD_0", "WORD_0"); SBE_SDWA_ADD(ad1, s01, x.x, "WORD_1", "WORD_1");
+                SBE_SDWA_ADD(ad2, s23, x.y, "WORD_0", "WORD_0"); SBE_SDWA_ADD(ad3, s23, x.y, "WORD_1", "WORD_1");
+            } else {
+                const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)offv.x, ql);
+                const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)offv.y, ql);
+                const uint32_t s2 = (uint32_t)__builtin_amdgcn_readlane((int)offv.z, ql);
+                const uint32_t s3 = (uint32_t)__builtin_amdgcn_readlane((int)offv.w, ql);
+                SBE_SDWA_ADD(ad0, s0, x.x, "DWORD", "WORD_0"); SBE_SDWA_ADD(ad1, s1, x.x, "DWORD", "WORD_1");
+                SBE_SDWA_ADD(ad2, s2, x.y, "DWORD", "WORD_0"); SBE_SDWA_ADD(ad3, s3, x.y, "DWORD", "WORD_1");
+            }
+            a0 += *(lds_cdouble_t*)(uintptr_t)ad0; a1 += *(lds_cdouble_t*)(uintptr_t)ad1;
+            a2 += *(lds_cdouble_t*)(uintptr_t)ad2; a3 += *(lds_cdouble_t*)(uintptr_t)ad3;
+        };
+#ifdef SBE_ABL_NOGATHER
+        if (p.N < 0)
+#endif
+        for (int g0 = 0; g0 < n_my; g0 += kWave) {                          // groups of 64 quads (one offset load)
+            const int ng = min(kWave, n_my - g0);
+            if (g0) {
+                offv = load_offsets(g0);
+                if (OFF16) { olo = offv.x | (offv.y << 16); ohi = offv.z | (offv.w << 16); }
+#pragma unroll
+                for (int i = 0; i < QB; ++i) xa[i] = load_quad(g0 + i);
+#pragma unroll
+                for (int i = 0; i < QB; ++i) xb[i] = load_quad(g0 + QB + i);
+            }
+            // batches alternate between the two register sets; a set is refilled (two batches ahead) as soon
+            // as it has been consumed
+            int i = 0;
+            for (; i + 2 * QB <= ng; i += 2 * QB) {
+#pragma unroll
+                for (int j = 0; j < QB; ++j) quad(xa[j], i + j);
+#pragma unroll
+                for (int j = 0; j < QB; ++j) xa[j] = load_quad(g0 + i + 2 * QB + j);
+#pragma unroll
+                for (int j = 0; j < QB; ++j) quad(xb[j], i + QB + j);
+#pragma unroll
+                for (int j = 0; j < QB; ++j) xb[j] = load_quad(g0 + i + 3 * QB + j);
+            }
+            // tail (< 2*QB quads): already loaded, in xa then xb
+            for (int j = 0; i < ng; ++i, ++j) {
+                u32x2_t x = xa[0];
+#pragma unroll
+                for (int k = 1; k < QB; ++k) x = j == k ? xa[k] : x;
+#pragma unroll
+                for (int k = 0; k < QB; ++k) x = j == QB + k ? xb[k] : x;
+                quad(x, i);
+            }
+        }
+    } else {
+        // ---- sub-row mode for a narrow last tile (ragged_w <= 32 valid features): RW lanes per row, 64/RW
+        // rows per wave step, everything per lane (vector side).  ~64/RW times less work than a full tile. --
+        int sh = 0;
+        while ((1 << sh) < p.ragged_w) ++sh;                                 // RW = 1 << sh lanes per row
+        const int RW = 1 << sh, SUB = kWave >> sh;
+        const int fl = lane & (RW - 1), sub = lane >> sh;
+        const bool live = fl < p.ragged_w;
+        for (int r0 = w * SUB; r0 < n_rows; r0 += 4 * SUB) {
+            const int r = r0 + sub;
+            if (r < n_rows) {
+                const uint32_t t = (uint32_t)r / (uint32_t)S, st = (uint32_t)r - t * (uint32_t)S;
+                const double* wr = reinterpret_cast<const double*>(lds_raw + w_off) + (uint32_t)tuple_p[t] * (uint32_t)(C * FT) + fl;
+                double v = 0.0;
+#pragma unroll
+                for (int c = 0; c < CU; ++c) {
+                    if (CT || c < C) {
+                        const float pc = probs_tile[((uint32_t)tuple_g[t * kMaxComponents + c] * (uint32_t)S + st) * FT + fl];
+                        const double term = wr[c * FT] * (double)pc;
+                        v = c == 0 ? term : v + term;                           // NumPy order, no FMA
+                    }
+                }
+                *(lds_double_t*)(uintptr_t)((t * (uint32_t)S1 + st) * (FT * 8u) + (uint32_t)fl * 8u) = tab_log_pos(live ? v : 1.0, tab_off);
+            }
+        }
+        SBE_STAMP();
+        __syncthreads();
+        SBE_STAMP();
+        const uint2* sh2 = p.state_h + (int64_t)(q0 + qa) * p.Fq + (tile * FT + fl);
+#ifdef SBE_ABL_NOGATHER
+        if (p.N < 0)
+#endif
+        for (int ql0 = 0; ql0 < n_my; ql0 += SUB) {
+            const int ql = ql0 + sub;
+            if (ql < n_my) {
+                const uint2 x = sh2[(int64_t)ql * p.Fq];
+                const uint4 o = toff4[ql];
+                a0 += *(lds_cdouble_t*)(uintptr_t)(o.x + (x.x & 0xFFFFu));
+                a1 += *(lds_cdouble_t*)(uintptr_t)(o.y + (x.x >> 16));
+                a2 += *(lds_cdouble_t*)(uintptr_t)(o.z + (x.y & 0xFFFFu));
+                a3 += *(lds_cdouble_t*)(uintptr_t)(o.w + (x.y >> 16));
+            }
+        }
+    }
+    SBE_STAMP();
+    const double total = block_sum((a0 + a2) + (a1 + a3), red4);
+    if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + work] = total;
+#ifdef SBE_STAMPS
+    SBE_STAMP();
+    if (p.stamps && lane == 0) {
+        uint64_t* o = p.stamps + ((int64_t)blockIdx.x * 4 + w) * 8;
+        for (int i = 0; i < n_stamp; ++i) o[i] = stamp[i];
+        o[7] = (uint64_t)ragged;
+    }
+#endif
+}
+#undef SBE_STAMP
+#undef SBE_SDWA_ADD
 
 // ==========================================================================================
 // cluster-membership marginals

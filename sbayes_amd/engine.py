@@ -14,6 +14,7 @@ import numpy as np
 from . import _lib
 
 MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE, MIXTURE_ONEHOT_GENERAL = 0, 1, 2, 3, 4
+MIXTURE_PACKED_TUPLE_LDS = 5
 LOG_PER_OBS, LOG_PRODUCT = 0, 1
 _OPT_KERNEL, _OPT_LOG, _OPT_DEFERRED = 1, 2, 3
 
@@ -508,6 +509,13 @@ class Engine:
         a, b = np.empty_like(x), np.empty_like(x)
         self._check(self._lib.sbe_test_fast_log(self._h, _ptr(x), x.size, _ptr(a), _ptr(b)))
         return a, b
+
+    def test_tab_log(self, x):
+        """Table-driven fp64 log of k_mixture_tuple64's table build, computed on the device (self-test)."""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        out = np.empty_like(x)
+        self._check(self._lib.sbe_test_tab_log(self._h, _ptr(x), x.size, _ptr(out)))
+        return out
 
     def copy_slot(self, dst, src):
         self._check(self._lib.sbe_copy_slot(self._h, dst, src))

@@ -9,7 +9,7 @@ import pytest
 
 from oracle import sbayes_oracle as orc
 from sbayes_amd.engine import (LOG_PER_OBS, LOG_PRODUCT, MIXTURE_ONEHOT, MIXTURE_PACKED, MIXTURE_ONEHOT_GENERAL, MIXTURE_PACKED_GENERAL,
-                               MIXTURE_PACKED_TUPLE, Engine, EngineError)
+                               MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, Engine, EngineError)
 from sbayes_amd.synthetic import make_state, make_workload
 from tests._fixtures import GOLDEN, crc, load_json, load_npz
 
@@ -62,7 +62,8 @@ def test_dense_outputs_bit_exact(name):
 
 
 @pytest.mark.parametrize("name", NPZ)
-@pytest.mark.parametrize("kernel", [MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE, MIXTURE_ONEHOT_GENERAL])
+@pytest.mark.parametrize("kernel", [MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS,
+                                    MIXTURE_ONEHOT_GENERAL])
 @pytest.mark.parametrize("log_mode", [LOG_PER_OBS, LOG_PRODUCT])
 def test_mixture_loglik(name, kernel, log_mode):
     fx = load_npz(name)
@@ -173,7 +174,7 @@ def test_big_synthetic_against_reference_digests(name):
         assert crc(eng.observation_lh(0)) == meta["obs_crc"]
         assert crc(eng.likelihood_per_component_exact(0)) == meta["lh_exact_crc"]
         want = meta["mixture_ll"]
-        for kernel in (MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_ONEHOT_GENERAL) + ((MIXTURE_PACKED_TUPLE,) if name == "headline" else ()):
+        for kernel in (MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_ONEHOT_GENERAL) + ((MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS) if name == "headline" else ()):
             for log_mode in (LOG_PER_OBS, LOG_PRODUCT):
                 eng.set_option(kernel=kernel, log_mode=log_mode)
                 ll = eng.mixture_loglik(0)
@@ -202,7 +203,7 @@ def test_batch_of_states_matches_oracle():
             want.append(orc.mixture_loglik(wl.features, wl.na_values, groups, counts, wl.concentration, weights))
         got = eng.mixture_loglik_batch(0, B)
         np.testing.assert_allclose(got, np.array(want), rtol=MIX_RTOL)
-        for kernel in (MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_GENERAL, MIXTURE_ONEHOT, MIXTURE_ONEHOT_GENERAL):
+        for kernel in (MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, MIXTURE_PACKED_GENERAL, MIXTURE_ONEHOT, MIXTURE_ONEHOT_GENERAL):
             eng.set_option(kernel=kernel)
             np.testing.assert_allclose(eng.mixture_loglik_batch(0, B), np.array(want), rtol=MIX_RTOL)
         eng.set_option(kernel=MIXTURE_PACKED)
@@ -317,5 +318,19 @@ def test_fast_log_accuracy():
         assert err.max() <= 1.0, (err.max(), x[err.argmax()])
         assert fast[x == 1.0][0] == 0.0
         special, _ = eng.test_fast_log(np.array([0.0, -1.0, np.inf, np.nan, 5e-324]))
+        assert special[0] == -np.inf and np.isnan(special[1]) and special[2] == np.inf and np.isnan(special[3])
+        assert np.isclose(special[4], np.log(5e-324), rtol=1e-15)
+        # table-driven log of k_mixture_tuple64: <= 1 ulp + 2^-53 absolute (the absolute term shows only where
+        # k*ln2 + log c cancels, just below 1); log(1) = 0 exactly; special values through the library log
+        xs = np.concatenate([x, 1.0 - rng.random(100000) * 2.0 ** -8, 1.0 + rng.random(100000) * 2.0 ** -7,
+                             1.0 + rng.uniform(-1e-9, 1e-9, 10000)])
+        tab = eng.test_tab_log(xs)
+        want = np.log(xs)
+        ulp = np.spacing(np.abs(want))
+        ulp[want == 0] = 0.0
+        err = np.abs(tab - want) / (ulp + 2.0 ** -53)
+        assert err.max() <= 1.5, (err.max(), xs[err.argmax()])        # 1.5: NumPy's own log is within 0.5 ulp
+        assert tab[xs == 1.0][0] == 0.0
+        special = eng.test_tab_log(np.array([0.0, -1.0, np.inf, np.nan, 5e-324]))
         assert special[0] == -np.inf and np.isnan(special[1]) and special[2] == np.inf and np.isnan(special[3])
         assert np.isclose(special[4], np.log(5e-324), rtol=1e-15)

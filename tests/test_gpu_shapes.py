@@ -9,7 +9,7 @@ import pytest
 
 from oracle import sbayes_oracle as orc
 from sbayes_amd.engine import (LOG_PER_OBS, LOG_PRODUCT, MIXTURE_ONEHOT, MIXTURE_PACKED, MIXTURE_ONEHOT_GENERAL, MIXTURE_PACKED_GENERAL,
-                               MIXTURE_PACKED_TUPLE, Engine, EngineError)
+                               MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, Engine, EngineError)
 
 pytestmark = pytest.mark.gpu
 
@@ -126,13 +126,14 @@ def _run_case(feats, groups, weights, source, conc, n_groups, rng, light=False):
             assert np.array_equal(eng.likelihood_per_component_exact(0),
                                   orc.likelihood_per_component_exact(feats, na, groups, counts, conc, source))
             want = np.log(obs)[~na].sum()
-        for kernel in (MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE, MIXTURE_ONEHOT_GENERAL):
+        for kernel in (MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS,
+                       MIXTURE_ONEHOT_GENERAL):
             for log_mode in (LOG_PER_OBS, LOG_PRODUCT):
                 eng.set_option(kernel=kernel, log_mode=log_mode)
                 try:
                     got = eng.mixture_loglik(0)
                 except EngineError as exc:
-                    if kernel == MIXTURE_PACKED_TUPLE and "not applicable" in str(exc):
+                    if kernel in (MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS) and "not applicable" in str(exc):
                         continue                 # more than 64 distinct group tuples / table too large
                     raise
                 if np.isfinite(want):
