@@ -536,15 +536,15 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
 #ifdef SBE_STAMPS
         static uint64_t* d_stamps = nullptr;
         if (combo && tuple64 && getenv("SBE_STAMPS_FILE")) {
-            if (!d_stamps) (void)hipMalloc((void**)&d_stamps, (size_t)grid.x * 32 * sizeof(uint64_t));
-            (void)hipMemsetAsync(d_stamps, 0, (size_t)grid.x * 32 * sizeof(uint64_t), e->stream);
+            if (!d_stamps) (void)hipMalloc((void**)&d_stamps, (size_t)grid.x * 48 * sizeof(uint64_t));
+            (void)hipMemsetAsync(d_stamps, 0, (size_t)grid.x * 48 * sizeof(uint64_t), e->stream);
             p.stamps = d_stamps;
         }
 #endif
         if (combo && tuple64) launch_tuple64(e->C, p, grid, combo_lds, e->stream);
 #ifdef SBE_STAMPS
         if (p.stamps) {
-            std::vector<uint64_t> h((size_t)grid.x * 32);
+            std::vector<uint64_t> h((size_t)grid.x * 48);
             (void)hipStreamSynchronize(e->stream);
             (void)hipMemcpy(h.data(), d_stamps, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
             FILE* f = fopen(getenv("SBE_STAMPS_FILE"), "wb");

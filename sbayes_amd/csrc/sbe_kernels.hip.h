@@ -1291,6 +1291,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
     const uint32_t lane8 = (uint32_t)lane * 8u;
 #ifdef SBE_STAMPS
     uint64_t stamp[8]; int n_stamp = 0;
+    const uint64_t rt0 = wall_clock64();
 #define SBE_STAMP() do { stamp[n_stamp++] = __builtin_readcyclecounter(); } while (0)
 #else
 #define SBE_STAMP() do {} while (0)
@@ -1332,9 +1333,11 @@ __global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
         const int q = min(q0 + qa + q_wave, q0 + nq - 1);                 //  clamped to the chunk: always in bounds)
         return __builtin_amdgcn_raw_buffer_load_b64(sh_rsrc, fcol8, (int)((uint32_t)q * qrow_bytes), 0);
     };
-    constexpr int QB = 4;                                                  // quads per batch
+    // two batches of QB quads of the state stream are kept in flight (measured: a deeper rolling window does
+    // not pay -- the gather runs at ~80 % of its VALU issue bound and wants its 32 LDS reads per trip batched)
+    constexpr int QB = 4;
     uint4 offv = make_uint4(0u, 0u, 0u, 0u);
-    u32x2_t xa[QB], xb[QB];                                                // two batches of state in flight
+    u32x2_t xa[QB], xb[QB];
     if (!ragged) {
         offv = load_offsets(0);
 #pragma unroll
@@ -1342,6 +1345,40 @@ __global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
 #pragma unroll
         for (int i = 0; i < QB; ++i) xb[i] = load_quad(QB + i);
     }
+
+    // ---- table-build operands of the wave's first rows, also in flight before the first barrier --------
+    // A wave owns rows r = w, w+4, .. of the KT*S (tuple, state) rows; lane l <-> its l-th row (64 rows per
+    // pass): the offsets of everything a row needs are computed on the vector side and handed to the scalar
+    // side row by row with v_readlane; the probability loads of a batch of U rows are issued together.
+    const __amdgpu_buffer_rsrc_t pr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(probs_tile), 0, (int)((uint32_t)(p.Gtot + 1) * (uint32_t)S * FT * 4u), 0x00020000);
+    const int lane4 = lane * 4;
+    const int my_rows = (!ragged && n_rows > w) ? (n_rows - w + 3) >> 2 : 0;
+    constexpr int U = CU <= 2 ? 16 : (CU <= 4 ? 8 : 4);
+    uint32_t v_goff[CU], v_woff = 0u, v_doff = 0u;
+    auto row_offsets = [&](int base) {
+        const uint32_t r = (uint32_t)(w + 4 * min(base + lane, my_rows - 1));
+        const uint32_t t = r / (uint32_t)S, st = r - t * (uint32_t)S;
+#pragma unroll
+        for (int c = 0; c < CU; ++c)
+            v_goff[c] = (CT || c < C) ? ((uint32_t)tuple_g[t * kMaxComponents + c] * (uint32_t)S + st) * (FT * 4u) : 0u;
+        v_woff = w_off + (uint32_t)tuple_p[t] * (uint32_t)(C * FT * 8);
+        v_doff = (t * (uint32_t)S1 + st) * (FT * 8u);
+    };
+    float pr[U][CU];
+    auto row_loads = [&](int i0, int n_here) {                             // rows i0 .. i0+U-1 of the current pass
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u < n_here) {
+#pragma unroll
+                for (int c = 0; c < CU; ++c)
+                    if (CT || c < C)
+                        pr[u][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            pr_rsrc, lane4, __builtin_amdgcn_readlane((int)v_goff[c], i0 + u), 0));
+            }
+        }
+    };
+    if (my_rows > 0) { row_offsets(0); row_loads(0, min(kWave, my_rows)); }
 
     {   // weights of the tile, the NA rows, the log table
         const double* wpat_t = p.wpat_t + (int64_t)slot * p.wpat_t_stride + (int64_t)tile * p.wpat_tile_stride;
@@ -1357,38 +1394,14 @@ __global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
 
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (!ragged) {
-        // ---- log table: a wave owns rows r = w, w+4, .. of the KT*S (tuple, state) rows --------------------
+        // ---- log table ------------------------------------------------------------------------------------
         {
-            const __amdgpu_buffer_rsrc_t pr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(probs_tile), 0, (int)((uint32_t)(p.Gtot + 1) * (uint32_t)S * FT * 4u), 0x00020000);
             const bool live = tile * FT + lane < p.F;
-            const int lane4 = lane * 4;
-            const int my_rows = n_rows > w ? (n_rows - w + 3) >> 2 : 0;
-            constexpr int U = CU <= 2 ? 8 : (CU <= 4 ? 4 : 2);
             for (int base = 0; base < my_rows; base += kWave) {
-                // lane l <-> row base + l of this wave: offsets of everything the row needs
-                const int ri = base + lane;
-                const uint32_t r = (uint32_t)(w + 4 * min(ri, my_rows - 1));
-                const uint32_t t = r / (uint32_t)S, st = r - t * (uint32_t)S;
-                uint32_t v_goff[CU];
-#pragma unroll
-                for (int c = 0; c < CU; ++c)
-                    v_goff[c] = (CT || c < C) ? ((uint32_t)tuple_g[t * kMaxComponents + c] * (uint32_t)S + st) * (FT * 4u) : 0u;
-                const uint32_t v_woff = w_off + (uint32_t)tuple_p[t] * (uint32_t)(C * FT * 8);
-                const uint32_t v_doff = (t * (uint32_t)S1 + st) * (FT * 8u);
                 const int n_here = min(kWave, my_rows - base);
+                if (base) row_offsets(base);
                 for (int i0 = 0; i0 < n_here; i0 += U) {
-                    float pr[U][CU];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        if (i0 + u < n_here) {
-#pragma unroll
-                            for (int c = 0; c < CU; ++c)
-                                if (CT || c < C)
-                                    pr[u][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                        pr_rsrc, lane4, __builtin_amdgcn_readlane((int)v_goff[c], i0 + u), 0));
-                        }
-                    }
+                    if (base || i0) row_loads(i0, n_here);                      // (the first batch is already in flight)
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         if (i0 + u < n_here) {
@@ -1507,15 +1520,22 @@ __global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
 #ifdef SBE_ABL_NOGATHER
         if (p.N < 0)
 #endif
-        for (int ql0 = 0; ql0 < n_my; ql0 += SUB) {
-            const int ql = ql0 + sub;
-            if (ql < n_my) {
-                const uint2 x = sh2[(int64_t)ql * p.Fq];
-                const uint4 o = toff4[ql];
-                a0 += *(lds_cdouble_t*)(uintptr_t)(o.x + (x.x & 0xFFFFu));
-                a1 += *(lds_cdouble_t*)(uintptr_t)(o.y + (x.x >> 16));
-                a2 += *(lds_cdouble_t*)(uintptr_t)(o.z + (x.y & 0xFFFFu));
-                a3 += *(lds_cdouble_t*)(uintptr_t)(o.w + (x.y >> 16));
+        for (int ql0 = 0; ql0 < n_my; ql0 += 8 * SUB) {                      // 8 steps' loads in flight
+            uint2 x[8]; uint4 o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ql = min(ql0 + u * SUB + sub, n_my - 1);
+                x[u] = sh2[(int64_t)ql * p.Fq];
+                o[u] = toff4[ql];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (ql0 + u * SUB + sub < n_my) {
+                    a0 += *(lds_cdouble_t*)(uintptr_t)(o[u].x + (x[u].x & 0xFFFFu));
+                    a1 += *(lds_cdouble_t*)(uintptr_t)(o[u].y + (x[u].x >> 16));
+                    a2 += *(lds_cdouble_t*)(uintptr_t)(o[u].z + (x[u].y & 0xFFFFu));
+                    a3 += *(lds_cdouble_t*)(uintptr_t)(o[u].w + (x[u].y >> 16));
+                }
             }
         }
     }
@@ -1525,9 +1545,9 @@ __global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
 #ifdef SBE_STAMPS
     SBE_STAMP();
     if (p.stamps && lane == 0) {
-        uint64_t* o = p.stamps + ((int64_t)blockIdx.x * 4 + w) * 8;
+        uint64_t* o = p.stamps + ((int64_t)blockIdx.x * 4 + w) * 12;
         for (int i = 0; i < n_stamp; ++i) o[i] = stamp[i];
-        o[7] = (uint64_t)ragged;
+        o[7] = (uint64_t)ragged; o[8] = rt0; o[9] = wall_clock64();
     }
 #endif
 }
