@@ -7,7 +7,8 @@ Metric (BASELINE.json): log-likelihood evals/sec at 1000 sites x 200 feats x 10 
 
 A "step" = one pass of the hot path over one batch: `--batch` B distinct resident sample
 states (independent chains / candidate states of the sampler, sbayes/sampling/mcmc.py:239-241)
-evaluated by one launch sequence of the fused kernel.  Everything (feature block, group ids,
+evaluated by one launch sequence of the fused kernel (default B = 1024: four generations of
+workgroups per launch; `batch_sweep` in the output line reports B = 1 .. 1024).  Everything (feature block, group ids,
 probability tables, weights) is resident in HBM before the timed region; the B scalars are
 fetched to the host inside the timed region.
 
@@ -47,7 +48,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="headline", choices=["cfg1", "headline", "stress"])
-    ap.add_argument("--batch", type=int, default=256,
+    ap.add_argument("--batch", type=int, default=1024,
                     help="resident sample states (chains x candidate states) evaluated per step")
     ap.add_argument("--kernel", default="packed", choices=["packed", "packed_general", "packed_tuple_lds", "onehot", "onehot_general"],
                     help="packed: state-index stream, group-tuple form when it applies (default); "
@@ -124,7 +125,7 @@ def secondary_figures(eng, wl, B, args):
     _t, k1 = eng.profile_mixture(0, 1, 100)
     out["single_eval_kernel_us"] = round(k1 * 1e3, 3)
     sweep = {}
-    for b in (1, 8, 64, 256):
+    for b in (1, 8, 64, 256, 1024):
         if b > B:
             break
         eng.sync()
@@ -269,7 +270,8 @@ def main():
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-        "kernel": {"packed": "k_mixture_combo (group-tuple form; k_mixture_v2 when not applicable)",
+        "kernel": {"packed": "k_mixture_tuple64 (group-tuple form, 64-feature tiles; k_mixture_combo / k_mixture_v2 when not applicable)",
+                   "packed_tuple_lds": "k_mixture_combo (group-tuple form, LDS-metadata variant)",
                    "packed_general": f"k_mixture_v2<{args.log_mode}>",
                    "onehot": "k_mixture_combo<onehot> (group-tuple form; k_mixture_onehot_v2 when not applicable)",
                    "onehot_general": f"k_mixture_onehot_v2<{args.log_mode}>"}[args.kernel],

@@ -527,8 +527,11 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
         p.toff = e->d_toff; p.toff_stride = e->Np;
         p.logtab = e->d_logtab;
         p.ragged_w = (tuple64 && e->F % 64 != 0 && e->F % 64 <= 32) ? e->F % 64 : 0;
-        if (combo && tuple64)     // own block order (slots dealt to XCDs, heavy work items first; see the kernel)
-            grid = n >= 8 ? dim3(8 * div_up(n, 8) * g.n_blocks, 1) : dim3(n * g.n_blocks, 1);
+        if (combo && tuple64) {   // own block order (slots dealt to XCDs, generations, heavy work items first; see the kernel)
+            p.gen_slots = std::max(1, (4 * e->compute_units / 8) / g.n_blocks);
+            const int gens = div_up(div_up(n, 8), p.gen_slots);
+            grid = n >= 8 ? dim3(8 * gens * p.gen_slots * g.n_blocks, 1) : dim3(n * g.n_blocks, 1);
+        }
         p.tuple_g = e->d_tuple_g; p.tuple_g_stride = (int64_t)kMaxTuples * kMaxComponents;
         p.tuple_p = e->d_tuple_p; p.tuple_p_stride = kMaxTuples;
         p.combo_w_off = combo_w_off; p.combo_tab_off = combo_tab_off;

@@ -659,6 +659,7 @@ struct Mix2Params {
     const uint2* state_h;                          // [NQ][Fq] 4 x u16 prepared LDS offsets (k_mixture_tuple64), or null
     const uint32_t* toff;  int64_t toff_stride;    // per slot [Np] byte offset of the object's tuple block
     const double2* logtab;                         // [128] {1/c, log c} of tab_log_pos
+    int gen_slots;                                 // k_mixture_tuple64 block order: slots per XCD and generation
     int ragged_w;                                  // valid features of the last tile if it runs in sub-row mode (<= 32), else 0
     uint64_t* stamps;                              // diagnostic builds (-DSBE_STAMPS): [blocks][4 waves][8] cycle stamps
     const uint8_t* onehot; int rs_pitch;           // [N][rs_pitch] (one-hot variant)
@@ -1257,9 +1258,10 @@ __global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
     constexpr int FT = 64;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // Block order.  Work items = (tile, chunk); the last tile is LIGHT when it runs in sub-row mode (ragged_w).
-    // Slots are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), and inside an XCD all heavy work
-    // items come before all light ones, so that whatever order the dispatcher fills the CUs in, every CU ends
-    // up with the same mix.  Fewer than 8 slots: plain slot-major order.
+    // Slots are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8).  Inside an XCD the blocks come in
+    // generations of `gen_slots` slots (one generation = as many blocks as the XCD's CUs hold at once), and
+    // inside a generation all heavy work items come before all light ones, so that whatever order the
+    // dispatcher fills the CUs in, every CU ends up with the same mix.  Fewer than 8 slots: slot-major order.
     int slot_i, work;
     {
         const int n_chunks = p.n_work / p.n_ftiles;
@@ -1267,12 +1269,20 @@ __global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
         if (p.n_batch >= 8) {
             const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
             const int slots_here = (p.n_batch - xcd + 7) >> 3;               // slots xcd, xcd + 8, ...
-            const int heavy_here = slots_here * n_heavy;
+            const int gen = j / (p.gen_slots * p.n_work), jj = j - gen * (p.gen_slots * p.n_work);
+            const int s0 = gen * p.gen_slots, s_gen = min(p.gen_slots, slots_here - s0);   // this generation's slots
+            if (s_gen <= 0) return;                                          // padding blocks (before any barrier)
+            const int heavy_gen = s_gen * n_heavy;
             int sl, wk;
-            if (j < heavy_here) { sl = j / n_heavy; wk = j - sl * n_heavy; wk = (wk / (p.n_ftiles - (n_light ? 1 : 0))) * p.n_ftiles + wk % (p.n_ftiles - (n_light ? 1 : 0)); }
-            else { const int jl = j - heavy_here; sl = jl / max(n_light, 1); wk = (jl - sl * max(n_light, 1)) * p.n_ftiles + (p.n_ftiles - 1); }
-            if (sl >= slots_here || (j >= heavy_here && !n_light)) return;  // padding blocks (before any barrier)
-            slot_i = sl * 8 + xcd; work = wk;
+            if (jj < heavy_gen) {
+                const int ht = p.n_ftiles - (n_light ? 1 : 0);               // heavy tiles
+                sl = jj / n_heavy; wk = jj - sl * n_heavy; wk = (wk / ht) * p.n_ftiles + wk % ht;
+            } else {
+                const int jl = jj - heavy_gen;
+                if (jl >= s_gen * n_light) return;                           // padding
+                sl = jl / n_light; wk = (jl - sl * n_light) * p.n_ftiles + (p.n_ftiles - 1);
+            }
+            slot_i = (s0 + sl) * 8 + xcd; work = wk;
         } else {
             slot_i = (int)blockIdx.x / p.n_work; work = (int)blockIdx.x - slot_i * p.n_work;
             if (slot_i >= p.n_batch) return;

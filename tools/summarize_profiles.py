@@ -54,12 +54,13 @@ corr4 = 1.0 / calib["read_dword"]["reported_fraction"] if "read_dword" in calib 
 corr16 = 1.0 / calib["read_dwordx4"]["reported_fraction"] if "read_dwordx4" in calib else None
 
 traffic = {}
-for wl, batch in (("headline", 256), ("stress", 8)):
-    for kern in ("packed", "packed_general", "onehot", "onehot_general"):
-        if wl == "stress" and kern.endswith("_general"):
+for wl, batch in (("headline", 1024), ("stress", 8)):
+    for kern in ("packed", "packed_tuple_lds", "packed_general", "onehot", "onehot_general"):
+        if wl == "stress" and kern not in ("packed", "onehot"):
             continue
         suffix = kern if wl == "headline" else f"stress_{kern}"
-        prefix = {"packed": "sbe::k_mixture_combo" if wl == "headline" else "sbe::k_mixture_v2",
+        prefix = {"packed": "sbe::k_mixture_tuple64" if wl == "headline" else "sbe::k_mixture_v2",
+                  "packed_tuple_lds": "sbe::k_mixture_combo",
                   "packed_general": "sbe::k_mixture_v2",
                   "onehot": "sbe::k_mixture_combo" if wl == "headline" else "sbe::k_mixture_onehot_v2",
                   "onehot_general": "sbe::k_mixture_onehot_v2"}[kern]
@@ -70,7 +71,7 @@ for wl, batch in (("headline", 256), ("stress", 8)):
             raw = fetch["FETCH_SIZE"]["mean"] * 1024
             # packed streams 4-byte lane loads + 16-byte table staging, onehot 16-byte lane loads:
             # apply the calibrated factor of the dominant access width
-            factor = (corr16 if kern.startswith("onehot") else corr4) or 1.0
+            factor = (corr16 if kern.startswith("onehot") else corr4) or 2.0     # (gfx950: FETCH_SIZE reports 1/2)
             entry.update(fetch_raw_bytes=raw, fetch_correction=factor, fetch_bytes=raw * factor)
         if "WRITE_SIZE" in write:
             entry["write_bytes"] = write["WRITE_SIZE"]["mean"] * 1024
