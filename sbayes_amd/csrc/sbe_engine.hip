@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -25,6 +26,10 @@ struct Slot {
     std::vector<uint8_t> h_pid;           // [N]
     std::vector<uint32_t> patterns;       // distinct has_components bit patterns, sorted like np.unique
     int n_tuples = 0;                     // distinct group tuples of the objects (0 = more than kMaxTuples)
+    std::vector<uint8_t> h_tid;           // [Np] tuple index per object            } host mirrors of the group-tuple
+    std::vector<uint32_t> h_toff;         // [Np] tid * (S+1) * 512                  } tables (valid when n_tuples > 0;
+    std::vector<uint16_t> h_tuple_g;      // [kMaxTuples][kMaxComponents]            } the one-call step ships them in
+    std::vector<uint8_t> h_tuple_p;       // [kMaxTuples]                            } its payload)
     bool groups_set = false, weights_set = false, source_set = false;
     std::vector<uint8_t> probs_set, counts_set;   // per component
     bool patterns_dirty = true;
@@ -87,6 +92,12 @@ struct sbe_engine {
     uint8_t* d_changed = nullptr;  // [Gtot]
     float* d_step_pf = nullptr;    // [Gtot][F]  per-feature collapsed log-pdf of the fused step call
     double* d_step_pg = nullptr;   // [Gtot]     per-group collapsed log-likelihood of the fused step call
+    // one-call step (sbe_step): payload sections (byte offsets into d_step_payload / its pinned staging copy) and
+    // the host-mapped result block (per-group values | data-check words | changed-group flags)
+    struct StepLayout { size_t ids, pid, tid, toff, tuple_g, tuple_p, patbits, weights, row_of, subset, objects, rows, total; } sl{};
+    int step_max_rows = 0;
+    uint8_t* h_step_payload = nullptr; uint8_t* d_step_payload = nullptr;   // host-mapped pinned: the kernels read it over PCIe
+    uint8_t* h_step = nullptr;     uint8_t* d_step_host = nullptr;   // mapped: [Gtot] f64 | [ST_WORDS] i32 | [Gtot] u8
     uint8_t* d_scratch = nullptr;  size_t scratch_bytes = 0;     // general staging
     uint8_t* h_pinned = nullptr;   size_t pinned_bytes = 0;      // pinned D2H staging
     uint8_t* h_arena = nullptr;    size_t arena_bytes = 0, arena_off = 0;   // pinned H2D staging ring
@@ -264,6 +275,33 @@ void derive_patterns(sbe_engine* e, Slot& s) {
     for (int n = 0; n < N; ++n) s.h_pid[n] = index_of[bits[n]];
 }
 
+// distinct group tuples (g_0..g_{C-1}) of the objects, for the group-tuple kernels (host mirrors only)
+void derive_tuples(sbe_engine* e, Slot& s) {
+    const int N = e->N, C = e->C;
+    s.h_tid.assign(e->Np, 0);
+    s.h_toff.assign(e->Np, 0);
+    s.h_tuple_g.assign((size_t)kMaxTuples * kMaxComponents, (uint16_t)e->Gtot);
+    s.h_tuple_p.assign(kMaxTuples, 0);
+    uint16_t tuples[kMaxTuples][kMaxComponents];
+    int n_tup = 0;
+    bool ok = true;
+    for (int n = 0; n < N && ok; ++n) {
+        uint16_t key[kMaxComponents];
+        for (int c = 0; c < C; ++c) key[c] = s.h_gid[(size_t)c * N + n];
+        int t = 0;
+        for (; t < n_tup; ++t) if (memcmp(tuples[t], key, (size_t)C * sizeof(uint16_t)) == 0) break;
+        if (t == n_tup) {
+            if (n_tup == kMaxTuples) { ok = false; break; }
+            memcpy(tuples[n_tup++], key, (size_t)C * sizeof(uint16_t));
+            for (int c = 0; c < C; ++c) s.h_tuple_g[(size_t)t * kMaxComponents + c] = key[c] == kNoGroup ? (uint16_t)e->Gtot : key[c];
+            s.h_tuple_p[t] = s.h_pid[n];
+        }
+        s.h_tid[n] = (uint8_t)t;
+        s.h_toff[n] = (uint32_t)t * (uint32_t)(e->S + 1) * 512u;
+    }
+    s.n_tuples = ok ? n_tup : 0;
+}
+
 int upload_patterns_and_weights(sbe_engine* e, int slot) {
     Slot& s = e->slots[slot];
     if (s.patterns_dirty) {
@@ -274,38 +312,13 @@ int upload_patterns_and_weights(sbe_engine* e, int slot) {
         { int _urc = upload(e, e->d_pid + (int64_t)slot * e->Np, s.h_pid.data(), e->N); if (_urc) return _urc; }
         { int _urc = upload(e, e->d_patbits + (int64_t)slot * e->Pmax, s.patterns.data(),
                                  s.patterns.size() * sizeof(uint32_t)); if (_urc) return _urc; }
-        // distinct group tuples (g_0..g_{C-1}) of the objects, for the group-tuple kernel
-        {
-            const int N = e->N, C = e->C;
-            std::vector<uint8_t> tid(e->Np, 0);
-            std::vector<uint32_t> toff(e->Np, 0);
-            std::vector<uint16_t> tg((size_t)kMaxTuples * kMaxComponents, (uint16_t)e->Gtot);
-            std::vector<uint8_t> tp(kMaxTuples, 0);
-            uint16_t tuples[kMaxTuples][kMaxComponents];
-            int n_tup = 0;
-            bool ok = true;
-            for (int n = 0; n < N && ok; ++n) {
-                uint16_t key[kMaxComponents];
-                for (int c = 0; c < C; ++c) key[c] = s.h_gid[(size_t)c * N + n];
-                int t = 0;
-                for (; t < n_tup; ++t) if (memcmp(tuples[t], key, (size_t)C * sizeof(uint16_t)) == 0) break;
-                if (t == n_tup) {
-                    if (n_tup == kMaxTuples) { ok = false; break; }
-                    memcpy(tuples[n_tup++], key, (size_t)C * sizeof(uint16_t));
-                    for (int c = 0; c < C; ++c) tg[(size_t)t * kMaxComponents + c] = key[c] == kNoGroup ? (uint16_t)e->Gtot : key[c];
-                    tp[t] = s.h_pid[n];
-                }
-                tid[n] = (uint8_t)t;
-                toff[n] = (uint32_t)t * (uint32_t)(e->S + 1) * 512u;
-            }
-            s.n_tuples = ok ? n_tup : 0;
-            if (ok) {
-                { int _urc = upload(e, e->d_tid + (int64_t)slot * e->Np, tid.data(), e->Np); if (_urc) return _urc; }
-                { int _urc = upload(e, e->d_toff + (int64_t)slot * e->Np, toff.data(), (size_t)e->Np * sizeof(uint32_t)); if (_urc) return _urc; }
-                { int _urc = upload(e, e->d_tuple_g + (int64_t)slot * kMaxTuples * kMaxComponents, tg.data(),
-                                         tg.size() * sizeof(uint16_t)); if (_urc) return _urc; }
-                { int _urc = upload(e, e->d_tuple_p + (int64_t)slot * kMaxTuples, tp.data(), tp.size()); if (_urc) return _urc; }
-            }
+        derive_tuples(e, s);
+        if (s.n_tuples) {
+            { int _urc = upload(e, e->d_tid + (int64_t)slot * e->Np, s.h_tid.data(), e->Np); if (_urc) return _urc; }
+            { int _urc = upload(e, e->d_toff + (int64_t)slot * e->Np, s.h_toff.data(), (size_t)e->Np * sizeof(uint32_t)); if (_urc) return _urc; }
+            { int _urc = upload(e, e->d_tuple_g + (int64_t)slot * kMaxTuples * kMaxComponents, s.h_tuple_g.data(),
+                                     s.h_tuple_g.size() * sizeof(uint16_t)); if (_urc) return _urc; }
+            { int _urc = upload(e, e->d_tuple_p + (int64_t)slot * kMaxTuples, s.h_tuple_p.data(), s.h_tuple_p.size()); if (_urc) return _urc; }
         }
         s.patterns_dirty = false;
     }
@@ -448,7 +461,8 @@ void launch_v2(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStr
 
 // Enqueue the dominant kernel (optionally bracketed by an event pair) and the fixed-order
 // partial reduction.  mode: LOG_PER_OBS / LOG_PRODUCT.
-int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev_a, hipEvent_t ev_b) {
+int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev_a, hipEvent_t ev_b,
+                   const StepFinish* fin = nullptr) {
     const int P = max_patterns(e, first_slot, n);
     const bool onehot = e->opt_kernel == SBE_MIXTURE_ONEHOT || e->opt_kernel == SBE_MIXTURE_ONEHOT_GENERAL;
     MixGeom g = mix_geometry_v2(e, P, n);
@@ -566,8 +580,8 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     }
     if (ev_b) HIPCHK(e, hipEventRecord(ev_b, e->stream));
     HIPCHK(e, hipGetLastError());
-    k_reduce_partials<<<n, kBlock, 0, e->stream>>>(e->d_partials, e->partials_stride, g.n_blocks,
-                                                  e->d_results, first_slot);
+    k_reduce_partials<<<n + (fin ? 1 : 0), kBlock, 0, e->stream>>>(e->d_partials, e->partials_stride, g.n_blocks,
+                                                                  e->d_results, first_slot, n, fin ? *fin : StepFinish{});
     HIPCHK(e, hipGetLastError());
     return SBE_OK;
 }
@@ -631,6 +645,8 @@ int sbe_destroy(sbe_engine* e) {
     if (!e) return SBE_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->h_step) (void)hipHostFree(e->h_step);
+    if (e->h_step_payload) (void)hipHostFree(e->h_step_payload);
     void* dev_ptrs[] = {e->d_step_pf, e->d_step_pg, e->d_logtab, e->d_state_h, e->d_toff, e->d_tid, e->d_tuple_g, e->d_tuple_p, e->d_state_q, e->d_probs_t, e->d_wpat_t, e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
                         e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_unif, e->d_partials,
                         e->d_status, e->d_changed, e->d_scratch};
@@ -778,6 +794,30 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_RC(dmalloc(e, &e->d_changed, (int64_t)e->Gtot));
     CREATE_RC(dmalloc(e, &e->d_step_pf, (int64_t)e->Gtot * F));
     CREATE_RC(dmalloc(e, &e->d_step_pg, (int64_t)e->Gtot));
+    {   // one-call step: payload layout (every section 16-byte aligned) and the mapped result block
+        auto al = [](size_t v) { return (v + 15) / 16 * 16; };
+        e->step_max_rows = (int)std::min<int64_t>(N, 256);
+        size_t o = 0;
+        e->sl.ids = o;      o = al(o + (size_t)e->Np * 2);
+        e->sl.pid = o;      o = al(o + (size_t)e->Np);
+        e->sl.tid = o;      o = al(o + (size_t)e->Np);
+        e->sl.toff = o;     o = al(o + (size_t)e->Np * 4);
+        e->sl.tuple_g = o;  o = al(o + (size_t)kMaxTuples * kMaxComponents * 2);
+        e->sl.tuple_p = o;  o = al(o + (size_t)kMaxTuples);
+        e->sl.patbits = o;  o = al(o + (size_t)e->Pmax * 4);
+        e->sl.weights = o;  o = al(o + (size_t)(F * C) * 4);
+        e->sl.row_of = o;   o = al(o + (size_t)e->Np * 2);
+        e->sl.subset = o;   o = al(o + (size_t)e->Np * 4);
+        e->sl.objects = o;  o = al(o + (size_t)e->step_max_rows * 4);
+        e->sl.rows = o;     o = al(o + (size_t)e->step_max_rows * (size_t)(F * C));
+        e->sl.total = o;
+        CREATE_CHK(hipHostMalloc((void**)&e->h_step_payload, e->sl.total, hipHostMallocMapped));
+        CREATE_CHK(hipHostGetDevicePointer((void**)&e->d_step_payload, e->h_step_payload, 0));
+        const size_t hb = (size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int) + (size_t)e->Gtot;
+        CREATE_CHK(hipHostMalloc((void**)&e->h_step, hb, hipHostMallocMapped));
+        memset(e->h_step, 0, hb);
+        CREATE_CHK(hipHostGetDevicePointer((void**)&e->d_step_host, e->h_step, 0));
+    }
     CREATE_CHK(hipHostMalloc((void**)&e->h_results, NS * sizeof(double), hipHostMallocMapped));
     CREATE_CHK(hipHostGetDevicePointer((void**)&e->d_results, e->h_results, 0));
     CREATE_CHK(hipHostMalloc((void**)&e->h_status, ST_WORDS * sizeof(int), hipHostMallocDefault));
@@ -1538,7 +1578,7 @@ int finish_log_q(sbe_engine* e, const float* d_psel, int64_t n, double* d_partia
     const int nb = (int)std::min<int64_t>(div_up(n, 4 * kBlock), 256);
     k_sum_log_f32<<<nb, kBlock, 0, e->stream>>>(d_psel, n, d_partials);
     HIPCHK(e, hipGetLastError());
-    k_reduce_partials<<<1, kBlock, 0, e->stream>>>(d_partials, 0, nb, d_partials + 256, 0);
+    k_reduce_partials<<<1, kBlock, 0, e->stream>>>(d_partials, 0, nb, d_partials + 256, 0, 1, StepFinish{});
     HIPCHK(e, hipGetLastError());
     int rc = d2h(e, log_q_out, d_partials + 256, sizeof(double));
     if (rc) return rc;
@@ -1717,6 +1757,13 @@ int sbe_observation_lh_exact(sbe_engine* e, int slot, double* out) {
 
 // ---- one MCMC step in one call: delta in, likelihoods out (north_star: "only the proposed cluster-
 // assignment delta crosses PCIe") ---------------------------------------------------------------------
+static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters, const int32_t* changed_objects,
+                     int n_changed, const uint8_t* source_rows, const float* weights, double* group_logliks_out,
+                     double* mixture_out, uint8_t* changed_groups_out);
+static int step_general(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters, const int32_t* changed_objects,
+                        int n_changed, const uint8_t* source_rows, const float* weights, double* group_logliks_out,
+                        double* mixture_out, uint8_t* changed_groups_out);
+
 int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters, const int32_t* changed_objects,
              int n_changed, const uint8_t* source_rows, const float* weights, double* group_logliks_out,
              double* mixture_out, uint8_t* changed_groups_out) {
@@ -1732,6 +1779,194 @@ int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters
     for (int i = 0; i < n_changed; ++i)
         if (changed_objects[i] < 0 || changed_objects[i] >= e->N) return fail(e, SBE_ERR_ARG, "object index %d out of range", changed_objects[i]);
     HIPCHK(e, hipSetDevice(e->device));
+    // few-launch form (one H2D payload, four kernels, results through mapped memory) whenever the step fits its
+    // payload; the call-by-call form otherwise (many changed rows, never-uploaded patterns) or on request
+    static const bool force_general = getenv("SBE_STEP_GENERAL") && atoi(getenv("SBE_STEP_GENERAL")) == 1;
+    if (!force_general && n_changed <= e->step_max_rows && !cur.patterns_dirty)
+        return step_lean(e, cur_slot, cand_slot, clusters, changed_objects, n_changed, source_rows, weights,
+                         group_logliks_out, mixture_out, changed_groups_out);
+    return step_general(e, cur_slot, cand_slot, clusters, changed_objects, n_changed, source_rows, weights,
+                        group_logliks_out, mixture_out, changed_groups_out);
+}
+
+static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters, const int32_t* changed_objects,
+                     int n_changed, const uint8_t* source_rows, const float* weights, double* group_logliks_out,
+                     double* mixture_out, uint8_t* changed_groups_out) {
+    if (e->status_pending) {                  // deliver a deferred data check before this step reuses the words
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        int rc = synced(e);
+        if (rc) return rc;
+    }
+    // SBE_STEP_TIMING=1: host-side phase times (prepare / enqueue / wait), printed every 2000 steps (diagnostic)
+    static const bool timing = getenv("SBE_STEP_TIMING") && atoi(getenv("SBE_STEP_TIMING")) == 1;
+    static double t_acc[3] = {0, 0, 0};
+    static int t_n = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int N = e->N, Np = e->Np, F = e->F, C = e->C;
+    const Slot& cur = e->slots[cur_slot];
+    Slot cd = cur;                            // host state of the candidate (committed at the end)
+    // objects whose counts may change: listed source rows + objects whose cluster membership changed
+    std::vector<uint8_t> moved(N, 0);
+    for (int i = 0; i < n_changed; ++i) moved[changed_objects[i]] = 1;
+    const bool regroup = clusters != nullptr;
+    if (regroup) {
+        const int K = e->G[0];
+        uint16_t* ids = cd.h_gid.data();      // component 0: group offset 0
+        std::fill(ids, ids + N, kNoGroup);
+        for (int g = 0; g < K; ++g) {
+            const uint8_t* row = clusters + (size_t)g * N;
+            for (int n = 0; n < N; ++n) if (row[n]) ids[n] = (uint16_t)g;
+        }
+        for (int n = 0; n < N; ++n) if (ids[n] != cur.h_gid[n]) moved[n] = 1;
+        derive_patterns(e, cd);
+        if ((int)cd.patterns.size() > e->Pmax)
+            return fail(e, SBE_ERR_ARG, "%zu distinct has_components patterns exceed capacity %d", cd.patterns.size(), e->Pmax);
+        derive_tuples(e, cd);
+        cd.patterns_dirty = false;
+    }
+    // ---- payload: packed in host-mapped pinned memory; the kernels read it in place (a few tens of KB over
+    // PCIe, no copy engine in the chain).  Every step ends with a stream synchronisation, so the single buffer is
+    // free again when the next step starts.
+    const auto& L = e->sl;
+    uint8_t* st = e->h_step_payload;
+    int n_subset = 0;
+    {
+        int32_t* sub = reinterpret_cast<int32_t*>(st + L.subset);
+        for (int n = 0; n < N; ++n) if (moved[n]) sub[n_subset++] = n;
+    }
+    if (regroup) {
+        memcpy(st + L.ids, cd.h_gid.data(), (size_t)N * 2);
+        if (Np > N) memset(st + L.ids + (size_t)N * 2, 0xFF, (size_t)(Np - N) * 2);
+        memset(st + L.pid, 0, Np); memcpy(st + L.pid, cd.h_pid.data(), N);
+        memcpy(st + L.tid, cd.h_tid.data(), Np);
+        memcpy(st + L.toff, cd.h_toff.data(), (size_t)Np * 4);
+        memcpy(st + L.tuple_g, cd.h_tuple_g.data(), (size_t)kMaxTuples * kMaxComponents * 2);
+        memcpy(st + L.tuple_p, cd.h_tuple_p.data(), kMaxTuples);
+        memset(st + L.patbits, 0, (size_t)e->Pmax * 4);
+        memcpy(st + L.patbits, cd.patterns.data(), cd.patterns.size() * 4);
+    }
+    if (weights) memcpy(st + L.weights, weights, (size_t)F * C * 4);
+    if (n_changed > 0) {
+        int16_t* row_of = reinterpret_cast<int16_t*>(st + L.row_of);
+        std::fill(row_of, row_of + Np, (int16_t)-1);
+        for (int i = 0; i < n_changed; ++i) row_of[changed_objects[i]] = (int16_t)i;    // (a repeated object: last row wins)
+        memcpy(st + L.objects, changed_objects, (size_t)n_changed * 4);
+        memcpy(st + L.rows, source_rows, (size_t)n_changed * F * C);
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    const uint8_t* pl = e->d_step_payload;
+
+    // ---- kernel 1: candidate slot = current slot + payload ---------------------------------------------------
+    StepApply a{};
+    uint32_t run = 0;
+    auto seg = [&](auto* base, int64_t elems, const void* payload_src) {       // per-slot array `base`, elems per slot
+        const int64_t bytes = elems * (int64_t)sizeof(*base);
+        a.cs.src[a.cs.n] = payload_src ? reinterpret_cast<const uint32_t*>(payload_src)
+                                       : reinterpret_cast<const uint32_t*>(base + (int64_t)cur_slot * elems);
+        a.cs.dst[a.cs.n] = reinterpret_cast<uint32_t*>(base + (int64_t)cand_slot * elems);
+        run += (uint32_t)(bytes / 4);
+        a.cs.end[a.cs.n++] = run;
+    };
+    // gid: component 0 from the payload when the clusters changed; the other components from the current slot
+    {
+        uint16_t* g_cur = e->d_gid + (int64_t)cur_slot * C * Np;
+        uint16_t* g_cand = e->d_gid + (int64_t)cand_slot * C * Np;
+        a.cs.src[a.cs.n] = reinterpret_cast<const uint32_t*>(regroup ? (const void*)(pl + L.ids) : (const void*)g_cur);
+        a.cs.dst[a.cs.n] = reinterpret_cast<uint32_t*>(g_cand);
+        run += (uint32_t)(Np * 2 / 4); a.cs.end[a.cs.n++] = run;
+        if (C > 1) {
+            a.cs.src[a.cs.n] = reinterpret_cast<const uint32_t*>(g_cur + Np);
+            a.cs.dst[a.cs.n] = reinterpret_cast<uint32_t*>(g_cand + Np);
+            run += (uint32_t)((int64_t)(C - 1) * Np * 2 / 4); a.cs.end[a.cs.n++] = run;
+        }
+    }
+    seg(e->d_pid, (int64_t)Np, regroup ? pl + L.pid : nullptr);
+    seg(e->d_tid, (int64_t)Np, regroup ? pl + L.tid : nullptr);
+    seg(e->d_toff, (int64_t)Np, regroup ? pl + L.toff : nullptr);
+    seg(e->d_tuple_g, (int64_t)kMaxTuples * kMaxComponents, regroup ? pl + L.tuple_g : nullptr);
+    seg(e->d_tuple_p, (int64_t)kMaxTuples, regroup ? pl + L.tuple_p : nullptr);
+    seg(e->d_patbits, (int64_t)e->Pmax, regroup ? pl + L.patbits : nullptr);
+    seg(e->d_weights, (int64_t)F * C, weights ? pl + L.weights : nullptr);
+    a.src_seg = a.cs.n;
+    seg(e->d_src, (int64_t)N * e->Fp, nullptr);
+    seg(e->d_counts, e->table_elems(), nullptr);
+    a.row_of = n_changed > 0 ? reinterpret_cast<const int16_t*>(pl + L.row_of) : nullptr;
+    a.rows = pl + L.rows;
+    a.objects = reinterpret_cast<const int32_t*>(pl + L.objects);
+    a.src_dst = e->d_src + (int64_t)cand_slot * N * e->Fp;
+    a.n_changed = n_changed; a.F = F; a.C = C; a.Fp = e->Fp;
+    a.changed = e->d_changed; a.Gtot = e->Gtot; a.status = e->d_status;
+    k_step_apply<<<std::min<int64_t>(div_up(run, 256), 4 * e->compute_units), 256, 0, e->stream>>>(a);
+    HIPCHK(e, hipGetLastError());
+    // ---- kernel 2: count delta over the moved objects ---------------------------------------------------------
+    if (n_subset > 0) {
+        int rc = counts_launch(e, cand_slot, +1, cur_slot, -1, reinterpret_cast<const int32_t*>(pl + L.subset), n_subset,
+                               cand_slot, true, e->d_changed);
+        if (rc) return rc;
+    }
+    // ---- kernel 3: every table of the candidate ---------------------------------------------------------------
+    const int P = (int)cd.patterns.size();
+    StepTables t{};
+    t.counts = e->d_counts + (int64_t)cand_slot * e->table_elems(); t.conc = e->d_conc;
+    t.probs = e->d_probs + (int64_t)cand_slot * e->table_elems();
+    t.probs_t = e->d_probs_t + (int64_t)cand_slot * e->probs_t_elems();
+    t.per_feature = e->d_step_pf;
+    t.weights = e->d_weights + (int64_t)cand_slot * F * C;
+    t.pattern_bits = e->d_patbits + (int64_t)cand_slot * e->Pmax;
+    t.wpat = e->d_wpat + (int64_t)cand_slot * e->Pmax * F * C;
+    t.wpat_t = e->d_wpat_t + (int64_t)cand_slot * e->wpat_t_elems();
+    t.Gtot = e->Gtot; t.F = F; t.S = e->S; t.C = C; t.P = P; t.Pmax = e->Pmax; t.ft = e->ft; t.n_ftiles = e->n_ftiles;
+    t.status = e->d_status;
+    {
+        const int rpb = e->S <= kBlock ? std::min(kStepRowsMax, kBlock / e->S) : 0;
+        if (rpb == 0) return fail(e, SBE_ERR_ARG, "one-call step: %d states per feature exceed the table kernel's row width", e->S);
+        const int row_blocks = div_up((int64_t)e->Gtot * F, rpb);
+        k_step_tables<<<row_blocks + div_up((int64_t)P * F, kBlock), kBlock, 0, e->stream>>>(t, rpb, row_blocks);
+    }
+    HIPCHK(e, hipGetLastError());
+    std::fill(cd.probs_set.begin(), cd.probs_set.end(), 1);
+    cd.weights_set = true;
+    e->slots[cand_slot] = cd;
+    // ---- kernels 4 + 5: fused mixture eval, reduction + step epilogue (mapped-memory results) -------------------
+    StepFinish fin{};
+    fin.per_feature = e->d_step_pf;
+    fin.group_out = reinterpret_cast<double*>(e->d_step_host);
+    fin.status = e->d_status;
+    fin.status_out = reinterpret_cast<int*>(e->d_step_host + (size_t)e->Gtot * sizeof(double));
+    fin.changed = e->d_changed;
+    fin.changed_out = e->d_step_host + (size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int);
+    fin.Gtot = e->Gtot; fin.F = F;
+    int rc = launch_mixture(e, cand_slot, 1, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, &fin);
+    if (rc) return rc;
+    const auto t2 = std::chrono::steady_clock::now();
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (timing) {
+        const auto t3 = std::chrono::steady_clock::now();
+        t_acc[0] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+        t_acc[1] += std::chrono::duration<double, std::micro>(t2 - t1).count();
+        t_acc[2] += std::chrono::duration<double, std::micro>(t3 - t2).count();
+        if (++t_n == 2000) {
+            fprintf(stderr, "[sbe_step] host prepare %.1f us, enqueue %.1f us, wait %.1f us per step\n", t_acc[0] / t_n, t_acc[1] / t_n, t_acc[2] / t_n);
+            t_acc[0] = t_acc[1] = t_acc[2] = 0; t_n = 0;
+        }
+    }
+    const int* hst = reinterpret_cast<const int*>(e->h_step + (size_t)e->Gtot * sizeof(double));
+    if (hst[ST_BAD_NORMALIZE] || hst[ST_MULTI_SOURCE]) {
+        const int bad_norm = hst[ST_BAD_NORMALIZE], multi_src = hst[ST_MULTI_SOURCE];
+        (void)hipMemsetAsync(e->d_status + ST_BAD_NORMALIZE, 0, 2 * sizeof(int), e->stream);
+        if (bad_norm) return fail(e, SBE_ERR_DATA, "normalize: %d rows have a non-positive sum (sbayes/util.py:1006 assert)", bad_norm);
+        return fail(e, SBE_ERR_DATA, "source is not one-hot over components in %d observations", multi_src);
+    }
+    memcpy(group_logliks_out, e->h_step, (size_t)e->Gtot * sizeof(double));
+    if (changed_groups_out) memcpy(changed_groups_out, e->h_step + (size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int), (size_t)e->Gtot);
+    *mixture_out = e->h_results[cand_slot];
+    return SBE_OK;
+}
+
+static int step_general(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters, const int32_t* changed_objects,
+                        int n_changed, const uint8_t* source_rows, const float* weights, double* group_logliks_out,
+                        double* mixture_out, uint8_t* changed_groups_out) {
+    Slot& cur = e->slots[cur_slot];
     const int saved_deferred = e->opt_deferred;
     e->opt_deferred = 1;                       // no intermediate synchronisation inside the step
     auto done = [&](int rc) { e->opt_deferred = saved_deferred; return rc; };

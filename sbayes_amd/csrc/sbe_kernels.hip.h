@@ -613,11 +613,48 @@ __global__ void k_observation_lh(const uint8_t* __restrict__ state, const uint16
 //                 binary exponent is stripped with integer ops; one fp64 log per thread (see ProdAcc)
 enum MixMode : int { LOG_PER_OBS = 0, LOG_PRODUCT = 1, WRITE_OBS = 2 };
 
-// Final fixed-order reduction of the per-block partials: one block per slot.
+// Epilogue of the one-call MCMC step (sbe_step), run by ONE extra block of k_reduce_partials: per-group collapsed
+// log-likelihood (a7: float32 NumPy-order sum of the per-feature values, likelihood.py:74-77), the changed-group
+// flags and the data-check words, all written straight into host-mapped pinned memory -- no D2H copies.
+struct StepFinish {
+    const float* per_feature;      // [Gtot][F] (k_step_tables); nullptr = no epilogue
+    double* group_out;             // mapped [Gtot]
+    const uint8_t* changed;        // [Gtot]
+    uint8_t* changed_out;          // mapped [Gtot]
+    const int* status;             // [ST_WORDS]
+    int* status_out;               // mapped [ST_WORDS]
+    int Gtot, F;
+};
+
+// Final fixed-order reduction of the per-block partials: one block per slot (+ one for the step epilogue).
 __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __restrict__ partials,
                                                            int64_t partials_stride, int n_blocks,
-                                                           double* __restrict__ results, int first_slot) {
+                                                           double* __restrict__ results, int first_slot,
+                                                           int n_slots, StepFinish fin) {
     __shared__ double red4[4];
+    if ((int)blockIdx.x >= n_slots) {                                   // step epilogue block
+        // per-feature values staged through LDS in chunks of whole groups (coalesced loads; the ordered sums
+        // then run at LDS latency instead of one L2 round trip per 8 elements)
+        __shared__ float stage[8192];
+        const int gpc = max(1, 8192 / fin.F);                            // groups per chunk
+        for (int g0 = 0; g0 < fin.Gtot; g0 += gpc) {
+            const int ng = min(gpc, fin.Gtot - g0);
+            const bool fits = fin.F <= 8192;
+            if (fits) {
+                for (int i = threadIdx.x; i < ng * fin.F; i += kBlock) stage[i] = fin.per_feature[(int64_t)g0 * fin.F + i];
+                __syncthreads();
+            }
+            for (int g = threadIdx.x; g < ng; g += kBlock) {
+                const float* p = fits ? stage + g * fin.F : fin.per_feature + (int64_t)(g0 + g) * fin.F;
+                auto get = [&](int i) -> float { return p[i]; };
+                fin.group_out[g0 + g] = (double)np_pairwise_sum<float>(get, fin.F);
+                fin.changed_out[g0 + g] = fin.changed[g0 + g];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x < ST_WORDS) fin.status_out[threadIdx.x] = fin.status[threadIdx.x];
+        return;
+    }
     const int slot = first_slot + blockIdx.x;
     const double* p = partials + (int64_t)slot * partials_stride;
     double v = 0.0;
@@ -1837,6 +1874,130 @@ __global__ void k_multi_copy(CopySegs cs) {
         while (i >= cs.end[k]) ++k;
         const uint32_t base = k ? cs.end[k - 1] : 0u;
         cs.dst[k][i - base] = cs.src[k][i - base];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// One-call MCMC step (sbe_step), kernel 1 of 4: build the candidate slot from the current slot and the step's
+// payload (ONE H2D copy: new cluster ids / pattern ids / tuple tables, changed source rows, weights).
+//   * every per-slot array = one segment, copied from the current slot OR from a payload section;
+//   * the source rows of the changed objects are not copied but converted from the payload's bool rows
+//     (k_ingest_source's job); `row_of[n]` = row index of object n in the payload or -1;
+//   * the changed-group flags are cleared for the count kernel that follows.
+// ------------------------------------------------------------------------------------------
+struct StepApply {
+    CopySegs cs;
+    int src_seg;                   // segment index of the source array in cs
+    const int16_t* row_of;         // [Np] (payload) or nullptr when no source row changes
+    const uint8_t* rows;           // [n_changed][F][C] bool (payload)
+    const int32_t* objects;        // [n_changed] (payload)
+    uint8_t* src_dst;              // candidate slot's source ids [N][Fp]
+    int n_changed, F, C, Fp;
+    uint8_t* changed; int Gtot;
+    int* status;
+};
+
+__global__ void k_step_apply(StepApply a) {
+    const uint32_t total = a.cs.end[a.cs.n - 1];
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    for (uint32_t i = tid; i < total; i += nthreads) {
+        int k = 0;
+        while (i >= a.cs.end[k]) ++k;
+        const uint32_t j = i - (k ? a.cs.end[k - 1] : 0u);
+        if (k == a.src_seg && a.row_of && a.row_of[(j * 4u) / (uint32_t)a.Fp] >= 0) continue;   // converted below
+        a.cs.dst[k][j] = a.cs.src[k][j];
+    }
+    int multi = 0;
+    for (uint32_t i = tid; i < (uint32_t)a.n_changed * (uint32_t)a.F; i += nthreads) {
+        const int r = (int)(i / (uint32_t)a.F), f = (int)(i % (uint32_t)a.F);
+        const uint8_t* p = a.rows + (int64_t)i * a.C;
+        int id = kNA, cnt = 0;
+        for (int c = 0; c < a.C; ++c)
+            if (p[c]) { id = c; ++cnt; }
+        a.src_dst[(int64_t)a.objects[r] * a.Fp + f] = (uint8_t)id;
+        multi += cnt > 1;
+    }
+    for (uint32_t g = tid; g < (uint32_t)a.Gtot; g += nthreads) a.changed[g] = 0;
+    // (the data-check words are zero on entry: the host delivers any pending check before a step starts and
+    //  clears the words after reporting)
+    if (multi) atomicAdd(&a.status[ST_MULTI_SOURCE], multi);
+}
+
+// Kernel 3 of 4: every table of the candidate slot in one launch (replaces k_probs + k_tile_probs + k_dcl +
+// k_weight_patterns + k_tile_weights of the call-by-call flow; same arithmetic, same NumPy orders).
+//   threads [0, Gtot*F): row (group, feature): probs = normalize(counts + conc) -> canonical + tile-transposed
+//                        copy; collapsed per-feature log-pdf (a8)
+//   threads [Gtot*F, Gtot*F + P*F): row (pattern, feature): normalised weights -> [P][F][C] f32 + tiled f64
+struct StepTables {
+    const int32_t* counts; const double* conc; float* probs; float* probs_t; float* per_feature;
+    const float* weights; const uint32_t* pattern_bits; float* wpat; double* wpat_t;
+    int Gtot, F, S, C, P, Pmax, ft, n_ftiles;
+    int* status;
+};
+
+// Rows are spread over the lanes: thread <-> table element (row, state) for the two lgammas and the posterior
+// count of its element (LDS), then the row's first thread does the NumPy-order sums over the S staged values
+// (S small) and every element thread writes its own probability -- 22 serial lgammas per thread became 2.
+constexpr int kStepRowsMax = 128;                    // rows per block (S >= 2: 256 / S <= 128; S == 1: 128)
+__global__ __launch_bounds__(kBlock) void k_step_tables(StepTables a, int rows_per_block, int n_row_blocks) {
+    __shared__ double sh_post[kBlock], sh_ser[kBlock], sh_total[kStepRowsMax];
+    __shared__ float sh_cnt[kBlock];
+    const int S = a.S;
+    if ((int)blockIdx.x < n_row_blocks) {
+        const int64_t n_rows = (int64_t)a.Gtot * a.F;
+        const int rl = S <= kBlock ? (int)threadIdx.x / S : 0, s = S <= kBlock ? (int)threadIdx.x % S : 0;
+        const int64_t row = (int64_t)blockIdx.x * rows_per_block + rl;
+        const bool act = rl < rows_per_block && row < n_rows;
+        double post = 0.0, conc = 0.0;
+        float cf = 0.0f;
+        if (act) {
+            cf = (float)a.counts[row * S + s];
+            conc = a.conc[row * S + s];
+            post = (double)cf + conc;
+            sh_post[threadIdx.x] = post;
+            sh_cnt[threadIdx.x] = cf;
+            sh_ser[threadIdx.x] = conc > 0.0 ? lgamma((double)cf + conc) - lgamma(conc) : 0.0;
+        }
+        __syncthreads();
+        if (act && s == 0) {                          // the row's ordered sums (NumPy pairwise order)
+            const double* pp = sh_post + rl * S; const double* ps = sh_ser + rl * S; const float* pc = sh_cnt + rl * S;
+            const int64_t base = row * S;
+            auto post_at = [&](int k) -> double { return pp[k]; };
+            auto ser_at = [&](int k) -> double { return ps[k]; };
+            auto cnt_at = [&](int k) -> float { return pc[k]; };
+            auto conc_at = [&](int k) -> double { return a.conc[base + k]; };
+            const double total = np_pairwise_sum<double>(post_at, S);
+            if (!(total > 0.0)) atomicAdd(&a.status[ST_BAD_NORMALIZE], 1);
+            sh_total[rl] = total;
+            const float n = np_pairwise_sum<float>(cnt_at, S);
+            const double sum_a = np_pairwise_sum<double>(conc_at, S);
+            const double cst = lgamma(sum_a) - lgamma((double)n + sum_a);
+            a.per_feature[row] = (float)(cst + np_pairwise_sum<double>(ser_at, S));
+        }
+        __syncthreads();
+        if (act) {
+            const int g = (int)(row / a.F), f = (int)(row % a.F);
+            const float pr = (float)(post / sh_total[rl]);
+            a.probs[row * S + s] = pr;
+            const int tile = f / a.ft, fl = f % a.ft;
+            a.probs_t[((((int64_t)tile * (a.Gtot + 1) + g) * S) + s) * a.ft + fl] = pr;
+        }
+        return;
+    }
+    const int64_t j = (int64_t)((int)blockIdx.x - n_row_blocks) * kBlock + threadIdx.x;
+    if (j >= (int64_t)a.P * a.F) return;
+    const int p = (int)(j / a.F), f = (int)(j % a.F);
+    const uint32_t bits = a.pattern_bits[p];
+    const float* w = a.weights + (int64_t)f * a.C;
+    auto masked = [&](int c) -> float { return ((bits >> c) & 1u) ? w[c] : 0.0f * w[c]; };
+    const float total = np_pairwise_sum<float>(masked, a.C);
+    float* out = a.wpat + ((int64_t)p * a.F + f) * a.C;
+    const int tile = f / a.ft, fl = f % a.ft;
+    double* ot = a.wpat_t + (((int64_t)tile * a.Pmax + p) * a.C) * a.ft + fl;
+    for (int c = 0; c < a.C; ++c) {
+        const float v = masked(c) / total;
+        out[c] = v;
+        ot[(int64_t)c * a.ft] = (double)v;
     }
 }
 

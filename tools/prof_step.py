@@ -26,3 +26,9 @@ eng.sync(); print("copy_slot", round((time.perf_counter() - t0) / 500 * 1e6, 1),
 t0 = time.perf_counter()
 for _ in range(500): eng.mixture_loglik(0)
 print("mixture", round((time.perf_counter() - t0) / 500 * 1e6, 1), "us")
+# C-level phase times of the one-call step (SBE_STEP_TIMING=1 prints to stderr every 2000 steps)
+import os
+if os.environ.get("SBE_STEP_TIMING") == "1":
+    kw = {"clusters": clusters, "source_rows": (objs, rows)}
+    for _ in range(4100):
+        chain.step(**kw); chain.accept()
