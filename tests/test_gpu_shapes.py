@@ -154,3 +154,52 @@ def _run_case(feats, groups, weights, source, conc, n_groups, rng, light=False):
             assert np.array_equal(eng.effect_counts(groups[c], source[..., c], sub),
                                   orc.compute_effect_counts(feats, groups[c], source[..., c], sub))
             assert np.array_equal(eng.normalize_tables(counts[c], conc[c]), orc.component_probs(counts[c], conc[c]))
+
+
+@pytest.mark.parametrize("shape", [
+    # N,   F,   S,  groups,     n_slots  (what it exercises in k_mixture_tuple64)
+    (203,  72,  4,  [3, 1],     19),     # narrow last tile (8 features: sub-row mode), batch not a multiple of 8
+    (203,  64,  4,  [3, 1],     9),      # no ragged tile
+    (150,  100, 3,  [2, 1, 2],  8),      # last tile 36 features wide: full-tile mode with dead lanes; C = 3
+    (97,   130, 20, [6, 1],     11),     # table beyond 64 KiB: 32-bit tuple-block offsets; 2-feature last tile
+    (1100, 70,  3,  [4, 1],     3),      # fewer than 8 slots (slot-major order), short chunks
+    (2203, 70,  3,  [4, 1],     128),    # long chunks: more than 64 quads per wave (two offset groups)
+    (40,   72,  3,  [2, 1],     600),    # more slots than one generation of blocks per XCD holds (64): two generations
+], ids=lambda s: f"N{s[0]}F{s[1]}S{s[2]}C{len(s[3])}B{s[4]}")
+def test_tuple_kernel_batches(shape):
+    """Batches through the scalar-unit group-tuple kernel: every slot holds a different state; the batched
+    launch (XCD-dealt, generation-ordered blocks) must give each slot the value of its own single evaluation
+    and of the oracle.  A state with a zero-probability observation (-inf) rides along."""
+    N, F, S, n_groups, B = shape
+    rng = np.random.default_rng(N * 1000 + F)
+    feats, groups0, _w, _s, conc = random_case(rng, N, F, S, n_groups, 0.05)
+    na = ~feats.any(-1)
+    with Engine(feats, n_groups, n_slots=B) as eng:
+        C = len(n_groups)
+        for c in range(C):
+            eng.set_concentration(c, conc[c])
+        want = []
+        for b in range(B):
+            a = rng.integers(0, 2 * n_groups[0], size=N)
+            groups = [np.stack([a == k for k in range(n_groups[0])])] + groups0[1:]
+            weights = rng.dirichlet(np.ones(C), size=F).astype(np.float32)
+            hc = orc.has_components(groups)
+            src_idx = np.argmax(rng.random((N, F, C)) * hc[:, None, :], axis=-1)      # a random available component
+            source = np.eye(C, dtype=bool)[src_idx]
+            source[na] = False
+            eng.load_state(b, groups, weights, source=source)
+            for c in range(C):
+                eng.update_probs(b, c)
+            counts = orc.recalculate_feature_counts(feats, groups, source)
+            want.append(orc.mixture_loglik(feats, na, groups, counts, conc, weights))
+        want = np.array(want)
+        for kernel in (MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, MIXTURE_PACKED_GENERAL):
+            eng.set_option(kernel=kernel)
+            got = eng.mixture_loglik_batch(0, B)
+            np.testing.assert_allclose(got, want, rtol=1e-10, err_msg=f"kernel {kernel}")
+            singles = np.array([eng.mixture_loglik(b) for b in range(B)])
+            np.testing.assert_allclose(singles, want, rtol=1e-10, err_msg=f"kernel {kernel} (single)")
+        # sub-ranges of slots
+        eng.set_option(kernel=MIXTURE_PACKED_TUPLE)
+        if B > 2:
+            np.testing.assert_allclose(eng.mixture_loglik_batch(1, B - 2), want[1:B - 1], rtol=1e-10)
