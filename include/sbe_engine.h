@@ -59,6 +59,8 @@ typedef struct sbe_engine sbe_engine;
                                        assert, one-hot source) are reported by the next call that
                                        synchronizes (sbe_sync, any result fetch) instead of
                                        immediately, so state-setting calls never stall the stream */
+#define SBE_OPT_STEP_FORM 4         /* sbe_step: 0 = few-launch form whenever the step fits its payload
+                                       (default), 1 = always the call-by-call form (testing / A-B)   */
 
 typedef struct sbe_info {
     int32_t abi_version;

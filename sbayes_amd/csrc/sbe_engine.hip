@@ -101,6 +101,7 @@ struct sbe_engine {
     uint8_t* d_scratch = nullptr;  size_t scratch_bytes = 0;     // general staging
     uint8_t* h_pinned = nullptr;   size_t pinned_bytes = 0;      // pinned D2H staging
     uint8_t* h_arena = nullptr;    size_t arena_bytes = 0, arena_off = 0;   // pinned H2D staging ring
+    int opt_step_form = 0;         // SBE_OPT_STEP_FORM
     int opt_deferred = 0;          // SBE_OPT_DEFERRED_CHECKS: data checks reported at the next sync
     bool status_pending = false;
     std::vector<Slot> slots;
@@ -885,6 +886,7 @@ int sbe_set_option(sbe_engine* e, int option, int value) {
     CHECK_ENGINE(e);
     if (option == SBE_OPT_MIXTURE_KERNEL && (value == SBE_MIXTURE_PACKED || value == SBE_MIXTURE_ONEHOT || value == SBE_MIXTURE_PACKED_GENERAL || value == SBE_MIXTURE_PACKED_TUPLE || value == SBE_MIXTURE_PACKED_TUPLE_LDS || value == SBE_MIXTURE_ONEHOT_GENERAL)) { e->opt_kernel = value; return SBE_OK; }
     if (option == SBE_OPT_LOG_MODE && (value == SBE_LOG_PER_OBS || value == SBE_LOG_PRODUCT)) { e->opt_log = value; return SBE_OK; }
+    if (option == SBE_OPT_STEP_FORM && (value == 0 || value == 1)) { e->opt_step_form = value; return SBE_OK; }
     if (option == SBE_OPT_DEFERRED_CHECKS && (value == 0 || value == 1)) {
         if (!value && e->status_pending) { HIPCHK(e, hipStreamSynchronize(e->stream)); int rc = synced(e); e->opt_deferred = 0; return rc; }
         e->opt_deferred = value;
@@ -1782,7 +1784,7 @@ int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters
     // few-launch form (one H2D payload, four kernels, results through mapped memory) whenever the step fits its
     // payload; the call-by-call form otherwise (many changed rows, never-uploaded patterns) or on request
     static const bool force_general = getenv("SBE_STEP_GENERAL") && atoi(getenv("SBE_STEP_GENERAL")) == 1;
-    if (!force_general && n_changed <= e->step_max_rows && !cur.patterns_dirty)
+    if (!force_general && e->opt_step_form == 0 && n_changed <= e->step_max_rows && !cur.patterns_dirty)
         return step_lean(e, cur_slot, cand_slot, clusters, changed_objects, n_changed, source_rows, weights,
                          group_logliks_out, mixture_out, changed_groups_out);
     return step_general(e, cur_slot, cand_slot, clusters, changed_objects, n_changed, source_rows, weights,

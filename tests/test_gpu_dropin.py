@@ -259,3 +259,69 @@ def test_trace_replay_one_call_steps(name):
     counts = orc.recalculate_feature_counts(fx.features, [prev_clusters] + fx.groups[1:], prev_source)
     for c in range(fx.n_comp):
         assert np.array_equal(chain.current.counts(c), counts[c])
+
+
+def test_step_forms_agree_bit_for_bit():
+    """sbe_step's few-launch form (payload in mapped memory, fused table kernel, epilogue in mapped memory) and its
+    call-by-call form give the same numbers bit for bit on random deltas -- cluster moves, source-row changes,
+    weight changes, every source row at once, nothing at all -- with accepted and rejected steps; the counts are
+    also checked against the oracle's full recount."""
+    from sbayes_amd.engine import Engine
+    from sbayes_amd.synthetic import make_state, make_workload
+    wl = make_workload("cfg1")
+    N, F, S = wl.shape
+    rng = np.random.default_rng(3)
+    engines = []
+    for form in (0, 1):
+        eng = Engine(wl.features, [g.shape[0] for g in wl.groups], n_slots=2)
+        eng.set_option(step_form=form)
+        for c in range(wl.n_components):
+            eng.set_concentration(c, wl.concentration[c])
+        eng.load_state(0, wl.groups, wl.weights, source=wl.source)
+        for c in range(wl.n_components):
+            eng.update_probs(0, c)
+        eng.mixture_loglik(0)                       # patterns uploaded
+        engines.append(eng)
+    try:
+        cur_state = (wl.clusters.copy(), wl.weights.copy(), wl.source.copy())
+        cur, cand = 0, 1
+        for step in range(60):
+            clusters, weights, source = (x.copy() for x in cur_state)
+            kind = step % 6
+            kw = {}
+            if kind in (0, 1, 4):                   # move some objects between clusters
+                for n in rng.integers(0, N, size=3):
+                    clusters[:, n] = False
+                    k = int(rng.integers(0, clusters.shape[0] + 1))
+                    if k < clusters.shape[0]:
+                        clusters[k, n] = True
+                kw["clusters"] = clusters
+            if kind in (0, 2, 4):                   # resample source rows of a few objects (valid components only)
+                _cl, _w, src2 = make_state(wl.features, wl.groups[1:], clusters.shape[0], seed=500 + step)
+                objs = np.unique(rng.integers(0, N, size=5 if kind != 4 else 4 * N)).astype(np.int32)
+                hc = np.stack([clusters.any(axis=0)] + [g.any(axis=0) for g in wl.groups[1:]], axis=1)
+                rows = src2[objs] & hc[objs][:, None, :]
+                fix = ~rows.any(-1) & wl.features[objs].any(-1)          # component vanished: use the universal one
+                rows[fix, 1] = True
+                source[objs] = rows
+                kw.update(changed_objects=objs, source_rows=rows)
+            if kind in (3, 4):
+                weights = rng.dirichlet(np.ones(wl.n_components), size=F).astype(np.float32)
+                kw["weights"] = weights
+            outs = [eng.step(cur, cand, **kw) for eng in engines]
+            (g0, m0, c0), (g1, m1, c1) = outs
+            assert np.array_equal(g0, g1), (step, kind)
+            assert m0 == m1, (step, kind, m0, m1)
+            assert np.array_equal(c0, c1), (step, kind)
+            for c in range(wl.n_components):
+                assert np.array_equal(engines[0].get_counts(cand, c), engines[1].get_counts(cand, c))
+                assert np.array_equal(engines[0].get_probs(cand, c), engines[1].get_probs(cand, c))
+            counts = orc.recalculate_feature_counts(wl.features, [clusters] + wl.groups[1:], source)
+            for c in range(wl.n_components):
+                assert np.array_equal(engines[0].get_counts(cand, c), counts[c]), (step, kind, c)
+            if step % 4 != 3:                       # accept; else reject: the next step starts from `cur` again
+                cur, cand = cand, cur
+                cur_state = (clusters, weights, source)
+    finally:
+        for eng in engines:
+            eng.close()
