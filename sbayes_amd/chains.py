@@ -37,10 +37,14 @@ def init_process_group(backend=None):
         return None
     import torch
     import torch.distributed as dist
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     if backend is None:
-        backend = os.environ.get("SBAYES_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        # RCCL wants one device per rank; with more ranks than devices on this node (rehearsals on a one-GPU box)
+        # gloo serves the barrier and the max-over-ranks equally -- the data path has no collective
+        backend = os.environ.get("SBAYES_AMD_DIST_BACKEND") or ("nccl" if n_dev >= local_world and n_dev > 0 else "gloo")
     if backend == "nccl":
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank % n_dev)
     if not dist.is_initialized():
         try:
             dist.init_process_group(backend=backend)
