@@ -90,6 +90,7 @@ struct sbe_engine {
     int* d_status = nullptr;       // [ST_WORDS]
     int* h_status = nullptr;       // pinned
     uint8_t* d_changed = nullptr;  // [Gtot]
+    uint32_t* d_step_stamp = nullptr;  uint32_t step_id = 0;   // [Gtot] group changed in step `step_id` (k_step_core)
     float* d_step_pf = nullptr;    // [Gtot][F]  per-feature collapsed log-pdf of the fused step call
     double* d_step_pg = nullptr;   // [Gtot]     per-group collapsed log-likelihood of the fused step call
     // one-call step (sbe_step): payload sections (byte offsets into d_step_payload / its pinned staging copy) and
@@ -650,7 +651,7 @@ int sbe_destroy(sbe_engine* e) {
     if (e->h_step_payload) (void)hipHostFree(e->h_step_payload);
     void* dev_ptrs[] = {e->d_step_pf, e->d_step_pg, e->d_logtab, e->d_state_h, e->d_toff, e->d_tid, e->d_tuple_g, e->d_tuple_p, e->d_state_q, e->d_probs_t, e->d_wpat_t, e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
                         e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_unif, e->d_partials,
-                        e->d_status, e->d_changed, e->d_scratch};
+                        e->d_status, e->d_changed, e->d_step_stamp, e->d_scratch};
     for (void* p : dev_ptrs) if (p) (void)hipFree(p);
     if (e->h_results) (void)hipHostFree(e->h_results);
     if (e->h_status) (void)hipHostFree(e->h_status);
@@ -793,6 +794,8 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_RC(dmalloc(e, &e->d_partials, NS * e->partials_stride));
     CREATE_RC(dmalloc(e, &e->d_status, (int64_t)ST_WORDS));
     CREATE_RC(dmalloc(e, &e->d_changed, (int64_t)e->Gtot));
+    CREATE_RC(dmalloc(e, &e->d_step_stamp, (int64_t)e->Gtot));
+    CREATE_CHK(hipMemsetAsync(e->d_step_stamp, 0, e->Gtot * sizeof(uint32_t), e->stream));
     CREATE_RC(dmalloc(e, &e->d_step_pf, (int64_t)e->Gtot * F));
     CREATE_RC(dmalloc(e, &e->d_step_pg, (int64_t)e->Gtot));
     {   // one-call step: payload layout (every section 16-byte aligned) and the mapped result block
@@ -1784,7 +1787,8 @@ int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters
     // few-launch form (one H2D payload, four kernels, results through mapped memory) whenever the step fits its
     // payload; the call-by-call form otherwise (many changed rows, never-uploaded patterns) or on request
     static const bool force_general = getenv("SBE_STEP_GENERAL") && atoi(getenv("SBE_STEP_GENERAL")) == 1;
-    if (!force_general && e->opt_step_form == 0 && n_changed <= e->step_max_rows && !cur.patterns_dirty)
+    if (!force_general && e->opt_step_form == 0 && n_changed <= e->step_max_rows && !cur.patterns_dirty &&
+        (int64_t)e->Gtot * e->S * 28 <= 60 * 1024)        // (k_step_core's LDS image of one feature column)
         return step_lean(e, cur_slot, cand_slot, clusters, changed_objects, n_changed, source_rows, weights,
                          group_logliks_out, mixture_out, changed_groups_out);
     return step_general(e, cur_slot, cand_slot, clusters, changed_objects, n_changed, source_rows, weights,
@@ -1858,8 +1862,8 @@ static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* 
     const auto t1 = std::chrono::steady_clock::now();
     const uint8_t* pl = e->d_step_payload;
 
-    // ---- kernel 1: candidate slot = current slot + payload ---------------------------------------------------
-    StepApply a{};
+    // ---- kernel 1: candidate slot = current slot + payload, count delta, every table ---------------------------
+    StepCore a{};
     uint32_t run = 0;
     auto seg = [&](auto* base, int64_t elems, const void* payload_src) {       // per-slot array `base`, elems per slot
         const int64_t bytes = elems * (int64_t)sizeof(*base);
@@ -1869,9 +1873,9 @@ static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* 
         run += (uint32_t)(bytes / 4);
         a.cs.end[a.cs.n++] = run;
     };
+    uint16_t* g_cur = e->d_gid + (int64_t)cur_slot * C * Np;
     // gid: component 0 from the payload when the clusters changed; the other components from the current slot
     {
-        uint16_t* g_cur = e->d_gid + (int64_t)cur_slot * C * Np;
         uint16_t* g_cand = e->d_gid + (int64_t)cand_slot * C * Np;
         a.cs.src[a.cs.n] = reinterpret_cast<const uint32_t*>(regroup ? (const void*)(pl + L.ids) : (const void*)g_cur);
         a.cs.dst[a.cs.n] = reinterpret_cast<uint32_t*>(g_cand);
@@ -1891,51 +1895,54 @@ static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* 
     seg(e->d_weights, (int64_t)F * C, weights ? pl + L.weights : nullptr);
     a.src_seg = a.cs.n;
     seg(e->d_src, (int64_t)N * e->Fp, nullptr);
-    seg(e->d_counts, e->table_elems(), nullptr);
     a.row_of = n_changed > 0 ? reinterpret_cast<const int16_t*>(pl + L.row_of) : nullptr;
     a.rows = pl + L.rows;
     a.objects = reinterpret_cast<const int32_t*>(pl + L.objects);
     a.src_dst = e->d_src + (int64_t)cand_slot * N * e->Fp;
-    a.n_changed = n_changed; a.F = F; a.C = C; a.Fp = e->Fp;
-    a.changed = e->d_changed; a.Gtot = e->Gtot; a.status = e->d_status;
-    k_step_apply<<<std::min<int64_t>(div_up(run, 256), 4 * e->compute_units), 256, 0, e->stream>>>(a);
-    HIPCHK(e, hipGetLastError());
-    // ---- kernel 2: count delta over the moved objects ---------------------------------------------------------
-    if (n_subset > 0) {
-        int rc = counts_launch(e, cand_slot, +1, cur_slot, -1, reinterpret_cast<const int32_t*>(pl + L.subset), n_subset,
-                               cand_slot, true, e->d_changed);
-        if (rc) return rc;
-    }
-    // ---- kernel 3: every table of the candidate ---------------------------------------------------------------
+    a.n_changed = n_changed; a.F = F; a.C = C; a.Fp = e->Fp; a.status = e->d_status;
+    // tile blocks
     const int P = (int)cd.patterns.size();
-    StepTables t{};
-    t.counts = e->d_counts + (int64_t)cand_slot * e->table_elems(); t.conc = e->d_conc;
-    t.probs = e->d_probs + (int64_t)cand_slot * e->table_elems();
-    t.probs_t = e->d_probs_t + (int64_t)cand_slot * e->probs_t_elems();
-    t.per_feature = e->d_step_pf;
-    t.weights = e->d_weights + (int64_t)cand_slot * F * C;
-    t.pattern_bits = e->d_patbits + (int64_t)cand_slot * e->Pmax;
-    t.wpat = e->d_wpat + (int64_t)cand_slot * e->Pmax * F * C;
-    t.wpat_t = e->d_wpat_t + (int64_t)cand_slot * e->wpat_t_elems();
-    t.Gtot = e->Gtot; t.F = F; t.S = e->S; t.C = C; t.P = P; t.Pmax = e->Pmax; t.ft = e->ft; t.n_ftiles = e->n_ftiles;
-    t.status = e->d_status;
-    {
-        const int rpb = e->S <= kBlock ? std::min(kStepRowsMax, kBlock / e->S) : 0;
-        if (rpb == 0) return fail(e, SBE_ERR_ARG, "one-call step: %d states per feature exceed the table kernel's row width", e->S);
-        const int row_blocks = div_up((int64_t)e->Gtot * F, rpb);
-        k_step_tables<<<row_blocks + div_up((int64_t)P * F, kBlock), kBlock, 0, e->stream>>>(t, rpb, row_blocks);
+    a.state = e->d_state; a.gid_cur = g_cur;
+    a.ids_new = regroup ? reinterpret_cast<const uint16_t*>(pl + L.ids) : nullptr;
+    a.src_cur = e->d_src + (int64_t)cur_slot * N * e->Fp;
+    a.subset = reinterpret_cast<const int32_t*>(pl + L.subset); a.n_subset = n_subset;
+    a.counts_cur = e->d_counts + (int64_t)cur_slot * e->table_elems();
+    a.counts_new = e->d_counts + (int64_t)cand_slot * e->table_elems();
+    a.conc = e->d_conc;
+    a.probs = e->d_probs + (int64_t)cand_slot * e->table_elems();
+    a.probs_t = e->d_probs_t + (int64_t)cand_slot * e->probs_t_elems();
+    a.per_feature = e->d_step_pf;
+    if (++e->step_id == 0) {                  // stamp wrap-around (2^32 steps): start over from clean stamps
+        HIPCHK(e, hipMemsetAsync(e->d_step_stamp, 0, e->Gtot * sizeof(uint32_t), e->stream));
+        e->step_id = 1;
     }
-    HIPCHK(e, hipGetLastError());
+    a.stamp = e->d_step_stamp; a.step_id = e->step_id;
+    a.Np = Np; a.S = e->S; a.Gtot = e->Gtot; a.ft = e->ft;
+    a.ftc = (int)std::max<int64_t>(1, std::min<int64_t>(8, 2048 / ((int64_t)e->Gtot * e->S)));
+    a.n_tile_blocks = div_up(F, a.ftc);
+    // weight blocks
+    a.weights = weights ? reinterpret_cast<const float*>(pl + L.weights) : e->d_weights + (int64_t)cur_slot * F * C;
+    a.pattern_bits = regroup ? reinterpret_cast<const uint32_t*>(pl + L.patbits) : e->d_patbits + (int64_t)cur_slot * e->Pmax;
+    a.wpat = e->d_wpat + (int64_t)cand_slot * e->Pmax * F * C;
+    a.wpat_t = e->d_wpat_t + (int64_t)cand_slot * e->wpat_t_elems();
+    a.P = P; a.Pmax = e->Pmax; a.n_weight_blocks = div_up((int64_t)P * F, kBlock);
+    {
+        const int64_t E = (int64_t)e->Gtot * a.ftc * e->S, R = (int64_t)e->Gtot * a.ftc;
+        const size_t lds = (size_t)((E * 4 + 15) / 16 * 16) + (size_t)(2 * E + R) * sizeof(double);
+        const int copy_blocks = (int)std::min<int64_t>(div_up(run, 1024), 2 * e->compute_units);
+        k_step_core<<<a.n_tile_blocks + a.n_weight_blocks + std::max(copy_blocks, 1), kBlock, lds, e->stream>>>(a);
+        HIPCHK(e, hipGetLastError());
+    }
     std::fill(cd.probs_set.begin(), cd.probs_set.end(), 1);
     cd.weights_set = true;
     e->slots[cand_slot] = cd;
-    // ---- kernels 4 + 5: fused mixture eval, reduction + step epilogue (mapped-memory results) -------------------
+    // ---- kernels 2 + 3: fused mixture eval, reduction + step epilogue (mapped-memory results) -------------------
     StepFinish fin{};
     fin.per_feature = e->d_step_pf;
     fin.group_out = reinterpret_cast<double*>(e->d_step_host);
     fin.status = e->d_status;
     fin.status_out = reinterpret_cast<int*>(e->d_step_host + (size_t)e->Gtot * sizeof(double));
-    fin.changed = e->d_changed;
+    fin.changed = nullptr; fin.stamp = e->d_step_stamp; fin.step_id = e->step_id;
     fin.changed_out = e->d_step_host + (size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int);
     fin.Gtot = e->Gtot; fin.F = F;
     int rc = launch_mixture(e, cand_slot, 1, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, &fin);

@@ -619,7 +619,9 @@ enum MixMode : int { LOG_PER_OBS = 0, LOG_PRODUCT = 1, WRITE_OBS = 2 };
 struct StepFinish {
     const float* per_feature;      // [Gtot][F] (k_step_tables); nullptr = no epilogue
     double* group_out;             // mapped [Gtot]
-    const uint8_t* changed;        // [Gtot]
+    const uint8_t* changed;        // [Gtot] flags, or nullptr when `stamp` is used
+    const uint32_t* stamp;         // [Gtot] group changed in step `step_id` iff stamp[g] == step_id (k_step_core)
+    uint32_t step_id;
     uint8_t* changed_out;          // mapped [Gtot]
     const int* status;             // [ST_WORDS]
     int* status_out;               // mapped [ST_WORDS]
@@ -648,7 +650,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __rest
                 const float* p = fits ? stage + g * fin.F : fin.per_feature + (int64_t)(g0 + g) * fin.F;
                 auto get = [&](int i) -> float { return p[i]; };
                 fin.group_out[g0 + g] = (double)np_pairwise_sum<float>(get, fin.F);
-                fin.changed_out[g0 + g] = fin.changed[g0 + g];
+                fin.changed_out[g0 + g] = fin.stamp ? (uint8_t)(fin.stamp[g0 + g] == fin.step_id) : fin.changed[g0 + g];
             }
             __syncthreads();
         }
@@ -1878,28 +1880,141 @@ __global__ void k_multi_copy(CopySegs cs) {
 }
 
 // ------------------------------------------------------------------------------------------
-// One-call MCMC step (sbe_step), kernel 1 of 4: build the candidate slot from the current slot and the step's
-// payload (ONE H2D copy: new cluster ids / pattern ids / tuple tables, changed source rows, weights).
-//   * every per-slot array = one segment, copied from the current slot OR from a payload section;
-//   * the source rows of the changed objects are not copied but converted from the payload's bool rows
-//     (k_ingest_source's job); `row_of[n]` = row index of object n in the payload or -1;
-//   * the changed-group flags are cleared for the count kernel that follows.
+// One-call MCMC step (sbe_step), kernel 1 of 3: the candidate slot = current slot + the step's payload (new
+// cluster / pattern / tuple ids, changed source rows, weights; host-mapped pinned memory read in place), its count
+// delta and every one of its tables in ONE launch -- no kernel boundary is needed between "apply", "count" and
+// "tables" once every block works from the CURRENT slot and the payload only:
+//   tile blocks   [0, n_tile_blocks): a block owns `ftc` features of every group: count delta of the moved
+//                 objects (LDS histogram; the new group / source of an object come from the payload where it
+//                 carries them, else from the current slot), candidate counts = current + delta, then the
+//                 block's rows of every table (k_step_tables' arithmetic).  Changed groups are stamped with
+//                 the step number (no flag array to clear).
+//   weight blocks: normalised weights per pattern (from the payload's / the current slot's weights and patterns)
+//   copy blocks  : the other per-slot arrays, current slot or payload -> candidate (k_step_apply without counts)
 // ------------------------------------------------------------------------------------------
-struct StepApply {
-    CopySegs cs;
-    int src_seg;                   // segment index of the source array in cs
-    const int16_t* row_of;         // [Np] (payload) or nullptr when no source row changes
-    const uint8_t* rows;           // [n_changed][F][C] bool (payload)
-    const int32_t* objects;        // [n_changed] (payload)
-    uint8_t* src_dst;              // candidate slot's source ids [N][Fp]
+struct StepCore {
+    // copy blocks
+    CopySegs cs; int src_seg;
+    const int16_t* row_of; const uint8_t* rows; const int32_t* objects; uint8_t* src_dst;
     int n_changed, F, C, Fp;
-    uint8_t* changed; int Gtot;
     int* status;
+    // tile blocks
+    const uint8_t* state; const uint16_t* gid_cur; const uint16_t* ids_new; const uint8_t* src_cur;
+    const int32_t* subset; int n_subset;
+    const int32_t* counts_cur; int32_t* counts_new;
+    const double* conc; float* probs; float* probs_t; float* per_feature;
+    uint32_t* stamp; uint32_t step_id;
+    int Np, S, Gtot, ft, ftc, n_tile_blocks;
+    // weight blocks
+    const float* weights; const uint32_t* pattern_bits; float* wpat; double* wpat_t;
+    int P, Pmax, n_weight_blocks;
 };
 
-__global__ void k_step_apply(StepApply a) {
+__global__ __launch_bounds__(kBlock) void k_step_core(StepCore a) {
+    extern __shared__ __align__(16) unsigned char core_lds[];
+    const int S = a.S, C = a.C, F = a.F;
+    if ((int)blockIdx.x < a.n_tile_blocks) {
+        const int ftc = a.ftc, f0 = (int)blockIdx.x * ftc;
+        const int E = a.Gtot * ftc * S, R = a.Gtot * ftc;
+        int32_t* hist = reinterpret_cast<int32_t*>(core_lds);                       // [Gtot][ftc][S] delta, then counts
+        double* sh_post = reinterpret_cast<double*>(core_lds + ((size_t)E * 4 + 15) / 16 * 16);
+        double* sh_ser = sh_post + E;
+        double* sh_total = sh_ser + E;                                              // [Gtot][ftc]
+        for (int e = threadIdx.x; e < E; e += kBlock) hist[e] = 0;
+        __syncthreads();
+        for (int k = threadIdx.x; k < a.n_subset * ftc; k += kBlock) {
+            const int i = k / ftc, fl = k - i * ftc, f = f0 + fl;
+            if (f >= F) continue;
+            const int n = a.subset[i];
+            const uint8_t x = a.state[(int64_t)n * a.Fp + f];
+            if (x == kNA) continue;
+            const int c_old = a.src_cur[(int64_t)n * a.Fp + f];
+            if (c_old < C) {
+                const uint16_t g = a.gid_cur[(int64_t)c_old * a.Np + n];
+                if (g != kNoGroup) atomicAdd(&hist[((int)g * ftc + fl) * S + x], -1);
+            }
+            int c_new = c_old;
+            const int r = a.row_of ? a.row_of[n] : -1;
+            if (r >= 0) {
+                const uint8_t* pr = a.rows + ((int64_t)r * F + f) * C;
+                c_new = kNA;
+                for (int c = 0; c < C; ++c) if (pr[c]) c_new = c;
+            }
+            if (c_new < C) {
+                const uint16_t g = (c_new == 0 && a.ids_new) ? a.ids_new[n] : a.gid_cur[(int64_t)c_new * a.Np + n];
+                if (g != kNoGroup) atomicAdd(&hist[((int)g * ftc + fl) * S + x], 1);
+            }
+        }
+        __syncthreads();
+        // candidate counts; posterior counts and lgamma terms of every element
+        for (int e = threadIdx.x; e < E; e += kBlock) {
+            const int g = e / (ftc * S), rem = e - g * (ftc * S), fl = rem / S, s = rem - fl * S;
+            const int f = f0 + fl;
+            if (f >= F) continue;
+            const int64_t gi = ((int64_t)g * F + f) * S + s;
+            const int d = hist[e];
+            const int cn = a.counts_cur[gi] + d;
+            a.counts_new[gi] = cn;
+            if (d != 0) a.stamp[g] = a.step_id;
+            hist[e] = cn;
+            const float cf = (float)cn;
+            const double conc = a.conc[gi];
+            sh_post[e] = (double)cf + conc;
+            sh_ser[e] = conc > 0.0 ? lgamma((double)cf + conc) - lgamma(conc) : 0.0;
+        }
+        __syncthreads();
+        for (int r = threadIdx.x; r < R; r += kBlock) {                              // ordered sums of a row
+            const int g = r / ftc, fl = r - g * ftc, f = f0 + fl;
+            if (f >= F) continue;
+            const int e0 = r * S;
+            const int64_t base = ((int64_t)g * F + f) * S;
+            auto post_at = [&](int k) -> double { return sh_post[e0 + k]; };
+            auto ser_at = [&](int k) -> double { return sh_ser[e0 + k]; };
+            auto cnt_at = [&](int k) -> float { return (float)hist[e0 + k]; };
+            auto conc_at = [&](int k) -> double { return a.conc[base + k]; };
+            const double total = np_pairwise_sum<double>(post_at, S);
+            if (!(total > 0.0)) atomicAdd(&a.status[ST_BAD_NORMALIZE], 1);
+            sh_total[r] = total;
+            const float n = np_pairwise_sum<float>(cnt_at, S);
+            const double sum_a = np_pairwise_sum<double>(conc_at, S);
+            const double cst = lgamma(sum_a) - lgamma((double)n + sum_a);
+            a.per_feature[(int64_t)g * F + f] = (float)(cst + np_pairwise_sum<double>(ser_at, S));
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < E; e += kBlock) {
+            const int g = e / (ftc * S), rem = e - g * (ftc * S), fl = rem / S, s = rem - fl * S;
+            const int f = f0 + fl;
+            if (f >= F) continue;
+            const float pr = (float)(sh_post[e] / sh_total[g * ftc + fl]);
+            a.probs[((int64_t)g * F + f) * S + s] = pr;
+            const int tile = f / a.ft, tl = f % a.ft;
+            a.probs_t[((((int64_t)tile * (a.Gtot + 1) + g) * S) + s) * a.ft + tl] = pr;
+        }
+        return;
+    }
+    const int wb = (int)blockIdx.x - a.n_tile_blocks;
+    if (wb < a.n_weight_blocks) {
+        const int64_t j = (int64_t)wb * kBlock + threadIdx.x;
+        if (j >= (int64_t)a.P * F) return;
+        const int p = (int)(j / F), f = (int)(j % F);
+        const uint32_t bits = a.pattern_bits[p];
+        const float* w = a.weights + (int64_t)f * C;
+        auto masked = [&](int c) -> float { return ((bits >> c) & 1u) ? w[c] : 0.0f * w[c]; };
+        const float total = np_pairwise_sum<float>(masked, C);
+        float* out = a.wpat + ((int64_t)p * F + f) * C;
+        const int tile = f / a.ft, tl = f % a.ft;
+        double* ot = a.wpat_t + (((int64_t)tile * a.Pmax + p) * C) * a.ft + tl;
+        for (int c = 0; c < C; ++c) {
+            const float v = masked(c) / total;
+            out[c] = v;
+            ot[(int64_t)c * a.ft] = (double)v;
+        }
+        return;
+    }
+    // copy blocks
+    const uint32_t n_copy = gridDim.x - (uint32_t)(a.n_tile_blocks + a.n_weight_blocks);
+    const uint32_t tid = (uint32_t)(wb - a.n_weight_blocks) * kBlock + threadIdx.x, nthreads = n_copy * kBlock;
     const uint32_t total = a.cs.end[a.cs.n - 1];
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
     for (uint32_t i = tid; i < total; i += nthreads) {
         int k = 0;
         while (i >= a.cs.end[k]) ++k;
@@ -1908,97 +2023,18 @@ __global__ void k_step_apply(StepApply a) {
         a.cs.dst[k][j] = a.cs.src[k][j];
     }
     int multi = 0;
-    for (uint32_t i = tid; i < (uint32_t)a.n_changed * (uint32_t)a.F; i += nthreads) {
-        const int r = (int)(i / (uint32_t)a.F), f = (int)(i % (uint32_t)a.F);
-        const uint8_t* p = a.rows + (int64_t)i * a.C;
+    for (uint32_t i = tid; i < (uint32_t)a.n_changed * (uint32_t)F; i += nthreads) {
+        const int r = (int)(i / (uint32_t)F), f = (int)(i % (uint32_t)F);
+        const int n = a.objects[r];
+        if (a.row_of[n] != r) continue;                      // an object listed twice: the row the tile blocks use
+        const uint8_t* p = a.rows + (int64_t)i * C;
         int id = kNA, cnt = 0;
-        for (int c = 0; c < a.C; ++c)
+        for (int c = 0; c < C; ++c)
             if (p[c]) { id = c; ++cnt; }
-        a.src_dst[(int64_t)a.objects[r] * a.Fp + f] = (uint8_t)id;
+        a.src_dst[(int64_t)n * a.Fp + f] = (uint8_t)id;
         multi += cnt > 1;
     }
-    for (uint32_t g = tid; g < (uint32_t)a.Gtot; g += nthreads) a.changed[g] = 0;
-    // (the data-check words are zero on entry: the host delivers any pending check before a step starts and
-    //  clears the words after reporting)
     if (multi) atomicAdd(&a.status[ST_MULTI_SOURCE], multi);
-}
-
-// Kernel 3 of 4: every table of the candidate slot in one launch (replaces k_probs + k_tile_probs + k_dcl +
-// k_weight_patterns + k_tile_weights of the call-by-call flow; same arithmetic, same NumPy orders).
-//   threads [0, Gtot*F): row (group, feature): probs = normalize(counts + conc) -> canonical + tile-transposed
-//                        copy; collapsed per-feature log-pdf (a8)
-//   threads [Gtot*F, Gtot*F + P*F): row (pattern, feature): normalised weights -> [P][F][C] f32 + tiled f64
-struct StepTables {
-    const int32_t* counts; const double* conc; float* probs; float* probs_t; float* per_feature;
-    const float* weights; const uint32_t* pattern_bits; float* wpat; double* wpat_t;
-    int Gtot, F, S, C, P, Pmax, ft, n_ftiles;
-    int* status;
-};
-
-// Rows are spread over the lanes: thread <-> table element (row, state) for the two lgammas and the posterior
-// count of its element (LDS), then the row's first thread does the NumPy-order sums over the S staged values
-// (S small) and every element thread writes its own probability -- 22 serial lgammas per thread became 2.
-constexpr int kStepRowsMax = 128;                    // rows per block (S >= 2: 256 / S <= 128; S == 1: 128)
-__global__ __launch_bounds__(kBlock) void k_step_tables(StepTables a, int rows_per_block, int n_row_blocks) {
-    __shared__ double sh_post[kBlock], sh_ser[kBlock], sh_total[kStepRowsMax];
-    __shared__ float sh_cnt[kBlock];
-    const int S = a.S;
-    if ((int)blockIdx.x < n_row_blocks) {
-        const int64_t n_rows = (int64_t)a.Gtot * a.F;
-        const int rl = S <= kBlock ? (int)threadIdx.x / S : 0, s = S <= kBlock ? (int)threadIdx.x % S : 0;
-        const int64_t row = (int64_t)blockIdx.x * rows_per_block + rl;
-        const bool act = rl < rows_per_block && row < n_rows;
-        double post = 0.0, conc = 0.0;
-        float cf = 0.0f;
-        if (act) {
-            cf = (float)a.counts[row * S + s];
-            conc = a.conc[row * S + s];
-            post = (double)cf + conc;
-            sh_post[threadIdx.x] = post;
-            sh_cnt[threadIdx.x] = cf;
-            sh_ser[threadIdx.x] = conc > 0.0 ? lgamma((double)cf + conc) - lgamma(conc) : 0.0;
-        }
-        __syncthreads();
-        if (act && s == 0) {                          // the row's ordered sums (NumPy pairwise order)
-            const double* pp = sh_post + rl * S; const double* ps = sh_ser + rl * S; const float* pc = sh_cnt + rl * S;
-            const int64_t base = row * S;
-            auto post_at = [&](int k) -> double { return pp[k]; };
-            auto ser_at = [&](int k) -> double { return ps[k]; };
-            auto cnt_at = [&](int k) -> float { return pc[k]; };
-            auto conc_at = [&](int k) -> double { return a.conc[base + k]; };
-            const double total = np_pairwise_sum<double>(post_at, S);
-            if (!(total > 0.0)) atomicAdd(&a.status[ST_BAD_NORMALIZE], 1);
-            sh_total[rl] = total;
-            const float n = np_pairwise_sum<float>(cnt_at, S);
-            const double sum_a = np_pairwise_sum<double>(conc_at, S);
-            const double cst = lgamma(sum_a) - lgamma((double)n + sum_a);
-            a.per_feature[row] = (float)(cst + np_pairwise_sum<double>(ser_at, S));
-        }
-        __syncthreads();
-        if (act) {
-            const int g = (int)(row / a.F), f = (int)(row % a.F);
-            const float pr = (float)(post / sh_total[rl]);
-            a.probs[row * S + s] = pr;
-            const int tile = f / a.ft, fl = f % a.ft;
-            a.probs_t[((((int64_t)tile * (a.Gtot + 1) + g) * S) + s) * a.ft + fl] = pr;
-        }
-        return;
-    }
-    const int64_t j = (int64_t)((int)blockIdx.x - n_row_blocks) * kBlock + threadIdx.x;
-    if (j >= (int64_t)a.P * a.F) return;
-    const int p = (int)(j / a.F), f = (int)(j % a.F);
-    const uint32_t bits = a.pattern_bits[p];
-    const float* w = a.weights + (int64_t)f * a.C;
-    auto masked = [&](int c) -> float { return ((bits >> c) & 1u) ? w[c] : 0.0f * w[c]; };
-    const float total = np_pairwise_sum<float>(masked, a.C);
-    float* out = a.wpat + ((int64_t)p * a.F + f) * a.C;
-    const int tile = f / a.ft, fl = f % a.ft;
-    double* ot = a.wpat_t + (((int64_t)tile * a.Pmax + p) * a.C) * a.ft + fl;
-    for (int c = 0; c < a.C; ++c) {
-        const float v = masked(c) / total;
-        out[c] = v;
-        ot[(int64_t)c * a.ft] = (double)v;
-    }
 }
 
 // canonical probs [Gtot][F][S] -> tile-transposed probs_t [n_ftiles][Gtot+1][S][FT] for the
