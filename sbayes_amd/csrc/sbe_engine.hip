@@ -283,7 +283,7 @@ void derive_tuples(sbe_engine* e, Slot& s) {
     s.h_tid.assign(e->Np, 0);
     s.h_toff.assign(e->Np, 0);
     s.h_tuple_g.assign((size_t)kMaxTuples * kMaxComponents, (uint16_t)e->Gtot);
-    s.h_tuple_p.assign(kMaxTuples, 0);
+    s.h_tuple_p.assign(kMaxTuples, 0xFF);            // 0xFF = tuple not present in this slot
     uint16_t tuples[kMaxTuples][kMaxComponents];
     int n_tup = 0;
     bool ok = true;

@@ -1134,7 +1134,8 @@ __global__ __launch_bounds__(kBlock) void k_mixture_combo(Mix2Params p) {
                 const int s = r % S, t = r / S;
                 tt[u] = t;
                 // features past F in the last tile are never gathered (their state bytes are NA): no log for them
-                dst[u] = (e < n_ent && tile * FT + fl < p.F) ? (t * S1 + s) * FT + fl : -1;
+                // ... nor for tuples this slot does not have (pattern 0xFF: the launch's KT is the batch maximum)
+                dst[u] = (e < n_ent && tile * FT + fl < p.F && tpl[t] != 0xFFu) ? (t * S1 + s) * FT + fl : -1;
 #pragma unroll
                 for (int c = 0; c < CU; ++c)
                     pr[u][c] = (CT || c < C) ? probs_t[((int64_t)tgl[t * CU + c] * S + s) * FT + fl] : 0.0f;
@@ -1411,8 +1412,10 @@ __global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
 #pragma unroll
         for (int c = 0; c < CU; ++c)
             v_goff[c] = (CT || c < C) ? ((uint32_t)tuple_g[t * kMaxComponents + c] * (uint32_t)S + st) * (FT * 4u) : 0u;
-        v_woff = w_off + (uint32_t)tuple_p[t] * (uint32_t)(C * FT * 8);
-        v_doff = (t * (uint32_t)S1 + st) * (FT * 8u);
+        const uint32_t pat = tuple_p[t];
+        v_woff = w_off + pat * (uint32_t)(C * FT * 8);
+        // a tuple this slot does not have (pattern 0xFF: the launch's KT is the batch maximum): row skipped
+        v_doff = pat != 0xFFu ? (t * (uint32_t)S1 + st) * (FT * 8u) : 0xFFFFFFFFu;
     };
     float pr[U][CU];
     auto row_loads = [&](int i0, int n_here) {                             // rows i0 .. i0+U-1 of the current pass
@@ -1453,7 +1456,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
                     if (base || i0) row_loads(i0, n_here);                      // (the first batch is already in flight)
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        if (i0 + u < n_here) {
+                        if (i0 + u < n_here && (uint32_t)__builtin_amdgcn_readlane((int)v_doff, i0 + u) != 0xFFFFFFFFu) {
                             const uint32_t woff = (uint32_t)__builtin_amdgcn_readlane((int)v_woff, i0 + u) + lane8;
                             const uint32_t doff = (uint32_t)__builtin_amdgcn_readlane((int)v_doff, i0 + u) + lane8;
                             double v = 0.0;
@@ -1547,7 +1550,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
         const bool live = fl < p.ragged_w;
         for (int r0 = w * SUB; r0 < n_rows; r0 += 4 * SUB) {
             const int r = r0 + sub;
-            if (r < n_rows) {
+            if (r < n_rows && tuple_p[(uint32_t)r / (uint32_t)S] != 0xFFu) {
                 const uint32_t t = (uint32_t)r / (uint32_t)S, st = (uint32_t)r - t * (uint32_t)S;
                 const double* wr = reinterpret_cast<const double*>(lds_raw + w_off) + (uint32_t)tuple_p[t] * (uint32_t)(C * FT) + fl;
                 double v = 0.0;

@@ -169,7 +169,7 @@ def _run_case(feats, groups, weights, source, conc, n_groups, rng, light=False):
 def test_tuple_kernel_batches(shape):
     """Batches through the scalar-unit group-tuple kernel: every slot holds a different state; the batched
     launch (XCD-dealt, generation-ordered blocks) must give each slot the value of its own single evaluation
-    and of the oracle.  A state with a zero-probability observation (-inf) rides along."""
+    and of the oracle.  One slot has fewer group tuples than the launch's maximum (its unused table rows are skipped)."""
     N, F, S, n_groups, B = shape
     rng = np.random.default_rng(N * 1000 + F)
     feats, groups0, _w, _s, conc = random_case(rng, N, F, S, n_groups, 0.05)
@@ -181,6 +181,8 @@ def test_tuple_kernel_batches(shape):
         want = []
         for b in range(B):
             a = rng.integers(0, 2 * n_groups[0], size=N)
+            if b == 1:
+                a[:] = 2 * n_groups[0] - 1          # nobody in a cluster: fewer group tuples than the other slots
             groups = [np.stack([a == k for k in range(n_groups[0])])] + groups0[1:]
             weights = rng.dirichlet(np.ones(C), size=F).astype(np.float32)
             hc = orc.has_components(groups)
