@@ -867,14 +867,14 @@ __global__ __launch_bounds__(kBlock) void k_mixture_v2(Mix2Params p) {
             const uint32_t xc = valid ? x : 0u;
             const uint32_t pj = (pq >> (8 * j)) & 0xFFu;
             const float* tj = tab_l + xc * FT;
-            const double* wj = wl_l + pj * (uint32_t)(C * FT);
+            const double* wj = wl_l + __umul24(pj, (uint32_t)(C * FT));
             double vj = 0.0;
 #pragma unroll
             for (int c = 0; c < CU; ++c) {
                 if (CT || c < C) {
                     uint32_t g = (uint32_t)(gq[c] >> (16 * j)) & 0xFFFFu;
                     g = g < gmax ? g : gmax;                        // no group -> zero row
-                    const double t = wj[c * FT] * (double)tj[g * row];
+                    const double t = wj[c * FT] * (double)tj[__umul24(g, row)];   // (24-bit multiply: full rate; g < 2^16, row < 2^24)
                     vj = c == 0 ? t : vj + t;                       // NumPy order, no FMA
                 }
             }
@@ -990,12 +990,12 @@ __global__ __launch_bounds__(kBlock) void k_mixture_onehot_v2(Mix2Params p) {
         const int fl = (int)((float)j * inv_s + half_inv_s);        // j / S
         const int x = j - fl * S;
         const float* tj = L.tab + x * FT + fl;
-        const double* wj = L.wl + pidn * (uint32_t)(C * FT) + fl;
+        const double* wj = L.wl + __umul24(pidn, (uint32_t)(C * FT)) + fl;
         double vj = 0.0;
 #pragma unroll
         for (int c = 0; c < CU; ++c) {
             if (CT || c < C) {
-                const double t = wj[c * FT] * (double)tj[g[c] * row];
+                const double t = wj[c * FT] * (double)tj[__umul24(g[c], row)];
                 vj = c == 0 ? t : vj + t;
             }
         }
