@@ -12,6 +12,11 @@ workgroups per launch; `batch_sweep` in the output line reports B = 1 .. 1024). 
 probability tables, weights) is resident in HBM before the timed region; the B scalars are
 fetched to the host inside the timed region.
 
+The roofline's kernel duration comes from HIP event pairs recorded (on the engine's own stream) around the
+dominant kernel of K launches identical to the timed ones, issued right after the timed region (`--events-in-loop`
+records them inside the timed loop instead; the event records between back-to-back launches then cost the loop
+several us per step).
+
   python bench.py                       # 1 GPU, defaults finish in well under a minute
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
@@ -56,6 +61,10 @@ def parse():
     ap.add_argument("--log-mode", default="product", choices=["product", "per_obs"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--events-in-loop", action="store_true",
+                    help="record the roofline's HIP event pairs inside the timed loop itself (perturbs it: an event "
+                         "record between back-to-back launches costs several us per step) instead of in an identical "
+                         "loop of K launches right after it")
     ap.add_argument("--explore", action="store_true", help="also print the batch sweep to stderr")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (latency, sweep, a1/a7 rates)")
     return ap.parse_args()
@@ -247,12 +256,21 @@ def main():
     eng.fetch_results(0, B)
 
     barrier()
+    if args.events_in_loop:
+        eng.kernel_timing_start()              # one HIP event pair per launch of the dominant kernel, engine stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     results = eng.fetch_results(0, B)          # D2H of the B scalars + stream sync, inside the timed region
     barrier()
     elapsed = chains.max_over_ranks(time.perf_counter() - t0, dist)
+    if not args.events_in_loop:                # the same K launches again, each bracketed by an event pair
+        eng.kernel_timing_start()
+        for _ in range(args.steps):
+            step()
+        eng.fetch_results(0, B)
+    n_timed, kern_ms = eng.kernel_timing_stop()
+    assert n_timed == args.steps
     assert np.all(np.isfinite(results))
 
     evals = args.steps * B * n_gpus
@@ -264,8 +282,6 @@ def main():
     n_pat = len(np.unique(has_comp, axis=0))          # distinct has_components rows (likelihood.py:183)
     packed = not args.kernel.startswith("onehot")
     b_eval = algorithmic_bytes(n_obj, n_feat, n_states, [g.shape[0] for g in wl.groups], n_pat, packed=packed)
-    prof_iters = min(max(args.steps, 20), 200)
-    _total_ms, kern_ms = eng.profile_mixture(0, B, prof_iters)
     achieved = b_eval * B / (kern_ms * 1e-3) / 1e9
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -321,6 +321,10 @@ int sbe_timer_stop(sbe_engine* e, float* elapsed_ms);
 /* Times `iters` back-to-back launches of the fused mixture kernel sequence on slots
  * [first_slot, first_slot+n) with one HIP event pair per launch sequence; returns the sum and
  * the per-launch average of the dominant kernel's duration in milliseconds. */
+/* Event timing of the dominant kernel INSIDE the caller's own loop: enable = 1 starts recording one HIP event pair
+   (on the engine's stream) around the fused kernel of every sbe_mixture_loglik[_batch[_async]] call; enable = 0 stops,
+   synchronises and returns the number of recorded launches and their average duration. */
+int sbe_kernel_timing(sbe_engine* e, int enable, int* n_launches, float* main_kernel_avg_ms);
 int sbe_profile_mixture(sbe_engine* e, int first_slot, int n, int iters, float* total_ms,
                         float* main_kernel_avg_ms);
 

@@ -42,6 +42,7 @@ struct sbe_engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ev_pool;
+    bool ev_timing = false;  int ev_used = 0;      // sbe_kernel_timing: event pairs recorded around the dominant kernel
     int N = 0, F = 0, S = 0, C = 0, n_slots = 0;
     int Fp = 0, rs_pitch = 0, Gtot = 0, Pmax = 0;
     int Np = 0, NQ = 0;            // objects padded to a multiple of 4; object quads
@@ -601,7 +602,17 @@ int enqueue_mixture(sbe_engine* e, int first_slot, int n, int mode) {
         if (rc) return rc;
         if (e->slots[s].patterns_dirty) { rc = upload_patterns_and_weights(e, s); if (rc) return rc; }
     }
-    return launch_mixture(e, first_slot, n, mode, nullptr, nullptr);
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    if (e->ev_timing) {                             // one event pair per launch, on the engine's own stream
+        while ((int)e->ev_pool.size() < 2 * (e->ev_used + 1)) {
+            hipEvent_t ev;
+            HIPCHK(e, hipEventCreate(&ev));
+            e->ev_pool.push_back(ev);
+        }
+        ev_a = e->ev_pool[2 * e->ev_used]; ev_b = e->ev_pool[2 * e->ev_used + 1];
+        ++e->ev_used;
+    }
+    return launch_mixture(e, first_slot, n, mode, ev_a, ev_b);
 }
 
 int counts_launch(sbe_engine* e, int slot_a, int sign_a, int slot_b, int sign_b, const int32_t* d_objects,
@@ -2120,6 +2131,25 @@ int sbe_timer_stop(sbe_engine* e, float* elapsed_ms) {
     HIPCHK(e, hipEventSynchronize(e->ev1));
     HIPCHK(e, hipEventElapsedTime(elapsed_ms, e->ev0, e->ev1));
     return SBE_OK;
+}
+
+int sbe_kernel_timing(sbe_engine* e, int enable, int* n_launches, float* main_kernel_avg_ms) {
+    CHECK_ENGINE(e);
+    HIPCHK(e, hipSetDevice(e->device));
+    if (enable) { e->ev_timing = true; e->ev_used = 0; return SBE_OK; }
+    CHECK_PTR(e, n_launches); CHECK_PTR(e, main_kernel_avg_ms);
+    e->ev_timing = false;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    double acc = 0.0;
+    for (int it = 0; it < e->ev_used; ++it) {
+        float ms = 0.f;
+        HIPCHK(e, hipEventElapsedTime(&ms, e->ev_pool[2 * it], e->ev_pool[2 * it + 1]));
+        acc += ms;
+    }
+    *n_launches = e->ev_used;
+    *main_kernel_avg_ms = e->ev_used ? (float)(acc / e->ev_used) : 0.f;
+    e->ev_used = 0;
+    return synced(e);
 }
 
 int sbe_profile_mixture(sbe_engine* e, int first_slot, int n, int iters, float* total_ms, float* main_kernel_avg_ms) {

@@ -531,6 +531,16 @@ class Engine:
         self._check(self._lib.sbe_timer_stop(self._h, ct.byref(ms)))
         return ms.value
 
+    def kernel_timing_start(self):
+        """Record one HIP event pair (engine stream) around the fused kernel of every mixture launch from now on."""
+        self._check(self._lib.sbe_kernel_timing(self._h, 1, None, None))
+
+    def kernel_timing_stop(self):
+        """-> (recorded launches, average duration of the fused kernel in ms)."""
+        n, avg = ct.c_int(0), ct.c_float(0.0)
+        self._check(self._lib.sbe_kernel_timing(self._h, 0, ct.byref(n), ct.byref(avg)))
+        return n.value, avg.value
+
     def profile_mixture(self, first_slot, n, iters):
         total, avg = ct.c_float(0.0), ct.c_float(0.0)
         self._check(self._lib.sbe_profile_mixture(self._h, first_slot, n, iters, ct.byref(total), ct.byref(avg)))
