@@ -77,6 +77,11 @@ def likelihood_per_component(model, sample, caching=True):
     return cache.value
 
 
+# The reference's `likelihood_per_component_subset` (conditionals.py:226-297) is a line-for-line duplicate of
+# `likelihood_per_component` with no caller in the reference; it is served by the same function.
+likelihood_per_component_subset = likelihood_per_component
+
+
 def _bind_slot(eng, model, sample, slot, with_source=False):
     """Upload one sample's state into an engine slot: group ids, counts, weights (small),
     optionally the source assignment.  Probability tables are then built on the device."""

@@ -4,7 +4,7 @@ Patches the names through which the reference reaches the path:
   sbayes.model.likelihood.{Likelihood, compute_component_likelihood, update_weights, normalize_weights}
   sbayes.model.{Likelihood, ...} re-exports, sbayes.model.model.Likelihood (model.py:7, :45)
   sbayes.sampling.conditionals.{compute_component_likelihood, likelihood_per_component,
-                                update_weights}                      (conditionals.py:14)
+                                likelihood_per_component_subset, update_weights}   (conditionals.py:14)
   sbayes.sampling.counts.{compute_effect_counts, recalculate_feature_counts, update_feature_counts}
 Only when sBayes is importable; raises otherwise.  uninstall() restores the originals."""
 from __future__ import annotations
@@ -48,6 +48,7 @@ def install():
         swap(mod, "update_weights", my_lik.update_weights)
         swap(mod, "normalize_weights", my_lik.normalize_weights)
     swap(cond, "likelihood_per_component", my_cond.likelihood_per_component)
+    swap(cond, "likelihood_per_component_subset", my_cond.likelihood_per_component_subset)
     for mod in (counts, lik, cond):
         swap(mod, "compute_effect_counts", my_counts.compute_effect_counts)
         swap(mod, "recalculate_feature_counts", my_counts.recalculate_feature_counts)
