@@ -99,6 +99,8 @@ struct sbe_engine {
     struct StepLayout { size_t ids, pid, tid, toff, tuple_g, tuple_p, patbits, weights, row_of, subset, objects, rows, total; } sl{};
     int step_max_rows = 0;
     uint8_t* h_step_payload = nullptr; uint8_t* d_step_payload = nullptr;   // host-mapped pinned: the kernels read it over PCIe
+    uint8_t* h_io = nullptr; uint8_t* d_io = nullptr; size_t io_bytes = 0;  // host-mapped pinned: small inputs / outputs of
+                                                                            // latency-bound calls, read / written in place
     uint8_t* h_step = nullptr;     uint8_t* d_step_host = nullptr;   // mapped: [Gtot] f64 | [ST_WORDS] i32 | [Gtot] u8
     uint8_t* d_scratch = nullptr;  size_t scratch_bytes = 0;     // general staging
     uint8_t* h_pinned = nullptr;   size_t pinned_bytes = 0;      // pinned D2H staging
@@ -161,6 +163,18 @@ int ensure_scratch(sbe_engine* e, size_t bytes) {
     if (e->d_scratch) { HIPCHK(e, hipStreamSynchronize(e->stream)); HIPCHK(e, hipFree(e->d_scratch)); }
     e->scratch_bytes = bytes + bytes / 4 + 4096;
     HIPCHK(e, hipMalloc((void**)&e->d_scratch, e->scratch_bytes));
+    return SBE_OK;
+}
+
+// host-mapped I/O block for latency-bound calls (the kernels read their small inputs and write their small results
+// over PCIe in place: no copy-engine hop in the dependency chain); one call at a time, each ends with a stream sync
+int ensure_io(sbe_engine* e, size_t bytes) {
+    if (bytes <= e->io_bytes) return SBE_OK;
+    if (e->h_io) { HIPCHK(e, hipStreamSynchronize(e->stream)); HIPCHK(e, hipHostFree(e->h_io)); e->h_io = nullptr; e->io_bytes = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(e, hipHostMalloc((void**)&e->h_io, want, hipHostMallocMapped));
+    HIPCHK(e, hipHostGetDevicePointer((void**)&e->d_io, e->h_io, 0));
+    e->io_bytes = want;
     return SBE_OK;
 }
 
@@ -667,6 +681,7 @@ int sbe_destroy(sbe_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->h_step) (void)hipHostFree(e->h_step);
     if (e->h_step_payload) (void)hipHostFree(e->h_step_payload);
+    if (e->h_io) (void)hipHostFree(e->h_io);
     void* dev_ptrs[] = {e->d_step_pf, e->d_step_pg, e->d_logtab, e->d_state_h, e->d_toff, e->d_tid, e->d_tuple_g, e->d_tuple_p, e->d_state_q, e->d_probs_t, e->d_wpat_t, e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
                         e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_unif, e->d_partials,
                         e->d_status, e->d_changed, e->d_step_stamp, e->d_scratch};
@@ -1529,29 +1544,29 @@ int sbe_cluster_marginals(sbe_engine* e, int slot, const float* table, const int
     HIPCHK(e, hipSetDevice(e->device));
     Slot& s = e->slots[slot];
     if (s.patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
-    const int P = (int)s.patterns.size(), F = e->F, S = e->S, C = e->C;
+    const int F = e->F, S = e->S, C = e->C;
     const size_t tb = ((size_t)F * S * sizeof(float) + 255) / 256 * 256;
-    const size_t wb = ((size_t)P * F * C * sizeof(float) + 255) / 256 * 256;
     const size_t ob = ((size_t)n_objects_av * sizeof(int32_t) + 255) / 256 * 256;
-    rc = ensure_scratch(e, tb + 2 * wb + ob + (size_t)2 * n_objects_av * sizeof(double));
+    const size_t out_bytes = (size_t)2 * n_objects_av * sizeof(double);
+    // table, object list and the result live in host-mapped memory (a few KB each): ONE kernel and one
+    // synchronisation, no copy-engine operation in the chain
+    rc = ensure_io(e, tb + ob + out_bytes);
     if (rc) return rc;
-    float* d_tab = (float*)e->d_scratch;
-    float* d_wc = (float*)(e->d_scratch + tb);
-    float* d_wf = (float*)(e->d_scratch + tb + wb);
-    int32_t* d_obj = (int32_t*)(e->d_scratch + tb + 2 * wb);
-    double* d_out = (double*)(e->d_scratch + tb + 2 * wb + ob);
-    { int _urc = upload(e, d_tab, table, (size_t)F * S * sizeof(float)); if (_urc) return _urc; }
-    { int _urc = upload(e, d_obj, objects, (size_t)n_objects_av * sizeof(int32_t)); if (_urc) return _urc; }
+    memcpy(e->h_io, table, (size_t)F * S * sizeof(float));
+    memcpy(e->h_io + tb, objects, (size_t)n_objects_av * sizeof(int32_t));
+    const float* d_tab = (const float*)e->d_io;
+    const int32_t* d_obj = (const int32_t*)(e->d_io + tb);
+    double* d_out = (double*)(e->d_io + tb + ob);
     const double inv = 1.0 / prior_temperature;
-    k_weight_tables_z<<<div_up((int64_t)P * F, 256), 256, 0, e->stream>>>(
-        e->d_weights + (int64_t)slot * F * C, e->d_patbits + (int64_t)slot * e->Pmax, d_wc, d_wf, P, F, C,
-        (float)inv, inv != 1.0 ? 1 : 0);
-    HIPCHK(e, hipGetLastError());
-    k_cluster_marginals<<<div_up(n_objects_av, kBlock / kWave), kBlock, 0, e->stream>>>(
+    k_cluster_marginals<<<n_objects_av, kBlock, 0, e->stream>>>(
         e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np,
-        e->d_probs + (int64_t)slot * e->table_elems(), d_tab, d_wc, d_wf, d_obj, n_objects_av, d_out, e->Np, F, S, C, e->Fp);
+        e->d_probs + (int64_t)slot * e->table_elems(), d_tab, e->d_weights + (int64_t)slot * F * C,
+        e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0, d_obj, n_objects_av, d_out,
+        reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C, e->Fp);
     HIPCHK(e, hipGetLastError());
-    return d2h(e, out, d_out, (size_t)2 * n_objects_av * sizeof(double));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    memcpy(out, e->h_io + tb + ob, out_bytes);
+    return synced(e);
 }
 
 // ---- data-parallel cores of Gibbs source resampling ---------------------------

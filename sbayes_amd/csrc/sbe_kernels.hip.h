@@ -1621,14 +1621,10 @@ __global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
 //   wcur  = normalize( normalize_weights(weights, pattern) ** (1/T_prior) )
 //   wflip = normalize_weights( weights ** (1/T_prior), pattern with the cluster bit flipped )
 // float32 throughout, NumPy reduction order; x ** 1.0 is exact, other exponents go through powf.
-__global__ void k_weight_tables_z(const float* __restrict__ weights, const uint32_t* __restrict__ pattern_bits,
-                                  float* __restrict__ wcur, float* __restrict__ wflip, int P, int F, int C,
-                                  float inv_tp, int use_pow) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P * F) return;
-    const int p = i / F, f = i % F;
-    const uint32_t bits = pattern_bits[p], fbits = bits ^ 1u;
-    const float* w = weights + (int64_t)f * C;
+// One (pattern, feature) row of those tables: wc[c] = wcur, wf[c] = wflip.
+__device__ __forceinline__ void weight_tables_z_row(const float* __restrict__ w, uint32_t bits, int C, float inv_tp,
+                                                    int use_pow, float* wc, float* wf) {
+    const uint32_t fbits = bits ^ 1u;
     auto masked = [&](int c) -> float { return ((bits >> c) & 1u) ? w[c] : 0.0f * w[c]; };
     const float tot = np_pairwise_sum<float>(masked, C);
     auto powd = [&](int c) -> float { const float a = masked(c) / tot; return use_pow ? powf(a, inv_tp) : a; };
@@ -1638,27 +1634,33 @@ __global__ void k_weight_tables_z(const float* __restrict__ weights, const uint3
         return ((fbits >> c) & 1u) ? pw : 0.0f * pw;
     };
     const float tot3 = np_pairwise_sum<float>(fl, C);
-    float* oc = wcur + ((int64_t)p * F + f) * C;
-    float* of = wflip + ((int64_t)p * F + f) * C;
-    for (int c = 0; c < C; ++c) { oc[c] = powd(c) / tot2; of[c] = fl(c) / tot3; }
+    for (int c = 0; c < C; ++c) { wc[c] = powd(c) / tot2; wf[c] = fl(c) / tot3; }
 }
 
+// One BLOCK per available object, thread <-> feature: the with/without weight row of the object's pattern is
+// computed in place (no table kernel in front), a lane's loads (state byte, weights, table entries of every
+// component) are all in flight together and there is one dependent-load chain per object instead of one per
+// 64 features; the two fp64 logs per observation are table-driven (tab_log_pos; the sums of logs carry far more
+// accuracy than the reference's linear-space products).  Fixed-order block reduction: deterministic.
 __global__ __launch_bounds__(kBlock) void k_cluster_marginals(
     const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid, const uint8_t* __restrict__ pid,
-    const float* __restrict__ probs, const float* __restrict__ table0, const float* __restrict__ wcur,
-    const float* __restrict__ wflip, const int32_t* __restrict__ objects, int n_av, double* __restrict__ out,
-    int Np, int F, int S, int C, int Fp) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int i = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);        // one wave per available object
-    if (i >= n_av) return;
+    const float* __restrict__ probs, const float* __restrict__ table0, const float* __restrict__ weights,
+    const uint32_t* __restrict__ pattern_bits, float inv_tp, int use_pow, const int32_t* __restrict__ objects,
+    int n_av, double* __restrict__ out, const f64x2_t* __restrict__ logtab, int Np, int F, int S, int C, int Fp) {
+    __shared__ f64x2_t tab[kLogTabEntries];
+    __shared__ double red[8];
+    if (threadIdx.x < kLogTabEntries) tab[threadIdx.x] = logtab[threadIdx.x];
+    __syncthreads();
+    const uint32_t tab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) f64x2_t*)tab;
+    const int i = blockIdx.x;
     const int n = objects[i];
     const bool inside = gid[n] != kNoGroup;                                  // component 0 = clusters
-    const int p = pid[n];
+    const uint32_t bits = pattern_bits[pid[n]];
     double acc0 = 0.0, acc1 = 0.0;
-    for (int f = lane; f < F; f += kWave) {
+    for (int f = threadIdx.x; f < F; f += kBlock) {
         const uint8_t x = state[(int64_t)n * Fp + f];
-        const float* wc = wcur + ((int64_t)p * F + f) * C;
-        const float* wf = wflip + ((int64_t)p * F + f) * C;
+        float wc[kMaxComponents], wf[kMaxComponents];
+        weight_tables_z_row(weights + (int64_t)f * C, bits, C, inv_tp, use_pow, wc, wf);   // this object's pattern
         double v0 = 0.0, v1 = 0.0;
         for (int c = 0; c < C; ++c) {
             double lh = 1.0;
@@ -1673,12 +1675,18 @@ __global__ __launch_bounds__(kBlock) void k_cluster_marginals(
             v1 = v1 + lh * (inside ? a : b);         // z = 1: the object is (or becomes) a cluster member
             v0 = v0 + lh * (inside ? b : a);
         }
-        acc0 += log(v0);
-        acc1 += log(v1);
+        acc0 += tab_log_pos(v0, tab_addr);
+        acc1 += tab_log_pos(v1, tab_addr);
     }
     acc0 = wave_sum(acc0);
     acc1 = wave_sum(acc1);
-    if (lane == 0) { out[i] = acc0; out[(int64_t)n_av + i] = acc1; }
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
+    if (lane == 0) { red[wid] = acc0; red[4 + wid] = acc1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[i] = (red[0] + red[1]) + (red[2] + red[3]);
+        out[(int64_t)n_av + i] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
 }
 
 // ==========================================================================================
