@@ -106,6 +106,42 @@ class ResidentChain:
         self._pending = True
         return _SlotView(self, self.cand)
 
+    def propose_gibbs_source(self, objects, temperature=1.0, prior_temperature=1.0, sample_from_prior=False,
+                             z=None, device_rng=False):
+        """GibbsSampleSource._propose (operators.py:495-552) on the resident state: the source assignments of the
+        listed objects are redrawn from their posterior ON THE DEVICE into the `cand` slot, counts and tables follow
+        there, and both transition log-probabilities come back -- only the object ids (and, unless
+        device_rng, the uniforms) cross PCIe; nothing of the sample state is re-uploaded (the drop-in operator
+        form, operators.gibbs_sample_source, rebinds the whole sample on every call).
+        z: uniforms [n, F] (default: np.random.random([n, F, 1]) drawn exactly where the reference draws them);
+        device_rng=True: the engine's Philox stream instead.  Returns (candidate view, log_q, log_q_back);
+        follow with accept() or reject()."""
+        eng = self.eng
+        objects = np.asarray(objects)
+        if objects.dtype == np.bool_:
+            objects = np.flatnonzero(objects)
+        objects = np.ascontiguousarray(objects, dtype=np.int32)
+        for c in self._probs_dirty[self.cur]:               # the posterior needs the current tables
+            eng.update_probs(self.cur, c)
+        self._probs_dirty[self.cur] = set()
+        if device_rng:
+            z = None
+        elif z is None:
+            z = np.random.random([objects.size, eng.n_features, 1])
+        eng.copy_slot(self.cand, self.cur)
+        log_q = eng.sample_source(self.cur, self.cand, objects, z, temperature, prior_temperature, sample_from_prior)
+        self.changed_groups = eng.update_counts(self.cand, self.cur, objects) if objects.size else \
+            np.zeros(eng.n_groups_total, dtype=bool)
+        off = eng.group_offsets
+        for c in range(eng.n_components):
+            if self.changed_groups[off[c]:off[c + 1]].any():
+                eng.update_probs(self.cand, c)               # log_q_back is evaluated against the NEW tables
+        self._probs_dirty[self.cand] = set()
+        log_q_back = eng.source_logprob(self.cand, self.cur, objects, temperature, prior_temperature, sample_from_prior)
+        self._cand_clusters = self._clusters
+        self._pending = True
+        return _SlotView(self, self.cand), log_q, log_q_back
+
     def accept(self):
         if not self._pending:
             raise RuntimeError("no pending proposal")

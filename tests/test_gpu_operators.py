@@ -163,6 +163,51 @@ def test_gibbs_source_proposal_draw_for_draw(tag):
     assert np.array_equal(sample.source.value, fx.source)
 
 
+@pytest.mark.parametrize("tag", ["all", "subset", "mc3", "prior"])
+def test_resident_gibbs_source_proposal(tag):
+    """The same operator on the RESIDENT state (ResidentChain.propose_gibbs_source: nothing of the sample is
+    re-uploaded): the reference's new source rows and counts bit for bit with the reference's uniforms, log_q /
+    log_q_back to float32 accuracy (the device sums the float64 logs of the float32 probabilities; the reference sums
+    float32 logs), candidate likelihoods equal to a from-scratch evaluation of the new state; reject leaves the
+    current state untouched, accept makes the candidate current."""
+    from sbayes_amd.registry import release_all
+    from sbayes_amd.resident import ResidentChain
+    fx, model, sample = _gibbs_fixture()
+    z = fx.z
+    objects = z[f"gs_{tag}_objects"]
+    temp, ptemp, from_prior = z[f"gs_{tag}_temps"]
+    try:
+        chain = ResidentChain(model, sample)
+        ll_cur, mix_cur = chain.current.collapsed_loglik(), chain.current.mixture_loglik()
+        cand, log_q, log_q_back = chain.propose_gibbs_source(objects, float(temp), float(ptemp), bool(from_prior),
+                                                             z=z[f"gs_{tag}_z"])
+        eng = chain.eng
+        all_objects = np.arange(sample.n_objects)
+        assert np.array_equal(eng.get_source_rows(chain.cand, all_objects), z[f"gs_{tag}_new_source"])
+        for c in range(eng.n_components):
+            assert np.array_equal(cand.counts(c), z[f"gs_{tag}_counts_{c}"])
+        assert abs(log_q - z[f"gs_{tag}_log_q"]) <= 3e-6 * abs(z[f"gs_{tag}_log_q"])
+        assert abs(log_q_back - z[f"gs_{tag}_log_q_back"]) <= 3e-6 * abs(z[f"gs_{tag}_log_q_back"])
+        # candidate likelihoods == the oracle's from-scratch evaluation of the new state
+        groups = fx.groups
+        new_source = z[f"gs_{tag}_new_source"]
+        counts = orc.recalculate_feature_counts(fx.features, groups, new_source)
+        na = ~fx.features.any(-1)
+        want_mix = orc.mixture_loglik(fx.features, na, groups, counts, fx.conc, fx.weights)
+        got_mix = cand.mixture_loglik()
+        assert abs(got_mix - want_mix) <= 1e-10 * abs(want_mix)
+        ll_cand = cand.collapsed_loglik()
+        chain.reject()
+        assert chain.current.collapsed_loglik() == ll_cur and chain.current.mixture_loglik() == mix_cur
+        cand2, log_q2, log_q_back2 = chain.propose_gibbs_source(objects, float(temp), float(ptemp), bool(from_prior),
+                                                                z=z[f"gs_{tag}_z"])
+        assert (log_q2, log_q_back2) == (log_q, log_q_back)
+        chain.accept()
+        assert chain.current.collapsed_loglik() == ll_cand and chain.current.mixture_loglik() == got_mix
+    finally:
+        release_all()
+
+
 def test_gibbs_source_same_global_rng_stream_as_reference():
     """Without explicit uniforms the operator draws np.random.random([n, F, 1]) like sample_categorical
     does: seeding np.random as the fixture did reproduces the recorded proposal."""
