@@ -207,6 +207,15 @@ def secondary_figures(eng, wl, B, args):
         chain.accept()
         return res
     out["f2_one_call_steps_per_s"] = round(_rate(one_call_step), 1)
+
+    # SURVEY.md 8(f) rank 3 on the resident state: the Gibbs source operator as one engine call (20 objects'
+    # source redrawn on the device with the caller's uniforms, counts / tables / likelihoods of the candidate)
+    def one_call_gibbs_step():
+        objs = np.unique(rng.integers(0, n_obj, size=20))
+        res = chain.gibbs_step(objs)
+        chain.accept()
+        return res
+    out["f3_one_call_gibbs_steps_per_s"] = round(_rate(one_call_gibbs_step), 1)
     release_all()
     return out
 

@@ -307,6 +307,18 @@ int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters
              const float* weights, double* group_logliks_out, double* mixture_out,
              uint8_t* changed_groups_out);
 
+/* One MCMC step of the Gibbs source operator on the resident state (GibbsSampleSource._propose,
+   sbayes/sampling/operators.py:495-552, + the likelihoods the MH ratio needs): candidate slot = current slot with the
+   source of the listed objects redrawn from its posterior on the device (z: the caller's uniforms [n_sub][F], drawn
+   where sample_categorical, preprocessing.py:248, draws them; NULL: the engine's Philox stream), count delta and
+   tables follow on the device.  Out: log_q, log_q_back (fp64 sums of the logs of the float32 probabilities), the
+   candidate's collapsed per-group log-likelihoods [G_total], its mixture log-likelihood, changed-group flags
+   [G_total] (may be NULL).  One synchronisation; nothing of the sample state crosses PCIe. */
+int sbe_gibbs_step(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* objects, int n_sub, double temperature,
+                   double prior_temperature, int from_prior, const double* z, double* log_q_out,
+                   double* log_q_back_out, double* group_logliks_out, double* mixture_out,
+                   uint8_t* changed_groups_out);
+
 /* ---- self-test hook: fp64 log used by the group-tuple table build vs the device library's log ---- */
 int sbe_test_fast_log(sbe_engine* e, const double* in, int n, double* out_fast, double* out_lib);
 /* table-driven fp64 log of k_mixture_tuple64's table build (error <= 1 ulp + 2^-53 absolute) */

@@ -850,7 +850,7 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
         e->sl.total = o;
         CREATE_CHK(hipHostMalloc((void**)&e->h_step_payload, e->sl.total, hipHostMallocMapped));
         CREATE_CHK(hipHostGetDevicePointer((void**)&e->d_step_payload, e->h_step_payload, 0));
-        const size_t hb = (size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int) + (size_t)e->Gtot;
+        const size_t hb = ((size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int) + (size_t)e->Gtot + 7) / 8 * 8 + 2 * sizeof(double);   // (step_host_lq_offset + log_q, log_q_back)
         CREATE_CHK(hipHostMalloc((void**)&e->h_step, hb, hipHostMallocMapped));
         memset(e->h_step, 0, hb);
         CREATE_CHK(hipHostGetDevicePointer((void**)&e->d_step_host, e->h_step, 0));
@@ -1795,6 +1795,131 @@ int sbe_observation_lh_exact(sbe_engine* e, int slot, double* out) {
 
 // ---- one MCMC step in one call: delta in, likelihoods out (north_star: "only the proposed cluster-
 // assignment delta crosses PCIe") ---------------------------------------------------------------------
+namespace {
+// Inputs of k_step_core that differ between the one-call MCMC step (payload from the host) and the one-call Gibbs
+// step (new source sampled on the device).
+struct CoreInputs {
+    const void* ids_new = nullptr;       // component-0 group ids of the candidate [Np] u16, or nullptr (unchanged)
+    const void* pid = nullptr; const void* tid = nullptr; const void* toff = nullptr;      // with ids_new: the tables
+    const void* tuple_g = nullptr; const void* tuple_p = nullptr; const void* patbits = nullptr;   // derived from them
+    const void* weights = nullptr;       // new weights [F][C] f32, or nullptr (unchanged)
+    const int16_t* row_of = nullptr;     // [Np]: >= 0 marks an object whose source changes
+    const uint8_t* rows = nullptr; const int32_t* objects = nullptr; int n_changed = 0;   // payload source rows
+    const uint8_t* src_new = nullptr;    // device-sampled source (the candidate's array) instead of payload rows
+    const int32_t* subset = nullptr; int n_subset = 0;      // objects whose counts may change
+    int P = 1;                           // has_components patterns of the candidate
+};
+
+// kernel 1 of the one-call steps: candidate slot = current slot + inputs, count delta, every table
+int launch_step_core(sbe_engine* e, int cur_slot, int cand_slot, const CoreInputs& in) {
+    const int N = e->N, Np = e->Np, F = e->F, C = e->C;
+    const bool regroup = in.ids_new != nullptr;
+    StepCore a{};
+    uint32_t run = 0;
+    auto seg = [&](auto* base, int64_t elems, const void* other_src) {       // per-slot array `base`, elems per slot
+        const int64_t bytes = elems * (int64_t)sizeof(*base);
+        a.cs.src[a.cs.n] = other_src ? reinterpret_cast<const uint32_t*>(other_src)
+                                     : reinterpret_cast<const uint32_t*>(base + (int64_t)cur_slot * elems);
+        a.cs.dst[a.cs.n] = reinterpret_cast<uint32_t*>(base + (int64_t)cand_slot * elems);
+        run += (uint32_t)(bytes / 4);
+        a.cs.end[a.cs.n++] = run;
+    };
+    uint16_t* g_cur = e->d_gid + (int64_t)cur_slot * C * Np;
+    // gid: component 0 from the inputs when the clusters changed; the other components from the current slot
+    {
+        uint16_t* g_cand = e->d_gid + (int64_t)cand_slot * C * Np;
+        a.cs.src[a.cs.n] = reinterpret_cast<const uint32_t*>(regroup ? in.ids_new : (const void*)g_cur);
+        a.cs.dst[a.cs.n] = reinterpret_cast<uint32_t*>(g_cand);
+        run += (uint32_t)(Np * 2 / 4); a.cs.end[a.cs.n++] = run;
+        if (C > 1) {
+            a.cs.src[a.cs.n] = reinterpret_cast<const uint32_t*>(g_cur + Np);
+            a.cs.dst[a.cs.n] = reinterpret_cast<uint32_t*>(g_cand + Np);
+            run += (uint32_t)((int64_t)(C - 1) * Np * 2 / 4); a.cs.end[a.cs.n++] = run;
+        }
+    }
+    seg(e->d_pid, (int64_t)Np, regroup ? in.pid : nullptr);
+    seg(e->d_tid, (int64_t)Np, regroup ? in.tid : nullptr);
+    seg(e->d_toff, (int64_t)Np, regroup ? in.toff : nullptr);
+    seg(e->d_tuple_g, (int64_t)kMaxTuples * kMaxComponents, regroup ? in.tuple_g : nullptr);
+    seg(e->d_tuple_p, (int64_t)kMaxTuples, regroup ? in.tuple_p : nullptr);
+    seg(e->d_patbits, (int64_t)e->Pmax, regroup ? in.patbits : nullptr);
+    seg(e->d_weights, (int64_t)F * C, in.weights);
+    a.src_seg = a.cs.n;
+    seg(e->d_src, (int64_t)N * e->Fp, nullptr);
+    a.row_of = in.row_of;
+    a.rows = in.rows;
+    a.objects = in.objects;
+    a.src_dst = e->d_src + (int64_t)cand_slot * N * e->Fp;
+    a.n_changed = in.n_changed; a.F = F; a.C = C; a.Fp = e->Fp; a.status = e->d_status;
+    // tile blocks
+    a.state = e->d_state; a.gid_cur = g_cur;
+    a.ids_new = reinterpret_cast<const uint16_t*>(in.ids_new);
+    a.src_cur = e->d_src + (int64_t)cur_slot * N * e->Fp;
+    a.src_new = in.src_new;
+    a.subset = in.subset; a.n_subset = in.n_subset;
+    a.counts_cur = e->d_counts + (int64_t)cur_slot * e->table_elems();
+    a.counts_new = e->d_counts + (int64_t)cand_slot * e->table_elems();
+    a.conc = e->d_conc;
+    a.probs = e->d_probs + (int64_t)cand_slot * e->table_elems();
+    a.probs_t = e->d_probs_t + (int64_t)cand_slot * e->probs_t_elems();
+    a.per_feature = e->d_step_pf;
+    if (++e->step_id == 0) {                  // stamp wrap-around (2^32 steps): start over from clean stamps
+        HIPCHK(e, hipMemsetAsync(e->d_step_stamp, 0, e->Gtot * sizeof(uint32_t), e->stream));
+        e->step_id = 1;
+    }
+    a.stamp = e->d_step_stamp; a.step_id = e->step_id;
+    a.Np = Np; a.S = e->S; a.Gtot = e->Gtot; a.ft = e->ft;
+    a.ftc = (int)std::max<int64_t>(1, std::min<int64_t>(8, 2048 / ((int64_t)e->Gtot * e->S)));
+    a.n_tile_blocks = div_up(F, a.ftc);
+    // weight blocks
+    a.weights = in.weights ? reinterpret_cast<const float*>(in.weights) : e->d_weights + (int64_t)cur_slot * F * C;
+    a.pattern_bits = regroup ? reinterpret_cast<const uint32_t*>(in.patbits) : e->d_patbits + (int64_t)cur_slot * e->Pmax;
+    a.wpat = e->d_wpat + (int64_t)cand_slot * e->Pmax * F * C;
+    a.wpat_t = e->d_wpat_t + (int64_t)cand_slot * e->wpat_t_elems();
+    a.P = in.P; a.Pmax = e->Pmax; a.n_weight_blocks = div_up((int64_t)in.P * F, kBlock);
+    const int64_t E = (int64_t)e->Gtot * a.ftc * e->S, R = (int64_t)e->Gtot * a.ftc;
+    const size_t lds = (size_t)((E * 4 + 15) / 16 * 16) + (size_t)(2 * E + R) * sizeof(double);
+    const int copy_blocks = (int)std::min<int64_t>(div_up(run, 1024), 2 * e->compute_units);
+    k_step_core<<<a.n_tile_blocks + a.n_weight_blocks + std::max(copy_blocks, 1), kBlock, lds, e->stream>>>(a);
+    HIPCHK(e, hipGetLastError());
+    return SBE_OK;
+}
+
+// the step epilogue's mapped-memory block: [Gtot] f64 | [ST_WORDS] i32 | [Gtot] u8 (padded to 8) | [2] f64 (log_q, log_q_back)
+inline size_t step_host_lq_offset(const sbe_engine* e) {
+    return ((size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int) + (size_t)e->Gtot + 7) / 8 * 8;
+}
+
+StepFinish make_step_finish(sbe_engine* e) {
+    StepFinish fin{};
+    fin.per_feature = e->d_step_pf;
+    fin.group_out = reinterpret_cast<double*>(e->d_step_host);
+    fin.status = e->d_status;
+    fin.status_out = reinterpret_cast<int*>(e->d_step_host + (size_t)e->Gtot * sizeof(double));
+    fin.changed = nullptr; fin.stamp = e->d_step_stamp; fin.step_id = e->step_id;
+    fin.changed_out = e->d_step_host + (size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int);
+    fin.Gtot = e->Gtot; fin.F = e->F;
+    return fin;
+}
+
+// after the synchronisation that ends a one-call step: data checks, then the results out of the mapped block
+int read_step_results(sbe_engine* e, int cand_slot, double* group_logliks_out, double* mixture_out,
+                      uint8_t* changed_groups_out, const char* bad_norm_what) {
+    const int* hst = reinterpret_cast<const int*>(e->h_step + (size_t)e->Gtot * sizeof(double));
+    if (hst[ST_BAD_NORMALIZE] || hst[ST_MULTI_SOURCE]) {
+        const int bad_norm = hst[ST_BAD_NORMALIZE], multi_src = hst[ST_MULTI_SOURCE];
+        (void)hipMemsetAsync(e->d_status + ST_BAD_NORMALIZE, 0, 2 * sizeof(int), e->stream);
+        if (bad_norm) return fail(e, SBE_ERR_DATA, "normalize: %d %s have a non-positive sum (sbayes/util.py:1006 assert)", bad_norm, bad_norm_what);
+        return fail(e, SBE_ERR_DATA, "source is not one-hot over components in %d observations", multi_src);
+    }
+    memcpy(group_logliks_out, e->h_step, (size_t)e->Gtot * sizeof(double));
+    if (changed_groups_out) memcpy(changed_groups_out, e->h_step + (size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int), (size_t)e->Gtot);
+    *mixture_out = e->h_results[cand_slot];
+    return SBE_OK;
+}
+
+}  // namespace
+
 static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters, const int32_t* changed_objects,
                      int n_changed, const uint8_t* source_rows, const float* weights, double* group_logliks_out,
                      double* mixture_out, uint8_t* changed_groups_out);
@@ -1896,88 +2021,29 @@ static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* 
     const uint8_t* pl = e->d_step_payload;
 
     // ---- kernel 1: candidate slot = current slot + payload, count delta, every table ---------------------------
-    StepCore a{};
-    uint32_t run = 0;
-    auto seg = [&](auto* base, int64_t elems, const void* payload_src) {       // per-slot array `base`, elems per slot
-        const int64_t bytes = elems * (int64_t)sizeof(*base);
-        a.cs.src[a.cs.n] = payload_src ? reinterpret_cast<const uint32_t*>(payload_src)
-                                       : reinterpret_cast<const uint32_t*>(base + (int64_t)cur_slot * elems);
-        a.cs.dst[a.cs.n] = reinterpret_cast<uint32_t*>(base + (int64_t)cand_slot * elems);
-        run += (uint32_t)(bytes / 4);
-        a.cs.end[a.cs.n++] = run;
-    };
-    uint16_t* g_cur = e->d_gid + (int64_t)cur_slot * C * Np;
-    // gid: component 0 from the payload when the clusters changed; the other components from the current slot
     {
-        uint16_t* g_cand = e->d_gid + (int64_t)cand_slot * C * Np;
-        a.cs.src[a.cs.n] = reinterpret_cast<const uint32_t*>(regroup ? (const void*)(pl + L.ids) : (const void*)g_cur);
-        a.cs.dst[a.cs.n] = reinterpret_cast<uint32_t*>(g_cand);
-        run += (uint32_t)(Np * 2 / 4); a.cs.end[a.cs.n++] = run;
-        if (C > 1) {
-            a.cs.src[a.cs.n] = reinterpret_cast<const uint32_t*>(g_cur + Np);
-            a.cs.dst[a.cs.n] = reinterpret_cast<uint32_t*>(g_cand + Np);
-            run += (uint32_t)((int64_t)(C - 1) * Np * 2 / 4); a.cs.end[a.cs.n++] = run;
+        CoreInputs in;
+        if (regroup) {
+            in.ids_new = pl + L.ids; in.pid = pl + L.pid; in.tid = pl + L.tid; in.toff = pl + L.toff;
+            in.tuple_g = pl + L.tuple_g; in.tuple_p = pl + L.tuple_p; in.patbits = pl + L.patbits;
         }
-    }
-    seg(e->d_pid, (int64_t)Np, regroup ? pl + L.pid : nullptr);
-    seg(e->d_tid, (int64_t)Np, regroup ? pl + L.tid : nullptr);
-    seg(e->d_toff, (int64_t)Np, regroup ? pl + L.toff : nullptr);
-    seg(e->d_tuple_g, (int64_t)kMaxTuples * kMaxComponents, regroup ? pl + L.tuple_g : nullptr);
-    seg(e->d_tuple_p, (int64_t)kMaxTuples, regroup ? pl + L.tuple_p : nullptr);
-    seg(e->d_patbits, (int64_t)e->Pmax, regroup ? pl + L.patbits : nullptr);
-    seg(e->d_weights, (int64_t)F * C, weights ? pl + L.weights : nullptr);
-    a.src_seg = a.cs.n;
-    seg(e->d_src, (int64_t)N * e->Fp, nullptr);
-    a.row_of = n_changed > 0 ? reinterpret_cast<const int16_t*>(pl + L.row_of) : nullptr;
-    a.rows = pl + L.rows;
-    a.objects = reinterpret_cast<const int32_t*>(pl + L.objects);
-    a.src_dst = e->d_src + (int64_t)cand_slot * N * e->Fp;
-    a.n_changed = n_changed; a.F = F; a.C = C; a.Fp = e->Fp; a.status = e->d_status;
-    // tile blocks
-    const int P = (int)cd.patterns.size();
-    a.state = e->d_state; a.gid_cur = g_cur;
-    a.ids_new = regroup ? reinterpret_cast<const uint16_t*>(pl + L.ids) : nullptr;
-    a.src_cur = e->d_src + (int64_t)cur_slot * N * e->Fp;
-    a.subset = reinterpret_cast<const int32_t*>(pl + L.subset); a.n_subset = n_subset;
-    a.counts_cur = e->d_counts + (int64_t)cur_slot * e->table_elems();
-    a.counts_new = e->d_counts + (int64_t)cand_slot * e->table_elems();
-    a.conc = e->d_conc;
-    a.probs = e->d_probs + (int64_t)cand_slot * e->table_elems();
-    a.probs_t = e->d_probs_t + (int64_t)cand_slot * e->probs_t_elems();
-    a.per_feature = e->d_step_pf;
-    if (++e->step_id == 0) {                  // stamp wrap-around (2^32 steps): start over from clean stamps
-        HIPCHK(e, hipMemsetAsync(e->d_step_stamp, 0, e->Gtot * sizeof(uint32_t), e->stream));
-        e->step_id = 1;
-    }
-    a.stamp = e->d_step_stamp; a.step_id = e->step_id;
-    a.Np = Np; a.S = e->S; a.Gtot = e->Gtot; a.ft = e->ft;
-    a.ftc = (int)std::max<int64_t>(1, std::min<int64_t>(8, 2048 / ((int64_t)e->Gtot * e->S)));
-    a.n_tile_blocks = div_up(F, a.ftc);
-    // weight blocks
-    a.weights = weights ? reinterpret_cast<const float*>(pl + L.weights) : e->d_weights + (int64_t)cur_slot * F * C;
-    a.pattern_bits = regroup ? reinterpret_cast<const uint32_t*>(pl + L.patbits) : e->d_patbits + (int64_t)cur_slot * e->Pmax;
-    a.wpat = e->d_wpat + (int64_t)cand_slot * e->Pmax * F * C;
-    a.wpat_t = e->d_wpat_t + (int64_t)cand_slot * e->wpat_t_elems();
-    a.P = P; a.Pmax = e->Pmax; a.n_weight_blocks = div_up((int64_t)P * F, kBlock);
-    {
-        const int64_t E = (int64_t)e->Gtot * a.ftc * e->S, R = (int64_t)e->Gtot * a.ftc;
-        const size_t lds = (size_t)((E * 4 + 15) / 16 * 16) + (size_t)(2 * E + R) * sizeof(double);
-        const int copy_blocks = (int)std::min<int64_t>(div_up(run, 1024), 2 * e->compute_units);
-        k_step_core<<<a.n_tile_blocks + a.n_weight_blocks + std::max(copy_blocks, 1), kBlock, lds, e->stream>>>(a);
-        HIPCHK(e, hipGetLastError());
+        if (weights) in.weights = pl + L.weights;
+        if (n_changed > 0) {
+            in.row_of = reinterpret_cast<const int16_t*>(pl + L.row_of);
+            in.rows = pl + L.rows;
+            in.objects = reinterpret_cast<const int32_t*>(pl + L.objects);
+            in.n_changed = n_changed;
+        }
+        in.subset = reinterpret_cast<const int32_t*>(pl + L.subset); in.n_subset = n_subset;
+        in.P = (int)cd.patterns.size();
+        int rc = launch_step_core(e, cur_slot, cand_slot, in);
+        if (rc) return rc;
     }
     std::fill(cd.probs_set.begin(), cd.probs_set.end(), 1);
     cd.weights_set = true;
     e->slots[cand_slot] = cd;
     // ---- kernels 2 + 3: fused mixture eval, reduction + step epilogue (mapped-memory results) -------------------
-    StepFinish fin{};
-    fin.per_feature = e->d_step_pf;
-    fin.group_out = reinterpret_cast<double*>(e->d_step_host);
-    fin.status = e->d_status;
-    fin.status_out = reinterpret_cast<int*>(e->d_step_host + (size_t)e->Gtot * sizeof(double));
-    fin.changed = nullptr; fin.stamp = e->d_step_stamp; fin.step_id = e->step_id;
-    fin.changed_out = e->d_step_host + (size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int);
-    fin.Gtot = e->Gtot; fin.F = F;
+    StepFinish fin = make_step_finish(e);
     int rc = launch_mixture(e, cand_slot, 1, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, &fin);
     if (rc) return rc;
     const auto t2 = std::chrono::steady_clock::now();
@@ -1992,16 +2058,114 @@ static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* 
             t_acc[0] = t_acc[1] = t_acc[2] = 0; t_n = 0;
         }
     }
-    const int* hst = reinterpret_cast<const int*>(e->h_step + (size_t)e->Gtot * sizeof(double));
-    if (hst[ST_BAD_NORMALIZE] || hst[ST_MULTI_SOURCE]) {
-        const int bad_norm = hst[ST_BAD_NORMALIZE], multi_src = hst[ST_MULTI_SOURCE];
-        (void)hipMemsetAsync(e->d_status + ST_BAD_NORMALIZE, 0, 2 * sizeof(int), e->stream);
-        if (bad_norm) return fail(e, SBE_ERR_DATA, "normalize: %d rows have a non-positive sum (sbayes/util.py:1006 assert)", bad_norm);
-        return fail(e, SBE_ERR_DATA, "source is not one-hot over components in %d observations", multi_src);
+    return read_step_results(e, cand_slot, group_logliks_out, mixture_out, changed_groups_out, "rows");
+}
+
+// ---- one-call Gibbs source step (GibbsSampleSource._propose, operators.py:495-552, on the resident state) ------
+// candidate = current with the source of the listed objects redrawn from its posterior ON THE DEVICE; count delta,
+// every table, both transition log-probabilities, collapsed per-group and mixture log-likelihood of the candidate:
+// seven launches, one synchronisation; objects (and the caller's uniforms) are read from host-mapped memory, all
+// results arrive through host-mapped memory.
+int sbe_gibbs_step(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* objects, int n_sub, double temperature,
+                   double prior_temperature, int from_prior, const double* z, double* log_q_out, double* log_q_back_out,
+                   double* group_logliks_out, double* mixture_out, uint8_t* changed_groups_out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, cur_slot); CHECK_SLOT(e, cand_slot);
+    CHECK_PTR(e, log_q_out); CHECK_PTR(e, log_q_back_out); CHECK_PTR(e, group_logliks_out); CHECK_PTR(e, mixture_out);
+    if (cur_slot == cand_slot) return fail(e, SBE_ERR_ARG, "current and candidate slot must differ");
+    if (n_sub < 1) return fail(e, SBE_ERR_ARG, "n_sub=%d (nothing to resample)", n_sub);
+    CHECK_PTR(e, objects);
+    if (!(temperature > 0.0) || !(prior_temperature > 0.0)) return fail(e, SBE_ERR_ARG, "temperatures must be positive");
+    Slot& cur = e->slots[cur_slot];
+    if (!cur.groups_set || !cur.source_set || !cur.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", cur_slot);
+    for (int c = 0; c < e->C; ++c)
+        if (!cur.counts_set[c] || !e->conc_set[c] || !cur.probs_set[c])
+            return fail(e, SBE_ERR_STATE, "slot %d: counts / concentration / probability tables of component %d not set", cur_slot, c);
+    for (int i = 0; i < n_sub; ++i)
+        if (objects[i] < 0 || objects[i] >= e->N) return fail(e, SBE_ERR_ARG, "object index %d out of range", objects[i]);
+    if ((int64_t)e->Gtot * e->S * 28 > 60 * 1024)
+        return fail(e, SBE_ERR_ARG, "one-call Gibbs step: tables too large for the fused table kernel (G_total=%d, S=%d)", e->Gtot, e->S);
+    HIPCHK(e, hipSetDevice(e->device));
+    if (cur.patterns_dirty) { int rc = upload_patterns_and_weights(e, cur_slot); if (rc) return rc; }
+    if (e->status_pending) {                  // deliver a deferred data check before this step reuses the words
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        int rc = synced(e);
+        if (rc) return rc;
     }
-    memcpy(group_logliks_out, e->h_step, (size_t)e->Gtot * sizeof(double));
-    if (changed_groups_out) memcpy(changed_groups_out, e->h_step + (size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int), (size_t)e->Gtot);
-    *mixture_out = e->h_results[cand_slot];
+    const int N = e->N, Np = e->Np, F = e->F, C = e->C;
+    const int64_t n_obs = (int64_t)n_sub * F;
+    // host-mapped inputs: objects | row_of marks | uniforms (when they are few; a large block is copied instead)
+    const size_t ob = ((size_t)n_sub * sizeof(int32_t) + 255) / 256 * 256;
+    const size_t rb = ((size_t)Np * sizeof(int16_t) + 255) / 256 * 256;
+    const size_t zbytes = z ? (size_t)n_obs * sizeof(double) : 0;
+    const bool z_mapped = zbytes <= ((size_t)1 << 19);
+    int rc = ensure_io(e, ob + rb + (z_mapped ? zbytes : 0));
+    if (rc) return rc;
+    memcpy(e->h_io, objects, (size_t)n_sub * sizeof(int32_t));
+    int16_t* row_of = reinterpret_cast<int16_t*>(e->h_io + ob);
+    std::fill(row_of, row_of + Np, (int16_t)-1);
+    for (int i = 0; i < n_sub; ++i) row_of[objects[i]] = 0;
+    const int32_t* d_obj = reinterpret_cast<const int32_t*>(e->d_io);
+    // device scratch: selected probabilities (forward / back), their partial log sums, uniforms if copied
+    const size_t pb = ((size_t)n_obs * sizeof(float) + 255) / 256 * 256;
+    const size_t zb = (z && !z_mapped) ? (zbytes + 255) / 256 * 256 : 0;
+    rc = ensure_scratch(e, 2 * pb + 2 * 256 * sizeof(double) + zb);
+    if (rc) return rc;
+    float* d_psel_f = (float*)e->d_scratch;
+    float* d_psel_b = (float*)(e->d_scratch + pb);
+    double* d_part_f = (double*)(e->d_scratch + 2 * pb);
+    double* d_part_b = d_part_f + 256;
+    const double* d_z = nullptr;
+    if (z && z_mapped) { memcpy(e->h_io + ob + rb, z, zbytes); d_z = reinterpret_cast<const double*>(e->d_io + ob + rb); }
+    else if (z) {
+        double* dz = (double*)(e->d_scratch + 2 * pb + 2 * 256 * sizeof(double));
+        int _urc = upload(e, dz, z, zbytes); if (_urc) return _urc;
+        d_z = dz;
+    }
+    const double inv_t = 1.0 / temperature, inv_tp = 1.0 / prior_temperature;
+    auto post_args = [&](int slot) {
+        return SrcPostArgs{e->d_state, e->d_gid + (int64_t)slot * C * Np, e->d_pid + (int64_t)slot * Np,
+                           e->d_probs + (int64_t)slot * e->table_elems(), e->d_wpat + (int64_t)slot * e->Pmax * F * C,
+                           d_obj, n_sub, Np, F, e->S, C, e->Fp, inv_t, (float)inv_tp, inv_t != 1.0, inv_tp != 1.0,
+                           from_prior != 0};
+    };
+    const int nb = (int)std::min<int64_t>(div_up(n_obs, 4 * kBlock), 256);
+    uint8_t* src_cand = e->d_src + (int64_t)cand_slot * N * e->Fp;
+    // 1: the draw (posterior from the current tables) -> the candidate's source rows of the listed objects; 2: log_q partials
+    k_sample_source<<<div_up(n_obs, 256), 256, 0, e->stream>>>(post_args(cur_slot), d_z, e->rng_seed, e->rng_draw, src_cand, d_psel_f, e->d_status);
+    if (!z) ++e->rng_draw;
+    HIPCHK(e, hipGetLastError());
+    k_sum_log_f32<<<nb, kBlock, 0, e->stream>>>(d_psel_f, n_obs, d_part_f);
+    HIPCHK(e, hipGetLastError());
+    // 3: the rest of the candidate slot, its count delta and every one of its tables
+    Slot cd = cur;
+    {
+        CoreInputs in;
+        in.row_of = reinterpret_cast<const int16_t*>(e->d_io + ob);
+        in.src_new = src_cand;
+        in.subset = d_obj; in.n_subset = n_sub;
+        in.P = (int)cd.patterns.size();
+        rc = launch_step_core(e, cur_slot, cand_slot, in);
+        if (rc) return rc;
+    }
+    std::fill(cd.probs_set.begin(), cd.probs_set.end(), 1);
+    e->slots[cand_slot] = cd;
+    // 4 + 5: log_q_back -- the candidate's posterior evaluated at the CURRENT source assignment
+    k_source_logprob<<<div_up(n_obs, 256), 256, 0, e->stream>>>(post_args(cand_slot), e->d_src + (int64_t)cur_slot * N * e->Fp, d_psel_b, e->d_status);
+    HIPCHK(e, hipGetLastError());
+    k_sum_log_f32<<<nb, kBlock, 0, e->stream>>>(d_psel_b, n_obs, d_part_b);
+    HIPCHK(e, hipGetLastError());
+    // 6 + 7: fused mixture eval, reduction + epilogue (per-group collapsed values, flags, checks, log_q / log_q_back)
+    StepFinish fin = make_step_finish(e);
+    fin.lq_partials[0] = d_part_f; fin.lq_partials[1] = d_part_b; fin.lq_n[0] = fin.lq_n[1] = nb;
+    fin.lq_out = reinterpret_cast<double*>(e->d_step_host + step_host_lq_offset(e));
+    rc = launch_mixture(e, cand_slot, 1, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, &fin);
+    if (rc) return rc;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    rc = read_step_results(e, cand_slot, group_logliks_out, mixture_out, changed_groups_out, "posterior rows / table rows");
+    if (rc) return rc;
+    const double* lq = reinterpret_cast<const double*>(e->h_step + step_host_lq_offset(e));
+    *log_q_out = lq[0];
+    *log_q_back_out = lq[1];
     return SBE_OK;
 }
 

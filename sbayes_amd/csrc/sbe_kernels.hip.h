@@ -626,6 +626,9 @@ struct StepFinish {
     const int* status;             // [ST_WORDS]
     int* status_out;               // mapped [ST_WORDS]
     int Gtot, F;
+    // one-call Gibbs step: the two transition log-probabilities = fixed-order sums of k_sum_log_f32's partials
+    const double* lq_partials[2]; int lq_n[2];
+    double* lq_out;                // mapped [2] (nullptr: none)
 };
 
 // Final fixed-order reduction of the per-block partials: one block per slot (+ one for the step epilogue).
@@ -655,6 +658,11 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __rest
             __syncthreads();
         }
         if (threadIdx.x < ST_WORDS) fin.status_out[threadIdx.x] = fin.status[threadIdx.x];
+        if (fin.lq_out && threadIdx.x < 2) {
+            double acc = 0.0;
+            for (int i = 0; i < fin.lq_n[threadIdx.x]; ++i) acc += fin.lq_partials[threadIdx.x][i];
+            fin.lq_out[threadIdx.x] = acc;
+        }
         return;
     }
     const int slot = first_slot + blockIdx.x;
@@ -1911,6 +1919,8 @@ struct StepCore {
     int* status;
     // tile blocks
     const uint8_t* state; const uint16_t* gid_cur; const uint16_t* ids_new; const uint8_t* src_cur;
+    const uint8_t* src_new;        // one-call Gibbs step: the new source of the marked objects was SAMPLED into this
+                                   // [N][Fp] array (the candidate's) by k_sample_source; nullptr: payload rows
     const int32_t* subset; int n_subset;
     const int32_t* counts_cur; int32_t* counts_new;
     const double* conc; float* probs; float* probs_t; float* per_feature;
@@ -1946,7 +1956,8 @@ __global__ __launch_bounds__(kBlock) void k_step_core(StepCore a) {
             }
             int c_new = c_old;
             const int r = a.row_of ? a.row_of[n] : -1;
-            if (r >= 0) {
+            if (r >= 0 && a.src_new) c_new = a.src_new[(int64_t)n * a.Fp + f];
+            else if (r >= 0) {
                 const uint8_t* pr = a.rows + ((int64_t)r * F + f) * C;
                 c_new = kNA;
                 for (int c = 0; c < C; ++c) if (pr[c]) c_new = c;

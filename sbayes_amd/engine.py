@@ -505,6 +505,25 @@ class Engine:
                                        _ptr(glh), ct.byref(mix), _ptr(changed)))
         return glh, mix.value, changed.astype(bool)
 
+    def gibbs_step(self, cur_slot, cand_slot, objects, z=None, temperature=1.0, prior_temperature=1.0, from_prior=False):
+        """One Gibbs-source MCMC step in one call (sbe_gibbs_step): the listed objects' source is redrawn on the
+        device into `cand_slot`, counts / tables / likelihoods follow.  z: uniforms [n, F] or None (engine's Philox
+        stream).  Returns (log_q, log_q_back, group_logliks [G_total], mixture_ll, changed_groups bool [G_total])."""
+        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        zz = None
+        if z is not None:
+            zz = _c(z, np.float64).reshape(objs.size, -1)
+            if zz.shape != (objs.size, self.n_features):
+                raise ValueError(f"z must be [{objs.size}, {self.n_features}]")
+        glh = np.empty(self.n_groups_total, dtype=np.float64)
+        lq, lqb, mix = ct.c_double(0.0), ct.c_double(0.0), ct.c_double(0.0)
+        changed = np.zeros(self.n_groups_total, dtype=np.uint8)
+        self._check(self._lib.sbe_gibbs_step(self._h, cur_slot, cand_slot, _ptr(objs), objs.size, float(temperature),
+                                             float(prior_temperature), int(bool(from_prior)),
+                                             _ptr(zz) if zz is not None else None, ct.byref(lq), ct.byref(lqb),
+                                             _ptr(glh), ct.byref(mix), _ptr(changed)))
+        return lq.value, lqb.value, glh, mix.value, changed.astype(bool)
+
     def test_fast_log(self, x):
         """(fast, library) fp64 logs of x computed on the device (self-test of the table-build log)."""
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)

@@ -142,6 +142,30 @@ class ResidentChain:
         self._pending = True
         return _SlotView(self, self.cand), log_q, log_q_back
 
+    def gibbs_step(self, objects, temperature=1.0, prior_temperature=1.0, sample_from_prior=False, z=None,
+                   device_rng=False):
+        """propose_gibbs_source + evaluation of the candidate in ONE engine call (sbe_gibbs_step: seven launches, one
+        synchronisation).  Returns (log_q, log_q_back, collapsed log-likelihood, per-group values, mixture
+        log-likelihood).  Follow with accept() or reject()."""
+        eng = self.eng
+        objects = np.asarray(objects)
+        if objects.dtype == np.bool_:
+            objects = np.flatnonzero(objects)
+        for c in self._probs_dirty[self.cur]:
+            eng.update_probs(self.cur, c)
+        self._probs_dirty[self.cur] = set()
+        if device_rng:
+            z = None
+        elif z is None:
+            z = np.random.random([objects.size, eng.n_features, 1])
+        log_q, log_q_back, glh, mix, changed = eng.gibbs_step(self.cur, self.cand, objects, z, temperature,
+                                                              prior_temperature, sample_from_prior)
+        self.changed_groups = changed
+        self._probs_dirty[self.cand] = set()
+        self._cand_clusters = self._clusters
+        self._pending = True
+        return log_q, log_q_back, float(glh.sum()), glh, mix
+
     def accept(self):
         if not self._pending:
             raise RuntimeError("no pending proposal")

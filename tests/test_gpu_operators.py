@@ -202,10 +202,23 @@ def test_resident_gibbs_source_proposal(tag):
         cand2, log_q2, log_q_back2 = chain.propose_gibbs_source(objects, float(temp), float(ptemp), bool(from_prior),
                                                                 z=z[f"gs_{tag}_z"])
         assert (log_q2, log_q_back2) == (log_q, log_q_back)
+        # the one-call form (sbe_gibbs_step) gives the same numbers
+        chain.reject()
+        log_q3, log_q_back3, ll3, glh3, mix3 = chain.gibbs_step(objects, float(temp), float(ptemp), bool(from_prior),
+                                                                z=z[f"gs_{tag}_z"])
+        assert abs(log_q3 - log_q) <= 1e-13 * abs(log_q) and abs(log_q_back3 - log_q_back) <= 1e-13 * abs(log_q_back)
+        assert mix3 == got_mix and abs(ll3 - ll_cand) <= 1e-12 * abs(ll_cand)
+        assert np.array_equal(eng.get_source_rows(chain.cand, all_objects), z[f"gs_{tag}_new_source"])
+        for c in range(eng.n_components):
+            assert np.array_equal(_SlotCounts(chain, c), z[f"gs_{tag}_counts_{c}"])
         chain.accept()
         assert chain.current.collapsed_loglik() == ll_cand and chain.current.mixture_loglik() == got_mix
     finally:
         release_all()
+
+
+def _SlotCounts(chain, c):
+    return chain.eng.get_counts(chain.cand, c)
 
 
 def test_gibbs_source_same_global_rng_stream_as_reference():

@@ -37,3 +37,13 @@ for device_rng in (False, True):
             ll, mix = cand.collapsed_loglik(), cand.mixture_loglik()
             chain.accept()
         print(f"resident gibbs step device_rng={device_rng} n={n_obj}: {(time.perf_counter() - t0) / n * 1e6:.0f} us/step (incl. collapsed + mixture eval)")
+for device_rng in (False, True):
+    for n_obj in (20, 1000):
+        objs = np.sort(rng.choice(1000, size=n_obj, replace=False))
+        for _ in range(5):
+            chain.gibbs_step(objs, device_rng=device_rng); chain.reject()
+        t0 = time.perf_counter(); n = 200
+        for _ in range(n):
+            chain.gibbs_step(objs, device_rng=device_rng)
+            chain.accept()
+        print(f"one-call gibbs step device_rng={device_rng} n={n_obj}: {(time.perf_counter() - t0) / n * 1e6:.0f} us/step")
