@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Randomised differential test on the GPU box: random shapes / states / batch sizes through every fused-kernel form,
+both sbe_step forms and the one-call Gibbs step, against the CPU oracle.  Not part of the pytest suite (open-ended
+run time):  python tools/fuzz_gpu.py --seconds 300 [--seed 0]"""
+import argparse
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+from oracle import sbayes_oracle as orc                                       # noqa: E402  (checker only)
+from sbayes_amd.engine import (MIXTURE_ONEHOT, MIXTURE_ONEHOT_GENERAL, MIXTURE_PACKED, MIXTURE_PACKED_GENERAL,   # noqa: E402
+                               MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, Engine, EngineError)
+from tests.test_gpu_shapes import random_case                                  # noqa: E402
+
+
+def random_state(rng, feats, groups0, n_groups):
+    N, F, _ = feats.shape
+    C = len(n_groups)
+    if C == 1:
+        groups = groups0
+    else:
+        a = rng.integers(0, n_groups[0] + rng.integers(0, n_groups[0] + 1), size=N)
+        groups = [np.stack([a == k for k in range(n_groups[0])])] + groups0[1:]
+    weights = rng.dirichlet(np.ones(C), size=F).astype(np.float32)
+    hc = orc.has_components(groups)
+    covered = hc.any(axis=1)
+    src_idx = np.argmax(rng.random((N, F, C)) * hc[:, None, :], axis=-1)
+    source = np.eye(C, dtype=bool)[src_idx]
+    source[~feats.any(-1)] = False
+    source[~covered] = False
+    return groups, weights, source, covered
+
+
+def one_case(rng, stats):
+    N = int(rng.choice([rng.integers(1, 40), rng.integers(40, 400), rng.integers(400, 3000)]))
+    F = int(rng.choice([rng.integers(1, 20), rng.integers(20, 140), rng.integers(140, 300)]))
+    S = int(rng.choice([rng.integers(1, 6), rng.integers(6, 40)]))
+    C = int(rng.integers(1, 5))
+    n_groups = [int(rng.integers(1, 7))] + [1 if c == 1 else int(rng.integers(1, 9)) for c in range(1, C)]
+    B = int(rng.choice([1, 2, rng.integers(3, 9), rng.integers(9, 40)]))
+    na_rate = float(rng.choice([0.0, 0.03, 0.3]))
+    feats, groups0, _w, _s, conc = random_case(rng, N, F, S, n_groups, na_rate)
+    na = ~feats.any(-1)
+    tag = f"N{N} F{F} S{S} groups{n_groups} B{B} na{na_rate}"
+    with Engine(feats, n_groups, n_slots=B + 1) as eng:
+        for c in range(C):
+            eng.set_concentration(c, conc[c])
+        want, states = [], []
+        for b in range(B):
+            groups, weights, source, covered = random_state(rng, feats, groups0, n_groups)
+            if not covered.all() and C == 1:
+                return
+            eng.load_state(b, groups, weights, source=source)
+            for c in range(C):
+                eng.update_probs(b, c)
+            counts = orc.recalculate_feature_counts(feats, groups, source)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                w = orc.normalize_weights(weights, orc.has_components(groups))
+                obs = orc.mixture_observation_lh(w, orc.likelihood_per_component(feats, na, groups, counts, conc))
+                want.append(np.log(obs)[~na].sum())
+            states.append((groups, weights, source, counts))
+        want = np.array(want)
+        if not np.all(np.isfinite(want)):
+            return                                  # objects without any component: the reference asserts there
+        for kernel in (MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS,
+                       MIXTURE_ONEHOT_GENERAL):
+            eng.set_option(kernel=kernel)
+            try:
+                got = eng.mixture_loglik_batch(0, B)
+            except EngineError as exc:
+                if "not applicable" in str(exc):
+                    continue
+                raise
+            # 1e-10 relative (north_star), with an absolute floor of 1e-16 per observation: the product form of the log
+            # accumulation rounds every factor at 2^-53 of ~1, which is all that is left when the sum itself is ~0
+            # (S = 1: every probability is 1, the terms are the float32 rounding of the weights)
+            tol = 1e-10 * np.abs(want) + 1e-16 * N * F
+            assert np.all((np.abs(got - want) <= tol) | (got == want)), (tag, kernel, got, want)
+            stats["evals"] += B
+        eng.set_option(kernel=MIXTURE_PACKED)
+        # one-call steps from state 0: lean vs general form, counts vs the oracle
+        groups, weights, source, counts = states[0]
+        if C >= 2 and N >= 2:
+            clusters = groups[0].copy()
+            for n in rng.integers(0, N, size=min(3, N)):
+                clusters[:, n] = False
+                k = int(rng.integers(0, clusters.shape[0] + 1))
+                if k < clusters.shape[0]:
+                    clusters[k, n] = True
+            new_groups = [clusters] + groups[1:]
+            hc = orc.has_components(new_groups)
+            if hc.any(axis=1).all():
+                objs = np.unique(rng.integers(0, N, size=min(5, N))).astype(np.int32)
+                moved = np.union1d(objs, np.flatnonzero((clusters != groups[0]).any(axis=0)))
+                new_source = source.copy()
+                idx = np.argmax(rng.random((moved.size, F, C)) * hc[moved][:, None, :], axis=-1)
+                rows = np.eye(C, dtype=bool)[idx]
+                rows[na[moved]] = False
+                new_source[moved] = rows
+                outs = []
+                for form in (0, 1):
+                    eng.set_option(step_form=form)
+                    outs.append(eng.step(0, B, clusters=clusters, changed_objects=moved.astype(np.int32), source_rows=rows))
+                (g0, m0, c0), (g1, m1, c1) = outs
+                assert np.array_equal(g0, g1) and m0 == m1 and np.array_equal(c0, c1), (tag, "step forms")
+                new_counts = orc.recalculate_feature_counts(feats, new_groups, new_source)
+                for c in range(C):
+                    assert np.array_equal(eng.get_counts(B, c), new_counts[c]), (tag, "step counts", c)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    w = orc.normalize_weights(weights, hc)
+                    obs = orc.mixture_observation_lh(w, orc.likelihood_per_component(feats, na, new_groups, new_counts, conc))
+                    want_mix = np.log(obs)[~na].sum()
+                if np.isfinite(want_mix):
+                    assert abs(m0 - want_mix) <= 1e-10 * abs(want_mix) + 1e-16 * N * F, (tag, "step mixture", m0, want_mix)
+                stats["steps"] += 1
+        # one-call Gibbs step from state 0: counts consistent with the source it drew
+        eng.set_option(step_form=0)
+        objs = np.unique(rng.integers(0, N, size=min(6, N))).astype(np.int32)
+        try:
+            lq, lqb, glh, mix, changed = eng.gibbs_step(0, B, objs, z=rng.random((objs.size, F)))
+        except EngineError as exc:
+            if "too large" not in str(exc):
+                raise
+        else:
+            drawn = eng.get_source_rows(B, np.arange(N, dtype=np.int32))
+            others = np.setdiff1d(np.arange(N), objs)
+            assert np.array_equal(drawn[others], source[others]), (tag, "gibbs untouched rows")
+            assert not drawn[na].any(), (tag, "gibbs NA rows")
+            new_counts = orc.recalculate_feature_counts(feats, groups, drawn)
+            for c in range(C):
+                assert np.array_equal(eng.get_counts(B, c), new_counts[c]), (tag, "gibbs counts", c)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                w = orc.normalize_weights(weights, orc.has_components(groups))
+                obs = orc.mixture_observation_lh(w, orc.likelihood_per_component(feats, na, groups, new_counts, conc))
+                want_mix = np.log(obs)[~na].sum()
+            if np.isfinite(want_mix):
+                assert abs(mix - want_mix) <= 1e-10 * abs(want_mix) + 1e-16 * N * F, (tag, "gibbs mixture", mix, want_mix)
+            assert np.isfinite(lq) and np.isfinite(lqb) and lq <= 1e-9 and lqb <= 1e-9, (tag, lq, lqb)
+            stats["gibbs"] += 1
+    stats["cases"] += 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    stats = {"cases": 0, "evals": 0, "steps": 0, "gibbs": 0}
+    t0 = last = time.time()
+    while time.time() - t0 < args.seconds:
+        one_case(rng, stats)
+        if time.time() - last > 30:
+            last = time.time()
+            print(f"[fuzz] {time.time() - t0:5.0f} s  {stats}", flush=True)
+    print(f"[fuzz] done, no mismatch: {stats}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
