@@ -35,13 +35,21 @@ def random_state(rng, feats, groups0, n_groups):
     return groups, weights, source, covered
 
 
-def one_case(rng, stats):
-    N = int(rng.choice([rng.integers(1, 40), rng.integers(40, 400), rng.integers(400, 3000)]))
-    F = int(rng.choice([rng.integers(1, 20), rng.integers(20, 140), rng.integers(140, 300)]))
-    S = int(rng.choice([rng.integers(1, 6), rng.integers(6, 40)]))
-    C = int(rng.integers(1, 5))
-    n_groups = [int(rng.integers(1, 7))] + [1 if c == 1 else int(rng.integers(1, 9)) for c in range(1, C)]
-    B = int(rng.choice([1, 2, rng.integers(3, 9), rng.integers(9, 40)]))
+def one_case(rng, stats, big=False):
+    if big:                                             # long chunks, several block generations, ragged tiles
+        N = int(rng.integers(600, 4000))
+        F = int(rng.choice([rng.integers(60, 80), rng.integers(120, 140), rng.integers(180, 270)]))
+        S = int(rng.integers(2, 12))
+        C = int(rng.integers(1, 4))
+        n_groups = [int(rng.integers(1, 6))] + [1 if c == 1 else int(rng.integers(1, 4)) for c in range(1, C)]
+        B = int(rng.choice([rng.integers(8, 64), rng.integers(64, 200), rng.integers(200, 700)]))
+    else:
+        N = int(rng.choice([rng.integers(1, 40), rng.integers(40, 400), rng.integers(400, 3000)]))
+        F = int(rng.choice([rng.integers(1, 20), rng.integers(20, 140), rng.integers(140, 300)]))
+        S = int(rng.choice([rng.integers(1, 6), rng.integers(6, 40)]))
+        C = int(rng.integers(1, 5))
+        n_groups = [int(rng.integers(1, 7))] + [1 if c == 1 else int(rng.integers(1, 9)) for c in range(1, C)]
+        B = int(rng.choice([1, 2, rng.integers(3, 9), rng.integers(9, 40)]))
     na_rate = float(rng.choice([0.0, 0.03, 0.3]))
     feats, groups0, _w, _s, conc = random_case(rng, N, F, S, n_groups, na_rate)
     na = ~feats.any(-1)
@@ -148,12 +156,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--big", action="store_true", help="large shapes and batches (long chunks, several block generations)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     stats = {"cases": 0, "evals": 0, "steps": 0, "gibbs": 0}
     t0 = last = time.time()
     while time.time() - t0 < args.seconds:
-        one_case(rng, stats)
+        one_case(rng, stats, big=args.big)
         if time.time() - last > 30:
             last = time.time()
             print(f"[fuzz] {time.time() - t0:5.0f} s  {stats}", flush=True)
