@@ -44,7 +44,9 @@ typedef struct sbe_engine sbe_engine;
 #define SBE_OPT_MIXTURE_KERNEL 1
 #define SBE_MIXTURE_PACKED 0   /* reads the packed state-index block  (N*F bytes); uses the
                                   group-tuple form (one log per (tuple, state, feature)
-                                  instead of per observation) whenever it applies          */
+                                  instead of per observation) whenever it applies: the
+                                  scalar-unit kernel k_mixture_tuple64 at tile width 64 and
+                                  S <= 127, k_mixture_combo otherwise                       */
 #define SBE_MIXTURE_ONEHOT 1   /* reads the one-hot block as handed over (N*F*S bytes);
                                   group-tuple form whenever it applies                      */
 #define SBE_MIXTURE_ONEHOT_GENERAL 4  /* one-hot stream, never the group-tuple form          */

@@ -675,7 +675,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __rest
 
 
 // ==========================================================================================
-// Fused mixture log-likelihood, v2 (the default PACKED path).
+// Fused mixture log-likelihood, v2: the GENERAL packed form (single evals, many group tuples, large tables).
 //
 // Mapping (chosen from rocprof/HIP-event measurements of v1):
 //   lane   <-> feature inside a tile of FT features (FT = 64: one wave spans the tile)
@@ -1071,7 +1071,8 @@ __global__ __launch_bounds__(kBlock) void k_mixture_onehot_v2(Mix2Params p) {
 }
 
 // ==========================================================================================
-// Fused mixture log-likelihood, group-tuple form (default PACKED path when it applies).
+// Fused mixture log-likelihood, group-tuple form with the tuple metadata in LDS (tile widths 32 / 16, S > 127, the
+// one-hot stream; at tile width 64 the packed stream runs k_mixture_tuple64 below).
 //
 // Observation (n, f) contributes log v with v = sum_c w[pat(n)][f][c] * p_c[g_c(n)][f][x(n,f)]:
 // v depends on n only through the tuple of group indices t(n) = (g_0(n), .., g_{C-1}(n)), and the
