@@ -6,7 +6,15 @@ Patches the names through which the reference reaches the path:
   sbayes.sampling.conditionals.{compute_component_likelihood, likelihood_per_component,
                                 likelihood_per_component_subset, update_weights}   (conditionals.py:14)
   sbayes.sampling.counts.{compute_effect_counts, recalculate_feature_counts, update_feature_counts}
-Only when sBayes is importable; raises otherwise.  uninstall() restores the originals."""
+Only when sBayes is importable; raises otherwise.  uninstall() restores the originals.
+
+install(operators=True) additionally replaces the two heaviest consumers of the `[N, F, C]` component-likelihood
+array inside the reference's operators by their device forms, so that array no longer
+has to cross PCIe for them:
+  sbayes.sampling.operators.AlterCluster.compute_cluster_posterior        (operators.py:1035-1073; inherited by
+                                                                            AlterClusterWide)
+  sbayes.sampling.operators.GibbsSampleSource.calculate_source_posterior  (operators.py:554-574)
+Proposal logic, RNG use and everything else of the operators stay the reference's."""
 from __future__ import annotations
 
 import importlib
@@ -14,7 +22,7 @@ import importlib
 _SAVED = []
 
 
-def install():
+def install(operators=False):
     from . import conditionals as my_cond
     from . import counts as my_counts
     from . import likelihood as my_lik
@@ -53,6 +61,8 @@ def install():
         swap(mod, "compute_effect_counts", my_counts.compute_effect_counts)
         swap(mod, "recalculate_feature_counts", my_counts.recalculate_feature_counts)
         swap(mod, "update_feature_counts", my_counts.update_feature_counts)
+    if operators:
+        _install_operator_forms(swap)
     for m in importers:
         for name, new in (("likelihood_per_component", my_cond.likelihood_per_component),
                           ("update_weights", my_lik.update_weights),
@@ -62,6 +72,32 @@ def install():
                           ("compute_effect_counts", my_counts.compute_effect_counts),
                           ("compute_component_likelihood", my_lik.compute_component_likelihood)):
             swap(m, name, new)
+
+
+def _install_operator_forms(swap):
+    import numpy as np
+
+    from . import operators as my_ops
+    ref_ops = importlib.import_module("sbayes.sampling.operators")
+
+    def compute_cluster_posterior(self, sample, i_cluster, available):
+        """AlterCluster.compute_cluster_posterior (operators.py:1035-1073) on the device."""
+        if self.sample_from_prior or not self.gibbsish:
+            return 0.5 * np.ones(np.count_nonzero(available))
+        geo = None
+        if self.consider_geo_prior:
+            geo = np.exp(self.model.prior.geo_prior.get_costs_per_object(sample, i_cluster)[available]
+                         / self.prior_temperature)
+        return my_ops.compute_cluster_posterior(self.model, sample, i_cluster, available, self.temperature,
+                                                self.prior_temperature, self.additive_smoothing, geo)
+
+    def calculate_source_posterior(self, sample, object_subset=slice(None)):
+        """GibbsSampleSource.calculate_source_posterior (operators.py:554-574) on the device."""
+        return my_ops.calculate_source_posterior(self.model, sample, object_subset, self.temperature,
+                                                 self.prior_temperature)
+
+    swap(ref_ops.AlterCluster, "compute_cluster_posterior", compute_cluster_posterior)
+    swap(ref_ops.GibbsSampleSource, "calculate_source_posterior", calculate_source_posterior)
 
 
 def uninstall():

@@ -15,6 +15,8 @@ class FakeEngine:
         self.n_groups = list(n_groups) if n_groups is not None else [1]
         self.n_components = len(self.n_groups)
         self.calls = []
+        self.slots = {}                 # slot -> {"groups": {c: bool [G, N]}, "counts": {c: ...}, "weights": ...}
+        self.conc = {}
 
     def close(self):
         pass
@@ -56,6 +58,49 @@ class FakeEngine:
         subset = slice(None) if object_subset is None else np.asarray(object_subset)
         return orc.compute_effect_counts(self.features, np.asarray(group_assignment, dtype=bool),
                                          np.asarray(source_is_component, dtype=bool), subset)
+
+    # ---- resident-slot surface used by the device forms of the operators (sbayes_amd/operators.py) ----
+    def _slot(self, slot):
+        return self.slots.setdefault(slot, {"groups": {}, "counts": {}, "weights": None})
+
+    def set_groups(self, slot, component, groups):
+        self._slot(slot)["groups"][component] = np.asarray(groups, dtype=bool).copy()
+
+    def set_concentration(self, component, concentration):
+        self.conc[component] = np.asarray(concentration, dtype=np.float64).copy()
+
+    def set_counts(self, slot, component, counts):
+        self._slot(slot)["counts"][component] = np.asarray(counts, dtype=np.float32).copy()
+
+    def set_weights(self, slot, weights):
+        self._slot(slot)["weights"] = np.asarray(weights, dtype=np.float32).copy()
+
+    def update_probs(self, slot, component):
+        pass                            # tables are derived on demand below
+
+    def _state(self, slot):
+        s = self.slots[slot]
+        C = len(s["groups"])
+        groups = [s["groups"][c] for c in range(C)]
+        counts = [s["counts"][c] for c in range(C)]
+        conc = [self.conc[c] for c in range(C)]
+        lh = orc.likelihood_per_component(self.features, self.na_values(), groups, counts, conc)
+        return groups, s["weights"], lh
+
+    def cluster_marginals(self, slot, table, objects, prior_temperature=1.0):
+        self.calls.append(("cluster_marginals", len(objects)))
+        groups, weights, lh = self._state(slot)
+        available = np.zeros(self.n_objects, dtype=bool)
+        available[np.asarray(objects)] = True
+        wz = orc.feature_weights_with_and_without(weights, orc.has_components(groups), available, prior_temperature)
+        with np.errstate(divide="ignore"):
+            return np.log(orc.cluster_marginals(self.features, self.na_values(), lh, np.asarray(table), available, wz))
+
+    def source_posterior(self, slot, objects, temperature=1.0, prior_temperature=1.0):
+        self.calls.append(("source_posterior", len(objects)))
+        groups, weights, lh = self._state(slot)
+        w = orc.normalize_weights(weights, orc.has_components(groups))
+        return orc.source_posterior(lh, w, np.asarray(objects), temperature, prior_temperature)
 
     def normalize_weights(self, weights, has_components):
         return orc.normalize_weights(np.asarray(weights, dtype=np.float32), np.asarray(has_components, dtype=bool))

@@ -19,7 +19,8 @@ REF = "/root/reference"
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference sBayes not present")
 
 
-def run_chain(config_src: Path, tag: str, n_steps: int, seed: int, patched: bool, monkeypatch, tmp_path):
+def run_chain(config_src: Path, tag: str, n_steps: int, seed: int, patched: bool, monkeypatch, tmp_path,
+              operators: bool = False):
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
     import _ref_stubs
     _ref_stubs.install()
@@ -35,7 +36,7 @@ def run_chain(config_src: Path, tag: str, n_steps: int, seed: int, patched: bool
     from sbayes_amd import conditionals, counts, likelihood, patch, registry
     from tests._fake_engine import FakeEngine
 
-    work = tmp_path / f"{tag}_{'patched' if patched else 'plain'}"
+    work = tmp_path / f"{tag}_{'patched' if patched else 'plain'}{'_ops' if operators else ''}"
     shutil.copytree(config_src, work)
     engines = {}
 
@@ -52,7 +53,7 @@ def run_chain(config_src: Path, tag: str, n_steps: int, seed: int, patched: bool
         monkeypatch.setattr(registry, "engine_for_shape",
                             lambda n, f: next((e for e in engines.values() if e.n_objects == n and e.n_features == f),
                                               None) or FakeEngine(np.zeros((n, f, 1), dtype=bool)))
-        patch.install()
+        patch.install(operators=operators)
     try:
         np.random.seed(seed)
         random.seed(seed)
@@ -102,3 +103,23 @@ def test_reference_sampler_on_drop_in_layer_is_the_same_markov_chain(tag, src, n
     eng = next(iter(patched[4].values()))
     kinds = {c[0] for c in eng.calls}
     assert {"component_lh", "normalize_tables", "dirichlet_logpdf"} <= kinds   # the path really ran through the layer
+
+
+@pytest.mark.parametrize("tag,src,n_steps", [
+    ("test_files", Path(REF) / "test" / "test_files", 250),
+    ("south_america", Path(REF) / "experiments" / "south_america", 60),
+])
+def test_reference_sampler_with_device_operator_forms(tag, src, n_steps, monkeypatch, tmp_path):
+    """patch.install(operators=True): AlterCluster.compute_cluster_posterior and
+    GibbsSampleSource.calculate_source_posterior replaced by their device forms (here: the oracle-backed double).
+    The proposal probabilities then come from the log-space formulation (equal to the reference's linear-space ones
+    to ~1e-15), every decision of the sampler is unchanged: same operators, same states, same likelihood / prior trace."""
+    plain = run_chain(src, tag, n_steps, 11, False, monkeypatch, tmp_path)
+    patched = run_chain(src, tag, n_steps, 11, True, monkeypatch, tmp_path, operators=True)
+    assert [t[2] for t in patched[0]] == [t[2] for t in plain[0]]
+    np.testing.assert_allclose([t[:2] for t in patched[0]], [t[:2] for t in plain[0]], rtol=1e-12)
+    assert np.array_equal(patched[1], plain[1]) and np.array_equal(patched[2], plain[2])
+    assert np.array_equal(patched[3], plain[3])
+    eng = next(iter(patched[4].values()))
+    kinds = {c[0] for c in eng.calls}
+    assert {"cluster_marginals", "source_posterior"} <= kinds        # the operator forms really ran
