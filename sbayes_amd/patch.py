@@ -14,6 +14,7 @@ has to cross PCIe for them:
   sbayes.sampling.operators.AlterCluster.compute_cluster_posterior        (operators.py:1035-1073; inherited by
                                                                             AlterClusterWide)
   sbayes.sampling.operators.GibbsSampleSource.calculate_source_posterior  (operators.py:554-574)
+  sbayes.sampling.operators.component_likelihood_given_unchanged          (operators.py:863-928)
 Proposal logic, RNG use and everything else of the operators stay the reference's."""
 from __future__ import annotations
 
@@ -98,6 +99,8 @@ def _install_operator_forms(swap):
 
     swap(ref_ops.AlterCluster, "compute_cluster_posterior", compute_cluster_posterior)
     swap(ref_ops.GibbsSampleSource, "calculate_source_posterior", calculate_source_posterior)
+    # module-level function with the reference's own signature (operators.py:863-928)
+    swap(ref_ops, "component_likelihood_given_unchanged", my_ops.component_likelihood_given_unchanged)
 
 
 def uninstall():

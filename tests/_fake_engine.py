@@ -102,5 +102,20 @@ class FakeEngine:
         w = orc.normalize_weights(weights, orc.has_components(groups))
         return orc.source_posterior(lh, w, np.asarray(objects), temperature, prior_temperature)
 
+    def subset_lh(self, objects, tables, group_idx, temperature=1.0):
+        """float32 [n, F, C]: tables[c][group_idx[c][i]][f][x(objects[i], f)], -1 -> 0, NA -> 1, then ** (1/T)."""
+        self.calls.append(("subset_lh", len(objects)))
+        objects = np.asarray(objects)
+        feats = self.features[objects]
+        out = np.zeros((objects.size, self.n_features, len(tables)), dtype=np.float32)
+        for c, tab in enumerate(tables):
+            tab = np.asarray(tab, dtype=np.float32)
+            gi = np.asarray(group_idx[c])
+            has = gi >= 0
+            lh = np.einsum("ijk,ijk->ij", feats[has], tab[gi[has]])
+            out[has, :, c] = lh
+        out[self.na_values()[objects]] = 1.0
+        return out ** np.float32(1 / temperature) if temperature != 1.0 else out
+
     def normalize_weights(self, weights, has_components):
         return orc.normalize_weights(np.asarray(weights, dtype=np.float32), np.asarray(has_components, dtype=bool))

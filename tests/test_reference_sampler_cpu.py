@@ -110,8 +110,8 @@ def test_reference_sampler_on_drop_in_layer_is_the_same_markov_chain(tag, src, n
     ("south_america", Path(REF) / "experiments" / "south_america", 60),
 ])
 def test_reference_sampler_with_device_operator_forms(tag, src, n_steps, monkeypatch, tmp_path):
-    """patch.install(operators=True): AlterCluster.compute_cluster_posterior and
-    GibbsSampleSource.calculate_source_posterior replaced by their device forms (here: the oracle-backed double).
+    """patch.install(operators=True): AlterCluster.compute_cluster_posterior, GibbsSampleSource.calculate_source_posterior
+    and component_likelihood_given_unchanged replaced by their device forms (here: the oracle-backed double).
     The proposal probabilities then come from the log-space formulation (equal to the reference's linear-space ones
     to ~1e-15), every decision of the sampler is unchanged: same operators, same states, same likelihood / prior trace."""
     plain = run_chain(src, tag, n_steps, 11, False, monkeypatch, tmp_path)
@@ -122,4 +122,4 @@ def test_reference_sampler_with_device_operator_forms(tag, src, n_steps, monkeyp
     assert np.array_equal(patched[3], plain[3])
     eng = next(iter(patched[4].values()))
     kinds = {c[0] for c in eng.calls}
-    assert {"cluster_marginals", "source_posterior"} <= kinds        # the operator forms really ran
+    assert {"cluster_marginals", "source_posterior", "subset_lh"} <= kinds        # the operator forms really ran
