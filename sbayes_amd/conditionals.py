@@ -82,20 +82,79 @@ def likelihood_per_component(model, sample, caching=True):
 likelihood_per_component_subset = likelihood_per_component
 
 
+def _same(arr, cached):
+    """True if `arr` is what `cached` = (object, private copy) recorded.  Identity counts only for read-only arrays
+    (the reference's and the mirror's parameters are frozen between edits, sbayes/sampling/state.py:43-61)."""
+    if cached is None:
+        return False
+    ref, copy = cached
+    if arr is ref and not arr.flags.writeable:
+        return True
+    return arr.shape == copy.shape and arr.dtype == copy.dtype and np.array_equal(arr, copy)
+
+
+def _remember(arr):
+    return arr, (arr if not arr.flags.writeable else arr.copy())
+
+
 def _bind_slot(eng, model, sample, slot, with_source=False):
-    """Upload one sample's state into an engine slot: group ids, counts, weights (small),
-    optionally the source assignment.  Probability tables are then built on the device."""
+    """Upload one sample's state into an engine slot: group ids, counts, weights (small), optionally the source
+    assignment.  Only what differs from what the slot was last bound to is sent (the operators evaluate the same or
+    nearly the same sample many times in a row); returns the components whose probability tables are stale."""
     names = sample.component_names
-    groups = [sample.clusters.value] + [c.group_assignment for c in sample.confounders.values()]
+    C = len(names)
+    groups = [np.asarray(sample.clusters.value)] + [np.asarray(c.group_assignment) for c in sample.confounders.values()]
     conc = [np.asarray(model.prior.prior_cluster_effect.concentration_array)] + [
         np.asarray(model.prior.prior_confounding_effects[k].concentration_array(sample)) for k in names[1:]]
-    for c, name in enumerate(names):
-        eng.set_groups(slot, c, groups[c])
+    counts = [np.asarray(sample.feature_counts[name].value) for name in names]
+    weights = np.asarray(sample.weights.value)
+    source = np.asarray(sample.source.value) if with_source else None
+    cache = getattr(eng, "_bound", None)
+    if cache is None:                               # an engine without a bind cache (test doubles): send everything
+        for c in range(C):
+            eng.set_groups(slot, c, groups[c])
+            eng.set_concentration(c, conc[c])
+            eng.set_counts(slot, c, counts[c])
+        if with_source:
+            eng.set_source(slot, source)
+        eng.set_weights(slot, weights)
+        return set(range(C))
+    old = cache.get(slot) or {"groups": [None] * C, "counts": [None] * C, "weights": None, "source": None, "stale": set(range(C))}
+    new = {"groups": list(old["groups"]), "counts": list(old["counts"]), "weights": old["weights"], "source": old["source"],
+           "stale": set(old["stale"])}
+    conc_changed = [c for c in range(C) if not _same(conc[c], eng._bound_conc.get(c))]
+    for c in conc_changed:                          # (drops every slot's entry: all tables depend on it)
         eng.set_concentration(c, conc[c])
-        eng.set_counts(slot, c, sample.feature_counts[name].value)
-    if with_source:
-        eng.set_source(slot, sample.source.value)
-    eng.set_weights(slot, sample.weights.value)
+    if conc_changed:
+        new["stale"] = set(range(C))
+    for c in range(C):
+        if not _same(groups[c], old["groups"][c]):
+            eng.set_groups(slot, c, groups[c])
+            new["groups"][c] = _remember(groups[c])
+        if not _same(counts[c], old["counts"][c]):
+            eng.set_counts(slot, c, counts[c])
+            new["counts"][c] = _remember(counts[c])
+            new["stale"].add(c)
+    if with_source and not _same(source, old["source"]):
+        eng.set_source(slot, source)
+        new["source"] = _remember(source)
+    if not _same(weights, old["weights"]):
+        eng.set_weights(slot, weights)
+        new["weights"] = _remember(weights)
+    for c in conc_changed:
+        eng._bound_conc[c] = _remember(conc[c])
+    cache[slot] = new                               # (the setters above dropped the slot's entry)
+    return new["stale"]
+
+
+def _tables_current(eng, slot):
+    """Rebuild the probability tables that the last _bind_slot left stale."""
+    entry = getattr(eng, "_bound", {}).get(slot)
+    stale = set(range(eng.n_components)) if entry is None else entry["stale"]
+    for c in sorted(stale):
+        eng.update_probs(slot, c)
+    if entry is not None:
+        entry["stale"] = set()
 
 
 def likelihood_per_component_exact(model, sample, slot=0):
@@ -109,8 +168,7 @@ def mixture_log_likelihood(model, sample, slot=0) -> float:
     """One uncached eval of the marginal mixture log-likelihood by the fused kernel."""
     eng = _engine(model)
     _bind_slot(eng, model, sample, slot)
-    for c in range(eng.n_components):
-        eng.update_probs(slot, c)
+    _tables_current(eng, slot)
     return eng.mixture_loglik(slot)
 
 
@@ -121,8 +179,7 @@ def observation_likelihoods(model, sample, slot=0, exact=False):
         _bind_slot(eng, model, sample, slot, with_source=True)
         return eng.observation_lh_exact(slot)
     _bind_slot(eng, model, sample, slot)
-    for c in range(eng.n_components):
-        eng.update_probs(slot, c)
+    _tables_current(eng, slot)
     return eng.observation_lh(slot)
 
 

@@ -71,8 +71,15 @@ class Engine:
             raise EngineError(rc, msg.decode() if msg else "sbe_create failed")
         self.group_offsets = np.concatenate([[0], np.cumsum(self.n_groups)]).astype(int)
         self.n_groups_total = int(self.group_offsets[-1])
+        self._bound = {}                    # slot -> what conditionals._bind_slot last uploaded there
+        self._bound_conc = {}               # component -> concentration table last uploaded
 
     # -- plumbing -----------------------------------------------------------------------------
+    # -- bind cache (sbayes_amd.conditionals._bind_slot): what a slot was last bound to; every method that changes a
+    #    slot's state drops the slot's entry, so a cached entry always describes the device state ------------------
+    def _touch(self, slot):
+        self._bound.pop(slot, None)
+
     def _check(self, rc):
         if rc != 0:
             msg = self._lib.sbe_last_error(self._h)
@@ -152,12 +159,14 @@ class Engine:
         if g.shape != (self.n_groups[component], self.n_objects):
             raise ValueError(f"groups of component {component} must be {(self.n_groups[component], self.n_objects)}, got {g.shape}")
         g = _c(g.astype(bool, copy=False), np.uint8)
+        self._touch(slot)
         self._check(self._lib.sbe_set_groups(self._h, slot, component, _ptr(g)))
 
     def set_group_ids(self, slot, component, ids):
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         if ids.shape != (self.n_objects,):
             raise ValueError("ids must be [n_objects]")
+        self._touch(slot)
         self._check(self._lib.sbe_set_group_ids(self._h, slot, component, _ptr(ids)))
 
     def set_source(self, slot, source):
@@ -165,6 +174,7 @@ class Engine:
         if s.shape != (self.n_objects, self.n_features, self.n_components):
             raise ValueError(f"source must be {(self.n_objects, self.n_features, self.n_components)}, got {s.shape}")
         s = _c(s.astype(bool, copy=False), np.uint8)
+        self._touch(slot)
         self._check(self._lib.sbe_set_source(self._h, slot, _ptr(s)))
 
     def set_source_rows(self, slot, objects, rows):
@@ -173,6 +183,7 @@ class Engine:
         if rows.shape != (objects.size, self.n_features, self.n_components):
             raise ValueError("rows must be [len(objects), n_features, n_components]")
         rows = _c(rows.astype(bool, copy=False), np.uint8)
+        self._touch(slot)
         self._check(self._lib.sbe_set_source_rows(self._h, slot, _ptr(objects), objects.size, _ptr(rows)))
 
     def get_source_rows(self, slot, objects):
@@ -183,18 +194,21 @@ class Engine:
         return rows.view(bool)
 
     def recount(self, slot, component=-1):
+        self._touch(slot)
         self._check(self._lib.sbe_recount(self._h, slot, component))
 
     def update_counts(self, slot_new, slot_old, objects):
         """update_feature_counts (counts.py:55-95); returns bool[G_total] of changed groups."""
         objects = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
         changed = np.zeros(self.n_groups_total, dtype=np.uint8)
+        self._touch(slot_new)
         self._check(self._lib.sbe_update_counts(self._h, slot_new, slot_old, _ptr(objects), objects.size, _ptr(changed)))
         return changed.astype(bool)
 
     def accumulate_counts(self, slot, objects, sign):
         objects = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
         changed = np.zeros(self.n_groups_total, dtype=np.uint8)
+        self._touch(slot)
         self._check(self._lib.sbe_accumulate_counts(self._h, slot, _ptr(objects), objects.size, int(sign), _ptr(changed)))
         return changed.astype(bool)
 
@@ -202,6 +216,7 @@ class Engine:
         c = _c(counts, np.float32)
         if c.shape != (self.n_groups[component], self.n_features, self.n_states):
             raise ValueError("bad counts shape")
+        self._touch(slot)
         self._check(self._lib.sbe_set_counts(self._h, slot, component, _ptr(c)))
 
     def get_counts(self, slot, component):
@@ -218,6 +233,8 @@ class Engine:
             per_group = 1
         else:
             raise ValueError(f"concentration of component {component} must be {fs} or [G]+{fs}, got {conc.shape}")
+        self._bound.clear()                 # tables of every slot depend on it
+        self._bound_conc.pop(component, None)
         self._check(self._lib.sbe_set_concentration(self._h, component, _ptr(conc), per_group))
 
     def update_probs(self, slot, component, temperature=None, prior_temperature=None, unif_counts=None):
@@ -231,12 +248,15 @@ class Engine:
             u = _c(unif_counts, np.float64)
             if u.shape != (self.n_features, self.n_states):
                 raise ValueError("unif_counts must be [n_features, n_states]")
+        if temperature is not None or prior_temperature is not None:
+            self._touch(slot)               # tempered tables are not the ones the bind cache vouches for
         self._check(self._lib.sbe_update_probs(self._h, slot, component, t, tp, _ptr(u) if u is not None else None))
 
     def set_probs(self, slot, component, probs):
         p = _c(probs, np.float32)
         if p.shape != (self.n_groups[component], self.n_features, self.n_states):
             raise ValueError("bad probs shape")
+        self._touch(slot)
         self._check(self._lib.sbe_set_probs(self._h, slot, component, _ptr(p)))
 
     def get_probs(self, slot, component):
@@ -248,6 +268,7 @@ class Engine:
         w = _c(weights, np.float32)
         if w.shape != (self.n_features, self.n_components):
             raise ValueError(f"weights must be {(self.n_features, self.n_components)}, got {w.shape}")
+        self._touch(slot)
         self._check(self._lib.sbe_set_weights(self._h, slot, _ptr(w)))
 
     def weights_normalized(self, slot):
@@ -413,6 +434,7 @@ class Engine:
                 raise ValueError(f"z must be [{objs.size}, {self.n_features}]")
         sel = np.empty((objs.size, self.n_features), dtype=np.float32) if return_selected else None
         log_q = ct.c_double()
+        self._touch(dst_slot)
         self._check(self._lib.sbe_sample_source(self._h, slot, dst_slot, _ptr(objs), objs.size, float(temperature),
                                                 float(prior_temperature), int(bool(from_prior)),
                                                 _ptr(zz) if zz is not None else None, ct.byref(log_q),
@@ -499,6 +521,7 @@ class Engine:
         glh = np.empty(self.n_groups_total, dtype=np.float64)
         mix = ct.c_double(0.0)
         changed = np.zeros(self.n_groups_total, dtype=np.uint8)
+        self._touch(cand_slot)
         self._check(self._lib.sbe_step(self._h, cur_slot, cand_slot, _ptr(cl) if cl is not None else None,
                                        _ptr(objs) if objs is not None else None, n_changed,
                                        _ptr(rows) if rows is not None else None, _ptr(w) if w is not None else None,
@@ -518,6 +541,7 @@ class Engine:
         glh = np.empty(self.n_groups_total, dtype=np.float64)
         lq, lqb, mix = ct.c_double(0.0), ct.c_double(0.0), ct.c_double(0.0)
         changed = np.zeros(self.n_groups_total, dtype=np.uint8)
+        self._touch(cand_slot)
         self._check(self._lib.sbe_gibbs_step(self._h, cur_slot, cand_slot, _ptr(objs), objs.size, float(temperature),
                                              float(prior_temperature), int(bool(from_prior)),
                                              _ptr(zz) if zz is not None else None, ct.byref(lq), ct.byref(lqb),
@@ -539,6 +563,7 @@ class Engine:
         return out
 
     def copy_slot(self, dst, src):
+        self._touch(dst)
         self._check(self._lib.sbe_copy_slot(self._h, dst, src))
 
     # -- measurement ---------------------------------------------------------------------------------

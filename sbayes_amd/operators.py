@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .conditionals import _bind_slot, _engine
+from .conditionals import _bind_slot, _engine, _tables_current
 
 EPS = np.finfo(np.float32).eps        # sbayes/util.py:34
 
@@ -26,8 +26,7 @@ EPS = np.finfo(np.float32).eps        # sbayes/util.py:34
 def _prepare(model, sample, slot):
     eng = _engine(model)
     _bind_slot(eng, model, sample, slot)
-    for c in range(eng.n_components):
-        eng.update_probs(slot, c)
+    _tables_current(eng, slot)
     return eng
 
 
@@ -101,8 +100,7 @@ def gibbs_sample_source(model, sample, object_subset=slice(None), temperature=1.
     eng = _engine(model)
     cur, new = slots
     _bind_slot(eng, model, sample, cur, with_source=True)
-    for c in range(eng.n_components):
-        eng.update_probs(cur, c)
+    _tables_current(eng, cur)
     n_objects = sample.n_objects
     if isinstance(object_subset, slice):
         objects = np.arange(n_objects)[object_subset]

@@ -11,7 +11,7 @@ from sbayes_amd import model as sbm
 from sbayes_amd.counts import recalculate_feature_counts
 from sbayes_amd.operators import compute_cluster_posterior, compute_raw_cluster_probs
 from sbayes_amd.registry import release_all
-from sbayes_amd.synthetic import make_workload
+from sbayes_amd.synthetic import make_state, make_workload
 from tests._fixtures import load_npz
 
 pytestmark = pytest.mark.gpu
@@ -332,3 +332,53 @@ def test_gibbs_source_device_rng_frequencies_follow_the_posterior():
     dof = cells.sum() - valid.sum()
     assert abs(chi2 - dof) < 5 * np.sqrt(2 * dof), (chi2, dof)
     assert np.all(freq[valid][expected == 0] == 0)
+
+
+def test_bind_cache_sends_only_what_changed_and_never_goes_stale():
+    """The operator forms bind the sample into an engine slot on every call; the bind cache skips what the slot
+    already holds.  Same results with and without it, through changes of counts, clusters and weights, through
+    foreign writes to the slot (any Engine method that changes a slot drops its cache entry), and for writable
+    arrays modified in place (compared by content, not identity)."""
+    from sbayes_amd.conditionals import _bind_slot, _engine, mixture_log_likelihood
+    wl = make_workload("cfg1")
+    model, sample = sbm.build(wl.features, wl.states_per_feature, wl.component_names, wl.groups, wl.concentration,
+                              wl.weights, wl.source)
+    recalculate_feature_counts(model.data.features.values, sample)
+    try:
+        eng = _engine(model)
+        na = ~wl.features.any(-1)
+
+        def want(groups, source, weights):
+            counts = orc.recalculate_feature_counts(wl.features, groups, source)
+            return orc.mixture_loglik(wl.features, na, groups, counts, wl.concentration, weights)
+
+        ll0 = mixture_log_likelihood(model, sample)
+        assert abs(ll0 - want(wl.groups, wl.source, wl.weights)) <= 1e-10 * abs(ll0)
+        calls = []
+        orig = eng.set_counts
+        eng.set_counts = lambda *a, **k: (calls.append("set_counts"), orig(*a, **k))[1]
+        assert mixture_log_likelihood(model, sample) == ll0 and calls == []          # nothing re-sent
+        # a foreign write to the slot drops the entry: everything is sent again, result unchanged
+        eng.set_weights(0, np.full_like(wl.weights, 1.0 / wl.n_components))
+        assert mixture_log_likelihood(model, sample) == ll0 and len(calls) == wl.n_components
+        # a new state (clusters, source, counts, weights changed) through the same slot
+        clusters2, weights2, source2 = make_state(wl.features, wl.groups[1:], wl.clusters.shape[0], seed=77)
+        groups2 = [clusters2] + wl.groups[1:]
+        model2, sample2 = sbm.build(wl.features, wl.states_per_feature, wl.component_names, groups2, wl.concentration,
+                                    weights2, source2)
+        recalculate_feature_counts(model2.data.features.values, sample2)
+        ll2 = mixture_log_likelihood(model, sample2)
+        assert abs(ll2 - want(groups2, source2, weights2)) <= 1e-10 * abs(ll2)
+        assert mixture_log_likelihood(model, sample) == ll0                          # and back
+        # a writable array modified in place is compared by content, a frozen one by identity
+        from sbayes_amd.conditionals import _remember, _same
+        w = np.array(wl.weights)
+        rec = _remember(w)
+        assert _same(w, rec)
+        w[0, 0] += 0.25
+        assert not _same(w, rec)
+        w.setflags(write=False)
+        rec = _remember(w)
+        assert rec[1] is w and _same(w, rec) and _same(w.copy(), rec) and not _same(np.zeros_like(w), rec)
+    finally:
+        release_all()

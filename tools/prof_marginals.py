@@ -19,3 +19,22 @@ t0 = time.perf_counter(); n = 1000
 for _ in range(n):
     eng.cluster_marginals(0, table, available)
 print("cluster_marginals", round((time.perf_counter() - t0) / n * 1e6, 1), "us/call for", available.size, "objects")
+# the operator form (what patch.install(operators=True) puts under AlterCluster): binds the sample, builds the
+# candidate table, evaluates
+from sbayes_amd import model as sbm
+from sbayes_amd.counts import recalculate_feature_counts
+from sbayes_amd.operators import calculate_source_posterior, compute_cluster_posterior
+model, sample = sbm.build(wl.features, wl.states_per_feature, wl.component_names, wl.groups, wl.concentration, wl.weights, wl.source)
+recalculate_feature_counts(model.data.features.values, sample)
+avail = np.zeros(wl.shape[0], dtype=bool); avail[available] = True
+for _ in range(20):
+    compute_cluster_posterior(model, sample, 0, avail)
+t0 = time.perf_counter(); n = 300
+for _ in range(n):
+    compute_cluster_posterior(model, sample, 0, avail)
+print("operators.compute_cluster_posterior", round((time.perf_counter() - t0) / n * 1e6, 1), "us/call")
+objs = np.arange(0, 1000, 50)
+t0 = time.perf_counter()
+for _ in range(n):
+    calculate_source_posterior(model, sample, objs)
+print("operators.calculate_source_posterior (20 objects)", round((time.perf_counter() - t0) / n * 1e6, 1), "us/call")
