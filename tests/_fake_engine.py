@@ -17,6 +17,8 @@ class FakeEngine:
         self.calls = []
         self.slots = {}                 # slot -> {"groups": {c: bool [G, N]}, "counts": {c: ...}, "weights": ...}
         self.conc = {}
+        self._bound = {}                # the real Engine's bind cache protocol (conditionals._bind_slot): every
+        self._bound_conc = {}           # slot-changing method drops the slot's entry
 
     def close(self):
         pass
@@ -64,15 +66,23 @@ class FakeEngine:
         return self.slots.setdefault(slot, {"groups": {}, "counts": {}, "weights": None})
 
     def set_groups(self, slot, component, groups):
+        self._bound.pop(slot, None)
+        self.calls.append(("set_groups", component))
         self._slot(slot)["groups"][component] = np.asarray(groups, dtype=bool).copy()
 
     def set_concentration(self, component, concentration):
+        self._bound.clear()
+        self._bound_conc.pop(component, None)
         self.conc[component] = np.asarray(concentration, dtype=np.float64).copy()
 
     def set_counts(self, slot, component, counts):
+        self._bound.pop(slot, None)
+        self.calls.append(("set_counts", component))
         self._slot(slot)["counts"][component] = np.asarray(counts, dtype=np.float32).copy()
 
     def set_weights(self, slot, weights):
+        self._bound.pop(slot, None)
+        self.calls.append(("set_weights",))
         self._slot(slot)["weights"] = np.asarray(weights, dtype=np.float32).copy()
 
     def update_probs(self, slot, component):

@@ -123,3 +123,7 @@ def test_reference_sampler_with_device_operator_forms(tag, src, n_steps, monkeyp
     eng = next(iter(patched[4].values()))
     kinds = {c[0] for c in eng.calls}
     assert {"cluster_marginals", "source_posterior", "subset_lh"} <= kinds        # the operator forms really ran
+    # ... through the bind cache: far fewer uploads than evaluations (and, above, the same chain)
+    n_eval = sum(c[0] in ("cluster_marginals", "source_posterior") for c in eng.calls)
+    n_counts = sum(c[0] == "set_counts" for c in eng.calls)
+    assert n_counts < n_eval * len(eng.conc), (n_counts, n_eval, len(eng.conc))
