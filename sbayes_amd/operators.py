@@ -71,6 +71,17 @@ def compute_raw_cluster_probs(model, sample, i_cluster, available, temperature=1
     return m[1] / (m[0] + m[1] + EPS)
 
 
+def cluster_log_marginals(model, sample, table, available, temperature=1.0, prior_temperature=1.0, slot=0):
+    """float64 [2, n_available]: log of AlterClusterWide's `marginal_lh_z01` (operators.py:1444-1451) for a candidate
+    cluster table `table` [1, F, S] float32 supplied by the caller (any of the reference's ClusterEffectProposals):
+    log prod_f (sum_c lh ** (1/T) ... ) ** (1/T), evaluated as sums of logs on the device."""
+    eng = _prepare(model, sample, slot)
+    table = np.asarray(table, dtype=np.float32)
+    if temperature != 1.0:
+        table = table ** (1 / temperature)          # inner1d(features, p) ** (1/T): elementwise on the table
+    return _log_marginals(eng, slot, table, available, prior_temperature) / temperature
+
+
 def calculate_source_posterior(model, sample, object_subset, temperature=1.0, prior_temperature=1.0, slot=0):
     """GibbsSampleSource.calculate_source_posterior (operators.py:554-574): float32
     [n_subset, F, C] posterior of the source assignment of every observation of the subset."""

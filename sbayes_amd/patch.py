@@ -13,6 +13,7 @@ array inside the reference's operators by their device forms (SURVEY.md 8(f) ran
 has to cross PCIe for them:
   sbayes.sampling.operators.AlterCluster.compute_cluster_posterior        (operators.py:1035-1073; inherited by
                                                                             AlterClusterWide)
+  sbayes.sampling.operators.AlterClusterWide.compute_raw_cluster_probs    (operators.py:1420-1472)
   sbayes.sampling.operators.GibbsSampleSource.calculate_source_posterior  (operators.py:554-574)
   sbayes.sampling.operators.component_likelihood_given_unchanged          (operators.py:863-928)
 Proposal logic, RNG use and everything else of the operators stay the reference's."""
@@ -97,7 +98,28 @@ def _install_operator_forms(swap):
         return my_ops.calculate_source_posterior(self.model, sample, object_subset, self.temperature,
                                                  self.prior_temperature)
 
+    def compute_raw_cluster_probs(self, sample, i_cluster, available):
+        """AlterClusterWide.compute_raw_cluster_probs (operators.py:1420-1472): the candidate table comes from the
+        reference's own cluster_effect_proposal, the marginals from the device; the geo-prior part is the reference's."""
+        model = self.model
+        if self.sample_from_prior:
+            return 0.5 * np.ones(np.count_nonzero(available))
+        p = self.cluster_effect_proposal(model, sample, i_cluster, self.temperature, self.prior_temperature)
+        with np.errstate(under="ignore"):
+            marginal_lh_z01 = np.exp(my_ops.cluster_log_marginals(model, sample, p, available, self.temperature,
+                                                                  self.prior_temperature))
+        if self.consider_geo_prior:
+            if self.cluster_effect_proposal is ref_ops.ClusterEffectProposals.residual_counts:
+                distances = model.data.geo_cost_matrix[available][:, available]
+                z = ref_ops.normalize(marginal_lh_z01[1] / (marginal_lh_z01[0] + marginal_lh_z01[1] + ref_ops.EPS))
+                log_geo_prior_ratio = -z.dot(distances) / model.prior.geo_prior.scale
+            else:
+                log_geo_prior_ratio = model.prior.geo_prior.get_costs_per_object(sample, i_cluster)[available]
+            marginal_lh_z01[1] *= np.exp(log_geo_prior_ratio / self.prior_temperature / self.geo_scaler)
+        return marginal_lh_z01[1] / (marginal_lh_z01[0] + marginal_lh_z01[1] + ref_ops.EPS)
+
     swap(ref_ops.AlterCluster, "compute_cluster_posterior", compute_cluster_posterior)
+    swap(ref_ops.AlterClusterWide, "compute_raw_cluster_probs", compute_raw_cluster_probs)
     swap(ref_ops.GibbsSampleSource, "calculate_source_posterior", calculate_source_posterior)
     # module-level function with the reference's own signature (operators.py:863-928)
     swap(ref_ops, "component_likelihood_given_unchanged", my_ops.component_likelihood_given_unchanged)

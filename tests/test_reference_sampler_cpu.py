@@ -110,8 +110,9 @@ def test_reference_sampler_on_drop_in_layer_is_the_same_markov_chain(tag, src, n
     ("south_america", Path(REF) / "experiments" / "south_america", 60),
 ])
 def test_reference_sampler_with_device_operator_forms(tag, src, n_steps, monkeypatch, tmp_path):
-    """patch.install(operators=True): AlterCluster.compute_cluster_posterior, GibbsSampleSource.calculate_source_posterior
-    and component_likelihood_given_unchanged replaced by their device forms (here: the oracle-backed double).
+    """patch.install(operators=True): AlterCluster.compute_cluster_posterior, AlterClusterWide.compute_raw_cluster_probs,
+    GibbsSampleSource.calculate_source_posterior and component_likelihood_given_unchanged replaced by their device
+    forms (here: the oracle-backed double) -- no operator pulls the [N, F, C] component-likelihood array to the host.
     The proposal probabilities then come from the log-space formulation (equal to the reference's linear-space ones
     to ~1e-15), every decision of the sampler is unchanged: same operators, same states, same likelihood / prior trace."""
     plain = run_chain(src, tag, n_steps, 11, False, monkeypatch, tmp_path)
@@ -123,6 +124,8 @@ def test_reference_sampler_with_device_operator_forms(tag, src, n_steps, monkeyp
     eng = next(iter(patched[4].values()))
     kinds = {c[0] for c in eng.calls}
     assert {"cluster_marginals", "source_posterior", "subset_lh"} <= kinds        # the operator forms really ran
+    names = {t[2] for t in patched[0]}
+    assert any("wide" in n for n in names) and any("source" in n for n in names), names   # every patched form was hit
     # ... through the bind cache: far fewer uploads than evaluations (and, above, the same chain)
     n_eval = sum(c[0] in ("cluster_marginals", "source_posterior") for c in eng.calls)
     n_counts = sum(c[0] == "set_counts" for c in eng.calls)
