@@ -125,7 +125,7 @@ def test_reference_sampler_with_device_operator_forms(tag, src, n_steps, monkeyp
     kinds = {c[0] for c in eng.calls}
     assert {"cluster_marginals", "source_posterior", "subset_lh"} <= kinds        # the operator forms really ran
     names = {t[2] for t in patched[0]}
-    assert any("wide" in n for n in names) and any("source" in n for n in names), names   # every patched form was hit
+    assert {"AlterCluster", "AlterClusterWide", "GibbsSampleSource"} <= names, names        # every patched form was hit
     # ... through the bind cache: far fewer uploads than evaluations (and, above, the same chain)
     n_eval = sum(c[0] in ("cluster_marginals", "source_posterior") for c in eng.calls)
     n_counts = sum(c[0] == "set_counts" for c in eng.calls)
