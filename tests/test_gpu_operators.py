@@ -9,7 +9,7 @@ import pytest
 from oracle import sbayes_oracle as orc
 from sbayes_amd import model as sbm
 from sbayes_amd.counts import recalculate_feature_counts
-from sbayes_amd.operators import compute_cluster_posterior, compute_raw_cluster_probs
+from sbayes_amd.operators import cluster_log_marginals, compute_cluster_posterior, compute_raw_cluster_probs
 from sbayes_amd.registry import release_all
 from sbayes_amd.synthetic import make_state, make_workload
 from tests._fixtures import load_npz
@@ -41,6 +41,14 @@ def test_cluster_posterior_matches_reference_operators(name):
             np.testing.assert_allclose(post, z[key + "_posterior"], rtol=rtol, atol=1e-300)
             raw = compute_raw_cluster_probs(model, sample, k, available, temperature=temp, prior_temperature=ptemp)
             np.testing.assert_allclose(raw, z[key + "_wide_raw"], rtol=rtol, atol=1e-300)
+            # the form patch.install(operators=True) uses: the candidate table comes from the caller (here: the
+            # reference's ClusterEffectProposals.gibbs formula, operators.py:1254-1282), the marginals from the device
+            prior = model.prior.prior_cluster_effect
+            u, a = np.asarray(prior.uniform_concentration_array), np.asarray(prior.concentration_array)
+            table = orc.normalize(u + (a - u) / ptemp + fx.counts[0][[k]] / temp, axis=-1)
+            m = np.exp(cluster_log_marginals(model, sample, table, available, temp, ptemp))
+            np.testing.assert_allclose(m[1] / (m[0] + m[1] + np.finfo(np.float32).eps), z[key + "_wide_raw"],
+                                       rtol=rtol, atol=1e-300)
             if k == 0 and tag == "t1":
                 log_m = model.likelihood.engine.cluster_marginals(0, z[key + "_table"], np.flatnonzero(available))
                 np.testing.assert_allclose(np.exp(log_m), z[key + "_marginal_z01"], rtol=1e-12)
