@@ -16,6 +16,7 @@ has to cross PCIe for them:
   sbayes.sampling.operators.AlterClusterWide.compute_raw_cluster_probs    (operators.py:1420-1472)
   sbayes.sampling.operators.GibbsSampleSource.calculate_source_posterior  (operators.py:554-574)
   sbayes.sampling.operators.component_likelihood_given_unchanged          (operators.py:863-928)
+  sbayes.sampling.loggers.LikelihoodLogger._write_sample                  (loggers.py:354-359)
 Proposal logic, RNG use and everything else of the operators stay the reference's."""
 from __future__ import annotations
 
@@ -123,6 +124,21 @@ def _install_operator_forms(swap):
     swap(ref_ops.GibbsSampleSource, "calculate_source_posterior", calculate_source_posterior)
     # module-level function with the reference's own signature (operators.py:863-928)
     swap(ref_ops, "component_likelihood_given_unchanged", my_ops.component_likelihood_given_unchanged)
+    # the per-observation likelihood row of the LikelihoodLogger (loggers.py:354-359): one [N, F] float64 array from
+    # the device instead of the [N, F, C] leave-one-out array and the [N, F, C] weights
+    try:
+        ref_loggers = importlib.import_module("sbayes.sampling.loggers")
+    except ImportError:
+        ref_loggers = None
+    if ref_loggers is not None and hasattr(ref_loggers, "LikelihoodLogger"):
+        from . import conditionals as my_cond
+
+        def _write_sample(self, sample):
+            lh = my_cond.observation_likelihoods(self.model, sample, exact=True).ravel()
+            self.logged_likelihood_array.append(lh[None, ...])
+            self.file.flush()
+
+        swap(ref_loggers.LikelihoodLogger, "_write_sample", _write_sample)
 
 
 def uninstall():

@@ -80,6 +80,21 @@ class FakeEngine:
         self.calls.append(("set_counts", component))
         self._slot(slot)["counts"][component] = np.asarray(counts, dtype=np.float32).copy()
 
+    def set_source(self, slot, source):
+        self._bound.pop(slot, None)
+        self._slot(slot)["source"] = np.asarray(source, dtype=bool).copy()
+
+    def observation_lh_exact(self, slot):
+        self.calls.append(("observation_lh_exact",))
+        s = self.slots[slot]
+        C = len(s["groups"])
+        groups = [s["groups"][c] for c in range(C)]
+        counts = [s["counts"][c] for c in range(C)]
+        conc = [self.conc[c] for c in range(C)]
+        lh = orc.likelihood_per_component_exact(self.features, self.na_values(), groups, counts, conc, s["source"])
+        w = orc.normalize_weights(s["weights"], orc.has_components(groups))
+        return orc.logger_row(w, lh).reshape(self.n_objects, self.n_features)
+
     def set_weights(self, slot, weights):
         self._bound.pop(slot, None)
         self.calls.append(("set_weights",))

@@ -130,3 +130,82 @@ def test_reference_sampler_with_device_operator_forms(tag, src, n_steps, monkeyp
     n_eval = sum(c[0] in ("cluster_marginals", "source_posterior") for c in eng.calls)
     n_counts = sum(c[0] == "set_counts" for c in eng.calls)
     assert n_counts < n_eval * len(eng.conc), (n_counts, n_eval, len(eng.conc))
+
+
+def test_likelihood_logger_row_from_the_device_form(monkeypatch, tmp_path):
+    """patch.install(operators=True) also serves LikelihoodLogger._write_sample (loggers.py:354-359) from the device
+    form of the per-observation likelihood: the appended row equals the reference's, bit for bit."""
+    src = Path(REF) / "test" / "test_files"
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import _ref_stubs
+    _ref_stubs.install()
+    import sbayes.model                                  # (import order: sbayes.model before sbayes.sampling.state)
+    import sbayes.sampling.loggers as ref_loggers
+
+    class _Sink:
+        def __init__(self):
+            self.rows = []
+
+        def append(self, row):
+            self.rows.append(np.array(row))
+
+        def flush(self):
+            pass
+
+    def logged_row(patched):
+        # a sampler state to log: rebuild it the same way in both worlds (seeded), then call the logger's method
+        sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+        from sbayes_amd import conditionals, counts, likelihood, patch, registry
+        from tests._fake_engine import FakeEngine
+        engines = {}
+
+        def get_engine(features, n_groups=None, n_slots=4, device=None):
+            key = (np.asarray(features).ctypes.data, np.asarray(features).shape)
+            return engines.setdefault(key, FakeEngine(features, n_groups))
+
+        if patched:
+            for mod in (registry, likelihood, conditionals, counts):
+                monkeypatch.setattr(mod, "get_engine", get_engine, raising=True)
+            monkeypatch.setattr(registry, "_ENGINES", {})
+            patch.install(operators=True)
+        try:
+            from sbayes.experiment_setup import Experiment
+            from sbayes.load_data import Data
+            from sbayes.model import Model
+            from sbayes.sampling.initializers import SbayesInitializer
+            work = tmp_path / f"logger_{'p' if patched else 'u'}"
+            shutil.copytree(src, work)
+            cwd = os.getcwd()
+            os.chdir(work)
+            try:
+                np.random.seed(5)
+                random.seed(5)
+                import sbayes.sampling.operators as ref_ops
+                import sbayes.sampling.initializers as ref_init
+                import sbayes.util as ref_util
+                for mod in (ref_ops, ref_init, ref_util):
+                    monkeypatch.setattr(mod, "RNG", np.random.default_rng(5), raising=True)
+                experiment = Experiment(config_file=work / "config.yaml", experiment_name="logger", log=False)
+                data = Data.from_config(experiment.config)
+                model = Model(data, experiment.config.model)
+                cfg = experiment.config.mcmc
+                init = SbayesInitializer(model=model, data=data, initial_size=cfg.initialization.objects_per_cluster,
+                                         attempts=cfg.initialization.attempts,
+                                         initial_cluster_steps=cfg.initialization._initial_cluster_steps)
+                sample = init.generate_sample(c=0)
+                logger = object.__new__(ref_loggers.LikelihoodLogger)
+                logger.model = model
+                logger.logged_likelihood_array = _Sink()
+                logger.file = _Sink()
+                logger._write_sample(sample)
+                return logger.logged_likelihood_array.rows[0], engines
+            finally:
+                os.chdir(cwd)
+        finally:
+            if patched:
+                patch.uninstall()
+
+    row_ref, _ = logged_row(False)
+    row_dev, engines = logged_row(True)
+    assert row_dev.shape == row_ref.shape and np.array_equal(row_dev, row_ref)
+    assert any(("observation_lh_exact",) in e.calls for e in engines.values())
