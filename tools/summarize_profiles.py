@@ -18,9 +18,15 @@ DST = REPO / "profiles" / TAG
 DST.mkdir(parents=True, exist_ok=True)
 
 
+def newest(pattern):
+    """The most recently written match (a directory may hold the files of earlier runs of the same pass)."""
+    files = sorted(glob.glob(pattern), key=lambda f: Path(f).stat().st_mtime)
+    return files[-1:]
+
+
 def counters(dirname):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(str(SRC / dirname / "*" / "*_counter_collection.csv")):
+    for f in newest(str(SRC / dirname / "*" / "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
             out[name][(r["Counter_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
@@ -85,7 +91,7 @@ for wl, batch in (("headline", 1024), ("stress", 8)):
                 sq.update({k: v["mean"] for k, v in dominant(counters(f"pmc_{part}_{suffix}"), prefix).items()})
         if sq:
             summary[f"sq_counters_{wl}_{kern}_b{batch}"] = sq
-        for f in glob.glob(str(SRC / f"trace_{suffix}" / "*" / "*_kernel_stats.csv")):
+        for f in newest(str(SRC / f"trace_{suffix}" / "*" / "*_kernel_stats.csv")):
             shutil.copy(f, DST / f"kernel_stats_{wl}_{kern}_b{batch}.csv")
         b = SRC / f"bench_{suffix}.json"
         if b.exists() and b.stat().st_size:
