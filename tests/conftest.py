@@ -14,6 +14,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The engine library is a build artefact (git-ignored): (re)build it in-tree when it is missing or older than
+    its sources and hipcc is here (hipcc cross-compiles gfx950 without a GPU; the GPU box receives the built file)."""
+    import shutil
+    sys.path.insert(0, str(REPO))
+    import __graft_entry__ as entry
+    deps = [entry.SRC, entry.SRC.with_name("sbe_kernels.hip.h"), REPO / "include" / "sbe_engine.h"]
+    stale = not entry.OUT.exists() or any(d.stat().st_mtime > entry.OUT.stat().st_mtime for d in deps)
+    if stale and (os.path.exists(entry.HIPCC) or shutil.which("hipcc")):
+        entry.build()
+
+
 @pytest.fixture(scope="session")
 def engine_lib():
     """The C-ABI shared library (built in-tree by __graft_entry__.build())."""
