@@ -1658,7 +1658,7 @@ int sbe_sample_source(sbe_engine* e, int slot, int dst_slot, const int32_t* obje
     double* d_partials = (double*)(d_extra + zb + pb);
     if (z) { int _urc = upload(e, d_z, z, (size_t)n_obs * sizeof(double)); if (_urc) return _urc; }
     k_sample_source<<<div_up(n_obs, 256), 256, 0, e->stream>>>(a, z ? d_z : nullptr, e->rng_seed, e->rng_draw,
-                                                               e->d_src + (int64_t)dst_slot * e->N * e->Fp, d_psel, e->d_status);
+                                                               e->d_src + (int64_t)dst_slot * e->N * e->Fp, d_psel, e->d_status, nullptr);
     if (!z) ++e->rng_draw;
     HIPCHK(e, hipGetLastError());
     return finish_log_q(e, d_psel, n_obs, d_partials, log_q_out, p_selected_out);
@@ -1704,7 +1704,7 @@ int sbe_source_logprob(sbe_engine* e, int slot, int src_slot, const int32_t* obj
     if (rc) return rc;
     float* d_psel = (float*)d_extra;
     double* d_partials = (double*)(d_extra + pb);
-    k_source_logprob<<<div_up(n_obs, 256), 256, 0, e->stream>>>(a, e->d_src + (int64_t)src_slot * e->N * e->Fp, d_psel, e->d_status);
+    k_source_logprob<<<div_up(n_obs, 256), 256, 0, e->stream>>>(a, e->d_src + (int64_t)src_slot * e->N * e->Fp, d_psel, e->d_status, nullptr);
     HIPCHK(e, hipGetLastError());
     return finish_log_q(e, d_psel, n_obs, d_partials, log_q_out, p_selected_out);
 }
@@ -2064,7 +2064,7 @@ static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* 
 // ---- one-call Gibbs source step (GibbsSampleSource._propose, operators.py:495-552, on the resident state) ------
 // candidate = current with the source of the listed objects redrawn from its posterior ON THE DEVICE; count delta,
 // every table, both transition log-probabilities, collapsed per-group and mixture log-likelihood of the candidate:
-// seven launches, one synchronisation; objects (and the caller's uniforms) are read from host-mapped memory, all
+// five launches, one synchronisation; objects (and the caller's uniforms) are read from host-mapped memory, all
 // results arrive through host-mapped memory.
 int sbe_gibbs_step(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* objects, int n_sub, double temperature,
                    double prior_temperature, int from_prior, const double* z, double* log_q_out, double* log_q_back_out,
@@ -2108,16 +2108,18 @@ int sbe_gibbs_step(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* ob
     // device scratch: selected probabilities (forward / back), their partial log sums, uniforms if copied
     const size_t pb = ((size_t)n_obs * sizeof(float) + 255) / 256 * 256;
     const size_t zb = (z && !z_mapped) ? (zbytes + 255) / 256 * 256 : 0;
-    rc = ensure_scratch(e, 2 * pb + 2 * 256 * sizeof(double) + zb);
+    const int nblk = div_up(n_obs, kBlock);                   // one log-sum partial per block of the two posterior kernels
+    const size_t qb_bytes = ((size_t)nblk * sizeof(double) + 255) / 256 * 256;
+    rc = ensure_scratch(e, 2 * pb + 2 * qb_bytes + zb);
     if (rc) return rc;
     float* d_psel_f = (float*)e->d_scratch;
     float* d_psel_b = (float*)(e->d_scratch + pb);
     double* d_part_f = (double*)(e->d_scratch + 2 * pb);
-    double* d_part_b = d_part_f + 256;
+    double* d_part_b = (double*)(e->d_scratch + 2 * pb + qb_bytes);
     const double* d_z = nullptr;
     if (z && z_mapped) { memcpy(e->h_io + ob + rb, z, zbytes); d_z = reinterpret_cast<const double*>(e->d_io + ob + rb); }
     else if (z) {
-        double* dz = (double*)(e->d_scratch + 2 * pb + 2 * 256 * sizeof(double));
+        double* dz = (double*)(e->d_scratch + 2 * pb + 2 * qb_bytes);
         int _urc = upload(e, dz, z, zbytes); if (_urc) return _urc;
         d_z = dz;
     }
@@ -2128,15 +2130,13 @@ int sbe_gibbs_step(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* ob
                            d_obj, n_sub, Np, F, e->S, C, e->Fp, inv_t, (float)inv_tp, inv_t != 1.0, inv_tp != 1.0,
                            from_prior != 0};
     };
-    const int nb = (int)std::min<int64_t>(div_up(n_obs, 4 * kBlock), 256);
     uint8_t* src_cand = e->d_src + (int64_t)cand_slot * N * e->Fp;
-    // 1: the draw (posterior from the current tables) -> the candidate's source rows of the listed objects; 2: log_q partials
-    k_sample_source<<<div_up(n_obs, 256), 256, 0, e->stream>>>(post_args(cur_slot), d_z, e->rng_seed, e->rng_draw, src_cand, d_psel_f, e->d_status);
+    // 1: the draw (posterior from the current tables) -> the candidate's source rows of the listed objects, and the
+    //    per-block partial sums of log_q
+    k_sample_source<<<nblk, kBlock, 0, e->stream>>>(post_args(cur_slot), d_z, e->rng_seed, e->rng_draw, src_cand, d_psel_f, e->d_status, d_part_f);
     if (!z) ++e->rng_draw;
     HIPCHK(e, hipGetLastError());
-    k_sum_log_f32<<<nb, kBlock, 0, e->stream>>>(d_psel_f, n_obs, d_part_f);
-    HIPCHK(e, hipGetLastError());
-    // 3: the rest of the candidate slot, its count delta and every one of its tables
+    // 2: the rest of the candidate slot, its count delta and every one of its tables
     Slot cd = cur;
     {
         CoreInputs in;
@@ -2149,14 +2149,12 @@ int sbe_gibbs_step(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* ob
     }
     std::fill(cd.probs_set.begin(), cd.probs_set.end(), 1);
     e->slots[cand_slot] = cd;
-    // 4 + 5: log_q_back -- the candidate's posterior evaluated at the CURRENT source assignment
-    k_source_logprob<<<div_up(n_obs, 256), 256, 0, e->stream>>>(post_args(cand_slot), e->d_src + (int64_t)cur_slot * N * e->Fp, d_psel_b, e->d_status);
+    // 3: log_q_back -- the candidate's posterior evaluated at the CURRENT source assignment (+ its partial sums)
+    k_source_logprob<<<nblk, kBlock, 0, e->stream>>>(post_args(cand_slot), e->d_src + (int64_t)cur_slot * N * e->Fp, d_psel_b, e->d_status, d_part_b);
     HIPCHK(e, hipGetLastError());
-    k_sum_log_f32<<<nb, kBlock, 0, e->stream>>>(d_psel_b, n_obs, d_part_b);
-    HIPCHK(e, hipGetLastError());
-    // 6 + 7: fused mixture eval, reduction + epilogue (per-group collapsed values, flags, checks, log_q / log_q_back)
+    // 4 + 5: fused mixture eval, reduction + epilogue (per-group collapsed values, flags, checks, log_q / log_q_back)
     StepFinish fin = make_step_finish(e);
-    fin.lq_partials[0] = d_part_f; fin.lq_partials[1] = d_part_b; fin.lq_n[0] = fin.lq_n[1] = nb;
+    fin.lq_partials[0] = d_part_f; fin.lq_partials[1] = d_part_b; fin.lq_n[0] = fin.lq_n[1] = nblk;
     fin.lq_out = reinterpret_cast<double*>(e->d_step_host + step_host_lq_offset(e));
     rc = launch_mixture(e, cand_slot, 1, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, &fin);
     if (rc) return rc;

@@ -658,10 +658,14 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __rest
             __syncthreads();
         }
         if (threadIdx.x < ST_WORDS) fin.status_out[threadIdx.x] = fin.status[threadIdx.x];
-        if (fin.lq_out && threadIdx.x < 2) {
-            double acc = 0.0;
-            for (int i = 0; i < fin.lq_n[threadIdx.x]; ++i) acc += fin.lq_partials[threadIdx.x][i];
-            fin.lq_out[threadIdx.x] = acc;
+        if (fin.lq_out) {                                                // kernel-uniform; fixed order: deterministic
+            for (int t = 0; t < 2; ++t) {
+                double acc = 0.0;
+                for (int i = threadIdx.x; i < fin.lq_n[t]; i += kBlock) acc += fin.lq_partials[t][i];
+                __syncthreads();                                         // (red4 reuse)
+                const double total = block_sum(acc, red4);
+                if (threadIdx.x == 0) fin.lq_out[t] = total;
+            }
         }
         return;
     }
@@ -1782,44 +1786,62 @@ __global__ void k_source_posterior(SrcPostArgs a, float* __restrict__ out, int* 
 // (z == nullptr: uniform i of the engine's Philox stream, SURVEY.md 8(f) rank 3 "device RNG")
 // -- writes component k (0xFF for NA observations, operators.py:527) into the destination slot's
 // source and keeps p[k] (1 for NA) for the transition log-probability log_q = sum log p[k].
-__global__ void k_sample_source(SrcPostArgs a, const double* __restrict__ z, uint64_t seed, uint64_t draw,
-                                uint8_t* __restrict__ src_dst, float* __restrict__ p_sel,
-                                int* __restrict__ status) {
+// log_partials != nullptr (one-call Gibbs step): the block's sum of log(selected probability) goes to
+// log_partials[blockIdx.x] (fixed order inside the block; the step epilogue adds the blocks in order) -- no separate
+// k_sum_log_f32 launch.  Blocks are 256 threads.
+__device__ __forceinline__ void block_log_partial(float sel, bool active, double* __restrict__ log_partials) {
+    if (!log_partials) return;                                   // kernel-uniform
+    __shared__ double red4[4];
+    const double total = block_sum(active ? log((double)sel) : 0.0, red4);
+    if (threadIdx.x == 0) log_partials[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kBlock) void k_sample_source(SrcPostArgs a, const double* __restrict__ z, uint64_t seed,
+                                                         uint64_t draw, uint8_t* __restrict__ src_dst,
+                                                         float* __restrict__ p_sel, int* __restrict__ status,
+                                                         double* __restrict__ log_partials) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)a.n_sub * a.F) return;
-    const int r = (int)(i / a.F), f = (int)(i % a.F);
-    const int n = a.objects[r];
-    float p[kMaxComponents];
-    if (!source_posterior_row(a, n, f, p)) atomicAdd(&status[ST_BAD_NORMALIZE], 1);
-    float cdf[kMaxComponents];
-    float run = p[0];
-    cdf[0] = run;
-    for (int c = 1; c < a.C; ++c) { run = run + p[c]; cdf[c] = run; }
-    const float last = cdf[a.C - 1];
-    const double zz = z ? z[i] : philox_uniform(seed, draw, (uint64_t)i);     // z == nullptr: the engine's own stream
-    int k = 0;
-    for (int c = a.C - 1; c >= 0; --c)
-        if (zz < (double)(cdf[c] / last)) k = c;
-    const bool na = a.state[(int64_t)n * a.Fp + f] == kNA;
-    src_dst[(int64_t)n * a.Fp + f] = na ? (uint8_t)kNA : (uint8_t)k;
+    const bool active = i < (int64_t)a.n_sub * a.F;
     float sel = 1.0f;
-    for (int c = 0; c < a.C; ++c) sel = (!na && c == k) ? p[c] : sel;
-    p_sel[i] = sel;
+    if (active) {
+        const int r = (int)(i / a.F), f = (int)(i % a.F);
+        const int n = a.objects[r];
+        float p[kMaxComponents];
+        if (!source_posterior_row(a, n, f, p)) atomicAdd(&status[ST_BAD_NORMALIZE], 1);
+        float cdf[kMaxComponents];
+        float run = p[0];
+        cdf[0] = run;
+        for (int c = 1; c < a.C; ++c) { run = run + p[c]; cdf[c] = run; }
+        const float last = cdf[a.C - 1];
+        const double zz = z ? z[i] : philox_uniform(seed, draw, (uint64_t)i);     // z == nullptr: the engine's own stream
+        int k = 0;
+        for (int c = a.C - 1; c >= 0; --c)
+            if (zz < (double)(cdf[c] / last)) k = c;
+        const bool na = a.state[(int64_t)n * a.Fp + f] == kNA;
+        src_dst[(int64_t)n * a.Fp + f] = na ? (uint8_t)kNA : (uint8_t)k;
+        for (int c = 0; c < a.C; ++c) sel = (!na && c == k) ? p[c] : sel;
+        p_sel[i] = sel;
+    }
+    block_log_partial(sel, active, log_partials);        // (one convergent call: it contains a barrier)
 }
 
 // log_q_back (operators.py:544-550): p of `a`'s state evaluated at ANOTHER slot's source assignment.
-__global__ void k_source_logprob(SrcPostArgs a, const uint8_t* __restrict__ src, float* __restrict__ p_sel,
-                                 int* __restrict__ status) {
+__global__ __launch_bounds__(kBlock) void k_source_logprob(SrcPostArgs a, const uint8_t* __restrict__ src,
+                                                          float* __restrict__ p_sel, int* __restrict__ status,
+                                                          double* __restrict__ log_partials) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)a.n_sub * a.F) return;
-    const int r = (int)(i / a.F), f = (int)(i % a.F);
-    const int n = a.objects[r];
-    float p[kMaxComponents];
-    if (!source_posterior_row(a, n, f, p)) atomicAdd(&status[ST_BAD_NORMALIZE], 1);
-    const int id = src[(int64_t)n * a.Fp + f];
+    const bool active = i < (int64_t)a.n_sub * a.F;
     float sel = 1.0f;
-    for (int c = 0; c < a.C; ++c) sel = (c == id) ? p[c] : sel;
-    p_sel[i] = sel;
+    if (active) {
+        const int r = (int)(i / a.F), f = (int)(i % a.F);
+        const int n = a.objects[r];
+        float p[kMaxComponents];
+        if (!source_posterior_row(a, n, f, p)) atomicAdd(&status[ST_BAD_NORMALIZE], 1);
+        const int id = src[(int64_t)n * a.Fp + f];
+        for (int c = 0; c < a.C; ++c) sel = (c == id) ? p[c] : sel;
+        p_sel[i] = sel;
+    }
+    block_log_partial(sel, active, log_partials);        // (one convergent call: it contains a barrier)
 }
 
 // partials[b] = sum of log(v[i]) over block b's grid-stride share (fp64 logs, fixed order);

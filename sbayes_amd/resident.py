@@ -144,7 +144,7 @@ class ResidentChain:
 
     def gibbs_step(self, objects, temperature=1.0, prior_temperature=1.0, sample_from_prior=False, z=None,
                    device_rng=False):
-        """propose_gibbs_source + evaluation of the candidate in ONE engine call (sbe_gibbs_step: seven launches, one
+        """propose_gibbs_source + evaluation of the candidate in ONE engine call (sbe_gibbs_step: five launches, one
         synchronisation).  Returns (log_q, log_q_back, collapsed log-likelihood, per-group values, mixture
         log-likelihood).  Follow with accept() or reject()."""
         eng = self.eng
