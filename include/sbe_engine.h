@@ -30,7 +30,7 @@ extern "C" {
 
 typedef struct sbe_engine sbe_engine;
 
-#define SBE_ABI_VERSION 1
+#define SBE_ABI_VERSION 2
 
 /* error codes */
 #define SBE_OK 0
@@ -87,7 +87,9 @@ const char* sbe_last_error(const sbe_engine* e);
  * every (object, feature) row has at most one set state, derives the packed state-index
  * block [N][F] (0xFF = NA) on the device.
  *   n_groups[c]: number of groups of mixture component c (c = 0: clusters, K;
- *                c >= 1: confounders, load_data.py:138-184).  */
+ *                c >= 1: confounders, load_data.py:138-184).  0 is allowed (n_clusters == 0, the
+ *                confounders-only baseline, sbayes/sampling/initializers.py:357): that component has
+ *                empty tables and contributes nothing; at least one component must have a group.  */
 int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int n_states,
                int n_components, const int32_t* n_groups, int n_slots,
                const uint8_t* features_onehot /* [N][F][S] bool */);
@@ -213,7 +215,10 @@ int sbe_collapsed_loglik(sbe_engine* e, int slot, int component, double* per_gro
  * sbe_effect_counts    : compute_effect_counts(features, group_assignment,
  *                        source_is_component, object_subset) (counts.py:10-32);
  *                        n_subset = -1 means all objects
- * sbe_normalize_weights: normalize_weights(weights, has_components) (likelihood.py:171-190) */
+ * sbe_normalize_weights: normalize_weights(weights, has_components) (likelihood.py:171-190); has_components has
+ *                        `n_rows` rows -- all objects (update_weights, likelihood.py:153-168) or any subset of them
+ *                        (compute_feature_weights_with_and_without passes has_components[available],
+ *                        operators.py:1075-1095); only F is taken from the engine */
 int sbe_normalize_tables(sbe_engine* e, const float* counts /* [G][F][S] */, int n_groups,
                          const double* conc, int conc_per_group, double temperature,
                          double prior_temperature, const double* unif_counts, float* out);
@@ -224,7 +229,8 @@ int sbe_effect_counts(sbe_engine* e, const uint8_t* groups /* [G][N] bool */, in
                       const uint8_t* source_is_component /* [N][F] bool */, const int32_t* objects,
                       int n_subset, float* out /* [G][F][S] */);
 int sbe_normalize_weights(sbe_engine* e, const float* weights /* [F][C] */, int n_comp,
-                          const uint8_t* has_components /* [N][C] bool */, float* out /* [N][F][C] */);
+                          const uint8_t* has_components /* [n_rows][C] bool */, int n_rows,
+                          float* out /* [n_rows][F][C] */);
 
 /* ---- cluster-membership marginals --------------------------------------
  * AlterCluster.compute_cluster_posterior (sbayes/sampling/operators.py:1035-1073) and

@@ -9,6 +9,7 @@ import os
 from pathlib import Path
 
 LIB_NAME = "libsbe_engine.so"
+ABI_VERSION = 2                    # SBE_ABI_VERSION of include/sbe_engine.h
 _LIB = None
 
 c_engine_p = ct.c_void_p
@@ -73,7 +74,7 @@ PROTOTYPES = {
                                         ct.c_void_p]),
     "sbe_effect_counts": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int,
                                      ct.c_void_p]),
-    "sbe_normalize_weights": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p]),
+    "sbe_normalize_weights": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_cluster_marginals": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_double,
                                          ct.c_void_p]),
     "sbe_source_posterior": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double,
@@ -126,7 +127,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.sbe_abi_version() != 1:
-        raise RuntimeError(f"sbayes_amd: ABI version mismatch ({lib.sbe_abi_version()} != 1)")
+    if lib.sbe_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"sbayes_amd: ABI version mismatch ({lib.sbe_abi_version()} != {ABI_VERSION})")
     _LIB = lib
     return lib

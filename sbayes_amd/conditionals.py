@@ -82,19 +82,34 @@ def likelihood_per_component(model, sample, caching=True):
 likelihood_per_component_subset = likelihood_per_component
 
 
-def _same(arr, cached):
-    """True if `arr` is what `cached` = (object, private copy) recorded.  Identity counts only for read-only arrays
-    (the reference's and the mirror's parameters are frozen between edits, sbayes/sampling/state.py:43-61)."""
+def _token(param):
+    """(array, version) of a state parameter.  The reference's (and the mirror's) parameters bump `version` on every
+    edit -- set_value, set_items, edit(), edit_group(s), set_groups, FeatureCounts.add_changes
+    (sbayes/sampling/state.py:34-61, 97-161, 340-350) -- and edit the SAME ndarray in place whenever the parameter is
+    not shared with a copy, so array identity alone says nothing; plain arrays (confounder group matrices,
+    concentration tables) have no version and are compared by content."""
+    value = getattr(param, "value", param)
+    return np.asarray(value), getattr(param, "version", None)
+
+
+def _same(tok, cached):
+    """True if the token `tok` = (array, version) denotes what `cached` = (array, version, private copy) recorded.
+    Versioned parameters: same ndarray object AND same version (an in-place edit through the parameter API always
+    bumps the version; a copy-on-write edit always creates a new ndarray).  Unversioned arrays: content equality
+    against the private copy -- identity is never trusted."""
     if cached is None:
         return False
-    ref, copy = cached
-    if arr is ref and not arr.flags.writeable:
-        return True
-    return arr.shape == copy.shape and arr.dtype == copy.dtype and np.array_equal(arr, copy)
+    arr, version = tok
+    ref, ref_version, copy = cached
+    if version is not None and ref_version is not None:
+        return arr is ref and version == ref_version
+    return copy is not None and arr.shape == copy.shape and arr.dtype == copy.dtype and np.array_equal(arr, copy)
 
 
-def _remember(arr):
-    return arr, (arr if not arr.flags.writeable else arr.copy())
+def _remember(tok):
+    arr, version = tok
+    # the ndarray itself is kept alive so that its id cannot be recycled for another array while the entry lives
+    return arr, version, (None if version is not None else arr.copy())
 
 
 def _bind_slot(eng, model, sample, slot, with_source=False):
@@ -103,43 +118,43 @@ def _bind_slot(eng, model, sample, slot, with_source=False):
     nearly the same sample many times in a row); returns the components whose probability tables are stale."""
     names = sample.component_names
     C = len(names)
-    groups = [np.asarray(sample.clusters.value)] + [np.asarray(c.group_assignment) for c in sample.confounders.values()]
-    conc = [np.asarray(model.prior.prior_cluster_effect.concentration_array)] + [
-        np.asarray(model.prior.prior_confounding_effects[k].concentration_array(sample)) for k in names[1:]]
-    counts = [np.asarray(sample.feature_counts[name].value) for name in names]
-    weights = np.asarray(sample.weights.value)
-    source = np.asarray(sample.source.value) if with_source else None
+    groups = [_token(sample.clusters)] + [_token(c.group_assignment) for c in sample.confounders.values()]
+    conc = [_token(model.prior.prior_cluster_effect.concentration_array)] + [
+        _token(model.prior.prior_confounding_effects[k].concentration_array(sample)) for k in names[1:]]
+    counts = [_token(sample.feature_counts[name]) for name in names]
+    weights = _token(sample.weights)
+    source = _token(sample.source) if with_source else None
     cache = getattr(eng, "_bound", None)
     if cache is None:                               # an engine without a bind cache (test doubles): send everything
         for c in range(C):
-            eng.set_groups(slot, c, groups[c])
-            eng.set_concentration(c, conc[c])
-            eng.set_counts(slot, c, counts[c])
+            eng.set_groups(slot, c, groups[c][0])
+            eng.set_concentration(c, conc[c][0])
+            eng.set_counts(slot, c, counts[c][0])
         if with_source:
-            eng.set_source(slot, source)
-        eng.set_weights(slot, weights)
+            eng.set_source(slot, source[0])
+        eng.set_weights(slot, weights[0])
         return set(range(C))
     old = cache.get(slot) or {"groups": [None] * C, "counts": [None] * C, "weights": None, "source": None, "stale": set(range(C))}
     new = {"groups": list(old["groups"]), "counts": list(old["counts"]), "weights": old["weights"], "source": old["source"],
            "stale": set(old["stale"])}
     conc_changed = [c for c in range(C) if not _same(conc[c], eng._bound_conc.get(c))]
     for c in conc_changed:                          # (drops every slot's entry: all tables depend on it)
-        eng.set_concentration(c, conc[c])
+        eng.set_concentration(c, conc[c][0])
     if conc_changed:
         new["stale"] = set(range(C))
     for c in range(C):
         if not _same(groups[c], old["groups"][c]):
-            eng.set_groups(slot, c, groups[c])
+            eng.set_groups(slot, c, groups[c][0])
             new["groups"][c] = _remember(groups[c])
         if not _same(counts[c], old["counts"][c]):
-            eng.set_counts(slot, c, counts[c])
+            eng.set_counts(slot, c, counts[c][0])
             new["counts"][c] = _remember(counts[c])
             new["stale"].add(c)
     if with_source and not _same(source, old["source"]):
-        eng.set_source(slot, source)
+        eng.set_source(slot, source[0])
         new["source"] = _remember(source)
     if not _same(weights, old["weights"]):
-        eng.set_weights(slot, weights)
+        eng.set_weights(slot, weights[0])
         new["weights"] = _remember(weights)
     for c in conc_changed:
         eng._bound_conc[c] = _remember(conc[c])

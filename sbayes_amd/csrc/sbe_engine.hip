@@ -357,6 +357,7 @@ int upload_patterns_and_weights(sbe_engine* e, int slot) {
 int retile_probs(sbe_engine* e, int slot, int component) {
     const int g_lo = e->goff[component], g_hi = g_lo + e->G[component];
     const int64_t n = (int64_t)(g_hi - g_lo) * e->S * e->ft * e->n_ftiles;
+    if (n == 0) return SBE_OK;                     // component without groups
     k_tile_probs<<<div_up(n, 256), 256, 0, e->stream>>>(
         e->d_probs + (int64_t)slot * e->table_elems(), e->d_probs_t + (int64_t)slot * e->probs_t_elems(),
         g_lo, g_hi, e->Gtot, e->F, e->S, e->ft, e->n_ftiles);
@@ -709,9 +710,13 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     if (n_slots < 1 || n_slots > 4096) return fail(nullptr, SBE_ERR_ARG, "n_slots=%d unsupported (1..4096)", n_slots);
     int64_t gtot = 0;
     for (int c = 0; c < n_components; ++c) {
-        if (n_groups[c] < 1) return fail(nullptr, SBE_ERR_ARG, "component %d has %d groups", c, n_groups[c]);
+        // a component may have no group at all (n_clusters == 0, the confounders-only baseline: the reference's
+        // initializer returns an empty cluster matrix, sbayes/sampling/initializers.py:357): its tables are empty and
+        // every object is in "no group" of it
+        if (n_groups[c] < 0) return fail(nullptr, SBE_ERR_ARG, "component %d has %d groups", c, n_groups[c]);
         gtot += n_groups[c];
     }
+    if (gtot < 1) return fail(nullptr, SBE_ERR_ARG, "no component has any group");
     if (gtot >= 0xFFFF) return fail(nullptr, SBE_ERR_ARG, "%lld groups in total exceed the 16-bit group index", (long long)gtot);
 
     int ndev = 0;
@@ -1005,7 +1010,8 @@ static int set_gid_common(sbe_engine* e, int slot, int component, const std::vec
 }
 
 int sbe_set_groups(sbe_engine* e, int slot, int component, const uint8_t* groups) {
-    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component); CHECK_PTR(e, groups);
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component);
+    if (e->G[component] > 0) CHECK_PTR(e, groups);
     HIPCHK(e, hipSetDevice(e->device));
     const int N = e->N, G = e->G[component], off = e->goff[component];
     std::vector<uint16_t> ids(N, kNoGroup);
@@ -1151,7 +1157,9 @@ int sbe_accumulate_counts(sbe_engine* e, int slot, const int32_t* objects, int n
 }
 
 int sbe_set_counts(sbe_engine* e, int slot, int component, const float* counts) {
-    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component); CHECK_PTR(e, counts);
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component);
+    if (e->G[component] == 0) { e->slots[slot].counts_set[component] = 1; return SBE_OK; }
+    CHECK_PTR(e, counts);
     HIPCHK(e, hipSetDevice(e->device));
     const int64_t n = (int64_t)e->G[component] * e->F * e->S;
     int rc = ensure_scratch(e, n * sizeof(float));
@@ -1165,7 +1173,9 @@ int sbe_set_counts(sbe_engine* e, int slot, int component, const float* counts) 
 }
 
 int sbe_get_counts(sbe_engine* e, int slot, int component, float* out) {
-    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component); CHECK_PTR(e, out);
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component);
+    if (e->G[component] == 0) return SBE_OK;
+    CHECK_PTR(e, out);
     HIPCHK(e, hipSetDevice(e->device));
     const int64_t n = (int64_t)e->G[component] * e->F * e->S;
     int rc = ensure_scratch(e, n * sizeof(float));
@@ -1178,7 +1188,9 @@ int sbe_get_counts(sbe_engine* e, int slot, int component, float* out) {
 
 // ---- concentration / probs ----------------------------------------------------------------------
 int sbe_set_concentration(sbe_engine* e, int component, const double* conc, int per_group) {
-    CHECK_ENGINE(e); CHECK_COMP(e, component); CHECK_PTR(e, conc);
+    CHECK_ENGINE(e); CHECK_COMP(e, component);
+    if (e->G[component] == 0) { e->conc_set[component] = 1; return SBE_OK; }
+    CHECK_PTR(e, conc);
     HIPCHK(e, hipSetDevice(e->device));
     const int64_t fs = (int64_t)e->F * e->S;
     double* dst = e->d_conc + (int64_t)e->goff[component] * fs;
@@ -1196,6 +1208,7 @@ int sbe_update_probs(sbe_engine* e, int slot, int component, double temperature,
                      const double* unif_counts) {
     CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component);
     Slot& s = e->slots[slot];
+    if (e->G[component] == 0) { s.probs_set[component] = 1; return SBE_OK; }       // component without groups: empty tables
     if (!e->conc_set[component]) return fail(e, SBE_ERR_STATE, "concentration of component %d not set", component);
     if (!s.counts_set[component]) return fail(e, SBE_ERR_STATE, "slot %d: counts of component %d not set", slot, component);
     if (prior_temperature > 0.0 && !unif_counts) return fail(e, SBE_ERR_ARG, "prior_temperature given without unif_counts (conditionals.py:114)");
@@ -1219,7 +1232,9 @@ int sbe_update_probs(sbe_engine* e, int slot, int component, double temperature,
 }
 
 int sbe_set_probs(sbe_engine* e, int slot, int component, const float* probs) {
-    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component); CHECK_PTR(e, probs);
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component);
+    if (e->G[component] == 0) { e->slots[slot].probs_set[component] = 1; return SBE_OK; }
+    CHECK_PTR(e, probs);
     HIPCHK(e, hipSetDevice(e->device));
     const int64_t n = (int64_t)e->G[component] * e->F * e->S;
     float* dst = e->d_probs + (int64_t)slot * e->table_elems() + (int64_t)e->goff[component] * e->F * e->S;
@@ -1232,7 +1247,9 @@ int sbe_set_probs(sbe_engine* e, int slot, int component, const float* probs) {
 }
 
 int sbe_get_probs(sbe_engine* e, int slot, int component, float* out) {
-    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component); CHECK_PTR(e, out);
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component);
+    if (e->G[component] == 0) return SBE_OK;
+    CHECK_PTR(e, out);
     if (!e->slots[slot].probs_set[component]) return fail(e, SBE_ERR_STATE, "slot %d: probs of component %d not set", slot, component);
     HIPCHK(e, hipSetDevice(e->device));
     const int64_t n = (int64_t)e->G[component] * e->F * e->S;
@@ -1349,7 +1366,9 @@ int sbe_mixture_loglik(sbe_engine* e, int slot, double* out) { return sbe_mixtur
 
 // ---- collapsed likelihood -------------------------------------------------------------------------
 int sbe_collapsed_loglik(sbe_engine* e, int slot, int component, double* per_group_out, float* per_feature_out) {
-    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component); CHECK_PTR(e, per_group_out);
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component);
+    if (e->G[component] == 0) return SBE_OK;       // no group: Likelihood.compute_lh_clusters sums an empty cache
+    CHECK_PTR(e, per_group_out);
     Slot& s = e->slots[slot];
     if (!s.counts_set[component]) return fail(e, SBE_ERR_STATE, "slot %d: counts of component %d not set", slot, component);
     if (!e->conc_set[component]) return fail(e, SBE_ERR_STATE, "concentration of component %d not set", component);
@@ -1487,11 +1506,15 @@ int sbe_effect_counts(sbe_engine* e, const uint8_t* groups, int n_groups, const 
     return d2h(e, out, d_out, (size_t)n_out * sizeof(float));
 }
 
-int sbe_normalize_weights(sbe_engine* e, const float* weights, int n_comp, const uint8_t* has_components, float* out) {
-    CHECK_ENGINE(e); CHECK_PTR(e, weights); CHECK_PTR(e, has_components); CHECK_PTR(e, out);
+int sbe_normalize_weights(sbe_engine* e, const float* weights, int n_comp, const uint8_t* has_components, int n_rows,
+                          float* out) {
+    CHECK_ENGINE(e); CHECK_PTR(e, weights);
     if (n_comp < 1 || n_comp > kMaxComponents) return fail(e, SBE_ERR_ARG, "n_comp=%d unsupported (1..%d)", n_comp, kMaxComponents);
+    if (n_rows < 0) return fail(e, SBE_ERR_ARG, "n_rows=%d", n_rows);
+    if (n_rows == 0) return SBE_OK;
+    CHECK_PTR(e, has_components); CHECK_PTR(e, out);
     HIPCHK(e, hipSetDevice(e->device));
-    const int N = e->N, F = e->F, C = n_comp;
+    const int N = n_rows, F = e->F, C = n_comp;     // the rows are whatever the caller hands over (has_components[available], operators.py:1086)
     // distinct rows in np.unique(axis=0) order (lexicographic, False < True)
     std::vector<uint32_t> bits(N);
     for (int n = 0; n < N; ++n) {

@@ -389,14 +389,15 @@ class Engine:
         return out
 
     def normalize_weights(self, weights, has_components):
-        """normalize_weights (likelihood.py:171-190) -> float32 [N, F, C]."""
+        """normalize_weights (likelihood.py:171-190) -> float32 [n_rows, F, C]; has_components may have any number
+        of rows (all objects, or has_components[available] as in operators.py:1086)."""
         w = _c(weights, np.float32)
         hc = np.asarray(has_components)
-        if w.ndim != 2 or w.shape[0] != self.n_features or hc.shape != (self.n_objects, w.shape[1]):
-            raise ValueError("weights must be [n_features, C] and has_components [n_objects, C]")
+        if w.ndim != 2 or w.shape[0] != self.n_features or hc.ndim != 2 or hc.shape[1] != w.shape[1]:
+            raise ValueError("weights must be [n_features, C] and has_components [n_rows, C]")
         hc = _c(hc.astype(bool, copy=False), np.uint8)
-        out = np.empty((self.n_objects, self.n_features, w.shape[1]), dtype=np.float32)
-        self._check(self._lib.sbe_normalize_weights(self._h, _ptr(w), w.shape[1], _ptr(hc), _ptr(out)))
+        out = np.empty((hc.shape[0], self.n_features, w.shape[1]), dtype=np.float32)
+        self._check(self._lib.sbe_normalize_weights(self._h, _ptr(w), w.shape[1], _ptr(hc), hc.shape[0], _ptr(out)))
         return out
 
     def cluster_marginals(self, slot, table, objects, prior_temperature=1.0):

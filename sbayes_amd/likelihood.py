@@ -124,13 +124,14 @@ def compute_component_likelihood_exact(features, probs, groups, changed_groups, 
 
 
 def normalize_weights(weights, has_components, features=None):
-    """float32 [n_objects, n_features, n_components]: weights masked by has_components and
-    renormalised over components.  `features` (optional) selects the engine explicitly."""
+    """float32 [n_rows, n_features, n_components]: weights masked by has_components and renormalised over
+    components; has_components may have any number of rows (the reference also calls it with
+    has_components[available], operators.py:1086).  `features` (optional) selects the engine explicitly."""
     has_components = np.asarray(has_components)
     if features is not None:
         eng = get_engine(features)
     else:
-        eng = registry.engine_for_shape(has_components.shape[0], np.shape(weights)[0])
+        eng = registry.engine_for_features(np.shape(weights)[0])
     return eng.normalize_weights(weights, has_components)
 
 

@@ -34,7 +34,7 @@ def get_engine(features, n_groups=None, n_slots=4, device=None) -> Engine:
         eng.close()
         del _ENGINES[key]
     if device is None:
-        device = int(os.environ.get("SBAYES_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        device = default_device()
     eng = Engine(features, list(n_groups) if n_groups is not None else [1], n_slots=n_slots, device=device)
     try:
         ref = weakref.ref(features)
@@ -44,32 +44,47 @@ def get_engine(features, n_groups=None, n_slots=4, device=None) -> Engine:
     return eng
 
 
-_KNOWN = {}      # (n_objects, n_features) -> (weakref to a feature block, n_groups) noted by Likelihood(...)
+_KNOWN = {}      # n_features -> (weakref to a feature block, n_groups) noted by Likelihood(...)
+
+
+def default_device() -> int:
+    """Device of this process: SBAYES_AMD_DEVICE, else LOCAL_RANK folded onto the visible devices (chains.device_for:
+    ranks may outnumber GPUs in rehearsals on a one-GPU box), else 0."""
+    if "SBAYES_AMD_DEVICE" in os.environ:
+        return int(os.environ["SBAYES_AMD_DEVICE"])
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_rank == 0:
+        return 0
+    from .chains import device_for
+    from .engine import device_count
+    return device_for(local_rank, device_count())
 
 
 def note_features(features, n_groups=None):
-    """Remember a feature block (weakly) so that shape-only calls can find / create its engine."""
+    """Remember a feature block (weakly) so that calls which do not carry it can find / create its engine."""
     features = np.asarray(features)
     try:
-        _KNOWN[(features.shape[0], features.shape[1])] = (weakref.ref(features), list(n_groups) if n_groups else None)
+        _KNOWN[features.shape[1]] = (weakref.ref(features), list(n_groups) if n_groups else None)
     except TypeError:
         pass
 
 
-def engine_for_shape(n_objects: int, n_features: int) -> Engine:
-    """Engine for calls that do not carry the feature block (normalize_weights(weights, has_components),
-    likelihood.py:171-190): an existing engine of that shape, else the engine of a block noted by
-    Likelihood(...), else a featureless stand-in of that shape (the call only needs N and F)."""
+def engine_for_features(n_features: int) -> Engine:
+    """Engine for calls that carry neither the feature block nor a fixed row count
+    (normalize_weights(weights, has_components), likelihood.py:171-190: has_components has N rows in update_weights
+    but n_available rows in AlterCluster.compute_feature_weights_with_and_without, operators.py:1086).  The call needs
+    nothing of the engine but F, its stream and its scratch memory: any live engine with that many features serves,
+    else the engine of a block noted by Likelihood(...), else ONE featureless stand-in per F (never one per row
+    count: a run would otherwise accumulate an engine, with its pinned arenas, for every value n_available takes)."""
     for eng, ref in _ENGINES.values():
-        if eng.n_objects == n_objects and eng.n_features == n_features and (ref is None or ref() is not None):
+        if eng.n_features == n_features and (ref is None or ref() is not None):
             return eng
-    known = _KNOWN.get((n_objects, n_features))
+    known = _KNOWN.get(n_features)
     if known is not None and known[0]() is not None:
         return get_engine(known[0](), known[1])
-    key = ("shape", n_objects, n_features)
+    key = ("features", n_features)
     if key not in _ENGINES:
-        _ENGINES[key] = (Engine(np.zeros((n_objects, n_features, 1), dtype=bool), [1], n_slots=1,
-                                device=int(os.environ.get("SBAYES_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))), None)
+        _ENGINES[key] = (Engine(np.zeros((1, n_features, 1), dtype=bool), [1], n_slots=1, device=default_device()), None)
     return _ENGINES[key][0]
 
 

@@ -12,6 +12,8 @@ mixture log-likelihood (8(d)) are all recomputed on the device from resident dat
 The accept/reject decision, proposal logic and RNG stay with the (reference) sampler."""
 from __future__ import annotations
 
+from contextlib import contextmanager
+
 import numpy as np
 
 from .conditionals import _engine
@@ -44,15 +46,35 @@ class _SlotView:
 class ResidentChain:
     """Two slots per chain: `cur` (accepted state) and `cand` (proposal under evaluation)."""
 
-    def __init__(self, model, sample, slots=(0, 1)):
+    def __init__(self, model, sample, slots=None):
         self.model = model
         self.eng = _engine(model)
-        if max(slots) >= self.eng.n_slots:
-            raise ValueError(f"engine has {self.eng.n_slots} slots, need slots {slots}")
+        if slots is None:
+            # the engine is shared through the registry with the drop-in operator forms, which bind samples into
+            # slot 0 / slots (0, 1) by default: the chain's resident state lives in the TOP two slots
+            if self.eng.n_slots < 4:
+                raise ValueError(f"engine has {self.eng.n_slots} slots; a ResidentChain next to the drop-in forms needs 4")
+            slots = (self.eng.n_slots - 2, self.eng.n_slots - 1)
+        if max(slots) >= self.eng.n_slots or min(slots) < 0 or slots[0] == slots[1]:
+            raise ValueError(f"engine has {self.eng.n_slots} slots, need two distinct slots, got {slots}")
         self.cur, self.cand = slots
         self.names = list(sample.component_names)
+        with self._deferred_checks():
+            self._upload(model, sample)
+
+    @contextmanager
+    def _deferred_checks(self):
+        """Inside: state-setting calls never stall the stream (their data checks are queued).  On exit the option is
+        restored, which synchronises and raises a queued check HERE -- in the chain call that caused it, not in some
+        later call of another user of the shared engine."""
+        self.eng.set_option(deferred_checks=True)
+        try:
+            yield
+        finally:
+            self.eng.set_option(deferred_checks=False)
+
+    def _upload(self, model, sample):
         eng = self.eng
-        eng.set_option(deferred_checks=True)      # setters never stall the stream; checks surface at the next fetch
         conc = [np.asarray(model.prior.prior_cluster_effect.concentration_array)] + [
             np.asarray(model.prior.prior_confounding_effects[k].concentration_array(sample)) for k in self.names[1:]]
         groups = [sample.clusters.value] + [c.group_assignment for c in sample.confounders.values()]
@@ -78,6 +100,10 @@ class ResidentChain:
         source_rows: (object indices, bool rows [n, F, C]) of the objects whose source changed;
         weights: float32 [F, C] or None.  Counts are delta-updated on the device over the union of
         the objects whose cluster membership or source changed."""
+        with self._deferred_checks():
+            return self._propose(clusters, source_rows, weights)
+
+    def _propose(self, clusters, source_rows, weights):
         eng = self.eng
         eng.copy_slot(self.cand, self.cur)
         self._probs_dirty[self.cand] = set(self._probs_dirty[self.cur])
@@ -116,6 +142,10 @@ class ResidentChain:
         z: uniforms [n, F] (default: np.random.random([n, F, 1]) drawn exactly where the reference draws them);
         device_rng=True: the engine's Philox stream instead.  Returns (candidate view, log_q, log_q_back);
         follow with accept() or reject()."""
+        with self._deferred_checks():
+            return self._propose_gibbs_source(objects, temperature, prior_temperature, sample_from_prior, z, device_rng)
+
+    def _propose_gibbs_source(self, objects, temperature, prior_temperature, sample_from_prior, z, device_rng):
         eng = self.eng
         objects = np.asarray(objects)
         if objects.dtype == np.bool_:

@@ -82,6 +82,7 @@ class FakeEngine:
 
     def set_source(self, slot, source):
         self._bound.pop(slot, None)
+        self.calls.append(("set_source",))
         self._slot(slot)["source"] = np.asarray(source, dtype=bool).copy()
 
     def observation_lh_exact(self, slot):

@@ -378,15 +378,32 @@ def test_bind_cache_sends_only_what_changed_and_never_goes_stale():
         ll2 = mixture_log_likelihood(model, sample2)
         assert abs(ll2 - want(groups2, source2, weights2)) <= 1e-10 * abs(ll2)
         assert mixture_log_likelihood(model, sample) == ll0                          # and back
-        # a writable array modified in place is compared by content, a frozen one by identity
-        from sbayes_amd.conditionals import _remember, _same
+        # in-place edits through the parameter API between two binds (unshared parameters edit the SAME ndarray and bump
+        # the version: sbayes/sampling/state.py:43-61, 340-350): the cache is keyed on (array, version), never on identity
+        fresh_model, fresh = sbm.build(wl.features, wl.states_per_feature, wl.component_names, wl.groups, wl.concentration,
+                                       wl.weights, wl.source)
+        recalculate_feature_counts(fresh_model.data.features.values, fresh)
+        assert mixture_log_likelihood(model, fresh) == ll0
+        w_arr, c_arr = fresh.weights.value, fresh.feature_counts["clusters"].value
+        with fresh.weights.edit() as w:
+            w[:] = weights2
+        diff = np.zeros_like(c_arr)
+        diff[0, 0, int(np.flatnonzero(wl.states_per_feature[0])[0])] = 3.0
+        fresh.feature_counts["clusters"].add_changes(diff)
+        assert fresh.weights.value is w_arr and fresh.feature_counts["clusters"].value is c_arr      # same ndarrays
+        counts_now = [fresh.feature_counts[k].value for k in fresh.component_names]
+        want_now = orc.mixture_loglik(wl.features, na, wl.groups, counts_now, wl.concentration, weights2)
+        got_now = mixture_log_likelihood(model, fresh)
+        assert abs(got_now - want_now) <= 1e-10 * abs(want_now) and got_now != ll0
+        # unversioned arrays (confounder group matrices, concentration tables) are compared by content
+        from sbayes_amd.conditionals import _remember, _same, _token
         w = np.array(wl.weights)
-        rec = _remember(w)
-        assert _same(w, rec)
+        rec = _remember(_token(w))
+        assert _same(_token(w), rec) and _same(_token(w.copy()), rec)
         w[0, 0] += 0.25
-        assert not _same(w, rec)
+        assert not _same(_token(w), rec)
         w.setflags(write=False)
-        rec = _remember(w)
-        assert rec[1] is w and _same(w, rec) and _same(w.copy(), rec) and not _same(np.zeros_like(w), rec)
+        rec = _remember(_token(w))
+        assert _same(_token(w), rec) and not _same(_token(np.zeros_like(w)), rec)
     finally:
         release_all()

@@ -29,9 +29,9 @@ def fake(monkeypatch):
     import sbayes_amd.counts as counts_mod
     monkeypatch.setattr(counts_mod, "get_engine", get_engine, raising=True)
     monkeypatch.setattr(registry, "_ENGINES", {})
-    monkeypatch.setattr(registry, "engine_for_shape",
-                        lambda n, f: next((e for e in engines.values() if e.n_objects == n and e.n_features == f),
-                                          None) or FakeEngine(np.zeros((n, f, 1), dtype=bool)))
+    monkeypatch.setattr(registry, "engine_for_features",
+                        lambda f: next((e for e in engines.values() if e.n_features == f), None)
+                        or FakeEngine(np.zeros((1, f, 1), dtype=bool)))
     return engines
 
 
@@ -105,6 +105,74 @@ def test_uncached_equals_cached_and_cache_hit_does_no_device_work(fake):
     eng.calls.clear()
     assert model.likelihood(sample, caching=True) == v1 and not eng.calls
     assert model.likelihood(sample, caching=False) == pytest.approx(fx.meta["collapsed_ll"], rel=1e-12)
+
+
+def test_bind_cache_sees_in_place_edits(fake):
+    """unshared parameters are edited IN PLACE (same ndarray, version bumped: sbayes/sampling/state.py:43-61,
+    340-350); a bind cache keyed on array identity would keep the slot's old data.  Bind, edit weights / counts /
+    clusters / source in place, bind again: every edit reaches the engine, and an untouched sample re-sends nothing."""
+    fx = load_npz("cfg1")
+    model, sample = build(fx)
+    feats = model.data.features.values
+    recalculate_feature_counts(feats, sample)
+    eng = conditionals._engine(model)
+    conditionals._bind_slot(eng, model, sample, 0, with_source=True)
+    eng.calls.clear()
+    conditionals._bind_slot(eng, model, sample, 0, with_source=True)
+    assert not [c for c in eng.calls if c[0].startswith("set_")]                      # nothing re-sent
+    arrays = (sample.weights.value, sample.feature_counts["clusters"].value, sample.clusters.value, sample.source.value)
+    with sample.weights.edit() as w:
+        w[0] = w[0][::-1].copy()
+    diff = np.zeros_like(sample.feature_counts["clusters"].value)
+    diff[1, 2, 0] = 1.0
+    sample.feature_counts["clusters"].add_changes(diff)
+    free = int(np.flatnonzero(~sample.clusters.value.any(axis=0))[0])
+    sample.clusters.add_object(1, free)
+    with sample.source.edit() as src:
+        src[free, 0, :] = False
+    assert all(a is b for a, b in zip(arrays, (sample.weights.value, sample.feature_counts["clusters"].value,
+                                               sample.clusters.value, sample.source.value)))    # edited in place
+    eng.calls.clear()
+    stale = conditionals._bind_slot(eng, model, sample, 0, with_source=True)
+    kinds = [c[0] for c in eng.calls]
+    assert kinds.count("set_weights") == 1 and kinds.count("set_source") == 1
+    assert ("set_groups", 0) in [c[:2] for c in eng.calls] and ("set_counts", 0) in [c[:2] for c in eng.calls]
+    assert ("set_counts", 1) not in [c[:2] for c in eng.calls] and 0 in stale
+    st = eng._slot(0)
+    assert np.array_equal(st["weights"], sample.weights.value) and np.array_equal(st["source"], sample.source.value)
+    assert np.array_equal(st["counts"][0], sample.feature_counts["clusters"].value)
+    assert np.array_equal(st["groups"][0], sample.clusters.value)
+    # a copy shares the arrays and the versions: nothing is re-sent for it either
+    eng.calls.clear()
+    conditionals._bind_slot(eng, model, sample.copy(), 0, with_source=True)
+    assert not [c for c in eng.calls if c[0].startswith("set_")]
+
+
+def test_normalize_weights_never_creates_engines_per_row_count(monkeypatch):
+    """normalize_weights is also called with has_components[available] (operators.py:1086), whose row count
+    changes from step to step; the engine is looked up by F only."""
+    made = []
+
+    class Stub:
+        def __init__(self, features, n_groups, n_slots=1, device=0):
+            self.n_objects, self.n_features = features.shape[:2]
+            made.append(self)
+
+        def normalize_weights(self, weights, has_components):
+            return np.zeros((len(has_components),) + np.shape(weights), dtype=np.float32)
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(registry, "Engine", Stub)
+    monkeypatch.setattr(registry, "_ENGINES", {})
+    monkeypatch.setattr(registry, "_KNOWN", {})
+    monkeypatch.setattr(registry, "default_device", lambda: 0)
+    w = np.full((7, 2), 0.5, dtype=np.float32)
+    for n in (3, 50, 11, 3, 49):
+        out = likelihood.normalize_weights(w, np.ones((n, 2), dtype=bool))
+        assert out.shape == (n, 7, 2)
+    assert len(made) == 1 and made[0].n_features == 7
 
 
 def test_likelihood_pickles_without_device_state(fake):

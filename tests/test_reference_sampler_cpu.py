@@ -50,9 +50,9 @@ def run_chain(config_src: Path, tag: str, n_steps: int, seed: int, patched: bool
         for mod in (registry, likelihood, conditionals, counts):
             monkeypatch.setattr(mod, "get_engine", get_engine, raising=True)
         monkeypatch.setattr(registry, "_ENGINES", {})
-        monkeypatch.setattr(registry, "engine_for_shape",
-                            lambda n, f: next((e for e in engines.values() if e.n_objects == n and e.n_features == f),
-                                              None) or FakeEngine(np.zeros((n, f, 1), dtype=bool)))
+        monkeypatch.setattr(registry, "engine_for_features",
+                            lambda f: next((e for e in engines.values() if e.n_features == f), None)
+                            or FakeEngine(np.zeros((1, f, 1), dtype=bool)))
         patch.install(operators=operators)
     try:
         np.random.seed(seed)
