@@ -1397,7 +1397,9 @@ int sbe_collapsed_loglik(sbe_engine* e, int slot, int component, double* per_gro
 // =============================================================================================
 int sbe_normalize_tables(sbe_engine* e, const float* counts, int n_groups, const double* conc, int conc_per_group,
                          double temperature, double prior_temperature, const double* unif_counts, float* out) {
-    CHECK_ENGINE(e); CHECK_PTR(e, counts); CHECK_PTR(e, conc); CHECK_PTR(e, out);
+    CHECK_ENGINE(e);
+    if (n_groups == 0) return SBE_OK;              // empty table set (a component without groups)
+    CHECK_PTR(e, counts); CHECK_PTR(e, conc); CHECK_PTR(e, out);
     if (n_groups < 1) return fail(e, SBE_ERR_ARG, "n_groups=%d", n_groups);
     if (prior_temperature > 0.0 && !unif_counts) return fail(e, SBE_ERR_ARG, "prior_temperature given without unif_counts (conditionals.py:114)");
     HIPCHK(e, hipSetDevice(e->device));
@@ -1434,7 +1436,9 @@ int sbe_normalize_tables(sbe_engine* e, const float* counts, int n_groups, const
 
 int sbe_dirichlet_logpdf(sbe_engine* e, const float* counts, int n_groups, const double* conc, int conc_per_group,
                          float* per_feature_out, double* per_group_out) {
-    CHECK_ENGINE(e); CHECK_PTR(e, counts); CHECK_PTR(e, conc);
+    CHECK_ENGINE(e);
+    if (n_groups == 0) return SBE_OK;
+    CHECK_PTR(e, counts); CHECK_PTR(e, conc);
     if (!per_feature_out && !per_group_out) return fail(e, SBE_ERR_ARG, "no output requested");
     if (n_groups < 1) return fail(e, SBE_ERR_ARG, "n_groups=%d", n_groups);
     HIPCHK(e, hipSetDevice(e->device));
@@ -1464,7 +1468,9 @@ int sbe_dirichlet_logpdf(sbe_engine* e, const float* counts, int n_groups, const
 
 int sbe_effect_counts(sbe_engine* e, const uint8_t* groups, int n_groups, const uint8_t* source_is_component,
                       const int32_t* objects, int n_subset, float* out) {
-    CHECK_ENGINE(e); CHECK_PTR(e, groups); CHECK_PTR(e, source_is_component); CHECK_PTR(e, out);
+    CHECK_ENGINE(e);
+    if (n_groups == 0) return SBE_OK;              // compute_effect_counts of an empty group matrix: empty counts
+    CHECK_PTR(e, groups); CHECK_PTR(e, source_is_component); CHECK_PTR(e, out);
     if (n_groups < 1) return fail(e, SBE_ERR_ARG, "n_groups=%d", n_groups);
     if (n_subset < -1 || (n_subset > 0 && !objects)) return fail(e, SBE_ERR_ARG, "bad object subset");
     for (int i = 0; i < n_subset; ++i)

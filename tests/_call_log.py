@@ -1,0 +1,185 @@
+"""Engine-level call logs of the REAL reference sampler -- TEST INFRASTRUCTURE.
+
+Recording (build container only, tests/golden/make_golden.py:call_log_fixtures): the reference's sampler runs on the
+drop-in host layer under patch.install(operators=True) with the device replaced by `RecordingEngine`, an oracle-backed
+double (tests/_fake_engine.py) that writes down every Engine-level call the host layer makes: method, arguments
+(arrays stored once, content-addressed) and the expected result (small results in full, large ones as SHA-1).  What
+is recorded is DATA: call names, argument arrays, result arrays / digests -- no reference code.
+
+Replay (tests/test_gpu_call_log.py on the GPU box; tests/test_call_log_cpu.py against the double): the same call
+sequence against an engine, every result checked.  The sequence carries the reference's true aliasing and
+caching pattern through conditionals._bind_slot (which slot state is re-sent when, which tables are left stale), so
+the device's slot state machine is exercised exactly as the unchanged sampler would drive it.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+
+import numpy as np
+
+from tests._fake_engine import FakeEngine
+
+SENTINEL = -7.25                      # fill of component_lh's `out` when its expected result is computed
+FULL_RESULT_BYTES = 1 << 15           # results up to this size are stored in full, larger ones as a digest
+
+
+def _digest(a: np.ndarray) -> str:
+    a = np.ascontiguousarray(a)
+    return hashlib.sha1(str((a.dtype.str, a.shape)).encode() + a.tobytes()).hexdigest()
+
+
+class _Store:
+    def __init__(self):
+        self.arrays, self.index = [], {}
+
+    def put(self, a) -> int:
+        a = np.ascontiguousarray(a)
+        key = _digest(a)
+        if key not in self.index:
+            self.index[key] = len(self.arrays)
+            self.arrays.append(a.copy())
+        return self.index[key]
+
+
+# how each result is compared on replay: exact = bit for bit; otherwise (rtol, atol)
+COMPARE = {
+    "component_lh": "exact", "normalize_tables": "exact", "effect_counts": "exact", "normalize_weights": "exact",
+    "observation_lh_exact": "exact", "na_values": "exact",
+    "dirichlet_logpdf": (2e-6, 1e-6),        # float32 per feature in the reference
+    "cluster_marginals": (1e-9, 1e-9),       # log-space sums on the device vs log of the linear-space product
+    "source_posterior": "exact_at_t1",       # bit-exact at temperature 1, float32 powf tolerance when tempered
+    "subset_lh": "exact_at_t1",
+}
+SETTERS = {"set_groups", "set_concentration", "set_counts", "set_source", "set_weights", "update_probs"}
+
+
+class RecordingEngine(FakeEngine):
+    """FakeEngine that logs every call (see module docstring)."""
+
+    def __init__(self, features, n_groups=None, n_slots=4, device=0):
+        super().__init__(features, n_groups, n_slots, device)
+        self.store = _Store()
+        self.log = []
+
+    # -- helpers --------------------------------------------------------------------------------------------
+    def _arg(self, v):
+        if isinstance(v, np.ndarray) or isinstance(v, (list, tuple)) and len(v) and isinstance(v[0], np.ndarray):
+            if isinstance(v, (list, tuple)):
+                return {"list": [self.store.put(np.asarray(x)) for x in v]}
+            return {"arr": self.store.put(v)}
+        if v is None or isinstance(v, (bool, int, float, str)):
+            return {"val": v}
+        if isinstance(v, (np.integer, np.floating, np.bool_)):
+            return {"val": v.item()}
+        return {"arr": self.store.put(np.asarray(v))}
+
+    def _result(self, name, r):
+        if r is None:
+            return None
+        if isinstance(r, tuple):
+            return {"tuple": [self._result(name, x) for x in r]}
+        r = np.asarray(r)
+        if r.nbytes <= FULL_RESULT_BYTES or COMPARE[name] not in ("exact",):
+            return {"arr": self.store.put(r)}
+        return {"sha": _digest(r), "shape": list(r.shape), "dtype": r.dtype.str}
+
+    def _rec(self, name, args, kwargs, result):
+        self.log.append({"m": name, "a": [self._arg(a) for a in args], "k": {k: self._arg(v) for k, v in kwargs.items()},
+                         "r": self._result(name, result)})
+
+    # -- logged surface (everything the host layer calls on an engine) -----------------------------------------
+    def component_lh(self, probs, groups, changed_groups, out, na_value=0.0):
+        res = super().component_lh(probs, groups, changed_groups, out, na_value)
+        probe = np.full(out.shape, SENTINEL)              # expected result on a sentinel-filled buffer: rows the call
+        FakeEngine.component_lh(self, probs, groups, changed_groups, probe, na_value)     # must not touch stay SENTINEL
+        self.calls.pop()
+        self._rec("component_lh", (np.asarray(probs), np.asarray(groups, dtype=bool),
+                                   np.asarray(changed_groups, dtype=np.int64)), {"na_value": float(na_value)}, probe)
+        return res
+
+
+def _wrap(name):
+    def method(self, *args, **kwargs):
+        res = getattr(FakeEngine, name)(self, *args, **kwargs)
+        self._rec(name, tuple(np.asarray(a) if isinstance(a, np.ndarray) else a for a in args), kwargs,
+                  None if name in SETTERS else res)
+        return res
+    method.__name__ = name
+    return method
+
+
+for _name in ("normalize_tables", "dirichlet_logpdf", "effect_counts", "set_groups", "set_concentration", "set_counts",
+              "set_source", "set_weights", "update_probs", "cluster_marginals", "source_posterior", "subset_lh",
+              "normalize_weights", "observation_lh_exact"):
+    setattr(RecordingEngine, _name, _wrap(_name))
+
+
+def save(path, eng: RecordingEngine, meta: dict):
+    arrays = {f"arr_{i}": a for i, a in enumerate(eng.store.arrays)}
+    np.savez_compressed(path, calls=np.array(json.dumps(eng.log)), meta=np.array(json.dumps(meta)),
+                        n_arrays=np.int64(len(eng.store.arrays)), **arrays)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# replay
+# ---------------------------------------------------------------------------------------------------------------
+def _load_arg(z, spec):
+    if "arr" in spec:
+        return z[f"arr_{spec['arr']}"]
+    if "list" in spec:
+        return [z[f"arr_{i}"] for i in spec["list"]]
+    return spec["val"]
+
+
+def _check(name, spec, got, z, where, temperature):
+    if spec is None:
+        return
+    if "tuple" in spec:
+        assert isinstance(got, tuple) and len(got) == len(spec["tuple"]), where
+        for s, g in zip(spec["tuple"], got):
+            _check(name, s, g, z, where, temperature)
+        return
+    got = np.asarray(got)
+    mode = COMPARE[name]
+    if mode == "exact_at_t1":
+        mode = "exact" if temperature == 1.0 else (2e-6, 1e-7)
+    if "sha" in spec:
+        assert list(got.shape) == spec["shape"] and got.dtype.str == spec["dtype"], where
+        assert _digest(got) == spec["sha"], f"{where}: result digest differs"
+        return
+    want = z[f"arr_{spec['arr']}"]
+    assert got.shape == want.shape, (where, got.shape, want.shape)
+    if mode == "exact":
+        assert got.dtype == want.dtype and np.array_equal(got, want), f"{where}: result differs"
+    else:
+        np.testing.assert_allclose(got, want, rtol=mode[0], atol=mode[1], err_msg=where)
+
+
+def replay(path, make_engine):
+    """Run the recorded call sequence against `make_engine(n_groups)`; returns per-method call counts."""
+    z = np.load(path, allow_pickle=False)
+    calls = json.loads(str(z["calls"]))
+    meta = json.loads(str(z["meta"]))
+    eng = make_engine(meta["n_groups"])
+    counts = {}
+    try:
+        for i, c in enumerate(calls):
+            name = c["m"]
+            args = [_load_arg(z, a) for a in c["a"]]
+            kwargs = {k: _load_arg(z, v) for k, v in c["k"].items()}
+            where = f"call {i} ({name})"
+            counts[name] = counts.get(name, 0) + 1
+            if name == "component_lh":
+                out = np.full((eng.n_objects, eng.n_features), SENTINEL)
+                eng.component_lh(args[0], args[1], args[2], out, kwargs.get("na_value", 0.0))
+                got = out
+            else:
+                got = getattr(eng, name)(*args, **kwargs)
+            temperature = kwargs.get("temperature", 1.0)
+            if name in ("source_posterior", "subset_lh") and len(args) >= (3 if name == "source_posterior" else 4):
+                temperature = args[2] if name == "source_posterior" else args[3]
+            _check(name, c["r"], got, z, where, float(temperature if temperature is not None else 1.0))
+    finally:
+        eng.close()
+    return counts, meta

@@ -15,9 +15,21 @@ Fixtures
   stress.json         5000x500x20 synthetic: same
   south_america.npz   experiments/south_america real data through the reference loader:
                       tensors, real Dirichlet prior tables, initial sample, all outputs
-  south_america_trace.npz   400 MCMC steps of the reference sampler: per-step state + scalars
+  south_america_trace.npz   400 MCMC steps of the reference sampler: initial state, per-step state DELTAS + scalars
   test_files.npz      test/test_files (5 objects x 2 features): tensors + outputs
   test_files_trace.npz  300 MCMC steps on it
+  cfg1_trace.npz      300 MCMC steps of the reference sampler on the cfg1 synthetic (50 x 30 x 5, K = 2): the synthetic
+                      features are written as CSV + config.yaml and go through the reference's own loader, priors,
+                      initialiser and operators ("cfg1 >= 200 steps")
+  headline_trace.npz  300 MCMC steps at the headline shape (1000 x 200 x 10, K = 5): several feature tiles and object
+                      chunks for the trace-replay tests
+  *_calls.npz         the engine-level call log of the REAL sampler running on the drop-in layer under
+                      patch.install(operators=True) (argument arrays, expected results / digests): replayed against
+                      the real Engine on the GPU box (tests/test_gpu_call_log.py)
+
+Every RNG the reference draws from is seeded before a recording -- np.random, random, and the reference's
+module-level generators sbayes.util.RNG / sbayes.sampling.initializers.RNG (set in place) -- so re-running this
+script regenerates every fixture bit for bit (tests/test_golden_reproducible_cpu.py checks test_files).
   known_answers.json  hand-derivable cases from the reference's commented-out test
   gibbs_source.npz    GibbsSampleSource._propose on south_america with pinned subsets and uniforms
                       (python tests/golden/make_golden.py gibbs_source regenerates only this one)
@@ -60,7 +72,8 @@ from sbayes.util import dirichlet_categorical_logpdf, normalize  # noqa: E402
 
 from sbayes_amd.synthetic import make_workload  # noqa: E402
 
-WORK = Path("/tmp/sbayes_amd_golden_work")
+WORK = Path(os.environ.get("SBAYES_AMD_GOLDEN_WORK", "/tmp/sbayes_amd_golden_work"))
+OUT = Path(os.environ.get("SBAYES_AMD_GOLDEN_OUT", str(HERE)))     # where the fixtures are written (tests: a scratch dir)
 
 
 def crc(a) -> int:
@@ -69,6 +82,18 @@ def crc(a) -> int:
 
 def sha(a) -> str:
     return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def seed_reference(seed: int):
+    """Seed everything the reference draws from: np.random (sample_categorical, preprocessing.py:248), random, and
+    its two module-level generators (sbayes/util.py:36 -- imported by name into operators.py:19 and mcmc_setup.py:35,
+    so the state is set IN PLACE -- and sbayes/sampling/initializers.py:19)."""
+    import sbayes.sampling.initializers as ref_init
+    import sbayes.util as ref_util
+    np.random.seed(seed)
+    random.seed(seed)
+    ref_util.RNG.bit_generator.state = np.random.default_rng(seed).bit_generator.state
+    ref_init.RNG.bit_generator.state = np.random.default_rng(seed + 1).bit_generator.state
 
 
 # ----------------------------------------------------------------------------------------
@@ -253,7 +278,7 @@ def synthetic_fixture(name: str, full: bool):
         extra.update(delta_counts_case(model, sample, rng))
         extra.update(effect_mean_case(model, sample))
         np.savez_compressed(
-            HERE / f"{name}.npz", features=wl.features, states_per_feature=wl.states_per_feature,
+            OUT / f"{name}.npz", features=wl.features, states_per_feature=wl.states_per_feature,
             weights=wl.weights, source=wl.source, meta=json.dumps(meta), **arrs, **extra)
     else:
         # spot values of the big arrays so a mismatch can be localised without the CRC
@@ -261,7 +286,7 @@ def synthetic_fixture(name: str, full: bool):
         idx = np.random.default_rng(11).integers(0, lh.size, size=64)
         meta["lh_spot_idx"] = idx.tolist()
         meta["lh_spot_val"] = lh.reshape(-1)[idx].tolist()
-        with open(HERE / f"{name}.json", "w") as fh:
+        with open(OUT / f"{name}.json", "w") as fh:
             json.dump(meta, fh, indent=1)
     print(f"[golden] {name}: mixture_ll={scal['mixture_ll']!r} collapsed_ll={scal['collapsed_ll']!r}")
 
@@ -359,8 +384,7 @@ def real_fixture(tag: str, config_path: Path, n_trace_steps: int, seed: int):
     from sbayes.sampling.initializers import SbayesInitializer
     from sbayes.sampling.mcmc_chain import MCMCChain
 
-    np.random.seed(seed)
-    random.seed(seed)
+    seed_reference(seed)
     cwd = os.getcwd()
     os.chdir(config_path.parent)
     try:
@@ -389,52 +413,164 @@ def real_fixture(tag: str, config_path: Path, n_trace_steps: int, seed: int):
                     component_names=sample.component_names,
                     groups=[int(sample.n_groups(k)) for k in sample.component_names], **scal, **dig)
         np.savez_compressed(
-            HERE / f"{tag}.npz", features=data.features.values,
+            OUT / f"{tag}.npz", features=data.features.values,
             states_per_feature=data.features.states,
             weights=sample.weights.value, source=sample.source.value,
             meta=json.dumps(meta), **arrs, **extra)
         print(f"[golden] {tag}: mixture_ll={scal['mixture_ll']!r} collapsed_ll={scal['collapsed_ll']!r}")
 
-        # ---- recorded MCMC trace (SURVEY.md 8(c) "trace-replay") -------------------------
-        chain = MCMCChain(model=model, data=data, operators=mcmc_cfg.operators, sample_loggers=[])
-        chain._ll = chain.likelihood(sample)
-        chain._prior = chain.prior(sample)
-        na = data.features.na_values
-        rec = dict(clusters=[], weights=[], source=[], last_lh=[], mixture_ll=[], lh_sha=[],
-                   collapsed_uncached=[], group_lh=[], operator=[])
-        for i_step in range(1, n_trace_steps + 1):
-            sample = chain.step(sample)
-            sample.i_step = i_step
-            lh = likelihood_per_component(model, sample, caching=True)
-            w = update_weights(sample, caching=True)
-            with np.errstate(divide="ignore"):
-                mix = float(np.log(np.sum(w * lh, axis=-1))[~na].sum())
-            rec["clusters"].append(np.packbits(sample.clusters.value))
-            rec["weights"].append(sample.weights.value.copy())
-            rec["source"].append(np.packbits(sample.source.value))
-            rec["last_lh"].append(float(chain._ll))
-            rec["mixture_ll"].append(mix)
-            rec["lh_sha"].append(sha(lh))
-            rec["group_lh"].append(np.concatenate(
-                [sample.cache.group_likelihoods[k].value for k in sample.component_names]))
-            rec["operator"].append(chain.previous_operator.operator_name)
-        # a few uncached cross-checks of the reference against itself
-        final = sample.copy()
-        rec_final_uncached = float(model.likelihood(final, caching=False))
-        assert np.allclose(rec_final_uncached, rec["last_lh"][-1])
-        np.savez_compressed(
-            HERE / f"{tag}_trace.npz",
-            clusters=np.stack(rec["clusters"]), weights=np.stack(rec["weights"]),
-            source=np.stack(rec["source"]), last_lh=np.array(rec["last_lh"]),
-            mixture_ll=np.array(rec["mixture_ll"]), lh_sha=np.array(rec["lh_sha"]),
-            group_lh=np.stack(rec["group_lh"]), operator=np.array(rec["operator"]),
-            clusters_shape=np.array(sample.clusters.value.shape),
-            source_shape=np.array(sample.source.value.shape),
-            final_collapsed_uncached=rec_final_uncached,
-        )
-        n_acc = len({s.tobytes() for s in rec["clusters"]})
-        print(f"[golden] {tag}_trace: {n_trace_steps} steps, {n_acc} distinct cluster states, "
-              f"ll {rec['last_lh'][0]:.3f} -> {rec['last_lh'][-1]:.3f}")
+        record_trace(tag, model, data, mcmc_cfg, sample, n_trace_steps)
+    finally:
+        os.chdir(cwd)
+
+
+def record_trace(tag, model, data, mcmc_cfg, sample, n_steps, extra=None):
+    """n_steps of the reference's MCMCChain.step (sbayes/sampling/mcmc_chain.py:186-238) from `sample`; per step the
+    state DELTA (cluster matrix, changed weights, changed source rows) and what the reference computed on it.
+    Format 2 (tests/_fixtures.py:load_trace): init_* = the state before step 0; clusters[i] packed bits;
+    weights_step / weights_val = the steps at which the weights changed and their new values; src_ptr / src_obj /
+    src_rows = CSR list of the objects whose source rows changed in step i and their new rows (packed bits)."""
+    from sbayes.sampling.mcmc_chain import MCMCChain
+    chain = MCMCChain(model=model, data=data, operators=mcmc_cfg.operators, sample_loggers=[])
+    chain._ll = chain.likelihood(sample)
+    chain._prior = chain.prior(sample)
+    na = data.features.na_values
+    names = sample.component_names
+    init = dict(init_clusters=np.packbits(sample.clusters.value), init_source=np.packbits(sample.source.value),
+                init_weights=sample.weights.value.copy())
+    for i, k in enumerate(names):
+        init[f"init_counts_{i}"] = sample.feature_counts[k].value.copy()
+    lh0 = likelihood_per_component(model, sample, caching=True)
+    w0 = update_weights(sample, caching=True)
+    with np.errstate(divide="ignore"):
+        init["init_mixture_ll"] = np.float64(np.log(np.sum(w0 * lh0, axis=-1))[~na].sum())
+    init["init_collapsed_ll"] = np.float64(chain._ll)
+    prev_source, prev_weights = sample.source.value.copy(), sample.weights.value.copy()
+    rec = dict(clusters=[], last_lh=[], mixture_ll=[], lh_sha=[], group_lh=[], operator=[])
+    w_step, w_val, src_ptr, src_obj, src_rows = [], [], [0], [], []
+    for i_step in range(1, n_steps + 1):
+        sample = chain.step(sample)
+        sample.i_step = i_step
+        lh = likelihood_per_component(model, sample, caching=True)
+        w = update_weights(sample, caching=True)
+        with np.errstate(divide="ignore"):
+            mix = float(np.log(np.sum(w * lh, axis=-1))[~na].sum())
+        rec["clusters"].append(np.packbits(sample.clusters.value))
+        if not np.array_equal(sample.weights.value, prev_weights):
+            prev_weights = sample.weights.value.copy()
+            w_step.append(i_step - 1)
+            w_val.append(prev_weights)
+        changed = np.flatnonzero((sample.source.value != prev_source).any(axis=(1, 2)))
+        src_obj.extend(int(o) for o in changed)
+        src_rows.extend(np.packbits(sample.source.value[o]) for o in changed)
+        src_ptr.append(len(src_obj))
+        prev_source = sample.source.value.copy()
+        rec["last_lh"].append(float(chain._ll))
+        rec["mixture_ll"].append(mix)
+        rec["lh_sha"].append(sha(lh))
+        rec["group_lh"].append(np.concatenate([sample.cache.group_likelihoods[k].value for k in names]))
+        rec["operator"].append(chain.previous_operator.operator_name)
+    final = sample.copy()
+    rec_final_uncached = float(model.likelihood(final, caching=False))
+    assert np.allclose(rec_final_uncached, rec["last_lh"][-1])
+    f_shape = sample.source.value.shape[1:]
+    np.savez_compressed(
+        OUT / f"{tag}_trace.npz", format=np.int32(2),
+        clusters=np.stack(rec["clusters"]),
+        weights_step=np.array(w_step, dtype=np.int32),
+        weights_val=np.stack(w_val) if w_val else np.zeros((0,) + f_shape, dtype=np.float32),
+        src_ptr=np.array(src_ptr, dtype=np.int64), src_obj=np.array(src_obj, dtype=np.int32),
+        src_rows=np.stack(src_rows) if src_rows else np.zeros((0, (f_shape[0] * f_shape[1] + 7) // 8), dtype=np.uint8),
+        last_lh=np.array(rec["last_lh"]), mixture_ll=np.array(rec["mixture_ll"]), lh_sha=np.array(rec["lh_sha"]),
+        group_lh=np.stack(rec["group_lh"]), operator=np.array(rec["operator"]),
+        clusters_shape=np.array(sample.clusters.value.shape), source_shape=np.array(sample.source.value.shape),
+        final_collapsed_uncached=rec_final_uncached, **init, **(extra or {}))
+    n_acc = len({s.tobytes() for s in rec["clusters"]})
+    ops = sorted(set(rec["operator"]))
+    print(f"[golden] {tag}_trace: {n_steps} steps, {n_acc} distinct cluster states, {len(src_obj)} changed source rows, "
+          f"{len(w_step)} weight changes, ll {rec['last_lh'][0]:.3f} -> {rec['last_lh'][-1]:.3f}; operators {ops}")
+
+
+# ----------------------------------------------------------------------------------------
+# synthetic workloads through the reference's own loader, priors, initialiser and sampler
+# ----------------------------------------------------------------------------------------
+SYNTHETIC_MCMC = {
+    #            objects_per_cluster (init), size prior min / max
+    "cfg1":     (5, 2, 25),
+    "headline": (60, 3, 300),
+}
+
+
+def write_synthetic_config(name: str) -> Path:
+    """features.csv + feature_states.csv + config.yaml of the synthetic workload `name` in the reference's input
+    formats (sbayes/load_data.py:285-320, sbayes/util.py:294-346): state j of feature f is named s<j>, NA is an empty
+    cell, no confounder column (=> `universal` applies to all objects, load_data.py:163-167)."""
+    import pandas as pd
+    wl = make_workload(name)
+    n, f, s_max = wl.shape
+    assert wl.component_names == ["clusters", "universal"], "only universal-confounder synthetics are recorded"
+    dst = WORK / f"synthetic_{name}"
+    if dst.exists():
+        shutil.rmtree(dst)
+    dst.mkdir(parents=True)
+    x = wl.features.argmax(axis=-1)
+    cols = {"id": [f"o{i}" for i in range(n)], "name": [f"object{i}" for i in range(n)]}
+    rng = np.random.default_rng(99)
+    cols["x"] = rng.random(n) * 100.0
+    cols["y"] = rng.random(n) * 100.0
+    for j in range(f):
+        col = np.array([f"s{v}" for v in x[:, j]], dtype=object)
+        col[wl.na_values[:, j]] = ""
+        cols[f"F{j}"] = col
+    pd.DataFrame(cols).to_csv(dst / "features.csv", index=False)
+    states = {f"F{j}": [f"s{k}" if wl.states_per_feature[j, k] else "" for k in range(s_max)] for j in range(f)}
+    pd.DataFrame(states).to_csv(dst / "feature_states.csv", index=False)
+    per_cluster, size_min, size_max = SYNTHETIC_MCMC[name]
+    cfg = dict(
+        mcmc=dict(steps=1000, samples=10, runs=1, operators=dict(clusters=60, weights=15, source=25),
+                  initialization=dict(objects_per_cluster=per_cluster, attempts=2),
+                  warmup=dict(warmup_steps=10, warmup_chains=2), sample_from_prior=False),
+        model=dict(clusters=int(wl.clusters.shape[0]), confounders=["universal"],
+                   prior=dict(objects_per_cluster=dict(type="uniform_area", min=size_min, max=size_max),
+                              geo=dict(type="uniform"), weights=dict(type="uniform"),
+                              cluster_effect=dict(type="uniform"),
+                              confounding_effects=dict(universal={"<ALL>": dict(type="uniform")}))),
+        data=dict(features="features.csv", feature_states="feature_states.csv"))
+    import yaml
+    with open(dst / "config.yaml", "w") as fh:
+        yaml.safe_dump(cfg, fh)
+    return dst / "config.yaml"
+
+
+def synthetic_trace_fixture(name: str, n_steps: int, seed: int):
+    """A recorded reference MCMC trace on the synthetic workload `name`: the synthetic tensor goes through the
+    reference's CSV loader (and must come out identical to make_workload(name).features), the model gets the
+    reference's own priors, the chain its own initialiser and operator schedule."""
+    from sbayes.experiment_setup import Experiment
+    from sbayes.sampling.initializers import SbayesInitializer
+    cfg_path = write_synthetic_config(name)
+    wl = make_workload(name)
+    seed_reference(seed)
+    cwd = os.getcwd()
+    os.chdir(cfg_path.parent)
+    try:
+        experiment = Experiment(config_file=cfg_path, experiment_name=f"golden_{name}", log=False)
+        data = Data.from_config(experiment.config)
+        assert np.array_equal(data.features.values, wl.features), "CSV round trip changed the synthetic tensor"
+        assert np.array_equal(data.features.states, wl.states_per_feature)
+        model = Model(data, experiment.config.model)
+        mcmc_cfg = experiment.config.mcmc
+        init = SbayesInitializer(model=model, data=data, initial_size=mcmc_cfg.initialization.objects_per_cluster,
+                                 attempts=mcmc_cfg.initialization.attempts,
+                                 initial_cluster_steps=mcmc_cfg.initialization._initial_cluster_steps)
+        sample = init.generate_sample(c=0)
+        recalculate_feature_counts(data.features.values, sample)
+        conc = concentration_list(model, sample)
+        for c, want in zip(conc, wl.concentration):
+            assert np.array_equal(np.broadcast_to(c, want.shape), want), "reference prior tables differ from the workload's"
+        extra = dict(workload=np.array(name), features_crc=np.int64(crc(data.features.values)),
+                     component_names=np.array(sample.component_names))
+        record_trace(name, model, data, mcmc_cfg, sample, n_steps, extra=extra)
     finally:
         os.chdir(cwd)
 
@@ -471,7 +607,7 @@ def known_answers():
     v = dirichlet_categorical_logpdf(np.array([[2, 1, 0, 0]], dtype=np.float32),
                                      np.array([[1.0, 1.0, 0.0, 0.0]]))
     cases.append(dict(name="dirichlet_categorical_log_1_12", value=float(v[0]), expected=float(np.log(1 / 12))))
-    with open(HERE / "known_answers.json", "w") as fh:
+    with open(OUT / "known_answers.json", "w") as fh:
         json.dump(cases, fh, indent=1)
     print("[golden] known_answers.json")
 
@@ -544,7 +680,7 @@ def state_fixture():
     wl = make_workload("cfg1")
     _, sample = reference_objects(wl)
     log = state_script(sample)
-    with open(HERE / "state_versions.json", "w") as fh:
+    with open(OUT / "state_versions.json", "w") as fh:
         json.dump(log, fh, indent=1)
     print(f"[golden] state_versions.json ({len(log)} snapshots)")
 
@@ -559,8 +695,7 @@ def gibbs_source_fixture():
     from sbayes.sampling.operators import get_operator_schedule
 
     cfg = stage_config(Path("/root/reference/experiments/south_america"), "south_america_gs") / "config.yaml"
-    np.random.seed(77)
-    random.seed(77)
+    seed_reference(77)
     cwd = os.getcwd()
     os.chdir(cfg.parent)
     try:
@@ -605,17 +740,108 @@ def gibbs_source_fixture():
                   f"changed={int(np.count_nonzero(new.source.value ^ sample.source.value))}")
         meta = dict(name="gibbs_source", shape=list(data.features.values.shape), component_names=names,
                     groups=[int(sample.n_groups(k)) for k in names], cases=list(cases), **scal, **dig)
-        np.savez_compressed(HERE / "gibbs_source.npz", features=data.features.values,
+        np.savez_compressed(OUT / "gibbs_source.npz", features=data.features.values,
                             states_per_feature=data.features.states, weights=sample.weights.value,
                             source=sample.source.value, meta=json.dumps(meta), **arrs, **extra)
     finally:
         os.chdir(cwd)
 
 
+def call_log_fixture(tag, config_path: Path, n_steps: int, seed: int):
+    """The reference's own sampler -- initialiser, operator schedule, MH loop -- on the drop-in host layer under
+    patch.install(operators=True), the device replaced by the recording double (tests/_call_log.py): writes
+    <tag>_calls.npz = the sequence of Engine-level calls with their argument arrays and expected results."""
+    from unittest import mock
+
+    from sbayes.experiment_setup import Experiment
+    from sbayes.sampling.initializers import SbayesInitializer
+    from sbayes.sampling.mcmc_chain import MCMCChain
+    from sbayes_amd import conditionals, counts, likelihood, patch, registry
+    from tests._call_log import RecordingEngine, save
+
+    engines = {}
+
+    def get_engine(features, n_groups=None, n_slots=4, device=None):
+        key = (np.asarray(features).ctypes.data, np.asarray(features).shape)
+        if key not in engines:
+            engines[key] = RecordingEngine(features, n_groups)
+        elif n_groups is not None and list(n_groups) != engines[key].n_groups and engines[key].n_groups == [1]:
+            engines[key].n_groups = list(n_groups)                # first seen through a stateless call
+            engines[key].n_components = len(n_groups)
+        return engines[key]
+
+    def engine_for_features(f):                               # registry.engine_for_features with the double
+        for e in engines.values():
+            if e.n_features == f:
+                return e
+        feats_ref, n_groups = registry._KNOWN[f]                  # noted by Likelihood(...)
+        return get_engine(feats_ref(), n_groups)
+
+    patches = [mock.patch.object(mod, "get_engine", get_engine) for mod in (registry, likelihood, conditionals, counts)]
+    patches += [mock.patch.object(registry, "_ENGINES", {}), mock.patch.object(registry, "engine_for_features", engine_for_features)]
+    for p in patches:
+        p.start()
+    patch.install(operators=True)
+    cwd = os.getcwd()
+    try:
+        seed_reference(seed)
+        os.chdir(config_path.parent)
+        experiment = Experiment(config_file=config_path, experiment_name=f"calls_{tag}", log=False)
+        data = Data.from_config(experiment.config)
+        from sbayes.model import Model as PatchedModel
+        model = PatchedModel(data, experiment.config.model)
+        assert type(model.likelihood).__module__ == "sbayes_amd.likelihood"
+        cfg = experiment.config.mcmc
+        init = SbayesInitializer(model=model, data=data, initial_size=cfg.initialization.objects_per_cluster,
+                                 attempts=cfg.initialization.attempts,
+                                 initial_cluster_steps=cfg.initialization._initial_cluster_steps)
+        sample = init.generate_sample(c=0)
+        chain = MCMCChain(model=model, data=data, operators=cfg.operators, sample_loggers=[])
+        chain._ll = chain.likelihood(sample)
+        chain._prior = chain.prior(sample)
+        ops = []
+        for i in range(1, n_steps + 1):
+            sample = chain.step(sample)
+            sample.i_step = i
+            ops.append(chain.previous_operator.operator_name)
+        assert len(engines) == 1, f"{len(engines)} engines were created"
+        eng = next(iter(engines.values()))
+        meta = dict(tag=tag, n_steps=n_steps, seed=seed, n_groups=[int(g) for g in eng.n_groups],
+                    shape=list(data.features.values.shape), features_crc=crc(data.features.values),
+                    operators=sorted(set(ops)), final_ll=float(chain._ll))
+        save(OUT / f"{tag}_calls.npz", eng, meta)
+        kinds = {}
+        for c in eng.log:
+            kinds[c["m"]] = kinds.get(c["m"], 0) + 1
+        print(f"[golden] {tag}_calls: {len(eng.log)} calls, {len(eng.store.arrays)} distinct arrays, "
+              f"{sum(a.nbytes for a in eng.store.arrays) / 1e6:.1f} MB raw; {kinds}")
+    finally:
+        os.chdir(cwd)
+        patch.uninstall()
+        for p in patches:
+            p.stop()
+
+
+def call_log_fixtures():
+    tf = stage_config(Path("/root/reference/test/test_files"), "test_files_calls")
+    call_log_fixture("test_files", tf / "config.yaml", n_steps=200, seed=21)
+    sa = stage_config(Path("/root/reference/experiments/south_america"), "south_america_calls")
+    call_log_fixture("south_america", sa / "config.yaml", n_steps=60, seed=22)
+    call_log_fixture("cfg1", write_synthetic_config("cfg1"), n_steps=80, seed=23)
+
+
 def main():
     WORK.mkdir(parents=True, exist_ok=True)
-    if sys.argv[1:] == ["gibbs_source"]:            # one fixture only (the others stay untouched)
-        gibbs_source_fixture()
+    only = sys.argv[1:]                               # e.g. `make_golden.py headline_trace`: that fixture only
+    single = {"gibbs_source": gibbs_source_fixture,
+              "cfg1_trace": lambda: synthetic_trace_fixture("cfg1", 300, 11),
+              "headline_trace": lambda: synthetic_trace_fixture("headline", 300, 12),
+              "test_files": lambda: real_fixture("test_files", stage_config(Path("/root/reference/test/test_files"), "test_files") / "config.yaml", 300, 321),
+              "south_america": lambda: real_fixture("south_america", stage_config(Path("/root/reference/experiments/south_america"), "south_america") / "config.yaml", 400, 123),
+              "call_logs": call_log_fixtures}
+    if only:
+        for name in only:
+            single[name]()
         return
     known_answers()
     state_fixture()
@@ -627,6 +853,9 @@ def main():
     tf = stage_config(Path("/root/reference/test/test_files"), "test_files")
     real_fixture("test_files", tf / "config.yaml", n_trace_steps=300, seed=321)
     gibbs_source_fixture()
+    synthetic_trace_fixture("cfg1", 300, 11)
+    synthetic_trace_fixture("headline", 300, 12)
+    call_log_fixtures()
 
 
 if __name__ == "__main__":

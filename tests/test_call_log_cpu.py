@@ -1,0 +1,29 @@
+"""The recorded engine-level call logs of the real sampler (tests/golden/*_calls.npz, tests/_call_log.py) load and
+replay consistently against the oracle-backed double: checks the replay harness itself on CPU; the same replay runs
+against the real Engine in tests/test_gpu_call_log.py."""
+import numpy as np
+import pytest
+
+from tests._call_log import replay
+from tests._fake_engine import FakeEngine
+from tests._fixtures import GOLDEN, crc, load_npz
+
+
+def features_of(tag):
+    if tag == "cfg1":
+        from sbayes_amd.synthetic import make_workload
+        return make_workload("cfg1").features
+    return load_npz(tag).features
+
+
+@pytest.mark.parametrize("tag", ["test_files", "south_america", "cfg1"])
+def test_call_log_replays_on_the_double(tag):
+    feats = features_of(tag)
+    counts, meta = replay(GOLDEN / f"{tag}_calls.npz", lambda n_groups: FakeEngine(feats, n_groups))
+    assert crc(feats) == meta["features_crc"] and list(feats.shape) == meta["shape"]
+    # the operator forms and the collapsed likelihood really ran through the engine surface
+    assert {"cluster_marginals", "source_posterior", "subset_lh", "dirichlet_logpdf", "normalize_tables",
+            "effect_counts", "set_counts", "set_groups", "set_weights"} <= set(counts)
+    assert {"AlterCluster", "GibbsSampleSource"} <= set(meta["operators"])
+    # through the bind cache: fewer uploads than evaluations
+    assert counts["set_groups"] < counts["cluster_marginals"] + counts["source_posterior"]

@@ -16,11 +16,22 @@ from sbayes_amd.counts import compute_effect_counts, recalculate_feature_counts,
 from sbayes_amd.likelihood import (compute_component_likelihood, compute_component_likelihood_exact,
                                    normalize_weights, update_weights)
 from sbayes_amd.registry import release_all
-from tests._fixtures import load_npz, load_trace, sha
+from tests._fixtures import load_npz, load_synthetic_trace, load_trace, sha
 
 pytestmark = pytest.mark.gpu
 
 NPZ = ["cfg1", "south_america", "test_files"]
+
+
+TRACES = ["test_files", "south_america", "cfg1", "headline"]     # recorded reference MCMC traces
+
+
+def load_case(name):
+    """(fixture, trace): real configs keep their tensors in <name>.npz; the synthetic ones (cfg1: 50 x 30 x 5,
+    headline: 1000 x 200 x 10 -- four feature tiles, several object chunks) regenerate them from the seed."""
+    if name in ("cfg1", "headline"):
+        return load_synthetic_trace(name)
+    return load_npz(name), load_trace(name)
 
 
 def names_of(fx):
@@ -132,13 +143,12 @@ def test_likelihood_survives_pickle_and_recreates_engine():
     assert clone(sample, caching=True) == before
 
 
-@pytest.mark.parametrize("name", ["test_files", "south_america"])
+@pytest.mark.parametrize("name", TRACES)
 def test_trace_replay_cached_pipeline(name):
     """Replay the recorded reference MCMC trace through the cached drop-in pipeline: every step
     builds a candidate by copy(), applies the recorded state delta through the Sample API,
     delta-updates the counts on the device and evaluates with caching=True."""
-    fx = load_npz(name)
-    tr = load_trace(name)
+    fx, tr = load_case(name)
     model, sample = build(fx)
     feats = model.data.features.values
     na = model.data.features.na_values
@@ -180,18 +190,17 @@ def test_trace_replay_cached_pipeline(name):
             for k in cand.component_names:
                 assert np.array_equal(chk.feature_counts[k].value, cand.feature_counts[k].value)
         sample = cand
-    if name == "south_america":
+    if name in ("south_america", "headline"):
         assert n_partial > 20       # the partial-update path (strict subset of groups) was exercised
 
 
-@pytest.mark.parametrize("name", ["test_files", "south_america"])
+@pytest.mark.parametrize("name", TRACES)
 def test_trace_replay_resident_flow(name):
     """the recorded reference trace replayed through the resident flow --
     state lives in engine slots, each step ships only the delta, counts / tables / collapsed and
     mixture likelihood are recomputed on the device."""
     from sbayes_amd.resident import ResidentChain
-    fx = load_npz(name)
-    tr = load_trace(name)
+    fx, tr = load_case(name)
     model, sample = build(fx)
     chain = ResidentChain(model, sample)
     for c in range(fx.n_comp):
@@ -230,13 +239,12 @@ def test_trace_replay_resident_flow(name):
         assert np.array_equal(chain.current.counts(c), counts[c])
 
 
-@pytest.mark.parametrize("name", ["test_files", "south_america"])
+@pytest.mark.parametrize("name", TRACES)
 def test_trace_replay_one_call_steps(name):
     """The recorded reference trace through sbe_step: one engine call (one PCIe round trip, one
     synchronisation) per MCMC step -- delta in; collapsed per-group and mixture log-likelihood out."""
     from sbayes_amd.resident import ResidentChain
-    fx = load_npz(name)
-    tr = load_trace(name)
+    fx, tr = load_case(name)
     model, sample = build(fx)
     chain = ResidentChain(model, sample)
     prev_clusters, prev_source, prev_weights = fx.groups[0], fx.source, fx.weights

@@ -11,7 +11,7 @@ from sbayes_amd import conditionals, likelihood, registry
 from sbayes_amd import model as sbm
 from sbayes_amd.counts import recalculate_feature_counts, update_feature_counts
 from tests._fake_engine import FakeEngine
-from tests._fixtures import load_npz, load_trace, sha
+from tests._fixtures import load_npz, load_synthetic_trace, load_trace, sha
 
 
 @pytest.fixture()
@@ -40,10 +40,9 @@ def build(fx):
     return sbm.build(fx.features, fx.states_per_feature, names, fx.groups, fx.conc, fx.weights, fx.source)
 
 
-@pytest.mark.parametrize("name", ["test_files", "south_america"])
+@pytest.mark.parametrize("name", ["test_files", "south_america", "cfg1"])
 def test_cached_pipeline_replays_reference_trace(name, fake):
-    fx = load_npz(name)
-    tr = load_trace(name)
+    fx, tr = load_synthetic_trace(name) if name == "cfg1" else (load_npz(name), load_trace(name))
     model, sample = build(fx)
     feats = model.data.features.values
     na = model.data.features.na_values
@@ -52,7 +51,7 @@ def test_cached_pipeline_replays_reference_trace(name, fake):
     model.likelihood(sample, caching=True)
     eng = next(iter(fake.values()))
     n_partial = n_skipped = 0
-    for i in range(tr.n_steps if name == "test_files" else 150):
+    for i in range(150 if name == "south_america" else tr.n_steps):
         cand = sample.copy()
         new_clusters, new_source, new_weights = tr.clusters(i), tr.source(i), tr.weights[i]
         moved = np.flatnonzero((new_clusters != sample.clusters.value).any(axis=0) |
