@@ -8,16 +8,19 @@ Metric (BASELINE.json): log-likelihood evals/sec at 1000 sites x 200 feats x 10 
 A "step" = one pass of the hot path over one batch: `--batch` B distinct resident sample
 states (independent chains / candidate states of the sampler, sbayes/sampling/mcmc.py:239-241)
 evaluated by one launch sequence of the fused kernel (default B = 1024: four generations of
-workgroups per launch; `batch_sweep` in the output line reports B = 1 .. 1024).  Everything (feature block, group ids,
-probability tables, weights) is resident in HBM before the timed region; the B scalars are
-fetched to the host inside the timed region.
+workgroups per launch).  Everything (feature block, group ids, probability tables, weights) is
+resident in HBM before the timed region; the B scalars are fetched to the host inside it.
+`single_chain` in the output line is what ONE chain sees (B = 1, host-synchronous), `per_config`
+covers every 1-GPU BASELINE config (cfg1, south_america, headline, stress) at B = 1 / 8 / 64.
 
-The roofline's kernel duration comes from HIP event pairs recorded (on the engine's own stream) around the
-dominant kernel of K launches identical to the timed ones, issued right after the timed region (`--events-in-loop`
-records them inside the timed loop instead; the event records between back-to-back launches then cost the loop
-several us per step).
+Roofline: every number in `roofline` comes from THIS run.  The dominant kernel's duration is measured with HIP
+event pairs on the engine's own stream around every `--event-stride`-th launch INSIDE the timed loop (default 4:
+an event record between back-to-back launches costs the loop a few us, so not every launch is bracketed;
+`--event-stride 1` brackets all of them, 0 moves the pairs to an identical loop after the timed one).
+`roofline_valu` (what actually bounds the headline kernel) and `roofline.traffic` are STATIC figures from the
+committed rocprofv3 PMC passes (profiles/), labelled with their source file.
 
-  python bench.py                       # 1 GPU, defaults finish in well under a minute
+  python bench.py                       # 1 GPU, defaults finish in about a minute
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -33,6 +36,7 @@ import os
 import sys
 import time
 from pathlib import Path
+from types import SimpleNamespace
 
 import numpy as np
 
@@ -41,6 +45,10 @@ sys.path.insert(0, str(REPO))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+N_SIMDS = 1024             # 256 CUs x 4 SIMD-32
+NOMINAL_CLOCK_GHZ = 2.4    # MI355X_MICROARCH.md "Max clock"
+PMC_FILE = "profiles/r2/pmc_summary.json"
+TRAFFIC_FILE = "profiles/traffic_latest.json"
 
 
 def log(*a):
@@ -52,55 +60,94 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="headline", choices=["cfg1", "headline", "stress"])
-    ap.add_argument("--batch", type=int, default=1024,
-                    help="resident sample states (chains x candidate states) evaluated per step")
+    ap.add_argument("--workload", default="headline", choices=["cfg1", "south_america", "headline", "stress"])
+    ap.add_argument("--batch", type=int, default=None,
+                    help="resident sample states (chains x candidate states) evaluated per step "
+                         "(default: 1024 for cfg1 / south_america / headline, 64 for stress)")
     ap.add_argument("--kernel", default="packed", choices=["packed", "packed_general", "packed_tuple_lds", "onehot", "onehot_general"],
                     help="packed: state-index stream, group-tuple form when it applies (default); "
                          "packed_general: never the group-tuple form; onehot: stream the one-hot block")
     ap.add_argument("--log-mode", default="product", choices=["product", "per_obs"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--events-in-loop", action="store_true",
-                    help="record the roofline's HIP event pairs inside the timed loop itself (perturbs it: an event "
-                         "record between back-to-back launches costs several us per step) instead of in an identical "
-                         "loop of K launches right after it")
+    ap.add_argument("--event-stride", type=int, default=4,
+                    help="HIP event pair around the dominant kernel of every n-th launch of the timed loop "
+                         "(1: every launch; 0: none in the timed loop, an identical loop right after it instead)")
     ap.add_argument("--explore", action="store_true", help="also print the batch sweep to stderr")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (latency, sweep, a1/a7 rates)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (latency, sweep, per_config, a1/a7 rates)")
     return ap.parse_args()
 
 
-def setup_engine(wl, batch, device, kernel, log_mode):
+# ------------------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------------------
+def load_workload(name):
+    """The synthetic BASELINE workloads (seeded generator) or the south_america fixture (the reference's own loader
+    output, recorded by tests/golden/make_golden.py: real CSV data + real Dirichlet prior tables)."""
+    from sbayes_amd.synthetic import make_workload
+    if name != "south_america":
+        return make_workload(name)
+    z = np.load(REPO / "tests" / "golden" / "south_america.npz", allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    C = len(meta["groups"])
+    wl = SimpleNamespace(name=name, features=z["features"], states_per_feature=z["states_per_feature"],
+                         component_names=meta["component_names"], groups=[z[f"groups_{i}"] for i in range(C)],
+                         concentration=[z[f"conc_{i}"] for i in range(C)], weights=z["weights"], source=z["source"])
+    wl.na_values = ~wl.features.any(axis=-1)
+    wl.shape = wl.features.shape
+    wl.n_components = C
+    wl.clusters = wl.groups[0]
+    return wl
+
+
+def setup_engine(wl, batch, device, kernel="packed", log_mode="product"):
+    """Engine with `batch` distinct resident states.  Slot 0 is the workload's own state (the parity gate checks it
+    against the oracle); the others get random clusters and weights from the host (a few KB each) and their source
+    assignment drawn ON THE DEVICE from its prior given those (sbe_sample_source, Philox stream) -- the recipe of
+    sbayes_amd.synthetic.make_state without N*F*C host work per state, so 1024 states are ready in about a second
+    and eight ranks do not spend minutes of start-up in eight contending Python processes."""
     from sbayes_amd.engine import (LOG_PER_OBS, LOG_PRODUCT, MIXTURE_ONEHOT, MIXTURE_ONEHOT_GENERAL, MIXTURE_PACKED,
                                    MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE_LDS, Engine)
-    from sbayes_amd.synthetic import make_state
-
+    n_obj, n_feat, _ = wl.shape
+    C = wl.n_components
+    K = wl.clusters.shape[0]
     eng = Engine(wl.features, [g.shape[0] for g in wl.groups], n_slots=batch, device=device)
     eng.set_option(kernel={"onehot": MIXTURE_ONEHOT, "onehot_general": MIXTURE_ONEHOT_GENERAL, "packed": MIXTURE_PACKED,
                            "packed_general": MIXTURE_PACKED_GENERAL, "packed_tuple_lds": MIXTURE_PACKED_TUPLE_LDS}[kernel],
                    log_mode=LOG_PRODUCT if log_mode == "product" else LOG_PER_OBS)
-    for c in range(wl.n_components):
+    for c in range(C):
         eng.set_concentration(c, wl.concentration[c])
-    states = []
-    for b in range(batch):
-        if b == 0:
-            clusters, weights, source = wl.clusters, wl.weights, wl.source
-        else:
-            clusters, weights, source = make_state(wl.features, wl.groups[1:], wl.clusters.shape[0], seed=1000 + b)
-        groups = [clusters] + wl.groups[1:]
-        eng.load_state(b, groups, weights, source=source)      # counts on the device (a9)
-        for c in range(wl.n_components):
-            eng.update_probs(b, c)                             # tables on the device (a4)
-        states.append((groups, weights, source))
-    return eng, states
+    eng.load_state(0, wl.groups, wl.weights, source=wl.source)      # counts on the device (a9)
+    for c in range(C):
+        eng.update_probs(0, c)                                      # tables on the device (a4)
+    eng.set_option(deferred_checks=True)
+    eng.set_rng(2024, 0)
+    all_objects = np.arange(n_obj, dtype=np.int32)
+    rng = np.random.default_rng(1000)
+    for b in range(1, batch):
+        eng.copy_slot(b, 0)
+        a = rng.integers(0, 2 * K, size=n_obj)
+        eng.set_group_ids(b, 0, np.where(a < K, a, -1).astype(np.int32))
+        eng.set_weights(b, rng.dirichlet(np.ones(C), size=n_feat).astype(np.float32))
+        eng.sample_source(b, b, all_objects, None, from_prior=True)
+        eng.recount(b)
+        for c in range(C):
+            eng.update_probs(b, c)
+    eng.set_option(deferred_checks=False)
+    return eng
+
+
+def oracle_eval(wl):
+    from oracle import sbayes_oracle as orc
+    counts = orc.recalculate_feature_counts(wl.features, wl.groups, wl.source)
+    args = (wl.features, wl.na_values, wl.groups, counts, wl.concentration, wl.weights)
+    return orc, args
 
 
 def cpu_baseline(wl, seconds):
     """The CPU oracle (NumPy restatement of the reference path, validated against the reference's
     golden vectors) timed single-threaded on this host.  Checker/baseline only."""
-    from oracle import sbayes_oracle as orc
-    counts = orc.recalculate_feature_counts(wl.features, wl.groups, wl.source)
-    args = (wl.features, wl.na_values, wl.groups, counts, wl.concentration, wl.weights)
+    orc, args = oracle_eval(wl)
     ll = orc.mixture_loglik(*args)          # warm-up call
     n, t0 = 0, time.perf_counter()
     while True:
@@ -110,6 +157,24 @@ def cpu_baseline(wl, seconds):
         if el >= seconds or n >= 100000:
             break
     return ll, n / el, n, el
+
+
+def _cpu_worker(args):
+    name, seconds = args
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[var] = "1"
+    _ll, _rate, n, el = cpu_baseline(load_workload(name), seconds)
+    return n, el
+
+
+def cpu_baseline_processes(name, seconds, n_proc):
+    """`min(8, cores)` independent single-thread processes (the 8-chain configs: one chain per
+    process, the reference's own MC3 layout, sbayes/mcmc_setup.py:271-282) timed concurrently on this host."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(n_proc) as pool:
+        res = pool.map(_cpu_worker, [(name, seconds)] * n_proc)
+    return sum(n / el for n, el in res), sum(n for n, _ in res), max(el for _, el in res)
 
 
 def _rate(fn, min_time=0.3, min_calls=5):
@@ -123,6 +188,51 @@ def _rate(fn, min_time=0.3, min_calls=5):
             return n / el
 
 
+def batch_rate(eng, b, reps=100):
+    eng.sync()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        eng.mixture_loglik_batch_async(0, b)
+    eng.fetch_results(0, b)
+    dt = time.perf_counter() - t1
+    _t, kb = eng.profile_mixture(0, b, max(10, reps // 2))
+    return reps * b / dt, kb * 1e3
+
+
+def per_config_block(device, headline_eng, cpu_seconds):
+    """Every 1-GPU BASELINE config (cfg1 = configs[0] shape, south_america = configs[1], headline = configs[2],
+    stress = configs[4] shape) at B in {1, 8, 64}: evals/s of the async batch loop and the dominant kernel's HIP-event
+    duration; the oracle's single-thread rate beside it (bounded sample)."""
+    from sbayes_amd.synthetic import algorithmic_bytes
+    out = {}
+    for name in ("cfg1", "south_america", "headline", "stress"):
+        wl = load_workload(name)
+        eng = headline_eng if name == "headline" else setup_engine(wl, 64, device)
+        try:
+            orc, args = oracle_eval(wl)
+            want = orc.mixture_loglik(*args)
+            got = eng.mixture_loglik(0)
+            assert abs(got - want) <= 1e-10 * abs(want), (name, got, want)
+            has_comp = np.stack([g.any(axis=0) for g in wl.groups], axis=1)
+            n_pat = len(np.unique(has_comp, axis=0))
+            b_eval = algorithmic_bytes(*wl.shape, [g.shape[0] for g in wl.groups], n_pat, packed=True)
+            entry = {"shape": list(wl.shape), "groups": [int(g.shape[0]) for g in wl.groups],
+                     "algorithmic_bytes_per_eval_packed": b_eval, "parity_rel_err": abs(got - want) / abs(want)}
+            for b in (1, 8, 64):
+                r, k_us = batch_rate(eng, b, reps=60 if name == "stress" else 100)
+                entry[f"b{b}"] = {"evals_per_s": round(r), "kernel_us": round(k_us, 2),
+                                  "frac_of_hbm_peak": round(b_eval * b / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+            entry["single_eval_sync_us"] = round(1e6 / _rate(lambda: eng.mixture_loglik(0), 0.2, 100), 2)
+            if cpu_seconds > 0:
+                _ll, rate, n, el = cpu_baseline(wl, min(cpu_seconds, 3.0 if name == "stress" else 1.0))
+                entry["cpu_oracle_evals_per_s"] = round(rate, 3)
+            out[name] = entry
+        finally:
+            if eng is not headline_eng:
+                eng.close()
+    return out
+
+
 def secondary_figures(eng, wl, B, args):
     """Figures SURVEY.md 8(d) asks to report beside the headline: single-eval latency, batch sweep,
     the literal a1 / a3 / a7 call rates and the PCIe-inclusive eval (state re-uploaded per eval).
@@ -130,24 +240,19 @@ def secondary_figures(eng, wl, B, args):
     out = {}
     for _ in range(20):
         eng.mixture_loglik(0)
-    out["single_eval_sync_us"] = round(1e6 / _rate(lambda: eng.mixture_loglik(0), 0.2, 200), 2)
+    single_us = 1e6 / _rate(lambda: eng.mixture_loglik(0), 0.2, 200)
     _t, k1 = eng.profile_mixture(0, 1, 100)
-    out["single_eval_kernel_us"] = round(k1 * 1e3, 3)
+    out["single_chain"] = {"evals_per_s": round(1e6 / single_us, 1), "us_per_eval": round(single_us, 2),
+                           "kernel_us": round(k1 * 1e3, 3),
+                           "note": "one chain, one state per call, host-synchronous (BASELINE configs[2] '1 chain')"}
     sweep = {}
     for b in (1, 8, 64, 256, 1024):
         if b > B:
             break
-        eng.sync()
-        reps = 100
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            eng.mixture_loglik_batch_async(0, b)
-        eng.fetch_results(0, b)
-        dt = time.perf_counter() - t1
-        _t, kb = eng.profile_mixture(0, b, 50)
-        sweep[str(b)] = {"evals_per_s": round(reps * b / dt), "kernel_us": round(kb * 1e3, 2)}
+        r, kb = batch_rate(eng, b)
+        sweep[str(b)] = {"evals_per_s": round(r), "kernel_us": round(kb, 2)}
         if args.explore:
-            log(f"[explore] batch {b:4d}: {reps * b / dt:12.0f} evals/s  main kernel {kb * 1e3:9.2f} us")
+            log(f"[explore] batch {b:4d}: {r:12.0f} evals/s  main kernel {kb:9.2f} us")
     out["batch_sweep"] = sweep
     # literal call surface (results cross PCIe every call: SURVEY.md H3)
     n_obj, n_feat, _ = wl.shape
@@ -220,6 +325,42 @@ def secondary_figures(eng, wl, B, args):
     return out
 
 
+def static_profile_figures(workload, kernel, B, kern_us):
+    """STATIC figures from the committed rocprofv3 PMC passes (never measured in this run): the HBM traffic per launch
+    and the VALU roofline of the dominant kernel.  Each carries the file it was read from."""
+    traffic, valu = None, None
+    tf = REPO / TRAFFIC_FILE
+    if tf.exists():
+        try:
+            tr = json.loads(tf.read_text())
+            key = f"{workload}:{kernel}:{B}"
+            if key in tr:
+                traffic = {"bytes_per_launch": tr[key], "source": f"{TRAFFIC_FILE} (static: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE "
+                                                                  "passes of an earlier run of this command)"}
+        except Exception:
+            pass
+    for cand in (PMC_FILE, "profiles/r1b/pmc_summary.json"):
+        pf = REPO / cand
+        if not pf.exists():
+            continue
+        try:
+            sq = json.loads(pf.read_text()).get(f"sq_counters_{workload}_{kernel}_b{B}")
+        except Exception:
+            sq = None
+        if sq and "SQ_INSTS_VALU" in sq:
+            # a wave64 VALU instruction occupies its SIMD-32 for 2 passes x 2 cycles = 4 cycles when issued back to
+            # back by one wave (MI355X_MICROARCH.md, "vector-instruction ISSUE cost"); peak = every SIMD issuing always
+            busy = sq["SQ_INSTS_VALU"] * 4.0
+            avail = N_SIMDS * NOMINAL_CLOCK_GHZ * 1e9 * kern_us * 1e-6
+            valu = {"bound": "valu", "unit": "SIMD issue cycles per launch", "achieved": round(busy), "peak": round(avail),
+                    "frac": round(busy / avail, 4), "valu_instructions_per_launch": round(sq["SQ_INSTS_VALU"]),
+                    "clock_ghz": NOMINAL_CLOCK_GHZ, "kernel_us": round(kern_us, 3),
+                    "source": f"{cand} (static PMC pass: SQ_INSTS_VALU) x 4 cycles / (1024 SIMDs x nominal clock x the "
+                              "kernel time measured in this run)"}
+            break
+    return traffic, valu
+
+
 def main():
     args = parse()
     from sbayes_amd import chains
@@ -230,25 +371,29 @@ def main():
     dist = chains.init_process_group()
 
     from sbayes_amd.engine import device_count
-    from sbayes_amd.synthetic import algorithmic_bytes, make_workload
+    from sbayes_amd.synthetic import algorithmic_bytes
 
-    device = chains.device_for(local_rank, device_count())
-
-    wl = make_workload(args.workload)
+    n_dev = device_count()
+    device = chains.device_for(local_rank, n_dev)
+    wl = load_workload(args.workload)
     n_obj, n_feat, n_states = wl.shape
-    B = args.batch
-    eng, states = setup_engine(wl, B, device, args.kernel, args.log_mode)
+    B = args.batch if args.batch else (64 if args.workload == "stress" else 1024)
+    t_setup = time.perf_counter()
+    eng = setup_engine(wl, B, device, args.kernel, args.log_mode)
+    t_setup = time.perf_counter() - t_setup
     info = eng.info()
+    if n_dev >= world > 1:                          # one GPU per rank: every rank must sit on its own device
+        devices = chains.gather_chain_values([rank], [info["device"]], world, dist)
+        assert len(set(int(d) for d in devices)) == world, f"ranks share devices: {devices}"
 
     # ---- parity gate reported with the timing (rank-local, cheap): slot 0 vs the oracle ------
     parity = None
     if rank == 0:
-        from oracle import sbayes_oracle as orc
-        counts = orc.recalculate_feature_counts(wl.features, wl.groups, wl.source)
-        want = orc.mixture_loglik(wl.features, wl.na_values, wl.groups, counts, wl.concentration, wl.weights)
+        orc, oargs = oracle_eval(wl)
+        want = orc.mixture_loglik(*oargs)
         got = eng.mixture_loglik(0)
         parity = abs(got - want) / abs(want)
-        log(f"[bench] parity slot0: gpu {got!r} oracle {want!r} rel.err {parity:.3e}")
+        log(f"[bench] parity slot0: gpu {got!r} oracle {want!r} rel.err {parity:.3e}; {B} states ready in {t_setup:.1f} s")
         if parity > 1e-10:
             raise RuntimeError(f"parity gate failed: rel.err {parity:.3e} > 1e-10")
 
@@ -264,22 +409,28 @@ def main():
         step()
     eng.fetch_results(0, B)
 
+    stride = args.event_stride
+    eng.kernel_timing_start(reset=True)            # (events are bracketing nothing until resumed inside the loop)
+    eng.kernel_timing_pause()
     barrier()
-    if args.events_in_loop:
-        eng.kernel_timing_start()              # one HIP event pair per launch of the dominant kernel, engine stream
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    results = eng.fetch_results(0, B)          # D2H of the B scalars + stream sync, inside the timed region
+    for i in range(args.steps):
+        if stride > 0 and i % stride == 0:
+            eng.kernel_timing_start()              # HIP event pair around the dominant kernel of this launch
+            step()
+            eng.kernel_timing_pause()
+        else:
+            step()
+    results = eng.fetch_results(0, B)              # D2H of the B scalars + stream sync, inside the timed region
     barrier()
     elapsed = chains.max_over_ranks(time.perf_counter() - t0, dist)
-    if not args.events_in_loop:                # the same K launches again, each bracketed by an event pair
-        eng.kernel_timing_start()
+    if stride <= 0:                                # the same K launches again, each bracketed by an event pair
+        eng.kernel_timing_start(reset=True)
         for _ in range(args.steps):
             step()
         eng.fetch_results(0, B)
     n_timed, kern_ms = eng.kernel_timing_stop()
-    assert n_timed == args.steps
+    assert n_timed == (args.steps if stride <= 0 else (args.steps + stride - 1) // stride), n_timed
     assert np.all(np.isfinite(results))
 
     evals = args.steps * B * n_gpus
@@ -292,31 +443,28 @@ def main():
     packed = not args.kernel.startswith("onehot")
     b_eval = algorithmic_bytes(n_obj, n_feat, n_states, [g.shape[0] for g in wl.groups], n_pat, packed=packed)
     achieved = b_eval * B / (kern_ms * 1e-3) / 1e9
+    traffic, valu = static_profile_figures(args.workload, args.kernel, B, kern_ms * 1e3)
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-        "kernel": {"packed": "k_mixture_tuple64 (group-tuple form, 64-feature tiles; k_mixture_combo / k_mixture_v2 when not applicable)",
-                   "packed_tuple_lds": "k_mixture_combo (group-tuple form, LDS-metadata variant)",
-                   "packed_general": f"k_mixture_v2<{args.log_mode}>",
-                   "onehot": "k_mixture_combo<onehot> (group-tuple form; k_mixture_onehot_v2 when not applicable)",
-                   "onehot_general": f"k_mixture_onehot_v2<{args.log_mode}>"}[args.kernel],
+        "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "traffic": traffic["bytes_per_launch"] if traffic else None,
+        "traffic_source": traffic["source"] if traffic else None,
+        "kernel": eng.last_mixture_kernel(),
         "kernel_avg_us": round(kern_ms * 1e3, 3),
+        "kernel_avg_source": (f"HIP event pairs on the engine's stream around every {stride}-th launch of the timed loop "
+                              f"({n_timed} of {args.steps} launches)" if stride > 0 else
+                              f"HIP event pairs around {n_timed} identical launches issued right after the timed loop"),
         "algorithmic_bytes_per_eval": b_eval, "evals_per_launch": B,
         "representation": "packed state index (N*F bytes)" if packed else "one-hot (N*F*S bytes)",
+        "note": "contractual HBM roofline (algorithmic bytes / 8 TB/s); at the headline shape the working set is "
+                "L2/MALL-resident and the kernel is VALU-issue bound: see roofline_valu",
     }
-    traffic_file = REPO / "profiles" / "traffic_latest.json"
-    if traffic_file.exists():
-        try:
-            tr = json.loads(traffic_file.read_text())
-            key = f"{args.workload}:{args.kernel}:{B}"
-            if key in tr:
-                roofline["traffic"] = tr[key]
-        except Exception:
-            pass
 
     extra = {}
     if rank == 0 and n_gpus == 1 and not args.no_secondary:
         extra = secondary_figures(eng, wl, B, args)
+        extra["per_config"] = per_config_block(device, eng if args.workload == "headline" and B >= 64 else None,
+                                               0.0 if args.no_cpu_baseline else args.cpu_seconds)
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
@@ -324,23 +472,33 @@ def main():
         cpu = {"value": round(cpu_rate, 3), "unit": "evals/s", "cores": 1, "kind": "port",
                "sample": f"{n_cpu} uncached mixture-LL evals of the {args.workload} workload in {cpu_el:.1f} s, "
                          f"single-thread NumPy oracle (oracle/sbayes_oracle.py), host has {os.cpu_count()} cores"}
+        n_proc = min(8, os.cpu_count() or 1)
+        rate8, n8, el8 = cpu_baseline_processes(args.workload, args.cpu_seconds, n_proc)
+        extra["cpu_baseline_processes"] = {
+            "value": round(rate8, 3), "unit": "evals/s", "cores": n_proc, "kind": "port",
+            "sample": f"{n8} evals by {n_proc} independent single-thread processes in {el8:.1f} s "
+                      f"(BASELINE.md section 3: min(8, cores) processes for the 8-chain configs)"}
 
     if rank == 0:
         line = {
             "metric": "log-likelihood evals/sec at 1000 sites x 200 feats x 10 states; 1/2/4/8-GPU chains",
             "value": round(value, 2), "unit": "evals/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload} synthetic {n_obj}x{n_feat}x{n_states}, K={wl.clusters.shape[0]}, "
-                                   f"C={wl.n_components} (BASELINE.json configs[2])" if args.workload == "headline"
-                       else f"{args.workload} synthetic {n_obj}x{n_feat}x{n_states}",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if args.workload != "south_america" else "south_america fixture (real data)",
+            "config": {"workload": {"headline": f"headline synthetic {n_obj}x{n_feat}x{n_states}, K={wl.clusters.shape[0]}, C={wl.n_components} (BASELINE.json configs[2])",
+                                    "south_america": f"experiments/south_america {n_obj}x{n_feat}x{n_states} (BASELINE.json configs[1])",
+                                    "stress": f"stress synthetic {n_obj}x{n_feat}x{n_states}, K={wl.clusters.shape[0]}, C={wl.n_components} (BASELINE.json configs[4] shape)",
+                                    "cfg1": f"cfg1 synthetic {n_obj}x{n_feat}x{n_states} (BASELINE.json configs[0] shape)"}[args.workload],
                        "evals_per_step": B, "chains_per_gpu": B, "kernel": args.kernel, "log_mode": args.log_mode,
                        "parallelism": f"{n_gpus} independent engine(s), one per GPU, no collectives"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity_rel_err": parity,
             "device": info["device_name"],
+            "setup_s": round(t_setup, 2),
         }
+        if valu:
+            line["roofline_valu"] = valu
         if cpu:
             line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
         line.update(extra)

@@ -342,9 +342,12 @@ int sbe_timer_stop(sbe_engine* e, float* elapsed_ms);
  * [first_slot, first_slot+n) with one HIP event pair per launch sequence; returns the sum and
  * the per-launch average of the dominant kernel's duration in milliseconds. */
 /* Event timing of the dominant kernel INSIDE the caller's own loop: enable = 1 starts recording one HIP event pair
-   (on the engine's stream) around the fused kernel of every sbe_mixture_loglik[_batch[_async]] call; enable = 0 stops,
-   synchronises and returns the number of recorded launches and their average duration. */
+   (on the engine's stream) around the fused kernel of every sbe_mixture_loglik[_batch[_async]] call; 2 pauses and
+   3 resumes without forgetting the recorded pairs (so that only some launches of a loop are bracketed); enable = 0
+   stops, synchronises and returns the number of recorded launches and their average duration. */
 int sbe_kernel_timing(sbe_engine* e, int enable, int* n_launches, float* main_kernel_avg_ms);
+/* name and form of the kernel the most recent fused-kernel launch ran (static string owned by the engine) */
+const char* sbe_last_mixture_kernel(const sbe_engine* e);
 int sbe_profile_mixture(sbe_engine* e, int first_slot, int n, int iters, float* total_ms,
                         float* main_kernel_avg_ms);
 

@@ -101,6 +101,7 @@ PROTOTYPES = {
     "sbe_timer_start": (ct.c_int, [c_engine_p]),
     "sbe_timer_stop": (ct.c_int, [c_engine_p, ct.POINTER(ct.c_float)]),
     "sbe_kernel_timing": (ct.c_int, [c_engine_p, ct.c_int, ct.POINTER(ct.c_int), ct.POINTER(ct.c_float)]),
+    "sbe_last_mixture_kernel": (ct.c_char_p, [c_engine_p]),
     "sbe_profile_mixture": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_int, ct.POINTER(ct.c_float),
                                        ct.POINTER(ct.c_float)]),
 }

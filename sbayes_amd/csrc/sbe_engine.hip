@@ -55,6 +55,7 @@ struct sbe_engine {
     int64_t hbm_bytes = 0;
     std::string last_error;
     char device_name[64] = {0};
+    char last_kernel[96] = "none";     // kernel form of the most recent fused-kernel launch (sbe_last_mixture_kernel)
 
     // options
     int opt_kernel = SBE_MIXTURE_PACKED;
@@ -583,6 +584,9 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
             p.stamps = d_stamps;
         }
 #endif
+        snprintf(e->last_kernel, sizeof e->last_kernel, "%s<%s%s, tile %d, C=%d>",
+                 combo ? (tuple64 ? "k_mixture_tuple64" : "k_mixture_combo") : (onehot ? "k_mixture_onehot_v2" : "k_mixture_v2"),
+                 onehot ? "one-hot stream" : "packed stream", combo ? ", group-tuple form" : (e->direct ? ", direct tables" : ""), g.ft, e->C);
         if (combo && tuple64) launch_tuple64(e->C, p, grid, combo_lds, e->stream);
 #ifdef SBE_STAMPS
         if (p.stamps) {
@@ -785,6 +789,11 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     CREATE_CHK(hipEventCreate(&e->ev0));
     CREATE_CHK(hipEventCreate(&e->ev1));
+    for (int i = 0; i < 64; ++i) {                  // event pool of sbe_kernel_timing (grown on demand beyond this)
+        hipEvent_t ev;
+        CREATE_CHK(hipEventCreate(&ev));
+        e->ev_pool.push_back(ev);
+    }
 
     const int64_t N = e->N, F = e->F, S = e->S, C = e->C, NS = n_slots;
     CREATE_RC(dmalloc(e, &e->d_onehot, N * e->rs_pitch));
@@ -2342,7 +2351,10 @@ int sbe_timer_stop(sbe_engine* e, float* elapsed_ms) {
 int sbe_kernel_timing(sbe_engine* e, int enable, int* n_launches, float* main_kernel_avg_ms) {
     CHECK_ENGINE(e);
     HIPCHK(e, hipSetDevice(e->device));
-    if (enable) { e->ev_timing = true; e->ev_used = 0; return SBE_OK; }
+    if (enable == 1) { e->ev_timing = true; e->ev_used = 0; return SBE_OK; }     // start: forget earlier pairs
+    if (enable == 2) { e->ev_timing = false; return SBE_OK; }                    // pause: keep the recorded pairs
+    if (enable == 3) { e->ev_timing = true; return SBE_OK; }                     // resume
+    if (enable != 0) return fail(e, SBE_ERR_ARG, "sbe_kernel_timing: enable=%d", enable);
     CHECK_PTR(e, n_launches); CHECK_PTR(e, main_kernel_avg_ms);
     e->ev_timing = false;
     HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -2357,6 +2369,8 @@ int sbe_kernel_timing(sbe_engine* e, int enable, int* n_launches, float* main_ke
     e->ev_used = 0;
     return synced(e);
 }
+
+const char* sbe_last_mixture_kernel(const sbe_engine* e) { return e ? e->last_kernel : "none"; }
 
 int sbe_profile_mixture(sbe_engine* e, int first_slot, int n, int iters, float* total_ms, float* main_kernel_avg_ms) {
     CHECK_ENGINE(e); CHECK_SLOT(e, first_slot); CHECK_PTR(e, total_ms); CHECK_PTR(e, main_kernel_avg_ms);

@@ -576,9 +576,18 @@ class Engine:
         self._check(self._lib.sbe_timer_stop(self._h, ct.byref(ms)))
         return ms.value
 
-    def kernel_timing_start(self):
-        """Record one HIP event pair (engine stream) around the fused kernel of every mixture launch from now on."""
-        self._check(self._lib.sbe_kernel_timing(self._h, 1, None, None))
+    def kernel_timing_start(self, reset=False):
+        """Record one HIP event pair (engine stream) around the fused kernel of every mixture launch from now on
+        (reset=True forgets the pairs recorded so far)."""
+        self._check(self._lib.sbe_kernel_timing(self._h, 1 if reset else 3, None, None))
+
+    def kernel_timing_pause(self):
+        """Stop bracketing launches; the recorded pairs are kept (kernel_timing_start resumes)."""
+        self._check(self._lib.sbe_kernel_timing(self._h, 2, None, None))
+
+    def last_mixture_kernel(self) -> str:
+        """Kernel form the most recent fused mixture launch ran, e.g. 'k_mixture_tuple64<packed stream, ...>'."""
+        return self._lib.sbe_last_mixture_kernel(self._h).decode()
 
     def kernel_timing_stop(self):
         """-> (recorded launches, average duration of the fused kernel in ms)."""

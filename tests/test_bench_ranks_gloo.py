@@ -1,0 +1,73 @@
+"""bench.py's rank logic at world_size 8 on CPU (gloo), the device replaced by a stub engine: the launch line of the
+driver's scaling run (`python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8`) starts, every rank
+sets up its engine on its own device, the barrier / max-over-ranks / whole-job aggregation work, and rank 0 prints
+exactly one JSON line with the contract's keys.  No GPU involved."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+
+STUB_RUNNER = textwrap.dedent('''
+    import os, sys, time
+    import numpy as np
+    sys.path.insert(0, %(repo)r)
+    import bench
+    import sbayes_amd.engine as engine_mod
+
+    class StubEngine:
+        """Stands in for sbayes_amd.engine.Engine: remembers its device, returns the oracle-free constant results."""
+        def __init__(self, wl, batch, device):
+            self.device, self.batch = device, batch
+            self.n_timed = 0
+        def info(self):
+            return {"device": self.device, "device_name": "stub"}
+        def sync(self): pass
+        def mixture_loglik(self, slot): return -1.0
+        def mixture_loglik_batch_async(self, first, n): time.sleep(0.001)
+        def fetch_results(self, first, n): return np.full(n, -1.0)
+        def kernel_timing_start(self, reset=False):
+            if reset: self.n_timed = 0
+            self._on = True
+        def kernel_timing_pause(self):
+            self.n_timed += 1
+        def kernel_timing_stop(self): return self.n_timed - 1, 0.05      # (the reset call paused once)
+        def last_mixture_kernel(self): return "stub"
+        def close(self): pass
+
+    bench.setup_engine = lambda wl, batch, device, kernel="packed", log_mode="product": StubEngine(wl, batch, device)
+    engine_mod.device_count = lambda: 8                       # "an 8-GPU node"
+    import sbayes_amd.chains as chains
+    _orig = chains.init_process_group
+    chains.init_process_group = lambda backend=None: _orig("gloo")
+    bench.oracle_eval = lambda wl: (type("O", (), {"mixture_loglik": staticmethod(lambda *a: -1.0)}), ())
+    sys.argv = ["bench.py", "--gpus", "8", "--steps", "6", "--warmup", "2", "--workload", "cfg1", "--batch", "4"]
+    bench.main()
+''')
+
+
+def test_bench_rank_logic_world_size_8(tmp_path):
+    runner = tmp_path / "runner.py"
+    runner.write_text(STUB_RUNNER % {"repo": str(REPO)})
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(runner)],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout                     # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["steps"] == 6 and line["warmup"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["evals_per_step"] == 4
+    # whole-job aggregate: 8 ranks x 6 steps x 4 evals over the max-over-ranks time
+    assert abs(line["value"] - 8 * 6 * 4 / (line["ms_per_step"] * 6 / 1e3)) <= 1e-3 * line["value"]
+    assert line["cpu_baseline"] is None and "per_config" not in line      # N > 1: no CPU leg, no secondary figures
+    for key in ("metric", "unit", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
+        assert key in line
