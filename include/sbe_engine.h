@@ -50,7 +50,11 @@ typedef struct sbe_engine sbe_engine;
 #define SBE_MIXTURE_ONEHOT 1   /* reads the one-hot block as handed over (N*F*S bytes);
                                   group-tuple form whenever it applies                      */
 #define SBE_MIXTURE_ONEHOT_GENERAL 4  /* one-hot stream, never the group-tuple form          */
-#define SBE_MIXTURE_PACKED_GENERAL 2  /* packed, but never the group-tuple form (testing / A-B) */
+#define SBE_MIXTURE_PACKED_GENERAL 2  /* packed, but never the group-tuple form: the rows kernel k_mixture_rows
+                                         (1024-thread blocks over 32-feature tiles) when its LDS image fits and
+                                         C <= 4, else k_mixture_v2 */
+#define SBE_MIXTURE_PACKED_V2 6       /* packed, never the group-tuple form, never the rows kernel: k_mixture_v2
+                                         (testing / A-B) */
 #define SBE_MIXTURE_PACKED_TUPLE 3    /* packed, group-tuple form forced (error if not applicable) */
 #define SBE_MIXTURE_PACKED_TUPLE_LDS 5  /* same, but never the scalar-unit 64-feature-tile variant
                                           (k_mixture_tuple64): the LDS-metadata kernel (testing / A-B) */

@@ -33,6 +33,7 @@ struct Slot {
     bool groups_set = false, weights_set = false, source_set = false;
     std::vector<uint8_t> probs_set, counts_set;   // per component
     bool patterns_dirty = true;
+    uint64_t group_epoch = 0;             // identifies the content of the slot's group / pattern ids (k_rowoff's inputs)
 };
 
 }  // namespace
@@ -79,6 +80,10 @@ struct sbe_engine {
     uint16_t* d_state_h = nullptr; // [NQ][Fq][4] prepared LDS offsets of k_mixture_tuple64 (ft == 64, S <= 127) or null
     double2* d_logtab = nullptr;   // [128] {1/c, log c}: table of tab_log_pos (k_mixture_tuple64's table build)
     uint32_t* d_toff = nullptr;    // [slots][Np] byte offset of the object's tuple block, tid*(S+1)*512 (k_mixture_tuple64)
+    uint32_t* d_rowoff = nullptr;  // [slots][C+1][Np] LDS byte offsets of k_mixture_rows (k_rowoff), or null
+    int rows_ft = 0;               // tile width of k_mixture_rows (32 / 16; 0: its LDS image does not fit, or C > 4)
+    std::vector<uint64_t> rowoff_epoch;   // per slot: Slot::group_epoch the device array was built from
+    uint64_t epoch_counter = 0;
     uint8_t* d_tid = nullptr;      // [slots][Np] group-tuple index per object (k_mixture_combo)
     uint16_t* d_tuple_g = nullptr; // [slots][kMaxTuples][kMaxComponents]
     uint8_t* d_tuple_p = nullptr;  // [slots][kMaxTuples]
@@ -485,6 +490,22 @@ void launch_v2(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStr
     else launch_v2_ft<MODE, 16>(C, p, grid, lds, st);
 }
 
+template <int MODE, int FT>
+void launch_rows_ft(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
+    switch (C) {
+        case 1: k_mixture_rows<MODE, FT, 1><<<grid, kRowsBlock, lds, st>>>(p); break;
+        case 2: k_mixture_rows<MODE, FT, 2><<<grid, kRowsBlock, lds, st>>>(p); break;
+        case 3: k_mixture_rows<MODE, FT, 3><<<grid, kRowsBlock, lds, st>>>(p); break;
+        default: k_mixture_rows<MODE, FT, 4><<<grid, kRowsBlock, lds, st>>>(p); break;
+    }
+}
+
+template <int MODE>
+void launch_rows(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
+    if (ft == 32) launch_rows_ft<MODE, 32>(C, p, grid, lds, st);
+    else launch_rows_ft<MODE, 16>(C, p, grid, lds, st);
+}
+
 // Enqueue the dominant kernel (optionally bracketed by an event pair) and the fixed-order
 // partial reduction.  mode: LOG_PER_OBS / LOG_PRODUCT.
 int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev_a, hipEvent_t ev_b,
@@ -536,8 +557,41 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     } else if (force_combo) {
         return fail(e, SBE_ERR_ARG, "group-tuple kernel forced but not applicable (tuples=%d, LDS %zu bytes)", KT, combo_lds);
     }
+    // rows form (k_mixture_rows): the general packed kernel whenever its LDS image fits -- 1024-thread blocks over
+    // 32-feature (or 16-feature) tiles; SBE_MIXTURE_PACKED_V2 keeps the older k_mixture_v2 (A/B, tests)
+    bool rows = !combo && !onehot && e->rows_ft != 0 && e->opt_kernel != SBE_MIXTURE_PACKED_V2;
+    const size_t rows_image = rows ? (size_t)(e->Gtot + 1) * (e->S + 1) * e->rows_ft * 4 + (size_t)P * ((e->C + 1) / 2) * e->rows_ft * 16 : 0;
+    // a single eval with a large image (stress shape: 153 KB per block) is staging-bound in the rows form (measured
+    // 13.8 us against 12.5 us for k_mixture_v2's many small blocks); from two evals per launch on the rows form wins
+    if (rows && n == 1 && rows_image > 72 * 1024 && e->opt_kernel != SBE_MIXTURE_PACKED_GENERAL) rows = false;
+    if (rows) {
+        const int rft = e->rows_ft, gran = kRowsWaves * (kWave / rft);         // quads per block step
+        const int n_t = div_up(e->F, rft);
+        const size_t image = rows_image;
+        // every block stages the whole image: with a large image one block per CU and as few object chunks as fill
+        // the chip; small images take two generations of blocks
+        // (a block that stages a large image wants at least ~8 block steps of work behind it)
+        const int64_t target = (int64_t)e->compute_units * (image > 72 * 1024 ? 1 : 2);
+        int min_steps = image > 72 * 1024 ? 8 : image > 24 * 1024 ? 4 : 1;
+        if (const char* env = getenv("SBE_ROWS_MIN_STEPS")) { if (atoi(env) > 0) min_steps = atoi(env); }   // experiments
+        int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(div_up(e->NQ, (int64_t)gran * min_steps), div_up(target, (int64_t)n_t * n)));
+        const int qpc = round_up(div_up(e->NQ, chunks), gran);
+        g.ft = rft; g.n_ftiles = n_t; g.objs_per_chunk = qpc; g.n_chunks = div_up(e->NQ, qpc);
+        g.n_blocks = g.n_chunks * n_t; g.lds_bytes = image;
+        // per-object row offsets of the slots whose group ids changed since their offsets were built
+        bool stale = false;
+        for (int sl = first_slot; sl < first_slot + n; ++sl) stale |= e->rowoff_epoch[sl] != e->slots[sl].group_epoch;
+        if (stale) {
+            const int cells = (e->C + 1) * e->Np;
+            k_rowoff<<<dim3(div_up(cells, 256), n), 256, 0, e->stream>>>(
+                e->d_gid, e->d_pid, e->d_rowoff, (int64_t)e->C * e->Np, e->Np, (int64_t)cells, first_slot, e->N, e->Np,
+                e->C, e->Gtot, (uint32_t)((e->S + 1) * rft * 4), (uint32_t)(((e->C + 1) / 2) * rft * 16));
+            HIPCHK(e, hipGetLastError());
+            for (int sl = first_slot; sl < first_slot + n; ++sl) e->rowoff_epoch[sl] = e->slots[sl].group_epoch;
+        }
+    }
     if (g.n_blocks > e->partials_stride) return fail(e, SBE_ERR_STATE, "internal: partials buffer too small (%d > %lld)", g.n_blocks, (long long)e->partials_stride);
-    if (!combo && g.lds_bytes > 159 * 1024)
+    if (!combo && !rows && g.lds_bytes > 159 * 1024)
         return fail(e, SBE_ERR_ARG, "probability / weight tables too large for LDS staging at tile width %d (%zu bytes; G_total=%d, S=%d, P=%d)",
                     g.ft, g.lds_bytes, e->Gtot, e->S, P);
     dim3 grid(g.n_blocks, n);
@@ -576,20 +630,40 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
         p.tuple_p = e->d_tuple_p; p.tuple_p_stride = kMaxTuples;
         p.combo_w_off = combo_w_off; p.combo_tab_off = combo_tab_off;
         p.KT = KT;
+        p.eft = e->ft;
+        p.wpat = e->d_wpat; p.wpat_stride = (int64_t)e->Pmax * e->F * e->C;
+        p.rowoff = e->d_rowoff; p.rowoff_stride = (int64_t)(e->C + 1) * e->Np;
 #ifdef SBE_STAMPS
         static uint64_t* d_stamps = nullptr;
-        if (combo && tuple64 && getenv("SBE_STAMPS_FILE")) {
-            if (!d_stamps) (void)hipMalloc((void**)&d_stamps, (size_t)grid.x * 48 * sizeof(uint64_t));
+        if (((combo && tuple64) || rows) && getenv("SBE_STAMPS_FILE")) {
+            static size_t stamps_cap = 0;
+            if (grid.x > stamps_cap) {
+                if (d_stamps) { (void)hipStreamSynchronize(e->stream); (void)hipFree(d_stamps); }
+                stamps_cap = (size_t)grid.x;
+                (void)hipMalloc((void**)&d_stamps, stamps_cap * 48 * sizeof(uint64_t));
+            }
             (void)hipMemsetAsync(d_stamps, 0, (size_t)grid.x * 48 * sizeof(uint64_t), e->stream);
             p.stamps = d_stamps;
         }
 #endif
         snprintf(e->last_kernel, sizeof e->last_kernel, "%s<%s%s, tile %d, C=%d>",
-                 combo ? (tuple64 ? "k_mixture_tuple64" : "k_mixture_combo") : (onehot ? "k_mixture_onehot_v2" : "k_mixture_v2"),
+                 combo ? (tuple64 ? "k_mixture_tuple64" : "k_mixture_combo") : rows ? "k_mixture_rows" : (onehot ? "k_mixture_onehot_v2" : "k_mixture_v2"),
                  onehot ? "one-hot stream" : "packed stream", combo ? ", group-tuple form" : (e->direct ? ", direct tables" : ""), g.ft, e->C);
         if (combo && tuple64) launch_tuple64(e->C, p, grid, combo_lds, e->stream);
+        else if (combo) {
+            if (onehot) launch_combo<true>(g.ft, e->C, p, grid, combo_lds, e->stream);
+            else launch_combo<false>(g.ft, e->C, p, grid, combo_lds, e->stream);
+        } else if (rows) {
+            if (mode == LOG_PRODUCT) launch_rows<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
+            else launch_rows<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
+        } else
+        if (onehot) {
+            if (mode == LOG_PRODUCT) launch_oh2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
+            else launch_oh2<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
+        } else if (mode == LOG_PRODUCT) launch_v2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
+        else launch_v2<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
 #ifdef SBE_STAMPS
-        if (p.stamps) {
+        if (p.stamps) {                             // diagnostic build: dump the in-kernel stamps of this launch
             std::vector<uint64_t> h((size_t)grid.x * 48);
             (void)hipStreamSynchronize(e->stream);
             (void)hipMemcpy(h.data(), d_stamps, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
@@ -597,15 +671,6 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
             if (f) { fwrite(h.data(), sizeof(uint64_t), h.size(), f); fclose(f); }
         }
 #endif
-        else if (combo) {
-            if (onehot) launch_combo<true>(g.ft, e->C, p, grid, combo_lds, e->stream);
-            else launch_combo<false>(g.ft, e->C, p, grid, combo_lds, e->stream);
-        } else
-        if (onehot) {
-            if (mode == LOG_PRODUCT) launch_oh2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
-            else launch_oh2<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
-        } else if (mode == LOG_PRODUCT) launch_v2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
-        else launch_v2<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
     }
     if (ev_b) HIPCHK(e, hipEventRecord(ev_b, e->stream));
     HIPCHK(e, hipGetLastError());
@@ -688,7 +753,7 @@ int sbe_destroy(sbe_engine* e) {
     if (e->h_step_payload) (void)hipHostFree(e->h_step_payload);
     if (e->h_io) (void)hipHostFree(e->h_io);
     void* dev_ptrs[] = {e->d_step_pf, e->d_step_pg, e->d_logtab, e->d_state_h, e->d_toff, e->d_tid, e->d_tuple_g, e->d_tuple_p, e->d_state_q, e->d_probs_t, e->d_wpat_t, e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
-                        e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_unif, e->d_partials,
+                        e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_unif, e->d_partials, e->d_rowoff,
                         e->d_status, e->d_changed, e->d_step_stamp, e->d_scratch};
     for (void* p : dev_ptrs) if (p) (void)hipFree(p);
     if (e->h_results) (void)hipHostFree(e->h_results);
@@ -756,7 +821,7 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
         if (getenv("SBE_DIRECT") && atoi(getenv("SBE_DIRECT")) == 1) { ft = 16; e->direct = true; }   // experiments / tests
         e->ft = ft;
         e->n_ftiles = div_up(n_features, ft);
-        e->Fq = e->n_ftiles * ft;
+        e->Fq = round_up(n_features, 64);       // row pitch of the quad-interleaved state streams (>= any tiling of F)
     }
     e->conc_set.assign(n_components, 0);
     e->slots.resize(n_slots);
@@ -812,6 +877,15 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_RC(dmalloc(e, &e->d_tid, NS * e->Np));
     CREATE_RC(dmalloc(e, &e->d_toff, NS * e->Np + 64));       // + padding: the kernel prefetches 16 entries ahead
     CREATE_CHK(hipMemsetAsync(e->d_toff, 0, (NS * e->Np + 64) * sizeof(uint32_t), e->stream));
+    if (C <= 4) {   // k_mixture_rows: widest tile whose LDS image (tables f32 [(Gtot+1)][S+1][ft] + f64 weight planes) fits
+        auto rows_lds = [&](int t) { return (size_t)(gtot + 1) * (S + 1) * t * 4 + (size_t)e->Pmax * ((C + 1) / 2) * t * 16; };
+        e->rows_ft = rows_lds(32) <= 160 * 1024 - 512 ? 32 : rows_lds(16) <= 160 * 1024 - 512 ? 16 : 0;
+        if (const char* env = getenv("SBE_ROWS_FT")) { const int v = atoi(env); if (v == 0 || ((v == 16 || v == 32) && rows_lds(v) <= 160 * 1024 - 512)) e->rows_ft = v; }
+        if (e->rows_ft) {
+            CREATE_RC(dmalloc(e, &e->d_rowoff, NS * (C + 1) * e->Np));
+            e->rowoff_epoch.assign(n_slots, ~0ull);
+        }
+    }
     {   // table of tab_log_pos: interval centres c_i = 1 + (i + 1/2)/128 (c_0 = 1), {RN(1/c), RN(-log(RN(1/c)))}
         std::vector<double> tab(2 * kLogTabEntries);
         for (int i = 0; i < kLogTabEntries; ++i) {
@@ -934,7 +1008,7 @@ int sbe_get_na(const sbe_engine* ce, uint8_t* out_na) {
 
 int sbe_set_option(sbe_engine* e, int option, int value) {
     CHECK_ENGINE(e);
-    if (option == SBE_OPT_MIXTURE_KERNEL && (value == SBE_MIXTURE_PACKED || value == SBE_MIXTURE_ONEHOT || value == SBE_MIXTURE_PACKED_GENERAL || value == SBE_MIXTURE_PACKED_TUPLE || value == SBE_MIXTURE_PACKED_TUPLE_LDS || value == SBE_MIXTURE_ONEHOT_GENERAL)) { e->opt_kernel = value; return SBE_OK; }
+    if (option == SBE_OPT_MIXTURE_KERNEL && (value == SBE_MIXTURE_PACKED || value == SBE_MIXTURE_ONEHOT || value == SBE_MIXTURE_PACKED_GENERAL || value == SBE_MIXTURE_PACKED_TUPLE || value == SBE_MIXTURE_PACKED_TUPLE_LDS || value == SBE_MIXTURE_ONEHOT_GENERAL || value == SBE_MIXTURE_PACKED_V2)) { e->opt_kernel = value; return SBE_OK; }
     if (option == SBE_OPT_LOG_MODE && (value == SBE_LOG_PER_OBS || value == SBE_LOG_PRODUCT)) { e->opt_log = value; return SBE_OK; }
     if (option == SBE_OPT_STEP_FORM && (value == 0 || value == 1)) { e->opt_step_form = value; return SBE_OK; }
     if (option == SBE_OPT_DEFERRED_CHECKS && (value == 0 || value == 1)) {
@@ -1014,6 +1088,7 @@ static int set_gid_common(sbe_engine* e, int slot, int component, const std::vec
     { int _urc = upload(e, e->d_gid + ((int64_t)slot * e->C + component) * e->Np, ids.data(),
                              (size_t)e->N * sizeof(uint16_t)); if (_urc) return _urc; }
     s.patterns_dirty = true;
+    s.group_epoch = ++e->epoch_counter;
     s.groups_set = true;   // components never set keep "no group" ids
     return SBE_OK;
 }
@@ -2025,6 +2100,7 @@ static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* 
             return fail(e, SBE_ERR_ARG, "%zu distinct has_components patterns exceed capacity %d", cd.patterns.size(), e->Pmax);
         derive_tuples(e, cd);
         cd.patterns_dirty = false;
+        cd.group_epoch = ++e->epoch_counter;
     }
     // ---- payload: packed in host-mapped pinned memory; the kernels read it in place (a few tens of KB over
     // PCIe, no copy engine in the chain).  Every step ends with a stream synchronisation, so the single buffer is

@@ -154,6 +154,8 @@ __global__ void k_test_fast_log(const double* __restrict__ in, double* __restric
 // `tab`: absolute LDS byte address of the 128 {inv_c, logc} pairs.
 // ------------------------------------------------------------------------------------------
 typedef double f64x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const f64x2_t lds_cf64x2_t;
 constexpr int kLogTabEntries = 128;
 
@@ -721,6 +723,10 @@ struct Mix2Params {
     int wpat_tile_stride;                          // Pmax*C*FT
     double* partials;      int64_t partials_stride;
     int first_slot;
+    // rows kernel (k_mixture_rows): engine tile width of probs_t, canonical per-pattern weights, per-object row offsets
+    int eft;                                       // tile width of probs_t (64 / 32 / 16)
+    const float* wpat;     int64_t wpat_stride;    // per slot [Pmax][F][C] float32 normalised weights (a5)
+    const uint32_t* rowoff; int64_t rowoff_stride; // per slot [C+1][Np]: LDS byte offsets (see k_rowoff)
 };
 
 // LOG_PRODUCT, branch-free form used by the v2 kernel: the four observation likelihoods of a
@@ -1075,6 +1081,243 @@ __global__ __launch_bounds__(kBlock) void k_mixture_onehot_v2(Mix2Params p) {
 }
 
 // ==========================================================================================
+// Fused mixture log-likelihood, "rows" form: the GENERAL packed kernel for samples with many distinct group tuples
+// (stress shape: 10 clusters x 2 confounders of 20 groups => thousands of tuples, no group-tuple table) and for
+// every launch the tuple kernels do not take.  Same value per observation as the reference, same order:
+//        v(n, f) = ((w0*p0 + w1*p1) + w2*p2) + ...   (fp64; w*p of two float32 is exact in fp64, so the fma chain below
+//                                                      rounds exactly where NumPy's mul-then-add does)
+// What differs from k_mixture_v2 is the machine mapping:
+//   block   1024 threads = 16 waves sharing ONE LDS image of a 32-feature tile (16 features when 32 do not fit):
+//           at the stress shape the image (54 group rows x 21 state rows x 32 features x 4 B = 145 KB + weights)
+//           fills the CU's LDS once instead of twice per 16 features, and 16 waves hide the gather latency
+//   lane    <-> feature of the tile; a half-wave (FT = 32) is one object quad: its 32 lanes read 32 consecutive
+//           banks of one table row -- conflict-free for any row (k_mixture_v2 at FT = 16 put four objects in a
+//           wave: two rows per half-wave, a 2-way bank conflict whenever their parities agree)
+//   tables  f32 [(Gtot+1)][S+1][FT]: row S of every group is the NA row (zeros), row block Gtot is "no group" (zeros)
+//   weights f64 planes [P][ceil(C/2)][FT][2]: one ds_read_b128 brings two components' weights, conflict-free
+//   offsets the LDS byte offset of every object's group row per component and of its weight pattern come precomputed
+//           (k_rowoff, [C+1][Np] u32 per slot): one v_add3 per (observation, component), no id decode, no multiply
+//   NA      the accumulator starts at 1.0 for an NA observation and its table row is zero: v = 1 exactly, log 1 = 0,
+//           no select at the end
+// ==========================================================================================
+constexpr int kRowsBlock = 1024;
+constexpr int kRowsWaves = kRowsBlock / kWave;
+
+// Per-object LDS byte offsets of k_mixture_rows, rebuilt whenever a slot's group ids change:
+//   out[c][n]  (c < C) = row(g_c(n)) * (S+1) * FT * 4      row = global group index, Gtot for "no group"
+//   out[C][n]          = pattern(n) * ceil(C/2) * FT * 16  (weight planes of the object's has_components pattern)
+// objects n >= N of the last quad get the "no group" row and pattern 0 (their state bytes are NA).
+__global__ void k_rowoff(const uint16_t* __restrict__ gid, const uint8_t* __restrict__ pid, uint32_t* __restrict__ out,
+                         int64_t gid_stride, int64_t pid_stride, int64_t out_stride, int first_slot, int N, int Np,
+                         int C, int Gtot, uint32_t row_bytes, uint32_t pat_bytes) {
+    const int slot = first_slot + (int)blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (c, n)
+    if (i >= (C + 1) * Np) return;
+    const int c = i / Np, n = i - c * Np;
+    uint32_t v;
+    if (c < C) {
+        const uint32_t g = n < N ? gid[(int64_t)slot * gid_stride + (int64_t)c * Np + n] : (uint32_t)kNoGroup;
+        v = (g < (uint32_t)Gtot ? g : (uint32_t)Gtot) * row_bytes;
+    } else {
+        v = (n < N ? (uint32_t)pid[(int64_t)slot * pid_stride + n] : 0u) * pat_bytes;
+    }
+    out[(int64_t)slot * out_stride + i] = v;
+}
+
+template <int MODE, int FT, int CT>
+__global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mixture_rows(Mix2Params p) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ double red[kRowsWaves];
+    // XCD-aware 1-D grid, same scheme as k_mixture_v2 (b % 8 labels the XCD group; speed only)
+    const int unit = ((int)(blockIdx.x >> 3) / p.slots_per_group) * 8 + (int)(blockIdx.x & 7);
+    const int slot_i = (unit % p.slot_groups) * p.slots_per_group + (int)(blockIdx.x >> 3) % p.slots_per_group;
+    const int work = unit / p.slot_groups;                 // (tile, chunk) index
+    if (work >= p.n_work || slot_i >= p.n_batch) return;   // padding blocks (before any barrier)
+    const int slot = p.first_slot + slot_i;
+    const int tile = work % p.n_ftiles, chunk = work / p.n_ftiles;       // (n_ftiles: tiles of FT features here)
+    constexpr int C = CT, CP = (CT + 1) / 2;
+    const int S = p.S, S1 = p.S + 1;
+#ifdef SBE_STAMPS
+    if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 48 + 0] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const uint32_t state_bytes = FT * 4;                                  // one state row of a group block
+    const uint32_t row_bytes = (uint32_t)S1 * state_bytes;
+    const uint32_t tab_bytes = (uint32_t)(p.Gtot + 1) * row_bytes;
+    const int q0 = chunk * p.quads_per_chunk;
+    const int q1 = min(p.NQ, q0 + p.quads_per_chunk);
+    const int nq = q1 - q0;                                               // >= 1
+
+    // ---- LDS image of the tile ---------------------------------------------------------------------------------
+    // Tables: 16-byte pieces straight from the engine's tile-transposed copy probs_t[tile_e][g][s][eft] (a 32-feature
+    // tile is half a 64-wide engine tile, one 32-wide one or two 16-wide ones).  A wave owns the groups w, w+16, ..;
+    // four groups' loads are in flight together per lane (no division: a group's [S][FT] block is walked by piece).
+    {
+        const int lane_s = threadIdx.x & (kWave - 1), wave_s = threadIdx.x >> 6;
+        constexpr int PPR = FT / 4;                                       // 16-byte pieces per state row
+        const float* probs_t = p.probs_t + (int64_t)slot * p.probs_t_stride;
+        const int n_tiles_e = (p.F + p.eft - 1) / p.eft;
+        const int per_g = S * PPR;
+        const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+        constexpr int GU = 4, JU = 3;                                     // 12 sixteen-byte loads in flight per lane
+        for (int gb = wave_s; gb <= p.Gtot; gb += GU * kRowsWaves) {
+            for (int jb = lane_s; jb < per_g; jb += JU * kWave) {
+                uint4 v[GU][JU];
+#pragma unroll
+                for (int ju = 0; ju < JU; ++ju) {
+                    const int j = jb + ju * kWave;
+                    const int srow = j / PPR, part = j % PPR;             // (compile-time divisor)
+                    const int f0 = tile * FT + part * 4;
+                    const int te = f0 / p.eft, fle = f0 % p.eft;          // eft is 16 / 32 / 64: shifts
+#pragma unroll
+                    for (int u = 0; u < GU; ++u) {
+                        const int g = gb + u * kRowsWaves;
+                        v[u][ju] = (j < per_g && g <= p.Gtot && te < n_tiles_e)
+                            ? *reinterpret_cast<const uint4*>(probs_t + (((int64_t)te * (p.Gtot + 1) + g) * S + srow) * p.eft + fle)
+                            : zero4;
+                    }
+                }
+#pragma unroll
+                for (int ju = 0; ju < JU; ++ju) {
+                    const int j = jb + ju * kWave;
+                    const int srow = j / PPR, part = j % PPR;
+#pragma unroll
+                    for (int u = 0; u < GU; ++u) {
+                        const int g = gb + u * kRowsWaves;
+                        if (j < per_g && g <= p.Gtot)
+                            *reinterpret_cast<uint4*>(lds_raw + (uint32_t)(g * S1 + srow) * state_bytes + (uint32_t)part * 16u) = v[u][ju];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {                                // NA row of each of the four groups: zeros
+                const int g = gb + u * kRowsWaves;
+                if (g <= p.Gtot && lane_s < PPR)
+                    *reinterpret_cast<uint4*>(lds_raw + (uint32_t)(g * S1 + S) * state_bytes + (uint32_t)lane_s * 16u) = zero4;
+            }
+        }
+        double* wl = reinterpret_cast<double*>(lds_raw + tab_bytes);      // [P][CP][FT][2]
+        const float* wpat = p.wpat + (int64_t)slot * p.wpat_stride;
+        for (int k = threadIdx.x; k < p.P * CP * FT * 2; k += kRowsBlock) {
+            const int e = k & 1, fl2 = (k >> 1) % FT, hp = (k >> 1) / FT, h = hp % CP, pp = hp / CP;
+            const int c = 2 * h + e, f2 = tile * FT + fl2;
+            wl[k] = (c < C && f2 < p.F) ? (double)wpat[((int64_t)pp * p.F + f2) * C + c] : 0.0;
+        }
+    }
+    __syncthreads();
+#ifdef SBE_STAMPS
+    if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 48 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    constexpr int SUBS = kWave / FT;                                      // object quads per wave step
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int fl = lane % FT, sub = lane / FT;
+    const int f = tile * FT + fl;                                         // < Fq (Fq = F rounded up to 64)
+    const uint32_t lane_tab = (uint32_t)fl * 4u;
+    const uint32_t lane_w = tab_bytes + (uint32_t)fl * 16u;
+    const uint32_t na4 = (uint32_t)S * 0x01010101u;                        // four NA state bytes
+    const int n_steps = (nq + kRowsWaves * SUBS - 1) / (kRowsWaves * SUBS);   // same for every wave
+    // streamed operands through buffer descriptors (plain buffer loads: no flat path, no 64-bit address arithmetic):
+    // the quad-interleaved state block (shared by every slot) and the slot's per-object row offsets
+    const __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(p.state_q), 0, (int)((uint32_t)p.NQ * (uint32_t)p.Fq * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(p.rowoff + (int64_t)slot * p.rowoff_stride), 0, (int)((uint32_t)(CT + 1) * (uint32_t)p.Np * 4u), 0x00020000);
+    const uint32_t st_row = (uint32_t)p.Fq * 4u, st_col = (uint32_t)f * 4u;
+    const uint32_t ro_comp = (uint32_t)p.Np * 4u;                          // bytes between two components' offset rows
+
+    struct Step { uint32_t xs; u32x4_t ro[CT]; u32x4_t po; };
+    auto local_quad = [&](int k) { return (k * kRowsWaves + wave) * SUBS + sub; };
+    auto load_step = [&](int k) -> Step {
+        Step st;
+        const int i = local_quad(k);
+        const uint32_t q = (uint32_t)(q0 + min(i, nq - 1));               // always in bounds
+        const uint32_t xs = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, (int)(q * st_row + st_col), 0, 0);
+        st.xs = i < nq ? xs : na4;                                         // past the chunk: four NA observations
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+            st.ro[c] = __builtin_amdgcn_raw_buffer_load_b128(ro_rsrc, (int)(q * 16u), (int)((uint32_t)c * ro_comp), 0);
+        st.po = __builtin_amdgcn_raw_buffer_load_b128(ro_rsrc, (int)(q * 16u), (int)((uint32_t)CT * ro_comp), 0);
+        return st;
+    };
+    // the four observation likelihoods of a step (NA -> exactly 1.0)
+    auto step_values = [&](const Step& st, double (&v)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t x = (st.xs >> (8 * j)) & 0xFFu;                 // <= S (NA / padding byte is S)
+            const uint32_t xo = x * state_bytes + lane_tab;
+            const uint32_t pj = st.po[j];
+            double w[2 * CP];
+#pragma unroll
+            for (int h = 0; h < CP; ++h) {
+                const f64x2_t ww = *reinterpret_cast<const f64x2_t*>(lds_raw + lane_w + pj + (uint32_t)h * (FT * 16u));
+                w[2 * h] = ww.x; w[2 * h + 1] = ww.y;
+            }
+            double acc = x >= (uint32_t)S ? 1.0 : 0.0;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float t = *reinterpret_cast<const float*>(lds_raw + st.ro[c][j] + xo);
+                acc = fma(w[c], (double)t, acc);                          // exact product, one rounding: NumPy's order
+            }
+            v[j] = acc;
+        }
+    };
+
+    // Explicit two-stage software pipeline (ping-pong A / B): the loads of step k+1 are issued before the arithmetic
+    // of step k; the scheduling barriers keep hipcc from sinking them below it.
+    double thread_ll;
+    {
+        ProdAcc pa{1.0, 0, 0, 0u};
+        double sum = 0.0;
+        auto consume = [&](const Step& st) {
+            double v[4];
+            step_values(st, v);
+            if (MODE == LOG_PRODUCT) prod_add4(pa, v[0], v[1], v[2], v[3]);
+            else { sum += log(v[0]); sum += log(v[1]); sum += log(v[2]); sum += log(v[3]); }
+        };
+        Step A = load_step(0), B;
+        int k = 0;
+        for (; k + 1 < n_steps; k += 2) {
+            B = load_step(k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(A);
+            __builtin_amdgcn_sched_barrier(0);
+            A = load_step(k + 2);                                        // (clamped past the end: four NA observations)
+            __builtin_amdgcn_sched_barrier(0);
+            consume(B);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (k < n_steps) consume(A);
+#ifdef SBE_STAMPS
+        if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 48 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (MODE == LOG_PRODUCT) {
+            thread_ll = log(pa.mant) + (double)(pa.expo - 1023 * n_steps) * 0.693147180559945309417232;
+            if (__builtin_expect(pa.bad != 0u, 0)) {                     // rare: redo this thread per observation
+                double s2 = 0.0;
+                for (int kk = 0; kk < n_steps; ++kk) {
+                    double v[4];
+                    step_values(load_step(kk), v);
+                    s2 += log(v[0]); s2 += log(v[1]); s2 += log(v[2]); s2 += log(v[3]);
+                }
+                thread_ll = s2;
+            }
+        } else thread_ll = sum;
+    }
+    const double wsum = wave_sum(thread_ll);
+    if (lane == 0) red[wave] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double total = 0.0;
+#pragma unroll
+        for (int w = 0; w < kRowsWaves; ++w) total += red[w];            // fixed order: run-to-run deterministic
+        p.partials[(int64_t)slot * p.partials_stride + work] = total;
+#ifdef SBE_STAMPS
+        if (p.stamps) p.stamps[(size_t)blockIdx.x * 48 + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
+    }
+}
+
+// ==========================================================================================
 // Fused mixture log-likelihood, group-tuple form with the tuple metadata in LDS (tile widths 32 / 16, S > 127, the
 // one-hot stream; at tile width 64 the packed stream runs k_mixture_tuple64 below).
 //
@@ -1300,7 +1543,6 @@ __global__ __launch_bounds__(kBlock) void k_mixture_combo(Mix2Params p) {
 typedef __attribute__((address_space(3))) const double lds_cdouble_t;
 typedef __attribute__((address_space(3))) double lds_double_t;
 typedef __attribute__((address_space(3))) unsigned char lds_uchar_t;
-typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 #define SBE_SDWA_ADD(dst, soff, vx, sel0, sel1)                                                             \
     asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" sel0 " src1_sel:" sel1   \

@@ -15,6 +15,7 @@ from . import _lib
 
 MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE, MIXTURE_ONEHOT_GENERAL = 0, 1, 2, 3, 4
 MIXTURE_PACKED_TUPLE_LDS = 5
+MIXTURE_PACKED_V2 = 6
 LOG_PER_OBS, LOG_PRODUCT = 0, 1
 _OPT_KERNEL, _OPT_LOG, _OPT_DEFERRED = 1, 2, 3
 

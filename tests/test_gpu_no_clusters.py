@@ -8,7 +8,7 @@ from oracle import sbayes_oracle as orc
 from sbayes_amd import model as sbm
 from sbayes_amd.conditionals import likelihood_per_component, mixture_log_likelihood
 from sbayes_amd.counts import recalculate_feature_counts
-from sbayes_amd.engine import MIXTURE_ONEHOT, MIXTURE_PACKED, MIXTURE_PACKED_GENERAL, Engine
+from sbayes_amd.engine import MIXTURE_ONEHOT, MIXTURE_PACKED, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2, Engine
 from sbayes_amd.likelihood import update_weights
 from sbayes_amd.registry import release_all
 from sbayes_amd.synthetic import make_workload
@@ -58,7 +58,7 @@ def test_engine_with_zero_clusters(name):
         got_lh = eng.likelihood_per_component(0)
         assert np.array_equal(got_lh[..., 1:], lh[..., 1:])
         assert np.array_equal(got_lh[..., 0][~wl.na_values], np.zeros(np.count_nonzero(~wl.na_values)))
-        for kernel in (MIXTURE_PACKED, MIXTURE_PACKED_GENERAL, MIXTURE_ONEHOT):
+        for kernel in (MIXTURE_PACKED, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2, MIXTURE_ONEHOT):
             eng.set_option(kernel=kernel)
             got = eng.mixture_loglik(0)
             assert abs(got - mix) <= 1e-10 * abs(mix), (kernel, got, mix)

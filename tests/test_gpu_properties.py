@@ -4,7 +4,7 @@ delta/inverse-delta round trip, idempotence -- checked on the device results the
 import numpy as np
 import pytest
 
-from sbayes_amd.engine import MIXTURE_ONEHOT, MIXTURE_PACKED, MIXTURE_PACKED_GENERAL, Engine
+from sbayes_amd.engine import MIXTURE_ONEHOT, MIXTURE_PACKED, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2, Engine
 from sbayes_amd.registry import get_engine, release_all
 from sbayes_amd.synthetic import make_state, make_workload
 
@@ -34,7 +34,7 @@ def test_full_size_properties(name):
         load(eng, 0, wl)
         total = eng.mixture_loglik(0)
         # (1) every kernel form agrees on the same resident state
-        for kernel in (MIXTURE_PACKED_GENERAL, MIXTURE_ONEHOT, MIXTURE_PACKED):
+        for kernel in (MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2, MIXTURE_ONEHOT, MIXTURE_PACKED):
             eng.set_option(kernel=kernel)
             assert abs(eng.mixture_loglik(0) - total) <= 1e-10 * abs(total)
         # (2) count conservation: every valid observation whose source is set is counted exactly once
@@ -69,7 +69,10 @@ def test_full_size_properties(name):
             eng.update_probs(1, c)
             eng.update_probs(2, c)
         singles = np.array([eng.mixture_loglik(s) for s in range(3)])
-        assert np.array_equal(eng.mixture_loglik_batch(0, 3), singles)
+        # (the block geometry -- how many object chunks a tile is cut into -- depends on the batch size, so a batched
+        #  eval may sum its per-block partials in another grouping than a single one: equal to rounding, not bit for bit)
+        np.testing.assert_allclose(eng.mixture_loglik_batch(0, 3), singles, rtol=1e-13, atol=0)
+        assert np.array_equal(eng.mixture_loglik_batch(0, 3), eng.mixture_loglik_batch(0, 3))      # run-to-run deterministic
         assert singles[2] == singles[0] and singles[1] != singles[0]
         tables = [eng.get_probs(0, c) for c in range(wl.n_components)]
 

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import sbayes_oracle as orc
-from sbayes_amd.engine import (LOG_PER_OBS, LOG_PRODUCT, MIXTURE_ONEHOT, MIXTURE_PACKED, MIXTURE_ONEHOT_GENERAL, MIXTURE_PACKED_GENERAL,
+from sbayes_amd.engine import (LOG_PER_OBS, LOG_PRODUCT, MIXTURE_ONEHOT, MIXTURE_PACKED, MIXTURE_ONEHOT_GENERAL, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2,
                                MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, Engine, EngineError)
 
 pytestmark = pytest.mark.gpu
@@ -126,7 +126,7 @@ def _run_case(feats, groups, weights, source, conc, n_groups, rng, light=False):
             assert np.array_equal(eng.likelihood_per_component_exact(0),
                                   orc.likelihood_per_component_exact(feats, na, groups, counts, conc, source))
             want = np.log(obs)[~na].sum()
-        for kernel in (MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS,
+        for kernel in (MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2, MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS,
                        MIXTURE_ONEHOT_GENERAL):
             for log_mode in (LOG_PER_OBS, LOG_PRODUCT):
                 eng.set_option(kernel=kernel, log_mode=log_mode)
@@ -195,7 +195,7 @@ def test_tuple_kernel_batches(shape):
             counts = orc.recalculate_feature_counts(feats, groups, source)
             want.append(orc.mixture_loglik(feats, na, groups, counts, conc, weights))
         want = np.array(want)
-        for kernel in (MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, MIXTURE_PACKED_GENERAL):
+        for kernel in (MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2):
             eng.set_option(kernel=kernel)
             got = eng.mixture_loglik_batch(0, B)
             np.testing.assert_allclose(got, want, rtol=1e-10, err_msg=f"kernel {kernel}")
