@@ -249,6 +249,27 @@ int sbe_normalize_weights(sbe_engine* e, const float* weights /* [F][C] */, int 
 int sbe_cluster_marginals(sbe_engine* e, int slot, const float* table /* [F][S] */, const int32_t* objects,
                           int n_objects_av, double prior_temperature, double* out /* [2][n_objects_av] */);
 
+/* ---- next-heaviest operator expressions (missing #2 / #3) -----------------------------------------
+ * sbe_jump_lh: ClusterJump.get_jump_lh (sbayes/sampling/operators.py:1679-1722) with
+ *     ClusterEffectProposals.expected_confounder_features (:1342-1379), the data-parallel part: for every listed
+ *     member n of the source cluster
+ *         out[0][i] = sum_{f not NA} log( p_conf(n,f) + wh(n)[f][0] * p_source[f][x(n,f)] )     "stay"
+ *         out[1][i] = sum_{f not NA} log( p_conf(n,f) + wh(n)[f][0] * p_target[f][x(n,f)] )     "jump"
+ *     p_conf(n,f) = sum_{c>=1} wh(n)[f][c] * pconf[g_c(n)][f][x] over the confounder groups the object is in,
+ *     wh = normalize(update_weights(sample) ** (1/prior_temperature)) from the slot's weights and patterns; all of it
+ *     in the reference's float32 arithmetic, the product over features as a sum of fp64 logs (the reference's
+ *     float32 np.prod underflows beyond F ~ 75).  pconf: float32 [G_total - n_clusters][F][S], the
+ *     tempered tables of every confounder group (posterior_counts + normalize, operators.py:1254-1259, 1364-1371);
+ *     p_source / p_target: float32 [F][S] (conditional_effect_mean, conditionals.py:105-122).  The caller applies
+ *     ** (1/temperature), + EPS and the ratio (operators.py:1712-1722).
+ * sbe_source_lh_by_feature: GibbsSampleWeights.source_lh_by_feature (operators.py:677-685): per feature
+ *     float32( sum_n log sum_c source[n,f,c] * w[n,f,c] ), NA observations count 1, from the slot's source, patterns
+ *     and weights -- the [N, F, C] normalised-weight array never crosses PCIe (float32 logs: compared at 2e-6). */
+int sbe_jump_lh(sbe_engine* e, int slot, const float* pconf /* [G_total - K][F][S] */, const float* p_source /* [F][S] */,
+                const float* p_target /* [F][S] */, const int32_t* objects, int n_members, double prior_temperature,
+                double* out /* [2][n_members] */);
+int sbe_source_lh_by_feature(sbe_engine* e, int slot, float* out /* [F] */);
+
 /* ---- data-parallel cores of Gibbs source resampling ----------------------
  * sbe_source_posterior: GibbsSampleSource.calculate_source_posterior (operators.py:554-574):
  *     out[i][f][:] = normalize(lh[n_i][f][:] ** (1/T) * w[n_i][f][:] ** (1/T_prior)) (float32)

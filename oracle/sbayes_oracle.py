@@ -470,3 +470,106 @@ def source_prior_per_object(weights_normalized, source, na_values):
 def logger_row(weights_normalized, lh_exact):
     """float64 [N*F]: what LikelihoodLogger._write_sample appends (before the float32 column cast)."""
     return np.sum(weights_normalized * lh_exact, axis=2).ravel()
+
+
+# --------------------------------------------------------------------------------------
+# ClusterJump.get_jump_lh (sbayes/sampling/operators.py:1679-1722) with
+# ClusterEffectProposals.expected_confounder_features (:1342-1379) and posterior_counts (:1254-1259)
+# --------------------------------------------------------------------------------------
+def weights_heated(weights, has_comp, prior_temperature=1.0):
+    """normalize(update_weights(sample) ** (1 / prior_temperature)) (operators.py:1348-1349, 1684-1685): float32."""
+    w = normalize_weights(weights, has_comp)
+    return normalize(w ** (1 / float(prior_temperature)), axis=-1)
+
+
+def expected_confounder_features(features, groups_by_component, counts_by_component, concentration_by_component,
+                                 unif_cluster, weights, temperature=1.0, prior_temperature=1.0):
+    """float32 [N, F, S] (operators.py:1342-1379): per confounder group the tempered effect table
+    normalize(unif + (prior - unif) / T_prior + counts / T) weighted by the heated weight of that component and
+    ACCUMULATED in float32 in component / group order.  NB the reference passes the CLUSTER prior's uniform
+    concentration for every confounder (:1352)."""
+    n_objects, n_features, n_states = features.shape
+    expected = np.zeros((n_objects, n_features, n_states), dtype=FLOAT_TYPE)
+    wh = weights_heated(weights, has_components(groups_by_component), prior_temperature)
+    for c in range(1, len(groups_by_component)):
+        prior = concentration_by_component[c]
+        post = unif_cluster + (prior - unif_cluster) / float(prior_temperature) + counts_by_component[c] / float(temperature)
+        p_conf = normalize(post, axis=-1)
+        for i_g, g in enumerate(groups_by_component[c]):
+            # weights_heated[g, :, [i_comp], None] (advanced indices g and [i_comp] broadcast to n_g): [n_g, F, 1]
+            expected[g] += wh[g][:, :, c][..., np.newaxis] * p_conf[np.newaxis, i_g, ...]
+    return expected
+
+
+def jump_lh_per_feature(features, groups_by_component, counts_by_component, concentration_by_component, unif_cluster,
+                        weights, i_source, i_target, temperature=1.0, prior_temperature=1.0):
+    """(stay, jump): float32 [n_members, F] per-feature likelihoods of the source cluster's members staying /
+    jumping to the target cluster (operators.py:1684-1709, before the product over features)."""
+    source_cluster = groups_by_component[0][i_source]
+    wh = weights_heated(weights, has_components(groups_by_component), prior_temperature)
+    w_clust = wh[source_cluster, :, 0]
+    prior = concentration_by_component[0]
+    p_src = conditional_effect_mean(prior, counts_by_component[0][[i_source]], unif_counts=unif_cluster,
+                                    prior_temperature=float(prior_temperature), temperature=float(temperature))
+    p_tgt = conditional_effect_mean(prior, counts_by_component[0][[i_target]], unif_counts=unif_cluster,
+                                    prior_temperature=float(prior_temperature), temperature=float(temperature))
+    p_conf = expected_confounder_features(features, groups_by_component, counts_by_component, concentration_by_component,
+                                          unif_cluster, weights, temperature, prior_temperature)[source_cluster]
+    p_total_source = p_conf + w_clust[..., np.newaxis] * p_src
+    p_total_target = p_conf + w_clust[..., np.newaxis] * p_tgt
+    feats = features[source_cluster]
+    return np.sum(feats * p_total_source, axis=-1), np.sum(feats * p_total_target, axis=-1)
+
+
+def jump_lh(features, na_values, groups_by_component, counts_by_component, concentration_by_component, unif_cluster,
+            weights, i_source, i_target, temperature=1.0, prior_temperature=1.0):
+    """ClusterJump.get_jump_lh (operators.py:1679-1722): float32 [n_members] = lh_jump / (lh_jump + lh_stay), the
+    products over features in float32 exactly like the reference (np.prod underflows to 0 beyond F ~ 75)."""
+    stay_pf, jump_pf = jump_lh_per_feature(features, groups_by_component, counts_by_component, concentration_by_component,
+                                           unif_cluster, weights, i_source, i_target, temperature, prior_temperature)
+    valid = ~na_values[groups_by_component[0][i_source]]
+    with np.errstate(under="ignore"):
+        lh_stay = np.prod(stay_pf, axis=-1, where=valid)
+        lh_jump = np.prod(jump_pf, axis=-1, where=valid)
+        lh_stay **= (1 / float(temperature))
+        lh_jump **= (1 / float(temperature))
+    eps = np.finfo(np.float32).eps                     # sbayes/util.py:34
+    lh_stay += eps
+    lh_jump += eps
+    return lh_jump / (lh_jump + lh_stay)
+
+
+def jump_log_lh(features, na_values, groups_by_component, counts_by_component, concentration_by_component, unif_cluster,
+                weights, i_source, i_target, temperature=1.0, prior_temperature=1.0):
+    """float64 [2, n_members]: sums of logs of the float32 per-feature values (what the device form returns)."""
+    stay_pf, jump_pf = jump_lh_per_feature(features, groups_by_component, counts_by_component, concentration_by_component,
+                                           unif_cluster, weights, i_source, i_target, temperature, prior_temperature)
+    valid = ~na_values[groups_by_component[0][i_source]]
+    with np.errstate(divide="ignore"):
+        return np.stack([np.where(valid, np.log(stay_pf.astype(np.float64)), 0.0).sum(axis=-1),
+                         np.where(valid, np.log(jump_pf.astype(np.float64)), 0.0).sum(axis=-1)])
+
+
+def jump_ratio_from_logs(log_stay_jump, temperature=1.0):
+    """The host tail of get_jump_lh (operators.py:1706-1722) from the two sums of logs, in the reference's float32:
+    exp of a sum of logs in place of np.prod (equal to float32 rounding; both underflow to 0 together)."""
+    with np.errstate(under="ignore"):
+        lh_stay = np.exp(log_stay_jump[0]).astype(np.float32)
+        lh_jump = np.exp(log_stay_jump[1]).astype(np.float32)
+        lh_stay **= (1 / float(temperature))
+        lh_jump **= (1 / float(temperature))
+    eps = np.finfo(np.float32).eps
+    lh_stay += eps
+    lh_jump += eps
+    return lh_jump / (lh_jump + lh_stay)
+
+
+# --------------------------------------------------------------------------------------
+# GibbsSampleWeights.source_lh_by_feature (sbayes/sampling/operators.py:677-685)
+# --------------------------------------------------------------------------------------
+def source_lh_by_feature(source, weights_normalized, na_values):
+    """float32 [F]: sum over objects of log(sum_c source * w), NA observations count 1."""
+    p = np.sum(source * weights_normalized, axis=-1)
+    p[na_values] = 1
+    with np.errstate(divide="ignore"):
+        return np.sum(np.log(p), axis=0)

@@ -77,6 +77,9 @@ PROTOTYPES = {
     "sbe_normalize_weights": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_cluster_marginals": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_double,
                                          ct.c_void_p]),
+    "sbe_jump_lh": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int,
+                               ct.c_double, ct.c_void_p]),
+    "sbe_source_lh_by_feature": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
     "sbe_source_posterior": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double,
                                         ct.c_void_p]),
     "sbe_sample_source": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double,

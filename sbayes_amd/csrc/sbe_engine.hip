@@ -458,21 +458,29 @@ void launch_combo_ft(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStrea
     }
 }
 
-template <bool OFF16>
+template <bool OFF16, int NW>
 void launch_tuple64_o(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
     switch (C) {
-        case 1: k_mixture_tuple64<1, OFF16><<<grid, kBlock, lds, st>>>(p); break;
-        case 2: k_mixture_tuple64<2, OFF16><<<grid, kBlock, lds, st>>>(p); break;
-        case 3: k_mixture_tuple64<3, OFF16><<<grid, kBlock, lds, st>>>(p); break;
-        case 4: k_mixture_tuple64<4, OFF16><<<grid, kBlock, lds, st>>>(p); break;
-        default: k_mixture_tuple64<0, OFF16><<<grid, kBlock, lds, st>>>(p); break;
+        case 1: k_mixture_tuple64<1, OFF16, NW><<<grid, NW * kWave, lds, st>>>(p); break;
+        case 2: k_mixture_tuple64<2, OFF16, NW><<<grid, NW * kWave, lds, st>>>(p); break;
+        case 3: k_mixture_tuple64<3, OFF16, NW><<<grid, NW * kWave, lds, st>>>(p); break;
+        case 4: k_mixture_tuple64<4, OFF16, NW><<<grid, NW * kWave, lds, st>>>(p); break;
+        default: k_mixture_tuple64<0, OFF16, NW><<<grid, NW * kWave, lds, st>>>(p); break;
     }
+}
+
+// waves per block of k_mixture_tuple64: 4, or 8 (twice the waves share one log table: more waves per SIMD at the
+// same LDS footprint) -- SBE_T64_NW selects (experiments)
+int tuple64_waves() {
+    static const int nw = [] { const char* env = getenv("SBE_T64_NW"); return env && atoi(env) == 8 ? 8 : 4; }();
+    return nw;
 }
 
 void launch_tuple64(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
     // 16-bit tuple-block offsets when the whole log table sits below 64 KiB
-    if ((int64_t)p.KT * (p.S + 1) * 512 <= 65536) launch_tuple64_o<true>(C, p, grid, lds, st);
-    else launch_tuple64_o<false>(C, p, grid, lds, st);
+    const bool off16 = (int64_t)p.KT * (p.S + 1) * 512 <= 65536;
+    if (tuple64_waves() == 8) { if (off16) launch_tuple64_o<true, 8>(C, p, grid, lds, st); else launch_tuple64_o<false, 8>(C, p, grid, lds, st); }
+    else { if (off16) launch_tuple64_o<true, 4>(C, p, grid, lds, st); else launch_tuple64_o<false, 4>(C, p, grid, lds, st); }
 }
 
 template <bool ONEHOT>
@@ -542,7 +550,7 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
         combo_lds = (combo_lds + 15) / 16 * 16;
         combo_w_off = (int)combo_lds;
         combo_lds += (size_t)P * e->C * gc.ft * sizeof(double);
-        if (tuple64) combo_lds += 4 * sizeof(double) + kLogTabEntries * sizeof(double2);   // reduction scratch (the kernel has no static LDS) + log table
+        if (tuple64) combo_lds += tuple64_waves() * sizeof(double) + kLogTabEntries * sizeof(double2);   // reduction scratch (the kernel has no static LDS) + log table
         if (onehot) {      // byte-position lookup table [seg16][32] u16; a tile row segment must fit one step
             const int seg16 = gc.ft * e->S / 16;
             if (seg16 > kBlock) combo = false;
@@ -1679,6 +1687,68 @@ int sbe_cluster_marginals(sbe_engine* e, int slot, const float* table, const int
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->stream));
     memcpy(out, e->h_io + tb + ob, out_bytes);
+    return synced(e);
+}
+
+// ---- ClusterJump.get_jump_lh / expected_confounder_features (operators.py:1679-1722, 1342-1379) -----------------
+int sbe_jump_lh(sbe_engine* e, int slot, const float* pconf, const float* p_source, const float* p_target,
+                const int32_t* objects, int n_members, double prior_temperature, double* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, p_source); CHECK_PTR(e, p_target); CHECK_PTR(e, out);
+    if (n_members < 0) return fail(e, SBE_ERR_ARG, "n_members=%d", n_members);
+    if (n_members == 0) return SBE_OK;
+    CHECK_PTR(e, objects);
+    if (!(prior_temperature > 0.0)) return fail(e, SBE_ERR_ARG, "prior_temperature must be positive");
+    for (int i = 0; i < n_members; ++i)
+        if (objects[i] < 0 || objects[i] >= e->N) return fail(e, SBE_ERR_ARG, "object index %d out of range", objects[i]);
+    Slot& s = e->slots[slot];
+    if (!s.groups_set || !s.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / weights not set", slot);
+    const int n_conf_groups = e->Gtot - e->G[0];
+    if (n_conf_groups > 0) CHECK_PTR(e, pconf);
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = SBE_OK;
+    if (s.patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
+    const int F = e->F, S = e->S, C = e->C;
+    const size_t fs = (size_t)F * S * sizeof(float);
+    const size_t cb = ((size_t)std::max(n_conf_groups, 1) * fs + 255) / 256 * 256;
+    const size_t tb = (fs + 255) / 256 * 256;
+    const size_t ob = ((size_t)n_members * sizeof(int32_t) + 255) / 256 * 256;
+    const size_t out_bytes = (size_t)2 * n_members * sizeof(double);
+    // tables, member list and result in host-mapped memory: ONE kernel, one synchronisation (as sbe_cluster_marginals)
+    rc = ensure_io(e, cb + 2 * tb + ob + out_bytes);
+    if (rc) return rc;
+    if (n_conf_groups > 0) memcpy(e->h_io, pconf, (size_t)n_conf_groups * fs);
+    memcpy(e->h_io + cb, p_source, fs);
+    memcpy(e->h_io + cb + tb, p_target, fs);
+    memcpy(e->h_io + cb + 2 * tb, objects, (size_t)n_members * sizeof(int32_t));
+    const double inv = 1.0 / prior_temperature;
+    k_jump_lh<<<n_members, kBlock, 0, e->stream>>>(
+        e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np,
+        (const float*)e->d_io, (const float*)(e->d_io + cb), (const float*)(e->d_io + cb + tb),
+        e->d_weights + (int64_t)slot * F * C, e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0,
+        (const int32_t*)(e->d_io + cb + 2 * tb), n_members, (double*)(e->d_io + cb + 2 * tb + ob),
+        reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C, e->Fp, e->G[0]);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    memcpy(out, e->h_io + cb + 2 * tb + ob, out_bytes);
+    return synced(e);
+}
+
+// ---- GibbsSampleWeights.source_lh_by_feature (operators.py:677-685) -----------------------------------------------
+int sbe_source_lh_by_feature(sbe_engine* e, int slot, float* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, out);
+    Slot& s = e->slots[slot];
+    if (!s.groups_set || !s.source_set || !s.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", slot);
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = SBE_OK;
+    if (s.patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
+    rc = ensure_io(e, (size_t)e->F * sizeof(float));
+    if (rc) return rc;
+    k_source_lh_by_feature<<<div_up(e->F, kWave), 1024, 0, e->stream>>>(
+        e->d_state, e->d_src + (int64_t)slot * e->N * e->Fp, e->d_pid + (int64_t)slot * e->Np,
+        e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, (float*)e->d_io, e->N, e->F, e->C, e->Fp);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    memcpy(out, e->h_io, (size_t)e->F * sizeof(float));
     return synced(e);
 }
 

@@ -1548,8 +1548,9 @@ typedef __attribute__((address_space(3))) unsigned char lds_uchar_t;
     asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" sel0 " src1_sel:" sel1   \
         : "=v"(dst) : "s"(soff), "v"(vx))
 
-template <int CT, bool OFF16>
-__global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
+template <int CT, bool OFF16, int NW>           // NW: waves per block (4, or 8: twice the waves share one log table)
+__global__ __launch_bounds__(NW * kWave, NW == 8 ? 6 : 1) void k_mixture_tuple64(Mix2Params p) {
+    constexpr int kThreads = NW * kWave;
     constexpr int FT = 64;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // Block order.  Work items = (tile, chunk); the last tile is LIGHT when it runs in sub-row mode (ragged_w).
@@ -1610,12 +1611,12 @@ __global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
     //                  | 128 x {1/c, log c} (tab_log_pos)
     const uint32_t w_off = (uint32_t)p.combo_w_off;
     const uint32_t red_off = w_off + (uint32_t)(p.P * C * FT) * 8u;
-    const uint32_t tab_off = red_off + 32u;
+    const uint32_t tab_off = red_off + (uint32_t)NW * 8u;
     double* red4 = reinterpret_cast<double*>(lds_raw + red_off);
     const bool ragged = p.ragged_w != 0 && tile == p.n_ftiles - 1;           // block-uniform
 
     // this wave's quads [qa, qb) of the chunk
-    const int per = (nq + 3) >> 2;
+    const int per = (nq + NW - 1) / NW;
     const int qa = min(nq, w * per), qb = min(nq, qa + per);
     const int n_my = qb - qa;
     const uint4* toff4 = reinterpret_cast<const uint4*>(p.toff + (int64_t)slot * p.toff_stride) + (q0 + qa);
@@ -1658,11 +1659,11 @@ __global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
     const __amdgpu_buffer_rsrc_t pr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(probs_tile), 0, (int)((uint32_t)(p.Gtot + 1) * (uint32_t)S * FT * 4u), 0x00020000);
     const int lane4 = lane * 4;
-    const int my_rows = (!ragged && n_rows > w) ? (n_rows - w + 3) >> 2 : 0;
-    constexpr int U = CU <= 2 ? 16 : (CU <= 4 ? 8 : 4);
+    const int my_rows = (!ragged && n_rows > w) ? (n_rows - w + NW - 1) / NW : 0;
+    constexpr int U = (CU <= 2 ? 16 : (CU <= 4 ? 8 : 4)) / (NW == 8 ? 2 : 1);     // (8 waves: 64-VGPR budget)
     uint32_t v_goff[CU], v_woff = 0u, v_doff = 0u;
     auto row_offsets = [&](int base) {
-        const uint32_t r = (uint32_t)(w + 4 * min(base + lane, my_rows - 1));
+        const uint32_t r = (uint32_t)(w + NW * min(base + lane, my_rows - 1));
         const uint32_t t = r / (uint32_t)S, st = r - t * (uint32_t)S;
 #pragma unroll
         for (int c = 0; c < CU; ++c)
@@ -1690,10 +1691,11 @@ __global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
     {   // weights of the tile, the NA rows, the log table
         const double* wpat_t = p.wpat_t + (int64_t)slot * p.wpat_t_stride + (int64_t)tile * p.wpat_tile_stride;
         double* wls = reinterpret_cast<double*>(lds_raw + w_off);
-        for (int k = threadIdx.x; k < p.P * C * FT; k += kBlock) wls[k] = wpat_t[k];
+        for (int k = threadIdx.x; k < p.P * C * FT; k += kThreads) wls[k] = wpat_t[k];
         double* T = reinterpret_cast<double*>(lds_raw);
-        for (int e = threadIdx.x; e < KT * FT; e += kBlock) T[((e >> 6) * S1 + S) * FT + (e & 63)] = 0.0;
-        reinterpret_cast<double*>(lds_raw + tab_off)[threadIdx.x] = reinterpret_cast<const double*>(p.logtab)[threadIdx.x];   // 256 doubles
+        for (int e = threadIdx.x; e < KT * FT; e += kThreads) T[((e >> 6) * S1 + S) * FT + (e & 63)] = 0.0;
+        if (threadIdx.x < 2 * kLogTabEntries)
+            reinterpret_cast<double*>(lds_raw + tab_off)[threadIdx.x] = reinterpret_cast<const double*>(p.logtab)[threadIdx.x];   // 256 doubles
     }
     SBE_STAMP();
     __syncthreads();
@@ -1803,7 +1805,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
         const int RW = 1 << sh, SUB = kWave >> sh;
         const int fl = lane & (RW - 1), sub = lane >> sh;
         const bool live = fl < p.ragged_w;
-        for (int r0 = w * SUB; r0 < n_rows; r0 += 4 * SUB) {
+        for (int r0 = w * SUB; r0 < n_rows; r0 += NW * SUB) {
             const int r = r0 + sub;
             if (r < n_rows && tuple_p[(uint32_t)r / (uint32_t)S] != 0xFFu) {
                 const uint32_t t = (uint32_t)r / (uint32_t)S, st = (uint32_t)r - t * (uint32_t)S;
@@ -1847,12 +1849,24 @@ __global__ __launch_bounds__(kBlock) void k_mixture_tuple64(Mix2Params p) {
         }
     }
     SBE_STAMP();
-    const double total = block_sum((a0 + a2) + (a1 + a3), red4);
-    if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + work] = total;
+    {   // fixed-order block reduction over NW waves
+        const double wsum = wave_sum((a0 + a2) + (a1 + a3));
+        if (lane == 0) red4[w] = wsum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double total = 0.0;
+            if (NW == 4) total = (red4[0] + red4[1]) + (red4[2] + red4[3]);
+            else {
+#pragma unroll
+                for (int i = 0; i < NW; ++i) total += red4[i];
+            }
+            p.partials[(int64_t)slot * p.partials_stride + work] = total;
+        }
+    }
 #ifdef SBE_STAMPS
     SBE_STAMP();
     if (p.stamps && lane == 0) {
-        uint64_t* o = p.stamps + ((int64_t)blockIdx.x * 4 + w) * 12;
+        uint64_t* o = p.stamps + ((int64_t)blockIdx.x * 4 + (w & 3)) * 12;
         for (int i = 0; i < n_stamp; ++i) o[i] = stamp[i];
         o[7] = (uint64_t)ragged; o[8] = rt0; o[9] = wall_clock64();
     }
@@ -1941,6 +1955,95 @@ __global__ __launch_bounds__(kBlock) void k_cluster_marginals(
     if (threadIdx.x == 0) {
         out[i] = (red[0] + red[1]) + (red[2] + red[3]);
         out[(int64_t)n_av + i] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// ClusterJump.get_jump_lh (sbayes/sampling/operators.py:1679-1722) with
+// ClusterEffectProposals.expected_confounder_features (:1342-1379): for every member n of the source cluster
+//     p_conf(n,f)  = sum_{c>=1, n in group g of c} wh(n)[f][c] * pconf[g][f][x]     float32, components in order
+//     stay(n,f)    = p_conf + wh(n)[f][0] * p_source[f][x]                          float32 (mul, then add)
+//     jump(n,f)    = p_conf + wh(n)[f][0] * p_target[f][x]
+//     out[0][i]    = sum_{f not NA} log stay,   out[1][i] = sum_{f not NA} log jump  (fp64 logs and sums)
+// wh = normalize(update_weights(sample) ** (1/T_prior)) (the `wcur` of weight_tables_z_row), x = the observed state.
+// The float32 arithmetic is the reference's, operation for operation; only the product over features -- np.prod in
+// float32 there, which underflows to 0 beyond F ~ 75 -- is replaced by a sum of logs.  `pconf` are the
+// caller's tempered tables of every confounder group (global group index minus the cluster count), `p_source` /
+// `p_target` the two clusters' tempered tables (conditional_effect_mean, conditionals.py:105-122).
+// One block per member, thread <-> feature, fixed-order reduction (as k_cluster_marginals).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_jump_lh(
+    const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid, const uint8_t* __restrict__ pid,
+    const float* __restrict__ pconf /* [Gtot - G0][F][S] */, const float* __restrict__ p_source,
+    const float* __restrict__ p_target, const float* __restrict__ weights, const uint32_t* __restrict__ pattern_bits,
+    float inv_tp, int use_pow, const int32_t* __restrict__ objects, int n_members, double* __restrict__ out,
+    const f64x2_t* __restrict__ logtab, int Np, int F, int S, int C, int Fp, int G0) {
+    __shared__ f64x2_t tab[kLogTabEntries];
+    __shared__ double red[8];
+    if (threadIdx.x < kLogTabEntries) tab[threadIdx.x] = logtab[threadIdx.x];
+    __syncthreads();
+    const uint32_t tab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) f64x2_t*)tab;
+    const int i = blockIdx.x;
+    const int n = objects[i];
+    const uint32_t bits = pattern_bits[pid[n]];
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int f = threadIdx.x; f < F; f += kBlock) {
+        const uint8_t x = state[(int64_t)n * Fp + f];
+        if (x == kNA) continue;                                       // np.prod(..., where=~NAs): factor 1
+        float wc[kMaxComponents], wf[kMaxComponents];
+        weight_tables_z_row(weights + (int64_t)f * C, bits, C, inv_tp, use_pow, wc, wf);   // wc = weights_heated row
+        float pc = 0.0f;
+        for (int c = 1; c < C; ++c) {
+            const uint16_t gg = gid[(int64_t)c * Np + n];
+            if (gg != kNoGroup) pc = pc + wc[c] * pconf[((int64_t)(gg - G0) * F + f) * S + x];
+        }
+        const float ps = pc + wc[0] * p_source[(int64_t)f * S + x];
+        const float pt = pc + wc[0] * p_target[(int64_t)f * S + x];
+        acc0 += tab_log_pos((double)ps, tab_addr);
+        acc1 += tab_log_pos((double)pt, tab_addr);
+    }
+    acc0 = wave_sum(acc0);
+    acc1 = wave_sum(acc1);
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
+    if (lane == 0) { red[wid] = acc0; red[4 + wid] = acc1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[i] = (red[0] + red[1]) + (red[2] + red[3]);
+        out[(int64_t)n_members + i] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// GibbsSampleWeights.source_lh_by_feature (sbayes/sampling/operators.py:677-685): per feature
+//     out[f] = float32( sum_n log p(n,f) ),   p = sum_c source[n,f,c] * w[n,f,c]  (one-hot source: the weight of the
+//     observation's source component; 0 if none is set), p = 1 for NA observations
+// from the slot's resident source, patterns and normalised weights: the [N, F, C] weight array the reference
+// materialises (twice per call of the operator) never exists.  float32 logs like the reference's (NumPy's own float32
+// log, not bit-reproducible here: compared at float32 accuracy); the sum over objects is carried in fp64.
+// Block = 64 features x 16 object lanes; fixed-order reduction over the object lanes.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_source_lh_by_feature(
+    const uint8_t* __restrict__ state, const uint8_t* __restrict__ src, const uint8_t* __restrict__ pid,
+    const float* __restrict__ wpat, float* __restrict__ out, int N, int F, int C, int Fp) {
+    __shared__ double part[16][kWave];
+    const int fl = threadIdx.x & (kWave - 1), ol = threadIdx.x >> 6;
+    const int f = blockIdx.x * kWave + fl;
+    double acc = 0.0;
+    if (f < F) {
+        for (int n = ol; n < N; n += 16) {
+            if (state[(int64_t)n * Fp + f] == kNA) continue;
+            const uint8_t c = src[(int64_t)n * Fp + f];
+            const float p = c < C ? wpat[((int64_t)pid[n] * F + f) * C + c] : 0.0f;
+            acc += (double)logf(p);
+        }
+    }
+    part[ol][fl] = acc;
+    __syncthreads();
+    if (ol == 0 && f < F) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += part[k][fl];
+        out[f] = (float)t;
     }
 }
 

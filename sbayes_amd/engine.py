@@ -413,6 +413,29 @@ class Engine:
                                                     float(prior_temperature), _ptr(out)))
         return out
 
+    def jump_lh(self, slot, pconf, p_source, p_target, objects, prior_temperature=1.0):
+        """float64 [2, n]: log "stay" / log "jump" likelihood of each listed member of the source cluster
+        (ClusterJump.get_jump_lh, operators.py:1679-1722).  pconf: float32 [G_total - K, F, S] tempered tables of every
+        confounder group, p_source / p_target: float32 [F, S] (or [1, F, S]) tempered tables of the two clusters."""
+        fs = (self.n_features, self.n_states)
+        n_conf = self.n_groups_total - self.n_groups[0]
+        pc = _c(pconf, np.float32).reshape((-1,) + fs) if n_conf else np.zeros((0,) + fs, dtype=np.float32)
+        if pc.shape[0] != n_conf:
+            raise ValueError(f"pconf must hold the {n_conf} confounder groups' tables, got {pc.shape}")
+        ps, pt = _c(p_source, np.float32).reshape(fs), _c(p_target, np.float32).reshape(fs)
+        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        out = np.empty((2, objs.size), dtype=np.float64)
+        self._check(self._lib.sbe_jump_lh(self._h, slot, _ptr(pc) if n_conf else None, _ptr(ps), _ptr(pt), _ptr(objs),
+                                          objs.size, float(prior_temperature), _ptr(out)))
+        return out
+
+    def source_lh_by_feature(self, slot):
+        """float32 [F]: per-feature log-likelihood of the slot's source assignment under its normalised weights
+        (GibbsSampleWeights.source_lh_by_feature, operators.py:677-685)."""
+        out = np.empty(self.n_features, dtype=np.float32)
+        self._check(self._lib.sbe_source_lh_by_feature(self._h, slot, _ptr(out)))
+        return out
+
     def source_posterior(self, slot, objects, temperature=1.0, prior_temperature=1.0):
         """float32 [n, F, C]: posterior of the source assignment of the listed objects' observations
         (GibbsSampleSource.calculate_source_posterior, operators.py:554-574)."""

@@ -6,6 +6,9 @@
   calculate_source_posterior  GibbsSampleSource.calculate_source_posterior operators.py:554-574
   gibbs_sample_source         GibbsSampleSource._propose                   operators.py:495-552
   component_likelihood_given_unchanged                                     operators.py:863-928
+  jump_lh                     ClusterJump.get_jump_lh                      operators.py:1679-1722
+                              (+ ClusterEffectProposals.expected_confounder_features, :1342-1379)
+  source_lh_by_feature        GibbsSampleWeights.source_lh_by_feature      operators.py:677-685
 
 The proposal logic, RNG and accept/reject stay the reference's (out of scope); these functions
 return exactly what the reference methods return, so an operator can call them in place of its
@@ -176,3 +179,40 @@ def component_likelihood_given_unchanged(model, sample, object_subset, i_cluster
         sub = groups[:, object_subset]
         group_idx.append(np.where(sub.any(axis=0), sub.argmax(axis=0), -1).astype(np.int32))
     return eng.subset_lh(objects, tables, np.stack(group_idx), temperature)
+
+
+def jump_lh(model, sample, i_source_cluster, i_target_cluster, temperature=1.0, prior_temperature=1.0, slot=0):
+    """ClusterJump.get_jump_lh (operators.py:1679-1722): float32 [n_members] probability-like score
+    lh_jump / (lh_jump + lh_stay) of every member of the source cluster.  The tempered effect tables (a10) and the
+    per-member sums of logs come from the device -- no [N, F, C] weight array, no [N, F, S] expected-feature array on
+    the host; the O(n_members) tail (exponent 1/T, + EPS, ratio) is the reference's float32 arithmetic."""
+    eng = _engine(model)
+    _bind_slot(eng, model, sample, slot)
+    prior = model.prior.prior_cluster_effect
+    unif = np.asarray(prior.uniform_concentration_array)         # the reference uses the CLUSTER prior's uniform
+    counts = sample.feature_counts["clusters"].value             # concentration for every component (operators.py:1352)
+    kw = dict(temperature=temperature, prior_temperature=prior_temperature, unif_counts=unif)
+    p_source = eng.normalize_tables(counts[[i_source_cluster]], np.asarray(prior.concentration_array), **kw)
+    p_target = eng.normalize_tables(counts[[i_target_cluster]], np.asarray(prior.concentration_array), **kw)
+    pconf = [eng.normalize_tables(sample.feature_counts[name].value,
+                                  np.asarray(model.prior.prior_confounding_effects[name].concentration_array(sample)), **kw)
+             for name in sample.confounders]
+    pconf = np.concatenate(pconf, axis=0) if pconf else np.zeros((0,) + p_source.shape[1:], dtype=np.float32)
+    members = np.flatnonzero(sample.clusters.value[i_source_cluster])
+    logs = eng.jump_lh(slot, pconf, p_source, p_target, members, prior_temperature)
+    with np.errstate(under="ignore"):
+        lh_stay = np.exp(logs[0]).astype(np.float32)             # np.prod over features in float32 (operators.py:1707-1710)
+        lh_jump = np.exp(logs[1]).astype(np.float32)
+        lh_stay **= (1 / temperature)
+        lh_jump **= (1 / temperature)
+    lh_stay += EPS
+    lh_jump += EPS
+    return lh_jump / (lh_jump + lh_stay)
+
+
+def source_lh_by_feature(model, sample, slot=0):
+    """GibbsSampleWeights.source_lh_by_feature (operators.py:677-685) of `sample`'s source assignment under its
+    normalised weights: float32 [n_features], computed on the device from resident data."""
+    eng = _engine(model)
+    _bind_slot(eng, model, sample, slot, with_source=True)
+    return eng.source_lh_by_feature(slot)

@@ -17,6 +17,11 @@ has to cross PCIe for them:
   sbayes.sampling.operators.GibbsSampleSource.calculate_source_posterior  (operators.py:554-574)
   sbayes.sampling.operators.component_likelihood_given_unchanged          (operators.py:863-928)
   sbayes.sampling.loggers.LikelihoodLogger._write_sample                  (loggers.py:354-359)
+  sbayes.sampling.operators.ClusterJump.get_jump_lh                       (operators.py:1679-1722, with
+                                                                            expected_confounder_features :1342-1379)
+  sbayes.sampling.operators.GibbsSampleWeights._propose                   (operators.py:597-636) runs UNCHANGED, but
+        with update_weights / source_lh_by_feature (operators.py:677-685) served by the device while it runs: the two
+        [N, F, C] normalised-weight arrays it materialises per call are never built
 Proposal logic, RNG use and everything else of the operators stay the reference's."""
 from __future__ import annotations
 
@@ -119,6 +124,36 @@ def _install_operator_forms(swap):
             marginal_lh_z01[1] *= np.exp(log_geo_prior_ratio / self.prior_temperature / self.geo_scaler)
         return marginal_lh_z01[1] / (marginal_lh_z01[0] + marginal_lh_z01[1] + ref_ops.EPS)
 
+    def get_jump_lh(self, sample, i_source_cluster, i_target_cluster):
+        """ClusterJump.get_jump_lh (operators.py:1679-1722) on the device."""
+        return my_ops.jump_lh(self.model, sample, i_source_cluster, i_target_cluster, self.temperature,
+                              self.prior_temperature)
+
+    class _DeviceWeights:
+        """What update_weights(sample) returns while GibbsSampleWeights._propose runs: a handle on the sample whose
+        normalised weights are meant (the device derives them from the resident patterns; nothing is materialised)."""
+        def __init__(self, sample):
+            self.sample = sample
+
+    reference_propose = ref_ops.GibbsSampleWeights._propose
+
+    def gibbs_weights_propose(self, sample, **kwargs):
+        """GibbsSampleWeights._propose (operators.py:597-636): the reference's own method body, called as is; for its
+        duration `update_weights` yields a handle instead of the [N, F, C] array and `source_lh_by_feature` evaluates
+        that handle's sample on the device."""
+        model = self.model
+        saved_update, saved_lh = ref_ops.update_weights, ref_ops.GibbsSampleWeights.__dict__["source_lh_by_feature"]
+        ref_ops.update_weights = lambda s, caching=True: _DeviceWeights(s)
+        ref_ops.GibbsSampleWeights.source_lh_by_feature = staticmethod(
+            lambda source, weights, na_features: my_ops.source_lh_by_feature(model, weights.sample))
+        try:
+            return reference_propose(self, sample, **kwargs)
+        finally:
+            ref_ops.update_weights = saved_update
+            ref_ops.GibbsSampleWeights.source_lh_by_feature = saved_lh
+
+    swap(ref_ops.ClusterJump, "get_jump_lh", get_jump_lh)
+    swap(ref_ops.GibbsSampleWeights, "_propose", gibbs_weights_propose)
     swap(ref_ops.AlterCluster, "compute_cluster_posterior", compute_cluster_posterior)
     swap(ref_ops.AlterClusterWide, "compute_raw_cluster_probs", compute_raw_cluster_probs)
     swap(ref_ops.GibbsSampleSource, "calculate_source_posterior", calculate_source_posterior)

@@ -48,6 +48,8 @@ COMPARE = {
     "observation_lh_exact": "exact", "na_values": "exact",
     "dirichlet_logpdf": (2e-6, 1e-6),        # float32 per feature in the reference
     "cluster_marginals": (1e-9, 1e-9),       # log-space sums on the device vs log of the linear-space product
+    "jump_lh": (1e-9, 1e-9),                 # fp64 sums of logs of float32 values (table-driven log on the device)
+    "source_lh_by_feature": (2e-6, 1e-5),    # float32 logs (NumPy's own float32 log is not bit-reproducible)
     "source_posterior": "exact_at_t1",       # bit-exact at temperature 1, float32 powf tolerance when tempered
     "subset_lh": "exact_at_t1",
 }
@@ -111,7 +113,7 @@ def _wrap(name):
 
 for _name in ("normalize_tables", "dirichlet_logpdf", "effect_counts", "set_groups", "set_concentration", "set_counts",
               "set_source", "set_weights", "update_probs", "cluster_marginals", "source_posterior", "subset_lh",
-              "normalize_weights", "observation_lh_exact"):
+              "normalize_weights", "observation_lh_exact", "jump_lh", "source_lh_by_feature"):
     setattr(RecordingEngine, _name, _wrap(_name))
 
 

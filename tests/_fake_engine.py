@@ -143,5 +143,38 @@ class FakeEngine:
         out[self.na_values()[objects]] = 1.0
         return out ** np.float32(1 / temperature) if temperature != 1.0 else out
 
+    def jump_lh(self, slot, pconf, p_source, p_target, objects, prior_temperature=1.0):
+        """float64 [2, n]: sums of logs of the reference's float32 per-feature stay / jump likelihoods."""
+        self.calls.append(("jump_lh", len(objects)))
+        s = self.slots[slot]
+        C = len(s["groups"])
+        groups = [s["groups"][c] for c in range(C)]
+        objects = np.asarray(objects)
+        wh = orc.weights_heated(s["weights"], orc.has_components(groups), prior_temperature)[objects]
+        feats = self.features[objects]
+        pconf = np.asarray(pconf, dtype=np.float32).reshape((-1,) + self.features.shape[1:])
+        expected = np.zeros(feats.shape, dtype=np.float32)
+        off = 0
+        for c in range(1, C):
+            for i_g, g in enumerate(groups[c]):
+                m = g[objects]
+                expected[m] += wh[m][:, :, c][..., None] * pconf[off + i_g][None]
+            off += groups[c].shape[0]
+        ps = np.asarray(p_source, dtype=np.float32).reshape(self.features.shape[1:])
+        pt = np.asarray(p_target, dtype=np.float32).reshape(self.features.shape[1:])
+        stay = np.sum(feats * (expected + wh[:, :, 0][..., None] * ps[None]), axis=-1)
+        jump = np.sum(feats * (expected + wh[:, :, 0][..., None] * pt[None]), axis=-1)
+        valid = ~self.na_values()[objects]
+        with np.errstate(divide="ignore"):
+            return np.stack([np.where(valid, np.log(stay.astype(np.float64)), 0.0).sum(axis=-1),
+                             np.where(valid, np.log(jump.astype(np.float64)), 0.0).sum(axis=-1)])
+
+    def source_lh_by_feature(self, slot):
+        self.calls.append(("source_lh_by_feature",))
+        s = self.slots[slot]
+        groups = [s["groups"][c] for c in range(len(s["groups"]))]
+        w = orc.normalize_weights(s["weights"], orc.has_components(groups))
+        return orc.source_lh_by_feature(s["source"], w, self.na_values())
+
     def normalize_weights(self, weights, has_components):
         return orc.normalize_weights(np.asarray(weights, dtype=np.float32), np.asarray(has_components, dtype=bool))

@@ -379,6 +379,47 @@ def source_prior_case(model, sample):
                 logger_row_f32=row.astype(np.float32))
 
 
+def operator_extras_case(model, data, sample, mcmc_cfg, max_pairs=None):
+    """VERDICT r1 missing #2 / #3: ClusterJump.get_jump_lh (operators.py:1679-1722, with
+    ClusterEffectProposals.expected_confounder_features :1342-1379) for every ordered cluster pair, plain and
+    MC3-tempered -- the operator's own output plus the float32 per-feature values it multiplies (recomputed here from
+    the reference's own functions, operators.py:1684-1709) -- and GibbsSampleWeights.source_lh_by_feature
+    (operators.py:677-685) on the sample."""
+    from sbayes.sampling.operators import ClusterEffectProposals, GibbsSampleWeights, get_operator_schedule
+    out = {}
+    feats, na = data.features.values, data.features.na_values
+    prior = model.prior.prior_cluster_effect
+    for tag, (temp, ptemp) in {"t1": (1.0, 1.0), "mc3": (1.3, 1.5)}.items():
+        ops = get_operator_schedule(mcmc_cfg.operators, model, data, temperature=temp, prior_temperature=ptemp,
+                                    sample_from_prior=False)
+        jump = ops.get("cluster_jump_gibbsish")
+        if jump is None or sample.n_clusters < 2:
+            continue
+        w = update_weights(sample)
+        wh = normalize(w ** (1 / ptemp), axis=-1)
+        p_conf_all = ClusterEffectProposals.expected_confounder_features(model, sample, temperature=temp,
+                                                                         prior_temperature=ptemp)
+        pairs = [(a, b) for a in range(sample.n_clusters) for b in range(sample.n_clusters)
+                 if a != b and sample.clusters.value[a].any()]
+        for i_s, i_t in pairs[:max_pairs]:
+            if True:
+                key = f"jp_{tag}_s{i_s}_t{i_t}"
+                out[key] = np.asarray(jump.get_jump_lh(sample, i_s, i_t))
+                members = sample.clusters.value[i_s]
+                w_clust = wh[members, :, 0]
+                tabs = [conditional_effect_mean(prior_counts=prior.concentration_array,
+                                                feature_counts=sample.feature_counts["clusters"].value[[k]],
+                                                unif_counts=prior.uniform_concentration_array,
+                                                temperature=temp, prior_temperature=ptemp) for k in (i_s, i_t)]
+                for name, tab in zip(("stay", "jump"), tabs):
+                    pf = np.sum(feats[members] * (p_conf_all[members] + w_clust[..., np.newaxis] * tab), axis=-1)
+                    out[f"{key}_{name}_pf"] = pf[:16]                      # (the first 16 members: fixture size)
+                    out[f"{key}_{name}_pf_crc"] = np.int64(crc(pf))        # ... and a CRC of all of them
+    out["jp_cluster_unif"] = np.asarray(prior.uniform_concentration_array, dtype=np.float64)
+    out["swl_lh_by_feature"] = GibbsSampleWeights.source_lh_by_feature(sample.source.value, update_weights(sample), na)
+    return out
+
+
 def real_fixture(tag: str, config_path: Path, n_trace_steps: int, seed: int):
     from sbayes.experiment_setup import Experiment
     from sbayes.sampling.initializers import SbayesInitializer
@@ -409,6 +450,7 @@ def real_fixture(tag: str, config_path: Path, n_trace_steps: int, seed: int):
         extra.update(cluster_posterior_case(model, data, sample, mcmc_cfg))
         extra.update(source_posterior_case(model, data, sample, mcmc_cfg))
         extra.update(source_prior_case(model, sample))
+        extra.update(operator_extras_case(model, data, sample, mcmc_cfg))
         meta = dict(name=tag, shape=list(data.features.values.shape),
                     component_names=sample.component_names,
                     groups=[int(sample.n_groups(k)) for k in sample.component_names], **scal, **dig)
@@ -570,6 +612,7 @@ def synthetic_trace_fixture(name: str, n_steps: int, seed: int):
             assert np.array_equal(np.broadcast_to(c, want.shape), want), "reference prior tables differ from the workload's"
         extra = dict(workload=np.array(name), features_crc=np.int64(crc(data.features.values)),
                      component_names=np.array(sample.component_names))
+        extra.update(operator_extras_case(model, data, sample, mcmc_cfg, max_pairs=2))
         record_trace(name, model, data, mcmc_cfg, sample, n_steps, extra=extra)
     finally:
         os.chdir(cwd)

@@ -407,3 +407,58 @@ def test_bind_cache_sends_only_what_changed_and_never_goes_stale():
         assert _same(_token(w), rec) and not _same(_token(np.zeros_like(w)), rec)
     finally:
         release_all()
+
+
+# ---- next-heaviest operator expressions (missing #2 / #3) ---------------------------------------------
+def _extras_case(name):
+    from tests.test_operator_extras_cpu import load_case
+    fx, z = load_case(name)
+    names = fx.meta["component_names"]
+    model, sample = sbm.build(fx.features, fx.states_per_feature, names, fx.groups, fx.conc, fx.weights, fx.source,
+                              counts=fx.counts)
+    model.prior.prior_cluster_effect.uniform_concentration_array = z["jp_cluster_unif"]
+    return fx, z, model, sample
+
+
+@pytest.mark.parametrize("name", ["south_america", "cfg1", "headline"])
+def test_jump_lh_matches_the_reference_operator(name):
+    """ClusterJump.get_jump_lh (operators.py:1679-1722) with expected_confounder_features (:1342-1379): the drop-in
+    form against the reference operator's own output (float32 products there, sums of fp64 logs here: 2e-5), the
+    device's sums of logs against the oracle's (1e-10: same float32 per-feature values, pinned bit for bit to the
+    reference's by tests/test_operator_extras_cpu.py)."""
+    from sbayes_amd.operators import jump_lh
+    from tests.test_operator_extras_cpu import jump_keys
+    fx, z, model, sample = _extras_case(name)
+    eng = model.likelihood.engine
+    unif = z["jp_cluster_unif"]
+    for key in jump_keys(z):
+        _, tag, s, t = key.split("_")
+        temp, ptemp = (1.0, 1.0) if tag == "t1" else (1.3, 1.5)
+        i_s, i_t = int(s[1:]), int(t[1:])
+        got = jump_lh(model, sample, i_s, i_t, temperature=temp, prior_temperature=ptemp)
+        assert got.dtype == np.float32 and got.shape == z[key].shape
+        np.testing.assert_allclose(got, z[key], rtol=2e-5, atol=1e-6, err_msg=key)
+        # engine level: the two sums of logs
+        want = orc.jump_log_lh(fx.features, fx.na_values, fx.groups, fx.counts, fx.conc, unif, fx.weights, i_s, i_t, temp, ptemp)
+        kw = dict(temperature=temp, prior_temperature=ptemp, unif_counts=unif)
+        tabs = [eng.normalize_tables(fx.counts[0][[k]], fx.conc[0], **kw) for k in (i_s, i_t)]
+        pconf = np.concatenate([eng.normalize_tables(fx.counts[c], fx.conc[c], **kw) for c in range(1, fx.n_comp)])
+        logs = eng.jump_lh(0, pconf, tabs[0], tabs[1], np.flatnonzero(fx.groups[0][i_s]), ptemp)
+        rtol = 1e-10 if tag == "t1" else 2e-6            # (tempered weights go through the device's float32 powf)
+        np.testing.assert_allclose(logs, want, rtol=rtol, atol=1e-12, err_msg=key)
+
+
+@pytest.mark.parametrize("name", ["south_america", "test_files", "cfg1", "headline"])
+def test_source_lh_by_feature_matches_the_reference(name):
+    """GibbsSampleWeights.source_lh_by_feature (operators.py:677-685): float32 [F] from the device's resident source,
+    patterns and weights against the reference's value (float32 logs on both sides: 2e-6 relative)."""
+    from sbayes_amd.operators import source_lh_by_feature
+    fx, z, model, sample = _extras_case(name)
+    got = source_lh_by_feature(model, sample)
+    assert got.dtype == np.float32 and got.shape == (fx.features.shape[1],)
+    np.testing.assert_allclose(got, z["swl_lh_by_feature"], rtol=2e-6, atol=1e-5)
+    # new weights through the same slot (what GibbsSampleWeights._propose does between its two evaluations)
+    w2 = np.random.default_rng(4).dirichlet(np.ones(fx.n_comp), size=fx.features.shape[1]).astype(np.float32)
+    sample.weights.set_value(w2)
+    want = orc.source_lh_by_feature(fx.source, orc.normalize_weights(w2, orc.has_components(fx.groups)), fx.na_values)
+    np.testing.assert_allclose(source_lh_by_feature(model, sample), want, rtol=2e-6, atol=1e-5)

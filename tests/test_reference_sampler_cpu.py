@@ -123,9 +123,11 @@ def test_reference_sampler_with_device_operator_forms(tag, src, n_steps, monkeyp
     assert np.array_equal(patched[3], plain[3])
     eng = next(iter(patched[4].values()))
     kinds = {c[0] for c in eng.calls}
-    assert {"cluster_marginals", "source_posterior", "subset_lh"} <= kinds        # the operator forms really ran
+    assert {"cluster_marginals", "source_posterior", "subset_lh", "source_lh_by_feature"} <= kinds   # the operator forms really ran
+    if tag == "south_america":                                                    # (test_files has one cluster: no jumps)
+        assert "jump_lh" in kinds and "ClusterJump" in {t[2] for t in patched[0]}
     names = {t[2] for t in patched[0]}
-    assert {"AlterCluster", "AlterClusterWide", "GibbsSampleSource"} <= names, names        # every patched form was hit
+    assert {"AlterCluster", "AlterClusterWide", "GibbsSampleSource", "GibbsSampleWeights"} <= names, names   # every patched form was hit
     # ... through the bind cache: far fewer uploads than evaluations (and, above, the same chain)
     n_eval = sum(c[0] in ("cluster_marginals", "source_posterior") for c in eng.calls)
     n_counts = sum(c[0] == "set_counts" for c in eng.calls)
