@@ -2019,32 +2019,33 @@ __global__ __launch_bounds__(kBlock) void k_jump_lh(
 //     observation's source component; 0 if none is set), p = 1 for NA observations
 // from the slot's resident source, patterns and normalised weights: the [N, F, C] weight array the reference
 // materialises (twice per call of the operator) never exists.  float32 logs like the reference's (NumPy's own float32
-// log, not bit-reproducible here: compared at float32 accuracy); the sum over objects is carried in fp64.
-// Block = 64 features x 16 object lanes; fixed-order reduction over the object lanes.
+// log is not bit-reproducible here: compared at float32 accuracy) and the reference's summation: float32, objects in
+// order (np.sum(axis=0) of a C-ordered float32 [N, F] array adds row after row).
+// Block = 64 features x 16 object lanes: sixteen objects' logs at a time, then the feature's owner adds them in order.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_source_lh_by_feature(
     const uint8_t* __restrict__ state, const uint8_t* __restrict__ src, const uint8_t* __restrict__ pid,
     const float* __restrict__ wpat, float* __restrict__ out, int N, int F, int C, int Fp) {
-    __shared__ double part[16][kWave];
+    __shared__ float part[16][kWave];
     const int fl = threadIdx.x & (kWave - 1), ol = threadIdx.x >> 6;
     const int f = blockIdx.x * kWave + fl;
-    double acc = 0.0;
-    if (f < F) {
-        for (int n = ol; n < N; n += 16) {
-            if (state[(int64_t)n * Fp + f] == kNA) continue;
+    float acc = 0.0f;                                      // float32, objects in order: np.sum(axis=0) of a float32 array
+    for (int n0 = 0; n0 < N; n0 += 16) {
+        const int n = n0 + ol;
+        float v = 0.0f;                                    // NA: p = 1, log p = 0
+        if (n < N && f < F && state[(int64_t)n * Fp + f] != kNA) {
             const uint8_t c = src[(int64_t)n * Fp + f];
-            const float p = c < C ? wpat[((int64_t)pid[n] * F + f) * C + c] : 0.0f;
-            acc += (double)logf(p);
+            v = logf(c < C ? wpat[((int64_t)pid[n] * F + f) * C + c] : 0.0f);
         }
+        part[ol][fl] = v;
+        __syncthreads();
+        if (ol == 0) {
+            const int m = min(16, N - n0);
+            for (int k = 0; k < m; ++k) acc = acc + part[k][fl];
+        }
+        __syncthreads();
     }
-    part[ol][fl] = acc;
-    __syncthreads();
-    if (ol == 0 && f < F) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += part[k][fl];
-        out[f] = (float)t;
-    }
+    if (ol == 0 && f < F) out[f] = acc;
 }
 
 // ==========================================================================================

@@ -49,7 +49,7 @@ COMPARE = {
     "dirichlet_logpdf": (2e-6, 1e-6),        # float32 per feature in the reference
     "cluster_marginals": (1e-9, 1e-9),       # log-space sums on the device vs log of the linear-space product
     "jump_lh": (1e-9, 1e-9),                 # fp64 sums of logs of float32 values (table-driven log on the device)
-    "source_lh_by_feature": (2e-6, 1e-5),    # float32 logs (NumPy's own float32 log is not bit-reproducible)
+    "source_lh_by_feature": (3e-5, 1e-5),    # float32 logs summed in float32 over the objects (N * 2^-24 / 2 at N = 1000)
     "source_posterior": "exact_at_t1",       # bit-exact at temperature 1, float32 powf tolerance when tempered
     "subset_lh": "exact_at_t1",
 }

@@ -451,14 +451,18 @@ def test_jump_lh_matches_the_reference_operator(name):
 @pytest.mark.parametrize("name", ["south_america", "test_files", "cfg1", "headline"])
 def test_source_lh_by_feature_matches_the_reference(name):
     """GibbsSampleWeights.source_lh_by_feature (operators.py:677-685): float32 [F] from the device's resident source,
-    patterns and weights against the reference's value (float32 logs on both sides: 2e-6 relative)."""
+    patterns and weights against the reference's value.  Tolerance: both sides take float32 logs (NumPy's own SIMD
+    log there, logf here: ~1 ulp apart) and add them up in float32 in object order; a float32 running sum of N terms
+    carries up to N * 2^-24 relative error, and one-ulp differences in the terms move its rounding decisions, so the two
+    sums agree to a fraction of that bound, not to float32 epsilon."""
     from sbayes_amd.operators import source_lh_by_feature
     fx, z, model, sample = _extras_case(name)
     got = source_lh_by_feature(model, sample)
     assert got.dtype == np.float32 and got.shape == (fx.features.shape[1],)
-    np.testing.assert_allclose(got, z["swl_lh_by_feature"], rtol=2e-6, atol=1e-5)
+    rtol = max(2e-6, 0.5 * fx.features.shape[0] * 2.0 ** -24)
+    np.testing.assert_allclose(got, z["swl_lh_by_feature"], rtol=rtol, atol=1e-5)
     # new weights through the same slot (what GibbsSampleWeights._propose does between its two evaluations)
     w2 = np.random.default_rng(4).dirichlet(np.ones(fx.n_comp), size=fx.features.shape[1]).astype(np.float32)
     sample.weights.set_value(w2)
     want = orc.source_lh_by_feature(fx.source, orc.normalize_weights(w2, orc.has_components(fx.groups)), fx.na_values)
-    np.testing.assert_allclose(source_lh_by_feature(model, sample), want, rtol=2e-6, atol=1e-5)
+    np.testing.assert_allclose(source_lh_by_feature(model, sample), want, rtol=rtol, atol=1e-5)
