@@ -322,6 +322,39 @@ def secondary_figures(eng, wl, B, args):
         return res
     out["f3_one_call_gibbs_steps_per_s"] = round(_rate(one_call_gibbs_step), 1)
     release_all()
+
+    # batched multi-chain step (sbe_step_batch): 64 chains' deltas (a cluster move + 20 changed source rows each, as in
+    # the one-call step above) in ONE engine call per sweep; the deltas are prepared outside the timed loop (proposal
+    # logic belongs to the sampler), four different sweeps cycled
+    from sbayes_amd.resident import ResidentChainBatch
+    n_chains = 64
+    batch = ResidentChainBatch(model, [sample] * n_chains, device=eng.device)
+    sweeps = []
+    for _ in range(4):
+        cl = np.broadcast_to(wl.clusters, (n_chains,) + wl.clusters.shape).copy()
+        objs_all, ptr = [], [0]
+        for i in range(n_chains):
+            n = int(rng.integers(0, n_obj))
+            cl[i][:, n] = False
+            cl[i][int(rng.integers(0, cl.shape[1])), n] = True
+            objs = np.unique(np.append(rng.integers(0, n_obj, size=19), n)).astype(np.int32)
+            objs_all.append(objs)
+            ptr.append(ptr[-1] + objs.size)
+        objs_cat = np.concatenate(objs_all)
+        sweeps.append((cl, np.array(ptr, dtype=np.int32), objs_cat, np.ascontiguousarray(wl.source[objs_cat])))
+    state = {"k": 0}
+
+    def batched_sweep():
+        cl, ptr, objs_cat, rows = sweeps[state["k"] % 4]
+        state["k"] += 1
+        res = batch.step_arrays(cl, None, ptr, objs_cat, rows)
+        batch.accept()
+        return res
+    sweeps_per_s = _rate(batched_sweep, 0.5, 20)
+    out["f2_batched_steps_per_s"] = round(sweeps_per_s * n_chains, 1)
+    out["f2_batched_chains"] = n_chains
+    out["f2_batched_sweep_us"] = round(1e6 / sweeps_per_s, 1)
+    batch.close()
     return out
 
 

@@ -341,6 +341,27 @@ int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters
              const float* weights, double* group_logliks_out, double* mixture_out,
              uint8_t* changed_groups_out);
 
+/* ---- batched multi-chain step: one sbe_step for each of n_chains independent chains, in ONE call ------------------
+ * The reference steps its chains one after the other in one Python loop (MCMC.generate_samples,
+ * sbayes/sampling/mcmc.py:237-241; MC3 workers, sbayes/mcmc_setup.py:528-534); chains are independent, so their
+ * candidates are built by one launch (chain <-> blockIdx.y), evaluated by one launch of the fused mixture kernel over
+ * the candidate slots and finished by one reduction launch: one synchronisation per batch, the per-chain host work
+ * spread over a few worker threads.  Chain i: current slot cur_slots[i], candidate slot cand_slots[i] (all distinct).
+ *   clusters       bool [n_chains][K][N] (chain i's block is read iff clusters_mask == NULL or clusters_mask[i] != 0),
+ *                  or NULL: no chain changes its clusters
+ *   rows_ptr       [n_chains + 1], rows_ptr[0] = 0: chain i's changed objects are changed_objects[rows_ptr[i] ..
+ *                  rows_ptr[i+1]) and its rows source_rows[rows_ptr[i] ..) (bool [.][F][C]); at most 256 per chain
+ *   weights        float32 [n_chains][F][C] (read iff weights_mask == NULL or weights_mask[i] != 0), or NULL
+ *   out            group_logliks_out float64 [n_chains][G_total], mixture_out float64 [n_chains],
+ *                  changed_groups_out bool [n_chains][G_total] (may be NULL)
+ * Same numbers as n_chains calls of sbe_step (bit for bit for counts, tables and per-group values; the mixture scalar to
+ * rounding: its block geometry depends on the launch's batch size).  Accept = swap a chain's two slots, reject = nothing. */
+int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const int32_t* cand_slots,
+                   const uint8_t* clusters, const uint8_t* clusters_mask, const int32_t* rows_ptr,
+                   const int32_t* changed_objects, const uint8_t* source_rows, const float* weights,
+                   const uint8_t* weights_mask, double* group_logliks_out, double* mixture_out,
+                   uint8_t* changed_groups_out);
+
 /* One MCMC step of the Gibbs source operator on the resident state (GibbsSampleSource._propose,
    sbayes/sampling/operators.py:495-552, + the likelihoods the MH ratio needs): candidate slot = current slot with the
    source of the listed objects redrawn from its posterior on the device (z: the caller's uniforms [n_sub][F], drawn

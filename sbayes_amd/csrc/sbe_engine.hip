@@ -12,7 +12,12 @@
 #include <cstdio>
 #include <cstring>
 #include <chrono>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace sbe;
@@ -83,7 +88,7 @@ struct sbe_engine {
     uint32_t* d_rowoff = nullptr;  // [slots][C+1][Np] LDS byte offsets of k_mixture_rows (k_rowoff), or null
     int rows_ft = 0;               // tile width of k_mixture_rows (32 / 16; 0: its LDS image does not fit, or C > 4)
     std::vector<uint64_t> rowoff_epoch;   // per slot: Slot::group_epoch the device array was built from
-    uint64_t epoch_counter = 0;
+    std::atomic<uint64_t> epoch_counter{0};
     uint8_t* d_tid = nullptr;      // [slots][Np] group-tuple index per object (k_mixture_combo)
     uint16_t* d_tuple_g = nullptr; // [slots][kMaxTuples][kMaxComponents]
     uint8_t* d_tuple_p = nullptr;  // [slots][kMaxTuples]
@@ -108,6 +113,14 @@ struct sbe_engine {
     uint8_t* h_io = nullptr; uint8_t* d_io = nullptr; size_t io_bytes = 0;  // host-mapped pinned: small inputs / outputs of
                                                                             // latency-bound calls, read / written in place
     uint8_t* h_step = nullptr;     uint8_t* d_step_host = nullptr;   // mapped: [Gtot] f64 | [ST_WORDS] i32 | [Gtot] u8
+    // batched steps (sbe_step_batch): one lane per chain of the batch = its own payload block, result block,
+    // per-feature buffer and change stamps (lane 0 of the single-step calls is the set of members above)
+    struct Lane { uint8_t* h_payload; uint8_t* d_payload; uint8_t* h_step; uint8_t* d_step_host; float* d_pf;
+                  uint32_t* d_stamp; uint32_t step_id; };
+    std::vector<Lane> lanes;
+    uint8_t* d_batch_meta = nullptr; size_t batch_meta_bytes = 0;     // device copy of the batch's StepCore / StepFinish / slot lists
+    struct Pool;                                                      // host worker threads of sbe_step_batch (lazily started)
+    Pool* pool = nullptr;
     uint8_t* d_scratch = nullptr;  size_t scratch_bytes = 0;     // general staging
     uint8_t* h_pinned = nullptr;   size_t pinned_bytes = 0;      // pinned D2H staging
     uint8_t* h_arena = nullptr;    size_t arena_bytes = 0, arena_off = 0;   // pinned H2D staging ring
@@ -121,6 +134,58 @@ struct sbe_engine {
     int64_t probs_t_elems() const { return (int64_t)n_ftiles * tile_tab_elems(); }
     int64_t wpat_tile_elems() const { return (int64_t)Pmax * C * ft; }
     int64_t wpat_t_elems() const { return (int64_t)n_ftiles * wpat_tile_elems(); }
+};
+
+// Host worker threads of sbe_step_batch: run job(0..n-1) on the workers and the calling thread.
+struct sbe_engine::Pool {
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::function<void(int)> job;      // job(i) for i in [0, n_items)
+    int n_items = 0, next = 0, done = 0;
+    uint64_t generation = 0;
+    bool stop = false;
+
+    explicit Pool(int n_threads) {
+        for (int t = 0; t < n_threads; ++t) workers.emplace_back([this] { loop(); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv_work.notify_all();
+        for (auto& w : workers) w.join();
+    }
+    void loop() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv_work.wait(lk, [&] { return stop || (generation != seen && next < n_items); });
+            if (stop) return;
+            while (next < n_items) {
+                const int i = next++;
+                lk.unlock();
+                job(i);
+                lk.lock();
+                if (++done == n_items) cv_done.notify_all();
+            }
+            seen = generation;
+        }
+    }
+    // run job(0..n-1) on the workers and the calling thread; returns when all are done
+    void run(int n, std::function<void(int)> f) {
+        std::unique_lock<std::mutex> lk(m);
+        job = std::move(f); n_items = n; next = 0; done = 0; ++generation;
+        lk.unlock();
+        cv_work.notify_all();
+        lk.lock();
+        while (next < n_items) {
+            const int i = next++;
+            lk.unlock();
+            job(i);
+            lk.lock();
+            ++done;
+        }
+        cv_done.wait(lk, [&] { return done == n_items; });
+    }
 };
 
 namespace {
@@ -516,9 +581,14 @@ void launch_rows(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipS
 
 // Enqueue the dominant kernel (optionally bracketed by an event pair) and the fixed-order
 // partial reduction.  mode: LOG_PER_OBS / LOG_PRODUCT.
+// Slots: first_slot .. first_slot+n-1, or (batched steps) the n slots listed in `slots` (host) / `d_slots` (the same
+// list, device-visible); then `d_fins` holds one step epilogue per listed slot.
 int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev_a, hipEvent_t ev_b,
-                   const StepFinish* fin = nullptr) {
-    const int P = max_patterns(e, first_slot, n);
+                   const StepFinish* fin = nullptr, const int32_t* slots = nullptr, const int32_t* d_slots = nullptr,
+                   const StepFinish* d_fins = nullptr) {
+    auto slot_at = [&](int i) { return slots ? (int)slots[i] : first_slot + i; };
+    int P = 1;
+    for (int i = 0; i < n; ++i) P = std::max<int>(P, (int)e->slots[slot_at(i)].patterns.size());
     const bool onehot = e->opt_kernel == SBE_MIXTURE_ONEHOT || e->opt_kernel == SBE_MIXTURE_ONEHOT_GENERAL;
     MixGeom g = mix_geometry_v2(e, P, n);
     if (!g.ft) return fail(e, SBE_ERR_ARG, "probability tables too large for LDS staging (G_total=%d, S=%d)", e->Gtot, e->S);
@@ -528,7 +598,8 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     int KT = 0;
     const bool force_combo = e->opt_kernel == SBE_MIXTURE_PACKED_TUPLE || e->opt_kernel == SBE_MIXTURE_PACKED_TUPLE_LDS;
     bool combo = e->opt_kernel == SBE_MIXTURE_PACKED || e->opt_kernel == SBE_MIXTURE_ONEHOT || force_combo;
-    for (int sl = first_slot; sl < first_slot + n && combo; ++sl) {
+    for (int i = 0; i < n && combo; ++i) {
+        const int sl = slot_at(i);
         if (e->slots[sl].n_tuples == 0) combo = false;
         KT = std::max(KT, e->slots[sl].n_tuples);
     }
@@ -588,14 +659,14 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
         g.n_blocks = g.n_chunks * n_t; g.lds_bytes = image;
         // per-object row offsets of the slots whose group ids changed since their offsets were built
         bool stale = false;
-        for (int sl = first_slot; sl < first_slot + n; ++sl) stale |= e->rowoff_epoch[sl] != e->slots[sl].group_epoch;
+        for (int i = 0; i < n; ++i) stale |= e->rowoff_epoch[slot_at(i)] != e->slots[slot_at(i)].group_epoch;
         if (stale) {
             const int cells = (e->C + 1) * e->Np;
             k_rowoff<<<dim3(div_up(cells, 256), n), 256, 0, e->stream>>>(
-                e->d_gid, e->d_pid, e->d_rowoff, (int64_t)e->C * e->Np, e->Np, (int64_t)cells, first_slot, e->N, e->Np,
+                e->d_gid, e->d_pid, e->d_rowoff, (int64_t)e->C * e->Np, e->Np, (int64_t)cells, first_slot, d_slots, e->N, e->Np,
                 e->C, e->Gtot, (uint32_t)((e->S + 1) * rft * 4), (uint32_t)(((e->C + 1) / 2) * rft * 16));
             HIPCHK(e, hipGetLastError());
-            for (int sl = first_slot; sl < first_slot + n; ++sl) e->rowoff_epoch[sl] = e->slots[sl].group_epoch;
+            for (int i = 0; i < n; ++i) e->rowoff_epoch[slot_at(i)] = e->slots[slot_at(i)].group_epoch;
         }
     }
     if (g.n_blocks > e->partials_stride) return fail(e, SBE_ERR_STATE, "internal: partials buffer too small (%d > %lld)", g.n_blocks, (long long)e->partials_stride);
@@ -622,6 +693,7 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
         p.probs_t = e->d_probs_t; p.probs_t_stride = e->probs_t_elems();
         p.wpat_t = e->d_wpat_t; p.wpat_t_stride = e->wpat_t_elems(); p.wpat_tile_stride = (int)e->wpat_tile_elems();
         p.partials = e->d_partials; p.partials_stride = e->partials_stride; p.first_slot = first_slot;
+        p.slot_list = d_slots;
         p.n_work = g.n_blocks; p.n_batch = n;
         p.slot_groups = slot_groups; p.slots_per_group = slots_per_group;
         p.tid = e->d_tid; p.tid_stride = e->Np;
@@ -682,8 +754,9 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     }
     if (ev_b) HIPCHK(e, hipEventRecord(ev_b, e->stream));
     HIPCHK(e, hipGetLastError());
-    k_reduce_partials<<<n + (fin ? 1 : 0), kBlock, 0, e->stream>>>(e->d_partials, e->partials_stride, g.n_blocks,
-                                                                  e->d_results, first_slot, n, fin ? *fin : StepFinish{});
+    k_reduce_partials<<<n + (d_fins ? n : (fin ? 1 : 0)), kBlock, 0, e->stream>>>(e->d_partials, e->partials_stride, g.n_blocks,
+                                                                  e->d_results, first_slot, n, fin ? *fin : StepFinish{},
+                                                                  d_slots, d_fins);
     HIPCHK(e, hipGetLastError());
     return SBE_OK;
 }
@@ -757,6 +830,14 @@ int sbe_destroy(sbe_engine* e) {
     if (!e) return SBE_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    delete e->pool;
+    for (auto& ln : e->lanes) {
+        if (ln.h_payload) (void)hipHostFree(ln.h_payload);
+        if (ln.h_step) (void)hipHostFree(ln.h_step);
+        if (ln.d_pf) (void)hipFree(ln.d_pf);
+        if (ln.d_stamp) (void)hipFree(ln.d_stamp);
+    }
+    if (e->d_batch_meta) (void)hipFree(e->d_batch_meta);
     if (e->h_step) (void)hipHostFree(e->h_step);
     if (e->h_step_payload) (void)hipHostFree(e->h_step_payload);
     if (e->h_io) (void)hipHostFree(e->h_io);
@@ -1993,11 +2074,18 @@ struct CoreInputs {
     int P = 1;                           // has_components patterns of the candidate
 };
 
-// kernel 1 of the one-call steps: candidate slot = current slot + inputs, count delta, every table
-int launch_step_core(sbe_engine* e, int cur_slot, int cand_slot, const CoreInputs& in) {
+// the single-step calls' lane: the engine's own payload / result blocks
+sbe_engine::Lane lane0(sbe_engine* e) {
+    return sbe_engine::Lane{e->h_step_payload, e->d_step_payload, e->h_step, e->d_step_host, e->d_step_pf, e->d_step_stamp, e->step_id};
+}
+
+// kernel 1 of the one-call steps: candidate slot = current slot + inputs, count delta, every table.
+// build_step_core fills the kernel's argument block for one chain (lane); the caller launches it.
+int build_step_core(sbe_engine* e, sbe_engine::Lane& lane, int cur_slot, int cand_slot, const CoreInputs& in,
+                    StepCore& a, size_t& lds_out, int& n_blocks_out) {
     const int N = e->N, Np = e->Np, F = e->F, C = e->C;
     const bool regroup = in.ids_new != nullptr;
-    StepCore a{};
+    a = StepCore{};
     uint32_t run = 0;
     auto seg = [&](auto* base, int64_t elems, const void* other_src) {       // per-slot array `base`, elems per slot
         const int64_t bytes = elems * (int64_t)sizeof(*base);
@@ -2045,12 +2133,12 @@ int launch_step_core(sbe_engine* e, int cur_slot, int cand_slot, const CoreInput
     a.conc = e->d_conc;
     a.probs = e->d_probs + (int64_t)cand_slot * e->table_elems();
     a.probs_t = e->d_probs_t + (int64_t)cand_slot * e->probs_t_elems();
-    a.per_feature = e->d_step_pf;
-    if (++e->step_id == 0) {                  // stamp wrap-around (2^32 steps): start over from clean stamps
-        HIPCHK(e, hipMemsetAsync(e->d_step_stamp, 0, e->Gtot * sizeof(uint32_t), e->stream));
-        e->step_id = 1;
+    a.per_feature = lane.d_pf;
+    if (++lane.step_id == 0) {                // stamp wrap-around (2^32 steps): start over from clean stamps
+        HIPCHK(e, hipMemsetAsync(lane.d_stamp, 0, e->Gtot * sizeof(uint32_t), e->stream));
+        lane.step_id = 1;
     }
-    a.stamp = e->d_step_stamp; a.step_id = e->step_id;
+    a.stamp = lane.d_stamp; a.step_id = lane.step_id;
     a.Np = Np; a.S = e->S; a.Gtot = e->Gtot; a.ft = e->ft;
     a.ftc = (int)std::max<int64_t>(1, std::min<int64_t>(8, 2048 / ((int64_t)e->Gtot * e->S)));
     a.n_tile_blocks = div_up(F, a.ftc);
@@ -2062,8 +2150,19 @@ int launch_step_core(sbe_engine* e, int cur_slot, int cand_slot, const CoreInput
     a.P = in.P; a.Pmax = e->Pmax; a.n_weight_blocks = div_up((int64_t)in.P * F, kBlock);
     const int64_t E = (int64_t)e->Gtot * a.ftc * e->S, R = (int64_t)e->Gtot * a.ftc;
     const size_t lds = (size_t)((E * 4 + 15) / 16 * 16) + (size_t)(2 * E + R) * sizeof(double);
-    const int copy_blocks = (int)std::min<int64_t>(div_up(run, 1024), 2 * e->compute_units);
-    k_step_core<<<a.n_tile_blocks + a.n_weight_blocks + std::max(copy_blocks, 1), kBlock, lds, e->stream>>>(a);
+    a.n_copy_blocks = std::max(1, (int)std::min<int64_t>(div_up(run, 1024), 2 * e->compute_units));
+    lds_out = lds;
+    n_blocks_out = a.n_tile_blocks + a.n_weight_blocks + a.n_copy_blocks;
+    return SBE_OK;
+}
+
+int launch_step_core(sbe_engine* e, int cur_slot, int cand_slot, const CoreInputs& in) {
+    sbe_engine::Lane lane = lane0(e);
+    StepCore a; size_t lds = 0; int n_blocks = 0;
+    int rc = build_step_core(e, lane, cur_slot, cand_slot, in, a, lds, n_blocks);
+    e->step_id = lane.step_id;
+    if (rc) return rc;
+    k_step_core<<<n_blocks, kBlock, lds, e->stream>>>(a);
     HIPCHK(e, hipGetLastError());
     return SBE_OK;
 }
@@ -2073,32 +2172,37 @@ inline size_t step_host_lq_offset(const sbe_engine* e) {
     return ((size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int) + (size_t)e->Gtot + 7) / 8 * 8;
 }
 
-StepFinish make_step_finish(sbe_engine* e) {
+StepFinish make_step_finish_lane(sbe_engine* e, const sbe_engine::Lane& lane) {
     StepFinish fin{};
-    fin.per_feature = e->d_step_pf;
-    fin.group_out = reinterpret_cast<double*>(e->d_step_host);
+    fin.per_feature = lane.d_pf;
+    fin.group_out = reinterpret_cast<double*>(lane.d_step_host);
     fin.status = e->d_status;
-    fin.status_out = reinterpret_cast<int*>(e->d_step_host + (size_t)e->Gtot * sizeof(double));
-    fin.changed = nullptr; fin.stamp = e->d_step_stamp; fin.step_id = e->step_id;
-    fin.changed_out = e->d_step_host + (size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int);
+    fin.status_out = reinterpret_cast<int*>(lane.d_step_host + (size_t)e->Gtot * sizeof(double));
+    fin.changed = nullptr; fin.stamp = lane.d_stamp; fin.step_id = lane.step_id;
+    fin.changed_out = lane.d_step_host + (size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int);
     fin.Gtot = e->Gtot; fin.F = e->F;
     return fin;
 }
+StepFinish make_step_finish(sbe_engine* e) { return make_step_finish_lane(e, lane0(e)); }
 
 // after the synchronisation that ends a one-call step: data checks, then the results out of the mapped block
-int read_step_results(sbe_engine* e, int cand_slot, double* group_logliks_out, double* mixture_out,
+int read_step_results_lane(sbe_engine* e, const uint8_t* h_step, int cand_slot, double* group_logliks_out, double* mixture_out,
                       uint8_t* changed_groups_out, const char* bad_norm_what) {
-    const int* hst = reinterpret_cast<const int*>(e->h_step + (size_t)e->Gtot * sizeof(double));
+    const int* hst = reinterpret_cast<const int*>(h_step + (size_t)e->Gtot * sizeof(double));
     if (hst[ST_BAD_NORMALIZE] || hst[ST_MULTI_SOURCE]) {
         const int bad_norm = hst[ST_BAD_NORMALIZE], multi_src = hst[ST_MULTI_SOURCE];
         (void)hipMemsetAsync(e->d_status + ST_BAD_NORMALIZE, 0, 2 * sizeof(int), e->stream);
         if (bad_norm) return fail(e, SBE_ERR_DATA, "normalize: %d %s have a non-positive sum (sbayes/util.py:1006 assert)", bad_norm, bad_norm_what);
         return fail(e, SBE_ERR_DATA, "source is not one-hot over components in %d observations", multi_src);
     }
-    memcpy(group_logliks_out, e->h_step, (size_t)e->Gtot * sizeof(double));
-    if (changed_groups_out) memcpy(changed_groups_out, e->h_step + (size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int), (size_t)e->Gtot);
+    memcpy(group_logliks_out, h_step, (size_t)e->Gtot * sizeof(double));
+    if (changed_groups_out) memcpy(changed_groups_out, h_step + (size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int), (size_t)e->Gtot);
     *mixture_out = e->h_results[cand_slot];
     return SBE_OK;
+}
+int read_step_results(sbe_engine* e, int cand_slot, double* group_logliks_out, double* mixture_out,
+                      uint8_t* changed_groups_out, const char* bad_norm_what) {
+    return read_step_results_lane(e, e->h_step, cand_slot, group_logliks_out, mixture_out, changed_groups_out, bad_norm_what);
 }
 
 }  // namespace
@@ -2136,22 +2240,15 @@ int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters
                         group_logliks_out, mixture_out, changed_groups_out);
 }
 
-static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters, const int32_t* changed_objects,
-                     int n_changed, const uint8_t* source_rows, const float* weights, double* group_logliks_out,
-                     double* mixture_out, uint8_t* changed_groups_out) {
-    if (e->status_pending) {                  // deliver a deferred data check before this step reuses the words
-        HIPCHK(e, hipStreamSynchronize(e->stream));
-        int rc = synced(e);
-        if (rc) return rc;
-    }
-    // SBE_STEP_TIMING=1: host-side phase times (prepare / enqueue / wait), printed every 2000 steps (diagnostic)
-    static const bool timing = getenv("SBE_STEP_TIMING") && atoi(getenv("SBE_STEP_TIMING")) == 1;
-    static double t_acc[3] = {0, 0, 0};
-    static int t_n = 0;
-    const auto t0 = std::chrono::steady_clock::now();
+// Host half of a lean step for one chain: the candidate's host state `cd` (= current + delta) and the step's payload
+// packed into the lane's host-mapped block; `in` receives the device-side views of that payload.  Touches only the lane,
+// `cd` and read-only engine state, so the chains of a batch can be prepared by several host threads at once.
+static int prepare_step(sbe_engine* e, const sbe_engine::Lane& lane, int cur_slot, const uint8_t* clusters,
+                        const int32_t* changed_objects, int n_changed, const uint8_t* source_rows, const float* weights,
+                        Slot& cd, CoreInputs& in, std::string* err) {
     const int N = e->N, Np = e->Np, F = e->F, C = e->C;
     const Slot& cur = e->slots[cur_slot];
-    Slot cd = cur;                            // host state of the candidate (committed at the end)
+    cd = cur;                                 // host state of the candidate (committed by the caller)
     // objects whose counts may change: listed source rows + objects whose cluster membership changed
     std::vector<uint8_t> moved(N, 0);
     for (int i = 0; i < n_changed; ++i) moved[changed_objects[i]] = 1;
@@ -2166,17 +2263,21 @@ static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* 
         }
         for (int n = 0; n < N; ++n) if (ids[n] != cur.h_gid[n]) moved[n] = 1;
         derive_patterns(e, cd);
-        if ((int)cd.patterns.size() > e->Pmax)
-            return fail(e, SBE_ERR_ARG, "%zu distinct has_components patterns exceed capacity %d", cd.patterns.size(), e->Pmax);
+        if ((int)cd.patterns.size() > e->Pmax) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "%zu distinct has_components patterns exceed capacity %d", cd.patterns.size(), e->Pmax);
+            *err = buf;
+            return SBE_ERR_ARG;
+        }
         derive_tuples(e, cd);
         cd.patterns_dirty = false;
         cd.group_epoch = ++e->epoch_counter;
     }
     // ---- payload: packed in host-mapped pinned memory; the kernels read it in place (a few tens of KB over
-    // PCIe, no copy engine in the chain).  Every step ends with a stream synchronisation, so the single buffer is
+    // PCIe, no copy engine in the chain).  Every step ends with a stream synchronisation, so the lane's buffer is
     // free again when the next step starts.
     const auto& L = e->sl;
-    uint8_t* st = e->h_step_payload;
+    uint8_t* st = lane.h_payload;
     int n_subset = 0;
     {
         int32_t* sub = reinterpret_cast<int32_t*>(st + L.subset);
@@ -2201,34 +2302,54 @@ static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* 
         memcpy(st + L.objects, changed_objects, (size_t)n_changed * 4);
         memcpy(st + L.rows, source_rows, (size_t)n_changed * F * C);
     }
-    const auto t1 = std::chrono::steady_clock::now();
-    const uint8_t* pl = e->d_step_payload;
-
-    // ---- kernel 1: candidate slot = current slot + payload, count delta, every table ---------------------------
-    {
-        CoreInputs in;
-        if (regroup) {
-            in.ids_new = pl + L.ids; in.pid = pl + L.pid; in.tid = pl + L.tid; in.toff = pl + L.toff;
-            in.tuple_g = pl + L.tuple_g; in.tuple_p = pl + L.tuple_p; in.patbits = pl + L.patbits;
-        }
-        if (weights) in.weights = pl + L.weights;
-        if (n_changed > 0) {
-            in.row_of = reinterpret_cast<const int16_t*>(pl + L.row_of);
-            in.rows = pl + L.rows;
-            in.objects = reinterpret_cast<const int32_t*>(pl + L.objects);
-            in.n_changed = n_changed;
-        }
-        in.subset = reinterpret_cast<const int32_t*>(pl + L.subset); in.n_subset = n_subset;
-        in.P = (int)cd.patterns.size();
-        int rc = launch_step_core(e, cur_slot, cand_slot, in);
-        if (rc) return rc;
+    const uint8_t* pl = lane.d_payload;
+    in = CoreInputs{};
+    if (regroup) {
+        in.ids_new = pl + L.ids; in.pid = pl + L.pid; in.tid = pl + L.tid; in.toff = pl + L.toff;
+        in.tuple_g = pl + L.tuple_g; in.tuple_p = pl + L.tuple_p; in.patbits = pl + L.patbits;
     }
+    if (weights) in.weights = pl + L.weights;
+    if (n_changed > 0) {
+        in.row_of = reinterpret_cast<const int16_t*>(pl + L.row_of);
+        in.rows = pl + L.rows;
+        in.objects = reinterpret_cast<const int32_t*>(pl + L.objects);
+        in.n_changed = n_changed;
+    }
+    in.subset = reinterpret_cast<const int32_t*>(pl + L.subset); in.n_subset = n_subset;
+    in.P = (int)cd.patterns.size();
     std::fill(cd.probs_set.begin(), cd.probs_set.end(), 1);
     cd.weights_set = true;
+    return SBE_OK;
+}
+
+static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters, const int32_t* changed_objects,
+                     int n_changed, const uint8_t* source_rows, const float* weights, double* group_logliks_out,
+                     double* mixture_out, uint8_t* changed_groups_out) {
+    if (e->status_pending) {                  // deliver a deferred data check before this step reuses the words
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        int rc = synced(e);
+        if (rc) return rc;
+    }
+    // SBE_STEP_TIMING=1: host-side phase times (prepare / enqueue / wait), printed every 2000 steps (diagnostic)
+    static const bool timing = getenv("SBE_STEP_TIMING") && atoi(getenv("SBE_STEP_TIMING")) == 1;
+    static double t_acc[3] = {0, 0, 0};
+    static int t_n = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    Slot cd;
+    CoreInputs in;
+    {
+        std::string err;
+        int rc = prepare_step(e, lane0(e), cur_slot, clusters, changed_objects, n_changed, source_rows, weights, cd, in, &err);
+        if (rc) return fail(e, rc, "%s", err.c_str());
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    // ---- kernel 1: candidate slot = current slot + payload, count delta, every table ---------------------------
+    int rc = launch_step_core(e, cur_slot, cand_slot, in);
+    if (rc) return rc;
     e->slots[cand_slot] = cd;
     // ---- kernels 2 + 3: fused mixture eval, reduction + step epilogue (mapped-memory results) -------------------
     StepFinish fin = make_step_finish(e);
-    int rc = launch_mixture(e, cand_slot, 1, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, &fin);
+    rc = launch_mixture(e, cand_slot, 1, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, &fin);
     if (rc) return rc;
     const auto t2 = std::chrono::steady_clock::now();
     HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -2243,6 +2364,131 @@ static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* 
         }
     }
     return read_step_results(e, cand_slot, group_logliks_out, mixture_out, changed_groups_out, "rows");
+}
+
+// ---- batched multi-chain step (missing #4): B chains' deltas in ONE call ------------------------------
+// The reference steps its chains one after the other in one Python loop (MCMC.generate_samples,
+// sbayes/sampling/mcmc.py:237-241).  Here the chains' candidate slots are built by ONE launch of k_step_core_batch
+// (chain <-> blockIdx.y), evaluated by ONE launch of the fused mixture kernel over the candidate slot list and
+// finished by ONE launch of k_reduce_partials (a reduction block and an epilogue block per chain); the host halves
+// (candidate host state, payload packing) run on a small pool of worker threads.  One synchronisation per batch.
+namespace {
+int ensure_lanes(sbe_engine* e, int n) {
+    const size_t hb = step_host_lq_offset(e) + 2 * sizeof(double);
+    while ((int)e->lanes.size() < n) {
+        sbe_engine::Lane ln{};
+        HIPCHK(e, hipHostMalloc((void**)&ln.h_payload, e->sl.total, hipHostMallocMapped));
+        HIPCHK(e, hipHostGetDevicePointer((void**)&ln.d_payload, ln.h_payload, 0));
+        HIPCHK(e, hipHostMalloc((void**)&ln.h_step, hb, hipHostMallocMapped));
+        memset(ln.h_step, 0, hb);
+        HIPCHK(e, hipHostGetDevicePointer((void**)&ln.d_step_host, ln.h_step, 0));
+        HIPCHK(e, hipMalloc((void**)&ln.d_pf, (size_t)e->Gtot * e->F * sizeof(float)));
+        HIPCHK(e, hipMalloc((void**)&ln.d_stamp, (size_t)e->Gtot * sizeof(uint32_t)));
+        HIPCHK(e, hipMemsetAsync(ln.d_stamp, 0, (size_t)e->Gtot * sizeof(uint32_t), e->stream));
+        ln.step_id = 0;
+        e->lanes.push_back(ln);
+    }
+    return SBE_OK;
+}
+}  // namespace
+
+int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const int32_t* cand_slots,
+                   const uint8_t* clusters, const uint8_t* clusters_mask, const int32_t* rows_ptr,
+                   const int32_t* changed_objects, const uint8_t* source_rows, const float* weights,
+                   const uint8_t* weights_mask, double* group_logliks_out, double* mixture_out,
+                   uint8_t* changed_groups_out) {
+    CHECK_ENGINE(e); CHECK_PTR(e, cur_slots); CHECK_PTR(e, cand_slots); CHECK_PTR(e, rows_ptr);
+    CHECK_PTR(e, group_logliks_out); CHECK_PTR(e, mixture_out);
+    if (n_chains < 1 || n_chains > e->n_slots / 2) return fail(e, SBE_ERR_ARG, "n_chains=%d (1..%d: two slots per chain)", n_chains, e->n_slots / 2);
+    if ((int64_t)e->Gtot * e->S * 28 > 60 * 1024) return fail(e, SBE_ERR_ARG, "sbe_step_batch: tables too large for the one-launch step (G_total=%d, S=%d)", e->Gtot, e->S);
+    const int N = e->N, F = e->F, C = e->C, K = e->G[0];
+    if (rows_ptr[0] != 0) return fail(e, SBE_ERR_ARG, "rows_ptr[0] must be 0");
+    {   // argument checks before anything is touched
+        std::vector<uint8_t> used(e->n_slots, 0);
+        for (int i = 0; i < n_chains; ++i) {
+            const int a = cur_slots[i], b = cand_slots[i];
+            if (a < 0 || a >= e->n_slots || b < 0 || b >= e->n_slots || a == b) return fail(e, SBE_ERR_ARG, "chain %d: bad slots (%d, %d)", i, a, b);
+            if (used[a] || used[b]) return fail(e, SBE_ERR_ARG, "chain %d: slot used by another chain of the batch", i);
+            used[a] = used[b] = 1;
+            const int nr = rows_ptr[i + 1] - rows_ptr[i];
+            if (nr < 0 || nr > e->step_max_rows) return fail(e, SBE_ERR_ARG, "chain %d: %d changed source rows (0..%d per chain in a batched step)", i, nr, e->step_max_rows);
+            if (nr > 0 && (!changed_objects || !source_rows)) return fail(e, SBE_ERR_ARG, "changed_objects / source_rows missing");
+            for (int k = rows_ptr[i]; k < rows_ptr[i + 1]; ++k)
+                if (changed_objects[k] < 0 || changed_objects[k] >= N) return fail(e, SBE_ERR_ARG, "chain %d: object index %d out of range", i, changed_objects[k]);
+            const Slot& cur = e->slots[a];
+            if (!cur.groups_set || !cur.source_set || !cur.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", a);
+            for (int c = 0; c < C; ++c)
+                if (!cur.counts_set[c] || !e->conc_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts / concentration of component %d not set", a, c);
+        }
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    if (e->status_pending) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        int rc = synced(e);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < n_chains; ++i)       // never-uploaded patterns of a current slot (first step after set_groups)
+        if (e->slots[cur_slots[i]].patterns_dirty) { int rc = upload_patterns_and_weights(e, cur_slots[i]); if (rc) return rc; }
+    int rc = ensure_lanes(e, n_chains);
+    if (rc) return rc;
+    if (!e->pool) {
+        int nt = 7;                                                  // + the calling thread
+        if (const char* env = getenv("SBE_STEP_THREADS")) nt = std::max(0, atoi(env) - 1);
+        nt = std::min<int>(nt, std::max(0, (int)std::thread::hardware_concurrency() - 1));
+        e->pool = new sbe_engine::Pool(nt);
+    }
+    // ---- host halves, in parallel over the chains ---------------------------------------------------------------
+    std::vector<Slot> cds(n_chains);
+    std::vector<CoreInputs> ins(n_chains);
+    std::vector<int> rcs(n_chains, SBE_OK);
+    std::vector<std::string> errs(n_chains);
+    e->pool->run(n_chains, [&](int i) {
+        const bool regroup = clusters && (!clusters_mask || clusters_mask[i]);
+        const bool reweight = weights && (!weights_mask || weights_mask[i]);
+        const int r0 = rows_ptr[i], nr = rows_ptr[i + 1] - r0;
+        rcs[i] = prepare_step(e, e->lanes[i], cur_slots[i], regroup ? clusters + (size_t)i * K * N : nullptr,
+                              nr ? changed_objects + r0 : nullptr, nr, nr ? source_rows + (size_t)r0 * F * C : nullptr,
+                              reweight ? weights + (size_t)i * F * C : nullptr, cds[i], ins[i], &errs[i]);
+    });
+    for (int i = 0; i < n_chains; ++i) if (rcs[i]) return fail(e, rcs[i], "chain %d: %s", i, errs[i].c_str());
+    // ---- device: argument blocks (StepCore per chain | StepFinish per chain | candidate slot list) -----------------
+    const size_t cores_bytes = (size_t)n_chains * sizeof(StepCore), fins_bytes = (size_t)n_chains * sizeof(StepFinish);
+    const size_t cores_pad = (cores_bytes + 255) / 256 * 256, fins_pad = (fins_bytes + 255) / 256 * 256;
+    const size_t meta_bytes = cores_pad + fins_pad + (size_t)n_chains * sizeof(int32_t);
+    if (meta_bytes > e->batch_meta_bytes) {
+        if (e->d_batch_meta) { HIPCHK(e, hipStreamSynchronize(e->stream)); HIPCHK(e, hipFree(e->d_batch_meta)); }
+        e->batch_meta_bytes = meta_bytes + meta_bytes / 2;
+        HIPCHK(e, hipMalloc((void**)&e->d_batch_meta, e->batch_meta_bytes));
+    }
+    std::vector<uint8_t> meta(meta_bytes);
+    StepCore* cores = reinterpret_cast<StepCore*>(meta.data());
+    StepFinish* fins = reinterpret_cast<StepFinish*>(meta.data() + cores_pad);
+    int32_t* slot_list = reinterpret_cast<int32_t*>(meta.data() + cores_pad + fins_pad);
+    size_t lds = 0; int max_blocks = 0;
+    for (int i = 0; i < n_chains; ++i) {
+        size_t l = 0; int nb = 0;
+        rc = build_step_core(e, e->lanes[i], cur_slots[i], cand_slots[i], ins[i], cores[i], l, nb);
+        if (rc) return rc;
+        lds = std::max(lds, l); max_blocks = std::max(max_blocks, nb);
+        fins[i] = make_step_finish_lane(e, e->lanes[i]);
+        slot_list[i] = cand_slots[i];
+    }
+    rc = upload(e, e->d_batch_meta, meta.data(), meta_bytes);
+    if (rc) return rc;
+    k_step_core_batch<<<dim3(max_blocks, n_chains), kBlock, lds, e->stream>>>(reinterpret_cast<const StepCore*>(e->d_batch_meta));
+    HIPCHK(e, hipGetLastError());
+    for (int i = 0; i < n_chains; ++i) e->slots[cand_slots[i]] = std::move(cds[i]);
+    rc = launch_mixture(e, 0, n_chains, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, nullptr,
+                        cand_slots, reinterpret_cast<const int32_t*>(e->d_batch_meta + cores_pad + fins_pad),
+                        reinterpret_cast<const StepFinish*>(e->d_batch_meta + cores_pad));
+    if (rc) return rc;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (int i = 0; i < n_chains; ++i) {
+        rc = read_step_results_lane(e, e->lanes[i].h_step, cand_slots[i], group_logliks_out + (size_t)i * e->Gtot, mixture_out + i,
+                               changed_groups_out ? changed_groups_out + (size_t)i * e->Gtot : nullptr, "rows");
+        if (rc) return rc;
+    }
+    return SBE_OK;
 }
 
 // ---- one-call Gibbs source step (GibbsSampleSource._propose, operators.py:495-552, on the resident state) ------

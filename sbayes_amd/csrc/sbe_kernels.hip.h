@@ -634,12 +634,16 @@ struct StepFinish {
 };
 
 // Final fixed-order reduction of the per-block partials: one block per slot (+ one for the step epilogue).
+// Batched steps (sbe_step_batch): `slot_list` names the slots, `fins` holds one epilogue per chain (n_fin blocks).
 __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __restrict__ partials,
                                                            int64_t partials_stride, int n_blocks,
                                                            double* __restrict__ results, int first_slot,
-                                                           int n_slots, StepFinish fin) {
+                                                           int n_slots, StepFinish fin_single,
+                                                           const int32_t* __restrict__ slot_list = nullptr,
+                                                           const StepFinish* __restrict__ fins = nullptr) {
     __shared__ double red4[4];
     if ((int)blockIdx.x >= n_slots) {                                   // step epilogue block
+        const StepFinish fin = fins ? fins[(int)blockIdx.x - n_slots] : fin_single;
         // per-feature values staged through LDS in chunks of whole groups (coalesced loads; the ordered sums
         // then run at LDS latency instead of one L2 round trip per 8 elements)
         __shared__ float stage[8192];
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __rest
         }
         return;
     }
-    const int slot = first_slot + blockIdx.x;
+    const int slot = slot_list ? slot_list[blockIdx.x] : first_slot + (int)blockIdx.x;
     const double* p = partials + (int64_t)slot * partials_stride;
     double v = 0.0;
     for (int i = threadIdx.x; i < n_blocks; i += kBlock) v += p[i];
@@ -723,6 +727,7 @@ struct Mix2Params {
     int wpat_tile_stride;                          // Pmax*C*FT
     double* partials;      int64_t partials_stride;
     int first_slot;
+    const int32_t* slot_list;                      // slots of this launch (n_batch entries), or null: first_slot + i
     // rows kernel (k_mixture_rows): engine tile width of probs_t, canonical per-pattern weights, per-object row offsets
     int eft;                                       // tile width of probs_t (64 / 32 / 16)
     const float* wpat;     int64_t wpat_stride;    // per slot [Pmax][F][C] float32 normalised weights (a5)
@@ -830,7 +835,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_v2(Mix2Params p) {
     const int slot_i = (unit % p.slot_groups) * p.slots_per_group + (int)(blockIdx.x >> 3) % p.slots_per_group;
     const int work = unit / p.slot_groups;                 // (tile, chunk) index
     if (work >= p.n_work || slot_i >= p.n_batch) return;   // padding blocks (before any barrier)
-    const int slot = p.first_slot + slot_i;
+    const int slot = p.slot_list ? p.slot_list[slot_i] : p.first_slot + slot_i;
     const int tile = work % p.n_ftiles, chunk = work / p.n_ftiles;
     const int S = p.S;
     const int C = CT ? CT : p.C;
@@ -964,7 +969,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_onehot_v2(Mix2Params p) {
     const int slot_i = (unit % p.slot_groups) * p.slots_per_group + (int)(blockIdx.x >> 3) % p.slots_per_group;
     const int work = unit / p.slot_groups;                 // (tile, chunk) index
     if (work >= p.n_work || slot_i >= p.n_batch) return;   // padding blocks (before any barrier)
-    const int slot = p.first_slot + slot_i;
+    const int slot = p.slot_list ? p.slot_list[slot_i] : p.first_slot + slot_i;
     const int tile = work % p.n_ftiles, chunk = work / p.n_ftiles;
     const int S = p.S;
     const int C = CT ? CT : p.C;
@@ -1108,9 +1113,10 @@ constexpr int kRowsWaves = kRowsBlock / kWave;
 //   out[C][n]          = pattern(n) * ceil(C/2) * FT * 16  (weight planes of the object's has_components pattern)
 // objects n >= N of the last quad get the "no group" row and pattern 0 (their state bytes are NA).
 __global__ void k_rowoff(const uint16_t* __restrict__ gid, const uint8_t* __restrict__ pid, uint32_t* __restrict__ out,
-                         int64_t gid_stride, int64_t pid_stride, int64_t out_stride, int first_slot, int N, int Np,
+                         int64_t gid_stride, int64_t pid_stride, int64_t out_stride, int first_slot,
+                         const int32_t* __restrict__ slot_list, int N, int Np,
                          int C, int Gtot, uint32_t row_bytes, uint32_t pat_bytes) {
-    const int slot = first_slot + (int)blockIdx.y;
+    const int slot = slot_list ? slot_list[blockIdx.y] : first_slot + (int)blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (c, n)
     if (i >= (C + 1) * Np) return;
     const int c = i / Np, n = i - c * Np;
@@ -1133,7 +1139,7 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
     const int slot_i = (unit % p.slot_groups) * p.slots_per_group + (int)(blockIdx.x >> 3) % p.slots_per_group;
     const int work = unit / p.slot_groups;                 // (tile, chunk) index
     if (work >= p.n_work || slot_i >= p.n_batch) return;   // padding blocks (before any barrier)
-    const int slot = p.first_slot + slot_i;
+    const int slot = p.slot_list ? p.slot_list[slot_i] : p.first_slot + slot_i;
     const int tile = work % p.n_ftiles, chunk = work / p.n_ftiles;       // (n_ftiles: tiles of FT features here)
     constexpr int C = CT, CP = (CT + 1) / 2;
     const int S = p.S, S1 = p.S + 1;
@@ -1342,7 +1348,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_combo(Mix2Params p) {
     const int slot_i = (unit % p.slot_groups) * p.slots_per_group + (int)(blockIdx.x >> 3) % p.slots_per_group;
     const int work = unit / p.slot_groups;
     if (work >= p.n_work || slot_i >= p.n_batch) return;
-    const int slot = p.first_slot + slot_i;
+    const int slot = p.slot_list ? p.slot_list[slot_i] : p.first_slot + slot_i;
     const int tile = work % p.n_ftiles, chunk = work / p.n_ftiles;
     const int S = p.S, S1 = p.S + 1;
     const int C = CT ? CT : p.C;
@@ -1584,7 +1590,7 @@ __global__ __launch_bounds__(NW * kWave, NW == 8 ? 6 : 1) void k_mixture_tuple64
             if (slot_i >= p.n_batch) return;
         }
     }
-    const int slot = p.first_slot + slot_i;
+    const int slot = p.slot_list ? p.slot_list[slot_i] : p.first_slot + slot_i;
     const int tile = work % p.n_ftiles, chunk = work / p.n_ftiles;
     const int S = p.S, S1 = p.S + 1;
     const int C = CT ? CT : p.C;
@@ -2298,13 +2304,14 @@ struct StepCore {
     // weight blocks
     const float* weights; const uint32_t* pattern_bits; float* wpat; double* wpat_t;
     int P, Pmax, n_weight_blocks;
+    int n_copy_blocks;             // (batched launch: the grid is sized for the largest chain; surplus blocks exit)
 };
 
-__global__ __launch_bounds__(kBlock) void k_step_core(StepCore a) {
-    extern __shared__ __align__(16) unsigned char core_lds[];
+__device__ __forceinline__ void step_core_body(const StepCore& a, unsigned char* core_lds, const int bx) {
     const int S = a.S, C = a.C, F = a.F;
-    if ((int)blockIdx.x < a.n_tile_blocks) {
-        const int ftc = a.ftc, f0 = (int)blockIdx.x * ftc;
+    if (bx >= a.n_tile_blocks + a.n_weight_blocks + a.n_copy_blocks) return;      // surplus block of a batched launch
+    if (bx < a.n_tile_blocks) {
+        const int ftc = a.ftc, f0 = bx * ftc;
         const int E = a.Gtot * ftc * S, R = a.Gtot * ftc;
         int32_t* hist = reinterpret_cast<int32_t*>(core_lds);                       // [Gtot][ftc][S] delta, then counts
         double* sh_post = reinterpret_cast<double*>(core_lds + ((size_t)E * 4 + 15) / 16 * 16);
@@ -2383,7 +2390,7 @@ __global__ __launch_bounds__(kBlock) void k_step_core(StepCore a) {
         }
         return;
     }
-    const int wb = (int)blockIdx.x - a.n_tile_blocks;
+    const int wb = bx - a.n_tile_blocks;
     if (wb < a.n_weight_blocks) {
         const int64_t j = (int64_t)wb * kBlock + threadIdx.x;
         if (j >= (int64_t)a.P * F) return;
@@ -2403,7 +2410,7 @@ __global__ __launch_bounds__(kBlock) void k_step_core(StepCore a) {
         return;
     }
     // copy blocks
-    const uint32_t n_copy = gridDim.x - (uint32_t)(a.n_tile_blocks + a.n_weight_blocks);
+    const uint32_t n_copy = (uint32_t)a.n_copy_blocks;
     const uint32_t tid = (uint32_t)(wb - a.n_weight_blocks) * kBlock + threadIdx.x, nthreads = n_copy * kBlock;
     const uint32_t total = a.cs.end[a.cs.n - 1];
     for (uint32_t i = tid; i < total; i += nthreads) {
@@ -2426,6 +2433,17 @@ __global__ __launch_bounds__(kBlock) void k_step_core(StepCore a) {
         multi += cnt > 1;
     }
     if (multi) atomicAdd(&a.status[ST_MULTI_SOURCE], multi);
+}
+
+__global__ __launch_bounds__(kBlock) void k_step_core(StepCore a) {
+    extern __shared__ __align__(16) unsigned char core_lds[];
+    step_core_body(a, core_lds, (int)blockIdx.x);
+}
+
+// sbe_step_batch: one chain per blockIdx.y, each with its own StepCore (current / candidate slot, payload, counts ...)
+__global__ __launch_bounds__(kBlock) void k_step_core_batch(const StepCore* __restrict__ cores) {
+    extern __shared__ __align__(16) unsigned char core_lds[];
+    step_core_body(cores[blockIdx.y], core_lds, (int)blockIdx.x);
 }
 
 // canonical probs [Gtot][F][S] -> tile-transposed probs_t [n_ftiles][Gtot+1][S][FT] for the

@@ -553,6 +553,56 @@ class Engine:
                                        _ptr(glh), ct.byref(mix), _ptr(changed)))
         return glh, mix.value, changed.astype(bool)
 
+    def step_batch(self, cur_slots, cand_slots, clusters=None, clusters_mask=None, rows_ptr=None, changed_objects=None,
+                   source_rows=None, weights=None, weights_mask=None):
+        """One MCMC step for each of n chains in ONE call (sbe_step_batch).  Stacked inputs: clusters bool [n, K, N]
+        (or None), clusters_mask bool [n] (or None = every chain), rows_ptr int [n+1] CSR over changed_objects /
+        source_rows bool [total, F, C] (or None = no source change), weights float32 [n, F, C] + weights_mask.
+        Returns (group_logliks float64 [n, G_total], mixture_ll float64 [n], changed_groups bool [n, G_total])."""
+        cur = np.ascontiguousarray(cur_slots, dtype=np.int32).reshape(-1)
+        cand = np.ascontiguousarray(cand_slots, dtype=np.int32).reshape(-1)
+        n = cur.size
+        if cand.size != n:
+            raise ValueError("cur_slots and cand_slots must have the same length")
+        cl = cm = None
+        if clusters is not None:
+            cl = np.asarray(clusters)
+            if cl.shape != (n, self.n_groups[0], self.n_objects):
+                raise ValueError(f"clusters must be {(n, self.n_groups[0], self.n_objects)}, got {cl.shape}")
+            cl = _c(cl.astype(bool, copy=False), np.uint8)
+            if clusters_mask is not None:
+                cm = _c(np.asarray(clusters_mask, dtype=bool), np.uint8).reshape(n)
+        if rows_ptr is None:
+            ptr = np.zeros(n + 1, dtype=np.int32)
+            objs = rows = None
+        else:
+            ptr = np.ascontiguousarray(rows_ptr, dtype=np.int32).reshape(-1)
+            if ptr.size != n + 1:
+                raise ValueError("rows_ptr must have n_chains + 1 entries")
+            total = int(ptr[-1])
+            objs = np.ascontiguousarray(changed_objects, dtype=np.int32).reshape(-1) if total else None
+            rows = np.asarray(source_rows) if total else None
+            if total and (objs.size != total or rows.shape != (total, self.n_features, self.n_components)):
+                raise ValueError("changed_objects / source_rows do not match rows_ptr")
+            if total:
+                rows = _c(rows.astype(bool, copy=False), np.uint8)
+        w = wm = None
+        if weights is not None:
+            w = _c(weights, np.float32)
+            if w.shape != (n, self.n_features, self.n_components):
+                raise ValueError(f"weights must be {(n, self.n_features, self.n_components)}")
+            if weights_mask is not None:
+                wm = _c(np.asarray(weights_mask, dtype=bool), np.uint8).reshape(n)
+        glh = np.empty((n, self.n_groups_total), dtype=np.float64)
+        mix = np.empty(n, dtype=np.float64)
+        changed = np.zeros((n, self.n_groups_total), dtype=np.uint8)
+        for s in cand:
+            self._touch(int(s))
+        opt = lambda a: _ptr(a) if a is not None else None          # noqa: E731
+        self._check(self._lib.sbe_step_batch(self._h, n, _ptr(cur), _ptr(cand), opt(cl), opt(cm), _ptr(ptr), opt(objs), opt(rows),
+                                             opt(w), opt(wm), _ptr(glh), _ptr(mix), _ptr(changed)))
+        return glh, mix, changed.astype(bool)
+
     def gibbs_step(self, cur_slot, cand_slot, objects, z=None, temperature=1.0, prior_temperature=1.0, from_prior=False):
         """One Gibbs-source MCMC step in one call (sbe_gibbs_step): the listed objects' source is redrawn on the
         device into `cand_slot`, counts / tables / likelihoods follow.  z: uniforms [n, F] or None (engine's Philox

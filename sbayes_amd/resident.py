@@ -218,3 +218,101 @@ class ResidentChain:
         self._probs_dirty[self.cand] = set()
         self._pending = True
         return float(glh.sum()), glh, mix
+
+
+class ResidentChainBatch:
+    """B independent chains resident on one engine, stepped together (sbe_step_batch): the reference's
+    `for c in chains: self.step(...)` (MCMC.generate_samples, sbayes/sampling/mcmc.py:237-241) as ONE engine call per
+    sweep -- one candidate-building launch, one fused mixture launch over the B candidates, one reduction launch,
+    one synchronisation.  Chain i owns the slots (2i, 2i+1): current and candidate, swapped on accept.
+
+        batch = ResidentChainBatch(model, [sample_0, ..., sample_{B-1}])
+        ll, group_lh, mix = batch.step(clusters=[...], source_rows=[...], weights=[...])   # per chain, None = unchanged
+        batch.accept(mask)                                     # bool [B]: accepted proposals swap their slots
+
+    Proposal logic, RNG and the accept / reject decisions stay with the sampler."""
+
+    def __init__(self, model, samples, device=None):
+        from .engine import Engine
+        from .registry import default_device
+        self.model = model
+        self.n = len(samples)
+        first = samples[0]
+        self.names = list(first.component_names)
+        feats = model.data.features.values
+        n_groups = [model.shapes.n_clusters] + [c.n_groups for c in model.data.confounders.values()]
+        self.eng = eng = Engine(feats, n_groups, n_slots=2 * self.n, device=default_device() if device is None else device)
+        conc = [np.asarray(model.prior.prior_cluster_effect.concentration_array)] + [
+            np.asarray(model.prior.prior_confounding_effects[k].concentration_array(first)) for k in self.names[1:]]
+        for c in range(eng.n_components):
+            eng.set_concentration(c, conc[c])
+        eng.set_option(deferred_checks=True)
+        self.cur = np.arange(0, 2 * self.n, 2, dtype=np.int32)
+        self.cand = self.cur + 1
+        self._clusters = []
+        for i, sample in enumerate(samples):
+            slot = int(self.cur[i])
+            groups = [sample.clusters.value] + [c.group_assignment for c in sample.confounders.values()]
+            for c in range(eng.n_components):
+                eng.set_groups(slot, c, groups[c])
+            eng.set_source(slot, sample.source.value)
+            eng.recount(slot)
+            for c in range(eng.n_components):
+                eng.update_probs(slot, c)
+            eng.set_weights(slot, sample.weights.value)
+            self._clusters.append(np.array(sample.clusters.value, dtype=bool))
+        eng.set_option(deferred_checks=False)                   # (synchronises: a queued data check is raised here)
+        self._cand_clusters = list(self._clusters)
+        self.changed_groups = None
+
+    def close(self):
+        self.eng.close()
+
+    def step(self, clusters=None, source_rows=None, weights=None):
+        """Per-chain deltas as lists of length B (entries None = unchanged): clusters bool [K, N]; source_rows
+        (object indices, bool rows [n, F, C]); weights float32 [F, C].  Returns (collapsed log-likelihood [B],
+        per-group values [B, G_total], mixture log-likelihood [B]) of the B candidates."""
+        eng, n = self.eng, self.n
+        cl = cm = w = wm = None
+        if clusters is not None and any(c is not None for c in clusters):
+            cm = np.array([c is not None for c in clusters])
+            cl = np.stack([np.asarray(c, dtype=bool) if c is not None else self._clusters[i] for i, c in enumerate(clusters)])
+        if weights is not None and any(x is not None for x in weights):
+            wm = np.array([x is not None for x in weights])
+            zero = np.zeros((eng.n_features, eng.n_components), dtype=np.float32)
+            w = np.stack([np.asarray(x, dtype=np.float32) if x is not None else zero for x in weights])
+        ptr = objs = rows = None
+        if source_rows is not None and any(r is not None and len(r[0]) for r in source_rows):
+            counts = [0 if r is None else len(r[0]) for r in source_rows]
+            ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+            objs = np.concatenate([np.asarray(r[0], dtype=np.int32) for r in source_rows if r is not None and len(r[0])])
+            rows = np.concatenate([np.asarray(r[1], dtype=bool) for r in source_rows if r is not None and len(r[0])])
+        return self.step_arrays(cl, cm, ptr, objs, rows, w, wm)
+
+    def step_arrays(self, clusters=None, clusters_mask=None, rows_ptr=None, changed_objects=None, source_rows=None,
+                    weights=None, weights_mask=None):
+        """The same with the deltas already stacked (Engine.step_batch's arguments): no per-chain Python work."""
+        glh, mix, changed = self.eng.step_batch(self.cur, self.cand, clusters, clusters_mask, rows_ptr, changed_objects,
+                                                source_rows, weights, weights_mask)
+        if clusters is not None:
+            for i in range(self.n):
+                if clusters_mask is None or clusters_mask[i]:
+                    self._cand_clusters[i] = np.array(clusters[i], dtype=bool)
+                else:
+                    self._cand_clusters[i] = self._clusters[i]
+        else:
+            self._cand_clusters = list(self._clusters)
+        self.changed_groups = changed
+        return glh.sum(axis=1), glh, mix
+
+    def accept(self, mask=None):
+        """Swap the slots of the accepted chains (all of them by default); rejected chains keep their current slot."""
+        mask = np.ones(self.n, dtype=bool) if mask is None else np.asarray(mask, dtype=bool)
+        cur, cand = self.cur.copy(), self.cand.copy()
+        self.cur = np.where(mask, cand, cur).astype(np.int32)
+        self.cand = np.where(mask, cur, cand).astype(np.int32)
+        for i in np.flatnonzero(mask):
+            self._clusters[i] = self._cand_clusters[i]
+
+    def counts(self, chain, component):
+        return self.eng.get_counts(int(self.cur[chain]), component)

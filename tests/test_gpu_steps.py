@@ -202,3 +202,132 @@ def test_one_call_steps_at_baseline_workloads(name):
         want = _expected(feats, na, wl.groups, new_source, wl.concentration, wl.weights)
         _check_candidate(eng, 1, glh, mix, want, (name, "gibbs"))
         assert abs(lq - want_q) <= 3e-6 * abs(want_q) and abs(lqb - want_qb) <= 3e-6 * abs(want_qb)
+
+
+# ---- batched multi-chain step (sbe_step_batch) -----------------------------------------------------------------
+def test_step_batch_equals_single_steps():
+    """B chains stepped by ONE sbe_step_batch call give what B sbe_step calls give: counts, tables, per-group collapsed
+    values and changed-group flags bit for bit, the mixture scalar to rounding (its block geometry depends on the
+    launch's batch size); mixed deltas -- cluster moves, source rows, weights, nothing -- accepted and rejected."""
+    wl = make_workload("headline")
+    feats, na = wl.features, wl.na_values
+    N, F, S = wl.shape
+    C = wl.n_components
+    B = 12
+    rng = np.random.default_rng(8)
+    n_groups = [g.shape[0] for g in wl.groups]
+    with Engine(feats, n_groups, n_slots=2 * B) as eb, Engine(feats, n_groups, n_slots=2) as es:
+        for eng in (eb, es):
+            for c in range(C):
+                eng.set_concentration(c, wl.concentration[c])
+        states = []
+        for i in range(B):
+            clusters, weights, source = (wl.clusters, wl.weights, wl.source) if i == 0 else \
+                make_state(feats, wl.groups[1:], wl.clusters.shape[0], seed=300 + i)
+            eb.load_state(2 * i, [clusters] + wl.groups[1:], weights, source=source)
+            for c in range(C):
+                eb.update_probs(2 * i, c)
+            states.append((clusters, weights, source))
+        cur = np.arange(0, 2 * B, 2, dtype=np.int32)
+        cand = cur + 1
+        for sweep in range(4):
+            cl = np.stack([s[0] for s in states]).copy()
+            cm = np.zeros(B, dtype=bool)
+            wts = np.zeros((B, F, C), dtype=np.float32)
+            wm = np.zeros(B, dtype=bool)
+            ptr, objs_all, rows_all, new_states = [0], [], [], []
+            for i in range(B):
+                clusters, weights, source = states[i]
+                kind = (i + sweep) % 4
+                new_clusters, new_source, new_weights = clusters, source, weights
+                objs = np.zeros(0, dtype=np.int32)
+                rows = np.zeros((0, F, C), dtype=bool)
+                if kind in (0, 1):
+                    new_clusters, new_groups, objs, rows, new_source = _propose(
+                        rng, feats, na, [clusters] + wl.groups[1:], source, weights, 12 if kind == 0 else 0, True)
+                    cl[i], cm[i] = new_clusters, True
+                elif kind == 2:
+                    _c2, new_groups, objs, rows, new_source = _propose(rng, feats, na, [clusters] + wl.groups[1:], source,
+                                                                      weights, 25, False)
+                if kind in (1, 3) and i % 2 == 0:
+                    new_weights = rng.dirichlet(np.ones(C), size=F).astype(np.float32)
+                    wts[i], wm[i] = new_weights, True
+                objs_all.append(np.asarray(objs, dtype=np.int32))
+                rows_all.append(rows if rows is not None else np.zeros((0, F, C), dtype=bool))
+                ptr.append(ptr[-1] + len(objs))
+                new_states.append((new_clusters, new_weights, new_source))
+            glh, mix, changed = eb.step_batch(cur, cand, cl, cm, np.array(ptr, dtype=np.int32), np.concatenate(objs_all),
+                                              np.concatenate(rows_all), wts, wm)
+            for i in range(B):
+                clusters, weights, source = states[i]
+                es.load_state(0, [clusters] + wl.groups[1:], weights, source=source)
+                for c in range(C):
+                    es.update_probs(0, c)
+                es.mixture_loglik(0)
+                kw = {}
+                if cm[i]:
+                    kw["clusters"] = cl[i]
+                if len(objs_all[i]):
+                    kw.update(changed_objects=objs_all[i], source_rows=rows_all[i])
+                if wm[i]:
+                    kw["weights"] = wts[i]
+                g1, m1, c1 = es.step(0, 1, **kw)
+                assert np.array_equal(glh[i], g1) and np.array_equal(changed[i], c1), (sweep, i)
+                assert abs(mix[i] - m1) <= 1e-13 * abs(m1), (sweep, i, mix[i], m1)
+                for c in range(C):
+                    assert np.array_equal(eb.get_counts(int(cand[i]), c), es.get_counts(1, c))
+                    assert np.array_equal(eb.get_probs(int(cand[i]), c), es.get_probs(1, c))
+            accept = rng.random(B) < 0.7
+            cur, cand = np.where(accept, cand, cur).astype(np.int32), np.where(accept, cur, cand).astype(np.int32)
+            states = [new_states[i] if accept[i] else states[i] for i in range(B)]
+        # the resident states after the sweeps equal a from-scratch evaluation by the oracle
+        for i in (0, B - 1):
+            clusters, weights, source = states[i]
+            want = _expected(feats, na, [clusters] + wl.groups[1:], source, wl.concentration, weights)
+            got = eb.mixture_loglik(int(cur[i]))
+            assert abs(got - want[3]) <= 1e-10 * abs(want[3])
+            for c in range(C):
+                assert np.array_equal(eb.get_counts(int(cur[i]), c), want[0][c])
+
+
+@pytest.mark.parametrize("name,n_chains", [("south_america", 64), ("headline", 16)])
+def test_step_batch_replays_interleaved_reference_traces(name, n_chains):
+    """n_chains copies of the recorded reference MCMC trace, chain i lagging i steps behind chain i-1, stepped together
+    by sbe_step_batch through ResidentChainBatch: every chain reproduces the reference's recorded collapsed and mixture
+    log-likelihood at every step (chains that have not started or have finished pass an empty delta)."""
+    from sbayes_amd import model as sbm
+    from sbayes_amd.resident import ResidentChainBatch
+    from tests.test_gpu_dropin import build, load_case
+    fx, tr = load_case(name)
+    model, sample = build(fx)
+    n_steps = min(tr.n_steps, 120)
+    batch = ResidentChainBatch(model, [sample] * n_chains)
+    try:
+        deltas = []                                                # per trace step: (clusters or None, (objs, rows), weights or None)
+        prev_c, prev_w = fx.groups[0], fx.weights
+        for t in range(n_steps):
+            c, w = tr.clusters(t), tr.weights[t]
+            objs, rows = tr.source_delta(t)
+            deltas.append((c if not np.array_equal(c, prev_c) else None, (objs, rows),
+                           w if not np.array_equal(w, prev_w) else None))
+            prev_c, prev_w = c, w
+        for sweep in range(n_steps + n_chains - 1):
+            ts = [sweep - i for i in range(n_chains)]
+            live = [0 <= t < n_steps for t in ts]
+            ll, glh, mix = batch.step(clusters=[deltas[t][0] if ok else None for t, ok in zip(ts, live)],
+                                      source_rows=[deltas[t][1] if ok else None for t, ok in zip(ts, live)],
+                                      weights=[deltas[t][2] if ok else None for t, ok in zip(ts, live)])
+            for i, (t, ok) in enumerate(zip(ts, live)):
+                if ok:
+                    assert abs(ll[i] - tr.last_lh[t]) <= 1e-6 * abs(tr.last_lh[t]), (sweep, i, t)
+                    np.testing.assert_allclose(glh[i], tr.group_lh[t], rtol=1e-6, atol=1e-6)
+                    assert abs(mix[i] - tr.mixture_ll[t]) <= 1e-10 * abs(tr.mixture_ll[t]), (sweep, i, t)
+            batch.accept(np.array(live))
+        final_counts = orc.recalculate_feature_counts(fx.features, [tr.clusters(n_steps - 1)] + fx.groups[1:], tr.source(n_steps - 1))
+        for c in range(fx.n_comp):
+            assert np.array_equal(batch.counts(0, c), final_counts[c])
+            assert np.array_equal(batch.counts(n_chains - 1, c), final_counts[c])
+    finally:
+        batch.close()
+        from sbayes_amd.registry import release_all
+        release_all()
