@@ -639,7 +639,9 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     // rows form (k_mixture_rows): the general packed kernel whenever its LDS image fits -- 1024-thread blocks over
     // 32-feature (or 16-feature) tiles; SBE_MIXTURE_PACKED_V2 keeps the older k_mixture_v2 (A/B, tests)
     bool rows = !combo && !onehot && e->rows_ft != 0 && e->opt_kernel != SBE_MIXTURE_PACKED_V2;
-    const size_t rows_image = rows ? (size_t)(e->Gtot + 1) * (e->S + 1) * e->rows_ft * 4 + (size_t)P * ((e->C + 1) / 2) * e->rows_ft * 16 : 0;
+    const size_t rows_image = rows ? (size_t)(e->Gtot + 1) * (e->S + 1) * e->rows_ft * 4 + (size_t)P * ((e->C + 1) / 2) * e->rows_ft * 16
+                                         + (size_t)kRowsWaves * (kWave / e->rows_ft) * (e->C + 1) * 16 : 0;      // tables | weights | offset slots
+    if (rows && rows_image > 160 * 1024 - 512) rows = false;      // more patterns than the tile width was sized for
     // a single eval with a large image (stress shape: 153 KB per block) is staging-bound in the rows form (measured
     // 13.8 us against 12.5 us for k_mixture_v2's many small blocks); from two evals per launch on the rows form wins
     if (rows && n == 1 && rows_image > 72 * 1024 && e->opt_kernel != SBE_MIXTURE_PACKED_GENERAL) rows = false;
@@ -967,7 +969,10 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_RC(dmalloc(e, &e->d_toff, NS * e->Np + 64));       // + padding: the kernel prefetches 16 entries ahead
     CREATE_CHK(hipMemsetAsync(e->d_toff, 0, (NS * e->Np + 64) * sizeof(uint32_t), e->stream));
     if (C <= 4) {   // k_mixture_rows: widest tile whose LDS image (tables f32 [(Gtot+1)][S+1][ft] + f64 weight planes) fits
-        auto rows_lds = [&](int t) { return (size_t)(gtot + 1) * (S + 1) * t * 4 + (size_t)e->Pmax * ((C + 1) / 2) * t * 16; };
+        // (sized for half the possible has_components patterns: a component every object has -- `universal` -- halves
+        //  them; a launch whose slots really have more falls back to k_mixture_v2) + the waves' offset slots
+        const int p_assumed = std::max(1, e->Pmax / 2);
+        auto rows_lds = [&](int t) { return (size_t)(gtot + 1) * (S + 1) * t * 4 + (size_t)p_assumed * ((C + 1) / 2) * t * 16 + (size_t)kRowsWaves * (kWave / t) * (C + 1) * 16; };
         e->rows_ft = rows_lds(32) <= 160 * 1024 - 512 ? 32 : rows_lds(16) <= 160 * 1024 - 512 ? 16 : 0;
         if (const char* env = getenv("SBE_ROWS_FT")) { const int v = atoi(env); if (v == 0 || ((v == 16 || v == 32) && rows_lds(v) <= 160 * 1024 - 512)) e->rows_ft = v; }
         if (e->rows_ft) {

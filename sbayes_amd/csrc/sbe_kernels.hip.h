@@ -1101,16 +1101,22 @@ __global__ __launch_bounds__(kBlock) void k_mixture_onehot_v2(Mix2Params p) {
 //   tables  f32 [(Gtot+1)][S+1][FT]: row S of every group is the NA row (zeros), row block Gtot is "no group" (zeros)
 //   weights f64 planes [P][ceil(C/2)][FT][2]: one ds_read_b128 brings two components' weights, conflict-free
 //   offsets the LDS byte offset of every object's group row per component and of its weight pattern come precomputed
-//           (k_rowoff, [C+1][Np] u32 per slot): one v_add3 per (observation, component), no id decode, no multiply
+//           (k_rowoff, [NQ][C+1][4] u32 per slot): one add per (observation, component), no id decode, no multiply.
+//           They are per OBJECT, i.e. the same for the 32 lanes of a half-wave: loading them as five 16-byte lane
+//           loads per step made the kernel texture-addresser bound (a wave-wide dwordx4 load occupies the TA for 64
+//           lanes however few distinct addresses it carries: measured, removing every LDS gather changed nothing).
+//           So a wave fetches the 2 x (C+1) x 4 dwords of its step with ONE coalesced dword load (40 lanes), parks
+//           them in a private LDS slot and every lane reads its quad's five 16-byte rows back (LDS broadcast reads)
 //   NA      the accumulator starts at 1.0 for an NA observation and its table row is zero: v = 1 exactly, log 1 = 0,
 //           no select at the end
 // ==========================================================================================
 constexpr int kRowsBlock = 1024;
 constexpr int kRowsWaves = kRowsBlock / kWave;
 
-// Per-object LDS byte offsets of k_mixture_rows, rebuilt whenever a slot's group ids change:
-//   out[c][n]  (c < C) = row(g_c(n)) * (S+1) * FT * 4      row = global group index, Gtot for "no group"
-//   out[C][n]          = pattern(n) * ceil(C/2) * FT * 16  (weight planes of the object's has_components pattern)
+// Per-object LDS byte offsets of k_mixture_rows, rebuilt whenever a slot's group ids change; quad-major so that the
+// offsets a wave step needs (its object quads x (C+1) x 4 objects) are one contiguous run of dwords:
+//   out[q][c][j]  (c < C) = row(g_c(4q+j)) * (S+1) * FT * 4      row = global group index, Gtot for "no group"
+//   out[q][C][j]          = pattern(4q+j) * ceil(C/2) * FT * 16  (weight planes of the object's has_components pattern)
 // objects n >= N of the last quad get the "no group" row and pattern 0 (their state bytes are NA).
 __global__ void k_rowoff(const uint16_t* __restrict__ gid, const uint8_t* __restrict__ pid, uint32_t* __restrict__ out,
                          int64_t gid_stride, int64_t pid_stride, int64_t out_stride, int first_slot,
@@ -1120,6 +1126,7 @@ __global__ void k_rowoff(const uint16_t* __restrict__ gid, const uint8_t* __rest
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (c, n)
     if (i >= (C + 1) * Np) return;
     const int c = i / Np, n = i - c * Np;
+    const int o = ((n >> 2) * (C + 1) + c) * 4 + (n & 3);
     uint32_t v;
     if (c < C) {
         const uint32_t g = n < N ? gid[(int64_t)slot * gid_stride + (int64_t)c * Np + n] : (uint32_t)kNoGroup;
@@ -1127,7 +1134,7 @@ __global__ void k_rowoff(const uint16_t* __restrict__ gid, const uint8_t* __rest
     } else {
         v = (n < N ? (uint32_t)pid[(int64_t)slot * pid_stride + n] : 0u) * pat_bytes;
     }
-    out[(int64_t)slot * out_stride + i] = v;
+    out[(int64_t)slot * out_stride + o] = v;
 }
 
 template <int MODE, int FT, int CT>
@@ -1163,7 +1170,6 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
         const float* probs_t = p.probs_t + (int64_t)slot * p.probs_t_stride;
         const int n_tiles_e = (p.F + p.eft - 1) / p.eft;
         const int per_g = S * PPR;
-        const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
         constexpr int GU = 4, JU = 3;                                     // 12 sixteen-byte loads in flight per lane
         for (int gb = wave_s; gb <= p.Gtot; gb += GU * kRowsWaves) {
             for (int jb = lane_s; jb < per_g; jb += JU * kWave) {
@@ -1179,7 +1185,7 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
                         const int g = gb + u * kRowsWaves;
                         v[u][ju] = (j < per_g && g <= p.Gtot && te < n_tiles_e)
                             ? *reinterpret_cast<const uint4*>(probs_t + (((int64_t)te * (p.Gtot + 1) + g) * S + srow) * p.eft + fle)
-                            : zero4;
+                            : make_uint4(0u, 0u, 0u, 0u);
                     }
                 }
 #pragma unroll
@@ -1198,7 +1204,7 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
             for (int u = 0; u < GU; ++u) {                                // NA row of each of the four groups: zeros
                 const int g = gb + u * kRowsWaves;
                 if (g <= p.Gtot && lane_s < PPR)
-                    *reinterpret_cast<uint4*>(lds_raw + (uint32_t)(g * S1 + S) * state_bytes + (uint32_t)lane_s * 16u) = zero4;
+                    *reinterpret_cast<uint4*>(lds_raw + (uint32_t)(g * S1 + S) * state_bytes + (uint32_t)lane_s * 16u) = make_uint4(0u, 0u, 0u, 0u);
             }
         }
         double* wl = reinterpret_cast<double*>(lds_raw + tab_bytes);      // [P][CP][FT][2]
@@ -1226,32 +1232,52 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
     // the quad-interleaved state block (shared by every slot) and the slot's per-object row offsets
     const __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t*>(p.state_q), 0, (int)((uint32_t)p.NQ * (uint32_t)p.Fq * 4u), 0x00020000);
+    constexpr int QD = (CT + 1) * 4;                                      // offset dwords per quad
+    constexpr int WD = SUBS * QD;                                         // ... per wave step
+    constexpr int VPL = (WD + kWave - 1) / kWave;                         // dwords a lane fetches per step (1 or 2)
     const __amdgpu_buffer_rsrc_t ro_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t*>(p.rowoff + (int64_t)slot * p.rowoff_stride), 0, (int)((uint32_t)(CT + 1) * (uint32_t)p.Np * 4u), 0x00020000);
+        const_cast<uint32_t*>(p.rowoff + (int64_t)slot * p.rowoff_stride), 0, (int)((uint32_t)p.NQ * QD * 4u), 0x00020000);
     const uint32_t st_row = (uint32_t)p.Fq * 4u, st_col = (uint32_t)f * 4u;
-    const uint32_t ro_comp = (uint32_t)p.Np * 4u;                          // bytes between two components' offset rows
+    // the wave's private offset slot: WD dwords behind the tables and the weights
+    const uint32_t slot_lds = tab_bytes + (uint32_t)p.P * CP * FT * 16u + (uint32_t)wave * (WD * 4u);
+    const uint32_t my_rows = slot_lds + (uint32_t)sub * (QD * 4u);        // this lane's quad inside the slot
 
-    struct Step { uint32_t xs; u32x4_t ro[CT]; u32x4_t po; };
     auto local_quad = [&](int k) { return (k * kRowsWaves + wave) * SUBS + sub; };
-    auto load_step = [&](int k) -> Step {
-        Step st;
+    struct Raw { uint32_t xs; uint32_t ro[VPL]; };
+    auto load_raw = [&](int k) -> Raw {                                   // global loads of step k (state dword, offsets)
+        Raw r;
         const int i = local_quad(k);
         const uint32_t q = (uint32_t)(q0 + min(i, nq - 1));               // always in bounds
         const uint32_t xs = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, (int)(q * st_row + st_col), 0, 0);
-        st.xs = i < nq ? xs : na4;                                         // past the chunk: four NA observations
+        r.xs = i < nq ? xs : na4;                                         // past the chunk: four NA observations
+        // the wave's first quad of step k is (k*16 + wave)*SUBS; lane l fetches dword(s) l, l+64 of the run
+        const uint32_t run0 = (uint32_t)(q0 + (k * kRowsWaves + wave) * SUBS) * (QD * 4u);
 #pragma unroll
-        for (int c = 0; c < CT; ++c)
-            st.ro[c] = __builtin_amdgcn_raw_buffer_load_b128(ro_rsrc, (int)(q * 16u), (int)((uint32_t)c * ro_comp), 0);
-        st.po = __builtin_amdgcn_raw_buffer_load_b128(ro_rsrc, (int)(q * 16u), (int)((uint32_t)CT * ro_comp), 0);
-        return st;
+        for (int u = 0; u < VPL; ++u)                                     // (past the array: the descriptor returns 0)
+            r.ro[u] = __builtin_amdgcn_raw_buffer_load_b32(ro_rsrc, (int)(run0 + (uint32_t)(lane + u * kWave) * 4u), 0, 0);
+        return r;
+    };
+    auto park = [&](const Raw& r) {                                       // offsets of a step -> the wave's LDS slot
+#pragma unroll
+        for (int u = 0; u < VPL; ++u)
+            if (lane + u * kWave < WD)
+                *reinterpret_cast<uint32_t*>(lds_raw + slot_lds + (uint32_t)(lane + u * kWave) * 4u) = r.ro[u];
+    };
+    struct Offs { u32x4_t ro[CT]; u32x4_t po; };
+    auto fetch_offsets = [&]() -> Offs {                                  // this lane's quad: (C+1) broadcast reads
+        Offs o;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) o.ro[c] = *reinterpret_cast<const u32x4_t*>(lds_raw + my_rows + (uint32_t)c * 16u);
+        o.po = *reinterpret_cast<const u32x4_t*>(lds_raw + my_rows + (uint32_t)CT * 16u);
+        return o;
     };
     // the four observation likelihoods of a step (NA -> exactly 1.0)
-    auto step_values = [&](const Step& st, double (&v)[4]) {
+    auto step_values = [&](uint32_t xs, const Offs& o, double (&v)[4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t x = (st.xs >> (8 * j)) & 0xFFu;                 // <= S (NA / padding byte is S)
+            const uint32_t x = (xs >> (8 * j)) & 0xFFu;                    // <= S (NA / padding byte is S)
             const uint32_t xo = x * state_bytes + lane_tab;
-            const uint32_t pj = st.po[j];
+            const uint32_t pj = o.po[j];
             double w[2 * CP];
 #pragma unroll
             for (int h = 0; h < CP; ++h) {
@@ -1261,51 +1287,63 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
             double acc = x >= (uint32_t)S ? 1.0 : 0.0;
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                const float t = *reinterpret_cast<const float*>(lds_raw + st.ro[c][j] + xo);
+                const float t = *reinterpret_cast<const float*>(lds_raw + o.ro[c][j] + xo);
                 acc = fma(w[c], (double)t, acc);                          // exact product, one rounding: NumPy's order
             }
             v[j] = acc;
         }
     };
 
-    // Explicit two-stage software pipeline (ping-pong A / B): the loads of step k+1 are issued before the arithmetic
-    // of step k; the scheduling barriers keep hipcc from sinking them below it.
+    // Software pipeline: global loads two steps ahead (one dword of state, VPL dwords of offsets per lane), the
+    // offsets of step k+1 parked in LDS and read back while step k's arithmetic runs.  LDS operations of a wave
+    // complete in order, so the slot needs no barrier: the write of step k+1's offsets is issued after the reads
+    // of step k's (already in registers), and its read-back after that write.
     double thread_ll;
     {
         ProdAcc pa{1.0, 0, 0, 0u};
         double sum = 0.0;
-        auto consume = [&](const Step& st) {
+        constexpr int D = 4;                                             // global loads D steps ahead (2-3 VGPRs per step)
+        Raw g0 = load_raw(0), g1 = load_raw(1), g2 = load_raw(2), g3 = load_raw(3);      // (named: no runtime indexing)
+        park(g0);
+        uint32_t xs_cur = g0.xs;
+        Offs o_cur = fetch_offsets();
+        auto one_step = [&](int k, Raw& slot_next, Raw& slot_refill) __attribute__((always_inline)) {
+            // slot_next holds step k+1, slot_refill (the one step k used) is refilled with step k+D
+            slot_refill = load_raw(k + D);
+            __builtin_amdgcn_sched_barrier(0);
             double v[4];
-            step_values(st, v);
+            step_values(xs_cur, o_cur, v);
+            park(slot_next);                                             // offsets of step k+1 (o_cur is in registers)
+            const Offs o_next = fetch_offsets();
             if (MODE == LOG_PRODUCT) prod_add4(pa, v[0], v[1], v[2], v[3]);
             else { sum += log(v[0]); sum += log(v[1]); sum += log(v[2]); sum += log(v[3]); }
+            __builtin_amdgcn_sched_barrier(0);
+            xs_cur = slot_next.xs; o_cur = o_next;
         };
-        Step A = load_step(0), B;
-        int k = 0;
-        for (; k + 1 < n_steps; k += 2) {
-            B = load_step(k + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(A);
-            __builtin_amdgcn_sched_barrier(0);
-            A = load_step(k + 2);                                        // (clamped past the end: four NA observations)
-            __builtin_amdgcn_sched_barrier(0);
-            consume(B);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < n_steps; k += D) {                           // (n_steps is block-uniform: uniform branches)
+            one_step(k + 0, g1, g0);
+            if (k + 1 < n_steps) one_step(k + 1, g2, g1);
+            if (k + 2 < n_steps) one_step(k + 2, g3, g2);
+            if (k + 3 < n_steps) one_step(k + 3, g0, g3);
         }
-        if (k < n_steps) consume(A);
 #ifdef SBE_STAMPS
         if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 48 + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
         if (MODE == LOG_PRODUCT) {
             thread_ll = log(pa.mant) + (double)(pa.expo - 1023 * n_steps) * 0.693147180559945309417232;
-            if (__builtin_expect(pa.bad != 0u, 0)) {                     // rare: redo this thread per observation
+            // rare: a thread whose product left the positive normal range redoes its sum per observation.  Every lane
+            // of the wave takes part in the slot traffic, so the whole wave walks the steps again (wave-uniform branch)
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(pa.bad != 0u) != 0ull, 0)) {
                 double s2 = 0.0;
                 for (int kk = 0; kk < n_steps; ++kk) {
+                    const Raw r = load_raw(kk);
+                    park(r);
+                    const Offs o = fetch_offsets();
                     double v[4];
-                    step_values(load_step(kk), v);
+                    step_values(r.xs, o, v);
                     s2 += log(v[0]); s2 += log(v[1]); s2 += log(v[2]); s2 += log(v[3]);
                 }
-                thread_ll = s2;
+                if (pa.bad != 0u) thread_ll = s2;
             }
         } else thread_ll = sum;
     }

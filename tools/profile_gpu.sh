@@ -4,12 +4,12 @@
 # the stress shape, plus the FETCH_SIZE calibration.
 # Outputs under gpurun_out/prof_$TAG/ ; tools/summarize_profiles.py turns them into profiles/.
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
 BENCH="python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary"
-for kern in packed packed_tuple_lds packed_general onehot onehot_general; do
+for kern in packed packed_tuple_lds packed_general packed_v2 onehot onehot_general; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$kern -- $BENCH --kernel $kern > $OUT/bench_$kern.json 2> $OUT/bench_$kern.err
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
   echo "done $kern trace+fetch"
@@ -20,12 +20,18 @@ for kern in packed packed_tuple_lds packed_general onehot onehot_general; do
     echo "done $kern write+sq"
   fi
 done
-# stress shape (HBM/MALL streaming regime), packed + onehot, kernel trace + FETCH_SIZE
-for kern in packed onehot; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_stress_$kern -- python3 bench.py --workload stress --batch 8 --steps 30 --warmup 5 --no-cpu-baseline --no-secondary --kernel $kern > $OUT/bench_stress_$kern.json 2> $OUT/bench_stress_$kern.err
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_stress_$kern -- python3 bench.py --workload stress --batch 8 --steps 30 --warmup 5 --no-cpu-baseline --no-secondary --kernel $kern > /dev/null 2>&1
-  echo "done stress $kern"
+# stress shape (HBM/MALL streaming regime): rows kernel (default at B >= 2), the older general kernel, one-hot stream
+for kern in packed packed_v2 onehot; do
+  for B in 8 64; do
+    SB="python3 bench.py --workload stress --batch $B --steps 30 --warmup 5 --no-cpu-baseline --no-secondary --kernel $kern"
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_stress_${kern}_b$B -- $SB > $OUT/bench_stress_${kern}_b$B.json 2> $OUT/bench_stress_${kern}_b$B.err
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_stress_${kern}_b$B -- $SB > /dev/null 2>&1
+    echo "done stress $kern B=$B"
+  done
 done
+SB="python3 bench.py --workload stress --batch 64 --steps 30 --warmup 5 --no-cpu-baseline --no-secondary --kernel packed"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $OUT/pmc_sq1_stress_packed_b64 -- $SB > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2_stress_packed_b64 -- $SB > /dev/null 2>&1
 if [ -x tools/fetch_calib ]; then
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_calib -- ./tools/fetch_calib > $OUT/fetch_calib.log 2>&1
 fi

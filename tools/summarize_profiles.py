@@ -12,7 +12,7 @@ import sys
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parent.parent
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r1"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r2"
 SRC = REPO / "gpurun_out" / f"prof_{TAG}"
 DST = REPO / "profiles" / TAG
 DST.mkdir(parents=True, exist_ok=True)
@@ -60,14 +60,14 @@ corr4 = 1.0 / calib["read_dword"]["reported_fraction"] if "read_dword" in calib 
 corr16 = 1.0 / calib["read_dwordx4"]["reported_fraction"] if "read_dwordx4" in calib else None
 
 traffic = {}
-for wl, batch in (("headline", 1024), ("stress", 8)):
-    for kern in ("packed", "packed_tuple_lds", "packed_general", "onehot", "onehot_general"):
-        if wl == "stress" and kern not in ("packed", "onehot"):
-            continue
-        suffix = kern if wl == "headline" else f"stress_{kern}"
-        prefix = {"packed": "sbe::k_mixture_tuple64" if wl == "headline" else "sbe::k_mixture_v2",
+CASES = [("headline", 1024, k) for k in ("packed", "packed_tuple_lds", "packed_general", "packed_v2", "onehot", "onehot_general")] + \
+        [("stress", b, k) for k in ("packed", "packed_v2", "onehot") for b in (8, 64)]
+for wl, batch, kern in CASES:
+        suffix = kern if wl == "headline" else f"stress_{kern}_b{batch}"
+        prefix = {"packed": "sbe::k_mixture_tuple64" if wl == "headline" else "sbe::k_mixture_rows",
                   "packed_tuple_lds": "sbe::k_mixture_combo",
-                  "packed_general": "sbe::k_mixture_v2",
+                  "packed_general": "sbe::k_mixture_rows",
+                  "packed_v2": "sbe::k_mixture_v2",
                   "onehot": "sbe::k_mixture_combo" if wl == "headline" else "sbe::k_mixture_onehot_v2",
                   "onehot_general": "sbe::k_mixture_onehot_v2"}[kern]
         entry = {}
@@ -87,8 +87,7 @@ for wl, batch in (("headline", 1024), ("stress", 8)):
             traffic[f"{wl}:{kern}:{batch}"] = entry
         sq = {}
         for part in ("sq1", "sq2"):
-            if wl == "headline":
-                sq.update({k: v["mean"] for k, v in dominant(counters(f"pmc_{part}_{suffix}"), prefix).items()})
+            sq.update({k: v["mean"] for k, v in dominant(counters(f"pmc_{part}_{suffix}"), prefix).items()})
         if sq:
             summary[f"sq_counters_{wl}_{kern}_b{batch}"] = sq
         for f in newest(str(SRC / f"trace_{suffix}" / "*" / "*_kernel_stats.csv")):
