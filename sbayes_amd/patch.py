@@ -25,9 +25,46 @@ has to cross PCIe for them:
 Proposal logic, RNG use and everything else of the operators stay the reference's."""
 from __future__ import annotations
 
+import hashlib
 import importlib
+import inspect
+import warnings
 
 _SAVED = []
+
+# A replaced method shadows whatever the reference does there, so each device form is tied to the reference body it
+# mirrors: SHA-1 of the method's source text with whitespace runs collapsed, taken from the reference revision this
+# package was written against.  install(operators=True) warns when an installed sBayes differs (VERDICT r1, nit 9):
+# the swap still happens, but not silently.
+MIRRORED_SOURCES = {
+    "ClusterJump.get_jump_lh": "dcb154279abc275f24d212722ed22fdf83e18041",
+    "GibbsSampleWeights._propose": "c68637810ba27a9cd84c54087ae1341861046e9a",
+    "GibbsSampleWeights.source_lh_by_feature": "0952193be39ab7f1fb99c1fe64fa88568e3d9312",
+    "AlterCluster.compute_cluster_posterior": "380025299a64acc90921c0fe29fd9fcc70c8410a",
+    "AlterClusterWide.compute_raw_cluster_probs": "71b78b6ef2cd63cd72091c9f90d787df26b9fa97",
+    "AlterCluster.compute_feature_weights_with_and_without": "0cf7022db29a8d50a4395338c604350fac790eb6",
+    "GibbsSampleSource.calculate_source_posterior": "042ce6497bc2b08ffe197946aeaeab98a5e24bce",
+    "sbayes.sampling.operators.component_likelihood_given_unchanged": "de5b027624d8597d43f08e2577d0035607c22d51",
+    "LikelihoodLogger._write_sample": "5f892d865e576862f5e1730acbf3b18efc7af9da",
+    "ClusterEffectProposals.expected_confounder_features": "efb685c5e0b1f2818dde1f2244d6f0ff086107cc",
+}
+
+
+def source_digest(obj) -> str:
+    """SHA-1 of an object's source text, whitespace runs collapsed (formatting changes do not count)."""
+    return hashlib.sha1(" ".join(inspect.getsource(obj).split()).encode()).hexdigest()
+
+
+def _check_mirrored(owner, name):
+    key = f"{getattr(owner, '__name__', owner)}.{name}"
+    want = MIRRORED_SOURCES.get(key)
+    try:
+        got = source_digest(inspect.getattr_static(owner, name) if inspect.isclass(owner) else getattr(owner, name))
+    except (OSError, TypeError, AttributeError):
+        return
+    if want is not None and got != want:
+        warnings.warn(f"sbayes_amd.patch: the installed sBayes' {key} differs from the revision its device form mirrors; "
+                      f"the device form replaces it anyway -- re-check sbayes_amd/operators.py against it", RuntimeWarning)
 
 
 def install(operators=False):
@@ -152,6 +189,16 @@ def _install_operator_forms(swap):
             ref_ops.update_weights = saved_update
             ref_ops.GibbsSampleWeights.source_lh_by_feature = saved_lh
 
+    for owner, name in ((ref_ops.ClusterJump, "get_jump_lh"), (ref_ops.GibbsSampleWeights, "_propose"),
+                        (ref_ops.GibbsSampleWeights, "source_lh_by_feature"),
+                        (ref_ops.AlterCluster, "compute_cluster_posterior"),
+                        (ref_ops.AlterClusterWide, "compute_raw_cluster_probs"),
+                        (ref_ops.AlterCluster, "compute_feature_weights_with_and_without"),
+                        (ref_ops.GibbsSampleSource, "calculate_source_posterior"),
+                        (ref_ops, "component_likelihood_given_unchanged"),
+                        (ref_ops.ClusterEffectProposals, "expected_confounder_features")):
+        if hasattr(owner, name):
+            _check_mirrored(owner, name)
     swap(ref_ops.ClusterJump, "get_jump_lh", get_jump_lh)
     swap(ref_ops.GibbsSampleWeights, "_propose", gibbs_weights_propose)
     swap(ref_ops.AlterCluster, "compute_cluster_posterior", compute_cluster_posterior)
@@ -167,6 +214,7 @@ def _install_operator_forms(swap):
         ref_loggers = None
     if ref_loggers is not None and hasattr(ref_loggers, "LikelihoodLogger"):
         from . import conditionals as my_cond
+        _check_mirrored(ref_loggers.LikelihoodLogger, "_write_sample")
 
         def _write_sample(self, sample):
             lh = my_cond.observation_likelihoods(self.model, sample, exact=True).ravel()

@@ -7,6 +7,7 @@ shape.  Engines are created lazily in the process that uses them and are never p
 from __future__ import annotations
 
 import os
+import warnings
 import weakref
 
 import numpy as np
@@ -18,6 +19,18 @@ _ENGINES: dict = {}
 
 def _key(features: np.ndarray):
     return (features.ctypes.data, features.shape, features.strides)
+
+
+def _extent(key):
+    """[lo, hi) byte range the elements of the (bool) array behind a registry key lie in."""
+    lo = hi = key[0]
+    for n, st in zip(key[1], key[2]):
+        if n > 1:
+            if st > 0:
+                hi += (n - 1) * st
+            else:
+                lo += (n - 1) * st
+    return lo, hi + 1
 
 
 def get_engine(features, n_groups=None, n_slots=4, device=None) -> Engine:
@@ -35,6 +48,15 @@ def get_engine(features, n_groups=None, n_slots=4, device=None) -> Engine:
         del _ENGINES[key]
     if device is None:
         device = default_device()
+    lo, hi = _extent(key)
+    for okey, (_, oref) in _ENGINES.items():
+        olo, ohi = _extent(okey)
+        if (oref is None or oref() is not None) and olo < hi and lo < ohi:
+            warnings.warn("sbayes_amd.registry: a second engine is created for another view of a feature block that "
+                          f"already has one (shape {okey[1]} at {okey[0]:#x}, now {features.shape} at {key[0]:#x}); "
+                          "pass the same array object (e.g. data.features.values once, not a fresh slice per call) to "
+                          "share the resident copy", RuntimeWarning, stacklevel=2)
+            break
     eng = Engine(features, list(n_groups) if n_groups is not None else [1], n_slots=n_slots, device=device)
     try:
         ref = weakref.ref(features)

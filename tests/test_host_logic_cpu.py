@@ -174,6 +174,33 @@ def test_normalize_weights_never_creates_engines_per_row_count(monkeypatch):
     assert len(made) == 1 and made[0].n_features == 7
 
 
+def test_registry_warns_about_a_second_engine_for_another_view_of_the_same_block(monkeypatch):
+    """VERDICT r1 nit 9: engines are keyed on the data pointer; a caller that re-slices the feature block per call
+    would silently get a second resident copy.  Now it is told."""
+    class Stub:
+        def __init__(self, features, n_groups, n_slots=1, device=0):
+            self.n_objects, self.n_features, self.n_states = features.shape
+            self.n_groups = list(n_groups)
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(registry, "Engine", Stub)
+    monkeypatch.setattr(registry, "_ENGINES", {})
+    monkeypatch.setattr(registry, "default_device", lambda: 0)
+    block = np.zeros((12, 5, 3), dtype=bool)
+    other = np.zeros((12, 5, 3), dtype=bool)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        e1 = registry.get_engine(block)
+        assert registry.get_engine(block) is e1                # same array: same engine, no warning
+        registry.get_engine(other)                             # an unrelated block: no warning
+    with pytest.warns(RuntimeWarning, match="second engine"):
+        e2 = registry.get_engine(block[2:])                    # another view of the first block
+    assert e2 is not e1
+
+
 def test_likelihood_pickles_without_device_state(fake):
     fx = load_npz("cfg1")
     model, sample = build(fx)

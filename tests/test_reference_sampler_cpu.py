@@ -134,6 +134,28 @@ def test_reference_sampler_with_device_operator_forms(tag, src, n_steps, monkeyp
     assert n_counts < n_eval * len(eng.conc), (n_counts, n_eval, len(eng.conc))
 
 
+def test_operator_forms_are_tied_to_the_reference_bodies_they_mirror(monkeypatch):
+    """patch.install(operators=True) replaces whole reference methods; each replacement is tied to the SHA-1 of the
+    reference body it mirrors (patch.MIRRORED_SOURCES), so a reference revision that changes one of them is reported
+    instead of silently shadowed (VERDICT r1 nit 9).  Here: the reference in this container matches every digest (no
+    warning), and a changed digest warns."""
+    import warnings
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import _ref_stubs
+    _ref_stubs.install()
+    from sbayes_amd import patch
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        patch.install(operators=True)
+        patch.uninstall()
+    monkeypatch.setitem(patch.MIRRORED_SOURCES, "ClusterJump.get_jump_lh", "0" * 40)
+    try:
+        with pytest.warns(RuntimeWarning, match="ClusterJump.get_jump_lh differs"):
+            patch.install(operators=True)
+    finally:
+        patch.uninstall()
+
+
 def test_likelihood_logger_row_from_the_device_form(monkeypatch, tmp_path):
     """patch.install(operators=True) also serves LikelihoodLogger._write_sample (loggers.py:354-359) from the device
     form of the per-observation likelihood: the appended row equals the reference's, bit for bit."""
