@@ -645,6 +645,16 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     // a single eval with a large image (stress shape: 153 KB per block) is staging-bound in the rows form (measured
     // 13.8 us against 12.5 us for k_mixture_v2's many small blocks); from two evals per launch on the rows form wins
     if (rows && n == 1 && rows_image > 72 * 1024 && e->opt_kernel != SBE_MIXTURE_PACKED_GENERAL) rows = false;
+    // The rows form needs long object ranges (a 1024-thread block covers 32 quads per step) and enough observations
+    // per launch to fill one block per CU; below that k_mixture_v2's 256-thread blocks win.  Thresholds from
+    // tools/rows_crossover.py on an MI355X (kernel time of both forms over N = 500..5000, B = 8..256, C = 2 / 4,
+    // and the stress shape itself): they depend on the tile width k_mixture_v2 would run at (64: efficient, 16: not).
+    if (rows && e->opt_kernel != SBE_MIXTURE_PACKED_GENERAL) {
+        const int64_t obs = (int64_t)n * e->N * e->F;
+        const int64_t min_obs = g.ft >= 64 ? 64000000 : g.ft >= 32 ? 24000000 : 10000000;
+        const int min_quads = g.ft >= 64 ? 500 : g.ft >= 32 ? 375 : 250;
+        if (obs < min_obs || e->NQ < min_quads) rows = false;
+    }
     if (rows) {
         const int rft = e->rows_ft, gran = kRowsWaves * (kWave / rft);         // quads per block step
         const int n_t = div_up(e->F, rft);

@@ -1328,6 +1328,8 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
         }
 #ifdef SBE_STAMPS
         if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 48 + 2] = __builtin_amdgcn_s_memrealtime();
+        if (p.stamps && lane == 0) p.stamps[(size_t)blockIdx.x * 48 + 4 + wave] = __builtin_amdgcn_s_memrealtime();       // per wave:
+        if (p.stamps && lane == 0) p.stamps[(size_t)blockIdx.x * 48 + 20 + wave] = __builtin_amdgcn_ballot_w64(pa.bad != 0u);   // loop end, bad lanes
 #endif
         if (MODE == LOG_PRODUCT) {
             thread_ll = log(pa.mant) + (double)(pa.expo - 1023 * n_steps) * 0.693147180559945309417232;
