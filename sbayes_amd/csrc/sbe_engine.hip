@@ -542,6 +542,7 @@ int tuple64_waves() {
 }
 
 void launch_tuple64(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
+    if (const char* env = getenv("SBE_T64_LDS_PAD")) lds += (size_t)atoi(env);        // experiments: fewer blocks per CU
     // 16-bit tuple-block offsets when the whole log table sits below 64 KiB
     const bool off16 = (int64_t)p.KT * (p.S + 1) * 512 <= 65536;
     if (tuple64_waves() == 8) { if (off16) launch_tuple64_o<true, 8>(C, p, grid, lds, st); else launch_tuple64_o<false, 8>(C, p, grid, lds, st); }
@@ -715,6 +716,7 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
         p.ragged_w = (tuple64 && e->F % 64 != 0 && e->F % 64 <= 32) ? e->F % 64 : 0;
         if (combo && tuple64) {   // own block order (slots dealt to XCDs, generations, heavy work items first; see the kernel)
             p.gen_slots = std::max(1, (4 * e->compute_units / 8) / g.n_blocks);
+            if (const char* env = getenv("SBE_T64_GEN_SLOTS")) { if (atoi(env) > 0) p.gen_slots = atoi(env); }      // experiments: block order
             const int gens = div_up(div_up(n, 8), p.gen_slots);
             grid = n >= 8 ? dim3(8 * gens * p.gen_slots * g.n_blocks, 1) : dim3(n * g.n_blocks, 1);
         }

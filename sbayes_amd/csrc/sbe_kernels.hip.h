@@ -159,10 +159,14 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const f64x2_t lds_cf64x2_t;
 constexpr int kLogTabEntries = 128;
 
-__device__ __forceinline__ double tab_log_pos(double v, uint32_t tab) {
+// (tab_log_core: the straight-line part, garbage for arguments that are not positive normal doubles --
+//  tab_log_special tells; callers that interleave several logs test the specials once, after the batch)
+__device__ __forceinline__ bool tab_log_special(double v) {
+    return ((uint32_t)__double2hiint(v) >> 20) - 1u >= 0x7FEu;
+}
+__device__ __forceinline__ double tab_log_core(double v, uint32_t tab) {
     const uint32_t hi = (uint32_t)__double2hiint(v);
     const uint32_t ex = hi >> 20;                                 // sign + exponent
-    if (__builtin_expect(ex - 1u >= 0x7FEu, 0)) return log(v);
     const f64x2_t e = *(lds_cf64x2_t*)(uintptr_t)(tab + ((hi >> 9) & 0x7F0u));        // entry (hi >> 13) & 127
     const double m = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), __double2loint(v));
     const double r = fma(m, e.x, -1.0);
@@ -175,6 +179,10 @@ __device__ __forceinline__ double tab_log_pos(double v, uint32_t tab) {
     const double lp = fma(r * r, q, r);                           // log1p(r)
     const double kd = (double)((int)ex - 1023);
     return fma(kd, 6.93147180369123816490e-01, e.y) + fma(kd, 1.90821492927058770002e-10, lp);
+}
+__device__ __forceinline__ double tab_log_pos(double v, uint32_t tab) {
+    if (__builtin_expect(tab_log_special(v), 0)) return log(v);
+    return tab_log_core(v, tab);
 }
 
 __global__ void k_test_tab_log(const double* __restrict__ in, const double2* __restrict__ logtab,
@@ -1614,14 +1622,14 @@ __global__ __launch_bounds__(NW * kWave, NW == 8 ? 6 : 1) void k_mixture_tuple64
             const int gen = j / (p.gen_slots * p.n_work), jj = j - gen * (p.gen_slots * p.n_work);
             const int s0 = gen * p.gen_slots, s_gen = min(p.gen_slots, slots_here - s0);   // this generation's slots
             if (s_gen <= 0) return;                                          // padding blocks (before any barrier)
-            const int heavy_gen = s_gen * n_heavy;
+            const int heavy_gen = s_gen * n_heavy, light_gen = s_gen * n_light;
             int sl, wk;
-            if (jj < heavy_gen) {
+            const int jh = jj, jl = jj - heavy_gen;
+            if (jh < heavy_gen) {
                 const int ht = p.n_ftiles - (n_light ? 1 : 0);               // heavy tiles
-                sl = jj / n_heavy; wk = jj - sl * n_heavy; wk = (wk / ht) * p.n_ftiles + wk % ht;
+                sl = jh / n_heavy; wk = jh - sl * n_heavy; wk = (wk / ht) * p.n_ftiles + wk % ht;
             } else {
-                const int jl = jj - heavy_gen;
-                if (jl >= s_gen * n_light) return;                           // padding
+                if (jl >= light_gen) return;                                 // padding
                 sl = jl / n_light; wk = (jl - sl * n_light) * p.n_ftiles + (p.n_ftiles - 1);
             }
             slot_i = (s0 + sl) * 8 + xcd; work = wk;
@@ -1690,13 +1698,6 @@ __global__ __launch_bounds__(NW * kWave, NW == 8 ? 6 : 1) void k_mixture_tuple64
     constexpr int QB = 4;
     uint4 offv = make_uint4(0u, 0u, 0u, 0u);
     u32x2_t xa[QB], xb[QB];
-    if (!ragged) {
-        offv = load_offsets(0);
-#pragma unroll
-        for (int i = 0; i < QB; ++i) xa[i] = load_quad(i);
-#pragma unroll
-        for (int i = 0; i < QB; ++i) xb[i] = load_quad(QB + i);
-    }
 
     // ---- table-build operands of the wave's first rows, also in flight before the first barrier --------
     // A wave owns rows r = w, w+4, .. of the KT*S (tuple, state) rows; lane l <-> its l-th row (64 rows per
@@ -1732,16 +1733,42 @@ __global__ __launch_bounds__(NW * kWave, NW == 8 ? 6 : 1) void k_mixture_tuple64
             }
         }
     };
-    if (my_rows > 0) { row_offsets(0); row_loads(0, min(kWave, my_rows)); }
+    // Start-up loads in TWO dependent levels (a block's start is pure memory latency, ~1 us per level under
+    // load): level 1 = everything that needs no other load -- the tuple rows / patterns of the wave's table rows
+    // (issued first: level 2 waits for them only), the tile's weights, the log table, the gather operands --
+    // level 2 = the probability rows; the LDS fills follow.
+    if (my_rows > 0) row_offsets(0);
+    const double* wpat_t = p.wpat_t + (int64_t)slot * p.wpat_t_stride + (int64_t)tile * p.wpat_tile_stride;
+    const int n_wl = p.P * C * FT;
+    constexpr int WPRE = 2;                                                  // weight loads per thread held in registers
+    double w_pre[WPRE];
+#pragma unroll
+    for (int j = 0; j < WPRE; ++j) {
+        const int k = (int)threadIdx.x + j * kThreads;
+        w_pre[j] = k < n_wl ? wpat_t[k] : 0.0;
+    }
+    const int lt_i = (int)threadIdx.x & (2 * kLogTabEntries - 1);            // (8-wave blocks: the upper half repeats)
+    const double lt_pre = reinterpret_cast<const double*>(p.logtab)[lt_i];   // 256 doubles
+    if (!ragged) {
+        offv = load_offsets(0);
+#pragma unroll
+        for (int i = 0; i < QB; ++i) xa[i] = load_quad(i);
+#pragma unroll
+        for (int i = 0; i < QB; ++i) xb[i] = load_quad(QB + i);
+    }
+    if (my_rows > 0) row_loads(0, min(kWave, my_rows));
 
     {   // weights of the tile, the NA rows, the log table
-        const double* wpat_t = p.wpat_t + (int64_t)slot * p.wpat_t_stride + (int64_t)tile * p.wpat_tile_stride;
         double* wls = reinterpret_cast<double*>(lds_raw + w_off);
-        for (int k = threadIdx.x; k < p.P * C * FT; k += kThreads) wls[k] = wpat_t[k];
+#pragma unroll
+        for (int j = 0; j < WPRE; ++j) {
+            const int k = (int)threadIdx.x + j * kThreads;
+            if (k < n_wl) wls[k] = w_pre[j];
+        }
+        for (int k = (int)threadIdx.x + WPRE * kThreads; k < n_wl; k += kThreads) wls[k] = wpat_t[k];
         double* T = reinterpret_cast<double*>(lds_raw);
         for (int e = threadIdx.x; e < KT * FT; e += kThreads) T[((e >> 6) * S1 + S) * FT + (e & 63)] = 0.0;
-        if (threadIdx.x < 2 * kLogTabEntries)
-            reinterpret_cast<double*>(lds_raw + tab_off)[threadIdx.x] = reinterpret_cast<const double*>(p.logtab)[threadIdx.x];   // 256 doubles
+        if (threadIdx.x < 2 * kLogTabEntries) reinterpret_cast<double*>(lds_raw + tab_off)[threadIdx.x] = lt_pre;
     }
     SBE_STAMP();
     __syncthreads();
@@ -1757,11 +1784,23 @@ __global__ __launch_bounds__(NW * kWave, NW == 8 ? 6 : 1) void k_mixture_tuple64
                 if (base) row_offsets(base);
                 for (int i0 = 0; i0 < n_here; i0 += U) {
                     if (base || i0) row_loads(i0, n_here);                      // (the first batch is already in flight)
+                    // G rows at a time: the G log chains (each ~20 dependent FMAs) are straight-line code the
+                    // scheduler interleaves -- a wave that walks its rows one by one issues one vector instruction per
+                    // dependent-issue latency and four such waves do not fill a SIMD (measured: a block alone on
+                    // its CU is only 20 % faster than one of four)
+                    constexpr int G = U < 4 ? U : 4;
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        if (i0 + u < n_here && (uint32_t)__builtin_amdgcn_readlane((int)v_doff, i0 + u) != 0xFFFFFFFFu) {
+                    for (int u0 = 0; u0 < U; u0 += G) {
+                        double vv[G];
+                        uint32_t dd[G];
+                        bool ok[G];
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            const int u = u0 + g;                                // (i0 + u <= 63: U divides 64)
+                            const uint32_t doff_s = (uint32_t)__builtin_amdgcn_readlane((int)v_doff, i0 + u);
+                            ok[g] = i0 + u < n_here && doff_s != 0xFFFFFFFFu;     // wave-uniform
                             const uint32_t woff = (uint32_t)__builtin_amdgcn_readlane((int)v_woff, i0 + u) + lane8;
-                            const uint32_t doff = (uint32_t)__builtin_amdgcn_readlane((int)v_doff, i0 + u) + lane8;
+                            dd[g] = doff_s + lane8;
                             double v = 0.0;
 #pragma unroll
                             for (int c = 0; c < CU; ++c) {
@@ -1771,12 +1810,25 @@ __global__ __launch_bounds__(NW * kWave, NW == 8 ? 6 : 1) void k_mixture_tuple64
                                     v = c == 0 ? term : v + term;               // NumPy order, no FMA
                                 }
                             }
-#ifdef SBE_ABL_NOLOG
-                            *(lds_double_t*)(uintptr_t)doff = live ? v : 1.0;
-#else
-                            *(lds_double_t*)(uintptr_t)doff = tab_log_pos(live ? v : 1.0, tab_off);   // dead lanes of the last tile: log 1
-#endif
+                            vv[g] = (ok[g] && live) ? v : 1.0;                   // dead lanes of the last tile, rows not there: log 1
                         }
+#ifdef SBE_ABL_NOLOG
+                        double lg[G];
+#pragma unroll
+                        for (int g = 0; g < G; ++g) lg[g] = vv[g];
+#else
+                        double lg[G];
+                        bool special = false;
+#pragma unroll
+                        for (int g = 0; g < G; ++g) { lg[g] = tab_log_core(vv[g], tab_off); special |= tab_log_special(vv[g]); }
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0ull, 0)) {     // rare: library log
+#pragma unroll
+                            for (int g = 0; g < G; ++g) if (tab_log_special(vv[g])) lg[g] = log(vv[g]);
+                        }
+#endif
+#pragma unroll
+                        for (int g = 0; g < G; ++g)
+                            if (ok[g]) *(lds_double_t*)(uintptr_t)dd[g] = lg[g];
                     }
                 }
             }
@@ -1845,44 +1897,82 @@ __global__ __launch_bounds__(NW * kWave, NW == 8 ? 6 : 1) void k_mixture_tuple64
         }
     } else {
         // ---- sub-row mode for a narrow last tile (ragged_w <= 32 valid features): RW lanes per row, 64/RW
-        // rows per wave step, everything per lane (vector side).  ~64/RW times less work than a full tile. --
+        // rows per wave step, everything per lane (vector side).  ~64/RW times less work than a full tile, so the
+        // block is all memory latency: every load that does not depend on another is issued up front -- the first
+        // batch of gather operands before the table build, the build's operands for RI rows per lane in two
+        // levels (tuple rows / patterns, then probabilities) instead of three levels per row. --
         int sh = 0;
         while ((1 << sh) < p.ragged_w) ++sh;                                 // RW = 1 << sh lanes per row
         const int RW = 1 << sh, SUB = kWave >> sh;
         const int fl = lane & (RW - 1), sub = lane >> sh;
         const bool live = fl < p.ragged_w;
-        for (int r0 = w * SUB; r0 < n_rows; r0 += NW * SUB) {
-            const int r = r0 + sub;
-            if (r < n_rows && tuple_p[(uint32_t)r / (uint32_t)S] != 0xFFu) {
-                const uint32_t t = (uint32_t)r / (uint32_t)S, st = (uint32_t)r - t * (uint32_t)S;
-                const double* wr = reinterpret_cast<const double*>(lds_raw + w_off) + (uint32_t)tuple_p[t] * (uint32_t)(C * FT) + fl;
+        const uint2* sh2 = p.state_h + (int64_t)(q0 + qa) * p.Fq + (tile * FT + fl);
+        uint2 x[8]; uint4 o[8];
+        auto load_batch = [&](int ql0) {                                    // 8 steps' gather operands
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ql = max(0, min(ql0 + u * SUB + sub, n_my - 1));
+                x[u] = sh2[(int64_t)ql * p.Fq];
+                o[u] = toff4[ql];
+            }
+        };
+#ifdef SBE_ABL_NOGATHER
+        if (p.N < 0)
+#endif
+        if (n_my > 0) load_batch(0);
+        constexpr int RI = CU <= 2 ? 4 : (CU <= 4 ? 2 : 1);                 // rows per lane and pass
+        for (int r0 = w * SUB; r0 < n_rows; r0 += NW * SUB * RI) {
+            uint32_t t[RI], st[RI], pat[RI], gr[RI][CU];
+            float pc[RI][CU];
+#pragma unroll
+            for (int i = 0; i < RI; ++i) {
+                const uint32_t r = (uint32_t)min(r0 + i * NW * SUB + sub, n_rows - 1);
+                t[i] = r / (uint32_t)S; st[i] = r - t[i] * (uint32_t)S;
+                pat[i] = tuple_p[t[i]];
+#pragma unroll
+                for (int c = 0; c < CU; ++c)
+                    gr[i][c] = (CT || c < C) ? (uint32_t)tuple_g[t[i] * kMaxComponents + c] : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < RI; ++i)
+#pragma unroll
+                for (int c = 0; c < CU; ++c)
+                    pc[i][c] = (CT || c < C) ? probs_tile[(gr[i][c] * (uint32_t)S + st[i]) * FT + fl] : 0.0f;
+            double vv[RI], lg[RI];
+            bool ok[RI], special = false;
+#pragma unroll
+            for (int i = 0; i < RI; ++i) {
+                // (a tuple this slot does not have -- pattern 0xFF -- has no row: skipped)
+                ok[i] = r0 + i * NW * SUB + sub < n_rows && pat[i] != 0xFFu;
+                const double* wr = reinterpret_cast<const double*>(lds_raw + w_off) + (ok[i] ? pat[i] : 0u) * (uint32_t)(C * FT) + fl;
                 double v = 0.0;
 #pragma unroll
                 for (int c = 0; c < CU; ++c) {
                     if (CT || c < C) {
-                        const float pc = probs_tile[((uint32_t)tuple_g[t * kMaxComponents + c] * (uint32_t)S + st) * FT + fl];
-                        const double term = wr[c * FT] * (double)pc;
+                        const double term = wr[c * FT] * (double)pc[i][c];
                         v = c == 0 ? term : v + term;                           // NumPy order, no FMA
                     }
                 }
-                *(lds_double_t*)(uintptr_t)((t * (uint32_t)S1 + st) * (FT * 8u) + (uint32_t)fl * 8u) = tab_log_pos(live ? v : 1.0, tab_off);
+                vv[i] = (ok[i] && live) ? v : 1.0;
             }
+#pragma unroll
+            for (int i = 0; i < RI; ++i) { lg[i] = tab_log_core(vv[i], tab_off); special |= tab_log_special(vv[i]); }   // interleaved chains
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0ull, 0)) {                 // rare: library log
+#pragma unroll
+                for (int i = 0; i < RI; ++i) if (tab_log_special(vv[i])) lg[i] = log(vv[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < RI; ++i)
+                if (ok[i]) *(lds_double_t*)(uintptr_t)((t[i] * (uint32_t)S1 + st[i]) * (FT * 8u) + (uint32_t)fl * 8u) = lg[i];
         }
         SBE_STAMP();
         __syncthreads();
         SBE_STAMP();
-        const uint2* sh2 = p.state_h + (int64_t)(q0 + qa) * p.Fq + (tile * FT + fl);
 #ifdef SBE_ABL_NOGATHER
         if (p.N < 0)
 #endif
-        for (int ql0 = 0; ql0 < n_my; ql0 += 8 * SUB) {                      // 8 steps' loads in flight
-            uint2 x[8]; uint4 o[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int ql = min(ql0 + u * SUB + sub, n_my - 1);
-                x[u] = sh2[(int64_t)ql * p.Fq];
-                o[u] = toff4[ql];
-            }
+        for (int ql0 = 0; ql0 < n_my; ql0 += 8 * SUB) {
+            if (ql0) load_batch(ql0);                                        // (the first batch is already in flight)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (ql0 + u * SUB + sub < n_my) {
