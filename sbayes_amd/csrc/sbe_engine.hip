@@ -534,19 +534,16 @@ void launch_tuple64_o(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStre
     }
 }
 
-// waves per block of k_mixture_tuple64: 4, or 8 (twice the waves share one log table: more waves per SIMD at the
-// same LDS footprint) -- SBE_T64_NW selects (experiments)
-int tuple64_waves() {
-    static const int nw = [] { const char* env = getenv("SBE_T64_NW"); return env && atoi(env) == 8 ? 8 : 4; }();
-    return nw;
-}
+// waves per block of k_mixture_tuple64.  (8-wave blocks -- twice the waves per SIMD at the same LDS footprint -- were
+// measured twice: 72.7 us at 80 VGPRs / 3 blocks per CU, 107 us at 64 VGPRs / 4 blocks per CU, against 61-63 us: the
+// kernel does not fit those register budgets without spilling in its table build.)
+constexpr int tuple64_waves() { return 4; }
 
 void launch_tuple64(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
     if (const char* env = getenv("SBE_T64_LDS_PAD")) lds += (size_t)atoi(env);        // experiments: fewer blocks per CU
     // 16-bit tuple-block offsets when the whole log table sits below 64 KiB
     const bool off16 = (int64_t)p.KT * (p.S + 1) * 512 <= 65536;
-    if (tuple64_waves() == 8) { if (off16) launch_tuple64_o<true, 8>(C, p, grid, lds, st); else launch_tuple64_o<false, 8>(C, p, grid, lds, st); }
-    else { if (off16) launch_tuple64_o<true, 4>(C, p, grid, lds, st); else launch_tuple64_o<false, 4>(C, p, grid, lds, st); }
+    if (off16) launch_tuple64_o<true, 4>(C, p, grid, lds, st); else launch_tuple64_o<false, 4>(C, p, grid, lds, st);
 }
 
 template <bool ONEHOT>

@@ -184,6 +184,39 @@ __device__ __forceinline__ double tab_log_pos(double v, uint32_t tab) {
     if (__builtin_expect(tab_log_special(v), 0)) return log(v);
     return tab_log_core(v, tab);
 }
+// G logs at once, written stage by stage so that the G dependent chains are interleaved in program order (the
+// compiler keeps a chain-by-chain source order chain by chain: one vector instruction per dependent-issue latency)
+template <int G>
+__device__ __forceinline__ void tab_log_core_n(const double (&v)[G], double (&out)[G], uint32_t tab) {
+    f64x2_t e[G];
+    double m[G], r[G], q[G], kd[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const uint32_t hi = (uint32_t)__double2hiint(v[g]);
+        e[g] = *(lds_cf64x2_t*)(uintptr_t)(tab + ((hi >> 9) & 0x7F0u));
+        m[g] = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), __double2loint(v[g]));
+        kd[g] = (double)((int)(hi >> 20) - 1023);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) r[g] = fma(m[g], e[g].x, -1.0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) q[g] = fma(-0.125, r[g], 1.0 / 7.0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) q[g] = fma(q[g], r[g], -1.0 / 6.0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) q[g] = fma(q[g], r[g], 0.2);
+#pragma unroll
+    for (int g = 0; g < G; ++g) q[g] = fma(q[g], r[g], -0.25);
+#pragma unroll
+    for (int g = 0; g < G; ++g) q[g] = fma(q[g], r[g], 1.0 / 3.0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) q[g] = fma(q[g], r[g], -0.5);
+#pragma unroll
+    for (int g = 0; g < G; ++g) q[g] = fma(r[g] * r[g], q[g], r[g]);          // log1p(r)
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        out[g] = fma(kd[g], 6.93147180369123816490e-01, e[g].y) + fma(kd[g], 1.90821492927058770002e-10, q[g]);
+}
 
 __global__ void k_test_tab_log(const double* __restrict__ in, const double2* __restrict__ logtab,
                                double* __restrict__ out, int n) {
@@ -1602,8 +1635,8 @@ typedef __attribute__((address_space(3))) unsigned char lds_uchar_t;
     asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" sel0 " src1_sel:" sel1   \
         : "=v"(dst) : "s"(soff), "v"(vx))
 
-template <int CT, bool OFF16, int NW>           // NW: waves per block (4, or 8: twice the waves share one log table)
-__global__ __launch_bounds__(NW * kWave, NW == 8 ? 6 : 1) void k_mixture_tuple64(Mix2Params p) {
+template <int CT, bool OFF16, int NW>           // NW: waves per block (4; 8-wave blocks were tried twice and lose: 80 or 64 VGPRs spill)
+__global__ __launch_bounds__(NW * kWave, 4) void k_mixture_tuple64(Mix2Params p) {
     constexpr int kThreads = NW * kWave;
     constexpr int FT = 64;
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -1707,7 +1740,7 @@ __global__ __launch_bounds__(NW * kWave, NW == 8 ? 6 : 1) void k_mixture_tuple64
         const_cast<float*>(probs_tile), 0, (int)((uint32_t)(p.Gtot + 1) * (uint32_t)S * FT * 4u), 0x00020000);
     const int lane4 = lane * 4;
     const int my_rows = (!ragged && n_rows > w) ? (n_rows - w + NW - 1) / NW : 0;
-    constexpr int U = (CU <= 2 ? 16 : (CU <= 4 ? 8 : 4)) / (NW == 8 ? 2 : 1);     // (8 waves: 64-VGPR budget)
+    constexpr int U = CU <= 2 ? 16 : (CU <= 4 ? 8 : 4);
     uint32_t v_goff[CU], v_woff = 0u, v_doff = 0u;
     auto row_offsets = [&](int base) {
         const uint32_t r = (uint32_t)(w + NW * min(base + lane, my_rows - 1));
@@ -1820,7 +1853,8 @@ __global__ __launch_bounds__(NW * kWave, NW == 8 ? 6 : 1) void k_mixture_tuple64
                         double lg[G];
                         bool special = false;
 #pragma unroll
-                        for (int g = 0; g < G; ++g) { lg[g] = tab_log_core(vv[g], tab_off); special |= tab_log_special(vv[g]); }
+                        for (int g = 0; g < G; ++g) special |= tab_log_special(vv[g]);
+                        tab_log_core_n<G>(vv, lg, tab_off);
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0ull, 0)) {     // rare: library log
 #pragma unroll
                             for (int g = 0; g < G; ++g) if (tab_log_special(vv[g])) lg[g] = log(vv[g]);
@@ -1956,7 +1990,8 @@ __global__ __launch_bounds__(NW * kWave, NW == 8 ? 6 : 1) void k_mixture_tuple64
                 vv[i] = (ok[i] && live) ? v : 1.0;
             }
 #pragma unroll
-            for (int i = 0; i < RI; ++i) { lg[i] = tab_log_core(vv[i], tab_off); special |= tab_log_special(vv[i]); }   // interleaved chains
+            for (int i = 0; i < RI; ++i) special |= tab_log_special(vv[i]);
+            tab_log_core_n<RI>(vv, lg, tab_off);                                                       // interleaved chains
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0ull, 0)) {                 // rare: library log
 #pragma unroll
                 for (int i = 0; i < RI; ++i) if (tab_log_special(vv[i])) lg[i] = log(vv[i]);
