@@ -119,6 +119,10 @@ struct sbe_engine {
                   uint32_t* d_stamp; uint32_t step_id; };
     std::vector<Lane> lanes;
     uint8_t* d_batch_meta = nullptr; size_t batch_meta_bytes = 0;     // device copy of the batch's StepCore / StepFinish / slot lists
+    // batched steps: the chains' payloads packed back to back in ONE pinned block and sent with ONE copy into device
+    // memory (64 chains reading ~25 KB each in place over PCIe made k_step_core_batch PCIe-bound: 160 us)
+    uint8_t* h_batch_payload = nullptr; uint8_t* d_batch_payload = nullptr; size_t batch_payload_bytes = 0;
+    std::vector<Slot> batch_cands;                                    // candidates' host state, storage reused across calls
     struct Pool;                                                      // host worker threads of sbe_step_batch (lazily started)
     Pool* pool = nullptr;
     uint8_t* d_scratch = nullptr;  size_t scratch_bytes = 0;     // general staging
@@ -849,6 +853,8 @@ int sbe_destroy(sbe_engine* e) {
         if (ln.d_stamp) (void)hipFree(ln.d_stamp);
     }
     if (e->d_batch_meta) (void)hipFree(e->d_batch_meta);
+    if (e->h_batch_payload) (void)hipHostFree(e->h_batch_payload);
+    if (e->d_batch_payload) (void)hipFree(e->d_batch_payload);
     if (e->h_step) (void)hipHostFree(e->h_step);
     if (e->h_step_payload) (void)hipHostFree(e->h_step_payload);
     if (e->h_io) (void)hipHostFree(e->h_io);
@@ -2096,7 +2102,7 @@ sbe_engine::Lane lane0(sbe_engine* e) {
 // kernel 1 of the one-call steps: candidate slot = current slot + inputs, count delta, every table.
 // build_step_core fills the kernel's argument block for one chain (lane); the caller launches it.
 int build_step_core(sbe_engine* e, sbe_engine::Lane& lane, int cur_slot, int cand_slot, const CoreInputs& in,
-                    StepCore& a, size_t& lds_out, int& n_blocks_out) {
+                    StepCore& a, size_t& lds_out, int& n_blocks_out, int n_chains = 1) {
     const int N = e->N, Np = e->Np, F = e->F, C = e->C;
     const bool regroup = in.ids_new != nullptr;
     a = StepCore{};
@@ -2164,7 +2170,9 @@ int build_step_core(sbe_engine* e, sbe_engine::Lane& lane, int cur_slot, int can
     a.P = in.P; a.Pmax = e->Pmax; a.n_weight_blocks = div_up((int64_t)in.P * F, kBlock);
     const int64_t E = (int64_t)e->Gtot * a.ftc * e->S, R = (int64_t)e->Gtot * a.ftc;
     const size_t lds = (size_t)((E * 4 + 15) / 16 * 16) + (size_t)(2 * E + R) * sizeof(double);
-    a.n_copy_blocks = std::max(1, (int)std::min<int64_t>(div_up(run, 1024), 2 * e->compute_units));
+    // copy blocks: enough to fill the chip for ONE chain; a batch of chains shares it (64 chains x 68 four-KB copy
+    // blocks made the batched launch workgroup-dispatch bound: 6 000 blocks, 99 us)
+    a.n_copy_blocks = std::max(1, (int)std::min<int64_t>(div_up(run, 1024), std::max(4, 2 * e->compute_units / std::max(1, n_chains))));
     lds_out = lds;
     n_blocks_out = a.n_tile_blocks + a.n_weight_blocks + a.n_copy_blocks;
     return SBE_OK;
@@ -2264,7 +2272,8 @@ static int prepare_step(sbe_engine* e, const sbe_engine::Lane& lane, int cur_slo
     const Slot& cur = e->slots[cur_slot];
     cd = cur;                                 // host state of the candidate (committed by the caller)
     // objects whose counts may change: listed source rows + objects whose cluster membership changed
-    std::vector<uint8_t> moved(N, 0);
+    static thread_local std::vector<uint8_t> moved;                   // (no allocation per step: the chains of a batch are
+    moved.assign(N, 0);                                                //  prepared by pool threads)
     for (int i = 0; i < n_changed; ++i) moved[changed_objects[i]] = 1;
     const bool regroup = clusters != nullptr;
     if (regroup) {
@@ -2417,6 +2426,12 @@ int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const 
     if ((int64_t)e->Gtot * e->S * 28 > 60 * 1024) return fail(e, SBE_ERR_ARG, "sbe_step_batch: tables too large for the one-launch step (G_total=%d, S=%d)", e->Gtot, e->S);
     const int N = e->N, F = e->F, C = e->C, K = e->G[0];
     if (rows_ptr[0] != 0) return fail(e, SBE_ERR_ARG, "rows_ptr[0] must be 0");
+    // SBE_STEP_TIMING=1: per-phase wall clock of this call on stderr (tools/prof_step_batch.py)
+    static const bool timing = getenv("SBE_STEP_TIMING") && atoi(getenv("SBE_STEP_TIMING")) != 0;
+    using clk = std::chrono::steady_clock;
+    clk::time_point tp[12]; int ntp = 0;
+    auto mark = [&] { if (timing && ntp < 12) tp[ntp++] = clk::now(); };
+    mark();
     {   // argument checks before anything is touched
         std::vector<uint8_t> used(e->n_slots, 0);
         for (int i = 0; i < n_chains; ++i) {
@@ -2446,61 +2461,109 @@ int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const 
     int rc = ensure_lanes(e, n_chains);
     if (rc) return rc;
     if (!e->pool) {
-        int nt = 7;                                                  // + the calling thread
+        int nt = 15;                                                 // + the calling thread
         if (const char* env = getenv("SBE_STEP_THREADS")) nt = std::max(0, atoi(env) - 1);
         nt = std::min<int>(nt, std::max(0, (int)std::thread::hardware_concurrency() - 1));
         e->pool = new sbe_engine::Pool(nt);
     }
+    mark();
     // ---- host halves, in parallel over the chains ---------------------------------------------------------------
-    std::vector<Slot> cds(n_chains);
+    if ((int)e->batch_cands.size() < n_chains) e->batch_cands.resize(n_chains);
+    std::vector<Slot>& cds = e->batch_cands;
     std::vector<CoreInputs> ins(n_chains);
-    std::vector<int> rcs(n_chains, SBE_OK);
-    std::vector<std::string> errs(n_chains);
-    e->pool->run(n_chains, [&](int i) {
-        const bool regroup = clusters && (!clusters_mask || clusters_mask[i]);
-        const bool reweight = weights && (!weights_mask || weights_mask[i]);
-        const int r0 = rows_ptr[i], nr = rows_ptr[i + 1] - r0;
-        rcs[i] = prepare_step(e, e->lanes[i], cur_slots[i], regroup ? clusters + (size_t)i * K * N : nullptr,
-                              nr ? changed_objects + r0 : nullptr, nr, nr ? source_rows + (size_t)r0 * F * C : nullptr,
-                              reweight ? weights + (size_t)i * F * C : nullptr, cds[i], ins[i], &errs[i]);
-    });
-    for (int i = 0; i < n_chains; ++i) if (rcs[i]) return fail(e, rcs[i], "chain %d: %s", i, errs[i].c_str());
-    // ---- device: argument blocks (StepCore per chain | StepFinish per chain | candidate slot list) -----------------
-    const size_t cores_bytes = (size_t)n_chains * sizeof(StepCore), fins_bytes = (size_t)n_chains * sizeof(StepFinish);
-    const size_t cores_pad = (cores_bytes + 255) / 256 * 256, fins_pad = (fins_bytes + 255) / 256 * 256;
-    const size_t meta_bytes = cores_pad + fins_pad + (size_t)n_chains * sizeof(int32_t);
+    // payload blocks: chain i's used prefix (fixed sections + its changed rows) at a running offset of one pinned block
+    std::vector<size_t> pay_off(n_chains + 1, 0);
+    for (int i = 0; i < n_chains; ++i)
+        pay_off[i + 1] = pay_off[i] + (e->sl.rows + (size_t)(rows_ptr[i + 1] - rows_ptr[i]) * F * C + 255) / 256 * 256;
+    if (pay_off[n_chains] > e->batch_payload_bytes) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (e->h_batch_payload) { HIPCHK(e, hipHostFree(e->h_batch_payload)); e->h_batch_payload = nullptr; }
+        if (e->d_batch_payload) { HIPCHK(e, hipFree(e->d_batch_payload)); e->d_batch_payload = nullptr; }
+        e->batch_payload_bytes = pay_off[n_chains] + pay_off[n_chains] / 2;
+        HIPCHK(e, hipHostMalloc((void**)&e->h_batch_payload, e->batch_payload_bytes, hipHostMallocDefault));
+        HIPCHK(e, hipMalloc((void**)&e->d_batch_payload, e->batch_payload_bytes));
+    }
+    // ---- device argument blocks, per part: StepCore per chain | StepFinish per chain | candidate slot list --------
+    // A large batch is cut into two parts: the host halves of the second run while the device works on the first
+    // (measured, headline shape: 256 chains 655 us in two parts against ~740 in one; at 64 chains the per-part
+    // fixed costs of the three launches outweigh the overlap -- 245 us in one part, 271 in two).
+    int n_parts = n_chains >= 128 ? 2 : 1;
+    if (const char* env = getenv("SBE_STEP_PARTS")) n_parts = std::max(1, std::min(atoi(env), n_chains));
+    const int per_part = div_up(n_chains, n_parts);
+    const size_t part_cores = ((size_t)per_part * sizeof(StepCore) + 255) / 256 * 256;
+    const size_t part_fins = ((size_t)per_part * sizeof(StepFinish) + 255) / 256 * 256;
+    const size_t part_bytes = part_cores + part_fins + ((size_t)per_part * sizeof(int32_t) + 255) / 256 * 256;
+    const size_t meta_bytes = part_bytes * n_parts;
     if (meta_bytes > e->batch_meta_bytes) {
         if (e->d_batch_meta) { HIPCHK(e, hipStreamSynchronize(e->stream)); HIPCHK(e, hipFree(e->d_batch_meta)); }
         e->batch_meta_bytes = meta_bytes + meta_bytes / 2;
         HIPCHK(e, hipMalloc((void**)&e->d_batch_meta, e->batch_meta_bytes));
     }
     std::vector<uint8_t> meta(meta_bytes);
-    StepCore* cores = reinterpret_cast<StepCore*>(meta.data());
-    StepFinish* fins = reinterpret_cast<StepFinish*>(meta.data() + cores_pad);
-    int32_t* slot_list = reinterpret_cast<int32_t*>(meta.data() + cores_pad + fins_pad);
-    size_t lds = 0; int max_blocks = 0;
-    for (int i = 0; i < n_chains; ++i) {
-        size_t l = 0; int nb = 0;
-        rc = build_step_core(e, e->lanes[i], cur_slots[i], cand_slots[i], ins[i], cores[i], l, nb);
+    std::vector<int> rcs(n_chains, SBE_OK);
+    std::vector<std::string> errs(n_chains);
+    for (int part = 0; part < n_parts; ++part) {
+        const int i0 = part * per_part, i1 = std::min(n_chains, i0 + per_part), np = i1 - i0;
+        if (np <= 0) break;
+        e->pool->run(np, [&](int j) {
+            const int i = i0 + j;
+            const bool regroup = clusters && (!clusters_mask || clusters_mask[i]);
+            const bool reweight = weights && (!weights_mask || weights_mask[i]);
+            const int r0 = rows_ptr[i], nr = rows_ptr[i + 1] - r0;
+            sbe_engine::Lane lane = e->lanes[i];                      // this chain's lane with its slice of the packed payload
+            lane.h_payload = e->h_batch_payload + pay_off[i];
+            lane.d_payload = e->d_batch_payload + pay_off[i];
+            rcs[i] = prepare_step(e, lane, cur_slots[i], regroup ? clusters + (size_t)i * K * N : nullptr,
+                                  nr ? changed_objects + r0 : nullptr, nr, nr ? source_rows + (size_t)r0 * F * C : nullptr,
+                                  reweight ? weights + (size_t)i * F * C : nullptr, cds[i], ins[i], &errs[i]);
+        });
+        for (int i = i0; i < i1; ++i)
+            if (rcs[i]) { (void)hipStreamSynchronize(e->stream); return fail(e, rcs[i], "chain %d: %s", i, errs[i].c_str()); }
+        if (part == 0) mark();
+        uint8_t* pm = meta.data() + (size_t)part * part_bytes;
+        StepCore* cores = reinterpret_cast<StepCore*>(pm);
+        StepFinish* fins = reinterpret_cast<StepFinish*>(pm + part_cores);
+        int32_t* slot_list = reinterpret_cast<int32_t*>(pm + part_cores + part_fins);
+        size_t lds = 0; int max_blocks = 0;
+        for (int i = i0; i < i1; ++i) {
+            size_t l = 0; int nb = 0;
+            rc = build_step_core(e, e->lanes[i], cur_slots[i], cand_slots[i], ins[i], cores[i - i0], l, nb, n_chains);
+            if (rc) return rc;
+            lds = std::max(lds, l); max_blocks = std::max(max_blocks, nb);
+            fins[i - i0] = make_step_finish_lane(e, e->lanes[i]);
+            slot_list[i - i0] = cand_slots[i];
+        }
+        if (part == 0) mark();
+        uint8_t* dm = e->d_batch_meta + (size_t)part * part_bytes;
+        HIPCHK(e, hipMemcpyAsync(e->d_batch_payload + pay_off[i0], e->h_batch_payload + pay_off[i0], pay_off[i1] - pay_off[i0],
+                                 hipMemcpyHostToDevice, e->stream));
+        rc = upload(e, dm, pm, part_bytes);
         if (rc) return rc;
-        lds = std::max(lds, l); max_blocks = std::max(max_blocks, nb);
-        fins[i] = make_step_finish_lane(e, e->lanes[i]);
-        slot_list[i] = cand_slots[i];
+        if (part == 0) mark();
+        k_step_core_batch<<<dim3(max_blocks, np), kBlock, lds, e->stream>>>(reinterpret_cast<const StepCore*>(dm));
+        HIPCHK(e, hipGetLastError());
+        if (part == 0) mark();
+        for (int i = i0; i < i1; ++i) std::swap(e->slots[cand_slots[i]], cds[i]);     // (swap: both keep their storage)
+        if (part == 0) mark();
+        rc = launch_mixture(e, 0, np, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, nullptr,
+                            cand_slots + i0, reinterpret_cast<const int32_t*>(dm + part_cores + part_fins),
+                            reinterpret_cast<const StepFinish*>(dm + part_cores));
+        if (rc) return rc;
     }
-    rc = upload(e, e->d_batch_meta, meta.data(), meta_bytes);
-    if (rc) return rc;
-    k_step_core_batch<<<dim3(max_blocks, n_chains), kBlock, lds, e->stream>>>(reinterpret_cast<const StepCore*>(e->d_batch_meta));
-    HIPCHK(e, hipGetLastError());
-    for (int i = 0; i < n_chains; ++i) e->slots[cand_slots[i]] = std::move(cds[i]);
-    rc = launch_mixture(e, 0, n_chains, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, nullptr,
-                        cand_slots, reinterpret_cast<const int32_t*>(e->d_batch_meta + cores_pad + fins_pad),
-                        reinterpret_cast<const StepFinish*>(e->d_batch_meta + cores_pad));
-    if (rc) return rc;
+    mark();
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    mark();
     for (int i = 0; i < n_chains; ++i) {
         rc = read_step_results_lane(e, e->lanes[i].h_step, cand_slots[i], group_logliks_out + (size_t)i * e->Gtot, mixture_out + i,
                                changed_groups_out ? changed_groups_out + (size_t)i * e->Gtot : nullptr, "rows");
         if (rc) return rc;
+    }
+    mark();
+    if (timing && ntp == 10) {
+        auto us = [&](int a, int b) { return std::chrono::duration<double, std::micro>(tp[b] - tp[a]).count(); };
+        fprintf(stderr, "[sbe_step_batch] %d chains (first part): checks %.1f | prepare (pool) %.1f | step cores %.1f | upload %.1f | launch core %.1f | "
+                        "slot moves %.1f | mixture + reduce launches and the other parts %.1f | wait for the device %.1f | read results %.1f us\n", n_chains,
+                us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7), us(7, 8), us(8, 9));
     }
     return SBE_OK;
 }

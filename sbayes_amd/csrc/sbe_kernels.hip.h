@@ -2577,13 +2577,26 @@ __device__ __forceinline__ void step_core_body(const StepCore& a, unsigned char*
     // copy blocks
     const uint32_t n_copy = (uint32_t)a.n_copy_blocks;
     const uint32_t tid = (uint32_t)(wb - a.n_weight_blocks) * kBlock + threadIdx.x, nthreads = n_copy * kBlock;
-    const uint32_t total = a.cs.end[a.cs.n - 1];
-    for (uint32_t i = tid; i < total; i += nthreads) {
-        int k = 0;
-        while (i >= a.cs.end[k]) ++k;
-        const uint32_t j = i - (k ? a.cs.end[k - 1] : 0u);
-        if (k == a.src_seg && a.row_of && a.row_of[(j * 4u) / (uint32_t)a.Fp] >= 0) continue;   // converted below
-        a.cs.dst[k][j] = a.cs.src[k][j];
+    // segment by segment, 16 bytes per lane where both ends allow it (the source-assignment array, 95 % of the bytes,
+    // always does: its rows are Fp = 64k bytes); rows of the source array that the payload replaces are skipped
+    for (int k = 0; k < a.cs.n; ++k) {
+        const uint32_t len = a.cs.end[k] - (k ? a.cs.end[k - 1] : 0u);              // dwords
+        const uint32_t* src = a.cs.src[k];
+        uint32_t* dst = a.cs.dst[k];
+        const bool filtered = k == a.src_seg && a.row_of != nullptr;
+        if ((((uintptr_t)src | (uintptr_t)dst) & 15u) == 0 && (len & 3u) == 0 && (!filtered || (a.Fp & 15) == 0)) {
+            const uint4* s4 = reinterpret_cast<const uint4*>(src);
+            uint4* d4 = reinterpret_cast<uint4*>(dst);
+            for (uint32_t i = tid; i < len / 4u; i += nthreads) {
+                if (filtered && a.row_of[(i * 16u) / (uint32_t)a.Fp] >= 0) continue;   // converted below
+                d4[i] = s4[i];
+            }
+        } else {
+            for (uint32_t j = tid; j < len; j += nthreads) {
+                if (filtered && a.row_of[(j * 4u) / (uint32_t)a.Fp] >= 0) continue;
+                dst[j] = src[j];
+            }
+        }
     }
     int multi = 0;
     for (uint32_t i = tid; i < (uint32_t)a.n_changed * (uint32_t)F; i += nthreads) {

@@ -596,8 +596,9 @@ class Engine:
         glh = np.empty((n, self.n_groups_total), dtype=np.float64)
         mix = np.empty(n, dtype=np.float64)
         changed = np.zeros((n, self.n_groups_total), dtype=np.uint8)
-        for s in cand:
-            self._touch(int(s))
+        if self._bound:                                              # (bind-cache entries of the candidate slots)
+            for s in cand.tolist():
+                self._bound.pop(s, None)
         opt = lambda a: _ptr(a) if a is not None else None          # noqa: E731
         self._check(self._lib.sbe_step_batch(self._h, n, _ptr(cur), _ptr(cand), opt(cl), opt(cm), _ptr(ptr), opt(objs), opt(rows),
                                              opt(w), opt(wm), _ptr(glh), _ptr(mix), _ptr(changed)))

@@ -249,7 +249,7 @@ class ResidentChainBatch:
         eng.set_option(deferred_checks=True)
         self.cur = np.arange(0, 2 * self.n, 2, dtype=np.int32)
         self.cand = self.cur + 1
-        self._clusters = []
+        clusters0 = []
         for i, sample in enumerate(samples):
             slot = int(self.cur[i])
             groups = [sample.clusters.value] + [c.group_assignment for c in sample.confounders.values()]
@@ -260,9 +260,12 @@ class ResidentChainBatch:
             for c in range(eng.n_components):
                 eng.update_probs(slot, c)
             eng.set_weights(slot, sample.weights.value)
-            self._clusters.append(np.array(sample.clusters.value, dtype=bool))
+            clusters0.append(np.array(sample.clusters.value, dtype=bool))
         eng.set_option(deferred_checks=False)                   # (synchronises: a queued data check is raised here)
-        self._cand_clusters = list(self._clusters)
+        # host mirror of the chains' cluster matrices, stacked [B, K, N]; the candidates are kept as a reference to the
+        # caller's stacked array (+ mask) until accept() -- no per-chain Python work on the step path
+        self._clusters = np.stack(clusters0) if clusters0 else np.zeros((0, n_groups[0], feats.shape[0]), dtype=bool)
+        self._cand = None                                        # (stacked candidate clusters, mask) of the last step
         self.changed_groups = None
 
     def close(self):
@@ -294,14 +297,7 @@ class ResidentChainBatch:
         """The same with the deltas already stacked (Engine.step_batch's arguments): no per-chain Python work."""
         glh, mix, changed = self.eng.step_batch(self.cur, self.cand, clusters, clusters_mask, rows_ptr, changed_objects,
                                                 source_rows, weights, weights_mask)
-        if clusters is not None:
-            for i in range(self.n):
-                if clusters_mask is None or clusters_mask[i]:
-                    self._cand_clusters[i] = np.array(clusters[i], dtype=bool)
-                else:
-                    self._cand_clusters[i] = self._clusters[i]
-        else:
-            self._cand_clusters = list(self._clusters)
+        self._cand = None if clusters is None else (clusters, None if clusters_mask is None else np.asarray(clusters_mask, dtype=bool))
         self.changed_groups = changed
         return glh.sum(axis=1), glh, mix
 
@@ -311,8 +307,14 @@ class ResidentChainBatch:
         cur, cand = self.cur.copy(), self.cand.copy()
         self.cur = np.where(mask, cand, cur).astype(np.int32)
         self.cand = np.where(mask, cur, cand).astype(np.int32)
-        for i in np.flatnonzero(mask):
-            self._clusters[i] = self._cand_clusters[i]
+        if self._cand is not None:                               # the accepted chains' candidate clusters become current
+            cl, cm = self._cand
+            take = mask if cm is None else mask & cm
+            if take.all():
+                self._clusters = np.array(cl, dtype=bool)
+            elif take.any():
+                self._clusters[take] = np.asarray(cl)[take]
+            self._cand = None
 
     def counts(self, chain, component):
         return self.eng.get_counts(int(self.cur[chain]), component)
