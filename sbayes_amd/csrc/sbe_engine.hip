@@ -144,51 +144,72 @@ struct sbe_engine {
 struct sbe_engine::Pool {
     std::vector<std::thread> workers;
     std::mutex m;
-    std::condition_variable cv_work, cv_done;
+    std::condition_variable cv_work, cv_idle;
     std::function<void(int)> job;      // job(i) for i in [0, n_items)
-    int n_items = 0, next = 0, done = 0;
+    int n_items = 0;
+    std::atomic<int> next{0}, done{0}; // items are claimed and counted without the lock (16 threads on one mutex
+                                       // cost more than the 5 us jobs they were handing out)
+    int active = 0;                    // workers inside the claim loop of the current generation (under m)
     uint64_t generation = 0;
     bool stop = false;
+    // A sleeping worker needs tens of microseconds to wake -- as long as the whole host half of a 64-chain sweep.  So a
+    // worker that has just finished keeps polling this counter for a short while (kSpinUs) before it blocks: while
+    // sweeps follow each other (an MCMC loop) the pool stays hot, an idle engine costs nothing.
+    std::atomic<uint64_t> gen_hint{0};
+    std::atomic<bool> stop_hint{false};
+    static constexpr int kSpinUs = 400;
 
     explicit Pool(int n_threads) {
         for (int t = 0; t < n_threads; ++t) workers.emplace_back([this] { loop(); });
     }
     ~Pool() {
-        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        { std::lock_guard<std::mutex> lk(m); stop = true; stop_hint.store(true); }
         cv_work.notify_all();
         for (auto& w : workers) w.join();
+    }
+    void claim_loop() {
+        for (;;) {
+            const int i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n_items) break;
+            job(i);
+            done.fetch_add(1, std::memory_order_release);
+        }
     }
     void loop() {
         uint64_t seen = 0;
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
-            cv_work.wait(lk, [&] { return stop || (generation != seen && next < n_items); });
-            if (stop) return;
-            while (next < n_items) {
-                const int i = next++;
+            if (seen != 0) {                                         // (after the first job: poll before blocking)
                 lk.unlock();
-                job(i);
+                const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(kSpinUs);
+                while (gen_hint.load(std::memory_order_acquire) == seen && !stop_hint.load(std::memory_order_relaxed) &&
+                       std::chrono::steady_clock::now() < t_end)
+                    __builtin_ia32_pause();
                 lk.lock();
-                if (++done == n_items) cv_done.notify_all();
             }
+            cv_work.wait(lk, [&] { return stop || generation != seen; });
+            if (stop) return;
             seen = generation;
+            ++active;                                                // run() does not touch job / n_items while active > 0
+            lk.unlock();
+            claim_loop();
+            lk.lock();
+            if (--active == 0) cv_idle.notify_all();
         }
     }
     // run job(0..n-1) on the workers and the calling thread; returns when all are done
     void run(int n, std::function<void(int)> f) {
-        std::unique_lock<std::mutex> lk(m);
-        job = std::move(f); n_items = n; next = 0; done = 0; ++generation;
-        lk.unlock();
-        cv_work.notify_all();
-        lk.lock();
-        while (next < n_items) {
-            const int i = next++;
-            lk.unlock();
-            job(i);
-            lk.lock();
-            ++done;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv_idle.wait(lk, [&] { return active == 0; });           // (a worker that woke late for the previous run)
+            job = std::move(f); n_items = n;
+            done.store(0, std::memory_order_relaxed); next.store(0, std::memory_order_relaxed);
+            ++generation;
+            gen_hint.store(generation, std::memory_order_release);
         }
-        cv_done.wait(lk, [&] { return done == n_items; });
+        cv_work.notify_all();
+        claim_loop();
+        while (done.load(std::memory_order_acquire) < n) __builtin_ia32_pause();   // (jobs are microseconds long)
     }
 };
 
@@ -343,7 +364,8 @@ int clear_status_word(sbe_engine* e, int word) {
 // components 0..C-1 with False < True (likelihood.py:183).
 void derive_patterns(sbe_engine* e, Slot& s) {
     const int N = e->N, C = e->C;          // C <= 8: a pattern is an 8-bit mask
-    std::vector<uint8_t> bits(N);
+    static thread_local std::vector<uint8_t> bits;     // (called per chain and step by the batched step's pool threads)
+    bits.resize(N);
     bool seen[256] = {false};
     for (int n = 0; n < N; ++n) {
         uint32_t b = 0;
@@ -377,11 +399,22 @@ void derive_tuples(sbe_engine* e, Slot& s) {
     uint16_t tuples[kMaxTuples][kMaxComponents];
     int n_tup = 0;
     bool ok = true;
+    uint64_t packed[kMaxTuples];                      // C <= 4: a tuple is one 64-bit key (integer compares, no memcmp)
+    int last = 0;                                     // neighbouring objects often share their tuple
     for (int n = 0; n < N && ok; ++n) {
         uint16_t key[kMaxComponents];
         for (int c = 0; c < C; ++c) key[c] = s.h_gid[(size_t)c * N + n];
         int t = 0;
-        for (; t < n_tup; ++t) if (memcmp(tuples[t], key, (size_t)C * sizeof(uint16_t)) == 0) break;
+        if (C <= 4) {
+            uint64_t k64 = 0;
+            for (int c = 0; c < C; ++c) k64 |= (uint64_t)key[c] << (16 * c);
+            if (n_tup && packed[last] == k64) t = last;
+            else for (; t < n_tup; ++t) if (packed[t] == k64) break;
+            if (t == n_tup && n_tup < kMaxTuples) packed[n_tup] = k64;
+        } else {
+            for (; t < n_tup; ++t) if (memcmp(tuples[t], key, (size_t)C * sizeof(uint16_t)) == 0) break;
+        }
+        last = t;
         if (t == n_tup) {
             if (n_tup == kMaxTuples) { ok = false; break; }
             memcpy(tuples[n_tup++], key, (size_t)C * sizeof(uint16_t));
@@ -2280,9 +2313,16 @@ static int prepare_step(sbe_engine* e, const sbe_engine::Lane& lane, int cur_slo
         const int K = e->G[0];
         uint16_t* ids = cd.h_gid.data();      // component 0: group offset 0
         std::fill(ids, ids + N, kNoGroup);
-        for (int g = 0; g < K; ++g) {
+        for (int g = 0; g < K; ++g) {                 // (mostly zeros: eight objects per test)
             const uint8_t* row = clusters + (size_t)g * N;
-            for (int n = 0; n < N; ++n) if (row[n]) ids[n] = (uint16_t)g;
+            int n = 0;
+            for (; n + 8 <= N; n += 8) {
+                uint64_t w8;
+                memcpy(&w8, row + n, 8);
+                if (!w8) continue;
+                for (int k = 0; k < 8; ++k) if (row[n + k]) ids[n + k] = (uint16_t)g;
+            }
+            for (; n < N; ++n) if (row[n]) ids[n] = (uint16_t)g;
         }
         for (int n = 0; n < N; ++n) if (ids[n] != cur.h_gid[n]) moved[n] = 1;
         derive_patterns(e, cd);
@@ -2461,7 +2501,9 @@ int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const 
     int rc = ensure_lanes(e, n_chains);
     if (rc) return rc;
     if (!e->pool) {
-        int nt = 15;                                                 // + the calling thread
+        int nt = 7;                                                  // + the calling thread.  (Measured on a 16-CPU share:
+        // 64 chains 747 / 416 / 304 / 246 / 225 us per sweep with 1 / 2 / 4 / 8 / 16 threads; the workers poll while sweeps
+        // follow each other, so more threads than free cores is far worse than too few: 32 threads 3.5 ms.)
         if (const char* env = getenv("SBE_STEP_THREADS")) nt = std::max(0, atoi(env) - 1);
         nt = std::min<int>(nt, std::max(0, (int)std::thread::hardware_concurrency() - 1));
         e->pool = new sbe_engine::Pool(nt);

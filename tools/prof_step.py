@@ -21,10 +21,10 @@ for variant in ("full", "no_clusters", "no_rows", "nothing"):
         chain.step(**kw); chain.accept()
     print(variant, round((time.perf_counter() - t0) / n * 1e6, 1), "us/step")
 t0 = time.perf_counter()
-for _ in range(500): eng.copy_slot(1, 0)
+for _ in range(500): eng.copy_slot(chain.cand, chain.cur)
 eng.sync(); print("copy_slot", round((time.perf_counter() - t0) / 500 * 1e6, 1), "us")
 t0 = time.perf_counter()
-for _ in range(500): eng.mixture_loglik(0)
+for _ in range(500): eng.mixture_loglik(chain.cur)
 print("mixture", round((time.perf_counter() - t0) / 500 * 1e6, 1), "us")
 # C-level phase times of the one-call step (SBE_STEP_TIMING=1 prints to stderr every 2000 steps)
 import os
