@@ -54,7 +54,7 @@ def one_case(rng, stats, big=False):
     feats, groups0, _w, _s, conc = random_case(rng, N, F, S, n_groups, na_rate)
     na = ~feats.any(-1)
     tag = f"N{N} F{F} S{S} groups{n_groups} B{B} na{na_rate}"
-    with Engine(feats, n_groups, n_slots=B + 1) as eng:
+    with Engine(feats, n_groups, n_slots=B + 3) as eng:
         for c in range(C):
             eng.set_concentration(c, conc[c])
         want, states = [], []
@@ -125,6 +125,27 @@ def one_case(rng, stats, big=False):
                 if np.isfinite(want_mix):
                     assert abs(m0 - want_mix) <= 1e-10 * abs(want_mix) + 1e-16 * N * F, (tag, "step mixture", m0, want_mix)
                 stats["steps"] += 1
+                # the same delta as chain 0 of a two-chain batched step (chain 1: a copy of state 0 with the source rows
+                # only): every chain of the batch must reproduce its single step bit for bit
+                eng.set_option(step_form=0)
+                try:
+                    eng.copy_slot(B + 1, 0)
+                    single_b = eng.step(B + 1, B + 2, changed_objects=moved.astype(np.int32), source_rows=rows)
+                    stack = np.stack([clusters, groups[0]])
+                    glh, mixb, chg = eng.step_batch(np.array([0, B + 1]), np.array([B, B + 2]), stack, np.array([True, False]),
+                                                    np.array([0, moved.size, 2 * moved.size], dtype=np.int32),
+                                                    np.concatenate([moved, moved]).astype(np.int32), np.concatenate([rows, rows]))
+                except EngineError as exc:
+                    if "too large" not in str(exc):
+                        raise
+                else:
+                    # (the mixture kernel's chunk geometry depends on the number of slots of a launch: the partial sums of
+                    #  a batched eval may be grouped differently -- equal to rounding, everything else bit for bit)
+                    close = lambda a, b: a == b or abs(a - b) <= 1e-13 * abs(b) + 1e-16 * N * F          # noqa: E731
+                    assert np.array_equal(glh[0], g0) and np.array_equal(chg[0], c0), (tag, "batched step, chain 0", glh[0], g0)
+                    assert close(mixb[0], m0), (tag, "batched step mixture, chain 0", mixb[0], m0)
+                    assert np.array_equal(glh[1], single_b[0]) and close(mixb[1], single_b[1]), (tag, "batched step, chain 1")
+                    stats["batched"] = stats.get("batched", 0) + 1
         # one-call Gibbs step from state 0: counts consistent with the source it drew
         eng.set_option(step_form=0)
         objs = np.unique(rng.integers(0, N, size=min(6, N))).astype(np.int32)
