@@ -761,6 +761,21 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
         p.eft = e->ft;
         p.wpat = e->d_wpat; p.wpat_stride = (int64_t)e->Pmax * e->F * e->C;
         p.rowoff = e->d_rowoff; p.rowoff_stride = (int64_t)(e->C + 1) * e->Np;
+        {   // shares of a rows block's steps by wave age class (see k_mixture_rows); SBE_ROWS_SPLIT="a,b,c,d" per mille
+            static int split[4] = {450, 270, 170, 110};
+            static bool parsed = false;
+            if (!parsed) {
+                parsed = true;
+                if (const char* env = getenv("SBE_ROWS_SPLIT")) {
+                    int v[4];
+                    if (sscanf(env, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] + v[1] + v[2] + v[3] == 1000 &&
+                        v[0] >= 0 && v[1] >= 0 && v[2] >= 0 && v[3] >= 0)
+                        for (int i = 0; i < 4; ++i) split[i] = v[i];
+                }
+            }
+            p.rows_cum[0] = 0;
+            for (int i = 0; i < 4; ++i) p.rows_cum[i + 1] = p.rows_cum[i] + split[i];
+        }
 #ifdef SBE_STAMPS
         static uint64_t* d_stamps = nullptr;
         if (((combo && tuple64) || rows) && getenv("SBE_STAMPS_FILE")) {

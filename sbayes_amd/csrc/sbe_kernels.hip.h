@@ -758,6 +758,7 @@ struct Mix2Params {
     const uint32_t* toff;  int64_t toff_stride;    // per slot [Np] byte offset of the object's tuple block
     const double2* logtab;                         // [128] {1/c, log c} of tab_log_pos
     int gen_slots;                                 // k_mixture_tuple64 block order: slots per XCD and generation
+    int rows_cum[5];                               // k_mixture_rows: cumulative per-mille shares of a block's steps by wave age class
     int ragged_w;                                  // valid features of the last tile if it runs in sub-row mode (<= 32), else 0
     uint64_t* stamps;                              // diagnostic builds (-DSBE_STAMPS): [blocks][4 waves][8] cycle stamps
     const uint8_t* onehot; int rs_pitch;           // [N][rs_pitch] (one-hot variant)
@@ -1268,7 +1269,17 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
     const uint32_t lane_tab = (uint32_t)fl * 4u;
     const uint32_t lane_w = tab_bytes + (uint32_t)fl * 16u;
     const uint32_t na4 = (uint32_t)S * 0x01010101u;                        // four NA state bytes
-    const int n_steps = (nq + kRowsWaves * SUBS - 1) / (kRowsWaves * SUBS);   // same for every wave
+    // Steps of the chunk (one step = SUBS object quads x FT features) are NOT dealt evenly to the 16 waves.  The SIMD
+    // issues oldest-first: with equal shares waves 0-3 (the oldest on their SIMDs) left the loop after 17.8 us, waves
+    // 4-7 after 23.9, 8-11 after 30.4 and 12-15 after 36.0 us (in-kernel stamps), so the last third of every block ran
+    // with one or two waves per SIMD while the block held the CU.  Age class a = wave / 4 gets the share rows_cum[a+1] -
+    // rows_cum[a] (per mille; host: 45 / 27 / 17 / 11 %, measured best) of the steps, as one contiguous range dealt round-robin to its
+    // four waves.  Static, so results stay run-to-run deterministic.
+    const int total_steps = (nq + SUBS - 1) / SUBS;
+    const int cls = wave >> 2, wic = wave & 3;
+    const int sb0 = (int)(((int64_t)total_steps * p.rows_cum[cls]) / 1000), sb1 = (int)(((int64_t)total_steps * p.rows_cum[cls + 1]) / 1000);
+    const int n_steps = max(0, (sb1 - sb0 - wic + 3) / 4);                 // this wave's steps: sb0 + wic + 4k < sb1
+    auto step_of = [&](int k) { return sb0 + wic + 4 * k; };
     // streamed operands through buffer descriptors (plain buffer loads: no flat path, no 64-bit address arithmetic):
     // the quad-interleaved state block (shared by every slot) and the slot's per-object row offsets
     const __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -1283,7 +1294,7 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
     const uint32_t slot_lds = tab_bytes + (uint32_t)p.P * CP * FT * 16u + (uint32_t)wave * (WD * 4u);
     const uint32_t my_rows = slot_lds + (uint32_t)sub * (QD * 4u);        // this lane's quad inside the slot
 
-    auto local_quad = [&](int k) { return (k * kRowsWaves + wave) * SUBS + sub; };
+    auto local_quad = [&](int k) { return step_of(k) * SUBS + sub; };
     struct Raw { uint32_t xs; uint32_t ro[VPL]; };
     auto load_raw = [&](int k) -> Raw {                                   // global loads of step k (state dword, offsets)
         Raw r;
@@ -1291,8 +1302,8 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
         const uint32_t q = (uint32_t)(q0 + min(i, nq - 1));               // always in bounds
         const uint32_t xs = __builtin_amdgcn_raw_buffer_load_b32(st_rsrc, (int)(q * st_row + st_col), 0, 0);
         r.xs = i < nq ? xs : na4;                                         // past the chunk: four NA observations
-        // the wave's first quad of step k is (k*16 + wave)*SUBS; lane l fetches dword(s) l, l+64 of the run
-        const uint32_t run0 = (uint32_t)(q0 + (k * kRowsWaves + wave) * SUBS) * (QD * 4u);
+        // the wave's first quad of step k is step_of(k)*SUBS; lane l fetches dword(s) l, l+64 of the run
+        const uint32_t run0 = (uint32_t)(q0 + step_of(k) * SUBS) * (QD * 4u);
 #pragma unroll
         for (int u = 0; u < VPL; ++u)                                     // (past the array: the descriptor returns 0)
             r.ro[u] = __builtin_amdgcn_raw_buffer_load_b32(ro_rsrc, (int)(run0 + (uint32_t)(lane + u * kWave) * 4u), 0, 0);
@@ -1361,7 +1372,7 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
             __builtin_amdgcn_sched_barrier(0);
             xs_cur = slot_next.xs; o_cur = o_next;
         };
-        for (int k = 0; k < n_steps; k += D) {                           // (n_steps is block-uniform: uniform branches)
+        for (int k = 0; k < n_steps; k += D) {                           // (n_steps is wave-uniform: uniform branches)
             one_step(k + 0, g1, g0);
             if (k + 1 < n_steps) one_step(k + 1, g2, g1);
             if (k + 2 < n_steps) one_step(k + 2, g3, g2);
