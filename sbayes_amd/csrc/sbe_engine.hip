@@ -2455,8 +2455,7 @@ int ensure_lanes(sbe_engine* e, int n) {
     const size_t hb = step_host_lq_offset(e) + 2 * sizeof(double);
     while ((int)e->lanes.size() < n) {
         sbe_engine::Lane ln{};
-        HIPCHK(e, hipHostMalloc((void**)&ln.h_payload, e->sl.total, hipHostMallocMapped));
-        HIPCHK(e, hipHostGetDevicePointer((void**)&ln.d_payload, ln.h_payload, 0));
+        // (no payload block of its own: a batch's payloads live back to back in h_batch_payload / d_batch_payload)
         HIPCHK(e, hipHostMalloc((void**)&ln.h_step, hb, hipHostMallocMapped));
         memset(ln.h_step, 0, hb);
         HIPCHK(e, hipHostGetDevicePointer((void**)&ln.d_step_host, ln.h_step, 0));
