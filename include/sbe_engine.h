@@ -355,7 +355,11 @@ int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters
  *   out            group_logliks_out float64 [n_chains][G_total], mixture_out float64 [n_chains],
  *                  changed_groups_out bool [n_chains][G_total] (may be NULL)
  * Same numbers as n_chains calls of sbe_step (bit for bit for counts, tables and per-group values; the mixture scalar to
- * rounding: its block geometry depends on the launch's batch size).  Accept = swap a chain's two slots, reject = nothing. */
+ * rounding: its block geometry depends on the launch's batch size).  Accept = swap a chain's two slots, reject = nothing.
+ * Host side: the chains' payloads are packed into one pinned block by a pool of worker threads (8 including the caller;
+ * environment SBE_STEP_THREADS) and sent with one copy; from 128 chains on the batch runs as two pipelined parts
+ * (SBE_STEP_PARTS).  The workers poll for ~400 us after a call before they block, so consecutive sweeps find them awake:
+ * keep the thread count below the number of free cores.  SBE_STEP_TIMING=1 prints the call's phase times to stderr. */
 int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const int32_t* cand_slots,
                    const uint8_t* clusters, const uint8_t* clusters_mask, const int32_t* rows_ptr,
                    const int32_t* changed_objects, const uint8_t* source_rows, const float* weights,
