@@ -127,6 +127,7 @@ struct sbe_engine {
     Pool* pool = nullptr;
     uint8_t* d_scratch = nullptr;  size_t scratch_bytes = 0;     // general staging
     uint8_t* h_pinned = nullptr;   size_t pinned_bytes = 0;      // pinned D2H staging
+    std::vector<hipEvent_t> d2h_events;                          // piecewise D2H of large results (d2h)
     uint8_t* h_arena = nullptr;    size_t arena_bytes = 0, arena_off = 0;   // pinned H2D staging ring
     int opt_step_form = 0;         // SBE_OPT_STEP_FORM
     int opt_deferred = 0;          // SBE_OPT_DEFERRED_CHECKS: data checks reported at the next sync
@@ -290,6 +291,29 @@ int synced(sbe_engine* e);
 int d2h(sbe_engine* e, void* dst, const void* src_dev, size_t bytes) {
     int rc = ensure_pinned(e, bytes);
     if (rc) return rc;
+    // large results ([N, F] / [N, F, C] float64 arrays of the literal a1 / a3 surfaces): in four pieces, the host copy
+    // of piece k under the DMA of pieces k+1.. (the copy out of the staging buffer costs as much as the DMA itself)
+    constexpr int kPieces = 4;
+    if (bytes >= ((size_t)1 << 20)) {
+        if (e->d2h_events.empty()) {
+            e->d2h_events.resize(kPieces);
+            for (auto& ev : e->d2h_events) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+        const size_t piece = ((bytes + kPieces - 1) / kPieces + 255) / 256 * 256;
+        int n_pieces = 0;
+        for (size_t off = 0; off < bytes; off += piece, ++n_pieces) {
+            const size_t nb = std::min(piece, bytes - off);
+            HIPCHK(e, hipMemcpyAsync(e->h_pinned + off, (const uint8_t*)src_dev + off, nb, hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(e, hipEventRecord(e->d2h_events[n_pieces], e->stream));
+        }
+        size_t off = 0;
+        for (int k = 0; k < n_pieces; ++k, off += piece) {
+            HIPCHK(e, hipEventSynchronize(e->d2h_events[k]));
+            memcpy((uint8_t*)dst + off, e->h_pinned + off, std::min(piece, bytes - off));
+        }
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        return synced(e);
+    }
     HIPCHK(e, hipMemcpyAsync(e->h_pinned, src_dev, bytes, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     memcpy(dst, e->h_pinned, bytes);
@@ -900,6 +924,7 @@ int sbe_destroy(sbe_engine* e) {
         if (ln.d_pf) (void)hipFree(ln.d_pf);
         if (ln.d_stamp) (void)hipFree(ln.d_stamp);
     }
+    for (auto ev : e->d2h_events) (void)hipEventDestroy(ev);
     if (e->d_batch_meta) (void)hipFree(e->d_batch_meta);
     if (e->h_batch_payload) (void)hipHostFree(e->h_batch_payload);
     if (e->d_batch_payload) (void)hipFree(e->d_batch_payload);
