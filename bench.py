@@ -266,7 +266,7 @@ def secondary_figures(eng, wl, B, args):
 
     def collapsed():
         eng.recount(0)
-        return sum(eng.collapsed_loglik(0, c).sum() for c in range(wl.n_components))
+        return eng.collapsed_loglik_all(0).sum()
     out["a7_collapsed_uncached_per_s"] = round(_rate(collapsed), 1)
     # PCIe-inclusive eval: groups + counts + weights re-uploaded, tables rebuilt, one scalar back
     counts = [eng.get_counts(0, c) for c in range(wl.n_components)]

@@ -209,6 +209,9 @@ int sbe_fetch_results(sbe_engine* e, int first_slot, int n, double* out /* [n] *
  * per_feature_out (may be NULL): float32 [G_c][F]. */
 int sbe_collapsed_loglik(sbe_engine* e, int slot, int component, double* per_group_out,
                          float* per_feature_out);
+/* The same for every component of the slot in one call and one synchronisation (Likelihood.__call__ with
+ * caching=False sums all of them, likelihood.py:47-63): per_group_out float64 [G_total], components in order. */
+int sbe_collapsed_loglik_all(sbe_engine* e, int slot, double* per_group_out);
 
 /* ---- stateless forms of the reference's free functions (no slot involved) ----------------
  * sbe_normalize_tables : normalize(counts [/T] + prior['], axis=-1) -> float32

@@ -68,6 +68,7 @@ PROTOTYPES = {
     "sbe_mixture_loglik_batch_async": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int]),
     "sbe_fetch_results": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
     "sbe_collapsed_loglik": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p]),
+    "sbe_collapsed_loglik_all": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
     "sbe_normalize_tables": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double,
                                         ct.c_double, ct.c_void_p, ct.c_void_p]),
     "sbe_dirichlet_logpdf": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p,

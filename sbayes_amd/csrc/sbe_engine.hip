@@ -1631,6 +1631,29 @@ int sbe_mixture_loglik_batch(sbe_engine* e, int first_slot, int n, double* out) 
 int sbe_mixture_loglik(sbe_engine* e, int slot, double* out) { return sbe_mixture_loglik_batch(e, slot, 1, out); }
 
 // ---- collapsed likelihood -------------------------------------------------------------------------
+int sbe_collapsed_loglik_all(sbe_engine* e, int slot, double* per_group_out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, per_group_out);
+    Slot& s = e->slots[slot];
+    for (int c = 0; c < e->C; ++c) {
+        if (e->G[c] == 0) continue;
+        if (!s.counts_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts of component %d not set", slot, c);
+        if (!e->conc_set[c]) return fail(e, SBE_ERR_STATE, "concentration of component %d not set", c);
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    const int G = e->Gtot;
+    const size_t pf_bytes = ((size_t)G * e->F * sizeof(float) + 255) / 256 * 256;
+    int rc = ensure_scratch(e, pf_bytes + (size_t)G * sizeof(double));
+    if (rc) return rc;
+    float* d_pf = (float*)e->d_scratch;
+    double* d_pg = (double*)(e->d_scratch + pf_bytes);
+    k_dcl<int32_t><<<div_up((int64_t)G * e->F, 256), 256, 0, e->stream>>>(e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc,
+                                                                       d_pf, 0, G, e->F, e->S, 1);
+    HIPCHK(e, hipGetLastError());
+    k_group_sum_f32<<<div_up(G, 64), 64, 0, e->stream>>>(d_pf, d_pg, G, e->F);
+    HIPCHK(e, hipGetLastError());
+    return d2h(e, per_group_out, d_pg, (size_t)G * sizeof(double));
+}
+
 int sbe_collapsed_loglik(sbe_engine* e, int slot, int component, double* per_group_out, float* per_feature_out) {
     CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component);
     if (e->G[component] == 0) return SBE_OK;       // no group: Likelihood.compute_lh_clusters sums an empty cache

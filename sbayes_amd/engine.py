@@ -322,6 +322,13 @@ class Engine:
                                                    _ptr(pf) if pf is not None else None))
         return (per_group, pf) if per_feature else per_group
 
+    def collapsed_loglik_all(self, slot):
+        """float64 [G_total]: the collapsed per-group log-likelihoods of every component in one call and one
+        synchronisation (Likelihood.__call__(caching=False) = their sum, likelihood.py:47-63)."""
+        out = np.empty(self.n_groups_total, dtype=np.float64)
+        self._check(self._lib.sbe_collapsed_loglik_all(self._h, slot, _ptr(out)))
+        return out
+
     # -- stateless forms of the reference's free functions -----------------------------------------
     def normalize_tables(self, counts, concentration, temperature=None, prior_temperature=None, unif_counts=None):
         """normalize(counts [/T] + prior['], axis=-1) -> float32 [G, F, S] (util.py:990-1007)."""

@@ -26,7 +26,9 @@ class _SlotView:
     def collapsed_loglik(self) -> float:
         """Likelihood.__call__(sample, caching=False) value from the slot's resident counts."""
         eng = self.chain.eng
-        return float(sum(eng.collapsed_loglik(self.slot, c).sum() for c in range(eng.n_components)))
+        per_group = eng.collapsed_loglik_all(self.slot)
+        off = np.concatenate([[0], np.cumsum(eng.n_groups)])
+        return float(sum(per_group[off[c]:off[c + 1]].sum() for c in range(eng.n_components)))
 
     def collapsed_group_logliks(self):
         eng = self.chain.eng

@@ -89,6 +89,9 @@ def test_collapsed_loglik(name):
             np.testing.assert_allclose(per_group, fx.group_lh[c], rtol=COLLAPSED_RTOL)
             total += per_group.sum()
         assert abs(total - fx.meta["collapsed_ll"]) <= COLLAPSED_RTOL * abs(fx.meta["collapsed_ll"])
+        # all components in one call: the same per-group values, bit for bit
+        every = eng.collapsed_loglik_all(0)
+        assert np.array_equal(every, np.concatenate([eng.collapsed_loglik(0, c) for c in range(fx.n_comp)]))
 
 
 @pytest.mark.parametrize("name", NPZ)
