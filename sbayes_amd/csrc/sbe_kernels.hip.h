@@ -1263,7 +1263,8 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
 #endif
 
     constexpr int SUBS = kWave / FT;                                      // object quads per wave step
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: the step range and loop bounds derived from it stay on the scalar unit)
     const int fl = lane % FT, sub = lane / FT;
     const int f = tile * FT + fl;                                         // < Fq (Fq = F rounded up to 64)
     const uint32_t lane_tab = (uint32_t)fl * 4u;
