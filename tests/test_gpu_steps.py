@@ -205,10 +205,15 @@ def test_one_call_steps_at_baseline_workloads(name):
 
 
 # ---- batched multi-chain step (sbe_step_batch) -----------------------------------------------------------------
-def test_step_batch_equals_single_steps():
+@pytest.mark.parametrize("parts", [None, "2", "5"])
+def test_step_batch_equals_single_steps(parts, monkeypatch):
     """B chains stepped by ONE sbe_step_batch call give what B sbe_step calls give: counts, tables, per-group collapsed
     values and changed-group flags bit for bit, the mixture scalar to rounding (its block geometry depends on the
-    launch's batch size); mixed deltas -- cluster moves, source rows, weights, nothing -- accepted and rejected."""
+    launch's batch size); mixed deltas -- cluster moves, source rows, weights, nothing -- accepted and rejected.
+    `parts`: the pipelined form large batches take (from 128 chains on: the host halves of part k+1 under the device work
+    of part k), forced here on 12 chains through SBE_STEP_PARTS."""
+    if parts is not None:
+        monkeypatch.setenv("SBE_STEP_PARTS", parts)
     wl = make_workload("headline")
     feats, na = wl.features, wl.na_values
     N, F, S = wl.shape
