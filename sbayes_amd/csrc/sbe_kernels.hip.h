@@ -2631,7 +2631,11 @@ __global__ __launch_bounds__(kBlock) void k_step_core(StepCore a) {
 }
 
 // sbe_step_batch: one chain per blockIdx.y, each with its own StepCore (current / candidate slot, payload, counts ...)
-__global__ __launch_bounds__(kBlock) void k_step_core_batch(const StepCore* __restrict__ cores) {
+// (the single-chain kernel takes what registers it wants -- 255, its lgamma expansions are wide -- at two blocks per CU;
+//  a batch has thousands of blocks and is better off at 128 VGPRs / four blocks per CU despite more spills: 225 against
+//  231 us per 64-chain sweep; 64 VGPRs: 268 us)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_step_core_batch(const StepCore* __restrict__ cores) {
     extern __shared__ __align__(16) unsigned char core_lds[];
     step_core_body(cores[blockIdx.y], core_lds, (int)blockIdx.x);
 }
