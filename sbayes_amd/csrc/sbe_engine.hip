@@ -2865,6 +2865,21 @@ int sbe_test_fast_log(sbe_engine* e, const double* in, int n, double* out_fast, 
     return d2h(e, out_lib, d_l, (size_t)n * sizeof(double));
 }
 
+int sbe_test_lgamma(sbe_engine* e, const double* in, int n, double* out) {
+    CHECK_ENGINE(e); CHECK_PTR(e, in); CHECK_PTR(e, out);
+    if (n < 1) return fail(e, SBE_ERR_ARG, "n=%d", n);
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t b = ((size_t)n * sizeof(double) + 255) / 256 * 256;
+    int rc = ensure_scratch(e, 2 * b);
+    if (rc) return rc;
+    double* d_in = (double*)e->d_scratch;
+    double* d_o = (double*)(e->d_scratch + b);
+    { int _urc = upload(e, d_in, in, (size_t)n * sizeof(double)); if (_urc) return _urc; }
+    k_test_lgamma<<<div_up(n, 256), 256, 0, e->stream>>>(d_in, d_o, n);
+    HIPCHK(e, hipGetLastError());
+    return d2h(e, out, d_o, (size_t)n * sizeof(double));
+}
+
 int sbe_test_tab_log(sbe_engine* e, const double* in, int n, double* out) {
     CHECK_ENGINE(e); CHECK_PTR(e, in); CHECK_PTR(e, out);
     if (n < 1) return fail(e, SBE_ERR_ARG, "n=%d", n);

@@ -109,10 +109,15 @@ __device__ __forceinline__ double block_sum(double v, double* lds4) {
 // < 1 ulp over positive normal doubles (tests/test_gpu_engine.py::test_fast_log_accuracy).  Anything
 // else (0, subnormal, negative, inf, NaN) takes the library log so -inf / NaN behave like NumPy's.
 // ------------------------------------------------------------------------------------------
+// (the library routines behind the rare paths are NOT inlined: inlined, their coefficient tables are hoisted out of the
+//  callers' loops and held in ~150 VGPRs for the whole kernel -- k_step_core stood at 255 VGPRs + scratch for it)
+__device__ __attribute__((noinline)) double lib_log(double v) { return log(v); }
+__device__ __attribute__((noinline)) double lib_lgamma(double v) { return lgamma(v); }
+
 __device__ __forceinline__ double fast_log_pos(double v) {
     const uint64_t bits = (uint64_t)__double_as_longlong(v);
     const uint32_t ex = (uint32_t)(bits >> 52);                  // sign + exponent
-    if (__builtin_expect(ex - 1u >= 0x7FEu, 0)) return log(v);   // not a positive normal finite double
+    if (__builtin_expect(ex - 1u >= 0x7FEu, 0)) return lib_log(v);   // not a positive normal finite double
     int k = (int)ex - 1023;
     double m = __longlong_as_double((long long)((bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));   // [1, 2)
     if (m > 1.4142135623730951) { m *= 0.5; ++k; }               // [sqrt(1/2), sqrt(2))
@@ -131,6 +136,44 @@ __device__ __forceinline__ double fast_log_pos(double v) {
     const double dk = (double)k;
     // log(v) = k*ln2_hi - ((hfsq - (s*(hfsq+R) + k*ln2_lo)) - f)
     return fma(dk, 6.93147180369123816490e-01, -((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f));
+}
+
+// ------------------------------------------------------------------------------------------
+// lgamma for the Dirichlet-categorical terms (a8: util.py:1373-1394, arguments = concentrations and counts +
+// concentrations: x > 0).  The device library's lgamma keeps ~150 VGPRs of polynomial coefficients live across the
+// table loops of k_step_core (255 VGPRs, 688 bytes of scratch, two blocks per CU).  This one: shift x up to y >= 8 with
+// the recurrence (at most 8 multiplications), Stirling's series at y to 1/y^13 (truncation < 2e-15 relative at y = 8)
+// and two logs (fast_log_pos).  Absolute error <= 1e-14 * max(1, |lgamma(x)|) (observed 6.3e-15): the results are differenced, summed
+// per feature and cast to float32 (the reference's own arithmetic there is float32 and numba fastmath),
+// tests/test_gpu_engine.py::test_lgamma_accuracy pins it against SciPy's gammaln.  x <= 0, inf, NaN: library lgamma.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sbe_lgamma_pos(double x) {
+    if (__builtin_expect(!(x > 0.0) || x > 1e300, 0)) return lib_lgamma(x);
+    double p = 1.0, y = x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                                 // branch-free: lanes differ in how far they are from 8
+        const bool s = y < 8.0;
+        p = s ? p * y : p;
+        y = s ? y + 1.0 : y;
+    }
+    double r = __builtin_amdgcn_rcp(y);
+    r = fma(fma(-y, r, 1.0), r, r);
+    r = fma(fma(-y, r, 1.0), r, r);
+    const double r2 = r * r;
+    double q = 1.0 / 156.0;                                       // B_{2k} / (2k (2k-1)), k = 7 .. 1
+    q = fma(q, r2, -691.0 / 360360.0);
+    q = fma(q, r2, 1.0 / 1188.0);
+    q = fma(q, r2, -1.0 / 1680.0);
+    q = fma(q, r2, 1.0 / 1260.0);
+    q = fma(q, r2, -1.0 / 360.0);
+    q = fma(q, r2, 1.0 / 12.0);
+    const double lg = fma(y - 0.5, fast_log_pos(y), -y) + (fma(q, r, 0.91893853320467274178));
+    return x < 8.0 ? lg - fast_log_pos(p) : lg;
+}
+
+__global__ void k_test_lgamma(const double* __restrict__ in, double* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = sbe_lgamma_pos(in[i]);
 }
 
 __global__ void k_test_fast_log(const double* __restrict__ in, double* __restrict__ out_fast,
@@ -181,7 +224,7 @@ __device__ __forceinline__ double tab_log_core(double v, uint32_t tab) {
     return fma(kd, 6.93147180369123816490e-01, e.y) + fma(kd, 1.90821492927058770002e-10, lp);
 }
 __device__ __forceinline__ double tab_log_pos(double v, uint32_t tab) {
-    if (__builtin_expect(tab_log_special(v), 0)) return log(v);
+    if (__builtin_expect(tab_log_special(v), 0)) return lib_log(v);
     return tab_log_core(v, tab);
 }
 // G logs at once, written stage by stage so that the G dependent chains are interleaved in program order (the
@@ -607,10 +650,10 @@ __global__ void k_dcl(const TC* __restrict__ counts, const double* __restrict__ 
     auto a = [&](int s) -> double { return conc[base + s]; };
     const float n = np_pairwise_sum<float>(cnt, S);
     const double sum_a = np_pairwise_sum<double>(a, S);
-    const double cst = lgamma(sum_a) - lgamma((double)n + sum_a);
+    const double cst = sbe_lgamma_pos(sum_a) - sbe_lgamma_pos((double)n + sum_a);
     auto series = [&](int s) -> double {
         const double as = conc[base + s];
-        return as > 0.0 ? lgamma((double)(float)counts[base + s] + as) - lgamma(as) : 0.0;
+        return as > 0.0 ? sbe_lgamma_pos((double)(float)counts[base + s] + as) - sbe_lgamma_pos(as) : 0.0;
     };
     per_feature[row] = (float)(cst + np_pairwise_sum<double>(series, S));
 }
@@ -1869,7 +1912,7 @@ __global__ __launch_bounds__(NW * kWave, 4) void k_mixture_tuple64(Mix2Params p)
                         tab_log_core_n<G>(vv, lg, tab_off);
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0ull, 0)) {     // rare: library log
 #pragma unroll
-                            for (int g = 0; g < G; ++g) if (tab_log_special(vv[g])) lg[g] = log(vv[g]);
+                            for (int g = 0; g < G; ++g) if (tab_log_special(vv[g])) lg[g] = lib_log(vv[g]);
                         }
 #endif
 #pragma unroll
@@ -2006,7 +2049,7 @@ __global__ __launch_bounds__(NW * kWave, 4) void k_mixture_tuple64(Mix2Params p)
             tab_log_core_n<RI>(vv, lg, tab_off);                                                       // interleaved chains
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0ull, 0)) {                 // rare: library log
 #pragma unroll
-                for (int i = 0; i < RI; ++i) if (tab_log_special(vv[i])) lg[i] = log(vv[i]);
+                for (int i = 0; i < RI; ++i) if (tab_log_special(vv[i])) lg[i] = lib_log(vv[i]);
             }
 #pragma unroll
             for (int i = 0; i < RI; ++i)
@@ -2535,7 +2578,7 @@ __device__ __forceinline__ void step_core_body(const StepCore& a, unsigned char*
             const float cf = (float)cn;
             const double conc = a.conc[gi];
             sh_post[e] = (double)cf + conc;
-            sh_ser[e] = conc > 0.0 ? lgamma((double)cf + conc) - lgamma(conc) : 0.0;
+            sh_ser[e] = conc > 0.0 ? sbe_lgamma_pos((double)cf + conc) - sbe_lgamma_pos(conc) : 0.0;
         }
         __syncthreads();
         for (int r = threadIdx.x; r < R; r += kBlock) {                              // ordered sums of a row
@@ -2552,7 +2595,7 @@ __device__ __forceinline__ void step_core_body(const StepCore& a, unsigned char*
             sh_total[r] = total;
             const float n = np_pairwise_sum<float>(cnt_at, S);
             const double sum_a = np_pairwise_sum<double>(conc_at, S);
-            const double cst = lgamma(sum_a) - lgamma((double)n + sum_a);
+            const double cst = sbe_lgamma_pos(sum_a) - sbe_lgamma_pos((double)n + sum_a);
             a.per_feature[(int64_t)g * F + f] = (float)(cst + np_pairwise_sum<double>(ser_at, S));
         }
         __syncthreads();

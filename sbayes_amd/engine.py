@@ -638,6 +638,13 @@ class Engine:
         self._check(self._lib.sbe_test_fast_log(self._h, _ptr(x), x.size, _ptr(a), _ptr(b)))
         return a, b
 
+    def test_lgamma(self, x):
+        """The engine's lgamma (Dirichlet-categorical terms) of x, computed on the device (self-test)."""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        out = np.empty_like(x)
+        self._check(self._lib.sbe_test_lgamma(self._h, _ptr(x), x.size, _ptr(out)))
+        return out
+
     def test_tab_log(self, x):
         """Table-driven fp64 log of k_mixture_tuple64's table build, computed on the device (self-test)."""
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
