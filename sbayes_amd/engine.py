@@ -51,6 +51,7 @@ class Engine:
     def __init__(self, features, n_groups, n_slots=2, device=0):
         self._lib = _lib.load()
         self._h = ct.c_void_p()
+        self.h2d_bytes = self.d2h_bytes = self.n_calls = 0
         features = np.asarray(features)
         if features.ndim != 3:
             raise ValueError(f"features must be [n_objects, n_features, n_states], got shape {features.shape}")
@@ -65,13 +66,14 @@ class Engine:
         ng = np.asarray(self.n_groups, dtype=np.int32)
         rc = self._lib.sbe_create(ct.byref(self._h), self.device, self.n_objects, self.n_features,
                                   self.n_states, self.n_components,
-                                  ng.ctypes.data_as(ct.POINTER(ct.c_int32)), self.n_slots, _ptr(feats))
+                                  ng.ctypes.data_as(ct.POINTER(ct.c_int32)), self.n_slots, self._i(feats))
         if rc != 0:
             msg = self._lib.sbe_last_error(None)
             self._h = ct.c_void_p()
             raise EngineError(rc, msg.decode() if msg else "sbe_create failed")
         self.group_offsets = np.concatenate([[0], np.cumsum(self.n_groups)]).astype(int)
         self.n_groups_total = int(self.group_offsets[-1])
+        self._deferred = False
         self._bound = {}                    # slot -> what conditionals._bind_slot last uploaded there
         self._bound_conc = {}               # component -> concentration table last uploaded
 
@@ -81,7 +83,25 @@ class Engine:
     def _touch(self, slot):
         self._bound.pop(slot, None)
 
+    # PCIe accounting at the ABI boundary: bytes of every caller buffer the library reads (h2d) / writes (d2h).
+    # sampler_replay in bench.py reports them per MCMC step (SURVEY.md 8(b) "What crosses PCIe per step").
+    def _i(self, a):
+        self.h2d_bytes += a.nbytes
+        return a.ctypes.data_as(ct.c_void_p)
+
+    def _o(self, a):
+        self.d2h_bytes += a.nbytes
+        return a.ctypes.data_as(ct.c_void_p)
+
+    def traffic(self, reset=False):
+        """(bytes handed to the library, bytes written back by it, ABI calls) since creation / the last reset."""
+        t = (self.h2d_bytes, self.d2h_bytes, self.n_calls)
+        if reset:
+            self.h2d_bytes = self.d2h_bytes = self.n_calls = 0
+        return t
+
     def _check(self, rc):
+        self.n_calls += 1
         if rc != 0:
             msg = self._lib.sbe_last_error(self._h)
             raise EngineError(rc, msg.decode() if msg else "?")
@@ -116,6 +136,7 @@ class Engine:
             self._check(self._lib.sbe_set_option(self._h, 4, int(step_form)))      # SBE_OPT_STEP_FORM
         if deferred_checks is not None:
             self._check(self._lib.sbe_set_option(self._h, _OPT_DEFERRED, int(bool(deferred_checks))))
+            self._deferred = bool(deferred_checks)          # mirrored: users of a shared engine restore what they found
         if kernel is not None:
             self._check(self._lib.sbe_set_option(self._h, _OPT_KERNEL, int(kernel)))
         if log_mode is not None:
@@ -126,7 +147,7 @@ class Engine:
 
     def na_values(self):
         out = np.empty((self.n_objects, self.n_features), dtype=np.bool_)
-        self._check(self._lib.sbe_get_na(self._h, _ptr(out)))
+        self._check(self._lib.sbe_get_na(self._h, self._o(out)))
         return out
 
     # -- a1 -------------------------------------------------------------------------------------
@@ -149,9 +170,10 @@ class Engine:
         p = _c(probs, np.float64 if f64 else np.float32)
         g = _c(groups.astype(bool, copy=False), np.uint8)
         ch = np.ascontiguousarray(changed_groups, dtype=np.int64).reshape(-1)
-        self._check(self._lib.sbe_component_lh(self._h, _ptr(p), int(f64), n_groups, _ptr(g), _ptr(ch), ch.size,
+        self._check(self._lib.sbe_component_lh(self._h, self._i(p), int(f64), n_groups, self._i(g), self._i(ch), ch.size,
                                                ct.c_void_p(out.ctypes.data), out.strides[0], out.strides[1],
                                                float(na_value)))
+        self.d2h_bytes += out.size * 8              # (rows the call leaves untouched are not written; counted as the upper bound)
         return out
 
     # -- slot state -----------------------------------------------------------------------------
@@ -161,14 +183,14 @@ class Engine:
             raise ValueError(f"groups of component {component} must be {(self.n_groups[component], self.n_objects)}, got {g.shape}")
         g = _c(g.astype(bool, copy=False), np.uint8)
         self._touch(slot)
-        self._check(self._lib.sbe_set_groups(self._h, slot, component, _ptr(g)))
+        self._check(self._lib.sbe_set_groups(self._h, slot, component, self._i(g)))
 
     def set_group_ids(self, slot, component, ids):
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         if ids.shape != (self.n_objects,):
             raise ValueError("ids must be [n_objects]")
         self._touch(slot)
-        self._check(self._lib.sbe_set_group_ids(self._h, slot, component, _ptr(ids)))
+        self._check(self._lib.sbe_set_group_ids(self._h, slot, component, self._i(ids)))
 
     def set_source(self, slot, source):
         s = np.asarray(source)
@@ -176,7 +198,7 @@ class Engine:
             raise ValueError(f"source must be {(self.n_objects, self.n_features, self.n_components)}, got {s.shape}")
         s = _c(s.astype(bool, copy=False), np.uint8)
         self._touch(slot)
-        self._check(self._lib.sbe_set_source(self._h, slot, _ptr(s)))
+        self._check(self._lib.sbe_set_source(self._h, slot, self._i(s)))
 
     def set_source_rows(self, slot, objects, rows):
         objects = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
@@ -185,13 +207,13 @@ class Engine:
             raise ValueError("rows must be [len(objects), n_features, n_components]")
         rows = _c(rows.astype(bool, copy=False), np.uint8)
         self._touch(slot)
-        self._check(self._lib.sbe_set_source_rows(self._h, slot, _ptr(objects), objects.size, _ptr(rows)))
+        self._check(self._lib.sbe_set_source_rows(self._h, slot, self._i(objects), objects.size, self._i(rows)))
 
     def get_source_rows(self, slot, objects):
         """bool [n, F, C]: the listed objects' rows of the slot's source."""
         objects = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
         rows = np.empty((objects.size, self.n_features, self.n_components), dtype=np.uint8)
-        self._check(self._lib.sbe_get_source_rows(self._h, slot, _ptr(objects), objects.size, _ptr(rows)))
+        self._check(self._lib.sbe_get_source_rows(self._h, slot, self._i(objects), objects.size, self._o(rows)))
         return rows.view(bool)
 
     def recount(self, slot, component=-1):
@@ -203,14 +225,14 @@ class Engine:
         objects = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
         changed = np.zeros(self.n_groups_total, dtype=np.uint8)
         self._touch(slot_new)
-        self._check(self._lib.sbe_update_counts(self._h, slot_new, slot_old, _ptr(objects), objects.size, _ptr(changed)))
+        self._check(self._lib.sbe_update_counts(self._h, slot_new, slot_old, self._i(objects), objects.size, self._o(changed)))
         return changed.astype(bool)
 
     def accumulate_counts(self, slot, objects, sign):
         objects = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
         changed = np.zeros(self.n_groups_total, dtype=np.uint8)
         self._touch(slot)
-        self._check(self._lib.sbe_accumulate_counts(self._h, slot, _ptr(objects), objects.size, int(sign), _ptr(changed)))
+        self._check(self._lib.sbe_accumulate_counts(self._h, slot, self._i(objects), objects.size, int(sign), self._o(changed)))
         return changed.astype(bool)
 
     def set_counts(self, slot, component, counts):
@@ -218,11 +240,11 @@ class Engine:
         if c.shape != (self.n_groups[component], self.n_features, self.n_states):
             raise ValueError("bad counts shape")
         self._touch(slot)
-        self._check(self._lib.sbe_set_counts(self._h, slot, component, _ptr(c)))
+        self._check(self._lib.sbe_set_counts(self._h, slot, component, self._i(c)))
 
     def get_counts(self, slot, component):
         out = np.empty((self.n_groups[component], self.n_features, self.n_states), dtype=np.float32)
-        self._check(self._lib.sbe_get_counts(self._h, slot, component, _ptr(out)))
+        self._check(self._lib.sbe_get_counts(self._h, slot, component, self._o(out)))
         return out
 
     def set_concentration(self, component, conc):
@@ -236,7 +258,7 @@ class Engine:
             raise ValueError(f"concentration of component {component} must be {fs} or [G]+{fs}, got {conc.shape}")
         self._bound.clear()                 # tables of every slot depend on it
         self._bound_conc.pop(component, None)
-        self._check(self._lib.sbe_set_concentration(self._h, component, _ptr(conc), per_group))
+        self._check(self._lib.sbe_set_concentration(self._h, component, self._i(conc), per_group))
 
     def update_probs(self, slot, component, temperature=None, prior_temperature=None, unif_counts=None):
         """probs = normalize(counts [/T] + prior['] ) on the device (conditionals.py:105-122, 175-179)."""
@@ -251,18 +273,18 @@ class Engine:
                 raise ValueError("unif_counts must be [n_features, n_states]")
         if temperature is not None or prior_temperature is not None:
             self._touch(slot)               # tempered tables are not the ones the bind cache vouches for
-        self._check(self._lib.sbe_update_probs(self._h, slot, component, t, tp, _ptr(u) if u is not None else None))
+        self._check(self._lib.sbe_update_probs(self._h, slot, component, t, tp, self._i(u) if u is not None else None))
 
     def set_probs(self, slot, component, probs):
         p = _c(probs, np.float32)
         if p.shape != (self.n_groups[component], self.n_features, self.n_states):
             raise ValueError("bad probs shape")
         self._touch(slot)
-        self._check(self._lib.sbe_set_probs(self._h, slot, component, _ptr(p)))
+        self._check(self._lib.sbe_set_probs(self._h, slot, component, self._i(p)))
 
     def get_probs(self, slot, component):
         out = np.empty((self.n_groups[component], self.n_features, self.n_states), dtype=np.float32)
-        self._check(self._lib.sbe_get_probs(self._h, slot, component, _ptr(out)))
+        self._check(self._lib.sbe_get_probs(self._h, slot, component, self._o(out)))
         return out
 
     def set_weights(self, slot, weights):
@@ -270,11 +292,11 @@ class Engine:
         if w.shape != (self.n_features, self.n_components):
             raise ValueError(f"weights must be {(self.n_features, self.n_components)}, got {w.shape}")
         self._touch(slot)
-        self._check(self._lib.sbe_set_weights(self._h, slot, _ptr(w)))
+        self._check(self._lib.sbe_set_weights(self._h, slot, self._i(w)))
 
     def weights_normalized(self, slot):
         out = np.empty((self.n_objects, self.n_features, self.n_components), dtype=np.float32)
-        self._check(self._lib.sbe_get_weights_normalized(self._h, slot, _ptr(out)))
+        self._check(self._lib.sbe_get_weights_normalized(self._h, slot, self._o(out)))
         return out
 
     # -- dense outputs ---------------------------------------------------------------------------
@@ -282,17 +304,17 @@ class Engine:
         if out is None:
             out = np.empty((self.n_objects, self.n_features, self.n_components), dtype=np.float64)
         assert out.flags.c_contiguous and out.dtype == np.float64
-        self._check(self._lib.sbe_likelihood_per_component(self._h, slot, _ptr(out)))
+        self._check(self._lib.sbe_likelihood_per_component(self._h, slot, self._o(out)))
         return out
 
     def likelihood_per_component_exact(self, slot):
         out = np.empty((self.n_objects, self.n_features, self.n_components), dtype=np.float64)
-        self._check(self._lib.sbe_likelihood_per_component_exact(self._h, slot, _ptr(out)))
+        self._check(self._lib.sbe_likelihood_per_component_exact(self._h, slot, self._o(out)))
         return out
 
     def observation_lh(self, slot):
         out = np.empty((self.n_objects, self.n_features), dtype=np.float64)
-        self._check(self._lib.sbe_observation_lh(self._h, slot, _ptr(out)))
+        self._check(self._lib.sbe_observation_lh(self._h, slot, self._o(out)))
         return out
 
     # -- north-star scalar -------------------------------------------------------------------------
@@ -303,7 +325,7 @@ class Engine:
 
     def mixture_loglik_batch(self, first_slot, n):
         out = np.empty(n, dtype=np.float64)
-        self._check(self._lib.sbe_mixture_loglik_batch(self._h, first_slot, n, _ptr(out)))
+        self._check(self._lib.sbe_mixture_loglik_batch(self._h, first_slot, n, self._o(out)))
         return out
 
     def mixture_loglik_batch_async(self, first_slot, n):
@@ -311,22 +333,22 @@ class Engine:
 
     def fetch_results(self, first_slot, n):
         out = np.empty(n, dtype=np.float64)
-        self._check(self._lib.sbe_fetch_results(self._h, first_slot, n, _ptr(out)))
+        self._check(self._lib.sbe_fetch_results(self._h, first_slot, n, self._o(out)))
         return out
 
     def collapsed_loglik(self, slot, component, per_feature=False):
         g = self.n_groups[component]
         per_group = np.empty(g, dtype=np.float64)
         pf = np.empty((g, self.n_features), dtype=np.float32) if per_feature else None
-        self._check(self._lib.sbe_collapsed_loglik(self._h, slot, component, _ptr(per_group),
-                                                   _ptr(pf) if pf is not None else None))
+        self._check(self._lib.sbe_collapsed_loglik(self._h, slot, component, self._o(per_group),
+                                                   self._o(pf) if pf is not None else None))
         return (per_group, pf) if per_feature else per_group
 
     def collapsed_loglik_all(self, slot):
         """float64 [G_total]: the collapsed per-group log-likelihoods of every component in one call and one
         synchronisation (Likelihood.__call__(caching=False) = their sum, likelihood.py:47-63)."""
         out = np.empty(self.n_groups_total, dtype=np.float64)
-        self._check(self._lib.sbe_collapsed_loglik_all(self._h, slot, _ptr(out)))
+        self._check(self._lib.sbe_collapsed_loglik_all(self._h, slot, self._o(out)))
         return out
 
     # -- stateless forms of the reference's free functions -----------------------------------------
@@ -350,8 +372,8 @@ class Engine:
             assert unif_counts is not None
             u = _c(np.broadcast_to(unif_counts, counts.shape)[0] if np.ndim(unif_counts) == 3 else unif_counts, np.float64)
         out = np.empty(counts.shape, dtype=np.float32)
-        self._check(self._lib.sbe_normalize_tables(self._h, _ptr(counts), counts.shape[0], _ptr(conc), per_group, t, tp,
-                                                   _ptr(u) if u is not None else None, _ptr(out)))
+        self._check(self._lib.sbe_normalize_tables(self._h, self._i(counts), counts.shape[0], self._i(conc), per_group, t, tp,
+                                                   self._i(u) if u is not None else None, self._o(out)))
         return out
 
     def dirichlet_logpdf(self, counts, concentration, per_group=False):
@@ -371,8 +393,8 @@ class Engine:
             raise ValueError(f"concentration must be {fs} or {counts.shape}, got {conc.shape}")
         pf = np.empty(counts.shape[:2], dtype=np.float32)
         g = np.empty(counts.shape[0], dtype=np.float64) if per_group else None
-        self._check(self._lib.sbe_dirichlet_logpdf(self._h, _ptr(counts), counts.shape[0], _ptr(conc), pg, _ptr(pf),
-                                                   _ptr(g) if g is not None else None))
+        self._check(self._lib.sbe_dirichlet_logpdf(self._h, self._i(counts), counts.shape[0], self._i(conc), pg, self._o(pf),
+                                                   self._o(g) if g is not None else None))
         pf = pf[0] if squeeze else pf
         return (pf, g) if per_group else pf
 
@@ -392,8 +414,8 @@ class Engine:
         else:
             objs = np.ascontiguousarray(object_subset, dtype=np.int32).reshape(-1)
             n_sub = objs.size
-        self._check(self._lib.sbe_effect_counts(self._h, _ptr(g), g.shape[0], _ptr(m),
-                                                _ptr(objs) if objs is not None and n_sub > 0 else None, n_sub, _ptr(out)))
+        self._check(self._lib.sbe_effect_counts(self._h, self._i(g), g.shape[0], self._i(m),
+                                                self._i(objs) if objs is not None and n_sub > 0 else None, n_sub, self._o(out)))
         return out
 
     def normalize_weights(self, weights, has_components):
@@ -405,7 +427,7 @@ class Engine:
             raise ValueError("weights must be [n_features, C] and has_components [n_rows, C]")
         hc = _c(hc.astype(bool, copy=False), np.uint8)
         out = np.empty((hc.shape[0], self.n_features, w.shape[1]), dtype=np.float32)
-        self._check(self._lib.sbe_normalize_weights(self._h, _ptr(w), w.shape[1], _ptr(hc), hc.shape[0], _ptr(out)))
+        self._check(self._lib.sbe_normalize_weights(self._h, self._i(w), w.shape[1], self._i(hc), hc.shape[0], self._o(out)))
         return out
 
     def cluster_marginals(self, slot, table, objects, prior_temperature=1.0):
@@ -416,8 +438,8 @@ class Engine:
             raise ValueError(f"table must be [{self.n_features}, {self.n_states}] (or [1, F, S])")
         objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
         out = np.empty((2, objs.size), dtype=np.float64)
-        self._check(self._lib.sbe_cluster_marginals(self._h, slot, _ptr(t), _ptr(objs), objs.size,
-                                                    float(prior_temperature), _ptr(out)))
+        self._check(self._lib.sbe_cluster_marginals(self._h, slot, self._i(t), self._i(objs), objs.size,
+                                                    float(prior_temperature), self._o(out)))
         return out
 
     def jump_lh(self, slot, pconf, p_source, p_target, objects, prior_temperature=1.0):
@@ -432,15 +454,15 @@ class Engine:
         ps, pt = _c(p_source, np.float32).reshape(fs), _c(p_target, np.float32).reshape(fs)
         objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
         out = np.empty((2, objs.size), dtype=np.float64)
-        self._check(self._lib.sbe_jump_lh(self._h, slot, _ptr(pc) if n_conf else None, _ptr(ps), _ptr(pt), _ptr(objs),
-                                          objs.size, float(prior_temperature), _ptr(out)))
+        self._check(self._lib.sbe_jump_lh(self._h, slot, self._i(pc) if n_conf else None, self._i(ps), self._i(pt), self._i(objs),
+                                          objs.size, float(prior_temperature), self._o(out)))
         return out
 
     def source_lh_by_feature(self, slot):
         """float32 [F]: per-feature log-likelihood of the slot's source assignment under its normalised weights
         (GibbsSampleWeights.source_lh_by_feature, operators.py:677-685)."""
         out = np.empty(self.n_features, dtype=np.float32)
-        self._check(self._lib.sbe_source_lh_by_feature(self._h, slot, _ptr(out)))
+        self._check(self._lib.sbe_source_lh_by_feature(self._h, slot, self._o(out)))
         return out
 
     def source_posterior(self, slot, objects, temperature=1.0, prior_temperature=1.0):
@@ -448,8 +470,8 @@ class Engine:
         (GibbsSampleSource.calculate_source_posterior, operators.py:554-574)."""
         objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
         out = np.empty((objs.size, self.n_features, self.n_components), dtype=np.float32)
-        self._check(self._lib.sbe_source_posterior(self._h, slot, _ptr(objs), objs.size, float(temperature),
-                                                   float(prior_temperature), _ptr(out)))
+        self._check(self._lib.sbe_source_posterior(self._h, slot, self._i(objs), objs.size, float(temperature),
+                                                   float(prior_temperature), self._o(out)))
         return out
 
     def sample_source(self, slot, dst_slot, objects, z, temperature=1.0, prior_temperature=1.0, from_prior=False,
@@ -467,10 +489,10 @@ class Engine:
         sel = np.empty((objs.size, self.n_features), dtype=np.float32) if return_selected else None
         log_q = ct.c_double()
         self._touch(dst_slot)
-        self._check(self._lib.sbe_sample_source(self._h, slot, dst_slot, _ptr(objs), objs.size, float(temperature),
+        self._check(self._lib.sbe_sample_source(self._h, slot, dst_slot, self._i(objs), objs.size, float(temperature),
                                                 float(prior_temperature), int(bool(from_prior)),
-                                                _ptr(zz) if zz is not None else None, ct.byref(log_q),
-                                                _ptr(sel) if return_selected else None))
+                                                self._i(zz) if zz is not None else None, ct.byref(log_q),
+                                                self._o(sel) if return_selected else None))
         return (log_q.value, sel) if return_selected else log_q.value
 
     def set_rng(self, seed, draw=0):
@@ -485,7 +507,7 @@ class Engine:
     def test_philox(self, ctr_key):
         ck = _c(ctr_key, np.uint32).reshape(-1, 6)
         out = np.empty((ck.shape[0], 4), dtype=np.uint32)
-        self._check(self._lib.sbe_test_philox(self._h, _ptr(ck), ck.shape[0], _ptr(out)))
+        self._check(self._lib.sbe_test_philox(self._h, self._i(ck), ck.shape[0], self._o(out)))
         return out
 
     def source_logprob(self, slot, src_slot, objects, temperature=1.0, prior_temperature=1.0, from_prior=False,
@@ -495,9 +517,9 @@ class Engine:
         objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
         sel = np.empty((objs.size, self.n_features), dtype=np.float32) if return_selected else None
         log_q = ct.c_double()
-        self._check(self._lib.sbe_source_logprob(self._h, slot, src_slot, _ptr(objs), objs.size, float(temperature),
+        self._check(self._lib.sbe_source_logprob(self._h, slot, src_slot, self._i(objs), objs.size, float(temperature),
                                                  float(prior_temperature), int(bool(from_prior)), ct.byref(log_q),
-                                                 _ptr(sel) if return_selected else None))
+                                                 self._o(sel) if return_selected else None))
         return (log_q.value, sel) if return_selected else log_q.value
 
     def subset_lh(self, objects, tables, group_idx, temperature=1.0):
@@ -511,20 +533,20 @@ class Engine:
         if gi.shape != (len(tabs), objs.size):
             raise ValueError("group_idx must be [n_components, n_objects_in_subset]")
         out = np.empty((objs.size, self.n_features, len(tabs)), dtype=np.float32)
-        self._check(self._lib.sbe_subset_lh(self._h, _ptr(objs), objs.size, len(tabs), _ptr(cat), _ptr(offsets[:-1].copy()),
-                                            int(offsets[-1]), _ptr(gi), float(temperature), _ptr(out)))
+        self._check(self._lib.sbe_subset_lh(self._h, self._i(objs), objs.size, len(tabs), self._i(cat), self._i(offsets[:-1].copy()),
+                                            int(offsets[-1]), self._i(gi), float(temperature), self._o(out)))
         return out
 
     def source_prior(self, slot):
         """float64 [N]: per-object log source prior (SourcePrior.__call__, prior.py:573-611)."""
         out = np.empty(self.n_objects, dtype=np.float64)
-        self._check(self._lib.sbe_source_prior(self._h, slot, _ptr(out)))
+        self._check(self._lib.sbe_source_prior(self._h, slot, self._o(out)))
         return out
 
     def observation_lh_exact(self, slot):
         """float64 [N, F]: sum_c w * lh_exact, the LikelihoodLogger row (loggers.py:354-359)."""
         out = np.empty((self.n_objects, self.n_features), dtype=np.float64)
-        self._check(self._lib.sbe_observation_lh_exact(self._h, slot, _ptr(out)))
+        self._check(self._lib.sbe_observation_lh_exact(self._h, slot, self._o(out)))
         return out
 
     def step(self, cur_slot, cand_slot, clusters=None, changed_objects=None, source_rows=None, weights=None):
@@ -554,10 +576,10 @@ class Engine:
         mix = ct.c_double(0.0)
         changed = np.zeros(self.n_groups_total, dtype=np.uint8)
         self._touch(cand_slot)
-        self._check(self._lib.sbe_step(self._h, cur_slot, cand_slot, _ptr(cl) if cl is not None else None,
-                                       _ptr(objs) if objs is not None else None, n_changed,
-                                       _ptr(rows) if rows is not None else None, _ptr(w) if w is not None else None,
-                                       _ptr(glh), ct.byref(mix), _ptr(changed)))
+        self._check(self._lib.sbe_step(self._h, cur_slot, cand_slot, self._i(cl) if cl is not None else None,
+                                       self._i(objs) if objs is not None else None, n_changed,
+                                       self._i(rows) if rows is not None else None, self._i(w) if w is not None else None,
+                                       self._o(glh), ct.byref(mix), self._o(changed)))
         return glh, mix.value, changed.astype(bool)
 
     def step_batch(self, cur_slots, cand_slots, clusters=None, clusters_mask=None, rows_ptr=None, changed_objects=None,
@@ -606,9 +628,9 @@ class Engine:
         if self._bound:                                              # (bind-cache entries of the candidate slots)
             for s in cand.tolist():
                 self._bound.pop(s, None)
-        opt = lambda a: _ptr(a) if a is not None else None          # noqa: E731
-        self._check(self._lib.sbe_step_batch(self._h, n, _ptr(cur), _ptr(cand), opt(cl), opt(cm), _ptr(ptr), opt(objs), opt(rows),
-                                             opt(w), opt(wm), _ptr(glh), _ptr(mix), _ptr(changed)))
+        opt = lambda a: self._i(a) if a is not None else None          # noqa: E731
+        self._check(self._lib.sbe_step_batch(self._h, n, self._i(cur), self._i(cand), opt(cl), opt(cm), self._i(ptr), opt(objs), opt(rows),
+                                             opt(w), opt(wm), self._o(glh), self._o(mix), self._o(changed)))
         return glh, mix, changed.astype(bool)
 
     def gibbs_step(self, cur_slot, cand_slot, objects, z=None, temperature=1.0, prior_temperature=1.0, from_prior=False):
@@ -625,31 +647,31 @@ class Engine:
         lq, lqb, mix = ct.c_double(0.0), ct.c_double(0.0), ct.c_double(0.0)
         changed = np.zeros(self.n_groups_total, dtype=np.uint8)
         self._touch(cand_slot)
-        self._check(self._lib.sbe_gibbs_step(self._h, cur_slot, cand_slot, _ptr(objs), objs.size, float(temperature),
+        self._check(self._lib.sbe_gibbs_step(self._h, cur_slot, cand_slot, self._i(objs), objs.size, float(temperature),
                                              float(prior_temperature), int(bool(from_prior)),
-                                             _ptr(zz) if zz is not None else None, ct.byref(lq), ct.byref(lqb),
-                                             _ptr(glh), ct.byref(mix), _ptr(changed)))
+                                             self._i(zz) if zz is not None else None, ct.byref(lq), ct.byref(lqb),
+                                             self._o(glh), ct.byref(mix), self._o(changed)))
         return lq.value, lqb.value, glh, mix.value, changed.astype(bool)
 
     def test_fast_log(self, x):
         """(fast, library) fp64 logs of x computed on the device (self-test of the table-build log)."""
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
         a, b = np.empty_like(x), np.empty_like(x)
-        self._check(self._lib.sbe_test_fast_log(self._h, _ptr(x), x.size, _ptr(a), _ptr(b)))
+        self._check(self._lib.sbe_test_fast_log(self._h, self._i(x), x.size, self._o(a), self._o(b)))
         return a, b
 
     def test_lgamma(self, x):
         """The engine's lgamma (Dirichlet-categorical terms) of x, computed on the device (self-test)."""
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
         out = np.empty_like(x)
-        self._check(self._lib.sbe_test_lgamma(self._h, _ptr(x), x.size, _ptr(out)))
+        self._check(self._lib.sbe_test_lgamma(self._h, self._i(x), x.size, self._o(out)))
         return out
 
     def test_tab_log(self, x):
         """Table-driven fp64 log of k_mixture_tuple64's table build, computed on the device (self-test)."""
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
         out = np.empty_like(x)
-        self._check(self._lib.sbe_test_tab_log(self._h, _ptr(x), x.size, _ptr(out)))
+        self._check(self._lib.sbe_test_tab_log(self._h, self._i(x), x.size, self._o(out)))
         return out
 
     def copy_slot(self, dst, src):
@@ -665,13 +687,17 @@ class Engine:
         self._check(self._lib.sbe_timer_stop(self._h, ct.byref(ms)))
         return ms.value
 
-    def kernel_timing_start(self, reset=False):
-        """Record one HIP event pair (engine stream) around the fused kernel of every mixture launch from now on
-        (reset=True forgets the pairs recorded so far)."""
-        self._check(self._lib.sbe_kernel_timing(self._h, 1 if reset else 3, None, None))
+    def kernel_timing_start(self):
+        """Record one HIP event pair (engine stream) around the fused kernel of every mixture launch from now on;
+        pairs recorded earlier are forgotten (kernel_timing_resume keeps them)."""
+        self._check(self._lib.sbe_kernel_timing(self._h, 1, None, None))
+
+    def kernel_timing_resume(self):
+        """Bracket launches again after kernel_timing_pause, keeping the pairs recorded so far."""
+        self._check(self._lib.sbe_kernel_timing(self._h, 3, None, None))
 
     def kernel_timing_pause(self):
-        """Stop bracketing launches; the recorded pairs are kept (kernel_timing_start resumes)."""
+        """Stop bracketing launches; the recorded pairs are kept (kernel_timing_resume continues)."""
         self._check(self._lib.sbe_kernel_timing(self._h, 2, None, None))
 
     def last_mixture_kernel(self) -> str:

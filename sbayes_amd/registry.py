@@ -50,6 +50,8 @@ def get_engine(features, n_groups=None, n_slots=4, device=None) -> Engine:
         device = default_device()
     lo, hi = _extent(key)
     for okey, (_, oref) in _ENGINES.items():
+        if not isinstance(okey[0], int):             # the featureless stand-ins of engine_for_features: no array behind them
+            continue
         olo, ohi = _extent(okey)
         if (oref is None or oref() is not None) and olo < hi and lo < ohi:
             warnings.warn("sbayes_amd.registry: a second engine is created for another view of a feature block that "

@@ -69,11 +69,13 @@ class ResidentChain:
         """Inside: state-setting calls never stall the stream (their data checks are queued).  On exit the option is
         restored, which synchronises and raises a queued check HERE -- in the chain call that caused it, not in some
         later call of another user of the shared engine."""
-        self.eng.set_option(deferred_checks=True)
+        previous = getattr(self.eng, "_deferred", False)       # the engine is shared through the registry: another user
+        self.eng.set_option(deferred_checks=True)               # (bench, an outer chain call) may have turned it on
         try:
             yield
         finally:
-            self.eng.set_option(deferred_checks=False)
+            if not previous:
+                self.eng.set_option(deferred_checks=False)
 
     def _upload(self, model, sample):
         eng = self.eng
@@ -267,8 +269,9 @@ class ResidentChainBatch:
         # host mirror of the chains' cluster matrices, stacked [B, K, N]; the candidates are kept as a reference to the
         # caller's stacked array (+ mask) until accept() -- no per-chain Python work on the step path
         self._clusters = np.stack(clusters0) if clusters0 else np.zeros((0, n_groups[0], feats.shape[0]), dtype=bool)
-        self._cand = None                                        # (stacked candidate clusters, mask) of the last step
+        self._cand = None                                        # private copy of the last step's candidate clusters
         self.changed_groups = None
+        self._pending = False
 
     def close(self):
         self.eng.close()
@@ -297,26 +300,41 @@ class ResidentChainBatch:
     def step_arrays(self, clusters=None, clusters_mask=None, rows_ptr=None, changed_objects=None, source_rows=None,
                     weights=None, weights_mask=None):
         """The same with the deltas already stacked (Engine.step_batch's arguments): no per-chain Python work."""
-        glh, mix, changed = self.eng.step_batch(self.cur, self.cand, clusters, clusters_mask, rows_ptr, changed_objects,
+        self._cand, self.changed_groups, self._pending = None, None, False     # nothing of an earlier step survives a
+        glh, mix, changed = self.eng.step_batch(self.cur, self.cand, clusters, clusters_mask, rows_ptr, changed_objects,   # failed call
                                                 source_rows, weights, weights_mask)
-        self._cand = None if clusters is None else (clusters, None if clusters_mask is None else np.asarray(clusters_mask, dtype=bool))
+        if clusters is not None:
+            # the candidates' cluster rows are COPIED here (masked chains only): the caller may reuse its stacked array
+            # in place before accept()
+            cm = None if clusters_mask is None else np.array(clusters_mask, dtype=bool)
+            cl = np.asarray(clusters)
+            self._cand = (np.array(cl, dtype=bool) if cm is None else (np.flatnonzero(cm), np.array(cl[cm], dtype=bool)), cm)
         self.changed_groups = changed
+        self._pending = True
         return glh.sum(axis=1), glh, mix
 
     def accept(self, mask=None):
         """Swap the slots of the accepted chains (all of them by default); rejected chains keep their current slot."""
+        if not self._pending:
+            raise RuntimeError("no pending step: accept() follows exactly one step() / step_arrays()")
         mask = np.ones(self.n, dtype=bool) if mask is None else np.asarray(mask, dtype=bool)
         cur, cand = self.cur.copy(), self.cand.copy()
         self.cur = np.where(mask, cand, cur).astype(np.int32)
         self.cand = np.where(mask, cur, cand).astype(np.int32)
         if self._cand is not None:                               # the accepted chains' candidate clusters become current
             cl, cm = self._cand
-            take = mask if cm is None else mask & cm
-            if take.all():
-                self._clusters = np.array(cl, dtype=bool)
-            elif take.any():
-                self._clusters[take] = np.asarray(cl)[take]
+            if cm is None:
+                self._clusters[mask] = cl[mask]
+            else:
+                idx, rows = cl
+                keep = mask[idx]
+                self._clusters[idx[keep]] = rows[keep]
             self._cand = None
+        self._pending = False
+
+    def reject(self):
+        """Drop the pending step of every chain (same as accept(all False))."""
+        self._cand, self._pending = None, False
 
     def counts(self, chain, component):
         return self.eng.get_counts(int(self.cur[chain]), component)

@@ -30,12 +30,11 @@ STUB_RUNNER = textwrap.dedent('''
         def mixture_loglik(self, slot): return -1.0
         def mixture_loglik_batch_async(self, first, n): time.sleep(0.001)
         def fetch_results(self, first, n): return np.full(n, -1.0)
-        def kernel_timing_start(self, reset=False):
-            if reset: self.n_timed = 0
-            self._on = True
-        def kernel_timing_pause(self):
-            self.n_timed += 1
-        def kernel_timing_stop(self): return self.n_timed - 1, 0.05      # (the reset call paused once)
+        def profile_mixture(self, first, n, iters): return 0.0, 0.0
+        def kernel_timing_start(self): self.n_timed = 0
+        def kernel_timing_resume(self): self.n_timed += 1
+        def kernel_timing_pause(self): pass
+        def kernel_timing_stop(self): return self.n_timed, 0.05
         def last_mixture_kernel(self): return "stub"
         def close(self): pass
 
@@ -66,7 +65,8 @@ def test_bench_rank_logic_world_size_8(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 8 and line["steps"] == 6 and line["warmup"] == 2 and line["scaling"] == "weak"
     assert line["config"]["evals_per_step"] == 4
-    # whole-job aggregate: 8 ranks x 6 steps x 4 evals over the max-over-ranks time
+    assert line["n_reps"] >= 4 and line["dist_backend"] == "gloo"          # >= 20 bracketed launches: 2 per repetition here
+    # whole-job aggregate: 8 ranks x 6 steps x 4 evals over the (median repetition's) max-over-ranks time
     assert abs(line["value"] - 8 * 6 * 4 / (line["ms_per_step"] * 6 / 1e3)) <= 1e-3 * line["value"]
     assert line["cpu_baseline"] is None and "per_config" not in line      # N > 1: no CPU leg, no secondary figures
     for key in ("metric", "unit", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):

@@ -174,6 +174,31 @@ def test_normalize_weights_never_creates_engines_per_row_count(monkeypatch):
     assert len(made) == 1 and made[0].n_features == 7
 
 
+def test_get_engine_after_a_featureless_stand_in(monkeypatch):
+    """ADVICE r2: normalize_weights() before any engine exists creates the stand-in under the key ("features", F);
+    get_engine's overlap scan must step over it instead of reading it as an array key."""
+    class Stub:
+        def __init__(self, features, n_groups, n_slots=1, device=0):
+            self.n_objects, self.n_features, self.n_states = features.shape
+            self.n_groups = list(n_groups)
+
+        def normalize_weights(self, weights, has_components):
+            return np.zeros((len(has_components),) + np.shape(weights), dtype=np.float32)
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(registry, "Engine", Stub)
+    monkeypatch.setattr(registry, "_ENGINES", {})
+    monkeypatch.setattr(registry, "_KNOWN", {})
+    monkeypatch.setattr(registry, "default_device", lambda: 0)
+    likelihood.normalize_weights(np.full((5, 2), 0.5, dtype=np.float32), np.ones((3, 2), dtype=bool))
+    assert ("features", 5) in registry._ENGINES
+    block = np.zeros((12, 5, 3), dtype=bool)
+    eng = registry.get_engine(block, [2, 1])                   # raised IndexError before the fix
+    assert eng.n_groups == [2, 1] and registry.get_engine(block) is eng
+
+
 def test_registry_warns_about_a_second_engine_for_another_view_of_the_same_block(monkeypatch):
     """VERDICT r1 nit 9: engines are keyed on the data pointer; a caller that re-slices the feature block per call
     would silently get a second resident copy.  Now it is told."""
