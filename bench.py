@@ -398,6 +398,28 @@ def secondary_figures(eng, wl, B, args):
     return out
 
 
+def sampler_replay_block(device, with_cpu):
+    """Device cost of the UNCHANGED reference sampler (north_star: "the existing Python MCMC sampler ... drops onto it
+    unchanged").  tests/golden/<tag>_calls.npz hold the engine-level call sequence of the REAL sampler -- the reference's
+    initialiser, operator schedule and MH loop (sbayes/sampling/mcmc_chain.py:186-238) running on the drop-in layer under
+    patch.install(operators=True), recorded in the build container with step markers.  Here the recorded MCMC steps are
+    replayed against the real Engine (timing only; tests/test_gpu_call_log.py checks every result) and -- the CPU
+    baseline leg -- against the oracle-backed double on this host: wall time per MCMC step, engine calls per step and the
+    bytes that crossed the C ABI per step (counted in Engine)."""
+    from tools.replay_bench import run
+    out = {}
+    for tag in ("cfg1", "south_america", "headline"):
+        try:
+            out[tag] = run(tag, cpu=with_cpu, repeats=3, device=device)
+        except FileNotFoundError as exc:                 # a fixture that was not shipped
+            out[tag] = {"error": str(exc)}
+    out["note"] = ("per recorded MCMC step of the real sampler: engine-side cost only (the reference's own Python -- proposal "
+                   "logic, RNG, cache bookkeeping -- is the same on both sides and not in either figure); cpu_us_per_step = "
+                   "the same call sequence served by the NumPy oracle on this host, single thread; reference sampler as a "
+                   "whole: 26 steps/s at the headline shape (SURVEY.md section 6)")
+    return out
+
+
 def static_profile_figures(workload, kernel, B, kern_us):
     """STATIC figures from the committed rocprofv3 PMC passes (never measured in this run): the HBM traffic per launch
     and the VALU roofline of the dominant kernel.  Each carries the file it was read from."""
@@ -557,6 +579,7 @@ def main():
         extra = secondary_figures(eng, wl, B, args)
         extra["per_config"] = per_config_block(device, eng if args.workload == "headline" and B >= 64 else None,
                                                0.0 if args.no_cpu_baseline else args.cpu_seconds)
+        extra["sampler_replay"] = sampler_replay_block(device, not args.no_cpu_baseline)
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:

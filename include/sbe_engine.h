@@ -30,7 +30,7 @@ extern "C" {
 
 typedef struct sbe_engine sbe_engine;
 
-#define SBE_ABI_VERSION 2
+#define SBE_ABI_VERSION 3
 
 /* error codes */
 #define SBE_OK 0
@@ -273,6 +273,46 @@ int sbe_jump_lh(sbe_engine* e, int slot, const float* pconf /* [G_total - K][F][
                 const float* p_target /* [F][S] */, const int32_t* objects, int n_members, double prior_temperature,
                 double* out /* [2][n_members] */);
 int sbe_source_lh_by_feature(sbe_engine* e, int slot, float* out /* [F] */);
+
+/* ---- round 3: delta / resident forms for the UNCHANGED sampler on the drop-in layer -----------
+ * What the reference's own operators ask per MCMC step crosses PCIe as object lists and a few changed rows, never as
+ * [N][F] masks or whole [G][F][S] tables ("What crosses PCIe per step").
+ *
+ * sbe_set_uniform_counts: DirichletPrior.uniform_concentration_array (sbayes/model/prior.py:184-186), float64 [F][S]:
+ *     1 on applicable states, 0 elsewhere.  Resident operand of the tempered tables below (conditional_effect_mean,
+ *     sbayes/sampling/conditionals.py:105-122: normalize(counts/T + unif + (prior - unif)/T_prior)).
+ * sbe_counts_delta: update_feature_counts(sample_old, sample_new, features, object_subset)
+ *     (sbayes/sampling/counts.py:55-95), stateless.  For the n_subset listed objects the caller passes both states:
+ *     gid_old / gid_new int32 [C][n_subset] = global group index of the object in each component (-1: in no group),
+ *     src_old / src_new uint8 [n_subset][F] = source component of each observation (0xFF: none), and `touched` =
+ *     the global indices of the groups any listed object is in, in either state.  out_diff float32
+ *     [n_touched][F][S] = rows `touched` of the reference's `new_counts - old_counts`, all components at once
+ *     (every other row of that difference is zero).  The caller adds them with FeatureCounts.add_changes
+ *     (sbayes/sampling/state.py:340-350).
+ * sbe_set_counts_rows: rows `group_idx` (global) of the slot's resident counts <- rows float32 [n_rows][F][S]: the bind
+ *     cache of the host layer sends only the groups whose counts differ from what the slot holds.
+ * sbe_given_unchanged_lh: component_likelihood_given_unchanged(model, sample, object_subset, i_cluster, T, T_prior)
+ *     (sbayes/sampling/operators.py:863-928) for static priors, from RESIDENT data of the slot the candidate is bound
+ *     to (new clusters, source not yet resampled, counts still the old state's -- exactly the reference's inputs at
+ *     that point): kept cluster counts (:876-883), unchangeable confounder counts (:896-901), their tempered tables,
+ *     the gather, NA -> 1, ** (1/T).  out float32 [n_sub][F][C].  Only the object list goes up.
+ * sbe_cluster_posterior_marginals: sbe_cluster_marginals with the candidate table built on the device from the
+ *     slot's resident counts of cluster `i_cluster`: conditional_effect_mean(prior, counts[[i_cluster]], unif, T_prior,
+ *     T) (AlterCluster.compute_cluster_posterior, operators.py:1046-1052).  out float64 [2][n].
+ * sbe_jump_lh_resident: sbe_jump_lh with the tempered tables of the source / target cluster and of every confounder
+ *     group built on the device from the slot's resident counts (ClusterJump.get_jump_lh, operators.py:1679-1722;
+ *     expected_confounder_features :1342-1379).  out float64 [2][n_members]. */
+int sbe_set_uniform_counts(sbe_engine* e, const double* unif_counts /* [F][S] */);
+int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const int32_t* gid_old /* [C][n_subset] */,
+                     const int32_t* gid_new, const uint8_t* src_old /* [n_subset][F] */, const uint8_t* src_new,
+                     const int32_t* touched, int n_touched, float* out_diff /* [n_touched][F][S] */);
+int sbe_set_counts_rows(sbe_engine* e, int slot, const int32_t* group_idx, int n_rows, const float* rows /* [n_rows][F][S] */);
+int sbe_given_unchanged_lh(sbe_engine* e, int slot, int i_cluster, const int32_t* objects, int n_sub, double temperature,
+                           double prior_temperature, float* out /* [n_sub][F][C] */);
+int sbe_cluster_posterior_marginals(sbe_engine* e, int slot, int i_cluster, double temperature, double prior_temperature,
+                                    const int32_t* objects, int n_objects_av, double* out /* [2][n_objects_av] */);
+int sbe_jump_lh_resident(sbe_engine* e, int slot, int i_source, int i_target, double temperature, double prior_temperature,
+                         const int32_t* objects, int n_members, double* out /* [2][n_members] */);
 
 /* ---- data-parallel cores of Gibbs source resampling ----------------------
  * sbe_source_posterior: GibbsSampleSource.calculate_source_posterior (operators.py:554-574):

@@ -9,7 +9,7 @@ import os
 from pathlib import Path
 
 LIB_NAME = "libsbe_engine.so"
-ABI_VERSION = 2                    # SBE_ABI_VERSION of include/sbe_engine.h
+ABI_VERSION = 3                    # SBE_ABI_VERSION of include/sbe_engine.h
 _LIB = None
 
 c_engine_p = ct.c_void_p
@@ -92,6 +92,16 @@ PROTOTYPES = {
     "sbe_test_philox": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_subset_lh": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int,
                                  ct.c_void_p, ct.c_double, ct.c_void_p]),
+    "sbe_set_uniform_counts": (ct.c_int, [c_engine_p, ct.c_void_p]),
+    "sbe_counts_delta": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p,
+                                    ct.c_void_p, ct.c_int, ct.c_void_p]),
+    "sbe_set_counts_rows": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),
+    "sbe_given_unchanged_lh": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double,
+                                          ct.c_void_p]),
+    "sbe_cluster_posterior_marginals": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_double, ct.c_double, ct.c_void_p,
+                                                   ct.c_int, ct.c_void_p]),
+    "sbe_jump_lh_resident": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_int, ct.c_double, ct.c_double, ct.c_void_p,
+                                        ct.c_int, ct.c_void_p]),
     "sbe_source_prior": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
     "sbe_observation_lh_exact": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
     "sbe_gibbs_step": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double, ct.c_int,

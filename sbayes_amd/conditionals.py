@@ -12,16 +12,10 @@ from __future__ import annotations
 
 import numpy as np
 
+from .binding import (_bind_slot, _bind_uniform, _engine, _remember, _same, _tables_current,      # noqa: F401
+                      _token)                                                                  # (re-exported)
 from .likelihood import compute_component_likelihood
 from .registry import get_engine
-
-
-def _engine(model):
-    lik = getattr(model, "likelihood", None)
-    if lik is not None and hasattr(lik, "engine"):
-        return lik.engine
-    n_groups = [model.shapes.n_clusters] + [c.n_groups for c in model.data.confounders.values()]
-    return get_engine(model.data.features.values, n_groups)
 
 
 def conditional_effect_mean(prior_counts, feature_counts, unif_counts=None, prior_temperature=None,
@@ -82,96 +76,6 @@ def likelihood_per_component(model, sample, caching=True):
 likelihood_per_component_subset = likelihood_per_component
 
 
-def _token(param):
-    """(array, version) of a state parameter.  The reference's (and the mirror's) parameters bump `version` on every
-    edit -- set_value, set_items, edit(), edit_group(s), set_groups, FeatureCounts.add_changes
-    (sbayes/sampling/state.py:34-61, 97-161, 340-350) -- and edit the SAME ndarray in place whenever the parameter is
-    not shared with a copy, so array identity alone says nothing; plain arrays (confounder group matrices,
-    concentration tables) have no version and are compared by content."""
-    value = getattr(param, "value", param)
-    return np.asarray(value), getattr(param, "version", None)
-
-
-def _same(tok, cached):
-    """True if the token `tok` = (array, version) denotes what `cached` = (array, version, private copy) recorded.
-    Versioned parameters: same ndarray object AND same version (an in-place edit through the parameter API always
-    bumps the version; a copy-on-write edit always creates a new ndarray).  Unversioned arrays: content equality
-    against the private copy -- identity is never trusted."""
-    if cached is None:
-        return False
-    arr, version = tok
-    ref, ref_version, copy = cached
-    if version is not None and ref_version is not None:
-        return arr is ref and version == ref_version
-    return copy is not None and arr.shape == copy.shape and arr.dtype == copy.dtype and np.array_equal(arr, copy)
-
-
-def _remember(tok):
-    arr, version = tok
-    # the ndarray itself is kept alive so that its id cannot be recycled for another array while the entry lives
-    return arr, version, (None if version is not None else arr.copy())
-
-
-def _bind_slot(eng, model, sample, slot, with_source=False):
-    """Upload one sample's state into an engine slot: group ids, counts, weights (small), optionally the source
-    assignment.  Only what differs from what the slot was last bound to is sent (the operators evaluate the same or
-    nearly the same sample many times in a row); returns the components whose probability tables are stale."""
-    names = sample.component_names
-    C = len(names)
-    groups = [_token(sample.clusters)] + [_token(c.group_assignment) for c in sample.confounders.values()]
-    conc = [_token(model.prior.prior_cluster_effect.concentration_array)] + [
-        _token(model.prior.prior_confounding_effects[k].concentration_array(sample)) for k in names[1:]]
-    counts = [_token(sample.feature_counts[name]) for name in names]
-    weights = _token(sample.weights)
-    source = _token(sample.source) if with_source else None
-    cache = getattr(eng, "_bound", None)
-    if cache is None:                               # an engine without a bind cache (test doubles): send everything
-        for c in range(C):
-            eng.set_groups(slot, c, groups[c][0])
-            eng.set_concentration(c, conc[c][0])
-            eng.set_counts(slot, c, counts[c][0])
-        if with_source:
-            eng.set_source(slot, source[0])
-        eng.set_weights(slot, weights[0])
-        return set(range(C))
-    old = cache.get(slot) or {"groups": [None] * C, "counts": [None] * C, "weights": None, "source": None, "stale": set(range(C))}
-    new = {"groups": list(old["groups"]), "counts": list(old["counts"]), "weights": old["weights"], "source": old["source"],
-           "stale": set(old["stale"])}
-    conc_changed = [c for c in range(C) if not _same(conc[c], eng._bound_conc.get(c))]
-    for c in conc_changed:                          # (drops every slot's entry: all tables depend on it)
-        eng.set_concentration(c, conc[c][0])
-    if conc_changed:
-        new["stale"] = set(range(C))
-    for c in range(C):
-        if not _same(groups[c], old["groups"][c]):
-            eng.set_groups(slot, c, groups[c][0])
-            new["groups"][c] = _remember(groups[c])
-        if not _same(counts[c], old["counts"][c]):
-            eng.set_counts(slot, c, counts[c][0])
-            new["counts"][c] = _remember(counts[c])
-            new["stale"].add(c)
-    if with_source and not _same(source, old["source"]):
-        eng.set_source(slot, source[0])
-        new["source"] = _remember(source)
-    if not _same(weights, old["weights"]):
-        eng.set_weights(slot, weights[0])
-        new["weights"] = _remember(weights)
-    for c in conc_changed:
-        eng._bound_conc[c] = _remember(conc[c])
-    cache[slot] = new                               # (the setters above dropped the slot's entry)
-    return new["stale"]
-
-
-def _tables_current(eng, slot):
-    """Rebuild the probability tables that the last _bind_slot left stale."""
-    entry = getattr(eng, "_bound", {}).get(slot)
-    stale = set(range(eng.n_components)) if entry is None else entry["stale"]
-    for c in sorted(stale):
-        eng.update_probs(slot, c)
-    if entry is not None:
-        entry["stale"] = set()
-
-
 def likelihood_per_component_exact(model, sample, slot=0):
     """Leave-one-out component likelihoods (used by the reference's LikelihoodLogger)."""
     eng = _engine(model)
@@ -199,16 +103,24 @@ def observation_likelihoods(model, sample, slot=0, exact=False):
 
 
 def source_prior(model, sample, slot=0, caching=True) -> float:
-    """SourcePrior.__call__ (sbayes/model/prior.py:573-611): log prior of the source assignment given
-    the weights, cached per object in sample.cache.source_prior when the sample has that node."""
-    eng = _engine(model)
+    """SourcePrior.__call__ (sbayes/model/prior.py:573-611): log prior of the source assignment given the weights, with
+    the reference's per-object cache protocol -- everything when the weights changed (`cache.ahead_of("weights")`),
+    else the objects whose source rows changed (`what_changed("source")`) -- and the per-object values from the device:
+    the sample is bound with its source (changed rows only), N doubles come back."""
     cache = getattr(sample.cache, "source_prior", None)
-    if cache is not None and caching and not cache.is_outdated():
+    if cache is None:                                 # a sample type without that cache node
+        eng = _engine(model)
+        _bind_slot(eng, model, sample, slot, with_source=True)
+        return eng.source_prior(slot).sum()
+    if caching and not cache.is_outdated():
         return cache.value.sum()
-    _bind_slot(eng, model, sample, slot, with_source=True)
-    per_object = eng.source_prior(slot)
-    if cache is not None:
-        with cache.edit() as arr:
-            arr[:] = per_object
-        return cache.value.sum()
-    return per_object.sum()
+    with cache.edit() as per_object:
+        if cache.ahead_of("weights"):
+            changed = np.arange(sample.n_objects)
+        else:
+            changed = cache.what_changed(input_key=["source"], caching=caching)
+        if len(changed) > 0:
+            eng = _engine(model)
+            _bind_slot(eng, model, sample, slot, with_source=True)
+            per_object[changed] = eng.source_prior(slot)[changed]
+    return cache.value.sum()

@@ -26,28 +26,63 @@ def compute_effect_counts(features, group_assignment, source_is_component, objec
 
 
 def recalculate_feature_counts(features, sample):
-    """Recount every mixture component from `sample.source` and store the result in
-    `sample.feature_counts` (set_value bumps all group versions, like the reference)."""
-    source = sample.source.value
-    sample.feature_counts["clusters"].set_value(
-        compute_effect_counts(features, sample.clusters.value, source[..., 0]))
-    for i, conf in enumerate(sample.confounders.keys(), start=1):
-        groups = sample.confounders[conf].group_assignment
-        sample.feature_counts[conf].set_value(compute_effect_counts(features, groups, source[..., i]))
+    """Recount every mixture component from `sample.source` and store the result in `sample.feature_counts`
+    (set_value bumps all group versions, like the reference).  The counting runs on the sample's RESIDENT state: only
+    the source rows / group ids that differ from what the engine slot holds go up, the [G, F, S] tables come back."""
+    from .binding import recount_bound
+    names = ["clusters", *sample.confounders.keys()]
+    n_groups = [int(np.shape(sample.clusters.value)[0])] + [int(np.shape(sample.confounders[k].group_assignment)[0])
+                                                           for k in names[1:]]
+    eng = get_engine(features, n_groups)
+    for name, table in zip(names, recount_bound(eng, sample)):
+        sample.feature_counts[name].set_value(table)
     return sample.feature_counts
 
 
+def _subset_indices(object_subset, n_objects):
+    if isinstance(object_subset, slice):
+        return np.arange(n_objects)[object_subset]
+    subset = np.asarray(object_subset)
+    return np.flatnonzero(subset) if subset.dtype == np.bool_ else subset.astype(np.int64, copy=False).reshape(-1)
+
+
+def _group_ids(groups, objs, offset):
+    """Global group index of each listed object in one component (-1: in no group)."""
+    sub = np.asarray(groups)[:, objs]
+    return np.where(sub.any(axis=0), sub.argmax(axis=0) + offset, -1).astype(np.int32)
+
+
+def _source_ids(source_rows):
+    """bool [n, F, C] -> component id per observation (255: none)."""
+    return np.where(source_rows.any(axis=-1), source_rows.argmax(axis=-1), 255).astype(np.uint8)
+
+
 def update_feature_counts(sample_old, sample_new, features, object_subset):
-    """Delta update of `sample_new.feature_counts` for the objects whose assignment changed."""
+    """Delta update of `sample_new.feature_counts` for the objects whose assignment changed (counts.py:55-95).
+    ONE device call for all components: the subset's group ids and source rows of both samples go up (n * (8 C + 2 F)
+    bytes), the count rows of the groups those objects are in come back; the reference's `add_changes(diff)` follows
+    with the same `diff` it would have computed (zero rows for every other group)."""
     counts = sample_new.feature_counts
     names = ["clusters", *sample_new.confounders.keys()]
-    for i, name in enumerate(names):
-        if name == "clusters":
-            g_old, g_new = sample_old.clusters.value, sample_new.clusters.value
-        else:
-            g_old = sample_old.confounders[name].group_assignment
-            g_new = sample_new.confounders[name].group_assignment
-        old = compute_effect_counts(features, g_old, sample_old.source.value[..., i], object_subset)
-        new = compute_effect_counts(features, g_new, sample_new.source.value[..., i], object_subset)
-        counts[name].add_changes(diff=new - old)
+    groups_old = [sample_old.clusters.value] + [sample_old.confounders[k].group_assignment for k in names[1:]]
+    groups_new = [sample_new.clusters.value] + [sample_new.confounders[k].group_assignment for k in names[1:]]
+    n_groups = [int(np.shape(g)[0]) for g in groups_new]
+    eng = get_engine(features, n_groups)
+    objs = _subset_indices(object_subset, np.shape(features)[0])
+    off = np.concatenate([[0], np.cumsum(n_groups)]).astype(int)
+    if len(np.unique(objs)) != len(objs):          # (the reference's fancy index would count a repeated object twice)
+        for i, name in enumerate(names):
+            old = compute_effect_counts(features, groups_old[i], sample_old.source.value[..., i], object_subset)
+            new = compute_effect_counts(features, groups_new[i], sample_new.source.value[..., i], object_subset)
+            counts[name].add_changes(diff=new - old)
+        return counts
+    gid_old = np.stack([_group_ids(groups_old[c], objs, off[c]) for c in range(len(names))])
+    gid_new = np.stack([_group_ids(groups_new[c], objs, off[c]) for c in range(len(names))])
+    touched, rows = eng.counts_delta(objs, gid_old, gid_new, _source_ids(sample_old.source.value[objs]),
+                                     _source_ids(sample_new.source.value[objs]))
+    for c, name in enumerate(names):
+        diff = np.zeros(counts[name].value.shape, dtype=np.float32)
+        mine = (touched >= off[c]) & (touched < off[c + 1])
+        diff[touched[mine] - off[c]] = rows[mine]
+        counts[name].add_changes(diff=diff)
     return counts

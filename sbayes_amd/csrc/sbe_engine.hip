@@ -94,7 +94,9 @@ struct sbe_engine {
     uint16_t* d_tuple_g = nullptr; // [slots][kMaxTuples][kMaxComponents]
     uint8_t* d_tuple_p = nullptr;  // [slots][kMaxTuples]
     double* d_conc = nullptr;      // [Gtot][F][S]
-    double* d_unif = nullptr;      // [F][S]
+    double* d_unif = nullptr;      // [F][S]  staging of the per-call unif_counts argument
+    double* d_unif_res = nullptr;  bool unif_set = false;   // [F][S] resident (sbe_set_uniform_counts): the resident operator forms
+    int32_t* d_comp_of_group = nullptr;                     // [Gtot] mixture component of every global group index
     std::vector<uint8_t> conc_set;
     // scratch
     double* d_partials = nullptr;  int64_t partials_stride = 0;   // [slots][max_blocks]
@@ -939,7 +941,7 @@ int sbe_destroy(sbe_engine* e) {
     if (e->h_step_payload) (void)hipHostFree(e->h_step_payload);
     if (e->h_io) (void)hipHostFree(e->h_io);
     void* dev_ptrs[] = {e->d_step_pf, e->d_step_pg, e->d_logtab, e->d_state_h, e->d_toff, e->d_tid, e->d_tuple_g, e->d_tuple_p, e->d_state_q, e->d_probs_t, e->d_wpat_t, e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
-                        e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_unif, e->d_partials, e->d_rowoff,
+                        e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_unif, e->d_unif_res, e->d_comp_of_group, e->d_partials, e->d_rowoff,
                         e->d_status, e->d_changed, e->d_step_stamp, e->d_scratch};
     for (void* p : dev_ptrs) if (p) (void)hipFree(p);
     if (e->h_results) (void)hipHostFree(e->h_results);
@@ -1096,6 +1098,14 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_CHK(hipMemsetAsync(e->d_tid, 0, NS * e->Np, e->stream));
     CREATE_RC(dmalloc(e, &e->d_conc, e->table_elems()));
     CREATE_RC(dmalloc(e, &e->d_unif, F * S));
+    CREATE_RC(dmalloc(e, &e->d_unif_res, F * S));
+    CREATE_RC(dmalloc(e, &e->d_comp_of_group, e->Gtot));
+    {
+        std::vector<int32_t> cog(std::max(e->Gtot, 1), 0);
+        for (int c = 0; c < e->C; ++c)
+            for (int g = 0; g < e->G[c]; ++g) cog[e->goff[c] + g] = c;
+        CREATE_CHK(hipMemcpy(e->d_comp_of_group, cog.data(), (size_t)std::max(e->Gtot, 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     // partials: worst-case block count of the fused kernel (ft = 16, one packed step per thread)
     {
         const int64_t min_objs = kBlock / (16 / 4);
@@ -2134,6 +2144,301 @@ int sbe_subset_lh(sbe_engine* e, const int32_t* objects, int n_sub, int n_comp, 
         e->d_state, d_tab, d_off, d_gi, d_obj, n_sub, d_out, e->F, e->S, n_comp, e->Fp, (float)inv_t, inv_t != 1.0);
     HIPCHK(e, hipGetLastError());
     return d2h(e, out, d_out, (size_t)n_out * sizeof(float));
+}
+
+// ---- round 3: delta / resident forms for the drop-in host layer ----------------------------------------------------
+// What the unchanged reference sampler asks per MCMC step goes over PCIe as object lists and a few changed rows
+// (last row): no [N][F] mask, no whole [G][F][S] table.
+namespace {
+
+// queue the status read-back in front of the call's final synchronisation and report after it (one sync per call)
+int sync_and_report(sbe_engine* e) {
+    HIPCHK(e, hipMemcpyAsync(e->h_status, e->d_status, ST_WORDS * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->status_pending = false;
+    return report_status(e);
+}
+
+int check_objects(sbe_engine* e, const int32_t* objects, int n) {
+    for (int i = 0; i < n; ++i)
+        if (objects[i] < 0 || objects[i] >= e->N) return fail(e, SBE_ERR_ARG, "object index %d out of range", objects[i]);
+    return SBE_OK;
+}
+
+inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+
+int sbe_set_uniform_counts(sbe_engine* e, const double* unif_counts) {
+    CHECK_ENGINE(e); CHECK_PTR(e, unif_counts);
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = upload(e, e->d_unif_res, unif_counts, (size_t)e->F * e->S * sizeof(double));
+    if (rc) return rc;
+    e->unif_set = true;
+    return SBE_OK;
+}
+
+int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const int32_t* gid_old, const int32_t* gid_new,
+                     const uint8_t* src_old, const uint8_t* src_new, const int32_t* touched, int n_touched, float* out_diff) {
+    CHECK_ENGINE(e);
+    if (n_subset < 0 || n_touched < 0) return fail(e, SBE_ERR_ARG, "n_subset=%d n_touched=%d", n_subset, n_touched);
+    if (n_touched == 0) return SBE_OK;
+    CHECK_PTR(e, touched); CHECK_PTR(e, out_diff);
+    const int F = e->F, S = e->S, C = e->C;
+    const size_t out_bytes = (size_t)n_touched * F * S * sizeof(float);
+    if (n_subset == 0) { memset(out_diff, 0, out_bytes); return SBE_OK; }
+    CHECK_PTR(e, objects); CHECK_PTR(e, gid_old); CHECK_PTR(e, gid_new); CHECK_PTR(e, src_old); CHECK_PTR(e, src_new);
+    int rc = check_objects(e, objects, n_subset);
+    if (rc) return rc;
+    std::vector<int32_t> comp(n_touched);
+    for (int t = 0; t < n_touched; ++t) {
+        if (touched[t] < 0 || touched[t] >= e->Gtot) return fail(e, SBE_ERR_ARG, "touched group %d out of range [0,%d)", touched[t], e->Gtot);
+        int c = 0;
+        while (c + 1 < C && touched[t] >= e->goff[c + 1]) ++c;
+        comp[t] = c;
+    }
+    for (int64_t i = 0; i < (int64_t)C * n_subset; ++i)
+        if (gid_old[i] < -1 || gid_old[i] >= e->Gtot || gid_new[i] < -1 || gid_new[i] >= e->Gtot)
+            return fail(e, SBE_ERR_ARG, "group index out of range in the subset's ids");
+    HIPCHK(e, hipSetDevice(e->device));
+    // inputs (a few KB) in host-mapped memory, read by the kernel in place; the diff rows come back the same way when
+    // they are small, through the staging copy otherwise
+    const size_t ob = al256((size_t)n_subset * 4), gb = al256((size_t)C * n_subset * 4), sb = al256((size_t)n_subset * F);
+    const size_t tb = al256((size_t)n_touched * 4);
+    const bool mapped_out = out_bytes <= ((size_t)1 << 18);
+    rc = ensure_io(e, ob + 2 * gb + 2 * sb + 2 * tb + (mapped_out ? out_bytes : 0));
+    if (rc) return rc;
+    uint8_t* h = e->h_io;
+    size_t o = 0;
+    const size_t o_obj = o;  memcpy(h + o, objects, (size_t)n_subset * 4); o += ob;
+    const size_t o_go = o;   memcpy(h + o, gid_old, (size_t)C * n_subset * 4); o += gb;
+    const size_t o_gn = o;   memcpy(h + o, gid_new, (size_t)C * n_subset * 4); o += gb;
+    const size_t o_so = o;   memcpy(h + o, src_old, (size_t)n_subset * F); o += sb;
+    const size_t o_sn = o;   memcpy(h + o, src_new, (size_t)n_subset * F); o += sb;
+    const size_t o_t = o;    memcpy(h + o, touched, (size_t)n_touched * 4); o += tb;
+    const size_t o_tc = o;   memcpy(h + o, comp.data(), (size_t)n_touched * 4); o += tb;
+    float* d_out = nullptr;
+    if (mapped_out) d_out = (float*)(e->d_io + o);
+    else { rc = ensure_scratch(e, out_bytes); if (rc) return rc; d_out = (float*)e->d_scratch; }
+    k_counts_delta<<<dim3(n_touched, div_up(F, 64)), kBlock, (size_t)64 * S * sizeof(int32_t), e->stream>>>(
+        e->d_state, (const int32_t*)(e->d_io + o_obj), n_subset, (const int32_t*)(e->d_io + o_go), (const int32_t*)(e->d_io + o_gn),
+        e->d_io + o_so, e->d_io + o_sn, (const int32_t*)(e->d_io + o_t), (const int32_t*)(e->d_io + o_tc), d_out, F, S, e->Fp);
+    HIPCHK(e, hipGetLastError());
+    if (!mapped_out) return d2h(e, out_diff, d_out, out_bytes);
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    memcpy(out_diff, h + o, out_bytes);
+    return synced(e);
+}
+
+int sbe_set_counts_rows(sbe_engine* e, int slot, const int32_t* group_idx, int n_rows, const float* rows) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot);
+    if (n_rows < 0) return fail(e, SBE_ERR_ARG, "n_rows=%d", n_rows);
+    if (n_rows == 0) return SBE_OK;
+    CHECK_PTR(e, group_idx); CHECK_PTR(e, rows);
+    for (int i = 0; i < n_rows; ++i)
+        if (group_idx[i] < 0 || group_idx[i] >= e->Gtot) return fail(e, SBE_ERR_ARG, "group index %d out of range [0,%d)", group_idx[i], e->Gtot);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int64_t fs = (int64_t)e->F * e->S;
+    const size_t rb = al256((size_t)n_rows * fs * sizeof(float));
+    int rc = ensure_scratch(e, rb + (size_t)n_rows * sizeof(int32_t));
+    if (rc) return rc;
+    { int _urc = upload(e, e->d_scratch, rows, (size_t)n_rows * fs * sizeof(float)); if (_urc) return _urc; }
+    { int _urc = upload(e, e->d_scratch + rb, group_idx, (size_t)n_rows * sizeof(int32_t)); if (_urc) return _urc; }
+    k_set_count_rows<<<div_up((int64_t)n_rows * fs, 256), 256, 0, e->stream>>>(
+        (const float*)e->d_scratch, (const int32_t*)(e->d_scratch + rb), e->d_counts + (int64_t)slot * e->table_elems(), n_rows, fs);
+    HIPCHK(e, hipGetLastError());
+    return SBE_OK;
+}
+
+int sbe_given_unchanged_lh(sbe_engine* e, int slot, int i_cluster, const int32_t* objects, int n_sub, double temperature,
+                           double prior_temperature, float* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot);
+    if (n_sub < 0) return fail(e, SBE_ERR_ARG, "n_sub=%d", n_sub);
+    if (n_sub == 0) return SBE_OK;
+    CHECK_PTR(e, objects); CHECK_PTR(e, out);
+    const int N = e->N, F = e->F, S = e->S, C = e->C, K = e->G[0];
+    if (i_cluster < 0 || i_cluster >= K) return fail(e, SBE_ERR_ARG, "cluster %d out of range [0,%d)", i_cluster, K);
+    if (!(temperature > 0.0) || !(prior_temperature > 0.0)) return fail(e, SBE_ERR_ARG, "temperatures must be positive");
+    int rc = check_objects(e, objects, n_sub);
+    if (rc) return rc;
+    Slot& s = e->slots[slot];
+    if (!s.groups_set || !s.source_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source not set", slot);
+    for (int c = 0; c < C; ++c) {
+        if (!e->conc_set[c]) return fail(e, SBE_ERR_STATE, "concentration of component %d not set", c);
+        if (c > 0 && !s.counts_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts of component %d not set", slot, c);
+    }
+    if (!e->unif_set) return fail(e, SBE_ERR_STATE, "uniform concentration not set (sbe_set_uniform_counts)");
+    HIPCHK(e, hipSetDevice(e->device));
+    const int R = 1 + e->Gtot - K;                              // table rows: the cluster + every confounder group
+    const int64_t fs = (int64_t)F * S;
+    const size_t out_bytes = (size_t)n_sub * F * C * sizeof(float);
+    const bool mapped_out = out_bytes <= ((size_t)1 << 18);
+    // host-mapped inputs: object list | subset flags [N] | table row of each (component, subset object) | table offsets
+    const size_t ob = al256((size_t)n_sub * 4), mb = al256((size_t)N), gb = al256((size_t)C * n_sub * 4), fb = al256((size_t)C * 4);
+    rc = ensure_io(e, ob + mb + gb + fb + (mapped_out ? out_bytes : 0));
+    if (rc) return rc;
+    uint8_t* h = e->h_io;
+    memcpy(h, objects, (size_t)n_sub * 4);
+    memset(h + ob, 0, (size_t)N);
+    for (int i = 0; i < n_sub; ++i) h[ob + objects[i]] = 1;
+    int32_t* gi = (int32_t*)(h + ob + mb);
+    int32_t* off = (int32_t*)(h + ob + mb + gb);
+    for (int c = 0; c < C; ++c) {
+        off[c] = c == 0 ? 0 : 1 + e->goff[c] - K;
+        for (int i = 0; i < n_sub; ++i) {
+            if (c == 0) { gi[i] = 0; continue; }                // every subset object sees the cluster's table (operators.py:884)
+            const uint16_t gg = s.h_gid[(size_t)c * N + objects[i]];
+            gi[(size_t)c * n_sub + i] = gg == kNoGroup ? -1 : (int)gg - e->goff[c];
+        }
+    }
+    const size_t cb = al256((size_t)R * fs * sizeof(float));
+    rc = ensure_scratch(e, 2 * cb + (mapped_out ? 0 : out_bytes));
+    if (rc) return rc;
+    float* d_cnt = (float*)e->d_scratch;
+    float* d_tab = (float*)(e->d_scratch + cb);
+    float* d_out = mapped_out ? (float*)(e->d_io + ob + mb + gb + fb) : (float*)(e->d_scratch + 2 * cb);
+    rc = clear_status_word(e, ST_BAD_NORMALIZE);
+    if (rc) return rc;
+    k_unchanged_counts<<<dim3(R, div_up(F, 64)), kBlock, (size_t)64 * S * sizeof(int32_t), e->stream>>>(
+        e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_src + (int64_t)slot * N * e->Fp,
+        e->d_counts + (int64_t)slot * e->table_elems(), e->d_io + ob, (const int32_t*)e->d_io, n_sub, e->d_comp_of_group,
+        i_cluster, K, N, e->Np, F, S, e->Fp, d_cnt);
+    HIPCHK(e, hipGetLastError());
+    // conditional_effect_mean (conditionals.py:105-122) of the kept counts: the cluster's row with the cluster prior,
+    // the confounder rows with theirs
+    k_probs<float><<<div_up((int64_t)F, 256), 256, 0, e->stream>>>(
+        d_cnt, e->d_conc + (int64_t)i_cluster * fs, e->d_unif_res, d_tab, 0, 1, F, S, temperature, prior_temperature, 1, e->d_status);
+    HIPCHK(e, hipGetLastError());
+    if (R > 1) {
+        k_probs<float><<<div_up((int64_t)(R - 1) * F, 256), 256, 0, e->stream>>>(
+            d_cnt + fs, e->d_conc + (int64_t)K * fs, e->d_unif_res, d_tab + fs, 0, R - 1, F, S, temperature, prior_temperature, 1,
+            e->d_status);
+        HIPCHK(e, hipGetLastError());
+    }
+    const double inv_t = 1.0 / temperature;
+    k_subset_lh<<<div_up((int64_t)n_sub * F, 256), 256, 0, e->stream>>>(
+        e->d_state, d_tab, (const int32_t*)(e->d_io + ob + mb + gb), (const int32_t*)(e->d_io + ob + mb), (const int32_t*)e->d_io,
+        n_sub, d_out, F, S, C, e->Fp, (float)inv_t, inv_t != 1.0);
+    HIPCHK(e, hipGetLastError());
+    if (!mapped_out) {
+        rc = d2h(e, out, d_out, out_bytes);
+        if (rc) return rc;
+        rc = read_status(e);
+        if (rc) return rc;
+        return report_status(e);
+    }
+    rc = sync_and_report(e);
+    if (rc) return rc;
+    memcpy(out, h + ob + mb + gb + fb, out_bytes);
+    return SBE_OK;
+}
+
+int sbe_cluster_posterior_marginals(sbe_engine* e, int slot, int i_cluster, double temperature, double prior_temperature,
+                                    const int32_t* objects, int n_objects_av, double* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, out);
+    if (n_objects_av < 0) return fail(e, SBE_ERR_ARG, "n_objects=%d", n_objects_av);
+    if (n_objects_av == 0) return SBE_OK;
+    CHECK_PTR(e, objects);
+    const int F = e->F, S = e->S, C = e->C, K = e->G[0];
+    if (i_cluster < 0 || i_cluster >= K) return fail(e, SBE_ERR_ARG, "cluster %d out of range [0,%d)", i_cluster, K);
+    if (!(temperature > 0.0) || !(prior_temperature > 0.0)) return fail(e, SBE_ERR_ARG, "temperatures must be positive");
+    int rc = check_objects(e, objects, n_objects_av);
+    if (rc) return rc;
+    rc = check_slot_ready(e, slot, true);
+    if (rc) return rc;
+    Slot& s = e->slots[slot];
+    if (!s.counts_set[0] || !e->conc_set[0]) return fail(e, SBE_ERR_STATE, "slot %d: cluster counts / concentration not set", slot);
+    if (!e->unif_set) return fail(e, SBE_ERR_STATE, "uniform concentration not set (sbe_set_uniform_counts)");
+    HIPCHK(e, hipSetDevice(e->device));
+    if (s.patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
+    const int64_t fs = (int64_t)F * S;
+    rc = ensure_scratch(e, (size_t)fs * sizeof(float));
+    if (rc) return rc;
+    float* d_tab = (float*)e->d_scratch;
+    const size_t ob = al256((size_t)n_objects_av * sizeof(int32_t));
+    const size_t out_bytes = (size_t)2 * n_objects_av * sizeof(double);
+    rc = ensure_io(e, ob + out_bytes);
+    if (rc) return rc;
+    memcpy(e->h_io, objects, (size_t)n_objects_av * sizeof(int32_t));
+    rc = clear_status_word(e, ST_BAD_NORMALIZE);
+    if (rc) return rc;
+    // the candidate table: conditional_effect_mean(prior, counts[[i_cluster]], unif, T_prior, T) (operators.py:1046-1052)
+    // from the slot's resident counts -- nothing table-sized crosses PCIe
+    k_probs<int32_t><<<div_up((int64_t)F, 256), 256, 0, e->stream>>>(
+        e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc, e->d_unif_res, d_tab, i_cluster, i_cluster + 1, F, S,
+        temperature, prior_temperature, 1, e->d_status, -(int64_t)i_cluster * fs);
+    HIPCHK(e, hipGetLastError());
+    const double inv = 1.0 / prior_temperature;
+    k_cluster_marginals<<<n_objects_av, kBlock, 0, e->stream>>>(
+        e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np,
+        e->d_probs + (int64_t)slot * e->table_elems(), d_tab, e->d_weights + (int64_t)slot * F * C,
+        e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0, (const int32_t*)e->d_io, n_objects_av,
+        (double*)(e->d_io + ob), reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C, e->Fp);
+    HIPCHK(e, hipGetLastError());
+    rc = sync_and_report(e);
+    if (rc) return rc;
+    memcpy(out, e->h_io + ob, out_bytes);
+    return SBE_OK;
+}
+
+int sbe_jump_lh_resident(sbe_engine* e, int slot, int i_source, int i_target, double temperature, double prior_temperature,
+                         const int32_t* objects, int n_members, double* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, out);
+    if (n_members < 0) return fail(e, SBE_ERR_ARG, "n_members=%d", n_members);
+    if (n_members == 0) return SBE_OK;
+    CHECK_PTR(e, objects);
+    const int F = e->F, S = e->S, C = e->C, K = e->G[0];
+    if (i_source < 0 || i_source >= K || i_target < 0 || i_target >= K) return fail(e, SBE_ERR_ARG, "cluster index out of range");
+    if (!(temperature > 0.0) || !(prior_temperature > 0.0)) return fail(e, SBE_ERR_ARG, "temperatures must be positive");
+    int rc = check_objects(e, objects, n_members);
+    if (rc) return rc;
+    Slot& s = e->slots[slot];
+    if (!s.groups_set || !s.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / weights not set", slot);
+    for (int c = 0; c < C; ++c)
+        if (!s.counts_set[c] || !e->conc_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts / concentration of component %d not set", slot, c);
+    if (!e->unif_set) return fail(e, SBE_ERR_STATE, "uniform concentration not set (sbe_set_uniform_counts)");
+    HIPCHK(e, hipSetDevice(e->device));
+    if (s.patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
+    const int64_t fs = (int64_t)F * S;
+    const int n_conf = e->Gtot - K;
+    rc = ensure_scratch(e, (size_t)(2 + std::max(n_conf, 1)) * fs * sizeof(float));
+    if (rc) return rc;
+    float* d_ps = (float*)e->d_scratch;
+    float* d_pt = d_ps + fs;
+    float* d_pc = d_pt + fs;
+    const size_t ob = al256((size_t)n_members * sizeof(int32_t));
+    const size_t out_bytes = (size_t)2 * n_members * sizeof(double);
+    rc = ensure_io(e, ob + out_bytes);
+    if (rc) return rc;
+    memcpy(e->h_io, objects, (size_t)n_members * sizeof(int32_t));
+    rc = clear_status_word(e, ST_BAD_NORMALIZE);
+    if (rc) return rc;
+    // tempered tables of the two clusters and of every confounder group (ClusterEffectProposals.posterior_counts +
+    // normalize, operators.py:1254-1259, 1364-1371) from the slot's resident counts; the reference uses the CLUSTER
+    // prior's uniform concentration for every component (operators.py:1352)
+    const int32_t* cnt = e->d_counts + (int64_t)slot * e->table_elems();
+    k_probs<int32_t><<<div_up((int64_t)F, 256), 256, 0, e->stream>>>(cnt, e->d_conc, e->d_unif_res, d_ps, i_source, i_source + 1, F, S,
+        temperature, prior_temperature, 1, e->d_status, -(int64_t)i_source * fs);
+    HIPCHK(e, hipGetLastError());
+    k_probs<int32_t><<<div_up((int64_t)F, 256), 256, 0, e->stream>>>(cnt, e->d_conc, e->d_unif_res, d_pt, i_target, i_target + 1, F, S,
+        temperature, prior_temperature, 1, e->d_status, -(int64_t)i_target * fs);
+    HIPCHK(e, hipGetLastError());
+    if (n_conf > 0) {
+        k_probs<int32_t><<<div_up((int64_t)n_conf * F, 256), 256, 0, e->stream>>>(cnt, e->d_conc, e->d_unif_res, d_pc, K, e->Gtot, F, S,
+            temperature, prior_temperature, 1, e->d_status, -(int64_t)K * fs);
+        HIPCHK(e, hipGetLastError());
+    }
+    const double inv = 1.0 / prior_temperature;
+    k_jump_lh<<<n_members, kBlock, 0, e->stream>>>(
+        e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np, d_pc, d_ps, d_pt,
+        e->d_weights + (int64_t)slot * F * C, e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0,
+        (const int32_t*)e->d_io, n_members, (double*)(e->d_io + ob), reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C,
+        e->Fp, K);
+    HIPCHK(e, hipGetLastError());
+    rc = sync_and_report(e);
+    if (rc) return rc;
+    memcpy(out, e->h_io + ob, out_bytes);
+    return SBE_OK;
 }
 
 // ---- source prior and the LikelihoodLogger row --------------------------------

@@ -493,7 +493,7 @@ template <class TC>
 __global__ void k_probs(const TC* __restrict__ counts, const double* __restrict__ conc,
                         const double* __restrict__ unif /* [F][S] or null */, float* __restrict__ probs,
                         int g_lo, int g_hi, int F, int S, double temperature, double prior_temperature,
-                        int conc_per_group, int* __restrict__ status) {
+                        int conc_per_group, int* __restrict__ status, int64_t out_shift = 0) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n_rows = (int64_t)(g_hi - g_lo) * F;
     if (row >= n_rows) return;
@@ -514,7 +514,7 @@ __global__ void k_probs(const TC* __restrict__ counts, const double* __restrict_
     };
     const double total = np_pairwise_sum<double>(post, S);
     if (!(total > 0.0)) atomicAdd(&status[ST_BAD_NORMALIZE], 1);
-    for (int s = 0; s < S; ++s) probs[base + s] = (float)(post(s) / total);
+    for (int s = 0; s < S; ++s) probs[base + out_shift + s] = (float)(post(s) / total);   // (out_shift: rows of a scratch table)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2714,6 +2714,106 @@ __global__ void k_tile_weights(const float* __restrict__ wpat, double* __restric
     const int f = tile * ft + fl;
     const double v = f < F ? (double)wpat[((int64_t)pp * F + f) * C + c] : 0.0;
     wpat_t[(((int64_t)tile * Pmax + pp) * C + c) * ft + fl] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 3: delta forms for the drop-in host layer -- what the UNCHANGED reference sampler asks per MCMC step crosses
+// PCIe as object lists and a few changed rows, never as [N][F] masks or whole [G][F][S] tables (SURVEY.md 8(b),
+// last row).
+//
+// k_counts_delta: update_feature_counts(sample_old, sample_new, features, object_subset) (counts.py:55-95), stateless.
+// For the listed objects the caller hands over both states -- global group index per component (-1: none) and source
+// component id per observation (0xFF: none) -- and the list of groups any of them is in ("touched"); the kernel
+// writes, for every touched group,
+//     diff[t][f][s] = #{i: new state counts (object i, f) at state s in group t} - #{i: old state ...}
+// = the rows of the reference's `new_counts - old_counts` that can be non-zero (as float32: FLOAT_TYPE, counts.py:20).
+// Block = (touched group, 64-feature tile); 64 features x 4 object lanes; LDS histogram [64][S].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_counts_delta(
+    const uint8_t* __restrict__ state, const int32_t* __restrict__ objects, int n,
+    const int32_t* __restrict__ gid_old /* [C][n] */, const int32_t* __restrict__ gid_new,
+    const uint8_t* __restrict__ src_old /* [n][F] */, const uint8_t* __restrict__ src_new,
+    const int32_t* __restrict__ touched /* [T] global group index */, const int32_t* __restrict__ touched_comp /* [T] */,
+    float* __restrict__ out /* [T][F][S] */, int F, int S, int Fp) {
+    extern __shared__ int32_t hist[];
+    const int t = blockIdx.x, f0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 64 * S; i += kBlock) hist[i] = 0;
+    __syncthreads();
+    const int fl = threadIdx.x & 63, ol = threadIdx.x >> 6;
+    const int f = f0 + fl;
+    const int gg = touched[t], c = touched_comp[t];
+    if (f < F) {
+        for (int i = ol; i < n; i += kBlock / 64) {
+            const uint8_t x = state[(int64_t)objects[i] * Fp + f];
+            if (x == kNA) continue;
+            const int d = (int)(gid_new[(int64_t)c * n + i] == gg && src_new[(int64_t)i * F + f] == c) -
+                          (int)(gid_old[(int64_t)c * n + i] == gg && src_old[(int64_t)i * F + f] == c);
+            if (d) atomicAdd(&hist[fl * S + x], d);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * S; i += kBlock) {
+        const int ff = f0 + i / S;
+        if (ff < F) out[((int64_t)t * F + ff) * S + i % S] = (float)hist[i];
+    }
+}
+
+// float32 count rows of listed groups -> the slot's resident int32 counts (Engine.set_counts_rows: the bind cache
+// sends only the groups whose rows differ from what the slot holds)
+__global__ void k_set_count_rows(const float* __restrict__ rows /* [n][F][S] */, const int32_t* __restrict__ group_idx,
+                                 int32_t* __restrict__ counts /* slot's [Gtot][F][S] */, int n, int64_t fs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * fs) return;
+    counts[(int64_t)group_idx[i / fs] * fs + i % fs] = (int32_t)rows[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// component_likelihood_given_unchanged (operators.py:863-928), count part, from RESIDENT data: the float32 count tables
+// the reference builds from the observations that are NOT being resampled,
+//   row 0            = sum over members of cluster `i_cluster` outside the subset of [source == 0] * one-hot   (:876-883)
+//   row 1 + (gg - K) = counts[gg] - sum over subset objects in confounder group gg of [source == c] * one-hot   (:896-901)
+// from the slot's group ids and source (the bound candidate: new clusters, source not yet resampled) and its resident
+// counts (still the old state's, which is what sample.feature_counts holds at that point).  `in_subset` [N] bytes.
+// Block = (row, 64-feature tile), 64 features x 4 object lanes, LDS histogram [64][S].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_unchanged_counts(
+    const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid /* slot's [C][Np] */,
+    const uint8_t* __restrict__ src /* slot's [N][Fp] */, const int32_t* __restrict__ counts /* slot's [Gtot][F][S] */,
+    const uint8_t* __restrict__ in_subset /* [N] */, const int32_t* __restrict__ objects, int n_sub,
+    const int32_t* __restrict__ comp_of_group /* [Gtot] */, int i_cluster, int K, int N, int Np, int F, int S, int Fp,
+    float* __restrict__ out /* [1 + Gtot - K][F][S] */) {
+    extern __shared__ int32_t hist[];
+    const int r = blockIdx.x, f0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 64 * S; i += kBlock) hist[i] = 0;
+    __syncthreads();
+    const int fl = threadIdx.x & 63, ol = threadIdx.x >> 6;
+    const int f = f0 + fl;
+    if (f < F) {
+        if (r == 0) {
+            const uint16_t want = (uint16_t)i_cluster;                  // component 0: global index = cluster index
+            for (int n = ol; n < N; n += kBlock / 64) {
+                if (gid[n] != want || in_subset[n]) continue;
+                const uint8_t x = state[(int64_t)n * Fp + f];
+                if (x != kNA && src[(int64_t)n * Fp + f] == 0) atomicAdd(&hist[fl * S + x], 1);
+            }
+        } else {
+            const int gg = K + r - 1, c = comp_of_group[gg];
+            for (int i = ol; i < n_sub; i += kBlock / 64) {
+                const int n = objects[i];
+                if (gid[(int64_t)c * Np + n] != (uint16_t)gg) continue;
+                const uint8_t x = state[(int64_t)n * Fp + f];
+                if (x != kNA && src[(int64_t)n * Fp + f] == c) atomicAdd(&hist[fl * S + x], -1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * S; i += kBlock) {
+        const int ff = f0 + i / S;
+        if (ff >= F) continue;
+        const int s = i % S;
+        const int base = r == 0 ? 0 : counts[((int64_t)(K + r - 1) * F + ff) * S + s];
+        out[((int64_t)r * F + ff) * S + s] = (float)(base + hist[i]);
+    }
 }
 
 }  // namespace sbe

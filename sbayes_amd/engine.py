@@ -74,14 +74,17 @@ class Engine:
         self.group_offsets = np.concatenate([[0], np.cumsum(self.n_groups)]).astype(int)
         self.n_groups_total = int(self.group_offsets[-1])
         self._deferred = False
-        self._bound = {}                    # slot -> what conditionals._bind_slot last uploaded there
+        self._bound = {}                    # slot -> what binding._bind_slot last uploaded there
         self._bound_conc = {}               # component -> concentration table last uploaded
+        self._bound_unif = None             # uniform concentration last uploaded (binding._bind_uniform)
+        self._mirror = {}                   # slot -> host mirrors of the slot's counts / source (delta uploads)
 
     # -- plumbing -----------------------------------------------------------------------------
     # -- bind cache (sbayes_amd.conditionals._bind_slot): what a slot was last bound to; every method that changes a
     #    slot's state drops the slot's entry, so a cached entry always describes the device state ------------------
     def _touch(self, slot):
         self._bound.pop(slot, None)
+        self._mirror.pop(slot, None)
 
     # PCIe accounting at the ABI boundary: bytes of every caller buffer the library reads (h2d) / writes (d2h).
     # sampler_replay in bench.py reports them per MCMC step (SURVEY.md 8(b) "What crosses PCIe per step").
@@ -537,6 +540,72 @@ class Engine:
                                             int(offsets[-1]), self._i(gi), float(temperature), self._o(out)))
         return out
 
+    # -- round 3: delta / resident forms for the drop-in host layer (what crosses PCIe per MCMC step: object lists and a
+    #    few changed rows) ------------------------------------------------------------------------------------------
+    def set_uniform_counts(self, unif_counts):
+        """DirichletPrior.uniform_concentration_array (prior.py:184-186), float64 [F, S]: resident operand of the tempered
+        tables of cluster_posterior_marginals / given_unchanged_lh / jump_lh_resident."""
+        u = _c(unif_counts, np.float64)
+        if u.shape != (self.n_features, self.n_states):
+            raise ValueError(f"unif_counts must be {(self.n_features, self.n_states)}, got {u.shape}")
+        self._check(self._lib.sbe_set_uniform_counts(self._h, self._i(u)))
+
+    def counts_delta(self, objects, gid_old, gid_new, src_old, src_new):
+        """update_feature_counts (counts.py:55-95) for the listed objects, stateless: gid_* int [C, n] global group index
+        per component (-1: none), src_* uint8 [n, F] source component per observation (255: none).  Returns
+        (touched, diff): the sorted global indices of the groups any listed object is in (either state) and the float32
+        rows [len(touched), F, S] of new_counts - old_counts; every other row of that difference is zero."""
+        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        n = objs.size
+        go = np.ascontiguousarray(gid_old, dtype=np.int32).reshape(self.n_components, n)
+        gn = np.ascontiguousarray(gid_new, dtype=np.int32).reshape(self.n_components, n)
+        so = np.ascontiguousarray(src_old, dtype=np.uint8)
+        sn = np.ascontiguousarray(src_new, dtype=np.uint8)
+        if so.shape != (n, self.n_features) or sn.shape != so.shape:
+            raise ValueError(f"src_old / src_new must be [{n}, {self.n_features}]")
+        touched = np.union1d(go[go >= 0], gn[gn >= 0]).astype(np.int32)
+        diff = np.zeros((touched.size, self.n_features, self.n_states), dtype=np.float32)
+        if touched.size and n:
+            self._check(self._lib.sbe_counts_delta(self._h, self._i(objs), n, self._i(go), self._i(gn), self._i(so), self._i(sn),
+                                                   self._i(touched), touched.size, self._o(diff)))
+        return touched, diff
+
+    def set_counts_rows(self, slot, group_idx, rows):
+        """Rows `group_idx` (global group indices) of the slot's resident counts <- float32 rows [n, F, S]."""
+        gi = np.ascontiguousarray(group_idx, dtype=np.int32).reshape(-1)
+        r = _c(rows, np.float32)
+        if r.shape != (gi.size, self.n_features, self.n_states):
+            raise ValueError(f"rows must be [{gi.size}, {self.n_features}, {self.n_states}], got {r.shape}")
+        self._touch(slot)
+        if gi.size:
+            self._check(self._lib.sbe_set_counts_rows(self._h, slot, self._i(gi), gi.size, self._i(r)))
+
+    def given_unchanged_lh(self, slot, i_cluster, objects, temperature=1.0, prior_temperature=1.0):
+        """component_likelihood_given_unchanged (operators.py:863-928) of the sample bound to `slot` (groups, source,
+        counts, concentrations resident): float32 [n, F, C].  Only the object list goes up."""
+        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        out = np.empty((objs.size, self.n_features, self.n_components), dtype=np.float32)
+        self._check(self._lib.sbe_given_unchanged_lh(self._h, slot, int(i_cluster), self._i(objs), objs.size, float(temperature),
+                                                     float(prior_temperature), self._o(out)))
+        return out
+
+    def cluster_posterior_marginals(self, slot, i_cluster, objects, temperature=1.0, prior_temperature=1.0):
+        """cluster_marginals with the candidate table conditional_effect_mean(prior, counts[[i_cluster]], unif, T_prior, T)
+        built on the device from the slot's resident counts (operators.py:1046-1052): float64 [2, n]."""
+        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        out = np.empty((2, objs.size), dtype=np.float64)
+        self._check(self._lib.sbe_cluster_posterior_marginals(self._h, slot, int(i_cluster), float(temperature),
+                                                              float(prior_temperature), self._i(objs), objs.size, self._o(out)))
+        return out
+
+    def jump_lh_resident(self, slot, i_source, i_target, objects, temperature=1.0, prior_temperature=1.0):
+        """jump_lh with every tempered table built on the device from the slot's resident counts: float64 [2, n]."""
+        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        out = np.empty((2, objs.size), dtype=np.float64)
+        self._check(self._lib.sbe_jump_lh_resident(self._h, slot, int(i_source), int(i_target), float(temperature),
+                                                   float(prior_temperature), self._i(objs), objs.size, self._o(out)))
+        return out
+
     def source_prior(self, slot):
         """float64 [N]: per-object log source prior (SourcePrior.__call__, prior.py:573-611)."""
         out = np.empty(self.n_objects, dtype=np.float64)
@@ -625,9 +694,9 @@ class Engine:
         glh = np.empty((n, self.n_groups_total), dtype=np.float64)
         mix = np.empty(n, dtype=np.float64)
         changed = np.zeros((n, self.n_groups_total), dtype=np.uint8)
-        if self._bound:                                              # (bind-cache entries of the candidate slots)
+        if self._bound or self._mirror:                              # (bind-cache entries of the candidate slots)
             for s in cand.tolist():
-                self._bound.pop(s, None)
+                self._touch(s)
         opt = lambda a: self._i(a) if a is not None else None          # noqa: E731
         self._check(self._lib.sbe_step_batch(self._h, n, self._i(cur), self._i(cand), opt(cl), opt(cm), self._i(ptr), opt(objs), opt(rows),
                                              opt(w), opt(wm), self._o(glh), self._o(mix), self._o(changed)))

@@ -12,10 +12,13 @@ fallback: without the HIP library / a GPU these functions raise.
 """
 from __future__ import annotations
 
+from types import SimpleNamespace
+
 import numpy as np
 
 from .counts import recalculate_feature_counts
 from . import registry
+from .binding import _bind_slot
 from .registry import get_engine
 
 
@@ -32,6 +35,14 @@ class Likelihood:
             self.source_index[conf] = i
         self._na_features = None
         registry.note_features(self.features, self.n_groups)
+        # patch.install(operators=True) serves SourcePrior.__call__ (prior.py:573-611) from the device; that method has no
+        # way back to the model, so the model's likelihood leaves a note on the prior's SourcePrior instance
+        source_prior = getattr(prior, "source_prior", None)
+        if source_prior is not None:
+            try:
+                source_prior._sbayes_amd_owner = SimpleNamespace(prior=prior, likelihood=self)
+            except AttributeError:
+                pass
 
     # device handles are per process: never pickled, re-created lazily (mcmc_setup.py:299, model.py:53)
     def __getstate__(self):
@@ -63,33 +74,31 @@ class Likelihood:
             log_lh += self.compute_lh_confounder(sample, conf, caching=caching)
         return log_lh
 
-    def _group_logliks(self, counts, concentration, groups):
-        """float64 per listed group: float32-summed Dirichlet-categorical log-pdf (device)."""
-        groups = np.asarray(groups)
-        conc = concentration if concentration.ndim == 2 else concentration[groups]
-        _, per_group = self.engine.dirichlet_logpdf(counts[groups], conc, per_group=True)
-        return per_group
+    def _group_logliks(self, sample, component, groups, slot=0):
+        """float64 per listed group of one component: float32-summed Dirichlet-categorical log-pdf (a7/a8) from the
+        RESIDENT counts and concentration tables of the slot `sample` is bound to -- the bind sends the count rows of
+        the groups that changed since the slot was last bound (those are the `groups` asked for here), nothing else
+        goes up, G_c doubles come back."""
+        eng = self.engine
+        _bind_slot(eng, SimpleNamespace(prior=self.prior), sample, slot)
+        return eng.collapsed_loglik(slot, component)[np.asarray(groups)]
 
     def compute_lh_clusters(self, sample, caching=True) -> float:
         cache = sample.cache.group_likelihoods["clusters"]
-        feature_counts = sample.feature_counts["clusters"].value
         with cache.edit() as lh:
             changed = cache.what_changed("counts", caching=caching)
             if len(changed) > 0:
-                lh[changed] = self._group_logliks(
-                    feature_counts, np.asarray(self.prior.prior_cluster_effect.concentration_array), changed)
+                lh[changed] = self._group_logliks(sample, 0, changed)
         return cache.value.sum()
 
     def compute_lh_confounder(self, sample, conf, caching=True) -> float:
         cache = sample.cache.group_likelihoods[conf]
-        feature_counts = sample.feature_counts[conf].value
         conf_prior = self.prior.prior_confounding_effects[conf]
         with cache.edit() as lh:
-            prior_concentration = conf_prior.concentration_array(sample)
             hyperprior_has_changed = conf_prior.any_dynamic_priors and cache.ahead_of("universal_counts")
             changed = cache.what_changed("counts", caching=caching and not hyperprior_has_changed)
             if len(changed) > 0:
-                lh[changed] = self._group_logliks(feature_counts, np.asarray(prior_concentration), changed)
+                lh[changed] = self._group_logliks(sample, self.source_index[conf], changed)
         return cache.value.sum()
 
 
@@ -135,9 +144,104 @@ def normalize_weights(weights, has_components, features=None):
     return eng.normalize_weights(weights, has_components)
 
 
+class NormalizedWeights(np.lib.mixins.NDArrayOperatorsMixin):
+    """What update_weights(sample) returns: the float32 [n_objects, n_features, n_components] array of
+    normalize_weights(weights, has_components) (likelihood.py:153-190), materialised LAZILY.
+
+    Inside an MCMC step the reference only ever reads a few object rows of it -- `update_weights(sample)[object_subset]`
+    (operators.py:520, 756-757, 819-842, 1790; prior.py:603) -- so indexing with an object subset (bool mask, index
+    array, list, slice or int along axis 0) computes exactly those rows on the device (normalize_weights of
+    has_components[subset]: bit-identical to the rows of the full array, each row depends only on its own
+    has_components pattern) and the N * F * C * 4 bytes of the full array never cross PCIe.  Every other use
+    (np.asarray, arithmetic, ufuncs, any other attribute or index form) materialises the full array once, on the
+    device, and behaves like it.  The object is immutable: copies share it."""
+
+    __array_priority__ = 100
+
+    def __init__(self, weights, has_components, features=None):
+        self._weights = np.array(weights, dtype=np.float32)              # private snapshots: evaluation may come later
+        self._has_components = np.array(has_components, dtype=bool)
+        self._features = features
+        self._full = None
+
+    # -- what the consumers look at without needing values
+    @property
+    def shape(self):
+        return (self._has_components.shape[0],) + self._weights.shape
+
+    dtype = np.dtype(np.float32)
+    ndim = 3
+
+    def __len__(self):
+        return self._has_components.shape[0]
+
+    def __copy__(self):
+        return self
+
+    def __deepcopy__(self, memo):
+        return self
+
+    def materialize(self):
+        if self._full is None:
+            full = normalize_weights(self._weights, self._has_components, self._features)
+            full.flags.writeable = False
+            self._full = full
+        return self._full
+
+    def __array__(self, dtype=None, copy=None):
+        full = self.materialize()
+        return full if dtype is None or dtype == full.dtype else full.astype(dtype)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        inputs = tuple(x.materialize() if isinstance(x, NormalizedWeights) else x for x in inputs)
+        if "out" in kwargs:
+            kwargs["out"] = tuple(x.materialize() if isinstance(x, NormalizedWeights) else x for x in kwargs["out"])
+        return getattr(ufunc, method)(*inputs, **kwargs)
+
+    def __array_function__(self, func, types, args, kwargs):
+        def conv(x):
+            if isinstance(x, NormalizedWeights):
+                return x.materialize()
+            if isinstance(x, (list, tuple)):
+                return type(x)(conv(y) for y in x)
+            return x
+        return func(*conv(args), **{k: conv(v) for k, v in kwargs.items()})
+
+    def _rows(self, idx):
+        """has_components rows an axis-0 index selects, or None when `idx` is anything else."""
+        if isinstance(idx, (int, np.integer)):
+            return None                                                   # (drops the axis: rare, use the full array)
+        if isinstance(idx, slice):
+            return self._has_components[idx]
+        if isinstance(idx, (list, np.ndarray)):
+            arr = np.asarray(idx)
+            if arr.ndim == 1 and (arr.dtype == np.bool_ or np.issubdtype(arr.dtype, np.integer)):
+                return self._has_components[arr]
+        return None
+
+    def __getitem__(self, idx):
+        if self._full is None:
+            rows = self._rows(idx)
+            if rows is not None:
+                if rows.shape[0] == 0:
+                    return np.zeros((0,) + self._weights.shape, dtype=np.float32)
+                if 2 * rows.shape[0] <= self._has_components.shape[0]:
+                    return normalize_weights(self._weights, rows, self._features)
+        return self.materialize()[idx]
+
+    def __getattr__(self, name):                                          # everything else an ndarray offers
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    def __repr__(self):
+        return f"NormalizedWeights(shape={self.shape}, materialized={self._full is not None})"
+
+
 def update_weights(sample, caching=True, features=None):
-    """Normalised mixture weights of `sample`, cached on (has_components, weights) versions."""
+    """Normalised mixture weights of `sample`, cached on (has_components, weights) versions (likelihood.py:153-168);
+    returned as a lazily materialised array (NormalizedWeights)."""
     cache = sample.cache.weights_normalized
     if (not caching) or cache.is_outdated():
-        cache.update_value(normalize_weights(sample.weights.value, sample.cache.has_components.value, features))
+        cache.update_value(NormalizedWeights(sample.weights.value, sample.cache.has_components.value, features))
     return cache.value

@@ -21,7 +21,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .conditionals import _bind_slot, _engine, _tables_current
+from .binding import _bind_slot, _bind_uniform, _engine, _tables_current
 
 EPS = np.finfo(np.float32).eps        # sbayes/util.py:34
 
@@ -42,12 +42,11 @@ def compute_cluster_posterior(model, sample, i_cluster, available, temperature=1
                               additive_smoothing=1e-6, geo_likelihoods=None, slot=0):
     """Posterior probability of each available object to belong to cluster `i_cluster`."""
     eng = _prepare(model, sample, slot)
-    prior = model.prior.prior_cluster_effect
-    table = eng.normalize_tables(
-        sample.feature_counts["clusters"].value[[i_cluster]], np.asarray(prior.concentration_array),
-        temperature=temperature, prior_temperature=prior_temperature,
-        unif_counts=np.asarray(prior.uniform_concentration_array))
-    log_m = _log_marginals(eng, slot, table, available, prior_temperature) / temperature
+    _bind_uniform(eng, model)
+    # the candidate table conditional_effect_mean(prior, counts[[i_cluster]], unif, T_prior, T) (operators.py:1046-1052)
+    # is built on the device from the slot's resident counts: object ids up, 2 x n doubles back
+    objects = np.flatnonzero(available) if np.asarray(available).dtype == np.bool_ else np.asarray(available)
+    log_m = eng.cluster_posterior_marginals(slot, i_cluster, objects, temperature, prior_temperature) / temperature
     if geo_likelihoods is not None:
         log_m[1] += np.log(geo_likelihoods)
     posterior = 1.0 / (1.0 + np.exp(log_m[0] - log_m[1]))        # m1 / (m0 + m1)
@@ -149,13 +148,21 @@ def gibbs_sample_source(model, sample, object_subset=slice(None), temperature=1.
 
 
 def component_likelihood_given_unchanged(model, sample, object_subset, i_cluster, temperature=1.0,
-                                         prior_temperature=1.0):
+                                         prior_temperature=1.0, slot=0):
     """operators.py:863-928: float32 [n_subset, F, C] component likelihoods of the subset's
     observations under effect tables built only from the observations that are NOT resampled.
     `object_subset` is a bool mask [n_objects].  Counts (a9) and tables (a10) come from the device."""
     eng = _engine(model)
     object_subset = np.asarray(object_subset, dtype=bool)
     objects = np.flatnonzero(object_subset)
+    if not any(model.prior.prior_confounding_effects[conf].any_dynamic_priors for conf in sample.confounders):
+        # static priors: everything the reference reads here is resident once `sample` is bound -- its (new) clusters,
+        # its not-yet-resampled source, its counts, the priors' tables -- so the kept / unchangeable counts
+        # (operators.py:876-901), their tempered tables and the gather run on the device in ONE call; the object list
+        # goes up, [n, F, C] float32 comes back
+        _bind_slot(eng, model, sample, slot, with_source=True)
+        _bind_uniform(eng, model)
+        return eng.given_unchanged_lh(slot, i_cluster, objects, temperature, prior_temperature)
     source = sample.source.value
     prior = model.prior.prior_cluster_effect
     cluster = sample.clusters.value[i_cluster]
@@ -188,18 +195,9 @@ def jump_lh(model, sample, i_source_cluster, i_target_cluster, temperature=1.0, 
     the host; the O(n_members) tail (exponent 1/T, + EPS, ratio) is the reference's float32 arithmetic."""
     eng = _engine(model)
     _bind_slot(eng, model, sample, slot)
-    prior = model.prior.prior_cluster_effect
-    unif = np.asarray(prior.uniform_concentration_array)         # the reference uses the CLUSTER prior's uniform
-    counts = sample.feature_counts["clusters"].value             # concentration for every component (operators.py:1352)
-    kw = dict(temperature=temperature, prior_temperature=prior_temperature, unif_counts=unif)
-    p_source = eng.normalize_tables(counts[[i_source_cluster]], np.asarray(prior.concentration_array), **kw)
-    p_target = eng.normalize_tables(counts[[i_target_cluster]], np.asarray(prior.concentration_array), **kw)
-    pconf = [eng.normalize_tables(sample.feature_counts[name].value,
-                                  np.asarray(model.prior.prior_confounding_effects[name].concentration_array(sample)), **kw)
-             for name in sample.confounders]
-    pconf = np.concatenate(pconf, axis=0) if pconf else np.zeros((0,) + p_source.shape[1:], dtype=np.float32)
-    members = np.flatnonzero(sample.clusters.value[i_source_cluster])
-    logs = eng.jump_lh(slot, pconf, p_source, p_target, members, prior_temperature)
+    _bind_uniform(eng, model)          # the reference uses the CLUSTER prior's uniform concentration for every component
+    members = np.flatnonzero(sample.clusters.value[i_source_cluster])                               # (operators.py:1352)
+    logs = eng.jump_lh_resident(slot, i_source_cluster, i_target_cluster, members, temperature, prior_temperature)
     with np.errstate(under="ignore"):
         lh_stay = np.exp(logs[0]).astype(np.float32)             # np.prod over features in float32 (operators.py:1707-1710)
         lh_jump = np.exp(logs[1]).astype(np.float32)

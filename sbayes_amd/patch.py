@@ -6,6 +6,7 @@ Patches the names through which the reference reaches the path:
   sbayes.sampling.conditionals.{compute_component_likelihood, likelihood_per_component,
                                 likelihood_per_component_subset, update_weights}   (conditionals.py:14)
   sbayes.sampling.counts.{compute_effect_counts, recalculate_feature_counts, update_feature_counts}
+  sbayes.model.prior.{update_weights, normalize_weights}                          (prior.py:20)
 Only when sBayes is importable; raises otherwise.  uninstall() restores the originals.
 
 install(operators=True) additionally replaces the two heaviest consumers of the `[N, F, C]` component-likelihood
@@ -17,6 +18,7 @@ has to cross PCIe for them:
   sbayes.sampling.operators.GibbsSampleSource.calculate_source_posterior  (operators.py:554-574)
   sbayes.sampling.operators.component_likelihood_given_unchanged          (operators.py:863-928)
   sbayes.sampling.loggers.LikelihoodLogger._write_sample                  (loggers.py:354-359)
+  sbayes.model.prior.SourcePrior.__call__                                 (prior.py:573-611; per-object cache protocol kept)
   sbayes.sampling.operators.ClusterJump.get_jump_lh                       (operators.py:1679-1722, with
                                                                             expected_confounder_features :1342-1379)
   sbayes.sampling.operators.GibbsSampleWeights._propose                   (operators.py:597-636) runs UNCHANGED, but
@@ -47,6 +49,7 @@ MIRRORED_SOURCES = {
     "sbayes.sampling.operators.component_likelihood_given_unchanged": "de5b027624d8597d43f08e2577d0035607c22d51",
     "LikelihoodLogger._write_sample": "5f892d865e576862f5e1730acbf3b18efc7af9da",
     "ClusterEffectProposals.expected_confounder_features": "efb685c5e0b1f2818dde1f2244d6f0ff086107cc",
+    "SourcePrior.__call__": "c76b2825409bc280761a6b598113f74c9b395dbb",
 }
 
 
@@ -83,7 +86,7 @@ def install(operators=False):
     # the swap would bind the replacements as its "originals" and uninstall() could not restore them
     importers = []
     for modname in ("sbayes.sampling.operators", "sbayes.sampling.initializers", "sbayes.sampling.loggers",
-                    "sbayes.sampling.mcmc", "sbayes.sampling.mcmc_chain", "sbayes.mcmc_setup"):
+                    "sbayes.sampling.mcmc", "sbayes.sampling.mcmc_chain", "sbayes.mcmc_setup", "sbayes.model.prior"):
         try:
             importers.append(importlib.import_module(modname))
         except ImportError:
@@ -188,6 +191,24 @@ def _install_operator_forms(swap):
         finally:
             ref_ops.update_weights = saved_update
             ref_ops.GibbsSampleWeights.source_lh_by_feature = saved_lh
+
+    # SourcePrior.__call__ (prior.py:573-611): per-object log prior from the device, the reference's cache protocol kept
+    try:
+        ref_prior = importlib.import_module("sbayes.model.prior")
+    except ImportError:
+        ref_prior = None
+    if ref_prior is not None and hasattr(ref_prior, "SourcePrior"):
+        from . import conditionals as my_cond_sp
+        _check_mirrored(ref_prior.SourcePrior, "__call__")
+        reference_source_prior = ref_prior.SourcePrior.__call__
+
+        def source_prior_call(self, sample, caching=True):
+            owner = getattr(self, "_sbayes_amd_owner", None)     # left by sbayes_amd.likelihood.Likelihood.__init__
+            if owner is None:                                      # a SourcePrior outside a (patched) Model
+                return reference_source_prior(self, sample, caching=caching)
+            return my_cond_sp.source_prior(owner, sample, caching=caching)
+
+        swap(ref_prior.SourcePrior, "__call__", source_prior_call)
 
     for owner, name in ((ref_ops.ClusterJump, "get_jump_lh"), (ref_ops.GibbsSampleWeights, "_propose"),
                         (ref_ops.GibbsSampleWeights, "source_lh_by_feature"),

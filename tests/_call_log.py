@@ -52,8 +52,24 @@ COMPARE = {
     "source_lh_by_feature": (3e-5, 1e-5),    # float32 logs summed in float32 over the objects (N * 2^-24 / 2 at N = 1000)
     "source_posterior": "exact_at_t1",       # bit-exact at temperature 1, float32 powf tolerance when tempered
     "subset_lh": "exact_at_t1",
+    "counts_delta": "exact", "given_unchanged_lh": "exact_at_t1", "get_counts": "exact",
+    "collapsed_loglik": (2e-6, 1e-6),        # float32 per feature in the reference
+    "source_prior": (2e-6, 1e-6),            # float32 logs, fp64 accumulation on the device
+    "cluster_posterior_marginals": (1e-9, 1e-9), "jump_lh_resident": (1e-9, 1e-9),
 }
-SETTERS = {"set_groups", "set_concentration", "set_counts", "set_source", "set_weights", "update_probs"}
+SETTERS = {"set_groups", "set_concentration", "set_counts", "set_source", "set_weights", "update_probs", "set_counts_rows",
+           "set_source_rows", "set_uniform_counts", "recount"}
+
+
+_TEMPERATURE_ARG = {"source_posterior": 2, "subset_lh": 3, "given_unchanged_lh": 3}     # positional index of `temperature`
+
+
+def _temperature_of(name, args, kwargs):
+    t = kwargs.get("temperature", None)
+    i = _TEMPERATURE_ARG.get(name)
+    if t is None and i is not None and len(args) > i:
+        t = args[i]
+    return 1.0 if t is None else float(t)
 
 
 class RecordingEngine(FakeEngine):
@@ -76,19 +92,29 @@ class RecordingEngine(FakeEngine):
             return {"val": v.item()}
         return {"arr": self.store.put(np.asarray(v))}
 
-    def _result(self, name, r):
+    def _result(self, name, r, exact=None):
         if r is None:
             return None
+        if exact is None:
+            exact = COMPARE[name] == "exact"
         if isinstance(r, tuple):
-            return {"tuple": [self._result(name, x) for x in r]}
+            return {"tuple": [self._result(name, x, exact) for x in r]}
         r = np.asarray(r)
-        if r.nbytes <= FULL_RESULT_BYTES or COMPARE[name] not in ("exact",):
+        if r.nbytes <= FULL_RESULT_BYTES or not exact:
             return {"arr": self.store.put(r)}
         return {"sha": _digest(r), "shape": list(r.shape), "dtype": r.dtype.str}
 
+    def mark_step(self, i_step, operator=None):
+        """Step boundary of the sampler's MH loop (MCMCChain.step): everything logged since the previous marker is
+        what the unchanged sampler asked of the engine for this one MCMC step."""
+        self.log.append({"m": "__step__", "i": int(i_step), "op": operator})
+
     def _rec(self, name, args, kwargs, result):
+        exact = None
+        if COMPARE.get(name) == "exact_at_t1":          # bit-exact (hence a digest for a large result) at temperature 1
+            exact = _temperature_of(name, args, kwargs) == 1.0
         self.log.append({"m": name, "a": [self._arg(a) for a in args], "k": {k: self._arg(v) for k, v in kwargs.items()},
-                         "r": self._result(name, result)})
+                         "r": self._result(name, result, exact)})
 
     # -- logged surface (everything the host layer calls on an engine) -----------------------------------------
     def component_lh(self, probs, groups, changed_groups, out, na_value=0.0):
@@ -113,7 +139,9 @@ def _wrap(name):
 
 for _name in ("normalize_tables", "dirichlet_logpdf", "effect_counts", "set_groups", "set_concentration", "set_counts",
               "set_source", "set_weights", "update_probs", "cluster_marginals", "source_posterior", "subset_lh",
-              "normalize_weights", "observation_lh_exact", "jump_lh", "source_lh_by_feature"):
+              "normalize_weights", "observation_lh_exact", "jump_lh", "source_lh_by_feature", "set_counts_rows",
+              "set_source_rows", "set_uniform_counts", "counts_delta", "collapsed_loglik", "source_prior",
+              "given_unchanged_lh", "cluster_posterior_marginals", "jump_lh_resident", "recount", "get_counts"):
     setattr(RecordingEngine, _name, _wrap(_name))
 
 
@@ -168,6 +196,9 @@ def replay(path, make_engine):
     try:
         for i, c in enumerate(calls):
             name = c["m"]
+            if name == "__step__":
+                counts["__step__"] = counts.get("__step__", 0) + 1
+                continue
             args = [_load_arg(z, a) for a in c["a"]]
             kwargs = {k: _load_arg(z, v) for k, v in c["k"].items()}
             where = f"call {i} ({name})"
@@ -178,10 +209,60 @@ def replay(path, make_engine):
                 got = out
             else:
                 got = getattr(eng, name)(*args, **kwargs)
-            temperature = kwargs.get("temperature", 1.0)
-            if name in ("source_posterior", "subset_lh") and len(args) >= (3 if name == "source_posterior" else 4):
-                temperature = args[2] if name == "source_posterior" else args[3]
-            _check(name, c["r"], got, z, where, float(temperature if temperature is not None else 1.0))
+            _check(name, c["r"], got, z, where, _temperature_of(name, args, kwargs))
     finally:
         eng.close()
     return counts, meta
+
+
+def replay_timed(path, make_engine, repeats=1):
+    """Timing-only replay (bench.py's sampler_replay block): the recorded call sequence against `make_engine(n_groups)`
+    with no result checks (tests/test_gpu_call_log.py does those) and the argument arrays loaded beforehand.  Calls
+    before the first step marker (model set-up, initialiser) are excluded.  Returns a dict: steps, calls, seconds of the
+    MCMC-step part, and -- when the engine counts them (Engine.traffic) -- the bytes that crossed the ABI."""
+    import time
+    z = np.load(path, allow_pickle=False)
+    calls = json.loads(str(z["calls"]))
+    meta = json.loads(str(z["meta"]))
+    arrays = {k: z[k] for k in z.files if k.startswith("arr_")}
+    prepared = []
+    for c in calls:
+        if c["m"] == "__step__":
+            prepared.append(None)
+            continue
+        args = [_load_arg(arrays, a) for a in c["a"]]
+        kwargs = {k: _load_arg(arrays, v) for k, v in c["k"].items()}
+        prepared.append((c["m"], args, kwargs))
+    first_marker = next((i for i, c in enumerate(prepared) if c is None), len(prepared))
+    n_steps = sum(1 for c in prepared if c is None)
+    eng = make_engine(meta["n_groups"])
+    out_buf = np.empty((eng.n_objects, eng.n_features))
+    best = None
+    try:
+        for _ in range(max(1, repeats)):
+            t_steps, n_calls = 0.0, 0
+            for i, c in enumerate(prepared):
+                if i == first_marker:
+                    if hasattr(eng, "sync"):
+                        eng.sync()
+                    if hasattr(eng, "traffic"):
+                        eng.traffic(reset=True)
+                    t0 = time.perf_counter()
+                if c is None:
+                    continue
+                name, args, kwargs = c
+                if name == "component_lh":
+                    eng.component_lh(args[0], args[1], args[2], out_buf, kwargs.get("na_value", 0.0))
+                else:
+                    getattr(eng, name)(*args, **kwargs)
+                n_calls += i > first_marker
+            if hasattr(eng, "sync"):
+                eng.sync()
+            t_steps = time.perf_counter() - t0 if n_steps else 0.0
+            tr = eng.traffic() if hasattr(eng, "traffic") else None
+            if best is None or t_steps < best["seconds"]:
+                best = {"steps": n_steps, "calls": n_calls, "seconds": t_steps, "traffic": tr}
+    finally:
+        eng.close()
+    best["meta"] = meta
+    return best

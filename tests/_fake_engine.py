@@ -17,8 +17,23 @@ class FakeEngine:
         self.calls = []
         self.slots = {}                 # slot -> {"groups": {c: bool [G, N]}, "counts": {c: ...}, "weights": ...}
         self.conc = {}
-        self._bound = {}                # the real Engine's bind cache protocol (conditionals._bind_slot): every
+        self._bound = {}                # the real Engine's bind cache protocol (binding._bind_slot): every
         self._bound_conc = {}           # slot-changing method drops the slot's entry
+        self._bound_unif = None
+        self._mirror = {}
+        self.unif = None
+
+    @property
+    def group_offsets(self):
+        return np.concatenate([[0], np.cumsum(self.n_groups)]).astype(int)
+
+    @property
+    def n_groups_total(self):
+        return int(sum(self.n_groups))
+
+    def _touch(self, slot):
+        self._bound.pop(slot, None)
+        self._mirror.pop(slot, None)
 
     def close(self):
         pass
@@ -66,7 +81,7 @@ class FakeEngine:
         return self.slots.setdefault(slot, {"groups": {}, "counts": {}, "weights": None})
 
     def set_groups(self, slot, component, groups):
-        self._bound.pop(slot, None)
+        self._touch(slot)
         self.calls.append(("set_groups", component))
         self._slot(slot)["groups"][component] = np.asarray(groups, dtype=bool).copy()
 
@@ -76,12 +91,12 @@ class FakeEngine:
         self.conc[component] = np.asarray(concentration, dtype=np.float64).copy()
 
     def set_counts(self, slot, component, counts):
-        self._bound.pop(slot, None)
+        self._touch(slot)
         self.calls.append(("set_counts", component))
         self._slot(slot)["counts"][component] = np.asarray(counts, dtype=np.float32).copy()
 
     def set_source(self, slot, source):
-        self._bound.pop(slot, None)
+        self._touch(slot)
         self.calls.append(("set_source",))
         self._slot(slot)["source"] = np.asarray(source, dtype=bool).copy()
 
@@ -97,7 +112,7 @@ class FakeEngine:
         return orc.logger_row(w, lh).reshape(self.n_objects, self.n_features)
 
     def set_weights(self, slot, weights):
-        self._bound.pop(slot, None)
+        self._touch(slot)
         self.calls.append(("set_weights",))
         self._slot(slot)["weights"] = np.asarray(weights, dtype=np.float32).copy()
 
@@ -178,3 +193,105 @@ class FakeEngine:
 
     def normalize_weights(self, weights, has_components):
         return orc.normalize_weights(np.asarray(weights, dtype=np.float32), np.asarray(has_components, dtype=bool))
+
+    def recount(self, slot, component=-1):
+        self._touch(slot)
+        self.calls.append(("recount",))
+        s = self._slot(slot)
+        groups = [s["groups"][c] for c in range(len(s["groups"]))]
+        for c, table in enumerate(orc.recalculate_feature_counts(self.features, groups, s["source"])):
+            s["counts"][c] = table
+
+    def get_counts(self, slot, component):
+        return self._slot(slot)["counts"][component].copy()
+
+    # ---- round 3: delta / resident forms ------------------------------------------------------------------------
+    def set_uniform_counts(self, unif_counts):
+        self.unif = np.asarray(unif_counts, dtype=np.float64).copy()
+
+    def set_counts_rows(self, slot, group_idx, rows):
+        self._touch(slot)
+        self.calls.append(("set_counts_rows", len(group_idx)))
+        off = self.group_offsets
+        for gg, row in zip(np.asarray(group_idx), np.asarray(rows, dtype=np.float32)):
+            c = int(np.searchsorted(off, gg, side="right") - 1)
+            self._slot(slot)["counts"][c][gg - off[c]] = row
+
+    def set_source_rows(self, slot, objects, rows):
+        self._touch(slot)
+        self.calls.append(("set_source_rows", len(objects)))
+        self._slot(slot)["source"][np.asarray(objects)] = np.asarray(rows, dtype=bool)
+
+    def counts_delta(self, objects, gid_old, gid_new, src_old, src_new):
+        """(touched, diff rows) of update_feature_counts for the listed objects: the oracle's a9 on one-object
+        group matrices rebuilt from the ids."""
+        self.calls.append(("counts_delta", len(objects)))
+        objects = np.asarray(objects)
+        gid_old, gid_new = np.asarray(gid_old), np.asarray(gid_new)
+        src_old, src_new = np.asarray(src_old), np.asarray(src_new)
+        touched = np.union1d(gid_old[gid_old >= 0], gid_new[gid_new >= 0]).astype(np.int32)
+        off = self.group_offsets
+        diff = np.zeros((touched.size, self.n_features, self.n_states), dtype=np.float32)
+        feats = self.features[objects]
+        for t, gg in enumerate(touched):
+            c = int(np.searchsorted(off, gg, side="right") - 1)
+            for sign, gid, src in ((1.0, gid_new, src_new), (-1.0, gid_old, src_old)):
+                members = gid[c] == gg
+                if members.any():
+                    diff[t] += sign * np.count_nonzero((src[members] == c)[:, :, None] & feats[members], axis=0)
+        return touched, diff
+
+    def _full_state(self, slot):
+        s = self.slots[slot]
+        C = len(s["groups"])
+        return ([s["groups"][c] for c in range(C)], [s["counts"][c] for c in range(C)], [self.conc[c] for c in range(C)], s)
+
+    def collapsed_loglik(self, slot, component, per_feature=False):
+        self.calls.append(("collapsed_loglik", component))
+        _, counts, conc, _ = self._full_state(slot)
+        return orc.collapsed_group_logliks(counts[component], conc[component])
+
+    def source_prior(self, slot):
+        self.calls.append(("source_prior",))
+        groups, _, _, s = self._full_state(slot)
+        w = orc.normalize_weights(s["weights"], orc.has_components(groups))
+        return orc.source_prior_per_object(w, s["source"], self.na_values())
+
+    def given_unchanged_lh(self, slot, i_cluster, objects, temperature=1.0, prior_temperature=1.0):
+        self.calls.append(("given_unchanged_lh", len(objects)))
+        groups, counts, conc, s = self._full_state(slot)
+        subset = np.zeros(self.n_objects, dtype=bool)
+        subset[np.asarray(objects)] = True
+        return orc.component_likelihood_given_unchanged(
+            self.features, self.na_values(), groups, counts, conc, s["source"], subset, i_cluster, self.unif,
+            [self.unif] * (len(groups) - 1), temperature=temperature, prior_temperature=prior_temperature)
+
+    def cluster_posterior_marginals(self, slot, i_cluster, objects, temperature=1.0, prior_temperature=1.0):
+        _, counts, conc, _ = self._full_state(slot)
+        table = orc.conditional_effect_mean(conc[0], counts[0][[i_cluster]], unif_counts=self.unif,
+                                            prior_temperature=prior_temperature, temperature=temperature)
+        return self.cluster_marginals(slot, table, objects, prior_temperature)
+
+    def jump_lh_resident(self, slot, i_source, i_target, objects, temperature=1.0, prior_temperature=1.0):
+        self.calls.append(("jump_lh_resident", len(objects)))
+        groups, counts, conc, s = self._full_state(slot)
+        assert np.array_equal(np.asarray(objects), np.flatnonzero(groups[0][i_source]))
+        return orc.jump_log_lh(self.features, self.na_values(), groups, counts, conc, self.unif, s["weights"], i_source,
+                               i_target, temperature, prior_temperature)
+
+
+def make_get_engine(engines, cls=None):
+    """`registry.get_engine` for the tests: one double per feature block, kept in the dict `engines`.  Like the real
+    registry (which re-creates an engine whose component layout differs), a double first made by a stateless call
+    (n_groups unknown -> [1]) adopts the layout once a caller names it."""
+    cls = cls or FakeEngine
+
+    def get_engine(features, n_groups=None, n_slots=4, device=None):
+        key = (np.asarray(features).ctypes.data, np.asarray(features).shape)
+        if key not in engines:
+            engines[key] = cls(features, n_groups)
+        elif n_groups is not None and list(n_groups) != engines[key].n_groups and engines[key].n_groups == [1]:
+            engines[key].n_groups = [int(g) for g in n_groups]
+            engines[key].n_components = len(n_groups)
+        return engines[key]
+    return get_engine

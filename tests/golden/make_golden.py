@@ -801,17 +801,11 @@ def call_log_fixture(tag, config_path: Path, n_steps: int, seed: int):
     from sbayes.sampling.mcmc_chain import MCMCChain
     from sbayes_amd import conditionals, counts, likelihood, patch, registry
     from tests._call_log import RecordingEngine, save
+    from tests._fake_engine import make_get_engine
 
     engines = {}
 
-    def get_engine(features, n_groups=None, n_slots=4, device=None):
-        key = (np.asarray(features).ctypes.data, np.asarray(features).shape)
-        if key not in engines:
-            engines[key] = RecordingEngine(features, n_groups)
-        elif n_groups is not None and list(n_groups) != engines[key].n_groups and engines[key].n_groups == [1]:
-            engines[key].n_groups = list(n_groups)                # first seen through a stateless call
-            engines[key].n_components = len(n_groups)
-        return engines[key]
+    get_engine = make_get_engine(engines, RecordingEngine)
 
     def engine_for_features(f):                               # registry.engine_for_features with the double
         for e in engines.values():
@@ -843,12 +837,14 @@ def call_log_fixture(tag, config_path: Path, n_steps: int, seed: int):
         chain._ll = chain.likelihood(sample)
         chain._prior = chain.prior(sample)
         ops = []
+        assert len(engines) == 1, f"{len(engines)} engines were created"
+        eng = next(iter(engines.values()))
         for i in range(1, n_steps + 1):
+            eng.mark_step(i)
             sample = chain.step(sample)
             sample.i_step = i
             ops.append(chain.previous_operator.operator_name)
-        assert len(engines) == 1, f"{len(engines)} engines were created"
-        eng = next(iter(engines.values()))
+            eng.log[-1 - next(k for k, c in enumerate(reversed(eng.log)) if c["m"] == "__step__")]["op"] = ops[-1]
         meta = dict(tag=tag, n_steps=n_steps, seed=seed, n_groups=[int(g) for g in eng.n_groups],
                     shape=list(data.features.values.shape), features_crc=crc(data.features.values),
                     operators=sorted(set(ops)), final_ll=float(chain._ll))
@@ -871,6 +867,7 @@ def call_log_fixtures():
     sa = stage_config(Path("/root/reference/experiments/south_america"), "south_america_calls")
     call_log_fixture("south_america", sa / "config.yaml", n_steps=60, seed=22)
     call_log_fixture("cfg1", write_synthetic_config("cfg1"), n_steps=80, seed=23)
+    call_log_fixture("headline", write_synthetic_config("headline"), n_steps=48, seed=24)
 
 
 def main():

@@ -10,20 +10,23 @@ from tests._fixtures import GOLDEN, crc, load_npz
 
 
 def features_of(tag):
-    if tag == "cfg1":
+    if tag in ("cfg1", "headline"):
         from sbayes_amd.synthetic import make_workload
-        return make_workload("cfg1").features
+        return make_workload(tag).features
     return load_npz(tag).features
 
 
-@pytest.mark.parametrize("tag", ["test_files", "south_america", "cfg1"])
+@pytest.mark.parametrize("tag", ["test_files", "south_america", "cfg1", "headline"])
 def test_call_log_replays_on_the_double(tag):
     feats = features_of(tag)
     counts, meta = replay(GOLDEN / f"{tag}_calls.npz", lambda n_groups: FakeEngine(feats, n_groups))
     assert crc(feats) == meta["features_crc"] and list(feats.shape) == meta["shape"]
     # the operator forms and the collapsed likelihood really ran through the engine surface
-    assert {"cluster_marginals", "source_posterior", "subset_lh", "dirichlet_logpdf", "normalize_tables",
-            "effect_counts", "set_counts", "set_groups", "set_weights"} <= set(counts)
+    assert {"cluster_marginals", "cluster_posterior_marginals", "source_posterior", "given_unchanged_lh", "collapsed_loglik",
+            "counts_delta", "source_prior", "set_counts", "set_counts_rows", "set_source_rows", "set_groups",
+            "set_weights", "__step__"} <= set(counts)
+    # round 3: no whole [N, F] mask and no stateless whole-table call is left on the per-step path
+    assert not {"effect_counts", "dirichlet_logpdf"} & set(counts)
     assert {"AlterCluster", "GibbsSampleSource"} <= set(meta["operators"])
     # through the bind cache: fewer uploads than evaluations
     assert counts["set_groups"] < counts["cluster_marginals"] + counts["source_posterior"]

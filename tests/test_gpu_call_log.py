@@ -16,8 +16,8 @@ from tests.test_call_log_cpu import features_of
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("tag", ["test_files", "south_america", "cfg1"])
+@pytest.mark.parametrize("tag", ["test_files", "south_america", "cfg1", "headline"])
 def test_recorded_sampler_calls_on_the_device(tag):
     feats = features_of(tag)
     counts, meta = replay(GOLDEN / f"{tag}_calls.npz", lambda n_groups: Engine(feats, n_groups, n_slots=4))
-    assert sum(counts.values()) > 1000
+    assert sum(counts.values()) > 800 and counts["__step__"] >= 48

@@ -1,0 +1,162 @@
+"""Round-3 delta / resident forms of the drop-in layer on the device (include/sbe_engine.h "round 3"): what the
+unchanged reference sampler asks per MCMC step, as object lists and changed rows.  Every form is checked against the
+oracle-backed double (tests/_fake_engine.py: the NumPy restatement of the reference expressions) on the same state:
+
+  counts_delta                 update_feature_counts               sbayes/sampling/counts.py:55-95        bit-exact
+  set_counts_rows              (bind cache delta upload)                                                  bit-exact
+  given_unchanged_lh           component_likelihood_given_unchanged operators.py:863-928   bit-exact at T = 1,
+                                                                                            2e-6 tempered (float32 powf)
+  cluster_posterior_marginals  AlterCluster.compute_cluster_posterior operators.py:1035-1073              1e-9 (log space)
+  jump_lh_resident             ClusterJump.get_jump_lh              operators.py:1679-1722                1e-9
+"""
+import numpy as np
+import pytest
+
+from sbayes_amd.engine import Engine
+from sbayes_amd.synthetic import make_state, make_workload
+from tests._fake_engine import FakeEngine
+from tests._fixtures import load_npz
+
+pytestmark = pytest.mark.gpu
+
+
+def _workload(name):
+    if name in ("south_america", "cfg1_fixture"):
+        fx = load_npz("south_america" if name == "south_america" else "cfg1")
+        unif = fx.states_per_feature.astype(np.float64)
+        return fx.features, fx.groups, fx.conc, fx.weights, fx.source, fx.counts, unif
+    if name == "wide":                                   # several 64-feature tiles, S = 33, three confounders
+        wl = make_workload("wide", shape=(260, 150, 33, 4, (3, 5), True))
+    else:
+        wl = make_workload(name)
+    from oracle import sbayes_oracle as orc
+    counts = orc.recalculate_feature_counts(wl.features, wl.groups, wl.source)
+    return wl.features, wl.groups, wl.concentration, wl.weights, wl.source, counts, wl.states_per_feature.astype(np.float64)
+
+
+def _pair(name):
+    feats, groups, conc, weights, source, counts, unif = _workload(name)
+    n_groups = [g.shape[0] for g in groups]
+    eng, fake = Engine(feats, n_groups, n_slots=2), FakeEngine(feats, n_groups)
+    for e in (eng, fake):
+        for c in range(len(groups)):
+            e.set_concentration(c, conc[c])
+            e.set_groups(0, c, groups[c])
+            e.set_counts(0, c, counts[c])
+        e.set_source(0, source)
+        e.set_weights(0, weights)
+        e.set_uniform_counts(unif)
+    for c in range(len(groups)):
+        eng.update_probs(0, c)
+    return eng, fake, groups, source, counts
+
+
+def _ids(groups, objs, off):
+    sub = groups[:, objs]
+    return np.where(sub.any(axis=0), sub.argmax(axis=0) + off, -1).astype(np.int32)
+
+
+@pytest.mark.parametrize("name", ["cfg1_fixture", "south_america", "headline", "wide"])
+def test_counts_delta_and_row_uploads(name):
+    eng, fake, groups, source, counts = _pair(name)
+    try:
+        rng = np.random.default_rng(7)
+        N, F, C = source.shape
+        K = groups[0].shape[0]
+        off = eng.group_offsets
+        for n in (1, 2, 30, min(N, 700)):
+            objs = np.sort(rng.choice(N, size=min(n, N), replace=False))
+            new_clusters = groups[0].copy()
+            new_clusters[:, objs] = False
+            move = rng.integers(0, K + 1, size=objs.size)                  # K = leaves every cluster
+            new_clusters[move[move < K], objs[move < K]] = True
+            new_source = source.copy()
+            pick = rng.integers(0, C + 1, size=(objs.size, F))             # C = no source (an NA-like row)
+            new_source[objs] = pick[..., None] == np.arange(C)
+            gid_old = np.stack([_ids(groups[c], objs, off[c]) for c in range(C)])
+            gid_new = gid_old.copy()
+            gid_new[0] = _ids(new_clusters, objs, 0)
+            so = np.where(source[objs].any(-1), source[objs].argmax(-1), 255).astype(np.uint8)
+            sn = np.where(new_source[objs].any(-1), new_source[objs].argmax(-1), 255).astype(np.uint8)
+            touched, diff = eng.counts_delta(objs, gid_old, gid_new, so, sn)
+            want_t, want_d = fake.counts_delta(objs, gid_old, gid_new, so, sn)
+            assert np.array_equal(touched, want_t)
+            assert diff.dtype == np.float32 and np.array_equal(diff, want_d), (name, n)
+            # ... and it is the reference's new_counts - old_counts, component by component
+            from oracle import sbayes_oracle as orc
+            all_groups_new = [new_clusters] + list(groups[1:])
+            for c in range(C):
+                ref = (orc.compute_effect_counts(fake.features, all_groups_new[c], new_source[..., c], objs)
+                       - orc.compute_effect_counts(fake.features, groups[c], source[..., c], objs))
+                full = np.zeros_like(ref)
+                mine = (touched >= off[c]) & (touched < off[c + 1])
+                full[touched[mine] - off[c]] = diff[mine]
+                assert np.array_equal(full, ref), (name, n, c)
+        # delta upload of count rows: only the listed groups change
+        for c in range(C):
+            g = int(rng.integers(0, groups[c].shape[0]))
+            row = rng.integers(0, 50, size=counts[c][g].shape).astype(np.float32)
+            eng.set_counts_rows(0, [off[c] + g], row[None])
+            want = counts[c].copy()
+            want[g] = row
+            assert np.array_equal(eng.get_counts(0, c), want)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("name", ["cfg1_fixture", "south_america", "headline", "wide"])
+def test_resident_operator_forms(name):
+    eng, fake, groups, source, counts = _pair(name)
+    try:
+        rng = np.random.default_rng(11)
+        N = source.shape[0]
+        K = groups[0].shape[0]
+        for temp, ptemp in ((1.0, 1.0), (1.3, 1.5)):
+            for k in range(min(K, 3)):
+                # component_likelihood_given_unchanged: subsets of 1, a few, and many objects
+                for n in (1, 9, min(N, 300)):
+                    objs = np.sort(rng.choice(N, size=min(n, N), replace=False))
+                    got = eng.given_unchanged_lh(0, k, objs, temp, ptemp)
+                    want = fake.given_unchanged_lh(0, k, objs, temp, ptemp)
+                    assert got.dtype == np.float32 and got.shape == want.shape
+                    if temp == 1.0:
+                        assert np.array_equal(got, want), (name, k, n)
+                    else:
+                        np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-7)
+                # cluster-membership marginals of the available objects with the candidate table built on the device
+                available = np.flatnonzero(~groups[0].any(axis=0) | groups[0][k])
+                got = eng.cluster_posterior_marginals(0, k, available, temp, ptemp)
+                want = fake.cluster_posterior_marginals(0, k, available, temp, ptemp)
+                np.testing.assert_allclose(got, want, rtol=1e-9 if temp == 1.0 else 2e-6, atol=1e-9)
+                # the explicit-table form gives the same numbers (same kernel, table from the stateless a10 call)
+                table = eng.normalize_tables(counts[0][[k]], fake.conc[0], temperature=temp, prior_temperature=ptemp,
+                                             unif_counts=fake.unif)
+                assert np.array_equal(eng.cluster_marginals(0, table, available, ptemp), got)
+                # ClusterJump: members of cluster k staying / jumping to the next cluster
+                if K > 1 and groups[0][k].any():
+                    members = np.flatnonzero(groups[0][k])
+                    got = eng.jump_lh_resident(0, k, (k + 1) % K, members, temp, ptemp)
+                    want = fake.jump_lh_resident(0, k, (k + 1) % K, members, temp, ptemp)
+                    np.testing.assert_allclose(got, want, rtol=1e-9 if ptemp == 1.0 else 2e-6, atol=1e-9)
+        # per-group collapsed values and the per-object source prior from the resident state
+        for c in range(len(groups)):
+            np.testing.assert_allclose(eng.collapsed_loglik(0, c), fake.collapsed_loglik(0, c), rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(eng.source_prior(0), fake.source_prior(0), rtol=2e-6, atol=1e-6)
+    finally:
+        eng.close()
+
+
+def test_argument_checks():
+    eng, fake, groups, source, counts = _pair("cfg1_fixture")
+    try:
+        with pytest.raises(Exception, match="out of range"):
+            eng.given_unchanged_lh(0, 99, [0])
+        with pytest.raises(Exception, match="out of range"):
+            eng.cluster_posterior_marginals(0, 0, [10 ** 6])
+        with pytest.raises(Exception, match="out of range"):
+            eng.set_counts_rows(0, [10 ** 6], np.zeros((1,) + counts[0].shape[1:], dtype=np.float32))
+        touched, diff = eng.counts_delta(np.zeros(0, dtype=np.int32), np.zeros((len(groups), 0)), np.zeros((len(groups), 0)),
+                                         np.zeros((0, source.shape[1])), np.zeros((0, source.shape[1])))
+        assert touched.size == 0 and diff.shape[0] == 0
+    finally:
+        eng.close()

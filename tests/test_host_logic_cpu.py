@@ -10,7 +10,7 @@ import pytest
 from sbayes_amd import conditionals, likelihood, registry
 from sbayes_amd import model as sbm
 from sbayes_amd.counts import recalculate_feature_counts, update_feature_counts
-from tests._fake_engine import FakeEngine
+from tests._fake_engine import FakeEngine, make_get_engine
 from tests._fixtures import load_npz, load_synthetic_trace, load_trace, sha
 
 
@@ -18,11 +18,7 @@ from tests._fixtures import load_npz, load_synthetic_trace, load_trace, sha
 def fake(monkeypatch):
     engines = {}
 
-    def get_engine(features, n_groups=None, n_slots=4, device=None):
-        key = (np.asarray(features).ctypes.data, np.asarray(features).shape)
-        if key not in engines:
-            engines[key] = FakeEngine(features, n_groups)
-        return engines[key]
+    get_engine = make_get_engine(engines)
 
     for mod in (registry, likelihood, conditionals):
         monkeypatch.setattr(mod, "get_engine", get_engine, raising=True)
@@ -134,9 +130,10 @@ def test_bind_cache_sees_in_place_edits(fake):
     eng.calls.clear()
     stale = conditionals._bind_slot(eng, model, sample, 0, with_source=True)
     kinds = [c[0] for c in eng.calls]
-    assert kinds.count("set_weights") == 1 and kinds.count("set_source") == 1
-    assert ("set_groups", 0) in [c[:2] for c in eng.calls] and ("set_counts", 0) in [c[:2] for c in eng.calls]
-    assert ("set_counts", 1) not in [c[:2] for c in eng.calls] and 0 in stale
+    # round 3: only the DELTA goes up -- the one object's source row, the one group's count row
+    assert kinds.count("set_weights") == 1 and "set_source" not in kinds and "set_counts" not in kinds
+    assert ("set_source_rows", 1) in eng.calls and ("set_counts_rows", 1) in eng.calls
+    assert ("set_groups", 0) in [c[:2] for c in eng.calls] and 0 in stale
     st = eng._slot(0)
     assert np.array_equal(st["weights"], sample.weights.value) and np.array_equal(st["source"], sample.source.value)
     assert np.array_equal(st["counts"][0], sample.feature_counts["clusters"].value)

@@ -34,17 +34,13 @@ def run_chain(config_src: Path, tag: str, n_steps: int, seed: int, patched: bool
     from sbayes.sampling.mcmc_chain import MCMCChain
 
     from sbayes_amd import conditionals, counts, likelihood, patch, registry
-    from tests._fake_engine import FakeEngine
+    from tests._fake_engine import FakeEngine, make_get_engine
 
     work = tmp_path / f"{tag}_{'patched' if patched else 'plain'}{'_ops' if operators else ''}"
     shutil.copytree(config_src, work)
     engines = {}
 
-    def get_engine(features, n_groups=None, n_slots=4, device=None):
-        key = (np.asarray(features).ctypes.data, np.asarray(features).shape)
-        if key not in engines:
-            engines[key] = FakeEngine(features, n_groups)
-        return engines[key]
+    get_engine = make_get_engine(engines)
 
     if patched:
         for mod in (registry, likelihood, conditionals, counts):
@@ -102,7 +98,7 @@ def test_reference_sampler_on_drop_in_layer_is_the_same_markov_chain(tag, src, n
     assert np.array_equal(patched[3], plain[3])
     eng = next(iter(patched[4].values()))
     kinds = {c[0] for c in eng.calls}
-    assert {"component_lh", "normalize_tables", "dirichlet_logpdf"} <= kinds   # the path really ran through the layer
+    assert {"component_lh", "normalize_tables", "collapsed_loglik", "counts_delta"} <= kinds   # the path really ran through the layer
 
 
 @pytest.mark.parametrize("tag,src,n_steps", [
@@ -123,15 +119,20 @@ def test_reference_sampler_with_device_operator_forms(tag, src, n_steps, monkeyp
     assert np.array_equal(patched[3], plain[3])
     eng = next(iter(patched[4].values()))
     kinds = {c[0] for c in eng.calls}
-    assert {"cluster_marginals", "source_posterior", "subset_lh", "source_lh_by_feature"} <= kinds   # the operator forms really ran
+    assert {"cluster_marginals", "source_posterior", "given_unchanged_lh", "source_lh_by_feature", "source_prior",
+            "counts_delta", "collapsed_loglik"} <= kinds                             # the operator forms really ran
     if tag == "south_america":                                                    # (test_files has one cluster: no jumps)
-        assert "jump_lh" in kinds and "ClusterJump" in {t[2] for t in patched[0]}
+        assert "jump_lh_resident" in kinds and "ClusterJump" in {t[2] for t in patched[0]}
     names = {t[2] for t in patched[0]}
     assert {"AlterCluster", "AlterClusterWide", "GibbsSampleSource", "GibbsSampleWeights"} <= names, names   # every patched form was hit
     # ... through the bind cache: far fewer uploads than evaluations (and, above, the same chain)
     n_eval = sum(c[0] in ("cluster_marginals", "source_posterior") for c in eng.calls)
     n_counts = sum(c[0] == "set_counts" for c in eng.calls)
     assert n_counts < n_eval * len(eng.conc), (n_counts, n_eval, len(eng.conc))
+    # round 3: after the first binds only DELTAS go up -- whole count tables / whole source arrays are the exception
+    n_rows = sum(c[0] in ("set_counts_rows", "set_source_rows") for c in eng.calls)
+    n_full = sum(c[0] in ("set_counts", "set_source") for c in eng.calls)
+    assert n_rows > 0 and (tag == "test_files" or n_full < n_rows), (n_full, n_rows)
 
 
 def test_operator_forms_are_tied_to_the_reference_bodies_they_mirror(monkeypatch):
@@ -180,12 +181,10 @@ def test_likelihood_logger_row_from_the_device_form(monkeypatch, tmp_path):
         # a sampler state to log: rebuild it the same way in both worlds (seeded), then call the logger's method
         sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
         from sbayes_amd import conditionals, counts, likelihood, patch, registry
-        from tests._fake_engine import FakeEngine
+        from tests._fake_engine import FakeEngine, make_get_engine
         engines = {}
 
-        def get_engine(features, n_groups=None, n_slots=4, device=None):
-            key = (np.asarray(features).ctypes.data, np.asarray(features).shape)
-            return engines.setdefault(key, FakeEngine(features, n_groups))
+        get_engine = make_get_engine(engines)
 
         if patched:
             for mod in (registry, likelihood, conditionals, counts):

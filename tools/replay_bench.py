@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Device cost of the UNCHANGED reference sampler: replay the recorded engine-level call logs of the real sampler
+(tests/golden/*_calls.npz) against the real Engine and -- as the same-host CPU baseline -- against the oracle-backed
+double, and print wall time per recorded MCMC step, calls and ABI bytes per step.  (bench.py's sampler_replay block
+runs the same function.)   python tools/replay_bench.py [tag ...]"""
+import json
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+
+from tests._call_log import replay_timed          # noqa: E402
+from tests._fake_engine import FakeEngine          # noqa: E402
+from tests.test_call_log_cpu import features_of    # noqa: E402
+
+
+def run(tag, path=None, cpu=True, repeats=3, device=0):
+    from sbayes_amd.engine import Engine
+    path = path or REPO / "tests" / "golden" / f"{tag}_calls.npz"
+    base = tag.replace("_before", "")
+    feats = features_of(base)
+    gpu = replay_timed(path, lambda n_groups: Engine(feats, n_groups, n_slots=4, device=device), repeats=repeats)
+    out = {"tag": tag, "steps": gpu["steps"], "calls_per_step": round(gpu["calls"] / max(1, gpu["steps"]), 1),
+           "gpu_us_per_step": round(gpu["seconds"] / max(1, gpu["steps"]) * 1e6, 1)}
+    if gpu["traffic"]:
+        h2d, d2h, n_abi = gpu["traffic"]
+        out.update(h2d_bytes_per_step=round(h2d / max(1, gpu["steps"])), d2h_bytes_per_step=round(d2h / max(1, gpu["steps"])),
+                   abi_calls_per_step=round(n_abi / max(1, gpu["steps"]), 1))
+    if cpu:
+        ref = replay_timed(path, lambda n_groups: FakeEngine(feats, n_groups), repeats=1)
+        out["cpu_us_per_step"] = round(ref["seconds"] / max(1, ref["steps"]) * 1e6, 1)
+        out["speedup"] = round(out["cpu_us_per_step"] / out["gpu_us_per_step"], 2)
+    return out
+
+
+if __name__ == "__main__":
+    for tag in sys.argv[1:] or ["cfg1", "south_america", "headline"]:
+        print(json.dumps(run(tag)), flush=True)
