@@ -1688,12 +1688,20 @@ int sbe_collapsed_loglik(sbe_engine* e, int slot, int component, double* per_gro
     k_dcl<int32_t><<<div_up((int64_t)G * e->F, 256), 256, 0, e->stream>>>(e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc,
                                                                        d_pf, g_lo, g_lo + G, e->F, e->S, 1);
     HIPCHK(e, hipGetLastError());
+    if (!per_feature_out) {                    // the G doubles land in host-mapped memory: no copy-engine hop in the chain
+        rc = ensure_io(e, (size_t)G * sizeof(double));
+        if (rc) return rc;
+        k_group_sum_f32<<<div_up(G, 64), 64, 0, e->stream>>>(d_pf, (double*)e->d_io, G, e->F);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        memcpy(per_group_out, e->h_io, (size_t)G * sizeof(double));
+        return synced(e);
+    }
     k_group_sum_f32<<<div_up(G, 64), 64, 0, e->stream>>>(d_pf, d_pg, G, e->F);
     HIPCHK(e, hipGetLastError());
     rc = d2h(e, per_group_out, d_pg, (size_t)G * sizeof(double));
     if (rc) return rc;
-    if (per_feature_out) return d2h(e, per_feature_out, d_pf, (size_t)G * e->F * sizeof(float));
-    return SBE_OK;
+    return d2h(e, per_feature_out, d_pf, (size_t)G * e->F * sizeof(float));
 }
 
 
@@ -2217,12 +2225,18 @@ int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const 
     const size_t o_sn = o;   memcpy(h + o, src_new, (size_t)n_subset * F); o += sb;
     const size_t o_t = o;    memcpy(h + o, touched, (size_t)n_touched * 4); o += tb;
     const size_t o_tc = o;   memcpy(h + o, comp.data(), (size_t)n_touched * 4); o += tb;
-    float* d_out = nullptr;
-    if (mapped_out) d_out = (float*)(e->d_io + o);
-    else { rc = ensure_scratch(e, out_bytes); if (rc) return rc; d_out = (float*)e->d_scratch; }
+    // the kernel walks the listed objects one after another (ids, then the object's rows): out of host-mapped memory
+    // every step of that walk would be a PCIe round trip, so the packed inputs go to device memory with ONE copy from
+    // the pinned block; the diff rows come back through the mapped block (posted writes)
+    const size_t in_bytes = o;
+    rc = ensure_scratch(e, in_bytes + (mapped_out ? 0 : out_bytes));
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpyAsync(e->d_scratch, h, in_bytes, hipMemcpyHostToDevice, e->stream));
+    const uint8_t* din = e->d_scratch;
+    float* d_out = mapped_out ? (float*)(e->d_io + o) : (float*)(e->d_scratch + in_bytes);
     k_counts_delta<<<dim3(n_touched, div_up(F, 64)), kBlock, (size_t)64 * S * sizeof(int32_t), e->stream>>>(
-        e->d_state, (const int32_t*)(e->d_io + o_obj), n_subset, (const int32_t*)(e->d_io + o_go), (const int32_t*)(e->d_io + o_gn),
-        e->d_io + o_so, e->d_io + o_sn, (const int32_t*)(e->d_io + o_t), (const int32_t*)(e->d_io + o_tc), d_out, F, S, e->Fp);
+        e->d_state, (const int32_t*)(din + o_obj), n_subset, (const int32_t*)(din + o_go), (const int32_t*)(din + o_gn),
+        din + o_so, din + o_sn, (const int32_t*)(din + o_t), (const int32_t*)(din + o_tc), d_out, F, S, e->Fp);
     HIPCHK(e, hipGetLastError());
     if (!mapped_out) return d2h(e, out_diff, d_out, out_bytes);
     HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -2299,7 +2313,7 @@ int sbe_given_unchanged_lh(sbe_engine* e, int slot, int i_cluster, const int32_t
     float* d_out = mapped_out ? (float*)(e->d_io + ob + mb + gb + fb) : (float*)(e->d_scratch + 2 * cb);
     rc = clear_status_word(e, ST_BAD_NORMALIZE);
     if (rc) return rc;
-    k_unchanged_counts<<<dim3(R, div_up(F, 64)), kBlock, (size_t)64 * S * sizeof(int32_t), e->stream>>>(
+    k_unchanged_counts<<<dim3(R, div_up(F, 16)), kBlock, (size_t)16 * S * sizeof(int32_t), e->stream>>>(
         e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_src + (int64_t)slot * N * e->Fp,
         e->d_counts + (int64_t)slot * e->table_elems(), e->d_io + ob, (const int32_t*)e->d_io, n_sub, e->d_comp_of_group,
         i_cluster, K, N, e->Np, F, S, e->Fp, d_cnt);

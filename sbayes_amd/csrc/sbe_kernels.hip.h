@@ -2782,23 +2782,26 @@ __global__ __launch_bounds__(kBlock) void k_unchanged_counts(
     const uint8_t* __restrict__ in_subset /* [N] */, const int32_t* __restrict__ objects, int n_sub,
     const int32_t* __restrict__ comp_of_group /* [Gtot] */, int i_cluster, int K, int N, int Np, int F, int S, int Fp,
     float* __restrict__ out /* [1 + Gtot - K][F][S] */) {
+    // 16 features x 16 object lanes: row 0 walks ALL objects (the cluster's members are found by id), so the object
+    // axis gets the lanes; a wave reads four 16-byte runs of four state rows per step
+    constexpr int FTU = 16, OL = kBlock / FTU;
     extern __shared__ int32_t hist[];
-    const int r = blockIdx.x, f0 = blockIdx.y * 64;
-    for (int i = threadIdx.x; i < 64 * S; i += kBlock) hist[i] = 0;
+    const int r = blockIdx.x, f0 = blockIdx.y * FTU;
+    for (int i = threadIdx.x; i < FTU * S; i += kBlock) hist[i] = 0;
     __syncthreads();
-    const int fl = threadIdx.x & 63, ol = threadIdx.x >> 6;
+    const int fl = threadIdx.x & (FTU - 1), ol = threadIdx.x / FTU;
     const int f = f0 + fl;
     if (f < F) {
         if (r == 0) {
             const uint16_t want = (uint16_t)i_cluster;                  // component 0: global index = cluster index
-            for (int n = ol; n < N; n += kBlock / 64) {
+            for (int n = ol; n < N; n += OL) {
                 if (gid[n] != want || in_subset[n]) continue;
                 const uint8_t x = state[(int64_t)n * Fp + f];
                 if (x != kNA && src[(int64_t)n * Fp + f] == 0) atomicAdd(&hist[fl * S + x], 1);
             }
         } else {
             const int gg = K + r - 1, c = comp_of_group[gg];
-            for (int i = ol; i < n_sub; i += kBlock / 64) {
+            for (int i = ol; i < n_sub; i += OL) {
                 const int n = objects[i];
                 if (gid[(int64_t)c * Np + n] != (uint16_t)gg) continue;
                 const uint8_t x = state[(int64_t)n * Fp + f];
@@ -2807,7 +2810,7 @@ __global__ __launch_bounds__(kBlock) void k_unchanged_counts(
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 64 * S; i += kBlock) {
+    for (int i = threadIdx.x; i < FTU * S; i += kBlock) {
         const int ff = f0 + i / S;
         if (ff >= F) continue;
         const int s = i % S;

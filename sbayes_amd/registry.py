@@ -60,6 +60,11 @@ def get_engine(features, n_groups=None, n_slots=4, device=None) -> Engine:
                           "share the resident copy", RuntimeWarning, stacklevel=2)
             break
     eng = Engine(features, list(n_groups) if n_groups is not None else [1], n_slots=n_slots, device=device)
+    # the drop-in layer's state-setting calls (bind cache: changed rows, ids, weights, table rebuilds) never stall the
+    # stream: a data check they raise (normalize's positive-sum assert, a source row that is not one-hot) is reported
+    # by the next call that fetches a result -- in the same host function, a few lines later
+    if hasattr(eng, "set_option"):                  # (test doubles without options)
+        eng.set_option(deferred_checks=True)
     try:
         ref = weakref.ref(features)
     except TypeError:

@@ -215,7 +215,7 @@ def replay(path, make_engine):
     return counts, meta
 
 
-def replay_timed(path, make_engine, repeats=1):
+def replay_timed(path, make_engine, repeats=1, by_method=None):
     """Timing-only replay (bench.py's sampler_replay block): the recorded call sequence against `make_engine(n_groups)`
     with no result checks (tests/test_gpu_call_log.py does those) and the argument arrays loaded beforehand.  Calls
     before the first step marker (model set-up, initialiser) are excluded.  Returns a dict: steps, calls, seconds of the
@@ -251,10 +251,16 @@ def replay_timed(path, make_engine, repeats=1):
                 if c is None:
                     continue
                 name, args, kwargs = c
+                if by_method is not None and i > first_marker:
+                    t_call = time.perf_counter()
                 if name == "component_lh":
                     eng.component_lh(args[0], args[1], args[2], out_buf, kwargs.get("na_value", 0.0))
                 else:
                     getattr(eng, name)(*args, **kwargs)
+                if by_method is not None and i > first_marker:
+                    acc = by_method.setdefault(name, [0, 0.0])
+                    acc[0] += 1
+                    acc[1] += time.perf_counter() - t_call
                 n_calls += i > first_marker
             if hasattr(eng, "sync"):
                 eng.sync()

@@ -20,7 +20,12 @@ def run(tag, path=None, cpu=True, repeats=3, device=0):
     path = path or REPO / "tests" / "golden" / f"{tag}_calls.npz"
     base = tag.replace("_before", "")
     feats = features_of(base)
-    gpu = replay_timed(path, lambda n_groups: Engine(feats, n_groups, n_slots=4, device=device), repeats=repeats)
+
+    def make(n_groups):                                # the engine as the drop-in layer creates it (registry.get_engine)
+        eng = Engine(feats, n_groups, n_slots=4, device=device)
+        eng.set_option(deferred_checks=True)
+        return eng
+    gpu = replay_timed(path, make, repeats=repeats)
     out = {"tag": tag, "steps": gpu["steps"], "calls_per_step": round(gpu["calls"] / max(1, gpu["steps"]), 1),
            "gpu_us_per_step": round(gpu["seconds"] / max(1, gpu["steps"]) * 1e6, 1)}
     if gpu["traffic"]:
@@ -34,6 +39,27 @@ def run(tag, path=None, cpu=True, repeats=3, device=0):
     return out
 
 
+def by_method(tag):
+    """Where the per-step time goes: wall time inside each Engine method over one replay (setters are asynchronous:
+    their cost shows up in the next call that synchronises)."""
+    from sbayes_amd.engine import Engine
+    feats = features_of(tag)
+    acc = {}
+    def make(n_groups):
+        eng = Engine(feats, n_groups, n_slots=4)
+        eng.set_option(deferred_checks=True)
+        return eng
+    res = replay_timed(REPO / "tests" / "golden" / f"{tag}_calls.npz", make, 1, acc)
+    steps = max(1, res["steps"])
+    return {k: {"calls_per_step": round(n / steps, 2), "us_per_call": round(t / n * 1e6, 1), "us_per_step": round(t / steps * 1e6, 1)}
+            for k, (n, t) in sorted(acc.items(), key=lambda kv: -kv[1][1])}
+
+
 if __name__ == "__main__":
-    for tag in sys.argv[1:] or ["cfg1", "south_america", "headline"]:
-        print(json.dumps(run(tag)), flush=True)
+    args = sys.argv[1:]
+    if args and args[0] == "--by-method":
+        for tag in args[1:] or ["headline"]:
+            print(json.dumps({"tag": tag, "by_method": by_method(tag)}), flush=True)
+    else:
+        for tag in args or ["cfg1", "south_america", "headline"]:
+            print(json.dumps(run(tag)), flush=True)
