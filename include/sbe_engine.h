@@ -68,6 +68,10 @@ typedef struct sbe_engine sbe_engine;
 #define SBE_OPT_STEP_FORM 4         /* sbe_step: 0 = few-launch form whenever the step fits its payload
                                        (default), 1 = always the call-by-call form (testing / A-B)   */
 
+#define SBE_OPT_STEP_DERIVE 5       /* one-call steps: 0 = the has_components patterns / group tuples of a candidate are updated
+                                       from the current slot's for the moved objects only (default), 1 = always derived
+                                       from all objects (testing / A-B) */
+
 typedef struct sbe_info {
     int32_t abi_version;
     int32_t device;

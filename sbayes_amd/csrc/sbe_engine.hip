@@ -39,6 +39,11 @@ struct Slot {
     bool groups_set = false, weights_set = false, source_set = false;
     std::vector<uint8_t> probs_set, counts_set;   // per component
     bool patterns_dirty = true;
+    // round 3: object counts behind the pattern / tuple tables, so that a step which moves a few objects updates the
+    // tables in O(moved objects) instead of re-deriving them from all N (prepare_step); valid while inc_ok
+    std::vector<int32_t> pat_cnt;         // [256] objects per has_components bit pattern
+    std::vector<int32_t> tup_cnt;         // [kMaxTuples] objects per group tuple
+    bool inc_ok = false;
     uint64_t group_epoch = 0;             // identifies the content of the slot's group / pattern ids (k_rowoff's inputs)
 };
 
@@ -95,6 +100,7 @@ struct sbe_engine {
     uint8_t* d_tuple_p = nullptr;  // [slots][kMaxTuples]
     double* d_conc = nullptr;      // [Gtot][F][S]
     double* d_unif = nullptr;      // [F][S]  staging of the per-call unif_counts argument
+    double* d_lg_conc = nullptr; double* d_sum_a = nullptr; double* d_lg_sum_a = nullptr;   // k_conc_lgamma: [Gtot][F][S], [Gtot][F] x 2
     double* d_unif_res = nullptr;  bool unif_set = false;   // [F][S] resident (sbe_set_uniform_counts): the resident operator forms
     int32_t* d_comp_of_group = nullptr;                     // [Gtot] mixture component of every global group index
     std::vector<uint8_t> conc_set;
@@ -110,7 +116,7 @@ struct sbe_engine {
     double* d_step_pg = nullptr;   // [Gtot]     per-group collapsed log-likelihood of the fused step call
     // one-call step (sbe_step): payload sections (byte offsets into d_step_payload / its pinned staging copy) and
     // the host-mapped result block (per-group values | data-check words | changed-group flags)
-    struct StepLayout { size_t ids, pid, tid, toff, tuple_g, tuple_p, patbits, weights, row_of, subset, objects, rows, total; } sl{};
+    struct StepLayout { size_t ids, pid, tid, toff, tuple_g, tuple_p, patbits, weights, row_of, subset, stale, objects, rows, total; } sl{};
     int step_max_rows = 0;
     uint8_t* h_step_payload = nullptr; uint8_t* d_step_payload = nullptr;   // host-mapped pinned: the kernels read it over PCIe
     uint8_t* h_io = nullptr; uint8_t* d_io = nullptr; size_t io_bytes = 0;  // host-mapped pinned: small inputs / outputs of
@@ -133,9 +139,19 @@ struct sbe_engine {
     std::vector<hipEvent_t> d2h_events;                          // piecewise D2H of large results (d2h)
     uint8_t* h_arena = nullptr;    size_t arena_bytes = 0, arena_off = 0;   // pinned H2D staging ring
     int opt_step_form = 0;         // SBE_OPT_STEP_FORM
+    int opt_step_derive = 0;       // SBE_OPT_STEP_DERIVE: 1 = always re-derive patterns / tuples from all objects
     int opt_deferred = 0;          // SBE_OPT_DEFERRED_CHECKS: data checks reported at the next sync
     bool status_pending = false;
     std::vector<Slot> slots;
+    // One-call steps: which rows of a slot's source array differ from its partner slot's (round 3).  A chain's two
+    // slots hold the same source except for the rows the LAST step changed (accepted: the old current slot lacks them;
+    // rejected: the candidate slot carries them), so the next step copies those rows instead of the whole [N][Fp]
+    // array (256 KB per chain and step at the headline shape).  `version` counts every write to the slot's source;
+    // a record is valid only while both versions are the ones it was made at -- any other writer (sbe_set_source[_rows],
+    // sbe_sample_source, sbe_copy_slot, the call-by-call step, sbe_gibbs_step) bumps the version and the next step
+    // falls back to the full copy.  Kept outside `Slot` (slots are assigned wholesale: candidate = copy of current).
+    struct SrcSync { uint64_t version = 1; int peer = -1; uint64_t peer_version = 0, own_version = 0; std::vector<int32_t> diff; };
+    std::vector<SrcSync> src_sync;
 
     int64_t table_elems() const { return (int64_t)Gtot * F * S; }
     int64_t tile_tab_elems() const { return (int64_t)(Gtot + 1) * S * ft; }
@@ -145,6 +161,10 @@ struct sbe_engine {
 };
 
 // Host worker threads of sbe_step_batch: run job(0..n-1) on the workers and the calling thread.
+namespace {
+inline void bump_src(sbe_engine* e, int slot) { ++e->src_sync[slot].version; }
+}
+
 struct sbe_engine::Pool {
     std::vector<std::thread> workers;
     std::mutex m;
@@ -303,7 +323,8 @@ int d2h(sbe_engine* e, void* dst, const void* src_dev, size_t bytes) {
     // large results ([N, F] / [N, F, C] float64 arrays of the literal a1 / a3 surfaces): in four pieces, the host copy
     // of piece k under the DMA of pieces k+1.. (the copy out of the staging buffer costs as much as the DMA itself)
     constexpr int kPieces = 4;
-    if (bytes >= ((size_t)1 << 20)) {
+    static const bool single_copy = [] { const char* v = getenv("SBE_D2H_PIECES"); return v && atoi(v) == 1; }();   // (A/B: tools/ab_d2h.py)
+    if (bytes >= ((size_t)1 << 20) && !single_copy) {
         if (e->d2h_events.empty()) {
             e->d2h_events.resize(kPieces);
             for (auto& ev : e->d2h_events) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -400,12 +421,14 @@ void derive_patterns(sbe_engine* e, Slot& s) {
     static thread_local std::vector<uint8_t> bits;     // (called per chain and step by the batched step's pool threads)
     bits.resize(N);
     bool seen[256] = {false};
+    s.pat_cnt.assign(256, 0);
     for (int n = 0; n < N; ++n) {
         uint32_t b = 0;
         for (int c = 0; c < C; ++c)
             if (s.h_gid[(size_t)c * N + n] != kNoGroup) b |= 1u << c;
         bits[n] = (uint8_t)b;
         seen[b] = true;
+        ++s.pat_cnt[b];
     }
     auto key = [C](uint32_t b) {   // component 0 most significant => lexicographic row order of np.unique
         uint32_t k = 0;
@@ -432,6 +455,7 @@ void derive_tuples(sbe_engine* e, Slot& s) {
     uint16_t tuples[kMaxTuples][kMaxComponents];
     int n_tup = 0;
     bool ok = true;
+    s.tup_cnt.assign(kMaxTuples, 0);
     uint64_t packed[kMaxTuples];                      // C <= 4: a tuple is one 64-bit key (integer compares, no memcmp)
     int last = 0;                                     // neighbouring objects often share their tuple
     for (int n = 0; n < N && ok; ++n) {
@@ -456,8 +480,67 @@ void derive_tuples(sbe_engine* e, Slot& s) {
         }
         s.h_tid[n] = (uint8_t)t;
         s.h_toff[n] = (uint32_t)t * (uint32_t)(e->S + 1) * 512u;
+        ++s.tup_cnt[t];
     }
     s.n_tuples = ok ? n_tup : 0;
+    s.inc_ok = ok;                                    // (derive_patterns ran just before: both count tables are current)
+}
+
+// The same tables after a few objects changed their component-0 group (a cluster move), in O(moved): `s` holds the
+// OLD tables and counts and already the NEW ids in h_gid; `moved` lists the objects, `old_gid0` their previous ids.
+// Returns false when the update needs the full derivation (the SET of patterns changes, or no tuple index is free);
+// `s` is then only partly updated and the caller re-derives everything.  Tuple numbering is history-dependent (a
+// vacated index is reused by the next new tuple); the kernels only look tuples up, so results do not depend on it.
+bool update_patterns_and_tuples(sbe_engine* e, Slot& s, const int32_t* moved, const uint16_t* old_gid0, int n_moved) {
+    const int N = e->N, C = e->C;
+    if (!s.inc_ok || s.n_tuples == 0 || (int)s.pat_cnt.size() != 256 || (int)s.tup_cnt.size() != kMaxTuples) return false;
+    auto bits_rest = [&](int n) { uint32_t b = 0; for (int c = 1; c < C; ++c) if (s.h_gid[(size_t)c * N + n] != kNoGroup) b |= 1u << c; return b; };
+    // pass 1: the set of patterns must stay what it is (ranks of the other patterns would shift otherwise)
+    for (int i = 0; i < n_moved; ++i) {
+        const int n = moved[i];
+        const uint32_t rest = bits_rest(n);
+        const uint32_t b0 = rest | (old_gid0[i] != kNoGroup ? 1u : 0u), b1 = rest | (s.h_gid[n] != kNoGroup ? 1u : 0u);
+        if (b0 == b1) continue;
+        --s.pat_cnt[b0]; ++s.pat_cnt[b1];
+    }
+    {
+        size_t live = 0;
+        for (uint32_t b = 0; b < 256; ++b) if (s.pat_cnt[b] > 0) ++live;
+        bool same = live == s.patterns.size();
+        for (size_t i = 0; same && i < s.patterns.size(); ++i) same = s.pat_cnt[s.patterns[i]] > 0;
+        if (!same) return false;
+    }
+    uint8_t rank_of[256];
+    for (size_t i = 0; i < s.patterns.size(); ++i) rank_of[s.patterns[i]] = (uint8_t)i;
+    // pass 2: pattern id and tuple of every moved object
+    for (int i = 0; i < n_moved; ++i) {
+        const int n = moved[i];
+        const uint32_t b1 = bits_rest(n) | (s.h_gid[n] != kNoGroup ? 1u : 0u);
+        s.h_pid[n] = rank_of[b1];
+        uint16_t key[kMaxComponents];
+        for (int c = 0; c < C; ++c) { const uint16_t g = s.h_gid[(size_t)c * N + n]; key[c] = g == kNoGroup ? (uint16_t)e->Gtot : g; }
+        const int t0 = s.h_tid[n];
+        int t1 = -1, free_t = -1;
+        for (int t = 0; t < s.n_tuples; ++t) {
+            if (s.tup_cnt[t] == 0) { if (free_t < 0 && t != t0) free_t = t; continue; }
+            if (memcmp(&s.h_tuple_g[(size_t)t * kMaxComponents], key, (size_t)C * sizeof(uint16_t)) == 0) { t1 = t; break; }
+        }
+        if (t1 < 0) {                                     // a tuple no object had: a vacated index, else a new one
+            if (s.tup_cnt[t0] == 1) t1 = t0;              // (the object was alone in its tuple: the index moves with it)
+            else if (free_t >= 0) t1 = free_t;
+            else if (s.n_tuples < kMaxTuples) t1 = s.n_tuples++;
+            else return false;
+            for (int c = 0; c < C; ++c) s.h_tuple_g[(size_t)t1 * kMaxComponents + c] = key[c];
+        }
+        if (t1 != t0) {
+            if (--s.tup_cnt[t0] == 0) s.h_tuple_p[t0] = 0xFF;          // no object left: "not present", like the full derivation
+            ++s.tup_cnt[t1];
+        }
+        s.h_tuple_p[t1] = s.h_pid[n];
+        s.h_tid[n] = (uint8_t)t1;
+        s.h_toff[n] = (uint32_t)t1 * (uint32_t)(e->S + 1) * 512u;
+    }
+    return true;
 }
 
 int upload_patterns_and_weights(sbe_engine* e, int slot) {
@@ -941,7 +1024,7 @@ int sbe_destroy(sbe_engine* e) {
     if (e->h_step_payload) (void)hipHostFree(e->h_step_payload);
     if (e->h_io) (void)hipHostFree(e->h_io);
     void* dev_ptrs[] = {e->d_step_pf, e->d_step_pg, e->d_logtab, e->d_state_h, e->d_toff, e->d_tid, e->d_tuple_g, e->d_tuple_p, e->d_state_q, e->d_probs_t, e->d_wpat_t, e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
-                        e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_unif, e->d_unif_res, e->d_comp_of_group, e->d_partials, e->d_rowoff,
+                        e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_lg_conc, e->d_sum_a, e->d_lg_sum_a, e->d_unif, e->d_unif_res, e->d_comp_of_group, e->d_partials, e->d_rowoff,
                         e->d_status, e->d_changed, e->d_step_stamp, e->d_scratch};
     for (void* p : dev_ptrs) if (p) (void)hipFree(p);
     if (e->h_results) (void)hipHostFree(e->h_results);
@@ -1013,6 +1096,7 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     }
     e->conc_set.assign(n_components, 0);
     e->slots.resize(n_slots);
+    e->src_sync.resize(n_slots);
     for (Slot& s : e->slots) {
         s.h_gid.assign((size_t)n_components * n_objects, kNoGroup);
         s.probs_set.assign(n_components, 0);
@@ -1099,6 +1183,9 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_RC(dmalloc(e, &e->d_conc, e->table_elems()));
     CREATE_RC(dmalloc(e, &e->d_unif, F * S));
     CREATE_RC(dmalloc(e, &e->d_unif_res, F * S));
+    CREATE_RC(dmalloc(e, &e->d_lg_conc, e->table_elems()));
+    CREATE_RC(dmalloc(e, &e->d_sum_a, (int64_t)e->Gtot * F));
+    CREATE_RC(dmalloc(e, &e->d_lg_sum_a, (int64_t)e->Gtot * F));
     CREATE_RC(dmalloc(e, &e->d_comp_of_group, e->Gtot));
     {
         std::vector<int32_t> cog(std::max(e->Gtot, 1), 0);
@@ -1132,6 +1219,7 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
         e->sl.weights = o;  o = al(o + (size_t)(F * C) * 4);
         e->sl.row_of = o;   o = al(o + (size_t)e->Np * 2);
         e->sl.subset = o;   o = al(o + (size_t)e->Np * 4);
+        e->sl.stale = o;    o = al(o + (size_t)e->step_max_rows * 4);
         e->sl.objects = o;  o = al(o + (size_t)e->step_max_rows * 4);
         e->sl.rows = o;     o = al(o + (size_t)e->step_max_rows * (size_t)(F * C));
         e->sl.total = o;
@@ -1210,6 +1298,7 @@ int sbe_set_option(sbe_engine* e, int option, int value) {
     if (option == SBE_OPT_MIXTURE_KERNEL && (value == SBE_MIXTURE_PACKED || value == SBE_MIXTURE_ONEHOT || value == SBE_MIXTURE_PACKED_GENERAL || value == SBE_MIXTURE_PACKED_TUPLE || value == SBE_MIXTURE_PACKED_TUPLE_LDS || value == SBE_MIXTURE_ONEHOT_GENERAL || value == SBE_MIXTURE_PACKED_V2)) { e->opt_kernel = value; return SBE_OK; }
     if (option == SBE_OPT_LOG_MODE && (value == SBE_LOG_PER_OBS || value == SBE_LOG_PRODUCT)) { e->opt_log = value; return SBE_OK; }
     if (option == SBE_OPT_STEP_FORM && (value == 0 || value == 1)) { e->opt_step_form = value; return SBE_OK; }
+    if (option == SBE_OPT_STEP_DERIVE && (value == 0 || value == 1)) { e->opt_step_derive = value; return SBE_OK; }
     if (option == SBE_OPT_DEFERRED_CHECKS && (value == 0 || value == 1)) {
         if (!value && e->status_pending) { HIPCHK(e, hipStreamSynchronize(e->stream)); int rc = synced(e); e->opt_deferred = 0; return rc; }
         e->opt_deferred = value;
@@ -1330,6 +1419,7 @@ int sbe_set_source(sbe_engine* e, int slot, const uint8_t* source) {
     k_ingest_source<<<div_up((int64_t)e->N * e->F, 256), 256, 0, e->stream>>>(
         e->d_scratch, nullptr, e->d_src + (int64_t)slot * e->N * e->Fp, e->N, e->F, e->C, e->Fp, e->d_status);
     HIPCHK(e, hipGetLastError());
+    bump_src(e, slot);
     e->slots[slot].source_set = true;
     return check_after(e);
 }
@@ -1354,6 +1444,7 @@ int sbe_set_source_rows(sbe_engine* e, int slot, const int32_t* objects, int n_r
     k_ingest_source<<<div_up((int64_t)n_rows * e->F, 256), 256, 0, e->stream>>>(
         e->d_scratch, d_obj, e->d_src + (int64_t)slot * e->N * e->Fp, n_rows, e->F, e->C, e->Fp, e->d_status);
     HIPCHK(e, hipGetLastError());
+    bump_src(e, slot);
     return check_after(e);
 }
 
@@ -1483,6 +1574,11 @@ int sbe_set_concentration(sbe_engine* e, int component, const double* conc, int 
         for (int g = 0; g < e->G[component]; ++g)
             { int _urc = upload(e, dst + g * fs, conc, fs * sizeof(double)); if (_urc) return _urc; }
     }
+    // the count-independent lgamma terms of this component's tables, for the one-call steps
+    const int g_lo = e->goff[component], g_hi = g_lo + e->G[component];
+    k_conc_lgamma<<<div_up((int64_t)(g_hi - g_lo) * e->F, 256), 256, 0, e->stream>>>(e->d_conc, e->d_lg_conc, e->d_sum_a, e->d_lg_sum_a,
+                                                                              g_lo, g_hi, e->F, e->S);
+    HIPCHK(e, hipGetLastError());
     e->conc_set[component] = 1;
     return SBE_OK;
 }
@@ -2064,6 +2160,7 @@ int sbe_sample_source(sbe_engine* e, int slot, int dst_slot, const int32_t* obje
     if (z) { int _urc = upload(e, d_z, z, (size_t)n_obs * sizeof(double)); if (_urc) return _urc; }
     k_sample_source<<<div_up(n_obs, 256), 256, 0, e->stream>>>(a, z ? d_z : nullptr, e->rng_seed, e->rng_draw,
                                                                e->d_src + (int64_t)dst_slot * e->N * e->Fp, d_psel, e->d_status, nullptr);
+    bump_src(e, dst_slot);
     if (!z) ++e->rng_draw;
     HIPCHK(e, hipGetLastError());
     return finish_log_q(e, d_psel, n_obs, d_partials, log_q_out, p_selected_out);
@@ -2514,6 +2611,9 @@ struct CoreInputs {
     const uint8_t* src_new = nullptr;    // device-sampled source (the candidate's array) instead of payload rows
     const int32_t* subset = nullptr; int n_subset = 0;      // objects whose counts may change
     int P = 1;                           // has_components patterns of the candidate
+    // source array of the candidate slot: the whole array is copied from the current slot (full_src_copy), or only the
+    // rows in which the candidate slot is known to differ from it (sbe_engine::SrcSync)
+    bool full_src_copy = true; const int32_t* stale = nullptr; int n_stale = 0;
 };
 
 // the single-step calls' lane: the engine's own payload / result blocks
@@ -2558,7 +2658,9 @@ int build_step_core(sbe_engine* e, sbe_engine::Lane& lane, int cur_slot, int can
     seg(e->d_patbits, (int64_t)e->Pmax, regroup ? in.patbits : nullptr);
     seg(e->d_weights, (int64_t)F * C, in.weights);
     a.src_seg = a.cs.n;
-    seg(e->d_src, (int64_t)N * e->Fp, nullptr);
+    if (in.full_src_copy) seg(e->d_src, (int64_t)N * e->Fp, nullptr);
+    a.stale = in.stale; a.n_stale = in.full_src_copy ? 0 : in.n_stale;
+    a.src_cur_rows = e->d_src + (int64_t)cur_slot * N * e->Fp;
     a.row_of = in.row_of;
     a.rows = in.rows;
     a.objects = in.objects;
@@ -2572,7 +2674,7 @@ int build_step_core(sbe_engine* e, sbe_engine::Lane& lane, int cur_slot, int can
     a.subset = in.subset; a.n_subset = in.n_subset;
     a.counts_cur = e->d_counts + (int64_t)cur_slot * e->table_elems();
     a.counts_new = e->d_counts + (int64_t)cand_slot * e->table_elems();
-    a.conc = e->d_conc;
+    a.conc = e->d_conc; a.lg_conc = e->d_lg_conc; a.sum_a = e->d_sum_a; a.lg_sum_a = e->d_lg_sum_a;
     a.probs = e->d_probs + (int64_t)cand_slot * e->table_elems();
     a.probs_t = e->d_probs_t + (int64_t)cand_slot * e->probs_t_elems();
     a.per_feature = lane.d_pf;
@@ -2687,16 +2789,16 @@ int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters
 // Host half of a lean step for one chain: the candidate's host state `cd` (= current + delta) and the step's payload
 // packed into the lane's host-mapped block; `in` receives the device-side views of that payload.  Touches only the lane,
 // `cd` and read-only engine state, so the chains of a batch can be prepared by several host threads at once.
-static int prepare_step(sbe_engine* e, const sbe_engine::Lane& lane, int cur_slot, const uint8_t* clusters,
+static int prepare_step(sbe_engine* e, const sbe_engine::Lane& lane, int cur_slot, int cand_slot, const uint8_t* clusters,
                         const int32_t* changed_objects, int n_changed, const uint8_t* source_rows, const float* weights,
                         Slot& cd, CoreInputs& in, std::string* err) {
     const int N = e->N, Np = e->Np, F = e->F, C = e->C;
     const Slot& cur = e->slots[cur_slot];
     cd = cur;                                 // host state of the candidate (committed by the caller)
     // objects whose counts may change: listed source rows + objects whose cluster membership changed
-    static thread_local std::vector<uint8_t> moved;                   // (no allocation per step: the chains of a batch are
-    moved.assign(N, 0);                                                //  prepared by pool threads)
-    for (int i = 0; i < n_changed; ++i) moved[changed_objects[i]] = 1;
+    static thread_local std::vector<int32_t> mv;                      // (no allocation per step: the chains of a batch are
+    static thread_local std::vector<uint16_t> mv_old;                  //  prepared by pool threads)
+    mv.clear(); mv_old.clear();
     const bool regroup = clusters != nullptr;
     if (regroup) {
         const int K = e->G[0];
@@ -2713,15 +2815,22 @@ static int prepare_step(sbe_engine* e, const sbe_engine::Lane& lane, int cur_slo
             }
             for (; n < N; ++n) if (row[n]) ids[n] = (uint16_t)g;
         }
-        for (int n = 0; n < N; ++n) if (ids[n] != cur.h_gid[n]) moved[n] = 1;
-        derive_patterns(e, cd);
-        if ((int)cd.patterns.size() > e->Pmax) {
-            char buf[160];
-            snprintf(buf, sizeof buf, "%zu distinct has_components patterns exceed capacity %d", cd.patterns.size(), e->Pmax);
-            *err = buf;
-            return SBE_ERR_ARG;
+        const uint16_t* old_ids = cur.h_gid.data();
+        for (int n = 0; n < N; ++n) if (ids[n] != old_ids[n]) { mv.push_back(n); mv_old.push_back(old_ids[n]); }
+        // pattern ids and group tuples of the candidate: the moved objects' entries updated in place (cd holds the
+        // current slot's tables), the full derivation when the set of patterns changes, the counts are not there
+        // (slot never derived in full) or on request
+        if (e->opt_step_derive == 1 || (int)mv.size() > N / 8 ||
+            !update_patterns_and_tuples(e, cd, mv.data(), mv_old.data(), (int)mv.size())) {
+            derive_patterns(e, cd);
+            if ((int)cd.patterns.size() > e->Pmax) {
+                char buf[160];
+                snprintf(buf, sizeof buf, "%zu distinct has_components patterns exceed capacity %d", cd.patterns.size(), e->Pmax);
+                *err = buf;
+                return SBE_ERR_ARG;
+            }
+            derive_tuples(e, cd);
         }
-        derive_tuples(e, cd);
         cd.patterns_dirty = false;
         cd.group_epoch = ++e->epoch_counter;
     }
@@ -2731,9 +2840,16 @@ static int prepare_step(sbe_engine* e, const sbe_engine::Lane& lane, int cur_slo
     const auto& L = e->sl;
     uint8_t* st = lane.h_payload;
     int n_subset = 0;
-    {
+    {   // sorted union of the objects that changed cluster and the objects with new source rows
         int32_t* sub = reinterpret_cast<int32_t*>(st + L.subset);
-        for (int n = 0; n < N; ++n) if (moved[n]) sub[n_subset++] = n;
+        if (n_changed == 0) { memcpy(sub, mv.data(), mv.size() * sizeof(int32_t)); n_subset = (int)mv.size(); }
+        else {
+            static thread_local std::vector<int32_t> ch;
+            ch.assign(changed_objects, changed_objects + n_changed);
+            std::sort(ch.begin(), ch.end());
+            ch.erase(std::unique(ch.begin(), ch.end()), ch.end());
+            n_subset = (int)(std::set_union(mv.begin(), mv.end(), ch.begin(), ch.end(), sub) - sub);
+        }
     }
     if (regroup) {
         memcpy(st + L.ids, cd.h_gid.data(), (size_t)N * 2);
@@ -2769,9 +2885,35 @@ static int prepare_step(sbe_engine* e, const sbe_engine::Lane& lane, int cur_slo
     }
     in.subset = reinterpret_cast<const int32_t*>(pl + L.subset); in.n_subset = n_subset;
     in.P = (int)cd.patterns.size();
+    {   // source array: rows to bring over from the current slot (sbe_engine::SrcSync), or the whole array
+        const sbe_engine::SrcSync& rec = e->src_sync[cand_slot];
+        const sbe_engine::SrcSync& cs = e->src_sync[cur_slot];
+        if (rec.peer == cur_slot && rec.peer_version == cs.version && rec.own_version == rec.version &&
+            (int)rec.diff.size() <= e->step_max_rows) {
+            int32_t* stale = reinterpret_cast<int32_t*>(st + L.stale);
+            const int16_t* row_of = n_changed > 0 ? reinterpret_cast<const int16_t*>(st + L.row_of) : nullptr;
+            int ns = 0;
+            for (int32_t n : rec.diff)                       // (rows this step rewrites anyway are left to it)
+                if (!row_of || row_of[n] < 0) stale[ns++] = n;
+            in.full_src_copy = false;
+            in.stale = reinterpret_cast<const int32_t*>(pl + L.stale);
+            in.n_stale = ns;
+        }
+    }
     std::fill(cd.probs_set.begin(), cd.probs_set.end(), 1);
     cd.weights_set = true;
     return SBE_OK;
+}
+
+// after a one-call step was enqueued: the candidate's source = the current slot's except the rows the step wrote
+static void commit_src_sync(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* changed_objects, int n_changed) {
+    sbe_engine::SrcSync& rc = e->src_sync[cand_slot];
+    sbe_engine::SrcSync& cu = e->src_sync[cur_slot];
+    ++rc.version;
+    rc.peer = cur_slot; rc.peer_version = cu.version; rc.own_version = rc.version;
+    rc.diff.assign(changed_objects, changed_objects + n_changed);
+    cu.peer = cand_slot; cu.peer_version = rc.version; cu.own_version = cu.version;
+    cu.diff = rc.diff;
 }
 
 static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters, const int32_t* changed_objects,
@@ -2791,13 +2933,14 @@ static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* 
     CoreInputs in;
     {
         std::string err;
-        int rc = prepare_step(e, lane0(e), cur_slot, clusters, changed_objects, n_changed, source_rows, weights, cd, in, &err);
+        int rc = prepare_step(e, lane0(e), cur_slot, cand_slot, clusters, changed_objects, n_changed, source_rows, weights, cd, in, &err);
         if (rc) return fail(e, rc, "%s", err.c_str());
     }
     const auto t1 = std::chrono::steady_clock::now();
     // ---- kernel 1: candidate slot = current slot + payload, count delta, every table ---------------------------
     int rc = launch_step_core(e, cur_slot, cand_slot, in);
     if (rc) return rc;
+    commit_src_sync(e, cur_slot, cand_slot, changed_objects, n_changed);
     e->slots[cand_slot] = cd;
     // ---- kernels 2 + 3: fused mixture eval, reduction + step epilogue (mapped-memory results) -------------------
     StepFinish fin = make_step_finish(e);
@@ -2970,7 +3113,7 @@ int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const 
             sbe_engine::Lane lane = e->lanes[i];                      // this chain's lane with its slice of the packed payload
             lane.h_payload = e->h_batch_payload + pay_off[i];
             lane.d_payload = e->d_batch_payload + pay_off[i];
-            rcs[i] = prepare_step(e, lane, cur_slots[i], regroup ? clusters + (size_t)i * K * N : nullptr,
+            rcs[i] = prepare_step(e, lane, cur_slots[i], cand_slots[i], regroup ? clusters + (size_t)i * K * N : nullptr,
                                   nr ? changed_objects + r0 : nullptr, nr, nr ? source_rows + (size_t)r0 * F * C : nullptr,
                                   reweight ? weights + (size_t)i * F * C : nullptr, cds[i], ins[i], &errs[i]);
             chunk_done[j / kCopyChunk].fetch_add(1, std::memory_order_release);
@@ -3001,7 +3144,11 @@ int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const 
         k_step_core_batch<<<dim3(max_blocks, np), kBlock, lds, e->stream>>>(reinterpret_cast<const StepCore*>(dm));
         HIPCHK(e, hipGetLastError());
         if (part == 0) mark();
-        for (int i = i0; i < i1; ++i) std::swap(e->slots[cand_slots[i]], cds[i]);     // (swap: both keep their storage)
+        for (int i = i0; i < i1; ++i) {
+            commit_src_sync(e, cur_slots[i], cand_slots[i], changed_objects ? changed_objects + rows_ptr[i] : nullptr,
+                            rows_ptr[i + 1] - rows_ptr[i]);
+            std::swap(e->slots[cand_slots[i]], cds[i]);                               // (swap: both keep their storage)
+        }
         if (part == 0) mark();
         rc = launch_mixture(e, 0, np, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, nullptr,
                             cand_slots + i0, reinterpret_cast<const int32_t*>(dm + part_cores + part_fins),
@@ -3096,6 +3243,7 @@ int sbe_gibbs_step(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* ob
                            from_prior != 0};
     };
     uint8_t* src_cand = e->d_src + (int64_t)cand_slot * N * e->Fp;
+    bump_src(e, cand_slot);                  // (the Gibbs step draws into the candidate's array and copies the rest in full)
     // 1: the draw (posterior from the current tables) -> the candidate's source rows of the listed objects, and the
     //    per-block partial sums of log_q
     k_sample_source<<<nblk, kBlock, 0, e->stream>>>(post_args(cur_slot), d_z, e->rng_seed, e->rng_draw, src_cand, d_psel_f, e->d_status, d_part_f);
@@ -3271,6 +3419,7 @@ int sbe_copy_slot(sbe_engine* e, int dst, int src) {
     seg(e->d_weights, F * C); seg(e->d_wpat, (int64_t)e->Pmax * F * C); seg(e->d_patbits, (int64_t)e->Pmax);
     k_multi_copy<<<std::min<int64_t>(div_up(run, 256), 4 * e->compute_units), 256, 0, e->stream>>>(cs);
     HIPCHK(e, hipGetLastError());
+    bump_src(e, dst);
     e->slots[dst] = e->slots[src];
     return SBE_OK;
 }

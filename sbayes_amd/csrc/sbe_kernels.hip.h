@@ -2506,6 +2506,25 @@ __global__ void k_multi_copy(CopySegs cs) {
 //   weight blocks: normalised weights per pattern (from the payload's / the current slot's weights and patterns)
 //   copy blocks  : the other per-slot arrays, current slot or payload -> candidate (k_step_apply without counts)
 // ------------------------------------------------------------------------------------------
+// lgamma terms of the concentration tables that do not depend on the counts (one-call steps, round 3): per element
+// lgamma(conc) (0 where conc <= 0: that state is not applicable), per (group, feature) row sum_a = the NumPy-order sum
+// of the row and lgamma(sum_a).  Built once per sbe_set_concentration; k_step_core then evaluates ONE lgamma per
+// element and per row instead of two (same function, same arguments: the values are the ones it computed itself).
+__global__ void k_conc_lgamma(const double* __restrict__ conc, double* __restrict__ lg_conc, double* __restrict__ sum_a,
+                              double* __restrict__ lg_sum_a, int g_lo, int g_hi, int F, int S) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= (int64_t)(g_hi - g_lo) * F) return;
+    const int64_t r = (int64_t)g_lo * F + row, base = r * S;
+    for (int s = 0; s < S; ++s) {
+        const double a = conc[base + s];
+        lg_conc[base + s] = a > 0.0 ? sbe_lgamma_pos(a) : 0.0;
+    }
+    auto conc_at = [&](int k) -> double { return conc[base + k]; };
+    const double sa = np_pairwise_sum<double>(conc_at, S);
+    sum_a[r] = sa;
+    lg_sum_a[r] = sbe_lgamma_pos(sa);
+}
+
 struct StepCore {
     // copy blocks
     CopySegs cs; int src_seg;
@@ -2519,12 +2538,16 @@ struct StepCore {
     const int32_t* subset; int n_subset;
     const int32_t* counts_cur; int32_t* counts_new;
     const double* conc; float* probs; float* probs_t; float* per_feature;
+    const double* lg_conc; const double* sum_a; const double* lg_sum_a;   // k_conc_lgamma's tables of `conc`
     uint32_t* stamp; uint32_t step_id;
     int Np, S, Gtot, ft, ftc, n_tile_blocks;
     // weight blocks
     const float* weights; const uint32_t* pattern_bits; float* wpat; double* wpat_t;
     int P, Pmax, n_weight_blocks;
     int n_copy_blocks;             // (batched launch: the grid is sized for the largest chain; surplus blocks exit)
+    // round 3: when the candidate slot's source array is known to differ from the current slot's only in `stale` rows
+    // (the previous step's changed rows), those rows are copied instead of the whole array (no src segment in `cs`)
+    const int32_t* stale; int n_stale; const uint8_t* src_cur_rows;
 };
 
 __device__ __forceinline__ void step_core_body(const StepCore& a, unsigned char* core_lds, const int bx) {
@@ -2578,24 +2601,22 @@ __device__ __forceinline__ void step_core_body(const StepCore& a, unsigned char*
             const float cf = (float)cn;
             const double conc = a.conc[gi];
             sh_post[e] = (double)cf + conc;
-            sh_ser[e] = conc > 0.0 ? sbe_lgamma_pos((double)cf + conc) - sbe_lgamma_pos(conc) : 0.0;
+            sh_ser[e] = conc > 0.0 ? sbe_lgamma_pos((double)cf + conc) - a.lg_conc[gi] : 0.0;
         }
         __syncthreads();
         for (int r = threadIdx.x; r < R; r += kBlock) {                              // ordered sums of a row
             const int g = r / ftc, fl = r - g * ftc, f = f0 + fl;
             if (f >= F) continue;
             const int e0 = r * S;
-            const int64_t base = ((int64_t)g * F + f) * S;
             auto post_at = [&](int k) -> double { return sh_post[e0 + k]; };
             auto ser_at = [&](int k) -> double { return sh_ser[e0 + k]; };
             auto cnt_at = [&](int k) -> float { return (float)hist[e0 + k]; };
-            auto conc_at = [&](int k) -> double { return a.conc[base + k]; };
             const double total = np_pairwise_sum<double>(post_at, S);
             if (!(total > 0.0)) atomicAdd(&a.status[ST_BAD_NORMALIZE], 1);
             sh_total[r] = total;
             const float n = np_pairwise_sum<float>(cnt_at, S);
-            const double sum_a = np_pairwise_sum<double>(conc_at, S);
-            const double cst = sbe_lgamma_pos(sum_a) - sbe_lgamma_pos((double)n + sum_a);
+            const double sum_a = a.sum_a[(int64_t)g * F + f];
+            const double cst = a.lg_sum_a[(int64_t)g * F + f] - sbe_lgamma_pos((double)n + sum_a);
             a.per_feature[(int64_t)g * F + f] = (float)(cst + np_pairwise_sum<double>(ser_at, S));
         }
         __syncthreads();
@@ -2651,6 +2672,14 @@ __device__ __forceinline__ void step_core_body(const StepCore& a, unsigned char*
                 if (filtered && a.row_of[(j * 4u) / (uint32_t)a.Fp] >= 0) continue;
                 dst[j] = src[j];
             }
+        }
+    }
+    if (a.n_stale > 0) {                                     // stale rows of the candidate's source <- the current slot's
+        const uint32_t per_row = (uint32_t)a.Fp / 16u;       // (Fp is a multiple of 64)
+        for (uint32_t i = tid; i < (uint32_t)a.n_stale * per_row; i += nthreads) {
+            const uint32_t r = i / per_row, k = i - r * per_row;
+            const int64_t off = (int64_t)a.stale[r] * a.Fp + (int64_t)k * 16;
+            *reinterpret_cast<uint4*>(a.src_dst + off) = *reinterpret_cast<const uint4*>(a.src_cur_rows + off);
         }
     }
     int multi = 0;

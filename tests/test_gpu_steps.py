@@ -205,21 +205,14 @@ def test_one_call_steps_at_baseline_workloads(name):
 
 
 # ---- batched multi-chain step (sbe_step_batch) -----------------------------------------------------------------
-@pytest.mark.parametrize("parts", [None, "2", "5"])
-def test_step_batch_equals_single_steps(parts, monkeypatch):
-    """B chains stepped by ONE sbe_step_batch call give what B sbe_step calls give: counts, tables, per-group collapsed
-    values and changed-group flags bit for bit, the mixture scalar to rounding (its block geometry depends on the
-    launch's batch size); mixed deltas -- cluster moves, source rows, weights, nothing -- accepted and rejected.
-    `parts`: the pipelined form large batches take (from 128 chains on: the host halves of part k+1 under the device work
-    of part k), forced here on 12 chains through SBE_STEP_PARTS."""
-    if parts is not None:
-        monkeypatch.setenv("SBE_STEP_PARTS", parts)
-    wl = make_workload("headline")
+def _batch_equals_single_steps(workload, B, n_sweeps, seed=8, distinct_states=None):
+    """B chains stepped by ONE sbe_step_batch call against B sbe_step calls and, at the end, the oracle."""
+    wl = make_workload(workload)
     feats, na = wl.features, wl.na_values
     N, F, S = wl.shape
     C = wl.n_components
-    B = 12
-    rng = np.random.default_rng(8)
+    rng = np.random.default_rng(seed)
+    distinct_states = B if distinct_states is None else distinct_states
     n_groups = [g.shape[0] for g in wl.groups]
     with Engine(feats, n_groups, n_slots=2 * B) as eb, Engine(feats, n_groups, n_slots=2) as es:
         for eng in (eb, es):
@@ -227,15 +220,16 @@ def test_step_batch_equals_single_steps(parts, monkeypatch):
                 eng.set_concentration(c, wl.concentration[c])
         states = []
         for i in range(B):
-            clusters, weights, source = (wl.clusters, wl.weights, wl.source) if i == 0 else \
-                make_state(feats, wl.groups[1:], wl.clusters.shape[0], seed=300 + i)
+            clusters, weights, source = (wl.clusters, wl.weights, wl.source) if i % distinct_states == 0 else \
+                (states[i % distinct_states] if i >= distinct_states else
+                 make_state(feats, wl.groups[1:], wl.clusters.shape[0], seed=300 + i))
             eb.load_state(2 * i, [clusters] + wl.groups[1:], weights, source=source)
             for c in range(C):
                 eb.update_probs(2 * i, c)
             states.append((clusters, weights, source))
         cur = np.arange(0, 2 * B, 2, dtype=np.int32)
         cand = cur + 1
-        for sweep in range(4):
+        for sweep in range(n_sweeps):
             cl = np.stack([s[0] for s in states]).copy()
             cm = np.zeros(B, dtype=bool)
             wts = np.zeros((B, F, C), dtype=np.float32)
@@ -295,6 +289,32 @@ def test_step_batch_equals_single_steps(parts, monkeypatch):
                 assert np.array_equal(eb.get_counts(int(cur[i]), c), want[0][c])
 
 
+@pytest.mark.parametrize("parts", [None, "2", "5"])
+def test_step_batch_equals_single_steps(parts, monkeypatch):
+    """B chains stepped by ONE sbe_step_batch call give what B sbe_step calls give: counts, tables, per-group collapsed
+    values and changed-group flags bit for bit, the mixture scalar to rounding (its block geometry depends on the
+    launch's batch size); mixed deltas -- cluster moves, source rows, weights, nothing -- accepted and rejected.
+    `parts`: the pipelined form large batches take (from 128 chains on: the host halves of part k+1 under the device work
+    of part k), forced here on 12 chains through SBE_STEP_PARTS."""
+    if parts is not None:
+        monkeypatch.setenv("SBE_STEP_PARTS", parts)
+    _batch_equals_single_steps("headline", 12, 4)
+
+
+def test_step_batch_natural_two_part_pipeline_160_chains(monkeypatch):
+    """the NATURAL two-part pipeline (>= 128 chains, include/sbe_engine.h) and the 16-chain payload
+    chunks -- 160 chains without SBE_STEP_PARTS: ten full chunks over two parts -- against single sbe_step calls."""
+    monkeypatch.delenv("SBE_STEP_PARTS", raising=False)
+    _batch_equals_single_steps("headline", 160, 2, seed=18, distinct_states=8)
+
+
+def test_step_batch_stress_workload_8_chains(monkeypatch):
+    """the batch step at the stress shape (5000 x 500 x 20, C = 4: the general rows kernel, several
+    feature tiles and object chunks per chain) with 8 chains, against single sbe_step calls and the oracle."""
+    monkeypatch.delenv("SBE_STEP_PARTS", raising=False)
+    _batch_equals_single_steps("stress", 8, 2, seed=28, distinct_states=3)
+
+
 @pytest.mark.parametrize("name,n_chains", [("south_america", 64), ("headline", 16)])
 def test_step_batch_replays_interleaved_reference_traces(name, n_chains):
     """n_chains copies of the recorded reference MCMC trace, chain i lagging i steps behind chain i-1, stepped together
@@ -336,3 +356,62 @@ def test_step_batch_replays_interleaved_reference_traces(name, n_chains):
         batch.close()
         from sbayes_amd.registry import release_all
         release_all()
+
+
+@pytest.mark.parametrize("name", ["headline", "south_america_like", "many_tuples"])
+def test_incremental_pattern_and_tuple_update_equals_full_derivation(name):
+    """Round 3: a step that moves a few objects between clusters updates the candidate's has_components pattern ids and
+    group-tuple tables for those objects only (sbe_engine.hip: update_patterns_and_tuples); SBE_OPT_STEP_DERIVE = 1
+    re-derives them from all N objects as before.  Forty chained steps (accept / reject mixed; moves that empty a tuple,
+    create one, empty a CLUSTER -- the pattern set changes and the full derivation takes over) on two engines, one per
+    mode: counts, tables, flags and per-group values bit for bit, the mixture scalar to rounding (the tuple numbering
+    may differ, the looked-up values may not), and at the end the oracle."""
+    if name == "headline":
+        wl = make_workload("headline")
+    elif name == "south_america_like":                     # three components, small clusters that do get emptied
+        wl = make_workload("sa_like", shape=(120, 70, 5, 3, (6,), True))
+    else:                                                  # dozens of tuples: indices are vacated and reused
+        wl = make_workload("tuples", shape=(400, 64, 4, 6, (3, 2), False))
+    feats, na = wl.features, wl.na_values
+    N, F, S = wl.shape
+    C = wl.n_components
+    K = wl.clusters.shape[0]
+    rng = np.random.default_rng(77)
+    n_groups = [g.shape[0] for g in wl.groups]
+    with Engine(feats, n_groups, n_slots=2) as ea, Engine(feats, n_groups, n_slots=2) as eb:
+        eb.set_option(step_derive=1)
+        for eng in (ea, eb):
+            for c in range(C):
+                eng.set_concentration(c, wl.concentration[c])
+            eng.load_state(0, wl.groups, wl.weights, source=wl.source)
+            for c in range(C):
+                eng.update_probs(0, c)
+            eng.mixture_loglik(0)
+        cur, cand = 0, 1
+        groups, source, weights = list(wl.groups), wl.source, wl.weights
+        for i_step in range(40):
+            if i_step % 10 == 7:                           # empty a whole cluster: a has_components pattern may vanish
+                clusters = groups[0].copy()
+                clusters[int(rng.integers(0, K))] = False
+                objs = np.zeros(0, dtype=np.int32)
+                rows, new_source = None, source
+            else:
+                clusters, _g, objs, rows, new_source = _propose(rng, feats, na, groups, source, weights,
+                                                               int(rng.integers(0, 12)), True)
+            kw = {"clusters": clusters}
+            if len(objs):
+                kw.update(changed_objects=objs, source_rows=rows)
+            ga, ma, ca = ea.step(cur, cand, **kw)
+            gb, mb, cb = eb.step(cur, cand, **kw)
+            assert np.array_equal(ga, gb) and np.array_equal(ca, cb), i_step
+            assert abs(ma - mb) <= 1e-13 * abs(mb), (i_step, ma, mb)
+            for c in range(C):
+                assert np.array_equal(ea.get_counts(cand, c), eb.get_counts(cand, c))
+                assert np.array_equal(ea.get_probs(cand, c), eb.get_probs(cand, c))
+            if rng.random() < 0.7:
+                cur, cand = cand, cur
+                groups, source = [clusters] + groups[1:], new_source
+        want = _expected(feats, na, groups, source, wl.concentration, weights)
+        for eng in (ea, eb):
+            got = eng.mixture_loglik(cur)
+            assert abs(got - want[3]) <= 1e-10 * abs(want[3])
