@@ -6,6 +6,7 @@
 // slot's state stay resident in HBM; only small tables / id vectors cross PCIe per call.
 #include "sbe_kernels.hip.h"
 #include "../../include/sbe_engine.h"
+#include "sbe_pool.h"          // host worker threads of sbe_step_batch (plain C++: also built under ThreadSanitizer)
 
 #include <sched.h>
 #include <algorithm>
@@ -160,88 +161,11 @@ struct sbe_engine {
     int64_t wpat_t_elems() const { return (int64_t)n_ftiles * wpat_tile_elems(); }
 };
 
-// Host worker threads of sbe_step_batch: run job(0..n-1) on the workers and the calling thread.
 namespace {
 inline void bump_src(sbe_engine* e, int slot) { ++e->src_sync[slot].version; }
 }
 
-struct sbe_engine::Pool {
-    std::vector<std::thread> workers;
-    std::mutex m;
-    std::condition_variable cv_work, cv_idle;
-    std::function<void(int)> job;      // job(i) for i in [0, n_items)
-    int n_items = 0;
-    std::atomic<int> next{0}, done{0}; // items are claimed and counted without the lock (16 threads on one mutex
-                                       // cost more than the 5 us jobs they were handing out)
-    int active = 0;                    // workers inside the claim loop of the current generation (under m)
-    uint64_t generation = 0;
-    bool stop = false;
-    // A sleeping worker needs tens of microseconds to wake -- as long as the whole host half of a 64-chain sweep.  So a
-    // worker that has just finished keeps polling this counter for a short while (kSpinUs) before it blocks: while
-    // sweeps follow each other (an MCMC loop) the pool stays hot, an idle engine costs nothing.
-    std::atomic<uint64_t> gen_hint{0};
-    std::atomic<bool> stop_hint{false};
-    static constexpr int kSpinUs = 400;
-
-    explicit Pool(int n_threads) {
-        for (int t = 0; t < n_threads; ++t) workers.emplace_back([this] { loop(); });
-    }
-    ~Pool() {
-        { std::lock_guard<std::mutex> lk(m); stop = true; stop_hint.store(true); }
-        cv_work.notify_all();
-        for (auto& w : workers) w.join();
-    }
-    void claim_loop(const std::function<void()>* poll = nullptr) {
-        for (;;) {
-            const int i = next.fetch_add(1, std::memory_order_relaxed);
-            if (i >= n_items) break;
-            job(i);
-            done.fetch_add(1, std::memory_order_release);
-            if (poll) (*poll)();
-        }
-    }
-    void loop() {
-        uint64_t seen = 0;
-        std::unique_lock<std::mutex> lk(m);
-        for (;;) {
-            if (seen != 0) {                                         // (after the first job: poll before blocking)
-                lk.unlock();
-                const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(kSpinUs);
-                while (gen_hint.load(std::memory_order_acquire) == seen && !stop_hint.load(std::memory_order_relaxed) &&
-                       std::chrono::steady_clock::now() < t_end)
-                    __builtin_ia32_pause();
-                lk.lock();
-            }
-            cv_work.wait(lk, [&] { return stop || generation != seen; });
-            if (stop) return;
-            seen = generation;
-            ++active;                                                // run() does not touch job / n_items while active > 0
-            lk.unlock();
-            claim_loop();
-            lk.lock();
-            if (--active == 0) cv_idle.notify_all();
-        }
-    }
-    // run job(0..n-1) on the workers and the calling thread; returns when all are done.  `poll` (optional) is called by
-    // the CALLING thread after each of its own items and while it waits for the others (e.g. to issue HIP copies for
-    // the items that are finished: HIP calls stay on one thread)
-    void run(int n, std::function<void(int)> f, const std::function<void()>* poll = nullptr) {
-        {
-            std::unique_lock<std::mutex> lk(m);
-            cv_idle.wait(lk, [&] { return active == 0; });           // (a worker that woke late for the previous run)
-            job = std::move(f); n_items = n;
-            done.store(0, std::memory_order_relaxed); next.store(0, std::memory_order_relaxed);
-            ++generation;
-            gen_hint.store(generation, std::memory_order_release);
-        }
-        cv_work.notify_all();
-        claim_loop(poll);
-        while (done.load(std::memory_order_acquire) < n) {                          // (jobs are microseconds long)
-            if (poll) (*poll)();
-            __builtin_ia32_pause();
-        }
-    }
-};
+struct sbe_engine::Pool : sbe_host::StepPool { using sbe_host::StepPool::StepPool; };
 
 namespace {
 
