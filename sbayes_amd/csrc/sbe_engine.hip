@@ -126,7 +126,9 @@ struct sbe_engine {
     // batched steps (sbe_step_batch): one lane per chain of the batch = its own payload block, result block,
     // per-feature buffer and change stamps (lane 0 of the single-step calls is the set of members above)
     struct Lane { uint8_t* h_payload; uint8_t* d_payload; uint8_t* h_step; uint8_t* d_step_host; float* d_pf;
-                  uint32_t* d_stamp; uint32_t step_id; };
+                  uint32_t* d_stamp; uint32_t step_id;
+                  int* d_status; };     // data-check words of THIS lane's kernels: a malformed proposal of one chain of a
+                                        // batch is reported for that chain only (lane 0 of the single steps: e->d_status)
     std::vector<Lane> lanes;
     uint8_t* d_batch_meta = nullptr; size_t batch_meta_bytes = 0;     // device copy of the batch's StepCore / StepFinish / slot lists
     // batched steps: the chains' payloads packed back to back in ONE pinned block and sent with ONE copy into device
@@ -939,6 +941,7 @@ int sbe_destroy(sbe_engine* e) {
         if (ln.h_step) (void)hipHostFree(ln.h_step);
         if (ln.d_pf) (void)hipFree(ln.d_pf);
         if (ln.d_stamp) (void)hipFree(ln.d_stamp);
+        if (ln.d_status) (void)hipFree(ln.d_status);
     }
     for (auto ev : e->d2h_events) (void)hipEventDestroy(ev);
     if (e->d_batch_meta) (void)hipFree(e->d_batch_meta);
@@ -2542,7 +2545,8 @@ struct CoreInputs {
 
 // the single-step calls' lane: the engine's own payload / result blocks
 sbe_engine::Lane lane0(sbe_engine* e) {
-    return sbe_engine::Lane{e->h_step_payload, e->d_step_payload, e->h_step, e->d_step_host, e->d_step_pf, e->d_step_stamp, e->step_id};
+    return sbe_engine::Lane{e->h_step_payload, e->d_step_payload, e->h_step, e->d_step_host, e->d_step_pf, e->d_step_stamp, e->step_id,
+                            e->d_status};
 }
 
 // kernel 1 of the one-call steps: candidate slot = current slot + inputs, count delta, every table.
@@ -2589,7 +2593,7 @@ int build_step_core(sbe_engine* e, sbe_engine::Lane& lane, int cur_slot, int can
     a.rows = in.rows;
     a.objects = in.objects;
     a.src_dst = e->d_src + (int64_t)cand_slot * N * e->Fp;
-    a.n_changed = in.n_changed; a.F = F; a.C = C; a.Fp = e->Fp; a.status = e->d_status;
+    a.n_changed = in.n_changed; a.F = F; a.C = C; a.Fp = e->Fp; a.status = lane.d_status;
     // tile blocks
     a.state = e->d_state; a.gid_cur = g_cur;
     a.ids_new = reinterpret_cast<const uint16_t*>(in.ids_new);
@@ -2646,7 +2650,7 @@ StepFinish make_step_finish_lane(sbe_engine* e, const sbe_engine::Lane& lane) {
     StepFinish fin{};
     fin.per_feature = lane.d_pf;
     fin.group_out = reinterpret_cast<double*>(lane.d_step_host);
-    fin.status = e->d_status;
+    fin.status = lane.d_status;
     fin.status_out = reinterpret_cast<int*>(lane.d_step_host + (size_t)e->Gtot * sizeof(double));
     fin.changed = nullptr; fin.stamp = lane.d_stamp; fin.step_id = lane.step_id;
     fin.changed_out = lane.d_step_host + (size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int);
@@ -2657,13 +2661,15 @@ StepFinish make_step_finish(sbe_engine* e) { return make_step_finish_lane(e, lan
 
 // after the synchronisation that ends a one-call step: data checks, then the results out of the mapped block
 int read_step_results_lane(sbe_engine* e, const uint8_t* h_step, int cand_slot, double* group_logliks_out, double* mixture_out,
-                      uint8_t* changed_groups_out, const char* bad_norm_what) {
+                      uint8_t* changed_groups_out, const char* bad_norm_what, int* d_status = nullptr, int chain = -1) {
     const int* hst = reinterpret_cast<const int*>(h_step + (size_t)e->Gtot * sizeof(double));
     if (hst[ST_BAD_NORMALIZE] || hst[ST_MULTI_SOURCE]) {
         const int bad_norm = hst[ST_BAD_NORMALIZE], multi_src = hst[ST_MULTI_SOURCE];
-        (void)hipMemsetAsync(e->d_status + ST_BAD_NORMALIZE, 0, 2 * sizeof(int), e->stream);
-        if (bad_norm) return fail(e, SBE_ERR_DATA, "normalize: %d %s have a non-positive sum (sbayes/util.py:1006 assert)", bad_norm, bad_norm_what);
-        return fail(e, SBE_ERR_DATA, "source is not one-hot over components in %d observations", multi_src);
+        (void)hipMemsetAsync((d_status ? d_status : e->d_status) + ST_BAD_NORMALIZE, 0, 2 * sizeof(int), e->stream);
+        char who[32] = "";
+        if (chain >= 0) snprintf(who, sizeof who, "chain %d: ", chain);
+        if (bad_norm) return fail(e, SBE_ERR_DATA, "%snormalize: %d %s have a non-positive sum (sbayes/util.py:1006 assert)", who, bad_norm, bad_norm_what);
+        return fail(e, SBE_ERR_DATA, "%ssource is not one-hot over components in %d observations", who, multi_src);
     }
     memcpy(group_logliks_out, h_step, (size_t)e->Gtot * sizeof(double));
     if (changed_groups_out) memcpy(changed_groups_out, h_step + (size_t)e->Gtot * sizeof(double) + ST_WORDS * sizeof(int), (size_t)e->Gtot);
@@ -2903,6 +2909,8 @@ int ensure_lanes(sbe_engine* e, int n) {
         HIPCHK(e, hipMalloc((void**)&ln.d_pf, (size_t)e->Gtot * e->F * sizeof(float)));
         HIPCHK(e, hipMalloc((void**)&ln.d_stamp, (size_t)e->Gtot * sizeof(uint32_t)));
         HIPCHK(e, hipMemsetAsync(ln.d_stamp, 0, (size_t)e->Gtot * sizeof(uint32_t), e->stream));
+        HIPCHK(e, hipMalloc((void**)&ln.d_status, ST_WORDS * sizeof(int)));
+        HIPCHK(e, hipMemsetAsync(ln.d_status, 0, ST_WORDS * sizeof(int), e->stream));
         ln.step_id = 0;
         e->lanes.push_back(ln);
     }
@@ -3082,11 +3090,16 @@ int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const 
     mark();
     HIPCHK(e, hipStreamSynchronize(e->stream));
     mark();
+    // every chain's results are delivered; a chain whose proposal was malformed (its own data-check words) is reported
+    // by index after that -- the other chains' outputs stay usable
+    int first_bad = SBE_OK;
+    std::string first_msg;
     for (int i = 0; i < n_chains; ++i) {
         rc = read_step_results_lane(e, e->lanes[i].h_step, cand_slots[i], group_logliks_out + (size_t)i * e->Gtot, mixture_out + i,
-                               changed_groups_out ? changed_groups_out + (size_t)i * e->Gtot : nullptr, "rows");
-        if (rc) return rc;
+                               changed_groups_out ? changed_groups_out + (size_t)i * e->Gtot : nullptr, "rows", e->lanes[i].d_status, i);
+        if (rc && !first_bad) { first_bad = rc; first_msg = e->last_error; }
     }
+    if (first_bad) return fail(e, first_bad, "%s", first_msg.c_str());
     mark();
     if (timing && ntp == 10) {
         auto us = [&](int a, int b) { return std::chrono::duration<double, std::micro>(tp[b] - tp[a]).count(); };

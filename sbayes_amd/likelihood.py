@@ -12,6 +12,7 @@ fallback: without the HIP library / a GPU these functions raise.
 """
 from __future__ import annotations
 
+import weakref
 from types import SimpleNamespace
 
 import numpy as np
@@ -158,11 +159,27 @@ class NormalizedWeights(np.lib.mixins.NDArrayOperatorsMixin):
 
     __array_priority__ = 100
 
-    def __init__(self, weights, has_components, features=None):
+    def __init__(self, weights, has_components, features=None, owner=None):
         self._weights = np.array(weights, dtype=np.float32)              # private snapshots: evaluation may come later
         self._has_components = np.array(has_components, dtype=bool)
         self._features = features
         self._full = None
+        try:                                                              # the sample these weights were derived from
+            self._owner = weakref.ref(owner) if owner is not None else None
+        except TypeError:
+            self._owner = None
+
+    def sample_if_current(self):
+        """The sample update_weights() derived this array from, if it still has these weights and this has_components
+        (device forms that work on the sample's resident state -- source_lh_by_feature -- use it instead of the
+        [N, F, C] array); None otherwise."""
+        sample = self._owner() if self._owner is not None else None
+        if sample is None:
+            return None
+        if not (np.array_equal(np.asarray(sample.weights.value, dtype=np.float32), self._weights)
+                and np.array_equal(sample.cache.has_components.value, self._has_components)):
+            return None
+        return sample
 
     # -- what the consumers look at without needing values
     @property
@@ -243,5 +260,5 @@ def update_weights(sample, caching=True, features=None):
     returned as a lazily materialised array (NormalizedWeights)."""
     cache = sample.cache.weights_normalized
     if (not caching) or cache.is_outdated():
-        cache.update_value(NormalizedWeights(sample.weights.value, sample.cache.has_components.value, features))
+        cache.update_value(NormalizedWeights(sample.weights.value, sample.cache.has_components.value, features, owner=sample))
     return cache.value

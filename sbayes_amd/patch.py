@@ -21,9 +21,9 @@ has to cross PCIe for them:
   sbayes.model.prior.SourcePrior.__call__                                 (prior.py:573-611; per-object cache protocol kept)
   sbayes.sampling.operators.ClusterJump.get_jump_lh                       (operators.py:1679-1722, with
                                                                             expected_confounder_features :1342-1379)
-  sbayes.sampling.operators.GibbsSampleWeights._propose                   (operators.py:597-636) runs UNCHANGED, but
-        with update_weights / source_lh_by_feature (operators.py:677-685) served by the device while it runs: the two
-        [N, F, C] normalised-weight arrays it materialises per call are never built
+  sbayes.sampling.operators.GibbsSampleWeights.source_lh_by_feature       (operators.py:677-685; _propose :597-636 runs
+        UNCHANGED: update_weights hands it a lazily materialised array that knows its sample, and this static method
+        evaluates that sample's resident state on the device -- the two [N, F, C] arrays per call are never built)
 Proposal logic, RNG use and everything else of the operators stay the reference's."""
 from __future__ import annotations
 
@@ -94,7 +94,9 @@ def install(operators=False):
 
     def swap(mod, name, new):
         if hasattr(mod, name) and getattr(mod, name) is not new:
-            _SAVED.append((mod, name, getattr(mod, name)))
+            # (a class attribute is saved as it sits in the class dict: a staticmethod must come back as one)
+            old = mod.__dict__[name] if inspect.isclass(mod) and name in mod.__dict__ else getattr(mod, name)
+            _SAVED.append((mod, name, old))
             setattr(mod, name, new)
 
     for mod in (lik, model_pkg, model_mod):
@@ -169,28 +171,25 @@ def _install_operator_forms(swap):
         return my_ops.jump_lh(self.model, sample, i_source_cluster, i_target_cluster, self.temperature,
                               self.prior_temperature)
 
-    class _DeviceWeights:
-        """What update_weights(sample) returns while GibbsSampleWeights._propose runs: a handle on the sample whose
-        normalised weights are meant (the device derives them from the resident patterns; nothing is materialised)."""
-        def __init__(self, sample):
-            self.sample = sample
+    reference_source_lh = ref_ops.GibbsSampleWeights.__dict__["source_lh_by_feature"].__func__
 
-    reference_propose = ref_ops.GibbsSampleWeights._propose
-
-    def gibbs_weights_propose(self, sample, **kwargs):
-        """GibbsSampleWeights._propose (operators.py:597-636): the reference's own method body, called as is; for its
-        duration `update_weights` yields a handle instead of the [N, F, C] array and `source_lh_by_feature` evaluates
-        that handle's sample on the device."""
-        model = self.model
-        saved_update, saved_lh = ref_ops.update_weights, ref_ops.GibbsSampleWeights.__dict__["source_lh_by_feature"]
-        ref_ops.update_weights = lambda s, caching=True: _DeviceWeights(s)
-        ref_ops.GibbsSampleWeights.source_lh_by_feature = staticmethod(
-            lambda source, weights, na_features: my_ops.source_lh_by_feature(model, weights.sample))
-        try:
-            return reference_propose(self, sample, **kwargs)
-        finally:
-            ref_ops.update_weights = saved_update
-            ref_ops.GibbsSampleWeights.source_lh_by_feature = saved_lh
+    def source_lh_by_feature(source, weights, na_features):
+        """GibbsSampleWeights.source_lh_by_feature (operators.py:677-685).  The reference's _propose (:597-636) runs
+        UNCHANGED and hands over `update_weights(sample)` -- here a lazily materialised NormalizedWeights that knows its
+        sample: when `source` and the weights are that sample's current ones, the per-feature sums come from the
+        sample's RESIDENT state on the device (changed source rows, group ids and F*C weights go up, F floats come
+        back; the [N, F, C] array is never built).  Any other argument combination is served by the reference's own
+        expression on the materialised array.  Installed once, no name is swapped while a proposal runs."""
+        from .binding import _bind_slot
+        from .likelihood import NormalizedWeights
+        from . import registry
+        sample = weights.sample_if_current() if isinstance(weights, NormalizedWeights) else None
+        if sample is not None and source is sample.source.value:
+            eng = registry.engine_for_features(np.shape(source)[1])
+            if eng is not None and eng.n_objects == np.shape(source)[0] and eng.n_components == np.shape(source)[2]:
+                _bind_slot(eng, None, sample, 0, with_source=True)
+                return eng.source_lh_by_feature(0)
+        return reference_source_lh(source, np.asarray(weights), na_features)
 
     # SourcePrior.__call__ (prior.py:573-611): per-object log prior from the device, the reference's cache protocol kept
     try:
@@ -221,7 +220,7 @@ def _install_operator_forms(swap):
         if hasattr(owner, name):
             _check_mirrored(owner, name)
     swap(ref_ops.ClusterJump, "get_jump_lh", get_jump_lh)
-    swap(ref_ops.GibbsSampleWeights, "_propose", gibbs_weights_propose)
+    swap(ref_ops.GibbsSampleWeights, "source_lh_by_feature", staticmethod(source_lh_by_feature))
     swap(ref_ops.AlterCluster, "compute_cluster_posterior", compute_cluster_posterior)
     swap(ref_ops.AlterClusterWide, "compute_raw_cluster_probs", compute_raw_cluster_probs)
     swap(ref_ops.GibbsSampleSource, "calculate_source_posterior", calculate_source_posterior)

@@ -415,3 +415,41 @@ def test_incremental_pattern_and_tuple_update_equals_full_derivation(name):
         for eng in (ea, eb):
             got = eng.mixture_loglik(cur)
             assert abs(got - want[3]) <= 1e-10 * abs(want[3])
+
+
+def test_step_batch_reports_the_malformed_chain_by_index():
+    """every chain of a batch has its own data-check words.  One chain's proposal carries a source row with
+    two components set: the error names THAT chain, and the other chains' results were delivered all the same."""
+    wl = make_workload("cfg1")
+    feats = wl.features
+    N, F, S = wl.shape
+    C = wl.n_components
+    B = 5
+    n_groups = [g.shape[0] for g in wl.groups]
+    with Engine(feats, n_groups, n_slots=2 * B) as eb, Engine(feats, n_groups, n_slots=2) as es:
+        for eng in (eb, es):
+            for c in range(C):
+                eng.set_concentration(c, wl.concentration[c])
+        for i in range(B):
+            eb.load_state(2 * i, wl.groups, wl.weights, source=wl.source)
+            for c in range(C):
+                eb.update_probs(2 * i, c)
+        es.load_state(0, wl.groups, wl.weights, source=wl.source)
+        for c in range(C):
+            es.update_probs(0, c)
+        es.mixture_loglik(0)
+        objs = np.array([1, 4], dtype=np.int32)
+        good = wl.source[objs].copy()
+        bad = good.copy()
+        bad[0, 0, :] = True                                              # two components set in one observation
+        rows = np.concatenate([bad if i == 3 else good for i in range(B)])
+        ptr = np.arange(0, 2 * B + 1, 2, dtype=np.int32)
+        cur = np.arange(0, 2 * B, 2, dtype=np.int32)
+        with pytest.raises(EngineError, match="chain 3: source is not one-hot") as exc:
+            eb.step_batch(cur, cur + 1, None, None, ptr, np.tile(objs, B), rows)
+        assert "chain 3" in str(exc.value)
+        # the batch still works afterwards, and a clean sweep equals the single step
+        glh, mix, changed = eb.step_batch(cur, cur + 1, None, None, ptr, np.tile(objs, B), np.concatenate([good] * B))
+        g1, m1, c1 = es.step(0, 1, changed_objects=objs, source_rows=good)
+        for i in range(B):
+            assert np.array_equal(glh[i], g1) and abs(mix[i] - m1) <= 1e-13 * abs(m1)

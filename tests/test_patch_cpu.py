@@ -36,3 +36,34 @@ def test_install_and_uninstall_swap_names():
         patch.uninstall()
     assert (ref_model.Likelihood, ref_cond.compute_component_likelihood, ref_cond.likelihood_per_component,
             ref_counts.update_feature_counts, ref_ops.update_weights) == orig
+
+
+def test_operator_forms_install_and_uninstall():
+    """install(operators=True): the prior module's names and SourcePrior.__call__ are swapped, the
+    static method GibbsSampleWeights.source_lh_by_feature is replaced ONCE (no name is swapped while a proposal runs:
+    ADVICE r2) and comes back as a staticmethod on uninstall."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import _ref_stubs
+    _ref_stubs.install()
+    import sbayes.model.prior as ref_prior
+    import sbayes.sampling.operators as ref_ops
+
+    from sbayes_amd import likelihood, patch
+    orig_static = ref_ops.GibbsSampleWeights.__dict__["source_lh_by_feature"]
+    orig_propose = ref_ops.GibbsSampleWeights.__dict__["_propose"]
+    orig_sp = ref_prior.SourcePrior.__dict__["__call__"]
+    orig_uw = ref_prior.update_weights
+    assert isinstance(orig_static, staticmethod)
+    patch.install(operators=True)
+    try:
+        assert ref_prior.update_weights is likelihood.update_weights
+        assert ref_prior.normalize_weights is likelihood.normalize_weights
+        assert ref_prior.SourcePrior.__dict__["__call__"] is not orig_sp
+        assert isinstance(ref_ops.GibbsSampleWeights.__dict__["source_lh_by_feature"], staticmethod)
+        assert ref_ops.GibbsSampleWeights.__dict__["source_lh_by_feature"] is not orig_static
+        assert ref_ops.GibbsSampleWeights.__dict__["_propose"] is orig_propose          # the reference's own body runs
+        assert "SourcePrior.__call__" in patch.MIRRORED_SOURCES
+    finally:
+        patch.uninstall()
+    assert ref_ops.GibbsSampleWeights.__dict__["source_lh_by_feature"] is orig_static
+    assert ref_prior.SourcePrior.__dict__["__call__"] is orig_sp and ref_prior.update_weights is orig_uw
