@@ -47,7 +47,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 N_SIMDS = 1024             # 256 CUs x 4 SIMD-32
 NOMINAL_CLOCK_GHZ = 2.4    # MI355X_MICROARCH.md "Max clock"
-PMC_FILE = "profiles/r2/pmc_summary.json"
+PMC_FILE = "profiles/r3/pmc_summary.json"
 TRAFFIC_FILE = "profiles/traffic_latest.json"
 
 
@@ -439,7 +439,7 @@ def static_profile_figures(workload, kernel, B, kern_us):
                                                                   "passes of an earlier run of this command)"}
         except Exception:
             pass
-    for cand in (PMC_FILE, "profiles/r1b/pmc_summary.json"):
+    for cand in (PMC_FILE, "profiles/r2/pmc_summary.json"):
         pf = REPO / cand
         if not pf.exists():
             continue
