@@ -396,9 +396,31 @@ def secondary_figures(eng, wl, B, args):
         batch.accept()
         return res
     sweeps_per_s = _rate(batched_sweep, 0.5, 20)
+    out["f2_batched_matrix_form_steps_per_s"] = round(sweeps_per_s * n_chains, 1)
+    out["f2_batched_matrix_form_sweep_us"] = round(1e6 / sweeps_per_s, 1)
+    # the same sweeps in DELTA form (sbe_step_batch_delta, round 3): what an operator produces -- the moved objects with
+    # their new cluster, the changed source rows -- goes in as it is; the candidates are patched in O(delta)
+    delta_sweeps = []
+    for cl, ptr, objs_cat, rows in sweeps:
+        mptr, mobj, mcl = [0], [], []
+        for i in range(n_chains):
+            moved = np.flatnonzero((cl[i] != wl.clusters).any(axis=0)).astype(np.int32)
+            mobj.append(moved)
+            mcl.append(np.where(cl[i][:, moved].any(axis=0), cl[i][:, moved].argmax(axis=0), -1).astype(np.int32))
+            mptr.append(mptr[-1] + moved.size)
+        delta_sweeps.append((np.array(mptr, dtype=np.int32), np.concatenate(mobj), np.concatenate(mcl), ptr, objs_cat, rows))
+
+    def batched_delta_sweep():
+        mptr, mobj, mcl, ptr, objs_cat, rows = delta_sweeps[state["k"] % 4]
+        state["k"] += 1
+        res = batch.step_delta(mptr, mobj, mcl, ptr, objs_cat, rows)
+        batch.accept()                                      # (like the matrix-form loop: every proposal is accepted)
+        return res
+    sweeps_per_s = _rate(batched_delta_sweep, 0.5, 20)
     out["f2_batched_steps_per_s"] = round(sweeps_per_s * n_chains, 1)
     out["f2_batched_chains"] = n_chains
     out["f2_batched_sweep_us"] = round(1e6 / sweeps_per_s, 1)
+    out["f2_batched_form"] = "delta (sbe_step_batch_delta); matrix form: f2_batched_matrix_form_*"
     batch.close()
     return out
 

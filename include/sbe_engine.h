@@ -413,6 +413,22 @@ int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const 
                    const uint8_t* weights_mask, double* group_logliks_out, double* mixture_out,
                    uint8_t* changed_groups_out);
 
+/* The same batched step with the proposals in DELTA form (round 3; what an MCMC operator actually produces): per chain
+ * the objects that change cluster with their new cluster index (-1: leaves every cluster; CSR by moved_ptr) and the
+ * objects whose source rows change, each listed once (CSR by rows_ptr).  A chain's two slots differ only in what its last
+ * step changed, so the candidate is built by patching -- host mirror, device id arrays, source rows -- in O(delta): no
+ * [K][N] matrix is scanned, no slot state copied, no [N]-sized array packed or sent.  Chains whose slots were touched
+ * by another call since their last step (or that step for the first time), and steps that change the SET of
+ * has_components patterns or overflow the tuple table, run through sbe_step_batch internally; results are the same
+ * (counts, tables, per-group values, flags bit for bit; the mixture scalar to rounding).  Outputs as sbe_step_batch. */
+int sbe_step_batch_delta(sbe_engine* e, int n_chains, const int32_t* cur_slots, const int32_t* cand_slots,
+                         const int32_t* moved_ptr /* [n_chains + 1] */, const int32_t* moved_objects,
+                         const int32_t* moved_cluster, const int32_t* rows_ptr /* [n_chains + 1] */,
+                         const int32_t* changed_objects, const uint8_t* source_rows /* [total][F][C] bool */,
+                         const float* weights /* [n_chains][F][C] or NULL */, const uint8_t* weights_mask /* [n_chains] or NULL */,
+                         double* group_logliks_out /* [n_chains][G_total] */, double* mixture_out /* [n_chains] */,
+                         uint8_t* changed_groups_out /* [n_chains][G_total] or NULL */);
+
 /* One MCMC step of the Gibbs source operator on the resident state (GibbsSampleSource._propose,
    sbayes/sampling/operators.py:495-552, + the likelihoods the MH ratio needs): candidate slot = current slot with the
    source of the listed objects redrawn from its posterior on the device (z: the caller's uniforms [n_sub][F], drawn

@@ -109,6 +109,9 @@ PROTOTYPES = {
                                   ct.POINTER(ct.c_double), ct.c_void_p]),
     "sbe_step_batch": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p,
                                   ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p]),
+    "sbe_step_batch_delta": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p,
+                                        ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p,
+                                        ct.c_void_p]),
     "sbe_step": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p,
                             ct.c_void_p, ct.c_void_p, ct.c_void_p]),
     "sbe_test_fast_log": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p]),

@@ -135,6 +135,8 @@ struct sbe_engine {
     // memory (64 chains reading ~25 KB each in place over PCIe made k_step_core_batch PCIe-bound: 160 us)
     uint8_t* h_batch_payload = nullptr; uint8_t* d_batch_payload = nullptr; size_t batch_payload_bytes = 0;
     std::vector<Slot> batch_cands;                                    // candidates' host state, storage reused across calls
+    std::vector<std::vector<int32_t>> batch_moved;                    // per chain of a batch: the objects its step moved
+    std::vector<int32_t> step_moved;                                  // ... of the single step
     struct Pool;                                                      // host worker threads of sbe_step_batch (lazily started)
     Pool* pool = nullptr;
     uint8_t* d_scratch = nullptr;  size_t scratch_bytes = 0;     // general staging
@@ -155,6 +157,10 @@ struct sbe_engine {
     // falls back to the full copy.  Kept outside `Slot` (slots are assigned wholesale: candidate = copy of current).
     struct SrcSync { uint64_t version = 1; int peer = -1; uint64_t peer_version = 0, own_version = 0; std::vector<int32_t> diff; };
     std::vector<SrcSync> src_sync;
+    // the same bookkeeping for the per-object id arrays (group id of component 0, pattern id, tuple id / offset) on the
+    // device AND in the host mirror `Slot`: `diff` = the objects whose entries differ between the two slots of a chain
+    // (sbe_step_batch_delta patches those entries instead of re-deriving / copying whole arrays)
+    std::vector<SrcSync> ids_sync;
 
     int64_t table_elems() const { return (int64_t)Gtot * F * S; }
     int64_t tile_tab_elems() const { return (int64_t)(Gtot + 1) * S * ft; }
@@ -165,6 +171,7 @@ struct sbe_engine {
 
 namespace {
 inline void bump_src(sbe_engine* e, int slot) { ++e->src_sync[slot].version; }
+inline void bump_ids(sbe_engine* e, int slot) { ++e->ids_sync[slot].version; }
 }
 
 struct sbe_engine::Pool : sbe_host::StepPool { using sbe_host::StepPool::StepPool; };
@@ -1024,6 +1031,7 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     e->conc_set.assign(n_components, 0);
     e->slots.resize(n_slots);
     e->src_sync.resize(n_slots);
+    e->ids_sync.resize(n_slots);
     for (Slot& s : e->slots) {
         s.h_gid.assign((size_t)n_components * n_objects, kNoGroup);
         s.probs_set.assign(n_components, 0);
@@ -1304,6 +1312,7 @@ static int set_gid_common(sbe_engine* e, int slot, int component, const std::vec
                              (size_t)e->N * sizeof(uint16_t)); if (_urc) return _urc; }
     s.patterns_dirty = true;
     s.group_epoch = ++e->epoch_counter;
+    bump_ids(e, slot);
     s.groups_set = true;   // components never set keep "no group" ids
     return SBE_OK;
 }
@@ -2541,6 +2550,10 @@ struct CoreInputs {
     // source array of the candidate slot: the whole array is copied from the current slot (full_src_copy), or only the
     // rows in which the candidate slot is known to differ from it (sbe_engine::SrcSync)
     bool full_src_copy = true; const int32_t* stale = nullptr; int n_stale = 0;
+    // delta layout (sbe_step_batch_delta): patched id arrays, per-subset-entry row / cluster id (StepCore)
+    const int32_t* patch_n = nullptr; const uint16_t* patch_gid = nullptr; const uint8_t* patch_pid = nullptr;
+    const uint8_t* patch_tid = nullptr; int n_patch = -1;
+    const int16_t* sub_row = nullptr; const uint16_t* sub_gid0 = nullptr;
 };
 
 // the single-step calls' lane: the engine's own payload / result blocks
@@ -2566,8 +2579,9 @@ int build_step_core(sbe_engine* e, sbe_engine::Lane& lane, int cur_slot, int can
         a.cs.end[a.cs.n++] = run;
     };
     uint16_t* g_cur = e->d_gid + (int64_t)cur_slot * C * Np;
-    // gid: component 0 from the inputs when the clusters changed; the other components from the current slot
-    {
+    const bool delta = in.n_patch >= 0;          // sbe_step_batch_delta: the per-object id arrays are patched, not copied
+    if (!delta) {
+        // gid: component 0 from the inputs when the clusters changed; the other components from the current slot
         uint16_t* g_cand = e->d_gid + (int64_t)cand_slot * C * Np;
         a.cs.src[a.cs.n] = reinterpret_cast<const uint32_t*>(regroup ? in.ids_new : (const void*)g_cur);
         a.cs.dst[a.cs.n] = reinterpret_cast<uint32_t*>(g_cand);
@@ -2577,13 +2591,18 @@ int build_step_core(sbe_engine* e, sbe_engine::Lane& lane, int cur_slot, int can
             a.cs.dst[a.cs.n] = reinterpret_cast<uint32_t*>(g_cand + Np);
             run += (uint32_t)((int64_t)(C - 1) * Np * 2 / 4); a.cs.end[a.cs.n++] = run;
         }
+        seg(e->d_pid, (int64_t)Np, regroup ? in.pid : nullptr);
+        seg(e->d_tid, (int64_t)Np, regroup ? in.tid : nullptr);
+        seg(e->d_toff, (int64_t)Np, regroup ? in.toff : nullptr);
     }
-    seg(e->d_pid, (int64_t)Np, regroup ? in.pid : nullptr);
-    seg(e->d_tid, (int64_t)Np, regroup ? in.tid : nullptr);
-    seg(e->d_toff, (int64_t)Np, regroup ? in.toff : nullptr);
-    seg(e->d_tuple_g, (int64_t)kMaxTuples * kMaxComponents, regroup ? in.tuple_g : nullptr);
-    seg(e->d_tuple_p, (int64_t)kMaxTuples, regroup ? in.tuple_p : nullptr);
-    seg(e->d_patbits, (int64_t)e->Pmax, regroup ? in.patbits : nullptr);
+    a.n_patch = in.n_patch; a.patch_n = in.patch_n; a.patch_gid = in.patch_gid; a.patch_pid = in.patch_pid; a.patch_tid = in.patch_tid;
+    a.gid_dst = e->d_gid + (int64_t)cand_slot * C * Np; a.pid_dst = e->d_pid + (int64_t)cand_slot * Np;
+    a.tid_dst = e->d_tid + (int64_t)cand_slot * Np; a.toff_dst = e->d_toff + (int64_t)cand_slot * Np;
+    a.toff_mul = (uint32_t)(e->S + 1) * 512u;
+    a.sub_row = in.sub_row; a.sub_gid0 = in.sub_gid0;
+    seg(e->d_tuple_g, (int64_t)kMaxTuples * kMaxComponents, in.tuple_g);
+    seg(e->d_tuple_p, (int64_t)kMaxTuples, in.tuple_p);
+    seg(e->d_patbits, (int64_t)e->Pmax, in.patbits);
     seg(e->d_weights, (int64_t)F * C, in.weights);
     a.src_seg = a.cs.n;
     if (in.full_src_copy) seg(e->d_src, (int64_t)N * e->Fp, nullptr);
@@ -2616,7 +2635,7 @@ int build_step_core(sbe_engine* e, sbe_engine::Lane& lane, int cur_slot, int can
     a.n_tile_blocks = div_up(F, a.ftc);
     // weight blocks
     a.weights = in.weights ? reinterpret_cast<const float*>(in.weights) : e->d_weights + (int64_t)cur_slot * F * C;
-    a.pattern_bits = regroup ? reinterpret_cast<const uint32_t*>(in.patbits) : e->d_patbits + (int64_t)cur_slot * e->Pmax;
+    a.pattern_bits = in.patbits ? reinterpret_cast<const uint32_t*>(in.patbits) : e->d_patbits + (int64_t)cur_slot * e->Pmax;
     a.wpat = e->d_wpat + (int64_t)cand_slot * e->Pmax * F * C;
     a.wpat_t = e->d_wpat_t + (int64_t)cand_slot * e->wpat_t_elems();
     a.P = in.P; a.Pmax = e->Pmax; a.n_weight_blocks = div_up((int64_t)in.P * F, kBlock);
@@ -2721,7 +2740,7 @@ int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters
 // `cd` and read-only engine state, so the chains of a batch can be prepared by several host threads at once.
 static int prepare_step(sbe_engine* e, const sbe_engine::Lane& lane, int cur_slot, int cand_slot, const uint8_t* clusters,
                         const int32_t* changed_objects, int n_changed, const uint8_t* source_rows, const float* weights,
-                        Slot& cd, CoreInputs& in, std::string* err) {
+                        Slot& cd, CoreInputs& in, std::string* err, std::vector<int32_t>* moved_out = nullptr) {
     const int N = e->N, Np = e->Np, F = e->F, C = e->C;
     const Slot& cur = e->slots[cur_slot];
     cd = cur;                                 // host state of the candidate (committed by the caller)
@@ -2729,6 +2748,7 @@ static int prepare_step(sbe_engine* e, const sbe_engine::Lane& lane, int cur_slo
     static thread_local std::vector<int32_t> mv;                      // (no allocation per step: the chains of a batch are
     static thread_local std::vector<uint16_t> mv_old;                  //  prepared by pool threads)
     mv.clear(); mv_old.clear();
+    bool full_derive = false;
     const bool regroup = clusters != nullptr;
     if (regroup) {
         const int K = e->G[0];
@@ -2752,6 +2772,7 @@ static int prepare_step(sbe_engine* e, const sbe_engine::Lane& lane, int cur_slo
         // (slot never derived in full) or on request
         if (e->opt_step_derive == 1 || (int)mv.size() > N / 8 ||
             !update_patterns_and_tuples(e, cd, mv.data(), mv_old.data(), (int)mv.size())) {
+            full_derive = true;                        // pattern ranks / tuple numbers of ANY object may change
             derive_patterns(e, cd);
             if ((int)cd.patterns.size() > e->Pmax) {
                 char buf[160];
@@ -2763,6 +2784,10 @@ static int prepare_step(sbe_engine* e, const sbe_engine::Lane& lane, int cur_slo
         }
         cd.patterns_dirty = false;
         cd.group_epoch = ++e->epoch_counter;
+    }
+    if (moved_out) {
+        *moved_out = mv;
+        if (full_derive) moved_out->assign(1, -1);     // "every entry may differ": commit_ids_sync leaves no usable record
     }
     // ---- payload: packed in host-mapped pinned memory; the kernels read it in place (a few tens of KB over
     // PCIe, no copy engine in the chain).  Every step ends with a stream synchronisation, so the lane's buffer is
@@ -2835,6 +2860,20 @@ static int prepare_step(sbe_engine* e, const sbe_engine::Lane& lane, int cur_slo
     return SBE_OK;
 }
 
+// ... and its id arrays = the current slot's except the moved objects' entries
+static void commit_ids_sync(sbe_engine* e, int cur_slot, int cand_slot, const std::vector<int32_t>& moved) {
+    sbe_engine::SrcSync& rc = e->ids_sync[cand_slot];
+    sbe_engine::SrcSync& cu = e->ids_sync[cur_slot];
+    ++rc.version;
+    if (moved.size() == 1 && moved[0] < 0) {           // the candidate's tables were derived afresh (prepare_step): the two
+        rc.peer = cu.peer = -1;                        // slots' pattern / tuple numbering is unrelated from here on
+        rc.diff.clear(); cu.diff.clear();
+        return;
+    }
+    rc.peer = cur_slot; rc.peer_version = cu.version; rc.own_version = rc.version; rc.diff = moved;
+    cu.peer = cand_slot; cu.peer_version = rc.version; cu.own_version = cu.version; cu.diff = moved;
+}
+
 // after a one-call step was enqueued: the candidate's source = the current slot's except the rows the step wrote
 static void commit_src_sync(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* changed_objects, int n_changed) {
     sbe_engine::SrcSync& rc = e->src_sync[cand_slot];
@@ -2863,7 +2902,8 @@ static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* 
     CoreInputs in;
     {
         std::string err;
-        int rc = prepare_step(e, lane0(e), cur_slot, cand_slot, clusters, changed_objects, n_changed, source_rows, weights, cd, in, &err);
+        int rc = prepare_step(e, lane0(e), cur_slot, cand_slot, clusters, changed_objects, n_changed, source_rows, weights, cd, in, &err,
+                              &e->step_moved);
         if (rc) return fail(e, rc, "%s", err.c_str());
     }
     const auto t1 = std::chrono::steady_clock::now();
@@ -2871,6 +2911,7 @@ static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* 
     int rc = launch_step_core(e, cur_slot, cand_slot, in);
     if (rc) return rc;
     commit_src_sync(e, cur_slot, cand_slot, changed_objects, n_changed);
+    commit_ids_sync(e, cur_slot, cand_slot, e->step_moved);
     e->slots[cand_slot] = cd;
     // ---- kernels 2 + 3: fused mixture eval, reduction + step epilogue (mapped-memory results) -------------------
     StepFinish fin = make_step_finish(e);
@@ -2913,6 +2954,28 @@ int ensure_lanes(sbe_engine* e, int n) {
         HIPCHK(e, hipMemsetAsync(ln.d_status, 0, ST_WORDS * sizeof(int), e->stream));
         ln.step_id = 0;
         e->lanes.push_back(ln);
+    }
+    return SBE_OK;
+}
+}  // namespace
+
+namespace {
+int ensure_step_pool(sbe_engine* e) {
+    if (!e->pool) {
+        int nt = 7;                                                  // + the calling thread.  (Measured on a 16-CPU share:
+        // 64 chains 747 / 416 / 304 / 246 / 225 us per sweep with 1 / 2 / 4 / 8 / 16 threads; the workers poll while sweeps
+        // follow each other, so more threads than free cores is far worse than too few: 32 threads 3.5 ms.)
+        if (const char* env = getenv("SBE_STEP_THREADS")) nt = std::max(0, atoi(env) - 1);
+        // this process' share of the host: the CPUs it may run on, divided by the ranks of the node (one process per
+        // GPU, torch.distributed.run exports LOCAL_WORLD_SIZE) -- eight ranks x eight polling threads on one host is
+        // exactly the oversubscribed regime above
+        int cpus = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = std::min(cpus > 0 ? cpus : CPU_COUNT(&set), CPU_COUNT(&set));
+        int local_world = 1;
+        if (const char* env = getenv("LOCAL_WORLD_SIZE")) local_world = std::max(1, atoi(env));
+        nt = std::min<int>(nt, std::max(0, cpus / local_world - 1));
+        e->pool = new sbe_engine::Pool(nt);
     }
     return SBE_OK;
 }
@@ -2963,25 +3026,12 @@ int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const 
         if (e->slots[cur_slots[i]].patterns_dirty) { int rc = upload_patterns_and_weights(e, cur_slots[i]); if (rc) return rc; }
     int rc = ensure_lanes(e, n_chains);
     if (rc) return rc;
-    if (!e->pool) {
-        int nt = 7;                                                  // + the calling thread.  (Measured on a 16-CPU share:
-        // 64 chains 747 / 416 / 304 / 246 / 225 us per sweep with 1 / 2 / 4 / 8 / 16 threads; the workers poll while sweeps
-        // follow each other, so more threads than free cores is far worse than too few: 32 threads 3.5 ms.)
-        if (const char* env = getenv("SBE_STEP_THREADS")) nt = std::max(0, atoi(env) - 1);
-        // this process' share of the host: the CPUs it may run on, divided by the ranks of the node (one process per
-        // GPU, torch.distributed.run exports LOCAL_WORLD_SIZE) -- eight ranks x eight polling threads on one host is
-        // exactly the oversubscribed regime above
-        int cpus = (int)std::thread::hardware_concurrency();
-        cpu_set_t set;
-        if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = std::min(cpus > 0 ? cpus : CPU_COUNT(&set), CPU_COUNT(&set));
-        int local_world = 1;
-        if (const char* env = getenv("LOCAL_WORLD_SIZE")) local_world = std::max(1, atoi(env));
-        nt = std::min<int>(nt, std::max(0, cpus / local_world - 1));
-        e->pool = new sbe_engine::Pool(nt);
-    }
+    rc = ensure_step_pool(e);
+    if (rc) return rc;
     mark();
     // ---- host halves, in parallel over the chains ---------------------------------------------------------------
     if ((int)e->batch_cands.size() < n_chains) e->batch_cands.resize(n_chains);
+    if ((int)e->batch_moved.size() < n_chains) e->batch_moved.resize(n_chains);
     std::vector<Slot>& cds = e->batch_cands;
     std::vector<CoreInputs> ins(n_chains);
     // payload blocks: chain i's used prefix (fixed sections + its changed rows) at a running offset of one pinned block
@@ -3047,7 +3097,7 @@ int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const 
             lane.d_payload = e->d_batch_payload + pay_off[i];
             rcs[i] = prepare_step(e, lane, cur_slots[i], cand_slots[i], regroup ? clusters + (size_t)i * K * N : nullptr,
                                   nr ? changed_objects + r0 : nullptr, nr, nr ? source_rows + (size_t)r0 * F * C : nullptr,
-                                  reweight ? weights + (size_t)i * F * C : nullptr, cds[i], ins[i], &errs[i]);
+                                  reweight ? weights + (size_t)i * F * C : nullptr, cds[i], ins[i], &errs[i], &e->batch_moved[i]);
             chunk_done[j / kCopyChunk].fetch_add(1, std::memory_order_release);
         }, &poll);
         send_ready();
@@ -3079,6 +3129,7 @@ int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const 
         for (int i = i0; i < i1; ++i) {
             commit_src_sync(e, cur_slots[i], cand_slots[i], changed_objects ? changed_objects + rows_ptr[i] : nullptr,
                             rows_ptr[i + 1] - rows_ptr[i]);
+            commit_ids_sync(e, cur_slots[i], cand_slots[i], e->batch_moved[i]);
             std::swap(e->slots[cand_slots[i]], cds[i]);                               // (swap: both keep their storage)
         }
         if (part == 0) mark();
@@ -3107,6 +3158,363 @@ int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const 
                         "slot moves %.1f | mixture + reduce launches and the other parts %.1f | wait for the device %.1f | read results %.1f us\n", n_chains,
                 us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7), us(7, 8), us(8, 9));
     }
+    return SBE_OK;
+}
+
+// ---- batched step, DELTA form (round 3) -------------------------------------------------------
+// The same step as sbe_step_batch with the proposal handed over as what it is -- a few moved objects:
+//     moved_objects / moved_cluster (CSR by moved_ptr): objects that change cluster and their new cluster (-1: none)
+//     changed_objects / source_rows (CSR by rows_ptr):  objects whose source rows change, each listed once
+// A chain's two slots differ only in what its LAST step changed (SrcSync records for the source rows and for the id
+// arrays), so the candidate is built by PATCHING: host mirror, device id arrays and source rows in O(delta); no
+// [K][N] matrix is scanned, no slot state copied, no [N]-sized array packed or sent.  A chain whose records do not hold
+// (first sweep, a slot touched by another call) or whose step changes the SET of has_components patterns / overflows
+// the tuple table goes through sbe_step_batch itself (cluster matrix rebuilt from the ids); results are identical.
+namespace {
+
+struct DeltaPlan {           // per chain: payload section offsets (bytes from the chain's base) and capacities
+    size_t subset, sub_row, sub_gid0, patch_n, patch_gid, patch_pid, patch_tid, stale, objects, tuple_g, tuple_p, patbits, weights, rows, total;
+};
+
+inline size_t al16(size_t v) { return (v + 15) / 16 * 16; }
+
+DeltaPlan plan_delta(const sbe_engine* e, int n_mv, int n_changed, int n_last_ids, int n_last_src, bool reweight) {
+    DeltaPlan p{};
+    const size_t n_sub = (size_t)n_mv + n_changed, n_patch = (size_t)n_mv + n_last_ids;
+    size_t o = 0;
+    p.subset = o;    o = al16(o + n_sub * 4);
+    p.sub_row = o;   o = al16(o + n_sub * 2);
+    p.sub_gid0 = o;  o = al16(o + n_sub * 2);
+    p.patch_n = o;   o = al16(o + n_patch * 4);
+    p.patch_gid = o; o = al16(o + n_patch * 2);
+    p.patch_pid = o; o = al16(o + n_patch);
+    p.patch_tid = o; o = al16(o + n_patch);
+    p.stale = o;     o = al16(o + (size_t)n_last_src * 4);
+    p.objects = o;   o = al16(o + (size_t)n_changed * 4);
+    p.tuple_g = o;   o = al16(o + (size_t)kMaxTuples * kMaxComponents * 2);
+    p.tuple_p = o;   o = al16(o + (size_t)kMaxTuples);
+    p.patbits = o;   o = al16(o + (size_t)e->Pmax * 4);
+    p.weights = o;   o = al16(o + (reweight ? (size_t)e->F * e->C * 4 : 0));
+    p.rows = o;      o = al16(o + (size_t)n_changed * e->F * e->C);
+    p.total = (o + 255) / 256 * 256;
+    return p;
+}
+
+// Host half of one chain in the delta form.  Patches e->slots[cand_slot] in place (it holds the current slot's state
+// except the entries of the last step's moved objects).  Returns 1 when the chain must take the classic path instead
+// (pattern set changes, tuple table full); the candidate's host state is then unspecified (the classic path rewrites it).
+int prepare_step_delta(sbe_engine* e, uint8_t* h_base, const uint8_t* d_base, const DeltaPlan& L, int cur_slot, int cand_slot,
+                       const int32_t* mv_objects, const int32_t* mv_cluster, int n_mv, const int32_t* changed_objects, int n_changed,
+                       const uint8_t* source_rows, const float* weights, CoreInputs& in, std::vector<int32_t>& moved_out) {
+    const int F = e->F, C = e->C;
+    const Slot& cur = e->slots[cur_slot];
+    Slot& cd = e->slots[cand_slot];
+    const sbe_engine::SrcSync& irec = e->ids_sync[cand_slot];
+    // 1. the candidate's host mirror back to the current slot's state: entries of the last step's moved objects
+    for (int32_t n : irec.diff) {
+        cd.h_gid[n] = cur.h_gid[n]; cd.h_pid[n] = cur.h_pid[n]; cd.h_tid[n] = cur.h_tid[n]; cd.h_toff[n] = cur.h_toff[n];
+    }
+    cd.patterns = cur.patterns; cd.n_tuples = cur.n_tuples;
+    cd.h_tuple_g = cur.h_tuple_g; cd.h_tuple_p = cur.h_tuple_p; cd.pat_cnt = cur.pat_cnt; cd.tup_cnt = cur.tup_cnt;
+    cd.inc_ok = cur.inc_ok; cd.patterns_dirty = false;
+    cd.groups_set = cur.groups_set; cd.weights_set = true; cd.source_set = cur.source_set;
+    cd.counts_set = cur.counts_set;
+    // 2. this step's moves
+    static thread_local std::vector<int32_t> mv;
+    static thread_local std::vector<uint16_t> mv_old;
+    mv.clear(); mv_old.clear();
+    for (int i = 0; i < n_mv; ++i) {
+        const int n = mv_objects[i];
+        const uint16_t g_new = mv_cluster[i] < 0 ? kNoGroup : (uint16_t)mv_cluster[i];
+        if (cd.h_gid[n] == g_new) continue;                              // (not a move)
+        mv.push_back(n); mv_old.push_back(cd.h_gid[n]);
+        cd.h_gid[n] = g_new;
+    }
+    if (!mv.empty()) {
+        if (e->opt_step_derive == 1 || !update_patterns_and_tuples(e, cd, mv.data(), mv_old.data(), (int)mv.size())) return 1;
+        cd.group_epoch = ++e->epoch_counter;
+    } else cd.group_epoch = cur.group_epoch;
+    std::fill(cd.probs_set.begin(), cd.probs_set.end(), 1);
+    moved_out = mv;
+    // 3. payload
+    uint8_t* st = h_base;
+    in = CoreInputs{};
+    int32_t* sub = reinterpret_cast<int32_t*>(st + L.subset);
+    int16_t* sub_row = reinterpret_cast<int16_t*>(st + L.sub_row);
+    uint16_t* sub_gid0 = reinterpret_cast<uint16_t*>(st + L.sub_gid0);
+    int n_subset = 0;
+    {   // sorted union of moved and changed objects; per entry its row in `rows` (-1: none) and its candidate cluster id
+        static thread_local std::vector<std::pair<int32_t, int32_t>> ch;     // (object, row)
+        ch.clear();
+        for (int i = 0; i < n_changed; ++i) ch.emplace_back(changed_objects[i], i);
+        std::sort(ch.begin(), ch.end());
+        std::sort(mv.begin(), mv.end());
+        size_t a = 0, b = 0;
+        while (a < mv.size() || b < ch.size()) {
+            int32_t n; int r = -1;
+            if (b == ch.size() || (a < mv.size() && mv[a] < ch[b].first)) n = mv[a++];
+            else { n = ch[b].first; r = ch[b].second; if (a < mv.size() && mv[a] == n) ++a; ++b; }
+            sub[n_subset] = n; sub_row[n_subset] = (int16_t)r; sub_gid0[n_subset] = cd.h_gid[n];
+            ++n_subset;
+        }
+    }
+    int n_patch = 0;
+    {   // id entries to (re)write in the candidate's device arrays: last step's leftovers and this step's moves
+        int32_t* pn = reinterpret_cast<int32_t*>(st + L.patch_n);
+        uint16_t* pg = reinterpret_cast<uint16_t*>(st + L.patch_gid);
+        uint8_t* pp = st + L.patch_pid; uint8_t* pt = st + L.patch_tid;
+        auto put = [&](int32_t n) { pn[n_patch] = n; pg[n_patch] = cd.h_gid[n]; pp[n_patch] = cd.h_pid[n]; pt[n_patch] = cd.h_tid[n]; ++n_patch; };
+        for (int32_t n : irec.diff) put(n);
+        for (int32_t n : mv) put(n);                                      // (an object in both lists: same value twice)
+    }
+    const bool tables_changed = cd.patterns != cur.patterns || cd.h_tuple_p != cur.h_tuple_p || cd.h_tuple_g != cur.h_tuple_g;
+    if (tables_changed) {
+        memcpy(st + L.tuple_g, cd.h_tuple_g.data(), (size_t)kMaxTuples * kMaxComponents * 2);
+        memcpy(st + L.tuple_p, cd.h_tuple_p.data(), kMaxTuples);
+        memset(st + L.patbits, 0, (size_t)e->Pmax * 4);
+        memcpy(st + L.patbits, cd.patterns.data(), cd.patterns.size() * 4);
+        in.tuple_g = d_base + L.tuple_g; in.tuple_p = d_base + L.tuple_p; in.patbits = d_base + L.patbits;
+    }
+    if (weights) { memcpy(st + L.weights, weights, (size_t)F * C * 4); in.weights = d_base + L.weights; }
+    if (n_changed > 0) {
+        memcpy(st + L.objects, changed_objects, (size_t)n_changed * 4);
+        memcpy(st + L.rows, source_rows, (size_t)n_changed * F * C);
+        in.rows = d_base + L.rows;
+        in.objects = reinterpret_cast<const int32_t*>(d_base + L.objects);
+        in.n_changed = n_changed;
+    }
+    in.subset = reinterpret_cast<const int32_t*>(d_base + L.subset); in.n_subset = n_subset;
+    in.sub_row = reinterpret_cast<const int16_t*>(d_base + L.sub_row);
+    in.sub_gid0 = reinterpret_cast<const uint16_t*>(d_base + L.sub_gid0);
+    in.patch_n = reinterpret_cast<const int32_t*>(d_base + L.patch_n);
+    in.patch_gid = reinterpret_cast<const uint16_t*>(d_base + L.patch_gid);
+    in.patch_pid = d_base + L.patch_pid; in.patch_tid = d_base + L.patch_tid; in.n_patch = n_patch;
+    in.P = (int)cd.patterns.size();
+    {   // source rows to bring over from the current slot (the last step's rows that this step does not rewrite)
+        const sbe_engine::SrcSync& rec = e->src_sync[cand_slot];
+        int32_t* stale = reinterpret_cast<int32_t*>(st + L.stale);
+        int ns = 0;
+        for (int32_t n : rec.diff) {
+            bool rewritten = false;
+            for (int i = 0; i < n_changed && !rewritten; ++i) rewritten = changed_objects[i] == n;
+            if (!rewritten) stale[ns++] = n;
+        }
+        in.full_src_copy = false;
+        in.stale = reinterpret_cast<const int32_t*>(d_base + L.stale);
+        in.n_stale = ns;
+    }
+    return 0;
+}
+
+bool sync_valid(const sbe_engine::SrcSync& rec, const sbe_engine::SrcSync& peer, int peer_slot, int cap) {
+    return rec.peer == peer_slot && rec.peer_version == peer.version && rec.own_version == rec.version && (int)rec.diff.size() <= cap;
+}
+
+}  // namespace
+
+int sbe_step_batch_delta(sbe_engine* e, int n_chains, const int32_t* cur_slots, const int32_t* cand_slots,
+                         const int32_t* moved_ptr, const int32_t* moved_objects, const int32_t* moved_cluster,
+                         const int32_t* rows_ptr, const int32_t* changed_objects, const uint8_t* source_rows,
+                         const float* weights, const uint8_t* weights_mask, double* group_logliks_out, double* mixture_out,
+                         uint8_t* changed_groups_out) {
+    CHECK_ENGINE(e); CHECK_PTR(e, cur_slots); CHECK_PTR(e, cand_slots); CHECK_PTR(e, moved_ptr); CHECK_PTR(e, rows_ptr);
+    CHECK_PTR(e, group_logliks_out); CHECK_PTR(e, mixture_out);
+    const auto t_start = std::chrono::steady_clock::now();
+    std::chrono::steady_clock::time_point tq[8]; int nq = 0;
+    auto markd = [&] { if (nq < 8) tq[nq++] = std::chrono::steady_clock::now(); };
+    if (n_chains < 1 || n_chains > e->n_slots / 2) return fail(e, SBE_ERR_ARG, "n_chains=%d (1..%d: two slots per chain)", n_chains, e->n_slots / 2);
+    if ((int64_t)e->Gtot * e->S * 28 > 60 * 1024) return fail(e, SBE_ERR_ARG, "sbe_step_batch_delta: tables too large for the one-launch step (G_total=%d, S=%d)", e->Gtot, e->S);
+    const int N = e->N, F = e->F, C = e->C, K = e->G[0];
+    if (rows_ptr[0] != 0 || moved_ptr[0] != 0) return fail(e, SBE_ERR_ARG, "rows_ptr[0] / moved_ptr[0] must be 0");
+    {
+        std::vector<uint8_t> used(e->n_slots, 0);
+        std::vector<uint32_t> seen(N, 0);
+        for (int i = 0; i < n_chains; ++i) {
+            const int a = cur_slots[i], b = cand_slots[i];
+            if (a < 0 || a >= e->n_slots || b < 0 || b >= e->n_slots || a == b) return fail(e, SBE_ERR_ARG, "chain %d: bad slots (%d, %d)", i, a, b);
+            if (used[a] || used[b]) return fail(e, SBE_ERR_ARG, "chain %d: slot used by another chain of the batch", i);
+            used[a] = used[b] = 1;
+            const int nr = rows_ptr[i + 1] - rows_ptr[i], nm = moved_ptr[i + 1] - moved_ptr[i];
+            if (nr < 0 || nr > e->step_max_rows) return fail(e, SBE_ERR_ARG, "chain %d: %d changed source rows (0..%d per chain in a batched step)", i, nr, e->step_max_rows);
+            if (nm < 0 || nm > N) return fail(e, SBE_ERR_ARG, "chain %d: %d moved objects", i, nm);
+            if ((nr > 0 && (!changed_objects || !source_rows)) || (nm > 0 && (!moved_objects || !moved_cluster))) return fail(e, SBE_ERR_ARG, "chain %d: delta arrays missing", i);
+            for (int k = rows_ptr[i]; k < rows_ptr[i + 1]; ++k) {
+                const int n = changed_objects[k];
+                if (n < 0 || n >= N) return fail(e, SBE_ERR_ARG, "chain %d: object index %d out of range", i, n);
+                if (seen[n] == (uint32_t)(2 * i + 1)) return fail(e, SBE_ERR_ARG, "chain %d: object %d listed twice in changed_objects", i, n);
+                seen[n] = (uint32_t)(2 * i + 1);
+            }
+            for (int k = moved_ptr[i]; k < moved_ptr[i + 1]; ++k) {
+                const int n = moved_objects[k];
+                if (n < 0 || n >= N) return fail(e, SBE_ERR_ARG, "chain %d: moved object index %d out of range", i, n);
+                if (moved_cluster[k] < -1 || moved_cluster[k] >= K) return fail(e, SBE_ERR_ARG, "chain %d: cluster %d out of range [-1,%d)", i, moved_cluster[k], K);
+            }
+            const Slot& cur = e->slots[a];
+            if (!cur.groups_set || !cur.source_set || !cur.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", a);
+            for (int c = 0; c < C; ++c)
+                if (!cur.counts_set[c] || !e->conc_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts / concentration of component %d not set", a, c);
+        }
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    if (e->status_pending) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        int rc = synced(e);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < n_chains; ++i)
+        if (e->slots[cur_slots[i]].patterns_dirty) { int rc = upload_patterns_and_weights(e, cur_slots[i]); if (rc) return rc; }
+    int rc = ensure_lanes(e, n_chains);
+    if (rc) return rc;
+    rc = ensure_step_pool(e);
+    if (rc) return rc;
+    if ((int)e->batch_moved.size() < n_chains) e->batch_moved.resize(n_chains);
+    markd();                                     // 0: checks done
+    // ---- which chains can be patched; their payload plans -------------------------------------------------------------
+    std::vector<int> fast, slow;
+    std::vector<DeltaPlan> plans(n_chains);
+    std::vector<size_t> pay_off(n_chains + 1, 0);
+    for (int i = 0; i < n_chains; ++i) {
+        const int a = cur_slots[i], b = cand_slots[i];
+        const bool ok = sync_valid(e->ids_sync[b], e->ids_sync[a], a, e->step_max_rows) &&
+                        sync_valid(e->src_sync[b], e->src_sync[a], a, e->step_max_rows) &&
+                        e->slots[a].inc_ok && e->slots[a].n_tuples > 0 && e->slots[b].h_gid.size() == e->slots[a].h_gid.size();
+        if (ok) {
+            const bool reweight = weights && (!weights_mask || weights_mask[i]);
+            plans[i] = plan_delta(e, moved_ptr[i + 1] - moved_ptr[i], rows_ptr[i + 1] - rows_ptr[i], (int)e->ids_sync[b].diff.size(),
+                                  (int)e->src_sync[b].diff.size(), reweight);
+            pay_off[i + 1] = pay_off[i] + plans[i].total;
+            fast.push_back(i);
+        } else { pay_off[i + 1] = pay_off[i]; slow.push_back(i); }
+    }
+    // Chains that cannot be patched run through the classic entry point (cluster matrices rebuilt from the ids).  That call
+    // uses the lanes, the payload block and the per-chain scratch of ITS chain numbering and synchronises: it runs either
+    // before the patched chains are prepared or after their results have been read, never in between.
+    auto run_classic = [&](const std::vector<int>& which, int& rc_out, std::string& msg_out) {
+        rc_out = SBE_OK;
+        if (which.empty()) return;
+        const int ns = (int)which.size();
+        std::vector<int32_t> s_cur(ns), s_cand(ns), s_ptr(ns + 1, 0), s_objs;
+        std::vector<uint8_t> s_cl((size_t)ns * K * N, 0), s_rows, s_wm(ns, 0);
+        std::vector<float> s_w(weights ? (size_t)ns * F * C : 0);
+        for (int j = 0; j < ns; ++j) {
+            const int i = which[j];
+            s_cur[j] = cur_slots[i]; s_cand[j] = cand_slots[i];
+            const Slot& cur = e->slots[cur_slots[i]];
+            std::vector<uint16_t> ids(cur.h_gid.begin(), cur.h_gid.begin() + N);
+            for (int k = moved_ptr[i]; k < moved_ptr[i + 1]; ++k) ids[moved_objects[k]] = moved_cluster[k] < 0 ? kNoGroup : (uint16_t)moved_cluster[k];
+            uint8_t* cl = s_cl.data() + (size_t)j * K * N;
+            for (int n = 0; n < N; ++n) if (ids[n] != kNoGroup) cl[(size_t)ids[n] * N + n] = 1;
+            const int r0 = rows_ptr[i], nr = rows_ptr[i + 1] - r0;
+            s_ptr[j + 1] = s_ptr[j] + nr;
+            if (nr) {
+                s_objs.insert(s_objs.end(), changed_objects + r0, changed_objects + r0 + nr);
+                s_rows.insert(s_rows.end(), source_rows + (size_t)r0 * F * C, source_rows + (size_t)(r0 + nr) * F * C);
+            }
+            if (weights && (!weights_mask || weights_mask[i])) { s_wm[j] = 1; memcpy(&s_w[(size_t)j * F * C], weights + (size_t)i * F * C, (size_t)F * C * 4); }
+        }
+        std::vector<double> s_glh((size_t)ns * e->Gtot), s_mix(ns);
+        std::vector<uint8_t> s_chg((size_t)ns * e->Gtot);
+        rc_out = sbe_step_batch(e, ns, s_cur.data(), s_cand.data(), s_cl.data(), nullptr, s_ptr.data(), s_objs.empty() ? nullptr : s_objs.data(),
+                                s_rows.empty() ? nullptr : s_rows.data(), weights ? s_w.data() : nullptr, weights ? s_wm.data() : nullptr,
+                                s_glh.data(), s_mix.data(), s_chg.data());
+        if (rc_out) { msg_out = e->last_error; return; }
+        for (int j = 0; j < ns; ++j) {
+            const int i = which[j];
+            memcpy(group_logliks_out + (size_t)i * e->Gtot, &s_glh[(size_t)j * e->Gtot], (size_t)e->Gtot * sizeof(double));
+            mixture_out[i] = s_mix[j];
+            if (changed_groups_out) memcpy(changed_groups_out + (size_t)i * e->Gtot, &s_chg[(size_t)j * e->Gtot], (size_t)e->Gtot);
+        }
+    };
+    int slow_rc = SBE_OK; std::string slow_msg;
+    run_classic(slow, slow_rc, slow_msg);        // (chains without usable records: before the patched chains touch anything)
+    markd();                                     // 1: plans (+ the unpatched chains)
+    // ---- host halves of the patched chains (pool) ----------------------------------------------------------------------
+    // The delta payload is small (~10 KB per chain): it goes up in ONE copy together with the launch arguments (every
+    // copy-engine operation costs ~10 us of latency in the stream; the chunked upload of the matrix form paid five).
+    std::vector<CoreInputs> ins(n_chains);
+    std::vector<int> fb(n_chains, 0);
+    const int nf = (int)fast.size();
+    const size_t part_cores = ((size_t)std::max(nf, 1) * sizeof(StepCore) + 255) / 256 * 256;
+    const size_t part_fins = ((size_t)std::max(nf, 1) * sizeof(StepFinish) + 255) / 256 * 256;
+    const size_t meta_bytes = part_cores + part_fins + ((size_t)std::max(nf, 1) * sizeof(int32_t) + 255) / 256 * 256;
+    const size_t meta_off = pay_off[n_chains];
+    if (meta_off + meta_bytes > e->batch_payload_bytes) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (e->h_batch_payload) { HIPCHK(e, hipHostFree(e->h_batch_payload)); e->h_batch_payload = nullptr; }
+        if (e->d_batch_payload) { HIPCHK(e, hipFree(e->d_batch_payload)); e->d_batch_payload = nullptr; }
+        e->batch_payload_bytes = (meta_off + meta_bytes) * 3 / 2;
+        HIPCHK(e, hipHostMalloc((void**)&e->h_batch_payload, e->batch_payload_bytes, hipHostMallocDefault));
+        HIPCHK(e, hipMalloc((void**)&e->d_batch_payload, e->batch_payload_bytes));
+    }
+    if (nf > 0) {
+        e->pool->run(nf, [&](int j) {
+            const int i = fast[j];
+            const bool reweight = weights && (!weights_mask || weights_mask[i]);
+            const int r0 = rows_ptr[i], nr = rows_ptr[i + 1] - r0, m0 = moved_ptr[i], nm = moved_ptr[i + 1] - m0;
+            fb[i] = prepare_step_delta(e, e->h_batch_payload + pay_off[i], e->d_batch_payload + pay_off[i], plans[i], cur_slots[i], cand_slots[i],
+                                       nm ? moved_objects + m0 : nullptr, nm ? moved_cluster + m0 : nullptr, nm,
+                                       nr ? changed_objects + r0 : nullptr, nr, nr ? source_rows + (size_t)r0 * F * C : nullptr,
+                                       reweight ? weights + (size_t)i * F * C : nullptr, ins[i], e->batch_moved[i]);
+        });
+    }
+    markd();                                     // 2: host halves
+    std::vector<int> go, late;                             // patched chains that stay on the fast path / that turned out not to
+    for (int i : fast) { if (fb[i]) { late.push_back(i); bump_ids(e, cand_slots[i]); } else go.push_back(i); }
+    const int ng = (int)go.size();
+    if (ng > 0) {
+        uint8_t* pm = e->h_batch_payload + meta_off;
+        uint8_t* dm = e->d_batch_payload + meta_off;
+        StepCore* cores = reinterpret_cast<StepCore*>(pm);
+        StepFinish* fins = reinterpret_cast<StepFinish*>(pm + part_cores);
+        int32_t* slot_list = reinterpret_cast<int32_t*>(pm + part_cores + part_fins);
+        std::vector<int32_t> cand_go(ng);
+        size_t lds = 0; int max_blocks = 0;
+        for (int j = 0; j < ng; ++j) {
+            const int i = go[j];
+            size_t l = 0; int nb = 0;
+            rc = build_step_core(e, e->lanes[i], cur_slots[i], cand_slots[i], ins[i], cores[j], l, nb, ng);
+            if (rc) return rc;
+            lds = std::max(lds, l); max_blocks = std::max(max_blocks, nb);
+            fins[j] = make_step_finish_lane(e, e->lanes[i]);
+            slot_list[j] = cand_go[j] = cand_slots[i];
+        }
+        HIPCHK(e, hipMemcpyAsync(e->d_batch_payload, e->h_batch_payload, meta_off + meta_bytes, hipMemcpyHostToDevice, e->stream));
+        k_step_core_batch<<<dim3(max_blocks, ng), kBlock, lds, e->stream>>>(reinterpret_cast<const StepCore*>(dm));
+        HIPCHK(e, hipGetLastError());
+        markd();                                 // 3: step cores built, uploaded, launched
+        rc = launch_mixture(e, 0, ng, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, nullptr,
+                            cand_go.data(), reinterpret_cast<const int32_t*>(dm + part_cores + part_fins),
+                            reinterpret_cast<const StepFinish*>(dm + part_cores));
+        for (int j = 0; j < ng; ++j) {           // (bookkeeping under the device work: everything is enqueued)
+            const int i = go[j];
+            commit_src_sync(e, cur_slots[i], cand_slots[i], changed_objects ? changed_objects + rows_ptr[i] : nullptr, rows_ptr[i + 1] - rows_ptr[i]);
+            commit_ids_sync(e, cur_slots[i], cand_slots[i], e->batch_moved[i]);
+        }
+        if (rc) return rc;
+    }
+    static const bool timing_d = getenv("SBE_STEP_TIMING") && atoi(getenv("SBE_STEP_TIMING")) != 0;
+    const auto t_enq = std::chrono::steady_clock::now();
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (timing_d) {
+        const auto t_done = std::chrono::steady_clock::now();
+        auto us = [&](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "[sbe_step_batch_delta] %d chains: %d patched, %d + %d through sbe_step_batch | checks %.1f | plans %.1f | host halves (pool) %.1f | cores + launch %.1f | "
+                        "mixture launches + records %.1f | wait %.1f us\n", n_chains, ng, (int)slow.size(), (int)late.size(), nq > 0 ? us(t_start, tq[0]) : 0.0,
+                nq > 1 ? us(tq[0], tq[1]) : 0.0, nq > 2 ? us(tq[1], tq[2]) : 0.0, nq > 3 ? us(tq[2], tq[3]) : 0.0, nq > 3 ? us(tq[3], t_enq) : 0.0, us(t_enq, t_done));
+    }
+    int first_bad = slow_rc; std::string first_msg = slow_msg;
+    for (int i : go) {
+        rc = read_step_results_lane(e, e->lanes[i].h_step, cand_slots[i], group_logliks_out + (size_t)i * e->Gtot, mixture_out + i,
+                                    changed_groups_out ? changed_groups_out + (size_t)i * e->Gtot : nullptr, "rows", e->lanes[i].d_status, i);
+        if (rc && !first_bad) { first_bad = rc; first_msg = e->last_error; }
+    }
+    // ---- chains whose step turned out to need the full derivation: now that the patched chains' results are out ---------
+    if (!late.empty()) {
+        int late_rc = SBE_OK; std::string late_msg;
+        run_classic(late, late_rc, late_msg);
+        if (late_rc && !first_bad) { first_bad = late_rc; first_msg = late_msg; }
+    }
+    if (first_bad) return fail(e, first_bad, "%s", first_msg.c_str());
     return SBE_OK;
 }
 
@@ -3181,6 +3589,7 @@ int sbe_gibbs_step(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* ob
     };
     uint8_t* src_cand = e->d_src + (int64_t)cand_slot * N * e->Fp;
     bump_src(e, cand_slot);                  // (the Gibbs step draws into the candidate's array and copies the rest in full)
+    bump_ids(e, cand_slot);
     // 1: the draw (posterior from the current tables) -> the candidate's source rows of the listed objects, and the
     //    per-block partial sums of log_q
     k_sample_source<<<nblk, kBlock, 0, e->stream>>>(post_args(cur_slot), d_z, e->rng_seed, e->rng_draw, src_cand, d_psel_f, e->d_status, d_part_f);
@@ -3357,6 +3766,7 @@ int sbe_copy_slot(sbe_engine* e, int dst, int src) {
     k_multi_copy<<<std::min<int64_t>(div_up(run, 256), 4 * e->compute_units), 256, 0, e->stream>>>(cs);
     HIPCHK(e, hipGetLastError());
     bump_src(e, dst);
+    bump_ids(e, dst);
     e->slots[dst] = e->slots[src];
     return SBE_OK;
 }

@@ -2548,6 +2548,14 @@ struct StepCore {
     // round 3: when the candidate slot's source array is known to differ from the current slot's only in `stale` rows
     // (the previous step's changed rows), those rows are copied instead of the whole array (no src segment in `cs`)
     const int32_t* stale; int n_stale; const uint8_t* src_cur_rows;
+    // round 3, delta layout (sbe_step_batch_delta): the candidate slot's per-object id arrays are PATCHED, not copied --
+    // entry i of the patch lists holds the candidate's (gid of component 0, pattern id, tuple id) of object patch_n[i]
+    // (the objects this step moves and the ones the previous step left different in this slot); `sub_row` / `sub_gid0`
+    // give, per entry of `subset`, the object's row in `rows` (-1: its source does not change) and its candidate
+    // component-0 group id, in place of the [Np] arrays row_of / ids_new.  n_patch < 0: classic layout.
+    const int32_t* patch_n; const uint16_t* patch_gid; const uint8_t* patch_pid; const uint8_t* patch_tid; int n_patch;
+    uint16_t* gid_dst; uint8_t* pid_dst; uint8_t* tid_dst; uint32_t* toff_dst; uint32_t toff_mul;
+    const int16_t* sub_row; const uint16_t* sub_gid0;
 };
 
 __device__ __forceinline__ void step_core_body(const StepCore& a, unsigned char* core_lds, const int bx) {
@@ -2574,7 +2582,7 @@ __device__ __forceinline__ void step_core_body(const StepCore& a, unsigned char*
                 if (g != kNoGroup) atomicAdd(&hist[((int)g * ftc + fl) * S + x], -1);
             }
             int c_new = c_old;
-            const int r = a.row_of ? a.row_of[n] : -1;
+            const int r = a.sub_row ? a.sub_row[i] : (a.row_of ? a.row_of[n] : -1);
             if (r >= 0 && a.src_new) c_new = a.src_new[(int64_t)n * a.Fp + f];
             else if (r >= 0) {
                 const uint8_t* pr = a.rows + ((int64_t)r * F + f) * C;
@@ -2582,7 +2590,8 @@ __device__ __forceinline__ void step_core_body(const StepCore& a, unsigned char*
                 for (int c = 0; c < C; ++c) if (pr[c]) c_new = c;
             }
             if (c_new < C) {
-                const uint16_t g = (c_new == 0 && a.ids_new) ? a.ids_new[n] : a.gid_cur[(int64_t)c_new * a.Np + n];
+                const uint16_t g = c_new == 0 ? (a.sub_gid0 ? a.sub_gid0[i] : (a.ids_new ? a.ids_new[n] : a.gid_cur[n]))
+                                              : a.gid_cur[(int64_t)c_new * a.Np + n];
                 if (g != kNoGroup) atomicAdd(&hist[((int)g * ftc + fl) * S + x], 1);
             }
         }
@@ -2674,6 +2683,13 @@ __device__ __forceinline__ void step_core_body(const StepCore& a, unsigned char*
             }
         }
     }
+    for (uint32_t i = tid; i < (uint32_t)max(a.n_patch, 0); i += nthreads) {      // delta layout: patched id entries
+        const int n = a.patch_n[i];
+        a.gid_dst[n] = a.patch_gid[i];
+        a.pid_dst[n] = a.patch_pid[i];
+        a.tid_dst[n] = a.patch_tid[i];
+        a.toff_dst[n] = (uint32_t)a.patch_tid[i] * a.toff_mul;
+    }
     if (a.n_stale > 0) {                                     // stale rows of the candidate's source <- the current slot's
         const uint32_t per_row = (uint32_t)a.Fp / 16u;       // (Fp is a multiple of 64)
         for (uint32_t i = tid; i < (uint32_t)a.n_stale * per_row; i += nthreads) {
@@ -2686,7 +2702,7 @@ __device__ __forceinline__ void step_core_body(const StepCore& a, unsigned char*
     for (uint32_t i = tid; i < (uint32_t)a.n_changed * (uint32_t)F; i += nthreads) {
         const int r = (int)(i / (uint32_t)F), f = (int)(i % (uint32_t)F);
         const int n = a.objects[r];
-        if (a.row_of[n] != r) continue;                      // an object listed twice: the row the tile blocks use
+        if (a.row_of && a.row_of[n] != r) continue;          // an object listed twice: the row the tile blocks use
         const uint8_t* p = a.rows + (int64_t)i * C;
         int id = kNA, cnt = 0;
         for (int c = 0; c < C; ++c)

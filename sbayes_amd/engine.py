@@ -704,6 +704,54 @@ class Engine:
                                              opt(w), opt(wm), self._o(glh), self._o(mix), self._o(changed)))
         return glh, mix, changed.astype(bool)
 
+    def step_batch_delta(self, cur_slots, cand_slots, moved_ptr, moved_objects, moved_cluster, rows_ptr=None,
+                         changed_objects=None, source_rows=None, weights=None, weights_mask=None):
+        """sbe_step_batch with the proposals in delta form: moved_ptr int [n+1] CSR over moved_objects / moved_cluster
+        (new cluster index, -1 = none); rows_ptr / changed_objects / source_rows as in step_batch (each object once per
+        chain); weights float32 [n, F, C] + weights_mask.  Same return values as step_batch."""
+        cur = np.ascontiguousarray(cur_slots, dtype=np.int32).reshape(-1)
+        cand = np.ascontiguousarray(cand_slots, dtype=np.int32).reshape(-1)
+        n = cur.size
+        mp = np.ascontiguousarray(moved_ptr, dtype=np.int32).reshape(-1)
+        if cand.size != n or mp.size != n + 1:
+            raise ValueError("cur_slots / cand_slots / moved_ptr do not match")
+        mo = np.ascontiguousarray(moved_objects, dtype=np.int32).reshape(-1)
+        mc = np.ascontiguousarray(moved_cluster, dtype=np.int32).reshape(-1)
+        if mo.size != int(mp[-1]) or mc.size != mo.size:
+            raise ValueError("moved_objects / moved_cluster do not match moved_ptr")
+        if rows_ptr is None:
+            ptr = np.zeros(n + 1, dtype=np.int32)
+            objs = rows = None
+        else:
+            ptr = np.ascontiguousarray(rows_ptr, dtype=np.int32).reshape(-1)
+            if ptr.size != n + 1:
+                raise ValueError("rows_ptr must have n_chains + 1 entries")
+            total = int(ptr[-1])
+            objs = np.ascontiguousarray(changed_objects, dtype=np.int32).reshape(-1) if total else None
+            rows = np.asarray(source_rows) if total else None
+            if total and (objs.size != total or rows.shape != (total, self.n_features, self.n_components)):
+                raise ValueError("changed_objects / source_rows do not match rows_ptr")
+            if total:
+                rows = _c(rows.astype(bool, copy=False), np.uint8)
+        w = wm = None
+        if weights is not None:
+            w = _c(weights, np.float32)
+            if w.shape != (n, self.n_features, self.n_components):
+                raise ValueError(f"weights must be {(n, self.n_features, self.n_components)}")
+            if weights_mask is not None:
+                wm = _c(np.asarray(weights_mask, dtype=bool), np.uint8).reshape(n)
+        glh = np.empty((n, self.n_groups_total), dtype=np.float64)
+        mix = np.empty(n, dtype=np.float64)
+        changed = np.zeros((n, self.n_groups_total), dtype=np.uint8)
+        if self._bound or self._mirror:
+            for s in cand.tolist():
+                self._touch(s)
+        opt = lambda a: self._i(a) if a is not None else None        # noqa: E731
+        self._check(self._lib.sbe_step_batch_delta(self._h, n, self._i(cur), self._i(cand), self._i(mp), opt(mo if mo.size else None),
+                                                   opt(mc if mc.size else None), self._i(ptr), opt(objs), opt(rows), opt(w), opt(wm),
+                                                   self._o(glh), self._o(mix), self._o(changed)))
+        return glh, mix, changed.astype(bool)
+
     def gibbs_step(self, cur_slot, cand_slot, objects, z=None, temperature=1.0, prior_temperature=1.0, from_prior=False):
         """One Gibbs-source MCMC step in one call (sbe_gibbs_step): the listed objects' source is redrawn on the
         device into `cand_slot`, counts / tables / likelihoods follow.  z: uniforms [n, F] or None (engine's Philox

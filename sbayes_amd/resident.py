@@ -313,6 +313,21 @@ class ResidentChainBatch:
         self._pending = True
         return glh.sum(axis=1), glh, mix
 
+    def step_delta(self, moved_ptr, moved_objects, moved_cluster, rows_ptr=None, changed_objects=None, source_rows=None,
+                   weights=None, weights_mask=None):
+        """One step per chain with the proposals in DELTA form (sbe_step_batch_delta): per chain the objects that change
+        cluster and their new cluster (-1: none), CSR by moved_ptr, and the objects whose source rows change (each once).
+        What an operator produces goes in as it is: no [K, N] cluster matrices are built, stacked, scanned or sent, and
+        the library patches the candidates in O(delta).  Same return values as step_arrays; follow with accept(mask)."""
+        self._cand, self.changed_groups, self._pending = None, None, False
+        glh, mix, changed = self.eng.step_batch_delta(self.cur, self.cand, moved_ptr, moved_objects, moved_cluster, rows_ptr,
+                                                      changed_objects, source_rows, weights, weights_mask)
+        self._cand = ("delta", np.array(moved_ptr, dtype=np.int64), np.array(moved_objects, dtype=np.int64),
+                      np.array(moved_cluster, dtype=np.int64))
+        self.changed_groups = changed
+        self._pending = True
+        return glh.sum(axis=1), glh, mix
+
     def accept(self, mask=None):
         """Swap the slots of the accepted chains (all of them by default); rejected chains keep their current slot."""
         if not self._pending:
@@ -321,7 +336,16 @@ class ResidentChainBatch:
         cur, cand = self.cur.copy(), self.cand.copy()
         self.cur = np.where(mask, cand, cur).astype(np.int32)
         self.cand = np.where(mask, cur, cand).astype(np.int32)
-        if self._cand is not None:                               # the accepted chains' candidate clusters become current
+        if self._cand is not None and isinstance(self._cand[0], str):      # ("delta", ...): the accepted chains' moves into the host mirror
+            _tag, mp, mo, mc = self._cand
+            if mo.size:                                                    # (vectorised over every chain's moves)
+                chain = np.repeat(np.arange(self.n), np.diff(mp))
+                keep = mask[chain]
+                self._clusters[chain[keep], :, mo[keep]] = False
+                inside = keep & (mc >= 0)
+                self._clusters[chain[inside], mc[inside], mo[inside]] = True
+            self._cand = None
+        elif self._cand is not None:                             # the accepted chains' candidate clusters become current
             cl, cm = self._cand
             if cm is None:
                 self._clusters[mask] = cl[mask]

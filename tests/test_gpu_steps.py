@@ -315,9 +315,12 @@ def test_step_batch_stress_workload_8_chains(monkeypatch):
     _batch_equals_single_steps("stress", 8, 2, seed=28, distinct_states=3)
 
 
+@pytest.mark.parametrize("form", ["matrix", "delta"])
 @pytest.mark.parametrize("name,n_chains", [("south_america", 64), ("headline", 16)])
-def test_step_batch_replays_interleaved_reference_traces(name, n_chains):
-    """n_chains copies of the recorded reference MCMC trace, chain i lagging i steps behind chain i-1, stepped together
+def test_step_batch_replays_interleaved_reference_traces(name, n_chains, form):
+    """(form = delta: the same sweeps through ResidentChainBatch.step_delta / sbe_step_batch_delta -- the moved objects
+    and their new clusters instead of cluster matrices; the candidates are patched in O(delta).)
+    n_chains copies of the recorded reference MCMC trace, chain i lagging i steps behind chain i-1, stepped together
     by sbe_step_batch through ResidentChainBatch: every chain reproduces the reference's recorded collapsed and mixture
     log-likelihood at every step (chains that have not started or have finished pass an empty delta)."""
     from sbayes_amd import model as sbm
@@ -326,6 +329,7 @@ def test_step_batch_replays_interleaved_reference_traces(name, n_chains):
     fx, tr = load_case(name)
     model, sample = build(fx)
     n_steps = min(tr.n_steps, 120)
+    F, C = fx.features.shape[1], fx.n_comp
     batch = ResidentChainBatch(model, [sample] * n_chains)
     try:
         deltas = []                                                # per trace step: (clusters or None, (objs, rows), weights or None)
@@ -339,9 +343,32 @@ def test_step_batch_replays_interleaved_reference_traces(name, n_chains):
         for sweep in range(n_steps + n_chains - 1):
             ts = [sweep - i for i in range(n_chains)]
             live = [0 <= t < n_steps for t in ts]
-            ll, glh, mix = batch.step(clusters=[deltas[t][0] if ok else None for t, ok in zip(ts, live)],
-                                      source_rows=[deltas[t][1] if ok else None for t, ok in zip(ts, live)],
-                                      weights=[deltas[t][2] if ok else None for t, ok in zip(ts, live)])
+            if form == "matrix":
+                ll, glh, mix = batch.step(clusters=[deltas[t][0] if ok else None for t, ok in zip(ts, live)],
+                                          source_rows=[deltas[t][1] if ok else None for t, ok in zip(ts, live)],
+                                          weights=[deltas[t][2] if ok else None for t, ok in zip(ts, live)])
+            else:
+                mptr, mobj, mcl, ptr, objs_l, rows_l = [0], [], [], [0], [], []
+                w = np.zeros((n_chains, F, C), dtype=np.float32)
+                wm = np.zeros(n_chains, dtype=bool)
+                for i, (t, ok) in enumerate(zip(ts, live)):
+                    moved = np.zeros(0, dtype=np.int64)
+                    if ok and deltas[t][0] is not None:
+                        prev = tr.clusters(t - 1) if t > 0 else fx.groups[0]
+                        moved = np.flatnonzero((deltas[t][0] != prev).any(axis=0))
+                        mcl.append(np.where(deltas[t][0][:, moved].any(axis=0), deltas[t][0][:, moved].argmax(axis=0), -1))
+                    else:
+                        mcl.append(np.zeros(0, dtype=np.int64))
+                    mobj.append(moved)
+                    mptr.append(mptr[-1] + moved.size)
+                    objs, rows = deltas[t][1] if ok else (np.zeros(0, dtype=np.int32), np.zeros((0, F, C), dtype=bool))
+                    objs_l.append(np.asarray(objs, dtype=np.int32))
+                    rows_l.append(np.asarray(rows, dtype=bool).reshape(-1, F, C))
+                    ptr.append(ptr[-1] + len(objs))
+                    if ok and deltas[t][2] is not None:
+                        w[i], wm[i] = deltas[t][2], True
+                ll, glh, mix = batch.step_delta(np.array(mptr), np.concatenate(mobj), np.concatenate(mcl), np.array(ptr),
+                                                np.concatenate(objs_l), np.concatenate(rows_l), w, wm)
             for i, (t, ok) in enumerate(zip(ts, live)):
                 if ok:
                     assert abs(ll[i] - tr.last_lh[t]) <= 1e-6 * abs(tr.last_lh[t]), (sweep, i, t)
@@ -453,3 +480,92 @@ def test_step_batch_reports_the_malformed_chain_by_index():
         g1, m1, c1 = es.step(0, 1, changed_objects=objs, source_rows=good)
         for i in range(B):
             assert np.array_equal(glh[i], g1) and abs(mix[i] - m1) <= 1e-13 * abs(m1)
+
+
+@pytest.mark.parametrize("name,B", [("headline", 12), ("many_tuples", 6), ("stress_like", 4)])
+def test_step_batch_delta_equals_matrix_form(name, B):
+    """sbe_step_batch_delta (proposals as moved objects + changed rows; candidates PATCHED in O(delta)) against
+    sbe_step_batch (full cluster matrices; candidates rebuilt): eight sweeps of mixed proposals -- cluster moves, moves out
+    of every cluster, source rows, weights, nothing, a whole cluster emptied (the pattern set changes: that chain falls
+    back inside the call) -- with random accepts.  Counts, tables, per-group values and flags bit for bit, the mixture
+    scalar to rounding; at the end the oracle.  The first sweep of the delta engine is the fallback (no records yet)."""
+    if name == "headline":
+        wl = make_workload("headline")
+    elif name == "many_tuples":
+        wl = make_workload("tuples", shape=(400, 64, 4, 6, (3, 2), False))
+    else:                                                  # C = 4, hundreds of tuples: the rows kernel evaluates the candidates
+        wl = make_workload("stress_like", shape=(900, 150, 12, 8, (15, 15), False))
+    feats, na = wl.features, wl.na_values
+    N, F, S = wl.shape
+    C = wl.n_components
+    K = wl.clusters.shape[0]
+    rng = np.random.default_rng(91)
+    n_groups = [g.shape[0] for g in wl.groups]
+    with Engine(feats, n_groups, n_slots=2 * B) as ea, Engine(feats, n_groups, n_slots=2 * B) as eb:
+        states = []
+        for i in range(B):
+            clusters, weights, source = (wl.clusters, wl.weights, wl.source) if i == 0 else \
+                make_state(feats, wl.groups[1:], K, seed=500 + i)
+            states.append((clusters, weights, source))
+        for eng in (ea, eb):
+            for c in range(C):
+                eng.set_concentration(c, wl.concentration[c])
+            for i, (clusters, weights, source) in enumerate(states):
+                eng.load_state(2 * i, [clusters] + wl.groups[1:], weights, source=source)
+                for c in range(C):
+                    eng.update_probs(2 * i, c)
+        cur = np.arange(0, 2 * B, 2, dtype=np.int32)
+        cand = cur + 1
+        for sweep in range(8):
+            cl = np.stack([s[0] for s in states]).copy()
+            wts = np.zeros((B, F, C), dtype=np.float32)
+            wm = np.zeros(B, dtype=bool)
+            mptr, mobj, mcl, ptr, objs_all, rows_all, new_states = [0], [], [], [0], [], [], []
+            for i in range(B):
+                clusters, weights, source = states[i]
+                kind = (i + sweep) % 5
+                new_clusters, new_source, new_weights = clusters, source, weights
+                objs, rows = np.zeros(0, dtype=np.int32), np.zeros((0, F, C), dtype=bool)
+                if kind in (0, 1):
+                    new_clusters, _g, objs, rows, new_source = _propose(rng, feats, na, [clusters] + wl.groups[1:], source, weights,
+                                                                       12 if kind == 0 else 0, True)
+                elif kind == 2:
+                    _c2, _g, objs, rows, new_source = _propose(rng, feats, na, [clusters] + wl.groups[1:], source, weights, 25, False)
+                elif kind == 3 and sweep >= 2:                          # a whole cluster emptied
+                    new_clusters = clusters.copy()
+                    new_clusters[int(rng.integers(0, K))] = False
+                if kind in (1, 4) and i % 2 == 0:
+                    new_weights = rng.dirichlet(np.ones(C), size=F).astype(np.float32)
+                    wts[i], wm[i] = new_weights, True
+                cl[i] = new_clusters
+                moved = np.flatnonzero((new_clusters != clusters).any(axis=0))
+                if sweep % 2 == 1 and moved.size < N:                   # sometimes also list an object that does not move
+                    moved = np.union1d(moved, [int(rng.integers(0, N))])
+                mobj.append(moved.astype(np.int32))
+                mcl.append(np.where(new_clusters[:, moved].any(axis=0), new_clusters[:, moved].argmax(axis=0), -1).astype(np.int32))
+                mptr.append(mptr[-1] + moved.size)
+                objs_all.append(np.asarray(objs, dtype=np.int32))
+                rows_all.append(rows if rows is not None and len(objs) else np.zeros((0, F, C), dtype=bool))
+                ptr.append(ptr[-1] + len(objs))
+                new_states.append((new_clusters, new_weights, new_source))
+            ptr_a = np.array(ptr, dtype=np.int32)
+            ga, ma, ca = ea.step_batch(cur, cand, cl, None, ptr_a, np.concatenate(objs_all), np.concatenate(rows_all), wts, wm)
+            gb, mb, cb = eb.step_batch_delta(cur, cand, np.array(mptr, dtype=np.int32), np.concatenate(mobj), np.concatenate(mcl),
+                                             ptr_a, np.concatenate(objs_all), np.concatenate(rows_all), wts, wm)
+            assert np.array_equal(ga, gb) and np.array_equal(ca, cb), (name, sweep)
+            assert np.all(np.abs(ma - mb) <= 1e-13 * np.abs(ma)), (name, sweep, ma, mb)
+            for i in (0, B // 2, B - 1):
+                for c in range(C):
+                    assert np.array_equal(ea.get_counts(int(cand[i]), c), eb.get_counts(int(cand[i]), c)), (sweep, i, c)
+                    assert np.array_equal(ea.get_probs(int(cand[i]), c), eb.get_probs(int(cand[i]), c)), (sweep, i, c)
+            accept = rng.random(B) < 0.6
+            cur, cand = np.where(accept, cand, cur).astype(np.int32), np.where(accept, cur, cand).astype(np.int32)
+            states = [new_states[i] if accept[i] else states[i] for i in range(B)]
+        for i in (0, B - 1):
+            clusters, weights, source = states[i]
+            want = _expected(feats, na, [clusters] + wl.groups[1:], source, wl.concentration, weights)
+            for eng in (ea, eb):
+                got = eng.mixture_loglik(int(cur[i]))
+                assert abs(got - want[3]) <= 1e-10 * abs(want[3])
+                for c in range(C):
+                    assert np.array_equal(eng.get_counts(int(cur[i]), c), want[0][c])

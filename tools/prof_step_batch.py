@@ -61,6 +61,28 @@ def raw():
     eng._lib.sbe_step_batch(*args)
 
 
+# the same sweep in delta form: moved objects + new cluster instead of the [K, N] matrices
+mptr, mobj, mcl = [0], [], []
+for i in range(n_chains):
+    moved = np.flatnonzero((cl[i] != wl.clusters).any(axis=0)).astype(np.int32)
+    mobj.append(moved)
+    mcl.append(np.where(cl[i][:, moved].any(axis=0), cl[i][:, moved].argmax(axis=0), -1).astype(np.int32))
+    mptr.append(mptr[-1] + moved.size)
+mptr = np.array(mptr, dtype=np.int32); mobj = np.concatenate(mobj); mcl = np.concatenate(mcl)
+dargs = (eng._h, n_chains, _ptr(cur), _ptr(cand), _ptr(mptr), _ptr(mobj), _ptr(mcl), _ptr(ptr), _ptr(objs_cat), _ptr(rowsu), None, None,
+         _ptr(glh), _ptr(mix), _ptr(changed))
+
+
+def raw_delta():
+    eng._lib.sbe_step_batch_delta(*dargs)
+
+
+def face_delta():
+    batch.step_delta(mptr, mobj, mcl, ptr, objs_cat, rows)
+    batch.accept()
+
+
+print(f"{n_chains} chains, {wl.name}, DELTA form: raw C call {rate(raw_delta):8.1f} us | ResidentChainBatch.step_delta + accept {rate(face_delta):8.1f} us")
 print(f"{n_chains} chains, {wl.name}: raw C call {rate(raw):8.1f} us | Engine.step_batch {rate(engine_only):8.1f} us | "
       f"ResidentChainBatch.step_arrays + accept {rate(face):8.1f} us")
 batch.close()
