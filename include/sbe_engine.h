@@ -413,6 +413,14 @@ int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const 
                    const uint8_t* weights_mask, double* group_logliks_out, double* mixture_out,
                    uint8_t* changed_groups_out);
 
+/* The single-chain step with the proposal in delta form (see sbe_step_batch_delta below): moved objects + their new
+ * cluster (-1: none), changed source rows (each object once).  Falls back to sbe_step internally when the two slots'
+ * records do not allow patching.  Outputs as sbe_step. */
+int sbe_step_delta(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* moved_objects, const int32_t* moved_cluster,
+                   int n_moved, const int32_t* changed_objects, int n_changed, const uint8_t* source_rows /* [n_changed][F][C] bool */,
+                   const float* weights /* [F][C] or NULL */, double* group_logliks_out /* [G_total] */, double* mixture_out,
+                   uint8_t* changed_groups_out /* [G_total] or NULL */);
+
 /* The same batched step with the proposals in DELTA form (round 3; what an MCMC operator actually produces): per chain
  * the objects that change cluster with their new cluster index (-1: leaves every cluster; CSR by moved_ptr) and the
  * objects whose source rows change, each listed once (CSR by rows_ptr).  A chain's two slots differ only in what its last

@@ -3518,6 +3518,71 @@ int sbe_step_batch_delta(sbe_engine* e, int n_chains, const int32_t* cur_slots, 
     return SBE_OK;
 }
 
+// The single-chain step in delta form: sbe_step with the proposal as moved objects + changed rows (see
+// sbe_step_batch_delta); the payload sits in the lane's host-mapped block, so no copy-engine operation is in the chain.
+int sbe_step_delta(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* moved_objects, const int32_t* moved_cluster, int n_moved,
+                   const int32_t* changed_objects, int n_changed, const uint8_t* source_rows, const float* weights,
+                   double* group_logliks_out, double* mixture_out, uint8_t* changed_groups_out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, cur_slot); CHECK_SLOT(e, cand_slot);
+    CHECK_PTR(e, group_logliks_out); CHECK_PTR(e, mixture_out);
+    if (cur_slot == cand_slot) return fail(e, SBE_ERR_ARG, "current and candidate slot must differ");
+    const int N = e->N, C = e->C, K = e->G[0];
+    if (n_moved < 0 || n_moved > N || (n_moved > 0 && (!moved_objects || !moved_cluster))) return fail(e, SBE_ERR_ARG, "moved_objects / moved_cluster missing for n_moved=%d", n_moved);
+    if (n_changed < 0 || (n_changed > 0 && (!changed_objects || !source_rows))) return fail(e, SBE_ERR_ARG, "changed_objects / source_rows missing for n_changed=%d", n_changed);
+    for (int i = 0; i < n_moved; ++i) {
+        if (moved_objects[i] < 0 || moved_objects[i] >= N) return fail(e, SBE_ERR_ARG, "moved object index %d out of range", moved_objects[i]);
+        if (moved_cluster[i] < -1 || moved_cluster[i] >= K) return fail(e, SBE_ERR_ARG, "cluster %d out of range [-1,%d)", moved_cluster[i], K);
+    }
+    bool dup = false;
+    for (int i = 0; i < n_changed; ++i) {
+        if (changed_objects[i] < 0 || changed_objects[i] >= N) return fail(e, SBE_ERR_ARG, "object index %d out of range", changed_objects[i]);
+        for (int j = 0; j < i && !dup && n_changed <= 64; ++j) dup = changed_objects[j] == changed_objects[i];
+    }
+    const Slot& cur = e->slots[cur_slot];
+    if (!cur.groups_set || !cur.source_set || !cur.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", cur_slot);
+    for (int c = 0; c < C; ++c)
+        if (!cur.counts_set[c] || !e->conc_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts / concentration of component %d not set", cur_slot, c);
+    HIPCHK(e, hipSetDevice(e->device));
+    // the matrix form serves whatever the patching form cannot: no usable records, a large or repeated row list, a
+    // step that needs the full derivation, tables too large for the one-launch step
+    auto classic = [&]() {
+        std::vector<uint16_t> ids(cur.h_gid.begin(), cur.h_gid.begin() + N);
+        for (int k = 0; k < n_moved; ++k) ids[moved_objects[k]] = moved_cluster[k] < 0 ? kNoGroup : (uint16_t)moved_cluster[k];
+        std::vector<uint8_t> cl((size_t)std::max(K, 1) * N, 0);
+        for (int n = 0; n < N; ++n) if (ids[n] != kNoGroup) cl[(size_t)ids[n] * N + n] = 1;
+        return sbe_step(e, cur_slot, cand_slot, n_moved > 0 ? cl.data() : nullptr, changed_objects, n_changed, source_rows, weights,
+                        group_logliks_out, mixture_out, changed_groups_out);
+    };
+    const bool ok = !dup && n_changed <= std::min(e->step_max_rows, 64) && e->opt_step_form == 0 && !cur.patterns_dirty &&
+                    (int64_t)e->Gtot * e->S * 28 <= 60 * 1024 &&
+                    sync_valid(e->ids_sync[cand_slot], e->ids_sync[cur_slot], cur_slot, e->step_max_rows) &&
+                    sync_valid(e->src_sync[cand_slot], e->src_sync[cur_slot], cur_slot, e->step_max_rows) &&
+                    cur.inc_ok && cur.n_tuples > 0 && e->slots[cand_slot].h_gid.size() == cur.h_gid.size();
+    if (!ok) return classic();
+    const DeltaPlan plan = plan_delta(e, n_moved, n_changed, (int)e->ids_sync[cand_slot].diff.size(), (int)e->src_sync[cand_slot].diff.size(), weights != nullptr);
+    if (plan.total > e->sl.total) return classic();
+    if (e->status_pending) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        int rc = synced(e);
+        if (rc) return rc;
+    }
+    CoreInputs in;
+    if (prepare_step_delta(e, e->h_step_payload, e->d_step_payload, plan, cur_slot, cand_slot, moved_objects, moved_cluster, n_moved,
+                           changed_objects, n_changed, source_rows, weights, in, e->step_moved)) {
+        bump_ids(e, cand_slot);
+        return classic();
+    }
+    int rc = launch_step_core(e, cur_slot, cand_slot, in);
+    if (rc) return rc;
+    commit_src_sync(e, cur_slot, cand_slot, changed_objects, n_changed);
+    commit_ids_sync(e, cur_slot, cand_slot, e->step_moved);
+    StepFinish fin = make_step_finish(e);
+    rc = launch_mixture(e, cand_slot, 1, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, &fin);
+    if (rc) return rc;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return read_step_results(e, cand_slot, group_logliks_out, mixture_out, changed_groups_out, "rows");
+}
+
 // ---- one-call Gibbs source step (GibbsSampleSource._propose, operators.py:495-552, on the resident state) ------
 // candidate = current with the source of the listed objects redrawn from its posterior ON THE DEVICE; count delta,
 // every table, both transition log-probabilities, collapsed per-group and mixture log-likelihood of the candidate:

@@ -704,6 +704,37 @@ class Engine:
                                              opt(w), opt(wm), self._o(glh), self._o(mix), self._o(changed)))
         return glh, mix, changed.astype(bool)
 
+    def step_delta(self, cur_slot, cand_slot, moved_objects=None, moved_cluster=None, changed_objects=None, source_rows=None,
+                   weights=None):
+        """sbe_step with the proposal in delta form: the objects that change cluster and their new cluster (-1: none), the
+        objects whose source rows change (each once) with their rows.  Same return values as step()."""
+        mo = np.ascontiguousarray(moved_objects if moved_objects is not None else [], dtype=np.int32).reshape(-1)
+        mc = np.ascontiguousarray(moved_cluster if moved_cluster is not None else [], dtype=np.int32).reshape(-1)
+        if mo.size != mc.size:
+            raise ValueError("moved_objects and moved_cluster must have the same length")
+        objs = rows = None
+        n_changed = 0
+        if changed_objects is not None and len(changed_objects):
+            objs = np.ascontiguousarray(changed_objects, dtype=np.int32).reshape(-1)
+            rows = np.asarray(source_rows)
+            if rows.shape != (objs.size, self.n_features, self.n_components):
+                raise ValueError("source_rows must be [len(changed_objects), n_features, n_components]")
+            rows = _c(rows.astype(bool, copy=False), np.uint8)
+            n_changed = objs.size
+        w = None
+        if weights is not None:
+            w = _c(weights, np.float32)
+            if w.shape != (self.n_features, self.n_components):
+                raise ValueError("weights must be [n_features, n_components]")
+        glh = np.empty(self.n_groups_total, dtype=np.float64)
+        mix = ct.c_double(0.0)
+        changed = np.zeros(self.n_groups_total, dtype=np.uint8)
+        self._touch(cand_slot)
+        opt = lambda a: self._i(a) if a is not None and a.size else None     # noqa: E731
+        self._check(self._lib.sbe_step_delta(self._h, cur_slot, cand_slot, opt(mo), opt(mc), mo.size, opt(objs), n_changed, opt(rows),
+                                             self._i(w) if w is not None else None, self._o(glh), ct.byref(mix), self._o(changed)))
+        return glh, mix.value, changed.astype(bool)
+
     def step_batch_delta(self, cur_slots, cand_slots, moved_ptr, moved_objects, moved_cluster, rows_ptr=None,
                          changed_objects=None, source_rows=None, weights=None, weights_mask=None):
         """sbe_step_batch with the proposals in delta form: moved_ptr int [n+1] CSR over moved_objects / moved_cluster

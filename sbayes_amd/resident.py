@@ -204,7 +204,14 @@ class ResidentChain:
         if not self._pending:
             raise RuntimeError("no pending proposal")
         self.cur, self.cand = self.cand, self.cur
-        self._clusters = self._cand_clusters
+        if self._cand_clusters is not None:
+            self._clusters = self._cand_clusters
+        elif getattr(self, "_cand_delta", None) is not None:        # step_delta: the accepted moves into the host mirror
+            mo, mc = self._cand_delta
+            self._clusters = self._clusters.copy()
+            self._clusters[:, mo] = False
+            self._clusters[mc[mc >= 0], mo[mc >= 0]] = True
+        self._cand_delta = None
         self._pending = False
 
     def reject(self):
@@ -218,6 +225,20 @@ class ResidentChain:
         glh, mix, changed = self.eng.step(self.cur, self.cand, clusters=clusters, changed_objects=objs,
                                           source_rows=rows, weights=weights)
         self._cand_clusters = np.asarray(clusters, dtype=bool).copy() if clusters is not None else self._clusters
+        self.changed_groups = changed
+        self._probs_dirty[self.cand] = set()
+        self._pending = True
+        return float(glh.sum()), glh, mix
+
+
+    def step_delta(self, moved_objects=None, moved_cluster=None, source_rows=None, weights=None):
+        """step() with the proposal in delta form (sbe_step_delta): the objects that change cluster with their new
+        cluster index (-1: none) instead of the full cluster matrix.  Follow with accept() or reject()."""
+        objs, rows = (None, None) if source_rows is None else source_rows
+        glh, mix, changed = self.eng.step_delta(self.cur, self.cand, moved_objects, moved_cluster, objs, rows, weights)
+        self._cand_clusters = None                   # (built from the delta on accept: nothing [K, N]-sized per step)
+        self._cand_delta = None if moved_objects is None or not len(moved_objects) else \
+            (np.array(moved_objects, dtype=np.int64), np.array(moved_cluster, dtype=np.int64))
         self.changed_groups = changed
         self._probs_dirty[self.cand] = set()
         self._pending = True

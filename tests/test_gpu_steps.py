@@ -569,3 +569,52 @@ def test_step_batch_delta_equals_matrix_form(name, B):
                 assert abs(got - want[3]) <= 1e-10 * abs(want[3])
                 for c in range(C):
                     assert np.array_equal(eng.get_counts(int(cur[i]), c), want[0][c])
+
+
+@pytest.mark.parametrize("name", ["headline", "many_tuples"])
+def test_single_step_delta_equals_matrix_form(name):
+    """sbe_step_delta (ResidentChain-level: moved objects + changed rows, candidate patched in O(delta)) against sbe_step
+    (cluster matrix): thirty chained steps with accepts and rejects on two engines; counts, tables, per-group values
+    and flags bit for bit, the mixture scalar to rounding, the oracle at the end."""
+    wl = make_workload("headline") if name == "headline" else make_workload("tuples", shape=(400, 64, 4, 6, (3, 2), False))
+    feats, na = wl.features, wl.na_values
+    N, F, S = wl.shape
+    C = wl.n_components
+    rng = np.random.default_rng(17)
+    n_groups = [g.shape[0] for g in wl.groups]
+    with Engine(feats, n_groups, n_slots=2) as ea, Engine(feats, n_groups, n_slots=2) as eb:
+        for eng in (ea, eb):
+            for c in range(C):
+                eng.set_concentration(c, wl.concentration[c])
+            eng.load_state(0, wl.groups, wl.weights, source=wl.source)
+            for c in range(C):
+                eng.update_probs(0, c)
+            eng.mixture_loglik(0)
+        cur, cand = 0, 1
+        groups, source, weights = list(wl.groups), wl.source, wl.weights
+        for i_step in range(30):
+            clusters, _g, objs, rows, new_source = _propose(rng, feats, na, groups, source, weights, int(rng.integers(0, 15)),
+                                                           i_step % 3 != 2)
+            new_weights = rng.dirichlet(np.ones(C), size=F).astype(np.float32) if i_step % 7 == 3 else None
+            kw = {"clusters": clusters}
+            if len(objs):
+                kw.update(changed_objects=objs, source_rows=rows)
+            if new_weights is not None:
+                kw["weights"] = new_weights
+            ga, ma, ca = ea.step(cur, cand, **kw)
+            moved = np.flatnonzero((clusters != groups[0]).any(axis=0))
+            mcl = np.where(clusters[:, moved].any(axis=0), clusters[:, moved].argmax(axis=0), -1)
+            gb, mb, cb = eb.step_delta(cur, cand, moved, mcl, objs if len(objs) else None, rows if len(objs) else None, new_weights)
+            assert np.array_equal(ga, gb) and np.array_equal(ca, cb), i_step
+            assert abs(ma - mb) <= 1e-13 * abs(ma), (i_step, ma, mb)
+            for c in range(C):
+                assert np.array_equal(ea.get_counts(cand, c), eb.get_counts(cand, c))
+                assert np.array_equal(ea.get_probs(cand, c), eb.get_probs(cand, c))
+            if rng.random() < 0.6:
+                cur, cand = cand, cur
+                groups, source = [clusters] + groups[1:], new_source
+                weights = new_weights if new_weights is not None else weights
+        want = _expected(feats, na, groups, source, wl.concentration, weights)
+        for eng in (ea, eb):
+            got = eng.mixture_loglik(cur)
+            assert abs(got - want[3]) <= 1e-10 * abs(want[3])

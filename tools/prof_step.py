@@ -20,6 +20,33 @@ for variant in ("full", "no_clusters", "no_rows", "nothing"):
     for _ in range(n):
         chain.step(**kw); chain.accept()
     print(variant, round((time.perf_counter() - t0) / n * 1e6, 1), "us/step")
+# the same step in delta form (sbe_step_delta): one object changes cluster back and forth, the same 20 rows
+cl_of = np.where(clusters.any(axis=0), clusters.argmax(axis=0), -1)
+obj = int(np.flatnonzero(cl_of >= 0)[0])
+alt = [(int(cl_of[obj]) + 1) % clusters.shape[0], int(cl_of[obj])]
+for _ in range(50):
+    chain.step_delta([obj], [alt[_ % 2]], (objs, rows)); chain.accept()
+t0 = time.perf_counter(); n = 500
+for k in range(n):
+    chain.step_delta([obj], [alt[k % 2]], (objs, rows)); chain.accept()
+print("delta form: move + 20 rows", round((time.perf_counter() - t0) / n * 1e6, 1), "us/step")
+t0 = time.perf_counter()
+for k in range(n):
+    chain.step_delta(None, None, (objs, rows)); chain.accept()
+print("delta form: 20 rows", round((time.perf_counter() - t0) / n * 1e6, 1), "us/step")
+# raw engine calls (no ResidentChain bookkeeping): matrix form against delta form
+mo = np.array([obj], dtype=np.int32)
+for form in ("matrix", "delta"):
+    cur, cand = chain.cur, chain.cand
+    t0 = time.perf_counter()
+    for k in range(n):
+        if form == "matrix":
+            eng.step(cur, cand, clusters=clusters, changed_objects=objs, source_rows=rows)
+        else:
+            eng.step_delta(cur, cand, mo, np.array([alt[k % 2]], dtype=np.int32), objs, rows)
+        cur, cand = cand, cur
+    print("Engine-level", form, round((time.perf_counter() - t0) / n * 1e6, 1), "us/step")
+chain.cur, chain.cand = cur, cand
 t0 = time.perf_counter()
 for _ in range(500): eng.copy_slot(chain.cand, chain.cur)
 eng.sync(); print("copy_slot", round((time.perf_counter() - t0) / 500 * 1e6, 1), "us")
