@@ -146,6 +146,32 @@ def one_case(rng, stats, big=False):
                     assert close(mixb[0], m0), (tag, "batched step mixture, chain 0", mixb[0], m0)
                     assert np.array_equal(glh[1], single_b[0]) and close(mixb[1], single_b[1]), (tag, "batched step, chain 1")
                     stats["batched"] = stats.get("batched", 0) + 1
+                    # round 3: the same two proposals once more in DELTA form (both were left pending = rejected: the
+                    # candidates are patched from the records the matrix-form step left), then chained: accept chain 0,
+                    # propose a second delta from the new state
+                    mv0 = np.flatnonzero((clusters != groups[0]).any(axis=0)).astype(np.int32)
+                    mc0 = np.where(clusters[:, mv0].any(axis=0), clusters[:, mv0].argmax(axis=0), -1).astype(np.int32)
+                    args_d = (np.array([0, mv0.size, mv0.size], dtype=np.int32), mv0, mc0,
+                              np.array([0, moved.size, 2 * moved.size], dtype=np.int32), np.concatenate([moved, moved]).astype(np.int32),
+                              np.concatenate([rows, rows]))
+                    glh_d, mix_d, chg_d = eng.step_batch_delta(np.array([0, B + 1]), np.array([B, B + 2]), *args_d)
+                    assert np.array_equal(glh_d, glh) and np.array_equal(chg_d, chg), (tag, "delta batched step")
+                    assert close(mix_d[0], mixb[0]) and close(mix_d[1], mixb[1]), (tag, "delta batched mixture", mix_d, mixb)
+                    # accept chain 0 (slots swap roles), move one more object, compare with the matrix form on a copy
+                    n2 = int(rng.integers(0, N))
+                    k2 = int(rng.integers(-1, clusters.shape[0]))
+                    cl2 = clusters.copy()
+                    cl2[:, n2] = False
+                    if k2 >= 0:
+                        cl2[k2, n2] = True
+                    if orc.has_components([cl2] + groups[1:]).any(axis=1).all():
+                        g_d, m_d, c_d = eng.step_delta(B, 0, [n2], [k2])
+                        eng.copy_slot(B + 1, B)
+                        g_m, m_m, c_m = eng.step(B + 1, B + 2, clusters=cl2)
+                        assert np.array_equal(g_d, g_m) and np.array_equal(c_d, c_m) and close(m_d, m_m), (tag, "chained delta step")
+                        for c in range(C):
+                            assert np.array_equal(eng.get_counts(0, c), eng.get_counts(B + 2, c)), (tag, "chained delta counts", c)
+                    stats["delta"] = stats.get("delta", 0) + 1
         # one-call Gibbs step from state 0: counts consistent with the source it drew
         eng.set_option(step_form=0)
         objs = np.unique(rng.integers(0, N, size=min(6, N))).astype(np.int32)
