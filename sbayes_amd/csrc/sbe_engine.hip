@@ -473,7 +473,14 @@ bool update_patterns_and_tuples(sbe_engine* e, Slot& s, const int32_t* moved, co
         s.h_tid[n] = (uint8_t)t1;
         s.h_toff[n] = (uint32_t)t1 * (uint32_t)(e->S + 1) * 512u;
     }
-    return true;
+    // the table must stay DENSE: the number of tuples decides which fused kernel evaluates the slot and with which
+    // geometry, and that must not depend on the slot's history (found by tools/fuzz_gpu.py: a vacated index inside the
+    // table made the two step forms pick different kernels at N = 18).  Vacated indices at the end are dropped; one in
+    // the middle sends the step to the full derivation.
+    while (s.n_tuples > 0 && s.tup_cnt[s.n_tuples - 1] == 0) --s.n_tuples;
+    for (int t = 0; t < s.n_tuples; ++t)
+        if (s.tup_cnt[t] == 0) return false;
+    return s.n_tuples > 0;
 }
 
 int upload_patterns_and_weights(sbe_engine* e, int slot) {
@@ -1698,7 +1705,7 @@ int sbe_collapsed_loglik_all(sbe_engine* e, int slot, double* per_group_out) {
     k_dcl<int32_t><<<div_up((int64_t)G * e->F, 256), 256, 0, e->stream>>>(e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc,
                                                                        d_pf, 0, G, e->F, e->S, 1);
     HIPCHK(e, hipGetLastError());
-    k_group_sum_f32<<<div_up(G, 64), 64, 0, e->stream>>>(d_pf, d_pg, G, e->F);
+    k_group_sum_f32<<<div_up((int64_t)G * 8, 64), 64, 0, e->stream>>>(d_pf, d_pg, G, e->F);
     HIPCHK(e, hipGetLastError());
     return d2h(e, per_group_out, d_pg, (size_t)G * sizeof(double));
 }
@@ -1723,13 +1730,13 @@ int sbe_collapsed_loglik(sbe_engine* e, int slot, int component, double* per_gro
     if (!per_feature_out) {                    // the G doubles land in host-mapped memory: no copy-engine hop in the chain
         rc = ensure_io(e, (size_t)G * sizeof(double));
         if (rc) return rc;
-        k_group_sum_f32<<<div_up(G, 64), 64, 0, e->stream>>>(d_pf, (double*)e->d_io, G, e->F);
+        k_group_sum_f32<<<div_up((int64_t)G * 8, 64), 64, 0, e->stream>>>(d_pf, (double*)e->d_io, G, e->F);
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipStreamSynchronize(e->stream));
         memcpy(per_group_out, e->h_io, (size_t)G * sizeof(double));
         return synced(e);
     }
-    k_group_sum_f32<<<div_up(G, 64), 64, 0, e->stream>>>(d_pf, d_pg, G, e->F);
+    k_group_sum_f32<<<div_up((int64_t)G * 8, 64), 64, 0, e->stream>>>(d_pf, d_pg, G, e->F);
     HIPCHK(e, hipGetLastError());
     rc = d2h(e, per_group_out, d_pg, (size_t)G * sizeof(double));
     if (rc) return rc;
@@ -1803,7 +1810,7 @@ int sbe_dirichlet_logpdf(sbe_engine* e, const float* counts, int n_groups, const
     k_dcl<float><<<div_up((int64_t)n_groups * e->F, 256), 256, 0, e->stream>>>(d_cnt, d_a, d_pf, 0, n_groups, e->F, e->S, conc_per_group ? 1 : 0);
     HIPCHK(e, hipGetLastError());
     if (per_group_out) {
-        k_group_sum_f32<<<div_up(n_groups, 64), 64, 0, e->stream>>>(d_pf, d_pg, n_groups, e->F);
+        k_group_sum_f32<<<div_up((int64_t)n_groups * 8, 64), 64, 0, e->stream>>>(d_pf, d_pg, n_groups, e->F);
         HIPCHK(e, hipGetLastError());
         rc = d2h(e, per_group_out, d_pg, (size_t)n_groups * sizeof(double));
         if (rc) return rc;
@@ -3742,7 +3749,7 @@ static int step_general(sbe_engine* e, int cur_slot, int cand_slot, const uint8_
     // collapsed likelihood of every group (a7/a8) into a device buffer
     k_dcl<int32_t><<<div_up((int64_t)e->Gtot * e->F, 256), 256, 0, e->stream>>>(
         e->d_counts + (int64_t)cand_slot * e->table_elems(), e->d_conc, e->d_step_pf, 0, e->Gtot, e->F, e->S, 1);
-    k_group_sum_f32<<<div_up(e->Gtot, 64), 64, 0, e->stream>>>(e->d_step_pf, e->d_step_pg, e->Gtot, e->F);
+    k_group_sum_f32<<<div_up((int64_t)e->Gtot * 8, 64), 64, 0, e->stream>>>(e->d_step_pf, e->d_step_pg, e->Gtot, e->F);
     HIPCHK(e, hipGetLastError());
     rc = enqueue_mixture(e, cand_slot, 1, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS);
     if (rc) return done(rc);

@@ -82,6 +82,51 @@ __device__ T np_pairwise_sum(Get get, int n) {
     return ret;
 }
 
+// The same sum computed by EIGHT consecutive lanes together (lane j of the octet owns NumPy's accumulator r[j] of every
+// 128-element leaf; the leaf's r[] tree is three shuffle steps): identical operations in identical order, so the result
+// is bit for bit np_pairwise_sum's, at an eighth of the dependent-add chain.  Every lane of the octet must call it with
+// the same n; the result is valid on all eight lanes.  (round 3: the step epilogue's per-group sums over F features)
+template <class Get>
+__device__ float np_pairwise_sum_f32_x8(Get get, int n, int j) {
+    auto leaf = [&](int lo, int m) -> float {
+        float res;
+        if (m < 8) {
+            res = 0.0f;
+            for (int i = 0; i < m; ++i) res = res + get(lo + i);
+        } else {
+            float r = get(lo + j);
+            const int lim = m - (m % 8);
+            for (int i = 8; i < lim; i += 8) r = r + get(lo + i + j);
+            r = r + __shfl_down(r, 1, 8);                    // lanes 0, 2, 4, 6: r0+r1, r2+r3, r4+r5, r6+r7
+            r = r + __shfl_down(r, 2, 8);                    // lanes 0, 4: (r0+r1)+(r2+r3), (r4+r5)+(r6+r7)
+            r = r + __shfl_down(r, 4, 8);                    // lane 0
+            res = __shfl(r, 0, 8);
+            for (int i = lim; i < m; ++i) res = res + get(lo + i);
+        }
+        return res;
+    };
+    if (n <= 128) return leaf(0, n);
+    struct Frame { int lo, n, stage; float left; };
+    Frame st[28];
+    int sp = 0;
+    float ret = 0.0f;
+    st[sp++] = Frame{0, n, 0, 0.0f};
+    while (sp > 0) {
+        Frame& f = st[sp - 1];
+        if (f.stage == 0) {
+            if (f.n <= 128) { ret = leaf(f.lo, f.n); --sp; }
+            else { int n2 = f.n / 2; n2 -= n2 % 8; f.stage = 1; st[sp++] = Frame{f.lo, n2, 0, 0.0f}; }
+        } else if (f.stage == 1) {
+            f.left = ret; f.stage = 2;
+            int n2 = f.n / 2; n2 -= n2 % 8;
+            st[sp++] = Frame{f.lo + n2, f.n - n2, 0, 0.0f};
+        } else {
+            ret = f.left + ret; --sp;
+        }
+    }
+    return ret;
+}
+
 // ------------------------------------------------------------------------------------------
 // wave64 / block reductions (fixed order => run-to-run deterministic)
 // ------------------------------------------------------------------------------------------
@@ -660,11 +705,13 @@ __global__ void k_dcl(const TC* __restrict__ counts, const double* __restrict__ 
 
 __global__ void k_group_sum_f32(const float* __restrict__ per_feature, double* __restrict__ per_group,
                                 int n_groups, int F) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    // one group per octet of lanes (np_pairwise_sum_f32_x8: NumPy's order, an eighth of the dependent chain)
+    const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
     if (g >= n_groups) return;
     const float* p = per_feature + (int64_t)g * F;
     auto get = [&](int i) -> float { return p[i]; };
-    per_group[g] = (double)np_pairwise_sum<float>(get, F);
+    const float total = np_pairwise_sum_f32_x8(get, F, (int)(threadIdx.x & 7));
+    if ((threadIdx.x & 7) == 0) per_group[g] = (double)total;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -739,11 +786,16 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __rest
                 for (int i = threadIdx.x; i < ng * fin.F; i += kBlock) stage[i] = fin.per_feature[(int64_t)g0 * fin.F + i];
                 __syncthreads();
             }
-            for (int g = threadIdx.x; g < ng; g += kBlock) {
+            // one group per octet of lanes: NumPy's float32 pairwise sum over the F features with its eight accumulators
+            // on eight lanes (np_pairwise_sum_f32_x8) -- a thread per group walked 200 dependent LDS reads + adds (6 us)
+            for (int g = threadIdx.x >> 3; g < ng; g += kBlock / 8) {
                 const float* p = fits ? stage + g * fin.F : fin.per_feature + (int64_t)(g0 + g) * fin.F;
                 auto get = [&](int i) -> float { return p[i]; };
-                fin.group_out[g0 + g] = (double)np_pairwise_sum<float>(get, fin.F);
-                fin.changed_out[g0 + g] = fin.stamp ? (uint8_t)(fin.stamp[g0 + g] == fin.step_id) : fin.changed[g0 + g];
+                const float total = np_pairwise_sum_f32_x8(get, fin.F, (int)(threadIdx.x & 7));
+                if ((threadIdx.x & 7) == 0) {
+                    fin.group_out[g0 + g] = (double)total;
+                    fin.changed_out[g0 + g] = fin.stamp ? (uint8_t)(fin.stamp[g0 + g] == fin.step_id) : fin.changed[g0 + g];
+                }
             }
             __syncthreads();
         }

@@ -133,3 +133,39 @@ def test_small_api_corners():
     want = orc.normalize_weights(wl.weights, hc)
     assert np.array_equal(normalize_weights(wl.weights, hc), want)
     release_all()
+
+
+@pytest.mark.parametrize("F", [3, 8, 37, 128, 130, 200, 333, 500, 1031])
+def test_group_sums_follow_numpys_float32_pairwise_order(F):
+    """Round 3: the per-group sums over the F per-feature values (likelihood.py:74-77: a float32 ndarray.sum()) run on eight
+    lanes per group (np_pairwise_sum_f32_x8) -- NumPy's pairwise order exactly: the device's own float32 per-feature
+    values summed by NumPy must give the device's per-group value BIT FOR BIT, for every leaf / tail structure of F;
+    and the one-call step's epilogue (the same routine) must agree with it."""
+    import numpy as np
+    from sbayes_amd.engine import Engine
+    rng = np.random.default_rng(F)
+    N, S, G = 40, 4, 5
+    x = rng.integers(0, S, size=(N, F))
+    feats = np.eye(S, dtype=bool)[x]
+    groups = [np.stack([rng.integers(0, G + 1, size=N) == g for g in range(G)]), np.ones((1, N), dtype=bool)]
+    conc = [np.ones((F, S)), np.ones((1, F, S))]
+    with Engine(feats, [G, 1], n_slots=2) as eng:
+        counts = rng.integers(0, 30, size=(G, F, S)).astype(np.float32)
+        pf, pg = eng.dirichlet_logpdf(counts, conc[0], per_group=True)
+        assert pf.dtype == np.float32
+        for g in range(G):
+            assert pg[g] == np.float64(pf[g].sum()), (F, g)            # ndarray.sum() of a float32 row: NumPy's pairwise order
+        # the step epilogue: per-group values of a candidate equal the stateless call on its counts
+        src = np.zeros((N, F, 2), dtype=bool)
+        src[..., 0] = groups[0].any(axis=0)[:, None]
+        src[..., 1] = ~src[..., 0]
+        for c in range(2):
+            eng.set_concentration(c, conc[c])
+        eng.load_state(0, groups, np.full((F, 2), 0.5, dtype=np.float32), source=src)
+        for c in range(2):
+            eng.update_probs(0, c)
+        eng.mixture_loglik(0)
+        glh, _mix, _chg = eng.step(0, 1, changed_objects=np.array([0, 1], dtype=np.int32), source_rows=src[[0, 1]])
+        for c, (lo, hi) in enumerate(((0, G), (G, G + 1))):
+            _pf, want = eng.dirichlet_logpdf(eng.get_counts(1, c), conc[c], per_group=True)
+            assert np.array_equal(glh[lo:hi], want), (F, c)

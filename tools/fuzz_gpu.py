@@ -54,7 +54,7 @@ def one_case(rng, stats, big=False):
     feats, groups0, _w, _s, conc = random_case(rng, N, F, S, n_groups, na_rate)
     na = ~feats.any(-1)
     tag = f"N{N} F{F} S{S} groups{n_groups} B{B} na{na_rate}"
-    with Engine(feats, n_groups, n_slots=B + 3) as eng:
+    with Engine(feats, n_groups, n_slots=B + 5) as eng:
         for c in range(C):
             eng.set_concentration(c, conc[c])
         want, states = [], []
@@ -157,20 +157,21 @@ def one_case(rng, stats, big=False):
                     glh_d, mix_d, chg_d = eng.step_batch_delta(np.array([0, B + 1]), np.array([B, B + 2]), *args_d)
                     assert np.array_equal(glh_d, glh) and np.array_equal(chg_d, chg), (tag, "delta batched step")
                     assert close(mix_d[0], mixb[0]) and close(mix_d[1], mixb[1]), (tag, "delta batched mixture", mix_d, mixb)
-                    # accept chain 0 (slots swap roles), move one more object, compare with the matrix form on a copy
+                    # accept chain 1 (its slots swap roles: B + 2 is current now), move one more object in delta form -- the
+                    # candidate B + 1 is patched from the records -- and compare with the matrix form on copies (B + 3, B + 4)
                     n2 = int(rng.integers(0, N))
                     k2 = int(rng.integers(-1, clusters.shape[0]))
-                    cl2 = clusters.copy()
+                    cl2 = groups[0].copy()
                     cl2[:, n2] = False
                     if k2 >= 0:
                         cl2[k2, n2] = True
                     if orc.has_components([cl2] + groups[1:]).any(axis=1).all():
-                        g_d, m_d, c_d = eng.step_delta(B, 0, [n2], [k2])
-                        eng.copy_slot(B + 1, B)
-                        g_m, m_m, c_m = eng.step(B + 1, B + 2, clusters=cl2)
+                        eng.copy_slot(B + 3, B + 2)
+                        g_d, m_d, c_d = eng.step_delta(B + 2, B + 1, [n2], [k2])
+                        g_m, m_m, c_m = eng.step(B + 3, B + 4, clusters=cl2)
                         assert np.array_equal(g_d, g_m) and np.array_equal(c_d, c_m) and close(m_d, m_m), (tag, "chained delta step")
                         for c in range(C):
-                            assert np.array_equal(eng.get_counts(0, c), eng.get_counts(B + 2, c)), (tag, "chained delta counts", c)
+                            assert np.array_equal(eng.get_counts(B + 1, c), eng.get_counts(B + 4, c)), (tag, "chained delta counts", c)
                     stats["delta"] = stats.get("delta", 0) + 1
         # one-call Gibbs step from state 0: counts consistent with the source it drew
         eng.set_option(step_form=0)
