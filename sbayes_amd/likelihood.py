@@ -169,6 +169,14 @@ class NormalizedWeights(np.lib.mixins.NDArrayOperatorsMixin):
         except TypeError:
             self._owner = None
 
+    # Samples are pickled (MC3 pipes, StateDumper: sbayes/mcmc_setup.py:320-324, sampling/loggers.py:426-442): the
+    # weights travel as their two small inputs; the sample reference and the feature block stay behind
+    def __getstate__(self):
+        return {"_weights": self._weights, "_has_components": self._has_components, "_features": None, "_full": None, "_owner": None}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
     def sample_if_current(self):
         """The sample update_weights() derived this array from, if it still has these weights and this has_components
         (device forms that work on the sample's resident state -- source_lh_by_feature -- use it instead of the

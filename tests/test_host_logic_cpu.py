@@ -241,3 +241,25 @@ def test_argument_validation_happens_before_the_abi():
         Engine(np.zeros((3, 4), dtype=bool), [1])
     with pytest.raises(TypeError, match="bool"):
         Engine(np.zeros((3, 4, 2), dtype=np.float64), [1])
+
+
+def test_sample_with_lazy_normalized_weights_pickles_and_copies(fake):
+    """Round 3: update_weights() caches a lazily materialised NormalizedWeights that remembers its sample (weakly).  Samples
+    are pickled by the reference (MC3 pipes, StateDumper) and copied on every proposal: the cached object must survive
+    both -- as its two small inputs, without the sample reference -- and still give the reference's array."""
+    fx = load_npz("cfg1")
+    model, sample = build(fx)
+    w = likelihood.update_weights(sample, features=model.data.features.values)
+    assert isinstance(w, likelihood.NormalizedWeights) and w.sample_if_current() is sample
+    want = np.asarray(w).copy()
+    assert np.array_equal(want, fx.z["weights_normalized"])
+    clone = pickle.loads(pickle.dumps(sample))
+    cw = clone.cache.weights_normalized.value
+    assert isinstance(cw, likelihood.NormalizedWeights) and cw.sample_if_current() is None
+    assert np.array_equal(np.asarray(cw), want)
+    cand = sample.copy()
+    assert cand.cache.weights_normalized.value is w                                  # immutable: copies share it
+    rows = w[[1, 3, 4]]
+    assert np.array_equal(rows, want[[1, 3, 4]])
+    sample.weights.set_value(sample.weights.value[:, ::-1].copy())
+    assert w.sample_if_current() is None                                              # no longer that sample's weights
