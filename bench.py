@@ -7,8 +7,8 @@ Metric (BASELINE.json): log-likelihood evals/sec at 1000 sites x 200 feats x 10 
 
 A "step" = one pass of the hot path over one batch: `--batch` B distinct resident sample
 states (independent chains / candidate states of the sampler, sbayes/sampling/mcmc.py:239-241)
-evaluated by one launch sequence of the fused kernel (default B = 1024: four generations of
-workgroups per launch).  Everything (feature block, group ids, probability tables, weights) is
+evaluated by one launch sequence of the fused kernel (default B = 2048: eight generations of
+workgroups per launch; measured 1024 / 2048 / 4096 -> 18.1 / 19.8 / 19.4 M evals/s).  Everything (feature block, group ids, probability tables, weights) is
 resident in HBM before the timed region; the B scalars are fetched to the host inside it.
 `single_chain` in the output line is what ONE chain sees (B = 1, host-synchronous), `per_config`
 covers every 1-GPU BASELINE config (cfg1, south_america, headline, stress) at B = 1 / 8 / 64.
@@ -46,6 +46,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 N_SIMDS = 1024             # 256 CUs x 4 SIMD-32
+HEADLINE_BATCH = 2048      # resident states per launch sequence (tools/summarize_profiles.py keys the PMC passes on it)
 NOMINAL_CLOCK_GHZ = 2.4    # MI355X_MICROARCH.md "Max clock"
 PMC_FILE = "profiles/r3/pmc_summary.json"
 TRAFFIC_FILE = "profiles/traffic_latest.json"
@@ -63,7 +64,7 @@ def parse():
     ap.add_argument("--workload", default="headline", choices=["cfg1", "south_america", "headline", "stress"])
     ap.add_argument("--batch", type=int, default=None,
                     help="resident sample states (chains x candidate states) evaluated per step "
-                         "(default: 1024 for cfg1 / south_america / headline, 64 for stress)")
+                         "(default: 2048 for cfg1 / south_america / headline, 64 for stress)")
     ap.add_argument("--kernel", default="packed", choices=["packed", "packed_general", "packed_v2", "packed_tuple_lds", "onehot", "onehot_general"],
                     help="packed: state-index stream, group-tuple form when it applies (default); "
                          "packed_general: never the group-tuple form (k_mixture_rows); packed_v2: the older general "
@@ -109,7 +110,7 @@ def setup_engine(wl, batch, device, kernel="packed", log_mode="product"):
     """Engine with `batch` distinct resident states.  Slot 0 is the workload's own state (the parity gate checks it
     against the oracle); the others get random clusters and weights from the host (a few KB each) and their source
     assignment drawn ON THE DEVICE from its prior given those (sbe_sample_source, Philox stream) -- the recipe of
-    sbayes_amd.synthetic.make_state without N*F*C host work per state, so 1024 states are ready in about a second
+    sbayes_amd.synthetic.make_state without N*F*C host work per state, so a few thousand states are ready in a second or two
     and eight ranks do not spend minutes of start-up in eight contending Python processes."""
     from sbayes_amd.engine import (LOG_PER_OBS, LOG_PRODUCT, MIXTURE_ONEHOT, MIXTURE_ONEHOT_GENERAL, MIXTURE_PACKED,
                                    MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE_LDS, MIXTURE_PACKED_V2, Engine)
@@ -280,7 +281,7 @@ def secondary_figures(eng, wl, B, args):
                            "kernel_us": round(k1 * 1e3, 3),
                            "note": "one chain, one state per call, host-synchronous (BASELINE configs[2] '1 chain')"}
     sweep = {}
-    for b in (1, 8, 64, 256, 1024):
+    for b in (1, 8, 64, 256, 1024, 2048, 4096):
         if b > B:
             break
         r, kb = batch_rate(eng, b)
@@ -499,7 +500,7 @@ def main():
     device = chains.device_for(local_rank, n_dev)
     wl = load_workload(args.workload)
     n_obj, n_feat, n_states = wl.shape
-    B = args.batch if args.batch else (64 if args.workload == "stress" else 1024)
+    B = args.batch if args.batch else (64 if args.workload == "stress" else HEADLINE_BATCH)
     t_setup = time.perf_counter()
     eng = setup_engine(wl, B, device, args.kernel, args.log_mode)
     t_setup = time.perf_counter() - t_setup

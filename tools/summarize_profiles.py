@@ -60,7 +60,7 @@ corr4 = 1.0 / calib["read_dword"]["reported_fraction"] if "read_dword" in calib 
 corr16 = 1.0 / calib["read_dwordx4"]["reported_fraction"] if "read_dwordx4" in calib else None
 
 traffic = {}
-CASES = [("headline", 1024, k) for k in ("packed", "packed_tuple_lds", "packed_general", "packed_v2", "onehot", "onehot_general")] + \
+CASES = [("headline", 2048, k) for k in ("packed", "packed_tuple_lds", "packed_general", "packed_v2", "onehot", "onehot_general")] + \
         [("stress", b, k) for k in ("packed", "packed_v2", "onehot") for b in (8, 64)]
 for wl, batch, kern in CASES:
         suffix = kern if wl == "headline" else f"stress_{kern}_b{batch}"
