@@ -111,6 +111,7 @@ struct sbe_engine {
     double* h_results = nullptr;   // pinned + mapped [slots]: k_reduce_partials writes straight to the host
     int* d_status = nullptr;       // [ST_WORDS]
     int* h_status = nullptr;       // pinned
+    int* h_flag = nullptr;  int* d_flag = nullptr;   // host-mapped [ST_WORDS]: "a kernel raised this word" (raise_status)
     uint8_t* d_changed = nullptr;  // [Gtot]
     uint32_t* d_step_stamp = nullptr;  uint32_t step_id = 0;   // [Gtot] group changed in step `step_id` (k_step_core)
     float* d_step_pf = nullptr;    // [Gtot][F]  per-feature collapsed log-pdf of the fused step call
@@ -142,7 +143,7 @@ struct sbe_engine {
     uint8_t* d_scratch = nullptr;  size_t scratch_bytes = 0;     // general staging
     uint8_t* h_pinned = nullptr;   size_t pinned_bytes = 0;      // pinned D2H staging
     std::vector<hipEvent_t> d2h_events;                          // piecewise D2H of large results (d2h)
-    uint8_t* h_arena = nullptr;    size_t arena_bytes = 0, arena_off = 0;   // pinned H2D staging ring
+    uint8_t* h_arena = nullptr;    uint8_t* d_arena = nullptr;   size_t arena_bytes = 0, arena_off = 0;   // pinned, host-mapped H2D staging ring
     int opt_step_form = 0;         // SBE_OPT_STEP_FORM
     int opt_step_derive = 0;       // SBE_OPT_STEP_DERIVE: 1 = always re-derive patterns / tuples from all objects
     int opt_deferred = 0;          // SBE_OPT_DEFERRED_CHECKS: data checks reported at the next sync
@@ -308,21 +309,87 @@ int upload(sbe_engine* e, void* dst_dev, const void* src, size_t bytes) {
     return SBE_OK;
 }
 
-// Data checks raised by kernels (normalize's positive-sum assert, one-hot source).  Immediate mode:
-// synchronize and report now.  Deferred mode (SBE_OPT_DEFERRED_CHECKS): queue the status read-back and
-// report at the next call that synchronizes anyway.
-int report_status(sbe_engine* e) {
+// Host data that ONE kernel reads once, element-parallel (rows to ingest, index lists): staged in the mapped ring and
+// read by that kernel in place over PCIe -- no copy operation in the stream, one enqueue per setter instead of one per
+// array.  (Not for kernels that WALK their input: every dependent step would be a PCIe round trip -- sbe_counts_delta.)
+// Payloads above 64 KB go to `dev_fallback` with an ordinary upload.  *out = what the kernel reads.
+int stage(sbe_engine* e, const void* src, size_t bytes, void* dev_fallback, const void** out) {
+    constexpr size_t kDirect = (size_t)64 << 10;
+    *out = dev_fallback;
+    if (bytes == 0) return SBE_OK;
+    if (!e->d_arena || bytes > kDirect) return upload(e, dev_fallback, src, bytes);
+    const size_t need = (bytes + 63) / 64 * 64;
+    if (e->arena_off + need > e->arena_bytes) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        e->arena_off = 0;
+    }
+    memcpy(e->h_arena + e->arena_off, src, bytes);
+    *out = e->d_arena + e->arena_off;
+    e->arena_off += need;
+    return SBE_OK;
+}
+
+// Up to eight small host arrays to their resident places with ONE enqueue (k_scatter_bytes out of the mapped ring);
+// ordinary uploads, one per array, when the arrays do not fit the direct path.
+struct UploadSeg { void* dst; const void* src; size_t bytes; };
+int upload_segments(sbe_engine* e, const UploadSeg* segs, int n) {
+    size_t total = 0, largest = 0;
+    for (int i = 0; i < n; ++i) { total += (segs[i].bytes + 63) / 64 * 64; largest = std::max(largest, segs[i].bytes); }
+    if (total == 0) return SBE_OK;
+    if (!e->d_arena || n > 8 || total > ((size_t)64 << 10)) {
+        for (int i = 0; i < n; ++i) { int rc = upload(e, segs[i].dst, segs[i].src, segs[i].bytes); if (rc) return rc; }
+        return SBE_OK;
+    }
+    if (e->arena_off + total > e->arena_bytes) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        e->arena_off = 0;
+    }
+    ScatterSegs sg{};
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (segs[i].bytes == 0) continue;
+        memcpy(e->h_arena + e->arena_off + off, segs[i].src, segs[i].bytes);
+        sg.dst[sg.n] = (uint8_t*)segs[i].dst; sg.off[sg.n] = (uint32_t)off; sg.bytes[sg.n] = (uint32_t)segs[i].bytes;
+        ++sg.n;
+        off += (segs[i].bytes + 63) / 64 * 64;
+    }
+    k_scatter_bytes<<<dim3((unsigned)std::min<size_t>(div_up((int64_t)largest, 1024), 16), sg.n), 256, 0, e->stream>>>(e->d_arena + e->arena_off, sg);
+    HIPCHK(e, hipGetLastError());
+    e->arena_off += total;
+    return SBE_OK;
+}
+
+// The device words hold the counts; the host-mapped flag words (raise_status) say whether anything was raised, so a
+// clean call costs no read-back.  Flags are read after a stream synchronisation (kernel stores are visible then).
+bool status_raised(const sbe_engine* e) {
+    const volatile int* f = e->h_flag;
+    return (f[ST_BAD_NORMALIZE] | f[ST_MULTI_SOURCE]) != 0;
+}
+
+// slow path (something was raised): the counts into h_status, device words and flags back to zero.  Stream idle on return.
+int fetch_and_clear_status(sbe_engine* e) {
+    HIPCHK(e, hipMemcpyAsync(e->h_status, e->d_status, ST_FLAG_PTR * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemsetAsync(e->d_status + ST_BAD_NORMALIZE, 0, 2 * sizeof(int), e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->h_flag[ST_BAD_NORMALIZE] = e->h_flag[ST_MULTI_SOURCE] = 0;
+    return SBE_OK;
+}
+
+int report_status(sbe_engine* e) {        // after a stream synchronisation
+    if (!status_raised(e)) return SBE_OK;
+    int rc = fetch_and_clear_status(e);
+    if (rc) return rc;
     const int bad_norm = e->h_status[ST_BAD_NORMALIZE], multi_src = e->h_status[ST_MULTI_SOURCE];
-    if (!bad_norm && !multi_src) return SBE_OK;
     e->h_status[ST_BAD_NORMALIZE] = e->h_status[ST_MULTI_SOURCE] = 0;
-    (void)hipMemsetAsync(e->d_status + ST_BAD_NORMALIZE, 0, 2 * sizeof(int), e->stream);
     if (bad_norm)
         return fail(e, SBE_ERR_DATA, "normalize: %d rows have a non-positive sum (sbayes/util.py:1006 assert)", bad_norm);
     return fail(e, SBE_ERR_DATA, "source is not one-hot over components in %d observations", multi_src);
 }
 
+// Data checks raised by kernels (normalize's positive-sum assert, one-hot source).  Immediate mode: synchronize and
+// report now.  Deferred mode (SBE_OPT_DEFERRED_CHECKS): nothing is enqueued; the next call that synchronizes anyway
+// looks at the flag words and reports.
 int check_after(sbe_engine* e) {          // after enqueuing a kernel that may raise a data check
-    HIPCHK(e, hipMemcpyAsync(e->h_status, e->d_status, ST_WORDS * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     if (e->opt_deferred) { e->status_pending = true; return SBE_OK; }
     HIPCHK(e, hipStreamSynchronize(e->stream));
     e->status_pending = false;
@@ -335,15 +402,23 @@ int synced(sbe_engine* e) {               // call right after any hipStreamSynch
     return report_status(e);
 }
 
+// Synchronize; deliver a deferred report; then leave THIS call's counts in h_status (zeros when nothing was raised)
+// for callers with their own wording.  Device words and flags are cleared either way.
 int read_status(sbe_engine* e) {
-    HIPCHK(e, hipMemcpyAsync(e->h_status, e->d_status, ST_WORDS * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    int rc = synced(e);
+    if (rc) return rc;
+    e->h_status[ST_BAD_NORMALIZE] = e->h_status[ST_MULTI_SOURCE] = 0;
+    if (status_raised(e)) return fetch_and_clear_status(e);
     return SBE_OK;
 }
 
 int clear_status_word(sbe_engine* e, int word) {
     if (e->status_pending) return SBE_OK;      // sticky until the deferred report has been delivered
+    if (!e->h_flag[word]) return SBE_OK;       // never raised since the last report: the device word is zero
+    HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipMemsetAsync(e->d_status + word, 0, sizeof(int), e->stream));
+    e->h_flag[word] = 0;
     return SBE_OK;
 }
 
@@ -483,35 +558,40 @@ bool update_patterns_and_tuples(sbe_engine* e, Slot& s, const int32_t* moved, co
     return s.n_tuples > 0;
 }
 
-int upload_patterns_and_weights(sbe_engine* e, int slot) {
+int upload_patterns_and_weights(sbe_engine* e, int slot, const float* new_weights = nullptr) {
     Slot& s = e->slots[slot];
     if (s.patterns_dirty) {
         derive_patterns(e, s);
         if ((int)s.patterns.size() > e->Pmax)
             return fail(e, SBE_ERR_ARG, "%zu distinct has_components patterns exceed capacity %d",
                         s.patterns.size(), e->Pmax);
-        { int _urc = upload(e, e->d_pid + (int64_t)slot * e->Np, s.h_pid.data(), e->N); if (_urc) return _urc; }
-        { int _urc = upload(e, e->d_patbits + (int64_t)slot * e->Pmax, s.patterns.data(),
-                                 s.patterns.size() * sizeof(uint32_t)); if (_urc) return _urc; }
         derive_tuples(e, s);
+        UploadSeg segs[6] = {{e->d_pid + (int64_t)slot * e->Np, s.h_pid.data(), (size_t)e->N},
+                             {e->d_patbits + (int64_t)slot * e->Pmax, s.patterns.data(), s.patterns.size() * sizeof(uint32_t)}};
+        int n_segs = 2;
         if (s.n_tuples) {
-            { int _urc = upload(e, e->d_tid + (int64_t)slot * e->Np, s.h_tid.data(), e->Np); if (_urc) return _urc; }
-            { int _urc = upload(e, e->d_toff + (int64_t)slot * e->Np, s.h_toff.data(), (size_t)e->Np * sizeof(uint32_t)); if (_urc) return _urc; }
-            { int _urc = upload(e, e->d_tuple_g + (int64_t)slot * kMaxTuples * kMaxComponents, s.h_tuple_g.data(),
-                                     s.h_tuple_g.size() * sizeof(uint16_t)); if (_urc) return _urc; }
-            { int _urc = upload(e, e->d_tuple_p + (int64_t)slot * kMaxTuples, s.h_tuple_p.data(), s.h_tuple_p.size()); if (_urc) return _urc; }
+            segs[n_segs++] = {e->d_tid + (int64_t)slot * e->Np, s.h_tid.data(), (size_t)e->Np};
+            segs[n_segs++] = {e->d_toff + (int64_t)slot * e->Np, s.h_toff.data(), (size_t)e->Np * sizeof(uint32_t)};
+            segs[n_segs++] = {e->d_tuple_g + (int64_t)slot * kMaxTuples * kMaxComponents, s.h_tuple_g.data(), s.h_tuple_g.size() * sizeof(uint16_t)};
+            segs[n_segs++] = {e->d_tuple_p + (int64_t)slot * kMaxTuples, s.h_tuple_p.data(), s.h_tuple_p.size()};
         }
+        { int _urc = upload_segments(e, segs, n_segs); if (_urc) return _urc; }
         s.patterns_dirty = false;
     }
-    if (s.weights_set) {
-        const int P = (int)s.patterns.size();
+    float* d_w = e->d_weights + (int64_t)slot * e->F * e->C;
+    const int P = (int)s.patterns.size();
+    if (new_weights && P == 0) {                   // nothing to normalise for: just keep the weights
+        int rc = upload(e, d_w, new_weights, (size_t)e->F * e->C * sizeof(float));
+        if (rc) return rc;
+    }
+    if ((s.weights_set || new_weights) && P > 0) {
+        // one launch: per-pattern normalised weights, their tile-transposed copy and -- sbe_set_weights -- the slot's
+        // resident copy of the new weights, read out of the mapped staging ring
+        const void* w_in = d_w;
+        if (new_weights) { int rc = stage(e, new_weights, (size_t)e->F * e->C * sizeof(float), d_w, &w_in); if (rc) return rc; }
         k_weight_patterns<<<div_up((int64_t)P * e->F, 256), 256, 0, e->stream>>>(
-            e->d_weights + (int64_t)slot * e->F * e->C, e->d_patbits + (int64_t)slot * e->Pmax,
-            e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, P, e->F, e->C);
-        HIPCHK(e, hipGetLastError());
-        k_tile_weights<<<div_up((int64_t)P * e->C * e->ft * e->n_ftiles, 256), 256, 0, e->stream>>>(
-            e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, e->d_wpat_t + (int64_t)slot * e->wpat_t_elems(),
-            P, e->Pmax, e->F, e->C, e->ft, e->n_ftiles);
+            (const float*)w_in, e->d_patbits + (int64_t)slot * e->Pmax, e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, P, e->F, e->C,
+            w_in != d_w ? d_w : nullptr, e->d_wpat_t + (int64_t)slot * e->wpat_t_elems(), e->Pmax, e->ft);
         HIPCHK(e, hipGetLastError());
     }
     return SBE_OK;
@@ -970,6 +1050,7 @@ int sbe_destroy(sbe_engine* e) {
     for (void* p : dev_ptrs) if (p) (void)hipFree(p);
     if (e->h_results) (void)hipHostFree(e->h_results);
     if (e->h_status) (void)hipHostFree(e->h_status);
+    if (e->h_flag) (void)hipHostFree(e->h_flag);
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     if (e->h_arena) (void)hipHostFree(e->h_arena);
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
@@ -1176,10 +1257,15 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_CHK(hipHostGetDevicePointer((void**)&e->d_results, e->h_results, 0));
     CREATE_CHK(hipHostMalloc((void**)&e->h_status, ST_WORDS * sizeof(int), hipHostMallocDefault));
     memset(e->h_status, 0, ST_WORDS * sizeof(int));
+    CREATE_CHK(hipHostMalloc((void**)&e->h_flag, ST_WORDS * sizeof(int), hipHostMallocMapped));
+    CREATE_CHK(hipHostGetDevicePointer((void**)&e->d_flag, e->h_flag, 0));
+    memset(e->h_flag, 0, ST_WORDS * sizeof(int));
     e->arena_bytes = (size_t)16 << 20;
-    CREATE_CHK(hipHostMalloc((void**)&e->h_arena, e->arena_bytes, hipHostMallocDefault));
+    CREATE_CHK(hipHostMalloc((void**)&e->h_arena, e->arena_bytes, hipHostMallocMapped));
+    CREATE_CHK(hipHostGetDevicePointer((void**)&e->d_arena, e->h_arena, 0));
 
     CREATE_CHK(hipMemsetAsync(e->d_status, 0, ST_WORDS * sizeof(int), e->stream));
+    CREATE_CHK(hipMemcpyAsync(e->d_status + ST_FLAG_PTR, &e->d_flag, sizeof(int*), hipMemcpyHostToDevice, e->stream));
     CREATE_CHK(hipMemsetAsync(e->d_onehot, 0, N * e->rs_pitch, e->stream));
     CREATE_CHK(hipMemsetAsync(e->d_state, 0xFF, N * e->Fp, e->stream));
     CREATE_CHK(hipMemsetAsync(e->d_src, 0xFF, NS * N * e->Fp, e->stream));
@@ -1196,7 +1282,8 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     k_ingest_onehot<<<div_up(N * F, 256), 256, 0, e->stream>>>(e->d_scratch, e->d_onehot, e->d_state, e->d_state_q,
                                                               e->d_state_h, e->N, e->F, e->S, e->rs_pitch, e->Fp, e->Fq, e->d_status);
     CREATE_CHK(hipGetLastError());
-    CREATE_RC(read_status(e));
+    CREATE_CHK(hipMemcpyAsync(e->h_status, e->d_status, ST_FLAG_PTR * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    CREATE_CHK(hipStreamSynchronize(e->stream));
     if (e->h_status[ST_MULTI_STATE] != 0) {
         int rc = fail(nullptr, SBE_ERR_DATA, "features are not one-hot: %d (object, feature) rows have more than one state set",
                       e->h_status[ST_MULTI_STATE]);
@@ -1381,11 +1468,13 @@ int sbe_set_source_rows(sbe_engine* e, int slot, const int32_t* objects, int n_r
     if (rc) return rc;
     rc = clear_status_word(e, ST_MULTI_SOURCE);
     if (rc) return rc;
-    int32_t* d_obj = (int32_t*)(e->d_scratch + row_pad);
-    { int _urc = upload(e, e->d_scratch, rows, row_bytes); if (_urc) return _urc; }
-    { int _urc = upload(e, d_obj, objects, (size_t)n_rows * sizeof(int32_t)); if (_urc) return _urc; }
+    const void *v_rows, *v_obj;
+    rc = stage(e, rows, row_bytes, e->d_scratch, &v_rows);
+    if (rc) return rc;
+    rc = stage(e, objects, (size_t)n_rows * sizeof(int32_t), e->d_scratch + row_pad, &v_obj);
+    if (rc) return rc;
     k_ingest_source<<<div_up((int64_t)n_rows * e->F, 256), 256, 0, e->stream>>>(
-        e->d_scratch, d_obj, e->d_src + (int64_t)slot * e->N * e->Fp, n_rows, e->F, e->C, e->Fp, e->d_status);
+        (const uint8_t*)v_rows, (const int32_t*)v_obj, e->d_src + (int64_t)slot * e->N * e->Fp, n_rows, e->F, e->C, e->Fp, e->d_status);
     HIPCHK(e, hipGetLastError());
     bump_src(e, slot);
     return check_after(e);
@@ -1481,9 +1570,11 @@ int sbe_set_counts(sbe_engine* e, int slot, int component, const float* counts) 
     const int64_t n = (int64_t)e->G[component] * e->F * e->S;
     int rc = ensure_scratch(e, n * sizeof(float));
     if (rc) return rc;
-    { int _urc = upload(e, e->d_scratch, counts, n * sizeof(float)); if (_urc) return _urc; }
+    const void* v_counts;
+    rc = stage(e, counts, n * sizeof(float), e->d_scratch, &v_counts);
+    if (rc) return rc;
     int32_t* dst = e->d_counts + (int64_t)slot * e->table_elems() + (int64_t)e->goff[component] * e->F * e->S;
-    k_f32_to_i32<<<div_up(n, 256), 256, 0, e->stream>>>((const float*)e->d_scratch, dst, n);
+    k_f32_to_i32<<<div_up(n, 256), 256, 0, e->stream>>>((const float*)v_counts, dst, n);
     HIPCHK(e, hipGetLastError());
     e->slots[slot].counts_set[component] = 1;
     return SBE_OK;
@@ -1545,10 +1636,9 @@ int sbe_update_probs(sbe_engine* e, int slot, int component, double temperature,
     const int g_lo = e->goff[component], g_hi = g_lo + e->G[component];
     k_probs<int32_t><<<div_up((int64_t)(g_hi - g_lo) * e->F, 256), 256, 0, e->stream>>>(
         e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc, d_unif,
-        e->d_probs + (int64_t)slot * e->table_elems(), g_lo, g_hi, e->F, e->S, temperature, prior_temperature, 1, e->d_status);
+        e->d_probs + (int64_t)slot * e->table_elems(), g_lo, g_hi, e->F, e->S, temperature, prior_temperature, 1, e->d_status, 0,
+        e->d_probs_t + (int64_t)slot * e->probs_t_elems(), e->Gtot, e->ft);       // (+ the tile-transposed copy: one launch)
     HIPCHK(e, hipGetLastError());
-    rc = retile_probs(e, slot, component);
-    if (rc) return rc;
     s.probs_set[component] = 1;
     return check_after(e);
 }
@@ -1583,10 +1673,10 @@ int sbe_get_probs(sbe_engine* e, int slot, int component, float* out) {
 int sbe_set_weights(sbe_engine* e, int slot, const float* weights) {
     CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, weights);
     HIPCHK(e, hipSetDevice(e->device));
-    int rc = h2d(e, e->d_weights + (int64_t)slot * e->F * e->C, weights, (size_t)e->F * e->C * sizeof(float));
+    int rc = upload_patterns_and_weights(e, slot, weights);
     if (rc) return rc;
     e->slots[slot].weights_set = true;
-    return upload_patterns_and_weights(e, slot);
+    return SBE_OK;
 }
 
 int sbe_get_weights_normalized(sbe_engine* e, int slot, float* out) {
@@ -1687,6 +1777,34 @@ int sbe_mixture_loglik_batch(sbe_engine* e, int first_slot, int n, double* out) 
 int sbe_mixture_loglik(sbe_engine* e, int slot, double* out) { return sbe_mixture_loglik_batch(e, slot, 1, out); }
 
 // ---- collapsed likelihood -------------------------------------------------------------------------
+// a7/a8 of the groups [g_lo, g_lo + G) of a slot: per-group float64 into host-mapped memory (and, optionally, the
+// float32 per-feature rows into d_pf).  One launch (k_collapsed_groups) when a group's F*S terms fit LDS, the k_dcl /
+// k_group_sum_f32 pair otherwise.  Ends with the stream synchronised; results at e->h_io.
+static int collapsed_groups(sbe_engine* e, int slot, int g_lo, int G, float* d_pf) {
+    int rc = ensure_io(e, (size_t)G * sizeof(double));
+    if (rc) return rc;
+    const int32_t* counts = e->d_counts + (int64_t)slot * e->table_elems();
+    const size_t lds = (size_t)e->F * e->S * sizeof(double) + (size_t)e->F * sizeof(float);
+    if (lds <= ((size_t)96 << 10)) {
+        k_collapsed_groups<int32_t><<<G, 1024, lds, e->stream>>>(counts, e->d_conc, e->d_lg_conc, e->d_sum_a, e->d_lg_sum_a, d_pf,
+                                                                  (double*)e->d_io, g_lo, e->F, e->S);
+        HIPCHK(e, hipGetLastError());
+    } else {
+        float* pf = d_pf;
+        if (!pf) {
+            rc = ensure_scratch(e, (size_t)G * e->F * sizeof(float));
+            if (rc) return rc;
+            pf = (float*)e->d_scratch;
+        }
+        k_dcl<int32_t><<<div_up((int64_t)G * e->F, 256), 256, 0, e->stream>>>(counts, e->d_conc, pf, g_lo, g_lo + G, e->F, e->S, 1);
+        HIPCHK(e, hipGetLastError());
+        k_group_sum_f32<<<div_up((int64_t)G * 8, 64), 64, 0, e->stream>>>(pf, (double*)e->d_io, G, e->F);
+        HIPCHK(e, hipGetLastError());
+    }
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return synced(e);
+}
+
 int sbe_collapsed_loglik_all(sbe_engine* e, int slot, double* per_group_out) {
     CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, per_group_out);
     Slot& s = e->slots[slot];
@@ -1696,18 +1814,10 @@ int sbe_collapsed_loglik_all(sbe_engine* e, int slot, double* per_group_out) {
         if (!e->conc_set[c]) return fail(e, SBE_ERR_STATE, "concentration of component %d not set", c);
     }
     HIPCHK(e, hipSetDevice(e->device));
-    const int G = e->Gtot;
-    const size_t pf_bytes = ((size_t)G * e->F * sizeof(float) + 255) / 256 * 256;
-    int rc = ensure_scratch(e, pf_bytes + (size_t)G * sizeof(double));
+    int rc = collapsed_groups(e, slot, 0, e->Gtot, nullptr);
     if (rc) return rc;
-    float* d_pf = (float*)e->d_scratch;
-    double* d_pg = (double*)(e->d_scratch + pf_bytes);
-    k_dcl<int32_t><<<div_up((int64_t)G * e->F, 256), 256, 0, e->stream>>>(e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc,
-                                                                       d_pf, 0, G, e->F, e->S, 1);
-    HIPCHK(e, hipGetLastError());
-    k_group_sum_f32<<<div_up((int64_t)G * 8, 64), 64, 0, e->stream>>>(d_pf, d_pg, G, e->F);
-    HIPCHK(e, hipGetLastError());
-    return d2h(e, per_group_out, d_pg, (size_t)G * sizeof(double));
+    memcpy(per_group_out, e->h_io, (size_t)e->Gtot * sizeof(double));
+    return SBE_OK;
 }
 
 int sbe_collapsed_loglik(sbe_engine* e, int slot, int component, double* per_group_out, float* per_feature_out) {
@@ -1719,28 +1829,18 @@ int sbe_collapsed_loglik(sbe_engine* e, int slot, int component, double* per_gro
     if (!e->conc_set[component]) return fail(e, SBE_ERR_STATE, "concentration of component %d not set", component);
     HIPCHK(e, hipSetDevice(e->device));
     const int G = e->G[component], g_lo = e->goff[component];
-    const size_t pf_bytes = ((size_t)G * e->F * sizeof(float) + 255) / 256 * 256;
-    int rc = ensure_scratch(e, pf_bytes + (size_t)G * sizeof(double));
-    if (rc) return rc;
-    float* d_pf = (float*)e->d_scratch;
-    double* d_pg = (double*)(e->d_scratch + pf_bytes);
-    k_dcl<int32_t><<<div_up((int64_t)G * e->F, 256), 256, 0, e->stream>>>(e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc,
-                                                                       d_pf, g_lo, g_lo + G, e->F, e->S, 1);
-    HIPCHK(e, hipGetLastError());
-    if (!per_feature_out) {                    // the G doubles land in host-mapped memory: no copy-engine hop in the chain
-        rc = ensure_io(e, (size_t)G * sizeof(double));
+    float* d_pf = nullptr;
+    int rc = SBE_OK;
+    if (per_feature_out) {
+        rc = ensure_scratch(e, (size_t)G * e->F * sizeof(float));
         if (rc) return rc;
-        k_group_sum_f32<<<div_up((int64_t)G * 8, 64), 64, 0, e->stream>>>(d_pf, (double*)e->d_io, G, e->F);
-        HIPCHK(e, hipGetLastError());
-        HIPCHK(e, hipStreamSynchronize(e->stream));
-        memcpy(per_group_out, e->h_io, (size_t)G * sizeof(double));
-        return synced(e);
+        d_pf = (float*)e->d_scratch;
     }
-    k_group_sum_f32<<<div_up((int64_t)G * 8, 64), 64, 0, e->stream>>>(d_pf, d_pg, G, e->F);
-    HIPCHK(e, hipGetLastError());
-    rc = d2h(e, per_group_out, d_pg, (size_t)G * sizeof(double));
+    rc = collapsed_groups(e, slot, g_lo, G, d_pf);  // (the G doubles land in host-mapped memory: no copy-engine hop in the chain)
     if (rc) return rc;
-    return d2h(e, per_feature_out, d_pf, (size_t)G * e->F * sizeof(float));
+    memcpy(per_group_out, e->h_io, (size_t)G * sizeof(double));
+    if (per_feature_out) return d2h(e, per_feature_out, d_pf, (size_t)G * e->F * sizeof(float));
+    return SBE_OK;
 }
 
 
@@ -2004,7 +2104,7 @@ int sbe_source_lh_by_feature(sbe_engine* e, int slot, float* out) {
     if (s.patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
     rc = ensure_io(e, (size_t)e->F * sizeof(float));
     if (rc) return rc;
-    k_source_lh_by_feature<<<div_up(e->F, kWave), 1024, 0, e->stream>>>(
+    k_source_lh_by_feature<<<div_up(e->F, kSlfFT), 1024, 0, e->stream>>>(
         e->d_state, e->d_src + (int64_t)slot * e->N * e->Fp, e->d_pid + (int64_t)slot * e->Np,
         e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, (float*)e->d_io, e->N, e->F, e->C, e->Fp);
     HIPCHK(e, hipGetLastError());
@@ -2199,9 +2299,8 @@ int sbe_subset_lh(sbe_engine* e, const int32_t* objects, int n_sub, int n_comp, 
 // (last row): no [N][F] mask, no whole [G][F][S] table.
 namespace {
 
-// queue the status read-back in front of the call's final synchronisation and report after it (one sync per call)
+// the call's final synchronisation, then the data checks its kernels may have raised (flag words: no read-back)
 int sync_and_report(sbe_engine* e) {
-    HIPCHK(e, hipMemcpyAsync(e->h_status, e->d_status, ST_WORDS * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     e->status_pending = false;
     return report_status(e);
@@ -2274,7 +2373,7 @@ int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const 
     HIPCHK(e, hipMemcpyAsync(e->d_scratch, h, in_bytes, hipMemcpyHostToDevice, e->stream));
     const uint8_t* din = e->d_scratch;
     float* d_out = mapped_out ? (float*)(e->d_io + o) : (float*)(e->d_scratch + in_bytes);
-    k_counts_delta<<<dim3(n_touched, div_up(F, 64)), kBlock, (size_t)64 * S * sizeof(int32_t), e->stream>>>(
+    k_counts_delta<<<dim3(n_touched, div_up(F, kDeltaFT)), kBlock, (size_t)kDeltaFT * S * sizeof(int32_t), e->stream>>>(
         e->d_state, (const int32_t*)(din + o_obj), n_subset, (const int32_t*)(din + o_go), (const int32_t*)(din + o_gn),
         din + o_so, din + o_sn, (const int32_t*)(din + o_t), (const int32_t*)(din + o_tc), d_out, F, S, e->Fp);
     HIPCHK(e, hipGetLastError());
@@ -2296,10 +2395,13 @@ int sbe_set_counts_rows(sbe_engine* e, int slot, const int32_t* group_idx, int n
     const size_t rb = al256((size_t)n_rows * fs * sizeof(float));
     int rc = ensure_scratch(e, rb + (size_t)n_rows * sizeof(int32_t));
     if (rc) return rc;
-    { int _urc = upload(e, e->d_scratch, rows, (size_t)n_rows * fs * sizeof(float)); if (_urc) return _urc; }
-    { int _urc = upload(e, e->d_scratch + rb, group_idx, (size_t)n_rows * sizeof(int32_t)); if (_urc) return _urc; }
+    const void *v_rows, *v_idx;
+    rc = stage(e, rows, (size_t)n_rows * fs * sizeof(float), e->d_scratch, &v_rows);
+    if (rc) return rc;
+    rc = stage(e, group_idx, (size_t)n_rows * sizeof(int32_t), e->d_scratch + rb, &v_idx);
+    if (rc) return rc;
     k_set_count_rows<<<div_up((int64_t)n_rows * fs, 256), 256, 0, e->stream>>>(
-        (const float*)e->d_scratch, (const int32_t*)(e->d_scratch + rb), e->d_counts + (int64_t)slot * e->table_elems(), n_rows, fs);
+        (const float*)v_rows, (const int32_t*)v_idx, e->d_counts + (int64_t)slot * e->table_elems(), n_rows, fs);
     HIPCHK(e, hipGetLastError());
     return SBE_OK;
 }
@@ -2346,29 +2448,19 @@ int sbe_given_unchanged_lh(sbe_engine* e, int slot, int i_cluster, const int32_t
         }
     }
     const size_t cb = al256((size_t)R * fs * sizeof(float));
-    rc = ensure_scratch(e, 2 * cb + (mapped_out ? 0 : out_bytes));
+    rc = ensure_scratch(e, cb + (mapped_out ? 0 : out_bytes));
     if (rc) return rc;
-    float* d_cnt = (float*)e->d_scratch;
-    float* d_tab = (float*)(e->d_scratch + cb);
-    float* d_out = mapped_out ? (float*)(e->d_io + ob + mb + gb + fb) : (float*)(e->d_scratch + 2 * cb);
+    float* d_tab = (float*)e->d_scratch;
+    float* d_out = mapped_out ? (float*)(e->d_io + ob + mb + gb + fb) : (float*)(e->d_scratch + cb);
     rc = clear_status_word(e, ST_BAD_NORMALIZE);
     if (rc) return rc;
-    k_unchanged_counts<<<dim3(R, div_up(F, 16)), kBlock, (size_t)16 * S * sizeof(int32_t), e->stream>>>(
+    // kept counts and their conditional_effect_mean (conditionals.py:105-122) in one launch: the cluster's row with the
+    // cluster prior, the confounder rows with theirs
+    k_unchanged_counts<<<dim3(R, div_up(F, 16)), kUnchangedBlock, (size_t)16 * S * sizeof(int32_t), e->stream>>>(
         e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_src + (int64_t)slot * N * e->Fp,
         e->d_counts + (int64_t)slot * e->table_elems(), e->d_io + ob, (const int32_t*)e->d_io, n_sub, e->d_comp_of_group,
-        i_cluster, K, N, e->Np, F, S, e->Fp, d_cnt);
+        i_cluster, K, N, e->Np, F, S, e->Fp, e->d_conc, e->d_unif_res, temperature, prior_temperature, e->d_status, d_tab);
     HIPCHK(e, hipGetLastError());
-    // conditional_effect_mean (conditionals.py:105-122) of the kept counts: the cluster's row with the cluster prior,
-    // the confounder rows with theirs
-    k_probs<float><<<div_up((int64_t)F, 256), 256, 0, e->stream>>>(
-        d_cnt, e->d_conc + (int64_t)i_cluster * fs, e->d_unif_res, d_tab, 0, 1, F, S, temperature, prior_temperature, 1, e->d_status);
-    HIPCHK(e, hipGetLastError());
-    if (R > 1) {
-        k_probs<float><<<div_up((int64_t)(R - 1) * F, 256), 256, 0, e->stream>>>(
-            d_cnt + fs, e->d_conc + (int64_t)K * fs, e->d_unif_res, d_tab + fs, 0, R - 1, F, S, temperature, prior_temperature, 1,
-            e->d_status);
-        HIPCHK(e, hipGetLastError());
-    }
     const double inv_t = 1.0 / temperature;
     k_subset_lh<<<div_up((int64_t)n_sub * F, 256), 256, 0, e->stream>>>(
         e->d_state, d_tab, (const int32_t*)(e->d_io + ob + mb + gb), (const int32_t*)(e->d_io + ob + mb), (const int32_t*)e->d_io,
@@ -2377,9 +2469,7 @@ int sbe_given_unchanged_lh(sbe_engine* e, int slot, int i_cluster, const int32_t
     if (!mapped_out) {
         rc = d2h(e, out, d_out, out_bytes);
         if (rc) return rc;
-        rc = read_status(e);
-        if (rc) return rc;
-        return report_status(e);
+        return report_status(e);                    // (d2h synchronised)
     }
     rc = sync_and_report(e);
     if (rc) return rc;
@@ -2692,6 +2782,7 @@ int read_step_results_lane(sbe_engine* e, const uint8_t* h_step, int cand_slot, 
     if (hst[ST_BAD_NORMALIZE] || hst[ST_MULTI_SOURCE]) {
         const int bad_norm = hst[ST_BAD_NORMALIZE], multi_src = hst[ST_MULTI_SOURCE];
         (void)hipMemsetAsync((d_status ? d_status : e->d_status) + ST_BAD_NORMALIZE, 0, 2 * sizeof(int), e->stream);
+        if (!d_status || d_status == e->d_status) e->h_flag[ST_BAD_NORMALIZE] = e->h_flag[ST_MULTI_SOURCE] = 0;
         char who[32] = "";
         if (chain >= 0) snprintf(who, sizeof who, "chain %d: ", chain);
         if (bad_norm) return fail(e, SBE_ERR_DATA, "%snormalize: %d %s have a non-positive sum (sbayes/util.py:1006 assert)", who, bad_norm, bad_norm_what);

@@ -28,8 +28,19 @@ enum StatusWord : int {
     ST_NA_COUNT = 1,         // NA observations
     ST_BAD_NORMALIZE = 2,    // normalize(): a row sum was not > 0 (util.py:1006 assert)
     ST_MULTI_SOURCE = 3,     // source rows with more than one component set
+    ST_FLAG_PTR = 4,         // words 4..5: 64-bit address of the engine's host-mapped flag words, or 0 (lane-private status
+                             // arrays of the batched steps: their words travel in the step epilogue's mapped block)
     ST_WORDS = 8
 };
+
+// A kernel-raised data check: the count goes to the device word, and -- error path only -- a plain store marks the
+// engine's host-mapped flag word, so that the host learns "nothing was raised" from its own memory after the
+// synchronisation it performs anyway, without a status read-back per call.
+__device__ __forceinline__ void raise_status(int* status, int word, int count) {
+    atomicAdd(&status[word], count);
+    int* flag = *reinterpret_cast<int* const*>(status + ST_FLAG_PTR);
+    if (flag) __hip_atomic_store(flag + word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // ------------------------------------------------------------------------------------------
 // NumPy reduction order (pairwise sum, PW_BLOCKSIZE = 128, 8-way unrolled block).
@@ -363,6 +374,22 @@ __global__ void k_init_state_h(uint16_t* __restrict__ state_h, int64_t n_entries
     o[0] = v; o[1] = v; o[2] = v; o[3] = v;
 }
 
+// Several small host arrays to their resident places in ONE launch: the arrays are staged back to back in the mapped
+// ring (`base`, read over PCIe element-parallel), segment y goes to sg.dst[y].  Words when everything is 4-byte aligned.
+struct ScatterSegs { uint8_t* dst[8]; uint32_t off[8]; uint32_t bytes[8]; int n; };
+__global__ void k_scatter_bytes(const uint8_t* __restrict__ base, ScatterSegs sg) {
+    const int y = blockIdx.y;
+    if (y >= sg.n) return;
+    const uint8_t* src = base + sg.off[y];
+    uint8_t* dst = sg.dst[y];
+    const uint32_t nb = sg.bytes[y], stride = gridDim.x * blockDim.x, i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((((uintptr_t)dst | (uintptr_t)src | nb) & 3) == 0) {
+        for (uint32_t j = i0; j < nb / 4; j += stride) reinterpret_cast<uint32_t*>(dst)[j] = reinterpret_cast<const uint32_t*>(src)[j];
+    } else {
+        for (uint32_t j = i0; j < nb; j += stride) dst[j] = src[j];
+    }
+}
+
 // K0b: source ingest.  bool rows [rows][F][C] -> component id per observation (0xFF = none).
 // `objects` == nullptr: row r is object r.
 __global__ void k_ingest_source(const uint8_t* __restrict__ rows, const int32_t* __restrict__ objects,
@@ -381,7 +408,7 @@ __global__ void k_ingest_source(const uint8_t* __restrict__ rows, const int32_t*
         multi = cnt > 1;
     }
     const int m = __popcll(__ballot(multi));
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&status[ST_MULTI_SOURCE], m);
+    if ((threadIdx.x & 63) == 0 && m) raise_status(status, ST_MULTI_SOURCE, m);
 }
 
 // Inverse of K0b for the listed objects: component id -> bool row [F][C] (all False for 0xFF).
@@ -534,50 +561,77 @@ __global__ void k_f32_to_i32(const float* __restrict__ in, int32_t* __restrict__
 //   counts are float32 in the reference (counts.py:20): counts / T is a float32 division
 //   (NumPy: float32 array / Python float), then + float64 prior -> float64.
 // ------------------------------------------------------------------------------------------
-template <class TC>
-__global__ void k_probs(const TC* __restrict__ counts, const double* __restrict__ conc,
-                        const double* __restrict__ unif /* [F][S] or null */, float* __restrict__ probs,
-                        int g_lo, int g_hi, int F, int S, double temperature, double prior_temperature,
-                        int conc_per_group, int* __restrict__ status, int64_t out_shift = 0) {
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n_rows = (int64_t)(g_hi - g_lo) * F;
-    if (row >= n_rows) return;
-    const int64_t base = ((int64_t)g_lo * F + row) * S;
-    const int f = (int)(row % F);
+// One table row of normalize(counts / T + prior') -> float32 (util.py:990-1007, conditionals.py:105-122): the S states
+// summed in NumPy's pairwise order.  `cnt(s)` = the count as the reference's float32; `unif_row` null: prior untempered.
+template <class GetCount, class Emit>
+__device__ __forceinline__ void probs_row(GetCount cnt, const double* __restrict__ conc_row, const double* __restrict__ unif_row,
+                                          int S, double temperature, double prior_temperature, int* __restrict__ status, Emit emit) {
     const bool tempered = temperature > 0.0;
-    const bool prior_tempered = prior_temperature > 0.0 && unif != nullptr;
+    const bool prior_tempered = prior_temperature > 0.0 && unif_row != nullptr;
     const float t32 = (float)temperature;
     auto post = [&](int s) -> double {
-        float c = (float)counts[base + s];
+        float c = cnt(s);
         if (tempered) c = c / t32;
-        double a = conc_per_group ? conc[base + s] : conc[(int64_t)f * S + s];
+        double a = conc_row[s];
         if (prior_tempered) {
-            const double u = unif[(int64_t)f * S + s];
+            const double u = unif_row[s];
             a = u + (a - u) / prior_temperature;
         }
         return (double)c + a;
     };
     const double total = np_pairwise_sum<double>(post, S);
-    if (!(total > 0.0)) atomicAdd(&status[ST_BAD_NORMALIZE], 1);
-    for (int s = 0; s < S; ++s) probs[base + out_shift + s] = (float)(post(s) / total);   // (out_shift: rows of a scratch table)
+    if (!(total > 0.0)) raise_status(status, ST_BAD_NORMALIZE, 1);
+    for (int s = 0; s < S; ++s) emit(s, (float)(post(s) / total));
+}
+
+template <class TC>
+__global__ void k_probs(const TC* __restrict__ counts, const double* __restrict__ conc,
+                        const double* __restrict__ unif /* [F][S] or null */, float* __restrict__ probs,
+                        int g_lo, int g_hi, int F, int S, double temperature, double prior_temperature,
+                        int conc_per_group, int* __restrict__ status, int64_t out_shift = 0,
+                        float* __restrict__ probs_t = nullptr /* tile-transposed copy [n_ftiles][Gtot+1][S][ft], or null */,
+                        int Gtot = 0, int ft = 1) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_rows = (int64_t)(g_hi - g_lo) * F;
+    if (row >= n_rows) return;
+    const int64_t base = ((int64_t)g_lo * F + row) * S;
+    const int f = (int)(row % F);
+    const int g = g_lo + (int)(row / F), tile = f / ft, tl = f % ft;
+    float* out_row = probs + base + out_shift;                                 // (out_shift: rows of a scratch table)
+    float* out_t = probs_t ? probs_t + (((int64_t)tile * (Gtot + 1) + g) * S) * ft + tl : nullptr;   // (k_tile_probs' layout)
+    probs_row([&](int s) { return (float)counts[base + s]; }, conc_per_group ? conc + base : conc + (int64_t)f * S,
+              unif ? unif + (int64_t)f * S : nullptr, S, temperature, prior_temperature, status,
+              [&](int s, float v) { out_row[s] = v; if (out_t) out_t[(int64_t)s * ft] = v; });
 }
 
 // ------------------------------------------------------------------------------------------
 // a5: per-pattern normalised weights (likelihood.py:171-190).  One thread per (pattern, f).
 //   w = pattern * weights (bool x float32 -> float32);  w /= sum_c w   (float32, NumPy order)
 // ------------------------------------------------------------------------------------------
+// Optional extras of the slot form (one launch per sbe_set_weights): `weights_keep` = the slot's resident [F][C] copy
+// of `weights` (which may then be host-mapped staging memory), `wpat_t` = the tile-transposed float64 copy
+// [n_ftiles][Pmax][C][ft] (k_tile_weights' layout; padding features stay zero from creation).
 __global__ void k_weight_patterns(const float* __restrict__ weights /* [F][C] */,
                                   const uint32_t* __restrict__ pattern_bits /* [P] */,
-                                  float* __restrict__ wpat /* [P][F][C] */, int P, int F, int C) {
+                                  float* __restrict__ wpat /* [P][F][C] */, int P, int F, int C,
+                                  float* __restrict__ weights_keep = nullptr, double* __restrict__ wpat_t = nullptr,
+                                  int Pmax = 0, int ft = 1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P * F) return;
     const int p = i / F, f = i % F;
     const uint32_t bits = pattern_bits[p];
-    const float* w = weights + (int64_t)f * C;
+    float w[kMaxComponents];
+    for (int c = 0; c < C; ++c) w[c] = weights[(int64_t)f * C + c];
+    if (weights_keep && p == 0) for (int c = 0; c < C; ++c) weights_keep[(int64_t)f * C + c] = w[c];
     auto masked = [&](int c) -> float { return ((bits >> c) & 1u) ? w[c] : 0.0f * w[c]; };
     const float total = np_pairwise_sum<float>(masked, C);
     float* out = wpat + ((int64_t)p * F + f) * C;
-    for (int c = 0; c < C; ++c) out[c] = masked(c) / total;
+    double* out_t = wpat_t ? wpat_t + (((int64_t)(f / ft) * Pmax + p) * C) * ft + f % ft : nullptr;
+    for (int c = 0; c < C; ++c) {
+        const float v = masked(c) / total;
+        out[c] = v;
+        if (out_t) out_t[(int64_t)c * ft] = (double)v;
+    }
 }
 
 __global__ void k_expand_weights(const float* __restrict__ wpat, const uint8_t* __restrict__ pid,
@@ -664,7 +718,7 @@ __global__ void k_lh_exact(const uint8_t* __restrict__ state, const uint8_t* __r
                     return s == x ? a - own : a - 0.0;
                 };
                 const double total = np_pairwise_sum<double>(post, S);
-                if (!(total > 0.0)) atomicAdd(&status[ST_BAD_NORMALIZE], 1);
+                if (!(total > 0.0)) raise_status(status, ST_BAD_NORMALIZE, 1);
                 v = (double)(float)(post(x) / total);
             }
         }
@@ -712,6 +766,46 @@ __global__ void k_group_sum_f32(const float* __restrict__ per_feature, double* _
     auto get = [&](int i) -> float { return p[i]; };
     const float total = np_pairwise_sum_f32_x8(get, F, (int)(threadIdx.x & 7));
     if ((threadIdx.x & 7) == 0) per_group[g] = (double)total;
+}
+
+// a7 + a8 in ONE launch (round 3: the drop-in Likelihood.__call__ asks for this once or twice per MCMC step, and a
+// launch costs more than the arithmetic): block = one group.  Phase 1, one thread per table element: the lgamma term
+// of the element, with k_conc_lgamma's count-independent tables (ONE lgamma per element -- same function, same
+// arguments as k_dcl's two, so the same value); phase 2, one thread per feature: the ordered sums over the S states,
+// the row constant, the float32 cast (k_dcl's expression); phase 3, eight lanes: the float32 NumPy-order sum over the
+// features (k_group_sum_f32's).  Dynamic LDS: F*S doubles + F floats.  `per_feature` (may be null) gets the rows.
+template <class TC>
+__global__ __launch_bounds__(1024) void k_collapsed_groups(
+    const TC* __restrict__ counts, const double* __restrict__ conc, const double* __restrict__ lg_conc,
+    const double* __restrict__ sum_a, const double* __restrict__ lg_sum_a, float* __restrict__ per_feature,
+    double* __restrict__ per_group, int g_lo, int F, int S) {
+    extern __shared__ __align__(16) unsigned char cg_lds[];
+    double* ser = reinterpret_cast<double*>(cg_lds);                       // [F][S]
+    float* pf = reinterpret_cast<float*>(cg_lds + (size_t)F * S * sizeof(double));   // [F]
+    const int g = g_lo + blockIdx.x;
+    const int64_t gbase = (int64_t)g * F * S;
+    for (int e = threadIdx.x; e < F * S; e += blockDim.x) {
+        const double as = conc[gbase + e];
+        ser[e] = as > 0.0 ? sbe_lgamma_pos((double)(float)counts[gbase + e] + as) - lg_conc[gbase + e] : 0.0;
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        const int64_t base = gbase + (int64_t)f * S;
+        auto cnt = [&](int k) -> float { return (float)counts[base + k]; };
+        auto ser_at = [&](int k) -> double { return ser[f * S + k]; };
+        const float n = np_pairwise_sum<float>(cnt, S);
+        const double sa = sum_a[(int64_t)g * F + f];
+        const double cst = lg_sum_a[(int64_t)g * F + f] - sbe_lgamma_pos((double)n + sa);
+        const float v = (float)(cst + np_pairwise_sum<double>(ser_at, S));
+        pf[f] = v;
+        if (per_feature) per_feature[(int64_t)blockIdx.x * F + f] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        auto get = [&](int i) -> float { return pf[i]; };
+        const float total = np_pairwise_sum_f32_x8(get, F, (int)threadIdx.x);
+        if (threadIdx.x == 0) per_group[blockIdx.x] = (double)total;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2299,27 +2393,44 @@ __global__ __launch_bounds__(kBlock) void k_jump_lh(
 // materialises (twice per call of the operator) never exists.  float32 logs like the reference's (NumPy's own float32
 // log is not bit-reproducible here: compared at float32 accuracy) and the reference's summation: float32, objects in
 // order (np.sum(axis=0) of a C-ordered float32 [N, F] array adds row after row).
-// Block = 64 features x 16 object lanes: sixteen objects' logs at a time, then the feature's owner adds them in order.
+// Block = 16 features x 64 object lanes.  The logs of 512 objects at a time go to LDS -- eight independent loads and
+// logs per thread, in flight together -- then the feature's owner lane adds the 512 values in object order (the serial
+// float32 chain is what the reference computes; one barrier pair per 512 objects, F/16 blocks).
 // ------------------------------------------------------------------------------------------
+constexpr int kSlfFT = 16, kSlfChunk = 512;
 __global__ __launch_bounds__(1024) void k_source_lh_by_feature(
     const uint8_t* __restrict__ state, const uint8_t* __restrict__ src, const uint8_t* __restrict__ pid,
     const float* __restrict__ wpat, float* __restrict__ out, int N, int F, int C, int Fp) {
-    __shared__ float part[16][kWave];
-    const int fl = threadIdx.x & (kWave - 1), ol = threadIdx.x >> 6;
-    const int f = blockIdx.x * kWave + fl;
+    constexpr int OL = 1024 / kSlfFT, PER = kSlfChunk / OL;
+    __shared__ float part[kSlfChunk][kSlfFT];              // 32 KB
+    const int fl = threadIdx.x & (kSlfFT - 1), ol = threadIdx.x / kSlfFT;
+    const int f = blockIdx.x * kSlfFT + fl;
     float acc = 0.0f;                                      // float32, objects in order: np.sum(axis=0) of a float32 array
-    for (int n0 = 0; n0 < N; n0 += 16) {
-        const int n = n0 + ol;
-        float v = 0.0f;                                    // NA: p = 1, log p = 0
-        if (n < N && f < F && state[(int64_t)n * Fp + f] != kNA) {
-            const uint8_t c = src[(int64_t)n * Fp + f];
-            v = logf(c < C ? wpat[((int64_t)pid[n] * F + f) * C + c] : 0.0f);
+    for (int n0 = 0; n0 < N; n0 += kSlfChunk) {
+        float w[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int n = n0 + ol + OL * j;
+            w[j] = 1.0f;                                   // NA: p = 1, log p = 0
+            if (n < N && f < F && state[(int64_t)n * Fp + f] != kNA) {
+                const uint8_t c = src[(int64_t)n * Fp + f];
+                w[j] = c < C ? wpat[((int64_t)pid[n] * F + f) * C + c] : 0.0f;
+            }
         }
-        part[ol][fl] = v;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) part[ol + OL * j][fl] = logf(w[j]);
         __syncthreads();
         if (ol == 0) {
-            const int m = min(16, N - n0);
-            for (int k = 0; k < m; ++k) acc = acc + part[k][fl];
+            const int m = min(kSlfChunk, N - n0);
+            int k = 0;
+            for (; k + 8 <= m; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = part[k + u][fl];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = acc + v[u];
+            }
+            for (; k < m; ++k) acc = acc + part[k][fl];
         }
         __syncthreads();
     }
@@ -2399,7 +2510,7 @@ __global__ void k_source_posterior(SrcPostArgs a, float* __restrict__ out, int* 
     if (i >= (int64_t)a.n_sub * a.F) return;
     const int r = (int)(i / a.F), f = (int)(i % a.F);
     float p[kMaxComponents];
-    if (!source_posterior_row(a, a.objects[r], f, p)) atomicAdd(&status[ST_BAD_NORMALIZE], 1);
+    if (!source_posterior_row(a, a.objects[r], f, p)) raise_status(status, ST_BAD_NORMALIZE, 1);
     float* o = out + i * a.C;
     for (int c = 0; c < a.C; ++c) o[c] = p[c];
 }
@@ -2431,7 +2542,7 @@ __global__ __launch_bounds__(kBlock) void k_sample_source(SrcPostArgs a, const d
         const int r = (int)(i / a.F), f = (int)(i % a.F);
         const int n = a.objects[r];
         float p[kMaxComponents];
-        if (!source_posterior_row(a, n, f, p)) atomicAdd(&status[ST_BAD_NORMALIZE], 1);
+        if (!source_posterior_row(a, n, f, p)) raise_status(status, ST_BAD_NORMALIZE, 1);
         float cdf[kMaxComponents];
         float run = p[0];
         cdf[0] = run;
@@ -2460,7 +2571,7 @@ __global__ __launch_bounds__(kBlock) void k_source_logprob(SrcPostArgs a, const 
         const int r = (int)(i / a.F), f = (int)(i % a.F);
         const int n = a.objects[r];
         float p[kMaxComponents];
-        if (!source_posterior_row(a, n, f, p)) atomicAdd(&status[ST_BAD_NORMALIZE], 1);
+        if (!source_posterior_row(a, n, f, p)) raise_status(status, ST_BAD_NORMALIZE, 1);
         const int id = src[(int64_t)n * a.Fp + f];
         for (int c = 0; c < a.C; ++c) sel = (c == id) ? p[c] : sel;
         p_sel[i] = sel;
@@ -2673,7 +2784,7 @@ __device__ __forceinline__ void step_core_body(const StepCore& a, unsigned char*
             auto ser_at = [&](int k) -> double { return sh_ser[e0 + k]; };
             auto cnt_at = [&](int k) -> float { return (float)hist[e0 + k]; };
             const double total = np_pairwise_sum<double>(post_at, S);
-            if (!(total > 0.0)) atomicAdd(&a.status[ST_BAD_NORMALIZE], 1);
+            if (!(total > 0.0)) raise_status(a.status, ST_BAD_NORMALIZE, 1);
             sh_total[r] = total;
             const float n = np_pairwise_sum<float>(cnt_at, S);
             const double sum_a = a.sum_a[(int64_t)g * F + f];
@@ -2762,7 +2873,7 @@ __device__ __forceinline__ void step_core_body(const StepCore& a, unsigned char*
         a.src_dst[(int64_t)n * a.Fp + f] = (uint8_t)id;
         multi += cnt > 1;
     }
-    if (multi) atomicAdd(&a.status[ST_MULTI_SOURCE], multi);
+    if (multi) raise_status(a.status, ST_MULTI_SOURCE, multi);
 }
 
 __global__ __launch_bounds__(kBlock) void k_step_core(StepCore a) {
@@ -2824,32 +2935,37 @@ __global__ void k_tile_weights(const float* __restrict__ wpat, double* __restric
 // writes, for every touched group,
 //     diff[t][f][s] = #{i: new state counts (object i, f) at state s in group t} - #{i: old state ...}
 // = the rows of the reference's `new_counts - old_counts` that can be non-zero (as float32: FLOAT_TYPE, counts.py:20).
-// Block = (touched group, 64-feature tile); 64 features x 4 object lanes; LDS histogram [64][S].
+// Block = (touched group, 16-feature tile); 16 features x 16 object lanes (a subset can be a whole cluster: the object
+// axis gets the lanes, and every step of a lane's walk is a chain of dependent loads); LDS histogram [16][S].
 // ------------------------------------------------------------------------------------------
+constexpr int kDeltaFT = 16;
 __global__ __launch_bounds__(kBlock) void k_counts_delta(
     const uint8_t* __restrict__ state, const int32_t* __restrict__ objects, int n,
     const int32_t* __restrict__ gid_old /* [C][n] */, const int32_t* __restrict__ gid_new,
     const uint8_t* __restrict__ src_old /* [n][F] */, const uint8_t* __restrict__ src_new,
     const int32_t* __restrict__ touched /* [T] global group index */, const int32_t* __restrict__ touched_comp /* [T] */,
     float* __restrict__ out /* [T][F][S] */, int F, int S, int Fp) {
+    constexpr int FTU = kDeltaFT, OL = kBlock / FTU;
     extern __shared__ int32_t hist[];
-    const int t = blockIdx.x, f0 = blockIdx.y * 64;
-    for (int i = threadIdx.x; i < 64 * S; i += kBlock) hist[i] = 0;
+    const int t = blockIdx.x, f0 = blockIdx.y * FTU;
+    for (int i = threadIdx.x; i < FTU * S; i += kBlock) hist[i] = 0;
     __syncthreads();
-    const int fl = threadIdx.x & 63, ol = threadIdx.x >> 6;
+    const int fl = threadIdx.x & (FTU - 1), ol = threadIdx.x / FTU;
     const int f = f0 + fl;
     const int gg = touched[t], c = touched_comp[t];
     if (f < F) {
-        for (int i = ol; i < n; i += kBlock / 64) {
+#pragma unroll 2
+        for (int i = ol; i < n; i += OL) {
+            const bool in_new = gid_new[(int64_t)c * n + i] == gg, in_old = gid_old[(int64_t)c * n + i] == gg;
+            if (!in_new && !in_old) continue;                       // the object is in another group of this component
             const uint8_t x = state[(int64_t)objects[i] * Fp + f];
             if (x == kNA) continue;
-            const int d = (int)(gid_new[(int64_t)c * n + i] == gg && src_new[(int64_t)i * F + f] == c) -
-                          (int)(gid_old[(int64_t)c * n + i] == gg && src_old[(int64_t)i * F + f] == c);
+            const int d = (int)(in_new && src_new[(int64_t)i * F + f] == c) - (int)(in_old && src_old[(int64_t)i * F + f] == c);
             if (d) atomicAdd(&hist[fl * S + x], d);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 64 * S; i += kBlock) {
+    for (int i = threadIdx.x; i < FTU * S; i += kBlock) {
         const int ff = f0 + i / S;
         if (ff < F) out[((int64_t)t * F + ff) * S + i % S] = (float)hist[i];
     }
@@ -2871,20 +2987,22 @@ __global__ void k_set_count_rows(const float* __restrict__ rows /* [n][F][S] */,
 //   row 1 + (gg - K) = counts[gg] - sum over subset objects in confounder group gg of [source == c] * one-hot   (:896-901)
 // from the slot's group ids and source (the bound candidate: new clusters, source not yet resampled) and its resident
 // counts (still the old state's, which is what sample.feature_counts holds at that point).  `in_subset` [N] bytes.
-// Block = (row, 64-feature tile), 64 features x 4 object lanes, LDS histogram [64][S].
+// Block = (row, 16-feature tile), 16 features x 64 object lanes (1024 threads), LDS histogram [16][S].
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_unchanged_counts(
+constexpr int kUnchangedBlock = 1024;
+__global__ __launch_bounds__(kUnchangedBlock) void k_unchanged_counts(
     const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid /* slot's [C][Np] */,
     const uint8_t* __restrict__ src /* slot's [N][Fp] */, const int32_t* __restrict__ counts /* slot's [Gtot][F][S] */,
     const uint8_t* __restrict__ in_subset /* [N] */, const int32_t* __restrict__ objects, int n_sub,
     const int32_t* __restrict__ comp_of_group /* [Gtot] */, int i_cluster, int K, int N, int Np, int F, int S, int Fp,
-    float* __restrict__ out /* [1 + Gtot - K][F][S] */) {
-    // 16 features x 16 object lanes: row 0 walks ALL objects (the cluster's members are found by id), so the object
+    const double* __restrict__ conc /* [Gtot][F][S] */, const double* __restrict__ unif /* [F][S] */, double temperature,
+    double prior_temperature, int* __restrict__ status, float* __restrict__ out /* [1 + Gtot - K][F][S] probability tables */) {
+    // 16 features x 64 object lanes: row 0 walks ALL objects (the cluster's members are found by id), so the object
     // axis gets the lanes; a wave reads four 16-byte runs of four state rows per step
-    constexpr int FTU = 16, OL = kBlock / FTU;
+    constexpr int FTU = 16, OL = kUnchangedBlock / FTU;
     extern __shared__ int32_t hist[];
     const int r = blockIdx.x, f0 = blockIdx.y * FTU;
-    for (int i = threadIdx.x; i < FTU * S; i += kBlock) hist[i] = 0;
+    for (int i = threadIdx.x; i < FTU * S; i += kUnchangedBlock) hist[i] = 0;
     __syncthreads();
     const int fl = threadIdx.x & (FTU - 1), ol = threadIdx.x / FTU;
     const int f = f0 + fl;
@@ -2907,12 +3025,16 @@ __global__ __launch_bounds__(kBlock) void k_unchanged_counts(
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < FTU * S; i += kBlock) {
-        const int ff = f0 + i / S;
-        if (ff >= F) continue;
-        const int s = i % S;
-        const int base = r == 0 ? 0 : counts[((int64_t)(K + r - 1) * F + ff) * S + s];
-        out[((int64_t)r * F + ff) * S + s] = (float)(base + hist[i]);
+    // conditional_effect_mean (conditionals.py:105-122) of the kept counts, row by row: the cluster's row with the
+    // cluster's prior, a confounder group's row with its own (k_probs' arithmetic: probs_row)
+    if (threadIdx.x < FTU && f0 + threadIdx.x < F) {
+        const int ff = f0 + threadIdx.x;
+        const int gg = r == 0 ? i_cluster : K + r - 1;
+        const int32_t* base = counts + ((int64_t)gg * F + ff) * S;
+        const int32_t* h = hist + threadIdx.x * S;
+        float* out_row = out + ((int64_t)r * F + ff) * S;
+        probs_row([&](int s) { return (float)((r == 0 ? 0 : base[s]) + h[s]); }, conc + ((int64_t)gg * F + ff) * S,
+                  unif + (int64_t)ff * S, S, temperature, prior_temperature, status, [&](int s, float v) { out_row[s] = v; });
     }
 }
 

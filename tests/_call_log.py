@@ -215,7 +215,7 @@ def replay(path, make_engine):
     return counts, meta
 
 
-def replay_timed(path, make_engine, repeats=1, by_method=None):
+def replay_timed(path, make_engine, repeats=1, by_method=None, drain=False):
     """Timing-only replay (bench.py's sampler_replay block): the recorded call sequence against `make_engine(n_groups)`
     with no result checks (tests/test_gpu_call_log.py does those) and the argument arrays loaded beforehand.  Calls
     before the first step marker (model set-up, initialiser) are excluded.  Returns a dict: steps, calls, seconds of the
@@ -258,9 +258,13 @@ def replay_timed(path, make_engine, repeats=1, by_method=None):
                 else:
                     getattr(eng, name)(*args, **kwargs)
                 if by_method is not None and i > first_marker:
-                    acc = by_method.setdefault(name, [0, 0.0])
+                    acc = by_method.setdefault(name, [0, 0.0, 0.0])
                     acc[0] += 1
-                    acc[1] += time.perf_counter() - t_call
+                    t_ret = time.perf_counter()
+                    acc[1] += t_ret - t_call
+                    if drain:                       # what the call left queued on the stream, charged to the call itself
+                        eng.sync()
+                        acc[2] += time.perf_counter() - t_ret
                 n_calls += i > first_marker
             if hasattr(eng, "sync"):
                 eng.sync()

@@ -39,9 +39,10 @@ def run(tag, path=None, cpu=True, repeats=3, device=0):
     return out
 
 
-def by_method(tag):
+def by_method(tag, drain=False):
     """Where the per-step time goes: wall time inside each Engine method over one replay (setters are asynchronous:
-    their cost shows up in the next call that synchronises)."""
+    their cost shows up in the next call that synchronises -- unless `drain`: then the stream is synchronised after
+    every call and what the call left queued is reported as its `drain_us_per_call`)."""
     from sbayes_amd.engine import Engine
     feats = features_of(tag)
     acc = {}
@@ -49,17 +50,18 @@ def by_method(tag):
         eng = Engine(feats, n_groups, n_slots=4)
         eng.set_option(deferred_checks=True)
         return eng
-    res = replay_timed(REPO / "tests" / "golden" / f"{tag}_calls.npz", make, 1, acc)
+    res = replay_timed(REPO / "tests" / "golden" / f"{tag}_calls.npz", make, 1, acc, drain)
     steps = max(1, res["steps"])
-    return {k: {"calls_per_step": round(n / steps, 2), "us_per_call": round(t / n * 1e6, 1), "us_per_step": round(t / steps * 1e6, 1)}
-            for k, (n, t) in sorted(acc.items(), key=lambda kv: -kv[1][1])}
+    return {k: {"calls_per_step": round(n / steps, 2), "us_per_call": round(t / n * 1e6, 1), "us_per_step": round(t / steps * 1e6, 1),
+                **({"drain_us_per_call": round(d / n * 1e6, 1)} if drain else {})}
+            for k, (n, t, d) in sorted(acc.items(), key=lambda kv: -kv[1][1])}
 
 
 if __name__ == "__main__":
     args = sys.argv[1:]
-    if args and args[0] == "--by-method":
+    if args and args[0] in ("--by-method", "--by-method-drain"):
         for tag in args[1:] or ["headline"]:
-            print(json.dumps({"tag": tag, "by_method": by_method(tag)}), flush=True)
+            print(json.dumps({"tag": tag, "by_method": by_method(tag, drain=args[0].endswith("drain"))}), flush=True)
     else:
         for tag in args or ["cfg1", "south_america", "headline"]:
             print(json.dumps(run(tag)), flush=True)
