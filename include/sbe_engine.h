@@ -178,6 +178,11 @@ int sbe_set_concentration(sbe_engine* e, int component, const double* conc, int 
  * sbe_set_probs: explicit tables instead. */
 int sbe_update_probs(sbe_engine* e, int slot, int component, double temperature,
                      double prior_temperature, const double* unif_counts /* [F][S] or NULL */);
+/* The same for every component whose bit is set in `component_mask` (bit c = component c): components with adjacent
+ * group ranges share a launch.  likelihood_per_component (conditionals.py:175-179, 200-204) refreshes the tables of
+ * all components whose counts changed since the last evaluation; the drop-in layer asks for them together. */
+int sbe_update_probs_mask(sbe_engine* e, int slot, unsigned component_mask, double temperature,
+                          double prior_temperature, const double* unif_counts /* [F][S] or NULL */);
 int sbe_set_probs(sbe_engine* e, int slot, int component, const float* probs /* [G_c][F][S] */);
 int sbe_get_probs(sbe_engine* e, int slot, int component, float* out /* [G_c][F][S] */);
 

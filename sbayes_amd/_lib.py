@@ -57,6 +57,7 @@ PROTOTYPES = {
     "sbe_get_counts": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
     "sbe_set_concentration": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int]),
     "sbe_update_probs": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_double, ct.c_double, ct.c_void_p]),
+    "sbe_update_probs_mask": (ct.c_int, [c_engine_p, ct.c_int, ct.c_uint, ct.c_double, ct.c_double, ct.c_void_p]),
     "sbe_set_probs": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
     "sbe_get_probs": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
     "sbe_set_weights": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),

@@ -71,8 +71,10 @@ def _changed_rows(new, mirror):
     return np.flatnonzero((a != b).any(axis=1))
 
 
-def _send_counts(eng, slot, c, new, mirror):
-    """Bring the slot's counts of component c to `new` [G, F, S]; returns (mirror, anything changed)."""
+def _send_counts(eng, slot, c, new, mirror, pending):
+    """Bring the slot's counts of component c to `new` [G, F, S]; returns (mirror, anything changed).  Changed rows are
+    appended to `pending` = ([global group indices], [rows]) -- _bind_slot sends the rows of ALL components with one
+    set_counts_rows call; a component the slot has never held goes up whole."""
     new = np.asarray(new, dtype=np.float32)
     if mirror is None or mirror.shape != new.shape or not hasattr(eng, "set_counts_rows"):
         eng.set_counts(slot, c, new)
@@ -80,10 +82,8 @@ def _send_counts(eng, slot, c, new, mirror):
     rows = _changed_rows(new, mirror)
     if rows.size == 0:
         return mirror, False
-    if 2 * rows.size > new.shape[0]:
-        eng.set_counts(slot, c, new)
-        return new.copy(), True
-    eng.set_counts_rows(slot, int(eng.group_offsets[c]) + rows, new[rows])
+    pending[0].append(int(eng.group_offsets[c]) + rows)
+    pending[1].append(new[rows])
     mirror[rows] = new[rows]
     return mirror, True
 
@@ -137,21 +137,26 @@ def _bind_slot(eng, model, sample, slot, with_source=False):
     mirrors = eng._mirror.setdefault(slot, {"counts": [None] * C, "source": None}) if hasattr(eng, "_mirror") else \
         {"counts": [None] * C, "source": None}
     new = {"groups": list(old["groups"]), "counts": list(old["counts"]), "weights": old["weights"], "source": old["source"],
-           "stale": set(old["stale"])}
+           "stale": set(old["stale"]), "lh_all": old.get("lh_all")}
+    pending = ([], [])                              # count rows of all components: one set_counts_rows call
     conc_changed = [] if conc is None else [c for c in range(C) if not _same(conc[c], eng._bound_conc.get(c))]
     for c in conc_changed:                          # (drops every slot's entry: all tables depend on it)
         eng.set_concentration(c, conc[c][0])
     if conc_changed:
         new["stale"] = set(range(C))
+        new["lh_all"] = None
     for c in range(C):
         if not _same(groups[c], old["groups"][c]):
             eng.set_groups(slot, c, groups[c][0])
             new["groups"][c] = _remember(groups[c])
         if counts is not None and not _same(counts[c], old["counts"][c]):
-            mirrors["counts"][c], changed = _send_counts(eng, slot, c, counts[c][0], mirrors["counts"][c])
+            mirrors["counts"][c], changed = _send_counts(eng, slot, c, counts[c][0], mirrors["counts"][c], pending)
             new["counts"][c] = _remember(counts[c])
             if changed:
                 new["stale"].add(c)
+                new["lh_all"] = None                # (Likelihood._group_logliks' memo of the collapsed log-likelihoods)
+    if pending[0]:
+        eng.set_counts_rows(slot, np.concatenate(pending[0]), np.concatenate(pending[1]))
     if with_source and not _same(source, old["source"]):
         mirrors["source"] = _send_source(eng, slot, source[0], mirrors["source"])
         new["source"] = _remember(source)
@@ -179,6 +184,7 @@ def recount_bound(eng, sample, slot=0):
     if entry is not None and mirrors is not None:
         entry["counts"] = [None] * eng.n_components          # whatever parameter holds them next is compared by content
         entry["stale"] = set(range(eng.n_components))
+        entry["lh_all"] = None
         mirrors["counts"] = [t.copy() for t in tables]
         eng._bound[slot], eng._mirror[slot] = entry, mirrors
     return tables
@@ -197,7 +203,9 @@ def _tables_current(eng, slot):
     """Rebuild the probability tables that the last _bind_slot left stale."""
     entry = getattr(eng, "_bound", {}).get(slot)
     stale = set(range(eng.n_components)) if entry is None else entry["stale"]
-    for c in sorted(stale):
-        eng.update_probs(slot, c)
+    if len(stale) == 1:
+        eng.update_probs(slot, next(iter(stale)))
+    elif stale:
+        eng.update_probs(slot, sorted(stale))      # one call (adjacent components: one launch)
     if entry is not None:
         entry["stale"] = set()

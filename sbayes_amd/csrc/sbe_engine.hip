@@ -218,6 +218,8 @@ int dmalloc(sbe_engine* e, T** p, int64_t n) {
     return SBE_OK;
 }
 
+inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+
 int ensure_scratch(sbe_engine* e, size_t bytes) {
     if (bytes <= e->scratch_bytes) return SBE_OK;
     if (e->d_scratch) { HIPCHK(e, hipStreamSynchronize(e->stream)); HIPCHK(e, hipFree(e->d_scratch)); }
@@ -281,6 +283,25 @@ int d2h(sbe_engine* e, void* dst, const void* src_dev, size_t bytes) {
     HIPCHK(e, hipMemcpyAsync(e->h_pinned, src_dev, bytes, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     memcpy(dst, e->h_pinned, bytes);
+    return synced(e);
+}
+
+// Where a result kernel writes: small results go straight into the host-mapped I/O block (posted PCIe writes, no copy
+// operation behind the kernel), large ones into `dev_fallback` and back through the staging copy.  For calls that do
+// not use the I/O block for anything else.  out_fetch ends the call: synchronise, data checks, result to the caller.
+constexpr size_t kMappedOutMax = (size_t)1 << 18;
+int out_target(sbe_engine* e, size_t bytes, void* dev_fallback, void** target) {
+    *target = dev_fallback;
+    if (bytes > kMappedOutMax) return SBE_OK;
+    int rc = ensure_io(e, bytes);
+    if (rc) return rc;
+    *target = e->d_io;
+    return SBE_OK;
+}
+int out_fetch(sbe_engine* e, void* host_out, const void* target, size_t bytes) {
+    if (target != (const void*)e->d_io) return d2h(e, host_out, target, bytes);
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    memcpy(host_out, e->h_io, bytes);
     return synced(e);
 }
 
@@ -1589,9 +1610,12 @@ int sbe_get_counts(sbe_engine* e, int slot, int component, float* out) {
     int rc = ensure_scratch(e, n * sizeof(float));
     if (rc) return rc;
     const int32_t* src = e->d_counts + (int64_t)slot * e->table_elems() + (int64_t)e->goff[component] * e->F * e->S;
-    k_i32_to_f32<<<div_up(n, 256), 256, 0, e->stream>>>(src, (float*)e->d_scratch, n);
+    void* d_out;
+    rc = out_target(e, n * sizeof(float), e->d_scratch, &d_out);
+    if (rc) return rc;
+    k_i32_to_f32<<<div_up(n, 256), 256, 0, e->stream>>>(src, (float*)d_out, n);
     HIPCHK(e, hipGetLastError());
-    return d2h(e, out, e->d_scratch, n * sizeof(float));
+    return out_fetch(e, out, d_out, n * sizeof(float));
 }
 
 // ---- concentration / probs ----------------------------------------------------------------------
@@ -1617,13 +1641,20 @@ int sbe_set_concentration(sbe_engine* e, int component, const double* conc, int 
     return SBE_OK;
 }
 
-int sbe_update_probs(sbe_engine* e, int slot, int component, double temperature, double prior_temperature,
-                     const double* unif_counts) {
-    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component);
+int sbe_update_probs_mask(sbe_engine* e, int slot, unsigned component_mask, double temperature, double prior_temperature,
+                          const double* unif_counts) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot);
+    if (e->C < 32 && (component_mask >> e->C) != 0) return fail(e, SBE_ERR_ARG, "component mask 0x%x names components >= %d", component_mask, e->C);
     Slot& s = e->slots[slot];
-    if (e->G[component] == 0) { s.probs_set[component] = 1; return SBE_OK; }       // component without groups: empty tables
-    if (!e->conc_set[component]) return fail(e, SBE_ERR_STATE, "concentration of component %d not set", component);
-    if (!s.counts_set[component]) return fail(e, SBE_ERR_STATE, "slot %d: counts of component %d not set", slot, component);
+    bool any = false;
+    for (int c = 0; c < e->C; ++c) {
+        if (!((component_mask >> c) & 1u)) continue;
+        if (e->G[c] == 0) { s.probs_set[c] = 1; continue; }                        // component without groups: empty tables
+        if (!e->conc_set[c]) return fail(e, SBE_ERR_STATE, "concentration of component %d not set", c);
+        if (!s.counts_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts of component %d not set", slot, c);
+        any = true;
+    }
+    if (!any) return SBE_OK;
     if (prior_temperature > 0.0 && !unif_counts) return fail(e, SBE_ERR_ARG, "prior_temperature given without unif_counts (conditionals.py:114)");
     HIPCHK(e, hipSetDevice(e->device));
     const double* d_unif = nullptr;
@@ -1633,14 +1664,25 @@ int sbe_update_probs(sbe_engine* e, int slot, int component, double temperature,
     }
     int rc = clear_status_word(e, ST_BAD_NORMALIZE);
     if (rc) return rc;
-    const int g_lo = e->goff[component], g_hi = g_lo + e->G[component];
-    k_probs<int32_t><<<div_up((int64_t)(g_hi - g_lo) * e->F, 256), 256, 0, e->stream>>>(
-        e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc, d_unif,
-        e->d_probs + (int64_t)slot * e->table_elems(), g_lo, g_hi, e->F, e->S, temperature, prior_temperature, 1, e->d_status, 0,
-        e->d_probs_t + (int64_t)slot * e->probs_t_elems(), e->Gtot, e->ft);       // (+ the tile-transposed copy: one launch)
-    HIPCHK(e, hipGetLastError());
-    s.probs_set[component] = 1;
+    for (int c = 0; c < e->C; ++c) {                       // runs of selected components: adjacent group ranges, one launch
+        if (!((component_mask >> c) & 1u) || e->G[c] == 0) continue;
+        const int g_lo = e->goff[c];
+        int g_hi = g_lo + e->G[c];
+        s.probs_set[c] = 1;
+        while (c + 1 < e->C && ((component_mask >> (c + 1)) & 1u)) { ++c; g_hi = e->goff[c] + e->G[c]; s.probs_set[c] = 1; }
+        k_probs<int32_t><<<div_up((int64_t)(g_hi - g_lo) * e->F, 256), 256, 0, e->stream>>>(
+            e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc, d_unif,
+            e->d_probs + (int64_t)slot * e->table_elems(), g_lo, g_hi, e->F, e->S, temperature, prior_temperature, 1, e->d_status, 0,
+            e->d_probs_t + (int64_t)slot * e->probs_t_elems(), e->Gtot, e->ft);   // (+ the tile-transposed copy: one launch)
+        HIPCHK(e, hipGetLastError());
+    }
     return check_after(e);
+}
+
+int sbe_update_probs(sbe_engine* e, int slot, int component, double temperature, double prior_temperature,
+                     const double* unif_counts) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component);
+    return sbe_update_probs_mask(e, slot, 1u << component, temperature, prior_temperature, unif_counts);
 }
 
 int sbe_set_probs(sbe_engine* e, int slot, int component, const float* probs) {
@@ -1974,41 +2016,25 @@ int sbe_normalize_weights(sbe_engine* e, const float* weights, int n_comp, const
     CHECK_PTR(e, has_components); CHECK_PTR(e, out);
     HIPCHK(e, hipSetDevice(e->device));
     const int N = n_rows, F = e->F, C = n_comp;     // the rows are whatever the caller hands over (has_components[available], operators.py:1086)
-    // distinct rows in np.unique(axis=0) order (lexicographic, False < True)
-    std::vector<uint32_t> bits(N);
-    for (int n = 0; n < N; ++n) {
-        uint32_t b = 0;
-        for (int c = 0; c < C; ++c) if (has_components[(size_t)n * C + c]) b |= 1u << c;
-        bits[n] = b;
-    }
-    auto key = [C](uint32_t b) { uint32_t k = 0; for (int c = 0; c < C; ++c) k |= ((b >> c) & 1u) << (C - 1 - c); return k; };
-    std::vector<uint32_t> uniq(bits);
-    std::sort(uniq.begin(), uniq.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
-    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-    const int P = (int)uniq.size();
-    if (P > 255) return fail(e, SBE_ERR_ARG, "%d distinct has_components patterns", P);
-    std::vector<uint8_t> pid(N);
-    for (int n = 0; n < N; ++n) pid[n] = (uint8_t)(std::find(uniq.begin(), uniq.end(), bits[n]) - uniq.begin());
-    const size_t wb = ((size_t)F * C * sizeof(float) + 255) / 256 * 256;
-    const size_t pb = ((size_t)P * sizeof(uint32_t) + 255) / 256 * 256;
-    const size_t tb = ((size_t)P * F * C * sizeof(float) + 255) / 256 * 256;
-    const size_t ib = ((size_t)N + 255) / 256 * 256;
+    // row form (k_normalize_weight_rows): no pattern sort on either side, one launch; a few rows read the weights out of
+    // the mapped staging ring, many rows out of device memory (every block reads them once)
+    const size_t wb = al256((size_t)F * C * sizeof(float)), hb = al256((size_t)N * C);
     const int64_t n_out = (int64_t)N * F * C;
-    int rc = ensure_scratch(e, wb + pb + tb + ib + (size_t)n_out * sizeof(float));
+    int rc = ensure_scratch(e, wb + hb + (size_t)n_out * sizeof(float));
     if (rc) return rc;
-    float* d_w = (float*)e->d_scratch;
-    uint32_t* d_pb = (uint32_t*)(e->d_scratch + wb);
-    float* d_tab = (float*)(e->d_scratch + wb + pb);
-    uint8_t* d_pid = e->d_scratch + wb + pb + tb;
-    float* d_out = (float*)(e->d_scratch + wb + pb + tb + ib);
-    { int _urc = upload(e, d_w, weights, (size_t)F * C * sizeof(float)); if (_urc) return _urc; }
-    { int _urc = upload(e, d_pb, uniq.data(), (size_t)P * sizeof(uint32_t)); if (_urc) return _urc; }
-    { int _urc = upload(e, d_pid, pid.data(), (size_t)N); if (_urc) return _urc; }
-    k_weight_patterns<<<div_up((int64_t)P * F, 256), 256, 0, e->stream>>>(d_w, d_pb, d_tab, P, F, C);
+    const void *v_w = e->d_scratch, *v_hc;
+    if (N <= 256) rc = stage(e, weights, (size_t)F * C * sizeof(float), e->d_scratch, &v_w);
+    else rc = upload(e, e->d_scratch, weights, (size_t)F * C * sizeof(float));
+    if (rc) return rc;
+    rc = stage(e, has_components, (size_t)N * C, e->d_scratch + wb, &v_hc);
+    if (rc) return rc;
+    void* d_out;
+    rc = out_target(e, (size_t)n_out * sizeof(float), e->d_scratch + wb + hb, &d_out);
+    if (rc) return rc;
+    k_normalize_weight_rows<<<div_up(N, kNwRows), 256, (size_t)F * C * sizeof(float), e->stream>>>(
+        (const float*)v_w, (const uint8_t*)v_hc, (float*)d_out, N, F, C);
     HIPCHK(e, hipGetLastError());
-    k_expand_weights<<<div_up(n_out, 256), 256, 0, e->stream>>>(d_tab, d_pid, d_out, N, F, C);
-    HIPCHK(e, hipGetLastError());
-    return d2h(e, out, d_out, (size_t)n_out * sizeof(float));
+    return out_fetch(e, out, d_out, (size_t)n_out * sizeof(float));
 }
 
 // ---- cluster-membership marginals ---------------------------------------------
@@ -2177,10 +2203,12 @@ int sbe_source_posterior(sbe_engine* e, int slot, const int32_t* objects, int n_
     SrcPostArgs a; uint8_t* d_extra = nullptr;
     int rc = source_posterior_setup(e, slot, objects, n_sub, temperature, prior_temperature, 0, (size_t)n_out * sizeof(float), &a, &d_extra);
     if (rc || n_sub == 0) return rc;
-    float* d_out = (float*)d_extra;
-    k_source_posterior<<<div_up((int64_t)n_sub * e->F, 256), 256, 0, e->stream>>>(a, d_out, e->d_status);
+    void* d_out;
+    rc = out_target(e, (size_t)n_out * sizeof(float), d_extra, &d_out);
+    if (rc) return rc;
+    k_source_posterior<<<div_up((int64_t)n_sub * e->F, 256), 256, 0, e->stream>>>(a, (float*)d_out, e->d_status);
     HIPCHK(e, hipGetLastError());
-    rc = d2h(e, out, d_out, (size_t)n_out * sizeof(float));
+    rc = out_fetch(e, out, d_out, (size_t)n_out * sizeof(float));
     if (rc) return rc;
     return source_posterior_status(e);
 }
@@ -2312,7 +2340,6 @@ int check_objects(sbe_engine* e, const int32_t* objects, int n) {
     return SBE_OK;
 }
 
-inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 }  // namespace
 
@@ -2595,11 +2622,14 @@ int sbe_source_prior(sbe_engine* e, int slot, double* per_object_out) {
     if (s.patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
     rc = ensure_scratch(e, (size_t)e->N * sizeof(double));
     if (rc) return rc;
+    void* d_out;
+    rc = out_target(e, (size_t)e->N * sizeof(double), e->d_scratch, &d_out);
+    if (rc) return rc;
     k_source_prior<<<div_up(e->N, kBlock / kWave), kBlock, 0, e->stream>>>(
         e->d_state, e->d_src + (int64_t)slot * e->N * e->Fp, e->d_pid + (int64_t)slot * e->Np,
-        e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, (double*)e->d_scratch, e->N, e->F, e->C, e->Fp);
+        e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, (double*)d_out, e->N, e->F, e->C, e->Fp);
     HIPCHK(e, hipGetLastError());
-    return d2h(e, per_object_out, e->d_scratch, (size_t)e->N * sizeof(double));
+    return out_fetch(e, per_object_out, d_out, (size_t)e->N * sizeof(double));
 }
 
 int sbe_observation_lh_exact(sbe_engine* e, int slot, double* out) {

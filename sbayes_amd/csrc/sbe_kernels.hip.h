@@ -634,6 +634,37 @@ __global__ void k_weight_patterns(const float* __restrict__ weights /* [F][C] */
     }
 }
 
+// normalize_weights (likelihood.py:171-190), stateless, ROW form: out[n][f][:] = has_components[n] * weights[f] / sum --
+// k_weight_patterns' arithmetic evaluated per row instead of per distinct pattern (the same operations on the same
+// operands: the same bits), so nobody sorts patterns and the call is ONE launch.  Block = 8 rows; the [F][C] weights
+// and the block's has_components rows are read once into LDS (both may live in host-mapped staging memory).
+constexpr int kNwRows = 8;
+__global__ void k_normalize_weight_rows(const float* __restrict__ weights /* [F][C] */,
+                                        const uint8_t* __restrict__ has_components /* [N][C] */,
+                                        float* __restrict__ out /* [N][F][C] */, int N, int F, int C) {
+    extern __shared__ float nw_lds[];                        // [F][C] weights
+    __shared__ uint32_t bits[kNwRows];
+    for (int i = threadIdx.x; i < F * C; i += blockDim.x) nw_lds[i] = weights[i];
+    const int n0 = blockIdx.x * kNwRows;
+    if (threadIdx.x < kNwRows) {
+        uint32_t b = 0;
+        const int n = n0 + threadIdx.x;
+        if (n < N) for (int c = 0; c < C; ++c) if (has_components[(int64_t)n * C + c]) b |= 1u << c;
+        bits[threadIdx.x] = b;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kNwRows * F; i += blockDim.x) {
+        const int r = i / F, f = i - r * F, n = n0 + r;
+        if (n >= N) break;
+        const uint32_t b = bits[r];
+        const float* w = nw_lds + f * C;
+        auto masked = [&](int c) -> float { return ((b >> c) & 1u) ? w[c] : 0.0f * w[c]; };
+        const float total = np_pairwise_sum<float>(masked, C);
+        float* o = out + ((int64_t)n * F + f) * C;
+        for (int c = 0; c < C; ++c) o[c] = masked(c) / total;
+    }
+}
+
 __global__ void k_expand_weights(const float* __restrict__ wpat, const uint8_t* __restrict__ pid,
                                  float* __restrict__ out /* [N][F][C] */, int N, int F, int C) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2423,12 +2454,20 @@ __global__ __launch_bounds__(1024) void k_source_lh_by_feature(
         if (ol == 0) {
             const int m = min(kSlfChunk, N - n0);
             int k = 0;
-            for (; k + 8 <= m; k += 8) {
-                float v[8];
+            float v[8], nx[8];                             // the next eight values are on their way while these are added
+            if (m >= 8) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = part[k + u][fl];
+                for (int u = 0; u < 8; ++u) v[u] = part[u][fl];
+            }
+            for (; k + 8 <= m; k += 8) {
+                if (k + 16 <= m) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) nx[u] = part[k + 8 + u][fl];
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc = acc + v[u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = nx[u];
             }
             for (; k < m; ++k) acc = acc + part[k][fl];
         }
@@ -3009,10 +3048,23 @@ __global__ __launch_bounds__(kUnchangedBlock) void k_unchanged_counts(
     if (f < F) {
         if (r == 0) {
             const uint16_t want = (uint16_t)i_cluster;                  // component 0: global index = cluster index
-            for (int n = ol; n < N; n += OL) {
-                if (gid[n] != want || in_subset[n]) continue;
-                const uint8_t x = state[(int64_t)n * Fp + f];
-                if (x != kNA && src[(int64_t)n * Fp + f] == 0) atomicAdd(&hist[fl * S + x], 1);
+            for (int n = ol; n < N; n += 4 * OL) {                      // four objects per lane and step: their loads overlap
+                bool take[4];
+                uint8_t x[4], sc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int nn = n + j * OL;
+                    take[j] = nn < N && gid[nn] == want && !in_subset[nn];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t at = (int64_t)(n + j * OL) * Fp + f;
+                    x[j] = take[j] ? state[at] : kNA;
+                    sc[j] = take[j] ? src[at] : kNA;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (x[j] != kNA && sc[j] == 0) atomicAdd(&hist[fl * S + x[j]], 1);
             }
         } else {
             const int gg = K + r - 1, c = comp_of_group[gg];

@@ -266,7 +266,8 @@ class Engine:
         self._check(self._lib.sbe_set_concentration(self._h, component, self._i(conc), per_group))
 
     def update_probs(self, slot, component, temperature=None, prior_temperature=None, unif_counts=None):
-        """probs = normalize(counts [/T] + prior['] ) on the device (conditionals.py:105-122, 175-179)."""
+        """probs = normalize(counts [/T] + prior['] ) on the device (conditionals.py:105-122, 175-179).  `component`:
+        one index, or several (any iterable of indices): their tables in one call."""
         t = float(temperature) if temperature is not None else 0.0
         tp = float(prior_temperature) if prior_temperature is not None else 0.0
         u = None
@@ -278,7 +279,15 @@ class Engine:
                 raise ValueError("unif_counts must be [n_features, n_states]")
         if temperature is not None or prior_temperature is not None:
             self._touch(slot)               # tempered tables are not the ones the bind cache vouches for
-        self._check(self._lib.sbe_update_probs(self._h, slot, component, t, tp, self._i(u) if u is not None else None))
+        if isinstance(component, (int, np.integer)):
+            self._check(self._lib.sbe_update_probs(self._h, slot, int(component), t, tp, self._i(u) if u is not None else None))
+            return
+        mask = 0
+        for c in component:
+            if not 0 <= int(c) < self.n_components:
+                raise ValueError(f"component {c} out of range")
+            mask |= 1 << int(c)
+        self._check(self._lib.sbe_update_probs_mask(self._h, slot, mask, t, tp, self._i(u) if u is not None else None))
 
     def set_probs(self, slot, component, probs):
         p = _c(probs, np.float32)

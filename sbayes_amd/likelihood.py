@@ -82,7 +82,16 @@ class Likelihood:
         goes up, G_c doubles come back."""
         eng = self.engine
         _bind_slot(eng, SimpleNamespace(prior=self.prior), sample, slot)
-        return eng.collapsed_loglik(slot, component)[np.asarray(groups)]
+        # Likelihood.__call__ asks component after component (likelihood.py:58-63): every component's groups are
+        # evaluated by the first request (one launch, one synchronisation) and kept on the slot's bind entry until a
+        # count row or a concentration table changes
+        entry = eng._bound.get(slot) if getattr(eng, "_bound", None) is not None else None
+        lh_all = entry.get("lh_all") if entry is not None else None
+        if lh_all is None:
+            lh_all = eng.collapsed_loglik_all(slot)
+            if entry is not None:
+                entry["lh_all"] = lh_all
+        return lh_all[int(eng.group_offsets[component]) + np.asarray(groups)]
 
     def compute_lh_clusters(self, sample, caching=True) -> float:
         cache = sample.cache.group_likelihoods["clusters"]

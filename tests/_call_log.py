@@ -54,6 +54,7 @@ COMPARE = {
     "subset_lh": "exact_at_t1",
     "counts_delta": "exact", "given_unchanged_lh": "exact_at_t1", "get_counts": "exact",
     "collapsed_loglik": (2e-6, 1e-6),        # float32 per feature in the reference
+    "collapsed_loglik_all": (2e-6, 1e-6),
     "source_prior": (2e-6, 1e-6),            # float32 logs, fp64 accumulation on the device
     "cluster_posterior_marginals": (1e-9, 1e-9), "jump_lh_resident": (1e-9, 1e-9),
 }
@@ -140,7 +141,7 @@ def _wrap(name):
 for _name in ("normalize_tables", "dirichlet_logpdf", "effect_counts", "set_groups", "set_concentration", "set_counts",
               "set_source", "set_weights", "update_probs", "cluster_marginals", "source_posterior", "subset_lh",
               "normalize_weights", "observation_lh_exact", "jump_lh", "source_lh_by_feature", "set_counts_rows",
-              "set_source_rows", "set_uniform_counts", "counts_delta", "collapsed_loglik", "source_prior",
+              "set_source_rows", "set_uniform_counts", "counts_delta", "collapsed_loglik", "collapsed_loglik_all", "source_prior",
               "given_unchanged_lh", "cluster_posterior_marginals", "jump_lh_resident", "recount", "get_counts"):
     setattr(RecordingEngine, _name, _wrap(_name))
 

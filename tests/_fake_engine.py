@@ -117,7 +117,7 @@ class FakeEngine:
         self._slot(slot)["weights"] = np.asarray(weights, dtype=np.float32).copy()
 
     def update_probs(self, slot, component):
-        pass                            # tables are derived on demand below
+        pass                            # (one index or several) tables are derived on demand below
 
     def _state(self, slot):
         s = self.slots[slot]
@@ -251,6 +251,13 @@ class FakeEngine:
         _, counts, conc, _ = self._full_state(slot)
         return orc.collapsed_group_logliks(counts[component], conc[component])
 
+    def collapsed_loglik_all(self, slot):
+        self.calls.append(("collapsed_loglik_all",))
+        _, counts, conc, _ = self._full_state(slot)
+        parts = [orc.collapsed_group_logliks(counts[c], conc[c]) if self.n_groups[c] else np.zeros(0)
+                 for c in range(len(counts))]
+        return np.concatenate(parts).astype(np.float64)
+
     def source_prior(self, slot):
         self.calls.append(("source_prior",))
         groups, _, _, s = self._full_state(slot)
@@ -270,7 +277,7 @@ class FakeEngine:
         _, counts, conc, _ = self._full_state(slot)
         table = orc.conditional_effect_mean(conc[0], counts[0][[i_cluster]], unif_counts=self.unif,
                                             prior_temperature=prior_temperature, temperature=temperature)
-        return self.cluster_marginals(slot, table, objects, prior_temperature)
+        return FakeEngine.cluster_marginals(self, slot, table, objects, prior_temperature)     # (not the recording subclass's: ONE engine call)
 
     def jump_lh_resident(self, slot, i_source, i_target, objects, temperature=1.0, prior_temperature=1.0):
         self.calls.append(("jump_lh_resident", len(objects)))

@@ -22,11 +22,11 @@ def test_call_log_replays_on_the_double(tag):
     counts, meta = replay(GOLDEN / f"{tag}_calls.npz", lambda n_groups: FakeEngine(feats, n_groups))
     assert crc(feats) == meta["features_crc"] and list(feats.shape) == meta["shape"]
     # the operator forms and the collapsed likelihood really ran through the engine surface
-    assert {"cluster_marginals", "cluster_posterior_marginals", "source_posterior", "given_unchanged_lh", "collapsed_loglik",
-            "counts_delta", "source_prior", "set_counts", "set_counts_rows", "set_source_rows", "set_groups",
+    assert {"cluster_marginals", "cluster_posterior_marginals", "source_posterior", "given_unchanged_lh", "collapsed_loglik_all",
+            "counts_delta", "source_prior", "set_counts_rows", "set_source_rows", "set_groups",
             "set_weights", "__step__"} <= set(counts)
     # round 3: no whole [N, F] mask and no stateless whole-table call is left on the per-step path
     assert not {"effect_counts", "dirichlet_logpdf"} & set(counts)
     assert {"AlterCluster", "GibbsSampleSource"} <= set(meta["operators"])
     # through the bind cache: fewer uploads than evaluations
-    assert counts["set_groups"] < counts["cluster_marginals"] + counts["source_posterior"]
+    assert counts["set_groups"] < counts["cluster_marginals"] + counts["cluster_posterior_marginals"] + counts["source_posterior"]

@@ -98,7 +98,7 @@ def test_reference_sampler_on_drop_in_layer_is_the_same_markov_chain(tag, src, n
     assert np.array_equal(patched[3], plain[3])
     eng = next(iter(patched[4].values()))
     kinds = {c[0] for c in eng.calls}
-    assert {"component_lh", "normalize_tables", "collapsed_loglik", "counts_delta"} <= kinds   # the path really ran through the layer
+    assert {"component_lh", "normalize_tables", "collapsed_loglik_all", "counts_delta"} <= kinds   # the path really ran through the layer
 
 
 @pytest.mark.parametrize("tag,src,n_steps", [
@@ -120,7 +120,7 @@ def test_reference_sampler_with_device_operator_forms(tag, src, n_steps, monkeyp
     eng = next(iter(patched[4].values()))
     kinds = {c[0] for c in eng.calls}
     assert {"cluster_marginals", "source_posterior", "given_unchanged_lh", "source_lh_by_feature", "source_prior",
-            "counts_delta", "collapsed_loglik"} <= kinds                             # the operator forms really ran
+            "counts_delta", "collapsed_loglik_all"} <= kinds                             # the operator forms really ran
     if tag == "south_america":                                                    # (test_files has one cluster: no jumps)
         assert "jump_lh_resident" in kinds and "ClusterJump" in {t[2] for t in patched[0]}
     names = {t[2] for t in patched[0]}
