@@ -2456,14 +2456,12 @@ int sbe_given_unchanged_lh(sbe_engine* e, int slot, int i_cluster, const int32_t
     const int64_t fs = (int64_t)F * S;
     const size_t out_bytes = (size_t)n_sub * F * C * sizeof(float);
     const bool mapped_out = out_bytes <= ((size_t)1 << 18);
-    // host-mapped inputs: object list | subset flags [N] | table row of each (component, subset object) | table offsets
-    const size_t ob = al256((size_t)n_sub * 4), mb = al256((size_t)N), gb = al256((size_t)C * n_sub * 4), fb = al256((size_t)C * 4);
+    // host-mapped inputs: object list | table row of each (component, subset object) | table offsets
+    const size_t ob = al256((size_t)n_sub * 4), mb = 0, gb = al256((size_t)C * n_sub * 4), fb = al256((size_t)C * 4);
     rc = ensure_io(e, ob + mb + gb + fb + (mapped_out ? out_bytes : 0));
     if (rc) return rc;
     uint8_t* h = e->h_io;
     memcpy(h, objects, (size_t)n_sub * 4);
-    memset(h + ob, 0, (size_t)N);
-    for (int i = 0; i < n_sub; ++i) h[ob + objects[i]] = 1;
     int32_t* gi = (int32_t*)(h + ob + mb);
     int32_t* off = (int32_t*)(h + ob + mb + gb);
     for (int c = 0; c < C; ++c) {
@@ -2483,9 +2481,10 @@ int sbe_given_unchanged_lh(sbe_engine* e, int slot, int i_cluster, const int32_t
     if (rc) return rc;
     // kept counts and their conditional_effect_mean (conditionals.py:105-122) in one launch: the cluster's row with the
     // cluster prior, the confounder rows with theirs
-    k_unchanged_counts<<<dim3(R, div_up(F, 16)), kUnchangedBlock, (size_t)16 * S * sizeof(int32_t), e->stream>>>(
+    k_unchanged_counts<<<dim3(R, div_up(F, 16)), kUnchangedBlock,
+                         ((size_t)16 * S + n_sub + (N + 31) / 32) * sizeof(int32_t), e->stream>>>(
         e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_src + (int64_t)slot * N * e->Fp,
-        e->d_counts + (int64_t)slot * e->table_elems(), e->d_io + ob, (const int32_t*)e->d_io, n_sub, e->d_comp_of_group,
+        e->d_counts + (int64_t)slot * e->table_elems(), (const int32_t*)e->d_io, n_sub, e->d_comp_of_group,
         i_cluster, K, N, e->Np, F, S, e->Fp, e->d_conc, e->d_unif_res, temperature, prior_temperature, e->d_status, d_tab);
     HIPCHK(e, hipGetLastError());
     const double inv_t = 1.0 / temperature;

@@ -2421,59 +2421,52 @@ __global__ __launch_bounds__(kBlock) void k_jump_lh(
 //     out[f] = float32( sum_n log p(n,f) ),   p = sum_c source[n,f,c] * w[n,f,c]  (one-hot source: the weight of the
 //     observation's source component; 0 if none is set), p = 1 for NA observations
 // from the slot's resident source, patterns and normalised weights: the [N, F, C] weight array the reference
-// materialises (twice per call of the operator) never exists.  float32 logs like the reference's (NumPy's own float32
-// log is not bit-reproducible here: compared at float32 accuracy) and the reference's summation: float32, objects in
-// order (np.sum(axis=0) of a C-ordered float32 [N, F] array adds row after row).
-// Block = 16 features x 64 object lanes.  The logs of 512 objects at a time go to LDS -- eight independent loads and
-// logs per thread, in flight together -- then the feature's owner lane adds the 512 values in object order (the serial
-// float32 chain is what the reference computes; one barrier pair per 512 objects, F/16 blocks).
+// materialises (twice per call of the operator) never exists.  float32 logs like the reference's.  NumPy's own float32
+// log is not bit-reproducible here, so the result is compared at float32 accuracy (tests/_call_log.py:COMPARE), and the
+// sum over the objects is taken where it is cheap AND no less accurate than the reference's: the reference adds the N
+// float32 logs in float32, object after object (np.sum(axis=0) of a C-ordered float32 [N, F] array: a serial chain
+// with up to N/2 ulp of accumulated rounding); here every lane adds its objects' logs in float64, the 64 lanes of a
+// feature are combined by a fixed tree, and the total is rounded to float32 once.  (Round 3, first form: the serial
+// float32 chain itself, 18 us per call at N = 1000 whatever the tiling -- a thousand dependent adds per feature.)
+// Block = 16 features x 64 object lanes; loads unconditional and grouped by level so that they are in flight together.
 // ------------------------------------------------------------------------------------------
-constexpr int kSlfFT = 16, kSlfChunk = 512;
+constexpr int kSlfFT = 16;
 __global__ __launch_bounds__(1024) void k_source_lh_by_feature(
     const uint8_t* __restrict__ state, const uint8_t* __restrict__ src, const uint8_t* __restrict__ pid,
     const float* __restrict__ wpat, float* __restrict__ out, int N, int F, int C, int Fp) {
-    constexpr int OL = 1024 / kSlfFT, PER = kSlfChunk / OL;
-    __shared__ float part[kSlfChunk][kSlfFT];              // 32 KB
+    constexpr int OL = 1024 / kSlfFT, PER = 8;
+    __shared__ double part[OL][kSlfFT];                    // 8 KB
     const int fl = threadIdx.x & (kSlfFT - 1), ol = threadIdx.x / kSlfFT;
     const int f = blockIdx.x * kSlfFT + fl;
-    float acc = 0.0f;                                      // float32, objects in order: np.sum(axis=0) of a float32 array
-    for (int n0 = 0; n0 < N; n0 += kSlfChunk) {
+    const int fc = min(f, F - 1);                          // (clamped: every load below is unconditional)
+    double acc = 0.0;
+    for (int n0 = 0; n0 < N; n0 += OL * PER) {
         float w[PER];
+        uint8_t x[PER], sc[PER], pp[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int n = min(n0 + ol + OL * j, N - 1);
+            x[j] = state[(int64_t)n * Fp + fc];
+            sc[j] = src[(int64_t)n * Fp + fc];
+            pp[j] = pid[n];
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) w[j] = wpat[((int64_t)pp[j] * F + fc) * C + min((int)sc[j], C - 1)];
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const int n = n0 + ol + OL * j;
-            w[j] = 1.0f;                                   // NA: p = 1, log p = 0
-            if (n < N && f < F && state[(int64_t)n * Fp + f] != kNA) {
-                const uint8_t c = src[(int64_t)n * Fp + f];
-                w[j] = c < C ? wpat[((int64_t)pid[n] * F + f) * C + c] : 0.0f;
-            }
+            if (!(n < N && f < F) || x[j] == kNA) w[j] = 1.0f;          // NA (and padding): p = 1, log p = 0
+            else if (sc[j] >= C) w[j] = 0.0f;                           // no source component set: log 0 = -inf
+            acc += (double)logf(w[j]);
         }
-#pragma unroll
-        for (int j = 0; j < PER; ++j) part[ol + OL * j][fl] = logf(w[j]);
-        __syncthreads();
-        if (ol == 0) {
-            const int m = min(kSlfChunk, N - n0);
-            int k = 0;
-            float v[8], nx[8];                             // the next eight values are on their way while these are added
-            if (m >= 8) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = part[u][fl];
-            }
-            for (; k + 8 <= m; k += 8) {
-                if (k + 16 <= m) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) nx[u] = part[k + 8 + u][fl];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc = acc + v[u];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = nx[u];
-            }
-            for (; k < m; ++k) acc = acc + part[k][fl];
-        }
+    }
+    part[ol][fl] = acc;
+    __syncthreads();
+    for (int half = OL / 2; half > 0; half >>= 1) {        // fixed tree over the object lanes
+        if (ol < half) part[ol][fl] += part[ol + half][fl];
         __syncthreads();
     }
-    if (ol == 0 && f < F) out[f] = acc;
+    if (ol == 0 && f < F) out[f] = (float)part[0][fl];
 }
 
 // ==========================================================================================
@@ -2993,14 +2986,31 @@ __global__ __launch_bounds__(kBlock) void k_counts_delta(
     const int f = f0 + fl;
     const int gg = touched[t], c = touched_comp[t];
     if (f < F) {
-#pragma unroll 2
-        for (int i = ol; i < n; i += OL) {
-            const bool in_new = gid_new[(int64_t)c * n + i] == gg, in_old = gid_old[(int64_t)c * n + i] == gg;
-            if (!in_new && !in_old) continue;                       // the object is in another group of this component
-            const uint8_t x = state[(int64_t)objects[i] * Fp + f];
-            if (x == kNA) continue;
-            const int d = (int)(in_new && src_new[(int64_t)i * F + f] == c) - (int)(in_old && src_old[(int64_t)i * F + f] == c);
-            if (d) atomicAdd(&hist[fl * S + x], d);
+        for (int i0 = ol; i0 < n; i0 += 4 * OL) {                   // four objects per lane and step: their loads overlap
+            bool in_new[4], in_old[4];
+            int obj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = min(i0 + j * OL, n - 1);
+                const bool live = i0 + j * OL < n;
+                in_new[j] = live && gid_new[(int64_t)c * n + i] == gg;
+                in_old[j] = live && gid_old[(int64_t)c * n + i] == gg;
+                obj[j] = objects[i];
+            }
+            uint8_t x[4], sn[4], so[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = min(i0 + j * OL, n - 1);
+                x[j] = state[(int64_t)obj[j] * Fp + f];
+                sn[j] = src_new[(int64_t)i * F + f];
+                so[j] = src_old[(int64_t)i * F + f];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (x[j] == kNA) continue;
+                const int d = (int)(in_new[j] && sn[j] == c) - (int)(in_old[j] && so[j] == c);
+                if (d) atomicAdd(&hist[fl * S + x[j]], d);
+            }
         }
     }
     __syncthreads();
@@ -3032,44 +3042,54 @@ constexpr int kUnchangedBlock = 1024;
 __global__ __launch_bounds__(kUnchangedBlock) void k_unchanged_counts(
     const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid /* slot's [C][Np] */,
     const uint8_t* __restrict__ src /* slot's [N][Fp] */, const int32_t* __restrict__ counts /* slot's [Gtot][F][S] */,
-    const uint8_t* __restrict__ in_subset /* [N] */, const int32_t* __restrict__ objects, int n_sub,
+    const int32_t* __restrict__ objects /* [n_sub]; may be host-mapped: read ONCE per block */, int n_sub,
     const int32_t* __restrict__ comp_of_group /* [Gtot] */, int i_cluster, int K, int N, int Np, int F, int S, int Fp,
     const double* __restrict__ conc /* [Gtot][F][S] */, const double* __restrict__ unif /* [F][S] */, double temperature,
     double prior_temperature, int* __restrict__ status, float* __restrict__ out /* [1 + Gtot - K][F][S] probability tables */) {
     // 16 features x 64 object lanes: row 0 walks ALL objects (the cluster's members are found by id), so the object
     // axis gets the lanes; a wave reads four 16-byte runs of four state rows per step
+    // The subset's object list lives in host-mapped memory: the block copies it into LDS with one coalesced pass (a
+    // walk over it in place would pay a PCIe round trip per step) and, for row 0, turns it into a bitmap over all objects.
     constexpr int FTU = 16, OL = kUnchangedBlock / FTU;
-    extern __shared__ int32_t hist[];
+    extern __shared__ int32_t hist[];                                   // [16][S] | object list [n_sub] | bitmap [(N + 31) / 32]
+    int32_t* sub = hist + FTU * S;
+    uint32_t* in_subset = reinterpret_cast<uint32_t*>(sub + n_sub);
     const int r = blockIdx.x, f0 = blockIdx.y * FTU;
     for (int i = threadIdx.x; i < FTU * S; i += kUnchangedBlock) hist[i] = 0;
+    for (int i = threadIdx.x; i < n_sub; i += kUnchangedBlock) sub[i] = objects[i];
+    if (r == 0) for (int i = threadIdx.x; i < (N + 31) / 32; i += kUnchangedBlock) in_subset[i] = 0u;
     __syncthreads();
+    if (r == 0) {
+        for (int i = threadIdx.x; i < n_sub; i += kUnchangedBlock) atomicOr(&in_subset[sub[i] >> 5], 1u << (sub[i] & 31));
+        __syncthreads();
+    }
     const int fl = threadIdx.x & (FTU - 1), ol = threadIdx.x / FTU;
     const int f = f0 + fl;
     if (f < F) {
         if (r == 0) {
             const uint16_t want = (uint16_t)i_cluster;                  // component 0: global index = cluster index
-            for (int n = ol; n < N; n += 4 * OL) {                      // four objects per lane and step: their loads overlap
-                bool take[4];
-                uint8_t x[4], sc[4];
+            for (int n = ol; n < N; n += 8 * OL) {                      // eight objects per lane and step: their loads overlap
+                bool take[8];
+                uint8_t x[8], sc[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 8; ++j) {
                     const int nn = n + j * OL;
-                    take[j] = nn < N && gid[nn] == want && !in_subset[nn];
+                    take[j] = nn < N && gid[nn] == want && !((in_subset[nn >> 5] >> (nn & 31)) & 1u);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 8; ++j) {
                     const int64_t at = (int64_t)(n + j * OL) * Fp + f;
                     x[j] = take[j] ? state[at] : kNA;
                     sc[j] = take[j] ? src[at] : kNA;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 8; ++j)
                     if (x[j] != kNA && sc[j] == 0) atomicAdd(&hist[fl * S + x[j]], 1);
             }
         } else {
             const int gg = K + r - 1, c = comp_of_group[gg];
             for (int i = ol; i < n_sub; i += OL) {
-                const int n = objects[i];
+                const int n = sub[i];
                 if (gid[(int64_t)c * Np + n] != (uint16_t)gg) continue;
                 const uint8_t x = state[(int64_t)n * Fp + f];
                 if (x != kNA && src[(int64_t)n * Fp + f] == c) atomicAdd(&hist[fl * S + x], -1);
