@@ -35,7 +35,10 @@ def _c(a, dtype):
 
 
 def _ptr(a):
-    return a.ctypes.data_as(ct.c_void_p)
+    # the buffer address as a plain int (every array argument of the ABI is declared c_void_p, which takes one):
+    # ndarray.ctypes.data_as builds two helper objects per call, 2 us apiece on the hosts measured -- with three to
+    # seven array arguments that was a quarter of a latency-bound call
+    return a.__array_interface__["data"][0]
 
 
 def device_count() -> int:
@@ -90,11 +93,11 @@ class Engine:
     # sampler_replay in bench.py reports them per MCMC step (SURVEY.md 8(b) "What crosses PCIe per step").
     def _i(self, a):
         self.h2d_bytes += a.nbytes
-        return a.ctypes.data_as(ct.c_void_p)
+        return a.__array_interface__["data"][0]          # (_ptr)
 
     def _o(self, a):
         self.d2h_bytes += a.nbytes
-        return a.ctypes.data_as(ct.c_void_p)
+        return a.__array_interface__["data"][0]          # (_ptr)
 
     def traffic(self, reset=False):
         """(bytes handed to the library, bytes written back by it, ABI calls) since creation / the last reset."""

@@ -1,0 +1,152 @@
+"""Both branches of the engine's small-input / small-result plumbing (round 3, second pass over the drop-in path):
+
+  stage()            input read in place out of the mapped ring (<= 64 KB)  |  ordinary upload to scratch
+  upload_segments()  patterns + tuple tables with one scatter launch        |  one upload per array (> 64 KB together)
+  out_target()       result written straight into host-mapped memory        |  device scratch + staging copy
+  collapsed_groups() one launch, F*S terms of a group in LDS                |  k_dcl + k_group_sum_f32 (> 96 KB)
+  normalize_weights  weights read out of the ring (<= 256 rows)             |  out of device memory
+  update_probs       one component                                          |  a set of components (sbe_update_probs_mask)
+
+The suite's fixtures mostly sit on the left-hand side; the shapes here are chosen to take the right-hand one as well.
+Everything is compared with the oracle-backed double on the same state (bit-exact unless stated)."""
+import numpy as np
+import pytest
+
+from oracle import sbayes_oracle as orc
+from sbayes_amd.engine import Engine
+from sbayes_amd.synthetic import make_workload
+from tests._fake_engine import FakeEngine
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    "flat": (24, 20, 4, 2, (), False),                       # everything small: the in-place / mapped branches
+    "wide_tables": (48, 700, 20, 3, (2,), True),             # F*S*8 = 112 KB per group: two-kernel collapsed form; 56 KB rows
+    "long": (30000, 6, 3, 4, (5,), False),                   # 30 000 objects: pattern / tuple arrays > 64 KB, big id lists
+}
+
+
+def _pair(name):
+    wl = make_workload(name, shape=SHAPES[name])
+    counts = orc.recalculate_feature_counts(wl.features, wl.groups, wl.source)
+    n_groups = [g.shape[0] for g in wl.groups]
+    eng, fake = Engine(wl.features, n_groups, n_slots=2), FakeEngine(wl.features, n_groups)
+    for e in (eng, fake):
+        for c in range(len(wl.groups)):
+            e.set_concentration(c, wl.concentration[c])
+            e.set_groups(0, c, wl.groups[c])
+            e.set_counts(0, c, counts[c])
+        e.set_source(0, wl.source)
+        e.set_weights(0, wl.weights)
+        e.set_uniform_counts(wl.states_per_feature.astype(np.float64))
+    return eng, fake, wl, counts
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_collapsed_loglik_both_forms(name):
+    eng, fake, wl, counts = _pair(name)
+    try:
+        want_all = fake.collapsed_loglik_all(0)
+        np.testing.assert_allclose(eng.collapsed_loglik_all(0), want_all, rtol=2e-6, atol=1e-6)
+        for c in range(eng.n_components):
+            per_group, per_feature = eng.collapsed_loglik(0, c, per_feature=True)
+            want_pf = orc.dirichlet_categorical_logpdf(counts[c], wl.concentration[c])
+            np.testing.assert_allclose(per_feature, want_pf, rtol=2e-6, atol=1e-6)
+            # the group value is the float32 NumPy-order sum of the engine's own per-feature row: exact
+            assert np.array_equal(per_group, np.array([row.sum(dtype=np.float32) for row in per_feature], dtype=np.float64))
+            assert np.array_equal(eng.collapsed_loglik(0, c), per_group)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_row_uploads_and_component_sets(name):
+    """set_counts_rows / set_source_rows (in place or through scratch), get_counts / get_source_rows (mapped or copied),
+    update_probs with a set of components: resident state and tables equal the double's, bit for bit."""
+    eng, fake, wl, counts = _pair(name)
+    try:
+        rng = np.random.default_rng(3)
+        N, F, C = wl.source.shape
+        off = eng.group_offsets
+        # new count rows for a few groups of several components, one call
+        idx = np.unique(rng.integers(0, eng.n_groups_total, size=min(4, eng.n_groups_total)))
+        rows = rng.integers(0, 50, size=(idx.size, F, eng.n_states)).astype(np.float32)
+        for e in (eng, fake):
+            e.set_counts_rows(0, idx, rows)
+        # new source rows for a subset (big enough to leave the in-place branch at the long shape)
+        objs = np.sort(rng.choice(N, size=min(N, 12000 if name == "long" else 9), replace=False))
+        pick = rng.integers(0, C, size=(objs.size, F))
+        new_rows = pick[..., None] == np.arange(C)
+        new_rows[~wl.features[objs].any(-1)] = False
+        for e in (eng, fake):
+            e.set_source_rows(0, objs, new_rows)
+        assert np.array_equal(eng.get_source_rows(0, objs), new_rows)
+        for c in range(C):
+            assert np.array_equal(eng.get_counts(0, c), fake._slot(0)["counts"][c])
+        # tables: every component singly on one side, as sets on the other
+        sets = [[0], list(range(1, C))] if C > 1 else [[0]]
+        for s in sets:
+            eng.update_probs(0, s)
+        for c in range(C):
+            want = orc.component_probs(fake._slot(0)["counts"][c], wl.concentration[c])
+            assert np.array_equal(eng.get_probs(0, c), want), c
+        eng.update_probs(0, range(C))
+        for c in range(C):
+            assert np.array_equal(eng.get_probs(0, c), orc.component_probs(fake._slot(0)["counts"][c], wl.concentration[c]))
+        with pytest.raises(ValueError):
+            eng.update_probs(0, [C])
+        # and the fused evaluation sees all of it
+        ll = eng.mixture_loglik(0)
+        want_ll = orc.mixture_loglik(wl.features, ~wl.features.any(-1), wl.groups, fake._slot(0)["counts"], wl.concentration,
+                                     wl.weights)
+        assert abs(ll - want_ll) <= 1e-10 * abs(want_ll)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+@pytest.mark.parametrize("n_rows", [1, 7, 256, 300])
+def test_normalize_weights_row_form(name, n_rows):
+    """normalize_weights(weights, has_components[rows]) (likelihood.py:171-190) in row form, both input branches:
+    bit-exact against the oracle's np.unique form."""
+    eng, fake, wl, _ = _pair(name)
+    try:
+        rng = np.random.default_rng(n_rows)
+        C = eng.n_components
+        hc = rng.random((n_rows, C)) < 0.6
+        hc[:, min(1, C - 1)] = True                                # (the universal confounder: never an all-False row)
+        got = eng.normalize_weights(wl.weights, hc)
+        assert got.dtype == np.float32 and got.shape == (n_rows, eng.n_features, C)
+        assert np.array_equal(got, orc.normalize_weights(wl.weights, hc))
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("name", ["flat", "long"])
+def test_resident_operator_forms_at_both_sizes(name):
+    """source_prior / source_posterior / source_lh_by_feature / given_unchanged_lh with small (mapped) and large (copied)
+    results and subset lists."""
+    eng, fake, wl, _ = _pair(name)
+    try:
+        rng = np.random.default_rng(5)
+        N = wl.source.shape[0]
+        for c in range(eng.n_components):
+            eng.update_probs(0, c)
+        np.testing.assert_allclose(eng.source_prior(0), fake.source_prior(0), rtol=2e-6, atol=1e-6)
+        # the reference adds N float32 logs in float32, one after the other (up to N/2 ulp of accumulated rounding: 2e-4
+        # relative observed at N = 30 000); the device adds them in float64 and rounds once -- so it agrees with the
+        # reference's value within the reference's own rounding bound, and with the exactly summed logs at float32 accuracy
+        got = eng.source_lh_by_feature(0)
+        np.testing.assert_allclose(got, fake.source_lh_by_feature(0), rtol=max(3e-5, N * 2.0 ** -25), atol=1e-5)
+        w = orc.normalize_weights(wl.weights, orc.has_components(wl.groups))
+        p = np.where(~wl.features.any(-1), np.float32(1), (w * wl.source).sum(-1, dtype=np.float32))
+        with np.errstate(divide="ignore"):
+            exact = np.log(p, dtype=np.float32).astype(np.float64).sum(axis=0)
+        np.testing.assert_allclose(got, exact, rtol=2e-6, atol=1e-5)
+        for n in (1, 40, min(N, 9000)):
+            objs = np.sort(rng.choice(N, size=min(n, N), replace=False))
+            assert np.array_equal(eng.source_posterior(0, objs), fake.source_posterior(0, objs)), n
+            got = eng.given_unchanged_lh(0, 1, objs)
+            assert np.array_equal(got, fake.given_unchanged_lh(0, 1, objs)), n
+    finally:
+        eng.close()
