@@ -17,6 +17,13 @@
  *     or current + candidate) are resident at once; every state call names its slot.
  *   - one engine per process per GPU; calls on one engine must be serialised by the caller.
  *     Calls are synchronous unless the name ends in _async.
+ *   - how a synchronous call waits: latency-bound result calls (one eval, the one-call steps, the
+ *     resident operator forms) write their results into host-mapped memory, and the last block of
+ *     the call's final kernel then stores a sequence number into a host-mapped word; the host spins
+ *     on that word for up to 300 us and falls back to the HIP stream wait (long launches, faults).
+ *     Measured 3-4 us per call below hipStreamSynchronize.  Environment SBE_POLL_DONE=0 uses the
+ *     stream wait everywhere (same results: tests/test_gpu_poll_done.py).  A caller thread inside
+ *     such a call therefore busy-waits on one core for the duration of the launch.
  *   - bool arrays are one byte per element (NumPy bool layout), C order.
  */
 #ifndef SBE_ENGINE_H

@@ -112,6 +112,8 @@ struct sbe_engine {
     int* d_status = nullptr;       // [ST_WORDS]
     int* h_status = nullptr;       // pinned
     int* h_flag = nullptr;  int* d_flag = nullptr;   // host-mapped [ST_WORDS]: "a kernel raised this word" (raise_status)
+    unsigned long long* h_done = nullptr;  unsigned long long* d_done = nullptr;   // host-mapped: sequence number of the last call
+    unsigned* d_ticket = nullptr;  unsigned long long done_seq = 0;                // finished by flag (signal_done / wait_done)
     uint8_t* d_changed = nullptr;  // [Gtot]
     uint32_t* d_step_stamp = nullptr;  uint32_t step_id = 0;   // [Gtot] group changed in step `step_id` (k_step_core)
     float* d_step_pf = nullptr;    // [Gtot][F]  per-feature collapsed log-pdf of the fused step call
@@ -298,9 +300,16 @@ int out_target(sbe_engine* e, size_t bytes, void* dev_fallback, void** target) {
     *target = e->d_io;
     return SBE_OK;
 }
-int out_fetch(sbe_engine* e, void* host_out, const void* target, size_t bytes) {
+int wait_done(sbe_engine* e, const DoneSig& d);
+DoneSig next_done(sbe_engine* e, unsigned n_blocks);
+// (`done`: the descriptor the result kernel was launched with -- out_done() -- when the result is in mapped memory)
+DoneSig out_done(sbe_engine* e, const void* target, unsigned n_blocks) {
+    return target == (const void*)e->d_io ? next_done(e, n_blocks) : DoneSig{};
+}
+int out_fetch(sbe_engine* e, void* host_out, const void* target, size_t bytes, const DoneSig& done = DoneSig{}) {
     if (target != (const void*)e->d_io) return d2h(e, host_out, target, bytes);
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    int rc = wait_done(e, done);
+    if (rc) return rc;
     memcpy(host_out, e->h_io, bytes);
     return synced(e);
 }
@@ -380,6 +389,33 @@ int upload_segments(sbe_engine* e, const UploadSeg* segs, int n) {
     return SBE_OK;
 }
 
+// Completion by flag (signal_done in the kernels): the call's last kernel carries next_done()'s descriptor, the host
+// spins on the mapped word in wait_done() -- a few hundred microseconds at most, then the runtime's wait (a long launch, or
+// a fault, which that wait reports).  After wait_done() the results in host-mapped memory are complete and every earlier
+// operation of the in-order stream has finished; what may still be pending is the kernel's own retirement.
+// SBE_POLL_DONE=0 switches the mechanism off (every wait is hipStreamSynchronize: A/B and fallback).
+bool poll_done_enabled() {
+    static const bool on = [] { const char* v = getenv("SBE_POLL_DONE"); return !(v && atoi(v) == 0); }();
+    return on;
+}
+DoneSig next_done(sbe_engine* e, unsigned n_blocks) {
+    if (!poll_done_enabled()) return DoneSig{};
+    return DoneSig{e->d_ticket, e->d_done, ++e->done_seq, n_blocks};
+}
+int wait_done(sbe_engine* e, const DoneSig& d) {
+    if (d.flag) {
+        const volatile unsigned long long* f = e->h_done;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 1;; ++spins) {
+            if (*f == d.seq) { std::atomic_thread_fence(std::memory_order_acquire); return SBE_OK; }
+            __builtin_ia32_pause();
+            if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+        }
+    }
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return SBE_OK;
+}
+
 // The device words hold the counts; the host-mapped flag words (raise_status) say whether anything was raised, so a
 // clean call costs no read-back.  Flags are read after a stream synchronisation (kernel stores are visible then).
 bool status_raised(const sbe_engine* e) {
@@ -429,6 +465,13 @@ int read_status(sbe_engine* e) {
     HIPCHK(e, hipStreamSynchronize(e->stream));
     int rc = synced(e);
     if (rc) return rc;
+    e->h_status[ST_BAD_NORMALIZE] = e->h_status[ST_MULTI_SOURCE] = 0;
+    if (status_raised(e)) return fetch_and_clear_status(e);
+    return SBE_OK;
+}
+
+// read_status for a call that has already waited (wait_done / out_fetch): this call's counts into h_status.
+int take_status(sbe_engine* e) {
     e->h_status[ST_BAD_NORMALIZE] = e->h_status[ST_MULTI_SOURCE] = 0;
     if (status_raised(e)) return fetch_and_clear_status(e);
     return SBE_OK;
@@ -777,7 +820,7 @@ void launch_rows(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipS
 // list, device-visible); then `d_fins` holds one step epilogue per listed slot.
 int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev_a, hipEvent_t ev_b,
                    const StepFinish* fin = nullptr, const int32_t* slots = nullptr, const int32_t* d_slots = nullptr,
-                   const StepFinish* d_fins = nullptr) {
+                   const StepFinish* d_fins = nullptr, DoneSig* done_out = nullptr) {
     auto slot_at = [&](int i) { return slots ? (int)slots[i] : first_slot + i; };
     int P = 1;
     for (int i = 0; i < n; ++i) P = std::max<int>(P, (int)e->slots[slot_at(i)].patterns.size());
@@ -974,14 +1017,17 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     }
     if (ev_b) HIPCHK(e, hipEventRecord(ev_b, e->stream));
     HIPCHK(e, hipGetLastError());
-    k_reduce_partials<<<n + (d_fins ? n : (fin ? 1 : 0)), kBlock, 0, e->stream>>>(e->d_partials, e->partials_stride, g.n_blocks,
-                                                                  e->d_results, first_slot, n, fin ? *fin : StepFinish{},
-                                                                  d_slots, d_fins);
+    const unsigned n_red = (unsigned)(n + (d_fins ? n : (fin ? 1 : 0)));
+    const DoneSig done = done_out ? next_done(e, n_red) : DoneSig{};      // (the caller waits with wait_done)
+    if (done_out) *done_out = done;
+    k_reduce_partials<<<n_red, kBlock, 0, e->stream>>>(e->d_partials, e->partials_stride, g.n_blocks,
+                                                       e->d_results, first_slot, n, fin ? *fin : StepFinish{},
+                                                       d_slots, d_fins, done);
     HIPCHK(e, hipGetLastError());
     return SBE_OK;
 }
 
-int enqueue_mixture(sbe_engine* e, int first_slot, int n, int mode) {
+int enqueue_mixture(sbe_engine* e, int first_slot, int n, int mode, DoneSig* done_out = nullptr) {
     for (int s = first_slot; s < first_slot + n; ++s) {
         int rc = check_slot_ready(e, s, true);
         if (rc) return rc;
@@ -997,7 +1043,7 @@ int enqueue_mixture(sbe_engine* e, int first_slot, int n, int mode) {
         ev_a = e->ev_pool[2 * e->ev_used]; ev_b = e->ev_pool[2 * e->ev_used + 1];
         ++e->ev_used;
     }
-    return launch_mixture(e, first_slot, n, mode, ev_a, ev_b);
+    return launch_mixture(e, first_slot, n, mode, ev_a, ev_b, nullptr, nullptr, nullptr, nullptr, done_out);
 }
 
 int counts_launch(sbe_engine* e, int slot_a, int sign_a, int slot_b, int sign_b, const int32_t* d_objects,
@@ -1072,6 +1118,8 @@ int sbe_destroy(sbe_engine* e) {
     if (e->h_results) (void)hipHostFree(e->h_results);
     if (e->h_status) (void)hipHostFree(e->h_status);
     if (e->h_flag) (void)hipHostFree(e->h_flag);
+    if (e->h_done) (void)hipHostFree(e->h_done);
+    if (e->d_ticket) (void)hipFree(e->d_ticket);
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     if (e->h_arena) (void)hipHostFree(e->h_arena);
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
@@ -1281,6 +1329,11 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_CHK(hipHostMalloc((void**)&e->h_flag, ST_WORDS * sizeof(int), hipHostMallocMapped));
     CREATE_CHK(hipHostGetDevicePointer((void**)&e->d_flag, e->h_flag, 0));
     memset(e->h_flag, 0, ST_WORDS * sizeof(int));
+    CREATE_CHK(hipHostMalloc((void**)&e->h_done, 64, hipHostMallocMapped));
+    CREATE_CHK(hipHostGetDevicePointer((void**)&e->d_done, e->h_done, 0));
+    memset(e->h_done, 0, 64);
+    CREATE_CHK(hipMalloc((void**)&e->d_ticket, 64));
+    CREATE_CHK(hipMemsetAsync(e->d_ticket, 0, 64, e->stream));
     e->arena_bytes = (size_t)16 << 20;
     CREATE_CHK(hipHostMalloc((void**)&e->h_arena, e->arena_bytes, hipHostMallocMapped));
     CREATE_CHK(hipHostGetDevicePointer((void**)&e->d_arena, e->h_arena, 0));
@@ -1810,10 +1863,16 @@ int sbe_fetch_results(sbe_engine* e, int first_slot, int n, double* out) {
 }
 
 int sbe_mixture_loglik_batch(sbe_engine* e, int first_slot, int n, double* out) {
-    CHECK_ENGINE(e); CHECK_PTR(e, out);
-    int rc = sbe_mixture_loglik_batch_async(e, first_slot, n);
+    CHECK_ENGINE(e); CHECK_SLOT(e, first_slot); CHECK_PTR(e, out);
+    if (n < 1 || first_slot + n > e->n_slots) return fail(e, SBE_ERR_ARG, "slot range out of range");
+    HIPCHK(e, hipSetDevice(e->device));
+    DoneSig done;
+    int rc = enqueue_mixture(e, first_slot, n, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, &done);
     if (rc) return rc;
-    return sbe_fetch_results(e, first_slot, n, out);
+    rc = wait_done(e, done);                        // results were written straight into mapped host memory
+    if (rc) return rc;
+    memcpy(out, e->h_results + first_slot, (size_t)n * sizeof(double));
+    return synced(e);
 }
 
 int sbe_mixture_loglik(sbe_engine* e, int slot, double* out) { return sbe_mixture_loglik_batch(e, slot, 1, out); }
@@ -1828,9 +1887,13 @@ static int collapsed_groups(sbe_engine* e, int slot, int g_lo, int G, float* d_p
     const int32_t* counts = e->d_counts + (int64_t)slot * e->table_elems();
     const size_t lds = (size_t)e->F * e->S * sizeof(double) + (size_t)e->F * sizeof(float);
     if (lds <= ((size_t)96 << 10)) {
+        const DoneSig done = next_done(e, (unsigned)G);
         k_collapsed_groups<int32_t><<<G, 1024, lds, e->stream>>>(counts, e->d_conc, e->d_lg_conc, e->d_sum_a, e->d_lg_sum_a, d_pf,
-                                                                  (double*)e->d_io, g_lo, e->F, e->S);
+                                                                  (double*)e->d_io, g_lo, e->F, e->S, done);
         HIPCHK(e, hipGetLastError());
+        rc = wait_done(e, done);
+        if (rc) return rc;
+        return synced(e);
     } else {
         float* pf = d_pf;
         if (!pf) {
@@ -2031,10 +2094,11 @@ int sbe_normalize_weights(sbe_engine* e, const float* weights, int n_comp, const
     void* d_out;
     rc = out_target(e, (size_t)n_out * sizeof(float), e->d_scratch + wb + hb, &d_out);
     if (rc) return rc;
+    const DoneSig done = out_done(e, d_out, (unsigned)div_up(N, kNwRows));
     k_normalize_weight_rows<<<div_up(N, kNwRows), 256, (size_t)F * C * sizeof(float), e->stream>>>(
-        (const float*)v_w, (const uint8_t*)v_hc, (float*)d_out, N, F, C);
+        (const float*)v_w, (const uint8_t*)v_hc, (float*)d_out, N, F, C, done);
     HIPCHK(e, hipGetLastError());
-    return out_fetch(e, out, d_out, (size_t)n_out * sizeof(float));
+    return out_fetch(e, out, d_out, (size_t)n_out * sizeof(float), done);
 }
 
 // ---- cluster-membership marginals ---------------------------------------------
@@ -2130,11 +2194,13 @@ int sbe_source_lh_by_feature(sbe_engine* e, int slot, float* out) {
     if (s.patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
     rc = ensure_io(e, (size_t)e->F * sizeof(float));
     if (rc) return rc;
+    const DoneSig done = next_done(e, (unsigned)div_up(e->F, kSlfFT));
     k_source_lh_by_feature<<<div_up(e->F, kSlfFT), 1024, 0, e->stream>>>(
         e->d_state, e->d_src + (int64_t)slot * e->N * e->Fp, e->d_pid + (int64_t)slot * e->Np,
-        e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, (float*)e->d_io, e->N, e->F, e->C, e->Fp);
+        e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, (float*)e->d_io, e->N, e->F, e->C, e->Fp, done);
     HIPCHK(e, hipGetLastError());
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    rc = wait_done(e, done);
+    if (rc) return rc;
     memcpy(out, e->h_io, (size_t)e->F * sizeof(float));
     return synced(e);
 }
@@ -2173,8 +2239,8 @@ int source_posterior_setup(sbe_engine* e, int slot, const int32_t* objects, int 
     return SBE_OK;
 }
 
-int source_posterior_status(sbe_engine* e) {
-    int rc = read_status(e);
+int source_posterior_status(sbe_engine* e, bool waited = false) {
+    int rc = waited ? take_status(e) : read_status(e);
     if (rc) return rc;
     if (e->h_status[ST_BAD_NORMALIZE])
         return fail(e, SBE_ERR_DATA, "normalize: %d observations have a non-positive posterior sum (sbayes/util.py:1006 assert)", e->h_status[ST_BAD_NORMALIZE]);
@@ -2206,11 +2272,13 @@ int sbe_source_posterior(sbe_engine* e, int slot, const int32_t* objects, int n_
     void* d_out;
     rc = out_target(e, (size_t)n_out * sizeof(float), d_extra, &d_out);
     if (rc) return rc;
-    k_source_posterior<<<div_up((int64_t)n_sub * e->F, 256), 256, 0, e->stream>>>(a, (float*)d_out, e->d_status);
+    const unsigned nb = (unsigned)div_up((int64_t)n_sub * e->F, 256);
+    const DoneSig done = out_done(e, d_out, nb);
+    k_source_posterior<<<nb, 256, 0, e->stream>>>(a, (float*)d_out, e->d_status, done);
     HIPCHK(e, hipGetLastError());
-    rc = out_fetch(e, out, d_out, (size_t)n_out * sizeof(float));
+    rc = out_fetch(e, out, d_out, (size_t)n_out * sizeof(float), done);
     if (rc) return rc;
-    return source_posterior_status(e);
+    return source_posterior_status(e, /*waited=*/true);
 }
 
 int sbe_sample_source(sbe_engine* e, int slot, int dst_slot, const int32_t* objects, int n_sub, double temperature,
@@ -2328,8 +2396,8 @@ int sbe_subset_lh(sbe_engine* e, const int32_t* objects, int n_sub, int n_comp, 
 namespace {
 
 // the call's final synchronisation, then the data checks its kernels may have raised (flag words: no read-back)
-int sync_and_report(sbe_engine* e) {
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+int sync_and_report(sbe_engine* e, const DoneSig& done = DoneSig{}) {
+    { int rc = wait_done(e, done); if (rc) return rc; }          // (no flag asked for: the runtime's stream wait)
     e->status_pending = false;
     return report_status(e);
 }
@@ -2400,12 +2468,14 @@ int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const 
     HIPCHK(e, hipMemcpyAsync(e->d_scratch, h, in_bytes, hipMemcpyHostToDevice, e->stream));
     const uint8_t* din = e->d_scratch;
     float* d_out = mapped_out ? (float*)(e->d_io + o) : (float*)(e->d_scratch + in_bytes);
+    const DoneSig done = mapped_out ? next_done(e, (unsigned)(n_touched * div_up(F, kDeltaFT))) : DoneSig{};
     k_counts_delta<<<dim3(n_touched, div_up(F, kDeltaFT)), kBlock, (size_t)kDeltaFT * S * sizeof(int32_t), e->stream>>>(
         e->d_state, (const int32_t*)(din + o_obj), n_subset, (const int32_t*)(din + o_go), (const int32_t*)(din + o_gn),
-        din + o_so, din + o_sn, (const int32_t*)(din + o_t), (const int32_t*)(din + o_tc), d_out, F, S, e->Fp);
+        din + o_so, din + o_sn, (const int32_t*)(din + o_t), (const int32_t*)(din + o_tc), d_out, F, S, e->Fp, done);
     HIPCHK(e, hipGetLastError());
     if (!mapped_out) return d2h(e, out_diff, d_out, out_bytes);
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    rc = wait_done(e, done);
+    if (rc) return rc;
     memcpy(out_diff, h + o, out_bytes);
     return synced(e);
 }
@@ -2488,16 +2558,17 @@ int sbe_given_unchanged_lh(sbe_engine* e, int slot, int i_cluster, const int32_t
         i_cluster, K, N, e->Np, F, S, e->Fp, e->d_conc, e->d_unif_res, temperature, prior_temperature, e->d_status, d_tab);
     HIPCHK(e, hipGetLastError());
     const double inv_t = 1.0 / temperature;
+    const DoneSig done = mapped_out ? next_done(e, (unsigned)div_up((int64_t)n_sub * F, 256)) : DoneSig{};
     k_subset_lh<<<div_up((int64_t)n_sub * F, 256), 256, 0, e->stream>>>(
         e->d_state, d_tab, (const int32_t*)(e->d_io + ob + mb + gb), (const int32_t*)(e->d_io + ob + mb), (const int32_t*)e->d_io,
-        n_sub, d_out, F, S, C, e->Fp, (float)inv_t, inv_t != 1.0);
+        n_sub, d_out, F, S, C, e->Fp, (float)inv_t, inv_t != 1.0, done);
     HIPCHK(e, hipGetLastError());
     if (!mapped_out) {
         rc = d2h(e, out, d_out, out_bytes);
         if (rc) return rc;
         return report_status(e);                    // (d2h synchronised)
     }
-    rc = sync_and_report(e);
+    rc = sync_and_report(e, done);
     if (rc) return rc;
     memcpy(out, h + ob + mb + gb + fb, out_bytes);
     return SBE_OK;
@@ -2539,13 +2610,14 @@ int sbe_cluster_posterior_marginals(sbe_engine* e, int slot, int i_cluster, doub
         temperature, prior_temperature, 1, e->d_status, -(int64_t)i_cluster * fs);
     HIPCHK(e, hipGetLastError());
     const double inv = 1.0 / prior_temperature;
+    const DoneSig done = next_done(e, (unsigned)n_objects_av);
     k_cluster_marginals<<<n_objects_av, kBlock, 0, e->stream>>>(
         e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np,
         e->d_probs + (int64_t)slot * e->table_elems(), d_tab, e->d_weights + (int64_t)slot * F * C,
         e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0, (const int32_t*)e->d_io, n_objects_av,
-        (double*)(e->d_io + ob), reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C, e->Fp);
+        (double*)(e->d_io + ob), reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C, e->Fp, done);
     HIPCHK(e, hipGetLastError());
-    rc = sync_and_report(e);
+    rc = sync_and_report(e, done);
     if (rc) return rc;
     memcpy(out, e->h_io + ob, out_bytes);
     return SBE_OK;
@@ -2599,13 +2671,14 @@ int sbe_jump_lh_resident(sbe_engine* e, int slot, int i_source, int i_target, do
         HIPCHK(e, hipGetLastError());
     }
     const double inv = 1.0 / prior_temperature;
+    const DoneSig done = next_done(e, (unsigned)n_members);
     k_jump_lh<<<n_members, kBlock, 0, e->stream>>>(
         e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np, d_pc, d_ps, d_pt,
         e->d_weights + (int64_t)slot * F * C, e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0,
         (const int32_t*)e->d_io, n_members, (double*)(e->d_io + ob), reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C,
-        e->Fp, K);
+        e->Fp, K, done);
     HIPCHK(e, hipGetLastError());
-    rc = sync_and_report(e);
+    rc = sync_and_report(e, done);
     if (rc) return rc;
     memcpy(out, e->h_io + ob, out_bytes);
     return SBE_OK;
@@ -2624,11 +2697,13 @@ int sbe_source_prior(sbe_engine* e, int slot, double* per_object_out) {
     void* d_out;
     rc = out_target(e, (size_t)e->N * sizeof(double), e->d_scratch, &d_out);
     if (rc) return rc;
-    k_source_prior<<<div_up(e->N, kBlock / kWave), kBlock, 0, e->stream>>>(
+    const unsigned nb = (unsigned)div_up(e->N, kBlock / kWave);
+    const DoneSig done = out_done(e, d_out, nb);
+    k_source_prior<<<nb, kBlock, 0, e->stream>>>(
         e->d_state, e->d_src + (int64_t)slot * e->N * e->Fp, e->d_pid + (int64_t)slot * e->Np,
-        e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, (double*)d_out, e->N, e->F, e->C, e->Fp);
+        e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, (double*)d_out, e->N, e->F, e->C, e->Fp, done);
     HIPCHK(e, hipGetLastError());
-    return out_fetch(e, per_object_out, d_out, (size_t)e->N * sizeof(double));
+    return out_fetch(e, per_object_out, d_out, (size_t)e->N * sizeof(double), done);
 }
 
 int sbe_observation_lh_exact(sbe_engine* e, int slot, double* out) {
@@ -3042,10 +3117,13 @@ static int step_lean(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* 
     e->slots[cand_slot] = cd;
     // ---- kernels 2 + 3: fused mixture eval, reduction + step epilogue (mapped-memory results) -------------------
     StepFinish fin = make_step_finish(e);
-    rc = launch_mixture(e, cand_slot, 1, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, &fin);
+    DoneSig done;
+    rc = launch_mixture(e, cand_slot, 1, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, &fin, nullptr, nullptr,
+                        nullptr, &done);
     if (rc) return rc;
     const auto t2 = std::chrono::steady_clock::now();
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    rc = wait_done(e, done);
+    if (rc) return rc;
     if (timing) {
         const auto t3 = std::chrono::steady_clock::now();
         t_acc[0] += std::chrono::duration<double, std::micro>(t1 - t0).count();
@@ -3192,6 +3270,7 @@ int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const 
     std::vector<uint8_t> meta(meta_bytes);
     std::vector<int> rcs(n_chains, SBE_OK);
     std::vector<std::string> errs(n_chains);
+    DoneSig batch_done{};
     for (int part = 0; part < n_parts; ++part) {
         const int i0 = part * per_part, i1 = std::min(n_chains, i0 + per_part), np = i1 - i0;
         if (np <= 0) break;
@@ -3262,11 +3341,11 @@ int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const 
         if (part == 0) mark();
         rc = launch_mixture(e, 0, np, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, nullptr,
                             cand_slots + i0, reinterpret_cast<const int32_t*>(dm + part_cores + part_fins),
-                            reinterpret_cast<const StepFinish*>(dm + part_cores));
+                            reinterpret_cast<const StepFinish*>(dm + part_cores), part == n_parts - 1 ? &batch_done : nullptr);
         if (rc) return rc;
     }
     mark();
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    { int wrc = wait_done(e, batch_done); if (wrc) return wrc; }       // (the last part's reduction carries the flag)
     mark();
     // every chain's results are delivered; a chain whose proposal was malformed (its own data-check words) is reported
     // by index after that -- the other chains' outputs stay usable
@@ -3588,6 +3667,7 @@ int sbe_step_batch_delta(sbe_engine* e, int n_chains, const int32_t* cur_slots, 
     std::vector<int> go, late;                             // patched chains that stay on the fast path / that turned out not to
     for (int i : fast) { if (fb[i]) { late.push_back(i); bump_ids(e, cand_slots[i]); } else go.push_back(i); }
     const int ng = (int)go.size();
+    DoneSig fast_done{};
     if (ng > 0) {
         uint8_t* pm = e->h_batch_payload + meta_off;
         uint8_t* dm = e->d_batch_payload + meta_off;
@@ -3611,7 +3691,7 @@ int sbe_step_batch_delta(sbe_engine* e, int n_chains, const int32_t* cur_slots, 
         markd();                                 // 3: step cores built, uploaded, launched
         rc = launch_mixture(e, 0, ng, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, nullptr,
                             cand_go.data(), reinterpret_cast<const int32_t*>(dm + part_cores + part_fins),
-                            reinterpret_cast<const StepFinish*>(dm + part_cores));
+                            reinterpret_cast<const StepFinish*>(dm + part_cores), &fast_done);
         for (int j = 0; j < ng; ++j) {           // (bookkeeping under the device work: everything is enqueued)
             const int i = go[j];
             commit_src_sync(e, cur_slots[i], cand_slots[i], changed_objects ? changed_objects + rows_ptr[i] : nullptr, rows_ptr[i + 1] - rows_ptr[i]);
@@ -3621,7 +3701,7 @@ int sbe_step_batch_delta(sbe_engine* e, int n_chains, const int32_t* cur_slots, 
     }
     static const bool timing_d = getenv("SBE_STEP_TIMING") && atoi(getenv("SBE_STEP_TIMING")) != 0;
     const auto t_enq = std::chrono::steady_clock::now();
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    { int wrc = wait_done(e, fast_done); if (wrc) return wrc; }        // (no patched chain: nothing was launched, plain wait)
     if (timing_d) {
         const auto t_done = std::chrono::steady_clock::now();
         auto us = [&](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
@@ -3704,9 +3784,12 @@ int sbe_step_delta(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* mo
     commit_src_sync(e, cur_slot, cand_slot, changed_objects, n_changed);
     commit_ids_sync(e, cur_slot, cand_slot, e->step_moved);
     StepFinish fin = make_step_finish(e);
-    rc = launch_mixture(e, cand_slot, 1, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, &fin);
+    DoneSig done;
+    rc = launch_mixture(e, cand_slot, 1, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, &fin, nullptr, nullptr,
+                        nullptr, &done);
     if (rc) return rc;
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    rc = wait_done(e, done);
+    if (rc) return rc;
     return read_step_results(e, cand_slot, group_logliks_out, mixture_out, changed_groups_out, "rows");
 }
 
@@ -3807,9 +3890,12 @@ int sbe_gibbs_step(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* ob
     StepFinish fin = make_step_finish(e);
     fin.lq_partials[0] = d_part_f; fin.lq_partials[1] = d_part_b; fin.lq_n[0] = fin.lq_n[1] = nblk;
     fin.lq_out = reinterpret_cast<double*>(e->d_step_host + step_host_lq_offset(e));
-    rc = launch_mixture(e, cand_slot, 1, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, &fin);
+    DoneSig done;
+    rc = launch_mixture(e, cand_slot, 1, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, &fin, nullptr, nullptr,
+                        nullptr, &done);
     if (rc) return rc;
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    rc = wait_done(e, done);
+    if (rc) return rc;
     rc = read_step_results(e, cand_slot, group_logliks_out, mixture_out, changed_groups_out, "posterior rows / table rows");
     if (rc) return rc;
     const double* lq = reinterpret_cast<const double*>(e->h_step + step_host_lq_offset(e));

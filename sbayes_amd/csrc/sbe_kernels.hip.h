@@ -42,6 +42,33 @@ __device__ __forceinline__ void raise_status(int* status, int word, int count) {
     if (flag) __hip_atomic_store(flag + word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Completion by flag (latency-bound calls): the LAST block of a call's final kernel stores the call's sequence number
+// into a host-mapped word once every block's results are on their way, so the host can spin on its own memory instead of
+// going through the runtime's stream wait.  Every block calls signal_done() as its last action, all threads of the block
+// together.  `flag` == nullptr: no signalling asked for.
+// Ordering.  Every wave waits until its own stores are acknowledged (s_waitcnt vmcnt(0): on gfx9 stores count in vmcnt;
+// the acknowledgement comes from the XCD's L2), then ONE thread of the block issues a system-scope release fence -- it
+// pushes that L2's pending writes out to the fabric and waits for them -- before the block takes its ticket (a device-wide
+// atomic).  When the last ticket is taken every block's results are therefore globally visible, and the flag follows.
+// Two cheaper forms were measured and dropped: a system-scope fence in EVERY thread (+15 us on a 64-chain sweep whose
+// step cores had just dirtied megabytes of L2: 32 k fences), and no fence at all, relying on the store acknowledgement
+// alone -- the flag then overtook a result written by the same thread (tests/test_gpu_c_abi.py caught it at once).
+struct DoneSig { unsigned* ticket; unsigned long long* flag; unsigned long long seq; unsigned n_blocks; };
+__device__ __forceinline__ void signal_done(const DoneSig& d) {
+    if (!d.flag) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's result stores are acknowledged by the L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");       // system scope: the L2's pending writes are out and confirmed
+        const unsigned t = __hip_atomic_fetch_add(d.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == d.n_blocks - 1) {                          // every other block fenced before its ticket
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (pairs with their release fences through the ticket chain)
+            __hip_atomic_store(d.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d.flag, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // NumPy reduction order (pairwise sum, PW_BLOCKSIZE = 128, 8-way unrolled block).
 // `get(i)` returns element i as T.  Matches @TYPE@_pairwise_sum for any n.
@@ -641,7 +668,7 @@ __global__ void k_weight_patterns(const float* __restrict__ weights /* [F][C] */
 constexpr int kNwRows = 8;
 __global__ void k_normalize_weight_rows(const float* __restrict__ weights /* [F][C] */,
                                         const uint8_t* __restrict__ has_components /* [N][C] */,
-                                        float* __restrict__ out /* [N][F][C] */, int N, int F, int C) {
+                                        float* __restrict__ out /* [N][F][C] */, int N, int F, int C, DoneSig done = DoneSig{}) {
     extern __shared__ float nw_lds[];                        // [F][C] weights
     __shared__ uint32_t bits[kNwRows];
     for (int i = threadIdx.x; i < F * C; i += blockDim.x) nw_lds[i] = weights[i];
@@ -663,6 +690,7 @@ __global__ void k_normalize_weight_rows(const float* __restrict__ weights /* [F]
         float* o = out + ((int64_t)n * F + f) * C;
         for (int c = 0; c < C; ++c) o[c] = masked(c) / total;
     }
+    signal_done(done);
 }
 
 __global__ void k_expand_weights(const float* __restrict__ wpat, const uint8_t* __restrict__ pid,
@@ -809,7 +837,7 @@ template <class TC>
 __global__ __launch_bounds__(1024) void k_collapsed_groups(
     const TC* __restrict__ counts, const double* __restrict__ conc, const double* __restrict__ lg_conc,
     const double* __restrict__ sum_a, const double* __restrict__ lg_sum_a, float* __restrict__ per_feature,
-    double* __restrict__ per_group, int g_lo, int F, int S) {
+    double* __restrict__ per_group, int g_lo, int F, int S, DoneSig done = DoneSig{}) {
     extern __shared__ __align__(16) unsigned char cg_lds[];
     double* ser = reinterpret_cast<double*>(cg_lds);                       // [F][S]
     float* pf = reinterpret_cast<float*>(cg_lds + (size_t)F * S * sizeof(double));   // [F]
@@ -837,6 +865,7 @@ __global__ __launch_bounds__(1024) void k_collapsed_groups(
         const float total = np_pairwise_sum_f32_x8(get, F, (int)threadIdx.x);
         if (threadIdx.x == 0) per_group[blockIdx.x] = (double)total;
     }
+    signal_done(done);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -896,7 +925,8 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __rest
                                                            double* __restrict__ results, int first_slot,
                                                            int n_slots, StepFinish fin_single,
                                                            const int32_t* __restrict__ slot_list = nullptr,
-                                                           const StepFinish* __restrict__ fins = nullptr) {
+                                                           const StepFinish* __restrict__ fins = nullptr,
+                                                           DoneSig done = DoneSig{}) {
     __shared__ double red4[4];
     if ((int)blockIdx.x >= n_slots) {                                   // step epilogue block
         const StepFinish fin = fins ? fins[(int)blockIdx.x - n_slots] : fin_single;
@@ -934,6 +964,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __rest
                 if (threadIdx.x == 0) fin.lq_out[t] = total;
             }
         }
+        signal_done(done);
         return;
     }
     const int slot = slot_list ? slot_list[blockIdx.x] : first_slot + (int)blockIdx.x;
@@ -942,6 +973,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __rest
     for (int i = threadIdx.x; i < n_blocks; i += kBlock) v += p[i];
     const double total = block_sum(v, red4);
     if (threadIdx.x == 0) results[slot] = total;
+    signal_done(done);
 }
 
 
@@ -2318,7 +2350,8 @@ __global__ __launch_bounds__(kBlock) void k_cluster_marginals(
     const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid, const uint8_t* __restrict__ pid,
     const float* __restrict__ probs, const float* __restrict__ table0, const float* __restrict__ weights,
     const uint32_t* __restrict__ pattern_bits, float inv_tp, int use_pow, const int32_t* __restrict__ objects,
-    int n_av, double* __restrict__ out, const f64x2_t* __restrict__ logtab, int Np, int F, int S, int C, int Fp) {
+    int n_av, double* __restrict__ out, const f64x2_t* __restrict__ logtab, int Np, int F, int S, int C, int Fp,
+    DoneSig done = DoneSig{}) {
     __shared__ f64x2_t tab[kLogTabEntries];
     __shared__ double red[8];
     if (threadIdx.x < kLogTabEntries) tab[threadIdx.x] = logtab[threadIdx.x];
@@ -2359,6 +2392,7 @@ __global__ __launch_bounds__(kBlock) void k_cluster_marginals(
         out[i] = (red[0] + red[1]) + (red[2] + red[3]);
         out[(int64_t)n_av + i] = (red[4] + red[5]) + (red[6] + red[7]);
     }
+    signal_done(done);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2380,7 +2414,8 @@ __global__ __launch_bounds__(kBlock) void k_jump_lh(
     const float* __restrict__ pconf /* [Gtot - G0][F][S] */, const float* __restrict__ p_source,
     const float* __restrict__ p_target, const float* __restrict__ weights, const uint32_t* __restrict__ pattern_bits,
     float inv_tp, int use_pow, const int32_t* __restrict__ objects, int n_members, double* __restrict__ out,
-    const f64x2_t* __restrict__ logtab, int Np, int F, int S, int C, int Fp, int G0) {
+    const f64x2_t* __restrict__ logtab, int Np, int F, int S, int C, int Fp, int G0,
+    DoneSig done = DoneSig{}) {
     __shared__ f64x2_t tab[kLogTabEntries];
     __shared__ double red[8];
     if (threadIdx.x < kLogTabEntries) tab[threadIdx.x] = logtab[threadIdx.x];
@@ -2414,6 +2449,7 @@ __global__ __launch_bounds__(kBlock) void k_jump_lh(
         out[i] = (red[0] + red[1]) + (red[2] + red[3]);
         out[(int64_t)n_members + i] = (red[4] + red[5]) + (red[6] + red[7]);
     }
+    signal_done(done);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2433,7 +2469,7 @@ __global__ __launch_bounds__(kBlock) void k_jump_lh(
 constexpr int kSlfFT = 16;
 __global__ __launch_bounds__(1024) void k_source_lh_by_feature(
     const uint8_t* __restrict__ state, const uint8_t* __restrict__ src, const uint8_t* __restrict__ pid,
-    const float* __restrict__ wpat, float* __restrict__ out, int N, int F, int C, int Fp) {
+    const float* __restrict__ wpat, float* __restrict__ out, int N, int F, int C, int Fp, DoneSig done = DoneSig{}) {
     constexpr int OL = 1024 / kSlfFT, PER = 8;
     __shared__ double part[OL][kSlfFT];                    // 8 KB
     const int fl = threadIdx.x & (kSlfFT - 1), ol = threadIdx.x / kSlfFT;
@@ -2467,6 +2503,7 @@ __global__ __launch_bounds__(1024) void k_source_lh_by_feature(
         __syncthreads();
     }
     if (ol == 0 && f < F) out[f] = (float)part[0][fl];
+    signal_done(done);
 }
 
 // ==========================================================================================
@@ -2537,14 +2574,16 @@ __device__ inline bool source_posterior_row(const SrcPostArgs& a, int n, int f, 
     return total > 0.0;
 }
 
-__global__ void k_source_posterior(SrcPostArgs a, float* __restrict__ out, int* __restrict__ status) {
+__global__ void k_source_posterior(SrcPostArgs a, float* __restrict__ out, int* __restrict__ status, DoneSig done = DoneSig{}) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)a.n_sub * a.F) return;
-    const int r = (int)(i / a.F), f = (int)(i % a.F);
-    float p[kMaxComponents];
-    if (!source_posterior_row(a, a.objects[r], f, p)) raise_status(status, ST_BAD_NORMALIZE, 1);
-    float* o = out + i * a.C;
-    for (int c = 0; c < a.C; ++c) o[c] = p[c];
+    if (i < (int64_t)a.n_sub * a.F) {
+        const int r = (int)(i / a.F), f = (int)(i % a.F);
+        float p[kMaxComponents];
+        if (!source_posterior_row(a, a.objects[r], f, p)) raise_status(status, ST_BAD_NORMALIZE, 1);
+        float* o = out + i * a.C;
+        for (int c = 0; c < a.C; ++c) o[c] = p[c];
+    }
+    signal_done(done);
 }
 
 // GibbsSampleSource._propose (operators.py:495-552), the draw: sample_categorical
@@ -2630,20 +2669,22 @@ __global__ __launch_bounds__(kBlock) void k_sum_log_f32(const float* __restrict_
 __global__ void k_subset_lh(const uint8_t* __restrict__ state, const float* __restrict__ tables,
                             const int32_t* __restrict__ table_offsets, const int32_t* __restrict__ group_idx,
                             const int32_t* __restrict__ objects, int n_sub, float* __restrict__ out, int F, int S,
-                            int C, int Fp, float inv_t, int use_pow) {
+                            int C, int Fp, float inv_t, int use_pow, DoneSig done = DoneSig{}) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)n_sub * F) return;
-    const int r = (int)(i / F), f = (int)(i % F);
-    const uint8_t x = state[(int64_t)objects[r] * Fp + f];
-    float* o = out + i * C;
-    for (int c = 0; c < C; ++c) {
-        float v = 1.0f;
-        if (x != kNA) {
-            const int g = group_idx[(int64_t)c * n_sub + r];
-            v = g < 0 ? 0.0f : tables[((int64_t)(table_offsets[c] + g) * F + f) * S + x];
+    if (i < (int64_t)n_sub * F) {
+        const int r = (int)(i / F), f = (int)(i % F);
+        const uint8_t x = state[(int64_t)objects[r] * Fp + f];
+        float* o = out + i * C;
+        for (int c = 0; c < C; ++c) {
+            float v = 1.0f;
+            if (x != kNA) {
+                const int g = group_idx[(int64_t)c * n_sub + r];
+                v = g < 0 ? 0.0f : tables[((int64_t)(table_offsets[c] + g) * F + f) * S + x];
+            }
+            o[c] = use_pow ? powf(v, inv_t) : v;
         }
-        o[c] = use_pow ? powf(v, inv_t) : v;
     }
+    signal_done(done);
 }
 
 // SourcePrior.__call__ (prior.py:573-611), per-object values:
@@ -2654,20 +2695,22 @@ __global__ __launch_bounds__(kBlock) void k_source_prior(const uint8_t* __restri
                                                         const uint8_t* __restrict__ src,
                                                         const uint8_t* __restrict__ pid,
                                                         const float* __restrict__ wpat, double* __restrict__ out,
-                                                        int N, int F, int C, int Fp) {
+                                                        int N, int F, int C, int Fp, DoneSig done = DoneSig{}) {
     const int lane = threadIdx.x & (kWave - 1);
     const int n = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-    if (n >= N) return;
-    const float* w = wpat + (int64_t)pid[n] * F * C;
-    double acc = 0.0;
-    for (int f = lane; f < F; f += kWave) {
-        if (state[(int64_t)n * Fp + f] == kNA) continue;
-        const uint8_t c = src[(int64_t)n * Fp + f];
-        const float ow = c < C ? w[(int64_t)f * C + c] : 0.0f;
-        acc += (double)logf(ow);
+    if (n < N) {                                           // (wave-uniform)
+        const float* w = wpat + (int64_t)pid[n] * F * C;
+        double acc = 0.0;
+        for (int f = lane; f < F; f += kWave) {
+            if (state[(int64_t)n * Fp + f] == kNA) continue;
+            const uint8_t c = src[(int64_t)n * Fp + f];
+            const float ow = c < C ? w[(int64_t)f * C + c] : 0.0f;
+            acc += (double)logf(ow);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) out[n] = (double)(float)acc;
     }
-    acc = wave_sum(acc);
-    if (lane == 0) out[n] = (double)(float)acc;
+    signal_done(done);
 }
 
 // One-launch copy of all per-slot arrays (sbe_copy_slot): up to 16 dword-granular segments.
@@ -2976,7 +3019,7 @@ __global__ __launch_bounds__(kBlock) void k_counts_delta(
     const int32_t* __restrict__ gid_old /* [C][n] */, const int32_t* __restrict__ gid_new,
     const uint8_t* __restrict__ src_old /* [n][F] */, const uint8_t* __restrict__ src_new,
     const int32_t* __restrict__ touched /* [T] global group index */, const int32_t* __restrict__ touched_comp /* [T] */,
-    float* __restrict__ out /* [T][F][S] */, int F, int S, int Fp) {
+    float* __restrict__ out /* [T][F][S] */, int F, int S, int Fp, DoneSig done = DoneSig{}) {
     constexpr int FTU = kDeltaFT, OL = kBlock / FTU;
     extern __shared__ int32_t hist[];
     const int t = blockIdx.x, f0 = blockIdx.y * FTU;
@@ -3018,6 +3061,7 @@ __global__ __launch_bounds__(kBlock) void k_counts_delta(
         const int ff = f0 + i / S;
         if (ff < F) out[((int64_t)t * F + ff) * S + i % S] = (float)hist[i];
     }
+    signal_done(done);
 }
 
 // float32 count rows of listed groups -> the slot's resident int32 counts (Engine.set_counts_rows: the bind cache
