@@ -2697,9 +2697,9 @@ int sbe_source_prior(sbe_engine* e, int slot, double* per_object_out) {
     void* d_out;
     rc = out_target(e, (size_t)e->N * sizeof(double), e->d_scratch, &d_out);
     if (rc) return rc;
-    const unsigned nb = (unsigned)div_up(e->N, kBlock / kWave);
+    const unsigned nb = (unsigned)div_up(e->N, 1024 / kWave);
     const DoneSig done = out_done(e, d_out, nb);
-    k_source_prior<<<nb, kBlock, 0, e->stream>>>(
+    k_source_prior<<<nb, 1024, 0, e->stream>>>(
         e->d_state, e->d_src + (int64_t)slot * e->N * e->Fp, e->d_pid + (int64_t)slot * e->Np,
         e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, (double*)d_out, e->N, e->F, e->C, e->Fp, done);
     HIPCHK(e, hipGetLastError());

@@ -2704,14 +2704,14 @@ __global__ void k_subset_lh(const uint8_t* __restrict__ state, const float* __re
 //   sp[n] = float32( sum_{f valid} log( w[pat(n)][f][source(n,f)] ) )     (float32 logs)
 // One wave per object, lanes over features, wave64 shuffle reduce.  An observation whose source has no
 // component set contributes log(0) = -inf like the reference's sum(w * s) = 0.
-__global__ __launch_bounds__(kBlock) void k_source_prior(const uint8_t* __restrict__ state,
+__global__ __launch_bounds__(1024) void k_source_prior(const uint8_t* __restrict__ state,
                                                         const uint8_t* __restrict__ src,
                                                         const uint8_t* __restrict__ pid,
                                                         const float* __restrict__ wpat, double* __restrict__ out,
                                                         int N, int F, int C, int Fp, DoneSig done = DoneSig{}) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int n = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-    if (n < N) {                                           // (wave-uniform)
+    const int n = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);      // (16 objects per 1024-thread block: a block's
+    if (n < N) {                                           // (wave-uniform)           completion fence is per block)
         const float* w = wpat + (int64_t)pid[n] * F * C;
         double acc = 0.0;
         for (int f = lane; f < F; f += kWave) {

@@ -35,6 +35,68 @@ def random_state(rng, feats, groups0, n_groups):
     return groups, weights, source, covered
 
 
+def forms_case(rng, eng, feats, n_groups, conc, state, tag, stats):
+    """collapsed_loglik_all / source_prior / source_lh_by_feature / source_posterior / normalize_weights / counts_delta /
+    given_unchanged_lh / cluster_posterior_marginals / jump_lh_resident of the slot-0 state at random subsets."""
+    from tests._fake_engine import FakeEngine
+    groups, weights, source, counts = state
+    N, F, C = source.shape
+    K = n_groups[0]
+    fake = FakeEngine(feats, n_groups)
+    unif = feats.any(axis=0).astype(np.float64)                     # (the cluster prior's uniform concentration: 1 on seen states)
+    unif[~unif.any(axis=1), 0] = 1.0
+    for c in range(C):
+        fake.set_concentration(c, conc[c]); fake.set_groups(0, c, groups[c]); fake.set_counts(0, c, counts[c])
+    fake.set_source(0, source); fake.set_weights(0, weights); fake.set_uniform_counts(unif)
+    eng.set_uniform_counts(unif)
+    np.testing.assert_allclose(eng.collapsed_loglik_all(0), fake.collapsed_loglik_all(0), rtol=2e-6, atol=1e-5, err_msg=tag)
+    with np.errstate(divide="ignore"):
+        np.testing.assert_allclose(eng.source_prior(0), fake.source_prior(0), rtol=2e-6, atol=1e-5, err_msg=tag)
+        np.testing.assert_allclose(eng.source_lh_by_feature(0), fake.source_lh_by_feature(0), rtol=max(3e-5, N * 2.0 ** -25), atol=1e-4, err_msg=tag)
+    hc = rng.random((int(rng.integers(1, 40)), C)) < 0.6
+    hc[:, 1] = True
+    assert np.array_equal(eng.normalize_weights(weights, hc), fake.normalize_weights(weights, hc)), (tag, "normalize_weights")
+    objs = np.unique(rng.integers(0, N, size=int(rng.integers(1, min(N, 60) + 1)))).astype(np.int32)
+    assert np.array_equal(eng.source_posterior(0, objs), fake.source_posterior(0, objs)), (tag, "source_posterior")
+    i_cl = int(rng.integers(0, K))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want = fake.given_unchanged_lh(0, i_cl, objs)
+    assert np.array_equal(eng.given_unchanged_lh(0, i_cl, objs), want), (tag, "given_unchanged_lh")
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want = fake.cluster_posterior_marginals(0, i_cl, objs)
+        got = eng.cluster_posterior_marginals(0, i_cl, objs)
+    ok = np.isfinite(want) & (want > -690.0)      # (and above the denormal range: the product keeps its digits)
+    # (the double takes the log of a linear-space product over the features, which underflows beyond F ~ 75 --
+    #  SURVEY.md H5 -- where the device's sum of logs stays finite: compared where the reference value exists)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=1e-9, atol=1e-9, err_msg=tag)
+    # update_feature_counts in delta form: the subset's clusters and source rows change
+    off = eng.group_offsets
+    new_clusters = groups[0].copy()
+    new_clusters[:, objs] = False
+    move = rng.integers(0, K + 1, size=objs.size)
+    new_clusters[move[move < K], objs[move < K]] = True
+    pick = rng.integers(0, C + 1, size=(objs.size, F))
+    new_rows = pick[..., None] == np.arange(C)
+    ids = lambda g, o: np.where(g[:, objs].any(axis=0), g[:, objs].argmax(axis=0) + o, -1).astype(np.int32)   # noqa: E731
+    gid_old = np.stack([ids(groups[c], off[c]) for c in range(C)])
+    gid_new = gid_old.copy()
+    gid_new[0] = ids(new_clusters, 0)
+    so = np.where(source[objs].any(-1), source[objs].argmax(-1), 255).astype(np.uint8)
+    sn = np.where(new_rows.any(-1), new_rows.argmax(-1), 255).astype(np.uint8)
+    t_got, d_got = eng.counts_delta(objs, gid_old, gid_new, so, sn)
+    t_want, d_want = fake.counts_delta(objs, gid_old, gid_new, so, sn)
+    assert np.array_equal(t_got, t_want) and np.array_equal(d_got, d_want), (tag, "counts_delta")
+    members = np.flatnonzero(groups[0][i_cl]).astype(np.int32)
+    if members.size and K >= 2:
+        i_tg = (i_cl + 1) % K
+        with np.errstate(divide="ignore", invalid="ignore"):
+            want = fake.jump_lh_resident(0, i_cl, i_tg, members)
+            got = eng.jump_lh_resident(0, i_cl, i_tg, members)
+        ok = np.isfinite(want) & (want > -690.0)
+        np.testing.assert_allclose(got[ok], want[ok], rtol=1e-9, atol=1e-9, err_msg=tag)
+    stats["forms"] = stats.get("forms", 0) + 1
+
+
 def one_case(rng, stats, big=False):
     if big:                                             # long chunks, several block generations, ragged tiles
         N = int(rng.integers(600, 4000))
@@ -173,6 +235,9 @@ def one_case(rng, stats, big=False):
                         for c in range(C):
                             assert np.array_equal(eng.get_counts(B + 1, c), eng.get_counts(B + 4, c)), (tag, "chained delta counts", c)
                     stats["delta"] = stats.get("delta", 0) + 1
+        # the resident operator forms of the drop-in layer (round 3) on state 0, against the oracle-backed double
+        if C >= 2 and N >= 2 and not big:
+            forms_case(rng, eng, feats, n_groups, conc, states[0], tag, stats)
         # one-call Gibbs step from state 0: counts consistent with the source it drew
         eng.set_option(step_form=0)
         objs = np.unique(rng.integers(0, N, size=min(6, N))).astype(np.int32)
