@@ -2086,8 +2086,10 @@ int sbe_normalize_weights(sbe_engine* e, const float* weights, int n_comp, const
     int rc = ensure_scratch(e, wb + hb + (size_t)n_out * sizeof(float));
     if (rc) return rc;
     const void *v_w = e->d_scratch, *v_hc;
-    if (N <= 256) rc = stage(e, weights, (size_t)F * C * sizeof(float), e->d_scratch, &v_w);
-    else rc = upload(e, e->d_scratch, weights, (size_t)F * C * sizeof(float));
+    const size_t w_lds = (size_t)F * C * sizeof(float);
+    const bool in_lds = w_lds <= ((size_t)64 << 10);              // (beyond that the blocks read the device copy in place)
+    if (N <= 256 && in_lds) rc = stage(e, weights, w_lds, e->d_scratch, &v_w);
+    else rc = upload(e, e->d_scratch, weights, w_lds);
     if (rc) return rc;
     rc = stage(e, has_components, (size_t)N * C, e->d_scratch + wb, &v_hc);
     if (rc) return rc;
@@ -2095,8 +2097,8 @@ int sbe_normalize_weights(sbe_engine* e, const float* weights, int n_comp, const
     rc = out_target(e, (size_t)n_out * sizeof(float), e->d_scratch + wb + hb, &d_out);
     if (rc) return rc;
     const DoneSig done = out_done(e, d_out, (unsigned)div_up(N, kNwRows));
-    k_normalize_weight_rows<<<div_up(N, kNwRows), 256, (size_t)F * C * sizeof(float), e->stream>>>(
-        (const float*)v_w, (const uint8_t*)v_hc, (float*)d_out, N, F, C, done);
+    k_normalize_weight_rows<<<div_up(N, kNwRows), 256, in_lds ? w_lds : 0, e->stream>>>(
+        (const float*)v_w, (const uint8_t*)v_hc, (float*)d_out, N, F, C, in_lds ? 1 : 0, done);
     HIPCHK(e, hipGetLastError());
     return out_fetch(e, out, d_out, (size_t)n_out * sizeof(float), done);
 }
@@ -2551,11 +2553,15 @@ int sbe_given_unchanged_lh(sbe_engine* e, int slot, int i_cluster, const int32_t
     if (rc) return rc;
     // kept counts and their conditional_effect_mean (conditionals.py:105-122) in one launch: the cluster's row with the
     // cluster prior, the confounder rows with theirs
+    const bool list_in_lds = (size_t)n_sub * sizeof(int32_t) <= ((size_t)32 << 10);
+    if (((size_t)16 * S + (N + 31) / 32) * sizeof(int32_t) > ((size_t)96 << 10))
+        return fail(e, SBE_ERR_ARG, "component_likelihood_given_unchanged: %d objects x %d states exceed the kernel's LDS image", N, S);
     k_unchanged_counts<<<dim3(R, div_up(F, 16)), kUnchangedBlock,
-                         ((size_t)16 * S + n_sub + (N + 31) / 32) * sizeof(int32_t), e->stream>>>(
+                         ((size_t)16 * S + (list_in_lds ? n_sub : 0) + (N + 31) / 32) * sizeof(int32_t), e->stream>>>(
         e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_src + (int64_t)slot * N * e->Fp,
         e->d_counts + (int64_t)slot * e->table_elems(), (const int32_t*)e->d_io, n_sub, e->d_comp_of_group,
-        i_cluster, K, N, e->Np, F, S, e->Fp, e->d_conc, e->d_unif_res, temperature, prior_temperature, e->d_status, d_tab);
+        i_cluster, K, N, e->Np, F, S, e->Fp, e->d_conc, e->d_unif_res, temperature, prior_temperature, e->d_status, d_tab,
+        list_in_lds ? 1 : 0);
     HIPCHK(e, hipGetLastError());
     const double inv_t = 1.0 / temperature;
     const DoneSig done = mapped_out ? next_done(e, (unsigned)div_up((int64_t)n_sub * F, 256)) : DoneSig{};

@@ -681,10 +681,11 @@ __global__ void k_weight_patterns(const float* __restrict__ weights /* [F][C] */
 constexpr int kNwRows = 8;
 __global__ void k_normalize_weight_rows(const float* __restrict__ weights /* [F][C] */,
                                         const uint8_t* __restrict__ has_components /* [N][C] */,
-                                        float* __restrict__ out /* [N][F][C] */, int N, int F, int C, DoneSig done = DoneSig{}) {
-    extern __shared__ float nw_lds[];                        // [F][C] weights
-    __shared__ uint32_t bits[kNwRows];
-    for (int i = threadIdx.x; i < F * C; i += blockDim.x) nw_lds[i] = weights[i];
+                                        float* __restrict__ out /* [N][F][C] */, int N, int F, int C, int stage_weights,
+                                        DoneSig done = DoneSig{}) {
+    extern __shared__ float nw_lds[];                        // [F][C] weights (stage_weights == 0: read in place from
+    __shared__ uint32_t bits[kNwRows];                       //  device memory -- tables beyond the LDS budget)
+    if (stage_weights) for (int i = threadIdx.x; i < F * C; i += blockDim.x) nw_lds[i] = weights[i];
     const int n0 = blockIdx.x * kNwRows;
     if (threadIdx.x < kNwRows) {
         uint32_t b = 0;
@@ -697,7 +698,7 @@ __global__ void k_normalize_weight_rows(const float* __restrict__ weights /* [F]
         const int r = i / F, f = i - r * F, n = n0 + r;
         if (n >= N) break;
         const uint32_t b = bits[r];
-        const float* w = nw_lds + f * C;
+        const float* w = (stage_weights ? nw_lds : weights) + f * C;
         auto masked = [&](int c) -> float { return ((b >> c) & 1u) ? w[c] : 0.0f * w[c]; };
         const float total = np_pairwise_sum<float>(masked, C);
         float* o = out + ((int64_t)n * F + f) * C;
@@ -3109,18 +3110,20 @@ __global__ __launch_bounds__(kUnchangedBlock) void k_unchanged_counts(
     const int32_t* __restrict__ objects /* [n_sub]; may be host-mapped: read ONCE per block */, int n_sub,
     const int32_t* __restrict__ comp_of_group /* [Gtot] */, int i_cluster, int K, int N, int Np, int F, int S, int Fp,
     const double* __restrict__ conc /* [Gtot][F][S] */, const double* __restrict__ unif /* [F][S] */, double temperature,
-    double prior_temperature, int* __restrict__ status, float* __restrict__ out /* [1 + Gtot - K][F][S] probability tables */) {
+    double prior_temperature, int* __restrict__ status, float* __restrict__ out /* [1 + Gtot - K][F][S] probability tables */,
+    int list_in_lds /* 0: the object list is too long for LDS and is read in place */) {
     // 16 features x 64 object lanes: row 0 walks ALL objects (the cluster's members are found by id), so the object
     // axis gets the lanes; a wave reads four 16-byte runs of four state rows per step
     // The subset's object list lives in host-mapped memory: the block copies it into LDS with one coalesced pass (a
     // walk over it in place would pay a PCIe round trip per step) and, for row 0, turns it into a bitmap over all objects.
     constexpr int FTU = 16, OL = kUnchangedBlock / FTU;
     extern __shared__ int32_t hist[];                                   // [16][S] | object list [n_sub] | bitmap [(N + 31) / 32]
-    int32_t* sub = hist + FTU * S;
-    uint32_t* in_subset = reinterpret_cast<uint32_t*>(sub + n_sub);
+    int32_t* sub_lds = hist + FTU * S;
+    const int32_t* sub = list_in_lds ? sub_lds : objects;
+    uint32_t* in_subset = reinterpret_cast<uint32_t*>(sub_lds + (list_in_lds ? n_sub : 0));
     const int r = blockIdx.x, f0 = blockIdx.y * FTU;
     for (int i = threadIdx.x; i < FTU * S; i += kUnchangedBlock) hist[i] = 0;
-    for (int i = threadIdx.x; i < n_sub; i += kUnchangedBlock) sub[i] = objects[i];
+    if (list_in_lds) for (int i = threadIdx.x; i < n_sub; i += kUnchangedBlock) sub_lds[i] = objects[i];
     if (r == 0) for (int i = threadIdx.x; i < (N + 31) / 32; i += kUnchangedBlock) in_subset[i] = 0u;
     __syncthreads();
     if (r == 0) {
