@@ -645,6 +645,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity_rel_err": parity,
+            "results_sha1": __import__("hashlib").sha1(np.ascontiguousarray(results).tobytes()).hexdigest()[:16],   # (rank 0's B results of the last repetition: A/B runs of engine builds must agree on it)
             "device": info["device_name"],
             "dist_backend": chains.backend_name(dist),
             "setup_s": round(t_setup, 2),
