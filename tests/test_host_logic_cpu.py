@@ -144,6 +144,39 @@ def test_bind_cache_sees_in_place_edits(fake):
     assert not [c for c in eng.calls if c[0].startswith("set_")]
 
 
+def test_collapsed_values_of_all_components_come_from_one_call_and_follow_the_counts(fake):
+    """Likelihood.__call__ asks component after component (likelihood.py:58-63); the drop-in layer evaluates every
+    component with the first request (ONE collapsed_loglik_all) and keeps the values on the slot's bind entry until a
+    count row changes -- then the changed rows of ALL components go up in ONE set_counts_rows and the values are new."""
+    fx = load_npz("south_america")                                    # three components
+    model, sample = build(fx)
+    feats = model.data.features.values
+    recalculate_feature_counts(feats, sample)
+    eng = next(iter(fake.values()))
+    eng.calls.clear()
+    v0 = model.likelihood(sample, caching=False)
+    assert v0 == pytest.approx(fx.meta["collapsed_ll"], rel=1e-12)
+    assert [c[0] for c in eng.calls if c[0].startswith("collapsed")] == ["collapsed_loglik_all"]
+    # (caching=False recounts on the device first -- recount_bound drops the kept values, as it must; one call again)
+    eng.calls.clear()
+    assert model.likelihood(sample, caching=False) == v0
+    assert [c[0] for c in eng.calls if c[0].startswith("collapsed")] == ["collapsed_loglik_all"]
+    # one count row of the clusters and one of a confounder change: one row upload for both, one re-evaluation
+    names = sample.component_names
+    for name in (names[0], names[-1]):
+        diff = np.zeros_like(sample.feature_counts[name].value)
+        diff[0, 1, 0] = 1.0
+        sample.feature_counts[name].add_changes(diff)
+    eng.calls.clear()
+    v1 = model.likelihood(sample, caching=True)
+    kinds = [c[0] for c in eng.calls]
+    assert kinds.count("set_counts_rows") == 1 and ("set_counts_rows", 2) in eng.calls and "set_counts" not in kinds
+    assert kinds.count("collapsed_loglik_all") == 1 and v1 != v0
+    from oracle import sbayes_oracle as orc
+    want = sum(orc.collapsed_group_logliks(sample.feature_counts[n].value, c).sum() for n, c in zip(names, fx.conc))
+    assert v1 == pytest.approx(want, rel=1e-12)
+
+
 def test_normalize_weights_never_creates_engines_per_row_count(monkeypatch):
     """normalize_weights is also called with has_components[available] (operators.py:1086), whose row count
     changes from step to step; the engine is looked up by F only."""
