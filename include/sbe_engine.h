@@ -283,8 +283,10 @@ int sbe_cluster_marginals(sbe_engine* e, int slot, const float* table /* [F][S] 
  *     ** (1/temperature), + EPS and the ratio (operators.py:1712-1722).
  * sbe_source_lh_by_feature: GibbsSampleWeights.source_lh_by_feature (operators.py:677-685): per feature
  *     float32( sum_n log sum_c source[n,f,c] * w[n,f,c] ), NA observations count 1, from the slot's source, patterns
- *     and weights -- the [N, F, C] normalised-weight array never crosses PCIe.  float32 logs added up in float32 in
- *     object order like the reference's np.sum(axis=0): agreement to a fraction of N * 2^-24 relative. */
+ *     and weights -- the [N, F, C] normalised-weight array never crosses PCIe.  float32 logs like the reference's; the
+ *     sum over the objects is taken in float64 (fixed order) and rounded to float32 once, where the reference adds the N
+ *     float32 logs in float32 one after the other (np.sum(axis=0)): the two agree within the reference's own
+ *     accumulated rounding, at most N * 2^-25 relative (observed 2e-4 at N = 30 000, 1e-6 at N = 1000). */
 int sbe_jump_lh(sbe_engine* e, int slot, const float* pconf /* [G_total - K][F][S] */, const float* p_source /* [F][S] */,
                 const float* p_target /* [F][S] */, const int32_t* objects, int n_members, double prior_temperature,
                 double* out /* [2][n_members] */);
