@@ -650,7 +650,7 @@ __global__ void k_probs(const TC* __restrict__ counts, const double* __restrict_
 // ------------------------------------------------------------------------------------------
 // Optional extras of the slot form (one launch per sbe_set_weights): `weights_keep` = the slot's resident [F][C] copy
 // of `weights` (which may then be host-mapped staging memory), `wpat_t` = the tile-transposed float64 copy
-// [n_ftiles][Pmax][C][ft] (k_tile_weights' layout; padding features stay zero from creation).
+// [n_ftiles][Pmax][C][ft], exact widening (what the fused kernels read; padding features stay zero from creation).
 __global__ void k_weight_patterns(const float* __restrict__ weights /* [F][C] */,
                                   const uint32_t* __restrict__ pattern_bits /* [P] */,
                                   float* __restrict__ wpat /* [P][F][C] */, int P, int F, int C,
@@ -3002,22 +3002,6 @@ __global__ void k_tile_probs(const float* __restrict__ probs, float* __restrict_
     const int f = tile * ft + fl;
     const float v = f < F ? probs[((int64_t)g * F + f) * S + s] : 0.0f;
     probs_t[(((int64_t)tile * (Gtot + 1) + g) * S + s) * ft + fl] = v;
-}
-
-// wpat [P][F][C] float32 -> wpat_t [n_ftiles][Pmax][C][FT] float64 (exact widening)
-__global__ void k_tile_weights(const float* __restrict__ wpat, double* __restrict__ wpat_t, int P, int Pmax,
-                               int F, int C, int ft, int n_ftiles) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t per_tile = (int64_t)P * C * ft;
-    if (i >= per_tile * n_ftiles) return;
-    const int tile = (int)(i / per_tile);
-    int64_t r = i % per_tile;
-    const int pp = (int)(r / ((int64_t)C * ft));
-    r %= (int64_t)C * ft;
-    const int c = (int)(r / ft), fl = (int)(r % ft);
-    const int f = tile * ft + fl;
-    const double v = f < F ? (double)wpat[((int64_t)pp * F + f) * C + c] : 0.0;
-    wpat_t[(((int64_t)tile * Pmax + pp) * C + c) * ft + fl] = v;
 }
 
 // ------------------------------------------------------------------------------------------
