@@ -16,7 +16,7 @@ from sbayes_amd.synthetic import make_workload
 from tests._fake_engine import FakeEngine
 
 pytestmark = pytest.mark.gpu
-REPS = 20000
+REPS = int(os.environ.get("SBE_POLL_REPS", "20000"))        # (soak runs: SBE_POLL_REPS=2000000)
 
 
 def _setup(shape):
