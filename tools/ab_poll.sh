@@ -1,3 +1,6 @@
+#!/bin/bash
+# GPU box: completion by flag (default) against the runtime's stream wait (SBE_POLL_DONE=0), alternating on one box:
+# GPU suite once, then the call-log replay, the 64-chain batched step and the single-step timings.  (profiles/r3/ab_poll_done.log)
 python -m pytest tests -m gpu -x -q > gpurun_out/gputest_r3x.log 2>&1; tail -2 gpurun_out/gputest_r3x.log
 for i in 1 2 3; do
   for p in 0 1; do
