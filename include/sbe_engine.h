@@ -136,8 +136,14 @@ int sbe_component_lh(sbe_engine* e, const void* probs /* [G][F][S] */, int probs
 int sbe_likelihood_per_component_exact(sbe_engine* e, int slot, double* out);
 
 /* ---- slot state: groups (state.py Clusters / load_data.py Confounder.group_assignment) --
- * An object that is in several groups of one component takes the LAST one (what a1 does
- * when all groups are recomputed).  Also refreshes has_components (state.py:353-376). */
+ * Resident state keeps ONE group per object and component.  A matrix with an object in
+ * several rows of one component is rejected with SBE_ERR_DATA ("object n is in groups g1 and
+ * g2 of component c"): the reference counts such an object once per group
+ * (compute_effect_counts, counts.py:28-30) but lets the last written group win in a1
+ * (likelihood.py:126-130), and no single id follows both.  The stateless sbe_effect_counts
+ * and sbe_component_lh accept overlap and follow the reference.  The cluster matrices of
+ * sbe_step / sbe_step_batch are checked the same way (a batch reports the chain).
+ * Also refreshes has_components (state.py:353-376). */
 int sbe_set_groups(sbe_engine* e, int slot, int component, const uint8_t* groups /* [G_c][N] bool */);
 int sbe_set_group_ids(sbe_engine* e, int slot, int component, const int32_t* ids /* [N], -1 = none */);
 

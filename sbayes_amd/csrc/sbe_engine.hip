@@ -1485,16 +1485,49 @@ static int set_gid_common(sbe_engine* e, int slot, int component, const std::vec
     return SBE_OK;
 }
 
+// Resident slot state keeps ONE group per object and component (u16 ids).  A bool [G][N] matrix with an object in two
+// rows has no such form: the reference counts the object once per group it is in (compute_effect_counts,
+// sbayes/sampling/counts.py:28-30) while its a1 lets the last written group win (likelihood.py:126-130) -- collapsing the
+// matrix to ids would silently follow only one of the two.  Overlap is therefore REJECTED here (SBE_ERR_DATA); the
+// stateless sbe_effect_counts / sbe_component_lh take such matrices and follow the reference.  (sBayes itself never
+// produces overlap: operators.py:724-725, :1099-1101 for clusters, load_data.py:174-178 for confounders.)
+static void overlap_message(char* buf, size_t len, int n, int g1, int g2, int component) {
+    snprintf(buf, len, "object %d is in groups %d and %d of component %d: resident slot state keeps one group per object "
+             "and component (counts.py:28-30 would count it in both); overlapping groups are served by the stateless "
+             "sbe_effect_counts / sbe_component_lh only", n, g1, g2, component);
+}
+
+// bool [G][N] -> one id per object (off + g, kNoGroup: in no group).  false + message on overlap.
+static bool matrix_to_ids(const uint8_t* groups, int G, int N, int off, int component, uint16_t* ids, char* msg, size_t msg_len) {
+    std::fill(ids, ids + N, kNoGroup);
+    for (int g = 0; g < G; ++g) {                     // (mostly zeros: eight objects per test)
+        const uint8_t* row = groups + (size_t)g * N;
+        int n = 0;
+        for (; n + 8 <= N; n += 8) {
+            uint64_t w8;
+            memcpy(&w8, row + n, 8);
+            if (!w8) continue;
+            for (int k = 0; k < 8; ++k) if (row[n + k]) {
+                if (ids[n + k] != kNoGroup) { overlap_message(msg, msg_len, n + k, (int)ids[n + k] - off, g, component); return false; }
+                ids[n + k] = (uint16_t)(off + g);
+            }
+        }
+        for (; n < N; ++n) if (row[n]) {
+            if (ids[n] != kNoGroup) { overlap_message(msg, msg_len, n, (int)ids[n] - off, g, component); return false; }
+            ids[n] = (uint16_t)(off + g);
+        }
+    }
+    return true;
+}
+
 int sbe_set_groups(sbe_engine* e, int slot, int component, const uint8_t* groups) {
     CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component);
     if (e->G[component] > 0) CHECK_PTR(e, groups);
     HIPCHK(e, hipSetDevice(e->device));
     const int N = e->N, G = e->G[component], off = e->goff[component];
     std::vector<uint16_t> ids(N, kNoGroup);
-    for (int g = 0; g < G; ++g) {
-        const uint8_t* row = groups + (size_t)g * N;
-        for (int n = 0; n < N; ++n) if (row[n]) ids[n] = (uint16_t)(off + g);
-    }
+    char msg[320];
+    if (!matrix_to_ids(groups, G, N, off, component, ids.data(), msg, sizeof msg)) return fail(e, SBE_ERR_DATA, "%s", msg);
     return set_gid_common(e, slot, component, ids);
 }
 
@@ -2961,17 +2994,9 @@ static int prepare_step(sbe_engine* e, const sbe_engine::Lane& lane, int cur_slo
     if (regroup) {
         const int K = e->G[0];
         uint16_t* ids = cd.h_gid.data();      // component 0: group offset 0
-        std::fill(ids, ids + N, kNoGroup);
-        for (int g = 0; g < K; ++g) {                 // (mostly zeros: eight objects per test)
-            const uint8_t* row = clusters + (size_t)g * N;
-            int n = 0;
-            for (; n + 8 <= N; n += 8) {
-                uint64_t w8;
-                memcpy(&w8, row + n, 8);
-                if (!w8) continue;
-                for (int k = 0; k < 8; ++k) if (row[n + k]) ids[n + k] = (uint16_t)g;
-            }
-            for (; n < N; ++n) if (row[n]) ids[n] = (uint16_t)g;
+        {
+            char msg[320];
+            if (!matrix_to_ids(clusters, K, N, 0, 0, ids, msg, sizeof msg)) { *err = msg; return SBE_ERR_DATA; }
         }
         const uint16_t* old_ids = cur.h_gid.data();
         for (int n = 0; n < N; ++n) if (ids[n] != old_ids[n]) { mv.push_back(n); mv_old.push_back(old_ids[n]); }
@@ -3926,10 +3951,8 @@ static int step_general(sbe_engine* e, int cur_slot, int cand_slot, const uint8_
     if (clusters) {
         const int K = e->G[0];
         std::vector<uint16_t> ids(N, kNoGroup);
-        for (int g = 0; g < K; ++g) {
-            const uint8_t* row = clusters + (size_t)g * N;
-            for (int n = 0; n < N; ++n) if (row[n]) ids[n] = (uint16_t)g;      // component 0: offset 0
-        }
+        char msg[320];
+        if (!matrix_to_ids(clusters, K, N, 0, 0, ids.data(), msg, sizeof msg)) return done(fail(e, SBE_ERR_DATA, "%s", msg));   // component 0: offset 0
         for (int n = 0; n < N; ++n) if (ids[n] != cur.h_gid[n]) moved[n] = 1;
         rc = set_gid_common(e, cand_slot, 0, ids);
         if (rc) return done(rc);

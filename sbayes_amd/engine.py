@@ -8,10 +8,11 @@ Device handles are created lazily per process and are never pickled (MC3 workers
 from __future__ import annotations
 
 import ctypes as ct
+import os
 
 import numpy as np
 
-from . import _lib
+from . import _lib, _proc
 
 MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE, MIXTURE_ONEHOT_GENERAL = 0, 1, 2, 3, 4
 MIXTURE_PACKED_TUPLE_LDS = 5
@@ -42,9 +43,12 @@ def _ptr(a):
 
 
 def device_count() -> int:
+    _proc.check_usable()                 # a fork()ed child of a HIP-initialised parent may not touch the runtime
     lib = _lib.load()
     n = ct.c_int(0)
     lib.sbe_device_count(ct.byref(n))
+    if n.value > 0:
+        _proc.mark_hip_touched()         # hipGetDeviceCount initialised the runtime in this process
     return n.value
 
 
@@ -52,8 +56,10 @@ class Engine:
     """One resident one-hot feature block + `n_slots` sample states on one GPU."""
 
     def __init__(self, features, n_groups, n_slots=2, device=0):
+        _proc.check_usable()             # ForkedWithHipError in a fork()ed child of a HIP-initialised parent
         self._lib = _lib.load()
         self._h = ct.c_void_p()
+        self._pid = None                 # pid of the process the handle lives in (set once sbe_create succeeded)
         self.h2d_bytes = self.d2h_bytes = self.n_calls = 0
         features = np.asarray(features)
         if features.ndim != 3:
@@ -74,6 +80,9 @@ class Engine:
             msg = self._lib.sbe_last_error(None)
             self._h = ct.c_void_p()
             raise EngineError(rc, msg.decode() if msg else "sbe_create failed")
+        self._pid = os.getpid()
+        _proc.mark_hip_touched()
+        _proc.register_engine(self)
         self.group_offsets = np.concatenate([[0], np.cumsum(self.n_groups)]).astype(int)
         self.n_groups_total = int(self.group_offsets[-1])
         self._deferred = False
@@ -114,8 +123,19 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            self._lib.sbe_destroy(self._h)
+            if self._pid == os.getpid():         # (a handle that reached another process by any road is never destroyed there)
+                self._lib.sbe_destroy(self._h)
             self._h = ct.c_void_p()
+
+    def _forget(self, lib_face):
+        """After fork(), in the child (_proc._after_fork_in_child): drop the inherited handle WITHOUT sbe_destroy -- its
+        device memory, pinned arenas and stream belong to the parent -- and make every later call on this object raise."""
+        self._h = ct.c_void_p()
+        self._lib = lib_face
+        self._bound = {}
+        self._bound_conc = {}
+        self._bound_unif = None
+        self._mirror = {}
 
     def __del__(self):
         try:

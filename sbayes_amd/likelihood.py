@@ -47,9 +47,23 @@ class Likelihood:
 
     # device handles are per process: never pickled, re-created lazily (mcmc_setup.py:299, model.py:53)
     def __getstate__(self):
+        from . import patch
         state = dict(self.__dict__)
         state["_na_features"] = None
+        state["_sbayes_amd_patch"] = patch.installed()      # how the pickling process had sBayes patched, if at all
         return state
+
+    def __setstate__(self, state):
+        """Unpickled in another process (an MC3 worker, a Pool worker): under the spawn / forkserver start methods that
+        process is a fresh interpreter whose sBayes is not patched yet, and the model is the first thing it receives
+        (mcmc_setup.py:299, :554) -- re-install the patch the sender ran under, before the worker builds its chain."""
+        how = state.pop("_sbayes_amd_patch", None)
+        self.__dict__.update(state)
+        if how is not None:
+            from . import patch
+            if patch.installed() is None or (how["operators"] and not patch.installed()["operators"]):
+                patch.install(operators=how["operators"])
+        registry.note_features(self.features, self.n_groups)
 
     @property
     def n_groups(self):

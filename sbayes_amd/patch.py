@@ -24,7 +24,14 @@ has to cross PCIe for them:
   sbayes.sampling.operators.GibbsSampleWeights.source_lh_by_feature       (operators.py:677-685; _propose :597-636 runs
         UNCHANGED: update_weights hands it a lazily materialised array that knows its sample, and this static method
         evaluates that sample's resident state on the device -- the two [N, F, C] arrays per call are never built)
-Proposal logic, RNG use and everything else of the operators stay the reference's."""
+Proposal logic, RNG use and everything else of the operators stay the reference's.
+
+Process model (sbayes_amd/_proc.py, INTEGRATION.md "Processes").  The reference starts MC3 workers and run pools with
+`multiprocessing`'s default start method -- fork on Linux (mcmc_setup.py:271-282, cli.py:104-109) -- and a HIP context does
+not survive fork().  install(mp_start_method="forkserver" | "spawn") fixes the start method before the first worker exists;
+with either, a worker is a fresh interpreter in which nothing is patched yet, so a pickled `Likelihood` re-installs the
+patch (same `operators` choice) when it is unpickled there -- the model is the first thing a worker receives
+(`send_initialize_chain`, mcmc_setup.py:299, :554), before it builds its MCMCChain and operators."""
 from __future__ import annotations
 
 import hashlib
@@ -33,6 +40,7 @@ import inspect
 import warnings
 
 _SAVED = []
+_INSTALLED = None        # {"operators": bool} while the patch is installed in this process
 
 # A replaced method shadows whatever the reference does there, so each device form is tied to the reference body it
 # mirrors: SHA-1 of the method's source text with whitespace runs collapsed, taken from the reference revision this
@@ -70,7 +78,39 @@ def _check_mirrored(owner, name):
                       f"the device form replaces it anyway -- re-check sbayes_amd/operators.py against it", RuntimeWarning)
 
 
-def install(operators=False):
+def installed():
+    """{"operators": bool} if install() ran in this process (and uninstall() has not), else None."""
+    return dict(_INSTALLED) if _INSTALLED is not None else None
+
+
+def set_mp_start_method(method):
+    """Fix multiprocessing's start method to one that does not copy a HIP context into workers ("forkserver" or
+    "spawn"; "auto" = "forkserver" unless the application already fixed one).  Raises if the application fixed "fork"
+    and asks for something else here -- that is its decision to revisit, not ours to override."""
+    import multiprocessing as mp
+    current = mp.get_start_method(allow_none=True)
+    if method == "auto":
+        if current is None:
+            mp.set_start_method("forkserver")
+        elif current == "fork":
+            warnings.warn("sbayes_amd.patch: multiprocessing's start method is fixed to 'fork'; workers forked after this "
+                          "process first used the GPU cannot use it (sbayes_amd._proc.ForkedWithHipError).  Use "
+                          "'forkserver' or 'spawn'.", RuntimeWarning, stacklevel=3)
+        return mp.get_start_method(allow_none=True)
+    if method not in ("forkserver", "spawn"):
+        raise ValueError(f"mp_start_method must be 'forkserver', 'spawn' or 'auto', got {method!r}")
+    if current is None:
+        mp.set_start_method(method)
+    elif current != method:
+        raise RuntimeError(f"sbayes_amd.patch.install(mp_start_method={method!r}): multiprocessing's start method is "
+                           f"already fixed to {current!r}")
+    return method
+
+
+def install(operators=False, mp_start_method=None):
+    global _INSTALLED
+    if mp_start_method is not None:
+        set_mp_start_method(mp_start_method)
     from . import conditionals as my_cond
     from . import counts as my_counts
     from . import likelihood as my_lik
@@ -122,6 +162,7 @@ def install(operators=False):
                           ("compute_effect_counts", my_counts.compute_effect_counts),
                           ("compute_component_likelihood", my_lik.compute_component_likelihood)):
             swap(m, name, new)
+    _INSTALLED = {"operators": bool(operators) or bool(_INSTALLED and _INSTALLED["operators"])}
 
 
 def _install_operator_forms(swap):
@@ -245,6 +286,8 @@ def _install_operator_forms(swap):
 
 
 def uninstall():
+    global _INSTALLED
+    _INSTALLED = None
     while _SAVED:
         mod, name, old = _SAVED.pop()
         setattr(mod, name, old)

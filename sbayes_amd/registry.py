@@ -12,9 +12,10 @@ import weakref
 
 import numpy as np
 
+from . import _proc
 from .engine import Engine
 
-_ENGINES: dict = {}
+_ENGINES: dict = {}          # per process: emptied in a fork()ed child (_forget_inherited), never shared
 
 
 def _key(features: np.ndarray):
@@ -115,6 +116,14 @@ def engine_for_features(n_features: int) -> Engine:
     if key not in _ENGINES:
         _ENGINES[key] = (Engine(np.zeros((1, n_features, 1), dtype=bool), [1], n_slots=1, device=default_device()), None)
     return _ENGINES[key][0]
+
+
+@_proc.on_fork_clear
+def _forget_inherited():
+    """In a fork()ed child: the engines in these tables are the parent's (their handles were nulled by
+    _proc._after_fork_in_child, nothing is destroyed); the child starts with an empty registry."""
+    _ENGINES.clear()
+    _KNOWN.clear()
 
 
 def release_all():
