@@ -314,7 +314,9 @@ int sbe_source_lh_by_feature(sbe_engine* e, int slot, float* out /* [F] */);
  *     (every other row of that difference is zero).  The caller adds them with FeatureCounts.add_changes
  *     (sbayes/sampling/state.py:340-350).
  * sbe_set_counts_rows: rows `group_idx` (global) of the slot's resident counts <- rows float32 [n_rows][F][S]: the bind
- *     cache of the host layer sends only the groups whose counts differ from what the slot holds.
+ *     cache of the host layer sends only the groups whose counts differ from what the slot holds.  The rows PATCH a
+ *     table: the counts of every component a listed group belongs to must be resident already (sbe_set_counts,
+ *     sbe_recount or a step), else SBE_ERR_STATE -- a component is never marked set through rows alone.
  * sbe_given_unchanged_lh: component_likelihood_given_unchanged(model, sample, object_subset, i_cluster, T, T_prior)
  *     (sbayes/sampling/operators.py:863-928) for static priors, from RESIDENT data of the slot the candidate is bound
  *     to (new clusters, source not yet resampled, counts still the old state's -- exactly the reference's inputs at
@@ -434,8 +436,9 @@ int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const 
                    uint8_t* changed_groups_out);
 
 /* The single-chain step with the proposal in delta form (see sbe_step_batch_delta below): moved objects + their new
- * cluster (-1: none), changed source rows (each object once).  Falls back to sbe_step internally when the two slots'
- * records do not allow patching.  Outputs as sbe_step. */
+ * cluster (-1: none), changed source rows.  Falls back to sbe_step internally when the two slots' records do not allow
+ * patching, and when an object is listed more than once in either list (the last entry of a repeated object wins, as in
+ * the matrix form).  Outputs as sbe_step. */
 int sbe_step_delta(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* moved_objects, const int32_t* moved_cluster,
                    int n_moved, const int32_t* changed_objects, int n_changed, const uint8_t* source_rows /* [n_changed][F][C] bool */,
                    const float* weights /* [F][C] or NULL */, double* group_logliks_out /* [G_total] */, double* mixture_out,
@@ -443,7 +446,9 @@ int sbe_step_delta(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* mo
 
 /* The same batched step with the proposals in DELTA form (round 3; what an MCMC operator actually produces): per chain
  * the objects that change cluster with their new cluster index (-1: leaves every cluster; CSR by moved_ptr) and the
- * objects whose source rows change, each listed once (CSR by rows_ptr).  A chain's two slots differ only in what its last
+ * objects whose source rows change (CSR by rows_ptr).  Within a chain every object may be listed ONCE in moved_objects
+ * and ONCE in changed_objects: a repeated entry fails with SBE_ERR_ARG ("chain i: object n listed twice in ...") -- a
+ * patch applied twice is not the last-wins result of the matrix form.  A chain's two slots differ only in what its last
  * step changed, so the candidate is built by patching -- host mirror, device id arrays, source rows -- in O(delta): no
  * [K][N] matrix is scanned, no slot state copied, no [N]-sized array packed or sent.  Chains whose slots were touched
  * by another call since their last step (or that step for the first time), and steps that change the SET of

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from .engine import GroupOverlapError
 from .registry import get_engine
 
 
@@ -34,7 +35,15 @@ def recalculate_feature_counts(features, sample):
     n_groups = [int(np.shape(sample.clusters.value)[0])] + [int(np.shape(sample.confounders[k].group_assignment)[0])
                                                            for k in names[1:]]
     eng = get_engine(features, n_groups)
-    for name, table in zip(names, recount_bound(eng, sample)):
+    try:
+        tables = recount_bound(eng, sample)
+    except GroupOverlapError:
+        # an object in several groups of one component has no resident form (one group id per object and component);
+        # the reference counts it once per group (counts.py:28-30), and so does the stateless device histogram
+        groups = [sample.clusters.value] + [sample.confounders[k].group_assignment for k in names[1:]]
+        source = sample.source.value
+        tables = [eng.effect_counts(groups[c], source[..., c]) for c in range(len(names))]
+    for name, table in zip(names, tables):
         sample.feature_counts[name].set_value(table)
     return sample.feature_counts
 
@@ -47,9 +56,13 @@ def _subset_indices(object_subset, n_objects):
 
 
 def _group_ids(groups, objs, offset):
-    """Global group index of each listed object in one component (-1: in no group)."""
+    """Global group index of each listed object in one component (-1: in no group); None when a listed object is in
+    several groups (no single id: the caller counts through the stateless per-group form)."""
     sub = np.asarray(groups)[:, objs]
-    return np.where(sub.any(axis=0), sub.argmax(axis=0) + offset, -1).astype(np.int32)
+    k = np.count_nonzero(sub, axis=0)                 # groups each listed object is in
+    if k.size and k.max() > 1:
+        return None
+    return np.where(k > 0, sub.argmax(axis=0) + offset, -1).astype(np.int32)
 
 
 def _source_ids(source_rows):
@@ -70,14 +83,18 @@ def update_feature_counts(sample_old, sample_new, features, object_subset):
     eng = get_engine(features, n_groups)
     objs = _subset_indices(object_subset, np.shape(features)[0])
     off = np.concatenate([[0], np.cumsum(n_groups)]).astype(int)
-    if len(np.unique(objs)) != len(objs):          # (the reference's fancy index would count a repeated object twice)
+    unique = len(np.unique(objs)) == len(objs)     # (the reference's fancy index would count a repeated object twice)
+    gid_old = [_group_ids(groups_old[c], objs, off[c]) for c in range(len(names))] if unique else None
+    gid_new = [_group_ids(groups_new[c], objs, off[c]) for c in range(len(names))] if unique else None
+    if not unique or any(g is None for g in gid_old) or any(g is None for g in gid_new):
+        # repeated objects, or a listed object in several groups of one component (counted once per group,
+        # counts.py:28-30): the reference's own two-count difference, each count by the stateless device histogram
         for i, name in enumerate(names):
             old = compute_effect_counts(features, groups_old[i], sample_old.source.value[..., i], object_subset)
             new = compute_effect_counts(features, groups_new[i], sample_new.source.value[..., i], object_subset)
             counts[name].add_changes(diff=new - old)
         return counts
-    gid_old = np.stack([_group_ids(groups_old[c], objs, off[c]) for c in range(len(names))])
-    gid_new = np.stack([_group_ids(groups_new[c], objs, off[c]) for c in range(len(names))])
+    gid_old, gid_new = np.stack(gid_old), np.stack(gid_new)
     touched, rows = eng.counts_delta(objs, gid_old, gid_new, _source_ids(sample_old.source.value[objs]),
                                      _source_ids(sample_new.source.value[objs]))
     for c, name in enumerate(names):

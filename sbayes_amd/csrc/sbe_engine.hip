@@ -150,6 +150,10 @@ struct sbe_engine {
     int opt_step_derive = 0;       // SBE_OPT_STEP_DERIVE: 1 = always re-derive patterns / tuples from all objects
     int opt_deferred = 0;          // SBE_OPT_DEFERRED_CHECKS: data checks reported at the next sync
     bool status_pending = false;
+    // deferred data checks: which entry points enqueued a kernel that may have raised one since the last report
+    // (the report is delivered by a LATER call: its message names where the data came in)
+    const char* pending_origin[2] = {nullptr, nullptr};      // [0] normalize (tables), [1] one-hot source; most recent caller
+    int pending_calls = 0;
     std::vector<Slot> slots;
     // One-call steps: which rows of a slot's source array differ from its partner slot's (round 3).  A chain's two
     // slots hold the same source except for the rows the LAST step changed (accepted: the old current slot lacks them;
@@ -432,22 +436,37 @@ int fetch_and_clear_status(sbe_engine* e) {
     return SBE_OK;
 }
 
-int report_status(sbe_engine* e) {        // after a stream synchronisation
+int report_status(sbe_engine* e, bool deferred = false) {        // after a stream synchronisation
+    const int n_calls = e->pending_calls;
+    const char* origin[2] = {e->pending_origin[0], e->pending_origin[1]};
+    e->pending_calls = 0;
+    e->pending_origin[0] = e->pending_origin[1] = nullptr;
     if (!status_raised(e)) return SBE_OK;
     int rc = fetch_and_clear_status(e);
     if (rc) return rc;
     const int bad_norm = e->h_status[ST_BAD_NORMALIZE], multi_src = e->h_status[ST_MULTI_SOURCE];
     e->h_status[ST_BAD_NORMALIZE] = e->h_status[ST_MULTI_SOURCE] = 0;
+    // a deferred report surfaces in a later call than the one that supplied the data: say so, and say which
+    char where[200] = "";
+    const char* who = origin[bad_norm ? 0 : 1];
+    if (deferred && who)
+        snprintf(where, sizeof where, " [deferred data check: raised by %s (%d state-setting call%s queued since the last report), "
+                 "reported by the first call that waited for the device]", who, n_calls, n_calls == 1 ? "" : "s");
     if (bad_norm)
-        return fail(e, SBE_ERR_DATA, "normalize: %d rows have a non-positive sum (sbayes/util.py:1006 assert)", bad_norm);
-    return fail(e, SBE_ERR_DATA, "source is not one-hot over components in %d observations", multi_src);
+        return fail(e, SBE_ERR_DATA, "normalize: %d rows have a non-positive sum (sbayes/util.py:1006 assert)%s", bad_norm, where);
+    return fail(e, SBE_ERR_DATA, "source is not one-hot over components in %d observations%s", multi_src, where);
 }
 
 // Data checks raised by kernels (normalize's positive-sum assert, one-hot source).  Immediate mode: synchronize and
 // report now.  Deferred mode (SBE_OPT_DEFERRED_CHECKS): nothing is enqueued; the next call that synchronizes anyway
 // looks at the flag words and reports.
-int check_after(sbe_engine* e) {          // after enqueuing a kernel that may raise a data check
-    if (e->opt_deferred) { e->status_pending = true; return SBE_OK; }
+int check_after(sbe_engine* e, int word, const char* who = __builtin_FUNCTION()) {   // after enqueuing a kernel that may raise a data check
+    if (e->opt_deferred) {
+        e->status_pending = true;
+        e->pending_origin[word == ST_BAD_NORMALIZE ? 0 : 1] = who;
+        ++e->pending_calls;
+        return SBE_OK;
+    }
     HIPCHK(e, hipStreamSynchronize(e->stream));
     e->status_pending = false;
     return report_status(e);
@@ -456,7 +475,7 @@ int check_after(sbe_engine* e) {          // after enqueuing a kernel that may r
 int synced(sbe_engine* e) {               // call right after any hipStreamSynchronize in a result path
     if (!e->status_pending) return SBE_OK;
     e->status_pending = false;
-    return report_status(e);
+    return report_status(e, true);
 }
 
 // Synchronize; deliver a deferred report; then leave THIS call's counts in h_status (zeros when nothing was raised)
@@ -1558,7 +1577,7 @@ int sbe_set_source(sbe_engine* e, int slot, const uint8_t* source) {
     HIPCHK(e, hipGetLastError());
     bump_src(e, slot);
     e->slots[slot].source_set = true;
-    return check_after(e);
+    return check_after(e, ST_MULTI_SOURCE);
 }
 
 int sbe_set_source_rows(sbe_engine* e, int slot, const int32_t* objects, int n_rows, const uint8_t* rows) {
@@ -1584,7 +1603,7 @@ int sbe_set_source_rows(sbe_engine* e, int slot, const int32_t* objects, int n_r
         (const uint8_t*)v_rows, (const int32_t*)v_obj, e->d_src + (int64_t)slot * e->N * e->Fp, n_rows, e->F, e->C, e->Fp, e->d_status);
     HIPCHK(e, hipGetLastError());
     bump_src(e, slot);
-    return check_after(e);
+    return check_after(e, ST_MULTI_SOURCE);
 }
 
 int sbe_get_source_rows(sbe_engine* e, int slot, const int32_t* objects, int n_rows, uint8_t* rows_out) {
@@ -1762,7 +1781,7 @@ int sbe_update_probs_mask(sbe_engine* e, int slot, unsigned component_mask, doub
             e->d_probs_t + (int64_t)slot * e->probs_t_elems(), e->Gtot, e->ft);   // (+ the tile-transposed copy: one launch)
         HIPCHK(e, hipGetLastError());
     }
-    return check_after(e);
+    return check_after(e, ST_BAD_NORMALIZE);
 }
 
 int sbe_update_probs(sbe_engine* e, int slot, int component, double temperature, double prior_temperature,
@@ -2433,8 +2452,9 @@ namespace {
 // the call's final synchronisation, then the data checks its kernels may have raised (flag words: no read-back)
 int sync_and_report(sbe_engine* e, const DoneSig& done = DoneSig{}) {
     { int rc = wait_done(e, done); if (rc) return rc; }          // (no flag asked for: the runtime's stream wait)
+    const bool was_pending = e->status_pending;
     e->status_pending = false;
-    return report_status(e);
+    return report_status(e, was_pending);
 }
 
 int check_objects(sbe_engine* e, const int32_t* objects, int n) {
@@ -2522,6 +2542,15 @@ int sbe_set_counts_rows(sbe_engine* e, int slot, const int32_t* group_idx, int n
     CHECK_PTR(e, group_idx); CHECK_PTR(e, rows);
     for (int i = 0; i < n_rows; ++i)
         if (group_idx[i] < 0 || group_idx[i] >= e->Gtot) return fail(e, SBE_ERR_ARG, "group index %d out of range [0,%d)", group_idx[i], e->Gtot);
+    // rows PATCH a table: the component's counts must be resident already (sbe_set_counts / sbe_recount / a step),
+    // else the patched rows would sit among uninitialised ones and counts_set would stay false
+    for (int i = 0; i < n_rows; ++i) {
+        int c = 0;
+        while (c + 1 < e->C && group_idx[i] >= e->goff[c + 1]) ++c;
+        if (!e->slots[slot].counts_set[c])
+            return fail(e, SBE_ERR_STATE, "slot %d: counts of component %d not set (sbe_set_counts_rows patches resident tables: "
+                        "send the component whole with sbe_set_counts first); row for group %d refused", slot, c, group_idx[i]);
+    }
     HIPCHK(e, hipSetDevice(e->device));
     const int64_t fs = (int64_t)e->F * e->S;
     const size_t rb = al256((size_t)n_rows * fs * sizeof(float));
@@ -3565,7 +3594,7 @@ int sbe_step_batch_delta(sbe_engine* e, int n_chains, const int32_t* cur_slots, 
     if (rows_ptr[0] != 0 || moved_ptr[0] != 0) return fail(e, SBE_ERR_ARG, "rows_ptr[0] / moved_ptr[0] must be 0");
     {
         std::vector<uint8_t> used(e->n_slots, 0);
-        std::vector<uint32_t> seen(N, 0);
+        std::vector<uint32_t> seen(N, 0), seen_mv(N, 0);
         for (int i = 0; i < n_chains; ++i) {
             const int a = cur_slots[i], b = cand_slots[i];
             if (a < 0 || a >= e->n_slots || b < 0 || b >= e->n_slots || a == b) return fail(e, SBE_ERR_ARG, "chain %d: bad slots (%d, %d)", i, a, b);
@@ -3585,6 +3614,10 @@ int sbe_step_batch_delta(sbe_engine* e, int n_chains, const int32_t* cur_slots, 
                 const int n = moved_objects[k];
                 if (n < 0 || n >= N) return fail(e, SBE_ERR_ARG, "chain %d: moved object index %d out of range", i, n);
                 if (moved_cluster[k] < -1 || moved_cluster[k] >= K) return fail(e, SBE_ERR_ARG, "chain %d: cluster %d out of range [-1,%d)", i, moved_cluster[k], K);
+                // a repeated moved object would be patched twice (pattern counts decremented for a pattern the object
+                // was never in, its count delta added twice) while the matrix form resolves it last-wins: rejected
+                if (seen_mv[n] == (uint32_t)(i + 1)) return fail(e, SBE_ERR_ARG, "chain %d: object %d listed twice in moved_objects", i, n);
+                seen_mv[n] = (uint32_t)(i + 1);
             }
             const Slot& cur = e->slots[a];
             if (!cur.groups_set || !cur.source_set || !cur.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", a);
@@ -3767,11 +3800,18 @@ int sbe_step_delta(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* mo
     const int N = e->N, C = e->C, K = e->G[0];
     if (n_moved < 0 || n_moved > N || (n_moved > 0 && (!moved_objects || !moved_cluster))) return fail(e, SBE_ERR_ARG, "moved_objects / moved_cluster missing for n_moved=%d", n_moved);
     if (n_changed < 0 || (n_changed > 0 && (!changed_objects || !source_rows))) return fail(e, SBE_ERR_ARG, "changed_objects / source_rows missing for n_changed=%d", n_changed);
-    for (int i = 0; i < n_moved; ++i) {
-        if (moved_objects[i] < 0 || moved_objects[i] >= N) return fail(e, SBE_ERR_ARG, "moved object index %d out of range", moved_objects[i]);
-        if (moved_cluster[i] < -1 || moved_cluster[i] >= K) return fail(e, SBE_ERR_ARG, "cluster %d out of range [-1,%d)", moved_cluster[i], K);
+    bool dup = false;                  // a repeated object in either list: the matrix form resolves it (last entry wins)
+    {
+        static thread_local std::vector<uint32_t> stamp;
+        static thread_local uint32_t epoch = 0;
+        if ((int)stamp.size() < N || ++epoch == 0) { stamp.assign(N, 0); epoch = 1; }
+        for (int i = 0; i < n_moved; ++i) {
+            if (moved_objects[i] < 0 || moved_objects[i] >= N) return fail(e, SBE_ERR_ARG, "moved object index %d out of range", moved_objects[i]);
+            if (moved_cluster[i] < -1 || moved_cluster[i] >= K) return fail(e, SBE_ERR_ARG, "cluster %d out of range [-1,%d)", moved_cluster[i], K);
+            dup = dup || stamp[moved_objects[i]] == epoch;
+            stamp[moved_objects[i]] = epoch;
+        }
     }
-    bool dup = false;
     for (int i = 0; i < n_changed; ++i) {
         if (changed_objects[i] < 0 || changed_objects[i] >= N) return fail(e, SBE_ERR_ARG, "object index %d out of range", changed_objects[i]);
         for (int j = 0; j < i && !dup && n_changed <= 64; ++j) dup = changed_objects[j] == changed_objects[i];
@@ -3979,7 +4019,7 @@ static int step_general(sbe_engine* e, int cur_slot, int cand_slot, const uint8_
         0, e->Gtot, e->Gtot, e->F, e->S, e->ft, e->n_ftiles);
     HIPCHK(e, hipGetLastError());
     std::fill(e->slots[cand_slot].probs_set.begin(), e->slots[cand_slot].probs_set.end(), 1);
-    rc = check_after(e);
+    rc = check_after(e, ST_BAD_NORMALIZE);
     if (rc) return done(rc);
     // collapsed likelihood of every group (a7/a8) into a device buffer
     k_dcl<int32_t><<<div_up((int64_t)e->Gtot * e->F, 256), 256, 0, e->stream>>>(

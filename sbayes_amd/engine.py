@@ -27,6 +27,13 @@ class EngineError(RuntimeError):
         self.code = code
 
 
+class GroupOverlapError(EngineError):
+    """SBE_ERR_DATA from sbe_set_groups / sbe_step*: an object is in several groups of one component.  Resident slot
+    state keeps one group per object and component; the reference defines such input differently for counts (once per
+    group, counts.py:28-30) and for a1 (last written group wins, likelihood.py:126-130), so it is rejected rather than
+    collapsed.  The drop-in counts / collapsed-likelihood functions catch this and use the stateless device calls."""
+
+
 def _c(a, dtype):
     """C-contiguous view/copy with the exact dtype the ABI expects."""
     a = np.asarray(a)
@@ -119,7 +126,10 @@ class Engine:
         self.n_calls += 1
         if rc != 0:
             msg = self._lib.sbe_last_error(self._h)
-            raise EngineError(rc, msg.decode() if msg else "?")
+            msg = msg.decode() if msg else "?"
+            if rc == 4 and " is in groups " in msg:
+                raise GroupOverlapError(rc, msg)
+            raise EngineError(rc, msg)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -570,7 +580,9 @@ class Engine:
         if gi.shape != (len(tabs), objs.size):
             raise ValueError("group_idx must be [n_components, n_objects_in_subset]")
         out = np.empty((objs.size, self.n_features, len(tabs)), dtype=np.float32)
-        self._check(self._lib.sbe_subset_lh(self._h, self._i(objs), objs.size, len(tabs), self._i(cat), self._i(offsets[:-1].copy()),
+        # (_i hands over a bare address: every array passed must be bound to a name that outlives the call)
+        starts = np.ascontiguousarray(offsets[:-1])
+        self._check(self._lib.sbe_subset_lh(self._h, self._i(objs), objs.size, len(tabs), self._i(cat), self._i(starts),
                                             int(offsets[-1]), self._i(gi), float(temperature), self._o(out)))
         return out
 

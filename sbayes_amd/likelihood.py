@@ -20,6 +20,7 @@ import numpy as np
 from .counts import recalculate_feature_counts
 from . import registry
 from .binding import _bind_slot
+from .engine import GroupOverlapError
 from .registry import get_engine
 
 
@@ -95,7 +96,19 @@ class Likelihood:
         the groups that changed since the slot was last bound (those are the `groups` asked for here), nothing else
         goes up, G_c doubles come back."""
         eng = self.engine
-        _bind_slot(eng, SimpleNamespace(prior=self.prior), sample, slot)
+        try:
+            _bind_slot(eng, SimpleNamespace(prior=self.prior), sample, slot)
+        except GroupOverlapError:
+            # groups that overlap have no resident form; the collapsed likelihood needs none -- it is a function of the
+            # count and concentration tables alone (likelihood.py:65-101): the stateless device call
+            name = sample.component_names[component]
+            counts = np.asarray(sample.feature_counts[name].value)[np.asarray(groups)]
+            if component == 0:
+                conc = np.asarray(self.prior.prior_cluster_effect.concentration_array, dtype=np.float64)
+            else:
+                conc = np.asarray(self.prior.prior_confounding_effects[name].concentration_array(sample),
+                                  dtype=np.float64)[np.asarray(groups)]
+            return eng.dirichlet_logpdf(counts, conc, per_group=True)[1]
         # Likelihood.__call__ asks component after component (likelihood.py:58-63): every component's groups are
         # evaluated by the first request (one launch, one synchronisation) and kept on the slot's bind entry until a
         # count row or a concentration table changes

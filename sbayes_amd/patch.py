@@ -219,15 +219,18 @@ def _install_operator_forms(swap):
         UNCHANGED and hands over `update_weights(sample)` -- here a lazily materialised NormalizedWeights that knows its
         sample: when `source` and the weights are that sample's current ones, the per-feature sums come from the
         sample's RESIDENT state on the device (changed source rows, group ids and F*C weights go up, F floats come
-        back; the [N, F, C] array is never built).  Any other argument combination is served by the reference's own
-        expression on the materialised array.  Installed once, no name is swapped while a proposal runs."""
+        back; the [N, F, C] array is never built).  The engine is the one whose resident NA mask equals `na_features`
+        (registry.engine_for_observations).  Any other argument combination -- and a mask no live engine holds -- is
+        served by the reference's own expression on the materialised array.  Installed once, no name is swapped while a proposal runs."""
         from .binding import _bind_slot
         from .likelihood import NormalizedWeights
         from . import registry
         sample = weights.sample_if_current() if isinstance(weights, NormalizedWeights) else None
         if sample is not None and source is sample.source.value:
-            eng = registry.engine_for_features(np.shape(source)[1])
-            if eng is not None and eng.n_objects == np.shape(source)[0] and eng.n_components == np.shape(source)[2]:
+            # the engine is identified by the NA mask the caller hands over (it decides which observations count):
+            # two datasets of one (N, F, C) shape in one process never share an engine here
+            eng = registry.engine_for_observations(na_features, np.shape(source)[2])
+            if eng is not None:
                 _bind_slot(eng, None, sample, 0, with_source=True)
                 return eng.source_lh_by_feature(0)
         return reference_source_lh(source, np.asarray(weights), na_features)

@@ -118,6 +118,33 @@ def engine_for_features(n_features: int) -> Engine:
     return _ENGINES[key][0]
 
 
+def engine_for_observations(na_features, n_components):
+    """The live engine whose resident feature block has exactly the NA mask `na_features` (bool [N, F]) and
+    `n_components` mixture components, or None.  For calls that receive the NA mask but neither the feature block nor
+    the model (GibbsSampleWeights.source_lh_by_feature(source, weights, na_features), operators.py:677-685): the shape
+    alone does not identify a dataset -- two datasets of one shape differ in which observations count -- so the mask
+    is compared with the engine's own (fetched once per engine; an array object verified once is recognised by
+    identity afterwards, it is kept alive by the entry)."""
+    na = np.asarray(na_features)
+    if na.ndim != 2:
+        return None
+    for eng, ref in _ENGINES.values():
+        if (eng.n_objects, eng.n_features) != na.shape or eng.n_components != n_components:
+            continue
+        if ref is not None and ref() is None:
+            continue
+        seen = getattr(eng, "_na_verified", None)
+        if seen is not None and seen is na:
+            return eng
+        mask = getattr(eng, "_na_host", None)
+        if mask is None:
+            mask = eng._na_host = eng.na_values()
+        if na.dtype == np.bool_ and np.array_equal(mask, na):
+            eng._na_verified = na
+            return eng
+    return None
+
+
 @_proc.on_fork_clear
 def _forget_inherited():
     """In a fork()ed child: the engines in these tables are the parent's (their handles were nulled by

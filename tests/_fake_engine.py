@@ -83,7 +83,14 @@ class FakeEngine:
     def set_groups(self, slot, component, groups):
         self._touch(slot)
         self.calls.append(("set_groups", component))
-        self._slot(slot)["groups"][component] = np.asarray(groups, dtype=bool).copy()
+        g = np.asarray(groups, dtype=bool)
+        multi = np.flatnonzero(g.sum(axis=0) > 1)
+        if multi.size:                  # the real engine's contract (sbe_set_groups): overlap has no resident form
+            from sbayes_amd.engine import GroupOverlapError
+            n = int(multi[0])
+            g1, g2 = (int(v) for v in np.flatnonzero(g[:, n])[:2])
+            raise GroupOverlapError(4, f"object {n} is in groups {g1} and {g2} of component {component}")
+        self._slot(slot)["groups"][component] = g.copy()
 
     def set_concentration(self, component, concentration):
         self._bound.clear()
@@ -302,3 +309,14 @@ def make_get_engine(engines, cls=None):
             engines[key].n_components = len(n_groups)
         return engines[key]
     return get_engine
+
+
+def make_engine_for_observations(engines):
+    """`registry.engine_for_observations` for the tests: the double whose feature block has the NA mask handed over."""
+    def engine_for_observations(na_features, n_components):
+        na = np.asarray(na_features)
+        for e in engines.values():
+            if (e.n_objects, e.n_features) == na.shape and e.n_components == n_components and np.array_equal(e.na_values(), na):
+                return e
+        return None
+    return engine_for_observations

@@ -31,6 +31,9 @@ Every RNG the reference draws from is seeded before a recording -- np.random, ra
 module-level generators sbayes.util.RNG / sbayes.sampling.initializers.RNG (set in place) -- so re-running this
 script regenerates every fixture bit for bit (tests/test_golden_reproducible_cpu.py checks test_files).
   known_answers.json  hand-derivable cases from the reference's commented-out test
+  overlap.npz         objects in several groups of one component: the reference's a1 (last written group
+                      wins, in changed_groups order), a9 (counted once per group), recount / delta counts / collapsed
+                      likelihood of a sample whose third component has overlapping groups
   gibbs_source.npz    GibbsSampleSource._propose on south_america with pinned subsets and uniforms
                       (python tests/golden/make_golden.py gibbs_source regenerates only this one)
 """
@@ -656,6 +659,96 @@ def known_answers():
 
 
 # ----------------------------------------------------------------------------------------
+# overlapping groups: an object in several groups of one component.
+# The reference counts it once per group (counts.py:28-30) and lets the LAST WRITTEN group win in a1
+# (likelihood.py:126-130, in the order `changed_groups` lists them); sBayes never produces such input
+# itself, but both functions define it.  Every array below is the reference's own output.
+# ----------------------------------------------------------------------------------------
+def overlap_fixture():
+    from sbayes_amd.synthetic import Workload
+    base = make_workload("cfg1")
+    n, f, s = base.shape
+    rng = np.random.default_rng(77)
+    G = 4
+    ov = rng.random((G, n)) < 0.35                       # bool [G, N]: ~1.4 groups per object on average
+    ov[:, :4] = False                                    # objects 0..3: in no group
+    ov[:, 4] = True                                      # object 4: in all four
+    ov[:, 5] = [True, False, True, False]                # object 5: in groups 0 and 2
+    ov[:, 6] = [False, True, False, True]                # object 6: in groups 1 and 3
+    assert (ov.sum(axis=0) > 1).sum() >= 10 and (ov.sum(axis=0) == 0).sum() >= 4
+    arrs = dict(groups=ov)
+    # ---- a1 on raw arrays ----
+    probs = normalize(rng.integers(0, 6, size=(G, f, s)).astype(np.float32) + base.states_per_feature, axis=-1)
+    arrs["probs"] = probs
+    sentinel = rng.random((n, f, 2))
+    arrs["a1_before"] = sentinel
+    for tag, changed in (("all", np.arange(G)), ("rev", np.arange(G)[::-1].copy()), ("c20", np.array([2, 0])),
+                         ("c02", np.array([0, 2])), ("c1", np.array([1])), ("none", np.zeros(0, dtype=np.int64))):
+        buf = sentinel.copy()
+        compute_component_likelihood(features=base.features, probs=probs, groups=ov,
+                                     changed_groups=changed.astype(np.int64), out=buf[..., 1])
+        arrs[f"a1_changed_{tag}"] = changed.astype(np.int64)
+        arrs[f"a1_after_{tag}"] = buf
+    # ---- a9 on raw arrays ----
+    src = base.source[..., 1]                            # any bool [N, F] selector will do
+    subset_idx = np.sort(rng.choice(n, size=17, replace=False))
+    subset_idx[:3] = [4, 5, 6]                           # (the multi-group objects are in it)
+    subset_idx = np.unique(subset_idx)
+    subset_mask = np.zeros(n, dtype=bool)
+    subset_mask[subset_idx] = True
+    arrs["subset_idx"] = subset_idx
+    arrs["counts_full"] = compute_effect_counts(base.features, ov, src)
+    arrs["counts_subset_idx"] = compute_effect_counts(base.features, ov, src, subset_idx)
+    arrs["counts_subset_mask"] = compute_effect_counts(base.features, ov, src, subset_mask)
+    assert arrs["counts_full"].sum() > src[base.features.any(axis=-1)].sum() * 0      # (shape check only)
+    # ---- sample level: a third component whose groups overlap ----
+    groups = [base.groups[0], base.groups[1], ov]
+    names = ["clusters", "universal", "overlapping"]
+    unif = base.states_per_feature.astype(np.float64)
+    conc = [unif.copy(), np.broadcast_to(unif, (1,) + unif.shape).copy(),
+            (np.broadcast_to(unif, (G,) + unif.shape) * rng.integers(1, 4, size=(G, 1, 1))).astype(np.float64)]
+    weights = rng.dirichlet(np.ones(3), size=f).astype(np.float32)
+    has = np.stack([g.any(axis=0) for g in groups], axis=1)
+    pick = np.stack([[rng.choice(np.flatnonzero(has[o])) for _ in range(f)] for o in range(n)])
+    source = np.eye(3, dtype=bool)[pick]
+    source[base.na_values] = False
+    wl = Workload(name="overlap", features=base.features, states_per_feature=base.states_per_feature,
+                  component_names=names, groups=groups, concentration=conc, weights=weights, source=source)
+    model, sample = reference_objects(wl)                # (recalculate_feature_counts ran: counted once per group)
+    arrs.update(weights=weights, source=source, conc_2=conc[2])
+    for i, k in enumerate(names):
+        arrs[f"sample_counts_{i}"] = sample.feature_counts[k].value.copy()
+    n_in_overlap = int((source[..., 2] & base.features.any(axis=-1))[ov.sum(axis=0) > 1].sum())
+    assert arrs["sample_counts_2"].sum() > (source[..., 2] & base.features.any(axis=-1)).sum() and n_in_overlap > 0
+    collapsed = float(model.likelihood(sample, caching=False))
+    arrs["group_lh_2"] = sample.cache.group_likelihoods["overlapping"].value.copy()
+    lh = likelihood_per_component(model, sample, caching=False).copy()
+    arrs["lh_per_component"] = lh
+    w = update_weights(sample, caching=False).copy()
+    with np.errstate(divide="ignore"):
+        mixture_ll = float(np.log(np.sum(w * lh, axis=-1))[~base.na_values].sum())
+    # delta counts with the multi-group objects in the subset
+    new = sample.copy()
+    with new.source.edit() as srcs:
+        for o in subset_idx:
+            allowed = np.flatnonzero(has[o])
+            srcs[o] = np.eye(3, dtype=bool)[rng.choice(allowed, size=f)]
+            srcs[o][base.na_values[o]] = False
+    update_feature_counts(sample, new, base.features, subset_idx)
+    arrs["delta_source_new"] = new.source.value.copy()
+    for i, k in enumerate(names):
+        arrs[f"delta_counts_{i}"] = new.feature_counts[k].value.copy()
+    chk = new.copy()
+    recalculate_feature_counts(base.features, chk)
+    for i, k in enumerate(names):
+        assert np.array_equal(chk.feature_counts[k].value, arrs[f"delta_counts_{i}"])
+    meta = dict(collapsed_ll=collapsed, mixture_ll=mixture_ll, component_names=names,
+                note="features / clusters / universal group = make_workload('cfg1'); everything else is in this file")
+    np.savez_compressed(OUT / "overlap.npz", meta=json.dumps(meta), **arrs)
+    print("[golden] overlap.npz", {k: v.shape for k, v in arrs.items() if k.startswith("counts") or k.startswith("a1_after")})
+
+
+# ----------------------------------------------------------------------------------------
 # boundary types (a11): a scripted edit sequence on the REFERENCE's Sample / CacheNode classes;
 # the recorded version counters, group versions and what_changed() answers pin the mirror in
 # sbayes_amd/state.py (tests/test_state_cpu.py replays the same script on it).
@@ -801,7 +894,7 @@ def call_log_fixture(tag, config_path: Path, n_steps: int, seed: int):
     from sbayes.sampling.mcmc_chain import MCMCChain
     from sbayes_amd import conditionals, counts, likelihood, patch, registry
     from tests._call_log import RecordingEngine, save
-    from tests._fake_engine import make_get_engine
+    from tests._fake_engine import make_engine_for_observations, make_get_engine
 
     engines = {}
 
@@ -815,7 +908,8 @@ def call_log_fixture(tag, config_path: Path, n_steps: int, seed: int):
         return get_engine(feats_ref(), n_groups)
 
     patches = [mock.patch.object(mod, "get_engine", get_engine) for mod in (registry, likelihood, conditionals, counts)]
-    patches += [mock.patch.object(registry, "_ENGINES", {}), mock.patch.object(registry, "engine_for_features", engine_for_features)]
+    patches += [mock.patch.object(registry, "_ENGINES", {}), mock.patch.object(registry, "engine_for_features", engine_for_features),
+                mock.patch.object(registry, "engine_for_observations", make_engine_for_observations(engines))]
     for p in patches:
         p.start()
     patch.install(operators=True)
@@ -878,12 +972,13 @@ def main():
               "headline_trace": lambda: synthetic_trace_fixture("headline", 300, 12),
               "test_files": lambda: real_fixture("test_files", stage_config(Path("/root/reference/test/test_files"), "test_files") / "config.yaml", 300, 321),
               "south_america": lambda: real_fixture("south_america", stage_config(Path("/root/reference/experiments/south_america"), "south_america") / "config.yaml", 400, 123),
-              "call_logs": call_log_fixtures}
+              "call_logs": call_log_fixtures, "overlap": overlap_fixture}
     if only:
         for name in only:
             single[name]()
         return
     known_answers()
+    overlap_fixture()
     state_fixture()
     synthetic_fixture("cfg1", full=True)
     synthetic_fixture("headline", full=False)

@@ -61,3 +61,36 @@ def test_engine_without_gpu_raises():
         pytest.skip("a GPU is present")
     with pytest.raises(EngineError, match="no CPU fallback"):
         Engine(np.zeros((4, 3, 2), dtype=bool), n_groups=[1], n_slots=1)
+
+
+@pytest.mark.parametrize("shape,n_groups,text", [
+    ((2, 2, 255), [1], r"n_states=255 unsupported \(1\.\.254; state index is one byte, 0xFF = NA\)"),
+    ((2, 2, 2), [1] * 9, r"n_components=9 unsupported \(1\.\.8\)"),
+    ((2, 2, 2), [40000, 25535], r"65535 groups in total exceed the 16-bit group index"),
+    ((2, 2, 2), [2, -1], r"component 1 has -1 groups"),
+    ((2, 2, 2), [0, 0], r"no component has any group"),
+])
+def test_engine_limits_the_reference_does_not_have_are_reported_by_name(shape, n_groups, text):
+    """n_states <= 254, n_components <= 8, G_total <= 65534 (u8 state ids with 0xFF = NA, 8-bit has_components patterns,
+    u16 group ids with 0xFFFF = none): fine for every BASELINE config, absent from the reference -- a dataset beyond
+    them fails at sbe_create with the limit in the message, before the device is touched (VERDICT r3 missing #5)."""
+    from sbayes_amd.engine import Engine, EngineError
+    with pytest.raises(EngineError, match=text) as info:
+        Engine(np.zeros(shape, dtype=bool), n_groups)
+    assert info.value.code == 1
+
+
+def test_every_array_handed_to_the_library_is_bound_to_a_name():
+    """Engine._i / _o pass a bare address (no ctypes helper object keeps the array alive): the argument must be a plain
+    local name, never an expression whose temporary dies before the library reads it (engine.py subset_lh)."""
+    import ast
+    import inspect
+    from sbayes_amd import engine
+    tree = ast.parse(inspect.getsource(engine))
+    bad = []
+    for node in ast.walk(tree):
+        if (isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr in ("_i", "_o")
+                and isinstance(node.func.value, ast.Name) and node.func.value.id == "self"):
+            if len(node.args) != 1 or not isinstance(node.args[0], ast.Name):
+                bad.append((node.lineno, ast.unparse(node)))
+    assert not bad, bad

@@ -10,7 +10,7 @@ import pytest
 from sbayes_amd import conditionals, likelihood, registry
 from sbayes_amd import model as sbm
 from sbayes_amd.counts import recalculate_feature_counts, update_feature_counts
-from tests._fake_engine import FakeEngine, make_get_engine
+from tests._fake_engine import make_engine_for_observations, FakeEngine, make_get_engine
 from tests._fixtures import load_npz, load_synthetic_trace, load_trace, sha
 
 
@@ -28,6 +28,7 @@ def fake(monkeypatch):
     monkeypatch.setattr(registry, "engine_for_features",
                         lambda f: next((e for e in engines.values() if e.n_features == f), None)
                         or FakeEngine(np.zeros((1, f, 1), dtype=bool)))
+    monkeypatch.setattr(registry, "engine_for_observations", make_engine_for_observations(engines))
     return engines
 
 

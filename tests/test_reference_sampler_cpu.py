@@ -34,7 +34,7 @@ def run_chain(config_src: Path, tag: str, n_steps: int, seed: int, patched: bool
     from sbayes.sampling.mcmc_chain import MCMCChain
 
     from sbayes_amd import conditionals, counts, likelihood, patch, registry
-    from tests._fake_engine import FakeEngine, make_get_engine
+    from tests._fake_engine import FakeEngine, make_engine_for_observations, make_get_engine
 
     work = tmp_path / f"{tag}_{'patched' if patched else 'plain'}{'_ops' if operators else ''}"
     shutil.copytree(config_src, work)
@@ -49,6 +49,7 @@ def run_chain(config_src: Path, tag: str, n_steps: int, seed: int, patched: bool
         monkeypatch.setattr(registry, "engine_for_features",
                             lambda f: next((e for e in engines.values() if e.n_features == f), None)
                             or FakeEngine(np.zeros((1, f, 1), dtype=bool)))
+        monkeypatch.setattr(registry, "engine_for_observations", make_engine_for_observations(engines))
         patch.install(operators=operators)
     try:
         np.random.seed(seed)
