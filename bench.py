@@ -48,7 +48,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 N_SIMDS = 1024             # 256 CUs x 4 SIMD-32
 HEADLINE_BATCH = 2048      # resident states per launch sequence (tools/summarize_profiles.py keys the PMC passes on it)
 NOMINAL_CLOCK_GHZ = 2.4    # MI355X_MICROARCH.md "Max clock"
-PMC_FILE = "profiles/r3/pmc_summary.json"
+PMC_FILE = "profiles/r4/pmc_summary.json"
 TRAFFIC_FILE = "profiles/traffic_latest.json"
 
 
@@ -436,33 +436,75 @@ def sampler_replay_block(device, with_cpu):
     bytes that crossed the C ABI per step (counted in Engine)."""
     from tools.replay_bench import run
     out = {}
+    residual = {}
+    try:                                                  # tools/host_residual.py, build container (static, labelled)
+        residual = json.loads((REPO / "tests" / "golden" / "host_residual.json").read_text())
+    except Exception:
+        pass
+    survey_steps_per_s = {"cfg1": 417, "south_america": 300, "headline": 26}       # SURVEY.md section 6 (survey container)
     for tag in ("cfg1", "south_america", "headline"):
         try:
             out[tag] = run(tag, cpu=with_cpu, repeats=3, device=device)
         except FileNotFoundError as exc:                 # a fixture that was not shipped
             out[tag] = {"error": str(exc)}
-    out["note"] = ("per recorded MCMC step of the real sampler: engine-side cost only (the reference's own Python -- proposal "
-                   "logic, RNG, cache bookkeeping -- is the same on both sides and not in either figure); cpu_us_per_step = "
-                   "the same call sequence served by the NumPy oracle on this host, single thread; reference sampler as a "
-                   "whole: 26 steps/s at the headline shape (SURVEY.md section 6)")
+            continue
+        r = residual.get("shapes", {}).get(tag)
+        if r:
+            host_us = r["host_python_us_per_step"]["mean"]
+            gpu_us = out[tag]["gpu_us_per_step"]
+            out[tag].update(
+                host_python_us_per_step=host_us,
+                host_layer_us_per_step=r["of_which_this_packages_host_layer_us_per_step"]["mean"],
+                end_to_end_steps_per_s_bound=round(1e6 / (host_us + gpu_us), 1),
+                limiter="reference's Python" if host_us - r["of_which_this_packages_host_layer_us_per_step"]["mean"] > gpu_us else "engine",
+                reference_steps_per_s={"same_container_as_host_python": r["plain_reference_steps_per_s"],
+                                       "survey_section_6": survey_steps_per_s[tag]},
+                end_to_end_speedup_bound=round(1e6 / (host_us + gpu_us) / r["plain_reference_steps_per_s"], 2))
+    out["note"] = ("per recorded MCMC step of the real sampler.  gpu_us_per_step: engine-side cost measured in this run (the "
+                   "recorded engine calls replayed against the device); cpu_us_per_step: the same call sequence served by the "
+                   "NumPy oracle on this host, single thread.  host_python_us_per_step (STATIC, tests/golden/host_residual.json, "
+                   "measured in the build container by tools/host_residual.py -- the reference cannot run on the GPU box): wall "
+                   "time of the real sampler's MCMC step when every engine call returns a recorded result in O(1) = the "
+                   "reference's own Python (proposal logic, RNG, cache bookkeeping, priors) plus host_layer_us_per_step of this "
+                   "package's host layer.  end_to_end_steps_per_s_bound = 1e6 / (host_python_us_per_step + gpu_us_per_step): "
+                   "what the patched sampler can reach; reference_steps_per_s: the unpatched reference (NumPy path).")
     return out
 
 
-def static_profile_figures(workload, kernel, B, kern_us):
+def static_profile_figures(workload, kernel, B, kern_us, kernel_name=None, results_sha1=None):
     """STATIC figures from the committed rocprofv3 PMC passes (never measured in this run): the HBM traffic per launch
-    and the VALU roofline of the dominant kernel.  Each carries the file it was read from."""
-    traffic, valu = None, None
+    and the VALU roofline of the dominant kernel.  Each carries the file it was read from AND is self-checking: the
+    profile records the dominant kernel's name and the digest of the profiled run's results (tools/summarize_profiles.py);
+    a figure whose identity differs from THIS run's (`sbe_last_mixture_kernel`, `results_sha1`) -- a kernel was changed
+    and tools/profile_gpu.sh not re-run -- is withheld (None) and the reason returned as `stale`."""
+    traffic, valu, stale = None, None, {}
+
+    def identity_ok(what, rec_kernel, rec_sha):
+        if rec_kernel is None or rec_sha is None:
+            stale[what] = "the committed profile carries no kernel identity (written before round 4): re-run tools/profile_gpu.sh"
+            return False
+        if kernel_name is not None and rec_kernel != kernel_name:
+            stale[what] = f"profiled kernel {rec_kernel!r} != this run's {kernel_name!r}"
+            return False
+        if results_sha1 is not None and rec_sha != results_sha1:
+            stale[what] = f"profiled run's results digest {rec_sha} != this run's {results_sha1}"
+            return False
+        return True
+
     tf = REPO / TRAFFIC_FILE
     if tf.exists():
         try:
             tr = json.loads(tf.read_text())
             key = f"{workload}:{kernel}:{B}"
             if key in tr:
-                traffic = {"bytes_per_launch": tr[key], "source": f"{TRAFFIC_FILE} (static: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE "
-                                                                  "passes of an earlier run of this command)"}
+                rec = tr[key] if isinstance(tr[key], dict) else {"bytes": tr[key]}
+                if identity_ok("traffic", rec.get("kernel"), rec.get("results_sha1")):
+                    traffic = {"bytes_per_launch": rec["bytes"],
+                               "source": f"{TRAFFIC_FILE} (static: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes of an earlier run "
+                                         f"of this command, profile {rec.get('profile')}; kernel name and results digest match this run)"}
         except Exception:
             pass
-    for cand in (PMC_FILE, "profiles/r2/pmc_summary.json"):
+    for cand in (PMC_FILE, "profiles/r3/pmc_summary.json", "profiles/r2/pmc_summary.json"):
         pf = REPO / cand
         if not pf.exists():
             continue
@@ -471,6 +513,8 @@ def static_profile_figures(workload, kernel, B, kern_us):
         except Exception:
             sq = None
         if sq and "SQ_INSTS_VALU" in sq:
+            if not identity_ok("roofline_valu", sq.get("_kernel"), sq.get("_results_sha1")):
+                break
             # a wave64 VALU instruction occupies its SIMD-32 for 2 passes x 2 cycles = 4 cycles when issued back to
             # back by one wave (MI355X_MICROARCH.md, "vector-instruction ISSUE cost"); peak = every SIMD issuing always
             busy = sq["SQ_INSTS_VALU"] * 4.0
@@ -478,10 +522,10 @@ def static_profile_figures(workload, kernel, B, kern_us):
             valu = {"bound": "valu", "unit": "SIMD issue cycles per launch", "achieved": round(busy), "peak": round(avail),
                     "frac": round(busy / avail, 4), "valu_instructions_per_launch": round(sq["SQ_INSTS_VALU"]),
                     "clock_ghz": NOMINAL_CLOCK_GHZ, "kernel_us": round(kern_us, 3),
-                    "source": f"{cand} (static PMC pass: SQ_INSTS_VALU) x 4 cycles / (1024 SIMDs x nominal clock x the "
-                              "kernel time measured in this run)"}
+                    "source": f"{cand} (static PMC pass: SQ_INSTS_VALU; kernel name and results digest match this run) x 4 cycles "
+                              "/ (1024 SIMDs x nominal clock x the kernel time measured in this run)"}
             break
-    return traffic, valu
+    return traffic, valu, stale
 
 
 def main():
@@ -585,7 +629,9 @@ def main():
     packed = not args.kernel.startswith("onehot")
     b_eval = algorithmic_bytes(n_obj, n_feat, n_states, [g.shape[0] for g in wl.groups], n_pat, packed=packed)
     achieved = b_eval * B / (kern_ms * 1e-3) / 1e9
-    traffic, valu = static_profile_figures(args.workload, args.kernel, B, kern_ms * 1e3)
+    results_digest = __import__("hashlib").sha1(np.ascontiguousarray(results).tobytes()).hexdigest()[:16]
+    traffic, valu, stale = static_profile_figures(args.workload, args.kernel, B, kern_ms * 1e3, eng.last_mixture_kernel(),
+                                                  results_digest)
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -645,13 +691,15 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity_rel_err": parity,
-            "results_sha1": __import__("hashlib").sha1(np.ascontiguousarray(results).tobytes()).hexdigest()[:16],   # (rank 0's B results of the last repetition: A/B runs of engine builds must agree on it)
+            "results_sha1": results_digest,   # (rank 0's B results of the last repetition: A/B runs of engine builds must agree on it)
             "device": info["device_name"],
             "dist_backend": chains.backend_name(dist),
             "setup_s": round(t_setup, 2),
         }
         if valu:
             line["roofline_valu"] = valu
+        if stale:
+            line["static_profile_stale"] = stale          # a static figure was withheld: its profile is not of this build
         if cpu:
             line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
         line.update(extra)

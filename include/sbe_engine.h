@@ -328,6 +328,17 @@ int sbe_source_lh_by_feature(sbe_engine* e, int slot, float* out /* [F] */);
  * sbe_jump_lh_resident: sbe_jump_lh with the tempered tables of the source / target cluster and of every confounder
  *     group built on the device from the slot's resident counts (ClusterJump.get_jump_lh, operators.py:1679-1722;
  *     expected_confounder_features :1342-1379).  out float64 [2][n_members]. */
+/* Host helpers of the marshalling for sbe_counts_delta (no device, no engine; return 0 = ok, 1 = a listed object is in
+ * several groups: no single id, -1 = bad argument):
+ * sbe_host_group_ids: ids_out[i] = offset + g for the one row g of `groups` ([n_groups][n_objects] bool, C order) that
+ *     has objects[i] set, -1 if none (group_assignment[:, object_subset], sbayes/sampling/counts.py:21-24).
+ * sbe_host_source_ids: ids_out[i][f] = the component c with source[objects[i]][f][c] set, 0xFF if none
+ *     (source[object_subset, :, c], counts.py:25-27); `source` is [n_objects][F][C] bool, C order. */
+int sbe_host_group_ids(const uint8_t* groups, int n_groups, int64_t n_objects, const int32_t* objects, int n, int offset,
+                       int32_t* ids_out /* [n] */);
+int sbe_host_source_ids(const uint8_t* source, int64_t n_objects, int n_features, int n_components, const int32_t* objects,
+                        int n, uint8_t* ids_out /* [n][F] */);
+
 int sbe_set_uniform_counts(sbe_engine* e, const double* unif_counts /* [F][S] */);
 int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const int32_t* gid_old /* [C][n_subset] */,
                      const int32_t* gid_new, const uint8_t* src_old /* [n_subset][F] */, const uint8_t* src_new,

@@ -93,6 +93,8 @@ PROTOTYPES = {
     "sbe_test_philox": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_subset_lh": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int,
                                  ct.c_void_p, ct.c_double, ct.c_void_p]),
+    "sbe_host_group_ids": (ct.c_int, [ct.c_void_p, ct.c_int, ct.c_int64, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p]),
+    "sbe_host_source_ids": (ct.c_int, [ct.c_void_p, ct.c_int64, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_set_uniform_counts": (ct.c_int, [c_engine_p, ct.c_void_p]),
     "sbe_counts_delta": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p,
                                     ct.c_void_p, ct.c_int, ct.c_void_p]),

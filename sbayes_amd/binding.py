@@ -30,34 +30,53 @@ def _engine(model):
     return get_engine(model.data.features.values, n_groups)
 
 
+_ndarray = np.ndarray
+
+
 def _token(param):
     """(array, version) of a state parameter.  The reference's (and the mirror's) parameters bump `version` on every
     edit -- set_value, set_items, edit(), edit_group(s), set_groups, FeatureCounts.add_changes
     (sbayes/sampling/state.py:34-61, 97-161, 340-350) -- and edit the SAME ndarray in place whenever the parameter is
     not shared with a copy, so array identity alone says nothing; plain arrays (confounder group matrices,
-    concentration tables) have no version and are compared by content."""
+    concentration tables) have no version and are compared by content, or by identity when they are frozen (_same)."""
     value = getattr(param, "value", param)
-    return np.asarray(value), getattr(param, "version", None)
+    if type(value) is not _ndarray:
+        value = np.asarray(value)
+    return value, getattr(param, "version", None)
 
 
 def _same(tok, cached):
     """True if the token `tok` = (array, version) denotes what `cached` = (array, version, private copy) recorded.
     Versioned parameters: same ndarray object AND same version (an in-place edit through the parameter API always
-    bumps the version; a copy-on-write edit always creates a new ndarray).  Unversioned arrays: content equality
-    against the private copy -- identity is never trusted."""
+    bumps the version; a copy-on-write edit always creates a new ndarray).  Unversioned arrays: the SAME ndarray object
+    (kept alive by the entry, so its id cannot be recycled) that owns its data and is read-only cannot have changed in
+    place -- the reference freezes its static concentration tables exactly so (sbayes/model/prior.py:322-323), and the
+    drop-in Likelihood freezes the confounders' group matrices and the cluster prior's tables (likelihood.py
+    `_freeze_static_inputs`); anything else -- a writeable array (dynamic priors rewrite theirs in place,
+    prior.py:325-354), a view -- is compared by content against the private copy."""
     if cached is None:
         return False
     arr, version = tok
     ref, ref_version, copy = cached
     if version is not None and ref_version is not None:
         return arr is ref and version == ref_version
+    if arr is ref and copy is None:                 # (_remember kept no copy: the array was frozen and owned its data)
+        flags = arr.flags
+        if not flags.writeable and flags.owndata:
+            return True
+        return False                                # thawed since: what it holds now is unknown -> re-send
     return copy is not None and arr.shape == copy.shape and arr.dtype == copy.dtype and np.array_equal(arr, copy)
 
 
 def _remember(tok):
     arr, version = tok
     # the ndarray itself is kept alive so that its id cannot be recycled for another array while the entry lives
-    return arr, version, (None if version is not None else arr.copy())
+    if version is not None:
+        return arr, version, None
+    flags = arr.flags
+    if not flags.writeable and flags.owndata:       # frozen: identity is the whole comparison (no copy to keep)
+        return arr, None, None
+    return arr, None, arr.copy()
 
 
 def _changed_rows(new, mirror):
@@ -108,65 +127,103 @@ def _bind_slot(eng, model, sample, slot, with_source=False):
     """Make engine slot `slot` hold `sample`: group ids, counts, weights, optionally the source assignment, and the
     priors' concentration tables.  Only what differs from what the slot holds is sent (module docstring); returns the
     components whose probability tables are stale.  `model=None` binds the state without the priors' tables and
-    without the counts (recount_bound: the counts are about to be recomputed on the device)."""
-    names = sample.component_names
-    C = len(names)
-    groups = [_token(sample.clusters)] + [_token(c.group_assignment) for c in sample.confounders.values()]
-    if model is not None:
-        conc = [_token(model.prior.prior_cluster_effect.concentration_array)] + [
-            _token(model.prior.prior_confounding_effects[k].concentration_array(sample)) for k in names[1:]]
-        counts = [_token(sample.feature_counts[name]) for name in names]
-    else:
-        conc = counts = None
-    weights = _token(sample.weights)
-    source = _token(sample.source) if with_source else None
+    without the counts (recount_bound: the counts are about to be recomputed on the device).
+
+    The common case inside an MCMC step -- the slot already holds this sample, or differs from it in one or two
+    parameters -- costs a handful of identity / version comparisons: nothing is copied, allocated or rebuilt unless a
+    parameter really differs (tools/host_residual.py measures this layer: it is host time of every MCMC step)."""
+    confounders = sample.confounders
+    conf_names = list(confounders)
+    C = 1 + len(conf_names)
     cache = getattr(eng, "_bound", None)
     if cache is None:                               # an engine without a bind cache (test doubles): send everything
+        names = ["clusters", *conf_names]
+        eng.set_groups(slot, 0, np.asarray(sample.clusters.value))
         for c in range(C):
-            eng.set_groups(slot, c, groups[c][0])
+            if c:
+                eng.set_groups(slot, c, np.asarray(confounders[names[c]].group_assignment))
             if model is not None:
-                eng.set_concentration(c, conc[c][0])
-                eng.set_counts(slot, c, counts[c][0])
+                conc_c = model.prior.prior_cluster_effect.concentration_array if c == 0 else \
+                    model.prior.prior_confounding_effects[names[c]].concentration_array(sample)
+                eng.set_concentration(c, np.asarray(conc_c))
+                eng.set_counts(slot, c, np.asarray(sample.feature_counts[names[c]].value))
         if with_source:
-            eng.set_source(slot, source[0])
-        eng.set_weights(slot, weights[0])
+            eng.set_source(slot, np.asarray(sample.source.value))
+        eng.set_weights(slot, np.asarray(sample.weights.value))
         return set(range(C))
-    old = cache.get(slot) or {"groups": [None] * C, "counts": [None] * C, "weights": None, "source": None, "stale": set(range(C))}
+    old = cache.get(slot)
+    if old is None:
+        old = {"groups": [None] * C, "counts": [None] * C, "weights": None, "source": None, "stale": set(range(C)), "lh_all": None}
+    # ---- what differs?  (tokens are built once; nothing is written until something does differ) ----
+    groups = [_token(sample.clusters)]
+    for k in conf_names:
+        groups.append(_token(confounders[k].group_assignment))
+    old_groups, old_counts = old["groups"], old["counts"]
+    groups_changed = [c for c in range(C) if not _same(groups[c], old_groups[c])]
+    conc = counts = None
+    conc_changed = counts_changed = ()
+    if model is not None:
+        prior = model.prior
+        conc = [_token(prior.prior_cluster_effect.concentration_array)]
+        feature_counts = sample.feature_counts
+        counts = [_token(feature_counts["clusters"])]
+        conf_priors = prior.prior_confounding_effects
+        for k in conf_names:
+            conc.append(_token(conf_priors[k].concentration_array(sample)))
+            counts.append(_token(feature_counts[k]))
+        bound_conc = eng._bound_conc
+        conc_changed = [c for c in range(C) if not _same(conc[c], bound_conc.get(c))]
+        counts_changed = [c for c in range(C) if not _same(counts[c], old_counts[c])]
+    weights = _token(sample.weights)
+    weights_changed = not _same(weights, old["weights"])
+    source = None
+    source_changed = False
+    if with_source:
+        source = _token(sample.source)
+        source_changed = not _same(source, old["source"])
+    if not (groups_changed or conc_changed or counts_changed or weights_changed or source_changed):
+        if slot not in cache:                       # (a first bind of an empty state: keep the entry)
+            cache[slot] = old
+        return old["stale"]
+    # ---- send the differences ----
     # the host mirrors of what the slot holds survive the entry being dropped by the engine's own setters as long as
     # those setters are the ones called from here (eng._mirror is cleared by every OTHER slot-changing call: _touch)
-    mirrors = eng._mirror.setdefault(slot, {"counts": [None] * C, "source": None}) if hasattr(eng, "_mirror") else \
-        {"counts": [None] * C, "source": None}
-    new = {"groups": list(old["groups"]), "counts": list(old["counts"]), "weights": old["weights"], "source": old["source"],
+    has_mirror = hasattr(eng, "_mirror")
+    mirrors = eng._mirror.get(slot) if has_mirror else None
+    if mirrors is None:
+        mirrors = {"counts": [None] * C, "source": None}
+    new = {"groups": list(old_groups), "counts": list(old_counts), "weights": old["weights"], "source": old["source"],
            "stale": set(old["stale"]), "lh_all": old.get("lh_all")}
     pending = ([], [])                              # count rows of all components: one set_counts_rows call
-    conc_changed = [] if conc is None else [c for c in range(C) if not _same(conc[c], eng._bound_conc.get(c))]
     for c in conc_changed:                          # (drops every slot's entry: all tables depend on it)
         eng.set_concentration(c, conc[c][0])
     if conc_changed:
         new["stale"] = set(range(C))
         new["lh_all"] = None
-    for c in range(C):
-        if not _same(groups[c], old["groups"][c]):
-            eng.set_groups(slot, c, groups[c][0])
-            new["groups"][c] = _remember(groups[c])
-        if counts is not None and not _same(counts[c], old["counts"][c]):
-            mirrors["counts"][c], changed = _send_counts(eng, slot, c, counts[c][0], mirrors["counts"][c], pending)
-            new["counts"][c] = _remember(counts[c])
-            if changed:
-                new["stale"].add(c)
-                new["lh_all"] = None                # (Likelihood._group_logliks' memo of the collapsed log-likelihoods)
+    for c in groups_changed:
+        eng.set_groups(slot, c, groups[c][0])
+        new["groups"][c] = _remember(groups[c])
+    for c in counts_changed:
+        mirrors["counts"][c], changed = _send_counts(eng, slot, c, counts[c][0], mirrors["counts"][c], pending)
+        new["counts"][c] = _remember(counts[c])
+        if changed:
+            new["stale"].add(c)
+            new["lh_all"] = None                    # (Likelihood._group_logliks' memo of the collapsed log-likelihoods)
     if pending[0]:
-        eng.set_counts_rows(slot, np.concatenate(pending[0]), np.concatenate(pending[1]))
-    if with_source and not _same(source, old["source"]):
+        if len(pending[0]) == 1:
+            eng.set_counts_rows(slot, pending[0][0], pending[1][0])
+        else:
+            eng.set_counts_rows(slot, np.concatenate(pending[0]), np.concatenate(pending[1]))
+    if source_changed:
         mirrors["source"] = _send_source(eng, slot, source[0], mirrors["source"])
         new["source"] = _remember(source)
-    if not _same(weights, old["weights"]):
+    if weights_changed:
         eng.set_weights(slot, weights[0])
         new["weights"] = _remember(weights)
     for c in conc_changed:
         eng._bound_conc[c] = _remember(conc[c])
     cache[slot] = new                               # (the setters above dropped the slot's entry)
-    if hasattr(eng, "_mirror"):
+    if has_mirror:
         eng._mirror[slot] = mirrors                 # (and its mirrors)
     return new["stale"]
 

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from . import _lib
 from .engine import GroupOverlapError
 from .registry import get_engine
 
@@ -55,19 +56,32 @@ def _subset_indices(object_subset, n_objects):
     return np.flatnonzero(subset) if subset.dtype == np.bool_ else subset.astype(np.int64, copy=False).reshape(-1)
 
 
-def _group_ids(groups, objs, offset):
-    """Global group index of each listed object in one component (-1: in no group); None when a listed object is in
-    several groups (no single id: the caller counts through the stateless per-group form)."""
-    sub = np.asarray(groups)[:, objs]
-    k = np.count_nonzero(sub, axis=0)                 # groups each listed object is in
-    if k.size and k.max() > 1:
-        return None
-    return np.where(k > 0, sub.argmax(axis=0) + offset, -1).astype(np.int32)
+def _addr(a):
+    return a.__array_interface__["data"][0]
 
 
-def _source_ids(source_rows):
-    """bool [n, F, C] -> component id per observation (255: none)."""
-    return np.where(source_rows.any(axis=-1), source_rows.argmax(axis=-1), 255).astype(np.uint8)
+def _group_ids(groups, objs, offset, out):
+    """out[:] = global group index of each listed object in one component (-1: in no group), by the library's host
+    helper (one pass, no temporaries); False when a listed object is in several groups (no single id: the caller
+    counts through the stateless per-group form).  `objs` is int32, C-contiguous."""
+    g = groups if type(groups) is np.ndarray else np.asarray(groups)
+    if g.dtype != np.bool_ or not g.flags.c_contiguous:
+        g = np.ascontiguousarray(g, dtype=bool)
+    rc = _lib.load().sbe_host_group_ids(_addr(g), g.shape[0], g.shape[1], _addr(objs), objs.size, int(offset), _addr(out))
+    if rc < 0:
+        raise ValueError("object index out of range in object_subset")
+    return rc == 0
+
+
+def _source_ids(source, objs):
+    """bool [N, F, C] one-hot over components, listed objects -> uint8 [n, F] component id per observation (255: none)."""
+    s = source if type(source) is np.ndarray else np.asarray(source)
+    if s.dtype != np.bool_ or not s.flags.c_contiguous:
+        s = np.ascontiguousarray(s, dtype=bool)
+    out = np.empty((objs.size, s.shape[1]), dtype=np.uint8)
+    if _lib.load().sbe_host_source_ids(_addr(s), s.shape[0], s.shape[1], s.shape[2], _addr(objs), objs.size, _addr(out)) != 0:
+        raise ValueError("object index out of range in object_subset")
+    return out
 
 
 def update_feature_counts(sample_old, sample_new, features, object_subset):
@@ -76,17 +90,29 @@ def update_feature_counts(sample_old, sample_new, features, object_subset):
     bytes), the count rows of the groups those objects are in come back; the reference's `add_changes(diff)` follows
     with the same `diff` it would have computed (zero rows for every other group)."""
     counts = sample_new.feature_counts
-    names = ["clusters", *sample_new.confounders.keys()]
-    groups_old = [sample_old.clusters.value] + [sample_old.confounders[k].group_assignment for k in names[1:]]
-    groups_new = [sample_new.clusters.value] + [sample_new.confounders[k].group_assignment for k in names[1:]]
-    n_groups = [int(np.shape(g)[0]) for g in groups_new]
+    conf_names = list(sample_new.confounders)
+    names = ["clusters", *conf_names]
+    C = len(names)
+    groups_old = [sample_old.clusters.value] + [sample_old.confounders[k].group_assignment for k in conf_names]
+    groups_new = [sample_new.clusters.value] + [sample_new.confounders[k].group_assignment for k in conf_names]
+    n_groups = [g.shape[0] for g in groups_new]
     eng = get_engine(features, n_groups)
-    objs = _subset_indices(object_subset, np.shape(features)[0])
-    off = np.concatenate([[0], np.cumsum(n_groups)]).astype(int)
-    unique = len(np.unique(objs)) == len(objs)     # (the reference's fancy index would count a repeated object twice)
-    gid_old = [_group_ids(groups_old[c], objs, off[c]) for c in range(len(names))] if unique else None
-    gid_new = [_group_ids(groups_new[c], objs, off[c]) for c in range(len(names))] if unique else None
-    if not unique or any(g is None for g in gid_old) or any(g is None for g in gid_new):
+    objs = np.ascontiguousarray(_subset_indices(object_subset, features.shape[0]), dtype=np.int32)
+    n = objs.size
+    off = eng.group_offsets
+    single = n < 2 or len(np.unique(objs)) == n      # (the reference's fancy index would count a repeated object twice)
+    if single:
+        gid_new = np.empty((C, n), dtype=np.int32)
+        gid_old = np.empty((C, n), dtype=np.int32)
+        for c in range(C):
+            single = single and _group_ids(groups_new[c], objs, off[c], gid_new[c])
+            if groups_old[c] is groups_new[c]:       # (every confounder: the same matrix object in both samples)
+                gid_old[c] = gid_new[c]
+            else:
+                single = single and _group_ids(groups_old[c], objs, off[c], gid_old[c])
+            if not single:
+                break
+    if not single:
         # repeated objects, or a listed object in several groups of one component (counted once per group,
         # counts.py:28-30): the reference's own two-count difference, each count by the stateless device histogram
         for i, name in enumerate(names):
@@ -94,12 +120,16 @@ def update_feature_counts(sample_old, sample_new, features, object_subset):
             new = compute_effect_counts(features, groups_new[i], sample_new.source.value[..., i], object_subset)
             counts[name].add_changes(diff=new - old)
         return counts
-    gid_old, gid_new = np.stack(gid_old), np.stack(gid_new)
-    touched, rows = eng.counts_delta(objs, gid_old, gid_new, _source_ids(sample_old.source.value[objs]),
-                                     _source_ids(sample_new.source.value[objs]))
+    src_old, src_new = sample_old.source.value, sample_new.source.value
+    sid_new = _source_ids(src_new, objs)
+    sid_old = sid_new if src_old is src_new else _source_ids(src_old, objs)
+    touched, rows = eng.counts_delta(objs, gid_old, gid_new, sid_old, sid_new)
+    bounds = np.searchsorted(touched, off)           # `touched` is sorted: the rows of component c are bounds[c]:bounds[c+1]
     for c, name in enumerate(names):
-        diff = np.zeros(counts[name].value.shape, dtype=np.float32)
-        mine = (touched >= off[c]) & (touched < off[c + 1])
-        diff[touched[mine] - off[c]] = rows[mine]
-        counts[name].add_changes(diff=diff)
+        node = counts[name]
+        diff = np.zeros(node.value.shape, dtype=np.float32)
+        lo, hi = bounds[c], bounds[c + 1]
+        if hi > lo:
+            diff[touched[lo:hi] - off[c]] = rows[lo:hi]
+        node.add_changes(diff=diff)
     return counts

@@ -1111,6 +1111,46 @@ int sbe_device_count(int* out_count) {
 
 const char* sbe_last_error(const sbe_engine* e) { return e ? e->last_error.c_str() : g_last_error.c_str(); }
 
+// ---- host helpers of the drop-in layer's marshalling (no device, no engine) -----------------------------------------
+// What update_feature_counts hands to sbe_counts_delta is derived from the samples' own arrays: the listed objects'
+// group id per component (group_assignment[:, object_subset], counts.py:21-24) and source component per observation
+// (source[object_subset], counts.py:25-27).  In NumPy that derivation is a dozen small array operations per MCMC step
+// (tools/host_residual.py: the host layer, not the device, bounds the patched sampler); here it is one pass each.
+int sbe_host_group_ids(const uint8_t* groups, int n_groups, int64_t n_objects, const int32_t* objects, int n, int offset,
+                       int32_t* ids_out) {
+    if ((n_groups > 0 && !groups) || (n > 0 && (!objects || !ids_out)) || n_groups < 0 || n < 0) return -1;
+    for (int i = 0; i < n; ++i) {
+        const int64_t o = objects[i];
+        if (o < 0 || o >= n_objects) return -1;
+        int32_t id = -1;
+        for (int g = 0; g < n_groups; ++g)
+            if (groups[(int64_t)g * n_objects + o]) {
+                if (id >= 0) return 1;                 // in several groups: no single id (the caller counts per group)
+                id = offset + g;
+            }
+        ids_out[i] = id;
+    }
+    return 0;
+}
+
+int sbe_host_source_ids(const uint8_t* source, int64_t n_objects, int n_features, int n_components, const int32_t* objects, int n,
+                        uint8_t* ids_out) {
+    if ((n > 0 && (!source || !objects || !ids_out)) || n < 0 || n_features < 0 || n_components < 1 || n_components > 254) return -1;
+    const int64_t row = (int64_t)n_features * n_components;
+    for (int i = 0; i < n; ++i) {
+        const int64_t o = objects[i];
+        if (o < 0 || o >= n_objects) return -1;
+        const uint8_t* src = source + o * row;
+        uint8_t* out = ids_out + (int64_t)i * n_features;
+        for (int f = 0; f < n_features; ++f) {
+            uint8_t id = 0xFF;
+            for (int c = 0; c < n_components; ++c) if (src[(int64_t)f * n_components + c]) { id = (uint8_t)c; break; }   // (first set: argmax)
+            out[f] = id;
+        }
+    }
+    return 0;
+}
+
 int sbe_destroy(sbe_engine* e) {
     if (!e) return SBE_OK;
     (void)hipSetDevice(e->device);

@@ -609,7 +609,10 @@ class Engine:
         sn = np.ascontiguousarray(src_new, dtype=np.uint8)
         if so.shape != (n, self.n_features) or sn.shape != so.shape:
             raise ValueError(f"src_old / src_new must be [{n}, {self.n_features}]")
-        touched = np.union1d(go[go >= 0], gn[gn >= 0]).astype(np.int32)
+        flags = np.zeros(self.n_groups_total + 1, dtype=np.bool_)      # (index -1 = "no group" lands on the spare last entry)
+        flags[go] = True
+        flags[gn] = True
+        touched = np.flatnonzero(flags[:-1]).astype(np.int32)
         diff = np.zeros((touched.size, self.n_features, self.n_states), dtype=np.float32)
         if touched.size and n:
             self._check(self._lib.sbe_counts_delta(self._h, self._i(objs), n, self._i(go), self._i(gn), self._i(so), self._i(sn),

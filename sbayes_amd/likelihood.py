@@ -36,6 +36,9 @@ class Likelihood:
         for i, conf in enumerate(self.confounders, start=1):
             self.source_index[conf] = i
         self._na_features = None
+        self._engine = None
+        self._bind_model = SimpleNamespace(prior=prior)      # what binding._bind_slot reads of a model
+        self._freeze_static_inputs()
         registry.note_features(self.features, self.n_groups)
         # patch.install(operators=True) serves SourcePrior.__call__ (prior.py:573-611) from the device; that method has no
         # way back to the model, so the model's likelihood leaves a note on the prior's SourcePrior instance
@@ -46,11 +49,25 @@ class Likelihood:
             except AttributeError:
                 pass
 
+    def _freeze_static_inputs(self):
+        """Inputs of the path that nothing in the sampler ever writes -- the confounders' group matrices
+        (load_data.py:139-184) and the cluster-effect prior's concentration tables (prior.py:440-455) -- are marked
+        read-only, the way the reference itself freezes its static confounding-effect tables (prior.py:322-323).  The bind
+        cache then recognises them by identity (binding._same) instead of comparing their content on every call, and
+        an in-place write -- which would silently desynchronise the resident copy -- raises instead."""
+        arrays = [getattr(conf, "group_assignment", None) for conf in self.confounders.values()]
+        cluster_prior = getattr(self.prior, "prior_cluster_effect", None)
+        arrays += [getattr(cluster_prior, "concentration_array", None), getattr(cluster_prior, "uniform_concentration_array", None)]
+        for arr in arrays:
+            if type(arr) is np.ndarray and arr.flags.owndata and arr.flags.writeable:
+                arr.setflags(write=False)
+
     # device handles are per process: never pickled, re-created lazily (mcmc_setup.py:299, model.py:53)
     def __getstate__(self):
         from . import patch
         state = dict(self.__dict__)
         state["_na_features"] = None
+        state["_engine"] = None
         state["_sbayes_amd_patch"] = patch.installed()      # how the pickling process had sBayes patched, if at all
         return state
 
@@ -60,6 +77,8 @@ class Likelihood:
         (mcmc_setup.py:299, :554) -- re-install the patch the sender ran under, before the worker builds its chain."""
         how = state.pop("_sbayes_amd_patch", None)
         self.__dict__.update(state)
+        self._engine = None
+        self._freeze_static_inputs()                        # (flags do not travel through pickle)
         if how is not None:
             from . import patch
             if patch.installed() is None or (how["operators"] and not patch.installed()["operators"]):
@@ -72,7 +91,12 @@ class Likelihood:
 
     @property
     def engine(self):
-        return get_engine(self.features, self.n_groups)
+        # the registry lookup (key of the feature block, weak reference, layout check) once per engine: a live handle
+        # created by this process is reused; a closed one (registry.release_all, fork: _proc) is looked up again
+        eng = self.__dict__.get("_engine")
+        if eng is None or not getattr(eng, "_h", True):
+            eng = self._engine = get_engine(self.features, self.n_groups)
+        return eng
 
     @property
     def na_features(self):
@@ -97,7 +121,7 @@ class Likelihood:
         goes up, G_c doubles come back."""
         eng = self.engine
         try:
-            _bind_slot(eng, SimpleNamespace(prior=self.prior), sample, slot)
+            _bind_slot(eng, self._bind_model, sample, slot)
         except GroupOverlapError:
             # groups that overlap have no resident form; the collapsed likelihood needs none -- it is a function of the
             # count and concentration tables alone (likelihood.py:65-101): the stateless device call

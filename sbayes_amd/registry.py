@@ -16,6 +16,7 @@ from . import _proc
 from .engine import Engine
 
 _ENGINES: dict = {}          # per process: emptied in a fork()ed child (_forget_inherited), never shared
+_LAST = [None]               # (feature array object, its engine) of the last get_engine call: identity fast path
 
 
 def _key(features: np.ndarray):
@@ -37,6 +38,13 @@ def _extent(key):
 def get_engine(features, n_groups=None, n_slots=4, device=None) -> Engine:
     """Engine holding `features`; created on first use.  `n_groups` (groups per mixture
     component) sizes the slot state; stateless calls work without it."""
+    # the same array OBJECT as in the last call (the drop-in functions pass data.features.values every time): its
+    # engine, unless that was closed or the caller names another component layout -- no key is built, nothing is hashed
+    last = _LAST[0]
+    if last is not None and last[0] is features:
+        eng = last[1]
+        if getattr(eng, "_h", True) and (n_groups is None or list(n_groups) == eng.n_groups):
+            return eng
     features = np.asarray(features)
     key = _key(features)
     entry = _ENGINES.get(key)
@@ -44,6 +52,7 @@ def get_engine(features, n_groups=None, n_slots=4, device=None) -> Engine:
         eng, ref = entry
         alive = ref() is not None if ref is not None else True
         if alive and (n_groups is None or list(n_groups) == eng.n_groups):
+            _LAST[0] = (features, eng)
             return eng
         eng.close()
         del _ENGINES[key]
@@ -71,6 +80,7 @@ def get_engine(features, n_groups=None, n_slots=4, device=None) -> Engine:
     except TypeError:
         ref = None
     _ENGINES[key] = (eng, ref)
+    _LAST[0] = (features, eng)
     return eng
 
 
@@ -151,6 +161,7 @@ def _forget_inherited():
     _proc._after_fork_in_child, nothing is destroyed); the child starts with an empty registry."""
     _ENGINES.clear()
     _KNOWN.clear()
+    _LAST[0] = None
 
 
 def release_all():
@@ -158,3 +169,4 @@ def release_all():
         eng.close()
     _ENGINES.clear()
     _KNOWN.clear()
+    _LAST[0] = None

@@ -125,7 +125,66 @@ class ReplayEngine:
         return method
 
 
-def _run(config_path: Path, tag: str, n_steps: int, seed: int, mode: str, memo=None):
+class _LayerClock:
+    """Wall time spent inside this package's host layer, outermost entries only: every name patch.install() swapped into
+    the reference (functions, methods, the Likelihood class's __call__) is wrapped by a timer that counts when the
+    nesting depth is zero.  What it measures: binding.py / counts.py / likelihood.py / conditionals.py / operators.py /
+    patch.py Python ABOVE the Engine methods (the double's own time is subtracted by the caller)."""
+
+    def __init__(self):
+        self.depth, self.total, self.undo, self.by_name = 0, 0.0, [], {}
+
+    def wrap(self, fn):
+        clock = self
+        name = getattr(fn, "__name__", "?")
+
+        def timed(*args, **kwargs):
+            if clock.depth:
+                return fn(*args, **kwargs)
+            clock.depth = 1
+            t0 = time.perf_counter()
+            try:
+                return fn(*args, **kwargs)
+            finally:
+                dt = time.perf_counter() - t0
+                clock.total += dt
+                acc = clock.by_name.setdefault(name, [0, 0.0])
+                acc[0] += 1
+                acc[1] += dt
+                clock.depth = 0
+        timed.__name__ = getattr(fn, "__name__", "timed")
+        timed.__wrapped__ = fn
+        return timed
+
+    def install(self):
+        import inspect
+        from sbayes_amd import likelihood as my_lik, patch
+        seen = set()
+        for mod, name, _old in list(patch._SAVED):
+            cur = mod.__dict__[name] if inspect.isclass(mod) and name in mod.__dict__ else getattr(mod, name)
+            if (id(mod), name) in seen:
+                continue
+            seen.add((id(mod), name))
+            if inspect.isclass(cur):
+                continue                                             # (the Likelihood class: its __call__ below)
+            if isinstance(cur, staticmethod):
+                new = staticmethod(self.wrap(cur.__func__))
+            else:
+                new = self.wrap(cur)
+            setattr(mod, name, new)
+            self.undo.append((mod, name, cur))
+        for name in ("__call__", "compute_lh_clusters", "compute_lh_confounder"):
+            cur = my_lik.Likelihood.__dict__[name]
+            setattr(my_lik.Likelihood, name, self.wrap(cur))
+            self.undo.append((my_lik.Likelihood, name, cur))
+
+    def remove(self):
+        while self.undo:
+            mod, name, cur = self.undo.pop()
+            setattr(mod, name, cur)
+
+
+def _run(config_path: Path, tag: str, n_steps: int, seed: int, mode: str, memo=None, layer_clock=False):
     """mode: 'memo' (pass 1), 'replay' (pass 2), 'plain' (unpatched reference).  Returns (per-step seconds, operator
     names, engine)."""
     from sbayes.experiment_setup import Experiment
@@ -166,6 +225,10 @@ def _run(config_path: Path, tag: str, n_steps: int, seed: int, mode: str, memo=N
         for p in patches:
             p.start()
         patch.install(operators=True)
+    clock = None
+    if layer_clock and mode == "replay":
+        clock = _LayerClock()
+        clock.install()
     cwd = os.getcwd()
     try:
         mg.seed_reference(seed)
@@ -183,26 +246,33 @@ def _run(config_path: Path, tag: str, n_steps: int, seed: int, mode: str, memo=N
         chain._ll = chain.likelihood(sample)
         chain._prior = chain.prior(sample)
         eng = next(iter(engines.values())) if engines else None
-        secs, inside, ops = [], [], []
+        secs, inside, ops, layer = [], [], [], []
         gc.collect()
         gc.disable()
         try:
             for i in range(1, n_steps + 1):
                 in0 = eng.inside if mode == "replay" else 0.0
+                lay0 = clock.total if clock is not None else 0.0
                 t0 = time.perf_counter()
                 sample = chain.step(sample)
                 t1 = time.perf_counter()
                 sample.i_step = i
                 secs.append(t1 - t0)
                 inside.append((eng.inside - in0) if mode == "replay" else 0.0)
+                layer.append((clock.total - lay0) if clock is not None else 0.0)
                 ops.append(chain.previous_operator.operator_name)
                 if i % 50 == 0:
                     gc.enable(); gc.collect(); gc.disable()          # (outside the timed region)
         finally:
             gc.enable()
+        if layer_clock:
+            _run.last_clock = clock
+            return secs, inside, ops, eng, float(chain._ll), layer
         return secs, inside, ops, eng, float(chain._ll)
     finally:
         os.chdir(cwd)
+        if clock is not None:
+            clock.remove()
         if mode != "plain":
             patch.uninstall()
             for p in patches:
@@ -225,6 +295,9 @@ def measure(tag, config_path, n_steps, seed):
         if best is None or sum(secs2) < sum(best[0]):
             best = (secs2, inside2)
     secs2, inside2 = best
+    # one more replay with the host-layer clock on (its wrappers cost a little: not the run the residual is taken from)
+    _s, inside3, _o, _e, _l, layer3 = _run(config_path, tag, n_steps, seed, "replay", memo=memo, layer_clock=True)
+    ours = np.asarray(layer3) - np.asarray(inside3)
     secs0, _, ops0, _, ll0 = _run(config_path, tag, n_steps, seed, "plain")
     resid = np.asarray(secs2) - np.asarray(inside2)
     by_op = {}
@@ -235,6 +308,7 @@ def measure(tag, config_path, n_steps, seed):
     return {
         "tag": tag, "n_steps": n_steps, "seed": seed, "engine_calls_total": n_calls,
         "host_python_us_per_step": _summary(resid),
+        "of_which_this_packages_host_layer_us_per_step": _summary(ours),
         "replay_double_us_per_step": _summary(inside2),
         "oracle_backed_us_per_step": _summary(secs1),
         "plain_reference_us_per_step": _summary(secs0),

@@ -95,8 +95,21 @@ for wl, batch, kern in CASES:
         b = SRC / f"bench_{suffix}.json"
         if b.exists() and b.stat().st_size:
             shutil.copy(b, DST / f"bench_line_{wl}_{kern}_b{batch}_under_rocprof.json")
+            # identity of what was profiled: the dominant kernel's name as the engine reports it and the digest of the
+            # run's results -- bench.py refuses a static figure whose identity differs from the run it is quoted beside
+            try:
+                line = json.loads([ln for ln in b.read_text().splitlines() if ln.startswith("{")][-1])
+                ident = {"kernel": line["roofline"]["kernel"], "results_sha1": line["results_sha1"]}
+            except Exception:
+                ident = None
+            if ident:
+                if f"{wl}:{kern}:{batch}" in traffic:
+                    traffic[f"{wl}:{kern}:{batch}"].update(ident)
+                if sq:
+                    summary[f"sq_counters_{wl}_{kern}_b{batch}"].update({"_kernel": ident["kernel"], "_results_sha1": ident["results_sha1"]})
 summary["traffic"] = traffic
 (DST / "pmc_summary.json").write_text(json.dumps(summary, indent=1))
 (REPO / "profiles" / "traffic_latest.json").write_text(json.dumps(
-    {k: round(v["hbm_bytes_per_launch"]) for k, v in traffic.items()}, indent=1))
+    {k: {"bytes": round(v["hbm_bytes_per_launch"]), "kernel": v.get("kernel"), "results_sha1": v.get("results_sha1"), "profile": TAG}
+     for k, v in traffic.items()}, indent=1))
 print(json.dumps(summary, indent=1)[:6000])
