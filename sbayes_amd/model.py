@@ -33,10 +33,50 @@ class ConfoundingEffectsPrior:
         return self._concentration_array
 
 
+class UniversalConfoundingEffectsPrior(ConfoundingEffectsPrior):
+    """The reference's DYNAMIC confounding-effects prior (group prior type `universal`, sbayes/model/prior.py:309-315):
+    the concentration of every group follows the posterior mean of the `universal` confounder's single group -- it is
+    a function of the SAMPLE (`any_dynamic_priors = True`), rewritten in place on every request (prior.py:325-354),
+    with the leave-subset-out form of component_likelihood_given_unchanged (prior.py:356-387).  The reference's config
+    layer still rejects this type ("not implemented yet", config/config.py:226-232), so the branches it switches on in
+    the likelihood path (likelihood.py:92-93, conditionals.py:197-200, operators.py:912-915) are reachable only with
+    a hand-built prior: this mirror exists so that they are driven at all (tests/test_dynamic_priors_*.py)."""
+    any_dynamic_priors = True
+
+    def __init__(self, n_groups, states_per_feature, precision, universal_prior, features):
+        states = np.asarray(states_per_feature, dtype=bool)
+        super().__init__(np.broadcast_to(states.astype(np.float64), (n_groups,) + states.shape).copy())
+        self.states_per_feature = states
+        self.precision = float(precision)
+        self.universal_prior = universal_prior          # the `universal` confounder's (static) prior
+        self.features = np.asarray(features, dtype=bool)
+
+    def _fill(self, univ_counts):
+        with np.errstate(invalid="ignore"):
+            mean = univ_counts / univ_counts.sum(axis=-1, keepdims=True)                       # normalize (util.py:990-1007)
+        mean = mean.astype(np.float32)
+        uniform = (self.states_per_feature / self.states_per_feature.sum(axis=-1, keepdims=True)).astype(np.float32)
+        mean = 0.95 * mean + 0.05 * uniform                                                     # prior.py:337-338
+        precision = self.precision * self.states_per_feature.sum(axis=-1)[:, np.newaxis]        # prior.py:347
+        self._concentration_array[:] = mean * precision                                        # in place, every group
+        return self._concentration_array
+
+    def concentration_array(self, sample=None):
+        univ = self.universal_prior.concentration_array(sample)[0] + sample.feature_counts["universal"].value[0]
+        return self._fill(univ)
+
+    def concentration_array_given_unchanged(self, sample, changed_objects):
+        univ = self.universal_prior.concentration_array(sample)[0] + sample.feature_counts["universal"].value[0]
+        # (the reference subtracts the subset's observations whose source is component 0 here, prior.py:363-364)
+        changeable = np.sum(sample.source.value[changed_objects, :, 0, None] * self.features[changed_objects, :, :], axis=0)
+        return self._fill(univ - changeable)
+
+
 class Prior:
     def __init__(self, cluster_concentration, confounder_concentrations: dict):
         self.prior_cluster_effect = ClusterEffectPrior(cluster_concentration)
-        self.prior_confounding_effects = {k: ConfoundingEffectsPrior(v) for k, v in confounder_concentrations.items()}
+        self.prior_confounding_effects = {k: (v if isinstance(v, ConfoundingEffectsPrior) else ConfoundingEffectsPrior(v))
+                                          for k, v in confounder_concentrations.items()}
 
 
 class Data:

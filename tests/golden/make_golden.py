@@ -31,6 +31,10 @@ Every RNG the reference draws from is seeded before a recording -- np.random, ra
 module-level generators sbayes.util.RNG / sbayes.sampling.initializers.RNG (set in place) -- so re-running this
 script regenerates every fixture bit for bit (tests/test_golden_reproducible_cpu.py checks test_files).
   known_answers.json  hand-derivable cases from the reference's commented-out test
+  dynamic_prior.npz   the reference's own ConfoundingEffectsPrior with the `universal` (dynamic) group prior type on a
+                      60 x 24 x 4 synthetic: concentration tables that follow the universal counts, the cached
+                      Likelihood.__call__ / likelihood_per_component across a hyperprior change, and
+                      component_likelihood_given_unchanged with concentration_array_given_unchanged
   overlap.npz         objects in several groups of one component: the reference's a1 (last written group
                       wins, in changed_groups order), a9 (counted once per group), recount / delta counts / collapsed
                       likelihood of a sample whose third component has overlapping groups
@@ -749,6 +753,99 @@ def overlap_fixture():
 
 
 # ----------------------------------------------------------------------------------------
+# dynamic (universal) confounding-effects prior: the `any_dynamic_priors = True` branches of the path
+# (likelihood.py:92-93, conditionals.py:197-200, operators.py:905-915).  The reference's config layer refuses the
+# `universal` prior type ("not implemented yet", config/config.py:226-232), so its OWN ConfoundingEffectsPrior class is
+# instantiated here with a config object built without validation (pydantic model_construct): the prior, the cache
+# wiring (has_universal_prior, state.py:448-449), Likelihood.__call__, likelihood_per_component and
+# component_likelihood_given_unchanged below are all the reference's code.
+# ----------------------------------------------------------------------------------------
+def dynamic_prior_fixture():
+    from sbayes.config.config import ConfoundingEffectPriorConfig
+    from sbayes.model.prior import ConfoundingEffectsPrior
+    from sbayes.sampling.operators import component_likelihood_given_unchanged
+    shape = (60, 24, 4, 2, (5,), True)
+    wl = make_workload("dynamic", shape=shape)
+    n, f, s = wl.shape
+    names = wl.component_names                            # clusters, universal, conf1
+    features = Features(
+        values=wl.features, names=np.array([f"F{i}" for i in range(f)]), states=wl.states_per_feature,
+        state_names=[[f"s{j}" for j in range(int(k))] for k in wl.states_per_feature.sum(axis=1)],
+        na_number=int(wl.na_values.sum()))
+    confounders = OrderedDict()
+    for name, g in zip(names[1:], wl.groups[1:]):
+        confounders[name] = Confounder(name=name, group_assignment=g, group_names=[f"g{j}" for j in range(g.shape[0])])
+    shapes = ModelShapes(n_clusters=wl.clusters.shape[0], n_sites=n, n_features=f, n_states=s,
+                         states_per_feature=wl.states_per_feature, n_confounders=len(confounders),
+                         n_groups={k: c.n_groups for k, c in confounders.items()})
+    conf_priors = {}
+    Types = ConfoundingEffectPriorConfig.Types
+    for name in names[1:]:
+        if name == "universal":
+            cfg = {g: ConfoundingEffectPriorConfig(type="uniform") for g in confounders[name].group_names}
+        else:
+            cfg = {g: ConfoundingEffectPriorConfig.model_construct(type=Types.UNIVERSAL, prior_concentration=3.0, file=None, parameters=None)
+                   for g in confounders[name].group_names}
+        conf_priors[name] = ConfoundingEffectsPrior(
+            config=cfg, shapes=shapes, conf=name, feature_names=features.feature_and_state_names,
+            group_names=confounders[name].group_names, conf_effect_priors=conf_priors, features=features.values)
+        if conf_priors[name].any_dynamic_priors:
+            confounders[name].has_universal_prior = True              # (Prior.__init__, prior.py:69-70)
+    assert conf_priors["conf1"].any_dynamic_priors and not conf_priors["universal"].any_dynamic_priors
+    unif = wl.states_per_feature.astype(np.float64)
+    prior = SimpleNamespace(
+        prior_cluster_effect=SimpleNamespace(concentration_array=unif.copy(), uniform_concentration_array=unif.copy()),
+        prior_confounding_effects=conf_priors)
+    data = SimpleNamespace(features=features, confounders=confounders)
+    model = SimpleNamespace(data=data, prior=prior, shapes=shapes)
+    model.likelihood = Likelihood(data=data, shapes=shapes, prior=prior)
+    counts0 = {k: np.zeros((g.shape[0], f, s), dtype=np.float32) for k, g in zip(names, wl.groups)}
+    sample = Sample.from_numpy_arrays(clusters=wl.clusters.copy(), weights=wl.weights.copy(), confounders=confounders,
+                                      source=wl.source.copy(), feature_counts=counts0, model_shapes=shapes)
+    recalculate_feature_counts(features.values, sample)
+    arrs, meta = {}, dict(shape=list(shape[:4]) + [list(shape[4]), shape[5]], precision=3.0, component_names=names)
+
+    def snapshot(tag, smp):
+        arrs[f"{tag}_conc_2"] = np.array(conf_priors["conf1"].concentration_array(smp))
+        meta[f"{tag}_collapsed_ll"] = float(model.likelihood(smp, caching=True))
+        for i, k in enumerate(names):
+            arrs[f"{tag}_counts_{i}"] = smp.feature_counts[k].value.copy()
+            arrs[f"{tag}_group_lh_{i}"] = smp.cache.group_likelihoods[k].value.copy()
+        arrs[f"{tag}_lh"] = likelihood_per_component(model, smp, caching=True).copy()
+
+    snapshot("s0", sample)
+    # step 1: a source edit that moves observations between `clusters` and `universal` only: conf1's counts do not
+    # change, its concentration does (hyperprior_has_changed) -> every group of conf1 is re-evaluated from the cache path
+    rng = np.random.default_rng(5)
+    new = sample.copy()
+    in_cluster = np.flatnonzero(sample.clusters.value.any(axis=0))
+    subset = np.sort(rng.choice(in_cluster, size=8, replace=False))
+    with new.source.edit() as src:
+        for o in subset:
+            rows = src[o]
+            flip = rows[:, 0] | rows[:, 1]
+            rows[flip, 0], rows[flip, 1] = rows[flip, 1].copy(), rows[flip, 0].copy()
+    update_feature_counts(sample, new, features.values, subset)
+    assert np.array_equal(new.feature_counts["conf1"].value, sample.feature_counts["conf1"].value)
+    assert not np.array_equal(new.feature_counts["universal"].value, sample.feature_counts["universal"].value)
+    arrs["s1_subset"], arrs["s1_source"] = subset, new.source.value.copy()
+    snapshot("s1", new)
+    assert not np.array_equal(arrs["s1_group_lh_2"], arrs["s0_group_lh_2"])      # the cached values were NOT reused
+    chk = float(model.likelihood(new, caching=False))
+    assert abs(chk - meta["s1_collapsed_ll"]) <= 1e-9 * abs(chk)
+    # the leave-subset-out form of the operators (operators.py:863-928 with concentration_array_given_unchanged)
+    mask = np.zeros(n, dtype=bool)
+    mask[subset] = True
+    for tag, t, tp in (("plain", 1.0, 1.0), ("tempered", 2.5, 1.7)):
+        arrs[f"given_unchanged_{tag}"] = component_likelihood_given_unchanged(
+            model, new, mask, i_cluster=0, temperature=t, prior_temperature=tp)
+        arrs[f"given_unchanged_conc_{tag}"] = np.array(conf_priors["conf1"].concentration_array_given_unchanged(new, mask))
+    np.savez_compressed(OUT / "dynamic_prior.npz", meta=json.dumps(meta), clusters=wl.clusters, weights=wl.weights,
+                        source=wl.source, **arrs)
+    print("[golden] dynamic_prior.npz", meta)
+
+
+# ----------------------------------------------------------------------------------------
 # boundary types (a11): a scripted edit sequence on the REFERENCE's Sample / CacheNode classes;
 # the recorded version counters, group versions and what_changed() answers pin the mirror in
 # sbayes_amd/state.py (tests/test_state_cpu.py replays the same script on it).
@@ -972,13 +1069,14 @@ def main():
               "headline_trace": lambda: synthetic_trace_fixture("headline", 300, 12),
               "test_files": lambda: real_fixture("test_files", stage_config(Path("/root/reference/test/test_files"), "test_files") / "config.yaml", 300, 321),
               "south_america": lambda: real_fixture("south_america", stage_config(Path("/root/reference/experiments/south_america"), "south_america") / "config.yaml", 400, 123),
-              "call_logs": call_log_fixtures, "overlap": overlap_fixture}
+              "call_logs": call_log_fixtures, "overlap": overlap_fixture, "dynamic_prior": dynamic_prior_fixture}
     if only:
         for name in only:
             single[name]()
         return
     known_answers()
     overlap_fixture()
+    dynamic_prior_fixture()
     state_fixture()
     synthetic_fixture("cfg1", full=True)
     synthetic_fixture("headline", full=False)

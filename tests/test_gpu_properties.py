@@ -147,7 +147,8 @@ def test_group_sums_follow_numpys_float32_pairwise_order(F):
     N, S, G = 40, 4, 5
     x = rng.integers(0, S, size=(N, F))
     feats = np.eye(S, dtype=bool)[x]
-    groups = [np.stack([rng.integers(0, G + 1, size=N) == g for g in range(G)]), np.ones((1, N), dtype=bool)]
+    gid = rng.integers(0, G + 1, size=N)                       # one id per object (G = in no group): disjoint groups
+    groups = [np.stack([gid == g for g in range(G)]), np.ones((1, N), dtype=bool)]
     conc = [np.ones((F, S)), np.ones((1, F, S))]
     with Engine(feats, [G, 1], n_slots=2) as eng:
         counts = rng.integers(0, 30, size=(G, F, S)).astype(np.float32)
