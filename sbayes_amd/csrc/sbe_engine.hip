@@ -114,6 +114,11 @@ struct sbe_engine {
     int* h_flag = nullptr;  int* d_flag = nullptr;   // host-mapped [ST_WORDS]: "a kernel raised this word" (raise_status)
     unsigned long long* h_done = nullptr;  unsigned long long* d_done = nullptr;   // host-mapped: sequence number of the last call
     unsigned* d_ticket = nullptr;  unsigned long long done_seq = 0;                // finished by flag (signal_done / wait_done)
+    // results streamed by the kernel into host-mapped staging, chunk by chunk (signal_chunk / stream_result)
+    static constexpr int kMaxChunks = 16;
+    unsigned long long* h_chunk_flags = nullptr;  unsigned long long* d_chunk_flags = nullptr;   // host-mapped [kMaxChunks]
+    unsigned* d_chunk_tickets = nullptr;  unsigned long long chunk_seq = 0;
+    uint8_t* h_stream = nullptr;  uint8_t* d_stream = nullptr;  size_t stream_bytes = 0;        // host-mapped staging + its device view
     uint8_t* d_changed = nullptr;  // [Gtot]
     uint32_t* d_step_stamp = nullptr;  uint32_t step_id = 0;   // [Gtot] group changed in step `step_id` (k_step_core)
     float* d_step_pf = nullptr;    // [Gtot][F]  per-feature collapsed log-pdf of the fused step call
@@ -144,7 +149,6 @@ struct sbe_engine {
     Pool* pool = nullptr;
     uint8_t* d_scratch = nullptr;  size_t scratch_bytes = 0;     // general staging
     uint8_t* h_pinned = nullptr;   size_t pinned_bytes = 0;      // pinned D2H staging
-    std::vector<hipEvent_t> d2h_events;                          // piecewise D2H of large results (d2h)
     uint8_t* h_arena = nullptr;    uint8_t* d_arena = nullptr;   size_t arena_bytes = 0, arena_off = 0;   // pinned, host-mapped H2D staging ring
     int opt_step_form = 0;         // SBE_OPT_STEP_FORM
     int opt_step_derive = 0;       // SBE_OPT_STEP_DERIVE: 1 = always re-derive patterns / tuples from all objects
@@ -257,37 +261,86 @@ int ensure_pinned(sbe_engine* e, size_t bytes) {
 int upload(sbe_engine* e, void* dst_dev, const void* src, size_t bytes);
 int synced(sbe_engine* e);
 
+int ensure_step_pool(sbe_engine* e);
+
+// ---- large results streamed by the kernel (the literal a1 / a3 surfaces) ---------------------------
+// tools/d2h_probe.hip on an MI355X box: 3.2 MB cross PCIe in 67 us by one hipMemcpyAsync and in 69 us when a kernel
+// stores them straight into host-mapped memory; every further copy operation on the stream costs ~7 us and every event
+// behind one more (four pieces with events: the round-2 / round-3 form, ~40 us over the plain copy); one host thread
+// copies out of pinned memory at 27 GB/s -- 120 us for 3.2 MB, twice the transfer.  So: the kernel writes its result
+// into the host-mapped staging buffer `h_stream` and reports completion chunk by chunk (signal_chunk); the host jobs --
+// work(j) copies / scatters staging bytes [.., job_end(j)) to the caller -- run on the engine's pool (sbe_pool.h:
+// run_as_ready) as the chunks land, the calling thread reading the chunk flags.  No copy engine, no event, one launch.
+int ensure_stream(sbe_engine* e, size_t bytes) {
+    if (bytes <= e->stream_bytes) return SBE_OK;
+    if (e->h_stream) { HIPCHK(e, hipStreamSynchronize(e->stream)); HIPCHK(e, hipHostFree(e->h_stream)); e->h_stream = nullptr; e->stream_bytes = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(e, hipHostMalloc((void**)&e->h_stream, want, hipHostMallocMapped));
+    HIPCHK(e, hipHostGetDevicePointer((void**)&e->d_stream, e->h_stream, 0));
+    e->stream_bytes = want;
+    return SBE_OK;
+}
+
+struct StreamPlan { ChunkSig sig; int n_chunks; size_t chunk_bytes; size_t bytes; };
+
+// chunks of whole blocks: `bytes_per_block` result bytes per block, n_blocks blocks, at most kMaxChunks chunks of >= 128 KB
+StreamPlan plan_stream(sbe_engine* e, unsigned n_blocks, size_t bytes_per_block, size_t bytes) {
+    unsigned per = std::max<unsigned>(1, (unsigned)div_up((int64_t)n_blocks, sbe_engine::kMaxChunks));
+    per = std::max<unsigned>(per, (unsigned)div_up((int64_t)128 << 10, (int64_t)bytes_per_block));
+    const int n_chunks = (int)div_up((int64_t)n_blocks, (int64_t)per);
+    return StreamPlan{ChunkSig{e->d_chunk_tickets, e->d_chunk_flags, ++e->chunk_seq, per, n_blocks}, n_chunks, (size_t)per * bytes_per_block, bytes};
+}
+
+template <class JobBegin, class JobEnd, class Work>
+int stream_result(sbe_engine* e, const StreamPlan& plan, int n_jobs, JobBegin job_begin, JobEnd job_end, Work work) {
+    static const bool single_thread = [] { const char* v = getenv("SBE_D2H_THREADS"); return v && atoi(v) == 1; }();   // (A/B)
+    if (!single_thread) { int rc = ensure_step_pool(e); if (rc) return rc; }
+    std::atomic<bool> all_landed{false};
+    hipError_t sync_err = hipSuccess;
+    const volatile unsigned long long* flags = e->h_chunk_flags;
+    const unsigned long long seq = plan.sig.seq;
+    const size_t chunk_bytes = plan.chunk_bytes;
+    const auto t_limit = std::chrono::steady_clock::now() + std::chrono::microseconds(2000 + (int64_t)(plan.bytes / 10000));   // 2 ms + 10 GB/s
+    unsigned spins = 0;
+    sbe_host::run_as_chunks_land(
+        single_thread ? nullptr : e->pool, n_jobs,
+        [=](int j) { return (int)(job_begin(j) / chunk_bytes); },
+        [=](int j) { return (int)((job_end(j) - 1) / chunk_bytes); },
+        [&, flags, seq](int k) { return flags[k] == seq || all_landed.load(std::memory_order_acquire); },
+        [&] {                                     // calling thread only: a kernel that never reports -> the runtime's wait ends the call
+            if ((++spins & 1023u) == 0 && !all_landed.load(std::memory_order_relaxed) && std::chrono::steady_clock::now() > t_limit) {
+                sync_err = hipStreamSynchronize(e->stream);
+                all_landed.store(true, std::memory_order_release);
+            }
+        },
+        work);
+    if (sync_err != hipSuccess) return fail(e, SBE_ERR_HIP, "hipStreamSynchronize (streamed result): %s", hipGetErrorString(sync_err));
+    return SBE_OK;                                // every chunk flag seen: the kernel's blocks have finished their stores
+}
+
 // D2H through the pinned staging buffer (pageable destinations would be staged by the
 // runtime anyway, in smaller pieces)
 int d2h(sbe_engine* e, void* dst, const void* src_dev, size_t bytes) {
     int rc = ensure_pinned(e, bytes);
     if (rc) return rc;
-    // large results ([N, F] / [N, F, C] float64 arrays of the literal a1 / a3 surfaces): in four pieces, the host copy
-    // of piece k under the DMA of pieces k+1.. (the copy out of the staging buffer costs as much as the DMA itself)
-    constexpr int kPieces = 4;
-    static const bool single_copy = [] { const char* v = getenv("SBE_D2H_PIECES"); return v && atoi(v) == 1; }();   // (A/B: tools/ab_d2h.py)
-    if (bytes >= ((size_t)1 << 20) && !single_copy) {
-        if (e->d2h_events.empty()) {
-            e->d2h_events.resize(kPieces);
-            for (auto& ev : e->d2h_events) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        }
-        const size_t piece = ((bytes + kPieces - 1) / kPieces + 255) / 256 * 256;
-        int n_pieces = 0;
-        for (size_t off = 0; off < bytes; off += piece, ++n_pieces) {
-            const size_t nb = std::min(piece, bytes - off);
-            HIPCHK(e, hipMemcpyAsync(e->h_pinned + off, (const uint8_t*)src_dev + off, nb, hipMemcpyDeviceToHost, e->stream));
-            HIPCHK(e, hipEventRecord(e->d2h_events[n_pieces], e->stream));
-        }
-        size_t off = 0;
-        for (int k = 0; k < n_pieces; ++k, off += piece) {
-            HIPCHK(e, hipEventSynchronize(e->d2h_events[k]));
-            memcpy((uint8_t*)dst + off, e->h_pinned + off, std::min(piece, bytes - off));
-        }
-        HIPCHK(e, hipStreamSynchronize(e->stream));
-        return synced(e);
-    }
     HIPCHK(e, hipMemcpyAsync(e->h_pinned, src_dev, bytes, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    // large results (observation likelihoods, exact forms, normalised weights; the [N, F] / [N, F, C] arrays of the
+    // literal a1 / a3 surfaces are streamed by their kernels: stream_result): ONE copy operation -- every further piece
+    // costs ~7 us of stream time and every event behind one more (tools/d2h_probe.hip), which is what the piecewise form
+    // of rounds 2-3 paid for its overlap -- then the copy out of the staging buffer (27 GB/s per thread: as long as the
+    // transfer itself on one thread) spread over the host pool in 64 KB jobs
+    static const bool single_copy = [] { const char* v = getenv("SBE_D2H_THREADS"); return v && atoi(v) == 1; }();   // (A/B: tools/ab_d2h.py)
+    if (bytes >= ((size_t)1 << 20) && !single_copy) {
+        rc = ensure_step_pool(e);
+        if (rc) return rc;
+        constexpr size_t kJob = (size_t)64 << 10;
+        uint8_t* out = (uint8_t*)dst;
+        const uint8_t* stage = e->h_pinned;
+        e->pool->run((int)((bytes + kJob - 1) / kJob),
+                     [=](int j) { const size_t o = (size_t)j * kJob; memcpy(out + o, stage + o, std::min(kJob, bytes - o)); });
+        return synced(e);
+    }
     memcpy(dst, e->h_pinned, bytes);
     return synced(e);
 }
@@ -1163,7 +1216,6 @@ int sbe_destroy(sbe_engine* e) {
         if (ln.d_stamp) (void)hipFree(ln.d_stamp);
         if (ln.d_status) (void)hipFree(ln.d_status);
     }
-    for (auto ev : e->d2h_events) (void)hipEventDestroy(ev);
     if (e->d_batch_meta) (void)hipFree(e->d_batch_meta);
     if (e->h_batch_payload) (void)hipHostFree(e->h_batch_payload);
     if (e->d_batch_payload) (void)hipFree(e->d_batch_payload);
@@ -1178,6 +1230,9 @@ int sbe_destroy(sbe_engine* e) {
     if (e->h_status) (void)hipHostFree(e->h_status);
     if (e->h_flag) (void)hipHostFree(e->h_flag);
     if (e->h_done) (void)hipHostFree(e->h_done);
+    if (e->h_chunk_flags) (void)hipHostFree(e->h_chunk_flags);
+    if (e->d_chunk_tickets) (void)hipFree(e->d_chunk_tickets);
+    if (e->h_stream) (void)hipHostFree(e->h_stream);
     if (e->d_ticket) (void)hipFree(e->d_ticket);
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     if (e->h_arena) (void)hipHostFree(e->h_arena);
@@ -1393,6 +1448,11 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     memset(e->h_done, 0, 64);
     CREATE_CHK(hipMalloc((void**)&e->d_ticket, 64));
     CREATE_CHK(hipMemsetAsync(e->d_ticket, 0, 64, e->stream));
+    CREATE_CHK(hipHostMalloc((void**)&e->h_chunk_flags, sbe_engine::kMaxChunks * sizeof(unsigned long long), hipHostMallocMapped));
+    CREATE_CHK(hipHostGetDevicePointer((void**)&e->d_chunk_flags, e->h_chunk_flags, 0));
+    memset(e->h_chunk_flags, 0, sbe_engine::kMaxChunks * sizeof(unsigned long long));
+    CREATE_CHK(hipMalloc((void**)&e->d_chunk_tickets, sbe_engine::kMaxChunks * sizeof(unsigned)));
+    CREATE_CHK(hipMemsetAsync(e->d_chunk_tickets, 0, sbe_engine::kMaxChunks * sizeof(unsigned), e->stream));
     e->arena_bytes = (size_t)16 << 20;
     CREATE_CHK(hipHostMalloc((void**)&e->h_arena, e->arena_bytes, hipHostMallocMapped));
     CREATE_CHK(hipHostGetDevicePointer((void**)&e->d_arena, e->h_arena, 0));
@@ -1509,9 +1569,42 @@ int sbe_component_lh(sbe_engine* e, const void* probs, int probs_f64, int n_grou
     uint8_t* d_tab = e->d_scratch;
     int32_t* d_sel = (int32_t*)(e->d_scratch + tab_pad);
     double* d_out = (double*)(e->d_scratch + tab_pad + sel_bytes);
-    { int _urc = upload(e, d_tab, probs, tab_bytes); if (_urc) return _urc; }
-    { int _urc = upload(e, d_sel, sel.data(), (size_t)N * sizeof(int32_t)); if (_urc) return _urc; }
-    const int blocks = div_up((int64_t)N * F, 256);
+    {   // table + row selector: one enqueue when they fit the mapped ring (upload_segments), two copies otherwise
+        const UploadSeg segs[2] = {{d_tab, probs, tab_bytes}, {d_sel, sel.data(), (size_t)N * sizeof(int32_t)}};
+        int _urc = upload_segments(e, segs, 2);
+        if (_urc) return _urc;
+    }
+    const int blocks = div_up((int64_t)N * F, 512);       // (k_component_lh: two output elements per thread)
+    const int32_t* selp = sel.data();
+    char* base = (char*)out;
+    auto scatter_rows = [=](const double* dense, int n0, int n1) {   // rows the call writes: the caller's (strided) view <- staging rows
+        for (int n = n0; n < n1; ++n) {
+            if (selp[n] == -2) continue;
+            char* row = base + (int64_t)n * out_stride_n_bytes;
+            const double* srow = dense + (size_t)n * F;
+            if (out_stride_f_bytes == (int64_t)sizeof(double)) memcpy(row, srow, (size_t)F * sizeof(double));
+            else for (int f = 0; f < F; ++f) *(double*)(row + (int64_t)f * out_stride_f_bytes) = srow[f];
+        }
+    };
+    static const bool no_stream = [] { const char* v = getenv("SBE_STREAM_RESULTS"); return v && atoi(v) == 0; }();   // (A/B)
+    if (out_bytes >= ((size_t)1 << 19) && !no_stream) {
+        // large result: the kernel stores it into host-mapped staging and reports chunk by chunk; the scatter into the
+        // caller's view runs on the host pool while the later chunks cross PCIe (stream_result)
+        rc = ensure_stream(e, out_bytes);
+        if (rc) return rc;
+        const StreamPlan plan = plan_stream(e, (unsigned)blocks, (size_t)512 * sizeof(double), out_bytes);
+        double* s_out = (double*)e->d_stream;
+        if (probs_f64) k_component_lh<double><<<blocks, 256, 0, e->stream>>>(e->d_state, (const double*)d_tab, d_sel, s_out, N, F, S, e->Fp, na_value, plan.sig);
+        else k_component_lh<float><<<blocks, 256, 0, e->stream>>>(e->d_state, (const float*)d_tab, d_sel, s_out, N, F, S, e->Fp, na_value, plan.sig);
+        HIPCHK(e, hipGetLastError());
+        const double* dense = (const double*)e->h_stream;
+        const int rows_per_job = std::max(1, (int)(((size_t)64 << 10) / ((size_t)F * sizeof(double))));
+        const int n_jobs = div_up(N, rows_per_job);
+        return stream_result(e, plan, n_jobs,
+                             [=](int j) { return (size_t)j * rows_per_job * F * sizeof(double); },
+                             [=](int j) { return (size_t)std::min(N, (j + 1) * rows_per_job) * F * sizeof(double); },
+                             [=](int j) { scatter_rows(dense, j * rows_per_job, std::min(N, (j + 1) * rows_per_job)); });
+    }
     if (probs_f64) k_component_lh<double><<<blocks, 256, 0, e->stream>>>(e->d_state, (const double*)d_tab, d_sel, d_out, N, F, S, e->Fp, na_value);
     else k_component_lh<float><<<blocks, 256, 0, e->stream>>>(e->d_state, (const float*)d_tab, d_sel, d_out, N, F, S, e->Fp, na_value);
     HIPCHK(e, hipGetLastError());
@@ -1519,15 +1612,7 @@ int sbe_component_lh(sbe_engine* e, const void* probs, int probs_f64, int n_grou
     if (rc) return rc;
     HIPCHK(e, hipMemcpyAsync(e->h_pinned, d_out, out_bytes, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    const double* dense = (const double*)e->h_pinned;
-    char* base = (char*)out;
-    for (int n = 0; n < N; ++n) {
-        if (sel[n] == -2) continue;
-        char* row = base + (int64_t)n * out_stride_n_bytes;
-        const double* srow = dense + (size_t)n * F;
-        if (out_stride_f_bytes == (int64_t)sizeof(double)) memcpy(row, srow, (size_t)F * sizeof(double));
-        else for (int f = 0; f < F; ++f) *(double*)(row + (int64_t)f * out_stride_f_bytes) = srow[f];
-    }
+    scatter_rows((const double*)e->h_pinned, 0, N);
     return SBE_OK;
 }
 
@@ -1888,9 +1973,32 @@ int sbe_likelihood_per_component(sbe_engine* e, int slot, double* out) {
     if (rc) return rc;
     HIPCHK(e, hipSetDevice(e->device));
     const int64_t n = (int64_t)e->N * e->F * e->C;
+    const int blocks = div_up(n, 512);                    // (k_lh_dense: two output elements per thread)
+    static const bool no_stream = [] { const char* v = getenv("SBE_STREAM_RESULTS"); return v && atoi(v) == 0; }();   // (A/B)
+    if ((size_t)n * sizeof(double) >= ((size_t)1 << 19) && !no_stream) {
+        // large result: stored by the kernel into host-mapped staging, copied to the caller chunk by chunk on the host
+        // pool while the rest crosses PCIe (stream_result)
+        const size_t bytes = (size_t)n * sizeof(double);
+        rc = ensure_stream(e, bytes);
+        if (rc) return rc;
+        const StreamPlan plan = plan_stream(e, (unsigned)blocks, (size_t)512 * sizeof(double), bytes);
+        k_lh_dense<<<blocks, 256, 0, e->stream>>>(
+            e->d_state, e->d_gid + (int64_t)slot * e->C * e->Np, e->d_probs + (int64_t)slot * e->table_elems(),
+            (double*)e->d_stream, e->N, e->Np, e->F, e->S, e->C, e->Fp, plan.sig);
+        HIPCHK(e, hipGetLastError());
+        constexpr size_t kJob = (size_t)64 << 10;
+        const int n_jobs = (int)((bytes + kJob - 1) / kJob);
+        uint8_t* dst = (uint8_t*)out;
+        const uint8_t* stage = e->h_stream;
+        rc = stream_result(e, plan, n_jobs,
+                           [=](int j) { return (size_t)j * kJob; },
+                           [=](int j) { return std::min(bytes, (size_t)(j + 1) * kJob); },
+                           [=](int j) { const size_t o = (size_t)j * kJob; memcpy(dst + o, stage + o, std::min(kJob, bytes - o)); });
+        return rc ? rc : synced(e);               // (the call waited for the device: a deferred data check is delivered here)
+    }
     rc = ensure_scratch(e, n * sizeof(double));
     if (rc) return rc;
-    k_lh_dense<<<div_up((int64_t)e->N * e->F, 256), 256, 0, e->stream>>>(
+    k_lh_dense<<<blocks, 256, 0, e->stream>>>(
         e->d_state, e->d_gid + (int64_t)slot * e->C * e->Np, e->d_probs + (int64_t)slot * e->table_elems(),
         (double*)e->d_scratch, e->N, e->Np, e->F, e->S, e->C, e->Fp);
     HIPCHK(e, hipGetLastError());

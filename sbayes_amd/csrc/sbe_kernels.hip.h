@@ -69,6 +69,31 @@ __device__ __forceinline__ void signal_done(const DoneSig& d) {
     }
 }
 
+// A LARGE result written by the kernel itself into host-mapped pinned memory (posted PCIe writes from every CU: as fast
+// as the copy engine on this platform, and no copy operation, event or second synchronisation behind the kernel), with
+// completion reported CHUNK BY CHUNK: consecutive blocks form a chunk; each block fences like signal_done and takes a
+// ticket of its chunk, the chunk's last block stores the call's sequence number into the chunk's host-mapped flag.  The
+// host copies a chunk out of the staging buffer as soon as its flag shows the sequence number, while the later chunks
+// are still crossing PCIe (sbe_engine.hip: stream_result).  Every thread of the block must reach the call.
+struct ChunkSig { unsigned* tickets; unsigned long long* flags; unsigned long long seq; unsigned blocks_per_chunk; unsigned n_blocks; };
+__device__ __forceinline__ void signal_chunk(const ChunkSig& c) {
+    if (!c.flags) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's result stores are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");       // system scope: the pending writes are out and confirmed
+        const unsigned chunk = blockIdx.x / c.blocks_per_chunk;
+        const unsigned first = chunk * c.blocks_per_chunk;
+        const unsigned in_chunk = min(c.blocks_per_chunk, c.n_blocks - first);
+        const unsigned t = __hip_atomic_fetch_add(c.tickets + chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == in_chunk - 1) {                            // every other block of the chunk fenced before its ticket
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(c.tickets + chunk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(c.flags + chunk, c.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // NumPy reduction order (pairwise sum, PW_BLOCKSIZE = 128, 8-way unrolled block).
 // `get(i)` returns element i as T.  Matches @TYPE@_pairwise_sum for any n.
@@ -724,40 +749,66 @@ __global__ void k_expand_weights(const float* __restrict__ wpat, const uint8_t* 
 // converted exactly to float64; NA rows sum to 0.
 // ------------------------------------------------------------------------------------------
 template <class TP>
-__global__ void k_component_lh(const uint8_t* __restrict__ state, const TP* __restrict__ probs,
-                               const int32_t* __restrict__ sel, double* __restrict__ out /* [N][F] */,
-                               int N, int F, int S, int Fp, double na_value) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)N * F) return;
+__device__ __forceinline__ double component_lh_value(const uint8_t* __restrict__ state, const TP* __restrict__ probs,
+                                                    const int32_t* __restrict__ sel, int64_t i, int F, int S, int Fp, double na_value) {
     const int n = (int)(i / F), f = (int)(i % F);
     const int g = sel[n];
     const uint8_t x = state[(int64_t)n * Fp + f];
-    double v = 0.0;
-    if (x == kNA) v = na_value;       // 0 for the literal a1 contract; 1 when serving likelihood_per_component
-    else if (g >= 0) v = (double)probs[((int64_t)g * F + f) * S + x];
-    out[i] = v;
+    if (x == kNA) return na_value;        // 0 for the literal a1 contract; 1 when serving likelihood_per_component
+    return g >= 0 ? (double)probs[((int64_t)g * F + f) * S + x] : 0.0;
+}
+
+// two consecutive output elements per thread, stored as one 16-byte word (tools/d2h_probe.hip: 16-byte stores into
+// host-mapped memory move 41-47 GB/s, 8-byte stores 36-43)
+template <class TP>
+__global__ void k_component_lh(const uint8_t* __restrict__ state, const TP* __restrict__ probs,
+                               const int32_t* __restrict__ sel, double* __restrict__ out /* [N][F] */,
+                               int N, int F, int S, int Fp, double na_value, ChunkSig chunks = ChunkSig{}) {
+    const int64_t i = 2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    const int64_t total = (int64_t)N * F;
+    if (i + 1 < total) {
+        double2 v;
+        v.x = component_lh_value(state, probs, sel, i, F, S, Fp, na_value);
+        v.y = component_lh_value(state, probs, sel, i + 1, F, S, Fp, na_value);
+        *reinterpret_cast<double2*>(out + i) = v;
+    } else if (i < total) {
+        out[i] = component_lh_value(state, probs, sel, i, F, S, Fp, na_value);
+    }
+    signal_chunk(chunks);                 // (`out` in host-mapped memory: completion chunk by chunk)
 }
 
 // ------------------------------------------------------------------------------------------
 // a3: likelihood_per_component (conditionals.py:152-223): dense [N][F][C] float64 from the
 // slot's group ids and tables; NA <- 1 (conditionals.py:216), no group <- 0 (likelihood.py:122).
 // ------------------------------------------------------------------------------------------
-__global__ void k_lh_dense(const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid,
-                           const float* __restrict__ probs, double* __restrict__ out, int N, int Np, int F,
-                           int S, int C, int Fp) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)N * F) return;
+__device__ __forceinline__ double lh_dense_value(const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid,
+                                                const float* __restrict__ probs, int64_t j, int Np, int F, int S, int C, int Fp) {
+    const int64_t i = j / C;
+    const int c = (int)(j - i * C);
     const int n = (int)(i / F), f = (int)(i % F);
     const uint8_t x = state[(int64_t)n * Fp + f];
-    double* o = out + i * C;
-    for (int c = 0; c < C; ++c) {
-        double v = 1.0;
-        if (x != kNA) {
-            const uint16_t gg = gid[(int64_t)c * Np + n];
-            v = gg == kNoGroup ? 0.0 : (double)probs[((int64_t)gg * F + f) * S + x];
-        }
-        o[c] = v;
+    if (x == kNA) return 1.0;
+    const uint16_t gg = gid[(int64_t)c * Np + n];
+    return gg == kNoGroup ? 0.0 : (double)probs[((int64_t)gg * F + f) * S + x];
+}
+
+__global__ void k_lh_dense(const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid,
+                           const float* __restrict__ probs, double* __restrict__ out, int N, int Np, int F,
+                           int S, int C, int Fp, ChunkSig chunks = ChunkSig{}) {
+    // consecutive lanes store consecutive OUTPUT elements (n, f, c), two per thread as one 16-byte word: full lines
+    // whether `out` is in HBM or, streamed, in host-mapped memory (a thread per observation storing C values at stride
+    // C left every store instruction with half-filled lines: 3.2 MB crossed PCIe in 300 us instead of 70)
+    const int64_t j = 2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    const int64_t total = (int64_t)N * F * C;
+    if (j + 1 < total) {
+        double2 v;
+        v.x = lh_dense_value(state, gid, probs, j, Np, F, S, C, Fp);
+        v.y = lh_dense_value(state, gid, probs, j + 1, Np, F, S, C, Fp);
+        *reinterpret_cast<double2*>(out + j) = v;
+    } else if (j < total) {
+        out[j] = lh_dense_value(state, gid, probs, j, Np, F, S, C, Fp);
     }
+    signal_chunk(chunks);                 // (`out` in host-mapped memory: completion chunk by chunk)
 }
 
 // a2: likelihood_per_component_exact (conditionals.py:300-367): leave-one-out tables.

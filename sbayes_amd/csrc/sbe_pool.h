@@ -93,4 +93,27 @@ struct StepPool {
     }
 };
 
+// Jobs that consume a large device-to-host result while it is still arriving (the literal a1 / a3 call surfaces hand back
+// [N, F] / [N, F, C] float64 arrays).  The result lands CHUNK BY CHUNK with one completion flag per chunk, in any order (a kernel storing into
+// host-mapped memory, sbe_kernels.hip.h signal_chunk): job j reads chunks first_chunk(j)..last_chunk(j) and every thread
+// looks at the flags ITSELF -- `chunk_ready(k)` only reads host memory -- so no job waits for another thread to notice.
+// `caller_tick` runs on the calling thread only (while it waits inside its own job, after each of its jobs, while it
+// waits for the others): the one place that may talk to the HIP runtime -- the engine uses it to fall back to a stream
+// synchronisation when a flag stays away, after which chunk_ready must return true for every chunk.
+template <class First, class Last, class Ready, class Tick, class Work>
+void run_as_chunks_land(StepPool* pool, int n, First first_chunk, Last last_chunk, Ready chunk_ready, Tick caller_tick, Work work) {
+    auto wait_for = [&](int j, bool mine) {
+        for (int k = first_chunk(j), k1 = last_chunk(j); k <= k1; ++k)
+            while (!chunk_ready(k)) { if (mine) caller_tick(); else __builtin_ia32_pause(); }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    };
+    if (!pool) {
+        for (int j = 0; j < n; ++j) { wait_for(j, true); work(j); }
+        return;
+    }
+    const std::thread::id caller = std::this_thread::get_id();
+    const std::function<void()> tick = [&] { caller_tick(); };
+    pool->run(n, [&](int j) { wait_for(j, std::this_thread::get_id() == caller); work(j); }, &tick);
+}
+
 }  // namespace sbe_host

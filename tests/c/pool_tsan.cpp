@@ -8,6 +8,7 @@
 // and make the exit code non-zero (TSAN_OPTIONS=halt_on_error=1 exitcode=66 by the test).
 #include "../../sbayes_amd/csrc/sbe_pool.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -47,6 +48,51 @@ int main(int argc, char** argv) {
         }
         if (round & 1) std::this_thread::sleep_for(std::chrono::milliseconds(2));               // destroy mid-idle (asleep)
     }                                                                                           // else: destroy while they poll
-    std::printf("pool_tsan: %d generations in %d pools, %ld items, %ld poll calls: ok\n", generations, rounds, items, polls);
+    // ---- run_as_chunks_land: the result lands chunk by chunk, each chunk with its own flag, in ANY order (a kernel storing
+    // into host-mapped memory); every thread reads the flags itself.  Producer threads stand in for the device: each fills
+    // its chunks (in a shuffled order) and raises their flags; one flag in a while is never raised and the caller's tick
+    // -- the engine's stream synchronisation -- declares everything landed instead (after joining the producers).
+    long chunk_jobs = 0, ticks = 0;
+    for (int round = 0; round < rounds; ++round) {
+        const int n_workers = (int)(rng() % 8);
+        sbe_host::StepPool pool(n_workers);
+        for (int g = 1; g <= std::max(4, generations / rounds / 8); ++g) {
+            const int n_chunks = 1 + (int)(rng() % 16);
+            const size_t chunk = 128 * (1 + rng() % 16), bytes = n_chunks * chunk - rng() % 100, job = 64 * (1 + rng() % 12);
+            const int n_jobs = (int)((bytes + job - 1) / job);
+            std::vector<unsigned char> stage(bytes, 0xEE), dst(bytes, 0);
+            std::vector<std::atomic<unsigned long long>> flags(n_chunks);
+            for (auto& f : flags) f.store(0);
+            const unsigned long long seq = (unsigned long long)g + 1000ull * round + 1;
+            const unsigned char tag = (unsigned char)(1 + (g + round) % 200);
+            std::vector<int> order(n_chunks);
+            for (int k = 0; k < n_chunks; ++k) order[k] = k;
+            std::shuffle(order.begin(), order.end(), rng);
+            const int lost = (g % 7 == 0) ? order[n_chunks / 2] : -1;           // this chunk's flag never comes
+            std::atomic<bool> all_landed{false};
+            std::thread device([&] {
+                for (int k : order) {
+                    if ((k + g) % 4 == 0) std::this_thread::sleep_for(std::chrono::microseconds(10));
+                    const size_t lo = k * chunk, hi = std::min(bytes, lo + chunk);
+                    for (size_t b = lo; b < hi; ++b) stage[b] = (unsigned char)(tag + b % 7);
+                    if (k != lost) flags[k].store(seq, std::memory_order_release);
+                }
+            });
+            bool joined = false;
+            long my_ticks = 0;
+            sbe_host::run_as_chunks_land((g + round) % 5 == 0 ? nullptr : &pool, n_jobs,
+                [&](int j) { return (int)((size_t)j * job / chunk); },
+                [&](int j) { return (int)((std::min(bytes, (size_t)(j + 1) * job) - 1) / chunk); },
+                [&](int k) { return flags[k].load(std::memory_order_acquire) == seq || all_landed.load(std::memory_order_acquire); },
+                [&] { if (++my_ticks > 2000 && !joined) { device.join(); joined = true; all_landed.store(true, std::memory_order_release); } },
+                [&](int j) { const size_t o = (size_t)j * job; std::copy(stage.begin() + o, stage.begin() + std::min(bytes, o + job), dst.begin() + o); });
+            if (!joined) device.join();
+            for (size_t b = 0; b < bytes; ++b)
+                if (dst[b] != (unsigned char)(tag + b % 7)) { std::fprintf(stderr, "pool_tsan: run_as_chunks_land copied byte %zu before it landed\n", b); return 1; }
+            chunk_jobs += n_jobs; ticks += my_ticks;
+        }
+    }
+    std::printf("pool_tsan: %d generations in %d pools, %ld items, %ld run_as_chunks_land jobs, %ld poll calls, %ld ticks: ok\n",
+                generations, rounds, items, chunk_jobs, polls, ticks);
     return 0;
 }

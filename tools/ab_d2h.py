@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Same-box A/B of the literal call surfaces: a1 / a3 / single eval / PCIe-inclusive eval with the
-piecewise D2H of large results (round 2, commit bafabae) against one plain copy (SBE_D2H_PIECES=1: round-1 behaviour).
-Each setting runs in a fresh child process (the switch is read once per process), alternating, three times."""
+"""Same-box A/B of the literal call surfaces: a1 / a3 / single eval / PCIe-inclusive eval
+with the pipelined copy-out of large results on the host pool (round 4) against the calling thread alone and against one
+plain copy (SBE_D2H_PIECES=1: round-1 behaviour).  Each setting runs in a fresh child process (the switches are read once
+per process), alternating, three times."""
 import json
 import os
 import subprocess
@@ -44,9 +45,15 @@ out = {"a1": rate(lambda: eng.component_lh(probs0, wl.groups[0], allg, buf[..., 
 print(json.dumps({k: round(v, 1) for k, v in out.items()}))
 ''' % str(REPO)
 
+# round 4: results streamed by the kernel into host-mapped staging and copied out chunk by chunk on the host pool (default)
+# against the calling thread alone (SBE_D2H_THREADS=1), against the copy-engine path (SBE_STREAM_RESULTS=0: one
+# hipMemcpyAsync, then the copy out of staging on the pool / on one thread = the round-1 form); pool sizes: SBE_STEP_THREADS
+SETTINGS = [("pool default", {}), ("one thread", {"SBE_D2H_THREADS": "1"}), ("not streamed", {"SBE_STREAM_RESULTS": "0"}),
+            ("not streamed, one thread", {"SBE_STREAM_RESULTS": "0", "SBE_D2H_THREADS": "1"}),
+            ("pool of 4", {"SBE_STEP_THREADS": "4"}), ("pool of 16", {"SBE_STEP_THREADS": "16"})]
 for rep in range(3):
-    for pieces in ("4", "1"):
-        env = dict(os.environ, SBE_D2H_PIECES=pieces)
+    for name, extra in SETTINGS:
+        env = dict(os.environ, **extra)
         res = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=env, timeout=300)
         line = res.stdout.strip().splitlines()[-1] if res.stdout.strip() else res.stderr[-300:]
-        print(f"d2h pieces {pieces}: {line}", flush=True)
+        print(f"{name:25s}: {line}", flush=True)
