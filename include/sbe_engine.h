@@ -24,6 +24,16 @@
  *     Measured 3-4 us per call below hipStreamSynchronize.  Environment SBE_POLL_DONE=0 uses the
  *     stream wait everywhere (same results: tests/test_gpu_poll_done.py).  A caller thread inside
  *     such a call therefore busy-waits on one core for the duration of the launch.
+ *   - how a large result reaches the caller: sbe_component_lh and sbe_likelihood_per_component hand back
+ *     [N][F] / [N][F][C] float64 arrays (1.6 / 3.2 MB at the headline shape).  From 512 KB on, their kernels
+ *     store the result straight into a host-mapped staging buffer (16-byte coalesced stores over PCIe) and
+ *     raise one host-mapped flag per chunk of >= 128 KB; the engine's host worker threads (the pool of the
+ *     batched steps: SBE_STEP_THREADS, default 8 including the caller) copy / scatter each chunk into the
+ *     caller's array as soon as its flag shows the call's sequence number, while the later chunks are still
+ *     in flight.  No copy-engine operation and no event is involved.  A flag that stays away for 2 ms + 10 GB/s
+ *     sends the calling thread to the HIP stream wait.  SBE_D2H_THREADS=1 keeps the copy on the calling thread,
+ *     SBE_STREAM_RESULTS=0 uses the copy engine (same bits: tests/test_gpu_streamed_results.py).  The worker
+ *     threads poll for ~400 us after a call before they block.
  *   - bool arrays are one byte per element (NumPy bool layout), C order.
  */
 #ifndef SBE_ENGINE_H
