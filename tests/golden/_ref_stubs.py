@@ -33,6 +33,40 @@ class _Dummy:
         return self
 
 
+# (module level, so that objects holding them pickle: the MC3 parent sends `data` -- with its CRS -- to its workers,
+#  sbayes/mcmc_setup.py:299, :554)
+class CRS:
+    def __init__(self, *a, **k):
+        pass
+
+    @classmethod
+    def from_user_input(cls, *a, **k):
+        return cls()
+
+    @classmethod
+    def from_epsg(cls, *a, **k):
+        return cls()
+
+
+class Transformer:
+    @classmethod
+    def from_crs(cls, *a, **k):
+        return cls()
+
+    def transform(self, x, y, *a, **k):
+        return x, y
+
+
+class Geodesic:
+    def inverse(self, loc, pts):
+        loc = np.asarray(loc, dtype=float).reshape(1, -1)
+        pts = np.asarray(pts, dtype=float)
+        d = np.sqrt(((pts - loc) ** 2).sum(axis=-1))
+        out = np.zeros((len(pts), 3))
+        out[:, 0] = d
+        return out
+
+
 def install():
     if "numba" in sys.modules and getattr(sys.modules["numba"], "_sbayes_amd_stub", False):
         return
@@ -51,28 +85,8 @@ def install():
 
     pyproj = types.ModuleType("pyproj")
 
-    class CRS:
-        def __init__(self, *a, **k):
-            pass
-
-        @classmethod
-        def from_user_input(cls, *a, **k):
-            return cls()
-
-        @classmethod
-        def from_epsg(cls, *a, **k):
-            return cls()
-
     pyproj.CRS = CRS
     transformer = types.ModuleType("pyproj.transformer")
-
-    class Transformer:
-        @classmethod
-        def from_crs(cls, *a, **k):
-            return cls()
-
-        def transform(self, x, y, *a, **k):
-            return x, y
 
     transformer.Transformer = Transformer
     pyproj.transformer = transformer
@@ -83,15 +97,6 @@ def install():
     cartopy = types.ModuleType("cartopy")
     cartopy.__version__ = "0.22.0"
     geodesic = types.ModuleType("cartopy.geodesic")
-
-    class Geodesic:
-        def inverse(self, loc, pts):
-            loc = np.asarray(loc, dtype=float).reshape(1, -1)
-            pts = np.asarray(pts, dtype=float)
-            d = np.sqrt(((pts - loc) ** 2).sum(axis=-1))
-            out = np.zeros((len(pts), 3))
-            out[:, 0] = d
-            return out
 
     geodesic.Geodesic = Geodesic
     cartopy.geodesic = geodesic
