@@ -343,9 +343,15 @@ int sbe_source_lh_by_feature(sbe_engine* e, int slot, float* out /* [F] */);
  * sbe_host_group_ids: ids_out[i] = offset + g for the one row g of `groups` ([n_groups][n_objects] bool, C order) that
  *     has objects[i] set, -1 if none (group_assignment[:, object_subset], sbayes/sampling/counts.py:21-24).
  * sbe_host_source_ids: ids_out[i][f] = the component c with source[objects[i]][f][c] set, 0xFF if none
- *     (source[object_subset, :, c], counts.py:25-27); `source` is [n_objects][F][C] bool, C order. */
+ *     (source[object_subset, :, c], counts.py:25-27); `source` is [n_objects][F][C] bool, C order.
+ * sbe_host_touched_groups: the sorted distinct global group indices >= 0 among gid_old / gid_new (`count` entries each):
+ *     sbe_counts_delta's `touched` argument (np.union1d of the two id arrays without the -1s); touched_out has room for
+ *     n_groups_total entries.
+ */
 int sbe_host_group_ids(const uint8_t* groups, int n_groups, int64_t n_objects, const int32_t* objects, int n, int offset,
                        int32_t* ids_out /* [n] */);
+int sbe_host_touched_groups(const int32_t* gid_old, const int32_t* gid_new, int64_t count, int n_groups_total,
+                            int32_t* touched_out /* [n_groups_total] */, int32_t* n_touched_out);
 int sbe_host_source_ids(const uint8_t* source, int64_t n_objects, int n_features, int n_components, const int32_t* objects,
                         int n, uint8_t* ids_out /* [n][F] */);
 

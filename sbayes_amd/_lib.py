@@ -94,6 +94,7 @@ PROTOTYPES = {
     "sbe_subset_lh": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int,
                                  ct.c_void_p, ct.c_double, ct.c_void_p]),
     "sbe_host_group_ids": (ct.c_int, [ct.c_void_p, ct.c_int, ct.c_int64, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p]),
+    "sbe_host_touched_groups": (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int64, ct.c_int, ct.c_void_p, ct.c_void_p]),
     "sbe_host_source_ids": (ct.c_int, [ct.c_void_p, ct.c_int64, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_set_uniform_counts": (ct.c_int, [c_engine_p, ct.c_void_p]),
     "sbe_counts_delta": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p,

@@ -1204,6 +1204,23 @@ int sbe_host_source_ids(const uint8_t* source, int64_t n_objects, int n_features
     return 0;
 }
 
+int sbe_host_touched_groups(const int32_t* gid_old, const int32_t* gid_new, int64_t count, int n_groups_total,
+                            int32_t* touched_out, int32_t* n_touched_out) {
+    if (count < 0 || n_groups_total < 0 || !touched_out || !n_touched_out || (count > 0 && (!gid_old || !gid_new))) return -1;
+    static thread_local std::vector<uint8_t> seen;
+    seen.assign((size_t)n_groups_total, 0);
+    for (int64_t i = 0; i < count; ++i) {
+        const int32_t a = gid_old[i], b = gid_new[i];
+        if (a < -1 || a >= n_groups_total || b < -1 || b >= n_groups_total) return -1;
+        if (a >= 0) seen[a] = 1;
+        if (b >= 0) seen[b] = 1;
+    }
+    int32_t n = 0;
+    for (int32_t g = 0; g < n_groups_total; ++g) if (seen[g]) touched_out[n++] = g;       // ascending, like np.union1d
+    *n_touched_out = n;
+    return 0;
+}
+
 int sbe_destroy(sbe_engine* e) {
     if (!e) return SBE_OK;
     (void)hipSetDevice(e->device);

@@ -36,9 +36,19 @@ class GroupOverlapError(EngineError):
 
 def _c(a, dtype):
     """C-contiguous view/copy with the exact dtype the ABI expects."""
+    if type(a) is np.ndarray and a.dtype == dtype and a.flags.c_contiguous:
+        return a
     a = np.asarray(a)
     if a.dtype == np.bool_ and dtype == np.uint8:
         a = a.view(np.uint8) if a.flags.c_contiguous else np.ascontiguousarray(a).view(np.uint8)
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _as(a, dtype):
+    """C-contiguous ndarray of exactly `dtype`: `a` itself when it already is one (the drop-in layer hands over arrays it
+    has just built in that form; np.ascontiguousarray costs a microsecond per argument to find that out)."""
+    if type(a) is np.ndarray and a.dtype == dtype and a.flags.c_contiguous:
+        return a
     return np.ascontiguousarray(a, dtype=dtype)
 
 
@@ -207,7 +217,7 @@ class Engine:
         f64 = probs.dtype == np.float64
         p = _c(probs, np.float64 if f64 else np.float32)
         g = _c(groups.astype(bool, copy=False), np.uint8)
-        ch = np.ascontiguousarray(changed_groups, dtype=np.int64).reshape(-1)
+        ch = _as(changed_groups, np.int64).reshape(-1)
         self._check(self._lib.sbe_component_lh(self._h, self._i(p), int(f64), n_groups, self._i(g), self._i(ch), ch.size,
                                                ct.c_void_p(out.ctypes.data), out.strides[0], out.strides[1],
                                                float(na_value)))
@@ -224,7 +234,7 @@ class Engine:
         self._check(self._lib.sbe_set_groups(self._h, slot, component, self._i(g)))
 
     def set_group_ids(self, slot, component, ids):
-        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        ids = _as(ids, np.int32)
         if ids.shape != (self.n_objects,):
             raise ValueError("ids must be [n_objects]")
         self._touch(slot)
@@ -239,7 +249,7 @@ class Engine:
         self._check(self._lib.sbe_set_source(self._h, slot, self._i(s)))
 
     def set_source_rows(self, slot, objects, rows):
-        objects = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        objects = _as(objects, np.int32).reshape(-1)
         rows = np.asarray(rows)
         if rows.shape != (objects.size, self.n_features, self.n_components):
             raise ValueError("rows must be [len(objects), n_features, n_components]")
@@ -249,7 +259,7 @@ class Engine:
 
     def get_source_rows(self, slot, objects):
         """bool [n, F, C]: the listed objects' rows of the slot's source."""
-        objects = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        objects = _as(objects, np.int32).reshape(-1)
         rows = np.empty((objects.size, self.n_features, self.n_components), dtype=np.uint8)
         self._check(self._lib.sbe_get_source_rows(self._h, slot, self._i(objects), objects.size, self._o(rows)))
         return rows.view(bool)
@@ -260,14 +270,14 @@ class Engine:
 
     def update_counts(self, slot_new, slot_old, objects):
         """update_feature_counts (counts.py:55-95); returns bool[G_total] of changed groups."""
-        objects = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        objects = _as(objects, np.int32).reshape(-1)
         changed = np.zeros(self.n_groups_total, dtype=np.uint8)
         self._touch(slot_new)
         self._check(self._lib.sbe_update_counts(self._h, slot_new, slot_old, self._i(objects), objects.size, self._o(changed)))
         return changed.astype(bool)
 
     def accumulate_counts(self, slot, objects, sign):
-        objects = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        objects = _as(objects, np.int32).reshape(-1)
         changed = np.zeros(self.n_groups_total, dtype=np.uint8)
         self._touch(slot)
         self._check(self._lib.sbe_accumulate_counts(self._h, slot, self._i(objects), objects.size, int(sign), self._o(changed)))
@@ -459,7 +469,7 @@ class Engine:
         if object_subset is None:
             objs, n_sub = None, -1
         else:
-            objs = np.ascontiguousarray(object_subset, dtype=np.int32).reshape(-1)
+            objs = _as(object_subset, np.int32).reshape(-1)
             n_sub = objs.size
         self._check(self._lib.sbe_effect_counts(self._h, self._i(g), g.shape[0], self._i(m),
                                                 self._i(objs) if objs is not None and n_sub > 0 else None, n_sub, self._o(out)))
@@ -483,7 +493,7 @@ class Engine:
         t = _c(table, np.float32).reshape(-1, self.n_states)
         if t.shape != (self.n_features, self.n_states):
             raise ValueError(f"table must be [{self.n_features}, {self.n_states}] (or [1, F, S])")
-        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        objs = _as(objects, np.int32).reshape(-1)
         out = np.empty((2, objs.size), dtype=np.float64)
         self._check(self._lib.sbe_cluster_marginals(self._h, slot, self._i(t), self._i(objs), objs.size,
                                                     float(prior_temperature), self._o(out)))
@@ -499,7 +509,7 @@ class Engine:
         if pc.shape[0] != n_conf:
             raise ValueError(f"pconf must hold the {n_conf} confounder groups' tables, got {pc.shape}")
         ps, pt = _c(p_source, np.float32).reshape(fs), _c(p_target, np.float32).reshape(fs)
-        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        objs = _as(objects, np.int32).reshape(-1)
         out = np.empty((2, objs.size), dtype=np.float64)
         self._check(self._lib.sbe_jump_lh(self._h, slot, self._i(pc) if n_conf else None, self._i(ps), self._i(pt), self._i(objs),
                                           objs.size, float(prior_temperature), self._o(out)))
@@ -515,7 +525,7 @@ class Engine:
     def source_posterior(self, slot, objects, temperature=1.0, prior_temperature=1.0):
         """float32 [n, F, C]: posterior of the source assignment of the listed objects' observations
         (GibbsSampleSource.calculate_source_posterior, operators.py:554-574)."""
-        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        objs = _as(objects, np.int32).reshape(-1)
         out = np.empty((objs.size, self.n_features, self.n_components), dtype=np.float32)
         self._check(self._lib.sbe_source_posterior(self._h, slot, self._i(objs), objs.size, float(temperature),
                                                    float(prior_temperature), self._o(out)))
@@ -527,7 +537,7 @@ class Engine:
         operators.py:518-528, with sample_categorical's uniforms `z` [n, F] supplied by the caller) and
         write them into `dst_slot`'s source.  Returns log_q (float), or (log_q, p_selected float32
         [n, F]) with return_selected."""
-        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        objs = _as(objects, np.int32).reshape(-1)
         zz = None
         if z is not None:                        # None: the engine's own Philox stream (set_rng)
             zz = _c(z, np.float64).reshape(objs.size, -1)
@@ -561,7 +571,7 @@ class Engine:
                        return_selected=False):
         """sum log p_slot[source of src_slot] over the listed objects' observations (log_q_back,
         operators.py:544-550)."""
-        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        objs = _as(objects, np.int32).reshape(-1)
         sel = np.empty((objs.size, self.n_features), dtype=np.float32) if return_selected else None
         log_q = ct.c_double()
         self._check(self._lib.sbe_source_logprob(self._h, slot, src_slot, self._i(objs), objs.size, float(temperature),
@@ -572,11 +582,11 @@ class Engine:
     def subset_lh(self, objects, tables, group_idx, temperature=1.0):
         """float32 [n, F, C]: likelihood of the listed objects' observations under per-component tables
         (`tables`: list of [G_c, F, S] float32; `group_idx`: int [C, n], -1 = no group)."""
-        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        objs = _as(objects, np.int32).reshape(-1)
         tabs = [_c(t, np.float32).reshape(-1, self.n_features, self.n_states) for t in tables]
         offsets = np.concatenate([[0], np.cumsum([t.shape[0] for t in tabs])]).astype(np.int32)
         cat = np.ascontiguousarray(np.concatenate(tabs, axis=0))
-        gi = np.ascontiguousarray(group_idx, dtype=np.int32)
+        gi = _as(group_idx, np.int32)
         if gi.shape != (len(tabs), objs.size):
             raise ValueError("group_idx must be [n_components, n_objects_in_subset]")
         out = np.empty((objs.size, self.n_features, len(tabs)), dtype=np.float32)
@@ -601,27 +611,30 @@ class Engine:
         per component (-1: none), src_* uint8 [n, F] source component per observation (255: none).  Returns
         (touched, diff): the sorted global indices of the groups any listed object is in (either state) and the float32
         rows [len(touched), F, S] of new_counts - old_counts; every other row of that difference is zero."""
-        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        objs = _as(objects, np.int32).reshape(-1)
         n = objs.size
-        go = np.ascontiguousarray(gid_old, dtype=np.int32).reshape(self.n_components, n)
-        gn = np.ascontiguousarray(gid_new, dtype=np.int32).reshape(self.n_components, n)
-        so = np.ascontiguousarray(src_old, dtype=np.uint8)
-        sn = np.ascontiguousarray(src_new, dtype=np.uint8)
-        if so.shape != (n, self.n_features) or sn.shape != so.shape:
-            raise ValueError(f"src_old / src_new must be [{n}, {self.n_features}]")
-        flags = np.zeros(self.n_groups_total + 1, dtype=np.bool_)      # (index -1 = "no group" lands on the spare last entry)
-        flags[go] = True
-        flags[gn] = True
-        touched = np.flatnonzero(flags[:-1]).astype(np.int32)
-        diff = np.zeros((touched.size, self.n_features, self.n_states), dtype=np.float32)
-        if touched.size and n:
-            self._check(self._lib.sbe_counts_delta(self._h, self._i(objs), n, self._i(go), self._i(gn), self._i(so), self._i(sn),
-                                                   self._i(touched), touched.size, self._o(diff)))
+        C, F = self.n_components, self.n_features
+        go = _as(gid_old, np.int32).reshape(C, n)
+        gn = _as(gid_new, np.int32).reshape(C, n)
+        so = _as(src_old, np.uint8)
+        sn = so if src_new is src_old else _as(src_new, np.uint8)
+        if so.shape != (n, F) or sn.shape != so.shape:
+            raise ValueError(f"src_old / src_new must be [{n}, {F}]")
+        # the groups any listed object is in, in either state (sorted): one pass in the library's host helper
+        touched = np.empty(self.n_groups_total, dtype=np.int32)
+        nt = ct.c_int32(0)
+        if self._lib.sbe_host_touched_groups(self._i(go), self._i(gn), C * n, self.n_groups_total, _ptr(touched), ct.byref(nt)) != 0:
+            raise ValueError("group index out of range in gid_old / gid_new")
+        touched = touched[:nt.value]
+        diff = np.zeros((nt.value, F, self.n_states), dtype=np.float32)
+        if nt.value and n:
+            self._check(self._lib.sbe_counts_delta(self._h, self._i(objs), n, _ptr(go), _ptr(gn), self._i(so), self._i(sn),
+                                                   self._i(touched), nt.value, self._o(diff)))
         return touched, diff
 
     def set_counts_rows(self, slot, group_idx, rows):
         """Rows `group_idx` (global group indices) of the slot's resident counts <- float32 rows [n, F, S]."""
-        gi = np.ascontiguousarray(group_idx, dtype=np.int32).reshape(-1)
+        gi = _as(group_idx, np.int32).reshape(-1)
         r = _c(rows, np.float32)
         if r.shape != (gi.size, self.n_features, self.n_states):
             raise ValueError(f"rows must be [{gi.size}, {self.n_features}, {self.n_states}], got {r.shape}")
@@ -632,7 +645,7 @@ class Engine:
     def given_unchanged_lh(self, slot, i_cluster, objects, temperature=1.0, prior_temperature=1.0):
         """component_likelihood_given_unchanged (operators.py:863-928) of the sample bound to `slot` (groups, source,
         counts, concentrations resident): float32 [n, F, C].  Only the object list goes up."""
-        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        objs = _as(objects, np.int32).reshape(-1)
         out = np.empty((objs.size, self.n_features, self.n_components), dtype=np.float32)
         self._check(self._lib.sbe_given_unchanged_lh(self._h, slot, int(i_cluster), self._i(objs), objs.size, float(temperature),
                                                      float(prior_temperature), self._o(out)))
@@ -641,7 +654,7 @@ class Engine:
     def cluster_posterior_marginals(self, slot, i_cluster, objects, temperature=1.0, prior_temperature=1.0):
         """cluster_marginals with the candidate table conditional_effect_mean(prior, counts[[i_cluster]], unif, T_prior, T)
         built on the device from the slot's resident counts (operators.py:1046-1052): float64 [2, n]."""
-        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        objs = _as(objects, np.int32).reshape(-1)
         out = np.empty((2, objs.size), dtype=np.float64)
         self._check(self._lib.sbe_cluster_posterior_marginals(self._h, slot, int(i_cluster), float(temperature),
                                                               float(prior_temperature), self._i(objs), objs.size, self._o(out)))
@@ -649,7 +662,7 @@ class Engine:
 
     def jump_lh_resident(self, slot, i_source, i_target, objects, temperature=1.0, prior_temperature=1.0):
         """jump_lh with every tempered table built on the device from the slot's resident counts: float64 [2, n]."""
-        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        objs = _as(objects, np.int32).reshape(-1)
         out = np.empty((2, objs.size), dtype=np.float64)
         self._check(self._lib.sbe_jump_lh_resident(self._h, slot, int(i_source), int(i_target), float(temperature),
                                                    float(prior_temperature), self._i(objs), objs.size, self._o(out)))
@@ -679,7 +692,7 @@ class Engine:
         objs = rows = None
         n_changed = 0
         if changed_objects is not None and len(changed_objects):
-            objs = np.ascontiguousarray(changed_objects, dtype=np.int32).reshape(-1)
+            objs = _as(changed_objects, np.int32).reshape(-1)
             rows = np.asarray(source_rows)
             if rows.shape != (objs.size, self.n_features, self.n_components):
                 raise ValueError("source_rows must be [len(changed_objects), n_features, n_components]")
@@ -706,8 +719,8 @@ class Engine:
         (or None), clusters_mask bool [n] (or None = every chain), rows_ptr int [n+1] CSR over changed_objects /
         source_rows bool [total, F, C] (or None = no source change), weights float32 [n, F, C] + weights_mask.
         Returns (group_logliks float64 [n, G_total], mixture_ll float64 [n], changed_groups bool [n, G_total])."""
-        cur = np.ascontiguousarray(cur_slots, dtype=np.int32).reshape(-1)
-        cand = np.ascontiguousarray(cand_slots, dtype=np.int32).reshape(-1)
+        cur = _as(cur_slots, np.int32).reshape(-1)
+        cand = _as(cand_slots, np.int32).reshape(-1)
         n = cur.size
         if cand.size != n:
             raise ValueError("cur_slots and cand_slots must have the same length")
@@ -723,11 +736,11 @@ class Engine:
             ptr = np.zeros(n + 1, dtype=np.int32)
             objs = rows = None
         else:
-            ptr = np.ascontiguousarray(rows_ptr, dtype=np.int32).reshape(-1)
+            ptr = _as(rows_ptr, np.int32).reshape(-1)
             if ptr.size != n + 1:
                 raise ValueError("rows_ptr must have n_chains + 1 entries")
             total = int(ptr[-1])
-            objs = np.ascontiguousarray(changed_objects, dtype=np.int32).reshape(-1) if total else None
+            objs = _as(changed_objects, np.int32).reshape(-1) if total else None
             rows = np.asarray(source_rows) if total else None
             if total and (objs.size != total or rows.shape != (total, self.n_features, self.n_components)):
                 raise ValueError("changed_objects / source_rows do not match rows_ptr")
@@ -762,7 +775,7 @@ class Engine:
         objs = rows = None
         n_changed = 0
         if changed_objects is not None and len(changed_objects):
-            objs = np.ascontiguousarray(changed_objects, dtype=np.int32).reshape(-1)
+            objs = _as(changed_objects, np.int32).reshape(-1)
             rows = np.asarray(source_rows)
             if rows.shape != (objs.size, self.n_features, self.n_components):
                 raise ValueError("source_rows must be [len(changed_objects), n_features, n_components]")
@@ -787,25 +800,25 @@ class Engine:
         """sbe_step_batch with the proposals in delta form: moved_ptr int [n+1] CSR over moved_objects / moved_cluster
         (new cluster index, -1 = none); rows_ptr / changed_objects / source_rows as in step_batch (each object once per
         chain); weights float32 [n, F, C] + weights_mask.  Same return values as step_batch."""
-        cur = np.ascontiguousarray(cur_slots, dtype=np.int32).reshape(-1)
-        cand = np.ascontiguousarray(cand_slots, dtype=np.int32).reshape(-1)
+        cur = _as(cur_slots, np.int32).reshape(-1)
+        cand = _as(cand_slots, np.int32).reshape(-1)
         n = cur.size
-        mp = np.ascontiguousarray(moved_ptr, dtype=np.int32).reshape(-1)
+        mp = _as(moved_ptr, np.int32).reshape(-1)
         if cand.size != n or mp.size != n + 1:
             raise ValueError("cur_slots / cand_slots / moved_ptr do not match")
-        mo = np.ascontiguousarray(moved_objects, dtype=np.int32).reshape(-1)
-        mc = np.ascontiguousarray(moved_cluster, dtype=np.int32).reshape(-1)
+        mo = _as(moved_objects, np.int32).reshape(-1)
+        mc = _as(moved_cluster, np.int32).reshape(-1)
         if mo.size != int(mp[-1]) or mc.size != mo.size:
             raise ValueError("moved_objects / moved_cluster do not match moved_ptr")
         if rows_ptr is None:
             ptr = np.zeros(n + 1, dtype=np.int32)
             objs = rows = None
         else:
-            ptr = np.ascontiguousarray(rows_ptr, dtype=np.int32).reshape(-1)
+            ptr = _as(rows_ptr, np.int32).reshape(-1)
             if ptr.size != n + 1:
                 raise ValueError("rows_ptr must have n_chains + 1 entries")
             total = int(ptr[-1])
-            objs = np.ascontiguousarray(changed_objects, dtype=np.int32).reshape(-1) if total else None
+            objs = _as(changed_objects, np.int32).reshape(-1) if total else None
             rows = np.asarray(source_rows) if total else None
             if total and (objs.size != total or rows.shape != (total, self.n_features, self.n_components)):
                 raise ValueError("changed_objects / source_rows do not match rows_ptr")
@@ -834,7 +847,7 @@ class Engine:
         """One Gibbs-source MCMC step in one call (sbe_gibbs_step): the listed objects' source is redrawn on the
         device into `cand_slot`, counts / tables / likelihoods follow.  z: uniforms [n, F] or None (engine's Philox
         stream).  Returns (log_q, log_q_back, group_logliks [G_total], mixture_ll, changed_groups bool [G_total])."""
-        objs = np.ascontiguousarray(objects, dtype=np.int32).reshape(-1)
+        objs = _as(objects, np.int32).reshape(-1)
         zz = None
         if z is not None:
             zz = _c(z, np.float64).reshape(objs.size, -1)
@@ -852,21 +865,21 @@ class Engine:
 
     def test_fast_log(self, x):
         """(fast, library) fp64 logs of x computed on the device (self-test of the table-build log)."""
-        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        x = _as(x, np.float64).reshape(-1)
         a, b = np.empty_like(x), np.empty_like(x)
         self._check(self._lib.sbe_test_fast_log(self._h, self._i(x), x.size, self._o(a), self._o(b)))
         return a, b
 
     def test_lgamma(self, x):
         """The engine's lgamma (Dirichlet-categorical terms) of x, computed on the device (self-test)."""
-        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        x = _as(x, np.float64).reshape(-1)
         out = np.empty_like(x)
         self._check(self._lib.sbe_test_lgamma(self._h, self._i(x), x.size, self._o(out)))
         return out
 
     def test_tab_log(self, x):
         """Table-driven fp64 log of k_mixture_tuple64's table build, computed on the device (self-test)."""
-        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        x = _as(x, np.float64).reshape(-1)
         out = np.empty_like(x)
         self._check(self._lib.sbe_test_tab_log(self._h, self._i(x), x.size, self._o(out)))
         return out
