@@ -460,6 +460,21 @@ def sampler_replay_block(device, with_cpu):
                 reference_steps_per_s={"same_container_as_host_python": r["plain_reference_steps_per_s"],
                                        "survey_section_6": survey_steps_per_s[tag]},
                 end_to_end_speedup_bound=round(1e6 / (host_us + gpu_us) / r["plain_reference_steps_per_s"], 2))
+            # the same run with GibbsSampleSource._propose's body on the device (patch.install(gibbs_source=True)): its own
+            # recorded call log where one is shipped, its own host residual
+            g = r.get("with_gibbs_source_on_device")
+            if g and (REPO / "tests" / "golden" / f"{tag}_gibbs_calls.npz").exists():
+                try:
+                    gr = run(f"{tag}_gibbs", cpu=False, repeats=3, device=device)
+                    g_host = g["host_python_us_per_step"]["mean"]
+                    out[tag]["gibbs_source_on_device"] = {
+                        "calls_per_step": gr["calls_per_step"], "gpu_us_per_step": gr["gpu_us_per_step"],
+                        "h2d_bytes_per_step": gr.get("h2d_bytes_per_step"), "d2h_bytes_per_step": gr.get("d2h_bytes_per_step"),
+                        "host_python_us_per_step": g_host,
+                        "end_to_end_steps_per_s_bound": round(1e6 / (g_host + gr["gpu_us_per_step"]), 1),
+                        "end_to_end_speedup_bound": round(1e6 / (g_host + gr["gpu_us_per_step"]) / r["plain_reference_steps_per_s"], 2)}
+                except Exception as exc:             # noqa: BLE001  (a secondary figure never takes the bench line down)
+                    out[tag]["gibbs_source_on_device"] = {"error": repr(exc)}
     out["note"] = ("per recorded MCMC step of the real sampler.  gpu_us_per_step: engine-side cost measured in this run (the "
                    "recorded engine calls replayed against the device); cpu_us_per_step: the same call sequence served by the "
                    "NumPy oracle on this host, single thread.  host_python_us_per_step (STATIC, tests/golden/host_residual.json, "
@@ -467,7 +482,10 @@ def sampler_replay_block(device, with_cpu):
                    "time of the real sampler's MCMC step when every engine call returns a recorded result in O(1) = the "
                    "reference's own Python (proposal logic, RNG, cache bookkeeping, priors) plus host_layer_us_per_step of this "
                    "package's host layer.  end_to_end_steps_per_s_bound = 1e6 / (host_python_us_per_step + gpu_us_per_step): "
-                   "what the patched sampler can reach; reference_steps_per_s: the unpatched reference (NumPy path).")
+                   "what the patched sampler can reach; reference_steps_per_s: the unpatched reference (NumPy path).  "
+                   "gibbs_source_on_device: the same with patch.install(gibbs_source=True) -- GibbsSampleSource._propose's body "
+                   "(posterior, draw with the reference's own uniforms, count delta, transition probabilities) as engine calls; "
+                   "same Markov chain (tests/test_reference_sampler_cpu.py), its own call log and host residual.")
     return out
 
 

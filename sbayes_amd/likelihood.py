@@ -81,8 +81,9 @@ class Likelihood:
         self._freeze_static_inputs()                        # (flags do not travel through pickle)
         if how is not None:
             from . import patch
-            if patch.installed() is None or (how["operators"] and not patch.installed()["operators"]):
-                patch.install(operators=how["operators"])
+            cur = patch.installed()
+            if cur is None or (how["operators"] and not cur["operators"]) or (how.get("gibbs_source") and not cur.get("gibbs_source")):
+                patch.install(operators=how["operators"], gibbs_source=bool(how.get("gibbs_source")))
         registry.note_features(self.features, self.n_groups)
 
     @property

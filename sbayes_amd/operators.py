@@ -22,6 +22,7 @@ from __future__ import annotations
 import numpy as np
 
 from .binding import _bind_slot, _bind_uniform, _engine, _tables_current
+from .counts import update_feature_counts
 
 EPS = np.finfo(np.float32).eps        # sbayes/util.py:34
 
@@ -142,8 +143,9 @@ def gibbs_sample_source(model, sample, object_subset=slice(None), temperature=1.
 
     sample_new = sample.copy()
     sample_new.source.set_groups(object_subset, eng.get_source_rows(new, objects))
-    for c, name in enumerate(sample.component_names):
-        sample_new.feature_counts[name].add_changes(diff=eng.get_counts(new, c) - eng.get_counts(cur, c))
+    # the count delta exactly as the reference applies it (update_feature_counts -> add_changes per component): one
+    # stateless call that returns the rows of the groups the subset's objects are in -- not 2 C whole tables
+    update_feature_counts(sample, sample_new, model.data.features.values, object_subset)
     return sample_new, log_q, log_q_back
 
 

@@ -58,6 +58,7 @@ MIRRORED_SOURCES = {
     "LikelihoodLogger._write_sample": "5f892d865e576862f5e1730acbf3b18efc7af9da",
     "ClusterEffectProposals.expected_confounder_features": "efb685c5e0b1f2818dde1f2244d6f0ff086107cc",
     "SourcePrior.__call__": "c76b2825409bc280761a6b598113f74c9b395dbb",
+    "GibbsSampleSource._propose": "61911f12df7948eea0f207e45f49d97d7e0e5352",
 }
 
 
@@ -107,8 +108,14 @@ def set_mp_start_method(method):
     return method
 
 
-def install(operators=False, mp_start_method=None):
+def install(operators=False, mp_start_method=None, gibbs_source=False):
+    """operators=True: the device forms listed in the module docstring.  gibbs_source=True (implies operators): the body
+    of GibbsSampleSource._propose (operators.py:495-552) after its own `select_object_subset` -- posterior, draw
+    (`sample_categorical` with the uniforms np.random yields at that point, draw for draw), new source rows, count delta,
+    both transition log-probabilities -- runs on the device (operators.gibbs_sample_source: SURVEY.md 8(f) rank 3); at the
+    headline shape that body is the largest single item of the reference's per-step Python."""
     global _INSTALLED
+    operators = bool(operators) or bool(gibbs_source)
     if mp_start_method is not None:
         set_mp_start_method(mp_start_method)
     from . import conditionals as my_cond
@@ -153,6 +160,8 @@ def install(operators=False, mp_start_method=None):
         swap(mod, "update_feature_counts", my_counts.update_feature_counts)
     if operators:
         _install_operator_forms(swap)
+    if gibbs_source:
+        _install_gibbs_source_form(swap)
     for m in importers:
         for name, new in (("likelihood_per_component", my_cond.likelihood_per_component),
                           ("update_weights", my_lik.update_weights),
@@ -162,7 +171,23 @@ def install(operators=False, mp_start_method=None):
                           ("compute_effect_counts", my_counts.compute_effect_counts),
                           ("compute_component_likelihood", my_lik.compute_component_likelihood)):
             swap(m, name, new)
-    _INSTALLED = {"operators": bool(operators) or bool(_INSTALLED and _INSTALLED["operators"])}
+    _INSTALLED = {"operators": bool(operators) or bool(_INSTALLED and _INSTALLED["operators"]),
+                  "gibbs_source": bool(gibbs_source) or bool(_INSTALLED and _INSTALLED.get("gibbs_source"))}
+
+
+def _install_gibbs_source_form(swap):
+    from . import operators as my_ops
+    ref_ops = importlib.import_module("sbayes.sampling.operators")
+    _check_mirrored(ref_ops.GibbsSampleSource, "_propose")
+
+    def _propose(self, sample, object_subset=slice(None), **kwargs):
+        """GibbsSampleSource._propose (operators.py:495-552): the subset comes from the reference's own
+        select_object_subset (its RNG use unchanged); everything after it runs on the device."""
+        object_subset = self.select_object_subset(sample)
+        return my_ops.gibbs_sample_source(self.model, sample, object_subset, self.temperature, self.prior_temperature,
+                                          self.sample_from_prior)
+
+    swap(ref_ops.GibbsSampleSource, "_propose", _propose)
 
 
 def _install_operator_forms(swap):

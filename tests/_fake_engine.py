@@ -212,6 +212,65 @@ class FakeEngine:
     def get_counts(self, slot, component):
         return self._slot(slot)["counts"][component].copy()
 
+    # ---- Gibbs source proposal on slot state (operators.gibbs_sample_source; sbe_sample_source / sbe_source_logprob) ----
+    def copy_slot(self, dst, src):
+        import copy
+        self._touch(dst)
+        self.calls.append(("copy_slot",))
+        self.slots[dst] = copy.deepcopy(self._slot(src))
+
+    def _source_probs(self, slot, objects, temperature, prior_temperature, from_prior):
+        groups, weights, lh = self._state(slot)
+        w = orc.normalize_weights(weights, orc.has_components(groups))
+        if from_prior:                                            # operators.py:520-522
+            return orc.normalize(w[objects] ** (1 / float(prior_temperature)), axis=-1)
+        return orc.source_posterior(lh, w, objects, float(temperature), float(prior_temperature))
+
+    def sample_source(self, slot, dst_slot, objects, z, temperature=1.0, prior_temperature=1.0, from_prior=False,
+                      return_selected=False):
+        self._touch(dst_slot)
+        self.calls.append(("sample_source", len(objects)))
+        objects = np.asarray(objects)
+        p = self._source_probs(slot, objects, temperature, prior_temperature, from_prior)
+        idx = orc.sample_categorical(p, np.asarray(z, dtype=np.float64).reshape(objects.size, self.n_features))
+        x = np.eye(p.shape[-1], dtype=bool)[idx]
+        na = self.na_values()[objects]
+        x[na] = False                                             # operators.py:527
+        self._slot(dst_slot)["source"][objects] = x
+        sel = np.take_along_axis(p, idx[..., None], axis=-1)[..., 0].astype(np.float32)
+        with np.errstate(divide="ignore"):
+            log_q = float(np.log(sel[~na]).sum())
+        return (log_q, sel) if return_selected else log_q
+
+    def source_logprob(self, slot, src_slot, objects, temperature=1.0, prior_temperature=1.0, from_prior=False,
+                       return_selected=False):
+        self.calls.append(("source_logprob", len(objects)))
+        objects = np.asarray(objects)
+        p = self._source_probs(slot, objects, temperature, prior_temperature, from_prior)
+        src = self._slot(src_slot)["source"][objects]
+        sel = np.where(src.any(axis=-1), np.take_along_axis(p, src.argmax(axis=-1)[..., None], axis=-1)[..., 0], 1.0).astype(np.float32)
+        na = self.na_values()[objects]
+        with np.errstate(divide="ignore"):
+            log_q = float(np.log(sel[~na]).sum())
+        return (log_q, sel) if return_selected else log_q
+
+    def update_counts(self, slot_new, slot_old, objects):
+        self._touch(slot_new)
+        self.calls.append(("update_counts", len(objects)))
+        new, old = self._slot(slot_new), self._slot(slot_old)
+        C = len(new["groups"])
+        mask = np.zeros(self.n_objects, dtype=bool)
+        mask[np.asarray(objects)] = True
+        counts, changed = orc.update_feature_counts([old["counts"][c] for c in range(C)], self.features,
+                                                    [old["groups"][c] for c in range(C)], [new["groups"][c] for c in range(C)],
+                                                    old["source"], new["source"], mask)
+        for c in range(C):
+            new["counts"][c] = counts[c]
+        return np.concatenate(changed)
+
+    def get_source_rows(self, slot, objects):
+        return self._slot(slot)["source"][np.asarray(objects)].copy()
+
     # ---- round 3: delta / resident forms ------------------------------------------------------------------------
     def set_uniform_counts(self, unif_counts):
         self.unif = np.asarray(unif_counts, dtype=np.float64).copy()

@@ -980,7 +980,7 @@ def gibbs_source_fixture():
         os.chdir(cwd)
 
 
-def call_log_fixture(tag, config_path: Path, n_steps: int, seed: int):
+def call_log_fixture(tag, config_path: Path, n_steps: int, seed: int, gibbs_source: bool = False):
     """The reference's own sampler -- initialiser, operator schedule, MH loop -- on the drop-in host layer under
     patch.install(operators=True), the device replaced by the recording double (tests/_call_log.py): writes
     <tag>_calls.npz = the sequence of Engine-level calls with their argument arrays and expected results."""
@@ -990,12 +990,14 @@ def call_log_fixture(tag, config_path: Path, n_steps: int, seed: int):
     from sbayes.sampling.initializers import SbayesInitializer
     from sbayes.sampling.mcmc_chain import MCMCChain
     from sbayes_amd import conditionals, counts, likelihood, patch, registry
-    from tests._call_log import RecordingEngine, save
+    from tests._call_log import RecordingEngine, record_uniform_draws, save
     from tests._fake_engine import make_engine_for_observations, make_get_engine
 
     engines = {}
 
     get_engine = make_get_engine(engines, RecordingEngine)
+    draws = record_uniform_draws()                            # (uniforms handed to an engine call are logged as generator states)
+    draws.__enter__()
 
     def engine_for_features(f):                               # registry.engine_for_features with the double
         for e in engines.values():
@@ -1009,12 +1011,13 @@ def call_log_fixture(tag, config_path: Path, n_steps: int, seed: int):
                 mock.patch.object(registry, "engine_for_observations", make_engine_for_observations(engines))]
     for p in patches:
         p.start()
-    patch.install(operators=True)
+    patch.install(operators=True, gibbs_source=gibbs_source)
+    out_tag = f"{tag}_gibbs" if gibbs_source else tag
     cwd = os.getcwd()
     try:
         seed_reference(seed)
         os.chdir(config_path.parent)
-        experiment = Experiment(config_file=config_path, experiment_name=f"calls_{tag}", log=False)
+        experiment = Experiment(config_file=config_path, experiment_name=f"calls_{out_tag}", log=False)
         data = Data.from_config(experiment.config)
         from sbayes.model import Model as PatchedModel
         model = PatchedModel(data, experiment.config.model)
@@ -1036,20 +1039,21 @@ def call_log_fixture(tag, config_path: Path, n_steps: int, seed: int):
             sample.i_step = i
             ops.append(chain.previous_operator.operator_name)
             eng.log[-1 - next(k for k, c in enumerate(reversed(eng.log)) if c["m"] == "__step__")]["op"] = ops[-1]
-        meta = dict(tag=tag, n_steps=n_steps, seed=seed, n_groups=[int(g) for g in eng.n_groups],
+        meta = dict(tag=out_tag, gibbs_source=gibbs_source, n_steps=n_steps, seed=seed, n_groups=[int(g) for g in eng.n_groups],
                     shape=list(data.features.values.shape), features_crc=crc(data.features.values),
                     operators=sorted(set(ops)), final_ll=float(chain._ll))
-        save(OUT / f"{tag}_calls.npz", eng, meta)
+        save(OUT / f"{out_tag}_calls.npz", eng, meta)
         kinds = {}
         for c in eng.log:
             kinds[c["m"]] = kinds.get(c["m"], 0) + 1
-        print(f"[golden] {tag}_calls: {len(eng.log)} calls, {len(eng.store.arrays)} distinct arrays, "
+        print(f"[golden] {out_tag}_calls: {len(eng.log)} calls, {len(eng.store.arrays)} distinct arrays, "
               f"{sum(a.nbytes for a in eng.store.arrays) / 1e6:.1f} MB raw; {kinds}")
     finally:
         os.chdir(cwd)
         patch.uninstall()
         for p in patches:
             p.stop()
+        draws.__exit__(None, None, None)
 
 
 def call_log_fixtures():
@@ -1059,6 +1063,10 @@ def call_log_fixtures():
     call_log_fixture("south_america", sa / "config.yaml", n_steps=60, seed=22)
     call_log_fixture("cfg1", write_synthetic_config("cfg1"), n_steps=80, seed=23)
     call_log_fixture("headline", write_synthetic_config("headline"), n_steps=48, seed=24)
+    # the same runs with the Gibbs source proposal on the device (patch.install(gibbs_source=True)): <tag>_gibbs_calls.npz
+    sa = stage_config(Path("/root/reference/experiments/south_america"), "south_america_gibbs_calls")
+    call_log_fixture("south_america", sa / "config.yaml", n_steps=60, seed=22, gibbs_source=True)
+    call_log_fixture("headline", write_synthetic_config("headline"), n_steps=48, seed=24, gibbs_source=True)
 
 
 def main():
@@ -1069,7 +1077,10 @@ def main():
               "headline_trace": lambda: synthetic_trace_fixture("headline", 300, 12),
               "test_files": lambda: real_fixture("test_files", stage_config(Path("/root/reference/test/test_files"), "test_files") / "config.yaml", 300, 321),
               "south_america": lambda: real_fixture("south_america", stage_config(Path("/root/reference/experiments/south_america"), "south_america") / "config.yaml", 400, 123),
-              "call_logs": call_log_fixtures, "overlap": overlap_fixture, "dynamic_prior": dynamic_prior_fixture}
+              "call_logs": call_log_fixtures, "overlap": overlap_fixture, "dynamic_prior": dynamic_prior_fixture,
+              "gibbs_call_logs": lambda: (
+                  call_log_fixture("south_america", stage_config(Path("/root/reference/experiments/south_america"), "south_america_gibbs_calls") / "config.yaml", 60, 22, True),
+                  call_log_fixture("headline", write_synthetic_config("headline"), 48, 24, True))}
     if only:
         for name in only:
             single[name]()

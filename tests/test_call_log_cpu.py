@@ -10,6 +10,7 @@ from tests._fixtures import GOLDEN, crc, load_npz
 
 
 def features_of(tag):
+    tag = tag.replace("_gibbs", "")                  # (<shape>_gibbs_calls.npz: the same data, patch.install(gibbs_source=True))
     if tag in ("cfg1", "headline"):
         from sbayes_amd.synthetic import make_workload
         return make_workload(tag).features
@@ -30,3 +31,16 @@ def test_call_log_replays_on_the_double(tag):
     assert {"AlterCluster", "GibbsSampleSource"} <= set(meta["operators"])
     # through the bind cache: fewer uploads than evaluations
     assert counts["set_groups"] < counts["cluster_marginals"] + counts["cluster_posterior_marginals"] + counts["source_posterior"]
+
+
+@pytest.mark.parametrize("tag", ["south_america_gibbs", "headline_gibbs"])
+def test_gibbs_source_call_log_replays_on_the_double(tag):
+    """The logs recorded under patch.install(gibbs_source=True): GibbsSampleSource._propose's body as engine calls on slot
+    state (copy_slot, sample_source with the uniforms regenerated from their recorded generator state, update_counts,
+    source_logprob, get_source_rows)."""
+    feats = features_of(tag)
+    counts, meta = replay(GOLDEN / f"{tag}_calls.npz", lambda n_groups: FakeEngine(feats, n_groups))
+    assert meta["gibbs_source"] and crc(feats) == meta["features_crc"]
+    assert {"copy_slot", "sample_source", "update_counts", "source_logprob", "get_source_rows", "counts_delta"} <= set(counts)
+    assert counts["sample_source"] == counts["source_logprob"] == counts["get_source_rows"] >= 10
+    assert "GibbsSampleSource" in meta["operators"]

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference sBayes
 
 
 def run_chain(config_src: Path, tag: str, n_steps: int, seed: int, patched: bool, monkeypatch, tmp_path,
-              operators: bool = False):
+              operators: bool = False, gibbs_source: bool = False):
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
     import _ref_stubs
     _ref_stubs.install()
@@ -36,7 +36,7 @@ def run_chain(config_src: Path, tag: str, n_steps: int, seed: int, patched: bool
     from sbayes_amd import conditionals, counts, likelihood, patch, registry
     from tests._fake_engine import FakeEngine, make_engine_for_observations, make_get_engine
 
-    work = tmp_path / f"{tag}_{'patched' if patched else 'plain'}{'_ops' if operators else ''}"
+    work = tmp_path / f"{tag}_{'patched' if patched else 'plain'}{'_ops' if operators else ''}{'_gibbs' if gibbs_source else ''}"
     shutil.copytree(config_src, work)
     engines = {}
 
@@ -50,7 +50,7 @@ def run_chain(config_src: Path, tag: str, n_steps: int, seed: int, patched: bool
                             lambda f: next((e for e in engines.values() if e.n_features == f), None)
                             or FakeEngine(np.zeros((1, f, 1), dtype=bool)))
         monkeypatch.setattr(registry, "engine_for_observations", make_engine_for_observations(engines))
-        patch.install(operators=operators)
+        patch.install(operators=operators, gibbs_source=gibbs_source)
     try:
         np.random.seed(seed)
         random.seed(seed)
@@ -134,6 +134,30 @@ def test_reference_sampler_with_device_operator_forms(tag, src, n_steps, monkeyp
     n_rows = sum(c[0] in ("set_counts_rows", "set_source_rows") for c in eng.calls)
     n_full = sum(c[0] in ("set_counts", "set_source") for c in eng.calls)
     assert n_rows > 0 and (tag == "test_files" or n_full < n_rows), (n_full, n_rows)
+
+
+@pytest.mark.parametrize("tag,src,n_steps", [
+    ("test_files", Path(REF) / "test" / "test_files", 250),
+    ("south_america", Path(REF) / "experiments" / "south_america", 120),
+])
+def test_reference_sampler_with_the_gibbs_source_proposal_on_the_device(tag, src, n_steps, monkeypatch, tmp_path):
+    """patch.install(gibbs_source=True): the body of GibbsSampleSource._propose (posterior, sample_categorical, new rows,
+    count delta, log_q, log_q_back -- operators.py:513-552) replaced by operators.gibbs_sample_source; the object subset
+    still comes from the reference's select_object_subset and the uniforms from np.random at the same point of its stream.
+    Same operators, same states (the draws are the reference's, draw for draw), same likelihood / prior trace."""
+    plain = run_chain(src, tag, n_steps, 11, False, monkeypatch, tmp_path)
+    patched = run_chain(src, tag, n_steps, 11, True, monkeypatch, tmp_path, operators=True, gibbs_source=True)
+    assert [t[2] for t in patched[0]] == [t[2] for t in plain[0]]
+    np.testing.assert_allclose([t[:2] for t in patched[0]], [t[:2] for t in plain[0]], rtol=1e-12)
+    assert np.array_equal(patched[1], plain[1]) and np.array_equal(patched[2], plain[2])       # clusters, source: identical
+    assert np.array_equal(patched[3], plain[3])
+    eng = next(iter(patched[4].values()))
+    kinds = {c[0] for c in eng.calls}
+    assert {"sample_source", "source_logprob", "update_counts", "copy_slot"} <= kinds, kinds
+    assert "GibbsSampleSource" in {t[2] for t in patched[0]}
+    n_gibbs = sum(t[2] == "GibbsSampleSource" for t in patched[0])
+    assert sum(c[0] == "sample_source" for c in eng.calls) >= n_gibbs               # every such step went through the device form
+    assert "source_posterior" not in kinds or tag == "south_america"                # (ClusterJump's own gibbs_sample_source_jump still asks the posterior)
 
 
 def test_operator_forms_are_tied_to_the_reference_bodies_they_mirror(monkeypatch):

@@ -41,7 +41,9 @@ import make_golden as mg  # noqa: E402  (installs the stubs, imports the referen
 
 from tests._fake_engine import FakeEngine, make_engine_for_observations, make_get_engine  # noqa: E402
 
-TOUCHERS = {"set_groups", "set_counts", "set_source", "set_weights", "recount", "set_counts_rows", "set_source_rows"}
+# methods of the real Engine that drop a slot's bind-cache entry (Engine._touch) -> which positional argument names the slot
+TOUCHERS = {"set_groups": 0, "set_counts": 0, "set_source": 0, "set_weights": 0, "recount": 0, "set_counts_rows": 0,
+            "set_source_rows": 0, "copy_slot": 0, "sample_source": 1, "update_counts": 0}
 PUBLIC = [n for n in dir(FakeEngine) if not n.startswith("_") and callable(getattr(FakeEngine, n))
           and n not in ("close", "na_values")]
 
@@ -110,7 +112,7 @@ class ReplayEngine:
             if want != name:
                 raise AssertionError(f"call {self._pos - 1}: pass 2 asks {name}, pass 1 asked {want}")
             if name in TOUCHERS:
-                self._touch(args[0])
+                self._touch(args[TOUCHERS[name]])
             elif name == "set_concentration":
                 self._bound.clear()
                 self._bound_conc.pop(args[0], None)
@@ -184,7 +186,7 @@ class _LayerClock:
             setattr(mod, name, cur)
 
 
-def _run(config_path: Path, tag: str, n_steps: int, seed: int, mode: str, memo=None, layer_clock=False):
+def _run(config_path: Path, tag: str, n_steps: int, seed: int, mode: str, memo=None, layer_clock=False, gibbs_source=False):
     """mode: 'memo' (pass 1), 'replay' (pass 2), 'plain' (unpatched reference).  Returns (per-step seconds, operator
     names, engine)."""
     from sbayes.experiment_setup import Experiment
@@ -224,7 +226,7 @@ def _run(config_path: Path, tag: str, n_steps: int, seed: int, mode: str, memo=N
                     mock.patch.object(registry, "engine_for_observations", make_engine_for_observations(engines))]
         for p in patches:
             p.start()
-        patch.install(operators=True)
+        patch.install(operators=True, gibbs_source=gibbs_source)
     clock = None
     if layer_clock and mode == "replay":
         clock = _LayerClock()
@@ -285,18 +287,19 @@ def _summary(secs):
             "p10": round(float(np.percentile(us, 10)), 2), "p90": round(float(np.percentile(us, 90)), 2)}
 
 
-def measure(tag, config_path, n_steps, seed):
-    secs1, _, ops1, eng1, ll1 = _run(config_path, tag, n_steps, seed, "memo")
+def measure(tag, config_path, n_steps, seed, gibbs_source=False):
+    secs1, _, ops1, eng1, ll1 = _run(config_path, tag, n_steps, seed, "memo", gibbs_source=gibbs_source)
     memo = eng1.memo
     best = None
     for _ in range(3):                                               # three replays, the fastest kept (host noise)
-        secs2, inside2, ops2, eng2, ll2 = _run(config_path, tag, n_steps, seed, "replay", memo=memo)
+        secs2, inside2, ops2, eng2, ll2 = _run(config_path, tag, n_steps, seed, "replay", memo=memo, gibbs_source=gibbs_source)
         assert ops2 == ops1 and ll2 == ll1 and eng2._pos <= len(memo)
         if best is None or sum(secs2) < sum(best[0]):
             best = (secs2, inside2)
     secs2, inside2 = best
     # one more replay with the host-layer clock on (its wrappers cost a little: not the run the residual is taken from)
-    _s, inside3, _o, _e, _l, layer3 = _run(config_path, tag, n_steps, seed, "replay", memo=memo, layer_clock=True)
+    _s, inside3, _o, _e, _l, layer3 = _run(config_path, tag, n_steps, seed, "replay", memo=memo, layer_clock=True,
+                                           gibbs_source=gibbs_source)
     ours = np.asarray(layer3) - np.asarray(inside3)
     secs0, _, ops0, _, ll0 = _run(config_path, tag, n_steps, seed, "plain")
     resid = np.asarray(secs2) - np.asarray(inside2)
@@ -306,7 +309,7 @@ def measure(tag, config_path, n_steps, seed):
         by_op[op] = {"steps": int(sel.sum()), "residual_us": _summary(resid[sel]), "plain_us": _summary(np.asarray(secs0)[np.array([o == op for o in ops0])]) if op in ops0 else None}
     n_calls = sum(1 for _ in memo)
     return {
-        "tag": tag, "n_steps": n_steps, "seed": seed, "engine_calls_total": n_calls,
+        "tag": tag, "n_steps": n_steps, "seed": seed, "engine_calls_total": n_calls, "gibbs_source_on_device": bool(gibbs_source),
         "host_python_us_per_step": _summary(resid),
         "of_which_this_packages_host_layer_us_per_step": _summary(ours),
         "replay_double_us_per_step": _summary(inside2),
@@ -342,6 +345,13 @@ def main():
         print(f"[residual] {tag}: host python {r['host_python_us_per_step']['mean']} us/step (median "
               f"{r['host_python_us_per_step']['median']}), plain reference {r['plain_reference_us_per_step']['mean']} us/step = "
               f"{r['plain_reference_steps_per_s']} steps/s, {time.time() - t0:.0f} s", flush=True)
+        # the same with GibbsSampleSource._propose's body on the device (patch.install(gibbs_source=True))
+        g = measure(tag, path, n, seed, gibbs_source=True)
+        assert g["same_chain_as_plain"], "the device Gibbs proposal changed the chain"
+        r["with_gibbs_source_on_device"] = {k: g[k] for k in ("host_python_us_per_step", "of_which_this_packages_host_layer_us_per_step",
+                                                                "engine_calls_total", "by_operator", "same_chain_as_plain")}
+        print(f"[residual] {tag}: with the Gibbs source proposal on the device {g['host_python_us_per_step']['mean']} us/step "
+              f"(median {g['host_python_us_per_step']['median']}), {time.time() - t0:.0f} s", flush=True)
     with open(args.out, "w") as fh:
         json.dump(out, fh, indent=1)
     print("[residual] wrote", args.out)

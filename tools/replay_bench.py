@@ -18,7 +18,7 @@ from tests.test_call_log_cpu import features_of    # noqa: E402
 def run(tag, path=None, cpu=True, repeats=3, device=0):
     from sbayes_amd.engine import Engine
     path = path or REPO / "tests" / "golden" / f"{tag}_calls.npz"
-    base = tag.replace("_before", "")
+    base = tag.replace("_before", "").replace("_gibbs", "")
     feats = features_of(base)
 
     def make(n_groups):                                # the engine as the drop-in layer creates it (registry.get_engine)
