@@ -196,7 +196,7 @@ assert patch.installed() is None
 lik = pickle.load(open({path!r}, "rb"))
 import sbayes.sampling.conditionals as cond, sbayes.sampling.operators as ops, sbayes.model.model as mm
 import sbayes_amd.likelihood as my
-assert patch.installed() == {{"operators": True}}, patch.installed()
+assert patch.installed() == {{"operators": True, "gibbs_source": False}}, patch.installed()
 assert cond.compute_component_likelihood is my.compute_component_likelihood
 assert mm.Likelihood is my.Likelihood and type(lik) is my.Likelihood
 assert ops.component_likelihood_given_unchanged.__module__ == "sbayes_amd.operators"
