@@ -238,6 +238,7 @@ class FakeEngine:
         x[na] = False                                             # operators.py:527
         self._slot(dst_slot)["source"][objects] = x
         sel = np.take_along_axis(p, idx[..., None], axis=-1)[..., 0].astype(np.float32)
+        sel[na] = 1.0                                             # (the engine's convention: an NA observation selects nothing)
         with np.errstate(divide="ignore"):
             log_q = float(np.log(sel[~na]).sum())
         return (log_q, sel) if return_selected else log_q
@@ -250,6 +251,7 @@ class FakeEngine:
         src = self._slot(src_slot)["source"][objects]
         sel = np.where(src.any(axis=-1), np.take_along_axis(p, src.argmax(axis=-1)[..., None], axis=-1)[..., 0], 1.0).astype(np.float32)
         na = self.na_values()[objects]
+        sel[na] = 1.0
         with np.errstate(divide="ignore"):
             log_q = float(np.log(sel[~na]).sum())
         return (log_q, sel) if return_selected else log_q
