@@ -35,9 +35,13 @@ def _extent(key):
     return lo, hi + 1
 
 
-def get_engine(features, n_groups=None, n_slots=4, device=None) -> Engine:
+def get_engine(features, n_groups=None, n_slots=4, device=None, deferred_checks=True) -> Engine:
     """Engine holding `features`; created on first use.  `n_groups` (groups per mixture
-    component) sizes the slot state; stateless calls work without it."""
+    component) sizes the slot state; stateless calls work without it.  `deferred_checks` (applied when the engine is
+    CREATED here): data checks of state-setting calls -- normalize's positive-sum assert, a source row that is not
+    one-hot -- are reported by the next call that waits for the device instead of stalling the stream at the setter; the
+    message names the call that supplied the data ("[deferred data check: raised by sbe_update_probs ...]").  The
+    drop-in layer relies on it (a bind is several setters); pass False for the reference's own timing of the assert."""
     # the same array OBJECT as in the last call (the drop-in functions pass data.features.values every time): its
     # engine, unless that was closed or the caller names another component layout -- no key is built, nothing is hashed
     last = _LAST[0]
@@ -73,7 +77,7 @@ def get_engine(features, n_groups=None, n_slots=4, device=None) -> Engine:
     # the drop-in layer's state-setting calls (bind cache: changed rows, ids, weights, table rebuilds) never stall the
     # stream: a data check they raise (normalize's positive-sum assert, a source row that is not one-hot) is reported
     # by the next call that fetches a result -- in the same host function, a few lines later
-    if hasattr(eng, "set_option"):                  # (test doubles without options)
+    if deferred_checks and hasattr(eng, "set_option"):          # (test doubles without options)
         eng.set_option(deferred_checks=True)
     try:
         ref = weakref.ref(features)
