@@ -362,6 +362,22 @@ int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const 
 int sbe_set_counts_rows(sbe_engine* e, int slot, const int32_t* group_idx, int n_rows, const float* rows /* [n_rows][F][S] */);
 int sbe_given_unchanged_lh(sbe_engine* e, int slot, int i_cluster, const int32_t* objects, int n_sub, double temperature,
                            double prior_temperature, float* out /* [n_sub][F][C] */);
+/* ClusterOperator.gibbs_sample_source (sbayes/sampling/operators.py:796-851: the source resampling inside every
+ * AlterCluster / AlterClusterWide / ClusterJump proposal) from RESIDENT data of the slot the NEW sample is bound to
+ * (clusters already changed, source not yet resampled, counts still the old state's -- the reference's own inputs):
+ *   lh     = component_likelihood_given_unchanged(model, sample_new, object_subset, i_cluster, T, T_prior)   (:808-811)
+ *   p      = normalize(update_weights(sample_new)[subset] ** (1/T_prior) * lh)   (sample_from_prior: the weights alone)
+ *   x      = sample_categorical(p) with the caller's uniforms z [n][F] (np.random.random((n, F, 1)) where the reference draws)
+ *   p_back = normalize(update_weights(sample_old)[subset] ** (1/T_prior) * lh)                                (:838-844)
+ * hc_new / hc_old: has_components rows [n][C] of the two samples for the listed objects (bool); src_old: the old sample's
+ * source component per observation [n][F] (0xFF: none).  Out: src_new_out [n][F] drawn component (0xFF: NA observation),
+ * sel_new_out = p[x] and sel_back_out = p_back[old source] float32 [n][F] (1 where nothing is selected): log_q and
+ * log_q_back are the float32 sums of their logs over the valid observations, taken by the caller as the reference takes
+ * them (:832, :847).  Static priors only (like sbe_given_unchanged_lh). */
+int sbe_given_unchanged_gibbs(sbe_engine* e, int slot, int i_cluster, const int32_t* objects, int n_sub, double temperature,
+                              double prior_temperature, int from_prior, const uint8_t* hc_new /* [n_sub][C] */,
+                              const uint8_t* hc_old, const uint8_t* src_old /* [n_sub][F] */, const double* z /* [n_sub][F] */,
+                              uint8_t* src_new_out /* [n_sub][F] */, float* sel_new_out, float* sel_back_out);
 int sbe_cluster_posterior_marginals(sbe_engine* e, int slot, int i_cluster, double temperature, double prior_temperature,
                                     const int32_t* objects, int n_objects_av, double* out /* [2][n_objects_av] */);
 int sbe_jump_lh_resident(sbe_engine* e, int slot, int i_source, int i_target, double temperature, double prior_temperature,

@@ -102,6 +102,9 @@ PROTOTYPES = {
     "sbe_set_counts_rows": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_given_unchanged_lh": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double,
                                           ct.c_void_p]),
+    "sbe_given_unchanged_gibbs": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double,
+                                             ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p,
+                                             ct.c_void_p]),
     "sbe_cluster_posterior_marginals": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_double, ct.c_double, ct.c_void_p,
                                                    ct.c_int, ct.c_void_p]),
     "sbe_jump_lh_resident": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_int, ct.c_double, ct.c_double, ct.c_void_p,

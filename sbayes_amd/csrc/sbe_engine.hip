@@ -2807,6 +2807,100 @@ int sbe_given_unchanged_lh(sbe_engine* e, int slot, int i_cluster, const int32_t
     return SBE_OK;
 }
 
+int sbe_given_unchanged_gibbs(sbe_engine* e, int slot, int i_cluster, const int32_t* objects, int n_sub, double temperature,
+                              double prior_temperature, int from_prior, const uint8_t* hc_new, const uint8_t* hc_old,
+                              const uint8_t* src_old, const double* z, uint8_t* src_new_out, float* sel_new_out,
+                              float* sel_back_out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot);
+    if (n_sub < 0) return fail(e, SBE_ERR_ARG, "n_sub=%d", n_sub);
+    if (n_sub == 0) return SBE_OK;
+    CHECK_PTR(e, objects); CHECK_PTR(e, hc_new); CHECK_PTR(e, hc_old); CHECK_PTR(e, src_old); CHECK_PTR(e, z);
+    CHECK_PTR(e, src_new_out); CHECK_PTR(e, sel_new_out); CHECK_PTR(e, sel_back_out);
+    const int N = e->N, F = e->F, S = e->S, C = e->C, K = e->G[0];
+    if (i_cluster < 0 || i_cluster >= K) return fail(e, SBE_ERR_ARG, "cluster %d out of range [0,%d)", i_cluster, K);
+    if (!(temperature > 0.0) || !(prior_temperature > 0.0)) return fail(e, SBE_ERR_ARG, "temperatures must be positive");
+    int rc = check_objects(e, objects, n_sub);
+    if (rc) return rc;
+    Slot& s = e->slots[slot];
+    if (!s.groups_set || !s.source_set || !s.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", slot);
+    for (int c = 0; c < C; ++c) {
+        if (!e->conc_set[c]) return fail(e, SBE_ERR_STATE, "concentration of component %d not set", c);
+        if (c > 0 && !s.counts_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts of component %d not set", slot, c);
+    }
+    if (!e->unif_set) return fail(e, SBE_ERR_STATE, "uniform concentration not set (sbe_set_uniform_counts)");
+    for (int64_t i = 0; i < (int64_t)n_sub * F; ++i)
+        if (src_old[i] != 0xFF && src_old[i] >= C) return fail(e, SBE_ERR_ARG, "old source component %d out of range [0,%d)", src_old[i], C);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int R = 1 + e->Gtot - K;                              // table rows: the cluster + every confounder group
+    const int64_t fs = (int64_t)F * S;
+    const size_t nf = (size_t)n_sub * F;
+    // host-mapped block: object list | table row per (component, subset object) | table offsets | has_components rows of
+    // both samples | -- outputs: drawn component ids | selected probabilities, forward and backward.  The old source ids and
+    // the uniforms (n F (1 + 8) bytes, read once, element-parallel) are staged through the ring / an upload.
+    const size_t ob = al256((size_t)n_sub * 4), gb = al256((size_t)C * n_sub * 4), fb = al256((size_t)C * 4);
+    const size_t hb = al256((size_t)n_sub * C);
+    const size_t idb = al256(nf), selb = al256(nf * sizeof(float));
+    const size_t in_bytes = ob + gb + fb + 2 * hb, out_bytes = idb + 2 * selb;
+    if (out_bytes > ((size_t)8 << 20)) return fail(e, SBE_ERR_ARG, "sbe_given_unchanged_gibbs: %d objects x %d features exceed the mapped result block", n_sub, F);
+    rc = ensure_io(e, in_bytes + out_bytes);
+    if (rc) return rc;
+    uint8_t* h = e->h_io;
+    memcpy(h, objects, (size_t)n_sub * 4);
+    int32_t* gi = (int32_t*)(h + ob);
+    int32_t* off = (int32_t*)(h + ob + gb);
+    for (int c = 0; c < C; ++c) {
+        off[c] = c == 0 ? 0 : 1 + e->goff[c] - K;
+        for (int i = 0; i < n_sub; ++i) {
+            if (c == 0) { gi[i] = 0; continue; }                // every subset object sees the cluster's table (operators.py:884)
+            const uint16_t gg = s.h_gid[(size_t)c * N + objects[i]];
+            gi[(size_t)c * n_sub + i] = gg == kNoGroup ? -1 : (int)gg - e->goff[c];
+        }
+    }
+    memcpy(h + ob + gb + fb, hc_new, (size_t)n_sub * C);
+    memcpy(h + ob + gb + fb + hb, hc_old, (size_t)n_sub * C);
+    const size_t cb = al256((size_t)R * fs * sizeof(float)), zb = al256(nf * sizeof(double)), sob = al256(nf);
+    rc = ensure_scratch(e, cb + zb + sob);
+    if (rc) return rc;
+    float* d_tab = (float*)e->d_scratch;
+    const void *v_z, *v_so;
+    rc = stage(e, z, nf * sizeof(double), e->d_scratch + cb, &v_z);
+    if (rc) return rc;
+    rc = stage(e, src_old, nf, e->d_scratch + cb + zb, &v_so);
+    if (rc) return rc;
+    rc = clear_status_word(e, ST_BAD_NORMALIZE);
+    if (rc) return rc;
+    const bool list_in_lds = (size_t)n_sub * sizeof(int32_t) <= ((size_t)32 << 10);
+    if (((size_t)16 * S + (N + 31) / 32) * sizeof(int32_t) > ((size_t)96 << 10))
+        return fail(e, SBE_ERR_ARG, "gibbs_sample_source: %d objects x %d states exceed the kernel's LDS image", N, S);
+    k_unchanged_counts<<<dim3(R, div_up(F, 16)), kUnchangedBlock,
+                         ((size_t)16 * S + (list_in_lds ? n_sub : 0) + (N + 31) / 32) * sizeof(int32_t), e->stream>>>(
+        e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_src + (int64_t)slot * N * e->Fp,
+        e->d_counts + (int64_t)slot * e->table_elems(), (const int32_t*)e->d_io, n_sub, e->d_comp_of_group,
+        i_cluster, K, N, e->Np, F, S, e->Fp, e->d_conc, e->d_unif_res, temperature, prior_temperature, e->d_status, d_tab,
+        list_in_lds ? 1 : 0);
+    HIPCHK(e, hipGetLastError());
+    GuGibbsArgs a{};
+    a.state = e->d_state; a.tables = d_tab; a.table_offsets = (const int32_t*)(e->d_io + ob + gb);
+    a.group_idx = (const int32_t*)(e->d_io + ob); a.objects = (const int32_t*)e->d_io;
+    a.weights = e->d_weights + (int64_t)slot * F * C;
+    a.hc_new = e->d_io + ob + gb + fb; a.hc_old = e->d_io + ob + gb + fb + hb;
+    a.src_old = (const uint8_t*)v_so; a.z = (const double*)v_z;
+    a.n_sub = n_sub; a.F = F; a.S = S; a.C = C; a.Fp = e->Fp;
+    const double inv_t = 1.0 / temperature, inv_tp = 1.0 / prior_temperature;
+    a.inv_t = (float)inv_t; a.inv_tp = (float)inv_tp; a.pow_lh = inv_t != 1.0; a.pow_w = inv_tp != 1.0; a.from_prior = from_prior ? 1 : 0;
+    const unsigned blocks = (unsigned)div_up((int64_t)nf, 256);
+    const DoneSig done = next_done(e, blocks);
+    uint8_t* d_ids = e->d_io + in_bytes;
+    k_given_unchanged_gibbs<<<blocks, kBlock, 0, e->stream>>>(a, d_ids, (float*)(d_ids + idb), (float*)(d_ids + idb + selb), e->d_status, done);
+    HIPCHK(e, hipGetLastError());
+    rc = sync_and_report(e, done);
+    if (rc) return rc;
+    memcpy(src_new_out, h + in_bytes, nf);
+    memcpy(sel_new_out, h + in_bytes + idb, nf * sizeof(float));
+    memcpy(sel_back_out, h + in_bytes + idb + selb, nf * sizeof(float));
+    return SBE_OK;
+}
+
 int sbe_cluster_posterior_marginals(sbe_engine* e, int slot, int i_cluster, double temperature, double prior_temperature,
                                     const int32_t* objects, int n_objects_av, double* out) {
     CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, out);

@@ -2752,6 +2752,85 @@ __global__ void k_subset_lh(const uint8_t* __restrict__ state, const float* __re
     signal_done(done);
 }
 
+// ClusterOperator.gibbs_sample_source (sbayes/sampling/operators.py:796-851), everything between the likelihood under the
+// kept observations (k_unchanged_counts' tempered tables, gathered here like k_subset_lh does) and the sample bookkeeping:
+//   lh[c]      = table value of the observation under component c, ** (1/T)                          float32
+//   w_new[c]   = normalize_weights(weights, has_components_NEW[n])[f][c] ** (1/T_prior)              float32 (k_normalize_weight_rows' arithmetic)
+//   p          = normalize(w_new * lh)          (sample_from_prior: p = w_new, NOT renormalised: operators.py:815-816)
+//   k          = sample_categorical(p) with the caller's uniform z[r][f]   (k_sample_source's draw)
+//   p_back     = normalize(w_old * lh) with has_components_OLD[n]          (operators.py:838-844)
+// out: the drawn component (0xFF for an NA observation), p[k] (1 for NA) and p_back[old source component] (1 when the
+// old source has none) -- the host sums their float32 logs the way the reference does.
+struct GuGibbsArgs {
+    const uint8_t* state; const float* tables; const int32_t* table_offsets; const int32_t* group_idx; const int32_t* objects;
+    const float* weights;            // the slot's [F][C] float32 mixture weights
+    const uint8_t* hc_new; const uint8_t* hc_old;   // [n_sub][C] has_components rows of the two samples
+    const uint8_t* src_old;          // [n_sub][F] old source component per observation (0xFF: none)
+    const double* z;                 // [n_sub][F] uniforms
+    int n_sub, F, S, C, Fp;
+    float inv_t, inv_tp; int pow_lh, pow_w, from_prior;
+};
+
+__global__ __launch_bounds__(kBlock) void k_given_unchanged_gibbs(GuGibbsArgs a, uint8_t* __restrict__ src_new,
+                                                                 float* __restrict__ sel_new, float* __restrict__ sel_back,
+                                                                 int* __restrict__ status, DoneSig done = DoneSig{}) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)a.n_sub * a.F) {
+        const int r = (int)(i / a.F), f = (int)(i % a.F);
+        const uint8_t x = a.state[(int64_t)a.objects[r] * a.Fp + f];
+        const bool na = x == kNA;
+        float lh[kMaxComponents];
+        for (int c = 0; c < a.C; ++c) {
+            float v = 1.0f;
+            if (!na) {
+                const int g = a.group_idx[(int64_t)c * a.n_sub + r];
+                v = g < 0 ? 0.0f : a.tables[((int64_t)(a.table_offsets[c] + g) * a.F + f) * a.S + x];
+            }
+            lh[c] = a.pow_lh ? powf(v, a.inv_t) : v;
+        }
+        const float* w = a.weights + (int64_t)f * a.C;
+        float p[2][kMaxComponents];
+        bool ok = true;
+        for (int side = 0; side < 2; ++side) {
+            const uint8_t* hc = (side == 0 ? a.hc_new : a.hc_old) + (int64_t)r * a.C;
+            auto masked = [&](int c) -> float { return hc[c] ? w[c] : 0.0f * w[c]; };
+            const float wtot = np_pairwise_sum<float>(masked, a.C);
+            float t[kMaxComponents];
+            for (int c = 0; c < a.C; ++c) {
+                float wc = masked(c) / wtot;                            // normalize_weights (likelihood.py:171-190)
+                if (a.pow_w) wc = powf(wc, a.inv_tp);
+                t[c] = a.from_prior ? wc : wc * lh[c];
+            }
+            if (a.from_prior) { for (int c = 0; c < a.C; ++c) p[side][c] = t[c]; continue; }
+            auto term = [&](int c) -> float { return t[c]; };
+            const float tot = np_pairwise_sum<float>(term, a.C);
+            ok = ok && tot > 0.0f;                                      // normalize's assert (util.py:1006)
+            for (int c = 0; c < a.C; ++c) p[side][c] = t[c] / tot;
+        }
+        if (!ok) raise_status(status, ST_BAD_NORMALIZE, 1);
+        // sample_categorical (preprocessing.py:224-256): float32 cumulative sums, divided by the last, first c with z < cdf[c]
+        float cdf[kMaxComponents];
+        float run = p[0][0];
+        cdf[0] = run;
+        for (int c = 1; c < a.C; ++c) { run = run + p[0][c]; cdf[c] = run; }
+        const float last = cdf[a.C - 1];
+        const double zz = a.z[i];
+        int k = 0;
+        for (int c = a.C - 1; c >= 0; --c)
+            if (zz < (double)(cdf[c] / last)) k = c;
+        src_new[i] = na ? (uint8_t)kNA : (uint8_t)k;
+        float sn = 1.0f, sb = 1.0f;
+        const int id_old = a.src_old[i];
+        for (int c = 0; c < a.C; ++c) {
+            sn = (!na && c == k) ? p[0][c] : sn;
+            sb = (c == id_old) ? p[1][c] : sb;
+        }
+        sel_new[i] = sn;
+        sel_back[i] = sb;
+    }
+    signal_done(done);
+}
+
 // SourcePrior.__call__ (prior.py:573-611), per-object values:
 //   sp[n] = float32( sum_{f valid} log( w[pat(n)][f][source(n,f)] ) )     (float32 logs)
 // One wave per object, lanes over features, wave64 shuffle reduce.  An observation whose source has no

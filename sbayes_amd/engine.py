@@ -651,6 +651,32 @@ class Engine:
                                                      float(prior_temperature), self._o(out)))
         return out
 
+    def given_unchanged_gibbs(self, slot, i_cluster, objects, hc_new, hc_old, src_old, z, temperature=1.0, prior_temperature=1.0,
+                              from_prior=False):
+        """ClusterOperator.gibbs_sample_source (operators.py:796-851) on the slot the NEW sample is bound to: returns
+        (src_new uint8 [n, F] drawn component, 255 = NA observation; sel_new float32 [n, F] = p[drawn]; sel_back float32
+        [n, F] = p_back[old source]).  hc_new / hc_old: bool [n, C] has_components rows of the new / old sample; src_old:
+        uint8 [n, F] old source component (255: none); z: uniforms [n, F]."""
+        objs = _as(objects, np.int32).reshape(-1)
+        n, F, C = objs.size, self.n_features, self.n_components
+        hn = _c(np.asarray(hc_new).astype(bool, copy=False), np.uint8)
+        ho = _c(np.asarray(hc_old).astype(bool, copy=False), np.uint8)
+        so = _as(src_old, np.uint8)
+        zz = _c(z, np.float64)
+        if zz.size != n * F:
+            raise ValueError(f"z must hold {n} x {F} uniforms")
+        zz = zz.reshape(n, F)
+        if hn.shape != (n, C) or ho.shape != (n, C) or so.shape != (n, F):
+            raise ValueError(f"hc_new / hc_old must be [{n}, {C}], src_old and z [{n}, {F}]")
+        ids = np.empty((n, F), dtype=np.uint8)
+        sel = np.empty((n, F), dtype=np.float32)
+        back = np.empty((n, F), dtype=np.float32)
+        if n:
+            self._check(self._lib.sbe_given_unchanged_gibbs(self._h, slot, int(i_cluster), self._i(objs), n, float(temperature),
+                                                            float(prior_temperature), int(bool(from_prior)), self._i(hn), self._i(ho),
+                                                            self._i(so), self._i(zz), self._o(ids), self._o(sel), self._o(back)))
+        return ids, sel, back
+
     def cluster_posterior_marginals(self, slot, i_cluster, objects, temperature=1.0, prior_temperature=1.0):
         """cluster_marginals with the candidate table conditional_effect_mean(prior, counts[[i_cluster]], unif, T_prior, T)
         built on the device from the slot's resident counts (operators.py:1046-1052): float64 [2, n]."""

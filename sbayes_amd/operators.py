@@ -22,7 +22,7 @@ from __future__ import annotations
 import numpy as np
 
 from .binding import _bind_slot, _bind_uniform, _engine, _tables_current
-from .counts import update_feature_counts
+from .counts import _source_ids, update_feature_counts
 
 EPS = np.finfo(np.float32).eps        # sbayes/util.py:34
 
@@ -146,6 +146,44 @@ def gibbs_sample_source(model, sample, object_subset=slice(None), temperature=1.
     # the count delta exactly as the reference applies it (update_feature_counts -> add_changes per component): one
     # stateless call that returns the rows of the groups the subset's objects are in -- not 2 C whole tables
     update_feature_counts(sample, sample_new, model.data.features.values, object_subset)
+    return sample_new, log_q, log_q_back
+
+
+def cluster_gibbs_sample_source(model, sample_new, sample_old, i_cluster, object_subset, temperature=1.0, prior_temperature=1.0,
+                                sample_from_prior=False, slot=0):
+    """ClusterOperator.gibbs_sample_source (operators.py:796-851): the source resampling inside every AlterCluster /
+    AlterClusterWide / ClusterJump proposal.  `sample_new` has the clusters already changed and the source not yet
+    resampled (its counts are still the old state's); everything between the two samples' bookkeeping -- the likelihood
+    under the kept observations, both posteriors, the draw, the selected probabilities -- runs on the device in one call
+    (sbe_given_unchanged_gibbs): the object list, 2 n C has_components bytes, n F old source ids and the n F uniforms
+    (np.random.random((n, F, 1)), drawn exactly where the reference's sample_categorical draws them) go up, n F drawn ids
+    and 2 n F float32 come back.  The sample edits (source.edit(), update_feature_counts) and the float32 sums of logs are
+    the reference's own, in its order.  Returns (sample_new, log_q, log_q_back).  Static priors only: None otherwise
+    (the caller keeps the reference's method)."""
+    if any(model.prior.prior_confounding_effects[conf].any_dynamic_priors for conf in sample_new.confounders):
+        return None
+    eng = _engine(model)
+    features = model.data.features.values
+    na_features = model.data.features.na_values
+    n_objects = sample_new.n_objects
+    mask = np.isin(np.arange(n_objects), object_subset)                    # (operators.py:805: a boolean index array)
+    objects = np.flatnonzero(mask).astype(np.int32)
+    _bind_slot(eng, model, sample_new, slot, with_source=True)
+    _bind_uniform(eng, model)
+    hc_new = sample_new.cache.has_components.value[objects]
+    hc_old = sample_old.cache.has_components.value[objects]
+    src_old = _source_ids(sample_old.source.value, objects)
+    z = np.random.random((objects.size, eng.n_features, 1))
+    ids, sel_new, sel_back = eng.given_unchanged_gibbs(slot, i_cluster, objects, hc_new, hc_old, src_old, z, temperature,
+                                                       prior_temperature, sample_from_prior)
+    x = ids[..., None] == np.arange(eng.n_components, dtype=np.uint8)     # one-hot; all False where NA (id 255)
+    with sample_new.source.edit() as source:
+        source[mask] = x                                                  # (NA observations stay 0: operators.py:825)
+    update_feature_counts(sample_old, sample_new, features, mask)
+    valid = ~na_features[objects]
+    with np.errstate(divide="ignore"):
+        log_q = np.log(sel_new[valid]).sum()                              # float32 logs, float32 sum (operators.py:832)
+        log_q_back = np.log(sel_back[valid & (src_old != 255)]).sum()     # (operators.py:847)
     return sample_new, log_q, log_q_back
 
 

@@ -59,6 +59,7 @@ MIRRORED_SOURCES = {
     "ClusterEffectProposals.expected_confounder_features": "efb685c5e0b1f2818dde1f2244d6f0ff086107cc",
     "SourcePrior.__call__": "c76b2825409bc280761a6b598113f74c9b395dbb",
     "GibbsSampleSource._propose": "61911f12df7948eea0f207e45f49d97d7e0e5352",
+    "ClusterOperator.gibbs_sample_source": "4c1f20c2821f64d9eed7ad4e8fa9cf50a76d0de1",
 }
 
 
@@ -109,11 +110,15 @@ def set_mp_start_method(method):
 
 
 def install(operators=False, mp_start_method=None, gibbs_source=False):
-    """operators=True: the device forms listed in the module docstring.  gibbs_source=True (implies operators): the body
-    of GibbsSampleSource._propose (operators.py:495-552) after its own `select_object_subset` -- posterior, draw
-    (`sample_categorical` with the uniforms np.random yields at that point, draw for draw), new source rows, count delta,
-    both transition log-probabilities -- runs on the device (operators.gibbs_sample_source: SURVEY.md 8(f) rank 3); at the
-    headline shape that body is the largest single item of the reference's per-step Python."""
+    """operators=True: the device forms listed in the module docstring.  gibbs_source=True (implies operators): the two
+    Gibbs source resamplings of the reference run on the device, with the uniforms np.random yields
+    at the point where the reference's `sample_categorical` draws them (draw for draw: the same Markov chain) --
+      GibbsSampleSource._propose (operators.py:495-552), its body after `select_object_subset`: posterior, draw, new source
+        rows, count delta, both transition log-probabilities (operators.gibbs_sample_source);
+      ClusterOperator.gibbs_sample_source (operators.py:796-851), the source resampling inside every AlterCluster /
+        AlterClusterWide / ClusterJump proposal: likelihood under the kept observations, both posteriors, draw, selected
+        probabilities in ONE engine call (operators.cluster_gibbs_sample_source).
+    At the headline shape these two bodies are the largest items of the reference's per-step Python."""
     global _INSTALLED
     operators = bool(operators) or bool(gibbs_source)
     if mp_start_method is not None:
@@ -188,6 +193,19 @@ def _install_gibbs_source_form(swap):
                                           self.sample_from_prior)
 
     swap(ref_ops.GibbsSampleSource, "_propose", _propose)
+
+    # ClusterOperator.gibbs_sample_source (operators.py:796-851): the source resampling of the cluster proposals
+    _check_mirrored(ref_ops.ClusterOperator, "gibbs_sample_source")
+    reference_cluster_gibbs = ref_ops.ClusterOperator.__dict__["gibbs_sample_source"]
+
+    def gibbs_sample_source(self, sample_new, sample_old, i_cluster, object_subset=slice(None)):
+        out = my_ops.cluster_gibbs_sample_source(self.model, sample_new, sample_old, i_cluster, object_subset, self.temperature,
+                                                 self.prior_temperature, self.sample_from_prior)
+        if out is None:                                          # dynamic priors: the reference's own body
+            return reference_cluster_gibbs(self, sample_new, sample_old, i_cluster, object_subset=object_subset)
+        return out
+
+    swap(ref_ops.ClusterOperator, "gibbs_sample_source", gibbs_sample_source)
 
 
 def _install_operator_forms(swap):

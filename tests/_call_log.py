@@ -94,12 +94,16 @@ COMPARE = {
     "sample_source": (2e-6, 1e-6),           # (log_q, selected probabilities): float32 posterior values; the DRAW itself is
     "source_logprob": (2e-6, 1e-6),          #   pinned exactly by get_source_rows below
     "update_counts": "exact", "get_source_rows": "exact",
+    # ClusterOperator.gibbs_sample_source in one call: (drawn ids, p[drawn], p_back[old source]) -- bit-exact at
+    # temperature 1 (ids always: a draw that differs changes the chain), float32 powf tolerance when tempered
+    "given_unchanged_gibbs": "exact_at_t1",
 }
 SETTERS = {"set_groups", "set_concentration", "set_counts", "set_source", "set_weights", "update_probs", "set_counts_rows",
            "set_source_rows", "set_uniform_counts", "recount", "copy_slot"}
 
 
-_TEMPERATURE_ARG = {"source_posterior": 2, "subset_lh": 3, "given_unchanged_lh": 3}     # positional index of `temperature`
+_TEMPERATURE_ARG = {"source_posterior": 2, "subset_lh": 3, "given_unchanged_lh": 3,      # positional index of `temperature`
+                    "given_unchanged_gibbs": 7}
 
 
 def _temperature_of(name, args, kwargs):
@@ -189,7 +193,7 @@ for _name in ("normalize_tables", "dirichlet_logpdf", "effect_counts", "set_grou
               "normalize_weights", "observation_lh_exact", "jump_lh", "source_lh_by_feature", "set_counts_rows",
               "set_source_rows", "set_uniform_counts", "counts_delta", "collapsed_loglik", "collapsed_loglik_all", "source_prior",
               "given_unchanged_lh", "cluster_posterior_marginals", "jump_lh_resident", "recount", "get_counts",
-              "copy_slot", "sample_source", "source_logprob", "update_counts", "get_source_rows"):
+              "copy_slot", "sample_source", "source_logprob", "update_counts", "get_source_rows", "given_unchanged_gibbs"):
     setattr(RecordingEngine, _name, _wrap(_name))
 
 

@@ -341,6 +341,32 @@ class FakeEngine:
             self.features, self.na_values(), groups, counts, conc, s["source"], subset, i_cluster, self.unif,
             [self.unif] * (len(groups) - 1), temperature=temperature, prior_temperature=prior_temperature)
 
+    def given_unchanged_gibbs(self, slot, i_cluster, objects, hc_new, hc_old, src_old, z, temperature=1.0, prior_temperature=1.0,
+                              from_prior=False):
+        """ClusterOperator.gibbs_sample_source (operators.py:808-847) restated with the oracle's pieces: the expressions of
+        the reference, in its dtypes, on the subset."""
+        objects = np.asarray(objects)
+        lh = self.given_unchanged_lh(slot, i_cluster, objects, temperature, prior_temperature)     # float32 [n, F, C]
+        self.calls[-1] = ("given_unchanged_gibbs", len(objects))
+        weights = self._slot(slot)["weights"]
+        inv_tp = 1 / float(prior_temperature)
+        na = self.na_values()[objects]
+        z = np.asarray(z, dtype=np.float64).reshape(objects.size, self.n_features)
+        probs = []
+        for hc in (hc_new, hc_old):
+            w = orc.normalize_weights(weights, np.asarray(hc, dtype=bool)) ** inv_tp
+            probs.append(w if from_prior else orc.normalize(w * lh, axis=-1))
+        p, p_back = probs
+        idx = orc.sample_categorical(p, z)
+        ids = idx.astype(np.uint8)
+        ids[na] = 255
+        sel = np.take_along_axis(p, idx[..., None], axis=-1)[..., 0].astype(np.float32)
+        sel[na] = 1.0
+        so = np.asarray(src_old)
+        back = np.where(so != 255, np.take_along_axis(p_back, np.minimum(so, p.shape[-1] - 1).astype(np.int64)[..., None], axis=-1)[..., 0],
+                        1.0).astype(np.float32)
+        return ids, sel, back
+
     def cluster_posterior_marginals(self, slot, i_cluster, objects, temperature=1.0, prior_temperature=1.0):
         _, counts, conc, _ = self._full_state(slot)
         table = orc.conditional_effect_mean(conc[0], counts[0][[i_cluster]], unif_counts=self.unif,

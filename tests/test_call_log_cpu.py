@@ -41,6 +41,7 @@ def test_gibbs_source_call_log_replays_on_the_double(tag):
     feats = features_of(tag)
     counts, meta = replay(GOLDEN / f"{tag}_calls.npz", lambda n_groups: FakeEngine(feats, n_groups))
     assert meta["gibbs_source"] and crc(feats) == meta["features_crc"]
-    assert {"copy_slot", "sample_source", "update_counts", "source_logprob", "get_source_rows", "counts_delta"} <= set(counts)
+    assert {"copy_slot", "sample_source", "update_counts", "source_logprob", "get_source_rows", "counts_delta",
+            "given_unchanged_gibbs"} <= set(counts)
     assert counts["sample_source"] == counts["source_logprob"] == counts["get_source_rows"] >= 10
     assert "GibbsSampleSource" in meta["operators"]

@@ -160,3 +160,46 @@ def test_argument_checks():
         assert touched.size == 0 and diff.shape[0] == 0
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("name", ["cfg1_fixture", "south_america", "headline", "wide"])
+@pytest.mark.parametrize("from_prior", [False, True], ids=["posterior", "from_prior"])
+def test_given_unchanged_gibbs_against_the_double(name, from_prior):
+    """sbe_given_unchanged_gibbs (ClusterOperator.gibbs_sample_source, operators.py:796-851) against the oracle-backed double's
+    restatement of the reference expressions: at T = T_prior = 1 the drawn components, p[drawn] and p_back[old source] are
+    bit-identical; tempered, the draws may differ only where a uniform falls within float32 powf distance of a cdf step
+    (none at these seeds) and the probabilities agree to 2e-6."""
+    eng, fake, groups, source, counts = _pair(name)
+    try:
+        rng = np.random.default_rng(17)
+        N, F, C = source.shape
+        K = groups[0].shape[0]
+        for trial in range(6):
+            i_cluster = int(rng.integers(0, K))
+            n = int(rng.integers(1, min(N, 40)))
+            objs = np.sort(rng.choice(N, size=n, replace=False)).astype(np.int32)
+            hc_new = np.stack([g[:, objs].any(axis=0) for g in groups], axis=1)
+            hc_old = hc_new.copy()
+            flip = rng.random(n) < 0.5                                   # the objects the proposal moved: their cluster bit differs
+            hc_old[flip, 0] = ~hc_old[flip, 0]
+            src_old = np.where(source[objs].any(-1), source[objs].argmax(-1), 255).astype(np.uint8)
+            z = rng.random((n, F))
+            for t, tp in ((1.0, 1.0), (2.5, 1.7)):
+                got = eng.given_unchanged_gibbs(0, i_cluster, objs, hc_new, hc_old, src_old, z, t, tp, from_prior)
+                want = fake.given_unchanged_gibbs(0, i_cluster, objs, hc_new, hc_old, src_old, z, t, tp, from_prior)
+                assert got[0].dtype == np.uint8 and got[1].dtype == np.float32 and got[2].dtype == np.float32
+                assert np.array_equal(got[0], want[0]), (name, trial, t)
+                if t == 1.0 and tp == 1.0:
+                    assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), (name, trial)
+                else:
+                    np.testing.assert_allclose(got[1], want[1], rtol=2e-6, atol=1e-7)
+                    np.testing.assert_allclose(got[2], want[2], rtol=2e-6, atol=1e-7)
+        with pytest.raises(Exception, match="out of range"):
+            eng.given_unchanged_gibbs(0, 99, [0], hc_new[:1], hc_old[:1], src_old[:1], z[:1])
+        bad = src_old[:1].copy()
+        bad[0, 0] = C                                                    # neither a component nor 255
+        with pytest.raises(Exception, match="old source component"):
+            eng.given_unchanged_gibbs(0, 0, objs[:1], hc_new[:1], hc_old[:1], bad, z[:1])
+    finally:
+        eng.close()
+

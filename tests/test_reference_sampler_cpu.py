@@ -153,7 +153,8 @@ def test_reference_sampler_with_the_gibbs_source_proposal_on_the_device(tag, src
     assert np.array_equal(patched[3], plain[3])
     eng = next(iter(patched[4].values()))
     kinds = {c[0] for c in eng.calls}
-    assert {"sample_source", "source_logprob", "update_counts", "copy_slot"} <= kinds, kinds
+    assert {"sample_source", "source_logprob", "update_counts", "copy_slot", "given_unchanged_gibbs"} <= kinds, kinds
+    # (given_unchanged_lh remains for ClusterJump.gibbs_sample_source_jump, operators.py:1775, which has its own body)
     assert "GibbsSampleSource" in {t[2] for t in patched[0]}
     n_gibbs = sum(t[2] == "GibbsSampleSource" for t in patched[0])
     assert sum(c[0] == "sample_source" for c in eng.calls) >= n_gibbs               # every such step went through the device form
