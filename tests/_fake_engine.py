@@ -346,7 +346,9 @@ class FakeEngine:
         """ClusterOperator.gibbs_sample_source (operators.py:808-847) restated with the oracle's pieces: the expressions of
         the reference, in its dtypes, on the subset."""
         objects = np.asarray(objects)
-        lh = self.given_unchanged_lh(slot, i_cluster, objects, temperature, prior_temperature)     # float32 [n, F, C]
+        # (class-qualified: a recording / memoising subclass must not log this inner step as a call of its own -- the real
+        #  engine receives ONE call)
+        lh = FakeEngine.given_unchanged_lh(self, slot, i_cluster, objects, temperature, prior_temperature)     # float32 [n, F, C]
         self.calls[-1] = ("given_unchanged_gibbs", len(objects))
         weights = self._slot(slot)["weights"]
         inv_tp = 1 / float(prior_temperature)
