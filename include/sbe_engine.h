@@ -47,7 +47,7 @@ extern "C" {
 
 typedef struct sbe_engine sbe_engine;
 
-#define SBE_ABI_VERSION 3
+#define SBE_ABI_VERSION 4   /* 4 (round 4): + sbe_given_unchanged_gibbs, sbe_host_*; sbe_set_groups rejects overlap */
 
 /* error codes */
 #define SBE_OK 0

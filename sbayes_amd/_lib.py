@@ -9,7 +9,7 @@ import os
 from pathlib import Path
 
 LIB_NAME = "libsbe_engine.so"
-ABI_VERSION = 3                    # SBE_ABI_VERSION of include/sbe_engine.h
+ABI_VERSION = 4                    # SBE_ABI_VERSION of include/sbe_engine.h
 _LIB = None
 
 c_engine_p = ct.c_void_p
