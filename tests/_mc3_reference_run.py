@@ -46,7 +46,8 @@ def main(work: Path):
     registry.engine_for_features = lambda f: (next((e for e in engines.values() if e.n_features == f), None)
                                               or FakeEngine(np.zeros((1, f, 1), dtype=bool)))
     registry.engine_for_observations = make_engine_for_observations(engines)
-    patch.install(operators=True)
+    gibbs_source = len(sys.argv) > 2 and sys.argv[2] == "gibbs_source"
+    patch.install(operators=True, gibbs_source=gibbs_source)
     import sbayes.sampling.initializers as ref_init
     import sbayes.util as ref_util
     np.random.seed(5)

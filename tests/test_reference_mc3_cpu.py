@@ -22,8 +22,9 @@ REF = "/root/reference"
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference sBayes not present")
 
 
-def test_reference_mc3_runs_on_the_drop_in_layer(tmp_path):
-    proc = subprocess.Popen([sys.executable, str(REPO / "tests" / "_mc3_reference_run.py"), str(tmp_path / "work")],
+@pytest.mark.parametrize("mode", ["operators", "gibbs_source"])
+def test_reference_mc3_runs_on_the_drop_in_layer(tmp_path, mode):
+    proc = subprocess.Popen([sys.executable, str(REPO / "tests" / "_mc3_reference_run.py"), str(tmp_path / "work"), mode],
                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=str(REPO), start_new_session=True)
     try:
         stdout, stderr = proc.communicate(timeout=900)

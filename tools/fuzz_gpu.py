@@ -62,6 +62,26 @@ def forms_case(rng, eng, feats, n_groups, conc, state, tag, stats):
     with np.errstate(divide="ignore", invalid="ignore"):
         want = fake.given_unchanged_lh(0, i_cl, objs)
     assert np.array_equal(eng.given_unchanged_lh(0, i_cl, objs), want), (tag, "given_unchanged_lh")
+    # ClusterOperator.gibbs_sample_source in one call (round 4): drawn components, p[drawn], p_back[old source] -- bit for bit at T = 1
+    hc_new = np.stack([g[:, objs].any(axis=0) for g in groups], axis=1)
+    hc_old = hc_new.copy()
+    flip = rng.random(objs.size) < 0.5
+    hc_old[flip, 0] = ~hc_old[flip, 0]
+    if C > 1:
+        hc_old[:, 1] = hc_new[:, 1] = True               # (an object in no component at all has no weight row)
+    so_g = np.where(source[objs].any(-1), source[objs].argmax(-1), 255).astype(np.uint8)
+    zz = rng.random((objs.size, F))
+    if (hc_new.any(axis=1) & hc_old.any(axis=1)).all():
+        from_prior = bool(rng.integers(0, 2))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            want_g = fake.given_unchanged_gibbs(0, i_cl, objs, hc_new, hc_old, so_g, zz, from_prior=from_prior)
+        degenerate = not from_prior and not np.isfinite(want_g[1]).all()   # (a posterior row with zero mass: the reference asserts)
+        if not degenerate:
+            got_g = eng.given_unchanged_gibbs(0, i_cl, objs, hc_new, hc_old, so_g, zz, from_prior=from_prior)
+            for a_, b_, what in zip(got_g, want_g, ("ids", "p[drawn]", "p_back[old]")):
+                ok_ = np.isfinite(b_) if b_.dtype != np.uint8 else np.ones(b_.shape, dtype=bool)
+                assert np.array_equal(a_[ok_], b_[ok_]), (tag, "given_unchanged_gibbs", what)
+            stats["cluster_gibbs"] = stats.get("cluster_gibbs", 0) + 1
     with np.errstate(divide="ignore", invalid="ignore"):
         want = fake.cluster_posterior_marginals(0, i_cl, objs)
         got = eng.cluster_posterior_marginals(0, i_cl, objs)
