@@ -1,6 +1,12 @@
 #!/bin/bash
-# Build the gfx950 engine library in-tree (also done by __graft_entry__.build()).
+# Build the gfx950 engine library in-tree (also done by __graft_entry__.build()): the two translation units are compiled
+# in parallel and linked into sbayes_amd/libsbe_engine.so.  Extra arguments are passed to both compiles (-DSBE_STAMPS ...).
 set -e
 cd "$(dirname "$0")"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 \
-  -Wall -Wno-unused-function "$@" sbayes_amd/csrc/sbe_engine.hip -o sbayes_amd/libsbe_engine.so
+FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function"
+mkdir -p build/obj
+/opt/rocm/bin/hipcc $FLAGS "$@" -c sbayes_amd/csrc/sbe_mixture.hip -o build/obj/sbe_mixture.o &
+pid=$!
+/opt/rocm/bin/hipcc $FLAGS "$@" -c sbayes_amd/csrc/sbe_engine.hip -o build/obj/sbe_engine.o
+wait $pid
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/obj/sbe_engine.o build/obj/sbe_mixture.o -o sbayes_amd/libsbe_engine.so

@@ -791,101 +791,6 @@ int check_slot_ready(sbe_engine* e, int slot, bool need_weights) {
     return SBE_OK;
 }
 
-template <int MODE, int FT, bool DIRECT = false>
-void launch_v2_ft(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
-    switch (C) {
-        case 1: k_mixture_v2<MODE, FT, 1, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
-        case 2: k_mixture_v2<MODE, FT, 2, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
-        case 3: k_mixture_v2<MODE, FT, 3, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
-        case 4: k_mixture_v2<MODE, FT, 4, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
-        default: k_mixture_v2<MODE, FT, 0, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
-    }
-}
-
-template <int MODE, int FT, bool DIRECT = false>
-void launch_oh2_ft(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
-    switch (C) {
-        case 1: k_mixture_onehot_v2<MODE, FT, 1, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
-        case 2: k_mixture_onehot_v2<MODE, FT, 2, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
-        case 3: k_mixture_onehot_v2<MODE, FT, 3, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
-        case 4: k_mixture_onehot_v2<MODE, FT, 4, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
-        default: k_mixture_onehot_v2<MODE, FT, 0, DIRECT><<<grid, kBlock, lds, st>>>(p); break;
-    }
-}
-
-template <int MODE>
-void launch_oh2(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st, bool direct) {
-    if (direct) launch_oh2_ft<MODE, 16, true>(C, p, grid, lds, st);
-    else if (ft == 64) launch_oh2_ft<MODE, 64>(C, p, grid, lds, st);
-    else if (ft == 32) launch_oh2_ft<MODE, 32>(C, p, grid, lds, st);
-    else launch_oh2_ft<MODE, 16>(C, p, grid, lds, st);
-}
-
-template <int FT, bool ONEHOT>
-void launch_combo_ft(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
-    switch (C) {
-        case 1: k_mixture_combo<FT, 1, ONEHOT><<<grid, kBlock, lds, st>>>(p); break;
-        case 2: k_mixture_combo<FT, 2, ONEHOT><<<grid, kBlock, lds, st>>>(p); break;
-        case 3: k_mixture_combo<FT, 3, ONEHOT><<<grid, kBlock, lds, st>>>(p); break;
-        case 4: k_mixture_combo<FT, 4, ONEHOT><<<grid, kBlock, lds, st>>>(p); break;
-        default: k_mixture_combo<FT, 0, ONEHOT><<<grid, kBlock, lds, st>>>(p); break;
-    }
-}
-
-template <bool OFF16, int NW>
-void launch_tuple64_o(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
-    switch (C) {
-        case 1: k_mixture_tuple64<1, OFF16, NW><<<grid, NW * kWave, lds, st>>>(p); break;
-        case 2: k_mixture_tuple64<2, OFF16, NW><<<grid, NW * kWave, lds, st>>>(p); break;
-        case 3: k_mixture_tuple64<3, OFF16, NW><<<grid, NW * kWave, lds, st>>>(p); break;
-        case 4: k_mixture_tuple64<4, OFF16, NW><<<grid, NW * kWave, lds, st>>>(p); break;
-        default: k_mixture_tuple64<0, OFF16, NW><<<grid, NW * kWave, lds, st>>>(p); break;
-    }
-}
-
-// waves per block of k_mixture_tuple64.  (8-wave blocks -- twice the waves per SIMD at the same LDS footprint -- were
-// measured twice: 72.7 us at 80 VGPRs / 3 blocks per CU, 107 us at 64 VGPRs / 4 blocks per CU, against 61-63 us: the
-// kernel does not fit those register budgets without spilling in its table build.)
-constexpr int tuple64_waves() { return 4; }
-
-void launch_tuple64(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
-    if (const char* env = getenv("SBE_T64_LDS_PAD")) lds += (size_t)atoi(env);        // experiments: fewer blocks per CU
-    // 16-bit tuple-block offsets when the whole log table sits below 64 KiB
-    const bool off16 = (int64_t)p.KT * (p.S + 1) * 512 <= 65536;
-    if (off16) launch_tuple64_o<true, 4>(C, p, grid, lds, st); else launch_tuple64_o<false, 4>(C, p, grid, lds, st);
-}
-
-template <bool ONEHOT>
-void launch_combo(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
-    if (ft == 64) launch_combo_ft<64, ONEHOT>(C, p, grid, lds, st);
-    else if (ft == 32) launch_combo_ft<32, ONEHOT>(C, p, grid, lds, st);
-    else launch_combo_ft<16, ONEHOT>(C, p, grid, lds, st);
-}
-
-template <int MODE>
-void launch_v2(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st, bool direct) {
-    if (direct) launch_v2_ft<MODE, 16, true>(C, p, grid, lds, st);
-    else if (ft == 64) launch_v2_ft<MODE, 64>(C, p, grid, lds, st);
-    else if (ft == 32) launch_v2_ft<MODE, 32>(C, p, grid, lds, st);
-    else launch_v2_ft<MODE, 16>(C, p, grid, lds, st);
-}
-
-template <int MODE, int FT>
-void launch_rows_ft(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
-    switch (C) {
-        case 1: k_mixture_rows<MODE, FT, 1><<<grid, kRowsBlock, lds, st>>>(p); break;
-        case 2: k_mixture_rows<MODE, FT, 2><<<grid, kRowsBlock, lds, st>>>(p); break;
-        case 3: k_mixture_rows<MODE, FT, 3><<<grid, kRowsBlock, lds, st>>>(p); break;
-        default: k_mixture_rows<MODE, FT, 4><<<grid, kRowsBlock, lds, st>>>(p); break;
-    }
-}
-
-template <int MODE>
-void launch_rows(int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st) {
-    if (ft == 32) launch_rows_ft<MODE, 32>(C, p, grid, lds, st);
-    else launch_rows_ft<MODE, 16>(C, p, grid, lds, st);
-}
-
 // Enqueue the dominant kernel (optionally bracketed by an event pair) and the fixed-order
 // partial reduction.  mode: LOG_PER_OBS / LOG_PRODUCT.
 // Slots: first_slot .. first_slot+n-1, or (batched steps) the n slots listed in `slots` (host) / `d_slots` (the same
@@ -1064,19 +969,12 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
         snprintf(e->last_kernel, sizeof e->last_kernel, "%s<%s%s, tile %d, C=%d>",
                  combo ? (tuple64 ? "k_mixture_tuple64" : "k_mixture_combo") : rows ? "k_mixture_rows" : (onehot ? "k_mixture_onehot_v2" : "k_mixture_v2"),
                  onehot ? "one-hot stream" : "packed stream", combo ? ", group-tuple form" : (e->direct ? ", direct tables" : ""), g.ft, e->C);
+        // (the kernels live in their own translation unit: sbe_mixture.hip)
         if (combo && tuple64) launch_tuple64(e->C, p, grid, combo_lds, e->stream);
-        else if (combo) {
-            if (onehot) launch_combo<true>(g.ft, e->C, p, grid, combo_lds, e->stream);
-            else launch_combo<false>(g.ft, e->C, p, grid, combo_lds, e->stream);
-        } else if (rows) {
-            if (mode == LOG_PRODUCT) launch_rows<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
-            else launch_rows<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream);
-        } else
-        if (onehot) {
-            if (mode == LOG_PRODUCT) launch_oh2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
-            else launch_oh2<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
-        } else if (mode == LOG_PRODUCT) launch_v2<LOG_PRODUCT>(g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
-        else launch_v2<LOG_PER_OBS>(g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
+        else if (combo) launch_combo(onehot, g.ft, e->C, p, grid, combo_lds, e->stream);
+        else if (rows) launch_rows(mode, g.ft, e->C, p, grid, g.lds_bytes, e->stream);
+        else if (onehot) launch_oh2(mode, g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
+        else launch_v2(mode, g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
 #ifdef SBE_STAMPS
         if (p.stamps) {                             // diagnostic build: dump the in-kernel stamps of this launch
             std::vector<uint64_t> h((size_t)grid.x * 48);

@@ -1,0 +1,68 @@
+// sbe_mixture.hip.h -- what the engine (sbe_engine.hip) and the fused mixture kernels' translation unit
+// (sbe_mixture.hip) share: the launch parameters of the north-star kernels and their launchers.  The kernels themselves
+// (sbe_kernels_mixture.hip.h: k_mixture_v2 / _onehot_v2 / _rows / _combo / _tuple64, 1 300 lines of templates and most of the
+// library's compile time) are compiled in their own translation unit, so a change to the engine's host code or to any other
+// kernel does not rebuild them.
+#pragma once
+#include "sbe_device_common.hip.h"
+
+namespace sbe {
+
+// Log-accumulation modes of the fused kernels:
+//   LOG_PER_OBS : fp64 log per observation, fp64 sum
+//   LOG_PRODUCT : the observation likelihoods of a step are multiplied into a running mantissa whose
+//                 binary exponent is stripped with integer ops; one fp64 log per thread (see ProdAcc)
+enum MixMode : int { LOG_PER_OBS = 0, LOG_PRODUCT = 1, WRITE_OBS = 2 };
+
+constexpr int kRowsBlock = 1024;
+constexpr int kRowsWaves = kRowsBlock / kWave;
+
+struct Mix2Params {
+    int N, NQ, Np, F, Fq, S, C, Gtot, P;
+    int n_ftiles, quads_per_chunk;
+    int n_work, n_batch;                           // (tile, chunk) work items per slot; slots in this launch
+    int slot_groups, slots_per_group;              // XCD-aware block order (see k_mixture_v2)
+    // group-tuple form (k_mixture_combo): per slot the distinct (g_0..g_{C-1}) tuples of its objects
+    const uint8_t* tid;      int64_t tid_stride;       // [Np] tuple index per object
+    const uint16_t* tuple_g; int64_t tuple_g_stride;   // [kMaxTuples][kMaxComponents] global group index (Gtot = none)
+    const uint8_t* tuple_p;  int64_t tuple_p_stride;   // [kMaxTuples] pattern id of the tuple
+    int KT;                                            // tuples used by the slots of this launch (max)
+    int combo_w_off;                                   // byte offset of the weight tile in the combo kernel's LDS
+    int combo_tab_off;                                 // byte offset of the one-hot byte -> (state, feature) table
+    const uint32_t* state_q;                       // [NQ][Fq]
+    const uint2* state_h;                          // [NQ][Fq] 4 x u16 prepared LDS offsets (k_mixture_tuple64), or null
+    const uint32_t* toff;  int64_t toff_stride;    // per slot [Np] byte offset of the object's tuple block
+    const double2* logtab;                         // [128] {1/c, log c} of tab_log_pos
+    int gen_slots;                                 // k_mixture_tuple64 block order: slots per XCD and generation
+    int rows_cum[5];                               // k_mixture_rows: cumulative per-mille shares of a block's steps by wave age class
+    int ragged_w;                                  // valid features of the last tile if it runs in sub-row mode (<= 32), else 0
+    uint64_t* stamps;                              // diagnostic builds (-DSBE_STAMPS): [blocks][4 waves][8] cycle stamps
+    const uint8_t* onehot; int rs_pitch;           // [N][rs_pitch] (one-hot variant)
+    const uint16_t* gid;   int64_t gid_stride;     // per slot [C][Np]
+    const uint8_t* pid;    int64_t pid_stride;     // per slot [Np]
+    const float* probs_t;  int64_t probs_t_stride; // per slot [n_ftiles][(Gtot+1)*S*FT]
+    const double* wpat_t;  int64_t wpat_t_stride;  // per slot [n_ftiles][Pmax*C*FT]
+    int wpat_tile_stride;                          // Pmax*C*FT
+    double* partials;      int64_t partials_stride;
+    int first_slot;
+    const int32_t* slot_list;                      // slots of this launch (n_batch entries), or null: first_slot + i
+    // rows kernel (k_mixture_rows): engine tile width of probs_t, canonical per-pattern weights, per-object row offsets
+    int eft;                                       // tile width of probs_t (64 / 32 / 16)
+    const float* wpat;     int64_t wpat_stride;    // per slot [Pmax][F][C] float32 normalised weights (a5)
+    const uint32_t* rowoff; int64_t rowoff_stride; // per slot [C+1][Np]: LDS byte offsets (see k_rowoff)
+};
+
+// waves per block of k_mixture_tuple64.  (8-wave blocks -- twice the waves per SIMD at the same LDS footprint -- were
+// measured twice: 72.7 us at 80 VGPRs / 3 blocks per CU, 107 us at 64 VGPRs / 4 blocks per CU, against 61-63 us: the
+// kernel does not fit those register budgets without spilling in its table build.)
+constexpr int tuple64_waves() { return 4; }
+
+// Launchers (sbe_mixture.hip): pick the template instance for (mode, tile width, component count) and enqueue it.
+// mode: LOG_PER_OBS / LOG_PRODUCT; ft: 64 / 32 / 16; C: components (1..4 compile-time instances, else the runtime form).
+void launch_v2(int mode, int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st, bool direct);
+void launch_oh2(int mode, int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st, bool direct);
+void launch_combo(bool onehot, int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st);
+void launch_tuple64(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st);
+void launch_rows(int mode, int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st);
+
+}  // namespace sbe

@@ -20,9 +20,7 @@ def pytest_sessionstart(session):
     import shutil
     sys.path.insert(0, str(REPO))
     import __graft_entry__ as entry
-    deps = [entry.SRC, entry.SRC.with_name("sbe_kernels.hip.h"), entry.SRC.with_name("sbe_pool.h"), REPO / "include" / "sbe_engine.h"]
-    stale = not entry.OUT.exists() or any(d.stat().st_mtime > entry.OUT.stat().st_mtime for d in deps)
-    if stale and (os.path.exists(entry.HIPCC) or shutil.which("hipcc")):
+    if entry.stale() and (os.path.exists(entry.HIPCC) or shutil.which("hipcc")):
         entry.build()
 
 

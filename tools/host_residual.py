@@ -16,6 +16,8 @@ Method, per shape (cfg1 50x30x5, south_america 100x36x5, headline 1000x200x10):
   plain   the unpatched reference (NumPy path) on the same seed and step count: steps/s of the baseline sampler on THIS
           host (SURVEY.md section 6 quotes 417 / ~300 / 26 from the survey container).
 
+  Every step's time is the fastest of its occurrences over 5 replays (2-3 for `plain`): same deterministic run each time.
+
   python tools/host_residual.py [--steps-small 400] [--steps-headline 120]
 """
 from __future__ import annotations
@@ -290,19 +292,26 @@ def _summary(secs):
 def measure(tag, config_path, n_steps, seed, gibbs_source=False):
     secs1, _, ops1, eng1, ll1 = _run(config_path, tag, n_steps, seed, "memo", gibbs_source=gibbs_source)
     memo = eng1.memo
-    best = None
-    for _ in range(3):                                               # three replays, the fastest kept (host noise)
-        secs2, inside2, ops2, eng2, ll2 = _run(config_path, tag, n_steps, seed, "replay", memo=memo, gibbs_source=gibbs_source)
+    # The same deterministic run is replayed several times and every STEP takes its fastest occurrence: the build container
+    # shares its cores, a step that was interrupted in one replay is not in another (whole-run means moved by +-10 %).
+    resid = inside2 = None
+    for _ in range(5):
+        secs2, ins2, ops2, eng2, ll2 = _run(config_path, tag, n_steps, seed, "replay", memo=memo, gibbs_source=gibbs_source)
         assert ops2 == ops1 and ll2 == ll1 and eng2._pos <= len(memo)
-        if best is None or sum(secs2) < sum(best[0]):
-            best = (secs2, inside2)
-    secs2, inside2 = best
-    # one more replay with the host-layer clock on (its wrappers cost a little: not the run the residual is taken from)
-    _s, inside3, _o, _e, _l, layer3 = _run(config_path, tag, n_steps, seed, "replay", memo=memo, layer_clock=True,
-                                           gibbs_source=gibbs_source)
-    ours = np.asarray(layer3) - np.asarray(inside3)
-    secs0, _, ops0, _, ll0 = _run(config_path, tag, n_steps, seed, "plain")
-    resid = np.asarray(secs2) - np.asarray(inside2)
+        r = np.asarray(secs2) - np.asarray(ins2)
+        resid = r if resid is None else np.minimum(resid, r)
+        inside2 = np.asarray(ins2) if inside2 is None else np.minimum(inside2, np.asarray(ins2))
+    # replays with the host-layer clock on (its wrappers cost a little: not the runs the residual is taken from)
+    ours = None
+    for _ in range(3):
+        _s, inside3, _o, _e, _l, layer3 = _run(config_path, tag, n_steps, seed, "replay", memo=memo, layer_clock=True,
+                                               gibbs_source=gibbs_source)
+        o = np.asarray(layer3) - np.asarray(inside3)
+        ours = o if ours is None else np.minimum(ours, o)
+    secs0 = None
+    for _ in range(3 if n_steps * 1 <= 200 else 2):
+        s0, _, ops0, _, ll0 = _run(config_path, tag, n_steps, seed, "plain")
+        secs0 = np.asarray(s0) if secs0 is None else np.minimum(secs0, np.asarray(s0))
     by_op = {}
     for op in sorted(set(ops1)):
         sel = np.array([o == op for o in ops1])
