@@ -68,6 +68,7 @@ class Likelihood:
         state = dict(self.__dict__)
         state["_na_features"] = None
         state["_engine"] = None
+        state["_call_memo"] = None
         state["_sbayes_amd_patch"] = patch.installed()      # how the pickling process had sBayes patched, if at all
         return state
 
@@ -109,11 +110,17 @@ class Likelihood:
     def __call__(self, sample, caching=True) -> float:
         if not caching:
             recalculate_feature_counts(self.features, sample)
-        log_lh = 0.0
-        log_lh += self.compute_lh_clusters(sample, caching=caching)
-        for conf in self.confounders:
-            log_lh += self.compute_lh_confounder(sample, conf, caching=caching)
-        return log_lh
+        # one bind and one fetch per call: the components are asked one after another (likelihood.py:58-63) for the SAME
+        # sample, so the per-group values of all of them are taken once (_group_logliks) and kept for the rest of the call
+        self._call_memo = [sample, None]
+        try:
+            log_lh = 0.0
+            log_lh += self.compute_lh_clusters(sample, caching=caching)
+            for conf in self.confounders:
+                log_lh += self.compute_lh_confounder(sample, conf, caching=caching)
+            return log_lh
+        finally:
+            self._call_memo = None
 
     def _group_logliks(self, sample, component, groups, slot=0):
         """float64 per listed group of one component: float32-summed Dirichlet-categorical log-pdf (a7/a8) from the
@@ -121,6 +128,9 @@ class Likelihood:
         the groups that changed since the slot was last bound (those are the `groups` asked for here), nothing else
         goes up, G_c doubles come back."""
         eng = self.engine
+        memo = self.__dict__.get("_call_memo")
+        if memo is not None and memo[0] is sample and memo[1] is not None:     # (later components of the same __call__)
+            return memo[1][int(eng.group_offsets[component]) + np.asarray(groups)]
         try:
             _bind_slot(eng, self._bind_model, sample, slot)
         except GroupOverlapError:
@@ -143,6 +153,8 @@ class Likelihood:
             lh_all = eng.collapsed_loglik_all(slot)
             if entry is not None:
                 entry["lh_all"] = lh_all
+        if memo is not None and memo[0] is sample:
+            memo[1] = lh_all
         return lh_all[int(eng.group_offsets[component]) + np.asarray(groups)]
 
     def compute_lh_clusters(self, sample, caching=True) -> float:
