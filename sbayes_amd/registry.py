@@ -45,7 +45,7 @@ def get_engine(features, n_groups=None, n_slots=4, device=None, deferred_checks=
     # the same array OBJECT as in the last call (the drop-in functions pass data.features.values every time): its
     # engine, unless that was closed or the caller names another component layout -- no key is built, nothing is hashed
     last = _LAST[0]
-    if last is not None and last[0] is features:
+    if last is not None and last[0]() is features:        # (weakly held: the registry never keeps a feature block alive)
         eng = last[1]
         if getattr(eng, "_h", True) and (n_groups is None or list(n_groups) == eng.n_groups):
             return eng
@@ -56,7 +56,8 @@ def get_engine(features, n_groups=None, n_slots=4, device=None, deferred_checks=
         eng, ref = entry
         alive = ref() is not None if ref is not None else True
         if alive and (n_groups is None or list(n_groups) == eng.n_groups):
-            _LAST[0] = (features, eng)
+            if ref is not None:
+                _LAST[0] = (ref, eng)
             return eng
         eng.close()
         del _ENGINES[key]
@@ -84,7 +85,8 @@ def get_engine(features, n_groups=None, n_slots=4, device=None, deferred_checks=
     except TypeError:
         ref = None
     _ENGINES[key] = (eng, ref)
-    _LAST[0] = (features, eng)
+    if ref is not None:
+        _LAST[0] = (ref, eng)
     return eng
 
 
