@@ -150,7 +150,7 @@ def gibbs_sample_source(model, sample, object_subset=slice(None), temperature=1.
 
 
 def cluster_gibbs_sample_source(model, sample_new, sample_old, i_cluster, object_subset, temperature=1.0, prior_temperature=1.0,
-                                sample_from_prior=False, slot=0):
+                                sample_from_prior=False, slot=0, z=None):
     """ClusterOperator.gibbs_sample_source (operators.py:796-851): the source resampling inside every AlterCluster /
     AlterClusterWide / ClusterJump proposal.  `sample_new` has the clusters already changed and the source not yet
     resampled (its counts are still the old state's); everything between the two samples' bookkeeping -- the likelihood
@@ -173,7 +173,8 @@ def cluster_gibbs_sample_source(model, sample_new, sample_old, i_cluster, object
     hc_new = sample_new.cache.has_components.value[objects]
     hc_old = sample_old.cache.has_components.value[objects]
     src_old = _source_ids(sample_old.source.value, objects)
-    z = np.random.random((objects.size, eng.n_features, 1))
+    if z is None:                                                          # (tests pass the reference's recorded uniforms)
+        z = np.random.random((objects.size, eng.n_features, 1))
     ids, sel_new, sel_back = eng.given_unchanged_gibbs(slot, i_cluster, objects, hc_new, hc_old, src_old, z, temperature,
                                                        prior_temperature, sample_from_prior)
     x = ids[..., None] == np.arange(eng.n_components, dtype=np.uint8)     # one-hot; all False where NA (id 255)

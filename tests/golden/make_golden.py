@@ -971,8 +971,43 @@ def gibbs_source_fixture():
                 extra[f"gs_{tag}_counts_{i}"] = new.feature_counts[k].value.copy()
             print(f"[golden] gibbs_source {tag}: n={idx.size} log_q={log_q!r} log_q_back={log_q_back!r} "
                   f"changed={int(np.count_nonzero(new.source.value ^ sample.source.value))}")
+        # ---- ClusterOperator.gibbs_sample_source (operators.py:796-851), the resampling inside a cluster proposal: the
+        # reference's own method on (sample_new = sample with objects moved into / out of a cluster, source not yet resampled)
+        cluster_cases = {"grow": (1.0, 1.0, False, True), "shrink": (1.0, 1.0, False, False),
+                         "mc3": (1.3, 1.5, False, True), "prior": (1.0, 1.0, True, True)}
+        # (sample_from_prior with T_prior != 1 is not a case: p = w ** (1/T_prior) is then not normalised and the reference's
+        #  own sample_categorical asserts, preprocessing.py:245)
+        for i_case, (tag, (temp, ptemp, from_prior, grow)) in enumerate(cluster_cases.items()):
+            ops = get_operator_schedule(mcmc_cfg.operators, model, data, temperature=temp, prior_temperature=ptemp,
+                                        sample_from_prior=from_prior)
+            op = ops["cluster_gibbsish"]
+            i_cluster = int(i_case % sample.n_clusters)
+            member = sample.clusters.value[i_cluster]
+            free = ~sample.clusters.value.any(axis=0)
+            pool = np.flatnonzero(free if grow else member)
+            moved = np.sort(rng.choice(pool, size=min(3, pool.size), replace=False))
+            sample_new = sample.copy()
+            for o in moved:
+                (sample_new.clusters.add_object if grow else sample_new.clusters.remove_object)(i_cluster, int(o))
+            seed = 2000 + i_case
+            np.random.seed(seed)
+            out_new, log_q, log_q_back = op.gibbs_sample_source(sample_new, sample, i_cluster, object_subset=moved)
+            np.random.seed(seed)
+            z = np.random.random([moved.size, F, 1])
+            extra[f"cg_{tag}_objects"] = moved.astype(np.int32)
+            extra[f"cg_{tag}_i_cluster"] = np.int64(i_cluster)
+            extra[f"cg_{tag}_z"] = z[..., 0]
+            extra[f"cg_{tag}_temps"] = np.array([temp, ptemp, float(from_prior)])
+            extra[f"cg_{tag}_clusters_new"] = out_new.clusters.value.copy()
+            extra[f"cg_{tag}_new_source"] = out_new.source.value.copy()
+            extra[f"cg_{tag}_log_q"] = np.float64(log_q)
+            extra[f"cg_{tag}_log_q_back"] = np.float64(log_q_back)
+            for i, k in enumerate(names):
+                extra[f"cg_{tag}_counts_{i}"] = out_new.feature_counts[k].value.copy()
+            print(f"[golden] cluster gibbs {tag}: cluster {i_cluster} objects {moved.tolist()} log_q={log_q!r} log_q_back={log_q_back!r}")
         meta = dict(name="gibbs_source", shape=list(data.features.values.shape), component_names=names,
-                    groups=[int(sample.n_groups(k)) for k in names], cases=list(cases), **scal, **dig)
+                    groups=[int(sample.n_groups(k)) for k in names], cases=list(cases), cluster_cases=list(cluster_cases),
+                    **scal, **dig)
         np.savez_compressed(OUT / "gibbs_source.npz", features=data.features.values,
                             states_per_feature=data.features.states, weights=sample.weights.value,
                             source=sample.source.value, meta=json.dumps(meta), **arrs, **extra)

@@ -466,3 +466,20 @@ def test_source_lh_by_feature_matches_the_reference(name):
     sample.weights.set_value(w2)
     want = orc.source_lh_by_feature(fx.source, orc.normalize_weights(w2, orc.has_components(fx.groups)), fx.na_values)
     np.testing.assert_allclose(source_lh_by_feature(model, sample), want, rtol=rtol, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["grow", "shrink", "mc3", "prior"])
+def test_cluster_gibbs_sample_source_draw_for_draw(tag):
+    """ClusterOperator.gibbs_sample_source (operators.py:796-851) in one engine call (sbe_given_unchanged_gibbs) with the
+    reference's own uniforms -> the reference's new source array and counts (always), float32 log_q / log_q_back bit-exact
+    at temperature 1 and within the float32 powf tolerance at MC3 temperatures."""
+    from tests import _cluster_gibbs_case as case
+    try:
+        exact, (lq, want_lq), (lqb, want_lqb), sample, objects, fx = case.run_case(tag)
+        if exact:
+            assert lq == np.float32(want_lq) and lqb == np.float32(want_lqb), (tag, lq, want_lq, lqb, want_lqb)
+        else:
+            assert abs(lq - want_lq) <= 2e-6 * max(1.0, abs(want_lq)) and abs(lqb - want_lqb) <= 2e-6 * max(1.0, abs(want_lqb))
+    finally:
+        release_all()
+

@@ -49,3 +49,25 @@ def test_oracle_source_lh_by_feature_matches_the_reference(name):
     w = orc.normalize_weights(fx.weights, orc.has_components(fx.groups))
     got = orc.source_lh_by_feature(fx.source, w, fx.na_values)
     assert got.dtype == np.float32 and np.array_equal(got, z["swl_lh_by_feature"])
+
+
+@pytest.mark.parametrize("tag", ["grow", "shrink", "mc3", "prior"])
+def test_cluster_gibbs_sample_source_on_the_double_matches_the_reference(tag, monkeypatch):
+    """operators.cluster_gibbs_sample_source (host logic) over the oracle-backed double's given_unchanged_gibbs == the
+    reference's ClusterOperator.gibbs_sample_source (operators.py:796-851) fed with the same uniforms: new source array,
+    counts and float32 log_q / log_q_back BIT FOR BIT, tempered cases included (the double restates the expressions in
+    the reference's dtypes)."""
+    from sbayes_amd import binding, conditionals, counts, likelihood, registry
+    from tests import _cluster_gibbs_case as case
+    from tests._fake_engine import make_get_engine
+    engines = {}
+    get_engine = make_get_engine(engines)
+    for mod in (registry, likelihood, conditionals, counts, binding):
+        monkeypatch.setattr(mod, "get_engine", get_engine, raising=True)
+    exact, (lq, want_lq), (lqb, want_lqb), sample, objects, fx = case.run_case(tag)
+    assert lq == np.float32(want_lq) and lqb == np.float32(want_lqb), (tag, lq, want_lq, lqb, want_lqb)
+    others = np.setdiff1d(np.arange(sample.n_objects), objects)
+    assert np.array_equal(sample.source.value, fx.source)                             # the old sample is not modified
+    kinds = [c[0] for c in next(iter(engines.values())).calls]
+    assert kinds.count("given_unchanged_gibbs") == 1 and "counts_delta" in kinds
+
