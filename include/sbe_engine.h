@@ -26,13 +26,15 @@
  *     such a call therefore busy-waits on one core for the duration of the launch.
  *   - how a large result reaches the caller: sbe_component_lh and sbe_likelihood_per_component hand back
  *     [N][F] / [N][F][C] float64 arrays (1.6 / 3.2 MB at the headline shape).  From 512 KB on, their kernels
- *     store the result straight into a host-mapped staging buffer (16-byte coalesced stores over PCIe) and
- *     raise one host-mapped flag per chunk of >= 128 KB; the engine's host worker threads (the pool of the
+ *     store the result straight into a host-mapped staging buffer (16-byte coalesced stores over PCIe), chunk
+ *     after chunk in order (8 chunks of >= 128 KB; the grid is one chunk's worth of blocks), and raise one
+ *     host-mapped flag per completed chunk; the engine's host worker threads (the pool of the
  *     batched steps: SBE_STEP_THREADS, default 8 including the caller) copy / scatter each chunk into the
  *     caller's array as soon as its flag shows the call's sequence number, while the later chunks are still
  *     in flight.  No copy-engine operation and no event is involved.  A flag that stays away for 2 ms + 10 GB/s
  *     sends the calling thread to the HIP stream wait.  SBE_D2H_THREADS=1 keeps the copy on the calling thread,
- *     SBE_STREAM_RESULTS=0 uses the copy engine (same bits: tests/test_gpu_streamed_results.py).  The worker
+ *     SBE_STREAM_RESULTS=0 uses the copy engine, SBE_STREAM_ORDERED=0 the one-block-per-tile form whose chunks all
+ *     complete at the end of the kernel (same bits: tests/test_gpu_streamed_results.py).  The worker
  *     threads poll for ~400 us after a call before they block.
  *   - bool arrays are one byte per element (NumPy bool layout), C order.
  */

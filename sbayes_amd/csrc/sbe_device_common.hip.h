@@ -67,7 +67,8 @@ __device__ __forceinline__ void signal_done(const DoneSig& d) {
 // ticket of its chunk, the chunk's last block stores the call's sequence number into the chunk's host-mapped flag.  The
 // host copies a chunk out of the staging buffer as soon as its flag shows the sequence number, while the later chunks
 // are still crossing PCIe (sbe_engine.hip: stream_result).  Every thread of the block must reach the call.
-struct ChunkSig { unsigned* tickets; unsigned long long* flags; unsigned long long seq; unsigned blocks_per_chunk; unsigned n_blocks; };
+struct ChunkSig { unsigned* tickets; unsigned long long* flags; unsigned long long seq; unsigned blocks_per_chunk; unsigned n_blocks;
+                  unsigned n_chunks; long long chunk_elems; };     // chunk_elems > 0: ORDERED form (every block walks the chunks in turn)
 __device__ __forceinline__ void signal_chunk(const ChunkSig& c) {
     if (!c.flags) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's result stores are acknowledged
@@ -84,6 +85,25 @@ __device__ __forceinline__ void signal_chunk(const ChunkSig& c) {
             __hip_atomic_store(c.flags + chunk, c.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+
+// ORDERED form: all blocks of the (small) grid work on chunk 0, then on chunk 1, ...: a chunk is complete -- and its flag
+// raised by the last block to get there -- while the later chunks have not been started, so the host copy of chunk k runs
+// under the transfer of chunk k+1 (with one block per 2 x 256 output elements and every block resident at once, as in the
+// plain form, all chunks complete together at the end of the kernel).
+__device__ __forceinline__ void signal_chunk_ordered(const ChunkSig& c, unsigned chunk) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        const unsigned t = __hip_atomic_fetch_add(c.tickets + chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(c.tickets + chunk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(c.flags + chunk, c.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------

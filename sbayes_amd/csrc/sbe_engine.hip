@@ -270,7 +270,9 @@ int ensure_step_pool(sbe_engine* e);
 // copies out of pinned memory at 27 GB/s -- 120 us for 3.2 MB, twice the transfer.  So: the kernel writes its result
 // into the host-mapped staging buffer `h_stream` and reports completion chunk by chunk (signal_chunk); the host jobs --
 // work(j) copies / scatters staging bytes [.., job_end(j)) to the caller -- run on the engine's pool (sbe_pool.h:
-// run_as_ready) as the chunks land, the calling thread reading the chunk flags.  No copy engine, no event, one launch.
+// run_as_chunks_land) as the chunks land, every thread reading the chunk flags.  No copy engine, no event, one launch.
+// The kernel's grid is ONE chunk's worth of blocks walking the chunks in order (plan_stream), so chunk k is complete and
+// being copied out while chunk k+1 crosses PCIe.
 int ensure_stream(sbe_engine* e, size_t bytes) {
     if (bytes <= e->stream_bytes) return SBE_OK;
     if (e->h_stream) { HIPCHK(e, hipStreamSynchronize(e->stream)); HIPCHK(e, hipHostFree(e->h_stream)); e->h_stream = nullptr; e->stream_bytes = 0; }
@@ -281,14 +283,28 @@ int ensure_stream(sbe_engine* e, size_t bytes) {
     return SBE_OK;
 }
 
-struct StreamPlan { ChunkSig sig; int n_chunks; size_t chunk_bytes; size_t bytes; };
+struct StreamPlan { ChunkSig sig; int n_chunks; size_t chunk_bytes; size_t bytes; unsigned grid; };
 
 // chunks of whole blocks: `bytes_per_block` result bytes per block, n_blocks blocks, at most kMaxChunks chunks of >= 128 KB
 StreamPlan plan_stream(sbe_engine* e, unsigned n_blocks, size_t bytes_per_block, size_t bytes) {
-    unsigned per = std::max<unsigned>(1, (unsigned)div_up((int64_t)n_blocks, sbe_engine::kMaxChunks));
+    // 8 chunks, walked IN ORDER by a grid of one chunk's worth of blocks (signal_chunk_ordered): same-box A/B
+    // (profiles/r4/ab_d2h_4_ordered_chunks.log) a1 11.6-12.1 -> 13.1-14.9 k calls/s, a3 9.3-10.3 -> 11.2-12.6 k against one block
+    // per 2 x 256 elements with every block resident at once (all chunks then complete together, at the end of the kernel,
+    // and the host copy overlaps nothing); 4 / 8 / 16 chunks within noise of each other.
+    static const int max_chunks = [] { const char* v = getenv("SBE_STREAM_CHUNKS"); const int n = v ? atoi(v) : 0;      // (experiments)
+                                       return n >= 1 && n <= sbe_engine::kMaxChunks ? n : 8; }();
+    unsigned per = std::max<unsigned>(1, (unsigned)div_up((int64_t)n_blocks, max_chunks));
     per = std::max<unsigned>(per, (unsigned)div_up((int64_t)128 << 10, (int64_t)bytes_per_block));
     const int n_chunks = (int)div_up((int64_t)n_blocks, (int64_t)per);
-    return StreamPlan{ChunkSig{e->d_chunk_tickets, e->d_chunk_flags, ++e->chunk_seq, per, n_blocks}, n_chunks, (size_t)per * bytes_per_block, bytes};
+    // SBE_STREAM_ORDERED=0 (A/B): one block per 2 x 256 elements, every block signalling its own chunk
+    static const bool ordered = [] { const char* v = getenv("SBE_STREAM_ORDERED"); return !(v && atoi(v) == 0); }();
+    ChunkSig sig{e->d_chunk_tickets, e->d_chunk_flags, ++e->chunk_seq, per, n_blocks, (unsigned)n_chunks, 0};
+    unsigned grid = n_blocks;
+    if (ordered && n_chunks > 1) {
+        sig.chunk_elems = (long long)per * (long long)(bytes_per_block / sizeof(double));
+        grid = per;
+    }
+    return StreamPlan{sig, n_chunks, (size_t)per * bytes_per_block, bytes, grid};
 }
 
 template <class JobBegin, class JobEnd, class Work>
@@ -1509,8 +1525,8 @@ int sbe_component_lh(sbe_engine* e, const void* probs, int probs_f64, int n_grou
         if (rc) return rc;
         const StreamPlan plan = plan_stream(e, (unsigned)blocks, (size_t)512 * sizeof(double), out_bytes);
         double* s_out = (double*)e->d_stream;
-        if (probs_f64) k_component_lh<double><<<blocks, 256, 0, e->stream>>>(e->d_state, (const double*)d_tab, d_sel, s_out, N, F, S, e->Fp, na_value, plan.sig);
-        else k_component_lh<float><<<blocks, 256, 0, e->stream>>>(e->d_state, (const float*)d_tab, d_sel, s_out, N, F, S, e->Fp, na_value, plan.sig);
+        if (probs_f64) k_component_lh<double><<<plan.grid, 256, 0, e->stream>>>(e->d_state, (const double*)d_tab, d_sel, s_out, N, F, S, e->Fp, na_value, plan.sig);
+        else k_component_lh<float><<<plan.grid, 256, 0, e->stream>>>(e->d_state, (const float*)d_tab, d_sel, s_out, N, F, S, e->Fp, na_value, plan.sig);
         HIPCHK(e, hipGetLastError());
         const double* dense = (const double*)e->h_stream;
         const int rows_per_job = std::max(1, (int)(((size_t)64 << 10) / ((size_t)F * sizeof(double))));
@@ -1897,7 +1913,7 @@ int sbe_likelihood_per_component(sbe_engine* e, int slot, double* out) {
         rc = ensure_stream(e, bytes);
         if (rc) return rc;
         const StreamPlan plan = plan_stream(e, (unsigned)blocks, (size_t)512 * sizeof(double), bytes);
-        k_lh_dense<<<blocks, 256, 0, e->stream>>>(
+        k_lh_dense<<<plan.grid, 256, 0, e->stream>>>(
             e->d_state, e->d_gid + (int64_t)slot * e->C * e->Np, e->d_probs + (int64_t)slot * e->table_elems(),
             (double*)e->d_stream, e->N, e->Np, e->F, e->S, e->C, e->Fp, plan.sig);
         HIPCHK(e, hipGetLastError());

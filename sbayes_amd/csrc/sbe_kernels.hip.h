@@ -411,16 +411,27 @@ template <class TP>
 __global__ void k_component_lh(const uint8_t* __restrict__ state, const TP* __restrict__ probs,
                                const int32_t* __restrict__ sel, double* __restrict__ out /* [N][F] */,
                                int N, int F, int S, int Fp, double na_value, ChunkSig chunks = ChunkSig{}) {
-    const int64_t i = 2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
     const int64_t total = (int64_t)N * F;
-    if (i + 1 < total) {
-        double2 v;
-        v.x = component_lh_value(state, probs, sel, i, F, S, Fp, na_value);
-        v.y = component_lh_value(state, probs, sel, i + 1, F, S, Fp, na_value);
-        *reinterpret_cast<double2*>(out + i) = v;
-    } else if (i < total) {
-        out[i] = component_lh_value(state, probs, sel, i, F, S, Fp, na_value);
+    auto store_pair = [&](int64_t i) {
+        if (i + 1 < total) {
+            double2 v;
+            v.x = component_lh_value(state, probs, sel, i, F, S, Fp, na_value);
+            v.y = component_lh_value(state, probs, sel, i + 1, F, S, Fp, na_value);
+            *reinterpret_cast<double2*>(out + i) = v;
+        } else if (i < total) {
+            out[i] = component_lh_value(state, probs, sel, i, F, S, Fp, na_value);
+        }
+    };
+    if (chunks.chunk_elems > 0) {         // ordered form: the grid walks the chunks one after another
+        for (unsigned c = 0; c < chunks.n_chunks; ++c) {
+            const int64_t lo = (int64_t)c * chunks.chunk_elems, hi = min(total, lo + (int64_t)chunks.chunk_elems);
+            for (int64_t i = lo + 2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x); i < hi; i += 2 * (int64_t)gridDim.x * blockDim.x)
+                store_pair(i);
+            signal_chunk_ordered(chunks, c);
+        }
+        return;
     }
+    store_pair(2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x));
     signal_chunk(chunks);                 // (`out` in host-mapped memory: completion chunk by chunk)
 }
 
@@ -445,16 +456,27 @@ __global__ void k_lh_dense(const uint8_t* __restrict__ state, const uint16_t* __
     // consecutive lanes store consecutive OUTPUT elements (n, f, c), two per thread as one 16-byte word: full lines
     // whether `out` is in HBM or, streamed, in host-mapped memory (a thread per observation storing C values at stride
     // C left every store instruction with half-filled lines: 3.2 MB crossed PCIe in 300 us instead of 70)
-    const int64_t j = 2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
     const int64_t total = (int64_t)N * F * C;
-    if (j + 1 < total) {
-        double2 v;
-        v.x = lh_dense_value(state, gid, probs, j, Np, F, S, C, Fp);
-        v.y = lh_dense_value(state, gid, probs, j + 1, Np, F, S, C, Fp);
-        *reinterpret_cast<double2*>(out + j) = v;
-    } else if (j < total) {
-        out[j] = lh_dense_value(state, gid, probs, j, Np, F, S, C, Fp);
+    auto store_pair = [&](int64_t j) {
+        if (j + 1 < total) {
+            double2 v;
+            v.x = lh_dense_value(state, gid, probs, j, Np, F, S, C, Fp);
+            v.y = lh_dense_value(state, gid, probs, j + 1, Np, F, S, C, Fp);
+            *reinterpret_cast<double2*>(out + j) = v;
+        } else if (j < total) {
+            out[j] = lh_dense_value(state, gid, probs, j, Np, F, S, C, Fp);
+        }
+    };
+    if (chunks.chunk_elems > 0) {         // ordered form: the grid walks the chunks one after another
+        for (unsigned c = 0; c < chunks.n_chunks; ++c) {
+            const int64_t lo = (int64_t)c * chunks.chunk_elems, hi = min(total, lo + (int64_t)chunks.chunk_elems);
+            for (int64_t j = lo + 2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x); j < hi; j += 2 * (int64_t)gridDim.x * blockDim.x)
+                store_pair(j);
+            signal_chunk_ordered(chunks, c);
+        }
+        return;
     }
+    store_pair(2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x));
     signal_chunk(chunks);                 // (`out` in host-mapped memory: completion chunk by chunk)
 }
 

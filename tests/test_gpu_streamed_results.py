@@ -1,7 +1,7 @@
 """Large results streamed by the kernel (include/sbe_engine.h "how a large result reaches the caller"):
 `sbe_component_lh` (a1) and `sbe_likelihood_per_component` (a3) store their `[N, F]` / `[N, F, C]` float64 result into
-host-mapped staging themselves and raise one flag per chunk; host threads copy a chunk to the caller as soon as its flag
-shows the call's sequence number.  If a flag could overtake its chunk's data, the host would copy what the PREVIOUS call left
+host-mapped staging themselves, chunk after chunk in order, and raise one flag per completed chunk; host threads copy a chunk
+to the caller as soon as its flag shows the call's sequence number.  If a flag could overtake its chunk's data, the host would copy what the PREVIOUS call left
 in the staging buffer.  So every call here produces a result that differs from the previous call's in (nearly) every
 element -- two table variants, alternating -- and is compared with the expected array in full, a few thousand times per
 path; the caller's array is poisoned before every call.  The forms must agree bit for bit: streamed + pool, streamed on the
@@ -81,8 +81,8 @@ print("OK")
 
 
 @pytest.mark.parametrize("env", [{"SBE_D2H_THREADS": "1"}, {"SBE_STREAM_RESULTS": "0"}, {"SBE_STREAM_RESULTS": "0", "SBE_D2H_THREADS": "1"},
-                                 {"SBE_STEP_THREADS": "3"}],
-                         ids=["one_thread", "copy_engine", "copy_engine_one_thread", "pool_of_3"])
+                                 {"SBE_STEP_THREADS": "3"}, {"SBE_STREAM_ORDERED": "0"}, {"SBE_STREAM_CHUNKS": "16"}],
+                         ids=["one_thread", "copy_engine", "copy_engine_one_thread", "pool_of_3", "unordered_chunks", "16_chunks"])
 def test_other_forms_give_the_same_bits(env):
     res = subprocess.run([sys.executable, "-c", _CHILD % str(REPO)], capture_output=True, text=True, timeout=900,
                          env=dict(os.environ, **env), cwd=str(REPO))

@@ -48,12 +48,12 @@ print(json.dumps({k: round(v, 1) for k, v in out.items()}))
 # round 4: results streamed by the kernel into host-mapped staging and copied out chunk by chunk on the host pool (default)
 # against the calling thread alone (SBE_D2H_THREADS=1), against the copy-engine path (SBE_STREAM_RESULTS=0: one
 # hipMemcpyAsync, then the copy out of staging on the pool / on one thread = the round-1 form); pool sizes: SBE_STEP_THREADS
-SETTINGS = [("pool default", {}), ("one thread", {"SBE_D2H_THREADS": "1"}), ("not streamed", {"SBE_STREAM_RESULTS": "0"}),
-            ("not streamed, one thread", {"SBE_STREAM_RESULTS": "0", "SBE_D2H_THREADS": "1"}),
-            ("pool of 4", {"SBE_STEP_THREADS": "4"}), ("pool of 16", {"SBE_STEP_THREADS": "16"})]
+SETTINGS = [("default (ordered, 8 chunks)", {}), ("one thread", {"SBE_D2H_THREADS": "1"}),
+            ("ordered, 16 chunks", {"SBE_STREAM_CHUNKS": "16"}), ("ordered, 4 chunks", {"SBE_STREAM_CHUNKS": "4"}),
+            ("unordered chunks", {"SBE_STREAM_ORDERED": "0", "SBE_STREAM_CHUNKS": "16"}), ("not streamed", {"SBE_STREAM_RESULTS": "0"})]
 for rep in range(3):
     for name, extra in SETTINGS:
         env = dict(os.environ, **extra)
         res = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=env, timeout=300)
         line = res.stdout.strip().splitlines()[-1] if res.stdout.strip() else res.stderr[-300:]
-        print(f"{name:25s}: {line}", flush=True)
+        print(f"{name:28s}: {line}", flush=True)
