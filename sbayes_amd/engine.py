@@ -219,8 +219,7 @@ class Engine:
         g = _c(groups.astype(bool, copy=False), np.uint8)
         ch = _as(changed_groups, np.int64).reshape(-1)
         self._check(self._lib.sbe_component_lh(self._h, self._i(p), int(f64), n_groups, self._i(g), self._i(ch), ch.size,
-                                               ct.c_void_p(out.ctypes.data), out.strides[0], out.strides[1],
-                                               float(na_value)))
+                                               _ptr(out), out.strides[0], out.strides[1], float(na_value)))
         self.d2h_bytes += out.size * 8              # (rows the call leaves untouched are not written; counted as the upper bound)
         return out
 
