@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "sbe_engine.h"
 
 #define LOAD(name) name##_t p_##name = (name##_t)dlsym(lib, #name); if (!p_##name) { fprintf(stderr, "missing %s\n", #name); return 2; }
@@ -21,6 +22,9 @@ typedef int (*sbe_set_weights_t)(sbe_engine*, int, const float*);
 typedef int (*sbe_mixture_loglik_t)(sbe_engine*, int, double*);
 typedef int (*sbe_collapsed_loglik_t)(sbe_engine*, int, int, double*, float*);
 typedef int (*sbe_get_info_t)(const sbe_engine*, sbe_info*);
+typedef int (*sbe_host_group_ids_t)(const uint8_t*, int, int64_t, const int32_t*, int, int, int32_t*);
+typedef int (*sbe_host_source_ids_t)(const uint8_t*, int64_t, int, int, const int32_t*, int, uint8_t*);
+typedef int (*sbe_host_touched_groups_t)(const int32_t*, const int32_t*, int64_t, int, int32_t*, int32_t*);
 
 static void* slurp(FILE* f, size_t bytes) {
     void* p = malloc(bytes ? bytes : 1);
@@ -35,6 +39,7 @@ int main(int argc, char** argv) {
     LOAD(sbe_create) LOAD(sbe_destroy) LOAD(sbe_last_error) LOAD(sbe_set_groups) LOAD(sbe_set_source) LOAD(sbe_recount)
     LOAD(sbe_set_concentration) LOAD(sbe_update_probs) LOAD(sbe_set_weights) LOAD(sbe_mixture_loglik)
     LOAD(sbe_collapsed_loglik) LOAD(sbe_get_info)
+    LOAD(sbe_host_group_ids) LOAD(sbe_host_source_ids) LOAD(sbe_host_touched_groups)
     FILE* f = fopen(argv[2], "rb");
     if (!f) { perror("case"); return 1; }
     int32_t hdr[4];                                   /* N, F, S, C */
@@ -44,11 +49,13 @@ int main(int argc, char** argv) {
     uint8_t* feats = (uint8_t*)slurp(f, (size_t)N * F * S);
     sbe_engine* e = NULL;
     if (p_sbe_create(&e, 0, N, F, S, C, G, 1, feats)) { fprintf(stderr, "create: %s\n", p_sbe_last_error(NULL)); return 4; }
+    uint8_t* clusters = NULL;
     for (int c = 0; c < C; ++c) {
         uint8_t* groups = (uint8_t*)slurp(f, (size_t)G[c] * N);
         double* conc = (double*)slurp(f, (size_t)G[c] * F * S * sizeof(double));
         if (p_sbe_set_groups(e, 0, c, groups) || p_sbe_set_concentration(e, c, conc, 1)) { fprintf(stderr, "%s\n", p_sbe_last_error(e)); return 5; }
-        free(groups); free(conc);
+        if (c == 0) clusters = groups; else free(groups);
+        free(conc);
     }
     uint8_t* source = (uint8_t*)slurp(f, (size_t)N * F * C);
     float* weights = (float*)slurp(f, (size_t)F * C * sizeof(float));
@@ -70,6 +77,37 @@ int main(int argc, char** argv) {
     /* error behaviour: a bad slot is reported through the return code + message, not a crash */
     if (p_sbe_mixture_loglik(e, 7, &ll) == 0) { fprintf(stderr, "bad slot accepted\n"); return 11; }
     printf("error_text %s\n", p_sbe_last_error(e));
+    /* round 4: a group matrix with an object in two rows has no resident form -> SBE_ERR_DATA naming object, groups, component
+       (needs two clusters); the slot keeps its previous ids */
+    if (G[0] >= 2) {
+        uint8_t* bad = (uint8_t*)malloc((size_t)G[0] * N);
+        memcpy(bad, clusters, (size_t)G[0] * N);
+        int n_first = -1;
+        for (int n = 0; n < N && n_first < 0; ++n) if (bad[n]) n_first = n;      /* a member of cluster 0 ... */
+        if (n_first >= 0) bad[(size_t)N + n_first] = 1;                            /* ... also put into cluster 1 */
+        const int rc = p_sbe_set_groups(e, 0, 0, bad);
+        printf("overlap_rc %d\noverlap_text %s\n", rc, p_sbe_last_error(e));
+        double again = 0.0;
+        if (p_sbe_mixture_loglik(e, 0, &again) || again != ll) { fprintf(stderr, "state changed by the refused call\n"); return 12; }
+        free(bad);
+    }
+    /* round 4: the host helpers of the marshalling (no device): ids of the first 5 objects */
+    {
+        int32_t objs[5] = {0, 1, 2, 3, 4}, gids[5], gids2[5], touched[64], n_touched = 0;
+        uint8_t* sids = (uint8_t*)malloc((size_t)5 * F);
+        const int n = N < 5 ? N : 5;
+        if (p_sbe_host_group_ids(clusters, G[0], N, objs, n, 0, gids) != 0) return 13;
+        if (p_sbe_host_source_ids(source, N, F, C, objs, n, sids) != 0) return 14;
+        for (int i = 0; i < n; ++i) gids2[i] = gids[i] < 0 ? -1 : (gids[i] + 1) % G[0];
+        if (p_sbe_host_touched_groups(gids, gids2, n, G[0], touched, &n_touched) != 0) return 15;
+        printf("host_gids");
+        for (int i = 0; i < n; ++i) printf(" %d", gids[i]);
+        printf("\nhost_sids");
+        for (int i = 0; i < n; ++i) printf(" %d", (int)sids[(size_t)i * F]);
+        printf("\nhost_touched %d\n", n_touched);
+        free(sids);
+    }
+    free(clusters);
     p_sbe_destroy(e);
     fclose(f);
     return 0;

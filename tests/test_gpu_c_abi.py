@@ -40,3 +40,12 @@ def test_plain_c_caller(tmp_path):
     assert abs(float(vals["collapsed_ll"]) - fx.meta["collapsed_ll"]) <= 1e-6 * abs(fx.meta["collapsed_ll"])
     assert int(vals["n_na"]) == int(fx.na_values.sum())
     assert "slot 7 out of range" in vals["error_text"]
+    # round 4: overlap is refused by name through the plain-C boundary; the host helpers answer like NumPy
+    assert int(vals["overlap_rc"]) == 4 and re.search(r"object \d+ is in groups 0 and 1 of component 0", vals["overlap_text"])
+    cl = fx.groups[0][:, :5]
+    want_gids = np.where(cl.any(axis=0), cl.argmax(axis=0), -1)
+    assert [int(v) for v in vals["host_gids"].split()] == want_gids.tolist()
+    src0 = fx.source[:5, 0, :]
+    assert [int(v) for v in vals["host_sids"].split()] == np.where(src0.any(-1), src0.argmax(-1), 255).tolist()
+    moved = np.where(want_gids < 0, -1, (want_gids + 1) % fx.groups[0].shape[0])
+    assert int(vals["host_touched"]) == len(set(want_gids[want_gids >= 0]) | set(moved[moved >= 0]))
