@@ -175,10 +175,19 @@ def test_operator_forms_are_tied_to_the_reference_bodies_they_mirror(monkeypatch
         warnings.simplefilter("error", RuntimeWarning)
         patch.install(operators=True)
         patch.uninstall()
+        patch.install(gibbs_source=True)                   # (+ GibbsSampleSource._propose, ClusterOperator.gibbs_sample_source)
+        assert patch.installed() == {"operators": True, "gibbs_source": True}
+        import sbayes.sampling.operators as ref_ops
+        assert ref_ops.ClusterOperator.gibbs_sample_source.__module__ == "sbayes_amd.patch"
+        patch.uninstall()
+        assert ref_ops.ClusterOperator.gibbs_sample_source.__module__ == "sbayes.sampling.operators" and patch.installed() is None
     monkeypatch.setitem(patch.MIRRORED_SOURCES, "ClusterJump.get_jump_lh", "0" * 40)
+    monkeypatch.setitem(patch.MIRRORED_SOURCES, "ClusterOperator.gibbs_sample_source", "1" * 40)
     try:
-        with pytest.warns(RuntimeWarning, match="ClusterJump.get_jump_lh differs"):
-            patch.install(operators=True)
+        with pytest.warns(RuntimeWarning) as caught:
+            patch.install(gibbs_source=True)
+        texts = " | ".join(str(w.message) for w in caught)
+        assert "ClusterJump.get_jump_lh differs" in texts and "ClusterOperator.gibbs_sample_source differs" in texts
     finally:
         patch.uninstall()
 
