@@ -62,6 +62,17 @@ def forms_case(rng, eng, feats, n_groups, conc, state, tag, stats):
     with np.errstate(divide="ignore", invalid="ignore"):
         want = fake.given_unchanged_lh(0, i_cl, objs)
     assert np.array_equal(eng.given_unchanged_lh(0, i_cl, objs), want), (tag, "given_unchanged_lh")
+    # the literal a3 / a1 surfaces (streamed by the kernel from 512 KB on, chunk after chunk): bit for bit, strided view, partial update
+    lh_want = orc.likelihood_per_component(feats, ~feats.any(-1), groups, counts, conc)
+    assert np.array_equal(eng.likelihood_per_component(0), lh_want), (tag, "likelihood_per_component")
+    probs0 = eng.get_probs(0, 0)
+    changed = np.flatnonzero(rng.random(K) < 0.6).astype(np.int64)
+    view = np.full((N, F, 3), -5.0)
+    want_v = view.copy()
+    eng.component_lh(probs0, groups[0], changed, view[..., 1])
+    orc.compute_component_likelihood(feats, probs0, groups[0], changed, want_v[..., 1])
+    assert np.array_equal(view, want_v), (tag, "component_lh")
+    stats["surfaces"] = stats.get("surfaces", 0) + 1
     # ClusterOperator.gibbs_sample_source in one call (round 4): drawn components, p[drawn], p_back[old source] -- bit for bit at T = 1
     hc_new = np.stack([g[:, objs].any(axis=0) for g in groups], axis=1)
     hc_old = hc_new.copy()
