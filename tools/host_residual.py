@@ -19,6 +19,7 @@ Method, per shape (cfg1 50x30x5, south_america 100x36x5, headline 1000x200x10):
   Every step's time is the fastest of its occurrences over 5 replays (2-3 for `plain`): same deterministic run each time.
 
   python tools/host_residual.py [--steps-small 400] [--steps-headline 120]
+  python tools/host_residual.py --by-function south_america [--gibbs-source]     # the host layer's share, function by function
 """
 from __future__ import annotations
 
@@ -330,12 +331,39 @@ def measure(tag, config_path, n_steps, seed, gibbs_source=False):
     }
 
 
+def by_function(tag, n_steps, gibbs_source=False):
+    """Where this package's host layer spends its share of a step: wall time inside every swapped-in function
+    (outermost entries), per call and per step -- the breakdown the round-4 host-layer work was steered by."""
+    mg.WORK.mkdir(parents=True, exist_ok=True)
+    if tag == "south_america":
+        path, seed = mg.stage_config(Path("/root/reference/experiments/south_america"), "south_america_residual") / "config.yaml", 22
+    else:
+        path, seed = mg.write_synthetic_config(tag), (23 if tag == "cfg1" else 24)
+    _s, _i, _o, eng1, _l = _run(path, tag, n_steps, seed, "memo", gibbs_source=gibbs_source)
+    best = None
+    for _ in range(3):
+        s, inside, _o, _e, _l, layer = _run(path, tag, n_steps, seed, "replay", memo=eng1.memo, layer_clock=True, gibbs_source=gibbs_source)
+        ours = (np.asarray(layer) - np.asarray(inside)).mean() * 1e6
+        if best is None or ours < best[0]:
+            best = (ours, (np.asarray(s) - np.asarray(inside)).mean() * 1e6, dict(_run.last_clock.by_name))
+    print(f"{tag}{' (gibbs_source)' if gibbs_source else ''}: host layer {best[0]:.1f} us/step of {best[1]:.1f} us/step host Python; "
+          f"engine calls/step {len(eng1.memo) / n_steps:.1f}")
+    for name, (calls, t) in sorted(best[2].items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"   {name:42s} {calls / n_steps:5.2f} calls/step  {t / calls * 1e6:7.1f} us/call  {t / n_steps * 1e6:7.1f} us/step")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps-small", type=int, default=400)
     ap.add_argument("--steps-headline", type=int, default=120)
     ap.add_argument("--out", default=str(REPO / "tests" / "golden" / "host_residual.json"))
+    ap.add_argument("--by-function", metavar="SHAPE", help="print the host layer's per-function breakdown for cfg1 / south_america / "
+                    "headline instead of writing the JSON")
+    ap.add_argument("--gibbs-source", action="store_true", help="with --by-function: under patch.install(gibbs_source=True)")
     args = ap.parse_args()
+    if args.by_function:
+        by_function(args.by_function, args.steps_headline if args.by_function == "headline" else args.steps_small, args.gibbs_source)
+        return
     mg.WORK.mkdir(parents=True, exist_ok=True)
     out = {"what": "Python microseconds per MCMC step of the unchanged reference sampler under patch.install(operators=True) "
                    "when every engine call returns a recorded result in O(1) (tools/host_residual.py): the host residual "
