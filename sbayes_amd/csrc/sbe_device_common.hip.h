@@ -10,6 +10,7 @@ namespace sbe {
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 constexpr int kMaxComponents = 8;
+constexpr int kInlineTableStates = 128;   // fused table entries (probs_entry): NumPy's sum of up to 128 terms is one unrolled leaf
 constexpr int kMaxTuples = 64;
 constexpr uint16_t kNoGroup = 0xFFFF;
 constexpr uint8_t kNA = 0xFF;

@@ -50,6 +50,12 @@ struct Slot {
 
 }  // namespace
 
+// SBE_OPT_FUSE_TABLES' default for new engines (environment SBE_FUSE_TABLES=0: table kernels in front, for A/B runs)
+static int fuse_tables_default() {
+    static const int on = [] { const char* v = getenv("SBE_FUSE_TABLES"); return (v && atoi(v) == 0) ? 0 : 1; }();
+    return on;
+}
+
 struct sbe_engine {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -73,6 +79,7 @@ struct sbe_engine {
     // options
     int opt_kernel = SBE_MIXTURE_PACKED;
     int opt_log = SBE_LOG_PRODUCT;
+    int opt_fuse_tables = fuse_tables_default();   // SBE_OPT_FUSE_TABLES
 
     // resident data
     uint8_t* d_onehot = nullptr;   // [N][rs_pitch]
@@ -1452,6 +1459,7 @@ int sbe_set_option(sbe_engine* e, int option, int value) {
     if (option == SBE_OPT_LOG_MODE && (value == SBE_LOG_PER_OBS || value == SBE_LOG_PRODUCT)) { e->opt_log = value; return SBE_OK; }
     if (option == SBE_OPT_STEP_FORM && (value == 0 || value == 1)) { e->opt_step_form = value; return SBE_OK; }
     if (option == SBE_OPT_STEP_DERIVE && (value == 0 || value == 1)) { e->opt_step_derive = value; return SBE_OK; }
+    if (option == SBE_OPT_FUSE_TABLES && (value == 0 || value == 1)) { e->opt_fuse_tables = value; return SBE_OK; }
     if (option == SBE_OPT_DEFERRED_CHECKS && (value == 0 || value == 1)) {
         if (!value && e->status_pending) { HIPCHK(e, hipStreamSynchronize(e->stream)); int rc = synced(e); e->opt_deferred = 0; return rc; }
         e->opt_deferred = value;
@@ -2263,7 +2271,7 @@ int sbe_cluster_marginals(sbe_engine* e, int slot, const float* table, const int
     const int32_t* d_obj = (const int32_t*)(e->d_io + tb);
     double* d_out = (double*)(e->d_io + tb + ob);
     const double inv = 1.0 / prior_temperature;
-    k_cluster_marginals<<<n_objects_av, kBlock, 0, e->stream>>>(
+    k_cluster_marginals<false><<<n_objects_av, kBlock, 0, e->stream>>>(
         e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np,
         e->d_probs + (int64_t)slot * e->table_elems(), d_tab, e->d_weights + (int64_t)slot * F * C,
         e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0, d_obj, n_objects_av, d_out,
@@ -2305,7 +2313,7 @@ int sbe_jump_lh(sbe_engine* e, int slot, const float* pconf, const float* p_sour
     memcpy(e->h_io + cb + tb, p_target, fs);
     memcpy(e->h_io + cb + 2 * tb, objects, (size_t)n_members * sizeof(int32_t));
     const double inv = 1.0 / prior_temperature;
-    k_jump_lh<<<n_members, kBlock, 0, e->stream>>>(
+    k_jump_lh<false><<<n_members, kBlock, 0, e->stream>>>(
         e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np,
         (const float*)e->d_io, (const float*)(e->d_io + cb), (const float*)(e->d_io + cb + tb),
         e->d_weights + (int64_t)slot * F * C, e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0,
@@ -2646,6 +2654,26 @@ int sbe_set_counts_rows(sbe_engine* e, int slot, const int32_t* group_idx, int n
     return SBE_OK;
 }
 
+// k_given_unchanged_fused: LDS image of a 16-feature tile and the arguments both forms share
+constexpr size_t kGuFusedLdsMax = (size_t)96 << 10;
+static size_t gu_fused_lds_bytes(int R, int S, int C, int n_sub, int N) {
+    return ((size_t)R * 16 * S + (size_t)n_sub * (1 + C) + (size_t)(N + 31) / 32) * sizeof(int32_t);
+}
+static GuFusedArgs gu_fused_args(sbe_engine* e, int slot, int i_cluster, int n_sub, int R, double temperature, double prior_temperature,
+                                 const int32_t* table_offsets_host, const int32_t* d_objects, const int32_t* d_group_idx) {
+    GuFusedArgs fa{};
+    const int C = e->C;
+    fa.state = e->d_state; fa.gid = e->d_gid + (int64_t)slot * C * e->Np; fa.src = e->d_src + (int64_t)slot * e->N * e->Fp;
+    fa.counts = e->d_counts + (int64_t)slot * e->table_elems();
+    fa.objects = d_objects; fa.group_idx = d_group_idx;
+    for (int c = 0; c < C; ++c) fa.table_offsets[c] = table_offsets_host[c];
+    fa.conc = e->d_conc; fa.unif = e->d_unif_res; fa.temperature = temperature; fa.prior_temperature = prior_temperature;
+    fa.status = e->d_status;
+    fa.n_sub = n_sub; fa.i_cluster = i_cluster; fa.K = e->G[0]; fa.N = e->N; fa.Np = e->Np; fa.F = e->F; fa.S = e->S; fa.C = C;
+    fa.Fp = e->Fp; fa.R = R;
+    return fa;
+}
+
 int sbe_given_unchanged_lh(sbe_engine* e, int slot, int i_cluster, const int32_t* objects, int n_sub, double temperature,
                            double prior_temperature, float* out) {
     CHECK_ENGINE(e); CHECK_SLOT(e, slot);
@@ -2692,6 +2720,23 @@ int sbe_given_unchanged_lh(sbe_engine* e, int slot, int i_cluster, const int32_t
     float* d_out = mapped_out ? (float*)(e->d_io + ob + mb + gb + fb) : (float*)(e->d_scratch + cb);
     rc = clear_status_word(e, ST_BAD_NORMALIZE);
     if (rc) return rc;
+    // one launch (k_given_unchanged_fused: tables built per 16-feature tile in LDS and consumed there) when the tile's
+    // image fits; otherwise -- or with SBE_OPT_FUSE_TABLES off -- the table kernel and the gather, two launches
+    const size_t fused_lds = gu_fused_lds_bytes(R, S, C, n_sub, N);
+    if (e->opt_fuse_tables && mapped_out && fused_lds <= kGuFusedLdsMax) {
+        GuFusedArgs fa = gu_fused_args(e, slot, i_cluster, n_sub, R, temperature, prior_temperature, off,
+                                       (const int32_t*)e->d_io, (const int32_t*)(e->d_io + ob + mb));
+        const double inv_t = 1.0 / temperature;
+        fa.out = d_out; fa.inv_t = (float)inv_t; fa.use_pow = inv_t != 1.0;
+        const unsigned blocks = (unsigned)div_up(F, 16);
+        const DoneSig done = next_done(e, blocks);
+        k_given_unchanged_fused<false><<<blocks, kUnchangedBlock, fused_lds, e->stream>>>(fa, GuGibbsArgs{}, nullptr, nullptr, nullptr, done);
+        HIPCHK(e, hipGetLastError());
+        rc = sync_and_report(e, done);
+        if (rc) return rc;
+        memcpy(out, h + ob + mb + gb + fb, out_bytes);
+        return SBE_OK;
+    }
     // kept counts and their conditional_effect_mean (conditionals.py:105-122) in one launch: the cluster's row with the
     // cluster prior, the confounder rows with theirs
     const bool list_in_lds = (size_t)n_sub * sizeof(int32_t) <= ((size_t)32 << 10);
@@ -2783,6 +2828,32 @@ int sbe_given_unchanged_gibbs(sbe_engine* e, int slot, int i_cluster, const int3
     if (rc) return rc;
     rc = clear_status_word(e, ST_BAD_NORMALIZE);
     if (rc) return rc;
+    GuGibbsArgs a{};
+    a.state = e->d_state; a.tables = d_tab; a.table_offsets = (const int32_t*)(e->d_io + ob + gb);
+    a.group_idx = (const int32_t*)(e->d_io + ob); a.objects = (const int32_t*)e->d_io;
+    a.weights = e->d_weights + (int64_t)slot * F * C;
+    a.hc_new = e->d_io + ob + gb + fb; a.hc_old = e->d_io + ob + gb + fb + hb;
+    a.src_old = (const uint8_t*)v_so; a.z = (const double*)v_z;
+    a.n_sub = n_sub; a.F = F; a.S = S; a.C = C; a.Fp = e->Fp;
+    const double inv_t = 1.0 / temperature, inv_tp = 1.0 / prior_temperature;
+    a.inv_t = (float)inv_t; a.inv_tp = (float)inv_tp; a.pow_lh = inv_t != 1.0; a.pow_w = inv_tp != 1.0; a.from_prior = from_prior ? 1 : 0;
+    uint8_t* d_ids = e->d_io + in_bytes;
+    const size_t fused_lds = gu_fused_lds_bytes(R, S, C, n_sub, N);
+    if (e->opt_fuse_tables && fused_lds <= kGuFusedLdsMax) {        // one launch (see sbe_given_unchanged_lh)
+        const GuFusedArgs fa = gu_fused_args(e, slot, i_cluster, n_sub, R, temperature, prior_temperature, off,
+                                             (const int32_t*)e->d_io, (const int32_t*)(e->d_io + ob));
+        const unsigned blocks = (unsigned)div_up(F, 16);
+        const DoneSig done = next_done(e, blocks);
+        k_given_unchanged_fused<true><<<blocks, kUnchangedBlock, fused_lds, e->stream>>>(
+            fa, a, d_ids, (float*)(d_ids + idb), (float*)(d_ids + idb + selb), done);
+        HIPCHK(e, hipGetLastError());
+        rc = sync_and_report(e, done);
+        if (rc) return rc;
+        memcpy(src_new_out, h + in_bytes, nf);
+        memcpy(sel_new_out, h + in_bytes + idb, nf * sizeof(float));
+        memcpy(sel_back_out, h + in_bytes + idb + selb, nf * sizeof(float));
+        return SBE_OK;
+    }
     const bool list_in_lds = (size_t)n_sub * sizeof(int32_t) <= ((size_t)32 << 10);
     if (((size_t)16 * S + (N + 31) / 32) * sizeof(int32_t) > ((size_t)96 << 10))
         return fail(e, SBE_ERR_ARG, "gibbs_sample_source: %d objects x %d states exceed the kernel's LDS image", N, S);
@@ -2793,18 +2864,8 @@ int sbe_given_unchanged_gibbs(sbe_engine* e, int slot, int i_cluster, const int3
         i_cluster, K, N, e->Np, F, S, e->Fp, e->d_conc, e->d_unif_res, temperature, prior_temperature, e->d_status, d_tab,
         list_in_lds ? 1 : 0);
     HIPCHK(e, hipGetLastError());
-    GuGibbsArgs a{};
-    a.state = e->d_state; a.tables = d_tab; a.table_offsets = (const int32_t*)(e->d_io + ob + gb);
-    a.group_idx = (const int32_t*)(e->d_io + ob); a.objects = (const int32_t*)e->d_io;
-    a.weights = e->d_weights + (int64_t)slot * F * C;
-    a.hc_new = e->d_io + ob + gb + fb; a.hc_old = e->d_io + ob + gb + fb + hb;
-    a.src_old = (const uint8_t*)v_so; a.z = (const double*)v_z;
-    a.n_sub = n_sub; a.F = F; a.S = S; a.C = C; a.Fp = e->Fp;
-    const double inv_t = 1.0 / temperature, inv_tp = 1.0 / prior_temperature;
-    a.inv_t = (float)inv_t; a.inv_tp = (float)inv_tp; a.pow_lh = inv_t != 1.0; a.pow_w = inv_tp != 1.0; a.from_prior = from_prior ? 1 : 0;
     const unsigned blocks = (unsigned)div_up((int64_t)nf, 256);
     const DoneSig done = next_done(e, blocks);
-    uint8_t* d_ids = e->d_io + in_bytes;
     k_given_unchanged_gibbs<<<blocks, kBlock, 0, e->stream>>>(a, d_ids, (float*)(d_ids + idb), (float*)(d_ids + idb + selb), e->d_status, done);
     HIPCHK(e, hipGetLastError());
     rc = sync_and_report(e, done);
@@ -2834,9 +2895,13 @@ int sbe_cluster_posterior_marginals(sbe_engine* e, int slot, int i_cluster, doub
     HIPCHK(e, hipSetDevice(e->device));
     if (s.patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
     const int64_t fs = (int64_t)F * S;
-    rc = ensure_scratch(e, (size_t)fs * sizeof(float));
-    if (rc) return rc;
-    float* d_tab = (float*)e->d_scratch;
+    const bool fused = S <= kInlineTableStates && e->opt_fuse_tables;   // (beyond: NumPy's sum recursion keeps frames in scratch memory)
+    float* d_tab = nullptr;
+    if (!fused) {
+        rc = ensure_scratch(e, (size_t)fs * sizeof(float));
+        if (rc) return rc;
+        d_tab = (float*)e->d_scratch;
+    }
     const size_t ob = al256((size_t)n_objects_av * sizeof(int32_t));
     const size_t out_bytes = (size_t)2 * n_objects_av * sizeof(double);
     rc = ensure_io(e, ob + out_bytes);
@@ -2845,18 +2910,29 @@ int sbe_cluster_posterior_marginals(sbe_engine* e, int slot, int i_cluster, doub
     rc = clear_status_word(e, ST_BAD_NORMALIZE);
     if (rc) return rc;
     // the candidate table: conditional_effect_mean(prior, counts[[i_cluster]], unif, T_prior, T) (operators.py:1046-1052)
-    // from the slot's resident counts -- nothing table-sized crosses PCIe
-    k_probs<int32_t><<<div_up((int64_t)F, 256), 256, 0, e->stream>>>(
-        e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc, e->d_unif_res, d_tab, i_cluster, i_cluster + 1, F, S,
-        temperature, prior_temperature, 1, e->d_status, -(int64_t)i_cluster * fs);
-    HIPCHK(e, hipGetLastError());
+    // from the slot's resident counts -- nothing table-sized crosses PCIe.  Fused form: every thread of the marginals
+    // kernel builds the one entry it reads (probs_entry: same operations, same bits); otherwise a table kernel in front.
+    const int32_t* cnt = e->d_counts + (int64_t)slot * e->table_elems();
+    InlineTables tin{};
+    if (fused) {
+        tin.row[0] = RowSource{cnt + (int64_t)i_cluster * fs, e->d_conc + (int64_t)i_cluster * fs};
+        tin.unif = e->d_unif_res; tin.temperature = temperature; tin.prior_temperature = prior_temperature; tin.status = e->d_status;
+    } else {
+        k_probs<int32_t><<<div_up((int64_t)F, 256), 256, 0, e->stream>>>(
+            cnt, e->d_conc, e->d_unif_res, d_tab, i_cluster, i_cluster + 1, F, S,
+            temperature, prior_temperature, 1, e->d_status, -(int64_t)i_cluster * fs);
+        HIPCHK(e, hipGetLastError());
+    }
     const double inv = 1.0 / prior_temperature;
     const DoneSig done = next_done(e, (unsigned)n_objects_av);
-    k_cluster_marginals<<<n_objects_av, kBlock, 0, e->stream>>>(
-        e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np,
-        e->d_probs + (int64_t)slot * e->table_elems(), d_tab, e->d_weights + (int64_t)slot * F * C,
-        e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0, (const int32_t*)e->d_io, n_objects_av,
-        (double*)(e->d_io + ob), reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C, e->Fp, done);
+    auto launch = [&](auto kernel) {
+        kernel<<<n_objects_av, kBlock, 0, e->stream>>>(
+            e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np,
+            e->d_probs + (int64_t)slot * e->table_elems(), d_tab, e->d_weights + (int64_t)slot * F * C,
+            e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0, (const int32_t*)e->d_io, n_objects_av,
+            (double*)(e->d_io + ob), reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C, e->Fp, done, tin);
+    };
+    if (fused) launch(k_cluster_marginals<true>); else launch(k_cluster_marginals<false>);
     HIPCHK(e, hipGetLastError());
     rc = sync_and_report(e, done);
     if (rc) return rc;
@@ -2884,11 +2960,15 @@ int sbe_jump_lh_resident(sbe_engine* e, int slot, int i_source, int i_target, do
     if (s.patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
     const int64_t fs = (int64_t)F * S;
     const int n_conf = e->Gtot - K;
-    rc = ensure_scratch(e, (size_t)(2 + std::max(n_conf, 1)) * fs * sizeof(float));
-    if (rc) return rc;
-    float* d_ps = (float*)e->d_scratch;
-    float* d_pt = d_ps + fs;
-    float* d_pc = d_pt + fs;
+    const bool fused = S <= kInlineTableStates && e->opt_fuse_tables;
+    float *d_ps = nullptr, *d_pt = nullptr, *d_pc = nullptr;
+    if (!fused) {
+        rc = ensure_scratch(e, (size_t)(2 + std::max(n_conf, 1)) * fs * sizeof(float));
+        if (rc) return rc;
+        d_ps = (float*)e->d_scratch;
+        d_pt = d_ps + fs;
+        d_pc = d_pt + fs;
+    }
     const size_t ob = al256((size_t)n_members * sizeof(int32_t));
     const size_t out_bytes = (size_t)2 * n_members * sizeof(double);
     rc = ensure_io(e, ob + out_bytes);
@@ -2898,26 +2978,38 @@ int sbe_jump_lh_resident(sbe_engine* e, int slot, int i_source, int i_target, do
     if (rc) return rc;
     // tempered tables of the two clusters and of every confounder group (ClusterEffectProposals.posterior_counts +
     // normalize, operators.py:1254-1259, 1364-1371) from the slot's resident counts; the reference uses the CLUSTER
-    // prior's uniform concentration for every component (operators.py:1352)
+    // prior's uniform concentration for every component (operators.py:1352).  Fused form: the entries are built where they
+    // are read (probs_entry), one launch; otherwise three table kernels in front.
     const int32_t* cnt = e->d_counts + (int64_t)slot * e->table_elems();
-    k_probs<int32_t><<<div_up((int64_t)F, 256), 256, 0, e->stream>>>(cnt, e->d_conc, e->d_unif_res, d_ps, i_source, i_source + 1, F, S,
-        temperature, prior_temperature, 1, e->d_status, -(int64_t)i_source * fs);
-    HIPCHK(e, hipGetLastError());
-    k_probs<int32_t><<<div_up((int64_t)F, 256), 256, 0, e->stream>>>(cnt, e->d_conc, e->d_unif_res, d_pt, i_target, i_target + 1, F, S,
-        temperature, prior_temperature, 1, e->d_status, -(int64_t)i_target * fs);
-    HIPCHK(e, hipGetLastError());
-    if (n_conf > 0) {
-        k_probs<int32_t><<<div_up((int64_t)n_conf * F, 256), 256, 0, e->stream>>>(cnt, e->d_conc, e->d_unif_res, d_pc, K, e->Gtot, F, S,
-            temperature, prior_temperature, 1, e->d_status, -(int64_t)K * fs);
+    InlineTables tin{};
+    if (fused) {
+        tin.row[0] = RowSource{cnt + (int64_t)i_source * fs, e->d_conc + (int64_t)i_source * fs};
+        tin.row[1] = RowSource{cnt + (int64_t)i_target * fs, e->d_conc + (int64_t)i_target * fs};
+        tin.counts = cnt; tin.conc = e->d_conc; tin.unif = e->d_unif_res;
+        tin.temperature = temperature; tin.prior_temperature = prior_temperature; tin.status = e->d_status; tin.n_groups_total = e->Gtot;
+    } else {
+        k_probs<int32_t><<<div_up((int64_t)F, 256), 256, 0, e->stream>>>(cnt, e->d_conc, e->d_unif_res, d_ps, i_source, i_source + 1, F, S,
+            temperature, prior_temperature, 1, e->d_status, -(int64_t)i_source * fs);
         HIPCHK(e, hipGetLastError());
+        k_probs<int32_t><<<div_up((int64_t)F, 256), 256, 0, e->stream>>>(cnt, e->d_conc, e->d_unif_res, d_pt, i_target, i_target + 1, F, S,
+            temperature, prior_temperature, 1, e->d_status, -(int64_t)i_target * fs);
+        HIPCHK(e, hipGetLastError());
+        if (n_conf > 0) {
+            k_probs<int32_t><<<div_up((int64_t)n_conf * F, 256), 256, 0, e->stream>>>(cnt, e->d_conc, e->d_unif_res, d_pc, K, e->Gtot, F, S,
+                temperature, prior_temperature, 1, e->d_status, -(int64_t)K * fs);
+            HIPCHK(e, hipGetLastError());
+        }
     }
     const double inv = 1.0 / prior_temperature;
     const DoneSig done = next_done(e, (unsigned)n_members);
-    k_jump_lh<<<n_members, kBlock, 0, e->stream>>>(
-        e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np, d_pc, d_ps, d_pt,
-        e->d_weights + (int64_t)slot * F * C, e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0,
-        (const int32_t*)e->d_io, n_members, (double*)(e->d_io + ob), reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C,
-        e->Fp, K, done);
+    auto launch = [&](auto kernel) {
+        kernel<<<n_members, kBlock, 0, e->stream>>>(
+            e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np, d_pc, d_ps, d_pt,
+            e->d_weights + (int64_t)slot * F * C, e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0,
+            (const int32_t*)e->d_io, n_members, (double*)(e->d_io + ob), reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C,
+            e->Fp, K, done, tin);
+    };
+    if (fused) launch(k_jump_lh<true>); else launch(k_jump_lh<false>);
     HIPCHK(e, hipGetLastError());
     rc = sync_and_report(e, done);
     if (rc) return rc;

@@ -296,6 +296,39 @@ __device__ __forceinline__ void probs_row(GetCount cnt, const double* __restrict
     for (int s = 0; s < S; ++s) emit(s, (float)(post(s) / total));
 }
 
+// The inputs of one tempered table row, resident in device memory: what a consumer kernel needs to build the ONE entry
+// it reads itself instead of waiting for a k_probs launch in front of it (one launch per drop-in call: VERDICT r3 item 4).
+struct RowSource {
+    const int32_t* counts;           // [F][S] integer counts of the row's group (the slot's resident table row)
+    const double* conc;              // [F][S] concentration of that group
+};
+
+// probs_row's value for state x alone, same operations in the same order (the S-term NumPy sum, then ONE division):
+// bit for bit the entry k_probs would have stored.  The row's sum is taken -- and checked -- whatever x is, like the
+// table kernel does for every row; x == kNA returns 1 (the caller's value for an unobserved feature).  `check`: this
+// thread is the one that reports the row (every block sees the same rows: one of them counts, so that the number of bad
+// rows in the error message is the table kernel's).
+__device__ __forceinline__ float probs_entry(const int32_t* __restrict__ cnt_row, const double* __restrict__ conc_row,
+                                             const double* __restrict__ unif_row, int S, double temperature,
+                                             double prior_temperature, int* __restrict__ status, uint8_t x, bool check) {
+    const bool tempered = temperature > 0.0;
+    const bool prior_tempered = prior_temperature > 0.0 && unif_row != nullptr;
+    const float t32 = (float)temperature;
+    auto post = [&](int s) -> double {
+        float c = (float)cnt_row[s];
+        if (tempered) c = c / t32;
+        double a = conc_row[s];
+        if (prior_tempered) {
+            const double u = unif_row[s];
+            a = u + (a - u) / prior_temperature;
+        }
+        return (double)c + a;
+    };
+    const double total = np_pairwise_sum<double>(post, S);
+    if (check && !(total > 0.0)) raise_status(status, ST_BAD_NORMALIZE, 1);
+    return x == kNA ? 1.0f : (float)(post(x) / total);
+}
+
 template <class TC>
 __global__ void k_probs(const TC* __restrict__ counts, const double* __restrict__ conc,
                         const double* __restrict__ unif /* [F][S] or null */, float* __restrict__ probs,
@@ -766,12 +799,25 @@ __device__ __forceinline__ void weight_tables_z_row(const float* __restrict__ w,
 // component) are all in flight together and there is one dependent-load chain per object instead of one per
 // 64 features; the two fp64 logs per observation are table-driven (tab_log_pos; the sums of logs carry far more
 // accuracy than the reference's linear-space products).  Fixed-order block reduction: deterministic.
+// kInline: the candidate table is not read from `table0` but built entry by entry from the cluster's resident counts
+// (`tin`: conditional_effect_mean, probs_entry) -- the call needs no table kernel in front (sbe_cluster_posterior_marginals).
+struct InlineTables {
+    RowSource row[2];                // candidate cluster (k_cluster_marginals) / source and target cluster (k_jump_lh)
+    const int32_t* counts;           // the slot's whole [Gtot][F][S] count table (k_jump_lh: confounder rows)
+    const double* conc;              // [Gtot][F][S]
+    const double* unif;              // [F][S] the cluster prior's uniform concentration
+    double temperature, prior_temperature;
+    int* status;
+    int n_groups_total;
+};
+
+template <bool kInline>
 __global__ __launch_bounds__(kBlock) void k_cluster_marginals(
     const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid, const uint8_t* __restrict__ pid,
     const float* __restrict__ probs, const float* __restrict__ table0, const float* __restrict__ weights,
     const uint32_t* __restrict__ pattern_bits, float inv_tp, int use_pow, const int32_t* __restrict__ objects,
     int n_av, double* __restrict__ out, const f64x2_t* __restrict__ logtab, int Np, int F, int S, int C, int Fp,
-    DoneSig done = DoneSig{}) {
+    DoneSig done = DoneSig{}, InlineTables tin = InlineTables{}) {
     __shared__ f64x2_t tab[kLogTabEntries];
     __shared__ double red[8];
     if (threadIdx.x < kLogTabEntries) tab[threadIdx.x] = logtab[threadIdx.x];
@@ -786,11 +832,16 @@ __global__ __launch_bounds__(kBlock) void k_cluster_marginals(
         const uint8_t x = state[(int64_t)n * Fp + f];
         float wc[kMaxComponents], wf[kMaxComponents];
         weight_tables_z_row(weights + (int64_t)f * C, bits, C, inv_tp, use_pow, wc, wf);   // this object's pattern
+        float t0 = 1.0f;
+        if constexpr (kInline)
+            t0 = probs_entry(tin.row[0].counts + (int64_t)f * S, tin.row[0].conc + (int64_t)f * S, tin.unif + (int64_t)f * S, S,
+                             tin.temperature, tin.prior_temperature, tin.status, x, blockIdx.x == 0);
+        else if (x != kNA) t0 = table0[(int64_t)f * S + x];
         double v0 = 0.0, v1 = 0.0;
         for (int c = 0; c < C; ++c) {
             double lh = 1.0;
             if (x != kNA) {
-                if (c == 0) lh = (double)table0[(int64_t)f * S + x];
+                if (c == 0) lh = (double)t0;
                 else {
                     const uint16_t gg = gid[(int64_t)c * Np + n];
                     lh = gg == kNoGroup ? 0.0 : (double)probs[((int64_t)gg * F + f) * S + x];
@@ -829,13 +880,16 @@ __global__ __launch_bounds__(kBlock) void k_cluster_marginals(
 // `p_target` the two clusters' tempered tables (conditional_effect_mean, conditionals.py:105-122).
 // One block per member, thread <-> feature, fixed-order reduction (as k_cluster_marginals).
 // ------------------------------------------------------------------------------------------
+// kInline: the tempered tables are built entry by entry from the slot's resident counts (`tin`; sbe_jump_lh_resident:
+// one launch instead of three table kernels + this one); the rows are checked like k_probs checks them, NA or not.
+template <bool kInline>
 __global__ __launch_bounds__(kBlock) void k_jump_lh(
     const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid, const uint8_t* __restrict__ pid,
     const float* __restrict__ pconf /* [Gtot - G0][F][S] */, const float* __restrict__ p_source,
     const float* __restrict__ p_target, const float* __restrict__ weights, const uint32_t* __restrict__ pattern_bits,
     float inv_tp, int use_pow, const int32_t* __restrict__ objects, int n_members, double* __restrict__ out,
     const f64x2_t* __restrict__ logtab, int Np, int F, int S, int C, int Fp, int G0,
-    DoneSig done = DoneSig{}) {
+    DoneSig done = DoneSig{}, InlineTables tin = InlineTables{}) {
     __shared__ f64x2_t tab[kLogTabEntries];
     __shared__ double red[8];
     if (threadIdx.x < kLogTabEntries) tab[threadIdx.x] = logtab[threadIdx.x];
@@ -847,16 +901,40 @@ __global__ __launch_bounds__(kBlock) void k_jump_lh(
     double acc0 = 0.0, acc1 = 0.0;
     for (int f = threadIdx.x; f < F; f += kBlock) {
         const uint8_t x = state[(int64_t)n * Fp + f];
-        if (x == kNA) continue;                                       // np.prod(..., where=~NAs): factor 1
+        if constexpr (!kInline) { if (x == kNA) continue; }           // np.prod(..., where=~NAs): factor 1
         float wc[kMaxComponents], wf[kMaxComponents];
         weight_tables_z_row(weights + (int64_t)f * C, bits, C, inv_tp, use_pow, wc, wf);   // wc = weights_heated row
-        float pc = 0.0f;
-        for (int c = 1; c < C; ++c) {
-            const uint16_t gg = gid[(int64_t)c * Np + n];
-            if (gg != kNoGroup) pc = pc + wc[c] * pconf[((int64_t)(gg - G0) * F + f) * S + x];
+        float pc = 0.0f, e_src, e_tgt;
+        if constexpr (kInline) {
+            const int64_t fo = (int64_t)f * S;
+            for (int c = 1; c < C; ++c) {
+                const uint16_t gg = gid[(int64_t)c * Np + n];
+                if (gg == kNoGroup) continue;
+                const int64_t ro = ((int64_t)gg * F + f) * S;
+                const float e = probs_entry(tin.counts + ro, tin.conc + ro, tin.unif + fo, S, tin.temperature, tin.prior_temperature,
+                                            tin.status, x, false);
+                pc = pc + wc[c] * e;
+            }
+            e_src = probs_entry(tin.row[0].counts + fo, tin.row[0].conc + fo, tin.unif + fo, S, tin.temperature, tin.prior_temperature,
+                                tin.status, x, i == 0);
+            e_tgt = probs_entry(tin.row[1].counts + fo, tin.row[1].conc + fo, tin.unif + fo, S, tin.temperature, tin.prior_temperature,
+                                tin.status, x, i == 0);
+            // normalize's assert covers the rows of EVERY confounder group (util.py:1006), member or not: the blocks share them
+            for (int gg = G0 + i; gg < tin.n_groups_total; gg += n_members) {
+                const int64_t ro = ((int64_t)gg * F + f) * S;
+                (void)probs_entry(tin.counts + ro, tin.conc + ro, tin.unif + fo, S, tin.temperature, tin.prior_temperature, tin.status, kNA, true);
+            }
+            if (x == kNA) continue;
+        } else {
+            for (int c = 1; c < C; ++c) {
+                const uint16_t gg = gid[(int64_t)c * Np + n];
+                if (gg != kNoGroup) pc = pc + wc[c] * pconf[((int64_t)(gg - G0) * F + f) * S + x];
+            }
+            e_src = p_source[(int64_t)f * S + x];
+            e_tgt = p_target[(int64_t)f * S + x];
         }
-        const float ps = pc + wc[0] * p_source[(int64_t)f * S + x];
-        const float pt = pc + wc[0] * p_target[(int64_t)f * S + x];
+        const float ps = pc + wc[0] * e_src;
+        const float pt = pc + wc[0] * e_tgt;
         acc0 += tab_log_pos((double)ps, tab_addr);
         acc1 += tab_log_pos((double)pt, tab_addr);
     }
@@ -1126,6 +1204,64 @@ struct GuGibbsArgs {
     float inv_t, inv_tp; int pow_lh, pow_w, from_prior;
 };
 
+// One observation (subset row r, feature f; i = r * F + f) of the above.  `table_at(c, g)` = the kept-observations table
+// entry of component c, group g (>= 0) for this feature and the observed state x; `group_of(c)` = the object's group in
+// component c (-1: none).
+template <class GroupOf, class TableAt>
+__device__ __forceinline__ void gu_gibbs_obs(const GuGibbsArgs& a, int64_t i, int r, int f, uint8_t x, GroupOf group_of, TableAt table_at,
+                                             uint8_t* __restrict__ src_new, float* __restrict__ sel_new, float* __restrict__ sel_back,
+                                             int* __restrict__ status) {
+    const bool na = x == kNA;
+    float lh[kMaxComponents];
+    for (int c = 0; c < a.C; ++c) {
+        float v = 1.0f;
+        if (!na) {
+            const int g = group_of(c);
+            v = g < 0 ? 0.0f : table_at(c, g);
+        }
+        lh[c] = a.pow_lh ? powf(v, a.inv_t) : v;
+    }
+    const float* w = a.weights + (int64_t)f * a.C;
+    float p[2][kMaxComponents];
+    bool ok = true;
+    for (int side = 0; side < 2; ++side) {
+        const uint8_t* hc = (side == 0 ? a.hc_new : a.hc_old) + (int64_t)r * a.C;
+        auto masked = [&](int c) -> float { return hc[c] ? w[c] : 0.0f * w[c]; };
+        const float wtot = np_pairwise_sum<float>(masked, a.C);
+        float t[kMaxComponents];
+        for (int c = 0; c < a.C; ++c) {
+            float wc = masked(c) / wtot;                            // normalize_weights (likelihood.py:171-190)
+            if (a.pow_w) wc = powf(wc, a.inv_tp);
+            t[c] = a.from_prior ? wc : wc * lh[c];
+        }
+        if (a.from_prior) { for (int c = 0; c < a.C; ++c) p[side][c] = t[c]; continue; }
+        auto term = [&](int c) -> float { return t[c]; };
+        const float tot = np_pairwise_sum<float>(term, a.C);
+        ok = ok && tot > 0.0f;                                      // normalize's assert (util.py:1006)
+        for (int c = 0; c < a.C; ++c) p[side][c] = t[c] / tot;
+    }
+    if (!ok) raise_status(status, ST_BAD_NORMALIZE, 1);
+    // sample_categorical (preprocessing.py:224-256): float32 cumulative sums, divided by the last, first c with z < cdf[c]
+    float cdf[kMaxComponents];
+    float run = p[0][0];
+    cdf[0] = run;
+    for (int c = 1; c < a.C; ++c) { run = run + p[0][c]; cdf[c] = run; }
+    const float last = cdf[a.C - 1];
+    const double zz = a.z[i];
+    int k = 0;
+    for (int c = a.C - 1; c >= 0; --c)
+        if (zz < (double)(cdf[c] / last)) k = c;
+    src_new[i] = na ? (uint8_t)kNA : (uint8_t)k;
+    float sn = 1.0f, sb = 1.0f;
+    const int id_old = a.src_old[i];
+    for (int c = 0; c < a.C; ++c) {
+        sn = (!na && c == k) ? p[0][c] : sn;
+        sb = (c == id_old) ? p[1][c] : sb;
+    }
+    sel_new[i] = sn;
+    sel_back[i] = sb;
+}
+
 __global__ __launch_bounds__(kBlock) void k_given_unchanged_gibbs(GuGibbsArgs a, uint8_t* __restrict__ src_new,
                                                                  float* __restrict__ sel_new, float* __restrict__ sel_back,
                                                                  int* __restrict__ status, DoneSig done = DoneSig{}) {
@@ -1133,55 +1269,9 @@ __global__ __launch_bounds__(kBlock) void k_given_unchanged_gibbs(GuGibbsArgs a,
     if (i < (int64_t)a.n_sub * a.F) {
         const int r = (int)(i / a.F), f = (int)(i % a.F);
         const uint8_t x = a.state[(int64_t)a.objects[r] * a.Fp + f];
-        const bool na = x == kNA;
-        float lh[kMaxComponents];
-        for (int c = 0; c < a.C; ++c) {
-            float v = 1.0f;
-            if (!na) {
-                const int g = a.group_idx[(int64_t)c * a.n_sub + r];
-                v = g < 0 ? 0.0f : a.tables[((int64_t)(a.table_offsets[c] + g) * a.F + f) * a.S + x];
-            }
-            lh[c] = a.pow_lh ? powf(v, a.inv_t) : v;
-        }
-        const float* w = a.weights + (int64_t)f * a.C;
-        float p[2][kMaxComponents];
-        bool ok = true;
-        for (int side = 0; side < 2; ++side) {
-            const uint8_t* hc = (side == 0 ? a.hc_new : a.hc_old) + (int64_t)r * a.C;
-            auto masked = [&](int c) -> float { return hc[c] ? w[c] : 0.0f * w[c]; };
-            const float wtot = np_pairwise_sum<float>(masked, a.C);
-            float t[kMaxComponents];
-            for (int c = 0; c < a.C; ++c) {
-                float wc = masked(c) / wtot;                            // normalize_weights (likelihood.py:171-190)
-                if (a.pow_w) wc = powf(wc, a.inv_tp);
-                t[c] = a.from_prior ? wc : wc * lh[c];
-            }
-            if (a.from_prior) { for (int c = 0; c < a.C; ++c) p[side][c] = t[c]; continue; }
-            auto term = [&](int c) -> float { return t[c]; };
-            const float tot = np_pairwise_sum<float>(term, a.C);
-            ok = ok && tot > 0.0f;                                      // normalize's assert (util.py:1006)
-            for (int c = 0; c < a.C; ++c) p[side][c] = t[c] / tot;
-        }
-        if (!ok) raise_status(status, ST_BAD_NORMALIZE, 1);
-        // sample_categorical (preprocessing.py:224-256): float32 cumulative sums, divided by the last, first c with z < cdf[c]
-        float cdf[kMaxComponents];
-        float run = p[0][0];
-        cdf[0] = run;
-        for (int c = 1; c < a.C; ++c) { run = run + p[0][c]; cdf[c] = run; }
-        const float last = cdf[a.C - 1];
-        const double zz = a.z[i];
-        int k = 0;
-        for (int c = a.C - 1; c >= 0; --c)
-            if (zz < (double)(cdf[c] / last)) k = c;
-        src_new[i] = na ? (uint8_t)kNA : (uint8_t)k;
-        float sn = 1.0f, sb = 1.0f;
-        const int id_old = a.src_old[i];
-        for (int c = 0; c < a.C; ++c) {
-            sn = (!na && c == k) ? p[0][c] : sn;
-            sb = (c == id_old) ? p[1][c] : sb;
-        }
-        sel_new[i] = sn;
-        sel_back[i] = sb;
+        gu_gibbs_obs(a, i, r, f, x, [&](int c) { return a.group_idx[(int64_t)c * a.n_sub + r]; },
+                     [&](int c, int g) { return a.tables[((int64_t)(a.table_offsets[c] + g) * a.F + f) * a.S + x]; },
+                     src_new, sel_new, sel_back, status);
     }
     signal_done(done);
 }
@@ -1644,6 +1734,117 @@ __global__ __launch_bounds__(kUnchangedBlock) void k_unchanged_counts(
         probs_row([&](int s) { return (float)((r == 0 ? 0 : base[s]) + h[s]); }, conc + ((int64_t)gg * F + ff) * S,
                   unif + (int64_t)ff * S, S, temperature, prior_temperature, status, [&](int s, float v) { out_row[s] = v; });
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// component_likelihood_given_unchanged / ClusterOperator.gibbs_sample_source in ONE launch: a block owns
+// a 16-feature tile, builds the kept-observations tables of ALL R rows for its features in LDS -- k_unchanged_counts'
+// histograms (row 0 over the cluster's members outside the subset, the confounder rows in one pass over the subset) and
+// probs_row's normalisation, same operations in the same order -- and then serves the subset's observations of its features
+// out of LDS: k_subset_lh's gather (kGibbs = false) or k_given_unchanged_gibbs' resampling (kGibbs = true).  No table in
+// global memory, no second launch waiting for the first.  The subset's object list and table rows (host-mapped) are read
+// once per block, coalesced.  LDS: tables [R][16][S] (int32 histogram, then float32 in place) | object list | rows | bitmap.
+// ------------------------------------------------------------------------------------------
+struct GuFusedArgs {
+    const uint8_t* state; const uint16_t* gid; const uint8_t* src; const int32_t* counts;
+    const int32_t* objects;          // [n_sub]            (host-mapped)
+    const int32_t* group_idx;        // [C][n_sub] group of the object within its component, -1 none (host-mapped)
+    int table_offsets[kMaxComponents];   // first table row of component c (0 for the cluster, 1 + goff[c] - K)
+    const double* conc; const double* unif;
+    double temperature, prior_temperature;
+    int* status;
+    int n_sub, i_cluster, K, N, Np, F, S, C, Fp, R;
+    float* out;                      // kGibbs = false: [n_sub][F][C]
+    float inv_t; int use_pow;
+};
+
+template <bool kGibbs>
+__global__ __launch_bounds__(kUnchangedBlock) void k_given_unchanged_fused(GuFusedArgs a, GuGibbsArgs gb, uint8_t* __restrict__ src_new,
+                                                                           float* __restrict__ sel_new, float* __restrict__ sel_back,
+                                                                           DoneSig done = DoneSig{}) {
+    constexpr int FTU = 16, OL = kUnchangedBlock / FTU;
+    extern __shared__ int32_t lds[];
+    const int S = a.S, R = a.R, n_sub = a.n_sub, C = a.C;
+    int32_t* hist = lds;                                                 // [R][FTU][S]
+    int32_t* sub = hist + R * FTU * S;                                   // [n_sub]
+    int32_t* gidx = sub + n_sub;                                         // [C][n_sub]
+    uint32_t* in_subset = reinterpret_cast<uint32_t*>(gidx + C * n_sub); // [(N + 31) / 32]
+    const int f0 = blockIdx.x * FTU;
+    for (int i = threadIdx.x; i < R * FTU * S; i += kUnchangedBlock) hist[i] = 0;
+    for (int i = threadIdx.x; i < n_sub; i += kUnchangedBlock) sub[i] = a.objects[i];
+    for (int i = threadIdx.x; i < C * n_sub; i += kUnchangedBlock) gidx[i] = a.group_idx[i];
+    for (int i = threadIdx.x; i < (a.N + 31) / 32; i += kUnchangedBlock) in_subset[i] = 0u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_sub; i += kUnchangedBlock) atomicOr(&in_subset[sub[i] >> 5], 1u << (sub[i] & 31));
+    __syncthreads();
+    const int fl = threadIdx.x & (FTU - 1), ol = threadIdx.x / FTU;
+    const int f = f0 + fl;
+    if (f < a.F) {
+        // row 0: members of the cluster outside the subset whose source is the cluster component (operators.py:876-883)
+        const uint16_t want = (uint16_t)a.i_cluster;
+        for (int n = ol; n < a.N; n += 8 * OL) {
+            bool take[8];
+            uint8_t x[8], sc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int nn = n + j * OL;
+                take[j] = nn < a.N && a.gid[nn] == want && !((in_subset[nn >> 5] >> (nn & 31)) & 1u);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t at = (int64_t)(n + j * OL) * a.Fp + f;
+                x[j] = take[j] ? a.state[at] : kNA;
+                sc[j] = take[j] ? a.src[at] : kNA;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (x[j] != kNA && sc[j] == 0) atomicAdd(&hist[fl * S + x[j]], 1);
+        }
+        // confounder rows: what the subset's objects contribute to their groups' counts comes off (operators.py:896-901)
+        for (int i = ol; i < n_sub; i += OL) {
+            const int64_t at = (int64_t)sub[i] * a.Fp + f;
+            const uint8_t x = a.state[at], sc = a.src[at];
+            if (x == kNA || sc == 0 || sc >= C) continue;
+            const int g = gidx[sc * n_sub + i];
+            if (g >= 0) atomicAdd(&hist[((a.table_offsets[sc] + g) * FTU + fl) * S + x], -1);
+        }
+    }
+    __syncthreads();
+    // conditional_effect_mean (conditionals.py:105-122) of the kept counts: one thread per (row, feature), in place
+    for (int t = threadIdx.x; t < R * FTU; t += kUnchangedBlock) {
+        const int r = t / FTU, tf = t % FTU, ff = f0 + tf;
+        if (ff >= a.F) continue;
+        const int gg = r == 0 ? a.i_cluster : a.K + r - 1;           // rows 1.. are the confounder groups in global order
+        const int32_t* base = a.counts + ((int64_t)gg * a.F + ff) * S;
+        int32_t* h = hist + (r * FTU + tf) * S;
+        probs_row([&](int s) { return (float)((r == 0 ? 0 : base[s]) + h[s]); }, a.conc + ((int64_t)gg * a.F + ff) * S,
+                  a.unif + (int64_t)ff * S, S, a.temperature, a.prior_temperature, a.status,
+                  [&](int s, float v) { h[s] = __float_as_int(v); });
+    }
+    __syncthreads();
+    const float* tab = reinterpret_cast<const float*>(hist);
+    for (int t = threadIdx.x; t < n_sub * FTU; t += kUnchangedBlock) {
+        const int r = t / FTU, tf = t % FTU, ff = f0 + tf;
+        if (ff >= a.F) continue;
+        const uint8_t x = a.state[(int64_t)sub[r] * a.Fp + ff];
+        const int64_t i = (int64_t)r * a.F + ff;
+        if constexpr (kGibbs) {
+            gu_gibbs_obs(gb, i, r, ff, x, [&](int c) { return gidx[c * n_sub + r]; },
+                         [&](int c, int g) { return tab[((a.table_offsets[c] + g) * FTU + tf) * S + x]; },
+                         src_new, sel_new, sel_back, a.status);
+        } else {
+            float* o = a.out + i * C;
+            for (int c = 0; c < C; ++c) {
+                float v = 1.0f;
+                if (x != kNA) {
+                    const int g = gidx[c * n_sub + r];
+                    v = g < 0 ? 0.0f : tab[((a.table_offsets[c] + g) * FTU + tf) * S + x];
+                }
+                o[c] = a.use_pow ? powf(v, a.inv_t) : v;
+            }
+        }
+    }
+    signal_done(done);
 }
 
 }  // namespace sbe

@@ -177,7 +177,9 @@ class Engine:
         self._check(self._lib.sbe_get_info(self._h, ct.byref(inf)))
         return {k: (getattr(inf, k).decode() if k == "device_name" else getattr(inf, k)) for k, _ in inf._fields_}
 
-    def set_option(self, kernel=None, log_mode=None, deferred_checks=None, step_form=None, step_derive=None):
+    def set_option(self, kernel=None, log_mode=None, deferred_checks=None, step_form=None, step_derive=None, fuse_tables=None):
+        if fuse_tables is not None:
+            self._check(self._lib.sbe_set_option(self._h, 6, int(bool(fuse_tables))))  # SBE_OPT_FUSE_TABLES
         if step_derive is not None:
             self._check(self._lib.sbe_set_option(self._h, 5, int(step_derive)))    # SBE_OPT_STEP_DERIVE
         if step_form is not None:

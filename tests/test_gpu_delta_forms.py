@@ -146,6 +146,70 @@ def test_resident_operator_forms(name):
         eng.close()
 
 
+@pytest.mark.parametrize("name", ["cfg1_fixture", "south_america", "headline", "wide"])
+def test_fused_tables_same_bits(name):
+    """SBE_OPT_FUSE_TABLES (round 4): the one-launch forms -- table entries built inside the consuming
+    kernel -- return the bits of the table-kernel-in-front forms, for every resident operator call that has both."""
+    eng, fake, groups, source, counts = _pair(name)
+    try:
+        rng = np.random.default_rng(23)
+        N, F, C = source.shape
+        K = groups[0].shape[0]
+        has = np.stack([g.any(axis=0) for g in groups], axis=1)                       # [N, C]
+
+        def both(call):
+            eng.set_option(fuse_tables=True)
+            a = call()
+            eng.set_option(fuse_tables=False)
+            b = call()
+            eng.set_option(fuse_tables=True)
+            return a, b
+
+        for temp, ptemp in ((1.0, 1.0), (1.3, 1.5)):
+            for k in range(min(K, 3)):
+                available = np.flatnonzero(~groups[0].any(axis=0) | groups[0][k])
+                a, b = both(lambda: eng.cluster_posterior_marginals(0, k, available, temp, ptemp))
+                assert np.array_equal(a, b), (name, "marginals", k, temp)
+                if K > 1 and groups[0][k].any():
+                    members = np.flatnonzero(groups[0][k])
+                    a, b = both(lambda: eng.jump_lh_resident(0, k, (k + 1) % K, members, temp, ptemp))
+                    assert np.array_equal(a, b), (name, "jump", k, temp)
+                for n in (1, 9, min(N, 300)):
+                    objs = np.sort(rng.choice(N, size=min(n, N), replace=False))
+                    a, b = both(lambda: eng.given_unchanged_lh(0, k, objs, temp, ptemp))
+                    assert np.array_equal(a, b), (name, "given_unchanged_lh", k, n, temp)
+                    hc_new = has[objs].copy()
+                    hc_new[:, 0] = rng.random(objs.size) < 0.5
+                    hc_new[~hc_new.any(axis=1), 1 if C > 1 else 0] = True
+                    hc_old = has[objs].copy()
+                    hc_old[~hc_old.any(axis=1), 1 if C > 1 else 0] = True
+                    src_old = np.where(source[objs].any(-1), source[objs].argmax(-1), 255).astype(np.uint8)
+                    z = rng.random((objs.size, F))
+                    for from_prior in (False, True):
+                        try:
+                            a = b = None
+                            a, b = both(lambda: eng.given_unchanged_gibbs(0, k, objs, hc_new, hc_old, src_old, z, temp, ptemp, from_prior))
+                        except Exception as exc:                     # (a random pattern may leave an observation no component:
+                            assert "normalize" in str(exc) or "sum" in str(exc), exc           # both forms raise it alike)
+                            eng.set_option(fuse_tables=True)
+                            continue
+                        for u, v in zip(a, b):
+                            assert np.array_equal(u, v), (name, "given_unchanged_gibbs", k, n, temp, from_prior)
+        # a count row that sums to nothing with a zero concentration: normalize's assert fires in both forms
+        if name == "cfg1_fixture":
+            conc0 = np.array(fake.conc[0], dtype=np.float64, copy=True)
+            conc0[..., 0, :] = 0.0
+            zero = np.zeros_like(counts[0])
+            eng.set_concentration(0, conc0)
+            eng.set_counts(0, 0, zero)
+            for fuse in (True, False):
+                eng.set_option(fuse_tables=fuse)
+                with pytest.raises(Exception, match="(?i)normali"):
+                    eng.cluster_posterior_marginals(0, 0, np.arange(5), 1.0, 1.0)
+    finally:
+        eng.close()
+
+
 def test_argument_checks():
     eng, fake, groups, source, counts = _pair("cfg1_fixture")
     try:
