@@ -10,3 +10,6 @@ pid=$!
 /opt/rocm/bin/hipcc $FLAGS "$@" -c sbayes_amd/csrc/sbe_engine.hip -o build/obj/sbe_engine.o
 wait $pid
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/obj/sbe_engine.o build/obj/sbe_mixture.o -o sbayes_amd/libsbe_engine.so
+# the host layer's CPython extension (plain C, no device code): sbayes_amd/_fast.py uses it when present
+gcc -O2 -fPIC -shared -Wall $(python3 -c "import sysconfig; print('-I' + sysconfig.get_paths()['include'])") sbayes_amd/csrc/sbe_pyhost.c \
+    -o sbayes_amd/_sbe_pyhost$(python3 -c "import sysconfig; print(sysconfig.get_config_var('EXT_SUFFIX'))")

@@ -49,7 +49,8 @@ extern "C" {
 
 typedef struct sbe_engine sbe_engine;
 
-#define SBE_ABI_VERSION 4   /* 4 (round 4): + sbe_given_unchanged_gibbs, sbe_host_*; sbe_set_groups rejects overlap */
+#define SBE_ABI_VERSION 5   /* 4 (round 4): + sbe_given_unchanged_gibbs, sbe_host_*; sbe_set_groups rejects overlap;
+                               5: + SBE_OPT_FUSE_TABLES, sbe_host_subset_ids, sbe_host_diff_rows */
 
 /* error codes */
 #define SBE_OK 0
@@ -363,6 +364,20 @@ int sbe_host_touched_groups(const int32_t* gid_old, const int32_t* gid_new, int6
                             int32_t* touched_out /* [n_groups_total] */, int32_t* n_touched_out);
 int sbe_host_source_ids(const uint8_t* source, int64_t n_objects, int n_features, int n_components, const int32_t* objects,
                         int n, uint8_t* ids_out /* [n][F] */);
+/* sbe_host_subset_ids: everything sbe_counts_delta needs about the listed objects in ONE pass over the reference's own
+ *     arrays (drop-in update_feature_counts, counts.py:55-95): group ids of every component in both samples
+ *     (groups_new[c] / groups_old[c]: [n_groups[c]][n_objects] bool; the same pointer in both = the ids are copied) and source
+ *     ids of both (source_*: [n_objects][F][C] bool; the same pointer = copied).  Returns 1 also when an object is listed
+ *     twice (the reference's fancy index counts it twice: the caller takes the two-count form).
+ * sbe_host_diff_rows: the bind cache's content compare (sbayes_amd/binding.py): rows of `rows` ([n_rows][row_bytes]) that
+ *     differ from `mirror` bytewise are copied into `mirror` and their indices written to changed_out (ascending);
+ *     returns how many, -1 on a bad argument. */
+int sbe_host_subset_ids(const int32_t* objects, int n, int64_t n_objects, int n_features, int n_components,
+                        const int32_t* n_groups /* [C] */, const uint8_t* const* groups_new /* [C] */,
+                        const uint8_t* const* groups_old /* [C] */, const uint8_t* source_new, const uint8_t* source_old,
+                        int32_t* gid_new_out /* [C][n] */, int32_t* gid_old_out /* [C][n] */, uint8_t* sid_new_out /* [n][F] */,
+                        uint8_t* sid_old_out /* [n][F] */);
+int64_t sbe_host_diff_rows(const void* rows, void* mirror, int64_t n_rows, int64_t row_bytes, int32_t* changed_out /* [n_rows] */);
 
 int sbe_set_uniform_counts(sbe_engine* e, const double* unif_counts /* [F][S] */);
 int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const int32_t* gid_old /* [C][n_subset] */,

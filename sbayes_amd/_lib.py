@@ -9,7 +9,7 @@ import os
 from pathlib import Path
 
 LIB_NAME = "libsbe_engine.so"
-ABI_VERSION = 4                    # SBE_ABI_VERSION of include/sbe_engine.h
+ABI_VERSION = 5                    # SBE_ABI_VERSION of include/sbe_engine.h
 _LIB = None
 
 c_engine_p = ct.c_void_p
@@ -96,6 +96,9 @@ PROTOTYPES = {
     "sbe_host_group_ids": (ct.c_int, [ct.c_void_p, ct.c_int, ct.c_int64, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p]),
     "sbe_host_touched_groups": (ct.c_int, [ct.c_void_p, ct.c_void_p, ct.c_int64, ct.c_int, ct.c_void_p, ct.c_void_p]),
     "sbe_host_source_ids": (ct.c_int, [ct.c_void_p, ct.c_int64, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),
+    "sbe_host_subset_ids": (ct.c_int, [ct.c_void_p, ct.c_int, ct.c_int64, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p,
+                                       ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p]),
+    "sbe_host_diff_rows": (ct.c_int64, [ct.c_void_p, ct.c_void_p, ct.c_int64, ct.c_int64, ct.c_void_p]),
     "sbe_set_uniform_counts": (ct.c_int, [c_engine_p, ct.c_void_p]),
     "sbe_counts_delta": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p,
                                     ct.c_void_p, ct.c_int, ct.c_void_p]),

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from . import _fast
 from .registry import get_engine
 
 
@@ -79,47 +80,39 @@ def _remember(tok):
     return arr, None, arr.copy()
 
 
-def _changed_rows(new, mirror):
-    """Indices along axis 0 where `new` differs from `mirror` (same shape and dtype), compared as raw bytes."""
-    if new.shape[0] == 0 or new.size == 0:
-        return np.zeros(0, dtype=np.int64)
-    a = np.ascontiguousarray(new).reshape(new.shape[0], -1)
-    b = mirror.reshape(mirror.shape[0], -1)
-    if a.dtype.itemsize == 1 and a.shape[1] % 8 == 0:           # bool rows: eight observations per compare
-        a, b = a.view(np.uint64), b.view(np.uint64)
-    return np.flatnonzero((a != b).any(axis=1))
+_changed_rows = _fast.diff_rows         # rows of `new` that differ from `mirror`; the mirror takes them on the way
 
 
 def _send_counts(eng, slot, c, new, mirror, pending):
     """Bring the slot's counts of component c to `new` [G, F, S]; returns (mirror, anything changed).  Changed rows are
     appended to `pending` = ([global group indices], [rows]) -- _bind_slot sends the rows of ALL components with one
     set_counts_rows call; a component the slot has never held goes up whole."""
-    new = np.asarray(new, dtype=np.float32)
+    if type(new) is not _ndarray or new.dtype != np.float32:
+        new = np.asarray(new, dtype=np.float32)
     if mirror is None or mirror.shape != new.shape or not hasattr(eng, "set_counts_rows"):
         eng.set_counts(slot, c, new)
         return new.copy(), True
-    rows = _changed_rows(new, mirror)
+    rows = _changed_rows(new, mirror)                # (the mirror now holds `new`)
     if rows.size == 0:
         return mirror, False
     pending[0].append(int(eng.group_offsets[c]) + rows)
     pending[1].append(new[rows])
-    mirror[rows] = new[rows]
     return mirror, True
 
 
 def _send_source(eng, slot, new, mirror):
-    new = np.asarray(new, dtype=bool)
+    if type(new) is not _ndarray or new.dtype != np.bool_:
+        new = np.asarray(new, dtype=bool)
     if mirror is None or mirror.shape != new.shape:
         eng.set_source(slot, new)
         return new.copy()
-    rows = _changed_rows(new, mirror)
+    rows = _changed_rows(new, mirror)                # (the mirror now holds `new`)
     if rows.size == 0:
         return mirror
     if 2 * rows.size > new.shape[0]:
         eng.set_source(slot, new)
-        return new.copy()
+        return mirror
     eng.set_source_rows(slot, rows, new[rows])
-    mirror[rows] = new[rows]
     return mirror
 
 

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import _lib
+from . import _fast, _lib
 from .engine import GroupOverlapError
 from .registry import get_engine
 
@@ -56,8 +56,7 @@ def _subset_indices(object_subset, n_objects):
     return np.flatnonzero(subset) if subset.dtype == np.bool_ else subset.astype(np.int64, copy=False).reshape(-1)
 
 
-def _addr(a):
-    return a.__array_interface__["data"][0]
+_addr = _fast.addr
 
 
 def _group_ids(groups, objs, offset, out):
@@ -88,31 +87,22 @@ def update_feature_counts(sample_old, sample_new, features, object_subset):
     """Delta update of `sample_new.feature_counts` for the objects whose assignment changed (counts.py:55-95).
     ONE device call for all components: the subset's group ids and source rows of both samples go up (n * (8 C + 2 F)
     bytes), the count rows of the groups those objects are in come back; the reference's `add_changes(diff)` follows
-    with the same `diff` it would have computed (zero rows for every other group)."""
+    with the same `diff` it would have computed (zero rows for every other group) -- in its row form
+    (FeatureCounts.add_changes_rows: patch.install / sbayes_amd.state) where the sample's class has one."""
     counts = sample_new.feature_counts
     conf_names = list(sample_new.confounders)
     names = ["clusters", *conf_names]
-    C = len(names)
     groups_old = [sample_old.clusters.value] + [sample_old.confounders[k].group_assignment for k in conf_names]
     groups_new = [sample_new.clusters.value] + [sample_new.confounders[k].group_assignment for k in conf_names]
     n_groups = [g.shape[0] for g in groups_new]
     eng = get_engine(features, n_groups)
-    objs = np.ascontiguousarray(_subset_indices(object_subset, features.shape[0]), dtype=np.int32)
-    n = objs.size
+    objs = _subset_indices(object_subset, features.shape[0])
+    if objs.dtype != np.int32 or not objs.flags.c_contiguous:
+        objs = np.ascontiguousarray(objs, dtype=np.int32)
     off = eng.group_offsets
-    single = n < 2 or len(np.unique(objs)) == n      # (the reference's fancy index would count a repeated object twice)
-    if single:
-        gid_new = np.empty((C, n), dtype=np.int32)
-        gid_old = np.empty((C, n), dtype=np.int32)
-        for c in range(C):
-            single = single and _group_ids(groups_new[c], objs, off[c], gid_new[c])
-            if groups_old[c] is groups_new[c]:       # (every confounder: the same matrix object in both samples)
-                gid_old[c] = gid_new[c]
-            else:
-                single = single and _group_ids(groups_old[c], objs, off[c], gid_old[c])
-            if not single:
-                break
-    if not single:
+    src_old, src_new = sample_old.source.value, sample_new.source.value
+    ids = _fast.subset_ids(objs, groups_new, groups_old, src_new, src_old)
+    if ids is None:
         # repeated objects, or a listed object in several groups of one component (counted once per group,
         # counts.py:28-30): the reference's own two-count difference, each count by the stateless device histogram
         for i, name in enumerate(names):
@@ -120,15 +110,16 @@ def update_feature_counts(sample_old, sample_new, features, object_subset):
             new = compute_effect_counts(features, groups_new[i], sample_new.source.value[..., i], object_subset)
             counts[name].add_changes(diff=new - old)
         return counts
-    src_old, src_new = sample_old.source.value, sample_new.source.value
-    sid_new = _source_ids(src_new, objs)
-    sid_old = sid_new if src_old is src_new else _source_ids(src_old, objs)
-    touched, rows = eng.counts_delta(objs, gid_old, gid_new, sid_old, sid_new)
-    bounds = np.searchsorted(touched, off)           # `touched` is sorted: the rows of component c are bounds[c]:bounds[c+1]
+    touched, rows = eng.counts_delta(objs, *ids)
+    bounds = np.searchsorted(touched, off).tolist()  # `touched` is sorted: the rows of component c are bounds[c]:bounds[c+1]
     for c, name in enumerate(names):
         node = counts[name]
-        diff = np.zeros(node.value.shape, dtype=np.float32)
         lo, hi = bounds[c], bounds[c + 1]
+        add_rows = getattr(node, "add_changes_rows", None)
+        if add_rows is not None:
+            add_rows(touched[lo:hi] - off[c], rows[lo:hi])
+            continue
+        diff = np.zeros(node.value.shape, dtype=np.float32)
         if hi > lo:
             diff[touched[lo:hi] - off[c]] = rows[lo:hi]
         node.add_changes(diff=diff)

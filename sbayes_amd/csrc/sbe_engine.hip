@@ -6,6 +6,7 @@
 // slot's state stay resident in HBM; only small tables / id vectors cross PCIe per call.
 #include "sbe_kernels.hip.h"
 #include "../../include/sbe_engine.h"
+#include "sbe_host_helpers.h"   // marshalling helpers shared with the CPython extension (plain C)
 #include "sbe_pool.h"          // host worker threads of sbe_step_batch (plain C++: also built under ThreadSanitizer)
 
 #include <sched.h>
@@ -1092,54 +1093,29 @@ const char* sbe_last_error(const sbe_engine* e) { return e ? e->last_error.c_str
 // (tools/host_residual.py: the host layer, not the device, bounds the patched sampler); here it is one pass each.
 int sbe_host_group_ids(const uint8_t* groups, int n_groups, int64_t n_objects, const int32_t* objects, int n, int offset,
                        int32_t* ids_out) {
-    if ((n_groups > 0 && !groups) || (n > 0 && (!objects || !ids_out)) || n_groups < 0 || n < 0) return -1;
-    for (int i = 0; i < n; ++i) {
-        const int64_t o = objects[i];
-        if (o < 0 || o >= n_objects) return -1;
-        int32_t id = -1;
-        for (int g = 0; g < n_groups; ++g)
-            if (groups[(int64_t)g * n_objects + o]) {
-                if (id >= 0) return 1;                 // in several groups: no single id (the caller counts per group)
-                id = offset + g;
-            }
-        ids_out[i] = id;
-    }
-    return 0;
+    return sbeh_group_ids(groups, n_groups, n_objects, objects, n, offset, ids_out);
 }
 
 int sbe_host_source_ids(const uint8_t* source, int64_t n_objects, int n_features, int n_components, const int32_t* objects, int n,
                         uint8_t* ids_out) {
-    if ((n > 0 && (!source || !objects || !ids_out)) || n < 0 || n_features < 0 || n_components < 1 || n_components > 254) return -1;
-    const int64_t row = (int64_t)n_features * n_components;
-    for (int i = 0; i < n; ++i) {
-        const int64_t o = objects[i];
-        if (o < 0 || o >= n_objects) return -1;
-        const uint8_t* src = source + o * row;
-        uint8_t* out = ids_out + (int64_t)i * n_features;
-        for (int f = 0; f < n_features; ++f) {
-            uint8_t id = 0xFF;
-            for (int c = 0; c < n_components; ++c) if (src[(int64_t)f * n_components + c]) { id = (uint8_t)c; break; }   // (first set: argmax)
-            out[f] = id;
-        }
-    }
-    return 0;
+    return sbeh_source_ids(source, n_objects, n_features, n_components, objects, n, ids_out);
 }
 
 int sbe_host_touched_groups(const int32_t* gid_old, const int32_t* gid_new, int64_t count, int n_groups_total,
                             int32_t* touched_out, int32_t* n_touched_out) {
-    if (count < 0 || n_groups_total < 0 || !touched_out || !n_touched_out || (count > 0 && (!gid_old || !gid_new))) return -1;
-    static thread_local std::vector<uint8_t> seen;
-    seen.assign((size_t)n_groups_total, 0);
-    for (int64_t i = 0; i < count; ++i) {
-        const int32_t a = gid_old[i], b = gid_new[i];
-        if (a < -1 || a >= n_groups_total || b < -1 || b >= n_groups_total) return -1;
-        if (a >= 0) seen[a] = 1;
-        if (b >= 0) seen[b] = 1;
-    }
-    int32_t n = 0;
-    for (int32_t g = 0; g < n_groups_total; ++g) if (seen[g]) touched_out[n++] = g;       // ascending, like np.union1d
-    *n_touched_out = n;
-    return 0;
+    return sbeh_touched_groups(gid_old, gid_new, count, n_groups_total, touched_out, n_touched_out);
+}
+
+int sbe_host_subset_ids(const int32_t* objects, int n, int64_t n_objects, int n_features, int n_components,
+                        const int32_t* n_groups, const uint8_t* const* groups_new, const uint8_t* const* groups_old,
+                        const uint8_t* source_new, const uint8_t* source_old,
+                        int32_t* gid_new_out, int32_t* gid_old_out, uint8_t* sid_new_out, uint8_t* sid_old_out) {
+    return sbeh_subset_ids(objects, n, n_objects, n_features, n_components, n_groups, groups_new, groups_old, source_new, source_old,
+                           gid_new_out, gid_old_out, sid_new_out, sid_old_out);
+}
+
+int64_t sbe_host_diff_rows(const void* rows, void* mirror, int64_t n_rows, int64_t row_bytes, int32_t* changed_out) {
+    return sbeh_diff_rows(rows, mirror, n_rows, row_bytes, changed_out);
 }
 
 int sbe_destroy(sbe_engine* e) {

@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 
-from . import _lib, _proc
+from . import _fast, _lib, _proc
 
 MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE, MIXTURE_ONEHOT_GENERAL = 0, 1, 2, 3, 4
 MIXTURE_PACKED_TUPLE_LDS = 5
@@ -52,11 +52,11 @@ def _as(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
 
 
-def _ptr(a):
-    # the buffer address as a plain int (every array argument of the ABI is declared c_void_p, which takes one):
-    # ndarray.ctypes.data_as builds two helper objects per call, 2 us apiece on the hosts measured -- with three to
-    # seven array arguments that was a quarter of a latency-bound call
-    return a.__array_interface__["data"][0]
+# the buffer address as a plain int (every array argument of the ABI is declared c_void_p, which takes one):
+# ndarray.ctypes.data_as builds two helper objects per call, 2 us apiece on the hosts measured, __array_interface__ a
+# dict (0.9 us) -- with three to seven array arguments a quarter of a latency-bound call; the extension's buffer-protocol
+# accessor (sbayes_amd/_fast.py) costs 0.08 us
+_ptr = _fast.addr
 
 
 def device_count() -> int:
@@ -119,11 +119,11 @@ class Engine:
     # sampler_replay in bench.py reports them per MCMC step (SURVEY.md 8(b) "What crosses PCIe per step").
     def _i(self, a):
         self.h2d_bytes += a.nbytes
-        return a.__array_interface__["data"][0]          # (_ptr)
+        return _ptr(a)
 
     def _o(self, a):
         self.d2h_bytes += a.nbytes
-        return a.__array_interface__["data"][0]          # (_ptr)
+        return _ptr(a)
 
     def traffic(self, reset=False):
         """(bytes handed to the library, bytes written back by it, ABI calls) since creation / the last reset."""
@@ -621,16 +621,14 @@ class Engine:
         sn = so if src_new is src_old else _as(src_new, np.uint8)
         if so.shape != (n, F) or sn.shape != so.shape:
             raise ValueError(f"src_old / src_new must be [{n}, {F}]")
-        # the groups any listed object is in, in either state (sorted): one pass in the library's host helper
-        touched = np.empty(self.n_groups_total, dtype=np.int32)
-        nt = ct.c_int32(0)
-        if self._lib.sbe_host_touched_groups(self._i(go), self._i(gn), C * n, self.n_groups_total, _ptr(touched), ct.byref(nt)) != 0:
-            raise ValueError("group index out of range in gid_old / gid_new")
-        touched = touched[:nt.value]
-        diff = np.zeros((nt.value, F, self.n_states), dtype=np.float32)
-        if nt.value and n:
+        # the groups any listed object is in, in either state (sorted): one pass in the host helper
+        touched = _fast.touched_groups(go, gn, self.n_groups_total)
+        self.h2d_bytes += go.nbytes + gn.nbytes
+        nt = touched.size
+        diff = np.zeros((nt, F, self.n_states), dtype=np.float32)
+        if nt and n:
             self._check(self._lib.sbe_counts_delta(self._h, self._i(objs), n, _ptr(go), _ptr(gn), self._i(so), self._i(sn),
-                                                   self._i(touched), nt.value, self._o(diff)))
+                                                   self._i(touched), nt, self._o(diff)))
         return touched, diff
 
     def set_counts_rows(self, slot, group_idx, rows):

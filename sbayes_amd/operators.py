@@ -149,6 +149,23 @@ def gibbs_sample_source(model, sample, object_subset=slice(None), temperature=1.
     return sample_new, log_q, log_q_back
 
 
+def _subset_as_sorted_ids(object_subset, n_objects):
+    """int32 ids, ascending and distinct, of the objects `np.isin(np.arange(n_objects), object_subset)` marks
+    (ClusterOperator.gibbs_sample_source, operators.py:805) -- through a flag array instead of the sort-based set
+    operation (42 us per call on the hosts measured); values outside [0, n_objects) match nothing, as there."""
+    subset = np.asarray(object_subset)
+    if subset.dtype == np.bool_ and subset.shape == (n_objects,):
+        return np.flatnonzero(subset).astype(np.int32)
+    subset = subset.reshape(-1)
+    if subset.dtype.kind not in "iu":
+        return np.flatnonzero(np.isin(np.arange(n_objects), subset)).astype(np.int32)
+    if subset.size and (int(subset.min()) < 0 or int(subset.max()) >= n_objects):
+        subset = subset[(subset >= 0) & (subset < n_objects)]
+    mask = np.zeros(n_objects, dtype=np.bool_)
+    mask[subset] = True
+    return np.flatnonzero(mask).astype(np.int32)
+
+
 def cluster_gibbs_sample_source(model, sample_new, sample_old, i_cluster, object_subset, temperature=1.0, prior_temperature=1.0,
                                 sample_from_prior=False, slot=0, z=None):
     """ClusterOperator.gibbs_sample_source (operators.py:796-851): the source resampling inside every AlterCluster /
@@ -165,9 +182,7 @@ def cluster_gibbs_sample_source(model, sample_new, sample_old, i_cluster, object
     eng = _engine(model)
     features = model.data.features.values
     na_features = model.data.features.na_values
-    n_objects = sample_new.n_objects
-    mask = np.isin(np.arange(n_objects), object_subset)                    # (operators.py:805: a boolean index array)
-    objects = np.flatnonzero(mask).astype(np.int32)
+    objects = _subset_as_sorted_ids(object_subset, sample_new.n_objects)   # (operators.py:805: np.isin(arange(N), subset))
     _bind_slot(eng, model, sample_new, slot, with_source=True)
     _bind_uniform(eng, model)
     hc_new = sample_new.cache.has_components.value[objects]
@@ -179,8 +194,8 @@ def cluster_gibbs_sample_source(model, sample_new, sample_old, i_cluster, object
                                                        prior_temperature, sample_from_prior)
     x = ids[..., None] == np.arange(eng.n_components, dtype=np.uint8)     # one-hot; all False where NA (id 255)
     with sample_new.source.edit() as source:
-        source[mask] = x                                                  # (NA observations stay 0: operators.py:825)
-    update_feature_counts(sample_old, sample_new, features, mask)
+        source[objects] = x                                               # (NA observations stay 0: operators.py:825)
+    update_feature_counts(sample_old, sample_new, features, objects)
     valid = ~na_features[objects]
     with np.errstate(divide="ignore"):
         log_q = np.log(sel_new[valid]).sum()                              # float32 logs, float32 sum (operators.py:832)

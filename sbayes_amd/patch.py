@@ -40,6 +40,7 @@ import inspect
 import warnings
 
 _SAVED = []
+_ADDED = []              # (class, attribute) pairs install() ADDED to reference classes (removed by uninstall())
 _INSTALLED = None        # {"operators": bool} while the patch is installed in this process
 
 # A replaced method shadows whatever the reference does there, so each device form is tied to the reference body it
@@ -60,6 +61,7 @@ MIRRORED_SOURCES = {
     "SourcePrior.__call__": "c76b2825409bc280761a6b598113f74c9b395dbb",
     "GibbsSampleSource._propose": "61911f12df7948eea0f207e45f49d97d7e0e5352",
     "ClusterOperator.gibbs_sample_source": "4c1f20c2821f64d9eed7ad4e8fa9cf50a76d0de1",
+    "FeatureCounts.add_changes": "7c38d633f8488c553f1a031f57751a7db58deed2",
 }
 
 
@@ -163,6 +165,7 @@ def install(operators=False, mp_start_method=None, gibbs_source=False):
         swap(mod, "compute_effect_counts", my_counts.compute_effect_counts)
         swap(mod, "recalculate_feature_counts", my_counts.recalculate_feature_counts)
         swap(mod, "update_feature_counts", my_counts.update_feature_counts)
+    _install_sparse_add_changes()
     if operators:
         _install_operator_forms(swap)
     if gibbs_source:
@@ -178,6 +181,38 @@ def install(operators=False, mp_start_method=None, gibbs_source=False):
             swap(m, name, new)
     _INSTALLED = {"operators": bool(operators) or bool(_INSTALLED and _INSTALLED["operators"]),
                   "gibbs_source": bool(gibbs_source) or bool(_INSTALLED and _INSTALLED.get("gibbs_source"))}
+
+
+def _install_sparse_add_changes():
+    """FeatureCounts.add_changes_rows(group_idx, rows): add_changes (sbayes/sampling/state.py:340-350) for a difference
+    that is zero outside the listed rows -- what the drop-in update_feature_counts has in hand.  Same value, version and
+    group versions as add_changes(dense diff); the [n_groups, F, S] zero array, the whole-table add and the whole-table
+    compare per component and call are not built (a third of update_feature_counts' host time, tools/host_residual.py).
+    Added only when the installed add_changes is the body this mirrors; otherwise the dense call stays."""
+    try:
+        state = importlib.import_module("sbayes.sampling.state")
+        cls = state.FeatureCounts
+        if source_digest(inspect.getattr_static(cls, "add_changes")) != MIRRORED_SOURCES["FeatureCounts.add_changes"]:
+            return
+    except (ImportError, AttributeError, OSError, TypeError):
+        return
+    if "add_changes_rows" in cls.__dict__:
+        return
+    import numpy as np
+
+    def add_changes_rows(self, group_idx, rows):
+        if self.shared:
+            self.resolve_sharing()
+        if len(group_idx):
+            self._value.flags.writeable = True
+            self._value[group_idx] += rows
+            self._value.flags.writeable = False
+        self.version += 1
+        if len(group_idx):
+            self.group_versions[group_idx[np.any(rows != 0, axis=(1, 2))]] = self.version
+
+    cls.add_changes_rows = add_changes_rows
+    _ADDED.append((cls, "add_changes_rows"))
 
 
 def _install_gibbs_source_form(swap):
@@ -337,3 +372,7 @@ def uninstall():
     while _SAVED:
         mod, name, old = _SAVED.pop()
         setattr(mod, name, old)
+    while _ADDED:
+        cls, name = _ADDED.pop()
+        if name in cls.__dict__:
+            delattr(cls, name)

@@ -198,6 +198,17 @@ class FeatureCounts(GroupedParameters):
         self._bump()
         self.group_versions[np.any(diff != 0, axis=(1, 2))] = self.version
 
+    def add_changes_rows(self, group_idx, rows):
+        """add_changes(diff) for a diff that is zero outside the rows `group_idx` (distinct): the same values, version and
+        group versions, without the dense [n_groups, F, S] operand (the drop-in update_feature_counts knows the rows)."""
+        self._own()
+        if len(group_idx):
+            self._value.flags.writeable = True
+            self._value[group_idx] += rows
+        self._bump()
+        if len(group_idx):
+            self.group_versions[group_idx[np.any(rows != 0, axis=(1, 2))]] = self.version
+
 
 class Confounder:
     """Static assignment of objects to the groups of one confounder (load_data.py:138-184)."""

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_text():
     lib = _lib.load()
-    assert lib.sbe_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.sbe_abi_version() == _lib.ABI_VERSION == 5
     assert lib.sbe_get_info(None, None) != 0
     assert b"null engine" in lib.sbe_last_error(None)
 
