@@ -50,7 +50,7 @@ extern "C" {
 typedef struct sbe_engine sbe_engine;
 
 #define SBE_ABI_VERSION 5   /* 4 (round 4): + sbe_given_unchanged_gibbs, sbe_host_*; sbe_set_groups rejects overlap;
-                               5: + SBE_OPT_FUSE_TABLES, sbe_host_subset_ids, sbe_host_diff_rows */
+                               5: + SBE_OPT_FUSE_TABLES, sbe_host_subset_ids, sbe_host_diff_rows, sbe_set_counts_rows_probs */
 
 /* error codes */
 #define SBE_OK 0
@@ -384,6 +384,11 @@ int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const 
                      const int32_t* gid_new, const uint8_t* src_old /* [n_subset][F] */, const uint8_t* src_new,
                      const int32_t* touched, int n_touched, float* out_diff /* [n_touched][F][S] */);
 int sbe_set_counts_rows(sbe_engine* e, int slot, const int32_t* group_idx, int n_rows, const float* rows /* [n_rows][F][S] */);
+/* sbe_set_counts_rows that also rebuilds the probability rows of the patched groups (normalize(counts + concentration),
+ * sbe_update_probs' untempered arithmetic) in the same launch: after it the slot's tables of those components are current
+ * again, provided they were before.  Requires the components' tables (sbe_update_probs) and concentrations to be set;
+ * normalize's positive-sum assert is reported like sbe_update_probs reports it. */
+int sbe_set_counts_rows_probs(sbe_engine* e, int slot, const int32_t* group_idx, int n_rows, const float* rows /* [n_rows][F][S] */);
 int sbe_given_unchanged_lh(sbe_engine* e, int slot, int i_cluster, const int32_t* objects, int n_sub, double temperature,
                            double prior_temperature, float* out /* [n_sub][F][C] */);
 /* ClusterOperator.gibbs_sample_source (sbayes/sampling/operators.py:796-851: the source resampling inside every

@@ -69,6 +69,31 @@ def _same(tok, cached):
     return copy is not None and arr.shape == copy.shape and arr.dtype == copy.dtype and np.array_equal(arr, copy)
 
 
+def _scan_py(params, cached):
+    """(tokens, changed): the token of every parameter and a bit mask of those that do not denote what `cached` recorded
+    (the extension's scan() is this loop in C: sbayes_amd/csrc/sbe_pyhost.c)."""
+    tokens = [_token(p) for p in params]
+    changed = 0
+    for i, tok in enumerate(tokens):
+        if not _same(tok, cached[i]):
+            changed |= 1 << i
+    return tokens, changed
+
+
+def _content_equal(arr, copy):
+    return arr.shape == copy.shape and arr.dtype == copy.dtype and np.array_equal(arr, copy)
+
+
+if _fast.HAVE_EXTENSION:
+    _fast._h.scan_setup(np.ndarray, np.asarray, _content_equal)
+    _scan = _fast._h.scan
+else:
+    _scan = _scan_py
+
+
+_ROWS_WITH_PROBS = True     # count rows go up with the rebuild of their probability rows (Engine.set_counts_rows(update_probs=True))
+
+
 def _remember(tok):
     arr, version = tok
     # the ndarray itself is kept alive so that its id cannot be recycled for another array while the entry lives
@@ -147,37 +172,55 @@ def _bind_slot(eng, model, sample, slot, with_source=False):
     old = cache.get(slot)
     if old is None:
         old = {"groups": [None] * C, "counts": [None] * C, "weights": None, "source": None, "stale": set(range(C)), "lh_all": None}
-    # ---- what differs?  (tokens are built once; nothing is written until something does differ) ----
-    groups = [_token(sample.clusters)]
-    for k in conf_names:
-        groups.append(_token(confounders[k].group_assignment))
+    # ---- what differs?  (one pass over the parameters -- _scan: the extension's C loop, or _token / _same below it --
+    # nothing is written until something does differ) ----
     old_groups, old_counts = old["groups"], old["counts"]
-    groups_changed = [c for c in range(C) if not _same(groups[c], old_groups[c])]
-    conc = counts = None
-    conc_changed = counts_changed = ()
+    params = [sample.clusters]
+    for k in conf_names:
+        params.append(confounders[k].group_assignment)
+    cached = list(old_groups)
     if model is not None:
         prior = model.prior
-        conc = [_token(prior.prior_cluster_effect.concentration_array)]
-        feature_counts = sample.feature_counts
-        counts = [_token(feature_counts["clusters"])]
         conf_priors = prior.prior_confounding_effects
-        for k in conf_names:
-            conc.append(_token(conf_priors[k].concentration_array(sample)))
-            counts.append(_token(feature_counts[k]))
+        feature_counts = sample.feature_counts
         bound_conc = eng._bound_conc
-        conc_changed = [c for c in range(C) if not _same(conc[c], bound_conc.get(c))]
-        counts_changed = [c for c in range(C) if not _same(counts[c], old_counts[c])]
-    weights = _token(sample.weights)
-    weights_changed = not _same(weights, old["weights"])
-    source = None
-    source_changed = False
+        params.append(prior.prior_cluster_effect.concentration_array)
+        cached.append(bound_conc.get(0))
+        for c, k in enumerate(conf_names, start=1):
+            params.append(conf_priors[k].concentration_array(sample))
+            cached.append(bound_conc.get(c))
+        params.append(feature_counts["clusters"])
+        for k in conf_names:
+            params.append(feature_counts[k])
+        cached += old_counts
+    params.append(sample.weights)
+    cached.append(old["weights"])
     if with_source:
-        source = _token(sample.source)
-        source_changed = not _same(source, old["source"])
-    if not (groups_changed or conc_changed or counts_changed or weights_changed or source_changed):
+        params.append(sample.source)
+        cached.append(old["source"])
+    tokens, changed = _scan(params, cached)
+    if not changed:
         if slot not in cache:                       # (a first bind of an empty state: keep the entry)
             cache[slot] = old
         return old["stale"]
+    comps = range(C)
+    groups = tokens[:C]
+    groups_changed = [c for c in comps if (changed >> c) & 1]
+    at = C
+    conc = counts = None
+    conc_changed = counts_changed = ()
+    if model is not None:
+        conc, counts = tokens[C:2 * C], tokens[2 * C:3 * C]
+        conc_changed = [c for c in comps if (changed >> (C + c)) & 1]
+        counts_changed = [c for c in comps if (changed >> (2 * C + c)) & 1]
+        at = 3 * C
+    weights = tokens[at]
+    weights_changed = (changed >> at) & 1
+    source = None
+    source_changed = False
+    if with_source:
+        source = tokens[at + 1]
+        source_changed = (changed >> (at + 1)) & 1
     # ---- send the differences ----
     # the host mirrors of what the slot holds survive the entry being dropped by the engine's own setters as long as
     # those setters are the ones called from here (eng._mirror is cleared by every OTHER slot-changing call: _touch)
@@ -196,17 +239,30 @@ def _bind_slot(eng, model, sample, slot, with_source=False):
     for c in groups_changed:
         eng.set_groups(slot, c, groups[c][0])
         new["groups"][c] = _remember(groups[c])
+    was_stale = set(new["stale"])
+    by_rows = []                                    # components whose change goes up as rows
     for c in counts_changed:
+        n_pending = len(pending[0])
         mirrors["counts"][c], changed = _send_counts(eng, slot, c, counts[c][0], mirrors["counts"][c], pending)
         new["counts"][c] = _remember(counts[c])
         if changed:
-            new["stale"].add(c)
+            if len(pending[0]) > n_pending:
+                by_rows.append(c)
+            else:
+                new["stale"].add(c)                 # (the component went up whole: every table row is stale)
             new["lh_all"] = None                    # (Likelihood._group_logliks' memo of the collapsed log-likelihoods)
     if pending[0]:
-        if len(pending[0]) == 1:
-            eng.set_counts_rows(slot, pending[0][0], pending[1][0])
+        # the probability rows of the patched groups are rebuilt by the same launch when the tables of those components
+        # were current (the usual case inside a step: the slot held the sample this one was copied from) -- nothing is
+        # left stale, _tables_current has no table kernel to run; otherwise the components join the stale set
+        fused = _ROWS_WITH_PROBS and all(c not in was_stale for c in by_rows)
+        idx = pending[0][0] if len(pending[0]) == 1 else np.concatenate(pending[0])
+        rows = pending[1][0] if len(pending[1]) == 1 else np.concatenate(pending[1])
+        if fused:
+            eng.set_counts_rows(slot, idx, rows, update_probs=True)
         else:
-            eng.set_counts_rows(slot, np.concatenate(pending[0]), np.concatenate(pending[1]))
+            eng.set_counts_rows(slot, idx, rows)
+            new["stale"].update(by_rows)
     if source_changed:
         mirrors["source"] = _send_source(eng, slot, source[0], mirrors["source"])
         new["source"] = _remember(source)

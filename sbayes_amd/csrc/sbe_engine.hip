@@ -2598,7 +2598,7 @@ int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const 
     return synced(e);
 }
 
-int sbe_set_counts_rows(sbe_engine* e, int slot, const int32_t* group_idx, int n_rows, const float* rows) {
+static int set_counts_rows_impl(sbe_engine* e, int slot, const int32_t* group_idx, int n_rows, const float* rows, bool with_probs) {
     CHECK_ENGINE(e); CHECK_SLOT(e, slot);
     if (n_rows < 0) return fail(e, SBE_ERR_ARG, "n_rows=%d", n_rows);
     if (n_rows == 0) return SBE_OK;
@@ -2613,6 +2613,9 @@ int sbe_set_counts_rows(sbe_engine* e, int slot, const int32_t* group_idx, int n
         if (!e->slots[slot].counts_set[c])
             return fail(e, SBE_ERR_STATE, "slot %d: counts of component %d not set (sbe_set_counts_rows patches resident tables: "
                         "send the component whole with sbe_set_counts first); row for group %d refused", slot, c, group_idx[i]);
+        if (with_probs && (!e->slots[slot].probs_set[c] || !e->conc_set[c]))
+            return fail(e, SBE_ERR_STATE, "slot %d: probability tables / concentration of component %d not set (sbe_set_counts_rows_probs "
+                        "rebuilds the rows of tables that exist: sbe_update_probs first); row for group %d refused", slot, c, group_idx[i]);
     }
     HIPCHK(e, hipSetDevice(e->device));
     const int64_t fs = (int64_t)e->F * e->S;
@@ -2624,10 +2627,28 @@ int sbe_set_counts_rows(sbe_engine* e, int slot, const int32_t* group_idx, int n
     if (rc) return rc;
     rc = stage(e, group_idx, (size_t)n_rows * sizeof(int32_t), e->d_scratch + rb, &v_idx);
     if (rc) return rc;
-    k_set_count_rows<<<div_up((int64_t)n_rows * fs, 256), 256, 0, e->stream>>>(
-        (const float*)v_rows, (const int32_t*)v_idx, e->d_counts + (int64_t)slot * e->table_elems(), n_rows, fs);
+    if (!with_probs) {
+        k_set_count_rows<<<div_up((int64_t)n_rows * fs, 256), 256, 0, e->stream>>>(
+            (const float*)v_rows, (const int32_t*)v_idx, e->d_counts + (int64_t)slot * e->table_elems(), n_rows, fs);
+        HIPCHK(e, hipGetLastError());
+        return SBE_OK;
+    }
+    rc = clear_status_word(e, ST_BAD_NORMALIZE);
+    if (rc) return rc;
+    k_set_count_rows_probs<<<div_up((int64_t)n_rows * e->F, 256), 256, 0, e->stream>>>(
+        (const float*)v_rows, (const int32_t*)v_idx, e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc,
+        e->d_probs + (int64_t)slot * e->table_elems(), e->d_probs_t + (int64_t)slot * e->probs_t_elems(), n_rows, e->F, e->S, e->Gtot,
+        e->ft, e->d_status);
     HIPCHK(e, hipGetLastError());
-    return SBE_OK;
+    return check_after(e, ST_BAD_NORMALIZE, "sbe_set_counts_rows_probs");
+}
+
+int sbe_set_counts_rows(sbe_engine* e, int slot, const int32_t* group_idx, int n_rows, const float* rows) {
+    return set_counts_rows_impl(e, slot, group_idx, n_rows, rows, false);
+}
+
+int sbe_set_counts_rows_probs(sbe_engine* e, int slot, const int32_t* group_idx, int n_rows, const float* rows) {
+    return set_counts_rows_impl(e, slot, group_idx, n_rows, rows, true);
 }
 
 // k_given_unchanged_fused: LDS image of a 16-feature tile and the arguments both forms share

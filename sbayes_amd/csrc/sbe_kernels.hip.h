@@ -1653,6 +1653,29 @@ __global__ void k_set_count_rows(const float* __restrict__ rows /* [n][F][S] */,
     counts[(int64_t)group_idx[i / fs] * fs + i % fs] = (int32_t)rows[i];
 }
 
+// The same patch with the probability rows of the patched groups rebuilt in the same launch (sbe_set_counts_rows_probs:
+// the bind cache sends the rows of the groups whose counts changed, and the tables of exactly those groups are what is
+// stale afterwards -- one launch instead of this one and a k_probs over the whole component).  One thread per (row,
+// feature): the S float32 counts go to the resident int32 table, probs_row (k_probs' arithmetic, untempered) writes the
+// slot's probability row and its tile-transposed copy.
+__global__ void k_set_count_rows_probs(const float* __restrict__ rows /* [n][F][S] */, const int32_t* __restrict__ group_idx,
+                                       int32_t* __restrict__ counts /* slot's [Gtot][F][S] */, const double* __restrict__ conc,
+                                       float* __restrict__ probs, float* __restrict__ probs_t, int n, int F, int S, int Gtot, int ft,
+                                       int* __restrict__ status) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n * F) return;
+    const int i = (int)(t / F), f = (int)(t % F);
+    const int g = group_idx[i], tile = f / ft, tl = f % ft;
+    const float* in = rows + t * S;
+    const int64_t base = ((int64_t)g * F + f) * S;
+    int32_t* cnt = counts + base;
+    for (int s = 0; s < S; ++s) cnt[s] = (int32_t)in[s];
+    float* out_row = probs + base;
+    float* out_t = probs_t + (((int64_t)tile * (Gtot + 1) + g) * S) * ft + tl;                 // (k_probs' tile layout)
+    probs_row([&](int s) { return (float)(int32_t)in[s]; }, conc + base, nullptr, S, 0.0, 0.0, status,
+              [&](int s, float v) { out_row[s] = v; out_t[(int64_t)s * ft] = v; });
+}
+
 // ------------------------------------------------------------------------------------------
 // component_likelihood_given_unchanged (operators.py:863-928), count part, from RESIDENT data: the float32 count tables
 // the reference builds from the observations that are NOT being resampled,

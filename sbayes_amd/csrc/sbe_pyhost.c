@@ -121,7 +121,115 @@ static PyObject* py_touched_groups(PyObject* self, PyObject* args) {
     return PyLong_FromLong(rc);
 }
 
+/* ---- the bind cache's tokens (sbayes_amd/binding.py: _token / _same) -----------------------------------------------------
+ * scan(params, cached) -> (tokens, changed): for every state parameter (or plain array) of `params` its token
+ * (array, version) -- `param.value` if it has one, else the object itself, made an ndarray; `param.version` or None -- and in
+ * `changed` bit i set unless the token denotes what cached[i] = (array, version, private copy) | None recorded:
+ *   versioned parameters   same ndarray OBJECT and equal version (an in-place edit through the parameter API bumps the
+ *                          version, a copy-on-write edit creates a new ndarray; sbayes/sampling/state.py:34-61, 97-161, 340-350)
+ *   unversioned arrays     the same object, recorded without a copy because it was frozen and owned its data, and still so;
+ *                          otherwise compared by content against the private copy (the Python callback)
+ * Thirteen parameters per bind and five binds per MCMC step: as Python this was 13 us per bind (tools/host_residual.py). */
+static PyObject *s_value, *s_version, *s_flags, *s_writeable, *s_owndata;
+static PyObject *g_ndarray = NULL, *g_asarray = NULL, *g_content_equal = NULL;
+
+static PyObject* py_scan_setup(PyObject* self, PyObject* args) {
+    PyObject *nd, *asarr, *ceq;
+    if (!PyArg_ParseTuple(args, "OOO", &nd, &asarr, &ceq)) return NULL;
+    Py_XDECREF(g_ndarray); Py_XDECREF(g_asarray); Py_XDECREF(g_content_equal);
+    Py_INCREF(nd); Py_INCREF(asarr); Py_INCREF(ceq);
+    g_ndarray = nd; g_asarray = asarr; g_content_equal = ceq;
+    Py_RETURN_NONE;
+}
+
+/* 1 same, 0 differs, -1 error */
+static int token_same(PyObject* value, PyObject* version, PyObject* cached) {
+    if (cached == Py_None) return 0;
+    if (!PyTuple_Check(cached) || PyTuple_GET_SIZE(cached) != 3) { PyErr_SetString(PyExc_TypeError, "cached entry must be a 3-tuple or None"); return -1; }
+    PyObject* ref = PyTuple_GET_ITEM(cached, 0);
+    PyObject* ref_version = PyTuple_GET_ITEM(cached, 1);
+    PyObject* copy = PyTuple_GET_ITEM(cached, 2);
+    if (version != Py_None && ref_version != Py_None) {
+        if (value != ref) return 0;
+        return PyObject_RichCompareBool(version, ref_version, Py_EQ);
+    }
+    if (value == ref && copy == Py_None) {              /* recorded frozen: still frozen and owning its data? */
+        PyObject* flags = PyObject_GetAttr(value, s_flags);
+        if (!flags) return -1;
+        PyObject* w = PyObject_GetAttr(flags, s_writeable);
+        PyObject* o = w ? PyObject_GetAttr(flags, s_owndata) : NULL;
+        Py_DECREF(flags);
+        if (!w || !o) { Py_XDECREF(w); Py_XDECREF(o); return -1; }
+        const int wr = PyObject_IsTrue(w), own = PyObject_IsTrue(o);
+        Py_DECREF(w); Py_DECREF(o);
+        if (wr < 0 || own < 0) return -1;
+        return !wr && own;
+    }
+    if (copy == Py_None) return 0;
+    PyObject* r = PyObject_CallFunctionObjArgs(g_content_equal, value, copy, NULL);
+    if (!r) return -1;
+    const int eq = PyObject_IsTrue(r);
+    Py_DECREF(r);
+    return eq;
+}
+
+static PyObject* py_scan(PyObject* self, PyObject* args) {
+    PyObject *params, *cached;
+    if (!PyArg_ParseTuple(args, "OO", &params, &cached)) return NULL;
+    if (!g_ndarray) { PyErr_SetString(PyExc_RuntimeError, "scan_setup() not called"); return NULL; }
+    if (!PyList_Check(params) || !PyList_Check(cached) || PyList_GET_SIZE(params) != PyList_GET_SIZE(cached) || PyList_GET_SIZE(params) > 62) {
+        PyErr_SetString(PyExc_TypeError, "scan(params, cached): two lists of equal length (at most 62)");
+        return NULL;
+    }
+    const Py_ssize_t n = PyList_GET_SIZE(params);
+    PyObject* tokens = PyList_New(n);
+    if (!tokens) return NULL;
+    unsigned long long changed = 0;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* param = PyList_GET_ITEM(params, i);
+        PyObject *value, *version;
+        if ((PyObject*)Py_TYPE(param) == g_ndarray) {       /* a plain array (group matrix, concentration table): no version */
+            value = param; Py_INCREF(value);
+            version = Py_None; Py_INCREF(version);
+        } else {
+            value = PyObject_GetAttr(param, s_value);
+            if (!value) {
+                if (!PyErr_ExceptionMatches(PyExc_AttributeError)) goto fail;
+                PyErr_Clear();
+                value = param; Py_INCREF(value);
+            }
+            if ((PyObject*)Py_TYPE(value) != g_ndarray) {
+                PyObject* conv = PyObject_CallFunctionObjArgs(g_asarray, value, NULL);
+                Py_DECREF(value);
+                if (!conv) goto fail;
+                value = conv;
+            }
+            version = PyObject_GetAttr(param, s_version);
+            if (!version) {
+                if (!PyErr_ExceptionMatches(PyExc_AttributeError)) { Py_DECREF(value); goto fail; }
+                PyErr_Clear();
+                version = Py_None; Py_INCREF(version);
+            }
+        }
+        const int same = token_same(value, version, PyList_GET_ITEM(cached, i));
+        PyObject* tok = same < 0 ? NULL : PyTuple_Pack(2, value, version);
+        Py_DECREF(value); Py_DECREF(version);
+        if (!tok) goto fail;
+        PyList_SET_ITEM(tokens, i, tok);
+        if (!same) changed |= 1ull << i;
+    }
+    {
+        PyObject* r = Py_BuildValue("(NK)", tokens, changed);
+        return r;
+    }
+fail:
+    Py_DECREF(tokens);
+    return NULL;
+}
+
 static PyMethodDef methods[] = {
+    {"scan_setup", py_scan_setup, METH_VARARGS, "scan_setup(ndarray_type, asarray, content_equal)"},
+    {"scan", py_scan, METH_VARARGS, "scan(params, cached) -> (tokens, changed bitmask): the bind cache's token comparison"},
     {"addr", py_addr, METH_O, "buffer address of an array (any strides), as int"},
     {"subset_ids", py_subset_ids, METH_VARARGS, "ids of the listed objects for sbe_counts_delta (sbeh_subset_ids)"},
     {"diff_rows", py_diff_rows, METH_VARARGS, "rows of `new` differing from `mirror`, copied into it (sbeh_diff_rows)"},
@@ -130,4 +238,12 @@ static PyMethodDef methods[] = {
 
 static struct PyModuleDef moduledef = {PyModuleDef_HEAD_INIT, "_sbe_pyhost", "host-layer helpers of sbayes_amd (no device code)", -1, methods};
 
-PyMODINIT_FUNC PyInit__sbe_pyhost(void) { return PyModule_Create(&moduledef); }
+PyMODINIT_FUNC PyInit__sbe_pyhost(void) {
+    s_value = PyUnicode_InternFromString("value");
+    s_version = PyUnicode_InternFromString("version");
+    s_flags = PyUnicode_InternFromString("flags");
+    s_writeable = PyUnicode_InternFromString("writeable");
+    s_owndata = PyUnicode_InternFromString("owndata");
+    if (!s_value || !s_version || !s_flags || !s_writeable || !s_owndata) return NULL;
+    return PyModule_Create(&moduledef);
+}

@@ -631,15 +631,18 @@ class Engine:
                                                    self._i(touched), nt, self._o(diff)))
         return touched, diff
 
-    def set_counts_rows(self, slot, group_idx, rows):
-        """Rows `group_idx` (global group indices) of the slot's resident counts <- float32 rows [n, F, S]."""
+    def set_counts_rows(self, slot, group_idx, rows, update_probs=False):
+        """Rows `group_idx` (global group indices) of the slot's resident counts <- float32 rows [n, F, S].
+        update_probs=True: the probability rows of those groups are rebuilt in the same launch (untempered, like
+        update_probs(slot, c)); the components' tables must exist (update_probs once) -- afterwards they are current again."""
         gi = _as(group_idx, np.int32).reshape(-1)
         r = _c(rows, np.float32)
         if r.shape != (gi.size, self.n_features, self.n_states):
             raise ValueError(f"rows must be [{gi.size}, {self.n_features}, {self.n_states}], got {r.shape}")
         self._touch(slot)
         if gi.size:
-            self._check(self._lib.sbe_set_counts_rows(self._h, slot, self._i(gi), gi.size, self._i(r)))
+            fn = self._lib.sbe_set_counts_rows_probs if update_probs else self._lib.sbe_set_counts_rows
+            self._check(fn(self._h, slot, self._i(gi), gi.size, self._i(r)))
 
     def given_unchanged_lh(self, slot, i_cluster, objects, temperature=1.0, prior_temperature=1.0):
         """component_likelihood_given_unchanged (operators.py:863-928) of the sample bound to `slot` (groups, source,

@@ -132,8 +132,7 @@ def gibbs_sample_source(model, sample, object_subset=slice(None), temperature=1.
     _, sel = eng.sample_source(cur, new, objects, z, temperature, prior_temperature, sample_from_prior,
                                return_selected=True)
     eng.update_counts(new, cur, objects)
-    for c in range(eng.n_components):
-        eng.update_probs(new, c)
+    eng.update_probs(new, range(eng.n_components))          # (one call: adjacent components, one launch)
     _, sel_back = eng.source_logprob(new, cur, objects, temperature, prior_temperature, sample_from_prior,
                                      return_selected=True)
     valid = ~eng.na_values()[objects]

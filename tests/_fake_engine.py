@@ -277,8 +277,8 @@ class FakeEngine:
     def set_uniform_counts(self, unif_counts):
         self.unif = np.asarray(unif_counts, dtype=np.float64).copy()
 
-    def set_counts_rows(self, slot, group_idx, rows):
-        self._touch(slot)
+    def set_counts_rows(self, slot, group_idx, rows, update_probs=False):
+        self._touch(slot)                               # (update_probs: tables are derived on demand here)
         self.calls.append(("set_counts_rows", len(group_idx)))
         off = self.group_offsets
         for gg, row in zip(np.asarray(group_idx), np.asarray(rows, dtype=np.float32)):

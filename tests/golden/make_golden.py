@@ -1102,6 +1102,7 @@ def call_log_fixtures():
     sa = stage_config(Path("/root/reference/experiments/south_america"), "south_america_gibbs_calls")
     call_log_fixture("south_america", sa / "config.yaml", n_steps=60, seed=22, gibbs_source=True)
     call_log_fixture("headline", write_synthetic_config("headline"), n_steps=48, seed=24, gibbs_source=True)
+    call_log_fixture("cfg1", write_synthetic_config("cfg1"), n_steps=80, seed=23, gibbs_source=True)
 
 
 def main():
@@ -1115,7 +1116,8 @@ def main():
               "call_logs": call_log_fixtures, "overlap": overlap_fixture, "dynamic_prior": dynamic_prior_fixture,
               "gibbs_call_logs": lambda: (
                   call_log_fixture("south_america", stage_config(Path("/root/reference/experiments/south_america"), "south_america_gibbs_calls") / "config.yaml", 60, 22, True),
-                  call_log_fixture("headline", write_synthetic_config("headline"), 48, 24, True))}
+                  call_log_fixture("headline", write_synthetic_config("headline"), 48, 24, True),
+                  call_log_fixture("cfg1", write_synthetic_config("cfg1"), 80, 23, True))}
     if only:
         for name in only:
             single[name]()

@@ -33,7 +33,7 @@ def test_call_log_replays_on_the_double(tag):
     assert counts["set_groups"] < counts["cluster_marginals"] + counts["cluster_posterior_marginals"] + counts["source_posterior"]
 
 
-@pytest.mark.parametrize("tag", ["south_america_gibbs", "headline_gibbs"])
+@pytest.mark.parametrize("tag", ["south_america_gibbs", "headline_gibbs", "cfg1_gibbs"])
 def test_gibbs_source_call_log_replays_on_the_double(tag):
     """The logs recorded under patch.install(gibbs_source=True): GibbsSampleSource._propose's body as engine calls on slot
     state (copy_slot, sample_source with the uniforms regenerated from their recorded generator state, update_counts,

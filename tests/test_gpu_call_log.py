@@ -16,7 +16,7 @@ from tests.test_call_log_cpu import features_of
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("tag", ["test_files", "south_america", "cfg1", "headline", "south_america_gibbs", "headline_gibbs"])
+@pytest.mark.parametrize("tag", ["test_files", "south_america", "cfg1", "headline", "south_america_gibbs", "headline_gibbs", "cfg1_gibbs"])
 def test_recorded_sampler_calls_on_the_device(tag):
     feats = features_of(tag)
     counts, meta = replay(GOLDEN / f"{tag}_calls.npz", lambda n_groups: Engine(feats, n_groups, n_slots=4))

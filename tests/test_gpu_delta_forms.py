@@ -210,6 +210,53 @@ def test_fused_tables_same_bits(name):
         eng.close()
 
 
+@pytest.mark.parametrize("name", ["cfg1_fixture", "south_america", "headline", "wide"])
+def test_count_rows_with_their_probability_rows(name):
+    """set_counts_rows(update_probs=True) = set_counts_rows + update_probs of the touched components: the same counts,
+    the same probability tables bit for bit (and so the same likelihoods), one launch; refused while the tables of a
+    touched component do not exist."""
+    eng, fake, groups, source, counts = _pair(name)
+    try:
+        rng = np.random.default_rng(31)
+        C = len(groups)
+        off = eng.group_offsets
+        eng.copy_slot(1, 0)
+        idx, rows = [], []
+        for c in range(C):
+            for g in rng.choice(groups[c].shape[0], size=min(2, groups[c].shape[0]), replace=False):
+                idx.append(off[c] + int(g))
+                rows.append(rng.integers(0, 40, size=counts[c][g].shape).astype(np.float32))
+        idx, rows = np.asarray(idx, dtype=np.int32), np.stack(rows)
+        eng.set_counts_rows(0, idx, rows, update_probs=True)
+        eng.set_counts_rows(1, idx, rows)
+        eng.update_probs(1, range(C))
+        for c in range(C):
+            assert np.array_equal(eng.get_counts(0, c), eng.get_counts(1, c))
+            assert np.array_equal(eng.get_probs(0, c), eng.get_probs(1, c)), (name, c)
+        assert eng.mixture_loglik(0) == eng.mixture_loglik(1)                    # (the tile-transposed copies agree too)
+        assert np.array_equal(eng.likelihood_per_component(0), eng.likelihood_per_component(1))
+        # a row that normalises to nothing is reported like update_probs reports it
+        if name == "cfg1_fixture":
+            conc0 = np.array(fake.conc[0], dtype=np.float64, copy=True)
+            conc0[..., 0, :] = 0.0
+            eng.set_concentration(0, conc0)
+            eng.update_probs(0, 0)
+            with pytest.raises(Exception, match="(?i)normali"):
+                eng.set_counts_rows(0, [0], np.zeros((1,) + counts[0].shape[1:], dtype=np.float32), update_probs=True)
+                eng.sync()
+    finally:
+        eng.close()
+    # tables that were never built cannot be patched row-wise
+    feats, groups, conc, weights, source, counts, unif = _workload("cfg1_fixture")
+    with Engine(feats, [g.shape[0] for g in groups], n_slots=1) as fresh:
+        for c in range(len(groups)):
+            fresh.set_concentration(c, conc[c])
+            fresh.set_counts(0, c, counts[c])
+        with pytest.raises(Exception, match="sbe_update_probs first"):
+            fresh.set_counts_rows(0, [0], counts[0][:1], update_probs=True)
+        fresh.set_counts_rows(0, [0], counts[0][:1])                               # (the plain patch needs no tables)
+
+
 def test_argument_checks():
     eng, fake, groups, source, counts = _pair("cfg1_fixture")
     try:
