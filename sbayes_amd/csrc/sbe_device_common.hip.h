@@ -10,7 +10,6 @@ namespace sbe {
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 constexpr int kMaxComponents = 8;
-constexpr int kInlineTableStates = 128;   // fused table entries (probs_entry): NumPy's sum of up to 128 terms is one unrolled leaf
 constexpr int kMaxTuples = 64;
 constexpr uint16_t kNoGroup = 0xFFFF;
 constexpr uint8_t kNA = 0xFF;
@@ -130,6 +129,36 @@ __device__ __forceinline__ T np_block_sum(Get get, int lo, int n) {
     }
     T res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
     for (; i < n; ++i) res = res + get(lo + i);
+    return res;
+}
+
+// np_block_sum over a REGISTER array of capacity CAP (a multiple of 8, <= 128; n <= CAP): the same additions in the same
+// order, written as fully unrolled, guarded code so that `v` is never indexed dynamically.  Why it exists: a run-time trip
+// count makes every get(i) of the general form a load the loop waits for before the next iteration (and a dynamically
+// indexed array lives in scratch memory); the small table kernels of the drop-in path are chains of such waits -- a
+// 10-state row cost 9 us.  With the values loaded up front (all loads in flight together) the sum is arithmetic only.
+template <class T, int CAP>
+__device__ __forceinline__ T np_sum_regs(const T (&v)[CAP], int n) {
+    static_assert(CAP % 8 == 0 && CAP <= 128, "one NumPy leaf");
+    if (n < 8) {
+        T res = T(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (i < n) res = res + v[i];
+        return res;
+    }
+    T r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = v[j];
+#pragma unroll
+    for (int k = 1; k < CAP / 8; ++k)
+        if (8 * k + 8 <= n) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = r[j] + v[8 * k + j];
+        }
+    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    const int lim = n - (n % 8);
+#pragma unroll
+    for (int i = 8; i < CAP; ++i) if (i >= lim && i < n) res = res + v[i];
     return res;
 }
 

@@ -2247,7 +2247,7 @@ int sbe_cluster_marginals(sbe_engine* e, int slot, const float* table, const int
     const int32_t* d_obj = (const int32_t*)(e->d_io + tb);
     double* d_out = (double*)(e->d_io + tb + ob);
     const double inv = 1.0 / prior_temperature;
-    k_cluster_marginals<false><<<n_objects_av, kBlock, 0, e->stream>>>(
+    k_cluster_marginals<<<n_objects_av, kBlock, 0, e->stream>>>(
         e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np,
         e->d_probs + (int64_t)slot * e->table_elems(), d_tab, e->d_weights + (int64_t)slot * F * C,
         e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0, d_obj, n_objects_av, d_out,
@@ -2289,7 +2289,7 @@ int sbe_jump_lh(sbe_engine* e, int slot, const float* pconf, const float* p_sour
     memcpy(e->h_io + cb + tb, p_target, fs);
     memcpy(e->h_io + cb + 2 * tb, objects, (size_t)n_members * sizeof(int32_t));
     const double inv = 1.0 / prior_temperature;
-    k_jump_lh<false><<<n_members, kBlock, 0, e->stream>>>(
+    k_jump_lh<<<n_members, kBlock, 0, e->stream>>>(
         e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np,
         (const float*)e->d_io, (const float*)(e->d_io + cb), (const float*)(e->d_io + cb + tb),
         e->d_weights + (int64_t)slot * F * C, e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0,
@@ -2892,13 +2892,12 @@ int sbe_cluster_posterior_marginals(sbe_engine* e, int slot, int i_cluster, doub
     HIPCHK(e, hipSetDevice(e->device));
     if (s.patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
     const int64_t fs = (int64_t)F * S;
-    const bool fused = S <= kInlineTableStates && e->opt_fuse_tables;   // (beyond: NumPy's sum recursion keeps frames in scratch memory)
-    float* d_tab = nullptr;
-    if (!fused) {
-        rc = ensure_scratch(e, (size_t)fs * sizeof(float));
-        if (rc) return rc;
-        d_tab = (float*)e->d_scratch;
-    }
+    // the candidate table: conditional_effect_mean(prior, counts[[i_cluster]], unif, T_prior, T) (operators.py:1046-1052)
+    // from the slot's resident counts -- nothing table-sized crosses PCIe.  Fused form (k_cluster_marginals_ws): builder
+    // waves of every block put it into LDS while the block's object waves run their load chains; otherwise -- table beyond
+    // 64 KB, more than kWsC components, SBE_OPT_FUSE_TABLES off -- a table kernel in front of the block-per-object kernel.
+    const size_t cand_bytes = (size_t)fs * sizeof(float);
+    const bool fused = e->opt_fuse_tables && C <= kWsC && cand_bytes <= ((size_t)64 << 10);
     const size_t ob = al256((size_t)n_objects_av * sizeof(int32_t));
     const size_t out_bytes = (size_t)2 * n_objects_av * sizeof(double);
     rc = ensure_io(e, ob + out_bytes);
@@ -2906,30 +2905,36 @@ int sbe_cluster_posterior_marginals(sbe_engine* e, int slot, int i_cluster, doub
     memcpy(e->h_io, objects, (size_t)n_objects_av * sizeof(int32_t));
     rc = clear_status_word(e, ST_BAD_NORMALIZE);
     if (rc) return rc;
-    // the candidate table: conditional_effect_mean(prior, counts[[i_cluster]], unif, T_prior, T) (operators.py:1046-1052)
-    // from the slot's resident counts -- nothing table-sized crosses PCIe.  Fused form: every thread of the marginals
-    // kernel builds the one entry it reads (probs_entry: same operations, same bits); otherwise a table kernel in front.
     const int32_t* cnt = e->d_counts + (int64_t)slot * e->table_elems();
-    InlineTables tin{};
+    const double inv = 1.0 / prior_temperature;
+    DoneSig done;
     if (fused) {
+        InlineTables tin{};
         tin.row[0] = RowSource{cnt + (int64_t)i_cluster * fs, e->d_conc + (int64_t)i_cluster * fs};
         tin.unif = e->d_unif_res; tin.temperature = temperature; tin.prior_temperature = prior_temperature; tin.status = e->d_status;
+        tin.n_rows = F;
+        const unsigned blocks = (unsigned)div_up(n_objects_av, kWsObjWaves);
+        done = next_done(e, blocks);
+        k_cluster_marginals_ws<<<blocks, kWsBlock, cand_bytes, e->stream>>>(
+            e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np,
+            e->d_probs + (int64_t)slot * e->table_elems(), e->d_weights + (int64_t)slot * F * C,
+            e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0, (const int32_t*)e->d_io, n_objects_av,
+            (double*)(e->d_io + ob), reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C, e->Fp, done, tin);
     } else {
+        rc = ensure_scratch(e, cand_bytes);
+        if (rc) return rc;
+        float* d_tab = (float*)e->d_scratch;
         k_probs<int32_t><<<div_up((int64_t)F, 256), 256, 0, e->stream>>>(
             cnt, e->d_conc, e->d_unif_res, d_tab, i_cluster, i_cluster + 1, F, S,
             temperature, prior_temperature, 1, e->d_status, -(int64_t)i_cluster * fs);
         HIPCHK(e, hipGetLastError());
-    }
-    const double inv = 1.0 / prior_temperature;
-    const DoneSig done = next_done(e, (unsigned)n_objects_av);
-    auto launch = [&](auto kernel) {
-        kernel<<<n_objects_av, kBlock, 0, e->stream>>>(
+        done = next_done(e, (unsigned)n_objects_av);
+        k_cluster_marginals<<<n_objects_av, kBlock, 0, e->stream>>>(
             e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np,
             e->d_probs + (int64_t)slot * e->table_elems(), d_tab, e->d_weights + (int64_t)slot * F * C,
             e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0, (const int32_t*)e->d_io, n_objects_av,
-            (double*)(e->d_io + ob), reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C, e->Fp, done, tin);
-    };
-    if (fused) launch(k_cluster_marginals<true>); else launch(k_cluster_marginals<false>);
+            (double*)(e->d_io + ob), reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C, e->Fp, done);
+    }
     HIPCHK(e, hipGetLastError());
     rc = sync_and_report(e, done);
     if (rc) return rc;
@@ -2957,15 +2962,12 @@ int sbe_jump_lh_resident(sbe_engine* e, int slot, int i_source, int i_target, do
     if (s.patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
     const int64_t fs = (int64_t)F * S;
     const int n_conf = e->Gtot - K;
-    const bool fused = S <= kInlineTableStates && e->opt_fuse_tables;
-    float *d_ps = nullptr, *d_pt = nullptr, *d_pc = nullptr;
-    if (!fused) {
-        rc = ensure_scratch(e, (size_t)(2 + std::max(n_conf, 1)) * fs * sizeof(float));
-        if (rc) return rc;
-        d_ps = (float*)e->d_scratch;
-        d_pt = d_ps + fs;
-        d_pc = d_pt + fs;
-    }
+    // tempered tables of the two clusters and of every confounder group (ClusterEffectProposals.posterior_counts +
+    // normalize, operators.py:1254-1259, 1364-1371) from the slot's resident counts; the reference uses the CLUSTER
+    // prior's uniform concentration for every component (operators.py:1352).  Fused form (k_jump_lh_ws): builder waves
+    // put them into LDS, one launch; otherwise (tables beyond 64 KB, C > kWsC, option off) three table kernels in front.
+    const size_t built_bytes = (size_t)(2 + n_conf) * fs * sizeof(float);
+    const bool fused = e->opt_fuse_tables && C <= kWsC && built_bytes <= ((size_t)64 << 10);
     const size_t ob = al256((size_t)n_members * sizeof(int32_t));
     const size_t out_bytes = (size_t)2 * n_members * sizeof(double);
     rc = ensure_io(e, ob + out_bytes);
@@ -2973,18 +2975,29 @@ int sbe_jump_lh_resident(sbe_engine* e, int slot, int i_source, int i_target, do
     memcpy(e->h_io, objects, (size_t)n_members * sizeof(int32_t));
     rc = clear_status_word(e, ST_BAD_NORMALIZE);
     if (rc) return rc;
-    // tempered tables of the two clusters and of every confounder group (ClusterEffectProposals.posterior_counts +
-    // normalize, operators.py:1254-1259, 1364-1371) from the slot's resident counts; the reference uses the CLUSTER
-    // prior's uniform concentration for every component (operators.py:1352).  Fused form: the entries are built where they
-    // are read (probs_entry), one launch; otherwise three table kernels in front.
     const int32_t* cnt = e->d_counts + (int64_t)slot * e->table_elems();
-    InlineTables tin{};
+    const double inv = 1.0 / prior_temperature;
+    DoneSig done;
     if (fused) {
+        InlineTables tin{};
         tin.row[0] = RowSource{cnt + (int64_t)i_source * fs, e->d_conc + (int64_t)i_source * fs};
         tin.row[1] = RowSource{cnt + (int64_t)i_target * fs, e->d_conc + (int64_t)i_target * fs};
-        tin.counts = cnt; tin.conc = e->d_conc; tin.unif = e->d_unif_res;
-        tin.temperature = temperature; tin.prior_temperature = prior_temperature; tin.status = e->d_status; tin.n_groups_total = e->Gtot;
+        tin.counts = cnt; tin.conc = e->d_conc; tin.first_conf_group = K;
+        tin.unif = e->d_unif_res; tin.temperature = temperature; tin.prior_temperature = prior_temperature; tin.status = e->d_status;
+        tin.n_rows = (2 + n_conf) * F;
+        const unsigned blocks = (unsigned)div_up(n_members, kWsObjWaves);
+        done = next_done(e, blocks);
+        k_jump_lh_ws<<<blocks, kWsBlock, built_bytes, e->stream>>>(
+            e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np,
+            e->d_weights + (int64_t)slot * F * C, e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0,
+            (const int32_t*)e->d_io, n_members, (double*)(e->d_io + ob), reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C,
+            e->Fp, K, done, tin);
     } else {
+        rc = ensure_scratch(e, (size_t)(2 + std::max(n_conf, 1)) * fs * sizeof(float));
+        if (rc) return rc;
+        float* d_ps = (float*)e->d_scratch;
+        float* d_pt = d_ps + fs;
+        float* d_pc = d_pt + fs;
         k_probs<int32_t><<<div_up((int64_t)F, 256), 256, 0, e->stream>>>(cnt, e->d_conc, e->d_unif_res, d_ps, i_source, i_source + 1, F, S,
             temperature, prior_temperature, 1, e->d_status, -(int64_t)i_source * fs);
         HIPCHK(e, hipGetLastError());
@@ -2996,17 +3009,13 @@ int sbe_jump_lh_resident(sbe_engine* e, int slot, int i_source, int i_target, do
                 temperature, prior_temperature, 1, e->d_status, -(int64_t)K * fs);
             HIPCHK(e, hipGetLastError());
         }
-    }
-    const double inv = 1.0 / prior_temperature;
-    const DoneSig done = next_done(e, (unsigned)n_members);
-    auto launch = [&](auto kernel) {
-        kernel<<<n_members, kBlock, 0, e->stream>>>(
+        done = next_done(e, (unsigned)n_members);
+        k_jump_lh<<<n_members, kBlock, 0, e->stream>>>(
             e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np, d_pc, d_ps, d_pt,
             e->d_weights + (int64_t)slot * F * C, e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0,
             (const int32_t*)e->d_io, n_members, (double*)(e->d_io + ob), reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C,
-            e->Fp, K, done, tin);
-    };
-    if (fused) launch(k_jump_lh<true>); else launch(k_jump_lh<false>);
+            e->Fp, K, done);
+    }
     HIPCHK(e, hipGetLastError());
     rc = sync_and_report(e, done);
     if (rc) return rc;

@@ -275,59 +275,82 @@ __global__ void k_f32_to_i32(const float* __restrict__ in, int32_t* __restrict__
 // ------------------------------------------------------------------------------------------
 // One table row of normalize(counts / T + prior') -> float32 (util.py:990-1007, conditionals.py:105-122): the S states
 // summed in NumPy's pairwise order.  `cnt(s)` = the count as the reference's float32; `unif_row` null: prior untempered.
-template <class GetCount, class Emit>
+// The two divisions that temper a row are exact no-ops at temperature 1 (x / 1 = x in IEEE arithmetic) and are skipped
+// there -- a correctly rounded fp64 division is a chain of a dozen dependent instructions, and a row has 2 S + S of them
+// otherwise; every table kernel is a latency chain of such rows.  The additions stay (u + (a - u) is not always a).
+#ifdef SBE_WS_CLOCK
+__device__ uint64_t g_probs_row_clk[4];      // (debug build: wall-clock stamps of the last probs_row, any thread)
+#endif
+// S <= CAP: the row's S posterior values are computed once into registers -- the 3 S loads issued together, the tempering
+// divisions independent of each other -- summed by np_sum_regs and divided; beyond CAP the general form (values recomputed
+// per pass, NumPy's recursion for S > 128).  Same operations on the same operands in the same order either way.
+template <int CAP = 16, class GetCount, class Emit>
 __device__ __forceinline__ void probs_row(GetCount cnt, const double* __restrict__ conc_row, const double* __restrict__ unif_row,
                                           int S, double temperature, double prior_temperature, int* __restrict__ status, Emit emit) {
-    const bool tempered = temperature > 0.0;
-    const bool prior_tempered = prior_temperature > 0.0 && unif_row != nullptr;
+    const bool tempered = temperature > 0.0 && temperature != 1.0;
+    const bool prior_shaped = prior_temperature > 0.0 && unif_row != nullptr;
+    const bool prior_tempered = prior_shaped && prior_temperature != 1.0;
     const float t32 = (float)temperature;
+    if (S <= CAP) {
+        float c[CAP];
+        double a[CAP], u[CAP], pv[CAP];
+#pragma unroll
+        for (int s = 0; s < CAP; ++s) {
+            const bool on = s < S;
+            c[s] = on ? cnt(s) : 0.0f;
+            a[s] = on ? conc_row[s] : 0.0;
+            u[s] = (on && prior_shaped) ? unif_row[s] : 0.0;
+        }
+#ifdef SBE_WS_CLOCK
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        g_probs_row_clk[0] = wall_clock64();
+#endif
+#pragma unroll
+        for (int s = 0; s < CAP; ++s) {
+            float cs = c[s];
+            if (tempered) cs = cs / t32;
+            double as = a[s];
+            if (prior_shaped) {
+                const double d = as - u[s];
+                as = u[s] + (prior_tempered ? d / prior_temperature : d);
+            }
+            pv[s] = (double)cs + as;
+        }
+        const double total = np_sum_regs<double, CAP>(pv, S);
+#ifdef SBE_WS_CLOCK
+        g_probs_row_clk[1] = wall_clock64() + (total > 1e300 ? 1 : 0);
+#endif
+        if (status && !(total > 0.0)) raise_status(status, ST_BAD_NORMALIZE, 1);     // (null: another block reports the row)
+#pragma unroll
+        for (int s = 0; s < CAP; ++s) if (s < S) emit(s, (float)(pv[s] / total));
+#ifdef SBE_WS_CLOCK
+        g_probs_row_clk[2] = wall_clock64();
+#endif
+        return;
+    }
     auto post = [&](int s) -> double {
         float c = cnt(s);
         if (tempered) c = c / t32;
         double a = conc_row[s];
-        if (prior_tempered) {
+        if (prior_shaped) {
             const double u = unif_row[s];
-            a = u + (a - u) / prior_temperature;
+            const double d = a - u;
+            a = u + (prior_tempered ? d / prior_temperature : d);
         }
         return (double)c + a;
     };
     const double total = np_pairwise_sum<double>(post, S);
-    if (!(total > 0.0)) raise_status(status, ST_BAD_NORMALIZE, 1);
+    if (status && !(total > 0.0)) raise_status(status, ST_BAD_NORMALIZE, 1);
     for (int s = 0; s < S; ++s) emit(s, (float)(post(s) / total));
 }
 
-// The inputs of one tempered table row, resident in device memory: what a consumer kernel needs to build the ONE entry
-// it reads itself instead of waiting for a k_probs launch in front of it (one launch per drop-in call: VERDICT r3 item 4).
+// The inputs of one tempered table row, resident in device memory: what a consumer kernel needs to build the rows it
+// reads itself -- once per block, into LDS -- instead of waiting for a k_probs launch in front of it (one launch per
+// drop-in call: VERDICT r3 item 4).
 struct RowSource {
     const int32_t* counts;           // [F][S] integer counts of the row's group (the slot's resident table row)
     const double* conc;              // [F][S] concentration of that group
 };
-
-// probs_row's value for state x alone, same operations in the same order (the S-term NumPy sum, then ONE division):
-// bit for bit the entry k_probs would have stored.  The row's sum is taken -- and checked -- whatever x is, like the
-// table kernel does for every row; x == kNA returns 1 (the caller's value for an unobserved feature).  `check`: this
-// thread is the one that reports the row (every block sees the same rows: one of them counts, so that the number of bad
-// rows in the error message is the table kernel's).
-__device__ __forceinline__ float probs_entry(const int32_t* __restrict__ cnt_row, const double* __restrict__ conc_row,
-                                             const double* __restrict__ unif_row, int S, double temperature,
-                                             double prior_temperature, int* __restrict__ status, uint8_t x, bool check) {
-    const bool tempered = temperature > 0.0;
-    const bool prior_tempered = prior_temperature > 0.0 && unif_row != nullptr;
-    const float t32 = (float)temperature;
-    auto post = [&](int s) -> double {
-        float c = (float)cnt_row[s];
-        if (tempered) c = c / t32;
-        double a = conc_row[s];
-        if (prior_tempered) {
-            const double u = unif_row[s];
-            a = u + (a - u) / prior_temperature;
-        }
-        return (double)c + a;
-    };
-    const double total = np_pairwise_sum<double>(post, S);
-    if (check && !(total > 0.0)) raise_status(status, ST_BAD_NORMALIZE, 1);
-    return x == kNA ? 1.0f : (float)(post(x) / total);
-}
 
 template <class TC>
 __global__ void k_probs(const TC* __restrict__ counts, const double* __restrict__ conc,
@@ -794,30 +817,95 @@ __device__ __forceinline__ void weight_tables_z_row(const float* __restrict__ w,
     for (int c = 0; c < C; ++c) { wc[c] = powd(c) / tot2; wf[c] = fl(c) / tot3; }
 }
 
+// Tables a resident operator call builds for itself (sbe_cluster_posterior_marginals, sbe_jump_lh_resident; one launch per
+// call): k_cluster_marginals_ws / k_jump_lh_ws below.  A block is 16 waves with two jobs.  Waves
+// 0..3 each take one object and run its dependent load chain -- object id over PCIe, group ids and pattern, state bytes,
+// the other components' table entries, the weight rows -- keeping what they loaded in registers.  Waves 4..15 meanwhile
+// build the call's tables into LDS, thread <-> table row (probs_row: k_probs' arithmetic, the same bits, the same data
+// checks; block 0 reports them).  One barrier joins the two, then the object waves look their entries up in LDS and
+// finish.  The table build runs UNDER the load chain instead of in front of it, and nothing crosses a block.
+// Measured forms that lost (profiles/r4/fused_operator_forms.log): every thread building the entry it reads (587
+// redundant builds: 23 us); one table per block with a wave per object, build first (a serial chain: 25 us); builder
+// BLOCKS with a device-wide flag the other blocks wait on (agent-scope acquire / release across the eight XCD L2s:
+// 21 us at 8 objects, 45 us at 587); the table kernel in front costs 6 us + a launch gap on top of the 9.5 us consumer.
+struct InlineTables {
+    RowSource row[2];                // candidate cluster (marginals) / source and target cluster (jump)
+    const int32_t* counts;           // the slot's whole [Gtot][F][S] count table (jump: confounder rows)
+    const double* conc;              // [Gtot][F][S]
+    const double* unif;              // [F][S] the cluster prior's uniform concentration
+    double temperature, prior_temperature;
+    int* status;
+    int n_rows;                      // table rows = (1 or 2 + confounder groups) * F
+    int first_conf_group;            // jump: rows 2 F.. are the groups first_conf_group.. in order
+};
+constexpr int kWsObjWaves = 4, kWsWaves = 16, kWsBlock = kWsWaves * kWave, kWsC = 4;   // (object waves; components held in registers)
+
+// Builder waves of a wave-specialised operator kernel: rows (wave - kWsObjWaves) * 64 + lane, + 768, ... into `built` (LDS).
+__device__ __forceinline__ void ws_build_rows(const InlineTables& tin, float* __restrict__ built, int F, int S) {
+    for (int t = (int)threadIdx.x - kWsObjWaves * kWave; t < tin.n_rows; t += kWsBlock - kWsObjWaves * kWave) {
+        const int r = t / F, f = t % F;
+        const int32_t* cnt;
+        const double* conc;
+        if (r < 2 && tin.row[r].counts) { cnt = tin.row[r].counts + (int64_t)f * S; conc = tin.row[r].conc + (int64_t)f * S; }
+        else {
+            const int64_t ro = ((int64_t)(tin.first_conf_group + r - 2) * F + f) * S;
+            cnt = tin.counts + ro; conc = tin.conc + ro;
+        }
+        float* row = built + (int64_t)t * S;
+        probs_row([&](int s) { return (float)cnt[s]; }, conc, tin.unif + (int64_t)f * S, S, tin.temperature, tin.prior_temperature,
+                  blockIdx.x == 0 ? tin.status : nullptr, [&](int s, float v) { row[s] = v; });
+    }
+}
+
+// The same row computed in REGISTERS (C <= CM < 8: NumPy's sum of fewer than eight terms is the plain left-to-right chain):
+// the C weights are loaded once, together, and every intermediate is a statically indexed register.  The general form
+// above reads w[c] from memory inside loops with a run-time trip count -- a dozen loads, each waited for before the
+// next -- which was 11 of the 19 us of the fused marginals kernel (profiles/r4/ws_kernel_clock.log).  Same arithmetic.
+template <int CM>
+__device__ __forceinline__ void weight_tables_z_row_reg(const float* __restrict__ w, uint32_t bits, int C, float inv_tp, int use_pow,
+                                                        float (&wc)[CM], float (&wf)[CM]) {
+    static_assert(CM < 8, "sequential NumPy sum");
+    const uint32_t fbits = bits ^ 1u;
+    float wr[CM], m[CM], pd[CM], fl[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) wr[c] = c < C ? w[c] : 0.0f;
+    float tot = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        m[c] = ((bits >> c) & 1u) ? wr[c] : 0.0f * wr[c];
+        if (c < C) tot = tot + m[c];
+    }
+    float tot2 = 0.0f, tot3 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        const float a = m[c] / tot;
+        pd[c] = use_pow ? powf(a, inv_tp) : a;
+        if (c < C) tot2 = tot2 + pd[c];
+    }
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        const float pw = use_pow ? powf(wr[c], inv_tp) : wr[c];
+        fl[c] = ((fbits >> c) & 1u) ? pw : 0.0f * pw;
+        if (c < C) tot3 = tot3 + fl[c];
+    }
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        wc[c] = c < C ? pd[c] / tot2 : 0.0f;
+        wf[c] = c < C ? fl[c] / tot3 : 0.0f;
+    }
+}
+
 // One BLOCK per available object, thread <-> feature: the with/without weight row of the object's pattern is
 // computed in place (no table kernel in front), a lane's loads (state byte, weights, table entries of every
 // component) are all in flight together and there is one dependent-load chain per object instead of one per
 // 64 features; the two fp64 logs per observation are table-driven (tab_log_pos; the sums of logs carry far more
 // accuracy than the reference's linear-space products).  Fixed-order block reduction: deterministic.
-// kInline: the candidate table is not read from `table0` but built entry by entry from the cluster's resident counts
-// (`tin`: conditional_effect_mean, probs_entry) -- the call needs no table kernel in front (sbe_cluster_posterior_marginals).
-struct InlineTables {
-    RowSource row[2];                // candidate cluster (k_cluster_marginals) / source and target cluster (k_jump_lh)
-    const int32_t* counts;           // the slot's whole [Gtot][F][S] count table (k_jump_lh: confounder rows)
-    const double* conc;              // [Gtot][F][S]
-    const double* unif;              // [F][S] the cluster prior's uniform concentration
-    double temperature, prior_temperature;
-    int* status;
-    int n_groups_total;
-};
-
-template <bool kInline>
 __global__ __launch_bounds__(kBlock) void k_cluster_marginals(
     const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid, const uint8_t* __restrict__ pid,
     const float* __restrict__ probs, const float* __restrict__ table0, const float* __restrict__ weights,
     const uint32_t* __restrict__ pattern_bits, float inv_tp, int use_pow, const int32_t* __restrict__ objects,
     int n_av, double* __restrict__ out, const f64x2_t* __restrict__ logtab, int Np, int F, int S, int C, int Fp,
-    DoneSig done = DoneSig{}, InlineTables tin = InlineTables{}) {
+    DoneSig done = DoneSig{}) {
     __shared__ f64x2_t tab[kLogTabEntries];
     __shared__ double red[8];
     if (threadIdx.x < kLogTabEntries) tab[threadIdx.x] = logtab[threadIdx.x];
@@ -832,16 +920,11 @@ __global__ __launch_bounds__(kBlock) void k_cluster_marginals(
         const uint8_t x = state[(int64_t)n * Fp + f];
         float wc[kMaxComponents], wf[kMaxComponents];
         weight_tables_z_row(weights + (int64_t)f * C, bits, C, inv_tp, use_pow, wc, wf);   // this object's pattern
-        float t0 = 1.0f;
-        if constexpr (kInline)
-            t0 = probs_entry(tin.row[0].counts + (int64_t)f * S, tin.row[0].conc + (int64_t)f * S, tin.unif + (int64_t)f * S, S,
-                             tin.temperature, tin.prior_temperature, tin.status, x, blockIdx.x == 0);
-        else if (x != kNA) t0 = table0[(int64_t)f * S + x];
         double v0 = 0.0, v1 = 0.0;
         for (int c = 0; c < C; ++c) {
             double lh = 1.0;
             if (x != kNA) {
-                if (c == 0) lh = (double)t0;
+                if (c == 0) lh = (double)table0[(int64_t)f * S + x];
                 else {
                     const uint16_t gg = gid[(int64_t)c * Np + n];
                     lh = gg == kNoGroup ? 0.0 : (double)probs[((int64_t)gg * F + f) * S + x];
@@ -866,6 +949,133 @@ __global__ __launch_bounds__(kBlock) void k_cluster_marginals(
     signal_done(done);
 }
 
+// The same marginals with the candidate table built by the block's builder waves (InlineTables above;
+// sbe_cluster_posterior_marginals).  An object wave holds, per lane, the four features the four waves of the block form
+// above would have given that lane (w * 64 + lane, + 256 k beyond), keeps the block form's four accumulators and reduces
+// them by the same wave tree in the same order: the result is that form's bit for bit.  C <= kWsC.
+__global__ __launch_bounds__(kWsBlock) void k_cluster_marginals_ws(
+    const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid, const uint8_t* __restrict__ pid,
+    const float* __restrict__ probs, const float* __restrict__ weights, const uint32_t* __restrict__ pattern_bits, float inv_tp,
+    int use_pow, const int32_t* __restrict__ objects, int n_av, double* __restrict__ out, const f64x2_t* __restrict__ logtab,
+    int Np, int F, int S, int C, int Fp, DoneSig done, InlineTables tin) {
+    __shared__ f64x2_t tab[kLogTabEntries];
+    extern __shared__ float cand[];                                          // the candidate table [F][S]
+#ifdef SBE_WS_CLOCK
+    const uint64_t t_start = wall_clock64();
+    uint64_t t_p0 = 0, t_bar = 0, t_a = 0, t_b = 0, t_c = 0;
+#define WS_STAMP(v) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); v = wall_clock64(); } while (0)
+#else
+#define WS_STAMP(v) do { } while (0)
+#endif
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
+    const int i = blockIdx.x * kWsObjWaves + wid;
+    const bool object_wave = wid < kWsObjWaves, active = object_wave && i < n_av;
+    uint8_t x[4];
+    float lhc[4][kWsC], wc[4][kWsC], wf[4][kWsC];
+    int n = 0;
+    bool inside = false;
+    uint32_t bits = 0;
+    uint16_t gg[kWsC];
+    // one (object, feature): the other components' entries and the weight rows, into registers
+    auto fetch = [&](int f, uint8_t xx, float (&l)[kWsC], float (&a)[kWsC], float (&b)[kWsC]) {
+        weight_tables_z_row_reg<kWsC>(weights + (int64_t)f * C, bits, C, inv_tp, use_pow, a, b);   // this object's pattern
+#pragma unroll
+        for (int c = 0; c < kWsC; ++c) {
+            l[c] = 1.0f;
+            if (c >= 1 && c < C && xx != kNA) l[c] = gg[c] == kNoGroup ? 0.0f : probs[((int64_t)gg[c] * F + f) * S + xx];
+        }
+    };
+    if (!object_wave) {
+        if (wid == kWsObjWaves) { tab[lane] = logtab[lane]; tab[lane + kWave] = logtab[lane + kWave]; }     // (kLogTabEntries = 128)
+        ws_build_rows(tin, cand, F, S);
+    } else if (active) {
+        n = objects[i];
+        WS_STAMP(t_a);
+        inside = gid[n] != kNoGroup;                                         // component 0 = clusters
+        bits = pattern_bits[pid[n]];
+#pragma unroll
+        for (int c = 0; c < kWsC; ++c) gg[c] = (c >= 1 && c < C) ? gid[(int64_t)c * Np + n] : kNoGroup;
+        WS_STAMP(t_b);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int f = w * kWave + lane;
+            x[w] = f < F ? state[(int64_t)n * Fp + f] : kNA;
+        }
+        WS_STAMP(t_c);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int f = w * kWave + lane;
+            if (f < F) fetch(f, x[w], lhc[w], wc[w], wf[w]);
+        }
+    }
+#ifdef SBE_WS_CLOCK
+    __shared__ double clk[4];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    t_p0 = wall_clock64();
+    if (wid == kWsObjWaves && lane == 0) {
+        clk[0] = (double)(t_p0 - t_start);
+        clk[1] = (double)(g_probs_row_clk[0] - t_start); clk[2] = (double)(g_probs_row_clk[1] - t_start); clk[3] = (double)(g_probs_row_clk[2] - t_start);
+    }
+#endif
+    __syncthreads();
+#ifdef SBE_WS_CLOCK
+    t_bar = wall_clock64();
+#endif
+    if (active) {
+        const uint32_t tab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) f64x2_t*)tab;
+        auto term = [&](const float (&l)[kWsC], const float (&a)[kWsC], const float (&b)[kWsC], double& acc0, double& acc1) {
+            double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+            for (int c = 0; c < kWsC; ++c) {
+                if (c < C) {
+                    const double lh = (double)l[c], wa = (double)a[c], wb = (double)b[c];
+                    v1 = v1 + lh * (inside ? wa : wb);   // z = 1: the object is (or becomes) a cluster member
+                    v0 = v0 + lh * (inside ? wb : wa);
+                }
+            }
+            acc0 += tab_log_pos(v0, tab_addr);
+            acc1 += tab_log_pos(v1, tab_addr);
+        };
+        double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int f = w * kWave + lane;
+            if (f < F) {
+                lhc[w][0] = x[w] != kNA ? cand[(int64_t)f * S + x[w]] : 1.0f;
+                term(lhc[w], wc[w], wf[w], a0[w], a1[w]);
+            }
+        }
+        for (int fb = kBlock; fb < F; fb += kBlock) {                        // (F > 256: the block form's later passes, in order)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int f = fb + w * kWave + lane;
+                if (f < F) {
+                    const uint8_t xx = state[(int64_t)n * Fp + f];
+                    float l[kWsC], a[kWsC], b[kWsC];
+                    fetch(f, xx, l, a, b);
+                    l[0] = xx != kNA ? cand[(int64_t)f * S + xx] : 1.0f;
+                    term(l, a, b, a0[w], a1[w]);
+                }
+            }
+        }
+        double r0[4], r1[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { r0[w] = wave_sum(a0[w]); r1[w] = wave_sum(a1[w]); }
+        if (lane == 0) {
+            out[i] = (r0[0] + r0[1]) + (r0[2] + r0[3]);
+            out[(int64_t)n_av + i] = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+        }
+#ifdef SBE_WS_CLOCK
+        if (blockIdx.x == 0 && wid == 0 && lane == 0 && n_av >= 8) {
+            out[0] = (double)(t_p0 - t_start); out[1] = clk[0]; out[2] = (double)(t_bar - t_start); out[3] = (double)(wall_clock64() - t_start);
+            out[4] = (double)(t_a - t_start); out[5] = (double)(t_b - t_start); out[6] = (double)(t_c - t_start);
+            out[7] = clk[1]; out[8 % n_av] = clk[2]; out[9 % n_av] = clk[3];
+        }
+#endif
+    }
+    signal_done(done);
+}
+
 // ------------------------------------------------------------------------------------------
 // ClusterJump.get_jump_lh (sbayes/sampling/operators.py:1679-1722) with
 // ClusterEffectProposals.expected_confounder_features (:1342-1379): for every member n of the source cluster
@@ -880,16 +1090,13 @@ __global__ __launch_bounds__(kBlock) void k_cluster_marginals(
 // `p_target` the two clusters' tempered tables (conditional_effect_mean, conditionals.py:105-122).
 // One block per member, thread <-> feature, fixed-order reduction (as k_cluster_marginals).
 // ------------------------------------------------------------------------------------------
-// kInline: the tempered tables are built entry by entry from the slot's resident counts (`tin`; sbe_jump_lh_resident:
-// one launch instead of three table kernels + this one); the rows are checked like k_probs checks them, NA or not.
-template <bool kInline>
 __global__ __launch_bounds__(kBlock) void k_jump_lh(
     const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid, const uint8_t* __restrict__ pid,
     const float* __restrict__ pconf /* [Gtot - G0][F][S] */, const float* __restrict__ p_source,
     const float* __restrict__ p_target, const float* __restrict__ weights, const uint32_t* __restrict__ pattern_bits,
     float inv_tp, int use_pow, const int32_t* __restrict__ objects, int n_members, double* __restrict__ out,
     const f64x2_t* __restrict__ logtab, int Np, int F, int S, int C, int Fp, int G0,
-    DoneSig done = DoneSig{}, InlineTables tin = InlineTables{}) {
+    DoneSig done = DoneSig{}) {
     __shared__ f64x2_t tab[kLogTabEntries];
     __shared__ double red[8];
     if (threadIdx.x < kLogTabEntries) tab[threadIdx.x] = logtab[threadIdx.x];
@@ -901,40 +1108,16 @@ __global__ __launch_bounds__(kBlock) void k_jump_lh(
     double acc0 = 0.0, acc1 = 0.0;
     for (int f = threadIdx.x; f < F; f += kBlock) {
         const uint8_t x = state[(int64_t)n * Fp + f];
-        if constexpr (!kInline) { if (x == kNA) continue; }           // np.prod(..., where=~NAs): factor 1
+        if (x == kNA) continue;                                       // np.prod(..., where=~NAs): factor 1
         float wc[kMaxComponents], wf[kMaxComponents];
         weight_tables_z_row(weights + (int64_t)f * C, bits, C, inv_tp, use_pow, wc, wf);   // wc = weights_heated row
-        float pc = 0.0f, e_src, e_tgt;
-        if constexpr (kInline) {
-            const int64_t fo = (int64_t)f * S;
-            for (int c = 1; c < C; ++c) {
-                const uint16_t gg = gid[(int64_t)c * Np + n];
-                if (gg == kNoGroup) continue;
-                const int64_t ro = ((int64_t)gg * F + f) * S;
-                const float e = probs_entry(tin.counts + ro, tin.conc + ro, tin.unif + fo, S, tin.temperature, tin.prior_temperature,
-                                            tin.status, x, false);
-                pc = pc + wc[c] * e;
-            }
-            e_src = probs_entry(tin.row[0].counts + fo, tin.row[0].conc + fo, tin.unif + fo, S, tin.temperature, tin.prior_temperature,
-                                tin.status, x, i == 0);
-            e_tgt = probs_entry(tin.row[1].counts + fo, tin.row[1].conc + fo, tin.unif + fo, S, tin.temperature, tin.prior_temperature,
-                                tin.status, x, i == 0);
-            // normalize's assert covers the rows of EVERY confounder group (util.py:1006), member or not: the blocks share them
-            for (int gg = G0 + i; gg < tin.n_groups_total; gg += n_members) {
-                const int64_t ro = ((int64_t)gg * F + f) * S;
-                (void)probs_entry(tin.counts + ro, tin.conc + ro, tin.unif + fo, S, tin.temperature, tin.prior_temperature, tin.status, kNA, true);
-            }
-            if (x == kNA) continue;
-        } else {
-            for (int c = 1; c < C; ++c) {
-                const uint16_t gg = gid[(int64_t)c * Np + n];
-                if (gg != kNoGroup) pc = pc + wc[c] * pconf[((int64_t)(gg - G0) * F + f) * S + x];
-            }
-            e_src = p_source[(int64_t)f * S + x];
-            e_tgt = p_target[(int64_t)f * S + x];
+        float pc = 0.0f;
+        for (int c = 1; c < C; ++c) {
+            const uint16_t gg = gid[(int64_t)c * Np + n];
+            if (gg != kNoGroup) pc = pc + wc[c] * pconf[((int64_t)(gg - G0) * F + f) * S + x];
         }
-        const float ps = pc + wc[0] * e_src;
-        const float pt = pc + wc[0] * e_tgt;
+        const float ps = pc + wc[0] * p_source[(int64_t)f * S + x];
+        const float pt = pc + wc[0] * p_target[(int64_t)f * S + x];
         acc0 += tab_log_pos((double)ps, tab_addr);
         acc1 += tab_log_pos((double)pt, tab_addr);
     }
@@ -946,6 +1129,92 @@ __global__ __launch_bounds__(kBlock) void k_jump_lh(
     if (threadIdx.x == 0) {
         out[i] = (red[0] + red[1]) + (red[2] + red[3]);
         out[(int64_t)n_members + i] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+    signal_done(done);
+}
+
+// The same scores with the tempered tables of the two clusters and of every confounder group built by the block's builder
+// waves from the slot's resident counts (InlineTables: rows 0..F-1 source, F..2F-1 target, then the confounder groups in
+// order; sbe_jump_lh_resident).  Object waves as in k_cluster_marginals_ws: the block form's bits.  C <= kWsC.
+__global__ __launch_bounds__(kWsBlock) void k_jump_lh_ws(
+    const uint8_t* __restrict__ state, const uint16_t* __restrict__ gid, const uint8_t* __restrict__ pid,
+    const float* __restrict__ weights, const uint32_t* __restrict__ pattern_bits, float inv_tp, int use_pow,
+    const int32_t* __restrict__ objects, int n_members, double* __restrict__ out, const f64x2_t* __restrict__ logtab, int Np, int F,
+    int S, int C, int Fp, int G0, DoneSig done, InlineTables tin) {
+    __shared__ f64x2_t tab[kLogTabEntries];
+    extern __shared__ float built[];                                         // source | target | confounder tables
+    const int64_t fs = (int64_t)F * S;
+    const float* ps = built;
+    const float* pt = built + fs;
+    const float* pc = built + 2 * fs;
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
+    const int i = blockIdx.x * kWsObjWaves + wid;
+    const bool object_wave = wid < kWsObjWaves, active = object_wave && i < n_members;
+    uint8_t x[4];
+    float wc[4][kWsC];
+    uint16_t gg[kWsC];
+    int n = 0;
+    uint32_t bits = 0;
+    if (!object_wave) {
+        if (wid == kWsObjWaves) { tab[lane] = logtab[lane]; tab[lane + kWave] = logtab[lane + kWave]; }     // (kLogTabEntries = 128)
+        ws_build_rows(tin, built, F, S);
+    } else if (active) {
+        n = objects[i];
+        bits = pattern_bits[pid[n]];
+#pragma unroll
+        for (int c = 0; c < kWsC; ++c) gg[c] = (c >= 1 && c < C) ? gid[(int64_t)c * Np + n] : kNoGroup;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int f = w * kWave + lane;
+            x[w] = f < F ? state[(int64_t)n * Fp + f] : kNA;
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int f = w * kWave + lane;
+            float unused[kWsC];
+            if (f < F && x[w] != kNA) weight_tables_z_row_reg<kWsC>(weights + (int64_t)f * C, bits, C, inv_tp, use_pow, wc[w], unused);
+        }
+    }
+    __syncthreads();
+    if (active) {
+        const uint32_t tab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) f64x2_t*)tab;
+        auto term = [&](uint8_t xx, int f, const float (&a)[kWsC], double& acc0, double& acc1) {
+            float p = 0.0f;
+#pragma unroll
+            for (int c = 1; c < kWsC; ++c)
+                if (c < C && gg[c] != kNoGroup) p = p + a[c] * pc[((int64_t)(gg[c] - G0) * F + f) * S + xx];
+            const float s_ = p + a[0] * ps[(int64_t)f * S + xx];
+            const float t_ = p + a[0] * pt[(int64_t)f * S + xx];
+            acc0 += tab_log_pos((double)s_, tab_addr);
+            acc1 += tab_log_pos((double)t_, tab_addr);
+        };
+        double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int f = w * kWave + lane;
+            if (f < F && x[w] != kNA) term(x[w], f, wc[w], a0[w], a1[w]);    // np.prod(..., where=~NAs): factor 1
+        }
+        for (int fb = kBlock; fb < F; fb += kBlock) {                        // (F > 256: the block form's later passes, in order)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int f = fb + w * kWave + lane;
+                if (f < F) {
+                    const uint8_t xx = state[(int64_t)n * Fp + f];
+                    if (xx != kNA) {
+                        float a[kWsC], unused[kWsC];
+                        weight_tables_z_row_reg<kWsC>(weights + (int64_t)f * C, bits, C, inv_tp, use_pow, a, unused);
+                        term(xx, f, a, a0[w], a1[w]);
+                    }
+                }
+            }
+        }
+        double r0[4], r1[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { r0[w] = wave_sum(a0[w]); r1[w] = wave_sum(a1[w]); }
+        if (lane == 0) {
+            out[i] = (r0[0] + r0[1]) + (r0[2] + r0[3]);
+            out[(int64_t)n_members + i] = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+        }
     }
     signal_done(done);
 }
