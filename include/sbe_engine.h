@@ -550,6 +550,9 @@ int sbe_gibbs_step(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* ob
 int sbe_test_fast_log(sbe_engine* e, const double* in, int n, double* out_fast, double* out_lib);
 /* table-driven fp64 log of k_mixture_tuple64's table build (error <= 1 ulp + 2^-53 absolute) */
 int sbe_test_tab_log(sbe_engine* e, const double* in, int n, double* out);
+/* the floor of a host-synchronous call: an empty kernel of n_blocks blocks that (mode bit 0) reads one word of the
+   host-mapped input block and (bit 1) stores one double per block to the host-mapped result block, completion by flag */
+int sbe_test_roundtrip(sbe_engine* e, int n_blocks, int mode);
 /* lgamma of the Dirichlet-categorical terms (recurrence + Stirling series; a8, util.py:39-45, 1373-1394) */
 int sbe_test_lgamma(sbe_engine* e, const double* in, int n, double* out);
 

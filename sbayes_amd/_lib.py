@@ -130,6 +130,7 @@ PROTOTYPES = {
     "sbe_test_fast_log": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p]),
     "sbe_test_lgamma": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_test_tab_log": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p]),
+    "sbe_test_roundtrip": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int]),
     "sbe_copy_slot": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int]),
     "sbe_timer_start": (ct.c_int, [c_engine_p]),
     "sbe_timer_stop": (ct.c_int, [c_engine_p, ct.POINTER(ct.c_float)]),

@@ -4346,6 +4346,18 @@ int sbe_test_lgamma(sbe_engine* e, const double* in, int n, double* out) {
     return d2h(e, out, d_o, (size_t)n * sizeof(double));
 }
 
+int sbe_test_roundtrip(sbe_engine* e, int n_blocks, int mode) {
+    CHECK_ENGINE(e);
+    if (n_blocks < 1 || n_blocks > 65535) return fail(e, SBE_ERR_ARG, "n_blocks=%d", n_blocks);
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = ensure_io(e, 256 + (size_t)n_blocks * sizeof(double));
+    if (rc) return rc;
+    const DoneSig done = next_done(e, (unsigned)n_blocks);
+    k_test_roundtrip<<<n_blocks, 64, 0, e->stream>>>((const int32_t*)e->d_io, (double*)(e->d_io + 256), mode, done);
+    HIPCHK(e, hipGetLastError());
+    return sync_and_report(e, done);
+}
+
 int sbe_test_tab_log(sbe_engine* e, const double* in, int n, double* out) {
     CHECK_ENGINE(e); CHECK_PTR(e, in); CHECK_PTR(e, out);
     if (n < 1) return fail(e, SBE_ERR_ARG, "n=%d", n);

@@ -29,6 +29,15 @@ __global__ void k_test_fast_log(const double* __restrict__ in, double* __restric
     out_lib[i] = log(in[i]);
 }
 
+// Round trip of a host-synchronous call with nothing to do (sbe_test_roundtrip: the floor every drop-in call pays):
+// mode bit 0: read one word of the host-mapped input block, bit 1: store one double to the host-mapped result block.
+__global__ void k_test_roundtrip(const int32_t* __restrict__ mapped_in, double* __restrict__ mapped_out, int mode, DoneSig done) {
+    int v = 0;
+    if ((mode & 1) && threadIdx.x == 0) v = mapped_in[0];
+    if ((mode & 2) && threadIdx.x == 0) mapped_out[blockIdx.x] = (double)v;
+    signal_done(done);
+}
+
 __global__ void k_test_tab_log(const double* __restrict__ in, const double2* __restrict__ logtab,
                                double* __restrict__ out, int n) {
     __shared__ double2 tab[kLogTabEntries];
@@ -418,7 +427,11 @@ __global__ void k_normalize_weight_rows(const float* __restrict__ weights /* [F]
     if (threadIdx.x < kNwRows) {
         uint32_t b = 0;
         const int n = n0 + threadIdx.x;
-        if (n < N) for (int c = 0; c < C; ++c) if (has_components[(int64_t)n * C + c]) b |= 1u << c;
+        uint8_t hb[kMaxComponents];                          // (the rows may sit in host-mapped memory: the C reads go out together)
+#pragma unroll
+        for (int c = 0; c < kMaxComponents; ++c) hb[c] = (n < N && c < C) ? has_components[(int64_t)n * C + c] : (uint8_t)0;
+#pragma unroll
+        for (int c = 0; c < kMaxComponents; ++c) if (hb[c]) b |= 1u << c;
         bits[threadIdx.x] = b;
     }
     __syncthreads();
@@ -1317,27 +1330,39 @@ struct SrcPostArgs {
 
 // One observation's posterior row p[0..C) (float32).  from_prior (operators.py:520-522): p =
 // normalize(w ** (1/T_prior)) entirely in float32, the likelihood plays no part.
+// (Register form: the C weights, group ids and table entries are loaded up front, together, and every term is computed
+// once -- the first form evaluated term(c) twice from memory inside run-time loops, a chain of waited-for loads.)
 __device__ inline bool source_posterior_row(const SrcPostArgs& a, int n, int f, float* p) {
+    constexpr int CM = kMaxComponents;
     const uint8_t x = a.state[(int64_t)n * a.Fp + f];
     const float* w = a.wpat + ((int64_t)a.pid[n] * a.F + f) * a.C;
+    float wr[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) wr[c] = c < a.C ? w[c] : 0.0f;
     if (a.from_prior) {
-        auto term = [&](int c) -> float { return a.pow_w ? powf(w[c], a.inv_tp) : w[c]; };
-        const float total = np_pairwise_sum<float>(term, a.C);
-        for (int c = 0; c < a.C; ++c) p[c] = term(c) / total;
+        float t[CM];
+#pragma unroll
+        for (int c = 0; c < CM; ++c) t[c] = a.pow_w ? powf(wr[c], a.inv_tp) : wr[c];
+        const float total = np_sum_regs<float, CM>(t, a.C);
+#pragma unroll
+        for (int c = 0; c < CM; ++c) if (c < a.C) p[c] = t[c] / total;
         return total > 0.0f;
     }
-    auto term = [&](int c) -> double {
+    uint16_t gg[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) gg[c] = (c < a.C && x != kNA) ? a.gid[(int64_t)c * a.Np + n] : kNoGroup;
+    double t[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
         double lh = 1.0;
-        if (x != kNA) {
-            const uint16_t gg = a.gid[(int64_t)c * a.Np + n];
-            lh = gg == kNoGroup ? 0.0 : (double)a.probs[((int64_t)gg * a.F + f) * a.S + x];
-        }
+        if (x != kNA) lh = gg[c] == kNoGroup ? 0.0 : (double)a.probs[((int64_t)gg[c] * a.F + f) * a.S + x];
         if (a.pow_lh) lh = pow(lh, a.inv_t);
-        const float wc = a.pow_w ? powf(w[c], a.inv_tp) : w[c];
-        return lh * (double)wc;
-    };
-    const double total = np_pairwise_sum<double>(term, a.C);
-    for (int c = 0; c < a.C; ++c) p[c] = (float)(term(c) / total);
+        const float wc = a.pow_w ? powf(wr[c], a.inv_tp) : wr[c];
+        t[c] = lh * (double)wc;
+    }
+    const double total = np_sum_regs<double, CM>(t, a.C);
+#pragma unroll
+    for (int c = 0; c < CM; ++c) if (c < a.C) p[c] = (float)(t[c] / total);
     return total > 0.0;
 }
 
@@ -1476,56 +1501,81 @@ struct GuGibbsArgs {
 // One observation (subset row r, feature f; i = r * F + f) of the above.  `table_at(c, g)` = the kept-observations table
 // entry of component c, group g (>= 0) for this feature and the observed state x; `group_of(c)` = the object's group in
 // component c (-1: none).
+// Register form: the has_components bytes (host-mapped: a PCIe read each), the weights and the table entries are loaded
+// once, up front and together; every array is indexed statically (unrolled, guarded by c < C).
 template <class GroupOf, class TableAt>
 __device__ __forceinline__ void gu_gibbs_obs(const GuGibbsArgs& a, int64_t i, int r, int f, uint8_t x, GroupOf group_of, TableAt table_at,
                                              uint8_t* __restrict__ src_new, float* __restrict__ sel_new, float* __restrict__ sel_back,
                                              int* __restrict__ status) {
+    constexpr int CM = kMaxComponents;
     const bool na = x == kNA;
-    float lh[kMaxComponents];
-    for (int c = 0; c < a.C; ++c) {
+    const int C = a.C;
+    const float* w = a.weights + (int64_t)f * C;
+    const uint8_t* hcn = a.hc_new + (int64_t)r * C;
+    const uint8_t* hco = a.hc_old + (int64_t)r * C;
+    const double zz = a.z[i];
+    const int id_old = a.src_old[i];
+    float wr[CM], lh[CM];
+    uint8_t hn[CM], ho[CM];
+    int g[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        const bool on = c < C;
+        wr[c] = on ? w[c] : 0.0f;
+        hn[c] = on ? hcn[c] : (uint8_t)0;
+        ho[c] = on ? hco[c] : (uint8_t)0;
+        g[c] = (on && !na) ? group_of(c) : -1;
+    }
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
         float v = 1.0f;
-        if (!na) {
-            const int g = group_of(c);
-            v = g < 0 ? 0.0f : table_at(c, g);
-        }
+        if (!na) v = g[c] < 0 ? 0.0f : table_at(c, g[c]);
         lh[c] = a.pow_lh ? powf(v, a.inv_t) : v;
     }
-    const float* w = a.weights + (int64_t)f * a.C;
-    float p[2][kMaxComponents];
+    float p[2][CM];
     bool ok = true;
+#pragma unroll
     for (int side = 0; side < 2; ++side) {
-        const uint8_t* hc = (side == 0 ? a.hc_new : a.hc_old) + (int64_t)r * a.C;
-        auto masked = [&](int c) -> float { return hc[c] ? w[c] : 0.0f * w[c]; };
-        const float wtot = np_pairwise_sum<float>(masked, a.C);
-        float t[kMaxComponents];
-        for (int c = 0; c < a.C; ++c) {
-            float wc = masked(c) / wtot;                            // normalize_weights (likelihood.py:171-190)
+        float m[CM], t[CM];
+#pragma unroll
+        for (int c = 0; c < CM; ++c) m[c] = (side == 0 ? hn[c] : ho[c]) ? wr[c] : 0.0f * wr[c];
+        const float wtot = np_sum_regs<float, CM>(m, C);
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+            float wc = m[c] / wtot;                                 // normalize_weights (likelihood.py:171-190)
             if (a.pow_w) wc = powf(wc, a.inv_tp);
             t[c] = a.from_prior ? wc : wc * lh[c];
         }
-        if (a.from_prior) { for (int c = 0; c < a.C; ++c) p[side][c] = t[c]; continue; }
-        auto term = [&](int c) -> float { return t[c]; };
-        const float tot = np_pairwise_sum<float>(term, a.C);
+        if (a.from_prior) {
+#pragma unroll
+            for (int c = 0; c < CM; ++c) p[side][c] = t[c];
+            continue;
+        }
+        const float tot = np_sum_regs<float, CM>(t, C);
         ok = ok && tot > 0.0f;                                      // normalize's assert (util.py:1006)
-        for (int c = 0; c < a.C; ++c) p[side][c] = t[c] / tot;
+#pragma unroll
+        for (int c = 0; c < CM; ++c) p[side][c] = t[c] / tot;
     }
     if (!ok) raise_status(status, ST_BAD_NORMALIZE, 1);
     // sample_categorical (preprocessing.py:224-256): float32 cumulative sums, divided by the last, first c with z < cdf[c]
-    float cdf[kMaxComponents];
+    float cdf[CM];
     float run = p[0][0];
     cdf[0] = run;
-    for (int c = 1; c < a.C; ++c) { run = run + p[0][c]; cdf[c] = run; }
-    const float last = cdf[a.C - 1];
-    const double zz = a.z[i];
+#pragma unroll
+    for (int c = 1; c < CM; ++c) { if (c < C) run = run + p[0][c]; cdf[c] = run; }
+    const float last = run;                                         // (= cdf[C - 1])
     int k = 0;
-    for (int c = a.C - 1; c >= 0; --c)
-        if (zz < (double)(cdf[c] / last)) k = c;
+#pragma unroll
+    for (int c = CM - 1; c >= 0; --c)
+        if (c < C && zz < (double)(cdf[c] / last)) k = c;
     src_new[i] = na ? (uint8_t)kNA : (uint8_t)k;
     float sn = 1.0f, sb = 1.0f;
-    const int id_old = a.src_old[i];
-    for (int c = 0; c < a.C; ++c) {
-        sn = (!na && c == k) ? p[0][c] : sn;
-        sb = (c == id_old) ? p[1][c] : sb;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        if (c < C) {
+            sn = (!na && c == k) ? p[0][c] : sn;
+            sb = (c == id_old) ? p[1][c] : sb;
+        }
     }
     sel_new[i] = sn;
     sel_back[i] = sb;
