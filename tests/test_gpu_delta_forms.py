@@ -20,13 +20,22 @@ from tests._fixtures import load_npz
 pytestmark = pytest.mark.gpu
 
 
+# shapes that reach the corners of the resident operator kernels (N, F, S, K, groups of the extra confounders, ragged states)
+_SHAPES = {
+    "wide": (260, 150, 33, 4, (3, 5), True),            # several 64-feature tiles, S = 33 (rows beyond the register form), C = 4
+    "long": (90, 530, 7, 3, (4, 2), True),              # F > 256: the fused kernels' later passes over the features
+    "five": (70, 40, 4, 2, (2, 3, 2), True),            # C = 5: more components than the fused kernels hold in registers
+    "eight": (50, 24, 3, 2, (2, 2, 2, 2, 2, 2), True),  # C = 8: NumPy sums eight terms by its eight-accumulator tree
+}
+
+
 def _workload(name):
     if name in ("south_america", "cfg1_fixture"):
         fx = load_npz("south_america" if name == "south_america" else "cfg1")
         unif = fx.states_per_feature.astype(np.float64)
         return fx.features, fx.groups, fx.conc, fx.weights, fx.source, fx.counts, unif
-    if name == "wide":                                   # several 64-feature tiles, S = 33, three confounders
-        wl = make_workload("wide", shape=(260, 150, 33, 4, (3, 5), True))
+    if name in _SHAPES:
+        wl = make_workload(name, shape=_SHAPES[name])
     else:
         wl = make_workload(name)
     from oracle import sbayes_oracle as orc
@@ -104,7 +113,7 @@ def test_counts_delta_and_row_uploads(name):
         eng.close()
 
 
-@pytest.mark.parametrize("name", ["cfg1_fixture", "south_america", "headline", "wide"])
+@pytest.mark.parametrize("name", ["cfg1_fixture", "south_america", "headline", "wide", "long", "five", "eight"])
 def test_resident_operator_forms(name):
     eng, fake, groups, source, counts = _pair(name)
     try:
@@ -123,11 +132,22 @@ def test_resident_operator_forms(name):
                         assert np.array_equal(got, want), (name, k, n)
                     else:
                         np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-7)
+                # GibbsSampleSource's posterior rows of a subset (operators.py:554-574), any component count
+                objs = np.sort(rng.choice(N, size=min(N, 17), replace=False))
+                got = eng.source_posterior(0, objs, temp, ptemp)
+                want = fake.source_posterior(0, objs, temp, ptemp)
+                if temp == 1.0 and ptemp == 1.0:
+                    assert np.array_equal(got, want), (name, k, "source_posterior")
+                else:
+                    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-7)
                 # cluster-membership marginals of the available objects with the candidate table built on the device
                 available = np.flatnonzero(~groups[0].any(axis=0) | groups[0][k])
                 got = eng.cluster_posterior_marginals(0, k, available, temp, ptemp)
-                want = fake.cluster_posterior_marginals(0, k, available, temp, ptemp)
-                np.testing.assert_allclose(got, want, rtol=1e-9 if temp == 1.0 else 2e-6, atol=1e-9)
+                underflows = source.shape[1] > 300       # the reference's linear-space products are 0 / denormal there:
+                if not underflows:                       # the device's sums of logs are checked against its own explicit-table form below
+                    want = fake.cluster_posterior_marginals(0, k, available, temp, ptemp)
+                    np.testing.assert_allclose(got, want, rtol=1e-9 if temp == 1.0 else 2e-6, atol=1e-9)
+                assert np.isfinite(got).all()
                 # the explicit-table form gives the same numbers (same kernel, table from the stateless a10 call)
                 table = eng.normalize_tables(counts[0][[k]], fake.conc[0], temperature=temp, prior_temperature=ptemp,
                                              unif_counts=fake.unif)
@@ -136,8 +156,10 @@ def test_resident_operator_forms(name):
                 if K > 1 and groups[0][k].any():
                     members = np.flatnonzero(groups[0][k])
                     got = eng.jump_lh_resident(0, k, (k + 1) % K, members, temp, ptemp)
-                    want = fake.jump_lh_resident(0, k, (k + 1) % K, members, temp, ptemp)
-                    np.testing.assert_allclose(got, want, rtol=1e-9 if ptemp == 1.0 else 2e-6, atol=1e-9)
+                    if not underflows:
+                        want = fake.jump_lh_resident(0, k, (k + 1) % K, members, temp, ptemp)
+                        np.testing.assert_allclose(got, want, rtol=1e-9 if ptemp == 1.0 else 2e-6, atol=1e-9)
+                    assert np.isfinite(got).all()
         # per-group collapsed values and the per-object source prior from the resident state
         for c in range(len(groups)):
             np.testing.assert_allclose(eng.collapsed_loglik(0, c), fake.collapsed_loglik(0, c), rtol=2e-6, atol=1e-6)
@@ -146,7 +168,7 @@ def test_resident_operator_forms(name):
         eng.close()
 
 
-@pytest.mark.parametrize("name", ["cfg1_fixture", "south_america", "headline", "wide"])
+@pytest.mark.parametrize("name", ["cfg1_fixture", "south_america", "headline", "wide", "long", "five", "eight"])
 def test_fused_tables_same_bits(name):
     """SBE_OPT_FUSE_TABLES (round 4): the one-launch forms -- table entries built inside the consuming
     kernel -- return the bits of the table-kernel-in-front forms, for every resident operator call that has both."""
@@ -195,6 +217,10 @@ def test_fused_tables_same_bits(name):
                             continue
                         for u, v in zip(a, b):
                             assert np.array_equal(u, v), (name, "given_unchanged_gibbs", k, n, temp, from_prior)
+                        if temp == 1.0 and ptemp == 1.0:             # ... and both are the oracle-backed double's bits
+                            want = fake.given_unchanged_gibbs(0, k, objs, hc_new, hc_old, src_old, z, temp, ptemp, from_prior)
+                            for u, v in zip(a, want):
+                                assert np.array_equal(u, v), (name, "given_unchanged_gibbs vs oracle", k, n, from_prior)
         # a count row that sums to nothing with a zero concentration: normalize's assert fires in both forms
         if name == "cfg1_fixture":
             conc0 = np.array(fake.conc[0], dtype=np.float64, copy=True)
@@ -210,7 +236,7 @@ def test_fused_tables_same_bits(name):
         eng.close()
 
 
-@pytest.mark.parametrize("name", ["cfg1_fixture", "south_america", "headline", "wide"])
+@pytest.mark.parametrize("name", ["cfg1_fixture", "south_america", "headline", "wide", "long", "eight"])
 def test_count_rows_with_their_probability_rows(name):
     """set_counts_rows(update_probs=True) = set_counts_rows + update_probs of the touched components: the same counts,
     the same probability tables bit for bit (and so the same likelihoods), one launch; refused while the tables of a
