@@ -50,7 +50,8 @@ extern "C" {
 typedef struct sbe_engine sbe_engine;
 
 #define SBE_ABI_VERSION 5   /* 4 (round 4): + sbe_given_unchanged_gibbs, sbe_host_*; sbe_set_groups rejects overlap;
-                               5: + SBE_OPT_FUSE_TABLES, sbe_host_subset_ids, sbe_host_diff_rows, sbe_set_counts_rows_probs */
+                               5: + SBE_OPT_FUSE_TABLES, sbe_host_subset_ids, sbe_host_diff_rows, sbe_set_counts_rows_probs,
+                               sbe_gibbs_propose, sbe_test_roundtrip */
 
 /* error codes */
 #define SBE_OK 0
@@ -541,6 +542,18 @@ int sbe_step_batch_delta(sbe_engine* e, int n_chains, const int32_t* cur_slots, 
    tables follow on the device.  Out: log_q, log_q_back (fp64 sums of the logs of the float32 probabilities), the
    candidate's collapsed per-group log-likelihoods [G_total], its mixture log-likelihood, changed-group flags
    [G_total] (may be NULL).  One synchronisation; nothing of the sample state crosses PCIe. */
+/* GibbsSampleSource._propose (sbayes/sampling/operators.py:495-552) for the drop-in layer, in one call: the device chain
+   of sbe_gibbs_step -- draw into the candidate slot with the caller's uniforms z [n_sub][F], the rest of the slot, count
+   delta, tables, backward probabilities -- and what the reference's sample bookkeeping needs of it: src_new_out [n_sub][F]
+   the drawn component of every observation (0xFF: an NA observation), sel_out / sel_back_out [n_sub][F] float32 = p[drawn]
+   and p_back[old source] (1 where there is none), touched_out [<= G_total] (ascending) + *n_touched_out = the groups the
+   listed objects are in, diff_rows_out [n_touched][F][S] = candidate counts - current counts of those groups (every other
+   row of that difference is zero: counts.py:55-95).  One synchronisation.  sbe_gibbs_propose_supported: 1 if the
+   engine's tables fit the fused table kernel the chain uses (else SBE_ERR_ARG here; the call-by-call forms remain). */
+int sbe_gibbs_propose_supported(sbe_engine* e);
+int sbe_gibbs_propose(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* objects, int n_sub, double temperature,
+                      double prior_temperature, int from_prior, const double* z, uint8_t* src_new_out, float* sel_out,
+                      float* sel_back_out, int32_t* touched_out, int32_t* n_touched_out, float* diff_rows_out);
 int sbe_gibbs_step(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* objects, int n_sub, double temperature,
                    double prior_temperature, int from_prior, const double* z, double* log_q_out,
                    double* log_q_back_out, double* group_logliks_out, double* mixture_out,

@@ -111,6 +111,13 @@ def update_feature_counts(sample_old, sample_new, features, object_subset):
             counts[name].add_changes(diff=new - old)
         return counts
     touched, rows = eng.counts_delta(objs, *ids)
+    return apply_count_rows(counts, names, off, touched, rows)
+
+
+def apply_count_rows(counts, names, off, touched, rows):
+    """The reference's `add_changes(diff)` per component (counts.py:77, :93) for a difference given as the rows of the global
+    group indices `touched` (ascending; every other row is zero): in its row form (FeatureCounts.add_changes_rows: patch.install
+    / sbayes_amd.state) where the sample's class has one, else through a dense diff."""
     bounds = np.searchsorted(touched, off).tolist()  # `touched` is sorted: the rows of component c are bounds[c]:bounds[c+1]
     for c, name in enumerate(names):
         node = counts[name]

@@ -4313,6 +4313,140 @@ static int step_general(sbe_engine* e, int cur_slot, int cand_slot, const uint8_
 }
 
 // ---- self-test hook: the table-build log against the device library's log -------------------------------
+// GibbsSampleSource._propose (operators.py:495-552) for the drop-in layer in ONE call: sbe_gibbs_step's device chain -- the
+// draw into the candidate slot, the rest of the slot with its count delta and tables (k_step_core), the backward
+// probabilities -- and then, instead of the likelihoods a resident chain wants, what the reference's sample bookkeeping
+// wants: the drawn ids, both selected-probability arrays and the count rows that changed, all in the host-mapped block,
+// one completion flag.  (As eight engine calls -- copy_slot, sample_source, update_counts, update_probs, source_logprob,
+// get_source_rows, counts_delta -- the same work cost 190 us per proposal in the sampler replay, seven stream
+// synchronisations among them.)
+int sbe_gibbs_propose_supported(sbe_engine* e) {
+    CHECK_ENGINE(e);
+    return ((int64_t)e->Gtot * e->S * 28 <= 60 * 1024) ? 1 : 0;          // (the fused table kernel of the step core)
+}
+
+int sbe_gibbs_propose(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* objects, int n_sub, double temperature,
+                      double prior_temperature, int from_prior, const double* z, uint8_t* src_new_out, float* sel_out,
+                      float* sel_back_out, int32_t* touched_out, int32_t* n_touched_out, float* diff_rows_out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, cur_slot); CHECK_SLOT(e, cand_slot);
+    CHECK_PTR(e, src_new_out); CHECK_PTR(e, sel_out); CHECK_PTR(e, sel_back_out); CHECK_PTR(e, touched_out); CHECK_PTR(e, n_touched_out);
+    CHECK_PTR(e, diff_rows_out); CHECK_PTR(e, z);
+    if (cur_slot == cand_slot) return fail(e, SBE_ERR_ARG, "current and candidate slot must differ");
+    if (n_sub < 1) return fail(e, SBE_ERR_ARG, "n_sub=%d (nothing to resample)", n_sub);
+    CHECK_PTR(e, objects);
+    if (!(temperature > 0.0) || !(prior_temperature > 0.0)) return fail(e, SBE_ERR_ARG, "temperatures must be positive");
+    Slot& cur = e->slots[cur_slot];
+    if (!cur.groups_set || !cur.source_set || !cur.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", cur_slot);
+    for (int c = 0; c < e->C; ++c)
+        if (!cur.counts_set[c] || !e->conc_set[c] || !cur.probs_set[c])
+            return fail(e, SBE_ERR_STATE, "slot %d: counts / concentration / probability tables of component %d not set", cur_slot, c);
+    int rc = check_objects(e, objects, n_sub);
+    if (rc) return rc;
+    if (!sbe_gibbs_propose_supported(e))
+        return fail(e, SBE_ERR_ARG, "sbe_gibbs_propose: tables too large for the fused table kernel (G_total=%d, S=%d)", e->Gtot, e->S);
+    const int N = e->N, Np = e->Np, F = e->F, C = e->C, S = e->S;
+    const int64_t n_obs = (int64_t)n_sub * F, fs = (int64_t)F * S;
+    // the groups the subset's objects are in (their count rows are the only ones the redraw can change), ascending
+    std::vector<uint8_t> seen((size_t)e->Gtot, 0);
+    for (int c = 0; c < C; ++c)
+        for (int i = 0; i < n_sub; ++i) {
+            const uint16_t gg = cur.h_gid[(size_t)c * N + objects[i]];
+            if (gg != kNoGroup) seen[gg] = 1;
+        }
+    int n_touched = 0;
+    for (int g = 0; g < e->Gtot; ++g) if (seen[g]) touched_out[n_touched++] = g;
+    *n_touched_out = n_touched;
+    HIPCHK(e, hipSetDevice(e->device));
+    if (cur.patterns_dirty) { rc = upload_patterns_and_weights(e, cur_slot); if (rc) return rc; }
+    if (e->status_pending) {                  // deliver a deferred data check before this call reuses the words
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        rc = synced(e);
+        if (rc) return rc;
+    }
+    // host-mapped block: objects | row_of marks | touched | uniforms (when few) || ids | sel | sel_back | count rows
+    const size_t ob = al256((size_t)n_sub * sizeof(int32_t)), rb = al256((size_t)Np * sizeof(int16_t));
+    const size_t tb = al256((size_t)std::max(n_touched, 1) * sizeof(int32_t));
+    const size_t zbytes = (size_t)n_obs * sizeof(double);
+    const bool z_mapped = zbytes <= ((size_t)1 << 19);
+    const size_t zb = z_mapped ? al256(zbytes) : 0;
+    const size_t idb = al256((size_t)n_obs), selb = al256((size_t)n_obs * sizeof(float));
+    const size_t rowb = al256((size_t)std::max(n_touched, 1) * fs * sizeof(float));
+    const size_t in_bytes = ob + rb + tb + zb, out_bytes = idb + 2 * selb + rowb;
+    if (out_bytes > ((size_t)8 << 20)) return fail(e, SBE_ERR_ARG, "sbe_gibbs_propose: %d objects x %d features exceed the mapped result block", n_sub, F);
+    rc = ensure_io(e, in_bytes + out_bytes);
+    if (rc) return rc;
+    uint8_t* h = e->h_io;
+    memcpy(h, objects, (size_t)n_sub * sizeof(int32_t));
+    int16_t* row_of = reinterpret_cast<int16_t*>(h + ob);
+    std::fill(row_of, row_of + Np, (int16_t)-1);
+    for (int i = 0; i < n_sub; ++i) row_of[objects[i]] = 0;
+    memcpy(h + ob + rb, touched_out, (size_t)n_touched * sizeof(int32_t));
+    const int32_t* d_obj = reinterpret_cast<const int32_t*>(e->d_io);
+    const int nblk = div_up(n_obs, kBlock);
+    const size_t qb_bytes = al256((size_t)nblk * sizeof(double));
+    rc = ensure_scratch(e, 2 * qb_bytes + (z_mapped ? 0 : al256(zbytes)));
+    if (rc) return rc;
+    double* d_part_f = (double*)e->d_scratch;
+    double* d_part_b = (double*)(e->d_scratch + qb_bytes);
+    const double* d_z;
+    if (z_mapped) { memcpy(h + ob + rb + tb, z, zbytes); d_z = reinterpret_cast<const double*>(e->d_io + ob + rb + tb); }
+    else {
+        double* dz = (double*)(e->d_scratch + 2 * qb_bytes);
+        int urc = upload(e, dz, z, zbytes); if (urc) return urc;
+        d_z = dz;
+    }
+    uint8_t* d_ids = e->d_io + in_bytes;
+    float* d_psel_f = (float*)(d_ids + idb);
+    float* d_psel_b = (float*)(d_ids + idb + selb);
+    float* d_rows = (float*)(d_ids + idb + 2 * selb);
+    rc = clear_status_word(e, ST_BAD_NORMALIZE);
+    if (rc) return rc;
+    const double inv_t = 1.0 / temperature, inv_tp = 1.0 / prior_temperature;
+    auto post_args = [&](int slot) {
+        return SrcPostArgs{e->d_state, e->d_gid + (int64_t)slot * C * Np, e->d_pid + (int64_t)slot * Np,
+                           e->d_probs + (int64_t)slot * e->table_elems(), e->d_wpat + (int64_t)slot * e->Pmax * F * C,
+                           d_obj, n_sub, Np, F, S, C, e->Fp, inv_t, (float)inv_tp, inv_t != 1.0, inv_tp != 1.0,
+                           from_prior != 0};
+    };
+    uint8_t* src_cand = e->d_src + (int64_t)cand_slot * N * e->Fp;
+    bump_src(e, cand_slot);
+    bump_ids(e, cand_slot);
+    // 1: the draw (posterior from the current tables) -> the candidate's source rows of the listed objects; p[drawn] out
+    k_sample_source<<<nblk, kBlock, 0, e->stream>>>(post_args(cur_slot), d_z, e->rng_seed, e->rng_draw, src_cand, d_psel_f, e->d_status, d_part_f);
+    HIPCHK(e, hipGetLastError());
+    // 2: the rest of the candidate slot, its count delta and every one of its tables
+    Slot cd = cur;
+    {
+        CoreInputs in;
+        in.row_of = reinterpret_cast<const int16_t*>(e->d_io + ob);
+        in.src_new = src_cand;
+        in.subset = d_obj; in.n_subset = n_sub;
+        in.P = (int)cd.patterns.size();
+        rc = launch_step_core(e, cur_slot, cand_slot, in);
+        if (rc) return rc;
+    }
+    std::fill(cd.probs_set.begin(), cd.probs_set.end(), 1);
+    e->slots[cand_slot] = cd;
+    // 3: the candidate's posterior evaluated at the CURRENT source assignment; p_back[old source] out
+    k_source_logprob<<<nblk, kBlock, 0, e->stream>>>(post_args(cand_slot), e->d_src + (int64_t)cur_slot * N * e->Fp, d_psel_b, e->d_status, d_part_b);
+    HIPCHK(e, hipGetLastError());
+    // 4: drawn ids and changed count rows, completion
+    const int64_t n_el = n_obs + (int64_t)n_touched * fs;
+    const unsigned blocks = (unsigned)std::min<int64_t>(div_up(n_el, 256), 256);
+    const DoneSig done = next_done(e, blocks);
+    k_gibbs_fetch<<<blocks, 256, 0, e->stream>>>(src_cand, d_obj, n_sub, d_ids, e->d_counts + (int64_t)cur_slot * e->table_elems(),
+                                                e->d_counts + (int64_t)cand_slot * e->table_elems(),
+                                                reinterpret_cast<const int32_t*>(e->d_io + ob + rb), n_touched, d_rows, F, S, e->Fp, done);
+    HIPCHK(e, hipGetLastError());
+    rc = sync_and_report(e, done);
+    if (rc) return rc;
+    memcpy(src_new_out, h + in_bytes, (size_t)n_obs);
+    memcpy(sel_out, h + in_bytes + idb, (size_t)n_obs * sizeof(float));
+    memcpy(sel_back_out, h + in_bytes + idb + selb, (size_t)n_obs * sizeof(float));
+    memcpy(diff_rows_out, h + in_bytes + idb + 2 * selb, (size_t)n_touched * fs * sizeof(float));
+    return SBE_OK;
+}
+
 int sbe_test_fast_log(sbe_engine* e, const double* in, int n, double* out_fast, double* out_lib) {
     CHECK_ENGINE(e); CHECK_PTR(e, in); CHECK_PTR(e, out_fast); CHECK_PTR(e, out_lib);
     if (n < 1) return fail(e, SBE_ERR_ARG, "n=%d", n);

@@ -1595,6 +1595,29 @@ __global__ __launch_bounds__(kBlock) void k_given_unchanged_gibbs(GuGibbsArgs a,
     signal_done(done);
 }
 
+// Last kernel of sbe_gibbs_propose (GibbsSampleSource._propose in one call): what the host bookkeeping needs of the candidate
+// slot, written straight into the host-mapped result block -- the drawn source component of every observation of the subset
+// (0xFF: none, i.e. an NA observation) and, for the groups the subset's objects are in, the rows of candidate counts minus
+// current counts (what update_feature_counts would have computed, counts.py:55-95).  Element-parallel; carries the call's
+// completion flag.
+__global__ void k_gibbs_fetch(const uint8_t* __restrict__ src_cand /* [N][Fp] */, const int32_t* __restrict__ objects, int n_sub,
+                              uint8_t* __restrict__ ids_out /* [n_sub][F] */, const int32_t* __restrict__ counts_cur,
+                              const int32_t* __restrict__ counts_cand, const int32_t* __restrict__ touched, int n_touched,
+                              float* __restrict__ rows_out /* [n_touched][F][S] */, int F, int S, int Fp, DoneSig done) {
+    const int64_t n_ids = (int64_t)n_sub * F, fs = (int64_t)F * S, n_rows = (int64_t)n_touched * fs;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ids + n_rows; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n_ids) {
+            const int r = (int)(i / F), f = (int)(i % F);
+            ids_out[i] = src_cand[(int64_t)objects[r] * Fp + f];
+        } else {
+            const int64_t j = i - n_ids;
+            const int64_t at = (int64_t)touched[j / fs] * fs + j % fs;
+            rows_out[j] = (float)(counts_cand[at] - counts_cur[at]);
+        }
+    }
+    signal_done(done);
+}
+
 // SourcePrior.__call__ (prior.py:573-611), per-object values:
 //   sp[n] = float32( sum_{f valid} log( w[pat(n)][f][source(n,f)] ) )     (float32 logs)
 // One wave per object, lanes over features, wave64 shuffle reduce.  An observation whose source has no

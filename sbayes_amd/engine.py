@@ -871,6 +871,36 @@ class Engine:
                                                    self._o(glh), self._o(mix), self._o(changed)))
         return glh, mix, changed.astype(bool)
 
+    def gibbs_propose_supported(self):
+        """True if gibbs_propose applies to this engine's shape (its tables fit the fused table kernel of the chain)."""
+        if getattr(self, "_gibbs_propose_ok", None) is None:
+            self._gibbs_propose_ok = self._lib.sbe_gibbs_propose_supported(self._h) == 1
+        return self._gibbs_propose_ok
+
+    def gibbs_propose(self, cur_slot, cand_slot, objects, z, temperature=1.0, prior_temperature=1.0, from_prior=False):
+        """GibbsSampleSource._propose (operators.py:495-552) in one call (sbe_gibbs_propose): the listed objects' source is
+        redrawn into `cand_slot` (= `cur_slot`'s state otherwise) with the uniforms z [n, F]; counts and tables follow on
+        the device.  Returns (ids uint8 [n, F]: drawn component, 255 = NA observation; sel float32 [n, F] = p[drawn];
+        sel_back float32 [n, F] = p_back[old source]; touched int32 [T]: the groups the objects are in, ascending;
+        rows float32 [T, F, S]: candidate counts - current counts of those groups)."""
+        objs = _as(objects, np.int32).reshape(-1)
+        n, F, S = objs.size, self.n_features, self.n_states
+        zz = _c(z, np.float64)
+        if zz.size != n * F:
+            raise ValueError(f"z must hold {n} x {F} uniforms")
+        ids = np.empty((n, F), dtype=np.uint8)
+        sel = np.empty((n, F), dtype=np.float32)
+        back = np.empty((n, F), dtype=np.float32)
+        touched = np.empty(self.n_groups_total, dtype=np.int32)
+        rows = np.empty((min(self.n_groups_total, n * self.n_components), F, S), dtype=np.float32)
+        nt = ct.c_int32(0)
+        self._touch(cand_slot)
+        self._check(self._lib.sbe_gibbs_propose(self._h, cur_slot, cand_slot, self._i(objs), n, float(temperature),
+                                                float(prior_temperature), int(bool(from_prior)), self._i(zz), self._o(ids),
+                                                self._o(sel), self._o(back), _ptr(touched), ct.byref(nt), _ptr(rows)))
+        self.d2h_bytes += nt.value * (4 + F * S * 4)
+        return ids, sel, back, touched[:nt.value], rows[:nt.value]
+
     def gibbs_step(self, cur_slot, cand_slot, objects, z=None, temperature=1.0, prior_temperature=1.0, from_prior=False):
         """One Gibbs-source MCMC step in one call (sbe_gibbs_step): the listed objects' source is redrawn on the
         device into `cand_slot`, counts / tables / likelihoods follow.  z: uniforms [n, F] or None (engine's Philox

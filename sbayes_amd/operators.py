@@ -22,7 +22,7 @@ from __future__ import annotations
 import numpy as np
 
 from .binding import _bind_slot, _bind_uniform, _engine, _tables_current
-from .counts import _source_ids, update_feature_counts
+from .counts import _source_ids, apply_count_rows, update_feature_counts
 
 EPS = np.finfo(np.float32).eps        # sbayes/util.py:34
 
@@ -128,6 +128,19 @@ def gibbs_sample_source(model, sample, object_subset=slice(None), temperature=1.
         if z is None:
             z = np.random.random([objects.size, eng.n_features, 1])
         z = np.asarray(z, dtype=np.float64).reshape(objects.size, eng.n_features)
+    if z is not None and objects.size and getattr(eng, "gibbs_propose_supported", lambda: False)() and \
+            (objects.size < 2 or np.unique(objects).size == objects.size):
+        # the whole proposal in ONE engine call (sbe_gibbs_propose): drawn ids, both selected-probability arrays and the
+        # count rows that changed come back together; the sample bookkeeping below is the reference's
+        ids, sel, sel_back, touched, rows = eng.gibbs_propose(cur, new, objects, z, temperature, prior_temperature, sample_from_prior)
+        valid = ids != 255                                   # (= ~na_features[objects]: NA observations get no component)
+        with np.errstate(divide="ignore"):
+            log_q = np.log(sel[valid]).sum()
+            log_q_back = np.log(sel_back[valid]).sum()
+        sample_new = sample.copy()
+        sample_new.source.set_groups(object_subset, ids[..., None] == np.arange(eng.n_components, dtype=np.uint8))
+        apply_count_rows(sample_new.feature_counts, ["clusters", *sample_new.confounders], eng.group_offsets, touched, rows)
+        return sample_new, log_q, log_q_back
     eng.copy_slot(new, cur)
     _, sel = eng.sample_source(cur, new, objects, z, temperature, prior_temperature, sample_from_prior,
                                return_selected=True)

@@ -97,13 +97,15 @@ COMPARE = {
     # ClusterOperator.gibbs_sample_source in one call: (drawn ids, p[drawn], p_back[old source]) -- bit-exact at
     # temperature 1 (ids always: a draw that differs changes the chain), float32 powf tolerance when tempered
     "given_unchanged_gibbs": "exact_at_t1",
+    # GibbsSampleSource._propose in one call: (drawn ids, p[drawn], p_back[old source], touched groups, count rows)
+    "gibbs_propose": "exact_at_t1",
 }
 SETTERS = {"set_groups", "set_concentration", "set_counts", "set_source", "set_weights", "update_probs", "set_counts_rows",
            "set_source_rows", "set_uniform_counts", "recount", "copy_slot"}
 
 
 _TEMPERATURE_ARG = {"source_posterior": 2, "subset_lh": 3, "given_unchanged_lh": 3,      # positional index of `temperature`
-                    "given_unchanged_gibbs": 7}
+                    "given_unchanged_gibbs": 7, "gibbs_propose": 4}
 
 
 def _temperature_of(name, args, kwargs):
@@ -193,7 +195,8 @@ for _name in ("normalize_tables", "dirichlet_logpdf", "effect_counts", "set_grou
               "normalize_weights", "observation_lh_exact", "jump_lh", "source_lh_by_feature", "set_counts_rows",
               "set_source_rows", "set_uniform_counts", "counts_delta", "collapsed_loglik", "collapsed_loglik_all", "source_prior",
               "given_unchanged_lh", "cluster_posterior_marginals", "jump_lh_resident", "recount", "get_counts",
-              "copy_slot", "sample_source", "source_logprob", "update_counts", "get_source_rows", "given_unchanged_gibbs"):
+              "copy_slot", "sample_source", "source_logprob", "update_counts", "get_source_rows", "given_unchanged_gibbs",
+              "gibbs_propose"):
     setattr(RecordingEngine, _name, _wrap(_name))
 
 

@@ -369,6 +369,36 @@ class FakeEngine:
                         1.0).astype(np.float32)
         return ids, sel, back
 
+    def gibbs_propose_supported(self):
+        return True
+
+    def gibbs_propose(self, cur_slot, cand_slot, objects, z, temperature=1.0, prior_temperature=1.0, from_prior=False):
+        """GibbsSampleSource._propose in one call, composed of the double's own pieces (class-qualified: ONE logged call)."""
+        objects = np.asarray(objects)
+        n_calls = len(self.calls)
+        FakeEngine.copy_slot(self, cand_slot, cur_slot)
+        _, sel = FakeEngine.sample_source(self, cur_slot, cand_slot, objects, z, temperature, prior_temperature, from_prior,
+                                          return_selected=True)
+        FakeEngine.update_counts(self, cand_slot, cur_slot, objects)
+        _, back = FakeEngine.source_logprob(self, cand_slot, cur_slot, objects, temperature, prior_temperature, from_prior,
+                                            return_selected=True)
+        rows_new = FakeEngine.get_source_rows(self, cand_slot, objects)
+        del self.calls[n_calls:]
+        self.calls.append(("gibbs_propose", len(objects)))
+        ids = np.where(rows_new.any(-1), rows_new.argmax(-1), 255).astype(np.uint8)
+        cur, cand = self._slot(cur_slot), self._slot(cand_slot)
+        off = self.group_offsets
+        seen = np.zeros(int(off[-1]), dtype=bool)
+        for c in range(len(cur["groups"])):
+            sub = np.asarray(cur["groups"][c])[:, objects]
+            seen[off[c] + np.flatnonzero(sub.any(axis=1))] = True
+        touched = np.flatnonzero(seen).astype(np.int32)
+        rows = np.zeros((touched.size, self.n_features, self.n_states), dtype=np.float32)
+        for j, gg in enumerate(touched):
+            c = int(np.searchsorted(off, gg, side="right") - 1)
+            rows[j] = cand["counts"][c][gg - off[c]] - cur["counts"][c][gg - off[c]]
+        return ids, np.asarray(sel, dtype=np.float32), np.asarray(back, dtype=np.float32), touched, rows
+
     def cluster_posterior_marginals(self, slot, i_cluster, objects, temperature=1.0, prior_temperature=1.0):
         _, counts, conc, _ = self._full_state(slot)
         table = orc.conditional_effect_mean(conc[0], counts[0][[i_cluster]], unif_counts=self.unif,

@@ -35,13 +35,13 @@ def test_call_log_replays_on_the_double(tag):
 
 @pytest.mark.parametrize("tag", ["south_america_gibbs", "headline_gibbs", "cfg1_gibbs"])
 def test_gibbs_source_call_log_replays_on_the_double(tag):
-    """The logs recorded under patch.install(gibbs_source=True): GibbsSampleSource._propose's body as engine calls on slot
-    state (copy_slot, sample_source with the uniforms regenerated from their recorded generator state, update_counts,
-    source_logprob, get_source_rows)."""
+    """The logs recorded under patch.install(gibbs_source=True): GibbsSampleSource._propose's body as ONE engine call on slot
+    state (gibbs_propose, with the uniforms regenerated from their recorded generator state) and the cluster operators'
+    source resampling as another (given_unchanged_gibbs)."""
     feats = features_of(tag)
     counts, meta = replay(GOLDEN / f"{tag}_calls.npz", lambda n_groups: FakeEngine(feats, n_groups))
     assert meta["gibbs_source"] and crc(feats) == meta["features_crc"]
-    assert {"copy_slot", "sample_source", "update_counts", "source_logprob", "get_source_rows", "counts_delta",
-            "given_unchanged_gibbs"} <= set(counts)
-    assert counts["sample_source"] == counts["source_logprob"] == counts["get_source_rows"] >= 10
+    assert {"gibbs_propose", "counts_delta", "given_unchanged_gibbs"} <= set(counts)
+    assert not {"copy_slot", "sample_source", "update_counts", "source_logprob", "get_source_rows"} & set(counts)
+    assert counts["gibbs_propose"] >= 10
     assert "GibbsSampleSource" in meta["operators"]

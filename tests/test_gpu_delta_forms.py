@@ -283,6 +283,46 @@ def test_count_rows_with_their_probability_rows(name):
         fresh.set_counts_rows(0, [0], counts[0][:1])                               # (the plain patch needs no tables)
 
 
+@pytest.mark.parametrize("name", ["cfg1_fixture", "south_america", "headline", "wide", "five"])
+def test_gibbs_propose_in_one_call(name):
+    """sbe_gibbs_propose (GibbsSampleSource._propose, operators.py:495-552, in one engine call) against the oracle-backed
+    double, which composes it from the call-by-call pieces: drawn ids, touched groups and count rows always bit for bit,
+    the selected probabilities bit for bit at temperature 1; and the candidate slot it leaves behind -- source rows, counts,
+    tables -- is the double's."""
+    eng, fake, groups, source, counts = _pair(name)
+    try:
+        if not eng.gibbs_propose_supported():
+            pytest.skip("tables beyond the fused table kernel of the chain")
+        rng = np.random.default_rng(41)
+        N, F, C = source.shape
+        for temp, ptemp, from_prior in ((1.0, 1.0, False), (1.0, 1.0, True), (1.4, 1.2, False)):
+            for n in (1, 7, min(N, 200)):
+                objs = np.sort(rng.choice(N, size=min(n, N), replace=False)).astype(np.int32)
+                z = rng.random((objs.size, F))
+                got = eng.gibbs_propose(0, 1, objs, z, temp, ptemp, from_prior)
+                want = fake.gibbs_propose(0, 1, objs, z, temp, ptemp, from_prior)
+                tags = ("ids", "sel", "sel_back", "touched", "rows")
+                for tag, g, w in zip(tags, got, want):
+                    assert g.shape == w.shape and g.dtype == w.dtype, (name, tag, g.dtype, w.dtype)
+                    if tag in ("ids", "touched", "rows") or (temp == 1.0 and ptemp == 1.0):
+                        assert np.array_equal(g, w), (name, tag, n, temp, from_prior)
+                    else:
+                        np.testing.assert_allclose(g, w, rtol=2e-6, atol=1e-7)
+                everyone = np.arange(N, dtype=np.int32)
+                assert np.array_equal(eng.get_source_rows(1, everyone), fake.get_source_rows(1, everyone))
+                for c in range(C):
+                    assert np.array_equal(eng.get_counts(1, c), fake._slot(1)["counts"][c]), (name, c)
+                assert np.array_equal(eng.likelihood_per_component(1), fake._state(1)[2])      # (the candidate's tables)
+                # the current slot is untouched
+                assert np.array_equal(eng.get_source_rows(0, everyone), source)
+        with pytest.raises(Exception, match="differ"):
+            eng.gibbs_propose(0, 0, [0], np.zeros((1, F)))
+        with pytest.raises(Exception, match="out of range"):
+            eng.gibbs_propose(0, 1, [N], np.zeros((1, F)))
+    finally:
+        eng.close()
+
+
 def test_argument_checks():
     eng, fake, groups, source, counts = _pair("cfg1_fixture")
     try:

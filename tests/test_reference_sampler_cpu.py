@@ -153,11 +153,12 @@ def test_reference_sampler_with_the_gibbs_source_proposal_on_the_device(tag, src
     assert np.array_equal(patched[3], plain[3])
     eng = next(iter(patched[4].values()))
     kinds = {c[0] for c in eng.calls}
-    assert {"sample_source", "source_logprob", "update_counts", "copy_slot", "given_unchanged_gibbs"} <= kinds, kinds
+    assert {"gibbs_propose", "given_unchanged_gibbs"} <= kinds, kinds                 # (the whole _propose body: ONE engine call)
+    assert not {"sample_source", "source_logprob", "update_counts", "copy_slot"} & kinds, kinds
     # (given_unchanged_lh remains for ClusterJump.gibbs_sample_source_jump, operators.py:1775, which has its own body)
     assert "GibbsSampleSource" in {t[2] for t in patched[0]}
     n_gibbs = sum(t[2] == "GibbsSampleSource" for t in patched[0])
-    assert sum(c[0] == "sample_source" for c in eng.calls) >= n_gibbs               # every such step went through the device form
+    assert sum(c[0] == "gibbs_propose" for c in eng.calls) >= n_gibbs               # every such step went through the device form
     assert "source_posterior" not in kinds or tag == "south_america"                # (ClusterJump's own gibbs_sample_source_jump still asks the posterior)
 
 
