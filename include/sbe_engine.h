@@ -95,8 +95,9 @@ typedef struct sbe_engine sbe_engine;
 
 #define SBE_OPT_FUSE_TABLES 6       /* resident operator calls whose kernel reads a tempered effect table built from the slot's
                                        counts (sbe_cluster_posterior_marginals, sbe_jump_lh_resident, sbe_given_unchanged_lh,
-                                       sbe_given_unchanged_gibbs): 1 = the consuming kernel builds the entries it reads itself,
-                                       one launch per call (default; same operations in the same order, same bits);
+                                       sbe_given_unchanged_gibbs): 1 = the consuming kernel builds the tables itself -- builder waves of
+                                       every block, into LDS, while the other waves run their load chains -- one launch per call
+                                       (default; same operations in the same order, same bits);
                                        0 = table kernels in front (testing / A-B; environment SBE_FUSE_TABLES=0 sets the
                                        default of new engines) */
 
