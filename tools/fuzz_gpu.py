@@ -125,6 +125,36 @@ def forms_case(rng, eng, feats, n_groups, conc, state, tag, stats):
             got = eng.jump_lh_resident(0, i_cl, i_tg, members)
         ok = np.isfinite(want) & (want > -690.0)
         np.testing.assert_allclose(got[ok], want[ok], rtol=1e-9, atol=1e-9, err_msg=tag)
+    # round 4, second session: the one-launch forms against the table-kernel forms (same bits), count rows with their
+    # probability rows, GibbsSampleSource._propose in one call against the double's composition of the call-by-call pieces
+    fused = (eng.cluster_posterior_marginals(0, i_cl, objs), eng.given_unchanged_lh(0, i_cl, objs),
+             eng.jump_lh_resident(0, i_cl, (i_cl + 1) % K, members) if members.size and K >= 2 else None)
+    eng.set_option(fuse_tables=False)
+    plain = (eng.cluster_posterior_marginals(0, i_cl, objs), eng.given_unchanged_lh(0, i_cl, objs),
+             eng.jump_lh_resident(0, i_cl, (i_cl + 1) % K, members) if members.size and K >= 2 else None)
+    eng.set_option(fuse_tables=True)
+    for a_, b_, what in zip(fused, plain, ("marginals", "given_unchanged_lh", "jump")):
+        assert a_ is None or np.array_equal(a_, b_), (tag, "fused != table kernel in front", what)
+    s1, s2 = eng.n_slots - 1, eng.n_slots - 2
+    eng.copy_slot(s1, 0)
+    eng.copy_slot(s2, 0)
+    c_pick = int(rng.integers(0, C))
+    g_pick = np.unique(rng.integers(0, n_groups[c_pick], size=2))
+    rows_new = rng.integers(0, 30, size=(g_pick.size,) + counts[c_pick].shape[1:]).astype(np.float32)
+    eng.set_counts_rows(s1, off[c_pick] + g_pick, rows_new, update_probs=True)
+    eng.set_counts_rows(s2, off[c_pick] + g_pick, rows_new)
+    eng.update_probs(s2, c_pick)
+    assert np.array_equal(eng.get_probs(s1, c_pick), eng.get_probs(s2, c_pick)), (tag, "set_counts_rows(update_probs=True)")
+    assert np.array_equal(eng.get_counts(s1, c_pick), eng.get_counts(s2, c_pick)), (tag, "set_counts_rows(update_probs=True): counts")
+    if eng.gibbs_propose_supported():
+        from_prior = bool(rng.integers(0, 2))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            want_p = fake.gibbs_propose(0, 1, objs, zz, from_prior=from_prior)
+        if np.isfinite(want_p[1]).all() and np.isfinite(want_p[2]).all():      # (a posterior row with zero mass: the reference asserts)
+            got_p = eng.gibbs_propose(0, s1, objs, zz, from_prior=from_prior)
+            for a_, b_, what in zip(got_p, want_p, ("ids", "p[drawn]", "p_back[old]", "touched", "count rows")):
+                assert a_.shape == b_.shape and np.array_equal(a_, b_), (tag, "gibbs_propose", what)
+            stats["gibbs_propose"] = stats.get("gibbs_propose", 0) + 1
     stats["forms"] = stats.get("forms", 0) + 1
 
 
