@@ -276,6 +276,10 @@ __device__ __forceinline__ double block_sum(double v, double* lds4) {
 //  callers' loops and held in ~150 VGPRs for the whole kernel -- k_step_core stood at 255 VGPRs + scratch for it)
 __device__ __attribute__((noinline)) double lib_log(double v) { return log(v); }
 __device__ __attribute__((noinline)) double lib_lgamma(double v) { return lgamma(v); }
+// powf / pow of the tempered paths (a temperature other than 1: heated MC3 chains only).  Inlined at every use they were
+// most of the 19 800 instructions of the fused marginals kernel -- code a latency-bound kernel has to fetch cold.
+__device__ __attribute__((noinline)) float lib_powf(float a, float b) { return powf(a, b); }
+__device__ __attribute__((noinline)) double lib_pow(double a, double b) { return pow(a, b); }
 
 __device__ __forceinline__ double fast_log_pos(double v) {
     const uint64_t bits = (uint64_t)__double_as_longlong(v);

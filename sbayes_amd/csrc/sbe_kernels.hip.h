@@ -852,6 +852,7 @@ struct InlineTables {
     int first_conf_group;            // jump: rows 2 F.. are the groups first_conf_group.. in order
 };
 constexpr int kWsObjWaves = 4, kWsWaves = 16, kWsBlock = kWsWaves * kWave, kWsC = 4;   // (object waves; components held in registers)
+static_assert(kLogTabEntries == 2 * kWave, "the first builder wave copies the log table with two loads per lane");
 
 // Builder waves of a wave-specialised operator kernel: rows (wave - kWsObjWaves) * 64 + lane, + 768, ... into `built` (LDS).
 __device__ __forceinline__ void ws_build_rows(const InlineTables& tin, float* __restrict__ built, int F, int S) {
@@ -892,12 +893,12 @@ __device__ __forceinline__ void weight_tables_z_row_reg(const float* __restrict_
 #pragma unroll
     for (int c = 0; c < CM; ++c) {
         const float a = m[c] / tot;
-        pd[c] = use_pow ? powf(a, inv_tp) : a;
+        pd[c] = use_pow ? lib_powf(a, inv_tp) : a;
         if (c < C) tot2 = tot2 + pd[c];
     }
 #pragma unroll
     for (int c = 0; c < CM; ++c) {
-        const float pw = use_pow ? powf(wr[c], inv_tp) : wr[c];
+        const float pw = use_pow ? lib_powf(wr[c], inv_tp) : wr[c];
         fl[c] = ((fbits >> c) & 1u) ? pw : 0.0f * pw;
         if (c < C) tot3 = tot3 + fl[c];
     }
@@ -1342,7 +1343,7 @@ __device__ inline bool source_posterior_row(const SrcPostArgs& a, int n, int f, 
     if (a.from_prior) {
         float t[CM];
 #pragma unroll
-        for (int c = 0; c < CM; ++c) t[c] = a.pow_w ? powf(wr[c], a.inv_tp) : wr[c];
+        for (int c = 0; c < CM; ++c) t[c] = a.pow_w ? lib_powf(wr[c], a.inv_tp) : wr[c];
         const float total = np_sum_regs<float, CM>(t, a.C);
 #pragma unroll
         for (int c = 0; c < CM; ++c) if (c < a.C) p[c] = t[c] / total;
@@ -1356,8 +1357,8 @@ __device__ inline bool source_posterior_row(const SrcPostArgs& a, int n, int f, 
     for (int c = 0; c < CM; ++c) {
         double lh = 1.0;
         if (x != kNA) lh = gg[c] == kNoGroup ? 0.0 : (double)a.probs[((int64_t)gg[c] * a.F + f) * a.S + x];
-        if (a.pow_lh) lh = pow(lh, a.inv_t);
-        const float wc = a.pow_w ? powf(wr[c], a.inv_tp) : wr[c];
+        if (a.pow_lh) lh = lib_pow(lh, a.inv_t);
+        const float wc = a.pow_w ? lib_powf(wr[c], a.inv_tp) : wr[c];
         t[c] = lh * (double)wc;
     }
     const double total = np_sum_regs<double, CM>(t, a.C);
@@ -1530,7 +1531,7 @@ __device__ __forceinline__ void gu_gibbs_obs(const GuGibbsArgs& a, int64_t i, in
     for (int c = 0; c < CM; ++c) {
         float v = 1.0f;
         if (!na) v = g[c] < 0 ? 0.0f : table_at(c, g[c]);
-        lh[c] = a.pow_lh ? powf(v, a.inv_t) : v;
+        lh[c] = a.pow_lh ? lib_powf(v, a.inv_t) : v;
     }
     float p[2][CM];
     bool ok = true;
@@ -1543,7 +1544,7 @@ __device__ __forceinline__ void gu_gibbs_obs(const GuGibbsArgs& a, int64_t i, in
 #pragma unroll
         for (int c = 0; c < CM; ++c) {
             float wc = m[c] / wtot;                                 // normalize_weights (likelihood.py:171-190)
-            if (a.pow_w) wc = powf(wc, a.inv_tp);
+            if (a.pow_w) wc = lib_powf(wc, a.inv_tp);
             t[c] = a.from_prior ? wc : wc * lh[c];
         }
         if (a.from_prior) {

@@ -25,6 +25,10 @@ typedef int (*sbe_get_info_t)(const sbe_engine*, sbe_info*);
 typedef int (*sbe_host_group_ids_t)(const uint8_t*, int, int64_t, const int32_t*, int, int, int32_t*);
 typedef int (*sbe_host_source_ids_t)(const uint8_t*, int64_t, int, int, const int32_t*, int, uint8_t*);
 typedef int (*sbe_host_touched_groups_t)(const int32_t*, const int32_t*, int64_t, int, int32_t*, int32_t*);
+typedef int (*sbe_gibbs_propose_supported_t)(sbe_engine*);
+typedef int (*sbe_gibbs_propose_t)(sbe_engine*, int, int, const int32_t*, int, double, double, int, const double*, uint8_t*, float*, float*,
+                                   int32_t*, int32_t*, float*);
+typedef int (*sbe_test_roundtrip_t)(sbe_engine*, int, int);
 
 static void* slurp(FILE* f, size_t bytes) {
     void* p = malloc(bytes ? bytes : 1);
@@ -40,6 +44,7 @@ int main(int argc, char** argv) {
     LOAD(sbe_set_concentration) LOAD(sbe_update_probs) LOAD(sbe_set_weights) LOAD(sbe_mixture_loglik)
     LOAD(sbe_collapsed_loglik) LOAD(sbe_get_info)
     LOAD(sbe_host_group_ids) LOAD(sbe_host_source_ids) LOAD(sbe_host_touched_groups)
+    LOAD(sbe_gibbs_propose_supported) LOAD(sbe_gibbs_propose) LOAD(sbe_test_roundtrip)
     FILE* f = fopen(argv[2], "rb");
     if (!f) { perror("case"); return 1; }
     int32_t hdr[4];                                   /* N, F, S, C */
@@ -48,7 +53,7 @@ int main(int argc, char** argv) {
     int32_t* G = (int32_t*)slurp(f, (size_t)C * sizeof(int32_t));
     uint8_t* feats = (uint8_t*)slurp(f, (size_t)N * F * S);
     sbe_engine* e = NULL;
-    if (p_sbe_create(&e, 0, N, F, S, C, G, 1, feats)) { fprintf(stderr, "create: %s\n", p_sbe_last_error(NULL)); return 4; }
+    if (p_sbe_create(&e, 0, N, F, S, C, G, 2, feats)) { fprintf(stderr, "create: %s\n", p_sbe_last_error(NULL)); return 4; }
     uint8_t* clusters = NULL;
     for (int c = 0; c < C; ++c) {
         uint8_t* groups = (uint8_t*)slurp(f, (size_t)G[c] * N);
@@ -106,6 +111,29 @@ int main(int argc, char** argv) {
         for (int i = 0; i < n; ++i) printf(" %d", (int)sids[(size_t)i * F]);
         printf("\nhost_touched %d\n", n_touched);
         free(sids);
+    }
+    /* round 4, second session: GibbsSampleSource._propose in ONE call (sbe_gibbs_propose), every uniform 0.5: the first
+       objects' source redrawn into slot 1; drawn ids, the groups touched and the sum of the count rows (a redraw moves
+       counts between rows: they sum to zero) */
+    if (p_sbe_test_roundtrip(e, 4, 3) != 0) { fprintf(stderr, "%s\n", p_sbe_last_error(e)); return 16; }
+    if (p_sbe_gibbs_propose_supported(e) == 1) {
+        const int n = N < 5 ? N : 5;
+        int32_t objs[5] = {0, 1, 2, 3, 4}, touched[256], n_touched = 0;
+        double* z = (double*)malloc((size_t)n * F * sizeof(double));
+        for (int i = 0; i < n * F; ++i) z[i] = 0.5;
+        uint8_t* ids = (uint8_t*)malloc((size_t)n * F);
+        float* sel = (float*)malloc((size_t)n * F * sizeof(float));
+        float* back = (float*)malloc((size_t)n * F * sizeof(float));
+        float* rows = (float*)malloc((size_t)256 * F * S * sizeof(float));
+        if (p_sbe_gibbs_propose(e, 0, 1, objs, n, 1.0, 1.0, 0, z, ids, sel, back, touched, &n_touched, rows)) {
+            fprintf(stderr, "%s\n", p_sbe_last_error(e)); return 17;
+        }
+        double row_sum = 0.0;
+        for (long i = 0; i < (long)n_touched * F * S; ++i) row_sum += rows[i];
+        printf("propose_ids");
+        for (int i = 0; i < n * F && i < 24; ++i) printf(" %d", (int)ids[i]);
+        printf("\npropose_touched %d\npropose_row_sum %.1f\npropose_sel0 %.9g\n", n_touched, row_sum, (double)sel[0]);
+        free(z); free(ids); free(sel); free(back); free(rows);
     }
     free(clusters);
     p_sbe_destroy(e);

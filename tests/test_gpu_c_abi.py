@@ -49,3 +49,19 @@ def test_plain_c_caller(tmp_path):
     assert [int(v) for v in vals["host_sids"].split()] == np.where(src0.any(-1), src0.argmax(-1), 255).tolist()
     moved = np.where(want_gids < 0, -1, (want_gids + 1) % fx.groups[0].shape[0])
     assert int(vals["host_touched"]) == len(set(want_gids[want_gids >= 0]) | set(moved[moved >= 0]))
+    # second session: the one-call Gibbs proposal through the plain-C boundary = the Python wrapper's answer for the same input
+    from sbayes_amd.engine import Engine
+    with Engine(fx.features, [g.shape[0] for g in fx.groups], n_slots=2) as eng:
+        for c in range(fx.n_comp):
+            eng.set_concentration(c, fx.conc[c])
+            eng.set_groups(0, c, fx.groups[c])
+        eng.set_source(0, fx.source)
+        eng.recount(0)
+        eng.update_probs(0, range(fx.n_comp))
+        eng.set_weights(0, fx.weights)
+        if eng.gibbs_propose_supported():
+            objs = np.arange(min(n, 5), dtype=np.int32)
+            ids, sel, _back, touched, rows = eng.gibbs_propose(0, 1, objs, np.full((objs.size, f), 0.5))
+            assert [int(v) for v in vals["propose_ids"].split()] == ids.reshape(-1)[:24].tolist()
+            assert int(vals["propose_touched"]) == touched.size and float(vals["propose_row_sum"]) == float(rows.sum()) == 0.0
+            assert abs(float(vals["propose_sel0"]) - float(sel[0, 0])) <= 1e-7
