@@ -10,7 +10,11 @@ import numpy as np
 
 from . import _lib
 
+import os
+
 try:
+    if os.environ.get("SBAYES_AMD_NO_PYHOST"):        # (tests: force the ctypes route)
+        raise ImportError("disabled by SBAYES_AMD_NO_PYHOST")
     from . import _sbe_pyhost as _h
 except ImportError:                                   # not built: the ctypes route below
     _h = None

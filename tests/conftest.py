@@ -22,6 +22,12 @@ def pytest_sessionstart(session):
     import __graft_entry__ as entry
     if entry.stale() and (os.path.exists(entry.HIPCC) or shutil.which("hipcc")):
         entry.build()
+    # the host layer's CPython extension (plain C): same rule; without a compiler the ctypes route of _fast.py serves
+    if shutil.which(os.environ.get("CC", "gcc")):
+        try:
+            entry.build_pyhost()
+        except Exception as exc:                         # (no Python.h here: the fallback is exercised instead)
+            print(f"[conftest] sbayes_amd._sbe_pyhost not built: {exc}", file=sys.stderr)
 
 
 @pytest.fixture(scope="session")

@@ -2,6 +2,10 @@
 gives what the Python / NumPy forms it replaces give -- addresses, subset ids (against the reference expressions of
 counts.py:21-27), row diffs, touched groups, and the bind cache's token comparison (binding._token / _same)."""
 import ctypes as ct
+import os
+import subprocess
+import sys
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -9,12 +13,27 @@ import pytest
 from sbayes_amd import _fast, _lib, binding
 from sbayes_amd import state as st
 
+REPO = Path(__file__).resolve().parent.parent
 ext = pytest.mark.skipif(not _fast.HAVE_EXTENSION, reason="sbayes_amd._sbe_pyhost not built (python __graft_entry__.py)")
 
 
 def test_the_extension_is_built_here():
     """build() compiles it; the suite runs the native route, not the fallback."""
-    assert _fast.HAVE_EXTENSION
+    assert _fast.HAVE_EXTENSION or os.environ.get("SBAYES_AMD_NO_PYHOST")
+
+
+def test_the_ctypes_route_gives_the_same_host_layer():
+    """Without the extension (SBAYES_AMD_NO_PYHOST=1: what a box without a C compiler gets) the same helpers run through
+    the engine library's sbe_host_* exports and the bind cache compares its tokens in Python: this file's checks and the host
+    logic tests pass unchanged."""
+    if os.environ.get("SBAYES_AMD_NO_PYHOST"):
+        pytest.skip("already on the ctypes route")
+    env = dict(os.environ, SBAYES_AMD_NO_PYHOST="1")
+    res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", str(REPO / "tests" / "test_fast_host_cpu.py"),
+                          str(REPO / "tests" / "test_host_logic_cpu.py"), str(REPO / "tests" / "test_dynamic_priors_cpu.py")],
+                         cwd=str(REPO), env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert "passed" in res.stdout
 
 
 @ext
