@@ -2635,10 +2635,15 @@ static int set_counts_rows_impl(sbe_engine* e, int slot, const int32_t* group_id
     }
     rc = clear_status_word(e, ST_BAD_NORMALIZE);
     if (rc) return rc;
-    k_set_count_rows_probs<<<div_up((int64_t)n_rows * e->F, 256), 256, 0, e->stream>>>(
-        (const float*)v_rows, (const int32_t*)v_idx, e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc,
-        e->d_probs + (int64_t)slot * e->table_elems(), e->d_probs_t + (int64_t)slot * e->probs_t_elems(), n_rows, e->F, e->S, e->Gtot,
-        e->ft, e->d_status);
+    auto launch = [&](auto kernel, int lanes_per_row) {
+        kernel<<<div_up((int64_t)n_rows * e->F * lanes_per_row, 256), 256, 0, e->stream>>>(
+            (const float*)v_rows, (const int32_t*)v_idx, e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc,
+            e->d_probs + (int64_t)slot * e->table_elems(), e->d_probs_t + (int64_t)slot * e->probs_t_elems(), n_rows, e->F, e->S, e->Gtot,
+            e->ft, e->d_status);
+    };
+    if (e->S <= 8) launch(k_set_count_rows_probs_x<8>, 8);
+    else if (e->S <= 16) launch(k_set_count_rows_probs_x<16>, 16);
+    else launch(k_set_count_rows_probs, 1);
     HIPCHK(e, hipGetLastError());
     return check_after(e, ST_BAD_NORMALIZE, "sbe_set_counts_rows_probs");
 }
@@ -2653,16 +2658,18 @@ int sbe_set_counts_rows_probs(sbe_engine* e, int slot, const int32_t* group_idx,
 
 // k_given_unchanged_fused: LDS image of a 16-feature tile and the arguments both forms share
 constexpr size_t kGuFusedLdsMax = (size_t)96 << 10;
-static size_t gu_fused_lds_bytes(int R, int S, int C, int n_sub, int N) {
-    return ((size_t)R * 16 * S + (size_t)n_sub * (1 + C) + (size_t)(N + 31) / 32) * sizeof(int32_t);
+static size_t gu_fused_lds_bytes(int R, int S, size_t in_bytes, int N) {
+    return ((size_t)R * 16 * S + (size_t)(N + 31) / 32) * sizeof(int32_t) + in_bytes;
 }
+// `in_bytes` of the call's host-mapped block (a multiple of 256) are staged by the kernel; the arrays sit at these byte offsets
 static GuFusedArgs gu_fused_args(sbe_engine* e, int slot, int i_cluster, int n_sub, int R, double temperature, double prior_temperature,
-                                 const int32_t* table_offsets_host, const int32_t* d_objects, const int32_t* d_group_idx) {
+                                 const int32_t* table_offsets_host, size_t in_bytes, size_t group_idx_at, size_t hc_new_at, size_t hc_old_at) {
     GuFusedArgs fa{};
     const int C = e->C;
     fa.state = e->d_state; fa.gid = e->d_gid + (int64_t)slot * C * e->Np; fa.src = e->d_src + (int64_t)slot * e->N * e->Fp;
     fa.counts = e->d_counts + (int64_t)slot * e->table_elems();
-    fa.objects = d_objects; fa.group_idx = d_group_idx;
+    fa.mapped_in = reinterpret_cast<const uint32_t*>(e->d_io); fa.in_words = (int)(in_bytes / 4);
+    fa.objects_word = 0; fa.group_idx_word = (int)(group_idx_at / 4); fa.hc_new_word = (int)(hc_new_at / 4); fa.hc_old_word = (int)(hc_old_at / 4);
     for (int c = 0; c < C; ++c) fa.table_offsets[c] = table_offsets_host[c];
     fa.conc = e->d_conc; fa.unif = e->d_unif_res; fa.temperature = temperature; fa.prior_temperature = prior_temperature;
     fa.status = e->d_status;
@@ -2719,10 +2726,9 @@ int sbe_given_unchanged_lh(sbe_engine* e, int slot, int i_cluster, const int32_t
     if (rc) return rc;
     // one launch (k_given_unchanged_fused: tables built per 16-feature tile in LDS and consumed there) when the tile's
     // image fits; otherwise -- or with SBE_OPT_FUSE_TABLES off -- the table kernel and the gather, two launches
-    const size_t fused_lds = gu_fused_lds_bytes(R, S, C, n_sub, N);
+    const size_t fused_lds = gu_fused_lds_bytes(R, S, ob + mb + gb, N);
     if (e->opt_fuse_tables && mapped_out && fused_lds <= kGuFusedLdsMax) {
-        GuFusedArgs fa = gu_fused_args(e, slot, i_cluster, n_sub, R, temperature, prior_temperature, off,
-                                       (const int32_t*)e->d_io, (const int32_t*)(e->d_io + ob + mb));
+        GuFusedArgs fa = gu_fused_args(e, slot, i_cluster, n_sub, R, temperature, prior_temperature, off, ob + mb + gb, ob + mb, 0, 0);
         const double inv_t = 1.0 / temperature;
         fa.out = d_out; fa.inv_t = (float)inv_t; fa.use_pow = inv_t != 1.0;
         const unsigned blocks = (unsigned)div_up(F, 16);
@@ -2835,10 +2841,10 @@ int sbe_given_unchanged_gibbs(sbe_engine* e, int slot, int i_cluster, const int3
     const double inv_t = 1.0 / temperature, inv_tp = 1.0 / prior_temperature;
     a.inv_t = (float)inv_t; a.inv_tp = (float)inv_tp; a.pow_lh = inv_t != 1.0; a.pow_w = inv_tp != 1.0; a.from_prior = from_prior ? 1 : 0;
     uint8_t* d_ids = e->d_io + in_bytes;
-    const size_t fused_lds = gu_fused_lds_bytes(R, S, C, n_sub, N);
+    const size_t fused_lds = gu_fused_lds_bytes(R, S, in_bytes, N);
     if (e->opt_fuse_tables && fused_lds <= kGuFusedLdsMax) {        // one launch (see sbe_given_unchanged_lh)
-        const GuFusedArgs fa = gu_fused_args(e, slot, i_cluster, n_sub, R, temperature, prior_temperature, off,
-                                             (const int32_t*)e->d_io, (const int32_t*)(e->d_io + ob));
+        const GuFusedArgs fa = gu_fused_args(e, slot, i_cluster, n_sub, R, temperature, prior_temperature, off, in_bytes, ob,
+                                             ob + gb + fb, ob + gb + fb + hb);
         const unsigned blocks = (unsigned)div_up(F, 16);
         const DoneSig done = next_done(e, blocks);
         k_given_unchanged_fused<true><<<blocks, kUnchangedBlock, fused_lds, e->stream>>>(
@@ -4479,6 +4485,16 @@ int sbe_test_lgamma(sbe_engine* e, const double* in, int n, double* out) {
     HIPCHK(e, hipGetLastError());
     return d2h(e, out, d_o, (size_t)n * sizeof(double));
 }
+
+#ifdef SBE_WS_CLOCK
+// debug build only: the wall-clock stamps block 0 of k_given_unchanged_fused left (100 MHz ticks)
+int sbe_debug_gu_clk(sbe_engine* e, unsigned long long* out16) {
+    CHECK_ENGINE(e);
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_gu_clk), 16 * sizeof(unsigned long long)));
+    return SBE_OK;
+}
+#endif
 
 int sbe_test_roundtrip(sbe_engine* e, int n_blocks, int mode) {
     CHECK_ENGINE(e);

@@ -289,6 +289,7 @@ __global__ void k_f32_to_i32(const float* __restrict__ in, int32_t* __restrict__
 // otherwise; every table kernel is a latency chain of such rows.  The additions stay (u + (a - u) is not always a).
 #ifdef SBE_WS_CLOCK
 __device__ uint64_t g_probs_row_clk[4];      // (debug build: wall-clock stamps of the last probs_row, any thread)
+__device__ uint64_t g_gu_clk[16];            // (debug build: stamps of block 0 of k_given_unchanged_fused)
 #endif
 // S <= CAP: the row's S posterior values are computed once into registers -- the 3 S loads issued together, the tempering
 // divisions independent of each other -- summed by np_sum_regs and divided; beyond CAP the general form (values recomputed
@@ -351,6 +352,37 @@ __device__ __forceinline__ void probs_row(GetCount cnt, const double* __restrict
     const double total = np_pairwise_sum<double>(post, S);
     if (status && !(total > 0.0)) raise_status(status, ST_BAD_NORMALIZE, 1);
     for (int s = 0; s < S; ++s) emit(s, (float)(post(s) / total));
+}
+
+// The same row built by W = 16 (or 8) consecutive lanes together (S <= W): lane j of the group loads and tempers state j -- the
+// group's loads are one coalesced access per operand instead of S strided ones per thread -- every lane gathers the sixteen
+// posterior values by shuffles and sums them itself in NumPy's order (np_sum_regs: the same additions on the same values),
+// and there is ONE division per lane instead of S in a row per thread (a correctly rounded fp64 division is a dependent
+// chain of a dozen instructions: ten of them back to back were half of a 4 us row; profiles/r4/gu_kernel_clock.log).
+// Convergent: every lane of the wave calls it, `row_on` says whether its group has a row.  Same bits as probs_row.
+template <int W = 16, class GetCount, class Emit>
+__device__ __forceinline__ void probs_row_x16(int j, bool row_on, GetCount cnt, const double* __restrict__ conc_row,
+                                              const double* __restrict__ unif_row, int S, double temperature, double prior_temperature,
+                                              int* __restrict__ status, Emit emit) {
+    const bool tempered = temperature > 0.0 && temperature != 1.0;
+    const bool prior_shaped = prior_temperature > 0.0 && unif_row != nullptr;
+    const bool prior_tempered = prior_shaped && prior_temperature != 1.0;
+    const bool on = row_on && j < S;
+    float c = on ? cnt(j) : 0.0f;
+    double a = on ? conc_row[j] : 0.0;
+    const double u = (on && prior_shaped) ? unif_row[j] : 0.0;
+    if (tempered) c = c / (float)temperature;
+    if (prior_shaped) {
+        const double d = a - u;
+        a = u + (prior_tempered ? d / prior_temperature : d);
+    }
+    const double pv = (double)c + a;
+    double v[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) v[k] = __shfl(pv, k, W);
+    const double total = np_sum_regs<double, W>(v, S);
+    if (row_on && j == 0 && status && !(total > 0.0)) raise_status(status, ST_BAD_NORMALIZE, 1);
+    if (on) emit(j, (float)(pv / total));
 }
 
 // The inputs of one tempered table row, resident in device memory: what a consumer kernel needs to build the rows it
@@ -1505,7 +1537,8 @@ struct GuGibbsArgs {
 // Register form: the has_components bytes (host-mapped: a PCIe read each), the weights and the table entries are loaded
 // once, up front and together; every array is indexed statically (unrolled, guarded by c < C).
 template <class GroupOf, class TableAt>
-__device__ __forceinline__ void gu_gibbs_obs(const GuGibbsArgs& a, int64_t i, int r, int f, uint8_t x, GroupOf group_of, TableAt table_at,
+__device__ __forceinline__ void gu_gibbs_obs(const GuGibbsArgs& a, int64_t i, int r, int f, uint8_t x, double zz, int id_old,
+                                             GroupOf group_of, TableAt table_at,
                                              uint8_t* __restrict__ src_new, float* __restrict__ sel_new, float* __restrict__ sel_back,
                                              int* __restrict__ status) {
     constexpr int CM = kMaxComponents;
@@ -1514,8 +1547,6 @@ __device__ __forceinline__ void gu_gibbs_obs(const GuGibbsArgs& a, int64_t i, in
     const float* w = a.weights + (int64_t)f * C;
     const uint8_t* hcn = a.hc_new + (int64_t)r * C;
     const uint8_t* hco = a.hc_old + (int64_t)r * C;
-    const double zz = a.z[i];
-    const int id_old = a.src_old[i];
     float wr[CM], lh[CM];
     uint8_t hn[CM], ho[CM];
     int g[CM];
@@ -1589,7 +1620,7 @@ __global__ __launch_bounds__(kBlock) void k_given_unchanged_gibbs(GuGibbsArgs a,
     if (i < (int64_t)a.n_sub * a.F) {
         const int r = (int)(i / a.F), f = (int)(i % a.F);
         const uint8_t x = a.state[(int64_t)a.objects[r] * a.Fp + f];
-        gu_gibbs_obs(a, i, r, f, x, [&](int c) { return a.group_idx[(int64_t)c * a.n_sub + r]; },
+        gu_gibbs_obs(a, i, r, f, x, a.z[i], (int)a.src_old[i], [&](int c) { return a.group_idx[(int64_t)c * a.n_sub + r]; },
                      [&](int c, int g) { return a.tables[((int64_t)(a.table_offsets[c] + g) * a.F + f) * a.S + x]; },
                      src_new, sel_new, sel_back, status);
     }
@@ -2019,6 +2050,29 @@ __global__ void k_set_count_rows_probs(const float* __restrict__ rows /* [n][F][
               [&](int s, float v) { out_row[s] = v; out_t[(int64_t)s * ft] = v; });
 }
 
+// The same for S <= W (8 or 16): W lanes per (row, feature), lane j <-> state j (probs_row_x16) -- the staged float rows are
+// read coalesced (they sit in host-mapped memory: S reads at a 4 S-byte stride per thread were S PCIe requests each), one
+// division per lane.
+template <int W>
+__global__ void k_set_count_rows_probs_x(const float* __restrict__ rows /* [n][F][S] */, const int32_t* __restrict__ group_idx,
+                                         int32_t* __restrict__ counts, const double* __restrict__ conc, float* __restrict__ probs,
+                                         float* __restrict__ probs_t, int n, int F, int S, int Gtot, int ft, int* __restrict__ status) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t grp = t / W;
+    const int j = (int)(t % W);
+    const bool row_on = grp < (int64_t)n * F;
+    const int i = row_on ? (int)(grp / F) : 0, f = row_on ? (int)(grp % F) : 0;
+    const int g = row_on ? group_idx[i] : 0, tile = f / ft, tl = f % ft;
+    const float* in = rows + grp * S;
+    const int64_t base = ((int64_t)g * F + f) * S;
+    float cj = 0.0f;
+    if (row_on && j < S) { cj = (float)(int32_t)in[j]; counts[base + j] = (int32_t)in[j]; }
+    float* out_row = probs + base;
+    float* out_t = probs_t + (((int64_t)tile * (Gtot + 1) + g) * S) * ft + tl;                 // (k_probs' tile layout)
+    probs_row_x16<W>(j, row_on, [&](int) { return cj; }, conc + base, nullptr, S, 0.0, 0.0, status,
+                     [&](int s, float v) { out_row[s] = v; out_t[(int64_t)s * ft] = v; });
+}
+
 // ------------------------------------------------------------------------------------------
 // component_likelihood_given_unchanged (operators.py:863-928), count part, from RESIDENT data: the float32 count tables
 // the reference builds from the observations that are NOT being resampled,
@@ -2108,13 +2162,15 @@ __global__ __launch_bounds__(kUnchangedBlock) void k_unchanged_counts(
 // histograms (row 0 over the cluster's members outside the subset, the confounder rows in one pass over the subset) and
 // probs_row's normalisation, same operations in the same order -- and then serves the subset's observations of its features
 // out of LDS: k_subset_lh's gather (kGibbs = false) or k_given_unchanged_gibbs' resampling (kGibbs = true).  No table in
-// global memory, no second launch waiting for the first.  The subset's object list and table rows (host-mapped) are read
-// once per block, coalesced.  LDS: tables [R][16][S] (int32 histogram, then float32 in place) | object list | rows | bitmap.
+// global memory, no second launch waiting for the first.  The call's host-mapped input block (object list, table rows,
+// has_components rows) is staged into LDS in one PCIe round trip per block.  LDS: tables [R][16][S] (int32 histogram, then
+// float32 in place) | staged input block | bitmap.
 // ------------------------------------------------------------------------------------------
 struct GuFusedArgs {
     const uint8_t* state; const uint16_t* gid; const uint8_t* src; const int32_t* counts;
-    const int32_t* objects;          // [n_sub]            (host-mapped)
-    const int32_t* group_idx;        // [C][n_sub] group of the object within its component, -1 none (host-mapped)
+    const uint32_t* mapped_in;       // the call's host-mapped input block: object list [n_sub] | group_idx [C][n_sub] (group of the
+    int in_words;                    //   object within its component, -1 none) | ... | has_components rows (Gibbs form); `in_words`
+    int objects_word, group_idx_word, hc_new_word, hc_old_word;   //   32-bit words in all, the arrays at these word offsets
     int table_offsets[kMaxComponents];   // first table row of component c (0 for the cluster, 1 + goff[c] - K)
     const double* conc; const double* unif;
     double temperature, prior_temperature;
@@ -2129,73 +2185,128 @@ __global__ __launch_bounds__(kUnchangedBlock) void k_given_unchanged_fused(GuFus
                                                                            float* __restrict__ sel_new, float* __restrict__ sel_back,
                                                                            DoneSig done = DoneSig{}) {
     constexpr int FTU = 16, OL = kUnchangedBlock / FTU;
+#ifdef SBE_WS_CLOCK
+#define GU_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_gu_clk[k] = wall_clock64(); } while (0)
+#else
+#define GU_STAMP(k) do { } while (0)
+#endif
+    GU_STAMP(0);
     extern __shared__ int32_t lds[];
     const int S = a.S, R = a.R, n_sub = a.n_sub, C = a.C;
     int32_t* hist = lds;                                                 // [R][FTU][S]
-    int32_t* sub = hist + R * FTU * S;                                   // [n_sub]
-    int32_t* gidx = sub + n_sub;                                         // [C][n_sub]
-    uint32_t* in_subset = reinterpret_cast<uint32_t*>(gidx + C * n_sub); // [(N + 31) / 32]
+    uint32_t* stage = reinterpret_cast<uint32_t*>(hist + R * FTU * S);   // the call's host-mapped input block, word for word
+    uint32_t* in_subset = stage + a.in_words;                            // [(N + 31) / 32]
+    const int32_t* sub = reinterpret_cast<const int32_t*>(stage + a.objects_word);       // [n_sub]
+    const int32_t* gidx = reinterpret_cast<const int32_t*>(stage + a.group_idx_word);    // [C][n_sub]
     const int f0 = blockIdx.x * FTU;
+    // the whole input block (object list, table rows, has_components rows) crosses PCIe in ONE round trip: every thread's
+    // loads are issued before the first LDS store waits for one (two loops over two mapped arrays were two round trips)
+    for (int i0 = threadIdx.x; i0 < a.in_words; i0 += 4 * kUnchangedBlock) {
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int i = i0 + j * kUnchangedBlock; v[j] = i < a.in_words ? a.mapped_in[i] : 0u; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int i = i0 + j * kUnchangedBlock; if (i < a.in_words) stage[i] = v[j]; }
+    }
+    // Gibbs form: the uniform and the old source id of the observation this thread serves first (the consumer loop below:
+    // t = threadIdx.x) are asked for now -- they sit in host-mapped staging, and their round trip hides behind the rest
+    double z_first = 0.0;
+    int id_old_first = 0xFF;
+    if constexpr (kGibbs) {
+        const int r = threadIdx.x / FTU, ff = f0 + (threadIdx.x & (FTU - 1));
+        if (r < n_sub && ff < a.F) { z_first = gb.z[(int64_t)r * a.F + ff]; id_old_first = gb.src_old[(int64_t)r * a.F + ff]; }
+    }
     for (int i = threadIdx.x; i < R * FTU * S; i += kUnchangedBlock) hist[i] = 0;
-    for (int i = threadIdx.x; i < n_sub; i += kUnchangedBlock) sub[i] = a.objects[i];
-    for (int i = threadIdx.x; i < C * n_sub; i += kUnchangedBlock) gidx[i] = a.group_idx[i];
     for (int i = threadIdx.x; i < (a.N + 31) / 32; i += kUnchangedBlock) in_subset[i] = 0u;
     __syncthreads();
+    GU_STAMP(1);
     for (int i = threadIdx.x; i < n_sub; i += kUnchangedBlock) atomicOr(&in_subset[sub[i] >> 5], 1u << (sub[i] & 31));
     __syncthreads();
+    GU_STAMP(2);
     const int fl = threadIdx.x & (FTU - 1), ol = threadIdx.x / FTU;
     const int f = f0 + fl;
     if (f < a.F) {
-        // row 0: members of the cluster outside the subset whose source is the cluster component (operators.py:876-883)
         const uint16_t want = (uint16_t)a.i_cluster;
-        for (int n = ol; n < a.N; n += 8 * OL) {
-            bool take[8];
-            uint8_t x[8], sc[8];
+        constexpr int U = 16;                                            // objects per lane and pass: two load levels per pass
+        for (int n = ol; n < a.N; n += U * OL) {
+            // row 0: members of the cluster outside the subset whose source is the cluster component (operators.py:876-883)
+            uint16_t gd[U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < U; ++j) { const int nn = n + j * OL; gd[j] = nn < a.N ? a.gid[nn] : kNoGroup; }
+            if (n == ol) {
+                // confounder rows, under the ids' flight: what the subset's objects contribute to their groups' counts comes
+                // off (operators.py:896-901)
+                for (int i = ol; i < n_sub; i += OL) {
+                    const int64_t at = (int64_t)sub[i] * a.Fp + f;
+                    const uint8_t x = a.state[at], sc = a.src[at];
+                    if (x == kNA || sc == 0 || sc >= C) continue;
+                    const int g = gidx[sc * n_sub + i];
+                    if (g >= 0) atomicAdd(&hist[((a.table_offsets[sc] + g) * FTU + fl) * S + x], -1);
+                }
+            }
+            uint8_t x[U], sc[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
                 const int nn = n + j * OL;
-                take[j] = nn < a.N && a.gid[nn] == want && !((in_subset[nn >> 5] >> (nn & 31)) & 1u);
+                const bool take = nn < a.N && gd[j] == want && !((in_subset[nn >> 5] >> (nn & 31)) & 1u);
+                const int64_t at = (int64_t)nn * a.Fp + f;
+                x[j] = take ? a.state[at] : kNA;
+                sc[j] = take ? a.src[at] : kNA;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int64_t at = (int64_t)(n + j * OL) * a.Fp + f;
-                x[j] = take[j] ? a.state[at] : kNA;
-                sc[j] = take[j] ? a.src[at] : kNA;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < U; ++j)
                 if (x[j] != kNA && sc[j] == 0) atomicAdd(&hist[fl * S + x[j]], 1);
         }
-        // confounder rows: what the subset's objects contribute to their groups' counts comes off (operators.py:896-901)
-        for (int i = ol; i < n_sub; i += OL) {
-            const int64_t at = (int64_t)sub[i] * a.Fp + f;
-            const uint8_t x = a.state[at], sc = a.src[at];
-            if (x == kNA || sc == 0 || sc >= C) continue;
-            const int g = gidx[sc * n_sub + i];
-            if (g >= 0) atomicAdd(&hist[((a.table_offsets[sc] + g) * FTU + fl) * S + x], -1);
+    }
+    __syncthreads();
+    GU_STAMP(3);
+    // conditional_effect_mean (conditionals.py:105-122) of the kept counts, in place: sixteen lanes per (row, feature) when
+    // S <= 16 (probs_row_x16), else one thread per row
+    auto rows_by_lane_groups = [&](auto width) {
+        constexpr int W = decltype(width)::value;
+        for (int row0 = 0; row0 < R * FTU; row0 += kUnchangedBlock / W) {
+            const int row = row0 + (int)threadIdx.x / W, j = threadIdx.x & (W - 1);
+            const int r = row / FTU, tf = row % FTU, ff = f0 + tf;
+            const bool row_on = row < R * FTU && ff < a.F;
+            const int gg = r == 0 ? a.i_cluster : a.K + r - 1;       // rows 1.. are the confounder groups in global order
+            const int64_t at = row_on ? ((int64_t)gg * a.F + ff) * S : 0;
+            int32_t* h = hist + (row_on ? (r * FTU + tf) * S : 0);
+            probs_row_x16<W>(j, row_on, [&](int s) { return (float)((r == 0 ? 0 : a.counts[at + s]) + h[s]); }, a.conc + at,
+                             a.unif + (row_on ? (int64_t)ff * S : 0), S, a.temperature, a.prior_temperature, a.status,
+                             [&](int s, float v) { h[s] = __float_as_int(v); });
+        }
+    };
+    if (S <= 8) rows_by_lane_groups(std::integral_constant<int, 8>{});
+    else if (S <= 16) rows_by_lane_groups(std::integral_constant<int, 16>{});
+    else {
+        for (int t = threadIdx.x; t < R * FTU; t += kUnchangedBlock) {
+            const int r = t / FTU, tf = t % FTU, ff = f0 + tf;
+            if (ff >= a.F) continue;
+            const int gg = r == 0 ? a.i_cluster : a.K + r - 1;
+            const int32_t* base = a.counts + ((int64_t)gg * a.F + ff) * S;
+            int32_t* h = hist + (r * FTU + tf) * S;
+            probs_row([&](int s) { return (float)((r == 0 ? 0 : base[s]) + h[s]); }, a.conc + ((int64_t)gg * a.F + ff) * S,
+                      a.unif + (int64_t)ff * S, S, a.temperature, a.prior_temperature, a.status,
+                      [&](int s, float v) { h[s] = __float_as_int(v); });
         }
     }
     __syncthreads();
-    // conditional_effect_mean (conditionals.py:105-122) of the kept counts: one thread per (row, feature), in place
-    for (int t = threadIdx.x; t < R * FTU; t += kUnchangedBlock) {
-        const int r = t / FTU, tf = t % FTU, ff = f0 + tf;
-        if (ff >= a.F) continue;
-        const int gg = r == 0 ? a.i_cluster : a.K + r - 1;           // rows 1.. are the confounder groups in global order
-        const int32_t* base = a.counts + ((int64_t)gg * a.F + ff) * S;
-        int32_t* h = hist + (r * FTU + tf) * S;
-        probs_row([&](int s) { return (float)((r == 0 ? 0 : base[s]) + h[s]); }, a.conc + ((int64_t)gg * a.F + ff) * S,
-                  a.unif + (int64_t)ff * S, S, a.temperature, a.prior_temperature, a.status,
-                  [&](int s, float v) { h[s] = __float_as_int(v); });
-    }
-    __syncthreads();
+    GU_STAMP(4);
     const float* tab = reinterpret_cast<const float*>(hist);
+    GuGibbsArgs g2 = gb;
+    if constexpr (kGibbs) {                                              // (the has_components rows: out of the staged block)
+        g2.hc_new = reinterpret_cast<const uint8_t*>(stage + a.hc_new_word);
+        g2.hc_old = reinterpret_cast<const uint8_t*>(stage + a.hc_old_word);
+    }
     for (int t = threadIdx.x; t < n_sub * FTU; t += kUnchangedBlock) {
         const int r = t / FTU, tf = t % FTU, ff = f0 + tf;
         if (ff >= a.F) continue;
         const uint8_t x = a.state[(int64_t)sub[r] * a.Fp + ff];
         const int64_t i = (int64_t)r * a.F + ff;
         if constexpr (kGibbs) {
-            gu_gibbs_obs(gb, i, r, ff, x, [&](int c) { return gidx[c * n_sub + r]; },
+            const bool first = t == (int)threadIdx.x;
+            gu_gibbs_obs(g2, i, r, ff, x, first ? z_first : gb.z[i], first ? id_old_first : (int)gb.src_old[i],
+                         [&](int c) { return gidx[c * n_sub + r]; },
                          [&](int c, int g) { return tab[((a.table_offsets[c] + g) * FTU + tf) * S + x]; },
                          src_new, sel_new, sel_back, a.status);
         } else {
@@ -2206,10 +2317,14 @@ __global__ __launch_bounds__(kUnchangedBlock) void k_given_unchanged_fused(GuFus
                     const int g = gidx[c * n_sub + r];
                     v = g < 0 ? 0.0f : tab[((a.table_offsets[c] + g) * FTU + tf) * S + x];
                 }
-                o[c] = a.use_pow ? powf(v, a.inv_t) : v;
+                o[c] = a.use_pow ? lib_powf(v, a.inv_t) : v;
             }
         }
     }
+#ifdef SBE_WS_CLOCK
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    GU_STAMP(5);
     signal_done(done);
 }
 
