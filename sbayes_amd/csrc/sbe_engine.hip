@@ -2577,9 +2577,27 @@ int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const 
     const size_t o_sn = o;   memcpy(h + o, src_new, (size_t)n_subset * F); o += sb;
     const size_t o_t = o;    memcpy(h + o, touched, (size_t)n_touched * 4); o += tb;
     const size_t o_tc = o;   memcpy(h + o, comp.data(), (size_t)n_touched * 4); o += tb;
-    // the kernel walks the listed objects one after another (ids, then the object's rows): out of host-mapped memory
-    // every step of that walk would be a PCIe round trip, so the packed inputs go to device memory with ONE copy from
-    // the pinned block; the diff rows come back through the mapped block (posted writes)
+    // small subsets (the usual update_feature_counts: a few dozen objects): one launch, a block per 16-feature tile stages
+    // what it needs of the mapped block into LDS in one PCIe round trip and serves every touched group (k_counts_delta_tile)
+    const size_t tile_lds = ((size_t)n_touched * kDeltaFT * S + (size_t)e->Gtot + (size_t)n_subset * (1 + 2 * C)) * sizeof(int32_t) +
+                            (size_t)2 * n_subset * kDeltaFT;
+    if (mapped_out && n_subset <= kDeltaTileMaxN && tile_lds <= ((size_t)64 << 10) && e->opt_fuse_tables) {
+        const uint8_t* din = e->d_io;
+        float* d_out = (float*)(e->d_io + o);
+        const unsigned blocks = (unsigned)div_up(F, kDeltaFT);
+        const DoneSig done = next_done(e, blocks);
+        k_counts_delta_tile<<<blocks, kBlock, tile_lds, e->stream>>>(
+            e->d_state, (const int32_t*)(din + o_obj), n_subset, (const int32_t*)(din + o_go), (const int32_t*)(din + o_gn),
+            din + o_so, din + o_sn, (const int32_t*)(din + o_t), n_touched, d_out, F, S, e->Fp, C, e->Gtot, done);
+        HIPCHK(e, hipGetLastError());
+        rc = wait_done(e, done);
+        if (rc) return rc;
+        memcpy(out_diff, h + o, out_bytes);
+        return synced(e);
+    }
+    // larger subsets: the kernel walks the listed objects one after another (ids, then the object's rows): out of
+    // host-mapped memory every step of that walk would be a PCIe round trip, so the packed inputs go to device memory with
+    // ONE copy from the pinned block; the diff rows come back through the mapped block (posted writes)
     const size_t in_bytes = o;
     rc = ensure_scratch(e, in_bytes + (mapped_out ? 0 : out_bytes));
     if (rc) return rc;

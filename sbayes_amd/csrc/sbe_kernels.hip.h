@@ -2018,6 +2018,108 @@ __global__ __launch_bounds__(kBlock) void k_counts_delta(
     signal_done(done);
 }
 
+// The same difference for SMALL subsets in one launch, no copy in front (sbe_counts_delta, n <= kDeltaTileMaxN): a block owns
+// a 16-feature tile and ALL touched groups.  It stages what it needs of the call's host-mapped input block into LDS in one
+// PCIe round trip -- object list, both id arrays, its 16 columns of both source-id arrays (13 blocks read 20 KB in all at
+// the headline shape; the grid over (touched group, tile) would have read every array 78 times) -- and then walks the
+// staged subset: an observation whose new source is component c adds one to its new group of c, one whose old source is c
+// takes one off its old group of c (counts.py:55-95: new counts - old counts over the subset, group by group).
+// LDS: hist [T][16][S] | pos [Gtot] (touched index of a group, -1) | objects [n] | gid_old, gid_new [C][n] | src_old, src_new [n][16].
+constexpr int kDeltaTileMaxN = 256;
+__global__ __launch_bounds__(kBlock) void k_counts_delta_tile(
+    const uint8_t* __restrict__ state, const int32_t* __restrict__ objects, int n, const int32_t* __restrict__ gid_old,
+    const int32_t* __restrict__ gid_new, const uint8_t* __restrict__ src_old, const uint8_t* __restrict__ src_new,
+    const int32_t* __restrict__ touched, int n_touched, float* __restrict__ out /* [T][F][S] */, int F, int S, int Fp, int C,
+    int Gtot, DoneSig done) {
+    constexpr int FTU = kDeltaFT, OL = kBlock / FTU;
+    extern __shared__ int32_t dl[];
+    int32_t* hist = dl;                                  // [T][FTU][S]
+    int32_t* pos = hist + n_touched * FTU * S;           // [Gtot]
+    int32_t* obj = pos + Gtot;                           // [n]
+    int32_t* go = obj + n;                               // [C][n]
+    int32_t* gn = go + C * n;                            // [C][n]
+    uint8_t* so = reinterpret_cast<uint8_t*>(gn + C * n);            // [n][FTU]
+    uint8_t* sn = so + n * FTU;                                      // [n][FTU]
+    const int f0 = blockIdx.x * FTU;
+    // one round trip: every mapped load of this thread is issued before the first LDS store waits
+    int32_t v_touched = -1;
+    {
+        int32_t v_obj = 0, v_go[kMaxComponents], v_gn[kMaxComponents];
+        const int i = threadIdx.x;                       // n <= kDeltaTileMaxN = blockDim: one object per thread
+        const bool on = i < n;
+        if (on) v_obj = objects[i];
+        v_touched = (int)threadIdx.x < n_touched ? touched[threadIdx.x] : -1;
+#pragma unroll
+        for (int c = 0; c < kMaxComponents; ++c) {
+            v_go[c] = (on && c < C) ? gid_old[c * n + i] : -1;
+            v_gn[c] = (on && c < C) ? gid_new[c * n + i] : -1;
+        }
+        uint32_t w_so[4], w_sn[4];                       // this thread's share of the source columns: n * 16 bytes = n * 4 words per array
+        int widx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int w = threadIdx.x + k * kBlock;      // word w <-> object w / 4, bytes (w % 4) * 4 .. + 3 of the tile
+            widx[k] = w;
+            w_so[k] = w_sn[k] = 0xFFFFFFFFu;
+            if (w < n * 4) {
+                const int oi = w >> 2, b0 = (w & 3) * 4;
+                if ((F & 3) == 0) {                      // rows of a multiple of four features: the four ids are one aligned word
+                    if (f0 + b0 < F) {
+                        w_so[k] = *reinterpret_cast<const uint32_t*>(src_old + (int64_t)oi * F + f0 + b0);
+                        w_sn[k] = *reinterpret_cast<const uint32_t*>(src_new + (int64_t)oi * F + f0 + b0);
+                    }
+                } else {
+                    uint32_t a = 0, b = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int f = f0 + b0 + q;
+                        const uint32_t x_o = f < F ? src_old[(int64_t)oi * F + f] : 0xFFu;
+                        const uint32_t x_n = f < F ? src_new[(int64_t)oi * F + f] : 0xFFu;
+                        a |= x_o << (8 * q);
+                        b |= x_n << (8 * q);
+                    }
+                    w_so[k] = a; w_sn[k] = b;
+                }
+            }
+        }
+        for (int t = threadIdx.x; t < n_touched * FTU * S; t += kBlock) hist[t] = 0;
+        for (int g = threadIdx.x; g < Gtot; g += kBlock) pos[g] = -1;
+        if (on) obj[i] = v_obj;
+#pragma unroll
+        for (int c = 0; c < kMaxComponents; ++c) if (on && c < C) { go[c * n + i] = v_go[c]; gn[c * n + i] = v_gn[c]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (widx[k] < n * 4) { reinterpret_cast<uint32_t*>(so)[widx[k]] = w_so[k]; reinterpret_cast<uint32_t*>(sn)[widx[k]] = w_sn[k]; }
+    }
+    __syncthreads();
+    if (v_touched >= 0) pos[v_touched] = threadIdx.x;
+    for (int t = threadIdx.x + kBlock; t < n_touched; t += kBlock) pos[touched[t]] = t;          // (more than 256 touched groups)
+    __syncthreads();
+    const int fl = threadIdx.x & (FTU - 1), ol = threadIdx.x / FTU;
+    const int f = f0 + fl;
+    if (f < F) {
+        for (int i0 = ol; i0 < n; i0 += 4 * OL) {                   // four objects per lane and pass: their state loads overlap
+            uint8_t x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int i = i0 + j * OL; x[j] = i < n ? state[(int64_t)obj[i] * Fp + f] : kNA; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j * OL;
+                if (i >= n || x[j] == kNA) continue;
+                const int c_new = sn[i * FTU + fl], c_old = so[i * FTU + fl];
+                if (c_new < C) { const int g = gn[c_new * n + i]; if (g >= 0 && pos[g] >= 0) atomicAdd(&hist[(pos[g] * FTU + fl) * S + x[j]], 1); }
+                if (c_old < C) { const int g = go[c_old * n + i]; if (g >= 0 && pos[g] >= 0) atomicAdd(&hist[(pos[g] * FTU + fl) * S + x[j]], -1); }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_touched * FTU * S; e += kBlock) {
+        const int t = e / (FTU * S), r = e % (FTU * S), ff = f0 + r / S;
+        if (ff < F) out[((int64_t)t * F + ff) * S + r % S] = (float)hist[e];
+    }
+    signal_done(done);
+}
+
 // float32 count rows of listed groups -> the slot's resident int32 counts (Engine.set_counts_rows: the bind cache
 // sends only the groups whose rows differ from what the slot holds)
 __global__ void k_set_count_rows(const float* __restrict__ rows /* [n][F][S] */, const int32_t* __restrict__ group_idx,
