@@ -51,7 +51,7 @@ typedef struct sbe_engine sbe_engine;
 
 #define SBE_ABI_VERSION 5   /* 4 (round 4): + sbe_given_unchanged_gibbs, sbe_host_*; sbe_set_groups rejects overlap;
                                5: + SBE_OPT_FUSE_TABLES, sbe_host_subset_ids, sbe_host_diff_rows, sbe_set_counts_rows_probs,
-                               sbe_gibbs_propose, sbe_test_roundtrip */
+                               sbe_gibbs_propose, sbe_given_unchanged_gibbs_counts, sbe_test_roundtrip */
 
 /* error codes */
 #define SBE_OK 0
@@ -409,6 +409,17 @@ int sbe_given_unchanged_gibbs(sbe_engine* e, int slot, int i_cluster, const int3
                               double prior_temperature, int from_prior, const uint8_t* hc_new /* [n_sub][C] */,
                               const uint8_t* hc_old, const uint8_t* src_old /* [n_sub][F] */, const double* z /* [n_sub][F] */,
                               uint8_t* src_new_out /* [n_sub][F] */, float* sel_new_out, float* sel_back_out);
+/* The same with the count delta of the proposal (update_feature_counts(sample_old, sample_new, features, subset),
+ * sbayes/sampling/counts.py:55-95, which the reference calls right after): gid_old / gid_new [C][n] = the listed objects'
+ * GLOBAL group index per component in the old / new sample (-1: none; sbe_host_subset_ids).  touched_out [<= G_total]
+ * (ascending) + *n_touched_out: the groups any listed object is in, in either sample; diff_rows_out [n_touched][F][S] =
+ * new counts - old counts of those groups (every other row of the difference is zero).  The kernel that draws the new
+ * source also bins the delta -- one launch, one synchronisation for what was this call followed by sbe_counts_delta. */
+int sbe_given_unchanged_gibbs_counts(sbe_engine* e, int slot, int i_cluster, const int32_t* objects, int n_sub, double temperature,
+                                     double prior_temperature, int from_prior, const uint8_t* hc_new, const uint8_t* hc_old,
+                                     const uint8_t* src_old, const double* z, const int32_t* gid_old, const int32_t* gid_new,
+                                     uint8_t* src_new_out, float* sel_new_out, float* sel_back_out, int32_t* touched_out,
+                                     int32_t* n_touched_out, float* diff_rows_out);
 int sbe_cluster_posterior_marginals(sbe_engine* e, int slot, int i_cluster, double temperature, double prior_temperature,
                                     const int32_t* objects, int n_objects_av, double* out /* [2][n_objects_av] */);
 int sbe_jump_lh_resident(sbe_engine* e, int slot, int i_source, int i_target, double temperature, double prior_temperature,

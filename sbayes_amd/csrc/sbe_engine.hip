@@ -2787,11 +2787,15 @@ int sbe_given_unchanged_lh(sbe_engine* e, int slot, int i_cluster, const int32_t
     return SBE_OK;
 }
 
-int sbe_given_unchanged_gibbs(sbe_engine* e, int slot, int i_cluster, const int32_t* objects, int n_sub, double temperature,
-                              double prior_temperature, int from_prior, const uint8_t* hc_new, const uint8_t* hc_old,
-                              const uint8_t* src_old, const double* z, uint8_t* src_new_out, float* sel_new_out,
-                              float* sel_back_out) {
+// `gid_old` non-null: the count delta of the proposal as well (sbe_given_unchanged_gibbs_counts)
+static int given_unchanged_gibbs_impl(sbe_engine* e, int slot, int i_cluster, const int32_t* objects, int n_sub, double temperature,
+                                      double prior_temperature, int from_prior, const uint8_t* hc_new, const uint8_t* hc_old,
+                                      const uint8_t* src_old, const double* z, uint8_t* src_new_out, float* sel_new_out,
+                                      float* sel_back_out, const int32_t* gid_old, const int32_t* gid_new, int32_t* touched_out,
+                                      int32_t* n_touched_out, float* diff_rows_out) {
     CHECK_ENGINE(e); CHECK_SLOT(e, slot);
+    const bool with_counts = gid_old != nullptr;
+    if (with_counts) { CHECK_PTR(e, gid_new); CHECK_PTR(e, touched_out); CHECK_PTR(e, n_touched_out); CHECK_PTR(e, diff_rows_out); *n_touched_out = 0; }
     if (n_sub < 0) return fail(e, SBE_ERR_ARG, "n_sub=%d", n_sub);
     if (n_sub == 0) return SBE_OK;
     CHECK_PTR(e, objects); CHECK_PTR(e, hc_new); CHECK_PTR(e, hc_old); CHECK_PTR(e, src_old); CHECK_PTR(e, z);
@@ -2820,7 +2824,16 @@ int sbe_given_unchanged_gibbs(sbe_engine* e, int slot, int i_cluster, const int3
     const size_t ob = al256((size_t)n_sub * 4), gb = al256((size_t)C * n_sub * 4), fb = al256((size_t)C * 4);
     const size_t hb = al256((size_t)n_sub * C);
     const size_t idb = al256(nf), selb = al256(nf * sizeof(float));
-    const size_t in_bytes = ob + gb + fb + 2 * hb, out_bytes = idb + 2 * selb;
+    // with the count delta: + the subset's global group ids in both samples and the touched groups (in), their rows (out)
+    int n_touched = 0;
+    if (with_counts) {
+        if (sbeh_touched_groups(gid_old, gid_new, (int64_t)C * n_sub, e->Gtot, touched_out, &n_touched) != 0)
+            return fail(e, SBE_ERR_ARG, "group index out of range in the subset's ids");
+        *n_touched_out = n_touched;
+    }
+    const size_t gidb = with_counts ? al256((size_t)C * n_sub * 4) : 0, tchb = with_counts ? al256((size_t)std::max(n_touched, 1) * 4) : 0;
+    const size_t rowb = with_counts ? al256((size_t)std::max(n_touched, 1) * fs * sizeof(float)) : 0;
+    const size_t in_bytes = ob + gb + fb + 2 * hb + 2 * gidb + tchb, out_bytes = idb + 2 * selb + rowb;
     if (out_bytes > ((size_t)8 << 20)) return fail(e, SBE_ERR_ARG, "sbe_given_unchanged_gibbs: %d objects x %d features exceed the mapped result block", n_sub, F);
     rc = ensure_io(e, in_bytes + out_bytes);
     if (rc) return rc;
@@ -2838,6 +2851,12 @@ int sbe_given_unchanged_gibbs(sbe_engine* e, int slot, int i_cluster, const int3
     }
     memcpy(h + ob + gb + fb, hc_new, (size_t)n_sub * C);
     memcpy(h + ob + gb + fb + hb, hc_old, (size_t)n_sub * C);
+    const size_t o_gold = ob + gb + fb + 2 * hb, o_gnew = o_gold + gidb, o_tch = o_gnew + gidb;
+    if (with_counts) {
+        memcpy(h + o_gold, gid_old, (size_t)C * n_sub * 4);
+        memcpy(h + o_gnew, gid_new, (size_t)C * n_sub * 4);
+        memcpy(h + o_tch, touched_out, (size_t)n_touched * 4);
+    }
     const size_t cb = al256((size_t)R * fs * sizeof(float)), zb = al256(nf * sizeof(double)), sob = al256(nf);
     rc = ensure_scratch(e, cb + zb + sob);
     if (rc) return rc;
@@ -2859,10 +2878,16 @@ int sbe_given_unchanged_gibbs(sbe_engine* e, int slot, int i_cluster, const int3
     const double inv_t = 1.0 / temperature, inv_tp = 1.0 / prior_temperature;
     a.inv_t = (float)inv_t; a.inv_tp = (float)inv_tp; a.pow_lh = inv_t != 1.0; a.pow_w = inv_tp != 1.0; a.from_prior = from_prior ? 1 : 0;
     uint8_t* d_ids = e->d_io + in_bytes;
-    const size_t fused_lds = gu_fused_lds_bytes(R, S, in_bytes, N);
+    const size_t fused_lds = gu_fused_lds_bytes(R, S, in_bytes, N) +
+                             (with_counts ? ((size_t)n_touched * 16 * S + (size_t)e->Gtot) * sizeof(int32_t) : 0);
     if (e->opt_fuse_tables && fused_lds <= kGuFusedLdsMax) {        // one launch (see sbe_given_unchanged_lh)
-        const GuFusedArgs fa = gu_fused_args(e, slot, i_cluster, n_sub, R, temperature, prior_temperature, off, in_bytes, ob,
-                                             ob + gb + fb, ob + gb + fb + hb);
+        GuFusedArgs fa = gu_fused_args(e, slot, i_cluster, n_sub, R, temperature, prior_temperature, off, in_bytes, ob,
+                                       ob + gb + fb, ob + gb + fb + hb);
+        if (with_counts) {
+            fa.gid_old_word = (int)(o_gold / 4); fa.gid_new_word = (int)(o_gnew / 4); fa.n_touched = n_touched; fa.Gtot = e->Gtot;
+            fa.touched = reinterpret_cast<const int32_t*>(e->d_io + o_tch);
+            fa.rows_out = reinterpret_cast<float*>(d_ids + idb + 2 * selb);
+        }
         const unsigned blocks = (unsigned)div_up(F, 16);
         const DoneSig done = next_done(e, blocks);
         k_given_unchanged_fused<true><<<blocks, kUnchangedBlock, fused_lds, e->stream>>>(
@@ -2873,6 +2898,7 @@ int sbe_given_unchanged_gibbs(sbe_engine* e, int slot, int i_cluster, const int3
         memcpy(src_new_out, h + in_bytes, nf);
         memcpy(sel_new_out, h + in_bytes + idb, nf * sizeof(float));
         memcpy(sel_back_out, h + in_bytes + idb + selb, nf * sizeof(float));
+        if (with_counts) memcpy(diff_rows_out, h + in_bytes + idb + 2 * selb, (size_t)n_touched * fs * sizeof(float));
         return SBE_OK;
     }
     const bool list_in_lds = (size_t)n_sub * sizeof(int32_t) <= ((size_t)32 << 10);
@@ -2894,7 +2920,28 @@ int sbe_given_unchanged_gibbs(sbe_engine* e, int slot, int i_cluster, const int3
     memcpy(src_new_out, h + in_bytes, nf);
     memcpy(sel_new_out, h + in_bytes + idb, nf * sizeof(float));
     memcpy(sel_back_out, h + in_bytes + idb + selb, nf * sizeof(float));
+    if (with_counts)       // (this shape has no one-launch form: the count delta by its own call, from the ids just drawn)
+        return sbe_counts_delta(e, objects, n_sub, gid_old, gid_new, src_old, src_new_out, touched_out, n_touched, diff_rows_out);
     return SBE_OK;
+}
+
+int sbe_given_unchanged_gibbs(sbe_engine* e, int slot, int i_cluster, const int32_t* objects, int n_sub, double temperature,
+                              double prior_temperature, int from_prior, const uint8_t* hc_new, const uint8_t* hc_old,
+                              const uint8_t* src_old, const double* z, uint8_t* src_new_out, float* sel_new_out,
+                              float* sel_back_out) {
+    return given_unchanged_gibbs_impl(e, slot, i_cluster, objects, n_sub, temperature, prior_temperature, from_prior, hc_new, hc_old,
+                                      src_old, z, src_new_out, sel_new_out, sel_back_out, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+int sbe_given_unchanged_gibbs_counts(sbe_engine* e, int slot, int i_cluster, const int32_t* objects, int n_sub, double temperature,
+                                     double prior_temperature, int from_prior, const uint8_t* hc_new, const uint8_t* hc_old,
+                                     const uint8_t* src_old, const double* z, const int32_t* gid_old, const int32_t* gid_new,
+                                     uint8_t* src_new_out, float* sel_new_out, float* sel_back_out, int32_t* touched_out,
+                                     int32_t* n_touched_out, float* diff_rows_out) {
+    CHECK_ENGINE(e); CHECK_PTR(e, gid_old);
+    return given_unchanged_gibbs_impl(e, slot, i_cluster, objects, n_sub, temperature, prior_temperature, from_prior, hc_new, hc_old,
+                                      src_old, z, src_new_out, sel_new_out, sel_back_out, gid_old, gid_new, touched_out, n_touched_out,
+                                      diff_rows_out);
 }
 
 int sbe_cluster_posterior_marginals(sbe_engine* e, int slot, int i_cluster, double temperature, double prior_temperature,

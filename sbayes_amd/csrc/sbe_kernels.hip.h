@@ -1537,7 +1537,7 @@ struct GuGibbsArgs {
 // Register form: the has_components bytes (host-mapped: a PCIe read each), the weights and the table entries are loaded
 // once, up front and together; every array is indexed statically (unrolled, guarded by c < C).
 template <class GroupOf, class TableAt>
-__device__ __forceinline__ void gu_gibbs_obs(const GuGibbsArgs& a, int64_t i, int r, int f, uint8_t x, double zz, int id_old,
+__device__ __forceinline__ int gu_gibbs_obs(const GuGibbsArgs& a, int64_t i, int r, int f, uint8_t x, double zz, int id_old,
                                              GroupOf group_of, TableAt table_at,
                                              uint8_t* __restrict__ src_new, float* __restrict__ sel_new, float* __restrict__ sel_back,
                                              int* __restrict__ status) {
@@ -1611,6 +1611,7 @@ __device__ __forceinline__ void gu_gibbs_obs(const GuGibbsArgs& a, int64_t i, in
     }
     sel_new[i] = sn;
     sel_back[i] = sb;
+    return na ? -1 : k;
 }
 
 __global__ __launch_bounds__(kBlock) void k_given_unchanged_gibbs(GuGibbsArgs a, uint8_t* __restrict__ src_new,
@@ -1620,7 +1621,7 @@ __global__ __launch_bounds__(kBlock) void k_given_unchanged_gibbs(GuGibbsArgs a,
     if (i < (int64_t)a.n_sub * a.F) {
         const int r = (int)(i / a.F), f = (int)(i % a.F);
         const uint8_t x = a.state[(int64_t)a.objects[r] * a.Fp + f];
-        gu_gibbs_obs(a, i, r, f, x, a.z[i], (int)a.src_old[i], [&](int c) { return a.group_idx[(int64_t)c * a.n_sub + r]; },
+        (void)gu_gibbs_obs(a, i, r, f, x, a.z[i], (int)a.src_old[i], [&](int c) { return a.group_idx[(int64_t)c * a.n_sub + r]; },
                      [&](int c, int g) { return a.tables[((int64_t)(a.table_offsets[c] + g) * a.F + f) * a.S + x]; },
                      src_new, sel_new, sel_back, status);
     }
@@ -2280,6 +2281,12 @@ struct GuFusedArgs {
     int n_sub, i_cluster, K, N, Np, F, S, C, Fp, R;
     float* out;                      // kGibbs = false: [n_sub][F][C]
     float inv_t; int use_pow;
+    // Gibbs form with the count delta of the proposal (sbe_given_unchanged_gibbs_counts; n_touched = 0: not asked for): the
+    // subset's GLOBAL group ids in both samples sit in the staged block ([C][n_sub] each, -1 none); the rows of new counts -
+    // old counts of the `touched` groups (ascending, host-mapped) go to rows_out [n_touched][F][S]
+    int gid_old_word, gid_new_word, n_touched, Gtot;
+    const int32_t* touched;
+    float* rows_out;
 };
 
 template <bool kGibbs>
@@ -2298,6 +2305,8 @@ __global__ __launch_bounds__(kUnchangedBlock) void k_given_unchanged_fused(GuFus
     int32_t* hist = lds;                                                 // [R][FTU][S]
     uint32_t* stage = reinterpret_cast<uint32_t*>(hist + R * FTU * S);   // the call's host-mapped input block, word for word
     uint32_t* in_subset = stage + a.in_words;                            // [(N + 31) / 32]
+    int32_t* dhist = reinterpret_cast<int32_t*>(in_subset + (a.N + 31) / 32);   // count delta [n_touched][FTU][S] (Gibbs form, if asked)
+    int32_t* dpos = dhist + a.n_touched * FTU * S;                       // touched index of a group, -1 [Gtot]
     const int32_t* sub = reinterpret_cast<const int32_t*>(stage + a.objects_word);       // [n_sub]
     const int32_t* gidx = reinterpret_cast<const int32_t*>(stage + a.group_idx_word);    // [C][n_sub]
     const int f0 = blockIdx.x * FTU;
@@ -2318,10 +2327,20 @@ __global__ __launch_bounds__(kUnchangedBlock) void k_given_unchanged_fused(GuFus
         const int r = threadIdx.x / FTU, ff = f0 + (threadIdx.x & (FTU - 1));
         if (r < n_sub && ff < a.F) { z_first = gb.z[(int64_t)r * a.F + ff]; id_old_first = gb.src_old[(int64_t)r * a.F + ff]; }
     }
+    int32_t touched_mine = -1;
+    if constexpr (kGibbs) {
+        if ((int)threadIdx.x < a.n_touched) touched_mine = a.touched[threadIdx.x];              // (host-mapped: asked for now)
+        for (int i = threadIdx.x; i < a.n_touched * FTU * S; i += kUnchangedBlock) dhist[i] = 0;
+        if (a.n_touched > 0) for (int i = threadIdx.x; i < a.Gtot; i += kUnchangedBlock) dpos[i] = -1;
+    }
     for (int i = threadIdx.x; i < R * FTU * S; i += kUnchangedBlock) hist[i] = 0;
     for (int i = threadIdx.x; i < (a.N + 31) / 32; i += kUnchangedBlock) in_subset[i] = 0u;
     __syncthreads();
     GU_STAMP(1);
+    if constexpr (kGibbs) {
+        if (touched_mine >= 0) dpos[touched_mine] = threadIdx.x;
+        for (int t = threadIdx.x + kUnchangedBlock; t < a.n_touched; t += kUnchangedBlock) dpos[a.touched[t]] = t;
+    }
     for (int i = threadIdx.x; i < n_sub; i += kUnchangedBlock) atomicOr(&in_subset[sub[i] >> 5], 1u << (sub[i] & 31));
     __syncthreads();
     GU_STAMP(2);
@@ -2407,10 +2426,23 @@ __global__ __launch_bounds__(kUnchangedBlock) void k_given_unchanged_fused(GuFus
         const int64_t i = (int64_t)r * a.F + ff;
         if constexpr (kGibbs) {
             const bool first = t == (int)threadIdx.x;
-            gu_gibbs_obs(g2, i, r, ff, x, first ? z_first : gb.z[i], first ? id_old_first : (int)gb.src_old[i],
-                         [&](int c) { return gidx[c * n_sub + r]; },
-                         [&](int c, int g) { return tab[((a.table_offsets[c] + g) * FTU + tf) * S + x]; },
-                         src_new, sel_new, sel_back, a.status);
+            const int id_old = first ? id_old_first : (int)gb.src_old[i];
+            const int k = gu_gibbs_obs(g2, i, r, ff, x, first ? z_first : gb.z[i], id_old,
+                                       [&](int c) { return gidx[c * n_sub + r]; },
+                                       [&](int c, int g) { return tab[((a.table_offsets[c] + g) * FTU + tf) * S + x]; },
+                                       src_new, sel_new, sel_back, a.status);
+            if (a.n_touched > 0 && k >= 0) {
+                // update_feature_counts (counts.py:55-95) of the proposal, this observation's share: one more in its NEW group of
+                // the drawn component, one less in its OLD group of the old source component
+                const int32_t* gid_new = reinterpret_cast<const int32_t*>(stage + a.gid_new_word);
+                const int32_t* gid_old = reinterpret_cast<const int32_t*>(stage + a.gid_old_word);
+                const int gn = gid_new[k * n_sub + r];
+                if (gn >= 0 && dpos[gn] >= 0) atomicAdd(&dhist[(dpos[gn] * FTU + tf) * S + x], 1);
+                if (id_old < C) {
+                    const int go = gid_old[id_old * n_sub + r];
+                    if (go >= 0 && dpos[go] >= 0) atomicAdd(&dhist[(dpos[go] * FTU + tf) * S + x], -1);
+                }
+            }
         } else {
             float* o = a.out + i * C;
             for (int c = 0; c < C; ++c) {
@@ -2420,6 +2452,15 @@ __global__ __launch_bounds__(kUnchangedBlock) void k_given_unchanged_fused(GuFus
                     v = g < 0 ? 0.0f : tab[((a.table_offsets[c] + g) * FTU + tf) * S + x];
                 }
                 o[c] = a.use_pow ? lib_powf(v, a.inv_t) : v;
+            }
+        }
+    }
+    if constexpr (kGibbs) {
+        if (a.n_touched > 0) {
+            __syncthreads();
+            for (int e = threadIdx.x; e < a.n_touched * FTU * S; e += kUnchangedBlock) {
+                const int t = e / (FTU * S), q = e % (FTU * S), ff = f0 + q / S;
+                if (ff < a.F) a.rows_out[((int64_t)t * a.F + ff) * S + q % S] = (float)dhist[e];
             }
         }
     }

@@ -654,7 +654,7 @@ class Engine:
         return out
 
     def given_unchanged_gibbs(self, slot, i_cluster, objects, hc_new, hc_old, src_old, z, temperature=1.0, prior_temperature=1.0,
-                              from_prior=False):
+                              from_prior=False, gid_old=None, gid_new=None):
         """ClusterOperator.gibbs_sample_source (operators.py:796-851) on the slot the NEW sample is bound to: returns
         (src_new uint8 [n, F] drawn component, 255 = NA observation; sel_new float32 [n, F] = p[drawn]; sel_back float32
         [n, F] = p_back[old source]).  hc_new / hc_old: bool [n, C] has_components rows of the new / old sample; src_old:
@@ -673,6 +673,22 @@ class Engine:
         ids = np.empty((n, F), dtype=np.uint8)
         sel = np.empty((n, F), dtype=np.float32)
         back = np.empty((n, F), dtype=np.float32)
+        if gid_old is not None:
+            # ... and the count delta of the proposal (update_feature_counts, counts.py:55-95) from the same launch:
+            # gid_old / gid_new int32 [C, n] global group ids of the objects in the old / new sample (-1: none); returns
+            # additionally (touched int32 [T] ascending, rows float32 [T, F, S] = new counts - old counts of those groups)
+            go = _as(gid_old, np.int32).reshape(C, n)
+            gn = _as(gid_new, np.int32).reshape(C, n)
+            touched = np.empty(self.n_groups_total, dtype=np.int32)
+            rows = np.empty((min(self.n_groups_total, 2 * C * max(n, 1)), F, self.n_states), dtype=np.float32)
+            nt = ct.c_int32(0)
+            if n:
+                self._check(self._lib.sbe_given_unchanged_gibbs_counts(
+                    self._h, slot, int(i_cluster), self._i(objs), n, float(temperature), float(prior_temperature), int(bool(from_prior)),
+                    self._i(hn), self._i(ho), self._i(so), self._i(zz), self._i(go), self._i(gn), self._o(ids), self._o(sel),
+                    self._o(back), _ptr(touched), ct.byref(nt), _ptr(rows)))
+                self.d2h_bytes += nt.value * (4 + F * self.n_states * 4)
+            return ids, sel, back, touched[:nt.value], rows[:nt.value]
         if n:
             self._check(self._lib.sbe_given_unchanged_gibbs(self._h, slot, int(i_cluster), self._i(objs), n, float(temperature),
                                                             float(prior_temperature), int(bool(from_prior)), self._i(hn), self._i(ho),

@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from . import _fast
 from .binding import _bind_slot, _bind_uniform, _engine, _tables_current
 from .counts import _source_ids, apply_count_rows, update_feature_counts
 
@@ -199,15 +200,30 @@ def cluster_gibbs_sample_source(model, sample_new, sample_old, i_cluster, object
     _bind_uniform(eng, model)
     hc_new = sample_new.cache.has_components.value[objects]
     hc_old = sample_old.cache.has_components.value[objects]
-    src_old = _source_ids(sample_old.source.value, objects)
+    # the subset's group ids in both samples and its old source ids, one pass of the host helper; the proposal's count
+    # delta (update_feature_counts, operators.py:827) then comes out of the SAME engine call as the draw -- None: an
+    # object in several groups of a component has no single id, the counts go through update_feature_counts below
+    conf_names = list(sample_new.confounders)
+    groups_old = [sample_old.clusters.value] + [sample_old.confounders[k].group_assignment for k in conf_names]
+    groups_new = [sample_new.clusters.value] + [sample_new.confounders[k].group_assignment for k in conf_names]
+    source_old = sample_old.source.value
+    sub = _fast.subset_ids(objects, groups_new, groups_old, source_old, source_old) if objects.size else None
+    src_old = sub[2] if sub is not None else _source_ids(source_old, objects)
     if z is None:                                                          # (tests pass the reference's recorded uniforms)
         z = np.random.random((objects.size, eng.n_features, 1))
-    ids, sel_new, sel_back = eng.given_unchanged_gibbs(slot, i_cluster, objects, hc_new, hc_old, src_old, z, temperature,
-                                                       prior_temperature, sample_from_prior)
+    if sub is not None:
+        ids, sel_new, sel_back, touched, rows = eng.given_unchanged_gibbs(slot, i_cluster, objects, hc_new, hc_old, src_old, z, temperature,
+                                                                          prior_temperature, sample_from_prior, gid_old=sub[0], gid_new=sub[1])
+    else:
+        ids, sel_new, sel_back = eng.given_unchanged_gibbs(slot, i_cluster, objects, hc_new, hc_old, src_old, z, temperature,
+                                                           prior_temperature, sample_from_prior)
     x = ids[..., None] == np.arange(eng.n_components, dtype=np.uint8)     # one-hot; all False where NA (id 255)
     with sample_new.source.edit() as source:
         source[objects] = x                                               # (NA observations stay 0: operators.py:825)
-    update_feature_counts(sample_old, sample_new, features, objects)
+    if sub is not None:
+        apply_count_rows(sample_new.feature_counts, ["clusters", *conf_names], eng.group_offsets, touched, rows)
+    else:
+        update_feature_counts(sample_old, sample_new, features, objects)
     valid = ~na_features[objects]
     with np.errstate(divide="ignore"):
         log_q = np.log(sel_new[valid]).sum()                              # float32 logs, float32 sum (operators.py:832)

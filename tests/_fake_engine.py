@@ -342,7 +342,7 @@ class FakeEngine:
             [self.unif] * (len(groups) - 1), temperature=temperature, prior_temperature=prior_temperature)
 
     def given_unchanged_gibbs(self, slot, i_cluster, objects, hc_new, hc_old, src_old, z, temperature=1.0, prior_temperature=1.0,
-                              from_prior=False):
+                              from_prior=False, gid_old=None, gid_new=None):
         """ClusterOperator.gibbs_sample_source (operators.py:808-847) restated with the oracle's pieces: the expressions of
         the reference, in its dtypes, on the subset."""
         objects = np.asarray(objects)
@@ -367,6 +367,10 @@ class FakeEngine:
         so = np.asarray(src_old)
         back = np.where(so != 255, np.take_along_axis(p_back, np.minimum(so, p.shape[-1] - 1).astype(np.int64)[..., None], axis=-1)[..., 0],
                         1.0).astype(np.float32)
+        if gid_old is not None:                 # + the proposal's count delta (the double's own counts_delta, not logged separately)
+            touched, rows = FakeEngine.counts_delta(self, objects, gid_old, gid_new, so, ids)
+            self.calls.pop()
+            return ids, sel, back, touched, rows
         return ids, sel, back
 
     def gibbs_propose_supported(self):

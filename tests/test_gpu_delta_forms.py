@@ -323,6 +323,57 @@ def test_gibbs_propose_in_one_call(name):
         eng.close()
 
 
+@pytest.mark.parametrize("name", ["cfg1_fixture", "south_america", "headline", "wide", "long", "five"])
+def test_cluster_gibbs_with_its_count_delta(name):
+    """sbe_given_unchanged_gibbs_counts: the cluster operators' source resampling AND the count delta of the proposal
+    (update_feature_counts, counts.py:55-95) from one launch -- the draw's three arrays are the plain call's, touched groups
+    and count rows are counts_delta's for the ids that were drawn (device and oracle-backed double), with the subset's
+    cluster membership changed between the two samples."""
+    eng, fake, groups, source, counts = _pair(name)
+    try:
+        rng = np.random.default_rng(53)
+        N, F, C = source.shape
+        K = groups[0].shape[0]
+        off = eng.group_offsets
+        has = np.stack([g.any(axis=0) for g in groups], axis=1)
+        for fuse in (True, False):
+            eng.set_option(fuse_tables=fuse)
+            for n in (1, 11, min(N, 120)):
+                objs = np.sort(rng.choice(N, size=min(n, N), replace=False)).astype(np.int32)
+                k = int(rng.integers(0, K))
+                old_clusters = groups[0].copy()                           # the OLD sample: the subset's membership differs
+                old_clusters[:, objs] = False
+                move = rng.integers(0, K + 1, size=objs.size)
+                old_clusters[move[move < K], objs[move < K]] = True
+                gid_new = np.stack([_ids(groups[c], objs, off[c]) for c in range(C)])
+                gid_old = gid_new.copy()
+                gid_old[0] = _ids(old_clusters, objs, 0)
+                hc_new = has[objs].copy()
+                hc_old = hc_new.copy()
+                hc_old[:, 0] = old_clusters[:, objs].any(axis=0)
+                if C > 1:
+                    hc_new[:, 1] = hc_old[:, 1] = True
+                src_old = np.where(source[objs].any(-1), source[objs].argmax(-1), 255).astype(np.uint8)
+                src_old[(src_old == 0) & ~hc_old[:, [0]].repeat(F, 1)] = 1 if C > 1 else 255       # (no cluster source without a cluster)
+                z = rng.random((objs.size, F))
+                try:
+                    plain = eng.given_unchanged_gibbs(0, k, objs, hc_new, hc_old, src_old, z)
+                except Exception as exc:
+                    assert "normalize" in str(exc), exc
+                    continue
+                got = eng.given_unchanged_gibbs(0, k, objs, hc_new, hc_old, src_old, z, gid_old=gid_old, gid_new=gid_new)
+                assert len(got) == 5
+                for a, b in zip(got[:3], plain):
+                    assert np.array_equal(a, b), (name, fuse, n, "draw differs with the count delta asked for")
+                t_want, r_want = eng.counts_delta(objs, gid_old, gid_new, src_old, got[0])
+                assert np.array_equal(got[3], t_want) and got[4].dtype == np.float32 and np.array_equal(got[4], r_want), (name, fuse, n)
+                want = fake.given_unchanged_gibbs(0, k, objs, hc_new, hc_old, src_old, z, gid_old=gid_old, gid_new=gid_new)
+                for a, b, what in zip(got, want, ("ids", "sel", "back", "touched", "rows")):
+                    assert np.array_equal(a, b), (name, fuse, n, what)
+    finally:
+        eng.close()
+
+
 def test_argument_checks():
     eng, fake, groups, source, counts = _pair("cfg1_fixture")
     try:
