@@ -62,13 +62,20 @@ def compute_raw_cluster_probs(model, sample, i_cluster, available, temperature=1
     """AlterClusterWide.compute_raw_cluster_probs with ClusterEffectProposals.gibbs."""
     eng = _prepare(model, sample, slot)
     prior = model.prior.prior_cluster_effect
-    table = eng.normalize_tables(
-        sample.feature_counts["clusters"].value[[i_cluster]], np.asarray(prior.concentration_array),
-        temperature=temperature, prior_temperature=prior_temperature,
-        unif_counts=np.asarray(prior.uniform_concentration_array))
-    if temperature != 1.0:
+    if temperature == 1.0:
+        # the `gibbs` proposal's table is conditional_effect_mean(prior, counts[[i_cluster]], unif, T_prior, T) (operators.py:1254-1282):
+        # at T = 1 exactly the candidate table sbe_cluster_posterior_marginals builds from the slot's resident counts -- one call,
+        # the same kernel and the same bits as the explicit-table form below (tests/test_gpu_delta_forms.py)
+        _bind_uniform(eng, model)
+        objects = np.flatnonzero(available) if np.asarray(available).dtype == np.bool_ else np.asarray(available)
+        log_m = eng.cluster_posterior_marginals(slot, i_cluster, objects, 1.0, prior_temperature)
+    else:
+        table = eng.normalize_tables(
+            sample.feature_counts["clusters"].value[[i_cluster]], np.asarray(prior.concentration_array),
+            temperature=temperature, prior_temperature=prior_temperature,
+            unif_counts=np.asarray(prior.uniform_concentration_array))
         table = table ** (1 / temperature)          # inner1d(features, p) ** (1/T): elementwise on the table
-    log_m = _log_marginals(eng, slot, table, available, prior_temperature) / temperature
+        log_m = _log_marginals(eng, slot, table, available, prior_temperature) / temperature
     m = np.exp(log_m)
     if geo_prior_ratio is not None:
         m[1] *= geo_prior_ratio
