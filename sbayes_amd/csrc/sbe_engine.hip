@@ -2247,13 +2247,15 @@ int sbe_cluster_marginals(sbe_engine* e, int slot, const float* table, const int
     const int32_t* d_obj = (const int32_t*)(e->d_io + tb);
     double* d_out = (double*)(e->d_io + tb + ob);
     const double inv = 1.0 / prior_temperature;
+    const DoneSig done = next_done(e, (unsigned)n_objects_av);
     k_cluster_marginals<<<n_objects_av, kBlock, 0, e->stream>>>(
         e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np,
         e->d_probs + (int64_t)slot * e->table_elems(), d_tab, e->d_weights + (int64_t)slot * F * C,
         e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0, d_obj, n_objects_av, d_out,
-        reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C, e->Fp);
+        reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C, e->Fp, done);
     HIPCHK(e, hipGetLastError());
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    rc = wait_done(e, done);
+    if (rc) return rc;
     memcpy(out, e->h_io + tb + ob, out_bytes);
     return synced(e);
 }
@@ -2289,14 +2291,16 @@ int sbe_jump_lh(sbe_engine* e, int slot, const float* pconf, const float* p_sour
     memcpy(e->h_io + cb + tb, p_target, fs);
     memcpy(e->h_io + cb + 2 * tb, objects, (size_t)n_members * sizeof(int32_t));
     const double inv = 1.0 / prior_temperature;
+    const DoneSig done = next_done(e, (unsigned)n_members);
     k_jump_lh<<<n_members, kBlock, 0, e->stream>>>(
         e->d_state, e->d_gid + (int64_t)slot * C * e->Np, e->d_pid + (int64_t)slot * e->Np,
         (const float*)e->d_io, (const float*)(e->d_io + cb), (const float*)(e->d_io + cb + tb),
         e->d_weights + (int64_t)slot * F * C, e->d_patbits + (int64_t)slot * e->Pmax, (float)inv, inv != 1.0 ? 1 : 0,
         (const int32_t*)(e->d_io + cb + 2 * tb), n_members, (double*)(e->d_io + cb + 2 * tb + ob),
-        reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C, e->Fp, e->G[0]);
+        reinterpret_cast<const f64x2_t*>(e->d_logtab), e->Np, F, S, C, e->Fp, e->G[0], done);
     HIPCHK(e, hipGetLastError());
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    rc = wait_done(e, done);
+    if (rc) return rc;
     memcpy(out, e->h_io + cb + 2 * tb + ob, out_bytes);
     return synced(e);
 }

@@ -910,30 +910,30 @@ __device__ __forceinline__ void ws_build_rows(const InlineTables& tin, float* __
 template <int CM>
 __device__ __forceinline__ void weight_tables_z_row_reg(const float* __restrict__ w, uint32_t bits, int C, float inv_tp, int use_pow,
                                                         float (&wc)[CM], float (&wf)[CM]) {
-    static_assert(CM < 8, "sequential NumPy sum");
+    static_assert(CM <= 8, "one NumPy leaf of at most eight terms (np_sum_regs: the plain chain below eight, the tree at eight)");
     const uint32_t fbits = bits ^ 1u;
-    float wr[CM], m[CM], pd[CM], fl[CM];
+    float wr[CM], m[8], pd[8], fl[8];
 #pragma unroll
     for (int c = 0; c < CM; ++c) wr[c] = c < C ? w[c] : 0.0f;
-    float tot = 0.0f;
 #pragma unroll
-    for (int c = 0; c < CM; ++c) {
-        m[c] = ((bits >> c) & 1u) ? wr[c] : 0.0f * wr[c];
-        if (c < C) tot = tot + m[c];
+    for (int c = 0; c < 8; ++c) {
+        const float v = wr[c < CM ? c : 0];                          // (c >= CM: padding of the eight-wide sum, never counted)
+        m[c] = c < CM ? (((bits >> c) & 1u) ? v : 0.0f * v) : 0.0f;
     }
-    float tot2 = 0.0f, tot3 = 0.0f;
+    const float tot = np_sum_regs<float, 8>(m, C);
 #pragma unroll
-    for (int c = 0; c < CM; ++c) {
+    for (int c = 0; c < 8; ++c) {
         const float a = m[c] / tot;
-        pd[c] = use_pow ? lib_powf(a, inv_tp) : a;
-        if (c < C) tot2 = tot2 + pd[c];
+        pd[c] = c < CM ? (use_pow ? lib_powf(a, inv_tp) : a) : 0.0f;
     }
+    const float tot2 = np_sum_regs<float, 8>(pd, C);
 #pragma unroll
-    for (int c = 0; c < CM; ++c) {
-        const float pw = use_pow ? lib_powf(wr[c], inv_tp) : wr[c];
+    for (int c = 0; c < 8; ++c) {
+        const float base = c < CM ? wr[c < CM ? c : 0] : 0.0f;
+        const float pw = c < CM ? (use_pow ? lib_powf(base, inv_tp) : base) : 0.0f;
         fl[c] = ((fbits >> c) & 1u) ? pw : 0.0f * pw;
-        if (c < C) tot3 = tot3 + fl[c];
     }
+    const float tot3 = np_sum_regs<float, 8>(fl, C);
 #pragma unroll
     for (int c = 0; c < CM; ++c) {
         wc[c] = c < C ? pd[c] / tot2 : 0.0f;
@@ -964,21 +964,27 @@ __global__ __launch_bounds__(kBlock) void k_cluster_marginals(
     double acc0 = 0.0, acc1 = 0.0;
     for (int f = threadIdx.x; f < F; f += kBlock) {
         const uint8_t x = state[(int64_t)n * Fp + f];
-        float wc[kMaxComponents], wf[kMaxComponents];
-        weight_tables_z_row(weights + (int64_t)f * C, bits, C, inv_tp, use_pow, wc, wf);   // this object's pattern
-        double v0 = 0.0, v1 = 0.0;
-        for (int c = 0; c < C; ++c) {
-            double lh = 1.0;
-            if (x != kNA) {
-                if (c == 0) lh = (double)table0[(int64_t)f * S + x];
+        float wc[kMaxComponents], wf[kMaxComponents], lhc[kMaxComponents];
+        weight_tables_z_row_reg<kMaxComponents>(weights + (int64_t)f * C, bits, C, inv_tp, use_pow, wc, wf);   // this object's pattern
+#pragma unroll
+        for (int c = 0; c < kMaxComponents; ++c) {                           // (every entry asked for before any is used)
+            lhc[c] = 1.0f;
+            if (c < C && x != kNA) {
+                if (c == 0) lhc[c] = table0[(int64_t)f * S + x];
                 else {
                     const uint16_t gg = gid[(int64_t)c * Np + n];
-                    lh = gg == kNoGroup ? 0.0 : (double)probs[((int64_t)gg * F + f) * S + x];
+                    lhc[c] = gg == kNoGroup ? 0.0f : probs[((int64_t)gg * F + f) * S + x];
                 }
             }
-            const double a = (double)wc[c], b = (double)wf[c];
-            v1 = v1 + lh * (inside ? a : b);         // z = 1: the object is (or becomes) a cluster member
-            v0 = v0 + lh * (inside ? b : a);
+        }
+        double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < kMaxComponents; ++c) {
+            if (c < C) {
+                const double lh = (double)lhc[c], a = (double)wc[c], b = (double)wf[c];
+                v1 = v1 + lh * (inside ? a : b);     // z = 1: the object is (or becomes) a cluster member
+                v0 = v0 + lh * (inside ? b : a);
+            }
         }
         acc0 += tab_log_pos(v0, tab_addr);
         acc1 += tab_log_pos(v1, tab_addr);
@@ -1155,15 +1161,21 @@ __global__ __launch_bounds__(kBlock) void k_jump_lh(
     for (int f = threadIdx.x; f < F; f += kBlock) {
         const uint8_t x = state[(int64_t)n * Fp + f];
         if (x == kNA) continue;                                       // np.prod(..., where=~NAs): factor 1
-        float wc[kMaxComponents], wf[kMaxComponents];
-        weight_tables_z_row(weights + (int64_t)f * C, bits, C, inv_tp, use_pow, wc, wf);   // wc = weights_heated row
+        float wc[kMaxComponents], wf[kMaxComponents], pcf[kMaxComponents];
+        uint16_t gg[kMaxComponents];
+        weight_tables_z_row_reg<kMaxComponents>(weights + (int64_t)f * C, bits, C, inv_tp, use_pow, wc, wf);   // wc = weights_heated row
+#pragma unroll
+        for (int c = 1; c < kMaxComponents; ++c) gg[c] = c < C ? gid[(int64_t)c * Np + n] : kNoGroup;
+#pragma unroll
+        for (int c = 1; c < kMaxComponents; ++c)                              // (every entry asked for before any is used)
+            pcf[c] = gg[c] != kNoGroup ? pconf[((int64_t)(gg[c] - G0) * F + f) * S + x] : 0.0f;
+        const float e_src = p_source[(int64_t)f * S + x], e_tgt = p_target[(int64_t)f * S + x];
         float pc = 0.0f;
-        for (int c = 1; c < C; ++c) {
-            const uint16_t gg = gid[(int64_t)c * Np + n];
-            if (gg != kNoGroup) pc = pc + wc[c] * pconf[((int64_t)(gg - G0) * F + f) * S + x];
-        }
-        const float ps = pc + wc[0] * p_source[(int64_t)f * S + x];
-        const float pt = pc + wc[0] * p_target[(int64_t)f * S + x];
+#pragma unroll
+        for (int c = 1; c < kMaxComponents; ++c)
+            if (gg[c] != kNoGroup) pc = pc + wc[c] * pcf[c];
+        const float ps = pc + wc[0] * e_src;
+        const float pt = pc + wc[0] * e_tgt;
         acc0 += tab_log_pos((double)ps, tab_addr);
         acc1 += tab_log_pos((double)pt, tab_addr);
     }
