@@ -20,10 +20,17 @@ static PyObject* py_addr(PyObject* self, PyObject* obj) {
     return r;
 }
 
-/* a C-contiguous buffer of 1-byte items (bool / uint8) or of `itemsize`-byte items with `ndim` dimensions; 0 on mismatch */
+/* a C-contiguous buffer with `ndim` dimensions of 1-byte items (bool / int8 / uint8) or of 4-byte INTEGERS (the ids: a float32
+   array has the same item size and must not pass); 0 on mismatch */
 static int get_c(PyObject* obj, Py_buffer* v, int ndim, Py_ssize_t itemsize, int writable) {
     if (PyObject_GetBuffer(obj, v, (writable ? PyBUF_WRITABLE : 0) | PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) { PyErr_Clear(); return 0; }
-    if (v->ndim != ndim || v->itemsize != itemsize) { PyBuffer_Release(v); return 0; }
+    int ok = v->ndim == ndim && v->itemsize == itemsize;
+    if (ok && v->format) {
+        const char* f = v->format;
+        const char code = f[strlen(f) ? strlen(f) - 1 : 0];              /* (a byte-order prefix may precede the type code) */
+        ok = itemsize == 1 ? (code == '?' || code == 'B' || code == 'b') : (code == 'i' || code == 'l' || code == 'I' || code == 'L');
+    }
+    if (!ok) { PyBuffer_Release(v); return 0; }
     return 1;
 }
 

@@ -106,6 +106,10 @@ def test_subset_ids_against_numpy_and_the_c_abi(seed):
         assert _fast.subset_ids(objs, over, g_old, s_new, s_old) is None
     with pytest.raises(ValueError):
         _fast.subset_ids(np.array([N], dtype=np.int32), g_new, g_old, s_new, s_old)
+    # ids handed over as float32 (same item size as int32) are converted, not reinterpreted
+    as_float = _fast.subset_ids(objs.astype(np.float32), g_new, g_old, s_new, s_old)
+    for a, b in zip(as_float, got):
+        assert np.array_equal(a, b)
     # arguments that are not C-contiguous bool arrays are converted (Fortran order, uint8 views, int64 ids)
     alt = _fast.subset_ids(objs.astype(np.int64), [np.asfortranarray(g) for g in g_new], [np.asfortranarray(g) for g in g_old],
                            np.asfortranarray(s_new), s_old.view(np.uint8))
