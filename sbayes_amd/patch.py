@@ -116,10 +116,12 @@ def install(operators=False, mp_start_method=None, gibbs_source=False):
     Gibbs source resamplings of the reference run on the device, with the uniforms np.random yields
     at the point where the reference's `sample_categorical` draws them (draw for draw: the same Markov chain) --
       GibbsSampleSource._propose (operators.py:495-552), its body after `select_object_subset`: posterior, draw, new source
-        rows, count delta, both transition log-probabilities (operators.gibbs_sample_source);
+        rows, count delta, both transition log-probabilities in ONE engine call (operators.gibbs_sample_source ->
+        sbe_gibbs_propose);
       ClusterOperator.gibbs_sample_source (operators.py:796-851), the source resampling inside every AlterCluster /
         AlterClusterWide / ClusterJump proposal: likelihood under the kept observations, both posteriors, draw, selected
-        probabilities in ONE engine call (operators.cluster_gibbs_sample_source).
+        probabilities AND the count delta the reference asks for next (update_feature_counts, :827) in ONE engine call
+        (operators.cluster_gibbs_sample_source -> sbe_given_unchanged_gibbs_counts).
     At the headline shape these two bodies are the largest items of the reference's per-step Python."""
     global _INSTALLED
     operators = bool(operators) or bool(gibbs_source)
