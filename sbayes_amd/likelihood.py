@@ -159,6 +159,10 @@ class Likelihood:
 
     def compute_lh_clusters(self, sample, caching=True) -> float:
         cache = sample.cache.group_likelihoods["clusters"]
+        if caching and not cache.is_outdated():
+            # every input still has the version the node was computed from: what_changed() would list nothing and edit()
+            # would re-record the same versions (state.py:232-270) -- the cached values are the answer
+            return cache.value.sum()
         with cache.edit() as lh:
             changed = cache.what_changed("counts", caching=caching)
             if len(changed) > 0:
@@ -167,6 +171,8 @@ class Likelihood:
 
     def compute_lh_confounder(self, sample, conf, caching=True) -> float:
         cache = sample.cache.group_likelihoods[conf]
+        if caching and not cache.is_outdated():             # (as above; a changed hyperprior input makes the node outdated too)
+            return cache.value.sum()
         conf_prior = self.prior.prior_confounding_effects[conf]
         with cache.edit() as lh:
             hyperprior_has_changed = conf_prior.any_dynamic_priors and cache.ahead_of("universal_counts")
