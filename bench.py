@@ -328,6 +328,27 @@ def secondary_figures(eng, wl, B, args):
     table = probs0[0]
     out["f1_cluster_marginals_calls_per_s"] = round(_rate(lambda: eng.cluster_marginals(0, table, available)), 1)
     out["f1_cluster_marginals_objects"] = int(available.size)
+    # the floor every host-synchronous engine call pays (an empty kernel with the completion flag; + one word read out of
+    # the host-mapped input block and one double stored to the mapped result block; the same with 64 / 1000 blocks of
+    # completion tickets) next to the one-launch calls of the drop-in path on resident state: microseconds per call
+    lib, h = eng._lib, eng._h
+    us = lambda fn: round(1e6 / _rate(fn, min_time=0.1), 2)                                    # noqa: E731
+    eng.set_uniform_counts(np.asarray(wl.states_per_feature, dtype=np.float64))
+    members = np.flatnonzero(wl.clusters[0])
+    few = np.arange(min(12, wl.features.shape[0]), dtype=np.int32)
+    out["sync_call_us"] = {
+        "floor_empty_kernel": us(lambda: lib.sbe_test_roundtrip(h, 1, 0)),
+        "floor_mapped_word_in_double_out": us(lambda: lib.sbe_test_roundtrip(h, 1, 3)),
+        "floor_64_blocks": us(lambda: lib.sbe_test_roundtrip(h, 64, 3)),
+        "floor_1000_blocks": us(lambda: lib.sbe_test_roundtrip(h, 1000, 3)),
+        "source_prior": us(lambda: eng.source_prior(0)),
+        "collapsed_loglik_all": us(lambda: eng.collapsed_loglik_all(0)),
+        "cluster_posterior_marginals": us(lambda: eng.cluster_posterior_marginals(0, 0, available, 1.0, 1.0)),
+        "jump_lh_resident": us(lambda: eng.jump_lh_resident(0, 0, 1 % wl.clusters.shape[0], members, 1.0, 1.0)) if members.size else None,
+        "given_unchanged_lh_12_objects": us(lambda: eng.given_unchanged_lh(0, 0, few, 1.0, 1.0)),
+        "source_posterior_12_objects": us(lambda: eng.source_posterior(0, few, 1.0, 1.0)),
+        "note": "one launch and one completion flag per call (DESIGN.md 7.3); tools/call_floor.py prints the same next to the ctypes-only times",
+    }
     # resident step flow -- delta in, collapsed + mixture log-likelihood out
     from sbayes_amd import model as sbm
     from sbayes_amd.registry import release_all
