@@ -560,8 +560,12 @@ int sbe_step_batch_delta(sbe_engine* e, int n_chains, const int32_t* cur_slots, 
    the drawn component of every observation (0xFF: an NA observation), sel_out / sel_back_out [n_sub][F] float32 = p[drawn]
    and p_back[old source] (1 where there is none), touched_out [<= G_total] (ascending) + *n_touched_out = the groups the
    listed objects are in, diff_rows_out [n_touched][F][S] = candidate counts - current counts of those groups (every other
-   row of that difference is zero: counts.py:55-95).  One synchronisation.  sbe_gibbs_propose_supported: 1 if the
-   engine's tables fit the fused table kernel the chain uses (else SBE_ERR_ARG here; the call-by-call forms remain). */
+   row of that difference is zero: counts.py:55-95).  One synchronisation.  Two forms, same results: ONE kernel, a block per
+   16-feature tile doing draw, count delta, the touched groups' new tables and the backward probabilities in LDS -- the
+   candidate slot is then NOT written -- or, when that kernel's LDS image does not fit (or SBE_OPT_FUSE_TABLES is 0),
+   sbe_gibbs_step's chain, which builds the candidate in cand_slot: treat cand_slot as scratch.
+   sbe_gibbs_propose_supported: 1 if the engine's tables fit the chain form (else the call can fail with SBE_ERR_ARG for
+   large subsets; the call-by-call forms remain). */
 int sbe_gibbs_propose_supported(sbe_engine* e);
 int sbe_gibbs_propose(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* objects, int n_sub, double temperature,
                       double prior_temperature, int from_prior, const double* z, uint8_t* src_new_out, float* sel_out,

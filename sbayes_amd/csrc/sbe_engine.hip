@@ -4395,7 +4395,7 @@ static int step_general(sbe_engine* e, int cur_slot, int cand_slot, const uint8_
 // one completion flag.  (As eight engine calls -- copy_slot, sample_source, update_counts, update_probs, source_logprob,
 // get_source_rows, counts_delta -- the same work cost 190 us per proposal in the sampler replay, seven stream
 // synchronisations among them.)
-int sbe_gibbs_propose_supported(sbe_engine* e) {
+int sbe_gibbs_propose_supported(sbe_engine* e) {                       // 1: the CHAIN form fits (the tile form is tried first, per call)
     CHECK_ENGINE(e);
     return ((int64_t)e->Gtot * e->S * 28 <= 60 * 1024) ? 1 : 0;          // (the fused table kernel of the step core)
 }
@@ -4417,8 +4417,6 @@ int sbe_gibbs_propose(sbe_engine* e, int cur_slot, int cand_slot, const int32_t*
             return fail(e, SBE_ERR_STATE, "slot %d: counts / concentration / probability tables of component %d not set", cur_slot, c);
     int rc = check_objects(e, objects, n_sub);
     if (rc) return rc;
-    if (!sbe_gibbs_propose_supported(e))
-        return fail(e, SBE_ERR_ARG, "sbe_gibbs_propose: tables too large for the fused table kernel (G_total=%d, S=%d)", e->Gtot, e->S);
     const int N = e->N, Np = e->Np, F = e->F, C = e->C, S = e->S;
     const int64_t n_obs = (int64_t)n_sub * F, fs = (int64_t)F * S;
     // the groups the subset's objects are in (their count rows are the only ones the redraw can change), ascending
@@ -4438,6 +4436,75 @@ int sbe_gibbs_propose(sbe_engine* e, int cur_slot, int cand_slot, const int32_t*
         rc = synced(e);
         if (rc) return rc;
     }
+    // ---- tile form: the whole proposal in ONE kernel (k_gibbs_propose_tile), no candidate slot built ----
+    {
+        const size_t t_ob = al256((size_t)n_sub * sizeof(int32_t)), t_gb = al256((size_t)C * n_sub * sizeof(int32_t));
+        const size_t t_tb = al256((size_t)std::max(n_touched, 1) * sizeof(int32_t));
+        const size_t t_in = t_ob + t_gb + t_tb;
+        const size_t t_lds = t_in + ((size_t)e->Gtot + (size_t)n_touched * 16 * S) * sizeof(int32_t) + (size_t)n_sub * 16;
+        const size_t zbytes_t = (size_t)n_obs * sizeof(double);
+        const bool z_map = zbytes_t <= ((size_t)1 << 19);
+        const size_t t_zb = z_map ? al256(zbytes_t) : 0;
+        const size_t t_idb = al256((size_t)n_obs), t_selb = al256((size_t)n_obs * sizeof(float));
+        const size_t t_rowb = al256((size_t)std::max(n_touched, 1) * fs * sizeof(float));
+        const size_t t_out = t_idb + 2 * t_selb + t_rowb;
+        // (a block serves ALL listed objects for its 16 features: beyond ~128 objects the chain form's grid over every
+        //  observation is the faster one -- 154 us against 64 us at 1000 objects, 13 us against 64 us at 30)
+        const bool chain_possible = sbe_gibbs_propose_supported(e) == 1;
+        if (e->opt_fuse_tables && t_lds <= kGuFusedLdsMax && t_out <= ((size_t)8 << 20) && (n_sub <= 128 || !chain_possible)) {
+            rc = ensure_io(e, t_in + t_zb + t_out);
+            if (rc) return rc;
+            uint8_t* h = e->h_io;
+            memcpy(h, objects, (size_t)n_sub * sizeof(int32_t));
+            int32_t* gl = reinterpret_cast<int32_t*>(h + t_ob);
+            for (int c = 0; c < C; ++c)
+                for (int i = 0; i < n_sub; ++i) {
+                    const uint16_t gg = cur.h_gid[(size_t)c * N + objects[i]];
+                    gl[(size_t)c * n_sub + i] = gg == kNoGroup ? -1 : (int32_t)gg;
+                }
+            memcpy(h + t_ob + t_gb, touched_out, (size_t)n_touched * sizeof(int32_t));
+            const double* d_zt;
+            if (z_map) { memcpy(h + t_in, z, zbytes_t); d_zt = reinterpret_cast<const double*>(e->d_io + t_in); }
+            else {
+                rc = ensure_scratch(e, al256(zbytes_t));
+                if (rc) return rc;
+                int urc = upload(e, e->d_scratch, z, zbytes_t); if (urc) return urc;
+                d_zt = reinterpret_cast<const double*>(e->d_scratch);
+            }
+            rc = clear_status_word(e, ST_BAD_NORMALIZE);
+            if (rc) return rc;
+            uint8_t* d_o = e->d_io + t_in + t_zb;
+            GibbsTileArgs ta{};
+            ta.state = e->d_state; ta.gid = e->d_gid + (int64_t)cur_slot * C * Np; ta.pid = e->d_pid + (int64_t)cur_slot * Np;
+            ta.src = e->d_src + (int64_t)cur_slot * N * e->Fp; ta.probs = e->d_probs + (int64_t)cur_slot * e->table_elems();
+            ta.wpat = e->d_wpat + (int64_t)cur_slot * e->Pmax * F * C; ta.counts = e->d_counts + (int64_t)cur_slot * e->table_elems();
+            ta.conc = e->d_conc;
+            ta.mapped_in = reinterpret_cast<const uint32_t*>(e->d_io); ta.in_words = (int)(t_in / 4);
+            ta.objects_word = 0; ta.gid_word = (int)(t_ob / 4); ta.touched_word = (int)((t_ob + t_gb) / 4);
+            ta.z = d_zt;
+            ta.ids_out = d_o; ta.sel_out = (float*)(d_o + t_idb); ta.back_out = (float*)(d_o + t_idb + t_selb);
+            ta.rows_out = (float*)(d_o + t_idb + 2 * t_selb);
+            ta.n_sub = n_sub; ta.n_touched = n_touched; ta.Gtot = e->Gtot; ta.Np = Np; ta.F = F; ta.S = S; ta.C = C; ta.Fp = e->Fp;
+            const double inv_t = 1.0 / temperature, inv_tp = 1.0 / prior_temperature;
+            ta.inv_t = inv_t; ta.inv_tp = (float)inv_tp; ta.pow_lh = inv_t != 1.0; ta.pow_w = inv_tp != 1.0; ta.from_prior = from_prior != 0;
+            ta.status = e->d_status;
+            const unsigned blocks = (unsigned)div_up(F, 16);
+            const DoneSig done = next_done(e, blocks);
+            k_gibbs_propose_tile<<<blocks, kTileBlock, t_lds, e->stream>>>(ta, done);
+            HIPCHK(e, hipGetLastError());
+            rc = sync_and_report(e, done);
+            if (rc) return rc;
+            const uint8_t* ho = h + t_in + t_zb;
+            memcpy(src_new_out, ho, (size_t)n_obs);
+            memcpy(sel_out, ho + t_idb, (size_t)n_obs * sizeof(float));
+            memcpy(sel_back_out, ho + t_idb + t_selb, (size_t)n_obs * sizeof(float));
+            memcpy(diff_rows_out, ho + t_idb + 2 * t_selb, (size_t)n_touched * fs * sizeof(float));
+            return SBE_OK;
+        }
+    }
+    // ---- chain form (tables beyond the tile kernel's LDS image, or SBE_OPT_FUSE_TABLES off): the candidate slot is built ----
+    if (!sbe_gibbs_propose_supported(e))
+        return fail(e, SBE_ERR_ARG, "sbe_gibbs_propose: tables too large for the fused table kernel (G_total=%d, S=%d)", e->Gtot, e->S);
     // host-mapped block: objects | row_of marks | touched | uniforms (when few) || ids | sel | sel_back | count rows
     const size_t ob = al256((size_t)n_sub * sizeof(int32_t)), rb = al256((size_t)Np * sizeof(int16_t));
     const size_t tb = al256((size_t)std::max(n_touched, 1) * sizeof(int32_t));

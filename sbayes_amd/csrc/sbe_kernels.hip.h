@@ -1377,38 +1377,48 @@ struct SrcPostArgs {
 // normalize(w ** (1/T_prior)) entirely in float32, the likelihood plays no part.
 // (Register form: the C weights, group ids and table entries are loaded up front, together, and every term is computed
 // once -- the first form evaluated term(c) twice from memory inside run-time loops, a chain of waited-for loads.)
-__device__ inline bool source_posterior_row(const SrcPostArgs& a, int n, int f, float* p) {
+// Core: `group_of(c)` = the object's group of component c as the caller indexes its tables (kNoGroup: none),
+// `table_at(c, g)` = that group's table entry for this feature and the observed state x.
+template <class GroupOf, class TableAt>
+__device__ __forceinline__ bool posterior_row_core(uint8_t x, const float* __restrict__ w, int C, bool from_prior, int pow_lh, double inv_t,
+                                                   int pow_w, float inv_tp, GroupOf group_of, TableAt table_at, float* p) {
     constexpr int CM = kMaxComponents;
-    const uint8_t x = a.state[(int64_t)n * a.Fp + f];
-    const float* w = a.wpat + ((int64_t)a.pid[n] * a.F + f) * a.C;
     float wr[CM];
 #pragma unroll
-    for (int c = 0; c < CM; ++c) wr[c] = c < a.C ? w[c] : 0.0f;
-    if (a.from_prior) {
+    for (int c = 0; c < CM; ++c) wr[c] = c < C ? w[c] : 0.0f;
+    if (from_prior) {
         float t[CM];
 #pragma unroll
-        for (int c = 0; c < CM; ++c) t[c] = a.pow_w ? lib_powf(wr[c], a.inv_tp) : wr[c];
-        const float total = np_sum_regs<float, CM>(t, a.C);
+        for (int c = 0; c < CM; ++c) t[c] = pow_w ? lib_powf(wr[c], inv_tp) : wr[c];
+        const float total = np_sum_regs<float, CM>(t, C);
 #pragma unroll
-        for (int c = 0; c < CM; ++c) if (c < a.C) p[c] = t[c] / total;
+        for (int c = 0; c < CM; ++c) if (c < C) p[c] = t[c] / total;
         return total > 0.0f;
     }
-    uint16_t gg[CM];
+    uint32_t gg[CM];
 #pragma unroll
-    for (int c = 0; c < CM; ++c) gg[c] = (c < a.C && x != kNA) ? a.gid[(int64_t)c * a.Np + n] : kNoGroup;
+    for (int c = 0; c < CM; ++c) gg[c] = (c < C && x != kNA) ? (uint32_t)group_of(c) : (uint32_t)kNoGroup;
     double t[CM];
 #pragma unroll
     for (int c = 0; c < CM; ++c) {
         double lh = 1.0;
-        if (x != kNA) lh = gg[c] == kNoGroup ? 0.0 : (double)a.probs[((int64_t)gg[c] * a.F + f) * a.S + x];
-        if (a.pow_lh) lh = lib_pow(lh, a.inv_t);
-        const float wc = a.pow_w ? lib_powf(wr[c], a.inv_tp) : wr[c];
+        if (x != kNA) lh = gg[c] == (uint32_t)kNoGroup ? 0.0 : (double)table_at(c, gg[c]);
+        if (pow_lh) lh = lib_pow(lh, inv_t);
+        const float wc = pow_w ? lib_powf(wr[c], inv_tp) : wr[c];
         t[c] = lh * (double)wc;
     }
-    const double total = np_sum_regs<double, CM>(t, a.C);
+    const double total = np_sum_regs<double, CM>(t, C);
 #pragma unroll
-    for (int c = 0; c < CM; ++c) if (c < a.C) p[c] = (float)(t[c] / total);
+    for (int c = 0; c < CM; ++c) if (c < C) p[c] = (float)(t[c] / total);
     return total > 0.0;
+}
+
+__device__ inline bool source_posterior_row(const SrcPostArgs& a, int n, int f, float* p) {
+    const uint8_t x = a.state[(int64_t)n * a.Fp + f];
+    const float* w = a.wpat + ((int64_t)a.pid[n] * a.F + f) * a.C;
+    return posterior_row_core(x, w, a.C, a.from_prior, a.pow_lh, a.inv_t, a.pow_w, a.inv_tp,
+                              [&](int c) { return a.gid[(int64_t)c * a.Np + n]; },
+                              [&](int c, uint32_t g) { return a.probs[((int64_t)g * a.F + f) * a.S + x]; }, p);
 }
 
 __global__ void k_source_posterior(SrcPostArgs a, float* __restrict__ out, int* __restrict__ status, DoneSig done = DoneSig{}) {
@@ -1659,6 +1669,155 @@ __global__ void k_gibbs_fetch(const uint8_t* __restrict__ src_cand /* [N][Fp] */
             const int64_t at = (int64_t)touched[j / fs] * fs + j % fs;
             rows_out[j] = (float)(counts_cand[at] - counts_cur[at]);
         }
+    }
+    signal_done(done);
+}
+
+// GibbsSampleSource._propose (operators.py:495-552) in ONE kernel (sbe_gibbs_propose's tile form): everything the proposal
+// needs is independent from feature to feature, so a block owns a 16-feature tile and does, for the listed objects,
+//   1. the draw: posterior of every observation under the slot's tables (posterior_row_core: k_sample_source's arithmetic),
+//      the caller's uniform picks the component; drawn id and p[drawn] go to the mapped result block;
+//   2. the count delta: one more in the object's group of the drawn component, one less in its group of the old one, per
+//      touched group in LDS; the rows go out as float32 (update_feature_counts, counts.py:55-95);
+//   3. the tables of the touched groups from counts + delta (probs_row_x16: update_probs' untempered arithmetic), in LDS --
+//      every group an object of the subset is in IS touched, so the backward pass reads nothing else;
+//   4. the backward probabilities: posterior under those tables, p_back[old source] (k_source_logprob's arithmetic).
+// No candidate slot is built (the chain form: k_sample_source, k_step_core -- a whole slot copied and every table rebuilt,
+// 33 us -- k_source_logprob, k_gibbs_fetch).  LDS: staged input block | pos [Gtot] | delta / tables [T][16][S] | drawn ids [n][16].
+constexpr int kTileBlock = 1024;                 // (= kUnchangedBlock below: the 16-feature-tile operator kernels)
+struct GibbsTileArgs {
+    const uint8_t* state; const uint16_t* gid; const uint8_t* pid; const uint8_t* src; const float* probs; const float* wpat;
+    const int32_t* counts; const double* conc;
+    const uint32_t* mapped_in; int in_words, objects_word, gid_word /* [C][n] GLOBAL group ids, -1 none */, touched_word;
+    const double* z;                 // [n][F] uniforms
+    uint8_t* ids_out; float* sel_out; float* back_out; float* rows_out;
+    int n_sub, n_touched, Gtot, Np, F, S, C, Fp;
+    double inv_t; float inv_tp; int pow_lh, pow_w, from_prior;
+    int* status;
+};
+
+__global__ __launch_bounds__(kTileBlock) void k_gibbs_propose_tile(GibbsTileArgs a, DoneSig done) {
+    constexpr int FTU = 16;
+    extern __shared__ int32_t gl[];
+    const int S = a.S, C = a.C, n_sub = a.n_sub, T = a.n_touched;
+    uint32_t* stage = reinterpret_cast<uint32_t*>(gl);
+    int32_t* pos = reinterpret_cast<int32_t*>(stage + a.in_words);       // [Gtot]
+    int32_t* dhist = pos + a.Gtot;                                       // [T][FTU][S]: delta, then the new tables (float)
+    uint8_t* knew = reinterpret_cast<uint8_t*>(dhist + T * FTU * S);     // [n_sub][FTU] drawn component (0xFF: NA)
+    const int32_t* obj = reinterpret_cast<const int32_t*>(stage + a.objects_word);
+    const int32_t* gidl = reinterpret_cast<const int32_t*>(stage + a.gid_word);
+    const int32_t* touched = reinterpret_cast<const int32_t*>(stage + a.touched_word);
+    const int f0 = blockIdx.x * FTU;
+    for (int i0 = threadIdx.x; i0 < a.in_words; i0 += 4 * kTileBlock) {       // one PCIe round trip (k_given_unchanged_fused)
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int i = i0 + j * kTileBlock; v[j] = i < a.in_words ? a.mapped_in[i] : 0u; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int i = i0 + j * kTileBlock; if (i < a.in_words) stage[i] = v[j]; }
+    }
+    // the uniform of the observation this thread draws first: asked for now (host-mapped or device memory)
+    double z_first = 0.0;
+    {
+        const int r = threadIdx.x / FTU, ff = f0 + (threadIdx.x & (FTU - 1));
+        if (r < n_sub && ff < a.F) z_first = a.z[(int64_t)r * a.F + ff];
+    }
+    for (int i = threadIdx.x; i < T * FTU * S; i += kTileBlock) dhist[i] = 0;
+    for (int i = threadIdx.x; i < a.Gtot; i += kTileBlock) pos[i] = -1;
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += kTileBlock) pos[touched[t]] = t;
+    __syncthreads();
+    // 1 + 2: the draw and the count delta
+    for (int t = threadIdx.x; t < n_sub * FTU; t += kTileBlock) {
+        const int r = t / FTU, tf = t % FTU, ff = f0 + tf;
+        if (ff >= a.F) continue;
+        const int n = obj[r];
+        const uint8_t x = a.state[(int64_t)n * a.Fp + ff];
+        const int64_t i = (int64_t)r * a.F + ff;
+        const float* w = a.wpat + ((int64_t)a.pid[n] * a.F + ff) * C;
+        float p[kMaxComponents];
+        const bool ok = posterior_row_core(x, w, C, a.from_prior, a.pow_lh, a.inv_t, a.pow_w, a.inv_tp,
+                                           [&](int c) { const int g = gidl[c * n_sub + r]; return g < 0 ? (uint32_t)kNoGroup : (uint32_t)g; },
+                                           [&](int, uint32_t g) { return a.probs[((int64_t)g * a.F + ff) * S + x]; }, p);
+        if (!ok) raise_status(a.status, ST_BAD_NORMALIZE, 1);
+        // sample_categorical (preprocessing.py:224-256), as k_sample_source draws: float32 cumulative sums / the last, first c with z < cdf[c]
+        float cdf[kMaxComponents];
+        float run = p[0];
+        cdf[0] = run;
+#pragma unroll
+        for (int c = 1; c < kMaxComponents; ++c) { if (c < C) run = run + p[c]; cdf[c] = run; }
+        const float last = run;
+        const double zz = t == (int)threadIdx.x ? z_first : a.z[i];
+        int k = 0;
+#pragma unroll
+        for (int c = kMaxComponents - 1; c >= 0; --c)
+            if (c < C && zz < (double)(cdf[c] / last)) k = c;
+        const bool na = x == kNA;
+        float sel = 1.0f;
+#pragma unroll
+        for (int c = 0; c < kMaxComponents; ++c) if (c < C) sel = (!na && c == k) ? p[c] : sel;
+        a.ids_out[i] = na ? (uint8_t)kNA : (uint8_t)k;
+        a.sel_out[i] = sel;
+        knew[t] = na ? (uint8_t)kNA : (uint8_t)k;
+        if (!na) {
+            const int g_new = gidl[k * n_sub + r];
+            if (g_new >= 0 && pos[g_new] >= 0) atomicAdd(&dhist[(pos[g_new] * FTU + tf) * S + x], 1);
+            const int so = a.src[(int64_t)n * a.Fp + ff];
+            if (so < C) {
+                const int g_old = gidl[so * n_sub + r];
+                if (g_old >= 0 && pos[g_old] >= 0) atomicAdd(&dhist[(pos[g_old] * FTU + tf) * S + x], -1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < T * FTU * S; e += kTileBlock) {
+        const int tt = e / (FTU * S), q = e % (FTU * S), ff = f0 + q / S;
+        if (ff < a.F) a.rows_out[((int64_t)tt * a.F + ff) * S + q % S] = (float)dhist[e];
+    }
+    __syncthreads();
+    // 3: the touched groups' tables from counts + delta, in place (update_probs' arithmetic: untempered)
+    auto rows_by_lane_groups = [&](auto width) {
+        constexpr int W = decltype(width)::value;
+        for (int row0 = 0; row0 < T * FTU; row0 += kTileBlock / W) {
+            const int row = row0 + (int)threadIdx.x / W, j = threadIdx.x & (W - 1);
+            const int tt = row / FTU, tf = row % FTU, ff = f0 + tf;
+            const bool row_on = row < T * FTU && ff < a.F;
+            const int64_t at = row_on ? ((int64_t)touched[tt] * a.F + ff) * S : 0;
+            int32_t* h = dhist + (row_on ? (tt * FTU + tf) * S : 0);
+            probs_row_x16<W>(j, row_on, [&](int s) { return (float)(a.counts[at + s] + h[s]); }, a.conc + at, nullptr, S, 0.0, 0.0, a.status,
+                             [&](int s, float v) { h[s] = __float_as_int(v); });
+        }
+    };
+    if (S <= 8) rows_by_lane_groups(std::integral_constant<int, 8>{});
+    else if (S <= 16) rows_by_lane_groups(std::integral_constant<int, 16>{});
+    else {
+        for (int t = threadIdx.x; t < T * FTU; t += kTileBlock) {
+            const int tt = t / FTU, tf = t % FTU, ff = f0 + tf;
+            if (ff >= a.F) continue;
+            const int64_t at = ((int64_t)touched[tt] * a.F + ff) * S;
+            int32_t* h = dhist + (tt * FTU + tf) * S;
+            probs_row([&](int s) { return (float)(a.counts[at + s] + h[s]); }, a.conc + at, nullptr, S, 0.0, 0.0, a.status,
+                      [&](int s, float v) { h[s] = __float_as_int(v); });
+        }
+    }
+    __syncthreads();
+    // 4: the backward probabilities under the new tables
+    const float* tab = reinterpret_cast<const float*>(dhist);
+    for (int t = threadIdx.x; t < n_sub * FTU; t += kTileBlock) {
+        const int r = t / FTU, tf = t % FTU, ff = f0 + tf;
+        if (ff >= a.F) continue;
+        const int n = obj[r];
+        const uint8_t x = a.state[(int64_t)n * a.Fp + ff];
+        const float* w = a.wpat + ((int64_t)a.pid[n] * a.F + ff) * C;
+        float p[kMaxComponents];
+        const bool ok = posterior_row_core(x, w, C, a.from_prior, a.pow_lh, a.inv_t, a.pow_w, a.inv_tp,
+                                           [&](int c) { const int g = gidl[c * n_sub + r]; return g < 0 ? (uint32_t)kNoGroup : (uint32_t)g; },
+                                           [&](int, uint32_t g) { return tab[(pos[g] * FTU + tf) * S + x]; }, p);
+        if (!ok) raise_status(a.status, ST_BAD_NORMALIZE, 1);
+        const int id = a.src[(int64_t)n * a.Fp + ff];
+        float sel = 1.0f;
+#pragma unroll
+        for (int c = 0; c < kMaxComponents; ++c) if (c < C) sel = (c == id) ? p[c] : sel;
+        a.back_out[(int64_t)r * a.F + ff] = sel;
     }
     signal_done(done);
 }

@@ -295,26 +295,34 @@ def test_gibbs_propose_in_one_call(name):
             pytest.skip("tables beyond the fused table kernel of the chain")
         rng = np.random.default_rng(41)
         N, F, C = source.shape
+        everyone = np.arange(N, dtype=np.int32)
         for temp, ptemp, from_prior in ((1.0, 1.0, False), (1.0, 1.0, True), (1.4, 1.2, False)):
             for n in (1, 7, min(N, 200)):
                 objs = np.sort(rng.choice(N, size=min(n, N), replace=False)).astype(np.int32)
                 z = rng.random((objs.size, F))
-                got = eng.gibbs_propose(0, 1, objs, z, temp, ptemp, from_prior)
                 want = fake.gibbs_propose(0, 1, objs, z, temp, ptemp, from_prior)
                 tags = ("ids", "sel", "sel_back", "touched", "rows")
-                for tag, g, w in zip(tags, got, want):
-                    assert g.shape == w.shape and g.dtype == w.dtype, (name, tag, g.dtype, w.dtype)
-                    if tag in ("ids", "touched", "rows") or (temp == 1.0 and ptemp == 1.0):
-                        assert np.array_equal(g, w), (name, tag, n, temp, from_prior)
-                    else:
-                        np.testing.assert_allclose(g, w, rtol=2e-6, atol=1e-7)
-                everyone = np.arange(N, dtype=np.int32)
+                results = []
+                for tile_form in (True, False):              # one kernel per feature tile / the chain that builds the candidate slot
+                    eng.set_option(fuse_tables=tile_form)
+                    got = eng.gibbs_propose(0, 1, objs, z, temp, ptemp, from_prior)
+                    results.append(got)
+                    for tag, g, w in zip(tags, got, want):
+                        assert g.shape == w.shape and g.dtype == w.dtype, (name, tag, g.dtype, w.dtype)
+                        if tag in ("ids", "touched", "rows") or (temp == 1.0 and ptemp == 1.0):
+                            assert np.array_equal(g, w), (name, tag, n, temp, from_prior, tile_form)
+                        else:
+                            np.testing.assert_allclose(g, w, rtol=2e-6, atol=1e-7)
+                    # the current slot is untouched
+                    assert np.array_equal(eng.get_source_rows(0, everyone), source)
+                for a, b in zip(*results):
+                    assert np.array_equal(a, b), (name, n, temp, from_prior, "tile form != chain form")
+                # the chain form (run last) leaves the candidate in slot 1: source rows, counts, tables are the double's
                 assert np.array_equal(eng.get_source_rows(1, everyone), fake.get_source_rows(1, everyone))
                 for c in range(C):
                     assert np.array_equal(eng.get_counts(1, c), fake._slot(1)["counts"][c]), (name, c)
                 assert np.array_equal(eng.likelihood_per_component(1), fake._state(1)[2])      # (the candidate's tables)
-                # the current slot is untouched
-                assert np.array_equal(eng.get_source_rows(0, everyone), source)
+        eng.set_option(fuse_tables=True)
         with pytest.raises(Exception, match="differ"):
             eng.gibbs_propose(0, 0, [0], np.zeros((1, F)))
         with pytest.raises(Exception, match="out of range"):
