@@ -2347,9 +2347,13 @@ int source_posterior_setup(sbe_engine* e, int slot, const int32_t* objects, int 
     const size_t ob = ((size_t)n_sub * sizeof(int32_t) + 255) / 256 * 256;
     rc = ensure_scratch(e, ob + extra_bytes);
     if (rc) return rc;
-    int32_t* d_obj = (int32_t*)e->d_scratch;
     *d_extra = e->d_scratch + ob;
-    { int _urc = upload(e, d_obj, objects, (size_t)n_sub * sizeof(int32_t)); if (_urc) return _urc; }
+    // the object list is read once per thread: out of the host-mapped staging ring in place (no copy operation in front of
+    // the kernel); lists beyond the ring's direct size go up with a copy
+    const void* v_obj;
+    rc = stage(e, objects, (size_t)n_sub * sizeof(int32_t), e->d_scratch, &v_obj);
+    if (rc) return rc;
+    const int32_t* d_obj = (const int32_t*)v_obj;
     rc = clear_status_word(e, ST_BAD_NORMALIZE);
     if (rc) return rc;
     const double inv_t = 1.0 / temperature, inv_tp = 1.0 / prior_temperature;
