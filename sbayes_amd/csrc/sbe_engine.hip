@@ -41,6 +41,7 @@ struct Slot {
     bool groups_set = false, weights_set = false, source_set = false;
     std::vector<uint8_t> probs_set, counts_set;   // per component
     bool patterns_dirty = true;
+    uint32_t gid_pending = 0;             // components whose new ids (h_gid) are not resident yet: they travel with the pattern tables
     // round 3: object counts behind the pattern / tuple tables, so that a step which moves a few objects updates the
     // tables in O(moved objects) instead of re-deriving them from all N (prepare_step); valid while inc_ok
     std::vector<int32_t> pat_cnt;         // [256] objects per has_components bit pattern
@@ -441,17 +442,24 @@ int stage(sbe_engine* e, const void* src, size_t bytes, void* dev_fallback, cons
 }
 
 // Up to eight small host arrays to their resident places with ONE enqueue (k_scatter_bytes out of the mapped ring);
-// ordinary uploads, one per array, when the arrays do not fit the direct path.
+// ordinary uploads, one per array, when the arrays do not fit the direct path.  `wp` (optional): the same launch also
+// computes a slot's per-pattern normalised weights (k_scatter_weight_patterns) -- pattern bits = segment wp->bits_seg as
+// staged, weights = the resident copy or `wp->new_weights` staged in the same reservation; wp->done says whether it did.
 struct UploadSeg { void* dst; const void* src; size_t bytes; };
-int upload_segments(sbe_engine* e, const UploadSeg* segs, int n) {
+struct FusedWeightPatterns { WeightPatternArgs args; int bits_seg; const float* new_weights; bool done; };
+int upload_segments(sbe_engine* e, const UploadSeg* segs, int n, FusedWeightPatterns* wp = nullptr) {
     size_t total = 0, largest = 0;
     for (int i = 0; i < n; ++i) { total += (segs[i].bytes + 63) / 64 * 64; largest = std::max(largest, segs[i].bytes); }
+    if (wp) wp->done = false;
     if (total == 0) return SBE_OK;
     if (!e->d_arena || n > 8 || total > ((size_t)64 << 10)) {
         for (int i = 0; i < n; ++i) { int rc = upload(e, segs[i].dst, segs[i].src, segs[i].bytes); if (rc) return rc; }
         return SBE_OK;
     }
-    if (e->arena_off + total > e->arena_bytes) {
+    const size_t w_bytes = wp && wp->new_weights ? (size_t)wp->args.F * wp->args.C * sizeof(float) : 0;
+    const bool fuse = wp && segs[wp->bits_seg].bytes > 0 && w_bytes <= ((size_t)64 << 10);
+    const size_t reserve = total + (fuse ? (w_bytes + 63) / 64 * 64 : 0);
+    if (e->arena_off + reserve > e->arena_bytes) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
         e->arena_off = 0;
     }
@@ -462,11 +470,23 @@ int upload_segments(sbe_engine* e, const UploadSeg* segs, int n) {
         memcpy(e->h_arena + e->arena_off + off, segs[i].src, segs[i].bytes);
         sg.dst[sg.n] = (uint8_t*)segs[i].dst; sg.off[sg.n] = (uint32_t)off; sg.bytes[sg.n] = (uint32_t)segs[i].bytes;
         ++sg.n;
+        if (fuse && i == wp->bits_seg) wp->args.pattern_bits = (const uint32_t*)(e->d_arena + e->arena_off + off);
         off += (segs[i].bytes + 63) / 64 * 64;
     }
-    k_scatter_bytes<<<dim3((unsigned)std::min<size_t>(div_up((int64_t)largest, 1024), 16), sg.n), 256, 0, e->stream>>>(e->d_arena + e->arena_off, sg);
+    const unsigned sx = (unsigned)std::min<size_t>(div_up((int64_t)largest, 1024), 16);
+    if (fuse) {
+        if (w_bytes) {
+            memcpy(e->h_arena + e->arena_off + off, wp->new_weights, w_bytes);
+            wp->args.weights = (const float*)(e->d_arena + e->arena_off + off);
+        }
+        const unsigned wx = (unsigned)div_up((int64_t)wp->args.P * wp->args.F, 256);
+        k_scatter_weight_patterns<<<dim3(std::max(sx, wx), sg.n + 1), 256, 0, e->stream>>>(e->d_arena + e->arena_off, sg, wp->args);
+        wp->done = true;
+    } else {
+        k_scatter_bytes<<<dim3(sx, sg.n), 256, 0, e->stream>>>(e->d_arena + e->arena_off, sg);
+    }
     HIPCHK(e, hipGetLastError());
-    e->arena_off += total;
+    e->arena_off += reserve;
     return SBE_OK;
 }
 
@@ -718,16 +738,30 @@ bool update_patterns_and_tuples(sbe_engine* e, Slot& s, const int32_t* moved, co
     return s.n_tuples > 0;
 }
 
-int upload_patterns_and_weights(sbe_engine* e, int slot, const float* new_weights = nullptr) {
+// The slot's pending state to the device: new group ids (gid_pending), the pattern / tuple tables derived from them and
+// the per-pattern normalised weights -- ONE launch when they fit the mapped ring (k_scatter_weight_patterns).  `eager`
+// (sbe_set_groups: the call comes straight from the setter): more patterns than the engine holds is not an error yet --
+// another component's ids may still follow -- the ids go up alone and the next consumer reports it.
+int upload_patterns_and_weights(sbe_engine* e, int slot, const float* new_weights = nullptr, bool eager = false) {
     Slot& s = e->slots[slot];
+    float* d_w = e->d_weights + (int64_t)slot * e->F * e->C;
+    auto gid_seg = [&](int c) { return UploadSeg{e->d_gid + ((int64_t)slot * e->C + c) * e->Np, s.h_gid.data() + (size_t)c * e->N, (size_t)e->N * sizeof(uint16_t)}; };
+    bool patterns_done = false;
     if (s.patterns_dirty) {
         derive_patterns(e, s);
-        if ((int)s.patterns.size() > e->Pmax)
+        if ((int)s.patterns.size() > e->Pmax) {
+            if (eager) {
+                for (int c = 0; c < e->C; ++c)
+                    if (s.gid_pending >> c & 1u) { const UploadSeg g = gid_seg(c); int rc = upload(e, g.dst, g.src, g.bytes); if (rc) return rc; }
+                s.gid_pending = 0;
+                return SBE_OK;
+            }
             return fail(e, SBE_ERR_ARG, "%zu distinct has_components patterns exceed capacity %d",
                         s.patterns.size(), e->Pmax);
+        }
         derive_tuples(e, s);
-        UploadSeg segs[6] = {{e->d_pid + (int64_t)slot * e->Np, s.h_pid.data(), (size_t)e->N},
-                             {e->d_patbits + (int64_t)slot * e->Pmax, s.patterns.data(), s.patterns.size() * sizeof(uint32_t)}};
+        UploadSeg segs[6 + kMaxComponents] = {{e->d_pid + (int64_t)slot * e->Np, s.h_pid.data(), (size_t)e->N},
+                                              {e->d_patbits + (int64_t)slot * e->Pmax, s.patterns.data(), s.patterns.size() * sizeof(uint32_t)}};
         int n_segs = 2;
         if (s.n_tuples) {
             segs[n_segs++] = {e->d_tid + (int64_t)slot * e->Np, s.h_tid.data(), (size_t)e->Np};
@@ -735,16 +769,27 @@ int upload_patterns_and_weights(sbe_engine* e, int slot, const float* new_weight
             segs[n_segs++] = {e->d_tuple_g + (int64_t)slot * kMaxTuples * kMaxComponents, s.h_tuple_g.data(), s.h_tuple_g.size() * sizeof(uint16_t)};
             segs[n_segs++] = {e->d_tuple_p + (int64_t)slot * kMaxTuples, s.h_tuple_p.data(), s.h_tuple_p.size()};
         }
-        { int _urc = upload_segments(e, segs, n_segs); if (_urc) return _urc; }
+        for (int c = 0; c < e->C; ++c) if (s.gid_pending >> c & 1u) segs[n_segs++] = gid_seg(c);
+        const int P = (int)s.patterns.size();
+        FusedWeightPatterns wp{};
+        const bool want_wp = (s.weights_set || new_weights) && P > 0;
+        if (want_wp) {
+            wp.args = WeightPatternArgs{d_w, nullptr, e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, new_weights ? d_w : nullptr,
+                                        e->d_wpat_t + (int64_t)slot * e->wpat_t_elems(), P, e->F, e->C, e->Pmax, e->ft};
+            wp.bits_seg = 1;
+            wp.new_weights = new_weights;
+        }
+        { int _urc = upload_segments(e, segs, n_segs, want_wp ? &wp : nullptr); if (_urc) return _urc; }
+        patterns_done = wp.done;
         s.patterns_dirty = false;
+        s.gid_pending = 0;
     }
-    float* d_w = e->d_weights + (int64_t)slot * e->F * e->C;
     const int P = (int)s.patterns.size();
     if (new_weights && P == 0) {                   // nothing to normalise for: just keep the weights
         int rc = upload(e, d_w, new_weights, (size_t)e->F * e->C * sizeof(float));
         if (rc) return rc;
     }
-    if ((s.weights_set || new_weights) && P > 0) {
+    if ((s.weights_set || new_weights) && P > 0 && !patterns_done) {
         // one launch: per-pattern normalised weights, their tile-transposed copy and -- sbe_set_weights -- the slot's
         // resident copy of the new weights, read out of the mapped staging ring
         const void* w_in = d_w;
@@ -1535,13 +1580,14 @@ int sbe_component_lh(sbe_engine* e, const void* probs, int probs_f64, int n_grou
 static int set_gid_common(sbe_engine* e, int slot, int component, const std::vector<uint16_t>& ids) {
     Slot& s = e->slots[slot];
     std::copy(ids.begin(), ids.end(), s.h_gid.begin() + (size_t)component * e->N);
-    { int _urc = upload(e, e->d_gid + ((int64_t)slot * e->C + component) * e->Np, ids.data(),
-                             (size_t)e->N * sizeof(uint16_t)); if (_urc) return _urc; }
+    s.gid_pending |= 1u << component;
     s.patterns_dirty = true;
     s.group_epoch = ++e->epoch_counter;
     bump_ids(e, slot);
     s.groups_set = true;   // components never set keep "no group" ids
-    return SBE_OK;
+    // the ids, the pattern / tuple tables they imply and the per-pattern weights go up together, now: one launch, and no
+    // reader of the resident ids ever sees the slot between the two
+    return upload_patterns_and_weights(e, slot, nullptr, true);
 }
 
 // Resident slot state keeps ONE group per object and component (u16 ids).  A bool [G][N] matrix with an object in two
@@ -1758,9 +1804,12 @@ int sbe_get_counts(sbe_engine* e, int slot, int component, float* out) {
     void* d_out;
     rc = out_target(e, n * sizeof(float), e->d_scratch, &d_out);
     if (rc) return rc;
-    k_i32_to_f32<<<div_up(n, 256), 256, 0, e->stream>>>(src, (float*)d_out, n);
+    const unsigned blocks = (unsigned)std::min<int64_t>(div_up(n, 1024), 64);
+    const DoneSig done = out_done(e, d_out, blocks);
+    if (done.flag) k_i32_to_f32_done<<<blocks, 1024, 0, e->stream>>>(src, (float*)d_out, n, done);
+    else k_i32_to_f32<<<div_up(n, 256), 256, 0, e->stream>>>(src, (float*)d_out, n);
     HIPCHK(e, hipGetLastError());
-    return out_fetch(e, out, d_out, n * sizeof(float));
+    return out_fetch(e, out, d_out, n * sizeof(float), done);
 }
 
 // ---- concentration / probs ----------------------------------------------------------------------

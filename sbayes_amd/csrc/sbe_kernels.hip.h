@@ -98,9 +98,7 @@ __global__ void k_init_state_h(uint16_t* __restrict__ state_h, int64_t n_entries
 // Several small host arrays to their resident places in ONE launch: the arrays are staged back to back in the mapped
 // ring (`base`, read over PCIe element-parallel), segment y goes to sg.dst[y].  Words when everything is 4-byte aligned.
 struct ScatterSegs { uint8_t* dst[8]; uint32_t off[8]; uint32_t bytes[8]; int n; };
-__global__ void k_scatter_bytes(const uint8_t* __restrict__ base, ScatterSegs sg) {
-    const int y = blockIdx.y;
-    if (y >= sg.n) return;
+__device__ __forceinline__ void scatter_segment(const uint8_t* __restrict__ base, const ScatterSegs& sg, int y) {
     const uint8_t* src = base + sg.off[y];
     uint8_t* dst = sg.dst[y];
     const uint32_t nb = sg.bytes[y], stride = gridDim.x * blockDim.x, i0 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,6 +107,9 @@ __global__ void k_scatter_bytes(const uint8_t* __restrict__ base, ScatterSegs sg
     } else {
         for (uint32_t j = i0; j < nb; j += stride) dst[j] = src[j];
     }
+}
+__global__ void k_scatter_bytes(const uint8_t* __restrict__ base, ScatterSegs sg) {
+    if ((int)blockIdx.y < sg.n) scatter_segment(base, sg, blockIdx.y);
 }
 
 // K0b: source ingest.  bool rows [rows][F][C] -> component id per observation (0xFF = none).
@@ -271,6 +272,12 @@ __global__ void k_i32_to_f32(const int32_t* __restrict__ in, float* __restrict__
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (float)in[i];
 }
+// the same conversion as a call's LAST kernel: any grid (the blocks stride over the array), completion by flag
+__global__ void k_i32_to_f32_done(const int32_t* __restrict__ in, float* __restrict__ out, int64_t n, DoneSig done) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (float)in[i];
+    signal_done(done);
+}
 __global__ void k_f32_to_i32(const float* __restrict__ in, int32_t* __restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (int32_t)in[i];
@@ -420,6 +427,31 @@ __global__ void k_probs(const TC* __restrict__ counts, const double* __restrict_
 // Optional extras of the slot form (one launch per sbe_set_weights): `weights_keep` = the slot's resident [F][C] copy
 // of `weights` (which may then be host-mapped staging memory), `wpat_t` = the tile-transposed float64 copy
 // [n_ftiles][Pmax][C][ft], exact widening (what the fused kernels read; padding features stay zero from creation).
+struct WeightPatternArgs {
+    const float* weights;          // [F][C]
+    const uint32_t* pattern_bits;  // [P]
+    float* wpat;                   // [P][F][C]
+    float* weights_keep;           // or nullptr
+    double* wpat_t;                // or nullptr
+    int P, F, C, Pmax, ft;
+};
+__device__ __forceinline__ void weight_patterns_item(int i, const WeightPatternArgs& a) {
+    const int F = a.F, C = a.C;
+    const int p = i / F, f = i % F;
+    const uint32_t bits = a.pattern_bits[p];
+    float w[kMaxComponents];
+    for (int c = 0; c < C; ++c) w[c] = a.weights[(int64_t)f * C + c];
+    if (a.weights_keep && p == 0) for (int c = 0; c < C; ++c) a.weights_keep[(int64_t)f * C + c] = w[c];
+    auto masked = [&](int c) -> float { return ((bits >> c) & 1u) ? w[c] : 0.0f * w[c]; };
+    const float total = np_pairwise_sum<float>(masked, C);
+    float* out = a.wpat + ((int64_t)p * F + f) * C;
+    double* out_t = a.wpat_t ? a.wpat_t + (((int64_t)(f / a.ft) * a.Pmax + p) * C) * a.ft + f % a.ft : nullptr;
+    for (int c = 0; c < C; ++c) {
+        const float v = masked(c) / total;
+        out[c] = v;
+        if (out_t) out_t[(int64_t)c * a.ft] = (double)v;
+    }
+}
 __global__ void k_weight_patterns(const float* __restrict__ weights /* [F][C] */,
                                   const uint32_t* __restrict__ pattern_bits /* [P] */,
                                   float* __restrict__ wpat /* [P][F][C] */, int P, int F, int C,
@@ -427,20 +459,18 @@ __global__ void k_weight_patterns(const float* __restrict__ weights /* [F][C] */
                                   int Pmax = 0, int ft = 1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P * F) return;
-    const int p = i / F, f = i % F;
-    const uint32_t bits = pattern_bits[p];
-    float w[kMaxComponents];
-    for (int c = 0; c < C; ++c) w[c] = weights[(int64_t)f * C + c];
-    if (weights_keep && p == 0) for (int c = 0; c < C; ++c) weights_keep[(int64_t)f * C + c] = w[c];
-    auto masked = [&](int c) -> float { return ((bits >> c) & 1u) ? w[c] : 0.0f * w[c]; };
-    const float total = np_pairwise_sum<float>(masked, C);
-    float* out = wpat + ((int64_t)p * F + f) * C;
-    double* out_t = wpat_t ? wpat_t + (((int64_t)(f / ft) * Pmax + p) * C) * ft + f % ft : nullptr;
-    for (int c = 0; c < C; ++c) {
-        const float v = masked(c) / total;
-        out[c] = v;
-        if (out_t) out_t[(int64_t)c * ft] = (double)v;
-    }
+    weight_patterns_item(i, WeightPatternArgs{weights, pattern_bits, wpat, weights_keep, wpat_t, P, F, C, Pmax, ft});
+}
+
+// A slot's new group ids in ONE launch (sbe_set_groups and friends): rows y < sg.n of the grid put the staged arrays (the
+// ids, the pattern id per object, the pattern bits, the group-tuple tables) in their resident places, row sg.n computes
+// the per-pattern normalised weights -- k_weight_patterns' arithmetic -- with the pattern bits read from the STAGED copy,
+// so the two halves do not depend on each other.
+__global__ void k_scatter_weight_patterns(const uint8_t* __restrict__ base, ScatterSegs sg, WeightPatternArgs wp) {
+    const int y = blockIdx.y;
+    if (y < sg.n) { scatter_segment(base, sg, y); return; }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < wp.P * wp.F) weight_patterns_item(i, wp);
 }
 
 // normalize_weights (likelihood.py:171-190), stateless, ROW form: out[n][f][:] = has_components[n] * weights[f] / sum --
@@ -452,16 +482,33 @@ __global__ void k_normalize_weight_rows(const float* __restrict__ weights /* [F]
                                         const uint8_t* __restrict__ has_components /* [N][C] */,
                                         float* __restrict__ out /* [N][F][C] */, int N, int F, int C, int stage_weights,
                                         DoneSig done = DoneSig{}) {
-    extern __shared__ float nw_lds[];                        // [F][C] weights (stage_weights == 0: read in place from
+    extern __shared__ __align__(16) float nw_lds[];          // [F][C] weights (stage_weights == 0: read in place from
     __shared__ uint32_t bits[kNwRows];                       //  device memory -- tables beyond the LDS budget)
-    if (stage_weights) for (int i = threadIdx.x; i < F * C; i += blockDim.x) nw_lds[i] = weights[i];
     const int n0 = blockIdx.x * kNwRows;
+    // Both inputs may live in host-mapped staging memory: every read of the block is asked for before the first one is
+    // waited for (the rows' flags, then the weights as 16-byte words, four per thread and pass), one trip over the link.
+    uint8_t hb[kMaxComponents];
+    {
+        const int n = n0 + (int)threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < kMaxComponents; ++c)
+            hb[c] = (threadIdx.x < kNwRows && n < N && c < C) ? has_components[(int64_t)n * C + c] : (uint8_t)0;
+    }
+    if (stage_weights) {
+        const int nw = F * C, n4 = nw >> 2;
+        const float4* w4 = reinterpret_cast<const float4*>(weights);   // (ring slots and the scratch base are 64-byte aligned)
+        const float tail = (int)threadIdx.x < (nw & 3) ? weights[(n4 << 2) + threadIdx.x] : 0.0f;
+        for (int base = 0; base < n4; base += 4 * (int)blockDim.x) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = base + u * (int)blockDim.x + (int)threadIdx.x; if (i < n4) v[u] = w4[i]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = base + u * (int)blockDim.x + (int)threadIdx.x; if (i < n4) reinterpret_cast<float4*>(nw_lds)[i] = v[u]; }
+        }
+        if ((int)threadIdx.x < (nw & 3)) nw_lds[(n4 << 2) + threadIdx.x] = tail;
+    }
     if (threadIdx.x < kNwRows) {
         uint32_t b = 0;
-        const int n = n0 + threadIdx.x;
-        uint8_t hb[kMaxComponents];                          // (the rows may sit in host-mapped memory: the C reads go out together)
-#pragma unroll
-        for (int c = 0; c < kMaxComponents; ++c) hb[c] = (n < N && c < C) ? has_components[(int64_t)n * C + c] : (uint8_t)0;
 #pragma unroll
         for (int c = 0; c < kMaxComponents; ++c) if (hb[c]) b |= 1u << c;
         bits[threadIdx.x] = b;
