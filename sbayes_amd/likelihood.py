@@ -12,6 +12,7 @@ fallback: without the HIP library / a GPU these functions raise.
 """
 from __future__ import annotations
 
+import collections
 import weakref
 from types import SimpleNamespace
 
@@ -212,6 +213,42 @@ def compute_component_likelihood_exact(features, probs, groups, changed_groups, 
     return out
 
 
+# normalize_weights for a FEW rows (the operators' update_weights(sample)[object_subset], operators.py:520, 756-757, 819-842):
+# a row depends on the weights and on its own has_components pattern only, so each pattern's row is computed on the
+# device ONCE per weights content and gathered from this memo afterwards -- a cluster step asks for the same objects'
+# rows before and after the move, and the weights only change at AlterWeights steps.  (Device results, kept: not a host
+# computation -- a pattern the memo does not hold is a device call.)
+_ROW_MEMO = collections.OrderedDict()      # (weights shape, weights bytes) -> {pattern bytes: float32 [F, C] device result}
+_ROW_MEMO_WEIGHTS = 4                      # weight arrays kept (MC3 chains alternate between theirs)
+_ROW_MEMO_ROWS = 64                        # row requests up to this size go through the memo
+
+
+def _pattern_rows(eng, w, hc):
+    key = (w.shape, w.tobytes())
+    memo = _ROW_MEMO.get(key)
+    if memo is None:
+        memo = _ROW_MEMO[key] = {}
+        if len(_ROW_MEMO) > _ROW_MEMO_WEIGHTS:
+            _ROW_MEMO.popitem(last=False)
+    else:
+        _ROW_MEMO.move_to_end(key)
+    keys = [row.tobytes() for row in hc]
+    missing = [k for k in dict.fromkeys(keys) if k not in memo]
+    if missing:
+        n_comp = w.shape[1]
+        want = list(missing)
+        if n_comp <= 4:                    # every other non-empty pattern rides along: the step's next request needs no call
+            want += [p for p in (bytes((b >> c) & 1 for c in range(n_comp)) for b in range(1, 1 << n_comp))
+                     if p not in memo and p not in missing]
+        rows = eng.normalize_weights(w, np.frombuffer(b"".join(want), dtype=np.bool_).reshape(len(want), n_comp))
+        for p, r in zip(want, rows):
+            memo[p] = r
+    out = np.empty((len(keys),) + w.shape, dtype=np.float32)
+    for i, k in enumerate(keys):
+        out[i] = memo[k]
+    return out
+
+
 def normalize_weights(weights, has_components, features=None):
     """float32 [n_rows, n_features, n_components]: weights masked by has_components and renormalised over
     components; has_components may have any number of rows (the reference also calls it with
@@ -221,6 +258,10 @@ def normalize_weights(weights, has_components, features=None):
         eng = get_engine(features)
     else:
         eng = registry.engine_for_features(np.shape(weights)[0])
+    if has_components.ndim == 2 and 0 < has_components.shape[0] <= _ROW_MEMO_ROWS:
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        if w.ndim == 2 and has_components.shape[1] == w.shape[1]:
+            return _pattern_rows(eng, w, np.ascontiguousarray(has_components, dtype=np.bool_))
     return eng.normalize_weights(weights, has_components)
 
 

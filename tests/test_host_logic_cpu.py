@@ -198,11 +198,58 @@ def test_normalize_weights_never_creates_engines_per_row_count(monkeypatch):
     monkeypatch.setattr(registry, "_ENGINES", {})
     monkeypatch.setattr(registry, "_KNOWN", {})
     monkeypatch.setattr(registry, "default_device", lambda: 0)
+    monkeypatch.setattr(likelihood, "_ROW_MEMO", type(likelihood._ROW_MEMO)())     # (the stub's zeros must not be kept)
     w = np.full((7, 2), 0.5, dtype=np.float32)
     for n in (3, 50, 11, 3, 49):
         out = likelihood.normalize_weights(w, np.ones((n, 2), dtype=bool))
         assert out.shape == (n, 7, 2)
     assert len(made) == 1 and made[0].n_features == 7
+
+
+def test_normalize_weights_rows_are_asked_of_the_device_once_per_pattern(monkeypatch):
+    """Few rows (update_weights(sample)[object_subset], operators.py:819-842): each has_components pattern's row is a device
+    result kept per weights content; the same rows again, or other objects with known patterns, cost no engine call; new
+    weights do.  The values are the engine's (here: the oracle's), row for row, and the returned array is the caller's."""
+    from oracle import sbayes_oracle as orc
+    calls = []
+
+    class Stub:
+        def __init__(self, features, n_groups, n_slots=1, device=0):
+            self.n_objects, self.n_features = features.shape[:2]
+
+        def normalize_weights(self, weights, has_components):
+            calls.append(np.array(has_components))
+            return orc.normalize_weights(np.asarray(weights, dtype=np.float32), np.asarray(has_components, dtype=bool))
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(registry, "Engine", Stub)
+    monkeypatch.setattr(registry, "_ENGINES", {})
+    monkeypatch.setattr(registry, "_KNOWN", {})
+    monkeypatch.setattr(registry, "default_device", lambda: 0)
+    monkeypatch.setattr(likelihood, "_ROW_MEMO", type(likelihood._ROW_MEMO)())
+    rng = np.random.default_rng(5)
+    w = rng.dirichlet(np.ones(3), size=9).astype(np.float32)
+    hc = np.array([[1, 1, 1], [0, 1, 1], [1, 1, 1], [0, 1, 0]], dtype=bool)
+    got = likelihood.normalize_weights(w, hc)
+    assert np.array_equal(got, orc.normalize_weights(w, hc)) and len(calls) == 1
+    assert len(calls[0]) == 7 and {tuple(r) for r in calls[0]} == {tuple((b >> c) & 1 for c in range(3)) for b in range(1, 8)}
+    got[0] = -1.0                                            # the caller's own array: the kept rows are untouched
+    again = likelihood.normalize_weights(w, np.array([[1, 0, 1], [1, 1, 1]], dtype=bool))
+    assert np.array_equal(again, orc.normalize_weights(w, np.array([[1, 0, 1], [1, 1, 1]], dtype=bool))) and len(calls) == 1
+    w2 = w.copy(); w2[0] = [0.2, 0.3, 0.5]
+    assert np.array_equal(likelihood.normalize_weights(w2, hc), orc.normalize_weights(w2, hc)) and len(calls) == 2
+    assert np.array_equal(likelihood.normalize_weights(w, hc[:1]), orc.normalize_weights(w, hc[:1])) and len(calls) == 2
+    # more components than the ride-along covers: exactly the missing patterns are asked for
+    w6 = rng.dirichlet(np.ones(6), size=9).astype(np.float32)
+    hc6 = rng.random((5, 6)) < 0.6
+    hc6[:, 0] = True
+    assert np.array_equal(likelihood.normalize_weights(w6, hc6), orc.normalize_weights(w6, hc6))
+    assert len(calls) == 3 and len(calls[2]) == len({r.tobytes() for r in hc6})
+    # many rows: the direct call
+    big = np.ones((likelihood._ROW_MEMO_ROWS + 1, 3), dtype=bool)
+    assert likelihood.normalize_weights(w, big).shape == (len(big), 9, 3) and len(calls) == 4 and len(calls[3]) == len(big)
 
 
 def test_get_engine_after_a_featureless_stand_in(monkeypatch):
