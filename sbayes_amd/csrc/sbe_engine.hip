@@ -42,6 +42,7 @@ struct Slot {
     std::vector<uint8_t> probs_set, counts_set;   // per component
     bool patterns_dirty = true;
     uint32_t gid_pending = 0;             // components whose new ids (h_gid) are not resident yet: they travel with the pattern tables
+    bool tables_follow = false;           // the host pattern / tuple tables already match h_gid (updated in O(moved objects))
     // round 3: object counts behind the pattern / tuple tables, so that a step which moves a few objects updates the
     // tables in O(moved objects) instead of re-deriving them from all N (prepare_step); valid while inc_ok
     std::vector<int32_t> pat_cnt;         // [256] objects per has_components bit pattern
@@ -748,7 +749,9 @@ int upload_patterns_and_weights(sbe_engine* e, int slot, const float* new_weight
     auto gid_seg = [&](int c) { return UploadSeg{e->d_gid + ((int64_t)slot * e->C + c) * e->Np, s.h_gid.data() + (size_t)c * e->N, (size_t)e->N * sizeof(uint16_t)}; };
     bool patterns_done = false;
     if (s.patterns_dirty) {
-        derive_patterns(e, s);
+        const bool follow = s.tables_follow;
+        s.tables_follow = false;
+        if (!follow) derive_patterns(e, s);
         if ((int)s.patterns.size() > e->Pmax) {
             if (eager) {
                 for (int c = 0; c < e->C; ++c)
@@ -759,7 +762,7 @@ int upload_patterns_and_weights(sbe_engine* e, int slot, const float* new_weight
             return fail(e, SBE_ERR_ARG, "%zu distinct has_components patterns exceed capacity %d",
                         s.patterns.size(), e->Pmax);
         }
-        derive_tuples(e, s);
+        if (!follow) derive_tuples(e, s);
         UploadSeg segs[6 + kMaxComponents] = {{e->d_pid + (int64_t)slot * e->Np, s.h_pid.data(), (size_t)e->N},
                                               {e->d_patbits + (int64_t)slot * e->Pmax, s.patterns.data(), s.patterns.size() * sizeof(uint32_t)}};
         int n_segs = 2;
@@ -1579,7 +1582,23 @@ int sbe_component_lh(sbe_engine* e, const void* probs, int probs_f64, int n_grou
 // ---- groups -----------------------------------------------------------------------------------
 static int set_gid_common(sbe_engine* e, int slot, int component, const std::vector<uint16_t>& ids) {
     Slot& s = e->slots[slot];
-    std::copy(ids.begin(), ids.end(), s.h_gid.begin() + (size_t)component * e->N);
+    // a cluster move changes the ids of a few objects of component 0: the host pattern / tuple tables follow in
+    // O(moved objects) (update_patterns_and_tuples, what the one-call steps use) instead of being derived from all N
+    s.tables_follow = false;
+    static const bool follow_on = [] { const char* v = getenv("SBE_FOLLOW_TABLES"); return !(v && atoi(v) == 0); }();   // (A/B: tools/ab_env.sh)
+    if (follow_on && component == 0 && !s.patterns_dirty && s.inc_ok) {
+        static thread_local std::vector<int32_t> moved;
+        static thread_local std::vector<uint16_t> old_ids;
+        moved.clear(); old_ids.clear();
+        const int N = e->N;
+        for (int n = 0; n < N; ++n)
+            if (ids[n] != s.h_gid[n]) { moved.push_back(n); old_ids.push_back(s.h_gid[n]); }
+        std::copy(ids.begin(), ids.end(), s.h_gid.begin());
+        s.tables_follow = (int)moved.size() * 8 <= N &&
+                          update_patterns_and_tuples(e, s, moved.data(), old_ids.data(), (int)moved.size());
+    } else {
+        std::copy(ids.begin(), ids.end(), s.h_gid.begin() + (size_t)component * e->N);
+    }
     s.gid_pending |= 1u << component;
     s.patterns_dirty = true;
     s.group_epoch = ++e->epoch_counter;

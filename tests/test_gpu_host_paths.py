@@ -150,3 +150,49 @@ def test_resident_operator_forms_at_both_sizes(name):
             assert np.array_equal(got, fake.given_unchanged_lh(0, 1, objs)), n
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("name", ["flat", "long"])
+def test_set_groups_after_small_moves_equals_a_fresh_slot(name):
+    """sbe_set_groups after a cluster move: the ids, the pattern / tuple tables (followed on the host in O(moved objects)
+    when the set of has_components patterns stays what it is, derived from all N otherwise) and the per-pattern weights go
+    up in one launch.  A slot walked through a chain of moves -- single objects, a handful, a move that empties a cluster
+    (the pattern set changes), a big reshuffle (full derivation) -- answers like a slot that receives the final groups
+    at once: same mixture log-likelihood bits, same source prior, same membership marginals."""
+    eng, fake, wl, counts = _pair(name)
+    try:
+        rng = np.random.default_rng(11)
+        clusters = wl.groups[0].copy()
+        K, N = clusters.shape
+        for c in range(eng.n_components):
+            eng.update_probs(0, c)
+        # slot 1: the same state, set up once per stop
+        def fresh(groups0):
+            for c in range(eng.n_components):
+                eng.set_groups(1, c, groups0 if c == 0 else wl.groups[c])
+                eng.set_counts(1, c, counts[c])
+                eng.update_probs(1, c)
+            eng.set_source(1, wl.source)
+            eng.set_weights(1, wl.weights)
+        def move(n_obj, empty_cluster=None):
+            if empty_cluster is not None:
+                clusters[empty_cluster] = False
+                return
+            for n in rng.choice(N, size=n_obj, replace=False):
+                clusters[:, n] = False
+                k = int(rng.integers(0, K + 1))
+                if k < K:
+                    clusters[k, n] = True
+        objs = np.sort(rng.choice(N, size=min(N, 50), replace=False))
+        for step, (n_obj, empty) in enumerate([(1, None), (1, None), (3, None), (1, None), (0, 1), (2, None), (N // 2, None), (1, None), (1, None)]):
+            move(n_obj, empty)
+            eng.set_groups(0, 0, clusters)
+            fresh(clusters)
+            assert eng.mixture_loglik(0) == eng.mixture_loglik(1), step
+            assert np.array_equal(eng.source_prior(0), eng.source_prior(1)), step
+            assert np.array_equal(eng.cluster_posterior_marginals(0, 0, objs), eng.cluster_posterior_marginals(1, 0, objs)), step
+            assert np.array_equal(eng.weights_normalized(0), eng.weights_normalized(1)), step
+        want = orc.normalize_weights(wl.weights, orc.has_components([clusters] + list(wl.groups[1:])))
+        assert np.array_equal(eng.weights_normalized(0), want)
+    finally:
+        eng.close()
