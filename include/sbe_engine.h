@@ -474,6 +474,11 @@ int sbe_subset_lh(sbe_engine* e, const int32_t* objects, int n_sub, int n_comp, 
  * sbe_observation_lh_exact: the row LikelihoodLogger._write_sample stores (loggers.py:354-359):
  *     sum_c w[n][f][c] * lh_exact[n][f][c] with the leave-one-out tables of a2; float64 [N][F]. */
 int sbe_source_prior(sbe_engine* e, int slot, double* per_object_out /* [N] */);
+/* Model.__call__ = likelihood + prior (sbayes/model/model.py:47-51; mcmc.py:273-328 asks one after the other for the
+ * same candidate): sbe_collapsed_loglik_all's and sbe_source_prior's results for the same slot state, ONE launch and
+ * one synchronisation.  Same values as the two calls, bit for bit. */
+int sbe_collapsed_and_source_prior(sbe_engine* e, int slot, double* per_group_out /* [G_total] */,
+                                   double* per_object_out /* [N] */);
 int sbe_observation_lh_exact(sbe_engine* e, int slot, double* out /* [N][F] */);
 
 /* ---- one MCMC step in one call (resident flow) ---------------------------

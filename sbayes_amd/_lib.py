@@ -114,6 +114,7 @@ PROTOTYPES = {
     "sbe_jump_lh_resident": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_int, ct.c_double, ct.c_double, ct.c_void_p,
                                         ct.c_int, ct.c_void_p]),
     "sbe_source_prior": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
+    "sbe_collapsed_and_source_prior": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_void_p]),
     "sbe_observation_lh_exact": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
     "sbe_gibbs_step": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double, ct.c_int,
                                   ct.c_void_p, ct.POINTER(ct.c_double), ct.POINTER(ct.c_double), ct.c_void_p,

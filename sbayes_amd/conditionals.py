@@ -102,6 +102,43 @@ def observation_likelihoods(model, sample, slot=0, exact=False):
     return eng.observation_lh(slot)
 
 
+# True while patch.install(operators=True) serves SourcePrior.__call__ from the device: Likelihood.__call__ then takes the
+# source prior of the sample along with its collapsed likelihood (one launch, store_source_prior_ahead below)
+DEVICE_SOURCE_PRIOR = False
+
+
+def _store_source_prior(cache, sample, values, caching):
+    """SourcePrior.__call__'s cache update (sbayes/model/prior.py:596-609): everything when the weights changed, else the
+    objects whose source rows changed; `values()` -> float64 [n_objects] is asked only when something is listed."""
+    with cache.edit() as per_object:
+        if cache.ahead_of("weights"):
+            changed = np.arange(sample.n_objects)
+        else:
+            changed = cache.what_changed(input_key=["source"], caching=caching)
+        if len(changed) > 0:
+            per_object[changed] = values()[changed]
+
+
+def source_prior_wanted(prior, sample):
+    """The sample's source-prior cache node if the prior's next evaluation of this sample would have to ask the device
+    for it (Model.__call__ = likelihood, then prior: sbayes/model/model.py:47-51), else None."""
+    if not DEVICE_SOURCE_PRIOR:
+        return None
+    sp = getattr(prior, "source_prior", None)
+    if sp is None or getattr(sp, "_sbayes_amd_owner", None) is None:
+        return None
+    cache = getattr(sample.cache, "source_prior", None)
+    if cache is None or getattr(sample, "source", None) is None or not cache.is_outdated():
+        return None
+    return cache
+
+
+def store_source_prior_ahead(cache, sample, per_object_values):
+    """The per-object values came back with the collapsed likelihood (Engine.collapsed_and_source_prior): the cache
+    node is updated now, by the protocol SourcePrior.__call__ would follow a moment later -- which then finds it current."""
+    _store_source_prior(cache, sample, lambda: per_object_values, True)
+
+
 def source_prior(model, sample, slot=0, caching=True) -> float:
     """SourcePrior.__call__ (sbayes/model/prior.py:573-611): log prior of the source assignment given the weights, with
     the reference's per-object cache protocol -- everything when the weights changed (`cache.ahead_of("weights")`),
@@ -114,13 +151,10 @@ def source_prior(model, sample, slot=0, caching=True) -> float:
         return eng.source_prior(slot).sum()
     if caching and not cache.is_outdated():
         return cache.value.sum()
-    with cache.edit() as per_object:
-        if cache.ahead_of("weights"):
-            changed = np.arange(sample.n_objects)
-        else:
-            changed = cache.what_changed(input_key=["source"], caching=caching)
-        if len(changed) > 0:
-            eng = _engine(model)
-            _bind_slot(eng, model, sample, slot, with_source=True)
-            per_object[changed] = eng.source_prior(slot)[changed]
+
+    def values():
+        eng = _engine(model)
+        _bind_slot(eng, model, sample, slot, with_source=True)
+        return eng.source_prior(slot)
+    _store_source_prior(cache, sample, values, caching)
     return cache.value.sum()

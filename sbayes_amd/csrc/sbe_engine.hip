@@ -3192,6 +3192,44 @@ int sbe_source_prior(sbe_engine* e, int slot, double* per_object_out) {
     return out_fetch(e, per_object_out, d_out, (size_t)e->N * sizeof(double), done);
 }
 
+// Model.__call__ = likelihood + prior (sbayes/model/model.py:47-51): what sbe_collapsed_loglik_all and sbe_source_prior
+// return, for the same slot state, in ONE launch and one synchronisation (k_collapsed_source_prior).  Shapes whose
+// group terms exceed the LDS budget take the two calls one after the other.
+int sbe_collapsed_and_source_prior(sbe_engine* e, int slot, double* per_group_out, double* per_object_out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, per_group_out); CHECK_PTR(e, per_object_out);
+    Slot& s = e->slots[slot];
+    for (int c = 0; c < e->C; ++c) {
+        if (e->G[c] == 0) continue;
+        if (!s.counts_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts of component %d not set", slot, c);
+        if (!e->conc_set[c]) return fail(e, SBE_ERR_STATE, "concentration of component %d not set", c);
+    }
+    if (!s.groups_set || !s.source_set || !s.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", slot);
+    const size_t lds = (size_t)e->F * e->S * sizeof(double) + (size_t)e->F * sizeof(float);
+    const size_t gb = al256((size_t)e->Gtot * sizeof(double)), out_bytes = gb + (size_t)e->N * sizeof(double);
+    if (e->Gtot == 0 || lds > ((size_t)96 << 10) || out_bytes > kMappedOutMax || !poll_done_enabled()) {
+        int rc = sbe_collapsed_loglik_all(e, slot, per_group_out);
+        if (rc) return rc;
+        return sbe_source_prior(e, slot, per_object_out);
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = SBE_OK;
+    if (s.patterns_dirty) { rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
+    rc = ensure_io(e, out_bytes);
+    if (rc) return rc;
+    const unsigned nb = (unsigned)e->Gtot + (unsigned)div_up(e->N, 1024 / kWave);
+    const DoneSig done = next_done(e, nb);
+    const SourcePriorArgs sp{e->d_state, e->d_src + (int64_t)slot * e->N * e->Fp, e->d_pid + (int64_t)slot * e->Np,
+                             e->d_wpat + (int64_t)slot * e->Pmax * e->F * e->C, (double*)(e->d_io + gb), e->N, e->F, e->C, e->Fp};
+    k_collapsed_source_prior<<<nb, 1024, lds, e->stream>>>(e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc, e->d_lg_conc,
+                                                          e->d_sum_a, e->d_lg_sum_a, (double*)e->d_io, e->Gtot, e->F, e->S, sp, done);
+    HIPCHK(e, hipGetLastError());
+    rc = wait_done(e, done);
+    if (rc) return rc;
+    memcpy(per_group_out, e->h_io, (size_t)e->Gtot * sizeof(double));
+    memcpy(per_object_out, e->h_io + gb, (size_t)e->N * sizeof(double));
+    return synced(e);
+}
+
 int sbe_observation_lh_exact(sbe_engine* e, int slot, double* out) {
     CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, out);
     Slot& s = e->slots[slot];

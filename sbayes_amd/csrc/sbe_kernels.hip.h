@@ -716,14 +716,13 @@ __global__ void k_group_sum_f32(const float* __restrict__ per_feature, double* _
 // the row constant, the float32 cast (k_dcl's expression); phase 3, eight lanes: the float32 NumPy-order sum over the
 // features (k_group_sum_f32's).  Dynamic LDS: F*S doubles + F floats.  `per_feature` (may be null) gets the rows.
 template <class TC>
-__global__ __launch_bounds__(1024) void k_collapsed_groups(
+__device__ __forceinline__ void collapsed_group_block(
     const TC* __restrict__ counts, const double* __restrict__ conc, const double* __restrict__ lg_conc,
     const double* __restrict__ sum_a, const double* __restrict__ lg_sum_a, float* __restrict__ per_feature,
-    double* __restrict__ per_group, int g_lo, int F, int S, DoneSig done = DoneSig{}) {
-    extern __shared__ __align__(16) unsigned char cg_lds[];
+    double* __restrict__ per_group, int g_lo, int F, int S, int block /* = group - g_lo */, unsigned char* cg_lds) {
     double* ser = reinterpret_cast<double*>(cg_lds);                       // [F][S]
     float* pf = reinterpret_cast<float*>(cg_lds + (size_t)F * S * sizeof(double));   // [F]
-    const int g = g_lo + blockIdx.x;
+    const int g = g_lo + block;
     const int64_t gbase = (int64_t)g * F * S;
     for (int e = threadIdx.x; e < F * S; e += blockDim.x) {
         const double as = conc[gbase + e];
@@ -739,14 +738,22 @@ __global__ __launch_bounds__(1024) void k_collapsed_groups(
         const double cst = lg_sum_a[(int64_t)g * F + f] - sbe_lgamma_pos((double)n + sa);
         const float v = (float)(cst + np_pairwise_sum<double>(ser_at, S));
         pf[f] = v;
-        if (per_feature) per_feature[(int64_t)blockIdx.x * F + f] = v;
+        if (per_feature) per_feature[(int64_t)block * F + f] = v;
     }
     __syncthreads();
     if (threadIdx.x < 8) {
         auto get = [&](int i) -> float { return pf[i]; };
         const float total = np_pairwise_sum_f32_x8(get, F, (int)threadIdx.x);
-        if (threadIdx.x == 0) per_group[blockIdx.x] = (double)total;
+        if (threadIdx.x == 0) per_group[block] = (double)total;
     }
+}
+template <class TC>
+__global__ __launch_bounds__(1024) void k_collapsed_groups(
+    const TC* __restrict__ counts, const double* __restrict__ conc, const double* __restrict__ lg_conc,
+    const double* __restrict__ sum_a, const double* __restrict__ lg_sum_a, float* __restrict__ per_feature,
+    double* __restrict__ per_group, int g_lo, int F, int S, DoneSig done = DoneSig{}) {
+    extern __shared__ __align__(16) unsigned char cg_lds[];
+    collapsed_group_block<TC>(counts, conc, lg_conc, sum_a, lg_sum_a, per_feature, per_group, g_lo, F, S, (int)blockIdx.x, cg_lds);
     signal_done(done);
 }
 
@@ -1873,13 +1880,11 @@ __global__ __launch_bounds__(kTileBlock) void k_gibbs_propose_tile(GibbsTileArgs
 //   sp[n] = float32( sum_{f valid} log( w[pat(n)][f][source(n,f)] ) )     (float32 logs)
 // One wave per object, lanes over features, wave64 shuffle reduce.  An observation whose source has no
 // component set contributes log(0) = -inf like the reference's sum(w * s) = 0.
-__global__ __launch_bounds__(1024) void k_source_prior(const uint8_t* __restrict__ state,
-                                                        const uint8_t* __restrict__ src,
-                                                        const uint8_t* __restrict__ pid,
-                                                        const float* __restrict__ wpat, double* __restrict__ out,
-                                                        int N, int F, int C, int Fp, DoneSig done = DoneSig{}) {
+__device__ __forceinline__ void source_prior_block(const uint8_t* __restrict__ state, const uint8_t* __restrict__ src,
+                                                   const uint8_t* __restrict__ pid, const float* __restrict__ wpat,
+                                                   double* __restrict__ out, int N, int F, int C, int Fp, int block) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int n = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);      // (16 objects per 1024-thread block: a block's
+    const int n = block * (blockDim.x / kWave) + (threadIdx.x >> 6);           // (16 objects per 1024-thread block: a block's
     if (n < N) {                                           // (wave-uniform)           completion fence is per block)
         const float* w = wpat + (int64_t)pid[n] * F * C;
         double acc = 0.0;
@@ -1892,6 +1897,29 @@ __global__ __launch_bounds__(1024) void k_source_prior(const uint8_t* __restrict
         acc = wave_sum(acc);
         if (lane == 0) out[n] = (double)(float)acc;
     }
+}
+__global__ __launch_bounds__(1024) void k_source_prior(const uint8_t* __restrict__ state,
+                                                        const uint8_t* __restrict__ src,
+                                                        const uint8_t* __restrict__ pid,
+                                                        const float* __restrict__ wpat, double* __restrict__ out,
+                                                        int N, int F, int C, int Fp, DoneSig done = DoneSig{}) {
+    source_prior_block(state, src, pid, wpat, out, N, F, C, Fp, (int)blockIdx.x);
+    signal_done(done);
+}
+
+// Model.__call__ = likelihood + prior (sbayes/model/model.py:47-51): the collapsed log-likelihood of every group
+// (k_collapsed_groups' blocks) and the per-object source prior (k_source_prior's blocks) of the same slot state in ONE
+// launch -- the two halves share nothing but the completion flag.  Blocks [0, G): groups; the rest: 16 objects each.
+struct SourcePriorArgs { const uint8_t* state; const uint8_t* src; const uint8_t* pid; const float* wpat; double* out; int N, F, C, Fp; };
+__global__ __launch_bounds__(1024) void k_collapsed_source_prior(
+    const int32_t* __restrict__ counts, const double* __restrict__ conc, const double* __restrict__ lg_conc,
+    const double* __restrict__ sum_a, const double* __restrict__ lg_sum_a, double* __restrict__ per_group, int G, int F, int S,
+    SourcePriorArgs sp, DoneSig done) {
+    extern __shared__ __align__(16) unsigned char cg_lds[];
+    if ((int)blockIdx.x < G)                                   // (block-uniform: the barriers inside are reached by the whole block)
+        collapsed_group_block<int32_t>(counts, conc, lg_conc, sum_a, lg_sum_a, nullptr, per_group, 0, F, S, (int)blockIdx.x, cg_lds);
+    else
+        source_prior_block(sp.state, sp.src, sp.pid, sp.wpat, sp.out, sp.N, sp.F, sp.C, sp.Fp, (int)blockIdx.x - G);
     signal_done(done);
 }
 

@@ -718,6 +718,14 @@ class Engine:
         self._check(self._lib.sbe_source_prior(self._h, slot, self._o(out)))
         return out
 
+    def collapsed_and_source_prior(self, slot):
+        """(collapsed_loglik_all(slot), source_prior(slot)) in one launch and one synchronisation: Model.__call__ asks
+        for the likelihood and then the prior of the same sample (sbayes/model/model.py:47-51)."""
+        per_group = np.empty(self.n_groups_total, dtype=np.float64)
+        per_object = np.empty(self.n_objects, dtype=np.float64)
+        self._check(self._lib.sbe_collapsed_and_source_prior(self._h, slot, self._o(per_group), self._o(per_object)))
+        return per_group, per_object
+
     def observation_lh_exact(self, slot):
         """float64 [N, F]: sum_c w * lh_exact, the LikelihoodLogger row (loggers.py:354-359)."""
         out = np.empty((self.n_objects, self.n_features), dtype=np.float64)

@@ -113,7 +113,7 @@ class Likelihood:
             recalculate_feature_counts(self.features, sample)
         # one bind and one fetch per call: the components are asked one after another (likelihood.py:58-63) for the SAME
         # sample, so the per-group values of all of them are taken once (_group_logliks) and kept for the rest of the call
-        self._call_memo = [sample, None]
+        self._call_memo = [sample, None, caching]
         try:
             log_lh = 0.0
             log_lh += self.compute_lh_clusters(sample, caching=caching)
@@ -151,7 +151,19 @@ class Likelihood:
         entry = eng._bound.get(slot) if getattr(eng, "_bound", None) is not None else None
         lh_all = entry.get("lh_all") if entry is not None else None
         if lh_all is None:
-            lh_all = eng.collapsed_loglik_all(slot)
+            # inside Model.__call__ (likelihood, then prior, of the same sample: sbayes/model/model.py:47-51) the source
+            # prior the prior is about to ask for comes back with the collapsed values: one launch instead of two
+            sp_cache = None
+            if memo is not None and memo[0] is sample and memo[2]:
+                from . import conditionals
+                sp_cache = conditionals.source_prior_wanted(self.prior, sample)
+            if sp_cache is not None:
+                _bind_slot(eng, self._bind_model, sample, slot, with_source=True)
+                entry = eng._bound.get(slot) if getattr(eng, "_bound", None) is not None else None
+                lh_all, per_object = eng.collapsed_and_source_prior(slot)
+                conditionals.store_source_prior_ahead(sp_cache, sample, per_object)
+            else:
+                lh_all = eng.collapsed_loglik_all(slot)
             if entry is not None:
                 entry["lh_all"] = lh_all
         if memo is not None and memo[0] is sample:

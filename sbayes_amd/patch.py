@@ -332,6 +332,7 @@ def _install_operator_forms(swap):
             return my_cond_sp.source_prior(owner, sample, caching=caching)
 
         swap(ref_prior.SourcePrior, "__call__", source_prior_call)
+        swap(my_cond_sp, "DEVICE_SOURCE_PRIOR", True)            # (Likelihood.__call__ takes the source prior along)
 
     for owner, name in ((ref_ops.ClusterJump, "get_jump_lh"), (ref_ops.GibbsSampleWeights, "_propose"),
                         (ref_ops.GibbsSampleWeights, "source_lh_by_feature"),

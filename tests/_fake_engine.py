@@ -332,6 +332,14 @@ class FakeEngine:
         w = orc.normalize_weights(s["weights"], orc.has_components(groups))
         return orc.source_prior_per_object(w, s["source"], self.na_values())
 
+    def collapsed_and_source_prior(self, slot):
+        self.calls.append(("collapsed_and_source_prior",))
+        groups, counts, conc, s = self._full_state(slot)
+        parts = [orc.collapsed_group_logliks(counts[c], conc[c]) if self.n_groups[c] else np.zeros(0)
+                 for c in range(len(counts))]
+        w = orc.normalize_weights(s["weights"], orc.has_components(groups))
+        return np.concatenate(parts).astype(np.float64), orc.source_prior_per_object(w, s["source"], self.na_values())
+
     def given_unchanged_lh(self, slot, i_cluster, objects, temperature=1.0, prior_temperature=1.0):
         self.calls.append(("given_unchanged_lh", len(objects)))
         groups, counts, conc, s = self._full_state(slot)

@@ -196,3 +196,28 @@ def test_set_groups_after_small_moves_equals_a_fresh_slot(name):
         assert np.array_equal(eng.weights_normalized(0), want)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_collapsed_likelihood_and_source_prior_in_one_call(name):
+    """Model.__call__ = likelihood + prior (model.py:47-51): sbe_collapsed_and_source_prior returns what the two calls
+    return, bit for bit -- one launch (flat, long) or the two calls behind one entry (wide_tables: a group's terms exceed
+    the LDS budget) -- and agrees with the double within the two calls' own tolerances."""
+    eng, fake, wl, _ = _pair(name)
+    try:
+        per_group, per_object = eng.collapsed_and_source_prior(0)
+        assert np.array_equal(per_group, eng.collapsed_loglik_all(0))
+        assert np.array_equal(per_object, eng.source_prior(0))
+        want_g, want_o = fake.collapsed_and_source_prior(0)
+        np.testing.assert_allclose(per_group, want_g, rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(per_object, want_o, rtol=2e-6, atol=1e-6)
+        # a moved object and a changed source row reach both halves
+        clusters = wl.groups[0].copy()
+        clusters[:, 3] = False
+        clusters[0, 3] = True
+        eng.set_groups(0, 0, clusters)
+        per_group2, per_object2 = eng.collapsed_and_source_prior(0)
+        assert np.array_equal(per_group2, per_group) and np.array_equal(per_object2, eng.source_prior(0))
+        assert not np.array_equal(per_object2, per_object) or np.array_equal(clusters, wl.groups[0])
+    finally:
+        eng.close()
