@@ -29,6 +29,7 @@ typedef int (*sbe_gibbs_propose_supported_t)(sbe_engine*);
 typedef int (*sbe_gibbs_propose_t)(sbe_engine*, int, int, const int32_t*, int, double, double, int, const double*, uint8_t*, float*, float*,
                                    int32_t*, int32_t*, float*);
 typedef int (*sbe_test_roundtrip_t)(sbe_engine*, int, int);
+typedef int (*sbe_collapsed_and_source_prior_t)(sbe_engine*, int, double*, double*);
 
 static void* slurp(FILE* f, size_t bytes) {
     void* p = malloc(bytes ? bytes : 1);
@@ -44,7 +45,7 @@ int main(int argc, char** argv) {
     LOAD(sbe_set_concentration) LOAD(sbe_update_probs) LOAD(sbe_set_weights) LOAD(sbe_mixture_loglik)
     LOAD(sbe_collapsed_loglik) LOAD(sbe_get_info)
     LOAD(sbe_host_group_ids) LOAD(sbe_host_source_ids) LOAD(sbe_host_touched_groups)
-    LOAD(sbe_gibbs_propose_supported) LOAD(sbe_gibbs_propose) LOAD(sbe_test_roundtrip)
+    LOAD(sbe_gibbs_propose_supported) LOAD(sbe_gibbs_propose) LOAD(sbe_test_roundtrip) LOAD(sbe_collapsed_and_source_prior)
     FILE* f = fopen(argv[2], "rb");
     if (!f) { perror("case"); return 1; }
     int32_t hdr[4];                                   /* N, F, S, C */
@@ -116,6 +117,18 @@ int main(int argc, char** argv) {
        objects' source redrawn into slot 1; drawn ids, the groups touched and the sum of the count rows (a redraw moves
        counts between rows: they sum to zero) */
     if (p_sbe_test_roundtrip(e, 4, 3) != 0) { fprintf(stderr, "%s\n", p_sbe_last_error(e)); return 16; }
+    {   /* Model.__call__ = likelihood + prior in one call: sum of the per-group values, sum of the per-object source prior */
+        int g_total = 0;
+        for (int c = 0; c < C; ++c) g_total += G[c];
+        double* per_group = (double*)malloc((size_t)g_total * sizeof(double));
+        double* per_object = (double*)malloc((size_t)N * sizeof(double));
+        if (p_sbe_collapsed_and_source_prior(e, 0, per_group, per_object)) { fprintf(stderr, "%s\n", p_sbe_last_error(e)); return 18; }
+        double sum_g = 0.0, sum_o = 0.0;
+        for (int g = 0; g < g_total; ++g) sum_g += per_group[g];
+        for (int n = 0; n < N; ++n) sum_o += per_object[n];
+        printf("fused_collapsed_ll %.17g\nfused_source_prior %.17g\n", sum_g, sum_o);
+        free(per_group); free(per_object);
+    }
     if (p_sbe_gibbs_propose_supported(e) == 1) {
         const int n = N < 5 ? N : 5;
         int32_t objs[5] = {0, 1, 2, 3, 4}, touched[256], n_touched = 0;

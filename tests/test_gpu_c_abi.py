@@ -59,6 +59,10 @@ def test_plain_c_caller(tmp_path):
         eng.recount(0)
         eng.update_probs(0, range(fx.n_comp))
         eng.set_weights(0, fx.weights)
+        per_group, per_object = eng.collapsed_and_source_prior(0)
+        assert float(vals["fused_collapsed_ll"]) == sum(per_group.tolist())       # (left to right, like the C loop)
+        assert abs(float(vals["fused_collapsed_ll"]) - fx.meta["collapsed_ll"]) <= 1e-6 * abs(fx.meta["collapsed_ll"])
+        assert float(vals["fused_source_prior"]) == sum(per_object.tolist())
         if eng.gibbs_propose_supported():
             objs = np.arange(min(n, 5), dtype=np.int32)
             ids, sel, _back, touched, rows = eng.gibbs_propose(0, 1, objs, np.full((objs.size, f), 0.5))

@@ -155,6 +155,33 @@ def forms_case(rng, eng, feats, n_groups, conc, state, tag, stats):
             for a_, b_, what in zip(got_p, want_p, ("ids", "p[drawn]", "p_back[old]", "touched", "count rows")):
                 assert a_.shape == b_.shape and np.array_equal(a_, b_), (tag, "gibbs_propose", what)
             stats["gibbs_propose"] = stats.get("gibbs_propose", 0) + 1
+    # third session: likelihood + prior in one call = the two calls, bit for bit; a slot walked through cluster moves (ids,
+    # pattern / tuple tables followed on the host, per-pattern weights: one launch per sbe_set_groups) = a slot set at once
+    pg, po = eng.collapsed_and_source_prior(0)
+    assert np.array_equal(pg, eng.collapsed_loglik_all(0)) and np.array_equal(po, eng.source_prior(0), equal_nan=True), (tag, "collapsed_and_source_prior")
+    walk = groups[0].copy()
+    eng.copy_slot(s1, 0)
+    try:
+        for step in range(4):
+            for n in rng.choice(N, size=min(N, int(rng.choice([1, 1, 2, max(1, N // 3)]))), replace=False):
+                walk[:, n] = False
+                k = int(rng.integers(0, K + 1))
+                if k < K:
+                    walk[k, n] = True
+            eng.set_groups(0, 0, walk)
+            eng.set_groups(s1, 0, walk)
+            if C > 1:
+                eng.set_groups(s1, 1, groups[1])        # (another component's ids: s1's tables are derived from all N)
+            with np.errstate(divide="ignore"):
+                a_, b_ = eng.source_prior(0), eng.source_prior(s1)
+            assert np.array_equal(a_, b_, equal_nan=True), (tag, "set_groups walk: source_prior", step)
+            assert eng.mixture_loglik(0) == eng.mixture_loglik(s1) or (np.isnan(eng.mixture_loglik(0)) and np.isnan(eng.mixture_loglik(s1))), (tag, "set_groups walk: mixture", step)
+            assert np.array_equal(eng.weights_normalized(0), eng.weights_normalized(s1), equal_nan=True), (tag, "set_groups walk: weights", step)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                want_w = orc.normalize_weights(weights, orc.has_components([walk] + list(groups[1:])))
+            assert np.array_equal(eng.weights_normalized(0), want_w, equal_nan=True), (tag, "set_groups walk: weights vs oracle", step)
+    finally:
+        eng.set_groups(0, 0, groups[0])
     stats["forms"] = stats.get("forms", 0) + 1
 
 
