@@ -343,6 +343,7 @@ def secondary_figures(eng, wl, B, args):
         "floor_1000_blocks": us(lambda: lib.sbe_test_roundtrip(h, 1000, 3)),
         "source_prior": us(lambda: eng.source_prior(0)),
         "collapsed_loglik_all": us(lambda: eng.collapsed_loglik_all(0)),
+        "collapsed_and_source_prior": us(lambda: eng.collapsed_and_source_prior(0)),
         "cluster_posterior_marginals": us(lambda: eng.cluster_posterior_marginals(0, 0, available, 1.0, 1.0)),
         "jump_lh_resident": us(lambda: eng.jump_lh_resident(0, 0, 1 % wl.clusters.shape[0], members, 1.0, 1.0)) if members.size else None,
         "given_unchanged_lh_12_objects": us(lambda: eng.given_unchanged_lh(0, 0, few, 1.0, 1.0)),

@@ -51,7 +51,8 @@ typedef struct sbe_engine sbe_engine;
 
 #define SBE_ABI_VERSION 5   /* 4 (round 4): + sbe_given_unchanged_gibbs, sbe_host_*; sbe_set_groups rejects overlap;
                                5: + SBE_OPT_FUSE_TABLES, sbe_host_subset_ids, sbe_host_diff_rows, sbe_set_counts_rows_probs,
-                               sbe_gibbs_propose, sbe_given_unchanged_gibbs_counts, sbe_test_roundtrip */
+                               sbe_gibbs_propose, sbe_given_unchanged_gibbs_counts, sbe_test_roundtrip,
+                               sbe_collapsed_and_source_prior */
 
 /* error codes */
 #define SBE_OK 0
@@ -165,7 +166,10 @@ int sbe_likelihood_per_component_exact(sbe_engine* e, int slot, double* out);
  * (likelihood.py:126-130), and no single id follows both.  The stateless sbe_effect_counts
  * and sbe_component_lh accept overlap and follow the reference.  The cluster matrices of
  * sbe_step / sbe_step_batch are checked the same way (a batch reports the chain).
- * Also refreshes has_components (state.py:353-376). */
+ * Also refreshes has_components (state.py:353-376): the ids, the has_components pattern of every object, the group-tuple
+ * tables and -- when the slot has weights -- the per-pattern normalised weights (likelihood.py:171-190) go up and are
+ * computed in ONE asynchronous launch; after a cluster move the host-side tables follow the moved objects.  More
+ * distinct patterns than the engine holds (min(2^C, 64)) is reported by the next call that reads them. */
 int sbe_set_groups(sbe_engine* e, int slot, int component, const uint8_t* groups /* [G_c][N] bool */);
 int sbe_set_group_ids(sbe_engine* e, int slot, int component, const int32_t* ids /* [N], -1 = none */);
 

@@ -49,6 +49,7 @@ def main():
         "roundtrip: 1000 blocks, read + store": (None, lambda: lib.sbe_test_roundtrip(h, 1000, 3)),
         "source_prior": (lambda: eng.source_prior(0), lambda: lib.sbe_source_prior(h, 0, _ptr(out_sp))),
         "collapsed_loglik_all": (lambda: eng.collapsed_loglik_all(0), lambda: lib.sbe_collapsed_loglik_all(h, 0, _ptr(out_cl))),
+        "collapsed_and_source_prior": (lambda: eng.collapsed_and_source_prior(0), None),
         "mixture_loglik": (lambda: eng.mixture_loglik(0), None),
         "source_lh_by_feature": (lambda: eng.source_lh_by_feature(0), None),
         f"cluster_posterior_marginals[{available.size}]": (
