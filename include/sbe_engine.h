@@ -52,7 +52,7 @@ typedef struct sbe_engine sbe_engine;
 #define SBE_ABI_VERSION 5   /* 4 (round 4): + sbe_given_unchanged_gibbs, sbe_host_*; sbe_set_groups rejects overlap;
                                5: + SBE_OPT_FUSE_TABLES, sbe_host_subset_ids, sbe_host_diff_rows, sbe_set_counts_rows_probs,
                                sbe_gibbs_propose, sbe_given_unchanged_gibbs_counts, sbe_test_roundtrip,
-                               sbe_collapsed_and_source_prior */
+                               sbe_collapsed_and_source_prior, sbe_counts_delta_apply */
 
 /* error codes */
 #define SBE_OK 0
@@ -389,6 +389,17 @@ int sbe_set_uniform_counts(sbe_engine* e, const double* unif_counts /* [F][S] */
 int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const int32_t* gid_old /* [C][n_subset] */,
                      const int32_t* gid_new, const uint8_t* src_old /* [n_subset][F] */, const uint8_t* src_new,
                      const int32_t* touched, int n_touched, float* out_diff /* [n_touched][F][S] */);
+/* sbe_counts_delta_apply: the same difference, and `slot` FOLLOWS it.  update_feature_counts (counts.py:55-95) adds the
+ * difference to the new sample's counts on the host; a slot that holds the counts the difference is added to -- the
+ * usual state inside an MCMC step -- takes it on the device (counts[touched rows] += difference; with update_probs != 0
+ * the probability rows of those groups are rebuilt, exactly sbe_set_counts_rows_probs' result), so the rows need not be
+ * sent back: inside the same launch for subsets of up to 256 objects, by one more kernel otherwise.  The touched
+ * components' counts (and, for update_probs, tables) must be resident (SBE_ERR_STATE); the caller vouches that the
+ * slot's rows of the touched groups are the counts the difference belongs to. */
+int sbe_counts_delta_apply(sbe_engine* e, int slot, int update_probs, const int32_t* objects, int n_subset,
+                           const int32_t* gid_old /* [C][n_subset] */, const int32_t* gid_new,
+                           const uint8_t* src_old /* [n_subset][F] */, const uint8_t* src_new, const int32_t* touched,
+                           int n_touched, float* out_diff /* [n_touched][F][S] */);
 int sbe_set_counts_rows(sbe_engine* e, int slot, const int32_t* group_idx, int n_rows, const float* rows /* [n_rows][F][S] */);
 /* sbe_set_counts_rows that also rebuilds the probability rows of the patched groups (normalize(counts + concentration),
  * sbe_update_probs' untempered arithmetic) in the same launch: after it the slot's tables of those components are current

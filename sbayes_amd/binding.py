@@ -277,6 +277,46 @@ def _bind_slot(eng, model, sample, slot, with_source=False):
     return new["stale"]
 
 
+def counts_follow_plan(eng, sample, names, slot=0):
+    """update_feature_counts (counts.py:55-95) is about to add a difference to `sample.feature_counts` on the host.  When
+    engine slot `slot` holds exactly those counts -- the bind entry's token of every component is the parameter's current
+    (array, version): the usual state inside an MCMC step, the slot was bound to the sample this one was copied from -- the
+    device can take the difference in the call that computes it (Engine.counts_delta(follow_slot=...)) and the rows need
+    not be sent back by the next bind.  Returns (entry, mirrors, stale components) or None."""
+    bound = getattr(eng, "_bound", None)
+    entry = bound.get(slot) if bound is not None else None
+    mirrors = eng._mirror.get(slot) if entry is not None and hasattr(eng, "_mirror") else None
+    if entry is None or mirrors is None:
+        return None
+    counts = sample.feature_counts
+    for c, name in enumerate(names):
+        cached = entry["counts"][c]
+        if cached is None or mirrors["counts"][c] is None or not _same(_token(counts[name]), cached):
+            return None
+    return entry, mirrors, entry["stale"]
+
+
+def counts_followed(eng, plan, sample, names, touched, bounds, probs_rebuilt, slot=0):
+    """After that call and the host's own add_changes: the slot's entry (dropped by the engine method) comes back with the
+    touched components' tokens and mirror rows brought to the sample's new counts; components whose probability rows were
+    not rebuilt by the call join the stale set."""
+    entry, mirrors, _ = plan
+    counts = sample.feature_counts
+    off = eng.group_offsets
+    for c, name in enumerate(names):
+        lo, hi = bounds[c], bounds[c + 1]
+        if hi > lo:
+            node = counts[name]
+            local = touched[lo:hi] - off[c]
+            mirrors["counts"][c][local] = node.value[local]
+            entry["counts"][c] = _remember(_token(node))
+            if not probs_rebuilt:
+                entry["stale"].add(c)
+    entry["lh_all"] = None
+    eng._bound[slot] = entry
+    eng._mirror[slot] = mirrors
+
+
 def recount_bound(eng, sample, slot=0):
     """recalculate_feature_counts (counts.py:35-52) from RESIDENT data: bind the sample's groups and source (deltas
     only), recount every component on the device, fetch the tables.  The slot's bind entry survives: its count

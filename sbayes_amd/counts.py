@@ -7,6 +7,8 @@ Same names, arguments and return conventions as the reference functions:
 The counting itself is the HIP histogram kernel behind sbe_effect_counts."""
 from __future__ import annotations
 
+import weakref
+
 import numpy as np
 
 from . import _fast, _lib
@@ -57,6 +59,28 @@ def _subset_indices(object_subset, n_objects):
 
 
 _addr = _fast.addr
+
+FOLLOW_COUNTS = True        # update_feature_counts: the bound slot takes the difference on the device (binding.counts_follow_plan)
+
+# A performance hint, never a correctness matter: ClusterJump evaluates new -> OLD -> new after its update_feature_counts
+# (forward resampling, then the backward proposal on the old state, operators.py:1724-1790), so a slot that followed the
+# difference would be sent the old rows again and then the new ones.  operators.jump_lh notes the sample it was asked about
+# (the step's old state); update_feature_counts from that sample leaves the slot alone; Likelihood.__call__ (the end of
+# every step) forgets the note.
+_no_follow_from = None
+
+
+def note_jump_state(sample):
+    global _no_follow_from
+    try:
+        _no_follow_from = weakref.ref(sample)
+    except TypeError:
+        _no_follow_from = None
+
+
+def forget_jump_state():
+    global _no_follow_from
+    _no_follow_from = None
 
 
 def _group_ids(groups, objs, offset, out):
@@ -110,11 +134,22 @@ def update_feature_counts(sample_old, sample_new, features, object_subset):
             new = compute_effect_counts(features, groups_new[i], sample_new.source.value[..., i], object_subset)
             counts[name].add_changes(diff=new - old)
         return counts
-    touched, rows = eng.counts_delta(objs, *ids)
-    return apply_count_rows(counts, names, off, touched, rows)
+    # a slot that holds the counts this difference is added to follows on the device, in the same call (binding.counts_follow_plan)
+    from .binding import counts_follow_plan, counts_followed
+    hold = _no_follow_from is not None and _no_follow_from() is sample_old
+    plan = counts_follow_plan(eng, sample_new, names) if FOLLOW_COUNTS and not hold else None
+    if plan is None:
+        touched, rows = eng.counts_delta(objs, *ids)
+        return apply_count_rows(counts, names, off, touched, rows)
+    # (the probability rows are rebuilt along when no table of the slot is stale: the touched components are not known yet)
+    rebuild = not plan[2]
+    touched, rows = eng.counts_delta(objs, *ids, follow_slot=0, update_probs=rebuild)
+    bounds = apply_count_rows(counts, names, off, touched, rows, return_bounds=True)
+    counts_followed(eng, plan, sample_new, names, touched, bounds, rebuild)
+    return counts
 
 
-def apply_count_rows(counts, names, off, touched, rows):
+def apply_count_rows(counts, names, off, touched, rows, return_bounds=False):
     """The reference's `add_changes(diff)` per component (counts.py:77, :93) for a difference given as the rows of the global
     group indices `touched` (ascending; every other row is zero): in its row form (FeatureCounts.add_changes_rows: patch.install
     / sbayes_amd.state) where the sample's class has one, else through a dense diff."""
@@ -130,4 +165,4 @@ def apply_count_rows(counts, names, off, touched, rows):
         if hi > lo:
             diff[touched[lo:hi] - off[c]] = rows[lo:hi]
         node.add_changes(diff=diff)
-    return counts
+    return bounds if return_bounds else counts

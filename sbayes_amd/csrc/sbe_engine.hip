@@ -2614,8 +2614,12 @@ int sbe_set_uniform_counts(sbe_engine* e, const double* unif_counts) {
     return SBE_OK;
 }
 
-int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const int32_t* gid_old, const int32_t* gid_new,
-                     const uint8_t* src_old, const uint8_t* src_new, const int32_t* touched, int n_touched, float* out_diff) {
+// `follow_slot` >= 0 (sbe_counts_delta_apply): the slot's resident counts -- the OLD state's -- take the difference, and with
+// `follow_probs` the probability rows of the touched groups are rebuilt: inside the tile kernel (the usual case), by one
+// more kernel behind the general one.
+static int counts_delta_impl(sbe_engine* e, int follow_slot, int follow_probs, const int32_t* objects, int n_subset, const int32_t* gid_old,
+                             const int32_t* gid_new, const uint8_t* src_old, const uint8_t* src_new, const int32_t* touched, int n_touched,
+                             float* out_diff) {
     CHECK_ENGINE(e);
     if (n_subset < 0 || n_touched < 0) return fail(e, SBE_ERR_ARG, "n_subset=%d n_touched=%d", n_subset, n_touched);
     if (n_touched == 0) return SBE_OK;
@@ -2636,7 +2640,24 @@ int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const 
     for (int64_t i = 0; i < (int64_t)C * n_subset; ++i)
         if (gid_old[i] < -1 || gid_old[i] >= e->Gtot || gid_new[i] < -1 || gid_new[i] >= e->Gtot)
             return fail(e, SBE_ERR_ARG, "group index out of range in the subset's ids");
+    DeltaFollow follow{};
+    if (follow_slot >= 0) {
+        const Slot& sl = e->slots[follow_slot];
+        for (int t = 0; t < n_touched; ++t) {
+            if (!sl.counts_set[comp[t]])
+                return fail(e, SBE_ERR_STATE, "slot %d: counts of component %d not set (sbe_counts_delta_apply adds to resident tables)", follow_slot, comp[t]);
+            if (follow_probs && (!sl.probs_set[comp[t]] || !e->conc_set[comp[t]]))
+                return fail(e, SBE_ERR_STATE, "slot %d: probability tables / concentration of component %d not set (update_probs = 1 rebuilds "
+                            "the rows of tables that exist: sbe_update_probs first)", follow_slot, comp[t]);
+        }
+        follow.counts = e->d_counts + (int64_t)follow_slot * e->table_elems();
+        if (follow_probs) {
+            follow.conc = e->d_conc; follow.probs = e->d_probs + (int64_t)follow_slot * e->table_elems();
+            follow.probs_t = e->d_probs_t + (int64_t)follow_slot * e->probs_t_elems(); follow.status = e->d_status; follow.ft = e->ft;
+        }
+    }
     HIPCHK(e, hipSetDevice(e->device));
+    if (follow.probs) { rc = clear_status_word(e, ST_BAD_NORMALIZE); if (rc) return rc; }
     // inputs (a few KB) in host-mapped memory, read by the kernel in place; the diff rows come back the same way when
     // they are small, through the staging copy otherwise
     const size_t ob = al256((size_t)n_subset * 4), gb = al256((size_t)C * n_subset * 4), sb = al256((size_t)n_subset * F);
@@ -2655,7 +2676,7 @@ int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const 
     const size_t o_tc = o;   memcpy(h + o, comp.data(), (size_t)n_touched * 4); o += tb;
     // small subsets (the usual update_feature_counts: a few dozen objects): one launch, a block per 16-feature tile stages
     // what it needs of the mapped block into LDS in one PCIe round trip and serves every touched group (k_counts_delta_tile)
-    const size_t tile_lds = ((size_t)n_touched * kDeltaFT * S + (size_t)e->Gtot + (size_t)n_subset * (1 + 2 * C)) * sizeof(int32_t) +
+    const size_t tile_lds = ((size_t)n_touched * kDeltaFT * S + (size_t)e->Gtot + (size_t)n_touched + (size_t)n_subset * (1 + 2 * C)) * sizeof(int32_t) +
                             (size_t)2 * n_subset * kDeltaFT;
     if (mapped_out && n_subset <= kDeltaTileMaxN && tile_lds <= ((size_t)64 << 10) && e->opt_fuse_tables) {
         const uint8_t* din = e->d_io;
@@ -2664,32 +2685,56 @@ int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const 
         const DoneSig done = next_done(e, blocks);
         k_counts_delta_tile<<<blocks, kBlock, tile_lds, e->stream>>>(
             e->d_state, (const int32_t*)(din + o_obj), n_subset, (const int32_t*)(din + o_go), (const int32_t*)(din + o_gn),
-            din + o_so, din + o_sn, (const int32_t*)(din + o_t), n_touched, d_out, F, S, e->Fp, C, e->Gtot, done);
+            din + o_so, din + o_sn, (const int32_t*)(din + o_t), n_touched, d_out, F, S, e->Fp, C, e->Gtot, done, follow);
         HIPCHK(e, hipGetLastError());
-        rc = wait_done(e, done);
+        rc = wait_done(e, done);                             // (the difference is complete; the slot follows behind the flag)
+        if (!rc) rc = synced(e);
         if (rc) return rc;
         memcpy(out_diff, h + o, out_bytes);
-        return synced(e);
+        // the rebuilt rows may raise normalize's data check after the flag: reported like a setter's (deferred mode: by the
+        // next call that waits for the device)
+        return follow.probs ? check_after(e, ST_BAD_NORMALIZE, "sbe_counts_delta_apply") : SBE_OK;
     }
     // larger subsets: the kernel walks the listed objects one after another (ids, then the object's rows): out of
     // host-mapped memory every step of that walk would be a PCIe round trip, so the packed inputs go to device memory with
     // ONE copy from the pinned block; the diff rows come back through the mapped block (posted writes)
     const size_t in_bytes = o;
-    rc = ensure_scratch(e, in_bytes + (mapped_out ? 0 : out_bytes));
+    const bool out_in_block = mapped_out && !follow.counts;     // (a following slot reads the rows after the call has returned: device memory)
+    rc = ensure_scratch(e, in_bytes + (out_in_block ? 0 : out_bytes));
     if (rc) return rc;
     HIPCHK(e, hipMemcpyAsync(e->d_scratch, h, in_bytes, hipMemcpyHostToDevice, e->stream));
     const uint8_t* din = e->d_scratch;
-    float* d_out = mapped_out ? (float*)(e->d_io + o) : (float*)(e->d_scratch + in_bytes);
-    const DoneSig done = mapped_out ? next_done(e, (unsigned)(n_touched * div_up(F, kDeltaFT))) : DoneSig{};
+    float* d_out = out_in_block ? (float*)(e->d_io + o) : (float*)(e->d_scratch + in_bytes);
+    const DoneSig done = out_in_block ? next_done(e, (unsigned)(n_touched * div_up(F, kDeltaFT))) : DoneSig{};
     k_counts_delta<<<dim3(n_touched, div_up(F, kDeltaFT)), kBlock, (size_t)kDeltaFT * S * sizeof(int32_t), e->stream>>>(
         e->d_state, (const int32_t*)(din + o_obj), n_subset, (const int32_t*)(din + o_go), (const int32_t*)(din + o_gn),
         din + o_so, din + o_sn, (const int32_t*)(din + o_t), (const int32_t*)(din + o_tc), d_out, F, S, e->Fp, done);
     HIPCHK(e, hipGetLastError());
-    if (!mapped_out) return d2h(e, out_diff, d_out, out_bytes);
+    if (follow.counts) {
+        k_add_count_rows<<<div_up((int64_t)n_touched * F, 256), 256, 0, e->stream>>>(d_out, (const int32_t*)(din + o_t), n_touched, F, S, e->Gtot, follow);
+        HIPCHK(e, hipGetLastError());
+    }
+    if (!out_in_block) {
+        rc = d2h(e, out_diff, d_out, out_bytes);
+        if (rc || !follow.probs) return rc;
+        return sync_and_report(e);
+    }
     rc = wait_done(e, done);
     if (rc) return rc;
     memcpy(out_diff, h + o, out_bytes);
     return synced(e);
+}
+
+int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const int32_t* gid_old, const int32_t* gid_new,
+                     const uint8_t* src_old, const uint8_t* src_new, const int32_t* touched, int n_touched, float* out_diff) {
+    return counts_delta_impl(e, -1, 0, objects, n_subset, gid_old, gid_new, src_old, src_new, touched, n_touched, out_diff);
+}
+
+int sbe_counts_delta_apply(sbe_engine* e, int slot, int update_probs, const int32_t* objects, int n_subset, const int32_t* gid_old,
+                           const int32_t* gid_new, const uint8_t* src_old, const uint8_t* src_new, const int32_t* touched, int n_touched,
+                           float* out_diff) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot);
+    return counts_delta_impl(e, slot, update_probs, objects, n_subset, gid_old, gid_new, src_old, src_new, touched, n_touched, out_diff);
 }
 
 static int set_counts_rows_impl(sbe_engine* e, int slot, const int32_t* group_idx, int n_rows, const float* rows, bool with_probs) {

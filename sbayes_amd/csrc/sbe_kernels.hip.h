@@ -2273,16 +2273,21 @@ __global__ __launch_bounds__(kBlock) void k_counts_delta(
 // takes one off its old group of c (counts.py:55-95: new counts - old counts over the subset, group by group).
 // LDS: hist [T][16][S] | pos [Gtot] (touched index of a group, -1) | objects [n] | gid_old, gid_new [C][n] | src_old, src_new [n][16].
 constexpr int kDeltaTileMaxN = 256;
+// `follow` (sbe_counts_delta_apply): a slot whose resident counts are the OLD state's takes the difference in the same launch
+// -- counts[touched rows] += delta, and (probs != nullptr) the probability rows of those groups rebuilt (update_probs'
+// arithmetic, k_set_count_rows_probs_x's row form) -- so that the host does not send back the rows it has just received.
+struct DeltaFollow { int32_t* counts; const double* conc; float* probs; float* probs_t; int* status; int ft; };
 __global__ __launch_bounds__(kBlock) void k_counts_delta_tile(
     const uint8_t* __restrict__ state, const int32_t* __restrict__ objects, int n, const int32_t* __restrict__ gid_old,
     const int32_t* __restrict__ gid_new, const uint8_t* __restrict__ src_old, const uint8_t* __restrict__ src_new,
     const int32_t* __restrict__ touched, int n_touched, float* __restrict__ out /* [T][F][S] */, int F, int S, int Fp, int C,
-    int Gtot, DoneSig done) {
+    int Gtot, DoneSig done, DeltaFollow follow = DeltaFollow{}) {
     constexpr int FTU = kDeltaFT, OL = kBlock / FTU;
     extern __shared__ int32_t dl[];
     int32_t* hist = dl;                                  // [T][FTU][S]
     int32_t* pos = hist + n_touched * FTU * S;           // [Gtot]
-    int32_t* obj = pos + Gtot;                           // [n]
+    int32_t* tgl = pos + Gtot;                           // [T] the touched groups
+    int32_t* obj = tgl + n_touched;                      // [n]
     int32_t* go = obj + n;                               // [C][n]
     int32_t* gn = go + C * n;                            // [C][n]
     uint8_t* so = reinterpret_cast<uint8_t*>(gn + C * n);            // [n][FTU]
@@ -2339,8 +2344,8 @@ __global__ __launch_bounds__(kBlock) void k_counts_delta_tile(
             if (widx[k] < n * 4) { reinterpret_cast<uint32_t*>(so)[widx[k]] = w_so[k]; reinterpret_cast<uint32_t*>(sn)[widx[k]] = w_sn[k]; }
     }
     __syncthreads();
-    if (v_touched >= 0) pos[v_touched] = threadIdx.x;
-    for (int t = threadIdx.x + kBlock; t < n_touched; t += kBlock) pos[touched[t]] = t;          // (more than 256 touched groups)
+    if (v_touched >= 0) { pos[v_touched] = threadIdx.x; tgl[threadIdx.x] = v_touched; }
+    for (int t = threadIdx.x + kBlock; t < n_touched; t += kBlock) { const int g = touched[t]; pos[g] = t; tgl[t] = g; }   // (more than 256 touched groups)
     __syncthreads();
     const int fl = threadIdx.x & (FTU - 1), ol = threadIdx.x / FTU;
     const int f = f0 + fl;
@@ -2364,7 +2369,71 @@ __global__ __launch_bounds__(kBlock) void k_counts_delta_tile(
         const int t = e / (FTU * S), r = e % (FTU * S), ff = f0 + r / S;
         if (ff < F) out[((int64_t)t * F + ff) * S + r % S] = (float)hist[e];
     }
+    // the caller waits for the difference only: the flag goes out before the following slot is brought up to date (the
+    // next operation of the stream is ordered behind this kernel's end anyway; nothing below reads the mapped block)
     signal_done(done);
+    if (follow.counts) {                                 // (this block owns its 16 features of every touched group)
+        auto rows_by_lane_groups = [&](auto width) {
+            constexpr int W = decltype(width)::value;
+            for (int row0 = 0; row0 < n_touched * FTU; row0 += kBlock / W) {
+                const int row = row0 + (int)threadIdx.x / W, j = threadIdx.x & (W - 1);
+                const int tt = row / FTU, tf = row % FTU, ff = f0 + tf;
+                const bool row_on = row < n_touched * FTU && ff < F;
+                const int g = row_on ? tgl[tt] : 0;
+                const int64_t at = row_on ? ((int64_t)g * F + ff) * S : 0;
+                float cj = 0.0f;
+                if (row_on && j < S) {
+                    const int32_t v = follow.counts[at + j] + hist[(tt * FTU + tf) * S + j];
+                    follow.counts[at + j] = v;
+                    cj = (float)v;
+                }
+                if (follow.probs) {
+                    float* out_row = follow.probs + at;
+                    float* out_t = follow.probs_t + (((int64_t)(ff / follow.ft) * (Gtot + 1) + g) * S) * follow.ft + ff % follow.ft;   // (k_probs' tile layout)
+                    probs_row_x16<W>(j, row_on, [&](int) { return cj; }, follow.conc + at, nullptr, S, 0.0, 0.0, follow.status,
+                                     [&](int s, float v) { out_row[s] = v; out_t[(int64_t)s * follow.ft] = v; });
+                }
+            }
+        };
+        if (S <= 8) rows_by_lane_groups(std::integral_constant<int, 8>{});
+        else if (S <= 16) rows_by_lane_groups(std::integral_constant<int, 16>{});
+        else {
+            for (int t = threadIdx.x; t < n_touched * FTU; t += kBlock) {
+                const int tt = t / FTU, tf = t % FTU, ff = f0 + tf;
+                if (ff >= F) continue;
+                const int g = tgl[tt];
+                const int64_t at = ((int64_t)g * F + ff) * S;
+                const int32_t* h = hist + (tt * FTU + tf) * S;
+                for (int k = 0; k < S; ++k) follow.counts[at + k] += h[k];
+                if (follow.probs) {
+                    float* out_row = follow.probs + at;
+                    float* out_t = follow.probs_t + (((int64_t)(ff / follow.ft) * (Gtot + 1) + g) * S) * follow.ft + ff % follow.ft;
+                    probs_row([&](int k) { return (float)follow.counts[at + k]; }, follow.conc + at, nullptr, S, 0.0, 0.0, follow.status,
+                              [&](int k, float v) { out_row[k] = v; out_t[(int64_t)k * follow.ft] = v; });
+                }
+            }
+        }
+    }
+}
+
+// The following slot of sbe_counts_delta_apply behind the GENERAL difference kernel (subsets beyond the tile form): the
+// difference rows [T][F][S] (device memory) are added to the slot's counts, the probability rows rebuilt.  One thread per
+// (touched group, feature); rare path.
+__global__ void k_add_count_rows(const float* __restrict__ diff /* [T][F][S] */, const int32_t* __restrict__ touched, int n_touched,
+                                 int F, int S, int Gtot, DeltaFollow follow) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n_touched * F) return;
+    const int i = (int)(t / F), f = (int)(t % F);
+    const int g = touched[i];
+    const int64_t at = ((int64_t)g * F + f) * S;
+    const float* d = diff + t * S;
+    for (int k = 0; k < S; ++k) follow.counts[at + k] += (int32_t)d[k];
+    if (follow.probs) {
+        float* out_row = follow.probs + at;
+        float* out_t = follow.probs_t + (((int64_t)(f / follow.ft) * (Gtot + 1) + g) * S) * follow.ft + f % follow.ft;   // (k_probs' tile layout)
+        probs_row([&](int k) { return (float)follow.counts[at + k]; }, follow.conc + at, nullptr, S, 0.0, 0.0, follow.status,
+                  [&](int k, float v) { out_row[k] = v; out_t[(int64_t)k * follow.ft] = v; });
+    }
 }
 
 // float32 count rows of listed groups -> the slot's resident int32 counts (Engine.set_counts_rows: the bind cache

@@ -18,7 +18,7 @@ from types import SimpleNamespace
 
 import numpy as np
 
-from .counts import recalculate_feature_counts
+from .counts import forget_jump_state, recalculate_feature_counts
 from . import registry
 from .binding import _bind_slot
 from .engine import GroupOverlapError
@@ -114,6 +114,7 @@ class Likelihood:
         # one bind and one fetch per call: the components are asked one after another (likelihood.py:58-63) for the SAME
         # sample, so the per-group values of all of them are taken once (_group_logliks) and kept for the rest of the call
         self._call_memo = [sample, None, caching]
+        forget_jump_state()                  # (counts.py: a hint that lives for one MCMC step)
         try:
             log_lh = 0.0
             log_lh += self.compute_lh_clusters(sample, caching=caching)

@@ -23,7 +23,7 @@ import numpy as np
 
 from . import _fast
 from .binding import _bind_slot, _bind_uniform, _engine, _tables_current
-from .counts import _source_ids, apply_count_rows, update_feature_counts
+from .counts import _source_ids, apply_count_rows, note_jump_state, update_feature_counts
 
 EPS = np.finfo(np.float32).eps        # sbayes/util.py:34
 
@@ -285,6 +285,7 @@ def jump_lh(model, sample, i_source_cluster, i_target_cluster, temperature=1.0, 
     per-member sums of logs come from the device -- no [N, F, C] weight array, no [N, F, S] expected-feature array on
     the host; the O(n_members) tail (exponent 1/T, + EPS, ratio) is the reference's float32 arithmetic."""
     eng = _engine(model)
+    note_jump_state(sample)            # (counts.py: the jump's update_feature_counts leaves the slot's counts alone)
     _bind_slot(eng, model, sample, slot)
     _bind_uniform(eng, model)          # the reference uses the CLUSTER prior's uniform concentration for every component
     members = np.flatnonzero(sample.clusters.value[i_source_cluster])                               # (operators.py:1352)

@@ -290,10 +290,13 @@ class FakeEngine:
         self.calls.append(("set_source_rows", len(objects)))
         self._slot(slot)["source"][np.asarray(objects)] = np.asarray(rows, dtype=bool)
 
-    def counts_delta(self, objects, gid_old, gid_new, src_old, src_new):
+    def counts_delta(self, objects, gid_old, gid_new, src_old, src_new, follow_slot=None, update_probs=False):
         """(touched, diff rows) of update_feature_counts for the listed objects: the oracle's a9 on one-object
-        group matrices rebuilt from the ids."""
+        group matrices rebuilt from the ids.  follow_slot: that slot's counts take the difference (tables are derived on
+        demand here, so update_probs has nothing to do)."""
         self.calls.append(("counts_delta", len(objects)))
+        if follow_slot is not None:
+            self._touch(follow_slot)
         objects = np.asarray(objects)
         gid_old, gid_new = np.asarray(gid_old), np.asarray(gid_new)
         src_old, src_new = np.asarray(src_old), np.asarray(src_new)
@@ -307,6 +310,8 @@ class FakeEngine:
                 members = gid[c] == gg
                 if members.any():
                     diff[t] += sign * np.count_nonzero((src[members] == c)[:, :, None] & feats[members], axis=0)
+            if follow_slot is not None:
+                self._slot(follow_slot)["counts"][c][gg - off[c]] += diff[t]
         return touched, diff
 
     def _full_state(self, slot):

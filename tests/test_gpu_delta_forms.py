@@ -46,7 +46,7 @@ def _workload(name):
 def _pair(name):
     feats, groups, conc, weights, source, counts, unif = _workload(name)
     n_groups = [g.shape[0] for g in groups]
-    eng, fake = Engine(feats, n_groups, n_slots=2), FakeEngine(feats, n_groups)
+    eng, fake = Engine(feats, n_groups, n_slots=3), FakeEngine(feats, n_groups)
     for e in (eng, fake):
         for c in range(len(groups)):
             e.set_concentration(c, conc[c])
@@ -101,6 +101,26 @@ def test_counts_delta_and_row_uploads(name):
                 mine = (touched >= off[c]) & (touched < off[c + 1])
                 full[touched[mine] - off[c]] = diff[mine]
                 assert np.array_equal(full, ref), (name, n, c)
+            # ... and a slot that holds the old counts FOLLOWS (sbe_counts_delta_apply): counts += difference, the probability
+            # rows of the touched groups rebuilt -- what set_counts_rows(update_probs=True) with the new rows leaves, bit for
+            # bit; inside the tile kernel (n <= 256) and behind the general one
+            eng.copy_slot(1, 0)
+            eng.copy_slot(2, 0)
+            t2, d2 = eng.counts_delta(objs, gid_old, gid_new, so, sn, follow_slot=1, update_probs=True)
+            assert np.array_equal(t2, touched) and np.array_equal(d2, diff), (name, n, "difference with a following slot")
+            comp_of = np.searchsorted(off, touched, side="right") - 1
+            new_rows = np.stack([counts[c][g - off[c]] for g, c in zip(touched, comp_of)]) + diff
+            assert (new_rows >= 0).all()
+            eng.set_counts_rows(2, touched, new_rows, update_probs=True)
+            for c in range(C):
+                assert np.array_equal(eng.get_counts(1, c), eng.get_counts(2, c)), (name, n, c, "following counts")
+                assert np.array_equal(eng.get_probs(1, c), eng.get_probs(2, c)), (name, n, c, "following probability rows")
+            assert eng.mixture_loglik(1) == eng.mixture_loglik(2), (name, n)            # (the tile-transposed copies too)
+            eng.copy_slot(1, 0)
+            eng.counts_delta(objs, gid_old, gid_new, so, sn, follow_slot=1)              # counts only: the tables stay
+            for c in range(C):
+                assert np.array_equal(eng.get_counts(1, c), eng.get_counts(2, c)), (name, n, c, "following counts, no tables")
+                assert np.array_equal(eng.get_probs(1, c), eng.get_probs(0, c)), (name, n, c)
         # delta upload of count rows: only the listed groups change
         for c in range(C):
             g = int(rng.integers(0, groups[c].shape[0]))
@@ -394,6 +414,17 @@ def test_argument_checks():
         touched, diff = eng.counts_delta(np.zeros(0, dtype=np.int32), np.zeros((len(groups), 0)), np.zeros((len(groups), 0)),
                                          np.zeros((0, source.shape[1])), np.zeros((0, source.shape[1])))
         assert touched.size == 0 and diff.shape[0] == 0
+        # a following slot must hold the tables the difference is added to (slot 2 was never set)
+        C, F = len(groups), source.shape[1]
+        ids = np.full((C, 1), -1, dtype=np.int32)
+        ids[0, 0] = 0
+        src = np.zeros((1, F), dtype=np.uint8)
+        with pytest.raises(Exception, match="counts of component 0 not set"):
+            eng.counts_delta([0], ids, ids, src, src, follow_slot=2)
+        eng.set_counts(2, 0, counts[0])                                   # (counts, but no probability tables yet)
+        with pytest.raises(Exception, match="sbe_update_probs first"):
+            eng.counts_delta([0], ids, ids, src, src, follow_slot=2, update_probs=True)
+        eng.counts_delta([0], ids, ids, src, src, follow_slot=2)
     finally:
         eng.close()
 

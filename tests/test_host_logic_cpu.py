@@ -344,3 +344,70 @@ def test_sample_with_lazy_normalized_weights_pickles_and_copies(fake):
     assert np.array_equal(rows, want[[1, 3, 4]])
     sample.weights.set_value(sample.weights.value[:, ::-1].copy())
     assert w.sample_if_current() is None                                              # no longer that sample's weights
+
+
+def test_update_feature_counts_lets_the_bound_slot_follow(fake):
+    """update_feature_counts (counts.py:55-95) on a sample whose counts the engine slot holds: the device takes the difference
+    in the call that computes it (counts_delta(follow_slot=0)) and the next bind sends no count rows; the jump operator's
+    note, or a slot bound to other counts, leaves the slot alone and the rows go up with the next bind.  Either way the
+    double's slot ends with the candidate's counts."""
+    import sbayes_amd.counts as counts_mod
+    fx = load_npz("cfg1")
+    model, sample = build(fx)
+    feats = model.data.features.values
+    recalculate_feature_counts(feats, sample)
+    model.likelihood(sample, caching=True)                    # binds slot 0 to `sample`
+    eng = next(iter(fake.values()))
+
+    def candidate(obj):
+        cand = sample.copy()
+        k_old = int(np.argmax(sample.clusters.value[:, obj])) if sample.clusters.value[:, obj].any() else -1
+        k_new = (k_old + 1) % sample.clusters.value.shape[0]
+        if k_old >= 0:
+            with cand.clusters.edit_cluster(k_old) as row:
+                row[obj] = False
+        with cand.clusters.edit_cluster(k_new) as row:
+            row[obj] = True
+        return cand
+
+    def slot_counts():
+        return [np.array(eng._slot(0)["counts"][c]) for c in range(fx.n_comp)]
+
+    from sbayes_amd.binding import _bind_slot
+    names = list(sample.feature_counts)
+    src_cluster = sample.source.value[..., 0].any(axis=1) & sample.clusters.value.any(axis=0)
+    o1, o2, o3 = np.flatnonzero(src_cluster)[:3]              # members of a cluster with observations explained by it
+    # 1. the slot holds the sample's counts: it follows, the bind that comes next has nothing to send
+    cand = candidate(o1)
+    eng.calls.clear()
+    update_feature_counts(sample, cand, feats, np.array([o1]))
+    assert [c[0] for c in eng.calls] == ["counts_delta"]
+    assert any(not np.array_equal(cand.feature_counts[n].value, sample.feature_counts[n].value) for n in names)
+    _bind_slot(eng, model, cand, 0)
+    kinds = [c[0] for c in eng.calls]
+    assert "set_counts_rows" not in kinds and "set_counts" not in kinds, kinds
+    for c, name in enumerate(names):
+        assert np.array_equal(slot_counts()[c], cand.feature_counts[name].value)
+    # 2. the jump operator's note: the slot is left alone, the rows go up with the next bind
+    _bind_slot(eng, model, sample, 0)                         # back to `sample` (a rejected step)
+    cand = candidate(o2)
+    counts_mod.note_jump_state(sample)
+    eng.calls.clear()
+    before = slot_counts()
+    update_feature_counts(sample, cand, feats, np.array([o2]))
+    assert all(np.array_equal(a, b) for a, b in zip(before, slot_counts()))
+    model.likelihood(cand, caching=True)                      # (binds; forgets the note)
+    assert "set_counts_rows" in [c[0] for c in eng.calls]
+    assert counts_mod._no_follow_from is None
+    for c, name in enumerate(names):
+        assert np.array_equal(slot_counts()[c], cand.feature_counts[name].value)
+    # 3. a slot that holds OTHER counts (still the candidate's) is not touched by an update of `sample`'s copy
+    cand2 = candidate(o3)
+    eng.calls.clear()
+    before = slot_counts()
+    update_feature_counts(sample, cand2, feats, np.array([o3]))
+    assert all(np.array_equal(a, b) for a, b in zip(before, slot_counts()))
+    _bind_slot(eng, model, cand2, 0)
+    assert "set_counts_rows" in [c[0] for c in eng.calls]
+    for c, name in enumerate(names):
+        assert np.array_equal(slot_counts()[c], cand2.feature_counts[name].value)

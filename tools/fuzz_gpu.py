@@ -117,6 +117,32 @@ def forms_case(rng, eng, feats, n_groups, conc, state, tag, stats):
     t_got, d_got = eng.counts_delta(objs, gid_old, gid_new, so, sn)
     t_want, d_want = fake.counts_delta(objs, gid_old, gid_new, so, sn)
     assert np.array_equal(t_got, t_want) and np.array_equal(d_got, d_want), (tag, "counts_delta")
+    # ... and a slot holding the old counts follows the difference (sbe_counts_delta_apply) = the rows patched the explicit way
+    if (counts[0] >= 0).all():
+        sa_, sb_ = eng.n_slots - 1, eng.n_slots - 2
+        eng.copy_slot(sa_, 0); eng.copy_slot(sb_, 0)
+        eng.update_probs(sa_, range(C)); eng.update_probs(sb_, range(C))
+        t_f, d_f = eng.counts_delta(objs, gid_old, gid_new, so, sn, follow_slot=sa_, update_probs=True)
+        assert np.array_equal(t_f, t_want) and np.array_equal(d_f, d_want), (tag, "counts_delta with a following slot")
+        comp_of = np.searchsorted(off, t_want, side="right") - 1
+        rows_f = np.stack([counts[c_][g_ - off[c_]] for g_, c_ in zip(t_want, comp_of)]) + d_want if t_want.size else np.zeros((0,) + counts[0].shape[1:], np.float32)
+        ok_rows = True
+        try:
+            eng.set_counts_rows(sb_, t_want, rows_f, update_probs=True)
+            eng.sync()
+        except Exception as exc:                      # (a row that normalises to nothing: both forms must say so)
+            ok_rows = False
+            assert "normali" in str(exc).lower(), (tag, exc)
+        if ok_rows:
+            for c_ in range(C):
+                assert np.array_equal(eng.get_counts(sa_, c_), eng.get_counts(sb_, c_)), (tag, "following counts", c_)
+                assert np.array_equal(eng.get_probs(sa_, c_), eng.get_probs(sb_, c_)), (tag, "following probability rows", c_)
+            stats["follow"] = stats.get("follow", 0) + 1
+        else:
+            try:
+                eng.sync()
+            except Exception:
+                pass
     members = np.flatnonzero(groups[0][i_cl]).astype(np.int32)
     if members.size and K >= 2:
         i_tg = (i_cl + 1) % K
