@@ -393,10 +393,12 @@ int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const 
  * difference to the new sample's counts on the host; a slot that holds the counts the difference is added to -- the
  * usual state inside an MCMC step -- takes it on the device (counts[touched rows] += difference; with update_probs != 0
  * the probability rows of those groups are rebuilt, exactly sbe_set_counts_rows_probs' result), so the rows need not be
- * sent back: inside the same launch for subsets of up to 256 objects, by one more kernel otherwise.  The touched
- * components' counts (and, for update_probs, tables) must be resident (SBE_ERR_STATE); the caller vouches that the
- * slot's rows of the touched groups are the counts the difference belongs to. */
-int sbe_counts_delta_apply(sbe_engine* e, int slot, int update_probs, const int32_t* objects, int n_subset,
+ * sent back: inside the same launch for subsets of up to 256 objects, by one more kernel otherwise.  With
+ * update_source != 0 the slot's source rows of the listed objects become src_new (the rows the operator has just drawn:
+ * they are in the call anyway).  The touched components' counts (and, for update_probs, tables; for update_source, a
+ * source) must be resident (SBE_ERR_STATE); the caller vouches that the slot's rows of the touched groups are the
+ * counts the difference belongs to. */
+int sbe_counts_delta_apply(sbe_engine* e, int slot, int update_probs, int update_source, const int32_t* objects, int n_subset,
                            const int32_t* gid_old /* [C][n_subset] */, const int32_t* gid_new,
                            const uint8_t* src_old /* [n_subset][F] */, const uint8_t* src_new, const int32_t* touched,
                            int n_touched, float* out_diff /* [n_touched][F][S] */);

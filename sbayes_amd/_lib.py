@@ -102,7 +102,7 @@ PROTOTYPES = {
     "sbe_set_uniform_counts": (ct.c_int, [c_engine_p, ct.c_void_p]),
     "sbe_counts_delta": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p,
                                     ct.c_void_p, ct.c_int, ct.c_void_p]),
-    "sbe_counts_delta_apply": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p,
+    "sbe_counts_delta_apply": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p,
                                           ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_set_counts_rows": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_set_counts_rows_probs": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),

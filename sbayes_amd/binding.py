@@ -296,11 +296,17 @@ def counts_follow_plan(eng, sample, names, slot=0):
     return entry, mirrors, entry["stale"]
 
 
-def counts_followed(eng, plan, sample, names, touched, bounds, probs_rebuilt, slot=0):
+def counts_followed(eng, plan, sample, names, touched, bounds, probs_rebuilt, source_rows=None, slot=0):
     """After that call and the host's own add_changes: the slot's entry (dropped by the engine method) comes back with the
     touched components' tokens and mirror rows brought to the sample's new counts; components whose probability rows were
-    not rebuilt by the call join the stale set."""
+    not rebuilt by the call join the stale set.  `source_rows` (object indices): the slot's source rows of those objects
+    were set to the sample's in the same call -- the mirror takes them, and the entry forgets which source parameter the
+    slot held, so the next bind with a source compares content with the mirror (and sends whatever else differs)."""
     entry, mirrors, _ = plan
+    if source_rows is not None:
+        src = sample.source.value
+        mirrors["source"][source_rows] = src[source_rows] if src.dtype == np.bool_ else np.asarray(src[source_rows], dtype=bool)
+        entry["source"] = None
     counts = sample.feature_counts
     off = eng.group_offsets
     for c, name in enumerate(names):

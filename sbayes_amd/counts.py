@@ -143,9 +143,12 @@ def update_feature_counts(sample_old, sample_new, features, object_subset):
         return apply_count_rows(counts, names, off, touched, rows)
     # (the probability rows are rebuilt along when no table of the slot is stale: the touched components are not known yet)
     rebuild = not plan[2]
-    touched, rows = eng.counts_delta(objs, *ids, follow_slot=0, update_probs=rebuild)
+    # the subset's new source rows are in the call anyway (src_new): a slot that has a source takes them too
+    mirror_src = plan[1]["source"]
+    with_source = mirror_src is not None and mirror_src.shape == np.shape(src_new)
+    touched, rows = eng.counts_delta(objs, *ids, follow_slot=0, update_probs=rebuild, update_source=with_source)
     bounds = apply_count_rows(counts, names, off, touched, rows, return_bounds=True)
-    counts_followed(eng, plan, sample_new, names, touched, bounds, rebuild)
+    counts_followed(eng, plan, sample_new, names, touched, bounds, rebuild, objs if with_source else None)
     return counts
 
 

@@ -2617,7 +2617,7 @@ int sbe_set_uniform_counts(sbe_engine* e, const double* unif_counts) {
 // `follow_slot` >= 0 (sbe_counts_delta_apply): the slot's resident counts -- the OLD state's -- take the difference, and with
 // `follow_probs` the probability rows of the touched groups are rebuilt: inside the tile kernel (the usual case), by one
 // more kernel behind the general one.
-static int counts_delta_impl(sbe_engine* e, int follow_slot, int follow_probs, const int32_t* objects, int n_subset, const int32_t* gid_old,
+static int counts_delta_impl(sbe_engine* e, int follow_slot, int follow_probs, int follow_source, const int32_t* objects, int n_subset, const int32_t* gid_old,
                              const int32_t* gid_new, const uint8_t* src_old, const uint8_t* src_new, const int32_t* touched, int n_touched,
                              float* out_diff) {
     CHECK_ENGINE(e);
@@ -2650,6 +2650,9 @@ static int counts_delta_impl(sbe_engine* e, int follow_slot, int follow_probs, c
                 return fail(e, SBE_ERR_STATE, "slot %d: probability tables / concentration of component %d not set (update_probs = 1 rebuilds "
                             "the rows of tables that exist: sbe_update_probs first)", follow_slot, comp[t]);
         }
+        if (follow_source && !sl.source_set)
+            return fail(e, SBE_ERR_STATE, "slot %d: source not set (update_source = 1 patches resident rows)", follow_slot);
+        if (follow_source) follow.src = e->d_src + (int64_t)follow_slot * e->N * e->Fp;
         follow.counts = e->d_counts + (int64_t)follow_slot * e->table_elems();
         if (follow_probs) {
             follow.conc = e->d_conc; follow.probs = e->d_probs + (int64_t)follow_slot * e->table_elems();
@@ -2714,6 +2717,10 @@ static int counts_delta_impl(sbe_engine* e, int follow_slot, int follow_probs, c
         k_add_count_rows<<<div_up((int64_t)n_touched * F, 256), 256, 0, e->stream>>>(d_out, (const int32_t*)(din + o_t), n_touched, F, S, e->Gtot, follow);
         HIPCHK(e, hipGetLastError());
     }
+    if (follow.src) {
+        k_set_source_ids<<<div_up((int64_t)n_subset * F, 256), 256, 0, e->stream>>>(din + o_sn, (const int32_t*)(din + o_obj), n_subset, F, e->Fp, follow.src);
+        HIPCHK(e, hipGetLastError());
+    }
     if (!out_in_block) {
         rc = d2h(e, out_diff, d_out, out_bytes);
         if (rc || !follow.probs) return rc;
@@ -2727,14 +2734,14 @@ static int counts_delta_impl(sbe_engine* e, int follow_slot, int follow_probs, c
 
 int sbe_counts_delta(sbe_engine* e, const int32_t* objects, int n_subset, const int32_t* gid_old, const int32_t* gid_new,
                      const uint8_t* src_old, const uint8_t* src_new, const int32_t* touched, int n_touched, float* out_diff) {
-    return counts_delta_impl(e, -1, 0, objects, n_subset, gid_old, gid_new, src_old, src_new, touched, n_touched, out_diff);
+    return counts_delta_impl(e, -1, 0, 0, objects, n_subset, gid_old, gid_new, src_old, src_new, touched, n_touched, out_diff);
 }
 
-int sbe_counts_delta_apply(sbe_engine* e, int slot, int update_probs, const int32_t* objects, int n_subset, const int32_t* gid_old,
-                           const int32_t* gid_new, const uint8_t* src_old, const uint8_t* src_new, const int32_t* touched, int n_touched,
-                           float* out_diff) {
+int sbe_counts_delta_apply(sbe_engine* e, int slot, int update_probs, int update_source, const int32_t* objects, int n_subset,
+                           const int32_t* gid_old, const int32_t* gid_new, const uint8_t* src_old, const uint8_t* src_new,
+                           const int32_t* touched, int n_touched, float* out_diff) {
     CHECK_ENGINE(e); CHECK_SLOT(e, slot);
-    return counts_delta_impl(e, slot, update_probs, objects, n_subset, gid_old, gid_new, src_old, src_new, touched, n_touched, out_diff);
+    return counts_delta_impl(e, slot, update_probs, update_source, objects, n_subset, gid_old, gid_new, src_old, src_new, touched, n_touched, out_diff);
 }
 
 static int set_counts_rows_impl(sbe_engine* e, int slot, const int32_t* group_idx, int n_rows, const float* rows, bool with_probs) {

@@ -2276,7 +2276,8 @@ constexpr int kDeltaTileMaxN = 256;
 // `follow` (sbe_counts_delta_apply): a slot whose resident counts are the OLD state's takes the difference in the same launch
 // -- counts[touched rows] += delta, and (probs != nullptr) the probability rows of those groups rebuilt (update_probs'
 // arithmetic, k_set_count_rows_probs_x's row form) -- so that the host does not send back the rows it has just received.
-struct DeltaFollow { int32_t* counts; const double* conc; float* probs; float* probs_t; int* status; int ft; };
+struct DeltaFollow { int32_t* counts; const double* conc; float* probs; float* probs_t; int* status; int ft;
+                     uint8_t* src; /* or nullptr: the slot's [N][Fp] source ids take the subset's new rows */ };
 __global__ __launch_bounds__(kBlock) void k_counts_delta_tile(
     const uint8_t* __restrict__ state, const int32_t* __restrict__ objects, int n, const int32_t* __restrict__ gid_old,
     const int32_t* __restrict__ gid_new, const uint8_t* __restrict__ src_old, const uint8_t* __restrict__ src_new,
@@ -2372,6 +2373,12 @@ __global__ __launch_bounds__(kBlock) void k_counts_delta_tile(
     // the caller waits for the difference only: the flag goes out before the following slot is brought up to date (the
     // next operation of the stream is ordered behind this kernel's end anyway; nothing below reads the mapped block)
     signal_done(done);
+    if (follow.src) {                                    // the subset's new source ids, this block's 16 columns
+        for (int t = threadIdx.x; t < n * FTU; t += kBlock) {
+            const int i = t / FTU, tf = t % FTU;
+            if (f0 + tf < F) follow.src[(int64_t)obj[i] * Fp + f0 + tf] = sn[i * FTU + tf];
+        }
+    }
     if (follow.counts) {                                 // (this block owns its 16 features of every touched group)
         auto rows_by_lane_groups = [&](auto width) {
             constexpr int W = decltype(width)::value;
@@ -2434,6 +2441,13 @@ __global__ void k_add_count_rows(const float* __restrict__ diff /* [T][F][S] */,
         probs_row([&](int k) { return (float)follow.counts[at + k]; }, follow.conc + at, nullptr, S, 0.0, 0.0, follow.status,
                   [&](int k, float v) { out_row[k] = v; out_t[(int64_t)k * follow.ft] = v; });
     }
+}
+
+__global__ void k_set_source_ids(const uint8_t* __restrict__ ids /* [n][F] */, const int32_t* __restrict__ objects, int n, int F, int Fp,
+                                 uint8_t* __restrict__ src /* slot's [N][Fp] */) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n * F) return;
+    src[(int64_t)objects[t / F] * Fp + t % F] = ids[t];
 }
 
 // float32 count rows of listed groups -> the slot's resident int32 counts (Engine.set_counts_rows: the bind cache

@@ -607,14 +607,15 @@ class Engine:
             raise ValueError(f"unif_counts must be {(self.n_features, self.n_states)}, got {u.shape}")
         self._check(self._lib.sbe_set_uniform_counts(self._h, self._i(u)))
 
-    def counts_delta(self, objects, gid_old, gid_new, src_old, src_new, follow_slot=None, update_probs=False):
+    def counts_delta(self, objects, gid_old, gid_new, src_old, src_new, follow_slot=None, update_probs=False, update_source=False):
         """update_feature_counts (counts.py:55-95) for the listed objects, stateless: gid_* int [C, n] global group index
         per component (-1: none), src_* uint8 [n, F] source component per observation (255: none).  Returns
         (touched, diff): the sorted global indices of the groups any listed object is in (either state) and the float32
         rows [len(touched), F, S] of new_counts - old_counts; every other row of that difference is zero.
         `follow_slot`: that slot's resident counts take the difference on the device (and, `update_probs`, the probability
-        rows of the touched groups are rebuilt) -- for a slot that holds the counts the difference is added to on the host,
-        so that the rows are not sent back (binding.counts_follow_*)."""
+        rows of the touched groups are rebuilt; `update_source`: its source rows of the listed objects become src_new) -- for
+        a slot that holds the counts the difference is added to on the host, so that the rows are not sent back
+        (binding.counts_follow_*)."""
         objs = _as(objects, np.int32).reshape(-1)
         n = objs.size
         C, F = self.n_components, self.n_features
@@ -636,7 +637,8 @@ class Engine:
                 self._check(self._lib.sbe_counts_delta(self._h, self._i(objs), n, _ptr(go), _ptr(gn), self._i(so), self._i(sn),
                                                        self._i(touched), nt, self._o(diff)))
             else:
-                self._check(self._lib.sbe_counts_delta_apply(self._h, int(follow_slot), 1 if update_probs else 0, self._i(objs), n,
+                self._check(self._lib.sbe_counts_delta_apply(self._h, int(follow_slot), 1 if update_probs else 0,
+                                                             1 if update_source else 0, self._i(objs), n,
                                                              _ptr(go), _ptr(gn), self._i(so), self._i(sn), self._i(touched), nt,
                                                              self._o(diff)))
         return touched, diff

@@ -290,7 +290,7 @@ class FakeEngine:
         self.calls.append(("set_source_rows", len(objects)))
         self._slot(slot)["source"][np.asarray(objects)] = np.asarray(rows, dtype=bool)
 
-    def counts_delta(self, objects, gid_old, gid_new, src_old, src_new, follow_slot=None, update_probs=False):
+    def counts_delta(self, objects, gid_old, gid_new, src_old, src_new, follow_slot=None, update_probs=False, update_source=False):
         """(touched, diff rows) of update_feature_counts for the listed objects: the oracle's a9 on one-object
         group matrices rebuilt from the ids.  follow_slot: that slot's counts take the difference (tables are derived on
         demand here, so update_probs has nothing to do)."""
@@ -312,6 +312,9 @@ class FakeEngine:
                     diff[t] += sign * np.count_nonzero((src[members] == c)[:, :, None] & feats[members], axis=0)
             if follow_slot is not None:
                 self._slot(follow_slot)["counts"][c][gg - off[c]] += diff[t]
+        if follow_slot is not None and update_source and objects.size:
+            n_comp = self._slot(follow_slot)["source"].shape[2]
+            self._slot(follow_slot)["source"][objects] = src_new[..., None] == np.arange(n_comp)
         return touched, diff
 
     def _full_state(self, slot):

@@ -121,6 +121,14 @@ def test_counts_delta_and_row_uploads(name):
             for c in range(C):
                 assert np.array_equal(eng.get_counts(1, c), eng.get_counts(2, c)), (name, n, c, "following counts, no tables")
                 assert np.array_equal(eng.get_probs(1, c), eng.get_probs(0, c)), (name, n, c)
+            assert np.array_equal(eng.get_source_rows(1, objs), source[objs])              # (and so does the source)
+            # ... update_source: the slot's source rows of the subset become the new rows (what set_source_rows leaves)
+            eng.copy_slot(1, 0)
+            eng.counts_delta(objs, gid_old, gid_new, so, sn, follow_slot=1, update_probs=True, update_source=True)
+            eng.set_source_rows(2, objs, new_source[objs])
+            assert np.array_equal(eng.get_source_rows(1, objs), new_source[objs]), (name, n, "following source rows")
+            with np.errstate(divide="ignore"):
+                assert np.array_equal(eng.source_prior(1), eng.source_prior(2), equal_nan=True), (name, n)
         # delta upload of count rows: only the listed groups change
         for c in range(C):
             g = int(rng.integers(0, groups[c].shape[0]))

@@ -122,7 +122,8 @@ def forms_case(rng, eng, feats, n_groups, conc, state, tag, stats):
         sa_, sb_ = eng.n_slots - 1, eng.n_slots - 2
         eng.copy_slot(sa_, 0); eng.copy_slot(sb_, 0)
         eng.update_probs(sa_, range(C)); eng.update_probs(sb_, range(C))
-        t_f, d_f = eng.counts_delta(objs, gid_old, gid_new, so, sn, follow_slot=sa_, update_probs=True)
+        t_f, d_f = eng.counts_delta(objs, gid_old, gid_new, so, sn, follow_slot=sa_, update_probs=True, update_source=True)
+        assert np.array_equal(eng.get_source_rows(sa_, objs), new_rows), (tag, "following source rows")
         assert np.array_equal(t_f, t_want) and np.array_equal(d_f, d_want), (tag, "counts_delta with a following slot")
         comp_of = np.searchsorted(off, t_want, side="right") - 1
         rows_f = np.stack([counts[c_][g_ - off[c_]] for g_, c_ in zip(t_want, comp_of)]) + d_want if t_want.size else np.zeros((0,) + counts[0].shape[1:], np.float32)
