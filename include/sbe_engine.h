@@ -52,7 +52,8 @@ typedef struct sbe_engine sbe_engine;
 #define SBE_ABI_VERSION 5   /* 4 (round 4): + sbe_given_unchanged_gibbs, sbe_host_*; sbe_set_groups rejects overlap;
                                5: + SBE_OPT_FUSE_TABLES, sbe_host_subset_ids, sbe_host_diff_rows, sbe_set_counts_rows_probs,
                                sbe_gibbs_propose, sbe_given_unchanged_gibbs_counts, sbe_test_roundtrip,
-                               sbe_collapsed_and_source_prior, sbe_counts_delta_apply */
+                               sbe_collapsed_and_source_prior, sbe_counts_delta_apply,
+                               sbe_given_unchanged_gibbs_apply */
 
 /* error codes */
 #define SBE_OK 0
@@ -437,6 +438,16 @@ int sbe_given_unchanged_gibbs_counts(sbe_engine* e, int slot, int i_cluster, con
                                      const uint8_t* src_old, const double* z, const int32_t* gid_old, const int32_t* gid_new,
                                      uint8_t* src_new_out, float* sel_new_out, float* sel_back_out, int32_t* touched_out,
                                      int32_t* n_touched_out, float* diff_rows_out);
+/* ... and the slot FOLLOWS the proposal (cf. sbe_counts_delta_apply): when the call touches any group, the slot's counts
+ * take the delta, the subset's source rows become the drawn ids and, with update_probs != 0, the probability rows of the
+ * touched groups are rebuilt -- behind the completion flag of the same launch, so that the bind that follows the
+ * reference's own bookkeeping (source.edit(), update_feature_counts) has nothing to send.  The caller vouches that the
+ * slot's counts are the ones the delta belongs to (they are: the call reads them). */
+int sbe_given_unchanged_gibbs_apply(sbe_engine* e, int slot, int update_probs, int i_cluster, const int32_t* objects, int n_sub,
+                                    double temperature, double prior_temperature, int from_prior, const uint8_t* hc_new,
+                                    const uint8_t* hc_old, const uint8_t* src_old, const double* z, const int32_t* gid_old,
+                                    const int32_t* gid_new, uint8_t* src_new_out, float* sel_new_out, float* sel_back_out,
+                                    int32_t* touched_out, int32_t* n_touched_out, float* diff_rows_out);
 int sbe_cluster_posterior_marginals(sbe_engine* e, int slot, int i_cluster, double temperature, double prior_temperature,
                                     const int32_t* objects, int n_objects_av, double* out /* [2][n_objects_av] */);
 int sbe_jump_lh_resident(sbe_engine* e, int slot, int i_source, int i_target, double temperature, double prior_temperature,

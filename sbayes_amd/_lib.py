@@ -134,6 +134,9 @@ PROTOTYPES = {
     "sbe_test_lgamma": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_test_tab_log": (ct.c_int, [c_engine_p, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_test_roundtrip": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int]),
+    "sbe_given_unchanged_gibbs_apply": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double, ct.c_int,
+                                                   ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p,
+                                                   ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p]),
     "sbe_given_unchanged_gibbs_counts": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double, ct.c_int,
                                                     ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p,
                                                     ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p]),

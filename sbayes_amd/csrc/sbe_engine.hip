@@ -2920,7 +2920,7 @@ static int given_unchanged_gibbs_impl(sbe_engine* e, int slot, int i_cluster, co
                                       double prior_temperature, int from_prior, const uint8_t* hc_new, const uint8_t* hc_old,
                                       const uint8_t* src_old, const double* z, uint8_t* src_new_out, float* sel_new_out,
                                       float* sel_back_out, const int32_t* gid_old, const int32_t* gid_new, int32_t* touched_out,
-                                      int32_t* n_touched_out, float* diff_rows_out) {
+                                      int32_t* n_touched_out, float* diff_rows_out, int follow = 0, int follow_probs = 0) {
     CHECK_ENGINE(e); CHECK_SLOT(e, slot);
     const bool with_counts = gid_old != nullptr;
     if (with_counts) { CHECK_PTR(e, gid_new); CHECK_PTR(e, touched_out); CHECK_PTR(e, n_touched_out); CHECK_PTR(e, diff_rows_out); *n_touched_out = 0; }
@@ -3006,8 +3006,29 @@ static int given_unchanged_gibbs_impl(sbe_engine* e, int slot, int i_cluster, co
     const double inv_t = 1.0 / temperature, inv_tp = 1.0 / prior_temperature;
     a.inv_t = (float)inv_t; a.inv_tp = (float)inv_tp; a.pow_lh = inv_t != 1.0; a.pow_w = inv_tp != 1.0; a.from_prior = from_prior ? 1 : 0;
     uint8_t* d_ids = e->d_io + in_bytes;
+    // the slot follows the proposal (sbe_given_unchanged_gibbs_apply): its counts take the delta, the touched groups' probability
+    // rows are rebuilt, the subset's source rows become the drawn ids -- behind the completion flag of the same launch
+    follow = follow && with_counts && n_touched > 0;
+    DeltaFollow dfollow{};
+    if (follow) {
+        const Slot& sl = e->slots[slot];
+        for (int t = 0; t < n_touched; ++t) {
+            int c = 0;
+            while (c + 1 < C && touched_out[t] >= e->goff[c + 1]) ++c;
+            if (follow_probs && !sl.probs_set[c])
+                return fail(e, SBE_ERR_STATE, "slot %d: probability tables of component %d not set (update_probs = 1 rebuilds the rows of "
+                            "tables that exist: sbe_update_probs first)", slot, c);
+        }
+        dfollow.counts = e->d_counts + (int64_t)slot * e->table_elems();
+        dfollow.src = e->d_src + (int64_t)slot * N * e->Fp;
+        if (follow_probs) {
+            dfollow.conc = e->d_conc; dfollow.probs = e->d_probs + (int64_t)slot * e->table_elems();
+            dfollow.probs_t = e->d_probs_t + (int64_t)slot * e->probs_t_elems(); dfollow.status = e->d_status; dfollow.ft = e->ft;
+        }
+    }
     const size_t fused_lds = gu_fused_lds_bytes(R, S, in_bytes, N) +
-                             (with_counts ? ((size_t)n_touched * 16 * S + (size_t)e->Gtot) * sizeof(int32_t) : 0);
+                             (with_counts ? ((size_t)n_touched * 16 * S + (size_t)e->Gtot) * sizeof(int32_t) : 0) +
+                             (follow ? (size_t)n_touched * sizeof(int32_t) + (size_t)n_sub * 16 : 0);
     if (e->opt_fuse_tables && fused_lds <= kGuFusedLdsMax) {        // one launch (see sbe_given_unchanged_lh)
         GuFusedArgs fa = gu_fused_args(e, slot, i_cluster, n_sub, R, temperature, prior_temperature, off, in_bytes, ob,
                                        ob + gb + fb, ob + gb + fb + hb);
@@ -3015,6 +3036,7 @@ static int given_unchanged_gibbs_impl(sbe_engine* e, int slot, int i_cluster, co
             fa.gid_old_word = (int)(o_gold / 4); fa.gid_new_word = (int)(o_gnew / 4); fa.n_touched = n_touched; fa.Gtot = e->Gtot;
             fa.touched = reinterpret_cast<const int32_t*>(e->d_io + o_tch);
             fa.rows_out = reinterpret_cast<float*>(d_ids + idb + 2 * selb);
+            fa.follow = dfollow;
         }
         const unsigned blocks = (unsigned)div_up(F, 16);
         const DoneSig done = next_done(e, blocks);
@@ -3027,7 +3049,8 @@ static int given_unchanged_gibbs_impl(sbe_engine* e, int slot, int i_cluster, co
         memcpy(sel_new_out, h + in_bytes + idb, nf * sizeof(float));
         memcpy(sel_back_out, h + in_bytes + idb + selb, nf * sizeof(float));
         if (with_counts) memcpy(diff_rows_out, h + in_bytes + idb + 2 * selb, (size_t)n_touched * fs * sizeof(float));
-        return SBE_OK;
+        // (rows rebuilt behind the flag may raise normalize's data check: reported like a setter's)
+        return dfollow.probs ? check_after(e, ST_BAD_NORMALIZE, "sbe_given_unchanged_gibbs_apply") : SBE_OK;
     }
     const bool list_in_lds = (size_t)n_sub * sizeof(int32_t) <= ((size_t)32 << 10);
     if (((size_t)16 * S + (N + 31) / 32) * sizeof(int32_t) > ((size_t)96 << 10))
@@ -3049,7 +3072,8 @@ static int given_unchanged_gibbs_impl(sbe_engine* e, int slot, int i_cluster, co
     memcpy(sel_new_out, h + in_bytes + idb, nf * sizeof(float));
     memcpy(sel_back_out, h + in_bytes + idb + selb, nf * sizeof(float));
     if (with_counts)       // (this shape has no one-launch form: the count delta by its own call, from the ids just drawn)
-        return sbe_counts_delta(e, objects, n_sub, gid_old, gid_new, src_old, src_new_out, touched_out, n_touched, diff_rows_out);
+        return counts_delta_impl(e, follow ? slot : -1, follow_probs, follow ? 1 : 0, objects, n_sub, gid_old, gid_new, src_old, src_new_out,
+                                 touched_out, n_touched, diff_rows_out);
     return SBE_OK;
 }
 
@@ -3070,6 +3094,17 @@ int sbe_given_unchanged_gibbs_counts(sbe_engine* e, int slot, int i_cluster, con
     return given_unchanged_gibbs_impl(e, slot, i_cluster, objects, n_sub, temperature, prior_temperature, from_prior, hc_new, hc_old,
                                       src_old, z, src_new_out, sel_new_out, sel_back_out, gid_old, gid_new, touched_out, n_touched_out,
                                       diff_rows_out);
+}
+
+int sbe_given_unchanged_gibbs_apply(sbe_engine* e, int slot, int update_probs, int i_cluster, const int32_t* objects, int n_sub,
+                                    double temperature, double prior_temperature, int from_prior, const uint8_t* hc_new, const uint8_t* hc_old,
+                                    const uint8_t* src_old, const double* z, const int32_t* gid_old, const int32_t* gid_new,
+                                    uint8_t* src_new_out, float* sel_new_out, float* sel_back_out, int32_t* touched_out,
+                                    int32_t* n_touched_out, float* diff_rows_out) {
+    CHECK_ENGINE(e); CHECK_PTR(e, gid_old);
+    return given_unchanged_gibbs_impl(e, slot, i_cluster, objects, n_sub, temperature, prior_temperature, from_prior, hc_new, hc_old,
+                                      src_old, z, src_new_out, sel_new_out, sel_back_out, gid_old, gid_new, touched_out, n_touched_out,
+                                      diff_rows_out, 1, update_probs);
 }
 
 int sbe_cluster_posterior_marginals(sbe_engine* e, int slot, int i_cluster, double temperature, double prior_temperature,

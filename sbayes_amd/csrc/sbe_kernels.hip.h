@@ -2278,6 +2278,56 @@ constexpr int kDeltaTileMaxN = 256;
 // arithmetic, k_set_count_rows_probs_x's row form) -- so that the host does not send back the rows it has just received.
 struct DeltaFollow { int32_t* counts; const double* conc; float* probs; float* probs_t; int* status; int ft;
                      uint8_t* src; /* or nullptr: the slot's [N][Fp] source ids take the subset's new rows */ };
+// The following slot's rows of one 16-feature tile (the calling block owns these features of every touched group): counts +=
+// the LDS histograms `hist` [T][16][S], and -- follow.probs -- the probability rows of those groups rebuilt (update_probs'
+// arithmetic in k_set_count_rows_probs_x's row form).  `tgl` [T]: the touched groups (LDS).  Every thread of the block calls.
+__device__ __forceinline__ void follow_tile_rows(const DeltaFollow& follow, const int32_t* hist, const int32_t* tgl, int n_touched, int f0,
+                                                 int F, int S, int Gtot) {
+    constexpr int FTU = 16;
+    if (!follow.counts) return;
+    const int nthr = blockDim.x;
+    auto rows_by_lane_groups = [&](auto width) {
+        constexpr int W = decltype(width)::value;
+        for (int row0 = 0; row0 < n_touched * FTU; row0 += nthr / W) {
+            const int row = row0 + (int)threadIdx.x / W, j = threadIdx.x & (W - 1);
+            const int tt = row / FTU, tf = row % FTU, ff = f0 + tf;
+            const bool row_on = row < n_touched * FTU && ff < F;
+            const int g = row_on ? tgl[tt] : 0;
+            const int64_t at = row_on ? ((int64_t)g * F + ff) * S : 0;
+            float cj = 0.0f;
+            if (row_on && j < S) {
+                const int32_t v = follow.counts[at + j] + hist[(tt * FTU + tf) * S + j];
+                follow.counts[at + j] = v;
+                cj = (float)v;
+            }
+            if (follow.probs) {
+                float* out_row = follow.probs + at;
+                float* out_t = follow.probs_t + (((int64_t)(ff / follow.ft) * (Gtot + 1) + g) * S) * follow.ft + ff % follow.ft;   // (k_probs' tile layout)
+                probs_row_x16<W>(j, row_on, [&](int) { return cj; }, follow.conc + at, nullptr, S, 0.0, 0.0, follow.status,
+                                 [&](int s, float v) { out_row[s] = v; out_t[(int64_t)s * follow.ft] = v; });
+            }
+        }
+    };
+    if (S <= 8) rows_by_lane_groups(std::integral_constant<int, 8>{});
+    else if (S <= 16) rows_by_lane_groups(std::integral_constant<int, 16>{});
+    else {
+        for (int t = threadIdx.x; t < n_touched * FTU; t += nthr) {
+            const int tt = t / FTU, tf = t % FTU, ff = f0 + tf;
+            if (ff >= F) continue;
+            const int g = tgl[tt];
+            const int64_t at = ((int64_t)g * F + ff) * S;
+            const int32_t* h = hist + (tt * FTU + tf) * S;
+            for (int k = 0; k < S; ++k) follow.counts[at + k] += h[k];
+            if (follow.probs) {
+                float* out_row = follow.probs + at;
+                float* out_t = follow.probs_t + (((int64_t)(ff / follow.ft) * (Gtot + 1) + g) * S) * follow.ft + ff % follow.ft;
+                probs_row([&](int k) { return (float)follow.counts[at + k]; }, follow.conc + at, nullptr, S, 0.0, 0.0, follow.status,
+                          [&](int k, float v) { out_row[k] = v; out_t[(int64_t)k * follow.ft] = v; });
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_counts_delta_tile(
     const uint8_t* __restrict__ state, const int32_t* __restrict__ objects, int n, const int32_t* __restrict__ gid_old,
     const int32_t* __restrict__ gid_new, const uint8_t* __restrict__ src_old, const uint8_t* __restrict__ src_new,
@@ -2379,48 +2429,7 @@ __global__ __launch_bounds__(kBlock) void k_counts_delta_tile(
             if (f0 + tf < F) follow.src[(int64_t)obj[i] * Fp + f0 + tf] = sn[i * FTU + tf];
         }
     }
-    if (follow.counts) {                                 // (this block owns its 16 features of every touched group)
-        auto rows_by_lane_groups = [&](auto width) {
-            constexpr int W = decltype(width)::value;
-            for (int row0 = 0; row0 < n_touched * FTU; row0 += kBlock / W) {
-                const int row = row0 + (int)threadIdx.x / W, j = threadIdx.x & (W - 1);
-                const int tt = row / FTU, tf = row % FTU, ff = f0 + tf;
-                const bool row_on = row < n_touched * FTU && ff < F;
-                const int g = row_on ? tgl[tt] : 0;
-                const int64_t at = row_on ? ((int64_t)g * F + ff) * S : 0;
-                float cj = 0.0f;
-                if (row_on && j < S) {
-                    const int32_t v = follow.counts[at + j] + hist[(tt * FTU + tf) * S + j];
-                    follow.counts[at + j] = v;
-                    cj = (float)v;
-                }
-                if (follow.probs) {
-                    float* out_row = follow.probs + at;
-                    float* out_t = follow.probs_t + (((int64_t)(ff / follow.ft) * (Gtot + 1) + g) * S) * follow.ft + ff % follow.ft;   // (k_probs' tile layout)
-                    probs_row_x16<W>(j, row_on, [&](int) { return cj; }, follow.conc + at, nullptr, S, 0.0, 0.0, follow.status,
-                                     [&](int s, float v) { out_row[s] = v; out_t[(int64_t)s * follow.ft] = v; });
-                }
-            }
-        };
-        if (S <= 8) rows_by_lane_groups(std::integral_constant<int, 8>{});
-        else if (S <= 16) rows_by_lane_groups(std::integral_constant<int, 16>{});
-        else {
-            for (int t = threadIdx.x; t < n_touched * FTU; t += kBlock) {
-                const int tt = t / FTU, tf = t % FTU, ff = f0 + tf;
-                if (ff >= F) continue;
-                const int g = tgl[tt];
-                const int64_t at = ((int64_t)g * F + ff) * S;
-                const int32_t* h = hist + (tt * FTU + tf) * S;
-                for (int k = 0; k < S; ++k) follow.counts[at + k] += h[k];
-                if (follow.probs) {
-                    float* out_row = follow.probs + at;
-                    float* out_t = follow.probs_t + (((int64_t)(ff / follow.ft) * (Gtot + 1) + g) * S) * follow.ft + ff % follow.ft;
-                    probs_row([&](int k) { return (float)follow.counts[at + k]; }, follow.conc + at, nullptr, S, 0.0, 0.0, follow.status,
-                              [&](int k, float v) { out_row[k] = v; out_t[(int64_t)k * follow.ft] = v; });
-                }
-            }
-        }
-    }
+    follow_tile_rows(follow, hist, tgl, n_touched, f0, F, S, Gtot);
 }
 
 // The following slot of sbe_counts_delta_apply behind the GENERAL difference kernel (subsets beyond the tile form): the
@@ -2616,6 +2625,10 @@ struct GuFusedArgs {
     int gid_old_word, gid_new_word, n_touched, Gtot;
     const int32_t* touched;
     float* rows_out;
+    // ... and the slot itself FOLLOWS the proposal (sbe_given_unchanged_gibbs_apply; follow.counts == nullptr: not asked for):
+    // behind the completion flag its counts take the delta, the touched groups' probability rows are rebuilt (follow.probs)
+    // and the subset's source rows become the drawn ids (follow.src).  LDS: + touched groups [n_touched] + drawn ids [n_sub][16].
+    DeltaFollow follow;
 };
 
 template <bool kGibbs>
@@ -2636,6 +2649,9 @@ __global__ __launch_bounds__(kUnchangedBlock) void k_given_unchanged_fused(GuFus
     uint32_t* in_subset = stage + a.in_words;                            // [(N + 31) / 32]
     int32_t* dhist = reinterpret_cast<int32_t*>(in_subset + (a.N + 31) / 32);   // count delta [n_touched][FTU][S] (Gibbs form, if asked)
     int32_t* dpos = dhist + a.n_touched * FTU * S;                       // touched index of a group, -1 [Gtot]
+    int32_t* tgl = dpos + a.Gtot;                                        // (following slot) the touched groups [n_touched]
+    uint8_t* knew = reinterpret_cast<uint8_t*>(tgl + a.n_touched);       // (following slot) drawn component [n_sub][FTU], 0xFF none
+    const bool following = kGibbs && a.n_touched > 0 && a.follow.counts != nullptr;
     const int32_t* sub = reinterpret_cast<const int32_t*>(stage + a.objects_word);       // [n_sub]
     const int32_t* gidx = reinterpret_cast<const int32_t*>(stage + a.group_idx_word);    // [C][n_sub]
     const int f0 = blockIdx.x * FTU;
@@ -2667,8 +2683,12 @@ __global__ __launch_bounds__(kUnchangedBlock) void k_given_unchanged_fused(GuFus
     __syncthreads();
     GU_STAMP(1);
     if constexpr (kGibbs) {
-        if (touched_mine >= 0) dpos[touched_mine] = threadIdx.x;
-        for (int t = threadIdx.x + kUnchangedBlock; t < a.n_touched; t += kUnchangedBlock) dpos[a.touched[t]] = t;
+        if (touched_mine >= 0) { dpos[touched_mine] = threadIdx.x; if (following) tgl[threadIdx.x] = touched_mine; }
+        for (int t = threadIdx.x + kUnchangedBlock; t < a.n_touched; t += kUnchangedBlock) {
+            const int g = a.touched[t];
+            dpos[g] = t;
+            if (following) tgl[t] = g;
+        }
     }
     for (int i = threadIdx.x; i < n_sub; i += kUnchangedBlock) atomicOr(&in_subset[sub[i] >> 5], 1u << (sub[i] & 31));
     __syncthreads();
@@ -2760,6 +2780,7 @@ __global__ __launch_bounds__(kUnchangedBlock) void k_given_unchanged_fused(GuFus
                                        [&](int c) { return gidx[c * n_sub + r]; },
                                        [&](int c, int g) { return tab[((a.table_offsets[c] + g) * FTU + tf) * S + x]; },
                                        src_new, sel_new, sel_back, a.status);
+            if (following) knew[r * FTU + tf] = k >= 0 ? (uint8_t)k : (uint8_t)0xFF;
             if (a.n_touched > 0 && k >= 0) {
                 // update_feature_counts (counts.py:55-95) of the proposal, this observation's share: one more in its NEW group of
                 // the drawn component, one less in its OLD group of the old source component
@@ -2798,6 +2819,18 @@ __global__ __launch_bounds__(kUnchangedBlock) void k_given_unchanged_fused(GuFus
 #endif
     GU_STAMP(5);
     signal_done(done);
+    if constexpr (kGibbs) {
+        if (following) {                                  // (block-uniform; nothing below reads the mapped block)
+            if (!done.flag) __syncthreads();              // (signal_done's barrier made knew / dhist complete otherwise)
+            if (a.follow.src) {
+                for (int t = threadIdx.x; t < n_sub * FTU; t += kUnchangedBlock) {
+                    const int r = t / FTU, tf = t % FTU;
+                    if (f0 + tf < a.F) a.follow.src[(int64_t)sub[r] * a.Fp + f0 + tf] = knew[t];
+                }
+            }
+            follow_tile_rows(a.follow, dhist, tgl, a.n_touched, f0, a.F, S, a.Gtot);
+        }
+    }
 }
 
 }  // namespace sbe

@@ -666,7 +666,7 @@ class Engine:
         return out
 
     def given_unchanged_gibbs(self, slot, i_cluster, objects, hc_new, hc_old, src_old, z, temperature=1.0, prior_temperature=1.0,
-                              from_prior=False, gid_old=None, gid_new=None):
+                              from_prior=False, gid_old=None, gid_new=None, follow=False, update_probs=False):
         """ClusterOperator.gibbs_sample_source (operators.py:796-851) on the slot the NEW sample is bound to: returns
         (src_new uint8 [n, F] drawn component, 255 = NA observation; sel_new float32 [n, F] = p[drawn]; sel_back float32
         [n, F] = p_back[old source]).  hc_new / hc_old: bool [n, C] has_components rows of the new / old sample; src_old:
@@ -694,7 +694,18 @@ class Engine:
             touched = np.empty(self.n_groups_total, dtype=np.int32)
             rows = np.empty((min(self.n_groups_total, 2 * C * max(n, 1)), F, self.n_states), dtype=np.float32)
             nt = ct.c_int32(0)
-            if n:
+            # follow=True: when the call touches any group, the slot itself takes the proposal -- counts += delta, the subset's
+            # source rows = the drawn ids, update_probs: the touched groups' probability rows -- behind the same launch
+            # (binding.counts_follow_*: the next bind has nothing to send)
+            if follow:
+                self._touch(slot)
+            if n and follow:
+                self._check(self._lib.sbe_given_unchanged_gibbs_apply(
+                    self._h, slot, 1 if update_probs else 0, int(i_cluster), self._i(objs), n, float(temperature), float(prior_temperature),
+                    int(bool(from_prior)), self._i(hn), self._i(ho), self._i(so), self._i(zz), self._i(go), self._i(gn), self._o(ids),
+                    self._o(sel), self._o(back), _ptr(touched), ct.byref(nt), _ptr(rows)))
+                self.d2h_bytes += nt.value * (4 + F * self.n_states * 4)
+            elif n:
                 self._check(self._lib.sbe_given_unchanged_gibbs_counts(
                     self._h, slot, int(i_cluster), self._i(objs), n, float(temperature), float(prior_temperature), int(bool(from_prior)),
                     self._i(hn), self._i(ho), self._i(so), self._i(zz), self._i(go), self._i(gn), self._o(ids), self._o(sel),

@@ -22,7 +22,8 @@ from __future__ import annotations
 import numpy as np
 
 from . import _fast
-from .binding import _bind_slot, _bind_uniform, _engine, _tables_current
+from . import counts as counts_mod
+from .binding import _bind_slot, _bind_uniform, _engine, _tables_current, counts_follow_plan, counts_followed
 from .counts import _source_ids, apply_count_rows, note_jump_state, update_feature_counts
 
 EPS = np.finfo(np.float32).eps        # sbayes/util.py:34
@@ -218,9 +219,23 @@ def cluster_gibbs_sample_source(model, sample_new, sample_old, i_cluster, object
     src_old = sub[2] if sub is not None else _source_ids(source_old, objects)
     if z is None:                                                          # (tests pass the reference's recorded uniforms)
         z = np.random.random((objects.size, eng.n_features, 1))
+    plan = None
     if sub is not None:
-        ids, sel_new, sel_back, touched, rows = eng.given_unchanged_gibbs(slot, i_cluster, objects, hc_new, hc_old, src_old, z, temperature,
-                                                                          prior_temperature, sample_from_prior, gid_old=sub[0], gid_new=sub[1])
+        # the slot holds `sample_new` as it is now (bound above: its counts are the ones the delta belongs to): it takes the
+        # proposal on the device -- counts, the touched groups' probability rows when no table is stale, the drawn source rows --
+        # and the binds that follow the bookkeeping below have nothing to send (binding.counts_follow_plan)
+        names = ["clusters", *conf_names]
+        plan = counts_follow_plan(eng, sample_new, names, slot) if counts_mod.FOLLOW_COUNTS and hasattr(eng, "_bound") else None
+        if plan is not None and (plan[1]["source"] is None or plan[1]["source"].shape != np.shape(source_old)):
+            plan = None
+        if plan is not None:
+            rebuild = not plan[2]
+            ids, sel_new, sel_back, touched, rows = eng.given_unchanged_gibbs(
+                slot, i_cluster, objects, hc_new, hc_old, src_old, z, temperature, prior_temperature, sample_from_prior,
+                gid_old=sub[0], gid_new=sub[1], follow=True, update_probs=rebuild)
+        else:
+            ids, sel_new, sel_back, touched, rows = eng.given_unchanged_gibbs(slot, i_cluster, objects, hc_new, hc_old, src_old, z, temperature,
+                                                                              prior_temperature, sample_from_prior, gid_old=sub[0], gid_new=sub[1])
     else:
         ids, sel_new, sel_back = eng.given_unchanged_gibbs(slot, i_cluster, objects, hc_new, hc_old, src_old, z, temperature,
                                                            prior_temperature, sample_from_prior)
@@ -228,7 +243,12 @@ def cluster_gibbs_sample_source(model, sample_new, sample_old, i_cluster, object
     with sample_new.source.edit() as source:
         source[objects] = x                                               # (NA observations stay 0: operators.py:825)
     if sub is not None:
-        apply_count_rows(sample_new.feature_counts, ["clusters", *conf_names], eng.group_offsets, touched, rows)
+        bounds = apply_count_rows(sample_new.feature_counts, ["clusters", *conf_names], eng.group_offsets, touched, rows, return_bounds=True)
+        if plan is not None:
+            if touched.size:                                               # (the engine's rule: nothing touched, nothing follows)
+                counts_followed(eng, plan, sample_new, names, touched, bounds, rebuild, objects, slot)
+            else:                                                          # (the call dropped the entry: it still describes the slot)
+                eng._bound[slot], eng._mirror[slot] = plan[0], plan[1]
     else:
         update_feature_counts(sample_old, sample_new, features, objects)
     valid = ~na_features[objects]

@@ -358,9 +358,10 @@ class FakeEngine:
             [self.unif] * (len(groups) - 1), temperature=temperature, prior_temperature=prior_temperature)
 
     def given_unchanged_gibbs(self, slot, i_cluster, objects, hc_new, hc_old, src_old, z, temperature=1.0, prior_temperature=1.0,
-                              from_prior=False, gid_old=None, gid_new=None):
+                              from_prior=False, gid_old=None, gid_new=None, follow=False, update_probs=False):
         """ClusterOperator.gibbs_sample_source (operators.py:808-847) restated with the oracle's pieces: the expressions of
-        the reference, in its dtypes, on the subset."""
+        the reference, in its dtypes, on the subset.  follow: the slot takes the proposal when it touches any group (counts
+        += delta, the subset's source rows = the drawn ids; tables are derived on demand here)."""
         objects = np.asarray(objects)
         # (class-qualified: a recording / memoising subclass must not log this inner step as a call of its own -- the real
         #  engine receives ONE call)
@@ -384,8 +385,11 @@ class FakeEngine:
         back = np.where(so != 255, np.take_along_axis(p_back, np.minimum(so, p.shape[-1] - 1).astype(np.int64)[..., None], axis=-1)[..., 0],
                         1.0).astype(np.float32)
         if gid_old is not None:                 # + the proposal's count delta (the double's own counts_delta, not logged separately)
-            touched, rows = FakeEngine.counts_delta(self, objects, gid_old, gid_new, so, ids)
+            touched, rows = FakeEngine.counts_delta(self, objects, gid_old, gid_new, so, ids,
+                                                    follow_slot=slot if follow else None, update_source=bool(follow))
             self.calls.pop()
+            if follow and touched.size == 0:          # (the engine's rule: nothing touched, nothing follows)
+                pass
             return ids, sel, back, touched, rows
         return ids, sel, back
 

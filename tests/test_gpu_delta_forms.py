@@ -406,6 +406,25 @@ def test_cluster_gibbs_with_its_count_delta(name):
                 want = fake.given_unchanged_gibbs(0, k, objs, hc_new, hc_old, src_old, z, gid_old=gid_old, gid_new=gid_new)
                 for a, b, what in zip(got, want, ("ids", "sel", "back", "touched", "rows")):
                     assert np.array_equal(a, b), (name, fuse, n, what)
+                # ... and the slot FOLLOWS the proposal (sbe_given_unchanged_gibbs_apply): the same five arrays, and behind them the
+                # slot's counts, probability rows and source rows are what the explicit patches of the same data leave
+                eng.copy_slot(1, 0)
+                eng.copy_slot(2, 0)
+                comp_of = np.searchsorted(off, got[3], side="right") - 1
+                new_rows = (np.stack([counts[c][g - off[c]] for g, c in zip(got[3], comp_of)]) + got[4]) if got[3].size else None
+                if new_rows is not None and (new_rows < 0).any():
+                    continue                                          # (this test's made-up old state took counts that are not there)
+                fol = eng.given_unchanged_gibbs(1, k, objs, hc_new, hc_old, src_old, z, gid_old=gid_old, gid_new=gid_new, follow=True,
+                                                update_probs=True)
+                for a, b, what in zip(fol, got, ("ids", "sel", "back", "touched", "rows")):
+                    assert np.array_equal(a, b), (name, fuse, n, what, "with the slot following")
+                if got[3].size:
+                    eng.set_counts_rows(2, got[3], new_rows, update_probs=True)
+                    eng.set_source_rows(2, objs, got[0][..., None] == np.arange(C, dtype=np.uint8))
+                for c in range(C):
+                    assert np.array_equal(eng.get_counts(1, c), eng.get_counts(2, c)), (name, fuse, n, c, "following counts")
+                    assert np.array_equal(eng.get_probs(1, c), eng.get_probs(2, c)), (name, fuse, n, c, "following probability rows")
+                assert np.array_equal(eng.get_source_rows(1, objs), eng.get_source_rows(2, objs)), (name, fuse, n, "following source rows")
     finally:
         eng.close()
 
