@@ -53,7 +53,7 @@ typedef struct sbe_engine sbe_engine;
                                5: + SBE_OPT_FUSE_TABLES, sbe_host_subset_ids, sbe_host_diff_rows, sbe_set_counts_rows_probs,
                                sbe_gibbs_propose, sbe_given_unchanged_gibbs_counts, sbe_test_roundtrip,
                                sbe_collapsed_and_source_prior, sbe_counts_delta_apply,
-                               sbe_given_unchanged_gibbs_apply */
+                               sbe_given_unchanged_gibbs_apply, sbe_gibbs_propose_apply */
 
 /* error codes */
 #define SBE_OK 0
@@ -601,6 +601,13 @@ int sbe_step_batch_delta(sbe_engine* e, int n_chains, const int32_t* cur_slots, 
    large subsets; the call-by-call forms remain). */
 int sbe_gibbs_propose_supported(sbe_engine* e);
 int sbe_gibbs_propose(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* objects, int n_sub, double temperature,
+                      double prior_temperature, int from_prior, const double* z, uint8_t* src_new_out, float* sel_out,
+                      float* sel_back_out, int32_t* touched_out, int32_t* n_touched_out, float* diff_rows_out);
+/* ... and the CURRENT slot takes the proposal (cf. sbe_counts_delta_apply): when it touches any group, cur_slot's counts,
+ * the touched groups' probability tables and the subset's source rows become the proposal's -- inside the same launch
+ * (tables and ids behind its completion flag), or as a copy of the candidate slot behind the chain form -- so the bind
+ * of the sample the caller builds from these results has nothing to send. */
+int sbe_gibbs_propose_apply(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* objects, int n_sub, double temperature,
                       double prior_temperature, int from_prior, const double* z, uint8_t* src_new_out, float* sel_out,
                       float* sel_back_out, int32_t* touched_out, int32_t* n_touched_out, float* diff_rows_out);
 int sbe_gibbs_step(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* objects, int n_sub, double temperature,

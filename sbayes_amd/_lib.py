@@ -143,6 +143,8 @@ PROTOTYPES = {
     "sbe_gibbs_propose_supported": (ct.c_int, [c_engine_p]),
     "sbe_gibbs_propose": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double, ct.c_int,
                                      ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p]),
+    "sbe_gibbs_propose_apply": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double, ct.c_int,
+                                           ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p]),
     "sbe_copy_slot": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int]),
     "sbe_timer_start": (ct.c_int, [c_engine_p]),
     "sbe_timer_stop": (ct.c_int, [c_engine_p, ct.POINTER(ct.c_float)]),

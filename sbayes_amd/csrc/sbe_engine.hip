@@ -4597,9 +4597,12 @@ int sbe_gibbs_propose_supported(sbe_engine* e) {                       // 1: the
     return ((int64_t)e->Gtot * e->S * 28 <= 60 * 1024) ? 1 : 0;          // (the fused table kernel of the step core)
 }
 
-int sbe_gibbs_propose(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* objects, int n_sub, double temperature,
-                      double prior_temperature, int from_prior, const double* z, uint8_t* src_new_out, float* sel_out,
-                      float* sel_back_out, int32_t* touched_out, int32_t* n_touched_out, float* diff_rows_out) {
+// `follow` (sbe_gibbs_propose_apply): when the proposal touches any group, the CURRENT slot takes it -- counts, the touched
+// groups' tables, the drawn source rows -- inside the tile kernel (tables and ids behind its completion flag), or as a copy of
+// the candidate slot behind the chain form.
+static int gibbs_propose_impl(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* objects, int n_sub, double temperature,
+                              double prior_temperature, int from_prior, const double* z, uint8_t* src_new_out, float* sel_out,
+                              float* sel_back_out, int32_t* touched_out, int32_t* n_touched_out, float* diff_rows_out, int follow) {
     CHECK_ENGINE(e); CHECK_SLOT(e, cur_slot); CHECK_SLOT(e, cand_slot);
     CHECK_PTR(e, src_new_out); CHECK_PTR(e, sel_out); CHECK_PTR(e, sel_back_out); CHECK_PTR(e, touched_out); CHECK_PTR(e, n_touched_out);
     CHECK_PTR(e, diff_rows_out); CHECK_PTR(e, z);
@@ -4685,6 +4688,13 @@ int sbe_gibbs_propose(sbe_engine* e, int cur_slot, int cand_slot, const int32_t*
             const double inv_t = 1.0 / temperature, inv_tp = 1.0 / prior_temperature;
             ta.inv_t = inv_t; ta.inv_tp = (float)inv_tp; ta.pow_lh = inv_t != 1.0; ta.pow_w = inv_tp != 1.0; ta.from_prior = from_prior != 0;
             ta.status = e->d_status;
+            if (follow && n_touched > 0) {
+                ta.follow.counts = e->d_counts + (int64_t)cur_slot * e->table_elems();
+                ta.follow.probs = e->d_probs + (int64_t)cur_slot * e->table_elems();
+                ta.follow.probs_t = e->d_probs_t + (int64_t)cur_slot * e->probs_t_elems();
+                ta.follow.ft = e->ft;
+                ta.follow.src = e->d_src + (int64_t)cur_slot * N * e->Fp;
+            }
             const unsigned blocks = (unsigned)div_up(F, 16);
             const DoneSig done = next_done(e, blocks);
             k_gibbs_propose_tile<<<blocks, kTileBlock, t_lds, e->stream>>>(ta, done);
@@ -4783,7 +4793,22 @@ int sbe_gibbs_propose(sbe_engine* e, int cur_slot, int cand_slot, const int32_t*
     memcpy(sel_out, h + in_bytes + idb, (size_t)n_obs * sizeof(float));
     memcpy(sel_back_out, h + in_bytes + idb + selb, (size_t)n_obs * sizeof(float));
     memcpy(diff_rows_out, h + in_bytes + idb + 2 * selb, (size_t)n_touched * fs * sizeof(float));
+    if (follow && n_touched > 0) return sbe_copy_slot(e, cur_slot, cand_slot);       // (the candidate IS the proposal: one copy launch)
     return SBE_OK;
+}
+
+int sbe_gibbs_propose(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* objects, int n_sub, double temperature,
+                      double prior_temperature, int from_prior, const double* z, uint8_t* src_new_out, float* sel_out,
+                      float* sel_back_out, int32_t* touched_out, int32_t* n_touched_out, float* diff_rows_out) {
+    return gibbs_propose_impl(e, cur_slot, cand_slot, objects, n_sub, temperature, prior_temperature, from_prior, z, src_new_out, sel_out,
+                              sel_back_out, touched_out, n_touched_out, diff_rows_out, 0);
+}
+
+int sbe_gibbs_propose_apply(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* objects, int n_sub, double temperature,
+                            double prior_temperature, int from_prior, const double* z, uint8_t* src_new_out, float* sel_out,
+                            float* sel_back_out, int32_t* touched_out, int32_t* n_touched_out, float* diff_rows_out) {
+    return gibbs_propose_impl(e, cur_slot, cand_slot, objects, n_sub, temperature, prior_temperature, from_prior, z, src_new_out, sel_out,
+                              sel_back_out, touched_out, n_touched_out, diff_rows_out, 1);
 }
 
 int sbe_test_fast_log(sbe_engine* e, const double* in, int n, double* out_fast, double* out_lib) {

@@ -1739,6 +1739,12 @@ __global__ void k_gibbs_fetch(const uint8_t* __restrict__ src_cand /* [N][Fp] */
 // No candidate slot is built (the chain form: k_sample_source, k_step_core -- a whole slot copied and every table rebuilt,
 // 33 us -- k_source_logprob, k_gibbs_fetch).  LDS: staged input block | pos [Gtot] | delta / tables [T][16][S] | drawn ids [n][16].
 constexpr int kTileBlock = 1024;                 // (= kUnchangedBlock below: the 16-feature-tile operator kernels)
+// A slot that FOLLOWS a call on the device (sbe_counts_delta_apply, sbe_given_unchanged_gibbs_apply, sbe_gibbs_propose_apply):
+// its resident counts take the call's count delta, the touched groups' probability rows are rebuilt (probs != nullptr), its
+// source rows of the subset become the new ids (src != nullptr).
+struct DeltaFollow { int32_t* counts; const double* conc; float* probs; float* probs_t; int* status; int ft;
+                     uint8_t* src; /* or nullptr: the slot's [N][Fp] source ids take the subset's new rows */ };
+
 struct GibbsTileArgs {
     const uint8_t* state; const uint16_t* gid; const uint8_t* pid; const uint8_t* src; const float* probs; const float* wpat;
     const int32_t* counts; const double* conc;
@@ -1748,6 +1754,7 @@ struct GibbsTileArgs {
     int n_sub, n_touched, Gtot, Np, F, S, C, Fp;
     double inv_t; float inv_tp; int pow_lh, pow_w, from_prior;
     int* status;
+    DeltaFollow follow;              // sbe_gibbs_propose_apply: the CURRENT slot takes the proposal (counts in step 3, tables and ids behind the flag)
 };
 
 __global__ __launch_bounds__(kTileBlock) void k_gibbs_propose_tile(GibbsTileArgs a, DoneSig done) {
@@ -1837,7 +1844,13 @@ __global__ __launch_bounds__(kTileBlock) void k_gibbs_propose_tile(GibbsTileArgs
             const bool row_on = row < T * FTU && ff < a.F;
             const int64_t at = row_on ? ((int64_t)touched[tt] * a.F + ff) * S : 0;
             int32_t* h = dhist + (row_on ? (tt * FTU + tf) * S : 0);
-            probs_row_x16<W>(j, row_on, [&](int s) { return (float)(a.counts[at + s] + h[s]); }, a.conc + at, nullptr, S, 0.0, 0.0, a.status,
+            float cj = 0.0f;
+            if (row_on && j < S) {
+                const int32_t v = a.counts[at + j] + h[j];
+                if (a.follow.counts) a.follow.counts[at + j] = v;         // (the following slot: this block owns the row)
+                cj = (float)v;
+            }
+            probs_row_x16<W>(j, row_on, [&](int) { return cj; }, a.conc + at, nullptr, S, 0.0, 0.0, a.status,
                              [&](int s, float v) { h[s] = __float_as_int(v); });
         }
     };
@@ -1849,6 +1862,12 @@ __global__ __launch_bounds__(kTileBlock) void k_gibbs_propose_tile(GibbsTileArgs
             if (ff >= a.F) continue;
             const int64_t at = ((int64_t)touched[tt] * a.F + ff) * S;
             int32_t* h = dhist + (tt * FTU + tf) * S;
+            if (a.follow.counts) {
+                for (int s = 0; s < S; ++s) a.follow.counts[at + s] = a.counts[at + s] + h[s];
+                probs_row([&](int s) { return (float)a.follow.counts[at + s]; }, a.conc + at, nullptr, S, 0.0, 0.0, a.status,
+                          [&](int s, float v) { h[s] = __float_as_int(v); });
+                continue;
+            }
             probs_row([&](int s) { return (float)(a.counts[at + s] + h[s]); }, a.conc + at, nullptr, S, 0.0, 0.0, a.status,
                       [&](int s, float v) { h[s] = __float_as_int(v); });
         }
@@ -1874,6 +1893,24 @@ __global__ __launch_bounds__(kTileBlock) void k_gibbs_propose_tile(GibbsTileArgs
         a.back_out[(int64_t)r * a.F + ff] = sel;
     }
     signal_done(done);
+    if (a.follow.counts) {                               // behind the flag: the touched groups' new tables (LDS) and the drawn ids
+        if (!done.flag) __syncthreads();
+        if (a.follow.probs) {
+            for (int e = threadIdx.x; e < T * FTU * S; e += kTileBlock) {
+                const int tt = e / (FTU * S), q = e % (FTU * S), tf = q / S, s = q % S, ff = f0 + tf;
+                if (ff >= a.F) continue;
+                const int g = touched[tt];
+                a.follow.probs[((int64_t)g * a.F + ff) * S + s] = tab[e];
+                a.follow.probs_t[((((int64_t)(ff / a.follow.ft) * (a.Gtot + 1) + g) * S + s)) * a.follow.ft + ff % a.follow.ft] = tab[e];
+            }
+        }
+        if (a.follow.src) {
+            for (int t = threadIdx.x; t < n_sub * FTU; t += kTileBlock) {
+                const int r = t / FTU, tf = t % FTU;
+                if (f0 + tf < a.F) a.follow.src[(int64_t)obj[r] * a.Fp + f0 + tf] = knew[t];
+            }
+        }
+    }
 }
 
 // SourcePrior.__call__ (prior.py:573-611), per-object values:
@@ -2276,8 +2313,6 @@ constexpr int kDeltaTileMaxN = 256;
 // `follow` (sbe_counts_delta_apply): a slot whose resident counts are the OLD state's takes the difference in the same launch
 // -- counts[touched rows] += delta, and (probs != nullptr) the probability rows of those groups rebuilt (update_probs'
 // arithmetic, k_set_count_rows_probs_x's row form) -- so that the host does not send back the rows it has just received.
-struct DeltaFollow { int32_t* counts; const double* conc; float* probs; float* probs_t; int* status; int ft;
-                     uint8_t* src; /* or nullptr: the slot's [N][Fp] source ids take the subset's new rows */ };
 // The following slot's rows of one 16-feature tile (the calling block owns these features of every touched group): counts +=
 // the LDS histograms `hist` [T][16][S], and -- follow.probs -- the probability rows of those groups rebuilt (update_probs'
 // arithmetic in k_set_count_rows_probs_x's row form).  `tgl` [T]: the touched groups (LDS).  Every thread of the block calls.

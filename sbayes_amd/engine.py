@@ -924,12 +924,13 @@ class Engine:
             self._gibbs_propose_ok = self._lib.sbe_gibbs_propose_supported(self._h) == 1
         return self._gibbs_propose_ok
 
-    def gibbs_propose(self, cur_slot, cand_slot, objects, z, temperature=1.0, prior_temperature=1.0, from_prior=False):
+    def gibbs_propose(self, cur_slot, cand_slot, objects, z, temperature=1.0, prior_temperature=1.0, from_prior=False, follow=False):
         """GibbsSampleSource._propose (operators.py:495-552) in one call (sbe_gibbs_propose): the listed objects' source is
         redrawn into `cand_slot` (= `cur_slot`'s state otherwise) with the uniforms z [n, F]; counts and tables follow on
         the device.  Returns (ids uint8 [n, F]: drawn component, 255 = NA observation; sel float32 [n, F] = p[drawn];
         sel_back float32 [n, F] = p_back[old source]; touched int32 [T]: the groups the objects are in, ascending;
-        rows float32 [T, F, S]: candidate counts - current counts of those groups)."""
+        rows float32 [T, F, S]: candidate counts - current counts of those groups).  follow=True: when the proposal touches
+        any group, `cur_slot` itself takes it on the device (counts, the touched groups' tables, the drawn source rows)."""
         objs = _as(objects, np.int32).reshape(-1)
         n, F, S = objs.size, self.n_features, self.n_states
         zz = _c(z, np.float64)
@@ -942,9 +943,12 @@ class Engine:
         rows = np.empty((min(self.n_groups_total, n * self.n_components), F, S), dtype=np.float32)
         nt = ct.c_int32(0)
         self._touch(cand_slot)
-        self._check(self._lib.sbe_gibbs_propose(self._h, cur_slot, cand_slot, self._i(objs), n, float(temperature),
-                                                float(prior_temperature), int(bool(from_prior)), self._i(zz), self._o(ids),
-                                                self._o(sel), self._o(back), _ptr(touched), ct.byref(nt), _ptr(rows)))
+        if follow:
+            self._touch(cur_slot)
+        fn = self._lib.sbe_gibbs_propose_apply if follow else self._lib.sbe_gibbs_propose
+        self._check(fn(self._h, cur_slot, cand_slot, self._i(objs), n, float(temperature),
+                       float(prior_temperature), int(bool(from_prior)), self._i(zz), self._o(ids),
+                       self._o(sel), self._o(back), _ptr(touched), ct.byref(nt), _ptr(rows)))
         self.d2h_bytes += nt.value * (4 + F * S * 4)
         return ids, sel, back, touched[:nt.value], rows[:nt.value]
 

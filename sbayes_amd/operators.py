@@ -141,14 +141,29 @@ def gibbs_sample_source(model, sample, object_subset=slice(None), temperature=1.
             (objects.size < 2 or np.unique(objects).size == objects.size):
         # the whole proposal in ONE engine call (sbe_gibbs_propose): drawn ids, both selected-probability arrays and the
         # count rows that changed come back together; the sample bookkeeping below is the reference's
-        ids, sel, sel_back, touched, rows = eng.gibbs_propose(cur, new, objects, z, temperature, prior_temperature, sample_from_prior)
+        # ... and the slot takes the proposal on the device (it holds `sample`, bound above, tables current): the bind of the
+        # sample built below has nothing to send (binding.counts_follow_plan)
+        names = ["clusters", *sample.confounders]
+        plan = counts_follow_plan(eng, sample, names, cur) if counts_mod.FOLLOW_COUNTS and hasattr(eng, "_bound") else None
+        if plan is not None and (plan[2] or plan[1]["source"] is None or plan[1]["source"].shape != np.shape(sample.source.value)):
+            plan = None
+        if plan is not None:
+            ids, sel, sel_back, touched, rows = eng.gibbs_propose(cur, new, objects, z, temperature, prior_temperature, sample_from_prior,
+                                                                  follow=True)
+        else:
+            ids, sel, sel_back, touched, rows = eng.gibbs_propose(cur, new, objects, z, temperature, prior_temperature, sample_from_prior)
         valid = ids != 255                                   # (= ~na_features[objects]: NA observations get no component)
         with np.errstate(divide="ignore"):
             log_q = np.log(sel[valid]).sum()
             log_q_back = np.log(sel_back[valid]).sum()
         sample_new = sample.copy()
         sample_new.source.set_groups(object_subset, ids[..., None] == np.arange(eng.n_components, dtype=np.uint8))
-        apply_count_rows(sample_new.feature_counts, ["clusters", *sample_new.confounders], eng.group_offsets, touched, rows)
+        bounds = apply_count_rows(sample_new.feature_counts, names, eng.group_offsets, touched, rows, return_bounds=True)
+        if plan is not None:
+            if touched.size:                                 # (the engine's rule: nothing touched, nothing follows)
+                counts_followed(eng, plan, sample_new, names, touched, bounds, True, objects, cur)
+            else:
+                eng._bound[cur], eng._mirror[cur] = plan[0], plan[1]
         return sample_new, log_q, log_q_back
     eng.copy_slot(new, cur)
     _, sel = eng.sample_source(cur, new, objects, z, temperature, prior_temperature, sample_from_prior,

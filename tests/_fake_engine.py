@@ -396,8 +396,9 @@ class FakeEngine:
     def gibbs_propose_supported(self):
         return True
 
-    def gibbs_propose(self, cur_slot, cand_slot, objects, z, temperature=1.0, prior_temperature=1.0, from_prior=False):
-        """GibbsSampleSource._propose in one call, composed of the double's own pieces (class-qualified: ONE logged call)."""
+    def gibbs_propose(self, cur_slot, cand_slot, objects, z, temperature=1.0, prior_temperature=1.0, from_prior=False, follow=False):
+        """GibbsSampleSource._propose in one call, composed of the double's own pieces (class-qualified: ONE logged call).
+        follow: when any group is touched, the current slot takes the proposal (it becomes the candidate's state)."""
         objects = np.asarray(objects)
         n_calls = len(self.calls)
         FakeEngine.copy_slot(self, cand_slot, cur_slot)
@@ -421,6 +422,10 @@ class FakeEngine:
         for j, gg in enumerate(touched):
             c = int(np.searchsorted(off, gg, side="right") - 1)
             rows[j] = cand["counts"][c][gg - off[c]] - cur["counts"][c][gg - off[c]]
+        if follow and touched.size:
+            import copy
+            self._touch(cur_slot)
+            self.slots[cur_slot] = copy.deepcopy(cand)
         return ids, np.asarray(sel, dtype=np.float32), np.asarray(back, dtype=np.float32), touched, rows
 
     def cluster_posterior_marginals(self, slot, i_cluster, objects, temperature=1.0, prior_temperature=1.0):

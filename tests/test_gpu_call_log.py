@@ -20,4 +20,4 @@ pytestmark = pytest.mark.gpu
 def test_recorded_sampler_calls_on_the_device(tag):
     feats = features_of(tag)
     counts, meta = replay(GOLDEN / f"{tag}_calls.npz", lambda n_groups: Engine(feats, n_groups, n_slots=4))
-    assert sum(counts.values()) > 500 and counts["__step__"] >= 48
+    assert sum(counts.values()) > 400 and counts["__step__"] >= 48      # (fewer calls every round: 633 -> 491 for 48 headline steps)

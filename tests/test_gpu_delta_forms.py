@@ -350,6 +350,22 @@ def test_gibbs_propose_in_one_call(name):
                 for c in range(C):
                     assert np.array_equal(eng.get_counts(1, c), fake._slot(1)["counts"][c]), (name, c)
                 assert np.array_equal(eng.likelihood_per_component(1), fake._state(1)[2])      # (the candidate's tables)
+                # ... and with follow=True the CURRENT slot takes the proposal (sbe_gibbs_propose_apply), in both forms: the same
+                # five arrays, and the slot ends as the candidate -- source rows, counts, tables (and their tile-transposed copy)
+                for tile_form in (True, False):
+                    eng.set_option(fuse_tables=tile_form)
+                    eng.copy_slot(2, 0)
+                    got_f = eng.gibbs_propose(2, 1, objs, z, temp, ptemp, from_prior, follow=True)
+                    for a, b in zip(got_f, results[0]):
+                        assert np.array_equal(a, b), (name, n, temp, from_prior, tile_form, "with the slot following")
+                    if got_f[3].size:
+                        assert np.array_equal(eng.get_source_rows(2, everyone), fake.get_source_rows(1, everyone)), (name, n, tile_form)
+                        for c in range(C):
+                            assert np.array_equal(eng.get_counts(2, c), fake._slot(1)["counts"][c]), (name, c, tile_form)
+                        assert np.array_equal(eng.likelihood_per_component(2), fake._state(1)[2]), (name, n, tile_form)
+                        eng.set_option(fuse_tables=False)
+                        eng.gibbs_propose(0, 1, objs, z, temp, ptemp, from_prior)               # (the chain form's candidate in slot 1)
+                        assert eng.mixture_loglik(2) == eng.mixture_loglik(1), (name, n, tile_form)
         eng.set_option(fuse_tables=True)
         with pytest.raises(Exception, match="differ"):
             eng.gibbs_propose(0, 0, [0], np.zeros((1, F)))
