@@ -93,6 +93,44 @@ def forms_case(rng, eng, feats, n_groups, conc, state, tag, stats):
                 ok_ = np.isfinite(b_) if b_.dtype != np.uint8 else np.ones(b_.shape, dtype=bool)
                 assert np.array_equal(a_[ok_], b_[ok_]), (tag, "given_unchanged_gibbs", what)
             stats["cluster_gibbs"] = stats.get("cluster_gibbs", 0) + 1
+            # ... the same call with its count delta, plain and with the slot FOLLOWING (sbe_given_unchanged_gibbs_apply): the same
+            # five arrays; the following slot ends as the explicit patches of the same data leave it
+            gid_n = np.stack([np.where(g[:, objs].any(axis=0), g[:, objs].argmax(axis=0) + eng.group_offsets[c_], -1).astype(np.int32)
+                              for c_, g in enumerate(groups)])
+            gid_o = gid_n.copy()
+            gid_o[0] = np.where(hc_old[:, 0], np.maximum(gid_n[0], 0), -1)
+            with_c = eng.given_unchanged_gibbs(0, i_cl, objs, hc_new, hc_old, so_g, zz, from_prior=from_prior, gid_old=gid_o, gid_new=gid_n)
+            sa_, sb_ = eng.n_slots - 1, eng.n_slots - 2
+            eng.copy_slot(sa_, 0); eng.copy_slot(sb_, 0)
+            eng.update_probs(sa_, range(C)); eng.update_probs(sb_, range(C))
+            off_ = eng.group_offsets
+            comp_ = np.searchsorted(off_, with_c[3], side="right") - 1
+            rows_n = (np.stack([counts[c_][g_ - off_[c_]] for g_, c_ in zip(with_c[3], comp_)]) + with_c[4]) if with_c[3].size else None
+            if rows_n is None or (rows_n >= 0).all():
+                fol = eng.given_unchanged_gibbs(sa_, i_cl, objs, hc_new, hc_old, so_g, zz, from_prior=from_prior, gid_old=gid_o, gid_new=gid_n,
+                                                follow=True, update_probs=True)
+                for a_, b_, what in zip(fol, with_c, ("ids", "sel", "back", "touched", "rows")):
+                    assert np.array_equal(a_, b_, equal_nan=True) if a_.dtype.kind == "f" else np.array_equal(a_, b_), (tag, "cluster gibbs following", what)
+                ok_rows = True
+                if with_c[3].size:
+                    try:
+                        eng.set_counts_rows(sb_, with_c[3], rows_n, update_probs=True)
+                        eng.sync()
+                    except Exception as exc:
+                        ok_rows = False
+                        assert "normali" in str(exc).lower(), (tag, exc)
+                    eng.set_source_rows(sb_, objs, with_c[0][..., None] == np.arange(C, dtype=np.uint8))
+                if ok_rows:
+                    for c_ in range(C):
+                        assert np.array_equal(eng.get_counts(sa_, c_), eng.get_counts(sb_, c_)), (tag, "cluster gibbs: following counts", c_)
+                        assert np.array_equal(eng.get_probs(sa_, c_), eng.get_probs(sb_, c_)), (tag, "cluster gibbs: following tables", c_)
+                    assert np.array_equal(eng.get_source_rows(sa_, objs), eng.get_source_rows(sb_, objs)), (tag, "cluster gibbs: following source rows")
+                    stats["gibbs_follow"] = stats.get("gibbs_follow", 0) + 1
+                else:
+                    try:
+                        eng.sync()
+                    except Exception:
+                        pass
     with np.errstate(divide="ignore", invalid="ignore"):
         want = fake.cluster_posterior_marginals(0, i_cl, objs)
         got = eng.cluster_posterior_marginals(0, i_cl, objs)
@@ -182,6 +220,17 @@ def forms_case(rng, eng, feats, n_groups, conc, state, tag, stats):
             for a_, b_, what in zip(got_p, want_p, ("ids", "p[drawn]", "p_back[old]", "touched", "count rows")):
                 assert a_.shape == b_.shape and np.array_equal(a_, b_), (tag, "gibbs_propose", what)
             stats["gibbs_propose"] = stats.get("gibbs_propose", 0) + 1
+            # ... and with the current slot FOLLOWING (sbe_gibbs_propose_apply): it ends as the double's candidate
+            eng.copy_slot(s2, 0)
+            eng.update_probs(s2, range(C))
+            got_f = eng.gibbs_propose(s2, s1, objs, zz, from_prior=from_prior, follow=True)
+            for a_, b_, what in zip(got_f, want_p, ("ids", "p[drawn]", "p_back[old]", "touched", "count rows")):
+                assert np.array_equal(a_, b_), (tag, "gibbs_propose following", what)
+            if got_f[3].size:
+                assert np.array_equal(eng.get_source_rows(s2, objs), fake.get_source_rows(1, objs)), (tag, "gibbs_propose: following source rows")
+                for c_ in range(C):
+                    assert np.array_equal(eng.get_counts(s2, c_), fake._slot(1)["counts"][c_]), (tag, "gibbs_propose: following counts", c_)
+                assert np.array_equal(eng.likelihood_per_component(s2), fake._state(1)[2]), (tag, "gibbs_propose: following tables")
     # third session: likelihood + prior in one call = the two calls, bit for bit; a slot walked through cluster moves (ids,
     # pattern / tuple tables followed on the host, per-pattern weights: one launch per sbe_set_groups) = a slot set at once
     pg, po = eng.collapsed_and_source_prior(0)

@@ -50,6 +50,16 @@ def main():
             rows_val = (counts[0][:1] + v).astype(np.float32)
             variants.append((objs, hc, so, z, gid, rows_val, available[v::2].copy(), members[v::2].copy(), v % K))
         rows_idx = np.array([0], dtype=np.int32)
+        eng.copy_slot(2, 0)                               # the FOLLOWING slot of the *_apply forms (third session)
+
+        def follow_pair(objs, gid, so):
+            """A slot follows a difference and its reverse (sbe_counts_delta_apply: counts, probability rows and source rows
+            behind the completion flag): what is read back right after each call is complete, and the slot returns to its base."""
+            sn = np.where(so == 255, 255, (so + 1) % C).astype(np.uint8)
+            _, d1 = eng.counts_delta(objs, gid, gid, so, sn, follow_slot=2, update_probs=True, update_source=True)
+            c1, p1, s1 = eng.get_counts(2, 0), eng.get_probs(2, 0), eng.get_source_rows(2, objs)
+            _, d2 = eng.counts_delta(objs, gid, gid, sn, so, follow_slot=2, update_probs=True, update_source=True)
+            return d1, c1, p1, s1, d2, eng.get_counts(2, 0), eng.get_probs(2, 0), eng.get_source_rows(2, objs)
 
         def forms(v):
             objs, hc, so, z, gid, rows_val, avail, memb, k = variants[v]
@@ -61,6 +71,7 @@ def main():
                 "gibbs_propose": (lambda: eng.gibbs_propose(0, 1, objs, z)) if eng.gibbs_propose_supported() else None,
                 "set_counts_rows(update_probs) + mixture": lambda: (eng.set_counts_rows(0, rows_idx, rows_val, update_probs=True), eng.mixture_loglik(0))[1],
                 "counts_delta": lambda: eng.counts_delta(objs, gid, gid, so, np.where(so == 255, 255, (so + 1) % C).astype(np.uint8)),
+                "counts_delta, a slot following + back": (lambda: follow_pair(objs, gid, so)) if C > 1 else None,
             }
         f0, f1 = forms(0), forms(1)
         for label in f0:
