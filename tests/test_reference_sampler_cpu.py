@@ -162,6 +162,27 @@ def test_reference_sampler_with_the_gibbs_source_proposal_on_the_device(tag, src
     assert "source_posterior" not in kinds or tag == "south_america"                # (ClusterJump's own gibbs_sample_source_jump still asks the posterior)
 
 
+def test_reference_sampler_without_the_following_slot(monkeypatch, tmp_path):
+    """sbayes_amd.counts.FOLLOW_COUNTS = False: the count differences come back without the slot following
+    them, the next bind sends the rows -- the round's earlier form, kept as a switch.  Still the reference's Markov chain; and
+    with the switch on (the default, every other test of this file) fewer row uploads for the same steps."""
+    import sbayes_amd.counts as counts_mod
+    src, tag, n_steps = Path(REF) / "test" / "test_files", "test_files", 150
+    plain = run_chain(src, tag, n_steps, 11, False, monkeypatch, tmp_path)
+    (tmp_path / "following").mkdir()
+    (tmp_path / "plain_binds").mkdir()
+    following = run_chain(src, tag, n_steps, 11, True, monkeypatch, tmp_path / "following", operators=True, gibbs_source=True)
+    rows_following = sum(c[0] in ("set_counts_rows", "set_source_rows") for c in next(iter(following[4].values())).calls)
+    monkeypatch.setattr(counts_mod, "FOLLOW_COUNTS", False)
+    patched = run_chain(src, tag, n_steps, 11, True, monkeypatch, tmp_path / "plain_binds", operators=True, gibbs_source=True)
+    rows_sent = sum(c[0] in ("set_counts_rows", "set_source_rows") for c in next(iter(patched[4].values())).calls)
+    for run in (following, patched):
+        assert [t[2] for t in run[0]] == [t[2] for t in plain[0]]
+        np.testing.assert_allclose([t[:2] for t in run[0]], [t[:2] for t in plain[0]], rtol=1e-12)
+        assert np.array_equal(run[1], plain[1]) and np.array_equal(run[2], plain[2]) and np.array_equal(run[3], plain[3])
+    assert rows_following < rows_sent, (rows_following, rows_sent)
+
+
 def test_operator_forms_are_tied_to_the_reference_bodies_they_mirror(monkeypatch):
     """patch.install(operators=True) replaces whole reference methods; each replacement is tied to the SHA-1 of the
     reference body it mirrors (patch.MIRRORED_SOURCES), so a reference revision that changes one of them is reported
