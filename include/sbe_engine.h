@@ -53,7 +53,8 @@ typedef struct sbe_engine sbe_engine;
                                5: + SBE_OPT_FUSE_TABLES, sbe_host_subset_ids, sbe_host_diff_rows, sbe_set_counts_rows_probs,
                                sbe_gibbs_propose, sbe_given_unchanged_gibbs_counts, sbe_test_roundtrip,
                                sbe_collapsed_and_source_prior, sbe_counts_delta_apply,
-                               sbe_given_unchanged_gibbs_apply, sbe_gibbs_propose_apply */
+                               sbe_given_unchanged_gibbs_apply, sbe_gibbs_propose_apply,
+                               sbe_set_slot_delta */
 
 /* error codes */
 #define SBE_OK 0
@@ -173,6 +174,16 @@ int sbe_likelihood_per_component_exact(sbe_engine* e, int slot, double* out);
  * distinct patterns than the engine holds (min(2^C, 64)) is reported by the next call that reads them. */
 int sbe_set_groups(sbe_engine* e, int slot, int component, const uint8_t* groups /* [G_c][N] bool */);
 int sbe_set_group_ids(sbe_engine* e, int slot, int component, const int32_t* ids /* [N], -1 = none */);
+
+/* sbe_set_slot_delta: several state-setting calls of one bind (conditionals._bind_slot: after a rejected step "the old group
+ * ids and the old count rows", after a proposal "the new group ids and the new source rows") as ONE launch.  Exactly
+ * sbe_set_groups(slot, groups_component, groups) when groups != NULL, then sbe_set_counts_rows (update_probs = 0) or
+ * sbe_set_counts_rows_probs (update_probs != 0) when n_count_rows > 0, then sbe_set_source_rows when n_src_rows > 0 -- the
+ * same checks and results; the kernels are issued together when the inputs went through the mapped staging ring (the three
+ * touch disjoint resident arrays), one after the other otherwise or with SBE_OPT_DEFERRED_CHECKS off. */
+int sbe_set_slot_delta(sbe_engine* e, int slot, int groups_component, const uint8_t* groups /* [G_c][N] bool or NULL */,
+                       const int32_t* count_idx, int n_count_rows, const float* count_rows /* [n][F][S] */, int update_probs,
+                       const int32_t* src_objects, int n_src_rows, const uint8_t* src_rows /* [n][F][C] bool */);
 
 /* ---- slot state: source (state.py:510, bool [N][F][C] one-hot over components) --------- */
 int sbe_set_source(sbe_engine* e, int slot, const uint8_t* source /* [N][F][C] bool */);

@@ -105,6 +105,8 @@ PROTOTYPES = {
     "sbe_counts_delta_apply": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p,
                                           ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_set_counts_rows": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),
+    "sbe_set_slot_delta": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int,
+                                      ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_set_counts_rows_probs": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_given_unchanged_lh": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double, ct.c_double,
                                           ct.c_void_p]),

@@ -126,19 +126,20 @@ def _send_counts(eng, slot, c, new, mirror, pending):
 
 
 def _send_source(eng, slot, new, mirror):
+    """Bring the slot's source to `new`; returns (mirror, rows op): a whole-array change goes up at once, a few changed rows are
+    handed back as (object indices, rows) for _bind_slot to send -- alone, or with the bind's other row uploads in one launch."""
     if type(new) is not _ndarray or new.dtype != np.bool_:
         new = np.asarray(new, dtype=bool)
     if mirror is None or mirror.shape != new.shape:
         eng.set_source(slot, new)
-        return new.copy()
+        return new.copy(), None
     rows = _changed_rows(new, mirror)                # (the mirror now holds `new`)
     if rows.size == 0:
-        return mirror
+        return mirror, None
     if 2 * rows.size > new.shape[0]:
         eng.set_source(slot, new)
-        return mirror
-    eng.set_source_rows(slot, rows, new[rows])
-    return mirror
+        return mirror, None
+    return mirror, (rows, new[rows])
 
 
 def _bind_slot(eng, model, sample, slot, with_source=False):
@@ -236,8 +237,14 @@ def _bind_slot(eng, model, sample, slot, with_source=False):
     if conc_changed:
         new["stale"] = set(range(C))
         new["lh_all"] = None
+    # one changed group matrix, the changed count rows and the changed source rows of a bind go up in ONE launch when the
+    # engine has the combined call (Engine.set_slot_delta) and at least two of them are there; else call by call, in this order
+    groups_op = None
     for c in groups_changed:
-        eng.set_groups(slot, c, groups[c][0])
+        if len(groups_changed) == 1 and hasattr(eng, "set_slot_delta"):
+            groups_op = (c, groups[c][0])
+        else:
+            eng.set_groups(slot, c, groups[c][0])
         new["groups"][c] = _remember(groups[c])
     was_stale = set(new["stale"])
     by_rows = []                                    # components whose change goes up as rows
@@ -251,6 +258,7 @@ def _bind_slot(eng, model, sample, slot, with_source=False):
             else:
                 new["stale"].add(c)                 # (the component went up whole: every table row is stale)
             new["lh_all"] = None                    # (Likelihood._group_logliks' memo of the collapsed log-likelihoods)
+    rows_op = None
     if pending[0]:
         # the probability rows of the patched groups are rebuilt by the same launch when the tables of those components
         # were current (the usual case inside a step: the slot held the sample this one was copied from) -- nothing is
@@ -258,14 +266,26 @@ def _bind_slot(eng, model, sample, slot, with_source=False):
         fused = _ROWS_WITH_PROBS and all(c not in was_stale for c in by_rows)
         idx = pending[0][0] if len(pending[0]) == 1 else np.concatenate(pending[0])
         rows = pending[1][0] if len(pending[1]) == 1 else np.concatenate(pending[1])
-        if fused:
-            eng.set_counts_rows(slot, idx, rows, update_probs=True)
-        else:
-            eng.set_counts_rows(slot, idx, rows)
+        rows_op = (idx, rows, fused)
+        if not fused:
             new["stale"].update(by_rows)
+    source_op = None
     if source_changed:
-        mirrors["source"] = _send_source(eng, slot, source[0], mirrors["source"])
+        mirrors["source"], source_op = _send_source(eng, slot, source[0], mirrors["source"])
         new["source"] = _remember(source)
+    if (groups_op is not None) + (rows_op is not None) + (source_op is not None) >= 2:
+        eng.set_slot_delta(slot,
+                           groups_component=groups_op[0] if groups_op else 0, groups=groups_op[1] if groups_op else None,
+                           count_idx=rows_op[0] if rows_op else None, count_rows=rows_op[1] if rows_op else None,
+                           update_probs=bool(rows_op[2]) if rows_op else False,
+                           source_objects=source_op[0] if source_op else None, source_rows=source_op[1] if source_op else None)
+    else:
+        if groups_op is not None:
+            eng.set_groups(slot, groups_op[0], groups_op[1])
+        if rows_op is not None:
+            eng.set_counts_rows(slot, rows_op[0], rows_op[1], update_probs=True) if rows_op[2] else eng.set_counts_rows(slot, rows_op[0], rows_op[1])
+        if source_op is not None:
+            eng.set_source_rows(slot, source_op[0], source_op[1])
     if weights_changed:
         eng.set_weights(slot, weights[0])
         new["weights"] = _remember(weights)

@@ -160,6 +160,7 @@ struct sbe_engine {
     uint8_t* d_scratch = nullptr;  size_t scratch_bytes = 0;     // general staging
     uint8_t* h_pinned = nullptr;   size_t pinned_bytes = 0;      // pinned D2H staging
     uint8_t* h_arena = nullptr;    uint8_t* d_arena = nullptr;   size_t arena_bytes = 0, arena_off = 0;   // pinned, host-mapped H2D staging ring
+    SetterJobs* batch = nullptr;   // sbe_set_slot_delta: the setters' launches are collected here and issued as ONE kernel
     int opt_step_form = 0;         // SBE_OPT_STEP_FORM
     int opt_step_derive = 0;       // SBE_OPT_STEP_DERIVE: 1 = always re-derive patterns / tuples from all objects
     int opt_deferred = 0;          // SBE_OPT_DEFERRED_CHECKS: data checks reported at the next sync
@@ -475,14 +476,23 @@ int upload_segments(sbe_engine* e, const UploadSeg* segs, int n, FusedWeightPatt
         off += (segs[i].bytes + 63) / 64 * 64;
     }
     const unsigned sx = (unsigned)std::min<size_t>(div_up((int64_t)largest, 1024), 16);
+    unsigned wx = 0;
     if (fuse) {
         if (w_bytes) {
             memcpy(e->h_arena + e->arena_off + off, wp->new_weights, w_bytes);
             wp->args.weights = (const float*)(e->d_arena + e->arena_off + off);
         }
-        const unsigned wx = (unsigned)div_up((int64_t)wp->args.P * wp->args.F, 256);
-        k_scatter_weight_patterns<<<dim3(std::max(sx, wx), sg.n + 1), 256, 0, e->stream>>>(e->d_arena + e->arena_off, sg, wp->args);
+        wx = (unsigned)div_up((int64_t)wp->args.P * wp->args.F, 256);
         wp->done = true;
+    }
+    if (e->batch && e->batch->n_group_blocks == 0 && (fuse || !wp)) {   // (sbe_set_slot_delta: launched with the call's other setters;
+                                                                        //  never when a separate weight kernel would follow the scatter)
+        SetterJobs& j = *e->batch;
+        j.group_base = e->d_arena + e->arena_off; j.sg = sg; j.has_wp = fuse ? 1 : 0;
+        if (fuse) j.wp = wp->args;
+        j.group_gx = std::max(sx, wx); j.n_group_blocks = j.group_gx * (unsigned)(sg.n + (fuse ? 1 : 0));
+    } else if (fuse) {
+        k_scatter_weight_patterns<<<dim3(std::max(sx, wx), sg.n + 1), 256, 0, e->stream>>>(e->d_arena + e->arena_off, sg, wp->args);
     } else {
         k_scatter_bytes<<<dim3(sx, sg.n), 256, 0, e->stream>>>(e->d_arena + e->arena_off, sg);
     }
@@ -1704,9 +1714,16 @@ int sbe_set_source_rows(sbe_engine* e, int slot, const int32_t* objects, int n_r
     if (rc) return rc;
     rc = stage(e, objects, (size_t)n_rows * sizeof(int32_t), e->d_scratch + row_pad, &v_obj);
     if (rc) return rc;
-    k_ingest_source<<<div_up((int64_t)n_rows * e->F, 256), 256, 0, e->stream>>>(
-        (const uint8_t*)v_rows, (const int32_t*)v_obj, e->d_src + (int64_t)slot * e->N * e->Fp, n_rows, e->F, e->C, e->Fp, e->d_status);
-    HIPCHK(e, hipGetLastError());
+    if (e->batch && e->batch->n_src_blocks == 0 && v_rows != (const void*)e->d_scratch) {     // (staged in the ring: sbe_set_slot_delta launches it)
+        SetterJobs& j = *e->batch;
+        j.src_rows = (const uint8_t*)v_rows; j.src_objects = (const int32_t*)v_obj; j.src_id = e->d_src + (int64_t)slot * e->N * e->Fp;
+        j.src_n = n_rows; j.src_F = e->F; j.src_C = e->C; j.src_Fp = e->Fp; j.src_status = e->d_status;
+        j.n_src_blocks = (unsigned)div_up((int64_t)n_rows * e->F, 256);
+    } else {
+        k_ingest_source<<<div_up((int64_t)n_rows * e->F, 256), 256, 0, e->stream>>>(
+            (const uint8_t*)v_rows, (const int32_t*)v_obj, e->d_src + (int64_t)slot * e->N * e->Fp, n_rows, e->F, e->C, e->Fp, e->d_status);
+        HIPCHK(e, hipGetLastError());
+    }
     bump_src(e, slot);
     return check_after(e, ST_MULTI_SOURCE);
 }
@@ -2773,23 +2790,33 @@ static int set_counts_rows_impl(sbe_engine* e, int slot, const int32_t* group_id
     if (rc) return rc;
     rc = stage(e, group_idx, (size_t)n_rows * sizeof(int32_t), e->d_scratch + rb, &v_idx);
     if (rc) return rc;
+    if (with_probs) { rc = clear_status_word(e, ST_BAD_NORMALIZE); if (rc) return rc; }
+    const int kind = !with_probs ? 0 : e->S <= 8 ? 8 : e->S <= 16 ? 16 : 1;
+    const int lanes_per_row = kind == 8 ? 8 : kind == 16 ? 16 : 1;
+    const int64_t n_threads = kind == 0 ? (int64_t)n_rows * fs : (int64_t)n_rows * e->F * lanes_per_row;
+    if (e->batch && e->batch->n_rows_blocks == 0 && v_rows != (const void*)e->d_scratch) {     // (staged in the ring: sbe_set_slot_delta launches it)
+        SetterJobs& j = *e->batch;
+        j.rows = CountRowsArgs{(const float*)v_rows, (const int32_t*)v_idx, e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc,
+                               e->d_probs + (int64_t)slot * e->table_elems(), e->d_probs_t + (int64_t)slot * e->probs_t_elems(), n_rows,
+                               e->F, e->S, e->Gtot, e->ft, e->d_status};
+        j.rows_kind = kind; j.n_rows_blocks = (unsigned)div_up(n_threads, 256);
+        return with_probs ? check_after(e, ST_BAD_NORMALIZE, "sbe_set_counts_rows_probs") : SBE_OK;
+    }
     if (!with_probs) {
         k_set_count_rows<<<div_up((int64_t)n_rows * fs, 256), 256, 0, e->stream>>>(
             (const float*)v_rows, (const int32_t*)v_idx, e->d_counts + (int64_t)slot * e->table_elems(), n_rows, fs);
         HIPCHK(e, hipGetLastError());
         return SBE_OK;
     }
-    rc = clear_status_word(e, ST_BAD_NORMALIZE);
-    if (rc) return rc;
-    auto launch = [&](auto kernel, int lanes_per_row) {
-        kernel<<<div_up((int64_t)n_rows * e->F * lanes_per_row, 256), 256, 0, e->stream>>>(
+    auto launch = [&](auto kernel) {
+        kernel<<<div_up(n_threads, 256), 256, 0, e->stream>>>(
             (const float*)v_rows, (const int32_t*)v_idx, e->d_counts + (int64_t)slot * e->table_elems(), e->d_conc,
             e->d_probs + (int64_t)slot * e->table_elems(), e->d_probs_t + (int64_t)slot * e->probs_t_elems(), n_rows, e->F, e->S, e->Gtot,
             e->ft, e->d_status);
     };
-    if (e->S <= 8) launch(k_set_count_rows_probs_x<8>, 8);
-    else if (e->S <= 16) launch(k_set_count_rows_probs_x<16>, 16);
-    else launch(k_set_count_rows_probs, 1);
+    if (kind == 8) launch(k_set_count_rows_probs_x<8>);
+    else if (kind == 16) launch(k_set_count_rows_probs_x<16>);
+    else launch(k_set_count_rows_probs);
     HIPCHK(e, hipGetLastError());
     return check_after(e, ST_BAD_NORMALIZE, "sbe_set_counts_rows_probs");
 }
@@ -2800,6 +2827,31 @@ int sbe_set_counts_rows(sbe_engine* e, int slot, const int32_t* group_idx, int n
 
 int sbe_set_counts_rows_probs(sbe_engine* e, int slot, const int32_t* group_idx, int n_rows, const float* rows) {
     return set_counts_rows_impl(e, slot, group_idx, n_rows, rows, true);
+}
+
+// Several state-setting calls of one bind as ONE launch: sbe_set_groups (groups != NULL), sbe_set_counts_rows /
+// sbe_set_counts_rows_probs (n_count_rows > 0), sbe_set_source_rows (n_src_rows > 0) -- the same checks, the same host-side
+// work and the same results as those calls in that order; their kernels (the three jobs touch disjoint resident arrays) are
+// collected and issued together (k_apply_setters) when their inputs went through the mapped ring, one by one otherwise.
+int sbe_set_slot_delta(sbe_engine* e, int slot, int groups_component, const uint8_t* groups, const int32_t* count_idx, int n_count_rows,
+                       const float* count_rows, int update_probs, const int32_t* src_objects, int n_src_rows, const uint8_t* src_rows) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot);
+    SetterJobs jobs{};
+    const bool batching = e->opt_deferred && e->batch == nullptr;      // (immediate data checks synchronise inside every setter)
+    if (batching) e->batch = &jobs;
+    int rc = SBE_OK;
+    if (groups) rc = sbe_set_groups(e, slot, groups_component, groups);
+    if (!rc && n_count_rows) rc = set_counts_rows_impl(e, slot, count_idx, n_count_rows, count_rows, update_probs != 0);
+    if (!rc && n_src_rows) rc = sbe_set_source_rows(e, slot, src_objects, n_src_rows, src_rows);
+    if (batching) {
+        e->batch = nullptr;
+        const unsigned n_blocks = jobs.n_group_blocks + jobs.n_rows_blocks + jobs.n_src_blocks;
+        if (n_blocks) {                         // (also after a later setter's error: the earlier ones' host state counts on their launch)
+            k_apply_setters<<<n_blocks, 256, 0, e->stream>>>(jobs);
+            if (hipGetLastError() != hipSuccess && !rc) rc = fail(e, SBE_ERR_HIP, "k_apply_setters launch failed");
+        }
+    }
+    return rc;
 }
 
 // k_given_unchanged_fused: LDS image of a 16-feature tile and the arguments both forms share

@@ -98,10 +98,10 @@ __global__ void k_init_state_h(uint16_t* __restrict__ state_h, int64_t n_entries
 // Several small host arrays to their resident places in ONE launch: the arrays are staged back to back in the mapped
 // ring (`base`, read over PCIe element-parallel), segment y goes to sg.dst[y].  Words when everything is 4-byte aligned.
 struct ScatterSegs { uint8_t* dst[8]; uint32_t off[8]; uint32_t bytes[8]; int n; };
-__device__ __forceinline__ void scatter_segment(const uint8_t* __restrict__ base, const ScatterSegs& sg, int y) {
+__device__ __forceinline__ void scatter_segment(const uint8_t* __restrict__ base, const ScatterSegs& sg, int y, uint32_t bx, uint32_t gx) {
     const uint8_t* src = base + sg.off[y];
     uint8_t* dst = sg.dst[y];
-    const uint32_t nb = sg.bytes[y], stride = gridDim.x * blockDim.x, i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nb = sg.bytes[y], stride = gx * blockDim.x, i0 = bx * blockDim.x + threadIdx.x;
     if ((((uintptr_t)dst | (uintptr_t)src | nb) & 3) == 0) {
         for (uint32_t j = i0; j < nb / 4; j += stride) reinterpret_cast<uint32_t*>(dst)[j] = reinterpret_cast<const uint32_t*>(src)[j];
     } else {
@@ -109,15 +109,15 @@ __device__ __forceinline__ void scatter_segment(const uint8_t* __restrict__ base
     }
 }
 __global__ void k_scatter_bytes(const uint8_t* __restrict__ base, ScatterSegs sg) {
-    if ((int)blockIdx.y < sg.n) scatter_segment(base, sg, blockIdx.y);
+    if ((int)blockIdx.y < sg.n) scatter_segment(base, sg, blockIdx.y, blockIdx.x, gridDim.x);
 }
 
 // K0b: source ingest.  bool rows [rows][F][C] -> component id per observation (0xFF = none).
 // `objects` == nullptr: row r is object r.
-__global__ void k_ingest_source(const uint8_t* __restrict__ rows, const int32_t* __restrict__ objects,
-                                uint8_t* __restrict__ src_id, int n_rows, int F, int C, int Fp,
-                                int* __restrict__ status) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void ingest_source_block(const uint8_t* __restrict__ rows, const int32_t* __restrict__ objects,
+                                                    uint8_t* __restrict__ src_id, int n_rows, int F, int C, int Fp,
+                                                    int* __restrict__ status, int64_t block) {
+    const int64_t i = block * blockDim.x + threadIdx.x;
     int multi = 0;
     if (i < (int64_t)n_rows * F) {
         const int r = (int)(i / F), f = (int)(i % F);
@@ -131,6 +131,11 @@ __global__ void k_ingest_source(const uint8_t* __restrict__ rows, const int32_t*
     }
     const int m = __popcll(__ballot(multi));
     if ((threadIdx.x & 63) == 0 && m) raise_status(status, ST_MULTI_SOURCE, m);
+}
+__global__ void k_ingest_source(const uint8_t* __restrict__ rows, const int32_t* __restrict__ objects,
+                                uint8_t* __restrict__ src_id, int n_rows, int F, int C, int Fp,
+                                int* __restrict__ status) {
+    ingest_source_block(rows, objects, src_id, n_rows, F, C, Fp, status, blockIdx.x);
 }
 
 // Inverse of K0b for the listed objects: component id -> bool row [F][C] (all False for 0xFF).
@@ -468,7 +473,7 @@ __global__ void k_weight_patterns(const float* __restrict__ weights /* [F][C] */
 // so the two halves do not depend on each other.
 __global__ void k_scatter_weight_patterns(const uint8_t* __restrict__ base, ScatterSegs sg, WeightPatternArgs wp) {
     const int y = blockIdx.y;
-    if (y < sg.n) { scatter_segment(base, sg, y); return; }
+    if (y < sg.n) { scatter_segment(base, sg, y, blockIdx.x, gridDim.x); return; }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < wp.P * wp.F) weight_patterns_item(i, wp);
 }
@@ -2496,6 +2501,15 @@ __global__ void k_set_source_ids(const uint8_t* __restrict__ ids /* [n][F] */, c
 
 // float32 count rows of listed groups -> the slot's resident int32 counts (Engine.set_counts_rows: the bind cache
 // sends only the groups whose rows differ from what the slot holds)
+struct CountRowsArgs {
+    const float* rows; const int32_t* group_idx; int32_t* counts; const double* conc; float* probs; float* probs_t;
+    int n, F, S, Gtot, ft; int* status;
+};
+__device__ __forceinline__ void set_count_rows_item(const CountRowsArgs& a, int64_t i) {
+    const int64_t fs = (int64_t)a.F * a.S;
+    if (i >= (int64_t)a.n * fs) return;
+    a.counts[(int64_t)a.group_idx[i / fs] * fs + i % fs] = (int32_t)a.rows[i];
+}
 __global__ void k_set_count_rows(const float* __restrict__ rows /* [n][F][S] */, const int32_t* __restrict__ group_idx,
                                  int32_t* __restrict__ counts /* slot's [Gtot][F][S] */, int n, int64_t fs) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2508,45 +2522,87 @@ __global__ void k_set_count_rows(const float* __restrict__ rows /* [n][F][S] */,
 // stale afterwards -- one launch instead of this one and a k_probs over the whole component).  One thread per (row,
 // feature): the S float32 counts go to the resident int32 table, probs_row (k_probs' arithmetic, untempered) writes the
 // slot's probability row and its tile-transposed copy.
+__device__ __forceinline__ void set_count_rows_probs_item(const CountRowsArgs& a, int64_t t) {
+    if (t >= (int64_t)a.n * a.F) return;
+    const int F = a.F, S = a.S, ft = a.ft;
+    const int i = (int)(t / F), f = (int)(t % F);
+    const int g = a.group_idx[i], tile = f / ft, tl = f % ft;
+    const float* in = a.rows + t * S;
+    const int64_t base = ((int64_t)g * F + f) * S;
+    int32_t* cnt = a.counts + base;
+    for (int s = 0; s < S; ++s) cnt[s] = (int32_t)in[s];
+    float* out_row = a.probs + base;
+    float* out_t = a.probs_t + (((int64_t)tile * (a.Gtot + 1) + g) * S) * ft + tl;                 // (k_probs' tile layout)
+    probs_row([&](int s) { return (float)(int32_t)in[s]; }, a.conc + base, nullptr, S, 0.0, 0.0, a.status,
+              [&](int s, float v) { out_row[s] = v; out_t[(int64_t)s * ft] = v; });
+}
 __global__ void k_set_count_rows_probs(const float* __restrict__ rows /* [n][F][S] */, const int32_t* __restrict__ group_idx,
                                        int32_t* __restrict__ counts /* slot's [Gtot][F][S] */, const double* __restrict__ conc,
                                        float* __restrict__ probs, float* __restrict__ probs_t, int n, int F, int S, int Gtot, int ft,
                                        int* __restrict__ status) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)n * F) return;
-    const int i = (int)(t / F), f = (int)(t % F);
-    const int g = group_idx[i], tile = f / ft, tl = f % ft;
-    const float* in = rows + t * S;
-    const int64_t base = ((int64_t)g * F + f) * S;
-    int32_t* cnt = counts + base;
-    for (int s = 0; s < S; ++s) cnt[s] = (int32_t)in[s];
-    float* out_row = probs + base;
-    float* out_t = probs_t + (((int64_t)tile * (Gtot + 1) + g) * S) * ft + tl;                 // (k_probs' tile layout)
-    probs_row([&](int s) { return (float)(int32_t)in[s]; }, conc + base, nullptr, S, 0.0, 0.0, status,
-              [&](int s, float v) { out_row[s] = v; out_t[(int64_t)s * ft] = v; });
+    set_count_rows_probs_item(CountRowsArgs{rows, group_idx, counts, conc, probs, probs_t, n, F, S, Gtot, ft, status},
+                              (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // The same for S <= W (8 or 16): W lanes per (row, feature), lane j <-> state j (probs_row_x16) -- the staged float rows are
 // read coalesced (they sit in host-mapped memory: S reads at a 4 S-byte stride per thread were S PCIe requests each), one
-// division per lane.
+// division per lane.  (Every thread of a wave calls: the row form shuffles.)
+template <int W>
+__device__ __forceinline__ void set_count_rows_probs_x_item(const CountRowsArgs& a, int64_t t) {
+    const int F = a.F, S = a.S, ft = a.ft;
+    const int64_t grp = t / W;
+    const int j = (int)(t % W);
+    const bool row_on = grp < (int64_t)a.n * F;
+    const int i = row_on ? (int)(grp / F) : 0, f = row_on ? (int)(grp % F) : 0;
+    const int g = row_on ? a.group_idx[i] : 0, tile = f / ft, tl = f % ft;
+    const float* in = a.rows + grp * S;
+    const int64_t base = ((int64_t)g * F + f) * S;
+    float cj = 0.0f;
+    if (row_on && j < S) { cj = (float)(int32_t)in[j]; a.counts[base + j] = (int32_t)in[j]; }
+    float* out_row = a.probs + base;
+    float* out_t = a.probs_t + (((int64_t)tile * (a.Gtot + 1) + g) * S) * ft + tl;                 // (k_probs' tile layout)
+    probs_row_x16<W>(j, row_on, [&](int) { return cj; }, a.conc + base, nullptr, S, 0.0, 0.0, a.status,
+                     [&](int s, float v) { out_row[s] = v; out_t[(int64_t)s * ft] = v; });
+}
 template <int W>
 __global__ void k_set_count_rows_probs_x(const float* __restrict__ rows /* [n][F][S] */, const int32_t* __restrict__ group_idx,
                                          int32_t* __restrict__ counts, const double* __restrict__ conc, float* __restrict__ probs,
                                          float* __restrict__ probs_t, int n, int F, int S, int Gtot, int ft, int* __restrict__ status) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t grp = t / W;
-    const int j = (int)(t % W);
-    const bool row_on = grp < (int64_t)n * F;
-    const int i = row_on ? (int)(grp / F) : 0, f = row_on ? (int)(grp % F) : 0;
-    const int g = row_on ? group_idx[i] : 0, tile = f / ft, tl = f % ft;
-    const float* in = rows + grp * S;
-    const int64_t base = ((int64_t)g * F + f) * S;
-    float cj = 0.0f;
-    if (row_on && j < S) { cj = (float)(int32_t)in[j]; counts[base + j] = (int32_t)in[j]; }
-    float* out_row = probs + base;
-    float* out_t = probs_t + (((int64_t)tile * (Gtot + 1) + g) * S) * ft + tl;                 // (k_probs' tile layout)
-    probs_row_x16<W>(j, row_on, [&](int) { return cj; }, conc + base, nullptr, S, 0.0, 0.0, status,
-                     [&](int s, float v) { out_row[s] = v; out_t[(int64_t)s * ft] = v; });
+    set_count_rows_probs_x_item<W>(CountRowsArgs{rows, group_idx, counts, conc, probs, probs_t, n, F, S, Gtot, ft, status},
+                                   (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Several state-setting calls of ONE bind in one launch (sbe_set_slot_delta: the bind cache's revert after a rejected step is
+// "old group ids + old count rows", its forward step "new group ids + new source rows"): block ranges [0, n_group_blocks) run
+// k_scatter_weight_patterns' grid (x = b % group_gx, y = b / group_gx), the next n_rows_blocks the count-row patch in the form
+// `rows_kind` says (0: counts only, 1: + probability rows, 8 / 16: + probability rows by lane groups), the rest the source ingest.
+// The three jobs touch disjoint resident arrays.
+struct SetterJobs {
+    const uint8_t* group_base; ScatterSegs sg; WeightPatternArgs wp; int has_wp; unsigned group_gx, n_group_blocks;
+    CountRowsArgs rows; int rows_kind; unsigned n_rows_blocks;
+    const uint8_t* src_rows; const int32_t* src_objects; uint8_t* src_id; int src_n, src_F, src_C, src_Fp; int* src_status; unsigned n_src_blocks;
+};
+__global__ __launch_bounds__(256) void k_apply_setters(SetterJobs j) {
+    unsigned b = blockIdx.x;
+    if (b < j.n_group_blocks) {
+        const unsigned bx = b % j.group_gx;
+        const int y = (int)(b / j.group_gx);
+        if (y < j.sg.n) { scatter_segment(j.group_base, j.sg, y, bx, j.group_gx); return; }
+        const int i = bx * blockDim.x + threadIdx.x;
+        if (j.has_wp && i < j.wp.P * j.wp.F) weight_patterns_item(i, j.wp);
+        return;
+    }
+    b -= j.n_group_blocks;
+    if (b < j.n_rows_blocks) {
+        const int64_t t = (int64_t)b * blockDim.x + threadIdx.x;
+        if (j.rows_kind == 0) set_count_rows_item(j.rows, t);
+        else if (j.rows_kind == 8) set_count_rows_probs_x_item<8>(j.rows, t);
+        else if (j.rows_kind == 16) set_count_rows_probs_x_item<16>(j.rows, t);
+        else set_count_rows_probs_item(j.rows, t);
+        return;
+    }
+    b -= j.n_rows_blocks;
+    if (b < j.n_src_blocks) ingest_source_block(j.src_rows, j.src_objects, j.src_id, j.src_n, j.src_F, j.src_C, j.src_Fp, j.src_status, b);
 }
 
 // ------------------------------------------------------------------------------------------

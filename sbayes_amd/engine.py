@@ -258,6 +258,40 @@ class Engine:
         self._touch(slot)
         self._check(self._lib.sbe_set_source_rows(self._h, slot, self._i(objects), objects.size, self._i(rows)))
 
+    def set_slot_delta(self, slot, groups_component=0, groups=None, count_idx=None, count_rows=None, update_probs=False,
+                       source_objects=None, source_rows=None):
+        """Several state-setting calls of one bind as ONE launch (sbe_set_slot_delta): set_groups(slot, groups_component, groups)
+        when `groups` is given, set_counts_rows(slot, count_idx, count_rows, update_probs) when `count_idx` is, set_source_rows(slot,
+        source_objects, source_rows) when `source_objects` is -- in that order, same checks and results."""
+        comp, g = int(groups_component), None
+        if groups is not None:
+            g = np.asarray(groups)
+            if g.shape != (self.n_groups[comp], self.n_objects):
+                raise ValueError(f"groups of component {comp} must be {(self.n_groups[comp], self.n_objects)}, got {g.shape}")
+            g = _c(g.astype(bool, copy=False), np.uint8)
+        gi = r = None
+        n_rows = 0
+        if count_idx is not None:
+            gi = _as(count_idx, np.int32).reshape(-1)
+            r = _c(count_rows, np.float32)
+            if r.shape != (gi.size, self.n_features, self.n_states):
+                raise ValueError(f"rows must be [{gi.size}, {self.n_features}, {self.n_states}], got {r.shape}")
+            n_rows = gi.size
+        objs = sr = None
+        n_src = 0
+        if source_objects is not None:
+            objs = _as(source_objects, np.int32).reshape(-1)
+            sr = np.asarray(source_rows)
+            if sr.shape != (objs.size, self.n_features, self.n_components):
+                raise ValueError("rows must be [len(objects), n_features, n_components]")
+            sr = _c(sr.astype(bool, copy=False), np.uint8)
+            n_src = objs.size
+        self._touch(slot)
+        self._check(self._lib.sbe_set_slot_delta(self._h, slot, comp, self._i(g) if g is not None else None,
+                                                 self._i(gi) if n_rows else None, n_rows, self._i(r) if n_rows else None,
+                                                 1 if update_probs else 0, self._i(objs) if n_src else None, n_src,
+                                                 self._i(sr) if n_src else None))
+
     def get_source_rows(self, slot, objects):
         """bool [n, F, C]: the listed objects' rows of the slot's source."""
         objects = _as(objects, np.int32).reshape(-1)

@@ -102,7 +102,7 @@ COMPARE = {
     "gibbs_propose": "exact_at_t1",
 }
 SETTERS = {"set_groups", "set_concentration", "set_counts", "set_source", "set_weights", "update_probs", "set_counts_rows",
-           "set_source_rows", "set_uniform_counts", "recount", "copy_slot"}
+           "set_source_rows", "set_uniform_counts", "recount", "copy_slot", "set_slot_delta"}
 
 
 _TEMPERATURE_ARG = {"source_posterior": 2, "subset_lh": 3, "given_unchanged_lh": 3,      # positional index of `temperature`
@@ -197,7 +197,7 @@ for _name in ("normalize_tables", "dirichlet_logpdf", "effect_counts", "set_grou
               "set_source_rows", "set_uniform_counts", "counts_delta", "collapsed_loglik", "collapsed_loglik_all", "source_prior",
               "given_unchanged_lh", "cluster_posterior_marginals", "jump_lh_resident", "recount", "get_counts",
               "copy_slot", "sample_source", "source_logprob", "update_counts", "get_source_rows", "given_unchanged_gibbs",
-              "gibbs_propose", "collapsed_and_source_prior"):
+              "gibbs_propose", "collapsed_and_source_prior", "set_slot_delta"):
     setattr(RecordingEngine, _name, _wrap(_name))
 
 

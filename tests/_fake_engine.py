@@ -285,6 +285,19 @@ class FakeEngine:
             c = int(np.searchsorted(off, gg, side="right") - 1)
             self._slot(slot)["counts"][c][gg - off[c]] = row
 
+    def set_slot_delta(self, slot, groups_component=0, groups=None, count_idx=None, count_rows=None, update_probs=False,
+                       source_objects=None, source_rows=None):
+        """set_groups, set_counts_rows, set_source_rows of one bind as ONE call (class-qualified: one logged call)."""
+        n_calls = len(self.calls)
+        if groups is not None:
+            FakeEngine.set_groups(self, slot, groups_component, groups)
+        if count_idx is not None:
+            FakeEngine.set_counts_rows(self, slot, count_idx, count_rows, update_probs=update_probs)
+        if source_objects is not None:
+            FakeEngine.set_source_rows(self, slot, source_objects, source_rows)
+        del self.calls[n_calls:]
+        self.calls.append(("set_slot_delta", groups is not None, count_idx is not None, source_objects is not None))
+
     def set_source_rows(self, slot, objects, rows):
         self._touch(slot)
         self.calls.append(("set_source_rows", len(objects)))

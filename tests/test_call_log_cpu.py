@@ -24,7 +24,7 @@ def test_call_log_replays_on_the_double(tag):
     assert crc(feats) == meta["features_crc"] and list(feats.shape) == meta["shape"]
     # the operator forms and the collapsed likelihood really ran through the engine surface
     assert {"cluster_marginals", "cluster_posterior_marginals", "source_posterior", "given_unchanged_lh", "collapsed_loglik_all",
-            "counts_delta", "source_prior", "collapsed_and_source_prior", "set_counts_rows", "set_source_rows", "set_groups",
+            "counts_delta", "source_prior", "collapsed_and_source_prior", "set_counts_rows", "set_slot_delta", "set_groups",
             "set_weights", "__step__"} <= set(counts)
     # round 3: no whole [N, F] mask and no stateless whole-table call is left on the per-step path
     assert not {"effect_counts", "dirichlet_logpdf"} & set(counts)

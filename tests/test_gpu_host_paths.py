@@ -221,3 +221,55 @@ def test_collapsed_likelihood_and_source_prior_in_one_call(name):
         assert not np.array_equal(per_object2, per_object) or np.array_equal(clusters, wl.groups[0])
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_set_slot_delta_is_the_three_setters(name):
+    """sbe_set_slot_delta: set_groups + set_counts_rows(update_probs) + set_source_rows of one bind in ONE launch (flat: all
+    three through the mapped ring; wide_tables: count rows beyond the ring's direct size; long: the pattern / tuple arrays
+    beyond it) -- the slot ends exactly as after the three calls: ids and tables (mixture log-likelihood, normalised weights),
+    counts and probability rows, source rows (source prior); every subset of the three as well."""
+    eng, fake, wl, counts = _pair(name)
+    try:
+        rng = np.random.default_rng(23)
+        C = eng.n_components
+        N = wl.source.shape[0]
+        off = eng.group_offsets
+        for c in range(C):
+            eng.update_probs(0, c)
+        clusters = wl.groups[0].copy()
+        moved = rng.choice(N, size=min(N, 3), replace=False)
+        clusters[:, moved] = False
+        clusters[0, moved] = True
+        idx = np.array([off[0], off[C - 1]], dtype=np.int32) if C > 1 else np.array([off[0]], dtype=np.int32)
+        rows = np.stack([rng.integers(0, 30, size=counts[0].shape[1:]).astype(np.float32) for _ in idx])
+        objs = np.sort(rng.choice(N, size=min(N, 5), replace=False)).astype(np.int32)
+        pick = rng.integers(0, C + 1, size=(objs.size, wl.source.shape[1]))
+        src_rows = pick[..., None] == np.arange(C)
+        for use in ((1, 1, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (0, 1, 0)):
+            eng.copy_slot(1, 0)
+            eng.set_slot_delta(1, groups_component=0, groups=clusters if use[0] else None,
+                               count_idx=idx if use[1] else None, count_rows=rows if use[1] else None, update_probs=True,
+                               source_objects=objs if use[2] else None, source_rows=src_rows if use[2] else None)
+            # (slot 1 is read back, then rebuilt call by call from the same start)
+            got = (eng.mixture_loglik(1), eng.weights_normalized(1), [eng.get_counts(1, c) for c in range(C)],
+                   [eng.get_probs(1, c) for c in range(C)], eng.get_source_rows(1, objs), eng.source_prior(1))
+            eng.copy_slot(1, 0)
+            if use[0]:
+                eng.set_groups(1, 0, clusters)
+            if use[1]:
+                eng.set_counts_rows(1, idx, rows, update_probs=True)
+            if use[2]:
+                eng.set_source_rows(1, objs, src_rows)
+            want = (eng.mixture_loglik(1), eng.weights_normalized(1), [eng.get_counts(1, c) for c in range(C)],
+                    [eng.get_probs(1, c) for c in range(C)], eng.get_source_rows(1, objs), eng.source_prior(1))
+            assert got[0] == want[0] or (np.isnan(got[0]) and np.isnan(want[0])), (name, use)
+            assert np.array_equal(got[1], want[1], equal_nan=True), (name, use, "weights")
+            for c in range(C):
+                assert np.array_equal(got[2][c], want[2][c]) and np.array_equal(got[3][c], want[3][c]), (name, use, c)
+            assert np.array_equal(got[4], want[4]) and np.array_equal(got[5], want[5], equal_nan=True), (name, use, "source")
+        with pytest.raises(Exception, match="out of range"):
+            eng.set_slot_delta(1, groups=clusters, count_idx=[10 ** 6], count_rows=rows[:1], update_probs=False)
+        assert np.array_equal(eng.weights_normalized(1), orc.normalize_weights(wl.weights, orc.has_components([clusters] + list(wl.groups[1:]))))
+    finally:
+        eng.close()

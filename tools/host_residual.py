@@ -45,7 +45,7 @@ import make_golden as mg  # noqa: E402  (installs the stubs, imports the referen
 from tests._fake_engine import FakeEngine, make_engine_for_observations, make_get_engine  # noqa: E402
 
 # methods of the real Engine that drop a slot's bind-cache entry (Engine._touch) -> which positional argument names the slot
-TOUCHERS = {"set_groups": 0, "set_counts": 0, "set_source": 0, "set_weights": 0, "recount": 0, "set_counts_rows": 0,
+TOUCHERS = {"set_groups": 0, "set_counts": 0, "set_source": 0, "set_weights": 0, "recount": 0, "set_counts_rows": 0, "set_slot_delta": 0,
             "set_source_rows": 0, "copy_slot": 0, "sample_source": 1, "update_counts": 0}
 PUBLIC = [n for n in dir(FakeEngine) if not n.startswith("_") and callable(getattr(FakeEngine, n))
           and n not in ("close", "na_values")]
