@@ -258,6 +258,32 @@ def forms_case(rng, eng, feats, n_groups, conc, state, tag, stats):
             assert np.array_equal(eng.weights_normalized(0), want_w, equal_nan=True), (tag, "set_groups walk: weights vs oracle", step)
     finally:
         eng.set_groups(0, 0, groups[0])
+    # the row uploads of a bind in one launch (sbe_set_slot_delta) = the three setters one after the other
+    eng.copy_slot(s1, 0); eng.copy_slot(s2, 0)
+    eng.update_probs(s1, range(C)); eng.update_probs(s2, range(C))
+    moved_cl = groups[0].copy()
+    for n in rng.choice(N, size=min(N, 2), replace=False):
+        moved_cl[:, n] = False
+        moved_cl[int(rng.integers(0, K)), n] = True
+    use = [bool(rng.integers(0, 2)) for _ in range(3)]
+    if sum(use) < 2:
+        use = [True, True, True]
+    kw = dict(groups_component=0, groups=moved_cl if use[0] else None,
+              count_idx=(off[c_pick] + g_pick) if use[1] else None, count_rows=rows_new if use[1] else None, update_probs=True,
+              source_objects=objs if use[2] else None, source_rows=new_rows if use[2] else None)
+    eng.set_slot_delta(s1, **kw)
+    if use[0]:
+        eng.set_groups(s2, 0, moved_cl)
+    if use[1]:
+        eng.set_counts_rows(s2, off[c_pick] + g_pick, rows_new, update_probs=True)
+    if use[2]:
+        eng.set_source_rows(s2, objs, new_rows)
+    for c_ in range(C):
+        assert np.array_equal(eng.get_counts(s1, c_), eng.get_counts(s2, c_)) and np.array_equal(eng.get_probs(s1, c_), eng.get_probs(s2, c_)), (tag, "set_slot_delta", c_)
+    assert np.array_equal(eng.get_source_rows(s1, objs), eng.get_source_rows(s2, objs)), (tag, "set_slot_delta: source rows")
+    assert np.array_equal(eng.weights_normalized(s1), eng.weights_normalized(s2), equal_nan=True), (tag, "set_slot_delta: weights")
+    a_, b_ = eng.mixture_loglik(s1), eng.mixture_loglik(s2)
+    assert a_ == b_ or (np.isnan(a_) and np.isnan(b_)), (tag, "set_slot_delta: mixture")
     stats["forms"] = stats.get("forms", 0) + 1
 
 
