@@ -54,7 +54,7 @@ typedef struct sbe_engine sbe_engine;
                                sbe_gibbs_propose, sbe_given_unchanged_gibbs_counts, sbe_test_roundtrip,
                                sbe_collapsed_and_source_prior, sbe_counts_delta_apply,
                                sbe_given_unchanged_gibbs_apply, sbe_gibbs_propose_apply,
-                               sbe_set_slot_delta */
+                               sbe_set_slot_delta, sbe_get_counts_all */
 
 /* error codes */
 #define SBE_OK 0
@@ -214,6 +214,8 @@ int sbe_accumulate_counts(sbe_engine* e, int slot, const int32_t* objects, int n
                           int sign, uint8_t* changed_groups_out);
 int sbe_set_counts(sbe_engine* e, int slot, int component, const float* counts /* [G_c][F][S] */);
 int sbe_get_counts(sbe_engine* e, int slot, int component, float* out /* [G_c][F][S] */);
+/* every component's table in one call, component after component (recalculate_feature_counts, counts.py:35-52, reads them all) */
+int sbe_get_counts_all(sbe_engine* e, int slot, float* out /* [G_total][F][S] */);
 
 /* ---- Dirichlet concentration tables (sbayes/model/prior.py:325-354, 453-455) -----------
  * per_group = 0: [F][S] broadcast over groups (cluster effect prior); 1: [G_c][F][S]. Shared

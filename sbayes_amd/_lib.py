@@ -55,6 +55,7 @@ PROTOTYPES = {
     "sbe_accumulate_counts": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p]),
     "sbe_set_counts": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
     "sbe_get_counts": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
+    "sbe_get_counts_all": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
     "sbe_set_concentration": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int]),
     "sbe_update_probs": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_double, ct.c_double, ct.c_void_p]),
     "sbe_update_probs_mask": (ct.c_int, [c_engine_p, ct.c_int, ct.c_uint, ct.c_double, ct.c_double, ct.c_void_p]),

@@ -352,7 +352,7 @@ def recount_bound(eng, sample, slot=0):
     entry = eng._bound.get(slot) if hasattr(eng, "_bound") else None
     mirrors = eng._mirror.get(slot) if hasattr(eng, "_mirror") else None
     eng.recount(slot)                               # (drops the slot's entry and mirrors: the counts changed under them)
-    tables = [eng.get_counts(slot, c) for c in range(eng.n_components)]
+    tables = list(eng.get_counts_all(slot)) if hasattr(eng, "get_counts_all") else [eng.get_counts(slot, c) for c in range(eng.n_components)]
     if entry is not None and mirrors is not None:
         entry["counts"] = [None] * eng.n_components          # whatever parameter holds them next is compared by content
         entry["stale"] = set(range(eng.n_components))

@@ -1930,6 +1930,29 @@ int sbe_set_probs(sbe_engine* e, int slot, int component, const float* probs) {
     return SBE_OK;
 }
 
+// every component's table in one call (recalculate_feature_counts reads them all back: counts.py:35-52)
+int sbe_get_counts_all(sbe_engine* e, int slot, float* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot);
+    if (e->Gtot == 0) return SBE_OK;
+    CHECK_PTR(e, out);
+    for (int c = 0; c < e->C; ++c)
+        if (e->G[c] > 0 && !e->slots[slot].counts_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts of component %d not set", slot, c);
+    HIPCHK(e, hipSetDevice(e->device));
+    const int64_t n = (int64_t)e->Gtot * e->F * e->S;
+    int rc = ensure_scratch(e, n * sizeof(float));
+    if (rc) return rc;
+    const int32_t* src = e->d_counts + (int64_t)slot * e->table_elems();
+    void* d_out;
+    rc = out_target(e, n * sizeof(float), e->d_scratch, &d_out);
+    if (rc) return rc;
+    const unsigned blocks = (unsigned)std::min<int64_t>(div_up(n, 1024), 64);
+    const DoneSig done = out_done(e, d_out, blocks);
+    if (done.flag) k_i32_to_f32_done<<<blocks, 1024, 0, e->stream>>>(src, (float*)d_out, n, done);
+    else k_i32_to_f32<<<div_up(n, 256), 256, 0, e->stream>>>(src, (float*)d_out, n);
+    HIPCHK(e, hipGetLastError());
+    return out_fetch(e, out, d_out, n * sizeof(float), done);
+}
+
 int sbe_get_probs(sbe_engine* e, int slot, int component, float* out) {
     CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component);
     if (e->G[component] == 0) return SBE_OK;

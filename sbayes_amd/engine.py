@@ -330,6 +330,13 @@ class Engine:
         self._check(self._lib.sbe_get_counts(self._h, slot, component, self._o(out)))
         return out
 
+    def get_counts_all(self, slot):
+        """The float32 [G_c, F, S] count tables of every component, one call (views of one array)."""
+        out = np.empty((self.n_groups_total, self.n_features, self.n_states), dtype=np.float32)
+        self._check(self._lib.sbe_get_counts_all(self._h, slot, self._o(out)))
+        off = self.group_offsets
+        return tuple(out[int(off[c]):int(off[c + 1])] for c in range(self.n_components))
+
     def set_concentration(self, component, conc):
         conc = _c(conc, np.float64)
         fs = (self.n_features, self.n_states)

@@ -90,6 +90,7 @@ COMPARE = {
     "collapsed_loglik_all": (2e-6, 1e-6),
     "source_prior": (2e-6, 1e-6),            # float32 logs, fp64 accumulation on the device
     "collapsed_and_source_prior": (2e-6, 1e-6),
+    "get_counts_all": "exact",
     "cluster_posterior_marginals": (1e-9, 1e-9), "jump_lh_resident": (1e-9, 1e-9),
     # the Gibbs source proposal on slot state (patch.install(gibbs_source=True) -> operators.gibbs_sample_source)
     "sample_source": (2e-6, 1e-6),           # (log_q, selected probabilities): float32 posterior values; the DRAW itself is
@@ -197,7 +198,7 @@ for _name in ("normalize_tables", "dirichlet_logpdf", "effect_counts", "set_grou
               "set_source_rows", "set_uniform_counts", "counts_delta", "collapsed_loglik", "collapsed_loglik_all", "source_prior",
               "given_unchanged_lh", "cluster_posterior_marginals", "jump_lh_resident", "recount", "get_counts",
               "copy_slot", "sample_source", "source_logprob", "update_counts", "get_source_rows", "given_unchanged_gibbs",
-              "gibbs_propose", "collapsed_and_source_prior", "set_slot_delta"):
+              "gibbs_propose", "collapsed_and_source_prior", "set_slot_delta", "get_counts_all"):
     setattr(RecordingEngine, _name, _wrap(_name))
 
 

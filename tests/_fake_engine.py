@@ -212,6 +212,10 @@ class FakeEngine:
     def get_counts(self, slot, component):
         return self._slot(slot)["counts"][component].copy()
 
+    def get_counts_all(self, slot):
+        self.calls.append(("get_counts_all",))
+        return tuple(self._slot(slot)["counts"][c].copy() for c in range(len(self.n_groups)))
+
     # ---- Gibbs source proposal on slot state (operators.gibbs_sample_source; sbe_sample_source / sbe_source_logprob) ----
     def copy_slot(self, dst, src):
         import copy

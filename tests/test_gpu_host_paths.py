@@ -203,8 +203,10 @@ def test_collapsed_likelihood_and_source_prior_in_one_call(name):
     """Model.__call__ = likelihood + prior (model.py:47-51): sbe_collapsed_and_source_prior returns what the two calls
     return, bit for bit -- one launch (flat, long) or the two calls behind one entry (wide_tables: a group's terms exceed
     the LDS budget) -- and agrees with the double within the two calls' own tolerances."""
-    eng, fake, wl, _ = _pair(name)
+    eng, fake, wl, counts = _pair(name)
     try:
+        for c, table in enumerate(eng.get_counts_all(0)):            # (every component's counts in one call)
+            assert table.dtype == np.float32 and np.array_equal(table, eng.get_counts(0, c)) and np.array_equal(table, counts[c])
         per_group, per_object = eng.collapsed_and_source_prior(0)
         assert np.array_equal(per_group, eng.collapsed_loglik_all(0))
         assert np.array_equal(per_object, eng.source_prior(0))
