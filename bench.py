@@ -65,8 +65,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=None,
                     help="resident sample states (chains x candidate states) evaluated per step "
                          "(default: 2048 for cfg1 / south_america / headline, 64 for stress)")
-    ap.add_argument("--kernel", default="packed", choices=["packed", "packed_general", "packed_v2", "packed_tuple_lds", "onehot", "onehot_general"],
+    ap.add_argument("--kernel", default="packed", choices=["packed", "packed_general", "packed_v2", "packed_tuple", "packed_tuple_lds", "packed_tuple_mfma", "onehot", "onehot_general"],
                     help="packed: state-index stream, group-tuple form when it applies (default); "
+                         "packed_tuple: group-tuple form on the vector pipe forced (k_mixture_tuple64: what `packed` ran before round 5); "
+                         "packed_tuple_mfma: its matrix-pipe form forced (k_mixture_tuple_mfma: what `packed` picks for >= 256 states); "
                          "packed_general: never the group-tuple form (k_mixture_rows); packed_v2: the older general "
                          "kernel k_mixture_v2; onehot: stream the one-hot block")
     ap.add_argument("--log-mode", default="product", choices=["product", "per_obs"])
@@ -113,14 +115,16 @@ def setup_engine(wl, batch, device, kernel="packed", log_mode="product"):
     sbayes_amd.synthetic.make_state without N*F*C host work per state, so a few thousand states are ready in a second or two
     and eight ranks do not spend minutes of start-up in eight contending Python processes."""
     from sbayes_amd.engine import (LOG_PER_OBS, LOG_PRODUCT, MIXTURE_ONEHOT, MIXTURE_ONEHOT_GENERAL, MIXTURE_PACKED,
-                                   MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE_LDS, MIXTURE_PACKED_V2, Engine)
+                                   MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, MIXTURE_PACKED_TUPLE_MFMA,
+                                   MIXTURE_PACKED_V2, Engine)
     n_obj, n_feat, _ = wl.shape
     C = wl.n_components
     K = wl.clusters.shape[0]
     eng = Engine(wl.features, [g.shape[0] for g in wl.groups], n_slots=batch, device=device)
     eng.set_option(kernel={"onehot": MIXTURE_ONEHOT, "onehot_general": MIXTURE_ONEHOT_GENERAL, "packed": MIXTURE_PACKED,
                            "packed_general": MIXTURE_PACKED_GENERAL, "packed_v2": MIXTURE_PACKED_V2,
-                           "packed_tuple_lds": MIXTURE_PACKED_TUPLE_LDS}[kernel],
+                           "packed_tuple": MIXTURE_PACKED_TUPLE, "packed_tuple_lds": MIXTURE_PACKED_TUPLE_LDS,
+                           "packed_tuple_mfma": MIXTURE_PACKED_TUPLE_MFMA}[kernel],
                    log_mode=LOG_PRODUCT if log_mode == "product" else LOG_PER_OBS)
     for c in range(C):
         eng.set_concentration(c, wl.concentration[c])

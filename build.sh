@@ -1,5 +1,5 @@
 #!/bin/bash
-# Build the gfx950 engine library in-tree (also done by __graft_entry__.build()): the two translation units are compiled
+# Build the gfx950 engine library in-tree (also done by __graft_entry__.build()): the translation units are compiled
 # in parallel and linked into sbayes_amd/libsbe_engine.so.  Extra arguments are passed to both compiles (-DSBE_STAMPS ...).
 set -e
 cd "$(dirname "$0")"
@@ -7,9 +7,12 @@ FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-u
 mkdir -p build/obj
 /opt/rocm/bin/hipcc $FLAGS "$@" -c sbayes_amd/csrc/sbe_mixture.hip -o build/obj/sbe_mixture.o &
 pid=$!
+/opt/rocm/bin/hipcc $FLAGS "$@" -c sbayes_amd/csrc/sbe_mixture_mfma.hip -o build/obj/sbe_mixture_mfma.o &
+pid2=$!
 /opt/rocm/bin/hipcc $FLAGS "$@" -c sbayes_amd/csrc/sbe_engine.hip -o build/obj/sbe_engine.o
 wait $pid
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/obj/sbe_engine.o build/obj/sbe_mixture.o -o sbayes_amd/libsbe_engine.so
+wait $pid2
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/obj/sbe_engine.o build/obj/sbe_mixture.o build/obj/sbe_mixture_mfma.o -o sbayes_amd/libsbe_engine.so
 # the host layer's CPython extension (plain C, no device code): sbayes_amd/_fast.py uses it when present
 gcc -O2 -fPIC -shared -Wall $(python3 -c "import sysconfig; print('-I' + sysconfig.get_paths()['include'])") sbayes_amd/csrc/sbe_pyhost.c \
     -o sbayes_amd/_sbe_pyhost$(python3 -c "import sysconfig; print(sysconfig.get_config_var('EXT_SUFFIX'))")

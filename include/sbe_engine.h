@@ -82,6 +82,11 @@ typedef struct sbe_engine sbe_engine;
 #define SBE_MIXTURE_PACKED_TUPLE 3    /* packed, group-tuple form forced (error if not applicable) */
 #define SBE_MIXTURE_PACKED_TUPLE_LDS 5  /* same, but never the scalar-unit 64-feature-tile variant
                                           (k_mixture_tuple64): the LDS-metadata kernel (testing / A-B) */
+#define SBE_MIXTURE_PACKED_TUPLE_MFMA 7  /* packed, group-tuple form with the per-observation gather done as an exact
+                                          0/1 byte contraction on the matrix pipe (k_mixture_tuple_mfma: counts per
+                                          (slot, tuple, feature, state) by v_mfma_i32_32x32x32_i8, then one log per table
+                                          entry), forced (error if not applicable: more than 8 tuples, C > 4, LDS).
+                                          SBE_MIXTURE_PACKED picks it by itself for launches of >= 256 slots         */
 #define SBE_OPT_LOG_MODE 2
 #define SBE_LOG_PER_OBS 0      /* fp64 log per observation, fp64 sum                        */
 #define SBE_LOG_PRODUCT 1      /* fp64 mantissa product + integer exponent, one log/thread  */

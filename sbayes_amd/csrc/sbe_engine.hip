@@ -106,6 +106,9 @@ struct sbe_engine {
     int rows_ft = 0;               // tile width of k_mixture_rows (32 / 16; 0: its LDS image does not fit, or C > 4)
     std::vector<uint64_t> rowoff_epoch;   // per slot: Slot::group_epoch the device array was built from
     std::atomic<uint64_t> epoch_counter{0};
+    uint8_t* d_xt = nullptr;       // one-hot block in MFMA fragment order (k_mixture_tuple_mfma), built at the first batched launch
+    int xt_NT = 0, xt_KBp = 0;  size_t xt_bytes = 0;
+    int mfma_min_batch = 256;      // smallest launch the matrix-pipe form is chosen for under SBE_MIXTURE_PACKED (SBE_MFMA_MIN_BATCH)
     uint8_t* d_tid = nullptr;      // [slots][Np] group-tuple index per object (k_mixture_combo)
     uint16_t* d_tuple_g = nullptr; // [slots][kMaxTuples][kMaxComponents]
     uint8_t* d_tuple_p = nullptr;  // [slots][kMaxTuples]
@@ -873,6 +876,69 @@ int check_slot_ready(sbe_engine* e, int slot, bool need_weights) {
     return SBE_OK;
 }
 
+// ---- matrix-pipe form of the group-tuple kernel (sbe_mixture_mfma.hip) ---------------------------------------------
+// The one-hot block in MFMA fragment order, built once, at the first launch that wants it: [NT + 1][KBp] fragments of
+// 1 KB (tile NT and the PF fragments behind it are zero: what the kernel reads instead of branching on bounds).
+int ensure_xt(sbe_engine* e) {
+    if (e->d_xt) return SBE_OK;
+    const int NT = div_up((int64_t)e->F * e->S, 32), KBp = round_up(div_up(e->N, 32), 4);
+    const size_t bytes = ((size_t)(NT + 1) * KBp + 4) * 1024;
+    HIPCHK(e, hipMalloc((void**)&e->d_xt, bytes));
+    e->hbm_bytes += (int64_t)bytes;
+    HIPCHK(e, hipMemsetAsync(e->d_xt, 0, bytes, e->stream));
+    launch_xt_frags(e->d_state, e->d_xt, e->N, e->F, e->S, e->Fp, NT, KBp, e->stream);
+    HIPCHK(e, hipGetLastError());
+    e->xt_NT = NT; e->xt_KBp = KBp; e->xt_bytes = bytes;
+    return SBE_OK;
+}
+
+// geometry of a matrix-pipe launch over n slots with at most KT tuples each; n_split = 0: the form does not apply
+struct MfmaGeom { int n_split, nt_per_split, MT; size_t lds; };
+MfmaGeom mfma_geometry(const sbe_engine* e, int n, int KT) {
+    MfmaGeom g{};
+    if (KT < 1 || KT > 8 || e->C > 4) return g;
+    const int NT = div_up((int64_t)e->F * e->S, 32), KBp = round_up(div_up(e->N, 32), 4);
+    g.MT = (KT + 1) / 2;
+    g.lds = tuple_mfma_lds_bytes(g.MT, e->C, KBp);
+    if (g.lds > 160 * 1024) return g;
+    // the tables are addressed through 32-bit buffer offsets
+    const int64_t probs_bytes = ((int64_t)e->n_slots * e->table_elems() + (int64_t)e->F * e->S) * 4;
+    const int64_t wpat_bytes = ((int64_t)e->n_slots * e->Pmax * e->F * e->C + (int64_t)e->F * e->C) * 4;
+    if (probs_bytes >= ((int64_t)1 << 32) || wpat_bytes >= ((int64_t)1 << 32) || ((int64_t)(NT + 1) * KBp + 4) * 1024 >= ((int64_t)1 << 31)) return g;
+    // one block = 16 slots x a range of column tiles; its 8 waves take the tiles in pairs, so a split of fewer than
+    // 16 tiles leaves waves idle: as many splits as fill the CUs, no finer
+    const int groups = div_up(n, 16);
+    int n_split = std::max(1, std::min(div_up(NT, 16), e->compute_units / std::max(1, groups)));
+    if (const char* env = getenv("SBE_MFMA_SPLIT")) { if (atoi(env) > 0) n_split = std::min(atoi(env), NT); }   // experiments
+    g.nt_per_split = round_up(div_up(NT, n_split), 2);
+    g.n_split = div_up(NT, g.nt_per_split);
+    return g;
+}
+
+int launch_mfma_form(sbe_engine* e, int first_slot, int n, int KT, const MfmaGeom& mg, const int32_t* d_slots) {
+    int rc = ensure_xt(e);
+    if (rc) return rc;
+    MfmaMixParams p{};
+    p.F = e->F; p.S = e->S; p.FS = e->F * e->S; p.Gtot = e->Gtot; p.Np = e->Np;
+    p.NT = e->xt_NT; p.KBp = e->xt_KBp; p.KT = KT;
+    p.n_batch = n; p.n_split = mg.n_split; p.nt_per_split = mg.nt_per_split;
+    p.first_slot = first_slot; p.slot_list = d_slots;
+    p.xt = e->d_xt; p.xt_bytes = (uint32_t)e->xt_bytes;
+    p.tid = e->d_tid; p.tid_stride = e->Np;
+    p.tuple_g = e->d_tuple_g; p.tuple_g_stride = (int64_t)kMaxTuples * kMaxComponents;
+    p.tuple_p = e->d_tuple_p; p.tuple_p_stride = kMaxTuples;
+    p.probs = e->d_probs; p.probs_stride = e->table_elems();
+    p.probs_zero_off = (uint32_t)((int64_t)e->n_slots * e->table_elems() * 4);
+    p.probs_bytes = p.probs_zero_off + (uint32_t)(e->F * e->S * 4);
+    p.wpat = e->d_wpat; p.wpat_stride = (int64_t)e->Pmax * e->F * e->C;
+    p.wpat_zero_off = (uint32_t)((int64_t)e->n_slots * e->Pmax * e->F * e->C * 4);
+    p.wpat_bytes = p.wpat_zero_off + (uint32_t)(e->F * e->C * 4);
+    p.logtab = e->d_logtab;
+    p.partials = e->d_partials; p.partials_stride = e->partials_stride;
+    launch_tuple_mfma(e->C, p, dim3((unsigned)(div_up(n, 16) * mg.n_split)), mg.lds, e->stream);
+    return SBE_OK;
+}
+
 // Enqueue the dominant kernel (optionally bracketed by an event pair) and the fixed-order
 // partial reduction.  mode: LOG_PER_OBS / LOG_PRODUCT.
 // Slots: first_slot .. first_slot+n-1, or (batched steps) the n slots listed in `slots` (host) / `d_slots` (the same
@@ -890,13 +956,21 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     // LDS and a block sees enough observations to amortise building it.  It prefers long chunks (one block
     // per CU is enough: the table build is per block), so it gets its own geometry.
     int KT = 0;
+    const bool force_mfma = e->opt_kernel == SBE_MIXTURE_PACKED_TUPLE_MFMA;
     const bool force_combo = e->opt_kernel == SBE_MIXTURE_PACKED_TUPLE || e->opt_kernel == SBE_MIXTURE_PACKED_TUPLE_LDS;
-    bool combo = e->opt_kernel == SBE_MIXTURE_PACKED || e->opt_kernel == SBE_MIXTURE_ONEHOT || force_combo;
+    bool combo = e->opt_kernel == SBE_MIXTURE_PACKED || e->opt_kernel == SBE_MIXTURE_ONEHOT || force_combo || force_mfma;
     for (int i = 0; i < n && combo; ++i) {
         const int sl = slot_at(i);
         if (e->slots[sl].n_tuples == 0) combo = false;
         KT = std::max(KT, e->slots[sl].n_tuples);
     }
+    // large batches: the per-observation gather as an integer contraction on the matrix pipe (k_mixture_tuple_mfma)
+    MfmaGeom mg{};
+    if (combo && (force_mfma || (e->opt_kernel == SBE_MIXTURE_PACKED && n >= e->mfma_min_batch))) mg = mfma_geometry(e, n, KT);
+    const bool mfma = mg.n_split > 0;
+    if (force_mfma && !mfma)
+        return fail(e, SBE_ERR_ARG, "matrix-pipe group-tuple kernel forced but not applicable (tuples=%d, C=%d, LDS %zu bytes)", KT, e->C, mg.lds);
+    if (mfma) combo = false;
     size_t combo_lds = 0;
     int combo_w_off = 0, combo_tab_off = 0;
     bool tuple64 = false;
@@ -932,7 +1006,7 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     }
     // rows form (k_mixture_rows): the general packed kernel whenever its LDS image fits -- 1024-thread blocks over
     // 32-feature (or 16-feature) tiles; SBE_MIXTURE_PACKED_V2 keeps the older k_mixture_v2 (A/B, tests)
-    bool rows = !combo && !onehot && e->rows_ft != 0 && e->opt_kernel != SBE_MIXTURE_PACKED_V2;
+    bool rows = !mfma && !combo && !onehot && e->rows_ft != 0 && e->opt_kernel != SBE_MIXTURE_PACKED_V2;
     const size_t rows_image = rows ? (size_t)(e->Gtot + 1) * (e->S + 1) * e->rows_ft * 4 + (size_t)P * ((e->C + 1) / 2) * e->rows_ft * 16
                                          + (size_t)kRowsWaves * (kWave / e->rows_ft) * (e->C + 1) * 16 : 0;      // tables | weights | offset slots
     if (rows && rows_image > 160 * 1024 - 512) rows = false;      // more patterns than the tile width was sized for
@@ -975,13 +1049,19 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
             for (int i = 0; i < n; ++i) e->rowoff_epoch[slot_at(i)] = e->slots[slot_at(i)].group_epoch;
         }
     }
+    if (mfma) g.n_blocks = mg.n_split;                // partial sums per slot: one per column split
     if (g.n_blocks > e->partials_stride) return fail(e, SBE_ERR_STATE, "internal: partials buffer too small (%d > %lld)", g.n_blocks, (long long)e->partials_stride);
-    if (!combo && !rows && g.lds_bytes > 159 * 1024)
+    if (!mfma && !combo && !rows && g.lds_bytes > 159 * 1024)
         return fail(e, SBE_ERR_ARG, "probability / weight tables too large for LDS staging at tile width %d (%zu bytes; G_total=%d, S=%d, P=%d)",
                     g.ft, g.lds_bytes, e->Gtot, e->S, P);
     dim3 grid(g.n_blocks, n);
+    if (mfma) { int rc = ensure_xt(e); if (rc) return rc; }      // (one-time build: outside the event pair)
     if (ev_a) HIPCHK(e, hipEventRecord(ev_a, e->stream));
-    {
+    if (mfma) {
+        snprintf(e->last_kernel, sizeof e->last_kernel, "k_mixture_tuple_mfma<packed stream, group-tuple form, matrix pipe, M tiles %d, C=%d>", mg.MT, e->C);
+        int rc = launch_mfma_form(e, first_slot, n, KT, mg, d_slots);
+        if (rc) return rc;
+    } else {
         // XCD-aware 1-D grid (see k_mixture_v2): units = work items x slot groups, unit u on XCD u % 8
         int gcd8 = 8;
         while (g.n_blocks % gcd8) gcd8 >>= 1;
@@ -1196,7 +1276,7 @@ int sbe_destroy(sbe_engine* e) {
     if (e->h_io) (void)hipHostFree(e->h_io);
     void* dev_ptrs[] = {e->d_step_pf, e->d_step_pg, e->d_logtab, e->d_state_h, e->d_toff, e->d_tid, e->d_tuple_g, e->d_tuple_p, e->d_state_q, e->d_probs_t, e->d_wpat_t, e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
                         e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_lg_conc, e->d_sum_a, e->d_lg_sum_a, e->d_unif, e->d_unif_res, e->d_comp_of_group, e->d_partials, e->d_rowoff,
-                        e->d_status, e->d_changed, e->d_step_stamp, e->d_scratch};
+                        e->d_status, e->d_changed, e->d_step_stamp, e->d_scratch, e->d_xt};
     for (void* p : dev_ptrs) if (p) (void)hipFree(p);
     if (e->h_results) (void)hipHostFree(e->h_results);
     if (e->h_status) (void)hipHostFree(e->h_status);
@@ -1300,6 +1380,7 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, device));
     e->compute_units = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* env = getenv("SBE_MFMA_MIN_BATCH")) { if (atoi(env) > 0) e->mfma_min_batch = atoi(env); }      // (A/B runs, tests)
     snprintf(e->device_name, sizeof e->device_name, "%s%s%s", prop.name, prop.name[0] ? " " : "", prop.gcnArchName);
     CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     CREATE_CHK(hipEventCreate(&e->ev0));
@@ -1320,9 +1401,11 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_RC(dmalloc(e, &e->d_pid, NS * e->Np));
     CREATE_RC(dmalloc(e, &e->d_src, NS * N * e->Fp));
     CREATE_RC(dmalloc(e, &e->d_counts, NS * e->table_elems()));
-    CREATE_RC(dmalloc(e, &e->d_probs, NS * e->table_elems()));
+    CREATE_RC(dmalloc(e, &e->d_probs, NS * e->table_elems() + F * S));      // + a zero row [F][S] } what k_mixture_tuple_mfma reads for
     CREATE_RC(dmalloc(e, &e->d_weights, NS * F * C));
-    CREATE_RC(dmalloc(e, &e->d_wpat, NS * e->Pmax * F * C));
+    CREATE_RC(dmalloc(e, &e->d_wpat, NS * e->Pmax * F * C + F * C));        // + a zero row [F][C] } tuples / groups that are not there
+    CREATE_CHK(hipMemsetAsync(e->d_probs + NS * e->table_elems(), 0, F * S * sizeof(float), e->stream));
+    CREATE_CHK(hipMemsetAsync(e->d_wpat + NS * e->Pmax * F * C, 0, F * C * sizeof(float), e->stream));
     CREATE_RC(dmalloc(e, &e->d_patbits, NS * e->Pmax));
     CREATE_RC(dmalloc(e, &e->d_tid, NS * e->Np));
     CREATE_RC(dmalloc(e, &e->d_toff, NS * e->Np + 64));       // + padding: the kernel prefetches 16 entries ahead
@@ -1489,7 +1572,7 @@ int sbe_get_na(const sbe_engine* ce, uint8_t* out_na) {
 
 int sbe_set_option(sbe_engine* e, int option, int value) {
     CHECK_ENGINE(e);
-    if (option == SBE_OPT_MIXTURE_KERNEL && (value == SBE_MIXTURE_PACKED || value == SBE_MIXTURE_ONEHOT || value == SBE_MIXTURE_PACKED_GENERAL || value == SBE_MIXTURE_PACKED_TUPLE || value == SBE_MIXTURE_PACKED_TUPLE_LDS || value == SBE_MIXTURE_ONEHOT_GENERAL || value == SBE_MIXTURE_PACKED_V2)) { e->opt_kernel = value; return SBE_OK; }
+    if (option == SBE_OPT_MIXTURE_KERNEL && (value == SBE_MIXTURE_PACKED || value == SBE_MIXTURE_ONEHOT || value == SBE_MIXTURE_PACKED_GENERAL || value == SBE_MIXTURE_PACKED_TUPLE || value == SBE_MIXTURE_PACKED_TUPLE_LDS || value == SBE_MIXTURE_ONEHOT_GENERAL || value == SBE_MIXTURE_PACKED_V2 || value == SBE_MIXTURE_PACKED_TUPLE_MFMA)) { e->opt_kernel = value; return SBE_OK; }
     if (option == SBE_OPT_LOG_MODE && (value == SBE_LOG_PER_OBS || value == SBE_LOG_PRODUCT)) { e->opt_log = value; return SBE_OK; }
     if (option == SBE_OPT_STEP_FORM && (value == 0 || value == 1)) { e->opt_step_form = value; return SBE_OK; }
     if (option == SBE_OPT_STEP_DERIVE && (value == 0 || value == 1)) { e->opt_step_derive = value; return SBE_OK; }

@@ -52,6 +52,25 @@ struct Mix2Params {
     const uint32_t* rowoff; int64_t rowoff_stride; // per slot [C+1][Np]: LDS byte offsets (see k_rowoff)
 };
 
+// batched group-tuple form on the matrix pipe (sbe_mixture_mfma.hip: k_mixture_tuple_mfma)
+struct MfmaMixParams {
+    int F, S, FS, Gtot, Np;
+    int NT, KBp;                                   // 32-column tiles of the (feature, state) axis; 32-object k-blocks (padded to a multiple of 4)
+    int KT;                                        // tuples used by the slots of this launch (max; <= 8)
+    int n_batch, n_split, nt_per_split;            // slots of the launch; column splits (blocks per group of 16 slots); column tiles per split
+    int first_slot;
+    const int32_t* slot_list;                      // slots of this launch (n_batch entries), or null: first_slot + i
+    const uint8_t* xt;  uint32_t xt_bytes;         // [NT + 1][KBp][64][16] (+ PF fragments) one-hot block in fragment order (k_xt_frags); tile NT is zero
+    const uint8_t* tid;      int64_t tid_stride;       // per slot [Np] tuple index per object
+    const uint16_t* tuple_g; int64_t tuple_g_stride;   // per slot [kMaxTuples][kMaxComponents] global group index (Gtot = none)
+    const uint8_t* tuple_p;  int64_t tuple_p_stride;   // per slot [kMaxTuples] pattern id of the tuple (0xFF: tuple not there)
+    const float* probs;      int64_t probs_stride;  uint32_t probs_bytes;   // per slot [Gtot][F][S] float32 tables (a4), whole array < 4 GiB
+    const float* wpat;       int64_t wpat_stride;   uint32_t wpat_bytes;    // per slot [Pmax][F][C] float32 normalised weights (a5)
+    uint32_t probs_zero_off, wpat_zero_off;        // byte offsets of the zero rows behind the two arrays (F*S / F*C floats)
+    const double2* logtab;                         // [128] {1/c, log c}
+    double* partials;        int64_t partials_stride;
+};
+
 // waves per block of k_mixture_tuple64.  (8-wave blocks -- twice the waves per SIMD at the same LDS footprint -- were
 // measured twice: 72.7 us at 80 VGPRs / 3 blocks per CU, 107 us at 64 VGPRs / 4 blocks per CU, against 61-63 us: the
 // kernel does not fit those register budgets without spilling in its table build.)
@@ -64,5 +83,9 @@ void launch_oh2(int mode, int ft, int C, const Mix2Params& p, dim3 grid, size_t 
 void launch_combo(bool onehot, int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st);
 void launch_tuple64(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st);
 void launch_rows(int mode, int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st);
+// sbe_mixture_mfma.hip
+void launch_xt_frags(const uint8_t* state, uint8_t* xt, int N, int F, int S, int Fp, int NT, int KBp, hipStream_t st);
+size_t tuple_mfma_lds_bytes(int MT, int C, int KBp);
+void launch_tuple_mfma(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st);
 
 }  // namespace sbe

@@ -1,0 +1,437 @@
+// sbe_mixture_mfma.hip -- the group-tuple form of the fused mixture log-likelihood for LARGE BATCHES of resident states,
+// with the per-observation gather replaced by an exact integer contraction on the matrix pipe (round 5).
+//
+// What it computes (reference expression: sbayes/sampling/loggers.py:355-357 over sbayes/model/likelihood.py:104-133,
+// 171-190): for every slot b of the launch
+//     LL[b] = sum_{n, f: not NA} log sum_c w[pat(n), f, c] * p_c[g_c(n), f, x(n, f)]
+// In the group-tuple form an object's (g_0 .. g_{C-1}) is one of KT tuples, so the log argument depends on
+// (tuple t, feature f, state s) only -- the table T_b[t][f][s] that k_mixture_tuple64 builds in LDS and then gathers
+// from, once per observation.  All B slots of a launch share ONE feature block; what differs is which tuple an object
+// belongs to.  Hence
+//     LL[b] = sum_{t, f, s} cnt_b[t][f][s] * T_b[t][f][s],      cnt_b[t][(f, s)] = sum_n [tid_b(n) = t] * X[n][(f, s)]
+// and cnt is a product of two 0/1 byte matrices: A[(b, t)][n] = [tid_b(n) = t] (built in LDS from the slots' tuple ids)
+// and X (the one-hot block, transposed once into MFMA fragment order: k_xt_frags).  v_mfma_i32_32x32x32_i8 accumulates it
+// exactly (counts <= N fit i32), the table entry is computed ONCE per (slot, tuple, feature, state) in the lane that holds
+// its count -- same products, same NumPy order of the component sum, same table-driven fp64 log as the other forms -- and
+// never goes through LDS.  NA observations have an all-zero one-hot row and are counted nowhere.
+//
+// Block = 16 slots x a range of 32-column tiles, 8 waves.  M tile m (32 rows) = tuples 2m, 2m+1 x the 16 slots
+// (row = (t & 1) * 16 + slot): the 32x32 accumulator layout (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
+// then gives every lane ONE column and, per register quad, ONE tuple of four consecutive slots.  A wave owns pairs of
+// column tiles: 2 x MT accumulator tiles, A fragments from LDS (shared by all waves), X fragments straight from L2 in
+// 1 KB fully coalesced pieces (fragment order in memory), four k-blocks ahead.  Both operands take their k index from the
+// same (lane half, byte) position, so the product does not depend on the instruction's internal k order.
+#include <cstdio>
+#include <cstdlib>
+
+#include "sbe_mixture.hip.h"
+
+namespace sbe {
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) const v4i_t lds_cv4i_t;
+
+constexpr int kMfmaWaves = 8;
+constexpr int kMfmaThreads = kMfmaWaves * kWave;
+constexpr int kMfmaSlots = 16;          // slots per block
+constexpr int kMfmaRN = 2;              // column tiles per wave pass
+
+// One-hot block -> fragment order.  Fragment (nt, kb): lane l holds bytes j = 0..15 = X[n = 32 kb + 16 (l >> 5) + j][col = 32 nt + (l & 31)]
+// with col = f * S + s; zero for n >= N, col >= F * S and NA observations.
+__global__ void k_xt_frags(const uint8_t* __restrict__ state /* [N][Fp], 0xFF = NA */, uint8_t* __restrict__ xt,
+                           int N, int F, int S, int Fp, int NT, int KBp) {
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= (int64_t)NT * KBp * 64) return;
+    const int l = (int)(u & 63), kb = (int)((u >> 6) % KBp), nt = (int)((u >> 6) / KBp);
+    const int col = nt * 32 + (l & 31), f = col / S, s = col - f * S;
+    const int n0 = kb * 32 + 16 * (l >> 5);
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    if (col < F * S) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int n = n0 + j;
+            if (n < N && state[(int64_t)n * Fp + f] == (uint8_t)s) w[j >> 2] |= 1u << (8 * (j & 3));
+        }
+    }
+    reinterpret_cast<uint4*>(xt)[u] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+void launch_xt_frags(const uint8_t* state, uint8_t* xt, int N, int F, int S, int Fp, int NT, int KBp, hipStream_t st) {
+    const int64_t units = (int64_t)NT * KBp * 64;
+    k_xt_frags<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(state, xt, N, F, S, Fp, NT, KBp);
+}
+
+// table-driven log of tab_log_core (sbe_device_common.hip.h), G chains interleaved, with the log1p series cut at degree 6:
+// |r| <= 2^-8, so the first dropped term is < 2^-56 / 7 -- below half an ulp of every result that is not a cancellation
+// (and those carry the table's 2^-53 absolute rounding anyway).
+template <int G>
+__device__ __forceinline__ void tab_log6_n(const double (&v)[G], double (&out)[G], uint32_t tab) {
+    f64x2_t e[G];
+    double m[G], r[G], q[G], kd[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const uint32_t hi = (uint32_t)__double2hiint(v[g]);
+        e[g] = *(lds_cf64x2_t*)(uintptr_t)(tab + ((hi >> 9) & 0x7F0u));
+        m[g] = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), __double2loint(v[g]));
+        kd[g] = (double)((int)(hi >> 20) - 1023);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) r[g] = fma(m[g], e[g].x, -1.0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) q[g] = fma(-1.0 / 6.0, r[g], 0.2);
+#pragma unroll
+    for (int g = 0; g < G; ++g) q[g] = fma(q[g], r[g], -0.25);
+#pragma unroll
+    for (int g = 0; g < G; ++g) q[g] = fma(q[g], r[g], 1.0 / 3.0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) q[g] = fma(q[g], r[g], -0.5);
+#pragma unroll
+    for (int g = 0; g < G; ++g) q[g] = fma(r[g] * r[g], q[g], r[g]);          // log1p(r)
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        out[g] = fma(kd[g], 6.93147180369123816490e-01, e[g].y) + fma(kd[g], 1.90821492927058770002e-10, q[g]);
+}
+
+// per (slot of the block, tuple): byte offsets of the tuple's probability rows inside the probs array and of its
+// pattern's weight rows inside the wpat array
+template <int CT>
+struct __attribute__((aligned(CT <= 1 ? 8 : (CT <= 3 ? 16 : 32)))) TupleMeta {
+    uint32_t woff;
+    uint32_t goff[CT];
+};
+
+#ifdef SBE_MFMA_DEBUG
+__device__ double g_mfma_dbg[2 * 4 * 16 * 64 * 8];     // [r][m][reg][lane]{cnt, v, woff, goff0} of block 0, wave 0, first pass
+#endif
+
+template <int MT, int CT, int GT = 4>
+__global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixParams p) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int split = (int)blockIdx.x % p.n_split, sg = (int)blockIdx.x / p.n_split;
+    const int KBp = p.KBp;
+    // LDS map: A fragments [MT][KBp][64] x 16 B | log table 128 x 16 B | meta [16][2 MT] | reduction [8 waves][16] f64
+    const uint32_t a_bytes = (uint32_t)MT * (uint32_t)KBp * 1024u;
+    const uint32_t tab_off = a_bytes;
+    const uint32_t meta_off = tab_off + kLogTabEntries * 16u;
+    const uint32_t red_off = meta_off + (uint32_t)(kMfmaSlots * 2 * MT * sizeof(TupleMeta<CT>));
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_raw;
+    typedef TupleMeta<CT> Meta;
+    Meta* meta = reinterpret_cast<Meta*>(lds_raw + meta_off);
+    double* red = reinterpret_cast<double*>(lds_raw + red_off);
+
+    auto slot_of = [&](int sl) -> int {          // absolute slot of the block's sl-th slot, or -1
+        const int i = sg * kMfmaSlots + sl;
+        if (i >= p.n_batch) return -1;
+        return p.slot_list ? p.slot_list[i] : p.first_slot + i;
+    };
+
+    // ---- column tiles of this wave; the first X fragments are asked for before anything else --------------------------
+    // X fragments come through a buffer descriptor: lane-constant vector offset, scalar fragment offset, no address
+    // arithmetic and no bounds branches -- a tile beyond the split's range reads the zero tile behind the array
+    // (index NT), and the PF fragments read ahead past a tile's last k-block are the next tile's first (discarded).
+    const int nt_lo = split * p.nt_per_split, nt_hi = min(p.NT, nt_lo + p.nt_per_split);
+    constexpr int PF = 4;                         // k-blocks in flight (KBp is a multiple of PF)
+    const __amdgpu_buffer_rsrc_t xt_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.xt), 0, (int)p.xt_bytes, 0x00020000);
+    const int lane16 = lane * 16;
+    auto tile_off = [&](int nt) -> int { return (nt < nt_hi ? nt : p.NT) * KBp * 1024; };       // scalar
+    auto load_b = [&](int toff, int kb) -> v4i_t {
+        const u32x4_t d = __builtin_amdgcn_raw_buffer_load_b128(xt_rsrc, lane16, toff + kb * 1024, 0);
+        v4i_t r; r.x = (int)d.x; r.y = (int)d.y; r.z = (int)d.z; r.w = (int)d.w;
+        return r;
+    };
+    v4i_t bq[PF][kMfmaRN];
+    {
+        const int nt0 = nt_lo + w * kMfmaRN;
+#pragma unroll
+        for (int i = 0; i < PF; ++i)
+#pragma unroll
+            for (int r = 0; r < kMfmaRN; ++r) bq[i][r] = load_b(tile_off(nt0 + r), i);
+    }
+
+    // ---- phase 0: tuple metadata, log table, A fragments ------------------------------------------------------------
+    // Offsets of a tuple that is not there (another slot's tuple, the padding tuple of an odd KT, a slot beyond the batch)
+    // and of a component the tuple has no group in point at the zero rows behind the two arrays: no observation is
+    // counted on the former, and the normalised weight of the latter is exactly 0.
+    if ((int)threadIdx.x < kMfmaSlots * 2 * MT) {
+        const int sl = (int)threadIdx.x / (2 * MT), t = (int)threadIdx.x % (2 * MT);
+        const int slot = slot_of(sl);
+        Meta md;
+        md.woff = p.wpat_zero_off;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) md.goff[c] = p.probs_zero_off;
+        if (slot >= 0 && t < p.KT) {
+            const uint32_t pat = p.tuple_p[(int64_t)slot * p.tuple_p_stride + t];
+            if (pat != 0xFFu) {
+                md.woff = (uint32_t)(((int64_t)slot * p.wpat_stride + (int64_t)pat * p.F * CT) * 4);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const uint32_t g = p.tuple_g[(int64_t)slot * p.tuple_g_stride + t * kMaxComponents + c];
+                    if ((int)g < p.Gtot) md.goff[c] = (uint32_t)(((int64_t)slot * p.probs_stride + (int64_t)g * p.FS) * 4);
+                }
+            }
+        }
+        meta[sl * 2 * MT + t] = md;
+    }
+    if (threadIdx.x < 2 * kLogTabEntries)
+        reinterpret_cast<double*>(lds_raw + tab_off)[threadIdx.x] = reinterpret_cast<const double*>(p.logtab)[threadIdx.x];
+    {
+        // one unit = the 16 tuple ids of (slot sl, 16 objects) -> the 2 MT indicator pieces of those objects
+        const int n_units = kMfmaSlots * KBp * 2;
+        for (int u = (int)threadIdx.x; u < n_units; u += kMfmaThreads) {
+            const int sl = u & 15, hk = u >> 4;            // hk = kb * 2 + h
+            const int kb = hk >> 1, h = hk & 1;
+            const int n0 = kb * 32 + 16 * h;
+            const int slot = slot_of(sl);
+            uint32_t d[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d[i] = 0xFFFFFFFFu;                                        // matches no tuple
+                if (slot >= 0 && n0 + 4 * i + 4 <= p.Np)
+                    d[i] = *reinterpret_cast<const uint32_t*>(p.tid + (int64_t)slot * p.tid_stride + n0 + 4 * i);
+            }
+#pragma unroll
+            for (int t = 0; t < 2 * MT; ++t) {
+                uint4 o;
+                uint32_t* ov = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t x = d[i] ^ ((uint32_t)t * 0x01010101u);
+                    const uint32_t nz = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;      // bit 7 of a byte: byte != 0
+                    ov[i] = (~nz >> 7) & 0x01010101u;
+                }
+                // fragment (m = t >> 1, kb): lane = h * 32 + (t & 1) * 16 + sl
+                const uint32_t fl = (uint32_t)(h * 32 + (t & 1) * 16 + sl);
+                *reinterpret_cast<uint4*>(lds_raw + (((uint32_t)(t >> 1) * (uint32_t)KBp + (uint32_t)kb) * 64u + fl) * 16u) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: counts on the matrix pipe, table entries + log + dot product on the vector pipe ----------------------
+    const int h = lane >> 5, cl = lane & 31;
+    double lsum[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lsum[i] = 0.0;
+    const __amdgpu_buffer_rsrc_t pr_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.probs), 0, (int)p.probs_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpat), 0, (int)p.wpat_bytes, 0x00020000);
+    const uint32_t a_lane = lds_base + (uint32_t)lane * 16u;
+    const uint32_t tab_abs = lds_base + tab_off;
+
+    for (int nt0 = nt_lo + w * kMfmaRN; nt0 < nt_hi; nt0 += kMfmaWaves * kMfmaRN) {
+        int toff[kMfmaRN];
+#pragma unroll
+        for (int r = 0; r < kMfmaRN; ++r) toff[r] = tile_off(nt0 + r);
+        if (nt0 != nt_lo + w * kMfmaRN) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+#pragma unroll
+                for (int r = 0; r < kMfmaRN; ++r) bq[i][r] = load_b(toff[r], i);
+        }
+        v16i_t acc[MT][kMfmaRN];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < kMfmaRN; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][r][i] = 0;
+        for (int kb0 = 0; kb0 < KBp; kb0 += PF) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int kb = kb0 + i;
+                v4i_t a[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    a[m] = *(lds_cv4i_t*)(uintptr_t)(a_lane + ((uint32_t)m * (uint32_t)KBp + (uint32_t)kb) * 1024u);
+                v4i_t b[kMfmaRN];
+#pragma unroll
+                for (int r = 0; r < kMfmaRN; ++r) b[r] = bq[i][r];
+#pragma unroll
+                for (int r = 0; r < kMfmaRN; ++r) bq[i][r] = load_b(toff[r], kb + PF);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < kMfmaRN; ++r)
+                        acc[m][r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[r], acc[m][r], 0, 0, 0);
+            }
+        }
+        // epilogue: LL += cnt * log(sum_c w * p) over the wave's 2 * MT count tiles.  A "quad" = the four entries
+        // (tuple t, slots sl0 .. sl0+3) of one register quad of one tile; software pipeline over the quads: the tuple
+        // metadata (LDS) two quads ahead, the table operands (L2 / HBM) one quad ahead.  Columns beyond F*S and tiles
+        // beyond the split have no counts (their X fragments are zero), so nothing needs a bounds condition here.
+        uint32_t col4[kMfmaRN], fw4[kMfmaRN];
+#pragma unroll
+        for (int r = 0; r < kMfmaRN; ++r) {
+            const uint32_t colc = (uint32_t)min((nt0 + r) * 32 + cl, p.FS - 1);
+            const uint32_t f = colc / (uint32_t)p.S;
+            col4[r] = colc * 4u; fw4[r] = f * (uint32_t)(CT * 4);
+        }
+        // A step = G entries of one register quad (G = 4: the whole quad; G = 2: half of it); steps run r-minor.
+        constexpr int G = GT;
+        constexpr int HQ = 4 / G;                                    // steps per quad
+        constexpr int NST = MT * 4 * HQ * kMfmaRN;                   // steps: (m, j, half) major, r minor
+        Meta mdq[G];
+        float prq[2][G][CT], wrq[2][G][CT];
+        auto st_meta = [&](int u) {                                 // u = (m * 4 + j) * HQ + half
+            const int mj = u / HQ, half = u % HQ, m = mj >> 2, j = mj & 3;
+            const int t = 2 * m + (j >> 1), sl0 = 8 * (j & 1) + 4 * h + half * G;
+#pragma unroll
+            for (int i = 0; i < G; ++i) mdq[i] = meta[(sl0 + i) * 2 * MT + t];
+        };
+        auto st_load = [&](int q) {
+            const int r = q % kMfmaRN;
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const uint32_t wo = mdq[i].woff + fw4[r];
+                if constexpr (CT == 2) {
+                    const u32x2_t v2 = __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, (int)wo, 0, 0);
+                    // (__uint_as_float of a copy: __builtin_bit_cast on a vector ELEMENT lvalue reads element 0 whatever the
+                    //  element -- clang 22 / ROCm 7.2; found with the debug dump of this kernel)
+                    const uint32_t e0 = v2.x, e1 = v2.y;
+                    wrq[q & 1][i][0] = __uint_as_float(e0); wrq[q & 1][i][1] = __uint_as_float(e1);
+                } else if constexpr (CT == 4) {
+                    const u32x4_t v4 = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)wo, 0, 0);
+                    const uint32_t e0 = v4.x, e1 = v4.y, e2 = v4.z, e3 = v4.w;
+                    wrq[q & 1][i][0] = __uint_as_float(e0); wrq[q & 1][i][1] = __uint_as_float(e1);
+                    wrq[q & 1][i][2] = __uint_as_float(e2); wrq[q & 1][i][3] = __uint_as_float(e3);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        wrq[q & 1][i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w_rsrc, (int)(wo + 4u * c), 0, 0));
+                }
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    prq[q & 1][i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr_rsrc, (int)(mdq[i].goff[c] + col4[r]), 0, 0));
+            }
+        };
+        auto st_comp = [&](int q) {
+            const int r = q % kMfmaRN, u = q / kMfmaRN, mj = u / HQ, half = u % HQ, m = mj >> 2, j = mj & 3;
+            double vv[G], lg[G];
+            int cnt[G];
+            bool special = false;
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                cnt[i] = acc[m][r][4 * j + half * G + i];
+                double v = 0.0;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const double term = (double)wrq[q & 1][i][c] * (double)prq[q & 1][i][c];
+                    v = c == 0 ? term : v + term;                       // NumPy order, no FMA
+                }
+                // entries no observation falls on contribute nothing whatever their table value is (the zero
+                // probability of an inapplicable state included): log 1
+#ifdef SBE_MFMA_DEBUG
+                if (blockIdx.x == 0 && w == 0 && nt0 == nt_lo) {
+                    double* o = g_mfma_dbg + ((((int64_t)r * 4 + m) * 16 + (4 * j + half * G + i)) * 64 + lane) * 8;
+                    o[0] = cnt[i]; o[1] = v; o[2] = wrq[q & 1][i][0]; o[3] = prq[q & 1][i][0];
+                    o[4] = wrq[q & 1][i][CT - 1]; o[5] = prq[q & 1][i][CT - 1]; o[6] = col4[r]; o[7] = fw4[r];
+                }
+#endif
+                vv[i] = cnt[i] != 0 ? v : 1.0;
+                special |= tab_log_special(vv[i]);
+            }
+            tab_log6_n<G>(vv, lg, tab_abs);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0ull, 0)) {     // rare: library log
+#pragma unroll
+                for (int i = 0; i < G; ++i) if (tab_log_special(vv[i])) lg[i] = lib_log(vv[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int k = (j & 1) * 4 + half * G + i;
+                lsum[k] = fma((double)cnt[i], lg[i], lsum[k]);
+                // (pins the sum in this step's block: the rare-path branch above splits the epilogue into basic blocks and
+                //  the compiler otherwise sinks the whole chain of sums to the last one, keeping every log alive: 150 spills)
+                asm volatile("" : "+v"(lsum[k]));
+            }
+        };
+        // the single metadata buffer is refilled as soon as the loads of its last step (r = RN - 1) are out
+        st_meta(0);
+        st_load(0);
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            if (q + 1 < NST) {
+                st_load(q + 1);
+                if ((q + 2) % kMfmaRN == 0 && q + 2 < NST) st_meta((q + 2) / kMfmaRN);
+            }
+            st_comp(q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- phase 2: fixed-order reduction: 32 columns of a lane half, then the 8 waves ------------------------------------
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        double v = lsum[i];
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        lsum[i] = v;
+    }
+    if (cl == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[w * kMfmaSlots + 8 * (i >> 2) + 4 * h + (i & 3)] = lsum[i];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < kMfmaSlots) {
+        const int slot = slot_of((int)threadIdx.x);
+        if (slot >= 0) {
+            double total = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < kMfmaWaves; ++ww) total += red[ww * kMfmaSlots + threadIdx.x];
+            p.partials[(int64_t)slot * p.partials_stride + split] = total;
+        }
+    }
+}
+
+size_t tuple_mfma_lds_bytes(int MT, int C, int KBp) {
+    const size_t meta = (size_t)kMfmaSlots * 2 * MT * (C <= 1 ? 8 : (C <= 3 ? 16 : 32));
+    return (size_t)MT * KBp * 1024 + kLogTabEntries * 16 + meta + (size_t)kMfmaWaves * kMfmaSlots * sizeof(double);
+}
+
+// entries per epilogue step: a whole register quad where the registers allow it, half a quad for the widest instances
+template <int MT, int CT> constexpr int mfma_gt() { return (MT >= 4 || (MT == 3 && CT >= 3)) ? 2 : 4; }
+
+template <int MT>
+static void launch_mfma_mt(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st) {
+    switch (C) {
+        case 1: k_mixture_tuple_mfma<MT, 1, mfma_gt<MT, 1>()><<<grid, kMfmaThreads, lds, st>>>(p); break;
+        case 2: k_mixture_tuple_mfma<MT, 2, mfma_gt<MT, 2>()><<<grid, kMfmaThreads, lds, st>>>(p); break;
+        case 3: k_mixture_tuple_mfma<MT, 3, mfma_gt<MT, 3>()><<<grid, kMfmaThreads, lds, st>>>(p); break;
+        default: k_mixture_tuple_mfma<MT, 4, mfma_gt<MT, 4>()><<<grid, kMfmaThreads, lds, st>>>(p); break;
+    }
+}
+
+// one-time: the kernels ask for up to the whole 160 KB of a CU's LDS
+template <int MT, int CT>
+static void allow_lds() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<MT, CT, mfma_gt<MT, CT>()>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+void launch_tuple_mfma(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st) {
+#ifdef SBE_MFMA_DEBUG
+    struct Dump { hipStream_t st; ~Dump() {
+        (void)hipStreamSynchronize(st);
+        static double h[2 * 4 * 16 * 64 * 8];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mfma_dbg), sizeof h);
+        if (const char* path = getenv("SBE_MFMA_DEBUG_FILE")) { FILE* f = fopen(path, "wb"); if (f) { fwrite(h, 1, sizeof h, f); fclose(f); } }
+    } } dump{st};
+#endif
+    static const bool once = [] {
+        allow_lds<1, 1>(); allow_lds<1, 2>(); allow_lds<1, 3>(); allow_lds<1, 4>();
+        allow_lds<2, 1>(); allow_lds<2, 2>(); allow_lds<2, 3>(); allow_lds<2, 4>();
+        allow_lds<3, 1>(); allow_lds<3, 2>(); allow_lds<3, 3>(); allow_lds<3, 4>();
+        allow_lds<4, 1>(); allow_lds<4, 2>(); allow_lds<4, 3>(); allow_lds<4, 4>();
+        return true;
+    }();
+    (void)once;
+    const int MT = (p.KT + 1) / 2;
+    switch (MT) {
+        case 1: launch_mfma_mt<1>(C, p, grid, lds, st); break;
+        case 2: launch_mfma_mt<2>(C, p, grid, lds, st); break;
+        case 3: launch_mfma_mt<3>(C, p, grid, lds, st); break;
+        default: launch_mfma_mt<4>(C, p, grid, lds, st); break;
+    }
+}
+
+}  // namespace sbe

@@ -17,6 +17,7 @@ from . import _fast, _lib, _proc
 MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_TUPLE, MIXTURE_ONEHOT_GENERAL = 0, 1, 2, 3, 4
 MIXTURE_PACKED_TUPLE_LDS = 5
 MIXTURE_PACKED_V2 = 6
+MIXTURE_PACKED_TUPLE_MFMA = 7
 LOG_PER_OBS, LOG_PRODUCT = 0, 1
 _OPT_KERNEL, _OPT_LOG, _OPT_DEFERRED = 1, 2, 3
 

@@ -9,7 +9,7 @@ import pytest
 
 from oracle import sbayes_oracle as orc
 from sbayes_amd.engine import (LOG_PER_OBS, LOG_PRODUCT, MIXTURE_ONEHOT, MIXTURE_PACKED, MIXTURE_ONEHOT_GENERAL, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2,
-                               MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, Engine, EngineError)
+                               MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, MIXTURE_PACKED_TUPLE_MFMA, Engine, EngineError)
 from sbayes_amd.synthetic import make_state, make_workload
 from tests._fixtures import GOLDEN, crc, load_json, load_npz
 
@@ -63,14 +63,19 @@ def test_dense_outputs_bit_exact(name):
 
 @pytest.mark.parametrize("name", NPZ)
 @pytest.mark.parametrize("kernel", [MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2, MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS,
-                                    MIXTURE_ONEHOT_GENERAL])
+                                    MIXTURE_ONEHOT_GENERAL, MIXTURE_PACKED_TUPLE_MFMA])
 @pytest.mark.parametrize("log_mode", [LOG_PER_OBS, LOG_PRODUCT])
 def test_mixture_loglik(name, kernel, log_mode):
     fx = load_npz(name)
     with engine_for(fx) as eng:
         load_fixture_state(eng, fx)
         eng.set_option(kernel=kernel, log_mode=log_mode)
-        ll = eng.mixture_loglik(0)
+        try:
+            ll = eng.mixture_loglik(0)
+        except EngineError as exc:                 # the matrix-pipe form holds at most 8 group tuples (south_america: 17)
+            assert kernel == MIXTURE_PACKED_TUPLE_MFMA and "not applicable" in str(exc), exc
+            assert name == "south_america"
+            return
         want = fx.meta["mixture_ll"]
         assert abs(ll - want) <= MIX_RTOL * abs(want), (ll, want)
         assert eng.mixture_loglik(0) == ll      # deterministic reduction order
@@ -177,7 +182,7 @@ def test_big_synthetic_against_reference_digests(name):
         assert crc(eng.observation_lh(0)) == meta["obs_crc"]
         assert crc(eng.likelihood_per_component_exact(0)) == meta["lh_exact_crc"]
         want = meta["mixture_ll"]
-        for kernel in (MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2, MIXTURE_ONEHOT_GENERAL) + ((MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS) if name == "headline" else ()):
+        for kernel in (MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2, MIXTURE_ONEHOT_GENERAL) + ((MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, MIXTURE_PACKED_TUPLE_MFMA) if name == "headline" else ()):
             for log_mode in (LOG_PER_OBS, LOG_PRODUCT):
                 eng.set_option(kernel=kernel, log_mode=log_mode)
                 ll = eng.mixture_loglik(0)
@@ -206,7 +211,7 @@ def test_batch_of_states_matches_oracle():
             want.append(orc.mixture_loglik(wl.features, wl.na_values, groups, counts, wl.concentration, weights))
         got = eng.mixture_loglik_batch(0, B)
         np.testing.assert_allclose(got, np.array(want), rtol=MIX_RTOL)
-        for kernel in (MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2, MIXTURE_ONEHOT, MIXTURE_ONEHOT_GENERAL):
+        for kernel in (MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, MIXTURE_PACKED_TUPLE_MFMA, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2, MIXTURE_ONEHOT, MIXTURE_ONEHOT_GENERAL):
             eng.set_option(kernel=kernel)
             np.testing.assert_allclose(eng.mixture_loglik_batch(0, B), np.array(want), rtol=MIX_RTOL)
         eng.set_option(kernel=MIXTURE_PACKED)

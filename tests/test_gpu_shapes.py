@@ -9,7 +9,7 @@ import pytest
 
 from oracle import sbayes_oracle as orc
 from sbayes_amd.engine import (LOG_PER_OBS, LOG_PRODUCT, MIXTURE_ONEHOT, MIXTURE_PACKED, MIXTURE_ONEHOT_GENERAL, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2,
-                               MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, Engine, EngineError)
+                               MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, MIXTURE_PACKED_TUPLE_MFMA, Engine, EngineError)
 
 pytestmark = pytest.mark.gpu
 
@@ -127,13 +127,13 @@ def _run_case(feats, groups, weights, source, conc, n_groups, rng, light=False):
                                   orc.likelihood_per_component_exact(feats, na, groups, counts, conc, source))
             want = np.log(obs)[~na].sum()
         for kernel in (MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2, MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS,
-                       MIXTURE_ONEHOT_GENERAL):
+                       MIXTURE_ONEHOT_GENERAL, MIXTURE_PACKED_TUPLE_MFMA):
             for log_mode in (LOG_PER_OBS, LOG_PRODUCT):
                 eng.set_option(kernel=kernel, log_mode=log_mode)
                 try:
                     got = eng.mixture_loglik(0)
                 except EngineError as exc:
-                    if kernel in (MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS) and "not applicable" in str(exc):
+                    if kernel in (MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, MIXTURE_PACKED_TUPLE_MFMA) and "not applicable" in str(exc):
                         continue                 # more than 64 distinct group tuples / table too large
                     raise
                 if np.isfinite(want):
@@ -195,9 +195,13 @@ def test_tuple_kernel_batches(shape):
             counts = orc.recalculate_feature_counts(feats, groups, source)
             want.append(orc.mixture_loglik(feats, na, groups, counts, conc, weights))
         want = np.array(want)
-        for kernel in (MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2):
+        for kernel in (MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, MIXTURE_PACKED_TUPLE_MFMA, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2):
             eng.set_option(kernel=kernel)
-            got = eng.mixture_loglik_batch(0, B)
+            try:
+                got = eng.mixture_loglik_batch(0, B)
+            except EngineError as exc:               # the matrix-pipe form holds at most 8 tuples
+                assert kernel == MIXTURE_PACKED_TUPLE_MFMA and "not applicable" in str(exc), exc
+                continue
             np.testing.assert_allclose(got, want, rtol=1e-10, err_msg=f"kernel {kernel}")
             singles = np.array([eng.mixture_loglik(b) for b in range(B)])
             np.testing.assert_allclose(singles, want, rtol=1e-10, err_msg=f"kernel {kernel} (single)")
@@ -205,3 +209,103 @@ def test_tuple_kernel_batches(shape):
         eng.set_option(kernel=MIXTURE_PACKED_TUPLE)
         if B > 2:
             np.testing.assert_allclose(eng.mixture_loglik_batch(1, B - 2), want[1:B - 1], rtol=1e-10)
+
+
+@pytest.mark.parametrize("shape", [
+    # N,   F,   S,  groups,     n_slots   (what it exercises in k_mixture_tuple_mfma)
+    (50,   30,  5,  [2, 1],     1),       # one slot of a 16-slot block; odd tuple count (padding tuple); 2 k-blocks padded to 4
+    (203,  72,  4,  [3, 1],     19),      # batch not a multiple of 16; 9 column tiles, one split
+    (97,   130, 20, [6, 1],     40),      # 7 tuples -> 4 M tiles (half-quad epilogue steps); 82 column tiles, several splits
+    (1000, 37,  3,  [5, 1],     64),      # 32 k-blocks (the headline's depth), last column tile 15 columns wide
+    (130,  40,  6,  [4],        33),      # C = 1 (every object in a group)
+    (120,  36,  5,  [2, 1, 1],  17),      # C = 3
+    (90,   25,  4,  [1, 1, 1, 1], 16),    # C = 4, exactly one block of slots
+    (40,   72,  3,  [2, 1],     600),     # many blocks per column split
+    (1301, 20,  3,  [2, 1],     16),      # 41 k-blocks padded to 44
+], ids=lambda s: f"N{s[0]}F{s[1]}S{s[2]}C{len(s[3])}B{s[4]}")
+def test_mfma_kernel_batches(shape):
+    """Batches through the matrix-pipe group-tuple kernel (counts per (slot, tuple, feature, state) by i8 MFMA, one log per
+    table entry): every slot holds a different state and must get the oracle's value and its own single-launch value.
+    States include inapplicable feature states (probability exactly 0 where no observation falls) and one slot with
+    fewer group tuples than the launch's maximum."""
+    N, F, S, n_groups, B = shape
+    rng = np.random.default_rng(N * 1000 + F + B)
+    feats, groups0, _w, _s, conc = random_case(rng, N, F, S, n_groups, 0.05)
+    # inapplicable states: the last state of every third feature never occurs and has concentration 0 (p = 0 exactly)
+    if S > 2:
+        dead = np.arange(F) % 3 == 0
+        moved = feats[:, dead, S - 1].copy()
+        feats[:, dead, S - 1] = False
+        feats[:, dead, 0] |= moved
+        for c in range(len(conc)):
+            conc[c] = conc[c].copy()
+            conc[c][..., dead, S - 1] = 0.0
+    na = ~feats.any(-1)
+    C = len(n_groups)
+    with Engine(feats, n_groups, n_slots=B) as eng:
+        for c in range(C):
+            eng.set_concentration(c, conc[c])
+        want = []
+        for b in range(B):
+            if C == 1:
+                groups = groups0
+            else:
+                a = rng.integers(0, 2 * n_groups[0], size=N)
+                if b == 1:
+                    a[:] = 2 * n_groups[0] - 1          # nobody in a cluster: fewer group tuples than the other slots
+                groups = [np.stack([a == k for k in range(n_groups[0])])] + groups0[1:]
+            weights = rng.dirichlet(np.ones(C), size=F).astype(np.float32)
+            hc = orc.has_components(groups)
+            src_idx = np.argmax(rng.random((N, F, C)) * hc[:, None, :], axis=-1)      # a random available component
+            source = np.eye(C, dtype=bool)[src_idx]
+            source[na] = False
+            source[~hc.any(1)] = False
+            eng.load_state(b, groups, weights, source=source)
+            for c in range(C):
+                eng.update_probs(b, c)
+            counts = orc.recalculate_feature_counts(feats, groups, source)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                want.append(orc.mixture_loglik(feats, na, groups, counts, conc, weights))
+        want = np.array(want)
+        assert np.all(np.isfinite(want))
+        eng.set_option(kernel=MIXTURE_PACKED_TUPLE_MFMA)
+        got = eng.mixture_loglik_batch(0, B)
+        assert "k_mixture_tuple_mfma" in eng.last_mixture_kernel()
+        np.testing.assert_allclose(got, want, rtol=1e-10)
+        assert np.array_equal(eng.mixture_loglik_batch(0, B), got)                     # fixed reduction order
+        picks = sorted(set([0, B - 1, B // 2]))
+        singles = np.array([eng.mixture_loglik(b) for b in picks])
+        np.testing.assert_allclose(singles, want[picks], rtol=1e-10)
+        if B > 2:
+            np.testing.assert_allclose(eng.mixture_loglik_batch(1, B - 2), want[1:B - 1], rtol=1e-10)
+        eng.set_option(kernel=MIXTURE_PACKED_TUPLE)
+        np.testing.assert_allclose(eng.mixture_loglik_batch(0, B), got, rtol=1e-12)    # the vector-pipe form of the same table
+
+
+def test_mfma_kernel_default_choice_and_zero_probability():
+    """SBE_MIXTURE_PACKED picks the matrix-pipe form from 256 slots per launch on (the vector-pipe form below), and a
+    zero-probability OBSERVED state gives -inf like the reference's log(0), in that slot only."""
+    rng = np.random.default_rng(5)
+    N, F, S, B = 60, 12, 3, 256
+    feats, groups0, _w, _s, _conc = random_case(rng, N, F, S, [2, 1], 0.0)
+    with Engine(feats, [2, 1], n_slots=B) as eng:
+        a = rng.integers(0, 4, size=N)
+        groups = [np.stack([a == k for k in range(2)])] + groups0[1:]
+        probs = [rng.dirichlet(np.ones(S), size=(2, F)).astype(np.float32), rng.dirichlet(np.ones(S), size=(1, F)).astype(np.float32)]
+        weights = rng.dirichlet(np.ones(2), size=F).astype(np.float32)
+        eng.load_state(0, groups, weights, probs=probs)
+        for b in range(1, B):
+            eng.copy_slot(b, 0)
+        bad = [p.copy() for p in probs]
+        bad[0][:, 3, :] = 0.0
+        bad[1][:, 3, :] = 0.0                           # feature 3: every component gives probability 0
+        eng.set_probs(7, 0, bad[0]); eng.set_probs(7, 1, bad[1])
+        eng.set_option(kernel=MIXTURE_PACKED)
+        got = eng.mixture_loglik_batch(0, B)
+        assert "k_mixture_tuple_mfma" in eng.last_mixture_kernel()
+        ref = eng.mixture_loglik_batch(0, B - 1)
+        assert "k_mixture_tuple64" in eng.last_mixture_kernel() or "k_mixture_combo" in eng.last_mixture_kernel()
+        assert got[7] == -np.inf and ref[7] == -np.inf
+        keep = np.arange(B - 1) != 7
+        np.testing.assert_allclose(got[:B - 1][keep], ref[keep], rtol=1e-12)
+        assert np.all(np.isfinite(got[np.arange(B) != 7]))

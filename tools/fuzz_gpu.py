@@ -13,7 +13,7 @@ REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO))
 from oracle import sbayes_oracle as orc                                       # noqa: E402  (checker only)
 from sbayes_amd.engine import (MIXTURE_ONEHOT, MIXTURE_ONEHOT_GENERAL, MIXTURE_PACKED, MIXTURE_PACKED_GENERAL,   # noqa: E402
-                               MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, MIXTURE_PACKED_V2, Engine, EngineError)
+                               MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS, MIXTURE_PACKED_TUPLE_MFMA, MIXTURE_PACKED_V2, Engine, EngineError)
 from tests.test_gpu_shapes import random_case                                  # noqa: E402
 
 
@@ -327,7 +327,7 @@ def one_case(rng, stats, big=False):
         if not np.all(np.isfinite(want)):
             return                                  # objects without any component: the reference asserts there
         for kernel in (MIXTURE_PACKED, MIXTURE_ONEHOT, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2, MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_LDS,
-                       MIXTURE_ONEHOT_GENERAL):
+                       MIXTURE_ONEHOT_GENERAL, MIXTURE_PACKED_TUPLE_MFMA):
             eng.set_option(kernel=kernel)
             try:
                 got = eng.mixture_loglik_batch(0, B)
