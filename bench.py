@@ -48,7 +48,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 N_SIMDS = 1024             # 256 CUs x 4 SIMD-32
 HEADLINE_BATCH = 2048      # resident states per launch sequence (tools/summarize_profiles.py keys the PMC passes on it)
 NOMINAL_CLOCK_GHZ = 2.4    # MI355X_MICROARCH.md "Max clock"
-PMC_FILE = "profiles/r4/pmc_summary.json"
+I8_MFMA_PEAK_TOPS = 5000.0 # MI355X_MICROARCH.md: dense i8 MFMA = 2 x the bf16 rate (~2.5 PF): ~5 POP/s
+PMC_FILE = "profiles/r5/pmc_summary.json"
 TRAFFIC_FILE = "profiles/traffic_latest.json"
 
 
@@ -68,7 +69,7 @@ def parse():
     ap.add_argument("--kernel", default="packed", choices=["packed", "packed_general", "packed_v2", "packed_tuple", "packed_tuple_lds", "packed_tuple_mfma", "onehot", "onehot_general"],
                     help="packed: state-index stream, group-tuple form when it applies (default); "
                          "packed_tuple: group-tuple form on the vector pipe forced (k_mixture_tuple64: what `packed` ran before round 5); "
-                         "packed_tuple_mfma: its matrix-pipe form forced (k_mixture_tuple_mfma: what `packed` picks for >= 256 states); "
+                         "packed_tuple_mfma: its matrix-pipe form forced (k_mixture_tuple_mfma: what `packed` picks for >= 512 states); "
                          "packed_general: never the group-tuple form (k_mixture_rows); packed_v2: the older general "
                          "kernel k_mixture_v2; onehot: stream the one-hot block")
     ap.add_argument("--log-mode", default="product", choices=["product", "per_obs"])
@@ -242,7 +243,7 @@ def per_config_block(device, headline_eng, cpu_seconds):
     """Every 1-GPU BASELINE config (cfg1 = configs[0] shape, south_america = configs[1], headline = configs[2],
     stress = configs[4] shape) at B in {1, 8, 64}: evals/s of the async batch loop and the dominant kernel's HIP-event
     duration; the oracle's single-thread rate beside it (bounded sample)."""
-    from sbayes_amd.synthetic import algorithmic_bytes
+    from sbayes_amd.synthetic import algorithmic_bytes, unique_bytes_per_launch
     out = {}
     for name in ("cfg1", "south_america", "headline", "stress"):
         wl = load_workload(name)
@@ -548,7 +549,7 @@ def static_profile_figures(workload, kernel, B, kern_us, kernel_name=None, resul
                                          f"of this command, profile {rec.get('profile')}; kernel name and results digest match this run)"}
         except Exception:
             pass
-    for cand in (PMC_FILE, "profiles/r3/pmc_summary.json", "profiles/r2/pmc_summary.json"):
+    for cand in (PMC_FILE, "profiles/r4/pmc_summary.json", "profiles/r3/pmc_summary.json", "profiles/r2/pmc_summary.json"):
         pf = REPO / cand
         if not pf.exists():
             continue
@@ -572,6 +573,58 @@ def static_profile_figures(workload, kernel, B, kern_us, kernel_name=None, resul
     return traffic, valu, stale
 
 
+def roofline_block(b_eval, unique_bytes, B, kern_ms, traffic, valu, kernel_name, packed, kernel_avg_source, shape=None):
+    """The `roofline` object of the output line (pure arithmetic: tests/test_bench_roofline_cpu.py).
+    Three HBM figures for the dominant kernel, all over the SAME measured kernel time:
+      frac          contract figure of SURVEY.md 8(d): algorithmic bytes per eval x evals per launch (the feature block
+                    counted once PER EVAL although the B states of a launch share it) / 8 TB/s -- exceeds 1 once the
+                    kernel stops re-reading the block per state;
+      frac_unique   the same inventory with the shared block counted ONCE per launch: what a launch must move at least;
+      frac_traffic  what the HBM counters saw (static PMC passes; None when no pass of this build is committed).
+    `bound` names the pipe that limits the kernel: "valu" when the vector-issue fraction (roofline_valu) exceeds the
+    measured traffic fraction, else "hbm"."""
+    kern_s = kern_ms * 1e-3
+    achieved = b_eval * B / kern_s / 1e9
+    frac_unique = unique_bytes / kern_s / 1e9 / HBM_PEAK_GBS
+    frac_traffic = traffic["bytes_per_launch"] / kern_s / 1e9 / HBM_PEAK_GBS if traffic else None
+    bound = "hbm"
+    if valu and valu.get("frac") is not None and (frac_traffic is None or valu["frac"] > frac_traffic) and valu["frac"] > frac_unique:
+        bound = "valu"
+    out = {
+        "bound": bound, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "traffic": traffic["bytes_per_launch"] if traffic else None,
+        "traffic_source": traffic["source"] if traffic else None,
+        "frac_traffic": round(frac_traffic, 5) if frac_traffic is not None else None,
+        "unique_bytes_per_launch": int(unique_bytes), "frac_unique": round(frac_unique, 5),
+        "kernel": kernel_name,
+        "kernel_avg_us": round(kern_ms * 1e3, 3),
+        "kernel_avg_source": kernel_avg_source,
+        "algorithmic_bytes_per_eval": b_eval, "evals_per_launch": B,
+        "representation": "packed state index (N*F bytes)" if packed else "one-hot (N*F*S bytes)",
+        "note": "frac = contractual HBM roofline (algorithmic bytes per eval x evals per launch / 8 TB/s): it counts the feature "
+                "block once per eval although the states of a launch share it, and exceeds 1 for a kernel that reads the block "
+                "once per launch; frac_unique counts the block once per launch (the figure that stays meaningful), frac_traffic "
+                "is what the HBM counters saw.  At the headline shape the working set is L2/MALL-resident and the kernel is "
+                "vector-issue bound: see roofline_valu",
+    }
+    if "k_mixture_tuple_mfma" in kernel_name and shape is not None:
+        # counts on the matrix pipe: rows (16 slots x 2 tuples per 32-row tile) x columns (F*S padded to 32) x objects (padded to 128)
+        import re
+        m = re.search(r"M tiles (\d+)", kernel_name)
+        mt = int(m.group(1)) if m else 1
+        n_obj, n_feat, n_states = shape
+        rows = -(-B // 16) * mt * 32
+        cols = -(-(n_feat * n_states) // 32) * 32
+        depth = -(-n_obj // 128) * 128
+        ops = 2.0 * rows * cols * depth
+        out["matrix_pipe"] = {"int8_ops_per_launch": ops, "achieved_tops": round(ops / kern_s / 1e12, 1), "peak_tops": I8_MFMA_PEAK_TOPS,
+                              "frac": round(ops / kern_s / 1e12 / I8_MFMA_PEAK_TOPS, 4),
+                              "note": "v_mfma_i32_32x32x32_i8 work of the count contraction (padded tile sizes) over the measured "
+                                      "kernel time; the kernel's vector epilogue (one log per table entry), not the matrix pipe, is its limiter"}
+    return out
+
+
 def main():
     args = parse()
     from sbayes_amd import chains
@@ -582,7 +635,7 @@ def main():
     dist = chains.init_process_group()
 
     from sbayes_amd.engine import device_count
-    from sbayes_amd.synthetic import algorithmic_bytes
+    from sbayes_amd.synthetic import algorithmic_bytes, unique_bytes_per_launch
 
     n_dev = device_count()
     device = chains.device_for(local_rank, n_dev)
@@ -625,6 +678,8 @@ def main():
     eng.kernel_timing_start()                      # (events are bracketing nothing until resumed inside the loop)
     eng.kernel_timing_pause()
 
+    own_times = []
+
     def timed_rep():
         """EXACTLY K steps, barrier + stream sync on both sides, max over ranks."""
         barrier()
@@ -637,7 +692,9 @@ def main():
             else:
                 step()
         res = eng.fetch_results(0, B)              # D2H of the B scalars + stream sync, inside the timed region
+        own = time.perf_counter() - t0             # this rank's own K steps (before it waits for the others)
         barrier()
+        own_times.append(own)
         return chains.max_over_ranks(time.perf_counter() - t0, dist), res
 
     # A K-step loop is ~1 ms at the driver's K = 20: one stray interrupt moves it by percents.  The loop is therefore
@@ -676,21 +733,30 @@ def main():
     results_digest = __import__("hashlib").sha1(np.ascontiguousarray(results).tobytes()).hexdigest()[:16]
     traffic, valu, stale = static_profile_figures(args.workload, args.kernel, B, kern_ms * 1e3, eng.last_mixture_kernel(),
                                                   results_digest)
-    roofline = {
-        "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5),
-        "traffic": traffic["bytes_per_launch"] if traffic else None,
-        "traffic_source": traffic["source"] if traffic else None,
-        "kernel": eng.last_mixture_kernel(),
-        "kernel_avg_us": round(kern_ms * 1e3, 3),
-        "kernel_avg_source": (f"HIP event pairs on the engine's stream around every {stride}-th launch of the timed loops "
-                              f"({n_timed} of {args.steps * n_reps} launches in {n_reps} repetitions)" if stride > 0 else
-                              f"HIP event pairs around {n_timed} identical launches issued right after the timed loop"),
-        "algorithmic_bytes_per_eval": b_eval, "evals_per_launch": B,
-        "representation": "packed state index (N*F bytes)" if packed else "one-hot (N*F*S bytes)",
-        "note": "contractual HBM roofline (algorithmic bytes / 8 TB/s); at the headline shape the working set is "
-                "L2/MALL-resident and the kernel is VALU-issue bound: see roofline_valu",
-    }
+    unique = unique_bytes_per_launch(n_obj, n_feat, n_states, [g.shape[0] for g in wl.groups], n_pat, B, packed=packed)
+    roofline = roofline_block(b_eval, unique, B, kern_ms, traffic, valu, eng.last_mixture_kernel(), packed,
+                              (f"HIP event pairs on the engine's stream around every {stride}-th launch of the timed loops "
+                               f"({n_timed} of {args.steps * n_reps} launches in {n_reps} repetitions)" if stride > 0 else
+                               f"HIP event pairs around {n_timed} identical launches issued right after the timed loop"),
+                              shape=(n_obj, n_feat, n_states))
+
+    # ---- what every rank (= every GPU's chains) saw by itself: north_star asks for PER-CHAIN throughput at each N ------
+    # (chains are independent in the reference: sbayes/sampling/mcmc.py:239-241, one OS process per chain in MC3:
+    #  sbayes/mcmc_setup.py:271-299).  Each rank reports its own batched rate (its own K steps, not the max over ranks),
+    #  its own kernel time and what ONE host-synchronous chain gets on its GPU while the other ranks do the same.
+    per_rank = None
+    if n_gpus > 1:
+        own_rate = args.steps * B / float(np.median(own_times))
+        barrier()
+        for _ in range(10):
+            eng.mixture_loglik(0)
+        single_rate = _rate(lambda: eng.mixture_loglik(0), 0.2, 200)
+        barrier()
+        rows = [chains.gather_chain_values([rank], [v], world, dist)
+                for v in (float(info["device"]), own_rate, kern_ms * 1e3, single_rate)]
+        per_rank = [{"rank": r, "device": int(rows[0][r]), "evals_per_s": round(float(rows[1][r]), 1),
+                     "kernel_avg_us": round(float(rows[2][r]), 3), "single_chain_evals_per_s": round(float(rows[3][r]), 1)}
+                    for r in range(world)]
 
     extra = {}
     if rank == 0 and n_gpus == 1 and not args.no_secondary:
@@ -740,6 +806,16 @@ def main():
             "dist_backend": chains.backend_name(dist),
             "setup_s": round(t_setup, 2),
         }
+        if per_rank:
+            line["per_rank"] = per_rank
+            line["per_rank_evals_per_s_min"] = min(r["evals_per_s"] for r in per_rank)
+            line["per_rank_evals_per_s_max"] = max(r["evals_per_s"] for r in per_rank)
+            line["per_chain_evals_per_s_min"] = min(r["single_chain_evals_per_s"] for r in per_rank)
+            line["per_chain_evals_per_s_max"] = max(r["single_chain_evals_per_s"] for r in per_rank)
+            line["per_rank_note"] = ("per_rank[i].evals_per_s: rank i's own K-step loops (median repetition, its own clock, B resident states per "
+                                     "launch); single_chain_evals_per_s: one host-synchronous chain on rank i's GPU, all ranks measuring at "
+                                     "once; per_chain_* = min / max of the latter over the ranks.  `value` stays the whole-job aggregate over "
+                                     "the max-over-ranks time.")
         if valu:
             line["roofline_valu"] = valu
         if stale:

@@ -86,7 +86,9 @@ typedef struct sbe_engine sbe_engine;
                                           0/1 byte contraction on the matrix pipe (k_mixture_tuple_mfma: counts per
                                           (slot, tuple, feature, state) by v_mfma_i32_32x32x32_i8, then one log per table
                                           entry), forced (error if not applicable: more than 8 tuples, C > 4, LDS).
-                                          SBE_MIXTURE_PACKED picks it by itself for launches of >= 256 slots         */
+                                          SBE_MIXTURE_PACKED picks it by itself for launches of >= 512 slots
+                                          (tools/ab_mfma.py: 28 / 30 / 32 / 50 us against 20 / 32 / 55 / 98 us of
+                                          k_mixture_tuple64 at 256 / 512 / 1024 / 2048 headline states)         */
 #define SBE_OPT_LOG_MODE 2
 #define SBE_LOG_PER_OBS 0      /* fp64 log per observation, fp64 sum                        */
 #define SBE_LOG_PRODUCT 1      /* fp64 mantissa product + integer exponent, one log/thread  */

@@ -108,7 +108,7 @@ struct sbe_engine {
     std::atomic<uint64_t> epoch_counter{0};
     uint8_t* d_xt = nullptr;       // one-hot block in MFMA fragment order (k_mixture_tuple_mfma), built at the first batched launch
     int xt_NT = 0, xt_KBp = 0;  size_t xt_bytes = 0;
-    int mfma_min_batch = 256;      // smallest launch the matrix-pipe form is chosen for under SBE_MIXTURE_PACKED (SBE_MFMA_MIN_BATCH)
+    int mfma_min_batch = 512;      // smallest launch the matrix-pipe form is chosen for under SBE_MIXTURE_PACKED (SBE_MFMA_MIN_BATCH)
     uint8_t* d_tid = nullptr;      // [slots][Np] group-tuple index per object (k_mixture_combo)
     uint16_t* d_tuple_g = nullptr; // [slots][kMaxTuples][kMaxComponents]
     uint8_t* d_tuple_p = nullptr;  // [slots][kMaxTuples]
@@ -928,11 +928,11 @@ int launch_mfma_form(sbe_engine* e, int first_slot, int n, int KT, const MfmaGeo
     p.tuple_g = e->d_tuple_g; p.tuple_g_stride = (int64_t)kMaxTuples * kMaxComponents;
     p.tuple_p = e->d_tuple_p; p.tuple_p_stride = kMaxTuples;
     p.probs = e->d_probs; p.probs_stride = e->table_elems();
-    p.probs_zero_off = (uint32_t)((int64_t)e->n_slots * e->table_elems() * 4);
-    p.probs_bytes = p.probs_zero_off + (uint32_t)(e->F * e->S * 4);
+    p.probs_ones_off = (uint32_t)((int64_t)e->n_slots * e->table_elems() * 4);
+    p.probs_bytes = p.probs_ones_off + (uint32_t)(e->F * e->S * 4);
     p.wpat = e->d_wpat; p.wpat_stride = (int64_t)e->Pmax * e->F * e->C;
-    p.wpat_zero_off = (uint32_t)((int64_t)e->n_slots * e->Pmax * e->F * e->C * 4);
-    p.wpat_bytes = p.wpat_zero_off + (uint32_t)(e->F * e->C * 4);
+    p.wpat_ones_off = (uint32_t)((int64_t)e->n_slots * e->Pmax * e->F * e->C * 4);
+    p.wpat_bytes = p.wpat_ones_off + (uint32_t)(e->F * e->C * 4);
     p.logtab = e->d_logtab;
     p.partials = e->d_partials; p.partials_stride = e->partials_stride;
     launch_tuple_mfma(e->C, p, dim3((unsigned)(div_up(n, 16) * mg.n_split)), mg.lds, e->stream);
@@ -1401,11 +1401,14 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_RC(dmalloc(e, &e->d_pid, NS * e->Np));
     CREATE_RC(dmalloc(e, &e->d_src, NS * N * e->Fp));
     CREATE_RC(dmalloc(e, &e->d_counts, NS * e->table_elems()));
-    CREATE_RC(dmalloc(e, &e->d_probs, NS * e->table_elems() + F * S));      // + a zero row [F][S] } what k_mixture_tuple_mfma reads for
+    CREATE_RC(dmalloc(e, &e->d_probs, NS * e->table_elems() + F * S));      // + a row of ones [F][S] } what k_mixture_tuple_mfma reads for
     CREATE_RC(dmalloc(e, &e->d_weights, NS * F * C));
-    CREATE_RC(dmalloc(e, &e->d_wpat, NS * e->Pmax * F * C + F * C));        // + a zero row [F][C] } tuples / groups that are not there
-    CREATE_CHK(hipMemsetAsync(e->d_probs + NS * e->table_elems(), 0, F * S * sizeof(float), e->stream));
-    CREATE_CHK(hipMemsetAsync(e->d_wpat + NS * e->Pmax * F * C, 0, F * C * sizeof(float), e->stream));
+    CREATE_RC(dmalloc(e, &e->d_wpat, NS * e->Pmax * F * C + F * C));        // + a row of ones [F][C] } tuples / groups that are not there
+    {
+        const std::vector<float> ones((size_t)(F * std::max(S, C)), 1.0f);
+        CREATE_CHK(hipMemcpy(e->d_probs + NS * e->table_elems(), ones.data(), F * S * sizeof(float), hipMemcpyHostToDevice));
+        CREATE_CHK(hipMemcpy(e->d_wpat + NS * e->Pmax * F * C, ones.data(), F * C * sizeof(float), hipMemcpyHostToDevice));
+    }
     CREATE_RC(dmalloc(e, &e->d_patbits, NS * e->Pmax));
     CREATE_RC(dmalloc(e, &e->d_tid, NS * e->Np));
     CREATE_RC(dmalloc(e, &e->d_toff, NS * e->Np + 64));       // + padding: the kernel prefetches 16 entries ahead

@@ -66,7 +66,7 @@ struct MfmaMixParams {
     const uint8_t* tuple_p;  int64_t tuple_p_stride;   // per slot [kMaxTuples] pattern id of the tuple (0xFF: tuple not there)
     const float* probs;      int64_t probs_stride;  uint32_t probs_bytes;   // per slot [Gtot][F][S] float32 tables (a4), whole array < 4 GiB
     const float* wpat;       int64_t wpat_stride;   uint32_t wpat_bytes;    // per slot [Pmax][F][C] float32 normalised weights (a5)
-    uint32_t probs_zero_off, wpat_zero_off;        // byte offsets of the zero rows behind the two arrays (F*S / F*C floats)
+    uint32_t probs_ones_off, wpat_ones_off;        // byte offsets of the rows of ones behind the two arrays (F*S / F*C floats)
     const double2* logtab;                         // [128] {1/c, log c}
     double* partials;        int64_t partials_stride;
 };

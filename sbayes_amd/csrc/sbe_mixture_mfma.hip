@@ -62,11 +62,14 @@ void launch_xt_frags(const uint8_t* state, uint8_t* xt, int N, int F, int S, int
     k_xt_frags<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(state, xt, N, F, S, Fp, NT, KBp);
 }
 
-// table-driven log of tab_log_core (sbe_device_common.hip.h), G chains interleaved, with the log1p series cut at degree 6:
-// |r| <= 2^-8, so the first dropped term is < 2^-56 / 7 -- below half an ulp of every result that is not a cancellation
-// (and those carry the table's 2^-53 absolute rounding anyway).
+// table-driven log of tab_log_core (sbe_device_common.hip.h), G chains interleaved, trimmed to what a SUM of ~N*F logs
+// needs at 1e-10 relative (its terms are O(1), so ~1e-13 absolute per log leaves three orders of magnitude):
+//   * log1p series cut after r^5: |r| <= 2^-8, first dropped term r^6 / 6 < 6e-16;
+//   * k * ln2 with ONE rounded constant instead of the hi / lo pair: error <= half an ulp of k * ln2 (< 2e-15 for the
+//     exponents of probabilities down to 1e-30).
+// Measured against the full form on the fixtures: the summed log-likelihoods agree to <= 2e-15 relative.
 template <int G>
-__device__ __forceinline__ void tab_log6_n(const double (&v)[G], double (&out)[G], uint32_t tab) {
+__device__ __forceinline__ void tab_log5_n(const double (&v)[G], double (&out)[G], uint32_t tab) {
     f64x2_t e[G];
     double m[G], r[G], q[G], kd[G];
 #pragma unroll
@@ -79,9 +82,7 @@ __device__ __forceinline__ void tab_log6_n(const double (&v)[G], double (&out)[G
 #pragma unroll
     for (int g = 0; g < G; ++g) r[g] = fma(m[g], e[g].x, -1.0);
 #pragma unroll
-    for (int g = 0; g < G; ++g) q[g] = fma(-1.0 / 6.0, r[g], 0.2);
-#pragma unroll
-    for (int g = 0; g < G; ++g) q[g] = fma(q[g], r[g], -0.25);
+    for (int g = 0; g < G; ++g) q[g] = fma(0.2, r[g], -0.25);
 #pragma unroll
     for (int g = 0; g < G; ++g) q[g] = fma(q[g], r[g], 1.0 / 3.0);
 #pragma unroll
@@ -89,8 +90,7 @@ __device__ __forceinline__ void tab_log6_n(const double (&v)[G], double (&out)[G
 #pragma unroll
     for (int g = 0; g < G; ++g) q[g] = fma(r[g] * r[g], q[g], r[g]);          // log1p(r)
 #pragma unroll
-    for (int g = 0; g < G; ++g)
-        out[g] = fma(kd[g], 6.93147180369123816490e-01, e[g].y) + fma(kd[g], 1.90821492927058770002e-10, q[g]);
+    for (int g = 0; g < G; ++g) out[g] = fma(kd[g], 6.93147180559945286227e-01, e[g].y) + q[g];
 }
 
 // per (slot of the block, tuple): byte offsets of the tuple's probability rows inside the probs array and of its
@@ -105,6 +105,13 @@ struct __attribute__((aligned(CT <= 1 ? 8 : (CT <= 3 ? 16 : 32)))) TupleMeta {
 __device__ double g_mfma_dbg[2 * 4 * 16 * 64 * 8];     // [r][m][reg][lane]{cnt, v, woff, goff0} of block 0, wave 0, first pass
 #endif
 
+#ifdef SBE_MFMA_STAMPS
+__device__ unsigned long long g_mfma_stamps[1024 * 8 * 16];    // [block][wave][16] shader-clock stamps (diagnostic build)
+#define MFMA_STAMP(k) do { if (lane == 0 && blockIdx.x < 1024) g_mfma_stamps[((int64_t)blockIdx.x * 8 + w) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MFMA_STAMP(k) do {} while (0)
+#endif
+
 template <int MT, int CT, int GT = 4>
 __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixParams p) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -112,16 +119,19 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int split = (int)blockIdx.x % p.n_split, sg = (int)blockIdx.x / p.n_split;
     const int KBp = p.KBp;
-    // LDS map: A fragments [MT][KBp][64] x 16 B | log table 128 x 16 B | meta [16][2 MT] | reduction [8 waves][16] f64
+    // LDS map: log table 128 x 16 B at ABSOLUTE address 0 (its index is the whole address: the kernel has no static LDS, so
+    // the dynamic block starts at 0 -- checked) | A fragments [MT][KBp][64] x 16 B | meta [16][2 MT] | reduction [8 waves][16] f64
+    constexpr uint32_t tab_off = 0u;
+    constexpr uint32_t a_off = kLogTabEntries * 16u;
     const uint32_t a_bytes = (uint32_t)MT * (uint32_t)KBp * 1024u;
-    const uint32_t tab_off = a_bytes;
-    const uint32_t meta_off = tab_off + kLogTabEntries * 16u;
+    const uint32_t meta_off = a_off + a_bytes;
     const uint32_t red_off = meta_off + (uint32_t)(kMfmaSlots * 2 * MT * sizeof(TupleMeta<CT>));
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_raw;
     typedef TupleMeta<CT> Meta;
     Meta* meta = reinterpret_cast<Meta*>(lds_raw + meta_off);
     double* red = reinterpret_cast<double*>(lds_raw + red_off);
 
+    MFMA_STAMP(0);
     auto slot_of = [&](int sl) -> int {          // absolute slot of the block's sl-th slot, or -1
         const int i = sg * kMfmaSlots + sl;
         if (i >= p.n_batch) return -1;
@@ -151,17 +161,25 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
             for (int r = 0; r < kMfmaRN; ++r) bq[i][r] = load_b(tile_off(nt0 + r), i);
     }
 
+    if (lds_base != 0u) {                                    // (block-uniform; before any barrier)
+        if ((int)threadIdx.x < kMfmaSlots) {
+            const int slot = slot_of((int)threadIdx.x);
+            if (slot >= 0) p.partials[(int64_t)slot * p.partials_stride + split] = __longlong_as_double(0x7FF8000000000000ll);
+        }
+        return;
+    }
+    MFMA_STAMP(8);
     // ---- phase 0: tuple metadata, log table, A fragments ------------------------------------------------------------
     // Offsets of a tuple that is not there (another slot's tuple, the padding tuple of an odd KT, a slot beyond the batch)
-    // and of a component the tuple has no group in point at the zero rows behind the two arrays: no observation is
-    // counted on the former, and the normalised weight of the latter is exactly 0.
+    // and of a component the tuple has no group in point at the rows of ONES behind the two arrays: no observation is
+    // counted on the former (and log C is an ordinary number), the normalised weight of the latter is exactly 0.
     if ((int)threadIdx.x < kMfmaSlots * 2 * MT) {
         const int sl = (int)threadIdx.x / (2 * MT), t = (int)threadIdx.x % (2 * MT);
         const int slot = slot_of(sl);
         Meta md;
-        md.woff = p.wpat_zero_off;
+        md.woff = p.wpat_ones_off;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) md.goff[c] = p.probs_zero_off;
+        for (int c = 0; c < CT; ++c) md.goff[c] = p.probs_ones_off;
         if (slot >= 0 && t < p.KT) {
             const uint32_t pat = p.tuple_p[(int64_t)slot * p.tuple_p_stride + t];
             if (pat != 0xFFu) {
@@ -169,46 +187,65 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
                     const uint32_t g = p.tuple_g[(int64_t)slot * p.tuple_g_stride + t * kMaxComponents + c];
+#ifdef SBE_MFMA_ABL_ALIAS      // ablation (wrong results): every slot reads slot 0's tables -- the table operands become cache hits
+                    if ((int)g < p.Gtot) md.goff[c] = (uint32_t)(((int64_t)g * p.FS) * 4);
+#else
                     if ((int)g < p.Gtot) md.goff[c] = (uint32_t)(((int64_t)slot * p.probs_stride + (int64_t)g * p.FS) * 4);
+#endif
                 }
             }
         }
         meta[sl * 2 * MT + t] = md;
     }
+    MFMA_STAMP(9);
     if (threadIdx.x < 2 * kLogTabEntries)
         reinterpret_cast<double*>(lds_raw + tab_off)[threadIdx.x] = reinterpret_cast<const double*>(p.logtab)[threadIdx.x];
+    MFMA_STAMP(10);
     {
-        // one unit = the 16 tuple ids of (slot sl, 16 objects) -> the 2 MT indicator pieces of those objects
+        // one unit = the 16 tuple ids of (slot sl, 16 objects) -> the 2 MT indicator pieces of those objects.  The ids of
+        // UB units are asked for together (a unit at a time the block's start is four dependent trips to L2 / HBM)
         const int n_units = kMfmaSlots * KBp * 2;
-        for (int u = (int)threadIdx.x; u < n_units; u += kMfmaThreads) {
-            const int sl = u & 15, hk = u >> 4;            // hk = kb * 2 + h
-            const int kb = hk >> 1, h = hk & 1;
-            const int n0 = kb * 32 + 16 * h;
-            const int slot = slot_of(sl);
-            uint32_t d[4];
+        constexpr int UB = 4;
+        for (int u0 = (int)threadIdx.x; u0 < n_units; u0 += UB * kMfmaThreads) {
+            uint32_t d[UB][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                d[i] = 0xFFFFFFFFu;                                        // matches no tuple
-                if (slot >= 0 && n0 + 4 * i + 4 <= p.Np)
-                    d[i] = *reinterpret_cast<const uint32_t*>(p.tid + (int64_t)slot * p.tid_stride + n0 + 4 * i);
-            }
-#pragma unroll
-            for (int t = 0; t < 2 * MT; ++t) {
-                uint4 o;
-                uint32_t* ov = reinterpret_cast<uint32_t*>(&o);
+            for (int k = 0; k < UB; ++k) {
+                const int u = u0 + k * kMfmaThreads;
+                const int sl = u & 15, n0 = (u >> 4) * 16;     // (u >> 4) = kb * 2 + h
+                const int slot = u < n_units ? slot_of(sl) : -1;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const uint32_t x = d[i] ^ ((uint32_t)t * 0x01010101u);
-                    const uint32_t nz = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;      // bit 7 of a byte: byte != 0
-                    ov[i] = (~nz >> 7) & 0x01010101u;
+                    d[k][i] = 0xFFFFFFFFu;                                        // matches no tuple
+                    if (slot >= 0 && n0 + 4 * i + 4 <= p.Np)
+                        d[k][i] = *reinterpret_cast<const uint32_t*>(p.tid + (int64_t)slot * p.tid_stride + n0 + 4 * i);
                 }
-                // fragment (m = t >> 1, kb): lane = h * 32 + (t & 1) * 16 + sl
-                const uint32_t fl = (uint32_t)(h * 32 + (t & 1) * 16 + sl);
-                *reinterpret_cast<uint4*>(lds_raw + (((uint32_t)(t >> 1) * (uint32_t)KBp + (uint32_t)kb) * 64u + fl) * 16u) = o;
+            }
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                const int u = u0 + k * kMfmaThreads;
+                if (u >= n_units) break;
+                const int sl = u & 15, hk = u >> 4;
+                const int kb = hk >> 1, h = hk & 1;
+#pragma unroll
+                for (int t = 0; t < 2 * MT; ++t) {
+                    uint4 o;
+                    uint32_t* ov = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t x = d[k][i] ^ ((uint32_t)t * 0x01010101u);
+                        const uint32_t nz = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;      // bit 7 of a byte: byte != 0
+                        ov[i] = (~nz >> 7) & 0x01010101u;
+                    }
+                    // fragment (m = t >> 1, kb): lane = h * 32 + (t & 1) * 16 + sl
+                    const uint32_t fl = (uint32_t)(h * 32 + (t & 1) * 16 + sl);
+                    *reinterpret_cast<uint4*>(lds_raw + a_off + (((uint32_t)(t >> 1) * (uint32_t)KBp + (uint32_t)kb) * 64u + fl) * 16u) = o;
+                }
             }
         }
     }
+    MFMA_STAMP(1);
     __syncthreads();
+    MFMA_STAMP(2);
 
     // ---- phase 1: counts on the matrix pipe, table entries + log + dot product on the vector pipe ----------------------
     const int h = lane >> 5, cl = lane & 31;
@@ -217,14 +254,14 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
     for (int i = 0; i < 8; ++i) lsum[i] = 0.0;
     const __amdgpu_buffer_rsrc_t pr_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.probs), 0, (int)p.probs_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpat), 0, (int)p.wpat_bytes, 0x00020000);
-    const uint32_t a_lane = lds_base + (uint32_t)lane * 16u;
-    const uint32_t tab_abs = lds_base + tab_off;
+    const uint32_t a_lane = a_off + (uint32_t)lane * 16u;
 
     for (int nt0 = nt_lo + w * kMfmaRN; nt0 < nt_hi; nt0 += kMfmaWaves * kMfmaRN) {
         int toff[kMfmaRN];
 #pragma unroll
         for (int r = 0; r < kMfmaRN; ++r) toff[r] = tile_off(nt0 + r);
-        if (nt0 != nt_lo + w * kMfmaRN) {
+        const bool first_pass = nt0 == nt_lo + w * kMfmaRN;
+        if (!first_pass) {
 #pragma unroll
             for (int i = 0; i < PF; ++i)
 #pragma unroll
@@ -237,14 +274,19 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
             for (int r = 0; r < kMfmaRN; ++r)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[m][r][i] = 0;
+        // A fragments one k-block ahead in their own registers (the read after the last k-block lands in the next M tile
+        // or in the log table: valid LDS, unused), X fragments PF k-blocks ahead; per k-block 3 LDS reads, 2 loads, 2 MT MFMAs
+        v4i_t a_cur[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a_cur[m] = *(lds_cv4i_t*)(uintptr_t)(a_lane + ((uint32_t)m * (uint32_t)KBp) * 1024u);
         for (int kb0 = 0; kb0 < KBp; kb0 += PF) {
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int kb = kb0 + i;
-                v4i_t a[MT];
+                v4i_t a_nxt[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    a[m] = *(lds_cv4i_t*)(uintptr_t)(a_lane + ((uint32_t)m * (uint32_t)KBp + (uint32_t)kb) * 1024u);
+                    a_nxt[m] = *(lds_cv4i_t*)(uintptr_t)(a_lane + ((uint32_t)m * (uint32_t)KBp + (uint32_t)(kb + 1)) * 1024u);
                 v4i_t b[kMfmaRN];
 #pragma unroll
                 for (int r = 0; r < kMfmaRN; ++r) b[r] = bq[i][r];
@@ -254,9 +296,15 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int r = 0; r < kMfmaRN; ++r)
-                        acc[m][r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[r], acc[m][r], 0, 0, 0);
+                        acc[m][r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_cur[m], b[r], acc[m][r], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
+                __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);                 // the next k-block's A fragments
+                __builtin_amdgcn_sched_group_barrier(0x020, kMfmaRN, 0);            // X fragments PF k-blocks ahead
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * kMfmaRN, 0);       // this k-block's MFMAs
             }
         }
+        if (first_pass) MFMA_STAMP(3); else MFMA_STAMP(5);
         // epilogue: LL += cnt * log(sum_c w * p) over the wave's 2 * MT count tiles.  A "quad" = the four entries
         // (tuple t, slots sl0 .. sl0+3) of one register quad of one tile; software pipeline over the quads: the tuple
         // metadata (LDS) two quads ahead, the table operands (L2 / HBM) one quad ahead.  Columns beyond F*S and tiles
@@ -314,14 +362,14 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 cnt[i] = acc[m][r][4 * j + half * G + i];
+                // sum_c w_c * p_c in NumPy's order.  The product of two float32 values is exact in fp64, so fma(w, p, v)
+                // rounds exactly like the reference's multiply-then-add: the same bits as the other kernel forms
                 double v = 0.0;
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
-                    const double term = (double)wrq[q & 1][i][c] * (double)prq[q & 1][i][c];
-                    v = c == 0 ? term : v + term;                       // NumPy order, no FMA
+                    const double wc = (double)wrq[q & 1][i][c], pc = (double)prq[q & 1][i][c];
+                    v = c == 0 ? wc * pc : fma(wc, pc, v);
                 }
-                // entries no observation falls on contribute nothing whatever their table value is (the zero
-                // probability of an inapplicable state included): log 1
 #ifdef SBE_MFMA_DEBUG
                 if (blockIdx.x == 0 && w == 0 && nt0 == nt_lo) {
                     double* o = g_mfma_dbg + ((((int64_t)r * 4 + m) * 16 + (4 * j + half * G + i)) * 64 + lane) * 8;
@@ -329,13 +377,17 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
                     o[4] = wrq[q & 1][i][CT - 1]; o[5] = prq[q & 1][i][CT - 1]; o[6] = col4[r]; o[7] = fw4[r];
                 }
 #endif
-                vv[i] = cnt[i] != 0 ? v : 1.0;
-                special |= tab_log_special(vv[i]);
+                vv[i] = v;
+                special |= __builtin_amdgcn_class(v, 0x2FF);            // anything but a positive normal double
             }
-            tab_log6_n<G>(vv, lg, tab_abs);
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0ull, 0)) {     // rare: library log
+            tab_log5_n<G>(vv, lg, tab_off);
+            // Rare: a table entry that is not a positive normal number -- the zero probability of an inapplicable state,
+            // which no observation falls on (contributes nothing, whatever it is), or of an observed one (log 0 = -inf,
+            // like the reference), or corrupt input (library log).
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0ull, 0)) {
 #pragma unroll
-                for (int i = 0; i < G; ++i) if (tab_log_special(vv[i])) lg[i] = lib_log(vv[i]);
+                for (int i = 0; i < G; ++i)
+                    if (__builtin_amdgcn_class(vv[i], 0x2FF)) lg[i] = cnt[i] != 0 ? lib_log(vv[i]) : 0.0;
             }
 #pragma unroll
             for (int i = 0; i < G; ++i) {
@@ -358,7 +410,9 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
             st_comp(q);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (first_pass) MFMA_STAMP(4); else MFMA_STAMP(6);
     }
+    MFMA_STAMP(7);
 
     // ---- phase 2: fixed-order reduction: 32 columns of a lane half, then the 8 waves ------------------------------------
 #pragma unroll
@@ -384,7 +438,7 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
     }
 }
 
-size_t tuple_mfma_lds_bytes(int MT, int C, int KBp) {
+size_t tuple_mfma_lds_bytes(int MT, int C, int KBp) {     // log table | A fragments | meta | reduction
     const size_t meta = (size_t)kMfmaSlots * 2 * MT * (C <= 1 ? 8 : (C <= 3 ? 16 : 32));
     return (size_t)MT * KBp * 1024 + kLogTabEntries * 16 + meta + (size_t)kMfmaWaves * kMfmaSlots * sizeof(double);
 }
@@ -409,6 +463,16 @@ static void allow_lds() {
 }
 
 void launch_tuple_mfma(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st) {
+#ifdef SBE_MFMA_STAMPS
+    struct DumpStamps { hipStream_t st; ~DumpStamps() {
+        const char* path = getenv("SBE_MFMA_STAMPS_FILE");
+        if (!path) return;
+        (void)hipStreamSynchronize(st);
+        static unsigned long long h[1024 * 8 * 16];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mfma_stamps), sizeof h);
+        FILE* f = fopen(path, "wb"); if (f) { fwrite(h, 1, sizeof h, f); fclose(f); }
+    } } dump_stamps{st};
+#endif
 #ifdef SBE_MFMA_DEBUG
     struct Dump { hipStream_t st; ~Dump() {
         (void)hipStreamSynchronize(st);

@@ -131,3 +131,13 @@ def algorithmic_bytes(n_objects, n_features, n_states, groups_per_component, n_p
     w_tables = n_patterns * n_features * n_comp * 4
     ids = n_objects * (n_comp + 1)
     return obs + tables + w_tables + ids + 8
+
+
+def unique_bytes_per_launch(n_objects, n_features, n_states, groups_per_component, n_patterns, n_evals, packed=False):
+    """What a launch of `n_evals` resident states must touch when the feature block the states SHARE is counted once:
+    the block + per state its tables, ids and result (algorithmic_bytes counts the block once per eval: the contract
+    figure of SURVEY.md 8(d); this is the same inventory with the shared part not multiplied)."""
+    obs = n_objects * n_features * (1 if packed else n_states)
+    per_state = algorithmic_bytes(n_objects, n_features, n_states, groups_per_component, n_patterns, packed) - obs
+    return obs + n_evals * per_state
+

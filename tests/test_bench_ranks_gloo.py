@@ -27,8 +27,10 @@ STUB_RUNNER = textwrap.dedent('''
         def info(self):
             return {"device": self.device, "device_name": "stub"}
         def sync(self): pass
-        def mixture_loglik(self, slot): return -1.0
-        def mixture_loglik_batch_async(self, first, n): time.sleep(0.001)
+        def mixture_loglik(self, slot):
+            time.sleep(0.0008 if self.device == 5 else 0.0002)
+            return -1.0
+        def mixture_loglik_batch_async(self, first, n): time.sleep(0.004 if self.device == 5 else 0.001)      # rank 5 is slow
         def fetch_results(self, first, n): return np.full(n, -1.0)
         def profile_mixture(self, first, n, iters): return 0.0, 0.0
         def kernel_timing_start(self): self.n_timed = 0
@@ -71,3 +73,18 @@ def test_bench_rank_logic_world_size_8(tmp_path):
     assert line["cpu_baseline"] is None and "per_config" not in line      # N > 1: no CPU leg, no secondary figures
     for key in ("metric", "unit", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
         assert key in line
+    # per-chain figures of the N > 1 line: every rank's own rate, kernel time and single-chain rate;
+    # the deliberately slow rank (device 5) is visible, and the whole-job value is bounded by it
+    pr = line["per_rank"]
+    assert [r["rank"] for r in pr] == list(range(8)) and sorted(r["device"] for r in pr) == list(range(8))
+    slow = next(r for r in pr if r["device"] == 5)
+    others = [r for r in pr if r["device"] != 5]
+    assert all(slow["evals_per_s"] < 0.6 * r["evals_per_s"] for r in others)
+    assert all(slow["single_chain_evals_per_s"] < 0.6 * r["single_chain_evals_per_s"] for r in others)
+    assert line["per_rank_evals_per_s_min"] == slow["evals_per_s"] and line["per_chain_evals_per_s_min"] == slow["single_chain_evals_per_s"]
+    assert line["per_rank_evals_per_s_max"] == max(r["evals_per_s"] for r in pr)
+    assert all(r["kernel_avg_us"] == 50.0 for r in pr)
+    assert line["value"] <= 8 * slow["evals_per_s"] * 1.05                # whole-job aggregate over the max-over-ranks time
+    rf = line["roofline"]
+    for key in ("frac", "frac_unique", "unique_bytes_per_launch", "frac_traffic", "bound"):
+        assert key in rf

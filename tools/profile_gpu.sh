@@ -9,7 +9,7 @@ OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
 BENCH="python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary"
-for kern in packed packed_tuple_lds packed_general packed_v2 onehot onehot_general; do
+for kern in packed packed_tuple packed_tuple_lds packed_general packed_v2 onehot onehot_general; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$kern -- $BENCH --kernel $kern > $OUT/bench_$kern.json 2> $OUT/bench_$kern.err
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
   echo "done $kern trace+fetch"
@@ -17,7 +17,12 @@ for kern in packed packed_tuple_lds packed_general packed_v2 onehot onehot_gener
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
     rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $OUT/pmc_sq1_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
     rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
+    rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq3_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
     echo "done $kern write+sq"
+  fi
+  if [ $kern = packed_tuple ]; then      # the vector-pipe form the matrix-pipe form replaced (same-box comparison of the two)
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
+    rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
   fi
 done
 # stress shape (HBM/MALL streaming regime): rows kernel (default at B >= 2), the older general kernel, one-hot stream

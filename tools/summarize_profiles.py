@@ -60,11 +60,12 @@ corr4 = 1.0 / calib["read_dword"]["reported_fraction"] if "read_dword" in calib 
 corr16 = 1.0 / calib["read_dwordx4"]["reported_fraction"] if "read_dwordx4" in calib else None
 
 traffic = {}
-CASES = [("headline", 2048, k) for k in ("packed", "packed_tuple_lds", "packed_general", "packed_v2", "onehot", "onehot_general")] + \
+CASES = [("headline", 2048, k) for k in ("packed", "packed_tuple", "packed_tuple_lds", "packed_general", "packed_v2", "onehot", "onehot_general")] + \
         [("stress", b, k) for k in ("packed", "packed_v2", "onehot") for b in (8, 64)]
 for wl, batch, kern in CASES:
         suffix = kern if wl == "headline" else f"stress_{kern}_b{batch}"
-        prefix = {"packed": "sbe::k_mixture_tuple64" if wl == "headline" else "sbe::k_mixture_rows",
+        prefix = {"packed": "sbe::k_mixture_tuple_mfma" if wl == "headline" else "sbe::k_mixture_rows",
+                  "packed_tuple": "sbe::k_mixture_tuple64",
                   "packed_tuple_lds": "sbe::k_mixture_combo",
                   "packed_general": "sbe::k_mixture_rows",
                   "packed_v2": "sbe::k_mixture_v2",
@@ -73,6 +74,7 @@ for wl, batch, kern in CASES:
         entry = {}
         fetch = dominant(counters(f"pmc_fetch_{suffix}"), prefix)
         write = dominant(counters(f"pmc_write_{suffix}"), prefix) if wl == "headline" else {}
+        # (k_mixture_tuple_mfma's HBM stream is 4-byte lane loads of the per-slot tables, like the packed forms)
         if "FETCH_SIZE" in fetch:
             raw = fetch["FETCH_SIZE"]["mean"] * 1024
             # packed streams 4-byte lane loads + 16-byte table staging, onehot 16-byte lane loads:
@@ -86,7 +88,7 @@ for wl, batch, kern in CASES:
             entry["evals_per_launch"] = batch
             traffic[f"{wl}:{kern}:{batch}"] = entry
         sq = {}
-        for part in ("sq1", "sq2"):
+        for part in ("sq1", "sq2", "sq3"):
             sq.update({k: v["mean"] for k, v in dominant(counters(f"pmc_{part}_{suffix}"), prefix).items()})
         if sq:
             summary[f"sq_counters_{wl}_{kern}_b{batch}"] = sq
