@@ -17,7 +17,7 @@ for kern in packed packed_tuple packed_tuple_lds packed_general packed_v2 onehot
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
     rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $OUT/pmc_sq1_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
     rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
-    rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq3_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
+    rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq3_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
     echo "done $kern write+sq"
   fi
   if [ $kern = packed_tuple ]; then      # the vector-pipe form the matrix-pipe form replaced (same-box comparison of the two)
