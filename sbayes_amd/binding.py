@@ -297,6 +297,15 @@ def _bind_slot(eng, model, sample, slot, with_source=False):
     return new["stale"]
 
 
+_bind_slot_py = _bind_slot                      # the reference form: what the native function transcribes, and its fallback
+if _fast.HAVE_EXTENSION:
+    # binding._bind_slot in native code (csrc/sbe_pyhost.c: bind_slot): the same comparisons, engine calls and cache entries --
+    # five binds per MCMC step, ~20 us each as Python (tools/host_residual.py); engines without a bind cache (test doubles)
+    # are handed back to the Python form by the function itself
+    _fast._h.bind_setup(_send_counts, _send_source, _remember, np.concatenate, _ROWS_WITH_PROBS, _bind_slot_py)
+    _bind_slot = _fast._h.bind_slot
+
+
 def counts_follow_plan(eng, sample, names, slot=0):
     """update_feature_counts (counts.py:55-95) is about to add a difference to `sample.feature_counts` on the host.  When
     engine slot `slot` holds exactly those counts -- the bind entry's token of every component is the parameter's current
@@ -323,6 +332,10 @@ def counts_followed(eng, plan, sample, names, touched, bounds, probs_rebuilt, so
     were set to the sample's in the same call -- the mirror takes them, and the entry forgets which source parameter the
     slot held, so the next bind with a source compares content with the mirror (and sends whatever else differs)."""
     entry, mirrors, _ = plan
+    if _fast._h is not None:                        # the same steps in one native call (csrc/sbe_pyhost.c: counts_followed)
+        _fast._h.counts_followed(eng, entry, mirrors, [sample.feature_counts[name] for name in names], eng.group_offsets, touched, bounds,
+                                 bool(probs_rebuilt), source_rows, sample.source.value if source_rows is not None else None, slot)
+        return
     if source_rows is not None:
         src = sample.source.value
         mirrors["source"][source_rows] = src[source_rows] if src.dtype == np.bool_ else np.asarray(src[source_rows], dtype=bool)

@@ -156,6 +156,12 @@ def apply_count_rows(counts, names, off, touched, rows, return_bounds=False):
     """The reference's `add_changes(diff)` per component (counts.py:77, :93) for a difference given as the rows of the global
     group indices `touched` (ascending; every other row is zero): in its row form (FeatureCounts.add_changes_rows: patch.install
     / sbayes_amd.state) where the sample's class has one, else through a dense diff."""
+    if _fast._h is not None and type(touched) is np.ndarray and touched.dtype == np.int32 and type(rows) is np.ndarray and rows.dtype == np.float32:
+        # every component in ONE native call (sbe_pyhost.c: add_rows_many -- the same resolve_sharing / += / version /
+        # group_versions steps as add_changes_rows, node by node); None: a node of another form, the loop below serves it
+        bounds = _fast._h.add_rows_many([counts[name] for name in names], off, touched, rows)
+        if bounds is not None:
+            return bounds if return_bounds else counts
     bounds = np.searchsorted(touched, off).tolist()  # `touched` is sorted: the rows of component c are bounds[c]:bounds[c+1]
     for c, name in enumerate(names):
         node = counts[name]

@@ -234,6 +234,631 @@ fail:
     return NULL;
 }
 
+
+/* ---- FeatureCounts.add_changes for a difference given as rows (sbayes/sampling/counts.py:77, :93 -> state.py:340-350) --------
+ * add_rows_many(nodes, off, touched, rows) -> bounds [C + 1] | None
+ * `touched` (int32, ascending global group indices) and `rows` (float32 [k, F, S]) are what sbe_counts_delta returned; component
+ * c owns the rows whose index lies in [off[c], off[c + 1]).  Per node exactly what add_changes_rows (sbayes_amd/state.py, and the
+ * method patch.install gives the reference's class) does -- resolve_sharing() if shared, value[group] += row, version += 1,
+ * group_versions[group] = version where the row is not all zero -- as ONE call instead of three Python method calls with two
+ * fancy-index operations and a reduction each (60 us per MCMC step at the south_america shape).  None: a node that is not in that
+ * form (the caller keeps the Python route). */
+static PyObject *s_shared, *s_resolve_sharing, *s__value, *s_group_versions;
+
+static int off_at(const Py_buffer* v, Py_ssize_t i, long long* out) {
+    if (v->itemsize == 8) { *out = ((const long long*)v->buf)[i]; return 1; }
+    if (v->itemsize == 4) { *out = ((const int*)v->buf)[i]; return 1; }
+    return 0;
+}
+
+static PyObject* py_add_rows_many(PyObject* self, PyObject* args) {
+    PyObject *nodes, *off, *touched, *rows;
+    if (!PyArg_ParseTuple(args, "OOOO", &nodes, &off, &touched, &rows)) return NULL;
+    if (!PyList_Check(nodes)) Py_RETURN_NONE;
+    const Py_ssize_t C = PyList_GET_SIZE(nodes);
+    Py_buffer vo, vt, vr;
+    if (PyObject_GetBuffer(off, &vo, PyBUF_C_CONTIGUOUS) != 0) { PyErr_Clear(); Py_RETURN_NONE; }
+    if (PyObject_GetBuffer(touched, &vt, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) { PyErr_Clear(); PyBuffer_Release(&vo); Py_RETURN_NONE; }
+    if (PyObject_GetBuffer(rows, &vr, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) { PyErr_Clear(); PyBuffer_Release(&vo); PyBuffer_Release(&vt); Py_RETURN_NONE; }
+    PyObject* result = NULL;
+    int unsupported = 0;
+    const Py_ssize_t k = vt.ndim == 1 ? vt.shape[0] : -1;
+    if (vo.ndim != 1 || vo.shape[0] < C + 1 || (vo.itemsize != 8 && vo.itemsize != 4) || k < 0 || vt.itemsize != 4 || vr.itemsize != 4 || !vr.format || vr.format[strlen(vr.format) - 1] != 'f' ||
+        (k > 0 && (vr.ndim != 3 || vr.shape[0] != k))) unsupported = 1;
+    const Py_ssize_t row_elems = (!unsupported && k > 0) ? vr.shape[1] * vr.shape[2] : 0;
+    const int* t = (const int*)vt.buf;
+    const float* r = (const float*)vr.buf;
+    /* pass 1: every node must be in the expected form BEFORE anything is changed */
+    for (Py_ssize_t c = 0; c < C && !unsupported; ++c) {
+        PyObject* node = PyList_GET_ITEM(nodes, c);
+        PyObject* val = PyObject_GetAttr(node, s__value);
+        PyObject* gv = val ? PyObject_GetAttr(node, s_group_versions) : NULL;
+        PyObject* ver = gv ? PyObject_GetAttr(node, s_version) : NULL;
+        if (!val || !gv || !ver || !PyLong_Check(ver) || !PyObject_HasAttr(node, s_shared)) { PyErr_Clear(); unsupported = 1; }
+        Py_XDECREF(val); Py_XDECREF(gv); Py_XDECREF(ver);
+    }
+    if (unsupported) { result = Py_None; Py_INCREF(result); goto done; }
+    result = PyList_New(C + 1);
+    if (!result) goto done;
+    {
+        Py_ssize_t pos = 0;
+        for (Py_ssize_t c = 0; c <= C; ++c) {
+            long long o = 0; off_at(&vo, c, &o);
+            while (pos < k && t[pos] < o) ++pos;
+            PyObject* b = PyLong_FromSsize_t(pos);
+            if (!b) { Py_CLEAR(result); goto done; }
+            PyList_SET_ITEM(result, c, b);
+        }
+    }
+    for (Py_ssize_t c = 0; c < C; ++c) {
+        PyObject* node = PyList_GET_ITEM(nodes, c);
+        const Py_ssize_t lo = PyLong_AsSsize_t(PyList_GET_ITEM(result, c)), hi = PyLong_AsSsize_t(PyList_GET_ITEM(result, c + 1));
+        long long o = 0; off_at(&vo, c, &o);
+        PyObject* shared = PyObject_GetAttr(node, s_shared);
+        if (!shared) { Py_CLEAR(result); goto done; }
+        const int is_shared = PyObject_IsTrue(shared);
+        Py_DECREF(shared);
+        if (is_shared < 0) { Py_CLEAR(result); goto done; }
+        if (is_shared) {
+            PyObject* rr = PyObject_CallMethodNoArgs(node, s_resolve_sharing);
+            if (!rr) { Py_CLEAR(result); goto done; }
+            Py_DECREF(rr);
+        }
+        PyObject* ver = PyObject_GetAttr(node, s_version);
+        if (!ver) { Py_CLEAR(result); goto done; }
+        const long long version = PyLong_AsLongLong(ver) + 1;
+        Py_DECREF(ver);
+        if (hi > lo) {
+            PyObject* val = PyObject_GetAttr(node, s__value);
+            PyObject* gv = val ? PyObject_GetAttr(node, s_group_versions) : NULL;
+            Py_buffer bv, bg;
+            int ok = val && gv && PyObject_GetBuffer(val, &bv, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) == 0;    /* (kept read-only between edits: written through anyway, like the flag toggle of the Python form) */
+            if (ok && PyObject_GetBuffer(gv, &bg, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT | PyBUF_WRITABLE) != 0) { PyBuffer_Release(&bv); ok = 0; }
+            if (ok) {
+                const char gf = bg.format ? bg.format[strlen(bg.format) - 1] : 0;
+                const int form_ok = bv.ndim == 3 && bv.itemsize == 4 && bv.format && bv.format[strlen(bv.format) - 1] == 'f' &&
+                                    bv.shape[1] * bv.shape[2] == row_elems && bg.ndim == 1 && bg.itemsize == 8 && bg.shape[0] == bv.shape[0] &&
+                                    (gf == 'd' || gf == 'l' || gf == 'q');
+                if (form_ok) {
+                    for (Py_ssize_t i = lo; i < hi && ok; ++i) {
+                        const long long g = (long long)t[i] - o;
+                        if (g < 0 || g >= bv.shape[0]) { PyErr_SetString(PyExc_IndexError, "add_rows_many: group index out of range"); ok = 0; break; }
+                        float* dst = (float*)bv.buf + g * row_elems;
+                        const float* src = r + i * row_elems;
+                        int nz = 0;
+                        for (Py_ssize_t e = 0; e < row_elems; ++e) { dst[e] += src[e]; nz |= src[e] != 0.0f; }
+                        if (nz) { if (gf == 'd') ((double*)bg.buf)[g] = (double)version; else ((long long*)bg.buf)[g] = version; }
+                    }
+                } else {
+                    PyErr_SetString(PyExc_TypeError, "add_rows_many: count node changed form between the check and the update");
+                    ok = 0;
+                }
+                PyBuffer_Release(&bv); PyBuffer_Release(&bg);
+            } else if (!PyErr_Occurred()) PyErr_SetString(PyExc_TypeError, "add_rows_many: count arrays are not plain C-contiguous buffers");
+            Py_XDECREF(val); Py_XDECREF(gv);
+            if (!ok) { Py_CLEAR(result); goto done; }
+        }
+        PyObject* nv = PyLong_FromLongLong(version);
+        if (!nv || PyObject_SetAttr(node, s_version, nv) != 0) { Py_XDECREF(nv); Py_CLEAR(result); goto done; }
+        Py_DECREF(nv);
+    }
+done:
+    PyBuffer_Release(&vo); PyBuffer_Release(&vt); PyBuffer_Release(&vr);
+    return result;
+}
+
+/* copy_rows(dst, src, idx): dst[idx] = src[idx] for two C-contiguous arrays of one shape and item size (rows = everything
+ * behind the first axis); idx int32.  The bind cache's mirrors follow the sample this way (binding.counts_followed). */
+static PyObject* py_copy_rows(PyObject* self, PyObject* args) {
+    PyObject *dst, *src, *idx;
+    if (!PyArg_ParseTuple(args, "OOO", &dst, &src, &idx)) return NULL;
+    Py_buffer vd, vs, vi;
+    long rc = -2;
+    if (PyObject_GetBuffer(dst, &vd, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) { PyErr_Clear(); return PyLong_FromLong(-2); }
+    if (PyObject_GetBuffer(src, &vs, PyBUF_C_CONTIGUOUS) != 0) { PyErr_Clear(); PyBuffer_Release(&vd); return PyLong_FromLong(-2); }
+    if (PyObject_GetBuffer(idx, &vi, PyBUF_C_CONTIGUOUS) != 0) { PyErr_Clear(); PyBuffer_Release(&vd); PyBuffer_Release(&vs); return PyLong_FromLong(-2); }
+    if (vd.ndim >= 1 && vd.ndim == vs.ndim && vd.len == vs.len && vd.itemsize == vs.itemsize && vd.shape[0] == vs.shape[0] && vd.shape[0] > 0 && vi.itemsize == 4) {
+        const Py_ssize_t row = vd.len / vd.shape[0], n = vi.len / 4;
+        const int* ix = (const int*)vi.buf;
+        rc = 0;
+        for (Py_ssize_t i = 0; i < n; ++i) {
+            if (ix[i] < 0 || ix[i] >= vd.shape[0]) { rc = -1; break; }
+            memcpy((char*)vd.buf + (Py_ssize_t)ix[i] * row, (const char*)vs.buf + (Py_ssize_t)ix[i] * row, (size_t)row);
+        }
+    }
+    PyBuffer_Release(&vd); PyBuffer_Release(&vs); PyBuffer_Release(&vi);
+    return PyLong_FromLong(rc);
+}
+
+/* ---- binding._bind_slot in native code -----------------------------------------------------------------------------------------
+ * bind_slot(eng, model, sample, slot, with_source) -> the stale components (a set), or NotImplemented when the engine keeps no
+ * bind cache (test doubles: the Python form sends everything).  A line-by-line transcription of the Python function (kept in
+ * binding.py as the reference form and the fallback: SBAYES_AMD_NO_PYHOST): the same comparisons, the same engine calls with the
+ * same arguments in the same order, the same entry / mirror dictionaries.  What it saves is the interpreter: ~90 bytecode lines
+ * per bind, five binds per MCMC step (tools/host_residual.py: 100 us of a 450 us host layer at the south_america shape).
+ * The content helpers stay Python callables handed over by bind_setup: _send_counts, _send_source, _remember (unversioned arrays),
+ * numpy.concatenate. */
+static PyObject *g_send_counts = NULL, *g_send_source = NULL, *g_remember = NULL, *g_concatenate = NULL, *g_bind_py = NULL;
+static int g_rows_with_probs = 1;
+static PyObject *s_confounders, *s_clusters, *s_group_assignment, *s_prior, *s_prior_confounding_effects, *s_prior_cluster_effect,
+                *s_concentration_array, *s_feature_counts, *s_weights, *s_source, *s__bound, *s__bound_conc, *s__mirror,
+                *s_set_concentration, *s_set_groups, *s_set_slot_delta, *s_set_counts_rows, *s_set_source_rows, *s_set_weights,
+                *k_groups, *k_counts, *k_weights, *k_source, *k_stale, *k_lh_all, *k_update_probs,
+                *k_groups_component, *k_count_idx, *k_count_rows, *k_source_objects, *k_source_rows;
+
+static PyObject* py_bind_setup(PyObject* self, PyObject* args) {
+    PyObject *sc, *ss, *rm, *cc, *bp;
+    int rwp;
+    if (!PyArg_ParseTuple(args, "OOOOpO", &sc, &ss, &rm, &cc, &rwp, &bp)) return NULL;
+    Py_XDECREF(g_send_counts); Py_XDECREF(g_send_source); Py_XDECREF(g_remember); Py_XDECREF(g_concatenate); Py_XDECREF(g_bind_py);
+    Py_INCREF(sc); Py_INCREF(ss); Py_INCREF(rm); Py_INCREF(cc); Py_INCREF(bp);
+    g_send_counts = sc; g_send_source = ss; g_remember = rm; g_concatenate = cc; g_rows_with_probs = rwp; g_bind_py = bp;
+    Py_RETURN_NONE;
+}
+
+/* _remember(token): (array, version, None) for a versioned parameter -- the common case, built here -- else the Python helper
+   (frozen arrays: identity; others: a private copy) */
+static PyObject* remember_token(PyObject* tok) {
+    PyObject* version = PyTuple_GET_ITEM(tok, 1);
+    if (version != Py_None) return PyTuple_Pack(3, PyTuple_GET_ITEM(tok, 0), version, Py_None);
+    return PyObject_CallFunctionObjArgs(g_remember, tok, NULL);
+}
+
+/* one token (value, version) of a parameter and whether it denotes `cached`; -1 on error */
+static int token_of(PyObject* param, PyObject* cached, PyObject** tok_out) {
+    PyObject *value, *version;
+    if ((PyObject*)Py_TYPE(param) == g_ndarray) {
+        value = param; Py_INCREF(value);
+        version = Py_None; Py_INCREF(version);
+    } else {
+        value = PyObject_GetAttr(param, s_value);
+        if (!value) {
+            if (!PyErr_ExceptionMatches(PyExc_AttributeError)) return -1;
+            PyErr_Clear();
+            value = param; Py_INCREF(value);
+        }
+        if ((PyObject*)Py_TYPE(value) != g_ndarray) {
+            PyObject* conv = PyObject_CallFunctionObjArgs(g_asarray, value, NULL);
+            Py_DECREF(value);
+            if (!conv) return -1;
+            value = conv;
+        }
+        version = PyObject_GetAttr(param, s_version);
+        if (!version) {
+            if (!PyErr_ExceptionMatches(PyExc_AttributeError)) { Py_DECREF(value); return -1; }
+            PyErr_Clear();
+            version = Py_None; Py_INCREF(version);
+        }
+    }
+    const int same = token_same(value, version, cached);
+    *tok_out = same < 0 ? NULL : PyTuple_Pack(2, value, version);
+    Py_DECREF(value); Py_DECREF(version);
+    if (!*tok_out) return -1;
+    return same;
+}
+
+#define BIND_MAXC 16
+/* an engine without a bind cache (test doubles), or more components than the fixed arrays hold: the Python form */
+static PyObject* bind_python_form(PyObject* eng, PyObject* model, PyObject* sample, PyObject* slot, int with_source) {
+    return PyObject_CallFunctionObjArgs(g_bind_py, eng, model, sample, slot, with_source ? Py_True : Py_False, NULL);
+}
+
+static PyObject* py_bind_slot(PyObject* self, PyObject* args, PyObject* kwargs) {
+    PyObject *eng, *model, *sample, *slot;
+    int with_source = 0;
+    static char* kwlist[] = {"eng", "model", "sample", "slot", "with_source", NULL};
+    if (!PyArg_ParseTupleAndKeywords(args, kwargs, "OOOO|p", kwlist, &eng, &model, &sample, &slot, &with_source)) return NULL;
+    if (!g_send_counts || !g_ndarray) { PyErr_SetString(PyExc_RuntimeError, "bind_setup() / scan_setup() not called"); return NULL; }
+    PyObject* cache = PyObject_GetAttr(eng, s__bound);
+    if (!cache) { PyErr_Clear(); return bind_python_form(eng, model, sample, slot, with_source); }
+    if (!PyDict_Check(cache)) { Py_DECREF(cache); return bind_python_form(eng, model, sample, slot, with_source); }
+    /* every owned reference of the function lives in `own` and is released at `out` */
+    PyObject* own[64 + 24 * BIND_MAXC]; int n_own = 0;
+#define OWN(x) (own[n_own++] = (x))
+    PyObject* result = NULL;
+    PyObject *tokens[3 * BIND_MAXC + 2]; int n_tok = 0;
+    memset(tokens, 0, sizeof tokens);
+    OWN(cache);
+    PyObject* confounders = OWN(PyObject_GetAttr(sample, s_confounders));
+    if (!confounders) goto out;
+    PyObject* conf_names = OWN(PySequence_List(confounders));
+    if (!conf_names) goto out;
+    const Py_ssize_t C = 1 + PyList_GET_SIZE(conf_names);
+    if (C > BIND_MAXC) { result = bind_python_form(eng, model, sample, slot, with_source); goto out; }
+    PyObject* old = PyDict_GetItemWithError(cache, slot);                 /* borrowed */
+    int old_is_new = 0;
+    if (!old) {
+        if (PyErr_Occurred()) goto out;
+        old = OWN(PyDict_New());
+        if (!old) goto out;
+        old_is_new = 1;
+        PyObject* g = OWN(PyList_New(C)); PyObject* cn = OWN(PyList_New(C)); PyObject* st = OWN(PySet_New(NULL));
+        if (!g || !cn || !st) goto out;
+        for (Py_ssize_t c = 0; c < C; ++c) {
+            Py_INCREF(Py_None); PyList_SET_ITEM(g, c, Py_None);
+            Py_INCREF(Py_None); PyList_SET_ITEM(cn, c, Py_None);
+            PyObject* ci = PyLong_FromSsize_t(c);
+            if (!ci || PySet_Add(st, ci) != 0) { Py_XDECREF(ci); goto out; }
+            Py_DECREF(ci);
+        }
+        if (PyDict_SetItem(old, k_groups, g) || PyDict_SetItem(old, k_counts, cn) || PyDict_SetItem(old, k_weights, Py_None) ||
+            PyDict_SetItem(old, k_source, Py_None) || PyDict_SetItem(old, k_stale, st) || PyDict_SetItem(old, k_lh_all, Py_None)) goto out;
+    } else if (!PyDict_Check(old)) { PyErr_SetString(PyExc_TypeError, "bind entry is not a dict"); goto out; }
+    else { Py_INCREF(old); OWN(old); }          /* (the engine's setters drop the slot's entry from the cache while it is still read here) */
+    PyObject* old_groups = PyDict_GetItem(old, k_groups);                 /* borrowed */
+    PyObject* old_counts = PyDict_GetItem(old, k_counts);
+    PyObject* old_stale = PyDict_GetItem(old, k_stale);
+    if (!old_groups || !old_counts || !old_stale || !PyList_Check(old_groups) || !PyList_Check(old_counts) ||
+        PyList_GET_SIZE(old_groups) != C || PyList_GET_SIZE(old_counts) != C) { PyErr_SetString(PyExc_TypeError, "malformed bind entry"); goto out; }
+    /* ---- what differs? ---- */
+    unsigned long long changed = 0;
+    PyObject *prior = NULL, *conf_priors = NULL, *feature_counts = NULL, *bound_conc = NULL;
+    const int have_model = model != Py_None;
+    {
+        PyObject* p = OWN(PyObject_GetAttr(sample, s_clusters));
+        if (!p) goto out;
+        int same = token_of(p, PyList_GET_ITEM(old_groups, 0), &tokens[n_tok]);
+        if (same < 0) goto out;
+        OWN(tokens[n_tok]); if (!same) changed |= 1ull << n_tok; ++n_tok;
+        for (Py_ssize_t c = 1; c < C; ++c) {
+            PyObject* conf = OWN(PyObject_GetItem(confounders, PyList_GET_ITEM(conf_names, c - 1)));
+            if (!conf) goto out;
+            PyObject* ga = OWN(PyObject_GetAttr(conf, s_group_assignment));
+            if (!ga) goto out;
+            same = token_of(ga, PyList_GET_ITEM(old_groups, c), &tokens[n_tok]);
+            if (same < 0) goto out;
+            OWN(tokens[n_tok]); if (!same) changed |= 1ull << n_tok; ++n_tok;
+        }
+    }
+    if (have_model) {
+        prior = OWN(PyObject_GetAttr(model, s_prior));
+        if (!prior) goto out;
+        conf_priors = OWN(PyObject_GetAttr(prior, s_prior_confounding_effects));
+        feature_counts = conf_priors ? OWN(PyObject_GetAttr(sample, s_feature_counts)) : NULL;
+        bound_conc = feature_counts ? OWN(PyObject_GetAttr(eng, s__bound_conc)) : NULL;
+        if (!bound_conc) goto out;
+        for (Py_ssize_t c = 0; c < C; ++c) {
+            PyObject* arr;
+            if (c == 0) {
+                PyObject* pce = OWN(PyObject_GetAttr(prior, s_prior_cluster_effect));
+                if (!pce) goto out;
+                arr = OWN(PyObject_GetAttr(pce, s_concentration_array));
+            } else {
+                PyObject* cp = OWN(PyObject_GetItem(conf_priors, PyList_GET_ITEM(conf_names, c - 1)));
+                if (!cp) goto out;
+                arr = OWN(PyObject_CallMethodObjArgs(cp, s_concentration_array, sample, NULL));
+            }
+            if (!arr) goto out;
+            PyObject* ci = PyLong_FromSsize_t(c);
+            if (!ci) goto out;
+            PyObject* cached = PyObject_GetItem(bound_conc, ci);                /* eng._bound_conc.get(c) */
+            Py_DECREF(ci);
+            if (!cached) { if (!PyErr_ExceptionMatches(PyExc_KeyError)) goto out; PyErr_Clear(); cached = Py_None; Py_INCREF(cached); }
+            OWN(cached);
+            const int same = token_of(arr, cached, &tokens[n_tok]);
+            if (same < 0) goto out;
+            OWN(tokens[n_tok]); if (!same) changed |= 1ull << n_tok; ++n_tok;
+        }
+        for (Py_ssize_t c = 0; c < C; ++c) {
+            PyObject* node = OWN(PyObject_GetItem(feature_counts, c == 0 ? s_clusters : PyList_GET_ITEM(conf_names, c - 1)));
+            if (!node) goto out;
+            const int same = token_of(node, PyList_GET_ITEM(old_counts, c), &tokens[n_tok]);
+            if (same < 0) goto out;
+            OWN(tokens[n_tok]); if (!same) changed |= 1ull << n_tok; ++n_tok;
+        }
+    }
+    const int at = have_model ? 3 * (int)C : (int)C;
+    {
+        PyObject* w = OWN(PyObject_GetAttr(sample, s_weights));
+        if (!w) goto out;
+        PyObject* ow = PyDict_GetItem(old, k_weights);
+        int same = token_of(w, ow ? ow : Py_None, &tokens[n_tok]);
+        if (same < 0) goto out;
+        OWN(tokens[n_tok]); if (!same) changed |= 1ull << n_tok; ++n_tok;
+        if (with_source) {
+            PyObject* src = OWN(PyObject_GetAttr(sample, s_source));
+            if (!src) goto out;
+            PyObject* os = PyDict_GetItem(old, k_source);
+            same = token_of(src, os ? os : Py_None, &tokens[n_tok]);
+            if (same < 0) goto out;
+            OWN(tokens[n_tok]); if (!same) changed |= 1ull << n_tok; ++n_tok;
+        }
+    }
+    if (!changed) {
+        if (old_is_new && PyDict_SetItem(cache, slot, old) != 0) goto out;      /* (a first bind of an empty state: keep the entry) */
+        result = old_stale; Py_INCREF(result);
+        goto out;
+    }
+    /* ---- send the differences ---- */
+    {
+        PyObject* mirror_map = PyObject_GetAttr(eng, s__mirror);
+        const int has_mirror = mirror_map != NULL;
+        if (!has_mirror) PyErr_Clear(); else OWN(mirror_map);
+        PyObject* mirrors = NULL;
+        if (has_mirror) {
+            mirrors = PyDict_GetItemWithError(mirror_map, slot);                /* borrowed */
+            if (!mirrors && PyErr_Occurred()) goto out;
+            if (mirrors) { Py_INCREF(mirrors); OWN(mirrors); }
+        }
+        if (!mirrors) {
+            mirrors = OWN(PyDict_New());
+            PyObject* mc = mirrors ? OWN(PyList_New(C)) : NULL;
+            if (!mc) goto out;
+            for (Py_ssize_t c = 0; c < C; ++c) { Py_INCREF(Py_None); PyList_SET_ITEM(mc, c, Py_None); }
+            if (PyDict_SetItem(mirrors, k_counts, mc) || PyDict_SetItem(mirrors, k_source, Py_None)) goto out;
+        }
+        PyObject* mirror_counts = PyDict_GetItem(mirrors, k_counts);            /* borrowed list */
+        if (!mirror_counts || !PyList_Check(mirror_counts) || PyList_GET_SIZE(mirror_counts) != C) { PyErr_SetString(PyExc_TypeError, "malformed mirror entry"); goto out; }
+        PyObject* nw = OWN(PyDict_New());
+        PyObject* new_groups = nw ? OWN(PySequence_List(old_groups)) : NULL;
+        PyObject* new_counts = new_groups ? OWN(PySequence_List(old_counts)) : NULL;
+        PyObject* new_stale = new_counts ? OWN(PySet_New(old_stale)) : NULL;
+        if (!new_stale) goto out;
+        {
+            PyObject* ow = PyDict_GetItem(old, k_weights); PyObject* os = PyDict_GetItem(old, k_source); PyObject* ol = PyDict_GetItem(old, k_lh_all);
+            if (PyDict_SetItem(nw, k_groups, new_groups) || PyDict_SetItem(nw, k_counts, new_counts) || PyDict_SetItem(nw, k_weights, ow ? ow : Py_None) ||
+                PyDict_SetItem(nw, k_source, os ? os : Py_None) || PyDict_SetItem(nw, k_stale, new_stale) || PyDict_SetItem(nw, k_lh_all, ol ? ol : Py_None)) goto out;
+        }
+        PyObject* pend_idx = OWN(PyList_New(0));
+        PyObject* pend_rows = pend_idx ? OWN(PyList_New(0)) : NULL;
+        PyObject* pending = pend_rows ? OWN(PyTuple_Pack(2, pend_idx, pend_rows)) : NULL;
+        if (!pending) goto out;
+        /* concentrations (drops every slot's entry: all tables depend on it) */
+        int any_conc = 0;
+        if (have_model) {
+            for (Py_ssize_t c = 0; c < C; ++c) {
+                if (!((changed >> (C + c)) & 1)) continue;
+                any_conc = 1;
+                PyObject* ci = OWN(PyLong_FromSsize_t(c));
+                PyObject* r = ci ? PyObject_CallMethodObjArgs(eng, s_set_concentration, ci, PyTuple_GET_ITEM(tokens[C + c], 0), NULL) : NULL;
+                if (!r) goto out;
+                Py_DECREF(r);
+            }
+        }
+        if (any_conc) {
+            if (PySet_Clear(new_stale) != 0) goto out;
+            for (Py_ssize_t c = 0; c < C; ++c) {
+                PyObject* ci = PyLong_FromSsize_t(c);
+                if (!ci || PySet_Add(new_stale, ci) != 0) { Py_XDECREF(ci); goto out; }
+                Py_DECREF(ci);
+            }
+            if (PyDict_SetItem(nw, k_lh_all, Py_None) != 0) goto out;
+        }
+        /* group matrices */
+        int n_groups_changed = 0;
+        for (Py_ssize_t c = 0; c < C; ++c) n_groups_changed += (int)((changed >> c) & 1);
+        const int has_delta = PyObject_HasAttr(eng, s_set_slot_delta);
+        PyObject *groups_c = NULL, *groups_arr = NULL;                         /* groups_op = (c, array) */
+        for (Py_ssize_t c = 0; c < C; ++c) {
+            if (!((changed >> c) & 1)) continue;
+            PyObject* ci = OWN(PyLong_FromSsize_t(c));
+            if (!ci) goto out;
+            if (n_groups_changed == 1 && has_delta) { groups_c = ci; groups_arr = PyTuple_GET_ITEM(tokens[c], 0); }
+            else {
+                PyObject* r = PyObject_CallMethodObjArgs(eng, s_set_groups, slot, ci, PyTuple_GET_ITEM(tokens[c], 0), NULL);
+                if (!r) goto out;
+                Py_DECREF(r);
+            }
+            PyObject* rem = remember_token(tokens[c]);
+            if (!rem || PyList_SetItem(new_groups, c, rem) != 0) goto out;      /* (SetItem steals rem) */
+        }
+        PyObject* was_stale = OWN(PySet_New(new_stale));
+        if (!was_stale) goto out;
+        /* counts */
+        int by_rows[BIND_MAXC], n_by_rows = 0;
+        if (have_model) {
+            for (Py_ssize_t c = 0; c < C; ++c) {
+                if (!((changed >> (2 * C + c)) & 1)) continue;
+                const Py_ssize_t n_pending = PyList_GET_SIZE(pend_idx);
+                PyObject* ci = OWN(PyLong_FromSsize_t(c));
+                if (!ci) goto out;
+                PyObject* r = OWN(PyObject_CallFunctionObjArgs(g_send_counts, eng, slot, ci, PyTuple_GET_ITEM(tokens[2 * C + c], 0),
+                                                               PyList_GET_ITEM(mirror_counts, c), pending, NULL));
+                if (!r) goto out;
+                if (!PyTuple_Check(r) || PyTuple_GET_SIZE(r) != 2) { PyErr_SetString(PyExc_TypeError, "_send_counts must return a pair"); goto out; }
+                PyObject* m = PyTuple_GET_ITEM(r, 0); Py_INCREF(m);
+                if (PyList_SetItem(mirror_counts, c, m) != 0) goto out;
+                const int ch = PyObject_IsTrue(PyTuple_GET_ITEM(r, 1));
+                if (ch < 0) goto out;
+                PyObject* rem = remember_token(tokens[2 * C + c]);
+                if (!rem || PyList_SetItem(new_counts, c, rem) != 0) goto out;
+                if (ch) {
+                    if (PyList_GET_SIZE(pend_idx) > n_pending) by_rows[n_by_rows++] = (int)c;
+                    else if (PySet_Add(new_stale, ci) != 0) goto out;              /* (the component went up whole) */
+                    if (PyDict_SetItem(nw, k_lh_all, Py_None) != 0) goto out;
+                }
+            }
+        }
+        PyObject *rows_idx = NULL, *rows_rows = NULL; int rows_fused = 0;
+        if (PyList_GET_SIZE(pend_idx) > 0) {
+            rows_fused = g_rows_with_probs;
+            for (int i = 0; i < n_by_rows && rows_fused; ++i) {
+                PyObject* ci = PyLong_FromLong(by_rows[i]);
+                if (!ci) goto out;
+                const int in = PySet_Contains(was_stale, ci);
+                Py_DECREF(ci);
+                if (in < 0) goto out;
+                if (in) rows_fused = 0;
+            }
+            if (PyList_GET_SIZE(pend_idx) == 1) {
+                rows_idx = PyList_GET_ITEM(pend_idx, 0); rows_rows = PyList_GET_ITEM(pend_rows, 0);
+            } else {
+                rows_idx = OWN(PyObject_CallFunctionObjArgs(g_concatenate, pend_idx, NULL));
+                rows_rows = rows_idx ? OWN(PyObject_CallFunctionObjArgs(g_concatenate, pend_rows, NULL)) : NULL;
+                if (!rows_rows) goto out;
+            }
+            if (!rows_fused) {
+                for (int i = 0; i < n_by_rows; ++i) {
+                    PyObject* ci = PyLong_FromLong(by_rows[i]);
+                    if (!ci || PySet_Add(new_stale, ci) != 0) { Py_XDECREF(ci); goto out; }
+                    Py_DECREF(ci);
+                }
+            }
+        }
+        /* source */
+        PyObject* source_op = NULL;                                             /* (rows, new[rows]) or None */
+        if (with_source && ((changed >> (at + 1)) & 1)) {
+            PyObject* ms = PyDict_GetItem(mirrors, k_source);
+            PyObject* r = OWN(PyObject_CallFunctionObjArgs(g_send_source, eng, slot, PyTuple_GET_ITEM(tokens[at + 1], 0), ms ? ms : Py_None, NULL));
+            if (!r) goto out;
+            if (!PyTuple_Check(r) || PyTuple_GET_SIZE(r) != 2) { PyErr_SetString(PyExc_TypeError, "_send_source must return a pair"); goto out; }
+            if (PyDict_SetItem(mirrors, k_source, PyTuple_GET_ITEM(r, 0)) != 0) goto out;
+            if (PyTuple_GET_ITEM(r, 1) != Py_None) source_op = PyTuple_GET_ITEM(r, 1);
+            PyObject* rem = OWN(remember_token(tokens[at + 1]));
+            if (!rem || PyDict_SetItem(nw, k_source, rem) != 0) goto out;
+        }
+        const int n_ops = (groups_c != NULL) + (rows_idx != NULL) + (source_op != NULL);
+        if (n_ops >= 2) {
+            PyObject* kw = OWN(PyDict_New());
+            PyObject* zero = kw ? OWN(PyLong_FromLong(0)) : NULL;
+            PyObject* meth = zero ? OWN(PyObject_GetAttr(eng, s_set_slot_delta)) : NULL;
+            PyObject* pos = meth ? OWN(PyTuple_Pack(1, slot)) : NULL;
+            if (!pos) goto out;
+            if (PyDict_SetItem(kw, k_groups_component, groups_c ? groups_c : zero) || PyDict_SetItem(kw, k_groups, groups_arr ? groups_arr : Py_None) ||
+                PyDict_SetItem(kw, k_count_idx, rows_idx ? rows_idx : Py_None) || PyDict_SetItem(kw, k_count_rows, rows_rows ? rows_rows : Py_None) ||
+                PyDict_SetItem(kw, k_update_probs, (rows_idx && rows_fused) ? Py_True : Py_False) ||
+                PyDict_SetItem(kw, k_source_objects, source_op ? PyTuple_GET_ITEM(source_op, 0) : Py_None) ||
+                PyDict_SetItem(kw, k_source_rows, source_op ? PyTuple_GET_ITEM(source_op, 1) : Py_None)) goto out;
+            PyObject* r = PyObject_Call(meth, pos, kw);
+            if (!r) goto out;
+            Py_DECREF(r);
+        } else {
+            if (groups_c) {
+                PyObject* r = PyObject_CallMethodObjArgs(eng, s_set_groups, slot, groups_c, groups_arr, NULL);
+                if (!r) goto out;
+                Py_DECREF(r);
+            }
+            if (rows_idx) {
+                PyObject* r;
+                if (rows_fused) {
+                    PyObject* meth = OWN(PyObject_GetAttr(eng, s_set_counts_rows));
+                    PyObject* pos = meth ? OWN(PyTuple_Pack(3, slot, rows_idx, rows_rows)) : NULL;
+                    PyObject* kw = pos ? OWN(PyDict_New()) : NULL;
+                    if (!kw || PyDict_SetItem(kw, k_update_probs, Py_True) != 0) goto out;
+                    r = PyObject_Call(meth, pos, kw);
+                } else r = PyObject_CallMethodObjArgs(eng, s_set_counts_rows, slot, rows_idx, rows_rows, NULL);
+                if (!r) goto out;
+                Py_DECREF(r);
+            }
+            if (source_op) {
+                PyObject* r = PyObject_CallMethodObjArgs(eng, s_set_source_rows, slot, PyTuple_GET_ITEM(source_op, 0), PyTuple_GET_ITEM(source_op, 1), NULL);
+                if (!r) goto out;
+                Py_DECREF(r);
+            }
+        }
+        if ((changed >> at) & 1) {
+            PyObject* r = PyObject_CallMethodObjArgs(eng, s_set_weights, slot, PyTuple_GET_ITEM(tokens[at], 0), NULL);
+            if (!r) goto out;
+            Py_DECREF(r);
+            PyObject* rem = OWN(remember_token(tokens[at]));
+            if (!rem || PyDict_SetItem(nw, k_weights, rem) != 0) goto out;
+        }
+        if (any_conc) {
+            for (Py_ssize_t c = 0; c < C; ++c) {
+                if (!((changed >> (C + c)) & 1)) continue;
+                PyObject* ci = OWN(PyLong_FromSsize_t(c));
+                PyObject* rem = ci ? OWN(remember_token(tokens[C + c])) : NULL;
+                if (!rem || PyObject_SetItem(bound_conc, ci, rem) != 0) goto out;
+            }
+        }
+        if (PyDict_SetItem(cache, slot, nw) != 0) goto out;                     /* (the setters above dropped the slot's entry) */
+        if (has_mirror && PyDict_SetItem(mirror_map, slot, mirrors) != 0) goto out;
+        result = new_stale; Py_INCREF(result);
+    }
+out:
+    for (int i = 0; i < n_own; ++i) Py_XDECREF(own[i]);
+    return result;
+#undef OWN
+}
+
+/* ---- binding.counts_followed in native code ---------------------------------------------------------------------------------------
+ * counts_followed(eng, entry, mirrors, nodes, off, touched, bounds, probs_rebuilt, source_rows | None, source_value | None, slot)
+ * After a call that left the slot holding the sample's new counts (Engine.counts_delta(follow_slot=...), the Gibbs proposals'
+ * `follow` forms) and the host's own add_changes: the touched components' mirror rows and tokens are brought to the sample's
+ * counts, components whose probability rows were not rebuilt join the stale set, the source mirror takes the listed rows, and the
+ * entry / mirrors go back into the engine's cache (the engine call dropped them). */
+static PyObject* py_counts_followed(PyObject* self, PyObject* args) {
+    PyObject *eng, *entry, *mirrors, *nodes, *off, *touched, *bounds, *source_rows, *source_value, *slot;
+    int probs_rebuilt;
+    if (!PyArg_ParseTuple(args, "OOOOOOOpOOO", &eng, &entry, &mirrors, &nodes, &off, &touched, &bounds, &probs_rebuilt, &source_rows, &source_value, &slot)) return NULL;
+    if (!PyDict_Check(entry) || !PyDict_Check(mirrors) || !PyList_Check(nodes) || !PyList_Check(bounds)) { PyErr_SetString(PyExc_TypeError, "counts_followed: entry / mirrors / nodes / bounds"); return NULL; }
+    const Py_ssize_t C = PyList_GET_SIZE(nodes);
+    PyObject* mcounts = PyDict_GetItem(mirrors, k_counts);
+    PyObject* ecounts = PyDict_GetItem(entry, k_counts);
+    PyObject* stale = PyDict_GetItem(entry, k_stale);
+    if (!mcounts || !ecounts || !stale || !PyList_Check(mcounts) || !PyList_Check(ecounts) || PyList_GET_SIZE(mcounts) != C || PyList_GET_SIZE(ecounts) != C ||
+        PyList_GET_SIZE(bounds) != C + 1) { PyErr_SetString(PyExc_TypeError, "counts_followed: malformed entry"); return NULL; }
+    if (source_rows != Py_None) {                       /* mirrors["source"][rows] = sample.source.value[rows]; entry["source"] = None */
+        PyObject* ms = PyDict_GetItem(mirrors, k_source);
+        Py_buffer vd, vs, vi;
+        if (!ms || PyObject_GetBuffer(ms, &vd, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_TypeError, "counts_followed: no source mirror"); return NULL; }
+        if (PyObject_GetBuffer(source_value, &vs, PyBUF_C_CONTIGUOUS) != 0) { PyBuffer_Release(&vd); return NULL; }
+        if (PyObject_GetBuffer(source_rows, &vi, PyBUF_C_CONTIGUOUS) != 0) { PyBuffer_Release(&vd); PyBuffer_Release(&vs); return NULL; }
+        int ok = vd.ndim >= 1 && vd.len == vs.len && vd.itemsize == 1 && vs.itemsize == 1 && vd.shape[0] == vs.shape[0] && vd.shape[0] > 0 &&
+                 (vi.itemsize == 4 || vi.itemsize == 8);
+        if (ok) {
+            const Py_ssize_t row = vd.len / vd.shape[0], n = vi.len / vi.itemsize;
+            for (Py_ssize_t i = 0; i < n && ok; ++i) {
+                const long long ix = vi.itemsize == 4 ? (long long)((const int*)vi.buf)[i] : ((const long long*)vi.buf)[i];
+                if (ix < 0 || ix >= vd.shape[0]) { ok = 0; break; }
+                const unsigned char* sp = (const unsigned char*)vs.buf + (Py_ssize_t)ix * row;
+                unsigned char* dp = (unsigned char*)vd.buf + (Py_ssize_t)ix * row;
+                for (Py_ssize_t e = 0; e < row; ++e) dp[e] = sp[e] != 0;          /* (np.asarray(..., dtype=bool) of a non-bool byte array) */
+            }
+        }
+        PyBuffer_Release(&vd); PyBuffer_Release(&vs); PyBuffer_Release(&vi);
+        if (!ok) { PyErr_SetString(PyExc_ValueError, "counts_followed: source mirror and source differ in form, or a row index is out of range"); return NULL; }
+        if (PyDict_SetItem(entry, k_source, Py_None) != 0) return NULL;
+    }
+    Py_buffer vo, vt;
+    if (PyObject_GetBuffer(off, &vo, PyBUF_C_CONTIGUOUS) != 0) return NULL;
+    if (PyObject_GetBuffer(touched, &vt, PyBUF_C_CONTIGUOUS) != 0) { PyBuffer_Release(&vo); return NULL; }
+    int fail = !(vo.ndim == 1 && vo.shape[0] >= C + 1 && (vo.itemsize == 8 || vo.itemsize == 4) && vt.itemsize == 4);
+    if (fail) PyErr_SetString(PyExc_TypeError, "counts_followed: off / touched");
+    for (Py_ssize_t c = 0; c < C && !fail; ++c) {
+        const Py_ssize_t lo = PyLong_AsSsize_t(PyList_GET_ITEM(bounds, c)), hi = PyLong_AsSsize_t(PyList_GET_ITEM(bounds, c + 1));
+        if (hi <= lo) continue;
+        if (lo < 0 || hi > vt.len / 4) { PyErr_SetString(PyExc_IndexError, "counts_followed: bounds"); fail = 1; break; }
+        long long o = 0; off_at(&vo, c, &o);
+        PyObject* node = PyList_GET_ITEM(nodes, c);
+        PyObject* tok = NULL;
+        if (token_of(node, Py_None, &tok) < 0) { fail = 1; break; }          /* (value, version) of the count parameter */
+        PyObject* mirror = PyList_GET_ITEM(mcounts, c);
+        Py_buffer vd, vs;
+        if (PyObject_GetBuffer(mirror, &vd, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) { Py_DECREF(tok); fail = 1; break; }
+        if (PyObject_GetBuffer(PyTuple_GET_ITEM(tok, 0), &vs, PyBUF_C_CONTIGUOUS) != 0) { PyBuffer_Release(&vd); Py_DECREF(tok); fail = 1; break; }
+        if (vd.ndim >= 1 && vd.len == vs.len && vd.itemsize == vs.itemsize && vd.shape[0] == vs.shape[0] && vd.shape[0] > 0) {
+            const Py_ssize_t row = vd.len / vd.shape[0];
+            const int* t = (const int*)vt.buf;
+            for (Py_ssize_t i = lo; i < hi; ++i) {
+                const long long g = (long long)t[i] - o;
+                if (g < 0 || g >= vd.shape[0]) { PyErr_SetString(PyExc_IndexError, "counts_followed: group index out of range"); fail = 1; break; }
+                memcpy((char*)vd.buf + g * row, (const char*)vs.buf + g * row, (size_t)row);
+            }
+        } else { PyErr_SetString(PyExc_ValueError, "counts_followed: mirror and counts differ in form"); fail = 1; }
+        PyBuffer_Release(&vd); PyBuffer_Release(&vs);
+        if (!fail) {
+            PyObject* rem = remember_token(tok);
+            if (!rem || PyList_SetItem(ecounts, c, rem) != 0) fail = 1;
+            if (!fail && !probs_rebuilt) {
+                PyObject* ci = PyLong_FromSsize_t(c);
+                if (!ci || PySet_Add(stale, ci) != 0) fail = 1;
+                Py_XDECREF(ci);
+            }
+        }
+        Py_DECREF(tok);
+    }
+    PyBuffer_Release(&vo); PyBuffer_Release(&vt);
+    if (fail) return NULL;
+    if (PyDict_SetItem(entry, k_lh_all, Py_None) != 0) return NULL;
+    PyObject* cache = PyObject_GetAttr(eng, s__bound);
+    PyObject* mirror_map = cache ? PyObject_GetAttr(eng, s__mirror) : NULL;
+    const int bad = !mirror_map || PyObject_SetItem(cache, slot, entry) != 0 || PyObject_SetItem(mirror_map, slot, mirrors) != 0;
+    Py_XDECREF(cache); Py_XDECREF(mirror_map);
+    if (bad) return NULL;
+    Py_RETURN_NONE;
+}
+
 static PyMethodDef methods[] = {
     {"scan_setup", py_scan_setup, METH_VARARGS, "scan_setup(ndarray_type, asarray, content_equal)"},
     {"scan", py_scan, METH_VARARGS, "scan(params, cached) -> (tokens, changed bitmask): the bind cache's token comparison"},
@@ -241,6 +866,11 @@ static PyMethodDef methods[] = {
     {"subset_ids", py_subset_ids, METH_VARARGS, "ids of the listed objects for sbe_counts_delta (sbeh_subset_ids)"},
     {"diff_rows", py_diff_rows, METH_VARARGS, "rows of `new` differing from `mirror`, copied into it (sbeh_diff_rows)"},
     {"touched_groups", py_touched_groups, METH_VARARGS, "sorted distinct group indices among two id arrays (sbeh_touched_groups)"},
+    {"bind_setup", py_bind_setup, METH_VARARGS, "bind_setup(_send_counts, _send_source, _remember, concatenate, rows_with_probs, python_bind_slot)"},
+    {"bind_slot", (PyCFunction)(void (*)(void))py_bind_slot, METH_VARARGS | METH_KEYWORDS, "bind_slot(eng, model, sample, slot, with_source=False) -> stale set (binding._bind_slot in C)"},
+    {"counts_followed", py_counts_followed, METH_VARARGS, "binding.counts_followed in C (mirrors and tokens follow the sample after a follow-slot call)"},
+    {"add_rows_many", py_add_rows_many, METH_VARARGS, "FeatureCounts.add_changes of every component for a difference given as rows -> bounds | None"},
+    {"copy_rows", py_copy_rows, METH_VARARGS, "dst[idx] = src[idx] (rows of two same-shaped C-contiguous arrays)"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef moduledef = {PyModuleDef_HEAD_INIT, "_sbe_pyhost", "host-layer helpers of sbayes_amd (no device code)", -1, methods};
@@ -251,6 +881,41 @@ PyMODINIT_FUNC PyInit__sbe_pyhost(void) {
     s_flags = PyUnicode_InternFromString("flags");
     s_writeable = PyUnicode_InternFromString("writeable");
     s_owndata = PyUnicode_InternFromString("owndata");
-    if (!s_value || !s_version || !s_flags || !s_writeable || !s_owndata) return NULL;
+    s_confounders = PyUnicode_InternFromString("confounders");
+    s_clusters = PyUnicode_InternFromString("clusters");
+    s_group_assignment = PyUnicode_InternFromString("group_assignment");
+    s_prior = PyUnicode_InternFromString("prior");
+    s_prior_confounding_effects = PyUnicode_InternFromString("prior_confounding_effects");
+    s_prior_cluster_effect = PyUnicode_InternFromString("prior_cluster_effect");
+    s_concentration_array = PyUnicode_InternFromString("concentration_array");
+    s_feature_counts = PyUnicode_InternFromString("feature_counts");
+    s_weights = PyUnicode_InternFromString("weights");
+    s_source = PyUnicode_InternFromString("source");
+    s__bound = PyUnicode_InternFromString("_bound");
+    s__bound_conc = PyUnicode_InternFromString("_bound_conc");
+    s__mirror = PyUnicode_InternFromString("_mirror");
+    s_set_concentration = PyUnicode_InternFromString("set_concentration");
+    s_set_groups = PyUnicode_InternFromString("set_groups");
+    s_set_slot_delta = PyUnicode_InternFromString("set_slot_delta");
+    s_set_counts_rows = PyUnicode_InternFromString("set_counts_rows");
+    s_set_source_rows = PyUnicode_InternFromString("set_source_rows");
+    s_set_weights = PyUnicode_InternFromString("set_weights");
+    k_groups = PyUnicode_InternFromString("groups");
+    k_counts = PyUnicode_InternFromString("counts");
+    k_weights = PyUnicode_InternFromString("weights");
+    k_source = PyUnicode_InternFromString("source");
+    k_stale = PyUnicode_InternFromString("stale");
+    k_lh_all = PyUnicode_InternFromString("lh_all");
+    k_update_probs = PyUnicode_InternFromString("update_probs");
+    k_groups_component = PyUnicode_InternFromString("groups_component");
+    k_count_idx = PyUnicode_InternFromString("count_idx");
+    k_count_rows = PyUnicode_InternFromString("count_rows");
+    k_source_objects = PyUnicode_InternFromString("source_objects");
+    k_source_rows = PyUnicode_InternFromString("source_rows");
+    s_shared = PyUnicode_InternFromString("shared");
+    s_resolve_sharing = PyUnicode_InternFromString("resolve_sharing");
+    s__value = PyUnicode_InternFromString("_value");
+    s_group_versions = PyUnicode_InternFromString("group_versions");
+    if (!s_value || !s_version || !s_flags || !s_writeable || !s_owndata || !s_shared || !s_resolve_sharing || !s__value || !s_group_versions) return NULL;
     return PyModule_Create(&moduledef);
 }
