@@ -14,7 +14,16 @@ call.  `_bind_slot` sends only what differs from what the slot holds (SURVEY.md 
 An entry is trusted only through the reference's own change tracking -- same ndarray object AND same parameter version
 (sbayes/sampling/state.py:34-61, 97-161, 340-350) -- or through content: when the token differs, counts and source are
 compared with the private host mirror of what the slot holds, row by row, and the differing rows go up.  Version
-numbers alone are never compared across arrays (independent chains carry similar version counters)."""
+numbers alone are never compared across arrays (independent chains carry similar version counters).
+
+CONTRACT for unversioned arrays (confounder group matrices, static concentration tables): an array that is READ-ONLY and owns
+its data is recognised by identity alone, with no private copy kept -- the reference freezes its static tables exactly so
+(sbayes/model/prior.py:322-323) and `Likelihood._freeze_static_inputs` freezes the group matrices and the cluster prior's
+tables.  Whoever thaws such an array (`setflags(write=True)`), writes into it and re-freezes it between two binds changes the
+data behind the bind cache's back: the resident copy goes stale SILENTLY.  The sampler never does that to these arrays (its
+own thaw / write / freeze pattern, FeatureCounts.add_changes, is on VERSIONED parameters, which are compared by version).
+`SBAYES_AMD_VERIFY_FROZEN=1` (debugging aid; the Python form of the bind) keeps a checksum of every frozen array it trusts
+and raises when the content behind an unchanged identity differs."""
 from __future__ import annotations
 
 import numpy as np
@@ -46,6 +55,15 @@ def _token(param):
     return value, getattr(param, "version", None)
 
 
+_VERIFY_FROZEN = bool(__import__("os").environ.get("SBAYES_AMD_VERIFY_FROZEN"))
+_FROZEN_SUMS = {}           # id(array) -> (array, adler32 of its bytes), SBAYES_AMD_VERIFY_FROZEN only
+
+
+def _frozen_sum(arr):
+    import zlib
+    return zlib.adler32(np.ascontiguousarray(arr).view(np.uint8).reshape(-1))
+
+
 def _same(tok, cached):
     """True if the token `tok` = (array, version) denotes what `cached` = (array, version, private copy) recorded.
     Versioned parameters: same ndarray object AND same version (an in-place edit through the parameter API always
@@ -64,6 +82,11 @@ def _same(tok, cached):
     if arr is ref and copy is None:                 # (_remember kept no copy: the array was frozen and owned its data)
         flags = arr.flags
         if not flags.writeable and flags.owndata:
+            if _VERIFY_FROZEN:
+                rec = _FROZEN_SUMS.get(id(arr))
+                if rec is not None and rec[0] is arr and rec[1] != _frozen_sum(arr):
+                    raise RuntimeError("sbayes_amd: a frozen array the bind cache recognises by identity was modified in place "
+                                       "(thawed, written, re-frozen) -- the resident copy is stale (binding.py: CONTRACT)")
             return True
         return False                                # thawed since: what it holds now is unknown -> re-send
     return copy is not None and arr.shape == copy.shape and arr.dtype == copy.dtype and np.array_equal(arr, copy)
@@ -86,7 +109,7 @@ def _content_equal(arr, copy):
 
 if _fast.HAVE_EXTENSION:
     _fast._h.scan_setup(np.ndarray, np.asarray, _content_equal)
-    _scan = _fast._h.scan
+    _scan = _fast._h.scan if not _VERIFY_FROZEN else _scan_py
 else:
     _scan = _scan_py
 
@@ -101,6 +124,8 @@ def _remember(tok):
         return arr, version, None
     flags = arr.flags
     if not flags.writeable and flags.owndata:       # frozen: identity is the whole comparison (no copy to keep)
+        if _VERIFY_FROZEN:
+            _FROZEN_SUMS[id(arr)] = (arr, _frozen_sum(arr))
         return arr, None, None
     return arr, None, arr.copy()
 
@@ -232,6 +257,31 @@ def _bind_slot(eng, model, sample, slot, with_source=False):
     new = {"groups": list(old_groups), "counts": list(old_counts), "weights": old["weights"], "source": old["source"],
            "stale": set(old["stale"]), "lh_all": old.get("lh_all")}
     pending = ([], [])                              # count rows of all components: one set_counts_rows call
+    try:
+        return _bind_send(eng, slot, C, changed_sets=(conc_changed, groups_changed, counts_changed, weights_changed, source_changed),
+                          toks=(conc, groups, counts, weights, source), new=new, mirrors=mirrors, pending=pending, cache=cache,
+                          has_mirror=has_mirror)
+    except BaseException:
+        # _changed_rows copies the differing rows INTO the host mirror before anything is sent: if a setter raises in
+        # between (a shape error, KeyboardInterrupt, a later component failing), mirror and entry would claim rows the
+        # device never received and the next bind would send nothing -- forget the slot instead
+        _forget_slot(eng, slot)
+        raise
+
+
+def _forget_slot(eng, slot):
+    touch = getattr(eng, "_touch", None)
+    if touch is not None:
+        touch(slot)
+    else:
+        getattr(eng, "_bound", {}).pop(slot, None)
+        getattr(eng, "_mirror", {}).pop(slot, None)
+
+
+def _bind_send(eng, slot, C, changed_sets, toks, new, mirrors, pending, cache, has_mirror):
+    """The send phase of _bind_slot (its own function so that a failure anywhere in it drops the slot's entry)."""
+    conc_changed, groups_changed, counts_changed, weights_changed, source_changed = changed_sets
+    conc, groups, counts, weights, source = toks
     for c in conc_changed:                          # (drops every slot's entry: all tables depend on it)
         eng.set_concentration(c, conc[c][0])
     if conc_changed:
@@ -298,7 +348,7 @@ def _bind_slot(eng, model, sample, slot, with_source=False):
 
 
 _bind_slot_py = _bind_slot                      # the reference form: what the native function transcribes, and its fallback
-if _fast.HAVE_EXTENSION:
+if _fast.HAVE_EXTENSION and not _VERIFY_FROZEN:
     # binding._bind_slot in native code (csrc/sbe_pyhost.c: bind_slot): the same comparisons, engine calls and cache entries --
     # five binds per MCMC step, ~20 us each as Python (tools/host_residual.py); engines without a bind cache (test doubles)
     # are handed back to the Python form by the function itself
@@ -333,8 +383,12 @@ def counts_followed(eng, plan, sample, names, touched, bounds, probs_rebuilt, so
     slot held, so the next bind with a source compares content with the mirror (and sends whatever else differs)."""
     entry, mirrors, _ = plan
     if _fast._h is not None:                        # the same steps in one native call (csrc/sbe_pyhost.c: counts_followed)
-        _fast._h.counts_followed(eng, entry, mirrors, [sample.feature_counts[name] for name in names], eng.group_offsets, touched, bounds,
-                                 bool(probs_rebuilt), source_rows, sample.source.value if source_rows is not None else None, slot)
+        try:
+            _fast._h.counts_followed(eng, entry, mirrors, [sample.feature_counts[name] for name in names], eng.group_offsets, touched, bounds,
+                                     bool(probs_rebuilt), source_rows, sample.source.value if source_rows is not None else None, slot)
+        except BaseException:                       # (half-updated mirrors must not come back into the cache)
+            _forget_slot(eng, slot)
+            raise
         return
     if source_rows is not None:
         src = sample.source.value

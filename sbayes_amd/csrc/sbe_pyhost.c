@@ -381,7 +381,7 @@ static PyObject* py_copy_rows(PyObject* self, PyObject* args) {
 static PyObject *g_send_counts = NULL, *g_send_source = NULL, *g_remember = NULL, *g_concatenate = NULL, *g_bind_py = NULL;
 static int g_rows_with_probs = 1;
 static PyObject *s_confounders, *s_clusters, *s_group_assignment, *s_prior, *s_prior_confounding_effects, *s_prior_cluster_effect,
-                *s_concentration_array, *s_feature_counts, *s_weights, *s_source, *s__bound, *s__bound_conc, *s__mirror,
+                *s_concentration_array, *s_feature_counts, *s_weights, *s_source, *s__bound, *s__bound_conc, *s__mirror, *s__touch,
                 *s_set_concentration, *s_set_groups, *s_set_slot_delta, *s_set_counts_rows, *s_set_source_rows, *s_set_weights,
                 *k_groups, *k_counts, *k_weights, *k_source, *k_stale, *k_lh_all, *k_update_probs,
                 *k_groups_component, *k_count_idx, *k_count_rows, *k_source_objects, *k_source_rows;
@@ -456,6 +456,7 @@ static PyObject* py_bind_slot(PyObject* self, PyObject* args, PyObject* kwargs) 
     PyObject* own[64 + 24 * BIND_MAXC]; int n_own = 0;
 #define OWN(x) (own[n_own++] = (x))
     PyObject* result = NULL;
+    int in_send = 0;
     PyObject *tokens[3 * BIND_MAXC + 2]; int n_tok = 0;
     memset(tokens, 0, sizeof tokens);
     OWN(cache);
@@ -570,6 +571,7 @@ static PyObject* py_bind_slot(PyObject* self, PyObject* args, PyObject* kwargs) 
         goto out;
     }
     /* ---- send the differences ---- */
+    in_send = 1;
     {
         PyObject* mirror_map = PyObject_GetAttr(eng, s__mirror);
         const int has_mirror = mirror_map != NULL;
@@ -766,6 +768,15 @@ static PyObject* py_bind_slot(PyObject* self, PyObject* args, PyObject* kwargs) 
         result = new_stale; Py_INCREF(result);
     }
 out:
+    if (!result && in_send) {
+        /* diff_rows copies the differing rows INTO the host mirror before anything is sent: a setter that raises in between
+           would leave mirror and entry claiming rows the device never received -- forget the slot */
+        PyObject *et, *ev, *tb;
+        PyErr_Fetch(&et, &ev, &tb);
+        PyObject* r = PyObject_CallMethodObjArgs(eng, s__touch, slot, NULL);
+        if (!r) PyErr_Clear(); else Py_DECREF(r);
+        PyErr_Restore(et, ev, tb);
+    }
     for (int i = 0; i < n_own; ++i) Py_XDECREF(own[i]);
     return result;
 #undef OWN
@@ -912,6 +923,7 @@ PyMODINIT_FUNC PyInit__sbe_pyhost(void) {
     k_count_rows = PyUnicode_InternFromString("count_rows");
     k_source_objects = PyUnicode_InternFromString("source_objects");
     k_source_rows = PyUnicode_InternFromString("source_rows");
+    s__touch = PyUnicode_InternFromString("_touch");
     s_shared = PyUnicode_InternFromString("shared");
     s_resolve_sharing = PyUnicode_InternFromString("resolve_sharing");
     s__value = PyUnicode_InternFromString("_value");

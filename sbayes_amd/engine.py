@@ -64,9 +64,8 @@ def device_count() -> int:
     _proc.check_usable()                 # a fork()ed child of a HIP-initialised parent may not touch the runtime
     lib = _lib.load()
     n = ct.c_int(0)
+    _proc.mark_hip_touched()             # marked on the ATTEMPT: hipGetDeviceCount initialises the runtime whatever it returns
     lib.sbe_device_count(ct.byref(n))
-    if n.value > 0:
-        _proc.mark_hip_touched()         # hipGetDeviceCount initialised the runtime in this process
     return n.value
 
 
@@ -91,6 +90,10 @@ class Engine:
         self.device = int(device)
         feats = _c(features, np.uint8)
         ng = np.asarray(self.n_groups, dtype=np.int32)
+        # marked on the ATTEMPT, not on success: a create that fails after the runtime came up (out of memory,
+        # a bad shape behind hipSetDevice) has initialised HIP all the same, and a child forked afterwards must not be
+        # taken for a fresh process
+        _proc.mark_hip_touched()
         rc = self._lib.sbe_create(ct.byref(self._h), self.device, self.n_objects, self.n_features,
                                   self.n_states, self.n_components,
                                   ng.ctypes.data_as(ct.POINTER(ct.c_int32)), self.n_slots, self._i(feats))
@@ -99,7 +102,6 @@ class Engine:
             self._h = ct.c_void_p()
             raise EngineError(rc, msg.decode() if msg else "sbe_create failed")
         self._pid = os.getpid()
-        _proc.mark_hip_touched()
         _proc.register_engine(self)
         self.group_offsets = np.concatenate([[0], np.cumsum(self.n_groups)]).astype(int)
         self.n_groups_total = int(self.group_offsets[-1])

@@ -134,9 +134,10 @@ def engine_for_features(n_features: int) -> Engine:
     return _ENGINES[key][0]
 
 
-def engine_for_observations(na_features, n_components):
+def engine_for_observations(na_features, n_components, n_groups=None):
     """The live engine whose resident feature block has exactly the NA mask `na_features` (bool [N, F]) and
-    `n_components` mixture components, or None.  For calls that receive the NA mask but neither the feature block nor
+    `n_components` mixture components -- and, when `n_groups` is given, exactly that group layout (two datasets of one
+    shape and one mask, e.g. no missing values, differ in their confounders' group counts: ADVICE r4) -- or None.  For calls that receive the NA mask but neither the feature block nor
     the model (GibbsSampleWeights.source_lh_by_feature(source, weights, na_features), operators.py:677-685): the shape
     alone does not identify a dataset -- two datasets of one shape differ in which observations count -- so the mask
     is compared with the engine's own (fetched once per engine; an array object verified once is recognised by
@@ -147,11 +148,13 @@ def engine_for_observations(na_features, n_components):
     for eng, ref in _ENGINES.values():
         if (eng.n_objects, eng.n_features) != na.shape or eng.n_components != n_components:
             continue
+        if n_groups is not None and [int(g) for g in n_groups] != list(eng.n_groups):
+            continue
         if ref is not None and ref() is None:
             continue
         seen = getattr(eng, "_na_verified", None)
-        if seen is not None and seen is na:
-            return eng
+        if seen is not None and seen is na and not na.flags.writeable:
+            return eng                      # (a read-only array verified once cannot have changed: identity is enough)
         mask = getattr(eng, "_na_host", None)
         if mask is None:
             mask = eng._na_host = eng.na_values()

@@ -478,9 +478,11 @@ def make_get_engine(engines, cls=None):
 
 def make_engine_for_observations(engines):
     """`registry.engine_for_observations` for the tests: the double whose feature block has the NA mask handed over."""
-    def engine_for_observations(na_features, n_components):
+    def engine_for_observations(na_features, n_components, n_groups=None):
         na = np.asarray(na_features)
         for e in engines.values():
+            if n_groups is not None and [int(g) for g in n_groups] != list(e.n_groups):
+                continue
             if (e.n_objects, e.n_features) == na.shape and e.n_components == n_components and np.array_equal(e.na_values(), na):
                 return e
         return None

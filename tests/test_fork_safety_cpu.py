@@ -161,12 +161,15 @@ def test_a_handle_is_never_destroyed_outside_its_process(standin):
     assert not eng._h and [c for c in _calls(standin) if c[1] == "destroy"] == []
 
 
-def test_failed_create_does_not_mark_the_process(standin, monkeypatch):
+def test_failed_create_marks_the_process(standin, monkeypatch):
+    """The process is marked on the ATTEMPT: a create that fails after hipSetDevice / hipMalloc has initialised the
+    runtime all the same, and a child forked afterwards must not be taken for a fresh process."""
     monkeypatch.setattr(standin, "sbe_create", lambda *a: 7)
-    monkeypatch.setattr(standin, "sbe_last_error", lambda h: b"no device")
+    monkeypatch.setattr(standin, "sbe_last_error", lambda h: b"out of memory")
+    assert not _proc.hip_touched()
     with pytest.raises(engine_mod.EngineError):
         engine_mod.Engine(np.zeros((2, 2, 2), dtype=bool), [1])
-    assert not _proc.hip_touched()
+    assert _proc.hip_touched()
 
 
 def test_start_method_helper(monkeypatch):

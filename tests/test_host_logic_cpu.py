@@ -412,3 +412,42 @@ def test_update_feature_counts_lets_the_bound_slot_follow(fake):
     assert any(c[0] == "set_counts_rows" or (c[0] == "set_slot_delta" and c[2]) for c in eng.calls)
     for c, name in enumerate(names):
         assert np.array_equal(slot_counts()[c], cand2.feature_counts[name].value)
+
+
+def test_bind_failure_forgets_the_slot():
+    """the bind's row diff copies the differing rows into the host mirror BEFORE they are sent; a setter that raises
+    in between must not leave mirror and entry claiming rows the device never received -- the slot's entry is dropped, the
+    next bind sends the rows again (both the native and the Python form of the bind)."""
+    from sbayes_amd import binding
+
+    fx = load_npz("cfg1")
+    model, sample = build(fx)
+    feats = model.data.features.values
+    recalculate_feature_counts.__wrapped__(feats, sample) if hasattr(recalculate_feature_counts, "__wrapped__") else None
+    n_groups = [g.shape[0] for g in fx.groups]
+    for bind in (binding._bind_slot, binding._bind_slot_py):
+        eng = FakeEngine(feats, n_groups)
+        for c, name in enumerate(sample.feature_counts):           # (counts from the fixture: the sample's own tables)
+            sample.feature_counts[name].set_value(np.asarray(fx.z[f"counts_{c}"], dtype=np.float32).copy())
+        bind(eng, model, sample, 0, with_source=True)
+        assert 0 in eng._bound and 0 in eng._mirror
+        # a counts change, and the next setter fails
+        node = sample.feature_counts["clusters"]
+        diff = np.zeros(node.value.shape, dtype=np.float32)
+        diff[0, 0, 0] = 1.0
+        node.add_changes(diff=diff)
+        want = node.value.copy()
+
+        def boom(*a, **k):
+            raise ValueError("injected")
+        saved = {name: getattr(eng, name) for name in ("set_counts_rows", "set_slot_delta") if hasattr(eng, name)}
+        for name in saved:
+            setattr(eng, name, boom)
+        with pytest.raises(ValueError, match="injected"):
+            bind(eng, model, sample, 0, with_source=True)
+        assert 0 not in eng._bound and 0 not in eng._mirror            # forgotten, not half-updated
+        for name, fn in saved.items():
+            setattr(eng, name, fn)
+        bind(eng, model, sample, 0, with_source=True)                 # sends everything the slot needs
+        assert np.array_equal(eng.get_counts(0, 0), want)
+        node.add_changes(diff=-diff)

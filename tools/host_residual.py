@@ -304,10 +304,13 @@ def measure(tag, config_path, n_steps, seed, gibbs_source=False):
         inside2 = np.asarray(ins2) if inside2 is None else np.minimum(inside2, np.asarray(ins2))
     # replays with the host-layer clock on (its wrappers cost a little: not the runs the residual is taken from)
     ours = None
+    by_fn = None
     for _ in range(3):
         _s, inside3, _o, _e, _l, layer3 = _run(config_path, tag, n_steps, seed, "replay", memo=memo, layer_clock=True,
                                                gibbs_source=gibbs_source)
         o = np.asarray(layer3) - np.asarray(inside3)
+        if by_fn is None or o.mean() < by_fn[0]:
+            by_fn = (o.mean(), dict(_run.last_clock.by_name))
         ours = o if ours is None else np.minimum(ours, o)
     secs0 = None
     for _ in range(3 if n_steps * 1 <= 200 else 2):
@@ -328,6 +331,11 @@ def measure(tag, config_path, n_steps, seed, gibbs_source=False):
         "plain_reference_steps_per_s": round(1e6 / float(np.mean(np.asarray(secs0) * 1e6)), 2),
         "same_chain_as_plain": bool(ops0 == ops1 and abs(ll0 - ll1) <= 1e-9 * abs(ll1)),
         "by_operator": by_op,
+        # where this package's host layer spends its share (outermost entries of every swapped-in function, the replay with
+        # the smallest layer total; includes the replay double's own time inside those functions)
+        "host_layer_by_function": {name: {"calls_per_step": round(calls / n_steps, 3), "us_per_call": round(t / calls * 1e6, 1),
+                                          "us_per_step": round(t / n_steps * 1e6, 1)}
+                                   for name, (calls, t) in sorted(by_fn[1].items(), key=lambda kv: -kv[1][1])},
     }
 
 
@@ -386,7 +394,7 @@ def main():
         g = measure(tag, path, n, seed, gibbs_source=True)
         assert g["same_chain_as_plain"], "the device Gibbs proposal changed the chain"
         r["with_gibbs_source_on_device"] = {k: g[k] for k in ("host_python_us_per_step", "of_which_this_packages_host_layer_us_per_step",
-                                                                "engine_calls_total", "by_operator", "same_chain_as_plain")}
+                                                                "engine_calls_total", "by_operator", "same_chain_as_plain", "host_layer_by_function")}
         print(f"[residual] {tag}: with the Gibbs source proposal on the device {g['host_python_us_per_step']['mean']} us/step "
               f"(median {g['host_python_us_per_step']['median']}), {time.time() - t0:.0f} s", flush=True)
     with open(args.out, "w") as fh:
