@@ -523,7 +523,9 @@ int wait_done(sbe_engine* e, const DoneSig& d) {
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 1;; ++spins) {
             if (*f == d.seq) { std::atomic_thread_fence(std::memory_order_acquire); return SBE_OK; }
-            __builtin_ia32_pause();
+            // (every 128th turn the core is offered to whoever else is runnable: several single-chain processes share a host,
+            //  and a spinner that never yields holds back the thread that would feed the GPU; free on an idle host)
+            if ((spins & 127u) == 0u) sched_yield(); else __builtin_ia32_pause();
             if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
         }
     }
@@ -3941,6 +3943,14 @@ int ensure_step_pool(sbe_engine* e) {
         int cpus = (int)std::thread::hardware_concurrency();
         cpu_set_t set;
         if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = std::min(cpus > 0 ? cpus : CPU_COUNT(&set), CPU_COUNT(&set));
+        // ... and the container's CPU quota, which the affinity mask does not show (a GPU box of this pool: 256 CPUs
+        // visible, 16 granted): cgroup v2 cpu.max = "<quota> <period>" or "max"
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            long long quota = 0, period = 0;
+            if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+                cpus = std::min<int>(cpus, (int)std::max<long long>(1, quota / period));
+            fclose(f);
+        }
         int local_world = 1;
         if (const char* env = getenv("LOCAL_WORLD_SIZE")) local_world = std::max(1, atoi(env));
         nt = std::min<int>(nt, std::max(0, cpus / local_world - 1));

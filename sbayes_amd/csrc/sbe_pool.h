@@ -12,8 +12,19 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <sched.h>
 
 namespace sbe_host {
+
+// One turn of a spin-wait.  Several engines share a host (one process per chain: sbayes/mcmc_setup.py:271-282), and their
+// waiting threads together can outnumber the cores the processes may use; a waiter that only pauses then burns the time slice
+// of a thread that has work (measured: six single-chain processes on one card moved half the streamed [N, F, C] results one
+// process moves alone, tests/test_gpu_processes.py).  So every 64th turn gives the core away -- sched_yield returns at once
+// when nobody else is runnable, i.e. it costs nothing on an idle host.
+struct SpinWait {
+    unsigned n = 0;
+    void turn() { if ((++n & 63u) == 0u) sched_yield(); else __builtin_ia32_pause(); }
+};
 
 struct StepPool {
     std::vector<std::thread> workers;
@@ -57,9 +68,10 @@ struct StepPool {
             if (seen != 0) {                                         // (after the first job: poll before blocking)
                 lk.unlock();
                 const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(kSpinUs);
+                SpinWait sw;
                 while (gen_hint.load(std::memory_order_acquire) == seen && !stop_hint.load(std::memory_order_relaxed) &&
                        std::chrono::steady_clock::now() < t_end)
-                    __builtin_ia32_pause();
+                    sw.turn();
                 lk.lock();
             }
             cv_work.wait(lk, [&] { return stop || generation != seen; });
@@ -86,9 +98,10 @@ struct StepPool {
         }
         cv_work.notify_all();
         claim_loop(poll);
+        SpinWait sw;
         while (done.load(std::memory_order_acquire) < n) {                          // (jobs are microseconds long)
             if (poll) (*poll)();
-            __builtin_ia32_pause();
+            sw.turn();
         }
     }
 };
@@ -103,8 +116,9 @@ struct StepPool {
 template <class First, class Last, class Ready, class Tick, class Work>
 void run_as_chunks_land(StepPool* pool, int n, First first_chunk, Last last_chunk, Ready chunk_ready, Tick caller_tick, Work work) {
     auto wait_for = [&](int j, bool mine) {
+        SpinWait sw;
         for (int k = first_chunk(j), k1 = last_chunk(j); k <= k1; ++k)
-            while (!chunk_ready(k)) { if (mine) caller_tick(); else __builtin_ia32_pause(); }
+            while (!chunk_ready(k)) { if (mine) caller_tick(); else sw.turn(); }
         std::atomic_thread_fence(std::memory_order_acquire);
     };
     if (!pool) {

@@ -118,3 +118,99 @@ def test_fork_from_a_process_with_a_live_context():
     assert child["registry_empty"] and child["handle_nulled"] and child["forked_from"] == out["parent"]
     for tag in ("inherited", "create", "direct"):
         assert "forkserver" in child[tag] and "fork()" in child[tag], child[tag]
+
+
+_CHAIN_PROBE = r"""
+import json, os, sys, time
+sys.path.insert(0, {repo!r})
+import numpy as np
+from sbayes_amd.engine import Engine
+from sbayes_amd.synthetic import make_workload
+
+wl = make_workload("headline")
+eng = Engine(wl.features, [g.shape[0] for g in wl.groups], n_slots=2, device=0)
+for c in range(wl.n_components):
+    eng.set_concentration(c, wl.concentration[c])
+eng.load_state(0, wl.groups, wl.weights, source=wl.source)
+for c in range(wl.n_components):
+    eng.update_probs(0, c)
+ll = eng.mixture_loglik(0)
+lh = eng.likelihood_per_component(0)
+print("READY", flush=True)
+start = float(sys.stdin.readline())                # every process starts its loops at the same wall-clock instant
+while time.time() < start:
+    pass
+t0 = time.perf_counter(); n = 0
+while time.perf_counter() - t0 < {seconds}:
+    for _ in range(50):
+        eng.mixture_loglik(0)                      # host-synchronous: the caller spins on the completion flag
+    n += 50
+evals = n / (time.perf_counter() - t0)
+t0 = time.perf_counter(); m = 0
+while time.perf_counter() - t0 < {seconds}:
+    for _ in range(10):
+        eng.likelihood_per_component(0)            # the streamed [N, F, C] result: the engine's host pool copies the chunks out
+    m += 10
+lh_calls = m / (time.perf_counter() - t0)
+print(json.dumps(dict(pid=os.getpid(), ll=ll, lh_sum=float(lh.sum()), evals_per_s=evals, lh_calls_per_s=lh_calls,
+                      cpus=os.cpu_count(), affinity=len(os.sched_getaffinity(0)),
+                      cpu_max=(open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else None),
+                      step_threads=os.environ.get("SBE_STEP_THREADS"))), flush=True)
+eng.close()
+"""
+
+
+def _run_chain_processes(n, seconds=1.5):
+    import time
+    env = {k: v for k, v in os.environ.items() if k != "SBE_STEP_THREADS"}            # the engine's own default
+    procs = [subprocess.Popen([sys.executable, "-c", _CHAIN_PROBE.format(repo=str(REPO), seconds=seconds)], stdin=subprocess.PIPE,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=str(REPO), env=env) for _ in range(n)]
+    try:
+        for p in procs:
+            assert p.stdout.readline().strip() == "READY", p.stderr.read()[-2000:]
+        start = time.time() + 0.3
+        for p in procs:
+            p.stdin.write(f"{start}\n"); p.stdin.flush()
+        out = []
+        for p in procs:
+            so, se = p.communicate(timeout=300)
+            assert p.returncode == 0, se[-2000:]
+            out.append(json.loads([ln for ln in so.splitlines() if ln.startswith("{")][-1]))
+        return out
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+
+
+def test_six_chain_processes_on_one_card_with_default_spin_waits():
+    """every synchronous call spins a core for up to 300 us and the engine's pool workers poll
+    after a call; several chains = several such processes on one host.  Fresh child processes (never a fork or exec of a
+    process that touched the GPU), each with its own engine on device 0 and the engine's DEFAULT thread settings, run the
+    same host-synchronous loops at the same time; the per-process rates go to gpurun_out/ for the record.  Six, not eight:
+    a GPU box of this pool admits at most six processes on its card.  Asserted: identical results in every process, no
+    process starved, and the six together deliver at least what one delivers alone (the card serialises their kernels;
+    their spin-waits must not make it worse than that)."""
+    solo = _run_chain_processes(1)[0]
+    six = _run_chain_processes(6)
+    assert len({r["pid"] for r in six}) == 6
+    assert all(r["ll"] == solo["ll"] and r["lh_sum"] == solo["lh_sum"] for r in six)
+    agg_evals = sum(r["evals_per_s"] for r in six)
+    agg_lh = sum(r["lh_calls_per_s"] for r in six)
+    record = dict(what="one vs six concurrent single-chain processes on ONE MI355X, headline shape, default SBE_STEP_THREADS",
+                  solo=solo, six=six, aggregate_evals_per_s=agg_evals, aggregate_lh_calls_per_s=agg_lh,
+                  evals_ratio_six_over_solo=agg_evals / solo["evals_per_s"], lh_ratio_six_over_solo=agg_lh / solo["lh_calls_per_s"])
+    out_dir = REPO / "gpurun_out"
+    try:
+        out_dir.mkdir(exist_ok=True)
+        (out_dir / "six_processes_one_card.json").write_text(json.dumps(record, indent=1))
+    except OSError:
+        pass
+    print(json.dumps(record))
+    slowest = min(r["evals_per_s"] for r in six)
+    assert slowest >= solo["evals_per_s"] / 24, record                    # nobody starved (a fair share would be 1/6)
+    assert agg_evals >= 0.8 * solo["evals_per_s"], record                 # contention does not eat the card
+    # the streamed [N, F, C] result (3.2 MB per call through ONE PCIe link and the host's copy threads): measured 0.50 of
+    # the solo rate for six processes, with and without yielding spin-waits (profiles/r5/six_processes_one_card*.json) --
+    # recorded, and bounded here only against a collapse
+    assert agg_lh >= 0.3 * solo["lh_calls_per_s"], record
