@@ -105,6 +105,12 @@ struct sbe_engine {
     uint32_t* d_rowoff = nullptr;  // [slots][C+1][Np] LDS byte offsets of k_mixture_rows (k_rowoff), or null
     int rows_ft = 0;               // tile width of k_mixture_rows (32 / 16; 0: its LDS image does not fit, or C > 4)
     std::vector<uint64_t> rowoff_epoch;   // per slot: Slot::group_epoch the device array was built from
+    // pattern-sorted form of the rows kernel (built at its first launch): the slot's objects by has_components pattern
+    uint32_t* d_rowoff_s = nullptr;  int rs_nq_max = 0;   // [slots][rs_nq_max][C+1][4] (k_rowsort)
+    int32_t* d_rs_nq = nullptr;           // [slots] quads of the slot's padded order
+    uint8_t* d_state_s = nullptr;         // [N + 1][Fp] state index, NA = S; row N all NA (the null object)
+    std::vector<uint64_t> rowsort_epoch;
+    int opt_rows_sorted = 1;              // SBE_ROWS_SORTED: 0 never, 1 launches of >= 16 slots at 32-feature tiles (default), 2 whenever it applies (tests)
     std::atomic<uint64_t> epoch_counter{0};
     uint8_t* d_xt = nullptr;       // one-hot block in MFMA fragment order (k_mixture_tuple_mfma), built at the first batched launch
     int xt_NT = 0, xt_KBp = 0;  size_t xt_bytes = 0;
@@ -1012,6 +1018,11 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     const size_t rows_image = rows ? (size_t)(e->Gtot + 1) * (e->S + 1) * e->rows_ft * 4 + (size_t)P * ((e->C + 1) / 2) * e->rows_ft * 16
                                          + (size_t)kRowsWaves * (kWave / e->rows_ft) * (e->C + 1) * 16 : 0;      // tables | weights | offset slots
     if (rows && rows_image > 160 * 1024 - 512) rows = false;      // more patterns than the tile width was sized for
+    // pattern-sorted objects (weights in registers): 32-feature tiles, a second offsets slot per wave in LDS, state-row
+    // offsets of 24 bits
+    const size_t sorted_image = rows_image + (size_t)kRowsWaves * (kWave / std::max(1, e->rows_ft)) * (e->C + 1) * 16;
+    const bool sorted = rows && (e->opt_rows_sorted == 2 || (e->opt_rows_sorted == 1 && n >= 16)) && e->rows_ft == 32 && sorted_image <= 160 * 1024 - 512 &&
+                        (int64_t)(e->N + 1) * e->Fq < ((int64_t)1 << 24) && e->Pmax <= 64;
     // a single eval with a large image (stress shape: 153 KB per block) is staging-bound in the rows form (measured
     // 13.8 us against 12.5 us for k_mixture_v2's many small blocks); from two evals per launch on the rows form wins
     if (rows && n == 1 && rows_image > 72 * 1024 && e->opt_kernel != SBE_MIXTURE_PACKED_GENERAL) rows = false;
@@ -1028,19 +1039,41 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     if (rows) {
         const int rft = e->rows_ft, gran = kRowsWaves * (kWave / rft);         // quads per block step
         const int n_t = div_up(e->F, rft);
-        const size_t image = rows_image;
+        const size_t image = sorted ? sorted_image : rows_image;
+        if (sorted && !e->d_rowoff_s) {                                        // one-time: the sorted form's arrays
+            const int step_objs = 4 * (kWave / rft);
+            e->rs_nq_max = round_up(e->N + e->Pmax * (step_objs - 1), step_objs) / 4;
+            int rc = dmalloc(e, &e->d_rowoff_s, (int64_t)e->n_slots * e->rs_nq_max * (e->C + 1) * 4); if (rc) return rc;
+            rc = dmalloc(e, &e->d_rs_nq, e->n_slots); if (rc) return rc;
+            rc = dmalloc(e, &e->d_state_s, (int64_t)(e->N + 1) * e->Fq); if (rc) return rc;
+            launch_state_s(e->d_state, e->d_state_s, e->N, e->F, e->Fp, e->Fq, e->S, e->stream);
+            HIPCHK(e, hipGetLastError());
+            e->rowsort_epoch.assign(e->n_slots, ~0ull);
+        }
+        const int NQ_geo = sorted ? e->rs_nq_max : e->NQ;                      // (sorted: the longest padded order a slot can have)
         // every block stages the whole image: with a large image one block per CU and as few object chunks as fill
         // the chip; small images take two generations of blocks
         // (a block that stages a large image wants at least ~8 block steps of work behind it)
         const int64_t target = (int64_t)e->compute_units * (image > 72 * 1024 ? 1 : 2);
         int min_steps = image > 72 * 1024 ? 8 : image > 24 * 1024 ? 4 : 1;
         if (const char* env = getenv("SBE_ROWS_MIN_STEPS")) { if (atoi(env) > 0) min_steps = atoi(env); }   // experiments
-        int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(div_up(e->NQ, (int64_t)gran * min_steps), div_up(target, (int64_t)n_t * n)));
-        const int qpc = round_up(div_up(e->NQ, chunks), gran);
-        g.ft = rft; g.n_ftiles = n_t; g.objs_per_chunk = qpc; g.n_chunks = div_up(e->NQ, qpc);
+        int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(div_up(NQ_geo, (int64_t)gran * min_steps), div_up(target, (int64_t)n_t * n)));
+        const int qpc = round_up(div_up(NQ_geo, chunks), gran);
+        g.ft = rft; g.n_ftiles = n_t; g.objs_per_chunk = qpc; g.n_chunks = div_up(NQ_geo, qpc);
         g.n_blocks = g.n_chunks * n_t; g.lds_bytes = image;
         // per-object row offsets of the slots whose group ids changed since their offsets were built
         bool stale = false;
+        if (sorted) {
+            for (int i = 0; i < n; ++i) stale |= e->rowsort_epoch[slot_at(i)] != e->slots[slot_at(i)].group_epoch;
+            if (stale) {
+                launch_rowsort(e->d_gid, e->d_pid, e->d_rowoff_s, e->d_rs_nq, (int64_t)e->C * e->Np, e->Np,
+                               (int64_t)e->rs_nq_max * (e->C + 1) * 4, first_slot, d_slots, n, e->N, e->Np, e->C, e->Gtot, e->Pmax,
+                               (uint32_t)((e->S + 1) * rft * 4), (uint32_t)e->Fq, 4 * (kWave / rft), e->stream);
+                HIPCHK(e, hipGetLastError());
+                for (int i = 0; i < n; ++i) e->rowsort_epoch[slot_at(i)] = e->slots[slot_at(i)].group_epoch;
+            }
+            stale = false;
+        } else
         for (int i = 0; i < n; ++i) stale |= e->rowoff_epoch[slot_at(i)] != e->slots[slot_at(i)].group_epoch;
         if (stale) {
             const int cells = (e->C + 1) * e->Np;
@@ -1102,6 +1135,8 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
         p.eft = e->ft;
         p.wpat = e->d_wpat; p.wpat_stride = (int64_t)e->Pmax * e->F * e->C;
         p.rowoff = e->d_rowoff; p.rowoff_stride = (int64_t)(e->C + 1) * e->Np;
+        p.rowoff_s = e->d_rowoff_s; p.rowoff_s_stride = (int64_t)e->rs_nq_max * (e->C + 1) * 4;
+        p.rs_nq = e->d_rs_nq; p.state_s = e->d_state_s; p.state_s_pitch = e->Fq;
         {   // shares of a rows block's steps by wave age class (see k_mixture_rows); SBE_ROWS_SPLIT="a,b,c,d" per mille
             static int split[4] = {450, 270, 170, 110};
             static bool parsed = false;
@@ -1132,11 +1167,11 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
 #endif
         snprintf(e->last_kernel, sizeof e->last_kernel, "%s<%s%s, tile %d, C=%d>",
                  combo ? (tuple64 ? "k_mixture_tuple64" : "k_mixture_combo") : rows ? "k_mixture_rows" : (onehot ? "k_mixture_onehot_v2" : "k_mixture_v2"),
-                 onehot ? "one-hot stream" : "packed stream", combo ? ", group-tuple form" : (e->direct ? ", direct tables" : ""), g.ft, e->C);
+                 onehot ? "one-hot stream" : "packed stream", combo ? ", group-tuple form" : (rows && sorted ? ", pattern-sorted objects" : (e->direct ? ", direct tables" : "")), g.ft, e->C);
         // (the kernels live in their own translation unit: sbe_mixture.hip)
         if (combo && tuple64) launch_tuple64(e->C, p, grid, combo_lds, e->stream);
         else if (combo) launch_combo(onehot, g.ft, e->C, p, grid, combo_lds, e->stream);
-        else if (rows) launch_rows(mode, g.ft, e->C, p, grid, g.lds_bytes, e->stream);
+        else if (rows) launch_rows(mode, g.ft, e->C, p, grid, g.lds_bytes, e->stream, sorted);
         else if (onehot) launch_oh2(mode, g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
         else launch_v2(mode, g.ft, e->C, p, grid, g.lds_bytes, e->stream, e->direct);
 #ifdef SBE_STAMPS
@@ -1278,7 +1313,7 @@ int sbe_destroy(sbe_engine* e) {
     if (e->h_io) (void)hipHostFree(e->h_io);
     void* dev_ptrs[] = {e->d_step_pf, e->d_step_pg, e->d_logtab, e->d_state_h, e->d_toff, e->d_tid, e->d_tuple_g, e->d_tuple_p, e->d_state_q, e->d_probs_t, e->d_wpat_t, e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
                         e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_lg_conc, e->d_sum_a, e->d_lg_sum_a, e->d_unif, e->d_unif_res, e->d_comp_of_group, e->d_partials, e->d_rowoff,
-                        e->d_status, e->d_changed, e->d_step_stamp, e->d_scratch, e->d_xt};
+                        e->d_status, e->d_changed, e->d_step_stamp, e->d_scratch, e->d_xt, e->d_rowoff_s, e->d_rs_nq, e->d_state_s};
     for (void* p : dev_ptrs) if (p) (void)hipFree(p);
     if (e->h_results) (void)hipHostFree(e->h_results);
     if (e->h_status) (void)hipHostFree(e->h_status);
@@ -1383,6 +1418,7 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     CREATE_CHK(hipGetDeviceProperties(&prop, device));
     e->compute_units = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* env = getenv("SBE_MFMA_MIN_BATCH")) { if (atoi(env) > 0) e->mfma_min_batch = atoi(env); }      // (A/B runs, tests)
+    if (const char* env = getenv("SBE_ROWS_SORTED")) e->opt_rows_sorted = atoi(env);
     snprintf(e->device_name, sizeof e->device_name, "%s%s%s", prop.name, prop.name[0] ? " " : "", prop.gcnArchName);
     CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     CREATE_CHK(hipEventCreate(&e->ev0));

@@ -400,7 +400,14 @@ __global__ __launch_bounds__(kBlock) void k_mixture_onehot_v2(Mix2Params p) {
 // ==========================================================================================
 
 
-template <int MODE, int FT, int CT>
+// SORTED (round 5, stress shape): the slot's objects come in an order in which every wave step (SUBS quads = 8 objects at
+// FT = 32) holds ONE has_components pattern (k_rowsort: counting sort by pattern id, runs padded to whole steps with null
+// objects), so the pattern's weights live in registers -- no per-observation weight read, a third of the loop's LDS traffic --
+// and are re-read only where a run ends.  The price is the state stream: it can no longer be the shared quad-interleaved
+// dword (four CONSECUTIVE objects), each observation's state byte is gathered from the object-major state block through the
+// permutation: the offsets stream carries, instead of the pattern's weight offset, (pattern << 24 | byte offset of the
+// object's state row), parked two steps ahead so that the four byte loads of a step are in flight for two steps.
+template <int MODE, int FT, int CT, bool SORTED = false>
 __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mixture_rows(Mix2Params p) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ double red[kRowsWaves];
@@ -419,9 +426,14 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
     const uint32_t state_bytes = FT * 4;                                  // one state row of a group block
     const uint32_t row_bytes = (uint32_t)S1 * state_bytes;
     const uint32_t tab_bytes = (uint32_t)(p.Gtot + 1) * row_bytes;
+    const int NQ_slot = SORTED ? p.rs_nq[slot] : p.NQ;                    // (sorted: the padded length of THIS slot's order)
     const int q0 = chunk * p.quads_per_chunk;
-    const int q1 = min(p.NQ, q0 + p.quads_per_chunk);
-    const int nq = q1 - q0;                                               // >= 1
+    const int q1 = min(NQ_slot, q0 + p.quads_per_chunk);
+    const int nq = max(0, q1 - q0);                                       // (sorted: a chunk beyond the slot's length is empty)
+    if (SORTED && nq == 0) {                                              // (block-uniform, before any barrier: nothing to stage for)
+        if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + work] = 0.0;
+        return;
+    }
 
     // ---- LDS image of the tile ---------------------------------------------------------------------------------
     // Tables: 16-byte pieces straight from the engine's tile-transposed copy probs_t[tile_e][g][s][eft] (a 32-feature
@@ -504,6 +516,8 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
     auto step_of = [&](int k) { return sb0 + wic + 4 * k; };
     // streamed operands through buffer descriptors (plain buffer loads: no flat path, no 64-bit address arithmetic):
     // the quad-interleaved state block (shared by every slot) and the slot's per-object row offsets
+    double thread_ll;
+    if constexpr (!SORTED) {
     const __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t*>(p.state_q), 0, (int)((uint32_t)p.NQ * (uint32_t)p.Fq * 4u), 0x00020000);
     constexpr int QD = (CT + 1) * 4;                                      // offset dwords per quad
@@ -572,7 +586,6 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
     // offsets of step k+1 parked in LDS and read back while step k's arithmetic runs.  LDS operations of a wave
     // complete in order, so the slot needs no barrier: the write of step k+1's offsets is issued after the reads
     // of step k's (already in registers), and its read-back after that write.
-    double thread_ll;
     {
         ProdAcc pa{1.0, 0, 0, 0u};
         double sum = 0.0;
@@ -622,6 +635,127 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
                 if (pa.bad != 0u) thread_ll = s2;
             }
         } else thread_ll = sum;
+    }
+    } else {
+    // ================= SORTED: pattern-uniform steps, weights in registers, gathered state bytes =================
+    constexpr int QD = (CT + 1) * 4;                                      // offset dwords per quad: C table rows + the state row
+    constexpr int WD = SUBS * QD;                                         // ... per wave step (<= 64: one dword per lane)
+    static_assert(WD <= kWave, "one offsets dword per lane and step");
+    const __amdgpu_buffer_rsrc_t ro_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t*>(p.rowoff_s + (int64_t)slot * p.rowoff_s_stride), 0, (int)((uint32_t)NQ_slot * QD * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t st8_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(p.state_s), 0, (int)((uint32_t)(p.N + 1) * (uint32_t)p.state_s_pitch), 0x00020000);
+    // two offset slots per wave (steps of even / odd parity): the state rows of step k+2 are read back while the table
+    // rows of step k+1 still wait in the other slot
+    const uint32_t slots_lds = tab_bytes + (uint32_t)p.P * CP * FT * 16u + (uint32_t)wave * (2u * WD * 4u);
+    auto slot_at = [&](int k) -> uint32_t { return slots_lds + (uint32_t)(k & 1) * (WD * 4u); };
+    const uint32_t my_quad = (uint32_t)sub * (QD * 4u);
+    auto load_ro = [&](int k) -> uint32_t {                               // offsets dword of step k for this lane
+        const uint32_t run0 = (uint32_t)(q0 + step_of(k) * SUBS) * (QD * 4u);
+        return __builtin_amdgcn_raw_buffer_load_b32(ro_rsrc, (int)(run0 + (uint32_t)lane * 4u), 0, 0);      // (past the slot's order: 0)
+    };
+    auto park = [&](int k, uint32_t ro) {
+        if (lane < WD) *reinterpret_cast<uint32_t*>(lds_raw + slot_at(k) + (uint32_t)lane * 4u) = ro;
+    };
+    struct StateRows { u32x4_t po; };
+    auto read_state_rows = [&](int k) -> u32x4_t {                       // (pattern << 24 | state row offset) of this lane's quad
+        return *reinterpret_cast<const u32x4_t*>(lds_raw + slot_at(k) + my_quad + (uint32_t)CT * 16u);
+    };
+    struct Xs { uint32_t x[4]; uint32_t pat; };
+    auto load_states = [&](int k, const u32x4_t po) -> Xs {              // the four state bytes of step k
+        // (a step past the wave's range is only ever PREFETCHED, never evaluated, and inside the range every quad of a step
+        //  exists -- runs and chunks are whole steps -- so whatever row the offsets name is read: no bounds selects.  Only
+        //  object 0 of the quad carries the pattern id above its 24-bit row offset.)
+        Xs r;
+        r.x[0] = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(st8_rsrc, (int)((po[0] & 0x00FFFFFFu) + (uint32_t)f), 0, 0);
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+            r.x[j] = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(st8_rsrc, (int)(po[j] + (uint32_t)f), 0, 0);
+        r.pat = po[0] >> 24;
+        return r;
+    };
+    struct Offs { u32x4_t ro[CT]; };
+    auto read_table_rows = [&](int k) -> Offs {
+        Offs o;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) o.ro[c] = *reinterpret_cast<const u32x4_t*>(lds_raw + slot_at(k) + my_quad + (uint32_t)c * 16u);
+        return o;
+    };
+    double w[2 * CP];                                                     // the current pattern's weights of this lane's feature
+    uint32_t w_pat = 0xFFFFFFFFu;
+    auto load_weights = [&](uint32_t pat) {
+#pragma unroll
+        for (int h = 0; h < CP; ++h) {
+            const f64x2_t ww = *reinterpret_cast<const f64x2_t*>(lds_raw + lane_w + pat * (uint32_t)(CP * FT * 16) + (uint32_t)h * (FT * 16u));
+            w[2 * h] = ww.x; w[2 * h + 1] = ww.y;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 2 * CP; ++i) w[i] = 0.0;
+    auto step_values = [&](const Xs& xs, const Offs& o, double (&v)[4]) {
+        const uint32_t pat = (uint32_t)__builtin_amdgcn_readfirstlane((int)xs.pat);           // (a step holds ONE pattern: wave-uniform)
+        if (pat != w_pat) { w_pat = pat; load_weights(pat); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t x = xs.x[j];                                    // <= S (NA byte is S in the sorted form's state block)
+            const uint32_t xo = x * state_bytes + lane_tab;
+            double acc = x >= (uint32_t)S ? 1.0 : 0.0;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float t = *reinterpret_cast<const float*>(lds_raw + o.ro[c][j] + xo);
+                acc = fma(w[c], (double)t, acc);
+            }
+            v[j] = acc;
+        }
+    };
+    {
+        ProdAcc pa{1.0, 0, 0, 0u};
+        double sum = 0.0;
+        constexpr int D = 4;
+        // prologue: offsets of steps 0 and 1 parked, their state bytes asked for, table rows of step 0 read
+        park(0, load_ro(0));
+        park(1, load_ro(1));
+        uint32_t g0 = load_ro(2), g1 = load_ro(3), g2 = load_ro(4), g3 = load_ro(5);       // (named: no runtime indexing)
+        Xs xs_cur = load_states(0, read_state_rows(0));
+        Xs xs_nx1 = load_states(1, read_state_rows(1));
+        Offs o_cur = read_table_rows(0);
+        auto one_step = [&](int k, uint32_t& g_k2) __attribute__((always_inline)) {
+            // g_k2 holds the offsets of step k+2; it is parked now (its slot's previous tenant, step k, is in registers) and
+            // refilled with step k+2+D
+            double v[4];
+            step_values(xs_cur, o_cur, v);
+            park(k + 2, g_k2);
+            g_k2 = load_ro(k + 2 + D);
+            const u32x4_t po2 = read_state_rows(k + 2);
+            const Xs xs_nx2 = load_states(k + 2, po2);
+            const Offs o_next = read_table_rows(k + 1);
+            if (MODE == LOG_PRODUCT) prod_add4(pa, v[0], v[1], v[2], v[3]);
+            else { sum += log(v[0]); sum += log(v[1]); sum += log(v[2]); sum += log(v[3]); }
+            __builtin_amdgcn_sched_barrier(0);
+            xs_cur = xs_nx1; xs_nx1 = xs_nx2; o_cur = o_next;
+        };
+        for (int k = 0; k < n_steps; k += D) {
+            one_step(k + 0, g0);
+            if (k + 1 < n_steps) one_step(k + 1, g1);
+            if (k + 2 < n_steps) one_step(k + 2, g2);
+            if (k + 3 < n_steps) one_step(k + 3, g3);
+        }
+        if (MODE == LOG_PRODUCT) {
+            thread_ll = log(pa.mant) + (double)(pa.expo - 1023 * n_steps) * 0.693147180559945309417232;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(pa.bad != 0u) != 0ull, 0)) {      // rare: the sum per observation
+                double s2 = 0.0;
+                for (int kk = 0; kk < n_steps; ++kk) {
+                    park(kk, load_ro(kk));
+                    const Xs xs = load_states(kk, read_state_rows(kk));
+                    const Offs o = read_table_rows(kk);
+                    double v[4];
+                    step_values(xs, o, v);
+                    s2 += log(v[0]); s2 += log(v[1]); s2 += log(v[2]); s2 += log(v[3]);
+                }
+                if (pa.bad != 0u) thread_ll = s2;
+            }
+        } else thread_ll = sum;
+    }
     }
     const double wsum = wave_sum(thread_ll);
     if (lane == 0) red[wave] = wsum;

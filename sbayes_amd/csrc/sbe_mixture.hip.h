@@ -50,6 +50,10 @@ struct Mix2Params {
     int eft;                                       // tile width of probs_t (64 / 32 / 16)
     const float* wpat;     int64_t wpat_stride;    // per slot [Pmax][F][C] float32 normalised weights (a5)
     const uint32_t* rowoff; int64_t rowoff_stride; // per slot [C+1][Np]: LDS byte offsets (see k_rowoff)
+    // pattern-sorted form of the rows kernel (k_rowsort): per slot the objects in pattern order, runs padded to whole wave steps
+    const uint32_t* rowoff_s; int64_t rowoff_s_stride;   // per slot [NQs][C+1][4]: C table-row offsets, then pattern << 24 | state-row byte offset
+    const int32_t* rs_nq;                          // per slot: quads of its padded order
+    const uint8_t* state_s; int state_s_pitch;     // [N + 1][pitch] state index per observation, NA = S; row N: the null object (all NA)
 };
 
 // batched group-tuple form on the matrix pipe (sbe_mixture_mfma.hip: k_mixture_tuple_mfma)
@@ -82,7 +86,12 @@ void launch_v2(int mode, int ft, int C, const Mix2Params& p, dim3 grid, size_t l
 void launch_oh2(int mode, int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st, bool direct);
 void launch_combo(bool onehot, int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st);
 void launch_tuple64(int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st);
-void launch_rows(int mode, int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st);
+void launch_rows(int mode, int ft, int C, const Mix2Params& p, dim3 grid, size_t lds, hipStream_t st, bool sorted = false);
+// the sorted form's inputs: the slot's objects by has_components pattern (one wave per slot), the NA = S state block
+void launch_rowsort(const uint16_t* gid, const uint8_t* pid, uint32_t* out, int32_t* nq_out, int64_t gid_stride, int64_t pid_stride,
+                    int64_t out_stride, int first_slot, const int32_t* slot_list, int n_slots, int N, int Np, int C, int Gtot, int Pmax,
+                    uint32_t row_bytes, uint32_t state_pitch, int step_objects, hipStream_t st);
+void launch_state_s(const uint8_t* state, uint8_t* state_s, int N, int F, int Fp, int pitch, int S, hipStream_t st);
 // sbe_mixture_mfma.hip
 void launch_xt_frags(const uint8_t* state, uint8_t* xt, int N, int F, int S, int Fp, int NT, int KBp, hipStream_t st);
 size_t tuple_mfma_lds_bytes(int MT, int C, int KBp);

@@ -183,34 +183,35 @@ def _run_chain_processes(n, seconds=1.5):
                 p.kill()
 
 
-def test_six_chain_processes_on_one_card_with_default_spin_waits():
+def test_four_chain_processes_on_one_card_with_default_spin_waits():
     """every synchronous call spins a core for up to 300 us and the engine's pool workers poll
     after a call; several chains = several such processes on one host.  Fresh child processes (never a fork or exec of a
     process that touched the GPU), each with its own engine on device 0 and the engine's DEFAULT thread settings, run the
-    same host-synchronous loops at the same time; the per-process rates go to gpurun_out/ for the record.  Six, not eight:
-    a GPU box of this pool admits at most six processes on its card.  Asserted: identical results in every process, no
-    process starved, and the six together deliver at least what one delivers alone (the card serialises their kernels;
-    their spin-waits must not make it worse than that)."""
+    same host-synchronous loops at the same time; the per-process rates go to gpurun_out/ for the record.  Four, not eight:
+    a GPU box of this pool admits at most six processes on its card, and the test runner itself (engines of earlier tests) is
+    one of them (six children were measured in a run of their own: profiles/r5/six_processes_one_card_yielding_spins.json).
+    Asserted: identical results in every process, no process starved, and the four together deliver at least what one
+    delivers alone (the card serialises their kernels; their spin-waits must not make it worse than that)."""
     solo = _run_chain_processes(1)[0]
-    six = _run_chain_processes(6)
-    assert len({r["pid"] for r in six}) == 6
+    six = _run_chain_processes(4)
+    assert len({r["pid"] for r in six}) == 4
     assert all(r["ll"] == solo["ll"] and r["lh_sum"] == solo["lh_sum"] for r in six)
     agg_evals = sum(r["evals_per_s"] for r in six)
     agg_lh = sum(r["lh_calls_per_s"] for r in six)
-    record = dict(what="one vs six concurrent single-chain processes on ONE MI355X, headline shape, default SBE_STEP_THREADS",
-                  solo=solo, six=six, aggregate_evals_per_s=agg_evals, aggregate_lh_calls_per_s=agg_lh,
-                  evals_ratio_six_over_solo=agg_evals / solo["evals_per_s"], lh_ratio_six_over_solo=agg_lh / solo["lh_calls_per_s"])
+    record = dict(what="one vs four concurrent single-chain processes on ONE MI355X, headline shape, default SBE_STEP_THREADS",
+                  solo=solo, concurrent=six, aggregate_evals_per_s=agg_evals, aggregate_lh_calls_per_s=agg_lh,
+                  evals_ratio_concurrent_over_solo=agg_evals / solo["evals_per_s"], lh_ratio_concurrent_over_solo=agg_lh / solo["lh_calls_per_s"])
     out_dir = REPO / "gpurun_out"
     try:
         out_dir.mkdir(exist_ok=True)
-        (out_dir / "six_processes_one_card.json").write_text(json.dumps(record, indent=1))
+        (out_dir / "four_processes_one_card.json").write_text(json.dumps(record, indent=1))
     except OSError:
         pass
     print(json.dumps(record))
     slowest = min(r["evals_per_s"] for r in six)
-    assert slowest >= solo["evals_per_s"] / 24, record                    # nobody starved (a fair share would be 1/6)
+    assert slowest >= solo["evals_per_s"] / 16, record                    # nobody starved (a fair share would be 1/4)
     assert agg_evals >= 0.8 * solo["evals_per_s"], record                 # contention does not eat the card
     # the streamed [N, F, C] result (3.2 MB per call through ONE PCIe link and the host's copy threads): measured 0.50 of
-    # the solo rate for six processes, with and without yielding spin-waits (profiles/r5/six_processes_one_card*.json) --
+    # the solo rate for SIX processes, with and without yielding spin-waits (profiles/r5/six_processes_one_card*.json) --
     # recorded, and bounded here only against a collapse
     assert agg_lh >= 0.3 * solo["lh_calls_per_s"], record

@@ -309,3 +309,76 @@ def test_mfma_kernel_default_choice_and_zero_probability():
         keep = np.arange(B - 1) != 7
         np.testing.assert_allclose(got[:B - 1][keep], ref[keep], rtol=1e-12)
         assert np.all(np.isfinite(got[np.arange(B) != 7]))
+
+
+@pytest.mark.parametrize("shape", [
+    # N,   F,   S,  groups,        n_slots   (what it exercises in the pattern-sorted rows form)
+    (1203, 70,  6,  [4, 1, 5, 3],  20),      # C = 4, 16 patterns possible, ragged last tile (70 = 2 * 32 + 6), runs of every length
+    (777,  96,  4,  [3, 1, 2],     17),      # C = 3, three whole tiles
+    (640,  33,  3,  [2, 1],        32),      # C = 2, a 1-feature last tile
+    (515,  64,  5,  [6],           16),      # C = 1: a single pattern (one run)
+], ids=lambda s: f"N{s[0]}F{s[1]}S{s[2]}C{len(s[3])}B{s[4]}")
+def test_rows_kernel_pattern_sorted_objects(shape, monkeypatch):
+    """k_mixture_rows with the slot's objects sorted by has_components pattern (weights in registers, state bytes gathered
+    through the permutation; k_rowsort): every slot's value equals the oracle's and the unsorted form's to 1e-10 / 1e-12,
+    the same call returns the same bits, and a slot whose groups change is re-sorted (its value follows)."""
+    N, F, S, n_groups, B = shape
+    monkeypatch.setenv("SBE_ROWS_SORTED", "2")
+    monkeypatch.setenv("SBE_ROWS_FT", "32")
+    rng = np.random.default_rng(N + F)
+    feats, groups0, _w, _s, conc = random_case(rng, N, F, S, n_groups, 0.04)
+    na = ~feats.any(-1)
+    C = len(n_groups)
+
+    def random_state():
+        if C == 1:
+            groups = groups0
+        else:
+            a = rng.integers(0, 2 * n_groups[0], size=N)
+            groups = [np.stack([a == k for k in range(n_groups[0])])] + groups0[1:]
+        weights = rng.dirichlet(np.ones(C), size=F).astype(np.float32)
+        hc = orc.has_components(groups)
+        src_idx = np.argmax(rng.random((N, F, C)) * hc[:, None, :], axis=-1)
+        source = np.eye(C, dtype=bool)[src_idx]
+        source[na] = False
+        source[~hc.any(1)] = False
+        return groups, weights, source
+
+    def oracle_ll(groups, weights, source):
+        counts = orc.recalculate_feature_counts(feats, groups, source)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            w = orc.normalize_weights(weights, orc.has_components(groups))
+            obs = orc.mixture_observation_lh(w, orc.likelihood_per_component(feats, na, groups, counts, conc))
+            return np.log(obs)[~na & orc.has_components(groups).any(1)[:, None]].sum()
+
+    with Engine(feats, n_groups, n_slots=B) as eng:
+        for c in range(C):
+            eng.set_concentration(c, conc[c])
+        want = []
+        for b in range(B):
+            groups, weights, source = random_state()
+            if C > 1 and not orc.has_components(groups).any(1).all():
+                groups[1][:] = True                                  # (every object keeps a component: the reference asserts it)
+            eng.load_state(b, groups, weights, source=source)
+            for c in range(C):
+                eng.update_probs(b, c)
+            want.append(oracle_ll(groups, weights, source))
+        want = np.array(want)
+        eng.set_option(kernel=MIXTURE_PACKED_GENERAL)
+        got = eng.mixture_loglik_batch(0, B)
+        assert "pattern-sorted objects" in eng.last_mixture_kernel(), eng.last_mixture_kernel()
+        np.testing.assert_allclose(got, want, rtol=1e-10)
+        assert np.array_equal(eng.mixture_loglik_batch(0, B), got)
+        # a slot's groups change: its order is rebuilt, the others stay
+        groups, weights, source = random_state()
+        if C > 1:
+            groups[1][:] = True
+        eng.load_state(3, groups, weights, source=source)
+        for c in range(C):
+            eng.update_probs(3, c)
+        got2 = eng.mixture_loglik_batch(0, B)
+        assert abs(got2[3] - oracle_ll(groups, weights, source)) <= 1e-10 * abs(got2[3])
+        keep = np.arange(B) != 3
+        assert np.array_equal(got2[keep], got[keep])
+        eng.set_option(kernel=MIXTURE_PACKED_V2)                         # the older general kernel: same values to rounding
+        np.testing.assert_allclose(eng.mixture_loglik_batch(0, B), got2, rtol=1e-12)

@@ -35,6 +35,8 @@ for kern in packed packed_v2 onehot; do
   done
 done
 SB="python3 bench.py --workload stress --batch 64 --steps 30 --warmup 5 --no-cpu-baseline --no-secondary --kernel packed"
+# (control: the rows kernel with the objects in their own order -- what ran before round 5)
+SBE_ROWS_SORTED=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_stress_packed_unsorted_b64 -- $SB > $OUT/bench_stress_packed_unsorted_b64.json 2> $OUT/bench_stress_packed_unsorted_b64.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $OUT/pmc_sq1_stress_packed_b64 -- $SB > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2_stress_packed_b64 -- $SB > /dev/null 2>&1
 if [ -x tools/fetch_calib ]; then

@@ -109,6 +109,8 @@ for wl, batch, kern in CASES:
                     traffic[f"{wl}:{kern}:{batch}"].update(ident)
                 if sq:
                     summary[f"sq_counters_{wl}_{kern}_b{batch}"].update({"_kernel": ident["kernel"], "_results_sha1": ident["results_sha1"]})
+for f in newest(str(SRC / "trace_stress_packed_unsorted_b64" / "*" / "*_kernel_stats.csv")):
+    shutil.copy(f, DST / "kernel_stats_stress_packed_unsorted_b64.csv")
 summary["traffic"] = traffic
 (DST / "pmc_summary.json").write_text(json.dumps(summary, indent=1))
 (REPO / "profiles" / "traffic_latest.json").write_text(json.dumps(
