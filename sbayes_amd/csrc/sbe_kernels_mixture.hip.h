@@ -420,9 +420,6 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
     const int tile = work % p.n_ftiles, chunk = work / p.n_ftiles;       // (n_ftiles: tiles of FT features here)
     constexpr int C = CT, CP = (CT + 1) / 2;
     const int S = p.S, S1 = p.S + 1;
-#ifdef SBE_STAMPS
-    if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 48 + 0] = __builtin_amdgcn_s_memrealtime();
-#endif
     const uint32_t state_bytes = FT * 4;                                  // one state row of a group block
     const uint32_t row_bytes = (uint32_t)S1 * state_bytes;
     const uint32_t tab_bytes = (uint32_t)(p.Gtot + 1) * row_bytes;
@@ -491,9 +488,6 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
         }
     }
     __syncthreads();
-#ifdef SBE_STAMPS
-    if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 48 + 1] = __builtin_amdgcn_s_memrealtime();
-#endif
 
     constexpr int SUBS = kWave / FT;                                      // object quads per wave step
     const int lane = threadIdx.x & (kWave - 1);
@@ -613,11 +607,6 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
             if (k + 2 < n_steps) one_step(k + 2, g3, g2);
             if (k + 3 < n_steps) one_step(k + 3, g0, g3);
         }
-#ifdef SBE_STAMPS
-        if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 48 + 2] = __builtin_amdgcn_s_memrealtime();
-        if (p.stamps && lane == 0) p.stamps[(size_t)blockIdx.x * 48 + 4 + wave] = __builtin_amdgcn_s_memrealtime();       // per wave:
-        if (p.stamps && lane == 0) p.stamps[(size_t)blockIdx.x * 48 + 20 + wave] = __builtin_amdgcn_ballot_w64(pa.bad != 0u);   // loop end, bad lanes
-#endif
         if (MODE == LOG_PRODUCT) {
             thread_ll = log(pa.mant) + (double)(pa.expo - 1023 * n_steps) * 0.693147180559945309417232;
             // rare: a thread whose product left the positive normal range redoes its sum per observation.  Every lane
@@ -765,9 +754,6 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
         for (int w = 0; w < kRowsWaves; ++w) total += red[w];            // fixed order: run-to-run deterministic
         p.partials[(int64_t)slot * p.partials_stride + work] = total;
-#ifdef SBE_STAMPS
-        if (p.stamps) p.stamps[(size_t)blockIdx.x * 48 + 3] = __builtin_amdgcn_s_memrealtime();
-#endif
     }
 }
 
@@ -1049,14 +1035,6 @@ __global__ __launch_bounds__(NW * kWave, 4) void k_mixture_tuple64(Mix2Params p)
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t lane8 = (uint32_t)lane * 8u;
-#ifdef SBE_STAMPS
-    uint64_t stamp[8]; int n_stamp = 0;
-    const uint64_t rt0 = wall_clock64();
-#define SBE_STAMP() do { stamp[n_stamp++] = __builtin_readcyclecounter(); } while (0)
-#else
-#define SBE_STAMP() do {} while (0)
-#endif
-    SBE_STAMP();
     if ((uint32_t)(uintptr_t)(lds_uchar_t*)lds_raw != 0u) {       // absolute LDS addressing needs base 0
         if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + work] = __longlong_as_double(0x7FF8000000000000ll);
         return;
@@ -1170,9 +1148,7 @@ __global__ __launch_bounds__(NW * kWave, 4) void k_mixture_tuple64(Mix2Params p)
         for (int e = threadIdx.x; e < KT * FT; e += kThreads) T[((e >> 6) * S1 + S) * FT + (e & 63)] = 0.0;
         if (threadIdx.x < 2 * kLogTabEntries) reinterpret_cast<double*>(lds_raw + tab_off)[threadIdx.x] = lt_pre;
     }
-    SBE_STAMP();
     __syncthreads();
-    SBE_STAMP();
 
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (!ragged) {
@@ -1212,11 +1188,6 @@ __global__ __launch_bounds__(NW * kWave, 4) void k_mixture_tuple64(Mix2Params p)
                             }
                             vv[g] = (ok[g] && live) ? v : 1.0;                   // dead lanes of the last tile, rows not there: log 1
                         }
-#ifdef SBE_ABL_NOLOG
-                        double lg[G];
-#pragma unroll
-                        for (int g = 0; g < G; ++g) lg[g] = vv[g];
-#else
                         double lg[G];
                         bool special = false;
 #pragma unroll
@@ -1226,7 +1197,6 @@ __global__ __launch_bounds__(NW * kWave, 4) void k_mixture_tuple64(Mix2Params p)
 #pragma unroll
                             for (int g = 0; g < G; ++g) if (tab_log_special(vv[g])) lg[g] = lib_log(vv[g]);
                         }
-#endif
 #pragma unroll
                         for (int g = 0; g < G; ++g)
                             if (ok[g]) *(lds_double_t*)(uintptr_t)dd[g] = lg[g];
@@ -1234,9 +1204,7 @@ __global__ __launch_bounds__(NW * kWave, 4) void k_mixture_tuple64(Mix2Params p)
                 }
             }
         }
-        SBE_STAMP();
         __syncthreads();
-        SBE_STAMP();
 
         // ---- gather: one address add + one LDS read + one fp64 add per observation ----------------------
         // OFF16: every tuple block starts below 64 KiB, so two offsets share an SGPR (2 v_readlane per quad
@@ -1260,9 +1228,6 @@ __global__ __launch_bounds__(NW * kWave, 4) void k_mixture_tuple64(Mix2Params p)
             a0 += *(lds_cdouble_t*)(uintptr_t)ad0; a1 += *(lds_cdouble_t*)(uintptr_t)ad1;
             a2 += *(lds_cdouble_t*)(uintptr_t)ad2; a3 += *(lds_cdouble_t*)(uintptr_t)ad3;
         };
-#ifdef SBE_ABL_NOGATHER
-        if (p.N < 0)
-#endif
         for (int g0 = 0; g0 < n_my; g0 += kWave) {                          // groups of 64 quads (one offset load)
             const int ng = min(kWave, n_my - g0);
             if (g0) {
@@ -1317,9 +1282,6 @@ __global__ __launch_bounds__(NW * kWave, 4) void k_mixture_tuple64(Mix2Params p)
                 o[u] = toff4[ql];
             }
         };
-#ifdef SBE_ABL_NOGATHER
-        if (p.N < 0)
-#endif
         if (n_my > 0) load_batch(0);
         constexpr int RI = CU <= 2 ? 4 : (CU <= 4 ? 2 : 1);                 // rows per lane and pass
         for (int r0 = w * SUB; r0 < n_rows; r0 += NW * SUB * RI) {
@@ -1367,12 +1329,7 @@ __global__ __launch_bounds__(NW * kWave, 4) void k_mixture_tuple64(Mix2Params p)
             for (int i = 0; i < RI; ++i)
                 if (ok[i]) *(lds_double_t*)(uintptr_t)((t[i] * (uint32_t)S1 + st[i]) * (FT * 8u) + (uint32_t)fl * 8u) = lg[i];
         }
-        SBE_STAMP();
         __syncthreads();
-        SBE_STAMP();
-#ifdef SBE_ABL_NOGATHER
-        if (p.N < 0)
-#endif
         for (int ql0 = 0; ql0 < n_my; ql0 += 8 * SUB) {
             if (ql0) load_batch(ql0);                                        // (the first batch is already in flight)
 #pragma unroll
@@ -1386,7 +1343,6 @@ __global__ __launch_bounds__(NW * kWave, 4) void k_mixture_tuple64(Mix2Params p)
             }
         }
     }
-    SBE_STAMP();
     {   // fixed-order block reduction over NW waves
         const double wsum = wave_sum((a0 + a2) + (a1 + a3));
         if (lane == 0) red4[w] = wsum;
@@ -1401,16 +1357,7 @@ __global__ __launch_bounds__(NW * kWave, 4) void k_mixture_tuple64(Mix2Params p)
             p.partials[(int64_t)slot * p.partials_stride + work] = total;
         }
     }
-#ifdef SBE_STAMPS
-    SBE_STAMP();
-    if (p.stamps && lane == 0) {
-        uint64_t* o = p.stamps + ((int64_t)blockIdx.x * 4 + (w & 3)) * 12;
-        for (int i = 0; i < n_stamp; ++i) o[i] = stamp[i];
-        o[7] = (uint64_t)ragged; o[8] = rt0; o[9] = wall_clock64();
-    }
-#endif
 }
-#undef SBE_STAMP
 #undef SBE_SDWA_ADD
 
 }  // namespace sbe

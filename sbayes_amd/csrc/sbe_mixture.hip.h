@@ -1,8 +1,8 @@
-// sbe_mixture.hip.h -- what the engine (sbe_engine.hip) and the fused mixture kernels' translation unit
-// (sbe_mixture.hip) share: the launch parameters of the north-star kernels and their launchers.  The kernels themselves
-// (sbe_kernels_mixture.hip.h: k_mixture_v2 / _onehot_v2 / _rows / _combo / _tuple64, 1 300 lines of templates and most of the
-// library's compile time) are compiled in their own translation unit, so a change to the engine's host code or to any other
-// kernel does not rebuild them.
+// sbe_mixture.hip.h -- what the engine's host units and the units of the fused mixture kernels share: the launch parameters of
+// the north-star kernels and their launchers.  The kernels themselves (sbe_kernels_mixture.hip.h: k_mixture_v2 / _onehot_v2 /
+// _rows / _combo / _tuple64; sbe_mixture_mfma.hip: k_mixture_tuple_mfma) are templates and most of the library's compile time;
+// they are compiled in units of their own (sbe_mixture.hip, sbe_mixture_tuple.hip, sbe_mixture_rows.hip, sbe_mixture_mfma.hip),
+// so a change to the engine's host code or to any other kernel does not rebuild them.
 #pragma once
 #include "sbe_device_common.hip.h"
 
@@ -36,7 +36,6 @@ struct Mix2Params {
     int gen_slots;                                 // k_mixture_tuple64 block order: slots per XCD and generation
     int rows_cum[5];                               // k_mixture_rows: cumulative per-mille shares of a block's steps by wave age class
     int ragged_w;                                  // valid features of the last tile if it runs in sub-row mode (<= 32), else 0
-    uint64_t* stamps;                              // diagnostic builds (-DSBE_STAMPS): [blocks][4 waves][8] cycle stamps
     const uint8_t* onehot; int rs_pitch;           // [N][rs_pitch] (one-hot variant)
     const uint16_t* gid;   int64_t gid_stride;     // per slot [C][Np]
     const uint8_t* pid;    int64_t pid_stride;     // per slot [Np]

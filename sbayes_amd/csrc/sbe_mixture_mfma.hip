@@ -101,16 +101,7 @@ struct __attribute__((aligned(CT <= 1 ? 8 : (CT <= 3 ? 16 : 32)))) TupleMeta {
     uint32_t goff[CT];
 };
 
-#ifdef SBE_MFMA_DEBUG
-__device__ double g_mfma_dbg[2 * 4 * 16 * 64 * 8];     // [r][m][reg][lane]{cnt, v, woff, goff0} of block 0, wave 0, first pass
-#endif
 
-#ifdef SBE_MFMA_STAMPS
-__device__ unsigned long long g_mfma_stamps[1024 * 8 * 16];    // [block][wave][16] shader-clock stamps (diagnostic build)
-#define MFMA_STAMP(k) do { if (lane == 0 && blockIdx.x < 1024) g_mfma_stamps[((int64_t)blockIdx.x * 8 + w) * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define MFMA_STAMP(k) do {} while (0)
-#endif
 
 template <int MT, int CT, int GT = 4>
 __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixParams p) {
@@ -131,7 +122,6 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
     Meta* meta = reinterpret_cast<Meta*>(lds_raw + meta_off);
     double* red = reinterpret_cast<double*>(lds_raw + red_off);
 
-    MFMA_STAMP(0);
     auto slot_of = [&](int sl) -> int {          // absolute slot of the block's sl-th slot, or -1
         const int i = sg * kMfmaSlots + sl;
         if (i >= p.n_batch) return -1;
@@ -168,7 +158,6 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
         }
         return;
     }
-    MFMA_STAMP(8);
     // ---- phase 0: tuple metadata, log table, A fragments ------------------------------------------------------------
     // Offsets of a tuple that is not there (another slot's tuple, the padding tuple of an odd KT, a slot beyond the batch)
     // and of a component the tuple has no group in point at the rows of ONES behind the two arrays: no observation is
@@ -187,20 +176,14 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
                     const uint32_t g = p.tuple_g[(int64_t)slot * p.tuple_g_stride + t * kMaxComponents + c];
-#ifdef SBE_MFMA_ABL_ALIAS      // ablation (wrong results): every slot reads slot 0's tables -- the table operands become cache hits
-                    if ((int)g < p.Gtot) md.goff[c] = (uint32_t)(((int64_t)g * p.FS) * 4);
-#else
                     if ((int)g < p.Gtot) md.goff[c] = (uint32_t)(((int64_t)slot * p.probs_stride + (int64_t)g * p.FS) * 4);
-#endif
                 }
             }
         }
         meta[sl * 2 * MT + t] = md;
     }
-    MFMA_STAMP(9);
     if (threadIdx.x < 2 * kLogTabEntries)
         reinterpret_cast<double*>(lds_raw + tab_off)[threadIdx.x] = reinterpret_cast<const double*>(p.logtab)[threadIdx.x];
-    MFMA_STAMP(10);
     {
         // one unit = the 16 tuple ids of (slot sl, 16 objects) -> the 2 MT indicator pieces of those objects.  The ids of
         // UB units are asked for together (a unit at a time the block's start is four dependent trips to L2 / HBM)
@@ -243,9 +226,7 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
             }
         }
     }
-    MFMA_STAMP(1);
     __syncthreads();
-    MFMA_STAMP(2);
 
     // ---- phase 1: counts on the matrix pipe, table entries + log + dot product on the vector pipe ----------------------
     const int h = lane >> 5, cl = lane & 31;
@@ -304,7 +285,7 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
                 __builtin_amdgcn_sched_group_barrier(0x008, MT * kMfmaRN, 0);       // this k-block's MFMAs
             }
         }
-        if (first_pass) MFMA_STAMP(3); else MFMA_STAMP(5);
+        
         // epilogue: LL += cnt * log(sum_c w * p) over the wave's 2 * MT count tiles.  A "quad" = the four entries
         // (tuple t, slots sl0 .. sl0+3) of one register quad of one tile; software pipeline over the quads: the tuple
         // metadata (LDS) two quads ahead, the table operands (L2 / HBM) one quad ahead.  Columns beyond F*S and tiles
@@ -370,13 +351,6 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
                     const double wc = (double)wrq[q & 1][i][c], pc = (double)prq[q & 1][i][c];
                     v = c == 0 ? wc * pc : fma(wc, pc, v);
                 }
-#ifdef SBE_MFMA_DEBUG
-                if (blockIdx.x == 0 && w == 0 && nt0 == nt_lo) {
-                    double* o = g_mfma_dbg + ((((int64_t)r * 4 + m) * 16 + (4 * j + half * G + i)) * 64 + lane) * 8;
-                    o[0] = cnt[i]; o[1] = v; o[2] = wrq[q & 1][i][0]; o[3] = prq[q & 1][i][0];
-                    o[4] = wrq[q & 1][i][CT - 1]; o[5] = prq[q & 1][i][CT - 1]; o[6] = col4[r]; o[7] = fw4[r];
-                }
-#endif
                 vv[i] = v;
                 special |= __builtin_amdgcn_class(v, 0x2FF);            // anything but a positive normal double
             }
@@ -410,9 +384,8 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
             st_comp(q);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (first_pass) MFMA_STAMP(4); else MFMA_STAMP(6);
+        
     }
-    MFMA_STAMP(7);
 
     // ---- phase 2: fixed-order reduction: 32 columns of a lane half, then the 8 waves ------------------------------------
 #pragma unroll
@@ -463,24 +436,6 @@ static void allow_lds() {
 }
 
 void launch_tuple_mfma(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st) {
-#ifdef SBE_MFMA_STAMPS
-    struct DumpStamps { hipStream_t st; ~DumpStamps() {
-        const char* path = getenv("SBE_MFMA_STAMPS_FILE");
-        if (!path) return;
-        (void)hipStreamSynchronize(st);
-        static unsigned long long h[1024 * 8 * 16];
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mfma_stamps), sizeof h);
-        FILE* f = fopen(path, "wb"); if (f) { fwrite(h, 1, sizeof h, f); fclose(f); }
-    } } dump_stamps{st};
-#endif
-#ifdef SBE_MFMA_DEBUG
-    struct Dump { hipStream_t st; ~Dump() {
-        (void)hipStreamSynchronize(st);
-        static double h[2 * 4 * 16 * 64 * 8];
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mfma_dbg), sizeof h);
-        if (const char* path = getenv("SBE_MFMA_DEBUG_FILE")) { FILE* f = fopen(path, "wb"); if (f) { fwrite(h, 1, sizeof h, f); fclose(f); } }
-    } } dump{st};
-#endif
     static const bool once = [] {
         allow_lds<1, 1>(); allow_lds<1, 2>(); allow_lds<1, 3>(); allow_lds<1, 4>();
         allow_lds<2, 1>(); allow_lds<2, 2>(); allow_lds<2, 3>(); allow_lds<2, 4>();
