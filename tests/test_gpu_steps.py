@@ -205,7 +205,7 @@ def test_one_call_steps_at_baseline_workloads(name):
 
 
 # ---- batched multi-chain step (sbe_step_batch) -----------------------------------------------------------------
-def _batch_equals_single_steps(workload, B, n_sweeps, seed=8, distinct_states=None):
+def _batch_equals_single_steps(workload, B, n_sweeps, seed=8, distinct_states=None, expect_kernel=None):
     """B chains stepped by ONE sbe_step_batch call against B sbe_step calls and, at the end, the oracle."""
     wl = make_workload(workload)
     feats, na = wl.features, wl.na_values
@@ -257,6 +257,8 @@ def _batch_equals_single_steps(workload, B, n_sweeps, seed=8, distinct_states=No
                 new_states.append((new_clusters, new_weights, new_source))
             glh, mix, changed = eb.step_batch(cur, cand, cl, cm, np.array(ptr, dtype=np.int32), np.concatenate(objs_all),
                                               np.concatenate(rows_all), wts, wm)
+            if expect_kernel is not None:
+                assert expect_kernel in eb.last_mixture_kernel(), eb.last_mixture_kernel()
             for i in range(B):
                 clusters, weights, source = states[i]
                 es.load_state(0, [clusters] + wl.groups[1:], weights, source=source)
@@ -299,6 +301,14 @@ def test_step_batch_equals_single_steps(parts, monkeypatch):
     if parts is not None:
         monkeypatch.setenv("SBE_STEP_PARTS", parts)
     _batch_equals_single_steps("headline", 12, 4)
+
+
+def test_step_batch_through_the_matrix_pipe_kernel(monkeypatch):
+    """The batched step's mixture launch takes its slots from a LIST (the candidates of the chains, interleaved with their
+    current slots); with the matrix-pipe form chosen for it (SBE_MFMA_MIN_BATCH lowered: 24 chains) every chain's scalar equals
+    the single step's to rounding, accepted and rejected proposals alike."""
+    monkeypatch.setenv("SBE_MFMA_MIN_BATCH", "8")
+    _batch_equals_single_steps("headline", 24, 3, seed=21, expect_kernel="k_mixture_tuple_mfma")
 
 
 def test_step_batch_natural_two_part_pipeline_160_chains(monkeypatch):
