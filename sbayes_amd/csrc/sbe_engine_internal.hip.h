@@ -119,8 +119,11 @@ struct sbe_engine {
     std::vector<uint64_t> rowsort_epoch;
     int opt_rows_sorted = 1;              // SBE_ROWS_SORTED: 0 never, 1 launches of >= 16 slots at 32-feature tiles (default), 2 whenever it applies (tests)
     std::atomic<uint64_t> epoch_counter{0};
+    unsigned* d_mfma_arrive = nullptr;   // tickets of the matrix-pipe kernel's in-kernel final reduction, one per group of 16 slots (left at 0)
     uint8_t* d_xt = nullptr;       // one-hot block in MFMA fragment order (k_mixture_tuple_mfma), built at the first batched launch
     int xt_NT = 0, xt_KBp = 0;  size_t xt_bytes = 0;
+    int mfma_fused = 0;            // the fused form of the matrix-pipe kernel (SBE_MFMA_FUSED)
+    int mfma_waves = 8;            // block shape of the matrix-pipe form: 8 waves x 2 column tiles or 16 x 1 (SBE_MFMA_WAVES)
     int mfma_min_batch = 512;      // smallest launch the matrix-pipe form is chosen for under SBE_MIXTURE_PACKED (SBE_MFMA_MIN_BATCH)
     uint8_t* d_tid = nullptr;      // [slots][Np] group-tuple index per object (k_mixture_combo)
     uint16_t* d_tuple_g = nullptr; // [slots][kMaxTuples][kMaxComponents]
@@ -901,6 +904,9 @@ int ensure_xt(sbe_engine* e) {
     HIPCHK(e, hipMalloc((void**)&e->d_xt, bytes));
     e->hbm_bytes += (int64_t)bytes;
     HIPCHK(e, hipMemsetAsync(e->d_xt, 0, bytes, e->stream));
+    const size_t arrive_bytes = (size_t)(div_up(e->n_slots, 16) + 1) * sizeof(unsigned);
+    HIPCHK(e, hipMalloc((void**)&e->d_mfma_arrive, arrive_bytes));
+    HIPCHK(e, hipMemsetAsync(e->d_mfma_arrive, 0, arrive_bytes, e->stream));
     launch_xt_frags(e->d_state, e->d_xt, e->N, e->F, e->S, e->Fp, NT, KBp, e->stream);
     HIPCHK(e, hipGetLastError());
     e->xt_NT = NT; e->xt_KBp = KBp; e->xt_bytes = bytes;
@@ -930,7 +936,8 @@ MfmaGeom mfma_geometry(const sbe_engine* e, int n, int KT) {
     return g;
 }
 
-int launch_mfma_form(sbe_engine* e, int first_slot, int n, int KT, const MfmaGeom& mg, const int32_t* d_slots) {
+int launch_mfma_form(sbe_engine* e, int first_slot, int n, int KT, const MfmaGeom& mg, const int32_t* d_slots,
+                     bool reduce_in_kernel = false, const DoneSig& done = DoneSig{}) {
     int rc = ensure_xt(e);
     if (rc) return rc;
     MfmaMixParams p{};
@@ -938,6 +945,7 @@ int launch_mfma_form(sbe_engine* e, int first_slot, int n, int KT, const MfmaGeo
     p.NT = e->xt_NT; p.KBp = e->xt_KBp; p.KT = KT;
     p.n_batch = n; p.n_split = mg.n_split; p.nt_per_split = mg.nt_per_split;
     p.first_slot = first_slot; p.slot_list = d_slots;
+    p.waves = e->mfma_waves; p.fused = e->mfma_fused;
     p.xt = e->d_xt; p.xt_bytes = (uint32_t)e->xt_bytes;
     p.tid = e->d_tid; p.tid_stride = e->Np;
     p.tuple_g = e->d_tuple_g; p.tuple_g_stride = (int64_t)kMaxTuples * kMaxComponents;
@@ -950,6 +958,7 @@ int launch_mfma_form(sbe_engine* e, int first_slot, int n, int KT, const MfmaGeo
     p.wpat_bytes = p.wpat_ones_off + (uint32_t)(e->F * e->C * 4);
     p.logtab = e->d_logtab;
     p.partials = e->d_partials; p.partials_stride = e->partials_stride;
+    if (reduce_in_kernel) { p.results = e->d_results; p.arrive = e->d_mfma_arrive; p.done = done; }
     launch_tuple_mfma(e->C, p, dim3((unsigned)(div_up(n, 16) * mg.n_split)), mg.lds, e->stream);
     return SBE_OK;
 }
@@ -1099,9 +1108,18 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     dim3 grid(g.n_blocks, n);
     if (mfma) { int rc = ensure_xt(e); if (rc) return rc; }      // (one-time build: outside the event pair)
     if (ev_a) HIPCHK(e, hipEventRecord(ev_a, e->stream));
+    // matrix-pipe form without a step epilogue: the kernel's last block per slot group does the final reduction itself
+    // (one launch per eval batch instead of two; SBE_MFMA_REDUCE=0 keeps k_reduce_partials: A/B runs)
+    static const bool mfma_reduce_opt = !(getenv("SBE_MFMA_REDUCE") && atoi(getenv("SBE_MFMA_REDUCE")) == 0);
+    const bool mfma_reduce = mfma && !fin && !d_fins && mfma_reduce_opt;
     if (mfma) {
         snprintf(e->last_kernel, sizeof e->last_kernel, "k_mixture_tuple_mfma<packed stream, group-tuple form, matrix pipe, M tiles %d, C=%d>", mg.MT, e->C);
-        int rc = launch_mfma_form(e, first_slot, n, KT, mg, d_slots);
+        DoneSig done{};
+        if (mfma_reduce) {
+            done = done_out ? next_done(e, (unsigned)div_up(n, 16)) : DoneSig{};
+            if (done_out) *done_out = done;
+        }
+        int rc = launch_mfma_form(e, first_slot, n, KT, mg, d_slots, mfma_reduce, done);
         if (rc) return rc;
     } else {
         // XCD-aware 1-D grid (see k_mixture_v2): units = work items x slot groups, unit u on XCD u % 8
@@ -1171,6 +1189,7 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     }
     if (ev_b) HIPCHK(e, hipEventRecord(ev_b, e->stream));
     HIPCHK(e, hipGetLastError());
+    if (mfma_reduce) return SBE_OK;
     const unsigned n_red = (unsigned)(n + (d_fins ? n : (fin ? 1 : 0)));
     const DoneSig done = done_out ? next_done(e, n_red) : DoneSig{};      // (the caller waits with wait_done)
     if (done_out) *done_out = done;

@@ -62,6 +62,8 @@ struct MfmaMixParams {
     int KT;                                        // tuples used by the slots of this launch (max; <= 8)
     int n_batch, n_split, nt_per_split;            // slots of the launch; column splits (blocks per group of 16 slots); column tiles per split
     int first_slot;
+    int waves;                                     // block shape: 8 (x 2 column tiles per pass) or 16 (x 1)
+    int fused;                                     // 8 waves x 1 column tile, the next tile's counts in the shadow of the epilogue
     const int32_t* slot_list;                      // slots of this launch (n_batch entries), or null: first_slot + i
     const uint8_t* xt;  uint32_t xt_bytes;         // [NT + 1][KBp][64][16] (+ PF fragments) one-hot block in fragment order (k_xt_frags); tile NT is zero
     const uint8_t* tid;      int64_t tid_stride;       // per slot [Np] tuple index per object
@@ -72,6 +74,12 @@ struct MfmaMixParams {
     uint32_t probs_ones_off, wpat_ones_off;        // byte offsets of the rows of ones behind the two arrays (F*S / F*C floats)
     const double2* logtab;                         // [128] {1/c, log c}
     double* partials;        int64_t partials_stride;
+    // final reduction inside the kernel (results != nullptr): the LAST of a slot group's n_split blocks to finish -- tickets in
+    // arrive[group], which it leaves at 0 -- adds the group's partial sums in split order and writes the 16 results; `done`
+    // (optional) is signalled by those blocks, one per slot group
+    double* results;
+    unsigned* arrive;
+    DoneSig done;
 };
 
 // waves per block of k_mixture_tuple64.  (8-wave blocks -- twice the waves per SIMD at the same LDS footprint -- were

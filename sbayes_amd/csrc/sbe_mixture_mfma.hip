@@ -21,6 +21,7 @@
 // column tiles: 2 x MT accumulator tiles, A fragments from LDS (shared by all waves), X fragments straight from L2 in
 // 1 KB fully coalesced pieces (fragment order in memory), four k-blocks ahead.  Both operands take their k index from the
 // same (lane half, byte) position, so the product does not depend on the instruction's internal k order.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -32,10 +33,12 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) const v4i_t lds_cv4i_t;
 
-constexpr int kMfmaWaves = 8;
-constexpr int kMfmaThreads = kMfmaWaves * kWave;
 constexpr int kMfmaSlots = 16;          // slots per block
-constexpr int kMfmaRN = 2;              // column tiles per wave pass
+// Two block shapes, both 16 column tiles per pass (template NW x RN):
+//   8 waves x 2 column tiles   96 accumulator registers at MT = 3: two waves per SIMD
+//   16 waves x 1 column tile   48 accumulator registers: four waves per SIMD (<= 128 registers each) -- the epilogue is
+//                              vector-issue bound and a SIMD issues fp64 work at 4.3 cycles per instruction from four waves
+//                              against 4.9-5.9 from two; the price is one A-fragment LDS read per MFMA instead of one per two
 
 // One-hot block -> fragment order.  Fragment (nt, kb): lane l holds bytes j = 0..15 = X[n = 32 kb + 16 (l >> 5) + j][col = 32 nt + (l & 31)]
 // with col = f * S + s; zero for n >= N, col >= F * S and NA observations.
@@ -103,8 +106,10 @@ struct __attribute__((aligned(CT <= 1 ? 8 : (CT <= 3 ? 16 : 32)))) TupleMeta {
 
 
 
-template <int MT, int CT, int GT = 4>
-__global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixParams p) {
+template <int MT, int CT, int GT = 4, int NW = 8, int RN = 2, int KB = 0>
+__global__ __launch_bounds__(NW * kWave, 1) void k_mixture_tuple_mfma(MfmaMixParams p) {
+    constexpr int kMfmaWaves = NW, kMfmaThreads = NW * kWave, kMfmaRN = RN;
+    static_assert(KB == 0 || RN == 1, "the fused form takes one column tile per wave and pass");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -154,7 +159,10 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
     if (lds_base != 0u) {                                    // (block-uniform; before any barrier)
         if ((int)threadIdx.x < kMfmaSlots) {
             const int slot = slot_of((int)threadIdx.x);
-            if (slot >= 0) p.partials[(int64_t)slot * p.partials_stride + split] = __longlong_as_double(0x7FF8000000000000ll);
+            if (slot >= 0) {
+                p.partials[(int64_t)slot * p.partials_stride + split] = __longlong_as_double(0x7FF8000000000000ll);
+                if (p.results) p.results[slot] = __longlong_as_double(0x7FF8000000000000ll);
+            }
         }
         return;
     }
@@ -237,18 +245,9 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpat), 0, (int)p.wpat_bytes, 0x00020000);
     const uint32_t a_lane = a_off + (uint32_t)lane * 16u;
 
-    for (int nt0 = nt_lo + w * kMfmaRN; nt0 < nt_hi; nt0 += kMfmaWaves * kMfmaRN) {
-        int toff[kMfmaRN];
-#pragma unroll
-        for (int r = 0; r < kMfmaRN; ++r) toff[r] = tile_off(nt0 + r);
-        const bool first_pass = nt0 == nt_lo + w * kMfmaRN;
-        if (!first_pass) {
-#pragma unroll
-            for (int i = 0; i < PF; ++i)
-#pragma unroll
-                for (int r = 0; r < kMfmaRN; ++r) bq[i][r] = load_b(toff[r], i);
-        }
-        v16i_t acc[MT][kMfmaRN];
+    // counts of one pass (RN column tiles from the scalar fragment offsets toff[]) into acc; the first PF X fragments of the
+    // pass are in bq already
+    auto counts_pass = [&](v16i_t (&acc)[MT][kMfmaRN], const int (&toff)[kMfmaRN]) __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -285,106 +284,192 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
                 __builtin_amdgcn_sched_group_barrier(0x008, MT * kMfmaRN, 0);       // this k-block's MFMAs
             }
         }
-        
-        // epilogue: LL += cnt * log(sum_c w * p) over the wave's 2 * MT count tiles.  A "quad" = the four entries
-        // (tuple t, slots sl0 .. sl0+3) of one register quad of one tile; software pipeline over the quads: the tuple
-        // metadata (LDS) two quads ahead, the table operands (L2 / HBM) one quad ahead.  Columns beyond F*S and tiles
-        // beyond the split have no counts (their X fragments are zero), so nothing needs a bounds condition here.
-        uint32_t col4[kMfmaRN], fw4[kMfmaRN];
+    };
+
+    // epilogue: LL += cnt * log(sum_c w * p) over the wave's RN * MT count tiles.  A "quad" = the four entries
+    // (tuple t, slots sl0 .. sl0+3) of one register quad of one tile; software pipeline over the quads: the tuple
+    // metadata (LDS) two quads ahead, the table operands (L2 / HBM) one quad ahead.  Columns beyond F*S and tiles
+    // beyond the split have no counts (their X fragments are zero), so nothing needs a bounds condition here.
+    // A step = G entries of one register quad (G = 4: the whole quad; G = 2: half of it); steps run r-minor.
+    constexpr int G = GT;
+    constexpr int HQ = 4 / G;                                    // steps per quad
+    constexpr int NST = MT * 4 * HQ * kMfmaRN;                   // steps: (m, j, half) major, r minor
+    uint32_t col4[kMfmaRN], fw4[kMfmaRN];
+    Meta mdq[G];
+    float prq[2][G][CT], wrq[2][G][CT];
+    auto st_cols = [&](int nt0) {
 #pragma unroll
         for (int r = 0; r < kMfmaRN; ++r) {
             const uint32_t colc = (uint32_t)min((nt0 + r) * 32 + cl, p.FS - 1);
             const uint32_t f = colc / (uint32_t)p.S;
             col4[r] = colc * 4u; fw4[r] = f * (uint32_t)(CT * 4);
         }
-        // A step = G entries of one register quad (G = 4: the whole quad; G = 2: half of it); steps run r-minor.
-        constexpr int G = GT;
-        constexpr int HQ = 4 / G;                                    // steps per quad
-        constexpr int NST = MT * 4 * HQ * kMfmaRN;                   // steps: (m, j, half) major, r minor
-        Meta mdq[G];
-        float prq[2][G][CT], wrq[2][G][CT];
-        auto st_meta = [&](int u) {                                 // u = (m * 4 + j) * HQ + half
-            const int mj = u / HQ, half = u % HQ, m = mj >> 2, j = mj & 3;
-            const int t = 2 * m + (j >> 1), sl0 = 8 * (j & 1) + 4 * h + half * G;
+    };
+    auto st_meta = [&](int u) {                                 // u = (m * 4 + j) * HQ + half
+        const int mj = u / HQ, half = u % HQ, m = mj >> 2, j = mj & 3;
+        const int t = 2 * m + (j >> 1), sl0 = 8 * (j & 1) + 4 * h + half * G;
 #pragma unroll
-            for (int i = 0; i < G; ++i) mdq[i] = meta[(sl0 + i) * 2 * MT + t];
-        };
-        auto st_load = [&](int q) {
-            const int r = q % kMfmaRN;
+        for (int i = 0; i < G; ++i) mdq[i] = meta[(sl0 + i) * 2 * MT + t];
+    };
+    auto st_load = [&](int q) {
+        const int r = q % kMfmaRN;
 #pragma unroll
-            for (int i = 0; i < G; ++i) {
-                const uint32_t wo = mdq[i].woff + fw4[r];
-                if constexpr (CT == 2) {
-                    const u32x2_t v2 = __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, (int)wo, 0, 0);
-                    // (__uint_as_float of a copy: __builtin_bit_cast on a vector ELEMENT lvalue reads element 0 whatever the
-                    //  element -- clang 22 / ROCm 7.2; found with the debug dump of this kernel)
-                    const uint32_t e0 = v2.x, e1 = v2.y;
-                    wrq[q & 1][i][0] = __uint_as_float(e0); wrq[q & 1][i][1] = __uint_as_float(e1);
-                } else if constexpr (CT == 4) {
-                    const u32x4_t v4 = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)wo, 0, 0);
-                    const uint32_t e0 = v4.x, e1 = v4.y, e2 = v4.z, e3 = v4.w;
-                    wrq[q & 1][i][0] = __uint_as_float(e0); wrq[q & 1][i][1] = __uint_as_float(e1);
-                    wrq[q & 1][i][2] = __uint_as_float(e2); wrq[q & 1][i][3] = __uint_as_float(e3);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < CT; ++c)
-                        wrq[q & 1][i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w_rsrc, (int)(wo + 4u * c), 0, 0));
-                }
+        for (int i = 0; i < G; ++i) {
+            const uint32_t wo = mdq[i].woff + fw4[r];
+            if constexpr (CT == 2) {
+                const u32x2_t v2 = __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, (int)wo, 0, 0);
+                // (__uint_as_float of a copy: __builtin_bit_cast on a vector ELEMENT lvalue reads element 0 whatever the
+                //  element -- clang 22 / ROCm 7.2; found with the debug dump of this kernel)
+                const uint32_t e0 = v2.x, e1 = v2.y;
+                wrq[q & 1][i][0] = __uint_as_float(e0); wrq[q & 1][i][1] = __uint_as_float(e1);
+            } else if constexpr (CT == 4) {
+                const u32x4_t v4 = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)wo, 0, 0);
+                const uint32_t e0 = v4.x, e1 = v4.y, e2 = v4.z, e3 = v4.w;
+                wrq[q & 1][i][0] = __uint_as_float(e0); wrq[q & 1][i][1] = __uint_as_float(e1);
+                wrq[q & 1][i][2] = __uint_as_float(e2); wrq[q & 1][i][3] = __uint_as_float(e3);
+            } else {
 #pragma unroll
                 for (int c = 0; c < CT; ++c)
-                    prq[q & 1][i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr_rsrc, (int)(mdq[i].goff[c] + col4[r]), 0, 0));
-            }
-        };
-        auto st_comp = [&](int q) {
-            const int r = q % kMfmaRN, u = q / kMfmaRN, mj = u / HQ, half = u % HQ, m = mj >> 2, j = mj & 3;
-            double vv[G], lg[G];
-            int cnt[G];
-            bool special = false;
-#pragma unroll
-            for (int i = 0; i < G; ++i) {
-                cnt[i] = acc[m][r][4 * j + half * G + i];
-                // sum_c w_c * p_c in NumPy's order.  The product of two float32 values is exact in fp64, so fma(w, p, v)
-                // rounds exactly like the reference's multiply-then-add: the same bits as the other kernel forms
-                double v = 0.0;
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    const double wc = (double)wrq[q & 1][i][c], pc = (double)prq[q & 1][i][c];
-                    v = c == 0 ? wc * pc : fma(wc, pc, v);
-                }
-                vv[i] = v;
-                special |= __builtin_amdgcn_class(v, 0x2FF);            // anything but a positive normal double
-            }
-            tab_log5_n<G>(vv, lg, tab_off);
-            // Rare: a table entry that is not a positive normal number -- the zero probability of an inapplicable state,
-            // which no observation falls on (contributes nothing, whatever it is), or of an observed one (log 0 = -inf,
-            // like the reference), or corrupt input (library log).
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0ull, 0)) {
-#pragma unroll
-                for (int i = 0; i < G; ++i)
-                    if (__builtin_amdgcn_class(vv[i], 0x2FF)) lg[i] = cnt[i] != 0 ? lib_log(vv[i]) : 0.0;
+                    wrq[q & 1][i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w_rsrc, (int)(wo + 4u * c), 0, 0));
             }
 #pragma unroll
-            for (int i = 0; i < G; ++i) {
-                const int k = (j & 1) * 4 + half * G + i;
-                lsum[k] = fma((double)cnt[i], lg[i], lsum[k]);
-                // (pins the sum in this step's block: the rare-path branch above splits the epilogue into basic blocks and
-                //  the compiler otherwise sinks the whole chain of sums to the last one, keeping every log alive: 150 spills)
-                asm volatile("" : "+v"(lsum[k]));
+            for (int c = 0; c < CT; ++c)
+                prq[q & 1][i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr_rsrc, (int)(mdq[i].goff[c] + col4[r]), 0, 0));
+        }
+    };
+    auto st_comp = [&](int q, const v16i_t (&acc)[MT][kMfmaRN]) __attribute__((always_inline)) {
+        const int r = q % kMfmaRN, u = q / kMfmaRN, mj = u / HQ, half = u % HQ, m = mj >> 2, j = mj & 3;
+        double vv[G], lg[G];
+        int cnt[G];
+        bool special = false;
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            cnt[i] = acc[m][r][4 * j + half * G + i];
+            // sum_c w_c * p_c in NumPy's order.  The product of two float32 values is exact in fp64, so fma(w, p, v)
+            // rounds exactly like the reference's multiply-then-add: the same bits as the other kernel forms
+            double v = 0.0;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const double wc = (double)wrq[q & 1][i][c], pc = (double)prq[q & 1][i][c];
+                v = c == 0 ? wc * pc : fma(wc, pc, v);
             }
-        };
+            vv[i] = v;
+            special |= __builtin_amdgcn_class(v, 0x2FF);            // anything but a positive normal double
+        }
+        tab_log5_n<G>(vv, lg, tab_off);
+        // Rare: a table entry that is not a positive normal number -- the zero probability of an inapplicable state,
+        // which no observation falls on (contributes nothing, whatever it is), or of an observed one (log 0 = -inf,
+        // like the reference), or corrupt input (library log).
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0ull, 0)) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+                if (__builtin_amdgcn_class(vv[i], 0x2FF)) lg[i] = cnt[i] != 0 ? lib_log(vv[i]) : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int k = (j & 1) * 4 + half * G + i;
+            lsum[k] = fma((double)cnt[i], lg[i], lsum[k]);
+            // (pins the sum in this step's block: the rare-path branch above splits the epilogue into basic blocks and
+            //  the compiler otherwise sinks the whole chain of sums to the last one, keeping every log alive: 150 spills)
+            asm volatile("" : "+v"(lsum[k]));
+        }
+    };
+
+    if constexpr (KB == 0) {
+    for (int nt0 = nt_lo + w * kMfmaRN; nt0 < nt_hi; nt0 += kMfmaWaves * kMfmaRN) {
+        int toff[kMfmaRN];
+#pragma unroll
+        for (int r = 0; r < kMfmaRN; ++r) toff[r] = tile_off(nt0 + r);
+        const bool first_pass = nt0 == nt_lo + w * kMfmaRN;
+        if (!first_pass) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+#pragma unroll
+                for (int r = 0; r < kMfmaRN; ++r) bq[i][r] = load_b(toff[r], i);
+        }
+        v16i_t acc[MT][kMfmaRN];
+        counts_pass(acc, toff);
+        st_cols(nt0);
         // the single metadata buffer is refilled as soon as the loads of its last step (r = RN - 1) are out
         st_meta(0);
         st_load(0);
+        if (kMfmaRN == 1 && NST > 1) st_meta(1);
 #pragma unroll
         for (int q = 0; q < NST; ++q) {
             if (q + 1 < NST) {
                 st_load(q + 1);
                 if ((q + 2) % kMfmaRN == 0 && q + 2 < NST) st_meta((q + 2) / kMfmaRN);
             }
-            st_comp(q);
+            st_comp(q, acc);
             __builtin_amdgcn_sched_barrier(0);
         }
-        
+    }
+    } else {
+    // ---- fused form: the counts of the wave's NEXT column tile run on the matrix pipe in the shadow of the epilogue of the
+    // current one.  A wave issues in order, but an MFMA only occupies the matrix pipe (32 cycles) once issued: the ~14 fp64
+    // vector instructions of the epilogue that stand between two MFMAs issue meanwhile (tools/probe/mfma_valu_overlap.hip:
+    // 42 FMAs + 3 MFMAs per iteration cost 184 ns against 169 ns for the FMAs alone and 255 ns for one after the other, at two
+    // waves per SIMD).  The KB k-block slots of a tile are dealt to the NST epilogue steps at compile time; slots beyond the
+    // launch's KBp multiply the zero tile.
+    int nt = nt_lo + w;
+    v16i_t acc_cur[MT][1];
+    {
+        int toff[1] = {tile_off(nt)};
+        counts_pass(acc_cur, toff);
+    }
+    uint32_t a_lane_m[MT];                                       // (k-block offsets ride in the LDS instruction's immediate)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a_lane_m[m] = a_lane + ((uint32_t)m * (uint32_t)KBp) * 1024u;
+    for (; nt < nt_hi; nt += kMfmaWaves) {
+        // the next tile through its own descriptor: KBp fragments long, so the k-block slots beyond KBp read zeros (a tile
+        // beyond the split is the zero tile); the A fragments of those slots are whatever follows in LDS -- times zero
+        const __amdgpu_buffer_rsrc_t xn_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(p.xt) + tile_off(nt + kMfmaWaves), 0, KBp * 1024, 0x00020000);
+        auto load_bn = [&](int kb) -> v4i_t {
+            const u32x4_t d = __builtin_amdgcn_raw_buffer_load_b128(xn_rsrc, lane16 + kb * 1024, 0, 0);
+            v4i_t r; r.x = (int)d.x; r.y = (int)d.y; r.z = (int)d.z; r.w = (int)d.w;
+            return r;
+        };
+#pragma unroll
+        for (int i = 0; i < PF; ++i) bq[i][0] = load_bn(i);
+        v16i_t acc_nxt[MT][1];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc_nxt[m][0][i] = 0;
+        v4i_t a_cur[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a_cur[m] = *(lds_cv4i_t*)(uintptr_t)(a_lane_m[m]);
+        st_cols(nt);
+        st_meta(0);
+        st_load(0);
+        if (NST > 1) st_meta(1);
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            if (q + 1 < NST) {
+                st_load(q + 1);
+                if (q + 2 < NST) st_meta(q + 2);
+            }
+            const int kb_lo = q * KB / NST, kb_hi = (q + 1) * KB / NST;
+#pragma unroll
+            for (int kb = kb_lo; kb < kb_hi; ++kb) {
+                v4i_t a_nxt[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a_nxt[m] = *(lds_cv4i_t*)(uintptr_t)(a_lane_m[m] + (uint32_t)(kb + 1) * 1024u);
+                const v4i_t b = bq[kb % PF][0];
+                bq[kb % PF][0] = load_bn(kb + PF);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc_nxt[m][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_cur[m], b, acc_nxt[m][0], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
+            }
+            st_comp(q, acc_cur);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc_cur[m][0] = acc_nxt[m][0];
+    }
     }
 
     // ---- phase 2: fixed-order reduction: 32 columns of a lane half, then the 8 waves ------------------------------------
@@ -400,32 +485,89 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
         for (int i = 0; i < 8; ++i) red[w * kMfmaSlots + 8 * (i >> 2) + 4 * h + (i & 3)] = lsum[i];
     }
     __syncthreads();
-    if ((int)threadIdx.x < kMfmaSlots) {
-        const int slot = slot_of((int)threadIdx.x);
-        if (slot >= 0) {
-            double total = 0.0;
+    if (w != 0) return;                                                    // the rest is wave 0's (no block barrier below)
+    const int my_slot = lane < kMfmaSlots ? slot_of(lane) : -1;
+    double total = 0.0;
+    if (my_slot >= 0) {
 #pragma unroll
-            for (int ww = 0; ww < kMfmaWaves; ++ww) total += red[ww * kMfmaSlots + threadIdx.x];
-            p.partials[(int64_t)slot * p.partials_stride + split] = total;
+        for (int ww = 0; ww < kMfmaWaves; ++ww) total += red[ww * kMfmaSlots + lane];
+    }
+    double* const my_partials = p.partials + (int64_t)max(my_slot, 0) * p.partials_stride;
+    if (!p.results) {
+        if (my_slot >= 0) my_partials[split] = total;
+        return;
+    }
+    // The group's last block adds the partial sums (fixed order: run-to-run deterministic whichever block that is).  The
+    // partial sums travel as agent-scope atomic stores / loads (write-through, coherent across the XCDs' L2s) ordered by
+    // s_waitcnt around the ticket: a release FENCE at agent scope writes the whole L2 back -- every wave doing that cost 26 us
+    // per launch, one wave per block still as much as the reduction kernel it replaces (measured)
+    if (p.n_split > 1) {
+        if (my_slot >= 0) __hip_atomic_store(my_partials + split, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned t = 0;
+        if (lane == 0) {
+            t = __hip_atomic_fetch_add(p.arrive + sg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == (unsigned)p.n_split - 1u) __hip_atomic_store(p.arrive + sg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        if (t != (unsigned)p.n_split - 1u) return;                         // (wave-uniform)
+        asm volatile("" ::: "memory");
+        if (my_slot >= 0) {
+            total = 0.0;
+            for (int k = 0; k < p.n_split; ++k) total += __hip_atomic_load(my_partials + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (my_slot >= 0) p.results[my_slot] = total;
+    signal_done(p.done);
 }
 
 size_t tuple_mfma_lds_bytes(int MT, int C, int KBp) {     // log table | A fragments | meta | reduction
     const size_t meta = (size_t)kMfmaSlots * 2 * MT * (C <= 1 ? 8 : (C <= 3 ? 16 : 32));
-    return (size_t)MT * KBp * 1024 + kLogTabEntries * 16 + meta + (size_t)kMfmaWaves * kMfmaSlots * sizeof(double);
+    return (size_t)MT * KBp * 1024 + kLogTabEntries * 16 + meta + (size_t)16 * kMfmaSlots * sizeof(double);      // (16 waves' worth: either block shape)
 }
 
 // entries per epilogue step: a whole register quad where the registers allow it, half a quad for the widest instances
 template <int MT, int CT> constexpr int mfma_gt() { return (MT >= 4 || (MT == 3 && CT >= 3)) ? 2 : 4; }
+// ... of the 16-wave shape (128 registers per wave)
+template <int MT, int CT> constexpr int mfma_gt16() { return 2; }
+
+template <int MT, int CT>
+static void launch_mfma_one(const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st) {
+    if constexpr (MT == 3 && CT == 2) {                       // EXPERIMENT variants
+        static const int variant = getenv("SBE_MFMA_VARIANT") ? atoi(getenv("SBE_MFMA_VARIANT")) : 0;
+        if (variant == 3) { k_mixture_tuple_mfma<3, 2, 2, 8, 2, 0><<<grid, 8 * kWave, lds, st>>>(p); return; }
+        if (variant == 4) { k_mixture_tuple_mfma<3, 2, 4, 8, 1, 0><<<grid, 8 * kWave, lds, st>>>(p); return; }
+        if (variant == 5) { k_mixture_tuple_mfma<3, 2, 2, 8, 1, 0><<<grid, 8 * kWave, lds, st>>>(p); return; }
+    }
+    if constexpr (MT >= 2 && MT <= 3 && CT >= 2) {
+        if (p.fused && p.KBp <= 48) {
+            // (the A-fragment reads of the k-block slots beyond KBp must stay inside the block's LDS allocation)
+            const int KB = p.KBp <= 16 ? 16 : p.KBp <= 32 ? 32 : 48;
+            const size_t lds_f = std::max(lds, (size_t)kLogTabEntries * 16 + ((size_t)(MT - 1) * p.KBp + KB + 1) * 1024);
+            if (lds_f <= 160 * 1024) {
+                if (KB == 16) k_mixture_tuple_mfma<MT, CT, 2, 8, 1, 16><<<grid, 8 * kWave, lds_f, st>>>(p);
+                else if (KB == 32) k_mixture_tuple_mfma<MT, CT, 2, 8, 1, 32><<<grid, 8 * kWave, lds_f, st>>>(p);
+                else k_mixture_tuple_mfma<MT, CT, 2, 8, 1, 48><<<grid, 8 * kWave, lds_f, st>>>(p);
+                return;
+            }
+        }
+    }
+    if constexpr (MT <= 3) {
+        if (p.waves == 16) {
+            k_mixture_tuple_mfma<MT, CT, mfma_gt16<MT, CT>(), 16, 1><<<grid, 16 * kWave, lds, st>>>(p);
+            return;
+        }
+    }
+    k_mixture_tuple_mfma<MT, CT, mfma_gt<MT, CT>()><<<grid, 8 * kWave, lds, st>>>(p);
+}
 
 template <int MT>
 static void launch_mfma_mt(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st) {
     switch (C) {
-        case 1: k_mixture_tuple_mfma<MT, 1, mfma_gt<MT, 1>()><<<grid, kMfmaThreads, lds, st>>>(p); break;
-        case 2: k_mixture_tuple_mfma<MT, 2, mfma_gt<MT, 2>()><<<grid, kMfmaThreads, lds, st>>>(p); break;
-        case 3: k_mixture_tuple_mfma<MT, 3, mfma_gt<MT, 3>()><<<grid, kMfmaThreads, lds, st>>>(p); break;
-        default: k_mixture_tuple_mfma<MT, 4, mfma_gt<MT, 4>()><<<grid, kMfmaThreads, lds, st>>>(p); break;
+        case 1: launch_mfma_one<MT, 1>(p, grid, lds, st); break;
+        case 2: launch_mfma_one<MT, 2>(p, grid, lds, st); break;
+        case 3: launch_mfma_one<MT, 3>(p, grid, lds, st); break;
+        default: launch_mfma_one<MT, 4>(p, grid, lds, st); break;
     }
 }
 
@@ -433,6 +575,18 @@ static void launch_mfma_mt(int C, const MfmaMixParams& p, dim3 grid, size_t lds,
 template <int MT, int CT>
 static void allow_lds() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<MT, CT, mfma_gt<MT, CT>()>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (MT <= 3)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<MT, CT, mfma_gt16<MT, CT>(), 16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (MT == 3 && CT == 2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<3, 2, 2, 8, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<3, 2, 4, 8, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<3, 2, 2, 8, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if constexpr (MT >= 2 && MT <= 3 && CT >= 2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<MT, CT, 2, 8, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<MT, CT, 2, 8, 1, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<MT, CT, 2, 8, 1, 48>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
 }
 
 void launch_tuple_mfma(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st) {
