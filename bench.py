@@ -737,7 +737,10 @@ def main():
     roofline = roofline_block(b_eval, unique, B, kern_ms, traffic, valu, eng.last_mixture_kernel(), packed,
                               (f"HIP event pairs on the engine's stream around every {stride}-th launch of the timed loops "
                                f"({n_timed} of {args.steps * n_reps} launches in {n_reps} repetitions)" if stride > 0 else
-                               f"HIP event pairs around {n_timed} identical launches issued right after the timed loop"),
+                               f"HIP event pairs around {n_timed} identical launches issued right after the timed loop")
+                              + "; an event pair also holds the dispatch gap behind the previous kernel (2-5 us: rocprofv3's kernel trace of "
+                                "the same command reads that much less, profiles/), so with ONE kernel per step -- the matrix-pipe form "
+                                "reduces inside the kernel -- kernel_avg_us can exceed ms_per_step",
                               shape=(n_obj, n_feat, n_states))
 
     # ---- what every rank (= every GPU's chains) saw by itself: north_star asks for PER-CHAIN throughput at each N ------

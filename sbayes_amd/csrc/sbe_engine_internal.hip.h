@@ -119,11 +119,10 @@ struct sbe_engine {
     std::vector<uint64_t> rowsort_epoch;
     int opt_rows_sorted = 1;              // SBE_ROWS_SORTED: 0 never, 1 launches of >= 16 slots at 32-feature tiles (default), 2 whenever it applies (tests)
     std::atomic<uint64_t> epoch_counter{0};
+    double2* d_logtab_fine = nullptr;    // the matrix-pipe kernel's 1024-interval log table (built with d_xt)
     unsigned* d_mfma_arrive = nullptr;   // tickets of the matrix-pipe kernel's in-kernel final reduction, one per group of 16 slots (left at 0)
     uint8_t* d_xt = nullptr;       // one-hot block in MFMA fragment order (k_mixture_tuple_mfma), built at the first batched launch
     int xt_NT = 0, xt_KBp = 0;  size_t xt_bytes = 0;
-    int mfma_fused = 0;            // the fused form of the matrix-pipe kernel (SBE_MFMA_FUSED)
-    int mfma_waves = 8;            // block shape of the matrix-pipe form: 8 waves x 2 column tiles or 16 x 1 (SBE_MFMA_WAVES)
     int mfma_min_batch = 512;      // smallest launch the matrix-pipe form is chosen for under SBE_MIXTURE_PACKED (SBE_MFMA_MIN_BATCH)
     uint8_t* d_tid = nullptr;      // [slots][Np] group-tuple index per object (k_mixture_combo)
     uint16_t* d_tuple_g = nullptr; // [slots][kMaxTuples][kMaxComponents]
@@ -904,6 +903,17 @@ int ensure_xt(sbe_engine* e) {
     HIPCHK(e, hipMalloc((void**)&e->d_xt, bytes));
     e->hbm_bytes += (int64_t)bytes;
     HIPCHK(e, hipMemsetAsync(e->d_xt, 0, bytes, e->stream));
+    {   // the kernel's log table: interval centres c_i = 1 + (i + 1/2)/1024 (c_0 = 1), {RN(1/c), RN(-log(RN(1/c)))}
+        std::vector<double> tab(2 * 1024);
+        for (int i = 0; i < 1024; ++i) {
+            const double c = i == 0 ? 1.0 : 1.0 + (i + 0.5) / 1024;
+            const double inv_c = 1.0 / c;
+            tab[2 * i] = inv_c;
+            tab[2 * i + 1] = i == 0 ? 0.0 : (double)(-logl((long double)inv_c));
+        }
+        HIPCHK(e, hipMalloc((void**)&e->d_logtab_fine, tab.size() * sizeof(double)));
+        HIPCHK(e, hipMemcpy(e->d_logtab_fine, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     const size_t arrive_bytes = (size_t)(div_up(e->n_slots, 16) + 1) * sizeof(unsigned);
     HIPCHK(e, hipMalloc((void**)&e->d_mfma_arrive, arrive_bytes));
     HIPCHK(e, hipMemsetAsync(e->d_mfma_arrive, 0, arrive_bytes, e->stream));
@@ -932,6 +942,9 @@ MfmaGeom mfma_geometry(const sbe_engine* e, int n, int KT) {
     int n_split = std::max(1, std::min(div_up(NT, 16), e->compute_units / std::max(1, groups)));
     if (const char* env = getenv("SBE_MFMA_SPLIT")) { if (atoi(env) > 0) n_split = std::min(atoi(env), NT); }   // experiments
     g.nt_per_split = round_up(div_up(NT, n_split), 2);
+    // (the kernel sums count * binary exponent in 32-bit integers, one accumulator per lane and slot: a lane sees one column
+    //  per pass of 16 tiles, a column's counts add up to at most N)
+    if ((int64_t)div_up(g.nt_per_split, 16) * e->N * 1100 >= ((int64_t)1 << 31)) return g;
     g.n_split = div_up(NT, g.nt_per_split);
     return g;
 }
@@ -945,7 +958,6 @@ int launch_mfma_form(sbe_engine* e, int first_slot, int n, int KT, const MfmaGeo
     p.NT = e->xt_NT; p.KBp = e->xt_KBp; p.KT = KT;
     p.n_batch = n; p.n_split = mg.n_split; p.nt_per_split = mg.nt_per_split;
     p.first_slot = first_slot; p.slot_list = d_slots;
-    p.waves = e->mfma_waves; p.fused = e->mfma_fused;
     p.xt = e->d_xt; p.xt_bytes = (uint32_t)e->xt_bytes;
     p.tid = e->d_tid; p.tid_stride = e->Np;
     p.tuple_g = e->d_tuple_g; p.tuple_g_stride = (int64_t)kMaxTuples * kMaxComponents;
@@ -956,7 +968,7 @@ int launch_mfma_form(sbe_engine* e, int first_slot, int n, int KT, const MfmaGeo
     p.wpat = e->d_wpat; p.wpat_stride = (int64_t)e->Pmax * e->F * e->C;
     p.wpat_ones_off = (uint32_t)((int64_t)e->n_slots * e->Pmax * e->F * e->C * 4);
     p.wpat_bytes = p.wpat_ones_off + (uint32_t)(e->F * e->C * 4);
-    p.logtab = e->d_logtab;
+    p.logtab = e->d_logtab_fine;
     p.partials = e->d_partials; p.partials_stride = e->partials_stride;
     if (reduce_in_kernel) { p.results = e->d_results; p.arrive = e->d_mfma_arrive; p.done = done; }
     launch_tuple_mfma(e->C, p, dim3((unsigned)(div_up(n, 16) * mg.n_split)), mg.lds, e->stream);

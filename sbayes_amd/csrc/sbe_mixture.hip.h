@@ -62,8 +62,6 @@ struct MfmaMixParams {
     int KT;                                        // tuples used by the slots of this launch (max; <= 8)
     int n_batch, n_split, nt_per_split;            // slots of the launch; column splits (blocks per group of 16 slots); column tiles per split
     int first_slot;
-    int waves;                                     // block shape: 8 (x 2 column tiles per pass) or 16 (x 1)
-    int fused;                                     // 8 waves x 1 column tile, the next tile's counts in the shadow of the epilogue
     const int32_t* slot_list;                      // slots of this launch (n_batch entries), or null: first_slot + i
     const uint8_t* xt;  uint32_t xt_bytes;         // [NT + 1][KBp][64][16] (+ PF fragments) one-hot block in fragment order (k_xt_frags); tile NT is zero
     const uint8_t* tid;      int64_t tid_stride;       // per slot [Np] tuple index per object
@@ -72,7 +70,7 @@ struct MfmaMixParams {
     const float* probs;      int64_t probs_stride;  uint32_t probs_bytes;   // per slot [Gtot][F][S] float32 tables (a4), whole array < 4 GiB
     const float* wpat;       int64_t wpat_stride;   uint32_t wpat_bytes;    // per slot [Pmax][F][C] float32 normalised weights (a5)
     uint32_t probs_ones_off, wpat_ones_off;        // byte offsets of the rows of ones behind the two arrays (F*S / F*C floats)
-    const double2* logtab;                         // [128] {1/c, log c}
+    const double2* logtab;                         // [1024] {1/c, log c}: this kernel's own finer table (tab_log3_n)
     double* partials;        int64_t partials_stride;
     // final reduction inside the kernel (results != nullptr): the LAST of a slot group's n_split blocks to finish -- tickets in
     // arrive[group], which it leaves at 0 -- adds the group's partial sums in split order and writes the 16 results; `done`

@@ -33,12 +33,12 @@ typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) const v4i_t lds_cv4i_t;
 
+constexpr int kMfmaWaves = 8;
+constexpr int kMfmaThreads = kMfmaWaves * kWave;
 constexpr int kMfmaSlots = 16;          // slots per block
-// Two block shapes, both 16 column tiles per pass (template NW x RN):
-//   8 waves x 2 column tiles   96 accumulator registers at MT = 3: two waves per SIMD
-//   16 waves x 1 column tile   48 accumulator registers: four waves per SIMD (<= 128 registers each) -- the epilogue is
-//                              vector-issue bound and a SIMD issues fp64 work at 4.3 cycles per instruction from four waves
-//                              against 4.9-5.9 from two; the price is one A-fragment LDS read per MFMA instead of one per two
+constexpr int kMfmaRN = 2;              // column tiles per wave pass
+// (Other block shapes were measured in round 5 and lost: 16 waves x 1 column tile at 128 registers, +9 %; 8 waves x 1 tile with
+//  the next tile's MFMAs issued inside the epilogue, +7 %: profiles/r5/mfma_kernel_experiments_session2.log.)
 
 // One-hot block -> fragment order.  Fragment (nt, kb): lane l holds bytes j = 0..15 = X[n = 32 kb + 16 (l >> 5) + j][col = 32 nt + (l & 31)]
 // with col = f * S + s; zero for n >= N, col >= F * S and NA observations.
@@ -65,35 +65,34 @@ void launch_xt_frags(const uint8_t* state, uint8_t* xt, int N, int F, int S, int
     k_xt_frags<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(state, xt, N, F, S, Fp, NT, KBp);
 }
 
-// table-driven log of tab_log_core (sbe_device_common.hip.h), G chains interleaved, trimmed to what a SUM of ~N*F logs
-// needs at 1e-10 relative (its terms are O(1), so ~1e-13 absolute per log leaves three orders of magnitude):
-//   * log1p series cut after r^5: |r| <= 2^-8, first dropped term r^6 / 6 < 6e-16;
-//   * k * ln2 with ONE rounded constant instead of the hi / lo pair: error <= half an ulp of k * ln2 (< 2e-15 for the
-//     exponents of probabilities down to 1e-30).
-// Measured against the full form on the fixtures: the summed log-likelihoods agree to <= 2e-15 relative.
+// Table-driven log for this kernel's epilogue, G chains interleaved: log v = k ln2 + log c_i + log1p(r), r = m / c_i - 1, with
+// its own FINER table (1024 intervals of the mantissa, kFineLogEntries x {RN(1/c), RN(-log RN(1/c))}, c_0 = 1 so that
+// log 1 = 0 exactly) so that |r| <= 2^-11 (2^-10 in interval 0) and the series stops after r^3: first dropped term r^4 / 4 <=
+// 1.4e-14 (2.3e-13 in interval 0) per log, three orders of magnitude inside what a SUM of O(1) terms needs at 1e-10 relative.
+// v_fma_f64 is the dearest instruction of the epilogue (tools/probe/valu_rates.hip: 6.5 cycles against 4.0 for 32-bit integer
+// work at two waves per SIMD): against the 128-entry / r^5 form this is two FMAs fewer per entry.  The binary exponent is NOT
+// folded in here: it is returned as an integer and summed exactly, count-weighted, by the caller (one v_mad_i32_i24 instead
+// of a conversion and an FMA per entry; k ln2 is applied once per accumulator at the end).
+constexpr int kFineLogEntries = 1024;
 template <int G>
-__device__ __forceinline__ void tab_log5_n(const double (&v)[G], double (&out)[G], uint32_t tab) {
+__device__ __forceinline__ void tab_log3_n(const double (&v)[G], double (&out)[G], int (&kexp)[G], uint32_t tab) {
     f64x2_t e[G];
-    double m[G], r[G], q[G], kd[G];
+    double m[G], r[G], q[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const uint32_t hi = (uint32_t)__double2hiint(v[g]);
-        e[g] = *(lds_cf64x2_t*)(uintptr_t)(tab + ((hi >> 9) & 0x7F0u));
+        e[g] = *(lds_cf64x2_t*)(uintptr_t)(tab + ((hi >> 6) & 0x3FF0u));        // entry (hi >> 10) & 1023
         m[g] = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), __double2loint(v[g]));
-        kd[g] = (double)((int)(hi >> 20) - 1023);
+        kexp[g] = (int)(hi >> 20) - 1023;
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) r[g] = fma(m[g], e[g].x, -1.0);
 #pragma unroll
-    for (int g = 0; g < G; ++g) q[g] = fma(0.2, r[g], -0.25);
-#pragma unroll
-    for (int g = 0; g < G; ++g) q[g] = fma(q[g], r[g], 1.0 / 3.0);
-#pragma unroll
-    for (int g = 0; g < G; ++g) q[g] = fma(q[g], r[g], -0.5);
+    for (int g = 0; g < G; ++g) q[g] = fma(1.0 / 3.0, r[g], -0.5);
 #pragma unroll
     for (int g = 0; g < G; ++g) q[g] = fma(r[g] * r[g], q[g], r[g]);          // log1p(r)
 #pragma unroll
-    for (int g = 0; g < G; ++g) out[g] = fma(kd[g], 6.93147180559945286227e-01, e[g].y) + q[g];
+    for (int g = 0; g < G; ++g) out[g] = e[g].y + q[g];
 }
 
 // per (slot of the block, tuple): byte offsets of the tuple's probability rows inside the probs array and of its
@@ -106,10 +105,8 @@ struct __attribute__((aligned(CT <= 1 ? 8 : (CT <= 3 ? 16 : 32)))) TupleMeta {
 
 
 
-template <int MT, int CT, int GT = 4, int NW = 8, int RN = 2, int KB = 0>
-__global__ __launch_bounds__(NW * kWave, 1) void k_mixture_tuple_mfma(MfmaMixParams p) {
-    constexpr int kMfmaWaves = NW, kMfmaThreads = NW * kWave, kMfmaRN = RN;
-    static_assert(KB == 0 || RN == 1, "the fused form takes one column tile per wave and pass");
+template <int MT, int CT, int GT = 4>
+__global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixParams p) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -118,7 +115,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void k_mixture_tuple_mfma(MfmaMixPar
     // LDS map: log table 128 x 16 B at ABSOLUTE address 0 (its index is the whole address: the kernel has no static LDS, so
     // the dynamic block starts at 0 -- checked) | A fragments [MT][KBp][64] x 16 B | meta [16][2 MT] | reduction [8 waves][16] f64
     constexpr uint32_t tab_off = 0u;
-    constexpr uint32_t a_off = kLogTabEntries * 16u;
+    constexpr uint32_t a_off = kFineLogEntries * 16u;
     const uint32_t a_bytes = (uint32_t)MT * (uint32_t)KBp * 1024u;
     const uint32_t meta_off = a_off + a_bytes;
     const uint32_t red_off = meta_off + (uint32_t)(kMfmaSlots * 2 * MT * sizeof(TupleMeta<CT>));
@@ -190,8 +187,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void k_mixture_tuple_mfma(MfmaMixPar
         }
         meta[sl * 2 * MT + t] = md;
     }
-    if (threadIdx.x < 2 * kLogTabEntries)
-        reinterpret_cast<double*>(lds_raw + tab_off)[threadIdx.x] = reinterpret_cast<const double*>(p.logtab)[threadIdx.x];
+    for (int i = (int)threadIdx.x; i < 2 * kFineLogEntries; i += kMfmaThreads)
+        reinterpret_cast<double*>(lds_raw + tab_off)[i] = reinterpret_cast<const double*>(p.logtab)[i];
     {
         // one unit = the 16 tuple ids of (slot sl, 16 objects) -> the 2 MT indicator pieces of those objects.  The ids of
         // UB units are asked for together (a unit at a time the block's start is four dependent trips to L2 / HBM)
@@ -238,9 +235,10 @@ __global__ __launch_bounds__(NW * kWave, 1) void k_mixture_tuple_mfma(MfmaMixPar
 
     // ---- phase 1: counts on the matrix pipe, table entries + log + dot product on the vector pipe ----------------------
     const int h = lane >> 5, cl = lane & 31;
-    double lsum[8];
+    double lsum[8];                                               // per slot of this lane: sum of cnt * log(mantissa part)
+    int ksum[8];                                                  // ... and of cnt * binary exponent (exact)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) lsum[i] = 0.0;
+    for (int i = 0; i < 8; ++i) { lsum[i] = 0.0; ksum[i] = 0; }
     const __amdgpu_buffer_rsrc_t pr_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.probs), 0, (int)p.probs_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpat), 0, (int)p.wpat_bytes, 0x00020000);
     const uint32_t a_lane = a_off + (uint32_t)lane * 16u;
@@ -356,26 +354,28 @@ __global__ __launch_bounds__(NW * kWave, 1) void k_mixture_tuple_mfma(MfmaMixPar
             vv[i] = v;
             special |= __builtin_amdgcn_class(v, 0x2FF);            // anything but a positive normal double
         }
-        tab_log5_n<G>(vv, lg, tab_off);
+        int kx[G];
+        tab_log3_n<G>(vv, lg, kx, tab_off);
         // Rare: a table entry that is not a positive normal number -- the zero probability of an inapplicable state,
         // which no observation falls on (contributes nothing, whatever it is), or of an observed one (log 0 = -inf,
         // like the reference), or corrupt input (library log).
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0ull, 0)) {
 #pragma unroll
             for (int i = 0; i < G; ++i)
-                if (__builtin_amdgcn_class(vv[i], 0x2FF)) lg[i] = cnt[i] != 0 ? lib_log(vv[i]) : 0.0;
+                if (__builtin_amdgcn_class(vv[i], 0x2FF)) { lg[i] = cnt[i] != 0 ? lib_log(vv[i]) : 0.0; kx[i] = 0; }
         }
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int k = (j & 1) * 4 + half * G + i;
             lsum[k] = fma((double)cnt[i], lg[i], lsum[k]);
+            ksum[k] = __mul24(cnt[i], kx[i]) + ksum[k];            // (host: passes * N * 1100 < 2^31)
+            asm volatile("" : "+v"(ksum[k]));
             // (pins the sum in this step's block: the rare-path branch above splits the epilogue into basic blocks and
             //  the compiler otherwise sinks the whole chain of sums to the last one, keeping every log alive: 150 spills)
             asm volatile("" : "+v"(lsum[k]));
         }
     };
 
-    if constexpr (KB == 0) {
     for (int nt0 = nt_lo + w * kMfmaRN; nt0 < nt_hi; nt0 += kMfmaWaves * kMfmaRN) {
         int toff[kMfmaRN];
 #pragma unroll
@@ -393,7 +393,6 @@ __global__ __launch_bounds__(NW * kWave, 1) void k_mixture_tuple_mfma(MfmaMixPar
         // the single metadata buffer is refilled as soon as the loads of its last step (r = RN - 1) are out
         st_meta(0);
         st_load(0);
-        if (kMfmaRN == 1 && NST > 1) st_meta(1);
 #pragma unroll
         for (int q = 0; q < NST; ++q) {
             if (q + 1 < NST) {
@@ -404,78 +403,11 @@ __global__ __launch_bounds__(NW * kWave, 1) void k_mixture_tuple_mfma(MfmaMixPar
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    } else {
-    // ---- fused form: the counts of the wave's NEXT column tile run on the matrix pipe in the shadow of the epilogue of the
-    // current one.  A wave issues in order, but an MFMA only occupies the matrix pipe (32 cycles) once issued: the ~14 fp64
-    // vector instructions of the epilogue that stand between two MFMAs issue meanwhile (tools/probe/mfma_valu_overlap.hip:
-    // 42 FMAs + 3 MFMAs per iteration cost 184 ns against 169 ns for the FMAs alone and 255 ns for one after the other, at two
-    // waves per SIMD).  The KB k-block slots of a tile are dealt to the NST epilogue steps at compile time; slots beyond the
-    // launch's KBp multiply the zero tile.
-    int nt = nt_lo + w;
-    v16i_t acc_cur[MT][1];
-    {
-        int toff[1] = {tile_off(nt)};
-        counts_pass(acc_cur, toff);
-    }
-    uint32_t a_lane_m[MT];                                       // (k-block offsets ride in the LDS instruction's immediate)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) a_lane_m[m] = a_lane + ((uint32_t)m * (uint32_t)KBp) * 1024u;
-    for (; nt < nt_hi; nt += kMfmaWaves) {
-        // the next tile through its own descriptor: KBp fragments long, so the k-block slots beyond KBp read zeros (a tile
-        // beyond the split is the zero tile); the A fragments of those slots are whatever follows in LDS -- times zero
-        const __amdgpu_buffer_rsrc_t xn_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint8_t*>(p.xt) + tile_off(nt + kMfmaWaves), 0, KBp * 1024, 0x00020000);
-        auto load_bn = [&](int kb) -> v4i_t {
-            const u32x4_t d = __builtin_amdgcn_raw_buffer_load_b128(xn_rsrc, lane16 + kb * 1024, 0, 0);
-            v4i_t r; r.x = (int)d.x; r.y = (int)d.y; r.z = (int)d.z; r.w = (int)d.w;
-            return r;
-        };
-#pragma unroll
-        for (int i = 0; i < PF; ++i) bq[i][0] = load_bn(i);
-        v16i_t acc_nxt[MT][1];
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc_nxt[m][0][i] = 0;
-        v4i_t a_cur[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) a_cur[m] = *(lds_cv4i_t*)(uintptr_t)(a_lane_m[m]);
-        st_cols(nt);
-        st_meta(0);
-        st_load(0);
-        if (NST > 1) st_meta(1);
-#pragma unroll
-        for (int q = 0; q < NST; ++q) {
-            if (q + 1 < NST) {
-                st_load(q + 1);
-                if (q + 2 < NST) st_meta(q + 2);
-            }
-            const int kb_lo = q * KB / NST, kb_hi = (q + 1) * KB / NST;
-#pragma unroll
-            for (int kb = kb_lo; kb < kb_hi; ++kb) {
-                v4i_t a_nxt[MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) a_nxt[m] = *(lds_cv4i_t*)(uintptr_t)(a_lane_m[m] + (uint32_t)(kb + 1) * 1024u);
-                const v4i_t b = bq[kb % PF][0];
-                bq[kb % PF][0] = load_bn(kb + PF);
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    acc_nxt[m][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_cur[m], b, acc_nxt[m][0], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
-            }
-            st_comp(q, acc_cur);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc_cur[m][0] = acc_nxt[m][0];
-    }
-    }
 
     // ---- phase 2: fixed-order reduction: 32 columns of a lane half, then the 8 waves ------------------------------------
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        double v = lsum[i];
+        double v = fma((double)ksum[i], 6.93147180559945286227e-01, lsum[i]);
 #pragma unroll
         for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
         lsum[i] = v;
@@ -523,51 +455,19 @@ __global__ __launch_bounds__(NW * kWave, 1) void k_mixture_tuple_mfma(MfmaMixPar
 
 size_t tuple_mfma_lds_bytes(int MT, int C, int KBp) {     // log table | A fragments | meta | reduction
     const size_t meta = (size_t)kMfmaSlots * 2 * MT * (C <= 1 ? 8 : (C <= 3 ? 16 : 32));
-    return (size_t)MT * KBp * 1024 + kLogTabEntries * 16 + meta + (size_t)16 * kMfmaSlots * sizeof(double);      // (16 waves' worth: either block shape)
+    return (size_t)MT * KBp * 1024 + kFineLogEntries * 16 + meta + (size_t)kMfmaWaves * kMfmaSlots * sizeof(double);
 }
 
 // entries per epilogue step: a whole register quad where the registers allow it, half a quad for the widest instances
 template <int MT, int CT> constexpr int mfma_gt() { return (MT >= 4 || (MT == 3 && CT >= 3)) ? 2 : 4; }
-// ... of the 16-wave shape (128 registers per wave)
-template <int MT, int CT> constexpr int mfma_gt16() { return 2; }
-
-template <int MT, int CT>
-static void launch_mfma_one(const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st) {
-    if constexpr (MT == 3 && CT == 2) {                       // EXPERIMENT variants
-        static const int variant = getenv("SBE_MFMA_VARIANT") ? atoi(getenv("SBE_MFMA_VARIANT")) : 0;
-        if (variant == 3) { k_mixture_tuple_mfma<3, 2, 2, 8, 2, 0><<<grid, 8 * kWave, lds, st>>>(p); return; }
-        if (variant == 4) { k_mixture_tuple_mfma<3, 2, 4, 8, 1, 0><<<grid, 8 * kWave, lds, st>>>(p); return; }
-        if (variant == 5) { k_mixture_tuple_mfma<3, 2, 2, 8, 1, 0><<<grid, 8 * kWave, lds, st>>>(p); return; }
-    }
-    if constexpr (MT >= 2 && MT <= 3 && CT >= 2) {
-        if (p.fused && p.KBp <= 48) {
-            // (the A-fragment reads of the k-block slots beyond KBp must stay inside the block's LDS allocation)
-            const int KB = p.KBp <= 16 ? 16 : p.KBp <= 32 ? 32 : 48;
-            const size_t lds_f = std::max(lds, (size_t)kLogTabEntries * 16 + ((size_t)(MT - 1) * p.KBp + KB + 1) * 1024);
-            if (lds_f <= 160 * 1024) {
-                if (KB == 16) k_mixture_tuple_mfma<MT, CT, 2, 8, 1, 16><<<grid, 8 * kWave, lds_f, st>>>(p);
-                else if (KB == 32) k_mixture_tuple_mfma<MT, CT, 2, 8, 1, 32><<<grid, 8 * kWave, lds_f, st>>>(p);
-                else k_mixture_tuple_mfma<MT, CT, 2, 8, 1, 48><<<grid, 8 * kWave, lds_f, st>>>(p);
-                return;
-            }
-        }
-    }
-    if constexpr (MT <= 3) {
-        if (p.waves == 16) {
-            k_mixture_tuple_mfma<MT, CT, mfma_gt16<MT, CT>(), 16, 1><<<grid, 16 * kWave, lds, st>>>(p);
-            return;
-        }
-    }
-    k_mixture_tuple_mfma<MT, CT, mfma_gt<MT, CT>()><<<grid, 8 * kWave, lds, st>>>(p);
-}
 
 template <int MT>
 static void launch_mfma_mt(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st) {
     switch (C) {
-        case 1: launch_mfma_one<MT, 1>(p, grid, lds, st); break;
-        case 2: launch_mfma_one<MT, 2>(p, grid, lds, st); break;
-        case 3: launch_mfma_one<MT, 3>(p, grid, lds, st); break;
-        default: launch_mfma_one<MT, 4>(p, grid, lds, st); break;
+        case 1: k_mixture_tuple_mfma<MT, 1, mfma_gt<MT, 1>()><<<grid, kMfmaThreads, lds, st>>>(p); break;
+        case 2: k_mixture_tuple_mfma<MT, 2, mfma_gt<MT, 2>()><<<grid, kMfmaThreads, lds, st>>>(p); break;
+        case 3: k_mixture_tuple_mfma<MT, 3, mfma_gt<MT, 3>()><<<grid, kMfmaThreads, lds, st>>>(p); break;
+        default: k_mixture_tuple_mfma<MT, 4, mfma_gt<MT, 4>()><<<grid, kMfmaThreads, lds, st>>>(p); break;
     }
 }
 
@@ -575,18 +475,6 @@ static void launch_mfma_mt(int C, const MfmaMixParams& p, dim3 grid, size_t lds,
 template <int MT, int CT>
 static void allow_lds() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<MT, CT, mfma_gt<MT, CT>()>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if constexpr (MT <= 3)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<MT, CT, mfma_gt16<MT, CT>(), 16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if constexpr (MT == 3 && CT == 2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<3, 2, 2, 8, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<3, 2, 4, 8, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<3, 2, 2, 8, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
-    if constexpr (MT >= 2 && MT <= 3 && CT >= 2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<MT, CT, 2, 8, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<MT, CT, 2, 8, 1, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<MT, CT, 2, 8, 1, 48>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
 }
 
 void launch_tuple_mfma(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st) {

@@ -311,6 +311,40 @@ def test_mfma_kernel_default_choice_and_zero_probability():
         assert np.all(np.isfinite(got[np.arange(B) != 7]))
 
 
+@pytest.mark.parametrize("n_split", [1, 2, 3, 5])
+def test_mfma_kernel_final_reduction_in_kernel(n_split, monkeypatch):
+    """The matrix-pipe kernel finishes its own reduction: the LAST of a slot group's column-split blocks (tickets) adds the
+    group's partial sums in split order.  Whichever block that is, the value is the same -- 60 launches return the same bits,
+    synchronous and asynchronous form alike -- and equals the vector-pipe form's; a batch that is not a multiple of the 16
+    slots of a block and a batch starting in the middle of the slots go through the same path."""
+    monkeypatch.setenv("SBE_MFMA_SPLIT", str(n_split))
+    rng = np.random.default_rng(77 + n_split)
+    N, F, S, B = 150, 40, 4, 83
+    feats, groups0, _w, _s, _conc = random_case(rng, N, F, S, [3, 1], 0.03)
+    with Engine(feats, [3, 1], n_slots=B) as eng:
+        for b in range(B):
+            a = rng.integers(0, 5, size=N)
+            groups = [np.stack([a == k for k in range(3)])] + groups0[1:]
+            probs = [rng.dirichlet(np.ones(S), size=(3, F)).astype(np.float32), rng.dirichlet(np.ones(S), size=(1, F)).astype(np.float32)]
+            eng.load_state(b, groups, rng.dirichlet(np.ones(2), size=F).astype(np.float32), probs=probs)
+        eng.set_option(kernel=MIXTURE_PACKED_TUPLE)
+        ref = eng.mixture_loglik_batch(0, B)
+        eng.set_option(kernel=MIXTURE_PACKED_TUPLE_MFMA)
+        got = eng.mixture_loglik_batch(0, B)
+        assert "k_mixture_tuple_mfma" in eng.last_mixture_kernel()
+        np.testing.assert_allclose(got, ref, rtol=1e-12)
+        for i in range(60):
+            if i % 2:
+                again = eng.mixture_loglik_batch(0, B)
+            else:
+                eng.mixture_loglik_batch_async(0, B)
+                eng.mixture_loglik_batch_async(0, B)              # (two launches in flight share the tickets, one after the other)
+                again = eng.fetch_results(0, B)
+            assert np.array_equal(again, got), i
+        assert np.array_equal(eng.mixture_loglik_batch(5, 40), got[5:45])
+        assert eng.mixture_loglik(B - 1) == pytest.approx(got[B - 1], rel=1e-12)
+
+
 @pytest.mark.parametrize("shape", [
     # N,   F,   S,  groups,        n_slots   (what it exercises in the pattern-sorted rows form)
     (1203, 70,  6,  [4, 1, 5, 3],  20),      # C = 4, 16 patterns possible, ragged last tile (70 = 2 * 32 + 6), runs of every length

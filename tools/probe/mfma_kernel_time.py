@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Kernel time of the matrix-pipe form at the headline shape, B = 2048, for the variant named by the environment
-(SBE_MFMA_VARIANT / SBE_MFMA_FUSED / SBE_MFMA_WAVES); one process per variant.  Prints the median of 5 x 20 launches."""
+"""Kernel time of the matrix-pipe form at the headline shape (HIP event pairs, median of 5 x 20 launches) for the library
+named by SBAYES_AMD_LIB (A/B of two builds on one box) and whatever SBE_* experiment variables are set; one process per
+build.    python tools/probe/mfma_kernel_time.py [B]"""
+import hashlib
 import os
 import sys
 from pathlib import Path
@@ -17,7 +19,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 wl = make_workload("headline")
 eng = bench.setup_engine(wl, B, 0)
 eng.set_option(kernel=MIXTURE_PACKED_TUPLE_MFMA)
-eng.mixture_loglik_batch(0, B)
+first = eng.mixture_loglik_batch(0, B)
 ts = []
 for _ in range(5):
     eng.kernel_timing_start()
@@ -26,7 +28,7 @@ for _ in range(5):
     got = eng.fetch_results(0, B)
     n, ms = eng.kernel_timing_stop()
     ts.append(ms * 1e3)
-import hashlib
-print(f"variant={os.environ.get('SBE_MFMA_VARIANT', '-')} fused={os.environ.get('SBE_MFMA_FUSED', '-')} waves={os.environ.get('SBE_MFMA_WAVES', '-')} "
-      f"B={B}: {np.median(ts):.2f} us (min {min(ts):.2f})  digest {hashlib.sha1(np.ascontiguousarray(got).tobytes()).hexdigest()[:16]}", flush=True)
+    assert np.array_equal(got, first), "results changed between launches"
+env = {k: v for k, v in os.environ.items() if k.startswith("SBE_") or k == "SBAYES_AMD_LIB"}
+print(f"{env} B={B}: {np.median(ts):.2f} us (min {min(ts):.2f})  digest {hashlib.sha1(np.ascontiguousarray(got).tobytes()).hexdigest()[:16]}", flush=True)
 eng.close()
