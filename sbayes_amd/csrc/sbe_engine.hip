@@ -75,7 +75,7 @@ int sbe_destroy(sbe_engine* e) {
     if (e->h_io) (void)hipHostFree(e->h_io);
     void* dev_ptrs[] = {e->d_step_pf, e->d_step_pg, e->d_logtab, e->d_state_h, e->d_toff, e->d_tid, e->d_tuple_g, e->d_tuple_p, e->d_state_q, e->d_probs_t, e->d_wpat_t, e->d_onehot, e->d_state, e->d_gid, e->d_pid, e->d_src, e->d_counts, e->d_probs,
                         e->d_weights, e->d_wpat, e->d_patbits, e->d_conc, e->d_lg_conc, e->d_sum_a, e->d_lg_sum_a, e->d_unif, e->d_unif_res, e->d_comp_of_group, e->d_partials, e->d_rowoff,
-                        e->d_status, e->d_changed, e->d_step_stamp, e->d_scratch, e->d_xt, e->d_mfma_arrive, e->d_logtab_fine, e->d_rowoff_s, e->d_rs_nq, e->d_state_s};
+                        e->d_status, e->d_changed, e->d_step_stamp, e->d_scratch, e->d_xt, e->d_arrive, e->d_logtab_fine, e->d_rowoff_s, e->d_rs_nq, e->d_state_s};
     for (void* p : dev_ptrs) if (p) (void)hipFree(p);
     if (e->h_results) (void)hipHostFree(e->h_results);
     if (e->h_status) (void)hipHostFree(e->h_status);
@@ -263,6 +263,8 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
         e->partials_stride = std::max<int64_t>(div_up(F, 16) * std::max<int64_t>(div_up(N, min_objs), 4 * e->compute_units), 1024);
     }
     CREATE_RC(dmalloc(e, &e->d_partials, NS * e->partials_stride));
+    CREATE_RC(dmalloc(e, &e->d_arrive, NS + 1));
+    CREATE_CHK(hipMemset(e->d_arrive, 0, (size_t)(NS + 1) * sizeof(unsigned)));
     CREATE_RC(dmalloc(e, &e->d_status, (int64_t)ST_WORDS));
     CREATE_RC(dmalloc(e, &e->d_changed, (int64_t)e->Gtot));
     CREATE_RC(dmalloc(e, &e->d_step_stamp, (int64_t)e->Gtot));

@@ -120,7 +120,8 @@ struct sbe_engine {
     int opt_rows_sorted = 1;              // SBE_ROWS_SORTED: 0 never, 1 launches of >= 16 slots at 32-feature tiles (default), 2 whenever it applies (tests)
     std::atomic<uint64_t> epoch_counter{0};
     double2* d_logtab_fine = nullptr;    // the matrix-pipe kernel's 1024-interval log table (built with d_xt)
-    unsigned* d_mfma_arrive = nullptr;   // tickets of the matrix-pipe kernel's in-kernel final reduction, one per group of 16 slots (left at 0)
+    unsigned* d_arrive = nullptr;  // [slots + 1] tickets of the north-star kernels' in-kernel final reduction (finish_partial: per slot; matrix-pipe
+                                   // form: per group of 16 slots); every launch leaves them at 0
     uint8_t* d_xt = nullptr;       // one-hot block in MFMA fragment order (k_mixture_tuple_mfma), built at the first batched launch
     int xt_NT = 0, xt_KBp = 0;  size_t xt_bytes = 0;
     int mfma_min_batch = 512;      // smallest launch the matrix-pipe form is chosen for under SBE_MIXTURE_PACKED (SBE_MFMA_MIN_BATCH)
@@ -914,9 +915,6 @@ int ensure_xt(sbe_engine* e) {
         HIPCHK(e, hipMalloc((void**)&e->d_logtab_fine, tab.size() * sizeof(double)));
         HIPCHK(e, hipMemcpy(e->d_logtab_fine, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     }
-    const size_t arrive_bytes = (size_t)(div_up(e->n_slots, 16) + 1) * sizeof(unsigned);
-    HIPCHK(e, hipMalloc((void**)&e->d_mfma_arrive, arrive_bytes));
-    HIPCHK(e, hipMemsetAsync(e->d_mfma_arrive, 0, arrive_bytes, e->stream));
     launch_xt_frags(e->d_state, e->d_xt, e->N, e->F, e->S, e->Fp, NT, KBp, e->stream);
     HIPCHK(e, hipGetLastError());
     e->xt_NT = NT; e->xt_KBp = KBp; e->xt_bytes = bytes;
@@ -970,7 +968,7 @@ int launch_mfma_form(sbe_engine* e, int first_slot, int n, int KT, const MfmaGeo
     p.wpat_bytes = p.wpat_ones_off + (uint32_t)(e->F * e->C * 4);
     p.logtab = e->d_logtab_fine;
     p.partials = e->d_partials; p.partials_stride = e->partials_stride;
-    if (reduce_in_kernel) { p.results = e->d_results; p.arrive = e->d_mfma_arrive; p.done = done; }
+    if (reduce_in_kernel) { p.results = e->d_results; p.arrive = e->d_arrive; p.done = done; }
     launch_tuple_mfma(e->C, p, dim3((unsigned)(div_up(n, 16) * mg.n_split)), mg.lds, e->stream);
     return SBE_OK;
 }
@@ -1120,18 +1118,25 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     dim3 grid(g.n_blocks, n);
     if (mfma) { int rc = ensure_xt(e); if (rc) return rc; }      // (one-time build: outside the event pair)
     if (ev_a) HIPCHK(e, hipEventRecord(ev_a, e->stream));
-    // matrix-pipe form without a step epilogue: the kernel's last block per slot group does the final reduction itself
-    // (one launch per eval batch instead of two; SBE_MFMA_REDUCE=0 keeps k_reduce_partials: A/B runs)
-    static const bool mfma_reduce_opt = !(getenv("SBE_MFMA_REDUCE") && atoi(getenv("SBE_MFMA_REDUCE")) == 0);
-    const bool mfma_reduce = mfma && !fin && !d_fins && mfma_reduce_opt;
+    // Without a step epilogue the kernel finishes the reduction itself (the last block of a slot -- of a group of 16 slots in
+    // the matrix-pipe form -- adds the partial sums): one launch per eval (batch) instead of two.  SBE_REDUCE_IN_KERNEL=0
+    // keeps k_reduce_partials (A/B runs).
+    static const bool in_kernel_opt = !(getenv("SBE_REDUCE_IN_KERNEL") && atoi(getenv("SBE_REDUCE_IN_KERNEL")) == 0);
+    // Where it pays (measured, tools/probe/single_eval_latency.py and bench.py): always in the matrix-pipe form (two to four
+    // blocks per 16 slots) and when a slot is ONE block (no tickets at all); for a few blocks per slot in the asynchronous
+    // calls (throughput: one launch less per eval, cfg1 138 -> 164 k evals/s).  A host-synchronous call waits for the last
+    // block's store -> ticket -> loads, three dependent trips to the coherence point, which is 1.2-2 us MORE than the second
+    // launch; and with hundreds of blocks per slot the tickets at one address serialise (headline, one eval: 8.1 -> 11.2 us).
+    const bool in_kernel = !fin && !d_fins && in_kernel_opt && (mfma || g.n_blocks == 1 || (!done_out && g.n_blocks <= 16));
+    const bool mfma_reduce = mfma && in_kernel;
+    DoneSig done_k{};
+    if (in_kernel) {
+        done_k = done_out ? next_done(e, (unsigned)(mfma ? div_up(n, 16) : n)) : DoneSig{};
+        if (done_out) *done_out = done_k;
+    }
     if (mfma) {
         snprintf(e->last_kernel, sizeof e->last_kernel, "k_mixture_tuple_mfma<packed stream, group-tuple form, matrix pipe, M tiles %d, C=%d>", mg.MT, e->C);
-        DoneSig done{};
-        if (mfma_reduce) {
-            done = done_out ? next_done(e, (unsigned)div_up(n, 16)) : DoneSig{};
-            if (done_out) *done_out = done;
-        }
-        int rc = launch_mfma_form(e, first_slot, n, KT, mg, d_slots, mfma_reduce, done);
+        int rc = launch_mfma_form(e, first_slot, n, KT, mg, d_slots, mfma_reduce, done_k);
         if (rc) return rc;
     } else {
         // XCD-aware 1-D grid (see k_mixture_v2): units = work items x slot groups, unit u on XCD u % 8
@@ -1151,6 +1156,7 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
         p.probs_t = e->d_probs_t; p.probs_t_stride = e->probs_t_elems();
         p.wpat_t = e->d_wpat_t; p.wpat_t_stride = e->wpat_t_elems(); p.wpat_tile_stride = (int)e->wpat_tile_elems();
         p.partials = e->d_partials; p.partials_stride = e->partials_stride; p.first_slot = first_slot;
+        if (in_kernel) { p.results = e->d_results; p.arrive = e->d_arrive; p.done = done_k; }
         p.slot_list = d_slots;
         p.n_work = g.n_blocks; p.n_batch = n;
         p.slot_groups = slot_groups; p.slots_per_group = slots_per_group;
@@ -1201,7 +1207,7 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     }
     if (ev_b) HIPCHK(e, hipEventRecord(ev_b, e->stream));
     HIPCHK(e, hipGetLastError());
-    if (mfma_reduce) return SBE_OK;
+    if (in_kernel) return SBE_OK;
     const unsigned n_red = (unsigned)(n + (d_fins ? n : (fin ? 1 : 0)));
     const DoneSig done = done_out ? next_done(e, n_red) : DoneSig{};      // (the caller waits with wait_done)
     if (done_out) *done_out = done;

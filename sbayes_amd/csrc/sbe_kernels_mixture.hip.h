@@ -22,6 +22,48 @@ namespace sbe {
 //              4-byte scalar loads; FT < 64: 64/FT quads per wave, per-lane broadcast loads.
 // ==========================================================================================
 
+// End of a block of the Mix2Params kernels, called by the 64 lanes of the block's FIRST wave with the block's partial sum in
+// lane 0.  Without p.results the sum goes to partials[slot][work] and k_reduce_partials adds them up (the step forms: their
+// epilogue block rides on that launch).  With p.results the kernel finishes by itself -- one launch per eval instead of two,
+// 3 us of a 14 us host-synchronous eval: the blocks of a slot take tickets (arrive[slot], left at 0), the LAST one adds the
+// slot's n_work partial sums in a fixed order (k_reduce_partials' own: the same bits whichever block is last) and
+// writes the result; p.done (optional) is signalled by those blocks, one per slot.  The partial sums travel as agent-scope
+// atomic stores / loads ordered by s_waitcnt around the ticket: coherent across the XCDs' L2s without a release fence (which
+// writes the whole L2 back -- measured on the matrix-pipe form, profiles/r5/mfma_kernel_experiments_session2.log).
+__device__ __forceinline__ void finish_partial(const Mix2Params& p, int slot, int work, double total) {
+    const int lane = threadIdx.x & (kWave - 1);
+    double* const my = p.partials + (int64_t)slot * p.partials_stride;
+    if (!p.results) {
+        if (lane == 0) my[work] = total;
+        return;
+    }
+    if (p.n_work > 1) {
+        unsigned t = 0;
+        if (lane == 0) {
+            __hip_atomic_store(my + work, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            t = __hip_atomic_fetch_add(p.arrive + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == (unsigned)p.n_work - 1u) __hip_atomic_store(p.arrive + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        if (t != (unsigned)p.n_work - 1u) return;                         // (wave-uniform)
+        asm volatile("" ::: "memory");
+        // the additions of k_reduce_partials, in its order (256 threads stride the partial sums, wave trees, then
+        // (w0 + w1) + (w2 + w3)): lane l stands for its threads l, l + 64, l + 128, l + 192 -- the step forms, which keep
+        // that kernel for their epilogue, and this path return the same bits
+        double ws[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double v = 0.0;
+            for (int i = lane + k * kWave; i < p.n_work; i += 4 * kWave) v += __hip_atomic_load(my + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ws[k] = wave_sum(v);
+        }
+        total = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+    }
+    if (lane == 0) p.results[slot] = total;
+    signal_done(p.done);
+}
+
 // LOG_PRODUCT, branch-free form used by the v2 kernel: the four observation likelihoods of a
 // step are multiplied into the running mantissa and the binary exponent is stripped once per
 // step.  Anything that is not a positive normal double (an observed state with probability 0,
@@ -228,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_v2(Mix2Params p) {
         thread_ll = sum;
     }
     const double total = block_sum(thread_ll, red4);
-    if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + work] = total;
+    if (threadIdx.x < kWave) finish_partial(p, slot, work, total);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -370,7 +412,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_onehot_v2(Mix2Params p) {
         thread_ll = sum;
     }
     const double total = block_sum(thread_ll, red4);
-    if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + work] = total;
+    if (threadIdx.x < kWave) finish_partial(p, slot, work, total);
 }
 
 // ==========================================================================================
@@ -428,7 +470,7 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
     const int q1 = min(NQ_slot, q0 + p.quads_per_chunk);
     const int nq = max(0, q1 - q0);                                       // (sorted: a chunk beyond the slot's length is empty)
     if (SORTED && nq == 0) {                                              // (block-uniform, before any barrier: nothing to stage for)
-        if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + work] = 0.0;
+        if (threadIdx.x < kWave) finish_partial(p, slot, work, 0.0);
         return;
     }
 
@@ -749,11 +791,11 @@ __global__ __launch_bounds__(kRowsBlock) __attribute__((amdgpu_waves_per_eu(4, 4
     const double wsum = wave_sum(thread_ll);
     if (lane == 0) red[wave] = wsum;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < kWave) {
         double total = 0.0;
 #pragma unroll
         for (int w = 0; w < kRowsWaves; ++w) total += red[w];            // fixed order: run-to-run deterministic
-        p.partials[(int64_t)slot * p.partials_stride + work] = total;
+        finish_partial(p, slot, work, total);
     }
 }
 
@@ -952,7 +994,7 @@ __global__ __launch_bounds__(kBlock) void k_mixture_combo(Mix2Params p) {
         }
     }
     const double total = block_sum(sum0 + sum1, red4);
-    if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + work] = total;
+    if (threadIdx.x < kWave) finish_partial(p, slot, work, total);
 }
 
 // ==========================================================================================
@@ -1036,7 +1078,7 @@ __global__ __launch_bounds__(NW * kWave, 4) void k_mixture_tuple64(Mix2Params p)
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t lane8 = (uint32_t)lane * 8u;
     if ((uint32_t)(uintptr_t)(lds_uchar_t*)lds_raw != 0u) {       // absolute LDS addressing needs base 0
-        if (threadIdx.x == 0) p.partials[(int64_t)slot * p.partials_stride + work] = __longlong_as_double(0x7FF8000000000000ll);
+        if (threadIdx.x < kWave) finish_partial(p, slot, work, __longlong_as_double(0x7FF8000000000000ll));
         return;
     }
     // LDS map (bytes): T [KT][S+1][64] f64 at 0 | weights [P][C][64] f64 at combo_w_off | 4 doubles (reduction)
@@ -1347,14 +1389,14 @@ __global__ __launch_bounds__(NW * kWave, 4) void k_mixture_tuple64(Mix2Params p)
         const double wsum = wave_sum((a0 + a2) + (a1 + a3));
         if (lane == 0) red4[w] = wsum;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (threadIdx.x < kWave) {
             double total = 0.0;
             if (NW == 4) total = (red4[0] + red4[1]) + (red4[2] + red4[3]);
             else {
 #pragma unroll
                 for (int i = 0; i < NW; ++i) total += red4[i];
             }
-            p.partials[(int64_t)slot * p.partials_stride + work] = total;
+            finish_partial(p, slot, work, total);
         }
     }
 }

@@ -43,6 +43,10 @@ struct Mix2Params {
     const double* wpat_t;  int64_t wpat_t_stride;  // per slot [n_ftiles][Pmax*C*FT]
     int wpat_tile_stride;                          // Pmax*C*FT
     double* partials;      int64_t partials_stride;
+    // final reduction inside the kernel (finish_partial): results != nullptr, tickets per slot in arrive[], optional signal
+    double* results;
+    unsigned* arrive;
+    DoneSig done;
     int first_slot;
     const int32_t* slot_list;                      // slots of this launch (n_batch entries), or null: first_slot + i
     // rows kernel (k_mixture_rows): engine tile width of probs_t, canonical per-pattern weights, per-object row offsets
