@@ -103,7 +103,7 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     if (n_objects < 1 || n_features < 1) return fail(nullptr, SBE_ERR_ARG, "empty feature block (%d objects x %d features)", n_objects, n_features);
     if (n_states < 1 || n_states > 254) return fail(nullptr, SBE_ERR_ARG, "n_states=%d unsupported (1..254; state index is one byte, 0xFF = NA)", n_states);
     if (n_components < 1 || n_components > kMaxComponents) return fail(nullptr, SBE_ERR_ARG, "n_components=%d unsupported (1..%d)", n_components, kMaxComponents);
-    if (n_slots < 1 || n_slots > 4096) return fail(nullptr, SBE_ERR_ARG, "n_slots=%d unsupported (1..4096)", n_slots);
+    if (n_slots < 1 || n_slots > 16384) return fail(nullptr, SBE_ERR_ARG, "n_slots=%d unsupported (1..16384)", n_slots);
     int64_t gtot = 0;
     for (int c = 0; c < n_components; ++c) {
         // a component may have no group at all (n_clusters == 0, the confounders-only baseline: the reference's

@@ -5,6 +5,7 @@
 # Outputs under gpurun_out/prof_$TAG/ ; tools/summarize_profiles.py turns them into profiles/.
 set -u
 TAG=${1:-r2}
+ONLY=${2:-all}            # "headline": the headline passes only (the stress shape and the calibration are skipped)
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
@@ -25,6 +26,11 @@ for kern in packed packed_tuple packed_tuple_lds packed_general packed_v2 onehot
     rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2_$kern -- $BENCH --kernel $kern > /dev/null 2>&1
   fi
 done
+if [ "$ONLY" = headline ]; then
+  find $OUT -name '*_kernel_trace.csv' -delete; find $OUT -name '*_agent_info.csv' -delete
+  for f in $(find $OUT -name '*_counter_collection.csv'); do (head -1 $f; grep -E 'k_mixture|read_dword' $f) > $f.tmp && mv $f.tmp $f; done
+  ls $OUT; exit 0
+fi
 # stress shape (HBM/MALL streaming regime): rows kernel (default at B >= 2), the older general kernel, one-hot stream
 for kern in packed packed_v2 onehot; do
   for B in 8 64; do

@@ -60,7 +60,9 @@ corr4 = 1.0 / calib["read_dword"]["reported_fraction"] if "read_dword" in calib 
 corr16 = 1.0 / calib["read_dwordx4"]["reported_fraction"] if "read_dwordx4" in calib else None
 
 traffic = {}
-CASES = [("headline", 2048, k) for k in ("packed", "packed_tuple", "packed_tuple_lds", "packed_general", "packed_v2", "onehot", "onehot_general")] + \
+sys.path.insert(0, str(REPO))
+from bench import HEADLINE_BATCH      # noqa: E402  (the default bench command's states per launch: what profile_gpu.sh ran)
+CASES = [("headline", HEADLINE_BATCH, k) for k in ("packed", "packed_tuple", "packed_tuple_lds", "packed_general", "packed_v2", "onehot", "onehot_general")] + \
         [("stress", b, k) for k in ("packed", "packed_v2", "onehot") for b in (8, 64)]
 for wl, batch, kern in CASES:
         suffix = kern if wl == "headline" else f"stress_{kern}_b{batch}"
@@ -111,9 +113,16 @@ for wl, batch, kern in CASES:
                     summary[f"sq_counters_{wl}_{kern}_b{batch}"].update({"_kernel": ident["kernel"], "_results_sha1": ident["results_sha1"]})
 for f in newest(str(SRC / "trace_stress_packed_unsorted_b64" / "*" / "*_kernel_stats.csv")):
     shutil.copy(f, DST / "kernel_stats_stress_packed_unsorted_b64.csv")
-summary["traffic"] = traffic
+# entries of earlier sessions of this round that this session did not re-measure (another batch size, a pass that was
+# skipped) are kept: every entry names the kernel and the results digest it belongs to
+old = json.loads((DST / "pmc_summary.json").read_text()) if (DST / "pmc_summary.json").exists() else {}
+old_traffic = old.pop("traffic", {})
+summary = {**old, **{k: v for k, v in summary.items() if v}}
+summary["traffic"] = {**old_traffic, **traffic}
 (DST / "pmc_summary.json").write_text(json.dumps(summary, indent=1))
-(REPO / "profiles" / "traffic_latest.json").write_text(json.dumps(
-    {k: {"bytes": round(v["hbm_bytes_per_launch"]), "kernel": v.get("kernel"), "results_sha1": v.get("results_sha1"), "profile": TAG}
-     for k, v in traffic.items()}, indent=1))
+latest_path = REPO / "profiles" / "traffic_latest.json"
+latest = json.loads(latest_path.read_text()) if latest_path.exists() else {}
+latest.update({k: {"bytes": round(v["hbm_bytes_per_launch"]), "kernel": v.get("kernel"), "results_sha1": v.get("results_sha1"), "profile": TAG}
+               for k, v in traffic.items()})
+latest_path.write_text(json.dumps(latest, indent=1))
 print(json.dumps(summary, indent=1)[:6000])
