@@ -904,14 +904,9 @@ int ensure_xt(sbe_engine* e) {
     HIPCHK(e, hipMalloc((void**)&e->d_xt, bytes));
     e->hbm_bytes += (int64_t)bytes;
     HIPCHK(e, hipMemsetAsync(e->d_xt, 0, bytes, e->stream));
-    {   // the kernel's log table: interval centres c_i = 1 + (i + 1/2)/1024 (c_0 = 1), {RN(1/c), RN(-log(RN(1/c)))}
+    {   // the kernel's own log table (tab_log4_n)
         std::vector<double> tab(2 * 1024);
-        for (int i = 0; i < 1024; ++i) {
-            const double c = i == 0 ? 1.0 : 1.0 + (i + 0.5) / 1024;
-            const double inv_c = 1.0 / c;
-            tab[2 * i] = inv_c;
-            tab[2 * i + 1] = i == 0 ? 0.0 : (double)(-logl((long double)inv_c));
-        }
+        fine_log_table(tab.data());
         HIPCHK(e, hipMalloc((void**)&e->d_logtab_fine, tab.size() * sizeof(double)));
         HIPCHK(e, hipMemcpy(e->d_logtab_fine, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     }

@@ -22,6 +22,7 @@
 // 1 KB fully coalesced pieces (fragment order in memory), four k-blocks ahead.  Both operands take their k index from the
 // same (lane half, byte) position, so the product does not depend on the instruction's internal k order.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -66,16 +67,24 @@ void launch_xt_frags(const uint8_t* state, uint8_t* xt, int N, int F, int S, int
 }
 
 // Table-driven log for this kernel's epilogue, G chains interleaved: log v = k ln2 + log c_i + log1p(r), r = m / c_i - 1, with
-// its own FINER table (1024 intervals of the mantissa, kFineLogEntries x {RN(1/c), RN(-log RN(1/c))}, c_0 = 1 so that
-// log 1 = 0 exactly) so that |r| <= 2^-11 (2^-10 in interval 0) and the series stops after r^3: first dropped term r^4 / 4 <=
-// 1.4e-14 (2.3e-13 in interval 0) per log, three orders of magnitude inside what a SUM of O(1) terms needs at 1e-10 relative.
-// v_fma_f64 is the dearest instruction of the epilogue (tools/probe/valu_rates.hip: 6.5 cycles against 4.0 for 32-bit integer
-// work at two waves per SIMD): against the 128-entry / r^5 form this is two FMAs fewer per entry.  The binary exponent is NOT
-// folded in here: it is returned as an integer and summed exactly, count-weighted, by the caller (one v_mad_i32_i24 instead
-// of a conversion and an FMA per entry; k ln2 is applied once per accumulator at the end).
+// its own FINER table (kFineLogEntries = 1024 intervals of the mantissa m in [1, 2): {RN(1/c_i), log c_i}, built by ensure_xt) so
+// that |r| <= 2^-11 (2^-10 in interval 0) and the series stops after r^4: first dropped term r^5 / 5 <= 6e-18 per log (2e-16 in
+// interval 0).  v_fma_f64 is the dearest instruction of the epilogue (tools/probe/valu_rates.hip: 6.5 cycles against 4.0 for
+// 32-bit integer work at two waves per SIMD): against the 128-entry / r^5 form this is one FMA fewer per entry.
+// The binary exponent is NOT folded in here: it is returned as an integer and summed exactly, count-weighted, by the caller (one
+// v_mad_i32_i24 instead of a conversion and an FMA per entry; k ln2 is applied once per accumulator at the end).  So that the
+// two sums never cancel, mantissas from sqrt(2) on (table index >= kFineLogSplit) count as m / 2 with k + 1 -- the exponent comes
+// from hi + kFineLogCarry, which carries exactly there, and their table rows hold log(c_i / 2) -- so a probability in [0.707, 1)
+// has k = 0 and a small negative mantissa part; the centres of the first and the last interval are 1 and 2 (log exactly 0):
+// log 1 = 0 exactly, and for v = 1 - eps the result is log1p(-eps) to 1e-13 relative (a state that every table entry gives
+// probability ~1 has a log-likelihood of ~0, which the reference gets to its own rounding: tools/fuzz_gpu.py checks to
+// 1e-10 relative + 1e-16 per observation, and caught a first form that summed k ln2 and log m apart without the split:
+// 2e-12 off at a log-likelihood of 1e-5).
 constexpr int kFineLogEntries = 1024;
+constexpr int kFineLogSplit = 424;                                        // 1 + 424/1024 = 1.4140625 ~ sqrt(2)
+constexpr uint32_t kFineLogCarry = 0x00100000u - ((uint32_t)kFineLogSplit << 10);
 template <int G>
-__device__ __forceinline__ void tab_log3_n(const double (&v)[G], double (&out)[G], int (&kexp)[G], uint32_t tab) {
+__device__ __forceinline__ void tab_log4_n(const double (&v)[G], double (&out)[G], int (&kexp)[G], uint32_t tab) {
     f64x2_t e[G];
     double m[G], r[G], q[G];
 #pragma unroll
@@ -83,16 +92,30 @@ __device__ __forceinline__ void tab_log3_n(const double (&v)[G], double (&out)[G
         const uint32_t hi = (uint32_t)__double2hiint(v[g]);
         e[g] = *(lds_cf64x2_t*)(uintptr_t)(tab + ((hi >> 6) & 0x3FF0u));        // entry (hi >> 10) & 1023
         m[g] = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), __double2loint(v[g]));
-        kexp[g] = (int)(hi >> 20) - 1023;
+        kexp[g] = (int)((hi + kFineLogCarry) >> 20) - 1023;
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) r[g] = fma(m[g], e[g].x, -1.0);
 #pragma unroll
-    for (int g = 0; g < G; ++g) q[g] = fma(1.0 / 3.0, r[g], -0.5);
+    for (int g = 0; g < G; ++g) q[g] = fma(-0.25, r[g], 1.0 / 3.0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) q[g] = fma(q[g], r[g], -0.5);
 #pragma unroll
     for (int g = 0; g < G; ++g) q[g] = fma(r[g] * r[g], q[g], r[g]);          // log1p(r)
 #pragma unroll
     for (int g = 0; g < G; ++g) out[g] = e[g].y + q[g];
+}
+
+// the table of tab_log4_n (host side: ensure_xt uploads it)
+void fine_log_table(double* tab /* [2 * kFineLogEntries] */) {
+    for (int i = 0; i < kFineLogEntries; ++i) {
+        const long double c = i == 0 ? 1.0L : i == kFineLogEntries - 1 ? 2.0L : 1.0L + (i + 0.5L) / kFineLogEntries;
+        const double inv_c = (double)(1.0L / c);
+        // log of the centre the kernel actually divides by (1 / inv_c), halved from the split on
+        const long double lc = -logl((long double)inv_c) - (i >= kFineLogSplit ? logl(2.0L) : 0.0L);
+        tab[2 * i] = inv_c;
+        tab[2 * i + 1] = (i == 0 || i == kFineLogEntries - 1) ? 0.0 : (double)lc;
+    }
 }
 
 // per (slot of the block, tuple): byte offsets of the tuple's probability rows inside the probs array and of its
@@ -355,7 +378,7 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
             special |= __builtin_amdgcn_class(v, 0x2FF);            // anything but a positive normal double
         }
         int kx[G];
-        tab_log3_n<G>(vv, lg, kx, tab_off);
+        tab_log4_n<G>(vv, lg, kx, tab_off);
         // Rare: a table entry that is not a positive normal number -- the zero probability of an inapplicable state,
         // which no observation falls on (contributes nothing, whatever it is), or of an observed one (log 0 = -inf,
         // like the reference), or corrupt input (library log).

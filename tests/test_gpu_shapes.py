@@ -311,6 +311,48 @@ def test_mfma_kernel_default_choice_and_zero_probability():
         assert np.all(np.isfinite(got[np.arange(B) != 7]))
 
 
+@pytest.mark.parametrize("S", [1, 2])
+def test_mfma_kernel_probabilities_next_to_one(S):
+    """States whose every observation has probability ~1 (a single state per feature; or a second state of probability 1e-7
+    that is never observed): the log-likelihood is ~0 -- the rounding of the float32 weights -- and the parts of a log
+    (exponent, table value, series) must not cancel it away.  Tolerance of tools/fuzz_gpu.py: 1e-10 relative + 1e-16 per
+    observation (found by the fuzzer: a first form of the kernel's own log summed k ln2 and log m apart, 2e-12 off)."""
+    rng = np.random.default_rng(1503 + S)
+    N, F, B = 143, 53, 20
+    n_groups = [1, 1, 3]
+    feats = np.zeros((N, F, S), dtype=bool)
+    feats[..., 0] = rng.random((N, F)) > 0.03
+    na = ~feats.any(-1)
+    conf = rng.integers(0, 3, size=N)
+    groups0 = [np.ones((1, N), dtype=bool), np.ones((1, N), dtype=bool), np.stack([conf == k for k in range(3)])]
+    with Engine(feats, n_groups, n_slots=B) as eng:
+        want = []
+        for b in range(B):
+            a = rng.random(N) < 0.5
+            groups = [a[None, :]] + groups0[1:]
+            probs = []
+            for g in n_groups:
+                p = np.zeros((g, F, S), dtype=np.float32)
+                p[..., 0] = 1.0 if S == 1 else np.float32(1.0) - np.float32(1e-7) * rng.integers(0, 4, size=(g, F)).astype(np.float32)
+                if S == 2:
+                    p[..., 1] = np.float32(1.0) - p[..., 0]
+                probs.append(p)
+            weights = rng.dirichlet(np.ones(3), size=F).astype(np.float32)
+            eng.load_state(b, groups, weights, probs=probs)
+            lh = np.empty((N, F, 3))
+            for c in range(3):                                   # (the reference's composition, SURVEY 8(d), from given tables)
+                orc.compute_component_likelihood(feats, probs[c], groups[c], np.arange(n_groups[c]), lh[..., c])
+            lh[na] = 1.0
+            w = orc.normalize_weights(weights, orc.has_components(groups))
+            want.append(np.log(orc.mixture_observation_lh(w, lh))[~na].sum())
+        want = np.array(want)
+        tol = 1e-10 * np.abs(want) + 1e-16 * N * F
+        for kern in (MIXTURE_PACKED_TUPLE_MFMA, MIXTURE_PACKED_TUPLE):
+            eng.set_option(kernel=kern)
+            got = eng.mixture_loglik_batch(0, B)
+            assert np.all(np.abs(got - want) <= tol), (kern, np.abs(got - want).max(), tol.min(), got[:3], want[:3])
+
+
 @pytest.mark.parametrize("n_split", [1, 2, 3, 5])
 def test_mfma_kernel_final_reduction_in_kernel(n_split, monkeypatch):
     """The matrix-pipe kernel finishes its own reduction: the LAST of a slot group's column-split blocks (tickets) adds the
