@@ -136,7 +136,8 @@ const char* sbe_last_error(const sbe_engine* e);
  *   n_groups[c]: number of groups of mixture component c (c = 0: clusters, K;
  *                c >= 1: confounders, load_data.py:138-184).  0 is allowed (n_clusters == 0, the
  *                confounders-only baseline, sbayes/sampling/initializers.py:357): that component has
- *                empty tables and contributes nothing; at least one component must have a group.  */
+ *                empty tables and contributes nothing; at least one component must have a group.
+ *   n_slots: 1 .. 16384 resident sample states.  */
 int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int n_states,
                int n_components, const int32_t* n_groups, int n_slots,
                const uint8_t* features_onehot /* [N][F][S] bool */);
