@@ -67,7 +67,7 @@ void launch_xt_frags(const uint8_t* state, uint8_t* xt, int N, int F, int S, int
 }
 
 // Table-driven log for this kernel's epilogue, G chains interleaved: log v = k ln2 + log c_i + log1p(r), r = m / c_i - 1, with
-// its own FINER table (kFineLogEntries = 1024 intervals of the mantissa m in [1, 2): {RN(1/c_i), log c_i}, built by ensure_xt) so
+// its own FINER table (kFineLogEntries = 1024 intervals of the mantissa m in [1, 2): {RN(1/c_i) / 2, log c_i}, built by ensure_xt) so
 // that |r| <= 2^-11 (2^-10 in interval 0) and the series stops after r^4: first dropped term r^5 / 5 <= 6e-18 per log (2e-16 in
 // interval 0).  v_fma_f64 is the dearest instruction of the epilogue (tools/probe/valu_rates.hip: 6.5 cycles against 4.0 for
 // 32-bit integer work at two waves per SIMD): against the 128-entry / r^5 form this is one FMA fewer per entry.
@@ -94,16 +94,20 @@ __device__ __forceinline__ void tab_log4_n(const double (&v)[G], double (&out)[G
         m[g] = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), __double2loint(v[g]));
         kexp[g] = (int)((hi + kFineLogCarry) >> 20) - 1023;
     }
+    // log1p(r) to r^4 in s = r / 2 (the table holds 1 / (2 c), so s comes out of the first FMA):
+    //     r - r^2/2 + r^3/3 - r^4/4 = s (2 + s (-2 + s (8/3 - 4 s)))
+    // Every constant but 8/3 is an inline operand, so the chain is five v_fma_f64 and nothing else (the Horner form in r needs
+    // two constants in one instruction: a register move per entry, and a separate r^2 and final add).
 #pragma unroll
-    for (int g = 0; g < G; ++g) r[g] = fma(m[g], e[g].x, -1.0);
+    for (int g = 0; g < G; ++g) r[g] = fma(m[g], e[g].x, -0.5);               // s
 #pragma unroll
-    for (int g = 0; g < G; ++g) q[g] = fma(-0.25, r[g], 1.0 / 3.0);
+    for (int g = 0; g < G; ++g) q[g] = fma(r[g], -4.0, 8.0 / 3.0);
 #pragma unroll
-    for (int g = 0; g < G; ++g) q[g] = fma(q[g], r[g], -0.5);
+    for (int g = 0; g < G; ++g) q[g] = fma(r[g], q[g], -2.0);
 #pragma unroll
-    for (int g = 0; g < G; ++g) q[g] = fma(r[g] * r[g], q[g], r[g]);          // log1p(r)
+    for (int g = 0; g < G; ++g) q[g] = fma(r[g], q[g], 2.0);
 #pragma unroll
-    for (int g = 0; g < G; ++g) out[g] = e[g].y + q[g];
+    for (int g = 0; g < G; ++g) out[g] = fma(r[g], q[g], e[g].y);
 }
 
 // the table of tab_log4_n (host side: ensure_xt uploads it)
@@ -113,7 +117,7 @@ void fine_log_table(double* tab /* [2 * kFineLogEntries] */) {
         const double inv_c = (double)(1.0L / c);
         // log of the centre the kernel actually divides by (1 / inv_c), halved from the split on
         const long double lc = -logl((long double)inv_c) - (i >= kFineLogSplit ? logl(2.0L) : 0.0L);
-        tab[2 * i] = inv_c;
+        tab[2 * i] = 0.5 * inv_c;                              // (exact: the kernel's first FMA yields s = r / 2)
         tab[2 * i + 1] = (i == 0 || i == kFineLogEntries - 1) ? 0.0 : (double)lc;
     }
 }
