@@ -133,8 +133,15 @@ class Likelihood:
         memo = self.__dict__.get("_call_memo")
         if memo is not None and memo[0] is sample and memo[1] is not None:     # (later components of the same __call__)
             return memo[1][int(eng.group_offsets[component]) + np.asarray(groups)]
+        # inside Model.__call__ (likelihood, then prior, of the same sample: sbayes/model/model.py:47-51) the source prior the
+        # prior is about to ask for comes back with the collapsed values: one launch instead of two -- and ONE bind, which then
+        # takes the sample's source rows along
+        sp_cache = None
+        if memo is not None and memo[0] is sample and memo[2]:
+            from . import conditionals
+            sp_cache = conditionals.source_prior_wanted(self.prior, sample)
         try:
-            _bind_slot(eng, self._bind_model, sample, slot)
+            _bind_slot(eng, self._bind_model, sample, slot, with_source=sp_cache is not None)
         except GroupOverlapError:
             # groups that overlap have no resident form; the collapsed likelihood needs none -- it is a function of the
             # count and concentration tables alone (likelihood.py:65-101): the stateless device call
@@ -152,15 +159,7 @@ class Likelihood:
         entry = eng._bound.get(slot) if getattr(eng, "_bound", None) is not None else None
         lh_all = entry.get("lh_all") if entry is not None else None
         if lh_all is None:
-            # inside Model.__call__ (likelihood, then prior, of the same sample: sbayes/model/model.py:47-51) the source
-            # prior the prior is about to ask for comes back with the collapsed values: one launch instead of two
-            sp_cache = None
-            if memo is not None and memo[0] is sample and memo[2]:
-                from . import conditionals
-                sp_cache = conditionals.source_prior_wanted(self.prior, sample)
             if sp_cache is not None:
-                _bind_slot(eng, self._bind_model, sample, slot, with_source=True)
-                entry = eng._bound.get(slot) if getattr(eng, "_bound", None) is not None else None
                 lh_all, per_object = eng.collapsed_and_source_prior(slot)
                 conditionals.store_source_prior_ahead(sp_cache, sample, per_object)
             else:
