@@ -387,6 +387,31 @@ def test_mfma_kernel_final_reduction_in_kernel(n_split, monkeypatch):
         assert eng.mixture_loglik(B - 1) == pytest.approx(got[B - 1], rel=1e-12)
 
 
+def test_many_slots_one_launch():
+    """More resident states than the former limit of 4096 (sbe_create takes up to 16384): one launch over 5000 small states through
+    the matrix-pipe form -- slot groups beyond the 256th, a last group of 8 slots -- equals the vector-pipe form slot by slot."""
+    rng = np.random.default_rng(50)
+    N, F, S, B = 40, 9, 3, 5000
+    feats, groups0, _w, _s, _conc = random_case(rng, N, F, S, [2, 1], 0.02)
+    with Engine(feats, [2, 1], n_slots=B) as eng:
+        a = rng.integers(0, 3, size=N)
+        groups = [np.stack([a == k for k in range(2)])] + groups0[1:]
+        for b in range(0, B, 250):                     # 20 distinct states, copied into the slots between
+            probs = [rng.dirichlet(np.ones(S), size=(2, F)).astype(np.float32), rng.dirichlet(np.ones(S), size=(1, F)).astype(np.float32)]
+            eng.load_state(b, groups, rng.dirichlet(np.ones(2), size=F).astype(np.float32), probs=probs)
+            for k in range(1, 250):
+                eng.copy_slot(b + k, b)
+        eng.set_option(kernel=MIXTURE_PACKED_TUPLE_MFMA)
+        got = eng.mixture_loglik_batch(0, B)
+        assert "k_mixture_tuple_mfma" in eng.last_mixture_kernel()
+        eng.set_option(kernel=MIXTURE_PACKED_TUPLE)
+        ref = eng.mixture_loglik_batch(0, B)
+        np.testing.assert_allclose(got, ref, rtol=1e-12)
+        assert np.array_equal(got.reshape(20, 250), np.repeat(got[::250, None], 250, axis=1))
+    with pytest.raises(EngineError, match="n_slots"):
+        Engine(feats, [2, 1], n_slots=16385)
+
+
 @pytest.mark.parametrize("shape", [
     # N,   F,   S,  groups,        n_slots   (what it exercises in the pattern-sorted rows form)
     (1203, 70,  6,  [4, 1, 5, 3],  20),      # C = 4, 16 patterns possible, ragged last tile (70 = 2 * 32 + 6), runs of every length
