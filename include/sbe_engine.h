@@ -49,12 +49,17 @@ extern "C" {
 
 typedef struct sbe_engine sbe_engine;
 
-#define SBE_ABI_VERSION 5   /* 4 (round 4): + sbe_given_unchanged_gibbs, sbe_host_*; sbe_set_groups rejects overlap;
+#define SBE_ABI_VERSION 6   /* 4 (round 4): + sbe_given_unchanged_gibbs, sbe_host_*; sbe_set_groups rejects overlap;
                                5: + SBE_OPT_FUSE_TABLES, sbe_host_subset_ids, sbe_host_diff_rows, sbe_set_counts_rows_probs,
                                sbe_gibbs_propose, sbe_given_unchanged_gibbs_counts, sbe_test_roundtrip,
                                sbe_collapsed_and_source_prior, sbe_counts_delta_apply,
                                sbe_given_unchanged_gibbs_apply, sbe_gibbs_propose_apply,
-                               sbe_set_slot_delta, sbe_get_counts_all */
+                               sbe_set_slot_delta, sbe_get_counts_all;
+                               6 (round 6): + sbe_get_group_ids, sbe_get_weights, sbe_timer_mark, sbe_timer_elapsed; the
+                               header is split in three: THIS file holds the production surface -- every entry cites
+                               the reference function it serves; sbe_engine_steps.h the one-call MCMC step family (no
+                               caller in the reference, frozen); sbe_engine_diag.h self-tests and measurement hooks.
+                               One library exports all three. */
 
 /* error codes */
 #define SBE_OK 0
@@ -182,6 +187,10 @@ int sbe_likelihood_per_component_exact(sbe_engine* e, int slot, double* out);
  * distinct patterns than the engine holds (min(2^C, 64)) is reported by the next call that reads them. */
 int sbe_set_groups(sbe_engine* e, int slot, int component, const uint8_t* groups /* [G_c][N] bool */);
 int sbe_set_group_ids(sbe_engine* e, int slot, int component, const int32_t* ids /* [N], -1 = none */);
+/* The slot's resident ids of one component read back from the device (a pickled / resumed sample is re-bound from the host
+ * arrays; this is the inverse of sbe_set_group_ids for checkers: bench.py's parity gate rebuilds a slot's state
+ * from what the device holds).  ids_out [N]: group index inside the component, -1 = in no group. */
+int sbe_get_group_ids(sbe_engine* e, int slot, int component, int32_t* ids_out /* [N] */);
 
 /* sbe_set_slot_delta: several state-setting calls of one bind (conditionals._bind_slot: after a rejected step "the old group
  * ids and the old count rows", after a proposal "the new group ids and the new source rows") as ONE launch.  Exactly
@@ -252,6 +261,8 @@ int sbe_get_probs(sbe_engine* e, int slot, int component, float* out /* [G_c][F]
  * normalised tables on the device from the slot's has_components. */
 int sbe_set_weights(sbe_engine* e, int slot, const float* weights /* [F][C] */);
 int sbe_get_weights_normalized(sbe_engine* e, int slot, float* out /* [N][F][C] */);
+/* the slot's resident mixture weights as set (Sample.weights.value, sbayes/sampling/state.py:546): float32 [F][C] */
+int sbe_get_weights(sbe_engine* e, int slot, float* out /* [F][C] */);
 
 /* ---- a3: likelihood_per_component (sbayes/sampling/conditionals.py:152-223) -------------
  * Dense float64 [N][F][C] from the slot's groups + probs; NA observations <- 1, objects in
@@ -509,8 +520,6 @@ int sbe_source_logprob(sbe_engine* e, int slot, int src_slot, const int32_t* obj
                        float* p_selected_out /* [n_sub][F] or NULL */);
 int sbe_set_rng(sbe_engine* e, uint64_t seed, uint64_t draw);
 int sbe_get_rng(sbe_engine* e, uint64_t* seed, uint64_t* draw);
-/* test hook: out[i][0..4) = philox4x32_10(counter = ctr_key[i][0..4), key = ctr_key[i][4..6)) */
-int sbe_test_philox(sbe_engine* e, const uint32_t* ctr_key /* [n][6] */, int n, uint32_t* out /* [n][4] */);
 int sbe_subset_lh(sbe_engine* e, const int32_t* objects, int n_sub, int n_comp, const float* tables,
                   const int32_t* table_offsets /* [n_comp] */, int n_tables_total,
                   const int32_t* group_idx /* [n_comp][n_sub] */, double temperature,
@@ -530,84 +539,6 @@ int sbe_collapsed_and_source_prior(sbe_engine* e, int slot, double* per_group_ou
                                    double* per_object_out /* [N] */);
 int sbe_observation_lh_exact(sbe_engine* e, int slot, double* out /* [N][F] */);
 
-/* ---- one MCMC step in one call (resident flow) ---------------------------
- * Builds the candidate state in `cand_slot` from `cur_slot` plus the proposed delta and evaluates it:
- *   clusters        bool [K][N] of the candidate, or NULL if the clusters did not change
- *   changed_objects / source_rows  the objects whose source assignment changed and their bool
- *                   rows [n_changed][F][C]
- *   weights         float32 [F][C], or NULL if unchanged
- * On the device: slot copy, id / source-row update, delta update of the feature counts
- * (counts.py:55-95), probability tables of every component (conditionals.py:175-204), collapsed
- * per-group log-likelihoods (likelihood.py:65-101) and the fused mixture log-likelihood
- * (SURVEY.md 8(d)).  One PCIe round trip, one stream synchronisation.
- *   group_logliks_out  float64 [G_total] (Likelihood.__call__ = their sum)
- *   mixture_out        float64 scalar
- *   changed_groups_out bool [G_total] (may be NULL): groups whose counts changed
- * The caller accepts by swapping the roles of the two slots, rejects by doing nothing. */
-int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters,
-             const int32_t* changed_objects, int n_changed, const uint8_t* source_rows,
-             const float* weights, double* group_logliks_out, double* mixture_out,
-             uint8_t* changed_groups_out);
-
-/* ---- batched multi-chain step: one sbe_step for each of n_chains independent chains, in ONE call ------------------
- * The reference steps its chains one after the other in one Python loop (MCMC.generate_samples,
- * sbayes/sampling/mcmc.py:237-241; MC3 workers, sbayes/mcmc_setup.py:528-534); chains are independent, so their
- * candidates are built by one launch (chain <-> blockIdx.y), evaluated by one launch of the fused mixture kernel over
- * the candidate slots and finished by one reduction launch: one synchronisation per batch, the per-chain host work
- * spread over a few worker threads.  Chain i: current slot cur_slots[i], candidate slot cand_slots[i] (all distinct).
- *   clusters       bool [n_chains][K][N] (chain i's block is read iff clusters_mask == NULL or clusters_mask[i] != 0),
- *                  or NULL: no chain changes its clusters
- *   rows_ptr       [n_chains + 1], rows_ptr[0] = 0: chain i's changed objects are changed_objects[rows_ptr[i] ..
- *                  rows_ptr[i+1]) and its rows source_rows[rows_ptr[i] ..) (bool [.][F][C]); at most 256 per chain
- *   weights        float32 [n_chains][F][C] (read iff weights_mask == NULL or weights_mask[i] != 0), or NULL
- *   out            group_logliks_out float64 [n_chains][G_total], mixture_out float64 [n_chains],
- *                  changed_groups_out bool [n_chains][G_total] (may be NULL)
- * Same numbers as n_chains calls of sbe_step (bit for bit for counts, tables and per-group values; the mixture scalar to
- * rounding: its block geometry depends on the launch's batch size).  Accept = swap a chain's two slots, reject = nothing.
- * Host side: the chains' payloads are packed into one pinned block by a pool of worker threads (8 including the caller;
- * environment SBE_STEP_THREADS) and sent with one copy; from 128 chains on the batch runs as two pipelined parts
- * (SBE_STEP_PARTS).  The workers poll for ~400 us after a call before they block, so consecutive sweeps find them awake:
- * keep the thread count below the number of free cores.  SBE_STEP_TIMING=1 prints the call's phase times to stderr. */
-int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const int32_t* cand_slots,
-                   const uint8_t* clusters, const uint8_t* clusters_mask, const int32_t* rows_ptr,
-                   const int32_t* changed_objects, const uint8_t* source_rows, const float* weights,
-                   const uint8_t* weights_mask, double* group_logliks_out, double* mixture_out,
-                   uint8_t* changed_groups_out);
-
-/* The single-chain step with the proposal in delta form (see sbe_step_batch_delta below): moved objects + their new
- * cluster (-1: none), changed source rows.  Falls back to sbe_step internally when the two slots' records do not allow
- * patching, and when an object is listed more than once in either list (the last entry of a repeated object wins, as in
- * the matrix form).  Outputs as sbe_step. */
-int sbe_step_delta(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* moved_objects, const int32_t* moved_cluster,
-                   int n_moved, const int32_t* changed_objects, int n_changed, const uint8_t* source_rows /* [n_changed][F][C] bool */,
-                   const float* weights /* [F][C] or NULL */, double* group_logliks_out /* [G_total] */, double* mixture_out,
-                   uint8_t* changed_groups_out /* [G_total] or NULL */);
-
-/* The same batched step with the proposals in DELTA form (round 3; what an MCMC operator actually produces): per chain
- * the objects that change cluster with their new cluster index (-1: leaves every cluster; CSR by moved_ptr) and the
- * objects whose source rows change (CSR by rows_ptr).  Within a chain every object may be listed ONCE in moved_objects
- * and ONCE in changed_objects: a repeated entry fails with SBE_ERR_ARG ("chain i: object n listed twice in ...") -- a
- * patch applied twice is not the last-wins result of the matrix form.  A chain's two slots differ only in what its last
- * step changed, so the candidate is built by patching -- host mirror, device id arrays, source rows -- in O(delta): no
- * [K][N] matrix is scanned, no slot state copied, no [N]-sized array packed or sent.  Chains whose slots were touched
- * by another call since their last step (or that step for the first time), and steps that change the SET of
- * has_components patterns or overflow the tuple table, run through sbe_step_batch internally; results are the same
- * (counts, tables, per-group values, flags bit for bit; the mixture scalar to rounding).  Outputs as sbe_step_batch. */
-int sbe_step_batch_delta(sbe_engine* e, int n_chains, const int32_t* cur_slots, const int32_t* cand_slots,
-                         const int32_t* moved_ptr /* [n_chains + 1] */, const int32_t* moved_objects,
-                         const int32_t* moved_cluster, const int32_t* rows_ptr /* [n_chains + 1] */,
-                         const int32_t* changed_objects, const uint8_t* source_rows /* [total][F][C] bool */,
-                         const float* weights /* [n_chains][F][C] or NULL */, const uint8_t* weights_mask /* [n_chains] or NULL */,
-                         double* group_logliks_out /* [n_chains][G_total] */, double* mixture_out /* [n_chains] */,
-                         uint8_t* changed_groups_out /* [n_chains][G_total] or NULL */);
-
-/* One MCMC step of the Gibbs source operator on the resident state (GibbsSampleSource._propose,
-   sbayes/sampling/operators.py:495-552, + the likelihoods the MH ratio needs): candidate slot = current slot with the
-   source of the listed objects redrawn from its posterior on the device (z: the caller's uniforms [n_sub][F], drawn
-   where sample_categorical, preprocessing.py:248, draws them; NULL: the engine's Philox stream), count delta and
-   tables follow on the device.  Out: log_q, log_q_back (fp64 sums of the logs of the float32 probabilities), the
-   candidate's collapsed per-group log-likelihoods [G_total], its mixture log-likelihood, changed-group flags
-   [G_total] (may be NULL).  One synchronisation; nothing of the sample state crosses PCIe. */
 /* GibbsSampleSource._propose (sbayes/sampling/operators.py:495-552) for the drop-in layer, in one call: the device chain
    of sbe_gibbs_step -- draw into the candidate slot with the caller's uniforms z [n_sub][F], the rest of the slot, count
    delta, tables, backward probabilities -- and what the reference's sample bookkeeping needs of it: src_new_out [n_sub][F]
@@ -631,39 +562,9 @@ int sbe_gibbs_propose(sbe_engine* e, int cur_slot, int cand_slot, const int32_t*
 int sbe_gibbs_propose_apply(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* objects, int n_sub, double temperature,
                       double prior_temperature, int from_prior, const double* z, uint8_t* src_new_out, float* sel_out,
                       float* sel_back_out, int32_t* touched_out, int32_t* n_touched_out, float* diff_rows_out);
-int sbe_gibbs_step(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* objects, int n_sub, double temperature,
-                   double prior_temperature, int from_prior, const double* z, double* log_q_out,
-                   double* log_q_back_out, double* group_logliks_out, double* mixture_out,
-                   uint8_t* changed_groups_out);
-
-/* ---- self-test hook: fp64 log used by the group-tuple table build vs the device library's log ---- */
-int sbe_test_fast_log(sbe_engine* e, const double* in, int n, double* out_fast, double* out_lib);
-/* table-driven fp64 log of k_mixture_tuple64's table build (error <= 1 ulp + 2^-53 absolute) */
-int sbe_test_tab_log(sbe_engine* e, const double* in, int n, double* out);
-/* the floor of a host-synchronous call: an empty kernel of n_blocks blocks that (mode bit 0) reads one word of the
-   host-mapped input block and (bit 1) stores one double per block to the host-mapped result block, completion by flag */
-int sbe_test_roundtrip(sbe_engine* e, int n_blocks, int mode);
-/* lgamma of the Dirichlet-categorical terms (recurrence + Stirling series; a8, util.py:39-45, 1373-1394) */
-int sbe_test_lgamma(sbe_engine* e, const double* in, int n, double* out);
 
 /* ---- slot management -------------------------------------------------------------------- */
 int sbe_copy_slot(sbe_engine* e, int dst_slot, int src_slot);
-
-/* ---- measurement support (bench.py): HIP events on the engine's own stream -------------- */
-int sbe_timer_start(sbe_engine* e);
-int sbe_timer_stop(sbe_engine* e, float* elapsed_ms);
-/* Times `iters` back-to-back launches of the fused mixture kernel sequence on slots
- * [first_slot, first_slot+n) with one HIP event pair per launch sequence; returns the sum and
- * the per-launch average of the dominant kernel's duration in milliseconds. */
-/* Event timing of the dominant kernel INSIDE the caller's own loop: enable = 1 starts recording one HIP event pair
-   (on the engine's stream) around the fused kernel of every sbe_mixture_loglik[_batch[_async]] call; 2 pauses and
-   3 resumes without forgetting the recorded pairs (so that only some launches of a loop are bracketed); enable = 0
-   stops, synchronises and returns the number of recorded launches and their average duration. */
-int sbe_kernel_timing(sbe_engine* e, int enable, int* n_launches, float* main_kernel_avg_ms);
-/* name and form of the kernel the most recent fused-kernel launch ran (static string owned by the engine) */
-const char* sbe_last_mixture_kernel(const sbe_engine* e);
-int sbe_profile_mixture(sbe_engine* e, int first_slot, int n, int iters, float* total_ms,
-                        float* main_kernel_avg_ms);
 
 #ifdef __cplusplus
 }

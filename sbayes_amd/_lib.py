@@ -1,4 +1,5 @@
-"""ctypes binding of the C-ABI engine library (include/sbe_engine.h).
+"""ctypes binding of the C-ABI engine library (include/sbe_engine.h: the drop-in boundary; sbe_engine_steps.h: the one-call
+step family, no caller in the reference; sbe_engine_diag.h: self-tests and measurement hooks -- one library exports all three).
 
 The product has NO CPU fallback: if the HIP library is missing or no GPU is usable the
 loader / sbe_create raise -- nothing silently routes around the device."""
@@ -9,7 +10,7 @@ import os
 from pathlib import Path
 
 LIB_NAME = "libsbe_engine.so"
-ABI_VERSION = 5                    # SBE_ABI_VERSION of include/sbe_engine.h
+ABI_VERSION = 6                    # SBE_ABI_VERSION of include/sbe_engine.h
 _LIB = None
 
 c_engine_p = ct.c_void_p
@@ -30,7 +31,7 @@ class SbeInfo(ct.Structure):
     ]
 
 
-# name -> (restype, argtypes); mirrors include/sbe_engine.h one to one
+# name -> (restype, argtypes); mirrors the three headers under include/ one to one
 PROTOTYPES = {
     "sbe_abi_version": (ct.c_int, []),
     "sbe_device_count": (ct.c_int, [ct.POINTER(ct.c_int)]),
@@ -47,6 +48,8 @@ PROTOTYPES = {
     "sbe_likelihood_per_component_exact": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
     "sbe_set_groups": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
     "sbe_set_group_ids": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
+    "sbe_get_group_ids": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_void_p]),
+    "sbe_get_weights": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
     "sbe_set_source": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p]),
     "sbe_set_source_rows": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),
     "sbe_get_source_rows": (ct.c_int, [c_engine_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]),
@@ -151,6 +154,8 @@ PROTOTYPES = {
     "sbe_copy_slot": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int]),
     "sbe_timer_start": (ct.c_int, [c_engine_p]),
     "sbe_timer_stop": (ct.c_int, [c_engine_p, ct.POINTER(ct.c_float)]),
+    "sbe_timer_mark": (ct.c_int, [c_engine_p]),
+    "sbe_timer_elapsed": (ct.c_int, [c_engine_p, ct.POINTER(ct.c_float)]),
     "sbe_kernel_timing": (ct.c_int, [c_engine_p, ct.c_int, ct.POINTER(ct.c_int), ct.POINTER(ct.c_float)]),
     "sbe_last_mixture_kernel": (ct.c_char_p, [c_engine_p]),
     "sbe_profile_mixture": (ct.c_int, [c_engine_p, ct.c_int, ct.c_int, ct.c_int, ct.POINTER(ct.c_float),

@@ -501,6 +501,21 @@ int sbe_set_group_ids(sbe_engine* e, int slot, int component, const int32_t* ids
     return set_gid_common(e, slot, component, ids);
 }
 
+int sbe_get_group_ids(sbe_engine* e, int slot, int component, int32_t* ids_out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_COMP(e, component); CHECK_PTR(e, ids_out);
+    HIPCHK(e, hipSetDevice(e->device));
+    Slot& s = e->slots[slot];
+    if (!s.groups_set) return fail(e, SBE_ERR_STATE, "slot %d: groups not set", slot);
+    if (s.gid_pending) { int rc = upload_patterns_and_weights(e, slot); if (rc) return rc; }
+    // what the DEVICE holds (not the host mirror): the ids every resident kernel reads
+    std::vector<uint16_t> ids((size_t)e->N);
+    int rc = d2h(e, ids.data(), e->d_gid + ((int64_t)slot * e->C + component) * e->Np, ids.size() * sizeof(uint16_t));
+    if (rc) return rc;
+    const int off = e->goff[component];
+    for (int n = 0; n < e->N; ++n) ids_out[n] = ids[n] == kNoGroup ? -1 : (int32_t)ids[n] - off;
+    return SBE_OK;
+}
+
 // ---- source -----------------------------------------------------------------------------------
 int sbe_set_source(sbe_engine* e, int slot, const uint8_t* source) {
     CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, source);
@@ -796,6 +811,13 @@ int sbe_set_weights(sbe_engine* e, int slot, const float* weights) {
     if (rc) return rc;
     e->slots[slot].weights_set = true;
     return SBE_OK;
+}
+
+int sbe_get_weights(sbe_engine* e, int slot, float* out) {
+    CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, out);
+    if (!e->slots[slot].weights_set) return fail(e, SBE_ERR_STATE, "slot %d: weights not set", slot);
+    HIPCHK(e, hipSetDevice(e->device));
+    return d2h(e, out, e->d_weights + (int64_t)slot * e->F * e->C, (size_t)e->F * e->C * sizeof(float));
 }
 
 int sbe_get_weights_normalized(sbe_engine* e, int slot, float* out) {
@@ -1095,6 +1117,19 @@ int sbe_timer_start(sbe_engine* e) {
 int sbe_timer_stop(sbe_engine* e, float* elapsed_ms) {
     CHECK_ENGINE(e); CHECK_PTR(e, elapsed_ms);
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+    HIPCHK(e, hipEventSynchronize(e->ev1));
+    HIPCHK(e, hipEventElapsedTime(elapsed_ms, e->ev0, e->ev1));
+    return SBE_OK;
+}
+
+int sbe_timer_mark(sbe_engine* e) {
+    CHECK_ENGINE(e);
+    HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+    return SBE_OK;
+}
+
+int sbe_timer_elapsed(sbe_engine* e, float* elapsed_ms) {
+    CHECK_ENGINE(e); CHECK_PTR(e, elapsed_ms);
     HIPCHK(e, hipEventSynchronize(e->ev1));
     HIPCHK(e, hipEventElapsedTime(elapsed_ms, e->ev0, e->ev1));
     return SBE_OK;

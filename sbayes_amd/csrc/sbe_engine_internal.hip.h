@@ -12,6 +12,8 @@
 // slot's state stay resident in HBM; only small tables / id vectors cross PCIe per call.
 #include "sbe_kernels.hip.h"
 #include "../../include/sbe_engine.h"
+#include "../../include/sbe_engine_steps.h"
+#include "../../include/sbe_engine_diag.h"
 #include "sbe_host_helpers.h"   // marshalling helpers shared with the CPython extension (plain C)
 #include "sbe_pool.h"          // host worker threads of sbe_step_batch (plain C++: also built under ThreadSanitizer)
 
@@ -901,17 +903,30 @@ int ensure_xt(sbe_engine* e) {
     if (e->d_xt) return SBE_OK;
     const int NT = div_up((int64_t)e->F * e->S, 32), KBp = round_up(div_up(e->N, 32), 4);
     const size_t bytes = ((size_t)(NT + 1) * KBp + 4) * 1024;
-    HIPCHK(e, hipMalloc((void**)&e->d_xt, bytes));
-    e->hbm_bytes += (int64_t)bytes;
-    HIPCHK(e, hipMemsetAsync(e->d_xt, 0, bytes, e->stream));
-    {   // the kernel's own log table (tab_log4_n)
-        std::vector<double> tab(2 * 1024);
+    // built into locals and published only when every step has succeeded: a caller that catches the first
+    // error and retries gets the same error again, never a launch with half of this in place
+    uint8_t* xt = nullptr;
+    double2* logtab = nullptr;
+    auto build = [&]() -> int {
+        HIPCHK(e, hipMalloc((void**)&xt, bytes));
+        HIPCHK(e, hipMemsetAsync(xt, 0, bytes, e->stream));
+        std::vector<double> tab(2 * 1024);               // the kernel's own log table (tab_log4_n)
         fine_log_table(tab.data());
-        HIPCHK(e, hipMalloc((void**)&e->d_logtab_fine, tab.size() * sizeof(double)));
-        HIPCHK(e, hipMemcpy(e->d_logtab_fine, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(e, hipMalloc((void**)&logtab, tab.size() * sizeof(double)));
+        HIPCHK(e, hipMemcpy(logtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        launch_xt_frags(e->d_state, xt, e->N, e->F, e->S, e->Fp, NT, KBp, e->stream);
+        HIPCHK(e, hipGetLastError());
+        return SBE_OK;
+    };
+    const int rc = build();
+    if (rc) {
+        (void)hipStreamSynchronize(e->stream);
+        if (xt) (void)hipFree(xt);
+        if (logtab) (void)hipFree(logtab);
+        return rc;
     }
-    launch_xt_frags(e->d_state, e->d_xt, e->N, e->F, e->S, e->Fp, NT, KBp, e->stream);
-    HIPCHK(e, hipGetLastError());
+    e->d_xt = xt; e->d_logtab_fine = logtab;
+    e->hbm_bytes += (int64_t)bytes;
     e->xt_NT = NT; e->xt_KBp = KBp; e->xt_bytes = bytes;
     return SBE_OK;
 }
@@ -935,9 +950,11 @@ MfmaGeom mfma_geometry(const sbe_engine* e, int n, int KT) {
     int n_split = std::max(1, std::min(div_up(NT, 16), e->compute_units / std::max(1, groups)));
     if (const char* env = getenv("SBE_MFMA_SPLIT")) { if (atoi(env) > 0) n_split = std::min(atoi(env), NT); }   // experiments
     g.nt_per_split = round_up(div_up(NT, n_split), 2);
-    // (the kernel sums count * binary exponent in 32-bit integers, one accumulator per lane and slot: a lane sees one column
-    //  per pass of 16 tiles, a column's counts add up to at most N)
-    if ((int64_t)div_up(g.nt_per_split, 16) * e->N * 1100 >= ((int64_t)1 << 31)) return g;
+    // (the kernel sums count * binary exponent in 32-bit integers, one accumulator per lane and slot: in a pass of 16 tiles a
+    //  lane adds the entries of its kTupleMfmaColsPerPass columns -- over every M tile and both tuples of a tile -- into the
+    //  same accumulator, and a slot's counts of ONE column add up to at most N over its tuples; |exponent| <= 1100 covers
+    //  every double, the product of two float32 values stays above 2^-300)
+    if ((int64_t)div_up(g.nt_per_split, 16) * kTupleMfmaColsPerPass * e->N * 1100 >= ((int64_t)1 << 31)) return g;
     g.n_split = div_up(NT, g.nt_per_split);
     return g;
 }
@@ -964,7 +981,9 @@ int launch_mfma_form(sbe_engine* e, int first_slot, int n, int KT, const MfmaGeo
     p.logtab = e->d_logtab_fine;
     p.partials = e->d_partials; p.partials_stride = e->partials_stride;
     if (reduce_in_kernel) { p.results = e->d_results; p.arrive = e->d_arrive; p.done = done; }
-    launch_tuple_mfma(e->C, p, dim3((unsigned)(div_up(n, 16) * mg.n_split)), mg.lds, e->stream);
+    if (!launch_tuple_mfma(e->C, p, dim3((unsigned)(div_up(n, 16) * mg.n_split)), mg.lds, e->stream))
+        return fail(e, SBE_ERR_STATE, "k_mixture_tuple_mfma was built with static LDS: its log table must sit at LDS address 0 "
+                                      "(toolchain change; rebuild without static __shared__ in sbe_mixture_mfma.hip)");
     return SBE_OK;
 }
 

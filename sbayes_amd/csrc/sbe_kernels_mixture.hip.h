@@ -30,6 +30,14 @@ namespace sbe {
 // writes the result; p.done (optional) is signalled by those blocks, one per slot.  The partial sums travel as agent-scope
 // atomic stores / loads ordered by s_waitcnt around the ticket: coherent across the XCDs' L2s without a release fence (which
 // writes the whole L2 back -- measured on the matrix-pipe form, profiles/r5/mfma_kernel_experiments_session2.log).
+// MEMORY-MODEL NOTE: every access below is "relaxed"; there is no release / acquire pair of the HIP / LLVM memory
+// model here.  The order store -> s_waitcnt vmcnt(0) -> ticket RMW -> (last block) loads holds in hardware on gfx942 / gfx950:
+// agent-scope atomic stores are sc1 write-through and acknowledged at the coherence point the XCDs share, agent-scope atomic
+// loads bypass the reader's own L2.  Other targets are refused at compile time; SBE_REDUCE_IN_KERNEL=0 selects the two-launch
+// form with no such assumption (kept exercised by tests/test_gpu_shapes.py).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "finish_partial orders relaxed agent-scope atomics by s_waitcnt (gfx942 / gfx950 cache behaviour); not valid for this target"
+#endif
 __device__ __forceinline__ void finish_partial(const Mix2Params& p, int slot, int work, double total) {
     const int lane = threadIdx.x & (kWave - 1);
     double* const my = p.partials + (int64_t)slot * p.partials_stride;

@@ -105,6 +105,8 @@ void launch_state_s(const uint8_t* state, uint8_t* state_s, int N, int F, int Fp
 void launch_xt_frags(const uint8_t* state, uint8_t* xt, int N, int F, int S, int Fp, int NT, int KBp, hipStream_t st);
 size_t tuple_mfma_lds_bytes(int MT, int C, int KBp);
 void fine_log_table(double* tab);                 // [2 * 1024] {1/c, log c} of k_mixture_tuple_mfma's log (sbe_mixture_mfma.hip)
-void launch_tuple_mfma(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st);
+// false (nothing launched): an instance of the kernel carries static LDS, so its dynamic block does not start at address 0
+bool launch_tuple_mfma(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st);
+constexpr int kTupleMfmaColsPerPass = 2;          // column tiles a wave of k_mixture_tuple_mfma owns per pass (= columns per lane)
 
 }  // namespace sbe

@@ -28,6 +28,10 @@
 
 #include "sbe_mixture.hip.h"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "sbe_mixture_mfma.hip: the in-kernel final reduction orders relaxed agent-scope atomics by s_waitcnt (gfx942 / gfx950 cache behaviour); not valid for this target"
+#endif
+
 namespace sbe {
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -37,7 +41,7 @@ typedef __attribute__((address_space(3))) const v4i_t lds_cv4i_t;
 constexpr int kMfmaWaves = 8;
 constexpr int kMfmaThreads = kMfmaWaves * kWave;
 constexpr int kMfmaSlots = 16;          // slots per block
-constexpr int kMfmaRN = 2;              // column tiles per wave pass
+constexpr int kMfmaRN = kTupleMfmaColsPerPass;   // column tiles per wave pass (2; the host's overflow bound uses the same constant)
 // (Other block shapes were measured in round 5 and lost: 16 waves x 1 column tile at 128 registers, +9 %; 8 waves x 1 tile with
 //  the next tile's MFMAs issued inside the epilogue, +7 %: profiles/r5/mfma_kernel_experiments_session2.log.)
 
@@ -456,6 +460,12 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
         if (my_slot >= 0) my_partials[split] = total;
         return;
     }
+    // MEMORY-MODEL NOTE: what follows is NOT a release / acquire pair of the HIP / LLVM memory model.  It rests on
+    // gfx942 / gfx950 behaviour: an agent-scope atomic store is issued sc1 write-through and is acknowledged (vmcnt) only at
+    // the coherence point shared by the XCDs; an agent-scope atomic load bypasses the reader XCD's L2.  So store -> s_waitcnt
+    // vmcnt(0) -> ticket RMW -> (last block) loads is ordered in hardware although every access is "relaxed".  Another
+    // target must not compile this (the #error at the top of the unit); SBE_REDUCE_IN_KERNEL=0 takes the fence-free
+    // two-launch form, which tests/test_gpu_shapes.py::test_mfma_kernel_final_reduction_in_kernel keeps exercised.
     // The group's last block adds the partial sums (fixed order: run-to-run deterministic whichever block that is).  The
     // partial sums travel as agent-scope atomic stores / loads (write-through, coherent across the XCDs' L2s) ordered by
     // s_waitcnt around the ticket: a release FENCE at agent scope writes the whole L2 back -- every wave doing that cost 26 us
@@ -498,21 +508,28 @@ static void launch_mfma_mt(int C, const MfmaMixParams& p, dim3 grid, size_t lds,
     }
 }
 
-// one-time: the kernels ask for up to the whole 160 KB of a CU's LDS
+// one-time: the kernels ask for up to the whole 160 KB of a CU's LDS.  The log table's index is its whole LDS address
+// (tab_off = 0), which holds only while the kernel has NO static LDS: checked here, once, on the host -- the guard inside the
+// kernel would store NaNs but not take its completion tickets, and a host-synchronous caller would wait for them.
 template <int MT, int CT>
-static void allow_lds() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mixture_tuple_mfma<MT, CT, mfma_gt<MT, CT>()>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+static bool allow_lds() {
+    const void* fn = reinterpret_cast<const void*>(&k_mixture_tuple_mfma<MT, CT, mfma_gt<MT, CT>()>);
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncAttributes attr{};
+    if (hipFuncGetAttributes(&attr, fn) != hipSuccess) { (void)hipGetLastError(); return true; }   // (not answerable: the kernel's own guard stays)
+    return attr.sharedSizeBytes == 0;
 }
 
-void launch_tuple_mfma(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st) {
-    static const bool once = [] {
-        allow_lds<1, 1>(); allow_lds<1, 2>(); allow_lds<1, 3>(); allow_lds<1, 4>();
-        allow_lds<2, 1>(); allow_lds<2, 2>(); allow_lds<2, 3>(); allow_lds<2, 4>();
-        allow_lds<3, 1>(); allow_lds<3, 2>(); allow_lds<3, 3>(); allow_lds<3, 4>();
-        allow_lds<4, 1>(); allow_lds<4, 2>(); allow_lds<4, 3>(); allow_lds<4, 4>();
-        return true;
+bool launch_tuple_mfma(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st) {
+    static const bool no_static_lds = [] {
+        bool ok = true;
+        ok &= allow_lds<1, 1>(); ok &= allow_lds<1, 2>(); ok &= allow_lds<1, 3>(); ok &= allow_lds<1, 4>();
+        ok &= allow_lds<2, 1>(); ok &= allow_lds<2, 2>(); ok &= allow_lds<2, 3>(); ok &= allow_lds<2, 4>();
+        ok &= allow_lds<3, 1>(); ok &= allow_lds<3, 2>(); ok &= allow_lds<3, 3>(); ok &= allow_lds<3, 4>();
+        ok &= allow_lds<4, 1>(); ok &= allow_lds<4, 2>(); ok &= allow_lds<4, 3>(); ok &= allow_lds<4, 4>();
+        return ok;
     }();
-    (void)once;
+    if (!no_static_lds) return false;
     const int MT = (p.KT + 1) / 2;
     switch (MT) {
         case 1: launch_mfma_mt<1>(C, p, grid, lds, st); break;
@@ -520,6 +537,7 @@ void launch_tuple_mfma(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hip
         case 3: launch_mfma_mt<3>(C, p, grid, lds, st); break;
         default: launch_mfma_mt<4>(C, p, grid, lds, st); break;
     }
+    return true;
 }
 
 }  // namespace sbe

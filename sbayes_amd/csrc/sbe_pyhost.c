@@ -268,16 +268,8 @@ static PyObject* py_add_rows_many(PyObject* self, PyObject* args) {
     const Py_ssize_t row_elems = (!unsupported && k > 0) ? vr.shape[1] * vr.shape[2] : 0;
     const int* t = (const int*)vt.buf;
     const float* r = (const float*)vr.buf;
-    /* pass 1: every node must be in the expected form BEFORE anything is changed */
-    for (Py_ssize_t c = 0; c < C && !unsupported; ++c) {
-        PyObject* node = PyList_GET_ITEM(nodes, c);
-        PyObject* val = PyObject_GetAttr(node, s__value);
-        PyObject* gv = val ? PyObject_GetAttr(node, s_group_versions) : NULL;
-        PyObject* ver = gv ? PyObject_GetAttr(node, s_version) : NULL;
-        if (!val || !gv || !ver || !PyLong_Check(ver) || !PyObject_HasAttr(node, s_shared)) { PyErr_Clear(); unsupported = 1; }
-        Py_XDECREF(val); Py_XDECREF(gv); Py_XDECREF(ver);
-    }
     if (unsupported) { result = Py_None; Py_INCREF(result); goto done; }
+    /* component c owns touched[bounds[c] .. bounds[c + 1]) */
     result = PyList_New(C + 1);
     if (!result) goto done;
     {
@@ -290,6 +282,41 @@ static PyObject* py_add_rows_many(PyObject* self, PyObject* args) {
             PyList_SET_ITEM(result, c, b);
         }
     }
+    /* pass 1: EVERY node must be in the expected form -- attributes, buffer dtype / contiguity / shape, group indices in range --
+       BEFORE anything is changed (a node in another form sends the whole call down the Python route; no component is
+       ever left half-applied).  resolve_sharing() replaces _value by a copy of the same form, so the check holds for pass 2. */
+    for (Py_ssize_t c = 0; c < C && !unsupported; ++c) {
+        PyObject* node = PyList_GET_ITEM(nodes, c);
+        const Py_ssize_t lo = PyLong_AsSsize_t(PyList_GET_ITEM(result, c)), hi = PyLong_AsSsize_t(PyList_GET_ITEM(result, c + 1));
+        long long o = 0; off_at(&vo, c, &o);
+        PyObject* val = PyObject_GetAttr(node, s__value);
+        PyObject* gv = val ? PyObject_GetAttr(node, s_group_versions) : NULL;
+        PyObject* ver = gv ? PyObject_GetAttr(node, s_version) : NULL;
+        if (!val || !gv || !ver || !PyLong_Check(ver) || !PyObject_HasAttr(node, s_shared) || !PyObject_HasAttr(val, s_flags)) { PyErr_Clear(); unsupported = 1; }
+        if (!unsupported) {
+            Py_buffer bv, bg;
+            if (PyObject_GetBuffer(val, &bv, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) { PyErr_Clear(); unsupported = 1; }
+            else {
+                if (PyObject_GetBuffer(gv, &bg, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT | PyBUF_WRITABLE) != 0) { PyErr_Clear(); unsupported = 1; }
+                else {
+                    const char gf = bg.format ? bg.format[strlen(bg.format) - 1] : 0;
+                    const int form_ok = bv.ndim == 3 && bv.itemsize == 4 && bv.format && bv.format[strlen(bv.format) - 1] == 'f' &&
+                                        (hi == lo || bv.shape[1] * bv.shape[2] == row_elems) && bg.ndim == 1 && bg.itemsize == 8 &&
+                                        bg.shape[0] == bv.shape[0] && (gf == 'd' || gf == 'l' || gf == 'q');
+                    if (!form_ok) unsupported = 1;
+                    for (Py_ssize_t i = lo; i < hi && !unsupported; ++i) {
+                        const long long g = (long long)t[i] - o;
+                        if (g < 0 || g >= bv.shape[0]) unsupported = 1;
+                    }
+                    PyBuffer_Release(&bg);
+                }
+                PyBuffer_Release(&bv);
+            }
+        }
+        Py_XDECREF(val); Py_XDECREF(gv); Py_XDECREF(ver);
+    }
+    if (unsupported) { Py_CLEAR(result); result = Py_None; Py_INCREF(result); goto done; }
+    /* pass 2: the update (state.py:340-350 per node) */
     for (Py_ssize_t c = 0; c < C; ++c) {
         PyObject* node = PyList_GET_ITEM(nodes, c);
         const Py_ssize_t lo = PyLong_AsSsize_t(PyList_GET_ITEM(result, c)), hi = PyLong_AsSsize_t(PyList_GET_ITEM(result, c + 1));
@@ -308,14 +335,17 @@ static PyObject* py_add_rows_many(PyObject* self, PyObject* args) {
         if (!ver) { Py_CLEAR(result); goto done; }
         const long long version = PyLong_AsLongLong(ver) + 1;
         Py_DECREF(ver);
+        PyObject* val = PyObject_GetAttr(node, s__value);
+        if (!val) { Py_CLEAR(result); goto done; }
+        int ok = 1;
         if (hi > lo) {
-            PyObject* val = PyObject_GetAttr(node, s__value);
-            PyObject* gv = val ? PyObject_GetAttr(node, s_group_versions) : NULL;
+            PyObject* gv = PyObject_GetAttr(node, s_group_versions);
             Py_buffer bv, bg;
-            int ok = val && gv && PyObject_GetBuffer(val, &bv, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) == 0;    /* (kept read-only between edits: written through anyway, like the flag toggle of the Python form) */
+            ok = gv && PyObject_GetBuffer(val, &bv, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) == 0;    /* (kept read-only between edits: written through anyway, like the flag toggle of the Python form) */
             if (ok && PyObject_GetBuffer(gv, &bg, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT | PyBUF_WRITABLE) != 0) { PyBuffer_Release(&bv); ok = 0; }
             if (ok) {
                 const char gf = bg.format ? bg.format[strlen(bg.format) - 1] : 0;
+                /* (re-checked: resolve_sharing is a Python method and may be anything) */
                 const int form_ok = bv.ndim == 3 && bv.itemsize == 4 && bv.format && bv.format[strlen(bv.format) - 1] == 'f' &&
                                     bv.shape[1] * bv.shape[2] == row_elems && bg.ndim == 1 && bg.itemsize == 8 && bg.shape[0] == bv.shape[0] &&
                                     (gf == 'd' || gf == 'l' || gf == 'q');
@@ -335,9 +365,16 @@ static PyObject* py_add_rows_many(PyObject* self, PyObject* args) {
                 }
                 PyBuffer_Release(&bv); PyBuffer_Release(&bg);
             } else if (!PyErr_Occurred()) PyErr_SetString(PyExc_TypeError, "add_rows_many: count arrays are not plain C-contiguous buffers");
-            Py_XDECREF(val); Py_XDECREF(gv);
-            if (!ok) { Py_CLEAR(result); goto done; }
+            Py_XDECREF(gv);
         }
+        /* _value.flags.writeable = False, as add_changes leaves it (state.py:347): the copy resolve_sharing() made is writeable */
+        if (ok) {
+            PyObject* flags = PyObject_GetAttr(val, s_flags);
+            if (!flags || PyObject_SetAttr(flags, s_writeable, Py_False) != 0) ok = 0;
+            Py_XDECREF(flags);
+        }
+        Py_DECREF(val);
+        if (!ok) { Py_CLEAR(result); goto done; }
         PyObject* nv = PyLong_FromLongLong(version);
         if (!nv || PyObject_SetAttr(node, s_version, nv) != 0) { Py_XDECREF(nv); Py_CLEAR(result); goto done; }
         Py_DECREF(nv);

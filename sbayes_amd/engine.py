@@ -244,6 +244,12 @@ class Engine:
         self._touch(slot)
         self._check(self._lib.sbe_set_group_ids(self._h, slot, component, self._i(ids)))
 
+    def get_group_ids(self, slot, component):
+        """The slot's ids of one component as the DEVICE holds them: int32 [N], -1 = in no group (inverse of set_group_ids)."""
+        out = np.empty(self.n_objects, dtype=np.int32)
+        self._check(self._lib.sbe_get_group_ids(self._h, slot, component, self._o(out)))
+        return out
+
     def set_source(self, slot, source):
         s = np.asarray(source)
         if s.shape != (self.n_objects, self.n_features, self.n_components):
@@ -395,6 +401,12 @@ class Engine:
             raise ValueError(f"weights must be {(self.n_features, self.n_components)}, got {w.shape}")
         self._touch(slot)
         self._check(self._lib.sbe_set_weights(self._h, slot, self._i(w)))
+
+    def get_weights(self, slot):
+        """The slot's resident mixture weights as set: float32 [F, C]."""
+        out = np.empty((self.n_features, self.n_components), dtype=np.float32)
+        self._check(self._lib.sbe_get_weights(self._h, slot, self._o(out)))
+        return out
 
     def weights_normalized(self, slot):
         out = np.empty((self.n_objects, self.n_features, self.n_components), dtype=np.float32)
@@ -1048,6 +1060,16 @@ class Engine:
     def timer_stop(self) -> float:
         ms = ct.c_float(0.0)
         self._check(self._lib.sbe_timer_stop(self._h, ct.byref(ms)))
+        return ms.value
+
+    def timer_mark(self):
+        """Second event of the span opened by timer_start, recorded behind everything enqueued so far; no host wait."""
+        self._check(self._lib.sbe_timer_mark(self._h))
+
+    def timer_elapsed(self) -> float:
+        """Wait for timer_mark's event; -> span in ms since timer_start's."""
+        ms = ct.c_float(0.0)
+        self._check(self._lib.sbe_timer_elapsed(self._h, ct.byref(ms)))
         return ms.value
 
     def kernel_timing_start(self):

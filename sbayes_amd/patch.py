@@ -309,14 +309,17 @@ def _install_operator_forms(swap):
         if sample is not None and source is sample.source.value:
             # the engine is identified by the NA mask the caller hands over (it decides which observations count):
             # two datasets of one (N, F, C) shape in one process never share an engine here
+            # (only the layout computation and the engine lookup may decline -- a sample object of another form, a mask no
+            #  live engine holds: the reference expression below; an error of the bind or of the engine call is a real error
+            #  and propagates)
             try:
                 layout = [sample.clusters.value.shape[0]] + [c.group_assignment.shape[0] for c in sample.confounders.values()]
                 eng = registry.engine_for_observations(na_features, np.shape(source)[2], layout)
-                if eng is not None:
-                    _bind_slot(eng, None, sample, 0, with_source=True)
-                    return eng.source_lh_by_feature(0)
             except (ValueError, AttributeError):
-                pass                                 # a sample this engine cannot hold: the reference expression below
+                eng = None
+            if eng is not None:
+                _bind_slot(eng, None, sample, 0, with_source=True)
+                return eng.source_lh_by_feature(0)
         return reference_source_lh(source, np.asarray(weights), na_features)
 
     # SourcePrior.__call__ (prior.py:573-611): per-object log prior from the device, the reference's cache protocol kept

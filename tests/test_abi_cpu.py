@@ -1,5 +1,5 @@
 """CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol
-include/sbe_engine.h declares, and refuses to run without a GPU (no CPU fallback)."""
+include/*.h declare, and refuses to run without a GPU (no CPU fallback)."""
 import ctypes as ct
 import re
 from pathlib import Path
@@ -12,10 +12,16 @@ from sbayes_amd import _lib
 REPO = Path(__file__).resolve().parent.parent
 
 
-def declared_symbols():
-    text = (REPO / "include" / "sbe_engine.h").read_text()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(sbe_[a-z0-9_]+)\s*\(", text)))
+HEADERS = ("sbe_engine.h", "sbe_engine_steps.h", "sbe_engine_diag.h")
+
+
+def declared_symbols(headers=HEADERS):
+    names = set()
+    for h in headers:
+        text = (REPO / "include" / h).read_text()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(sbe_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -23,14 +29,25 @@ def test_library_exports_every_declared_symbol():
     names = declared_symbols()
     assert len(names) >= 30
     for name in names:
-        assert hasattr(lib, name), f"{name} declared in include/sbe_engine.h but not exported"
-    # and the ctypes binding covers exactly the header
+        assert hasattr(lib, name), f"{name} declared under include/ but not exported"
+    # and the ctypes binding covers exactly the headers
     assert sorted(_lib.PROTOTYPES) == names
+
+
+def test_production_header_holds_no_test_hooks_and_no_step_family():
+    """include/sbe_engine.h is the drop-in boundary -- self-tests, measurement hooks and the one-call
+    step family (no caller in the reference) live in their own headers."""
+    prod = declared_symbols(("sbe_engine.h",))
+    assert not [n for n in prod if n.startswith("sbe_test_") or n.startswith("sbe_timer_") or "profile" in n or "kernel_timing" in n]
+    assert not [n for n in prod if re.match(r"sbe_(gibbs_)?step", n)]
+    steps = declared_symbols(("sbe_engine_steps.h",))
+    assert steps == sorted(["sbe_step", "sbe_step_batch", "sbe_step_delta", "sbe_step_batch_delta", "sbe_gibbs_step"])
+    assert "NO CALLER IN THE REFERENCE" in (REPO / "include" / "sbe_engine_steps.h").read_text()
 
 
 def test_abi_version_and_error_text():
     lib = _lib.load()
-    assert lib.sbe_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.sbe_abi_version() == _lib.ABI_VERSION == 6
     assert lib.sbe_get_info(None, None) != 0
     assert b"null engine" in lib.sbe_last_error(None)
 

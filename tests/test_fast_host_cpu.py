@@ -200,3 +200,46 @@ def test_scan_is_the_python_token_comparison():
         assert (a[0] is b[0] or np.array_equal(a[0], b[0])) and a[1] == b[1]
     with pytest.raises(TypeError):
         binding._scan(params, cached[:-1])
+
+
+@ext
+def test_add_rows_many_refreezes_a_resolved_copy_and_checks_every_node_first():
+    """(1) after resolve_sharing() the fresh `_value` copy is writeable; the reference's add_changes
+    (sbayes/sampling/state.py:340-350) and both Python forms leave it frozen, so must the native form.  (2) dtype / contiguity /
+    shape of EVERY node are checked before the first node is touched: a later node in another form returns None (Python
+    route) with nothing applied, never a half-applied update."""
+    from sbayes_amd.counts import apply_count_rows
+    F, S = 3, 2
+
+    def nodes():
+        a = st.FeatureCounts(np.zeros((2, F, S), dtype=np.float32))
+        b = st.FeatureCounts(np.zeros((3, F, S), dtype=np.float32))
+        return a, b
+
+    off = np.array([0, 2, 5], dtype=np.int64)
+    touched = np.array([1, 3], dtype=np.int32)
+    rows = np.ones((2, F, S), dtype=np.float32)
+    a, b = nodes()
+    a2 = a.copy()                                        # a and a2 now share their array
+    assert a2.shared and a2.value is a.value
+    bounds = _fast._h.add_rows_many([a2, b], off, touched, rows)
+    assert bounds == [0, 1, 2]
+    assert not a2.shared and a2.value is not a.value
+    assert not a2.value.flags.writeable and not b.value.flags.writeable
+    assert a.value.sum() == 0 and a2.value[1].sum() == F * S and b.value[1].sum() == F * S
+    assert a2.version == 1 and list(a2.group_versions) == [0, 1] and list(b.group_versions) == [0, 1, 0]
+    with pytest.raises(ValueError):
+        a2.value[0, 0, 0] = 1.0
+    # a node of another dtype BEHIND a good one: nothing is applied, the caller takes the Python route
+    a, _ = nodes()
+    bad = st.FeatureCounts(np.zeros((3, F, S), dtype=np.float64))
+    assert _fast._h.add_rows_many([a, bad], off, touched, rows) is None
+    assert a.version == 0 and a.value.sum() == 0 and list(a.group_versions) == [0, 0]
+    # ... and an index beyond a later node's groups likewise
+    a, b = nodes()
+    assert _fast._h.add_rows_many([a, b], np.array([0, 2, 10], dtype=np.int64), np.array([1, 6], dtype=np.int32), rows) is None
+    assert a.version == 0 and a.value.sum() == 0
+    # the public entry serves the float64 node through the Python form with the same result
+    a, _ = nodes()
+    apply_count_rows({"x": a, "y": bad}, ["x", "y"], off, touched, rows)
+    assert a.version == 1 and bad.version == 1 and bad.value[1].sum() == F * S and not bad.value.flags.writeable
