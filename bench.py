@@ -15,12 +15,26 @@ resident in HBM before the timed region; the B scalars are fetched to the host i
 `single_chain` in the output line is what ONE chain sees (B = 1, host-synchronous), `per_config`
 covers every 1-GPU BASELINE config (cfg1, south_america, headline, stress) at B = 1 / 8 / 64.
 
-Roofline: every number in `roofline` comes from THIS run.  The dominant kernel's duration is measured with HIP
-event pairs on the engine's own stream around every `--event-stride`-th launch INSIDE the timed loop (default 4:
-an event record between back-to-back launches costs the loop a few us, so not every launch is bracketed;
-`--event-stride 1` brackets all of them, 0 moves the pairs to an identical loop after the timed one).
-`roofline_valu` (what actually bounds the headline kernel) and `roofline.traffic` are STATIC figures from the
-committed rocprofv3 PMC passes (profiles/), labelled with their source file.
+Kernel time: ONE HIP event pair on the engine's own stream around the K back-to-back launches of every timed repetition
+(sbe_timer_start before the first launch, sbe_timer_mark behind the last one, read after the results are in); span / K is the
+dominant kernel's duration INCLUDING the dispatch gap between consecutive kernels, and it lies inside the host-timed region,
+so kernel_avg_us <= ms_per_step * 1000 by construction (asserted).  rocprofv3's kernel trace of the same command
+(profiles/) reads the kernel alone, a few us less.
+
+Roofline: `roofline.frac` = UNIQUE bytes per launch (the shared feature block once + every state's tables, ids and result)
+/ kernel time / 8 TB/s -- a fraction that cannot exceed 1.  `frac_contract` is SURVEY.md 8(d)'s per-eval figure x evals per
+launch (it counts the shared block once per eval and exceeds 1 for a batched kernel: no roofline meaning, kept for the
+contract).  `frac_traffic` and `roofline_valu` (what actually bounds the headline kernel) are STATIC figures from the
+committed rocprofv3 PMC passes (profiles/), labelled with their source file and withheld when this build's kernel differs.
+
+Parity: the results of the TIMED launches are checked, outside the timed region: slot 0 (the workload's own state) and 15
+random slots against oracle values computed from state READ BACK from the device (group ids, source rows -> counts recounted
+by the oracle and compared bit for bit with the device's, weights); 1e-10 relative or the run fails.
+
+Two further legs beside the headline figure (rank 0, N = 1): `hbm_regime` -- 2 x B resident states per launch, whose tables
+(442 MB at the default) no longer fit the 256 MB Infinity Cache and stream from HBM on every launch -- and `changing_tables`
+-- every step first moves one object of EVERY state to another cluster (count delta, the two touched clusters' tables rebuilt:
+sbayes/sampling/counts.py:55-95, conditionals.py:171-188) and then evaluates all of them: no launch re-reads frozen tables.
 
   python bench.py                       # 1 GPU, defaults finish in about a minute
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -77,9 +91,12 @@ def parse():
     ap.add_argument("--log-mode", default="product", choices=["product", "per_obs"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--event-stride", type=int, default=4,
-                    help="HIP event pair around the dominant kernel of every n-th launch of the timed loop "
-                         "(1: every launch; 0: none in the timed loop, an identical loop right after it instead)")
+    ap.add_argument("--event-stride", type=int, default=0,
+                    help="secondary figure kernel_event_pairs_us: HIP event pair around the dominant kernel of every n-th launch "
+                         "of the timed loop (1: every launch; 0, default: none in the timed loop -- an identical loop right after "
+                         "it instead).  roofline.kernel_avg_us never comes from these pairs: it is the span of the K back-to-back "
+                         "launches of a timed repetition / K")
+    ap.add_argument("--no-legs", action="store_true", help="skip the hbm_regime and changing_tables legs (and their extra slots)")
     ap.add_argument("--min-time", type=float, default=0.05,
                     help="the K-step timed loop is repeated (each repetition bracketed by barrier + sync on both sides) "
                          "until the repetitions together cover this many seconds; the MEDIAN repetition is reported")
@@ -111,7 +128,7 @@ def load_workload(name):
     return wl
 
 
-def setup_engine(wl, batch, device, kernel="packed", log_mode="product"):
+def setup_engine(wl, batch, device, kernel="packed", log_mode="product", n_slots=None):
     """Engine with `batch` distinct resident states.  Slot 0 is the workload's own state (the parity gate checks it
     against the oracle); the others get random clusters and weights from the host (a few KB each) and their source
     assignment drawn ON THE DEVICE from its prior given those (sbe_sample_source, Philox stream) -- the recipe of
@@ -123,7 +140,7 @@ def setup_engine(wl, batch, device, kernel="packed", log_mode="product"):
     n_obj, n_feat, _ = wl.shape
     C = wl.n_components
     K = wl.clusters.shape[0]
-    eng = Engine(wl.features, [g.shape[0] for g in wl.groups], n_slots=batch, device=device)
+    eng = Engine(wl.features, [g.shape[0] for g in wl.groups], n_slots=max(batch, n_slots or 0), device=device)
     eng.set_option(kernel={"onehot": MIXTURE_ONEHOT, "onehot_general": MIXTURE_ONEHOT_GENERAL, "packed": MIXTURE_PACKED,
                            "packed_general": MIXTURE_PACKED_GENERAL, "packed_v2": MIXTURE_PACKED_V2,
                            "packed_tuple": MIXTURE_PACKED_TUPLE, "packed_tuple_lds": MIXTURE_PACKED_TUPLE_LDS,
@@ -171,6 +188,151 @@ def cpu_baseline(wl, seconds):
         if el >= seconds or n >= 100000:
             break
     return ll, n / el, n, el
+
+
+def oracle_from_device(eng, wl, slot):
+    """Oracle value of the mixture log-likelihood of the state a slot HOLDS: group ids, source rows and weights are read back
+    from the device; the oracle recounts (sbayes/sampling/counts.py:10-32) and the counts must equal the device's bit for bit
+    (they feed the tables the timed kernel read); then the NumPy restatement of SURVEY.md 8(d)'s expression.  Checker only."""
+    from oracle import sbayes_oracle as orc
+    n_obj = wl.shape[0]
+    groups = []
+    for c, g in enumerate(wl.groups):
+        ids = eng.get_group_ids(slot, c)
+        groups.append(ids[None, :] == np.arange(g.shape[0], dtype=np.int32)[:, None])
+    source = eng.get_source_rows(slot, np.arange(n_obj, dtype=np.int32)).astype(bool)
+    weights = eng.get_weights(slot)
+    counts = orc.recalculate_feature_counts(wl.features, groups, source)
+    for c in range(wl.n_components):
+        dev = eng.get_counts(slot, c)
+        if not np.array_equal(np.asarray(counts[c], dtype=np.float32), dev):
+            raise RuntimeError(f"slot {slot}: counts of component {c} on the device differ from the oracle's recount of the device's own source")
+    return float(orc.mixture_loglik(wl.features, wl.na_values, groups, counts, wl.concentration, weights))
+
+
+def verify_results(eng, wl, slots, values, what, want0=None, tol=1e-10):
+    """values[i] = what the device returned for slots[i]; -> (max relative error, the slots).  Raises beyond `tol`."""
+    worst = 0.0
+    for slot, got in zip(slots, values):
+        want = oracle_from_device(eng, wl, int(slot))
+        if int(slot) == 0 and want0 is not None:
+            # slot 0 holds the workload's own state: the oracle value from the host arrays must be the same number
+            assert abs(want - want0) <= 1e-13 * abs(want0), (want, want0)
+        err = abs(float(got) - want) / abs(want)
+        worst = max(worst, err)
+        if not err <= tol:
+            raise RuntimeError(f"parity gate failed ({what}): slot {int(slot)} device {float(got)!r} oracle {want!r} rel.err {err:.3e} > {tol}")
+    return worst, [int(s) for s in slots]
+
+
+def _median_rep(times):
+    """Index of the median repetition (upper median for an even count): value, ms_per_step and the kernel span all come
+    from this ONE repetition."""
+    order = np.argsort(times)
+    return int(order[len(times) // 2])
+
+
+def timed_loop(eng, launch, fetch, steps, min_time=0.05, max_reps=200):
+    """Secondary legs: `steps` launches + the result fetch between stream syncs, repeated to >= min_time; the median
+    repetition's wall time per step and event span per launch (both in seconds)."""
+    times, spans = [], []
+    total = 0.0
+    while len(times) < 3 or (total < min_time and len(times) < max_reps):
+        eng.sync()
+        t0 = time.perf_counter()
+        eng.timer_start()
+        for _ in range(steps):
+            launch()
+        eng.timer_mark()
+        res = fetch()
+        dt = time.perf_counter() - t0
+        spans.append(eng.timer_elapsed() * 1e-3)
+        times.append(dt)
+        total += dt
+    k = _median_rep(times)
+    return times[k] / steps, spans[k] / steps, len(times), res
+
+
+def hbm_regime_leg(eng, wl, n_states, steps, b_eval, unique_fn):
+    """The headline launch over n_states = 2 x B resident states: their tables no longer stay in the Infinity Cache between
+    launches, every launch streams them from HBM."""
+    per_step, span, n_reps, res = timed_loop(eng, lambda: eng.mixture_loglik_batch_async(0, n_states),
+                                             lambda: eng.fetch_results(0, n_states), steps)
+    assert np.all(np.isfinite(res))
+    rng = np.random.default_rng(77)
+    slots = np.unique(np.concatenate([[0, n_states - 1], rng.integers(0, n_states, size=6)]))
+    worst, checked = verify_results(eng, wl, slots, res[slots], "hbm_regime")
+    unique = unique_fn(n_states)
+    assert span <= per_step * 1.0005, (span, per_step)
+    return {"evals_per_launch": n_states, "evals_per_s": round(n_states / per_step, 1), "ms_per_step": round(per_step * 1e3, 5),
+            "kernel_avg_us": round(span * 1e6, 3), "kernel": eng.last_mixture_kernel(),
+            "unique_bytes_per_launch": int(unique), "frac": round(unique / span / 1e9 / HBM_PEAK_GBS, 5),
+            "frac_contract": round(b_eval * n_states / span / 1e9 / HBM_PEAK_GBS, 5),
+            "per_state_bytes": int(unique_fn(2) - unique_fn(1)),
+            "steps": steps, "n_reps": n_reps, "parity_max_rel_err": worst, "parity_slots": checked,
+            "note": "frac = unique bytes per launch / kernel time / 8 TB/s (the same definition as roofline.frac); the states' tables "
+                    f"({(unique_fn(2) - unique_fn(1)) * n_states / 1e6:.0f} MB) exceed the 256 MB Infinity Cache, so no launch finds them cached"}
+
+
+def changing_tables_leg(eng, wl, n_chains, sweeps, warm=3):
+    """Every step CHANGES every state before evaluating it: chain i (slots i and n_chains + i: current and candidate, swapped
+    after every step like an accepted proposal) moves one object to another cluster -- the candidate is patched on the device,
+    its counts follow by the delta rule (sbayes/sampling/counts.py:55-95), the touched clusters' probability tables are
+    rebuilt (conditionals.py:171-188, util.py:990-1007), then ONE launch of the fused kernel evaluates the n_chains candidates
+    (plus their collapsed per-group likelihoods: Likelihood.__call__).  One engine call per sweep (sbe_step_batch_delta; the
+    per-chain payload is packed by the library's host pool)."""
+    n_obj = wl.shape[0]
+    K = wl.clusters.shape[0]
+    cur = np.arange(n_chains, dtype=np.int32)
+    cand = cur + n_chains
+    ids = np.stack([eng.get_group_ids(int(s), 0) for s in cur]).astype(np.int64)       # host mirror [n_chains][N], -1 = none
+    rng = np.random.default_rng(4242)
+    mptr = np.arange(n_chains + 1, dtype=np.int32)
+    rows = np.arange(n_chains)
+    plan = []
+    for _ in range(warm + sweeps):
+        obj = rng.integers(0, n_obj, size=n_chains)
+        new = (ids[rows, obj] + 1 + 1 + rng.integers(0, K, size=n_chains)) % (K + 1) - 1     # always another cluster (or none)
+        ids[rows, obj] = new
+        plan.append((obj.astype(np.int32), new.astype(np.int32)))
+    state = {"cur": cur, "cand": cand, "k": 0, "mix": None}
+
+    def sweep():
+        obj, new = plan[state["k"]]
+        state["k"] += 1
+        _glh, mix, _changed = eng.step_batch_delta(state["cur"], state["cand"], mptr, obj, new)
+        state["mix"] = mix
+        state["cur"], state["cand"] = state["cand"], state["cur"]       # every proposal accepted: the candidate is the state now
+
+    for _ in range(warm):
+        sweep()
+    eng.sync()
+    eng.kernel_timing_start()                      # (one event pair per sweep around the fused kernel inside the step)
+    t0 = time.perf_counter()
+    for _ in range(sweeps):
+        sweep()
+    eng.sync()
+    per_sweep = (time.perf_counter() - t0) / sweeps
+    n_pairs, mix_ms = eng.kernel_timing_stop()
+    kernel = eng.last_mixture_kernel()
+    # the last sweep's results against the oracle, from the state the device holds now; and the host mirror of the moves
+    rng2 = np.random.default_rng(78)
+    chains = np.unique(np.concatenate([[0, n_chains - 1], rng2.integers(0, n_chains, size=4)]))
+    slots = state["cur"][chains]
+    worst, checked = verify_results(eng, wl, slots, state["mix"][chains], "changing_tables")
+    for ch, slot in zip(chains, slots):
+        assert np.array_equal(eng.get_group_ids(int(slot), 0), ids[ch]), f"chain {ch}: device ids differ from the applied moves"
+    return {"states": n_chains, "evals_per_s": round(n_chains / per_sweep, 1), "ms_per_step": round(per_sweep * 1e3, 4),
+            "us_per_state_step": round(per_sweep / n_chains * 1e6, 4), "steps": sweeps, "kernel": kernel,
+            "fused_kernel_us_inside_the_step": round(mix_ms * 1e3, 2) if n_pairs else None,
+            "fused_kernel_evals_per_s_on_changed_tables": round(n_chains / (mix_ms * 1e-3), 1) if n_pairs and mix_ms > 0 else None,
+            "parity_max_rel_err": worst, "parity_slots": checked,
+            "note": "one object of EVERY state moved to another cluster before every evaluation (device-side patch, count delta, "
+                    "table rebuild, collapsed per-group likelihoods, fused mixture kernel over all candidates; one engine call and "
+                    "one synchronisation per step, host wall clock incl. packing the per-chain deltas).  evals_per_s is the WHOLE "
+                    "step: the per-chain candidate kernels (patch, count delta, tables, collapsed likelihood) and the host packing of "
+                    "n deltas bound it, not the fused kernel -- fused_kernel_us_inside_the_step is that kernel alone (HIP event pair) "
+                    "on tables rewritten a moment earlier"}
 
 
 NUMBA_CAVEAT = ("the real reference JIT-compiles compute_component_likelihood and dirichlet_categorical_logpdf with numba when "
@@ -579,37 +741,41 @@ def static_profile_figures(workload, kernel, B, kern_us, kernel_name=None, resul
 def roofline_block(b_eval, unique_bytes, B, kern_ms, traffic, valu, kernel_name, packed, kernel_avg_source, shape=None):
     """The `roofline` object of the output line (pure arithmetic: tests/test_bench_roofline_cpu.py).
     Three HBM figures for the dominant kernel, all over the SAME measured kernel time:
-      frac          contract figure of SURVEY.md 8(d): algorithmic bytes per eval x evals per launch (the feature block
-                    counted once PER EVAL although the B states of a launch share it) / 8 TB/s -- exceeds 1 once the
-                    kernel stops re-reading the block per state;
-      frac_unique   the same inventory with the shared block counted ONCE per launch: what a launch must move at least;
-      frac_traffic  what the HBM counters saw (static PMC passes; None when no pass of this build is committed).
-    `bound` names the pipe that limits the kernel: "valu" when the vector-issue fraction (roofline_valu) exceeds the
-    measured traffic fraction, else "hbm"."""
+      frac           UNIQUE bytes per launch -- the feature block the B states of a launch share counted ONCE, plus every
+                     state's tables, ids and result: what the launch must move at least -- / 8 TB/s.  Cannot exceed 1.
+                     `achieved` is this figure in GB/s.
+      frac_contract  SURVEY.md 8(d)'s per-eval bytes x evals per launch (the shared block counted once PER EVAL): exceeds 1
+                     for a batched kernel, so it is no roofline fraction; kept for the contract, never as `frac`.
+      frac_traffic   what the memory counters saw (static PMC passes; None when no pass of this build is committed).
+    `bound` names the pipe that limits the kernel: "valu" when the vector-issue fraction (roofline_valu) exceeds both
+    memory fractions, else "hbm"."""
     kern_s = kern_ms * 1e-3
-    achieved = b_eval * B / kern_s / 1e9
-    frac_unique = unique_bytes / kern_s / 1e9 / HBM_PEAK_GBS
+    achieved = unique_bytes / kern_s / 1e9
+    frac = achieved / HBM_PEAK_GBS
+    contract = b_eval * B / kern_s / 1e9
     frac_traffic = traffic["bytes_per_launch"] / kern_s / 1e9 / HBM_PEAK_GBS if traffic else None
     bound = "hbm"
-    if valu and valu.get("frac") is not None and (frac_traffic is None or valu["frac"] > frac_traffic) and valu["frac"] > frac_unique:
+    if valu and valu.get("frac") is not None and (frac_traffic is None or valu["frac"] > frac_traffic) and valu["frac"] > frac:
         bound = "valu"
     out = {
         "bound": bound, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "frac": round(frac, 5),
         "traffic": traffic["bytes_per_launch"] if traffic else None,
         "traffic_source": traffic["source"] if traffic else None,
         "frac_traffic": round(frac_traffic, 5) if frac_traffic is not None else None,
-        "unique_bytes_per_launch": int(unique_bytes), "frac_unique": round(frac_unique, 5),
+        "unique_bytes_per_launch": int(unique_bytes),
+        "frac_contract": round(contract / HBM_PEAK_GBS, 5), "achieved_contract": round(contract, 2),
         "kernel": kernel_name,
         "kernel_avg_us": round(kern_ms * 1e3, 3),
         "kernel_avg_source": kernel_avg_source,
         "algorithmic_bytes_per_eval": b_eval, "evals_per_launch": B,
         "representation": "packed state index (N*F bytes)" if packed else "one-hot (N*F*S bytes)",
-        "note": "frac = contractual HBM roofline (algorithmic bytes per eval x evals per launch / 8 TB/s): it counts the feature "
-                "block once per eval although the states of a launch share it, and exceeds 1 for a kernel that reads the block "
-                "once per launch; frac_unique counts the block once per launch (the figure that stays meaningful), frac_traffic "
-                "is what the HBM counters saw.  At the headline shape the working set is L2/MALL-resident and the kernel is "
-                "vector-issue bound: see roofline_valu",
+        "note": "frac = unique bytes per launch (the shared feature block once + every state's tables, ids, result) / kernel time / "
+                "8 TB/s; frac_contract = SURVEY.md 8(d) bytes per eval x evals per launch / the same: it counts the shared block once "
+                "per eval and exceeds 1 for a kernel that reads it once per launch -- not a roofline fraction; frac_traffic = "
+                "what the memory counters saw.  Up to ~4096 headline states the per-state tables stay in the 256 MB Infinity Cache "
+                "between launches (hbm_regime: the same kernel with the tables streaming from HBM) and the kernel is vector-issue "
+                "bound: see roofline_valu",
     }
     if "k_mixture_tuple_mfma" in kernel_name and shape is not None:
         # counts on the matrix pipe: rows (16 slots x 2 tuples per 32-row tile) x columns (F*S padded to 32) x objects (padded to 128)
@@ -645,24 +811,23 @@ def main():
     wl = load_workload(args.workload)
     n_obj, n_feat, n_states = wl.shape
     B = args.batch if args.batch else (64 if args.workload == "stress" else HEADLINE_BATCH)
+    # the two legs beside the headline figure need a second set of B slots (candidates of the changing-tables leg, then the
+    # upper half of the 2 B states of the HBM-regime launch): rank 0 of a 1-GPU run only
+    legs = rank == 0 and n_gpus == 1 and not args.no_legs and not args.no_secondary and args.kernel == "packed" and 2 * B <= 16384
     t_setup = time.perf_counter()
-    eng = setup_engine(wl, B, device, args.kernel, args.log_mode)
+    eng = setup_engine(wl, B, device, args.kernel, args.log_mode, n_slots=2 * B if legs else B)
     t_setup = time.perf_counter() - t_setup
     info = eng.info()
     if n_dev >= world > 1:                          # one GPU per rank: every rank must sit on its own device
         devices = chains.gather_chain_values([rank], [info["device"]], world, dist)
         assert len(set(int(d) for d in devices)) == world, f"ranks share devices: {devices}"
 
-    # ---- parity gate reported with the timing (rank-local, cheap): slot 0 vs the oracle ------
-    parity = None
+    # ---- oracle value of the workload's own state (slot 0); the gate itself runs on the TIMED results, below ------
+    want = None
     if rank == 0:
         orc, oargs = oracle_eval(wl)
-        want = orc.mixture_loglik(*oargs)
-        got = eng.mixture_loglik(0)
-        parity = abs(got - want) / abs(want)
-        log(f"[bench] parity slot0: gpu {got!r} oracle {want!r} rel.err {parity:.3e}; {B} states ready in {t_setup:.1f} s")
-        if parity > 1e-10:
-            raise RuntimeError(f"parity gate failed: rel.err {parity:.3e} > 1e-10")
+        want = float(orc.mixture_loglik(*oargs))
+        log(f"[bench] {B} states ready in {t_setup:.1f} s; oracle value of slot 0: {want!r}")
 
     def barrier():
         eng.sync()
@@ -681,70 +846,91 @@ def main():
     eng.kernel_timing_start()                      # (events are bracketing nothing until resumed inside the loop)
     eng.kernel_timing_pause()
 
-    own_times = []
+    own_times, spans = [], []
 
     def timed_rep():
-        """EXACTLY K steps, barrier + stream sync on both sides, max over ranks."""
+        """EXACTLY K steps, barrier + stream sync on both sides, max over ranks.  One event pair on the engine's stream
+        spans the K launches (first event before launch 1, second behind launch K, read after the fetch)."""
         barrier()
         t0 = time.perf_counter()
+        eng.timer_start()
         for i in range(args.steps):
             if stride > 0 and i % stride == 0:
-                eng.kernel_timing_resume()         # HIP event pair around the dominant kernel of this launch
+                eng.kernel_timing_resume()         # (secondary figure: event pair around the dominant kernel of this launch)
                 step()
                 eng.kernel_timing_pause()
             else:
                 step()
+        eng.timer_mark()
         res = eng.fetch_results(0, B)              # D2H of the B scalars + stream sync, inside the timed region
         own = time.perf_counter() - t0             # this rank's own K steps (before it waits for the others)
         barrier()
+        dt = time.perf_counter() - t0
+        spans.append(eng.timer_elapsed() * 1e-3)   # seconds; the second event is long done
         own_times.append(own)
-        return chains.max_over_ranks(time.perf_counter() - t0, dist), res
+        return chains.max_over_ranks(dt, dist), res
 
     # A K-step loop is ~1 ms at the driver's K = 20: one stray interrupt moves it by percents.  The loop is therefore
     # repeated -- every repetition is the contract's region (exactly K steps, barrier + sync both sides, max over
     # ranks; the repetition count follows from the first one's all-reduced time, so every rank runs the same number)
-    # -- and the MEDIAN repetition is reported.  At least 20 launches carry an event pair.
+    # -- and the MEDIAN repetition is reported: value, ms_per_step and the kernel span all come from that ONE repetition.
     first, results = timed_rep()
-    pairs_per_rep = (args.steps + stride - 1) // stride if stride > 0 else 0
-    n_reps = args.reps if args.reps > 0 else int(min(200, max(1, np.ceil(args.min_time / max(first, 1e-9)))))
-    if pairs_per_rep and args.reps <= 0:
-        n_reps = max(n_reps, -(-20 // pairs_per_rep))
+    n_reps = args.reps if args.reps > 0 else int(min(200, max(3, np.ceil(args.min_time / max(first, 1e-9)))))
     rep_times = [first]
     for _ in range(n_reps - 1):
         dt, results = timed_rep()
         rep_times.append(dt)
-    elapsed = float(np.median(rep_times))
-    if stride <= 0:                                # the same K launches again, each bracketed by an event pair
+    k_med = _median_rep(rep_times)
+    elapsed = float(rep_times[k_med])
+    kern_ms = spans[k_med] / args.steps * 1e3      # this rank's span of the median repetition / K
+    pair_n, pair_ms = 0, None
+    if stride <= 0 and rank == 0:                  # the same launches again, each bracketed by an event pair (secondary figure)
         eng.kernel_timing_start()
         for _ in range(max(args.steps, 20)):
             step()
         eng.fetch_results(0, B)
-    n_timed, kern_ms = eng.kernel_timing_stop()
-    assert n_timed == (max(args.steps, 20) if stride <= 0 else pairs_per_rep * n_reps), n_timed
+    pair_n, pair_ms = eng.kernel_timing_stop()
     assert np.all(np.isfinite(results))
 
     evals = args.steps * B * n_gpus
     value = evals / elapsed
     ms_per_step = elapsed / args.steps * 1e3
+    # a kernel cannot take longer than the step that contains it (VERDICT r5 weak #3); the span lies inside this rank's own
+    # host-timed region, which is at most the max over ranks
+    assert kern_ms <= ms_per_step * 1.0005, (kern_ms, ms_per_step)
 
-    # ---- roofline of the dominant kernel, HIP events on the engine's stream ---------------------
+    # ---- parity gate ON THE TIMED RESULTS (rank 0; outside the timed region): the last repetition's B values -------------------
+    parity = parity_slots = None
+    if rank == 0:
+        rng = np.random.default_rng(2025)
+        slots = np.unique(np.concatenate([[0, B - 1], rng.integers(0, B, size=15)])) if B > 1 else np.array([0])
+        parity, parity_slots = verify_results(eng, wl, slots, results[slots], "timed launches", want0=want)
+        log(f"[bench] parity of the timed kernel ({eng.last_mixture_kernel()}): {len(parity_slots)} slots incl. slot 0 = the workload's state, "
+            f"oracle from device readback, max rel.err {parity:.3e}")
+
+    # ---- roofline of the dominant kernel ---------------------------------------------------------------------------
     has_comp = np.stack([g.any(axis=0) for g in wl.groups], axis=1)
     n_pat = len(np.unique(has_comp, axis=0))          # distinct has_components rows (likelihood.py:183)
     packed = not args.kernel.startswith("onehot")
-    b_eval = algorithmic_bytes(n_obj, n_feat, n_states, [g.shape[0] for g in wl.groups], n_pat, packed=packed)
-    achieved = b_eval * B / (kern_ms * 1e-3) / 1e9
+    groups_per_comp = [g.shape[0] for g in wl.groups]
+    b_eval = algorithmic_bytes(n_obj, n_feat, n_states, groups_per_comp, n_pat, packed=packed)
     results_digest = __import__("hashlib").sha1(np.ascontiguousarray(results).tobytes()).hexdigest()[:16]
-    traffic, valu, stale = static_profile_figures(args.workload, args.kernel, B, kern_ms * 1e3, eng.last_mixture_kernel(),
-                                                  results_digest)
-    unique = unique_bytes_per_launch(n_obj, n_feat, n_states, [g.shape[0] for g in wl.groups], n_pat, B, packed=packed)
-    roofline = roofline_block(b_eval, unique, B, kern_ms, traffic, valu, eng.last_mixture_kernel(), packed,
-                              (f"HIP event pairs on the engine's stream around every {stride}-th launch of the timed loops "
-                               f"({n_timed} of {args.steps * n_reps} launches in {n_reps} repetitions)" if stride > 0 else
-                               f"HIP event pairs around {n_timed} identical launches issued right after the timed loop")
-                              + "; an event pair also holds the dispatch gap behind the previous kernel (2-5 us: rocprofv3's kernel trace of "
-                                "the same command reads that much less, profiles/), so with ONE kernel per step -- the matrix-pipe form "
-                                "reduces inside the kernel -- kernel_avg_us can exceed ms_per_step",
+    timed_kernel = eng.last_mixture_kernel()
+    traffic, valu, stale = static_profile_figures(args.workload, args.kernel, B, kern_ms * 1e3, timed_kernel, results_digest)
+
+    def unique_fn(n):
+        return unique_bytes_per_launch(n_obj, n_feat, n_states, groups_per_comp, n_pat, n, packed=packed)
+    roofline = roofline_block(b_eval, unique_fn(B), B, kern_ms, traffic, valu, timed_kernel, packed,
+                              f"one HIP event pair on the engine's stream around the {args.steps} back-to-back launches of the median "
+                              f"repetition / {args.steps}: the kernel plus the dispatch gap to the next one; it lies inside the "
+                              "host-timed region, so kernel_avg_us <= ms_per_step x 1000 (asserted); rocprofv3's kernel trace of the same "
+                              "command (profiles/) reads the kernel alone",
                               shape=(n_obj, n_feat, n_states))
+    if pair_n:
+        roofline["kernel_event_pairs_us"] = round(pair_ms * 1e3, 3)
+        roofline["kernel_event_pairs_note"] = (f"secondary: HIP event pairs around {pair_n} single launches "
+                                               + ("issued right after the timed loops" if stride <= 0 else f"(every {stride}-th of the timed loops)")
+                                               + "; a pair also holds the dispatch gap behind the PREVIOUS kernel")
 
     # ---- what every rank (= every GPU's chains) saw by itself: north_star asks for PER-CHAIN throughput at each N ------
     # (chains are independent in the reference: sbayes/sampling/mcmc.py:239-241, one OS process per chain in MC3:
@@ -766,10 +952,27 @@ def main():
 
     extra = {}
     if rank == 0 and n_gpus == 1 and not args.no_secondary:
-        extra = secondary_figures(eng, wl, B, args)
+        extra.update(secondary_figures(eng, wl, B, args))
         extra["per_config"] = per_config_block(device, eng if args.workload == "headline" and B >= 64 else None,
                                                0.0 if args.no_cpu_baseline else args.cpu_seconds)
         extra["sampler_replay"] = sampler_replay_block(device, not args.no_cpu_baseline)
+    if legs:
+        # (after every figure that takes slot 0 for the workload's own state: the legs change what the slots hold)
+        # (order matters: the changing-tables leg builds a valid, distinct state in each of the upper B slots -- the candidates of
+        #  its last sweeps -- which the 2 B-state launch of the HBM-regime leg then evaluates next to the lower B)
+        for name, fn in (("changing_tables", lambda: changing_tables_leg(eng, wl, B, sweeps=max(5, min(args.steps, 20)))),
+                         ("hbm_regime", lambda: hbm_regime_leg(eng, wl, 2 * B, args.steps, b_eval, unique_fn))):
+            try:
+                extra[name] = fn()
+                log(f"[bench] {name}: {extra[name]['evals_per_s']:.0f} evals/s")
+            except RuntimeError as exc:
+                if "parity gate failed" in str(exc) or "differ from" in str(exc):
+                    raise                                   # wrong numbers take the whole line down
+                extra[name] = {"error": repr(exc)}
+        if "evals_per_s" in extra.get("hbm_regime", {}):
+            extra["value_hbm_regime"] = extra["hbm_regime"]["evals_per_s"]
+        if "evals_per_s" in extra.get("changing_tables", {}):
+            extra["value_changing_tables"] = extra["changing_tables"]["evals_per_s"]
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
@@ -803,10 +1006,16 @@ def main():
                                     "stress": f"stress synthetic {n_obj}x{n_feat}x{n_states}, K={wl.clusters.shape[0]}, C={wl.n_components} (BASELINE.json configs[4] shape)",
                                     "cfg1": f"cfg1 synthetic {n_obj}x{n_feat}x{n_states} (BASELINE.json configs[0] shape)"}[args.workload],
                        "evals_per_step": B, "chains_per_gpu": B, "kernel": args.kernel, "log_mode": args.log_mode,
+                       "single_chain_evals_per_s": extra.get("single_chain", {}).get("evals_per_s"),
                        "parallelism": f"{n_gpus} independent engine(s), one per GPU, no collectives"},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "parity_rel_err": parity,
+            "parity_timed_kernel_max_rel_err": parity,
+            "parity_timed_kernel": {"slots": parity_slots, "tolerance": 1e-10, "kernel": timed_kernel,
+                                    "what": "the B results of the last timed repetition; slot 0 = the workload's own state (its oracle value "
+                                            "from the host arrays and from the device readback agree), the others random: group ids, source "
+                                            "rows and weights read back from the device, counts recounted by the oracle and compared bit for "
+                                            "bit with the device's, then oracle/sbayes_oracle.py mixture_loglik"},
             "results_sha1": results_digest,   # (rank 0's B results of the last repetition: A/B runs of engine builds must agree on it)
             "device": info["device_name"],
             "dist_backend": chains.backend_name(dist),

@@ -987,6 +987,21 @@ int launch_mfma_form(sbe_engine* e, int first_slot, int n, int KT, const MfmaGeo
     return SBE_OK;
 }
 
+// sbe_kernel_timing: the next event pair of the pool while recording is on (one pair per fused-kernel launch, on the engine's
+// own stream), else two nulls
+int next_timing_events(sbe_engine* e, hipEvent_t* ev_a, hipEvent_t* ev_b) {
+    *ev_a = *ev_b = nullptr;
+    if (!e->ev_timing) return SBE_OK;
+    while ((int)e->ev_pool.size() < 2 * (e->ev_used + 1)) {
+        hipEvent_t ev;
+        HIPCHK(e, hipEventCreate(&ev));
+        e->ev_pool.push_back(ev);
+    }
+    *ev_a = e->ev_pool[2 * e->ev_used]; *ev_b = e->ev_pool[2 * e->ev_used + 1];
+    ++e->ev_used;
+    return SBE_OK;
+}
+
 // Enqueue the dominant kernel (optionally bracketed by an event pair) and the fixed-order
 // partial reduction.  mode: LOG_PER_OBS / LOG_PRODUCT.
 // Slots: first_slot .. first_slot+n-1, or (batched steps) the n slots listed in `slots` (host) / `d_slots` (the same
@@ -1239,15 +1254,7 @@ int enqueue_mixture(sbe_engine* e, int first_slot, int n, int mode, DoneSig* don
         if (e->slots[s].patterns_dirty) { rc = upload_patterns_and_weights(e, s); if (rc) return rc; }
     }
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    if (e->ev_timing) {                             // one event pair per launch, on the engine's own stream
-        while ((int)e->ev_pool.size() < 2 * (e->ev_used + 1)) {
-            hipEvent_t ev;
-            HIPCHK(e, hipEventCreate(&ev));
-            e->ev_pool.push_back(ev);
-        }
-        ev_a = e->ev_pool[2 * e->ev_used]; ev_b = e->ev_pool[2 * e->ev_used + 1];
-        ++e->ev_used;
-    }
+    { int rc = next_timing_events(e, &ev_a, &ev_b); if (rc) return rc; }
     return launch_mixture(e, first_slot, n, mode, ev_a, ev_b, nullptr, nullptr, nullptr, nullptr, done_out);
 }
 

@@ -935,7 +935,10 @@ int sbe_step_batch_delta(sbe_engine* e, int n_chains, const int32_t* cur_slots, 
         k_step_core_batch<<<dim3(max_blocks, ng), kBlock, lds, e->stream>>>(reinterpret_cast<const StepCore*>(dm));
         HIPCHK(e, hipGetLastError());
         markd();                                 // 3: step cores built, uploaded, launched
-        rc = launch_mixture(e, 0, ng, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, nullptr, nullptr, nullptr,
+        hipEvent_t tev_a = nullptr, tev_b = nullptr;       // (sbe_kernel_timing brackets the fused kernel of a batched step too)
+        rc = next_timing_events(e, &tev_a, &tev_b);
+        if (rc) return rc;
+        rc = launch_mixture(e, 0, ng, e->opt_log == SBE_LOG_PRODUCT ? LOG_PRODUCT : LOG_PER_OBS, tev_a, tev_b, nullptr,
                             cand_go.data(), reinterpret_cast<const int32_t*>(dm + part_cores + part_fins),
                             reinterpret_cast<const StepFinish*>(dm + part_cores), &fast_done);
         for (int j = 0; j < ng; ++j) {           // (bookkeeping under the device work: everything is enqueued)

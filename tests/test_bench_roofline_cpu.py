@@ -27,9 +27,14 @@ def test_roofline_block_fractions_and_bound():
     valu = {"frac": 0.55}
     rf = bench.roofline_block(b_eval, unique, B, kern_ms, traffic, valu, "k_mixture_tuple_mfma<..., M tiles 3, C=2>", True, "test",
                               shape=(1000, 200, 10))
-    assert abs(rf["achieved"] - b_eval * B / 50e-6 / 1e9) < 0.01
-    assert abs(rf["frac"] - b_eval * B / 50e-6 / 8e12) < 1e-5 and rf["frac"] > 1.0            # the contract figure exceeds 1
-    assert abs(rf["frac_unique"] - unique / 50e-6 / 8e12) < 1e-5 and rf["frac_unique"] < 0.5
+    # `frac` is the unique-bytes figure -- a fraction of the peak, <= 1 -- and `achieved` the same in GB/s
+    assert abs(rf["achieved"] - unique / 50e-6 / 1e9) < 0.01
+    assert abs(rf["frac"] - unique / 50e-6 / 8e12) < 1e-5 and rf["frac"] < 0.5
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5
+    # the contract figure (shared block counted once per eval) exceeds 1 and lives under its own key
+    assert abs(rf["frac_contract"] - b_eval * B / 50e-6 / 8e12) < 1e-5 and rf["frac_contract"] > 1.0
+    assert abs(rf["achieved_contract"] - b_eval * B / 50e-6 / 1e9) < 0.01
+    assert "frac_unique" not in rf
     assert abs(rf["frac_traffic"] - 150e6 / 50e-6 / 8e12) < 1e-5
     assert rf["unique_bytes_per_launch"] == unique and rf["traffic"] == 150e6
     assert rf["bound"] == "valu"                                      # 0.55 of vector issue > 0.375 of HBM
@@ -42,5 +47,23 @@ def test_roofline_block_fractions_and_bound():
     # a streaming kernel: traffic fraction above the vector fraction -> hbm
     rf3 = bench.roofline_block(4629008, 64 * 4629008, 64, 0.1466, {"bytes_per_launch": 248.6e6, "source": "t"}, {"frac": 0.15}, "k_mixture_rows<...>", True, "t")
     assert rf3["bound"] == "hbm" and abs(rf3["frac_traffic"] - 248.6e6 / 146.6e-6 / 8e12) < 1e-5
+    assert rf3["frac"] == rf3["frac_contract"]                        # one block per state: nothing is shared, the two agree
     # nothing static at all
     assert bench.roofline_block(b_eval, unique, B, kern_ms, None, None, "k", True, "t")["bound"] == "hbm"
+
+
+def test_frac_never_exceeds_one_for_any_kernel_time_the_hardware_allows():
+    """A launch cannot move its unique bytes faster than the peak: at the fastest physically possible kernel time
+    (unique / 8 TB/s) frac is exactly 1 while the contract figure is far above it."""
+    b_eval, B = 254208, 4096
+    unique = 200000 + B * (b_eval - 200000)
+    t_min_ms = unique / 8e12 * 1e3
+    rf = bench.roofline_block(b_eval, unique, B, t_min_ms, None, None, "k", True, "t")
+    assert abs(rf["frac"] - 1.0) < 1e-4 and rf["frac_contract"] > 4.0
+
+
+def test_median_repetition_pairs_time_and_span():
+    """value, ms_per_step and the kernel span come from ONE repetition: the median one (upper median for an even count)."""
+    assert bench._median_rep([3.0, 1.0, 2.0]) == 2
+    assert bench._median_rep([4.0, 1.0, 3.0, 2.0]) == 2
+    assert bench._median_rep([5.0]) == 0

@@ -1,0 +1,106 @@
+"""The BENCHMARKED path under `-m gpu`, as benchmarked: the headline workload (BASELINE.json
+configs[2]: 1000 x 200 x 10, K = 5, C = 2) through the engine's DEFAULT kernel selection, every slot of the launch a DISTINCT
+state, against the oracle.  Reference expression: sbayes/sampling/loggers.py:355-357 over sbayes/model/likelihood.py:104-133,
+171-190.  Tolerance: 1e-10 relative (north_star).
+
+The selection flips at 512 slots per launch (sbe_engine_internal.hip.h: mfma_min_batch): 511 -> k_mixture_tuple64 (vector
+pipe), 512 / 1024 -> k_mixture_tuple_mfma at MT = 3 x 32 k-blocks x 63 column tiles -- bench.py's kernel and geometry.  A
+fixed-seed 60-second slice of tools/fuzz_gpu.py's "big" generator follows (the open-ended fuzzer itself is not part of the suite)."""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+
+from oracle import sbayes_oracle as orc                               # noqa: E402  (checker)
+from sbayes_amd.engine import MIXTURE_PACKED, Engine                   # noqa: E402
+from sbayes_amd.synthetic import make_state, make_workload            # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+N_SLOTS = 1024
+
+
+@pytest.fixture(scope="module")
+def headline_engine():
+    """1024 distinct headline states: slot b = make_state(seed 5000 + b) -- its own clusters, weights and source assignment (the
+    reference's recipe: sample_categorical(normalize_weights(...)), conditionals.py:370-384) -- counts and tables on the device."""
+    wl = make_workload("headline")
+    conf_groups = wl.groups[1:]
+    K = wl.clusters.shape[0]
+    eng = Engine(wl.features, [g.shape[0] for g in wl.groups], n_slots=N_SLOTS)
+    for c in range(wl.n_components):
+        eng.set_concentration(c, wl.concentration[c])
+    eng.set_option(deferred_checks=True)
+    states = []
+    for b in range(N_SLOTS):
+        clusters, weights, source = make_state(wl.features, conf_groups, K, 5000 + b)
+        eng.load_state(b, [clusters, *conf_groups], weights, source=source)
+        for c in range(wl.n_components):
+            eng.update_probs(b, c)
+        states.append((clusters, weights, source))
+    eng.set_option(deferred_checks=False)
+    yield wl, eng, states
+    eng.close()
+
+
+def oracle_value(wl, state):
+    clusters, weights, source = state
+    groups = [clusters, *wl.groups[1:]]
+    counts = orc.recalculate_feature_counts(wl.features, groups, source)
+    return float(orc.mixture_loglik(wl.features, wl.na_values, groups, counts, wl.concentration, weights))
+
+
+@pytest.mark.parametrize("B,kernel", [(511, "k_mixture_tuple64"), (512, "k_mixture_tuple_mfma"), (1024, "k_mixture_tuple_mfma")])
+def test_headline_default_selection_distinct_slots_vs_oracle(headline_engine, B, kernel):
+    wl, eng, states = headline_engine
+    eng.set_option(kernel=MIXTURE_PACKED)                                      # the default: what bench.py runs
+    got = eng.mixture_loglik_batch(0, B)
+    assert kernel in eng.last_mixture_kernel(), eng.last_mixture_kernel()      # both sides of the threshold
+    if "mfma" in kernel:
+        assert "M tiles 3" in eng.last_mixture_kernel()                        # 6 tuples: K = 5 clusters + "no cluster", one universal group
+    assert np.all(np.isfinite(got)) and len(set(got.tolist())) == B            # every slot its own state
+    rng = np.random.default_rng(B)
+    picks = np.unique(np.concatenate([[0, 1, 15, 16, B - 17, B - 16, B - 1], rng.integers(0, B, size=17)]))
+    assert picks.size >= 16
+    want = np.array([oracle_value(wl, states[b]) for b in picks])
+    np.testing.assert_allclose(got[picks], want, rtol=1e-10, atol=0.0)
+    # the asynchronous route bench.py times returns the same bits; so does a second launch (fixed reduction order)
+    eng.mixture_loglik_batch_async(0, B)
+    assert np.array_equal(eng.fetch_results(0, B), got)
+    # and the two kernel forms agree with each other on EVERY slot far inside the tolerance (one of them is oracle-checked above)
+    other = eng.mixture_loglik_batch(0, 511 if B != 511 else 512)
+    n = min(B, other.size)
+    np.testing.assert_allclose(got[:n], other[:n], rtol=1e-12)
+
+
+def test_readback_of_resident_state_matches_what_was_loaded(headline_engine):
+    """sbe_get_group_ids / sbe_get_weights / sbe_get_source_rows (what bench.py's parity gate rebuilds a slot's state from)
+    return what the DEVICE holds, and that is what was loaded."""
+    wl, eng, states = headline_engine
+    for b in (0, 511, 1023):
+        clusters, weights, source = states[b]
+        ids = eng.get_group_ids(b, 0)
+        assert np.array_equal(ids, np.where(clusters.any(axis=0), clusters.argmax(axis=0), -1))
+        assert np.array_equal(eng.get_group_ids(b, 1), np.zeros(wl.shape[0], dtype=np.int32))       # the universal group
+        assert np.array_equal(eng.get_weights(b), weights)
+        rows = eng.get_source_rows(b, np.arange(wl.shape[0], dtype=np.int32))
+        assert np.array_equal(rows.astype(bool), source)
+
+
+def test_fixed_seed_slice_of_the_big_fuzz_generator():
+    """60 seconds of tools/fuzz_gpu.py --big at a fixed seed: shapes of 600-4000 objects x 60-270 features, batches up to 700,
+    through every kernel form (the matrix-pipe form forced wherever it applies) against the oracle at 1e-10 relative +
+    1e-16 per observation (the fuzzer's tolerance: see one_case)."""
+    from tools.fuzz_gpu import one_case
+    rng = np.random.default_rng(20260601)
+    stats = {"cases": 0, "evals": 0, "steps": 0, "gibbs": 0}
+    t0 = time.time()
+    while time.time() - t0 < 60.0 or stats["cases"] < 2:
+        one_case(rng, stats, big=True)
+    assert stats["cases"] >= 2 and stats["evals"] > 0
+    print(f"[fuzz slice] {stats} in {time.time() - t0:.0f} s")

@@ -27,5 +27,5 @@ def test_bench_under_a_forced_process_group(backend):
                          capture_output=True, text=True, timeout=600, env=env, cwd=str(REPO))
     assert res.returncode == 0, res.stderr[-3000:]
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 1 and line["value"] > 0 and line["parity_rel_err"] <= 1e-10
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["parity_timed_kernel_max_rel_err"] <= 1e-10
     assert line["dist_backend"] in (backend, f"gloo (after {backend} failed to initialise)")
