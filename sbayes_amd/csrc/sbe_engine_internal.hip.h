@@ -901,7 +901,7 @@ int check_slot_ready(sbe_engine* e, int slot, bool need_weights) {
 // 1 KB (tile NT and the PF fragments behind it are zero: what the kernel reads instead of branching on bounds).
 int ensure_xt(sbe_engine* e) {
     if (e->d_xt) return SBE_OK;
-    const int NT = div_up((int64_t)e->F * e->S, 32), KBp = round_up(div_up(e->N, 32), 4);
+    const int NT = div_up((int64_t)e->F * e->S, 32), KBp = round_up(div_up(e->N, tuple_mfma_kblock_objects()), 4);
     const size_t bytes = ((size_t)(NT + 1) * KBp + 4) * 1024;
     // built into locals and published only when every step has succeeded: a caller that catches the first
     // error and retries gets the same error again, never a launch with half of this in place
@@ -914,7 +914,7 @@ int ensure_xt(sbe_engine* e) {
         fine_log_table(tab.data());
         HIPCHK(e, hipMalloc((void**)&logtab, tab.size() * sizeof(double)));
         HIPCHK(e, hipMemcpy(logtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
-        launch_xt_frags(e->d_state, xt, e->N, e->F, e->S, e->Fp, NT, KBp, e->stream);
+        launch_xt_frags(e->d_state, xt, e->N, e->F, e->S, e->Fp, NT, KBp, tuple_mfma_fp4(), e->stream);
         HIPCHK(e, hipGetLastError());
         return SBE_OK;
     };
@@ -936,7 +936,7 @@ struct MfmaGeom { int n_split, nt_per_split, MT; size_t lds; };
 MfmaGeom mfma_geometry(const sbe_engine* e, int n, int KT) {
     MfmaGeom g{};
     if (KT < 1 || KT > 8 || e->C > 4) return g;
-    const int NT = div_up((int64_t)e->F * e->S, 32), KBp = round_up(div_up(e->N, 32), 4);
+    const int NT = div_up((int64_t)e->F * e->S, 32), KBp = round_up(div_up(e->N, tuple_mfma_kblock_objects()), 4);
     g.MT = (KT + 1) / 2;
     g.lds = tuple_mfma_lds_bytes(g.MT, e->C, KBp);
     if (g.lds > 160 * 1024) return g;
@@ -1164,7 +1164,7 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
         if (done_out) *done_out = done_k;
     }
     if (mfma) {
-        snprintf(e->last_kernel, sizeof e->last_kernel, "k_mixture_tuple_mfma<packed stream, group-tuple form, matrix pipe, M tiles %d, C=%d>", mg.MT, e->C);
+        snprintf(e->last_kernel, sizeof e->last_kernel, "k_mixture_tuple_mfma<packed stream, group-tuple form, matrix pipe %s, M tiles %d, C=%d>", tuple_mfma_fp4() ? "fp4" : "i8", mg.MT, e->C);
         int rc = launch_mfma_form(e, first_slot, n, KT, mg, d_slots, mfma_reduce, done_k);
         if (rc) return rc;
     } else {

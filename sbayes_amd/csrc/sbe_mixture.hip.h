@@ -62,7 +62,7 @@ struct Mix2Params {
 // batched group-tuple form on the matrix pipe (sbe_mixture_mfma.hip: k_mixture_tuple_mfma)
 struct MfmaMixParams {
     int F, S, FS, Gtot, Np;
-    int NT, KBp;                                   // 32-column tiles of the (feature, state) axis; 32-object k-blocks (padded to a multiple of 4)
+    int NT, KBp;                                   // 32-column tiles of the (feature, state) axis; k-blocks of 64 (FP4 operands) / 32 (i8) objects, padded to a multiple of 4
     int KT;                                        // tuples used by the slots of this launch (max; <= 8)
     int n_batch, n_split, nt_per_split;            // slots of the launch; column splits (blocks per group of 16 slots); column tiles per split
     int first_slot;
@@ -102,7 +102,9 @@ void launch_rowsort(const uint16_t* gid, const uint8_t* pid, uint32_t* out, int3
                     uint32_t row_bytes, uint32_t state_pitch, int step_objects, hipStream_t st);
 void launch_state_s(const uint8_t* state, uint8_t* state_s, int N, int F, int Fp, int pitch, int S, hipStream_t st);
 // sbe_mixture_mfma.hip
-void launch_xt_frags(const uint8_t* state, uint8_t* xt, int N, int F, int S, int Fp, int NT, int KBp, hipStream_t st);
+bool tuple_mfma_fp4();                            // operand format of the count contraction: FP4 (default; a k-block = 64 objects) or i8 (32)
+inline int tuple_mfma_kblock_objects() { return tuple_mfma_fp4() ? 64 : 32; }
+void launch_xt_frags(const uint8_t* state, uint8_t* xt, int N, int F, int S, int Fp, int NT, int KBp, bool fp4, hipStream_t st);
 size_t tuple_mfma_lds_bytes(int MT, int C, int KBp);
 void fine_log_table(double* tab);                 // [2 * 1024] {1/c, log c} of k_mixture_tuple_mfma's log (sbe_mixture_mfma.hip)
 // false (nothing launched): an instance of the kernel carries static LDS, so its dynamic block does not start at address 0

@@ -21,10 +21,20 @@
 // column tiles: 2 x MT accumulator tiles, A fragments from LDS (shared by all waves), X fragments straight from L2 in
 // 1 KB fully coalesced pieces (fragment order in memory), four k-blocks ahead.  Both operands take their k index from the
 // same (lane half, byte) position, so the product does not depend on the instruction's internal k order.
+//
+// Operand format (round 6): FP4.  0 and 1.0 are exact in e2m1 (0x0, 0x2) and a count <= N < 2^24 is exact in an f32 accumulator, so
+// v_mfma_f32_32x32x64_f8f6f4 (cbsz = blgp = 4, scale operands 0: the unscaled form) computes the SAME integers at twice the i8
+// instruction's depth for the same issue time (tools/probe/mfma_fp4_probe.hip: 35.1 against 35.1 counter ticks per instruction,
+// all 1024 outputs of an asymmetric 0/1 contraction exact): half the MFMAs, half the A image in LDS (48 KB instead of 96 KB at the
+// headline shape: N up to ~2 900 fits), half the X-fragment bytes from L2.  A k-block is then 64 objects; a lane's 16 bytes hold
+// 32 nibbles, byte b of dword w: low nibble = object 8 w + b, high nibble = object 8 w + 4 + b of the lane half's 32 objects --
+// the order in which the A build gets them out of the tuple-id bytes with two shifts; the X fragments (k_xt_frags) use the same
+// one.  The i8 form stays selectable (SBE_MFMA_FP4=0) for same-box comparisons; both are oracle-checked.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "sbe_mixture.hip.h"
 
@@ -35,7 +45,9 @@
 namespace sbe {
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
+typedef float v16f_t __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) const v4i_t lds_cv4i_t;
 
 constexpr int kMfmaWaves = 8;
@@ -45,29 +57,41 @@ constexpr int kMfmaRN = kTupleMfmaColsPerPass;   // column tiles per wave pass (
 // (Other block shapes were measured in round 5 and lost: 16 waves x 1 column tile at 128 registers, +9 %; 8 waves x 1 tile with
 //  the next tile's MFMAs issued inside the epilogue, +7 %: profiles/r5/mfma_kernel_experiments_session2.log.)
 
-// One-hot block -> fragment order.  Fragment (nt, kb): lane l holds bytes j = 0..15 = X[n = 32 kb + 16 (l >> 5) + j][col = 32 nt + (l & 31)]
-// with col = f * S + s; zero for n >= N, col >= F * S and NA observations.
+// One-hot block -> fragment order.  i8 operands: fragment (nt, kb): lane l holds bytes j = 0..15 = X[n = 32 kb + 16 (l >> 5) + j]
+// [col = 32 nt + (l & 31)] with col = f * S + s.  FP4 operands: a k-block is 64 objects; lane l holds 32 nibbles (1.0 = 0x2) of
+// the objects n0 = 64 kb + 32 (l >> 5) + ..: byte b of dword w, low nibble = object n0 + 8 w + b, high nibble = n0 + 8 w + 4 + b.
+// Zero for n >= N, col >= F * S and NA observations.
 __global__ void k_xt_frags(const uint8_t* __restrict__ state /* [N][Fp], 0xFF = NA */, uint8_t* __restrict__ xt,
-                           int N, int F, int S, int Fp, int NT, int KBp) {
+                           int N, int F, int S, int Fp, int NT, int KBp, int fp4) {
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= (int64_t)NT * KBp * 64) return;
     const int l = (int)(u & 63), kb = (int)((u >> 6) % KBp), nt = (int)((u >> 6) / KBp);
     const int col = nt * 32 + (l & 31), f = col / S, s = col - f * S;
-    const int n0 = kb * 32 + 16 * (l >> 5);
     uint32_t w[4] = {0u, 0u, 0u, 0u};
     if (col < F * S) {
+        if (fp4) {
+            const int n0 = kb * 64 + 32 * (l >> 5);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int n = n0 + j;
-            if (n < N && state[(int64_t)n * Fp + f] == (uint8_t)s) w[j >> 2] |= 1u << (8 * (j & 3));
+            for (int j = 0; j < 32; ++j) {
+                const int n = n0 + 8 * (j >> 3) + (j & 7);                     // object j of the lane half, in order
+                const int b = j & 3, hi = (j >> 2) & 1;                       // -> byte b of dword j >> 3, low / high nibble
+                if (n < N && state[(int64_t)n * Fp + f] == (uint8_t)s) w[j >> 3] |= 0x2u << (8 * b + 4 * hi);
+            }
+        } else {
+            const int n0 = kb * 32 + 16 * (l >> 5);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int n = n0 + j;
+                if (n < N && state[(int64_t)n * Fp + f] == (uint8_t)s) w[j >> 2] |= 1u << (8 * (j & 3));
+            }
         }
     }
     reinterpret_cast<uint4*>(xt)[u] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-void launch_xt_frags(const uint8_t* state, uint8_t* xt, int N, int F, int S, int Fp, int NT, int KBp, hipStream_t st) {
+void launch_xt_frags(const uint8_t* state, uint8_t* xt, int N, int F, int S, int Fp, int NT, int KBp, bool fp4, hipStream_t st) {
     const int64_t units = (int64_t)NT * KBp * 64;
-    k_xt_frags<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(state, xt, N, F, S, Fp, NT, KBp);
+    k_xt_frags<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(state, xt, N, F, S, Fp, NT, KBp, fp4 ? 1 : 0);
 }
 
 // Table-driven log for this kernel's epilogue, G chains interleaved: log v = k ln2 + log c_i + log1p(r), r = m / c_i - 1, with
@@ -136,8 +160,9 @@ struct __attribute__((aligned(CT <= 1 ? 8 : (CT <= 3 ? 16 : 32)))) TupleMeta {
 
 
 
-template <int MT, int CT, int GT = 4>
+template <int MT, int CT, int GT = 4, bool FP4 = true>
 __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixParams p) {
+    typedef typename std::conditional<FP4, v16f_t, v16i_t>::type acc_t;      // counts: exact integers either way
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -220,7 +245,52 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
     }
     for (int i = (int)threadIdx.x; i < 2 * kFineLogEntries; i += kMfmaThreads)
         reinterpret_cast<double*>(lds_raw + tab_off)[i] = reinterpret_cast<const double*>(p.logtab)[i];
-    {
+    if constexpr (FP4) {
+        // one unit = the 32 tuple ids of (slot sl, lane half h of k-block kb: 32 objects) -> the 2 MT indicator pieces (16 bytes =
+        // 32 nibbles each).  UB units' ids are asked for together (a unit at a time the block's start is dependent trips to L2 / HBM)
+        const int n_units = kMfmaSlots * KBp * 2;
+        constexpr int UB = 2;
+        for (int u0 = (int)threadIdx.x; u0 < n_units; u0 += UB * kMfmaThreads) {
+            uint32_t d[UB][8];
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                const int u = u0 + k * kMfmaThreads;
+                const int sl = u & 15, n0 = (u >> 4) * 32;     // (u >> 4) = kb * 2 + h
+                const int slot = u < n_units ? slot_of(sl) : -1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    d[k][i] = 0xFFFFFFFFu;                                        // matches no tuple
+                    if (slot >= 0 && n0 + 4 * i + 4 <= p.Np)
+                        d[k][i] = *reinterpret_cast<const uint32_t*>(p.tid + (int64_t)slot * p.tid_stride + n0 + 4 * i);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                const int u = u0 + k * kMfmaThreads;
+                if (u >= n_units) break;
+                const int sl = u & 15, hk = u >> 4;
+                const int kb = hk >> 1, h = hk & 1;
+#pragma unroll
+                for (int t = 0; t < 2 * MT; ++t) {
+                    uint4 o;
+                    uint32_t* ov = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+                    for (int wv = 0; wv < 4; ++wv) {
+                        uint32_t eq[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const uint32_t x = d[k][2 * wv + q] ^ ((uint32_t)t * 0x01010101u);
+                            const uint32_t nz = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;      // bit 7 of a byte: byte != 0
+                            eq[q] = (~nz >> 7) & 0x01010101u;
+                        }
+                        ov[wv] = (eq[0] << 1) | (eq[1] << 5);       // 1.0 = 0x2: low nibbles = objects 8 wv + b, high = 8 wv + 4 + b
+                    }
+                    const uint32_t fl = (uint32_t)(h * 32 + (t & 1) * 16 + sl);
+                    *reinterpret_cast<uint4*>(lds_raw + a_off + (((uint32_t)(t >> 1) * (uint32_t)KBp + (uint32_t)kb) * 64u + fl) * 16u) = o;
+                }
+            }
+        }
+    } else {
         // one unit = the 16 tuple ids of (slot sl, 16 objects) -> the 2 MT indicator pieces of those objects.  The ids of
         // UB units are asked for together (a unit at a time the block's start is four dependent trips to L2 / HBM)
         const int n_units = kMfmaSlots * KBp * 2;
@@ -276,7 +346,7 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
 
     // counts of one pass (RN column tiles from the scalar fragment offsets toff[]) into acc; the first PF X fragments of the
     // pass are in bq already
-    auto counts_pass = [&](v16i_t (&acc)[MT][kMfmaRN], const int (&toff)[kMfmaRN]) __attribute__((always_inline)) {
+    auto counts_pass = [&](acc_t (&acc)[MT][kMfmaRN], const int (&toff)[kMfmaRN]) __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -305,7 +375,14 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int r = 0; r < kMfmaRN; ++r)
-                        acc[m][r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_cur[m], b[r], acc[m][r], 0, 0, 0);
+                        if constexpr (FP4) {
+                            // (an FP4 operand is the first four registers of the eight-register operand)
+                            const v8i_t a8 = {a_cur[m].x, a_cur[m].y, a_cur[m].z, a_cur[m].w, 0, 0, 0, 0};
+                            const v8i_t b8 = {b[r].x, b[r].y, b[r].z, b[r].w, 0, 0, 0, 0};
+                            acc[m][r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[m][r], 4, 4, 0, 0, 0, 0);
+                        } else {
+                            acc[m][r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_cur[m], b[r], acc[m][r], 0, 0, 0);
+                        }
 #pragma unroll
                 for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
                 __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);                 // the next k-block's A fragments
@@ -366,14 +443,19 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
                 prq[q & 1][i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr_rsrc, (int)(mdq[i].goff[c] + col4[r]), 0, 0));
         }
     };
-    auto st_comp = [&](int q, const v16i_t (&acc)[MT][kMfmaRN]) __attribute__((always_inline)) {
+    auto st_comp = [&](int q, const acc_t (&acc)[MT][kMfmaRN]) __attribute__((always_inline)) {
         const int r = q % kMfmaRN, u = q / kMfmaRN, mj = u / HQ, half = u % HQ, m = mj >> 2, j = mj & 3;
-        double vv[G], lg[G];
+        double vv[G], lg[G], cntd[G];
         int cnt[G];
         bool special = false;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            cnt[i] = acc[m][r][4 * j + half * G + i];
+            if constexpr (FP4) {
+                const float c = acc[m][r][4 * j + half * G + i];          // an exact integer <= N
+                cnt[i] = (int)c; cntd[i] = (double)c;
+            } else {
+                cnt[i] = acc[m][r][4 * j + half * G + i]; cntd[i] = (double)cnt[i];
+            }
             // sum_c w_c * p_c in NumPy's order.  The product of two float32 values is exact in fp64, so fma(w, p, v)
             // rounds exactly like the reference's multiply-then-add: the same bits as the other kernel forms
             double v = 0.0;
@@ -398,7 +480,7 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int k = (j & 1) * 4 + half * G + i;
-            lsum[k] = fma((double)cnt[i], lg[i], lsum[k]);
+            lsum[k] = fma(cntd[i], lg[i], lsum[k]);
             ksum[k] = __mul24(cnt[i], kx[i]) + ksum[k];            // (host: passes * N * 1100 < 2^31)
             asm volatile("" : "+v"(ksum[k]));
             // (pins the sum in this step's block: the rare-path branch above splits the epilogue into basic blocks and
@@ -418,7 +500,7 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
 #pragma unroll
                 for (int r = 0; r < kMfmaRN; ++r) bq[i][r] = load_b(toff[r], i);
         }
-        v16i_t acc[MT][kMfmaRN];
+        acc_t acc[MT][kMfmaRN];
         counts_pass(acc, toff);
         st_cols(nt0);
         // the single metadata buffer is refilled as soon as the loads of its last step (r = RN - 1) are out
@@ -498,44 +580,63 @@ size_t tuple_mfma_lds_bytes(int MT, int C, int KBp) {     // log table | A fragm
 // entries per epilogue step: a whole register quad where the registers allow it, half a quad for the widest instances
 template <int MT, int CT> constexpr int mfma_gt() { return (MT >= 4 || (MT == 3 && CT >= 3)) ? 2 : 4; }
 
-template <int MT>
+template <int MT, bool FP4>
 static void launch_mfma_mt(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st) {
     switch (C) {
-        case 1: k_mixture_tuple_mfma<MT, 1, mfma_gt<MT, 1>()><<<grid, kMfmaThreads, lds, st>>>(p); break;
-        case 2: k_mixture_tuple_mfma<MT, 2, mfma_gt<MT, 2>()><<<grid, kMfmaThreads, lds, st>>>(p); break;
-        case 3: k_mixture_tuple_mfma<MT, 3, mfma_gt<MT, 3>()><<<grid, kMfmaThreads, lds, st>>>(p); break;
-        default: k_mixture_tuple_mfma<MT, 4, mfma_gt<MT, 4>()><<<grid, kMfmaThreads, lds, st>>>(p); break;
+        case 1: k_mixture_tuple_mfma<MT, 1, mfma_gt<MT, 1>(), FP4><<<grid, kMfmaThreads, lds, st>>>(p); break;
+        case 2: k_mixture_tuple_mfma<MT, 2, mfma_gt<MT, 2>(), FP4><<<grid, kMfmaThreads, lds, st>>>(p); break;
+        case 3: k_mixture_tuple_mfma<MT, 3, mfma_gt<MT, 3>(), FP4><<<grid, kMfmaThreads, lds, st>>>(p); break;
+        default: k_mixture_tuple_mfma<MT, 4, mfma_gt<MT, 4>(), FP4><<<grid, kMfmaThreads, lds, st>>>(p); break;
     }
 }
 
 // one-time: the kernels ask for up to the whole 160 KB of a CU's LDS.  The log table's index is its whole LDS address
 // (tab_off = 0), which holds only while the kernel has NO static LDS: checked here, once, on the host -- the guard inside the
 // kernel would store NaNs but not take its completion tickets, and a host-synchronous caller would wait for them.
-template <int MT, int CT>
+template <int MT, int CT, bool FP4>
 static bool allow_lds() {
-    const void* fn = reinterpret_cast<const void*>(&k_mixture_tuple_mfma<MT, CT, mfma_gt<MT, CT>()>);
+    const void* fn = reinterpret_cast<const void*>(&k_mixture_tuple_mfma<MT, CT, mfma_gt<MT, CT>(), FP4>);
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncAttributes attr{};
     if (hipFuncGetAttributes(&attr, fn) != hipSuccess) { (void)hipGetLastError(); return true; }   // (not answerable: the kernel's own guard stays)
     return attr.sharedSizeBytes == 0;
 }
 
+template <bool FP4>
+static bool allow_lds_all() {
+    bool ok = true;
+    ok &= allow_lds<1, 1, FP4>(); ok &= allow_lds<1, 2, FP4>(); ok &= allow_lds<1, 3, FP4>(); ok &= allow_lds<1, 4, FP4>();
+    ok &= allow_lds<2, 1, FP4>(); ok &= allow_lds<2, 2, FP4>(); ok &= allow_lds<2, 3, FP4>(); ok &= allow_lds<2, 4, FP4>();
+    ok &= allow_lds<3, 1, FP4>(); ok &= allow_lds<3, 2, FP4>(); ok &= allow_lds<3, 3, FP4>(); ok &= allow_lds<3, 4, FP4>();
+    ok &= allow_lds<4, 1, FP4>(); ok &= allow_lds<4, 2, FP4>(); ok &= allow_lds<4, 3, FP4>(); ok &= allow_lds<4, 4, FP4>();
+    return ok;
+}
+
+// operand format of the count contraction: FP4 (default) or i8 (SBE_MFMA_FP4=0: same-box comparisons); fixed for the process
+bool tuple_mfma_fp4() {
+    static const bool on = [] { const char* v = getenv("SBE_MFMA_FP4"); return !(v && atoi(v) == 0); }();
+    return on;
+}
+
 bool launch_tuple_mfma(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st) {
-    static const bool no_static_lds = [] {
-        bool ok = true;
-        ok &= allow_lds<1, 1>(); ok &= allow_lds<1, 2>(); ok &= allow_lds<1, 3>(); ok &= allow_lds<1, 4>();
-        ok &= allow_lds<2, 1>(); ok &= allow_lds<2, 2>(); ok &= allow_lds<2, 3>(); ok &= allow_lds<2, 4>();
-        ok &= allow_lds<3, 1>(); ok &= allow_lds<3, 2>(); ok &= allow_lds<3, 3>(); ok &= allow_lds<3, 4>();
-        ok &= allow_lds<4, 1>(); ok &= allow_lds<4, 2>(); ok &= allow_lds<4, 3>(); ok &= allow_lds<4, 4>();
-        return ok;
-    }();
+    const bool fp4 = tuple_mfma_fp4();
+    static const bool no_static_lds = tuple_mfma_fp4() ? allow_lds_all<true>() : allow_lds_all<false>();
     if (!no_static_lds) return false;
     const int MT = (p.KT + 1) / 2;
-    switch (MT) {
-        case 1: launch_mfma_mt<1>(C, p, grid, lds, st); break;
-        case 2: launch_mfma_mt<2>(C, p, grid, lds, st); break;
-        case 3: launch_mfma_mt<3>(C, p, grid, lds, st); break;
-        default: launch_mfma_mt<4>(C, p, grid, lds, st); break;
+    if (fp4) {
+        switch (MT) {
+            case 1: launch_mfma_mt<1, true>(C, p, grid, lds, st); break;
+            case 2: launch_mfma_mt<2, true>(C, p, grid, lds, st); break;
+            case 3: launch_mfma_mt<3, true>(C, p, grid, lds, st); break;
+            default: launch_mfma_mt<4, true>(C, p, grid, lds, st); break;
+        }
+    } else {
+        switch (MT) {
+            case 1: launch_mfma_mt<1, false>(C, p, grid, lds, st); break;
+            case 2: launch_mfma_mt<2, false>(C, p, grid, lds, st); break;
+            case 3: launch_mfma_mt<3, false>(C, p, grid, lds, st); break;
+            default: launch_mfma_mt<4, false>(C, p, grid, lds, st); break;
+        }
     }
     return true;
 }
