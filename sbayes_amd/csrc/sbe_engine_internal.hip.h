@@ -912,8 +912,11 @@ int ensure_xt(sbe_engine* e) {
         HIPCHK(e, hipMemsetAsync(xt, 0, bytes, e->stream));
         std::vector<double> tab(2 * 1024);               // the kernel's own log table (tab_log4_n)
         fine_log_table(tab.data());
-        HIPCHK(e, hipMalloc((void**)&logtab, tab.size() * sizeof(double)));
+        // (the per-column object counts of the exponent bias sit behind the table in the same allocation)
+        HIPCHK(e, hipMalloc((void**)&logtab, tab.size() * sizeof(double) + (size_t)(NT + 1) * 32 * sizeof(int32_t)));
         HIPCHK(e, hipMemcpy(logtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        launch_colcount(e->d_state, reinterpret_cast<int32_t*>(logtab + 1024), e->N, e->F, e->S, e->Fp, NT, e->stream);
+        HIPCHK(e, hipGetLastError());
         launch_xt_frags(e->d_state, xt, e->N, e->F, e->S, e->Fp, NT, KBp, tuple_mfma_fp4(), e->stream);
         HIPCHK(e, hipGetLastError());
         return SBE_OK;
@@ -952,9 +955,9 @@ MfmaGeom mfma_geometry(const sbe_engine* e, int n, int KT) {
     g.nt_per_split = round_up(div_up(NT, n_split), 2);
     // (the kernel sums count * binary exponent in 32-bit integers, one accumulator per lane and slot: in a pass of 16 tiles a
     //  lane adds the entries of its kTupleMfmaColsPerPass columns -- over every M tile and both tuples of a tile -- into the
-    //  same accumulator, and a slot's counts of ONE column add up to at most N over its tuples; |exponent| <= 1100 covers
-    //  every double, the product of two float32 values stays above 2^-300)
-    if ((int64_t)div_up(g.nt_per_split, 16) * kTupleMfmaColsPerPass * e->N * 1100 >= ((int64_t)1 << 31)) return g;
+    //  same accumulator, and a slot's counts of ONE column add up to at most N over its tuples; the exponents are summed
+    //  BIASED (0 .. 2046; the bias leaves as 1023 x the columns' object count at the end), 2100 covers every double)
+    if ((int64_t)div_up(g.nt_per_split, 16) * kTupleMfmaColsPerPass * e->N * 2100 >= ((int64_t)1 << 31)) return g;
     g.n_split = div_up(NT, g.nt_per_split);
     return g;
 }
@@ -979,6 +982,7 @@ int launch_mfma_form(sbe_engine* e, int first_slot, int n, int KT, const MfmaGeo
     p.wpat_ones_off = (uint32_t)((int64_t)e->n_slots * e->Pmax * e->F * e->C * 4);
     p.wpat_bytes = p.wpat_ones_off + (uint32_t)(e->F * e->C * 4);
     p.logtab = e->d_logtab_fine;
+    p.colcount = reinterpret_cast<const int32_t*>(e->d_logtab_fine + 1024);
     p.partials = e->d_partials; p.partials_stride = e->partials_stride;
     if (reduce_in_kernel) { p.results = e->d_results; p.arrive = e->d_arrive; p.done = done; }
     if (!launch_tuple_mfma(e->C, p, dim3((unsigned)(div_up(n, 16) * mg.n_split)), mg.lds, e->stream))

@@ -74,7 +74,8 @@ struct MfmaMixParams {
     const float* probs;      int64_t probs_stride;  uint32_t probs_bytes;   // per slot [Gtot][F][S] float32 tables (a4), whole array < 4 GiB
     const float* wpat;       int64_t wpat_stride;   uint32_t wpat_bytes;    // per slot [Pmax][F][C] float32 normalised weights (a5)
     uint32_t probs_ones_off, wpat_ones_off;        // byte offsets of the rows of ones behind the two arrays (F*S / F*C floats)
-    const double2* logtab;                         // [1024] {1/c, log c}: this kernel's own finer table (tab_log3_n)
+    const double2* logtab;                         // [1024] {1/c, log c}: this kernel's own finer table (tab_log4_n)
+    const int32_t* colcount;                       // [(NT + 1) * 32] objects per (feature, state) column over all tuples (k_colcount); zero padding
     double* partials;        int64_t partials_stride;
     // final reduction inside the kernel (results != nullptr): the LAST of a slot group's n_split blocks to finish -- tickets in
     // arrive[group], which it leaves at 0 -- adds the group's partial sums in split order and writes the 16 results; `done`
@@ -105,6 +106,7 @@ void launch_state_s(const uint8_t* state, uint8_t* state_s, int N, int F, int Fp
 bool tuple_mfma_fp4();                            // operand format of the count contraction: FP4 (default; a k-block = 64 objects) or i8 (32)
 inline int tuple_mfma_kblock_objects() { return tuple_mfma_fp4() ? 64 : 32; }
 void launch_xt_frags(const uint8_t* state, uint8_t* xt, int N, int F, int S, int Fp, int NT, int KBp, bool fp4, hipStream_t st);
+void launch_colcount(const uint8_t* state, int32_t* colcount, int N, int F, int S, int Fp, int NT, hipStream_t st);
 size_t tuple_mfma_lds_bytes(int MT, int C, int KBp);
 void fine_log_table(double* tab);                 // [2 * 1024] {1/c, log c} of k_mixture_tuple_mfma's log (sbe_mixture_mfma.hip)
 // false (nothing launched): an instance of the kernel carries static LDS, so its dynamic block does not start at address 0

@@ -89,6 +89,22 @@ __global__ void k_xt_frags(const uint8_t* __restrict__ state /* [N][Fp], 0xFF = 
     reinterpret_cast<uint4*>(xt)[u] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// colcount[col] = objects whose feature f is in state s (col = f * S + s); zero for the padding columns and the whole tile NT
+__global__ void k_colcount(const uint8_t* __restrict__ state, int32_t* __restrict__ colcount, int N, int F, int S, int Fp, int NT) {
+    const int col = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (col >= (NT + 1) * 32) return;
+    int c = 0;
+    if (col < F * S) {
+        const int f = col / S, s = col - f * S;
+        for (int n = 0; n < N; ++n) c += state[(int64_t)n * Fp + f] == (uint8_t)s;
+    }
+    colcount[col] = c;
+}
+
+void launch_colcount(const uint8_t* state, int32_t* colcount, int N, int F, int S, int Fp, int NT, hipStream_t st) {
+    k_colcount<<<(unsigned)(((NT + 1) * 32 + 255) / 256), 256, 0, st>>>(state, colcount, N, F, S, Fp, NT);
+}
+
 void launch_xt_frags(const uint8_t* state, uint8_t* xt, int N, int F, int S, int Fp, int NT, int KBp, bool fp4, hipStream_t st) {
     const int64_t units = (int64_t)NT * KBp * 64;
     k_xt_frags<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(state, xt, N, F, S, Fp, NT, KBp, fp4 ? 1 : 0);
@@ -111,16 +127,24 @@ void launch_xt_frags(const uint8_t* state, uint8_t* xt, int N, int F, int S, int
 constexpr int kFineLogEntries = 1024;
 constexpr int kFineLogSplit = 424;                                        // 1 + 424/1024 = 1.4140625 ~ sqrt(2)
 constexpr uint32_t kFineLogCarry = 0x00100000u - ((uint32_t)kFineLogSplit << 10);
+// (round 6: the exponent comes back BIASED -- (hi + carry) >> 20, no "- 1023" per entry: the caller takes 1023 x the column's
+//  object count off the integer sum once per lane -- and the mantissa's high word is one v_bfi_b32 with the mask in an SGPR and the
+//  exponent pattern in a VGPR instead of v_and + v_or with two literals: two vector instructions fewer per table entry.)
+constexpr int kFineLogBias = 1023;
 template <int G>
-__device__ __forceinline__ void tab_log4_n(const double (&v)[G], double (&out)[G], int (&kexp)[G], uint32_t tab) {
+__device__ __forceinline__ void tab_log4_n(const double (&v)[G], double (&out)[G], int (&kexp)[G], uint32_t tab, uint32_t one_hi /* 0x3FF00000 in a VGPR */) {
     f64x2_t e[G];
     double m[G], r[G], q[G];
+    uint32_t mant_mask = 0x000FFFFFu;
+    asm volatile("" : "+s"(mant_mask));                                          // (kept in an SGPR: v_bfi_b32 takes no literal)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const uint32_t hi = (uint32_t)__double2hiint(v[g]);
         e[g] = *(lds_cf64x2_t*)(uintptr_t)(tab + ((hi >> 6) & 0x3FF0u));        // entry (hi >> 10) & 1023
-        m[g] = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), __double2loint(v[g]));
-        kexp[g] = (int)((hi + kFineLogCarry) >> 20) - 1023;
+        uint32_t mh;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(mh) : "s"(mant_mask), "v"(hi), "v"(one_hi));   // (hi & 0xFFFFF) | 0x3FF00000
+        m[g] = __hiloint2double((int)mh, __double2loint(v[g]));
+        kexp[g] = (int)((hi + kFineLogCarry) >> 20);                              // biased by kFineLogBias
     }
     // log1p(r) to r^4 in s = r / 2 (the table holds 1 / (2 c), so s comes out of the first FMA):
     //     r - r^2/2 + r^3/3 - r^4/4 = s (2 + s (-2 + s (8/3 - 4 s)))
@@ -340,6 +364,9 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
     int ksum[8];                                                  // ... and of cnt * binary exponent (exact)
 #pragma unroll
     for (int i = 0; i < 8; ++i) { lsum[i] = 0.0; ksum[i] = 0; }
+    int csum = 0;                                                 // objects counted in this lane's columns so far (the same for every slot)
+    uint32_t one_hi = 0x3FF00000u;
+    asm volatile("" : "+v"(one_hi));                              // (a VGPR operand of tab_log4_n's v_bfi_b32)
     const __amdgpu_buffer_rsrc_t pr_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.probs), 0, (int)p.probs_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpat), 0, (int)p.wpat_bytes, 0x00020000);
     const uint32_t a_lane = a_off + (uint32_t)lane * 16u;
@@ -468,20 +495,20 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
             special |= __builtin_amdgcn_class(v, 0x2FF);            // anything but a positive normal double
         }
         int kx[G];
-        tab_log4_n<G>(vv, lg, kx, tab_off);
+        tab_log4_n<G>(vv, lg, kx, tab_off, one_hi);
         // Rare: a table entry that is not a positive normal number -- the zero probability of an inapplicable state,
         // which no observation falls on (contributes nothing, whatever it is), or of an observed one (log 0 = -inf,
         // like the reference), or corrupt input (library log).
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0ull, 0)) {
 #pragma unroll
             for (int i = 0; i < G; ++i)
-                if (__builtin_amdgcn_class(vv[i], 0x2FF)) { lg[i] = cnt[i] != 0 ? lib_log(vv[i]) : 0.0; kx[i] = 0; }
+                if (__builtin_amdgcn_class(vv[i], 0x2FF)) { lg[i] = cnt[i] != 0 ? lib_log(vv[i]) : 0.0; kx[i] = kFineLogBias; }
         }
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int k = (j & 1) * 4 + half * G + i;
             lsum[k] = fma(cntd[i], lg[i], lsum[k]);
-            ksum[k] = __mul24(cnt[i], kx[i]) + ksum[k];            // (host: passes * N * 1100 < 2^31)
+            ksum[k] = __mul24(cnt[i], kx[i]) + ksum[k];            // (biased exponents; host: passes * columns per lane * N * 2100 < 2^31)
             asm volatile("" : "+v"(ksum[k]));
             // (pins the sum in this step's block: the rare-path branch above splits the epilogue into basic blocks and
             //  the compiler otherwise sinks the whole chain of sums to the last one, keeping every log alive: 150 spills)
@@ -500,8 +527,15 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
 #pragma unroll
                 for (int r = 0; r < kMfmaRN; ++r) bq[i][r] = load_b(toff[r], i);
         }
+        // the column's object count over all tuples (data only: every object is in exactly one tuple of every slot), for the
+        // exponent bias; tiles beyond the split read the zero row behind the array
+        int ccnt[kMfmaRN];
+#pragma unroll
+        for (int r = 0; r < kMfmaRN; ++r) ccnt[r] = p.colcount[(nt0 + r < nt_hi ? nt0 + r : p.NT) * 32 + cl];
         acc_t acc[MT][kMfmaRN];
         counts_pass(acc, toff);
+#pragma unroll
+        for (int r = 0; r < kMfmaRN; ++r) csum += ccnt[r];
         st_cols(nt0);
         // the single metadata buffer is refilled as soon as the loads of its last step (r = RN - 1) are out
         st_meta(0);
@@ -520,7 +554,8 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
     // ---- phase 2: fixed-order reduction: 32 columns of a lane half, then the 8 waves ------------------------------------
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        double v = fma((double)ksum[i], 6.93147180559945286227e-01, lsum[i]);
+        // (slots beyond the batch counted nothing: their sums are discarded below, whatever the bias makes of them)
+        double v = fma((double)(ksum[i] - kFineLogBias * csum), 6.93147180559945286227e-01, lsum[i]);
 #pragma unroll
         for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
         lsum[i] = v;
