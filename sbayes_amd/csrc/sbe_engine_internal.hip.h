@@ -913,9 +913,9 @@ int ensure_xt(sbe_engine* e) {
         std::vector<double> tab(2 * 1024);               // the kernel's own log table (tab_log4_n)
         fine_log_table(tab.data());
         // (the per-column object counts of the exponent bias sit behind the table in the same allocation)
-        HIPCHK(e, hipMalloc((void**)&logtab, tab.size() * sizeof(double) + (size_t)(NT + 1) * 32 * sizeof(int32_t)));
+        HIPCHK(e, hipMalloc((void**)&logtab, tab.size() * sizeof(double) + column_tables_bytes(NT)));
         HIPCHK(e, hipMemcpy(logtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
-        launch_colcount(e->d_state, reinterpret_cast<int32_t*>(logtab + 1024), e->N, e->F, e->S, e->Fp, NT, e->stream);
+        launch_column_tables(e->d_state, reinterpret_cast<int32_t*>(logtab + 1024), e->N, e->F, e->S, e->Fp, NT, e->stream);
         HIPCHK(e, hipGetLastError());
         launch_xt_frags(e->d_state, xt, e->N, e->F, e->S, e->Fp, NT, KBp, tuple_mfma_fp4(), e->stream);
         HIPCHK(e, hipGetLastError());
@@ -935,13 +935,24 @@ int ensure_xt(sbe_engine* e) {
 }
 
 // geometry of a matrix-pipe launch over n slots with at most KT tuples each; n_split = 0: the form does not apply
-struct MfmaGeom { int n_split, nt_per_split, MT; size_t lds; };
+struct MfmaGeom { int n_split, nt_per_split, MT; size_t lds; bool ws; };
+// the wave-specialised kernel (sbe_mixture_mfma_ws.hip): OPT-IN (SBE_MFMA_WS=1).  Measured on hardware it loses to the
+// unspecialised kernel at the headline shape (72.0 against 64.5 us per 4096 states, profiles/r6/ws_experiment.log); kept, tested
+// (tests/test_gpu_shapes.py::test_mfma_wave_specialised_form) and selectable for same-box comparisons.
+static bool mfma_ws_wanted() {
+    static const bool on = [] { const char* v = getenv("SBE_MFMA_WS"); return v && atoi(v) == 1; }();
+    return on;
+}
 MfmaGeom mfma_geometry(const sbe_engine* e, int n, int KT) {
     MfmaGeom g{};
     if (KT < 1 || KT > 8 || e->C > 4) return g;
     const int NT = div_up((int64_t)e->F * e->S, 32), KBp = round_up(div_up(e->N, tuple_mfma_kblock_objects()), 4);
     g.MT = (KT + 1) / 2;
     g.lds = tuple_mfma_lds_bytes(g.MT, e->C, KBp);
+    if (tuple_mfma_fp4() && mfma_ws_wanted() && tuple_mfma_ws_lds_bytes(g.MT, e->C, KBp) <= 160 * 1024) {
+        g.ws = true;
+        g.lds = tuple_mfma_ws_lds_bytes(g.MT, e->C, KBp);
+    }
     if (g.lds > 160 * 1024) return g;
     // the tables are addressed through 32-bit buffer offsets
     const int64_t probs_bytes = ((int64_t)e->n_slots * e->table_elems() + (int64_t)e->F * e->S) * 4;
@@ -983,9 +994,12 @@ int launch_mfma_form(sbe_engine* e, int first_slot, int n, int KT, const MfmaGeo
     p.wpat_bytes = p.wpat_ones_off + (uint32_t)(e->F * e->C * 4);
     p.logtab = e->d_logtab_fine;
     p.colcount = reinterpret_cast<const int32_t*>(e->d_logtab_fine + 1024);
+    p.colfeat = p.colcount + (size_t)(e->xt_NT + 1) * 32;
+    p.tile_prefix = p.colcount + (size_t)(e->xt_NT + 1) * 64;
     p.partials = e->d_partials; p.partials_stride = e->partials_stride;
     if (reduce_in_kernel) { p.results = e->d_results; p.arrive = e->d_arrive; p.done = done; }
-    if (!launch_tuple_mfma(e->C, p, dim3((unsigned)(div_up(n, 16) * mg.n_split)), mg.lds, e->stream))
+    const dim3 grid((unsigned)(div_up(n, 16) * mg.n_split));
+    if (!(mg.ws ? launch_tuple_mfma_ws(e->C, p, grid, mg.lds, e->stream) : launch_tuple_mfma(e->C, p, grid, mg.lds, e->stream)))
         return fail(e, SBE_ERR_STATE, "k_mixture_tuple_mfma was built with static LDS: its log table must sit at LDS address 0 "
                                       "(toolchain change; rebuild without static __shared__ in sbe_mixture_mfma.hip)");
     return SBE_OK;
@@ -1168,7 +1182,7 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
         if (done_out) *done_out = done_k;
     }
     if (mfma) {
-        snprintf(e->last_kernel, sizeof e->last_kernel, "k_mixture_tuple_mfma<packed stream, group-tuple form, matrix pipe %s, M tiles %d, C=%d>", tuple_mfma_fp4() ? "fp4" : "i8", mg.MT, e->C);
+        snprintf(e->last_kernel, sizeof e->last_kernel, "k_mixture_tuple_mfma%s<packed stream, group-tuple form, matrix pipe %s, M tiles %d, C=%d>", mg.ws ? "_ws" : "", tuple_mfma_fp4() ? "fp4" : "i8", mg.MT, e->C);
         int rc = launch_mfma_form(e, first_slot, n, KT, mg, d_slots, mfma_reduce, done_k);
         if (rc) return rc;
     } else {

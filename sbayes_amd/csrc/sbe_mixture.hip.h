@@ -76,6 +76,8 @@ struct MfmaMixParams {
     uint32_t probs_ones_off, wpat_ones_off;        // byte offsets of the rows of ones behind the two arrays (F*S / F*C floats)
     const double2* logtab;                         // [1024] {1/c, log c}: this kernel's own finer table (tab_log4_n)
     const int32_t* colcount;                       // [(NT + 1) * 32] objects per (feature, state) column over all tuples (k_colcount); zero padding
+    const int32_t* colfeat;                        // [(NT + 1) * 32] feature of the column
+    const int32_t* tile_prefix;                    // [NT + 2] observations counted in the column tiles before t
     double* partials;        int64_t partials_stride;
     // final reduction inside the kernel (results != nullptr): the LAST of a slot group's n_split blocks to finish -- tickets in
     // arrive[group], which it leaves at 0 -- adds the group's partial sums in split order and writes the 16 results; `done`
@@ -106,7 +108,11 @@ void launch_state_s(const uint8_t* state, uint8_t* state_s, int N, int F, int Fp
 bool tuple_mfma_fp4();                            // operand format of the count contraction: FP4 (default; a k-block = 64 objects) or i8 (32)
 inline int tuple_mfma_kblock_objects() { return tuple_mfma_fp4() ? 64 : 32; }
 void launch_xt_frags(const uint8_t* state, uint8_t* xt, int N, int F, int S, int Fp, int NT, int KBp, bool fp4, hipStream_t st);
-void launch_colcount(const uint8_t* state, int32_t* colcount, int N, int F, int S, int Fp, int NT, hipStream_t st);
+size_t column_tables_bytes(int NT);               // colcount | colfeat | tile_prefix (MfmaMixParams), one allocation
+void launch_column_tables(const uint8_t* state, int32_t* out, int N, int F, int S, int Fp, int NT, hipStream_t st);
+// sbe_mixture_mfma_ws.hip: the wave-specialised form (producer waves count, consumer waves evaluate); FP4 operands only
+size_t tuple_mfma_ws_lds_bytes(int MT, int C, int KBp);
+bool launch_tuple_mfma_ws(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st);
 size_t tuple_mfma_lds_bytes(int MT, int C, int KBp);
 void fine_log_table(double* tab);                 // [2 * 1024] {1/c, log c} of k_mixture_tuple_mfma's log (sbe_mixture_mfma.hip)
 // false (nothing launched): an instance of the kernel carries static LDS, so its dynamic block does not start at address 0

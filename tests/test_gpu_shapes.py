@@ -3,6 +3,8 @@ fixtures do not reach -- N not a multiple of 4, F not a multiple of the tile wid
 C = 1..6 (compile-time 1..4 and the runtime-C instantiation), many groups, objects in no group,
 all three feature-tile widths (SBE_FT), both streamed representations, both log modes."""
 import os
+import sys
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -483,3 +485,51 @@ def test_rows_kernel_pattern_sorted_objects(shape, monkeypatch):
         assert np.array_equal(got2[keep], got[keep])
         eng.set_option(kernel=MIXTURE_PACKED_V2)                         # the older general kernel: same values to rounding
         np.testing.assert_allclose(eng.mixture_loglik_batch(0, B), got2, rtol=1e-12)
+
+
+def test_mfma_wave_specialised_form():
+    """The opt-in wave-specialised form of the matrix-pipe kernel (SBE_MFMA_WS=1: producer waves count, consumer waves evaluate;
+    sbe_mixture_mfma_ws.hip) gives the oracle's values.  The switch is read once per process, so this runs in a child."""
+    import subprocess
+    code = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import sbayes_oracle as orc
+from sbayes_amd.engine import MIXTURE_PACKED_TUPLE_MFMA, Engine
+from tests.test_gpu_shapes import random_case
+for (N, F, S, n_groups, B) in [(203, 72, 4, [3, 1], 19), (1000, 37, 3, [5, 1], 64), (120, 36, 5, [2, 1, 1], 17), (97, 130, 20, [6, 1], 40), (130, 40, 6, [4], 33)]:
+    rng = np.random.default_rng(N + B)
+    feats, groups0, _w, _s, conc = random_case(rng, N, F, S, n_groups, 0.05)
+    na = ~feats.any(-1)
+    C = len(n_groups)
+    with Engine(feats, n_groups, n_slots=B) as eng:
+        for c in range(C):
+            eng.set_concentration(c, conc[c])
+        want = []
+        for b in range(B):
+            if C == 1:
+                groups = groups0
+            else:
+                a = rng.integers(0, 2 * n_groups[0], size=N)
+                groups = [np.stack([a == k for k in range(n_groups[0])])] + groups0[1:]
+            weights = rng.dirichlet(np.ones(C), size=F).astype(np.float32)
+            hc = orc.has_components(groups)
+            source = np.eye(C, dtype=bool)[np.argmax(rng.random((N, F, C)) * hc[:, None, :], axis=-1)]
+            source[na] = False
+            source[~hc.any(1)] = False
+            eng.load_state(b, groups, weights, source=source)
+            for c in range(C):
+                eng.update_probs(b, c)
+            counts = orc.recalculate_feature_counts(feats, groups, source)
+            want.append(orc.mixture_loglik(feats, na, groups, counts, conc, weights))
+        eng.set_option(kernel=MIXTURE_PACKED_TUPLE_MFMA)
+        got = eng.mixture_loglik_batch(0, B)
+        assert "k_mixture_tuple_mfma_ws" in eng.last_mixture_kernel(), eng.last_mixture_kernel()
+        np.testing.assert_allclose(got, np.array(want), rtol=1e-10)
+        assert np.array_equal(eng.mixture_loglik_batch(0, B), got)
+print("ws ok")
+''' % str(Path(__file__).resolve().parent.parent)
+    env = dict(os.environ, SBE_MFMA_WS="1")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0 and "ws ok" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
