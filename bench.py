@@ -65,6 +65,7 @@ N_SIMDS = 1024             # 256 CUs x 4 SIMD-32
 HEADLINE_BATCH = 4096      # resident states per launch (tools/summarize_profiles.py keys the PMC passes on it)
 NOMINAL_CLOCK_GHZ = 2.4    # MI355X_MICROARCH.md "Max clock"
 I8_MFMA_PEAK_TOPS = 5000.0 # MI355X_MICROARCH.md: dense i8 MFMA = 2 x the bf16 rate (~2.5 PF): ~5 POP/s
+FP4_MFMA_PEAK_TOPS = 10000.0   # MI355X_MICROARCH.md: dense FP4 (v_mfma_f32_32x32x64_f8f6f4) = 4 x the bf16 rate: ~10 PF
 PMC_FILE = "profiles/r5/pmc_summary.json"
 TRAFFIC_FILE = "profiles/traffic_latest.json"
 
@@ -782,14 +783,19 @@ def roofline_block(b_eval, unique_bytes, B, kern_ms, traffic, valu, kernel_name,
         import re
         m = re.search(r"M tiles (\d+)", kernel_name)
         mt = int(m.group(1)) if m else 1
+        m = re.search(r"(\d+) slots x", kernel_name)
+        sl = int(m.group(1)) if m else 16                    # slots per block (16 / 4 / 2)
+        fp4 = "fp4" in kernel_name
         n_obj, n_feat, n_states = shape
-        rows = -(-B // 16) * mt * 32
+        rows = -(-B // sl) * mt * 32
         cols = -(-(n_feat * n_states) // 32) * 32
-        depth = -(-n_obj // 128) * 128
+        depth = -(-n_obj // 256) * 256 if fp4 else -(-n_obj // 128) * 128      # k-blocks of 64 (FP4) / 32 (i8) objects, four at a time
         ops = 2.0 * rows * cols * depth
-        out["matrix_pipe"] = {"int8_ops_per_launch": ops, "achieved_tops": round(ops / kern_s / 1e12, 1), "peak_tops": I8_MFMA_PEAK_TOPS,
-                              "frac": round(ops / kern_s / 1e12 / I8_MFMA_PEAK_TOPS, 4),
-                              "note": "v_mfma_i32_32x32x32_i8 work of the count contraction (padded tile sizes) over the measured "
+        peak = FP4_MFMA_PEAK_TOPS if fp4 else I8_MFMA_PEAK_TOPS
+        out["matrix_pipe"] = {("fp4_ops_per_launch" if fp4 else "int8_ops_per_launch"): ops, "achieved_tops": round(ops / kern_s / 1e12, 1),
+                              "peak_tops": peak, "frac": round(ops / kern_s / 1e12 / peak, 4),
+                              "note": ("v_mfma_f32_32x32x64_f8f6f4 (FP4 x FP4, exact 0/1 operands)" if fp4 else "v_mfma_i32_32x32x32_i8")
+                                      + " work of the count contraction (padded tile sizes) over the measured "
                                       "kernel time; the kernel's vector epilogue (one log per table entry), not the matrix pipe, is its limiter"}
     return out
 

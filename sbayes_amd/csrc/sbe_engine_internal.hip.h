@@ -86,7 +86,7 @@ struct sbe_engine {
     int64_t hbm_bytes = 0;
     std::string last_error;
     char device_name[64] = {0};
-    char last_kernel[96] = "none";     // kernel form of the most recent fused-kernel launch (sbe_last_mixture_kernel)
+    char last_kernel[128] = "none";     // kernel form of the most recent fused-kernel launch (sbe_last_mixture_kernel)
 
     // options
     int opt_kernel = SBE_MIXTURE_PACKED;
@@ -126,6 +126,7 @@ struct sbe_engine {
                                    // form: per group of 16 slots); every launch leaves them at 0
     uint8_t* d_xt = nullptr;       // one-hot block in MFMA fragment order (k_mixture_tuple_mfma), built at the first batched launch
     int xt_NT = 0, xt_KBp = 0;  size_t xt_bytes = 0;
+    int mfma_wide_min_share = 16;  // wide matrix-pipe forms (> 8 tuples) by default only from this many objects per padded tuple on (SBE_MFMA_WIDE_MIN_SHARE)
     int mfma_min_batch = 512;      // smallest launch the matrix-pipe form is chosen for under SBE_MIXTURE_PACKED (SBE_MFMA_MIN_BATCH)
     uint8_t* d_tid = nullptr;      // [slots][Np] group-tuple index per object (k_mixture_combo)
     uint16_t* d_tuple_g = nullptr; // [slots][kMaxTuples][kMaxComponents]
@@ -935,7 +936,7 @@ int ensure_xt(sbe_engine* e) {
 }
 
 // geometry of a matrix-pipe launch over n slots with at most KT tuples each; n_split = 0: the form does not apply
-struct MfmaGeom { int n_split, nt_per_split, MT; size_t lds; bool ws; };
+struct MfmaGeom { int n_split, nt_per_split, MT, SL; size_t lds; bool ws; };      // SL: slots per block (16 / 4 / 2)
 // the wave-specialised kernel (sbe_mixture_mfma_ws.hip): OPT-IN (SBE_MFMA_WS=1).  Measured on hardware it loses to the
 // unspecialised kernel at the headline shape (72.0 against 64.5 us per 4096 states, profiles/r6/ws_experiment.log); kept, tested
 // (tests/test_gpu_shapes.py::test_mfma_wave_specialised_form) and selectable for same-box comparisons.
@@ -945,11 +946,12 @@ static bool mfma_ws_wanted() {
 }
 MfmaGeom mfma_geometry(const sbe_engine* e, int n, int KT) {
     MfmaGeom g{};
-    if (KT < 1 || KT > 8 || e->C > 4) return g;
+    g.SL = tuple_mfma_slots_per_block(KT);           // 16 slots x <= 8 tuples, 4 x <= 32, 2 x <= 64 per block
+    if (g.SL == 0 || e->C > 4) return g;
     const int NT = div_up((int64_t)e->F * e->S, 32), KBp = round_up(div_up(e->N, tuple_mfma_kblock_objects()), 4);
-    g.MT = (KT + 1) / 2;
+    g.MT = div_up(KT, 32 / g.SL);
     g.lds = tuple_mfma_lds_bytes(g.MT, e->C, KBp);
-    if (tuple_mfma_fp4() && mfma_ws_wanted() && tuple_mfma_ws_lds_bytes(g.MT, e->C, KBp) <= 160 * 1024) {
+    if (g.SL == 16 && tuple_mfma_fp4() && mfma_ws_wanted() && tuple_mfma_ws_lds_bytes(g.MT, e->C, KBp) <= 160 * 1024) {
         g.ws = true;
         g.lds = tuple_mfma_ws_lds_bytes(g.MT, e->C, KBp);
     }
@@ -958,9 +960,9 @@ MfmaGeom mfma_geometry(const sbe_engine* e, int n, int KT) {
     const int64_t probs_bytes = ((int64_t)e->n_slots * e->table_elems() + (int64_t)e->F * e->S) * 4;
     const int64_t wpat_bytes = ((int64_t)e->n_slots * e->Pmax * e->F * e->C + (int64_t)e->F * e->C) * 4;
     if (probs_bytes >= ((int64_t)1 << 32) || wpat_bytes >= ((int64_t)1 << 32) || ((int64_t)(NT + 1) * KBp + 4) * 1024 >= ((int64_t)1 << 31)) return g;
-    // one block = 16 slots x a range of column tiles; its 8 waves take the tiles in pairs, so a split of fewer than
+    // one block = SL slots x a range of column tiles; its 8 waves take the tiles in pairs, so a split of fewer than
     // 16 tiles leaves waves idle: as many splits as fill the CUs, no finer
-    const int groups = div_up(n, 16);
+    const int groups = div_up(n, g.SL);
     int n_split = std::max(1, std::min(div_up(NT, 16), e->compute_units / std::max(1, groups)));
     if (const char* env = getenv("SBE_MFMA_SPLIT")) { if (atoi(env) > 0) n_split = std::min(atoi(env), NT); }   // experiments
     g.nt_per_split = round_up(div_up(NT, n_split), 2);
@@ -998,7 +1000,7 @@ int launch_mfma_form(sbe_engine* e, int first_slot, int n, int KT, const MfmaGeo
     p.tile_prefix = p.colcount + (size_t)(e->xt_NT + 1) * 64;
     p.partials = e->d_partials; p.partials_stride = e->partials_stride;
     if (reduce_in_kernel) { p.results = e->d_results; p.arrive = e->d_arrive; p.done = done; }
-    const dim3 grid((unsigned)(div_up(n, 16) * mg.n_split));
+    const dim3 grid((unsigned)(div_up(n, mg.SL) * mg.n_split));
     if (!(mg.ws ? launch_tuple_mfma_ws(e->C, p, grid, mg.lds, e->stream) : launch_tuple_mfma(e->C, p, grid, mg.lds, e->stream)))
         return fail(e, SBE_ERR_STATE, "k_mixture_tuple_mfma was built with static LDS: its log table must sit at LDS address 0 "
                                       "(toolchain change; rebuild without static __shared__ in sbe_mixture_mfma.hip)");
@@ -1047,7 +1049,13 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     }
     // large batches: the per-observation gather as an integer contraction on the matrix pipe (k_mixture_tuple_mfma)
     MfmaGeom mg{};
-    if (combo && (force_mfma || (e->opt_kernel == SBE_MIXTURE_PACKED && n >= e->mfma_min_batch))) mg = mfma_geometry(e, n, KT);
+    if (combo && (force_mfma || (e->opt_kernel == SBE_MIXTURE_PACKED && n >= e->mfma_min_batch))) {
+        mg = mfma_geometry(e, n, KT);
+        // The wide forms (more than 8 tuples: 4 / 2 slots per block) pay one log per (padded tuple, feature, state) where the
+        // vector-pipe form pays one gather per observation: by default only where a table entry is shared by enough objects
+        // (SBE_MFMA_WIDE_MIN_SHARE, objects per padded tuple; measured crossover: profiles/r6/wide_forms.log)
+        if (!force_mfma && mg.n_split > 0 && mg.SL != 16 && e->N < e->mfma_wide_min_share * mg.MT * (32 / mg.SL)) mg = MfmaGeom{};
+    }
     const bool mfma = mg.n_split > 0;
     if (force_mfma && !mfma)
         return fail(e, SBE_ERR_ARG, "matrix-pipe group-tuple kernel forced but not applicable (tuples=%d, C=%d, LDS %zu bytes)", KT, e->C, mg.lds);
@@ -1178,11 +1186,11 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     const bool mfma_reduce = mfma && in_kernel;
     DoneSig done_k{};
     if (in_kernel) {
-        done_k = done_out ? next_done(e, (unsigned)(mfma ? div_up(n, 16) : n)) : DoneSig{};
+        done_k = done_out ? next_done(e, (unsigned)(mfma ? div_up(n, mg.SL) : n)) : DoneSig{};
         if (done_out) *done_out = done_k;
     }
     if (mfma) {
-        snprintf(e->last_kernel, sizeof e->last_kernel, "k_mixture_tuple_mfma%s<packed stream, group-tuple form, matrix pipe %s, M tiles %d, C=%d>", mg.ws ? "_ws" : "", tuple_mfma_fp4() ? "fp4" : "i8", mg.MT, e->C);
+        snprintf(e->last_kernel, sizeof e->last_kernel, "k_mixture_tuple_mfma%s<packed stream, group-tuple form, matrix pipe %s, %d slots x M tiles %d, C=%d>", mg.ws ? "_ws" : "", tuple_mfma_fp4() ? "fp4" : "i8", mg.SL, mg.MT, e->C);
         int rc = launch_mfma_form(e, first_slot, n, KT, mg, d_slots, mfma_reduce, done_k);
         if (rc) return rc;
     } else {

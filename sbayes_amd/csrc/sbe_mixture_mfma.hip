@@ -133,9 +133,14 @@ void fine_log_table(double* tab /* [2 * kFineLogEntries] */) {
     }
 }
 
-template <int MT, int CT, int GT = 4, bool FP4 = true>
+// SLB = log2(slots per block): 4 (16 slots x <= 8 tuples: the form of round 5), 2 (4 slots x <= 32 tuples), 1 (2 slots x <= 64 tuples:
+// the whole tuple table) -- an M tile's 32 rows are 32 / SL tuples x SL slots (row = (tuple in tile) * SL + slot), so a block of
+// MT <= 4 tiles holds MT * 32 / SL tuples.  The wide forms (round 6) put datasets with several confounders on the matrix pipe.
+template <int MT, int CT, int GT = 4, bool FP4 = true, int SLB = 4>
 __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixParams p) {
     typedef typename std::conditional<FP4, v16f_t, v16i_t>::type acc_t;      // counts: exact integers either way
+    constexpr int SL = 1 << SLB, TPT = 32 / SL, TPB = MT * TPT;              // slots per block; tuples per M tile / per block
+    constexpr int NK = SL == 16 ? 8 : SL;                                    // slots a lane sums for
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -147,14 +152,14 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
     constexpr uint32_t a_off = kFineLogEntries * 16u;
     const uint32_t a_bytes = (uint32_t)MT * (uint32_t)KBp * 1024u;
     const uint32_t meta_off = a_off + a_bytes;
-    const uint32_t red_off = meta_off + (uint32_t)(kMfmaSlots * 2 * MT * sizeof(TupleMeta<CT>));
+    const uint32_t red_off = meta_off + (uint32_t)(SL * TPB * sizeof(TupleMeta<CT>));
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_raw;
     typedef TupleMeta<CT> Meta;
     Meta* meta = reinterpret_cast<Meta*>(lds_raw + meta_off);
     double* red = reinterpret_cast<double*>(lds_raw + red_off);
 
     auto slot_of = [&](int sl) -> int {          // absolute slot of the block's sl-th slot, or -1
-        const int i = sg * kMfmaSlots + sl;
+        const int i = sg * SL + sl;
         if (i >= p.n_batch) return -1;
         return p.slot_list ? p.slot_list[i] : p.first_slot + i;
     };
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
     }
 
     if (lds_base != 0u) {                                    // (block-uniform; before any barrier)
-        if ((int)threadIdx.x < kMfmaSlots) {
+        if ((int)threadIdx.x < SL) {
             const int slot = slot_of((int)threadIdx.x);
             if (slot >= 0) {
                 p.partials[(int64_t)slot * p.partials_stride + split] = __longlong_as_double(0x7FF8000000000000ll);
@@ -193,15 +198,21 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
         return;
     }
     // ---- phase 0: tuple metadata, log table, A fragments (sbe_mixture_mfma.hip.h) -----------------------------------------
-    mfma_phase0<MT, CT, FP4, kMfmaThreads>(lds_raw, p, slot_of, tab_off, a_off, meta, KBp);
+    mfma_phase0<MT, CT, FP4, kMfmaThreads, decltype(slot_of), SL>(lds_raw, p, slot_of, tab_off, a_off, meta, KBp);
     __syncthreads();
 
     // ---- phase 1: counts on the matrix pipe, table entries + log + dot product on the vector pipe ----------------------
     const int h = lane >> 5, cl = lane & 31;
-    double lsum[8];                                               // per slot of this lane: sum of cnt * log(mantissa part)
-    int ksum[8];                                                  // ... and of cnt * binary exponent (exact)
+    double lsum[NK];                                              // per slot of this lane: sum of cnt * log(mantissa part)
+    int ksum[NK];                                                 // ... and of cnt * binary exponent (exact)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { lsum[i] = 0.0; ksum[i] = 0; }
+    for (int i = 0; i < NK; ++i) { lsum[i] = 0.0; ksum[i] = 0; }
+    // entry = register e (0..15) of a count tile in lane half h: row = (e & 3) + 8 (e >> 2) + 4 h of the tile's 32 rows,
+    // slot = row % SL, tuple = row / SL (+ the tile's first tuple).  A register quad (4 consecutive rows) is one tuple's four
+    // consecutive slots (SL = 16, 4) or two tuples x two slots (SL = 2).
+    auto ent_slot = [&](int e) -> int { return ((e & 3) + 8 * (e >> 2) + 4 * h) & (SL - 1); };
+    auto ent_tuple = [&](int m, int e) -> int { return m * TPT + (((e & 3) + 8 * (e >> 2) + 4 * h) >> SLB); };
+    auto ent_k = [&](int e) -> int { return SL == 16 ? (e & 3) + 4 * ((e >> 2) & 1) : (e & (SL - 1)); };      // index into lsum / ksum (no h: static)
     int csum = 0;                                                 // objects counted in this lane's columns so far (the same for every slot)
     uint32_t one_hi = 0x3FF00000u;
     asm volatile("" : "+v"(one_hi));                              // (a VGPR operand of tab_log4_n's v_bfi_b32)
@@ -278,9 +289,11 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
     };
     auto st_meta = [&](int u) {                                 // u = (m * 4 + j) * HQ + half
         const int mj = u / HQ, half = u % HQ, m = mj >> 2, j = mj & 3;
-        const int t = 2 * m + (j >> 1), sl0 = 8 * (j & 1) + 4 * h + half * G;
 #pragma unroll
-        for (int i = 0; i < G; ++i) mdq[i] = meta[(sl0 + i) * 2 * MT + t];
+        for (int i = 0; i < G; ++i) {
+            const int e = 4 * j + half * G + i;
+            mdq[i] = meta[ent_slot(e) * TPB + ent_tuple(m, e)];
+        }
     };
     auto st_load = [&](int q) {
         const int r = q % kMfmaRN;
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
         }
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            const int k = (j & 1) * 4 + half * G + i;
+            const int k = ent_k(4 * j + half * G + i);
             lsum[k] = fma(cntd[i], lg[i], lsum[k]);
             ksum[k] = __mul24(cnt[i], kx[i]) + ksum[k];            // (biased exponents; host: passes * columns per lane * N * 2100 < 2^31)
             asm volatile("" : "+v"(ksum[k]));
@@ -389,26 +402,44 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
         }
     }
 
-    // ---- phase 2: fixed-order reduction: 32 columns of a lane half, then the 8 waves ------------------------------------
+    // ---- phase 2: fixed-order reduction: 32 columns of a lane half, then the lane halves and the 8 waves --------------------
+    // red[wave][lane half][16 slots].  SL = 16: a slot's tuples all sit in ONE lane half (bit 2 of the slot = h), whose lanes saw
+    // every object of their columns: the exponent bias leaves per lane, and the other half's entry of the slot is a zero.  Wide
+    // forms: a lane half sees the tuples of half the rows, so the two halves' exponent sums are added as integers first and the
+    // bias leaves once, in half 0.
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        // (slots beyond the batch counted nothing: their sums are discarded below, whatever the bias makes of them)
-        double v = fma((double)(ksum[i] - kFineLogBias * csum), 6.93147180559945286227e-01, lsum[i]);
+    for (int i = 0; i < NK; ++i) {
+        double v;
+        if constexpr (SL == 16) {
+            // (slots beyond the batch counted nothing: their sums are discarded below, whatever the bias makes of them)
+            v = fma((double)(ksum[i] - kFineLogBias * csum), 6.93147180559945286227e-01, lsum[i]);
+        } else {
+            const int ks = ksum[i] + __shfl_xor(ksum[i], 32, 64);
+            v = h == 0 ? fma((double)(ks - kFineLogBias * csum), 6.93147180559945286227e-01, lsum[i]) : lsum[i];
+        }
 #pragma unroll
         for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
         lsum[i] = v;
     }
     if (cl == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) red[w * kMfmaSlots + 8 * (i >> 2) + 4 * h + (i & 3)] = lsum[i];
+        for (int i = 0; i < NK; ++i) {
+            if constexpr (SL == 16) {
+                const int sl = 8 * (i >> 2) + 4 * h + (i & 3);
+                red[(w * 2 + h) * 16 + sl] = lsum[i];
+                red[(w * 2 + h) * 16 + (sl ^ 4)] = 0.0;             // the slots of the other lane half
+            } else {
+                red[(w * 2 + h) * 16 + i] = lsum[i];
+            }
+        }
     }
     __syncthreads();
     if (w != 0) return;                                                    // the rest is wave 0's (no block barrier below)
-    const int my_slot = lane < kMfmaSlots ? slot_of(lane) : -1;
+    const int my_slot = lane < SL ? slot_of(lane) : -1;
     double total = 0.0;
     if (my_slot >= 0) {
 #pragma unroll
-        for (int ww = 0; ww < kMfmaWaves; ++ww) total += red[ww * kMfmaSlots + lane];
+        for (int ww = 0; ww < kMfmaWaves; ++ww) { total += red[(ww * 2 + 0) * 16 + lane]; total += red[(ww * 2 + 1) * 16 + lane]; }
     }
     double* const my_partials = p.partials + (int64_t)max(my_slot, 0) * p.partials_stride;
     if (!p.results) {
@@ -445,43 +476,43 @@ __global__ __launch_bounds__(kMfmaThreads, 1) void k_mixture_tuple_mfma(MfmaMixP
     signal_done(p.done);
 }
 
-size_t tuple_mfma_lds_bytes(int MT, int C, int KBp) {     // log table | A fragments | meta | reduction
-    const size_t meta = (size_t)kMfmaSlots * 2 * MT * (C <= 1 ? 8 : (C <= 3 ? 16 : 32));
-    return (size_t)MT * KBp * 1024 + kFineLogEntries * 16 + meta + (size_t)kMfmaWaves * kMfmaSlots * sizeof(double);
+size_t tuple_mfma_lds_bytes(int MT, int C, int KBp) {     // log table | A fragments | meta (32 MT entries whatever the form) | reduction
+    const size_t meta = (size_t)32 * MT * (C <= 1 ? 8 : (C <= 3 ? 16 : 32));
+    return (size_t)MT * KBp * 1024 + kFineLogEntries * 16 + meta + (size_t)kMfmaWaves * 2 * 16 * sizeof(double);
 }
 
 // entries per epilogue step: a whole register quad where the registers allow it, half a quad for the widest instances
 template <int MT, int CT> constexpr int mfma_gt() { return (MT >= 4 || (MT == 3 && CT >= 3)) ? 2 : 4; }
 
-template <int MT, bool FP4>
+template <int MT, bool FP4, int SLB>
 static void launch_mfma_mt(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st) {
     switch (C) {
-        case 1: k_mixture_tuple_mfma<MT, 1, mfma_gt<MT, 1>(), FP4><<<grid, kMfmaThreads, lds, st>>>(p); break;
-        case 2: k_mixture_tuple_mfma<MT, 2, mfma_gt<MT, 2>(), FP4><<<grid, kMfmaThreads, lds, st>>>(p); break;
-        case 3: k_mixture_tuple_mfma<MT, 3, mfma_gt<MT, 3>(), FP4><<<grid, kMfmaThreads, lds, st>>>(p); break;
-        default: k_mixture_tuple_mfma<MT, 4, mfma_gt<MT, 4>(), FP4><<<grid, kMfmaThreads, lds, st>>>(p); break;
+        case 1: k_mixture_tuple_mfma<MT, 1, mfma_gt<MT, 1>(), FP4, SLB><<<grid, kMfmaThreads, lds, st>>>(p); break;
+        case 2: k_mixture_tuple_mfma<MT, 2, mfma_gt<MT, 2>(), FP4, SLB><<<grid, kMfmaThreads, lds, st>>>(p); break;
+        case 3: k_mixture_tuple_mfma<MT, 3, mfma_gt<MT, 3>(), FP4, SLB><<<grid, kMfmaThreads, lds, st>>>(p); break;
+        default: k_mixture_tuple_mfma<MT, 4, mfma_gt<MT, 4>(), FP4, SLB><<<grid, kMfmaThreads, lds, st>>>(p); break;
     }
 }
 
 // one-time: the kernels ask for up to the whole 160 KB of a CU's LDS.  The log table's index is its whole LDS address
 // (tab_off = 0), which holds only while the kernel has NO static LDS: checked here, once, on the host -- the guard inside the
 // kernel would store NaNs but not take its completion tickets, and a host-synchronous caller would wait for them.
-template <int MT, int CT, bool FP4>
+template <int MT, int CT, bool FP4, int SLB>
 static bool allow_lds() {
-    const void* fn = reinterpret_cast<const void*>(&k_mixture_tuple_mfma<MT, CT, mfma_gt<MT, CT>(), FP4>);
+    const void* fn = reinterpret_cast<const void*>(&k_mixture_tuple_mfma<MT, CT, mfma_gt<MT, CT>(), FP4, SLB>);
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncAttributes attr{};
     if (hipFuncGetAttributes(&attr, fn) != hipSuccess) { (void)hipGetLastError(); return true; }   // (not answerable: the kernel's own guard stays)
     return attr.sharedSizeBytes == 0;
 }
 
-template <bool FP4>
+template <bool FP4, int SLB>
 static bool allow_lds_all() {
     bool ok = true;
-    ok &= allow_lds<1, 1, FP4>(); ok &= allow_lds<1, 2, FP4>(); ok &= allow_lds<1, 3, FP4>(); ok &= allow_lds<1, 4, FP4>();
-    ok &= allow_lds<2, 1, FP4>(); ok &= allow_lds<2, 2, FP4>(); ok &= allow_lds<2, 3, FP4>(); ok &= allow_lds<2, 4, FP4>();
-    ok &= allow_lds<3, 1, FP4>(); ok &= allow_lds<3, 2, FP4>(); ok &= allow_lds<3, 3, FP4>(); ok &= allow_lds<3, 4, FP4>();
-    ok &= allow_lds<4, 1, FP4>(); ok &= allow_lds<4, 2, FP4>(); ok &= allow_lds<4, 3, FP4>(); ok &= allow_lds<4, 4, FP4>();
+    ok &= allow_lds<1, 1, FP4, SLB>(); ok &= allow_lds<1, 2, FP4, SLB>(); ok &= allow_lds<1, 3, FP4, SLB>(); ok &= allow_lds<1, 4, FP4, SLB>();
+    ok &= allow_lds<2, 1, FP4, SLB>(); ok &= allow_lds<2, 2, FP4, SLB>(); ok &= allow_lds<2, 3, FP4, SLB>(); ok &= allow_lds<2, 4, FP4, SLB>();
+    ok &= allow_lds<3, 1, FP4, SLB>(); ok &= allow_lds<3, 2, FP4, SLB>(); ok &= allow_lds<3, 3, FP4, SLB>(); ok &= allow_lds<3, 4, FP4, SLB>();
+    ok &= allow_lds<4, 1, FP4, SLB>(); ok &= allow_lds<4, 2, FP4, SLB>(); ok &= allow_lds<4, 3, FP4, SLB>(); ok &= allow_lds<4, 4, FP4, SLB>();
     return ok;
 }
 
@@ -491,26 +522,36 @@ bool tuple_mfma_fp4() {
     return on;
 }
 
+// slots per block for KT tuples (0: the form does not apply): 16 up to 8 tuples, 4 up to 32, 2 up to 64 -- the wide forms with FP4
+// operands only
+int tuple_mfma_slots_per_block(int KT) {
+    if (KT < 1 || KT > 64) return 0;
+    if (KT <= 8) return 16;
+    if (!tuple_mfma_fp4()) return 0;
+    return KT <= 32 ? 4 : 2;
+}
+
+template <bool FP4, int SLB>
+static void launch_mfma_slb(int MT, int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st) {
+    switch (MT) {
+        case 1: launch_mfma_mt<1, FP4, SLB>(C, p, grid, lds, st); break;
+        case 2: launch_mfma_mt<2, FP4, SLB>(C, p, grid, lds, st); break;
+        case 3: launch_mfma_mt<3, FP4, SLB>(C, p, grid, lds, st); break;
+        default: launch_mfma_mt<4, FP4, SLB>(C, p, grid, lds, st); break;
+    }
+}
+
 bool launch_tuple_mfma(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hipStream_t st) {
     const bool fp4 = tuple_mfma_fp4();
-    static const bool no_static_lds = tuple_mfma_fp4() ? allow_lds_all<true>() : allow_lds_all<false>();
+    static const bool no_static_lds = tuple_mfma_fp4() ? (allow_lds_all<true, 4>() & allow_lds_all<true, 2>() & allow_lds_all<true, 1>())
+                                                       : allow_lds_all<false, 4>();
     if (!no_static_lds) return false;
-    const int MT = (p.KT + 1) / 2;
-    if (fp4) {
-        switch (MT) {
-            case 1: launch_mfma_mt<1, true>(C, p, grid, lds, st); break;
-            case 2: launch_mfma_mt<2, true>(C, p, grid, lds, st); break;
-            case 3: launch_mfma_mt<3, true>(C, p, grid, lds, st); break;
-            default: launch_mfma_mt<4, true>(C, p, grid, lds, st); break;
-        }
-    } else {
-        switch (MT) {
-            case 1: launch_mfma_mt<1, false>(C, p, grid, lds, st); break;
-            case 2: launch_mfma_mt<2, false>(C, p, grid, lds, st); break;
-            case 3: launch_mfma_mt<3, false>(C, p, grid, lds, st); break;
-            default: launch_mfma_mt<4, false>(C, p, grid, lds, st); break;
-        }
-    }
+    const int SL = tuple_mfma_slots_per_block(p.KT);
+    const int MT = (p.KT + 32 / SL - 1) / (32 / SL);
+    if (!fp4) launch_mfma_slb<false, 4>(MT, C, p, grid, lds, st);
+    else if (SL == 16) launch_mfma_slb<true, 4>(MT, C, p, grid, lds, st);
+    else if (SL == 4) launch_mfma_slb<true, 2>(MT, C, p, grid, lds, st);
+    else launch_mfma_slb<true, 1>(MT, C, p, grid, lds, st);
     return true;
 }
 

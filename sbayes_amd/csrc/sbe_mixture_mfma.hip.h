@@ -15,7 +15,7 @@ typedef int v16i_t __attribute__((ext_vector_type(16)));
 typedef float v16f_t __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) const v4i_t lds_cv4i_t;
 
-constexpr int kMfmaSlots = 16;          // slots per block
+constexpr int kMfmaSlots = 16;          // slots per block in the narrow form (<= 8 tuples); wide forms: 4 (<= 32 tuples), 2 (<= 64)
 
 // Table-driven log for this kernel's epilogue, G chains interleaved: log v = k ln2 + log c_i + log1p(r), r = m / c_i - 1, with
 // its own FINER table (kFineLogEntries = 1024 intervals of the mantissa m in [1, 2): {RN(1/c_i) / 2, log c_i}, built by ensure_xt) so
@@ -80,11 +80,16 @@ struct __attribute__((aligned(CT <= 1 ? 8 : (CT <= 3 ? 16 : 32)))) TupleMeta {
 // Phase 0 of a block of NTHR threads (all of them call it; the caller's barrier follows): tuple metadata, log table, A fragments.
 // `slot_of(sl)`: absolute slot of the block's sl-th slot, or -1.  LDS: log table at tab_off (= 0), A fragments from a_off,
 // metadata at `meta`.
-template <int MT, int CT, bool FP4, int NTHR, typename SlotOf>
+// SL = slots per block (16 / 4 / 2): an M tile's 32 rows are 32 / SL tuples x SL slots, row = (tuple in tile) * SL + slot; the
+// block holds TPB = MT * 32 / SL tuples.
+template <int MT, int CT, bool FP4, int NTHR, typename SlotOf, int SL = kMfmaSlots>
 __device__ __forceinline__ void mfma_phase0(unsigned char* lds_raw, const MfmaMixParams& p, const SlotOf& slot_of, uint32_t tab_off,
                                             uint32_t a_off, TupleMeta<CT>* meta, int KBp) {
     typedef TupleMeta<CT> Meta;
     constexpr int kMfmaThreads = NTHR;
+    constexpr int TPT = 32 / SL, TPB = MT * TPT;                  // tuples per M tile / per block
+    static_assert(SL == 16 || SL == 4 || SL == 2, "slots per block");
+    static_assert(!(SL != 16 && !FP4), "the wide forms exist with FP4 operands only");
     // ---- phase 0: tuple metadata, log table, A fragments ------------------------------------------------------------
     // Offsets of a tuple that is not there (another slot's tuple, the padding tuple of an odd KT, a slot beyond the batch)
     // and of a component the tuple has no group in point at the rows of ONES behind the two arrays: no observation is
@@ -108,14 +113,14 @@ __device__ __forceinline__ void mfma_phase0(unsigned char* lds_raw, const MfmaMi
     if constexpr (FP4) {
         // one unit = the 32 tuple ids of (slot sl, lane half h of k-block kb: 32 objects) -> the 2 MT indicator pieces (16 bytes =
         // 32 nibbles each).  UB units' ids are asked for together.
-        const int n_units = kMfmaSlots * KBp * 2;
+        const int n_units = SL * KBp * 2;
         constexpr int UB = 2;
         uint32_t d[UB][8];
         auto load_ids = [&](int u0) {
 #pragma unroll
             for (int k = 0; k < UB; ++k) {
                 const int u = u0 + k * kMfmaThreads;
-                const int sl = u & 15, n0 = (u >> 4) * 32;     // (u >> 4) = kb * 2 + h
+                const int sl = u % SL, n0 = (u / SL) * 32;     // (u / SL) = kb * 2 + h
                 const int slot = u < n_units ? slot_of(sl) : -1;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -130,10 +135,10 @@ __device__ __forceinline__ void mfma_phase0(unsigned char* lds_raw, const MfmaMi
             for (int k = 0; k < UB; ++k) {
                 const int u = u0 + k * kMfmaThreads;
                 if (u >= n_units) break;
-                const int sl = u & 15, hk = u >> 4;
+                const int sl = u % SL, hk = u / SL;
                 const int kb = hk >> 1, h = hk & 1;
-#pragma unroll
-                for (int t = 0; t < 2 * MT; ++t) {
+#pragma unroll 8
+                for (int t = 0; t < TPB; ++t) {
                     uint4 o;
                     uint32_t* ov = reinterpret_cast<uint32_t*>(&o);
 #pragma unroll
@@ -147,8 +152,9 @@ __device__ __forceinline__ void mfma_phase0(unsigned char* lds_raw, const MfmaMi
                         }
                         ov[wv] = (eq[0] << 1) | (eq[1] << 5);       // 1.0 = 0x2: low nibbles = objects 8 wv + b, high = 8 wv + 4 + b
                     }
-                    const uint32_t fl = (uint32_t)(h * 32 + (t & 1) * 16 + sl);
-                    *reinterpret_cast<uint4*>(lds_raw + a_off + (((uint32_t)(t >> 1) * (uint32_t)KBp + (uint32_t)kb) * 64u + fl) * 16u) = o;
+                    // fragment (m = t / TPT, kb): lane = h * 32 + row, row = (t % TPT) * SL + sl
+                    const uint32_t fl = (uint32_t)(h * 32 + (t % TPT) * SL + sl);
+                    *reinterpret_cast<uint4*>(lds_raw + a_off + (((uint32_t)(t / TPT) * (uint32_t)KBp + (uint32_t)kb) * 64u + fl) * 16u) = o;
                 }
             }
         };
@@ -161,18 +167,18 @@ __device__ __forceinline__ void mfma_phase0(unsigned char* lds_raw, const MfmaMi
             const int i = (int)threadIdx.x + k * kMfmaThreads;
             lt[k] = i < 2 * kFineLogEntries ? reinterpret_cast<const double*>(p.logtab)[i] : 0.0;
         }
-        const bool has_meta = (int)threadIdx.x < kMfmaSlots * 2 * MT;
-        const int m_sl = (int)threadIdx.x / (2 * MT), m_t = (int)threadIdx.x % (2 * MT);
+        const bool has_meta = (int)threadIdx.x < SL * TPB;
+        const int m_sl = (int)threadIdx.x / TPB, m_t = (int)threadIdx.x % TPB;
         const int m_slot = has_meta ? slot_of(m_sl) : -1;
         uint32_t m_pat = 0xFFu, m_g[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) m_g[c] = 0xFFFFFFFFu;
-        if (m_slot >= 0) {                                   // (m_t < 2 MT <= kMaxTuples: the rows exist whatever KT is)
+        if (m_slot >= 0) {                                   // (m_t < TPB <= kMaxTuples: the rows exist whatever KT is)
             m_pat = p.tuple_p[(int64_t)m_slot * p.tuple_p_stride + m_t];
 #pragma unroll
             for (int c = 0; c < CT; ++c) m_g[c] = p.tuple_g[(int64_t)m_slot * p.tuple_g_stride + m_t * kMaxComponents + c];
         }
-        if (has_meta) meta[m_sl * 2 * MT + m_t] = meta_of(m_slot, m_t, m_pat, m_g);
+        if (has_meta) meta[m_sl * TPB + m_t] = meta_of(m_slot, m_t, m_pat, m_g);
 #pragma unroll
         for (int k = 0; k < LT; ++k) {
             const int i = (int)threadIdx.x + k * kMfmaThreads;

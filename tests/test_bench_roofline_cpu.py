@@ -41,6 +41,13 @@ def test_roofline_block_fractions_and_bound():
     mp = rf["matrix_pipe"]
     assert mp["int8_ops_per_launch"] == 2.0 * (128 * 96) * 2016 * 1024
     assert abs(mp["frac"] - mp["int8_ops_per_launch"] / 50e-6 / 5e15) < 1e-4
+    # FP4 operands, the round-6 name: slots per block parsed from the name, k-blocks of 64 objects, the FP4 peak
+    rf4 = bench.roofline_block(b_eval, unique, B, kern_ms, traffic, valu, "k_mixture_tuple_mfma<packed stream, group-tuple form, matrix pipe fp4, 16 slots x M tiles 3, C=2>",
+                               True, "test", shape=(1000, 200, 10))
+    assert rf4["matrix_pipe"]["fp4_ops_per_launch"] == 2.0 * (128 * 96) * 2016 * 1024 and rf4["matrix_pipe"]["peak_tops"] == 10000.0
+    rf5 = bench.roofline_block(b_eval, unique, B, kern_ms, traffic, valu, "k_mixture_tuple_mfma<packed stream, group-tuple form, matrix pipe fp4, 4 slots x M tiles 3, C=3>",
+                               True, "test", shape=(100, 36, 5))
+    assert rf5["matrix_pipe"]["fp4_ops_per_launch"] == 2.0 * (512 * 96) * 192 * 256
     # no counter pass of this build: frac_traffic withheld; the vector figure still decides against the unique-bytes figure
     rf2 = bench.roofline_block(b_eval, unique, B, kern_ms, None, valu, "k_mixture_tuple64<...>", True, "test")
     assert rf2["frac_traffic"] is None and rf2["traffic"] is None and rf2["bound"] == "valu" and "matrix_pipe" not in rf2

@@ -62,7 +62,7 @@ def test_headline_default_selection_distinct_slots_vs_oracle(headline_engine, B,
     got = eng.mixture_loglik_batch(0, B)
     assert kernel in eng.last_mixture_kernel(), eng.last_mixture_kernel()      # both sides of the threshold
     if "mfma" in kernel:
-        assert "M tiles 3" in eng.last_mixture_kernel()                        # 6 tuples: K = 5 clusters + "no cluster", one universal group
+        assert "16 slots x M tiles 3" in eng.last_mixture_kernel()                        # 6 tuples: K = 5 clusters + "no cluster", one universal group
     assert np.all(np.isfinite(got)) and len(set(got.tolist())) == B            # every slot its own state
     rng = np.random.default_rng(B)
     picks = np.unique(np.concatenate([[0, 1, 15, 16, B - 17, B - 16, B - 1], rng.integers(0, B, size=17)]))

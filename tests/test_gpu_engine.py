@@ -70,12 +70,12 @@ def test_mixture_loglik(name, kernel, log_mode):
     with engine_for(fx) as eng:
         load_fixture_state(eng, fx)
         eng.set_option(kernel=kernel, log_mode=log_mode)
-        try:
-            ll = eng.mixture_loglik(0)
-        except EngineError as exc:                 # the matrix-pipe form holds at most 8 group tuples (south_america: 17)
-            assert kernel == MIXTURE_PACKED_TUPLE_MFMA and "not applicable" in str(exc), exc
-            assert name == "south_america"
-            return
+        ll = eng.mixture_loglik(0)
+        if kernel == MIXTURE_PACKED_TUPLE_MFMA:
+            # every fixture takes the matrix-pipe form when forced: 16 slots x <= 8 tuples per block, or -- south_america's 17
+            # group tuples (3 clusters + none, universal, 6 families + none) -- the wide form of round 6: 4 slots x <= 32 tuples
+            assert "k_mixture_tuple_mfma" in eng.last_mixture_kernel()
+            assert ("4 slots x M tiles 3" if name == "south_america" else "16 slots x") in eng.last_mixture_kernel(), eng.last_mixture_kernel()
         want = fx.meta["mixture_ll"]
         assert abs(ll - want) <= MIX_RTOL * abs(want), (ll, want)
         assert eng.mixture_loglik(0) == ll      # deterministic reduction order

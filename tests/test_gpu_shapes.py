@@ -224,6 +224,12 @@ def test_tuple_kernel_batches(shape):
     (90,   25,  4,  [1, 1, 1, 1], 16),    # C = 4, exactly one block of slots
     (40,   72,  3,  [2, 1],     600),     # many blocks per column split
     (1301, 20,  3,  [2, 1],     16),      # 41 k-blocks padded to 44
+    # wide forms (round 6): more than 8 group tuples -> 4 slots x <= 32 tuples, 2 slots x <= 64 tuples per block
+    (300,  40,  4,  [3, 1, 4],  37),      # up to 4 x 5 = 20 tuples: 4 slots per block, 3 M tiles; batch not a multiple of 4
+    (100,  36,  5,  [3, 1, 6],  600),     # the south_america layout (up to 28 tuples), many blocks
+    (260,  24,  3,  [3, 1, 3, 3], 9),     # C = 4, up to 64 tuples: 2 slots per block, 4 M tiles; odd batch
+    (700,  33,  6,  [5, 1, 7],  10),      # up to 48 tuples: 2 slots per block, 3 M tiles; 11 k-blocks padded to 12
+    (150,  20,  2,  [8, 1],     21),      # 9 tuples: the smallest wide case (4 slots, 2 M tiles)
 ], ids=lambda s: f"N{s[0]}F{s[1]}S{s[2]}C{len(s[3])}B{s[4]}")
 def test_mfma_kernel_batches(shape):
     """Batches through the matrix-pipe group-tuple kernel (counts per (slot, tuple, feature, state) by i8 MFMA, one log per
@@ -281,7 +287,12 @@ def test_mfma_kernel_batches(shape):
         if B > 2:
             np.testing.assert_allclose(eng.mixture_loglik_batch(1, B - 2), want[1:B - 1], rtol=1e-10)
         eng.set_option(kernel=MIXTURE_PACKED_TUPLE)
-        np.testing.assert_allclose(eng.mixture_loglik_batch(0, B), got, rtol=1e-12)    # the vector-pipe form of the same table
+        try:
+            other = eng.mixture_loglik_batch(0, B)                                     # the vector-pipe form of the same table
+        except EngineError as exc:                   # (its LDS table image [tuples][S + 1][tile] can exceed a CU's LDS where the
+            assert "not applicable" in str(exc) and max(n_groups) > 4, exc             #  matrix-pipe form still runs: 48 tuples x 6 states)
+        else:
+            np.testing.assert_allclose(other, got, rtol=1e-12)
 
 
 def test_mfma_kernel_default_choice_and_zero_probability():
