@@ -16,6 +16,6 @@ for pid in $pids; do wait $pid; done
     -o sbayes_amd/libsbe_engine.so
 # the host layer's CPython extension (plain C, no device code): sbayes_amd/_fast.py uses it when present
 # (optional: without it sbayes_amd/_fast.py takes the ctypes route to the same helpers)
-gcc -O2 -fPIC -shared -Wall $(python3 -c "import sysconfig; print('-I' + sysconfig.get_paths()['include'])") sbayes_amd/csrc/sbe_pyhost.c \
+gcc -O3 -fPIC -shared -Wall $(python3 -c "import sysconfig; print('-I' + sysconfig.get_paths()['include'])") sbayes_amd/csrc/sbe_pyhost.c \
     -o sbayes_amd/_sbe_pyhost$(python3 -c "import sysconfig; print(sysconfig.get_config_var('EXT_SUFFIX'))") \
     || echo "[build.sh] warning: sbayes_amd._sbe_pyhost not built; the host layer takes the ctypes / Python route"

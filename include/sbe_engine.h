@@ -55,7 +55,8 @@ typedef struct sbe_engine sbe_engine;
                                sbe_collapsed_and_source_prior, sbe_counts_delta_apply,
                                sbe_given_unchanged_gibbs_apply, sbe_gibbs_propose_apply,
                                sbe_set_slot_delta, sbe_get_counts_all;
-                               6 (round 6): + sbe_get_group_ids, sbe_get_weights, sbe_timer_mark, sbe_timer_elapsed; the
+                               6 (round 6): + sbe_get_group_ids, sbe_get_weights, sbe_timer_mark, sbe_timer_elapsed;
+                               sbe_set_groups takes overlapping groups (last group = the id, slot marked); the
                                header is split in three: THIS file holds the production surface -- every entry cites
                                the reference function it serves; sbe_engine_steps.h the one-call MCMC step family (no
                                caller in the reference, frozen); sbe_engine_diag.h self-tests and measurement hooks.
@@ -174,13 +175,19 @@ int sbe_component_lh(sbe_engine* e, const void* probs /* [G][F][S] */, int probs
 int sbe_likelihood_per_component_exact(sbe_engine* e, int slot, double* out);
 
 /* ---- slot state: groups (state.py Clusters / load_data.py Confounder.group_assignment) --
- * Resident state keeps ONE group per object and component.  A matrix with an object in
- * several rows of one component is rejected with SBE_ERR_DATA ("object n is in groups g1 and
- * g2 of component c"): the reference counts such an object once per group
- * (compute_effect_counts, counts.py:28-30) but lets the last written group win in a1
- * (likelihood.py:126-130), and no single id follows both.  The stateless sbe_effect_counts
- * and sbe_component_lh accept overlap and follow the reference.  The cluster matrices of
- * sbe_step / sbe_step_batch are checked the same way (a batch reports the chain).
+ * Resident state keeps ONE group id per object and component.  For a matrix with an object in
+ * several rows of one component the reference has two readings: a1 lets the last WRITTEN group
+ * win (likelihood.py:126-130; an uncached evaluation writes the groups in index order), while
+ * compute_effect_counts counts the object once PER group (counts.py:28-30).  ABI 6: sbe_set_groups
+ * TAKES such a matrix -- the id is the LAST group containing the object, which is what every
+ * likelihood evaluation on resident state needs (sbe_mixture_loglik*, sbe_likelihood_per_component,
+ * sbe_observation_lh, the has_components patterns; the collapsed likelihood reads the counts the
+ * caller set) -- and marks the slot; calls that would DERIVE counts from the ids (sbe_recount,
+ * sbe_update_counts, sbe_accumulate_counts, the one-call steps, sbe_gibbs_propose*,
+ * sbe_given_unchanged_gibbs*, sbe_observation_lh_exact) refuse a marked slot with SBE_ERR_DATA
+ * ("object n is in groups g1 and g2 of component c ..."): there the caller's counts (sbe_set_counts) or
+ * the stateless sbe_effect_counts are the reference's.  sbe_set_group_ids clears the mark.  The
+ * cluster matrices handed to sbe_step / sbe_step_batch stay strict (a batch reports the chain).
  * Also refreshes has_components (state.py:353-376): the ids, the has_components pattern of every object, the group-tuple
  * tables and -- when the slot has weights -- the per-pattern normalised weights (likelihood.py:171-190) go up and are
  * computed in ONE asynchronous launch; after a cluster move the host-side tables follow the moved objects.  More

@@ -486,7 +486,15 @@ int sbe_set_groups(sbe_engine* e, int slot, int component, const uint8_t* groups
     const int N = e->N, G = e->G[component], off = e->goff[component];
     std::vector<uint16_t> ids(N, kNoGroup);
     char msg[320];
-    if (!matrix_to_ids(groups, G, N, off, component, ids.data(), msg, sizeof msg)) return fail(e, SBE_ERR_DATA, "%s", msg);
+    OverlapNote note;
+    (void)matrix_to_ids(groups, G, N, off, component, ids.data(), msg, sizeof msg, &note);      // (permissive: the last group wins)
+    Slot& s = e->slots[slot];
+    if (note.found) {
+        if (!s.overlap_mask) { s.ov_obj = note.obj; s.ov_g1 = note.g1; s.ov_g2 = note.g2; s.ov_comp = component; }
+        s.overlap_mask |= 1u << component;
+    } else {
+        s.overlap_mask &= ~(1u << component);
+    }
     return set_gid_common(e, slot, component, ids);
 }
 
@@ -499,6 +507,7 @@ int sbe_set_group_ids(sbe_engine* e, int slot, int component, const int32_t* ids
         if (ids_in[n] >= G) return fail(e, SBE_ERR_ARG, "group id %d of object %d out of range [0,%d)", ids_in[n], n, G);
         if (ids_in[n] >= 0) ids[n] = (uint16_t)(off + ids_in[n]);
     }
+    e->slots[slot].overlap_mask &= ~(1u << component);       // (one id per object: no overlap by construction)
     return set_gid_common(e, slot, component, ids);
 }
 
@@ -596,6 +605,7 @@ int sbe_recount(sbe_engine* e, int slot, int component) {
     Slot& s = e->slots[slot];
     if (!s.source_set) return fail(e, SBE_ERR_STATE, "slot %d: source not set", slot);
     if (!s.groups_set) return fail(e, SBE_ERR_STATE, "slot %d: groups not set", slot);
+    { int orc = reject_overlap(e, slot, "sbe_recount"); if (orc) return orc; }
     HIPCHK(e, hipSetDevice(e->device));
     // the kernel counts every component in one pass (each observation has one source
     // component); a single-component request recounts all and is still exact.
@@ -613,6 +623,7 @@ int sbe_update_counts(sbe_engine* e, int slot_new, int slot_old, const int32_t* 
     if (n_subset > 0) CHECK_PTR(e, objects);
     for (int i = 0; i < n_subset; ++i)
         if (objects[i] < 0 || objects[i] >= e->N) return fail(e, SBE_ERR_ARG, "object index %d out of range", objects[i]);
+    { int orc = reject_overlap(e, slot_new, "sbe_update_counts"); if (!orc) orc = reject_overlap(e, slot_old, "sbe_update_counts"); if (orc) return orc; }
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipMemsetAsync(e->d_changed, 0, e->Gtot, e->stream));
     if (n_subset > 0) {
@@ -637,6 +648,7 @@ int sbe_accumulate_counts(sbe_engine* e, int slot, const int32_t* objects, int n
     if (n_subset > 0) CHECK_PTR(e, objects);
     for (int i = 0; i < n_subset; ++i)
         if (objects[i] < 0 || objects[i] >= e->N) return fail(e, SBE_ERR_ARG, "object index %d out of range", objects[i]);
+    { int orc = reject_overlap(e, slot, "sbe_accumulate_counts"); if (orc) return orc; }
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipMemsetAsync(e->d_changed, 0, e->Gtot, e->stream));
     if (n_subset > 0) {

@@ -58,6 +58,11 @@ struct Slot {
     std::vector<int32_t> tup_cnt;         // [kMaxTuples] objects per group tuple
     bool inc_ok = false;
     uint64_t group_epoch = 0;             // identifies the content of the slot's group / pattern ids (k_rowoff's inputs)
+    // round 6: components whose bool [G][N] matrix had an object in SEVERAL groups (sbe_set_groups keeps the LAST one as the
+    // object's id: the group whose table an uncached evaluation ends up with, likelihood.py:126-130).  Calls that would DERIVE
+    // counts from one id per object refuse such a slot (reject_overlap); ov_* remember the first example for their message.
+    uint32_t overlap_mask = 0;
+    int32_t ov_obj = -1, ov_g1 = 0, ov_g2 = 0, ov_comp = 0;
 };
 
 }  // namespace
@@ -1345,21 +1350,37 @@ int set_gid_common(sbe_engine* e, int slot, int component, const std::vector<uin
     return upload_patterns_and_weights(e, slot, nullptr, true);
 }
 
-// Resident slot state keeps ONE group per object and component (u16 ids).  A bool [G][N] matrix with an object in two
-// rows has no such form: the reference counts the object once per group it is in (compute_effect_counts,
-// sbayes/sampling/counts.py:28-30) while its a1 lets the last written group win (likelihood.py:126-130) -- collapsing the
-// matrix to ids would silently follow only one of the two.  Overlap is therefore REJECTED here (SBE_ERR_DATA); the
-// stateless sbe_effect_counts / sbe_component_lh take such matrices and follow the reference.  (sBayes itself never
-// produces overlap: operators.py:724-725, :1099-1101 for clusters, load_data.py:174-178 for confounders.)
+// Resident slot state keeps ONE group id per object and component (u16).  A bool [G][N] matrix with an object in two rows has two
+// readings in the reference: its a1 lets the LAST WRITTEN group win (likelihood.py:126-130; an uncached evaluation writes the
+// groups in index order, so the highest group index containing the object), while compute_effect_counts counts the object once
+// PER GROUP it is in (sbayes/sampling/counts.py:28-30).  Round 6: sbe_set_groups takes such a matrix -- id = the last group,
+// which is what every likelihood evaluation on resident state needs (mixture, per-component and per-observation likelihoods,
+// has_components patterns, the collapsed likelihood of the caller's counts) -- and marks the slot (Slot::overlap_mask); the
+// calls that would derive COUNTS from the ids (recount, count deltas, the one-call steps, the Gibbs forms) refuse a marked
+// slot with SBE_ERR_DATA (reject_overlap): the caller's counts, or the stateless sbe_effect_counts, are the reference's there.
+// The one-call steps' cluster matrices stay strict.  (sBayes itself never produces overlap: operators.py:724-725, :1099-1101
+// for clusters, load_data.py:174-178 for confounders.)
 void overlap_message(char* buf, size_t len, int n, int g1, int g2, int component) {
-    snprintf(buf, len, "object %d is in groups %d and %d of component %d: resident slot state keeps one group per object "
-             "and component (counts.py:28-30 would count it in both); overlapping groups are served by the stateless "
-             "sbe_effect_counts / sbe_component_lh only", n, g1, g2, component);
+    snprintf(buf, len, "object %d is in groups %d and %d of component %d: resident slot state keeps one group id per object "
+             "and component (counts.py:28-30 would count it in both); counts of overlapping groups come from the caller or "
+             "the stateless sbe_effect_counts", n, g1, g2, component);
 }
 
-// bool [G][N] -> one id per object (off + g, kNoGroup: in no group).  false + message on overlap.
-bool matrix_to_ids(const uint8_t* groups, int G, int N, int off, int component, uint16_t* ids, char* msg, size_t msg_len) {
+struct OverlapNote { bool found = false; int obj = -1, g1 = 0, g2 = 0; };
+
+// bool [G][N] -> one id per object (off + g, kNoGroup: in no group).  Strict form (note == nullptr): false + message on
+// overlap.  Permissive form: the LAST group containing the object wins and the first overlapping object is noted.
+bool matrix_to_ids(const uint8_t* groups, int G, int N, int off, int component, uint16_t* ids, char* msg, size_t msg_len,
+                   OverlapNote* note = nullptr) {
     std::fill(ids, ids + N, kNoGroup);
+    auto hit = [&](int n, int g) -> bool {
+        if (ids[n] != kNoGroup) {
+            if (!note) { overlap_message(msg, msg_len, n, (int)ids[n] - off, g, component); return false; }
+            if (!note->found) { note->found = true; note->obj = n; note->g1 = (int)ids[n] - off; note->g2 = g; }
+        }
+        ids[n] = (uint16_t)(off + g);
+        return true;
+    };
     for (int g = 0; g < G; ++g) {                     // (mostly zeros: eight objects per test)
         const uint8_t* row = groups + (size_t)g * N;
         int n = 0;
@@ -1367,17 +1388,20 @@ bool matrix_to_ids(const uint8_t* groups, int G, int N, int off, int component, 
             uint64_t w8;
             memcpy(&w8, row + n, 8);
             if (!w8) continue;
-            for (int k = 0; k < 8; ++k) if (row[n + k]) {
-                if (ids[n + k] != kNoGroup) { overlap_message(msg, msg_len, n + k, (int)ids[n + k] - off, g, component); return false; }
-                ids[n + k] = (uint16_t)(off + g);
-            }
+            for (int k = 0; k < 8; ++k) if (row[n + k] && !hit(n + k, g)) return false;
         }
-        for (; n < N; ++n) if (row[n]) {
-            if (ids[n] != kNoGroup) { overlap_message(msg, msg_len, n, (int)ids[n] - off, g, component); return false; }
-            ids[n] = (uint16_t)(off + g);
-        }
+        for (; n < N; ++n) if (row[n] && !hit(n, g)) return false;
     }
     return true;
+}
+
+// SBE_ERR_DATA for a call that would derive counts from the ids of a slot holding overlapping groups
+int reject_overlap(sbe_engine* e, int slot, const char* what) {
+    const Slot& s = e->slots[slot];
+    if (!s.overlap_mask) return SBE_OK;
+    char msg[320];
+    overlap_message(msg, sizeof msg, s.ov_obj, s.ov_g1, s.ov_g2, s.ov_comp);
+    return fail(e, SBE_ERR_DATA, "%s (slot %d, %s)", msg, slot, what);
 }
 
 

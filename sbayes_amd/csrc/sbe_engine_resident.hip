@@ -372,6 +372,7 @@ static int given_unchanged_gibbs_impl(sbe_engine* e, int slot, int i_cluster, co
     if (rc) return rc;
     Slot& s = e->slots[slot];
     if (!s.groups_set || !s.source_set || !s.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", slot);
+    { int orc = reject_overlap(e, slot, "sbe_given_unchanged_gibbs"); if (orc) return orc; }
     for (int c = 0; c < C; ++c) {
         if (!e->conc_set[c]) return fail(e, SBE_ERR_STATE, "concentration of component %d not set", c);
         if (c > 0 && !s.counts_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts of component %d not set", slot, c);
@@ -758,6 +759,7 @@ int sbe_observation_lh_exact(sbe_engine* e, int slot, double* out) {
     CHECK_ENGINE(e); CHECK_SLOT(e, slot); CHECK_PTR(e, out);
     Slot& s = e->slots[slot];
     if (!s.groups_set || !s.source_set || !s.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", slot);
+    { int orc = reject_overlap(e, slot, "sbe_observation_lh_exact"); if (orc) return orc; }
     for (int c = 0; c < e->C; ++c)
         if (!s.counts_set[c] || !e->conc_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts / concentration of component %d not set", slot, c);
     HIPCHK(e, hipSetDevice(e->device));

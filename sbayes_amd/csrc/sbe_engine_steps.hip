@@ -192,6 +192,7 @@ int sbe_step(sbe_engine* e, int cur_slot, int cand_slot, const uint8_t* clusters
         return fail(e, SBE_ERR_ARG, "changed_objects / source_rows missing for n_changed=%d", n_changed);
     Slot& cur = e->slots[cur_slot];
     if (!cur.groups_set || !cur.source_set || !cur.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", cur_slot);
+    { int orc = reject_overlap(e, cur_slot, "one-call step"); if (orc) return orc; }
     for (int c = 0; c < e->C; ++c)
         if (!cur.counts_set[c] || !e->conc_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts / concentration of component %d not set", cur_slot, c);
     for (int i = 0; i < n_changed; ++i)
@@ -459,6 +460,7 @@ int sbe_step_batch(sbe_engine* e, int n_chains, const int32_t* cur_slots, const 
                 if (changed_objects[k] < 0 || changed_objects[k] >= N) return fail(e, SBE_ERR_ARG, "chain %d: object index %d out of range", i, changed_objects[k]);
             const Slot& cur = e->slots[a];
             if (!cur.groups_set || !cur.source_set || !cur.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", a);
+            { int orc = reject_overlap(e, a, "one-call step"); if (orc) return orc; }
             for (int c = 0; c < C; ++c)
                 if (!cur.counts_set[c] || !e->conc_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts / concentration of component %d not set", a, c);
         }
@@ -803,6 +805,7 @@ int sbe_step_batch_delta(sbe_engine* e, int n_chains, const int32_t* cur_slots, 
             }
             const Slot& cur = e->slots[a];
             if (!cur.groups_set || !cur.source_set || !cur.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", a);
+            { int orc = reject_overlap(e, a, "one-call step"); if (orc) return orc; }
             for (int c = 0; c < C; ++c)
                 if (!cur.counts_set[c] || !e->conc_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts / concentration of component %d not set", a, c);
         }
@@ -1003,6 +1006,7 @@ int sbe_step_delta(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* mo
     }
     const Slot& cur = e->slots[cur_slot];
     if (!cur.groups_set || !cur.source_set || !cur.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", cur_slot);
+    { int orc = reject_overlap(e, cur_slot, "one-call step"); if (orc) return orc; }
     for (int c = 0; c < C; ++c)
         if (!cur.counts_set[c] || !e->conc_set[c]) return fail(e, SBE_ERR_STATE, "slot %d: counts / concentration of component %d not set", cur_slot, c);
     HIPCHK(e, hipSetDevice(e->device));
@@ -1065,6 +1069,7 @@ int sbe_gibbs_step(sbe_engine* e, int cur_slot, int cand_slot, const int32_t* ob
     if (!(temperature > 0.0) || !(prior_temperature > 0.0)) return fail(e, SBE_ERR_ARG, "temperatures must be positive");
     Slot& cur = e->slots[cur_slot];
     if (!cur.groups_set || !cur.source_set || !cur.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", cur_slot);
+    { int orc = reject_overlap(e, cur_slot, "one-call step"); if (orc) return orc; }
     for (int c = 0; c < e->C; ++c)
         if (!cur.counts_set[c] || !e->conc_set[c] || !cur.probs_set[c])
             return fail(e, SBE_ERR_STATE, "slot %d: counts / concentration / probability tables of component %d not set", cur_slot, c);
@@ -1254,6 +1259,7 @@ static int gibbs_propose_impl(sbe_engine* e, int cur_slot, int cand_slot, const 
     if (!(temperature > 0.0) || !(prior_temperature > 0.0)) return fail(e, SBE_ERR_ARG, "temperatures must be positive");
     Slot& cur = e->slots[cur_slot];
     if (!cur.groups_set || !cur.source_set || !cur.weights_set) return fail(e, SBE_ERR_STATE, "slot %d: groups / source / weights not set", cur_slot);
+    { int orc = reject_overlap(e, cur_slot, "one-call step"); if (orc) return orc; }
     for (int c = 0; c < e->C; ++c)
         if (!cur.counts_set[c] || !e->conc_set[c] || !cur.probs_set[c])
             return fail(e, SBE_ERR_STATE, "slot %d: counts / concentration / probability tables of component %d not set", cur_slot, c);

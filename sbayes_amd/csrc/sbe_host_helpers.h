@@ -39,10 +39,23 @@ static inline int sbeh_source_ids(const uint8_t* source, int64_t n_objects, int 
         if (o < 0 || o >= n_objects) return -1;
         const uint8_t* src = source + o * row;
         uint8_t* out = ids_out + (int64_t)i * n_features;
-        for (int f = 0; f < n_features; ++f) {
-            uint8_t id = 0xFF;
-            for (int c = 0; c < n_components; ++c) if (src[(int64_t)f * n_components + c]) { id = (uint8_t)c; break; }   /* (first set: argmax) */
-            out[f] = id;
+        /* first set component (argmax), BIT-SELECTED -- no data-dependent branch: the source of an observation is as good as
+           random, and the first-hit scan with its mispredicted branches cost ~9 cycles per observation: a third of the host layer's
+           update_feature_counts at 1000 x 200 x 2 (round 6).  These loops vectorise. */
+        if (n_components == 2) {
+            for (int f = 0; f < n_features; ++f) {
+                const uint8_t m0 = (uint8_t)-(src[2 * f] != 0), m1 = (uint8_t)-(src[2 * f + 1] != 0);
+                out[f] = (uint8_t)(~m0 & ((uint8_t)(m1 & 1) | (uint8_t)~m1));          /* m0: 0; else m1: 1; else 0xFF */
+            }
+        } else {
+            for (int f = 0; f < n_features; ++f) {
+                uint8_t id = 0xFF;
+                for (int c = n_components - 1; c >= 0; --c) {
+                    const uint8_t m = (uint8_t)-(src[(int64_t)f * n_components + c] != 0);
+                    id = (uint8_t)((id & ~m) | ((uint8_t)c & m));
+                }
+                out[f] = id;
+            }
         }
     }
     return 0;

@@ -84,13 +84,24 @@ class FakeEngine:
         self._touch(slot)
         self.calls.append(("set_groups", component))
         g = np.asarray(groups, dtype=bool)
+        # the real engine's contract (sbe_set_groups, round 6): an object in several groups keeps the LAST one as its id -- what
+        # an uncached likelihood evaluation ends up with (likelihood.py:126-130; the oracle's a1 does the same on the matrix) --
+        # and the slot is marked: calls that would derive COUNTS from one id per object refuse it (_reject_overlap)
         multi = np.flatnonzero(g.sum(axis=0) > 1)
-        if multi.size:                  # the real engine's contract (sbe_set_groups): overlap has no resident form
-            from sbayes_amd.engine import GroupOverlapError
+        marks = self._slot(slot).setdefault("overlap", {})
+        if multi.size:
             n = int(multi[0])
             g1, g2 = (int(v) for v in np.flatnonzero(g[:, n])[:2])
-            raise GroupOverlapError(4, f"object {n} is in groups {g1} and {g2} of component {component}")
+            marks[component] = f"object {n} is in groups {g1} and {g2} of component {component}"
+        else:
+            marks.pop(component, None)
         self._slot(slot)["groups"][component] = g.copy()
+
+    def _reject_overlap(self, slot):
+        marks = self._slot(slot).get("overlap")
+        if marks:
+            from sbayes_amd.engine import GroupOverlapError
+            raise GroupOverlapError(4, next(iter(marks.values())))
 
     def set_concentration(self, component, concentration):
         self._bound.clear()
@@ -202,12 +213,18 @@ class FakeEngine:
         return orc.normalize_weights(np.asarray(weights, dtype=np.float32), np.asarray(has_components, dtype=bool))
 
     def recount(self, slot, component=-1):
+        self._reject_overlap(slot)
         self._touch(slot)
         self.calls.append(("recount",))
         s = self._slot(slot)
         groups = [s["groups"][c] for c in range(len(s["groups"]))]
         for c, table in enumerate(orc.recalculate_feature_counts(self.features, groups, s["source"])):
             s["counts"][c] = table
+
+    def mixture_loglik(self, slot=0):
+        self.calls.append(("mixture_loglik",))
+        groups, counts, conc, s = self._full_state(slot)
+        return float(orc.mixture_loglik(self.features, self.na_values(), groups, counts, conc, s["weights"]))
 
     def get_counts(self, slot, component):
         return self._slot(slot)["counts"][component].copy()

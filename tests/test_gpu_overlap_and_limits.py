@@ -3,9 +3,11 @@
 * stateless calls follow the reference on overlap, bit for bit against its recorded outputs (tests/golden/overlap.npz):
   sbe_component_lh -- the LAST WRITTEN group wins, in changed_groups order, unchanged groups' rows stay
   (likelihood.py:121-130); sbe_effect_counts -- once per group (counts.py:28-30);
-* resident state (one group id per object and component) REJECTS overlap with SBE_ERR_DATA naming object, groups and
-  component -- sbe_set_groups, the cluster matrices of sbe_step / sbe_step_batch (the batch names the chain);
-* the drop-in functions fall back to the stateless calls and reproduce the reference's sample-level results;
+* resident state (one group id per object and component; round 6): sbe_set_groups keeps the LAST group of an object in several --
+  the group an uncached likelihood evaluation ends up with -- and marks the slot; likelihood evaluations run on it (the fused
+  mixture kernel reproduces the reference's value), calls that would derive COUNTS from the ids refuse it with SBE_ERR_DATA
+  naming object, groups and component; the cluster matrices of sbe_step / sbe_step_batch stay strict (the batch names the chain);
+* the drop-in functions' count paths fall back to the stateless calls and reproduce the reference's sample-level results;
 * a repeated moved object (batch: SBE_ERR_ARG; single: last entry wins like the matrix form),
   sbe_set_counts_rows on a component whose counts are not resident (SBE_ERR_STATE), the origin named by a deferred
   data check."""
@@ -67,10 +69,22 @@ def test_resident_state_rejects_overlap_and_the_drop_in_layer_falls_back():
                               z["source"])
     feats = model.data.features.values
     eng = model.likelihood.engine
-    with pytest.raises(GroupOverlapError, match=r"object 4 is in groups 0 and 1 of component 2.*counts\.py:28-30") as info:
-        eng.set_groups(0, 2, groups[2])
+    # (round 6) sbe_set_groups takes the overlapping matrix: the LAST group containing an object is its resident id ...
+    eng.set_groups(0, 2, groups[2])
+    want_ids = np.full(wl.shape[0], -1, dtype=np.int32)
+    for g in range(groups[2].shape[0]):
+        want_ids[groups[2][g]] = g
+    assert np.array_equal(eng.get_group_ids(0, 2), want_ids) and groups[2].sum(axis=0).max() > 1
+    # ... and the calls that would derive COUNTS from one id per object refuse the marked slot, naming object, groups, component
+    eng.set_groups(0, 0, groups[0]); eng.set_groups(0, 1, groups[1]); eng.set_source(0, z["source"]); eng.set_weights(0, z["weights"])
+    with pytest.raises(GroupOverlapError, match=r"object 4 is in groups 0 and 1 of component 2.*counts\.py:28-30.*sbe_recount") as info:
+        eng.recount(0)
     assert info.value.code == 4                                            # SBE_ERR_DATA
-    eng.set_groups(0, 0, groups[0])                                        # (disjoint matrices are taken as before)
+    eng.copy_slot(1, 0)                                                    # (the mark travels with the slot)
+    with pytest.raises(GroupOverlapError, match=r"one-call step"):
+        eng.step(1, 2)
+    eng.set_group_ids(1, 2, want_ids)                                      # ids as such cannot overlap: the mark is gone
+    eng.recount(1)
     recalculate_feature_counts(feats, sample)
     for c, k in enumerate(meta["component_names"]):
         assert np.array_equal(sample.feature_counts[k].value, z[f"sample_counts_{c}"])
@@ -84,8 +98,15 @@ def test_resident_state_rejects_overlap_and_the_drop_in_layer_falls_back():
     update_feature_counts(sample, new, feats, z["subset_idx"])
     for c, k in enumerate(meta["component_names"]):
         assert np.array_equal(new.feature_counts[k].value, z[f"delta_counts_{c}"])
-    with pytest.raises(GroupOverlapError):
-        mixture_log_likelihood(model, sample)
+    # the fused evaluation on RESIDENT state = the reference's uncached evaluation of the overlapping sample (1e-10), and the
+    # collapsed likelihood now comes from the resident counts the bind sent (no stateless fall-back left in Likelihood.__call__)
+    mix = mixture_log_likelihood(model, sample)
+    assert abs(mix - meta["mixture_ll"]) <= 1e-10 * abs(meta["mixture_ll"]), (mix, meta["mixture_ll"])
+    from sbayes_amd.conditionals import observation_likelihoods
+    from oracle import sbayes_oracle as orc
+    lh = orc.likelihood_per_component(wl.features, wl.na_values, groups, [z[f"sample_counts_{c}"] for c in range(3)], conc)
+    w = orc.normalize_weights(z["weights"], orc.has_components(groups))
+    assert np.array_equal(observation_likelihoods(model, sample), orc.mixture_observation_lh(w, lh))
 
 
 def _resident_engine(wl, n_slots):
