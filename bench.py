@@ -66,7 +66,7 @@ HEADLINE_BATCH = 4096      # resident states per launch (tools/summarize_profile
 NOMINAL_CLOCK_GHZ = 2.4    # MI355X_MICROARCH.md "Max clock"
 I8_MFMA_PEAK_TOPS = 5000.0 # MI355X_MICROARCH.md: dense i8 MFMA = 2 x the bf16 rate (~2.5 PF): ~5 POP/s
 FP4_MFMA_PEAK_TOPS = 10000.0   # MI355X_MICROARCH.md: dense FP4 (v_mfma_f32_32x32x64_f8f6f4) = 4 x the bf16 rate: ~10 PF
-PMC_FILE = "profiles/r5/pmc_summary.json"
+PMC_FILE = "profiles/r6/pmc_summary.json"
 TRAFFIC_FILE = "profiles/traffic_latest.json"
 
 
@@ -715,7 +715,7 @@ def static_profile_figures(workload, kernel, B, kern_us, kernel_name=None, resul
                                          f"of this command, profile {rec.get('profile')}; kernel name and results digest match this run)"}
         except Exception:
             pass
-    for cand in (PMC_FILE, "profiles/r4/pmc_summary.json", "profiles/r3/pmc_summary.json", "profiles/r2/pmc_summary.json"):
+    for cand in (PMC_FILE, "profiles/r5/pmc_summary.json", "profiles/r4/pmc_summary.json", "profiles/r3/pmc_summary.json", "profiles/r2/pmc_summary.json"):
         pf = REPO / cand
         if not pf.exists():
             continue
