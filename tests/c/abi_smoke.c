@@ -83,18 +83,23 @@ int main(int argc, char** argv) {
     /* error behaviour: a bad slot is reported through the return code + message, not a crash */
     if (p_sbe_mixture_loglik(e, 7, &ll) == 0) { fprintf(stderr, "bad slot accepted\n"); return 11; }
     printf("error_text %s\n", p_sbe_last_error(e));
-    /* round 4: a group matrix with an object in two rows has no resident form -> SBE_ERR_DATA naming object, groups, component
-       (needs two clusters); the slot keeps its previous ids */
+    /* ABI 6: a group matrix with an object in two rows is TAKEN (the last group is the object's id: what an uncached likelihood
+       evaluation ends up with, likelihood.py:126-130) and the slot is marked; a call that would derive COUNTS from one id per object
+       -- sbe_recount -- refuses the marked slot with SBE_ERR_DATA naming object, groups, component (needs two clusters).  The original
+       matrix clears the mark and the slot evaluates as before. */
     if (G[0] >= 2) {
         uint8_t* bad = (uint8_t*)malloc((size_t)G[0] * N);
         memcpy(bad, clusters, (size_t)G[0] * N);
         int n_first = -1;
         for (int n = 0; n < N && n_first < 0; ++n) if (bad[n]) n_first = n;      /* a member of cluster 0 ... */
         if (n_first >= 0) bad[(size_t)N + n_first] = 1;                            /* ... also put into cluster 1 */
-        const int rc = p_sbe_set_groups(e, 0, 0, bad);
-        printf("overlap_rc %d\noverlap_text %s\n", rc, p_sbe_last_error(e));
+        const int rc_set = p_sbe_set_groups(e, 0, 0, bad);
+        const int rc = p_sbe_recount(e, 0, -1);
+        printf("overlap_set_rc %d\noverlap_rc %d\noverlap_text %s\n", rc_set, rc, p_sbe_last_error(e));
         double again = 0.0;
-        if (p_sbe_mixture_loglik(e, 0, &again) || again != ll) { fprintf(stderr, "state changed by the refused call\n"); return 12; }
+        if (p_sbe_set_groups(e, 0, 0, clusters) || p_sbe_recount(e, 0, -1)) { fprintf(stderr, "%s\n", p_sbe_last_error(e)); return 12; }
+        for (int c = 0; c < C; ++c) if (p_sbe_update_probs(e, 0, c, 0.0, 0.0, NULL)) { fprintf(stderr, "%s\n", p_sbe_last_error(e)); return 12; }
+        if (p_sbe_mixture_loglik(e, 0, &again) || again != ll) { fprintf(stderr, "state not restored by the original matrix\n"); return 12; }
         free(bad);
     }
     /* round 4: the host helpers of the marshalling (no device): ids of the first 5 objects */

@@ -40,7 +40,9 @@ def test_plain_c_caller(tmp_path):
     assert abs(float(vals["collapsed_ll"]) - fx.meta["collapsed_ll"]) <= 1e-6 * abs(fx.meta["collapsed_ll"])
     assert int(vals["n_na"]) == int(fx.na_values.sum())
     assert "slot 7 out of range" in vals["error_text"]
-    # round 4: overlap is refused by name through the plain-C boundary; the host helpers answer like NumPy
+    # ABI 6: an overlapping matrix is taken (last group = id, slot marked); the count-deriving call refuses the marked slot by name
+    # through the plain-C boundary; the host helpers answer like NumPy
+    assert int(vals["overlap_set_rc"]) == 0
     assert int(vals["overlap_rc"]) == 4 and re.search(r"object \d+ is in groups 0 and 1 of component 0", vals["overlap_text"])
     cl = fx.groups[0][:, :5]
     want_gids = np.where(cl.any(axis=0), cl.argmax(axis=0), -1)
