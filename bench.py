@@ -86,7 +86,7 @@ def parse():
     ap.add_argument("--kernel", default="packed", choices=["packed", "packed_general", "packed_v2", "packed_tuple", "packed_tuple_lds", "packed_tuple_mfma", "onehot", "onehot_general"],
                     help="packed: state-index stream, group-tuple form when it applies (default); "
                          "packed_tuple: group-tuple form on the vector pipe forced (k_mixture_tuple64: what `packed` ran before round 5); "
-                         "packed_tuple_mfma: its matrix-pipe form forced (k_mixture_tuple_mfma: what `packed` picks for >= 512 states); "
+                         "packed_tuple_mfma: its matrix-pipe form forced (k_mixture_tuple_mfma: what `packed` picks for >= 320 states); "
                          "packed_general: never the group-tuple form (k_mixture_rows); packed_v2: the older general "
                          "kernel k_mixture_v2; onehot: stream the one-hot block")
     ap.add_argument("--log-mode", default="product", choices=["product", "per_obs"])

@@ -90,11 +90,14 @@ typedef struct sbe_engine sbe_engine;
                                           (k_mixture_tuple64): the LDS-metadata kernel (testing / A-B) */
 #define SBE_MIXTURE_PACKED_TUPLE_MFMA 7  /* packed, group-tuple form with the per-observation gather done as an exact
                                           0/1 byte contraction on the matrix pipe (k_mixture_tuple_mfma: counts per
-                                          (slot, tuple, feature, state) by v_mfma_i32_32x32x32_i8, then one log per table
-                                          entry), forced (error if not applicable: more than 8 tuples, C > 4, LDS).
-                                          SBE_MIXTURE_PACKED picks it by itself for launches of >= 512 slots
-                                          (tools/ab_mfma.py: 28 / 30 / 32 / 50 us against 20 / 32 / 55 / 98 us of
-                                          k_mixture_tuple64 at 256 / 512 / 1024 / 2048 headline states)         */
+                                          (slot, tuple, feature, state) by v_mfma_f32_32x32x64_f8f6f4 on FP4 operands --
+                                          0 and 1 are exact in e2m1, the counts in the f32 accumulator -- then one log per
+                                          table entry), forced (error if not applicable: more than 64 tuples, C > 4, LDS).
+                                          SBE_MIXTURE_PACKED picks it by itself for launches of >= 320 slots with <= 8 group
+                                          tuples per slot, and -- 9..64 tuples: 4 / 2 slots per block -- from 16 objects per
+                                          padded tuple on (tools/diag/mfma_threshold.py: 24.5 / 24.6 / 24.8 / 25.8 us against
+                                          22.2 / 32.1 / 34.9 / 58.3 us of k_mixture_tuple64 at 256 / 384 / 512 / 1024 headline
+                                          states; profiles/r6/wide_forms.log)                                   */
 #define SBE_OPT_LOG_MODE 2
 #define SBE_LOG_PER_OBS 0      /* fp64 log per observation, fp64 sum                        */
 #define SBE_LOG_PRODUCT 1      /* fp64 mantissa product + integer exponent, one log/thread  */

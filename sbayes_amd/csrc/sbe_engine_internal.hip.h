@@ -132,7 +132,9 @@ struct sbe_engine {
     uint8_t* d_xt = nullptr;       // one-hot block in MFMA fragment order (k_mixture_tuple_mfma), built at the first batched launch
     int xt_NT = 0, xt_KBp = 0;  size_t xt_bytes = 0;
     int mfma_wide_min_share = 16;  // wide matrix-pipe forms (> 8 tuples) by default only from this many objects per padded tuple on (SBE_MFMA_WIDE_MIN_SHARE)
-    int mfma_min_batch = 512;      // smallest launch the matrix-pipe form is chosen for under SBE_MIXTURE_PACKED (SBE_MFMA_MIN_BATCH)
+    int mfma_min_batch = 320;      // smallest launch the matrix-pipe form is chosen for under SBE_MIXTURE_PACKED (SBE_MFMA_MIN_BATCH);
+                                   // round 6, FP4 operands: 24.5 / 24.6 / 24.8 us against 22.2 / 32.1 / 34.9 us of k_mixture_tuple64 at
+                                   // 256 / 384 / 512 headline states (tools/diag/mfma_threshold.py, profiles/r6/mfma_threshold.log)
     uint8_t* d_tid = nullptr;      // [slots][Np] group-tuple index per object (k_mixture_combo)
     uint16_t* d_tuple_g = nullptr; // [slots][kMaxTuples][kMaxComponents]
     uint8_t* d_tuple_p = nullptr;  // [slots][kMaxTuples]

@@ -3,8 +3,8 @@ configs[2]: 1000 x 200 x 10, K = 5, C = 2) through the engine's DEFAULT kernel s
 state, against the oracle.  Reference expression: sbayes/sampling/loggers.py:355-357 over sbayes/model/likelihood.py:104-133,
 171-190.  Tolerance: 1e-10 relative (north_star).
 
-The selection flips at 512 slots per launch (sbe_engine_internal.hip.h: mfma_min_batch): 511 -> k_mixture_tuple64 (vector
-pipe), 512 / 1024 -> k_mixture_tuple_mfma at MT = 3 x 32 k-blocks x 63 column tiles -- bench.py's kernel and geometry.  A
+The selection flips at 320 slots per launch (sbe_engine_internal.hip.h: mfma_min_batch): 319 -> k_mixture_tuple64 (vector
+pipe), 320 / 1024 -> k_mixture_tuple_mfma at MT = 3 x 16 k-blocks of 64 objects x 63 column tiles -- bench.py's kernel and geometry.  A
 fixed-seed 60-second slice of tools/fuzz_gpu.py's "big" generator follows (the open-ended fuzzer itself is not part of the suite)."""
 import sys
 import time
@@ -55,7 +55,7 @@ def oracle_value(wl, state):
     return float(orc.mixture_loglik(wl.features, wl.na_values, groups, counts, wl.concentration, weights))
 
 
-@pytest.mark.parametrize("B,kernel", [(511, "k_mixture_tuple64"), (512, "k_mixture_tuple_mfma"), (1024, "k_mixture_tuple_mfma")])
+@pytest.mark.parametrize("B,kernel", [(319, "k_mixture_tuple64"), (320, "k_mixture_tuple_mfma"), (1024, "k_mixture_tuple_mfma")])
 def test_headline_default_selection_distinct_slots_vs_oracle(headline_engine, B, kernel):
     wl, eng, states = headline_engine
     eng.set_option(kernel=MIXTURE_PACKED)                                      # the default: what bench.py runs
@@ -73,7 +73,7 @@ def test_headline_default_selection_distinct_slots_vs_oracle(headline_engine, B,
     eng.mixture_loglik_batch_async(0, B)
     assert np.array_equal(eng.fetch_results(0, B), got)
     # and the two kernel forms agree with each other on EVERY slot far inside the tolerance (one of them is oracle-checked above)
-    other = eng.mixture_loglik_batch(0, 511 if B != 511 else 512)
+    other = eng.mixture_loglik_batch(0, 319 if B != 319 else 320)
     n = min(B, other.size)
     np.testing.assert_allclose(got[:n], other[:n], rtol=1e-12)
 

@@ -296,10 +296,10 @@ def test_mfma_kernel_batches(shape):
 
 
 def test_mfma_kernel_default_choice_and_zero_probability():
-    """SBE_MIXTURE_PACKED picks the matrix-pipe form from 512 slots per launch on (the vector-pipe form below), and a
+    """SBE_MIXTURE_PACKED picks the matrix-pipe form from 320 slots per launch on (the vector-pipe form below), and a
     zero-probability OBSERVED state gives -inf like the reference's log(0), in that slot only."""
     rng = np.random.default_rng(5)
-    N, F, S, B = 60, 12, 3, 512
+    N, F, S, B = 60, 12, 3, 320
     feats, groups0, _w, _s, _conc = random_case(rng, N, F, S, [2, 1], 0.0)
     with Engine(feats, [2, 1], n_slots=B) as eng:
         a = rng.integers(0, 4, size=N)
