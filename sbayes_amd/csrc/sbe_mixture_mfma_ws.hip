@@ -97,7 +97,6 @@ __global__ __launch_bounds__((PW + PW * MT) * kWave, 1) void k_mixture_tuple_mfm
             for (int i = 0; i < PF; ++i) bq[i] = load_b(toff0, i);
         }
         for (int g = 0; g <= n_gen; ++g) {
-#ifndef SBE_WS_NO_PRODUCE                                   /* (experiment switch: tools/build_variant.sh) */
             if (g < n_gen) {
                 const int toff = tile_off(nt_lo + g * PW + w);
                 v16f_t acc[MT];
@@ -152,7 +151,6 @@ __global__ __launch_bounds__((PW + PW * MT) * kWave, 1) void k_mixture_tuple_mfm
                     }
                 }
             }
-#endif
             __syncthreads();
         }
     } else {
@@ -180,13 +178,6 @@ __global__ __launch_bounds__((PW + PW * MT) * kWave, 1) void k_mixture_tuple_mfm
         };
         auto st_load = [&](int q) {                                   // step q's table operands; its metadata sits in mdn[q & 1]
             const Meta (&mdq)[G] = mdn[q & 1];
-#ifdef SBE_WS_NO_LOADS                                      /* (experiment switch) */
-#pragma unroll
-            for (int i = 0; i < G; ++i)
-#pragma unroll
-                for (int cc = 0; cc < CT; ++cc) { wrq[q & 1][i][cc] = __uint_as_float(mdq[i].woff | 0x3F000000u); prq[q & 1][i][cc] = __uint_as_float(mdq[i].goff[cc] | 0x3F000000u); }
-            return;
-#endif
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 const uint32_t wo = mdq[i].woff + fw4;
@@ -228,12 +219,7 @@ __global__ __launch_bounds__((PW + PW * MT) * kWave, 1) void k_mixture_tuple_mfm
                 special |= __builtin_amdgcn_class(v, 0x2FF);            // anything but a positive normal double
             }
             int kx[G];
-#ifdef SBE_WS_NO_LOG                                        /* (experiment switch) */
-#pragma unroll
-            for (int i = 0; i < G; ++i) { lg[i] = vv[i]; kx[i] = 1; }
-#else
             tab_log4_n<G>(vv, lg, kx, tab_off, one_hi);
-#endif
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0ull, 0)) {      // rare: see k_mixture_tuple_mfma
 #pragma unroll
                 for (int i = 0; i < G; ++i)
@@ -255,7 +241,6 @@ __global__ __launch_bounds__((PW + PW * MT) * kWave, 1) void k_mixture_tuple_mfm
         st_meta(1, 1);
         st_load(0);
         for (int g = 0; g <= n_gen; ++g) {
-#ifndef SBE_WS_NO_CONSUME
             if (g > 0) {
                 const int nt = nt_lo + (g - 1) * PW + pw;             // this generation's tile of the consumer
                 const uint32_t tbase = ring_off + (uint32_t)(((((g - 1) & 1) * PW + pw) * MT + m)) * kTileBytes + (uint32_t)lane * 8u;
@@ -274,7 +259,6 @@ __global__ __launch_bounds__((PW + PW * MT) * kWave, 1) void k_mixture_tuple_mfm
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-#endif
             __syncthreads();
         }
         // ---- 32 columns of a lane half; the consumer's sums per slot go to LDS ------------------------------------------------
