@@ -55,7 +55,7 @@ def oracle_value(wl, state):
     return float(orc.mixture_loglik(wl.features, wl.na_values, groups, counts, wl.concentration, weights))
 
 
-@pytest.mark.parametrize("B,kernel", [(319, "k_mixture_tuple64"), (320, "k_mixture_tuple_mfma"), (1024, "k_mixture_tuple_mfma")])
+@pytest.mark.parametrize("B,kernel", [(319, "k_mixture_tuple64"), (320, "k_mixture_tuple_mfma"), (512, "k_mixture_tuple_mfma"), (1024, "k_mixture_tuple_mfma")])
 def test_headline_default_selection_distinct_slots_vs_oracle(headline_engine, B, kernel):
     wl, eng, states = headline_engine
     eng.set_option(kernel=MIXTURE_PACKED)                                      # the default: what bench.py runs
