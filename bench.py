@@ -98,6 +98,7 @@ def parse():
                          "it instead).  roofline.kernel_avg_us never comes from these pairs: it is the span of the K back-to-back "
                          "launches of a timed repetition / K")
     ap.add_argument("--no-legs", action="store_true", help="skip the hbm_regime and changing_tables legs (and their extra slots)")
+    ap.add_argument("--legs", action="store_true", help="run the two legs even with --no-secondary (tests)")
     ap.add_argument("--min-time", type=float, default=0.05,
                     help="the K-step timed loop is repeated (each repetition bracketed by barrier + sync on both sides) "
                          "until the repetitions together cover this many seconds; the MEDIAN repetition is reported")
@@ -819,7 +820,7 @@ def main():
     B = args.batch if args.batch else (64 if args.workload == "stress" else HEADLINE_BATCH)
     # the two legs beside the headline figure need a second set of B slots (candidates of the changing-tables leg, then the
     # upper half of the 2 B states of the HBM-regime launch): rank 0 of a 1-GPU run only
-    legs = rank == 0 and n_gpus == 1 and not args.no_legs and not args.no_secondary and args.kernel == "packed" and 2 * B <= 16384
+    legs = rank == 0 and n_gpus == 1 and not args.no_legs and (args.legs or not args.no_secondary) and args.kernel == "packed" and 2 * B <= 16384
     t_setup = time.perf_counter()
     eng = setup_engine(wl, B, device, args.kernel, args.log_mode, n_slots=2 * B if legs else B)
     t_setup = time.perf_counter() - t_setup

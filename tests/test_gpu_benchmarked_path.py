@@ -104,3 +104,24 @@ def test_fixed_seed_slice_of_the_big_fuzz_generator():
         one_case(rng, stats, big=True)
     assert stats["cases"] >= 2 and stats["evals"] > 0
     print(f"[fuzz slice] {stats} in {time.time() - t0:.0f} s")
+
+
+def test_bench_line_is_self_consistent_and_self_proving():
+    """bench.py at a small batch, legs included: the fraction is a fraction, the kernel fits inside the step,
+    the TIMED results and both legs' results passed the oracle gate (the run fails otherwise), the legs report their figures."""
+    import json
+    import subprocess
+    res = subprocess.run([sys.executable, str(REPO / "bench.py"), "--batch", "512", "--steps", "5", "--warmup", "2", "--no-secondary",
+                          "--no-cpu-baseline", "--legs"], capture_output=True, text=True, timeout=600, cwd=str(REPO))
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    rf = line["roofline"]
+    assert 0.0 < rf["frac"] <= 1.0 and rf["frac_contract"] >= rf["frac"]
+    assert rf["kernel_avg_us"] <= line["ms_per_step"] * 1000.0 * 1.0005
+    assert "k_mixture_tuple_mfma" in rf["kernel"] and line["parity_timed_kernel"]["kernel"] == rf["kernel"]
+    assert line["parity_timed_kernel_max_rel_err"] <= 1e-10 and len(line["parity_timed_kernel"]["slots"]) >= 8
+    hbm, chg = line["hbm_regime"], line["changing_tables"]
+    assert hbm["evals_per_launch"] == 1024 and hbm["parity_max_rel_err"] <= 1e-10 and 0.0 < hbm["frac"] <= 1.0
+    assert hbm["kernel_avg_us"] <= hbm["ms_per_step"] * 1000.0 * 1.0005
+    assert chg["states"] == 512 and chg["parity_max_rel_err"] <= 1e-10 and chg["evals_per_s"] > 0
+    assert line["value_hbm_regime"] == hbm["evals_per_s"] and line["value_changing_tables"] == chg["evals_per_s"]
