@@ -59,10 +59,6 @@ import numpy as np
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-# the engine's host pool (payload packing of the batched steps: the changing_tables leg; copies of large results) may use the box's
-# CPU share: the library caps the count by the affinity mask and the cgroup quota divided by LOCAL_WORLD_SIZE (16 for one GPU on the
-# pool's boxes; 8 is the library's own default).  Same results at any count.
-os.environ.setdefault("SBE_STEP_THREADS", "16")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 N_SIMDS = 1024             # 256 CUs x 4 SIMD-32
