@@ -337,6 +337,26 @@ def changing_tables_leg(eng, wl, n_chains, sweeps, warm=3):
                     "on tables rewritten a moment earlier"}
 
 
+def cpu_baseline_compiled(wl, seconds):
+    """The COMPILED single-thread CPU baseline: oracle/sbayes_oracle_c.c (plain C, gcc -O3; == the NumPy oracle at 1e-12,
+    tests/test_oracle_c_cpu.py) evaluating the same expression.  The real reference compiles two functions of this path with
+    numba when numba is installed (not in this image) and leaves the rest to NumPy: the whole eval in C is an upper bound on that
+    path's single-core rate.  Checker / baseline only."""
+    from oracle import sbayes_oracle as orc
+    from oracle import sbayes_oracle_c as orc_c
+    counts = orc.recalculate_feature_counts(wl.features, wl.groups, wl.source)
+    args = (wl.features, wl.na_values, wl.groups, counts, wl.concentration, wl.weights)
+    ll = orc_c.mixture_loglik(*args)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc_c.mixture_loglik(*args)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 100000:
+            break
+    return ll, n / el, n, el
+
+
 NUMBA_CAVEAT = ("the real reference JIT-compiles compute_component_likelihood and dirichlet_categorical_logpdf with numba when "
                 "numba is installed; the baseline north_star names is the NumPy path, and that is what is timed here "
                 "(BASELINE.md section 3)")
@@ -988,6 +1008,18 @@ def main():
                "sample": f"{n_cpu} uncached mixture-LL evals of the {args.workload} workload in {cpu_el:.1f} s, "
                          f"single-thread NumPy oracle (oracle/sbayes_oracle.py), host has {os.cpu_count()} cores",
                "caveat": NUMBA_CAVEAT}
+        try:
+            ll_c, rate_c, n_c, el_c = cpu_baseline_compiled(wl, min(args.cpu_seconds, 3.0))
+            assert abs(ll_c - ll_cpu) <= 1e-10 * abs(ll_cpu), (ll_c, ll_cpu)
+            extra["cpu_baseline_compiled"] = {
+                "value": round(rate_c, 2), "unit": "evals/s", "cores": 1, "kind": "port",
+                "sample": f"{n_c} evals in {el_c:.1f} s by oracle/sbayes_oracle_c.c (plain C, gcc -O3, one thread; the whole eval compiled)",
+                "note": "numba is not installed here, so the reference's JIT path cannot be timed; it compiles compute_component_likelihood "
+                        "and dirichlet_categorical_logpdf only and leaves the rest of this eval to NumPy: the whole expression in C is an "
+                        "UPPER bound on that path's single-core rate",
+                "speedup_of_value": round(value / rate_c, 1)}
+        except Exception as exc:                                  # noqa: BLE001  (no C compiler on the box: the figure is skipped)
+            extra["cpu_baseline_compiled"] = {"error": repr(exc)}
         n_proc = min(8, os.cpu_count() or 1)
         rate8, n8, el8 = cpu_baseline_processes(args.workload, args.cpu_seconds, n_proc)
         extra["cpu_baseline_processes"] = {
