@@ -902,7 +902,8 @@ def main():
     # ranks; the repetition count follows from the first one's all-reduced time, so every rank runs the same number)
     # -- and the MEDIAN repetition is reported: value, ms_per_step and the kernel span all come from that ONE repetition.
     first, results = timed_rep()
-    n_reps = args.reps if args.reps > 0 else int(min(200, max(3, np.ceil(args.min_time / max(first, 1e-9)))))
+    n_reps = args.reps if args.reps > 0 else int(min(200, max(5, np.ceil(args.min_time / max(first, 1e-9)))))
+    n_reps += 1 - n_reps % 2                           # an odd count: the median is ONE repetition, not the upper of two middle ones
     rep_times = [first]
     for _ in range(n_reps - 1):
         dt, results = timed_rep()
