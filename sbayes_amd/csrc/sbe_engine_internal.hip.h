@@ -953,11 +953,17 @@ static bool mfma_ws_wanted() {
 }
 MfmaGeom mfma_geometry(const sbe_engine* e, int n, int KT) {
     MfmaGeom g{};
-    g.SL = tuple_mfma_slots_per_block(KT);           // 16 slots x <= 8 tuples, 4 x <= 32, 2 x <= 64 per block
+    g.SL = tuple_mfma_slots_per_block(KT);           // 16 slots x <= 8 tuples, 4 x <= 32, 2 x <= 64 per block: the most KT allows
     if (g.SL == 0 || e->C > 4) return g;
     const int NT = div_up((int64_t)e->F * e->S, 32), KBp = round_up(div_up(e->N, tuple_mfma_kblock_objects()), 4);
-    g.MT = div_up(KT, 32 / g.SL);
-    g.lds = tuple_mfma_lds_bytes(g.MT, e->C, KBp);
+    // ... and fewer slots per block (FP4 operands) while the A image -- MT x KBp KB, MT = tuples x slots / 32 -- does not fit a
+    // CU's LDS: many objects with few tuples (5000 objects x 6 tuples: 16 slots need 3 x 80 KB, 4 slots 1 x 80 KB)
+    for (;;) {
+        g.MT = div_up(KT, 32 / g.SL);
+        g.lds = tuple_mfma_lds_bytes(g.MT, e->C, KBp);
+        if (g.lds <= 160 * 1024 || g.SL == 2 || !tuple_mfma_fp4()) break;
+        g.SL = g.SL == 16 ? 4 : 2;
+    }
     if (g.SL == 16 && tuple_mfma_fp4() && mfma_ws_wanted() && tuple_mfma_ws_lds_bytes(g.MT, e->C, KBp) <= 160 * 1024) {
         g.ws = true;
         g.lds = tuple_mfma_ws_lds_bytes(g.MT, e->C, KBp);
@@ -988,7 +994,7 @@ int launch_mfma_form(sbe_engine* e, int first_slot, int n, int KT, const MfmaGeo
     if (rc) return rc;
     MfmaMixParams p{};
     p.F = e->F; p.S = e->S; p.FS = e->F * e->S; p.Gtot = e->Gtot; p.Np = e->Np;
-    p.NT = e->xt_NT; p.KBp = e->xt_KBp; p.KT = KT;
+    p.NT = e->xt_NT; p.KBp = e->xt_KBp; p.KT = KT; p.SL = mg.SL;
     p.n_batch = n; p.n_split = mg.n_split; p.nt_per_split = mg.nt_per_split;
     p.first_slot = first_slot; p.slot_list = d_slots;
     p.xt = e->d_xt; p.xt_bytes = (uint32_t)e->xt_bytes;

@@ -63,7 +63,8 @@ struct Mix2Params {
 struct MfmaMixParams {
     int F, S, FS, Gtot, Np;
     int NT, KBp;                                   // 32-column tiles of the (feature, state) axis; k-blocks of 64 (FP4 operands) / 32 (i8) objects, padded to a multiple of 4
-    int KT;                                        // tuples used by the slots of this launch (max; <= 64: 16 / 4 / 2 slots per block)
+    int KT;                                        // tuples used by the slots of this launch (max; <= 64)
+    int SL;                                        // slots per block: 16 (KT <= 8), 4 (<= 32) or 2 (<= 64) -- the widest whose A image fits LDS
     int n_batch, n_split, nt_per_split;            // slots of the launch; column splits (blocks per group of 16 slots); column tiles per split
     int first_slot;
     const int32_t* slot_list;                      // slots of this launch (n_batch entries), or null: first_slot + i
@@ -107,7 +108,7 @@ void launch_state_s(const uint8_t* state, uint8_t* state_s, int N, int F, int Fp
 // sbe_mixture_mfma.hip
 bool tuple_mfma_fp4();                            // operand format of the count contraction: FP4 (default; a k-block = 64 objects) or i8 (32)
 inline int tuple_mfma_kblock_objects() { return tuple_mfma_fp4() ? 64 : 32; }
-int tuple_mfma_slots_per_block(int KT);           // 16 (KT <= 8) / 4 (<= 32) / 2 (<= 64) slots per block; 0: the form does not apply
+int tuple_mfma_slots_per_block(int KT);           // 16 (KT <= 8) / 4 (<= 32) / 2 (<= 64): the MOST slots per block KT tuples allow; 0: the form does not apply
 void launch_xt_frags(const uint8_t* state, uint8_t* xt, int N, int F, int S, int Fp, int NT, int KBp, bool fp4, hipStream_t st);
 size_t column_tables_bytes(int NT);               // colcount | colfeat | tile_prefix (MfmaMixParams), one allocation
 void launch_column_tables(const uint8_t* state, int32_t* out, int N, int F, int S, int Fp, int NT, hipStream_t st);

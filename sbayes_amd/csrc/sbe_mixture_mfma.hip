@@ -546,7 +546,7 @@ bool launch_tuple_mfma(int C, const MfmaMixParams& p, dim3 grid, size_t lds, hip
     static const bool no_static_lds = tuple_mfma_fp4() ? (allow_lds_all<true, 4>() & allow_lds_all<true, 2>() & allow_lds_all<true, 1>())
                                                        : allow_lds_all<false, 4>();
     if (!no_static_lds) return false;
-    const int SL = tuple_mfma_slots_per_block(p.KT);
+    const int SL = p.SL;                                 // (chosen by the host: mfma_geometry)
     const int MT = (p.KT + 32 / SL - 1) / (32 / SL);
     if (!fp4) launch_mfma_slb<false, 4>(MT, C, p, grid, lds, st);
     else if (SL == 16) launch_mfma_slb<true, 4>(MT, C, p, grid, lds, st);

@@ -230,6 +230,8 @@ def test_tuple_kernel_batches(shape):
     (260,  24,  3,  [3, 1, 3, 3], 9),     # C = 4, up to 64 tuples: 2 slots per block, 4 M tiles; odd batch
     (700,  33,  6,  [5, 1, 7],  10),      # up to 48 tuples: 2 slots per block, 3 M tiles; 11 k-blocks padded to 12
     (150,  20,  2,  [8, 1],     21),      # 9 tuples: the smallest wide case (4 slots, 2 M tiles)
+    (5200, 12,  3,  [5, 1],     10),      # many objects, few tuples: the A image of 16 slots (3 x 84 KB) does not fit LDS -> 4 slots per block
+    (8900, 6,   2,  [2, 1],     5),       # 140 k-blocks: 4 slots x 1 M tile, the A image 140 KB -- the largest that fits a CU's LDS
 ], ids=lambda s: f"N{s[0]}F{s[1]}S{s[2]}C{len(s[3])}B{s[4]}")
 def test_mfma_kernel_batches(shape):
     """Batches through the matrix-pipe group-tuple kernel (counts per (slot, tuple, feature, state) by i8 MFMA, one log per
@@ -279,6 +281,8 @@ def test_mfma_kernel_batches(shape):
         eng.set_option(kernel=MIXTURE_PACKED_TUPLE_MFMA)
         got = eng.mixture_loglik_batch(0, B)
         assert "k_mixture_tuple_mfma" in eng.last_mixture_kernel()
+        if N >= 5000:
+            assert "4 slots x M tiles 1" in eng.last_mixture_kernel(), eng.last_mixture_kernel()
         np.testing.assert_allclose(got, want, rtol=1e-10)
         assert np.array_equal(eng.mixture_loglik_batch(0, B), got)                     # fixed reduction order
         picks = sorted(set([0, B - 1, B // 2]))
