@@ -452,6 +452,47 @@ def one_case(rng, stats, big=False):
                 assert abs(mix - want_mix) <= 1e-10 * abs(want_mix) + 1e-16 * N * F, (tag, "gibbs mixture", mix, want_mix)
             assert np.isfinite(lq) and np.isfinite(lqb) and lq <= 1e-9 and lqb <= 1e-9, (tag, lq, lqb)
             stats["gibbs"] += 1
+        # round 6: RESIDENT OVERLAP -- some objects of the last component put into a SECOND group: sbe_set_groups keeps the last
+        # group as the id (what an uncached evaluation ends up with, likelihood.py:126-130), counts come from the caller (once per
+        # group, counts.py:28-30), every kernel form must return the oracle's value of the overlapping sample; the ids read back
+        # are the last groups; count-deriving calls refuse the marked slot
+        if C >= 2 and n_groups[C - 1] >= 2 and N >= 4:
+            groups, weights, source, counts = states[0]
+            ov = groups[C - 1].copy()
+            extra = rng.integers(0, N, size=max(1, N // 8))
+            ov[rng.integers(0, ov.shape[0], size=extra.size), extra] = True
+            if (ov.sum(axis=0) > 1).any():
+                ov_groups = groups[:C - 1] + [ov]
+                ov_counts = orc.recalculate_feature_counts(feats, ov_groups, source)
+                slot = B + 1
+                eng.copy_slot(slot, 0)
+                eng.set_groups(slot, C - 1, ov)
+                want_ids = np.full(N, -1, dtype=np.int32)
+                for g in range(ov.shape[0]):
+                    want_ids[ov[g]] = g
+                assert np.array_equal(eng.get_group_ids(slot, C - 1), want_ids), (tag, "overlap ids")
+                for c in range(C):
+                    eng.set_counts(slot, c, ov_counts[c])
+                    eng.update_probs(slot, c)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    want_ov = orc.mixture_loglik(feats, na, ov_groups, ov_counts, conc, weights)
+                if np.isfinite(want_ov):
+                    for kernel in (MIXTURE_PACKED, MIXTURE_PACKED_GENERAL, MIXTURE_PACKED_V2, MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_MFMA, MIXTURE_ONEHOT):
+                        eng.set_option(kernel=kernel)
+                        try:
+                            got_ov = eng.mixture_loglik(slot)
+                        except EngineError as exc:
+                            if "not applicable" in str(exc):
+                                continue
+                            raise
+                        assert abs(got_ov - want_ov) <= 1e-10 * abs(want_ov) + 1e-16 * N * F, (tag, "overlap", kernel, got_ov, want_ov)
+                    eng.set_option(kernel=MIXTURE_PACKED)
+                    try:
+                        eng.recount(slot)
+                        raise AssertionError((tag, "recount accepted a slot with overlapping groups"))
+                    except EngineError as exc:
+                        assert " is in groups " in str(exc), exc
+                    stats["overlap"] = stats.get("overlap", 0) + 1
     stats["cases"] += 1
 
 
