@@ -93,8 +93,8 @@ typedef struct sbe_engine sbe_engine;
                                           (slot, tuple, feature, state) by v_mfma_f32_32x32x64_f8f6f4 on FP4 operands --
                                           0 and 1 are exact in e2m1, the counts in the f32 accumulator -- then one log per
                                           table entry), forced (error if not applicable: more than 64 tuples, C > 4, LDS).
-                                          SBE_MIXTURE_PACKED picks it by itself for launches of >= 320 slots with <= 8 group
-                                          tuples per slot, and -- 9..64 tuples: 4 / 2 slots per block -- from 16 objects per
+                                          SBE_MIXTURE_PACKED picks it by itself for launches of >= 320 slots -- >= 32 when the launch holds
+                                          6.4 M observations: four slots per block -- with <= 8 group tuples per slot, and -- 9..64 tuples: 4 / 2 slots per block -- from 16 objects per
                                           padded tuple on (tools/diag/mfma_threshold.py: 24.5 / 24.6 / 24.8 / 25.8 us against
                                           22.2 / 32.1 / 34.9 / 58.3 us of k_mixture_tuple64 at 256 / 384 / 512 / 1024 headline
                                           states; profiles/r6/wide_forms.log)                                   */

@@ -181,6 +181,8 @@ int sbe_create(sbe_engine** out, int device, int n_objects, int n_features, int 
     e->compute_units = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* env = getenv("SBE_MFMA_MIN_BATCH")) { if (atoi(env) > 0) e->mfma_min_batch = atoi(env); }      // (A/B runs, tests)
     if (const char* env = getenv("SBE_MFMA_WIDE_MIN_SHARE")) { if (atoi(env) >= 0) e->mfma_wide_min_share = atoi(env); }
+    if (const char* env = getenv("SBE_MFMA_SMALL_SL4")) e->mfma_small_sl4 = atoi(env) != 0;
+    if (const char* env = getenv("SBE_MFMA_MIN_OBS")) { if (atoll(env) > 0) e->mfma_min_obs = atoll(env); }
     if (const char* env = getenv("SBE_ROWS_SORTED")) e->opt_rows_sorted = atoi(env);
     snprintf(e->device_name, sizeof e->device_name, "%s%s%s", prop.name, prop.name[0] ? " " : "", prop.gcnArchName);
     CREATE_CHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));

@@ -131,6 +131,8 @@ struct sbe_engine {
                                    // form: per group of 16 slots); every launch leaves them at 0
     uint8_t* d_xt = nullptr;       // one-hot block in MFMA fragment order (k_mixture_tuple_mfma), built at the first batched launch
     int xt_NT = 0, xt_KBp = 0;  size_t xt_bytes = 0;
+    int mfma_small_sl4 = 1;        // four slots per block for launches whose blocks fit two rounds on the CUs (SBE_MFMA_SMALL_SL4=0: A/B)
+    int64_t mfma_min_obs = 6400000;  // ... chosen from 32 states per launch on when n x N x F reaches this (SBE_MFMA_MIN_OBS)
     int mfma_wide_min_share = 16;  // wide matrix-pipe forms (> 8 tuples) by default only from this many objects per padded tuple on (SBE_MFMA_WIDE_MIN_SHARE)
     int mfma_min_batch = 320;      // smallest launch the matrix-pipe form is chosen for under SBE_MIXTURE_PACKED (SBE_MFMA_MIN_BATCH);
                                    // round 6, FP4 operands: 24.5 / 24.6 / 24.8 us against 22.2 / 32.1 / 34.9 us of k_mixture_tuple64 at
@@ -956,6 +958,23 @@ MfmaGeom mfma_geometry(const sbe_engine* e, int n, int KT) {
     g.SL = tuple_mfma_slots_per_block(KT);           // 16 slots x <= 8 tuples, 4 x <= 32, 2 x <= 64 per block: the most KT allows
     if (g.SL == 0 || e->C > 4) return g;
     const int NT = div_up((int64_t)e->F * e->S, 32), KBp = round_up(div_up(e->N, tuple_mfma_kblock_objects()), 4);
+    // Few states per launch: with 16 slots per block a launch of n states is ceil(n / 16) x (at most 4 column splits) blocks -- at
+    // 512 states half the CUs idle and every block still walks a whole pass of MT M tiles (24.6 us at 256..1024 headline states).
+    // Four slots per block (ONE M tile of <= 8 tuples x 4 slots) make four times the blocks of a third of the work per pass.  The
+    // two geometries are compared by rounds of blocks x passes per block x M tiles (a pass costs ~4.3 us per M tile at the headline
+    // shape): 14.6 / 16.1 / 17.9 / 21.4 us at 32 / 256 / 320 / 512 states (1 / 1 / 2 / 2 units against 3) where k_mixture_tuple64
+    // takes 16.0 / 21.1 / 26.5 / 35.1 us; at 576 states the four-slot form needs 4 units (30.6 us) and the 16-slot form stays
+    // (24.6 us): profiles/r6/mfma_threshold.log
+    if (g.SL == 16 && tuple_mfma_fp4() && e->mfma_small_sl4) {
+        auto units = [&](int SL, int MT) -> int64_t {
+            const int groups = div_up(n, SL);
+            const int split = std::max(1, std::min(div_up(NT, 16), e->compute_units / std::max(1, groups)));
+            const int passes = div_up(round_up(div_up(NT, split), 2), 16);
+            return (int64_t)div_up(groups * split, e->compute_units) * passes * MT;
+        };
+        if (units(4, 1) < units(16, div_up(KT, 2))) g.SL = 4;
+    }
+    if (const char* env = getenv("SBE_MFMA_SL")) { const int v = atoi(env); if ((v == 4 || v == 2) && v < g.SL && tuple_mfma_fp4()) g.SL = v; }   // experiments
     // ... and fewer slots per block (FP4 operands) while the A image -- MT x KBp KB, MT = tuples x slots / 32 -- does not fit a
     // CU's LDS: many objects with few tuples (5000 objects x 6 tuples: 16 slots need 3 x 80 KB, 4 slots 1 x 80 KB)
     for (;;) {
@@ -1062,12 +1081,16 @@ int launch_mixture(sbe_engine* e, int first_slot, int n, int mode, hipEvent_t ev
     }
     // large batches: the per-observation gather as an integer contraction on the matrix pipe (k_mixture_tuple_mfma)
     MfmaGeom mg{};
-    if (combo && (force_mfma || (e->opt_kernel == SBE_MIXTURE_PACKED && n >= e->mfma_min_batch))) {
+    // (default: from mfma_min_batch states per launch on whatever the shape, and -- FP4 operands, four slots per block -- from 32
+    //  states on when the launch holds enough observations for the kernel's fixed costs: 32 headline states = 6.4 M)
+    const bool mfma_default = e->opt_kernel == SBE_MIXTURE_PACKED &&
+                              (n >= e->mfma_min_batch || (tuple_mfma_fp4() && e->mfma_small_sl4 && n >= 32 && (int64_t)n * e->N * e->F >= e->mfma_min_obs));
+    if (combo && (force_mfma || mfma_default)) {
         mg = mfma_geometry(e, n, KT);
         // The wide forms (more than 8 tuples: 4 / 2 slots per block) pay one log per (padded tuple, feature, state) where the
         // vector-pipe form pays one gather per observation: by default only where a table entry is shared by enough objects
         // (SBE_MFMA_WIDE_MIN_SHARE, objects per padded tuple; measured crossover: profiles/r6/wide_forms.log)
-        if (!force_mfma && mg.n_split > 0 && mg.SL != 16 && e->N < e->mfma_wide_min_share * mg.MT * (32 / mg.SL)) mg = MfmaGeom{};
+        if (!force_mfma && mg.n_split > 0 && KT > 8 && e->N < e->mfma_wide_min_share * mg.MT * (32 / mg.SL)) mg = MfmaGeom{};
     }
     const bool mfma = mg.n_split > 0;
     if (force_mfma && !mfma)

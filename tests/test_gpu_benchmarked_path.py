@@ -3,8 +3,10 @@ configs[2]: 1000 x 200 x 10, K = 5, C = 2) through the engine's DEFAULT kernel s
 state, against the oracle.  Reference expression: sbayes/sampling/loggers.py:355-357 over sbayes/model/likelihood.py:104-133,
 171-190.  Tolerance: 1e-10 relative (north_star).
 
-The selection flips at 320 slots per launch (sbe_engine_internal.hip.h: mfma_min_batch): 319 -> k_mixture_tuple64 (vector
-pipe), 320 / 1024 -> k_mixture_tuple_mfma at MT = 3 x 16 k-blocks of 64 objects x 63 column tiles -- bench.py's kernel and geometry.  A
+The selection at this shape (sbe_engine_internal.hip.h: launch_mixture / mfma_geometry): 31 states per launch -> k_mixture_tuple64
+(vector pipe); from 32 states on (6.4 M observations per launch) k_mixture_tuple_mfma -- with FOUR slots per block while that
+geometry needs fewer rounds x passes x M tiles (32 .. 512 states: 4 slots x one M tile), with 16 slots per block beyond (513, 1024:
+MT = 3 x 16 k-blocks of 64 objects x 63 column tiles -- bench.py's kernel and geometry).  A
 fixed-seed 60-second slice of tools/fuzz_gpu.py's "big" generator follows (the open-ended fuzzer itself is not part of the suite)."""
 import sys
 import time
@@ -55,17 +57,18 @@ def oracle_value(wl, state):
     return float(orc.mixture_loglik(wl.features, wl.na_values, groups, counts, wl.concentration, weights))
 
 
-@pytest.mark.parametrize("B,kernel", [(319, "k_mixture_tuple64"), (320, "k_mixture_tuple_mfma"), (512, "k_mixture_tuple_mfma"), (1024, "k_mixture_tuple_mfma")])
+@pytest.mark.parametrize("B,kernel", [(31, "k_mixture_tuple64"), (32, "k_mixture_tuple_mfma"), (319, "k_mixture_tuple_mfma"), (512, "k_mixture_tuple_mfma"),
+                                      (513, "k_mixture_tuple_mfma"), (1024, "k_mixture_tuple_mfma")])
 def test_headline_default_selection_distinct_slots_vs_oracle(headline_engine, B, kernel):
     wl, eng, states = headline_engine
     eng.set_option(kernel=MIXTURE_PACKED)                                      # the default: what bench.py runs
     got = eng.mixture_loglik_batch(0, B)
     assert kernel in eng.last_mixture_kernel(), eng.last_mixture_kernel()      # both sides of the threshold
-    if "mfma" in kernel:
-        assert "16 slots x M tiles 3" in eng.last_mixture_kernel()                        # 6 tuples: K = 5 clusters + "no cluster", one universal group
+    if "mfma" in kernel:                       # 6 tuples: K = 5 clusters + "no cluster", one universal group
+        assert ("4 slots x M tiles 1" if B <= 512 else "16 slots x M tiles 3") in eng.last_mixture_kernel(), eng.last_mixture_kernel()
     assert np.all(np.isfinite(got)) and len(set(got.tolist())) == B            # every slot its own state
     rng = np.random.default_rng(B)
-    picks = np.unique(np.concatenate([[0, 1, 15, 16, B - 17, B - 16, B - 1], rng.integers(0, B, size=17)]))
+    picks = np.arange(B) if B <= 32 else np.unique(np.concatenate([[0, 1, 15, 16, B - 17, B - 16, B - 1], rng.integers(0, B, size=24)]))
     assert picks.size >= 16
     want = np.array([oracle_value(wl, states[b]) for b in picks])
     np.testing.assert_allclose(got[picks], want, rtol=1e-10, atol=0.0)
@@ -73,7 +76,7 @@ def test_headline_default_selection_distinct_slots_vs_oracle(headline_engine, B,
     eng.mixture_loglik_batch_async(0, B)
     assert np.array_equal(eng.fetch_results(0, B), got)
     # and the two kernel forms agree with each other on EVERY slot far inside the tolerance (one of them is oracle-checked above)
-    other = eng.mixture_loglik_batch(0, 319 if B != 319 else 320)
+    other = eng.mixture_loglik_batch(0, 31)                      # (the vector-pipe form)
     n = min(B, other.size)
     np.testing.assert_allclose(got[:n], other[:n], rtol=1e-12)
 

@@ -545,6 +545,6 @@ for (N, F, S, n_groups, B) in [(203, 72, 4, [3, 1], 19), (1000, 37, 3, [5, 1], 6
         assert np.array_equal(eng.mixture_loglik_batch(0, B), got)
 print("ws ok")
 ''' % str(Path(__file__).resolve().parent.parent)
-    env = dict(os.environ, SBE_MFMA_WS="1")
+    env = dict(os.environ, SBE_MFMA_WS="1", SBE_MFMA_SMALL_SL4="0")      # (small launches would take four slots per block: no ws form there)
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0 and "ws ok" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]

@@ -8,7 +8,7 @@ from sbayes_amd.engine import MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_MFMA
 
 wl = bench.load_workload("headline")
 eng = bench.setup_engine(wl, 1024, 0)
-for b in (32, 64, 128, 192, 256, 384, 512, 768, 1024):
+for b in (int(x) for x in (sys.argv[1:] or "32 64 128 192 256 384 512 768 1024".split())):
     row = [b]
     for k in (MIXTURE_PACKED_TUPLE, MIXTURE_PACKED_TUPLE_MFMA):
         eng.set_option(kernel=k)
