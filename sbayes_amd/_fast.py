@@ -86,6 +86,32 @@ def diff_rows(new, mirror):
     return idx[:k]
 
 
+def diff_rows_among(new, mirror, cand_a, cand_b=None):
+    """diff_rows restricted to the rows listed in `cand_a` (and `cand_b`): int32 index arrays, any order, repeats allowed --
+    for a caller that KNOWS every other row equals the mirror's (binding.py: source lineage).  Ascending int32 result."""
+    n_rows = new.shape[0]
+    if n_rows == 0 or new.size == 0:
+        return np.zeros(0, dtype=np.int32)
+    if not new.flags.c_contiguous:
+        new = np.ascontiguousarray(new)
+    k = -2
+    if _h is not None:
+        idx = np.empty(cand_a.size + (cand_b.size if cand_b is not None else 0), dtype=np.int32)
+        k = _h.diff_rows_among(new, mirror, cand_a, cand_b, idx)
+        if k >= 0:
+            return idx[:k]
+    if k == -2:                                       # not built, or the candidates are not int32: the same with NumPy
+        cand = np.asarray(cand_a).reshape(-1) if cand_b is None else np.concatenate([np.asarray(cand_a).reshape(-1), np.asarray(cand_b).reshape(-1)])
+        cand = np.unique(cand.astype(np.int64))
+        if cand.size and (cand[0] < 0 or cand[-1] >= n_rows):
+            raise ValueError("diff_rows_among: row index out of range")
+        differs = (new[cand] != mirror[cand]).reshape(cand.size, -1).any(axis=1)
+        rows = cand[differs].astype(np.int32)
+        mirror[rows] = new[rows]
+        return rows
+    raise ValueError("diff_rows_among: row index out of range, or `new` and `mirror` differ in size")
+
+
 def touched_groups(gid_old, gid_new, n_groups_total):
     """Sorted distinct group indices >= 0 among two int32 id arrays of equal size (np.union1d without the -1s)."""
     touched = np.empty(n_groups_total, dtype=np.int32)
@@ -97,3 +123,50 @@ def touched_groups(gid_old, gid_new, n_groups_total):
     if k < 0:
         raise ValueError("group index out of range in gid_old / gid_new")
     return touched[:k]
+
+
+# ---- the sample cache's node protocol (sbayes/sampling/state.py:215-321) -------------------------------------------------------
+# is_outdated / what_changed / set_up_to_date in native code for the node classes registered here (csrc/sbe_pyhost.c: node_*);
+# any other node class is served by its own methods, from inside the same functions.  Registered: sbayes_amd.state's classes
+# (at import) and the reference's (patch.install, when their source is the revision mirrored).
+_NODE_PLAIN, _NODE_GROUPED = [], []
+
+
+def register_node_classes(plain, grouped):
+    """`plain`: a CacheNode class whose is_outdated / ahead_of / what_changed / set_up_to_date / edit / version / value are the
+    reference's (exact class, not subclasses); `grouped`: its GroupedParameters class (isinstance)."""
+    if plain not in _NODE_PLAIN:
+        _NODE_PLAIN.append(plain)
+    if grouped not in _NODE_GROUPED:
+        _NODE_GROUPED.append(grouped)
+    if _h is not None:
+        _h.node_setup(tuple(_NODE_PLAIN), tuple(_NODE_GROUPED), _empty_i64)
+
+
+def unregister_node_classes(plain, grouped):
+    if plain in _NODE_PLAIN:
+        _NODE_PLAIN.remove(plain)
+    if grouped in _NODE_GROUPED:
+        _NODE_GROUPED.remove(grouped)
+    if _h is not None:
+        _h.node_setup(tuple(_NODE_PLAIN), tuple(_NODE_GROUPED), _empty_i64)
+
+
+def _empty_i64(n):
+    return np.empty(n, dtype=np.int64)
+
+
+if _h is not None:
+    _h.node_setup((), (), _empty_i64)
+    node_outdated = _h.node_outdated
+    node_changed = _h.node_changed
+    node_commit = _h.node_commit
+else:
+    def node_outdated(cache):
+        return cache.is_outdated()
+
+    def node_changed(cache, key, caching=True):
+        return cache.what_changed(key, caching=caching)
+
+    def node_commit(cache):
+        cache.set_up_to_date()

@@ -150,15 +150,87 @@ def _send_counts(eng, slot, c, new, mirror, pending):
     return mirror, True
 
 
-def _send_source(eng, slot, new, mirror):
-    """Bring the slot's source to `new`; returns (mirror, rows op): a whole-array change goes up at once, a few changed rows are
-    handed back as (object indices, rows) for _bind_slot to send -- alone, or with the bind's other row uploads in one launch."""
+# ---- source lineage -----------------------------------------------------------------------------------------------------------
+# The source array is the largest thing a bind compares (N * F * C bytes: 400 KB at 1000 x 200 x 2, 35 us per compare, 1.3
+# compares per MCMC step -- tools/host_residual.py).  Almost every source the sampler binds is the child of one it bound a moment
+# ago: `sample_new = sample.copy()`, a few objects' rows edited, `update_feature_counts(sample, sample_new, features,
+# object_subset)` (operators.py:520-560, 796-851, 1724-1790).  That call's own contract says where the two samples differ: the
+# counts it maintains are only right if nothing outside `object_subset` changed (counts.py:55-95).  So every such call leaves a
+# note -- child token = parent token + these rows -- and a bind whose slot holds the parent, or a sibling (the previous, rejected
+# proposal), or the child (back to the current sample after a reject) compares just the noted rows instead of the whole array.
+# Tokens are (ndarray object, parameter version), the same identity the whole bind cache rests on; the notes hold the arrays,
+# so an id cannot be recycled while a note lives.  No note, or any other relation: the full compare, as before.
+_LINEAGE = []               # newest last: (child array, child version, parent array, parent version, int32 rows)
+_LINEAGE_KEPT = 6
+
+
+def _rows32(rows):
+    rows = np.asarray(rows)
+    if rows.dtype == np.bool_:
+        rows = np.flatnonzero(rows)
+    if rows.dtype != np.int32 or not rows.flags.c_contiguous or rows.ndim != 1:
+        rows = np.ascontiguousarray(rows.reshape(-1), dtype=np.int32)
+    return rows
+
+
+def note_source_lineage(parent_tok, child_tok, rows):
+    """content(child) == content(parent) outside `rows` (object indices).  Versioned tokens only."""
+    p_arr, p_ver = parent_tok
+    c_arr, c_ver = child_tok
+    if p_ver is None or c_ver is None or (p_arr is c_arr and p_ver == c_ver) or np.shape(p_arr) != np.shape(c_arr):
+        return None
+    rec = (c_arr, c_ver, p_arr, p_ver, _rows32(rows))
+    _LINEAGE.append(rec)
+    if len(_LINEAGE) > _LINEAGE_KEPT:
+        del _LINEAGE[0]
+    return rec
+
+
+def forget_source_lineage():
+    del _LINEAGE[:]
+
+
+def _lineage_of(arr, version):
+    for rec in reversed(_LINEAGE):
+        if rec[0] is arr and rec[1] == version:
+            return rec
+    return None
+
+
+def _source_candidates(arr, version, rec, known, slot_parent):
+    """The rows in which the source (arr, version) can differ from what the slot holds, as a tuple of one or two index arrays, or
+    None when nothing is known.  `known`: the entry's token of the slot's source (its content equals the mirror's); `rec`:
+    the lineage note of (arr, version); `slot_parent`: (parent array, parent version, rows) of the slot's source."""
+    if version is None or known is None or known[1] is None:
+        return None
+    s_arr, s_ver = known[0], known[1]
+    if rec is not None and rec[2] is s_arr and rec[3] == s_ver:
+        return (rec[4],)                                              # the slot holds the parent
+    if slot_parent is not None:
+        if slot_parent[0] is arr and slot_parent[1] == version:
+            return (slot_parent[2],)                                  # the slot holds a child of this one (back after a reject)
+        if rec is not None and rec[2] is slot_parent[0] and rec[3] == slot_parent[1]:
+            return (rec[4], slot_parent[2])                           # siblings: the previous proposal was rejected
+    return None
+
+
+def _send_source(eng, slot, tok, mirrors, known=None):
+    """Bring the slot's source to the parameter token `tok` = (array, version); returns (mirror, rows op): a whole-array change
+    goes up at once, a few changed rows are handed back as (object indices, rows) for _bind_slot to send -- alone, or with the
+    bind's other row uploads in one launch.  `mirrors`: the slot's mirror dictionary (its "source" entry is compared and
+    updated; "source_parent" follows the lineage); `known`: the bind entry's token of the source the slot holds, if any."""
+    new, version = tok
+    mirror = mirrors.get("source")
+    rec = _lineage_of(new, version) if version is not None else None
+    slot_parent = mirrors.get("source_parent")
+    mirrors["source_parent"] = (rec[2], rec[3], rec[4]) if rec is not None else None
+    cand = _source_candidates(new, version, rec, known, slot_parent)
     if type(new) is not _ndarray or new.dtype != np.bool_:
         new = np.asarray(new, dtype=bool)
     if mirror is None or mirror.shape != new.shape:
         eng.set_source(slot, new)
         return new.copy(), None
-    rows = _changed_rows(new, mirror)                # (the mirror now holds `new`)
+    rows = _changed_rows(new, mirror) if cand is None else _fast.diff_rows_among(new, mirror, *cand)   # (the mirror now holds `new`)
     if rows.size == 0:
         return mirror, None
     if 2 * rows.size > new.shape[0]:
@@ -321,7 +393,7 @@ def _bind_send(eng, slot, C, changed_sets, toks, new, mirrors, pending, cache, h
             new["stale"].update(by_rows)
     source_op = None
     if source_changed:
-        mirrors["source"], source_op = _send_source(eng, slot, source[0], mirrors["source"])
+        mirrors["source"], source_op = _send_source(eng, slot, source, mirrors, new["source"])
         new["source"] = _remember(source)
     if (groups_op is not None) + (rows_op is not None) + (source_op is not None) >= 2:
         eng.set_slot_delta(slot,
@@ -375,17 +447,41 @@ def counts_follow_plan(eng, sample, names, slot=0):
     return entry, mirrors, entry["stale"]
 
 
-def counts_followed(eng, plan, sample, names, touched, bounds, probs_rebuilt, source_rows=None, slot=0):
+def _source_followed(entry, mirrors, known, parent_tok, sample, rows):
+    """The slot's source rows `rows` were set to the sample's.  If the slot held `parent_tok` -- the source the sample's was derived
+    from by editing exactly those rows -- it now holds the sample's source: the entry says so (the next bind with a source has
+    nothing to compare), and the lineage is noted.  Otherwise the entry stays without a source token (content compare)."""
+    mirrors["source_parent"] = None
+    if parent_tok is None:
+        return
+    child = _token(sample.source)
+    rec = note_source_lineage(parent_tok, child, rows)
+    if known is None or known[1] is None or known[0] is not parent_tok[0] or known[1] != parent_tok[1]:
+        return
+    if rec is None:
+        if child[1] is not None and child[0] is parent_tok[0] and child[1] == parent_tok[1]:
+            entry["source"] = known                 # (the same parameter state: the rows that went up were its own)
+        return
+    entry["source"] = (child[0], child[1], None)
+    mirrors["source_parent"] = (rec[2], rec[3], rec[4])
+
+
+def counts_followed(eng, plan, sample, names, touched, bounds, probs_rebuilt, source_rows=None, slot=0, source_parent=None):
     """After that call and the host's own add_changes: the slot's entry (dropped by the engine method) comes back with the
     touched components' tokens and mirror rows brought to the sample's new counts; components whose probability rows were
     not rebuilt by the call join the stale set.  `source_rows` (object indices): the slot's source rows of those objects
-    were set to the sample's in the same call -- the mirror takes them, and the entry forgets which source parameter the
-    slot held, so the next bind with a source compares content with the mirror (and sends whatever else differs)."""
+    were set to the sample's in the same call -- the mirror takes them.  `source_parent`: the token (array, version) of the
+    source parameter the sample's source was derived from by editing those rows; when the slot held exactly that, it now holds
+    the sample's source and the entry records its token (_source_followed); otherwise the entry forgets which source
+    parameter the slot held, so the next bind with a source compares content with the mirror (and sends whatever differs)."""
     entry, mirrors, _ = plan
+    known = entry.get("source") if source_rows is not None else None
     if _fast._h is not None:                        # the same steps in one native call (csrc/sbe_pyhost.c: counts_followed)
         try:
             _fast._h.counts_followed(eng, entry, mirrors, [sample.feature_counts[name] for name in names], eng.group_offsets, touched, bounds,
                                      bool(probs_rebuilt), source_rows, sample.source.value if source_rows is not None else None, slot)
+            if source_rows is not None:
+                _source_followed(entry, mirrors, known, source_parent, sample, source_rows)
         except BaseException:                       # (half-updated mirrors must not come back into the cache)
             _forget_slot(eng, slot)
             raise
@@ -394,6 +490,7 @@ def counts_followed(eng, plan, sample, names, touched, bounds, probs_rebuilt, so
         src = sample.source.value
         mirrors["source"][source_rows] = src[source_rows] if src.dtype == np.bool_ else np.asarray(src[source_rows], dtype=bool)
         entry["source"] = None
+        _source_followed(entry, mirrors, known, source_parent, sample, source_rows)
     counts = sample.feature_counts
     off = eng.group_offsets
     for c, name in enumerate(names):

@@ -135,11 +135,14 @@ def update_feature_counts(sample_old, sample_new, features, object_subset):
             counts[name].add_changes(diff=new - old)
         return counts
     # a slot that holds the counts this difference is added to follows on the device, in the same call (binding.counts_follow_plan)
-    from .binding import counts_follow_plan, counts_followed
+    from .binding import _token, counts_follow_plan, counts_followed, note_source_lineage
+    src_parent = _token(sample_old.source)
     hold = _no_follow_from is not None and _no_follow_from() is sample_old
     plan = counts_follow_plan(eng, sample_new, names) if FOLLOW_COUNTS and not hold else None
     if plan is None:
         touched, rows = eng.counts_delta(objs, *ids)
+        # where the two samples' sources differ, for the binds to come (binding.py: source lineage): this call's own contract
+        note_source_lineage(src_parent, _token(sample_new.source), objs)
         return apply_count_rows(counts, names, off, touched, rows)
     # (the probability rows are rebuilt along when no table of the slot is stale: the touched components are not known yet)
     rebuild = not plan[2]
@@ -148,7 +151,9 @@ def update_feature_counts(sample_old, sample_new, features, object_subset):
     with_source = mirror_src is not None and mirror_src.shape == np.shape(src_new)
     touched, rows = eng.counts_delta(objs, *ids, follow_slot=0, update_probs=rebuild, update_source=with_source)
     bounds = apply_count_rows(counts, names, off, touched, rows, return_bounds=True)
-    counts_followed(eng, plan, sample_new, names, touched, bounds, rebuild, objs if with_source else None)
+    if not with_source:
+        note_source_lineage(src_parent, _token(sample_new.source), objs)
+    counts_followed(eng, plan, sample_new, names, touched, bounds, rebuild, objs if with_source else None, source_parent=src_parent)
     return counts
 
 

@@ -140,4 +140,33 @@ static inline int64_t sbeh_diff_rows(const void* rows, void* mirror, int64_t n_r
     return n;
 }
 
+/* The same for the rows listed in cand_a and cand_b only (row indices in any order, repeats allowed; cand_b may be NULL): the
+ * caller KNOWS every other row equals the mirror's (binding.py: source lineage).  Differing rows are copied into the mirror and
+ * returned in ascending order (a repeated index compares equal the second time); -1 on an index out of range. */
+static inline int64_t sbeh_diff_rows_among(const void* rows, void* mirror, int64_t n_rows, int64_t row_bytes, const int32_t* cand_a, int64_t na,
+                                           const int32_t* cand_b, int64_t nb, int32_t* changed_out) {
+    if (n_rows < 0 || row_bytes < 0 || n_rows > INT32_MAX || na < 0 || nb < 0) return -1;
+    if (n_rows == 0 || row_bytes == 0) return 0;
+    if (!rows || !mirror || !changed_out || (na && !cand_a) || (nb && !cand_b)) return -1;
+    int64_t n = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int32_t* cand = pass ? cand_b : cand_a;
+        const int64_t nc = pass ? nb : na;
+        for (int64_t i = 0; i < nc; ++i) {
+            const int64_t r = cand[i];
+            if (r < 0 || r >= n_rows) return -1;
+            const uint8_t* a = (const uint8_t*)rows + r * row_bytes;
+            uint8_t* b = (uint8_t*)mirror + r * row_bytes;
+            if (memcmp(a, b, (size_t)row_bytes) != 0) { memcpy(b, a, (size_t)row_bytes); changed_out[n++] = (int32_t)r; }
+        }
+    }
+    for (int64_t i = 1; i < n; ++i) {                     /* (a handful of rows: insertion sort) */
+        const int32_t v = changed_out[i];
+        int64_t j = i;
+        while (j > 0 && changed_out[j - 1] > v) { changed_out[j] = changed_out[j - 1]; --j; }
+        changed_out[j] = v;
+    }
+    return n;
+}
+
 #endif

@@ -109,6 +109,31 @@ static PyObject* py_diff_rows(PyObject* self, PyObject* args) {
     return PyLong_FromLongLong(rc);
 }
 
+/* diff_rows_among(new, mirror, cand_a, cand_b | None, idx_out) -> number of differing rows among the listed ones (copied into
+ * mirror, indices ascending in idx_out); -1 bad index, -2 not in ABI form */
+static PyObject* py_diff_rows_among(PyObject* self, PyObject* args) {
+    PyObject *a, *m, *ca, *cb, *idx;
+    if (!PyArg_ParseTuple(args, "OOOOO", &a, &m, &ca, &cb, &idx)) return NULL;
+    Py_buffer va, vm, vi, v1, v2;
+    long long rc = -2;
+    int have2 = 0;
+    if (PyObject_GetBuffer(a, &va, PyBUF_C_CONTIGUOUS) != 0) { PyErr_Clear(); return PyLong_FromLong(-2); }
+    if (PyObject_GetBuffer(m, &vm, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) { PyErr_Clear(); PyBuffer_Release(&va); return PyLong_FromLong(-2); }
+    if (PyObject_GetBuffer(idx, &vi, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) { PyErr_Clear(); PyBuffer_Release(&va); PyBuffer_Release(&vm); return PyLong_FromLong(-2); }
+    if (!get_c(ca, &v1, 1, 4, 0)) { PyBuffer_Release(&va); PyBuffer_Release(&vm); PyBuffer_Release(&vi); return PyLong_FromLong(-2); }
+    if (cb != Py_None) {
+        if (!get_c(cb, &v2, 1, 4, 0)) { PyBuffer_Release(&va); PyBuffer_Release(&vm); PyBuffer_Release(&vi); PyBuffer_Release(&v1); return PyLong_FromLong(-2); }
+        have2 = 1;
+    }
+    const Py_ssize_t na = v1.shape[0], nb = have2 ? v2.shape[0] : 0;
+    if (va.ndim >= 1 && va.len == vm.len && va.shape[0] > 0 && vi.itemsize == 4 && vi.len >= 4 * (na + nb))
+        rc = sbeh_diff_rows_among(va.buf, vm.buf, (int64_t)va.shape[0], (int64_t)(va.len / va.shape[0]), (const int32_t*)v1.buf, (int64_t)na,
+                                  have2 ? (const int32_t*)v2.buf : NULL, (int64_t)nb, (int32_t*)vi.buf);
+    PyBuffer_Release(&va); PyBuffer_Release(&vm); PyBuffer_Release(&vi); PyBuffer_Release(&v1);
+    if (have2) PyBuffer_Release(&v2);
+    return PyLong_FromLongLong(rc);
+}
+
 /* touched_groups(gid_old, gid_new, n_groups_total, touched_out) -> n_touched, -1 bad index, -2 not in ABI form */
 static PyObject* py_touched_groups(PyObject* self, PyObject* args) {
     PyObject *go, *gn, *out;
@@ -737,8 +762,8 @@ static PyObject* py_bind_slot(PyObject* self, PyObject* args, PyObject* kwargs) 
         /* source */
         PyObject* source_op = NULL;                                             /* (rows, new[rows]) or None */
         if (with_source && ((changed >> (at + 1)) & 1)) {
-            PyObject* ms = PyDict_GetItem(mirrors, k_source);
-            PyObject* r = OWN(PyObject_CallFunctionObjArgs(g_send_source, eng, slot, PyTuple_GET_ITEM(tokens[at + 1], 0), ms ? ms : Py_None, NULL));
+            PyObject* os = PyDict_GetItem(old, k_source);                       /* what the mirror's content is known to equal, or None */
+            PyObject* r = OWN(PyObject_CallFunctionObjArgs(g_send_source, eng, slot, tokens[at + 1], mirrors, os ? os : Py_None, NULL));
             if (!r) goto out;
             if (!PyTuple_Check(r) || PyTuple_GET_SIZE(r) != 2) { PyErr_SetString(PyExc_TypeError, "_send_source must return a pair"); goto out; }
             if (PyDict_SetItem(mirrors, k_source, PyTuple_GET_ITEM(r, 0)) != 0) goto out;
@@ -907,17 +932,429 @@ static PyObject* py_counts_followed(PyObject* self, PyObject* args) {
     Py_RETURN_NONE;
 }
 
+/* ---- the CacheNode protocol of the reference's sample cache (sbayes/sampling/state.py:215-321) in native code --------------------------
+ * Every cached quantity of a step goes through it -- is_outdated(), what_changed(), edit() / set_up_to_date() -- ten is_outdated, four
+ * what_changed and six set_up_to_date calls per MCMC step, 2-8 us each where they run (cold interpreter paths between 400 KB
+ * NumPy operations: tools/host_residual.py).  The functions below do exactly what those methods do, attribute by attribute, for
+ * nodes whose class is one of the REGISTERED ones (node_setup: the reference's CacheNode when its methods' source digests are the
+ * mirrored ones -- sbayes_amd/patch.py -- and sbayes_amd.state.CacheNode); for any other node they call the node's own method. */
+static PyObject *g_plain_nodes = NULL, *g_grouped = NULL, *g_empty_i64 = NULL;
+static PyObject *s_inputs, *s_input_idx, *s_cached_version, *s_cached_group_versions, *s_copy, *s_is_outdated, *s_what_changed,
+                *s_set_up_to_date, *s_ahead_of, *s_cache, *s_group_likelihoods, *s_sum, *s_any_dynamic_priors, *s_n_groups, *s_caching,
+                *k_universal_counts, *k_counts_key, *k_weights_key, *k_source_key;
+
+static PyObject* py_node_setup(PyObject* self, PyObject* args) {
+    PyObject *plain, *grouped, *empty;
+    if (!PyArg_ParseTuple(args, "O!O!O", &PyTuple_Type, &plain, &PyTuple_Type, &grouped, &empty)) return NULL;
+    Py_XDECREF(g_plain_nodes); Py_XDECREF(g_grouped); Py_XDECREF(g_empty_i64);
+    Py_INCREF(plain); Py_INCREF(grouped); Py_INCREF(empty);
+    g_plain_nodes = plain; g_grouped = grouped; g_empty_i64 = empty;
+    Py_RETURN_NONE;
+}
+
+static int node_is_plain(PyObject* cache) {
+    if (!g_plain_nodes) return 0;
+    for (Py_ssize_t i = 0; i < PyTuple_GET_SIZE(g_plain_nodes); ++i)
+        if ((PyObject*)Py_TYPE(cache) == PyTuple_GET_ITEM(g_plain_nodes, i)) return 1;
+    return 0;
+}
+
+/* tuple(inpt.version for inpt in cache.inputs.values())  (state.py:294-297); new reference */
+static PyObject* node_version(PyObject* cache) {
+    PyObject* inputs = PyObject_GetAttr(cache, s_inputs);
+    if (!inputs) return NULL;
+    const Py_ssize_t n = PyObject_Length(inputs);
+    PyObject* it = n >= 0 ? PyObject_GetIter(inputs) : NULL;
+    PyObject* tup = it ? PyTuple_New(n) : NULL;
+    Py_ssize_t i = 0;
+    int ok = tup != NULL;
+    PyObject* key;
+    while (ok && (key = PyIter_Next(it)) != NULL) {
+        PyObject* inpt = PyObject_GetItem(inputs, key);
+        Py_DECREF(key);
+        PyObject* v = inpt ? PyObject_GetAttr(inpt, s_version) : NULL;
+        Py_XDECREF(inpt);
+        if (!v || i >= n) { Py_XDECREF(v); ok = 0; break; }
+        PyTuple_SET_ITEM(tup, i++, v);
+    }
+    if (ok && (PyErr_Occurred() || i != n)) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_RuntimeError, "cache node inputs changed size"); ok = 0; }
+    Py_XDECREF(it); Py_DECREF(inputs);
+    if (!ok) { Py_XDECREF(tup); return NULL; }
+    return tup;
+}
+
+/* cache.is_outdated()  (state.py:232-233): 1 / 0 / -1 */
+static int node_outdated(PyObject* cache) {
+    if (!node_is_plain(cache)) {
+        PyObject* r = PyObject_CallMethodNoArgs(cache, s_is_outdated);
+        if (!r) return -1;
+        const int b = PyObject_IsTrue(r);
+        Py_DECREF(r);
+        return b;
+    }
+    PyObject* ver = node_version(cache);
+    PyObject* cv = ver ? PyObject_GetAttr(cache, s_cached_version) : NULL;
+    const int b = cv ? PyObject_RichCompareBool(cv, ver, Py_NE) : -1;
+    Py_XDECREF(ver); Py_XDECREF(cv);
+    return b;
+}
+
+/* cache.ahead_of(key)  (state.py:235-237) */
+static int node_ahead_of(PyObject* cache, PyObject* key) {
+    if (!node_is_plain(cache)) {
+        PyObject* r = PyObject_CallMethodOneArg(cache, s_ahead_of, key);
+        if (!r) return -1;
+        const int b = PyObject_IsTrue(r);
+        Py_DECREF(r);
+        return b;
+    }
+    int b = -1;
+    PyObject* idx = PyObject_GetAttr(cache, s_input_idx);
+    PyObject* i = idx ? PyObject_GetItem(idx, key) : NULL;
+    PyObject* cv = i ? PyObject_GetAttr(cache, s_cached_version) : NULL;
+    PyObject* cvi = cv ? PyObject_GetItem(cv, i) : NULL;
+    PyObject* inputs = cvi ? PyObject_GetAttr(cache, s_inputs) : NULL;
+    PyObject* inpt = inputs ? PyObject_GetItem(inputs, key) : NULL;
+    PyObject* v = inpt ? PyObject_GetAttr(inpt, s_version) : NULL;
+    if (v) b = PyObject_RichCompareBool(cvi, v, Py_NE);
+    Py_XDECREF(idx); Py_XDECREF(i); Py_XDECREF(cv); Py_XDECREF(cvi); Py_XDECREF(inputs); Py_XDECREF(inpt); Py_XDECREF(v);
+    return b;
+}
+
+/* cache.set_up_to_date()  (state.py:265-270): 0 / -1 */
+static int node_commit(PyObject* cache) {
+    if (!node_is_plain(cache)) {
+        PyObject* r = PyObject_CallMethodNoArgs(cache, s_set_up_to_date);
+        if (!r) return -1;
+        Py_DECREF(r);
+        return 0;
+    }
+    PyObject* ver = node_version(cache);
+    if (!ver || PyObject_SetAttr(cache, s_cached_version, ver) != 0) { Py_XDECREF(ver); return -1; }
+    Py_DECREF(ver);
+    PyObject* inputs = PyObject_GetAttr(cache, s_inputs);
+    PyObject* cgv = inputs ? PyObject_GetAttr(cache, s_cached_group_versions) : NULL;
+    PyObject* it = cgv ? PyObject_GetIter(inputs) : NULL;
+    int ok = it != NULL;
+    PyObject* key;
+    while (ok && (key = PyIter_Next(it)) != NULL) {
+        PyObject* inpt = PyObject_GetItem(inputs, key);
+        const int grouped = inpt ? PyObject_IsInstance(inpt, g_grouped) : -1;
+        if (grouped < 0) ok = 0;
+        else if (grouped) {
+            PyObject* gv = PyObject_GetAttr(inpt, s_group_versions);
+            PyObject* stamp = gv ? PyObject_CallMethodNoArgs(gv, s_copy) : NULL;
+            PyObject* flags = stamp ? PyObject_GetAttr(stamp, s_flags) : NULL;
+            if (!flags || PyObject_SetAttr(flags, s_writeable, Py_False) != 0 || PyObject_SetItem(cgv, key, stamp) != 0) ok = 0;
+            Py_XDECREF(gv); Py_XDECREF(stamp); Py_XDECREF(flags);
+        }
+        Py_XDECREF(inpt); Py_DECREF(key);
+    }
+    if (ok && PyErr_Occurred()) ok = 0;
+    Py_XDECREF(it); Py_XDECREF(cgv); Py_XDECREF(inputs);
+    return ok ? 0 : -1;
+}
+
+/* cache.what_changed(key, caching)  (state.py:239-254) as a malloc'ed ascending index list: 0 ok (*idx, *n; caller frees), -1 error.
+   Nodes of another class, and group-version arrays that are not two equal-length one-dimensional arrays of one 8-byte type, go
+   through the node's own method (its result read through the buffer protocol). */
+static int node_changed(PyObject* cache, PyObject* key, int caching, long long** idx_out, Py_ssize_t* n_out) {
+    *idx_out = NULL; *n_out = 0;
+    int form = 0;                                          /* 1: handled natively */
+    if (node_is_plain(cache)) {
+        PyObject* inputs = PyObject_GetAttr(cache, s_inputs);
+        PyObject* inpt = inputs ? PyObject_GetItem(inputs, key) : NULL;
+        Py_XDECREF(inputs);
+        if (!inpt) return -1;
+        const int grouped = PyObject_IsInstance(inpt, g_grouped);
+        if (grouped < 0) { Py_DECREF(inpt); return -1; }
+        if (!grouped) { Py_DECREF(inpt); PyErr_SetString(PyExc_ValueError, "Can only track what changed for GroupedParameters"); return -1; }
+        if (!caching) {
+            PyObject* ng = PyObject_GetAttr(inpt, s_n_groups);
+            Py_DECREF(inpt);
+            if (!ng) return -1;
+            const Py_ssize_t n = PyLong_AsSsize_t(ng);
+            Py_DECREF(ng);
+            if (n < 0) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "n_groups"); return -1; }
+            long long* idx = (long long*)malloc((size_t)(n ? n : 1) * sizeof(long long));
+            if (!idx) { PyErr_NoMemory(); return -1; }
+            for (Py_ssize_t i = 0; i < n; ++i) idx[i] = i;
+            *idx_out = idx; *n_out = n;
+            return 0;
+        }
+        PyObject* gv = PyObject_GetAttr(inpt, s_group_versions);
+        Py_DECREF(inpt);
+        PyObject* cgvs = gv ? PyObject_GetAttr(cache, s_cached_group_versions) : NULL;
+        PyObject* cgv = cgvs ? PyObject_GetItem(cgvs, key) : NULL;
+        Py_XDECREF(cgvs);
+        if (!cgv) { Py_XDECREF(gv); return -1; }
+        Py_buffer a, b;
+        if (PyObject_GetBuffer(cgv, &a, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) == 0) {
+            if (PyObject_GetBuffer(gv, &b, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) == 0) {
+                const char fa = a.format ? a.format[strlen(a.format) ? strlen(a.format) - 1 : 0] : 0, fb = b.format ? b.format[strlen(b.format) ? strlen(b.format) - 1 : 0] : 0;
+                if (a.ndim == 1 && b.ndim == 1 && a.itemsize == 8 && b.itemsize == 8 && a.shape[0] == b.shape[0] && fa == fb && (fa == 'd' || fa == 'l' || fa == 'q')) {
+                    const Py_ssize_t n = a.shape[0];
+                    long long* idx = (long long*)malloc((size_t)(n ? n : 1) * sizeof(long long));
+                    if (!idx) { PyBuffer_Release(&a); PyBuffer_Release(&b); Py_DECREF(gv); Py_DECREF(cgv); PyErr_NoMemory(); return -1; }
+                    Py_ssize_t k = 0;
+                    if (fa == 'd') { const double *x = (const double*)a.buf, *y = (const double*)b.buf; for (Py_ssize_t i = 0; i < n; ++i) if (x[i] != y[i]) idx[k++] = i; }
+                    else { const long long *x = (const long long*)a.buf, *y = (const long long*)b.buf; for (Py_ssize_t i = 0; i < n; ++i) if (x[i] != y[i]) idx[k++] = i; }
+                    *idx_out = idx; *n_out = k;
+                    form = 1;
+                }
+                PyBuffer_Release(&b);
+            } else PyErr_Clear();
+            PyBuffer_Release(&a);
+        } else PyErr_Clear();
+        Py_DECREF(gv); Py_DECREF(cgv);
+        if (form) return 0;
+    }
+    /* the node's own method */
+    PyObject* meth = PyObject_GetAttr(cache, s_what_changed);
+    PyObject* pos = meth ? PyTuple_Pack(1, key) : NULL;
+    PyObject* kw = pos ? PyDict_New() : NULL;
+    PyObject* res = NULL;
+    if (kw && PyDict_SetItem(kw, s_caching, caching ? Py_True : Py_False) == 0) res = PyObject_Call(meth, pos, kw);
+    Py_XDECREF(meth); Py_XDECREF(pos); Py_XDECREF(kw);
+    if (!res) return -1;
+    Py_buffer r;
+    int rc = -1;
+    if (PyObject_GetBuffer(res, &r, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) == 0) {
+        const char fr = r.format ? r.format[strlen(r.format) ? strlen(r.format) - 1 : 0] : 0;
+        if (r.ndim == 1 && r.itemsize == 8 && (fr == 'l' || fr == 'q' || fr == 'L' || fr == 'Q')) {
+            const Py_ssize_t n = r.shape[0];
+            long long* idx = (long long*)malloc((size_t)(n ? n : 1) * sizeof(long long));
+            if (idx) { memcpy(idx, r.buf, (size_t)n * sizeof(long long)); *idx_out = idx; *n_out = n; rc = 0; } else PyErr_NoMemory();
+        } else PyErr_SetString(PyExc_TypeError, "what_changed() did not return a one-dimensional int64 array");
+        PyBuffer_Release(&r);
+    }
+    Py_DECREF(res);
+    return rc;
+}
+
+static PyObject* py_node_outdated(PyObject* self, PyObject* cache) {
+    const int b = node_outdated(cache);
+    if (b < 0) return NULL;
+    return PyBool_FromLong(b);
+}
+
+static PyObject* py_node_commit(PyObject* self, PyObject* cache) {
+    if (node_commit(cache) != 0) return NULL;
+    Py_RETURN_NONE;
+}
+
+/* node_changed(cache, key, caching) -> int64 ndarray: cache.what_changed(key, caching=caching) for ONE key */
+static PyObject* py_node_changed(PyObject* self, PyObject* args) {
+    PyObject *cache, *key;
+    int caching = 1;
+    if (!PyArg_ParseTuple(args, "OO|p", &cache, &key, &caching)) return NULL;
+    if (!g_empty_i64) { PyErr_SetString(PyExc_RuntimeError, "node_setup() not called"); return NULL; }
+    long long* idx; Py_ssize_t n;
+    if (node_changed(cache, key, caching, &idx, &n) != 0) return NULL;
+    PyObject* nn = PyLong_FromSsize_t(n);
+    PyObject* out = nn ? PyObject_CallOneArg(g_empty_i64, nn) : NULL;
+    Py_XDECREF(nn);
+    if (out && n > 0) {
+        Py_buffer v;
+        if (PyObject_GetBuffer(out, &v, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) { Py_CLEAR(out); }
+        else {
+            if (v.len == n * (Py_ssize_t)sizeof(long long)) memcpy(v.buf, idx, (size_t)v.len);
+            else { PyErr_SetString(PyExc_TypeError, "node_setup: empty_i64(n) must return n int64 items"); Py_CLEAR(out); }
+            PyBuffer_Release(&v);
+        }
+    }
+    free(idx);
+    return out;
+}
+
+/* a one-dimensional C-contiguous float64 buffer; 0 on mismatch (no exception left) */
+static int get_f64_1d(PyObject* obj, Py_buffer* v, int writable) {
+    if (PyObject_GetBuffer(obj, v, (writable ? PyBUF_WRITABLE : 0) | PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) { PyErr_Clear(); return 0; }
+    const char f = v->format ? v->format[strlen(v->format) ? strlen(v->format) - 1 : 0] : 0;
+    if (v->ndim != 1 || v->itemsize != 8 || f != 'd') { PyBuffer_Release(v); return 0; }
+    return 1;
+}
+
+/* ---- Likelihood.__call__ (sbayes/model/likelihood.py:47-101), caching path ------------------------------------------------------------
+ * likelihood_call(lik, sample, names, off, all_fn) -> the log-likelihood | NotImplemented | None
+ * Component after component exactly what compute_lh_clusters / compute_lh_confounder do (sbayes_amd/likelihood.py, the reference's
+ * :65-101): the cached sum when the node is current; else  lh = cache.value;  changed = what_changed("counts", caching=not
+ * (conf_prior.any_dynamic_priors and cache.ahead_of("universal_counts")));  lh[changed] = values;  set_up_to_date();  sum.  The
+ * values of ALL components come from `all_fn(sample)` (one bind, one device call: Likelihood._all_group_logliks), asked at the
+ * first component that has a changed group.  NotImplemented (nothing touched): a node of an unregistered class or a value array
+ * that is not a plain float64 vector -- the Python form serves the call.  None: all_fn returned None (groups that overlap have no
+ * resident form); nodes visited so far are left current or untouched, the Python form starts over and arrives at the same
+ * state. */
+static PyObject* py_likelihood_call(PyObject* self, PyObject* args) {
+    PyObject *lik, *sample, *names, *off, *all_fn;
+    if (!PyArg_ParseTuple(args, "OOO!OO", &lik, &sample, &PyList_Type, &names, &off, &all_fn)) return NULL;
+    const Py_ssize_t C = PyList_GET_SIZE(names);
+    if (C < 1 || C > BIND_MAXC || !g_plain_nodes) Py_RETURN_NOTIMPLEMENTED;
+    PyObject* nodes[BIND_MAXC];
+    PyObject* result = NULL;
+    PyObject *sc = NULL, *gl = NULL, *lh_all = NULL, *total = NULL, *conf_priors = NULL;
+    Py_buffer vo, vall;
+    int have_off = 0, have_all = 0;
+    Py_ssize_t n_nodes = 0;
+    sc = PyObject_GetAttr(sample, s_cache);
+    gl = sc ? PyObject_GetAttr(sc, s_group_likelihoods) : NULL;
+    if (!gl) goto done;
+    for (Py_ssize_t c = 0; c < C; ++c) {
+        PyObject* node = PyObject_GetItem(gl, PyList_GET_ITEM(names, c));
+        if (!node) goto done;
+        nodes[n_nodes++] = node;
+        int ok = node_is_plain(node);
+        if (ok) {
+            PyObject* val = PyObject_GetAttr(node, s_value);
+            if (!val) goto done;
+            Py_buffer v;
+            ok = get_f64_1d(val, &v, 1);
+            if (ok) PyBuffer_Release(&v);
+            Py_DECREF(val);
+        }
+        if (!ok) { result = Py_NotImplemented; Py_INCREF(result); goto done; }
+    }
+    if (PyObject_GetBuffer(off, &vo, PyBUF_C_CONTIGUOUS) != 0) goto done;
+    have_off = 1;
+    if (vo.ndim != 1 || vo.shape[0] < C + 1 || (vo.itemsize != 8 && vo.itemsize != 4)) { result = Py_NotImplemented; Py_INCREF(result); goto done; }
+    total = PyFloat_FromDouble(0.0);
+    if (!total) goto done;
+    for (Py_ssize_t c = 0; c < C; ++c) {
+        PyObject* cache = nodes[c];
+        const int outdated = node_outdated(cache);
+        if (outdated < 0) goto done;
+        if (outdated) {
+            int caching = 1;
+            if (c > 0) {
+                if (!conf_priors) {
+                    PyObject* prior = PyObject_GetAttr(lik, s_prior);
+                    conf_priors = prior ? PyObject_GetAttr(prior, s_prior_confounding_effects) : NULL;
+                    Py_XDECREF(prior);
+                    if (!conf_priors) goto done;
+                }
+                PyObject* cp = PyObject_GetItem(conf_priors, PyList_GET_ITEM(names, c));
+                PyObject* dyn = cp ? PyObject_GetAttr(cp, s_any_dynamic_priors) : NULL;
+                Py_XDECREF(cp);
+                if (!dyn) goto done;
+                const int is_dyn = PyObject_IsTrue(dyn);
+                Py_DECREF(dyn);
+                if (is_dyn < 0) goto done;
+                if (is_dyn) {
+                    const int ahead = node_ahead_of(cache, k_universal_counts);
+                    if (ahead < 0) goto done;
+                    if (ahead) caching = 0;
+                }
+            }
+            long long* idx; Py_ssize_t n;
+            if (node_changed(cache, k_counts_key, caching, &idx, &n) != 0) goto done;
+            if (n > 0) {
+                if (!lh_all) {
+                    lh_all = PyObject_CallOneArg(all_fn, sample);
+                    if (!lh_all) { free(idx); goto done; }
+                    if (lh_all == Py_None) { free(idx); result = Py_None; Py_INCREF(result); goto done; }
+                    if (!get_f64_1d(lh_all, &vall, 0)) { free(idx); PyErr_SetString(PyExc_TypeError, "likelihood_call: all_fn must return a float64 vector"); goto done; }
+                    have_all = 1;
+                }
+                PyObject* val = PyObject_GetAttr(cache, s_value);
+                Py_buffer v;
+                if (!val || !get_f64_1d(val, &v, 1)) { Py_XDECREF(val); free(idx); if (!PyErr_Occurred()) PyErr_SetString(PyExc_TypeError, "likelihood_call: the node's value changed form"); goto done; }
+                long long o = 0; off_at(&vo, c, &o);
+                int bad = 0;
+                for (Py_ssize_t i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= v.shape[0] || o + idx[i] < 0 || o + idx[i] >= vall.shape[0]) bad = 1;
+                if (!bad) for (Py_ssize_t i = 0; i < n; ++i) ((double*)v.buf)[idx[i]] = ((const double*)vall.buf)[o + idx[i]];
+                PyBuffer_Release(&v); Py_DECREF(val);
+                if (bad) { free(idx); PyErr_SetString(PyExc_IndexError, "likelihood_call: group index out of range"); goto done; }
+            }
+            free(idx);
+            if (node_commit(cache) != 0) goto done;
+        }
+        PyObject* val = PyObject_GetAttr(cache, s_value);
+        PyObject* s = val ? PyObject_CallMethodNoArgs(val, s_sum) : NULL;
+        Py_XDECREF(val);
+        if (!s) goto done;
+        PyObject* t2 = PyNumber_InPlaceAdd(total, s);
+        Py_DECREF(s);
+        if (!t2) goto done;
+        Py_DECREF(total);
+        total = t2;
+    }
+    result = total; total = NULL;
+done:
+    for (Py_ssize_t i = 0; i < n_nodes; ++i) Py_DECREF(nodes[i]);
+    if (have_off) PyBuffer_Release(&vo);
+    if (have_all) PyBuffer_Release(&vall);
+    Py_XDECREF(sc); Py_XDECREF(gl); Py_XDECREF(lh_all); Py_XDECREF(total); Py_XDECREF(conf_priors);
+    return result;
+}
+
+/* ---- SourcePrior.__call__'s cache update (sbayes/model/prior.py:596-609) -----------------------------------------------------------------
+ * store_per_object(cache, n_objects, values, caching) -> None | NotImplemented
+ *   per_object = cache.value
+ *   if cache.ahead_of("weights"): per_object[:] = values           (the reference's changed = arange(n_objects))
+ *   else: changed = cache.what_changed("source", caching); per_object[changed] = values[changed]
+ *   cache.set_up_to_date()
+ * `values`: a float64 vector [n_objects], or a callable returning one -- called only when something is listed, like the
+ * reference computes its values only then.  NotImplemented (nothing touched): an unregistered node class or a value that is not a
+ * plain float64 vector. */
+static PyObject* py_store_per_object(PyObject* self, PyObject* args) {
+    PyObject *cache, *values;
+    Py_ssize_t n_objects;
+    int caching = 1;
+    if (!PyArg_ParseTuple(args, "OnO|p", &cache, &n_objects, &values, &caching)) return NULL;
+    if (!node_is_plain(cache)) Py_RETURN_NOTIMPLEMENTED;
+    PyObject* val = PyObject_GetAttr(cache, s_value);
+    if (!val) return NULL;
+    Py_buffer v;
+    if (!get_f64_1d(val, &v, 1)) { Py_DECREF(val); Py_RETURN_NOTIMPLEMENTED; }
+    PyObject* result = NULL;
+    PyObject* got = NULL;
+    long long* idx = NULL; Py_ssize_t n = 0;
+    int all = node_ahead_of(cache, k_weights_key);
+    if (all < 0) goto done;
+    if (all) n = n_objects;
+    else if (node_changed(cache, k_source_key, caching, &idx, &n) != 0) goto done;
+    if (n > 0) {
+        if (PyCallable_Check(values)) { got = PyObject_CallNoArgs(values); if (!got) goto done; }
+        else { got = values; Py_INCREF(got); }
+        Py_buffer w;
+        if (!get_f64_1d(got, &w, 0)) { PyErr_SetString(PyExc_TypeError, "store_per_object: values must be a float64 vector"); goto done; }
+        int bad = 0;
+        if (all) {
+            if (w.shape[0] != v.shape[0] || n_objects != v.shape[0]) bad = 1;
+            else memcpy(v.buf, w.buf, (size_t)v.len);
+        } else {
+            for (Py_ssize_t i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= v.shape[0] || idx[i] >= w.shape[0]) bad = 1;
+            if (!bad) for (Py_ssize_t i = 0; i < n; ++i) ((double*)v.buf)[idx[i]] = ((const double*)w.buf)[idx[i]];
+        }
+        PyBuffer_Release(&w);
+        if (bad) { PyErr_SetString(PyExc_IndexError, "store_per_object: values and the cached vector differ in length"); goto done; }
+    }
+    if (node_commit(cache) != 0) goto done;
+    result = Py_None; Py_INCREF(result);
+done:
+    free(idx);
+    PyBuffer_Release(&v); Py_DECREF(val); Py_XDECREF(got);
+    return result;
+}
+
 static PyMethodDef methods[] = {
     {"scan_setup", py_scan_setup, METH_VARARGS, "scan_setup(ndarray_type, asarray, content_equal)"},
     {"scan", py_scan, METH_VARARGS, "scan(params, cached) -> (tokens, changed bitmask): the bind cache's token comparison"},
     {"addr", py_addr, METH_O, "buffer address of an array (any strides), as int"},
     {"subset_ids", py_subset_ids, METH_VARARGS, "ids of the listed objects for sbe_counts_delta (sbeh_subset_ids)"},
     {"diff_rows", py_diff_rows, METH_VARARGS, "rows of `new` differing from `mirror`, copied into it (sbeh_diff_rows)"},
+    {"diff_rows_among", py_diff_rows_among, METH_VARARGS, "the listed rows of `new` differing from `mirror`, copied into it (sbeh_diff_rows_among)"},
     {"touched_groups", py_touched_groups, METH_VARARGS, "sorted distinct group indices among two id arrays (sbeh_touched_groups)"},
     {"bind_setup", py_bind_setup, METH_VARARGS, "bind_setup(_send_counts, _send_source, _remember, concatenate, rows_with_probs, python_bind_slot)"},
     {"bind_slot", (PyCFunction)(void (*)(void))py_bind_slot, METH_VARARGS | METH_KEYWORDS, "bind_slot(eng, model, sample, slot, with_source=False) -> stale set (binding._bind_slot in C)"},
     {"counts_followed", py_counts_followed, METH_VARARGS, "binding.counts_followed in C (mirrors and tokens follow the sample after a follow-slot call)"},
     {"add_rows_many", py_add_rows_many, METH_VARARGS, "FeatureCounts.add_changes of every component for a difference given as rows -> bounds | None"},
+    {"node_setup", py_node_setup, METH_VARARGS, "node_setup(plain CacheNode classes, GroupedParameters classes, empty_i64)"},
+    {"node_outdated", py_node_outdated, METH_O, "cache.is_outdated()"},
+    {"node_commit", py_node_commit, METH_O, "cache.set_up_to_date()"},
+    {"node_changed", py_node_changed, METH_VARARGS, "cache.what_changed(key, caching=True) for one key -> int64 ndarray"},
+    {"likelihood_call", py_likelihood_call, METH_VARARGS, "Likelihood.__call__'s caching path: likelihood_call(lik, sample, names, off, all_fn)"},
+    {"store_per_object", py_store_per_object, METH_VARARGS, "SourcePrior.__call__'s cache update: store_per_object(cache, n_objects, values, caching=True)"},
     {"copy_rows", py_copy_rows, METH_VARARGS, "dst[idx] = src[idx] (rows of two same-shaped C-contiguous arrays)"},
     {NULL, NULL, 0, NULL}};
 
@@ -965,6 +1402,28 @@ PyMODINIT_FUNC PyInit__sbe_pyhost(void) {
     s_resolve_sharing = PyUnicode_InternFromString("resolve_sharing");
     s__value = PyUnicode_InternFromString("_value");
     s_group_versions = PyUnicode_InternFromString("group_versions");
+    s_inputs = PyUnicode_InternFromString("inputs");
+    s_input_idx = PyUnicode_InternFromString("input_idx");
+    s_cached_version = PyUnicode_InternFromString("cached_version");
+    s_cached_group_versions = PyUnicode_InternFromString("cached_group_versions");
+    s_copy = PyUnicode_InternFromString("copy");
+    s_is_outdated = PyUnicode_InternFromString("is_outdated");
+    s_what_changed = PyUnicode_InternFromString("what_changed");
+    s_set_up_to_date = PyUnicode_InternFromString("set_up_to_date");
+    s_ahead_of = PyUnicode_InternFromString("ahead_of");
+    s_cache = PyUnicode_InternFromString("cache");
+    s_group_likelihoods = PyUnicode_InternFromString("group_likelihoods");
+    s_sum = PyUnicode_InternFromString("sum");
+    s_any_dynamic_priors = PyUnicode_InternFromString("any_dynamic_priors");
+    s_n_groups = PyUnicode_InternFromString("n_groups");
+    s_caching = PyUnicode_InternFromString("caching");
+    k_universal_counts = PyUnicode_InternFromString("universal_counts");
+    k_counts_key = PyUnicode_InternFromString("counts");
+    k_weights_key = PyUnicode_InternFromString("weights");
+    k_source_key = PyUnicode_InternFromString("source");
+    if (!s_inputs || !s_input_idx || !s_cached_version || !s_cached_group_versions || !s_copy || !s_is_outdated || !s_what_changed || !s_set_up_to_date ||
+        !s_ahead_of || !s_cache || !s_group_likelihoods || !s_sum || !s_any_dynamic_priors || !s_n_groups || !s_caching || !k_universal_counts || !k_counts_key ||
+        !k_weights_key || !k_source_key) return NULL;
     if (!s_value || !s_version || !s_flags || !s_writeable || !s_owndata || !s_shared || !s_resolve_sharing || !s__value || !s_group_versions) return NULL;
     return PyModule_Create(&moduledef);
 }

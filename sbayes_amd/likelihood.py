@@ -19,7 +19,7 @@ from types import SimpleNamespace
 import numpy as np
 
 from .counts import forget_jump_state, recalculate_feature_counts
-from . import registry
+from . import _fast, registry
 from .binding import _bind_slot
 from .engine import GroupOverlapError
 from .registry import get_engine
@@ -70,6 +70,7 @@ class Likelihood:
         state["_na_features"] = None
         state["_engine"] = None
         state["_call_memo"] = None
+        state["_fast_call"] = None
         state["_sbayes_amd_patch"] = patch.installed()      # how the pickling process had sBayes patched, if at all
         return state
 
@@ -109,6 +110,18 @@ class Likelihood:
         return self._na_features
 
     def __call__(self, sample, caching=True) -> float:
+        if caching and _fast._h is not None:
+            # the whole caching path in one native call (csrc/sbe_pyhost.c: likelihood_call -- the cache-node protocol of
+            # compute_lh_clusters / compute_lh_confounder below, component after component, same order, same sums); the values
+            # come from _all_group_logliks.  NotImplemented: a node form it does not serve; None: overlapping groups -- the
+            # Python form below serves the call (nothing it would do differently has been done)
+            fast = self.__dict__.get("_fast_call")
+            if fast is None:
+                fast = self._fast_call = (["clusters", *self.confounders], self._all_group_logliks)
+            forget_jump_state()
+            res = _fast._h.likelihood_call(self, sample, fast[0], self.engine.group_offsets, fast[1])
+            if res is not NotImplemented and res is not None:
+                return res
         if not caching:
             recalculate_feature_counts(self.features, sample)
         # one bind and one fetch per call: the components are asked one after another (likelihood.py:58-63) for the SAME
@@ -124,6 +137,29 @@ class Likelihood:
         finally:
             self._call_memo = None
 
+    def _all_group_logliks(self, sample, slot=0):
+        """float64 [sum of G_c]: the collapsed log-likelihood of every group of every component of `sample`, inside a caching
+        Likelihood.__call__ (native form) -- one bind, one device call, the source prior the prior is about to ask for taken along
+        (see _group_logliks, which this is the first-request part of); None when the groups overlap (no resident form)."""
+        eng = self.engine
+        sp_cache = conditionals.source_prior_wanted(self.prior, sample)
+        try:
+            _bind_slot(eng, self._bind_model, sample, slot, with_source=sp_cache is not None)
+        except GroupOverlapError:
+            return None
+        bound = getattr(eng, "_bound", None)
+        entry = bound.get(slot) if bound is not None else None
+        lh_all = entry.get("lh_all") if entry is not None else None
+        if lh_all is None:
+            if sp_cache is not None:
+                lh_all, per_object = eng.collapsed_and_source_prior(slot)
+                conditionals.store_source_prior_ahead(sp_cache, sample, per_object)
+            else:
+                lh_all = eng.collapsed_loglik_all(slot)
+            if entry is not None:
+                entry["lh_all"] = lh_all
+        return lh_all
+
     def _group_logliks(self, sample, component, groups, slot=0):
         """float64 per listed group of one component: float32-summed Dirichlet-categorical log-pdf (a7/a8) from the
         RESIDENT counts and concentration tables of the slot `sample` is bound to -- the bind sends the count rows of
@@ -138,7 +174,6 @@ class Likelihood:
         # takes the sample's source rows along
         sp_cache = None
         if memo is not None and memo[0] is sample and memo[2]:
-            from . import conditionals
             sp_cache = conditionals.source_prior_wanted(self.prior, sample)
         try:
             _bind_slot(eng, self._bind_model, sample, slot, with_source=sp_cache is not None)
@@ -419,3 +454,6 @@ def update_weights(sample, caching=True, features=None):
         # 1000 x 200 x 2): round 6.
         value._rebind(sample)
     return value
+
+
+from . import conditionals  # noqa: E402  (conditionals imports this module: bound here, after everything it needs is defined)

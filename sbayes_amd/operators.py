@@ -23,7 +23,7 @@ import numpy as np
 
 from . import _fast
 from . import counts as counts_mod
-from .binding import _bind_slot, _bind_uniform, _engine, _tables_current, counts_follow_plan, counts_followed
+from .binding import _bind_slot, _bind_uniform, _engine, _tables_current, _token, counts_follow_plan, counts_followed, note_source_lineage
 from .counts import _source_ids, apply_count_rows, note_jump_state, update_feature_counts
 
 EPS = np.finfo(np.float32).eps        # sbayes/util.py:34
@@ -161,7 +161,7 @@ def gibbs_sample_source(model, sample, object_subset=slice(None), temperature=1.
         bounds = apply_count_rows(sample_new.feature_counts, names, eng.group_offsets, touched, rows, return_bounds=True)
         if plan is not None:
             if touched.size:                                 # (the engine's rule: nothing touched, nothing follows)
-                counts_followed(eng, plan, sample_new, names, touched, bounds, True, objects, cur)
+                counts_followed(eng, plan, sample_new, names, touched, bounds, True, objects, cur, source_parent=_token(sample.source))
             else:
                 eng._bound[cur], eng._mirror[cur] = plan[0], plan[1]
         return sample_new, log_q, log_q_back
@@ -255,15 +255,18 @@ def cluster_gibbs_sample_source(model, sample_new, sample_old, i_cluster, object
         ids, sel_new, sel_back = eng.given_unchanged_gibbs(slot, i_cluster, objects, hc_new, hc_old, src_old, z, temperature,
                                                            prior_temperature, sample_from_prior)
     x = ids[..., None] == np.arange(eng.n_components, dtype=np.uint8)     # one-hot; all False where NA (id 255)
+    src_parent = _token(sample_new.source)                                # (what the slot was bound to above: binding.py, source lineage)
     with sample_new.source.edit() as source:
         source[objects] = x                                               # (NA observations stay 0: operators.py:825)
     if sub is not None:
         bounds = apply_count_rows(sample_new.feature_counts, ["clusters", *conf_names], eng.group_offsets, touched, rows, return_bounds=True)
         if plan is not None:
             if touched.size:                                               # (the engine's rule: nothing touched, nothing follows)
-                counts_followed(eng, plan, sample_new, names, touched, bounds, rebuild, objects, slot)
+                counts_followed(eng, plan, sample_new, names, touched, bounds, rebuild, objects, slot, source_parent=src_parent)
             else:                                                          # (the call dropped the entry: it still describes the slot)
                 eng._bound[slot], eng._mirror[slot] = plan[0], plan[1]
+        else:
+            note_source_lineage(src_parent, _token(sample_new.source), objects)
     else:
         update_feature_counts(sample_old, sample_new, features, objects)
     valid = ~na_features[objects]

@@ -62,6 +62,14 @@ MIRRORED_SOURCES = {
     "GibbsSampleSource._propose": "61911f12df7948eea0f207e45f49d97d7e0e5352",
     "ClusterOperator.gibbs_sample_source": "4c1f20c2821f64d9eed7ad4e8fa9cf50a76d0de1",
     "FeatureCounts.add_changes": "7c38d633f8488c553f1a031f57751a7db58deed2",
+    # the cache-node protocol the host layer runs in native code for nodes of exactly this class (_register_cache_nodes)
+    "CacheNode.is_outdated": "7acdcaadcdb930b67a958d4e92cb6a22fbd99f68",
+    "CacheNode.ahead_of": "5cc191e87c93f012e12e18dda747d0d29c5f63de",
+    "CacheNode.what_changed": "897c8ba27633cf13b1a96dee47fba5a662c43cc7",
+    "CacheNode.set_up_to_date": "3d3d7d5348f3e7d579936415b3c978a88b910a54",
+    "CacheNode.edit": "f97842f4ecfda2357d10973488fedec3bf0f4415",
+    "CacheNode.version": "9f3783fe9344800ec2dd6711a391f439d17a9020",
+    "CacheNode.value": "2c599b691219e9e677be97749fab9ee166bf0018",
 }
 
 
@@ -168,6 +176,7 @@ def install(operators=False, mp_start_method=None, gibbs_source=False):
         swap(mod, "recalculate_feature_counts", my_counts.recalculate_feature_counts)
         swap(mod, "update_feature_counts", my_counts.update_feature_counts)
     _install_sparse_add_changes()
+    _register_cache_nodes()
     if operators:
         _install_operator_forms(swap)
     if gibbs_source:
@@ -183,6 +192,30 @@ def install(operators=False, mp_start_method=None, gibbs_source=False):
             swap(m, name, new)
     _INSTALLED = {"operators": bool(operators) or bool(_INSTALLED and _INSTALLED["operators"]),
                   "gibbs_source": bool(gibbs_source) or bool(_INSTALLED and _INSTALLED.get("gibbs_source"))}
+
+
+_NODE_CLASSES = []
+
+
+def _register_cache_nodes():
+    """The reference's CacheNode protocol (sbayes/sampling/state.py:215-321: is_outdated, ahead_of, what_changed, set_up_to_date,
+    edit, version, value) runs in native code inside the host layer's own functions (csrc/sbe_pyhost.c: node_*, likelihood_call,
+    store_per_object) for nodes of EXACTLY the reference's CacheNode class -- and only when every one of those methods is the
+    revision the native code mirrors; otherwise (and for subclasses such as HasComponents) the node's own methods are called."""
+    from . import _fast
+    try:
+        state = importlib.import_module("sbayes.sampling.state")
+        cls, grouped = state.CacheNode, state.GroupedParameters
+        for name in ("is_outdated", "ahead_of", "what_changed", "set_up_to_date", "edit", "version", "value"):
+            obj = inspect.getattr_static(cls, name)
+            if isinstance(obj, property):
+                obj = obj.fget
+            if source_digest(obj) != MIRRORED_SOURCES[f"CacheNode.{name}"]:
+                return
+    except (ImportError, AttributeError, OSError, TypeError):
+        return
+    _fast.register_node_classes(cls, grouped)
+    _NODE_CLASSES.append((cls, grouped))
 
 
 def _install_sparse_add_changes():
@@ -386,3 +419,6 @@ def uninstall():
         cls, name = _ADDED.pop()
         if name in cls.__dict__:
             delattr(cls, name)
+    while _NODE_CLASSES:
+        from . import _fast
+        _fast.unregister_node_classes(*_NODE_CLASSES.pop())

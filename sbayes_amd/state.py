@@ -463,3 +463,9 @@ class Sample:
         out = {name: conf.group_assignment for name, conf in self.confounders.items()}
         out["clusters"] = self.clusters.value
         return out
+
+
+# the node protocol above runs in native code inside the host layer's functions for nodes of exactly this class (_fast.py)
+from . import _fast as _fast_mod  # noqa: E402
+
+_fast_mod.register_node_classes(CacheNode, GroupedParameters)

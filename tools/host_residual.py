@@ -349,13 +349,16 @@ def by_function(tag, n_steps, gibbs_source=False):
         path, seed = mg.write_synthetic_config(tag), (23 if tag == "cfg1" else 24)
     _s, _i, _o, eng1, _l = _run(path, tag, n_steps, seed, "memo", gibbs_source=gibbs_source)
     best = None
-    for _ in range(3):
+    per_step = None                      # every step's fastest occurrence over the replays, as measure() takes it
+    for _ in range(5):
         s, inside, _o, _e, _l, layer = _run(path, tag, n_steps, seed, "replay", memo=eng1.memo, layer_clock=True, gibbs_source=gibbs_source)
-        ours = (np.asarray(layer) - np.asarray(inside)).mean() * 1e6
+        o = np.asarray(layer) - np.asarray(inside)
+        per_step = o if per_step is None else np.minimum(per_step, o)
+        ours = o.mean() * 1e6
         if best is None or ours < best[0]:
             best = (ours, (np.asarray(s) - np.asarray(inside)).mean() * 1e6, dict(_run.last_clock.by_name))
-    print(f"{tag}{' (gibbs_source)' if gibbs_source else ''}: host layer {best[0]:.1f} us/step of {best[1]:.1f} us/step host Python; "
-          f"engine calls/step {len(eng1.memo) / n_steps:.1f}")
+    print(f"{tag}{' (gibbs_source)' if gibbs_source else ''}: host layer {per_step.mean() * 1e6:.1f} us/step (per-step minimum over 5 replays; best "
+          f"whole replay {best[0]:.1f}) of {best[1]:.1f} us/step host Python; engine calls/step {len(eng1.memo) / n_steps:.1f}")
     for name, (calls, t) in sorted(best[2].items(), key=lambda kv: -kv[1][1])[:14]:
         print(f"   {name:42s} {calls / n_steps:5.2f} calls/step  {t / calls * 1e6:7.1f} us/call  {t / n_steps * 1e6:7.1f} us/step")
 
