@@ -43,7 +43,7 @@ def likelihood_per_component(model, sample, caching=True):
     eng = _engine(model)
 
     cache = sample.cache.component_likelihoods
-    if caching and not cache.is_outdated():
+    if caching and not _fast.node_outdated(cache):
         return cache.value
 
     with cache.edit() as component_likelihood:
@@ -138,7 +138,7 @@ def source_prior_wanted(prior, sample):
     if sp is None or getattr(sp, "_sbayes_amd_owner", None) is None:
         return None
     cache = getattr(sample.cache, "source_prior", None)
-    if cache is None or getattr(sample, "source", None) is None or not cache.is_outdated():
+    if cache is None or getattr(sample, "source", None) is None or not _fast.node_outdated(cache):
         return None
     return cache
 
@@ -159,7 +159,7 @@ def source_prior(model, sample, slot=0, caching=True) -> float:
         eng = _engine(model)
         _bind_slot(eng, model, sample, slot, with_source=True)
         return eng.source_prior(slot).sum()
-    if caching and not cache.is_outdated():
+    if caching and not _fast.node_outdated(cache):
         return cache.value.sum()
 
     def values():

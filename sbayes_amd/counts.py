@@ -112,7 +112,16 @@ def update_feature_counts(sample_old, sample_new, features, object_subset):
     ONE device call for all components: the subset's group ids and source rows of both samples go up (n * (8 C + 2 F)
     bytes), the count rows of the groups those objects are in come back; the reference's `add_changes(diff)` follows
     with the same `diff` it would have computed (zero rows for every other group) -- in its row form
-    (FeatureCounts.add_changes_rows: patch.install / sbayes_amd.state) where the sample's class has one."""
+    (FeatureCounts.add_changes_rows: patch.install / sbayes_amd.state) where the sample's class has one.
+
+    The function body below is the reference form; with the extension built the same steps run as one native call
+    (csrc/sbe_pyhost.c: update_counts -- the same ids, the same engine call, the same add_changes and bind-cache follow-up),
+    which hands back NotImplemented for the argument forms it does not serve (slices, lists, repeated objects, overlapping groups)."""
+    if _NATIVE_UPDATE:
+        hold = _no_follow_from is not None and _no_follow_from() is sample_old
+        res = _fast._h.update_counts(sample_old, sample_new, features, object_subset, FOLLOW_COUNTS and not hold)
+        if res is not NotImplemented:
+            return res
     counts = sample_new.feature_counts
     conf_names = list(sample_new.confounders)
     names = ["clusters", *conf_names]
@@ -180,3 +189,16 @@ def apply_count_rows(counts, names, off, touched, rows, return_bounds=False):
             diff[touched[lo:hi] - off[c]] = rows[lo:hi]
         node.add_changes(diff=diff)
     return bounds if return_bounds else counts
+
+
+def _get_engine_now(features, n_groups):
+    return get_engine(features, n_groups)          # (looked up at call time: tests swap the module's get_engine)
+
+
+_NATIVE_UPDATE = False
+if _fast._h is not None and hasattr(_fast._h, "update_counts"):
+    from . import binding as _binding
+    if _binding._bind_slot is not _binding._bind_slot_py:            # (the native bind is set up: its helpers are shared)
+        _fast._h.update_counts_setup(np.empty, np.dtype(np.int32), np.dtype(np.uint8), _get_engine_now, _binding.note_source_lineage,
+                                     _binding._source_followed, apply_count_rows)
+        _NATIVE_UPDATE = True

@@ -1337,6 +1337,292 @@ done:
     return result;
 }
 
+/* ---- counts.update_feature_counts (sbayes/sampling/counts.py:55-95) in native code ------------------------------------------------------
+ * update_counts(sample_old, sample_new, features, object_subset, follow_ok) -> sample_new.feature_counts | NotImplemented
+ * A transcription of the Python function (sbayes_amd/counts.py, kept as the reference form and the fallback): the same ids
+ * (sbeh_subset_ids), the same ONE engine call -- counts_delta(objs, gid_old, gid_new, sid_old, sid_new[, follow_slot=0,
+ * update_probs=..., update_source=...]) -- the same add_changes per component (add_rows_many), the same bind-cache follow-up
+ * (counts_followed, the source lineage notes).  NotImplemented (nothing touched, the Python form serves the call): a sample whose
+ * arrays are not plain C-contiguous bool arrays, an object_subset that is neither a bool mask [N] nor a one-dimensional int32
+ * array, an object listed twice or in several groups of one component (the reference's two-count difference applies). */
+static PyObject *g_np_empty = NULL, *g_dt_i32 = NULL, *g_dt_u8 = NULL, *g_get_engine = NULL, *g_note_lineage = NULL, *g_source_followed = NULL,
+                *g_apply_rows = NULL;
+static PyObject *s_counts_delta, *s_group_offsets, *k_follow_slot, *k_update_source;
+
+static PyObject* py_update_counts_setup(PyObject* self, PyObject* args) {
+    PyObject *e, *di, *du, *ge, *nl, *sf, *ar;
+    if (!PyArg_ParseTuple(args, "OOOOOOO", &e, &di, &du, &ge, &nl, &sf, &ar)) return NULL;
+    Py_XDECREF(g_np_empty); Py_XDECREF(g_dt_i32); Py_XDECREF(g_dt_u8); Py_XDECREF(g_get_engine); Py_XDECREF(g_note_lineage); Py_XDECREF(g_source_followed); Py_XDECREF(g_apply_rows);
+    Py_INCREF(e); Py_INCREF(di); Py_INCREF(du); Py_INCREF(ge); Py_INCREF(nl); Py_INCREF(sf); Py_INCREF(ar);
+    g_np_empty = e; g_dt_i32 = di; g_dt_u8 = du; g_get_engine = ge; g_note_lineage = nl; g_source_followed = sf; g_apply_rows = ar;
+    Py_RETURN_NONE;
+}
+
+/* np.empty((a, b), dtype) / np.empty((a,), dtype): new reference */
+static PyObject* np_empty2(Py_ssize_t a, Py_ssize_t b, PyObject* dtype) {
+    PyObject* shape = b < 0 ? Py_BuildValue("(n)", a) : Py_BuildValue("(nn)", a, b);
+    if (!shape) return NULL;
+    PyObject* r = PyObject_CallFunctionObjArgs(g_np_empty, shape, dtype, NULL);
+    Py_DECREF(shape);
+    return r;
+}
+
+static PyObject* py_update_counts(PyObject* self, PyObject* args) {
+    PyObject *s_old, *s_new, *features, *subset;
+    int follow_ok = 0;
+    if (!PyArg_ParseTuple(args, "OOOOp", &s_old, &s_new, &features, &subset, &follow_ok)) return NULL;
+    if (!g_np_empty || !g_ndarray || !g_send_counts) { PyErr_SetString(PyExc_RuntimeError, "update_counts_setup() / bind_setup() / scan_setup() not called"); return NULL; }
+    PyObject* own[96 + 12 * BIND_MAXC]; int n_own = 0;
+#define OWN(x) (own[n_own++] = (x))
+    Py_buffer vb[8 + 2 * BIND_MAXC]; int nb = 0;
+    PyObject* result = NULL;
+    int followed_started = 0;
+    PyObject* eng = NULL;
+    PyObject* counts = OWN(PyObject_GetAttr(s_new, s_feature_counts));
+    PyObject* conf_new = counts ? OWN(PyObject_GetAttr(s_new, s_confounders)) : NULL;
+    PyObject* conf_old = conf_new ? OWN(PyObject_GetAttr(s_old, s_confounders)) : NULL;
+    PyObject* conf_names = conf_old ? OWN(PySequence_List(conf_new)) : NULL;
+    if (!conf_names) goto out;
+    const Py_ssize_t C = 1 + PyList_GET_SIZE(conf_names);
+    if (C > BIND_MAXC) goto unsupported;
+    PyObject* names = OWN(PyList_New(C));
+    if (!names) goto out;
+    Py_INCREF(s_clusters); PyList_SET_ITEM(names, 0, s_clusters);
+    for (Py_ssize_t c = 1; c < C; ++c) { PyObject* k = PyList_GET_ITEM(conf_names, c - 1); Py_INCREF(k); PyList_SET_ITEM(names, c, k); }
+    /* the group matrices of both samples: plain C-contiguous bool [G_c, N] */
+    const uint8_t* pn[BIND_MAXC]; const uint8_t* po[BIND_MAXC]; int32_t ng[BIND_MAXC];
+    Py_ssize_t N = -1;
+    PyObject* n_groups = OWN(PyList_New(C));
+    if (!n_groups) goto out;
+    for (Py_ssize_t c = 0; c < C; ++c) {
+        PyObject *gn, *go;
+        if (c == 0) {
+            PyObject* p = OWN(PyObject_GetAttr(s_new, s_clusters));
+            gn = p ? OWN(PyObject_GetAttr(p, s_value)) : NULL;
+            PyObject* q = gn ? OWN(PyObject_GetAttr(s_old, s_clusters)) : NULL;
+            go = q ? OWN(PyObject_GetAttr(q, s_value)) : NULL;
+        } else {
+            PyObject* k = PyList_GET_ITEM(conf_names, c - 1);
+            PyObject* p = OWN(PyObject_GetItem(conf_new, k));
+            gn = p ? OWN(PyObject_GetAttr(p, s_group_assignment)) : NULL;
+            PyObject* q = gn ? OWN(PyObject_GetItem(conf_old, k)) : NULL;
+            go = q ? OWN(PyObject_GetAttr(q, s_group_assignment)) : NULL;
+        }
+        if (!go) goto out;
+        if ((PyObject*)Py_TYPE(gn) != g_ndarray || (PyObject*)Py_TYPE(go) != g_ndarray) goto unsupported;
+        if (!get_c(gn, &vb[nb], 2, 1, 0)) goto unsupported;
+        Py_buffer* va = &vb[nb++];
+        if (N < 0) N = va->shape[1];
+        if (va->shape[1] != N) goto unsupported;
+        pn[c] = (const uint8_t*)va->buf; ng[c] = (int32_t)va->shape[0];
+        if (go == gn) po[c] = pn[c];
+        else {
+            if (!get_c(go, &vb[nb], 2, 1, 0)) goto unsupported;
+            Py_buffer* vo = &vb[nb++];
+            if (vo->shape[0] != va->shape[0] || vo->shape[1] != N) goto unsupported;
+            po[c] = (const uint8_t*)vo->buf;
+        }
+        PyObject* g = PyLong_FromSsize_t(va->shape[0]);
+        if (!g) goto out;
+        PyList_SET_ITEM(n_groups, c, g);
+    }
+    /* source of both samples: plain C-contiguous bool [N, F, C] */
+    PyObject* sp_new = OWN(PyObject_GetAttr(s_new, s_source));
+    PyObject* src_new = sp_new ? OWN(PyObject_GetAttr(sp_new, s_value)) : NULL;
+    PyObject* sp_old = src_new ? OWN(PyObject_GetAttr(s_old, s_source)) : NULL;
+    PyObject* src_old = sp_old ? OWN(PyObject_GetAttr(sp_old, s_value)) : NULL;
+    if (!src_old) goto out;
+    if ((PyObject*)Py_TYPE(src_new) != g_ndarray || (PyObject*)Py_TYPE(src_old) != g_ndarray) goto unsupported;
+    if (!get_c(src_new, &vb[nb], 3, 1, 0)) goto unsupported;
+    Py_buffer* b_sn = &vb[nb++];
+    Py_buffer* b_so = b_sn;
+    if (src_old != src_new) { if (!get_c(src_old, &vb[nb], 3, 1, 0)) goto unsupported; b_so = &vb[nb++]; }
+    const Py_ssize_t F = b_sn->shape[1];
+    if (b_sn->shape[0] != N || b_sn->shape[2] != C || b_so->shape[0] != N || b_so->shape[1] != F || b_so->shape[2] != C) goto unsupported;
+    /* the listed objects: a bool mask [N] (np.flatnonzero) or int32 indices */
+    PyObject* objs = NULL;
+    if ((PyObject*)Py_TYPE(subset) != g_ndarray) goto unsupported;
+    {
+        Py_buffer vs;
+        if (PyObject_GetBuffer(subset, &vs, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) { PyErr_Clear(); goto unsupported; }
+        const char f = vs.format ? vs.format[strlen(vs.format) ? strlen(vs.format) - 1 : 0] : 0;
+        if (vs.ndim == 1 && vs.itemsize == 1 && f == '?' && vs.shape[0] == N) {
+            Py_ssize_t k = 0;
+            const uint8_t* m = (const uint8_t*)vs.buf;
+            for (Py_ssize_t i = 0; i < N; ++i) k += m[i] != 0;
+            objs = OWN(np_empty2(k, -1, g_dt_i32));
+            Py_buffer vo;
+            if (!objs || PyObject_GetBuffer(objs, &vo, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) { PyBuffer_Release(&vs); goto out; }
+            int32_t* o = (int32_t*)vo.buf;
+            Py_ssize_t j = 0;
+            if (vo.len == k * 4) for (Py_ssize_t i = 0; i < N; ++i) if (m[i]) o[j++] = (int32_t)i;
+            PyBuffer_Release(&vo);
+            PyBuffer_Release(&vs);
+            if (j != k) { PyErr_SetString(PyExc_TypeError, "update_counts_setup: np.empty(n, int32) expected"); goto out; }
+        } else if (vs.ndim == 1 && vs.itemsize == 4 && (f == 'i' || f == 'l')) {
+            PyBuffer_Release(&vs);
+            objs = subset;
+        } else { PyBuffer_Release(&vs); goto unsupported; }
+    }
+    if (!get_c(objs, &vb[nb], 1, 4, 0)) goto unsupported;
+    Py_buffer* b_objs = &vb[nb++];
+    const Py_ssize_t n = b_objs->shape[0];
+    /* ids of both samples for the listed objects */
+    PyObject* gid_new = OWN(np_empty2(C, n, g_dt_i32));
+    PyObject* gid_old = gid_new ? OWN(np_empty2(C, n, g_dt_i32)) : NULL;
+    PyObject* sid_new = gid_old ? OWN(np_empty2(n, F, g_dt_u8)) : NULL;
+    PyObject* sid_old = !sid_new ? NULL : (src_old == src_new ? sid_new : OWN(np_empty2(n, F, g_dt_u8)));
+    if (!sid_old) goto out;
+    {
+        Py_buffer g1, g2, s1, s2;
+        if (!get_c(gid_new, &g1, 2, 4, 1)) { PyErr_SetString(PyExc_TypeError, "update_counts: id scratch"); goto out; }
+        if (!get_c(gid_old, &g2, 2, 4, 1)) { PyBuffer_Release(&g1); PyErr_SetString(PyExc_TypeError, "update_counts: id scratch"); goto out; }
+        if (!get_c(sid_new, &s1, 2, 1, 1)) { PyBuffer_Release(&g1); PyBuffer_Release(&g2); PyErr_SetString(PyExc_TypeError, "update_counts: id scratch"); goto out; }
+        int have_s2 = 0;
+        if (sid_old != sid_new) { if (!get_c(sid_old, &s2, 2, 1, 1)) { PyBuffer_Release(&g1); PyBuffer_Release(&g2); PyBuffer_Release(&s1); PyErr_SetString(PyExc_TypeError, "update_counts: id scratch"); goto out; } have_s2 = 1; }
+        const int rc = sbeh_subset_ids((const int32_t*)b_objs->buf, (int)n, (int64_t)N, (int)F, (int)C, ng, pn, po, (const uint8_t*)b_sn->buf, (const uint8_t*)b_so->buf,
+                                       (int32_t*)g1.buf, (int32_t*)g2.buf, (uint8_t*)s1.buf, have_s2 ? (uint8_t*)s2.buf : (uint8_t*)s1.buf);
+        PyBuffer_Release(&g1); PyBuffer_Release(&g2); PyBuffer_Release(&s1); if (have_s2) PyBuffer_Release(&s2);
+        if (rc == 1) goto unsupported;                       /* (repeated objects / several groups: the two-count difference) */
+        if (rc < 0) { PyErr_SetString(PyExc_ValueError, "object index out of range in object_subset"); goto out; }
+    }
+    eng = OWN(PyObject_CallFunctionObjArgs(g_get_engine, features, n_groups, NULL));
+    if (!eng) goto out;
+    PyObject* off = OWN(PyObject_GetAttr(eng, s_group_offsets));
+    if (!off) goto out;
+    PyObject* parent_tok = NULL;                              /* (array, version) of sample_old.source: binding.py, source lineage */
+    if (token_of(sp_old, Py_None, &parent_tok) < 0) goto out;
+    OWN(parent_tok);
+    PyObject* slot0 = OWN(PyLong_FromLong(0));
+    if (!slot0) goto out;
+    /* a slot that holds the counts this difference is added to follows on the device (binding.counts_follow_plan) */
+    PyObject *entry = NULL, *mirrors = NULL, *nodes = NULL;
+    nodes = OWN(PyList_New(C));
+    if (!nodes) goto out;
+    for (Py_ssize_t c = 0; c < C; ++c) {
+        PyObject* node = PyObject_GetItem(counts, PyList_GET_ITEM(names, c));
+        if (!node) goto out;
+        PyList_SET_ITEM(nodes, c, node);
+    }
+    if (follow_ok) {
+        PyObject* bound = PyObject_GetAttr(eng, s__bound);
+        if (!bound) PyErr_Clear();
+        else {
+            OWN(bound);
+            PyObject* mm = PyObject_GetAttr(eng, s__mirror);
+            if (!mm) PyErr_Clear();
+            else {
+                OWN(mm);
+                PyObject* e = PyDict_Check(bound) ? PyDict_GetItemWithError(bound, slot0) : NULL;
+                PyObject* m = (e && PyDict_Check(mm)) ? PyDict_GetItemWithError(mm, slot0) : NULL;
+                if (PyErr_Occurred()) goto out;
+                if (e && m && PyDict_Check(e) && PyDict_Check(m)) {
+                    PyObject* ec = PyDict_GetItem(e, k_counts);
+                    PyObject* mc = PyDict_GetItem(m, k_counts);
+                    int all = ec && mc && PyList_Check(ec) && PyList_Check(mc) && PyList_GET_SIZE(ec) == C && PyList_GET_SIZE(mc) == C;
+                    for (Py_ssize_t c = 0; c < C && all; ++c) {
+                        PyObject* cached = PyList_GET_ITEM(ec, c);
+                        if (cached == Py_None || PyList_GET_ITEM(mc, c) == Py_None) { all = 0; break; }
+                        PyObject* tok = NULL;
+                        const int same = token_of(PyList_GET_ITEM(nodes, c), cached, &tok);
+                        Py_XDECREF(tok);
+                        if (same < 0) goto out;
+                        if (!same) all = 0;
+                    }
+                    if (all) { entry = e; mirrors = m; Py_INCREF(entry); Py_INCREF(mirrors); OWN(entry); OWN(mirrors); }
+                }
+            }
+        }
+    }
+    PyObject *touched = NULL, *rows = NULL;
+    int rebuild = 0, with_source = 0;
+    PyObject* known = NULL;
+    {
+        PyObject* meth = OWN(PyObject_GetAttr(eng, s_counts_delta));
+        PyObject* pos = meth ? OWN(PyTuple_Pack(5, objs, gid_old, gid_new, sid_old, sid_new)) : NULL;
+        if (!pos) goto out;
+        PyObject* r;
+        if (!entry) r = PyObject_Call(meth, pos, NULL);
+        else {
+            PyObject* stale = PyDict_GetItem(entry, k_stale);
+            const Py_ssize_t n_stale = stale ? PyObject_Length(stale) : -1;
+            if (n_stale < 0) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_TypeError, "malformed bind entry"); goto out; }
+            rebuild = n_stale == 0;                          /* (the probability rows are rebuilt along when no table of the slot is stale) */
+            PyObject* ms = PyDict_GetItem(mirrors, k_source);
+            if (ms && ms != Py_None) {                       /* the subset's new source rows are in the call anyway: a slot that has a source takes them */
+                Py_buffer vm;
+                if (PyObject_GetBuffer(ms, &vm, PyBUF_C_CONTIGUOUS) == 0) {
+                    with_source = vm.ndim == 3 && vm.shape[0] == N && vm.shape[1] == F && vm.shape[2] == C;
+                    PyBuffer_Release(&vm);
+                } else PyErr_Clear();
+            }
+            known = PyDict_GetItem(entry, k_source);          /* borrowed; the entry is ours (OWN) */
+            if (known) { Py_INCREF(known); OWN(known); }
+            PyObject* kw = OWN(PyDict_New());
+            if (!kw || PyDict_SetItem(kw, k_follow_slot, slot0) || PyDict_SetItem(kw, k_update_probs, rebuild ? Py_True : Py_False) ||
+                PyDict_SetItem(kw, k_update_source, with_source ? Py_True : Py_False)) goto out;
+            followed_started = 1;
+            r = PyObject_Call(meth, pos, kw);
+        }
+        if (!r) goto out;
+        OWN(r);
+        if (!PyTuple_Check(r) || PyTuple_GET_SIZE(r) != 2) { PyErr_SetString(PyExc_TypeError, "counts_delta must return (touched, rows)"); goto out; }
+        touched = PyTuple_GET_ITEM(r, 0); rows = PyTuple_GET_ITEM(r, 1);
+    }
+    /* where the two samples' sources differ, for the binds to come: this call's own contract (binding.py, source lineage) */
+    PyObject* child_tok = NULL;
+    if (!(entry && with_source)) {
+        if (token_of(sp_new, Py_None, &child_tok) < 0) goto out;
+        OWN(child_tok);
+        PyObject* r = PyObject_CallFunctionObjArgs(g_note_lineage, parent_tok, child_tok, objs, NULL);
+        if (!r) goto out;
+        Py_DECREF(r);
+    }
+    /* the reference's add_changes(diff) per component, in its row form */
+    PyObject* bounds;
+    {
+        PyObject* a = OWN(PyTuple_Pack(4, nodes, off, touched, rows));
+        bounds = a ? py_add_rows_many(NULL, a) : NULL;
+        if (!bounds) goto out;
+        OWN(bounds);
+        if (bounds == Py_None) {
+            bounds = OWN(PyObject_CallFunctionObjArgs(g_apply_rows, counts, names, off, touched, rows, Py_True, NULL));
+            if (!bounds) goto out;
+        }
+    }
+    if (entry) {
+        PyObject* a = OWN(Py_BuildValue("(OOOOOOOOOOO)", eng, entry, mirrors, nodes, off, touched, bounds, rebuild ? Py_True : Py_False,
+                                        with_source ? objs : Py_None, with_source ? src_new : Py_None, slot0));
+        PyObject* r = a ? py_counts_followed(NULL, a) : NULL;
+        if (!r) goto out;
+        Py_DECREF(r);
+        if (with_source) {
+            r = PyObject_CallFunctionObjArgs(g_source_followed, entry, mirrors, known ? known : Py_None, parent_tok, s_new, objs, NULL);
+            if (!r) goto out;
+            Py_DECREF(r);
+        }
+    }
+    followed_started = 0;
+    result = counts; Py_INCREF(result);
+    goto out;
+unsupported:
+    result = Py_NotImplemented; Py_INCREF(result);
+out:
+    if (!result && followed_started && eng) {                 /* (half-updated mirrors must not come back into the cache) */
+        PyObject *et, *ev, *tb;
+        PyErr_Fetch(&et, &ev, &tb);
+        PyObject* z = PyLong_FromLong(0);
+        PyObject* r = z ? PyObject_CallMethodObjArgs(eng, s__touch, z, NULL) : NULL;
+        if (!r) PyErr_Clear(); else Py_DECREF(r);
+        Py_XDECREF(z);
+        PyErr_Restore(et, ev, tb);
+    }
+    for (int i = 0; i < nb; ++i) PyBuffer_Release(&vb[i]);
+    for (int i = 0; i < n_own; ++i) Py_XDECREF(own[i]);
+    return result;
+#undef OWN
+}
+
 static PyMethodDef methods[] = {
     {"scan_setup", py_scan_setup, METH_VARARGS, "scan_setup(ndarray_type, asarray, content_equal)"},
     {"scan", py_scan, METH_VARARGS, "scan(params, cached) -> (tokens, changed bitmask): the bind cache's token comparison"},
@@ -1355,6 +1641,8 @@ static PyMethodDef methods[] = {
     {"node_changed", py_node_changed, METH_VARARGS, "cache.what_changed(key, caching=True) for one key -> int64 ndarray"},
     {"likelihood_call", py_likelihood_call, METH_VARARGS, "Likelihood.__call__'s caching path: likelihood_call(lik, sample, names, off, all_fn)"},
     {"store_per_object", py_store_per_object, METH_VARARGS, "SourcePrior.__call__'s cache update: store_per_object(cache, n_objects, values, caching=True)"},
+    {"update_counts_setup", py_update_counts_setup, METH_VARARGS, "update_counts_setup(np.empty, int32 dtype, uint8 dtype, get_engine, note_source_lineage, _source_followed, apply_count_rows)"},
+    {"update_counts", py_update_counts, METH_VARARGS, "counts.update_feature_counts in C: update_counts(sample_old, sample_new, features, object_subset, follow_ok)"},
     {"copy_rows", py_copy_rows, METH_VARARGS, "dst[idx] = src[idx] (rows of two same-shaped C-contiguous arrays)"},
     {NULL, NULL, 0, NULL}};
 
@@ -1421,6 +1709,11 @@ PyMODINIT_FUNC PyInit__sbe_pyhost(void) {
     k_counts_key = PyUnicode_InternFromString("counts");
     k_weights_key = PyUnicode_InternFromString("weights");
     k_source_key = PyUnicode_InternFromString("source");
+    s_counts_delta = PyUnicode_InternFromString("counts_delta");
+    s_group_offsets = PyUnicode_InternFromString("group_offsets");
+    k_follow_slot = PyUnicode_InternFromString("follow_slot");
+    k_update_source = PyUnicode_InternFromString("update_source");
+    if (!s_counts_delta || !s_group_offsets || !k_follow_slot || !k_update_source) return NULL;
     if (!s_inputs || !s_input_idx || !s_cached_version || !s_cached_group_versions || !s_copy || !s_is_outdated || !s_what_changed || !s_set_up_to_date ||
         !s_ahead_of || !s_cache || !s_group_likelihoods || !s_sum || !s_any_dynamic_priors || !s_n_groups || !s_caching || !k_universal_counts || !k_counts_key ||
         !k_weights_key || !k_source_key) return NULL;

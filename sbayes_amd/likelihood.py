@@ -270,7 +270,8 @@ _ROW_MEMO_WEIGHTS = 4                      # weight arrays kept (MC3 chains alte
 _ROW_MEMO_ROWS = 64                        # row requests up to this size go through the memo
 
 
-def _pattern_rows(eng, w, hc):
+def _memo_for(w):
+    """The pattern memo of one weights content (float32, C-contiguous [F, C])."""
     key = (w.shape, w.tobytes())
     memo = _ROW_MEMO.get(key)
     if memo is None:
@@ -279,7 +280,21 @@ def _pattern_rows(eng, w, hc):
             _ROW_MEMO.popitem(last=False)
     else:
         _ROW_MEMO.move_to_end(key)
-    keys = [row.tobytes() for row in hc]
+    return memo
+
+
+def _rows_from_memo(memo, w, hc, eng_of):
+    """float32 [n, F, C]: the rows of normalize_weights(w, hc) from `memo` (pattern bytes -> device result [F, C]); patterns it
+    does not hold are ONE device call (`eng_of()` -> the engine), with every other non-empty pattern riding along."""
+    n = hc.shape[0]
+    if n == 1:
+        k = hc.tobytes()
+        row = memo.get(k)
+        if row is not None:
+            return row[None].copy()
+        keys = [k]
+    else:
+        keys = [row.tobytes() for row in hc]
     missing = [k for k in dict.fromkeys(keys) if k not in memo]
     if missing:
         n_comp = w.shape[1]
@@ -287,13 +302,17 @@ def _pattern_rows(eng, w, hc):
         if n_comp <= 4:                    # every other non-empty pattern rides along: the step's next request needs no call
             want += [p for p in (bytes((b >> c) & 1 for c in range(n_comp)) for b in range(1, 1 << n_comp))
                      if p not in memo and p not in missing]
-        rows = eng.normalize_weights(w, np.frombuffer(b"".join(want), dtype=np.bool_).reshape(len(want), n_comp))
+        rows = eng_of().normalize_weights(w, np.frombuffer(b"".join(want), dtype=np.bool_).reshape(len(want), n_comp))
         for p, r in zip(want, rows):
             memo[p] = r
-    out = np.empty((len(keys),) + w.shape, dtype=np.float32)
+    out = np.empty((n,) + w.shape, dtype=np.float32)
     for i, k in enumerate(keys):
         out[i] = memo[k]
     return out
+
+
+def _pattern_rows(eng, w, hc):
+    return _rows_from_memo(_memo_for(w), w, hc, lambda: eng)
 
 
 def normalize_weights(weights, has_components, features=None):
@@ -331,6 +350,7 @@ class NormalizedWeights(np.lib.mixins.NDArrayOperatorsMixin):
         self._has_components = np.array(has_components, dtype=bool)
         self._features = features
         self._full = None
+        self._memo = None                                                 # (the pattern memo of these weights: _rows_from_memo)
         try:                                                              # the sample these weights were derived from
             self._owner = weakref.ref(owner) if owner is not None else None
         except TypeError:
@@ -339,7 +359,7 @@ class NormalizedWeights(np.lib.mixins.NDArrayOperatorsMixin):
     # Samples are pickled (MC3 pipes, StateDumper: sbayes/mcmc_setup.py:320-324, sampling/loggers.py:426-442): the
     # weights travel as their two small inputs; the sample reference and the feature block stay behind
     def __getstate__(self):
-        return {"_weights": self._weights, "_has_components": self._has_components, "_features": None, "_full": None, "_owner": None}
+        return {"_weights": self._weights, "_has_components": self._has_components, "_features": None, "_full": None, "_owner": None, "_memo": None}
 
     def __setstate__(self, state):
         self.__dict__.update(state)
@@ -409,6 +429,10 @@ class NormalizedWeights(np.lib.mixins.NDArrayOperatorsMixin):
 
     def _rows(self, idx):
         """has_components rows an axis-0 index selects, or None when `idx` is anything else."""
+        if type(idx) is np.ndarray:
+            if idx.ndim == 1 and (idx.dtype == np.bool_ or idx.dtype.kind in "iu"):
+                return self._has_components[idx]
+            return None
         if isinstance(idx, (int, np.integer)):
             return None                                                   # (drops the axis: rare, use the full array)
         if isinstance(idx, slice):
@@ -419,14 +443,27 @@ class NormalizedWeights(np.lib.mixins.NDArrayOperatorsMixin):
                 return self._has_components[arr]
         return None
 
+    def _engine(self):
+        if self._features is not None:
+            return get_engine(self._features)
+        return registry.engine_for_features(self._weights.shape[0])
+
     def __getitem__(self, idx):
         if self._full is None:
             rows = self._rows(idx)
             if rows is not None:
-                if rows.shape[0] == 0:
+                n = rows.shape[0]
+                if n == 0:
                     return np.zeros((0,) + self._weights.shape, dtype=np.float32)
-                if 2 * rows.shape[0] <= self._has_components.shape[0]:
-                    return normalize_weights(self._weights, rows, self._features)
+                if 2 * n <= self._has_components.shape[0]:
+                    w = self._weights
+                    if n <= _ROW_MEMO_ROWS and w.ndim == 2 and rows.ndim == 2 and rows.shape[1] == w.shape[1]:
+                        # a few rows: each is its has_components pattern's row, from the memo of these weights (found once)
+                        memo = self.__dict__.get("_memo")
+                        if memo is None:
+                            memo = self._memo = _memo_for(w)
+                        return _rows_from_memo(memo, w, rows, self._engine)
+                    return normalize_weights(w, rows, self._features)
         return self.materialize()[idx]
 
     def __getattr__(self, name):                                          # everything else an ndarray offers
@@ -442,7 +479,7 @@ def update_weights(sample, caching=True, features=None):
     """Normalised mixture weights of `sample`, cached on (has_components, weights) versions (likelihood.py:153-168);
     returned as a lazily materialised array (NormalizedWeights)."""
     cache = sample.cache.weights_normalized
-    if (not caching) or cache.is_outdated():
+    if (not caching) or _fast.node_outdated(cache):
         cache.update_value(NormalizedWeights(sample.weights.value, sample.cache.has_components.value, features, owner=sample))
         return cache.value
     value = cache.value
