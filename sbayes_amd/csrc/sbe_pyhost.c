@@ -448,6 +448,29 @@ static PyObject *s_confounders, *s_clusters, *s_group_assignment, *s_prior, *s_p
                 *k_groups, *k_counts, *k_weights, *k_source, *k_stale, *k_lh_all, *k_update_probs,
                 *k_groups_component, *k_count_idx, *k_count_rows, *k_source_objects, *k_source_rows;
 
+/* (shared with update_counts further down: np.empty and the dtypes, set by update_counts_setup) */
+static PyObject *g_np_empty = NULL, *g_dt_i32 = NULL, *g_dt_u8 = NULL, *g_get_engine = NULL, *g_note_lineage = NULL, *g_source_followed = NULL,
+                *g_apply_rows = NULL;
+static PyObject *s_counts_delta, *s_group_offsets, *k_follow_slot, *k_update_source;
+
+static PyObject* py_update_counts_setup(PyObject* self, PyObject* args) {
+    PyObject *e, *di, *du, *ge, *nl, *sf, *ar;
+    if (!PyArg_ParseTuple(args, "OOOOOOO", &e, &di, &du, &ge, &nl, &sf, &ar)) return NULL;
+    Py_XDECREF(g_np_empty); Py_XDECREF(g_dt_i32); Py_XDECREF(g_dt_u8); Py_XDECREF(g_get_engine); Py_XDECREF(g_note_lineage); Py_XDECREF(g_source_followed); Py_XDECREF(g_apply_rows);
+    Py_INCREF(e); Py_INCREF(di); Py_INCREF(du); Py_INCREF(ge); Py_INCREF(nl); Py_INCREF(sf); Py_INCREF(ar);
+    g_np_empty = e; g_dt_i32 = di; g_dt_u8 = du; g_get_engine = ge; g_note_lineage = nl; g_source_followed = sf; g_apply_rows = ar;
+    Py_RETURN_NONE;
+}
+
+/* np.empty((a, b), dtype) / np.empty((a,), dtype): new reference */
+static PyObject* np_empty2(Py_ssize_t a, Py_ssize_t b, PyObject* dtype) {
+    PyObject* shape = b < 0 ? Py_BuildValue("(n)", a) : Py_BuildValue("(nn)", a, b);
+    if (!shape) return NULL;
+    PyObject* r = PyObject_CallFunctionObjArgs(g_np_empty, shape, dtype, NULL);
+    Py_DECREF(shape);
+    return r;
+}
+
 static PyObject* py_bind_setup(PyObject* self, PyObject* args) {
     PyObject *sc, *ss, *rm, *cc, *bp;
     int rwp;
@@ -710,7 +733,86 @@ static PyObject* py_bind_slot(PyObject* self, PyObject* args, PyObject* kwargs) 
         if (!was_stale) goto out;
         /* counts */
         int by_rows[BIND_MAXC], n_by_rows = 0;
-        if (have_model) {
+        /* Native form of the loop below (binding._send_counts per component, then np.concatenate): when EVERY component whose
+           count parameter changed is a plain C-contiguous float32 [G, F, S] array with a mirror of the same shape, the rows that
+           differ are found (and copied into the mirrors) here and handed on as ONE pair (int32 global group indices, float32
+           rows) -- the same two arrays the Python helpers build.  Any other form: the loop below, unchanged. */
+        int counts_native = 0;
+        if (have_model && g_np_empty && PyObject_HasAttr(eng, s_set_counts_rows)) {
+            int32_t* diff[BIND_MAXC]; Py_ssize_t kdiff[BIND_MAXC]; int comp[BIND_MAXC]; int n_comp = 0;
+            Py_ssize_t K = 0, FS = -1, Fd = -1, Sd = -1;
+            int eligible = 1, any = 0;
+            for (Py_ssize_t c = 0; c < C && eligible; ++c) {
+                if (!((changed >> (2 * C + c)) & 1)) continue;
+                any = 1;
+                PyObject* arr = PyTuple_GET_ITEM(tokens[2 * C + c], 0);
+                PyObject* mir = PyList_GET_ITEM(mirror_counts, c);
+                if ((PyObject*)Py_TYPE(arr) != g_ndarray || mir == Py_None) { eligible = 0; break; }
+                Py_buffer a, m;
+                if (PyObject_GetBuffer(arr, &a, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) { PyErr_Clear(); eligible = 0; break; }
+                if (PyObject_GetBuffer(mir, &m, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT | PyBUF_WRITABLE) != 0) { PyErr_Clear(); PyBuffer_Release(&a); eligible = 0; break; }
+                const char fa = a.format ? a.format[strlen(a.format) ? strlen(a.format) - 1 : 0] : 0, fm = m.format ? m.format[strlen(m.format) ? strlen(m.format) - 1 : 0] : 0;
+                if (!(a.ndim == 3 && m.ndim == 3 && a.itemsize == 4 && m.itemsize == 4 && fa == 'f' && fm == 'f' && a.shape[0] == m.shape[0] && a.shape[1] == m.shape[1] &&
+                      a.shape[2] == m.shape[2] && a.shape[0] > 0 && a.shape[1] * a.shape[2] > 0 && (FS < 0 || (a.shape[1] == Fd && a.shape[2] == Sd)))) eligible = 0;
+                if (eligible) { Fd = a.shape[1]; Sd = a.shape[2]; FS = Fd * Sd; }
+                PyBuffer_Release(&a); PyBuffer_Release(&m);
+            }
+            if (eligible && any) {
+                counts_native = 1;
+                PyObject* offs = OWN(PyObject_GetAttr(eng, s_group_offsets));
+                Py_buffer vo;
+                if (!offs || PyObject_GetBuffer(offs, &vo, PyBUF_C_CONTIGUOUS) != 0) goto out;
+                int fail = !(vo.ndim == 1 && vo.shape[0] >= C + 1 && (vo.itemsize == 8 || vo.itemsize == 4));
+                for (Py_ssize_t c = 0; c < C && !fail; ++c) {
+                    if (!((changed >> (2 * C + c)) & 1)) continue;
+                    PyObject* arr = PyTuple_GET_ITEM(tokens[2 * C + c], 0);
+                    PyObject* mir = PyList_GET_ITEM(mirror_counts, c);
+                    Py_buffer a, m;
+                    if (PyObject_GetBuffer(arr, &a, PyBUF_C_CONTIGUOUS) != 0) { fail = 1; break; }
+                    if (PyObject_GetBuffer(mir, &m, PyBUF_C_CONTIGUOUS | PyBUF_WRITABLE) != 0) { PyBuffer_Release(&a); fail = 1; break; }
+                    int32_t* d = (int32_t*)malloc((size_t)a.shape[0] * sizeof(int32_t));
+                    const int64_t k = d ? sbeh_diff_rows(a.buf, m.buf, (int64_t)a.shape[0], (int64_t)(a.len / a.shape[0]), d) : -1;
+                    PyBuffer_Release(&a); PyBuffer_Release(&m);
+                    if (k < 0) { free(d); if (!PyErr_Occurred()) PyErr_NoMemory(); fail = 1; break; }
+                    PyObject* rem = remember_token(tokens[2 * C + c]);
+                    if (!rem || PyList_SetItem(new_counts, c, rem) != 0) { free(d); fail = 1; break; }
+                    if (k > 0) {
+                        diff[n_comp] = d; kdiff[n_comp] = (Py_ssize_t)k; comp[n_comp++] = (int)c; K += (Py_ssize_t)k;
+                        by_rows[n_by_rows++] = (int)c;
+                        if (PyDict_SetItem(nw, k_lh_all, Py_None) != 0) { fail = 1; break; }
+                    } else free(d);
+                }
+                if (!fail && K > 0) {
+                    PyObject* idx = OWN(np_empty2(K, -1, g_dt_i32));
+                    PyObject* shape = idx ? OWN(Py_BuildValue("(nnn)", K, Fd, Sd)) : NULL;
+                    PyObject* dt_f32 = shape ? OWN(PyObject_GetAttrString(PyTuple_GET_ITEM(tokens[2 * C + comp[0]], 0), "dtype")) : NULL;
+                    PyObject* rr = dt_f32 ? OWN(PyObject_CallFunctionObjArgs(g_np_empty, shape, dt_f32, NULL)) : NULL;
+                    Py_buffer vi, vr;
+                    if (!rr || PyObject_GetBuffer(idx, &vi, PyBUF_C_CONTIGUOUS | PyBUF_WRITABLE) != 0) fail = 1;
+                    else if (PyObject_GetBuffer(rr, &vr, PyBUF_C_CONTIGUOUS | PyBUF_WRITABLE) != 0) { PyBuffer_Release(&vi); fail = 1; }
+                    else {
+                        if (vi.len != K * 4 || vr.len != K * FS * 4) { PyErr_SetString(PyExc_TypeError, "bind_slot: np.empty scratch of another size"); fail = 1; }
+                        Py_ssize_t j = 0;
+                        for (int i = 0; i < n_comp && !fail; ++i) {
+                            long long o = 0; off_at(&vo, comp[i], &o);
+                            Py_buffer a;
+                            if (PyObject_GetBuffer(PyTuple_GET_ITEM(tokens[2 * C + comp[i]], 0), &a, PyBUF_C_CONTIGUOUS) != 0) { fail = 1; break; }
+                            for (Py_ssize_t q = 0; q < kdiff[i]; ++q, ++j) {
+                                ((int32_t*)vi.buf)[j] = (int32_t)(o + diff[i][q]);
+                                memcpy((char*)vr.buf + j * FS * 4, (const char*)a.buf + (Py_ssize_t)diff[i][q] * FS * 4, (size_t)FS * 4);
+                            }
+                            PyBuffer_Release(&a);
+                        }
+                        PyBuffer_Release(&vi); PyBuffer_Release(&vr);
+                    }
+                    if (!fail && (PyList_Append(pend_idx, idx) != 0 || PyList_Append(pend_rows, rr) != 0)) fail = 1;
+                }
+                for (int i = 0; i < n_comp; ++i) free(diff[i]);
+                PyBuffer_Release(&vo);
+                if (fail) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_RuntimeError, "bind_slot: native count rows"); goto out; }
+            }
+        }
+        if (have_model && !counts_native) {
             for (Py_ssize_t c = 0; c < C; ++c) {
                 if (!((changed >> (2 * C + c)) & 1)) continue;
                 const Py_ssize_t n_pending = PyList_GET_SIZE(pend_idx);
@@ -1345,28 +1447,6 @@ done:
  * (counts_followed, the source lineage notes).  NotImplemented (nothing touched, the Python form serves the call): a sample whose
  * arrays are not plain C-contiguous bool arrays, an object_subset that is neither a bool mask [N] nor a one-dimensional int32
  * array, an object listed twice or in several groups of one component (the reference's two-count difference applies). */
-static PyObject *g_np_empty = NULL, *g_dt_i32 = NULL, *g_dt_u8 = NULL, *g_get_engine = NULL, *g_note_lineage = NULL, *g_source_followed = NULL,
-                *g_apply_rows = NULL;
-static PyObject *s_counts_delta, *s_group_offsets, *k_follow_slot, *k_update_source;
-
-static PyObject* py_update_counts_setup(PyObject* self, PyObject* args) {
-    PyObject *e, *di, *du, *ge, *nl, *sf, *ar;
-    if (!PyArg_ParseTuple(args, "OOOOOOO", &e, &di, &du, &ge, &nl, &sf, &ar)) return NULL;
-    Py_XDECREF(g_np_empty); Py_XDECREF(g_dt_i32); Py_XDECREF(g_dt_u8); Py_XDECREF(g_get_engine); Py_XDECREF(g_note_lineage); Py_XDECREF(g_source_followed); Py_XDECREF(g_apply_rows);
-    Py_INCREF(e); Py_INCREF(di); Py_INCREF(du); Py_INCREF(ge); Py_INCREF(nl); Py_INCREF(sf); Py_INCREF(ar);
-    g_np_empty = e; g_dt_i32 = di; g_dt_u8 = du; g_get_engine = ge; g_note_lineage = nl; g_source_followed = sf; g_apply_rows = ar;
-    Py_RETURN_NONE;
-}
-
-/* np.empty((a, b), dtype) / np.empty((a,), dtype): new reference */
-static PyObject* np_empty2(Py_ssize_t a, Py_ssize_t b, PyObject* dtype) {
-    PyObject* shape = b < 0 ? Py_BuildValue("(n)", a) : Py_BuildValue("(nn)", a, b);
-    if (!shape) return NULL;
-    PyObject* r = PyObject_CallFunctionObjArgs(g_np_empty, shape, dtype, NULL);
-    Py_DECREF(shape);
-    return r;
-}
-
 static PyObject* py_update_counts(PyObject* self, PyObject* args) {
     PyObject *s_old, *s_new, *features, *subset;
     int follow_ok = 0;
