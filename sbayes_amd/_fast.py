@@ -170,3 +170,25 @@ else:
 
     def node_commit(cache):
         cache.set_up_to_date()
+
+
+# ---- classes whose read-only properties the native bind reads from the instance (csrc/sbe_pyhost.c: trust_setup) ----------------
+_TRUSTED = ([], [], [])         # sample classes, parameter classes, confounder prior classes (exact classes)
+
+
+def register_trusted(samples=(), params=(), conf_priors=()):
+    for have, new in zip(_TRUSTED, (samples, params, conf_priors)):
+        for cls in new:
+            if cls not in have:
+                have.append(cls)
+    if _h is not None:
+        _h.trust_setup(*(tuple(x) for x in _TRUSTED))
+
+
+def unregister_trusted(samples=(), params=(), conf_priors=()):
+    for have, gone in zip(_TRUSTED, (samples, params, conf_priors)):
+        for cls in gone:
+            if cls in have:
+                have.remove(cls)
+    if _h is not None:
+        _h.trust_setup(*(tuple(x) for x in _TRUSTED))

@@ -165,6 +165,61 @@ static PyObject* py_touched_groups(PyObject* self, PyObject* args) {
 static PyObject *s_value, *s_version, *s_flags, *s_writeable, *s_owndata;
 static PyObject *g_ndarray = NULL, *g_asarray = NULL, *g_content_equal = NULL;
 
+/* ---- trusted classes: their read-only properties are read where they live --------------------------------------------------------
+ * A bind walks thirteen parameters: sample.clusters / .weights / .source / .feature_counts, every parameter's .value, every
+ * confounder prior's concentration_array(sample) -- Python-level properties and one method that return an instance attribute
+ * (sbayes/sampling/state.py:30-32, 578-592; sbayes/model/prior.py:325-354 for a static prior), 0.4-1 us each where they run, four
+ * binds per MCMC step.  For objects of EXACTLY the classes registered here (trust_setup: sbayes_amd.state's, and the reference's
+ * when the source of those properties is the revision mirrored -- sbayes_amd/patch.py) the attribute is taken from the instance
+ * dictionary instead; any other class, or an instance without that entry, goes through the public name as before. */
+static PyObject *s_shared, *s_resolve_sharing, *s__value, *s_group_versions;
+static PyObject *g_trust_samples = NULL, *g_trust_params = NULL, *g_trust_conf_priors = NULL;
+static PyObject *s__clusters, *s__weights, *s__source, *s__feature_counts, *s__concentration_array, *s_any_dynamic_priors_attr;
+
+static PyObject* py_trust_setup(PyObject* self, PyObject* args) {
+    PyObject *a, *b, *c;
+    if (!PyArg_ParseTuple(args, "O!O!O!", &PyTuple_Type, &a, &PyTuple_Type, &b, &PyTuple_Type, &c)) return NULL;
+    Py_XDECREF(g_trust_samples); Py_XDECREF(g_trust_params); Py_XDECREF(g_trust_conf_priors);
+    Py_INCREF(a); Py_INCREF(b); Py_INCREF(c);
+    g_trust_samples = a; g_trust_params = b; g_trust_conf_priors = c;
+    Py_RETURN_NONE;
+}
+
+static inline int type_in(PyObject* types, PyObject* obj) {
+    if (!types) return 0;
+    const Py_ssize_t n = PyTuple_GET_SIZE(types);
+    for (Py_ssize_t i = 0; i < n; ++i) if ((PyObject*)Py_TYPE(obj) == PyTuple_GET_ITEM(types, i)) return 1;
+    return 0;
+}
+
+/* new reference to obj.__dict__[name], or NULL without an exception */
+static inline PyObject* inst_get(PyObject* obj, PyObject* name) {
+    PyObject** dp = _PyObject_GetDictPtr(obj);
+    if (!dp || !*dp) return NULL;
+    PyObject* v = PyDict_GetItemWithError(*dp, name);
+    if (!v) { PyErr_Clear(); return NULL; }
+    Py_INCREF(v);
+    return v;
+}
+
+/* param.value (new reference) */
+static inline PyObject* param_value(PyObject* param) {
+    if (type_in(g_trust_params, param)) {
+        PyObject* v = inst_get(param, s__value);
+        if (v) return v;
+    }
+    return PyObject_GetAttr(param, s_value);
+}
+
+/* sample.<public> (new reference) */
+static inline PyObject* sample_attr(PyObject* sample, PyObject* private_name, PyObject* public_name) {
+    if (type_in(g_trust_samples, sample)) {
+        PyObject* v = inst_get(sample, private_name);
+        if (v) return v;
+    }
+    return PyObject_GetAttr(sample, public_name);
+}
+
 static PyObject* py_scan_setup(PyObject* self, PyObject* args) {
     PyObject *nd, *asarr, *ceq;
     if (!PyArg_ParseTuple(args, "OOO", &nd, &asarr, &ceq)) return NULL;
@@ -268,7 +323,6 @@ fail:
  * group_versions[group] = version where the row is not all zero -- as ONE call instead of three Python method calls with two
  * fancy-index operations and a reduction each (60 us per MCMC step at the south_america shape).  None: a node that is not in that
  * form (the caller keeps the Python route). */
-static PyObject *s_shared, *s_resolve_sharing, *s__value, *s_group_versions;
 
 static int off_at(const Py_buffer* v, Py_ssize_t i, long long* out) {
     if (v->itemsize == 8) { *out = ((const long long*)v->buf)[i]; return 1; }
@@ -496,7 +550,8 @@ static int token_of(PyObject* param, PyObject* cached, PyObject** tok_out) {
         value = param; Py_INCREF(value);
         version = Py_None; Py_INCREF(version);
     } else {
-        value = PyObject_GetAttr(param, s_value);
+        value = type_in(g_trust_params, param) ? inst_get(param, s__value) : NULL;
+        if (!value) value = PyObject_GetAttr(param, s_value);
         if (!value) {
             if (!PyErr_ExceptionMatches(PyExc_AttributeError)) return -1;
             PyErr_Clear();
@@ -581,7 +636,7 @@ static PyObject* py_bind_slot(PyObject* self, PyObject* args, PyObject* kwargs) 
     PyObject *prior = NULL, *conf_priors = NULL, *feature_counts = NULL, *bound_conc = NULL;
     const int have_model = model != Py_None;
     {
-        PyObject* p = OWN(PyObject_GetAttr(sample, s_clusters));
+        PyObject* p = OWN(sample_attr(sample, s__clusters, s_clusters));
         if (!p) goto out;
         int same = token_of(p, PyList_GET_ITEM(old_groups, 0), &tokens[n_tok]);
         if (same < 0) goto out;
@@ -600,7 +655,7 @@ static PyObject* py_bind_slot(PyObject* self, PyObject* args, PyObject* kwargs) 
         prior = OWN(PyObject_GetAttr(model, s_prior));
         if (!prior) goto out;
         conf_priors = OWN(PyObject_GetAttr(prior, s_prior_confounding_effects));
-        feature_counts = conf_priors ? OWN(PyObject_GetAttr(sample, s_feature_counts)) : NULL;
+        feature_counts = conf_priors ? OWN(sample_attr(sample, s__feature_counts, s_feature_counts)) : NULL;
         bound_conc = feature_counts ? OWN(PyObject_GetAttr(eng, s__bound_conc)) : NULL;
         if (!bound_conc) goto out;
         for (Py_ssize_t c = 0; c < C; ++c) {
@@ -612,7 +667,14 @@ static PyObject* py_bind_slot(PyObject* self, PyObject* args, PyObject* kwargs) 
             } else {
                 PyObject* cp = OWN(PyObject_GetItem(conf_priors, PyList_GET_ITEM(conf_names, c - 1)));
                 if (!cp) goto out;
-                arr = OWN(PyObject_CallMethodObjArgs(cp, s_concentration_array, sample, NULL));
+                arr = NULL;
+                if (type_in(g_trust_conf_priors, cp)) {               /* a static prior's table is an instance attribute (prior.py:325-354) */
+                    PyObject* dyn = inst_get(cp, s_any_dynamic_priors_attr);
+                    if (dyn == Py_False) arr = inst_get(cp, s__concentration_array);
+                    Py_XDECREF(dyn);
+                }
+                if (!arr) arr = PyObject_CallMethodObjArgs(cp, s_concentration_array, sample, NULL);
+                OWN(arr);
             }
             if (!arr) goto out;
             PyObject* ci = PyLong_FromSsize_t(c);
@@ -635,14 +697,14 @@ static PyObject* py_bind_slot(PyObject* self, PyObject* args, PyObject* kwargs) 
     }
     const int at = have_model ? 3 * (int)C : (int)C;
     {
-        PyObject* w = OWN(PyObject_GetAttr(sample, s_weights));
+        PyObject* w = OWN(sample_attr(sample, s__weights, s_weights));
         if (!w) goto out;
         PyObject* ow = PyDict_GetItem(old, k_weights);
         int same = token_of(w, ow ? ow : Py_None, &tokens[n_tok]);
         if (same < 0) goto out;
         OWN(tokens[n_tok]); if (!same) changed |= 1ull << n_tok; ++n_tok;
         if (with_source) {
-            PyObject* src = OWN(PyObject_GetAttr(sample, s_source));
+            PyObject* src = OWN(sample_attr(sample, s__source, s_source));
             if (!src) goto out;
             PyObject* os = PyDict_GetItem(old, k_source);
             same = token_of(src, os ? os : Py_None, &tokens[n_tok]);
@@ -1458,7 +1520,7 @@ static PyObject* py_update_counts(PyObject* self, PyObject* args) {
     PyObject* result = NULL;
     int followed_started = 0;
     PyObject* eng = NULL;
-    PyObject* counts = OWN(PyObject_GetAttr(s_new, s_feature_counts));
+    PyObject* counts = OWN(sample_attr(s_new, s__feature_counts, s_feature_counts));
     PyObject* conf_new = counts ? OWN(PyObject_GetAttr(s_new, s_confounders)) : NULL;
     PyObject* conf_old = conf_new ? OWN(PyObject_GetAttr(s_old, s_confounders)) : NULL;
     PyObject* conf_names = conf_old ? OWN(PySequence_List(conf_new)) : NULL;
@@ -1477,10 +1539,10 @@ static PyObject* py_update_counts(PyObject* self, PyObject* args) {
     for (Py_ssize_t c = 0; c < C; ++c) {
         PyObject *gn, *go;
         if (c == 0) {
-            PyObject* p = OWN(PyObject_GetAttr(s_new, s_clusters));
-            gn = p ? OWN(PyObject_GetAttr(p, s_value)) : NULL;
-            PyObject* q = gn ? OWN(PyObject_GetAttr(s_old, s_clusters)) : NULL;
-            go = q ? OWN(PyObject_GetAttr(q, s_value)) : NULL;
+            PyObject* p = OWN(sample_attr(s_new, s__clusters, s_clusters));
+            gn = p ? OWN(param_value(p)) : NULL;
+            PyObject* q = gn ? OWN(sample_attr(s_old, s__clusters, s_clusters)) : NULL;
+            go = q ? OWN(param_value(q)) : NULL;
         } else {
             PyObject* k = PyList_GET_ITEM(conf_names, c - 1);
             PyObject* p = OWN(PyObject_GetItem(conf_new, k));
@@ -1507,10 +1569,10 @@ static PyObject* py_update_counts(PyObject* self, PyObject* args) {
         PyList_SET_ITEM(n_groups, c, g);
     }
     /* source of both samples: plain C-contiguous bool [N, F, C] */
-    PyObject* sp_new = OWN(PyObject_GetAttr(s_new, s_source));
-    PyObject* src_new = sp_new ? OWN(PyObject_GetAttr(sp_new, s_value)) : NULL;
-    PyObject* sp_old = src_new ? OWN(PyObject_GetAttr(s_old, s_source)) : NULL;
-    PyObject* src_old = sp_old ? OWN(PyObject_GetAttr(sp_old, s_value)) : NULL;
+    PyObject* sp_new = OWN(sample_attr(s_new, s__source, s_source));
+    PyObject* src_new = sp_new ? OWN(param_value(sp_new)) : NULL;
+    PyObject* sp_old = src_new ? OWN(sample_attr(s_old, s__source, s_source)) : NULL;
+    PyObject* src_old = sp_old ? OWN(param_value(sp_old)) : NULL;
     if (!src_old) goto out;
     if ((PyObject*)Py_TYPE(src_new) != g_ndarray || (PyObject*)Py_TYPE(src_old) != g_ndarray) goto unsupported;
     if (!get_c(src_new, &vb[nb], 3, 1, 0)) goto unsupported;
@@ -1723,6 +1785,7 @@ static PyMethodDef methods[] = {
     {"store_per_object", py_store_per_object, METH_VARARGS, "SourcePrior.__call__'s cache update: store_per_object(cache, n_objects, values, caching=True)"},
     {"update_counts_setup", py_update_counts_setup, METH_VARARGS, "update_counts_setup(np.empty, int32 dtype, uint8 dtype, get_engine, note_source_lineage, _source_followed, apply_count_rows)"},
     {"update_counts", py_update_counts, METH_VARARGS, "counts.update_feature_counts in C: update_counts(sample_old, sample_new, features, object_subset, follow_ok)"},
+    {"trust_setup", py_trust_setup, METH_VARARGS, "trust_setup(sample classes, parameter classes, confounder prior classes): exact classes whose read-only properties are read from the instance"},
     {"copy_rows", py_copy_rows, METH_VARARGS, "dst[idx] = src[idx] (rows of two same-shaped C-contiguous arrays)"},
     {NULL, NULL, 0, NULL}};
 
@@ -1789,6 +1852,13 @@ PyMODINIT_FUNC PyInit__sbe_pyhost(void) {
     k_counts_key = PyUnicode_InternFromString("counts");
     k_weights_key = PyUnicode_InternFromString("weights");
     k_source_key = PyUnicode_InternFromString("source");
+    s__clusters = PyUnicode_InternFromString("_clusters");
+    s__weights = PyUnicode_InternFromString("_weights");
+    s__source = PyUnicode_InternFromString("_source");
+    s__feature_counts = PyUnicode_InternFromString("_feature_counts");
+    s__concentration_array = PyUnicode_InternFromString("_concentration_array");
+    s_any_dynamic_priors_attr = PyUnicode_InternFromString("any_dynamic_priors");
+    if (!s__clusters || !s__weights || !s__source || !s__feature_counts || !s__concentration_array || !s_any_dynamic_priors_attr) return NULL;
     s_counts_delta = PyUnicode_InternFromString("counts_delta");
     s_group_offsets = PyUnicode_InternFromString("group_offsets");
     k_follow_slot = PyUnicode_InternFromString("follow_slot");

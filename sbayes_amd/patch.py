@@ -70,6 +70,13 @@ MIRRORED_SOURCES = {
     "CacheNode.edit": "f97842f4ecfda2357d10973488fedec3bf0f4415",
     "CacheNode.version": "9f3783fe9344800ec2dd6711a391f439d17a9020",
     "CacheNode.value": "2c599b691219e9e677be97749fab9ee166bf0018",
+    # read-only properties the native bind reads from the instance (_register_trusted_classes)
+    "Sample.clusters": "1c35d1fc15ec7e57e6f30149f4f21bdd0eebe6c7",
+    "Sample.weights": "f122fc33db30aa3a14db2a268452a137ad71f5cc",
+    "Sample.source": "a40fb15cd7c42bd6982c31b029f11cd455c1c9d3",
+    "Sample.feature_counts": "086f7821a38fd065ba46bd69d7a710c18beeeb26",
+    "Parameter.value": "2c599b691219e9e677be97749fab9ee166bf0018",
+    "ConfoundingEffectsPrior.concentration_array": "a089466a31285e330baf46ecc81f435fcd63a359",
 }
 
 
@@ -177,6 +184,7 @@ def install(operators=False, mp_start_method=None, gibbs_source=False):
         swap(mod, "update_feature_counts", my_counts.update_feature_counts)
     _install_sparse_add_changes()
     _register_cache_nodes()
+    _register_trusted_classes()
     if operators:
         _install_operator_forms(swap)
     if gibbs_source:
@@ -216,6 +224,46 @@ def _register_cache_nodes():
         return
     _fast.register_node_classes(cls, grouped)
     _NODE_CLASSES.append((cls, grouped))
+
+
+_TRUSTED_CLASSES = []
+
+
+def _register_trusted_classes():
+    """The reference's Sample.clusters / .weights / .source / .feature_counts and Parameter.value are properties that return the
+    attribute of the same name with a leading underscore (sbayes/sampling/state.py:30-32, 578-592), and a static
+    ConfoundingEffectsPrior.concentration_array(sample) returns self._concentration_array (sbayes/model/prior.py:325-354).  The
+    native bind (csrc/sbe_pyhost.c) reads those attributes from the instance for objects of EXACTLY these classes -- registered
+    only when the source of each property / method is the revision mirrored, and no parameter subclass overrides `value`."""
+    from . import _fast
+
+    def same(owner, name, key):
+        obj = inspect.getattr_static(owner, name)
+        if isinstance(obj, property):
+            obj = obj.fget
+        return source_digest(obj) == MIRRORED_SOURCES[key]
+
+    samples, params, conf_priors = [], [], []
+    try:
+        state = importlib.import_module("sbayes.sampling.state")
+        if all(same(state.Sample, n, f"Sample.{n}") for n in ("clusters", "weights", "source", "feature_counts")):
+            samples.append(state.Sample)
+        if same(state.Parameter, "value", "Parameter.value"):
+            base = inspect.getattr_static(state.Parameter, "value")
+            for name in ("ArrayParameter", "GroupedParameters", "Clusters", "FeatureCounts"):
+                cls = getattr(state, name, None)
+                if inspect.isclass(cls) and inspect.getattr_static(cls, "value") is base:
+                    params.append(cls)
+    except (ImportError, AttributeError, OSError, TypeError):
+        pass
+    try:
+        prior = importlib.import_module("sbayes.model.prior")
+        if same(prior.ConfoundingEffectsPrior, "concentration_array", "ConfoundingEffectsPrior.concentration_array"):
+            conf_priors.append(prior.ConfoundingEffectsPrior)
+    except (ImportError, AttributeError, OSError, TypeError):
+        pass
+    _fast.register_trusted(samples, params, conf_priors)
+    _TRUSTED_CLASSES.append((samples, params, conf_priors))
 
 
 def _install_sparse_add_changes():
@@ -422,3 +470,6 @@ def uninstall():
     while _NODE_CLASSES:
         from . import _fast
         _fast.unregister_node_classes(*_NODE_CLASSES.pop())
+    while _TRUSTED_CLASSES:
+        from . import _fast
+        _fast.unregister_trusted(*_TRUSTED_CLASSES.pop())
