@@ -161,7 +161,11 @@ if _h is not None:
     node_outdated = _h.node_outdated
     node_changed = _h.node_changed
     node_commit = _h.node_commit
+    node_update_value = _h.node_update_value
 else:
+    def node_update_value(cache, value):
+        cache.update_value(value)
+
     def node_outdated(cache):
         return cache.is_outdated()
 
@@ -173,11 +177,11 @@ else:
 
 
 # ---- classes whose read-only properties the native bind reads from the instance (csrc/sbe_pyhost.c: trust_setup) ----------------
-_TRUSTED = ([], [], [])         # sample classes, parameter classes, confounder prior classes (exact classes)
+_TRUSTED = ([], [], [], [])     # sample, parameter, confounder prior classes; count classes with the plain resolve_sharing (exact classes)
 
 
-def register_trusted(samples=(), params=(), conf_priors=()):
-    for have, new in zip(_TRUSTED, (samples, params, conf_priors)):
+def register_trusted(samples=(), params=(), conf_priors=(), counts=()):
+    for have, new in zip(_TRUSTED, (samples, params, conf_priors, counts)):
         for cls in new:
             if cls not in have:
                 have.append(cls)
@@ -185,8 +189,8 @@ def register_trusted(samples=(), params=(), conf_priors=()):
         _h.trust_setup(*(tuple(x) for x in _TRUSTED))
 
 
-def unregister_trusted(samples=(), params=(), conf_priors=()):
-    for have, gone in zip(_TRUSTED, (samples, params, conf_priors)):
+def unregister_trusted(samples=(), params=(), conf_priors=(), counts=()):
+    for have, gone in zip(_TRUSTED, (samples, params, conf_priors, counts)):
         for cls in gone:
             if cls in have:
                 have.remove(cls)

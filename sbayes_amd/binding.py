@@ -165,6 +165,8 @@ _LINEAGE_KEPT = 6
 
 
 def _rows32(rows):
+    if type(rows) is _ndarray and rows.dtype == np.int32 and rows.ndim == 1 and rows.flags.c_contiguous:
+        return rows
     rows = np.asarray(rows)
     if rows.dtype == np.bool_:
         rows = np.flatnonzero(rows)
@@ -177,7 +179,7 @@ def note_source_lineage(parent_tok, child_tok, rows):
     """content(child) == content(parent) outside `rows` (object indices).  Versioned tokens only."""
     p_arr, p_ver = parent_tok
     c_arr, c_ver = child_tok
-    if p_ver is None or c_ver is None or (p_arr is c_arr and p_ver == c_ver) or np.shape(p_arr) != np.shape(c_arr):
+    if p_ver is None or c_ver is None or (p_arr is c_arr and p_ver == c_ver) or p_arr.shape != c_arr.shape:
         return None
     rec = (c_arr, c_ver, p_arr, p_ver, _rows32(rows))
     _LINEAGE.append(rec)

@@ -172,16 +172,16 @@ static PyObject *g_ndarray = NULL, *g_asarray = NULL, *g_content_equal = NULL;
  * binds per MCMC step.  For objects of EXACTLY the classes registered here (trust_setup: sbayes_amd.state's, and the reference's
  * when the source of those properties is the revision mirrored -- sbayes_amd/patch.py) the attribute is taken from the instance
  * dictionary instead; any other class, or an instance without that entry, goes through the public name as before. */
-static PyObject *s_shared, *s_resolve_sharing, *s__value, *s_group_versions;
-static PyObject *g_trust_samples = NULL, *g_trust_params = NULL, *g_trust_conf_priors = NULL;
+static PyObject *s_shared, *s_resolve_sharing, *s__value, *s_group_versions, *s_copy_method;
+static PyObject *g_trust_samples = NULL, *g_trust_params = NULL, *g_trust_conf_priors = NULL, *g_trust_counts = NULL;
 static PyObject *s__clusters, *s__weights, *s__source, *s__feature_counts, *s__concentration_array, *s_any_dynamic_priors_attr;
 
 static PyObject* py_trust_setup(PyObject* self, PyObject* args) {
-    PyObject *a, *b, *c;
-    if (!PyArg_ParseTuple(args, "O!O!O!", &PyTuple_Type, &a, &PyTuple_Type, &b, &PyTuple_Type, &c)) return NULL;
-    Py_XDECREF(g_trust_samples); Py_XDECREF(g_trust_params); Py_XDECREF(g_trust_conf_priors);
-    Py_INCREF(a); Py_INCREF(b); Py_INCREF(c);
-    g_trust_samples = a; g_trust_params = b; g_trust_conf_priors = c;
+    PyObject *a, *b, *c, *d;
+    if (!PyArg_ParseTuple(args, "O!O!O!O!", &PyTuple_Type, &a, &PyTuple_Type, &b, &PyTuple_Type, &c, &PyTuple_Type, &d)) return NULL;
+    Py_XDECREF(g_trust_samples); Py_XDECREF(g_trust_params); Py_XDECREF(g_trust_conf_priors); Py_XDECREF(g_trust_counts);
+    Py_INCREF(a); Py_INCREF(b); Py_INCREF(c); Py_INCREF(d);
+    g_trust_samples = a; g_trust_params = b; g_trust_conf_priors = c; g_trust_counts = d;
     Py_RETURN_NONE;
 }
 
@@ -406,9 +406,22 @@ static PyObject* py_add_rows_many(PyObject* self, PyObject* args) {
         Py_DECREF(shared);
         if (is_shared < 0) { Py_CLEAR(result); goto done; }
         if (is_shared) {
-            PyObject* rr = PyObject_CallMethodNoArgs(node, s_resolve_sharing);
-            if (!rr) { Py_CLEAR(result); goto done; }
-            Py_DECREF(rr);
+            if (type_in(g_trust_counts, node)) {
+                /* GroupedParameters.resolve_sharing (state.py:166-168 over :82-84) of a registered count class:
+                   group_versions = group_versions.copy(); _value = _value.copy(); shared = False */
+                PyObject* gv = PyObject_GetAttr(node, s_group_versions);
+                PyObject* gv2 = gv ? PyObject_CallMethodNoArgs(gv, s_copy_method) : NULL;
+                PyObject* v0 = gv2 ? PyObject_GetAttr(node, s__value) : NULL;
+                PyObject* v2 = v0 ? PyObject_CallMethodNoArgs(v0, s_copy_method) : NULL;
+                const int bad = !v2 || PyObject_SetAttr(node, s_group_versions, gv2) != 0 || PyObject_SetAttr(node, s__value, v2) != 0 ||
+                                PyObject_SetAttr(node, s_shared, Py_False) != 0;
+                Py_XDECREF(gv); Py_XDECREF(gv2); Py_XDECREF(v0); Py_XDECREF(v2);
+                if (bad) { Py_CLEAR(result); goto done; }
+            } else {
+                PyObject* rr = PyObject_CallMethodNoArgs(node, s_resolve_sharing);
+                if (!rr) { Py_CLEAR(result); goto done; }
+                Py_DECREF(rr);
+            }
         }
         PyObject* ver = PyObject_GetAttr(node, s_version);
         if (!ver) { Py_CLEAR(result); goto done; }
@@ -1102,7 +1115,8 @@ static PyObject* py_counts_followed(PyObject* self, PyObject* args) {
  * NumPy operations: tools/host_residual.py).  The functions below do exactly what those methods do, attribute by attribute, for
  * nodes whose class is one of the REGISTERED ones (node_setup: the reference's CacheNode when its methods' source digests are the
  * mirrored ones -- sbayes_amd/patch.py -- and sbayes_amd.state.CacheNode); for any other node they call the node's own method. */
-static PyObject *g_plain_nodes = NULL, *g_grouped = NULL, *g_empty_i64 = NULL;
+static PyObject *g_plain_nodes = NULL, *g_grouped = NULL, *g_empty_i64 = NULL, *g_node_version_props = NULL;
+static PyObject *s_update_value;
 static PyObject *s_inputs, *s_input_idx, *s_cached_version, *s_cached_group_versions, *s_copy, *s_is_outdated, *s_what_changed,
                 *s_set_up_to_date, *s_ahead_of, *s_cache, *s_group_likelihoods, *s_sum, *s_any_dynamic_priors, *s_n_groups, *s_caching,
                 *k_universal_counts, *k_counts_key, *k_weights_key, *k_source_key;
@@ -1110,9 +1124,19 @@ static PyObject *s_inputs, *s_input_idx, *s_cached_version, *s_cached_group_vers
 static PyObject* py_node_setup(PyObject* self, PyObject* args) {
     PyObject *plain, *grouped, *empty;
     if (!PyArg_ParseTuple(args, "O!O!O", &PyTuple_Type, &plain, &PyTuple_Type, &grouped, &empty)) return NULL;
-    Py_XDECREF(g_plain_nodes); Py_XDECREF(g_grouped); Py_XDECREF(g_empty_i64);
+    /* the `version` property objects of the registered classes (what a subclass that does not override it inherits) */
+    PyObject* props = PyTuple_New(PyTuple_GET_SIZE(plain));
+    if (!props) return NULL;
+    for (Py_ssize_t i = 0; i < PyTuple_GET_SIZE(plain); ++i) {
+        PyObject* cls = PyTuple_GET_ITEM(plain, i);
+        PyObject* d = PyType_Check(cls) ? _PyType_Lookup((PyTypeObject*)cls, s_version) : NULL;
+        if (!d) d = Py_None;
+        Py_INCREF(d);
+        PyTuple_SET_ITEM(props, i, d);
+    }
+    Py_XDECREF(g_plain_nodes); Py_XDECREF(g_grouped); Py_XDECREF(g_empty_i64); Py_XDECREF(g_node_version_props);
     Py_INCREF(plain); Py_INCREF(grouped); Py_INCREF(empty);
-    g_plain_nodes = plain; g_grouped = grouped; g_empty_i64 = empty;
+    g_plain_nodes = plain; g_grouped = grouped; g_empty_i64 = empty; g_node_version_props = props;
     Py_RETURN_NONE;
 }
 
@@ -1136,7 +1160,15 @@ static PyObject* node_version(PyObject* cache) {
     while (ok && (key = PyIter_Next(it)) != NULL) {
         PyObject* inpt = PyObject_GetItem(inputs, key);
         Py_DECREF(key);
-        PyObject* v = inpt ? PyObject_GetAttr(inpt, s_version) : NULL;
+        PyObject* v = NULL;
+        if (inpt) {
+            /* an input that is itself a cache node whose `version` is the registered classes' property (HasComponents inherits
+               it): the same tuple, built here instead of by the property's generator */
+            PyObject* desc = g_node_version_props ? _PyType_Lookup(Py_TYPE(inpt), s_version) : NULL;      /* borrowed */
+            int nested = 0;
+            if (desc) for (Py_ssize_t j = 0; j < PyTuple_GET_SIZE(g_node_version_props); ++j) if (desc == PyTuple_GET_ITEM(g_node_version_props, j)) nested = 1;
+            v = nested ? node_version(inpt) : PyObject_GetAttr(inpt, s_version);
+        }
         Py_XDECREF(inpt);
         if (!v || i >= n) { Py_XDECREF(v); ok = 0; break; }
         PyTuple_SET_ITEM(tup, i++, v);
@@ -1300,6 +1332,15 @@ static PyObject* py_node_outdated(PyObject* self, PyObject* cache) {
     const int b = node_outdated(cache);
     if (b < 0) return NULL;
     return PyBool_FromLong(b);
+}
+
+/* cache.update_value(value)  (state.py:261-263) */
+static PyObject* py_node_update_value(PyObject* self, PyObject* args) {
+    PyObject *cache, *value;
+    if (!PyArg_ParseTuple(args, "OO", &cache, &value)) return NULL;
+    if (!node_is_plain(cache)) return PyObject_CallMethodOneArg(cache, s_update_value, value);
+    if (PyObject_SetAttr(cache, s__value, value) != 0 || node_commit(cache) != 0) return NULL;
+    Py_RETURN_NONE;
 }
 
 static PyObject* py_node_commit(PyObject* self, PyObject* cache) {
@@ -1780,6 +1821,7 @@ static PyMethodDef methods[] = {
     {"node_setup", py_node_setup, METH_VARARGS, "node_setup(plain CacheNode classes, GroupedParameters classes, empty_i64)"},
     {"node_outdated", py_node_outdated, METH_O, "cache.is_outdated()"},
     {"node_commit", py_node_commit, METH_O, "cache.set_up_to_date()"},
+    {"node_update_value", py_node_update_value, METH_VARARGS, "cache.update_value(value)"},
     {"node_changed", py_node_changed, METH_VARARGS, "cache.what_changed(key, caching=True) for one key -> int64 ndarray"},
     {"likelihood_call", py_likelihood_call, METH_VARARGS, "Likelihood.__call__'s caching path: likelihood_call(lik, sample, names, off, all_fn)"},
     {"store_per_object", py_store_per_object, METH_VARARGS, "SourcePrior.__call__'s cache update: store_per_object(cache, n_objects, values, caching=True)"},
@@ -1833,6 +1875,8 @@ PyMODINIT_FUNC PyInit__sbe_pyhost(void) {
     s_resolve_sharing = PyUnicode_InternFromString("resolve_sharing");
     s__value = PyUnicode_InternFromString("_value");
     s_group_versions = PyUnicode_InternFromString("group_versions");
+    s_update_value = PyUnicode_InternFromString("update_value");
+    if (!s_update_value) return NULL;
     s_inputs = PyUnicode_InternFromString("inputs");
     s_input_idx = PyUnicode_InternFromString("input_idx");
     s_cached_version = PyUnicode_InternFromString("cached_version");
@@ -1852,6 +1896,8 @@ PyMODINIT_FUNC PyInit__sbe_pyhost(void) {
     k_counts_key = PyUnicode_InternFromString("counts");
     k_weights_key = PyUnicode_InternFromString("weights");
     k_source_key = PyUnicode_InternFromString("source");
+    s_copy_method = PyUnicode_InternFromString("copy");
+    if (!s_copy_method) return NULL;
     s__clusters = PyUnicode_InternFromString("_clusters");
     s__weights = PyUnicode_InternFromString("_weights");
     s__source = PyUnicode_InternFromString("_source");

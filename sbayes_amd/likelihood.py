@@ -480,8 +480,9 @@ def update_weights(sample, caching=True, features=None):
     returned as a lazily materialised array (NormalizedWeights)."""
     cache = sample.cache.weights_normalized
     if (not caching) or _fast.node_outdated(cache):
-        cache.update_value(NormalizedWeights(sample.weights.value, sample.cache.has_components.value, features, owner=sample))
-        return cache.value
+        value = NormalizedWeights(sample.weights.value, sample.cache.has_components.value, features, owner=sample)
+        _fast.node_update_value(cache, value)
+        return value
     value = cache.value
     if type(value) is NormalizedWeights:
         # the node travels from sample to sample (Sample.copy -> CacheNode.assign_from shares the immutable value), so the sample

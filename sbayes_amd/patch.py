@@ -67,6 +67,7 @@ MIRRORED_SOURCES = {
     "CacheNode.ahead_of": "5cc191e87c93f012e12e18dda747d0d29c5f63de",
     "CacheNode.what_changed": "897c8ba27633cf13b1a96dee47fba5a662c43cc7",
     "CacheNode.set_up_to_date": "3d3d7d5348f3e7d579936415b3c978a88b910a54",
+    "CacheNode.update_value": "207072adb3b1f5857f9751156541e3b11d2fa7cf",
     "CacheNode.edit": "f97842f4ecfda2357d10973488fedec3bf0f4415",
     "CacheNode.version": "9f3783fe9344800ec2dd6711a391f439d17a9020",
     "CacheNode.value": "2c599b691219e9e677be97749fab9ee166bf0018",
@@ -77,6 +78,8 @@ MIRRORED_SOURCES = {
     "Sample.feature_counts": "086f7821a38fd065ba46bd69d7a710c18beeeb26",
     "Parameter.value": "2c599b691219e9e677be97749fab9ee166bf0018",
     "ConfoundingEffectsPrior.concentration_array": "a089466a31285e330baf46ecc81f435fcd63a359",
+    "ArrayParameter.resolve_sharing": "9456c9d76c849a1e341c66b73e69d630c52fb3bf",
+    "GroupedParameters.resolve_sharing": "e26fbdc96e79af850e2840a33297ddb0d997d967",
 }
 
 
@@ -214,7 +217,7 @@ def _register_cache_nodes():
     try:
         state = importlib.import_module("sbayes.sampling.state")
         cls, grouped = state.CacheNode, state.GroupedParameters
-        for name in ("is_outdated", "ahead_of", "what_changed", "set_up_to_date", "edit", "version", "value"):
+        for name in ("is_outdated", "ahead_of", "what_changed", "set_up_to_date", "update_value", "edit", "version", "value"):
             obj = inspect.getattr_static(cls, name)
             if isinstance(obj, property):
                 obj = obj.fget
@@ -243,9 +246,14 @@ def _register_trusted_classes():
             obj = obj.fget
         return source_digest(obj) == MIRRORED_SOURCES[key]
 
-    samples, params, conf_priors = [], [], []
+    samples, params, conf_priors, count_classes = [], [], [], []
     try:
         state = importlib.import_module("sbayes.sampling.state")
+        # FeatureCounts' copy-on-write step (add_changes -> resolve_sharing) in the native add_rows_many: the inherited two-liner
+        if (same(state.ArrayParameter, "resolve_sharing", "ArrayParameter.resolve_sharing")
+                and same(state.GroupedParameters, "resolve_sharing", "GroupedParameters.resolve_sharing")
+                and inspect.getattr_static(state.FeatureCounts, "resolve_sharing") is inspect.getattr_static(state.GroupedParameters, "resolve_sharing")):
+            count_classes.append(state.FeatureCounts)
         if all(same(state.Sample, n, f"Sample.{n}") for n in ("clusters", "weights", "source", "feature_counts")):
             samples.append(state.Sample)
         if same(state.Parameter, "value", "Parameter.value"):
@@ -262,8 +270,8 @@ def _register_trusted_classes():
             conf_priors.append(prior.ConfoundingEffectsPrior)
     except (ImportError, AttributeError, OSError, TypeError):
         pass
-    _fast.register_trusted(samples, params, conf_priors)
-    _TRUSTED_CLASSES.append((samples, params, conf_priors))
+    _fast.register_trusted(samples, params, conf_priors, count_classes)
+    _TRUSTED_CLASSES.append((samples, params, conf_priors, count_classes))
 
 
 def _install_sparse_add_changes():

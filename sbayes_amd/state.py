@@ -471,4 +471,4 @@ from . import _fast as _fast_mod  # noqa: E402
 _fast_mod.register_node_classes(CacheNode, GroupedParameters)
 # ... and these classes' read-only properties (Sample.clusters / .weights / .source / .feature_counts, the parameters' .value) are
 # read from the instance by the native bind: each returns the attribute of the same name with a leading underscore
-_fast_mod.register_trusted(samples=(Sample,), params=(ArrayParameter, GroupedParameters, Clusters, FeatureCounts))
+_fast_mod.register_trusted(samples=(Sample,), params=(ArrayParameter, GroupedParameters, Clusters, FeatureCounts), counts=(FeatureCounts,))

@@ -204,7 +204,16 @@ def _run(config_path: Path, tag: str, n_steps: int, seed: int, mode: str, memo=N
         if mode == "memo":
             get_engine = make_get_engine(engines, MemoEngine)
         else:
+            last = [None, None]                                      # (the identity fast path of registry.get_engine)
+
             def get_engine(features, n_groups=None, n_slots=4, device=None):
+                if last[0] is features and (n_groups is None or list(n_groups) == last[1].n_groups):
+                    return last[1]
+                eng = get_engine_by_key(features, n_groups)
+                last[0], last[1] = features, eng
+                return eng
+
+            def get_engine_by_key(features, n_groups=None):
                 key = (np.asarray(features).ctypes.data, np.asarray(features).shape)
                 if key not in engines:
                     f = np.asarray(features)
