@@ -103,6 +103,8 @@ def diff_rows_among(new, mirror, cand_a, cand_b=None):
     if k == -2:                                       # not built, or the candidates are not int32: the same with NumPy
         cand = np.asarray(cand_a).reshape(-1) if cand_b is None else np.concatenate([np.asarray(cand_a).reshape(-1), np.asarray(cand_b).reshape(-1)])
         cand = np.unique(cand.astype(np.int64))
+        if cand.size == 0:
+            return np.zeros(0, dtype=np.int32)
         if cand.size and (cand[0] < 0 or cand[-1] >= n_rows):
             raise ValueError("diff_rows_among: row index out of range")
         differs = (new[cand] != mirror[cand]).reshape(cand.size, -1).any(axis=1)
