@@ -20,9 +20,9 @@ from tests._fake_engine import make_get_engine
 ext = pytest.mark.skipif(not _fast.HAVE_EXTENSION, reason="sbayes_amd._sbe_pyhost is not built")
 
 
-def _problem(monkeypatch, engines, seed=3):
+def _problem(monkeypatch, engines, seed=3, cls=None):
     wl = make_workload("cfg1", state_seed=seed)
-    get_engine = make_get_engine(engines)
+    get_engine = make_get_engine(engines, cls)
     for mod in (registry, likelihood, conditionals, my_counts, binding):
         monkeypatch.setattr(mod, "get_engine", get_engine, raising=True)
     names = ["clusters"] + [f"conf{i}" for i in range(1, wl.n_components)]
@@ -57,7 +57,10 @@ def _move(rng, sample, wl):
     n = wl.shape[0]
     obj = int(rng.integers(0, n))
     k = int(rng.integers(0, new.clusters.value.shape[0]))
-    with new.clusters.edit_cluster(k) as c:
+    member_of = np.flatnonzero(new.clusters.value[:, obj])
+    if member_of.size:                                           # leaves its cluster ...
+        k = int(member_of[0])
+    with new.clusters.edit_cluster(k) as c:                       # ... or joins cluster k (never two clusters at once)
         c[obj] = not c[obj]
     objs = np.unique(np.concatenate([[obj], rng.integers(0, n, size=int(rng.integers(0, 3)))])).astype(np.int32)
     src = new.source.value[objs].copy()
