@@ -67,3 +67,38 @@ def test_operator_forms_install_and_uninstall():
         patch.uninstall()
     assert ref_ops.GibbsSampleWeights.__dict__["source_lh_by_feature"] is orig_static
     assert ref_prior.SourcePrior.__dict__["__call__"] is orig_sp and ref_prior.update_weights is orig_uw
+
+
+def test_native_protocol_is_registered_only_for_the_mirrored_revision(monkeypatch):
+    """patch.install() hands the reference's CacheNode / Sample / parameter / prior classes to the native host flow
+    (csrc/sbe_pyhost.c: node_*, trust_setup) only while the source of every method it stands in for is the revision mirrored
+    (patch.MIRRORED_SOURCES); a differing method leaves the class unregistered -- the nodes' own methods serve -- and uninstall()
+    takes the registrations back."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import _ref_stubs
+    _ref_stubs.install()
+    import sbayes.model.prior as ref_prior
+    import sbayes.sampling.state as ref_state
+
+    from sbayes_amd import _fast, patch
+    patch.install(operators=True)
+    try:
+        assert ref_state.CacheNode in _fast._NODE_PLAIN and ref_state.GroupedParameters in _fast._NODE_GROUPED
+        samples, params, conf_priors, count_classes = _fast._TRUSTED
+        assert ref_state.Sample in samples and ref_state.FeatureCounts in params and ref_state.Clusters in params
+        assert ref_prior.ConfoundingEffectsPrior in conf_priors and ref_state.FeatureCounts in count_classes
+        assert ref_state.HasComponents not in _fast._NODE_PLAIN                  # (overrides `value`: never by exact-class match)
+    finally:
+        patch.uninstall()
+    assert ref_state.CacheNode not in _fast._NODE_PLAIN and ref_state.Sample not in _fast._TRUSTED[0]
+    # another revision of one method: nothing of that family is registered
+    monkeypatch.setitem(patch.MIRRORED_SOURCES, "CacheNode.what_changed", "0" * 40)
+    monkeypatch.setitem(patch.MIRRORED_SOURCES, "Sample.source", "0" * 40)
+    monkeypatch.setitem(patch.MIRRORED_SOURCES, "GroupedParameters.resolve_sharing", "0" * 40)
+    patch.install(operators=True)
+    try:
+        assert ref_state.CacheNode not in _fast._NODE_PLAIN
+        assert ref_state.Sample not in _fast._TRUSTED[0] and ref_state.FeatureCounts not in _fast._TRUSTED[3]
+        assert ref_state.FeatureCounts in _fast._TRUSTED[1]                       # (Parameter.value is still the mirrored one)
+    finally:
+        patch.uninstall()

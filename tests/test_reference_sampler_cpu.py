@@ -183,6 +183,32 @@ def test_reference_sampler_without_the_following_slot(monkeypatch, tmp_path):
     assert rows_following < rows_sent, (rows_following, rows_sent)
 
 
+def test_reference_sampler_when_the_native_protocol_is_not_registered(monkeypatch, tmp_path):
+    """An installed sBayes whose CacheNode / Sample / parameter methods are ANOTHER revision than the one the native host flow
+    mirrors (patch.MIRRORED_SOURCES): its classes stay unregistered, the extension's functions call the nodes' own methods or
+    hand the call to the Python forms (likelihood_call / store_per_object -> NotImplemented) -- and the chain is still the
+    reference's, bit for bit, with the extension built."""
+    from sbayes_amd import _fast, patch
+    for key in list(patch.MIRRORED_SOURCES):
+        if key.split(".")[0] in ("CacheNode", "Sample", "Parameter", "ArrayParameter", "GroupedParameters", "ConfoundingEffectsPrior"):
+            monkeypatch.setitem(patch.MIRRORED_SOURCES, key, "0" * 40)
+    src, tag, n_steps = Path(REF) / "test" / "test_files", "test_files", 150
+    plain = run_chain(src, tag, n_steps, 11, False, monkeypatch, tmp_path)
+    registered = []
+    real_install = patch.install
+
+    def install(*a, **k):
+        real_install(*a, **k)
+        registered.append((list(_fast._NODE_PLAIN), [list(x) for x in _fast._TRUSTED]))
+    monkeypatch.setattr(patch, "install", install)
+    patched = run_chain(src, tag, n_steps, 11, True, monkeypatch, tmp_path, operators=True)
+    import sbayes.sampling.state as ref_state
+    assert registered and ref_state.CacheNode not in registered[0][0] and ref_state.Sample not in registered[0][1][0]
+    assert [t[2] for t in patched[0]] == [t[2] for t in plain[0]]
+    np.testing.assert_allclose([t[:2] for t in patched[0]], [t[:2] for t in plain[0]], rtol=1e-12)
+    assert np.array_equal(patched[1], plain[1]) and np.array_equal(patched[2], plain[2]) and np.array_equal(patched[3], plain[3])
+
+
 def test_operator_forms_are_tied_to_the_reference_bodies_they_mirror(monkeypatch):
     """patch.install(operators=True) replaces whole reference methods; each replacement is tied to the SHA-1 of the
     reference body it mirrors (patch.MIRRORED_SOURCES), so a reference revision that changes one of them is reported
