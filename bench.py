@@ -769,18 +769,19 @@ def roofline_block(b_eval, unique_bytes, B, kern_ms, traffic, valu, kernel_name,
       frac_contract  SURVEY.md 8(d)'s per-eval bytes x evals per launch (the shared block counted once PER EVAL): exceeds 1
                      for a batched kernel, so it is no roofline fraction; kept for the contract, never as `frac`.
       frac_traffic   what the memory counters saw (static PMC passes; None when no pass of this build is committed).
-    `bound` names the pipe that limits the kernel: "valu" when the vector-issue fraction (roofline_valu) exceeds both
-    memory fractions, else "hbm"."""
+    `bound` is the roofline these figures are priced against -- "hbm" (GB/s against 8 TB/s), one of the two the bench contract
+    names; `limiter` names the pipe that actually limits the kernel: "valu" when the vector-issue fraction (roofline_valu) exceeds
+    both memory fractions, else "hbm"."""
     kern_s = kern_ms * 1e-3
     achieved = unique_bytes / kern_s / 1e9
     frac = achieved / HBM_PEAK_GBS
     contract = b_eval * B / kern_s / 1e9
     frac_traffic = traffic["bytes_per_launch"] / kern_s / 1e9 / HBM_PEAK_GBS if traffic else None
-    bound = "hbm"
+    limiter = "hbm"
     if valu and valu.get("frac") is not None and (frac_traffic is None or valu["frac"] > frac_traffic) and valu["frac"] > frac:
-        bound = "valu"
+        limiter = "valu"
     out = {
-        "bound": bound, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "limiter": limiter, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(frac, 5),
         "traffic": traffic["bytes_per_launch"] if traffic else None,
         "traffic_source": traffic["source"] if traffic else None,

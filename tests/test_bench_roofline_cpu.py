@@ -1,5 +1,5 @@
 """Arithmetic of bench.py's roofline block: the contract figure, the unique-bytes figure and the
-counter-traffic figure over one measured kernel time, and the choice of `bound`."""
+counter-traffic figure over one measured kernel time, and the choice of `limiter` (`bound` is the roofline the figures are priced against: hbm)."""
 import sys
 from pathlib import Path
 
@@ -37,7 +37,7 @@ def test_roofline_block_fractions_and_bound():
     assert "frac_unique" not in rf
     assert abs(rf["frac_traffic"] - 150e6 / 50e-6 / 8e12) < 1e-5
     assert rf["unique_bytes_per_launch"] == unique and rf["traffic"] == 150e6
-    assert rf["bound"] == "valu"                                      # 0.55 of vector issue > 0.375 of HBM
+    assert rf["bound"] == "hbm" and rf["limiter"] == "valu"           # priced against HBM; 0.55 of vector issue > 0.375 of HBM limits it
     mp = rf["matrix_pipe"]
     assert mp["int8_ops_per_launch"] == 2.0 * (128 * 96) * 2016 * 1024
     assert abs(mp["frac"] - mp["int8_ops_per_launch"] / 50e-6 / 5e15) < 1e-4
@@ -50,13 +50,13 @@ def test_roofline_block_fractions_and_bound():
     assert rf5["matrix_pipe"]["fp4_ops_per_launch"] == 2.0 * (512 * 96) * 192 * 256
     # no counter pass of this build: frac_traffic withheld; the vector figure still decides against the unique-bytes figure
     rf2 = bench.roofline_block(b_eval, unique, B, kern_ms, None, valu, "k_mixture_tuple64<...>", True, "test")
-    assert rf2["frac_traffic"] is None and rf2["traffic"] is None and rf2["bound"] == "valu" and "matrix_pipe" not in rf2
+    assert rf2["frac_traffic"] is None and rf2["traffic"] is None and rf2["limiter"] == "valu" and rf2["bound"] == "hbm" and "matrix_pipe" not in rf2
     # a streaming kernel: traffic fraction above the vector fraction -> hbm
     rf3 = bench.roofline_block(4629008, 64 * 4629008, 64, 0.1466, {"bytes_per_launch": 248.6e6, "source": "t"}, {"frac": 0.15}, "k_mixture_rows<...>", True, "t")
-    assert rf3["bound"] == "hbm" and abs(rf3["frac_traffic"] - 248.6e6 / 146.6e-6 / 8e12) < 1e-5
+    assert rf3["bound"] == "hbm" and rf3["limiter"] == "hbm" and abs(rf3["frac_traffic"] - 248.6e6 / 146.6e-6 / 8e12) < 1e-5
     assert rf3["frac"] == rf3["frac_contract"]                        # one block per state: nothing is shared, the two agree
     # nothing static at all
-    assert bench.roofline_block(b_eval, unique, B, kern_ms, None, None, "k", True, "t")["bound"] == "hbm"
+    assert bench.roofline_block(b_eval, unique, B, kern_ms, None, None, "k", True, "t")["limiter"] == "hbm"
 
 
 def test_frac_never_exceeds_one_for_any_kernel_time_the_hardware_allows():
