@@ -181,7 +181,7 @@ def note_source_lineage(parent_tok, child_tok, rows):
     c_arr, c_ver = child_tok
     if p_ver is None or c_ver is None or (p_arr is c_arr and p_ver == c_ver) or p_arr.shape != c_arr.shape:
         return None
-    rec = (c_arr, c_ver, p_arr, p_ver, _rows32(rows))
+    rec = (c_arr, c_ver, p_arr, p_ver, _rows32(rows).copy())        # (a private copy: the caller's index array may be reused)
     _LINEAGE.append(rec)
     if len(_LINEAGE) > _LINEAGE_KEPT:
         del _LINEAGE[0]
