@@ -15,7 +15,7 @@ import numpy as np
 from . import _fast
 from .binding import (_bind_slot, _bind_uniform, _engine, _remember, _same, _tables_current,      # noqa: F401
                       _token)                                                                  # (re-exported)
-from .likelihood import compute_component_likelihood
+from .likelihood import LazyBlock, compute_component_likelihood
 from .registry import get_engine
 
 
@@ -45,6 +45,8 @@ def likelihood_per_component(model, sample, caching=True):
     cache = sample.cache.component_likelihoods
     if caching and not _fast.node_outdated(cache):
         return cache.value
+    if type(cache._value) is LazyBlock:               # (likelihood.LazyBlock: the block was never computed -- now it is)
+        cache._value = cache._value.materialize()
 
     with cache.edit() as component_likelihood:
         changed_clusters = cache.what_changed(input_key=["clusters", "clusters_counts"], caching=caching)

@@ -25,6 +25,66 @@ from .engine import GroupOverlapError
 from .registry import get_engine
 
 
+class LazyBlock:
+    """Stand-in for a cache array that was allocated but never computed.
+
+    Every reference sample carries `cache.component_likelihoods`, a float64 [n_objects, n_features, n_components] block that
+    ModelCache.__init__ allocates with np.empty (sbayes/sampling/state.py:398-400) and Sample.copy() copies with every proposal
+    (`assign_from`: state.py:317-321, :475) -- 3.2 MB, 250 us per MCMC step at the 1000 x 200 x 2 shape -- whether or not anything
+    ever computes it.  Under patch.install(operators=True) nothing in the sampling loop does (the operators that read
+    likelihood_per_component run their device forms), so a block that is NOT CURRENT for its sample is replaced by this object: shape and
+    dtype of the array it stands for, immutable, `copy()` of it is itself (what CacheNode.assign_from does to it), pickles as two
+    small tuples.  likelihood_per_component materialises it (np.empty, exactly what it replaced) before the first write; anything
+    else that wants values gets a fresh uninitialised array of the shape, like the original."""
+
+    __slots__ = ("shape", "dtype")
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+
+    ndim = property(lambda self: len(self.shape))
+
+    def materialize(self):
+        return np.empty(self.shape, dtype=self.dtype)
+
+    def __copy__(self):
+        return self
+
+    def __deepcopy__(self, memo):
+        return self
+
+    def __reduce__(self):
+        return LazyBlock, (self.shape, self.dtype.str)
+
+    def __array__(self, dtype=None, copy=None):
+        out = self.materialize()
+        return out if dtype is None else out.astype(dtype)
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+    def __repr__(self):
+        return f"LazyBlock(shape={self.shape}, dtype={self.dtype})"
+
+
+# set by patch.install(operators=True): Likelihood.__call__ replaces a sample's uncomputed component_likelihoods block (LazyBlock)
+LEAN_SAMPLES = False
+_LEAN_MIN_BYTES = 1 << 16
+
+
+def _lean_sample(sample):
+    node = getattr(sample.cache, "component_likelihoods", None)
+    if node is None:
+        return
+    value = node._value
+    if type(value) is np.ndarray and value.nbytes >= _LEAN_MIN_BYTES and _fast.node_outdated(node):
+        # never computed, or computed for an earlier state (the initialiser's samples) and not current for this one: nothing in the
+        # loop will bring it up to date.  clear() (state.py:304-308) marks every group as changed, so whoever does ask later
+        # (likelihood_per_component) recomputes the whole block instead of patching rows of the array dropped here
+        node.clear()
+        node._value = LazyBlock(value.shape, value.dtype)
+
+
 class Likelihood:
     """Collapsed Dirichlet-categorical likelihood of the sBayes mixture model."""
 
@@ -110,6 +170,8 @@ class Likelihood:
         return self._na_features
 
     def __call__(self, sample, caching=True) -> float:
+        if LEAN_SAMPLES:
+            _lean_sample(sample)
         if caching and _fast._h is not None:
             # the whole caching path in one native call (csrc/sbe_pyhost.c: likelihood_call -- the cache-node protocol of
             # compute_lh_clusters / compute_lh_confounder below, component after component, same order, same sums); the values

@@ -337,8 +337,12 @@ def _install_gibbs_source_form(swap):
 def _install_operator_forms(swap):
     import numpy as np
 
+    from . import likelihood as my_lik
     from . import operators as my_ops
     ref_ops = importlib.import_module("sbayes.sampling.operators")
+    # with the device forms below nothing in the sampling loop computes cache.component_likelihoods any more: a sample's stale
+    # 8 N F C byte block stops being copied by every Sample.copy() (likelihood.LazyBlock; Likelihood.__call__ swaps it in)
+    swap(my_lik, "LEAN_SAMPLES", True)
 
     def compute_cluster_posterior(self, sample, i_cluster, available):
         """AlterCluster.compute_cluster_posterior (operators.py:1035-1073) on the device."""
@@ -429,6 +433,7 @@ def _install_operator_forms(swap):
 
         swap(ref_prior.SourcePrior, "__call__", source_prior_call)
         swap(my_cond_sp, "DEVICE_SOURCE_PRIOR", True)            # (Likelihood.__call__ takes the source prior along)
+
 
     for owner, name in ((ref_ops.ClusterJump, "get_jump_lh"), (ref_ops.GibbsSampleWeights, "_propose"),
                         (ref_ops.GibbsSampleWeights, "source_lh_by_feature"),

@@ -245,3 +245,49 @@ def test_source_lineage_sends_what_a_full_compare_would(monkeypatch):
     assert len(a) == len(b) and len(a) > 0
     for (oa, ra), (ob, rb) in zip(a, b):
         assert np.array_equal(oa, ob) and np.array_equal(ra, rb)
+
+
+def test_lean_samples_drop_the_stale_component_block_and_recompute_it_whole(monkeypatch):
+    """likelihood.LazyBlock (patch.install(operators=True) sets LEAN_SAMPLES): a sample's cache.component_likelihoods block that is
+    not current -- never computed, or computed for an earlier state -- is replaced by a shape-only stand-in when the likelihood
+    of the sample is asked, so Sample.copy() (CacheNode.assign_from, state.py:317-321) stops copying 8 N F C bytes per proposal;
+    likelihood_per_component (conditionals.py:152-223) materialises it and computes EVERY group (the node was cleared), giving
+    the array an untouched twin gives."""
+    import pickle
+    results = []
+    for lean in (False, True):
+        with monkeypatch.context() as mp:
+            engines = {}
+            wl, model, sample = _problem(mp, engines)
+            mp.setattr(likelihood, "LEAN_SAMPLES", lean)
+            mp.setattr(likelihood, "_LEAN_MIN_BYTES", 1)
+            feats = model.data.features.values
+            rng = np.random.default_rng(4)
+            first = np.array(conditionals.likelihood_per_component(model, sample))            # computed once (an initialiser does)
+            for it in range(6):
+                new, objs = _move(rng, sample, wl)
+                my_counts.update_feature_counts(sample, new, feats, objs)
+                model.likelihood(new)
+                node = new.cache.component_likelihoods
+                if lean:
+                    assert type(node._value) is likelihood.LazyBlock and node._value.shape == first.shape and node.shape == first.shape
+                    assert new.copy().cache.component_likelihoods._value is node._value          # copies share the stand-in
+                    back = pickle.loads(pickle.dumps(node._value))
+                    assert type(back) is likelihood.LazyBlock and back.shape == first.shape and back.dtype == first.dtype
+                    assert np.asarray(node._value).shape == first.shape and node._value[0].shape == first.shape[1:]
+                else:
+                    assert type(node._value) is np.ndarray
+                sample = new
+            out = conditionals.likelihood_per_component(model, sample)
+            assert type(sample.cache.component_likelihoods._value) is np.ndarray and not sample.cache.component_likelihoods.is_outdated()
+            results.append((first, np.array(out)))
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    # a block that IS current stays (a weights-only change does not touch its inputs)
+    with monkeypatch.context() as mp:
+        engines = {}
+        wl, model, sample = _problem(mp, engines)
+        mp.setattr(likelihood, "LEAN_SAMPLES", True)
+        mp.setattr(likelihood, "_LEAN_MIN_BYTES", 1)
+        conditionals.likelihood_per_component(model, sample)
+        model.likelihood(sample)
+        assert type(sample.cache.component_likelihoods._value) is np.ndarray
