@@ -36,6 +36,7 @@ from __future__ import annotations
 
 import hashlib
 import importlib
+import os
 import inspect
 import warnings
 
@@ -342,7 +343,8 @@ def _install_operator_forms(swap):
     ref_ops = importlib.import_module("sbayes.sampling.operators")
     # with the device forms below nothing in the sampling loop computes cache.component_likelihoods any more: a sample's stale
     # 8 N F C byte block stops being copied by every Sample.copy() (likelihood.LazyBlock; Likelihood.__call__ swaps it in)
-    swap(my_lik, "LEAN_SAMPLES", True)
+    if os.environ.get("SBAYES_AMD_LEAN_SAMPLES", "1") != "0":
+        swap(my_lik, "LEAN_SAMPLES", True)
 
     def compute_cluster_posterior(self, sample, i_cluster, available):
         """AlterCluster.compute_cluster_posterior (operators.py:1035-1073) on the device."""

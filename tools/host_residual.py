@@ -16,7 +16,8 @@ Method, per shape (cfg1 50x30x5, south_america 100x36x5, headline 1000x200x10):
   plain   the unpatched reference (NumPy path) on the same seed and step count: steps/s of the baseline sampler on THIS
           host (SURVEY.md section 6 quotes 417 / ~300 / 26 from the survey container).
 
-  Every step's time is the fastest of its occurrences over 5 replays (2-3 for `plain`): same deterministic run each time.
+  Every step's time is the fastest of its occurrences over 5 replays (2-3 for `plain`; --replays / --clock-replays / --plain-runs
+  raise the counts on a busy host and are recorded in the output): same deterministic run each time.
 
   python tools/host_residual.py [--steps-small 400] [--steps-headline 120]
   python tools/host_residual.py --by-function south_america [--gibbs-source]     # the host layer's share, function by function
@@ -299,13 +300,16 @@ def _summary(secs):
             "p10": round(float(np.percentile(us, 10)), 2), "p90": round(float(np.percentile(us, 90)), 2)}
 
 
+REPLAYS, CLOCK_REPLAYS, PLAIN_RUNS = 5, 3, None        # (--replays / --clock-replays / --plain-runs: more on a busy host)
+
+
 def measure(tag, config_path, n_steps, seed, gibbs_source=False):
     secs1, _, ops1, eng1, ll1 = _run(config_path, tag, n_steps, seed, "memo", gibbs_source=gibbs_source)
     memo = eng1.memo
     # The same deterministic run is replayed several times and every STEP takes its fastest occurrence: the build container
     # shares its cores, a step that was interrupted in one replay is not in another (whole-run means moved by +-10 %).
     resid = inside2 = None
-    for _ in range(5):
+    for _ in range(REPLAYS):
         secs2, ins2, ops2, eng2, ll2 = _run(config_path, tag, n_steps, seed, "replay", memo=memo, gibbs_source=gibbs_source)
         assert ops2 == ops1 and ll2 == ll1 and eng2._pos <= len(memo)
         r = np.asarray(secs2) - np.asarray(ins2)
@@ -314,7 +318,7 @@ def measure(tag, config_path, n_steps, seed, gibbs_source=False):
     # replays with the host-layer clock on (its wrappers cost a little: not the runs the residual is taken from)
     ours = None
     by_fn = None
-    for _ in range(3):
+    for _ in range(CLOCK_REPLAYS):
         _s, inside3, _o, _e, _l, layer3 = _run(config_path, tag, n_steps, seed, "replay", memo=memo, layer_clock=True,
                                                gibbs_source=gibbs_source)
         o = np.asarray(layer3) - np.asarray(inside3)
@@ -322,7 +326,7 @@ def measure(tag, config_path, n_steps, seed, gibbs_source=False):
             by_fn = (o.mean(), dict(_run.last_clock.by_name))
         ours = o if ours is None else np.minimum(ours, o)
     secs0 = None
-    for _ in range(3 if n_steps * 1 <= 200 else 2):
+    for _ in range(PLAIN_RUNS if PLAIN_RUNS else (3 if n_steps * 1 <= 200 else 2)):
         s0, _, ops0, _, ll0 = _run(config_path, tag, n_steps, seed, "plain")
         secs0 = np.asarray(s0) if secs0 is None else np.minimum(secs0, np.asarray(s0))
     by_op = {}
@@ -332,6 +336,7 @@ def measure(tag, config_path, n_steps, seed, gibbs_source=False):
     n_calls = sum(1 for _ in memo)
     return {
         "tag": tag, "n_steps": n_steps, "seed": seed, "engine_calls_total": n_calls, "gibbs_source_on_device": bool(gibbs_source),
+        "replays": {"residual": REPLAYS, "layer_clock": CLOCK_REPLAYS},
         "host_python_us_per_step": _summary(resid),
         "of_which_this_packages_host_layer_us_per_step": _summary(ours),
         "replay_double_us_per_step": _summary(inside2),
@@ -380,7 +385,12 @@ def main():
     ap.add_argument("--by-function", metavar="SHAPE", help="print the host layer's per-function breakdown for cfg1 / south_america / "
                     "headline instead of writing the JSON")
     ap.add_argument("--gibbs-source", action="store_true", help="with --by-function: under patch.install(gibbs_source=True)")
+    ap.add_argument("--replays", type=int, default=5, help="replays each step's fastest occurrence is taken over (recorded in the output)")
+    ap.add_argument("--clock-replays", type=int, default=3, help="the same for the replays that carry the host-layer clock")
+    ap.add_argument("--plain-runs", type=int, default=0, help="runs of the unpatched reference (default 2-3)")
     args = ap.parse_args()
+    global REPLAYS, CLOCK_REPLAYS, PLAIN_RUNS
+    REPLAYS, CLOCK_REPLAYS, PLAIN_RUNS = max(1, args.replays), max(1, args.clock_replays), (args.plain_runs or None)
     if args.by_function:
         by_function(args.by_function, args.steps_headline if args.by_function == "headline" else args.steps_small, args.gibbs_source)
         return
