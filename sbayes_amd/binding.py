@@ -531,8 +531,17 @@ def recount_bound(eng, sample, slot=0):
 def _bind_uniform(eng, model):
     """The cluster prior's uniform concentration (prior.py:184-186) as the engine's resident `unif` operand of the
     tempered tables; sent when its content changes (once per model)."""
-    unif = _token(np.asarray(model.prior.prior_cluster_effect.uniform_concentration_array))
-    if not _same(unif, getattr(eng, "_bound_unif", None)):
+    arr = model.prior.prior_cluster_effect.uniform_concentration_array
+    cached = getattr(eng, "_bound_unif", None)
+    # the usual call: the very array the engine was given last time, recorded frozen (no private copy) and still frozen --
+    # _same()'s identity rule, without building the token (three of these per MCMC step)
+    if cached is not None and cached[0] is arr and cached[2] is None and cached[1] is None:
+        flags = arr.flags
+        if not flags.writeable and flags.owndata:
+            if not _VERIFY_FROZEN:
+                return
+    unif = _token(np.asarray(arr))
+    if not _same(unif, cached):
         eng.set_uniform_counts(unif[0])
         eng._bound_unif = _remember(unif)
 
@@ -541,6 +550,8 @@ def _tables_current(eng, slot):
     """Rebuild the probability tables that the last _bind_slot left stale."""
     entry = getattr(eng, "_bound", {}).get(slot)
     stale = set(range(eng.n_components)) if entry is None else entry["stale"]
+    if not stale:
+        return
     if len(stale) == 1:
         eng.update_probs(slot, next(iter(stale)))
     elif stale:

@@ -131,6 +131,7 @@ class Likelihood:
         state["_engine"] = None
         state["_call_memo"] = None
         state["_fast_call"] = None
+        state["_dynamic_priors_memo"] = None
         state["_sbayes_amd_patch"] = patch.installed()      # how the pickling process had sBayes patched, if at all
         return state
 

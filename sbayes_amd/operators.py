@@ -29,6 +29,20 @@ from .counts import _source_ids, apply_count_rows, note_jump_state, update_featu
 EPS = np.finfo(np.float32).eps        # sbayes/util.py:34
 
 
+def _any_dynamic_priors(model, sample):
+    """any(model.prior.prior_confounding_effects[conf].any_dynamic_priors for conf in sample.confounders) -- the flag is fixed when a
+    prior is built (sbayes/model/prior.py:273-314), so the answer is kept on the model's likelihood object per prior table."""
+    lik = getattr(model, "likelihood", None)
+    priors = model.prior.prior_confounding_effects
+    memo = lik.__dict__.get("_dynamic_priors_memo") if lik is not None and hasattr(lik, "__dict__") else None
+    if memo is not None and memo[0] is priors and memo[1] == len(sample.confounders):
+        return memo[2]
+    flag = any(priors[conf].any_dynamic_priors for conf in sample.confounders)
+    if lik is not None and hasattr(lik, "__dict__"):
+        lik.__dict__["_dynamic_priors_memo"] = (priors, len(sample.confounders), flag)
+    return flag
+
+
 def _prepare(model, sample, slot):
     eng = _engine(model)
     _bind_slot(eng, model, sample, slot)
@@ -213,7 +227,7 @@ def cluster_gibbs_sample_source(model, sample_new, sample_old, i_cluster, object
     and 2 n F float32 come back.  The sample edits (source.edit(), update_feature_counts) and the float32 sums of logs are
     the reference's own, in its order.  Returns (sample_new, log_q, log_q_back).  Static priors only: None otherwise
     (the caller keeps the reference's method)."""
-    if any(model.prior.prior_confounding_effects[conf].any_dynamic_priors for conf in sample_new.confounders):
+    if _any_dynamic_priors(model, sample_new):
         return None
     eng = _engine(model)
     features = model.data.features.values
@@ -284,7 +298,7 @@ def component_likelihood_given_unchanged(model, sample, object_subset, i_cluster
     eng = _engine(model)
     object_subset = np.asarray(object_subset, dtype=bool)
     objects = np.flatnonzero(object_subset)
-    if not any(model.prior.prior_confounding_effects[conf].any_dynamic_priors for conf in sample.confounders):
+    if not _any_dynamic_priors(model, sample):
         # static priors: everything the reference reads here is resident once `sample` is bound -- its (new) clusters,
         # its not-yet-resampled source, its counts, the priors' tables -- so the kept / unchangeable counts
         # (operators.py:876-901), their tempered tables and the gather run on the device in ONE call; the object list
