@@ -35,7 +35,7 @@ class LazyBlock:
     likelihood_per_component run their device forms), so a block that is NOT CURRENT for its sample is replaced by this object: shape and
     dtype of the array it stands for, immutable, `copy()` of it is itself (what CacheNode.assign_from does to it), pickles as two
     small tuples.  likelihood_per_component materialises it (np.empty, exactly what it replaced) before the first write; anything
-    else that wants values gets a fresh uninitialised array of the shape, like the original."""
+    else that asks it for values gets a RuntimeError, not garbage."""
 
     __slots__ = ("shape", "dtype")
 
@@ -56,12 +56,14 @@ class LazyBlock:
     def __reduce__(self):
         return LazyBlock, (self.shape, self.dtype.str)
 
-    def __array__(self, dtype=None, copy=None):
-        out = self.materialize()
-        return out if dtype is None else out.astype(dtype)
+    # values are not there: reading or writing elements fails loudly (a write into a temporary would be lost silently -- e.g. the
+    # reference's own likelihood_per_component after patch.uninstall() on a sample that still carries the stand-in)
+    def _no_values(self, *args, **kwargs):
+        raise RuntimeError("this cache block was dropped by sbayes_amd's lean samples (likelihood.LazyBlock): it holds no values; "
+                           "sbayes_amd.conditionals.likelihood_per_component(model, sample) rebuilds it, "
+                           "SBAYES_AMD_LEAN_SAMPLES=0 keeps the arrays")
 
-    def __getitem__(self, idx):
-        return self.materialize()[idx]
+    __array__ = __getitem__ = __setitem__ = _no_values
 
     def __repr__(self):
         return f"LazyBlock(shape={self.shape}, dtype={self.dtype})"
